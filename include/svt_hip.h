@@ -1,0 +1,94 @@
+/*
+ * svt_hip.h — C ABI of libsvtav1_hip.so: the MI355X (gfx950) implementation of SVT-AV1's
+ * per-superblock hot path (open-loop ME, transform/quant, in-loop filters).
+ *
+ * This is the drop-in boundary.  The reference binds kernels through global function pointers
+ * (Source/Lib/Encoder/Codec/aom_dsp_rtcd.h, Source/Lib/Common/Codec/common_dsp_rtcd.h) that are
+ * filled once in svt_av1_enc_init (Source/Lib/Encoder/Globals/EbEncHandle.c:1144-1145).  Two
+ * families of entry points are exported:
+ *
+ *   (1) batched, frame-level calls (svt_hip_*_frame / *_batch): one call = one kernel launch over
+ *       every 64x64 superblock of a picture.  They replace the per-SB loops of the reference's
+ *       process kernels (EbMotionEstimationProcess.c:831-963, EbDlfProcess.c:175-216,
+ *       EbCdefProcess.c:510-534 ...).  `_dev` variants take device pointers (inputs already
+ *       resident in HBM); the plain variants take host pointers and move the data themselves.
+ *   (2) per-call wrappers with the exact RTCD signatures (svt_*_hip), installable into the
+ *       reference's dispatch tables by svt_hip_setup_rtcd().  They exist for
+ *       parity testing against the reference's unit-test matrices; a per-block GPU round trip is
+ *       never the fast path.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a nonzero
+ * SvtHipStatus otherwise (the caller then keeps using the C pointer, mirroring the reference's
+ * "kernels cannot fail" convention).  No CPU fallback exists inside this library:
+ * if no gfx950 device is present svt_hip_init fails loudly.
+ */
+#ifndef SVT_HIP_H
+#define SVT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SVT_HIP_OK              = 0,
+    SVT_HIP_ERR_NO_DEVICE   = 1, /* no HIP device / not gfx950 */
+    SVT_HIP_ERR_BAD_ARG     = 2,
+    SVT_HIP_ERR_RUNTIME     = 3, /* a HIP call failed; see svt_hip_last_error() */
+    SVT_HIP_ERR_UNSUPPORTED = 4
+} SvtHipStatus;
+
+#define SVT_HIP_SQUARE_PU_COUNT 85              /* Encoder/Codec/EbMotionEstimationLcuResults.h:22 */
+#define SVT_HIP_MAX_SAD_VALUE (128 * 128 * 255) /* Encoder/Codec/EbMotionEstimation.h:93 */
+
+typedef struct SvtHipCtx SvtHipCtx; /* opaque: device, stream, scratch buffers */
+
+/* ------------------------------------------------------------------ context / memory ---------- */
+int         svt_hip_init(int device_id, SvtHipCtx **ctx);
+void        svt_hip_destroy(SvtHipCtx *ctx);
+const char *svt_hip_last_error(const SvtHipCtx *ctx);
+/* Adopt an externally owned hipStream_t (e.g. the caller's); NULL restores the context's own. */
+int  svt_hip_set_stream(SvtHipCtx *ctx, void *hip_stream);
+int  svt_hip_sync(SvtHipCtx *ctx);
+int  svt_hip_malloc(SvtHipCtx *ctx, void **dptr, size_t bytes);
+int  svt_hip_free(SvtHipCtx *ctx, void *dptr);
+int  svt_hip_memcpy_h2d(SvtHipCtx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int  svt_hip_memcpy_d2h(SvtHipCtx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* HIP-event stopwatch on the context's stream (used by bench.py for per-kernel device time). */
+int  svt_hip_timer_start(SvtHipCtx *ctx);
+int  svt_hip_timer_stop_ms(SvtHipCtx *ctx, float *elapsed_ms);
+
+/* ------------------------------------------------------------------ open-loop ME --------------- */
+/* Per-SB search descriptor = the window integer_search_sb derives for one (SB, reference)
+ * (Encoder/Codec/EbMotionEstimation.c:1922-2066).  svt_hip_me_search_window() reproduces that
+ * arithmetic on the host. */
+typedef struct {
+    int32_t sb_x, sb_y;                        /* SB origin in luma pixels */
+    int16_t x_origin, y_origin, width, height; /* search area: origin relative to the SB, size */
+} SvtHipSbSearch;
+
+SvtHipSbSearch svt_hip_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center,
+                                        int sa_width, int sa_height, int pic_width, int pic_height);
+
+/* Integer full search, all 85 square PUs, every SB of a frame, one reference.
+ * Replaces open_loop_me_fullpel_search_sblock (EbMotionEstimation.c:814) and the kernels behind
+ * svt_ext_all_sad_calculation_8x8_16x16 / svt_ext_eight_sad_calculation_32x32_64x64
+ * (aom_dsp_rtcd.h:640-641) + single-candidate tails (:630,:636).
+ *   src/ref : padded luma planes (u8), `stride` bytes per row (multiple of 4), pixel (0,0) at
+ *             [org_y*stride + org_x]; the window of every SB must lie inside the padded plane.
+ *   best_sad/best_mv : [n_sb][85] in EbMeTierZeroPu order (EbMotionEstimationContext.h:51-137);
+ *             MV word = (y_mv << 16) | x_mv in quarter-pel int16 halves (EbDefinitions.h:2346).
+ *   sub_sad : SUB_SAD_SEARCH (every other row, SAD doubled) vs FULL_SAD_SEARCH. */
+int svt_hip_me_fullpel_frame_dev(SvtHipCtx *ctx, const uint8_t *d_src, const uint8_t *d_ref, int stride,
+                                 int org_x, int org_y, const SvtHipSbSearch *d_sbs, int n_sb, int sub_sad,
+                                 uint32_t *d_best_sad, uint32_t *d_best_mv);
+int svt_hip_me_fullpel_frame(SvtHipCtx *ctx, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows,
+                             int org_x, int org_y, const SvtHipSbSearch *sbs, int n_sb, int sub_sad,
+                             uint32_t *best_sad, uint32_t *best_mv);
+/* Tuning knob (workgroup = 1, 2 or 4 waves per SB); default 2. */
+int svt_hip_me_set_waves_per_sb(SvtHipCtx *ctx, int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_H */

@@ -1,0 +1,86 @@
+/*
+ * svt_oracle.h — CPU restatement ("port") of the SVT-AV1 v0.8.6 per-superblock hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and there
+ * only as the checker.  The product (svt-av1_amd/csrc) never links or calls it.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit against the reference's own
+ * C functions (oracle/_ref/libsvtav1_ref.so, built by oracle/Makefile.ref from the sources under
+ * /root/reference) by tests/test_oracle_vs_ref.py on the reference unit tests' input
+ * distributions, and against the committed fixtures in tests/golden/ generated from that library
+ * by tests/golden/make_golden.py.
+ *
+ * All citations are file:line under /root/reference/Source/Lib.
+ */
+#ifndef SVT_ORACLE_H
+#define SVT_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_SQUARE_PU_COUNT 85 /* Encoder/Codec/EbMotionEstimationLcuResults.h:22 */
+#define ORC_MAX_SAD_VALUE (128 * 128 * 255) /* Encoder/Codec/EbMotionEstimation.h:93 */
+
+/* ---------------------------------------------------------------- ME: SAD kernels ------------ */
+/* Encoder/C_DEFAULT/EbComputeSAD_C.c:20  (svt_fast_loop_nxm_sad_kernel / svt_nxm_sad_kernel) */
+uint32_t orc_nxm_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                     uint32_t height, uint32_t width);
+/* Encoder/C_DEFAULT/EbComputeSAD_C.c:39 (sad_16b_kernel_c) */
+uint32_t orc_sad_16b(const uint16_t *src, uint32_t src_stride, const uint16_t *ref, uint32_t ref_stride,
+                     uint32_t height, uint32_t width);
+/* Encoder/C_DEFAULT/EbComputeSAD_C.c:58 (svt_sad_loop_kernel_c) */
+void orc_sad_loop(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                  uint32_t block_height, uint32_t block_width, uint64_t *best_sad, int16_t *x_center,
+                  int16_t *y_center, uint32_t src_stride_raw, int16_t sa_width, int16_t sa_height);
+/* Encoder/Codec/EbMotionEstimation.c:362 (svt_ext_all_sad_calculation_8x8_16x16_c) */
+void orc_ext_all_sad_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                               uint32_t ref_stride, uint32_t mv, uint32_t *best_sad8, uint32_t *best_sad16,
+                               uint32_t *best_mv8, uint32_t *best_mv16, uint32_t eight_sad16[16][8],
+                               uint32_t eight_sad8[64][8], int sub_sad);
+/* Encoder/Codec/EbMotionEstimation.c:396 (svt_ext_eight_sad_calculation_32x32_64x64_c) */
+void orc_ext_eight_sad_32x32_64x64(uint32_t sad16[16][8], uint32_t *best_sad32, uint32_t *best_sad64,
+                                   uint32_t *best_mv32, uint32_t *best_mv64, uint32_t mv,
+                                   uint32_t sad32[4][8]);
+/* Encoder/Codec/EbMotionEstimation.c:122 (svt_ext_sad_calculation_8x8_16x16_c) */
+void orc_ext_sad_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                           uint32_t *best_sad8, uint32_t *best_sad16, uint32_t *best_mv8,
+                           uint32_t *best_mv16, uint32_t mv, uint32_t *sad16, uint32_t *sad8, int sub_sad);
+/* Encoder/Codec/EbMotionEstimation.c:191 (svt_ext_sad_calculation_32x32_64x64_c) */
+void orc_ext_sad_32x32_64x64(const uint32_t *sad16, uint32_t *best_sad32, uint32_t *best_sad64,
+                             uint32_t *best_mv32, uint32_t *best_mv64, uint32_t mv, uint32_t *sad32);
+
+/* Encoder/Codec/EbMotionEstimation.c:814 (open_loop_me_fullpel_search_sblock) + the best-SAD
+ * initialisation of integer_search_sb (:2086).  `ref_tl` points at the reference sample of the
+ * top-left candidate (x_sa_origin, y_sa_origin relative to the SB); outputs use the 85-PU layout
+ * of EbMeTierZeroPu (Encoder/Codec/EbMotionEstimationContext.h:51-137). */
+void orc_me_fullpel_sb(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_tl, uint32_t ref_stride,
+                       int x_sa_origin, int y_sa_origin, uint32_t sa_width, uint32_t sa_height, int sub_sad,
+                       uint32_t best_sad[ORC_SQUARE_PU_COUNT], uint32_t best_mv[ORC_SQUARE_PU_COUNT]);
+
+/* Search-window arithmetic of integer_search_sb, Encoder/Codec/EbMotionEstimation.c:1922-2066
+ * (unrestricted-MV branch, int16 arithmetic, 63-px pad).  In/out: sa_w, sa_h (already scaled by the
+ * temporal-distance factor and divisor, :1930-1936), centre -> origin. */
+typedef struct {
+    int16_t x_origin, y_origin; /* search-area origin relative to the SB origin */
+    int16_t width, height;      /* adjusted search area */
+} OrcSearchWindow;
+OrcSearchWindow orc_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center,
+                                     int sa_width, int sa_height, int pic_width, int pic_height);
+
+/* Frame driver used by tests/bench: loops orc_me_fullpel_sb over all SBs.
+ * planes are the *padded* luma pictures; (org_x,org_y) is the offset of pixel (0,0) in them. */
+typedef struct {
+    int32_t sb_x, sb_y;       /* SB origin in pixels */
+    int16_t x_origin, y_origin, width, height; /* search window (from orc_me_search_window) */
+} OrcSbSearch;
+void orc_me_fullpel_frame(const uint8_t *src, const uint8_t *ref, int stride, int org_x, int org_y,
+                          const OrcSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad /*[n_sb][85]*/,
+                          uint32_t *best_mv /*[n_sb][85]*/, int sb_begin, int sb_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""svt-av1_amd — host-side Python binding (ctypes) of libsvtav1_hip.so.
+
+The product is the C-ABI shared library declared in include/svt_hip.h (built from csrc/ by
+__graft_entry__.build()).  This module only loads it and mirrors the prototypes so that tests and
+bench.py can drive it; there is NO CPU fallback here: if the library is missing, or no gfx950
+device is present, loading / svt_hip_init fails loudly.
+
+The directory name contains a '-', so import it through `load_package()` in tests/conftest.py
+(importlib, module name `svt_av1_amd`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvtav1_hip.so")
+
+SQUARE_PU_COUNT = 85
+MAX_SAD_VALUE = 128 * 128 * 255
+
+
+class SbSearch(C.Structure):
+    """SvtHipSbSearch (include/svt_hip.h)."""
+    _fields_ = [("sb_x", C.c_int32), ("sb_y", C.c_int32), ("x_origin", C.c_int16), ("y_origin", C.c_int16),
+                ("width", C.c_int16), ("height", C.c_int16)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsvtav1_hip.so (once) and attach prototypes. Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u8p, u32p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    L.svt_hip_init.argtypes = [i32, C.POINTER(vp)]
+    L.svt_hip_destroy.argtypes = [vp]
+    L.svt_hip_destroy.restype = None
+    L.svt_hip_last_error.argtypes = [vp]
+    L.svt_hip_last_error.restype = C.c_char_p
+    L.svt_hip_set_stream.argtypes = [vp, vp]
+    L.svt_hip_sync.argtypes = [vp]
+    L.svt_hip_malloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    L.svt_hip_free.argtypes = [vp, vp]
+    L.svt_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svt_hip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svt_hip_timer_start.argtypes = [vp]
+    L.svt_hip_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.svt_hip_me_search_window.argtypes = [i32] * 8
+    L.svt_hip_me_search_window.restype = SbSearch
+    L.svt_hip_me_fullpel_frame_dev.argtypes = [vp, u8p, u8p, i32, i32, i32, vp, i32, i32, u32p, u32p]
+    L.svt_hip_me_fullpel_frame.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp, i32, i32, u32p, u32p]
+    L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+class Context:
+    """RAII wrapper of SvtHipCtx."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.svt_hip_init(device, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"svt_hip_init failed with status {rc} (no gfx950 device?) — there is no CPU fallback")
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: status {rc}: {self.L.svt_hip_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.svt_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

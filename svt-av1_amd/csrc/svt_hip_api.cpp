@@ -1,0 +1,185 @@
+// svt_hip_api.cpp — the C-ABI layer of libsvtav1_hip.so (include/svt_hip.h): context, memory,
+// host-pointer convenience wrappers around the batched kernel launchers.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "svt_hip_internal.h"
+
+struct SvtHipCtx {
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    int         me_waves = 2;
+    std::string err;
+};
+
+static int fail(SvtHipCtx* c, hipError_t e, const char* what) {
+    if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SVT_HIP_ERR_RUNTIME;
+}
+#define HIPCHK(c, call)                                   \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail((c), e_, #call); \
+    } while (0)
+
+extern "C" {
+
+int svt_hip_init(int device_id, SvtHipCtx** out) {
+    if (!out) return SVT_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return SVT_HIP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return SVT_HIP_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "svt_hip_init: device %d is %s; this library is built for gfx950 only\n", device_id,
+                     prop.gcnArchName);
+        return SVT_HIP_ERR_NO_DEVICE;
+    }
+    SvtHipCtx* c = new SvtHipCtx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return SVT_HIP_ERR_RUNTIME;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SVT_HIP_OK;
+}
+
+void svt_hip_destroy(SvtHipCtx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* svt_hip_last_error(const SvtHipCtx* c) { return c ? c->err.c_str() : "null context"; }
+
+int svt_hip_set_stream(SvtHipCtx* c, void* s) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return SVT_HIP_OK;
+}
+int svt_hip_sync(SvtHipCtx* c) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_malloc(SvtHipCtx* c, void** p, size_t bytes) {
+    if (!c || !p) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(p, bytes ? bytes : 4));
+    return SVT_HIP_OK;
+}
+int svt_hip_free(SvtHipCtx* c, void* p) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipFree(p));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy_h2d(SvtHipCtx* c, void* d, const void* h, size_t bytes) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy_d2h(SvtHipCtx* c, void* h, const void* d, size_t bytes) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_timer_start(SvtHipCtx* c) {
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_timer_stop_ms(SvtHipCtx* c, float* ms) {
+    if (!c || !ms) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return SVT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- ME */
+// Host-side restatement of the search-window clamp (EbMotionEstimation.c:1945-2066, unrestricted-MV
+// branch; int16 arithmetic with int intermediates, statements in the reference's order).
+SvtHipSbSearch svt_hip_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center, int sa_width,
+                                        int sa_height, int pic_width, int pic_height) {
+    const int16_t pad = 63;
+    const int16_t ox = (int16_t)sb_origin_x, oy = (int16_t)sb_origin_y, pw = (int16_t)pic_width, ph = (int16_t)pic_height;
+    int16_t w = (int16_t)sa_width, h = (int16_t)sa_height;
+    int16_t xo = (int16_t)(x_center - (w >> 1)), yo = (int16_t)(y_center - (h >> 1));
+    xo = (int16_t)((ox + xo < -pad) ? -pad - ox : xo);
+    w  = (int16_t)((ox + xo < -pad) ? w - (-pad - (ox + xo)) : w);
+    xo = (int16_t)((ox + xo > pw - 1) ? xo - ((ox + xo) - (pw - 1)) : xo);
+    if (ox + xo + w > pw) { const int v = w - ((ox + xo + w) - pw); w = (int16_t)(v > 1 ? v : 1); }
+    w  = (int16_t)((w < 8) ? w : (w & ~0x07));
+    yo = (int16_t)((oy + yo < -pad) ? -pad - oy : yo);
+    h  = (int16_t)((oy + yo < -pad) ? h - (-pad - (oy + yo)) : h);
+    yo = (int16_t)((oy + yo > ph - 1) ? yo - ((oy + yo) - (ph - 1)) : yo);
+    if (oy + yo + h > ph) { const int v = h - ((oy + yo + h) - ph); h = (int16_t)(v > 1 ? v : 1); }
+    SvtHipSbSearch s;
+    s.sb_x = sb_origin_x; s.sb_y = sb_origin_y; s.x_origin = xo; s.y_origin = yo; s.width = w; s.height = h;
+    return s;
+}
+
+int svt_hip_me_set_waves_per_sb(SvtHipCtx* c, int waves) {
+    if (!c || (waves != 1 && waves != 2 && waves != 4)) return SVT_HIP_ERR_BAD_ARG;
+    c->me_waves = waves;
+    return SVT_HIP_OK;
+}
+
+int svt_hip_me_fullpel_frame_dev(SvtHipCtx* c, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
+                                 int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
+                                 uint32_t* d_best_mv) {
+    if (!c || !d_src || !d_ref || !d_sbs || !d_best_sad || !d_best_mv || n_sb < 0 || (stride & 3)) {
+        if (c) c->err = "svt_hip_me_fullpel_frame_dev: bad argument (stride must be a multiple of 4)";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_me_fullpel(c->stream, d_src, d_ref, stride, org_x, org_y, d_sbs, n_sb,
+                                                        sub_sad, d_best_sad, d_best_mv, c->me_waves);
+    if (e != hipSuccess) return fail(c, e, "me_fullpel launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_me_fullpel_frame(SvtHipCtx* c, const uint8_t* src, const uint8_t* ref, int stride, int plane_rows, int org_x,
+                             int org_y, const SvtHipSbSearch* sbs, int n_sb, int sub_sad, uint32_t* best_sad,
+                             uint32_t* best_mv) {
+    if (!c || !src || !ref || !sbs || !best_sad || !best_mv || n_sb < 0 || plane_rows <= 0) return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_sb; i++)
+        if ((int)sbs[i].width * (int)sbs[i].height > 65536 || sbs[i].width < 0 || sbs[i].height < 0) {
+            c->err = "svt_hip_me_fullpel_frame: search area larger than 65536 candidates";
+            return SVT_HIP_ERR_UNSUPPORTED;
+        }
+    const size_t plane = (size_t)stride * plane_rows, nres = (size_t)n_sb * SVT_HIP_SQUARE_PU_COUNT * 4;
+    uint8_t *d_src = nullptr, *d_ref = nullptr;
+    SvtHipSbSearch* d_sbs = nullptr;
+    uint32_t *d_sad = nullptr, *d_mv = nullptr;
+    int rc = SVT_HIP_OK;
+    if ((rc = svt_hip_malloc(c, (void**)&d_src, plane)) || (rc = svt_hip_malloc(c, (void**)&d_ref, plane)) ||
+        (rc = svt_hip_malloc(c, (void**)&d_sbs, sizeof(SvtHipSbSearch) * (size_t)(n_sb ? n_sb : 1))) ||
+        (rc = svt_hip_malloc(c, (void**)&d_sad, nres)) || (rc = svt_hip_malloc(c, (void**)&d_mv, nres)))
+        goto done;
+    if ((rc = svt_hip_memcpy_h2d(c, d_src, src, plane)) || (rc = svt_hip_memcpy_h2d(c, d_ref, ref, plane)) ||
+        (rc = svt_hip_memcpy_h2d(c, d_sbs, sbs, sizeof(SvtHipSbSearch) * (size_t)n_sb)))
+        goto done;
+    if ((rc = svt_hip_me_fullpel_frame_dev(c, d_src, d_ref, stride, org_x, org_y, d_sbs, n_sb, sub_sad, d_sad, d_mv))) goto done;
+    if ((rc = svt_hip_memcpy_d2h(c, best_sad, d_sad, nres)) || (rc = svt_hip_memcpy_d2h(c, best_mv, d_mv, nres))) goto done;
+done:
+    if (d_src) (void)hipFree(d_src);
+    if (d_ref) (void)hipFree(d_ref);
+    if (d_sbs) (void)hipFree(d_sbs);
+    if (d_sad) (void)hipFree(d_sad);
+    if (d_mv) (void)hipFree(d_mv);
+    return rc;
+}
+
+}  // extern "C"

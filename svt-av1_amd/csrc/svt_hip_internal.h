@@ -1,0 +1,12 @@
+// svt_hip_internal.h — launcher prototypes shared between the kernel translation units and the
+// C-ABI layer (svt_hip_api.cpp).  Not installed; the public surface is include/svt_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svt_hip.h"
+
+extern "C" {
+int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
+                              int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
+                              uint32_t* d_best_mv, int waves_per_sb);
+}
