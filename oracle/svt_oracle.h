@@ -80,6 +80,32 @@ void orc_me_fullpel_frame(const uint8_t *src, const uint8_t *ref, int stride, in
                           const OrcSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad /*[n_sb][85]*/,
                           uint32_t *best_mv /*[n_sb][85]*/, int sb_begin, int sb_end);
 
+/* ---------------------------------------------------------------- transforms (txfm_oracle.c) -- */
+/* tx_type: TxType enum order (DCT_DCT=0 .. H_FLIPADST=15), tx_size: TxSize enum order (TX_4X4=0 ..
+ * TX_64X16=18), Common/Codec/EbDefinitions.h. */
+const int32_t *orc_cospi_arr(int bit);
+int  orc_tx_width(int tx_size);
+int  orc_tx_height(int tx_size);
+void orc_fdct(const int32_t *in, int32_t *out, int n, int cos_bit);
+void orc_idct(const int32_t *in, int32_t *out, int n, int cos_bit, int clamp_bit);
+void orc_fadst(const int32_t *in, int32_t *out, int n, int cos_bit);
+void orc_iadst(const int32_t *in, int32_t *out, int n, int cos_bit, int clamp_bit);
+void orc_identity(const int32_t *in, int32_t *out, int n);
+void orc_fwd_txfm2d(const int16_t *input, int32_t *output, uint32_t stride, int tx_type, int tx_size, int bd);
+uint64_t orc_handle_transform(int32_t *coeff, int tx_size);
+void orc_inv_txfm2d_add(const int32_t *input, const uint16_t *pred, int32_t stride_r, uint16_t *recon,
+                        int32_t stride_w, int tx_type, int tx_size, int bd);
+void orc_inv_txfm_add_8bit(const int32_t *input, const uint8_t *pred, int32_t stride_r, uint8_t *recon,
+                           int32_t stride_w, int tx_type, int tx_size);
+void orc_residual_8bit(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride,
+                       int16_t *res, uint32_t res_stride, uint32_t w, uint32_t h);
+
+/* ---------------------------------------------------------------- quantisation (quant_oracle.c) */
+void orc_quantize(int variant, const int32_t *coeff, int n, const int16_t *zbin, const int16_t *round,
+                  const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                  const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale);
+int32_t orc_cul_level(const int32_t *qcoeff, const int16_t *scan, int eob);
+
 #ifdef __cplusplus
 }
 #endif

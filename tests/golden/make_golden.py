@@ -94,5 +94,60 @@ def gen_me():
     print("me_fullpel.npz:", len(cases), "arrays")
 
 
+def gen_txfm():
+    """Tables (scan orders, quantizer parameters, flips) and fwd-txfm / quant / inv-txfm vectors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import txfm_common as tc
+    tabs = {}
+    for ts in range(19):
+        for cls, tt in ((0, 0), (1, 10), (2, 11)):
+            if max(tc.TXW[ts], tc.TXH[ts]) > 16 and cls:
+                continue  # 1-D classes only exist for <= 16-pt transforms
+            sc, isc = tc.ref_scan(ref, ts, tt)
+            tabs[f"scan/{ts}/{cls}"] = sc; tabs[f"iscan/{ts}/{cls}"] = isc
+    for bd in (8, 10):
+        for qi in (0, 20, 60, 120, 200, 255):
+            for pl in range(3):
+                tabs[f"qp/{bd}/{qi}/{pl}"] = tc.ref_qparams(ref, bd, qi, pl)
+    fl = np.zeros((16, 2), np.int32)
+    for tt in range(16):
+        ud, lr = C.c_int(0), C.c_int(0)
+        ref.ref_shim_flip(tt, C.byref(ud), C.byref(lr)); fl[tt] = (ud.value, lr.value)
+    tabs["flip"] = fl
+    np.savez_compressed(os.path.join(HERE, "txfm_tables.npz"), **tabs)
+    print("txfm_tables.npz:", len(tabs), "arrays")
+
+    rng = np.random.default_rng(13596)
+    vec = {}
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        kw, kh = min(w, 32), min(h, 32)
+        types = tc.legal_types(ts)
+        pick = types if len(types) <= 2 else [0, 3, 6, 9, 10, 13, 15, int(rng.integers(0, 16))]
+        for tt in pick:
+            for bd in (8, 10):
+                lim = (1 << bd) - 1
+                x = rng.integers(-lim, lim + 1, (h, w), dtype=np.int16)
+                co = tc.ref_fwd(ref, x, w, tt, ts, bd)
+                en = tc.ref_handle(ref, co, ts) if max(w, h) == 64 else 0
+                co = np.ascontiguousarray(co[:kw * kh])
+                scan, iscan = tc.ref_scan(ref, ts, tt)
+                qp = tc.ref_qparams(ref, bd, 60, 0)
+                v = 0 if bd == 8 else 1
+                q, dq, eob = tc.ref_quant(ref, v, co, qp, scan, iscan, tc.TX_SCALE[ts])
+                qf, dqf, eobf = tc.ref_quant(ref, v + 2, co, qp, scan, iscan, tc.TX_SCALE[ts])
+                pred = rng.integers(0, 1 << bd, (h, w), dtype=np.uint16)
+                rec = np.zeros((h, w), np.uint16)
+                tc.ref_inv(ref, dq, pred, w, rec, w, tt, ts, bd)
+                k = f"{ts}/{tt}/{bd}"
+                vec[k + "/x"] = x; vec[k + "/coeff"] = co; vec[k + "/energy"] = np.array([en], np.uint64)
+                vec[k + "/q"] = q; vec[k + "/dq"] = dq; vec[k + "/eob"] = np.array([eob, eobf], np.int32)
+                vec[k + "/qf"] = qf; vec[k + "/dqf"] = dqf
+                vec[k + "/pred"] = pred; vec[k + "/rec"] = rec
+    np.savez_compressed(os.path.join(HERE, "txfm_quant.npz"), **vec)
+    print("txfm_quant.npz:", len(vec), "arrays")
+
+
 if __name__ == "__main__":
     gen_me()
+    gen_txfm()

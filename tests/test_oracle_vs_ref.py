@@ -78,3 +78,108 @@ def test_sad_loop_and_nxm(orc, ref):
             res.append((best.value, xc.value, yc.value))
         assert res[0] == res[1]
         assert ref.svt_fast_loop_nxm_sad_kernel(ptr(src), bw, ptr(refb), rs, bh, bw) == orc.orc_nxm_sad(ptr(src), bw, ptr(refb), rs, bh, bw)
+
+
+# ------------------------------------------------------------------------------------ transforms
+import txfm_common as tc
+
+
+def test_txfm_tables_and_1d(orc, ref):
+    """cospi table == reference's; every 1-D kernel (fdct/idct 4..64, fadst/iadst 4..16) bit-exact
+    (mirrors /root/reference/test/FwdTxfm1dTest.cc / InvTxfm1dTest.cc input ranges)."""
+    orc.orc_cospi_arr.restype = C.POINTER(C.c_int32)
+    t = (C.c_int32 * 64 * 7).in_dll(ref, "eb_av1_cospi_arr_data")
+    for bit in range(10, 17):
+        assert np.array_equal(np.ctypeslib.as_array(orc.orc_cospi_arr(bit), (64,)), np.array(t[bit - 10]))
+    rng = np.random.default_rng(0)
+    for n in (4, 8, 16, 32, 64):
+        for bit in (10, 11, 12, 13):
+            sr = (C.c_int8 * 12)(*([16] * 12))
+            for _ in range(30):
+                x = rng.integers(-(1 << 17), 1 << 17, n, dtype=np.int32)
+                a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                getattr(ref, f"svt_av1_fdct{n}_new")(ptr(x), ptr(a), C.c_int8(bit), sr)
+                orc.orc_fdct(ptr(x), ptr(b), n, bit)
+                assert np.array_equal(a, b), ("fdct", n, bit)
+        for cb in (16, 18):
+            sr = (C.c_int8 * 12)(*([cb] * 12))
+            for _ in range(30):
+                x = rng.integers(-(1 << (cb - 1)), 1 << (cb - 1), n, dtype=np.int32)
+                a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                getattr(ref, f"svt_av1_idct{n}_new")(ptr(x), ptr(a), C.c_int8(12), sr)
+                orc.orc_idct(ptr(x), ptr(b), n, 12, cb)
+                assert np.array_equal(a, b), ("idct", n, cb)
+    for n in (4, 8, 16):
+        sr = (C.c_int8 * 12)(*([16] * 12))
+        for bit in (12, 13):
+            for it in range(30):
+                x = rng.integers(-(1 << 16), 1 << 16, n, dtype=np.int32)
+                if it == 0: x[:] = 0
+                a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                getattr(ref, f"svt_av1_fadst{n}_new")(ptr(x), ptr(a), C.c_int8(bit), sr)
+                orc.orc_fadst(ptr(x), ptr(b), n, bit)
+                assert np.array_equal(a, b), ("fadst", n, bit)
+                getattr(ref, f"svt_av1_iadst{n}_new")(ptr(x), ptr(a), C.c_int8(12), sr)
+                orc.orc_iadst(ptr(x), ptr(b), n, 12, 16)
+                assert np.array_equal(a, b), ("iadst", n)
+
+
+def test_txfm_2d_all_sizes_types(orc, ref):
+    """All 19 sizes x legal types x bd 8/10, inputs +-(2^bd-1) incl. the extreme patterns
+    (/root/reference/test/FwdTxfm2dAsmTest.cc:153-454); inverse fed with the forward output and with
+    random coefficients (/root/reference/test/InvTxfm2dAsmTest.cc:436-470, :691-760)."""
+    rng = np.random.default_rng(13596)
+    orc.orc_handle_transform.restype = C.c_uint64
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        kw, kh = min(w, 32), min(h, 32)
+        for tt in tc.legal_types(ts):
+            for bd in (8, 10):
+                for it in range(4):
+                    lim = (1 << bd) - 1
+                    x = rng.integers(-lim, lim + 1, (h, w + 3), dtype=np.int16)
+                    if it == 0: x[:] = lim
+                    if it == 1: x[:] = -lim
+                    a = tc.ref_fwd(ref, x, w + 3, tt, ts, bd)
+                    b = tc.orc_fwd(orc, x, w + 3, tt, ts, bd)
+                    assert np.array_equal(a, b), ("fwd", ts, tt, bd, it)
+                    if max(w, h) == 64:
+                        ea = tc.ref_handle(ref, a, ts)
+                        eb = orc.orc_handle_transform(ptr(b), ts)
+                        assert ea == eb and np.array_equal(a[:kw * kh], b[:kw * kh]), ("handle", ts)
+                    co = np.ascontiguousarray((a[:kw * kh] // 5) * 5).astype(np.int32)
+                    if it == 2:
+                        co = rng.integers(-(1 << (bd + 7)), 1 << (bd + 7), kw * kh, dtype=np.int32)
+                    pred = rng.integers(0, 1 << bd, (h, w + 5), dtype=np.uint16)
+                    r1 = np.zeros((h, w + 7), np.uint16); r2 = np.zeros((h, w + 7), np.uint16)
+                    tc.ref_inv(ref, co, pred, w + 5, r1, w + 7, tt, ts, bd)
+                    orc.orc_inv_txfm2d_add(ptr(co), ptr(pred), w + 5, ptr(r2), w + 7, tt, ts, bd)
+                    assert np.array_equal(r1, r2), ("inv", ts, tt, bd, it)
+
+
+def test_quantize_variants(orc, ref):
+    """quantize_b (8-bit c_ii), highbd_quantize_b, quantize_fp (3 scales), highbd_quantize_fp vs the
+    reference across q-index, sizes and coefficient ranges +-2^(7+bd)
+    (/root/reference/test/QuantAsmTest.cc:88-335, quantize_func_test.cc:276-658)."""
+    rng = np.random.default_rng(42)
+    orc.orc_cul_level.restype = C.c_int32
+    for ts in (0, 1, 2, 3, 4, 5, 8, 9, 12, 13, 16, 17):
+        ls = tc.TX_SCALE[ts]
+        for tt in (0, 10, 11):
+            if tt not in tc.legal_types(ts) and tt != 0:
+                continue
+            scan, iscan = tc.ref_scan(ref, ts, tt)
+            n = len(scan)
+            assert np.array_equal(iscan[scan], np.arange(n))
+            for bd, variants in ((8, (0, 2)), (10, (1, 3))):
+                for qindex in (0, 1, 20, 60, 120, 200, 255):
+                    qp = tc.ref_qparams(ref, bd, qindex, int(rng.integers(0, 3)))
+                    for it in range(3):
+                        lim = 1 << (7 + bd)
+                        coeff = rng.integers(-lim, lim + 1, n, dtype=np.int32)
+                        if it == 1: coeff = (coeff // 64).astype(np.int32)      # mostly inside the dead zone
+                        if it == 2: coeff[rng.integers(0, n, n // 2)] = 0
+                        for v in variants:
+                            a = tc.ref_quant(ref, v, coeff, qp, scan, iscan, ls)
+                            b = tc.orc_quant(orc, v, coeff, qp, scan, ls)
+                            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (ts, tt, bd, qindex, v)
