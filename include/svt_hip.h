@@ -88,6 +88,49 @@ int svt_hip_me_fullpel_frame(SvtHipCtx *ctx, const uint8_t *src, const uint8_t *
 /* Tuning knob (workgroup = 1, 2 or 4 waves per SB); default 2. */
 int svt_hip_me_set_waves_per_sb(SvtHipCtx *ctx, int waves);
 
+/* ------------------------------------------------------- residual + transform + quantisation ---- */
+/* One launch = a list of transform blocks of ONE size in one plane.  A block descriptor packs the
+ * block position (pixels, relative to the plane pointers) and its TxType (enum order of the
+ * reference, DCT_DCT = 0 .. H_FLIPADST = 15, Source/Lib/Common/Codec/EbDefinitions.h). */
+#define SVT_HIP_TX_DESC(x, y, tx_type) ((uint32_t)(x) | ((uint32_t)(y) << 14) | ((uint32_t)(tx_type) << 28))
+
+/* Quantizer of a launch = the {dc, ac} entries the reference takes from Quants/Dequants for one
+ * (qindex, plane) (Encoder/Codec/EbFullLoop.c:1428-1489) plus the variant:
+ *   0 svt_aom_quantize_b (8-bit, EbFullLoop.c:37)      1 svt_aom_highbd_quantize_b (:171)
+ *   2 svt_av1_quantize_fp[_32x32|_64x64] (:379,557,580) 3 svt_av1_highbd_quantize_fp (:534)
+ * For variants 2/3 pass round_fp_qtx / quant_fp_qtx in round / quant (as the facades :603-711 do).
+ * log_scale = av1_get_tx_scale_tab[tx_size] (EbFullLoop.h:66).  Quant matrices are flat on this path. */
+typedef struct {
+    int32_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+    int32_t log_scale, variant;
+} SvtHipQuantParams;
+/* Device pointers to the inverse scan (position of coefficient rc in scan order) of the launch's
+ * tx_size for the three scan classes of av1_scan_orders (Common/Codec/EbCoefficients.h:2563):
+ * [0] default zig-zag, [1] mrow, [2] mcol.  Classes 1/2 are only read for sizes <= 16x16. */
+typedef struct {
+    const int16_t *iscan[3];
+} SvtHipScanTables;
+
+/* residual (src - pred) -> forward 2-D transform -> [64-pt zero-out/re-pack + energy] -> quantize.
+ * Replaces svt_residual_kernel8bit/16bit (common_dsp_rtcd.h:169), svt_av1_fwd_txfm2d_WxH
+ * (aom_dsp_rtcd.h:129-135), svt_handle_transform64x* (:230) and the quantizers (:252-258) +
+ * cul_level (EbFullLoop.c:1595-1608) for a whole list of blocks.
+ *   pix_bytes 1: uint8_t planes, 2: uint16_t planes; strides in pixels.
+ *   coeff / qcoeff+dqcoeff / eob / cul_level / energy may be NULL independently (qcoeff and dqcoeff
+ *   go together); outputs are packed min(W,32) x min(H,32) int32 per block, block after block. */
+int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes, const void *d_src, int src_stride,
+                                     const void *d_pred, int pred_stride, const uint32_t *d_descs, int nblk,
+                                     const SvtHipQuantParams *qp, const SvtHipScanTables *scans, int32_t *d_coeff,
+                                     int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int32_t *d_cul_level,
+                                     uint64_t *d_energy);
+/* dequantized coefficients -> inverse 2-D transform -> add to prediction -> clip -> recon.
+ * Replaces svt_av1_inv_txfm2d_add_WxH (common_dsp_rtcd.h:117-153) / svt_av1_inv_txfm_add (:156).
+ * recon may alias pred (in-place reconstruction). bd = 8 or 10 (bd 8 with pix_bytes 2 = the
+ * 16-bit pipeline on 8-bit content). */
+int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes, int bd, const int32_t *d_dqcoeff,
+                                   const void *d_pred, int pred_stride, void *d_recon, int recon_stride,
+                                   const uint32_t *d_descs, int nblk);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,21 @@ class SbSearch(C.Structure):
                 ("width", C.c_int16), ("height", C.c_int16)]
 
 
+class QuantParams(C.Structure):
+    """SvtHipQuantParams (include/svt_hip.h)."""
+    _fields_ = [("zbin", C.c_int32 * 2), ("round", C.c_int32 * 2), ("quant", C.c_int32 * 2), ("quant_shift", C.c_int32 * 2),
+                ("dequant", C.c_int32 * 2), ("log_scale", C.c_int32), ("variant", C.c_int32)]
+
+
+class ScanTables(C.Structure):
+    """SvtHipScanTables (include/svt_hip.h): device pointers."""
+    _fields_ = [("iscan", C.c_void_p * 3)]
+
+
+def tx_desc(x, y, tx_type):
+    return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
+
+
 _lib = None
 
 
@@ -54,6 +69,9 @@ def lib():
     L.svt_hip_me_fullpel_frame_dev.argtypes = [vp, u8p, u8p, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_fullpel_frame.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
+    L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
+                                                   C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
+    L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     _lib = L
     return L
 
@@ -71,6 +89,32 @@ class Context:
     def check(self, rc, what=""):
         if rc != 0:
             raise RuntimeError(f"{what} failed: status {rc}: {self.L.svt_hip_last_error(self.h).decode()}")
+
+    # ---- device memory through the C ABI (tests / tools; bench.py uses torch tensors instead)
+    def to_device(self, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self.check(self.L.svt_hip_malloc(self.h, C.byref(p), max(arr.nbytes, 4)), "malloc")
+        if arr.nbytes:
+            self.check(self.L.svt_hip_memcpy_h2d(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        return p
+
+    def empty(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.L.svt_hip_malloc(self.h, C.byref(p), max(nbytes, 4)), "malloc")
+        return p
+
+    def to_host(self, dptr, shape, dtype):
+        import numpy as np
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            self.check(self.L.svt_hip_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), dptr, out.nbytes), "d2h")
+        return out
+
+    def free(self, *ptrs):
+        for p in ptrs:
+            self.L.svt_hip_free(self.h, p)
 
     def close(self):
         if self.h:

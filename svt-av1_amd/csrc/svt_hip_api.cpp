@@ -182,4 +182,36 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------------- transform / quant */
+int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, const void* d_src, int src_stride,
+                                     const void* d_pred, int pred_stride, const uint32_t* d_descs, int nblk,
+                                     const SvtHipQuantParams* qp, const SvtHipScanTables* scans, int32_t* d_coeff,
+                                     int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob, int32_t* d_cul_level,
+                                     uint64_t* d_energy) {
+    if (!c || !d_src || !d_pred || !d_descs || nblk < 0 || tx_size < 0 || tx_size > 18 || (pix_bytes != 1 && pix_bytes != 2) ||
+        ((d_qcoeff != nullptr) != (d_dqcoeff != nullptr)) || (d_qcoeff && (!qp || !scans || !scans->iscan[0])) ||
+        (qp && (qp->variant < 0 || qp->variant > 3 || qp->log_scale < 0 || qp->log_scale > 2))) {
+        if (c) c->err = "svt_hip_fwd_txfm_quant_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_fwd_txfm_quant(c->stream, tx_size, pix_bytes, d_src, src_stride, d_pred, pred_stride,
+                                                            d_descs, nblk, qp, scans, d_coeff, d_qcoeff, d_dqcoeff, d_eob,
+                                                            d_cul_level, d_energy);
+    if (e != hipSuccess) return fail(c, e, "fwd_txfm_quant launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int bd, const int32_t* d_dqcoeff, const void* d_pred,
+                                   int pred_stride, void* d_recon, int recon_stride, const uint32_t* d_descs, int nblk) {
+    if (!c || !d_dqcoeff || !d_pred || !d_recon || !d_descs || nblk < 0 || tx_size < 0 || tx_size > 18 ||
+        (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) {
+        if (c) c->err = "svt_hip_inv_txfm_add_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_inv_txfm_add(c->stream, tx_size, pix_bytes, bd, d_dqcoeff, d_pred, pred_stride, d_recon,
+                                                          recon_stride, d_descs, nblk);
+    if (e != hipSuccess) return fail(c, e, "inv_txfm_add launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

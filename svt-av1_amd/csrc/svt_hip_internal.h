@@ -9,4 +9,10 @@ extern "C" {
 int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                               int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
                               uint32_t* d_best_mv, int waves_per_sb);
+int svt_hip_launch_fwd_txfm_quant(hipStream_t st, int tx_size, int pix_bytes, const void* src, int src_stride, const void* pred,
+                                  int pred_stride, const uint32_t* descs, int nblk, const SvtHipQuantParams* qp,
+                                  const SvtHipScanTables* scans, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
+                                  int32_t* cul_level, uint64_t* energy);
+int svt_hip_launch_inv_txfm_add(hipStream_t st, int tx_size, int pix_bytes, int bd, const int32_t* dqcoeff, const void* pred,
+                                int pred_stride, void* recon, int recon_stride, const uint32_t* descs, int nblk);
 }

@@ -1,0 +1,150 @@
+"""GPU parity: batched residual + forward transform + quantize, and inverse transform + recon (HIP,
+through the C ABI) vs the oracle restatement and the committed golden vectors.
+Matrix mirrors /root/reference/test/FwdTxfm2dAsmTest.cc:153-454, InvTxfm2dAsmTest.cc:691-760,
+QuantAsmTest.cc:88-335, quantize_func_test.cc:276-658: all 19 sizes x legal types x bd 8/10,
+inputs +-(2^bd-1) incl. all-max / all-min blocks, several q-indices, all four quantizers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ptr
+import txfm_common as tc
+from test_oracle_golden import T, V, golden_scan, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def qparams_struct(pkg, qp, variant, log_scale):
+    s = pkg.QuantParams()
+    rnd, qnt = (qp[5], qp[6]) if variant >= 2 else (qp[1], qp[2])
+    for name, row in (("zbin", qp[0]), ("round", rnd), ("quant", qnt), ("quant_shift", qp[3]), ("dequant", qp[4])):
+        getattr(s, name)[0] = int(row[0]); getattr(s, name)[1] = int(row[1])
+    s.log_scale = log_scale; s.variant = variant
+    return s
+
+
+def run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant, want_coeff=True):
+    """src/pred: 2-D pixel planes (u8 or u16).  Returns dict of host arrays."""
+    w, h = tc.TXW[ts], tc.TXH[ts]
+    nk = min(w, 32) * min(h, 32)
+    n = len(descs)
+    pix = src.dtype.itemsize
+    d_src, d_pred = hip.to_device(src), hip.to_device(pred)
+    d_desc = hip.to_device(np.asarray(descs, np.uint32))
+    scans = pkg.ScanTables(); keep = []
+    for cls in range(3):
+        key = f"iscan/{ts}/{cls}"
+        if key in T.files:
+            p = hip.to_device(np.ascontiguousarray(T[key])); keep.append(p); scans.iscan[cls] = p.value
+    d_co, d_q, d_dq = hip.empty(n * nk * 4), hip.empty(n * nk * 4), hip.empty(n * nk * 4)
+    d_eob, d_cul, d_en = hip.empty(n * 2), hip.empty(n * 4), hip.empty(n * 8)
+    qs = qparams_struct(pkg, qp, variant, tc.TX_SCALE[ts])
+    hip.check(hip.L.svt_hip_fwd_txfm_quant_batch_dev(hip.h, ts, pix, d_src, src.shape[1], d_pred, pred.shape[1], d_desc, n,
+                                                    C.byref(qs), C.byref(scans), d_co if want_coeff else None, d_q, d_dq, d_eob, d_cul, d_en), "fwd")
+    out = dict(coeff=hip.to_host(d_co, (n, nk), np.int32), q=hip.to_host(d_q, (n, nk), np.int32), dq=hip.to_host(d_dq, (n, nk), np.int32),
+               eob=hip.to_host(d_eob, (n,), np.uint16), cul=hip.to_host(d_cul, (n,), np.int32), energy=hip.to_host(d_en, (n,), np.uint64))
+    hip.free(d_src, d_pred, d_desc, d_co, d_q, d_dq, d_eob, d_cul, d_en, *keep)
+    return out
+
+
+def run_inv(hip, ts, bd, dq, pred, descs):
+    n = len(descs)
+    pix = pred.dtype.itemsize
+    d_dq, d_pred, d_desc = hip.to_device(dq), hip.to_device(pred), hip.to_device(np.asarray(descs, np.uint32))
+    d_rec = hip.to_device(np.zeros_like(pred))
+    hip.check(hip.L.svt_hip_inv_txfm_add_batch_dev(hip.h, ts, pix, bd, d_dq, d_pred, pred.shape[1], d_rec, pred.shape[1], d_desc, n), "inv")
+    rec = hip.to_host(d_rec, pred.shape, pred.dtype)
+    hip.free(d_dq, d_pred, d_desc, d_rec)
+    return rec
+
+
+def oracle_block(orc, ts, tt, bd, src, pred, x, y, qp, variant, scan):
+    w, h = tc.TXW[ts], tc.TXH[ts]
+    kw, kh = min(w, 32), min(h, 32)
+    res = (src[y:y + h, x:x + w].astype(np.int32) - pred[y:y + h, x:x + w].astype(np.int32)).astype(np.int16)
+    res = np.ascontiguousarray(res)
+    co = tc.orc_fwd(orc, res, w, tt, ts, bd)
+    orc.orc_handle_transform.restype = C.c_uint64
+    en = orc.orc_handle_transform(ptr(co), ts)
+    co = np.ascontiguousarray(co[:kw * kh])
+    q, dq, eob = tc.orc_quant(orc, variant, co, qp, scan, tc.TX_SCALE[ts])
+    orc.orc_cul_level.restype = C.c_int32
+    cul = orc.orc_cul_level(ptr(q), ptr(scan), eob)
+    return co, en, q, dq, eob, cul
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_fwd_quant_inv_all_types(hip, pkg, orc, ts):
+    w, h = tc.TXW[ts], tc.TXH[ts]
+    rng = np.random.default_rng(100 + ts)
+    for bd in (8, 10):
+        dt = np.uint8 if bd == 8 else np.uint16
+        types = tc.legal_types(ts)
+        PW, PH = 4 * 64 + 8, 3 * 64  # plane with an odd-ish stride
+        src = rng.integers(0, 1 << bd, (PH, PW)).astype(dt)
+        pred = rng.integers(0, 1 << bd, (PH, PW)).astype(dt)
+        src[0:64, 0:64] = (1 << bd) - 1; pred[0:64, 0:64] = 0           # residual = +max
+        src[0:64, 64:128] = 0; pred[0:64, 64:128] = (1 << bd) - 1       # residual = -max
+        pos = [(x, y) for y in range(0, PH - h + 1, h) for x in range(0, 256 - w + 1, w)]
+        rng.shuffle(pos)
+        pos = [(0, 0), (64, 0)] + pos[:min(len(pos), 70)]
+        descs, tts = [], []
+        for i, (x, y) in enumerate(pos):
+            tt = types[i % len(types)]
+            descs.append(pkg.tx_desc(x, y, tt)); tts.append(tt)
+        for qi, variant in ((60, 0 if bd == 8 else 1), (200, 2 if bd == 8 else 3), (20, 0 if bd == 8 else 1)):
+            qp = np.ascontiguousarray(T[f"qp/{bd}/{qi}/{qi % 3}"])
+            g = run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant)
+            for i, ((x, y), tt) in enumerate(zip(pos, tts)):
+                scan, _ = golden_scan(ts, tt)
+                co, en, q, dq, eob, cul = oracle_block(orc, ts, tt, bd, src, pred, x, y, qp, variant, scan)
+                assert np.array_equal(g["coeff"][i], co), ("coeff", ts, tt, bd, i)
+                assert int(g["energy"][i]) == en, ("energy", ts, tt, bd)
+                assert np.array_equal(g["q"][i], q) and np.array_equal(g["dq"][i], dq), ("quant", ts, tt, bd, qi, variant)
+                assert int(g["eob"][i]) == eob and int(g["cul"][i]) == cul, ("eob/cul", ts, tt, bd, qi, variant)
+            # inverse on the GPU's own dequantized coefficients, non-overlapping blocks only
+            seen, keep = set(), []
+            for i, (x, y) in enumerate(pos):
+                if (x, y) not in seen:
+                    seen.add((x, y)); keep.append(i)
+            rec = run_inv(hip, ts, bd, np.ascontiguousarray(g["dq"][keep]), pred, [descs[i] for i in keep])
+            p16 = pred.astype(np.uint16)
+            for i in keep:
+                x, y = pos[i]
+                exp = np.zeros((h, w), np.uint16)
+                orc.orc_inv_txfm2d_add(ptr(np.ascontiguousarray(g["dq"][i])), ptr(np.ascontiguousarray(p16[y:y + h, x:x + w])), w, ptr(exp), w, tts[i], ts, bd)
+                assert np.array_equal(rec[y:y + h, x:x + w].astype(np.uint16), exp), ("inv", ts, tts[i], bd, qi)
+
+
+def test_golden_vectors(hip, pkg):
+    """The committed reference-generated vectors through the HIP path (no oracle involved)."""
+    by_ts = {}
+    for ts, tt, bd in golden_cases():
+        by_ts.setdefault((ts, bd), []).append(tt)
+    for (ts, bd), tts in sorted(by_ts.items()):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        dt = np.uint8 if bd == 8 else np.uint16
+        n = len(tts)
+        src = np.zeros((h, n * w), np.int32); pred = np.zeros((h, n * w), np.int32)
+        for i, tt in enumerate(tts):
+            x = V[f"{ts}/{tt}/{bd}/x"].astype(np.int32)
+            # realise the residual x as src - pred with both inside the pixel range
+            pred[:, i * w:(i + 1) * w] = np.where(x < 0, -x, 0)
+            src[:, i * w:(i + 1) * w] = np.where(x < 0, 0, x)
+        descs = [pkg.tx_desc(i * w, 0, tt) for i, tt in enumerate(tts)]
+        qp = np.ascontiguousarray(T[f"qp/{bd}/60/0"])
+        for variant, kq, kdq, ke in ((0 if bd == 8 else 1, "q", "dq", 0), (2 if bd == 8 else 3, "qf", "dqf", 1)):
+            g = run_fwd(hip, pkg, ts, bd, src.astype(dt), pred.astype(dt), descs, qp, variant)
+            for i, tt in enumerate(tts):
+                k = f"{ts}/{tt}/{bd}"
+                assert np.array_equal(g["coeff"][i], V[k + "/coeff"]), k
+                assert int(g["energy"][i]) == int(V[k + "/energy"][0]), k
+                assert np.array_equal(g["q"][i], V[k + "/" + kq]) and np.array_equal(g["dq"][i], V[k + "/" + kdq]), (k, variant)
+                assert int(g["eob"][i]) == int(V[k + "/eob"][ke]), (k, variant)
+        gp = np.concatenate([V[f"{ts}/{tt}/{bd}/pred"] for tt in tts], axis=1).astype(dt)
+        dq = np.stack([V[f"{ts}/{tt}/{bd}/dq"] for tt in tts])
+        rec = run_inv(hip, ts, bd, np.ascontiguousarray(dq), np.ascontiguousarray(gp), descs)
+        for i, tt in enumerate(tts):
+            assert np.array_equal(rec[:, i * w:(i + 1) * w].astype(np.uint16), V[f"{ts}/{tt}/{bd}/rec"]), (ts, tt, bd)
