@@ -131,6 +131,30 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes, i
                                    const void *d_pred, int pred_stride, void *d_recon, int recon_stride,
                                    const uint32_t *d_descs, int nblk);
 
+/* ------------------------------------------------------------------ deblocking loop filter ------ */
+/* Per luma 4x4 unit summary of the reference's ModeInfo fields that set_lpf_parameters reads
+ * (Encoder/Codec/EbDeblockingFilter.c:168-319): transform size actually used by the block in each
+ * plane (get_transform_size, :134), prediction block size (sb_type), "skip && inter", and the filter
+ * level already looked up in LoopFilterInfoN.lvl[plane][seg][dir][ref][mode] for the block. */
+typedef struct {
+    uint8_t tx_w_log2, tx_h_log2;       /* luma transform block, pixels, log2 (2..6) */
+    uint8_t uv_tx_w_log2, uv_tx_h_log2; /* chroma transform block in chroma pixels, log2 */
+    uint8_t bw_log2, bh_log2;           /* prediction block in luma pixels, log2 */
+    uint8_t skip_inter;                 /* mbmi->skip && is_inter_block */
+    uint8_t level[3][2];                /* [plane][0 = vertical edges, 1 = horizontal edges] */
+} SvtHipDlfModeInfo;
+/* Host: edge descriptors of one plane from the mode-info grid; restates set_lpf_parameters.
+ * edges_v / edges_h: [units_h][units_w] uint16 = (level << 8) | filter_length(0,4,6,8,14) for the
+ * edge on the left / top of each 4x4 unit of the plane; units = ceil(plane dim / 4). */
+int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y,
+                            int plane_w, int plane_h, uint16_t *edges_v, uint16_t *edges_h);
+/* Deblock one plane in place: all vertical edges, then all horizontal edges (normative order;
+ * replaces svt_av1_loop_filter_frame for that plane, EbDeblockingFilter.c:711, and the 16 edge
+ * kernels svt_aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}, common_dsp_rtcd.h:1051-1081).
+ * Either descriptor pointer may be NULL to run a single direction (filter-level search probes). */
+int svt_hip_deblock_plane_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int bd, const uint16_t *d_edges_v,
+                              const uint16_t *d_edges_h, int units_w, int units_h, int sharpness);
+
 #ifdef __cplusplus
 }
 #endif

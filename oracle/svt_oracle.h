@@ -106,6 +106,13 @@ void orc_quantize(int variant, const int32_t *coeff, int n, const int16_t *zbin,
                   const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale);
 int32_t orc_cul_level(const int32_t *qcoeff, const int16_t *scan, int eob);
 
+/* ---------------------------------------------------------------- deblocking (dlf_oracle.c) ---- */
+void orc_lpf_core(int *px, int len, int blimit, int limit, int thresh, int bd);
+void orc_lpf_edge(void *s, int pix_bytes, int pitch, int dir, int len, int blimit, int limit, int thresh, int bd);
+void orc_lf_limits(int level, int sharpness, int *lim, int *mblim, int *hev_thr);
+void orc_deblock_plane(void *plane, int pix_bytes, int stride, int bd, const uint16_t *edges_v, const uint16_t *edges_h,
+                       int units_w, int units_h, int sharpness);
+
 #ifdef __cplusplus
 }
 #endif

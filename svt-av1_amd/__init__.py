@@ -35,6 +35,12 @@ class ScanTables(C.Structure):
     _fields_ = [("iscan", C.c_void_p * 3)]
 
 
+class DlfModeInfo(C.Structure):
+    """SvtHipDlfModeInfo (include/svt_hip.h)."""
+    _fields_ = [("tx_w_log2", C.c_uint8), ("tx_h_log2", C.c_uint8), ("uv_tx_w_log2", C.c_uint8), ("uv_tx_h_log2", C.c_uint8),
+                ("bw_log2", C.c_uint8), ("bh_log2", C.c_uint8), ("skip_inter", C.c_uint8), ("level", (C.c_uint8 * 2) * 3)]
+
+
 def tx_desc(x, y, tx_type):
     return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
 
@@ -72,6 +78,8 @@ def lib():
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
+    L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
     _lib = L
     return L
 

@@ -1,0 +1,149 @@
+// deblock.hip — AV1 deblocking loop filter, whole plane per launch, gfx950.
+//
+// Replaces (file:line under /root/reference/Source/Lib):
+//   Common/Codec/EbDeblockingCommon.c:251-393, :882-921   svt_aom_lpf_{horizontal,vertical}_{4,6,8,14}_c
+//   Common/Codec/EbDeblockingCommon.c:483-582, :698-805   svt_aom_highbd_lpf_*_c
+//   Encoder/Codec/EbDeblockingFilter.c:321-611            svt_av1_filter_block_plane_vert / _horz (the per-SB walk)
+//   Encoder/Codec/EbDeblockingFilter.c:711                svt_av1_loop_filter_frame
+// The reference walks SB by SB and interleaves "vertical edges of SB(x), horizontal edges of
+// SB(x-1)"; that is order-equivalent to the normative "all vertical edges of the picture, then all
+// horizontal edges", and inside one direction every edge segment is independent because the filter
+// length is bounded by the smaller transform next to the edge (set_lpf_parameters, :286-300).
+// So: two launches per plane, one lane per (edge, sample), the per-4x4 edge descriptors
+// ((level << 8) | length) are produced on the host (svt_hip_dlf_build_edges).
+// Lanes run along x in both passes, so plane reads/writes are coalesced rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svt_hip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// px[0..13] = p6..p0 q0..q6; returns how many samples on each side may have changed
+template <int BD>
+__device__ __forceinline__ int lpf_core(int (&px)[14], int len, int level, int sharpness) {
+    constexpr int sh = BD - 8, t80 = 0x80 << sh, lo = -t80, hi = t80 - 1, one = 1 << sh;
+    // limits of the level: update_sharpness (EbDeblockingCommon.c:587-606), hev_thr = lvl >> 4 (EbDeblockingFilter.c:38)
+    int inside = level >> ((sharpness > 0) + (sharpness > 4));
+    if (sharpness > 0) inside = min(inside, 9 - sharpness);
+    inside = max(inside, 1);
+    const int lim = inside << sh, blim = (2 * (level + 2) + inside) << sh, thr = (level >> 4) << sh;
+#define p(i) px[6 - (i)]
+#define q(i) px[7 + (i)]
+    bool m = (iabs(p(1) - p(0)) > lim) | (iabs(q(1) - q(0)) > lim) | ((iabs(p(0) - q(0)) * 2 + iabs(p(1) - q(1)) / 2) > blim);
+    if (len >= 6) m |= (iabs(p(2) - p(1)) > lim) | (iabs(q(2) - q(1)) > lim);
+    if (len >= 8) m |= (iabs(p(3) - p(2)) > lim) | (iabs(q(3) - q(2)) > lim);
+    const bool mask = !m;
+    bool flat = false, flat2 = false;
+    if (len >= 6) {
+        flat = !((iabs(p(1) - p(0)) > one) | (iabs(q(1) - q(0)) > one) | (iabs(p(2) - p(0)) > one) | (iabs(q(2) - q(0)) > one));
+        if (len >= 8) flat &= !((iabs(p(3) - p(0)) > one) | (iabs(q(3) - q(0)) > one));
+    }
+    if (len == 14)
+        flat2 = !((iabs(p(4) - p(0)) > one) | (iabs(q(4) - q(0)) > one) | (iabs(p(5) - p(0)) > one) | (iabs(q(5) - q(0)) > one) |
+                  (iabs(p(6) - p(0)) > one) | (iabs(q(6) - q(0)) > one));
+#define RP2(v, n) (((v) + (1 << ((n)-1))) >> (n))
+    if (len == 14 && flat2 && flat && mask) {
+        const int p6 = p(6), p5 = p(5), p4 = p(4), p3 = p(3), p2 = p(2), p1 = p(1), p0 = p(0);
+        const int q0 = q(0), q1 = q(1), q2 = q(2), q3 = q(3), q4 = q(4), q5 = q(5), q6 = q(6);
+        p(5) = RP2(p6 * 7 + p5 * 2 + p4 * 2 + p3 + p2 + p1 + p0 + q0, 4);
+        p(4) = RP2(p6 * 5 + p5 * 2 + p4 * 2 + p3 * 2 + p2 + p1 + p0 + q0 + q1, 4);
+        p(3) = RP2(p6 * 4 + p5 + p4 * 2 + p3 * 2 + p2 * 2 + p1 + p0 + q0 + q1 + q2, 4);
+        p(2) = RP2(p6 * 3 + p5 + p4 + p3 * 2 + p2 * 2 + p1 * 2 + p0 + q0 + q1 + q2 + q3, 4);
+        p(1) = RP2(p6 * 2 + p5 + p4 + p3 + p2 * 2 + p1 * 2 + p0 * 2 + q0 + q1 + q2 + q3 + q4, 4);
+        p(0) = RP2(p6 + p5 + p4 + p3 + p2 + p1 * 2 + p0 * 2 + q0 * 2 + q1 + q2 + q3 + q4 + q5, 4);
+        q(0) = RP2(p5 + p4 + p3 + p2 + p1 + p0 * 2 + q0 * 2 + q1 * 2 + q2 + q3 + q4 + q5 + q6, 4);
+        q(1) = RP2(p4 + p3 + p2 + p1 + p0 + q0 * 2 + q1 * 2 + q2 * 2 + q3 + q4 + q5 + q6 * 2, 4);
+        q(2) = RP2(p3 + p2 + p1 + p0 + q0 + q1 * 2 + q2 * 2 + q3 * 2 + q4 + q5 + q6 * 3, 4);
+        q(3) = RP2(p2 + p1 + p0 + q0 + q1 + q2 * 2 + q3 * 2 + q4 * 2 + q5 + q6 * 4, 4);
+        q(4) = RP2(p1 + p0 + q0 + q1 + q2 + q3 * 2 + q4 * 2 + q5 * 2 + q6 * 5, 4);
+        q(5) = RP2(p0 + q0 + q1 + q2 + q3 + q4 * 2 + q5 * 2 + q6 * 7, 4);
+        return 6;
+    }
+    if (len >= 8 && flat && mask) {
+        const int p3 = p(3), p2 = p(2), p1 = p(1), p0 = p(0), q0 = q(0), q1 = q(1), q2 = q(2), q3 = q(3);
+        p(2) = RP2(p3 + p3 + p3 + 2 * p2 + p1 + p0 + q0, 3);
+        p(1) = RP2(p3 + p3 + p2 + 2 * p1 + p0 + q0 + q1, 3);
+        p(0) = RP2(p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2, 3);
+        q(0) = RP2(p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3, 3);
+        q(1) = RP2(p1 + p0 + q0 + 2 * q1 + q2 + q3 + q3, 3);
+        q(2) = RP2(p0 + q0 + q1 + 2 * q2 + q3 + q3 + q3, 3);
+        return 3;
+    }
+    if (len == 6 && flat && mask) {
+        const int p2 = p(2), p1 = p(1), p0 = p(0), q0 = q(0), q1 = q(1), q2 = q(2);
+        p(1) = RP2(p2 * 3 + p1 * 2 + p0 * 2 + q0, 3);
+        p(0) = RP2(p2 + p1 * 2 + p0 * 2 + q0 * 2 + q1, 3);
+        q(0) = RP2(p1 + p0 * 2 + q0 * 2 + q1 * 2 + q2, 3);
+        q(1) = RP2(p0 + q0 * 2 + q1 * 2 + q2 * 3, 3);
+        return 2;
+    }
+    {
+        const int ps1 = p(1) - t80, ps0 = p(0) - t80, qs0 = q(0) - t80, qs1 = q(1) - t80;
+        const bool hev = (iabs(p(1) - p(0)) > thr) | (iabs(q(1) - q(0)) > thr);
+        int f = hev ? clampi(ps1 - qs1, lo, hi) : 0;
+        f = mask ? clampi(f + 3 * (qs0 - ps0), lo, hi) : 0;
+        const int f1 = clampi(f + 4, lo, hi) >> 3, f2 = clampi(f + 3, lo, hi) >> 3;
+        q(0) = clampi(qs0 - f1, lo, hi) + t80;
+        p(0) = clampi(ps0 + f2, lo, hi) + t80;
+        const int f3 = hev ? 0 : ((f1 + 1) >> 1);
+        q(1) = clampi(qs1 - f3, lo, hi) + t80;
+        p(1) = clampi(ps1 + f3, lo, hi) + t80;
+        return 2;
+    }
+#undef p
+#undef q
+#undef RP2
+}
+
+// DIR 0: vertical edges (taps along x); DIR 1: horizontal edges (taps along y)
+template <typename PIX, int BD, int DIR>
+__global__ void __launch_bounds__(256)
+deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restrict__ edges, int units_w, int units_h, int sharpness) {
+    int ux, uy, sx, sy;  // unit, sample position of q0
+    if (DIR == 0) {
+        ux = blockIdx.x * 256 + threadIdx.x;  sy = blockIdx.y;  uy = sy >> 2;  sx = 4 * ux;
+        if (ux >= units_w) return;
+    } else {
+        sx = blockIdx.x * 256 + threadIdx.x;  uy = blockIdx.y;  ux = sx >> 2;  sy = 4 * uy;
+        if (ux >= units_w) return;
+    }
+    const uint32_t e = edges[uy * units_w + ux];
+    const int len = e & 0xff, level = e >> 8;
+    if (!len) return;
+    const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+    const ptrdiff_t tap = DIR == 0 ? 1 : stride;
+    PIX* s = plane + (size_t)sy * stride + sx;
+    int px[14];
+#pragma unroll
+    for (int k = 1; k <= 7; k++) {
+        px[7 - k] = (k <= half) ? (int)s[-(ptrdiff_t)k * tap] : 0;
+        px[6 + k] = (k <= half) ? (int)s[(ptrdiff_t)(k - 1) * tap] : 0;
+    }
+    const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+    for (int k = 1; k <= 6; k++)
+        if (k <= changed) {
+            s[-(ptrdiff_t)k * tap]     = (PIX)px[7 - k];
+            s[(ptrdiff_t)(k - 1) * tap] = (PIX)px[6 + k];
+        }
+}
+
+template <typename PIX, int BD>
+int launch_both(hipStream_t st, PIX* plane, int stride, const uint16_t* ev, const uint16_t* eh, int uw, int uh, int sharp) {
+    if (ev) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh), dim3(256), 0, st, plane, stride, ev, uw, uh, sharp);
+    if (eh) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 1>), dim3((4 * uw + 255) / 256, uh), dim3(256), 0, st, plane, stride, eh, uw, uh, sharp);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
+                                            const uint16_t* edges_h, int units_w, int units_h, int sharpness) {
+    if (units_w <= 0 || units_h <= 0) return 0;
+    if (pix_bytes == 1) return launch_both<uint8_t, 8>(st, (uint8_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
+    if (bd == 8) return launch_both<uint16_t, 8>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
+    return launch_both<uint16_t, 10>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
+}

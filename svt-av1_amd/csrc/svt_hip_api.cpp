@@ -214,4 +214,58 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------------------- deblocking */
+// Restatement of set_lpf_parameters (Encoder/Codec/EbDeblockingFilter.c:168-319) over a plain grid.
+int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
+                            int plane_h, uint16_t* edges_v, uint16_t* edges_h) {
+    if (!mi || mi_cols <= 0 || mi_rows <= 0 || plane < 0 || plane > 2 || !edges_v || !edges_h) return SVT_HIP_ERR_BAD_ARG;
+    const int uw = (plane_w + 3) >> 2, uh = (plane_h + 3) >> 2;
+    for (int dir = 0; dir < 2; dir++) {
+        uint16_t* out = dir == 0 ? edges_v : edges_h;
+        for (int uy = 0; uy < uh; uy++)
+            for (int ux = 0; ux < uw; ux++) {
+                uint16_t v = 0;
+                const int x = 4 * ux, y = 4 * uy;
+                // chroma maps to the bottom/right mi of the co-located 8x8 (:196-197)
+                int mr = ss_y | ((y << ss_y) >> 2), mc = ss_x | ((x << ss_x) >> 2);
+                if (mr >= mi_rows) mr = mi_rows - 1;
+                if (mc >= mi_cols) mc = mi_cols - 1;
+                const SvtHipDlfModeInfo& cur = mi[mr * mi_cols + mc];
+                const int ts = plane == 0 ? (dir == 0 ? cur.tx_w_log2 : cur.tx_h_log2) : (dir == 0 ? cur.uv_tx_w_log2 : cur.uv_tx_h_log2);
+                const int coord = dir == 0 ? x : y;
+                if (!(coord & ((1 << ts) - 1)) && coord) {
+                    const int pr = dir == 0 ? mr : mr - (1 << ss_y), pc = dir == 0 ? mc - (1 << ss_x) : mc;
+                    if (pr >= 0 && pc >= 0) {
+                        const SvtHipDlfModeInfo& prv = mi[pr * mi_cols + pc];
+                        const int pts = plane == 0 ? (dir == 0 ? prv.tx_w_log2 : prv.tx_h_log2) : (dir == 0 ? prv.uv_tx_w_log2 : prv.uv_tx_h_log2);
+                        const int cl = cur.level[plane][dir], pl = prv.level[plane][dir];
+                        int bdim = dir == 0 ? cur.bw_log2 - (plane ? ss_x : 0) : cur.bh_log2 - (plane ? ss_y : 0);
+                        if (bdim < 2) bdim = 2;
+                        const bool pu_edge = !(coord & ((1 << bdim) - 1));
+                        if ((cl || pl) && (!prv.skip_inter || !cur.skip_inter || pu_edge)) {
+                            const int mts = ts < pts ? ts : pts;
+                            const int len = mts <= 2 ? 4 : (mts == 3 ? (plane ? 6 : 8) : (plane ? 6 : 14));
+                            v = (uint16_t)(((cl ? cl : pl) << 8) | len);
+                        }
+                    }
+                }
+                out[uy * uw + ux] = v;
+            }
+    }
+    return SVT_HIP_OK;
+}
+
+int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int bd, const uint16_t* d_edges_v,
+                              const uint16_t* d_edges_h, int units_w, int units_h, int sharpness) {
+    if (!c || !d_plane || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || units_w < 0 ||
+        units_h < 0 || sharpness < 0 || sharpness > 7 || (!d_edges_v && !d_edges_h)) {
+        if (c) c->err = "svt_hip_deblock_plane_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_deblock_plane(c->stream, d_plane, pix_bytes, stride, bd, d_edges_v, d_edges_h, units_w,
+                                                           units_h, sharpness);
+    if (e != hipSuccess) return fail(c, e, "deblock launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

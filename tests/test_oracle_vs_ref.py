@@ -183,3 +183,29 @@ def test_quantize_variants(orc, ref):
                             a = tc.ref_quant(ref, v, coeff, qp, scan, iscan, ls)
                             b = tc.orc_quant(orc, v, coeff, qp, scan, ls)
                             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (ts, tt, bd, qindex, v)
+
+
+# ------------------------------------------------------------------------------------ deblocking
+def test_deblock_edge_filters(orc, ref):
+    """All 16 edge filters (lbd/hbd x 4/6/8/14 x h/v) on random and smooth data
+    (/root/reference/test/DeblockTest.cc:210-306)."""
+    rng = np.random.default_rng(99)
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        for length in (4, 6, 8, 14):
+            for d, dname in ((0, "vertical"), (1, "horizontal")):
+                name = f"svt_aom_{'highbd_' if bd > 8 else ''}lpf_{dname}_{length}_c"
+                for it in range(300):
+                    base = rng.integers(0, 1 << bd)
+                    spread = int(rng.choice([1, 2, 4, 16, 64, 1 << bd]))
+                    buf = np.clip(base + rng.integers(-spread, spread + 1, (24, 24)), 0, (1 << bd) - 1).astype(dt)
+                    a, b = buf.copy(), buf.copy()
+                    bl = np.full(16, rng.integers(0, 256), np.uint8); li = np.full(16, rng.integers(0, 64), np.uint8)
+                    th = np.full(16, rng.integers(0, 16), np.uint8)
+                    off = 10 * 24 + 10
+                    pa = C.c_void_p(a.ctypes.data + off * a.itemsize); pb = C.c_void_p(b.ctypes.data + off * b.itemsize)
+                    if bd > 8:
+                        getattr(ref, name)(pa, 24, ptr(bl), ptr(li), ptr(th), bd)
+                    else:
+                        getattr(ref, name)(pa, 24, ptr(bl), ptr(li), ptr(th))
+                    orc.orc_lpf_edge(pb, a.itemsize, 24, d, length, int(bl[0]), int(li[0]), int(th[0]), bd)
+                    assert np.array_equal(a, b), (name, it)
