@@ -155,6 +155,32 @@ int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_row
 int svt_hip_deblock_plane_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int bd, const uint16_t *d_edges_v,
                               const uint16_t *d_edges_h, int units_w, int units_h, int sharpness);
 
+/* ------------------------------------------------------------------ CDEF ------------------------ */
+/* Strength search of cdef_seg_search / cdef_seg_search16bit (Encoder/Codec/EbCdefProcess.c:80-475)
+ * for every 64x64 filter block of a 4:2:0 frame in two launches (luma, then both chroma planes):
+ *   d_rec[3]  deblocked reconstruction planes, d_src[3] source planes (pixel (0,0) pointers, strides in
+ *             pixels); w x h = luma size (multiples of 8; a last filter block narrower than 16 luma
+ *             pixels is not supported, see DESIGN.md "CDEF borders")
+ *   d_skip8   [h/8][w/8], 1 = the 8x8 luma block is entirely skip (is_8x8_block_skip, EbEncCdef.c:239)
+ *   d_mse     [2][nfb][64] uint64: distortion of plane 0 (Y) / 1 (U+V) for strength index
+ *             gi = pri*4 + sec_idx of the full search (pcs->mse_seg, CDEF_FULL_SEARCH); the reduced
+ *             pick methods are subsets of these 64 entries (get_cdef_filter_strengths,
+ *             Common/Codec/EbDefinitions.h:1696).  Entries of all-skip filter blocks are not written.
+ *   d_dir/d_var [nfb][64] scratch/outputs: direction and variance of every 8x8 block (svt_cdef_find_dir).
+ * Replaces svt_cdef_find_dir, svt_cdef_filter_block, svt_copy_rect8_8bit_to_16bit,
+ * svt_compute_cdef_dist_{8bit,16bit} (common_dsp_rtcd.h:1032-1037, aom_dsp_rtcd.c:97-98). */
+int svt_hip_cdef_search_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *const d_rec[3], const int rec_stride[3],
+                                  const void *const d_src[3], const int src_stride[3], int w, int h,
+                                  const uint8_t *d_skip8, int pri_damping, int bd, uint64_t *d_mse, uint8_t *d_dir,
+                                  int32_t *d_var);
+/* Frame application of svt_av1_cdef_frame / av1_cdef_frame16bit (Encoder/Codec/EbEncCdef.c:292-1031).
+ * d_in = pre-CDEF planes, d_out = destination planes that must already hold a copy of d_in (blocks
+ * that are skipped or belong to an unfiltered fb are not touched); y/uv_strength[nfb] = the frame
+ * header strength value (pri*4 + sec_idx) selected for each filter block. */
+int svt_hip_cdef_apply_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *const d_in[3], void *const d_out[3],
+                                 const int stride[3], int w, int h, const uint8_t *d_skip8, const uint8_t *d_y_strength,
+                                 const uint8_t *d_uv_strength, int damping, int bd, uint8_t *d_dir);
+
 #ifdef __cplusplus
 }
 #endif

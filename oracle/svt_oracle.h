@@ -113,6 +113,20 @@ void orc_lf_limits(int level, int sharpness, int *lim, int *mblim, int *hev_thr)
 void orc_deblock_plane(void *plane, int pix_bytes, int stride, int bd, const uint16_t *edges_v, const uint16_t *edges_h,
                        int units_w, int units_h, int sharpness);
 
+/* ---------------------------------------------------------------- CDEF (cdef_oracle.c) --------- */
+int  orc_cdef_adjust_strength(int strength, int var);
+int  orc_cdef_find_dir(const uint16_t *img, int stride, int32_t *var, int coeff_shift);
+void orc_cdef_filter_block(uint8_t *dst8, uint16_t *dst16, int dstride, const uint16_t *in, int istride, int pri_strength,
+                           int sec_strength, int dir, int pri_damping, int sec_damping, int bw, int bh, int coeff_shift);
+uint64_t orc_cdef_dist_8x8(const uint16_t *a, int astride, const uint16_t *b, int bstride, int coeff_shift);
+int  orc_cdef_strength_count(int pick_method);
+void orc_cdef_strength(int pick_method, int gi, int *pri, int *sec);
+void orc_cdef_search_frame(const void *const rec[3], const int rec_stride[3], const void *const src[3], const int src_stride[3],
+                           int pix_bytes, int w, int h, const uint8_t *skip8, int pri_damping, int bd, int pick_method,
+                           uint64_t *mse, int fb_begin, int fb_end);
+void orc_cdef_apply_frame(const void *const in[3], void *const out[3], const int stride[3], int pix_bytes, int w, int h,
+                          const uint8_t *skip8, const uint8_t *y_strength, const uint8_t *uv_strength, int damping_hdr, int bd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,9 @@ def lib():
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
+    L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp]
     _lib = L
     return L
 

@@ -1,0 +1,451 @@
+// cdef.hip — CDEF strength search (distortion table per 64x64 filter block) and frame application, gfx950.
+//
+// Replaces (file:line under /root/reference/Source/Lib):
+//   Encoder/Codec/EbCdefProcess.c:80-475      cdef_seg_search / cdef_seg_search16bit (per-fb loops)
+//   Common/Codec/EbCdef.c:132,202,294         svt_cdef_find_dir_c, svt_cdef_filter_block_c, svt_cdef_filter_fb
+//   Encoder/Codec/EbEncCdef.c:25-220          dist_8x8_* / mse_* / compute_cdef_dist_{8bit,}_c
+//   Encoder/Codec/EbEncCdef.c:292-1031        svt_av1_cdef_frame / av1_cdef_frame16bit
+//
+// Search design.  The reference filters every block once per strength pair (64 x 3 planes).  The
+// filter sum is separable: sum = primary(pri, dir) + secondary(sec, dir or 0), and min/max do not
+// depend on the strengths — so per pixel we compute the 15 primary sums and the 2 x 3 secondary
+// sums once and then only combine/round/clamp 64 times.  One wave owns one 8x8 luma block (lane =
+// pixel) or four 4x4 chroma blocks; the 64 filtered values of a lane go to a [strength][lane] byte
+// table in LDS, after which lane g becomes the reducer of strength g: sum(y), sum(y^2), sum(y*s)
+// come from v_dot4_u32_u8 over 16 dwords (v_dot2 for 16-bit), and the luma perceptual distortion
+// (FP64, sqrt, floor — Encoder/Codec/EbEncCdef.c:100-104) is evaluated per (block, strength) in the
+// reference's operation order with contraction off.
+// The staging tile marks everything outside the picture CDEF_VERY_LARGE exactly like the
+// reference's inbuf (EbCdefProcess.c:210-226).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svt_hip_internal.h"
+
+namespace {
+
+constexpr int kVeryLarge = 16384;  // CDEF_VERY_LARGE, Common/Codec/EbCdef.h:37
+constexpr int kVB = 3, kHB = 8;    // CDEF_VBORDER / CDEF_HBORDER
+
+__device__ __constant__ int8_t kDirDy[8][2] = {{-1, -2}, {0, -1}, {0, 0}, {0, 1}, {1, 2}, {1, 2}, {1, 2}, {1, 2}};
+__device__ __constant__ int8_t kDirDx[8][2] = {{1, 2}, {1, 2}, {1, 2}, {1, 2}, {1, 2}, {0, 1}, {0, 0}, {0, -1}};
+
+__device__ __forceinline__ int msb(int n) { return 31 - __clz(n); }
+// Common/Codec/EbCdef.c:87-93; shift precomputed by the caller (uniform per strength)
+__device__ __forceinline__ int constrain(int diff, int threshold, int shift) {
+    const int a = abs(diff);
+    const int v = min(a, max(0, threshold - (a >> shift)));
+    return diff < 0 ? -v : v;
+}
+__device__ __forceinline__ int adjust_strength(int strength, int var) {  // EbCdef.c:112-116
+    const int i = (var >> 6) ? min(msb(var >> 6), 12) : 0;
+    return var ? (strength * (4 + i) + 8) >> 4 : 0;
+}
+
+template <typename PIX>
+__device__ __forceinline__ void stage_tile(uint16_t* tile, int tstride, const PIX* plane, int stride, int pw, int ph, int x0, int y0,
+                                           int tw, int th, int tid, int nt) {
+    // tile covers [x0 - 8, x0 + tw + 8) x [y0 - 3, y0 + th + 3)
+    const int cols = tw + 2 * kHB, rows = th + 2 * kVB;
+    for (int i = tid; i < rows * cols; i += nt) {
+        const int r = i / cols, c = i - r * cols;
+        const int x = x0 - kHB + c, y = y0 - kVB + r;
+        tile[r * tstride + c] = (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)plane[(size_t)y * stride + x] : (uint16_t)kVeryLarge;
+    }
+}
+
+// svt_cdef_find_dir_c (EbCdef.c:132-196) for one 8x8 block by one wave; lane = pixel.
+// part: per-wave LDS scratch [8][16] ints.  Returns dir, writes var (uniform).
+__device__ __forceinline__ int find_dir_wave(int x_px, int lane, int* part, int& var_out) {
+    const int i = lane >> 3, j = lane & 7;
+    for (int k = lane; k < 128; k += 64) part[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int x = x_px - 128;
+    atomicAdd(&part[0 * 16 + i + j], x);
+    atomicAdd(&part[1 * 16 + i + j / 2], x);
+    atomicAdd(&part[2 * 16 + i], x);
+    atomicAdd(&part[3 * 16 + 3 + i - j / 2], x);
+    atomicAdd(&part[4 * 16 + 7 + i - j], x);
+    atomicAdd(&part[5 * 16 + 3 - i / 2 + j], x);
+    atomicAdd(&part[6 * 16 + j], x);
+    atomicAdd(&part[7 * 16 + i / 2 + j], x);
+    __builtin_amdgcn_wave_barrier();
+    int cost = 0;
+    if (lane < 8) {
+        const int* p = part + lane * 16;
+        constexpr int dv[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+        if (lane == 2 || lane == 6) {
+            for (int k = 0; k < 8; k++) cost += p[k] * p[k];
+            cost *= dv[8];
+        } else if (lane == 0 || lane == 4) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) cost += (p[k] * p[k] + p[14 - k] * p[14 - k]) * dv[k + 1];
+            cost += p[7] * p[7] * dv[8];
+        } else {
+            for (int k = 0; k < 5; k++) cost += p[3 + k] * p[3 + k];
+            cost *= dv[8];
+#pragma unroll
+            for (int k = 0; k < 3; k++) cost += (p[k] * p[k] + p[10 - k] * p[10 - k]) * dv[2 * k + 2];
+        }
+    }
+    int best = 0, best_cost = 0, costs[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) costs[d] = __builtin_amdgcn_readlane(cost, d);
+#pragma unroll
+    for (int d = 0; d < 8; d++)
+        if (costs[d] > best_cost) { best_cost = costs[d]; best = d; }
+    int orth = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) if (d == ((best + 4) & 7)) orth = costs[d];
+    var_out = (best_cost - orth) >> 10;
+    return best;
+}
+
+// Everything the 64 strength pairs need for one pixel: primary sums for pri = 1..15, secondary sums
+// for sec in {1,2,4} with the block's direction (A) and with direction 0 (B, used when pri == 0),
+// and the two min/max pairs.
+struct PixelTerms {
+    int x;
+    int pri[16];     // [0] = 0
+    int secA[3], secB[3];
+    int mnA, mxA, mnB, mxB;
+};
+
+__device__ __forceinline__ void tap_minmax(int v, int& mn, int& mx) {
+    if (v != kVeryLarge) mx = max(mx, v);
+    mn = min(mn, v);
+}
+
+// tile points at the pixel; tstride in elements.  t_of[idx] = effective primary strength of index idx
+// (luma: adjusted by the block variance), cs = coeff_shift, damping already includes "+ cs - (pli != 0)".
+__device__ __forceinline__ void pixel_terms(const uint16_t* px, int tstride, int dir, const int (&t_of)[16], int cs, int damping,
+                                            PixelTerms& T) {
+    const int x = (int)(int16_t)px[0];
+    T.x = x;
+    int p[2][2], sa[2][4], sb[2][4], pb[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int o = kDirDy[dir][k] * tstride + kDirDx[dir][k];
+        p[k][0] = px[o]; p[k][1] = px[-o];
+        const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
+        const int o2 = kDirDy[d2][k] * tstride + kDirDx[d2][k], o6 = kDirDy[d6][k] * tstride + kDirDx[d6][k];
+        sa[k][0] = px[o2]; sa[k][1] = px[-o2]; sa[k][2] = px[o6]; sa[k][3] = px[-o6];
+        // direction 0 variant (pri == 0 -> filter_block is called with dir 0, EbCdef.c:371)
+        const int ob = kDirDy[0][k] * tstride + kDirDx[0][k];
+        pb[k][0] = px[ob]; pb[k][1] = px[-ob];
+        const int ob2 = kDirDy[2][k] * tstride + kDirDx[2][k], ob6 = kDirDy[6][k] * tstride + kDirDx[6][k];
+        sb[k][0] = px[ob2]; sb[k][1] = px[-ob2]; sb[k][2] = px[ob6]; sb[k][3] = px[-ob6];
+    }
+    T.mnA = T.mxA = T.mnB = T.mxB = x;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        tap_minmax(p[k][0], T.mnA, T.mxA); tap_minmax(p[k][1], T.mnA, T.mxA);
+        tap_minmax(pb[k][0], T.mnB, T.mxB); tap_minmax(pb[k][1], T.mnB, T.mxB);
+#pragma unroll
+        for (int t = 0; t < 4; t++) { tap_minmax(sa[k][t], T.mnA, T.mxA); tap_minmax(sb[k][t], T.mnB, T.mxB); }
+    }
+    T.pri[0] = 0;
+#pragma unroll
+    for (int idx = 1; idx < 16; idx++) {
+        const int t = t_of[idx];
+        int s = 0;
+        if (t) {
+            const int shift = max(0, damping - msb(t));
+            const int w0 = ((t >> cs) & 1) ? 3 : 4, w1 = ((t >> cs) & 1) ? 3 : 2;  // eb_cdef_pri_taps, EbCdef.c:198
+            s = w0 * (constrain(p[0][0] - x, t, shift) + constrain(p[0][1] - x, t, shift)) +
+                w1 * (constrain(p[1][0] - x, t, shift) + constrain(p[1][1] - x, t, shift));
+        }
+        T.pri[idx] = s;
+    }
+#pragma unroll
+    for (int si = 0; si < 3; si++) {
+        const int s = (1 << si) << cs;  // sec strengths 1, 2, 4 (index 3 means 4: "sec += sec == 3")
+        const int shift = max(0, damping - msb(s));
+        int a = 0, b = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            a += 2 * constrain(sa[0][t] - x, s, shift) + constrain(sa[1][t] - x, s, shift);  // eb_cdef_sec_taps {2,1}
+            b += 2 * constrain(sb[0][t] - x, s, shift) + constrain(sb[1][t] - x, s, shift);
+        }
+        T.secA[si] = a; T.secB[si] = b;
+    }
+}
+
+__device__ __forceinline__ int combine(const PixelTerms& T, int pri_idx, int sec_idx) {
+    int sum = T.pri[pri_idx];
+    if (sec_idx) sum += pri_idx ? T.secA[sec_idx - 1] : T.secB[sec_idx - 1];
+    const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
+    return pri_idx ? min(max(y, T.mnA), T.mxA) : min(max(y, T.mnB), T.mxB);
+}
+
+// sum(a), sum(a*a), sum(a*b) over 64 samples held as packed rows in LDS
+template <typename PIX> struct Dots;
+template <> struct Dots<uint8_t> {
+    static __device__ __forceinline__ void run(const uint8_t* a, const uint8_t* b, uint32_t& sa, uint32_t& saa, uint32_t& sab) {
+        const uint32_t* pa = (const uint32_t*)a; const uint32_t* pb = (const uint32_t*)b;
+        sa = saa = sab = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t va = pa[k], vb = pb[k];
+            sa  = __builtin_amdgcn_udot4(va, 0x01010101u, sa, false);
+            saa = __builtin_amdgcn_udot4(va, va, saa, false);
+            sab = __builtin_amdgcn_udot4(va, vb, sab, false);
+        }
+    }
+};
+template <> struct Dots<uint16_t> {
+    static __device__ __forceinline__ void run(const uint16_t* a, const uint16_t* b, uint32_t& sa, uint32_t& saa, uint32_t& sab) {
+        sa = saa = sab = 0;
+        for (int k = 0; k < 64; k++) { const uint32_t va = a[k], vb = b[k]; sa += va; saa += va * va; sab += va * vb; }
+    }
+};
+
+// ------------------------------------------------------------------------------- search, luma ---
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* __restrict__ src, int src_stride, int w, int h,
+                        const uint8_t* __restrict__ skip8, int pri_damping, int cs, uint64_t* __restrict__ mse,
+                        uint8_t* __restrict__ dir_out, int32_t* __restrict__ var_out) {
+    constexpr int TS = 64 + 2 * kHB;  // tile stride (elements)
+    __shared__ uint16_t tile[(64 + 2 * kVB) * TS];
+    __shared__ __attribute__((aligned(16))) PIX ytab[4][64][64 + 16 / sizeof(PIX)];  // [wave][strength][pixel] (+pad)
+    __shared__ __attribute__((aligned(16))) PIX stab[4][64];
+    __shared__ int part[4][128];
+    __shared__ unsigned long long accum[4][64];
+    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // svt_sb_all_skip (EbEncCdef.c:222): nothing to do, table entry stays untouched
+    int any = 0;
+    for (int b = lane; b < 64; b += 64) { const int by = b >> 3, bx = b & 7; if (by < nby && bx < nbx && !skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) any = 1; }
+    if (!__any(any)) return;
+    stage_tile(tile, TS, rec, rec_stride, w, h, 64 * fbc, 64 * fbr, 64, 64, tid, 256);
+    __syncthreads();
+    const int damping = pri_damping + cs;  // pli == 0 (EbCdef.c:306-307)
+    unsigned long long acc = 0;            // lane g: sum over this wave's blocks of dist(block, strength g)
+    const int i = lane >> 3, j = lane & 7;
+    for (int b = wave; b < 64; b += 4) {
+        const int by = b >> 3, bx = b & 7;
+        if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) {
+            if (lane == 0 && dir_out) { dir_out[fb * 64 + b] = 0; var_out[fb * 64 + b] = 0; }
+            continue;
+        }
+        const uint16_t* px = tile + (8 * by + i + kVB) * TS + 8 * bx + j + kHB;
+        int var;
+        const int dir = find_dir_wave(((int)px[0] >> cs), lane, part[wave], var);
+        if (lane == 0 && dir_out) { dir_out[fb * 64 + b] = (uint8_t)dir; var_out[fb * 64 + b] = var; }
+        int t_of[16];
+#pragma unroll
+        for (int idx = 0; idx < 16; idx++) t_of[idx] = adjust_strength(idx << cs, var);
+        PixelTerms T;
+        pixel_terms(px, TS, dir, t_of, cs, damping, T);
+#pragma unroll
+        for (int g = 0; g < 64; g++) ytab[wave][g][lane] = (PIX)combine(T, g >> 2, g & 3);
+        stab[wave][lane] = src[(size_t)(64 * fbr + 8 * by + i) * src_stride + 64 * fbc + 8 * bx + j];
+        __builtin_amdgcn_wave_barrier();
+        // lane g reduces strength g: dist_8x8 (EbEncCdef.c:79-105), names as in the reference:
+        //   s = filtered ("src" there), d = source picture ("dst" there)
+        uint32_t sum_s, sum_s2, sum_sd, sum_d, sum_d2, dummy;
+        Dots<PIX>::run(&ytab[wave][lane][0], &stab[wave][0], sum_s, sum_s2, sum_sd);
+        Dots<PIX>::run(&stab[wave][0], &stab[wave][0], sum_d, sum_d2, dummy);
+        const uint64_t svar = (uint64_t)sum_s2 - (((uint64_t)sum_s * sum_s + 32) >> 6);
+        const uint64_t dvar = (uint64_t)sum_d2 - (((uint64_t)sum_d * sum_d + 32) >> 6);
+        const double num = (double)((uint64_t)sum_d2 + sum_s2 - 2 * (uint64_t)sum_sd) * .5 * (double)(svar + dvar + (uint64_t)(400 << 2 * cs));
+        const double den = sqrt((double)(20000 << 4 * cs) + (double)svar * (double)dvar);
+        acc += (unsigned long long)floor(.5 + num / den);
+        __builtin_amdgcn_wave_barrier();
+    }
+    accum[wave][lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned long long t = accum[0][tid] + accum[1][tid] + accum[2][tid] + accum[3][tid];
+        mse[(size_t)fb * 64 + tid] = t >> (2 * cs);  // compute_cdef_dist_*: sum >> 2*coeff_shift
+    }
+}
+
+// ----------------------------------------------------------------------------- search, chroma ---
+// Both chroma planes of one filter block; mse[1][fb][g] = dist(U) + dist(V) (EbCdefProcess.c:268-271).
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+cdef_search_chroma_kernel(const PIX* __restrict__ rec_u, const PIX* __restrict__ rec_v, int rec_stride, const PIX* __restrict__ src_u,
+                          const PIX* __restrict__ src_v, int src_stride, int w, int h, const uint8_t* __restrict__ skip8,
+                          int pri_damping, int cs, uint64_t* __restrict__ mse_uv, const uint8_t* __restrict__ dir_in) {
+    constexpr int TS = 32 + 2 * kHB;
+    __shared__ uint16_t tile[2][(32 + 2 * kVB) * TS];
+    __shared__ __attribute__((aligned(16))) PIX ytab[4][64][64 + 16 / sizeof(PIX)];
+    __shared__ __attribute__((aligned(16))) PIX stab[4][64];
+    __shared__ unsigned long long accum[4][2][64];
+    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int any = 0;
+    for (int b = lane; b < 64; b += 64) { const int by = b >> 3, bx = b & 7; if (by < nby && bx < nbx && !skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) any = 1; }
+    if (!__any(any)) return;
+    stage_tile(tile[0], TS, rec_u, rec_stride, w >> 1, h >> 1, 32 * fbc, 32 * fbr, 32, 32, tid, 256);
+    stage_tile(tile[1], TS, rec_v, rec_stride, w >> 1, h >> 1, 32 * fbc, 32 * fbr, 32, 32, tid, 256);
+    __syncthreads();
+    const int damping = pri_damping + cs - 1;  // pli != 0
+    unsigned long long acc[2] = {0, 0};
+    // a pass = 4 horizontally adjacent 4x4 blocks (one 4x16 strip); lane -> (block q, row i, col j)
+    const int q = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
+    for (int pass = wave; pass < 32; pass += 4) {
+        const int pl = pass >> 4, strip = pass & 15;
+        const int by = strip >> 1, bx = (strip & 1) * 4 + q;
+        const bool live = by < nby && bx < nbx && !skip8[(8 * fbr + by) * c8 + 8 * fbc + bx];
+        const PIX* sp = pl ? src_v : src_u;
+        const int sy = min(32 * fbr + 4 * by + i, (h >> 1) - 1), sx = min(32 * fbc + 4 * bx + j, (w >> 1) - 1);
+        const PIX s = sp[(size_t)sy * src_stride + sx];
+        if (live) {
+            const uint16_t* px = tile[pl] + (4 * by + i + kVB) * TS + 4 * bx + j + kHB;
+            const int dir = dir_in[fb * 64 + by * 8 + bx];
+            int t_of[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; idx++) t_of[idx] = idx << cs;
+            PixelTerms T;
+            pixel_terms(px, TS, dir, t_of, cs, damping, T);
+#pragma unroll
+            for (int g = 0; g < 64; g++) ytab[wave][g][lane] = (PIX)combine(T, g >> 2, g & 3);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 64; g++) ytab[wave][g][lane] = s;  // contributes (y - s)^2 = 0
+        }
+        stab[wave][lane] = s;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sy1, sy2, sys, ss1, ss2, dummy;
+        Dots<PIX>::run(&ytab[wave][lane][0], &stab[wave][0], sy1, sy2, sys);
+        Dots<PIX>::run(&stab[wave][0], &stab[wave][0], ss1, ss2, dummy);
+        acc[pl] += (unsigned long long)sy2 + ss2 - 2ull * sys;  // sum (y - s)^2, mse_4_*: EbEncCdef.c:67-77,121-131
+        __builtin_amdgcn_wave_barrier();
+    }
+    accum[wave][0][lane] = acc[0];
+    accum[wave][1][lane] = acc[1];
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned long long u = accum[0][0][tid] + accum[1][0][tid] + accum[2][0][tid] + accum[3][0][tid];
+        const unsigned long long v = accum[0][1][tid] + accum[1][1][tid] + accum[2][1][tid] + accum[3][1][tid];
+        mse_uv[(size_t)fb * 64 + tid] = (u >> (2 * cs)) + (v >> (2 * cs));
+    }
+}
+
+// ---------------------------------------------------------------------------------- apply -------
+// One workgroup per (filter block, plane).  in = pre-CDEF plane, out = result plane (pre-initialised
+// with a copy of `in`).  strength[fb] = frame-header value pri*4 + sec_idx chosen for the fb.
+template <typename PIX, int PLANE_KIND>  // 0 luma, 1 chroma
+__global__ void __launch_bounds__(256)
+cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride, int w, int h, const uint8_t* __restrict__ skip8,
+                  const uint8_t* __restrict__ y_strength, const uint8_t* __restrict__ uv_strength, int damping_hdr, int cs,
+                  uint8_t* __restrict__ dir_buf) {
+    constexpr int DEC = PLANE_KIND, FBS = 64 >> DEC, TS = FBS + 2 * kHB;
+    __shared__ uint16_t tile[(FBS + 2 * kVB) * TS];
+    __shared__ int part[4][128];
+    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ly = y_strength[fb] >> 2, sy = y_strength[fb] & 3, lu = uv_strength[fb] >> 2, su = uv_strength[fb] & 3;
+    sy += sy == 3; su += su == 3;
+    if (ly == 0 && sy == 0 && lu == 0 && su == 0) return;  // EbEncCdef.c:434-441
+    const int level = PLANE_KIND ? lu : ly, sec = (PLANE_KIND ? su : sy) << cs;
+    stage_tile(tile, TS, in, stride, w >> DEC, h >> DEC, FBS * fbc, FBS * fbr, FBS, FBS, tid, 256);
+    __syncthreads();
+    const int damping = damping_hdr + cs - (PLANE_KIND != 0);
+    if (PLANE_KIND == 0) {
+        const int i = lane >> 3, j = lane & 7;
+        for (int b = wave; b < 64; b += 4) {
+            const int by = b >> 3, bx = b & 7;
+            if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) continue;
+            const uint16_t* px = tile + (8 * by + i + kVB) * TS + 8 * bx + j + kHB;
+            int var;
+            const int dir = find_dir_wave(((int)px[0] >> cs), lane, part[wave], var);
+            if (lane == 0) dir_buf[fb * 64 + b] = (uint8_t)dir;
+            const int t = level << cs;
+            int t_of[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; idx++) t_of[idx] = 0;
+            t_of[1] = adjust_strength(t, var);
+            // reuse the search machinery with "pri index" 1 = the chosen strength, direction rule t ? dir : 0
+            PixelTerms T;
+            pixel_terms(px, TS, t ? dir : 0, t_of, cs, damping, T);
+            int sum = T.pri[1];
+            if (sec) {
+                const int shift = max(0, damping - msb(sec));
+                const int d = t ? dir : 0, d2 = (d + 2) & 7, d6 = (d + 6) & 7;
+                const int x = T.x;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int o2 = kDirDy[d2][k] * TS + kDirDx[d2][k], o6 = kDirDy[d6][k] * TS + kDirDx[d6][k];
+                    const int wk = k ? 1 : 2;
+                    sum += wk * (constrain((int)px[o2] - x, sec, shift) + constrain((int)px[-o2] - x, sec, shift) +
+                                 constrain((int)px[o6] - x, sec, shift) + constrain((int)px[-o6] - x, sec, shift));
+                }
+            }
+            const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
+            out[(size_t)(64 * fbr + 8 * by + i) * stride + 64 * fbc + 8 * bx + j] = (PIX)min(max(y, T.mnA), T.mxA);
+        }
+    } else {
+        const int q = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
+        for (int strip = wave; strip < 16; strip += 4) {
+            const int by = strip >> 1, bx = (strip & 1) * 4 + q;
+            if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) continue;
+            const uint16_t* px = tile + (4 * by + i + kVB) * TS + 4 * bx + j + kHB;
+            const int t = level << cs;
+            const int dir = t ? dir_buf[fb * 64 + by * 8 + bx] : 0;
+            int t_of[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; idx++) t_of[idx] = 0;
+            t_of[1] = t;
+            PixelTerms T;
+            pixel_terms(px, TS, dir, t_of, cs, damping, T);
+            int sum = T.pri[1];
+            if (sec) {
+                const int shift = max(0, damping - msb(sec));
+                const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
+                const int x = T.x;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int o2 = kDirDy[d2][k] * TS + kDirDx[d2][k], o6 = kDirDy[d6][k] * TS + kDirDx[d6][k];
+                    const int wk = k ? 1 : 2;
+                    sum += wk * (constrain((int)px[o2] - x, sec, shift) + constrain((int)px[-o2] - x, sec, shift) +
+                                 constrain((int)px[o6] - x, sec, shift) + constrain((int)px[-o6] - x, sec, shift));
+                }
+            }
+            const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
+            out[(size_t)(32 * fbr + 4 * by + i) * stride + 32 * fbc + 4 * bx + j] = (PIX)min(max(y, T.mnA), T.mxA);
+        }
+    }
+}
+
+template <typename PIX>
+int search_t(hipStream_t st, const void* const rec[3], const int rs[3], const void* const src[3], const int ss[3], int w, int h,
+             const uint8_t* skip8, int pri_damping, int cs, uint64_t* mse, uint8_t* dir_buf, int32_t* var_buf) {
+    const int nfb = ((w + 63) >> 6) * ((h + 63) >> 6);
+    hipLaunchKernelGGL((cdef_search_luma_kernel<PIX>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[0], rs[0], (const PIX*)src[0], ss[0], w, h,
+                       skip8, pri_damping, cs, mse, dir_buf, var_buf);
+    hipLaunchKernelGGL((cdef_search_chroma_kernel<PIX>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[1], (const PIX*)rec[2], rs[1],
+                       (const PIX*)src[1], (const PIX*)src[2], ss[1], w, h, skip8, pri_damping, cs, mse + (size_t)nfb * 64, dir_buf);
+    return (int)hipGetLastError();
+}
+template <typename PIX>
+int apply_t(hipStream_t st, const void* const in[3], void* const out[3], const int stride[3], int w, int h, const uint8_t* skip8,
+            const uint8_t* ys, const uint8_t* uvs, int damping, int cs, uint8_t* dir_buf) {
+    const int nfb = ((w + 63) >> 6) * ((h + 63) >> 6);
+    hipLaunchKernelGGL((cdef_apply_kernel<PIX, 0>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[0], (PIX*)out[0], stride[0], w, h, skip8, ys, uvs, damping, cs, dir_buf);
+    for (int p = 1; p < 3; p++)
+        hipLaunchKernelGGL((cdef_apply_kernel<PIX, 1>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[p], (PIX*)out[p], stride[p], w, h, skip8, ys, uvs, damping, cs, dir_buf);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const rec[3], const int rec_stride[3],
+                                          const void* const src[3], const int src_stride[3], int w, int h, const uint8_t* skip8,
+                                          int pri_damping, int bd, uint64_t* mse, uint8_t* dir_buf, int32_t* var_buf) {
+    const int cs = bd - 8;
+    if (pix_bytes == 1) return search_t<uint8_t>(st, rec, rec_stride, src, src_stride, w, h, skip8, pri_damping, cs, mse, dir_buf, var_buf);
+    return search_t<uint16_t>(st, rec, rec_stride, src, src_stride, w, h, skip8, pri_damping, cs, mse, dir_buf, var_buf);
+}
+extern "C" int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3],
+                                         int w, int h, const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength,
+                                         int damping, int bd, uint8_t* dir_buf) {
+    const int cs = bd - 8;
+    if (pix_bytes == 1) return apply_t<uint8_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf);
+    return apply_t<uint16_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf);
+}

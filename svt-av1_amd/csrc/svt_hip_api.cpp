@@ -268,4 +268,33 @@ int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int st
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------------------------- CDEF */
+int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_rec[3], const int rec_stride[3],
+                                  const void* const d_src[3], const int src_stride[3], int w, int h, const uint8_t* d_skip8,
+                                  int pri_damping, int bd, uint64_t* d_mse, uint8_t* d_dir, int32_t* d_var) {
+    if (!c || !d_rec || !d_src || !rec_stride || !src_stride || !d_skip8 || !d_mse || !d_dir || !d_var || (pix_bytes != 1 && pix_bytes != 2) ||
+        (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7) || ((w & 63) && (w & 63) < 16) ||
+        ((h & 63) && (h & 63) < 16)) {
+        if (c) c->err = "svt_hip_cdef_search_frame_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_search(c->stream, pix_bytes, d_rec, rec_stride, d_src, src_stride, w, h, d_skip8,
+                                                         pri_damping, bd, d_mse, d_dir, d_var);
+    if (e != hipSuccess) return fail(c, e, "cdef search launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_apply_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_in[3], void* const d_out[3], const int stride[3], int w,
+                                 int h, const uint8_t* d_skip8, const uint8_t* d_y_strength, const uint8_t* d_uv_strength, int damping,
+                                 int bd, uint8_t* d_dir) {
+    if (!c || !d_in || !d_out || !stride || !d_skip8 || !d_y_strength || !d_uv_strength || !d_dir || (pix_bytes != 1 && pix_bytes != 2) ||
+        (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7)) {
+        if (c) c->err = "svt_hip_cdef_apply_frame_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_apply(c->stream, pix_bytes, d_in, d_out, stride, w, h, d_skip8, d_y_strength,
+                                                        d_uv_strength, damping, bd, d_dir);
+    if (e != hipSuccess) return fail(c, e, "cdef apply launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

@@ -17,4 +17,10 @@ int svt_hip_launch_inv_txfm_add(hipStream_t st, int tx_size, int pix_bytes, int 
                                 int pred_stride, void* recon, int recon_stride, const uint32_t* descs, int nblk);
 int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
                                  const uint16_t* edges_h, int units_w, int units_h, int sharpness);
+int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const rec[3], const int rec_stride[3], const void* const src[3],
+                               const int src_stride[3], int w, int h, const uint8_t* skip8, int pri_damping, int bd, uint64_t* mse,
+                               uint8_t* dir_buf, int32_t* var_buf);
+int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3], int w, int h,
+                              const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength, int damping, int bd,
+                              uint8_t* dir_buf);
 }

@@ -209,3 +209,53 @@ def test_deblock_edge_filters(orc, ref):
                         getattr(ref, name)(pa, 24, ptr(bl), ptr(li), ptr(th))
                     orc.orc_lpf_edge(pb, a.itemsize, 24, d, length, int(bl[0]), int(li[0]), int(th[0]), bd)
                     assert np.array_equal(a, b), (name, it)
+
+
+# ------------------------------------------------------------------------------------------ CDEF
+import cdef_common as cc
+
+
+def test_cdef_find_dir_and_filter_block(orc, ref):
+    """svt_cdef_find_dir_c and svt_cdef_filter_block_c for every direction / strength / damping / block
+    size / bit depth, with CDEF_VERY_LARGE borders (/root/reference/test/CdefTest.cc:342-590)."""
+    rng = np.random.default_rng(3)
+    for cs in (0, 2):
+        for it in range(200):
+            img = rng.integers(0, 256 << cs, (8, 8), dtype=np.uint16)
+            if it % 3 == 0:
+                yy, xx = np.mgrid[0:8, 0:8]; img = (((xx * (it % 5) + yy * (it % 7)) * 9) % (256 << cs)).astype(np.uint16)
+            v1, v2 = C.c_int32(0), C.c_int32(0)
+            d1 = ref.svt_cdef_find_dir_c(ptr(img), 8, C.byref(v1), cs)
+            d2 = orc.orc_cdef_find_dir(ptr(img), 8, C.byref(v2), cs)
+            assert (d1, v1.value) == (d2, v2.value)
+    for cs in (0, 2):
+        for bsize, (bw, bh) in ((3, (8, 8)), (0, (4, 4))):
+            for it in range(400):
+                buf = rng.integers(0, 256 << cs, (8 + 6, cc.BSTRIDE), dtype=np.uint16)
+                if it % 4 == 0: buf[:3] = cc.VERY_LARGE
+                if it % 4 == 1: buf[:, :8] = cc.VERY_LARGE
+                if it % 4 == 2: buf[3 + bh:] = cc.VERY_LARGE; buf[:, 8 + bw:] = cc.VERY_LARGE
+                pri = int(rng.integers(0, 16)) << cs; sec = int(rng.choice([0, 1, 2, 4])) << cs
+                d = int(rng.integers(0, 8)); pd = int(rng.integers(3, 7)) + cs; sd = int(rng.integers(3, 7)) + cs
+                inp = C.c_void_p(buf.ctypes.data + 2 * (3 * cc.BSTRIDE + 8))
+                a = np.zeros((8, 8), np.uint16); b = np.zeros((8, 8), np.uint16)
+                ref.svt_cdef_filter_block_c(None, ptr(a), 8, inp, pri, sec, d, pd, sd, bsize, cs)
+                orc.orc_cdef_filter_block(None, ptr(b), 8, inp, cc.BSTRIDE, pri, sec, d, pd, sd, bw, bh, cs)
+                assert np.array_equal(a, b), (cs, bsize, it)
+
+
+def test_cdef_search_filter_block_level(orc, ref):
+    """Whole filter-block strength search (64 strengths x 3 planes incl. the FP64 luma distortion) vs
+    svt_cdef_filter_fb + compute_cdef_dist* driven like cdef_seg_search; multi-fb frame so that inner
+    and picture-edge halos are both exercised."""
+    for bd in (8, 10):
+        src, rec, skip8 = cc.make_frame(144, 80, bd, seed=bd)   # 3 x 2 fbs, ragged right/bottom fb (16 px)
+        mse = cc.orc_search(orc, rec, src, bd, skip8, 5)
+        nh = 3
+        for fbr in range(2):
+            for fbc in range(3):
+                r = cc.ref_search_fb(ref, rec, src, bd, skip8, fbr, fbc, 5)
+                if r is None:
+                    continue
+                assert np.array_equal(r[0], mse[0, fbr * nh + fbc]), ("Y", bd, fbr, fbc)
+                assert np.array_equal(r[1], mse[1, fbr * nh + fbc]), ("UV", bd, fbr, fbc)
