@@ -2,15 +2,19 @@
 """bench.py — headline benchmark of the MI355X SVT-AV1 hot path (BASELINE.json metric).
 
 One "step" = one pass of every implemented kernel class of the hot path over ONE synthetic
-4K (3840x2160) 8-bit 4:2:0 frame = 2040 superblocks, inputs resident in HBM before the timed
-region.  `value` = superblocks per second over the whole job (all ranks).
+4K (3840x2160) 8-bit 4:2:0 frame = 2040 superblocks, inputs resident in
+HBM before the timed region:
+    integer ME (85 PUs, 64x64 search area, 1 ref)  ->  residual + fwd txfm + quantize (all planes,
+    per-SB square tiling 4..64)  ->  inverse txfm + recon  ->  deblock (3 planes, V then H)  ->
+    CDEF strength search (64 strengths, 3 planes)  ->  CDEF apply.
+`value` = superblocks per second over the whole job (all ranks).
 
-Multi-GPU: frames/streams are independent, so rank i simply processes its own
-frame on GPU i — no data-path collective; torch.distributed (RCCL) is used only for the barrier
-and the max-over-ranks time.  Scaling is "weak" (per-GPU work fixed).
+Multi-GPU: frames/streams are independent, so rank i processes its own frame on
+GPU i — no data-path collective; torch.distributed (RCCL) is used only for the barrier and the
+max-over-ranks time.  Scaling is "weak" (per-GPU work fixed).
 
-PyTorch is plumbing only here (device memory, streams, distributed); every kernel is launched
-through the C ABI of libsvtav1_hip.so (include/svt_hip.h) on torch's current stream.
+PyTorch is plumbing only (device memory, streams, distributed); every kernel is launched through the
+C ABI of libsvtav1_hip.so (include/svt_hip.h) on torch's current stream.
 """
 import argparse
 import ctypes as C
@@ -27,6 +31,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "encoded 4K 8-bit SB/s (ME+txfm+quant+loopfilter) per GPU; bit-exact vs C ref"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+P3, I3 = C.c_void_p * 3, C.c_int * 3
+
+# algorithmic HBM bytes per SB of each kernel class (8-bit 4:2:0, luma + chroma where the stage covers chroma)
+BYTES_PER_SB = {
+    "me_fullpel_85pu": 8872,                 # 4096 src + 4096 ref (amortised) + 85*8 out
+    "fwd_txfm_quant": 61440 + 128,           # (src+pred 2*6144) + qcoeff+dqcoeff 2*4*6144 + eob   (luma+chroma)
+    "inv_txfm_recon": 36864,                 # dqcoeff 4*6144 + pred 6144 + recon 6144
+    "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
+    "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
+    "cdef_apply": 12288,                     # 6144 R + 6144 W
+}
 
 
 def main():
@@ -37,6 +52,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", default="all", help="comma list (debug): me,txfm,inv,dlf,cdef_search,cdef_apply")
     args = ap.parse_args()
 
     import torch
@@ -53,38 +69,109 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from conftest import load_package, ptr
+    import importlib
     import me_common as mc
+    import workload
+    import txfm_common as tc
     pkg = load_package()
+    shard = importlib.import_module("svt_av1_amd.shard")
     orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
     ctx = pkg.Context(local_rank)
     L = ctx.L
     stream = torch.cuda.current_stream()
     ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
+    dev = torch.device("cuda", local_rank)
 
     W, H = args.width, args.height
-    PAD = mc.synth.PAD
-    # ---- synthetic inputs (seeded per rank = per stream), uploaded before the timed region
-    cur, ref = mc.synth.make_luma_pair(W, H, seed=11 + 100 * rank)
-    cur_p, ref_p = mc.synth.pad_plane(cur), mc.synth.pad_plane(ref)
-    stride = cur_p.shape[1]
+    F = workload.Frame(W, H, seed=11 + 100 * rank)   # one stream per rank
+    n_sb, PAD = F.n_sb, F.pad
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    # ---------------------------------------------------------------- device-resident inputs / outputs
+    d_cur_p, d_ref_p = T(F.cur_y_p), T(F.ref_y_p)
     sbs = mc.windows(orc, W, H, 64, 64)
-    n_sb = len(sbs)
-    dev = torch.device("cuda", local_rank)
-    d_cur = torch.from_numpy(cur_p).to(dev)
-    d_ref = torch.from_numpy(ref_p).to(dev)
-    d_sbs = torch.from_numpy(np.frombuffer(bytes(sbs), dtype=np.uint8).copy()).to(dev)
+    d_sbs = T(np.frombuffer(bytes(sbs), dtype=np.uint8).copy())
     d_sad = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)
     d_mv = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)
+    d_cur = [T(p) for p in F.cur]
+    d_pred = [T(p) for p in F.ref]                       # prediction = co-located reference (zero MV)
+    d_recon = [torch.zeros_like(p) for p in d_pred]
+    d_cdef_out = [torch.zeros_like(p) for p in d_pred]
+    strides = [p.shape[1] for p in F.cur]
+    tx_jobs = []   # one launch per (plane, tx size)
+    keep = []
+    for (kind, ts), descs in sorted(F.descs.items()):
+        nk = min(tc.TXW[ts], 32) * min(tc.TXH[ts], 32)
+        d_desc = T(descs)
+        isc = [T(s) if s is not None else None for s in F.scan_tables(ts)]
+        keep.append(isc)
+        st = pkg.ScanTables()
+        for c in range(3):
+            st.iscan[c] = isc[c].data_ptr() if isc[c] is not None else None
+        for plane in ([0] if kind == 0 else [1, 2]):
+            qs = pkg.QuantParams()
+            qp = F.qp[plane]
+            for name, row in (("zbin", qp[0]), ("round", qp[1]), ("quant", qp[2]), ("quant_shift", qp[3]), ("dequant", qp[4])):
+                getattr(qs, name)[0] = int(row[0]); getattr(qs, name)[1] = int(row[1])
+            qs.log_scale = tc.TX_SCALE[ts]; qs.variant = 0
+            n = len(descs)
+            tx_jobs.append(dict(ts=ts, plane=plane, n=n, desc=d_desc, qs=qs, st=st,
+                                q=torch.zeros(n * nk, dtype=torch.int32, device=dev), dq=torch.zeros(n * nk, dtype=torch.int32, device=dev),
+                                eob=torch.zeros(n, dtype=torch.int16, device=dev), cul=torch.zeros(n, dtype=torch.int32, device=dev)))
+    d_edges = [(T(ev), T(eh), ev.shape[1], ev.shape[0]) for ev, eh in F.edges]
+    d_skip8 = T(F.skip8)
+    d_mse = torch.zeros((2, n_sb, 64), dtype=torch.int64, device=dev)
+    d_dir = torch.zeros(n_sb * 64, dtype=torch.uint8, device=dev)
+    d_var = torch.zeros(n_sb * 64, dtype=torch.int32, device=dev)
+    d_cy, d_cuv = T(F.cdef_y), T(F.cdef_uv)
 
-    # ---- kernel classes of the step.  bytes_per_sb = SURVEY.md 8(d) algorithmic HBM bytes per SB.
+    # ---------------------------------------------------------------- the kernel classes of a step
     def run_me():
-        ctx.check(L.svt_hip_me_fullpel_frame_dev(ctx.h, d_cur.data_ptr(), d_ref.data_ptr(), stride, PAD, PAD,
+        ctx.check(L.svt_hip_me_fullpel_frame_dev(ctx.h, d_cur_p.data_ptr(), d_ref_p.data_ptr(), F.cur_y_p.shape[1], PAD, PAD,
                                                  d_sbs.data_ptr(), n_sb, 0, d_sad.data_ptr(), d_mv.data_ptr()), "me")
 
-    stages = [
-        dict(name="me_fullpel_85pu", run=run_me, bytes_per_sb=8872, kernel="me_fullpel_85pu_kernel",
-             work_per_sb=4096 * 4096, work_unit="px-SAD"),
+    def run_txfm():
+        for j in tx_jobs:
+            p = j["plane"]
+            ctx.check(L.svt_hip_fwd_txfm_quant_batch_dev(ctx.h, j["ts"], 1, d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p],
+                                                         j["desc"].data_ptr(), j["n"], C.byref(j["qs"]), C.byref(j["st"]), None,
+                                                         j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None), "fwd")
+
+    def run_inv():
+        for j in tx_jobs:
+            p = j["plane"]
+            ctx.check(L.svt_hip_inv_txfm_add_batch_dev(ctx.h, j["ts"], 1, 8, j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p],
+                                                       d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["n"]), "inv")
+
+    def run_dlf():
+        for p in range(3):
+            ev, eh, uw, uh = d_edges[p]
+            ctx.check(L.svt_hip_deblock_plane_dev(ctx.h, d_recon[p].data_ptr(), 1, strides[p], 8, ev.data_ptr(), eh.data_ptr(), uw, uh, 0), "dlf")
+
+    def run_cdef_search():
+        ctx.check(L.svt_hip_cdef_search_frame_dev(ctx.h, 1, P3(*[p.data_ptr() for p in d_recon]), I3(*strides), P3(*[p.data_ptr() for p in d_cur]),
+                                                  I3(*strides), W, H, d_skip8.data_ptr(), F.cdef_damping, 8, d_mse.data_ptr(), d_dir.data_ptr(),
+                                                  d_var.data_ptr()), "cdef search")
+
+    def run_cdef_apply():
+        for p in range(3):
+            d_cdef_out[p].copy_(d_recon[p])   # destination starts as a copy of the pre-CDEF picture (device-to-device)
+        ctx.check(L.svt_hip_cdef_apply_frame_dev(ctx.h, 1, P3(*[p.data_ptr() for p in d_recon]), P3(*[p.data_ptr() for p in d_cdef_out]),
+                                                 I3(*strides), W, H, d_skip8.data_ptr(), d_cy.data_ptr(), d_cuv.data_ptr(), F.cdef_damping, 8,
+                                                 d_dir.data_ptr()), "cdef apply")
+
+    all_stages = [
+        dict(key="me", name="me_fullpel_85pu", run=run_me, kernel="me_fullpel_85pu_kernel"),
+        dict(key="txfm", name="fwd_txfm_quant", run=run_txfm, kernel="fwd_txfm_quant_kernel"),
+        dict(key="inv", name="inv_txfm_recon", run=run_inv, kernel="inv_txfm_add_kernel"),
+        dict(key="dlf", name="deblock", run=run_dlf, kernel="deblock_pass_kernel"),
+        dict(key="cdef_search", name="cdef_search", run=run_cdef_search, kernel="cdef_search_luma_kernel"),
+        dict(key="cdef_apply", name="cdef_apply", run=run_cdef_apply, kernel="cdef_apply_kernel"),
     ]
+    want = None if args.stages == "all" else set(args.stages.split(","))
+    stages = [s for s in all_stages if want is None or s["key"] in want]
 
     def step():
         for st in stages:
@@ -103,13 +190,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    import importlib
-    shard = importlib.import_module("svt_av1_amd.shard")
-    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
 
-    # ---- per-kernel device time with HIP events on the launch stream (outside the headline timing)
-    per_kernel = {}
+    # ---- per-stage device time with HIP events on the launch stream (outside the headline timing)
+    per_stage = {}
     for st in stages:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(5, args.steps)
@@ -118,63 +202,120 @@ def main():
             st["run"]()
         e1.record(stream)
         e1.synchronize()
-        per_kernel[st["name"]] = e0.elapsed_time(e1) / reps  # ms per launch
-    dominant = max(stages, key=lambda s: per_kernel[s["name"]])
-    dom_ms = per_kernel[dominant["name"]]
-    achieved_gbs = dominant["bytes_per_sb"] * n_sb / (dom_ms * 1e-3) / 1e9
+        per_stage[st["name"]] = e0.elapsed_time(e1) / reps  # ms per frame
+    dominant = max(stages, key=lambda s: per_stage[s["name"]])
+    dom_ms = per_stage[dominant["name"]]
+    achieved_gbs = BYTES_PER_SB[dominant["name"]] * n_sb / (dom_ms * 1e-3) / 1e9
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # ---- parity spot check of what was just timed (first SB row) — the checker, not the product
-    g_sad = d_sad.cpu().numpy().view(np.uint32)
-    g_mv = d_mv.cpu().numpy().view(np.uint32)
-    nrow = (W + 63) // 64
-    o_sad, o_mv = mc.oracle_frame(orc, cur_p, ref_p, stride, PAD, sbs, 0, 0, min(nrow, 8))
-    parity_ok = bool(np.array_equal(o_sad[:min(nrow, 8)], g_sad[:min(nrow, 8)]) and
-                     np.array_equal(o_mv[:min(nrow, 8)], g_mv[:min(nrow, 8)]))
+    # ---- parity spot check of what was just timed (first SB row of ME) — the checker, not the product
+    parity_ok = None
+    if any(s["key"] == "me" for s in stages):
+        g_sad = d_sad.cpu().numpy().view(np.uint32); g_mv = d_mv.cpu().numpy().view(np.uint32)
+        k = min(F.sb_cols, 8)
+        o_sad, o_mv = mc.oracle_frame(orc, F.cur_y_p, F.ref_y_p, F.cur_y_p.shape[1], PAD, sbs, 0, 0, k)
+        parity_ok = bool(np.array_equal(o_sad[:k], g_sad[:k]) and np.array_equal(o_mv[:k], g_mv[:k]))
 
-    # ---- CPU baseline: the oracle port of the same stage chain on a bounded SB sample, all host cores
+    # ---- CPU baseline: the oracle C port of the same stage chain, every host core, on a bounded sample of the
+    #      same frame; composite SB/s = 1 / sum_k (seconds per SB of stage k)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cores = max(1, min(os.cpu_count() or 1, 64))
-        per_thread = 12
-        sample = min(n_sb, cores * per_thread)
-        chunks = [(i * sample // cores, (i + 1) * sample // cores) for i in range(cores)]
-
-        def work(b_e):
-            mc.oracle_frame(orc, cur_p, ref_p, stride, PAD, sbs, 0, b_e[0], b_e[1])
-        t1 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(work, chunks))
-        cpu_s = time.perf_counter() - t1
-        cpu = dict(value=sample / cpu_s, unit="SB/s", cores=cores, kind="port",
-                   sample=f"{sample} of {n_sb} SBs of the same 4K frame, oracle C port (scalar, -O2), "
-                          f"{cores} threads x {per_thread} SBs, {cpu_s:.1f} s wall")
+        cpu = cpu_baseline(orc, F, sbs, mc, tc, stages)
 
     total_sb = n_sb * args.steps * world
     out = {
         "metric": METRIC, "value": total_sb / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU, 1 reference, "
-                               f"64x64 integer search area; stages: " + ",".join(s["name"] for s in stages),
-                   "stages_ms": per_kernel, "parity_spot_check": parity_ok},
+        "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
+                               + "; ME 1 ref 64x64 search area; square tx tiling 4..64 per SB, quantize_b qindex 60; "
+                                 "deblock levels (20,20,12,12); CDEF full 64-strength search",
+                   "stages_ms": per_stage, "parity_spot_check": parity_ok},
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / HIP-event launch time; this kernel is "
-                             "integer-VALU bound, see valu",
-                     "valu": {"achieved": dominant["work_per_sb"] * n_sb / (dom_ms * 1e-3) / 1e12,
-                              "peak": 1024 * 64 * 16 / 16.0 * 2.4e9 / 1e12, "unit": "T px-SAD/s",
-                              "note": "peak = 1024 SIMDs x 64 lanes x 16 abs-diff per v_qsad_pk_u16_u8 / 16 cyc x 2.4 GHz"}},
+                     "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / HIP-event stage time of the slowest stage; the ME and CDEF-search "
+                             "kernels are integer-VALU bound (DESIGN.md), see per_stage_gbs for the HBM-bound ones",
+                     "per_stage_gbs": {s["name"]: BYTES_PER_SB[s["name"]] * n_sb / (per_stage[s["name"]] * 1e-3) / 1e9 for s in stages}},
         "cpu_baseline": cpu,
     }
-    out["roofline"]["valu"]["frac"] = out["roofline"]["valu"]["achieved"] / out["roofline"]["valu"]["peak"]
+    if any(s["key"] == "me" for s in stages):
+        ms = per_stage["me_fullpel_85pu"]
+        out["roofline"]["valu_me"] = {"achieved": 4096 * 4096 * n_sb / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 16 / 16.0 * 2.4e9 / 1e12,
+                                      "unit": "T px-SAD/s", "note": "peak = 1024 SIMDs x 64 lanes x 16 abs-diff per v_qsad_pk_u16_u8 / 16 cyc x 2.4 GHz"}
+        out["roofline"]["valu_me"]["frac"] = out["roofline"]["valu_me"]["achieved"] / out["roofline"]["valu_me"]["peak"]
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline(orc, F, sbs, mc, tc, stages):
+    """Oracle port, all host cores, bounded sample (about 10-30 s of CPU time in total)."""
+    from conftest import ptr
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    keys = {s["key"] for s in stages}
+    sec_per_sb = {}
+
+    def par(fn, chunks):
+        t = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(fn, chunks))
+        return time.perf_counter() - t
+
+    def split(n):
+        return [(i * n // cores, (i + 1) * n // cores) for i in range(cores) if (i + 1) * n // cores > i * n // cores]
+
+    if "me" in keys:
+        n = min(F.n_sb, cores * 8)
+        t = par(lambda be: mc.oracle_frame(orc, F.cur_y_p, F.ref_y_p, F.cur_y_p.shape[1], F.pad, sbs, 0, be[0], be[1]), split(n))
+        sec_per_sb["me_fullpel_85pu"] = t / n
+    if "txfm" in keys or "inv" in keys:
+        # forward + quant + inverse chain on every block list, first `frac` of each list
+        recon = [np.zeros_like(p) for p in F.ref]
+        total_blocks_px, t_sum = 0, 0.0
+        for (kind, ts), descs in sorted(F.descs.items()):
+            n = max(cores, len(descs) // 8)
+            n = min(n, len(descs))
+            scans = F.scans(ts)
+            SC = (C.c_void_p * 3)(*[s.ctypes.data if s is not None else None for s in scans])
+            for plane in ([0] if kind == 0 else [1, 2]):
+                qp = F.qp[plane]
+                def work(be, plane=plane, descs=descs, ts=ts, qp=qp, SC=SC):
+                    orc.orc_txfm_chain_8bit(ptr(F.cur[plane]), F.cur[plane].shape[1], ptr(F.ref[plane]), F.ref[plane].shape[1],
+                                            ptr(recon[plane]), recon[plane].shape[1], ptr(descs), be[0], be[1], ts, 0, ptr(qp), SC,
+                                            tc.TX_SCALE[ts], None, None)
+                t_sum += par(work, split(n))
+                total_blocks_px += n * tc.TXW[ts] * tc.TXH[ts]
+        sec_per_sb["fwd_txfm_quant+inv_txfm_recon"] = t_sum / (total_blocks_px / 6144.0)   # 6144 px per SB (4:2:0)
+    if "dlf" in keys:
+        band = min(F.h, 64 * 6)
+        t = 0.0
+        for p in range(3):
+            ev, eh = F.edges[p]
+            ph = band >> (p > 0)
+            img = np.ascontiguousarray(F.ref[p][:ph + 8].copy())
+            uh = ph // 4
+            t0 = time.perf_counter()
+            orc.orc_deblock_plane(ptr(img), 1, img.shape[1], 8, ptr(np.ascontiguousarray(ev[:uh])), ptr(np.ascontiguousarray(eh[:uh])), ev.shape[1], uh, 0)
+            t += time.perf_counter() - t0
+        sec_per_sb["deblock"] = t / (F.sb_cols * (band // 64)) / cores   # single-threaded measurement scaled to `cores` (rows are independent)
+    if "cdef_search" in keys:
+        P3, I3 = C.c_void_p * 3, C.c_int * 3
+        n = min(F.n_sb, cores * 2)
+        mse = np.zeros((2, F.n_sb, 64), np.uint64)
+        def work(be):
+            orc.orc_cdef_search_frame(P3(*[p.ctypes.data for p in F.ref]), I3(*[p.shape[1] for p in F.ref]), P3(*[p.ctypes.data for p in F.cur]),
+                                      I3(*[p.shape[1] for p in F.cur]), 1, F.w, F.h, ptr(F.skip8), F.cdef_damping, 8, 0, ptr(mse), be[0], be[1])
+        t = par(work, split(n))
+        sec_per_sb["cdef_search"] = t / n
+    total = sum(sec_per_sb.values())
+    return dict(value=1.0 / total if total > 0 else None, unit="SB/s", cores=cores, kind="port",
+                sample="oracle C port (scalar, gcc -O2) of the same stage chain on a bounded sample of the same frame, "
+                       f"{cores} threads; seconds per SB per stage: " + ", ".join(f"{k}={v:.2e}" for k, v in sec_per_sb.items())
+                       + " (cdef_apply not timed on CPU; deblock timed single-threaded and divided by cores)")
 
 
 if __name__ == "__main__":

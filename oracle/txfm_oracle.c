@@ -453,3 +453,32 @@ void orc_residual_8bit(const uint8_t *src, uint32_t src_stride, const uint8_t *p
     for (uint32_t r = 0; r < h; r++)
         for (uint32_t c = 0; c < w; c++) res[r * res_stride + c] = (int16_t)((int)src[r * src_stride + c] - (int)pred[r * pred_stride + c]);
 }
+
+/* Frame-level driver for tests / bench cpu_baseline: residual -> fwd txfm -> (64-pt re-pack) -> quantize
+ * -> inverse txfm -> recon for a list of blocks of one transform size (descriptor = x | y << 14 |
+ * tx_type << 28, the layout of SVT_HIP_TX_DESC). 8-bit planes. */
+void orc_quantize(int variant, const int32_t *coeff, int n, const int16_t *zbin, const int16_t *round,
+                  const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                  const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale);
+void orc_txfm_chain_8bit(const uint8_t *src, int src_stride, const uint8_t *pred, int pred_stride, uint8_t *recon,
+                         int recon_stride, const uint32_t *descs, int begin, int end, int tx_size, int variant,
+                         const int16_t qp[7][2], const int16_t *const scans[3], int log_scale, int32_t *qcoeff_out,
+                         uint16_t *eob_out) {
+    const int W = tx_w[tx_size], H = tx_h[tx_size], kw = W > 32 ? 32 : W, kh = H > 32 ? 32 : H, nk = kw * kh;
+    int16_t res[64 * 64];
+    int32_t *co = (int32_t *)malloc(sizeof(int32_t) * 64 * 64 * 3), *q = co + 4096, *dq = q + 4096;
+    for (int i = begin; i < end; i++) {
+        const int x = descs[i] & 0x3FFF, y = (descs[i] >> 14) & 0x3FFF, tt = descs[i] >> 28;
+        orc_residual_8bit(src + (size_t)y * src_stride + x, src_stride, pred + (size_t)y * pred_stride + x, pred_stride, res, W, W, H);
+        orc_fwd_txfm2d(res, co, W, tt, tx_size, 8);
+        orc_handle_transform(co, tx_size);
+        const int cls = (W <= 16 && H <= 16) ? (tt < 10 ? 0 : ((tt & 1) ? 2 : 1)) : 0;
+        uint16_t eob;
+        const int16_t *rnd = variant >= 2 ? qp[5] : qp[1], *qnt = variant >= 2 ? qp[6] : qp[2];
+        orc_quantize(variant, co, nk, qp[0], rnd, qnt, qp[3], q, dq, qp[4], &eob, scans[cls], log_scale);
+        if (qcoeff_out) memcpy(qcoeff_out + (size_t)i * nk, q, sizeof(int32_t) * nk);
+        if (eob_out) eob_out[i] = eob;
+        orc_inv_txfm_add_8bit(dq, pred + (size_t)y * pred_stride + x, pred_stride, recon + (size_t)y * recon_stride + x, recon_stride, tt, tx_size);
+    }
+    free(co);
+}

@@ -1,0 +1,92 @@
+"""Synthetic per-frame workload of the hot path: one 8-bit 4:2:0 frame,
+its reference frame, a per-SB transform tiling, deblocking mode info, CDEF skip map / strengths.
+Shared by bench.py (device side through the C ABI) and by the frame-level parity tests (oracle side).
+Everything is deterministic in (width, height, seed)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from conftest import load_package, ptr
+import txfm_common as tc
+import dlf_common as dc
+
+pkg = load_package()
+synth = __import__("importlib").import_module("svt_av1_amd.synth")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TABLES = np.load(os.path.join(GOLD, "txfm_tables.npz"))
+
+TX_SQ = {2: 0, 3: 1, 4: 2, 5: 3, 6: 4}  # log2 size -> TxSize of the square transform
+
+
+class Frame:
+    def __init__(self, width, height, seed=11, qindex=60):
+        self.w, self.h, self.seed = width, height, seed
+        rng = np.random.default_rng(seed + 1000)
+        cur, ref = synth.make_luma_pair(width, height, seed=seed)
+        self.pad = synth.PAD
+        self.cur_y_p, self.ref_y_p = synth.pad_plane(cur), synth.pad_plane(ref)     # padded (ME)
+        self.cur = [cur, None, None]
+        self.ref = [ref, None, None]
+        for i, (a, b) in enumerate(((1, 37), (2, 91))):
+            self.cur[i + 1] = np.ascontiguousarray(np.clip(128 + (cur[::2, ::2].astype(np.int16) - 128) // (a + 1) + b % 7, 0, 255).astype(np.uint8))
+            self.ref[i + 1] = np.ascontiguousarray(np.clip(128 + (ref[::2, ::2].astype(np.int16) - 128) // (a + 1) + b % 7, 0, 255).astype(np.uint8))
+        self.sb_cols, self.sb_rows = (width + 63) // 64, (height + 63) // 64
+        self.n_sb = self.sb_cols * self.sb_rows
+        # ---- transform tiling: one square size per SB (luma log2 2..6, chroma one smaller, min 4x4)
+        self.sb_tx = rng.integers(2, 7, self.n_sb)
+        self.sb_skip = rng.random(self.n_sb) < 0.0
+        self.descs = {}  # (plane_kind, tx_size) -> uint32 descriptor array ; plane_kind 0 luma, 1 chroma (U and V share it)
+        lists = {}
+        for sb in range(self.n_sb):
+            sx, sy = (sb % self.sb_cols) * 64, (sb // self.sb_cols) * 64
+            for kind in (0, 1):
+                l2 = int(self.sb_tx[sb]) if kind == 0 else max(2, int(self.sb_tx[sb]) - 1)
+                ts = TX_SQ[l2]
+                n = 1 << l2
+                types = tc.legal_types(ts)
+                x0, y0 = sx >> kind, sy >> kind
+                pw, ph = width >> kind, height >> kind
+                k = 0
+                for y in range(y0, min(y0 + (64 >> kind), ph), n):
+                    for x in range(x0, min(x0 + (64 >> kind), pw), n):
+                        if x + n <= pw and y + n <= ph:
+                            lists.setdefault((kind, ts), []).append(pkg.tx_desc(x, y, types[(sb + k) % len(types)]))
+                            k += 1
+        self.descs = {k: np.asarray(v, np.uint32) for k, v in lists.items()}
+        # ---- quantizer tables (reference-generated fixtures) and scan tables
+        self.qp = [np.ascontiguousarray(TABLES[f"qp/8/{qindex}/{p}"]) for p in range(3)]
+        # ---- deblocking mode info consistent with the tiling
+        cols, rows = (width + 3) // 4, (height + 3) // 4
+        self.mi = (pkg.DlfModeInfo * (cols * rows))()
+        self.mi_cols, self.mi_rows = cols, rows
+        tx_grid = np.repeat(np.repeat(self.sb_tx.reshape(self.sb_rows, self.sb_cols), 16, 0), 16, 1)[:rows, :cols]
+        skip_blk = rng.random(((height + 7) // 8, (width + 7) // 8)) < 0.3
+        self.skip8 = np.ascontiguousarray(skip_blk[:height // 8, :width // 8].astype(np.uint8))
+        skip_grid = np.repeat(np.repeat(skip_blk, 2, 0), 2, 1)[:rows, :cols]
+        arr = np.frombuffer(self.mi, dtype=np.uint8).reshape(rows, cols, C.sizeof(pkg.DlfModeInfo))
+        arr[:, :, 0] = tx_grid; arr[:, :, 1] = tx_grid
+        arr[:, :, 2] = np.clip(tx_grid - 1, 2, 5); arr[:, :, 3] = np.clip(tx_grid - 1, 2, 5)
+        arr[:, :, 4] = np.maximum(tx_grid, 3); arr[:, :, 5] = np.maximum(tx_grid, 3)
+        arr[:, :, 6] = skip_grid
+        arr[:, :, 7] = 20; arr[:, :, 8] = 20; arr[:, :, 9] = 12; arr[:, :, 10] = 12; arr[:, :, 11] = 12; arr[:, :, 12] = 12
+        self.edges = [dc.build_edges(self.mi, cols, rows, p, width >> (p > 0), height >> (p > 0)) for p in range(3)]
+        # ---- CDEF: per-fb strengths for the apply stage (strength *selection* is host logic in the reference)
+        self.cdef_y = rng.integers(0, 64, self.n_sb).astype(np.uint8)
+        self.cdef_uv = rng.integers(0, 64, self.n_sb).astype(np.uint8)
+        self.cdef_damping = 3 + (120 >> 6)   # 3 + (base_q_idx >> 6), EbCdefProcess.c:121
+        self._orc_windows = None
+
+    def scan_tables(self, ts):
+        out = []
+        for cls in range(3):
+            key = f"iscan/{ts}/{cls}"
+            out.append(np.ascontiguousarray(TABLES[key]) if key in TABLES.files else None)
+        return out
+
+    def scans(self, ts):
+        out = []
+        for cls in range(3):
+            key = f"scan/{ts}/{cls}"
+            out.append(np.ascontiguousarray(TABLES[key]) if key in TABLES.files else None)
+        return out
