@@ -181,6 +181,39 @@ int svt_hip_cdef_apply_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *cons
                                  const int stride[3], int w, int h, const uint8_t *d_skip8, const uint8_t *d_y_strength,
                                  const uint8_t *d_uv_strength, int damping, int bd, uint8_t *d_dir);
 
+/* ------------------------------------------------------- sub-pel prediction, block SAD / variance */
+/* One block of a batched prediction launch.  mode 0 = AV1 single-reference convolve, i.e. what
+ * convolve[subpel_x != 0][subpel_y != 0][0] dispatches to (svt_av1_[highbd_]convolve_{2d_copy,x,y,2d}_sr,
+ * common_dsp_rtcd.h:197-219; round_0 = 3, round_1 = 11); mode 1 = svt_aom_upsampled_pred
+ * (aom_dsp_rtcd.h:354; two convolve8 passes with an 8-bit intermediate; 8-bit planes only, pass
+ * subpel_q3 << 1 as the phase).  Kernel banks: 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP,
+ * 3 BILINEAR, 4 / 5 the 4-tap regular / smooth kernels AV1 uses for w <= 4
+ * (av1_get_interp_filter_params_with_block_size, Common/Codec/EbInterPrediction.c:1254). */
+typedef struct {
+    int32_t src_x, src_y; /* integer position of the block's top-left sample in the reference plane */
+    int32_t dst_x, dst_y;
+    uint8_t w, h;         /* 4..128 */
+    uint8_t bank_x, bank_y;
+    uint8_t subpel_x, subpel_y; /* q4 phase 0..15 */
+    uint8_t mode, reserved;
+} SvtHipConvBlk;
+/* The reference plane must be readable 3 samples left/above and 4 + 16-tile padding right/below of
+ * every block (the reference's padded pictures are).  strides in pixels. */
+int svt_hip_subpel_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int ref_stride, void *d_dst,
+                                     int dst_stride, const SvtHipConvBlk *d_blks, int nblk);
+
+typedef struct {
+    int32_t a_x, a_y, b_x, b_y;
+    uint16_t w, h;
+} SvtHipBlkPair;
+/* svt_nxm_sad_kernel / svt_aom_sad{W}x{H} / sad_16b_kernel (aom_dsp_rtcd.h:334-336, :644, :651) for a list
+ * of block pairs. */
+int svt_hip_block_sad_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, int a_stride, const void *d_b, int b_stride,
+                                const SvtHipBlkPair *d_pairs, int n, uint32_t *d_sad);
+/* svt_aom_variance{W}x{H} (8-bit) / svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:524, :568). */
+int svt_hip_block_variance_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_a, int a_stride, const void *d_b,
+                                     int b_stride, const SvtHipBlkPair *d_pairs, int n, uint32_t *d_var, uint32_t *d_sse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,132 @@
+/*
+ * conv_oracle.c — CPU restatement of SVT-AV1's single-reference sub-pel convolve (normative AV1
+ * interpolation, *_sr), the sub-pel-search predictor (svt_aom_upsampled_pred: two convolve8 passes
+ * with an 8-bit intermediate) and block variance / SAD helpers.
+ * TEST INFRASTRUCTURE ONLY (see svt_oracle.h).  Citations: file:line under /root/reference/Source/Lib.
+ */
+#include "svt_oracle.h"
+#include <string.h>
+
+/* AV1 interpolation kernels (normative constants): Common/Codec/EbInterPrediction.c:258-291, :1181-1249.
+ * bank 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR, 4 4-tap regular (w <= 4),
+ * 5 4-tap smooth (w <= 4) */
+const int16_t orc_interp_kernels[6][16][8] = {
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -6, 126, 8, -2, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -12, 116, 28, -8, 2, 0},
+     {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 84, 66, -12, 2, 0},
+     {0, 2, -14, 76, 76, -14, 2, 0}, {0, 2, -12, 66, 84, -14, 2, 0}, {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -12, 48, 102, -14, 2, 0},
+     {0, 2, -10, 38, 110, -14, 2, 0}, {0, 2, -8, 28, 116, -12, 2, 0}, {0, 0, -4, 18, 122, -10, 2, 0}, {0, 0, -2, 8, 126, -6, 2, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, 28, 62, 34, 2, 0, 0}, {0, 0, 26, 62, 36, 4, 0, 0}, {0, 0, 22, 62, 40, 4, 0, 0},
+     {0, 0, 20, 60, 42, 6, 0, 0}, {0, 0, 18, 58, 44, 8, 0, 0}, {0, 0, 16, 56, 46, 10, 0, 0}, {0, -2, 16, 54, 48, 12, 0, 0},
+     {0, -2, 14, 52, 52, 14, -2, 0}, {0, 0, 12, 48, 54, 16, -2, 0}, {0, 0, 10, 46, 56, 16, 0, 0}, {0, 0, 8, 44, 58, 18, 0, 0},
+     {0, 0, 6, 42, 60, 20, 0, 0}, {0, 0, 4, 40, 62, 22, 0, 0}, {0, 0, 4, 36, 62, 26, 0, 0}, {0, 0, 2, 34, 62, 28, 2, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {-2, 2, -6, 126, 8, -2, 2, 0}, {-2, 6, -12, 124, 16, -6, 4, -2}, {-2, 8, -18, 120, 26, -10, 6, -2},
+     {-4, 10, -22, 116, 38, -14, 6, -2}, {-4, 10, -22, 108, 48, -18, 8, -2}, {-4, 10, -24, 100, 60, -20, 8, -2}, {-4, 10, -24, 90, 70, -22, 10, -2},
+     {-4, 12, -24, 80, 80, -24, 12, -4}, {-2, 10, -22, 70, 90, -24, 10, -4}, {-2, 8, -20, 60, 100, -24, 10, -4}, {-2, 8, -18, 48, 108, -22, 10, -4},
+     {-2, 6, -14, 38, 116, -22, 10, -4}, {-2, 6, -10, 26, 120, -18, 8, -2}, {-2, 4, -6, 16, 124, -12, 6, -2}, {0, 2, -2, 8, 126, -6, 2, -2}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 120, 8, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 104, 24, 0, 0, 0},
+     {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 88, 40, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 72, 56, 0, 0, 0},
+     {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, -4, 126, 8, -2, 0, 0}, {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -10, 116, 28, -6, 0, 0},
+     {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 84, 66, -10, 0, 0},
+     {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0}, {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -10, 48, 102, -12, 0, 0},
+     {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0}, {0, 0, -4, 18, 122, -8, 0, 0}, {0, 0, -2, 8, 126, -4, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 30, 62, 34, 2, 0, 0}, {0, 0, 26, 62, 36, 4, 0, 0}, {0, 0, 22, 62, 40, 4, 0, 0},
+     {0, 0, 20, 60, 42, 6, 0, 0}, {0, 0, 18, 58, 44, 8, 0, 0}, {0, 0, 16, 56, 46, 10, 0, 0}, {0, 0, 14, 54, 48, 12, 0, 0},
+     {0, 0, 12, 52, 52, 12, 0, 0}, {0, 0, 12, 48, 54, 14, 0, 0}, {0, 0, 10, 46, 56, 16, 0, 0}, {0, 0, 8, 44, 58, 18, 0, 0},
+     {0, 0, 6, 42, 60, 20, 0, 0}, {0, 0, 4, 40, 62, 22, 0, 0}, {0, 0, 4, 36, 62, 26, 0, 0}, {0, 0, 2, 34, 62, 30, 0, 0}}};
+
+static inline int rp2(int v, int n) { return n == 0 ? v : ((v + (1 << (n - 1))) >> n); }
+static inline int clipbd(int v, int bd) { const int m = (1 << bd) - 1; return v < 0 ? 0 : (v > m ? m : v); }
+static inline int rdp(const void *b, int pb, ptrdiff_t i) { return pb == 1 ? ((const uint8_t *)b)[i] : ((const uint16_t *)b)[i]; }
+static inline void wrp(void *b, int pb, ptrdiff_t i, int v) { if (pb == 1) ((uint8_t *)b)[i] = (uint8_t)v; else ((uint16_t *)b)[i] = (uint16_t)v; }
+
+/* svt_av1_[highbd_]convolve_{2d_copy,x,y,2d}_sr_c, selected like convolve[sx != 0][sy != 0][0]
+ * (Common/Codec/EbInterPrediction.c:349-469, :744-866, :1161-1174), round_0 = 3, round_1 = 11
+ * (non-compound, bd <= 10).  src points at the block's top-left integer sample. */
+void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride, int pix_bytes, int w, int h, int bank_x, int bank_y,
+                     int subpel_x_q4, int subpel_y_q4, int bd) {
+    const int16_t *xf = orc_interp_kernels[bank_x][subpel_x_q4 & 15], *yf = orc_interp_kernels[bank_y][subpel_y_q4 & 15];
+    const int r0 = 3, r1 = 11, fo = 3;
+    if (!(subpel_x_q4 & 15) && !(subpel_y_q4 & 15)) {
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) wrp(dst, pix_bytes, (ptrdiff_t)y * dst_stride + x, rdp(src, pix_bytes, (ptrdiff_t)y * src_stride + x));
+    } else if (!(subpel_y_q4 & 15)) {
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int res = 0;
+            for (int k = 0; k < 8; k++) res += xf[k] * rdp(src, pix_bytes, (ptrdiff_t)y * src_stride + x - fo + k);
+            res = rp2(res, r0);
+            wrp(dst, pix_bytes, (ptrdiff_t)y * dst_stride + x, clipbd(rp2(res, 7 - r0), bd));
+        }
+    } else if (!(subpel_x_q4 & 15)) {
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int res = 0;
+            for (int k = 0; k < 8; k++) res += yf[k] * rdp(src, pix_bytes, (ptrdiff_t)(y - fo + k) * src_stride + x);
+            wrp(dst, pix_bytes, (ptrdiff_t)y * dst_stride + x, clipbd(rp2(res, 7), bd));
+        }
+    } else {
+        int16_t im[(128 + 7) * 128];
+        const int im_h = h + 7, offset_bits = bd + 14 - r0, bits = 14 - r0 - r1;
+        for (int y = 0; y < im_h; y++) for (int x = 0; x < w; x++) {
+            int sum = 1 << (bd + 6);
+            for (int k = 0; k < 8; k++) sum += xf[k] * rdp(src, pix_bytes, (ptrdiff_t)(y - fo) * src_stride + x - fo + k);
+            im[y * w + x] = (int16_t)rp2(sum, r0);
+        }
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int sum = 1 << offset_bits;
+            for (int k = 0; k < 8; k++) sum += yf[k] * im[(y + k) * w + x];
+            int res = rp2(sum, r1) - ((1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)));
+            if (pix_bytes == 1) res = (int16_t)res;
+            wrp(dst, pix_bytes, (ptrdiff_t)y * dst_stride + x, clipbd(rp2(res, bits), bd));
+        }
+    }
+}
+
+/* svt_aom_upsampled_pred_c (Encoder/C_DEFAULT/variance.c:212-269) over svt_aom_convolve8_{horiz,vert}_c
+ * (Common/Codec/convolve.c:249-307): 1/8-pel phases, 8-bit intermediate, output packed with stride `width`.
+ * bank: 3 (USE_2_TAPS), 4 (USE_4_TAPS) or 0 (USE_8_TAPS) — av1_get_filter, variance.c:198-209. */
+void orc_upsampled_pred(const uint8_t *ref, int ref_stride, uint8_t *pred, int width, int height, int subpel_x_q3, int subpel_y_q3, int bank) {
+    const int16_t *kx = orc_interp_kernels[bank][(subpel_x_q3 << 1) & 15], *ky = orc_interp_kernels[bank][(subpel_y_q3 << 1) & 15];
+    if (!subpel_x_q3 && !subpel_y_q3) {
+        for (int i = 0; i < height; i++) memcpy(pred + i * width, ref + (ptrdiff_t)i * ref_stride, width);
+    } else if (!subpel_y_q3) {
+        for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) {
+            int s = 0; for (int k = 0; k < 8; k++) s += ref[(ptrdiff_t)y * ref_stride + x - 3 + k] * kx[k];
+            pred[y * width + x] = (uint8_t)clipbd(rp2(s, 7), 8);
+        }
+    } else if (!subpel_x_q3) {
+        for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) {
+            int s = 0; for (int k = 0; k < 8; k++) s += ref[(ptrdiff_t)(y - 3 + k) * ref_stride + x] * ky[k];
+            pred[y * width + x] = (uint8_t)clipbd(rp2(s, 7), 8);
+        }
+    } else {
+        static uint8_t temp[(128 * 2 + 32) * 128];
+        const int ih = (((height - 1) * 8 + subpel_y_q3) >> 3) + 8;
+        uint8_t *t = (uint8_t *)__builtin_alloca((size_t)ih * 128);
+        (void)temp;
+        for (int y = 0; y < ih; y++) for (int x = 0; x < width; x++) {
+            int s = 0; for (int k = 0; k < 8; k++) s += ref[(ptrdiff_t)(y - 3) * ref_stride + x - 3 + k] * kx[k];
+            t[y * 128 + x] = (uint8_t)clipbd(rp2(s, 7), 8);
+        }
+        for (int y = 0; y < height; y++) for (int x = 0; x < width; x++) {
+            int s = 0; for (int k = 0; k < 8; k++) s += t[(y + k) * 128 + x] * ky[k];
+            pred[y * width + x] = (uint8_t)clipbd(rp2(s, 7), 8);
+        }
+    }
+}
+
+/* svt_aom_variance{W}x{H}_c (Encoder/C_DEFAULT/EbComputeVariance_C.c:14-77) */
+uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse) {
+    int sum = 0; uint32_t s2 = 0;
+    for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) { const int d = a[(ptrdiff_t)i * a_stride + j] - b[(ptrdiff_t)i * b_stride + j]; sum += d; s2 += (uint32_t)(d * d); }
+    *sse = s2;
+    return s2 - (uint32_t)(((int64_t)sum * sum) / (w * h));
+}
+/* svt_aom_highbd_10_variance{W}x{H}_c (Encoder/Codec/EbPsnr.c:170-233) */
+uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) {
+    int64_t tsum = 0; uint64_t tsse = 0;
+    for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) { const int d = a[(ptrdiff_t)i * a_stride + j] - b[(ptrdiff_t)i * b_stride + j]; tsum += d; tsse += (uint32_t)(d * d); }
+    *sse = (uint32_t)((tsse + 8) >> 4);
+    const int sum = (int)((tsum + 2) >> 2);
+    const int64_t var = (int64_t)(*sse) - (((int64_t)sum * sum) / (w * h));
+    return var >= 0 ? (uint32_t)var : 0;
+}

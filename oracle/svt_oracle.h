@@ -127,6 +127,14 @@ void orc_cdef_search_frame(const void *const rec[3], const int rec_stride[3], co
 void orc_cdef_apply_frame(const void *const in[3], void *const out[3], const int stride[3], int pix_bytes, int w, int h,
                           const uint8_t *skip8, const uint8_t *y_strength, const uint8_t *uv_strength, int damping_hdr, int bd);
 
+/* ---------------------------------------------------------------- sub-pel convolve (conv_oracle.c) */
+extern const int16_t orc_interp_kernels[6][16][8];
+void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride, int pix_bytes, int w, int h, int bank_x, int bank_y,
+                     int subpel_x_q4, int subpel_y_q4, int bd);
+void orc_upsampled_pred(const uint8_t *ref, int ref_stride, uint8_t *pred, int width, int height, int subpel_x_q3, int subpel_y_q3, int bank);
+uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse);
+uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
+
 #ifdef __cplusplus
 }
 #endif

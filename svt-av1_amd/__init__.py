@@ -41,6 +41,18 @@ class DlfModeInfo(C.Structure):
                 ("bw_log2", C.c_uint8), ("bh_log2", C.c_uint8), ("skip_inter", C.c_uint8), ("level", (C.c_uint8 * 2) * 3)]
 
 
+class ConvBlk(C.Structure):
+    """SvtHipConvBlk (include/svt_hip.h)."""
+    _fields_ = [("src_x", C.c_int32), ("src_y", C.c_int32), ("dst_x", C.c_int32), ("dst_y", C.c_int32), ("w", C.c_uint8), ("h", C.c_uint8),
+                ("bank_x", C.c_uint8), ("bank_y", C.c_uint8), ("subpel_x", C.c_uint8), ("subpel_y", C.c_uint8), ("mode", C.c_uint8),
+                ("reserved", C.c_uint8)]
+
+
+class BlkPair(C.Structure):
+    """SvtHipBlkPair (include/svt_hip.h)."""
+    _fields_ = [("a_x", C.c_int32), ("a_y", C.c_int32), ("b_x", C.c_int32), ("b_y", C.c_int32), ("w", C.c_uint16), ("h", C.c_uint16)]
+
+
 def tx_desc(x, y, tx_type):
     return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
 
@@ -80,6 +92,9 @@ def lib():
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
+    L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]
+    L.svt_hip_block_sad_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
+    L.svt_hip_block_variance_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]
     P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp]

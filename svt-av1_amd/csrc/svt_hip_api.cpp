@@ -297,4 +297,30 @@ int svt_hip_cdef_apply_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const 
     return SVT_HIP_OK;
 }
 
+/* -------------------------------------------------------------- sub-pel predict / SAD / variance */
+int svt_hip_subpel_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref, int ref_stride, void* d_dst, int dst_stride,
+                                     const SvtHipConvBlk* d_blks, int nblk) {
+    if (!c || !d_ref || !d_dst || !d_blks || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) {
+        if (c) c->err = "svt_hip_subpel_predict_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_subpel_predict(c->stream, pix_bytes, bd, d_ref, ref_stride, d_dst, dst_stride, d_blks, nblk);
+    if (e != hipSuccess) return fail(c, e, "subpel predict launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride,
+                                const SvtHipBlkPair* d_pairs, int n, uint32_t* d_sad) {
+    if (!c || !d_a || !d_b || !d_pairs || !d_sad || n < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_block_sad(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, d_pairs, n, d_sad);
+    if (e != hipSuccess) return fail(c, e, "block sad launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_a, int a_stride, const void* d_b, int b_stride,
+                                     const SvtHipBlkPair* d_pairs, int n, uint32_t* d_var, uint32_t* d_sse) {
+    if (!c || !d_a || !d_b || !d_pairs || !d_var || n < 0 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd == 10))) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_block_variance(c->stream, pix_bytes, bd, d_a, a_stride, d_b, b_stride, d_pairs, n, d_var, d_sse);
+    if (e != hipSuccess) return fail(c, e, "block variance launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

@@ -23,4 +23,10 @@ int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const 
 int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3], int w, int h,
                               const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength, int damping, int bd,
                               uint8_t* dir_buf);
+int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int bd, const void* ref, int ref_stride, void* dst, int dst_stride,
+                                  const SvtHipConvBlk* blks, int n);
+int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,
+                             const SvtHipBlkPair* d, int n, uint32_t* out);
+int svt_hip_launch_block_variance(hipStream_t st, int pix_bytes, int bd, const void* a, int a_stride, const void* b, int b_stride,
+                                  const SvtHipBlkPair* d, int n, uint32_t* var_out, uint32_t* sse_out);
 }

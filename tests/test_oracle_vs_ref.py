@@ -259,3 +259,80 @@ def test_cdef_search_filter_block_level(orc, ref):
                     continue
                 assert np.array_equal(r[0], mse[0, fbr * nh + fbc]), ("Y", bd, fbr, fbc)
                 assert np.array_equal(r[1], mse[1, fbr * nh + fbc]), ("UV", bd, fbr, fbc)
+
+
+# ----------------------------------------------------------------------- sub-pel convolve / variance
+class _IFP(C.Structure):
+    _fields_ = [("filter_ptr", C.c_void_p), ("taps", C.c_uint16), ("subpel_shifts", C.c_uint16), ("interp_filter", C.c_uint8)]
+
+
+class _ConvP(C.Structure):
+    _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("round_0", C.c_int32),
+                ("round_1", C.c_int32), ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32),
+                ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32), ("use_dist_wtd_comp_avg", C.c_int32)]
+
+
+REF_BANKS = ["sub_pel_filters_8", "sub_pel_filters_8smooth", "sub_pel_filters_8sharp", "bilinear_filters", "sub_pel_filters_4", "sub_pel_filters_4smooth"]
+
+
+def test_interp_kernels_and_convolve_sr(orc, ref):
+    """Kernel tables == the reference's; convolve copy/x/y/2d for all 16x16 phases, lbd + hbd
+    (/root/reference/test/convolve_2d_test.cc:785-1040)."""
+    mine = np.ctypeslib.as_array((C.c_int16 * 8 * 16 * 6).in_dll(orc, "orc_interp_kernels"))
+    for b, name in enumerate(REF_BANKS):
+        assert np.array_equal(mine[b], np.ctypeslib.as_array((C.c_int16 * 8 * 16).in_dll(ref, name))), name
+    rng = np.random.default_rng(2)
+    cp = _ConvP(); cp.round_0 = 3; cp.round_1 = 11
+    for bd, dt, pre in ((8, np.uint8, "svt_av1_"), (10, np.uint16, "svt_av1_highbd_")):
+        for it in range(300):
+            w = int(rng.choice([4, 8, 16, 32, 64, 128])); h = int(rng.choice([4, 8, 16, 32, 64, 128]))
+            bx = int(rng.integers(0, 6)); by_ = int(rng.integers(0, 6))
+            sx, sy = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+            if it % 5 == 0: sx = 0
+            if it % 7 == 0: sy = 0
+            src = rng.integers(0, 1 << bd, (h + 16, w + 24)).astype(dt)
+            if it % 11 == 0: src[:] = (1 << bd) - 1
+            a = np.zeros((h, w + 3), dt); b = np.zeros((h, w + 3), dt)
+            fx = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[bx])), 8, 16, 0)
+            fy = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[by_])), 8, 16, 0)
+            name = pre + "convolve_" + {(0, 0): "2d_copy", (1, 0): "x", (0, 1): "y", (1, 1): "2d"}[(int(sx != 0), int(sy != 0))] + "_sr_c"
+            sp = C.c_void_p(src.ctypes.data + (8 * src.shape[1] + 8) * src.itemsize)
+            args = [sp, src.shape[1], ptr(a), a.shape[1], w, h, C.byref(fx), C.byref(fy), sx, sy, C.byref(cp)]
+            if bd > 8: args.append(bd)
+            getattr(ref, name)(*args)
+            orc.orc_convolve_sr(sp, src.shape[1], ptr(b), b.shape[1], src.itemsize, w, h, bx, by_, sx, sy, bd)
+            assert np.array_equal(a, b), (name, w, h, sx, sy)
+
+
+def test_upsampled_pred_and_variance(orc, ref):
+    """svt_aom_upsampled_pred_c (2/4/8-tap) and the block variances (lbd + highbd_10)
+    (/root/reference/test/VarianceTest.cc:129-401, HbdVarianceTest.cc:295-700)."""
+    rng = np.random.default_rng(8)
+    for it in range(200):
+        w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([4, 8, 16, 32, 64]))
+        sx, sy = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        search = int(rng.integers(0, 3))   # USE_2_TAPS, USE_4_TAPS, USE_8_TAPS
+        bank = [3, 4, 0][search]
+        src = rng.integers(0, 256, (h + 20, w + 24)).astype(np.uint8)
+        sp = C.c_void_p(src.ctypes.data + 8 * src.shape[1] + 8)
+        a = np.zeros(w * h, np.uint8); b = np.zeros(w * h, np.uint8)
+        ref.svt_aom_upsampled_pred_c(None, None, 0, 0, None, ptr(a), w, h, sx, sy, sp, src.shape[1], search + 1)  # USE_2_TAPS = 1
+        orc.orc_upsampled_pred(sp, src.shape[1], ptr(b), w, h, sx, sy, bank)
+        assert np.array_equal(a, b), (w, h, sx, sy, search)
+    orc.orc_variance.restype = C.c_uint32; orc.orc_variance_hbd10.restype = C.c_uint32
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (16, 32), (32, 16), (64, 64), (8, 32), (64, 16)):
+        for it in range(40):
+            for bd, dt in ((8, np.uint8), (10, np.uint16)):
+                a = rng.integers(0, 1 << bd, (h, w + 5)).astype(dt); b = rng.integers(0, 1 << bd, (h, w + 9)).astype(dt)
+                if it == 0: a[:] = 0; b[:] = (1 << bd) - 1
+                if it == 1: b[:, :w] = a[:, :w]
+                s1, s2 = C.c_uint32(0), C.c_uint32(0)
+                if bd == 8:
+                    f = getattr(ref, f"svt_aom_variance{w}x{h}_c"); f.restype = C.c_uint32
+                    v1 = f(ptr(a), a.shape[1], ptr(b), b.shape[1], C.byref(s1))
+                    v2 = orc.orc_variance(ptr(a), a.shape[1], ptr(b), b.shape[1], w, h, C.byref(s2))
+                else:
+                    f = getattr(ref, f"svt_aom_highbd_10_variance{w}x{h}_c"); f.restype = C.c_uint32
+                    v1 = f(C.c_void_p(a.ctypes.data >> 1), a.shape[1], C.c_void_p(b.ctypes.data >> 1), b.shape[1], C.byref(s1))   # CONVERT_TO_BYTEPTR
+                    v2 = orc.orc_variance_hbd10(ptr(a), a.shape[1], ptr(b), b.shape[1], w, h, C.byref(s2))
+                assert (v1, s1.value) == (v2, s2.value), (w, h, bd, it)
