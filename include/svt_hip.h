@@ -214,6 +214,34 @@ int svt_hip_block_sad_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, 
 int svt_hip_block_variance_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_a, int a_stride, const void *d_b,
                                      int b_stride, const SvtHipBlkPair *d_pairs, int n, uint32_t *d_var, uint32_t *d_sse);
 
+/* ------------------------------------------------------- HME pyramids, variance pyramid, HME search */
+/* decimation_2d / downsample_2d (Encoder/Codec/EbPictureAnalysisProcess.c:193,223): step 2 or 4,
+ * filtered = 0 point-decimate, 1 = 2x2 box (a+b+c+d+2)>>2.  Output (w/step) x (h/step). */
+int svt_hip_downsample_2d_dev(SvtHipCtx *ctx, const uint8_t *d_in, int in_stride, int w, int h, uint8_t *d_out, int out_stride,
+                              int step, int filtered);
+/* compute_block_mean_compute_variance (EbPictureAnalysisProcess.c:1005) for every 64x64 SB of a luma
+ * plane whose (0,0) is 8-byte aligned with an 8-byte-multiple stride and at least 64 rows/cols of
+ * padding past the last SB (the reference's padded input picture).  Replaces
+ * svt_compute_interm_var_four8x8 / svt_compute_sub_mean_8x8 / svt_compute_mean_square_values_8x8
+ * (aom_dsp_rtcd.h:650).  Outputs [n_sb][85]: [0] 64x64, [1..4] 32x32, [5..20] 16x16, [21..84] 8x8, each
+ * level in raster order (pcs->y_mean / pcs->variance).  full_precision = BLOCK_MEAN_PREC_FULL. */
+int svt_hip_variance_pyramid_dev(SvtHipCtx *ctx, const uint8_t *d_plane, int stride, int sb_cols, int n_sb,
+                                 int full_precision, uint8_t *d_mean, uint16_t *d_var);
+/* One exhaustive block search = one svt_sad_loop_kernel call (aom_dsp_rtcd.h:597) as issued by
+ * hme_level_0/1/2 (Encoder/Codec/EbMotionEstimation.c:998,1146,1291).  row_step 2 reproduces the
+ * "sub-SAD" calling convention (strides doubled, block height halved; the caller doubles the SAD). */
+typedef struct {
+    int32_t src_x, src_y; /* block position in the (decimated) source plane */
+    int32_t ref_x, ref_y; /* position of the first candidate in the (decimated) reference plane */
+    int16_t bw, bh;       /* block size, <= 64 x 64 */
+    int16_t sa_w, sa_h;   /* search area */
+    int16_t row_step, reserved;
+} SvtHipSadLoop;
+/* d_best_sad[n] (0xffffff when no candidate), d_best_xy[n][2] = (x_search_center, y_search_center);
+ * first minimum in raster order, like the C kernel.  Entries are untouched when no candidate wins. */
+int svt_hip_sad_loop_batch_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, const uint8_t *d_ref, int ref_stride,
+                               const SvtHipSadLoop *d_searches, int n, uint32_t *d_best_sad, int16_t *d_best_xy);
+
 #ifdef __cplusplus
 }
 #endif

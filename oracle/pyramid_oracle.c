@@ -1,0 +1,61 @@
+/*
+ * pyramid_oracle.c — CPU restatement of the picture-analysis kernels that feed open-loop ME:
+ * 2-D decimation / 2x2 down-sampling for the HME pyramids and the per-SB mean / variance pyramid.
+ * TEST INFRASTRUCTURE ONLY (see svt_oracle.h).  Citations: file:line under /root/reference/Source/Lib.
+ */
+#include "svt_oracle.h"
+
+/* decimation_2d (Encoder/Codec/EbPictureAnalysisProcess.c:193-216) / downsample_2d (:223-255).
+ * step = 2 or 4; output is (w/step) x (h/step). */
+void orc_downsample_2d(const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
+    if (!filtered) {
+        for (int y = 0; y < h; y += step)
+            for (int x = 0; x < w; x += step) out[(y / step) * out_stride + (x >> (step >> 1))] = in[(size_t)y * in_stride + x];
+        return;
+    }
+    const int half = step >> 1;
+    for (int y = half, oy = 0; y < h; y += step, oy++)
+        for (int x = half, ox = 0; x < w; x += step, ox++) {
+            const unsigned s = in[(size_t)(y - 1) * in_stride + x - 1] + in[(size_t)(y - 1) * in_stride + x] +
+                               in[(size_t)y * in_stride + x - 1] + in[(size_t)y * in_stride + x];
+            out[oy * out_stride + ox] = (uint8_t)((s + 2) >> 2);
+        }
+}
+
+/* compute_block_mean_compute_variance (EbPictureAnalysisProcess.c:1005-2575) for one 64x64 SB.
+ * full_precision 0 = BLOCK_MEAN_PREC_SUB (default, EbSequenceControlSet.c:192): rows 0,2,4,6 only
+ * (svt_compute_sub_mean_8x8_c :310, compute_sub_mean_squared_values_c :329); 1 = BLOCK_MEAN_PREC_FULL
+ * (compute_mean_8x8 / svt_compute_mean_squared_values_c :287).  Output layout [85]: [0] 64x64,
+ * [1..4] 32x32, [5..20] 16x16, [21..84] 8x8, each level in RASTER order (as the reference writes
+ * pcs->y_mean / pcs->variance). */
+void orc_variance_pyramid_sb(const uint8_t *sb, int stride, int full_precision, uint8_t mean_out[85], uint16_t var_out[85]) {
+    uint64_t m8[64], q8[64], m16[16], q16[16], m32[4], q32[4], m64, q64;
+    for (int b = 0; b < 64; b++) {
+        const uint8_t *p = sb + (size_t)(b >> 3) * 8 * stride + (b & 7) * 8;
+        uint64_t s = 0, s2 = 0;
+        for (int y = 0; y < 8; y += full_precision ? 1 : 2)
+            for (int x = 0; x < 8; x++) { const unsigned v = p[(size_t)y * stride + x]; s += v; s2 += v * v; }
+        if (full_precision) { m8[b] = (s << 8) / 64; q8[b] = (s2 << 16) / 64; }
+        else                { m8[b] = s << 3;        q8[b] = s2 << 11; }
+    }
+    for (int Y = 0; Y < 4; Y++)
+        for (int X = 0; X < 4; X++) {
+            const int b = 16 * Y + 2 * X;
+            m16[4 * Y + X] = (m8[b] + m8[b + 1] + m8[b + 8] + m8[b + 9]) >> 2;
+            q16[4 * Y + X] = (q8[b] + q8[b + 1] + q8[b + 8] + q8[b + 9]) >> 2;
+        }
+    for (int Y = 0; Y < 2; Y++)
+        for (int X = 0; X < 2; X++) {
+            const int b = 8 * Y + 2 * X;
+            m32[2 * Y + X] = (m16[b] + m16[b + 1] + m16[b + 4] + m16[b + 5]) >> 2;
+            q32[2 * Y + X] = (q16[b] + q16[b + 1] + q16[b + 4] + q16[b + 5]) >> 2;
+        }
+    m64 = (m32[0] + m32[1] + m32[2] + m32[3]) >> 2;
+    q64 = (q32[0] + q32[1] + q32[2] + q32[3]) >> 2;
+#define PUT(i, m, q) do { mean_out[i] = (uint8_t)((m) >> 8); var_out[i] = (uint16_t)(((q) - (m) * (m)) >> 16); } while (0)
+    PUT(0, m64, q64);
+    for (int i = 0; i < 4; i++) PUT(1 + i, m32[i], q32[i]);
+    for (int i = 0; i < 16; i++) PUT(5 + i, m16[i], q16[i]);
+    for (int i = 0; i < 64; i++) PUT(21 + i, m8[i], q8[i]);
+#undef PUT
+}

@@ -135,6 +135,10 @@ void orc_upsampled_pred(const uint8_t *ref, int ref_stride, uint8_t *pred, int w
 uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse);
 uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
 
+/* ---------------------------------------------------------------- pyramids (pyramid_oracle.c) --- */
+void orc_downsample_2d(const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered);
+void orc_variance_pyramid_sb(const uint8_t *sb, int stride, int full_precision, uint8_t mean_out[85], uint16_t var_out[85]);
+
 #ifdef __cplusplus
 }
 #endif

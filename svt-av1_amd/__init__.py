@@ -53,6 +53,12 @@ class BlkPair(C.Structure):
     _fields_ = [("a_x", C.c_int32), ("a_y", C.c_int32), ("b_x", C.c_int32), ("b_y", C.c_int32), ("w", C.c_uint16), ("h", C.c_uint16)]
 
 
+class SadLoop(C.Structure):
+    """SvtHipSadLoop (include/svt_hip.h)."""
+    _fields_ = [("src_x", C.c_int32), ("src_y", C.c_int32), ("ref_x", C.c_int32), ("ref_y", C.c_int32), ("bw", C.c_int16), ("bh", C.c_int16),
+                ("sa_w", C.c_int16), ("sa_h", C.c_int16), ("row_step", C.c_int16), ("reserved", C.c_int16)]
+
+
 def tx_desc(x, y, tx_type):
     return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
 
@@ -95,6 +101,9 @@ def lib():
     L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]
     L.svt_hip_block_sad_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
     L.svt_hip_block_variance_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]
+    L.svt_hip_downsample_2d_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32]
+    L.svt_hip_variance_pyramid_dev.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.svt_hip_sad_loop_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp]
     P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp]

@@ -1,0 +1,125 @@
+// pyramid.hip — picture-analysis kernels that feed open-loop ME, and the HME search kernel; gfx950.
+//
+// Replaces (file:line under /root/reference/Source/Lib):
+//   Encoder/Codec/EbPictureAnalysisProcess.c:193,223    decimation_2d / downsample_2d
+//   Encoder/Codec/EbPictureAnalysisProcess.c:1005-2575  compute_block_mean_compute_variance
+//        (+ svt_compute_interm_var_four8x8 :352, svt_compute_sub_mean_8x8 :310, svt_compute_mean_squared_values :287)
+//   Encoder/C_DEFAULT/EbComputeSAD_C.c:58               svt_sad_loop_kernel_c  (hme_level_0/1/2, EbMotionEstimation.c:852,1028,1177)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svt_hip_internal.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+downsample_kernel(const uint8_t* __restrict__ in, int in_stride, int w, int h, uint8_t* __restrict__ out, int out_stride, int step, int filtered) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    const int ow = w / step;
+    if (ox >= ow) return;
+    if (!filtered) {
+        out[(size_t)oy * out_stride + ox] = in[(size_t)(oy * step) * in_stride + ox * step];
+    } else {
+        const int half = step >> 1, y = oy * step + half, x = ox * step + half;
+        const uint32_t s = in[(size_t)(y - 1) * in_stride + x - 1] + in[(size_t)(y - 1) * in_stride + x] + in[(size_t)y * in_stride + x - 1] +
+                           in[(size_t)y * in_stride + x];
+        out[(size_t)oy * out_stride + ox] = (uint8_t)((s + 2) >> 2);
+    }
+}
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    return ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), m, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
+}
+
+// one wave per 64x64 SB; lane = 8x8 block in raster order; outputs [sb][85]: 64x64, 32x32 x4, 16x16 x16, 8x8 x64 (raster per level)
+__global__ void __launch_bounds__(64)
+variance_pyramid_kernel(const uint8_t* __restrict__ plane, int stride, int sb_cols, int full_precision, uint8_t* __restrict__ mean_out,
+                        uint16_t* __restrict__ var_out) {
+    const int sb = blockIdx.x, lane = threadIdx.x;
+    const int sx = (sb % sb_cols) * 64, sy = (sb / sb_cols) * 64;
+    const uint8_t* p = plane + (size_t)(sy + (lane >> 3) * 8) * stride + sx + (lane & 7) * 8;
+    uint32_t s = 0, s2 = 0;
+    for (int y = 0; y < 8; y += full_precision ? 1 : 2) {
+        const uint2 v = *(const uint2*)(p + (size_t)y * stride);   // SB-aligned + 8-aligned column: needs plane/stride 8-byte aligned
+        s = __builtin_amdgcn_udot4(v.x, 0x01010101u, s, false); s = __builtin_amdgcn_udot4(v.y, 0x01010101u, s, false);
+        s2 = __builtin_amdgcn_udot4(v.x, v.x, s2, false); s2 = __builtin_amdgcn_udot4(v.y, v.y, s2, false);
+    }
+    uint64_t m8 = full_precision ? ((uint64_t)s << 8) / 64 : (uint64_t)s << 3;
+    uint64_t q8 = full_precision ? ((uint64_t)s2 << 16) / 64 : (uint64_t)s2 << 11;
+    // raster lanes: 16x16 = lanes {l, l^1, l^8, l^9}; 32x32 adds {^2, ^16}; 64x64 adds {^4, ^32}
+    uint64_t t = m8 + shfl_xor64(m8, 1); const uint64_t m16 = (t + shfl_xor64(t, 8)) >> 2;
+    t = q8 + shfl_xor64(q8, 1);          const uint64_t q16 = (t + shfl_xor64(t, 8)) >> 2;
+    t = m16 + shfl_xor64(m16, 2);        const uint64_t m32 = (t + shfl_xor64(t, 16)) >> 2;
+    t = q16 + shfl_xor64(q16, 2);        const uint64_t q32 = (t + shfl_xor64(t, 16)) >> 2;
+    t = m32 + shfl_xor64(m32, 4);        const uint64_t m64 = (t + shfl_xor64(t, 32)) >> 2;
+    t = q32 + shfl_xor64(q32, 4);        const uint64_t q64 = (t + shfl_xor64(t, 32)) >> 2;
+    uint8_t* mo = mean_out + (size_t)sb * 85;
+    uint16_t* vo = var_out + (size_t)sb * 85;
+#define PUT(i, m, q) do { mo[i] = (uint8_t)((m) >> 8); vo[i] = (uint16_t)(((q) - (m) * (m)) >> 16); } while (0)
+    PUT(21 + lane, m8, q8);
+    const int bx = lane & 7, by = lane >> 3;
+    if (!(bx & 1) && !(by & 1)) PUT(5 + (by >> 1) * 4 + (bx >> 1), m16, q16);
+    if (!(bx & 3) && !(by & 3)) PUT(1 + (by >> 2) * 2 + (bx >> 2), m32, q32);
+    if (lane == 0) PUT(0, m64, q64);
+#undef PUT
+}
+
+// svt_sad_loop_kernel for a list of searches; one workgroup per search, candidates strided over threads in
+// raster order, per-thread strict '<' then a (sad, raster index) minimum over the workgroup.
+__global__ void __launch_bounds__(256)
+sad_loop_kernel(const uint8_t* __restrict__ src, int src_stride, const uint8_t* __restrict__ ref, int ref_stride,
+                const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
+    __shared__ uint8_t s_blk[64 * 64];
+    __shared__ unsigned long long s_best[4];
+    const SvtHipSadLoop d = searches[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int rstep = d.row_step;  // 1 = every row, 2 = every other row (hme "sub-SAD": strides doubled, height halved)
+    const int rows = d.bh / rstep;
+    for (int i = tid; i < rows * d.bw; i += 256) {
+        const int y = i / d.bw, x = i - y * d.bw;
+        s_blk[i] = src[(size_t)(d.src_y + y * rstep) * src_stride + d.src_x + x];
+    }
+    __syncthreads();
+    unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;  // initial best_sad 0xffffff (EbComputeSAD_C.c:73)
+    const int ncand = d.sa_w * d.sa_h;
+    for (int c = tid; c < ncand; c += 256) {
+        const int cy = c / d.sa_w, cx = c - cy * d.sa_w;
+        const uint8_t* r = ref + (size_t)(d.ref_y + cy) * ref_stride + d.ref_x + cx;
+        uint32_t sad = 0;
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < d.bw; x++) sad += (uint32_t)abs((int)s_blk[y * d.bw + x] - (int)r[(size_t)(y * rstep) * ref_stride + x]);
+        const unsigned long long key = ((unsigned long long)sad << 32) | (uint32_t)c;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = shfl_xor64(best, m); best = o < best ? o : best; }
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) best = s_best[w] < best ? s_best[w] : best;
+        const uint32_t sad = (uint32_t)(best >> 32), c = (uint32_t)best;
+        best_sad[blockIdx.x] = sad;
+        if (sad < 0xffffffu && c < (uint32_t)ncand) {   // a candidate beat the initial value: centers are written
+            best_xy[2 * blockIdx.x] = (int16_t)(c % d.sa_w);
+            best_xy[2 * blockIdx.x + 1] = (int16_t)(c / d.sa_w);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svt_hip_launch_downsample(hipStream_t st, const uint8_t* in, int in_stride, int w, int h, uint8_t* out, int out_stride, int step, int filtered) {
+    hipLaunchKernelGGL(downsample_kernel, dim3((w / step + 255) / 256, h / step), dim3(256), 0, st, in, in_stride, w, h, out, out_stride, step, filtered);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_variance_pyramid(hipStream_t st, const uint8_t* plane, int stride, int sb_cols, int n_sb, int full_precision,
+                                               uint8_t* mean_out, uint16_t* var_out) {
+    if (n_sb <= 0) return 0;
+    hipLaunchKernelGGL(variance_pyramid_kernel, dim3(n_sb), dim3(64), 0, st, plane, stride, sb_cols, full_precision, mean_out, var_out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int src_stride, const uint8_t* ref, int ref_stride,
+                                       const SvtHipSadLoop* searches, int n, uint32_t* best_sad, int16_t* best_xy) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sad_loop_kernel, dim3(n), dim3(256), 0, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
+    return (int)hipGetLastError();
+}

@@ -323,4 +323,30 @@ int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------- pyramids / HME search */
+int svt_hip_downsample_2d_dev(SvtHipCtx* c, const uint8_t* d_in, int in_stride, int w, int h, uint8_t* d_out, int out_stride, int step,
+                              int filtered) {
+    if (!c || !d_in || !d_out || (step != 2 && step != 4) || w < step || h < step) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_downsample(c->stream, d_in, in_stride, w, h, d_out, out_stride, step, filtered);
+    if (e != hipSuccess) return fail(c, e, "downsample launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_variance_pyramid_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, int sb_cols, int n_sb, int full_precision,
+                                 uint8_t* d_mean, uint16_t* d_var) {
+    if (!c || !d_plane || !d_mean || !d_var || sb_cols <= 0 || n_sb < 0 || (stride & 7) || ((uintptr_t)d_plane & 7)) {
+        if (c) c->err = "svt_hip_variance_pyramid_dev: bad argument (plane and stride must be 8-byte aligned)";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_variance_pyramid(c->stream, d_plane, stride, sb_cols, n_sb, full_precision, d_mean, d_var);
+    if (e != hipSuccess) return fail(c, e, "variance pyramid launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_sad_loop_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, const uint8_t* d_ref, int ref_stride,
+                               const SvtHipSadLoop* d_searches, int n, uint32_t* d_best_sad, int16_t* d_best_xy) {
+    if (!c || !d_src || !d_ref || !d_searches || !d_best_sad || !d_best_xy || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_sad_loop(c->stream, d_src, src_stride, d_ref, ref_stride, d_searches, n, d_best_sad, d_best_xy);
+    if (e != hipSuccess) return fail(c, e, "sad loop launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

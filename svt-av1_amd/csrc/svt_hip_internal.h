@@ -29,4 +29,9 @@ int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a
                              const SvtHipBlkPair* d, int n, uint32_t* out);
 int svt_hip_launch_block_variance(hipStream_t st, int pix_bytes, int bd, const void* a, int a_stride, const void* b, int b_stride,
                                   const SvtHipBlkPair* d, int n, uint32_t* var_out, uint32_t* sse_out);
+int svt_hip_launch_downsample(hipStream_t st, const uint8_t* in, int in_stride, int w, int h, uint8_t* out, int out_stride, int step, int filtered);
+int svt_hip_launch_variance_pyramid(hipStream_t st, const uint8_t* plane, int stride, int sb_cols, int n_sb, int full_precision,
+                                    uint8_t* mean_out, uint16_t* var_out);
+int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int src_stride, const uint8_t* ref, int ref_stride,
+                            const SvtHipSadLoop* searches, int n, uint32_t* best_sad, int16_t* best_xy);
 }

@@ -336,3 +336,43 @@ def test_upsampled_pred_and_variance(orc, ref):
                     v1 = f(C.c_void_p(a.ctypes.data >> 1), a.shape[1], C.c_void_p(b.ctypes.data >> 1), b.shape[1], C.byref(s1))   # CONVERT_TO_BYTEPTR
                     v2 = orc.orc_variance_hbd10(ptr(a), a.shape[1], ptr(b), b.shape[1], w, h, C.byref(s2))
                 assert (v1, s1.value) == (v2, s2.value), (w, h, bd, it)
+
+
+# -------------------------------------------------------------------------- pyramids (HME inputs)
+def test_downsample_and_mean_kernels(orc, ref):
+    """decimation_2d / downsample_2d and the 8x8 mean / mean-of-squares kernels behind the variance
+    pyramid (/root/reference/test/compute_mean_test.cc:83-165)."""
+    rng = np.random.default_rng(12)
+    for step in (2, 4):
+        for filt, name in ((0, "decimation_2d"), (1, "downsample_2d")):
+            img = rng.integers(0, 256, (72, 104), dtype=np.uint8)
+            a = np.zeros((72 // step, 104 // step + 3), np.uint8); b = a.copy()
+            getattr(ref, name)(ptr(img), 104, 96, 64, ptr(a), a.shape[1], step)
+            orc.orc_downsample_2d(ptr(img), 104, 96, 64, ptr(b), b.shape[1], step, filt)
+            assert np.array_equal(a, b), (name, step)
+    ref.svt_compute_sub_mean_8x8_c.restype = C.c_uint64
+    ref.svt_compute_mean_squared_values_c.restype = C.c_uint64
+    for it in range(50):
+        sb = rng.integers(0, 256, (64, 80), dtype=np.uint8)
+        if it == 0: sb[:] = 255
+        if it == 1: sb[:] = 0
+        for full in (0, 1):
+            mean = np.zeros(85, np.uint8); var = np.zeros(85, np.uint16)
+            orc.orc_variance_pyramid_sb(ptr(sb), 80, full, ptr(mean), ptr(var))
+            # 8x8 level against the reference's kernels (raster order)
+            for b in range(64):
+                p = C.c_void_p(sb.ctypes.data + (b >> 3) * 8 * 80 + (b & 7) * 8)
+                if full:
+                    blk = sb[(b >> 3) * 8:(b >> 3) * 8 + 8, (b & 7) * 8:(b & 7) * 8 + 8].astype(np.uint64)
+                    m = (int(blk.sum()) << 8) // 64
+                    q = ref.svt_compute_mean_squared_values_c(p, 80, 8, 8)
+                else:
+                    m = ref.svt_compute_sub_mean_8x8_c(p, C.c_uint16(80))
+                    mm = (C.c_uint64 * 4)(); qq = (C.c_uint64 * 4)()
+                    if (b & 3) == 0:
+                        ref.svt_compute_interm_var_four8x8_c(p, C.c_uint16(80), mm, qq)
+                        assert mm[0] == m
+                        q = qq[0]
+                    else:
+                        continue
+                assert mean[21 + b] == (m >> 8) & 0xFF and var[21 + b] == ((q - m * m) >> 16) & 0xFFFF, (it, full, b)
