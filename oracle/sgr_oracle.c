@@ -1,0 +1,173 @@
+/*
+ * sgr_oracle.c — CPU restatement of SVT-AV1's self-guided restoration (SGRPROJ): the two box filters,
+ * the projection sums / solve / error used by the search, and the final application.
+ * TEST INFRASTRUCTURE ONLY (see svt_oracle.h).  Citations: file:line under /root/reference/Source/Lib.
+ *
+ * The reference computes the (2r+1)^2 box sums with running-sum helpers over a 3-pixel-extended copy
+ * of the processing unit (Common/Codec/EbRestoration.c:541-705); only full windows are ever consumed,
+ * so here every A/B entry is simply summed over its window.
+ */
+#include "svt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* eb_sgr_params (EbRestoration.c:136-153): {r0, r1, s0, s1} */
+const int32_t orc_sgr_params[16][4] = {{2, 1, 140, 3236}, {2, 1, 112, 2158}, {2, 1, 93, 1618}, {2, 1, 80, 1438}, {2, 1, 70, 1295}, {2, 1, 58, 1177},
+                                       {2, 1, 47, 1079},  {2, 1, 37, 996},   {2, 1, 30, 925},  {2, 1, 25, 863},  {0, 1, -1, 2589}, {0, 1, -1, 1618},
+                                       {0, 1, -1, 1177},  {0, 1, -1, 925},   {2, 0, 56, -1},   {2, 0, 22, -1}};
+/* eb_x_by_xplus1 (EbRestoration.c:720-736): round(256 z / (z + 1)) with the two documented exceptions
+ * [0] = 1 and [255] = 256; eb_one_by_x (:738-741): round(4096 / n). */
+int32_t orc_x_by_xplus1(int z) { return z == 0 ? 1 : (z == 255 ? 256 : (256 * z + (z + 1) / 2) / (z + 1)); }
+int32_t orc_one_by_x(int n) { return (4096 + n / 2) / n; }
+
+static inline int rdp(const void *b, int pb, ptrdiff_t i) { return pb == 1 ? ((const uint8_t *)b)[i] : ((const uint16_t *)b)[i]; }
+static inline uint32_t rp2u(uint32_t v, int n) { return n == 0 ? v : ((v + (1u << (n - 1))) >> n); }
+
+/* A'/B' at position (i, j) of the unit: EbRestoration.c:787-858 (r = 2) / :926-985 (r = 1) */
+static void ab_at(const void *dgd, int pb, int stride, int i, int j, int r, uint32_t s, int bd, int32_t *A, int32_t *B) {
+    uint32_t sum = 0, sq = 0;
+    for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) { const uint32_t v = (uint32_t)rdp(dgd, pb, (ptrdiff_t)(i + dy) * stride + j + dx); sum += v; sq += v * v; }
+    const uint32_t n = (uint32_t)((2 * r + 1) * (2 * r + 1));
+    const uint32_t a = rp2u(sq, 2 * (bd - 8)), b = rp2u(sum, bd - 8);
+    const uint32_t p = (a * n < b * b) ? 0 : a * n - b * b;
+    const uint32_t z = rp2u(p * s, 20);
+    const int32_t Ak = orc_x_by_xplus1(z < 255 ? (int)z : 255);
+    *A = Ak;
+    *B = (int32_t)rp2u((uint32_t)(256 - Ak) * sum * (uint32_t)orc_one_by_x((int)n), 12);
+}
+
+/* svt_av1_selfguided_restoration_c (EbRestoration.c:1012-1045) on one processing unit (w, h <= 64;
+ * 3 valid samples around it in `dgd`).  flt0 / flt1 untouched when the corresponding radius is 0. */
+void orc_sgr_filter(const void *dgd, int pix_bytes, int w, int h, int stride, int32_t *flt0, int32_t *flt1, int flt_stride, int ep, int bd) {
+    const int32_t *prm = orc_sgr_params[ep];
+    int32_t *A = (int32_t *)malloc(sizeof(int32_t) * 2 * 66 * 66), *B = A + 66 * 66;
+#define AT(M, i, j) M[((i) + 1) * 66 + (j) + 1]
+    if (prm[0] > 0) { /* selfguided_restoration_fast_internal, r = 2: A/B on rows -1, 1, 3, ... */
+        for (int i = -1; i < h + 1; i += 2)
+            for (int j = -1; j < w + 1; j++) ab_at(dgd, pix_bytes, stride, i, j, 2, (uint32_t)prm[2], bd, &AT(A, i, j), &AT(B, i, j));
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int32_t a, b, nb;
+                if (!(i & 1)) {
+                    nb = 5;
+                    a = (AT(A, i - 1, j) + AT(A, i + 1, j)) * 6 + (AT(A, i - 1, j - 1) + AT(A, i + 1, j - 1) + AT(A, i - 1, j + 1) + AT(A, i + 1, j + 1)) * 5;
+                    b = (AT(B, i - 1, j) + AT(B, i + 1, j)) * 6 + (AT(B, i - 1, j - 1) + AT(B, i + 1, j - 1) + AT(B, i - 1, j + 1) + AT(B, i + 1, j + 1)) * 5;
+                } else {
+                    nb = 4;
+                    a = AT(A, i, j) * 6 + (AT(A, i, j - 1) + AT(A, i, j + 1)) * 5;
+                    b = AT(B, i, j) * 6 + (AT(B, i, j - 1) + AT(B, i, j + 1)) * 5;
+                }
+                const int32_t v = a * rdp(dgd, pix_bytes, (ptrdiff_t)i * stride + j) + b;
+                flt0[i * flt_stride + j] = (v + (1 << (8 + nb - 4 - 1))) >> (8 + nb - 4);
+            }
+    }
+    if (prm[1] > 0) { /* selfguided_restoration_internal, r = 1 */
+        for (int i = -1; i < h + 1; i++)
+            for (int j = -1; j < w + 1; j++) ab_at(dgd, pix_bytes, stride, i, j, 1, (uint32_t)prm[3], bd, &AT(A, i, j), &AT(B, i, j));
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                const int32_t a = (AT(A, i, j) + AT(A, i, j - 1) + AT(A, i, j + 1) + AT(A, i - 1, j) + AT(A, i + 1, j)) * 4 +
+                                  (AT(A, i - 1, j - 1) + AT(A, i + 1, j - 1) + AT(A, i - 1, j + 1) + AT(A, i + 1, j + 1)) * 3;
+                const int32_t b = (AT(B, i, j) + AT(B, i, j - 1) + AT(B, i, j + 1) + AT(B, i - 1, j) + AT(B, i + 1, j)) * 4 +
+                                  (AT(B, i - 1, j - 1) + AT(B, i + 1, j - 1) + AT(B, i - 1, j + 1) + AT(B, i + 1, j + 1)) * 3;
+                const int32_t v = a * rdp(dgd, pix_bytes, (ptrdiff_t)i * stride + j) + b;
+                flt1[i * flt_stride + j] = (v + (1 << (8 + 5 - 4 - 1))) >> (8 + 5 - 4);
+            }
+    }
+#undef AT
+    free(A);
+}
+
+/* svt_decode_xq (EbRestoration.c:707-718) */
+void orc_sgr_decode_xq(const int32_t *xqd, int32_t *xq, int ep) {
+    const int32_t *prm = orc_sgr_params[ep];
+    if (prm[0] == 0) { xq[0] = 0; xq[1] = 128 - xqd[1]; }
+    else if (prm[1] == 0) { xq[0] = xqd[0]; xq[1] = 0; }
+    else { xq[0] = xqd[0]; xq[1] = 128 - xq[0] - xqd[1]; }
+}
+
+/* svt_apply_selfguided_restoration_c (EbRestoration.c:1047-1084) on a unit of any size, walked in
+ * 64x64 processing units like sgrproj_filter_stripe (:1086-1132) does. */
+void orc_sgr_apply(const void *dat, int pix_bytes, int w, int h, int stride, int ep, const int32_t *xqd, void *dst, int dst_stride, int bd) {
+    const int32_t *prm = orc_sgr_params[ep];
+    int32_t xq[2];
+    orc_sgr_decode_xq(xqd, xq, ep);
+    int32_t *f0 = (int32_t *)malloc(sizeof(int32_t) * 2 * 64 * 64), *f1 = f0 + 64 * 64;
+    for (int y0 = 0; y0 < h; y0 += 64)
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            const int pw = w - x0 < 64 ? w - x0 : 64, ph = h - y0 < 64 ? h - y0 : 64;
+            const uint8_t *d = (const uint8_t *)dat + ((size_t)y0 * stride + x0) * pix_bytes;
+            orc_sgr_filter(d, pix_bytes, pw, ph, stride, f0, f1, 64, ep, bd);
+            for (int i = 0; i < ph; i++)
+                for (int j = 0; j < pw; j++) {
+                    const int32_t u = rdp(d, pix_bytes, (ptrdiff_t)i * stride + j) << 4;
+                    int32_t v = u << 7;
+                    if (prm[0] > 0) v += xq[0] * (f0[i * 64 + j] - u);
+                    if (prm[1] > 0) v += xq[1] * (f1[i * 64 + j] - u);
+                    const int16_t wv = (int16_t)((v + (1 << 10)) >> 11);
+                    const int mx = (1 << bd) - 1, o = wv < 0 ? 0 : (wv > mx ? mx : wv);
+                    if (pix_bytes == 1) ((uint8_t *)dst)[(size_t)(y0 + i) * dst_stride + x0 + j] = (uint8_t)o;
+                    else ((uint16_t *)dst)[(size_t)(y0 + i) * dst_stride + x0 + j] = (uint16_t)o;
+                }
+        }
+    free(f0);
+}
+
+/* The five sums svt_get_proj_subspace_c accumulates (Encoder/Codec/EbRestorationPick.c:448-496) as exact
+ * integers: sums[0..4] = H00, H01, H11, C0, C1 (before the division by the pixel count). */
+void orc_sgr_proj_sums(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                       int f0_stride, const int32_t *flt1, int f1_stride, int ep, int64_t sums[5]) {
+    const int32_t *prm = orc_sgr_params[ep];
+    memset(sums, 0, sizeof(int64_t) * 5);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const int64_t u = rdp(dat, pix_bytes, (ptrdiff_t)i * dat_stride + j) << 4;
+            const int64_t s = (rdp(src, pix_bytes, (ptrdiff_t)i * src_stride + j) << 4) - u;
+            const int64_t f1 = prm[0] > 0 ? flt0[i * f0_stride + j] - u : 0, f2 = prm[1] > 0 ? flt1[i * f1_stride + j] - u : 0;
+            sums[0] += f1 * f1; sums[1] += f1 * f2; sums[2] += f2 * f2; sums[3] += f1 * s; sums[4] += f2 * s;
+        }
+}
+/* the FP64 solve of svt_get_proj_subspace_c (:497-538) from the integer sums */
+void orc_sgr_solve(const int64_t sums[5], int size, int ep, int32_t xq[2]) {
+    const int32_t *prm = orc_sgr_params[ep];
+    double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    H00 /= size; H01 /= size; H11 /= size; C0 /= size; C1 /= size;
+    const double H10 = H01;
+    xq[0] = xq[1] = 0;
+    if (prm[0] == 0) {
+        if (H11 < 1e-8) return;
+        xq[1] = (int32_t)rint((C1 / H11) * 128);
+    } else if (prm[1] == 0) {
+        if (H00 < 1e-8) return;
+        xq[0] = (int32_t)rint((C0 / H00) * 128);
+    } else {
+        const double det = H00 * H11 - H01 * H10;
+        if (det < 1e-8) return;
+        const double x0 = (H11 * C0 - H01 * C1) / det, x1 = (H00 * C1 - H10 * C0) / det;
+        xq[0] = (int32_t)rint(x0 * 128);
+        xq[1] = (int32_t)rint(x1 * 128);
+    }
+}
+/* svt_av1_{lowbd,highbd}_pixel_proj_error_c (EbRestorationPick.c:174-316) */
+int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                           int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep) {
+    const int32_t *prm = orc_sgr_params[ep];
+    int64_t err = 0;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const int32_t d = rdp(dat, pix_bytes, (ptrdiff_t)i * dat_stride + j), s = rdp(src, pix_bytes, (ptrdiff_t)i * src_stride + j);
+            int32_t e;
+            if (prm[0] <= 0 && prm[1] <= 0) e = d - s;
+            else {
+                const int32_t u = d << 4;
+                int32_t v = u << 7;
+                if (prm[0] > 0) v += xq[0] * (flt0[i * f0_stride + j] - u);
+                if (prm[1] > 0) v += xq[1] * (flt1[i * f1_stride + j] - u);
+                e = ((v + (1 << 10)) >> 11) - s;
+            }
+            err += (int64_t)e * e;
+        }
+    return err;
+}

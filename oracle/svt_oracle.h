@@ -139,6 +139,19 @@ uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, 
 void orc_downsample_2d(const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered);
 void orc_variance_pyramid_sb(const uint8_t *sb, int stride, int full_precision, uint8_t mean_out[85], uint16_t var_out[85]);
 
+/* ---------------------------------------------------------------- self-guided restoration (sgr_oracle.c) */
+extern const int32_t orc_sgr_params[16][4];
+int32_t orc_x_by_xplus1(int z);
+int32_t orc_one_by_x(int n);
+void orc_sgr_filter(const void *dgd, int pix_bytes, int w, int h, int stride, int32_t *flt0, int32_t *flt1, int flt_stride, int ep, int bd);
+void orc_sgr_decode_xq(const int32_t *xqd, int32_t *xq, int ep);
+void orc_sgr_apply(const void *dat, int pix_bytes, int w, int h, int stride, int ep, const int32_t *xqd, void *dst, int dst_stride, int bd);
+void orc_sgr_proj_sums(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                       int f0_stride, const int32_t *flt1, int f1_stride, int ep, int64_t sums[5]);
+void orc_sgr_solve(const int64_t sums[5], int size, int ep, int32_t xq[2]);
+int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                           int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep);
+
 #ifdef __cplusplus
 }
 #endif

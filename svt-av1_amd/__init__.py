@@ -104,6 +104,9 @@ def lib():
     L.svt_hip_downsample_2d_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32]
     L.svt_hip_variance_pyramid_dev.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.svt_hip_sad_loop_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp]
+    L.svt_hip_sgr_filter_plane_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32]
+    L.svt_hip_sgr_search_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, C.c_uint32, vp]
+    L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]
     P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp]

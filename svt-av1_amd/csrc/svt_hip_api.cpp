@@ -349,4 +349,35 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_strid
     return SVT_HIP_OK;
 }
 
+/* ---------------------------------------------------------------- self-guided restoration */
+static bool sgr_args_ok(int pix_bytes, int bd, int pw, int ph) {
+    return (pix_bytes == 1 || pix_bytes == 2) && (bd == 8 || bd == 10) && !(pix_bytes == 1 && bd != 8) && pw > 0 && ph > 0;
+}
+static int sgr_units(int size, int unit) { const int n = (size + unit / 2) / unit; return n > 0 ? n : 1; }
+
+int svt_hip_sgr_filter_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_plane, int stride, int pw, int ph, int ep,
+                                 int32_t* d_flt0, int32_t* d_flt1, int flt_stride) {
+    if (!c || !d_plane || !d_flt0 || !d_flt1 || ep < 0 || ep > 15 || !sgr_args_ok(pix_bytes, bd, pw, ph)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_filter(c->stream, pix_bytes, bd, d_plane, stride, pw, ph, ep, d_flt0, d_flt1, flt_stride);
+    if (e != hipSuccess) return fail(c, e, "sgr filter launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_sgr_search_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
+                                 int pw, int ph, int unit_size, uint32_t ep_mask, int64_t* d_sums) {
+    if (!c || !d_dgd || !d_src || !d_sums || unit_size < 64 || (unit_size & 63) || !sgr_args_ok(pix_bytes, bd, pw, ph)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_search(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size,
+                                                        sgr_units(pw, unit_size), sgr_units(ph, unit_size), ep_mask & 0xFFFFu, d_sums);
+    if (e != hipSuccess) return fail(c, e, "sgr search launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_sgr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw,
+                                int ph, int unit_size, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd) {
+    if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || unit_size < 64 || (unit_size & 63) || !sgr_args_ok(pix_bytes, bd, pw, ph))
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_apply(c->stream, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size,
+                                                       sgr_units(pw, unit_size), sgr_units(ph, unit_size), d_unit_ep, d_unit_xqd);
+    if (e != hipSuccess) return fail(c, e, "sgr apply launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

@@ -34,4 +34,10 @@ int svt_hip_launch_variance_pyramid(hipStream_t st, const uint8_t* plane, int st
                                     uint8_t* mean_out, uint16_t* var_out);
 int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int src_stride, const uint8_t* ref, int ref_stride,
                             const SvtHipSadLoop* searches, int n, uint32_t* best_sad, int16_t* best_xy);
+int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, const void* plane, int stride, int pw, int ph, int ep, int32_t* flt0,
+                              int32_t* flt1, int flt_stride);
+int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
+                              int ph, int unit_size, int units_x, int units_y, uint32_t ep_mask, int64_t* sums);
+int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph,
+                             int unit_size, int units_x, int units_y, const uint8_t* unit_ep, const int32_t* unit_xqd);
 }

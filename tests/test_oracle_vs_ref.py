@@ -376,3 +376,58 @@ def test_downsample_and_mean_kernels(orc, ref):
                     else:
                         continue
                 assert mean[21 + b] == (m >> 8) & 0xFF and var[21 + b] == ((q - m * m) >> 16) & 0xFFFF, (it, full, b)
+
+
+# ------------------------------------------------------------------------ self-guided restoration
+class _SgrP(C.Structure):
+    _fields_ = [("r", C.c_int32 * 2), ("s", C.c_int32 * 2)]
+
+
+def test_sgr_tables_filter_apply_and_projection(orc, ref):
+    """Tables, the two box filters for all 16 parameter sets (lbd/hbd), apply, projection sums/solve and
+    projection error (/root/reference/test/selfguided_filter_test.cc:248-562, RestorationPickTest.cc)."""
+    prm = np.ctypeslib.as_array((C.c_int32 * 4 * 16).in_dll(orc, "orc_sgr_params"))
+    rp = np.ctypeslib.as_array((C.c_int32 * 4 * 16).in_dll(ref, "eb_sgr_params"))      # {r[2], s[2]}
+    assert np.array_equal(prm, rp)
+    xt = np.ctypeslib.as_array((C.c_int32 * 256).in_dll(ref, "eb_x_by_xplus1")); ot = np.ctypeslib.as_array((C.c_int32 * 25).in_dll(ref, "eb_one_by_x"))
+    assert [orc.orc_x_by_xplus1(z) for z in range(256)] == list(xt) and [orc.orc_one_by_x(n) for n in range(1, 26)] == list(ot)
+    rng = np.random.default_rng(21)
+    orc.orc_sgr_proj_error.restype = C.c_int64
+    ref.svt_av1_lowbd_pixel_proj_error_c.restype = C.c_int64; ref.svt_av1_highbd_pixel_proj_error_c.restype = C.c_int64
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        hb = int(bd > 8)
+        for it in range(24):
+            ep = it % 16
+            w, h = int(rng.choice([64, 40, 8, 64])), int(rng.choice([64, 56, 24, 8]))
+            mode = it % 3
+            base = rng.integers(0, 1 << bd, (h + 6, w + 10)) if mode == 0 else (np.full((h + 6, w + 10), (1 << bd) - 1) if mode == 1 else
+                                                                                 (400 >> (10 - bd)) + rng.integers(-3, 4, (h + 6, w + 10)))
+            dgd = np.clip(base, 0, (1 << bd) - 1).astype(dt)
+            src = np.clip(dgd.astype(np.int32) + rng.integers(-12, 13, dgd.shape), 0, (1 << bd) - 1).astype(dt)
+            st = dgd.shape[1]
+            off = (3 * st + 3) * dgd.itemsize
+            pd, ps = dgd.ctypes.data + off, src.ctypes.data + off
+            cvt = (lambda a: C.c_void_p(a >> 1)) if hb else (lambda a: C.c_void_p(a))   # CONVERT_TO_BYTEPTR
+            a0 = np.full((h, w), -7, np.int32); a1 = a0.copy(); b0 = a0.copy(); b1 = a0.copy()
+            ref.svt_av1_selfguided_restoration_c(cvt(pd), w, h, st, ptr(a0), ptr(a1), w, ep, bd, hb)
+            orc.orc_sgr_filter(C.c_void_p(pd), dgd.itemsize, w, h, st, ptr(b0), ptr(b1), w, ep, bd)
+            assert np.array_equal(a0, b0) and np.array_equal(a1, b1), (bd, ep, it)
+            # projection: sums -> solve vs svt_get_proj_subspace_c, then the projection error
+            sp = _SgrP(); sp.r[0], sp.r[1], sp.s[0], sp.s[1] = [int(v) for v in prm[ep]]
+            xq1 = (C.c_int32 * 2)(); xq2 = (C.c_int32 * 2)(); sums = (C.c_int64 * 5)()
+            ref.svt_get_proj_subspace_c(cvt(ps), w, h, st, cvt(pd), st, hb, ptr(a0), w, ptr(a1), w, xq1, C.byref(sp))
+            orc.orc_sgr_proj_sums(C.c_void_p(ps), st, C.c_void_p(pd), st, dgd.itemsize, w, h, ptr(b0), w, ptr(b1), w, ep, sums)
+            orc.orc_sgr_solve(sums, w * h, ep, xq2)
+            assert list(xq1) == list(xq2), (bd, ep, list(xq1), list(xq2))
+            xq = (C.c_int32 * 2)(int(rng.integers(-96, 32)), int(rng.integers(-32, 96)))
+            f = ref.svt_av1_highbd_pixel_proj_error_c if hb else ref.svt_av1_lowbd_pixel_proj_error_c
+            e1 = f(cvt(ps), w, h, st, cvt(pd), st, ptr(a0), w, ptr(a1), w, xq, C.byref(sp))
+            e2 = orc.orc_sgr_proj_error(C.c_void_p(ps), st, C.c_void_p(pd), st, dgd.itemsize, w, h, ptr(b0), w, ptr(b1), w, xq, ep)
+            assert e1 == e2
+            # apply
+            xqd = (C.c_int32 * 2)(int(rng.integers(-96, 32)), int(rng.integers(-32, 96)))
+            o1 = np.zeros((h, w), dt); o2 = np.zeros((h, w), dt)
+            tmp = np.zeros(2 * 161 * 161 * 4 + 64, np.int32)
+            ref.svt_apply_selfguided_restoration_c(cvt(pd), w, h, st, ep, xqd, cvt(o1.ctypes.data), w, ptr(tmp), bd, hb)
+            orc.orc_sgr_apply(C.c_void_p(pd), dgd.itemsize, w, h, st, ep, xqd, ptr(o2), w, bd)
+            assert np.array_equal(o1, o2), (bd, ep, "apply")
