@@ -4,9 +4,10 @@
 One "step" = one pass of every implemented kernel class of the hot path over ONE synthetic
 4K (3840x2160) 8-bit 4:2:0 frame = 2040 superblocks, inputs resident in
 HBM before the timed region:
-    integer ME (85 PUs, 64x64 search area, 1 ref)  ->  residual + fwd txfm + quantize (all planes,
-    per-SB square tiling 4..64)  ->  inverse txfm + recon  ->  deblock (3 planes, V then H)  ->
-    CDEF strength search (64 strengths, 3 planes)  ->  CDEF apply.
+    HME pyramids + variance pyramid -> HME L0/L1/L2 -> integer ME (85 PUs, 64x64 search area, 1 ref) ->
+    sub-pel convolve (every 16x16 luma block) -> residual + fwd txfm + quantize (all planes, per-SB
+    square tiling 4..64) -> inverse txfm + recon -> deblock (3 planes, V then H) -> CDEF strength
+    search (64 strengths, 3 planes) -> CDEF apply -> SGR search (16 parameter sets, 3 planes) -> SGR apply.
 `value` = superblocks per second over the whole job (all ranks).
 
 Multi-GPU: frames/streams are independent, so rank i processes its own frame on
@@ -41,6 +42,11 @@ BYTES_PER_SB = {
     "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
     "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
     "cdef_apply": 12288,                     # 6144 R + 6144 W
+    "pyramids": 5376 + 4351,                 # decimation 4096 R + 1024 + 256 W ; variance pyramid 4096 R + 85*3 W
+    "hme_l0_l1_l2": 256 + 1024 + 4096 + 3 * 12,   # source blocks of the three levels + results (windows are cache-resident)
+    "subpel_convolve": 12560,                # 16 blocks x (16+7)^2 R + 4096 W (luma)
+    "sgr_search": 12288 + 640,               # dgd 6144 + source 6144 R + sums
+    "sgr_apply": 12288,                      # 6144 R + 6144 W
 }
 
 
@@ -52,7 +58,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stages", default="all", help="comma list (debug): me,txfm,inv,dlf,cdef_search,cdef_apply")
+    ap.add_argument("--stages", default="all", help="comma list (debug): pyr,hme,me,subpel,txfm,inv,dlf,cdef_search,cdef_apply,sgr_search,sgr_apply")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +132,49 @@ def main():
     d_dir = torch.zeros(n_sb * 64, dtype=torch.uint8, device=dev)
     d_var = torch.zeros(n_sb * 64, dtype=torch.int32, device=dev)
     d_cy, d_cuv = T(F.cdef_y), T(F.cdef_uv)
+    # pyramids / HME: 1/4 and 1/16 resolution source + reference, variance pyramid
+    PADQ, PADS = 32, 16
+    qw, qh, sw_, sh_ = W // 2, H // 2, W // 4, H // 4
+    d_cur_q = torch.zeros((qh + 2 * PADQ, qw + 2 * PADQ), dtype=torch.uint8, device=dev); d_ref_q = torch.zeros_like(d_cur_q)
+    d_cur_s = torch.zeros((sh_ + 2 * PADS, sw_ + 2 * PADS), dtype=torch.uint8, device=dev); d_ref_s = torch.zeros_like(d_cur_s)
+    d_ymean = torch.zeros((n_sb, 85), dtype=torch.uint8, device=dev); d_yvar = torch.zeros((n_sb, 85), dtype=torch.int16, device=dev)
+    # aligned copy of the current luma for the variance pyramid (needs an 8-byte aligned origin/stride and 64 px of slack)
+    vp = np.zeros((F.sb_rows * 64 + 64, F.sb_cols * 64 + 64), np.uint8); vp[:H, :W] = F.cur[0]
+    d_vp = T(vp)
+    hme = []
+    for lvl, (bsz, saw, sah) in enumerate(((16, 64, 32), (32, 16, 16), (64, 16, 16))):
+        S = (pkg.SadLoop * n_sb)()
+        sc = (4, 2, 1)[lvl]
+        pad = (PADS, PADQ, PAD)[lvl]
+        for i in range(n_sb):
+            sx, sy = (i % F.sb_cols) * 64 // sc, (i // F.sb_cols) * 64 // sc
+            pw_, ph_ = W // sc, H // sc
+            x0 = min(max(sx - saw // 2, -pad + 1), pw_ - 1); y0 = min(max(sy - sah // 2, -pad + 1), ph_ - 1)
+            S[i] = pkg.SadLoop(sx + pad, sy + pad, x0 + pad, y0 + pad, bsz, bsz, min(saw, pw_ + pad - 1 - bsz - x0), min(sah, ph_ + pad - 1 - bsz - y0), 1, 0)
+        hme.append(dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(n_sb, dtype=torch.int32, device=dev),
+                        xy=torch.zeros((n_sb, 2), dtype=torch.int16, device=dev)))
+    # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into a prediction plane
+    rng = np.random.default_rng(14 + rank)
+    nblk16 = (W // 16) * (H // 16)
+    CB = (pkg.ConvBlk * nblk16)()
+    k = 0
+    for by in range(0, H, 16):
+        for bx in range(0, W, 16):
+            if bx + 16 <= W and by + 16 <= H:
+                CB[k] = pkg.ConvBlk(bx + int(rng.integers(-8, 9)), by + int(rng.integers(-8, 9)), bx, by, 16, 16, 0, 0, int(rng.integers(0, 16)), int(rng.integers(0, 16)), 0, 0)
+                k += 1
+    nblk16 = k
+    d_cb = T(np.frombuffer(bytes(CB), np.uint8)[:k * C.sizeof(pkg.ConvBlk)].copy())
+    d_subpel = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+    # SGR: 3-px extended copies of the CDEF output, projection sums for all 16 sets, apply with fixed per-unit sets
+    EXT = 3
+    d_ext = [torch.zeros((p.shape[0] + 2 * EXT, p.shape[1] + 2 * EXT + ((-(p.shape[1] + 2 * EXT)) % 4), ), dtype=torch.uint8, device=dev) for p in d_pred]
+    US = [64, 64, 64]   # restoration unit size per plane in plane samples (64 luma = one unit per SB)
+    n_units = [max((F.cur[p].shape[1] + US[p] // 2) // US[p], 1) * max((F.cur[p].shape[0] + US[p] // 2) // US[p], 1) for p in range(3)]
+    d_sgr_sums = [torch.zeros((n_units[p], 16, 5), dtype=torch.int64, device=dev) for p in range(3)]
+    d_unit_ep = [T(rng.integers(0, 16, n_units[p]).astype(np.uint8)) for p in range(3)]
+    d_unit_xqd = [T(np.stack([rng.integers(-96, 32, n_units[p]), rng.integers(-32, 96, n_units[p])], 1).astype(np.int32)) for p in range(3)]
+    d_sgr_out = [torch.zeros_like(p) for p in d_pred]
 
     # ---------------------------------------------------------------- the kernel classes of a step
     def run_me():
@@ -162,13 +211,58 @@ def main():
                                                  I3(*strides), W, H, d_skip8.data_ptr(), d_cy.data_ptr(), d_cuv.data_ptr(), F.cdef_damping, 8,
                                                  d_dir.data_ptr()), "cdef apply")
 
+    def run_pyramids():
+        for src_p, q, s_ in ((d_cur_p, d_cur_q, d_cur_s), (d_ref_p, d_ref_q, d_ref_s)):
+            org = src_p.data_ptr() + PAD * F.cur_y_p.shape[1] + PAD
+            ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, q.data_ptr() + PADQ * q.shape[1] + PADQ, q.shape[1], 2, 1), "ds2")
+            ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, s_.data_ptr() + PADS * s_.shape[1] + PADS, s_.shape[1], 4, 1), "ds4")
+        ctx.check(L.svt_hip_variance_pyramid_dev(ctx.h, d_vp.data_ptr(), d_vp.shape[1], F.sb_cols, n_sb, 0, d_ymean.data_ptr(), d_yvar.data_ptr()), "varpyr")
+
+    def run_hme():
+        for lvl, (cur_t, ref_t) in enumerate(((d_cur_s, d_ref_s), (d_cur_q, d_ref_q), (d_cur_p, d_ref_p))):
+            j = hme[lvl]
+            ctx.check(L.svt_hip_sad_loop_batch_dev(ctx.h, cur_t.data_ptr(), cur_t.shape[1], ref_t.data_ptr(), ref_t.shape[1], j["S"].data_ptr(), n_sb,
+                                                   j["sad"].data_ptr(), j["xy"].data_ptr()), "hme")
+
+    def run_subpel():
+        ctx.check(L.svt_hip_subpel_predict_batch_dev(ctx.h, 1, 8, d_ref_p.data_ptr() + PAD * F.ref_y_p.shape[1] + PAD, F.ref_y_p.shape[1],
+                                                     d_subpel.data_ptr(), W, d_cb.data_ptr(), nblk16), "subpel")
+
+    def sgr_extend():
+        # svt_extend_frame equivalent (device-to-device, torch slicing = plumbing): 3-px edge replication of the CDEF output
+        for p in range(3):
+            h_, w_ = d_cdef_out[p].shape
+            e = d_ext[p]
+            e[EXT:EXT + h_, EXT:EXT + w_] = d_cdef_out[p]
+            e[EXT:EXT + h_, :EXT] = d_cdef_out[p][:, :1]; e[EXT:EXT + h_, EXT + w_:EXT + w_ + EXT] = d_cdef_out[p][:, -1:]
+            e[:EXT, :] = e[EXT:EXT + 1, :]; e[EXT + h_:EXT + h_ + EXT, :] = e[EXT + h_ - 1:EXT + h_, :]
+
+    def run_sgr_search():
+        sgr_extend()
+        for p in range(3):
+            d_sgr_sums[p].zero_()
+            h_, w_ = d_cdef_out[p].shape
+            ctx.check(L.svt_hip_sgr_search_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_cur[p].data_ptr(),
+                                                     strides[p], w_, h_, US[p], 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
+
+    def run_sgr_apply():
+        for p in range(3):
+            h_, w_ = d_cdef_out[p].shape
+            ctx.check(L.svt_hip_sgr_apply_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_sgr_out[p].data_ptr(),
+                                                    strides[p], w_, h_, US[p], d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
+
     all_stages = [
+        dict(key="pyr", name="pyramids", run=run_pyramids, kernel="downsample_kernel+variance_pyramid_kernel"),
+        dict(key="hme", name="hme_l0_l1_l2", run=run_hme, kernel="sad_loop_kernel"),
         dict(key="me", name="me_fullpel_85pu", run=run_me, kernel="me_fullpel_85pu_kernel"),
+        dict(key="subpel", name="subpel_convolve", run=run_subpel, kernel="subpel_predict_kernel"),
         dict(key="txfm", name="fwd_txfm_quant", run=run_txfm, kernel="fwd_txfm_quant_kernel"),
         dict(key="inv", name="inv_txfm_recon", run=run_inv, kernel="inv_txfm_add_kernel"),
         dict(key="dlf", name="deblock", run=run_dlf, kernel="deblock_pass_kernel"),
         dict(key="cdef_search", name="cdef_search", run=run_cdef_search, kernel="cdef_search_luma_kernel"),
         dict(key="cdef_apply", name="cdef_apply", run=run_cdef_apply, kernel="cdef_apply_kernel"),
+        dict(key="sgr_search", name="sgr_search", run=run_sgr_search, kernel="sgr_search_kernel"),
+        dict(key="sgr_apply", name="sgr_apply", run=run_sgr_apply, kernel="sgr_apply_kernel"),
     ]
     want = None if args.stages == "all" else set(args.stages.split(","))
     stages = [s for s in all_stages if want is None or s["key"] in want]
@@ -232,8 +326,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
-                               + "; ME 1 ref 64x64 search area; square tx tiling 4..64 per SB, quantize_b qindex 60; "
-                                 "deblock levels (20,20,12,12); CDEF full 64-strength search",
+                               + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16; square tx tiling "
+                                 "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets",
                    "stages_ms": per_stage, "parity_spot_check": parity_ok},
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
