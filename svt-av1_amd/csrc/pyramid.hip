@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
+#include "lds_stage.h"
 
 namespace {
 
@@ -63,32 +64,100 @@ variance_pyramid_kernel(const uint8_t* __restrict__ plane, int stride, int sb_co
 #undef PUT
 }
 
-// svt_sad_loop_kernel for a list of searches; one workgroup per search, candidates strided over threads in
-// raster order, per-thread strict '<' then a (sad, raster index) minimum over the workgroup.
+// svt_sad_loop_kernel for a list of searches; one workgroup per search.
+// Fast path (block width 16 / 32 / 64, plane strides multiples of 4): the same v_qsad_pk_u16_u8 scheme as the
+// integer ME kernel — source block and reference window staged in LDS with the byte misalignment removed, a
+// lane owns 8 adjacent candidates of one candidate row, packed u16 partial SADs are flushed into 32-bit sums
+// every 256/BW rows (before they can overflow), running (sad << 32 | raster index) key per lane.
+// Other widths (partial SBs at the picture edge) take the generic byte-wise path.
+constexpr int kHmeRefStrideDw = 48, kHmeRefRowDw = 36, kHmeSrcStrideDw = 16;
+
+template <int BW>
+__device__ __forceinline__ void sad_loop_fast(const SvtHipSadLoop& d, const uint8_t* __restrict__ src, int src_stride,
+                                              const uint8_t* __restrict__ ref, int ref_stride, uint32_t* lds_src, uint32_t* lds_ref, int tid,
+                                              unsigned long long& best) {
+    constexpr int SEGS = BW / 8, FLUSH = 256 / BW;
+    const int rstep = d.row_step, rows = d.bh / rstep;
+    stage_rows(lds_src, kHmeSrcStrideDw, src + (size_t)d.src_y * src_stride + d.src_x, src_stride * rstep, rows, BW / 4, BW, tid, 256);
+    for (int ty = 0; ty < d.sa_h; ty += 64) {
+        const int th = min(64, d.sa_h - ty);
+        for (int tx = 0; tx < d.sa_w; tx += 64) {
+            const int tw = min(64, d.sa_w - tx), ng = (tw + 7) >> 3;
+            __syncthreads();
+            stage_rows(lds_ref, kHmeRefStrideDw, ref + (size_t)(d.ref_y + ty) * ref_stride + d.ref_x + tx, ref_stride, th + (rows - 1) * rstep,
+                       kHmeRefRowDw, tw + BW - 1, tid, 256);
+            __syncthreads();
+            for (int u = tid; u < th * ng; u += 256) {
+                const int y = u / ng, g = u - y * ng;
+                uint32_t acc32[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc32[c] = 0;
+                for (int r0 = 0; r0 < rows; r0 += FLUSH) {
+                    uint64_t a0 = 0, a1 = 0;
+                    const int r1 = min(rows, r0 + FLUSH);
+                    for (int r = r0; r < r1; r++) {
+                        const uint32_t* rp = lds_ref + (y + r * rstep) * kHmeRefStrideDw + 2 * g;
+                        const uint32_t* sp = lds_src + r * kHmeSrcStrideDw;
+                        uint64_t ev[SEGS + 1], od[SEGS];
+#pragma unroll
+                        for (int k = 0; k <= SEGS; k++) ev[k] = *(const uint64_t*)(rp + 2 * k);
+#pragma unroll
+                        for (int k = 0; k < SEGS; k++) { Dw2 t = *(const Dw2*)(rp + 2 * k + 1); od[k] = pack64(t.x, t.y); }
+#pragma unroll
+                        for (int k = 0; k < SEGS; k++) {
+                            const uint32_t s0 = sp[2 * k], s1 = sp[2 * k + 1];
+                            a0 = __builtin_amdgcn_qsad_pk_u16_u8(ev[k], s0, a0);
+                            a0 = __builtin_amdgcn_qsad_pk_u16_u8(od[k], s1, a0);
+                            a1 = __builtin_amdgcn_qsad_pk_u16_u8(od[k], s0, a1);
+                            a1 = __builtin_amdgcn_qsad_pk_u16_u8(ev[k + 1], s1, a1);
+                        }
+                    }
+                    acc32[0] += (uint32_t)a0 & 0xFFFFu; acc32[1] += ((uint32_t)a0) >> 16; acc32[2] += (uint32_t)(a0 >> 32) & 0xFFFFu; acc32[3] += (uint32_t)(a0 >> 48);
+                    acc32[4] += (uint32_t)a1 & 0xFFFFu; acc32[5] += ((uint32_t)a1) >> 16; acc32[6] += (uint32_t)(a1 >> 32) & 0xFFFFu; acc32[7] += (uint32_t)(a1 >> 48);
+                }
+                const uint32_t idx0 = (uint32_t)((ty + y) * d.sa_w + tx + 8 * g);
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (8 * g + c < tw) {
+                        const unsigned long long key = ((unsigned long long)acc32[c] << 32) | (idx0 + c);
+                        best = key < best ? key : best;
+                    }
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 sad_loop_kernel(const uint8_t* __restrict__ src, int src_stride, const uint8_t* __restrict__ ref, int ref_stride,
                 const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
-    __shared__ uint8_t s_blk[64 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_src[64 * kHmeSrcStrideDw];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_ref[127 * kHmeRefStrideDw];
     __shared__ unsigned long long s_best[4];
     const SvtHipSadLoop d = searches[blockIdx.x];
     const int tid = threadIdx.x;
-    const int rstep = d.row_step;  // 1 = every row, 2 = every other row (hme "sub-SAD": strides doubled, height halved)
-    const int rows = d.bh / rstep;
-    for (int i = tid; i < rows * d.bw; i += 256) {
-        const int y = i / d.bw, x = i - y * d.bw;
-        s_blk[i] = src[(size_t)(d.src_y + y * rstep) * src_stride + d.src_x + x];
-    }
-    __syncthreads();
     unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;  // initial best_sad 0xffffff (EbComputeSAD_C.c:73)
     const int ncand = d.sa_w * d.sa_h;
-    for (int c = tid; c < ncand; c += 256) {
-        const int cy = c / d.sa_w, cx = c - cy * d.sa_w;
-        const uint8_t* r = ref + (size_t)(d.ref_y + cy) * ref_stride + d.ref_x + cx;
-        uint32_t sad = 0;
-        for (int y = 0; y < rows; y++)
-            for (int x = 0; x < d.bw; x++) sad += (uint32_t)abs((int)s_blk[y * d.bw + x] - (int)r[(size_t)(y * rstep) * ref_stride + x]);
-        const unsigned long long key = ((unsigned long long)sad << 32) | (uint32_t)c;
-        best = key < best ? key : best;
+    const bool aligned = !((src_stride | ref_stride) & 3) && d.bh <= 64 && (d.bh % d.row_step) == 0;
+    if (aligned && d.bw == 16) sad_loop_fast<16>(d, src, src_stride, ref, ref_stride, lds_src, lds_ref, tid, best);
+    else if (aligned && d.bw == 32) sad_loop_fast<32>(d, src, src_stride, ref, ref_stride, lds_src, lds_ref, tid, best);
+    else if (aligned && d.bw == 64) sad_loop_fast<64>(d, src, src_stride, ref, ref_stride, lds_src, lds_ref, tid, best);
+    else {
+        uint8_t* s_blk = (uint8_t*)lds_ref;  // generic path: source block in LDS, reference read through the caches
+        const int rstep = d.row_step, rows = d.bh / rstep;
+        for (int i = tid; i < rows * d.bw; i += 256) {
+            const int y = i / d.bw, x = i - y * d.bw;
+            s_blk[i] = src[(size_t)(d.src_y + y * rstep) * src_stride + d.src_x + x];
+        }
+        __syncthreads();
+        for (int c = tid; c < ncand; c += 256) {
+            const int cy = c / d.sa_w, cx = c - cy * d.sa_w;
+            const uint8_t* r = ref + (size_t)(d.ref_y + cy) * ref_stride + d.ref_x + cx;
+            uint32_t sad = 0;
+            for (int y = 0; y < rows; y++)
+                for (int x = 0; x < d.bw; x++) sad += (uint32_t)abs((int)s_blk[y * d.bw + x] - (int)r[(size_t)(y * rstep) * ref_stride + x]);
+            const unsigned long long key = ((unsigned long long)sad << 32) | (uint32_t)c;
+            best = key < best ? key : best;
+        }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = shfl_xor64(best, m); best = o < best ? o : best; }
