@@ -53,43 +53,48 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, int tstride, const PI
     }
 }
 
-// svt_cdef_find_dir_c (EbCdef.c:132-196) for one 8x8 block by one wave; lane = pixel.
-// part: per-wave LDS scratch [8][16] ints.  Returns dir, writes var (uniform).
-__device__ __forceinline__ int find_dir_wave(int x_px, int lane, int* part, int& var_out) {
-    const int i = lane >> 3, j = lane & 7;
-    for (int k = lane; k < 128; k += 64) part[k] = 0;
+// svt_cdef_find_dir_c (EbCdef.c:132-196) for one 8x8 block by one wave; lane = pixel on entry.
+// The 8 x 15 directional line sums are independent dot products: after the 64 samples are parked in LDS,
+// lane (d & 3, bin) sums the <= 8 pixels of its line (pixel lists precomputed below), squares and weights it
+// (div_table), and a 16-lane DPP row reduction yields the cost of direction d; two passes cover d = 0..3, 4..7.
+// xs: per-wave LDS scratch of 64 ints.  Returns dir, writes var (both wave-uniform).
+__device__ __constant__ uint8_t kDirBinPix[8][16][8] = {
+    {{0,255,255,255,255,255,255,255},{1,8,255,255,255,255,255,255},{2,9,16,255,255,255,255,255},{3,10,17,24,255,255,255,255},{4,11,18,25,32,255,255,255},{5,12,19,26,33,40,255,255},{6,13,20,27,34,41,48,255},{7,14,21,28,35,42,49,56},{15,22,29,36,43,50,57,255},{23,30,37,44,51,58,255,255},{31,38,45,52,59,255,255,255},{39,46,53,60,255,255,255,255},{47,54,61,255,255,255,255,255},{55,62,255,255,255,255,255,255},{63,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{0,1,255,255,255,255,255,255},{2,3,8,9,255,255,255,255},{4,5,10,11,16,17,255,255},{6,7,12,13,18,19,24,25},{14,15,20,21,26,27,32,33},{22,23,28,29,34,35,40,41},{30,31,36,37,42,43,48,49},{38,39,44,45,50,51,56,57},{46,47,52,53,58,59,255,255},{54,55,60,61,255,255,255,255},{62,63,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{0,1,2,3,4,5,6,7},{8,9,10,11,12,13,14,15},{16,17,18,19,20,21,22,23},{24,25,26,27,28,29,30,31},{32,33,34,35,36,37,38,39},{40,41,42,43,44,45,46,47},{48,49,50,51,52,53,54,55},{56,57,58,59,60,61,62,63},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{6,7,255,255,255,255,255,255},{4,5,14,15,255,255,255,255},{2,3,12,13,22,23,255,255},{0,1,10,11,20,21,30,31},{8,9,18,19,28,29,38,39},{16,17,26,27,36,37,46,47},{24,25,34,35,44,45,54,55},{32,33,42,43,52,53,62,63},{40,41,50,51,60,61,255,255},{48,49,58,59,255,255,255,255},{56,57,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{7,255,255,255,255,255,255,255},{6,15,255,255,255,255,255,255},{5,14,23,255,255,255,255,255},{4,13,22,31,255,255,255,255},{3,12,21,30,39,255,255,255},{2,11,20,29,38,47,255,255},{1,10,19,28,37,46,55,255},{0,9,18,27,36,45,54,63},{8,17,26,35,44,53,62,255},{16,25,34,43,52,61,255,255},{24,33,42,51,60,255,255,255},{32,41,50,59,255,255,255,255},{40,49,58,255,255,255,255,255},{48,57,255,255,255,255,255,255},{56,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{48,56,255,255,255,255,255,255},{32,40,49,57,255,255,255,255},{16,24,33,41,50,58,255,255},{0,8,17,25,34,42,51,59},{1,9,18,26,35,43,52,60},{2,10,19,27,36,44,53,61},{3,11,20,28,37,45,54,62},{4,12,21,29,38,46,55,63},{5,13,22,30,39,47,255,255},{6,14,23,31,255,255,255,255},{7,15,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{0,8,16,24,32,40,48,56},{1,9,17,25,33,41,49,57},{2,10,18,26,34,42,50,58},{3,11,19,27,35,43,51,59},{4,12,20,28,36,44,52,60},{5,13,21,29,37,45,53,61},{6,14,22,30,38,46,54,62},{7,15,23,31,39,47,55,63},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}},
+    {{0,8,255,255,255,255,255,255},{1,9,16,24,255,255,255,255},{2,10,17,25,32,40,255,255},{3,11,18,26,33,41,48,56},{4,12,19,27,34,42,49,57},{5,13,20,28,35,43,50,58},{6,14,21,29,36,44,51,59},{7,15,22,30,37,45,52,60},{23,31,38,46,53,61,255,255},{39,47,54,62,255,255,255,255},{55,63,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255},{255,255,255,255,255,255,255,255}}};
+__device__ __constant__ int kDirBinWeight[8][16] = {{840,420,280,210,168,140,120,105,120,140,168,210,280,420,840,0},{420,210,140,105,105,105,105,105,140,210,420,0,0,0,0,0},{105,105,105,105,105,105,105,105,0,0,0,0,0,0,0,0},{420,210,140,105,105,105,105,105,140,210,420,0,0,0,0,0},{840,420,280,210,168,140,120,105,120,140,168,210,280,420,840,0},{420,210,140,105,105,105,105,105,140,210,420,0,0,0,0,0},{105,105,105,105,105,105,105,105,0,0,0,0,0,0,0,0},{420,210,140,105,105,105,105,105,140,210,420,0,0,0,0,0}};
+__device__ __forceinline__ int row_sum16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ int find_dir_wave(int x_px, int lane, int* xs, int& var_out) {
+    xs[lane] = x_px - 128;
     __builtin_amdgcn_wave_barrier();
-    const int x = x_px - 128;
-    atomicAdd(&part[0 * 16 + i + j], x);
-    atomicAdd(&part[1 * 16 + i + j / 2], x);
-    atomicAdd(&part[2 * 16 + i], x);
-    atomicAdd(&part[3 * 16 + 3 + i - j / 2], x);
-    atomicAdd(&part[4 * 16 + 7 + i - j], x);
-    atomicAdd(&part[5 * 16 + 3 - i / 2 + j], x);
-    atomicAdd(&part[6 * 16 + j], x);
-    atomicAdd(&part[7 * 16 + i / 2 + j], x);
-    __builtin_amdgcn_wave_barrier();
-    int cost = 0;
-    if (lane < 8) {
-        const int* p = part + lane * 16;
-        constexpr int dv[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
-        if (lane == 2 || lane == 6) {
-            for (int k = 0; k < 8; k++) cost += p[k] * p[k];
-            cost *= dv[8];
-        } else if (lane == 0 || lane == 4) {
+    int costs[8];
 #pragma unroll
-            for (int k = 0; k < 7; k++) cost += (p[k] * p[k] + p[14 - k] * p[14 - k]) * dv[k + 1];
-            cost += p[7] * p[7] * dv[8];
-        } else {
-            for (int k = 0; k < 5; k++) cost += p[3 + k] * p[3 + k];
-            cost *= dv[8];
+    for (int pass = 0; pass < 2; pass++) {
+        const int d = 4 * pass + (lane >> 4), b = lane & 15;
+        const uint2 pix = *(const uint2*)kDirBinPix[d][b];
+        int s = 0;
 #pragma unroll
-            for (int k = 0; k < 3; k++) cost += (p[k] * p[k] + p[10 - k] * p[10 - k]) * dv[2 * k + 2];
+        for (int k = 0; k < 8; k++) {
+            const uint32_t idx = ((k < 4 ? pix.x : pix.y) >> (8 * (k & 3))) & 0xFFu;
+            s += idx < 64 ? xs[idx] : 0;
         }
-    }
-    int best = 0, best_cost = 0, costs[8];
+        const int c = row_sum16(s * s * kDirBinWeight[d][b]);
 #pragma unroll
-    for (int d = 0; d < 8; d++) costs[d] = __builtin_amdgcn_readlane(cost, d);
+        for (int q = 0; q < 4; q++) costs[4 * pass + q] = __builtin_amdgcn_readlane(c, 16 * q);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int best = 0, best_cost = 0;
 #pragma unroll
     for (int d = 0; d < 8; d++)
         if (costs[d] > best_cost) { best_cost = costs[d]; best = d; }
@@ -175,6 +180,28 @@ __device__ __forceinline__ int combine(const PixelTerms& T, int pri_idx, int sec
     if (sec_idx) sum += pri_idx ? T.secA[sec_idx - 1] : T.secB[sec_idx - 1];
     const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
     return pri_idx ? min(max(y, T.mnA), T.mxA) : min(max(y, T.mnB), T.mxB);
+}
+
+// One pixel, one (pri, sec, dir): svt_cdef_filter_block_c (EbCdef.c:202-257) without the search's shared-term machinery.
+__device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride, int pri, int sec, int dir, int cs, int damping) {
+    const int x = (int)(int16_t)px[0];
+    int sum = 0, mn = x, mx = x;
+    const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
+    const int w0 = ((pri >> cs) & 1) ? 3 : 4, w1 = ((pri >> cs) & 1) ? 3 : 2;
+    const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int o = kDirDy[dir][k] * tstride + kDirDx[dir][k];
+        const int p0 = px[o], p1 = px[-o];
+        tap_minmax(p0, mn, mx); tap_minmax(p1, mn, mx);
+        if (pri) sum += (k ? w1 : w0) * (constrain(p0 - x, pri, pshift) + constrain(p1 - x, pri, pshift));
+        const int o2 = kDirDy[d2][k] * tstride + kDirDx[d2][k], o6 = kDirDy[d6][k] * tstride + kDirDx[d6][k];
+        const int s0 = px[o2], s1 = px[-o2], s2 = px[o6], s3 = px[-o6];
+        tap_minmax(s0, mn, mx); tap_minmax(s1, mn, mx); tap_minmax(s2, mn, mx); tap_minmax(s3, mn, mx);
+        if (sec) sum += (k ? 1 : 2) * (constrain(s0 - x, sec, sshift) + constrain(s1 - x, sec, sshift) + constrain(s2 - x, sec, sshift) + constrain(s3 - x, sec, sshift));
+    }
+    const int y = x + ((8 + sum - (sum < 0)) >> 4);
+    return min(max(y, mn), mx);
 }
 
 // sum(a), sum(a*a), sum(a*b) over 64 samples held as packed rows in LDS
@@ -357,28 +384,8 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
             const int dir = find_dir_wave(((int)px[0] >> cs), lane, part[wave], var);
             if (lane == 0) dir_buf[fb * 64 + b] = (uint8_t)dir;
             const int t = level << cs;
-            int t_of[16];
-#pragma unroll
-            for (int idx = 0; idx < 16; idx++) t_of[idx] = 0;
-            t_of[1] = adjust_strength(t, var);
-            // reuse the search machinery with "pri index" 1 = the chosen strength, direction rule t ? dir : 0
-            PixelTerms T;
-            pixel_terms(px, TS, t ? dir : 0, t_of, cs, damping, T);
-            int sum = T.pri[1];
-            if (sec) {
-                const int shift = max(0, damping - msb(sec));
-                const int d = t ? dir : 0, d2 = (d + 2) & 7, d6 = (d + 6) & 7;
-                const int x = T.x;
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int o2 = kDirDy[d2][k] * TS + kDirDx[d2][k], o6 = kDirDy[d6][k] * TS + kDirDx[d6][k];
-                    const int wk = k ? 1 : 2;
-                    sum += wk * (constrain((int)px[o2] - x, sec, shift) + constrain((int)px[-o2] - x, sec, shift) +
-                                 constrain((int)px[o6] - x, sec, shift) + constrain((int)px[-o6] - x, sec, shift));
-                }
-            }
-            const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
-            out[(size_t)(64 * fbr + 8 * by + i) * stride + 64 * fbc + 8 * bx + j] = (PIX)min(max(y, T.mnA), T.mxA);
+            const int y = filter_px_single(px, TS, adjust_strength(t, var), sec, t ? dir : 0, cs, damping);
+            out[(size_t)(64 * fbr + 8 * by + i) * stride + 64 * fbc + 8 * bx + j] = (PIX)y;
         }
     } else {
         const int q = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
@@ -388,27 +395,8 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
             const uint16_t* px = tile + (4 * by + i + kVB) * TS + 4 * bx + j + kHB;
             const int t = level << cs;
             const int dir = t ? dir_buf[fb * 64 + by * 8 + bx] : 0;
-            int t_of[16];
-#pragma unroll
-            for (int idx = 0; idx < 16; idx++) t_of[idx] = 0;
-            t_of[1] = t;
-            PixelTerms T;
-            pixel_terms(px, TS, dir, t_of, cs, damping, T);
-            int sum = T.pri[1];
-            if (sec) {
-                const int shift = max(0, damping - msb(sec));
-                const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
-                const int x = T.x;
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int o2 = kDirDy[d2][k] * TS + kDirDx[d2][k], o6 = kDirDy[d6][k] * TS + kDirDx[d6][k];
-                    const int wk = k ? 1 : 2;
-                    sum += wk * (constrain((int)px[o2] - x, sec, shift) + constrain((int)px[-o2] - x, sec, shift) +
-                                 constrain((int)px[o6] - x, sec, shift) + constrain((int)px[-o6] - x, sec, shift));
-                }
-            }
-            const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
-            out[(size_t)(32 * fbr + 4 * by + i) * stride + 32 * fbc + 4 * bx + j] = (PIX)min(max(y, T.mnA), T.mxA);
+            const int y = filter_px_single(px, TS, t, sec, dir, cs, damping);
+            out[(size_t)(32 * fbr + 4 * by + i) * stride + 32 * fbc + 4 * bx + j] = (PIX)y;
         }
     }
 }
