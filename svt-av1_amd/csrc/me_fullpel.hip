@@ -27,6 +27,13 @@
 #include "svt_hip_internal.h"
 #include "lds_stage.h"
 
+#ifndef ME_R_UNROLL
+#define ME_R_UNROLL 1
+#endif
+#ifndef ME_WAVES_PER_EU
+#define ME_WAVES_PER_EU 2
+#endif
+
 namespace {
 
 constexpr int kTile   = 64;            // candidates per tile edge
@@ -34,7 +41,6 @@ constexpr int kRefRows = kTile + 63;   // window rows per tile
 constexpr int kRefRowDw = 36;          // dwords staged per window row (64+63 px + 8 over-read = 135 B -> 144 B)
 constexpr int kRefStrideDw = 48;       // LDS row stride in dwords (192 B): rows y..y+3 of a 32-lane group hit
                                        // disjoint 16-bank quarters for ds_read_b64 (banks = dword % 64)
-constexpr int kSrcStrideDw = 16;       // 64 B per source row
 
 // Wave-wide unsigned minimum, result uniform.  4 DPP steps inside each 16-lane row, then the four
 // row results are combined through SGPRs.
@@ -72,6 +78,16 @@ __device__ __forceinline__ uint32_t fold_key16(uint32_t key, uint32_t a_lo, uint
     return key;
 }
 
+// The folds below only feed the next unit / the final reduction, so LLVM's machine-sink pass moves
+// all 80 of them behind the last SAD loop and keeps every accumulator of the unit alive (448
+// registers, one wave per SIMD).  An empty volatile asm that "modifies" the key pins each fold to
+// the place it is written, which brings the kernel under 256 registers = two waves per SIMD.
+// Read-only for the whole launch and wave-uniform: the constant address space makes the backend pick
+// scalar (SMEM) loads even after barriers.
+typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+
+#define PIN(x) asm volatile("" : "+v"(x))
+
 struct Keys {
     uint32_t k8[64];   // indexed by 8x8 PU number - 21
     uint32_t k16[16];  // indexed by 16x16 PU number - 5
@@ -81,8 +97,8 @@ struct Keys {
 
 // All 85 PUs for the 8 candidates (row y, columns 8g..8g+7 of the tile) owned by this lane.
 template <bool SUB>
-__device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src, const uint32_t* __restrict__ lds_ref,
-                                            int y, int g, uint32_t idx0, Keys& K) {
+__device__ __forceinline__ void search_unit(const_u32_ptr src_dw, int src_pitch_dw, uint32_t src_shift,
+                                            const uint32_t* __restrict__ lds_ref, int y, int g, uint32_t idx0, Keys& K) {
     uint32_t h16[4][4];       // packed 16-wide partial sums of the even block row: [X][quad*2 + half]
     uint32_t s32[2][8];       // 32x32 running sums per candidate: [X>>1][cand]
     uint32_t s64[8];
@@ -96,19 +112,22 @@ __device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src
         for (int bx = 0; bx < 8; bx++) { acc[bx][0] = 0; acc[bx][1] = 0; }
 
         const uint32_t* rrow = lds_ref + (y + 8 * by) * kRefStrideDw + 2 * g;
-        const uint32_t* srow = lds_src + (8 * by) * kSrcStrideDw;
-#pragma unroll 1
+        const_u32_ptr srow = src_dw + (size_t)(8 * by) * src_pitch_dw;
+#pragma unroll ME_R_UNROLL
         for (int r = 0; r < 8; r += (SUB ? 2 : 1)) {
             const uint32_t* rp = rrow + r * kRefStrideDw;
-            const uint4*    sp = (const uint4*)(srow + r * kSrcStrideDw);
+            const_u32_ptr sp = srow + (size_t)r * src_pitch_dw;   // wave-uniform: scalar loads, S[] lives in SGPRs
             uint64_t ev[9], od[8];
 #pragma unroll
             for (int k = 0; k < 9; k++) ev[k] = *(const uint64_t*)(rp + 2 * k);           // 8-byte aligned
 #pragma unroll
             for (int k = 0; k < 8; k++) { Dw2 t = *(const Dw2*)(rp + 2 * k + 1); od[k] = pack64(t.x, t.y); }
-            uint32_t S[16];
+            uint32_t Wd[17], S[16];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { uint4 t = sp[k]; S[4 * k] = t.x; S[4 * k + 1] = t.y; S[4 * k + 2] = t.z; S[4 * k + 3] = t.w; }
+            for (int k = 0; k < 16; k++) Wd[k] = sp[k];
+            Wd[16] = src_shift ? sp[16] : 0u;   // the 17th dword only holds source bytes when the row is misaligned
+#pragma unroll
+            for (int k = 0; k < 16; k++) S[k] = (uint32_t)(pack64(Wd[k], Wd[k + 1]) >> src_shift);
 #pragma unroll
             for (int bx = 0; bx < 8; bx++) {
                 // quad 0: candidates 0..3 -> ref dwords (2bx, 2bx+1) for the left 4 px, (2bx+1, 2bx+2) for the right 4 px
@@ -132,6 +151,7 @@ __device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src
             }
             uint32_t& key = K.k8[pu8_index(bx, by) - 21];
             key = fold_key16(key, p[bx][0], p[bx][1], p[bx][2], p[bx][3], idx0);
+            PIN(key);
         }
         // ---- 16x16: packed u16 adds never carry between halves (max 256*255 = 65280)
         if ((by & 1) == 0) {
@@ -147,6 +167,7 @@ __device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src
                 for (int k = 0; k < 4; k++) q[k] = h16[X][k] + p[2 * X][k] + p[2 * X + 1][k];
                 uint32_t& key = K.k16[z16_index(X, by >> 1)];
                 key = fold_key16(key, q[0], q[1], q[2], q[3], idx0);
+                PIN(key);
                 // ---- 32x32 running sums (unpacked)
                 const int xh = X >> 1;
                 if ((X & 1) == 0 && (by & 3) == 1) {
@@ -167,6 +188,7 @@ __device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src
                         key = (k < key) ? k : key;
                         s64[c] += s32[xh][c];
                     }
+                    PIN(key);
                     K.k32[(by >> 2) * 2 + xh] = key;
                 }
             }
@@ -184,14 +206,14 @@ __device__ __forceinline__ void search_unit(const uint32_t* __restrict__ lds_src
 }
 
 template <int WAVES, bool SUB>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PER_EU, ME_WAVES_PER_EU)))
 me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ ref, int stride, int org_x, int org_y,
                        const SvtHipSbSearch* __restrict__ sbs, uint32_t* __restrict__ best_sad,
                        uint32_t* __restrict__ best_mv) {
     constexpr int NT = 64 * WAVES;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_src[64 * kSrcStrideDw];
     __shared__ __attribute__((aligned(16))) uint32_t lds_ref[kRefRows * kRefStrideDw];
-    __shared__ uint32_t lds_red[WAVES][2][88];  // per-wave reduced (sad, index)
+    __shared__ uint32_t lds_red[WAVES][2][8];   // per-wave reduced (sad, index) of the five 64-bit-key PUs
+    __shared__ uint32_t lds_part[NT], lds_fin[88];
 
     const int sb  = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,15 +230,20 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
     for (int i = 0; i < 4; i++) K.k32[i] = ~0ull;
     K.k64 = ~0ull;
 
-    const uint8_t* src_base = src + (size_t)(org_y + d.sb_y) * stride + (org_x + d.sb_x);
-    stage_rows(lds_src, kSrcStrideDw, src_base, stride, 64, 16, 64, tid, NT);
+    // The source SB is the same for every lane, so it is read with scalar loads straight into SGPRs
+    // (v_qsad's src1 may be an SGPR): no LDS traffic, no VGPRs.  Rows are fetched as aligned dwords
+    // and the byte misalignment of the SB origin is shifted out on the scalar ALU.
+    const uint8_t*  src_base  = src + (size_t)(org_y + d.sb_y) * stride + (org_x + d.sb_x);
+    const uint32_t  src_shift = 8u * (uint32_t)((uintptr_t)src_base & 3);
+    const_u32_ptr   src_dw    = (const_u32_ptr)((uintptr_t)src_base & ~(uintptr_t)3);
+    const int       src_pitch_dw = stride >> 2;
 
     for (int ty = 0; ty < sah; ty += kTile) {
         const int th = min(kTile, sah - ty);
         for (int tx = 0; tx < saw; tx += kTile) {
             const int tw = min(kTile, saw - tx);
             const int ng = tw >> 3;  // 8-candidate groups per candidate row (tw is a multiple of 8 here)
-            __syncthreads();               // previous tile fully consumed (and lds_src staged)
+            __syncthreads();               // previous tile fully consumed
             const uint8_t* ref_base = ref + (size_t)(org_y + d.sb_y + d.y_origin + ty) * stride +
                                       (org_x + d.sb_x + d.x_origin + tx);
             stage_rows(lds_ref, kRefStrideDw, ref_base, stride, th + 63, kRefRowDw, tw + 63, tid, NT);
@@ -225,16 +252,44 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
             for (int u = tid; u < units; u += NT) {
                 const int y = u / ng, g = u - y * ng;
                 const uint32_t idx0 = (uint32_t)((ty + y) * saw + tx + 8 * g);
-                search_unit<SUB>(lds_src, lds_ref, y, g, idx0, K);
+                search_unit<SUB>(src_dw, src_pitch_dw, src_shift, lds_ref, y, g, idx0, K);
             }
         }
     }
 
-    // ---- reduce the per-lane keys over the wave, then over the workgroup's waves
+    // ---- reduce the per-lane keys over the workgroup.
+    // The 80 32-bit keys (16x16 and 8x8 PUs) go through LDS transposed: every lane stores its keys
+    // as lds_keys[pu][lane], then one thread per (PU, slice) takes the minimum of a slice and a last
+    // step merges the slices -- ~200 instructions instead of 80 DPP/readlane wave reductions.
+    constexpr int PPH   = 4096 / NT;   // PUs handled per pass (16 KB of the idle window buffer)
+    constexpr int PARTS = NT / PPH;    // slices per PU, PPH entries each
+    uint32_t* lds_keys = lds_ref;
+    const int rp = tid % PPH, rq = tid / PPH;
 #pragma unroll
-    for (int i = 0; i < 64; i++) { uint32_t m = wave_min_u32(K.k8[i]); if (lane == 0) { lds_red[wave][0][21 + i] = m >> 16; lds_red[wave][1][21 + i] = m & 0xFFFFu; } }
+    for (int ph = 0; ph * PPH < 80; ph++) {
+        const int cnt = (80 - ph * PPH) < PPH ? (80 - ph * PPH) : PPH;
+        __syncthreads();   // window buffer / previous pass no longer read
 #pragma unroll
-    for (int i = 0; i < 16; i++) { uint32_t m = wave_min_u32(K.k16[i]); if (lane == 0) { lds_red[wave][0][5 + i] = m >> 16; lds_red[wave][1][5 + i] = m & 0xFFFFu; } }
+        for (int j = 0; j < cnt; j++) {
+            const int i = ph * PPH + j;   // PU number - 5
+            lds_keys[j * NT + tid] = (i < 16) ? K.k16[i] : K.k8[i - 16];
+        }
+        __syncthreads();
+        if (rp < cnt) {
+            uint32_t m = 0xFFFFFFFFu;
+#pragma unroll 8
+            for (int j = 0; j < PPH; j++) m = min(m, lds_keys[rp * NT + rq * PPH + ((j + rp) & (PPH - 1))]);  // rotated: conflict-free
+            lds_part[rq * PPH + rp] = m;
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            uint32_t m = lds_part[tid];
+#pragma unroll
+            for (int q = 1; q < PARTS; q++) m = min(m, lds_part[q * PPH + tid]);
+            lds_fin[5 + ph * PPH + tid] = m;
+        }
+    }
+    // The five 32x32 / 64x64 PUs carry 64-bit keys: two DPP wave reductions each.
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         const uint64_t k = (i < 4) ? K.k32[i] : K.k64;
@@ -246,11 +301,16 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
     }
     __syncthreads();
     for (int pu = tid; pu < SVT_HIP_SQUARE_PU_COUNT; pu += NT) {
-        uint32_t bs = lds_red[0][0][pu], bi = lds_red[0][1][pu];
+        uint32_t bs, bi;
+        if (pu >= 5) {
+            bs = lds_fin[pu] >> 16; bi = lds_fin[pu] & 0xFFFFu;
+        } else {
+            bs = lds_red[0][0][pu]; bi = lds_red[0][1][pu];
 #pragma unroll
-        for (int w = 1; w < WAVES; w++) {
-            const uint32_t s = lds_red[w][0][pu], ix = lds_red[w][1][pu];
-            if (s < bs || (s == bs && ix < bi)) { bs = s; bi = ix; }
+            for (int w = 1; w < WAVES; w++) {
+                const uint32_t s = lds_red[w][0][pu], ix = lds_red[w][1][pu];
+                if (s < bs || (s == bs && ix < bi)) { bs = s; bi = ix; }
+            }
         }
         uint32_t out_sad = SVT_HIP_MAX_SAD_VALUE, out_mv = 0;
         if (saw > 0 && sah > 0 && bi < (uint32_t)(saw * sah)) {
@@ -330,8 +390,8 @@ extern "C" int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_sr
 #define LAUNCH(W, S) hipLaunchKernelGGL((me_fullpel_85pu_kernel<W, S>), grid, dim3(64 * W), 0, stream, d_src, d_ref, stride, \
                                         org_x, org_y, d_sbs, d_best_sad, d_best_mv)
     if (waves_per_sb == 1) { if (sub_sad) LAUNCH(1, true); else LAUNCH(1, false); }
-    else if (waves_per_sb == 4) { if (sub_sad) LAUNCH(4, true); else LAUNCH(4, false); }
-    else { if (sub_sad) LAUNCH(2, true); else LAUNCH(2, false); }
+    else if (waves_per_sb == 2) { if (sub_sad) LAUNCH(2, true); else LAUNCH(2, false); }
+    else { if (sub_sad) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
     if (sub_sad) hipLaunchKernelGGL((me_fullpel_narrow_kernel<true>), grid, dim3(64), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
     else         hipLaunchKernelGGL((me_fullpel_narrow_kernel<false>), grid, dim3(64), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);

@@ -11,7 +11,7 @@ struct SvtHipCtx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
-    int         me_waves = 2;
+    int         me_waves = 4;   // 256 threads per SB: measured best on MI355X (tools/me_time.py)
     std::string err;
 };
 
