@@ -184,6 +184,193 @@ sgr_search_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 8-bit search kernel (the 4K north-star path).  Same results as sgr_search_kernel, ~1/3 of the
+// instructions per pixel and parameter set:
+//  * everything that does not depend on the parameter set is hoisted out of the 16-set loop and kept
+//    in REGISTERS: p = max(n*sumsq - sum^2, 0) and m = sum * one_by_n of the ~13 A/B positions a thread
+//    owns.  For 8-bit data p < 2^24 and the set's s < 2^12, so z and B are single v_mad_u32_u24;
+//  * A' and B' are packed as A' << 20 | B' (A' <= 256, B' <= 65088): the un-weighted sum of a 3x3
+//    neighbourhood (9 * 256 < 2^12, 9 * 65088 < 2^20) stays inside its field, so the neighbourhood is
+//    gathered with PACKED adds and the 4/3 (r = 1) and 6/5 (r = 2) weights become 3*S9 + S5 and
+//    5*S6 + S2 on the unpacked fields;
+//  * a lane walks 8 rows of one column, so the horizontal triple sums are reused by three output rows;
+//  * flt - u is formed inside the rounding shift ((a*x + b + 256 - (x << 13)) >> 9), the five projection
+//    sums are v_mad_i32_i24 in int32 (|flt - u| <= 4084, 8 px * 16 lanes * 4084^2 < 2^31), reduced over
+//    16-lane rows with DPP adds and accumulated per parameter set with 64-bit LDS atomics: one global
+//    atomic per (tile, set, sum) at the very end;
+//  * sets 11/12/13 (r0 = 0) share s1 with sets 2/5/8, so their H11/C1 are copies: 13 filter passes, not 16.
+constexpr int S_TW = 64, S_TH = 32;
+constexpr int S_IW = S_TW + 6, S_IH = S_TH + 6;
+constexpr int S_PW = S_TW + 2, S_P1H = S_TH + 2, S_P2H = S_TH / 2 + 1;
+constexpr int S_N1 = S_PW * S_P1H, S_N2 = S_PW * S_P2H, S_NP = S_N1 + S_N2;
+constexpr int S_KP = (S_NP + 255) / 256;
+
+__device__ __forceinline__ int32_t row16_sum(int32_t v) {   // every lane of a 16-lane row gets the row total
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return v;
+}
+
+#define FA_(v) ((v) >> 20)
+#define FB_(v) ((v) & 0xFFFFFu)
+
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
+                   int units_x, int units_y, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
+    __shared__ uint16_t in[S_IH * S_IW];
+    __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
+    __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
+    __shared__ unsigned long long acc[16][5];
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH, tid = threadIdx.x;
+    const int unit = min(y0 / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+
+    {
+        const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
+        xt[tid] = (A << 20) | (256u - A);
+        if (tid < 80) acc[tid / 5][tid % 5] = 0ull;
+    }
+    for (int i = tid; i < S_IH * S_IW; i += 256) {
+        const int r = i / S_IW, c = i - r * S_IW;
+        const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
+        in[i] = (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+    }
+    __syncthreads();
+
+    // ---- parameter-set independent part of A/B for the positions this thread owns
+    uint32_t P[S_KP], M[S_KP];
+#pragma unroll
+    for (int k = 0; k < S_KP; k++) {
+        const int i = tid + 256 * k;
+        uint32_t sm = 0, sq = 0, n = 9, obn = 455;
+        if (i < S_N1) {                        // r = 1: position (r - 1, c - 1), window centre in[r + 2][c + 2]
+            const int r = i / S_PW, c = i - r * S_PW;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) { const uint32_t v = in[(r + 2 + dy) * S_IW + c + 2 + dx]; sm += v; sq += v * v; }
+        } else if (i < S_NP) {                 // r = 2: picture rows -1, 1, 3, ...
+            const int i2 = i - S_N1, rr = i2 / S_PW, c = i2 - rr * S_PW, r = 2 * rr;
+            n = 25; obn = 164;
+#pragma unroll
+            for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+                for (int dx = -2; dx <= 2; dx++) { const uint32_t v = in[(r + 2 + dy) * S_IW + c + 2 + dx]; sm += v; sq += v * v; }
+        }
+        P[k] = (sq * n < sm * sm) ? 0u : sq * n - sm * sm;   // EbRestoration.c:804-806 / :935-937 (bit depth 8: no pre-rounding)
+        M[k] = sm * obn;
+    }
+
+    // ---- the 8 pixels (one column, 8 rows) this lane accumulates
+    const int j = tid & 63, i0 = (tid >> 6) * 8;
+    const int nvalid = min(max(ph - (y0 + i0), 0), 8);
+    const bool colvalid = x0 + j < pw;
+    uint32_t X[8]; int32_t SV[8], CX[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        X[r] = in[(i0 + r + 3) * S_IW + j + 3];
+        const int yy = min(y0 + i0 + r, ph - 1), xx = min(x0 + j, pw - 1);
+        SV[r] = ((int32_t)src[(size_t)yy * src_stride + xx] - (int32_t)X[r]) << 4;     // (src << 4) - u
+        CX[r] = 256 - (int32_t)(X[r] << 13);                                           // rounding - (u << 9)
+    }
+
+    // parameter sets that must be filtered: the masked ones, 11/12/13 folded onto 2/5/8
+    uint32_t cmask = ep_mask & 0xC7FFu;
+    if (ep_mask & (1u << 11)) cmask |= 1u << 2;
+    if (ep_mask & (1u << 12)) cmask |= 1u << 5;
+    if (ep_mask & (1u << 13)) cmask |= 1u << 8;
+
+    int buf = 0;
+    for (int ep = 0; ep < 16; ep++) {
+        if (!((cmask >> ep) & 1)) continue;
+        const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
+        const uint32_t s0 = (uint32_t)kSgr[ep][2], s1 = (uint32_t)kSgr[ep][3];
+        uint32_t* abw = ab[buf];
+        // ---- A'/B' of this set (EbRestoration.c:787-858 / :926-985)
+#pragma unroll
+        for (int k = 0; k < S_KP; k++) {
+            const int i = tid + 256 * k;
+            if (i < S_N1 ? has1 : (has0 && i < S_NP)) {
+                const uint32_t z = (__umul24(P[k], i < S_N1 ? s1 : s0) + (1u << 19)) >> 20;
+                const uint32_t t = xt[min(z, 255u)];
+                const uint32_t B = (__umul24(t & 0x1FFu, M[k]) + (1u << 11)) >> 12;
+                abw[i] = (t & 0xFFF00000u) | B;
+            }
+        }
+        __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
+
+        int32_t D0[8], D1[8];
+        if (has1) {
+            const uint32_t* a1 = abw + i0 * S_PW + j + 1;   // row index = picture row + 1
+            uint32_t Rm, Cm, R0, C0;
+            { const uint32_t l = a1[-1], c = a1[0], r = a1[1]; Rm = l + c + r; Cm = c; }
+            { const uint32_t l = a1[S_PW - 1], c = a1[S_PW], r = a1[S_PW + 1]; R0 = l + c + r; C0 = c; }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t* q = a1 + (r + 2) * S_PW;
+                const uint32_t l = q[-1], c = q[0], rt = q[1];
+                const uint32_t Rp = l + c + rt;
+                const uint32_t S9 = Rm + R0 + Rp, S5 = Cm + R0 + c;     // 4 * cross + 3 * corners = 3 * S9 + S5
+                const uint32_t a = __umul24(FA_(S9), 3u) + FA_(S5), b = __umul24(FB_(S9), 3u) + FB_(S5);
+                D1[r] = (int32_t)(__umul24(a, X[r]) + b + (uint32_t)CX[r]) >> 9;
+                Rm = R0; Cm = C0; R0 = Rp; C0 = c;
+            }
+        }
+        if (has0) {
+            const uint32_t* a2 = abw + S_N1 + (i0 / 2) * S_PW + j + 1;   // ab2 row rr holds picture row 2 * rr - 1
+            uint32_t H[5], C[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) { const uint32_t l = a2[q * S_PW - 1], c = a2[q * S_PW], r = a2[q * S_PW + 1]; H[q] = l + c + r; C[q] = c; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                {   // even row 2q: rows above/below, 6 * centres + 5 * sides = 5 * S6 + S2, >> 9
+                    const uint32_t S6 = H[q] + H[q + 1], S2 = C[q] + C[q + 1];
+                    const uint32_t a = __umul24(FA_(S6), 5u) + FA_(S2), b = __umul24(FB_(S6), 5u) + FB_(S2);
+                    D0[2 * q] = (int32_t)(__umul24(a, X[2 * q]) + b + (uint32_t)CX[2 * q]) >> 9;
+                }
+                {   // odd row 2q + 1: own row, >> 8 (rounding and u scale by one bit less: CX >> 1 is exact)
+                    const uint32_t a = __umul24(FA_(H[q + 1]), 5u) + FA_(C[q + 1]), b = __umul24(FB_(H[q + 1]), 5u) + FB_(C[q + 1]);
+                    D0[2 * q + 1] = (int32_t)(__umul24(a, X[2 * q + 1]) + b + (uint32_t)(CX[2 * q + 1] >> 1)) >> 8;
+                }
+            }
+        }
+        int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (r < nvalid) {   // wave-uniform
+                if (has0) { h00 += __mul24(D0[r], D0[r]); c0 += __mul24(D0[r], SV[r]); }
+                if (has1) { h11 += __mul24(D1[r], D1[r]); c1 += __mul24(D1[r], SV[r]); }
+                if (has0 && has1) h01 += __mul24(D0[r], D1[r]);
+            }
+        }
+        if (!colvalid) { h00 = 0; h01 = 0; h11 = 0; c0 = 0; c1 = 0; }
+        if (has0) { h00 = row16_sum(h00); c0 = row16_sum(c0); }
+        if (has1) { h11 = row16_sum(h11); c1 = row16_sum(c1); }
+        if (has0 && has1) h01 = row16_sum(h01);
+        if ((tid & 15) == 0) {
+            if (has0) { atomicAdd(&acc[ep][0], (unsigned long long)(long long)h00); atomicAdd(&acc[ep][3], (unsigned long long)(long long)c0); }
+            if (has1) { atomicAdd(&acc[ep][2], (unsigned long long)(long long)h11); atomicAdd(&acc[ep][4], (unsigned long long)(long long)c1); }
+            if (has0 && has1) atomicAdd(&acc[ep][1], (unsigned long long)(long long)h01);
+        }
+        buf ^= 1;
+    }
+    __syncthreads();
+    if (tid < 80) {
+        const int ep = tid / 5, q = tid - ep * 5;
+        if ((ep_mask >> ep) & 1) {
+            const int ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
+            const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
+            const bool used = q == 0 || q == 3 ? has0 : (q == 1 ? (has0 && has1) : has1);
+            if (used) atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + q], acc[ce][q]);
+        }
+    }
+}
+#undef FA_
+#undef FB_
+
 // ---- svt_apply_selfguided_restoration over a plane: per-unit parameter set (255 = unit not restored) and xqd
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
@@ -228,10 +415,10 @@ extern "C" int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, 
 }
 extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
                                          int pw, int ph, int unit_size, int units_x, int units_y, uint32_t ep_mask, int64_t* sums) {
-    dim3 grid((pw + 63) / 64, (ph + 15) / 16);
+    dim3 grid((pw + 63) / 64, (ph + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + S_TH - 1) / S_TH);
     unsigned long long* s = (unsigned long long*)sums;
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
     else hipLaunchKernelGGL((sgr_search_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
     return (int)hipGetLastError();
 }
