@@ -154,6 +154,30 @@ int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_row
  * Either descriptor pointer may be NULL to run a single direction (filter-level search probes). */
 int svt_hip_deblock_plane_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int bd, const uint16_t *d_edges_v,
                               const uint16_t *d_edges_h, int units_w, int units_h, int sharpness);
+/* Sum of squared differences of two planes: svt_spatial_full_distortion_kernel (8-bit) /
+ * svt_full_distortion_kernel16_bits (16-bit containers) as called by picture_sse_calculations
+ * (Encoder/Codec/EbDeblockingFilter.c:830-961).  *d_sse (device) receives the sum (it is cleared by the call). */
+int svt_hip_plane_sse_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, int a_stride, const void *d_b, int b_stride, int w,
+                          int h, uint64_t *d_sse);
+/* svt_av1_pick_filter_level's search for one plane / direction: search_filter_level + try_filter_frame
+ * (Encoder/Codec/EbDeblockingFilter.c:966-1187).  Every probe = copy of the unfiltered plane, whole-plane
+ * deblock at the probed level, SSE against the source; the probe sequence and the integer bias rule are the
+ * reference's.  As in the reference's search the level is frame-uniform (no segment / ref / mode deltas):
+ * the edge descriptors only supply the geometry (any non-zero level in them is replaced by the probed one). */
+typedef struct {
+    int plane;             /* 0 Y, 1 U, 2 V */
+    int dir;               /* luma: 0 = search filter_level[0] (vertical edges), 1 = filter_level[1]; ignored for chroma */
+    int other_level;       /* luma: the frame header's level of the other direction (try_filter_frame :976-979) */
+    int start_level;       /* last_frame_filter_level[dir | 2 | 3] */
+    int loop_filter_mode;  /* pcs->parent_pcs_ptr->loop_filter_mode: <= 2 -> one +-2 refinement, else the full step search */
+    int tx_mode_only_4x4;  /* frm_hdr->tx_mode == ONLY_4X4 (bias is not halved) */
+    int sharpness;
+} SvtHipDlfSearch;
+/* d_recon: unfiltered plane (read only); d_tmp: scratch plane of the same geometry; best_err = ss_err[best_level]. */
+int svt_hip_dlf_search_level_dev(SvtHipCtx *ctx, const SvtHipDlfSearch *p, const void *d_recon, void *d_tmp, int pix_bytes,
+                                 int stride, int bd, int plane_w, int plane_h, const void *d_src, int src_stride,
+                                 const uint16_t *d_edges_v, const uint16_t *d_edges_h, int units_w, int units_h,
+                                 uint64_t *d_sse_scratch, int *best_level, int64_t *best_err);
 
 /* ------------------------------------------------------------------ CDEF ------------------------ */
 /* Strength search of cdef_seg_search / cdef_seg_search16bit (Encoder/Codec/EbCdefProcess.c:80-475)

@@ -145,3 +145,97 @@ void orc_deblock_plane(void *plane, int pix_bytes, int stride, int bd, const uin
             }
     }
 }
+
+/* svt_spatial_full_distortion_kernel_c / svt_full_distortion_kernel16_bits_c (Common/Codec/EbPictureOperators.c:182-208
+ * and the 8-bit twin), as used by picture_sse_calculations (Encoder/Codec/EbDeblockingFilter.c:830-961). */
+uint64_t orc_plane_sse(int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h) {
+    uint64_t sse = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int64_t d = pix_bytes == 1 ? (int64_t)((const uint8_t *)a)[(size_t)y * a_stride + x] - ((const uint8_t *)b)[(size_t)y * b_stride + x]
+                                             : (int64_t)((const uint16_t *)a)[(size_t)y * a_stride + x] - ((const uint16_t *)b)[(size_t)y * b_stride + x];
+            sse += (uint64_t)(d * d);
+        }
+    return sse;
+}
+
+/* try_filter_frame (EbDeblockingFilter.c:966-1024) with a frame-uniform level: copy, deblock, SSE vs source. */
+static int64_t orc_try_level(const void *recon, void *tmp, int pix_bytes, int stride, int bd, int w, int h, const void *src, int src_stride,
+                             const uint16_t *ev, const uint16_t *eh, int uw, int uh, int sharpness, int lv_v, int lv_h) {
+    uint16_t *tv = (uint16_t *)malloc((size_t)uw * uh * 2), *th = (uint16_t *)malloc((size_t)uw * uh * 2);
+    for (int i = 0; i < uw * uh; i++) {   /* the level of every edge becomes the probed one; level 0 = edge not filtered (:245) */
+        tv[i] = (ev[i] & 0xff) && lv_v ? (uint16_t)((lv_v << 8) | (ev[i] & 0xff)) : 0;
+        th[i] = (eh[i] & 0xff) && lv_h ? (uint16_t)((lv_h << 8) | (eh[i] & 0xff)) : 0;
+    }
+    for (int y = 0; y < h; y++) memcpy((uint8_t *)tmp + (size_t)y * stride * pix_bytes, (const uint8_t *)recon + (size_t)y * stride * pix_bytes, (size_t)w * pix_bytes);
+    orc_deblock_plane(tmp, pix_bytes, stride, bd, tv, th, uw, uh, sharpness);
+    free(tv); free(th);
+    return (int64_t)orc_plane_sse(pix_bytes, src, src_stride, tmp, stride, w, h);
+}
+
+/* search_filter_level (EbDeblockingFilter.c:1026-1187).  Returns filt_best; *best_err = ss_err[filt_best]; probes[] (64 entries,
+ * optional) receives ss_err[] (-1 = level never probed) so a test can compare the probe sequence as well. */
+int orc_dlf_search_level(const void *recon, void *tmp, int pix_bytes, int stride, int bd, int w, int h, const void *src, int src_stride,
+                         const uint16_t *ev, const uint16_t *eh, int uw, int uh, int sharpness, int plane, int dir, int other_level,
+                         int start_level, int loop_filter_mode, int tx_mode_only_4x4, int64_t *best_err_out, int64_t *probes) {
+    int64_t ss_err[64];
+    memset(ss_err, 0xFF, sizeof(ss_err));
+    int filt_direction = 0;
+    int filt_mid = start_level < 0 ? 0 : (start_level > 63 ? 63 : start_level);
+    int filter_step = filt_mid < 16 ? 4 : filt_mid / 4;
+#define TRY(l) orc_try_level(recon, tmp, pix_bytes, stride, bd, w, h, src, src_stride, ev, eh, uw, uh, sharpness, \
+                             (plane == 0 && dir == 1) ? other_level : (l), (plane == 0 && dir == 0) ? other_level : (l))
+    int64_t best_err = TRY(filt_mid);
+    int filt_best = filt_mid;
+    ss_err[filt_mid] = best_err;
+    if (loop_filter_mode <= 2) {
+        filter_step = 2;
+        const int filt_high = filt_mid + filter_step > 63 ? 63 : filt_mid + filter_step;
+        const int filt_low = filt_mid - filter_step < 0 ? 0 : filt_mid - filter_step;
+        int64_t bias = (best_err >> (15 - (filt_mid / 8))) * filter_step;
+        if (!tx_mode_only_4x4) bias >>= 1;
+        if (filt_direction <= 0 && filt_low != filt_mid) {
+            if (ss_err[filt_low] < 0) ss_err[filt_low] = TRY(filt_low);
+            if (ss_err[filt_low] < (best_err + bias)) {
+                if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
+                filt_best = filt_low;
+            }
+        }
+        if (filt_direction >= 0 && filt_high != filt_mid) {
+            if (ss_err[filt_high] < 0) ss_err[filt_high] = TRY(filt_high);
+            if (ss_err[filt_high] < (best_err - bias)) filt_best = filt_high;
+        }
+    } else {
+        while (filter_step > 0) {
+            const int filt_high = filt_mid + filter_step > 63 ? 63 : filt_mid + filter_step;
+            const int filt_low = filt_mid - filter_step < 0 ? 0 : filt_mid - filter_step;
+            int64_t bias = (best_err >> (15 - (filt_mid / 8))) * filter_step;
+            if (!tx_mode_only_4x4) bias >>= 1;
+            if (filt_direction <= 0 && filt_low != filt_mid) {
+                if (ss_err[filt_low] < 0) ss_err[filt_low] = TRY(filt_low);
+                if (ss_err[filt_low] < (best_err + bias)) {
+                    if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
+                    filt_best = filt_low;
+                }
+            }
+            if (filt_direction >= 0 && filt_high != filt_mid) {
+                if (ss_err[filt_high] < 0) ss_err[filt_high] = TRY(filt_high);
+                if (ss_err[filt_high] < (best_err - bias)) {
+                    best_err = ss_err[filt_high];
+                    filt_best = filt_high;
+                }
+            }
+            if (filt_best == filt_mid) {
+                filter_step /= 2;
+                filt_direction = 0;
+            } else {
+                filt_direction = (filt_best < filt_mid) ? -1 : 1;
+                filt_mid = filt_best;
+            }
+        }
+    }
+#undef TRY
+    if (best_err_out) *best_err_out = ss_err[filt_best];
+    if (probes) memcpy(probes, ss_err, sizeof(ss_err));
+    return filt_best;
+}

@@ -112,6 +112,10 @@ void orc_lpf_edge(void *s, int pix_bytes, int pitch, int dir, int len, int blimi
 void orc_lf_limits(int level, int sharpness, int *lim, int *mblim, int *hev_thr);
 void orc_deblock_plane(void *plane, int pix_bytes, int stride, int bd, const uint16_t *edges_v, const uint16_t *edges_h,
                        int units_w, int units_h, int sharpness);
+uint64_t orc_plane_sse(int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h);
+int orc_dlf_search_level(const void *recon, void *tmp, int pix_bytes, int stride, int bd, int w, int h, const void *src, int src_stride,
+                         const uint16_t *ev, const uint16_t *eh, int uw, int uh, int sharpness, int plane, int dir, int other_level,
+                         int start_level, int loop_filter_mode, int tx_mode_only_4x4, int64_t *best_err_out, int64_t *probes);
 
 /* ---------------------------------------------------------------- CDEF (cdef_oracle.c) --------- */
 int  orc_cdef_adjust_strength(int strength, int var);

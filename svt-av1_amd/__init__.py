@@ -59,6 +59,12 @@ class SadLoop(C.Structure):
                 ("sa_w", C.c_int16), ("sa_h", C.c_int16), ("row_step", C.c_int16), ("reserved", C.c_int16)]
 
 
+class DlfSearch(C.Structure):
+    """SvtHipDlfSearch (include/svt_hip.h)."""
+    _fields_ = [("plane", C.c_int), ("dir", C.c_int), ("other_level", C.c_int), ("start_level", C.c_int), ("loop_filter_mode", C.c_int),
+                ("tx_mode_only_4x4", C.c_int), ("sharpness", C.c_int)]
+
+
 def tx_desc(x, y, tx_type):
     return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
 

@@ -101,7 +101,8 @@ __device__ __forceinline__ int lpf_core(int (&px)[14], int len, int level, int s
 // DIR 0: vertical edges (taps along x); DIR 1: horizontal edges (taps along y)
 template <typename PIX, int BD, int DIR>
 __global__ void __launch_bounds__(256)
-deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restrict__ edges, int units_w, int units_h, int sharpness) {
+deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restrict__ edges, int units_w, int units_h, int sharpness,
+                    int level_override) {
     int ux, uy, sx, sy;  // unit, sample position of q0
     if (DIR == 0) {
         ux = blockIdx.x * 256 + threadIdx.x;  sy = blockIdx.y;  uy = sy >> 2;  sx = 4 * ux;
@@ -111,8 +112,9 @@ deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restr
         if (ux >= units_w) return;
     }
     const uint32_t e = edges[uy * units_w + ux];
-    const int len = e & 0xff, level = e >> 8;
-    if (!len) return;
+    // level_override >= 0: frame-level probe of svt_av1_pick_filter_level (every block at the probed level, EbDeblockingFilter.c:966-1024)
+    const int len = e & 0xff, level = level_override >= 0 ? level_override : (int)(e >> 8);
+    if (!len || !level) return;
     const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
     const ptrdiff_t tap = DIR == 0 ? 1 : stride;
     PIX* s = plane + (size_t)sy * stride + sx;
@@ -132,18 +134,52 @@ deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restr
 }
 
 template <typename PIX, int BD>
-int launch_both(hipStream_t st, PIX* plane, int stride, const uint16_t* ev, const uint16_t* eh, int uw, int uh, int sharp) {
-    if (ev) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh), dim3(256), 0, st, plane, stride, ev, uw, uh, sharp);
-    if (eh) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 1>), dim3((4 * uw + 255) / 256, uh), dim3(256), 0, st, plane, stride, eh, uw, uh, sharp);
+int launch_both(hipStream_t st, PIX* plane, int stride, const uint16_t* ev, const uint16_t* eh, int uw, int uh, int sharp, int lv_v, int lv_h) {
+    if (ev) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh), dim3(256), 0, st, plane, stride, ev, uw, uh, sharp, lv_v);
+    if (eh) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 1>), dim3((4 * uw + 255) / 256, uh), dim3(256), 0, st, plane, stride, eh, uw, uh, sharp, lv_h);
     return (int)hipGetLastError();
+}
+
+// svt_spatial_full_distortion_kernel_c / svt_full_distortion_kernel16_bits_c (Common/Codec/EbPictureOperators.c; called by
+// picture_sse_calculations, EbDeblockingFilter.c:830-961): sum of squared differences of two planes.  A workgroup owns 8 rows
+// of 1024 columns; lanes read 4 consecutive samples, u32 partials (<= 8 * 4 * 1023^2 < 2^32), one u64 atomic per wave.
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+plane_sse_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __restrict__ b, int b_stride, int w, int h,
+                 unsigned long long* __restrict__ out) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = blockIdx.y * 8;
+    uint32_t acc = 0;
+    if (x < w) {
+        for (int y = y0; y < min(y0 + 8, h); y++) {
+            const PIX* pa = a + (size_t)y * a_stride + x;
+            const PIX* pb = b + (size_t)y * b_stride + x;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (x + k < w) { const int d = (int)pa[k] - (int)pb[k]; acc += (uint32_t)(d * d); }
+        }
+    }
+    unsigned long long v = acc;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += ((unsigned long long)(uint32_t)__shfl_xor((int)(v >> 32), m, 64) << 32) | (uint32_t)__shfl_xor((int)v, m, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
 }  // namespace
 
 extern "C" int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
-                                            const uint16_t* edges_h, int units_w, int units_h, int sharpness) {
+                                            const uint16_t* edges_h, int units_w, int units_h, int sharpness, int level_v, int level_h) {
     if (units_w <= 0 || units_h <= 0) return 0;
-    if (pix_bytes == 1) return launch_both<uint8_t, 8>(st, (uint8_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
-    if (bd == 8) return launch_both<uint16_t, 8>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
-    return launch_both<uint16_t, 10>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness);
+    if (pix_bytes == 1) return launch_both<uint8_t, 8>(st, (uint8_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
+    if (bd == 8) return launch_both<uint16_t, 8>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
+    return launch_both<uint16_t, 10>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
+}
+
+// *out must be zero before the launch (the caller enqueues the memset)
+extern "C" int svt_hip_launch_plane_sse(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride, int w, int h,
+                                        uint64_t* out) {
+    if (w <= 0 || h <= 0) return 0;
+    dim3 grid((w + 1023) / 1024, (h + 7) / 8);
+    if (pix_bytes == 1) hipLaunchKernelGGL((plane_sse_kernel<uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, w, h, (unsigned long long*)out);
+    else hipLaunchKernelGGL((plane_sse_kernel<uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, w, h, (unsigned long long*)out);
+    return (int)hipGetLastError();
 }

@@ -263,8 +263,92 @@ int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int st
         return SVT_HIP_ERR_BAD_ARG;
     }
     hipError_t e = (hipError_t)svt_hip_launch_deblock_plane(c->stream, d_plane, pix_bytes, stride, bd, d_edges_v, d_edges_h, units_w,
-                                                           units_h, sharpness);
+                                                           units_h, sharpness, -1, -1);
     if (e != hipSuccess) return fail(c, e, "deblock launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_plane_sse_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, int w, int h,
+                          uint64_t* d_sse) {
+    if (!c || !d_a || !d_b || !d_sse || (pix_bytes != 1 && pix_bytes != 2) || w <= 0 || h <= 0) {
+        if (c) c->err = "svt_hip_plane_sse_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    HIPCHK(c, hipMemsetAsync(d_sse, 0, sizeof(uint64_t), c->stream));
+    hipError_t e = (hipError_t)svt_hip_launch_plane_sse(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, w, h, d_sse);
+    if (e != hipSuccess) return fail(c, e, "plane sse launch");
+    return SVT_HIP_OK;
+}
+
+// search_filter_level (EbDeblockingFilter.c:1026-1187); every try_filter_frame (:966-1024) runs on the device.
+int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const void* d_recon, void* d_tmp, int pix_bytes, int stride,
+                                 int bd, int plane_w, int plane_h, const void* d_src, int src_stride, const uint16_t* d_edges_v,
+                                 const uint16_t* d_edges_h, int units_w, int units_h, uint64_t* d_sse_scratch, int* best_level,
+                                 int64_t* best_err_out) {
+    if (!c || !p || !d_recon || !d_tmp || !d_src || !d_edges_v || !d_edges_h || !d_sse_scratch || !best_level || p->plane < 0 ||
+        p->plane > 2 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || plane_w <= 0 ||
+        plane_h <= 0 || units_w != (plane_w + 3) / 4 || units_h != (plane_h + 3) / 4 || p->sharpness < 0 || p->sharpness > 7) {
+        if (c) c->err = "svt_hip_dlf_search_level_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    const int kMaxLoopFilter = 63;   // MAX_LOOP_FILTER
+    int64_t ss_err[kMaxLoopFilter + 1];
+    for (int i = 0; i <= kMaxLoopFilter; i++) ss_err[i] = -1;
+    int rc = SVT_HIP_OK;
+    auto try_level = [&](int lvl) -> int64_t {   // try_filter_frame
+        int lv_v = lvl, lv_h = lvl;
+        if (p->plane == 0 && p->dir == 0) lv_h = p->other_level;
+        if (p->plane == 0 && p->dir == 1) lv_v = p->other_level;
+        uint64_t sse = 0;
+        hipError_t e = hipMemcpy2DAsync(d_tmp, (size_t)stride * pix_bytes, d_recon, (size_t)stride * pix_bytes, (size_t)plane_w * pix_bytes,
+                                        plane_h, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = (hipError_t)svt_hip_launch_deblock_plane(c->stream, d_tmp, pix_bytes, stride, bd, d_edges_v, d_edges_h, units_w, units_h, p->sharpness, lv_v, lv_h);
+        if (e == hipSuccess) e = hipMemsetAsync(d_sse_scratch, 0, sizeof(uint64_t), c->stream);
+        if (e == hipSuccess) e = (hipError_t)svt_hip_launch_plane_sse(c->stream, pix_bytes, d_src, src_stride, d_tmp, stride, plane_w, plane_h, d_sse_scratch);
+        if (e == hipSuccess) e = hipMemcpyAsync(&sse, d_sse_scratch, sizeof(sse), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(c, e, "dlf level probe"); return 0; }
+        return (int64_t)sse;
+    };
+    int filt_direction = 0;
+    int filt_mid = p->start_level < 0 ? 0 : (p->start_level > kMaxLoopFilter ? kMaxLoopFilter : p->start_level);
+    int filter_step = filt_mid < 16 ? 4 : filt_mid / 4;
+    int64_t best_err = try_level(filt_mid);
+    int filt_best = filt_mid;
+    ss_err[filt_mid] = best_err;
+    const bool single = p->loop_filter_mode <= 2;
+    if (single) filter_step = 2;
+    while (rc == SVT_HIP_OK && filter_step > 0) {
+        const int filt_high = filt_mid + filter_step > kMaxLoopFilter ? kMaxLoopFilter : filt_mid + filter_step;
+        const int filt_low = filt_mid - filter_step < 0 ? 0 : filt_mid - filter_step;
+        int64_t bias = (best_err >> (15 - (filt_mid / 8))) * filter_step;   // bias against raising the level
+        if (!p->tx_mode_only_4x4) bias >>= 1;
+        if (filt_direction <= 0 && filt_low != filt_mid) {
+            if (ss_err[filt_low] < 0) ss_err[filt_low] = try_level(filt_low);
+            if (ss_err[filt_low] < best_err + bias) {
+                if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
+                filt_best = filt_low;
+            }
+        }
+        if (filt_direction >= 0 && filt_high != filt_mid) {
+            if (ss_err[filt_high] < 0) ss_err[filt_high] = try_level(filt_high);
+            if (ss_err[filt_high] < best_err - bias) {
+                if (!single) best_err = ss_err[filt_high];   // the mode <= 2 branch does not update best_err (:1121-1122)
+                filt_best = filt_high;
+            }
+        }
+        if (single) break;
+        if (filt_best == filt_mid) {
+            filter_step /= 2;
+            filt_direction = 0;
+        } else {
+            filt_direction = filt_best < filt_mid ? -1 : 1;
+            filt_mid = filt_best;
+        }
+    }
+    if (rc != SVT_HIP_OK) return rc;
+    *best_level = filt_best;
+    if (best_err_out) *best_err_out = ss_err[filt_best];
     return SVT_HIP_OK;
 }
 

@@ -70,3 +70,56 @@ def test_single_direction_and_4k_property(hip, orc):
     orc.orc_deblock_plane(ptr(exp2), 1, w, 8, ptr(ev), ptr(eh), ev.shape[1], ev.shape[0], 0)
     assert np.array_equal(got, exp2)
     hip.free(d_img, d_ev, d_eh)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_plane_sse(hip, orc, bd):
+    """picture_sse_calculations' kernel: ragged width / height, offset origins, full-range content."""
+    rng = np.random.default_rng(31 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    orc.orc_plane_sse.restype = C.c_uint64
+    for (w, h) in ((1, 1), (7, 3), (333, 77), (1920, 1080)):
+        a = rng.integers(0, 1 << bd, (h + 5, w + 9)).astype(dt)
+        b = rng.integers(0, 1 << bd, (h + 3, w + 20)).astype(dt)
+        exp = orc.orc_plane_sse(a.itemsize, C.c_void_p(a.ctypes.data + (2 * a.shape[1] + 3) * a.itemsize), a.shape[1],
+                                C.c_void_p(b.ctypes.data + (1 * b.shape[1] + 5) * b.itemsize), b.shape[1], w, h)
+        d_a, d_b, d_s = hip.to_device(a), hip.to_device(b), hip.empty(8)
+        hip.check(hip.L.svt_hip_plane_sse_dev(hip.h, a.itemsize, C.c_void_p(d_a.value + (2 * a.shape[1] + 3) * a.itemsize), a.shape[1],
+                                              C.c_void_p(d_b.value + (1 * b.shape[1] + 5) * b.itemsize), b.shape[1], w, h, d_s), "sse")
+        got = int(hip.to_host(d_s, (1,), np.uint64)[0])
+        hip.free(d_a, d_b, d_s)
+        assert got == exp, (bd, w, h, got, exp)
+
+
+@pytest.mark.parametrize("bd,mode", [(8, 1), (8, 3), (10, 3)])
+def test_filter_level_search(hip, orc, pkg, bd, mode):
+    """svt_av1_pick_filter_level's per-plane search on the device vs the oracle's restatement of
+    search_filter_level / try_filter_frame: same best level, same error, for luma (both directions) and chroma."""
+    w, h = 328, 200
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(91 + bd + mode)
+    mi, cols, rows = dc.make_mode_info(w, h, seed=21, varied=False)
+    for plane, (pw, ph) in enumerate(((w, h), (w // 2, h // 2), (w // 2, h // 2))):
+        ev, eh = dc.build_edges(mi, cols, rows, plane, pw, ph)
+        src = content(rng, ph, pw, bd, 1).astype(dt)
+        # "recon" = source with blocking artefacts on the transform grid + noise, so that some filtering helps
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        blk = (((xx // 8) * 5 + (yy // 8) * 3) % 7 - 3) * (2 << (bd - 8))
+        rec = np.clip(src.astype(np.int32) + blk + rng.integers(-1, 2, src.shape), 0, (1 << bd) - 1).astype(dt)
+        for dirn, start in (((0, 8), (1, 30)) if plane == 0 else ((0, 12),)):
+            tmp = np.zeros_like(rec)
+            best_err = C.c_int64()
+            probes = (C.c_int64 * 64)()
+            orc.orc_dlf_search_level.restype = C.c_int
+            exp_lvl = orc.orc_dlf_search_level(ptr(rec), ptr(tmp), rec.itemsize, pw, bd, pw, ph, ptr(src), pw, ptr(ev), ptr(eh), ev.shape[1], ev.shape[0],
+                                               2, plane, dirn, 9, start, mode, 0, C.byref(best_err), probes)
+            P = pkg.DlfSearch(plane, dirn, 9, start, mode, 0, 2)
+            d_rec, d_tmp, d_src, d_ev, d_eh, d_s = hip.to_device(rec), hip.empty(rec.nbytes), hip.to_device(src), hip.to_device(ev), hip.to_device(eh), hip.empty(8)
+            lvl, err = C.c_int(), C.c_int64()
+            hip.check(hip.L.svt_hip_dlf_search_level_dev(hip.h, C.byref(P), d_rec, d_tmp, rec.itemsize, pw, bd, pw, ph, d_src, pw, d_ev, d_eh,
+                                                        ev.shape[1], ev.shape[0], d_s, C.byref(lvl), C.byref(err)), "dlf search")
+            after = hip.to_host(d_rec, rec.shape, dt)
+            hip.free(d_rec, d_tmp, d_src, d_ev, d_eh, d_s)
+            assert np.array_equal(after, rec), "the unfiltered plane must stay untouched"
+            assert (lvl.value, err.value) == (exp_lvl, best_err.value), (bd, mode, plane, dirn, lvl.value, exp_lvl, err.value, best_err.value)
+            assert sum(1 for v in probes if v >= 0) >= 2

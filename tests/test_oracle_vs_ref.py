@@ -431,3 +431,19 @@ def test_sgr_tables_filter_apply_and_projection(orc, ref):
             ref.svt_apply_selfguided_restoration_c(cvt(pd), w, h, st, ep, xqd, cvt(o1.ctypes.data), w, ptr(tmp), bd, hb)
             orc.orc_sgr_apply(C.c_void_p(pd), dgd.itemsize, w, h, st, ep, xqd, ptr(o2), w, bd)
             assert np.array_equal(o1, o2), (bd, ep, "apply")
+
+
+def test_plane_sse_kernels(orc, ref):
+    """orc_plane_sse == svt_spatial_full_distortion_kernel_c (8-bit) / svt_full_distortion_kernel16_bits_c (16-bit),
+    the two kernels picture_sse_calculations calls (EbDeblockingFilter.c:830-961)."""
+    rng = np.random.default_rng(404)
+    orc.orc_plane_sse.restype = C.c_uint64
+    ref.svt_spatial_full_distortion_kernel_c.restype = C.c_uint64
+    ref.svt_full_distortion_kernel16_bits_c.restype = C.c_uint64
+    for (w, h) in ((4, 4), (37, 19), (128, 64), (641, 130)):
+        a8 = rng.integers(0, 256, (h, w + 11)).astype(np.uint8); b8 = rng.integers(0, 256, (h, w + 2)).astype(np.uint8)
+        assert orc.orc_plane_sse(1, ptr(a8), a8.shape[1], ptr(b8), b8.shape[1], w, h) == \
+            ref.svt_spatial_full_distortion_kernel_c(ptr(a8), 0, a8.shape[1], ptr(b8), 0, b8.shape[1], w, h)
+        a16 = rng.integers(0, 1024, (h, w + 5)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 8)).astype(np.uint16)
+        assert orc.orc_plane_sse(2, ptr(a16), a16.shape[1], ptr(b16), b16.shape[1], w, h) == \
+            ref.svt_full_distortion_kernel16_bits_c(ptr(a16), 0, a16.shape[1], ptr(b16), 0, b16.shape[1], w, h)
