@@ -244,13 +244,14 @@ def main():
             d_sgr_sums[p].zero_()
             h_, w_ = d_cdef_out[p].shape
             ctx.check(L.svt_hip_sgr_search_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_cur[p].data_ptr(),
-                                                     strides[p], w_, h_, US[p], 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
+                                                     strides[p], w_, h_, US[p], int(p > 0), 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
 
     def run_sgr_apply():
         for p in range(3):
             h_, w_ = d_cdef_out[p].shape
             ctx.check(L.svt_hip_sgr_apply_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_sgr_out[p].data_ptr(),
-                                                    strides[p], w_, h_, US[p], d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
+                                                    strides[p], w_, h_, US[p], int(p > 0), d_recon[p].data_ptr(), strides[p],   # stripe context rows from the deblocked picture
+                                                    d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
 
     all_stages = [
         dict(key="pyr", name="pyramids", run=run_pyramids, kernel="downsample_kernel+variance_pyramid_kernel"),

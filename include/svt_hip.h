@@ -271,25 +271,34 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_str
  * (svt_extend_frame, Common/Codec/EbRestoration.c:253); d_* pointers address sample (0,0); strides
  * in samples.  Restoration units are unit_size x unit_size (a multiple of 64) with the last row /
  * column of units absorbing the remainder, i.e. units_x = max((pw + unit_size/2) / unit_size, 1)
- * (av1 loop-restoration unit rule, EbRestoration.c:1413-1515).
+ * (av1 loop-restoration unit rule, EbRestoration.c:1413-1515); unit ROWS start RESTORATION_UNIT_OFFSET >> ss_y
+ * (8 luma / 4 chroma rows) above their nominal position (foreach_rest_unit_in_tile, :1388-1391), so ss_y
+ * (0 luma, 1 4:2:0 chroma) is part of every frame-level call.
  *
  * svt_hip_sgr_filter_plane_dev: svt_av1_selfguided_restoration (common_dsp_rtcd.h:191) for every
  *   processing unit of the plane and one parameter set `ep` (0..15): d_flt0 / d_flt1 int32 planes
  *   (flt_stride), written only for the radii the set uses.
  * svt_hip_sgr_search_plane_dev: the per-(unit, ep) sums svt_get_proj_subspace accumulates
- *   (Encoder/Codec/EbRestorationPick.c:448-496) for every ep in ep_mask, without materialising
- *   flt0 / flt1: d_sums[unit][16][5] += {H00, H01, H11, C0, C1} (exact integers; zero the buffer
- *   first; divide by the unit's pixel count and solve the 2x2 system on the host, :497-538).
- * svt_hip_sgr_apply_plane_dev: svt_apply_selfguided_restoration (common_dsp_rtcd.h:187) with a
- *   per-unit parameter set d_unit_ep[unit] (255 = unit not restored: left untouched) and
- *   d_unit_xqd[unit][2].  Stripe-boundary line substitution (EbRestoration.c:353-453) is the
- *   caller's: pass a plane that already holds the rows the stripe should see. */
+ *   (Encoder/Codec/EbRestorationPick.c:448-496, units as search_selfguided_restoration :583 sees them)
+ *   for every ep in ep_mask, without materialising flt0 / flt1: d_sums[unit][16][5] += {H00, H01, H11,
+ *   C0, C1} (exact integers; zero the buffer first; divide by the unit's pixel count and solve the 2x2
+ *   system on the host, :497-538).
+ * svt_hip_sgr_apply_plane_dev: svt_av1_loop_restoration_filter_frame for the SGRPROJ units of a plane
+ *   (EbRestoration.c:1293 -> svt_av1_loop_restoration_filter_unit :1162 -> sgrproj_filter_stripe :1086 ->
+ *   svt_apply_selfguided_restoration, common_dsp_rtcd.h:187) with a per-unit parameter set
+ *   d_unit_ep[unit] (255 = RESTORE_NONE: the unit is copied) and d_unit_xqd[unit][2].
+ *   d_dbl != NULL gives the normative stripe handling: the 3 context rows above / below every
+ *   (64 >> ss_y)-row stripe are taken from the DEBLOCKED (pre-CDEF) plane d_dbl exactly as
+ *   svt_av1_loop_restoration_save_boundary_lines (:1843) + setup_processing_stripe_boundary (:353-453)
+ *   arrange it (2 saved rows stretched to 3, edge-replicated); the GPU keeps that plane resident, so no
+ *   line buffers are copied.  d_dbl == NULL filters the extended plane as is (the search's view). */
 int svt_hip_sgr_filter_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_plane, int stride, int pw, int ph, int ep,
                                  int32_t *d_flt0, int32_t *d_flt1, int flt_stride);
 int svt_hip_sgr_search_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src,
-                                 int src_stride, int pw, int ph, int unit_size, uint32_t ep_mask, int64_t *d_sums);
+                                 int src_stride, int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int64_t *d_sums);
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride,
-                                int pw, int ph, int unit_size, const uint8_t *d_unit_ep, const int32_t *d_unit_xqd);
+                                int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride,
+                                const uint8_t *d_unit_ep, const int32_t *d_unit_xqd);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
  */
 #include "svt_oracle.h"
 #include <stdlib.h>
+#include <string.h>
 
 static inline int iabs(int v) { return v < 0 ? -v : v; }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -52,3 +52,114 @@ void ref_shim_qparams(int bd, int qindex, int plane, int16_t out[7][2]) {
     }
     for (int k = 0; k < 7; k++) { out[k][0] = src[k][0]; out[k][1] = src[k][1]; }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Loop-restoration frame level: drive the reference's own unit iterator, stripe
+ * boundary save / setup / restore and stripe filters for ONE plane with plain arguments, so that the
+ * oracle's restatement (oracle/sgr_oracle.c: orc_rest_unit_limits, orc_sgr_apply_plane) can be pinned.
+ * Nothing here restates an algorithm: it only builds the structs the reference functions take. */
+#include <stdlib.h>
+#include "Av1Common.h"
+#include "EbRestoration.h"
+#include "common_dsp_rtcd.h"
+
+void save_tile_row_boundary_lines(uint8_t *src, int32_t src_stride, int32_t src_width, int32_t src_height, int32_t use_highbd,
+                                  int32_t plane, Av1Common *cm, int32_t after_cdef, RestorationStripeBoundaries *boundaries);
+void av1_foreach_rest_unit_in_frame(Av1Common *cm, int32_t plane, RestTileStartVisitor on_tile, RestUnitVisitor on_rest_unit, void *priv);
+void svt_av1_loop_restoration_filter_unit(uint8_t need_bounadaries, const RestorationTileLimits *limits, const RestorationUnitInfo *rui,
+                                          const RestorationStripeBoundaries *rsb, RestorationLineBuffers *rlbs,
+                                          const Av1PixelRect *tile_rect, int32_t tile_stripe0, int32_t ss_x, int32_t ss_y,
+                                          int32_t highbd, int32_t bit_depth, uint8_t *data8, int32_t stride, uint8_t *dst8,
+                                          int32_t dst_stride, int32_t *tmpbuf, int32_t optimized_lr);
+
+static int shim_rtcd_ready = 0;
+static void shim_rtcd(void) {
+    if (!shim_rtcd_ready) { setup_common_rtcd_internal(0); shim_rtcd_ready = 1; }
+}
+static int shim_units(int unit_size, int size) { int n = (size + (unit_size >> 1)) / unit_size; return n > 1 ? n : 1; }  /* count_units_in_tile */
+
+typedef struct {
+    int32_t *limits;   /* [unit][4] = h_start, h_end, v_start, v_end */
+    int      n;
+} ShimLimitsCtx;
+static void shim_limits_visitor(const RestorationTileLimits *limits, const Av1PixelRect *tile_rect, int32_t unit_idx, void *priv) {
+    (void)tile_rect;
+    ShimLimitsCtx *c = (ShimLimitsCtx *)priv;
+    int32_t *o = c->limits + 4 * unit_idx;
+    o[0] = limits->h_start; o[1] = limits->h_end; o[2] = limits->v_start; o[3] = limits->v_end;
+    if (unit_idx + 1 > c->n) c->n = unit_idx + 1;
+}
+static Av1Common *shim_cm(int frame_w, int frame_h, int bd, int highbd, int plane, int unit_size) {
+    Av1Common *cm = (Av1Common *)calloc(1, sizeof(Av1Common));
+    cm->frm_size.frame_width = (uint16_t)frame_w; cm->frm_size.frame_height = (uint16_t)frame_h;
+    cm->frm_size.superres_upscaled_width = (uint16_t)frame_w; cm->frm_size.superres_upscaled_height = (uint16_t)frame_h;
+    cm->frm_size.superres_denominator = 8;
+    cm->subsampling_x = 1; cm->subsampling_y = 1; cm->bit_depth = bd; cm->use_highbitdepth = highbd;
+    cm->mi_rows = (frame_h + 3) >> 2; cm->mi_cols = (frame_w + 3) >> 2;
+    const int ss = plane > 0;
+    const int pw = (frame_w + ss) >> ss, ph = (frame_h + ss) >> ss;
+    RestorationInfo *rsi = &cm->rst_info[plane];
+    rsi->restoration_unit_size = unit_size;
+    rsi->frame_restoration_type = RESTORE_SGRPROJ;
+    rsi->horz_units_per_tile = shim_units(unit_size, pw);
+    rsi->vert_units_per_tile = shim_units(unit_size, ph);
+    rsi->units_per_tile = rsi->horz_units_per_tile * rsi->vert_units_per_tile;
+    return cm;
+}
+/* limits of every restoration unit of a plane as av1_foreach_rest_unit_in_frame hands them out; returns the unit count */
+int ref_shim_rest_unit_limits(int frame_w, int frame_h, int plane, int unit_size, int32_t *limits) {
+    Av1Common *cm = shim_cm(frame_w, frame_h, 8, 0, plane, unit_size);
+    ShimLimitsCtx c = {limits, 0};
+    av1_foreach_rest_unit_in_frame(cm, plane, NULL, shim_limits_visitor, &c);
+    free(cm);
+    return c.n;
+}
+
+typedef struct {
+    Av1Common *cm; RestorationInfo *rsi; RestorationLineBuffers *rlbs; int plane, highbd, bd;
+    uint8_t *data8, *dst8; int stride, dst_stride; int32_t *tmpbuf;
+} ShimFilterCtx;
+static void shim_filter_visitor(const RestorationTileLimits *limits, const Av1PixelRect *tile_rect, int32_t unit_idx, void *priv) {
+    ShimFilterCtx *c = (ShimFilterCtx *)priv;   /* filter_frame_on_unit, EbRestoration.c:1269-1291 */
+    svt_av1_loop_restoration_filter_unit(1, limits, &c->rsi->unit_info[unit_idx], &c->rsi->boundaries, c->rlbs, tile_rect, 0, c->plane > 0,
+                                         c->plane > 0, c->highbd, c->bd, c->data8, c->stride, c->dst8, c->dst_stride, c->tmpbuf, 0);
+}
+/* svt_av1_loop_restoration_save_boundary_lines (deblocked frame, then CDEF frame) + svt_av1_loop_restoration_filter_frame for one
+ * plane.  dbl / cdef / dst point at pixel (0,0); cdef needs a 3-pixel writable border (svt_extend_frame fills it);
+ * strides in pixels; unit_ep[u] = parameter set or 255 for RESTORE_NONE; unit_xqd[u][2]. */
+int ref_shim_lr_apply_plane(int plane, int bd, int highbd, int frame_w, int frame_h, void *dbl, int dbl_stride, void *cdef, int stride,
+                            void *dst, int dst_stride, int unit_size, const uint8_t *unit_ep, const int32_t *unit_xqd) {
+    shim_rtcd();
+    Av1Common *cm = shim_cm(frame_w, frame_h, bd, highbd, plane, unit_size);
+    const int ss = plane > 0;
+    const int pw = (frame_w + ss) >> ss, ph = (frame_h + ss) >> ss;
+    RestorationInfo *rsi = &cm->rst_info[plane];
+    rsi->unit_info = (RestorationUnitInfo *)calloc(rsi->units_per_tile, sizeof(RestorationUnitInfo));
+    for (int u = 0; u < rsi->units_per_tile; u++) {
+        rsi->unit_info[u].restoration_type = unit_ep[u] > 15 ? RESTORE_NONE : RESTORE_SGRPROJ;
+        rsi->unit_info[u].sgrproj_info.ep = unit_ep[u] > 15 ? 0 : unit_ep[u];
+        rsi->unit_info[u].sgrproj_info.xqd[0] = unit_xqd[2 * u]; rsi->unit_info[u].sgrproj_info.xqd[1] = unit_xqd[2 * u + 1];
+    }
+    /* svt_av1_alloc_restoration_buffers (EbRestoration.c:1872-1930): stripe count from the luma height, 32-aligned line stride */
+    const int num_stripes = (RESTORATION_UNIT_OFFSET + (cm->mi_rows << 2) + 63) / 64;
+    const int bstride = (pw + 2 * RESTORATION_EXTRA_HORZ + 31) & ~31;
+    const size_t bsize = (size_t)num_stripes * bstride * RESTORATION_CTX_VERT << highbd;
+    rsi->boundaries.stripe_boundary_above = (uint8_t *)calloc(bsize + 64, 1);
+    rsi->boundaries.stripe_boundary_below = (uint8_t *)calloc(bsize + 64, 1);
+    rsi->boundaries.stripe_boundary_stride = bstride;
+    rsi->boundaries.stripe_boundary_size = (int32_t)bsize;
+    uint8_t *dbl8 = highbd ? CONVERT_TO_BYTEPTR(dbl) : (uint8_t *)dbl;
+    uint8_t *cdef8 = highbd ? CONVERT_TO_BYTEPTR(cdef) : (uint8_t *)cdef;
+    uint8_t *dst8 = highbd ? CONVERT_TO_BYTEPTR(dst) : (uint8_t *)dst;
+    save_tile_row_boundary_lines(highbd ? (uint8_t *)dbl : dbl8, dbl_stride, pw, ph, highbd, plane, cm, 0, &rsi->boundaries);
+    save_tile_row_boundary_lines(highbd ? (uint8_t *)cdef : cdef8, stride, pw, ph, highbd, plane, cm, 1, &rsi->boundaries);
+    svt_extend_frame(cdef8, pw, ph, stride, RESTORATION_BORDER, RESTORATION_BORDER, highbd);
+    RestorationLineBuffers *rlbs = (RestorationLineBuffers *)calloc(1, sizeof(RestorationLineBuffers));
+    int32_t *tmpbuf = NULL;
+    if (posix_memalign((void **)&tmpbuf, 32, RESTORATION_TMPBUF_SIZE)) return -1;
+    ShimFilterCtx c = {cm, rsi, rlbs, plane, highbd, bd, cdef8, dst8, stride, dst_stride, tmpbuf};
+    av1_foreach_rest_unit_in_frame(cm, plane, NULL, shim_filter_visitor, &c);
+    free(tmpbuf); free(rlbs); free(rsi->boundaries.stripe_boundary_above); free(rsi->boundaries.stripe_boundary_below);
+    free(rsi->unit_info); free(cm);
+    return 0;
+}

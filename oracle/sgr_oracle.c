@@ -171,3 +171,121 @@ int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int
         }
     return err;
 }
+
+/* ---------------------------------------------------------------- frame level -- */
+/* count_units_in_tile (EbRestoration.c:172-180) */
+int orc_rest_units(int size, int unit_size) { const int n = (size + (unit_size >> 1)) / unit_size; return n > 1 ? n : 1; }
+
+/* foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) for the single-tile frame: limits[u][4] =
+ * {h_start, h_end, v_start, v_end}; unit rows are shifted up by RESTORATION_UNIT_OFFSET >> ss_y,
+ * the last row / column of units absorbs a remainder smaller than half a unit. */
+int orc_rest_unit_limits(int pw, int ph, int ss_y, int unit_size, int32_t *limits) {
+    const int ext = unit_size * 3 / 2, voff = 8 >> ss_y;
+    const int hunits = orc_rest_units(pw, unit_size);
+    int y0 = 0, i = 0, n = 0;
+    while (y0 < ph) {
+        const int rem_h = ph - y0, h = rem_h < ext ? rem_h : unit_size;
+        int v_start = y0, v_end = y0 + h;
+        v_start = v_start - voff > 0 ? v_start - voff : 0;
+        if (v_end < ph) v_end -= voff;
+        int x0 = 0, j = 0;
+        while (x0 < pw) {
+            const int rem_w = pw - x0, w = rem_w < ext ? rem_w : unit_size;
+            int32_t *o = limits + 4 * (i * hunits + j);
+            o[0] = x0; o[1] = x0 + w; o[2] = v_start; o[3] = v_end;
+            x0 += w; j++; n++;
+        }
+        y0 += h; i++;
+    }
+    return n;
+}
+
+/* The integer sums of search_selfguided_restoration (Encoder/Codec/EbRestorationPick.c:583-671) for every unit of a plane and every
+ * parameter set in ep_mask: apply_sgr (:554-581) walks the unit in (64 >> ss) processing units from the unit's own origin, then
+ * svt_get_proj_subspace accumulates over the whole unit.  dgd = pixel (0,0) of the 3-px extended picture.  sums[unit][16][5]. */
+void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void *src, int src_stride, int pw, int ph, int ss_x, int ss_y,
+                          int unit_size, int bd, uint32_t ep_mask, int64_t *sums) {
+    const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
+    int32_t *lim = (int32_t *)malloc(sizeof(int32_t) * 4 * nu);
+    orc_rest_unit_limits(pw, ph, ss_y, unit_size, lim);
+    const int puw = 64 >> ss_x, puh = 64 >> ss_y;
+    for (int u = 0; u < nu; u++) {
+        const int x0 = lim[4 * u], x1 = lim[4 * u + 1], y0 = lim[4 * u + 2], y1 = lim[4 * u + 3], w = x1 - x0, h = y1 - y0;
+        const int fs = ((w + 7) & ~7) + 8;
+        int32_t *f0 = (int32_t *)malloc(sizeof(int32_t) * 2 * fs * h), *f1 = f0 + (size_t)fs * h;
+        const uint8_t *d = (const uint8_t *)dgd + ((size_t)y0 * stride + x0) * pix_bytes;
+        const uint8_t *s = (const uint8_t *)src + ((size_t)y0 * src_stride + x0) * pix_bytes;
+        for (int ep = 0; ep < 16; ep++) {
+            int64_t *o = sums + ((size_t)u * 16 + ep) * 5;
+            if (!((ep_mask >> ep) & 1)) continue;
+            for (int i = 0; i < h; i += puh)
+                for (int j = 0; j < w; j += puw)
+                    orc_sgr_filter(d + ((size_t)i * stride + j) * pix_bytes, pix_bytes, w - j < puw ? w - j : puw, h - i < puh ? h - i : puh, stride,
+                                   f0 + (size_t)i * fs + j, f1 + (size_t)i * fs + j, fs, ep, bd);
+            orc_sgr_proj_sums(s, src_stride, d, stride, pix_bytes, w, h, f0, fs, f1, fs, ep, o);
+        }
+        free(f0);
+    }
+    free(lim);
+}
+
+/* svt_av1_loop_restoration_filter_frame for one plane (EbRestoration.c:1293-1366) = for every unit svt_av1_loop_restoration_filter_unit
+ * (:1162-1249): the unit is filtered stripe by stripe (64 >> ss_y rows, the first 8 >> ss_y shorter); the 3 rows above / below a
+ * stripe are replaced by the DEBLOCKED picture's rows (2 saved rows stretched to 3: get_stripe_boundary_info :321,
+ * setup_processing_stripe_boundary :353-453, saved by save_deblock_boundary_lines :1645-1697 with edge replication) unless the stripe
+ * touches the top / bottom of the frame, where the CDEF picture's own 3-px extension stays.
+ * dbl = deblocked plane, cdef = CDEF output plane with a valid 3-px extension (modified and restored like the reference does);
+ * unit_ep[u] > 15 = RESTORE_NONE (copy). */
+void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y,
+                         int unit_size, int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, void *dst, int dst_stride) {
+    const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
+    int32_t *lim = (int32_t *)malloc(sizeof(int32_t) * 4 * nu);
+    orc_rest_unit_limits(pw, ph, ss_y, unit_size, lim);
+    const int full = 64 >> ss_y, off = 8 >> ss_y, puw = 64 >> ss_x;
+    uint8_t *save = (uint8_t *)malloc((size_t)6 * (pw + 6) * pix_bytes);
+    for (int u = 0; u < nu; u++) {
+        const int x0 = lim[4 * u], x1 = lim[4 * u + 1], v0 = lim[4 * u + 2], v1 = lim[4 * u + 3], uw = x1 - x0;
+        if (unit_ep[u] > 15) {   /* copy_tile */
+            for (int y = v0; y < v1; y++)
+                memcpy((uint8_t *)dst + ((size_t)y * dst_stride + x0) * pix_bytes, (const uint8_t *)cdef + ((size_t)y * stride + x0) * pix_bytes, (size_t)uw * pix_bytes);
+            continue;
+        }
+        int i = 0;
+        while (i < v1 - v0) {
+            const int v = v0 + i;
+            const int first = v == 0, this_h = full - (first ? off : 0), last = v + this_h >= ph;
+            const int tile_stripe = (v + off) / full;
+            const int nominal = full - (tile_stripe == 0 ? off : 0), h = nominal < v1 - v ? nominal : v1 - v;
+            const int lx0 = x0 - 3, lw = uw + 6;   /* columns the filter reads (the reference swaps 4 extra px each side) */
+            uint8_t *sv = save;
+            for (int pass = 0; pass < 2; pass++) {            /* 0: above, 1: below */
+                if (pass == 0 ? first : last) continue;
+                for (int k = 0; k < 3; k++) {
+                    const int row = pass == 0 ? v - 3 + k : v + h + k;
+                    int srow = pass == 0 ? (v - 2) + (k - 1 > 0 ? k - 1 : 0) : v + h + (k < 1 ? k : 1);
+                    if (srow > ph - 1) srow = ph - 1;   /* lines_to_save == 1: the single line is duplicated */
+                    uint8_t *drow = (uint8_t *)cdef + ((ptrdiff_t)row * stride + lx0) * pix_bytes;
+                    memcpy(sv, drow, (size_t)lw * pix_bytes); sv += (size_t)lw * pix_bytes;
+                    for (int x = 0; x < lw; x++) {
+                        int sx = lx0 + x; sx = sx < 0 ? 0 : (sx > pw - 1 ? pw - 1 : sx);
+                        if (pix_bytes == 1) drow[x] = ((const uint8_t *)dbl)[(size_t)srow * dbl_stride + sx];
+                        else ((uint16_t *)drow)[x] = ((const uint16_t *)dbl)[(size_t)srow * dbl_stride + sx];
+                    }
+                }
+            }
+            for (int j = 0; j < uw; j += puw)   /* sgrproj_filter_stripe[_highbd] (:1086-1160) */
+                orc_sgr_apply((const uint8_t *)cdef + ((size_t)v * stride + x0 + j) * pix_bytes, pix_bytes, uw - j < puw ? uw - j : puw, h, stride, unit_ep[u],
+                              unit_xqd + 2 * u, (uint8_t *)dst + ((size_t)v * dst_stride + x0 + j) * pix_bytes, dst_stride, bd);
+            sv = save;
+            for (int pass = 0; pass < 2; pass++) {            /* restore_processing_stripe_boundary */
+                if (pass == 0 ? first : last) continue;
+                for (int k = 0; k < 3; k++) {
+                    const int row = pass == 0 ? v - 3 + k : v + h + k;
+                    memcpy((uint8_t *)cdef + ((ptrdiff_t)row * stride + lx0) * pix_bytes, sv, (size_t)lw * pix_bytes); sv += (size_t)lw * pix_bytes;
+                }
+            }
+            i += h;
+        }
+    }
+    free(save); free(lim);
+}

@@ -153,6 +153,12 @@ void orc_sgr_apply(const void *dat, int pix_bytes, int w, int h, int stride, int
 void orc_sgr_proj_sums(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                        int f0_stride, const int32_t *flt1, int f1_stride, int ep, int64_t sums[5]);
 void orc_sgr_solve(const int64_t sums[5], int size, int ep, int32_t xq[2]);
+int orc_rest_units(int size, int unit_size);
+int orc_rest_unit_limits(int pw, int ph, int ss_y, int unit_size, int32_t *limits);
+void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void *src, int src_stride, int pw, int ph, int ss_x, int ss_y,
+                          int unit_size, int bd, uint32_t ep_mask, int64_t *sums);
+void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y,
+                         int unit_size, int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, void *dst, int dst_stride);
 int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                            int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep);
 

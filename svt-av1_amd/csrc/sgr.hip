@@ -41,13 +41,33 @@ struct TileLds {
 
 __device__ __forceinline__ uint32_t rp2u(uint32_t v, int n) { return n == 0 ? v : ((v + (1u << (n - 1))) >> n); }
 
+// Where the rows just outside a restoration stripe come from (svt_av1_loop_restoration_filter_unit, EbRestoration.c:1162-1249):
+// the stripe [sy0, sy1) sees the DEBLOCKED picture in its 3 context rows above (rows sy0-2, sy0-2, sy0-1) and below
+// (sy1, sy1+1, sy1+1, bottom-clamped) -- setup_processing_stripe_boundary :353-453 with the lines of
+// save_deblock_boundary_lines :1645-1697 (edge-replicated) -- unless it touches the top / bottom of the frame.
 template <typename PIX>
-__device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restrict__ plane, int stride, int pw, int ph, int x0, int y0, int tid) {
+struct StripeCtx {
+    const PIX* dbl;   // nullptr: no substitution (search, plain filter)
+    int dbl_stride, sy0, sy1, above, below;
+};
+
+template <typename PIX>
+__device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restrict__ plane, int stride, int pw, int ph, int x0, int y0, int tid,
+                                                 const StripeCtx<PIX> sc = StripeCtx<PIX>{nullptr, 0, 0, 0, 0, 0}) {
     if (tid < 256) L.xtab[tid] = tid == 0 ? 1 : (tid == 255 ? 256 : (uint16_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
     for (int i = tid; i < IH * IW; i += 256) {
         const int r = i / IW, c = i - r * IW;
-        const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
-        L.in[i] = (uint16_t)plane[(ptrdiff_t)y * stride + x];
+        const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+        uint16_t v;
+        if (sc.above && yy < sc.sy0) {
+            v = (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+        } else if (sc.below && yy >= sc.sy1) {
+            v = (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+        } else {
+            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
+            v = (uint16_t)plane[(ptrdiff_t)y * stride + x];
+        }
+        L.in[i] = v;
     }
     __syncthreads();
     for (int i = tid; i < PH1 * PW; i += 256) {            // r = 1: position (i/PW - 1, i%PW - 1)
@@ -144,17 +164,19 @@ sgr_filter_kernel(const PIX* __restrict__ plane, int stride, int pw, int ph, int
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
 sgr_search_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                  int units_x, int units_y, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
+                  int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
     __shared__ TileLds L;
     __shared__ long long red[4][5];
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
-    const int unit = min(y0 / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    // unit rows start RESTORATION_UNIT_OFFSET >> ss_y above their nominal position (foreach_rest_unit_in_tile,
+    // EbRestoration.c:1388-1391); the tile grid is shifted by the same amount so a tile never straddles two units
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH - voff, tid = threadIdx.x;
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid);
     int32_t sv[4];   // (src << 4) - u per owned pixel; 0 for out-of-picture pixels
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int k = tid + 256 * t, i = k / TW, j = k - i * TW;
-        sv[t] = (x0 + j < pw && y0 + i < ph) ? ((int32_t)src[(size_t)(y0 + i) * src_stride + x0 + j] << 4) - ((int32_t)L.in[(i + 3) * IW + j + 3] << 4) : 0;
+        sv[t] = (x0 + j < pw && y0 + i < ph && y0 + i >= 0) ? ((int32_t)src[(size_t)(y0 + i) * src_stride + x0 + j] << 4) - ((int32_t)L.in[(i + 3) * IW + j + 3] << 4) : 0;
     }
     for (int ep = 0; ep < 16; ep++) {
         if (!((ep_mask >> ep) & 1)) continue;
@@ -164,7 +186,7 @@ sgr_search_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int k = tid + 256 * t, i = k / TW, j = k - i * TW;
-            if (x0 + j >= pw || y0 + i >= ph) continue;
+            if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
             int32_t f0 = 0, f1 = 0;
             filt_px(L, ep, i, j, f0, f1);
             const int32_t u = (int32_t)L.in[(i + 3) * IW + j + 3] << 4;
@@ -220,13 +242,13 @@ __device__ __forceinline__ int32_t row16_sum(int32_t v) {   // every lane of a 1
 template <typename PIX>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                   int units_x, int units_y, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
+                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
     __shared__ unsigned long long acc[16][5];
-    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH, tid = threadIdx.x;
-    const int unit = min(y0 / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (see sgr_search_kernel)
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
 
     {
         const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
@@ -266,13 +288,13 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 
     // ---- the 8 pixels (one column, 8 rows) this lane accumulates
     const int j = tid & 63, i0 = (tid >> 6) * 8;
-    const int nvalid = min(max(ph - (y0 + i0), 0), 8);
+    const int rlo = min(max(-(y0 + i0), 0), 8), rhi = min(max(ph - (y0 + i0), 0), 8);   // rows [rlo, rhi) of the 8 are inside the picture
     const bool colvalid = x0 + j < pw;
     uint32_t X[8]; int32_t SV[8], CX[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         X[r] = in[(i0 + r + 3) * S_IW + j + 3];
-        const int yy = min(y0 + i0 + r, ph - 1), xx = min(x0 + j, pw - 1);
+        const int yy = min(max(y0 + i0 + r, 0), ph - 1), xx = min(x0 + j, pw - 1);
         SV[r] = ((int32_t)src[(size_t)yy * src_stride + xx] - (int32_t)X[r]) << 4;     // (src << 4) - u
         CX[r] = 256 - (int32_t)(X[r] << 13);                                           // rounding - (u << 9)
     }
@@ -340,7 +362,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            if (r < nvalid) {   // wave-uniform
+            if (r >= rlo && r < rhi) {   // wave-uniform
                 if (has0) { h00 += __mul24(D0[r], D0[r]); c0 += __mul24(D0[r], SV[r]); }
                 if (has1) { h11 += __mul24(D1[r], D1[r]); c1 += __mul24(D1[r], SV[r]); }
                 if (has0 && has1) h01 += __mul24(D0[r], D1[r]);
@@ -371,17 +393,33 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 #undef FA_
 #undef FB_
 
-// ---- svt_apply_selfguided_restoration over a plane: per-unit parameter set (255 = unit not restored) and xqd
+// ---- svt_av1_loop_restoration_filter_frame for SGRPROJ units over a plane: per-unit parameter set (255 = RESTORE_NONE: copy) and xqd.
+// dbl != nullptr: normative stripe handling (StripeCtx); tiles are shifted by voff = 8 >> ss_y so that a 64x16 tile lies inside one
+// stripe (stripes are (64 >> ss_y) rows, the first one voff shorter) and inside one unit row.
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
 sgr_apply_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
-                 int units_y, const uint8_t* __restrict__ unit_ep, const int32_t* __restrict__ unit_xqd) {
+                 int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
+                 const int32_t* __restrict__ unit_xqd) {
     __shared__ TileLds L;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
-    const int unit = min(y0 / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH - voff, tid = threadIdx.x;
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     const int ep = unit_ep[unit];
-    if (ep > 15) return;
-    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid);
+    if (ep > 15) {   // copy_tile (EbRestoration.c:1174-1177)
+        for (int k = tid; k < TW * TH; k += 256) {
+            const int i = k / TW, j = k - i * TW;
+            if (x0 + j < pw && y0 + i < ph && y0 + i >= 0) dst[(size_t)(y0 + i) * dst_stride + x0 + j] = dgd[(ptrdiff_t)(y0 + i) * stride + x0 + j];
+        }
+        return;
+    }
+    StripeCtx<PIX> sc{nullptr, 0, 0, 0, 0, 0};
+    if (dbl) {
+        const int s = (y0 + voff) / stripe_h;
+        sc.dbl = dbl; sc.dbl_stride = dbl_stride;
+        sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
+        sc.above = s > 0; sc.below = sc.sy1 < ph;
+    }
+    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid, sc);
     build_ab<BD>(L, ep, tid);
     // svt_decode_xq (EbRestoration.c:707-718)
     const int32_t xqd0 = unit_xqd[2 * unit], xqd1 = unit_xqd[2 * unit + 1];
@@ -391,7 +429,7 @@ sgr_apply_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
     else { xq0 = xqd0; xq1 = 128 - xq0 - xqd1; }
     for (int k = tid; k < TW * TH; k += 256) {
         const int i = k / TW, j = k - i * TW;
-        if (x0 + j >= pw || y0 + i >= ph) continue;
+        if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
         int32_t f0 = 0, f1 = 0;
         filt_px(L, ep, i, j, f0, f1);
         const int32_t u = (int32_t)L.in[(i + 3) * IW + j + 3] << 4;
@@ -414,19 +452,22 @@ extern "C" int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, 
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
-                                         int pw, int ph, int unit_size, int units_x, int units_y, uint32_t ep_mask, int64_t* sums) {
-    dim3 grid((pw + 63) / 64, (ph + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + S_TH - 1) / S_TH);
+                                         int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums) {
+    const int voff = 8 >> ss_y;
+    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
     unsigned long long* s = (unsigned long long*)sums;
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
-    else hipLaunchKernelGGL((sgr_search_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, ep_mask, s);
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+    else hipLaunchKernelGGL((sgr_search_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,
-                                        int ph, int unit_size, int units_x, int units_y, const uint8_t* unit_ep, const int32_t* unit_xqd) {
-    dim3 grid((pw + 63) / 64, (ph + 15) / 16);
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_apply_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, unit_ep, unit_xqd);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, unit_ep, unit_xqd);
-    else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, unit_ep, unit_xqd);
+                                        int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
+                                        const uint8_t* unit_ep, const int32_t* unit_xqd) {
+    const int voff = 8 >> ss_y, sh = 64 >> ss_y;
+    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16);
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_apply_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd);
+    else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd);
     return (int)hipGetLastError();
 }

@@ -447,19 +447,23 @@ int svt_hip_sgr_filter_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void
     return SVT_HIP_OK;
 }
 int svt_hip_sgr_search_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
-                                 int pw, int ph, int unit_size, uint32_t ep_mask, int64_t* d_sums) {
-    if (!c || !d_dgd || !d_src || !d_sums || unit_size < 64 || (unit_size & 63) || !sgr_args_ok(pix_bytes, bd, pw, ph)) return SVT_HIP_ERR_BAD_ARG;
+                                 int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int64_t* d_sums) {
+    if (!c || !d_dgd || !d_src || !d_sums || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) || !sgr_args_ok(pix_bytes, bd, pw, ph))
+        return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size,
-                                                        sgr_units(pw, unit_size), sgr_units(ph, unit_size), ep_mask & 0xFFFFu, d_sums);
+                                                        sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, ep_mask & 0xFFFFu, d_sums);
     if (e != hipSuccess) return fail(c, e, "sgr search launch");
     return SVT_HIP_OK;
 }
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw,
-                                int ph, int unit_size, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd) {
-    if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || unit_size < 64 || (unit_size & 63) || !sgr_args_ok(pix_bytes, bd, pw, ph))
+                                int ph, int unit_size, int ss_y, const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep,
+                                const int32_t* d_unit_xqd) {
+    if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
+        !sgr_args_ok(pix_bytes, bd, pw, ph))
         return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sgr_apply(c->stream, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size,
-                                                       sgr_units(pw, unit_size), sgr_units(ph, unit_size), d_unit_ep, d_unit_xqd);
+                                                       sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_dbl, dbl_stride, d_unit_ep,
+                                                       d_unit_xqd);
     if (e != hipSuccess) return fail(c, e, "sgr apply launch");
     return SVT_HIP_OK;
 }

@@ -39,7 +39,8 @@ int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int src_stride, 
 int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, const void* plane, int stride, int pw, int ph, int ep, int32_t* flt0,
                               int32_t* flt1, int flt_stride);
 int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
-                              int ph, int unit_size, int units_x, int units_y, uint32_t ep_mask, int64_t* sums);
+                              int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums);
 int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph,
-                             int unit_size, int units_x, int units_y, const uint8_t* unit_ep, const int32_t* unit_xqd);
+                             int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride, const uint8_t* unit_ep,
+                             const int32_t* unit_xqd);
 }

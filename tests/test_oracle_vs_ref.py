@@ -447,3 +447,39 @@ def test_plane_sse_kernels(orc, ref):
         a16 = rng.integers(0, 1024, (h, w + 5)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 8)).astype(np.uint16)
         assert orc.orc_plane_sse(2, ptr(a16), a16.shape[1], ptr(b16), b16.shape[1], w, h) == \
             ref.svt_full_distortion_kernel16_bits_c(ptr(a16), 0, a16.shape[1], ptr(b16), 0, b16.shape[1], w, h)
+
+
+def test_restoration_units_and_stripe_apply(orc, ref):
+    """Frame-level loop restoration: the oracle's unit limits and stripe-boundary apply vs the reference's own
+    av1_foreach_rest_unit_in_frame + save_tile_row_boundary_lines + svt_av1_loop_restoration_filter_unit (driven through
+    oracle/ref_shim.c), luma and chroma, 8- and 10-bit, unit sizes 64 / 128, ragged picture sizes."""
+    rng = np.random.default_rng(77)
+    for (fw, fh) in ((200, 152), (328, 264), (64, 48), (136, 200)):
+        for plane in (0, 1):
+            ss = 1 if plane else 0
+            pw, ph = (fw + ss) >> ss, (fh + ss) >> ss
+            for US in (64, 128):
+                nu = orc.orc_rest_units(pw, US) * orc.orc_rest_units(ph, US)
+                lo = np.zeros((nu, 4), np.int32); lr = np.zeros((nu, 4), np.int32)
+                assert orc.orc_rest_unit_limits(pw, ph, ss, US, ptr(lo)) == nu
+                assert ref.ref_shim_rest_unit_limits(fw, fh, plane, US, ptr(lr)) == nu
+                assert np.array_equal(lo, lr), (fw, fh, plane, US)
+                for bd in (8, 10):
+                    dt = np.uint8 if bd == 8 else np.uint16
+                    yy, xx = np.mgrid[0:ph, 0:pw]
+                    base = (90 + 50 * np.sin(xx / 9.0) * np.cos(yy / 6.0) + 25 * (((xx // 8) + (yy // 8)) % 2)) * (1 << (bd - 8))
+                    dbl = np.clip(base + rng.normal(0, 6 * (1 << (bd - 8)), (ph, pw)), 0, (1 << bd) - 1).astype(dt)
+                    cdef = np.clip(dbl.astype(np.int32) + rng.integers(-3, 4, (ph, pw)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(dt)
+                    E = 8   # border of the CDEF picture buffer (the reference swaps 4 extra columns, reads 3)
+                    buf_o = np.ascontiguousarray(np.pad(cdef, E, mode="edge")); buf_r = buf_o.copy()
+                    st = buf_o.shape[1]; off = (E * st + E) * buf_o.itemsize
+                    u_ep = rng.integers(0, 16, nu).astype(np.uint8)
+                    if nu > 2: u_ep[1] = 255
+                    u_xqd = np.stack([rng.integers(-96, 32, nu), rng.integers(-32, 96, nu)], 1).astype(np.int32)
+                    dst_o = np.zeros((ph, pw), dt); dst_r = np.zeros((ph, pw), dt)
+                    orc.orc_sgr_apply_plane(ptr(dbl), pw, C.c_void_p(buf_o.ctypes.data + off), st, buf_o.itemsize, pw, ph, ss, ss, US, bd,
+                                            ptr(u_ep), ptr(u_xqd), ptr(dst_o), pw)
+                    assert ref.ref_shim_lr_apply_plane(plane, bd, int(bd > 8), fw, fh, ptr(dbl), pw, C.c_void_p(buf_r.ctypes.data + off), st,
+                                                       ptr(dst_r), pw, US, ptr(u_ep), ptr(u_xqd)) == 0
+                    assert np.array_equal(dst_o, dst_r), (fw, fh, plane, US, bd, np.argwhere(dst_o != dst_r)[:5])
+                    assert np.array_equal(buf_o, buf_r), "the CDEF picture must be restored after the stripes"

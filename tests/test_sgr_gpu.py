@@ -47,40 +47,63 @@ def test_filter_search_apply(hip, orc, bd):
                 p = C.c_void_p(ext.ctypes.data + off + (y0 * st + x0) * ext.itemsize)
                 orc.orc_sgr_filter(p, ext.itemsize, pw, ph, st, C.c_void_p(f0.ctypes.data + (y0 * w + x0) * 4), C.c_void_p(f1.ctypes.data + (y0 * w + x0) * 4), w, ep, bd)
         return f0, f1
-    e_sums = np.zeros((ux * uy, 16, 5), np.int64)
     d_f0, d_f1 = hip.empty(w * h * 4), hip.empty(w * h * 4)
     for ep in range(16):
         f0, f1 = orc_filter(ep)
         hip.check(hip.L.svt_hip_sgr_filter_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, w, h, ep, d_f0, d_f1, w), "filter")
         if prm[ep][0] > 0: assert np.array_equal(hip.to_host(d_f0, (h, w), np.int32), f0), ("flt0", bd, ep)
         if prm[ep][1] > 0: assert np.array_equal(hip.to_host(d_f1, (h, w), np.int32), f1), ("flt1", bd, ep)
-        for uyi in range(uy):
-            for uxi in range(ux):
-                x0, y0 = uxi * US, uyi * US
-                x1 = w if uxi == ux - 1 else x0 + US; y1 = h if uyi == uy - 1 else y0 + US
-                s = (C.c_int64 * 5)()
-                orc.orc_sgr_proj_sums(C.c_void_p(src.ctypes.data + (y0 * w + x0) * src.itemsize), w, C.c_void_p(ext.ctypes.data + off + (y0 * st + x0) * ext.itemsize), st,
-                                      ext.itemsize, x1 - x0, y1 - y0, C.c_void_p(f0.ctypes.data + (y0 * w + x0) * 4), w, C.c_void_p(f1.ctypes.data + (y0 * w + x0) * 4), w, ep, s)
-                e_sums[uyi * ux + uxi, ep] = list(s)
-    d_sums = hip.to_device(np.zeros_like(e_sums))
-    hip.check(hip.L.svt_hip_sgr_search_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, 0xFFFF, d_sums), "search")
-    assert np.array_equal(hip.to_host(d_sums, e_sums.shape, np.int64), e_sums)
-    # apply: per-unit parameter set + xqd, one unit left unrestored
-    rng = np.random.default_rng(3)
-    u_ep = rng.integers(0, 16, ux * uy).astype(np.uint8); u_ep[2] = 255
-    u_xqd = np.stack([rng.integers(-96, 32, ux * uy), rng.integers(-32, 96, ux * uy)], 1).astype(np.int32)
-    exp = ext[EXT:EXT + h, EXT:EXT + w].copy()
-    for uyi in range(uy):
-        for uxi in range(ux):
-            u = uyi * ux + uxi
-            if u_ep[u] > 15: continue
-            x0, y0 = uxi * US, uyi * US
-            x1 = w if uxi == ux - 1 else x0 + US; y1 = h if uyi == uy - 1 else y0 + US
-            orc.orc_sgr_apply(C.c_void_p(ext.ctypes.data + off + (y0 * st + x0) * ext.itemsize), ext.itemsize, x1 - x0, y1 - y0, st, int(u_ep[u]),
-                              ptr(np.ascontiguousarray(u_xqd[u])), C.c_void_p(exp.ctypes.data + (y0 * w + x0) * exp.itemsize), w, bd)
-    d_dst = hip.to_device(ext[EXT:EXT + h, EXT:EXT + w].copy()); d_ep, d_xqd = hip.to_device(u_ep), hip.to_device(u_xqd)
-    hip.check(hip.L.svt_hip_sgr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_dst, w, w, h, US, d_ep, d_xqd), "apply")
-    got = hip.to_host(d_dst, (h, w), ext.dtype)
-    assert (exp != ext[EXT:EXT + h, EXT:EXT + w]).any()
-    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
-    hip.free(d_ext, d_src, d_f0, d_f1, d_sums, d_dst, d_ep, d_xqd)
+    hip.free(d_ext, d_src, d_f0, d_f1)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_search_and_stripe_apply(hip, orc, bd, ss):
+    """Frame level: projection sums per restoration unit and the stripe-aware apply vs the oracle functions
+    that tests/test_oracle_vs_ref.py pins to av1_foreach_rest_unit_in_frame / svt_av1_loop_restoration_filter_unit:
+    unit rows offset by 8 >> ss_y, stripes of 64 >> ss_y rows seeing the deblocked picture across their boundaries."""
+    for (w, h, US) in ((200, 152, 64), (328, 264, 128)):
+        src, ext = make_planes(w, h, bd, 50 + bd + ss)
+        st = ext.shape[1]
+        off = (EXT * st + EXT) * ext.itemsize
+        rng = np.random.default_rng(3 + ss)
+        dbl = np.clip(ext[EXT:EXT + h, EXT:EXT + w].astype(np.int32) + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(ext.dtype)
+        ux, uy = units(w, US), units(h, US)
+        d_ext, d_src, d_dbl = hip.to_device(ext), hip.to_device(src), hip.to_device(dbl)
+        # --- search sums, all 16 sets and a sparse mask (sets 11-13 alias 2/5/8 inside the kernel)
+        for mask in (0xFFFF, 0x3801, 0x0124):
+            e_sums = np.zeros((ux * uy, 16, 5), np.int64)
+            orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_sums))
+            d_sums = hip.to_device(np.zeros_like(e_sums))
+            hip.check(hip.L.svt_hip_sgr_search_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_sums), "search")
+            got = hip.to_host(d_sums, e_sums.shape, np.int64)
+            hip.free(d_sums)
+            assert np.array_equal(got, e_sums), (bd, ss, w, h, US, hex(mask), np.argwhere(got != e_sums)[:5])
+        # --- apply: per-unit parameter set + xqd, one unit RESTORE_NONE; with and without stripe boundaries
+        u_ep = rng.integers(0, 16, ux * uy).astype(np.uint8); u_ep[2] = 255
+        u_xqd = np.stack([rng.integers(-96, 32, ux * uy), rng.integers(-32, 96, ux * uy)], 1).astype(np.int32)
+        d_ep, d_xqd = hip.to_device(u_ep), hip.to_device(u_xqd)
+        work = ext.copy()
+        exp = np.zeros((h, w), ext.dtype)
+        orc.orc_sgr_apply_plane(ptr(dbl), w, C.c_void_p(work.ctypes.data + off), st, ext.itemsize, w, h, ss, ss, US, bd, ptr(u_ep), ptr(u_xqd), ptr(exp), w)
+        assert np.array_equal(work, ext)
+        d_dst = hip.to_device(np.zeros((h, w), ext.dtype))
+        hip.check(hip.L.svt_hip_sgr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_dst, w, w, h, US, ss, d_dbl, w, d_ep, d_xqd), "apply")
+        got = hip.to_host(d_dst, (h, w), ext.dtype)
+        assert (exp != ext[EXT:EXT + h, EXT:EXT + w]).any()
+        assert np.array_equal(got, exp), (bd, ss, w, h, US, np.argwhere(got != exp)[:5])
+        # without the deblocked plane every unit is filtered from the extended CDEF picture as is (the search's view of the filter)
+        exp2 = np.zeros((h, w), ext.dtype)
+        lim = np.zeros((ux * uy, 4), np.int32)
+        orc.orc_rest_unit_limits(w, h, ss, US, ptr(lim))
+        for u, (x0, x1, y0, y1) in enumerate(lim):
+            if u_ep[u] > 15:
+                exp2[y0:y1, x0:x1] = ext[EXT + y0:EXT + y1, EXT + x0:EXT + x1]
+                continue
+            orc.orc_sgr_apply(C.c_void_p(ext.ctypes.data + off + (int(y0) * st + int(x0)) * ext.itemsize), ext.itemsize, int(x1 - x0), int(y1 - y0), st, int(u_ep[u]),
+                              ptr(np.ascontiguousarray(u_xqd[u])), C.c_void_p(exp2.ctypes.data + (int(y0) * w + int(x0)) * exp2.itemsize), w, bd)
+        hip.check(hip.L.svt_hip_sgr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_dst, w, w, h, US, ss, None, 0, d_ep, d_xqd), "apply")
+        got2 = hip.to_host(d_dst, (h, w), ext.dtype)
+        assert np.array_equal(got2, exp2), (bd, ss, "no stripes", np.argwhere(got2 != exp2)[:5])
+        assert (exp2 != exp).any(), "stripe boundaries must matter on this content"
+        hip.free(d_ext, d_src, d_dbl, d_dst, d_ep, d_xqd)
