@@ -1,0 +1,100 @@
+/*
+ * svt_hip_rtcd.h — per-call wrappers with the reference's RTCD signatures ("per-call
+ * pointer-compatible wrappers ... installed by setup_rtcd_hip()").
+ *
+ * The production boundary is the batched ABI in svt_hip.h (one call = one kernel class over a frame).
+ * These wrappers exist so that (a) the reference's own unit tests / a bring-up build can run every
+ * call site through the GPU kernels one block at a time and compare, and (b) a maintainer can switch
+ * pointers over incrementally.  Each wrapper stages its host buffers to the device, launches the SAME
+ * kernel the batched entry point uses with a batch of one, and copies the result back: exact, slow.
+ *
+ * Signatures are the ones in Source/Lib/Encoder/Codec/aom_dsp_rtcd.h and
+ * Source/Lib/Common/Codec/common_dsp_rtcd.h (line numbers next to each member).  Struct parameters are
+ * declared layout-compatible here so the header needs none of the reference's headers.
+ *
+ * Error convention: a wrapper never reports failure through its signature; if the HIP
+ * path fails it logs to stderr and calls the C pointer that was in the table when
+ * svt_hip_setup_rtcd() ran (a NULL saved pointer + a HIP failure aborts loudly, never a silent CPU
+ * fallback inside the product path: the fallback is the REFERENCE's own function, supplied by the caller).
+ * Thread safety: wrappers serialise on one mutex (the reference calls these pointers from many
+ * threads); the batched ABI is the concurrent path.
+ */
+#ifndef SVT_HIP_RTCD_H
+#define SVT_HIP_RTCD_H
+#include <stdint.h>
+#include "svt_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* InterpFilterParams / ConvolveParams, Source/Lib/Common/Codec/EbDefinitions.h:493-498 / :379-392 */
+typedef struct {
+    const int16_t *filter_ptr;
+    uint16_t       taps, subpel_shifts;
+    uint8_t        interp_filter; /* InterpFilter (ATTRIBUTE_PACKED enum) */
+} SvtHipInterpFilterParams;
+typedef struct {
+    int32_t   ref, do_average;
+    uint16_t *dst; /* ConvBufType* */
+    int32_t   dst_stride, round_0, round_1, plane, is_compound, use_jnt_comp_avg, fwd_offset, bck_offset, use_dist_wtd_comp_avg;
+} SvtHipConvolveParams;
+
+typedef void (*SvtHipSadLoopFn)(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                                uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
+                                uint32_t src_stride_raw, int16_t search_area_width, int16_t search_area_height);
+typedef uint32_t (*SvtHipNxmSadFn)(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height,
+                                   uint32_t width);
+typedef uint32_t (*SvtHipSadWxHFn)(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride);
+typedef unsigned (*SvtHipVarWxHFn)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned *sse);
+typedef void (*SvtHipConvolveSrFn)(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, int32_t w, int32_t h,
+                                   SvtHipInterpFilterParams *filter_params_x, SvtHipInterpFilterParams *filter_params_y,
+                                   const int32_t subpel_x_q4, const int32_t subpel_y_q4, SvtHipConvolveParams *conv_params);
+typedef void (*SvtHipHbdConvolveSrFn)(const uint16_t *src, int32_t src_stride, uint16_t *dst, int32_t dst_stride, int32_t w, int32_t h,
+                                      const SvtHipInterpFilterParams *filter_params_x, const SvtHipInterpFilterParams *filter_params_y,
+                                      const int32_t subpel_x_q4, const int32_t subpel_y_q4, SvtHipConvolveParams *conv_params, int32_t bd);
+typedef void (*SvtHipFwdTxfmFn)(int16_t *input, int32_t *output, uint32_t input_stride, uint8_t transform_type, uint8_t bit_depth);
+typedef void (*SvtHipInvTxfmSqFn)(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w,
+                                  uint8_t tx_type, int32_t bd);
+typedef void (*SvtHipInvTxfmRectFn)(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w,
+                                    uint8_t tx_type, uint8_t tx_size, int32_t eob, int32_t bd);
+typedef void (*SvtHipInvTxfmRect4Fn)(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w,
+                                     uint8_t tx_type, uint8_t tx_size, int32_t bd);
+typedef void (*SvtHipSgrFilterFn)(const uint8_t *dgd8, int32_t width, int32_t height, int32_t stride, int32_t *flt0, int32_t *flt1,
+                                  int32_t flt_stride, int32_t sgr_params_idx, int32_t bit_depth, int32_t highbd);
+typedef void (*SvtHipSgrApplyFn)(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd,
+                                 uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd);
+
+/* The 22 block sizes of svt_aom_sad{W}x{H} / svt_aom_variance{W}x{H} in BlockSize order
+ * (aom_dsp_rtcd.h:334-336, :524): index = position in this list. */
+#define SVT_HIP_RTCD_BLOCK_SIZES(X) /* X(index, W, H) */ \
+    X(0, 4, 4) X(1, 4, 8) X(2, 8, 4) X(3, 8, 8) X(4, 8, 16) X(5, 16, 8) X(6, 16, 16) X(7, 16, 32) X(8, 32, 16) X(9, 32, 32) X(10, 32, 64) X(11, 64, 32) X(12, 64, 64) X(13, 64, 128) X(14, 128, 64) X(15, 128, 128) X(16, 4, 16) X(17, 16, 4) X(18, 8, 32) X(19, 32, 8) X(20, 16, 64) X(21, 64, 16)
+/* The 14 forward transform sizes without a 64-point dimension, TxSize order (aom_dsp_rtcd.h:129-135); the 64-point
+ * sizes only exist fused with svt_handle_transform64x* in the batched entry point (packed 32x32 output). */
+#define SVT_HIP_RTCD_FWD_SIZES(X) /* X(index, TxSize, W, H) */ \
+    X(0, 0, 4, 4) X(1, 1, 8, 8) X(2, 2, 16, 16) X(3, 3, 32, 32) X(4, 5, 4, 8) X(5, 6, 8, 4) X(6, 7, 8, 16) X(7, 8, 16, 8) X(8, 9, 16, 32) X(9, 10, 32, 16) X(10, 13, 4, 16) X(11, 14, 16, 4) X(12, 15, 8, 32) X(13, 16, 32, 8)
+
+typedef struct SvtHipRtcd {
+    SvtHipSadLoopFn       svt_sad_loop_kernel;              /* aom_dsp_rtcd.h:597 */
+    SvtHipNxmSadFn        svt_nxm_sad_kernel;               /* :644 */
+    SvtHipSadWxHFn        svt_aom_sad[22];                  /* :334 svt_aom_sad{W}x{H}, SVT_HIP_RTCD_BLOCK_SIZES order */
+    SvtHipVarWxHFn        svt_aom_variance[22];             /* :524 */
+    SvtHipVarWxHFn        svt_aom_highbd_10_variance[22];   /* :568 (uint8_t* = CONVERT_TO_BYTEPTR(uint16_t*)) */
+    SvtHipConvolveSrFn    svt_av1_convolve_2d_sr, svt_av1_convolve_x_sr, svt_av1_convolve_y_sr, svt_av1_convolve_2d_copy_sr; /* common_dsp_rtcd.h:197-209 */
+    SvtHipHbdConvolveSrFn svt_av1_highbd_convolve_2d_sr, svt_av1_highbd_convolve_x_sr, svt_av1_highbd_convolve_y_sr,
+                          svt_av1_highbd_convolve_2d_copy_sr;                                                              /* :219-229 */
+    SvtHipFwdTxfmFn       svt_av1_fwd_txfm2d[14];           /* aom_dsp_rtcd.h:129-135, SVT_HIP_RTCD_FWD_SIZES order */
+    SvtHipInvTxfmSqFn     svt_av1_inv_txfm2d_add_sq[5];     /* common_dsp_rtcd.h:120-128: 4x4, 8x8, 16x16, 32x32, 64x64 */
+    SvtHipInvTxfmRectFn   svt_av1_inv_txfm2d_add_rect;      /* :129-148: rectangular sizes with both sides >= 8 (tx_size, eob arguments) */
+    SvtHipInvTxfmRect4Fn  svt_av1_inv_txfm2d_add_rect4;     /* :145-154: 4x8, 8x4, 4x16, 16x4 (tx_size argument, no eob) */
+    SvtHipSgrFilterFn     svt_av1_selfguided_restoration;   /* :191 */
+    SvtHipSgrApplyFn      svt_apply_selfguided_restoration; /* :187 */
+} SvtHipRtcd;
+
+/* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the
+ * corresponding *_hip wrapper bound to ctx; the incoming pointers are kept as the failure fallbacks. */
+int svt_hip_setup_rtcd(SvtHipCtx *ctx, SvtHipRtcd *table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,294 @@
+// rtcd_hip.cpp — per-call wrappers with the reference's RTCD signatures (include/svt_hip_rtcd.h).
+// Every wrapper stages its host operands into a small device arena, launches the batched entry point of
+// include/svt_hip.h with a batch of ONE, and copies the result back.  No arithmetic happens on the host.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include "../../include/svt_hip_rtcd.h"
+#include "svt_hip_internal.h"
+#include "interp_kernels.h"
+
+namespace {
+
+std::mutex  g_mu;
+SvtHipCtx*  g_ctx = nullptr;
+SvtHipRtcd  g_c;                 // the pointers that were installed before us (failure fallbacks)
+const int16_t h_interp[6][16][8] = SVT_HIP_INTERP_TABLE;
+
+struct Slot { void* p = nullptr; size_t cap = 0; };
+Slot g_slot[6];
+
+void* dev(int i, size_t bytes) {   // device scratch, grown on demand (called with g_mu held)
+    Slot& s = g_slot[i];
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (s.cap < bytes) {
+        if (s.p) (void)hipFree(s.p);
+        s.p = nullptr; s.cap = 0;
+        if (hipMalloc(&s.p, bytes + 256) != hipSuccess) return nullptr;
+        s.cap = bytes;
+    }
+    return s.p;
+}
+hipStream_t stream() { return (hipStream_t)svt_hip_ctx_stream(g_ctx); }
+
+// host rectangle -> packed device plane of pitch `dpitch` bytes
+bool up2d(void* d, size_t dpitch, const void* h, size_t hpitch, size_t wbytes, size_t rows) {
+    return hipMemcpy2DAsync(d, dpitch, h, hpitch, wbytes, rows, hipMemcpyHostToDevice, stream()) == hipSuccess;
+}
+bool down2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t wbytes, size_t rows) {
+    return hipMemcpy2DAsync(h, hpitch, d, dpitch, wbytes, rows, hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+           hipStreamSynchronize(stream()) == hipSuccess;
+}
+bool up(void* d, const void* h, size_t bytes) { return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream()) == hipSuccess; }
+bool down(void* h, const void* d, size_t bytes) {
+    return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream()) == hipSuccess && hipStreamSynchronize(stream()) == hipSuccess;
+}
+[[noreturn]] void die(const char* what) {
+    std::fprintf(stderr, "libsvtav1_hip: %s failed on the device and no fallback pointer was installed (%s)\n", what,
+                 g_ctx ? svt_hip_last_error(g_ctx) : "no context");
+    std::abort();
+}
+#define FALLBACK(name, member, ...)                                                                    \
+    do {                                                                                               \
+        std::fprintf(stderr, "libsvtav1_hip: %s fell back to the installed C pointer (%s)\n", name,    \
+                     g_ctx ? svt_hip_last_error(g_ctx) : "no context");                                 \
+        if (!g_c.member) die(name);                                                                    \
+        return g_c.member(__VA_ARGS__);                                                                \
+    } while (0)
+inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------- SAD
+void sad_loop_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t bh, uint32_t bw, uint64_t* best_sad,
+                  int16_t* xc, int16_t* yc, uint32_t src_stride_raw, int16_t saw, int16_t sah) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    bool ok = g_ctx && src_stride_raw && bw && bh && saw > 0 && sah > 0 && (ref_stride % src_stride_raw) == 0;
+    // sub-SAD convention: the caller doubles both strides and halves the height; candidate rows advance by the raw stride
+    const int step = ok ? (int)(ref_stride / src_stride_raw) : 1;
+    ok = ok && (step == 1 || step == 2);
+    if (ok) {
+        const int srows = ((int)bh - 1) * step + 1, rrows = (sah - 1) + srows, rw = saw + (int)bw - 1;
+        const size_t sp = rup(bw, 4), rp = rup((size_t)rw + 8, 4);
+        uint8_t *d_src = (uint8_t*)dev(0, sp * srows + 64), *d_ref = (uint8_t*)dev(1, rp * (rrows + 1) + 64);
+        SvtHipSadLoop job = {0, 0, 0, 0, (int16_t)bw, (int16_t)(bh * step), saw, sah, (int16_t)step, 0};
+        void* d_job = dev(2, sizeof(job)); uint32_t* d_out = (uint32_t*)dev(3, 16);
+        const uint32_t init[4] = {0xffffffu, 0, 0, 0};
+        struct { uint32_t sad; int16_t xy[2]; uint32_t pad[2]; } res;
+        ok = d_src && d_ref && d_job && d_out && up2d(d_src, sp, src, src_stride / step, bw, srows) &&
+             up2d(d_ref, rp, ref, src_stride_raw, rw, rrows) && up(d_job, &job, sizeof(job)) && up(d_out, init, sizeof(init)) &&
+             svt_hip_sad_loop_batch_dev(g_ctx, d_src, (int)sp, d_ref, (int)rp, (const SvtHipSadLoop*)d_job, 1, d_out, (int16_t*)(d_out + 1)) == 0 &&
+             down(&res, d_out, 8);
+        if (ok) {
+            *best_sad = res.sad;   // EbComputeSAD_C.c:73: 0xffffff when nothing beat it (centres untouched)
+            if (res.sad != 0xffffffu) { *xc = res.xy[0]; *yc = res.xy[1]; }
+            return;
+        }
+    }
+    FALLBACK("svt_sad_loop_kernel", svt_sad_loop_kernel, src, src_stride, ref, ref_stride, bh, bw, best_sad, xc, yc, src_stride_raw, saw, sah);
+}
+
+bool pair_stage(int pix_bytes, const void* a, int a_stride, const void* b, int b_stride, int w, int h, void** da, void** db, void** dj, uint32_t** dout,
+                size_t* pitch) {
+    const size_t p = rup((size_t)w * pix_bytes, 4);
+    *pitch = p;
+    *da = dev(0, p * h + 64); *db = dev(1, p * h + 64); *dj = dev(2, sizeof(SvtHipBlkPair)); *dout = (uint32_t*)dev(3, 16);
+    SvtHipBlkPair job = {0, 0, 0, 0, (uint16_t)w, (uint16_t)h};
+    return *da && *db && *dj && *dout && up2d(*da, p, a, (size_t)a_stride * pix_bytes, (size_t)w * pix_bytes, h) &&
+           up2d(*db, p, b, (size_t)b_stride * pix_bytes, (size_t)w * pix_bytes, h) && up(*dj, &job, sizeof(job));
+}
+bool sad_generic(const uint8_t* a, int a_stride, const uint8_t* b, int b_stride, int w, int h, uint32_t* out) {
+    void *da, *db, *dj; uint32_t* dout; size_t p;
+    return g_ctx && pair_stage(1, a, a_stride, b, b_stride, w, h, &da, &db, &dj, &dout, &p) &&
+           svt_hip_block_sad_batch_dev(g_ctx, 1, da, (int)p, db, (int)p, (const SvtHipBlkPair*)dj, 1, dout) == 0 && down(out, dout, 4);
+}
+uint32_t nxm_sad_hip(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t r;
+    if (sad_generic(src, (int)src_stride, ref, (int)ref_stride, (int)width, (int)height, &r)) return r;
+    FALLBACK("svt_nxm_sad_kernel", svt_nxm_sad_kernel, src, src_stride, ref, ref_stride, height, width);
+}
+bool var_generic(int pix_bytes, int bd, const void* a, int a_stride, const void* b, int b_stride, int w, int h, unsigned* var, unsigned* sse) {
+    void *da, *db, *dj; uint32_t* dout; size_t p; uint32_t res[2];
+    if (!(g_ctx && pair_stage(pix_bytes, a, a_stride, b, b_stride, w, h, &da, &db, &dj, &dout, &p) &&
+          svt_hip_block_variance_batch_dev(g_ctx, pix_bytes, bd, da, (int)(p / pix_bytes), db, (int)(p / pix_bytes), (const SvtHipBlkPair*)dj, 1, dout, dout + 1) == 0 &&
+          down(res, dout, 8)))
+        return false;
+    *var = res[0]; *sse = res[1];
+    return true;
+}
+template <int IDX, int W, int H> uint32_t sad_wxh_hip(const uint8_t* a, int as, const uint8_t* b, int bs) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t r;
+    if (sad_generic(a, as, b, bs, W, H, &r)) return r;
+    FALLBACK("svt_aom_sadWxH", svt_aom_sad[IDX], a, as, b, bs);
+}
+template <int IDX, int W, int H> unsigned var_wxh_hip(const uint8_t* a, int as, const uint8_t* b, int bs, unsigned* sse) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    unsigned v;
+    if (var_generic(1, 8, a, as, b, bs, W, H, &v, sse)) return v;
+    FALLBACK("svt_aom_varianceWxH", svt_aom_variance[IDX], a, as, b, bs, sse);
+}
+template <int IDX, int W, int H> unsigned var10_wxh_hip(const uint8_t* a8, int as, const uint8_t* b8, int bs, unsigned* sse) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    unsigned v;   // CONVERT_TO_SHORTPTR (Common/Codec/EbDefinitions.h): the byte pointer carries the uint16_t address >> 1
+    if (var_generic(2, 10, (const void*)((uintptr_t)a8 << 1), as, (const void*)((uintptr_t)b8 << 1), bs, W, H, &v, sse)) return v;
+    FALLBACK("svt_aom_highbd_10_varianceWxH", svt_aom_highbd_10_variance[IDX], a8, as, b8, bs, sse);
+}
+
+// ------------------------------------------------------------------------------------ convolve
+int bank_of(const SvtHipInterpFilterParams* f) {   // the kernel indexes its own normative tables; find the one the caller passed
+    if (!f || !f->filter_ptr) return -1;
+    for (int b = 0; b < 6; b++)
+        if (!std::memcmp(f->filter_ptr, h_interp[b], sizeof(h_interp[b]))) return b;
+    return -1;
+}
+bool conv_generic(int pix_bytes, int bd, const void* src, int src_stride, void* dst, int dst_stride, int w, int h, const SvtHipInterpFilterParams* fx,
+                  const SvtHipInterpFilterParams* fy, int sx, int sy, const SvtHipConvolveParams* cp) {
+    const int bx = bank_of(fx), by = bank_of(fy);
+    if (!g_ctx || bx < 0 || by < 0 || w < 2 || h < 2 || w > 128 || h > 128 || (cp && (cp->is_compound || cp->do_average))) return false;
+    // reference window: 3 samples left / above, 4 right / below, plus the slack the batched kernel's tile loads may touch
+    const int padl = 3, padr = 4 + 16, rw = w + padl + padr, rh = h + padl + padr;
+    const size_t rp = rup((size_t)rw * pix_bytes, 4), dp = rup((size_t)w * pix_bytes, 4);
+    uint8_t* d_ref = (uint8_t*)dev(0, rp * rh + 64); uint8_t* d_dst = (uint8_t*)dev(1, dp * h + 64); void* d_job = dev(2, sizeof(SvtHipConvBlk));
+    if (!d_ref || !d_dst || !d_job || hipMemsetAsync(d_ref, 0, rp * rh, stream()) != hipSuccess) return false;
+    // only the rows / columns the C kernel reads are copied (it reads [-3, +4] around the block: EbInterPrediction.c:349-393)
+    const uint8_t* s0 = (const uint8_t*)src - ((size_t)padl * src_stride + padl) * pix_bytes;
+    SvtHipConvBlk job = {padl, padl, 0, 0, (uint8_t)w, (uint8_t)h, (uint8_t)bx, (uint8_t)by, (uint8_t)(sx & 15), (uint8_t)(sy & 15), 0, 0};
+    return up2d(d_ref, rp, s0, (size_t)src_stride * pix_bytes, (size_t)(w + 7) * pix_bytes, h + 7) && up(d_job, &job, sizeof(job)) &&
+           svt_hip_subpel_predict_batch_dev(g_ctx, pix_bytes, bd, d_ref, (int)(rp / pix_bytes), d_dst, (int)(dp / pix_bytes), (const SvtHipConvBlk*)d_job, 1) == 0 &&
+           down2d(dst, (size_t)dst_stride * pix_bytes, d_dst, dp, (size_t)w * pix_bytes, h);
+}
+#define CONV_WRAPPER(NAME, MEMBER, SXM, SYM)                                                                                                         \
+    void NAME(const uint8_t* src, int32_t ss, uint8_t* dst, int32_t ds, int32_t w, int32_t h, SvtHipInterpFilterParams* fx, SvtHipInterpFilterParams* fy, \
+              const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp) {                                                                        \
+        std::lock_guard<std::mutex> lk(g_mu);                                                                                                        \
+        if (conv_generic(1, 8, src, ss, dst, ds, w, h, fx, fy, (SXM) ? sx : 0, (SYM) ? sy : 0, cp)) return;                                          \
+        FALLBACK("svt_av1_" #MEMBER, svt_av1_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp);                                                                       \
+    }                                                                                                                                                \
+    void NAME##_hbd(const uint16_t* src, int32_t ss, uint16_t* dst, int32_t ds, int32_t w, int32_t h, const SvtHipInterpFilterParams* fx,             \
+                    const SvtHipInterpFilterParams* fy, const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp, int32_t bd) {                  \
+        std::lock_guard<std::mutex> lk(g_mu);                                                                                                        \
+        if ((bd == 8 || bd == 10) && conv_generic(2, bd, src, ss, dst, ds, w, h, fx, fy, (SXM) ? sx : 0, (SYM) ? sy : 0, cp)) return;                 \
+        FALLBACK("highbd " #MEMBER, svt_av1_highbd_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp, bd);                                       \
+    }
+// each reference function ignores the phase of the direction it does not filter (EbInterPrediction.c:395-470)
+CONV_WRAPPER(conv_2d_hip, convolve_2d_sr, 1, 1)
+CONV_WRAPPER(conv_x_hip, convolve_x_sr, 1, 0)
+CONV_WRAPPER(conv_y_hip, convolve_y_sr, 0, 1)
+CONV_WRAPPER(conv_copy_hip, convolve_2d_copy_sr, 0, 0)
+
+// ----------------------------------------------------------------------------------- transforms
+constexpr int kTxW[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+constexpr int kTxH[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+
+bool fwd_generic(int ts, const int16_t* in, int32_t* out, int stride, int tx_type) {
+    const int w = kTxW[ts], h = kTxH[ts];
+    if (!g_ctx) return false;
+    // the batched entry point forms the residual itself; any residual r is src - pred with src = max(r, 0), pred = max(-r, 0)
+    static thread_local uint16_t hs[32 * 32], hp[32 * 32];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) { const int r = in[y * stride + x]; hs[y * w + x] = (uint16_t)(r > 0 ? r : 0); hp[y * w + x] = (uint16_t)(r < 0 ? -r : 0); }
+    uint16_t *d_s = (uint16_t*)dev(0, sizeof(hs)), *d_p = (uint16_t*)dev(1, sizeof(hp)); uint32_t* d_desc = (uint32_t*)dev(2, 16); int32_t* d_c = (int32_t*)dev(3, 32 * 32 * 4);
+    const uint32_t desc = SVT_HIP_TX_DESC(0, 0, tx_type);
+    return d_s && d_p && d_desc && d_c && up(d_s, hs, (size_t)w * h * 2) && up(d_p, hp, (size_t)w * h * 2) && up(d_desc, &desc, 4) &&
+           svt_hip_fwd_txfm_quant_batch_dev(g_ctx, ts, 2, d_s, w, d_p, w, d_desc, 1, nullptr, nullptr, d_c, nullptr, nullptr, nullptr, nullptr, nullptr) == 0 &&
+           down(out, d_c, (size_t)w * h * 4);
+}
+template <int SLOT, int TS> void fwd_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (fwd_generic(TS, in, out, (int)stride, tt)) return;
+    FALLBACK("svt_av1_fwd_txfm2d_WxH", svt_av1_fwd_txfm2d[SLOT], in, out, stride, tt, bd);
+}
+bool inv_generic(int ts, const int32_t* in, uint16_t* out_r, int stride_r, uint16_t* out_w, int stride_w, int tx_type, int bd) {
+    const int w = kTxW[ts], h = kTxH[ts], kw = w < 32 ? w : 32, kh = h < 32 ? h : 32;
+    if (!g_ctx || (bd != 8 && bd != 10)) return false;
+    const size_t p = (size_t)w * 2;
+    int32_t* d_c = (int32_t*)dev(0, (size_t)kw * kh * 4); uint16_t *d_r = (uint16_t*)dev(1, p * h), *d_w = (uint16_t*)dev(3, p * h); uint32_t* d_desc = (uint32_t*)dev(2, 16);
+    const uint32_t desc = SVT_HIP_TX_DESC(0, 0, tx_type);
+    return d_c && d_r && d_w && d_desc && up(d_c, in, (size_t)kw * kh * 4) && up2d(d_r, p, out_r, (size_t)stride_r * 2, p, h) && up(d_desc, &desc, 4) &&
+           svt_hip_inv_txfm_add_batch_dev(g_ctx, ts, 2, bd, d_c, d_r, w, d_w, w, d_desc, 1) == 0 && down2d(out_w, (size_t)stride_w * 2, d_w, p, p, h);
+}
+template <int SLOT, int TS> void inv_sq_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, int32_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (inv_generic(TS, in, r, sr, wv, sw, tt, bd)) return;
+    FALLBACK("svt_av1_inv_txfm2d_add (square)", svt_av1_inv_txfm2d_add_sq[SLOT], in, r, sr, wv, sw, tt, bd);
+}
+void inv_rect_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, uint8_t ts, int32_t eob, int32_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ts < 19 && inv_generic(ts, in, r, sr, wv, sw, tt, bd)) return;
+    FALLBACK("svt_av1_inv_txfm2d_add (rect)", svt_av1_inv_txfm2d_add_rect, in, r, sr, wv, sw, tt, ts, eob, bd);
+}
+void inv_rect4_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, uint8_t ts, int32_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ts < 19 && inv_generic(ts, in, r, sr, wv, sw, tt, bd)) return;
+    FALLBACK("svt_av1_inv_txfm2d_add (4xN)", svt_av1_inv_txfm2d_add_rect4, in, r, sr, wv, sw, tt, ts, bd);
+}
+
+// --------------------------------------------------------------------------------- self-guided
+bool sgr_stage(const uint8_t* dat8, int highbd, int w, int h, int stride, void** d_in, size_t* pitch_px) {
+    const int pb = highbd ? 2 : 1;
+    const uint8_t* base = highbd ? (const uint8_t*)((uintptr_t)dat8 << 1) : dat8;
+    const size_t p = rup((size_t)(w + 6) * pb, 4);
+    *pitch_px = p / pb;
+    *d_in = dev(0, p * (h + 6) + 64);
+    return *d_in && up2d(*d_in, p, base - ((size_t)3 * stride + 3) * pb, (size_t)stride * pb, (size_t)(w + 6) * pb, h + 6);
+}
+void sgr_filter_hip(const uint8_t* dgd8, int32_t w, int32_t h, int32_t stride, int32_t* flt0, int32_t* flt1, int32_t fs, int32_t ep, int32_t bd, int32_t highbd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    void* d_in; size_t pp; const int pb = highbd ? 2 : 1;
+    bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 64 && ep >= 0 && ep < 16 && (bd == 8 || bd == 10) && sgr_stage(dgd8, highbd, w, h, stride, &d_in, &pp);
+    if (ok) {
+        int32_t *d_f0 = (int32_t*)dev(1, (size_t)w * h * 4), *d_f1 = (int32_t*)dev(3, (size_t)w * h * 4);
+        ok = d_f0 && d_f1 && svt_hip_sgr_filter_plane_dev(g_ctx, pb, bd, (uint8_t*)d_in + (3 * pp + 3) * pb, (int)pp, w, h, ep, d_f0, d_f1, w) == 0;
+        // eb_sgr_params: sets 10-13 have r0 = 0 (flt0 untouched), 14-15 r1 = 0 (flt1 untouched), EbRestoration.c:136-153
+        if (ok && !(ep >= 10 && ep <= 13)) ok = down2d(flt0, (size_t)fs * 4, d_f0, (size_t)w * 4, (size_t)w * 4, h);
+        if (ok && ep < 14) ok = down2d(flt1, (size_t)fs * 4, d_f1, (size_t)w * 4, (size_t)w * 4, h);
+        if (ok) return;
+    }
+    FALLBACK("svt_av1_selfguided_restoration", svt_av1_selfguided_restoration, dgd8, w, h, stride, flt0, flt1, fs, ep, bd, highbd);
+}
+void sgr_apply_hip(const uint8_t* dat8, int32_t w, int32_t h, int32_t stride, int32_t eps, const int32_t* xqd, uint8_t* dst8, int32_t dst_stride, int32_t* tmpbuf,
+                   int32_t bd, int32_t highbd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    void* d_in; size_t pp; const int pb = highbd ? 2 : 1;
+    // one call = one processing unit (<= 64 x 64) of one stripe: a single restoration unit, rows attributed from the unit's own origin
+    bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 56 && eps >= 0 && eps < 16 && (bd == 8 || bd == 10) && sgr_stage(dat8, highbd, w, h, stride, &d_in, &pp);
+    if (ok) {
+        const size_t dp = rup((size_t)w * pb, 4);
+        uint8_t* d_dst = (uint8_t*)dev(1, dp * h + 64); uint8_t* d_ep = (uint8_t*)dev(2, 16); int32_t* d_xqd = (int32_t*)dev(3, 16);
+        const uint8_t ep8 = (uint8_t)eps;
+        ok = d_dst && d_ep && d_xqd && up(d_ep, &ep8, 1) && up(d_xqd, xqd, 8) &&
+             svt_hip_sgr_apply_plane_dev(g_ctx, pb, bd, (uint8_t*)d_in + (3 * pp + 3) * pb, (int)pp, d_dst, (int)(dp / pb), w, h, 64, 0, nullptr, 0, d_ep, d_xqd) == 0 &&
+             down2d(highbd ? (uint8_t*)((uintptr_t)dst8 << 1) : dst8, (size_t)dst_stride * pb, d_dst, dp, (size_t)w * pb, h);
+        if (ok) return;
+    }
+    FALLBACK("svt_apply_selfguided_restoration", svt_apply_selfguided_restoration, dat8, w, h, stride, eps, xqd, dst8, dst_stride, tmpbuf, bd, highbd);
+}
+
+}  // namespace
+
+extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
+    if (!ctx || !t) return SVT_HIP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_ctx = ctx;
+    g_c = *t;
+    t->svt_sad_loop_kernel = sad_loop_hip;
+    t->svt_nxm_sad_kernel = nxm_sad_hip;
+#define X(I, W, H) t->svt_aom_sad[I] = sad_wxh_hip<I, W, H>; t->svt_aom_variance[I] = var_wxh_hip<I, W, H>; t->svt_aom_highbd_10_variance[I] = var10_wxh_hip<I, W, H>;
+    SVT_HIP_RTCD_BLOCK_SIZES(X)
+#undef X
+    t->svt_av1_convolve_2d_sr = conv_2d_hip; t->svt_av1_convolve_x_sr = conv_x_hip; t->svt_av1_convolve_y_sr = conv_y_hip; t->svt_av1_convolve_2d_copy_sr = conv_copy_hip;
+    t->svt_av1_highbd_convolve_2d_sr = conv_2d_hip_hbd; t->svt_av1_highbd_convolve_x_sr = conv_x_hip_hbd; t->svt_av1_highbd_convolve_y_sr = conv_y_hip_hbd;
+    t->svt_av1_highbd_convolve_2d_copy_sr = conv_copy_hip_hbd;
+#define X(I, TS, W, H) t->svt_av1_fwd_txfm2d[I] = fwd_hip<I, TS>;
+    SVT_HIP_RTCD_FWD_SIZES(X)
+#undef X
+    t->svt_av1_inv_txfm2d_add_sq[0] = inv_sq_hip<0, 0>; t->svt_av1_inv_txfm2d_add_sq[1] = inv_sq_hip<1, 1>; t->svt_av1_inv_txfm2d_add_sq[2] = inv_sq_hip<2, 2>;
+    t->svt_av1_inv_txfm2d_add_sq[3] = inv_sq_hip<3, 3>; t->svt_av1_inv_txfm2d_add_sq[4] = inv_sq_hip<4, 4>;
+    t->svt_av1_inv_txfm2d_add_rect = inv_rect_hip;
+    t->svt_av1_inv_txfm2d_add_rect4 = inv_rect4_hip;
+    t->svt_av1_selfguided_restoration = sgr_filter_hip;
+    t->svt_apply_selfguided_restoration = sgr_apply_hip;
+    return SVT_HIP_OK;
+}

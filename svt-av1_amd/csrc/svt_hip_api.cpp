@@ -67,6 +67,7 @@ int svt_hip_set_stream(SvtHipCtx* c, void* s) {
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return SVT_HIP_OK;
 }
+void* svt_hip_ctx_stream(SvtHipCtx* c) { return c ? (void*)c->stream : nullptr; }
 int svt_hip_sync(SvtHipCtx* c) {
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));

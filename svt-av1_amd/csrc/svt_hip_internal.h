@@ -6,6 +6,7 @@
 #include "../../include/svt_hip.h"
 
 extern "C" {
+void* svt_hip_ctx_stream(SvtHipCtx* c);   /* the stream the context launches on (rtcd_hip.cpp) */
 int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                               int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
                               uint32_t* d_best_mv, int waves_per_sb);

@@ -1,0 +1,160 @@
+"""GPU parity of the per-call RTCD-signature wrappers (include/svt_hip_rtcd.h): every pointer that
+svt_hip_setup_rtcd() installs is called here exactly like the reference calls its RTCD pointers (host buffers,
+reference argument order) and compared with the oracle.  The saved-pointer table is left NULL, so a silent fallback
+is impossible: a HIP failure would abort the process."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import ptr
+import txfm_common as tc
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64), (64, 128),
+         (128, 64), (128, 128), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+FWD = [(0, 4, 4), (1, 8, 8), (2, 16, 16), (3, 32, 32), (5, 4, 8), (6, 8, 4), (7, 8, 16), (8, 16, 8), (9, 16, 32), (10, 32, 16), (13, 4, 16),
+       (14, 16, 4), (15, 8, 32), (16, 32, 8)]
+VP = C.c_void_p
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("filter_ptr", VP), ("taps", C.c_uint16), ("subpel_shifts", C.c_uint16), ("interp_filter", C.c_uint8)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", VP), ("dst_stride", C.c_int32), ("round_0", C.c_int32), ("round_1", C.c_int32),
+                ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32), ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32),
+                ("use_dist_wtd_comp_avg", C.c_int32)]
+
+
+SADLOOP = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_int16), C.POINTER(C.c_int16),
+                      C.c_uint32, C.c_int16, C.c_int16)
+NXM = C.CFUNCTYPE(C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+SADWH = C.CFUNCTYPE(C.c_uint32, VP, C.c_int, VP, C.c_int)
+VARWH = C.CFUNCTYPE(C.c_uint, VP, C.c_int, VP, C.c_int, C.POINTER(C.c_uint))
+CONV = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(FilterParams), C.POINTER(FilterParams), C.c_int32, C.c_int32,
+                   C.POINTER(ConvParams))
+CONVH = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(FilterParams), C.POINTER(FilterParams), C.c_int32, C.c_int32,
+                    C.POINTER(ConvParams), C.c_int32)
+FWDF = C.CFUNCTYPE(None, VP, VP, C.c_uint32, C.c_uint8, C.c_uint8)
+INVSQ = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_uint8, C.c_int32)
+INVR = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32, C.c_int32)
+INVR4 = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32)
+SGRF = C.CFUNCTYPE(None, VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
+SGRA = C.CFUNCTYPE(None, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32, VP, C.c_int32, C.c_int32)
+
+
+class Rtcd(C.Structure):
+    _fields_ = [("svt_sad_loop_kernel", SADLOOP), ("svt_nxm_sad_kernel", NXM), ("svt_aom_sad", SADWH * 22), ("svt_aom_variance", VARWH * 22),
+                ("svt_aom_highbd_10_variance", VARWH * 22),
+                ("svt_av1_convolve_2d_sr", CONV), ("svt_av1_convolve_x_sr", CONV), ("svt_av1_convolve_y_sr", CONV), ("svt_av1_convolve_2d_copy_sr", CONV),
+                ("svt_av1_highbd_convolve_2d_sr", CONVH), ("svt_av1_highbd_convolve_x_sr", CONVH), ("svt_av1_highbd_convolve_y_sr", CONVH),
+                ("svt_av1_highbd_convolve_2d_copy_sr", CONVH),
+                ("svt_av1_fwd_txfm2d", FWDF * 14), ("svt_av1_inv_txfm2d_add_sq", INVSQ * 5), ("svt_av1_inv_txfm2d_add_rect", INVR),
+                ("svt_av1_inv_txfm2d_add_rect4", INVR4), ("svt_av1_selfguided_restoration", SGRF), ("svt_apply_selfguided_restoration", SGRA)]
+
+
+@pytest.fixture(scope="module")
+def rtcd(hip):
+    t = Rtcd()   # all NULL: no fallbacks
+    hip.check(hip.L.svt_hip_setup_rtcd(hip.h, C.byref(t)), "setup_rtcd")
+    return t
+
+
+def test_sad_wrappers(rtcd, orc):
+    rng = np.random.default_rng(1)
+    ref = rng.integers(0, 256, (200, 240)).astype(np.uint8)
+    src = rng.integers(0, 256, (80, 96)).astype(np.uint8)
+    orc.orc_nxm_sad.restype = C.c_uint32
+    for (bw, bh, saw, sah, step) in ((16, 16, 64, 32, 1), (32, 32, 16, 16, 1), (64, 64, 16, 16, 2), (8, 8, 24, 9, 1), (64, 40, 5, 3, 1), (12, 6, 7, 5, 2)):
+        raw_s, raw_r = src.shape[1], ref.shape[1]
+        rows = bh // step
+        exp = (C.c_uint64(), C.c_int16(-7), C.c_int16(-7)); got = (C.c_uint64(), C.c_int16(-7), C.c_int16(-7))
+        orc.orc_sad_loop(ptr(src), raw_s * step, ptr(ref), raw_r * step, rows, bw, C.byref(exp[0]), C.byref(exp[1]), C.byref(exp[2]), raw_r, saw, sah)
+        rtcd.svt_sad_loop_kernel(src.ctypes.data, raw_s * step, ref.ctypes.data, raw_r * step, rows, bw, C.byref(got[0]), C.byref(got[1]), C.byref(got[2]), raw_r, saw, sah)
+        assert (got[0].value, got[1].value, got[2].value) == (exp[0].value, exp[1].value, exp[2].value), (bw, bh, saw, sah, step)
+    for (w, h) in ((64, 64), (7, 13), (128, 9)):
+        assert rtcd.svt_nxm_sad_kernel(src.ctypes.data + 5, 96, ref.ctypes.data + 11, 240, min(h, 70), min(w, 80)) == \
+            orc.orc_nxm_sad(C.c_void_p(src.ctypes.data + 5), 96, C.c_void_p(ref.ctypes.data + 11), 240, min(h, 70), min(w, 80))
+    a = rng.integers(0, 256, (140, 150)).astype(np.uint8); b = rng.integers(0, 256, (140, 170)).astype(np.uint8)
+    a16 = rng.integers(0, 1024, (140, 150)).astype(np.uint16); b16 = rng.integers(0, 1024, (140, 170)).astype(np.uint16)
+    orc.orc_variance.restype = C.c_uint32; orc.orc_variance_hbd10.restype = C.c_uint32
+    for i, (w, h) in enumerate(SIZES):
+        assert rtcd.svt_aom_sad[i](a.ctypes.data + 3, 150, b.ctypes.data + 7, 170) == orc.orc_nxm_sad(C.c_void_p(a.ctypes.data + 3), 150, C.c_void_p(b.ctypes.data + 7), 170, h, w), (w, h)
+        s1, s2 = C.c_uint(), C.c_uint32()
+        v = rtcd.svt_aom_variance[i](a.ctypes.data + 3, 150, b.ctypes.data + 7, 170, C.byref(s1))
+        assert (v, s1.value) == (orc.orc_variance(C.c_void_p(a.ctypes.data + 3), 150, C.c_void_p(b.ctypes.data + 7), 170, w, h, C.byref(s2)), s2.value), (w, h)
+        # CONVERT_TO_BYTEPTR: the byte pointer is the uint16_t address >> 1
+        v = rtcd.svt_aom_highbd_10_variance[i]((a16.ctypes.data + 6) >> 1, 150, (b16.ctypes.data + 14) >> 1, 170, C.byref(s1))
+        assert (v, s1.value) == (orc.orc_variance_hbd10(C.c_void_p(a16.ctypes.data + 6), 150, C.c_void_p(b16.ctypes.data + 14), 170, w, h, C.byref(s2)), s2.value), (w, h)
+
+
+def test_convolve_wrappers(rtcd, orc):
+    rng = np.random.default_rng(2)
+    banks = np.ctypeslib.as_array((C.c_int16 * 8 * 16 * 6).in_dll(orc, "orc_interp_kernels")).copy()
+    cp = ConvParams(0, 0, None, 0, 3, 11, 0, 0, 0, 0, 0, 0)
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        img = rng.integers(0, 1 << bd, (160, 176)).astype(dt)
+        for (w, h, bx, by, sx, sy) in ((16, 16, 0, 0, 5, 11), (64, 32, 2, 1, 8, 3), (4, 8, 4, 5, 9, 14), (128, 128, 0, 2, 15, 1), (8, 4, 3, 3, 7, 7)):
+            if w > 100: img = rng.integers(0, 1 << bd, (160, 176)).astype(dt)
+            fx = FilterParams(banks[bx].ctypes.data, 8, 16, bx % 4); fy = FilterParams(banks[by].ctypes.data, 8, 16, by % 4)
+            src_off = (12 * 176 + 10) * img.itemsize
+            for name, ex, ey in (("2d", sx, sy), ("x", sx, 0), ("y", 0, sy), ("2d_copy", 0, 0)):
+                exp = np.zeros((h, w + 3), dt); got = np.full((h, w + 3), 77, dt); exp[:, w:] = 77
+                orc.orc_convolve_sr(C.c_void_p(img.ctypes.data + src_off), 176, ptr(exp), w + 3, img.itemsize, w, h, bx, by, ex, ey, bd)
+                if bd == 8:
+                    getattr(rtcd, f"svt_av1_convolve_{name}_sr")(img.ctypes.data + src_off, 176, got.ctypes.data, w + 3, w, h, C.byref(fx), C.byref(fy), sx, sy, C.byref(cp))
+                else:
+                    getattr(rtcd, f"svt_av1_highbd_convolve_{name}_sr")(img.ctypes.data + src_off, 176, got.ctypes.data, w + 3, w, h, C.byref(fx), C.byref(fy), sx, sy, C.byref(cp), bd)
+                assert np.array_equal(got, exp), (bd, name, w, h, bx, by, sx, sy)
+
+
+def test_transform_wrappers(rtcd, orc):
+    rng = np.random.default_rng(3)
+    for slot, (ts, w, h) in enumerate(FWD):
+        for tt in tc.legal_types(ts)[::3]:
+            for bd in (8, 10):
+                stride = w + 5
+                x = rng.integers(-(1 << bd) + 1, 1 << bd, (h, stride)).astype(np.int16)
+                got = np.zeros(w * h, np.int32)
+                rtcd.svt_av1_fwd_txfm2d[slot](x.ctypes.data, got.ctypes.data, stride, tt, bd)
+                assert np.array_equal(got, tc.orc_fwd(orc, x, stride, tt, ts, bd)), ("fwd", ts, tt, bd)
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        kw, kh = min(w, 32), min(h, 32)
+        for tt in tc.legal_types(ts)[::5]:
+            for bd in (8, 10):
+                coef = (rng.integers(-600, 600, kw * kh) * (rng.random(kw * kh) < 0.3)).astype(np.int32)
+                pred = rng.integers(0, 1 << bd, (h, w + 9)).astype(np.uint16)
+                exp = np.zeros((h, w + 2), np.uint16); got = np.zeros((h, w + 2), np.uint16)
+                orc.orc_inv_txfm2d_add(ptr(coef), ptr(pred), w + 9, ptr(exp), w + 2, tt, ts, bd)
+                if w == h:
+                    rtcd.svt_av1_inv_txfm2d_add_sq[ts](coef.ctypes.data, pred.ctypes.data, w + 9, got.ctypes.data, w + 2, tt, bd)
+                elif min(w, h) == 4:
+                    rtcd.svt_av1_inv_txfm2d_add_rect4(coef.ctypes.data, pred.ctypes.data, w + 9, got.ctypes.data, w + 2, tt, ts, bd)
+                else:
+                    rtcd.svt_av1_inv_txfm2d_add_rect(coef.ctypes.data, pred.ctypes.data, w + 9, got.ctypes.data, w + 2, tt, ts, kw * kh, bd)
+                assert np.array_equal(got, exp), ("inv", ts, tt, bd)
+
+
+def test_selfguided_wrappers(rtcd, orc):
+    rng = np.random.default_rng(4)
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        img = np.clip(rng.normal(120, 40, (90, 100)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(dt)
+        for (w, h) in ((64, 56), (40, 24), (7, 10)):
+            org = (9 * 100 + 11) * img.itemsize
+            p = img.ctypes.data + org
+            p_ref = p >> 1 if bd > 8 else p   # CONVERT_TO_BYTEPTR
+            for ep in (0, 7, 10, 13, 14, 15):
+                e0 = np.full((h, w + 1), -5, np.int32); e1 = e0.copy(); g0 = e0.copy(); g1 = e0.copy()
+                orc.orc_sgr_filter(C.c_void_p(p), img.itemsize, w, h, 100, ptr(e0), ptr(e1), w + 1, ep, bd)
+                rtcd.svt_av1_selfguided_restoration(p_ref, w, h, 100, g0.ctypes.data, g1.ctypes.data, w + 1, ep, bd, int(bd > 8))
+                assert np.array_equal(g0, e0) and np.array_equal(g1, e1), ("sgr filter", bd, w, h, ep)
+                xqd = np.array([int(rng.integers(-96, 32)), int(rng.integers(-32, 96))], np.int32)
+                ed = np.zeros((h, w + 4), dt); gd = np.zeros((h, w + 4), dt)
+                orc.orc_sgr_apply(C.c_void_p(p), img.itemsize, w, h, 100, ep, ptr(xqd), ptr(ed), w + 4, bd)
+                dst = gd.ctypes.data >> 1 if bd > 8 else gd.ctypes.data
+                rtcd.svt_apply_selfguided_restoration(p_ref, w, h, 100, ep, xqd.ctypes.data, dst, w + 4, None, bd, int(bd > 8))
+                assert np.array_equal(gd, ed), ("sgr apply", bd, w, h, ep)
