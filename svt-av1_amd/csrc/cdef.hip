@@ -105,81 +105,133 @@ __device__ __forceinline__ int find_dir_wave(int x_px, int lane, int* xs, int& v
     return best;
 }
 
+// ---- packed 16-bit search arithmetic ------------------------------------------------------------
 // Everything the 64 strength pairs need for one pixel: primary sums for pri = 1..15, secondary sums
-// for sec in {1,2,4} with the block's direction (A) and with direction 0 (B, used when pri == 0),
-// and the two min/max pairs.
-struct PixelTerms {
-    int x;
-    int pri[16];     // [0] = 0
-    int secA[3], secB[3];
-    int mnA, mxA, mnB, mxB;
-};
+// for sec in {1,2,4} with the block's direction (A) and with direction 0 (B, used when pri == 0), and
+// the two min/max pairs.  All quantities fit int16 (taps <= 16384, sums <= 12 * 60), so the taps are
+// kept as PAIRS in one VGPR (the two mirrored taps of a (direction, distance), which share a weight)
+// and constrain() runs on both halves at once:
+//   |d|            v_pk_sub_i16 / v_pk_max_i16, once per pair
+//   t - (|d|>>s)   v_pk_lshrrev_b16 + v_pk_sub_u16 with unsigned saturation (= max(0, .))
+//   min(|d|, .)    v_pk_min_u16
+//   weight * sign  folded into a per-pair constant (+-w, +-w), applied together with the horizontal
+//                  add by one v_dot2_i32_i16 per pair and strength.
+// A CDEF_VERY_LARGE tap yields |d| >> s > t for every strength (EbCdef.c:87-93 relies on the same),
+// so it contributes 0 without a test.
+typedef short  s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 dup2(int v) { return s16x2{(short)v, (short)v}; }
+__device__ __forceinline__ s16x2 pack2(int lo, int hi) { return s16x2{(short)lo, (short)hi}; }
+__device__ __forceinline__ u16x2 as_u(s16x2 v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ s16x2 as_s(u16x2 v) { return __builtin_bit_cast(s16x2, v); }
 
-__device__ __forceinline__ void tap_minmax(int v, int& mn, int& mx) {
-    if (v != kVeryLarge) mx = max(mx, v);
-    mn = min(mn, v);
+struct TapPair {
+    u16x2 a;    // |tap - x| of both taps
+    s16x2 sg;   // 0 / -1 per half: sign of (tap - x)
+};
+__device__ __forceinline__ TapPair make_pair(int t0, int t1, s16x2 x2) {
+    const s16x2 d = pack2(t0, t1) - x2;
+    TapPair p;
+    p.a = as_u(__builtin_elementwise_max(d, -d));
+    p.sg = d >> 15;
+    return p;
 }
+// (w * sign0, w * sign1)
+__device__ __forceinline__ s16x2 signed_weight(const TapPair& p, int w) { return (dup2(w) ^ p.sg) - p.sg; }
+// sum over the two taps of weight * constrain(tap - x, t, shift), accumulated into acc
+__device__ __forceinline__ int constrain_pair(const TapPair& p, s16x2 sw, int t, int shift, int acc) {
+    const u16x2 hi = __builtin_elementwise_sub_sat(as_u(dup2(t)), p.a >> (unsigned short)shift);
+    const u16x2 v = __builtin_elementwise_min(p.a, hi);
+    return __builtin_amdgcn_sdot2(as_s(v), sw, acc, false);
+}
+__device__ __forceinline__ void minmax_pair(int t0, int t1, s16x2& mn, s16x2& mx) {
+    const s16x2 v = pack2(t0, t1);
+    mn = __builtin_elementwise_min(mn, v);
+    mx = __builtin_elementwise_max(mx, v & dup2(0x3FFF));   // CDEF_VERY_LARGE (0x4000) never wins the max (EbCdef.c:229-247)
+}
+
+struct PixelTerms {
+    s16x2 x2;          // (x, x)
+    s16x2 pri2[16];    // (pri sum, pri sum); [0] = 0
+    s16x2 secA[2], secB[2];   // [0] = (0, sec 1), [1] = (sec 2, sec 4)
+    s16x2 mnA, mxA, mnB, mxB; // duplicated in both halves
+};
 
 // tile points at the pixel; tstride in elements.  t_of[idx] = effective primary strength of index idx
 // (luma: adjusted by the block variance), cs = coeff_shift, damping already includes "+ cs - (pli != 0)".
 __device__ __forceinline__ void pixel_terms(const uint16_t* px, int tstride, int dir, const int (&t_of)[16], int cs, int damping,
                                             PixelTerms& T) {
     const int x = (int)(int16_t)px[0];
-    T.x = x;
-    int p[2][2], sa[2][4], sb[2][4], pb[2][2];
+    const s16x2 x2 = dup2(x);
+    T.x2 = x2;
+    TapPair pp[2], sa[2][2], sb[2][2];
+    s16x2 mnA = x2, mxA = x2, mnB = x2, mxB = x2;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int o = kDirDy[dir][k] * tstride + kDirDx[dir][k];
-        p[k][0] = px[o]; p[k][1] = px[-o];
         const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
         const int o2 = kDirDy[d2][k] * tstride + kDirDx[d2][k], o6 = kDirDy[d6][k] * tstride + kDirDx[d6][k];
-        sa[k][0] = px[o2]; sa[k][1] = px[-o2]; sa[k][2] = px[o6]; sa[k][3] = px[-o6];
-        // direction 0 variant (pri == 0 -> filter_block is called with dir 0, EbCdef.c:371)
+        const int p0 = px[o], p1 = px[-o], a0 = px[o2], a1 = px[-o2], a2 = px[o6], a3 = px[-o6];
+        pp[k] = make_pair(p0, p1, x2); sa[k][0] = make_pair(a0, a1, x2); sa[k][1] = make_pair(a2, a3, x2);
+        minmax_pair(p0, p1, mnA, mxA); minmax_pair(a0, a1, mnA, mxA); minmax_pair(a2, a3, mnA, mxA);
+        // direction 0 variant (pri == 0 -> filter_block is called with dir 0, EbCdef.c:371): its primary taps only feed min/max
         const int ob = kDirDy[0][k] * tstride + kDirDx[0][k];
-        pb[k][0] = px[ob]; pb[k][1] = px[-ob];
         const int ob2 = kDirDy[2][k] * tstride + kDirDx[2][k], ob6 = kDirDy[6][k] * tstride + kDirDx[6][k];
-        sb[k][0] = px[ob2]; sb[k][1] = px[-ob2]; sb[k][2] = px[ob6]; sb[k][3] = px[-ob6];
+        const int q0 = px[ob], q1 = px[-ob], b0 = px[ob2], b1 = px[-ob2], b2 = px[ob6], b3 = px[-ob6];
+        sb[k][0] = make_pair(b0, b1, x2); sb[k][1] = make_pair(b2, b3, x2);
+        minmax_pair(q0, q1, mnB, mxB); minmax_pair(b0, b1, mnB, mxB); minmax_pair(b2, b3, mnB, mxB);
     }
-    T.mnA = T.mxA = T.mnB = T.mxB = x;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        tap_minmax(p[k][0], T.mnA, T.mxA); tap_minmax(p[k][1], T.mnA, T.mxA);
-        tap_minmax(pb[k][0], T.mnB, T.mxB); tap_minmax(pb[k][1], T.mnB, T.mxB);
-#pragma unroll
-        for (int t = 0; t < 4; t++) { tap_minmax(sa[k][t], T.mnA, T.mxA); tap_minmax(sb[k][t], T.mnB, T.mxB); }
-    }
-    T.pri[0] = 0;
+    // fold the two halves of the running min / max and duplicate
+    T.mnA = __builtin_elementwise_min(mnA, mnA.yx); T.mxA = __builtin_elementwise_max(mxA, mxA.yx);
+    T.mnB = __builtin_elementwise_min(mnB, mnB.yx); T.mxB = __builtin_elementwise_max(mxB, mxB.yx);
+    // primary: eb_cdef_pri_taps (EbCdef.c:198) = {4, 2} or {3, 3} by the parity of (t >> cs)
+    const s16x2 w40 = signed_weight(pp[0], 4), w30 = signed_weight(pp[0], 3), w21 = signed_weight(pp[1], 2), w31 = signed_weight(pp[1], 3);
+    T.pri2[0] = dup2(0);
 #pragma unroll
     for (int idx = 1; idx < 16; idx++) {
-        const int t = t_of[idx];
+        const int t = t_of[idx];   // wave-uniform
         int s = 0;
         if (t) {
             const int shift = max(0, damping - msb(t));
-            const int w0 = ((t >> cs) & 1) ? 3 : 4, w1 = ((t >> cs) & 1) ? 3 : 2;  // eb_cdef_pri_taps, EbCdef.c:198
-            s = w0 * (constrain(p[0][0] - x, t, shift) + constrain(p[0][1] - x, t, shift)) +
-                w1 * (constrain(p[1][0] - x, t, shift) + constrain(p[1][1] - x, t, shift));
+            const bool odd = (t >> cs) & 1;
+            s = constrain_pair(pp[0], odd ? w30 : w40, t, shift, 0);
+            s = constrain_pair(pp[1], odd ? w31 : w21, t, shift, s);
         }
-        T.pri[idx] = s;
+        T.pri2[idx] = dup2(s);
     }
+    // secondary: eb_cdef_sec_taps {2, 1}; strengths 1, 2, 4 (index 3 means 4: "sec += sec == 3")
+    s16x2 wa[2][2], wb[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) { wa[k][h] = signed_weight(sa[k][h], 2 - k); wb[k][h] = signed_weight(sb[k][h], 2 - k); }
+    int a[3], b[3];
 #pragma unroll
     for (int si = 0; si < 3; si++) {
-        const int s = (1 << si) << cs;  // sec strengths 1, 2, 4 (index 3 means 4: "sec += sec == 3")
-        const int shift = max(0, damping - msb(s));
-        int a = 0, b = 0;
+        const int st = (1 << si) << cs;
+        const int shift = max(0, damping - msb(st));
+        int va = 0, vb = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            a += 2 * constrain(sa[0][t] - x, s, shift) + constrain(sa[1][t] - x, s, shift);  // eb_cdef_sec_taps {2,1}
-            b += 2 * constrain(sb[0][t] - x, s, shift) + constrain(sb[1][t] - x, s, shift);
-        }
-        T.secA[si] = a; T.secB[si] = b;
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) { va = constrain_pair(sa[k][h], wa[k][h], st, shift, va); vb = constrain_pair(sb[k][h], wb[k][h], st, shift, vb); }
+        a[si] = va; b[si] = vb;
     }
+    T.secA[0] = pack2(0, a[0]); T.secA[1] = pack2(a[1], a[2]);
+    T.secB[0] = pack2(0, b[0]); T.secB[1] = pack2(b[1], b[2]);
 }
 
-__device__ __forceinline__ int combine(const PixelTerms& T, int pri_idx, int sec_idx) {
-    int sum = T.pri[pri_idx];
-    if (sec_idx) sum += pri_idx ? T.secA[sec_idx - 1] : T.secB[sec_idx - 1];
-    const int y = T.x + ((8 + sum - (sum < 0)) >> 4);
-    return pri_idx ? min(max(y, T.mnA), T.mxA) : min(max(y, T.mnB), T.mxB);
+// filtered values of strengths (pri_idx, 2 * pair) and (pri_idx, 2 * pair + 1): y = x + ((8 + sum - (sum < 0)) >> 4), clamped
+__device__ __forceinline__ s16x2 combine2(const PixelTerms& T, int pri_idx, int pair) {
+    const s16x2 sum = T.pri2[pri_idx] + (pri_idx ? T.secA[pair] : T.secB[pair]);
+    const s16x2 y = T.x2 + ((sum + (sum >> 15) + dup2(8)) >> 4);
+    return pri_idx ? __builtin_elementwise_min(__builtin_elementwise_max(y, T.mnA), T.mxA)
+                   : __builtin_elementwise_min(__builtin_elementwise_max(y, T.mnB), T.mxB);
+}
+
+__device__ __forceinline__ void tap_minmax(int v, int& mn, int& mx) {
+    if (v != kVeryLarge) mx = max(mx, v);
+    mn = min(mn, v);
 }
 
 // One pixel, one (pri, sec, dir): svt_cdef_filter_block_c (EbCdef.c:202-257) without the search's shared-term machinery.
@@ -266,7 +318,10 @@ cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* 
         PixelTerms T;
         pixel_terms(px, TS, dir, t_of, cs, damping, T);
 #pragma unroll
-        for (int g = 0; g < 64; g++) ytab[wave][g][lane] = (PIX)combine(T, g >> 2, g & 3);
+        for (int g = 0; g < 64; g += 2) {
+            const s16x2 y = combine2(T, g >> 2, (g >> 1) & 1);
+            ytab[wave][g][lane] = (PIX)y.x; ytab[wave][g + 1][lane] = (PIX)y.y;
+        }
         stab[wave][lane] = src[(size_t)(64 * fbr + 8 * by + i) * src_stride + 64 * fbc + 8 * bx + j];
         __builtin_amdgcn_wave_barrier();
         // lane g reduces strength g: dist_8x8 (EbEncCdef.c:79-105), names as in the reference:
@@ -330,7 +385,10 @@ cdef_search_chroma_kernel(const PIX* __restrict__ rec_u, const PIX* __restrict__
             PixelTerms T;
             pixel_terms(px, TS, dir, t_of, cs, damping, T);
 #pragma unroll
-            for (int g = 0; g < 64; g++) ytab[wave][g][lane] = (PIX)combine(T, g >> 2, g & 3);
+            for (int g = 0; g < 64; g += 2) {
+                const s16x2 y = combine2(T, g >> 2, (g >> 1) & 1);
+                ytab[wave][g][lane] = (PIX)y.x; ytab[wave][g + 1][lane] = (PIX)y.y;
+            }
         } else {
 #pragma unroll
             for (int g = 0; g < 64; g++) ytab[wave][g][lane] = s;  // contributes (y - s)^2 = 0
