@@ -111,8 +111,12 @@ def lib():
     L.svt_hip_variance_pyramid_dev.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.svt_hip_sad_loop_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp]
     L.svt_hip_sgr_filter_plane_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32]
-    L.svt_hip_sgr_search_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, C.c_uint32, vp]
-    L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]
+    L.svt_hip_sgr_search_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp]
+    L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    L.svt_hip_plane_sse_dev.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp]
+    L.svt_hip_dlf_search_level_dev.argtypes = [vp, C.POINTER(DlfSearch), vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.svt_hip_setup_rtcd.argtypes = [vp, vp]
     P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp]
