@@ -335,6 +335,21 @@ def main():
     dominant = max(stages, key=lambda s: per_stage[s["name"]])
     dom_ms = per_stage[dominant["name"]]
     achieved_gbs = BYTES_PER_SB[dominant["name"]] * n_sb / (dom_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant stage per frame from the PMC passes of the latest profiled round (tools/collect_profiles.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs; summary committed as profiles/<round>/pmc_traffic.json)
+    traffic, traffic_src = None, None
+    try:
+        rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
+        if rounds:
+            traffic_src = f"profiles/{rounds[-1]}/pmc_traffic.json"
+            pt = json.load(open(os.path.join(ROOT, traffic_src)))
+            frames = max((e["launches"] for k, e in pt.items() if k.startswith("me_fullpel_85pu_kernel")), default=0)
+            names = dominant["kernel"].split("+")
+            tot = sum((e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)) * e["launches"]
+                      for k, e in pt.items() if any(k.startswith(nm) for nm in names))
+            traffic = tot / frames if frames and tot else None
+    except (OSError, ValueError, KeyError):
+        traffic = None
 
     if rank != 0:
         if world > 1:
@@ -366,7 +381,9 @@ def main():
                                  "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets",
                    "stages_ms": per_stage, "parity_spot_check": parity_ok},
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_note": None if traffic is None else f"bytes per frame of the stage's launches, FETCH_SIZE + WRITE_SIZE from {traffic_src} "
+                                     "(raw counters x 1024; narrow loads are uncalibrated on gfx950, Infinity-Cache hits included)",
                      "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / HIP-event stage time of the slowest stage; the ME and CDEF-search "
                              "kernels are integer-VALU bound (DESIGN.md), see per_stage_gbs for the HBM-bound ones",
                      "per_stage_gbs": {s["name"]: BYTES_PER_SB[s["name"]] * n_sb / (per_stage[s["name"]] * 1e-3) / 1e9 for s in stages}},

@@ -1,0 +1,63 @@
+"""Summarise gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>/:
+  kernel_stats.csv   rocprofv3 --stats per-kernel table (as written by rocprofv3)
+  pmc_traffic.json   per kernel: launches, average duration (us), FETCH_SIZE / WRITE_SIZE per launch in bytes (raw counter x 1024;
+                     the gfx950 caveats of /opt/skills/guides/MI355X_MICROARCH.md 'HBM' apply: wide coalesced reads are under-counted 2x,
+                     Infinity-Cache hits are included) and the SQ counters of the same step
+  bench.json         the bench line of the same build without the profiler"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    n = name.replace("void (anonymous namespace)::", "")
+    return n.split("(")[0]
+
+
+def pmc(dirname):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def durations(dirname):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, dirname, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return out
+
+
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+dur = durations("stats")
+fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
+res = {}
+for k in sorted(dur, key=lambda k: -sum(dur[k])):
+    if "elementwise" in k or "Fill" in k or "copy" in k.lower():
+        continue
+    e = {"launches": len(dur[k]), "avg_us": sum(dur[k]) / len(dur[k])}
+    if k in fetch and fetch[k].get("FETCH_SIZE"):
+        v = fetch[k]["FETCH_SIZE"]; e["fetch_bytes_per_launch"] = sum(v) / len(v) * 1024
+    if k in write and write[k].get("WRITE_SIZE"):
+        v = write[k]["WRITE_SIZE"]; e["write_bytes_per_launch"] = sum(v) / len(v) * 1024
+    if k in sq:
+        e["sq"] = {c: sum(v) / len(v) for c, v in sq[k].items()}
+    res[k] = e
+json.dump(res, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "bench.json")):
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
+for k, e in list(res.items())[:16]:
+    print(f"{k[:44]:44s} n={e['launches']:3d} avg={e['avg_us']:8.1f}us fetch={e.get('fetch_bytes_per_launch', 0)/1e6:8.2f}MB write={e.get('write_bytes_per_launch', 0)/1e6:8.2f}MB")
