@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="issue every launch on one stream (no intra-step concurrency)")
+    ap.add_argument("--lanes", type=int, default=3, help="streams for the independent launches of a stage (debug)")
+    ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the main stream (debug)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--stages", default="all", help="comma list (debug): pyr,hme,me,subpel,txfm,inv,dlf,cdef_search,cdef_apply,sgr_search,sgr_apply")
     args = ap.parse_args()
@@ -177,26 +180,79 @@ def main():
     d_unit_xqd = [T(np.stack([rng.integers(-96, 32, n_units[p]), rng.integers(-32, 96, n_units[p])], 1).astype(np.int32)) for p in range(3)]
     d_sgr_out = [torch.zeros_like(p) for p in d_pred]
 
+    # ---------------------------------------------------------------- streams
+    # Independent launches of a stage (planes, transform sizes) and the two data-independent halves of a step (the source-side
+    # chain pyramids -> HME -> ME -> sub-pel, and the reconstruction-side chain transform -> deblock -> CDEF -> restoration) are
+    # issued on separate HIP streams, forked from and joined back into the stream that carries the step; inside a captured graph
+    # these become parallel branches, so short kernels fill each other's tails and the VALU-bound search kernels overlap the
+    # HBM-bound transform / filter passes.  --serial keeps everything on one stream.
+    S = {"cur": stream}
+    n_lanes = 1 if args.serial else args.lanes
+    lanes = [torch.cuda.Stream() for _ in range(n_lanes)] if n_lanes > 1 else []
+    side = torch.cuda.Stream() if not (args.serial or args.no_side) else None
+
+    class on:
+        def __init__(self, st):
+            self.st = st
+
+        def __enter__(self):
+            self.prev = S["cur"]
+            S["cur"] = self.st
+            ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(self.st.cuda_stream)))
+            self.t = torch.cuda.stream(self.st)
+            self.t.__enter__()
+
+        def __exit__(self, *a):
+            self.t.__exit__(*a)
+            S["cur"] = self.prev
+            ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(self.prev.cuda_stream)))
+
+    def parallel(jobs):
+        """Run the callables round-robin on the lane streams, forked from / joined into the current stream."""
+        if not lanes or len(jobs) < 2 or S["cur"] is side:   # the lanes belong to the main chain
+            for j in jobs:
+                j()
+            return
+        base = S["cur"]
+        used = lanes[:min(len(lanes), len(jobs))]
+        for ln in used:
+            ln.wait_stream(base)
+        for i, j in enumerate(jobs):
+            with on(used[i % len(used)]):
+                j()
+        for ln in used:
+            base.wait_stream(ln)
+
     # ---------------------------------------------------------------- the kernel classes of a step
     def run_me():
         ctx.check(L.svt_hip_me_fullpel_frame_dev(ctx.h, d_cur_p.data_ptr(), d_ref_p.data_ptr(), F.cur_y_p.shape[1], PAD, PAD,
                                                  d_sbs.data_ptr(), n_sb, 0, d_sad.data_ptr(), d_mv.data_ptr()), "me")
 
     def run_txfm():
-        for j in tx_jobs:
+        parallel([lambda j=j: txfm_job(j) for j in tx_jobs])
+
+    def txfm_job(j):
+        if True:
             p = j["plane"]
             ctx.check(L.svt_hip_fwd_txfm_quant_batch_dev(ctx.h, j["ts"], 1, d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p],
                                                          j["desc"].data_ptr(), j["n"], C.byref(j["qs"]), C.byref(j["st"]), None,
                                                          j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None), "fwd")
 
     def run_inv():
-        for j in tx_jobs:
+        parallel([lambda j=j: inv_job(j) for j in tx_jobs])
+
+    def inv_job(j):
+        if True:
             p = j["plane"]
             ctx.check(L.svt_hip_inv_txfm_add_batch_dev(ctx.h, j["ts"], 1, 8, j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p],
                                                        d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["n"]), "inv")
 
     def run_dlf():
-        for p in range(3):
+        for p in range(3):   # ~10 us kernels: a fork / join costs more than it hides
+            dlf_plane(p)
+
+    def dlf_plane(p):
+        if True:
             ev, eh, uw, uh = d_edges[p]
             ctx.check(L.svt_hip_deblock_plane_dev(ctx.h, d_recon[p].data_ptr(), 1, strides[p], 8, ev.data_ptr(), eh.data_ptr(), uw, uh, 0), "dlf")
 
@@ -212,12 +268,14 @@ def main():
                                                  I3(*strides), W, H, d_skip8.data_ptr(), d_cy.data_ptr(), d_cuv.data_ptr(), F.cdef_damping, 8,
                                                  d_dir.data_ptr()), "cdef apply")
 
+    def pyr_job(src_p, dst_t, pad_, step_):
+        org = src_p.data_ptr() + PAD * F.cur_y_p.shape[1] + PAD
+        ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, dst_t.data_ptr() + pad_ * dst_t.shape[1] + pad_, dst_t.shape[1], step_, 1), "ds")
+
     def run_pyramids():
-        for src_p, q, s_ in ((d_cur_p, d_cur_q, d_cur_s), (d_ref_p, d_ref_q, d_ref_s)):
-            org = src_p.data_ptr() + PAD * F.cur_y_p.shape[1] + PAD
-            ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, q.data_ptr() + PADQ * q.shape[1] + PADQ, q.shape[1], 2, 1), "ds2")
-            ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, s_.data_ptr() + PADS * s_.shape[1] + PADS, s_.shape[1], 4, 1), "ds4")
-        ctx.check(L.svt_hip_variance_pyramid_dev(ctx.h, d_vp.data_ptr(), d_vp.shape[1], F.sb_cols, n_sb, 0, d_ymean.data_ptr(), d_yvar.data_ptr()), "varpyr")
+        parallel([lambda: pyr_job(d_cur_p, d_cur_q, PADQ, 2), lambda: pyr_job(d_cur_p, d_cur_s, PADS, 4),
+                  lambda: pyr_job(d_ref_p, d_ref_q, PADQ, 2), lambda: pyr_job(d_ref_p, d_ref_s, PADS, 4),
+                  lambda: ctx.check(L.svt_hip_variance_pyramid_dev(ctx.h, d_vp.data_ptr(), d_vp.shape[1], F.sb_cols, n_sb, 0, d_ymean.data_ptr(), d_yvar.data_ptr()), "varpyr")])
 
     def run_hme():
         for lvl, (cur_t, ref_t) in enumerate(((d_cur_s, d_ref_s), (d_cur_q, d_ref_q), (d_cur_p, d_ref_p))):
@@ -229,29 +287,32 @@ def main():
         ctx.check(L.svt_hip_subpel_predict_batch_dev(ctx.h, 1, 8, d_ref_p.data_ptr() + PAD * F.ref_y_p.shape[1] + PAD, F.ref_y_p.shape[1],
                                                      d_subpel.data_ptr(), W, d_cb.data_ptr(), nblk16), "subpel")
 
-    def sgr_extend():
+    def sgr_extend(p):
         # svt_extend_frame equivalent (device-to-device, torch slicing = plumbing): 3-px edge replication of the CDEF output
-        for p in range(3):
-            h_, w_ = d_cdef_out[p].shape
-            e = d_ext[p]
-            e[EXT:EXT + h_, EXT:EXT + w_] = d_cdef_out[p]
-            e[EXT:EXT + h_, :EXT] = d_cdef_out[p][:, :1]; e[EXT:EXT + h_, EXT + w_:EXT + w_ + EXT] = d_cdef_out[p][:, -1:]
-            e[:EXT, :] = e[EXT:EXT + 1, :]; e[EXT + h_:EXT + h_ + EXT, :] = e[EXT + h_ - 1:EXT + h_, :]
+        h_, w_ = d_cdef_out[p].shape
+        e = d_ext[p]
+        e[EXT:EXT + h_, EXT:EXT + w_] = d_cdef_out[p]
+        e[EXT:EXT + h_, :EXT] = d_cdef_out[p][:, :1]; e[EXT:EXT + h_, EXT + w_:EXT + w_ + EXT] = d_cdef_out[p][:, -1:]
+        e[:EXT, :] = e[EXT:EXT + 1, :]; e[EXT + h_:EXT + h_ + EXT, :] = e[EXT + h_ - 1:EXT + h_, :]
+
+    def sgr_search_plane(p):
+        sgr_extend(p)
+        d_sgr_sums[p].zero_()
+        h_, w_ = d_cdef_out[p].shape
+        ctx.check(L.svt_hip_sgr_search_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_cur[p].data_ptr(),
+                                                 strides[p], w_, h_, US[p], int(p > 0), 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
 
     def run_sgr_search():
-        sgr_extend()
-        for p in range(3):
-            d_sgr_sums[p].zero_()
-            h_, w_ = d_cdef_out[p].shape
-            ctx.check(L.svt_hip_sgr_search_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_cur[p].data_ptr(),
-                                                     strides[p], w_, h_, US[p], int(p > 0), 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
+        parallel([lambda p=p: sgr_search_plane(p) for p in range(3)])
+
+    def sgr_apply_plane(p):
+        h_, w_ = d_cdef_out[p].shape
+        ctx.check(L.svt_hip_sgr_apply_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_sgr_out[p].data_ptr(),
+                                                strides[p], w_, h_, US[p], int(p > 0), d_recon[p].data_ptr(), strides[p],   # stripe context rows from the deblocked picture
+                                                d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
 
     def run_sgr_apply():
-        for p in range(3):
-            h_, w_ = d_cdef_out[p].shape
-            ctx.check(L.svt_hip_sgr_apply_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_sgr_out[p].data_ptr(),
-                                                    strides[p], w_, h_, US[p], int(p > 0), d_recon[p].data_ptr(), strides[p],   # stripe context rows from the deblocked picture
-                                                    d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
+        parallel([lambda p=p: sgr_apply_plane(p) for p in range(3)])
 
     all_stages = [
         dict(key="pyr", name="pyramids", run=run_pyramids, kernel="downsample_kernel+variance_pyramid_kernel"),
@@ -269,9 +330,23 @@ def main():
     want = None if args.stages == "all" else set(args.stages.split(","))
     stages = [s for s in all_stages if want is None or s["key"] in want]
 
+    SOURCE_SIDE = ("pyr", "hme", "me", "subpel")   # read only the source / reference pictures: independent of the reconstruction chain
+
     def step():
+        if side is None:
+            for st in stages:
+                st["run"]()
+            return
+        base = S["cur"]
+        side.wait_stream(base)
+        with on(side):
+            for st in stages:
+                if st["key"] in SOURCE_SIDE:
+                    st["run"]()
         for st in stages:
-            st["run"]()
+            if st["key"] not in SOURCE_SIDE:
+                st["run"]()
+        base.wait_stream(side)
 
     def capture(fn, reps=1):
         """One HIP graph of `reps` back-to-back calls of fn(): a frame step is ~80 short launches, replaying a captured
@@ -281,11 +356,13 @@ def main():
         cap = torch.cuda.Stream()
         cap.wait_stream(stream)
         ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(cap.cuda_stream)))
+        S["cur"] = cap
         try:
             with torch.cuda.graph(g, stream=cap):
                 for _ in range(reps):
                     fn()
         finally:
+            S["cur"] = stream
             ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
         return g
 
@@ -375,7 +452,7 @@ def main():
         "metric": METRIC, "value": total_sb / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "launch": "eager" if not use_graph else "hip_graph_replay",
+        "launch": ("eager" if not use_graph else "hip_graph_replay") + (", single stream" if args.serial else f", 1+1+{n_lanes} forked streams per step"),
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
                                + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16; square tx tiling "
                                  "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets",
