@@ -146,6 +146,7 @@ def main():
     vp = np.zeros((F.sb_rows * 64 + 64, F.sb_cols * 64 + 64), np.uint8); vp[:H, :W] = F.cur[0]
     d_vp = T(vp)
     hme = []
+    hme_host = []
     for lvl, (bsz, saw, sah) in enumerate(((16, 64, 32), (32, 16, 16), (64, 16, 16))):
         S = (pkg.SadLoop * n_sb)()
         sc = (4, 2, 1)[lvl]
@@ -155,6 +156,7 @@ def main():
             pw_, ph_ = W // sc, H // sc
             x0 = min(max(sx - saw // 2, -pad + 1), pw_ - 1); y0 = min(max(sy - sah // 2, -pad + 1), ph_ - 1)
             S[i] = pkg.SadLoop(sx + pad, sy + pad, x0 + pad, y0 + pad, bsz, bsz, min(saw, pw_ + pad - 1 - bsz - x0), min(sah, ph_ + pad - 1 - bsz - y0), 1, 0)
+        hme_host.append(S)
         hme.append(dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(n_sb, dtype=torch.int32, device=dev),
                         xy=torch.zeros((n_sb, 2), dtype=torch.int16, device=dev)))
     # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into a prediction plane
@@ -445,7 +447,7 @@ def main():
     #      same frame; composite SB/s = 1 / sum_k (seconds per SB of stage k)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(orc, F, sbs, mc, tc, stages)
+        cpu = cpu_baseline(orc, F, sbs, mc, tc, stages, dict(hme=hme_host, conv=(CB, nblk16)))
 
     total_sb = n_sb * args.steps * world
     out = {
@@ -476,7 +478,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(orc, F, sbs, mc, tc, stages):
+def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
     """Oracle port, all host cores, bounded sample (about 10-30 s of CPU time in total)."""
     from conftest import ptr
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -535,11 +537,82 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages):
                                       I3(*[p.shape[1] for p in F.cur]), 1, F.w, F.h, ptr(F.skip8), F.cdef_damping, 8, 0, ptr(mse), be[0], be[1])
         t = par(work, split(n))
         sec_per_sb["cdef_search"] = t / n
+    if "cdef_apply" in keys:
+        # whole-frame call on a 4-SB-row crop of the picture (the function has no fb range): single-threaded, scaled to `cores`
+        P3, I3 = C.c_void_p * 3, C.c_int * 3
+        rows = min(F.h, 256)
+        ins = [np.ascontiguousarray(F.ref[p][:rows >> (p > 0)]) for p in range(3)]
+        outs = [a.copy() for a in ins]
+        nfb = F.sb_cols * (rows // 64)
+        t0 = time.perf_counter()
+        orc.orc_cdef_apply_frame(P3(*[a.ctypes.data for a in ins]), P3(*[a.ctypes.data for a in outs]), I3(*[a.shape[1] for a in ins]), 1, F.w, rows,
+                                 ptr(np.ascontiguousarray(F.skip8[:(rows // 8) * (F.w // 8)])), ptr(F.cdef_y[:nfb].copy()), ptr(F.cdef_uv[:nfb].copy()), F.cdef_damping, 8)
+        sec_per_sb["cdef_apply"] = (time.perf_counter() - t0) / nfb / cores
+    if "pyr" in keys or "hme" in keys:
+        W_, H_, st = F.w, F.h, F.cur_y_p.shape[1]
+        org = F.pad * st + F.pad
+        PQ, PS = 32, 16
+        planes = {}
+        t0 = time.perf_counter()
+        for name, src_p in (("cur", F.cur_y_p), ("ref", F.ref_y_p)):
+            q = np.zeros((H_ // 2 + 2 * PQ, W_ // 2 + 2 * PQ), np.uint8); s_ = np.zeros((H_ // 4 + 2 * PS, W_ // 4 + 2 * PS), np.uint8)
+            orc.orc_downsample_2d(C.c_void_p(src_p.ctypes.data + org), st, W_, H_, C.c_void_p(q.ctypes.data + PQ * q.shape[1] + PQ), q.shape[1], 2, 1)
+            orc.orc_downsample_2d(C.c_void_p(src_p.ctypes.data + org), st, W_, H_, C.c_void_p(s_.ctypes.data + PS * s_.shape[1] + PS), s_.shape[1], 4, 1)
+            planes[name] = (s_, q, src_p)
+        t_ds = time.perf_counter() - t0
+        nv = min(F.n_sb, 256)
+        mean, var = np.zeros(85, np.uint8), np.zeros(85, np.uint16)
+        t0 = time.perf_counter()
+        for i in range(nv):
+            sx, sy = (i % F.sb_cols) * 64, (i // F.sb_cols) * 64
+            orc.orc_variance_pyramid_sb(C.c_void_p(F.cur_y_p.ctypes.data + org + sy * st + sx), st, 0, ptr(mean), ptr(var))
+        t_vp = (time.perf_counter() - t0) / nv
+        if "pyr" in keys:
+            sec_per_sb["pyramids"] = (t_ds / F.n_sb + t_vp) / cores   # single-threaded, rows / SBs independent
+        if "hme" in keys:
+            # the same three SvtHipSadLoop job lists the GPU stage gets, one C call per thread and level
+            n = min(F.n_sb, cores * 8)
+            t = 0.0
+            for lvl in range(3):
+                cur_t, ref_t = planes["cur"][lvl], planes["ref"][lvl]
+                S_ = jobs["hme"][lvl]
+                sad_o = np.zeros(F.n_sb, np.uint32); xy_o = np.zeros((F.n_sb, 2), np.int16)
+                t += par(lambda be: orc.orc_sad_loop_batch(ptr(cur_t), cur_t.shape[1], ptr(ref_t), ref_t.shape[1], S_, be[0], be[1], ptr(sad_o), ptr(xy_o)), split(n))
+            sec_per_sb["hme_l0_l1_l2"] = t / n
+    if "subpel" in keys:
+        CB_, nb = jobs["conv"]   # the SvtHipConvBlk list of the GPU stage (16 blocks per SB, raster order)
+        n = min(nb, cores * 8 * 16)
+        st = F.ref_y_p.shape[1]
+        dst = np.zeros((F.h, F.w), np.uint8)
+        t = par(lambda be: orc.orc_subpel_predict_batch(1, 8, C.c_void_p(F.ref_y_p.ctypes.data + F.pad * st + F.pad), st, ptr(dst), F.w, CB_, be[0], be[1]), split(n))
+        sec_per_sb["subpel_convolve"] = t / (n / 16.0)
+    if "sgr_search" in keys or "sgr_apply" in keys:
+        # luma band of 4 unit rows, one unit column per work item; chroma adds half as many samples (x 1.5)
+        EXT_ = 3
+        rows = min(F.h, 256)
+        ext = np.ascontiguousarray(np.pad(F.ref[0][:rows], EXT_, mode="edge")); est = ext.shape[1]
+        eoff = EXT_ * est + EXT_
+        ncol = F.w // 64
+        nunit = ncol * (rows // 64)
+        if "sgr_search" in keys:
+            def work(c):
+                sums = np.zeros((rows // 64, 16, 5), np.int64)
+                orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + eoff + 64 * c), 1, est, C.c_void_p(F.cur[0].ctypes.data + 64 * c), F.cur[0].shape[1], 64, rows, 0, 0, 64, 8, 0xFFFF, ptr(sums))
+            sec_per_sb["sgr_search"] = par(work, list(range(ncol))) / nunit * 1.5
+        if "sgr_apply" in keys:
+            uep = np.full(rows // 64, 3, np.uint8); uxqd = np.tile(np.array([-30, 40], np.int32), (rows // 64, 1)).copy()
+            dst = np.zeros((rows, F.w), np.uint8)
+            work_ext = [ext.copy() for _ in range(cores)]
+            def work(c):
+                e = work_ext[c % cores]
+                orc.orc_sgr_apply_plane(C.c_void_p(F.ref[0].ctypes.data + 64 * c), F.ref[0].shape[1], C.c_void_p(e.ctypes.data + eoff + 64 * c), est, 1, 64, rows, 0, 0, 64, 8,
+                                        ptr(uep), ptr(uxqd), C.c_void_p(dst.ctypes.data + 64 * c), F.w)
+            sec_per_sb["sgr_apply"] = par(work, list(range(ncol))) / nunit * 1.5
     total = sum(sec_per_sb.values())
     return dict(value=1.0 / total if total > 0 else None, unit="SB/s", cores=cores, kind="port",
                 sample="oracle C port (scalar, gcc -O2) of the same stage chain on a bounded sample of the same frame, "
                        f"{cores} threads; seconds per SB per stage: " + ", ".join(f"{k}={v:.2e}" for k, v in sec_per_sb.items())
-                       + " (cdef_apply not timed on CPU; deblock timed single-threaded and divided by cores)")
+                       + " (deblock, cdef_apply, pyramids timed single-threaded and divided by cores; SGR timed on luma and scaled x1.5 for 4:2:0)")
 
 
 if __name__ == "__main__":

@@ -130,3 +130,25 @@ uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, 
     const int64_t var = (int64_t)(*sse) - (((int64_t)sum * sum) / (w * h));
     return var >= 0 ? (uint32_t)var : 0;
 }
+
+/* The prediction batch svt_hip_subpel_predict_batch_dev receives (include/svt_hip.h, SvtHipConvBlk), blocks [begin, end), walked
+ * with the single-block restatements above (mode 0: convolve_*_sr, mode 1: upsampled_pred).  Tests / bench.py CPU baseline. */
+typedef struct {
+    int32_t src_x, src_y, dst_x, dst_y;
+    uint8_t w, h, bank_x, bank_y, subpel_x, subpel_y, mode, reserved;
+} OrcConvBlk;
+void orc_subpel_predict_batch(int pix_bytes, int bd, const void *ref, int ref_stride, void *dst, int dst_stride, const void *blks_, int begin, int end) {
+    const OrcConvBlk *blks = (const OrcConvBlk *)blks_;
+    for (int i = begin; i < end; i++) {
+        const OrcConvBlk *b = &blks[i];
+        const uint8_t *s = (const uint8_t *)ref + ((ptrdiff_t)b->src_y * ref_stride + b->src_x) * pix_bytes;
+        uint8_t *d = (uint8_t *)dst + ((size_t)b->dst_y * dst_stride + b->dst_x) * pix_bytes;
+        if (b->mode == 0) {
+            orc_convolve_sr(s, ref_stride, d, dst_stride, pix_bytes, b->w, b->h, b->bank_x, b->bank_y, b->subpel_x, b->subpel_y, bd);
+        } else {
+            uint8_t tmp[128 * 128];
+            orc_upsampled_pred(s, ref_stride, tmp, b->w, b->h, b->subpel_x >> 1, b->subpel_y >> 1, b->bank_x);
+            for (int y = 0; y < b->h; y++) memcpy(d + (size_t)y * dst_stride, tmp + y * b->w, b->w);
+        }
+    }
+}

@@ -59,3 +59,24 @@ void orc_variance_pyramid_sb(const uint8_t *sb, int stride, int full_precision, 
     for (int i = 0; i < 64; i++) PUT(21 + i, m8[i], q8[i]);
 #undef PUT
 }
+
+/* The HME batch the GPU entry point svt_hip_sad_loop_batch_dev receives (include/svt_hip.h, SvtHipSadLoop), walked with the
+ * single-search restatement above: jobs [begin, end).  Used by tests and by bench.py's CPU baseline (one C call per thread). */
+typedef struct {
+    int32_t src_x, src_y, ref_x, ref_y;
+    int16_t bw, bh, sa_w, sa_h, row_step, reserved;
+} OrcSadLoopJob;
+void orc_sad_loop_batch(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, const void *jobs_, int begin, int end,
+                        uint32_t *best_sad, int16_t *best_xy) {
+    const OrcSadLoopJob *jobs = (const OrcSadLoopJob *)jobs_;
+    for (int i = begin; i < end; i++) {
+        const OrcSadLoopJob *j = &jobs[i];
+        uint64_t bs = 0xffffff;
+        int16_t xc = 0, yc = 0;
+        if (j->sa_w > 0 && j->sa_h > 0)
+            orc_sad_loop(src + (size_t)j->src_y * src_stride + j->src_x, (uint32_t)(src_stride * j->row_step), ref + (size_t)j->ref_y * ref_stride + j->ref_x,
+                         (uint32_t)(ref_stride * j->row_step), (uint32_t)(j->bh / j->row_step), (uint32_t)j->bw, &bs, &xc, &yc, (uint32_t)ref_stride, j->sa_w, j->sa_h);
+        best_sad[i] = (uint32_t)bs;
+        if (bs != 0xffffff) { best_xy[2 * i] = xc; best_xy[2 * i + 1] = yc; }
+    }
+}

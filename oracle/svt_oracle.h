@@ -140,6 +140,10 @@ uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_st
 uint32_t orc_variance_hbd10(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
 
 /* ---------------------------------------------------------------- pyramids (pyramid_oracle.c) --- */
+void orc_sad_loop_batch(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, const void *jobs /* SvtHipSadLoop[] */, int begin,
+                        int end, uint32_t *best_sad, int16_t *best_xy);
+void orc_subpel_predict_batch(int pix_bytes, int bd, const void *ref, int ref_stride, void *dst, int dst_stride, const void *blks /* SvtHipConvBlk[] */,
+                              int begin, int end);
 void orc_downsample_2d(const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered);
 void orc_variance_pyramid_sb(const uint8_t *sb, int stride, int full_precision, uint8_t mean_out[85], uint16_t var_out[85]);
 
