@@ -78,26 +78,37 @@ __device__ __forceinline__ void sad_loop_fast(const SvtHipSadLoop& d, const uint
                                               unsigned long long& best) {
     constexpr int SEGS = BW / 8, FLUSH = 256 / BW;
     const int rstep = d.row_step, rows = d.bh / rstep;
-    stage_rows(lds_src, kHmeSrcStrideDw, src + (size_t)d.src_y * src_stride + d.src_x, src_stride * rstep, rows, BW / 4, BW, tid, 256);
+    // HME searches are small (16x16 candidates = 32 units): the block's rows are dealt out to P adjacent lanes of a unit (lane p takes
+    // rows p, p+P, ...) so that all 256 lanes work; the P partial SAD vectors are added with lane shuffles.  The P lanes of a unit read
+    // P consecutive LDS rows at once, so the row strides are chosen per shape: 48 / 16 dwords put 4 consecutive rows of a 16-dword
+    // read on disjoint bank quarters (large windows, P = 1); 40 / 24 put 8 consecutive rows of a <= 4-dword read on disjoint 8-bank slots.
+    const int ng0 = (min(64, (int)d.sa_w) + 7) >> 3, th0 = min(64, (int)d.sa_h);
+    int P = 1;
+    while (P < 8 && th0 * ng0 * (2 * P) <= 256 && (rows % (2 * P)) == 0) P *= 2;
+    const int rs = P > 1 ? 40 : kHmeRefStrideDw, ss = P > 1 ? 24 : kHmeSrcStrideDw;
+    stage_rows(lds_src, ss, src + (size_t)d.src_y * src_stride + d.src_x, src_stride * rstep, rows, BW / 4, BW, tid, 256);
     for (int ty = 0; ty < d.sa_h; ty += 64) {
         const int th = min(64, d.sa_h - ty);
         for (int tx = 0; tx < d.sa_w; tx += 64) {
             const int tw = min(64, d.sa_w - tx), ng = (tw + 7) >> 3;
             __syncthreads();
-            stage_rows(lds_ref, kHmeRefStrideDw, ref + (size_t)(d.ref_y + ty) * ref_stride + d.ref_x + tx, ref_stride, th + (rows - 1) * rstep,
+            stage_rows(lds_ref, rs, ref + (size_t)(d.ref_y + ty) * ref_stride + d.ref_x + tx, ref_stride, th + (rows - 1) * rstep,
                        kHmeRefRowDw, tw + BW - 1, tid, 256);
             __syncthreads();
-            for (int u = tid; u < th * ng; u += 256) {
+            const int rows_p = rows / P;
+            for (int w = tid; w < th * ng * P; w += 256) {
+                const int u = w / P, part = w & (P - 1);
                 const int y = u / ng, g = u - y * ng;
                 uint32_t acc32[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) acc32[c] = 0;
-                for (int r0 = 0; r0 < rows; r0 += FLUSH) {
+                for (int n0 = 0; n0 < rows_p; n0 += FLUSH) {
                     uint64_t a0 = 0, a1 = 0;
-                    const int r1 = min(rows, r0 + FLUSH);
-                    for (int r = r0; r < r1; r++) {
-                        const uint32_t* rp = lds_ref + (y + r * rstep) * kHmeRefStrideDw + 2 * g;
-                        const uint32_t* sp = lds_src + r * kHmeSrcStrideDw;
+                    const int n1 = min(rows_p, n0 + FLUSH);
+                    for (int n = n0; n < n1; n++) {
+                        const int r = part + n * P;
+                        const uint32_t* rp = lds_ref + (y + r * rstep) * rs + 2 * g;
+                        const uint32_t* sp = lds_src + r * ss;
                         uint64_t ev[SEGS + 1], od[SEGS];
 #pragma unroll
                         for (int k = 0; k <= SEGS; k++) ev[k] = *(const uint64_t*)(rp + 2 * k);
@@ -115,13 +126,18 @@ __device__ __forceinline__ void sad_loop_fast(const SvtHipSadLoop& d, const uint
                     acc32[0] += (uint32_t)a0 & 0xFFFFu; acc32[1] += ((uint32_t)a0) >> 16; acc32[2] += (uint32_t)(a0 >> 32) & 0xFFFFu; acc32[3] += (uint32_t)(a0 >> 48);
                     acc32[4] += (uint32_t)a1 & 0xFFFFu; acc32[5] += ((uint32_t)a1) >> 16; acc32[6] += (uint32_t)(a1 >> 32) & 0xFFFFu; acc32[7] += (uint32_t)(a1 >> 48);
                 }
-                const uint32_t idx0 = (uint32_t)((ty + y) * d.sa_w + tx + 8 * g);
+                for (int m = 1; m < P; m <<= 1)   // P adjacent lanes hold the parts of one unit (groups never straddle the loop bound)
 #pragma unroll
-                for (int c = 0; c < 8; c++)
-                    if (8 * g + c < tw) {
-                        const unsigned long long key = ((unsigned long long)acc32[c] << 32) | (idx0 + c);
-                        best = key < best ? key : best;
-                    }
+                    for (int c = 0; c < 8; c++) acc32[c] += (uint32_t)__shfl_xor((int)acc32[c], m, 64);
+                const uint32_t idx0 = (uint32_t)((ty + y) * d.sa_w + tx + 8 * g);
+                if (part == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        if (8 * g + c < tw) {
+                            const unsigned long long key = ((unsigned long long)acc32[c] << 32) | (idx0 + c);
+                            best = key < best ? key : best;
+                        }
+                }
             }
         }
     }
@@ -130,7 +146,7 @@ __device__ __forceinline__ void sad_loop_fast(const SvtHipSadLoop& d, const uint
 __global__ void __launch_bounds__(256)
 sad_loop_kernel(const uint8_t* __restrict__ src, int src_stride, const uint8_t* __restrict__ ref, int ref_stride,
                 const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_src[64 * kHmeSrcStrideDw];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_src[64 * 24];   // row stride 16 or 24 dwords (see sad_loop_fast)
     __shared__ __attribute__((aligned(16))) uint32_t lds_ref[127 * kHmeRefStrideDw];
     __shared__ unsigned long long s_best[4];
     const SvtHipSadLoop d = searches[blockIdx.x];
