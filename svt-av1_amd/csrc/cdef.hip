@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
+#include "lds_stage.h"
 
 namespace {
 
@@ -46,11 +47,13 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, int tstride, const PI
                                            int tw, int th, int tid, int nt) {
     // tile covers [x0 - 8, x0 + tw + 8) x [y0 - 3, y0 + th + 3)
     const int cols = tw + 2 * kHB, rows = th + 2 * kVB;
-    for (int i = tid; i < rows * cols; i += nt) {
-        const int r = i / cols, c = i - r * cols;
-        const int x = x0 - kHB + c, y = y0 - kVB + r;
-        tile[r * tstride + c] = (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)plane[(size_t)y * stride + x] : (uint16_t)kVeryLarge;
-    }
+    batched_stage<8, uint16_t>(rows * cols, tid, nt,
+        [&](int i) {
+            const int r = i / cols, c = i - r * cols;
+            const int x = x0 - kHB + c, y = y0 - kVB + r;
+            return (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)plane[(size_t)y * stride + x] : (uint16_t)kVeryLarge;
+        },
+        [&](int i, uint16_t v) { const int r = i / cols, c = i - r * cols; tile[r * tstride + c] = v; });
 }
 
 // svt_cdef_find_dir_c (EbCdef.c:132-196) for one 8x8 block by one wave; lane = pixel on entry.

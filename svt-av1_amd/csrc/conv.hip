@@ -35,9 +35,18 @@ subpel_predict_kernel(const PIX* __restrict__ ref, int ref_stride, PIX* __restri
     for (int oy = 0; oy < b.h; oy += 16)
         for (int ox = 0; ox < b.w; ox += 16) {
             __syncthreads();
-            for (int i = tid; i < 23 * 23; i += 256) {
-                const int r = i / 23, c = i - r * 23;
-                s_src[r * 24 + c] = ref[(ptrdiff_t)(b.src_y + oy + r - 3) * ref_stride + (b.src_x + ox + c - 3)];
+            {   // 529 samples / 256 threads: issue all three loads before the first LDS store
+                PIX v[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int i = tid + 256 * u, r = i / 23, c = i - r * 23;
+                    if (i < 23 * 23) v[u] = ref[(ptrdiff_t)(b.src_y + oy + r - 3) * ref_stride + (b.src_x + ox + c - 3)];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int i = tid + 256 * u, r = i / 23, c = i - r * 23;
+                    if (i < 23 * 23) s_src[r * 24 + c] = v[u];
+                }
             }
             __syncthreads();
             const bool live = (ox + tx < b.w) && (oy + ty < b.h);

@@ -3,6 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// total elements, element i -> value load(i), then store(i, value): U independent global loads are issued before the first store, so a
+// thread pays one memory latency per U elements instead of one per element (the compiler does not pipeline the plain loop).
+template <int U, typename T, typename LoadF, typename StoreF>
+__device__ __forceinline__ void batched_stage(int total, int tid, int nthreads, LoadF load, StoreF store) {
+    for (int i0 = tid; i0 < total; i0 += nthreads * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nthreads; if (i < total) v[u] = load(i); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nthreads; if (i < total) store(i, v[u]); }
+    }
+}
+
 struct __attribute__((aligned(4))) Dw2 { uint32_t x, y; };  // 8-byte value that is only 4-byte aligned in LDS
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
+#include "lds_stage.h"
 
 namespace {
 
@@ -55,20 +56,18 @@ template <typename PIX>
 __device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restrict__ plane, int stride, int pw, int ph, int x0, int y0, int tid,
                                                  const StripeCtx<PIX> sc = StripeCtx<PIX>{nullptr, 0, 0, 0, 0, 0}) {
     if (tid < 256) L.xtab[tid] = tid == 0 ? 1 : (tid == 255 ? 256 : (uint16_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-        uint16_t v;
-        if (sc.above && yy < sc.sy0) {
-            v = (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-        } else if (sc.below && yy >= sc.sy1) {
-            v = (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-        } else {
+    batched_stage<4, uint16_t>(IH * IW, tid, 256,
+        [&](int i) {
+            const int r = i / IW, c = i - r * IW;
+            const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+            if (sc.above && yy < sc.sy0)
+                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+            if (sc.below && yy >= sc.sy1)
+                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
             const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
-            v = (uint16_t)plane[(ptrdiff_t)y * stride + x];
-        }
-        L.in[i] = v;
-    }
+            return (uint16_t)plane[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { L.in[i] = v; });
     __syncthreads();
     for (int i = tid; i < PH1 * PW; i += 256) {            // r = 1: position (i/PW - 1, i%PW - 1)
         const int r = i / PW, c = i - r * PW;               // window centre in `in` coordinates: (r + 2, c + 2)
@@ -255,11 +254,13 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         xt[tid] = (A << 20) | (256u - A);
         if (tid < 80) acc[tid / 5][tid % 5] = 0ull;
     }
-    for (int i = tid; i < S_IH * S_IW; i += 256) {
-        const int r = i / S_IW, c = i - r * S_IW;
-        const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
-        in[i] = (uint16_t)dgd[(ptrdiff_t)y * stride + x];
-    }
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
+        [&](int i) {
+            const int r = i / S_IW, c = i - r * S_IW;
+            const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
+            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { in[i] = v; });
     __syncthreads();
 
     // ---- parameter-set independent part of A/B for the positions this thread owns
