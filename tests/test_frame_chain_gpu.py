@@ -1,6 +1,6 @@
 """GPU parity of the WHOLE bench step on a small frame: ME -> fwd txfm + quant -> inv txfm + recon ->
-deblock -> CDEF search -> CDEF apply, every stage fed by the previous stage's GPU output and compared
-with the oracle running the same chain (workload identical to bench.py's, tests/workload.py)."""
+deblock -> CDEF search -> CDEF apply -> self-guided search -> self-guided apply (stripe-aware), every stage fed by the
+previous stage's GPU output and compared with the oracle running the same chain (workload identical to bench.py's, tests/workload.py)."""
 import ctypes as C
 
 import numpy as np
@@ -88,4 +88,25 @@ def test_chain_small_frame(hip, pkg, orc):
                                             d_cy, d_cuv, F.cdef_damping, 8, d_dir))
     for p in range(3):
         assert np.array_equal(hip.to_host(d_out[p], F.ref[p].shape, np.uint8), o_out[p]), ("cdef apply", p)
+    # ---------------- loop restoration on the CDEF output; stripe context rows come from the deblocked picture (d_rec)
+    EXT, US = 3, 64
+    rng = np.random.default_rng(77)
+    for p in range(3):
+        ss = int(p > 0)
+        ph, pw = o_out[p].shape
+        ext = np.ascontiguousarray(np.pad(o_out[p], EXT, mode="edge")); st = ext.shape[1]; off = EXT * st + EXT
+        nu = max((pw + US // 2) // US, 1) * max((ph + US // 2) // US, 1)
+        e_sums = np.zeros((nu, 16, 5), np.int64)
+        orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + off), 1, st, ptr(F.cur[p]), F.cur[p].shape[1], pw, ph, ss, ss, US, 8, 0xFFFF, ptr(e_sums))
+        u_ep = rng.integers(0, 16, nu).astype(np.uint8); u_ep[nu // 2] = 255
+        u_xqd = np.stack([rng.integers(-96, 32, nu), rng.integers(-32, 96, nu)], 1).astype(np.int32)
+        e_dst = np.zeros((ph, pw), np.uint8)
+        work = ext.copy()
+        orc.orc_sgr_apply_plane(ptr(o_dlf[p]), o_dlf[p].shape[1], C.c_void_p(work.ctypes.data + off), st, 1, pw, ph, ss, ss, US, 8, ptr(u_ep), ptr(u_xqd), ptr(e_dst), pw)
+        d_ext, d_sums, d_dst, d_ep, d_xqd = hip.to_device(ext), hip.to_device(np.zeros_like(e_sums)), hip.to_device(np.zeros_like(e_dst)), hip.to_device(u_ep), hip.to_device(u_xqd)
+        hip.check(L.svt_hip_sgr_search_plane_dev(hip.h, 1, 8, d_ext.value + off, st, d_cur[p], strides[p], pw, ph, US, ss, 0xFFFF, d_sums), "sgr search")
+        assert np.array_equal(hip.to_host(d_sums, e_sums.shape, np.int64), e_sums), ("sgr search", p)
+        hip.check(L.svt_hip_sgr_apply_plane_dev(hip.h, 1, 8, d_ext.value + off, st, d_dst, pw, pw, ph, US, ss, d_rec[p], strides[p], d_ep, d_xqd), "sgr apply")
+        assert np.array_equal(hip.to_host(d_dst, e_dst.shape, np.uint8), e_dst), ("sgr apply", p)
+        hip.free(d_ext, d_sums, d_dst, d_ep, d_xqd)
     hip.free(*d_cur, *d_pred, *d_rec, *d_out, d_skip, d_mse, d_dir, d_var, d_cy, d_cuv)
