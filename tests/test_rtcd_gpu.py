@@ -158,3 +158,63 @@ def test_selfguided_wrappers(rtcd, orc):
                 dst = gd.ctypes.data >> 1 if bd > 8 else gd.ctypes.data
                 rtcd.svt_apply_selfguided_restoration(p_ref, w, h, 100, ep, xqd.ctypes.data, dst, w + 4, None, bd, int(bd > 8))
                 assert np.array_equal(gd, ed), ("sgr apply", bd, w, h, ep)
+
+
+def test_wrappers_vs_reference_c(rtcd, ref):
+    """The drop-in claim stated literally: the reference's own `*_c` function (oracle/_ref/libsvtav1_ref.so, built from the
+    reference sources in place; skipped when that library is absent) and the HIP wrapper installed in the same RTCD slot get
+    identical arguments and must leave identical outputs."""
+    rng = np.random.default_rng(9)
+    # --- svt_sad_loop_kernel
+    ref_img = rng.integers(0, 256, (160, 200)).astype(np.uint8); src = rng.integers(0, 256, (64, 64)).astype(np.uint8)
+    for (bw, bh, saw, sah) in ((16, 16, 64, 32), (64, 64, 16, 16), (32, 32, 24, 8)):
+        out = []
+        for fn in (ref.svt_sad_loop_kernel_c, rtcd.svt_sad_loop_kernel):
+            bs, xc, yc = C.c_uint64(), C.c_int16(-3), C.c_int16(-3)
+            fn(C.c_void_p(src.ctypes.data), 64, C.c_void_p(ref_img.ctypes.data), 200, bh, bw, C.byref(bs), C.byref(xc), C.byref(yc), 200, saw, sah)
+            out.append((bs.value, xc.value, yc.value))
+        assert out[0] == out[1], (bw, bh, out)
+    # --- svt_aom_sad / variance (per-size pointers)
+    a = rng.integers(0, 256, (140, 150)).astype(np.uint8); b = rng.integers(0, 256, (140, 170)).astype(np.uint8)
+    for i, (w, h) in enumerate(SIZES):
+        f = getattr(ref, f"svt_aom_sad{w}x{h}_c"); f.restype = C.c_uint32
+        assert f(ptr(a), 150, ptr(b), 170) == rtcd.svt_aom_sad[i](a.ctypes.data, 150, b.ctypes.data, 170), (w, h)
+        f = getattr(ref, f"svt_aom_variance{w}x{h}_c"); f.restype = C.c_uint32
+        s0, s1 = C.c_uint(), C.c_uint()
+        assert f(ptr(a), 150, ptr(b), 170, C.byref(s0)) == rtcd.svt_aom_variance[i](a.ctypes.data, 150, b.ctypes.data, 170, C.byref(s1)) and s0.value == s1.value, (w, h)
+    # --- forward / inverse transforms
+    for slot, (ts, w, h) in enumerate(FWD):
+        tt = tc.legal_types(ts)[-1]
+        x = rng.integers(-255, 256, (h, w)).astype(np.int16)
+        e = tc.ref_fwd(ref, x, w, tt, ts, 8); g = np.zeros(w * h, np.int32)
+        rtcd.svt_av1_fwd_txfm2d[slot](x.ctypes.data, g.ctypes.data, w, tt, 8)
+        assert np.array_equal(e, g), ("fwd", ts)
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]; kw, kh = min(w, 32), min(h, 32)
+        tt = tc.legal_types(ts)[-1]
+        coef = (rng.integers(-500, 500, kw * kh) * (rng.random(kw * kh) < 0.3)).astype(np.int32)
+        cfull = np.zeros(w * h, np.int32); cfull[:kw * kh] = coef   # the reference reads up to W*H entries of its input buffer
+        pred = rng.integers(0, 1024, (h, w)).astype(np.uint16)
+        e = np.zeros((h, w), np.uint16); g = np.zeros((h, w), np.uint16)
+        tc.ref_inv(ref, cfull, pred, w, e, w, tt, ts, 10)
+        if w == h:
+            rtcd.svt_av1_inv_txfm2d_add_sq[ts](cfull.ctypes.data, pred.ctypes.data, w, g.ctypes.data, w, tt, 10)
+        elif min(w, h) == 4:
+            rtcd.svt_av1_inv_txfm2d_add_rect4(cfull.ctypes.data, pred.ctypes.data, w, g.ctypes.data, w, tt, ts, 10)
+        else:
+            rtcd.svt_av1_inv_txfm2d_add_rect(cfull.ctypes.data, pred.ctypes.data, w, g.ctypes.data, w, tt, ts, kw * kh, 10)
+        assert np.array_equal(e, g), ("inv", ts)
+    # --- self-guided filter / apply
+    img = np.clip(rng.normal(120, 40, (90, 100)), 0, 255).astype(np.uint8)
+    p = img.ctypes.data + 9 * 100 + 11
+    tmp = np.zeros(64 * 64 * 8 + 4096, np.int32)   # RESTORATION_TMPBUF_SIZE scratch of the reference
+    for ep in (0, 9, 12, 15):
+        e0 = np.zeros((56, 64), np.int32); e1 = e0.copy(); g0 = e0.copy(); g1 = e0.copy()
+        ref.svt_av1_selfguided_restoration_c(C.c_void_p(p), 64, 56, 100, ptr(e0), ptr(e1), 64, ep, 8, 0)
+        rtcd.svt_av1_selfguided_restoration(p, 64, 56, 100, g0.ctypes.data, g1.ctypes.data, 64, ep, 8, 0)
+        assert np.array_equal(e0, g0) and np.array_equal(e1, g1), ("sgr filter", ep)
+        xqd = np.array([-40, 50], np.int32)
+        ed = np.zeros((56, 64), np.uint8); gd = np.zeros((56, 64), np.uint8)
+        ref.svt_apply_selfguided_restoration_c(C.c_void_p(p), 64, 56, 100, ep, ptr(xqd), ptr(ed), 64, ptr(tmp), 8, 0)
+        rtcd.svt_apply_selfguided_restoration(p, 64, 56, 100, ep, xqd.ctypes.data, gd.ctypes.data, 64, None, 8, 0)
+        assert np.array_equal(ed, gd), ("sgr apply", ep)
