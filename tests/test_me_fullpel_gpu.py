@@ -103,3 +103,14 @@ def test_1080p_row_band_vs_oracle_and_properties(hip, orc):
                 cy = int(rng.integers(d.y_origin, d.y_origin + d.height))
                 r2 = ref_p[pad + d.sb_y + oy + cy: pad + d.sb_y + oy + cy + sz, pad + d.sb_x + ox + cx: pad + d.sb_x + ox + cx + sz].astype(np.int32)
                 assert int(np.abs(s - r2).sum()) >= int(g_sad[i, pu])
+
+
+def test_maximum_search_area(hip, orc):
+    """256 x 256 candidates per SB -- the reference's largest search area (MAX_SEARCH_AREA, 16 tiles of 64 x 64 per SB, raster index
+    up to 65535 = the full 16-bit key field) -- on a frame whose inner SBs get the whole window and whose border SBs get cropped ones;
+    flat regions make exact SAD ties common, so the raster-order tie-break is exercised across tile boundaries."""
+    w, h = 320, 256
+    cur, refp = mc.synth.make_luma_pair(w, h, seed=17)
+    cur[64:128, 64:192] = 90; refp[:, :96] = 90; refp[40:200, 150:300] = 90   # large flat areas -> ties
+    _run(hip, orc, cur, refp, w, h, 256, 256, 0)
+    _run(hip, orc, cur, refp, w, h, 256, 256, 1)
