@@ -416,7 +416,7 @@ def main():
     achieved_gbs = BYTES_PER_SB[dominant["name"]] * n_sb / (dom_ms * 1e-3) / 1e9
     # HBM traffic of the dominant stage per frame from the PMC passes of the latest profiled round (tools/collect_profiles.sh:
     # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs; summary committed as profiles/<round>/pmc_traffic.json)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_busy = None, None, None
     try:
         rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
         if rounds:
@@ -427,6 +427,10 @@ def main():
             tot = sum((e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)) * e["launches"]
                       for k, e in pt.items() if any(k.startswith(nm) for nm in names))
             traffic = tot / frames if frames and tot else None
+            # VALU issue utilisation of the same launches: SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs
+            act = sum(e.get("sq", {}).get("SQ_ACTIVE_INST_VALU", 0.0) * e["launches"] for k, e in pt.items() if any(k.startswith(nm) for nm in names))
+            dur = sum(e["avg_us"] * e["launches"] for k, e in pt.items() if any(k.startswith(nm) for nm in names))
+            valu_busy = (act * 4.0) / (1024 * dur * 1e-6 * 2.4e9) if dur else None
     except (OSError, ValueError, KeyError):
         traffic = None
 
@@ -461,6 +465,7 @@ def main():
                    "stages_ms": per_stage, "parity_spot_check": parity_ok},
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "valu_busy": valu_busy,   # fraction of VALU issue cycles used by the dominant stage's kernels (profiled round, 2.4 GHz)
                      "traffic_note": None if traffic is None else f"bytes per frame of the stage's launches, FETCH_SIZE + WRITE_SIZE from {traffic_src} "
                                      "(raw counters x 1024; narrow loads are uncalibrated on gfx950, Infinity-Cache hits included)",
                      "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / HIP-event stage time of the slowest stage; the ME and CDEF-search "

@@ -238,6 +238,18 @@ int svt_hip_block_sad_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, 
 int svt_hip_block_variance_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_a, int a_stride, const void *d_b,
                                      int b_stride, const SvtHipBlkPair *d_pairs, int n, uint32_t *d_var, uint32_t *d_sse);
 
+/* Coefficient-domain distortion of a list of transform blocks laid out like the outputs of svt_hip_fwd_txfm_quant_batch_dev
+ * (n_per_block int32 per block, block after block):  d_out[blk][0] = sum (coeff - recon_coeff)^2, [1] = sum coeff^2, [2] = sum |coeff|.
+ * Replaces svt_full_distortion_kernel32_bits (common_dsp_rtcd.h; Common/Codec/EbPictureOperators.c:156; [0] = DIST_CALC_RESIDUAL,
+ * [1] = DIST_CALC_PREDICTION), svt_full_distortion_kernel_cbf_zero32_bits (:212; pass d_recon_coeff = NULL: [0] = [1]),
+ * svt_av1_block_error (aom_dsp_rtcd.h, common_dsp_rtcd.c:56: returns [0], *ssz = [1]) and svt_aom_satd (:47: [2]). */
+int svt_hip_coeff_distortion_batch_dev(SvtHipCtx *ctx, const int32_t *d_coeff, const int32_t *d_recon_coeff, int n_per_block,
+                                       int nblk, uint64_t *d_out);
+/* svt_aom_sse / svt_aom_highbd_sse (aom_dsp_rtcd.h:93-94) and svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits
+ * (common_dsp_rtcd.h) for a list of block pairs: d_sse[n] = sum (a - b)^2. */
+int svt_hip_block_sse_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, int a_stride, const void *d_b, int b_stride,
+                                const SvtHipBlkPair *d_pairs, int n, uint64_t *d_sse);
+
 /* ------------------------------------------------------- HME pyramids, variance pyramid, HME search */
 /* decimation_2d / downsample_2d (Encoder/Codec/EbPictureAnalysisProcess.c:193,223): step 2 or 4,
  * filtered = 0 point-decimate, 1 = 2x2 box (a+b+c+d+2)>>2.  Output (w/step) x (h/step). */

@@ -80,3 +80,15 @@ int32_t orc_cul_level(const int32_t *qcoeff, const int16_t *scan, int eob) {
     else if (qcoeff[0] > 0) cul += 2 << 6;
     return cul;
 }
+
+/* Coefficient-domain distortion of one block (flat, n coefficients): out[0] = sum (c - r)^2 (r == NULL: sum c^2), out[1] = sum c^2,
+ * out[2] = sum |c|.  svt_full_distortion_kernel32_bits_c / _cbf_zero32_bits_c (Common/Codec/EbPictureOperators.c:156,212),
+ * svt_av1_block_error_c and svt_aom_satd_c (Common/Codec/common_dsp_rtcd.c:56,47). */
+void orc_coeff_distortion(const int32_t *coeff, const int32_t *recon, int n, uint64_t out[3]) {
+    uint64_t res = 0, pred = 0, satd = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t c = coeff[i], d = recon ? c - recon[i] : c;
+        res += (uint64_t)(d * d); pred += (uint64_t)(c * c); satd += (uint64_t)(c < 0 ? -c : c);
+    }
+    out[0] = res; out[1] = pred; out[2] = satd;
+}

@@ -104,6 +104,7 @@ void orc_residual_8bit(const uint8_t *src, uint32_t src_stride, const uint8_t *p
 void orc_quantize(int variant, const int32_t *coeff, int n, const int16_t *zbin, const int16_t *round,
                   const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
                   const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale);
+void orc_coeff_distortion(const int32_t *coeff, const int32_t *recon, int n, uint64_t out[3]);
 int32_t orc_cul_level(const int32_t *qcoeff, const int16_t *scan, int eob);
 
 /* ---------------------------------------------------------------- deblocking (dlf_oracle.c) ---- */

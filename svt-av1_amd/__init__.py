@@ -107,6 +107,8 @@ def lib():
     L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]
     L.svt_hip_block_sad_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
     L.svt_hip_block_variance_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]
+    L.svt_hip_coeff_distortion_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.svt_hip_block_sse_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
     L.svt_hip_downsample_2d_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32, i32]
     L.svt_hip_variance_pyramid_dev.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.svt_hip_sad_loop_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp]

@@ -400,6 +400,19 @@ int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, in
     if (e != hipSuccess) return fail(c, e, "block sad launch");
     return SVT_HIP_OK;
 }
+int svt_hip_coeff_distortion_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, const int32_t* d_recon_coeff, int n_per_block, int nblk, uint64_t* d_out) {
+    if (!c || !d_coeff || !d_out || n_per_block <= 0 || nblk < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_coeff_distortion(c->stream, d_coeff, d_recon_coeff, n_per_block, nblk, d_out);
+    if (e != hipSuccess) return fail(c, e, "coeff distortion launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_block_sse_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, const SvtHipBlkPair* d_pairs,
+                                int n, uint64_t* d_sse) {
+    if (!c || !d_a || !d_b || !d_pairs || !d_sse || n < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_block_sse(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, d_pairs, n, d_sse);
+    if (e != hipSuccess) return fail(c, e, "block sse launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_a, int a_stride, const void* d_b, int b_stride,
                                      const SvtHipBlkPair* d_pairs, int n, uint32_t* d_var, uint32_t* d_sse) {
     if (!c || !d_a || !d_b || !d_pairs || !d_var || n < 0 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd == 10))) return SVT_HIP_ERR_BAD_ARG;

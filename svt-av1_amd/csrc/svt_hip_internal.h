@@ -18,6 +18,9 @@ int svt_hip_launch_inv_txfm_add(hipStream_t st, int tx_size, int pix_bytes, int 
                                 int pred_stride, void* recon, int recon_stride, const uint32_t* descs, int nblk);
 int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
                                  const uint16_t* edges_h, int units_w, int units_h, int sharpness, int level_v, int level_h);
+int svt_hip_launch_coeff_distortion(hipStream_t st, const int32_t* coeff, const int32_t* recon, int n, int nblk, uint64_t* out);
+int svt_hip_launch_block_sse(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride, const SvtHipBlkPair* pairs, int n,
+                             uint64_t* out);
 int svt_hip_launch_plane_sse(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride, int w, int h,
                              uint64_t* out);
 int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const rec[3], const int rec_stride[3], const void* const src[3],

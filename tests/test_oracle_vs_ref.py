@@ -483,3 +483,29 @@ def test_restoration_units_and_stripe_apply(orc, ref):
                                                        ptr(dst_r), pw, US, ptr(u_ep), ptr(u_xqd)) == 0
                     assert np.array_equal(dst_o, dst_r), (fw, fh, plane, US, bd, np.argwhere(dst_o != dst_r)[:5])
                     assert np.array_equal(buf_o, buf_r), "the CDEF picture must be restored after the stripes"
+
+
+def test_coefficient_and_pixel_distortion(orc, ref):
+    """orc_coeff_distortion == svt_full_distortion_kernel32_bits_c / _cbf_zero32_bits_c / svt_av1_block_error_c /
+    svt_aom_satd_c; orc_plane_sse == svt_aom_sse_c on blocks."""
+    rng = np.random.default_rng(515)
+    ref.svt_av1_block_error_c.restype = C.c_int64
+    ref.svt_aom_sse_c.restype = C.c_int64
+    orc.orc_plane_sse.restype = C.c_uint64
+    for (w, h) in ((4, 4), (8, 16), (32, 32), (64, 16)):
+        n = w * h
+        c = rng.integers(-30000, 30000, n).astype(np.int32); r = (c + rng.integers(-900, 900, n)).astype(np.int32)
+        o = np.zeros(3, np.uint64); d = np.zeros(2, np.uint64)
+        orc.orc_coeff_distortion(ptr(c), ptr(r), n, ptr(o))
+        ref.svt_full_distortion_kernel32_bits_c(ptr(c), w, ptr(r), w, ptr(d), w, h)
+        assert (o[0], o[1]) == (d[0], d[1])
+        ssz = C.c_int64()
+        c2 = np.clip(c, -20000, 20000).astype(np.int32); r2 = (c2 + rng.integers(-900, 900, n)).astype(np.int32)   # block_error squares in 32-bit int
+        orc.orc_coeff_distortion(ptr(c2), ptr(r2), n, ptr(o))
+        assert ref.svt_av1_block_error_c(ptr(c2), ptr(r2), C.c_int64(n), C.byref(ssz)) == int(o[0]) and ssz.value == int(o[1])
+        assert ref.svt_aom_satd_c(ptr(c2), n) == int(o[2])
+        orc.orc_coeff_distortion(ptr(c), None, n, ptr(o))
+        ref.svt_full_distortion_kernel_cbf_zero32_bits_c(ptr(c), w, ptr(d), w, h)
+        assert (o[0], o[1]) == (d[0], d[1]) and o[0] == o[1]
+        a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 9)).astype(np.uint8)
+        assert ref.svt_aom_sse_c(ptr(a), w + 3, ptr(b), w + 9, w, h) == orc.orc_plane_sse(1, ptr(a), w + 3, ptr(b), w + 9, w, h)
