@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="issue every launch on one stream (no intra-step concurrency)")
     ap.add_argument("--lanes", type=int, default=3, help="streams for the independent launches of a stage (debug)")
+    ap.add_argument("--tx-multi", default="inv", help="which transform stages use the mixed-size launch (debug): fwd,inv / fwd / inv / none")
+    ap.add_argument("--side-keys", default="pyr,hme,me,subpel", help="stages issued on the side stream (debug; must be source-side stages)")
     ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the main stream (debug)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--stages", default="all", help="comma list (debug): pyr,hme,me,subpel,txfm,inv,dlf,cdef_search,cdef_apply,sgr_search,sgr_apply")
@@ -230,24 +232,36 @@ def main():
         ctx.check(L.svt_hip_me_fullpel_frame_dev(ctx.h, d_cur_p.data_ptr(), d_ref_p.data_ptr(), F.cur_y_p.shape[1], PAD, PAD,
                                                  d_sbs.data_ptr(), n_sb, 0, d_sad.data_ptr(), d_mv.data_ptr()), "me")
 
-    def run_txfm():
-        parallel([lambda j=j: txfm_job(j) for j in tx_jobs])
+    # one mixed-size launch per 16 (size, plane) job lists (svt_hip_*_multi_dev): the 19 lists of a frame are 400-4000 blocks each
+    FJ = (pkg.FwdTxJob * len(tx_jobs))(); IJ = (pkg.InvTxJob * len(tx_jobs))()
+    for k, j in enumerate(tx_jobs):
+        p = j["plane"]
+        FJ[k] = pkg.FwdTxJob(j["ts"], j["n"], d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["qs"], j["st"],
+                             None, j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None)
+        IJ[k] = pkg.InvTxJob(j["ts"], j["n"], j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p], d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr())
 
     def txfm_job(j):
-        if True:
-            p = j["plane"]
-            ctx.check(L.svt_hip_fwd_txfm_quant_batch_dev(ctx.h, j["ts"], 1, d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p],
-                                                         j["desc"].data_ptr(), j["n"], C.byref(j["qs"]), C.byref(j["st"]), None,
-                                                         j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None), "fwd")
-
-    def run_inv():
-        parallel([lambda j=j: inv_job(j) for j in tx_jobs])
+        p = j["plane"]
+        ctx.check(L.svt_hip_fwd_txfm_quant_batch_dev(ctx.h, j["ts"], 1, d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p],
+                                                     j["desc"].data_ptr(), j["n"], C.byref(j["qs"]), C.byref(j["st"]), None,
+                                                     j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None), "fwd")
 
     def inv_job(j):
-        if True:
-            p = j["plane"]
-            ctx.check(L.svt_hip_inv_txfm_add_batch_dev(ctx.h, j["ts"], 1, 8, j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p],
-                                                       d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["n"]), "inv")
+        p = j["plane"]
+        ctx.check(L.svt_hip_inv_txfm_add_batch_dev(ctx.h, j["ts"], 1, 8, j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p],
+                                                   d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["n"]), "inv")
+
+    def run_txfm():
+        if "fwd" in args.tx_multi:
+            ctx.check(L.svt_hip_fwd_txfm_quant_multi_dev(ctx.h, 1, FJ, len(tx_jobs)), "fwd")
+        else:
+            parallel([lambda j=j: txfm_job(j) for j in tx_jobs])
+
+    def run_inv():
+        if "inv" in args.tx_multi:
+            ctx.check(L.svt_hip_inv_txfm_add_multi_dev(ctx.h, 1, 8, IJ, len(tx_jobs)), "inv")
+        else:
+            parallel([lambda j=j: inv_job(j) for j in tx_jobs])
 
     def run_dlf():
         for p in range(3):   # ~10 us kernels: a fork / join costs more than it hides
@@ -321,8 +335,8 @@ def main():
         dict(key="hme", name="hme_l0_l1_l2", run=run_hme, kernel="sad_loop_kernel"),
         dict(key="me", name="me_fullpel_85pu", run=run_me, kernel="me_fullpel_85pu_kernel"),
         dict(key="subpel", name="subpel_convolve", run=run_subpel, kernel="subpel_predict_kernel"),
-        dict(key="txfm", name="fwd_txfm_quant", run=run_txfm, kernel="fwd_txfm_quant_kernel"),
-        dict(key="inv", name="inv_txfm_recon", run=run_inv, kernel="inv_txfm_add_kernel"),
+        dict(key="txfm", name="fwd_txfm_quant", run=run_txfm, kernel="fwd_txfm_quant_multi_kernel"),
+        dict(key="inv", name="inv_txfm_recon", run=run_inv, kernel="inv_txfm_add_multi_kernel"),
         dict(key="dlf", name="deblock", run=run_dlf, kernel="deblock_pass_kernel"),
         dict(key="cdef_search", name="cdef_search", run=run_cdef_search, kernel="cdef_search_luma_kernel"),
         dict(key="cdef_apply", name="cdef_apply", run=run_cdef_apply, kernel="cdef_apply_kernel"),
@@ -332,7 +346,8 @@ def main():
     want = None if args.stages == "all" else set(args.stages.split(","))
     stages = [s for s in all_stages if want is None or s["key"] in want]
 
-    SOURCE_SIDE = ("pyr", "hme", "me", "subpel")   # read only the source / reference pictures: independent of the reconstruction chain
+    # read only the source / reference pictures: independent of the reconstruction chain
+    SOURCE_SIDE = tuple(k for k in args.side_keys.split(",") if k in ("pyr", "hme", "me", "subpel"))
 
     def step():
         if side is None:

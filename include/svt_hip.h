@@ -131,6 +131,31 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes, i
                                    const void *d_pred, int pred_stride, void *d_recon, int recon_stride,
                                    const uint32_t *d_descs, int nblk);
 
+/* Mixed-size launches: the same two operations for up to any number of (transform size, plane) job lists in ONE launch per 16 jobs.
+ * A frame's transform work is 15-20 short lists; launched one by one each leaves most of the 256 CUs idle.  Fields as in the
+ * single-size entry points; jobs is a HOST array (copied into the kernel arguments), every pointer inside is a device pointer. */
+typedef struct {
+    int32_t tx_size, nblk;
+    const void *d_src;  int32_t src_stride;
+    const void *d_pred; int32_t pred_stride;
+    const uint32_t *d_descs;
+    SvtHipQuantParams qp;
+    SvtHipScanTables scans;
+    int32_t *d_coeff, *d_qcoeff, *d_dqcoeff;
+    uint16_t *d_eob;
+    int32_t *d_cul_level;
+    uint64_t *d_energy;
+} SvtHipFwdTxJob;
+typedef struct {
+    int32_t tx_size, nblk;
+    const int32_t *d_dqcoeff;
+    const void *d_pred; int32_t pred_stride;
+    void *d_recon;      int32_t recon_stride;
+    const uint32_t *d_descs;
+} SvtHipInvTxJob;
+int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx *ctx, int pix_bytes, const SvtHipFwdTxJob *jobs, int njobs);
+int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const SvtHipInvTxJob *jobs, int njobs);
+
 /* ------------------------------------------------------------------ deblocking loop filter ------ */
 /* Per luma 4x4 unit summary of the reference's ModeInfo fields that set_lpf_parameters reads
  * (Encoder/Codec/EbDeblockingFilter.c:168-319): transform size actually used by the block in each

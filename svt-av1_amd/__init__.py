@@ -59,6 +59,19 @@ class SadLoop(C.Structure):
                 ("sa_w", C.c_int16), ("sa_h", C.c_int16), ("row_step", C.c_int16), ("reserved", C.c_int16)]
 
 
+class FwdTxJob(C.Structure):
+    """SvtHipFwdTxJob (include/svt_hip.h)."""
+    _fields_ = [("tx_size", C.c_int32), ("nblk", C.c_int32), ("d_src", C.c_void_p), ("src_stride", C.c_int32), ("d_pred", C.c_void_p),
+                ("pred_stride", C.c_int32), ("d_descs", C.c_void_p), ("qp", QuantParams), ("scans", ScanTables), ("d_coeff", C.c_void_p),
+                ("d_qcoeff", C.c_void_p), ("d_dqcoeff", C.c_void_p), ("d_eob", C.c_void_p), ("d_cul_level", C.c_void_p), ("d_energy", C.c_void_p)]
+
+
+class InvTxJob(C.Structure):
+    """SvtHipInvTxJob (include/svt_hip.h)."""
+    _fields_ = [("tx_size", C.c_int32), ("nblk", C.c_int32), ("d_dqcoeff", C.c_void_p), ("d_pred", C.c_void_p), ("pred_stride", C.c_int32),
+                ("d_recon", C.c_void_p), ("recon_stride", C.c_int32), ("d_descs", C.c_void_p)]
+
+
 class DlfSearch(C.Structure):
     """SvtHipDlfSearch (include/svt_hip.h)."""
     _fields_ = [("plane", C.c_int), ("dir", C.c_int), ("other_level", C.c_int), ("start_level", C.c_int), ("loop_filter_mode", C.c_int),
@@ -102,6 +115,8 @@ def lib():
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
+    L.svt_hip_fwd_txfm_quant_multi_dev.argtypes = [vp, i32, vp, i32]
+    L.svt_hip_inv_txfm_add_multi_dev.argtypes = [vp, i32, i32, vp, i32]
     L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
     L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]

@@ -353,6 +353,36 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
     return SVT_HIP_OK;
 }
 
+int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs) {
+    if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
+    for (int j = 0; j < njobs; j++) {
+        const SvtHipFwdTxJob& J = jobs[j];
+        if (J.nblk < 0 || J.tx_size < 0 || J.tx_size > 18 || (J.nblk && (!J.d_src || !J.d_pred || !J.d_descs)) ||
+            ((J.d_qcoeff != nullptr) != (J.d_dqcoeff != nullptr)) || (J.d_qcoeff && !J.scans.iscan[0]) || J.qp.variant < 0 || J.qp.variant > 3 ||
+            J.qp.log_scale < 0 || J.qp.log_scale > 2) {
+            c->err = "svt_hip_fwd_txfm_quant_multi_dev: bad job";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_fwd_txfm_quant_multi(c->stream, pix_bytes, jobs, njobs);
+    if (e != hipSuccess) return fail(c, e, "fwd_txfm_quant multi launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx* c, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs) {
+    if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8))
+        return SVT_HIP_ERR_BAD_ARG;
+    for (int j = 0; j < njobs; j++) {
+        const SvtHipInvTxJob& J = jobs[j];
+        if (J.nblk < 0 || J.tx_size < 0 || J.tx_size > 18 || (J.nblk && (!J.d_dqcoeff || !J.d_pred || !J.d_recon || !J.d_descs))) {
+            c->err = "svt_hip_inv_txfm_add_multi_dev: bad job";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_inv_txfm_add_multi(c->stream, pix_bytes, bd, jobs, njobs);
+    if (e != hipSuccess) return fail(c, e, "inv_txfm_add multi launch");
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------------------------- CDEF */
 int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_rec[3], const int rec_stride[3],
                                   const void* const d_src[3], const int src_stride[3], int w, int h, const uint8_t* d_skip8,

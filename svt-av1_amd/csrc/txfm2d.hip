@@ -142,23 +142,26 @@ __device__ __forceinline__ int32_t quant_one(const SvtHipQuantParams& qp, int32_
 }
 
 // ================================================================== forward + quantize ==========
+// One workgroup's share of a forward launch: blocks [wg * TEAMS, (wg + 1) * TEAMS) of the list.  `tile` is TEAMS * H * (W + 1) dwords of
+// LDS.  Called by the single-size kernel and by the mixed-size kernel (where the workgroup always has 256 threads: threads beyond
+// threads_of(W, H) only take part in the barrier and the shuffles).
 template <int W, int H, typename PIX>
-__global__ void __launch_bounds__(256)
-fwd_txfm_quant_kernel(const PIX* __restrict__ src, int src_stride, const PIX* __restrict__ pred, int pred_stride,
-                      const uint32_t* __restrict__ descs, int nblk, SvtHipQuantParams qp, SvtHipScanTables scans,
-                      int32_t* __restrict__ coeff_out, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
-                      uint16_t* __restrict__ eob_out, int32_t* __restrict__ cul_out, uint64_t* __restrict__ energy_out) {
+__device__ __forceinline__ void fwd_block(int32_t* __restrict__ tile, int wg, int tid, const PIX* __restrict__ src, int src_stride,
+                                          const PIX* __restrict__ pred, int pred_stride, const uint32_t* __restrict__ descs, int nblk,
+                                          const SvtHipQuantParams& qp, const SvtHipScanTables& scans, int32_t* __restrict__ coeff_out,
+                                          int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob_out,
+                                          int32_t* __restrict__ cul_out, uint64_t* __restrict__ energy_out) {
     constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
     constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H, NK = KW * KH;
     constexpr int S0 = fwd_shift_of(W, H, 0), S1 = -fwd_shift_of(W, H, 1), S2 = -fwd_shift_of(W, H, 2);
     constexpr int CBC = fwd_cos_col_of(W, H), CBR = fwd_cos_row_of(W, H);
     constexpr bool RECT2 = (W == 2 * H) || (H == 2 * W);
     constexpr int LS = W + 1;  // padded LDS row stride (dwords)
-    __shared__ int32_t tile[TEAMS][H * LS];
+    constexpr int TS = H * LS; // dwords per team
 
-    const int team = threadIdx.x / L, t = threadIdx.x % L;
-    const int blk = blockIdx.x * TEAMS + team;
-    const bool live = blk < nblk;
+    const int team = tid / L, t = tid % L;
+    const int blk = wg * TEAMS + team;
+    const bool live = blk < nblk && team < TEAMS;
     uint32_t d = live ? descs[blk] : 0u;
     const int bx = d & 0x3FFF, by = (d >> 14) & 0x3FFF, tt = d >> 28;
     const int kc = kVtx[tt], kr = kHtx[tt];
@@ -175,7 +178,7 @@ fwd_txfm_quant_kernel(const PIX* __restrict__ src, int src_stride, const PIX* __
         fwd_1d<H, CBC>(kc, in, out);
         const int cc = (kr == 2) ? W - 1 - t : t;      // left-right flip on store (:2351-2356)
 #pragma unroll
-        for (int r = 0; r < H; r++) tile[team][r * LS + cc] = S1 ? rshift_round(out[r], S1 ? S1 : 1) : out[r];
+        for (int r = 0; r < H; r++) tile[team * TS + r * LS + cc] = S1 ? rshift_round(out[r], S1 ? S1 : 1) : out[r];
     }
     __syncthreads();
 
@@ -185,7 +188,7 @@ fwd_txfm_quant_kernel(const PIX* __restrict__ src, int src_stride, const PIX* __
     if (live && t < H) {
         int32_t in[W], out[W];
 #pragma unroll
-        for (int c = 0; c < W; c++) in[c] = tile[team][t * LS + c];
+        for (int c = 0; c < W; c++) in[c] = tile[team * TS + t * LS + c];
         fwd_1d<W, CBR>(kr, in, out);
 #pragma unroll
         for (int c = 0; c < W; c++) {
@@ -243,11 +246,22 @@ fwd_txfm_quant_kernel(const PIX* __restrict__ src, int src_stride, const PIX* __
     }
 }
 
+template <int W, int H, typename PIX>
+__global__ void __launch_bounds__(256)
+fwd_txfm_quant_kernel(const PIX* __restrict__ src, int src_stride, const PIX* __restrict__ pred, int pred_stride,
+                      const uint32_t* __restrict__ descs, int nblk, SvtHipQuantParams qp, SvtHipScanTables scans,
+                      int32_t* __restrict__ coeff_out, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+                      uint16_t* __restrict__ eob_out, int32_t* __restrict__ cul_out, uint64_t* __restrict__ energy_out) {
+    constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
+    __shared__ int32_t tile[TEAMS * H * (W + 1)];
+    fwd_block<W, H, PIX>(tile, blockIdx.x, threadIdx.x, src, src_stride, pred, pred_stride, descs, nblk, qp, scans, coeff_out, qcoeff, dqcoeff,
+                         eob_out, cul_out, energy_out);
+}
+
 // ================================================================== inverse + reconstruction =====
 template <int W, int H, int BD, typename PIX>
-__global__ void __launch_bounds__(256)
-inv_txfm_add_kernel(const int32_t* __restrict__ dqcoeff, const PIX* pred, int pred_stride, PIX* recon, int recon_stride,
-                    const uint32_t* __restrict__ descs, int nblk) {
+__device__ __forceinline__ void inv_block(int32_t* __restrict__ tile, int wg, int tid, const int32_t* __restrict__ dqcoeff, const PIX* pred,
+                                          int pred_stride, PIX* recon, int recon_stride, const uint32_t* __restrict__ descs, int nblk) {
     constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
     constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H, NK = KW * KH;
     constexpr int S0 = -inv_shift0_of(W, H), S1 = 4;
@@ -255,11 +269,11 @@ inv_txfm_add_kernel(const int32_t* __restrict__ dqcoeff, const PIX* pred, int pr
     constexpr int RNG_ROW = BD == 8 ? 16 : 18, RNG_COL = 16;     // svt_av1_gen_inv_stage_range, EbInvTransforms.c:23-60
     constexpr int IN_CLAMP = BD + 8, COL_CLAMP = (BD + 6 > 16) ? BD + 6 : 16;
     constexpr int LS = W + 1;
-    __shared__ int32_t tile[TEAMS][H * LS];
+    constexpr int TS = H * LS;
 
-    const int team = threadIdx.x / L, t = threadIdx.x % L;
-    const int blk = blockIdx.x * TEAMS + team;
-    const bool live = blk < nblk;
+    const int team = tid / L, t = tid % L;
+    const int blk = wg * TEAMS + team;
+    const bool live = blk < nblk && team < TEAMS;
     uint32_t d = live ? descs[blk] : 0u;
     const int bx = d & 0x3FFF, by = (d >> 14) & 0x3FFF, tt = d >> 28;
     const int kc = kVtx[tt], kr = kHtx[tt];
@@ -284,14 +298,14 @@ inv_txfm_add_kernel(const int32_t* __restrict__ dqcoeff, const PIX* pred, int pr
             for (int c = 0; c < W; c++) out[c] = 0;  // rows beyond the kept 32 are zero in, zero out
         }
 #pragma unroll
-        for (int c = 0; c < W; c++) tile[team][t * LS + c] = out[c];
+        for (int c = 0; c < W; c++) tile[team * TS + t * LS + c] = out[c];
     }
     __syncthreads();
     if (live && t < W) {
         int32_t in[H], out[H];
         const int cs = (kr == 2) ? W - 1 - t : t;
 #pragma unroll
-        for (int r = 0; r < H; r++) in[r] = clampv<COL_CLAMP>(tile[team][r * LS + cs]);
+        for (int r = 0; r < H; r++) in[r] = clampv<COL_CLAMP>(tile[team * TS + r * LS + cs]);
         inv_1d<H, 12, RNG_COL>(kc, in, out);
         constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), res_min = -res_max - 1;  // check_range, :2398-2411
         constexpr int32_t pix_max = (1 << BD) - 1;
@@ -306,6 +320,78 @@ inv_txfm_add_kernel(const int32_t* __restrict__ dqcoeff, const PIX* pred, int pr
             w[(size_t)r * recon_stride] = (PIX)min(max(px, 0), pix_max);
         }
     }
+}
+
+template <int W, int H, int BD, typename PIX>
+__global__ void __launch_bounds__(256)
+inv_txfm_add_kernel(const int32_t* __restrict__ dqcoeff, const PIX* pred, int pred_stride, PIX* recon, int recon_stride,
+                    const uint32_t* __restrict__ descs, int nblk) {
+    constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
+    __shared__ int32_t tile[TEAMS * H * (W + 1)];
+    inv_block<W, H, BD, PIX>(tile, blockIdx.x, threadIdx.x, dqcoeff, pred, pred_stride, recon, recon_stride, descs, nblk);
+}
+
+// ================================================================== mixed-size launches ==========
+// One launch over several (transform size, plane) job lists: a frame's transform work is 15-20 short lists (a few hundred to a few
+// thousand blocks each), too small to fill 256 CUs one at a time.  Every workgroup finds its job by its index (uniform scalar scan
+// over <= 16 prefix sums held in the kernel argument), then runs the size's body; LDS and registers are those of the largest size.
+constexpr int kMultiJobs = 16, kMultiTileDw = 8448;   // max over sizes of TEAMS * H * (W + 1)
+struct FwdMulti { int njobs; int first_wg[kMultiJobs + 1]; SvtHipFwdTxJob job[kMultiJobs]; };
+struct InvMulti { int njobs; int first_wg[kMultiJobs + 1]; SvtHipInvTxJob job[kMultiJobs]; };
+
+#define FOR_ALL_TX_SIZES_DEV(X) \
+    X(0, 4, 4) X(1, 8, 8) X(2, 16, 16) X(3, 32, 32) X(4, 64, 64) X(5, 4, 8) X(6, 8, 4) X(7, 8, 16) X(8, 16, 8) X(9, 16, 32) \
+    X(10, 32, 16) X(11, 32, 64) X(12, 64, 32) X(13, 4, 16) X(14, 16, 4) X(15, 8, 32) X(16, 32, 8) X(17, 16, 64) X(18, 64, 16)
+
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+fwd_txfm_quant_multi_kernel(const FwdMulti a) {
+    __shared__ int32_t tile[kMultiTileDw];
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_wg[j + 1]) j++;
+    const int wg = (int)blockIdx.x - a.first_wg[j];
+    // scalar copies of the job (references into the kernel-argument struct would force a private-memory copy of the whole struct)
+    const int tx_size = a.job[j].tx_size, nblk = a.job[j].nblk, src_stride = a.job[j].src_stride, pred_stride = a.job[j].pred_stride;
+    const PIX* src = (const PIX*)a.job[j].d_src; const PIX* pred = (const PIX*)a.job[j].d_pred;
+    const uint32_t* descs = a.job[j].d_descs;
+    const SvtHipQuantParams qp = a.job[j].qp;
+    const SvtHipScanTables scans = a.job[j].scans;
+    int32_t *coeff = a.job[j].d_coeff, *qcoeff = a.job[j].d_qcoeff, *dqcoeff = a.job[j].d_dqcoeff, *cul = a.job[j].d_cul_level;
+    uint16_t* eob = a.job[j].d_eob; uint64_t* energy = a.job[j].d_energy;
+    switch (tx_size) {
+#define X(id, w, h)                                                                                                                            \
+    case id:                                                                                                                                   \
+        fwd_block<w, h, PIX>(tile, wg, threadIdx.x, src, src_stride, pred, pred_stride, descs, nblk, qp, scans, coeff, qcoeff, dqcoeff, eob,  \
+                             cul, energy);                                                                                                     \
+        break;
+        FOR_ALL_TX_SIZES_DEV(X)
+#undef X
+    default: break;
+    }
+}
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(256)
+inv_txfm_add_multi_kernel(const InvMulti a) {
+    __shared__ int32_t tile[kMultiTileDw];
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_wg[j + 1]) j++;
+    const SvtHipInvTxJob& J = a.job[j];
+    const int wg = (int)blockIdx.x - a.first_wg[j];
+    switch (J.tx_size) {
+#define X(id, w, h)                                                                                                                     \
+    case id:                                                                                                                            \
+        inv_block<w, h, BD, PIX>(tile, wg, threadIdx.x, J.d_dqcoeff, (const PIX*)J.d_pred, J.pred_stride, (PIX*)J.d_recon, J.recon_stride, \
+                                 J.d_descs, J.nblk);                                                                                     \
+        break;
+        FOR_ALL_TX_SIZES_DEV(X)
+#undef X
+    default: break;
+    }
+}
+__host__ constexpr int teams_of(int ts) {
+    constexpr int w[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+    constexpr int h[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+    return threads_of(w[ts], h[ts]) / (w[ts] > h[ts] ? w[ts] : h[ts]);
 }
 
 template <int W, int H>
@@ -370,4 +456,42 @@ extern "C" int svt_hip_launch_inv_txfm_add(hipStream_t st, int tx_size, int pix_
 #undef X
     default: return (int)hipErrorInvalidValue;
     }
+}
+
+extern "C" int svt_hip_launch_fwd_txfm_quant_multi(hipStream_t st, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs) {
+    for (int j0 = 0; j0 < njobs; j0 += kMultiJobs) {
+        FwdMulti a = {};
+        int wg = 0;
+        for (int j = j0; j < njobs && j < j0 + kMultiJobs; j++) {
+            if (jobs[j].nblk <= 0) continue;
+            const int t = teams_of(jobs[j].tx_size);
+            a.first_wg[a.njobs] = wg;
+            a.job[a.njobs++] = jobs[j];
+            wg += (jobs[j].nblk + t - 1) / t;
+        }
+        a.first_wg[a.njobs] = wg;
+        if (!wg) continue;
+        if (pix_bytes == 1) hipLaunchKernelGGL((fwd_txfm_quant_multi_kernel<uint8_t>), dim3(wg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((fwd_txfm_quant_multi_kernel<uint16_t>), dim3(wg), dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_inv_txfm_add_multi(hipStream_t st, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs) {
+    for (int j0 = 0; j0 < njobs; j0 += kMultiJobs) {
+        InvMulti a = {};
+        int wg = 0;
+        for (int j = j0; j < njobs && j < j0 + kMultiJobs; j++) {
+            if (jobs[j].nblk <= 0) continue;
+            const int t = teams_of(jobs[j].tx_size);
+            a.first_wg[a.njobs] = wg;
+            a.job[a.njobs++] = jobs[j];
+            wg += (jobs[j].nblk + t - 1) / t;
+        }
+        a.first_wg[a.njobs] = wg;
+        if (!wg) continue;
+        if (pix_bytes == 1) hipLaunchKernelGGL((inv_txfm_add_multi_kernel<uint8_t, 8>), dim3(wg), dim3(256), 0, st, a);
+        else if (bd == 8) hipLaunchKernelGGL((inv_txfm_add_multi_kernel<uint16_t, 8>), dim3(wg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((inv_txfm_add_multi_kernel<uint16_t, 10>), dim3(wg), dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
 }

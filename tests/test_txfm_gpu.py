@@ -148,3 +148,58 @@ def test_golden_vectors(hip, pkg):
         rec = run_inv(hip, ts, bd, np.ascontiguousarray(dq), np.ascontiguousarray(gp), descs)
         for i, tt in enumerate(tts):
             assert np.array_equal(rec[:, i * w:(i + 1) * w].astype(np.uint16), V[f"{ts}/{tt}/{bd}/rec"]), (ts, tt, bd)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mixed_size_launches(hip, pkg, bd):
+    """svt_hip_fwd_txfm_quant_multi_dev / svt_hip_inv_txfm_add_multi_dev: all 19 sizes as 19 jobs of one call (two launches of <= 16
+    jobs) must reproduce the single-size entry points bit for bit (those are checked against the oracle above), including ragged
+    last workgroups and an empty job."""
+    rng = np.random.default_rng(70 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    Wp, Hp = 1024, 512
+    src = rng.integers(0, 1 << bd, (Hp, Wp)).astype(dt); pred = rng.integers(0, 1 << bd, (Hp, Wp)).astype(dt)
+    qp = T[f"qp/{bd}/60/0"]
+    variant = 0 if bd == 8 else 1
+    d_src, d_pred = hip.to_device(src), hip.to_device(pred)
+    d_rec_multi = hip.to_device(np.zeros_like(pred))
+    fj = (pkg.FwdTxJob * 20)(); ij = (pkg.InvTxJob * 20)()
+    keep, expect, outs = [], [], []
+    y0 = 0
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]; nk = min(w, 32) * min(h, 32)
+        n = int(rng.integers(3, 40))
+        tts = tc.legal_types(ts)
+        descs = np.array([pkg.tx_desc((k * w) % (Wp - w + 1) // w * w, y0, tts[k % len(tts)]) for k in range(n)], np.uint32)
+        exp = run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant)
+        exp["rec"] = run_inv(hip, ts, bd, exp["dq"], pred, descs)
+        expect.append((ts, descs, exp))
+        d_desc = hip.to_device(descs)
+        scans = pkg.ScanTables()
+        for cls in range(3):
+            key = f"iscan/{ts}/{cls}"
+            if key in T.files:
+                p = hip.to_device(np.ascontiguousarray(T[key])); keep.append(p); scans.iscan[cls] = p.value
+        o = dict(co=hip.empty(n * nk * 4), q=hip.empty(n * nk * 4), dq=hip.empty(n * nk * 4), eob=hip.empty(n * 2), cul=hip.empty(n * 4), en=hip.empty(n * 8))
+        outs.append(o); keep += [d_desc]
+        j = ts if ts < 7 else ts + 1      # job 7 stays empty (nblk = 0)
+        fj[j] = pkg.FwdTxJob(ts, n, d_src.value, Wp, d_pred.value, Wp, d_desc.value, qparams_struct(pkg, qp, variant, tc.TX_SCALE[ts]), scans,
+                             o["co"].value, o["q"].value, o["dq"].value, o["eob"].value, o["cul"].value, o["en"].value)
+        ij[j] = pkg.InvTxJob(ts, n, o["dq"].value, d_pred.value, Wp, d_rec_multi.value, Wp, d_desc.value)
+        y0 += h
+    hip.check(hip.L.svt_hip_fwd_txfm_quant_multi_dev(hip.h, src.itemsize, fj, 20), "fwd multi")
+    hip.check(hip.L.svt_hip_inv_txfm_add_multi_dev(hip.h, src.itemsize, bd, ij, 20), "inv multi")
+    rec = hip.to_host(d_rec_multi, pred.shape, dt)
+    for (ts, descs, exp), o in zip(expect, outs):
+        n = len(descs); nk = min(tc.TXW[ts], 32) * min(tc.TXH[ts], 32)
+        assert np.array_equal(hip.to_host(o["co"], (n, nk), np.int32), exp["coeff"]), ("coeff", ts)
+        assert np.array_equal(hip.to_host(o["q"], (n, nk), np.int32), exp["q"]), ("q", ts)
+        assert np.array_equal(hip.to_host(o["dq"], (n, nk), np.int32), exp["dq"]), ("dq", ts)
+        assert np.array_equal(hip.to_host(o["eob"], (n,), np.uint16), exp["eob"]), ("eob", ts)
+        assert np.array_equal(hip.to_host(o["cul"], (n,), np.int32), exp["cul"]), ("cul", ts)
+        assert np.array_equal(hip.to_host(o["en"], (n,), np.uint64), exp["energy"]), ("energy", ts)
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        for d in descs:
+            x, y = int(d & 0x3FFF), int((d >> 14) & 0x3FFF)
+            assert np.array_equal(rec[y:y + h, x:x + w], exp["rec"][y:y + h, x:x + w]), ("rec", ts)
+    hip.free(d_src, d_pred, d_rec_multi, *keep, *[v for o in outs for v in o.values()])
