@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="streams for the independent launches of a stage (debug)")
     ap.add_argument("--tx-multi", default="inv", help="which transform stages use the mixed-size launch (debug): fwd,inv / fwd / inv / none")
     ap.add_argument("--side-keys", default="pyr,hme,me,subpel", help="stages issued on the side stream (debug; must be source-side stages)")
+    ap.add_argument("--me-waves", type=int, default=4, help="svt_hip_me_set_waves_per_sb value (debug)")
     ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the main stream (debug)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--stages", default="all", help="comma list (debug): pyr,hme,me,subpel,txfm,inv,dlf,cdef_search,cdef_apply,sgr_search,sgr_apply")
@@ -93,6 +94,7 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
     dev = torch.device("cuda", local_rank)
+    ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, args.me_waves))
 
     W, H = args.width, args.height
     F = workload.Frame(W, H, seed=11 + 100 * rank)   # one stream per rank

@@ -85,7 +85,9 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *ctx, const uint8_t *d_src, const uin
 int svt_hip_me_fullpel_frame(SvtHipCtx *ctx, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows,
                              int org_x, int org_y, const SvtHipSbSearch *sbs, int n_sb, int sub_sad,
                              uint32_t *best_sad, uint32_t *best_mv);
-/* Tuning knob (workgroup = 1, 2 or 4 waves per SB); default 2. */
+/* Tuning knob: low 4 bits = waves per SB workgroup (1, 2 or 4; default 4); bits 4.. = KiB of unused LDS added to each workgroup
+ * (0 = off): with >= 56 only one ME workgroup fits a CU, which leaves half of every SIMD's registers to kernels running concurrently
+ * on other streams (measured: ME alone 0.40 -> 0.63 ms, whole step unchanged -- see DESIGN.md 5). */
 int svt_hip_me_set_waves_per_sb(SvtHipCtx *ctx, int waves);
 
 /* ------------------------------------------------------- residual + transform + quantisation ---- */

@@ -387,7 +387,11 @@ extern "C" int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_sr
                                          uint32_t* d_best_sad, uint32_t* d_best_mv, int waves_per_sb) {
     if (n_sb <= 0) return 0;
     dim3 grid(n_sb);
-#define LAUNCH(W, S) hipLaunchKernelGGL((me_fullpel_85pu_kernel<W, S>), grid, dim3(64 * W), 0, stream, d_src, d_ref, stride, \
+    // waves_per_sb >= 16: experimental "one workgroup per CU" mode -- (waves_per_sb >> 4) KiB of unused dynamic LDS keep a second ME
+    // workgroup off the CU, leaving half of every SIMD's registers to kernels that run concurrently on other streams
+    const int lds_pad = (waves_per_sb >> 4) * 1024;
+    waves_per_sb &= 15;
+#define LAUNCH(W, S) hipLaunchKernelGGL((me_fullpel_85pu_kernel<W, S>), grid, dim3(64 * W), lds_pad, stream, d_src, d_ref, stride, \
                                         org_x, org_y, d_sbs, d_best_sad, d_best_mv)
     if (waves_per_sb == 1) { if (sub_sad) LAUNCH(1, true); else LAUNCH(1, false); }
     else if (waves_per_sb == 2) { if (sub_sad) LAUNCH(2, true); else LAUNCH(2, false); }

@@ -133,7 +133,8 @@ SvtHipSbSearch svt_hip_me_search_window(int sb_origin_x, int sb_origin_y, int x_
 }
 
 int svt_hip_me_set_waves_per_sb(SvtHipCtx* c, int waves) {
-    if (!c || (waves != 1 && waves != 2 && waves != 4)) return SVT_HIP_ERR_BAD_ARG;
+    const int w = waves & 15;   // bits 4.. = KiB of LDS padding (experimental single-workgroup-per-CU mode, see me_fullpel.hip)
+    if (!c || (w != 1 && w != 2 && w != 4) || (waves >> 4) > 120) return SVT_HIP_ERR_BAD_ARG;
     c->me_waves = waves;
     return SVT_HIP_OK;
 }
