@@ -207,7 +207,7 @@ def test_wrappers_vs_reference_c(rtcd, ref):
     # --- self-guided filter / apply
     img = np.clip(rng.normal(120, 40, (90, 100)), 0, 255).astype(np.uint8)
     p = img.ctypes.data + 9 * 100 + 11
-    tmp = np.zeros(64 * 64 * 8 + 4096, np.int32)   # RESTORATION_TMPBUF_SIZE scratch of the reference
+    tmp = np.zeros(2 * 406 * 398 + 1024, np.int32)   # SGRPROJ_TMPBUF_SIZE: flt1 starts RESTORATION_UNITPELS_MAX (406 x 398) ints into it
     for ep in (0, 9, 12, 15):
         e0 = np.zeros((56, 64), np.int32); e1 = e0.copy(); g0 = e0.copy(); g1 = e0.copy()
         ref.svt_av1_selfguided_restoration_c(C.c_void_p(p), 64, 56, 100, ptr(e0), ptr(e1), 64, ep, 8, 0)
