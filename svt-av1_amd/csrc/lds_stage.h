@@ -23,15 +23,15 @@ __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((
 // == 0) into LDS with the (base & 3) misalignment removed.  Loads are aligned dwords; a dword is
 // fetched only if it overlaps [0, need_bytes) of its row so nothing outside the window's aligned
 // footprint is touched.
+template <int U = 8>
 __device__ __forceinline__ void stage_rows(uint32_t* lds, int lds_stride_dw, const uint8_t* base, int pitch,
                                            int rows, int row_dw, int need_bytes, int tid, int nthreads) {
     const uint32_t shift = (uint32_t)((uintptr_t)base & 3);
     const uint32_t* g0   = (const uint32_t*)(base - shift);
     const int last_dw    = (need_bytes + (int)shift + 3) / 4;  // dwords [0,last_dw) overlap the needed bytes
     const int total      = rows * row_dw;
-    // U independent loads are issued before the first one is consumed: a plain one-element-per-iteration loop exposes one full
+    // U (template parameter; registers: 3 per unit) independent loads are issued before the first one is consumed: a plain one-element-per-iteration loop exposes one full
     // global-memory latency per element (the compiler does not software-pipeline it), which made staging ~1/4 of a search kernel
-    constexpr int U = 8;
     for (int i0 = tid; i0 < total; i0 += nthreads * U) {
         uint32_t lo[U], hi[U];
         int dst[U];

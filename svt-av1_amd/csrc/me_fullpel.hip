@@ -246,7 +246,7 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
             __syncthreads();               // previous tile fully consumed
             const uint8_t* ref_base = ref + (size_t)(org_y + d.sb_y + d.y_origin + ty) * stride +
                                       (org_x + d.sb_x + d.x_origin + tx);
-            stage_rows(lds_ref, kRefStrideDw, ref_base, stride, th + 63, kRefRowDw, tw + 63, tid, NT);
+            stage_rows<4>(lds_ref, kRefStrideDw, ref_base, stride, th + 63, kRefRowDw, tw + 63, tid, NT);   // 4: the 90 key registers stay live here
             __syncthreads();
             const int units = th * ng;
             for (int u = tid; u < units; u += NT) {
