@@ -127,8 +127,15 @@ static void shim_filter_visitor(const RestorationTileLimits *limits, const Av1Pi
 /* svt_av1_loop_restoration_save_boundary_lines (deblocked frame, then CDEF frame) + svt_av1_loop_restoration_filter_frame for one
  * plane.  dbl / cdef / dst point at pixel (0,0); cdef needs a 3-pixel writable border (svt_extend_frame fills it);
  * strides in pixels; unit_ep[u] = parameter set or 255 for RESTORE_NONE; unit_xqd[u][2]. */
+int ref_shim_lr_apply_plane_ex(int plane, int bd, int highbd, int frame_w, int frame_h, void *dbl, int dbl_stride, void *cdef, int stride,
+                               void *dst, int dst_stride, int unit_size, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener);
 int ref_shim_lr_apply_plane(int plane, int bd, int highbd, int frame_w, int frame_h, void *dbl, int dbl_stride, void *cdef, int stride,
                             void *dst, int dst_stride, int unit_size, const uint8_t *unit_ep, const int32_t *unit_xqd) {
+    return ref_shim_lr_apply_plane_ex(plane, bd, highbd, frame_w, frame_h, dbl, dbl_stride, cdef, stride, dst, dst_stride, unit_size, unit_ep, unit_xqd, NULL);
+}
+/* unit_ep[u] == 254: RESTORE_WIENER with taps unit_wiener[u][0][8] (vertical) / [1][8] (horizontal) */
+int ref_shim_lr_apply_plane_ex(int plane, int bd, int highbd, int frame_w, int frame_h, void *dbl, int dbl_stride, void *cdef, int stride,
+                               void *dst, int dst_stride, int unit_size, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener) {
     shim_rtcd();
     Av1Common *cm = shim_cm(frame_w, frame_h, bd, highbd, plane, unit_size);
     const int ss = plane > 0;
@@ -136,7 +143,11 @@ int ref_shim_lr_apply_plane(int plane, int bd, int highbd, int frame_w, int fram
     RestorationInfo *rsi = &cm->rst_info[plane];
     rsi->unit_info = (RestorationUnitInfo *)calloc(rsi->units_per_tile, sizeof(RestorationUnitInfo));
     for (int u = 0; u < rsi->units_per_tile; u++) {
-        rsi->unit_info[u].restoration_type = unit_ep[u] > 15 ? RESTORE_NONE : RESTORE_SGRPROJ;
+        rsi->unit_info[u].restoration_type = unit_ep[u] == 254 && unit_wiener ? RESTORE_WIENER : (unit_ep[u] > 15 ? RESTORE_NONE : RESTORE_SGRPROJ);
+        if (unit_ep[u] == 254 && unit_wiener) {
+            memcpy(rsi->unit_info[u].wiener_info.vfilter, unit_wiener + 16 * u, 16);
+            memcpy(rsi->unit_info[u].wiener_info.hfilter, unit_wiener + 16 * u + 8, 16);
+        }
         rsi->unit_info[u].sgrproj_info.ep = unit_ep[u] > 15 ? 0 : unit_ep[u];
         rsi->unit_info[u].sgrproj_info.xqd[0] = unit_xqd[2 * u]; rsi->unit_info[u].sgrproj_info.xqd[1] = unit_xqd[2 * u + 1];
     }

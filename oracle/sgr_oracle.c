@@ -238,6 +238,13 @@ void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void
  * unit_ep[u] > 15 = RESTORE_NONE (copy). */
 void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y,
                          int unit_size, int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, void *dst, int dst_stride) {
+    orc_lr_apply_plane(dbl, dbl_stride, cdef, stride, pix_bytes, pw, ph, ss_x, ss_y, unit_size, bd, unit_ep, unit_xqd, NULL, dst, dst_stride);
+}
+/* ... with Wiener units as well: unit_ep[u] == 254 -> wiener_filter_stripe[_highbd] (EbRestoration.c:1040-1085, :1110-1132) with the taps
+ * unit_wiener[u][0][8] (vertical) / [u][1][8] (horizontal).  The reference rounds a stripe's last column block up to 16 columns and lets
+ * the neighbouring unit (or the padding) take the surplus; the restatement writes the unit's own columns only -- same picture. */
+void orc_lr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y, int unit_size,
+                        int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener, void *dst, int dst_stride) {
     const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
     int32_t *lim = (int32_t *)malloc(sizeof(int32_t) * 4 * nu);
     orc_rest_unit_limits(pw, ph, ss_y, unit_size, lim);
@@ -245,7 +252,8 @@ void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride
     uint8_t *save = (uint8_t *)malloc((size_t)6 * (pw + 6) * pix_bytes);
     for (int u = 0; u < nu; u++) {
         const int x0 = lim[4 * u], x1 = lim[4 * u + 1], v0 = lim[4 * u + 2], v1 = lim[4 * u + 3], uw = x1 - x0;
-        if (unit_ep[u] > 15) {   /* copy_tile */
+        const int is_wiener = unit_ep[u] == 254 && unit_wiener;
+        if (unit_ep[u] > 15 && !is_wiener) {   /* copy_tile */
             for (int y = v0; y < v1; y++)
                 memcpy((uint8_t *)dst + ((size_t)y * dst_stride + x0) * pix_bytes, (const uint8_t *)cdef + ((size_t)y * stride + x0) * pix_bytes, (size_t)uw * pix_bytes);
             continue;
@@ -273,7 +281,12 @@ void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride
                     }
                 }
             }
-            for (int j = 0; j < uw; j += puw)   /* sgrproj_filter_stripe[_highbd] (:1086-1160) */
+            for (int j = 0; j < uw; j += puw)   /* wiener_filter_stripe / sgrproj_filter_stripe[_highbd] (:1040-1160) */
+                if (is_wiener)
+                    orc_wiener_convolve_add_src((const uint8_t *)cdef + ((size_t)v * stride + x0 + j) * pix_bytes, stride,
+                                                (uint8_t *)dst + ((size_t)v * dst_stride + x0 + j) * pix_bytes, dst_stride, pix_bytes, unit_wiener + 16 * u + 8,
+                                                unit_wiener + 16 * u, uw - j < puw ? uw - j : puw, h, bd);
+                else
                 orc_sgr_apply((const uint8_t *)cdef + ((size_t)v * stride + x0 + j) * pix_bytes, pix_bytes, uw - j < puw ? uw - j : puw, h, stride, unit_ep[u],
                               unit_xqd + 2 * u, (uint8_t *)dst + ((size_t)v * dst_stride + x0 + j) * pix_bytes, dst_stride, bd);
             sv = save;

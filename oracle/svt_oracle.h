@@ -164,6 +164,15 @@ void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void
                           int unit_size, int bd, uint32_t ep_mask, int64_t *sums);
 void orc_sgr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y,
                          int unit_size, int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, void *dst, int dst_stride);
+void orc_lr_apply_plane(const void *dbl, int dbl_stride, void *cdef, int stride, int pix_bytes, int pw, int ph, int ss_x, int ss_y, int unit_size,
+                        int bd, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener, void *dst, int dst_stride);
+/* ---------------------------------------------------------------- Wiener restoration (wiener_oracle.c) */
+void orc_wiener_compute_stats(int win, const void *dgd, const void *src, int pix_bytes, int bd, int h_start, int h_end, int v_start, int v_end,
+                              int dgd_stride, int src_stride, int64_t *M, int64_t *H);
+void orc_wiener_convolve_add_src(const void *src, int src_stride, void *dst, int dst_stride, int pix_bytes, const int16_t *filter_x,
+                                 const int16_t *filter_y, int w, int h, int bd);
+void orc_wiener_stats_plane(int win, const void *dgd, int dgd_stride, const void *src, int src_stride, int pix_bytes, int bd, int pw, int ph, int ss_y,
+                            int unit_size, int64_t *M, int64_t *H);
 int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                            int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep);
 

@@ -475,12 +475,21 @@ def test_restoration_units_and_stripe_apply(orc, ref):
                     st = buf_o.shape[1]; off = (E * st + E) * buf_o.itemsize
                     u_ep = rng.integers(0, 16, nu).astype(np.uint8)
                     if nu > 2: u_ep[1] = 255
+                    u_ep[rng.random(nu) < 0.4] = 254                       # RESTORE_WIENER units
                     u_xqd = np.stack([rng.integers(-96, 32, nu), rng.integers(-32, 96, nu)], 1).astype(np.int32)
+                    u_wn = np.zeros((nu, 2, 8), np.int16)
+                    for u in range(nu):
+                        for d in range(2):
+                            t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                            if plane: t[0] = 0                              # 5-tap chroma filters
+                            u_wn[u, d, :7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
                     dst_o = np.zeros((ph, pw), dt); dst_r = np.zeros((ph, pw), dt)
-                    orc.orc_sgr_apply_plane(ptr(dbl), pw, C.c_void_p(buf_o.ctypes.data + off), st, buf_o.itemsize, pw, ph, ss, ss, US, bd,
-                                            ptr(u_ep), ptr(u_xqd), ptr(dst_o), pw)
-                    assert ref.ref_shim_lr_apply_plane(plane, bd, int(bd > 8), fw, fh, ptr(dbl), pw, C.c_void_p(buf_r.ctypes.data + off), st,
-                                                       ptr(dst_r), pw, US, ptr(u_ep), ptr(u_xqd)) == 0
+                    orc.orc_lr_apply_plane(ptr(dbl), pw, C.c_void_p(buf_o.ctypes.data + off), st, buf_o.itemsize, pw, ph, ss, ss, US, bd,
+                                           ptr(u_ep), ptr(u_xqd), ptr(u_wn), ptr(dst_o), pw)
+                    dst_pad = np.zeros((ph + 8, pw + 32), dt)               # the reference's stripe filter overshoots up to 15 columns
+                    assert ref.ref_shim_lr_apply_plane_ex(plane, bd, int(bd > 8), fw, fh, ptr(dbl), pw, C.c_void_p(buf_r.ctypes.data + off), st,
+                                                          ptr(dst_pad), pw + 32, US, ptr(u_ep), ptr(u_xqd), ptr(u_wn)) == 0
+                    dst_r = dst_pad[:ph, :pw]
                     assert np.array_equal(dst_o, dst_r), (fw, fh, plane, US, bd, np.argwhere(dst_o != dst_r)[:5])
                     assert np.array_equal(buf_o, buf_r), "the CDEF picture must be restored after the stripes"
 
@@ -509,3 +518,45 @@ def test_coefficient_and_pixel_distortion(orc, ref):
         assert (o[0], o[1]) == (d[0], d[1]) and o[0] == o[1]
         a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 9)).astype(np.uint8)
         assert ref.svt_aom_sse_c(ptr(a), w + 3, ptr(b), w + 9, w, h) == orc.orc_plane_sse(1, ptr(a), w + 3, ptr(b), w + 9, w, h)
+
+
+def test_wiener_stats_and_convolve(orc, ref):
+    """orc_wiener_compute_stats == svt_av1_compute_stats_c / _highbd_c (windows 7, 5, 3; ragged unit rectangles),
+    orc_wiener_convolve_add_src == svt_av1_[highbd_]wiener_convolve_add_src_c (symmetric 7-tap kernels over the legal tap ranges)."""
+    rng = np.random.default_rng(808)
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        dgd = rng.integers(0, 1 << bd, (120, 140)).astype(dt); src = np.clip(dgd.astype(np.int32) + rng.integers(-20, 21, dgd.shape), 0, (1 << bd) - 1).astype(dt)
+        for win in (7, 5, 3):
+            for (h0, h1, v0, v1) in ((8, 72, 8, 72), (10, 101, 5, 37), (30, 31, 40, 41)):
+                w2 = win * win
+                Mo, Ho = np.zeros(w2, np.int64), np.zeros(w2 * w2, np.int64); Mr, Hr = Mo.copy(), Ho.copy()
+                orc.orc_wiener_compute_stats(win, ptr(dgd), ptr(src), dgd.itemsize, bd, h0, h1, v0, v1, 140, 140, ptr(Mo), ptr(Ho))
+                if bd == 8:
+                    ref.svt_av1_compute_stats_c(win, ptr(dgd), ptr(src), h0, h1, v0, v1, 140, 140, ptr(Mr), ptr(Hr))
+                else:
+                    ref.svt_av1_compute_stats_highbd_c(win, C.c_void_p(dgd.ctypes.data >> 1), C.c_void_p(src.ctypes.data >> 1), h0, h1, v0, v1, 140, 140, ptr(Mr), ptr(Hr), bd)
+                assert np.array_equal(Mo, Mr) and np.array_equal(Ho, Hr), (bd, win, h0, h1, v0, v1)
+        # convolve: taps t0..t2 in the AV1 ranges, centre = -2 * (t0 + t1 + t2), tap[7] = 0 (EbRestoration.h:240-260)
+        class CP(C.Structure):
+            _fields_ = [("ref", C.c_int32), ("do_average", C.c_int32), ("dst", C.c_void_p), ("dst_stride", C.c_int32), ("round_0", C.c_int32), ("round_1", C.c_int32),
+                        ("plane", C.c_int32), ("is_compound", C.c_int32), ("use_jnt_comp_avg", C.c_int32), ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32),
+                        ("use_dist_wtd_comp_avg", C.c_int32)]
+        cp = CP(0, 0, None, 0, 3, 11, 0, 0, 0, 0, 0, 0)
+        for trial in range(6):
+            def taps():
+                t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                if trial == 0: t = [10, 8, 46]
+                if trial == 1: t = [-5, -23, -17]
+                f = np.zeros(64, np.int16)      # 128-byte block: the reference masks the pointer to a 256-byte table base
+                f[:7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
+                return f
+            fx, fy = taps(), taps()
+            w, h = (64, 56) if trial % 2 == 0 else (24, 9)
+            eo = np.zeros((h, w + 5), dt); er = np.zeros((h, w + 5), dt)
+            p = dgd.ctypes.data + (20 * 140 + 30) * dgd.itemsize
+            orc.orc_wiener_convolve_add_src(C.c_void_p(p), 140, ptr(eo), w + 5, dgd.itemsize, ptr(fx), ptr(fy), w, h, bd)
+            if bd == 8:
+                ref.svt_av1_wiener_convolve_add_src_c(C.c_void_p(p), C.c_int64(140), ptr(er), C.c_int64(w + 5), ptr(fx), ptr(fy), w, h, C.byref(cp))
+            else:
+                ref.svt_av1_highbd_wiener_convolve_add_src_c(C.c_void_p(p >> 1), C.c_int64(140), C.c_void_p(er.ctypes.data >> 1), C.c_int64(w + 5), ptr(fx), ptr(fy), w, h, C.byref(cp), bd)
+            assert np.array_equal(eo, er), (bd, trial)
