@@ -338,6 +338,13 @@ int svt_hip_sgr_search_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const vo
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride,
                                 int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride,
                                 const uint8_t *d_unit_ep, const int32_t *d_unit_xqd);
+/* The same frame pass with Wiener units as well (svt_av1_loop_restoration_filter_frame for all three restoration types):
+ * d_unit_ep[unit] = 254 selects RESTORE_WIENER with the taps d_unit_wiener[unit][0][8] (WienerInfo::vfilter) / [unit][1][8]
+ * (hfilter); wiener_filter_stripe[_highbd] -> svt_av1_[highbd_]wiener_convolve_add_src (common_dsp_rtcd.h:179-185,
+ * Common/Codec/convolve.c:105,207; round_0 = 3, round_1 = 11) with the same stripe-boundary rules as the self-guided units. */
+int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride,
+                               int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep,
+                               const int32_t *d_unit_xqd, const int16_t *d_unit_wiener);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ struct StripeCtx {
 
 template <typename PIX>
 __device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restrict__ plane, int stride, int pw, int ph, int x0, int y0, int tid,
-                                                 const StripeCtx<PIX> sc = StripeCtx<PIX>{nullptr, 0, 0, 0, 0, 0}) {
+                                                 const StripeCtx<PIX> sc = StripeCtx<PIX>{nullptr, 0, 0, 0, 0, 0}, bool box_sums = true) {
     if (tid < 256) L.xtab[tid] = tid == 0 ? 1 : (tid == 255 ? 256 : (uint16_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
     batched_stage<4, uint16_t>(IH * IW, tid, 256,
         [&](int i) {
@@ -69,6 +69,7 @@ __device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restri
         },
         [&](int i, uint16_t v) { L.in[i] = v; });
     __syncthreads();
+    if (!box_sums) return;
     for (int i = tid; i < PH1 * PW; i += 256) {            // r = 1: position (i/PW - 1, i%PW - 1)
         const int r = i / PW, c = i - r * PW;               // window centre in `in` coordinates: (r + 2, c + 2)
         uint32_t s = 0, q = 0;
@@ -401,12 +402,13 @@ template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
 sgr_apply_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
                  int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
-                 const int32_t* __restrict__ unit_xqd) {
+                 const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener) {
     __shared__ TileLds L;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH - voff, tid = threadIdx.x;
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     const int ep = unit_ep[unit];
-    if (ep > 15) {   // copy_tile (EbRestoration.c:1174-1177)
+    const bool wiener = ep == 254 && unit_wiener != nullptr;   // RESTORE_WIENER unit
+    if (ep > 15 && !wiener) {   // copy_tile (EbRestoration.c:1174-1177)
         for (int k = tid; k < TW * TH; k += 256) {
             const int i = k / TW, j = k - i * TW;
             if (x0 + j < pw && y0 + i < ph && y0 + i >= 0) dst[(size_t)(y0 + i) * dst_stride + x0 + j] = dgd[(ptrdiff_t)(y0 + i) * stride + x0 + j];
@@ -420,7 +422,32 @@ sgr_apply_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
         sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
         sc.above = s > 0; sc.below = sc.sy1 < ph;
     }
-    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid, sc);
+    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid, sc, !wiener);
+    if (wiener) {
+        // svt_av1_[highbd_]wiener_convolve_add_src (Common/Codec/convolve.c:60-241) on the staged tile: horizontal pass over the TH + 6
+        // rows into a 16-bit intermediate (round_0 = 3, clamped to WIENER_CLAMP_LIMIT), vertical pass (round_1 = 11) to the picture.
+        int fx[8], fy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { fy[k] = unit_wiener[16 * unit + k]; fx[k] = unit_wiener[16 * unit + 8 + k]; }
+        uint16_t* tmp = (uint16_t*)L.s1;   // [IH][TW], 22 x 64 x 2 B inside the (unused) box-sum area
+        for (int k = tid; k < IH * TW; k += 256) {
+            const int r = k / TW, c = k - r * TW;
+            int32_t sum = ((int32_t)L.in[r * IW + c + 3] << 7) + (1 << (BD + 6));
+#pragma unroll
+            for (int t = 0; t < 7; t++) sum += (int32_t)L.in[r * IW + c + t] * fx[t];
+            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);
+        }
+        __syncthreads();
+        for (int k = tid; k < TW * TH; k += 256) {
+            const int i = k / TW, j = k - i * TW;
+            if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
+            int32_t sum = ((int32_t)tmp[(i + 3) * TW + j] << 7) - (1 << (BD + 10));
+#pragma unroll
+            for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * TW + j] * fy[t];
+            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
+        }
+        return;
+    }
     build_ab<BD>(L, ep, tid);
     // svt_decode_xq (EbRestoration.c:707-718)
     const int32_t xqd0 = unit_xqd[2 * unit], xqd1 = unit_xqd[2 * unit + 1];
@@ -464,11 +491,11 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
 }
 extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,
                                         int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
-                                        const uint8_t* unit_ep, const int32_t* unit_xqd) {
+                                        const uint8_t* unit_ep, const int32_t* unit_xqd, const int16_t* unit_wiener) {
     const int voff = 8 >> ss_y, sh = 64 >> ss_y;
     dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16);
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_apply_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd);
-    else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd);
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_apply_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
     return (int)hipGetLastError();
 }

@@ -503,12 +503,18 @@ int svt_hip_sgr_search_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw,
                                 int ph, int unit_size, int ss_y, const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep,
                                 const int32_t* d_unit_xqd) {
+    return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size, ss_y, d_dbl, dbl_stride, d_unit_ep,
+                                      d_unit_xqd, nullptr);
+}
+int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw, int ph,
+                               int unit_size, int ss_y, const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd,
+                               const int16_t* d_unit_wiener) {
     if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
         !sgr_args_ok(pix_bytes, bd, pw, ph))
         return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sgr_apply(c->stream, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size,
                                                        sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_dbl, dbl_stride, d_unit_ep,
-                                                       d_unit_xqd);
+                                                       d_unit_xqd, d_unit_wiener);
     if (e != hipSuccess) return fail(c, e, "sgr apply launch");
     return SVT_HIP_OK;
 }

@@ -48,5 +48,5 @@ int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void*
                               int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums);
 int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph,
                              int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride, const uint8_t* unit_ep,
-                             const int32_t* unit_xqd);
+                             const int32_t* unit_xqd, const int16_t* unit_wiener);
 }

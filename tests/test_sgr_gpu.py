@@ -107,3 +107,32 @@ def test_search_and_stripe_apply(hip, orc, bd, ss):
         assert np.array_equal(got2, exp2), (bd, ss, "no stripes", np.argwhere(got2 != exp2)[:5])
         assert (exp2 != exp).any(), "stripe boundaries must matter on this content"
         hip.free(d_ext, d_src, d_dbl, d_dst, d_ep, d_xqd)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_mixed_wiener_sgr_apply(hip, orc, bd, ss):
+    """svt_hip_lr_apply_plane_dev: a plane whose units are a mix of RESTORE_NONE / RESTORE_WIENER / RESTORE_SGRPROJ, stripe boundaries
+    from the deblocked plane, vs orc_lr_apply_plane (pinned to svt_av1_loop_restoration_filter_unit incl. wiener_filter_stripe)."""
+    for (w, h, US) in ((200, 152, 64), (328, 264, 128)):
+        src, ext = make_planes(w, h, bd, 90 + bd + ss)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        rng = np.random.default_rng(13 + ss)
+        dbl = np.clip(ext[EXT:EXT + h, EXT:EXT + w].astype(np.int32) + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(ext.dtype)
+        nu = units(w, US) * units(h, US)
+        u_ep = rng.integers(0, 16, nu).astype(np.uint8); u_ep[::3] = 254; u_ep[1] = 255
+        u_xqd = np.stack([rng.integers(-96, 32, nu), rng.integers(-32, 96, nu)], 1).astype(np.int32)
+        u_wn = np.zeros((nu, 2, 8), np.int16)
+        for u in range(nu):
+            for d in range(2):
+                t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                if u == 0: t = [10, 8, 46] if d else [-5, -23, -17]          # extreme taps
+                if ss: t[0] = 0
+                u_wn[u, d, :7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
+        work = ext.copy(); exp = np.zeros((h, w), ext.dtype)
+        orc.orc_lr_apply_plane(ptr(dbl), w, C.c_void_p(work.ctypes.data + off), st, ext.itemsize, w, h, ss, ss, US, bd, ptr(u_ep), ptr(u_xqd), ptr(u_wn), ptr(exp), w)
+        d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst = hip.to_device(ext), hip.to_device(dbl), hip.to_device(u_ep), hip.to_device(u_xqd), hip.to_device(u_wn), hip.to_device(np.zeros_like(exp))
+        hip.check(hip.L.svt_hip_lr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_dst, w, w, h, US, ss, d_dbl, w, d_ep, d_xqd, d_wn), "lr apply")
+        got = hip.to_host(d_dst, (h, w), ext.dtype)
+        hip.free(d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst)
+        assert np.array_equal(got, exp), (bd, ss, w, h, US, np.argwhere(got != exp)[:5])
