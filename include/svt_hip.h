@@ -346,6 +346,14 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void
                                int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep,
                                const int32_t *d_unit_xqd, const int16_t *d_unit_wiener);
 
+/* ------------------------------------------------------------------ Wiener restoration search ---- */
+/* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as
+ * search_wiener_seg (:1347) calls it: d_M[unit][win * win], d_H[unit][win^2 * win^2] (exact int64; feature index = (dx + win/2) * win
+ * + (dy + win/2)).  win = 7 (luma), 5 (chroma) or 3.  The plane must be extended by 3 samples like for the self-guided calls.  The linear
+ * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090) stay on the host.  8-bit planes. */
+int svt_hip_wiener_stats_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int win, const void *d_dgd, int stride, const void *d_src,
+                                   int src_stride, int pw, int ph, int unit_size, int ss_y, int64_t *d_M, int64_t *d_H);
+
 #ifdef __cplusplus
 }
 #endif

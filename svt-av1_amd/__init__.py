@@ -131,6 +131,7 @@ def lib():
     L.svt_hip_sgr_search_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp]
     L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
+    L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_plane_sse_dev.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp]
     L.svt_hip_dlf_search_level_dev.argtypes = [vp, C.POINTER(DlfSearch), vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int64)]

@@ -519,4 +519,19 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* 
     return SVT_HIP_OK;
 }
 
+int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win, const void* d_dgd, int stride, const void* d_src, int src_stride,
+                                   int pw, int ph, int unit_size, int ss_y, int64_t* d_M, int64_t* d_H) {
+    if (!c || !d_dgd || !d_src || !d_M || !d_H || (win != 7 && win != 5 && win != 3) || unit_size < 64 || (unit_size & 63) || unit_size > 256 ||
+        (ss_y != 0 && ss_y != 1) || pw <= 0 || ph <= 0)
+        return SVT_HIP_ERR_BAD_ARG;
+    if (pix_bytes != 1 || bd != 8) {
+        c->err = "svt_hip_wiener_stats_plane_dev: only 8-bit planes are implemented";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_stats8(c->stream, win, (const uint8_t*)d_dgd, stride, (const uint8_t*)d_src, src_stride, pw, ph,
+                                                           unit_size, sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_M, d_H);
+    if (e != hipSuccess) return fail(c, e, "wiener stats launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

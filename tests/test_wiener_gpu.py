@@ -1,0 +1,37 @@
+"""GPU parity: Wiener restoration statistics on the matrix cores (svt_hip_wiener_stats_plane_dev) vs the oracle
+(orc_wiener_stats_plane, pinned to svt_av1_compute_stats_c + the reference's unit geometry): windows 7 / 5 / 3, unit sizes 64 / 128 / 256,
+ragged planes, luma and chroma unit offsets, extreme content (all-max / all-min / checkerboard units that stress the int8 bias)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import ptr
+
+pytestmark = pytest.mark.gpu
+EXT = 3
+
+
+def units(size, unit):
+    return max((size + unit // 2) // unit, 1)
+
+
+@pytest.mark.parametrize("win", [7, 5, 3])
+def test_wiener_stats(hip, orc, win):
+    rng = np.random.default_rng(40 + win)
+    for (w, h, US, ss) in ((200, 152, 64, 0), (328, 264, 128, 1), (520, 300, 256, 0), (96, 72, 64, 1)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        dgd = np.clip(110 + 70 * np.sin(xx / 13.0) * np.cos(yy / 7.0) + rng.normal(0, 12, (h, w)), 0, 255).astype(np.uint8)
+        dgd[:40, :70] = 255; dgd[40:80, :70] = 0; dgd[80:120, :64] = ((xx[80:120, :64] + yy[80:120, :64]) & 1) * 255
+        src = np.clip(dgd.astype(np.int32) + rng.integers(-25, 26, (h, w)), 0, 255).astype(np.uint8)
+        src[:20, :30] = 0
+        ext = np.ascontiguousarray(np.pad(dgd, EXT, mode="edge")); st = ext.shape[1]; off = EXT * st + EXT
+        nu = units(w, US) * units(h, US); w2 = win * win
+        Me, He = np.zeros((nu, w2), np.int64), np.zeros((nu, w2 * w2), np.int64)
+        orc.orc_wiener_stats_plane(win, C.c_void_p(ext.ctypes.data + off), st, ptr(src), w, 1, 8, w, h, ss, US, ptr(Me), ptr(He))
+        d_ext, d_src, d_M, d_H = hip.to_device(ext), hip.to_device(src), hip.empty(Me.nbytes), hip.empty(He.nbytes)
+        hip.check(hip.L.svt_hip_wiener_stats_plane_dev(hip.h, 1, 8, win, d_ext.value + off, st, d_src, w, w, h, US, ss, d_M, d_H), "wiener stats")
+        Mg, Hg = hip.to_host(d_M, Me.shape, np.int64), hip.to_host(d_H, He.shape, np.int64)
+        hip.free(d_ext, d_src, d_M, d_H)
+        assert np.array_equal(Mg, Me), (win, w, h, US, ss, np.argwhere(Mg != Me)[:5])
+        assert np.array_equal(Hg, He), (win, w, h, US, ss, np.argwhere(Hg != He)[:5])
