@@ -24,18 +24,45 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kRing = 16;        // rows kept in LDS (10 needed per 4-row step)
-constexpr int kPitch = 416;      // bytes per row copy: unit width <= 384 (1.5 x 256) + 2 x 3 window + 16-B over-read, multiple of 16
+// bytes per row copy (template parameter PITCH): 16 + unit width (< 1.5 x unit size) + 3 + 16-B over-read, multiple of 16: 144 / 240 / 432
 
-template <int WIN>
+// M, H of a unit from its Gram matrix G over the features [window samples (biased by -128) | source sample | 1]
+template <int WIN, typename GF>
+__device__ __forceinline__ void wiener_finish(GF G, int tid, long long* __restrict__ Mo, long long* __restrict__ Ho) {
+    constexpr int HALF = WIN / 2, NF = WIN * WIN, XF = NF, ONE = NF + 1;
+    const long long N = G(ONE, ONE);
+    const long long sum_d = G(HALF * WIN + HALF, ONE) + 128 * N;
+    const long long a = (long long)((unsigned long long)sum_d / (unsigned long long)N) - 128;   // find_average() - 128
+    const long long Sx = G(XF, ONE);
+    for (int i = tid; i < NF * NF + NF; i += 256) {
+        if (i < NF * NF) {
+            const int k = i / NF, l = i - k * NF;
+            Ho[i] = G(k, l) - a * (G(k, ONE) + G(l, ONE)) + N * a * a;
+        } else {
+            const int k = i - NF * NF;
+            Mo[k] = G(k, XF) - a * (G(k, ONE) + Sx) + N * a * a;
+        }
+    }
+}
+
+template <int WIN, int kPitch, bool BANDED>
 __global__ void __launch_bounds__(256)
 wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint8_t* __restrict__ src, int src_stride, int pw, int ph,
                      int unit_size, int units_x, int units_y, int voff, long long* __restrict__ M_out, long long* __restrict__ H_out) {
     constexpr int HALF = WIN / 2, NF = WIN * WIN, XF = NF, ONE = NF + 1, NBLK = (NF + 2 + 31) / 32, NT = NBLK == 1 ? 1 : 3;
-    __shared__ __attribute__((aligned(16))) int8_t ring[7][kRing][kPitch];   // copy c holds d'[col + (c - 3)] at byte col + 16
-    __shared__ __attribute__((aligned(16))) int8_t sring[4][kPitch];         // source rows of the current step (x' = s - 128)
+    // copy c of the row ring holds d'[col + (c - 3)] at byte col + 16; the same memory later holds the [NT][32 x 32] int64 tile sums
+    constexpr int kRingBytes = 7 * kRing * kPitch, kAccBytes = NT * 1024 * 8, kMainBytes = kRingBytes > kAccBytes ? kRingBytes : kAccBytes;
+    __shared__ __attribute__((aligned(16))) int8_t lds_main[kMainBytes];
+    int8_t (*ring)[kRing][kPitch] = (int8_t (*)[kRing][kPitch])lds_main;
+    __shared__ __attribute__((aligned(16))) int8_t sring[2][4][kPitch];      // source rows of the current / next step (x' = s - 128)
+    __shared__ __attribute__((aligned(16))) uint8_t raw[kRing][kPitch + 32];   // unbiased picture rows, byte 16 = column h0 - 3
     const int unit = blockIdx.x, ui = unit / units_x, uj = unit - ui * units_x;
     const int h0 = uj * unit_size, h1 = uj == units_x - 1 ? pw : h0 + unit_size;
-    const int v0 = max(0, ui * unit_size - voff), v1 = ui == units_y - 1 ? ph : (ui + 1) * unit_size - voff;
+    const int uv0 = max(0, ui * unit_size - voff), uv1 = ui == units_y - 1 ? ph : (ui + 1) * unit_size - voff;
+    // BANDED (unit sizes 128 / 256: fewer units than CUs): blockIdx.y picks a band of 64 rows of the unit; the bands add their Gram
+    // matrices into the unit's H buffer (packed upper triangle, zeroed by the launcher) and wiener_finalize_kernel turns it into M / H
+    const int v0 = BANDED ? uv0 + 64 * (int)blockIdx.y : uv0, v1 = BANDED ? min(uv1, v0 + 64) : uv1;
+    if (v0 >= v1) return;
     const int uw = h1 - h0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // lane -> features (block 0: lane & 31, block 1: 32 + (lane & 31)), k-group g = lane >> 5 (16 pixels each)
@@ -54,44 +81,63 @@ wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint
 #pragma unroll
         for (int r = 0; r < 16; r++) C[t][r] = 0;
 
-    auto stage_row = [&](int y) {   // all 256 threads: picture row y (clamped rows are never used by a valid pixel's window... they are:
-        // rows outside the picture come from the caller's 3-px extension, like the reference reads them)
-        const uint8_t* rowp = dgd + (ptrdiff_t)y * dgd_stride + h0;
-        const int slot = y & (kRing - 1);
-        for (int i = tid; i < (uw + 6 + 16 + 3) / 4 * 7; i += 256) {
-            const int c = i % 7, q = i / 7;            // copy c, dword q of the row: bytes col = 4q .. 4q+3  (col 0 <-> picture column h0 - 16)
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int x = 4 * q + b - 16 + (c - 3);     // picture column offset from h0 of the sample stored at byte 4q + b
-                const int px = (x >= -3 && x < uw + 3) ? (int)rowp[x] - 128 : 0;
-                v |= (uint32_t)(px & 0xFF) << (8 * b);
-            }
-            *(uint32_t*)&ring[c][slot][4 * q] = v;
+    // Row staging, two on-chip phases.  (A) picture rows -> raw[slot][] with plain dword loads and the byte misalignment of the row start
+    // removed (raw byte 16 + j = picture column h0 - 3 + j, j in [0, uw + 6)); (B) raw -> the seven shifted, int8-biased copies.
+    auto load_rows = [&](int ya, int yb) {          // picture rows [ya, yb] -> raw
+        const int row_dw = (uw + 6 + 3) >> 2, n = (yb - ya + 1) * row_dw;
+        for (int i = tid; i < n; i += 256) {
+            const int r = i / row_dw, j = i - r * row_dw;
+            const uint8_t* b = dgd + (ptrdiff_t)(ya + r) * dgd_stride + h0 - 3;
+            const uint32_t sh = (uint32_t)((uintptr_t)b & 3);
+            const uint32_t* gp = (const uint32_t*)(b - sh) + j;
+            const int last_dw = (uw + 6 + (int)sh + 3) >> 2;
+            const uint32_t lo = gp[0], hi = (sh && j + 1 < last_dw) ? gp[1] : 0u;
+            *(uint32_t*)&raw[(ya + r) & (kRing - 1)][16 + 4 * j] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        }
+    };
+    auto build_copies = [&](int ya, int yb) {       // raw rows [ya, yb] -> ring[0..6]
+        const int row_dw = (16 + uw + 3 + 3) >> 2, n = (yb - ya + 1) * 7 * row_dw;   // copy bytes [0, 16 + uw + 3) hold every window sample of a valid pixel
+        for (int i = tid; i < n; i += 256) {
+            const int q = i % row_dw, c = (i / row_dw) % 7, r = i / (7 * row_dw);
+            const int slot = (ya + r) & (kRing - 1);
+            // copy byte jj <-> picture column h0 + jj - 16 + (c - 3) <-> raw byte 16 + (jj - 16 + c - 3) + 3 = jj + c
+            const int rb = 4 * q + c;                   // raw byte index of the copy dword's first byte
+            const uint32_t* rp = (const uint32_t*)&raw[slot][rb & ~3];
+            *(uint32_t*)&ring[c][slot][4 * q] = __builtin_amdgcn_alignbyte(rp[1], rp[0], (uint32_t)(rb & 3)) ^ 0x80808080u;
         }
     };
 
-    int staged_to = v0 - 4;   // last staged picture row
-    for (int y = v0 - 3; y <= min(v0 + 2, v1 + 2); y++) stage_row(y);
-    staged_to = min(v0 + 2, v1 + 2);
-    for (int r0 = v0; r0 < v1; r0 += 4) {
-        __syncthreads();   // previous step's reads are done before the ring / source rows are overwritten
-        for (int y = staged_to + 1; y <= min(r0 + 6, v1 + 2); y++) stage_row(y);
-        staged_to = max(staged_to, min(r0 + 6, v1 + 2));
-        for (int i = tid; i < 4 * ((uw + 15) / 16 * 4); i += 256) {   // source rows r0 .. r0+3, dwords
-            const int q = i % ((uw + 15) / 16 * 4), rr = i / ((uw + 15) / 16 * 4);
+    auto load_src = [&](int r0, int buf) {          // source rows r0 .. r0+3 (x' = s - 128), alignment removed the same way
+        const int row_dw = (uw + 3) >> 2;
+        for (int i = tid; i < 4 * row_dw; i += 256) {
+            const int rr = i / row_dw, j = i - rr * row_dw;
             uint32_t v = 0;
             if (r0 + rr < v1) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int x = 4 * q + b;
-                    const int px = x < uw ? (int)src[(size_t)(r0 + rr) * src_stride + h0 + x] - 128 : 0;
-                    v |= (uint32_t)(px & 0xFF) << (8 * b);
-                }
+                const uint8_t* b = src + (size_t)(r0 + rr) * src_stride + h0;
+                const uint32_t sh = (uint32_t)((uintptr_t)b & 3);
+                const uint32_t* gp = (const uint32_t*)(b - sh) + j;
+                const int last_dw = (uw + (int)sh + 3) >> 2;
+                const uint32_t lo = gp[0], hi = (sh && j + 1 < last_dw) ? gp[1] : 0u;
+                v = __builtin_amdgcn_alignbyte(hi, lo, sh) ^ 0x80808080u;
             }
-            *(uint32_t*)&sring[rr][4 * q] = v;
+            *(uint32_t*)&sring[buf][rr][4 * j] = v;
         }
-        __syncthreads();
+    };
+
+    // software pipeline over 4-row steps: while the MFMAs of step s run, the rows of step s+1 are loaded into ring slots the current step
+    // does not read (16 slots >= 10 in use + 4 new) and into the other source buffer; two barriers per step
+    int staged_to = min(v0 + 6, v1 + 2);
+    load_rows(v0 - 3, staged_to);
+    load_src(v0, 0);
+    __syncthreads();
+    build_copies(v0 - 3, staged_to);
+    int sbuf = 0;
+    for (int r0 = v0; r0 < v1; r0 += 4, sbuf ^= 1) {
+        __syncthreads();   // copies of this step are complete; the previous step's operand reads are done
+        const int ya = staged_to + 1, yb = min(r0 + 10, v1 + 2);
+        const bool more = r0 + 4 < v1;
+        if (more && yb >= ya) load_rows(ya, yb);
+        if (more) load_src(r0 + 4, sbuf ^ 1);
         const int row = r0 + wave;
         if (row < v1) {
             for (int x0 = 0; x0 < uw; x0 += 32) {
@@ -102,7 +148,7 @@ wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint
                 for (int b = 0; b < NBLK; b++) {
                     v4i a = {0, 0, 0, 0};
                     if (kind[b] == 0) a = *(const v4i*)&ring[copy[b]][(row + dy[b]) & (kRing - 1)][16 + p0];
-                    else if (kind[b] == 1) a = *(const v4i*)&sring[wave][p0];
+                    else if (kind[b] == 1) a = *(const v4i*)&sring[sbuf][wave][p0];
                     else if (kind[b] == 2) a = v4i{0x01010101, 0x01010101, 0x01010101, 0x01010101};
                     if (nvalid < 16) {   // pixels past the unit's right edge contribute nothing (only the last 32-pixel step)
 #pragma unroll
@@ -120,11 +166,16 @@ wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint
                 }
             }
         }
+        if (more && yb >= ya) {
+            __syncthreads();   // raw rows of the next step have landed
+            build_copies(ya, yb);
+            staged_to = yb;
+        }
     }
     // ---- add the four waves' tiles (int32 -> int64) in LDS; element (row, col) of a tile: lane = col + 32 * ((row >> 2) & 1),
     //      register = (row & 3) + 4 * (row >> 3)   (C/D layout of the 32x32 MFMAs)
     __syncthreads();
-    unsigned long long* acc = (unsigned long long*)&ring[0][0][0];   // [NT][32 * 32]
+    unsigned long long* acc = (unsigned long long*)lds_main;   // [NT][32 * 32]
     for (int i = tid; i < NT * 1024; i += 256) acc[i] = 0ull;
     __syncthreads();
 #pragma unroll
@@ -140,21 +191,33 @@ wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint
         const int t = f2 < 32 ? 0 : (f1 < 32 ? 1 : 2);
         return (long long)acc[t * 1024 + (f1 & 31) * 32 + (f2 & 31)];
     };
-    const long long N = G(ONE, ONE);
-    const long long sum_d = G(HALF * WIN + HALF, ONE) + 128 * N;
-    const long long a = (long long)((unsigned long long)sum_d / (unsigned long long)N) - 128;   // find_average() - 128
-    const long long Sx = G(XF, ONE);
-    long long* Mo = M_out + (size_t)unit * NF;
-    long long* Ho = H_out + (size_t)unit * NF * NF;
-    for (int i = tid; i < NF * NF + NF; i += 256) {
-        if (i < NF * NF) {
-            const int k = i / NF, l = i - k * NF;
-            Ho[i] = G(k, l) - a * (G(k, ONE) + G(l, ONE)) + N * a * a;
-        } else {
-            const int k = i - NF * NF;
-            Mo[k] = G(k, XF) - a * (G(k, ONE) + Sx) + N * a * a;
+    if (BANDED) {
+        constexpr int F = NF + 2;
+        unsigned long long* P = (unsigned long long*)(H_out + (size_t)unit * NF * NF);
+        for (int i = tid; i < F * F; i += 256) {
+            const int f1 = i / F, f2 = i - f1 * F;
+            if (f1 <= f2) atomicAdd(&P[f1 * F - f1 * (f1 - 1) / 2 + (f2 - f1)], (unsigned long long)G(f1, f2));
         }
+        return;
     }
+    wiener_finish<WIN>(G, tid, M_out + (size_t)unit * NF, H_out + (size_t)unit * NF * NF);
+}
+
+// packed Gram matrix of a unit (written by the banded kernel into the unit's H buffer) -> M, H
+template <int WIN>
+__global__ void __launch_bounds__(256)
+wiener_finalize_kernel(long long* __restrict__ M_out, long long* __restrict__ H_out) {
+    constexpr int NF = WIN * WIN, F = NF + 2, NP = F * (F + 1) / 2;
+    __shared__ long long P[NP];
+    const int unit = blockIdx.x, tid = threadIdx.x;
+    long long* Ho = H_out + (size_t)unit * NF * NF;
+    for (int i = tid; i < NP; i += 256) P[i] = Ho[i];
+    __syncthreads();   // everything is read before the first H entry is overwritten
+    auto G = [&](int f1, int f2) -> long long {
+        if (f1 > f2) { const int t = f1; f1 = f2; f2 = t; }
+        return P[f1 * F - f1 * (f1 - 1) / 2 + (f2 - f1)];
+    };
+    wiener_finish<WIN>(G, tid, M_out + (size_t)unit * NF, Ho);
 }
 
 }  // namespace
@@ -163,8 +226,21 @@ extern "C" int svt_hip_launch_wiener_stats8(hipStream_t st, int win, const uint8
                                             int ph, int unit_size, int units_x, int units_y, int ss_y, int64_t* M, int64_t* H) {
     const int voff = 8 >> ss_y, n = units_x * units_y;
     if (n <= 0) return 0;
-    if (win == 7) hipLaunchKernelGGL((wiener_stats8_kernel<7>), dim3(n), dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size, units_x, units_y, voff, (long long*)M, (long long*)H);
-    else if (win == 5) hipLaunchKernelGGL((wiener_stats8_kernel<5>), dim3(n), dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size, units_x, units_y, voff, (long long*)M, (long long*)H);
-    else hipLaunchKernelGGL((wiener_stats8_kernel<3>), dim3(n), dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size, units_x, units_y, voff, (long long*)M, (long long*)H);
+#define LAUNCH(W, P, B, GRID) hipLaunchKernelGGL((wiener_stats8_kernel<W, P, B>), GRID, dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, \
+                                                 unit_size, units_x, units_y, voff, (long long*)M, (long long*)H)
+#define BY_WIN(P, B, GRID) do { if (win == 7) LAUNCH(7, P, B, GRID); else if (win == 5) LAUNCH(5, P, B, GRID); else LAUNCH(3, P, B, GRID); } while (0)
+    if (unit_size <= 64) {
+        BY_WIN(144, false, dim3(n));
+    } else {
+        // a unit is up to 1.5 x unit_size rows: ceil(1.5 * unit_size / 64) bands
+        const dim3 grid(n, (unit_size * 3 / 2 + 63) / 64);
+        if (hipMemsetAsync(H, 0, (size_t)n * win * win * win * win * sizeof(int64_t), st) != hipSuccess) return (int)hipGetLastError();
+        if (unit_size <= 128) BY_WIN(240, true, grid); else BY_WIN(432, true, grid);
+        if (win == 7) hipLaunchKernelGGL((wiener_finalize_kernel<7>), dim3(n), dim3(256), 0, st, (long long*)M, (long long*)H);
+        else if (win == 5) hipLaunchKernelGGL((wiener_finalize_kernel<5>), dim3(n), dim3(256), 0, st, (long long*)M, (long long*)H);
+        else hipLaunchKernelGGL((wiener_finalize_kernel<3>), dim3(n), dim3(256), 0, st, (long long*)M, (long long*)H);
+    }
+#undef BY_WIN
+#undef LAUNCH
     return (int)hipGetLastError();
 }
