@@ -179,7 +179,7 @@ def main():
     # SGR: 3-px extended copies of the CDEF output, projection sums for all 16 sets, apply with fixed per-unit sets
     EXT = 3
     d_ext = [torch.zeros((p.shape[0] + 2 * EXT, p.shape[1] + 2 * EXT + ((-(p.shape[1] + 2 * EXT)) % 4), ), dtype=torch.uint8, device=dev) for p in d_pred]
-    US = [64, 64, 64]   # restoration unit size per plane in plane samples (64 luma = one unit per SB)
+    US = [256, 256, 256]   # restoration unit size per plane: what the reference picks above CIF (set_restoration_unit_size, EbPictureControlSet.c:31-47)
     n_units = [max((F.cur[p].shape[1] + US[p] // 2) // US[p], 1) * max((F.cur[p].shape[0] + US[p] // 2) // US[p], 1) for p in range(3)]
     d_sgr_sums = [torch.zeros((n_units[p], 16, 5), dtype=torch.int64, device=dev) for p in range(3)]
     d_unit_ep = [T(rng.integers(0, 16, n_units[p]).astype(np.uint8)) for p in range(3)]
@@ -478,7 +478,7 @@ def main():
         "launch": ("eager" if not use_graph else "hip_graph_replay") + (", single stream" if args.serial else f", 1+1+{n_lanes} forked streams per step"),
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
                                + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16; square tx tiling "
-                                 "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets",
+                                 "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets, restoration units 256",
                    "stages_ms": per_stage, "parity_spot_check": parity_ok},
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
