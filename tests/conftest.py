@@ -29,7 +29,10 @@ def load_package():
 
 @pytest.fixture(scope="session")
 def pkg():
-    return load_package()
+    mod = load_package()
+    if not os.path.exists(mod.LIB_PATH):   # fresh checkout: same recipe as __graft_entry__.build() (hipcc cross-compiles without a GPU)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "svt-av1_amd", "csrc"), "-j", str(min(16, os.cpu_count() or 4)), "-s"])
+    return mod
 
 
 @pytest.fixture(scope="session")

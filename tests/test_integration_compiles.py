@@ -15,6 +15,8 @@ REF = "/root/reference"
 def test_integration_sources_compile_against_reference_headers():
     L = os.path.join(REF, "Source", "Lib")
     gen = os.path.join(ROOT, "oracle", "_ref", "gen")
+    if not os.path.exists(os.path.join(gen, "EbVersion.h")):   # the 5-line version header the reference's own build generates
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-s", os.path.join(gen, "EbVersion.h")])
     incs = [gen, os.path.join(REF, "Source", "API"), os.path.join(L, "Common", "Codec"), os.path.join(L, "Common", "C_DEFAULT"),
             os.path.join(L, "Encoder", "Codec"), os.path.join(L, "Encoder", "C_DEFAULT"), os.path.join(L, "Encoder", "Globals"),
             os.path.join(ROOT, "include"), os.path.join(ROOT, "integration")]
