@@ -264,7 +264,38 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         [&](int i, uint16_t v) { in[i] = v; });
     __syncthreads();
 
-    // ---- parameter-set independent part of A/B for the positions this thread owns
+    // ---- parameter-set independent part of A/B for the positions this thread owns.  The box sums are separable: (1) a lane takes one
+    // column of the staged tile and a third of its rows and writes the VERTICAL 3- and 5-sums of x and x^2 (15 LDS reads), (2) a position
+    // adds 3 (r = 1) or 5 (r = 2) neighbouring vertical sums.  ~27 instead of ~100 instructions per pixel.  The vertical sums live in
+    // the memory of the A/B buffers, which are first written after the barrier below.
+    uint16_t* vs3 = (uint16_t*)&ab[0][0];                       // [S_P1H][S_IW]
+    uint32_t* vq3 = (uint32_t*)(vs3 + S_P1H * S_IW);            // [S_P1H][S_IW]   (S_P1H * S_IW is even: 4-byte aligned)
+    uint16_t* vs5 = (uint16_t*)(vq3 + S_P1H * S_IW);            // [S_P2H][S_IW]
+    uint32_t* vq5 = (uint32_t*)(vs5 + S_P2H * S_IW + (S_P2H * S_IW & 1));
+    static_assert((S_P1H * S_IW * 6 + (S_P2H * S_IW + 1) * 6) <= (int)sizeof(uint32_t) * 2 * S_NP, "vertical sums must fit the A/B buffers");
+    if (tid < 3 * S_IW) {
+        const int c = tid % S_IW, b = tid / S_IW;               // column, row band: r = 1 position rows [12b, 12b + 12), r = 2 rows [6b, 6b + 6)
+        uint32_t x[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) x[k] = in[min(12 * b + k, S_IH - 1) * S_IW + c];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {                          // r = 1 position row pr: staged rows pr + 1 .. pr + 3
+            const int pr = 12 * b + k;
+            if (pr < S_P1H) {
+                vs3[pr * S_IW + c] = (uint16_t)(x[k + 1] + x[k + 2] + x[k + 3]);
+                vq3[pr * S_IW + c] = x[k + 1] * x[k + 1] + x[k + 2] * x[k + 2] + x[k + 3] * x[k + 3];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {                           // r = 2 position row rr: staged rows 2 rr .. 2 rr + 4
+            const int rr = 6 * b + k;
+            if (rr < S_P2H) {
+                vs5[rr * S_IW + c] = (uint16_t)(x[2 * k] + x[2 * k + 1] + x[2 * k + 2] + x[2 * k + 3] + x[2 * k + 4]);
+                vq5[rr * S_IW + c] = x[2 * k] * x[2 * k] + x[2 * k + 1] * x[2 * k + 1] + x[2 * k + 2] * x[2 * k + 2] + x[2 * k + 3] * x[2 * k + 3] + x[2 * k + 4] * x[2 * k + 4];
+            }
+        }
+    }
+    __syncthreads();
     uint32_t P[S_KP], M[S_KP];
 #pragma unroll
     for (int k = 0; k < S_KP; k++) {
@@ -272,21 +303,18 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         uint32_t sm = 0, sq = 0, n = 9, obn = 455;
         if (i < S_N1) {                        // r = 1: position (r - 1, c - 1), window centre in[r + 2][c + 2]
             const int r = i / S_PW, c = i - r * S_PW;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) { const uint32_t v = in[(r + 2 + dy) * S_IW + c + 2 + dx]; sm += v; sq += v * v; }
+            sm = (uint32_t)vs3[r * S_IW + c + 1] + vs3[r * S_IW + c + 2] + vs3[r * S_IW + c + 3];
+            sq = vq3[r * S_IW + c + 1] + vq3[r * S_IW + c + 2] + vq3[r * S_IW + c + 3];
         } else if (i < S_NP) {                 // r = 2: picture rows -1, 1, 3, ...
-            const int i2 = i - S_N1, rr = i2 / S_PW, c = i2 - rr * S_PW, r = 2 * rr;
+            const int i2 = i - S_N1, rr = i2 / S_PW, c = i2 - rr * S_PW;
             n = 25; obn = 164;
-#pragma unroll
-            for (int dy = -2; dy <= 2; dy++)
-#pragma unroll
-                for (int dx = -2; dx <= 2; dx++) { const uint32_t v = in[(r + 2 + dy) * S_IW + c + 2 + dx]; sm += v; sq += v * v; }
+            sm = (uint32_t)vs5[rr * S_IW + c] + vs5[rr * S_IW + c + 1] + vs5[rr * S_IW + c + 2] + vs5[rr * S_IW + c + 3] + vs5[rr * S_IW + c + 4];
+            sq = vq5[rr * S_IW + c] + vq5[rr * S_IW + c + 1] + vq5[rr * S_IW + c + 2] + vq5[rr * S_IW + c + 3] + vq5[rr * S_IW + c + 4];
         }
         P[k] = (sq * n < sm * sm) ? 0u : sq * n - sm * sm;   // EbRestoration.c:804-806 / :935-937 (bit depth 8: no pre-rounding)
         M[k] = sm * obn;
     }
+    __syncthreads();   // the vertical sums are dead: the first parameter set's A/B may overwrite them
 
     // ---- the 8 pixels (one column, 8 rows) this lane accumulates
     const int j = tid & 63, i0 = (tid >> 6) * 8;
