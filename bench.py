@@ -343,7 +343,7 @@ def main():
         dict(key="cdef_search", name="cdef_search", run=run_cdef_search, kernel="cdef_search_luma_kernel"),
         dict(key="cdef_apply", name="cdef_apply", run=run_cdef_apply, kernel="cdef_apply_kernel"),
         dict(key="sgr_search", name="sgr_search", run=run_sgr_search, kernel="sgr_search8_kernel"),
-        dict(key="sgr_apply", name="sgr_apply", run=run_sgr_apply, kernel="sgr_apply_kernel"),
+        dict(key="sgr_apply", name="sgr_apply", run=run_sgr_apply, kernel="lr_apply8_kernel"),
     ]
     want = None if args.stages == "all" else set(args.stages.split(","))
     stages = [s for s in all_stages if want is None or s["key"] in want]

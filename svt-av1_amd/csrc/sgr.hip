@@ -236,39 +236,14 @@ __device__ __forceinline__ int32_t row16_sum(int32_t v) {   // every lane of a 1
     return v;
 }
 
-#define FA_(v) ((v) >> 20)
-#define FB_(v) ((v) & 0xFFFFFu)
-
-template <typename PIX>
-__global__ void __launch_bounds__(256)
-sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
-    __shared__ uint16_t in[S_IH * S_IW];
-    __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
-    __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
-    __shared__ unsigned long long acc[16][5];
-    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (see sgr_search_kernel)
-    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
-
-    {
-        const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
-        xt[tid] = (A << 20) | (256u - A);
-        if (tid < 80) acc[tid / 5][tid % 5] = 0ull;
-    }
-    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
-        [&](int i) {
-            const int r = i / S_IW, c = i - r * S_IW;
-            const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
-            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
-        },
-        [&](int i, uint16_t v) { in[i] = v; });
-    __syncthreads();
-
-    // ---- parameter-set independent part of A/B for the positions this thread owns.  The box sums are separable: (1) a lane takes one
+// ---- building blocks shared by the 8-bit search and apply kernels (64 x 32 tiles) --------------------------------------------
+// `in`: staged tile [S_IH][S_IW]; abmem: 2 * S_NP dwords of scratch that later hold A'/B' (two barriers inside)
+__device__ __forceinline__ void sgr8_precompute(const uint16_t* __restrict__ in, uint32_t* __restrict__ abmem, int tid, uint32_t (&P)[S_KP], uint32_t (&M)[S_KP]) {
+    // parameter-set independent part of A/B for the positions this thread owns.  The box sums are separable: (1) a lane takes one
     // column of the staged tile and a third of its rows and writes the VERTICAL 3- and 5-sums of x and x^2 (15 LDS reads), (2) a position
     // adds 3 (r = 1) or 5 (r = 2) neighbouring vertical sums.  ~27 instead of ~100 instructions per pixel.  The vertical sums live in
     // the memory of the A/B buffers, which are first written after the barrier below.
-    uint16_t* vs3 = (uint16_t*)&ab[0][0];                       // [S_P1H][S_IW]
+    uint16_t* vs3 = (uint16_t*)abmem;                       // [S_P1H][S_IW]
     uint32_t* vq3 = (uint32_t*)(vs3 + S_P1H * S_IW);            // [S_P1H][S_IW]   (S_P1H * S_IW is even: 4-byte aligned)
     uint16_t* vs5 = (uint16_t*)(vq3 + S_P1H * S_IW);            // [S_P2H][S_IW]
     uint32_t* vq5 = (uint32_t*)(vs5 + S_P2H * S_IW + (S_P2H * S_IW & 1));
@@ -296,7 +271,6 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         }
     }
     __syncthreads();
-    uint32_t P[S_KP], M[S_KP];
 #pragma unroll
     for (int k = 0; k < S_KP; k++) {
         const int i = tid + 256 * k;
@@ -315,6 +289,94 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         M[k] = sm * obn;
     }
     __syncthreads();   // the vertical sums are dead: the first parameter set's A/B may overwrite them
+
+}
+
+// A'/B' of one parameter set for the positions this thread owns (EbRestoration.c:787-858 / :926-985), packed A' << 20 | B'
+__device__ __forceinline__ void sgr8_build(uint32_t* __restrict__ abw, const uint32_t* __restrict__ xt, const uint32_t (&P)[S_KP], const uint32_t (&M)[S_KP],
+                                           bool has0, bool has1, uint32_t s0, uint32_t s1, int tid) {
+#pragma unroll
+    for (int k = 0; k < S_KP; k++) {
+        const int i = tid + 256 * k;
+        if (i < S_N1 ? has1 : (has0 && i < S_NP)) {
+            const uint32_t z = (__umul24(P[k], i < S_N1 ? s1 : s0) + (1u << 19)) >> 20;
+            const uint32_t t = xt[min(z, 255u)];
+            const uint32_t B = (__umul24(t & 0x1FFu, M[k]) + (1u << 11)) >> 12;
+            abw[i] = (t & 0xFFF00000u) | B;
+        }
+    }
+}
+
+#define FA_(v) ((v) >> 20)
+#define FB_(v) ((v) & 0xFFFFFu)
+// flt0 - u (D0) and flt1 - u (D1) of the 8 pixels (column j, rows i0 .. i0 + 7) of a lane; X = pixel, CX = 256 - (X << 13)
+__device__ __forceinline__ void sgr8_filter(const uint32_t* __restrict__ abw, int i0, int j, const uint32_t (&X)[8], const int32_t (&CX)[8], bool has0, bool has1,
+                                            int32_t (&D0)[8], int32_t (&D1)[8]) {
+        if (has1) {
+        const uint32_t* a1 = abw + i0 * S_PW + j + 1;   // row index = picture row + 1
+        uint32_t Rm, Cm, R0, C0;
+        { const uint32_t l = a1[-1], c = a1[0], r = a1[1]; Rm = l + c + r; Cm = c; }
+        { const uint32_t l = a1[S_PW - 1], c = a1[S_PW], r = a1[S_PW + 1]; R0 = l + c + r; C0 = c; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t* q = a1 + (r + 2) * S_PW;
+            const uint32_t l = q[-1], c = q[0], rt = q[1];
+            const uint32_t Rp = l + c + rt;
+            const uint32_t S9 = Rm + R0 + Rp, S5 = Cm + R0 + c;     // 4 * cross + 3 * corners = 3 * S9 + S5
+            const uint32_t a = __umul24(FA_(S9), 3u) + FA_(S5), b = __umul24(FB_(S9), 3u) + FB_(S5);
+            D1[r] = (int32_t)(__umul24(a, X[r]) + b + (uint32_t)CX[r]) >> 9;
+            Rm = R0; Cm = C0; R0 = Rp; C0 = c;
+        }
+    }
+    if (has0) {
+        const uint32_t* a2 = abw + S_N1 + (i0 / 2) * S_PW + j + 1;   // ab2 row rr holds picture row 2 * rr - 1
+        uint32_t H[5], C[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) { const uint32_t l = a2[q * S_PW - 1], c = a2[q * S_PW], r = a2[q * S_PW + 1]; H[q] = l + c + r; C[q] = c; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            {   // even row 2q: rows above/below, 6 * centres + 5 * sides = 5 * S6 + S2, >> 9
+                const uint32_t S6 = H[q] + H[q + 1], S2 = C[q] + C[q + 1];
+                const uint32_t a = __umul24(FA_(S6), 5u) + FA_(S2), b = __umul24(FB_(S6), 5u) + FB_(S2);
+                D0[2 * q] = (int32_t)(__umul24(a, X[2 * q]) + b + (uint32_t)CX[2 * q]) >> 9;
+            }
+            {   // odd row 2q + 1: own row, >> 8 (rounding and u scale by one bit less: CX >> 1 is exact)
+                const uint32_t a = __umul24(FA_(H[q + 1]), 5u) + FA_(C[q + 1]), b = __umul24(FB_(H[q + 1]), 5u) + FB_(C[q + 1]);
+                D0[2 * q + 1] = (int32_t)(__umul24(a, X[2 * q + 1]) + b + (uint32_t)(CX[2 * q + 1] >> 1)) >> 8;
+            }
+        }
+    }
+}
+#undef FA_
+#undef FB_
+
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
+                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
+    __shared__ uint16_t in[S_IH * S_IW];
+    __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
+    __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
+    __shared__ unsigned long long acc[16][5];
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (see sgr_search_kernel)
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+
+    {
+        const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
+        xt[tid] = (A << 20) | (256u - A);
+        if (tid < 80) acc[tid / 5][tid % 5] = 0ull;
+    }
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
+        [&](int i) {
+            const int r = i / S_IW, c = i - r * S_IW;
+            const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);   // never leave the 3-px extension
+            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { in[i] = v; });
+    __syncthreads();
+
+    uint32_t P[S_KP], M[S_KP];
+    sgr8_precompute(in, &ab[0][0], tid, P, M);
 
     // ---- the 8 pixels (one column, 8 rows) this lane accumulates
     const int j = tid & 63, i0 = (tid >> 6) * 8;
@@ -341,54 +403,11 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
         const uint32_t s0 = (uint32_t)kSgr[ep][2], s1 = (uint32_t)kSgr[ep][3];
         uint32_t* abw = ab[buf];
-        // ---- A'/B' of this set (EbRestoration.c:787-858 / :926-985)
-#pragma unroll
-        for (int k = 0; k < S_KP; k++) {
-            const int i = tid + 256 * k;
-            if (i < S_N1 ? has1 : (has0 && i < S_NP)) {
-                const uint32_t z = (__umul24(P[k], i < S_N1 ? s1 : s0) + (1u << 19)) >> 20;
-                const uint32_t t = xt[min(z, 255u)];
-                const uint32_t B = (__umul24(t & 0x1FFu, M[k]) + (1u << 11)) >> 12;
-                abw[i] = (t & 0xFFF00000u) | B;
-            }
-        }
+        sgr8_build(abw, xt, P, M, has0, has1, s0, s1, tid);
         __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
 
         int32_t D0[8], D1[8];
-        if (has1) {
-            const uint32_t* a1 = abw + i0 * S_PW + j + 1;   // row index = picture row + 1
-            uint32_t Rm, Cm, R0, C0;
-            { const uint32_t l = a1[-1], c = a1[0], r = a1[1]; Rm = l + c + r; Cm = c; }
-            { const uint32_t l = a1[S_PW - 1], c = a1[S_PW], r = a1[S_PW + 1]; R0 = l + c + r; C0 = c; }
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t* q = a1 + (r + 2) * S_PW;
-                const uint32_t l = q[-1], c = q[0], rt = q[1];
-                const uint32_t Rp = l + c + rt;
-                const uint32_t S9 = Rm + R0 + Rp, S5 = Cm + R0 + c;     // 4 * cross + 3 * corners = 3 * S9 + S5
-                const uint32_t a = __umul24(FA_(S9), 3u) + FA_(S5), b = __umul24(FB_(S9), 3u) + FB_(S5);
-                D1[r] = (int32_t)(__umul24(a, X[r]) + b + (uint32_t)CX[r]) >> 9;
-                Rm = R0; Cm = C0; R0 = Rp; C0 = c;
-            }
-        }
-        if (has0) {
-            const uint32_t* a2 = abw + S_N1 + (i0 / 2) * S_PW + j + 1;   // ab2 row rr holds picture row 2 * rr - 1
-            uint32_t H[5], C[5];
-#pragma unroll
-            for (int q = 0; q < 5; q++) { const uint32_t l = a2[q * S_PW - 1], c = a2[q * S_PW], r = a2[q * S_PW + 1]; H[q] = l + c + r; C[q] = c; }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                {   // even row 2q: rows above/below, 6 * centres + 5 * sides = 5 * S6 + S2, >> 9
-                    const uint32_t S6 = H[q] + H[q + 1], S2 = C[q] + C[q + 1];
-                    const uint32_t a = __umul24(FA_(S6), 5u) + FA_(S2), b = __umul24(FB_(S6), 5u) + FB_(S2);
-                    D0[2 * q] = (int32_t)(__umul24(a, X[2 * q]) + b + (uint32_t)CX[2 * q]) >> 9;
-                }
-                {   // odd row 2q + 1: own row, >> 8 (rounding and u scale by one bit less: CX >> 1 is exact)
-                    const uint32_t a = __umul24(FA_(H[q + 1]), 5u) + FA_(C[q + 1]), b = __umul24(FB_(H[q + 1]), 5u) + FB_(C[q + 1]);
-                    D0[2 * q + 1] = (int32_t)(__umul24(a, X[2 * q + 1]) + b + (uint32_t)(CX[2 * q + 1] >> 1)) >> 8;
-                }
-            }
-        }
+        sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
         int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -422,6 +441,106 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 }
 #undef FA_
 #undef FB_
+
+// ---- 8-bit frame apply on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
+// RESTORE_NONE units are copied, RESTORE_WIENER units take the 7-tap separable filter, RESTORE_SGRPROJ units the self-guided filter.
+// A tile is one stripe high at most (stripes are 64 >> ss_y rows starting 8 >> ss_y above a multiple of that), so the StripeCtx rules
+// of the generic kernel apply unchanged.
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
+                 int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
+                 const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener) {
+    __shared__ uint16_t in[S_IH * S_IW];
+    __shared__ uint32_t ab[2][S_NP];
+    __shared__ uint32_t xt[256];
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    const int ep = unit_ep[unit];
+    const bool wiener = ep == 254 && unit_wiener != nullptr;
+    if (ep > 15 && !wiener) {   // copy_tile (EbRestoration.c:1174-1177)
+        for (int k = tid; k < S_TW * S_TH; k += 256) {
+            const int i = k / S_TW, j = k - i * S_TW;
+            if (x0 + j < pw && y0 + i < ph && y0 + i >= 0) dst[(size_t)(y0 + i) * dst_stride + x0 + j] = dgd[(ptrdiff_t)(y0 + i) * stride + x0 + j];
+        }
+        return;
+    }
+    StripeCtx<PIX> sc{nullptr, 0, 0, 0, 0, 0};
+    if (dbl) {
+        const int s = (y0 + voff) / stripe_h;
+        sc.dbl = dbl; sc.dbl_stride = dbl_stride;
+        sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
+        sc.above = s > 0; sc.below = sc.sy1 < ph;
+    }
+    {
+        const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
+        xt[tid] = (A << 20) | (256u - A);
+    }
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
+        [&](int i) {
+            const int r = i / S_IW, c = i - r * S_IW;
+            const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+            if (sc.above && yy < sc.sy0)
+                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+            if (sc.below && yy >= sc.sy1)
+                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
+            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { in[i] = v; });
+    __syncthreads();
+    const int j = tid & 63, i0 = (tid >> 6) * 8;
+    if (wiener) {   // svt_av1_wiener_convolve_add_src (Common/Codec/convolve.c:60-145): horizontal pass (round 3), vertical pass (round 11)
+        int fx[8], fy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { fy[k] = unit_wiener[16 * unit + k]; fx[k] = unit_wiener[16 * unit + 8 + k]; }
+        uint16_t* tmp = (uint16_t*)&ab[0][0];   // [S_IH][S_TW]
+        for (int k = tid; k < S_IH * S_TW; k += 256) {
+            const int r = k / S_TW, c = k - r * S_TW;
+            int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << 14);
+#pragma unroll
+            for (int t = 0; t < 7; t++) sum += (int32_t)in[r * S_IW + c + t] * fx[t];
+            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << 13) - 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i = i0 + r;
+            if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
+            int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << 18);
+#pragma unroll
+            for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * S_TW + j] * fy[t];
+            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), 255);
+        }
+        return;
+    }
+    uint32_t P[S_KP], M[S_KP];
+    sgr8_precompute(in, &ab[0][0], tid, P, M);
+    const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
+    sgr8_build(ab[0], xt, P, M, has0, has1, (uint32_t)kSgr[ep][2], (uint32_t)kSgr[ep][3], tid);
+    __syncthreads();
+    uint32_t X[8]; int32_t CX[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { X[r] = in[(i0 + r + 3) * S_IW + j + 3]; CX[r] = 256 - (int32_t)(X[r] << 13); }
+    int32_t D0[8], D1[8];
+    sgr8_filter(ab[0], i0, j, X, CX, has0, has1, D0, D1);
+    // svt_decode_xq (EbRestoration.c:707-718)
+    const int32_t xqd0 = unit_xqd[2 * unit], xqd1 = unit_xqd[2 * unit + 1];
+    int32_t xq0, xq1;
+    if (!has0) { xq0 = 0; xq1 = 128 - xqd1; }
+    else if (!has1) { xq0 = xqd0; xq1 = 0; }
+    else { xq0 = xqd0; xq1 = 128 - xq0 - xqd1; }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int i = i0 + r;
+        if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
+        int32_t v = (int32_t)(X[r] << 11);   // u << SGRPROJ_PRJ_BITS, u = x << SGRPROJ_RST_BITS
+        if (has0) v += xq0 * D0[r];
+        if (has1) v += xq1 * D1[r];
+        const int32_t w = (int32_t)(int16_t)((v + (1 << 10)) >> 11);
+        dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max(w, 0), 255);
+    }
+}
 
 // ---- svt_av1_loop_restoration_filter_frame for SGRPROJ units over a plane: per-unit parameter set (255 = RESTORE_NONE: copy) and xqd.
 // dbl != nullptr: normative stripe handling (StripeCtx); tiles are shifted by voff = 8 >> ss_y so that a 64x16 tile lies inside one
@@ -521,9 +640,9 @@ extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, c
                                         int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
                                         const uint8_t* unit_ep, const int32_t* unit_xqd, const int16_t* unit_wiener) {
     const int voff = 8 >> ss_y, sh = 64 >> ss_y;
-    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16);
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_apply_kernel<uint8_t, 8>), grid, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 8>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    if (pix_bytes == 1) hipLaunchKernelGGL((lr_apply8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    else if (bd == 8) hipLaunchKernelGGL((lr_apply8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
     else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
     return (int)hipGetLastError();
 }
