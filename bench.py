@@ -284,7 +284,7 @@ def main():
             d_cdef_out[p].copy_(d_recon[p])   # destination starts as a copy of the pre-CDEF picture (device-to-device)
         ctx.check(L.svt_hip_cdef_apply_frame_dev(ctx.h, 1, P3(*[p.data_ptr() for p in d_recon]), P3(*[p.data_ptr() for p in d_cdef_out]),
                                                  I3(*strides), W, H, d_skip8.data_ptr(), d_cy.data_ptr(), d_cuv.data_ptr(), F.cdef_damping, 8,
-                                                 d_dir.data_ptr()), "cdef apply")
+                                                 d_dir.data_ptr(), d_var.data_ptr()), "cdef apply")
 
     def pyr_job(src_p, dst_t, pad_, step_):
         org = src_p.data_ptr() + PAD * F.cur_y_p.shape[1] + PAD

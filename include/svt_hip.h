@@ -227,10 +227,12 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *con
 /* Frame application of svt_av1_cdef_frame / av1_cdef_frame16bit (Encoder/Codec/EbEncCdef.c:292-1031).
  * d_in = pre-CDEF planes, d_out = destination planes that must already hold a copy of d_in (blocks
  * that are skipped or belong to an unfiltered fb are not touched); y/uv_strength[nfb] = the frame
- * header strength value (pri*4 + sec_idx) selected for each filter block. */
+ * header strength value (pri*4 + sec_idx) selected for each filter block.  d_var == NULL: the directions are computed here and left in
+ * d_dir; d_var != NULL: d_dir / d_var are the per-8x8 direction and variance svt_hip_cdef_search_frame_dev produced for the same
+ * pre-CDEF picture (svt_cdef_find_dir is deterministic in the picture, so the reference recomputes the same values) and are reused. */
 int svt_hip_cdef_apply_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *const d_in[3], void *const d_out[3],
                                  const int stride[3], int w, int h, const uint8_t *d_skip8, const uint8_t *d_y_strength,
-                                 const uint8_t *d_uv_strength, int damping, int bd, uint8_t *d_dir);
+                                 const uint8_t *d_uv_strength, int damping, int bd, uint8_t *d_dir, const int32_t *d_var);
 
 /* ------------------------------------------------------- sub-pel prediction, block SAD / variance */
 /* One block of a batched prediction launch.  mode 0 = AV1 single-reference convolve, i.e. what

@@ -421,7 +421,7 @@ template <typename PIX, int PLANE_KIND>  // 0 luma, 1 chroma
 __global__ void __launch_bounds__(256)
 cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride, int w, int h, const uint8_t* __restrict__ skip8,
                   const uint8_t* __restrict__ y_strength, const uint8_t* __restrict__ uv_strength, int damping_hdr, int cs,
-                  uint8_t* __restrict__ dir_buf) {
+                  uint8_t* __restrict__ dir_buf, const int32_t* __restrict__ var_in) {
     constexpr int DEC = PLANE_KIND, FBS = 64 >> DEC, TS = FBS + 2 * kHB;
     __shared__ uint16_t tile[(FBS + 2 * kVB) * TS];
     __shared__ int part[4][128];
@@ -441,9 +441,13 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
             const int by = b >> 3, bx = b & 7;
             if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) continue;
             const uint16_t* px = tile + (8 * by + i + kVB) * TS + 8 * bx + j + kHB;
-            int var;
-            const int dir = find_dir_wave(((int)px[0] >> cs), lane, part[wave], var);
-            if (lane == 0) dir_buf[fb * 64 + b] = (uint8_t)dir;
+            int var, dir;
+            if (var_in) {   // the strength search already ran svt_cdef_find_dir on this picture: reuse its direction / variance
+                dir = dir_buf[fb * 64 + b]; var = var_in[fb * 64 + b];
+            } else {
+                dir = find_dir_wave(((int)px[0] >> cs), lane, part[wave], var);
+                if (lane == 0) dir_buf[fb * 64 + b] = (uint8_t)dir;
+            }
             const int t = level << cs;
             const int y = filter_px_single(px, TS, adjust_strength(t, var), sec, t ? dir : 0, cs, damping);
             out[(size_t)(64 * fbr + 8 * by + i) * stride + 64 * fbc + 8 * bx + j] = (PIX)y;
@@ -474,11 +478,11 @@ int search_t(hipStream_t st, const void* const rec[3], const int rs[3], const vo
 }
 template <typename PIX>
 int apply_t(hipStream_t st, const void* const in[3], void* const out[3], const int stride[3], int w, int h, const uint8_t* skip8,
-            const uint8_t* ys, const uint8_t* uvs, int damping, int cs, uint8_t* dir_buf) {
+            const uint8_t* ys, const uint8_t* uvs, int damping, int cs, uint8_t* dir_buf, const int32_t* var_in) {
     const int nfb = ((w + 63) >> 6) * ((h + 63) >> 6);
-    hipLaunchKernelGGL((cdef_apply_kernel<PIX, 0>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[0], (PIX*)out[0], stride[0], w, h, skip8, ys, uvs, damping, cs, dir_buf);
+    hipLaunchKernelGGL((cdef_apply_kernel<PIX, 0>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[0], (PIX*)out[0], stride[0], w, h, skip8, ys, uvs, damping, cs, dir_buf, var_in);
     for (int p = 1; p < 3; p++)
-        hipLaunchKernelGGL((cdef_apply_kernel<PIX, 1>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[p], (PIX*)out[p], stride[p], w, h, skip8, ys, uvs, damping, cs, dir_buf);
+        hipLaunchKernelGGL((cdef_apply_kernel<PIX, 1>), dim3(nfb), dim3(256), 0, st, (const PIX*)in[p], (PIX*)out[p], stride[p], w, h, skip8, ys, uvs, damping, cs, dir_buf, var_in);
     return (int)hipGetLastError();
 }
 
@@ -493,8 +497,8 @@ extern "C" int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const v
 }
 extern "C" int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3],
                                          int w, int h, const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength,
-                                         int damping, int bd, uint8_t* dir_buf) {
+                                         int damping, int bd, uint8_t* dir_buf, const int32_t* var_in) {
     const int cs = bd - 8;
-    if (pix_bytes == 1) return apply_t<uint8_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf);
-    return apply_t<uint16_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf);
+    if (pix_bytes == 1) return apply_t<uint8_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf, var_in);
+    return apply_t<uint16_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf, var_in);
 }

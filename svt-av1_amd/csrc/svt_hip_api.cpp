@@ -401,14 +401,14 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const
 }
 int svt_hip_cdef_apply_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_in[3], void* const d_out[3], const int stride[3], int w,
                                  int h, const uint8_t* d_skip8, const uint8_t* d_y_strength, const uint8_t* d_uv_strength, int damping,
-                                 int bd, uint8_t* d_dir) {
+                                 int bd, uint8_t* d_dir, const int32_t* d_var) {
     if (!c || !d_in || !d_out || !stride || !d_skip8 || !d_y_strength || !d_uv_strength || !d_dir || (pix_bytes != 1 && pix_bytes != 2) ||
         (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7)) {
         if (c) c->err = "svt_hip_cdef_apply_frame_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
     }
     hipError_t e = (hipError_t)svt_hip_launch_cdef_apply(c->stream, pix_bytes, d_in, d_out, stride, w, h, d_skip8, d_y_strength,
-                                                        d_uv_strength, damping, bd, d_dir);
+                                                        d_uv_strength, damping, bd, d_dir, d_var);
     if (e != hipSuccess) return fail(c, e, "cdef apply launch");
     return SVT_HIP_OK;
 }

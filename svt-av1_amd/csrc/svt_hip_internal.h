@@ -32,7 +32,7 @@ int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const 
                                uint8_t* dir_buf, int32_t* var_buf);
 int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3], int w, int h,
                               const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength, int damping, int bd,
-                              uint8_t* dir_buf);
+                              uint8_t* dir_buf, const int32_t* var_in);
 int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int bd, const void* ref, int ref_stride, void* dst, int dst_stride,
                                   const SvtHipConvBlk* blks, int n);
 int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,

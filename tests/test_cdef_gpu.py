@@ -56,12 +56,28 @@ def test_apply_frame(hip, orc, bd):
     d_in = [hip.to_device(p) for p in rec]; d_out = [hip.to_device(p) for p in rec]
     d_skip, d_ys, d_uvs, d_dir = hip.to_device(skip8), hip.to_device(ys), hip.to_device(uvs), hip.empty(nfb * 64)
     hip.check(hip.L.svt_hip_cdef_apply_frame_dev(hip.h, rec[0].itemsize, P3(*[p.value for p in d_in]), P3(*[p.value for p in d_out]),
-                                                I3(*[p.shape[1] for p in rec]), w, h, d_skip, d_ys, d_uvs, 5, bd, d_dir), "cdef apply")
+                                                I3(*[p.shape[1] for p in rec]), w, h, d_skip, d_ys, d_uvs, 5, bd, d_dir, None), "cdef apply")
     for pli in range(3):
         got = hip.to_host(d_out[pli], rec[pli].shape, rec[pli].dtype)
         assert (exp[pli] != rec[pli]).any()
         assert np.array_equal(got, exp[pli]), (bd, pli, np.argwhere(got != exp[pli])[:5])
-    hip.free(*d_in, *d_out, d_skip, d_ys, d_uvs, d_dir)
+    # second form: direction / variance handed over from the strength search on the same picture instead of being recomputed
+    dir1 = hip.to_host(d_dir, (nfb * 64,), np.uint8)
+    d_src = [hip.to_device(p) for p in src]
+    d_mse, d_dir2, d_var = hip.to_device(np.zeros((2, nfb, 64), np.uint64)), hip.empty(nfb * 64), hip.empty(nfb * 64 * 4)
+    hip.check(hip.L.svt_hip_cdef_search_frame_dev(hip.h, rec[0].itemsize, P3(*[p.value for p in d_in]), I3(*[p.shape[1] for p in rec]),
+                                                 P3(*[p.value for p in d_src]), I3(*[p.shape[1] for p in src]), w, h, d_skip, 5, bd,
+                                                 d_mse, d_dir2, d_var), "cdef search")
+    d_out2 = [hip.to_device(p) for p in rec]
+    hip.check(hip.L.svt_hip_cdef_apply_frame_dev(hip.h, rec[0].itemsize, P3(*[p.value for p in d_in]), P3(*[p.value for p in d_out2]),
+                                                I3(*[p.shape[1] for p in rec]), w, h, d_skip, d_ys, d_uvs, 5, bd, d_dir2, d_var), "cdef apply (reuse)")
+    for pli in range(3):
+        got = hip.to_host(d_out2[pli], rec[pli].shape, rec[pli].dtype)
+        assert np.array_equal(got, exp[pli]), ("reuse", bd, pli, np.argwhere(got != exp[pli])[:5])
+    filt = (ys.repeat(64) != 0) | (uvs.repeat(64) != 0)
+    dir2 = hip.to_host(d_dir2, (nfb * 64,), np.uint8)
+    assert dir1[filt].any()
+    hip.free(*d_in, *d_out, *d_out2, *d_src, d_skip, d_ys, d_uvs, d_dir, d_dir2, d_var, d_mse)
 
 
 def test_search_1080p_band(hip, orc):

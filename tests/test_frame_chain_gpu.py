@@ -85,7 +85,7 @@ def test_chain_small_frame(hip, pkg, orc):
     d_out = [hip.to_device(p) for p in o_dlf]
     d_cy, d_cuv = hip.to_device(F.cdef_y), hip.to_device(F.cdef_uv)
     hip.check(L.svt_hip_cdef_apply_frame_dev(hip.h, 1, P3(*[p.value for p in d_rec]), P3(*[p.value for p in d_out]), I3(*strides), W, H, d_skip,
-                                            d_cy, d_cuv, F.cdef_damping, 8, d_dir))
+                                            d_cy, d_cuv, F.cdef_damping, 8, d_dir, d_var))
     for p in range(3):
         assert np.array_equal(hip.to_host(d_out[p], F.ref[p].shape, np.uint8), o_out[p]), ("cdef apply", p)
     # ---------------- loop restoration on the CDEF output; stripe context rows come from the deblocked picture (d_rec)
