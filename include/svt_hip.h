@@ -356,6 +356,44 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int win, const void *d_dgd, int stride, const void *d_src,
                                    int src_stride, int pw, int ph, int unit_size, int ss_y, int64_t *d_M, int64_t *d_H);
 
+/* ------------------------------------------------------------------ alt-ref temporal filtering ---- */
+#define SVT_HIP_TF_MAX_REFS 16
+/* MeContext's TF fields of one 64x64 block after tf_32x32_sub_pel_search / tf_16x16_sub_pel_search / derive_tf_32x32_block_split_flag
+ * (Encoder/Codec/EbMotionEstimationContext.h:447-454): tf_16x16_mv_x/y, tf_16x16_block_error, tf_32x32_mv_x/y, tf_32x32_block_error,
+ * tf_32x32_block_split_flag. */
+typedef struct SvtHipTfBlk64 {
+    int16_t  mv16_x[16], mv16_y[16];
+    uint64_t err16[16];
+    int16_t  mv32_x[4], mv32_y[4];
+    uint64_t err32[4];
+    int32_t  split[4];
+} SvtHipTfBlk64;
+/* One frame of the filtering window: the motion-compensated predictor PICTURE (tf_inter_prediction's output, Encoder/Codec/
+ * EbTemporalFiltering.c:2294; here a full picture instead of a 64x64 block buffer) and the TF fields of every 64x64 block
+ * (raster, (w / 64) per row), all in device memory.  blocks == NULL marks the central picture (pred is ignored). */
+typedef struct SvtHipTfRef {
+    const void *pred[3];
+    int pred_stride[3];
+    const SvtHipTfBlk64 *blocks;
+} SvtHipTfRef;
+/* The pixel side of produce_temporally_filtered_pic (Encoder/Codec/EbTemporalFiltering.c:2136-2412) for a whole picture and the whole
+ * window in one launch: apply_filtering_central (:557), svt_av1_apply_temporal_filter_planewise(_hbd) (aom_dsp_rtcd.h:616-629; :643,
+ * :829) for every other frame and 32x32 block, get_final_filtered_pixels (:1943).  refs is a HOST array of n_refs <=
+ * SVT_HIP_TF_MAX_REFS entries in window order; d_dst may alias d_src (the reference filters the central picture in place).
+ * w / h = the multiple-of-64 extents the reference walks (blk_cols * 64, blk_rows * 64: the planes must be readable / writable there,
+ * as the reference's padded pictures are).  noise_levels / decay_control / min_frame_size as in the reference call (:2313-2320,
+ * MeContext::min_frame_size).  d_sse[0] / [1] receive filtered_sse / filtered_sse_uv.  4:2:0, 4:2:2 and 4:4:4. */
+int svt_hip_tf_filter_frame_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *const d_src[3], const int src_stride[3],
+                                void *const d_dst[3], const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma,
+                                const SvtHipTfRef *refs, int n_refs, const double noise_levels[3], int decay_control,
+                                int min_frame_size, uint64_t *d_sse);
+/* estimate_noise / estimate_noise_highbd (Encoder/Codec/EbTemporalFiltering.c:2414, :2451): d_out[0] = sum of the rounded |Laplacian|
+ * over the smooth pixels, d_out[1] = their number; sigma = out[0] / (6 * out[1]) * SQRT_PI_BY_2, or -1 when out[1] < 16 (host side,
+ * svt_hip_tf_noise_sigma). */
+int svt_hip_tf_estimate_noise_dev(SvtHipCtx *ctx, const void *d_src, int pix_bytes, int bd, int width, int height, int stride,
+                                  int64_t *d_out);
+double svt_hip_tf_noise_sigma(int64_t sum, int64_t num);
+
 #ifdef __cplusplus
 }
 #endif

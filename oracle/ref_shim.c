@@ -174,3 +174,40 @@ int ref_shim_lr_apply_plane_ex(int plane, int bd, int highbd, int frame_w, int f
     free(rsi->unit_info); free(cm);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Temporal filtering: drive the reference's plane-wise filter with a MeContext built from plain arrays. */
+#include "EbMotionEstimationContext.h"
+#include "EbTemporalFiltering.h"
+#include "EbBitstreamUnit.h"
+void ref_shim_tf_planewise(const int16_t *mv16_x, const int16_t *mv16_y, const uint64_t *err16, const int16_t *mv32_x, const int16_t *mv32_y,
+                           const uint64_t *err32, const int32_t *split, int block_row, int block_col, int tf_chroma, int min_frame_size,
+                           int highbd, int bd, const void *y_src, int y_src_stride, const void *y_pre, int y_pre_stride, const void *u_src,
+                           const void *v_src, int uv_src_stride, const void *u_pre, const void *v_pre, int uv_pre_stride, unsigned bw,
+                           unsigned bh, int ss_x, int ss_y, const double *noise_levels, int decay_control, uint32_t *y_accum,
+                           uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count, uint32_t *v_accum, uint16_t *v_count) {
+    MeContext *c = (MeContext *)calloc(1, sizeof(MeContext));
+    for (int i = 0; i < 16; i++) { c->tf_16x16_mv_x[i] = mv16_x[i]; c->tf_16x16_mv_y[i] = mv16_y[i]; c->tf_16x16_block_error[i] = err16[i]; }
+    for (int i = 0; i < 4; i++) {
+        c->tf_32x32_mv_x[i] = mv32_x[i]; c->tf_32x32_mv_y[i] = mv32_y[i]; c->tf_32x32_block_error[i] = err32[i];
+        c->tf_32x32_block_split_flag[i] = split[i];
+    }
+    c->tf_block_row = block_row; c->tf_block_col = block_col; c->tf_chroma = (uint8_t)tf_chroma; c->min_frame_size = (uint16_t)min_frame_size;
+    if (!highbd)
+        svt_av1_apply_temporal_filter_planewise_c(c, y_src, y_src_stride, y_pre, y_pre_stride, u_src, v_src, uv_src_stride, u_pre, v_pre,
+                                                  uv_pre_stride, bw, bh, ss_x, ss_y, noise_levels, decay_control, y_accum, y_count, u_accum,
+                                                  u_count, v_accum, v_count);
+    else
+        svt_av1_apply_temporal_filter_planewise_hbd_c(c, y_src, y_src_stride, y_pre, y_pre_stride, u_src, v_src, uv_src_stride, u_pre, v_pre,
+                                                      uv_pre_stride, bw, bh, ss_x, ss_y, noise_levels, decay_control, y_accum, y_count,
+                                                      u_accum, u_count, v_accum, v_count, (uint32_t)bd);
+    free(c);
+}
+/* OD_DIVU as get_final_filtered_pixels uses it (EbTemporalFiltering.c:1956-1961) */
+uint32_t ref_shim_od_divu(uint32_t x, uint32_t d) { return OD_DIVU(x, d); }
+double estimate_noise(const uint8_t *src, uint16_t width, uint16_t height, uint16_t stride_y);
+double estimate_noise_highbd(const uint16_t *src, int width, int height, int stride, int bd);
+double ref_shim_estimate_noise(const void *src, int highbd, int bd, int width, int height, int stride) {
+    return highbd ? estimate_noise_highbd((const uint16_t *)src, width, height, stride, bd)
+                  : estimate_noise((const uint8_t *)src, (uint16_t)width, (uint16_t)height, (uint16_t)stride);
+}

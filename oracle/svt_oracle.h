@@ -176,6 +176,33 @@ void orc_wiener_stats_plane(int win, const void *dgd, int dgd_stride, const void
 int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                            int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep);
 
+/* ---------------------------------------------------------------- temporal filtering (8(f) rank 3) */
+/* MeContext's TF fields of one 64x64 block after tf_32x32 / tf_16x16_sub_pel_search (Encoder/Codec/EbMotionEstimationContext.h:447-454) */
+typedef struct OrcTfBlk64 {
+    int16_t  mv16_x[16], mv16_y[16];
+    uint64_t err16[16];
+    int16_t  mv32_x[4], mv32_y[4];
+    uint64_t err32[4];
+    int32_t  split[4];
+} OrcTfBlk64;
+typedef struct OrcTfRef {       /* one frame of the filtering window; blocks == NULL marks the central picture */
+    const void *pred[3];
+    int pred_stride[3];
+    const OrcTfBlk64 *blocks;   /* raster over (w / 64) x (h / 64) */
+} OrcTfRef;
+/* Encoder/Codec/EbTemporalFiltering.c:643 / :829 (svt_av1_apply_temporal_filter_planewise(_hbd)_c) */
+void orc_tf_planewise(const OrcTfBlk64 *blk, int block_row, int block_col, int tf_chroma, int min_frame_size, int pix_bytes, int bd,
+                      const void *y_src, int y_src_stride, const void *y_pre, int y_pre_stride, const void *u_src, const void *v_src,
+                      int uv_src_stride, const void *u_pre, const void *v_pre, int uv_pre_stride, unsigned block_width,
+                      unsigned block_height, int ss_x, int ss_y, const double *noise_levels, int decay_control, uint32_t *y_accum,
+                      uint16_t *y_count, uint32_t *u_accum, uint16_t *u_count, uint32_t *v_accum, uint16_t *v_count);
+/* Encoder/Codec/EbTemporalFiltering.c:2136-2412 (pixel side of produce_temporally_filtered_pic) */
+void orc_tf_filter_frame(int pix_bytes, int bd, const void *const src[3], const int src_stride[3], void *const dst[3], const int dst_stride[3],
+                         int w, int h, int ss_x, int ss_y, int tf_chroma, const OrcTfRef *refs, int n_refs, const double *noise_levels,
+                         int decay_control, int min_frame_size, uint64_t sse[2]);
+/* Encoder/Codec/EbTemporalFiltering.c:2414 / :2451 (estimate_noise / estimate_noise_highbd); out = {sum, num} */
+double orc_tf_estimate_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, int64_t out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,15 @@ class InvTxJob(C.Structure):
                 ("d_recon", C.c_void_p), ("recon_stride", C.c_int32), ("d_descs", C.c_void_p)]
 
 
+class TfBlk64(C.Structure):   # SvtHipTfBlk64
+    _fields_ = [("mv16_x", C.c_int16 * 16), ("mv16_y", C.c_int16 * 16), ("err16", C.c_uint64 * 16),
+                ("mv32_x", C.c_int16 * 4), ("mv32_y", C.c_int16 * 4), ("err32", C.c_uint64 * 4), ("split", C.c_int32 * 4)]
+
+
+class TfRef(C.Structure):     # SvtHipTfRef
+    _fields_ = [("pred", C.c_void_p * 3), ("pred_stride", C.c_int * 3), ("blocks", C.c_void_p)]
+
+
 class DlfSearch(C.Structure):
     """SvtHipDlfSearch (include/svt_hip.h)."""
     _fields_ = [("plane", C.c_int), ("dir", C.c_int), ("other_level", C.c_int), ("start_level", C.c_int), ("loop_filter_mode", C.c_int),
@@ -94,6 +103,7 @@ def lib():
         raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(LIB_PATH)
     vp, i32, u8p, u32p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_init.argtypes = [i32, C.POINTER(vp)]
     L.svt_hip_destroy.argtypes = [vp]
     L.svt_hip_destroy.restype = None
@@ -132,11 +142,15 @@ def lib():
     L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.svt_hip_tf_filter_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, i32, i32, i32, i32, i32, C.POINTER(TfRef), i32,
+                                              C.POINTER(C.c_double), i32, i32, vp]
+    L.svt_hip_tf_estimate_noise_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.svt_hip_tf_noise_sigma.argtypes = [C.c_int64, C.c_int64]
+    L.svt_hip_tf_noise_sigma.restype = C.c_double
     L.svt_hip_plane_sse_dev.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp]
     L.svt_hip_dlf_search_level_dev.argtypes = [vp, C.POINTER(DlfSearch), vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.svt_hip_setup_rtcd.argtypes = [vp, vp]
-    P3, I3 = C.c_void_p * 3, C.c_int * 3
     L.svt_hip_cdef_search_frame_dev.argtypes = [vp, i32, P3, I3, P3, I3, i32, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_cdef_apply_frame_dev.argtypes = [vp, i32, P3, P3, I3, i32, i32, vp, vp, vp, i32, i32, vp, vp]
     _lib = L

@@ -1,6 +1,7 @@
 // svt_hip_api.cpp — the C-ABI layer of libsvtav1_hip.so (include/svt_hip.h): context, memory,
 // host-pointer convenience wrappers around the batched kernel launchers.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -532,6 +533,52 @@ int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win,
                                                            unit_size, sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_M, d_H);
     if (e != hipSuccess) return fail(c, e, "wiener stats launch");
     return SVT_HIP_OK;
+}
+
+int svt_hip_tf_filter_frame_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* const d_src[3], const int src_stride[3], void* const d_dst[3],
+                                const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef* refs, int n_refs,
+                                const double noise_levels[3], int decay_control, int min_frame_size, uint64_t* d_sse) {
+    if (!c || !d_src || !src_stride || !d_dst || !dst_stride || !refs || !noise_levels || !d_sse || (pix_bytes != 1 && pix_bytes != 2) ||
+        (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && (bd < 8 || bd > 12)) || w <= 0 || h <= 0 || (w & 63) || (h & 63) || n_refs < 1 ||
+        n_refs > SVT_HIP_TF_MAX_REFS || (ss_x != 0 && ss_x != 1) || (ss_y != 0 && ss_y != 1) || (ss_y == 1 && ss_x == 0) || decay_control <= 0) {
+        if (c) c->err = "svt_hip_tf_filter_frame_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    for (int p = 0; p < (tf_chroma ? 3 : 1); p++) {
+        if (!d_src[p] || !d_dst[p]) return SVT_HIP_ERR_BAD_ARG;
+        for (int f = 0; f < n_refs; f++)
+            if (refs[f].blocks && !refs[f].pred[p]) return SVT_HIP_ERR_BAD_ARG;
+    }
+    // the per-call scalars of EbTemporalFiltering.c:706 / :731-733, in the reference's own double arithmetic (host libm log1p)
+    double den[3];
+    for (int p = 0; p < 3; p++) {
+        const double n_decay = (double)decay_control * (0.7 + log1p(noise_levels[p]));
+        den[p] = 2 * n_decay * n_decay;
+    }
+    const double thr = min_frame_size * 0.1;
+    const double dist_thr = thr > 1 ? thr : 1;
+    hipError_t e = hipMemsetAsync(d_sse, 0, 2 * sizeof(uint64_t), c->stream);
+    if (e != hipSuccess) return fail(c, e, "tf sse memset");
+    e = (hipError_t)svt_hip_launch_tf_filter(c->stream, pix_bytes, bd, d_src, src_stride, d_dst, dst_stride, w, h, ss_x, ss_y, tf_chroma, refs, n_refs,
+                                             den, dist_thr, d_sse);
+    if (e != hipSuccess) return fail(c, e, "tf filter launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_tf_estimate_noise_dev(SvtHipCtx* c, const void* d_src, int pix_bytes, int bd, int width, int height, int stride, int64_t* d_out) {
+    if (!c || !d_src || !d_out || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && (bd < 8 || bd > 12)) ||
+        width <= 0 || height <= 0 || stride < width)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = hipMemsetAsync(d_out, 0, 2 * sizeof(int64_t), c->stream);
+    if (e != hipSuccess) return fail(c, e, "tf noise memset");
+    e = (hipError_t)svt_hip_launch_tf_noise(c->stream, d_src, pix_bytes, bd, width, height, stride, (uint64_t*)d_out);
+    if (e != hipSuccess) return fail(c, e, "tf noise launch");
+    return SVT_HIP_OK;
+}
+
+double svt_hip_tf_noise_sigma(int64_t sum, int64_t num) {   // EbTemporalFiltering.c:2442-2447
+    if (num < 16) return -1.0;
+    return (double)sum / (6 * num) * 1.25331413732;
 }
 
 }  // extern "C"

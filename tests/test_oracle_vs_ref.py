@@ -560,3 +560,74 @@ def test_wiener_stats_and_convolve(orc, ref):
             else:
                 ref.svt_av1_highbd_wiener_convolve_add_src_c(C.c_void_p(p >> 1), C.c_int64(140), C.c_void_p(er.ctypes.data >> 1), C.c_int64(w + 5), ptr(fx), ptr(fy), w, h, C.byref(cp), bd)
             assert np.array_equal(eo, er), (bd, trial)
+
+
+import tf_common as tfc
+
+
+def test_temporal_filter_planewise_noise_and_divu(orc, ref):
+    """orc_tf_planewise vs svt_av1_apply_temporal_filter_planewise(_hbd)_c (libm expf / log1p / sqrtf on both sides), estimate_noise,
+    and OD_DIVU == plain division on get_final_filtered_pixels' domain.  Inputs as test/TemporalFilterTestPlanewise.cc:200-330."""
+    rng = np.random.default_rng(2024)
+    def _cnt0(it):
+        r2 = np.random.default_rng(it); [r2.integers(0, 1 << 20, 32 * 64) for _ in range(3)]
+        return r2.integers(0, 3000, 32 * 64).astype(np.int64)
+    for bd in (8, 10):
+        dt = np.uint8 if bd == 8 else np.uint16
+        seen = set()
+        for it in range(24):
+            ss = 1 if it % 6 else 0
+            cw = 32 >> ss
+            blk = tfc.make_blocks(rng, 1, bd, big_mv=(it % 4 == 1), err_max=(0, 3, 20, 60)[it % 4])
+            if it % 3 == 0:     # the reference test's distribution: fully random pixels
+                src = [rng.integers(0, 1 << bd, (32, 80)).astype(dt), rng.integers(0, 1 << bd, (cw, 48)).astype(dt), rng.integers(0, 1 << bd, (cw, 48)).astype(dt)]
+                pre = [rng.integers(0, 1 << bd, (32, 64)).astype(dt), rng.integers(0, 1 << bd, (cw, 64 >> ss)).astype(dt), rng.integers(0, 1 << bd, (cw, 64 >> ss)).astype(dt)]
+            else:               # close predictors: weights spread over the whole 0..1000 range
+                src = [rng.integers(0, 1 << bd, (32, 80)).astype(dt), rng.integers(0, 1 << bd, (cw, 48)).astype(dt), rng.integers(0, 1 << bd, (cw, 48)).astype(dt)]
+                amp = 0 if it in (4, 16) else (0, 1, 2, 4, 8, 23)[it % 6] << (bd - 8)      # 4, 16: zero error -> weight 1000
+                pre = [np.clip(s[:, :p].astype(np.int32) + rng.integers(-amp, amp + 1, (s.shape[0], p)), 0, (1 << bd) - 1).astype(dt)
+                       for s, p in zip(src, (32, cw, cw))]
+                pre = [np.ascontiguousarray(np.pad(p, ((0, 0), (0, (64 >> (ss if i else 0)) - p.shape[1])))) for i, p in enumerate(pre)]
+            noise = rng.uniform(0.0, 8.0, 3)
+            decay = int(rng.integers(2, 5)); mfs = int(rng.choice([64, 240, 1080, 2160]))
+            r, c = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            outs = []
+            for which in ("ref", "orc"):
+                r2 = np.random.default_rng(it)
+                acc = [r2.integers(0, 1 << 20, 32 * 64).astype(np.uint32) for _ in range(3)]
+                cnt = [r2.integers(0, 3000, 32 * 64).astype(np.uint16) for _ in range(3)]
+                common = (r, c, it % 5 != 4, mfs)
+                tail = (ptr(src[0]), 80, ptr(pre[0]), 64, ptr(src[1]), ptr(src[2]), 48, ptr(pre[1]), ptr(pre[2]), 64 >> ss, 32, 32, ss, ss,
+                        ptr(noise), decay, ptr(acc[0]), ptr(cnt[0]), ptr(acc[1]), ptr(cnt[1]), ptr(acc[2]), ptr(cnt[2]))
+                if which == "ref":
+                    b = blk[0]
+                    ref.ref_shim_tf_planewise(ptr(np.ascontiguousarray(b["mv16_x"])), ptr(np.ascontiguousarray(b["mv16_y"])), ptr(np.ascontiguousarray(b["err16"])),
+                                              ptr(np.ascontiguousarray(b["mv32_x"])), ptr(np.ascontiguousarray(b["mv32_y"])), ptr(np.ascontiguousarray(b["err32"])),
+                                              ptr(np.ascontiguousarray(b["split"])), *common, int(bd > 8), bd, *tail)
+                else:
+                    orc.orc_tf_planewise(ptr(blk), *common, src[0].itemsize, bd, *tail)
+                outs.append(acc + cnt)
+            for i, (a, b) in enumerate(zip(*outs)):
+                assert np.array_equal(a, b), (bd, it, i, np.argwhere(a != b)[:4])
+            seen.update(np.unique((outs[0][3].astype(np.int64) - _cnt0(it)) & 0xffff).tolist())
+        assert 0 in seen and 1000 in seen and len(seen) > 300, (bd, len(seen))       # weights over the whole 0..1000 range were exercised
+        # noise estimate
+        ref.ref_shim_estimate_noise.restype = C.c_double; orc.orc_tf_estimate_noise.restype = C.c_double
+        for it in range(4):
+            w, h = 200 + 8 * it, 120
+            img = np.clip(120 + 40 * np.sin(np.arange(w) / 9.0)[None, :] + rng.normal(0, 1 + 3 * it, (h, w)), 0, 255)
+            img = (img * (1 << (bd - 8))).astype(dt)
+            if it == 3: img[:] = rng.integers(0, 1 << bd, (h, w))          # all edges: too few smooth pixels -> -1
+            out = np.zeros(2, np.int64)
+            e = ref.ref_shim_estimate_noise(ptr(img), int(bd > 8), bd, w, h, w)
+            g = orc.orc_tf_estimate_noise(ptr(img), img.itemsize, bd, w, h, w, ptr(out))
+            assert e == g, (bd, it, e, g)
+    ref.ref_shim_od_divu.restype = C.c_uint32
+    for d in (1, 2, 3, 999, 1000, 1001, 1023, 1024, 5000, 13000, 65535):
+        for x in (0, 1, d - 1, d, 255 * d + d // 2, 1023 * d + d // 2, 4095 * d + d // 2, 4095 * d + d // 2 - 1, (1 << 32) - 1):
+            if d >= 1024 or x < (1 << 32) // 2:       # OD_DIVU_SMALL is documented exact for x below 2^31 here
+                assert ref.ref_shim_od_divu(C.c_uint32(x), C.c_uint32(d)) == x // d, (x, d)
+    rng = np.random.default_rng(3)
+    for d in range(1000, 1024):
+        for x in rng.integers(0, 4096 * d, 400):
+            assert ref.ref_shim_od_divu(C.c_uint32(int(x)), C.c_uint32(d)) == int(x) // d
