@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
+                    help="reference = the reference's own SIMD kernels (oracle/_ref SIMD flavour); port = the oracle's scalar C; auto = reference when built")
+    ap.add_argument("--cpu-port-too", action="store_true", help="with the reference baseline, also time the scalar port")
     ap.add_argument("--serial", action="store_true", help="issue every launch on one stream (no intra-step concurrency)")
     ap.add_argument("--lanes", type=int, default=3, help="streams for the independent launches of a stage (debug)")
     ap.add_argument("--tx-multi", default="inv", help="which transform stages use the mixed-size launch (debug): fwd,inv / fwd / inv / none")
@@ -149,31 +152,12 @@ def main():
     # aligned copy of the current luma for the variance pyramid (needs an 8-byte aligned origin/stride and 64 px of slack)
     vp = np.zeros((F.sb_rows * 64 + 64, F.sb_cols * 64 + 64), np.uint8); vp[:H, :W] = F.cur[0]
     d_vp = T(vp)
-    hme = []
-    hme_host = []
-    for lvl, (bsz, saw, sah) in enumerate(((16, 64, 32), (32, 16, 16), (64, 16, 16))):
-        S = (pkg.SadLoop * n_sb)()
-        sc = (4, 2, 1)[lvl]
-        pad = (PADS, PADQ, PAD)[lvl]
-        for i in range(n_sb):
-            sx, sy = (i % F.sb_cols) * 64 // sc, (i // F.sb_cols) * 64 // sc
-            pw_, ph_ = W // sc, H // sc
-            x0 = min(max(sx - saw // 2, -pad + 1), pw_ - 1); y0 = min(max(sy - sah // 2, -pad + 1), ph_ - 1)
-            S[i] = pkg.SadLoop(sx + pad, sy + pad, x0 + pad, y0 + pad, bsz, bsz, min(saw, pw_ + pad - 1 - bsz - x0), min(sah, ph_ + pad - 1 - bsz - y0), 1, 0)
-        hme_host.append(S)
-        hme.append(dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(n_sb, dtype=torch.int32, device=dev),
-                        xy=torch.zeros((n_sb, 2), dtype=torch.int16, device=dev)))
+    hme_host = workload.hme_jobs(F)
+    hme = [dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(n_sb, dtype=torch.int32, device=dev),
+                xy=torch.zeros((n_sb, 2), dtype=torch.int16, device=dev)) for S in hme_host]
     # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into a prediction plane
-    rng = np.random.default_rng(14 + rank)
-    nblk16 = (W // 16) * (H // 16)
-    CB = (pkg.ConvBlk * nblk16)()
-    k = 0
-    for by in range(0, H, 16):
-        for bx in range(0, W, 16):
-            if bx + 16 <= W and by + 16 <= H:
-                CB[k] = pkg.ConvBlk(bx + int(rng.integers(-8, 9)), by + int(rng.integers(-8, 9)), bx, by, 16, 16, 0, 0, int(rng.integers(0, 16)), int(rng.integers(0, 16)), 0, 0)
-                k += 1
-    nblk16 = k
+    CB, nblk16 = workload.conv_jobs(F, 14 + rank)
+    k = nblk16
     d_cb = T(np.frombuffer(bytes(CB), np.uint8)[:k * C.sizeof(pkg.ConvBlk)].copy())
     d_subpel = torch.zeros((H, W), dtype=torch.uint8, device=dev)
     # SGR: 3-px extended copies of the CDEF output, projection sums for all 16 sets, apply with fixed per-unit sets
@@ -468,7 +452,16 @@ def main():
     #      same frame; composite SB/s = 1 / sum_k (seconds per SB of stage k)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(orc, F, sbs, mc, tc, stages, dict(hme=hme_host, conv=(CB, nblk16)))
+        jobs = dict(hme=hme_host, conv=(CB, nblk16), unit=US[0])
+        simd = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
+        if args.cpu_baseline in ("auto", "reference") and os.path.exists(simd):
+            cpu = cpu_baseline_reference(C.CDLL(simd), orc, F, sbs, mc, tc, stages, jobs)
+            if args.cpu_baseline == "auto" and args.cpu_port_too:
+                cpu["port"] = cpu_baseline(orc, F, sbs, mc, tc, stages, jobs)
+        elif args.cpu_baseline == "reference":
+            raise SystemExit("oracle/_ref/libsvtav1_ref_simd.so is not built (make -f oracle/Makefile.ref simd)")
+        else:
+            cpu = cpu_baseline(orc, F, sbs, mc, tc, stages, jobs)
 
     total_sb = n_sb * args.steps * world
     out = {
@@ -635,6 +628,149 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
                 sample="oracle C port (scalar, gcc -O2) of the same stage chain on a bounded sample of the same frame, "
                        f"{cores} threads; seconds per SB per stage: " + ", ".join(f"{k}={v:.2e}" for k, v in sec_per_sb.items())
                        + " (deblock, cdef_apply, pyramids timed single-threaded and divided by cores; SGR timed on luma and scaled x1.5 for 4:2:0)")
+
+
+def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
+    """The reference's own kernels as its x86 build dispatches them (SSE2 .. AVX2 / AVX-512 through setup_common_rtcd_internal /
+    setup_rtcd_internal with this host's CPU flags), driven by oracle/ref_bench.c over the SAME job lists as the HIP stages, on every
+    hardware thread (a pthread pool inside ref_bench.c: no Python in the timed region), the WHOLE frame per stage, best of 3.
+    tests/test_ref_bench.py shows these loops produce the oracle's outputs bit for bit."""
+    from conftest import ptr
+    refb.refb_setup.restype = C.c_uint64; refb.refb_setup.argtypes = [C.c_uint64]
+    refb.refb_parallel.restype = C.c_double
+    refb.refb_parallel.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    flags = refb.refb_setup(0xFFFFFFFFFFFFFFFF)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 512))
+    keys = {s["key"] for s in stages}
+    sec = {}
+    keep = []
+
+    def adr(x):
+        if x is None: return 0
+        if isinstance(x, np.ndarray):
+            keep.append(x)
+            return x.ctypes.data
+        if isinstance(x, int): return x
+        keep.append(x)
+        return C.addressof(x)
+
+    def run(stage, slots, n, chunk, reps=3):
+        a = (C.c_int64 * len(slots))(*[adr(v) for v in slots])
+        return refb.refb_parallel(stage, C.addressof(a), n, chunk, cores, reps)
+
+    W_, H_, n_sb = F.w, F.h, F.n_sb
+    st = F.cur_y_p.shape[1]
+    org = F.pad * st + F.pad
+    if "me" in keys:
+        sad = np.zeros((n_sb, 85), np.uint32); mv = np.zeros((n_sb, 85), np.uint32)
+        sec["me_fullpel_85pu"] = run(0, [F.cur_y_p, F.ref_y_p, st, F.pad, F.pad, sbs, n_sb, 0, sad, mv], n_sb, 1) / n_sb
+    if "pyr" in keys or "hme" in keys:
+        PQ, PS = 32, 16
+        planes = {}
+        t0 = time.perf_counter()
+        for name, src_p in (("cur", F.cur_y_p), ("ref", F.ref_y_p)):
+            q = np.zeros((H_ // 2 + 2 * PQ, W_ // 2 + 2 * PQ), np.uint8); s_ = np.zeros((H_ // 4 + 2 * PS, W_ // 4 + 2 * PS), np.uint8)
+            orc.orc_downsample_2d(C.c_void_p(src_p.ctypes.data + org), st, W_, H_, C.c_void_p(q.ctypes.data + PQ * q.shape[1] + PQ), q.shape[1], 2, 1)
+            orc.orc_downsample_2d(C.c_void_p(src_p.ctypes.data + org), st, W_, H_, C.c_void_p(s_.ctypes.data + PS * s_.shape[1] + PS), s_.shape[1], 4, 1)
+            planes[name] = (s_, q, src_p)
+        t_ds = time.perf_counter() - t0
+        if "pyr" in keys:   # decimation + variance pyramid: the oracle's scalar C (tens of ns per SB either way), single-threaded / threads
+            nv = min(n_sb, 256)
+            mean, var = np.zeros(85, np.uint8), np.zeros(85, np.uint16)
+            t0 = time.perf_counter()
+            for i in range(nv):
+                sx, sy = (i % F.sb_cols) * 64, (i // F.sb_cols) * 64
+                orc.orc_variance_pyramid_sb(C.c_void_p(F.cur_y_p.ctypes.data + org + sy * st + sx), st, 0, ptr(mean), ptr(var))
+            sec["pyramids"] = (t_ds / n_sb + (time.perf_counter() - t0) / nv) / cores
+        if "hme" in keys:
+            t = 0.0
+            for lvl in range(3):
+                cur_t, ref_t = planes["cur"][lvl], planes["ref"][lvl]
+                sad_o = np.zeros(n_sb, np.uint32); xy_o = np.zeros((n_sb, 2), np.int16)
+                t += run(1, [cur_t, cur_t.shape[1], ref_t, ref_t.shape[1], jobs["hme"][lvl], sad_o, xy_o], n_sb, 2)
+            sec["hme_l0_l1_l2"] = t / n_sb
+    if "subpel" in keys:
+        CB_, nb = jobs["conv"]
+        dst = np.zeros((H_, W_), np.uint8)
+        sec["subpel_convolve"] = run(2, [F.ref_y_p.ctypes.data + org, st, dst, W_, CB_], nb, 32) / n_sb
+    if "txfm" in keys or "inv" in keys:
+        recon = [np.zeros_like(p) for p in F.ref]
+        t_sum = 0.0
+        for (kind, ts), descs in sorted(F.descs.items()):
+            sc, isc = F.scans(ts), F.scan_tables(ts)
+            px = tc.TXW[ts] * tc.TXH[ts]
+            for plane in ([0] if kind == 0 else [1, 2]):
+                t_sum += run(3, [F.cur[plane], F.cur[plane].shape[1], F.ref[plane], F.ref[plane].shape[1], recon[plane], recon[plane].shape[1], descs, ts, F.qp[plane],
+                                 tc.TX_SCALE[ts], sc[0], sc[1], sc[2], isc[0], isc[1], isc[2]], len(descs), max(1, 4096 // px))
+        sec["fwd_txfm_quant+inv_txfm_recon"] = t_sum / n_sb
+    if "dlf" in keys:
+        t = 0.0
+        for p in range(3):
+            ev, eh = F.edges[p]
+            uh, uw = ev.shape
+            slots = []
+            nb_ = min(uh // 4, cores * 2) or 1   # private copies of row bands (+ 8 rows of margin): bands are filtered independently
+            for i in range(nb_):
+                u0, u1 = i * uh // nb_, (i + 1) * uh // nb_
+                r0, r1 = max(4 * u0 - 8, 0), min(4 * u1 + 8, F.ref[p].shape[0])
+                img = np.ascontiguousarray(F.ref[p][r0:r1]); keep.append(img)
+                slots += [img.ctypes.data + (4 * u0 - r0) * img.shape[1], img.shape[1], np.ascontiguousarray(ev[u0:u1]), np.ascontiguousarray(eh[u0:u1]), uw, u1 - u0] + [0] * 10
+            t += run(4, slots, nb_, 1, reps=1)
+        sec["deblock"] = t / n_sb
+    if "cdef_search" in keys:
+        mse = np.zeros((2, n_sb, 64), np.uint64)
+        sec["cdef_search"] = run(5, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + [F.cur[0], F.cur[1], F.cur[2]] + [p.shape[1] for p in F.cur]
+                                 + [W_, H_, F.skip8, F.cdef_damping, mse], n_sb, 1) / n_sb
+    if "cdef_apply" in keys:
+        outs = [p.copy() for p in F.ref]
+        sec["cdef_apply"] = run(6, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + outs + [W_, H_, F.skip8, F.cdef_y, F.cdef_uv, F.cdef_damping], n_sb, 2) / n_sb
+    if "sgr_search" in keys or "sgr_apply" in keys:
+        US = jobs.get("unit", 256)
+        EXT_ = 3
+        t_search = t_apply = 0.0
+        for p in range(3):
+            ssub = int(p > 0)
+            ph, pw = F.ref[p].shape
+            if "sgr_search" in keys:
+                ext = np.ascontiguousarray(np.pad(F.ref[p], EXT_, mode="edge")); est = ext.shape[1]; eoff = EXT_ * est + EXT_
+                nu = max((pw + US // 2) // US, 1) * max((ph + US // 2) // US, 1)
+                lim = np.zeros((nu, 4), np.int32)
+                orc.orc_rest_unit_limits(pw, ph, ssub, US, ptr(lim))
+                xq = np.zeros((nu, 16, 2), np.int32)
+                t_search += run(7, [ext.ctypes.data + eoff, est, F.cur[p], F.cur[p].shape[1], lim, 64 >> ssub, 64 >> ssub, 0xFFFF, xq], nu, 1, reps=2)
+                keep.append(ext)
+            if "sgr_apply" in keys:
+                # horizontal bands of the plane, each filtered as a picture of its own by the reference's frame-level restoration
+                # (boundary-line save, svt_av1_loop_restoration_filter_unit per unit / stripe): the same work per sample as one big picture
+                band_h = US
+                slots, nbands = [], 0
+                y0 = 0
+                while y0 < ph:
+                    y1 = ph if ph - (y0 + band_h) < band_h else y0 + band_h
+                    cdef_b = np.ascontiguousarray(np.pad(F.ref[p][y0:y1], EXT_, mode="edge")); dbl_b = np.ascontiguousarray(F.cur[p][y0:y1])
+                    hb = y1 - y0
+                    nu_b = max((pw + US // 2) // US, 1) * max((hb + US // 2) // US, 1)
+                    uep = np.full(nu_b, 3, np.uint8); uxqd = np.tile(np.array([-30, 40], np.int32), (nu_b, 1)).copy(); dst = np.zeros((hb, pw), np.uint8)
+                    slots += [p, pw << ssub, hb << ssub, dbl_b, pw, cdef_b.ctypes.data + EXT_ * cdef_b.shape[1] + EXT_, cdef_b.shape[1], dst, pw, US, uep, uxqd] + [0] * 4
+                    keep.append(cdef_b)
+                    nbands += 1
+                    y0 = y1
+                t_apply += run(8, slots, nbands, 1, reps=1)
+        if "sgr_search" in keys: sec["sgr_search"] = t_search / n_sb
+        if "sgr_apply" in keys: sec["sgr_apply"] = t_apply / n_sb
+    total = sum(sec.values())
+    return dict(value=1.0 / total if total > 0 else None, unit="SB/s", cores=cores, kind="reference",
+                sample="the reference's own kernels as its x86 build dispatches them on this host (cpu flags 0x%x: SSE2..AVX2%s; oracle/_ref SIMD flavour built by "
+                       "oracle/Makefile.ref from the reference sources, NASM-only helpers stubbed in C and not on this path), driven by oracle/ref_bench.c over the "
+                       "same job lists as the HIP stages, whole frame per stage, %d pthreads (all hardware threads), best of 3; seconds per SB per stage: " % (
+                           flags, " + AVX-512" if flags & (1 << 9) else "", cores)
+                       + ", ".join(f"{k}={v:.2e}" for k, v in sec.items())
+                       + " (pyramids: the oracle's scalar C / threads; deblock and restoration apply run on independent row bands; restoration search is "
+                         "one work item per restoration unit, as in the reference's rest segments)")
 
 
 if __name__ == "__main__":

@@ -72,9 +72,9 @@ void svt_av1_loop_restoration_filter_unit(uint8_t need_bounadaries, const Restor
                                           int32_t highbd, int32_t bit_depth, uint8_t *data8, int32_t stride, uint8_t *dst8,
                                           int32_t dst_stride, int32_t *tmpbuf, int32_t optimized_lr);
 
-static int shim_rtcd_ready = 0;
+int ref_shim_rtcd_ready = 0;   /* also set by refb_setup (ref_bench.c), which installs the host's SIMD kernels instead of the C ones */
 static void shim_rtcd(void) {
-    if (!shim_rtcd_ready) { setup_common_rtcd_internal(0); shim_rtcd_ready = 1; }
+    if (!ref_shim_rtcd_ready) { setup_common_rtcd_internal(0); ref_shim_rtcd_ready = 1; }
 }
 static int shim_units(int unit_size, int size) { int n = (size + (unit_size >> 1)) / unit_size; return n > 1 ? n : 1; }  /* count_units_in_tile */
 

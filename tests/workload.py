@@ -90,3 +90,37 @@ class Frame:
             key = f"scan/{ts}/{cls}"
             out.append(np.ascontiguousarray(TABLES[key]) if key in TABLES.files else None)
         return out
+
+
+PADQ, PADS = 32, 16   # padding of the 1/4- and 1/16-resolution HME planes
+
+
+def hme_jobs(F):
+    """The three SvtHipSadLoop job lists of the HME stage (level 0 on the 1/16 planes: 16x16 block, 64x32 window; levels 1 / 2: 32x32 and
+    64x64 blocks, 16x16 windows), one search per SB, windows clipped to the padded planes."""
+    out = []
+    for lvl, (bsz, saw, sah) in enumerate(((16, 64, 32), (32, 16, 16), (64, 16, 16))):
+        S = (pkg.SadLoop * F.n_sb)()
+        sc = (4, 2, 1)[lvl]
+        pad = (PADS, PADQ, F.pad)[lvl]
+        for i in range(F.n_sb):
+            sx, sy = (i % F.sb_cols) * 64 // sc, (i // F.sb_cols) * 64 // sc
+            pw_, ph_ = F.w // sc, F.h // sc
+            x0 = min(max(sx - saw // 2, -pad + 1), pw_ - 1); y0 = min(max(sy - sah // 2, -pad + 1), ph_ - 1)
+            S[i] = pkg.SadLoop(sx + pad, sy + pad, x0 + pad, y0 + pad, bsz, bsz, min(saw, pw_ + pad - 1 - bsz - x0), min(sah, ph_ + pad - 1 - bsz - y0), 1, 0)
+        out.append(S)
+    return out
+
+
+def conv_jobs(F, seed):
+    """Every whole 16x16 luma block predicted at a random eighth-pel MV (EIGHTTAP_REGULAR both ways): SvtHipConvBlk list + count."""
+    rng = np.random.default_rng(seed)
+    n = (F.w // 16) * (F.h // 16)
+    CB = (pkg.ConvBlk * n)()
+    k = 0
+    for by in range(0, F.h, 16):
+        for bx in range(0, F.w, 16):
+            if bx + 16 <= F.w and by + 16 <= F.h:
+                CB[k] = pkg.ConvBlk(bx + int(rng.integers(-8, 9)), by + int(rng.integers(-8, 9)), bx, by, 16, 16, 0, 0, int(rng.integers(0, 16)), int(rng.integers(0, 16)), 0, 0)
+                k += 1
+    return CB, k
