@@ -158,6 +158,7 @@ def main():
     # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into a prediction plane
     CB, nblk16 = workload.conv_jobs(F, 14 + rank)
     k = nblk16
+    rng = np.random.default_rng(15 + rank)
     d_cb = T(np.frombuffer(bytes(CB), np.uint8)[:k * C.sizeof(pkg.ConvBlk)].copy())
     d_subpel = torch.zeros((H, W), dtype=torch.uint8, device=dev)
     # SGR: 3-px extended copies of the CDEF output, projection sums for all 16 sets, apply with fixed per-unit sets
