@@ -352,7 +352,9 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as
  * search_wiener_seg (:1347) calls it: d_M[unit][win * win], d_H[unit][win^2 * win^2] (exact int64; feature index = (dx + win/2) * win
  * + (dy + win/2)).  win = 7 (luma), 5 (chroma) or 3.  The plane must be extended by 3 samples like for the self-guided calls.  The linear
- * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090) stay on the host.  8-bit planes. */
+ * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090) stay on the host.  8-bit planes, and
+ * 16-bit planes (bd 8 / 10 / 12) = svt_av1_compute_stats_highbd (:741) incl. its bit_depth_divider; the 16-bit path keeps a library-owned
+ * device scratch buffer inside the context (allocated on first use, freed by svt_hip_destroy). */
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int win, const void *d_dgd, int stride, const void *d_src,
                                    int src_stride, int pw, int ph, int unit_size, int ss_y, int64_t *d_M, int64_t *d_H);
 

@@ -13,6 +13,8 @@ struct SvtHipCtx {
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     int         me_waves = 4;   // 256 threads per SB: measured best on MI355X (tools/me_time.py)
+    void*       scratch = nullptr;   // library-owned device scratch (16-bit Wiener statistics), grown on demand
+    size_t      scratch_bytes = 0;
     std::string err;
 };
 
@@ -57,6 +59,7 @@ void svt_hip_destroy(SvtHipCtx* c) {
     (void)hipSetDevice(c->device);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->scratch) (void)hipFree(c->scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -525,9 +528,24 @@ int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win,
     if (!c || !d_dgd || !d_src || !d_M || !d_H || (win != 7 && win != 5 && win != 3) || unit_size < 64 || (unit_size & 63) || unit_size > 256 ||
         (ss_y != 0 && ss_y != 1) || pw <= 0 || ph <= 0)
         return SVT_HIP_ERR_BAD_ARG;
-    if (pix_bytes != 1 || bd != 8) {
-        c->err = "svt_hip_wiener_stats_plane_dev: only 8-bit planes are implemented";
+    if ((pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10 && bd != 12) || (pix_bytes != 1 && pix_bytes != 2)) {
+        c->err = "svt_hip_wiener_stats_plane_dev: bad sample format";
         return SVT_HIP_ERR_BAD_ARG;
+    }
+    if (pix_bytes == 2) {
+        const int n_units = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
+        const size_t need = svt_hip_wiener_stats16_scratch(win, pw, ph, n_units);
+        if (need > c->scratch_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->scratch) HIPCHK(c, hipFree(c->scratch));
+            c->scratch = nullptr; c->scratch_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->scratch, need));
+            c->scratch_bytes = need;
+        }
+        hipError_t e16 = (hipError_t)svt_hip_launch_wiener_stats16(c->stream, win, bd, (const uint16_t*)d_dgd, stride, (const uint16_t*)d_src, src_stride, pw, ph,
+                                                                  unit_size, sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_M, d_H, (uint8_t*)c->scratch);
+        if (e16 != hipSuccess) return fail(c, e16, "wiener stats (16-bit) launch");
+        return SVT_HIP_OK;
     }
     hipError_t e = (hipError_t)svt_hip_launch_wiener_stats8(c->stream, win, (const uint8_t*)d_dgd, stride, (const uint8_t*)d_src, src_stride, pw, ph,
                                                            unit_size, sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_M, d_H);

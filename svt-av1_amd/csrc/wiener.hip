@@ -27,20 +27,23 @@ constexpr int kRing = 16;        // rows kept in LDS (10 needed per 4-row step)
 // bytes per row copy (template parameter PITCH): 16 + unit width (< 1.5 x unit size) + 3 + 16-B over-read, multiple of 16: 144 / 240 / 432
 
 // M, H of a unit from its Gram matrix G over the features [window samples (biased by -128) | source sample | 1]
+// `bias` = what was subtracted from every sample before the products (128 for 8-bit planes, 2^(bd-1) for the 16-bit path), `divider` =
+// svt_av1_compute_stats_highbd's bit_depth_divider (EbRestorationPick.c:753-757, :783-790; C division, truncating toward zero)
 template <int WIN, typename GF>
-__device__ __forceinline__ void wiener_finish(GF G, int tid, long long* __restrict__ Mo, long long* __restrict__ Ho) {
+__device__ __forceinline__ void wiener_finish(GF G, int tid, long long* __restrict__ Mo, long long* __restrict__ Ho, long long bias = 128,
+                                              long long divider = 1) {
     constexpr int HALF = WIN / 2, NF = WIN * WIN, XF = NF, ONE = NF + 1;
     const long long N = G(ONE, ONE);
-    const long long sum_d = G(HALF * WIN + HALF, ONE) + 128 * N;
-    const long long a = (long long)((unsigned long long)sum_d / (unsigned long long)N) - 128;   // find_average() - 128
+    const long long sum_d = G(HALF * WIN + HALF, ONE) + bias * N;
+    const long long a = (long long)((unsigned long long)sum_d / (unsigned long long)N) - bias;   // find_average() - bias
     const long long Sx = G(XF, ONE);
     for (int i = tid; i < NF * NF + NF; i += 256) {
         if (i < NF * NF) {
             const int k = i / NF, l = i - k * NF;
-            Ho[i] = G(k, l) - a * (G(k, ONE) + G(l, ONE)) + N * a * a;
+            Ho[i] = (G(k, l) - a * (G(k, ONE) + G(l, ONE)) + N * a * a) / divider;
         } else {
             const int k = i - NF * NF;
-            Mo[k] = G(k, XF) - a * (G(k, ONE) + Sx) + N * a * a;
+            Mo[k] = (G(k, XF) - a * (G(k, ONE) + Sx) + N * a * a) / divider;
         }
     }
 }
@@ -48,7 +51,8 @@ __device__ __forceinline__ void wiener_finish(GF G, int tid, long long* __restri
 template <int WIN, int kPitch, bool BANDED>
 __global__ void __launch_bounds__(256)
 wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint8_t* __restrict__ src, int src_stride, int pw, int ph,
-                     int unit_size, int units_x, int units_y, int voff, long long* __restrict__ M_out, long long* __restrict__ H_out) {
+                     int unit_size, int units_x, int units_y, int voff, long long* __restrict__ M_out, long long* __restrict__ H_out,
+                     long long* __restrict__ G_raw) {
     constexpr int HALF = WIN / 2, NF = WIN * WIN, XF = NF, ONE = NF + 1, NBLK = (NF + 2 + 31) / 32, NT = NBLK == 1 ? 1 : 3;
     // copy c of the row ring holds d'[col + (c - 3)] at byte col + 16; the same memory later holds the [NT][32 x 32] int64 tile sums
     constexpr int kRingBytes = 7 * kRing * kPitch, kAccBytes = NT * 1024 * 8, kMainBytes = kRingBytes > kAccBytes ? kRingBytes : kAccBytes;
@@ -191,9 +195,9 @@ wiener_stats8_kernel(const uint8_t* __restrict__ dgd, int dgd_stride, const uint
         const int t = f2 < 32 ? 0 : (f1 < 32 ? 1 : 2);
         return (long long)acc[t * 1024 + (f1 & 31) * 32 + (f2 & 31)];
     };
-    if (BANDED) {
+    if (BANDED || G_raw) {   // G_raw: the caller wants the packed Gram matrix itself (16-bit path: three 8-bit component planes, combined later)
         constexpr int F = NF + 2;
-        unsigned long long* P = (unsigned long long*)(H_out + (size_t)unit * NF * NF);
+        unsigned long long* P = G_raw ? (unsigned long long*)(G_raw + (size_t)unit * (F * (F + 1) / 2)) : (unsigned long long*)(H_out + (size_t)unit * NF * NF);
         for (int i = tid; i < F * F; i += 256) {
             const int f1 = i / F, f2 = i - f1 * F;
             if (f1 <= f2) atomicAdd(&P[f1 * F - f1 * (f1 - 1) / 2 + (f2 - f1)], (unsigned long long)G(f1, f2));
@@ -220,14 +224,109 @@ wiener_finalize_kernel(long long* __restrict__ M_out, long long* __restrict__ H_
     wiener_finish<WIN>(G, tid, M_out + (size_t)unit * NF, Ho);
 }
 
+// ---- 16-bit planes.  v = d - 2^(bd-1) is split as v = 32 h + l (h = v >> 5, l = v & 31): three 8-bit component planes H, L and S = H + L
+// (|h + l| < 128 up to 12 bits) go through the exact int8 Gram kernel above, and
+//   sum v_k v_l = 1024 G_hh + 32 (G_ss - G_hh - G_ll) + G_ll,   sum v_k = 32 S_h + S_l          (all int64, exact)
+// because (h_k + l_k)(h_l + l_l) - h_k h_l - l_k l_l = h_k l_l + l_k h_l.  Components are stored + 128 so that the 8-bit kernel's own
+// bias removal (x ^ 0x80) returns them.
+__global__ void __launch_bounds__(256)
+wiener_split16_kernel(const uint16_t* __restrict__ in, int in_stride, int w, int h, int bias, uint8_t* __restrict__ oh, uint8_t* __restrict__ ol,
+                      uint8_t* __restrict__ os, int pitch) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int v = (int)in[(size_t)y * in_stride + x] - bias;
+    const int hh = v >> 5, ll = v & 31;
+    oh[(size_t)y * pitch + x] = (uint8_t)(hh + 128); ol[(size_t)y * pitch + x] = (uint8_t)(ll + 128); os[(size_t)y * pitch + x] = (uint8_t)(hh + ll + 128);
+}
+
+template <int WIN>
+__global__ void __launch_bounds__(256)
+wiener_finalize16_kernel(const long long* __restrict__ Ghh, const long long* __restrict__ Gll, const long long* __restrict__ Gss, long long bias,
+                         long long divider, long long* __restrict__ M_out, long long* __restrict__ H_out) {
+    constexpr int NF = WIN * WIN, F = NF + 2, NP = F * (F + 1) / 2, ONE = NF + 1;
+    __shared__ long long P[NP];
+    const int unit = blockIdx.x, tid = threadIdx.x;
+    const long long *hh = Ghh + (size_t)unit * NP, *ll = Gll + (size_t)unit * NP, *ss = Gss + (size_t)unit * NP;
+    for (int f1 = 0; f1 < F; f1++)
+        for (int f2 = f1 + tid; f2 < F; f2 += 256) {
+            const int i = f1 * F - f1 * (f1 - 1) / 2 + (f2 - f1);
+            long long g;
+            if (f2 == ONE) g = f1 == ONE ? hh[i] : 32 * hh[i] + ll[i];
+            else g = 1024 * hh[i] + 32 * (ss[i] - hh[i] - ll[i]) + ll[i];
+            P[i] = g;
+        }
+    __syncthreads();
+    auto G = [&](int f1, int f2) -> long long {
+        if (f1 > f2) { const int t = f1; f1 = f2; f2 = t; }
+        return P[f1 * F - f1 * (f1 - 1) / 2 + (f2 - f1)];
+    };
+    wiener_finish<WIN>(G, tid, M_out + (size_t)unit * NF, H_out + (size_t)unit * NF * NF, bias, divider);
+}
+
+template <int WIN>
+int launch_raw(hipStream_t st, const uint8_t* dgd, int dgd_stride, const uint8_t* src, int src_stride, int pw, int ph, int unit_size, int units_x,
+               int units_y, int voff, long long* G) {
+    const int n = units_x * units_y;
+    if (unit_size <= 64) hipLaunchKernelGGL((wiener_stats8_kernel<WIN, 144, false>), dim3(n), dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size,
+                                            units_x, units_y, voff, (long long*)nullptr, (long long*)nullptr, G);
+    else {
+        const dim3 grid(n, (unit_size * 3 / 2 + 63) / 64);
+        if (unit_size <= 128) hipLaunchKernelGGL((wiener_stats8_kernel<WIN, 240, true>), grid, dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size,
+                                                 units_x, units_y, voff, (long long*)nullptr, (long long*)nullptr, G);
+        else hipLaunchKernelGGL((wiener_stats8_kernel<WIN, 432, true>), grid, dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, unit_size, units_x,
+                                units_y, voff, (long long*)nullptr, (long long*)nullptr, G);
+    }
+    return (int)hipGetLastError();
+}
+
 }  // namespace
+
+// scratch layout (bytes) of the 16-bit path; the API allocates it
+extern "C" size_t svt_hip_wiener_stats16_scratch(int win, int pw, int ph, int n_units) {
+    const size_t dp = ((size_t)pw + 6 + 63) & ~(size_t)63, sp = ((size_t)pw + 63) & ~(size_t)63;
+    const size_t F = (size_t)win * win + 2, np = F * (F + 1) / 2;
+    return 3 * (64 + dp * ((size_t)ph + 6) + 64) + 3 * (sp * (size_t)ph + 64) + 3 * np * 8 * (size_t)n_units + 256;
+}
+
+extern "C" int svt_hip_launch_wiener_stats16(hipStream_t st, int win, int bd, const uint16_t* dgd, int dgd_stride, const uint16_t* src, int src_stride,
+                                             int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, int64_t* M, int64_t* H, uint8_t* scratch) {
+    const int voff = 8 >> ss_y, n = units_x * units_y;
+    if (n <= 0) return 0;
+    const size_t dp = ((size_t)pw + 6 + 63) & ~(size_t)63, sp = ((size_t)pw + 63) & ~(size_t)63;
+    const size_t F = (size_t)win * win + 2, np = F * (F + 1) / 2;
+    uint8_t* p = (uint8_t*)(((uintptr_t)scratch + 63) & ~(uintptr_t)63);
+    uint8_t *dpl[3], *spl[3];
+    for (int i = 0; i < 3; i++) { dpl[i] = p + 64; p += 64 + dp * ((size_t)ph + 6) + 64; }   // 64 B of slack in front: the stats kernel reads aligned dwords
+    for (int i = 0; i < 3; i++) { spl[i] = p; p += sp * (size_t)ph + 64; }
+    p = (uint8_t*)(((uintptr_t)p + 63) & ~(uintptr_t)63);
+    long long* G[3];
+    for (int i = 0; i < 3; i++) { G[i] = (long long*)p; p += np * 8 * (size_t)n; }
+    if (hipMemsetAsync(G[0], 0, 3 * np * 8 * (size_t)n, st) != hipSuccess) return (int)hipGetLastError();
+    const int bias = 1 << (bd - 1);
+    hipLaunchKernelGGL(wiener_split16_kernel, dim3((pw + 6 + 255) / 256, ph + 6), dim3(256), 0, st, dgd - 3 * (ptrdiff_t)dgd_stride - 3, dgd_stride, pw + 6, ph + 6, bias,
+                       dpl[0], dpl[1], dpl[2], (int)dp);
+    hipLaunchKernelGGL(wiener_split16_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, st, src, src_stride, pw, ph, bias, spl[0], spl[1], spl[2], (int)sp);
+    for (int i = 0; i < 3; i++) {
+        const uint8_t* d0 = dpl[i] + 3 * dp + 3;
+        int e;
+        if (win == 7) e = launch_raw<7>(st, d0, (int)dp, spl[i], (int)sp, pw, ph, unit_size, units_x, units_y, voff, G[i]);
+        else if (win == 5) e = launch_raw<5>(st, d0, (int)dp, spl[i], (int)sp, pw, ph, unit_size, units_x, units_y, voff, G[i]);
+        else e = launch_raw<3>(st, d0, (int)dp, spl[i], (int)sp, pw, ph, unit_size, units_x, units_y, voff, G[i]);
+        if (e) return e;
+    }
+    const long long divider = bd == 12 ? 16 : (bd == 10 ? 4 : 1);
+    if (win == 7) hipLaunchKernelGGL((wiener_finalize16_kernel<7>), dim3(n), dim3(256), 0, st, G[0], G[1], G[2], (long long)bias, divider, (long long*)M, (long long*)H);
+    else if (win == 5) hipLaunchKernelGGL((wiener_finalize16_kernel<5>), dim3(n), dim3(256), 0, st, G[0], G[1], G[2], (long long)bias, divider, (long long*)M, (long long*)H);
+    else hipLaunchKernelGGL((wiener_finalize16_kernel<3>), dim3(n), dim3(256), 0, st, G[0], G[1], G[2], (long long)bias, divider, (long long*)M, (long long*)H);
+    return (int)hipGetLastError();
+}
 
 extern "C" int svt_hip_launch_wiener_stats8(hipStream_t st, int win, const uint8_t* dgd, int dgd_stride, const uint8_t* src, int src_stride, int pw,
                                             int ph, int unit_size, int units_x, int units_y, int ss_y, int64_t* M, int64_t* H) {
     const int voff = 8 >> ss_y, n = units_x * units_y;
     if (n <= 0) return 0;
 #define LAUNCH(W, P, B, GRID) hipLaunchKernelGGL((wiener_stats8_kernel<W, P, B>), GRID, dim3(256), 0, st, dgd, dgd_stride, src, src_stride, pw, ph, \
-                                                 unit_size, units_x, units_y, voff, (long long*)M, (long long*)H)
+                                                 unit_size, units_x, units_y, voff, (long long*)M, (long long*)H, (long long*)nullptr)
 #define BY_WIN(P, B, GRID) do { if (win == 7) LAUNCH(7, P, B, GRID); else if (win == 5) LAUNCH(5, P, B, GRID); else LAUNCH(3, P, B, GRID); } while (0)
     if (unit_size <= 64) {
         BY_WIN(144, false, dim3(n));

@@ -35,3 +35,30 @@ def test_wiener_stats(hip, orc, win):
         hip.free(d_ext, d_src, d_M, d_H)
         assert np.array_equal(Mg, Me), (win, w, h, US, ss, np.argwhere(Mg != Me)[:5])
         assert np.array_equal(Hg, He), (win, w, h, US, ss, np.argwhere(Hg != He)[:5])
+
+
+@pytest.mark.parametrize("bd", [10, 12])
+@pytest.mark.parametrize("win", [7, 5, 3])
+def test_wiener_stats_16bit(hip, orc, bd, win):
+    """svt_av1_compute_stats_highbd: the 16-bit path runs three 8-bit component planes (v = 32 h + l; H, L, H + L) through the int8 MFMA Gram
+    kernel and recombines exactly; bit_depth_divider applied with C truncation.  Extremes: all-max / all-zero / checkerboard units."""
+    rng = np.random.default_rng(60 + win + bd)
+    mx = (1 << bd) - 1
+    for (w, h, US, ss) in ((200, 152, 64, 0), (328, 264, 128, 1), (520, 300, 256, 0)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        dgd = np.clip((110 + 70 * np.sin(xx / 13.0) * np.cos(yy / 7.0)) * (1 << (bd - 8)) + rng.normal(0, 12 << (bd - 8), (h, w)), 0, mx).astype(np.uint16)
+        dgd[:40, :70] = mx; dgd[40:80, :70] = 0; dgd[80:120, :64] = ((xx[80:120, :64] + yy[80:120, :64]) & 1) * mx
+        src = np.clip(dgd.astype(np.int32) + rng.integers(-25 << (bd - 8), (25 << (bd - 8)) + 1, (h, w)), 0, mx).astype(np.uint16)
+        src[:20, :30] = 0; src[20:40, :30] = mx
+        src[64:128, 128:192] = mx - dgd[64:128, 128:192]          # an anti-correlated unit: negative sums, so the divider's truncation toward zero matters
+        ext = np.ascontiguousarray(np.pad(dgd, EXT, mode="edge")); st = ext.shape[1]; off = (EXT * st + EXT) * 2
+        nu = units(w, US) * units(h, US); w2 = win * win
+        Me, He = np.zeros((nu, w2), np.int64), np.zeros((nu, w2 * w2), np.int64)
+        orc.orc_wiener_stats_plane(win, C.c_void_p(ext.ctypes.data + off), st, ptr(src), w, 2, bd, w, h, ss, US, ptr(Me), ptr(He))
+        d_ext, d_src, d_M, d_H = hip.to_device(ext), hip.to_device(src), hip.empty(Me.nbytes), hip.empty(He.nbytes)
+        hip.check(hip.L.svt_hip_wiener_stats_plane_dev(hip.h, 2, bd, win, d_ext.value + off, st, d_src, w, w, h, US, ss, d_M, d_H), "wiener stats 16")
+        Mg, Hg = hip.to_host(d_M, Me.shape, np.int64), hip.to_host(d_H, He.shape, np.int64)
+        hip.free(d_ext, d_src, d_M, d_H)
+        assert np.array_equal(Mg, Me), (bd, win, w, h, US, ss, np.argwhere(Mg != Me)[:5], Mg[Mg != Me][:4], Me[Mg != Me][:4])
+        assert np.array_equal(Hg, He), (bd, win, w, h, US, ss, np.argwhere(Hg != He)[:5])
+        assert US != 64 or (Me < 0).any()
