@@ -54,6 +54,7 @@ int  svt_hip_malloc(SvtHipCtx *ctx, void **dptr, size_t bytes);
 int  svt_hip_free(SvtHipCtx *ctx, void *dptr);
 int  svt_hip_memcpy_h2d(SvtHipCtx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int  svt_hip_memcpy_d2h(SvtHipCtx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int  svt_hip_memcpy_d2d(SvtHipCtx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous, stream-ordered */
 /* HIP-event stopwatch on the context's stream (used by bench.py for per-kernel device time). */
 int  svt_hip_timer_start(SvtHipCtx *ctx);
 int  svt_hip_timer_stop_ms(SvtHipCtx *ctx, float *elapsed_ms);

@@ -115,6 +115,7 @@ def lib():
     L.svt_hip_free.argtypes = [vp, vp]
     L.svt_hip_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.svt_hip_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svt_hip_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.svt_hip_timer_start.argtypes = [vp]
     L.svt_hip_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.svt_hip_me_search_window.argtypes = [i32] * 8

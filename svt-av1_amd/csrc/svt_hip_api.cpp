@@ -100,6 +100,12 @@ int svt_hip_memcpy_d2h(SvtHipCtx* c, void* h, const void* d, size_t bytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SVT_HIP_OK;
 }
+int svt_hip_memcpy_d2d(SvtHipCtx* c, void* dst, const void* src, size_t bytes) {   // asynchronous, ordered on the context's stream
+    if (!c || (!dst && bytes) || (!src && bytes)) return SVT_HIP_ERR_BAD_ARG;
+    if (!bytes) return SVT_HIP_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return SVT_HIP_OK;
+}
 int svt_hip_timer_start(SvtHipCtx* c) {
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

@@ -25,3 +25,12 @@ def test_empty_batches(hip, pkg):
     hip.check(L.svt_hip_sync(hip.h))
     assert (hip.to_host(buf, (4096,), np.uint8) == 7).all()
     hip.free(buf)
+
+
+def test_memcpy_d2d(hip):
+    a = np.arange(5000, dtype=np.uint8)
+    d_a, d_b = hip.to_device(a), hip.empty(a.nbytes)
+    hip.check(hip.L.svt_hip_memcpy_d2d(hip.h, d_b, d_a, a.nbytes), "d2d")
+    assert np.array_equal(hip.to_host(d_b, a.shape, np.uint8), a)
+    assert hip.L.svt_hip_memcpy_d2d(hip.h, None, None, 0) == 0 and hip.L.svt_hip_memcpy_d2d(hip.h, None, d_a, 4) != 0
+    hip.free(d_a, d_b)
