@@ -397,6 +397,31 @@ int svt_hip_tf_estimate_noise_dev(SvtHipCtx *ctx, const void *d_src, int pix_byt
                                   int64_t *d_out);
 double svt_hip_tf_noise_sigma(int64_t sum, int64_t num);
 
+/* ------------------------------------------------------------------ compound inter prediction ---- */
+/* One two-reference block.  Both references are predicted like svt_av1_[highbd_]jnt_convolve_{2d_copy,x,y,2d} (common_dsp_rtcd.h:221-243;
+ * Common/Codec/EbInterPrediction.c:552-741, :944-1143; round_0 = 3 (5 at 12 bits), round_1 = COMPOUND_ROUND1_BITS) and combined by `type`:
+ *   0 COMPOUND_AVERAGE   (the do_average branch, use_jnt_comp_avg = 0)
+ *   1 COMPOUND_DISTANCE  (use_jnt_comp_avg = 1 with fwd_offset / bck_offset, sum 16)
+ *   2 COMPOUND_DIFFWTD   svt_av1_build_compound_diffwtd_mask_d16 (common_dsp_rtcd.h:115; mask_type 0 = DIFFWTD_38, 1 = DIFFWTD_38_INV); the
+ *                        w x h segmentation mask is also stored at d_masks + mask_off (stride w) unless mask_off < 0 — chroma reuses it
+ *   3 mask supplied      (wedge tables or a stored segmentation mask) at d_masks + mask_off, stride mask_stride; mask_sub = 1: the mask is at
+ *                        twice the block's resolution in both directions (4:2:0 chroma under a luma mask)
+ *   2, 3 blend with svt_aom_{lowbd,highbd}_blend_a64_d16_mask (Common/Codec/EbBlend_a64_mask.c:34, :110) as build_masked_compound_no_round does.
+ * Kernel banks as in SvtHipConvBlk; one filter pair for both references (AV1 signals one interp_filters per block). */
+typedef struct {
+    int32_t src0_x, src0_y, src1_x, src1_y; /* integer position of the block's top-left sample in reference plane 0 / 1 */
+    int32_t dst_x, dst_y;
+    uint8_t w, h;                           /* 4..128 */
+    uint8_t bank_x, bank_y;
+    uint8_t subpel0_x, subpel0_y, subpel1_x, subpel1_y; /* q4 phases */
+    uint8_t type, fwd_offset, bck_offset, mask_type;
+    uint8_t mask_sub, reserved[3];
+    int32_t mask_off, mask_stride;
+} SvtHipCompBlk;
+int svt_hip_compound_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref0, int ref0_stride, const void *d_ref1,
+                                       int ref1_stride, void *d_dst, int dst_stride, uint8_t *d_masks, const SvtHipCompBlk *d_blks,
+                                       int nblk);
+
 #ifdef __cplusplus
 }
 #endif

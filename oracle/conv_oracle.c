@@ -6,6 +6,7 @@
  */
 #include "svt_oracle.h"
 #include <string.h>
+#include <stdlib.h>
 
 /* AV1 interpolation kernels (normative constants): Common/Codec/EbInterPrediction.c:258-291, :1181-1249.
  * bank 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR, 4 4-tap regular (w <= 4),
@@ -150,5 +151,114 @@ void orc_subpel_predict_batch(int pix_bytes, int bd, const void *ref, int ref_st
             orc_upsampled_pred(s, ref_stride, tmp, b->w, b->h, b->subpel_x >> 1, b->subpel_y >> 1, b->bank_x);
             for (int y = 0; y < b->h; y++) memcpy(d + (size_t)y * dst_stride, tmp + y * b->w, b->w);
         }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Compound inter prediction.
+ * svt_av1_[highbd_]jnt_convolve_{2d_copy,x,y,2d}_c with do_average == 0 (Common/Codec/EbInterPrediction.c:552-741, :944-1143): the
+ * 16-bit intermediate ("ConvBufType") prediction of one reference; round_0 = 3 (5 for 12-bit), round_1 = COMPOUND_ROUND1_BITS = 7. */
+void orc_jnt_convolve_d16(const void *src, int src_stride, int pix_bytes, int w, int h, int bank_x, int bank_y, int subpel_x_q4, int subpel_y_q4, int bd,
+                          uint16_t *out, int out_stride) {
+    const int16_t *xf = orc_interp_kernels[bank_x][subpel_x_q4 & 15], *yf = orc_interp_kernels[bank_y][subpel_y_q4 & 15];
+    const int r0 = bd == 12 ? 5 : 3, r1 = 7, fo = 3;
+    const int offset_bits = bd + 14 - r0, round_offset = (1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1));
+    const int sx = subpel_x_q4 & 15, sy = subpel_y_q4 & 15;
+    if (!sx && !sy) {                                   /* 2d_copy :704-741 */
+        const int bits = 14 - r1 - r0;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++)
+            out[y * out_stride + x] = (uint16_t)((rdp(src, pix_bytes, (ptrdiff_t)y * src_stride + x) << bits) + round_offset);
+    } else if (!sy) {                                   /* x :658-702 */
+        const int bits = 7 - r1;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int res = 0;
+            for (int k = 0; k < 8; k++) res += xf[k] * rdp(src, pix_bytes, (ptrdiff_t)y * src_stride + x - fo + k);
+            res = (1 << bits) * rp2(res, r0) + round_offset;
+            out[y * out_stride + x] = (uint16_t)res;
+        }
+    } else if (!sx) {                                   /* y :612-656 */
+        const int bits = 7 - r0;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int res = 0;
+            for (int k = 0; k < 8; k++) res += yf[k] * rdp(src, pix_bytes, (ptrdiff_t)(y - fo + k) * src_stride + x);
+            res *= (1 << bits);
+            res = rp2(res, r1) + round_offset;
+            out[y * out_stride + x] = (uint16_t)res;
+        }
+    } else {                                            /* 2d :552-610 */
+        int16_t im[(128 + 7) * 128];
+        for (int y = 0; y < h + 7; y++) for (int x = 0; x < w; x++) {
+            int sum = 1 << (bd + 6);
+            for (int k = 0; k < 8; k++) sum += xf[k] * rdp(src, pix_bytes, (ptrdiff_t)(y - fo) * src_stride + x - fo + k);
+            im[y * w + x] = (int16_t)rp2(sum, r0);
+        }
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            int sum = 1 << offset_bits;
+            for (int k = 0; k < 8; k++) sum += yf[k] * im[(y + k) * w + x];
+            out[y * out_stride + x] = (uint16_t)rp2(sum, r1);
+        }
+    }
+}
+
+/* The blocks svt_hip_compound_predict_batch_dev receives (include/svt_hip.h, SvtHipCompBlk) */
+typedef struct {
+    int32_t src0_x, src0_y, src1_x, src1_y, dst_x, dst_y;
+    uint8_t w, h, bank_x, bank_y;
+    uint8_t subpel0_x, subpel0_y, subpel1_x, subpel1_y;
+    uint8_t type, fwd_offset, bck_offset, mask_type;
+    uint8_t mask_sub, reserved[3];
+    int32_t mask_off, mask_stride;
+} OrcCompBlk;
+
+/* Both references of a compound block and their combination:
+ *   type 0 COMPOUND_AVERAGE / 1 COMPOUND_DISTANCE: the do_average branch of the jnt_convolve functions (:593-606), use_jnt_comp_avg = type;
+ *   type 2 COMPOUND_DIFFWTD: svt_av1_build_compound_diffwtd_mask_d16_c (Common/C_DEFAULT/EbInterPrediction_c.c:15-43) written to
+ *          masks + mask_off (stride w; skipped when mask_off < 0), then the blend;
+ *   type 3 mask supplied (wedge, or a previously built seg_mask; mask_sub = 1: the mask is at luma resolution for a 4:2:0 chroma block)
+ *   blend = svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c (Common/Codec/EbBlend_a64_mask.c:34-110 / :112-230) as build_masked_compound_no_round
+ *   calls it (Encoder/Codec/EbEncInterPrediction.c:60-120). */
+void orc_compound_predict_batch(int pix_bytes, int bd, const void *ref0, int ref0_stride, const void *ref1, int ref1_stride, void *dst, int dst_stride,
+                                uint8_t *masks, const void *blks_, int begin, int end) {
+    const OrcCompBlk *blks = (const OrcCompBlk *)blks_;
+    static _Thread_local uint16_t a[128 * 128], b[128 * 128];
+    static _Thread_local uint8_t seg[128 * 128];
+    const int r0 = bd == 12 ? 5 : 3, r1 = 7;
+    const int offset_bits = bd + 14 - r0, round_offset = (1 << (offset_bits - r1)) + (1 << (offset_bits - r1 - 1)), round_bits = 14 - r0 - r1;
+    for (int i = begin; i < end; i++) {
+        const OrcCompBlk *c = &blks[i];
+        const int w = c->w, h = c->h;
+        orc_jnt_convolve_d16((const uint8_t *)ref0 + ((ptrdiff_t)c->src0_y * ref0_stride + c->src0_x) * pix_bytes, ref0_stride, pix_bytes, w, h, c->bank_x, c->bank_y,
+                             c->subpel0_x, c->subpel0_y, bd, a, w);
+        orc_jnt_convolve_d16((const uint8_t *)ref1 + ((ptrdiff_t)c->src1_y * ref1_stride + c->src1_x) * pix_bytes, ref1_stride, pix_bytes, w, h, c->bank_x, c->bank_y,
+                             c->subpel1_x, c->subpel1_y, bd, b, w);
+        const uint8_t *m = NULL; int ms = 0;
+        if (c->type == 2) {
+            const int round = 14 - r0 - r1 + (bd - 8);
+            for (int k = 0; k < w * h; k++) {
+                int diff = abs((int)a[k] - (int)b[k]);
+                diff = rp2(diff, round);
+                int mm = 38 + diff / 16;                                       /* DIFF_FACTOR = 16 */
+                mm = mm < 0 ? 0 : (mm > 64 ? 64 : mm);
+                seg[k] = (uint8_t)(c->mask_type ? 64 - mm : mm);
+            }
+            if (c->mask_off >= 0) for (int y = 0; y < h; y++) memcpy(masks + c->mask_off + (size_t)y * w, seg + y * w, (size_t)w);
+            m = seg; ms = w;
+        } else if (c->type == 3) { m = masks + c->mask_off; ms = c->mask_stride; }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int k = y * w + x;
+                int tmp;
+                if (c->type <= 1) {
+                    tmp = c->type ? ((int)a[k] * c->fwd_offset + (int)b[k] * c->bck_offset) >> 4 : ((int)a[k] + (int)b[k]) >> 1;
+                } else {
+                    int mm;
+                    if (c->type == 3 && c->mask_sub)
+                        mm = rp2(m[(2 * y) * ms + 2 * x] + m[(2 * y + 1) * ms + 2 * x] + m[(2 * y) * ms + 2 * x + 1] + m[(2 * y + 1) * ms + 2 * x + 1], 2);
+                    else mm = m[y * ms + x];
+                    tmp = (mm * (int)a[k] + (64 - mm) * (int)b[k]) >> 6;
+                }
+                tmp -= round_offset;
+                wrp(dst, pix_bytes, (ptrdiff_t)(c->dst_y + y) * dst_stride + c->dst_x + x, clipbd(rp2(tmp, round_bits), bd));
+            }
     }
 }

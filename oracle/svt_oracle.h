@@ -203,6 +203,12 @@ void orc_tf_filter_frame(int pix_bytes, int bd, const void *const src[3], const 
 /* Encoder/Codec/EbTemporalFiltering.c:2414 / :2451 (estimate_noise / estimate_noise_highbd); out = {sum, num} */
 double orc_tf_estimate_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, int64_t out[2]);
 
+/* ---------------------------------------------------------------- compound prediction (8(f) rank 4, conv_oracle.c) */
+void orc_jnt_convolve_d16(const void *src, int src_stride, int pix_bytes, int w, int h, int bank_x, int bank_y, int subpel_x_q4, int subpel_y_q4, int bd,
+                          uint16_t *out, int out_stride);
+void orc_compound_predict_batch(int pix_bytes, int bd, const void *ref0, int ref0_stride, const void *ref1, int ref1_stride, void *dst, int dst_stride,
+                                uint8_t *masks, const void *blks, int begin, int end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -605,4 +605,17 @@ double svt_hip_tf_noise_sigma(int64_t sum, int64_t num) {   // EbTemporalFilteri
     return (double)sum / (6 * num) * 1.25331413732;
 }
 
+int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref0, int ref0_stride, const void* d_ref1, int ref1_stride,
+                                       void* d_dst, int dst_stride, uint8_t* d_masks, const SvtHipCompBlk* d_blks, int nblk) {
+    if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10 && bd != 12)) {
+        if (c) c->err = "svt_hip_compound_predict_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    if (nblk == 0) return SVT_HIP_OK;
+    if (!d_ref0 || !d_ref1 || !d_dst || !d_blks) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_compound_predict(c->stream, pix_bytes, bd, d_ref0, ref0_stride, d_ref1, ref1_stride, d_dst, dst_stride, d_masks, d_blks, nblk);
+    if (e != hipSuccess) return fail(c, e, "compound predict launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,55 @@
+"""Shared definitions for the compound-prediction tests: the SvtHipCompBlk / OrcCompBlk record and random block lists."""
+import ctypes as C
+
+import numpy as np
+
+
+class CompBlk(C.Structure):
+    _fields_ = [("src0_x", C.c_int32), ("src0_y", C.c_int32), ("src1_x", C.c_int32), ("src1_y", C.c_int32), ("dst_x", C.c_int32), ("dst_y", C.c_int32),
+                ("w", C.c_uint8), ("h", C.c_uint8), ("bank_x", C.c_uint8), ("bank_y", C.c_uint8),
+                ("subpel0_x", C.c_uint8), ("subpel0_y", C.c_uint8), ("subpel1_x", C.c_uint8), ("subpel1_y", C.c_uint8),
+                ("type", C.c_uint8), ("fwd_offset", C.c_uint8), ("bck_offset", C.c_uint8), ("mask_type", C.c_uint8),
+                ("mask_sub", C.c_uint8), ("reserved", C.c_uint8 * 3), ("mask_off", C.c_int32), ("mask_stride", C.c_int32)]
+
+
+assert C.sizeof(CompBlk) == 48
+SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (4, 8), (8, 4), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (128, 64), (64, 128), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+# quant_dist_lookup_table[order_idx][..] pairs the encoder uses for COMPOUND_DISTANCE (fwd + bck = 16)
+DIST_PAIRS = [(9, 7), (11, 5), (12, 4), (13, 3), (7, 9), (5, 11), (4, 12), (3, 13)]
+
+
+def make_blocks(rng, W, H, n, mask_bytes):
+    """n random compound blocks tiling nothing in particular: destinations are disjoint cells of a 128-pixel grid.  Returns (array, mask buffer)."""
+    cols = W // 128
+    assert n <= cols * (H // 128)
+    blks = (CompBlk * n)()
+    masks = rng.integers(0, 65, mask_bytes).astype(np.uint8)
+    off = 0
+    for i in range(n):
+        w, h = SIZES[i % len(SIZES)]
+        cx, cy = (i % cols) * 128, (i // cols) * 128
+        b = blks[i]
+        b.dst_x, b.dst_y, b.w, b.h = cx, cy, w, h
+        b.src0_x, b.src0_y = cx + int(rng.integers(-6, 7)), cy + int(rng.integers(-6, 7))
+        b.src1_x, b.src1_y = cx + int(rng.integers(-6, 7)), cy + int(rng.integers(-6, 7))
+        b.bank_x = b.bank_y = int(rng.integers(0, 4)) if w > 4 and h > 4 else int(rng.integers(4, 6))
+        if i % 7 == 3: b.bank_y = int(rng.integers(0, 3))          # dual filters
+        sp = [int(rng.integers(0, 16)) for _ in range(4)]
+        if i % 5 == 0: sp[0] = 0
+        if i % 5 == 1: sp[1] = 0
+        if i % 11 == 2: sp = [0, 0, sp[2], 0]
+        b.subpel0_x, b.subpel0_y, b.subpel1_x, b.subpel1_y = sp
+        b.type = i % 4
+        b.fwd_offset, b.bck_offset = DIST_PAIRS[i % len(DIST_PAIRS)]
+        b.mask_type = (i // 4) & 1
+        b.mask_sub = 0
+        b.mask_off, b.mask_stride = -1, 0
+        if b.type == 2 and i % 8 != 2:
+            b.mask_off = off; off += w * h
+        if b.type == 3:
+            b.mask_sub = (i // 4) % 2 if max(w, h) <= 64 else 0
+            ms = (2 * w if b.mask_sub else w) + int(rng.integers(0, 9))
+            b.mask_off, b.mask_stride = off, ms
+            off += ms * (2 * h if b.mask_sub else h)
+        assert off <= mask_bytes
+    return blks, masks

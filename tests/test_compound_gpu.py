@@ -1,0 +1,43 @@
+"""GPU parity: compound (two-reference) prediction (HIP through the C ABI) vs the oracle, which tests/test_oracle_vs_ref.py pins to two
+svt_av1_[highbd_]jnt_convolve_*_c calls, svt_av1_build_compound_diffwtd_mask_d16_c and svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c.
+All 22 AV1 block sizes, the four convolve flavours per reference, average / distance / diff-weighted / supplied-mask (also sub-sampled)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import ptr
+import comp_common as cmc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_compound_blocks(hip, orc, bd):
+    rng = np.random.default_rng(500 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    W, H = 1536, 1152
+    ref0 = rng.integers(0, 1 << bd, (H, W)).astype(dt); ref1 = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+    ref0[:200, :200] = (1 << bd) - 1; ref1[:200, :200] = 0
+    n = 80
+    blks, masks = cmc.make_blocks(rng, W - 256, H - 128, n, 1 << 21)
+    for b in blks:
+        b.src0_x += 64; b.src0_y += 64; b.src1_x += 64; b.src1_y += 64; b.dst_x += 8; b.dst_y += 8
+    exp = np.zeros((H, W), dt); m_exp = masks.copy()
+    orc.orc_compound_predict_batch(ref0.itemsize, bd, ptr(ref0), W, ptr(ref1), W, ptr(exp), W, ptr(m_exp), blks, 0, n)
+    d_r0, d_r1, d_dst, d_m = hip.to_device(ref0), hip.to_device(ref1), hip.to_device(np.zeros((H, W), dt)), hip.to_device(masks)
+    d_b = hip.to_device(np.frombuffer(bytes(blks), np.uint8).copy())
+    hip.check(hip.L.svt_hip_compound_predict_batch_dev(hip.h, ref0.itemsize, bd, d_r0, W, d_r1, W, d_dst, W, d_m, d_b, n), "compound")
+    got = hip.to_host(d_dst, (H, W), dt); m_got = hip.to_host(d_m, masks.shape, np.uint8)
+    hip.free(d_r0, d_r1, d_dst, d_m, d_b)
+    for i, b in enumerate(blks):
+        g, e = got[b.dst_y:b.dst_y + b.h, b.dst_x:b.dst_x + b.w], exp[b.dst_y:b.dst_y + b.h, b.dst_x:b.dst_x + b.w]
+        assert np.array_equal(g, e), (bd, i, b.type, b.w, b.h, (b.subpel0_x, b.subpel0_y, b.subpel1_x, b.subpel1_y), np.argwhere(g != e)[:4])
+    assert np.array_equal(got, exp) and np.array_equal(m_got, m_exp)
+    assert (m_exp != masks).any() and exp.any()
+
+
+def test_compound_empty_and_bad_args(hip):
+    assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 8, None, 0, None, 0, None, 0, None, None, 0) == 0
+    assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 10, None, 0, None, 0, None, 0, None, None, 0) != 0
+    assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 8, None, 0, None, 0, None, 0, None, None, 3) != 0

@@ -631,3 +631,65 @@ def test_temporal_filter_planewise_noise_and_divu(orc, ref):
     for d in range(1000, 1024):
         for x in rng.integers(0, 4096 * d, 400):
             assert ref.ref_shim_od_divu(C.c_uint32(int(x)), C.c_uint32(d)) == int(x) // d
+
+
+import comp_common as cmc
+
+
+def test_compound_prediction(orc, ref):
+    """orc_jnt_convolve_d16 / orc_compound_predict_batch == two svt_av1_[highbd_]jnt_convolve_*_c calls (do_average 0, then 1
+    with / without use_jnt_comp_avg), svt_av1_build_compound_diffwtd_mask_d16_c + svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c.
+    Block sizes, phases and filters as /root/reference/test/convolve_2d_test.cc (jnt cases) and CompBlendTest.cc."""
+    rng = np.random.default_rng(77)
+    W, H = 1280, 1024
+    for bd, dt in ((8, np.uint8), (10, np.uint16), (12, np.uint16)):
+        r0 = 5 if bd == 12 else 3           # get_conv_params_no_round: ROUND0_BITS (+ 2 at 12 bits)
+        ref0 = rng.integers(0, 1 << bd, (H, W)).astype(dt); ref1 = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+        ref0[:130, :130] = (1 << bd) - 1; ref1[:130, :130] = 0                # extreme block
+        n = 44
+        blks, masks = cmc.make_blocks(rng, W - 256, H - 256, n, 1 << 20)
+        for b in blks:                                                          # keep 8 samples of context inside the planes
+            b.src0_x += 64; b.src0_y += 64; b.src1_x += 64; b.src1_y += 64
+        dst = np.zeros((H, W), dt); m_orc = masks.copy()
+        orc.orc_compound_predict_batch(ref0.itemsize, bd, ptr(ref0), W, ptr(ref1), W, ptr(dst), W, ptr(m_orc), blks, 0, n)
+        pre = "svt_av1_" if bd == 8 else "svt_av1_highbd_"
+        for i, b in enumerate(blks):
+            w, h = b.w, b.h
+            fx = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[b.bank_x])), 8, 16, 0)
+            fy = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[b.bank_y])), 8, 16, 0)
+            d16 = [np.zeros((h, w), np.uint16), np.zeros((h, w), np.uint16)]
+            out = np.zeros((h, w), dt)
+            for r, (plane, sx_, sy_, px, py) in enumerate(((ref0, b.subpel0_x, b.subpel0_y, b.src0_x, b.src0_y), (ref1, b.subpel1_x, b.subpel1_y, b.src1_x, b.src1_y))):
+                cp = _ConvP(); cp.round_0 = r0; cp.round_1 = 7; cp.is_compound = 1; cp.dst = d16[r].ctypes.data; cp.dst_stride = w
+                name = pre + "jnt_convolve_" + {(0, 0): "2d_copy", (1, 0): "x", (0, 1): "y", (1, 1): "2d"}[(int(sx_ != 0), int(sy_ != 0))] + "_c"
+                sp = C.c_void_p(plane.ctypes.data + (py * W + px) * plane.itemsize)
+                args = [sp, W, ptr(out), w, w, h, C.byref(fx), C.byref(fy), sx_, sy_, C.byref(cp)]
+                if bd > 8: args.append(bd)
+                getattr(ref, name)(*args)
+                mine = np.zeros((h, w), np.uint16)
+                orc.orc_jnt_convolve_d16(sp, W, plane.itemsize, w, h, b.bank_x, b.bank_y, sx_, sy_, bd, ptr(mine), w)
+                assert np.array_equal(mine, d16[r]), (bd, i, r, name)
+            cp = _ConvP(); cp.round_0 = r0; cp.round_1 = 7; cp.is_compound = 1
+            if b.type <= 1:      # second call with do_average: dst holds the first prediction
+                cp.dst = d16[0].ctypes.data; cp.dst_stride = w; cp.do_average = 1; cp.use_jnt_comp_avg = b.type
+                cp.fwd_offset, cp.bck_offset = b.fwd_offset, b.bck_offset
+                name = pre + "jnt_convolve_" + {(0, 0): "2d_copy", (1, 0): "x", (0, 1): "y", (1, 1): "2d"}[(int(b.subpel1_x != 0), int(b.subpel1_y != 0))] + "_c"
+                sp = C.c_void_p(ref1.ctypes.data + (b.src1_y * W + b.src1_x) * ref1.itemsize)
+                args = [sp, W, ptr(out), w, w, h, C.byref(fx), C.byref(fy), b.subpel1_x, b.subpel1_y, C.byref(cp)]
+                if bd > 8: args.append(bd)
+                getattr(ref, name)(*args)
+            else:
+                if b.type == 2:
+                    seg = np.zeros((h, w), np.uint8)
+                    ref.svt_av1_build_compound_diffwtd_mask_d16_c(ptr(seg), int(b.mask_type), ptr(d16[0]), w, ptr(d16[1]), w, h, w, C.byref(cp), bd)
+                    if b.mask_off >= 0:
+                        assert np.array_equal(m_orc[b.mask_off:b.mask_off + w * h].reshape(h, w), seg), (bd, i, "seg mask")
+                    mptr, mstride, sub = ptr(seg), w, 0
+                else:
+                    mptr, mstride, sub = C.c_void_p(masks.ctypes.data + b.mask_off), b.mask_stride, int(b.mask_sub)
+                if bd == 8:
+                    ref.svt_aom_lowbd_blend_a64_d16_mask_c(ptr(out), w, ptr(d16[0]), w, ptr(d16[1]), w, mptr, mstride, w, h, sub, sub, C.byref(cp))
+                else:
+                    ref.svt_aom_highbd_blend_a64_d16_mask_c(ptr(out), w, ptr(d16[0]), w, ptr(d16[1]), w, mptr, mstride, w, h, sub, sub, C.byref(cp), bd)
+            got = dst[b.dst_y:b.dst_y + h, b.dst_x:b.dst_x + w]
+            assert np.array_equal(got, out), (bd, i, b.type, w, h, np.argwhere(got != out)[:4])
