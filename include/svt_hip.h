@@ -422,6 +422,18 @@ int svt_hip_compound_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, co
                                        int ref1_stride, void *d_dst, int dst_stride, uint8_t *d_masks, const SvtHipCompBlk *d_blks,
                                        int nblk);
 
+/* OBMC motion-search costs of a list of blocks: svt_aom_obmc_sad{W}x{H} (aom_dsp_rtcd.h:356-398), svt_aom_obmc_variance{W}x{H} and
+ * svt_aom_obmc_sub_pixel_variance{W}x{H} (:399-...; Encoder/C_DEFAULT/sad_av1.c:18, variance.c:270-318).  d_wsrc / d_mask: the int32 arrays of
+ * calc_target_weighted_pred, block i at + wm_off with stride w.  d_out[i] = {sad, sse, variance at (xoffset, yoffset) eighths; 0, 0 = the
+ * plain variance}.  The predictor plane must be readable one sample right / below of every block.  8-bit (the reference has no 16-bit twin). */
+typedef struct {
+    int32_t pre_x, pre_y;
+    uint8_t w, h, xoffset, yoffset;
+    int32_t wm_off;
+} SvtHipObmcBlk;
+int svt_hip_obmc_cost_batch_dev(SvtHipCtx *ctx, const uint8_t *d_pre, int pre_stride, const int32_t *d_wsrc, const int32_t *d_mask,
+                                const SvtHipObmcBlk *d_blks, int nblk, uint32_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

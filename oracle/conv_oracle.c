@@ -262,3 +262,37 @@ void orc_compound_predict_batch(int pix_bytes, int bd, const void *ref0, int ref
             }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * OBMC motion-search costs: svt_aom_obmc_sad{W}x{H}_c (Encoder/C_DEFAULT/sad_av1.c:18-38),
+ * svt_aom_obmc_variance{W}x{H}_c and svt_aom_obmc_sub_pixel_variance{W}x{H}_c (Encoder/C_DEFAULT/variance.c:270-318; the 2-tap bilinear
+ * passes :32-75, bilinear_filters_2t[k] = {128 - 16 k, 16 k}).  wsrc / mask: int32, stride w.  out = {sad (unfiltered pre), sse, variance
+ * (pre filtered at (xoffset, yoffset) eighths; offset 0 is the identity, i.e. the plain variance function)}. */
+void orc_obmc_block(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, int w, int h, int xoffset, int yoffset, uint32_t out[3]) {
+    uint32_t sad = 0, sse = 0;
+    int sum = 0;
+    static _Thread_local uint16_t f1[129 * 128];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int d = wsrc[y * w + x] - pre[(ptrdiff_t)y * pre_stride + x] * mask[y * w + x];
+            sad += (uint32_t)rp2(abs(d), 12);
+        }
+    for (int y = 0; y < h + 1; y++)
+        for (int x = 0; x < w; x++)
+            f1[y * w + x] = (uint16_t)rp2(pre[(ptrdiff_t)y * pre_stride + x] * (128 - 16 * xoffset) + pre[(ptrdiff_t)y * pre_stride + x + 1] * (16 * xoffset), 7);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int p = (uint8_t)rp2(f1[y * w + x] * (128 - 16 * yoffset) + f1[(y + 1) * w + x] * (16 * yoffset), 7);
+            const int v = wsrc[y * w + x] - p * mask[y * w + x];
+            const int d = v < 0 ? -rp2(-v, 12) : rp2(v, 12);
+            sum += d; sse += (uint32_t)(d * d);
+        }
+    out[0] = sad; out[1] = sse; out[2] = sse - (uint32_t)(((int64_t)sum * sum) / (w * h));
+}
+typedef struct { int32_t pre_x, pre_y; uint8_t w, h, xoffset, yoffset; int32_t wm_off; } OrcObmcBlk;
+void orc_obmc_batch(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, const void *blks_, int n, uint32_t *out) {
+    const OrcObmcBlk *b = (const OrcObmcBlk *)blks_;
+    for (int i = 0; i < n; i++)
+        orc_obmc_block(pre + (ptrdiff_t)b[i].pre_y * pre_stride + b[i].pre_x, pre_stride, wsrc + b[i].wm_off, mask + b[i].wm_off, b[i].w, b[i].h, b[i].xoffset,
+                       b[i].yoffset, out + 3 * i);
+}

@@ -209,6 +209,10 @@ void orc_jnt_convolve_d16(const void *src, int src_stride, int pix_bytes, int w,
 void orc_compound_predict_batch(int pix_bytes, int bd, const void *ref0, int ref0_stride, const void *ref1, int ref1_stride, void *dst, int dst_stride,
                                 uint8_t *masks, const void *blks, int begin, int end);
 
+/* OBMC costs (8(f) rank 4, conv_oracle.c) */
+void orc_obmc_block(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, int w, int h, int xoffset, int yoffset, uint32_t out[3]);
+void orc_obmc_batch(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, const void *blks, int n, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,41 @@ compound_predict_kernel(const PIX* __restrict__ ref0, int ref0_stride, const PIX
         }
 }
 
+
+// ---- OBMC motion-search costs: svt_aom_obmc_sad{W}x{H} (Encoder/C_DEFAULT/sad_av1.c:18-38), svt_aom_obmc_variance{W}x{H} and
+// svt_aom_obmc_sub_pixel_variance{W}x{H} (Encoder/C_DEFAULT/variance.c:270-318): one wave per block; out[blk] = {sad, sse, variance}.
+// The bilinear sample is recomputed per pixel from its 2 x 2 neighbourhood (first pass rounded to 16 bits, second to 8, as the two passes do).
+__global__ void __launch_bounds__(256)
+obmc_cost_kernel(const uint8_t* __restrict__ pre, int pre_stride, const int32_t* __restrict__ wsrc, const int32_t* __restrict__ mask,
+                 const SvtHipObmcBlk* __restrict__ blks, int n, uint32_t* __restrict__ out) {
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blk >= n) return;
+    const SvtHipObmcBlk b = blks[blk];
+    const uint8_t* p = pre + (ptrdiff_t)b.pre_y * pre_stride + b.pre_x;
+    const int32_t *ws = wsrc + b.wm_off, *mk = mask + b.wm_off;
+    const int fx0 = 128 - 16 * b.xoffset, fx1 = 16 * b.xoffset, fy0 = 128 - 16 * b.yoffset, fy1 = 16 * b.yoffset;
+    uint32_t sad = 0, sse = 0;
+    int sum = 0;
+    for (int i = lane; i < b.w * b.h; i += 64) {
+        const int y = i / b.w, x = i - y * b.w;
+        const uint8_t* q = p + (ptrdiff_t)y * pre_stride + x;
+        const int a00 = q[0], a01 = q[1], a10 = q[pre_stride], a11 = q[pre_stride + 1];
+        const int m = mk[i], w0 = ws[i];
+        sad += (uint32_t)rp2(abs(w0 - a00 * m), 12);
+        const int r0 = rp2(a00 * fx0 + a01 * fx1, 7), r1 = rp2(a10 * fx0 + a11 * fx1, 7);
+        const int pf = rp2(r0 * fy0 + r1 * fy1, 7) & 0xff;
+        const int v = w0 - pf * m;
+        const int d = v < 0 ? -rp2(-v, 12) : rp2(v, 12);
+        sum += d; sse += (uint32_t)(d * d);
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { sad += (uint32_t)__shfl_xor((int)sad, s, 64); sse += (uint32_t)__shfl_xor((int)sse, s, 64); sum += __shfl_xor(sum, s, 64); }
+    if (lane == 0) {
+        out[3 * (size_t)blk] = sad; out[3 * (size_t)blk + 1] = sse;
+        out[3 * (size_t)blk + 2] = sse - (uint32_t)(((long long)sum * sum) / (b.w * b.h));
+    }
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_compound_predict(hipStream_t st, int pix_bytes, int bd, const void* ref0, int ref0_stride, const void* ref1, int ref1_stride,
@@ -128,5 +163,12 @@ extern "C" int svt_hip_launch_compound_predict(hipStream_t st, int pix_bytes, in
     else if (bd == 10) LAUNCH(uint16_t, 10);
     else LAUNCH(uint16_t, 12);
 #undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_obmc_cost(hipStream_t st, const uint8_t* pre, int pre_stride, const int32_t* wsrc, const int32_t* mask, const SvtHipObmcBlk* blks, int n,
+                                        uint32_t* out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(obmc_cost_kernel, dim3((n + 3) / 4), dim3(256), 0, st, pre, pre_stride, wsrc, mask, blks, n, out);
     return (int)hipGetLastError();
 }

@@ -618,4 +618,14 @@ int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
     return SVT_HIP_OK;
 }
 
+int svt_hip_obmc_cost_batch_dev(SvtHipCtx* c, const uint8_t* d_pre, int pre_stride, const int32_t* d_wsrc, const int32_t* d_mask, const SvtHipObmcBlk* d_blks,
+                                int nblk, uint32_t* d_out) {
+    if (!c || nblk < 0) return SVT_HIP_ERR_BAD_ARG;
+    if (nblk == 0) return SVT_HIP_OK;
+    if (!d_pre || !d_wsrc || !d_mask || !d_blks || !d_out) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_obmc_cost(c->stream, d_pre, pre_stride, d_wsrc, d_mask, d_blks, nblk, d_out);
+    if (e != hipSuccess) return fail(c, e, "obmc cost launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

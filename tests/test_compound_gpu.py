@@ -41,3 +41,32 @@ def test_compound_empty_and_bad_args(hip):
     assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 8, None, 0, None, 0, None, 0, None, None, 0) == 0
     assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 10, None, 0, None, 0, None, 0, None, None, 0) != 0
     assert hip.L.svt_hip_compound_predict_batch_dev(hip.h, 1, 8, None, 0, None, 0, None, 0, None, None, 3) != 0
+
+
+class ObmcBlk(C.Structure):
+    _fields_ = [("pre_x", C.c_int32), ("pre_y", C.c_int32), ("w", C.c_uint8), ("h", C.c_uint8), ("xoffset", C.c_uint8), ("yoffset", C.c_uint8), ("wm_off", C.c_int32)]
+
+
+def test_obmc_costs(hip, orc):
+    """svt_hip_obmc_cost_batch_dev vs the oracle (pinned to svt_aom_obmc_sad / obmc_variance / obmc_sub_pixel_variance for all block sizes)."""
+    rng = np.random.default_rng(9)
+    W, H = 640, 480
+    pre = rng.integers(0, 256, (H, W)).astype(np.uint8); pre[:140, :140] = 255
+    n = 4 * len(cmc.SIZES)
+    blks = (ObmcBlk * n)()
+    off = 0
+    for i in range(n):
+        w, h = cmc.SIZES[i % len(cmc.SIZES)]
+        blks[i] = ObmcBlk(int(rng.integers(0, W - 130)) if i else 0, int(rng.integers(0, H - 130)) if i else 0, w, h,
+                          0 if i % 3 == 0 else int(rng.integers(0, 8)), 0 if i % 3 == 0 else int(rng.integers(0, 8)), off)
+        off += w * h
+    wsrc = rng.integers(0, 255 * 4096 + 1, off).astype(np.int32); mask = rng.integers(0, 4097, off).astype(np.int32)
+    wsrc[:128 * 128] = 0; mask[:128 * 128] = 4096
+    exp = np.zeros((n, 3), np.uint32)
+    orc.orc_obmc_batch(ptr(pre), W, ptr(wsrc), ptr(mask), blks, n, ptr(exp))
+    d_pre, d_w, d_m, d_b, d_o = hip.to_device(pre), hip.to_device(wsrc), hip.to_device(mask), hip.to_device(np.frombuffer(bytes(blks), np.uint8).copy()), hip.empty(exp.nbytes)
+    hip.check(hip.L.svt_hip_obmc_cost_batch_dev(hip.h, d_pre, W, d_w, d_m, d_b, n, d_o), "obmc")
+    got = hip.to_host(d_o, exp.shape, np.uint32)
+    hip.free(d_pre, d_w, d_m, d_b, d_o)
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:6]
+    assert exp.any() and hip.L.svt_hip_obmc_cost_batch_dev(hip.h, None, 0, None, None, None, 0, None) == 0

@@ -693,3 +693,28 @@ def test_compound_prediction(orc, ref):
                     ref.svt_aom_highbd_blend_a64_d16_mask_c(ptr(out), w, ptr(d16[0]), w, ptr(d16[1]), w, mptr, mstride, w, h, sub, sub, C.byref(cp), bd)
             got = dst[b.dst_y:b.dst_y + h, b.dst_x:b.dst_x + w]
             assert np.array_equal(got, out), (bd, i, b.type, w, h, np.argwhere(got != out)[:4])
+
+
+def test_obmc_sad_variance(orc, ref):
+    """orc_obmc_block == svt_aom_obmc_sad{W}x{H}_c / svt_aom_obmc_variance{W}x{H}_c / svt_aom_obmc_sub_pixel_variance{W}x{H}_c for every block size;
+    wsrc / mask ranges as calc_target_weighted_pred produces them (mask <= 64 * 64, wsrc <= 255 * 4096) — /root/reference/test/OBMCSadTest.cc, OBMCVarianceTest.cc."""
+    rng = np.random.default_rng(808)
+    for (w, h) in cmc.SIZES:
+        for it in range(6):
+            pre = rng.integers(0, 256, (h + 2, w + 10)).astype(np.uint8)
+            mask = rng.integers(0, 4097, (h, w)).astype(np.int32)
+            wsrc = rng.integers(0, 255 * 4096 + 1, (h, w)).astype(np.int32)
+            if it == 1: pre[:] = 255; wsrc[:] = 0; mask[:] = 4096                 # largest differences
+            if it == 2: wsrc = (pre[:h, :w].astype(np.int32) * mask)              # zero difference
+            xo, yo = (0, 0) if it < 3 else (int(rng.integers(0, 8)), int(rng.integers(0, 8)))
+            out = np.zeros(3, np.uint32)
+            orc.orc_obmc_block(ptr(pre), pre.shape[1], ptr(wsrc), ptr(mask), w, h, xo, yo, ptr(out))
+            sad = getattr(ref, f"svt_aom_obmc_sad{w}x{h}_c")(ptr(pre), pre.shape[1], ptr(wsrc), ptr(mask))
+            sse = C.c_uint32(0)
+            if xo == 0 and yo == 0:
+                var = getattr(ref, f"svt_aom_obmc_variance{w}x{h}_c")(ptr(pre), pre.shape[1], ptr(wsrc), ptr(mask), C.byref(sse))
+                var2 = getattr(ref, f"svt_aom_obmc_sub_pixel_variance{w}x{h}_c")(ptr(pre), pre.shape[1], 0, 0, ptr(wsrc), ptr(mask), C.byref(sse))
+                assert (var & 0xFFFFFFFF) == (var2 & 0xFFFFFFFF)
+            else:
+                var = getattr(ref, f"svt_aom_obmc_sub_pixel_variance{w}x{h}_c")(ptr(pre), pre.shape[1], xo, yo, ptr(wsrc), ptr(mask), C.byref(sse))
+            assert (int(out[0]), int(out[1]), int(out[2])) == (sad & 0xFFFFFFFF, sse.value, var & 0xFFFFFFFF), (w, h, it, xo, yo)
