@@ -61,3 +61,5 @@ if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 for k, e in list(res.items())[:16]:
     print(f"{k[:44]:44s} n={e['launches']:3d} avg={e['avg_us']:8.1f}us fetch={e.get('fetch_bytes_per_launch', 0)/1e6:8.2f}MB write={e.get('write_bytes_per_launch', 0)/1e6:8.2f}MB")
+if os.path.exists(os.path.join(src, "extra_kernels.txt")):
+    shutil.copy(os.path.join(src, "extra_kernels.txt"), os.path.join(dst, "extra_kernels.txt"))
