@@ -434,6 +434,19 @@ typedef struct {
 int svt_hip_obmc_cost_batch_dev(SvtHipCtx *ctx, const uint8_t *d_pre, int pre_stride, const int32_t *d_wsrc, const int32_t *d_mask,
                                 const SvtHipObmcBlk *d_blks, int nblk, uint32_t *d_out);
 
+/* Warped (affine) prediction of a list of blocks of one plane: svt_av1_warp_affine / svt_av1_highbd_warp_affine (Common/Codec/EbWarpedMotion.c:577, :733),
+ * the non-compound path of svt_warp_plane / svt_highbd_warp_plane.  mat = EbWarpedMotionParams::wmmat[0..5], alpha .. delta = its shear
+ * parameters (svt_get_shear_params, :921, stays on the host); (p_col, p_row, p_width, p_height) = the block in the destination plane, sizes
+ * multiples of 8; width / height / stride describe the reference plane (samples outside are clamped to its edges, as in the reference). */
+typedef struct {
+    int32_t mat[6];
+    int16_t alpha, beta, gamma, delta;
+    int32_t p_col, p_row;
+    uint8_t p_width, p_height, reserved[2];
+} SvtHipWarpBlk;
+int svt_hip_warp_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int width, int height, int stride, void *d_dst,
+                                   int dst_stride, int ss_x, int ss_y, const SvtHipWarpBlk *d_blks, int nblk);
+
 #ifdef __cplusplus
 }
 #endif

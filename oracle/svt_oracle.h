@@ -213,6 +213,12 @@ void orc_compound_predict_batch(int pix_bytes, int bd, const void *ref0, int ref
 void orc_obmc_block(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, int w, int h, int xoffset, int yoffset, uint32_t out[3]);
 void orc_obmc_batch(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, const void *blks, int n, uint32_t *out);
 
+/* warped prediction (8(f) rank 4, warp_oracle.c) */
+void orc_warp_affine(const int32_t *mat, const void *ref, int pix_bytes, int bd, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                     int p_height, int p_stride, int ss_x, int ss_y, int alpha, int beta, int gamma, int delta);
+void orc_warp_predict_batch(int pix_bytes, int bd, const void *ref, int width, int height, int stride, void *dst, int dst_stride, int ss_x, int ss_y,
+                            const void *blks, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,3 +53,44 @@ def make_blocks(rng, W, H, n, mask_bytes):
             off += ms * (2 * h if b.mask_sub else h)
         assert off <= mask_bytes
     return blks, masks
+
+
+# ---------------------------------------------------------------- warped prediction
+class WarpBlk(C.Structure):
+    _fields_ = [("mat", C.c_int32 * 6), ("alpha", C.c_int16), ("beta", C.c_int16), ("gamma", C.c_int16), ("delta", C.c_int16),
+                ("p_col", C.c_int32), ("p_row", C.c_int32), ("p_width", C.c_uint8), ("p_height", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+assert C.sizeof(WarpBlk) == 44
+WARP_SIZES = [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (8, 16), (16, 8), (32, 16), (16, 32), (64, 32), (32, 64), (128, 64), (64, 128), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+def warp_model(rng, extreme=False):
+    """A model in the style of /root/reference/test/warp_filter_test_util.cc:47-110: random matrix around identity, shear parameters rounded to
+    multiples of 64 and inside is_affine_shear_allowed's bounds (4|a| + 7|b| < 2^16, 4|g| + 4|d| < 2^16)."""
+    while True:
+        lim = (1 << 13) - 64 if not extreme else 1 << 13
+        a, b, g, d = [int(rng.integers(-lim, lim + 1)) // 64 * 64 for _ in range(4)]
+        if extreme: a, b, g, d = [int(v) for v in rng.choice([-8192, 8192, -4096, 0, 4032], 4)]
+        if 4 * abs(a) + 7 * abs(b) >= (1 << 16) or 4 * abs(g) + 4 * abs(d) >= (1 << 16): continue
+        m2 = (1 << 16) + a; m3 = b
+        m4 = (g * m2) >> 16
+        m5 = (1 << 16) + d + (m3 * m4) // m2
+        m0, m1 = int(rng.integers(-(1 << 21), 1 << 21)), int(rng.integers(-(1 << 21), 1 << 21))
+        return [m0, m1, m2, m3, m4, m5], a, b, g, d
+
+
+def warp_blocks(rng, W, H, n):
+    cols = W // 128
+    assert n <= cols * (H // 128)
+    blks = (WarpBlk * n)()
+    for i in range(n):
+        mat, a, b, g, d = warp_model(rng, extreme=(i % 9 == 4))
+        if i % 7 == 0: mat[0] += 500 << 16        # far outside the plane: every sample clamps to the right edge
+        if i % 7 == 1: mat[1] -= 400 << 16        # ... to the top edge
+        w, h = WARP_SIZES[i % len(WARP_SIZES)]
+        bl = blks[i]
+        for k in range(6): bl.mat[k] = mat[k]
+        bl.alpha, bl.beta, bl.gamma, bl.delta = a, b, g, d
+        bl.p_col, bl.p_row, bl.p_width, bl.p_height = (i % cols) * 128, (i // cols) * 128, w, h
+    return blks

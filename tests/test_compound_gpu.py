@@ -70,3 +70,26 @@ def test_obmc_costs(hip, orc):
     hip.free(d_pre, d_w, d_m, d_b, d_o)
     assert np.array_equal(got, exp), np.argwhere(got != exp)[:6]
     assert exp.any() and hip.L.svt_hip_obmc_cost_batch_dev(hip.h, None, 0, None, None, None, 0, None) == 0
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_warp_blocks(hip, orc, bd, ss):
+    """svt_hip_warp_predict_batch_dev vs the oracle (pinned to svt_av1_[highbd_]warp_affine_c): block sizes 8..128, random and extreme shear,
+    models that move the block outside the plane (edge clamping), luma and 4:2:0 chroma sub-sampling."""
+    rng = np.random.default_rng(700 + bd + ss)
+    dt = np.uint8 if bd == 8 else np.uint16
+    W, H = 1152, 640
+    plane = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+    n = 40
+    blks = cmc.warp_blocks(rng, W, H, n)
+    exp = np.zeros((H, W), dt)
+    orc.orc_warp_predict_batch(plane.itemsize, bd, ptr(plane), W, H, W, ptr(exp), W, ss, ss, blks, n)
+    d_p, d_o, d_b = hip.to_device(plane), hip.to_device(np.zeros((H, W), dt)), hip.to_device(np.frombuffer(bytes(blks), np.uint8).copy())
+    hip.check(hip.L.svt_hip_warp_predict_batch_dev(hip.h, plane.itemsize, bd, d_p, W, H, W, d_o, W, ss, ss, d_b, n), "warp")
+    got = hip.to_host(d_o, (H, W), dt)
+    hip.free(d_p, d_o, d_b)
+    for i, b in enumerate(blks):
+        g, e = got[b.p_row:b.p_row + b.p_height, b.p_col:b.p_col + b.p_width], exp[b.p_row:b.p_row + b.p_height, b.p_col:b.p_col + b.p_width]
+        assert np.array_equal(g, e), (bd, ss, i, b.p_width, b.p_height, np.argwhere(g != e)[:4])
+    assert np.array_equal(got, exp) and exp.any()

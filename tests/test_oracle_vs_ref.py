@@ -718,3 +718,37 @@ def test_obmc_sad_variance(orc, ref):
             else:
                 var = getattr(ref, f"svt_aom_obmc_sub_pixel_variance{w}x{h}_c")(ptr(pre), pre.shape[1], xo, yo, ptr(wsrc), ptr(mask), C.byref(sse))
             assert (int(out[0]), int(out[1]), int(out[2])) == (sad & 0xFFFFFFFF, sse.value, var & 0xFFFFFFFF), (w, h, it, xo, yo)
+
+
+def test_warp_affine(orc, ref):
+    """orc_warp_affine == svt_av1_warp_affine_c / svt_av1_highbd_warp_affine_c (non-compound), models as /root/reference/test/warp_filter_test_util.cc,
+    including models that push the block outside the plane (edge clamping) and luma / 4:2:0 chroma sub-sampling."""
+    rng = np.random.default_rng(66)
+    W, H = 1024, 512
+    for bd, dt in ((8, np.uint8), (10, np.uint16), (12, np.uint16)):
+        plane = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+        n = 28
+        blks = cmc.warp_blocks(rng, W, H, n)
+        for ss in (0, 1):
+            for i, b in enumerate(blks):
+                w, h = b.p_width, b.p_height
+                a = np.zeros((h, w), dt); e = np.zeros((h, w), dt)
+                mat = (C.c_int32 * 8)(*list(b.mat), 0, 0)
+                cp = _ConvP(); cp.round_0 = 5 if bd == 12 else 3; cp.round_1 = 2 * 7 - cp.round_0
+                if bd == 8:
+                    ref.svt_av1_warp_affine_c(mat, ptr(plane), W, H, W, ptr(e), b.p_col, b.p_row, w, h, w, ss, ss, C.byref(cp), b.alpha, b.beta, b.gamma, b.delta)
+                else:
+                    ref.svt_av1_highbd_warp_affine_c(mat, ptr(plane), W, H, W, ptr(e), b.p_col, b.p_row, w, h, w, ss, ss, bd, C.byref(cp), b.alpha, b.beta, b.gamma, b.delta)
+                orc.orc_warp_affine(mat, ptr(plane), plane.itemsize, bd, W, H, W, ptr(a), b.p_col, b.p_row, w, h, w, ss, ss, b.alpha, b.beta, b.gamma, b.delta)
+                assert np.array_equal(a, e), (bd, ss, i, w, h, np.argwhere(a != e)[:4])
+
+
+def test_warp_filter_table_headers(ref):
+    """The generated Warped_Filters headers (HIP kernel and oracle) hold exactly the reference's eb_warped_filter."""
+    import os, re
+    from conftest import ROOT
+    want = [int(v) for row in (C.c_int16 * 8 * 193).in_dll(ref, "eb_warped_filter") for v in row]
+    for path in ("svt-av1_amd/csrc/warp_filter_table.h", "oracle/warp_filter_table.h"):
+        txt = open(os.path.join(ROOT, path)).read()
+        got = [int(v) for v in re.findall(r"-?\d+", txt[txt.index("#define SVT_WARPED_FILTER_TABLE"):])]
+        assert got == want, path
