@@ -108,7 +108,7 @@ def main():
 
     # ---------------------------------------------------------------- device-resident inputs / outputs
     d_cur_p, d_ref_p = T(F.cur_y_p), T(F.ref_y_p)
-    sbs = mc.windows(orc, W, H, 64, 64)
+    sbs = mc.windows_product(L, W, H, 64, 64)   # the product's own restatement of integer_search_sb's window clamp
     d_sbs = T(np.frombuffer(bytes(sbs), dtype=np.uint8).copy())
     d_sad = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)
     d_mv = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)

@@ -31,6 +31,17 @@ def windows(orc, width, height, sa_w, sa_h, centers=None):
     return arr
 
 
+def windows_product(L, width, height, sa_w, sa_h, centers=None):
+    """The same windows through the product's own host function (svt_hip_me_search_window, include/svt_hip.h): what a caller of the ABI uses."""
+    sbs = synth.sb_grid(width, height)
+    arr = (OrcSbSearch * len(sbs))()      # same record layout as SvtHipSbSearch
+    for i, (x, y) in enumerate(sbs):
+        cx, cy = centers[i] if centers is not None else (0, 0)
+        v = L.svt_hip_me_search_window(x, y, int(cx), int(cy), sa_w, sa_h, width, height)
+        arr[i] = OrcSbSearch(x, y, v.x_origin, v.y_origin, v.width, v.height)
+    return arr
+
+
 def oracle_frame(orc, cur_p, ref_p, stride, pad, sbs, sub_sad, begin=0, end=None):
     n = len(sbs)
     end = n if end is None else end
