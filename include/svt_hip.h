@@ -447,6 +447,18 @@ typedef struct {
 int svt_hip_warp_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int width, int height, int stride, void *d_dst,
                                    int dst_stride, int ss_x, int ss_y, const SvtHipWarpBlk *d_blks, int nblk);
 
+/* Pixel-domain mask blends of a list of blocks: svt_aom_[highbd_]blend_a64_mask (mode 0: 2-D mask at d_masks + mask_off with mask_stride, subw / subh = the
+ * mask is at twice the block's resolution in that direction), _hmask (mode 1: one mask value per column) and _vmask (mode 2: per row)
+ * (common_dsp_rtcd.h:75-90; Common/Codec/EbBlend_a64_mask.c:214-434) — the blends of OBMC (av1_build_obmc_inter_prediction with the
+ * av1_get_obmc_mask tables), inter-intra and pixel-domain masked compound.  d_dst may alias d_src0 (same stride), like the reference. */
+typedef struct {
+    int32_t src0_x, src0_y, src1_x, src1_y, dst_x, dst_y;
+    uint8_t w, h, mode, subw, subh, reserved[3];
+    int32_t mask_off, mask_stride;
+} SvtHipBlendBlk;
+int svt_hip_blend_a64_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_src0, int src0_stride, const void *d_src1, int src1_stride, void *d_dst,
+                                int dst_stride, const uint8_t *d_masks, const SvtHipBlendBlk *d_blks, int nblk);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,3 +296,35 @@ void orc_obmc_batch(const uint8_t *pre, int pre_stride, const int32_t *wsrc, con
         orc_obmc_block(pre + (ptrdiff_t)b[i].pre_y * pre_stride + b[i].pre_x, pre_stride, wsrc + b[i].wm_off, mask + b[i].wm_off, b[i].w, b[i].h, b[i].xoffset,
                        b[i].yoffset, out + 3 * i);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Pixel-domain mask blends: svt_aom_[highbd_]blend_a64_mask_c (Common/Codec/EbBlend_a64_mask.c:214-330; 2-D mask, the four
+ * sub-sampling combinations), svt_aom_[highbd_]blend_a64_vmask (:332-382; one mask value per row) and _hmask (:384-434; per column) — what OBMC
+ * (av1_build_obmc_inter_prediction), inter-intra and pixel-domain masked compound use.  dst may alias src0. */
+typedef struct {
+    int32_t src0_x, src0_y, src1_x, src1_y, dst_x, dst_y;
+    uint8_t w, h, mode, subw, subh, reserved[3];      /* mode 0: 2-D mask (mask_stride, subw, subh); 1: hmask; 2: vmask */
+    int32_t mask_off, mask_stride;
+} OrcBlendBlk;
+void orc_blend_a64_batch(int pix_bytes, const void *src0, int src0_stride, const void *src1, int src1_stride, void *dst, int dst_stride, const uint8_t *masks,
+                         const void *blks_, int n) {
+    const OrcBlendBlk *blks = (const OrcBlendBlk *)blks_;
+    for (int i = 0; i < n; i++) {
+        const OrcBlendBlk *b = &blks[i];
+        const uint8_t *mk = masks + b->mask_off;
+        const int ms = b->mask_stride;
+        for (int y = 0; y < b->h; y++)
+            for (int x = 0; x < b->w; x++) {
+                int m;
+                if (b->mode == 1) m = mk[x];
+                else if (b->mode == 2) m = mk[y];
+                else if (!b->subw && !b->subh) m = mk[y * ms + x];
+                else if (b->subw && b->subh) m = rp2(mk[(2 * y) * ms + 2 * x] + mk[(2 * y + 1) * ms + 2 * x] + mk[(2 * y) * ms + 2 * x + 1] + mk[(2 * y + 1) * ms + 2 * x + 1], 2);
+                else if (b->subw) m = rp2(mk[y * ms + 2 * x] + mk[y * ms + 2 * x + 1], 1);
+                else m = rp2(mk[(2 * y) * ms + x] + mk[(2 * y + 1) * ms + x], 1);
+                const int v0 = rdp(src0, pix_bytes, (ptrdiff_t)(b->src0_y + y) * src0_stride + b->src0_x + x);
+                const int v1 = rdp(src1, pix_bytes, (ptrdiff_t)(b->src1_y + y) * src1_stride + b->src1_x + x);
+                wrp(dst, pix_bytes, (ptrdiff_t)(b->dst_y + y) * dst_stride + b->dst_x + x, rp2(m * v0 + (64 - m) * v1, 6));
+            }
+    }
+}

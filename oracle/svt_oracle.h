@@ -219,6 +219,9 @@ void orc_warp_affine(const int32_t *mat, const void *ref, int pix_bytes, int bd,
 void orc_warp_predict_batch(int pix_bytes, int bd, const void *ref, int width, int height, int stride, void *dst, int dst_stride, int ss_x, int ss_y,
                             const void *blks, int n);
 
+void orc_blend_a64_batch(int pix_bytes, const void *src0, int src0_stride, const void *src1, int src1_stride, void *dst, int dst_stride, const uint8_t *masks,
+                         const void *blks, int n);
+
 #ifdef __cplusplus
 }
 #endif

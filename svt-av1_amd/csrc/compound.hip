@@ -151,6 +151,30 @@ obmc_cost_kernel(const uint8_t* __restrict__ pre, int pre_stride, const int32_t*
     }
 }
 
+
+// ---- pixel-domain mask blends: svt_aom_[highbd_]blend_a64_{mask,hmask,vmask} (Common/Codec/EbBlend_a64_mask.c:214-434): OBMC, inter-intra,
+// pixel-domain masked compound.  One workgroup per block, 256 threads stride over its samples.
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+blend_a64_kernel(const PIX* __restrict__ src0, int src0_stride, const PIX* __restrict__ src1, int src1_stride, PIX* __restrict__ dst, int dst_stride,
+                 const uint8_t* __restrict__ masks, const SvtHipBlendBlk* __restrict__ blks) {
+    const SvtHipBlendBlk b = blks[blockIdx.x];
+    const uint8_t* mk = masks + b.mask_off;
+    const int ms = b.mask_stride;
+    for (int i = threadIdx.x; i < b.w * b.h; i += 256) {
+        const int y = i / b.w, x = i - y * b.w;
+        int m;
+        if (b.mode == 1) m = mk[x];
+        else if (b.mode == 2) m = mk[y];
+        else if (!b.subw && !b.subh) m = mk[y * ms + x];
+        else if (b.subw && b.subh) m = rp2(mk[(2 * y) * ms + 2 * x] + mk[(2 * y + 1) * ms + 2 * x] + mk[(2 * y) * ms + 2 * x + 1] + mk[(2 * y + 1) * ms + 2 * x + 1], 2);
+        else if (b.subw) m = rp2(mk[y * ms + 2 * x] + mk[y * ms + 2 * x + 1], 1);
+        else m = rp2(mk[(2 * y) * ms + x] + mk[(2 * y + 1) * ms + x], 1);
+        const int v0 = src0[(ptrdiff_t)(b.src0_y + y) * src0_stride + b.src0_x + x], v1 = src1[(ptrdiff_t)(b.src1_y + y) * src1_stride + b.src1_x + x];
+        dst[(ptrdiff_t)(b.dst_y + y) * dst_stride + b.dst_x + x] = (PIX)rp2(m * v0 + (64 - m) * v1, 6);
+    }
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_compound_predict(hipStream_t st, int pix_bytes, int bd, const void* ref0, int ref0_stride, const void* ref1, int ref1_stride,
@@ -170,5 +194,15 @@ extern "C" int svt_hip_launch_obmc_cost(hipStream_t st, const uint8_t* pre, int 
                                         uint32_t* out) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(obmc_cost_kernel, dim3((n + 3) / 4), dim3(256), 0, st, pre, pre_stride, wsrc, mask, blks, n, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_blend_a64(hipStream_t st, int pix_bytes, const void* src0, int src0_stride, const void* src1, int src1_stride, void* dst, int dst_stride,
+                                        const uint8_t* masks, const SvtHipBlendBlk* blks, int n) {
+    if (n <= 0) return 0;
+    if (pix_bytes == 1) hipLaunchKernelGGL((blend_a64_kernel<uint8_t>), dim3(n), dim3(256), 0, st, (const uint8_t*)src0, src0_stride, (const uint8_t*)src1, src1_stride,
+                                           (uint8_t*)dst, dst_stride, masks, blks);
+    else hipLaunchKernelGGL((blend_a64_kernel<uint16_t>), dim3(n), dim3(256), 0, st, (const uint16_t*)src0, src0_stride, (const uint16_t*)src1, src1_stride, (uint16_t*)dst,
+                            dst_stride, masks, blks);
     return (int)hipGetLastError();
 }

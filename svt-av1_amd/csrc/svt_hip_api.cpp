@@ -642,4 +642,14 @@ int svt_hip_warp_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const vo
     return SVT_HIP_OK;
 }
 
+int svt_hip_blend_a64_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_src0, int src0_stride, const void* d_src1, int src1_stride, void* d_dst, int dst_stride,
+                                const uint8_t* d_masks, const SvtHipBlendBlk* d_blks, int nblk) {
+    if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
+    if (nblk == 0) return SVT_HIP_OK;
+    if (!d_src0 || !d_src1 || !d_dst || !d_masks || !d_blks) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_blend_a64(c->stream, pix_bytes, d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_masks, d_blks, nblk);
+    if (e != hipSuccess) return fail(c, e, "blend_a64 launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

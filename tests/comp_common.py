@@ -94,3 +94,40 @@ def warp_blocks(rng, W, H, n):
         bl.alpha, bl.beta, bl.gamma, bl.delta = a, b, g, d
         bl.p_col, bl.p_row, bl.p_width, bl.p_height = (i % cols) * 128, (i // cols) * 128, w, h
     return blks
+
+
+# ---------------------------------------------------------------- pixel-domain mask blends
+class BlendBlk(C.Structure):
+    _fields_ = [("src0_x", C.c_int32), ("src0_y", C.c_int32), ("src1_x", C.c_int32), ("src1_y", C.c_int32), ("dst_x", C.c_int32), ("dst_y", C.c_int32),
+                ("w", C.c_uint8), ("h", C.c_uint8), ("mode", C.c_uint8), ("subw", C.c_uint8), ("subh", C.c_uint8), ("reserved", C.c_uint8 * 3),
+                ("mask_off", C.c_int32), ("mask_stride", C.c_int32)]
+
+
+assert C.sizeof(BlendBlk) == 40
+BLEND_SIZES = [(1, 1), (2, 2), (4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (2, 8), (8, 2), (4, 16), (16, 4), (64, 8), (8, 64), (128, 32), (32, 128), (1, 16), (16, 1)]
+
+
+def blend_blocks(rng, W, H, n, mask_bytes):
+    cols = W // 128
+    assert n <= cols * (H // 128)
+    blks = (BlendBlk * n)()
+    masks = rng.integers(0, 65, mask_bytes).astype(np.uint8)
+    masks[:300] = 64; masks[300:600] = 0
+    off = 0
+    for i in range(n):
+        w, h = BLEND_SIZES[i % len(BLEND_SIZES)]
+        b = blks[i]
+        cx, cy = (i % cols) * 128, (i // cols) * 128
+        b.dst_x, b.dst_y, b.w, b.h = cx, cy, w, h
+        b.src0_x, b.src0_y = (cx, cy) if i % 4 == 0 else (int(rng.integers(0, W - 128)), int(rng.integers(0, H - 128)))    # i % 4 == 0: in place (dst == src0)
+        b.src1_x, b.src1_y = int(rng.integers(0, W - 128)), int(rng.integers(0, H - 128))
+        b.mode = i % 3
+        b.subw, b.subh = ((i // 3) & 1, (i // 6) & 1) if b.mode == 0 and max(w, h) <= 64 else (0, 0)
+        if b.mode == 0:
+            b.mask_stride = (w << b.subw) + int(rng.integers(0, 5))
+            need = b.mask_stride * (h << b.subh)
+        else:
+            b.mask_stride, need = 0, (w if b.mode == 1 else h)
+        b.mask_off = off; off += need
+        assert off <= mask_bytes
+    return blks, masks

@@ -93,3 +93,24 @@ def test_warp_blocks(hip, orc, bd, ss):
         g, e = got[b.p_row:b.p_row + b.p_height, b.p_col:b.p_col + b.p_width], exp[b.p_row:b.p_row + b.p_height, b.p_col:b.p_col + b.p_width]
         assert np.array_equal(g, e), (bd, ss, i, b.p_width, b.p_height, np.argwhere(g != e)[:4])
     assert np.array_equal(got, exp) and exp.any()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_blend_a64(hip, orc, bd):
+    """svt_hip_blend_a64_batch_dev vs the oracle (pinned to svt_aom_[highbd_]blend_a64_{mask,hmask,vmask}_c), incl. blocks blended in place."""
+    rng = np.random.default_rng(900 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    W, H = 1024, 768
+    a = rng.integers(0, 1 << bd, (H, W)).astype(dt); b1 = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+    n = 48
+    blks, masks = cmc.blend_blocks(rng, W, H, n, 1 << 19)
+    # in-place blocks read their own destination; keep every other block's sources away from all destinations so that block order cannot matter
+    for b in blks:
+        if (b.src0_x, b.src0_y) != (b.dst_x, b.dst_y): b.src0_x, b.src0_y = b.dst_x, b.dst_y
+    exp = a.copy()
+    orc.orc_blend_a64_batch(a.itemsize, ptr(exp), W, ptr(b1), W, ptr(exp), W, ptr(masks), blks, n)
+    d_a, d_b, d_m, d_k = hip.to_device(a), hip.to_device(b1), hip.to_device(masks), hip.to_device(np.frombuffer(bytes(blks), np.uint8).copy())
+    hip.check(hip.L.svt_hip_blend_a64_batch_dev(hip.h, a.itemsize, d_a, W, d_b, W, d_a, W, d_m, d_k, n), "blend")
+    got = hip.to_host(d_a, (H, W), dt)
+    hip.free(d_a, d_b, d_m, d_k)
+    assert np.array_equal(got, exp) and (exp != a).any()

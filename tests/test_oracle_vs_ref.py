@@ -752,3 +752,32 @@ def test_warp_filter_table_headers(ref):
         txt = open(os.path.join(ROOT, path)).read()
         got = [int(v) for v in re.findall(r"-?\d+", txt[txt.index("#define SVT_WARPED_FILTER_TABLE"):])]
         assert got == want, path
+
+
+def test_blend_a64_masks(orc, ref):
+    """orc_blend_a64_batch == svt_aom_[highbd_]blend_a64_{mask,hmask,vmask}_c (/root/reference/test/BlendA64MaskTest.cc sizes 1..128, masks 0..64,
+    the four mask sub-sampling combinations, in-place destination)."""
+    rng = np.random.default_rng(123)
+    W, H = 768, 640
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        a = rng.integers(0, 1 << bd, (H, W)).astype(dt); b1 = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+        n = 30
+        blks, masks = cmc.blend_blocks(rng, W, H, n, 1 << 18)
+        out = a.copy()                      # dst plane = src0 plane, so that the "in place" blocks really alias
+        orc.orc_blend_a64_batch(a.itemsize, ptr(out), W, ptr(b1), W, ptr(out), W, ptr(masks), blks, n)
+        run = a.copy()                      # the same sequence through the reference functions, block by block
+        for i, b in enumerate(blks):
+            w, h = b.w, b.h
+            s0 = np.ascontiguousarray(run[b.src0_y:b.src0_y + h, b.src0_x:b.src0_x + w]); s1 = np.ascontiguousarray(b1[b.src1_y:b.src1_y + h, b.src1_x:b.src1_x + w])
+            e = np.zeros((h, w), dt)
+            mp = C.c_void_p(masks.ctypes.data + b.mask_off)
+            if bd == 8:
+                if b.mode == 0: ref.svt_aom_blend_a64_mask_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, b.mask_stride, w, h, int(b.subw), int(b.subh))
+                elif b.mode == 1: ref.svt_aom_blend_a64_hmask_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, w, h)
+                else: ref.svt_aom_blend_a64_vmask_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, w, h)
+            else:
+                if b.mode == 0: ref.svt_aom_highbd_blend_a64_mask_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, b.mask_stride, w, h, int(b.subw), int(b.subh), bd)
+                elif b.mode == 1: ref.svt_aom_highbd_blend_a64_hmask_8bit_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, w, h, bd)
+                else: ref.svt_aom_highbd_blend_a64_vmask_8bit_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, w, h, bd)
+            run[b.dst_y:b.dst_y + h, b.dst_x:b.dst_x + w] = e
+        assert np.array_equal(out, run) and (out != a).any(), bd
