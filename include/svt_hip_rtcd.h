@@ -64,6 +64,30 @@ typedef void (*SvtHipSgrFilterFn)(const uint8_t *dgd8, int32_t width, int32_t he
 typedef void (*SvtHipSgrApplyFn)(const uint8_t *dat, int32_t width, int32_t height, int32_t stride, int32_t eps, const int32_t *xqd,
                                  uint8_t *dst, int32_t dst_stride, int32_t *tmpbuf, int32_t bit_depth, int32_t highbd);
 
+typedef unsigned (*SvtHipObmcSadFn)(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask);
+typedef unsigned (*SvtHipObmcVarFn)(const uint8_t *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, unsigned *sse);
+typedef unsigned (*SvtHipObmcSubpixVarFn)(const uint8_t *pre, int pre_stride, int xoffset, int yoffset, const int32_t *wsrc, const int32_t *mask,
+                                          unsigned *sse);
+typedef void (*SvtHipBlendMaskFn)(uint8_t *dst, uint32_t dst_stride, const uint8_t *src0, uint32_t src0_stride, const uint8_t *src1,
+                                  uint32_t src1_stride, const uint8_t *mask, uint32_t mask_stride, int w, int h, int subw, int subh);
+typedef void (*SvtHipBlendHVMaskFn)(uint8_t *dst, uint32_t dst_stride, const uint8_t *src0, uint32_t src0_stride, const uint8_t *src1,
+                                    uint32_t src1_stride, const uint8_t *mask, int w, int h);
+typedef void (*SvtHipHbdBlendMaskFn)(uint8_t *dst, uint32_t dst_stride, const uint8_t *src0, uint32_t src0_stride, const uint8_t *src1,
+                                     uint32_t src1_stride, const uint8_t *mask, uint32_t mask_stride, int w, int h, int subw, int subh, int bd);
+typedef void (*SvtHipHbdBlendHVMaskFn)(uint8_t *dst, uint32_t dst_stride, const uint8_t *src0, uint32_t src0_stride, const uint8_t *src1,
+                                       uint32_t src1_stride, const uint8_t *mask, int w, int h, int bd);
+typedef void (*SvtHipWarpAffineFn)(const int32_t *mat, const uint8_t *ref, int width, int height, int stride, uint8_t *pred, int p_col, int p_row,
+                                   int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y,
+                                   SvtHipConvolveParams *conv_params, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta);
+typedef void (*SvtHipHbdWarpAffineFn)(const int32_t *mat, const uint16_t *ref, int width, int height, int stride, uint16_t *pred, int p_col,
+                                      int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd,
+                                      SvtHipConvolveParams *conv_params, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta);
+typedef void (*SvtHipComputeStatsFn)(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
+                                     int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H);
+typedef void (*SvtHipHbdComputeStatsFn)(int32_t wiener_win, const uint8_t *dgd8, const uint8_t *src8, int32_t h_start, int32_t h_end,
+                                        int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
+                                        int32_t bit_depth /* AomBitDepth */);
+
 /* The 22 block sizes of svt_aom_sad{W}x{H} / svt_aom_variance{W}x{H} in BlockSize order
  * (aom_dsp_rtcd.h:334-336, :524): index = position in this list. */
 #define SVT_HIP_RTCD_BLOCK_SIZES(X) /* X(index, W, H) */ \
@@ -88,6 +112,18 @@ typedef struct SvtHipRtcd {
     SvtHipInvTxfmRect4Fn  svt_av1_inv_txfm2d_add_rect4;     /* :145-154: 4x8, 8x4, 4x16, 16x4 (tx_size argument, no eob) */
     SvtHipSgrFilterFn     svt_av1_selfguided_restoration;   /* :191 */
     SvtHipSgrApplyFn      svt_apply_selfguided_restoration; /* :187 */
+    /* --- SURVEY 8(f) rows (members added at the end: older tables stay layout-compatible) */
+    SvtHipObmcSadFn        svt_aom_obmc_sad[22];                 /* aom_dsp_rtcd.h:356-398, SVT_HIP_RTCD_BLOCK_SIZES order */
+    SvtHipObmcVarFn        svt_aom_obmc_variance[22];            /* :443-... */
+    SvtHipObmcSubpixVarFn  svt_aom_obmc_sub_pixel_variance[22];  /* :399-... */
+    SvtHipBlendMaskFn      svt_aom_blend_a64_mask;               /* common_dsp_rtcd.h:73 */
+    SvtHipBlendHVMaskFn    svt_aom_blend_a64_hmask, svt_aom_blend_a64_vmask;                           /* :75, :77 */
+    SvtHipHbdBlendMaskFn   svt_aom_highbd_blend_a64_mask;        /* uint8_t* arguments carry uint16_t* (no CONVERT_TO_SHORTPTR: EbBlend_a64_mask.c:275) */
+    SvtHipHbdBlendHVMaskFn svt_aom_highbd_blend_a64_hmask_8bit, svt_aom_highbd_blend_a64_vmask_8bit;   /* :78-80 */
+    SvtHipWarpAffineFn     svt_av1_warp_affine;                  /* non-compound calls; compound ones go to the saved pointer */
+    SvtHipHbdWarpAffineFn  svt_av1_highbd_warp_affine;
+    SvtHipComputeStatsFn   svt_av1_compute_stats;                /* aom_dsp_rtcd.h:99 */
+    SvtHipHbdComputeStatsFn svt_av1_compute_stats_highbd;        /* :103 */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

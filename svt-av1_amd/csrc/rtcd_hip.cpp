@@ -18,7 +18,7 @@ SvtHipRtcd  g_c;                 // the pointers that were installed before us (
 const int16_t h_interp[6][16][8] = SVT_HIP_INTERP_TABLE;
 
 struct Slot { void* p = nullptr; size_t cap = 0; };
-Slot g_slot[6];
+Slot g_slot[8];
 
 void* dev(int i, size_t bytes) {   // device scratch, grown on demand (called with g_mu held)
     Slot& s = g_slot[i];
@@ -266,6 +266,148 @@ void sgr_apply_hip(const uint8_t* dat8, int32_t w, int32_t h, int32_t stride, in
     FALLBACK("svt_apply_selfguided_restoration", svt_apply_selfguided_restoration, dat8, w, h, stride, eps, xqd, dst8, dst_stride, tmpbuf, bd, highbd);
 }
 
+// ----------------------------------------------------------------------------------- OBMC costs
+bool obmc_generic(const uint8_t* pre, int pre_stride, const int32_t* wsrc, const int32_t* mask, int w, int h, int xo, int yo, uint32_t res[3]) {
+    if (!g_ctx) return false;
+    const size_t pp = rup((size_t)w + 1, 4);
+    uint8_t* d_pre = (uint8_t*)dev(0, pp * (h + 1) + 64); int32_t* d_w = (int32_t*)dev(1, (size_t)w * h * 4); int32_t* d_m = (int32_t*)dev(2, (size_t)w * h * 4);
+    void* d_job = dev(3, sizeof(SvtHipObmcBlk)); uint32_t* d_out = (uint32_t*)dev(4, 16);
+    if (!d_pre || !d_w || !d_m || !d_job || !d_out) return false;
+    SvtHipObmcBlk job = {0, 0, (uint8_t)w, (uint8_t)h, (uint8_t)xo, (uint8_t)yo, 0};
+    // the sub-pixel variance reads one extra column / row (the 2-tap bilinear passes); the plain functions must not touch them
+    const int ew = (xo || yo) ? w + 1 : w, eh = (xo || yo) ? h + 1 : h;
+    return hipMemsetAsync(d_pre, 0, pp * (h + 1), stream()) == hipSuccess && up2d(d_pre, pp, pre, (size_t)pre_stride, (size_t)ew, eh) && up(d_w, wsrc, (size_t)w * h * 4) &&
+           up(d_m, mask, (size_t)w * h * 4) && up(d_job, &job, sizeof(job)) &&
+           svt_hip_obmc_cost_batch_dev(g_ctx, d_pre, (int)pp, d_w, d_m, (const SvtHipObmcBlk*)d_job, 1, d_out) == 0 && down(res, d_out, 12);
+}
+template <int IDX, int W, int H> unsigned obmc_sad_hip(const uint8_t* pre, int ps, const int32_t* wsrc, const int32_t* mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t r[3];
+    if (obmc_generic(pre, ps, wsrc, mask, W, H, 0, 0, r)) return r[0];
+    FALLBACK("svt_aom_obmc_sadWxH", svt_aom_obmc_sad[IDX], pre, ps, wsrc, mask);
+}
+template <int IDX, int W, int H> unsigned obmc_var_hip(const uint8_t* pre, int ps, const int32_t* wsrc, const int32_t* mask, unsigned* sse) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t r[3];
+    if (obmc_generic(pre, ps, wsrc, mask, W, H, 0, 0, r)) { *sse = r[1]; return r[2]; }
+    FALLBACK("svt_aom_obmc_varianceWxH", svt_aom_obmc_variance[IDX], pre, ps, wsrc, mask, sse);
+}
+template <int IDX, int W, int H> unsigned obmc_subvar_hip(const uint8_t* pre, int ps, int xo, int yo, const int32_t* wsrc, const int32_t* mask, unsigned* sse) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t r[3];
+    if (xo >= 0 && xo < 8 && yo >= 0 && yo < 8 && obmc_generic(pre, ps, wsrc, mask, W, H, xo, yo, r)) { *sse = r[1]; return r[2]; }
+    FALLBACK("svt_aom_obmc_sub_pixel_varianceWxH", svt_aom_obmc_sub_pixel_variance[IDX], pre, ps, xo, yo, wsrc, mask, sse);
+}
+
+// ----------------------------------------------------------------------------------- pixel-domain blends
+bool blend_generic(int pix_bytes, void* dst, int dst_stride, const void* s0, int s0_stride, const void* s1, int s1_stride, const uint8_t* mask, int mask_stride, int w, int h,
+                   int mode, int subw, int subh) {
+    if (!g_ctx || w < 1 || h < 1 || w > 128 || h > 128) return false;
+    const size_t p = rup((size_t)w * pix_bytes, 4);
+    const int mw = mode == 0 ? (w << subw) : (mode == 1 ? w : h), mh = mode == 0 ? (h << subh) : 1;
+    const size_t mp = rup((size_t)mw, 4);
+    uint8_t *d0 = (uint8_t*)dev(0, p * h), *d1 = (uint8_t*)dev(1, p * h), *dd = (uint8_t*)dev(2, p * h), *dm = (uint8_t*)dev(3, mp * mh);
+    void* d_job = dev(4, sizeof(SvtHipBlendBlk));
+    if (!d0 || !d1 || !dd || !dm || !d_job) return false;
+    SvtHipBlendBlk job = {0, 0, 0, 0, 0, 0, (uint8_t)w, (uint8_t)h, (uint8_t)mode, (uint8_t)subw, (uint8_t)subh, {0, 0, 0}, 0, (int32_t)mp};
+    return up2d(d0, p, s0, (size_t)s0_stride * pix_bytes, (size_t)w * pix_bytes, h) && up2d(d1, p, s1, (size_t)s1_stride * pix_bytes, (size_t)w * pix_bytes, h) &&
+           up2d(dm, mp, mask, mode == 0 ? (size_t)mask_stride : (size_t)mw, (size_t)mw, mh) && up(d_job, &job, sizeof(job)) &&
+           svt_hip_blend_a64_batch_dev(g_ctx, pix_bytes, d0, (int)(p / pix_bytes), d1, (int)(p / pix_bytes), dd, (int)(p / pix_bytes), dm, (const SvtHipBlendBlk*)d_job, 1) == 0 &&
+           down2d(dst, (size_t)dst_stride * pix_bytes, dd, p, (size_t)w * pix_bytes, h);
+}
+void blend_mask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, (int)ms, w, h, 0, subw, subh)) return;
+    FALLBACK("svt_aom_blend_a64_mask", svt_aom_blend_a64_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh);
+}
+void blend_hmask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 1, 0, 0)) return;
+    FALLBACK("svt_aom_blend_a64_hmask", svt_aom_blend_a64_hmask, dst, ds, s0, s0s, s1, s1s, mask, w, h);
+}
+void blend_vmask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 2, 0, 0)) return;
+    FALLBACK("svt_aom_blend_a64_vmask", svt_aom_blend_a64_vmask, dst, ds, s0, s0s, s1, s1s, mask, w, h);
+}
+void blend_mask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh, int bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, (int)ms, w, h, 0, subw, subh)) return;
+    FALLBACK("svt_aom_highbd_blend_a64_mask", svt_aom_highbd_blend_a64_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, bd);
+}
+void blend_hmask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h, int bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 1, 0, 0)) return;
+    FALLBACK("svt_aom_highbd_blend_a64_hmask_8bit", svt_aom_highbd_blend_a64_hmask_8bit, dst, ds, s0, s0s, s1, s1s, mask, w, h, bd);
+}
+void blend_vmask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h, int bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 2, 0, 0)) return;
+    FALLBACK("svt_aom_highbd_blend_a64_vmask_8bit", svt_aom_highbd_blend_a64_vmask_8bit, dst, ds, s0, s0s, s1, s1s, mask, w, h, bd);
+}
+
+// ----------------------------------------------------------------------------------- warped prediction
+bool warp_generic(int pix_bytes, int bd, const int32_t* mat, const void* ref, int width, int height, int stride, void* pred, int p_col, int p_row, int p_width, int p_height,
+                  int p_stride, int ss_x, int ss_y, const SvtHipConvolveParams* cp, int alpha, int beta, int gamma, int delta) {
+    if (!g_ctx || (cp && (cp->is_compound || cp->do_average)) || p_width < 8 || p_height < 8 || p_width > 128 || p_height > 128 || (p_width & 7) || (p_height & 7) ||
+        ss_x != ss_y || width <= 0 || height <= 0)
+        return false;
+    // the whole reference plane is uploaded (the model decides which part is read); a production caller keeps it resident and uses the batched entry
+    const size_t rp = rup((size_t)width * pix_bytes, 4), dp = rup((size_t)p_width * pix_bytes, 4);
+    uint8_t* d_ref = (uint8_t*)dev(5, rp * height); uint8_t* d_dst = (uint8_t*)dev(1, dp * p_height); void* d_job = dev(2, sizeof(SvtHipWarpBlk));
+    if (!d_ref || !d_dst || !d_job) return false;
+    SvtHipWarpBlk job;
+    for (int i = 0; i < 6; i++) job.mat[i] = mat[i];
+    job.alpha = (int16_t)alpha; job.beta = (int16_t)beta; job.gamma = (int16_t)gamma; job.delta = (int16_t)delta;
+    job.p_col = p_col; job.p_row = p_row; job.p_width = (uint8_t)p_width; job.p_height = (uint8_t)p_height; job.reserved[0] = job.reserved[1] = 0;
+    // destination pointer is biased so that (p_col, p_row) of the "plane" is element 0 of the packed block buffer
+    uint8_t* d_plane0 = d_dst - ((ptrdiff_t)p_row * (ptrdiff_t)(dp / pix_bytes) + p_col) * pix_bytes;
+    return up2d(d_ref, rp, ref, (size_t)stride * pix_bytes, (size_t)width * pix_bytes, height) && up(d_job, &job, sizeof(job)) &&
+           svt_hip_warp_predict_batch_dev(g_ctx, pix_bytes, bd, d_ref, width, height, (int)(rp / pix_bytes), d_plane0, (int)(dp / pix_bytes), ss_x, ss_y, (const SvtHipWarpBlk*)d_job, 1) == 0 &&
+           down2d(pred, (size_t)p_stride * pix_bytes, d_dst, dp, (size_t)p_width * pix_bytes, p_height);
+}
+void warp_hip(const int32_t* mat, const uint8_t* ref, int width, int height, int stride, uint8_t* pred, int p_col, int p_row, int p_width, int p_height, int p_stride, int ssx,
+              int ssy, SvtHipConvolveParams* cp, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (warp_generic(1, 8, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta)) return;
+    FALLBACK("svt_av1_warp_affine", svt_av1_warp_affine, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta);
+}
+void warp_hbd_hip(const int32_t* mat, const uint16_t* ref, int width, int height, int stride, uint16_t* pred, int p_col, int p_row, int p_width, int p_height, int p_stride,
+                  int ssx, int ssy, int bd, SvtHipConvolveParams* cp, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((bd == 8 || bd == 10 || bd == 12) && warp_generic(2, bd, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta)) return;
+    FALLBACK("svt_av1_highbd_warp_affine", svt_av1_highbd_warp_affine, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, bd, cp, alpha, beta, gamma, delta);
+}
+
+// ----------------------------------------------------------------------------------- Wiener statistics of one unit rectangle
+bool stats_generic(int pix_bytes, int bd, int win, const void* dgd, const void* src, int h0, int h1, int v0, int v1, int dgd_stride, int src_stride, int64_t* M, int64_t* H) {
+    const int w = h1 - h0, h = v1 - v0;
+    if (!g_ctx || (win != 7 && win != 5 && win != 3) || w < 1 || h < 1 || w > 383 || h > 383) return false;   // one restoration unit of size 256 spans at most 383 samples
+    // the rectangle becomes a one-unit "plane" (unit size 256 covers up to 384 samples), extended by 3 samples read from the caller's picture
+    const size_t dp = rup((size_t)(w + 6) * pix_bytes, 4), sp = rup((size_t)w * pix_bytes, 4);
+    const int w2 = win * win;
+    uint8_t* d_d = (uint8_t*)dev(5, dp * (h + 6) + 64); uint8_t* d_s = (uint8_t*)dev(1, sp * h + 64); int64_t* d_M = (int64_t*)dev(6, (size_t)w2 * 8); int64_t* d_H = (int64_t*)dev(7, (size_t)w2 * w2 * 8);
+    if (!d_d || !d_s || !d_M || !d_H) return false;
+    const uint8_t* dg = (const uint8_t*)dgd + ((ptrdiff_t)(v0 - 3) * dgd_stride + (h0 - 3)) * pix_bytes;
+    const uint8_t* sr = (const uint8_t*)src + ((ptrdiff_t)v0 * src_stride + h0) * pix_bytes;
+    // unit rows start 8 above a multiple of the unit size in a plane; a single unit covering the whole "plane" needs ss_y such that voff does not split it:
+    // with ph <= 1.5 * unit the plane has exactly one unit row, whatever the offset
+    return up2d(d_d, dp, dg, (size_t)dgd_stride * pix_bytes, (size_t)(w + 6) * pix_bytes, h + 6) && up2d(d_s, sp, sr, (size_t)src_stride * pix_bytes, (size_t)w * pix_bytes, h) &&
+           svt_hip_wiener_stats_plane_dev(g_ctx, pix_bytes, bd, win, d_d + 3 * dp + 3 * pix_bytes, (int)(dp / pix_bytes), d_s, (int)(sp / pix_bytes), w, h, 256, 0, d_M, d_H) == 0 &&
+           down(M, d_M, (size_t)w2 * 8) && down(H, d_H, (size_t)w2 * w2 * 8);
+}
+void stats_hip(int32_t win, const uint8_t* dgd, const uint8_t* src, int32_t h0, int32_t h1, int32_t v0, int32_t v1, int32_t ds, int32_t ss, int64_t* M, int64_t* H) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (stats_generic(1, 8, win, dgd, src, h0, h1, v0, v1, ds, ss, M, H)) return;
+    FALLBACK("svt_av1_compute_stats", svt_av1_compute_stats, win, dgd, src, h0, h1, v0, v1, ds, ss, M, H);
+}
+void stats_hbd_hip(int32_t win, const uint8_t* dgd8, const uint8_t* src8, int32_t h0, int32_t h1, int32_t v0, int32_t v1, int32_t ds, int32_t ss, int64_t* M, int64_t* H, int32_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((bd == 8 || bd == 10 || bd == 12) &&
+        stats_generic(2, bd, win, (const void*)((uintptr_t)dgd8 << 1), (const void*)((uintptr_t)src8 << 1), h0, h1, v0, v1, ds, ss, M, H)) return;
+    FALLBACK("svt_av1_compute_stats_highbd", svt_av1_compute_stats_highbd, win, dgd8, src8, h0, h1, v0, v1, ds, ss, M, H, bd);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -290,5 +432,12 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_av1_inv_txfm2d_add_rect4 = inv_rect4_hip;
     t->svt_av1_selfguided_restoration = sgr_filter_hip;
     t->svt_apply_selfguided_restoration = sgr_apply_hip;
+#define X(I, W, H) t->svt_aom_obmc_sad[I] = obmc_sad_hip<I, W, H>; t->svt_aom_obmc_variance[I] = obmc_var_hip<I, W, H>; t->svt_aom_obmc_sub_pixel_variance[I] = obmc_subvar_hip<I, W, H>;
+    SVT_HIP_RTCD_BLOCK_SIZES(X)
+#undef X
+    t->svt_aom_blend_a64_mask = blend_mask_hip; t->svt_aom_blend_a64_hmask = blend_hmask_hip; t->svt_aom_blend_a64_vmask = blend_vmask_hip;
+    t->svt_aom_highbd_blend_a64_mask = blend_mask_hbd_hip; t->svt_aom_highbd_blend_a64_hmask_8bit = blend_hmask_hbd_hip; t->svt_aom_highbd_blend_a64_vmask_8bit = blend_vmask_hbd_hip;
+    t->svt_av1_warp_affine = warp_hip; t->svt_av1_highbd_warp_affine = warp_hbd_hip;
+    t->svt_av1_compute_stats = stats_hip; t->svt_av1_compute_stats_highbd = stats_hbd_hip;
     return SVT_HIP_OK;
 }

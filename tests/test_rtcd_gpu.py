@@ -44,6 +44,19 @@ INVR = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_uint8, C.c_uint8,
 INVR4 = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32)
 SGRF = C.CFUNCTYPE(None, VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
 SGRA = C.CFUNCTYPE(None, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32, VP, C.c_int32, C.c_int32)
+OBSAD = C.CFUNCTYPE(C.c_uint, VP, C.c_int, VP, VP)
+OBVAR = C.CFUNCTYPE(C.c_uint, VP, C.c_int, VP, VP, C.POINTER(C.c_uint))
+OBSUB = C.CFUNCTYPE(C.c_uint, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.POINTER(C.c_uint))
+BLM = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int)
+BLHV = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_int, C.c_int)
+BLMH = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+BLHVH = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_int, C.c_int, C.c_int)
+WARP = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvParams),
+                   C.c_int16, C.c_int16, C.c_int16, C.c_int16)
+WARPH = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvParams),
+                    C.c_int16, C.c_int16, C.c_int16, C.c_int16)
+STATS = C.CFUNCTYPE(None, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP)
+STATSH = C.CFUNCTYPE(None, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32)
 
 
 class Rtcd(C.Structure):
@@ -53,7 +66,11 @@ class Rtcd(C.Structure):
                 ("svt_av1_highbd_convolve_2d_sr", CONVH), ("svt_av1_highbd_convolve_x_sr", CONVH), ("svt_av1_highbd_convolve_y_sr", CONVH),
                 ("svt_av1_highbd_convolve_2d_copy_sr", CONVH),
                 ("svt_av1_fwd_txfm2d", FWDF * 14), ("svt_av1_inv_txfm2d_add_sq", INVSQ * 5), ("svt_av1_inv_txfm2d_add_rect", INVR),
-                ("svt_av1_inv_txfm2d_add_rect4", INVR4), ("svt_av1_selfguided_restoration", SGRF), ("svt_apply_selfguided_restoration", SGRA)]
+                ("svt_av1_inv_txfm2d_add_rect4", INVR4), ("svt_av1_selfguided_restoration", SGRF), ("svt_apply_selfguided_restoration", SGRA),
+                ("svt_aom_obmc_sad", OBSAD * 22), ("svt_aom_obmc_variance", OBVAR * 22), ("svt_aom_obmc_sub_pixel_variance", OBSUB * 22),
+                ("svt_aom_blend_a64_mask", BLM), ("svt_aom_blend_a64_hmask", BLHV), ("svt_aom_blend_a64_vmask", BLHV),
+                ("svt_aom_highbd_blend_a64_mask", BLMH), ("svt_aom_highbd_blend_a64_hmask_8bit", BLHVH), ("svt_aom_highbd_blend_a64_vmask_8bit", BLHVH),
+                ("svt_av1_warp_affine", WARP), ("svt_av1_highbd_warp_affine", WARPH), ("svt_av1_compute_stats", STATS), ("svt_av1_compute_stats_highbd", STATSH)]
 
 
 @pytest.fixture(scope="module")
@@ -218,3 +235,64 @@ def test_wrappers_vs_reference_c(rtcd, ref):
         ref.svt_apply_selfguided_restoration_c(C.c_void_p(p), 64, 56, 100, ep, ptr(xqd), ptr(ed), 64, ptr(tmp), 8, 0)
         rtcd.svt_apply_selfguided_restoration(p, 64, 56, 100, ep, xqd.ctypes.data, gd.ctypes.data, 64, None, 8, 0)
         assert np.array_equal(ed, gd), ("sgr apply", ep)
+
+
+def test_next_row_wrappers(rtcd, orc):
+    """The wrappers of the SURVEY 8(f) kernels (OBMC costs, pixel-domain blends, warped prediction, Wiener statistics of one unit), called with the
+    reference's RTCD signatures on host buffers, vs the oracle."""
+    import comp_common as cmc
+    rng = np.random.default_rng(21)
+    # ---- OBMC
+    for idx, (w, h) in enumerate(SIZES):
+        pre = rng.integers(0, 256, (h + 3, w + 9)).astype(np.uint8)
+        wsrc = rng.integers(0, 255 * 4096 + 1, (h, w)).astype(np.int32); mask = rng.integers(0, 4097, (h, w)).astype(np.int32)
+        xo, yo = int(rng.integers(1, 8)), int(rng.integers(0, 8))
+        e0, e1 = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+        orc.orc_obmc_block(ptr(pre), pre.shape[1], ptr(wsrc), ptr(mask), w, h, 0, 0, ptr(e0)); orc.orc_obmc_block(ptr(pre), pre.shape[1], ptr(wsrc), ptr(mask), w, h, xo, yo, ptr(e1))
+        sse = C.c_uint(0)
+        assert rtcd.svt_aom_obmc_sad[idx](pre.ctypes.data, pre.shape[1], wsrc.ctypes.data, mask.ctypes.data) == int(e0[0]), (w, h)
+        assert rtcd.svt_aom_obmc_variance[idx](pre.ctypes.data, pre.shape[1], wsrc.ctypes.data, mask.ctypes.data, C.byref(sse)) == int(e0[2]) and sse.value == int(e0[1]), (w, h)
+        assert rtcd.svt_aom_obmc_sub_pixel_variance[idx](pre.ctypes.data, pre.shape[1], xo, yo, wsrc.ctypes.data, mask.ctypes.data, C.byref(sse)) == int(e1[2]) and sse.value == int(e1[1])
+    # ---- blends
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        for (w, h, mode, sw, sh) in ((16, 16, 0, 0, 0), (32, 8, 0, 1, 1), (8, 32, 0, 1, 0), (64, 64, 0, 0, 1), (16, 8, 1, 0, 0), (4, 16, 2, 0, 0), (128, 128, 0, 0, 0), (1, 4, 2, 0, 0)):
+            s0 = rng.integers(0, 1 << bd, (h, w + 5)).astype(dt); s1 = rng.integers(0, 1 << bd, (h, w + 3)).astype(dt)
+            ms = (w << sw) + 4
+            mask = rng.integers(0, 65, ((h << sh) + 1) * ms).astype(np.uint8)
+            blk = (cmc.BlendBlk * 1)(); b = blk[0]
+            b.w, b.h, b.mode, b.subw, b.subh, b.mask_off, b.mask_stride = w, h, mode, sw, sh, 0, ms
+            exp = np.zeros((h, w), dt)
+            orc.orc_blend_a64_batch(s0.itemsize, ptr(s0), s0.shape[1], ptr(s1), s1.shape[1], ptr(exp), w, ptr(mask), blk, 1)
+            got = np.zeros((h, w + 2), dt)
+            if bd == 8:
+                if mode == 0: rtcd.svt_aom_blend_a64_mask(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, ms, w, h, sw, sh)
+                elif mode == 1: rtcd.svt_aom_blend_a64_hmask(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, w, h)
+                else: rtcd.svt_aom_blend_a64_vmask(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, w, h)
+            else:
+                if mode == 0: rtcd.svt_aom_highbd_blend_a64_mask(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, ms, w, h, sw, sh, bd)
+                elif mode == 1: rtcd.svt_aom_highbd_blend_a64_hmask_8bit(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, w, h, bd)
+                else: rtcd.svt_aom_highbd_blend_a64_vmask_8bit(got.ctypes.data, w + 2, s0.ctypes.data, s0.shape[1], s1.ctypes.data, s1.shape[1], mask.ctypes.data, w, h, bd)
+            assert np.array_equal(got[:, :w], exp) and not got[:, w:].any(), (bd, w, h, mode, sw, sh)
+    # ---- warped prediction
+    W, H = 320, 200
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        plane = rng.integers(0, 1 << bd, (H, W + 8)).astype(dt)
+        for it, (pw, ph, pc, pr, ss) in enumerate(((8, 8, 0, 0, 0), (32, 16, 64, 40, 0), (64, 64, 128, 96, 1), (16, 32, 296, 160, 0), (128, 128, 64, 32, 0))):
+            mat, a, b_, g, d = cmc.warp_model(rng, extreme=(it == 3))
+            exp = np.zeros((ph, pw), dt); got = np.zeros((ph, pw + 4), dt)
+            m8 = (C.c_int32 * 8)(*mat, 0, 0)
+            orc.orc_warp_affine(m8, ptr(plane), plane.itemsize, bd, W, H, plane.shape[1], ptr(exp), pc, pr, pw, ph, pw, ss, ss, a, b_, g, d)
+            cp = ConvParams(); cp.round_0 = 3; cp.round_1 = 11
+            if bd == 8: rtcd.svt_av1_warp_affine(C.addressof(m8), plane.ctypes.data, W, H, plane.shape[1], got.ctypes.data, pc, pr, pw, ph, pw + 4, ss, ss, C.byref(cp), a, b_, g, d)
+            else: rtcd.svt_av1_highbd_warp_affine(C.addressof(m8), plane.ctypes.data, W, H, plane.shape[1], got.ctypes.data, pc, pr, pw, ph, pw + 4, ss, ss, bd, C.byref(cp), a, b_, g, d)
+            assert np.array_equal(got[:, :pw], exp) and not got[:, pw:].any(), (bd, it)
+    # ---- Wiener statistics of one unit rectangle inside a picture
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        dgd = rng.integers(0, 1 << bd, (150, 140)).astype(dt); src = rng.integers(0, 1 << bd, (150, 140)).astype(dt)
+        for win, (h0, h1, v0, v1) in ((7, (8, 72, 5, 61)), (5, (40, 137, 10, 146)), (3, (3, 4, 3, 4))):
+            w2 = win * win
+            Me, He, Mg, Hg = np.zeros(w2, np.int64), np.zeros(w2 * w2, np.int64), np.zeros(w2, np.int64), np.zeros(w2 * w2, np.int64)
+            orc.orc_wiener_compute_stats(win, ptr(dgd), ptr(src), dgd.itemsize, bd, h0, h1, v0, v1, 140, 140, ptr(Me), ptr(He))
+            if bd == 8: rtcd.svt_av1_compute_stats(win, dgd.ctypes.data, src.ctypes.data, h0, h1, v0, v1, 140, 140, Mg.ctypes.data, Hg.ctypes.data)
+            else: rtcd.svt_av1_compute_stats_highbd(win, dgd.ctypes.data >> 1, src.ctypes.data >> 1, h0, h1, v0, v1, 140, 140, Mg.ctypes.data, Hg.ctypes.data, bd)
+            assert np.array_equal(Mg, Me) and np.array_equal(Hg, He), (bd, win)
