@@ -448,6 +448,15 @@ def main():
         k = min(F.sb_cols, 8)
         o_sad, o_mv = mc.oracle_frame(orc, F.cur_y_p, F.ref_y_p, F.cur_y_p.shape[1], PAD, sbs, 0, 0, k)
         parity_ok = bool(np.array_equal(o_sad[:k], g_sad[:k]) and np.array_equal(o_mv[:k], g_mv[:k]))
+        simd_lib = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
+        if os.path.exists(simd_lib) and world == 1:   # the whole frame against the reference's own (SIMD) kernels: 2040 SBs x 85 PUs
+            refb = C.CDLL(simd_lib)
+            refb.refb_setup.restype = C.c_uint64; refb.refb_setup.argtypes = [C.c_uint64]; refb.refb_setup(0xFFFFFFFFFFFFFFFF)
+            refb.refb_parallel.restype = C.c_double; refb.refb_parallel.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+            r_sad = np.zeros((n_sb, 85), np.uint32); r_mv = np.zeros((n_sb, 85), np.uint32)
+            slots = (C.c_int64 * 10)(F.cur_y_p.ctypes.data, F.ref_y_p.ctypes.data, F.cur_y_p.shape[1], PAD, PAD, C.addressof(sbs), n_sb, 0, r_sad.ctypes.data, r_mv.ctypes.data)
+            refb.refb_parallel(0, C.addressof(slots), n_sb, 1, min(len(os.sched_getaffinity(0)), 128), 1)
+            parity_ok = bool(parity_ok and np.array_equal(r_sad, g_sad) and np.array_equal(r_mv, g_mv))
 
     # ---- CPU baseline: the oracle C port of the same stage chain, every host core, on a bounded sample of the
     #      same frame; composite SB/s = 1 / sum_k (seconds per SB of stage k)
@@ -473,7 +482,7 @@ def main():
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
                                + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16; square tx tiling "
                                  "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets, restoration units 256",
-                   "stages_ms": per_stage, "parity_spot_check": parity_ok},
+                   "stages_ms": per_stage, "parity_spot_check": parity_ok},   # ME: first SB row vs the oracle + (when oracle/_ref is present) the whole frame vs the reference's SIMD kernels
         "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "valu_busy": valu_busy,   # fraction of VALU issue cycles used by the dominant stage's kernels (profiled round, 2.4 GHz)
