@@ -361,3 +361,68 @@ double refb_parallel(int stage, const int64_t *args, int n, int chunk, int n_thr
     free(th);
     return best;
 }
+
+/* ---------------------------------------------------------------- high bit depth (BASELINE configs[3]) ------------------------------
+ * The same kind of drivers for 16-bit pictures: sad_16b_kernel + svt_aom_highbd_10_variance{W}x{H} on block pairs, the 64-point (or any)
+ * transform chain through av1_estimate_transform / svt_aom_highbd_quantize_b / av1_inv_transform_recon, and the self-guided search with
+ * use_highbitdepth.  (The restoration apply pass is ref_shim_lr_apply_plane with highbd = 1.) */
+typedef struct { int32_t a_x, a_y, b_x, b_y; uint16_t w, h; } RefbBlkPair;
+void refb_hbd_sad_var_batch(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, const RefbBlkPair *p, int begin, int end, uint32_t *sad, uint32_t *var,
+                            uint32_t *sse) {
+    for (int i = begin; i < end; i++) {
+        uint16_t *pa = (uint16_t *)a + (size_t)p[i].a_y * a_stride + p[i].a_x, *pb = (uint16_t *)b + (size_t)p[i].b_y * b_stride + p[i].b_x;
+        sad[i] = sad_16b_kernel(pa, (uint32_t)a_stride, pb, (uint32_t)b_stride, p[i].h, p[i].w);
+        unsigned int s = 0, v = 0xFFFFFFFFu;
+        const uint8_t *a8 = CONVERT_TO_BYTEPTR(pa), *b8 = CONVERT_TO_BYTEPTR(pb);
+        if (p[i].w == 64 && p[i].h == 64) v = svt_aom_highbd_10_variance64x64(a8, a_stride, b8, b_stride, &s);
+        else if (p[i].w == 32 && p[i].h == 32) v = svt_aom_highbd_10_variance32x32(a8, a_stride, b8, b_stride, &s);
+        else if (p[i].w == 16 && p[i].h == 16) v = svt_aom_highbd_10_variance16x16(a8, a_stride, b8, b_stride, &s);
+        else if (p[i].w == 8 && p[i].h == 8) v = svt_aom_highbd_10_variance8x8(a8, a_stride, b8, b_stride, &s);
+        var[i] = v; sse[i] = s;
+    }
+}
+void refb_txfm_chain_hbd(const uint16_t *src, int src_stride, const uint16_t *pred, int pred_stride, uint16_t *recon, int recon_stride, const uint32_t *descs, int begin,
+                         int end, int tx_size, int bd, const int16_t qp[7][2], const int16_t *const scans[3], const int16_t *const iscans[3], int log_scale,
+                         int32_t *qcoeff_out, int32_t *dqcoeff_out, uint16_t *eob_out) {
+    const int W = tx_size_wide[tx_size], H = tx_size_high[tx_size], kw = W > 32 ? 32 : W, kh = H > 32 ? 32 : H, nk = kw * kh;
+    int16_t *res = (int16_t *)svt_aom_memalign(64, sizeof(int16_t) * 64 * 64);
+    int32_t *co = (int32_t *)svt_aom_memalign(64, sizeof(int32_t) * 64 * 64 * 3), *q = co + 4096, *dq = q + 4096;
+    DECLARE_ALIGNED(16, int16_t, q8[5][8]);
+    for (int r = 0; r < 5; r++) for (int k = 0; k < 8; k++) q8[r][k] = qp[r][k ? 1 : 0];
+    for (int i = begin; i < end; i++) {
+        const int x = descs[i] & 0x3FFF, y = (descs[i] >> 14) & 0x3FFF, tt = descs[i] >> 28;
+        for (int r = 0; r < H; r++)      /* svt_residual_kernel16bit */
+            for (int c = 0; c < W; c++) res[r * W + c] = (int16_t)((int)src[(size_t)(y + r) * src_stride + x + c] - (int)pred[(size_t)(y + r) * pred_stride + x + c]);
+        uint64_t energy = 0;
+        av1_estimate_transform(res, W, co, W, (TxSize)tx_size, &energy, bd, (TxType)tt, PLANE_TYPE_Y, DEFAULT_SHAPE);
+        const int cls = (W <= 16 && H <= 16) ? (tt < 10 ? 0 : ((tt & 1) ? 2 : 1)) : 0;
+        uint16_t eob = 0;
+        svt_aom_highbd_quantize_b(co, nk, q8[0], q8[1], q8[2], q8[3], q, dq, q8[4], &eob, scans[cls], iscans[cls], NULL, NULL, log_scale);
+        if (qcoeff_out) memcpy(qcoeff_out + (size_t)i * nk, q, sizeof(int32_t) * nk);
+        if (dqcoeff_out) memcpy(dqcoeff_out + (size_t)i * nk, dq, sizeof(int32_t) * nk);
+        if (eob_out) eob_out[i] = eob;
+        av1_inv_transform_recon(dq, CONVERT_TO_BYTEPTR((uint16_t *)pred + (size_t)y * pred_stride + x), pred_stride,
+                                CONVERT_TO_BYTEPTR(recon + (size_t)y * recon_stride + x), recon_stride, (TxSize)tx_size, bd, (TxType)tt, PLANE_TYPE_Y, eob, 0);
+    }
+    svt_aom_free(res); svt_aom_free(co);
+}
+void refb_sgr_search_plane_hbd(const uint16_t *dgd, int stride, const uint16_t *src, int src_stride, const int32_t *limits, int unit_begin, int unit_end, int pu_w,
+                               int pu_h, uint32_t ep_mask, int bd, int32_t *xq_out) {
+    int32_t *flt0 = (int32_t *)svt_aom_memalign(32, sizeof(int32_t) * RESTORATION_UNITPELS_MAX * 2), *flt1 = flt0 + RESTORATION_UNITPELS_MAX;
+    for (int u = unit_begin; u < unit_end; u++) {
+        const int x0 = limits[4 * u], x1 = limits[4 * u + 1], y0 = limits[4 * u + 2], y1 = limits[4 * u + 3], w = x1 - x0, h = y1 - y0;
+        const uint16_t *d = dgd + (size_t)y0 * stride + x0, *s = src + (size_t)y0 * src_stride + x0;
+        const int fs = ((w + 7) & ~7) + 8;
+        for (int ep = 0; ep < SGRPROJ_PARAMS; ep++) {
+            if (!((ep_mask >> ep) & 1)) continue;
+            for (int i = 0; i < h; i += pu_h)
+                for (int j = 0; j < w; j += pu_w)
+                    svt_av1_selfguided_restoration(CONVERT_TO_BYTEPTR(d + (size_t)i * stride + j), AOMMIN(pu_w, w - j), AOMMIN(pu_h, h - i), stride, flt0 + i * fs + j,
+                                                   flt1 + i * fs + j, fs, ep, bd, 1);
+            int xq[2] = {0, 0};
+            svt_get_proj_subspace(CONVERT_TO_BYTEPTR(s), w, h, src_stride, CONVERT_TO_BYTEPTR(d), stride, 1, flt0, fs, flt1, fs, xq, &eb_sgr_params[ep]);
+            xq_out[((size_t)u * SGRPROJ_PARAMS + ep) * 2] = xq[0]; xq_out[((size_t)u * SGRPROJ_PARAMS + ep) * 2 + 1] = xq[1];
+        }
+    }
+    svt_aom_free(flt0);
+}

@@ -178,3 +178,90 @@ def test_whole_4k_frame_every_stage(hip, pkg, orc, refb):
         assert np.array_equal(hip.to_host(d_dst, (ph, pw), np.uint8), e_dst) and (e_dst != g_out[p]).any(), ("loop restoration apply", p)
         hip.free(d_ext, d_sums, d_dst, d_ep, d_xqd)
     hip.free(*d_cur, *d_pred, *d_rec, *d_out, d_skip, d_mse, d_dir, d_var, d_cy, d_cuv)
+
+
+def test_whole_4k_frame_10bit(hip, pkg, orc, refb):
+    """BASELINE.json configs[3] at full size against the reference itself: every 64x64 / 32x32 block pair of a 3840x2160 10-bit plane (sad_16b,
+    highbd_10 variance + sse), the 64-point transform chain of every 64x64 block (quantised / dequantised coefficients, EOB, reconstruction) and the
+    self-guided search (projection coefficients of all 2040 units x 16 sets) + stripe-aware apply of the whole plane — HIP vs the reference's SIMD kernels."""
+    from test_config4_hbd_gpu import frame10
+    BD = 10
+    cur, ref = frame10(5)
+    nt = min(len(os.sched_getaffinity(0)), 64)
+
+    def threads(fn, n):
+        with ThreadPoolExecutor(nt) as ex:
+            list(ex.map(fn, [(i * n // nt, (i + 1) * n // nt) for i in range(nt)]))
+
+    # ---------------------------------------------------------------- block SAD / variance
+    rng = np.random.default_rng(6)
+    pairs = []
+    for by in range(0, H - 63, 64):
+        for bx in range(0, W - 63, 64):
+            ox, oy = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            rx, ry = min(bx + ox, W - 64), min(by + oy, H - 64)
+            pairs.append((bx, by, rx, ry, 64, 64))
+            for q in range(4):
+                pairs.append((bx + 32 * (q & 1), by + 32 * (q >> 1), rx + 32 * (q & 1), ry + 32 * (q >> 1), 32, 32))
+    n = len(pairs)
+    P = (pkg.BlkPair * n)(*[pkg.BlkPair(*p) for p in pairs])
+    d_a, d_b, d_p = hip.to_device(cur), hip.to_device(ref), hip.to_device(np.frombuffer(bytes(P), np.uint8))
+    d_sad, d_var, d_sse = hip.empty(n * 4), hip.empty(n * 4), hip.empty(n * 4)
+    hip.check(hip.L.svt_hip_block_sad_batch_dev(hip.h, 2, d_a, W, d_b, W, d_p, n, d_sad), "sad16")
+    hip.check(hip.L.svt_hip_block_variance_batch_dev(hip.h, 2, BD, d_a, W, d_b, W, d_p, n, d_var, d_sse), "var10")
+    e_sad, e_var, e_sse = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    threads(lambda be: refb.refb_hbd_sad_var_batch(ptr(cur), W, ptr(ref), W, P, be[0], be[1], ptr(e_sad), ptr(e_var), ptr(e_sse)), n)
+    assert np.array_equal(hip.to_host(d_sad, (n,), np.uint32), e_sad) and np.array_equal(hip.to_host(d_var, (n,), np.uint32), e_var), "HBD SAD / variance"
+    assert np.array_equal(hip.to_host(d_sse, (n,), np.uint32), e_sse), "HBD sse"
+    hip.free(d_p, d_sad, d_var, d_sse)
+    # ---------------------------------------------------------------- 64-point transform chain on every 64x64 block
+    ts = 4
+    descs = np.array([pkg.tx_desc(x, y, 0) for y in range(0, H - 63, 64) for x in range(0, W - 63, 64)], np.uint32)
+    nb = len(descs); NK = 1024
+    g = np.load(os.path.join(ROOT, "tests", "golden", "txfm_tables.npz"))
+    qp = np.ascontiguousarray(g["qp/10/60/0"]); scan, iscan = np.ascontiguousarray(g[f"scan/{ts}/0"]), np.ascontiguousarray(g[f"iscan/{ts}/0"])
+    qs = pkg.QuantParams()
+    for name, row in (("zbin", qp[0]), ("round", qp[1]), ("quant", qp[2]), ("quant_shift", qp[3]), ("dequant", qp[4])):
+        getattr(qs, name)[0] = int(row[0]); getattr(qs, name)[1] = int(row[1])
+    qs.log_scale = tc.TX_SCALE[ts]; qs.variant = 1
+    d_isc = hip.to_device(iscan.astype(np.int16))
+    stt = pkg.ScanTables(); stt.iscan[0] = d_isc.value
+    d_desc = hip.to_device(descs)
+    d_q, d_dq, d_eob, d_rec = hip.empty(nb * NK * 4), hip.empty(nb * NK * 4), hip.empty(nb * 2), hip.to_device(np.zeros_like(cur))
+    hip.check(hip.L.svt_hip_fwd_txfm_quant_batch_dev(hip.h, ts, 2, d_a, W, d_b, W, d_desc, nb, C.byref(qs), C.byref(stt), None, d_q, d_dq, d_eob, None, None), "fwd64")
+    hip.check(hip.L.svt_hip_inv_txfm_add_batch_dev(hip.h, ts, 2, BD, d_dq, d_b, W, d_rec, W, d_desc, nb), "inv64")
+    e_q, e_dq, e_eob, e_rec = np.zeros((nb, NK), np.int32), np.zeros((nb, NK), np.int32), np.zeros(nb, np.uint16), np.zeros_like(cur)
+    SC = (C.c_void_p * 3)(scan.ctypes.data, None, None); ISC = (C.c_void_p * 3)(iscan.ctypes.data, None, None)
+    threads(lambda be: refb.refb_txfm_chain_hbd(ptr(cur), W, ptr(ref), W, ptr(e_rec), W, ptr(descs), be[0], be[1], ts, BD, ptr(qp), SC, ISC, tc.TX_SCALE[ts],
+                                                ptr(e_q), ptr(e_dq), ptr(e_eob)), nb)
+    assert np.array_equal(hip.to_host(d_q, (nb, NK), np.int32), e_q) and np.array_equal(hip.to_host(d_dq, (nb, NK), np.int32), e_dq), "64-point quantised coefficients"
+    assert np.array_equal(hip.to_host(d_eob, (nb,), np.uint16), e_eob) and e_eob.any()
+    assert np.array_equal(hip.to_host(d_rec, cur.shape, np.uint16), e_rec), "64-point reconstruction"
+    hip.free(d_desc, d_q, d_dq, d_eob, d_rec, d_isc, d_b)
+    # ---------------------------------------------------------------- self-guided restoration, whole luma plane, unit 64
+    EXT, US = 3, 64
+    dgd = ref
+    ext = np.ascontiguousarray(np.pad(dgd, EXT, mode="edge")); st = ext.shape[1]; off = (EXT * st + EXT) * 2
+    nu = max((W + 32) // 64, 1) * max((H + 32) // 64, 1)
+    lim = np.zeros((nu, 4), np.int32); orc.orc_rest_unit_limits(W, H, 0, US, ptr(lim))
+    d_ext, d_sums = hip.to_device(ext), hip.to_device(np.zeros((nu, 16, 5), np.int64))
+    hip.check(hip.L.svt_hip_sgr_search_plane_dev(hip.h, 2, BD, d_ext.value + off, st, d_a, W, W, H, US, 0, 0xFFFF, d_sums), "search10")
+    sums = hip.to_host(d_sums, (nu, 16, 5), np.int64)
+    g_xq = np.zeros((nu, 16, 2), np.int32)
+    for u in range(nu):
+        size = int((lim[u, 1] - lim[u, 0]) * (lim[u, 3] - lim[u, 2]))
+        for ep in range(16):
+            orc.orc_sgr_solve(C.c_void_p(sums.ctypes.data + (u * 16 + ep) * 40), size, ep, C.c_void_p(g_xq.ctypes.data + (u * 16 + ep) * 8))
+    e_xq = np.zeros((nu, 16, 2), np.int32)
+    threads(lambda be: refb.refb_sgr_search_plane_hbd(C.c_void_p(ext.ctypes.data + off), st, ptr(cur), W, ptr(lim), be[0], be[1], 64, 64, 0xFFFF, BD, ptr(e_xq)), nu)
+    assert np.array_equal(g_xq, e_xq) and e_xq.any(), "10-bit self-guided projection coefficients"
+    rng = np.random.default_rng(10)
+    u_ep = rng.integers(0, 16, nu).astype(np.uint8); u_ep[::11] = 255
+    u_xqd = np.stack([rng.integers(-96, 32, nu), rng.integers(-32, 96, nu)], 1).astype(np.int32)
+    d_ep, d_xqd, d_dst = hip.to_device(u_ep), hip.to_device(u_xqd), hip.to_device(np.zeros_like(cur))
+    hip.check(hip.L.svt_hip_sgr_apply_plane_dev(hip.h, 2, BD, d_ext.value + off, st, d_dst, W, W, H, US, 0, d_a, W, d_ep, d_xqd), "apply10")   # stripes see `cur` as the deblocked plane
+    e_dst = np.zeros_like(cur)
+    work = ext.copy(); dbl = cur.copy()
+    assert refb.ref_shim_lr_apply_plane(0, BD, 1, W, H, ptr(dbl), W, C.c_void_p(work.ctypes.data + off), st, ptr(e_dst), W, US, ptr(u_ep), ptr(u_xqd)) == 0
+    assert np.array_equal(hip.to_host(d_dst, cur.shape, np.uint16), e_dst) and (e_dst != dgd).any(), "10-bit loop restoration apply"
+    hip.free(d_a, d_ext, d_sums, d_ep, d_xqd, d_dst)

@@ -144,3 +144,63 @@ def test_deblock_cdef_sgr(orc, refb, F):
             refb.refb_sgr_search_plane(C.c_void_p(ext.ctypes.data + off), st, ptr(F.cur[p]), F.cur[p].shape[1], ptr(lim), 0, nu, 64 >> ssub, 64 >> ssub, 0xFFFF, ptr(g_xq))
             assert np.array_equal(e_xq, g_xq), (p, US, np.argwhere(e_xq != g_xq)[:5])
             assert e_xq.any()
+
+
+def test_hbd_drivers(orc, refb, pkg):
+    """The 16-bit drivers of oracle/ref_bench.c (BASELINE configs[3]) vs the oracle: sad_16b + highbd_10 variance, the 64-point transform chain at
+    bit depth 10 with svt_aom_highbd_quantize_b, the self-guided search with use_highbitdepth."""
+    rng = np.random.default_rng(31)
+    w, h, bd = 256, 192, 10
+    cur = rng.integers(0, 1024, (h, w)).astype(np.uint16)
+    prd = np.clip(cur.astype(np.int32) + rng.integers(-40, 41, (h, w)), 0, 1023).astype(np.uint16)
+    # ---- block pairs
+    pairs = [(x, y, min(x + 3, w - s), min(y + 2, h - s), s, s) for s in (64, 32, 16, 8) for y in range(0, h - s + 1, 64) for x in range(0, w - s + 1, 64)]
+    n = len(pairs)
+    P = (pkg.BlkPair * n)(*[pkg.BlkPair(*p) for p in pairs])
+    sad, var, sse = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    refb.refb_hbd_sad_var_batch(ptr(cur), w, ptr(prd), w, P, 0, n, ptr(sad), ptr(var), ptr(sse))
+    orc.orc_sad_16b.restype = C.c_uint32; orc.orc_variance_hbd10.restype = C.c_uint32
+    for i, (ax, ay, bx, by, bw, bh) in enumerate(pairs):
+        pa = C.c_void_p(cur.ctypes.data + (ay * w + ax) * 2); pb = C.c_void_p(prd.ctypes.data + (by * w + bx) * 2)
+        s = C.c_uint32()
+        assert sad[i] == orc.orc_sad_16b(pa, w, pb, w, bh, bw) and var[i] == orc.orc_variance_hbd10(pa, w, pb, w, bw, bh, C.byref(s)) and sse[i] == s.value, pairs[i]
+    # ---- transform chain, every square size incl. 64x64
+    g = np.load(os.path.join(ROOT, "tests", "golden", "txfm_tables.npz"))
+    qp = np.ascontiguousarray(g["qp/10/60/0"])
+    for ts, n_ in ((4, 64), (3, 32), (2, 16), (1, 8), (0, 4)):
+        descs = np.array([pkg.tx_desc(x, y, (x // n_ + y // n_) % (1 if ts >= 3 else 4)) for y in range(0, h - n_ + 1, n_) for x in range(0, w - n_ + 1, n_)], np.uint32)
+        nb = len(descs); nk = min(n_, 32) ** 2
+        sc = [np.ascontiguousarray(g[f"scan/{ts}/{c}"]) if f"scan/{ts}/{c}" in g.files else None for c in range(3)]
+        isc = [np.ascontiguousarray(g[f"iscan/{ts}/{c}"]) if f"iscan/{ts}/{c}" in g.files else None for c in range(3)]
+        SC = (C.c_void_p * 3)(*[s.ctypes.data if s is not None else None for s in sc]); ISC = (C.c_void_p * 3)(*[s.ctypes.data if s is not None else None for s in isc])
+        rec = np.zeros_like(cur); q = np.zeros((nb, nk), np.int32); dq = np.zeros((nb, nk), np.int32); eob = np.zeros(nb, np.uint16)
+        refb.refb_txfm_chain_hbd(ptr(cur), w, ptr(prd), w, ptr(rec), w, ptr(descs), 0, nb, ts, bd, ptr(qp), SC, ISC, tc.TX_SCALE[ts], ptr(q), ptr(dq), ptr(eob))
+        for i in range(0, nb, max(1, nb // 12)):
+            x, y, tt = int(descs[i] & 0x3FFF), int((descs[i] >> 14) & 0x3FFF), int(descs[i] >> 28)
+            res = (cur[y:y + n_, x:x + n_].astype(np.int32) - prd[y:y + n_, x:x + n_]).astype(np.int16)
+            co = tc.orc_fwd(orc, np.ascontiguousarray(res), n_, tt, ts, bd)
+            orc.orc_handle_transform.restype = C.c_uint64
+            orc.orc_handle_transform(ptr(co), ts)
+            cls = 0 if n_ > 16 else (0 if tt < 10 else (2 if tt & 1 else 1))
+            eq, edq = np.zeros(nk, np.int32), np.zeros(nk, np.int32); e_eob = C.c_uint16()
+            z = [np.array(r, np.int16) for r in qp[:5]]
+            orc.orc_quantize(1, ptr(co), nk, ptr(z[0]), ptr(z[1]), ptr(z[2]), ptr(z[3]), ptr(eq), ptr(edq), ptr(z[4]), C.byref(e_eob), ptr(sc[cls]), tc.TX_SCALE[ts])
+            assert np.array_equal(q[i], eq) and np.array_equal(dq[i], edq) and eob[i] == e_eob.value, (ts, i)
+            er = np.zeros((n_, n_), np.uint16)
+            orc.orc_inv_txfm2d_add(ptr(edq), ptr(np.ascontiguousarray(prd[y:y + n_, x:x + n_])), n_, ptr(er), n_, tt, ts, bd)
+            assert np.array_equal(rec[y:y + n_, x:x + n_], er), (ts, i)
+    # ---- self-guided search
+    EXT, US = 3, 64
+    ext = np.ascontiguousarray(np.pad(prd, EXT, mode="edge")); st = ext.shape[1]; off = (EXT * st + EXT) * 2
+    nu = max((w + 32) // 64, 1) * max((h + 32) // 64, 1)
+    lim = np.zeros((nu, 4), np.int32); orc.orc_rest_unit_limits(w, h, 0, US, ptr(lim))
+    sums = np.zeros((nu, 16, 5), np.int64)
+    orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + off), 2, st, ptr(cur), w, w, h, 0, 0, US, bd, 0xFFFF, ptr(sums))
+    e_xq = np.zeros((nu, 16, 2), np.int32)
+    for u in range(nu):
+        size = int((lim[u, 1] - lim[u, 0]) * (lim[u, 3] - lim[u, 2]))
+        for ep in range(16):
+            orc.orc_sgr_solve(ptr(np.ascontiguousarray(sums[u, ep])), size, ep, C.c_void_p(e_xq.ctypes.data + (u * 16 + ep) * 8))
+    g_xq = np.zeros((nu, 16, 2), np.int32)
+    refb.refb_sgr_search_plane_hbd(C.c_void_p(ext.ctypes.data + off), st, ptr(cur), w, ptr(lim), 0, nu, 64, 64, 0xFFFF, bd, ptr(g_xq))
+    assert np.array_equal(e_xq, g_xq) and e_xq.any()
