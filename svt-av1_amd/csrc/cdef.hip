@@ -237,10 +237,13 @@ __device__ __forceinline__ void tap_minmax(int v, int& mn, int& mx) {
     mn = min(mn, v);
 }
 
-// One pixel, one (pri, sec, dir): svt_cdef_filter_block_c (EbCdef.c:202-257) without the search's shared-term machinery.
+// One pixel, one (pri, sec, dir): svt_cdef_filter_block_c (EbCdef.c:202-257).  The two mirrored taps of every (direction, distance) share a weight,
+// so they are handled as a packed pair with the search's helpers (|d|, constrain and the weighted sum of both taps in ~9 instructions).
 __device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride, int pri, int sec, int dir, int cs, int damping) {
     const int x = (int)(int16_t)px[0];
-    int sum = 0, mn = x, mx = x;
+    const s16x2 x2 = dup2(x);
+    s16x2 mn = x2, mx = x2;
+    int sum = 0;
     const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
     const int w0 = ((pri >> cs) & 1) ? 3 : 4, w1 = ((pri >> cs) & 1) ? 3 : 2;
     const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
@@ -248,15 +251,23 @@ __device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride,
     for (int k = 0; k < 2; k++) {
         const int o = kDirDy[dir][k] * tstride + kDirDx[dir][k];
         const int p0 = px[o], p1 = px[-o];
-        tap_minmax(p0, mn, mx); tap_minmax(p1, mn, mx);
-        if (pri) sum += (k ? w1 : w0) * (constrain(p0 - x, pri, pshift) + constrain(p1 - x, pri, pshift));
+        minmax_pair(p0, p1, mn, mx);
+        if (pri) {   // wave-uniform
+            const TapPair pp = make_pair(p0, p1, x2);
+            sum = constrain_pair(pp, signed_weight(pp, k ? w1 : w0), pri, pshift, sum);
+        }
         const int o2 = kDirDy[d2][k] * tstride + kDirDx[d2][k], o6 = kDirDy[d6][k] * tstride + kDirDx[d6][k];
         const int s0 = px[o2], s1 = px[-o2], s2 = px[o6], s3 = px[-o6];
-        tap_minmax(s0, mn, mx); tap_minmax(s1, mn, mx); tap_minmax(s2, mn, mx); tap_minmax(s3, mn, mx);
-        if (sec) sum += (k ? 1 : 2) * (constrain(s0 - x, sec, sshift) + constrain(s1 - x, sec, sshift) + constrain(s2 - x, sec, sshift) + constrain(s3 - x, sec, sshift));
+        minmax_pair(s0, s1, mn, mx); minmax_pair(s2, s3, mn, mx);
+        if (sec) {
+            const TapPair a = make_pair(s0, s1, x2), b = make_pair(s2, s3, x2);
+            sum = constrain_pair(a, signed_weight(a, 2 - k), sec, sshift, sum);
+            sum = constrain_pair(b, signed_weight(b, 2 - k), sec, sshift, sum);
+        }
     }
+    const int lo = min((int)mn.x, (int)mn.y), hi = max((int)mx.x, (int)mx.y);
     const int y = x + ((8 + sum - (sum < 0)) >> 4);
-    return min(max(y, mn), mx);
+    return min(max(y, lo), hi);
 }
 
 // sum(a), sum(a*a), sum(a*b) over 64 samples held as packed rows in LDS
