@@ -250,9 +250,10 @@ def main():
         else:
             parallel([lambda j=j: inv_job(j) for j in tx_jobs])
 
-    def run_dlf():
-        for p in range(3):   # ~10 us kernels: a fork / join costs more than it hides
-            dlf_plane(p)
+    def run_dlf():   # all three planes: one launch per direction
+        ctx.check(L.svt_hip_deblock_frame_dev(ctx.h, P3(*[p.data_ptr() for p in d_recon]), 1, I3(*strides), 8, P3(*[d_edges[p][0].data_ptr() for p in range(3)]),
+                                              P3(*[d_edges[p][1].data_ptr() for p in range(3)]), I3(*[d_edges[p][2] for p in range(3)]),
+                                              I3(*[d_edges[p][3] for p in range(3)]), 0), "dlf")
 
     def dlf_plane(p):
         if True:

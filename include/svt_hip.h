@@ -182,6 +182,11 @@ int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_row
  * Either descriptor pointer may be NULL to run a single direction (filter-level search probes). */
 int svt_hip_deblock_plane_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int bd, const uint16_t *d_edges_v,
                               const uint16_t *d_edges_h, int units_w, int units_h, int sharpness);
+/* The same for all three planes of a picture in two launches (every vertical edge of every plane, then every horizontal edge):
+ * svt_av1_loop_filter_frame(frame, pcs, 0, 3).  A NULL plane pointer skips that plane (frame filter level 0). */
+int svt_hip_deblock_frame_dev(SvtHipCtx *ctx, void *const d_plane[3], int pix_bytes, const int stride[3], int bd,
+                              const uint16_t *const d_edges_v[3], const uint16_t *const d_edges_h[3], const int units_w[3],
+                              const int units_h[3], int sharpness);
 /* Sum of squared differences of two planes: svt_spatial_full_distortion_kernel (8-bit) /
  * svt_full_distortion_kernel16_bits (16-bit containers) as called by picture_sse_calculations
  * (Encoder/Codec/EbDeblockingFilter.c:830-961).  *d_sse (device) receives the sum (it is cleared by the call). */

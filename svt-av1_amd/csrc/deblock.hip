@@ -133,6 +133,57 @@ deblock_pass_kernel(PIX* __restrict__ plane, int stride, const uint16_t* __restr
         }
 }
 
+// all planes of a picture in one launch per direction (blockIdx.z = plane): svt_av1_loop_filter_frame(frame, pcs, 0, 3)
+struct DeblockFrame { void* plane[3]; int stride[3]; const uint16_t* ev[3]; const uint16_t* eh[3]; int units_w[3], units_h[3]; };
+template <typename PIX, int BD, int DIR>
+__global__ void __launch_bounds__(256)
+deblock_frame_pass_kernel(const DeblockFrame f, int sharpness) {
+    const int p = blockIdx.z;
+    // scalar copies (indexing the kernel-argument struct by reference would force a private-memory copy of it)
+    PIX* plane = (PIX*)(p == 0 ? f.plane[0] : (p == 1 ? f.plane[1] : f.plane[2]));
+    const int stride = p == 0 ? f.stride[0] : (p == 1 ? f.stride[1] : f.stride[2]);
+    const uint16_t* edges = DIR == 0 ? (p == 0 ? f.ev[0] : (p == 1 ? f.ev[1] : f.ev[2])) : (p == 0 ? f.eh[0] : (p == 1 ? f.eh[1] : f.eh[2]));
+    const int units_w = p == 0 ? f.units_w[0] : (p == 1 ? f.units_w[1] : f.units_w[2]);
+    const int units_h = p == 0 ? f.units_h[0] : (p == 1 ? f.units_h[1] : f.units_h[2]);
+    if (!plane || !edges) return;
+    int ux, uy, sx, sy;
+    if (DIR == 0) {
+        ux = blockIdx.x * 256 + threadIdx.x;  sy = blockIdx.y;  uy = sy >> 2;  sx = 4 * ux;
+        if (ux >= units_w || uy >= units_h) return;
+    } else {
+        sx = blockIdx.x * 256 + threadIdx.x;  uy = blockIdx.y;  ux = sx >> 2;  sy = 4 * uy;
+        if (ux >= units_w || uy >= units_h) return;
+    }
+    const uint32_t e = edges[uy * units_w + ux];
+    const int len = e & 0xff, level = (int)(e >> 8);
+    if (!len || !level) return;
+    const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+    const ptrdiff_t tap = DIR == 0 ? 1 : stride;
+    PIX* s = plane + (size_t)sy * stride + sx;
+    int px[14];
+#pragma unroll
+    for (int k = 1; k <= 7; k++) {
+        px[7 - k] = (k <= half) ? (int)s[-(ptrdiff_t)k * tap] : 0;
+        px[6 + k] = (k <= half) ? (int)s[(ptrdiff_t)(k - 1) * tap] : 0;
+    }
+    const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+    for (int k = 1; k <= 6; k++)
+        if (k <= changed) {
+            s[-(ptrdiff_t)k * tap]     = (PIX)px[7 - k];
+            s[(ptrdiff_t)(k - 1) * tap] = (PIX)px[6 + k];
+        }
+}
+template <typename PIX, int BD>
+int launch_frame(hipStream_t st, const DeblockFrame& f, int sharp) {
+    int uw = 0, uh = 0;
+    for (int p = 0; p < 3; p++) { if (f.plane[p]) { uw = f.units_w[p] > uw ? f.units_w[p] : uw; uh = f.units_h[p] > uh ? f.units_h[p] : uh; } }
+    if (uw <= 0 || uh <= 0) return 0;
+    hipLaunchKernelGGL((deblock_frame_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh, 3), dim3(256), 0, st, f, sharp);
+    hipLaunchKernelGGL((deblock_frame_pass_kernel<PIX, BD, 1>), dim3((4 * uw + 255) / 256, uh, 3), dim3(256), 0, st, f, sharp);
+    return (int)hipGetLastError();
+}
+
 template <typename PIX, int BD>
 int launch_both(hipStream_t st, PIX* plane, int stride, const uint16_t* ev, const uint16_t* eh, int uw, int uh, int sharp, int lv_v, int lv_h) {
     if (ev) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh), dim3(256), 0, st, plane, stride, ev, uw, uh, sharp, lv_v);
@@ -172,6 +223,15 @@ extern "C" int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix
     if (pix_bytes == 1) return launch_both<uint8_t, 8>(st, (uint8_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
     if (bd == 8) return launch_both<uint16_t, 8>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
     return launch_both<uint16_t, 10>(st, (uint16_t*)plane, stride, edges_v, edges_h, units_w, units_h, sharpness, level_v, level_h);
+}
+
+extern "C" int svt_hip_launch_deblock_frame(hipStream_t st, void* const plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t* const ev[3],
+                                            const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness) {
+    DeblockFrame f;
+    for (int p = 0; p < 3; p++) { f.plane[p] = plane[p]; f.stride[p] = stride[p]; f.ev[p] = ev[p]; f.eh[p] = eh[p]; f.units_w[p] = units_w[p]; f.units_h[p] = units_h[p]; }
+    if (pix_bytes == 1) return launch_frame<uint8_t, 8>(st, f, sharpness);
+    if (bd == 8) return launch_frame<uint16_t, 8>(st, f, sharpness);
+    return launch_frame<uint16_t, 10>(st, f, sharpness);
 }
 
 // *out must be zero before the launch (the caller enqueues the memset)

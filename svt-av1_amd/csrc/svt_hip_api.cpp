@@ -280,6 +280,20 @@ int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int st
     return SVT_HIP_OK;
 }
 
+int svt_hip_deblock_frame_dev(SvtHipCtx* c, void* const d_plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t* const d_edges_v[3],
+                              const uint16_t* const d_edges_h[3], const int units_w[3], const int units_h[3], int sharpness) {
+    if (!c || !d_plane || !stride || !d_edges_v || !d_edges_h || !units_w || !units_h || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) ||
+        (pix_bytes == 1 && bd != 8) || sharpness < 0 || sharpness > 7) {
+        if (c) c->err = "svt_hip_deblock_frame_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    for (int p = 0; p < 3; p++)
+        if (d_plane[p] && (units_w[p] < 0 || units_h[p] < 0 || !d_edges_v[p] || !d_edges_h[p])) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_deblock_frame(c->stream, d_plane, pix_bytes, stride, bd, d_edges_v, d_edges_h, units_w, units_h, sharpness);
+    if (e != hipSuccess) return fail(c, e, "deblock frame launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_plane_sse_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, int w, int h,
                           uint64_t* d_sse) {
     if (!c || !d_a || !d_b || !d_sse || (pix_bytes != 1 && pix_bytes != 2) || w <= 0 || h <= 0) {

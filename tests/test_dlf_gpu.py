@@ -123,3 +123,30 @@ def test_filter_level_search(hip, orc, pkg, bd, mode):
             assert np.array_equal(after, rec), "the unfiltered plane must stay untouched"
             assert (lvl.value, err.value) == (exp_lvl, best_err.value), (bd, mode, plane, dirn, lvl.value, exp_lvl, err.value, best_err.value)
             assert sum(1 for v in probes if v >= 0) >= 2
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_deblock_frame_all_planes(hip, orc, bd):
+    """svt_hip_deblock_frame_dev (all three planes, one launch per direction) == three oracle plane calls; a NULL plane is skipped."""
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    w, h = 328, 200
+    rng = np.random.default_rng(70 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    mi, cols, rows = dc.make_mode_info(w, h, seed=21, varied=True)
+    planes, exp, edges = [], [], []
+    for plane, (pw, ph) in enumerate(((w, h), (w // 2, h // 2), (w // 2, h // 2))):
+        ev, eh = dc.build_edges(mi, cols, rows, plane, pw, ph)
+        img = np.ascontiguousarray(content(rng, ph, pw + 8, bd, plane == 1).astype(dt))
+        e = img.copy()
+        orc.orc_deblock_plane(ptr(e), img.itemsize, img.shape[1], bd, ptr(ev), ptr(eh), ev.shape[1], ev.shape[0], 2)
+        planes.append(img); exp.append(e); edges.append((ev, eh))
+    for skip in (None, 1):
+        d_p = [hip.to_device(p) for p in planes]; d_ev = [hip.to_device(e[0]) for e in edges]; d_eh = [hip.to_device(e[1]) for e in edges]
+        pp = [d_p[i].value if i != skip else None for i in range(3)]
+        hip.check(hip.L.svt_hip_deblock_frame_dev(hip.h, P3(*pp), planes[0].itemsize, I3(*[p.shape[1] for p in planes]), bd, P3(*[d.value for d in d_ev]),
+                                                 P3(*[d.value for d in d_eh]), I3(*[e[0].shape[1] for e in edges]), I3(*[e[0].shape[0] for e in edges]), 2), "deblock frame")
+        for i in range(3):
+            got = hip.to_host(d_p[i], planes[i].shape, dt)
+            assert np.array_equal(got, planes[i] if i == skip else exp[i]), (bd, skip, i)
+            assert (exp[i] != planes[i]).any()
+        hip.free(*d_p, *d_ev, *d_eh)
