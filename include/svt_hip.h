@@ -464,6 +464,19 @@ typedef struct {
 int svt_hip_blend_a64_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_src0, int src0_stride, const void *d_src1, int src1_stride, void *d_dst,
                                 int dst_stride, const uint8_t *d_masks, const SvtHipBlendBlk *d_blks, int nblk);
 
+/* ------------------------------------------------------------------ picture formats around the high-bit-depth path ---- */
+/* The reference keeps 10-bit pictures as an 8-bit plane + a 2-bit plane; these are its conversions to / from the 16-bit samples the
+ * kernels above take (Common/C_DEFAULT/EbPackUnPack_C.c):
+ *   mode 0 svt_enc_msb_pack2_d        in0 = 8-bit plane, in1 = 2-bit plane (one byte per sample, bits on top)  -> out0 16-bit
+ *   mode 1 svt_compressed_packmsb     in1 = 2-bit plane packed 4 samples per byte (stride in bytes), w % 4 == 0 -> out0 16-bit
+ *   mode 2 svt_enc_msb_un_pack2_d     in0 16-bit -> out0 8-bit, out1 2-bit plane (may be NULL)
+ *   mode 3 svt_convert_8bit_to_16bit, mode 4 svt_convert_16bit_to_8bit
+ *   mode 5 svt_c_pack                 in0 = unpacked 2-bit plane -> out0 packed (stride in bytes), w % 4 == 0
+ *   mode 6 svt_unpack_avg             in0, in1 16-bit -> out0 = rounded average of their 8-bit MSBs
+ * Strides in samples of the respective plane. */
+int svt_hip_picture_format_dev(SvtHipCtx *ctx, int mode, const void *d_in0, int in0_stride, const void *d_in1, int in1_stride, void *d_out0,
+                               int out0_stride, void *d_out1, int out1_stride, int w, int h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,6 +222,10 @@ void orc_warp_predict_batch(int pix_bytes, int bd, const void *ref, int width, i
 void orc_blend_a64_batch(int pix_bytes, const void *src0, int src0_stride, const void *src1, int src1_stride, void *dst, int dst_stride, const uint8_t *masks,
                          const void *blks, int n);
 
+/* picture-format conversions around the high-bit-depth path (format_oracle.c) */
+void orc_picture_format(int mode, const void *in0, int in0_stride, const void *in1, int in1_stride, void *out0, int out0_stride, void *out1, int out1_stride,
+                        int w, int h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -666,4 +666,18 @@ int svt_hip_blend_a64_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_src0,
     return SVT_HIP_OK;
 }
 
+int svt_hip_picture_format_dev(SvtHipCtx* c, int mode, const void* d_in0, int in0_stride, const void* d_in1, int in1_stride, void* d_out0, int out0_stride,
+                               void* d_out1, int out1_stride, int w, int h) {
+    const bool two_in = mode == 0 || mode == 1 || mode == 6;
+    if (!c || mode < 0 || mode > 6 || w < 0 || h < 0 || ((mode == 1 || mode == 5) && (w & 3))) {
+        if (c) c->err = "svt_hip_picture_format_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    if (w == 0 || h == 0) return SVT_HIP_OK;
+    if (!d_in0 || !d_out0 || (two_in && !d_in1)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_picture_format(c->stream, mode, d_in0, in0_stride, d_in1, in1_stride, d_out0, out0_stride, d_out1, out1_stride, w, h);
+    if (e != hipSuccess) return fail(c, e, "picture format launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

@@ -781,3 +781,35 @@ def test_blend_a64_masks(orc, ref):
                 else: ref.svt_aom_highbd_blend_a64_vmask_8bit_c(ptr(e), w, ptr(s0), w, ptr(s1), w, mp, w, h, bd)
             run[b.dst_y:b.dst_y + h, b.dst_x:b.dst_x + w] = e
         assert np.array_equal(out, run) and (out != a).any(), bd
+
+
+def test_picture_format_conversions(orc, ref):
+    """orc_picture_format == the reference's 8+2-bit <-> 16-bit conversions (Common/C_DEFAULT/EbPackUnPack_C.c), ragged strides and sizes."""
+    rng = np.random.default_rng(55)
+    for (w, h) in ((64, 16), (200, 37), (8, 3), (1924, 5)):
+        w4 = w & ~3
+        in8 = rng.integers(0, 256, (h, w + 5)).astype(np.uint8); inn = (rng.integers(0, 256, (h, w + 3))).astype(np.uint8)
+        comp = rng.integers(0, 256, (h, w // 4 + 2)).astype(np.uint8)
+        in16 = rng.integers(0, 1024, (h, w + 7)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 1)).astype(np.uint16)
+        full16 = rng.integers(0, 65536, (h, w + 7)).astype(np.uint16)
+        def run(mode, i0, i1, o0dt, o0w, o1=False):
+            o0 = np.zeros((h, o0w + 2), o0dt); o1a = np.zeros((h, w + 4), np.uint8) if o1 else None
+            orc.orc_picture_format(mode, ptr(i0), i0.shape[1], ptr(i1) if i1 is not None else None, i1.shape[1] if i1 is not None else 0, ptr(o0), o0.shape[1],
+                                   ptr(o1a) if o1 else None, o1a.shape[1] if o1 else 0, w if mode not in (1, 5) else w4, h)
+            return o0, o1a
+        e = np.zeros((h, w + 2), np.uint16); ref.svt_enc_msb_pack2_d(ptr(in8), in8.shape[1], ptr(inn), ptr(e), inn.shape[1], e.shape[1], w, h)
+        assert np.array_equal(run(0, in8, inn, np.uint16, w)[0], e)
+        e = np.zeros((h, w + 2), np.uint16); ref.svt_compressed_packmsb_c(ptr(in8), in8.shape[1], ptr(comp), ptr(e), comp.shape[1], e.shape[1], w4, h)
+        assert np.array_equal(run(1, in8, comp, np.uint16, w)[0], e)
+        e8 = np.zeros((h, w + 2), np.uint8); en = np.zeros((h, w + 4), np.uint8)
+        ref.svt_enc_msb_un_pack2_d(ptr(full16), full16.shape[1], ptr(e8), ptr(en), e8.shape[1], en.shape[1], w, h)
+        g8, gn = run(2, full16, None, np.uint8, w, o1=True)
+        assert np.array_equal(g8, e8) and np.array_equal(gn, en)
+        e = np.zeros((h, w + 2), np.uint16); ref.svt_convert_8bit_to_16bit_c(ptr(in8), in8.shape[1], ptr(e), e.shape[1], w, h)
+        assert np.array_equal(run(3, in8, None, np.uint16, w)[0], e)
+        e = np.zeros((h, w + 2), np.uint8); ref.svt_convert_16bit_to_8bit_c(ptr(full16), full16.shape[1], ptr(e), e.shape[1], w, h)
+        assert np.array_equal(run(4, full16, None, np.uint8, w)[0], e)
+        e = np.zeros((h, w // 4 + 2), np.uint8); ref.svt_c_pack_c(ptr(inn), inn.shape[1], ptr(e), e.shape[1], None, w4, h)
+        assert np.array_equal(run(5, inn, None, np.uint8, w // 4)[0], e)
+        e = np.zeros((h, w + 2), np.uint8); ref.svt_unpack_avg_c(ptr(in16), in16.shape[1], ptr(b16), b16.shape[1], ptr(e), e.shape[1], w, h)
+        assert np.array_equal(run(6, in16, b16, np.uint8, w)[0], e)
