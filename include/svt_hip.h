@@ -477,6 +477,11 @@ int svt_hip_blend_a64_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_src
 int svt_hip_picture_format_dev(SvtHipCtx *ctx, int mode, const void *d_in0, int in0_stride, const void *d_in1, int in1_stride, void *d_out0,
                                int out0_stride, void *d_out1, int out1_stride, int w, int h);
 
+/* generate_padding / generate_padding16_bit (Common/Codec/EbMcp.c:112, :166) for a plane that is resident on the device: the border of pad_w columns /
+ * pad_h rows around the w x h picture is filled with the nearest picture sample (what the motion search and the sub-pel kernels expect of a
+ * reference picture, and svt_extend_frame's 3-sample border of the restoration input).  d_plane points at picture sample (0, 0). */
+int svt_hip_generate_padding_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
+
 #ifdef __cplusplus
 }
 #endif

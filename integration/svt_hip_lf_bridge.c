@@ -220,7 +220,8 @@ EbErrorType svt_hip_rest_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
                  svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn, sizeof(int16_t) * 16 * n);
         free(ep); free(xqd); free(wn);
         if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
-        /* the CDEF picture needs its 3-sample border (svt_extend_frame, EbRestoration.c:1306): the apply kernel clamps reads at the picture edge itself */
+        /* the CDEF picture's 3-sample border (svt_extend_frame, EbRestoration.c:1306) */
+        HIP_TRY(svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], pw, ph, LF_BORDER, LF_BORDER));
         HIP_TRY(svt_hip_lr_apply_plane_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
                                            pw, ph, rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl],
                                            p->d_unit_xqd[pl], p->d_unit_wiener[pl]));

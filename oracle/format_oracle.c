@@ -36,3 +36,16 @@ void orc_picture_format(int mode, const void *in0, int in0_stride, const void *i
             }
         }
 }
+
+/* generate_padding / generate_padding16_bit (Common/Codec/EbMcp.c:112-160, :166-214): replicate the picture edges into a border of pad_w columns and pad_h
+ * rows (rows first get their left / right border, then whole padded rows are copied up and down: every border sample = the nearest picture sample).
+ * `plane` points at picture sample (0, 0); the reference passes the buffer start and the padded stride. */
+void orc_generate_padding(void *plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
+    for (int y = -pad_h; y < h + pad_h; y++)
+        for (int x = -pad_w; x < w + pad_w; x++) {
+            if (x >= 0 && x < w && y >= 0 && y < h) continue;
+            const int sx = x < 0 ? 0 : (x >= w ? w - 1 : x), sy = y < 0 ? 0 : (y >= h ? h - 1 : y);
+            if (pix_bytes == 1) ((uint8_t *)plane)[(ptrdiff_t)y * stride + x] = ((uint8_t *)plane)[(ptrdiff_t)sy * stride + sx];
+            else ((uint16_t *)plane)[(ptrdiff_t)y * stride + x] = ((uint16_t *)plane)[(ptrdiff_t)sy * stride + sx];
+        }
+}

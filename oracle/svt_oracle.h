@@ -226,6 +226,8 @@ void orc_blend_a64_batch(int pix_bytes, const void *src0, int src0_stride, const
 void orc_picture_format(int mode, const void *in0, int in0_stride, const void *in1, int in1_stride, void *out0, int out0_stride, void *out1, int out1_stride,
                         int w, int h);
 
+void orc_generate_padding(void *plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,23 @@ picture_format_kernel(const void* __restrict__ in0, int s0, const void* __restri
     }
 }
 
+
+// generate_padding / generate_padding16_bit (Common/Codec/EbMcp.c:112, :166): every border sample = the nearest picture sample.  One thread per border
+// sample of a row; rows -pad_h .. h + pad_h - 1 (interior samples are skipped: the border only ever reads the picture, so one pass suffices).
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+generate_padding_kernel(PIX* __restrict__ plane, int stride, int w, int h, int pad_w, int pad_h) {
+    const int y = (int)blockIdx.y - pad_h;
+    const int sy = min(max(y, 0), h - 1);
+    const bool inner_row = y >= 0 && y < h;
+    const int n = inner_row ? 2 * pad_w : w + 2 * pad_w;   // border samples of this row
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int x = inner_row ? (i < pad_w ? i - pad_w : w + (i - pad_w)) : i - pad_w;
+        const int sx = min(max(x, 0), w - 1);
+        plane[(ptrdiff_t)y * stride + x] = plane[(ptrdiff_t)sy * stride + sx];
+    }
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_picture_format(hipStream_t st, int mode, const void* in0, int s0, const void* in1, int s1, void* out0, int t0, void* out1, int t1, int w,
@@ -58,5 +75,13 @@ extern "C" int svt_hip_launch_picture_format(hipStream_t st, int mode, const voi
     default: return (int)hipErrorInvalidValue;
     }
 #undef L
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_generate_padding(hipStream_t st, void* plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
+    if (w <= 0 || h <= 0 || (pad_w <= 0 && pad_h <= 0)) return 0;
+    const dim3 grid(min((w + 2 * pad_w + 255) / 256, 16), h + 2 * pad_h), block(256);
+    if (pix_bytes == 1) hipLaunchKernelGGL(generate_padding_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)plane, stride, w, h, pad_w, pad_h);
+    else hipLaunchKernelGGL(generate_padding_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)plane, stride, w, h, pad_w, pad_h);
     return (int)hipGetLastError();
 }

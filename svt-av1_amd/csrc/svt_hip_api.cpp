@@ -680,4 +680,13 @@ int svt_hip_picture_format_dev(SvtHipCtx* c, int mode, const void* d_in0, int in
     return SVT_HIP_OK;
 }
 
+int svt_hip_generate_padding_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
+    if (!c || (pix_bytes != 1 && pix_bytes != 2) || w < 0 || h < 0 || pad_w < 0 || pad_h < 0) return SVT_HIP_ERR_BAD_ARG;
+    if (w == 0 || h == 0 || (pad_w == 0 && pad_h == 0)) return SVT_HIP_OK;
+    if (!d_plane || stride < w + pad_w) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_generate_padding(c->stream, d_plane, pix_bytes, stride, w, h, pad_w, pad_h);
+    if (e != hipSuccess) return fail(c, e, "generate padding launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

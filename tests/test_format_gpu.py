@@ -54,3 +54,20 @@ def test_4k_10bit_round_trip(hip):
     assert np.array_equal(hip.to_host(d_back, (H, W), np.uint16), pic)
     assert np.array_equal(hip.to_host(d_8, (H, W), np.uint8), (pic >> 2).astype(np.uint8))
     hip.free(d_pic, d_8, d_n, d_c, d_back)
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.uint16])
+def test_generate_padding(hip, orc, dt):
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    for (w, h, pw, ph) in ((64, 48, 16, 8), (200, 37, 68, 68), (8, 3, 4, 2), (3840, 2160, 160, 160), (33, 17, 0, 5), (33, 17, 7, 0)):
+        buf = rng.integers(0, 250, (h + 2 * ph + 1, w + 2 * pw + 3)).astype(dt)
+        exp = buf.copy()
+        off = (ph * buf.shape[1] + pw) * buf.itemsize
+        orc.orc_generate_padding(C.c_void_p(exp.ctypes.data + off), buf.itemsize, buf.shape[1], w, h, pw, ph)
+        d = hip.to_device(buf)
+        hip.check(hip.L.svt_hip_generate_padding_dev(hip.h, d.value + off, buf.itemsize, buf.shape[1], w, h, pw, ph), "padding")
+        got = hip.to_host(d, buf.shape, dt)
+        hip.free(d)
+        assert np.array_equal(got, exp), (w, h, pw, ph)
+        assert np.array_equal(got[:h + 2 * ph, :w + 2 * pw], np.pad(buf[ph:ph + h, pw:pw + w], ((ph, ph), (pw, pw)), mode="edge"))

@@ -813,3 +813,17 @@ def test_picture_format_conversions(orc, ref):
         assert np.array_equal(run(5, inn, None, np.uint8, w // 4)[0], e)
         e = np.zeros((h, w + 2), np.uint8); ref.svt_unpack_avg_c(ptr(in16), in16.shape[1], ptr(b16), b16.shape[1], ptr(e), e.shape[1], w, h)
         assert np.array_equal(run(6, in16, b16, np.uint8, w)[0], e)
+
+
+def test_generate_padding(orc, ref):
+    """orc_generate_padding == generate_padding / generate_padding16_bit (Common/Codec/EbMcp.c) on a buffer whose stride is the padded width."""
+    rng = np.random.default_rng(77)
+    for (w, h, pw, ph) in ((64, 48, 16, 8), (200, 37, 68, 68), (8, 3, 4, 2), (33, 17, 1, 5)):
+        for dt in (np.uint8, np.uint16):
+            buf = rng.integers(0, 250, (h + 2 * ph, w + 2 * pw)).astype(dt)
+            a, b = buf.copy(), buf.copy()
+            if dt == np.uint8: ref.generate_padding(ptr(a), a.shape[1], w, h, pw, ph)
+            else: ref.generate_padding16_bit(ptr(a), a.shape[1] * 2, w * 2, h, pw * 2, ph)      # byte units (EbMcp.c:166-214)
+            orc.orc_generate_padding(C.c_void_p(b.ctypes.data + (ph * b.shape[1] + pw) * b.itemsize), b.itemsize, b.shape[1], w, h, pw, ph)
+            assert np.array_equal(a, b), (w, h, pw, ph, dt)
+            assert np.array_equal(b, np.pad(buf[ph:ph + h, pw:pw + w], ((ph, ph), (pw, pw)), mode="edge"))
