@@ -1,0 +1,44 @@
+/*
+ * svt_hip_tf_bridge.h — reference-side glue for the alt-ref temporal filter: produce_temporally_filtered_pic
+ * (Source/Lib/Encoder/Codec/EbTemporalFiltering.c:2012-2412) driven through svt_hip_tf_filter_frame_dev.
+ *
+ * Compiled INTO libSvtAv1Enc (includes the reference's headers); tests/test_integration_compiles.py syntax-checks it.
+ *
+ * The per-64x64-block loop keeps its motion search (motion_estimate_sb, tf_32x32 / tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag:
+ * host logic on top of the ME / sub-pel entry points) but
+ *   - instead of tf_inter_prediction into the 64x64 `pred` block buffer it predicts into a per-frame predictor PICTURE on the device
+ *     (svt_hip_subpel_predict_batch_dev with the block's MVs), and calls svt_hip_tf_record_block(), which copies the MeContext TF fields;
+ *   - apply_filtering_central / apply_filtering_block_plane_wise / get_final_filtered_pixels are dropped: after the last block of the
+ *     picture, svt_hip_tf_flush_picture() filters the whole picture over the whole window in one launch.
+ */
+#ifndef SVT_HIP_TF_BRIDGE_H
+#define SVT_HIP_TF_BRIDGE_H
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbMotionEstimationContext.h"
+#include "svt_hip.h"
+
+typedef struct SvtHipTfWindow {
+    int            n_frames, index_center;       /* past_altref_nframes + future_altref_nframes + 1, position of the central picture */
+    int            blk_cols, blk_rows;            /* 64x64 blocks of the (64-aligned) picture */
+    SvtHipTfBlk64 *h_blocks[SVT_HIP_TF_MAX_REFS]; /* host staging, one array per window frame */
+    SvtHipTfBlk64 *d_blocks[SVT_HIP_TF_MAX_REFS];
+    void          *d_pred[SVT_HIP_TF_MAX_REFS][3]; /* predictor pictures (device), same geometry as the central picture */
+    int            pred_stride[3];
+    uint64_t      *d_sse;                          /* filtered_sse, filtered_sse_uv */
+} SvtHipTfWindow;
+
+EbErrorType svt_hip_tf_window_ctor(SvtHipCtx *hip, SvtHipTfWindow *w, int n_frames, int index_center, int width, int height, int is_16bit, int ss_x, int ss_y);
+void        svt_hip_tf_window_dctor(SvtHipCtx *hip, SvtHipTfWindow *w);
+
+/* after derive_tf_32x32_block_split_flag for (frame_index, 64x64 block): keep what the plane-wise filter reads from MeContext */
+void svt_hip_tf_record_block(SvtHipTfWindow *w, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *context_ptr);
+
+/* once per central picture; d_src / d_dst: the central picture on the device (may alias), strides in samples.  noise_levels / decay_control as
+ * computed by svt_av1_init_temporal_filtering (:2786-2870); filtered_sse / filtered_sse_uv receive get_final_filtered_pixels' sums. */
+EbErrorType svt_hip_tf_flush_picture(SvtHipCtx *hip, SvtHipTfWindow *w, const MeContext *context_ptr, int is_16bit, int bd, void *const d_src[3],
+                                     const int src_stride[3], void *const d_dst[3], const int dst_stride[3], int ss_x, int ss_y, const double *noise_levels,
+                                     int decay_control, uint64_t *filtered_sse, uint64_t *filtered_sse_uv);
+
+#endif
