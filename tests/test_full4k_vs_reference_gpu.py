@@ -45,8 +45,10 @@ def par(refb, stage, slots, n, chunk):
     refb.refb_parallel(stage, C.addressof(a), n, chunk, min(len(os.sched_getaffinity(0)), 128), 1)
 
 
-def test_whole_4k_frame_every_stage(hip, pkg, orc, refb):
-    F = workload.Frame(W, H, seed=11)
+@pytest.mark.parametrize("size_seed", [(3840, 2160, 11), (1920, 1080, 21), (1280, 720, 22), (704, 400, 23), (352, 288, 24)])
+def test_whole_4k_frame_every_stage(hip, pkg, orc, refb, size_seed):
+    W, H, seed = size_seed          # the 4K bench frame first, then other picture sizes / seeds (ragged last SB row / column) through the same chain
+    F = workload.Frame(W, H, seed=seed)
     L = hip.L
     n_sb, st, org = F.n_sb, F.cur_y_p.shape[1], F.pad * F.cur_y_p.shape[1] + F.pad
     # ---------------------------------------------------------------- pyramids (GPU) + HME on them
@@ -175,7 +177,7 @@ def test_whole_4k_frame_every_stage(hip, pkg, orc, refb):
         e_dst = np.zeros((ph, pw), np.uint8)
         work = ext.copy(); dbl = g_dlf[p].copy()
         assert refb.ref_shim_lr_apply_plane(p, 8, 0, W, H, ptr(dbl), strides[p], C.c_void_p(work.ctypes.data + off), est, ptr(e_dst), pw, US, ptr(u_ep), ptr(u_xqd)) == 0
-        assert np.array_equal(hip.to_host(d_dst, (ph, pw), np.uint8), e_dst) and (e_dst != g_out[p]).any(), ("loop restoration apply", p)
+        assert np.array_equal(hip.to_host(d_dst, (ph, pw), np.uint8), e_dst) and (nu == 1 or (e_dst != g_out[p]).any()), ("loop restoration apply", p)   # nu == 1: the only unit is the RESTORE_NONE one
         hip.free(d_ext, d_sums, d_dst, d_ep, d_xqd)
     hip.free(*d_cur, *d_pred, *d_rec, *d_out, d_skip, d_mse, d_dir, d_var, d_cy, d_cuv)
 
