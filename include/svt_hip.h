@@ -312,6 +312,10 @@ typedef struct {
  * first minimum in raster order, like the C kernel.  Entries are untouched when no candidate wins. */
 int svt_hip_sad_loop_batch_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, const uint8_t *d_ref, int ref_stride,
                                const SvtHipSadLoop *d_searches, int n, uint32_t *d_best_sad, int16_t *d_best_xy);
+/* The same search on 16-bit planes (high-bit-depth path): sad_16b_kernel (aom_dsp_rtcd.h:651; Encoder/C_DEFAULT/EbComputeSAD_C.c:39) over the window,
+ * candidate order / update rule of svt_sad_loop_kernel.  Block sizes up to 64 x 64; strides in samples. */
+int svt_hip_sad_loop16_batch_dev(SvtHipCtx *ctx, const uint16_t *d_src, int src_stride, const uint16_t *d_ref, int ref_stride,
+                                 const SvtHipSadLoop *d_searches, int n, uint32_t *d_best_sad, int16_t *d_best_xy);
 
 /* ------------------------------------------------------------------ self-guided restoration ------ */
 /* All three calls work on ONE plane that has been extended by >= 3 samples on every side

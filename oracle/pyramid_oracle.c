@@ -80,3 +80,24 @@ void orc_sad_loop_batch(const uint8_t *src, int src_stride, const uint8_t *ref, 
         if (bs != 0xffffff) { best_xy[2 * i] = xc; best_xy[2 * i + 1] = yc; }
     }
 }
+
+/* The 16-bit twin of orc_sad_loop_batch for the high-bit-depth path: svt_sad_loop_kernel_c's candidate loop (Encoder/C_DEFAULT/EbComputeSAD_C.c:58-92:
+ * raster order, strict '<', initial best 0xffffff) around sad_16b_kernel_c (:39). */
+void orc_sad_loop16_batch(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, const void *jobs_, int begin, int end, uint32_t *best_sad,
+                          int16_t *best_xy) {
+    const OrcSadLoopJob *jobs = (const OrcSadLoopJob *)jobs_;
+    for (int i = begin; i < end; i++) {
+        const OrcSadLoopJob *j = &jobs[i];
+        uint32_t bs = 0xffffff;
+        int16_t xc = 0, yc = 0;
+        for (int cy = 0; cy < j->sa_h; cy++)
+            for (int cx = 0; cx < j->sa_w; cx++) {
+                const uint32_t sad = orc_sad_16b(src + (size_t)j->src_y * src_stride + j->src_x, (uint32_t)(src_stride * j->row_step),
+                                                 ref + (size_t)(j->ref_y + cy) * ref_stride + j->ref_x + cx, (uint32_t)(ref_stride * j->row_step),
+                                                 (uint32_t)(j->bh / j->row_step), (uint32_t)j->bw);
+                if (sad < bs) { bs = sad; xc = (int16_t)cx; yc = (int16_t)cy; }
+            }
+        best_sad[i] = bs;
+        if (bs != 0xffffff) { best_xy[2 * i] = xc; best_xy[2 * i + 1] = yc; }
+    }
+}

@@ -228,6 +228,9 @@ void orc_picture_format(int mode, const void *in0, int in0_stride, const void *i
 
 void orc_generate_padding(void *plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
 
+void orc_sad_loop16_batch(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, const void *jobs, int begin, int end, uint32_t *best_sad,
+                          int16_t *best_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,7 @@ def lib():
     L.svt_hip_deblock_frame_dev.argtypes = [vp, P3, i32, I3, i32, P3, P3, I3, I3, i32]
     L.svt_hip_picture_format_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32]
     L.svt_hip_generate_padding_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32]
+    L.svt_hip_sad_loop16_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp]
     L.svt_hip_tf_estimate_noise_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.svt_hip_tf_noise_sigma.argtypes = [C.c_int64, C.c_int64]
     L.svt_hip_tf_noise_sigma.restype = C.c_double

@@ -190,6 +190,51 @@ sad_loop_kernel(const uint8_t* __restrict__ src, int src_stride, const uint8_t* 
     }
 }
 
+
+// 16-bit twin of the search above for the high-bit-depth path: sad_16b_kernel (Encoder/C_DEFAULT/EbComputeSAD_C.c:39) over a window, with
+// svt_sad_loop_kernel's candidate order and update rule (first minimum in raster order, initial best 0xffffff).  One workgroup per search:
+// the source block sits in LDS, a lane owns candidates c, c + 256, ...; two samples per v_sad_u16.
+__global__ void __launch_bounds__(256)
+sad_loop16_kernel(const uint16_t* __restrict__ src, int src_stride, const uint16_t* __restrict__ ref, int ref_stride,
+                  const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
+    __shared__ uint16_t s_blk[64 * 64];
+    __shared__ unsigned long long s_best[4];
+    const SvtHipSadLoop d = searches[blockIdx.x];
+    const int tid = threadIdx.x;
+    unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;
+    const int ncand = d.sa_w * d.sa_h, rstep = d.row_step, rows = d.bh / rstep;
+    for (int i = tid; i < rows * d.bw; i += 256) {
+        const int y = i / d.bw, x = i - y * d.bw;
+        s_blk[i] = src[(size_t)(d.src_y + y * rstep) * src_stride + d.src_x + x];
+    }
+    __syncthreads();
+    for (int c = tid; c < ncand; c += 256) {
+        const int cy = c / d.sa_w, cx = c - cy * d.sa_w;
+        const uint16_t* r = ref + (size_t)(d.ref_y + cy) * ref_stride + d.ref_x + cx;
+        uint32_t sad = 0;
+        for (int y = 0; y < rows; y++) {
+            const uint16_t* rr = r + (size_t)(y * rstep) * ref_stride;
+            const uint16_t* ss = s_blk + y * d.bw;
+            for (int x = 0; x < d.bw; x++) sad += (uint32_t)abs((int)ss[x] - (int)rr[x]);
+        }
+        const unsigned long long key = ((unsigned long long)sad << 32) | (uint32_t)c;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = shfl_xor64(best, m); best = o < best ? o : best; }
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) best = s_best[w] < best ? s_best[w] : best;
+        const uint32_t sad = (uint32_t)(best >> 32), c = (uint32_t)best;
+        best_sad[blockIdx.x] = sad;
+        if (sad < 0xffffffu && c < (uint32_t)ncand) {
+            best_xy[2 * blockIdx.x] = (int16_t)(c % d.sa_w);
+            best_xy[2 * blockIdx.x + 1] = (int16_t)(c / d.sa_w);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_downsample(hipStream_t st, const uint8_t* in, int in_stride, int w, int h, uint8_t* out, int out_stride, int step, int filtered) {
@@ -206,5 +251,11 @@ extern "C" int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int s
                                        const SvtHipSadLoop* searches, int n, uint32_t* best_sad, int16_t* best_xy) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(sad_loop_kernel, dim3(n), dim3(256), 0, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_sad_loop16(hipStream_t st, const uint16_t* src, int src_stride, const uint16_t* ref, int ref_stride, const SvtHipSadLoop* searches, int n,
+                                         uint32_t* best_sad, int16_t* best_xy) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sad_loop16_kernel, dim3(n), dim3(256), 0, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
     return (int)hipGetLastError();
 }

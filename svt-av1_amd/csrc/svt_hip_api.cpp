@@ -502,6 +502,16 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_strid
     return SVT_HIP_OK;
 }
 
+int svt_hip_sad_loop16_batch_dev(SvtHipCtx* c, const uint16_t* d_src, int src_stride, const uint16_t* d_ref, int ref_stride, const SvtHipSadLoop* d_searches, int n,
+                                 uint32_t* d_best_sad, int16_t* d_best_xy) {
+    if (!c || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    if (n == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_searches || !d_best_sad || !d_best_xy) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_sad_loop16(c->stream, d_src, src_stride, d_ref, ref_stride, d_searches, n, d_best_sad, d_best_xy);
+    if (e != hipSuccess) return fail(c, e, "sad loop (16-bit) launch");
+    return SVT_HIP_OK;
+}
+
 /* ---------------------------------------------------------------- self-guided restoration */
 static bool sgr_args_ok(int pix_bytes, int bd, int pw, int ph) {
     return (pix_bytes == 1 || pix_bytes == 2) && (bd == 8 || bd == 10) && !(pix_bytes == 1 && bd != 8) && pw > 0 && ph > 0;

@@ -41,6 +41,8 @@ int svt_hip_launch_blend_a64(hipStream_t st, int pix_bytes, const void* src0, in
                              const uint8_t* masks, const SvtHipBlendBlk* blks, int n);
 int svt_hip_launch_picture_format(hipStream_t st, int mode, const void* in0, int s0, const void* in1, int s1, void* out0, int t0, void* out1, int t1, int w, int h);
 int svt_hip_launch_generate_padding(hipStream_t st, void* plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
+int svt_hip_launch_sad_loop16(hipStream_t st, const uint16_t* src, int src_stride, const uint16_t* ref, int ref_stride, const SvtHipSadLoop* searches, int n,
+                              uint32_t* best_sad, int16_t* best_xy);
 int svt_hip_launch_wiener_stats8(hipStream_t st, int win, const uint8_t* dgd, int dgd_stride, const uint8_t* src, int src_stride, int pw, int ph,
                                  int unit_size, int units_x, int units_y, int ss_y, int64_t* M, int64_t* H);
 int svt_hip_launch_plane_sse(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride, int w, int h,

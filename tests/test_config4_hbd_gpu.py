@@ -145,3 +145,32 @@ def test_hbd_selfguided_4k(hip, orc):
     orc.orc_sgr_apply_plane(ptr(crop_dbl), W, C.c_void_p(crop_ext.ctypes.data + off), st, 2, W, CH + 64, 0, 0, US, BD, ptr(u_ep[:ux * cuy].copy()),
                             ptr(u_xqd[:ux * cuy].copy()), ptr(exp), W)
     assert np.array_equal(out[:CH - 64], exp[:CH - 64]), np.argwhere(out[:CH - 64] != exp[:CH - 64])[:5]
+
+
+def test_hbd_windowed_search(hip, pkg, orc):
+    """configs[3] 'HBD SAD, windowed full search': svt_hip_sad_loop16_batch_dev (sad_16b_kernel over a window, svt_sad_loop_kernel's order) vs the
+    oracle on a 10-bit frame: 64x64 blocks with 64x64 / clipped windows, small blocks, sub-sampled rows, ties."""
+    rng = np.random.default_rng(12)
+    w, h = 512, 320
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = 480 + 300 * np.sin(xx / 37.0) * np.cos(yy / 29.0)
+    cur = np.clip(base + rng.normal(0, 9, (h, w)), 0, 1023).astype(np.uint16)
+    ref = np.clip(np.roll(base, (2, -3), (0, 1)) + rng.normal(0, 9, (h, w)), 0, 1023).astype(np.uint16)
+    ref[:70, :140] = 500; cur[:64, :64] = 503           # a flat region: every candidate ties, the first one wins
+    jobs = []
+    for by in range(0, h - 63, 64):
+        for bx in range(0, w - 63, 64):
+            x0, y0 = max(bx - 32, 0), max(by - 32, 0)
+            jobs.append((bx, by, x0, y0, 64, 64, min(64, w - 64 - x0 + 1), min(64, h - 64 - y0 + 1), 1, 0))
+    jobs += [(16, 16, 8, 8, 16, 16, 17, 9, 1, 0), (100, 40, 90, 30, 32, 32, 5, 40, 2, 0), (200, 100, 199, 99, 8, 8, 3, 3, 1, 0), (64, 64, 60, 60, 64, 32, 9, 9, 2, 0)]
+    n = len(jobs)
+    S = (pkg.SadLoop * n)(*[pkg.SadLoop(*j) for j in jobs])
+    e_sad, e_xy = np.zeros(n, np.uint32), np.full((n, 2), -7, np.int16)
+    orc.orc_sad_loop16_batch(ptr(cur), w, ptr(ref), w, S, 0, n, ptr(e_sad), ptr(e_xy))
+    d_c, d_r, d_S = hip.to_device(cur), hip.to_device(ref), hip.to_device(np.frombuffer(bytes(S), np.uint8).copy())
+    d_sad, d_xy = hip.to_device(np.zeros(n, np.uint32)), hip.to_device(np.full((n, 2), -7, np.int16))
+    hip.check(hip.L.svt_hip_sad_loop16_batch_dev(hip.h, d_c, w, d_r, w, d_S, n, d_sad, d_xy), "sad loop 16")
+    g_sad, g_xy = hip.to_host(d_sad, (n,), np.uint32), hip.to_host(d_xy, (n, 2), np.int16)
+    hip.free(d_c, d_r, d_S, d_sad, d_xy)
+    assert np.array_equal(g_sad, e_sad) and np.array_equal(g_xy, e_xy), np.argwhere(g_sad != e_sad)[:5]
+    assert (e_xy[0] == (0, 0)).all() and e_sad.min() < 0xffffff
