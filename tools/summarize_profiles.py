@@ -63,3 +63,5 @@ for k, e in list(res.items())[:16]:
     print(f"{k[:44]:44s} n={e['launches']:3d} avg={e['avg_us']:8.1f}us fetch={e.get('fetch_bytes_per_launch', 0)/1e6:8.2f}MB write={e.get('write_bytes_per_launch', 0)/1e6:8.2f}MB")
 if os.path.exists(os.path.join(src, "extra_kernels.txt")):
     shutil.copy(os.path.join(src, "extra_kernels.txt"), os.path.join(dst, "extra_kernels.txt"))
+for f in glob.glob(os.path.join(src, "extra_stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, "extra_kernel_stats.csv"))
