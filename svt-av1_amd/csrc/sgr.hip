@@ -160,55 +160,10 @@ sgr_filter_kernel(const PIX* __restrict__ plane, int stride, int pw, int ph, int
     }
 }
 
-// ---- projection sums of every (restoration unit, parameter set): sums[unit][16][5] += {H00, H01, H11, C0, C1}
-template <typename PIX, int BD>
-__global__ void __launch_bounds__(256)
-sgr_search_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                  int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
-    __shared__ TileLds L;
-    __shared__ long long red[4][5];
-    // unit rows start RESTORATION_UNIT_OFFSET >> ss_y above their nominal position (foreach_rest_unit_in_tile,
-    // EbRestoration.c:1388-1391); the tile grid is shifted by the same amount so a tile never straddles two units
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH - voff, tid = threadIdx.x;
-    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
-    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid);
-    int32_t sv[4];   // (src << 4) - u per owned pixel; 0 for out-of-picture pixels
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int k = tid + 256 * t, i = k / TW, j = k - i * TW;
-        sv[t] = (x0 + j < pw && y0 + i < ph && y0 + i >= 0) ? ((int32_t)src[(size_t)(y0 + i) * src_stride + x0 + j] << 4) - ((int32_t)L.in[(i + 3) * IW + j + 3] << 4) : 0;
-    }
-    for (int ep = 0; ep < 16; ep++) {
-        if (!((ep_mask >> ep) & 1)) continue;
-        __syncthreads();
-        build_ab<BD>(L, ep, tid);
-        long long h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int k = tid + 256 * t, i = k / TW, j = k - i * TW;
-            if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-            int32_t f0 = 0, f1 = 0;
-            filt_px(L, ep, i, j, f0, f1);
-            const int32_t u = (int32_t)L.in[(i + 3) * IW + j + 3] << 4;
-            const long long a = kSgr[ep][0] > 0 ? f0 - u : 0, b = kSgr[ep][1] > 0 ? f1 - u : 0;
-            h00 += a * a; h01 += a * b; h11 += b * b; c0 += a * sv[t]; c1 += b * sv[t];
-        }
-        long long v[5] = {h00, h01, h11, c0, c1};
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1)
-                v[q] += ((long long)__shfl_xor((int)(v[q] >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)v[q], m, 64);
-            if ((tid & 63) == 0) red[tid >> 6][q] = v[q];
-        }
-        __syncthreads();
-        if (tid < 5) atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + tid], (unsigned long long)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// 8-bit search kernel (the 4K north-star path).  Same results as sgr_search_kernel, ~1/3 of the
-// instructions per pixel and parameter set:
+// Search kernel: projection sums of every (restoration unit, parameter set), sums[unit][16][5] += {H00, H01, H11, C0, C1}.
+// Bit depth 8 (the 4K north-star path) and 10; ~1/3 of the instructions per pixel and parameter set of a per-pixel
+// box-sum formulation:
 //  * everything that does not depend on the parameter set is hoisted out of the 16-set loop and kept
 //    in REGISTERS: p = max(n*sumsq - sum^2, 0) and m = sum * one_by_n of the ~13 A/B positions a thread
 //    owns.  For 8-bit data p < 2^24 and the set's s < 2^12, so z and B are single v_mad_u32_u24;
@@ -238,6 +193,7 @@ __device__ __forceinline__ int32_t row16_sum(int32_t v) {   // every lane of a 1
 
 // ---- building blocks shared by the 8-bit search and apply kernels (64 x 32 tiles) --------------------------------------------
 // `in`: staged tile [S_IH][S_IW]; abmem: 2 * S_NP dwords of scratch that later hold A'/B' (two barriers inside)
+template <int BD = 8>
 __device__ __forceinline__ void sgr8_precompute(const uint16_t* __restrict__ in, uint32_t* __restrict__ abmem, int tid, uint32_t (&P)[S_KP], uint32_t (&M)[S_KP]) {
     // parameter-set independent part of A/B for the positions this thread owns.  The box sums are separable: (1) a lane takes one
     // column of the staged tile and a third of its rows and writes the VERTICAL 3- and 5-sums of x and x^2 (15 LDS reads), (2) a position
@@ -285,8 +241,12 @@ __device__ __forceinline__ void sgr8_precompute(const uint16_t* __restrict__ in,
             sm = (uint32_t)vs5[rr * S_IW + c] + vs5[rr * S_IW + c + 1] + vs5[rr * S_IW + c + 2] + vs5[rr * S_IW + c + 3] + vs5[rr * S_IW + c + 4];
             sq = vq5[rr * S_IW + c] + vq5[rr * S_IW + c + 1] + vq5[rr * S_IW + c + 2] + vq5[rr * S_IW + c + 3] + vq5[rr * S_IW + c + 4];
         }
-        P[k] = (sq * n < sm * sm) ? 0u : sq * n - sm * sm;   // EbRestoration.c:804-806 / :935-937 (bit depth 8: no pre-rounding)
-        M[k] = sm * obn;
+        // EbRestoration.c:790-806 / :926-937: the sums are rounded down to 8-bit scale first (no-op at bit depth 8).  p stays below 2^24 and
+        // p * s below 2^32 at bit depth 10 as well (r = 1: p <= 20 * 1023^2 / 16 + 2307 = 1 310 468, x 3236 < 2^32; r = 2: 10.21 M x 140).
+        uint32_t a = sq, d = sm;
+        if constexpr (BD > 8) { a = (sq + (1u << (2 * (BD - 8) - 1))) >> (2 * (BD - 8)); d = (sm + (1u << (BD - 9))) >> (BD - 8); }
+        P[k] = (a * n < d * d) ? 0u : a * n - d * d;
+        M[k] = sm * obn;                                     // <= 25 * 1023 * 164 < 2^24
     }
     __syncthreads();   // the vertical sums are dead: the first parameter set's A/B may overwrite them
 
@@ -350,7 +310,56 @@ __device__ __forceinline__ void sgr8_filter(const uint32_t* __restrict__ abw, in
 #undef FA_
 #undef FB_
 
-template <typename PIX>
+
+// The same for bit depth 10: B' <= 2^18, so only the horizontal triple (3 B' < 2^20) stays packed; the vertical part of the
+// neighbourhood sums is formed on the unpacked halves.
+__device__ __forceinline__ void sgr10_filter(const uint32_t* __restrict__ abw, int i0, int j, const uint32_t (&X)[8], const int32_t (&CX)[8], bool has0, bool has1,
+                                             int32_t (&D0)[8], int32_t (&D1)[8]) {
+    if (has1) {
+        const uint32_t* a1 = abw + i0 * S_PW + j + 1;
+        uint32_t RmA, RmB, CmA, CmB, R0A, R0B, C0A, C0B;
+        { const uint32_t l = a1[-1], c = a1[0], r = a1[1], t = l + c + r; RmA = t >> 20; RmB = t & 0xFFFFFu; CmA = c >> 20; CmB = c & 0xFFFFFu; }
+        { const uint32_t l = a1[S_PW - 1], c = a1[S_PW], r = a1[S_PW + 1], t = l + c + r; R0A = t >> 20; R0B = t & 0xFFFFFu; C0A = c >> 20; C0B = c & 0xFFFFFu; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t* q = a1 + (r + 2) * S_PW;
+            const uint32_t l = q[-1], c = q[0], rt = q[1], t = l + c + rt;
+            const uint32_t RpA = t >> 20, RpB = t & 0xFFFFFu, cA = c >> 20, cB = c & 0xFFFFFu;
+            const uint32_t a = __umul24(RmA + R0A + RpA, 3u) + (CmA + R0A + cA), b = __umul24(RmB + R0B + RpB, 3u) + (CmB + R0B + cB);
+            D1[r] = (int32_t)(__umul24(a, X[r]) + b + (uint32_t)CX[r]) >> 9;
+            RmA = R0A; RmB = R0B; CmA = C0A; CmB = C0B; R0A = RpA; R0B = RpB; C0A = cA; C0B = cB;
+        }
+    }
+    if (has0) {
+        const uint32_t* a2 = abw + S_N1 + (i0 / 2) * S_PW + j + 1;
+        uint32_t HA[5], HB[5], CA[5], CB[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const uint32_t l = a2[q * S_PW - 1], c = a2[q * S_PW], r = a2[q * S_PW + 1], t = l + c + r;
+            HA[q] = t >> 20; HB[q] = t & 0xFFFFFu; CA[q] = c >> 20; CB[q] = c & 0xFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            {
+                const uint32_t a = __umul24(HA[q] + HA[q + 1], 5u) + CA[q] + CA[q + 1], b = __umul24(HB[q] + HB[q + 1], 5u) + CB[q] + CB[q + 1];
+                D0[2 * q] = (int32_t)(__umul24(a, X[2 * q]) + b + (uint32_t)CX[2 * q]) >> 9;
+            }
+            {
+                const uint32_t a = __umul24(HA[q + 1], 5u) + CA[q + 1], b = __umul24(HB[q + 1], 5u) + CB[q + 1];
+                D0[2 * q + 1] = (int32_t)(__umul24(a, X[2 * q + 1]) + b + (uint32_t)(CX[2 * q + 1] >> 1)) >> 8;
+            }
+        }
+    }
+}
+
+// 16-lane row total of p0 + p1 as a 64-bit value (|p0|, |p1| < 2^31): the low 16 bits and the signed upper halves are reduced separately
+__device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
+    const int32_t lo = row16_sum((p0 & 0xFFFF) + (p1 & 0xFFFF));
+    const int32_t hi = row16_sum((p0 >> 16) + (p1 >> 16));
+    return (long long)hi * 65536 + lo;
+}
+
+template <typename PIX, int BD = 8>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
                    int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
@@ -358,7 +367,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
     __shared__ unsigned long long acc[16][5];
-    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (see sgr_search_kernel)
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
 
     {
@@ -376,7 +385,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
     __syncthreads();
 
     uint32_t P[S_KP], M[S_KP];
-    sgr8_precompute(in, &ab[0][0], tid, P, M);
+    sgr8_precompute<BD>(in, &ab[0][0], tid, P, M);
 
     // ---- the 8 pixels (one column, 8 rows) this lane accumulates
     const int j = tid & 63, i0 = (tid >> 6) * 8;
@@ -406,25 +415,50 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         sgr8_build(abw, xt, P, M, has0, has1, s0, s1, tid);
         __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
 
-        int32_t D0[8], D1[8];
-        sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
-        int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (r >= rlo && r < rhi) {   // wave-uniform
-                if (has0) { h00 += __mul24(D0[r], D0[r]); c0 += __mul24(D0[r], SV[r]); }
-                if (has1) { h11 += __mul24(D1[r], D1[r]); c1 += __mul24(D1[r], SV[r]); }
-                if (has0 && has1) h01 += __mul24(D0[r], D1[r]);
+        if (BD == 8) {
+            int32_t D0[8], D1[8];
+            sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+            int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
+    #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (r >= rlo && r < rhi) {   // wave-uniform
+                    if (has0) { h00 += __mul24(D0[r], D0[r]); c0 += __mul24(D0[r], SV[r]); }
+                    if (has1) { h11 += __mul24(D1[r], D1[r]); c1 += __mul24(D1[r], SV[r]); }
+                    if (has0 && has1) h01 += __mul24(D0[r], D1[r]);
+                }
             }
-        }
-        if (!colvalid) { h00 = 0; h01 = 0; h11 = 0; c0 = 0; c1 = 0; }
-        if (has0) { h00 = row16_sum(h00); c0 = row16_sum(c0); }
-        if (has1) { h11 = row16_sum(h11); c1 = row16_sum(c1); }
-        if (has0 && has1) h01 = row16_sum(h01);
-        if ((tid & 15) == 0) {
-            if (has0) { atomicAdd(&acc[ep][0], (unsigned long long)(long long)h00); atomicAdd(&acc[ep][3], (unsigned long long)(long long)c0); }
-            if (has1) { atomicAdd(&acc[ep][2], (unsigned long long)(long long)h11); atomicAdd(&acc[ep][4], (unsigned long long)(long long)c1); }
-            if (has0 && has1) atomicAdd(&acc[ep][1], (unsigned long long)(long long)h01);
+            if (!colvalid) { h00 = 0; h01 = 0; h11 = 0; c0 = 0; c1 = 0; }
+            if (has0) { h00 = row16_sum(h00); c0 = row16_sum(c0); }
+            if (has1) { h11 = row16_sum(h11); c1 = row16_sum(c1); }
+            if (has0 && has1) h01 = row16_sum(h01);
+            if ((tid & 15) == 0) {
+                if (has0) { atomicAdd(&acc[ep][0], (unsigned long long)(long long)h00); atomicAdd(&acc[ep][3], (unsigned long long)(long long)c0); }
+                if (has1) { atomicAdd(&acc[ep][2], (unsigned long long)(long long)h11); atomicAdd(&acc[ep][4], (unsigned long long)(long long)c1); }
+                if (has0 && has1) atomicAdd(&acc[ep][1], (unsigned long long)(long long)h01);
+            }
+        } else {
+            // bit depth 10: |flt - u| < 2^14.1, a product < 2^28.1 -> four rows per int32 partial, 64-bit from the row reduction on
+            int32_t D0[8], D1[8];
+            sgr10_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+            int32_t h00[2] = {0, 0}, h01[2] = {0, 0}, h11[2] = {0, 0}, c0[2] = {0, 0}, c1[2] = {0, 0};
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (r >= rlo && r < rhi) {   // wave-uniform
+                    if (has0) { h00[r >> 2] += __mul24(D0[r], D0[r]); c0[r >> 2] += __mul24(D0[r], SV[r]); }
+                    if (has1) { h11[r >> 2] += __mul24(D1[r], D1[r]); c1[r >> 2] += __mul24(D1[r], SV[r]); }
+                    if (has0 && has1) h01[r >> 2] += __mul24(D0[r], D1[r]);
+                }
+            }
+            if (!colvalid) { h00[0] = h00[1] = 0; h01[0] = h01[1] = 0; h11[0] = h11[1] = 0; c0[0] = c0[1] = 0; c1[0] = c1[1] = 0; }
+            long long w00 = 0, w01 = 0, w11 = 0, wc0 = 0, wc1 = 0;
+            if (has0) { w00 = row16_sum_wide(h00[0], h00[1]); wc0 = row16_sum_wide(c0[0], c0[1]); }
+            if (has1) { w11 = row16_sum_wide(h11[0], h11[1]); wc1 = row16_sum_wide(c1[0], c1[1]); }
+            if (has0 && has1) w01 = row16_sum_wide(h01[0], h01[1]);
+            if ((tid & 15) == 0) {
+                if (has0) { atomicAdd(&acc[ep][0], (unsigned long long)w00); atomicAdd(&acc[ep][3], (unsigned long long)wc0); }
+                if (has1) { atomicAdd(&acc[ep][2], (unsigned long long)w11); atomicAdd(&acc[ep][4], (unsigned long long)wc1); }
+                if (has0 && has1) atomicAdd(&acc[ep][1], (unsigned long long)w01);
+            }
         }
         buf ^= 1;
     }
@@ -442,11 +476,11 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 #undef FA_
 #undef FB_
 
-// ---- 8-bit frame apply on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
+// ---- frame apply (bit depth 8 and 10) on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
 // RESTORE_NONE units are copied, RESTORE_WIENER units take the 7-tap separable filter, RESTORE_SGRPROJ units the self-guided filter.
 // A tile is one stripe high at most (stripes are 64 >> ss_y rows starting 8 >> ss_y above a multiple of that), so the StripeCtx rules
 // of the generic kernel apply unchanged.
-template <typename PIX>
+template <typename PIX, int BD = 8>
 __global__ void __launch_bounds__(256)
 lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
                  int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
@@ -497,25 +531,25 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
         uint16_t* tmp = (uint16_t*)&ab[0][0];   // [S_IH][S_TW]
         for (int k = tid; k < S_IH * S_TW; k += 256) {
             const int r = k / S_TW, c = k - r * S_TW;
-            int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << 14);
+            int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << (BD + 6));
 #pragma unroll
             for (int t = 0; t < 7; t++) sum += (int32_t)in[r * S_IW + c + t] * fx[t];
-            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << 13) - 1);
+            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, bd)
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int i = i0 + r;
             if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-            int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << 18);
+            int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << (BD + 10));
 #pragma unroll
             for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * S_TW + j] * fy[t];
-            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), 255);
+            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
         }
         return;
     }
     uint32_t P[S_KP], M[S_KP];
-    sgr8_precompute(in, &ab[0][0], tid, P, M);
+    sgr8_precompute<BD>(in, &ab[0][0], tid, P, M);
     const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
     sgr8_build(ab[0], xt, P, M, has0, has1, (uint32_t)kSgr[ep][2], (uint32_t)kSgr[ep][3], tid);
     __syncthreads();
@@ -523,7 +557,8 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
 #pragma unroll
     for (int r = 0; r < 8; r++) { X[r] = in[(i0 + r + 3) * S_IW + j + 3]; CX[r] = 256 - (int32_t)(X[r] << 13); }
     int32_t D0[8], D1[8];
-    sgr8_filter(ab[0], i0, j, X, CX, has0, has1, D0, D1);
+    if constexpr (BD == 8) sgr8_filter(ab[0], i0, j, X, CX, has0, has1, D0, D1);
+    else sgr10_filter(ab[0], i0, j, X, CX, has0, has1, D0, D1);
     // svt_decode_xq (EbRestoration.c:707-718)
     const int32_t xqd0 = unit_xqd[2 * unit], xqd1 = unit_xqd[2 * unit + 1];
     int32_t xq0, xq1;
@@ -537,80 +572,6 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
         int32_t v = (int32_t)(X[r] << 11);   // u << SGRPROJ_PRJ_BITS, u = x << SGRPROJ_RST_BITS
         if (has0) v += xq0 * D0[r];
         if (has1) v += xq1 * D1[r];
-        const int32_t w = (int32_t)(int16_t)((v + (1 << 10)) >> 11);
-        dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max(w, 0), 255);
-    }
-}
-
-// ---- svt_av1_loop_restoration_filter_frame for SGRPROJ units over a plane: per-unit parameter set (255 = RESTORE_NONE: copy) and xqd.
-// dbl != nullptr: normative stripe handling (StripeCtx); tiles are shifted by voff = 8 >> ss_y so that a 64x16 tile lies inside one
-// stripe (stripes are (64 >> ss_y) rows, the first one voff shorter) and inside one unit row.
-template <typename PIX, int BD>
-__global__ void __launch_bounds__(256)
-sgr_apply_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
-                 int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
-                 const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener) {
-    __shared__ TileLds L;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH - voff, tid = threadIdx.x;
-    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
-    const int ep = unit_ep[unit];
-    const bool wiener = ep == 254 && unit_wiener != nullptr;   // RESTORE_WIENER unit
-    if (ep > 15 && !wiener) {   // copy_tile (EbRestoration.c:1174-1177)
-        for (int k = tid; k < TW * TH; k += 256) {
-            const int i = k / TW, j = k - i * TW;
-            if (x0 + j < pw && y0 + i < ph && y0 + i >= 0) dst[(size_t)(y0 + i) * dst_stride + x0 + j] = dgd[(ptrdiff_t)(y0 + i) * stride + x0 + j];
-        }
-        return;
-    }
-    StripeCtx<PIX> sc{nullptr, 0, 0, 0, 0, 0};
-    if (dbl) {
-        const int s = (y0 + voff) / stripe_h;
-        sc.dbl = dbl; sc.dbl_stride = dbl_stride;
-        sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
-        sc.above = s > 0; sc.below = sc.sy1 < ph;
-    }
-    stage_and_boxsum(L, dgd, stride, pw, ph, x0, y0, tid, sc, !wiener);
-    if (wiener) {
-        // svt_av1_[highbd_]wiener_convolve_add_src (Common/Codec/convolve.c:60-241) on the staged tile: horizontal pass over the TH + 6
-        // rows into a 16-bit intermediate (round_0 = 3, clamped to WIENER_CLAMP_LIMIT), vertical pass (round_1 = 11) to the picture.
-        int fx[8], fy[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { fy[k] = unit_wiener[16 * unit + k]; fx[k] = unit_wiener[16 * unit + 8 + k]; }
-        uint16_t* tmp = (uint16_t*)L.s1;   // [IH][TW], 22 x 64 x 2 B inside the (unused) box-sum area
-        for (int k = tid; k < IH * TW; k += 256) {
-            const int r = k / TW, c = k - r * TW;
-            int32_t sum = ((int32_t)L.in[r * IW + c + 3] << 7) + (1 << (BD + 6));
-#pragma unroll
-            for (int t = 0; t < 7; t++) sum += (int32_t)L.in[r * IW + c + t] * fx[t];
-            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);
-        }
-        __syncthreads();
-        for (int k = tid; k < TW * TH; k += 256) {
-            const int i = k / TW, j = k - i * TW;
-            if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-            int32_t sum = ((int32_t)tmp[(i + 3) * TW + j] << 7) - (1 << (BD + 10));
-#pragma unroll
-            for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * TW + j] * fy[t];
-            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
-        }
-        return;
-    }
-    build_ab<BD>(L, ep, tid);
-    // svt_decode_xq (EbRestoration.c:707-718)
-    const int32_t xqd0 = unit_xqd[2 * unit], xqd1 = unit_xqd[2 * unit + 1];
-    int32_t xq0, xq1;
-    if (kSgr[ep][0] == 0) { xq0 = 0; xq1 = 128 - xqd1; }
-    else if (kSgr[ep][1] == 0) { xq0 = xqd0; xq1 = 0; }
-    else { xq0 = xqd0; xq1 = 128 - xq0 - xqd1; }
-    for (int k = tid; k < TW * TH; k += 256) {
-        const int i = k / TW, j = k - i * TW;
-        if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-        int32_t f0 = 0, f1 = 0;
-        filt_px(L, ep, i, j, f0, f1);
-        const int32_t u = (int32_t)L.in[(i + 3) * IW + j + 3] << 4;
-        int32_t v = u << 7;
-        if (kSgr[ep][0] > 0) v += xq0 * (f0 - u);
-        if (kSgr[ep][1] > 0) v += xq1 * (f1 - u);
         const int32_t w = (int32_t)(int16_t)((v + (1 << 10)) >> 11);
         dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max(w, 0), (1 << BD) - 1);
     }
@@ -629,20 +590,20 @@ extern "C" int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, 
 extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
                                          int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums) {
     const int voff = 8 >> ss_y;
-    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
     unsigned long long* s = (unsigned long long*)sums;
     if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
-    else hipLaunchKernelGGL((sgr_search_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,
                                         int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
                                         const uint8_t* unit_ep, const int32_t* unit_xqd, const int16_t* unit_wiener) {
     const int voff = 8 >> ss_y, sh = 64 >> ss_y;
-    dim3 grid((pw + 63) / 64, (ph + voff + 15) / 16), grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
     if (pix_bytes == 1) hipLaunchKernelGGL((lr_apply8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
     else if (bd == 8) hipLaunchKernelGGL((lr_apply8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
-    else hipLaunchKernelGGL((sgr_apply_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    else hipLaunchKernelGGL((lr_apply8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
     return (int)hipGetLastError();
 }

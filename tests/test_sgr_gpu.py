@@ -136,3 +136,33 @@ def test_mixed_wiener_sgr_apply(hip, orc, bd, ss):
         got = hip.to_host(d_dst, (h, w), ext.dtype)
         hip.free(d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst)
         assert np.array_equal(got, exp), (bd, ss, w, h, US, np.argwhere(got != exp)[:5])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_extreme_content(hip, orc, bd):
+    """Bound proofs of the on-chip search (packed A'/B' fields, 24-bit multiplies, int32 partial sums): binary 0 / max content in flat
+    areas, single-pixel and 2x2 checkerboards, random binary noise and isolated spikes, against a source that is the complement."""
+    w, h, US = 264, 200, 64
+    mx = (1 << bd) - 1
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(77 + bd)
+    yy, xx = np.mgrid[0:h, 0:w]
+    dgd = np.zeros((h, w), np.int64)
+    dgd[:, :66] = mx * ((xx[:, :66] + yy[:, :66]) & 1)                       # 1-px checkerboard
+    dgd[:, 66:132] = mx * (((xx[:, 66:132] >> 1) + (yy[:, 66:132] >> 1)) & 1)  # 2x2 checkerboard
+    dgd[:, 132:198] = mx * rng.integers(0, 2, (h, 66))                       # binary noise
+    dgd[:, 198:] = mx; dgd[::5, 198::7] = 0                                  # flat max with isolated zero spikes
+    dgd[100:, 198:] = 0; dgd[100::6, 200::5] = mx                            # flat zero with isolated max spikes
+    for comp in (True, False):
+        src = (mx - dgd) if comp else np.full((h, w), mx, np.int64)
+        ext = np.ascontiguousarray(np.pad(dgd.astype(dt), EXT, mode="edge")); st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        srcp = np.ascontiguousarray(src.astype(dt))
+        ux, uy = units(w, US), units(h, US)
+        e_sums = np.zeros((ux * uy, 16, 5), np.int64)
+        orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(srcp), w, w, h, 0, 0, US, bd, 0xFFFF, ptr(e_sums))
+        d_ext, d_src, d_sums = hip.to_device(ext), hip.to_device(srcp), hip.to_device(np.zeros_like(e_sums))
+        hip.check(hip.L.svt_hip_sgr_search_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, 0, 0xFFFF, d_sums), "search")
+        got = hip.to_host(d_sums, e_sums.shape, np.int64)
+        hip.free(d_ext, d_src, d_sums)
+        if bd == 10 and comp: assert np.abs(e_sums).max() > (1 << 31), "content must push the sums past 32 bits"
+        assert np.array_equal(got, e_sums), (bd, comp, np.argwhere(got != e_sums)[:5])

@@ -1,0 +1,81 @@
+"""Times the in-loop filter search / apply entry points on a 3840x2160 4:2:0 picture at 8 and 10 bit (HIP events):
+CDEF search + apply, SGR search + apply — the stages whose 16-bit paths use different kernels from the 8-bit bench step.
+    python tools/hbd_time.py [--bd 10]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from conftest import load_package  # noqa: E402
+
+pkg = load_package()
+ap = argparse.ArgumentParser()
+ap.add_argument("--bd", type=int, default=10)
+args = ap.parse_args()
+hip = pkg.Context(0)
+L = hip.L
+W, H, bd = 3840, 2160, args.bd
+dt = np.uint8 if bd == 8 else np.uint16
+pb = 1 if bd == 8 else 2
+rng = np.random.default_rng(4)
+src, rec = [], []
+for p in range(3):
+    w, h = (W, H) if p == 0 else (W // 2, H // 2)
+    yy, xx = np.mgrid[0:h, 0:w]
+    s = (100 + 60 * np.sin(xx / 11.0 + p) * np.cos(yy / 9.0) + 30 * (((xx + 2 * yy) // 14) % 2)) * (1 << (bd - 8))
+    src.append(np.clip(s, 0, (1 << bd) - 1).astype(dt))
+    rec.append(np.clip(s + rng.normal(0, 5 * (1 << (bd - 8)), (h, w)), 0, (1 << bd) - 1).astype(dt))
+skip8 = (rng.random((H // 8, W // 8)) < 0.25).astype(np.uint8)
+P3, I3 = C.c_void_p * 3, C.c_int * 3
+d_src = [hip.to_device(p) for p in src]; d_rec = [hip.to_device(p) for p in rec]; d_out = [hip.to_device(p) for p in rec]
+strides = I3(*[p.shape[1] for p in rec])
+nfb = ((H + 63) // 64) * ((W + 63) // 64)
+d_skip = hip.to_device(skip8)
+d_mse = hip.to_device(np.zeros((nfb, 2, 64), np.uint64))
+d_dir = hip.to_device(np.zeros((H // 8, W // 8), np.uint8)); d_var = hip.to_device(np.zeros((H // 8, W // 8), np.int32))
+ys = rng.integers(0, 64, nfb).astype(np.uint8); uvs = rng.integers(0, 64, nfb).astype(np.uint8)
+d_ys, d_uvs = hip.to_device(ys), hip.to_device(uvs)
+EXT = 3
+ext = [np.ascontiguousarray(np.pad(p, EXT, mode="edge")) for p in rec]
+d_ext = [hip.to_device(e) for e in ext]
+US = (256, 128, 128)
+units = [max((p.shape[1] + US[i] // 2) // US[i], 1) * max((p.shape[0] + US[i] // 2) // US[i], 1) for i, p in enumerate(rec)]
+d_sums = [hip.to_device(np.zeros((n, 16, 5), np.int64)) for n in units]
+d_ep = [hip.to_device(rng.integers(0, 16, n).astype(np.uint8)) for n in units]
+d_xqd = [hip.to_device(np.stack([rng.integers(-96, 32, n), rng.integers(-32, 96, n)], 1).astype(np.int32)) for n in units]
+
+
+def cdef_search():
+    hip.check(L.svt_hip_cdef_search_frame_dev(hip.h, pb, P3(*[p.value for p in d_rec]), strides, P3(*[p.value for p in d_src]), strides, W, H, d_skip, 5, bd,
+                                              d_mse, d_dir, d_var), "cdef search")
+
+
+def cdef_apply():
+    hip.check(L.svt_hip_cdef_apply_frame_dev(hip.h, pb, P3(*[p.value for p in d_rec]), P3(*[p.value for p in d_out]), strides, W, H, d_skip, d_ys, d_uvs, 5, bd,
+                                             d_dir, d_var), "cdef apply")
+
+
+def sgr_search():
+    for p in range(3):
+        st = ext[p].shape[1]
+        hip.check(L.svt_hip_sgr_search_plane_dev(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
+                                                 US[p], int(p > 0), 0xFFFF, d_sums[p]), "sgr search")
+
+
+def sgr_apply():
+    for p in range(3):
+        st = ext[p].shape[1]
+        hip.check(L.svt_hip_sgr_apply_plane_dev(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_out[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
+                                                US[p], int(p > 0), d_rec[p], rec[p].shape[1], d_ep[p], d_xqd[p]), "sgr apply")
+
+
+ms = C.c_float()
+for name, fn in (("cdef_search", cdef_search), ("cdef_apply", cdef_apply), ("sgr_search", sgr_search), ("sgr_apply", sgr_apply)):
+    for _ in range(3): fn()
+    L.svt_hip_timer_start(hip.h)
+    for _ in range(10): fn()
+    L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
+    print(f"{name:12s} {W}x{H} bd{bd}: {ms.value / 10:.3f} ms")
