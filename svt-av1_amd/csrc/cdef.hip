@@ -286,11 +286,31 @@ template <> struct Dots<uint8_t> {
     }
 };
 template <> struct Dots<uint16_t> {
+    // packed pairs through v_dot2_u32_u16; 64 samples of <= 12 bits: every sum stays below 2^32
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ void run(const uint16_t* a, const uint16_t* b, uint32_t& sa, uint32_t& saa, uint32_t& sab) {
+        const uint32_t* pa = (const uint32_t*)a; const uint32_t* pb = (const uint32_t*)b;
         sa = saa = sab = 0;
-        for (int k = 0; k < 64; k++) { const uint32_t va = a[k], vb = b[k]; sa += va; saa += va * va; sab += va * vb; }
+        const u16x2 ones = {1, 1};
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const u16x2 va = __builtin_bit_cast(u16x2, pa[k]), vb = __builtin_bit_cast(u16x2, pb[k]);
+            sa  = __builtin_amdgcn_udot2(va, ones, sa, false);
+            saa = __builtin_amdgcn_udot2(va, va, saa, false);
+            sab = __builtin_amdgcn_udot2(va, vb, sab, false);
+        }
     }
 };
+
+// total of v over the 64 lanes of a wave (wave-uniform result): DPP inside the 16-lane rows, then the four row totals
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
 
 // ------------------------------------------------------------------------------- search, luma ---
 template <typename PIX>
@@ -336,13 +356,14 @@ cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* 
             const s16x2 y = combine2(T, g >> 2, (g >> 1) & 1);
             ytab[wave][g][lane] = (PIX)y.x; ytab[wave][g + 1][lane] = (PIX)y.y;
         }
-        stab[wave][lane] = src[(size_t)(64 * fbr + 8 * by + i) * src_stride + 64 * fbc + 8 * bx + j];
+        const uint32_t sv = src[(size_t)(64 * fbr + 8 * by + i) * src_stride + 64 * fbc + 8 * bx + j];
+        stab[wave][lane] = (PIX)sv;
         __builtin_amdgcn_wave_barrier();
         // lane g reduces strength g: dist_8x8 (EbEncCdef.c:79-105), names as in the reference:
         //   s = filtered ("src" there), d = source picture ("dst" there)
-        uint32_t sum_s, sum_s2, sum_sd, sum_d, sum_d2, dummy;
+        uint32_t sum_s, sum_s2, sum_sd;
         Dots<PIX>::run(&ytab[wave][lane][0], &stab[wave][0], sum_s, sum_s2, sum_sd);
-        Dots<PIX>::run(&stab[wave][0], &stab[wave][0], sum_d, sum_d2, dummy);
+        const uint32_t sum_d = wave_sum_u32(sv), sum_d2 = wave_sum_u32(sv * sv);   // the same for every strength
         const uint64_t svar = (uint64_t)sum_s2 - (((uint64_t)sum_s * sum_s + 32) >> 6);
         const uint64_t dvar = (uint64_t)sum_d2 - (((uint64_t)sum_d * sum_d + 32) >> 6);
         const double num = (double)((uint64_t)sum_d2 + sum_s2 - 2 * (uint64_t)sum_sd) * .5 * (double)(svar + dvar + (uint64_t)(400 << 2 * cs));
@@ -409,9 +430,9 @@ cdef_search_chroma_kernel(const PIX* __restrict__ rec_u, const PIX* __restrict__
         }
         stab[wave][lane] = s;
         __builtin_amdgcn_wave_barrier();
-        uint32_t sy1, sy2, sys, ss1, ss2, dummy;
+        uint32_t sy1, sy2, sys;
         Dots<PIX>::run(&ytab[wave][lane][0], &stab[wave][0], sy1, sy2, sys);
-        Dots<PIX>::run(&stab[wave][0], &stab[wave][0], ss1, ss2, dummy);
+        const uint32_t ss2 = wave_sum_u32((uint32_t)s * (uint32_t)s);
         acc[pl] += (unsigned long long)sy2 + ss2 - 2ull * sys;  // sum (y - s)^2, mse_4_*: EbEncCdef.c:67-77,121-131
         __builtin_amdgcn_wave_barrier();
     }
