@@ -1,5 +1,5 @@
 """Times the in-loop filter search / apply entry points on a 3840x2160 4:2:0 picture at 8 and 10 bit (HIP events):
-CDEF search + apply, SGR search + apply — the stages whose 16-bit paths use different kernels from the 8-bit bench step.
+deblock, CDEF search + apply, SGR search + apply and the 16x16 sub-pel prediction — the stages whose 16-bit paths differ from the 8-bit bench step.
     python tools/hbd_time.py [--bd 10]"""
 import argparse
 import ctypes as C
@@ -10,6 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from conftest import load_package  # noqa: E402
+import dlf_common as dc  # noqa: E402
 
 pkg = load_package()
 ap = argparse.ArgumentParser()
@@ -72,8 +73,36 @@ def sgr_apply():
                                                 US[p], int(p > 0), d_rec[p], rec[p].shape[1], d_ep[p], d_xqd[p]), "sgr apply")
 
 
+mi, cols, rows = dc.make_mode_info(W, H)
+edges = [dc.build_edges(mi, cols, rows, p, rec[p].shape[1], rec[p].shape[0]) for p in range(3)]
+d_ev = [hip.to_device(e[0]) for e in edges]; d_eh = [hip.to_device(e[1]) for e in edges]
+d_dbl = [hip.to_device(p) for p in rec]
+
+
+def deblock():   # in place on a scratch copy (content drifts over the repeats; the work per edge does not depend on it)
+    hip.check(L.svt_hip_deblock_frame_dev(hip.h, P3(*[p.value for p in d_dbl]), pb, strides, bd, P3(*[p.value for p in d_ev]), P3(*[p.value for p in d_eh]),
+                                          I3(*[e[0].shape[1] for e in edges]), I3(*[e[0].shape[0] for e in edges]), 0), "deblock")
+
+
+PAD = 32
+refp = np.ascontiguousarray(np.pad(rec[0], PAD, mode="edge"))
+d_refp = hip.to_device(refp); d_pred = hip.to_device(np.zeros_like(rec[0]))
+n16 = (W // 16) * (H // 16)
+CB = (pkg.ConvBlk * n16)()
+k = 0
+for by in range(0, H, 16):
+    for bx in range(0, W, 16):
+        CB[k] = pkg.ConvBlk(bx + int(rng.integers(-8, 9)), by + int(rng.integers(-8, 9)), bx, by, 16, 16, 0, 0, int(rng.integers(0, 16)), int(rng.integers(0, 16)), 0, 0)
+        k += 1
+d_cb = hip.to_device(np.frombuffer(bytes(CB), np.uint8))
+
+
+def subpel():
+    hip.check(L.svt_hip_subpel_predict_batch_dev(hip.h, pb, bd, d_refp.value + (PAD * refp.shape[1] + PAD) * pb, refp.shape[1], d_pred, W, d_cb, n16), "subpel")
+
+
 ms = C.c_float()
-for name, fn in (("cdef_search", cdef_search), ("cdef_apply", cdef_apply), ("sgr_search", sgr_search), ("sgr_apply", sgr_apply)):
+for name, fn in (("deblock", deblock), ("subpel_16x16", subpel), ("cdef_search", cdef_search), ("cdef_apply", cdef_apply), ("sgr_search", sgr_search), ("sgr_apply", sgr_apply)):
     for _ in range(3): fn()
     L.svt_hip_timer_start(hip.h)
     for _ in range(10): fn()
