@@ -102,10 +102,15 @@ int svt_hip_me_set_waves_per_sb(SvtHipCtx *ctx, int waves);
  *   0 svt_aom_quantize_b (8-bit, EbFullLoop.c:37)      1 svt_aom_highbd_quantize_b (:171)
  *   2 svt_av1_quantize_fp[_32x32|_64x64] (:379,557,580) 3 svt_av1_highbd_quantize_fp (:534)
  * For variants 2/3 pass round_fp_qtx / quant_fp_qtx in round / quant (as the facades :603-711 do).
- * log_scale = av1_get_tx_scale_tab[tx_size] (EbFullLoop.h:66).  Quant matrices are flat on this path. */
+ * log_scale = av1_get_tx_scale_tab[tx_size] (EbFullLoop.h:66).  Quant matrices are flat on this path.
+ * coeff_shape = the EB_TRANS_COEFF_SHAPE argument of av1_estimate_transform (Encoder/Codec/EbTransforms.c:3613,
+ * EbDefinitions.h:2610-2614): 0 DEFAULT_SHAPE, 1 N2_SHAPE (only the top-left W/2 x H/2 coefficients are produced, the
+ * rest are zero), 2 N4_SHAPE (W/4 x H/4), 3 ONLY_DC_SHAPE (coefficient 0 only).  For shapes 1-3 the 64-point energy
+ * is 0, as handle_transform*_N2_N4 (:2933-2964) returns it. */
 typedef struct {
     int32_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
     int32_t log_scale, variant;
+    int32_t coeff_shape;
 } SvtHipQuantParams;
 /* Device pointers to the inverse scan (position of coefficient rc in scan order) of the launch's
  * tx_size for the three scan classes of av1_scan_orders (Common/Codec/EbCoefficients.h:2563):
@@ -115,8 +120,9 @@ typedef struct {
 } SvtHipScanTables;
 
 /* residual (src - pred) -> forward 2-D transform -> [64-pt zero-out/re-pack + energy] -> quantize.
- * Replaces svt_residual_kernel8bit/16bit (common_dsp_rtcd.h:169), svt_av1_fwd_txfm2d_WxH
- * (aom_dsp_rtcd.h:129-135), svt_handle_transform64x* (:230) and the quantizers (:252-258) +
+ * Replaces svt_residual_kernel8bit/16bit (common_dsp_rtcd.h:169), av1_estimate_transform
+ * (EbTransforms.c:3613: svt_av1_fwd_txfm2d_WxH[_N2|_N4], aom_dsp_rtcd.h:129-135, 284-350;
+ * svt_handle_transform64x*[_N2_N4], :230; qp->coeff_shape, default shape when qp is NULL) and the quantizers (:252-258) +
  * cul_level (EbFullLoop.c:1595-1608) for a whole list of blocks.
  *   pix_bytes 1: uint8_t planes, 2: uint16_t planes; strides in pixels.
  *   coeff / qcoeff+dqcoeff / eob / cul_level / energy may be NULL independently (qcoeff and dqcoeff

@@ -93,6 +93,7 @@ void orc_iadst(const int32_t *in, int32_t *out, int n, int cos_bit, int clamp_bi
 void orc_identity(const int32_t *in, int32_t *out, int n);
 void orc_fwd_txfm2d(const int16_t *input, int32_t *output, uint32_t stride, int tx_type, int tx_size, int bd);
 uint64_t orc_handle_transform(int32_t *coeff, int tx_size);
+uint64_t orc_estimate_transform(const int16_t *residual, uint32_t stride, int32_t *coeff, int tx_type, int tx_size, int bd, int shape);
 void orc_inv_txfm2d_add(const int32_t *input, const uint16_t *pred, int32_t stride_r, uint16_t *recon,
                         int32_t stride_w, int tx_type, int tx_size, int bd);
 void orc_inv_txfm_add_8bit(const int32_t *input, const uint8_t *pred, int32_t stride_r, uint8_t *recon,

@@ -394,6 +394,32 @@ uint64_t orc_handle_transform(int32_t *coeff, int tx_size) {
     return e;
 }
 
+/* av1_estimate_transform (Encoder/Codec/EbTransforms.c:3613-3670) for a coefficient shape (EB_TRANS_COEFF_SHAPE, EbDefinitions.h:2610-2614:
+ * 0 DEFAULT_SHAPE, 1 N2_SHAPE, 2 N4_SHAPE, 3 ONLY_DC_SHAPE): forward transform + the 64-point zero-out / re-pack, output = the packed
+ * min(W,32) x min(H,32) block, return value = *three_quad_energy.
+ * The N2 / N4 transform families (:3840-7250) are the default butterfly graphs pruned to the outputs of the top-left W/2 x H/2 (W/4 x H/4)
+ * corner: those coefficients equal the default transform's, every other one is written as zero, and handle_transform*_N2_N4 (:2933-2964)
+ * only re-packs (energy 0).  ONLY_DC (:3407-3431) runs N4 and then clears everything except coefficient 0. */
+uint64_t orc_estimate_transform(const int16_t *residual, uint32_t stride, int32_t *coeff, int tx_type, int tx_size, int bd, int shape) {
+    const int W = tx_w[tx_size], H = tx_h[tx_size];
+    const int kw = W > 32 ? 32 : W, kh = H > 32 ? 32 : H;
+    int32_t *full = (int32_t *)malloc(sizeof(int32_t) * W * H);
+    orc_fwd_txfm2d(residual, full, stride, tx_type, tx_size, bd);
+    uint64_t energy = 0;
+    if (shape == 0) energy = orc_handle_transform(full, tx_size);
+    else {
+        const int cw = shape == 3 ? 1 : W >> shape, ch = shape == 3 ? 1 : H >> shape;
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++)
+                if (r >= ch || c >= cw) full[r * W + c] = 0;
+        if (kw != W)
+            for (int r = 1; r < kh; r++) memmove(full + r * kw, full + r * W, sizeof(int32_t) * kw);
+    }
+    memcpy(coeff, full, sizeof(int32_t) * kw * kh);
+    free(full);
+    return energy;
+}
+
 /* inv_txfm2d_add_c (Common/Codec/EbInvTransforms.c:2455-2533), svt_av1_get_inv_txfm_cfg (:2432),
  * svt_av1_gen_inv_stage_range (:23-60), the 64-pt input re-mapping (:2648-2714), pixel add with
  * highbd_clip_pixel_add/check_range (:2398-2416).  `input` is the packed min(W,32) x min(H,32) block. */

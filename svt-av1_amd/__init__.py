@@ -27,7 +27,7 @@ class SbSearch(C.Structure):
 class QuantParams(C.Structure):
     """SvtHipQuantParams (include/svt_hip.h)."""
     _fields_ = [("zbin", C.c_int32 * 2), ("round", C.c_int32 * 2), ("quant", C.c_int32 * 2), ("quant_shift", C.c_int32 * 2),
-                ("dequant", C.c_int32 * 2), ("log_scale", C.c_int32), ("variant", C.c_int32)]
+                ("dequant", C.c_int32 * 2), ("log_scale", C.c_int32), ("variant", C.c_int32), ("coeff_shape", C.c_int32)]
 
 
 class ScanTables(C.Structure):

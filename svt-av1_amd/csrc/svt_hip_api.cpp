@@ -202,7 +202,7 @@ int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, c
                                      uint64_t* d_energy) {
     if (!c || !d_src || !d_pred || !d_descs || nblk < 0 || tx_size < 0 || tx_size > 18 || (pix_bytes != 1 && pix_bytes != 2) ||
         ((d_qcoeff != nullptr) != (d_dqcoeff != nullptr)) || (d_qcoeff && (!qp || !scans || !scans->iscan[0])) ||
-        (qp && (qp->variant < 0 || qp->variant > 3 || qp->log_scale < 0 || qp->log_scale > 2))) {
+        (qp && (qp->variant < 0 || qp->variant > 3 || qp->log_scale < 0 || qp->log_scale > 2 || qp->coeff_shape < 0 || qp->coeff_shape > 3))) {
         if (c) c->err = "svt_hip_fwd_txfm_quant_batch_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
     }
@@ -384,7 +384,7 @@ int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFw
         const SvtHipFwdTxJob& J = jobs[j];
         if (J.nblk < 0 || J.tx_size < 0 || J.tx_size > 18 || (J.nblk && (!J.d_src || !J.d_pred || !J.d_descs)) ||
             ((J.d_qcoeff != nullptr) != (J.d_dqcoeff != nullptr)) || (J.d_qcoeff && !J.scans.iscan[0]) || J.qp.variant < 0 || J.qp.variant > 3 ||
-            J.qp.log_scale < 0 || J.qp.log_scale > 2) {
+            J.qp.log_scale < 0 || J.qp.log_scale > 2 || J.qp.coeff_shape < 0 || J.qp.coeff_shape > 3) {
             c->err = "svt_hip_fwd_txfm_quant_multi_dev: bad job";
             return SVT_HIP_ERR_BAD_ARG;
         }

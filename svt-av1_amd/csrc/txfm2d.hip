@@ -196,8 +196,15 @@ __device__ __forceinline__ void fwd_block(int32_t* __restrict__ tile, int wg, in
             if (RECT2) v = mul_sqrt2(v);
             out[c] = v;
         }
-        // 64-pt sizes keep the top-left 32x32 / 32x16 / 16x32 only (svt_handle_transform*, EbTransforms.c:2763-2931)
-        if constexpr (KW != W || KH != H) {
+        if (qp.coeff_shape) {
+            // N2 / N4 / ONLY_DC (av1_estimate_transform_N2 / _N4 / _ONLY_DC, EbTransforms.c:3055-3431): the pruned transform families produce
+            // the default coefficients of the top-left corner and zeros elsewhere; no energy of the discarded region (:2933-2964)
+            const int cw = qp.coeff_shape == 3 ? 1 : W >> qp.coeff_shape, ch = qp.coeff_shape == 3 ? 1 : H >> qp.coeff_shape;
+#pragma unroll
+            for (int c = 0; c < W; c++)
+                if (c >= cw || t >= ch) out[c] = 0;
+        } else if constexpr (KW != W || KH != H) {
+            // 64-pt sizes keep the top-left 32x32 / 32x16 / 16x32 only (svt_handle_transform*, EbTransforms.c:2763-2931)
 #pragma unroll
             for (int c = 0; c < W; c++)
                 if (c >= KW || t >= KH) energy += (uint64_t)((int64_t)out[c] * (int64_t)out[c]);

@@ -157,6 +157,29 @@ def test_txfm_2d_all_sizes_types(orc, ref):
                     assert np.array_equal(r1, r2), ("inv", ts, tt, bd, it)
 
 
+def test_estimate_transform_coeff_shapes(orc, ref):
+    """av1_estimate_transform (EbTransforms.c:3613) with every EB_TRANS_COEFF_SHAPE (DEFAULT / N2 / N4 / ONLY_DC): the packed coefficient
+    block and three_quad_energy, all 19 sizes x legal types x bd 8 / 10.  The output buffer is pre-filled with garbage: the N2 / N4
+    functions must write the zeros themselves."""
+    orc.orc_estimate_transform.restype = C.c_uint64
+    rng = np.random.default_rng(33)
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        kw, kh = min(w, 32), min(h, 32)
+        for bd in (8, 10):
+            for tt in tc.legal_types(ts):
+                res = rng.integers(-(1 << bd) + 1, 1 << bd, (h, w + 3)).astype(np.int16)
+                for shape in range(4):
+                    exp = np.full(w * h, 0x5A5A5A, np.int32)
+                    e_en = C.c_uint64(0)
+                    assert ref.av1_estimate_transform(ptr(res), w + 3, ptr(exp), w, ts, C.byref(e_en), bd, tt, 0, shape) == 0
+                    got = np.zeros(kw * kh, np.int32)
+                    g_en = orc.orc_estimate_transform(ptr(res), w + 3, ptr(got), tt, ts, bd, shape)
+                    assert np.array_equal(got, exp[:kw * kh]), (tc.TX_NAMES[ts], bd, tt, shape)
+                    assert g_en == e_en.value, (tc.TX_NAMES[ts], bd, tt, shape, g_en, e_en.value)
+                    if shape == 3: assert not got[1:].any()
+
+
 def test_quantize_variants(orc, ref):
     """quantize_b (8-bit c_ii), highbd_quantize_b, quantize_fp (3 scales), highbd_quantize_fp vs the
     reference across q-index, sizes and coefficient ranges +-2^(7+bd)

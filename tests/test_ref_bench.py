@@ -204,3 +204,29 @@ def test_hbd_drivers(orc, refb, pkg):
     g_xq = np.zeros((nu, 16, 2), np.int32)
     refb.refb_sgr_search_plane_hbd(C.c_void_p(ext.ctypes.data + off), st, ptr(cur), w, ptr(lim), 0, nu, 64, 64, 0xFFFF, bd, ptr(g_xq))
     assert np.array_equal(e_xq, g_xq) and e_xq.any()
+
+
+def test_estimate_transform_coeff_shapes(orc, refb):
+    """av1_estimate_transform through the RTCD pointers of either flavour (the AVX2 / AVX-512 N2 and N4 transform kernels on the SIMD
+    build) for the four coefficient shapes vs the oracle; 8-bit residuals, all sizes and legal types."""
+    import txfm_common as tc
+    orc.orc_estimate_transform.restype = C.c_uint64
+    rng = np.random.default_rng(34)
+
+    def aligned(n, dtype):   # the SIMD kernels use aligned loads / stores on both buffers
+        raw = np.zeros(n * np.dtype(dtype).itemsize + 64, np.uint8)
+        o = (-raw.ctypes.data) % 64
+        return raw[o:o + n * np.dtype(dtype).itemsize].view(dtype)
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        kw, kh = min(w, 32), min(h, 32)
+        for tt in tc.legal_types(ts):
+            res = aligned(w * h, np.int16); res[:] = rng.integers(-255, 256, w * h)
+            for shape in range(4):
+                exp = aligned(w * h, np.int32); exp[:] = 0x5A5A5A
+                e_en = C.c_uint64(0)
+                assert refb.av1_estimate_transform(ptr(res), w, ptr(exp), w, ts, C.byref(e_en), 8, tt, 0, shape) == 0
+                got = np.zeros(kw * kh, np.int32)
+                g_en = orc.orc_estimate_transform(ptr(res), w, ptr(got), tt, ts, 8, shape)
+                assert np.array_equal(got, exp[:kw * kh]), (tc.TX_NAMES[ts], tt, shape)
+                assert g_en == e_en.value, (tc.TX_NAMES[ts], tt, shape)

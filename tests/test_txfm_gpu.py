@@ -25,7 +25,7 @@ def qparams_struct(pkg, qp, variant, log_scale):
     return s
 
 
-def run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant, want_coeff=True):
+def run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant, want_coeff=True, shape=0):
     """src/pred: 2-D pixel planes (u8 or u16).  Returns dict of host arrays."""
     w, h = tc.TXW[ts], tc.TXH[ts]
     nk = min(w, 32) * min(h, 32)
@@ -40,7 +40,7 @@ def run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant, want_coeff=True):
             p = hip.to_device(np.ascontiguousarray(T[key])); keep.append(p); scans.iscan[cls] = p.value
     d_co, d_q, d_dq = hip.empty(n * nk * 4), hip.empty(n * nk * 4), hip.empty(n * nk * 4)
     d_eob, d_cul, d_en = hip.empty(n * 2), hip.empty(n * 4), hip.empty(n * 8)
-    qs = qparams_struct(pkg, qp, variant, tc.TX_SCALE[ts])
+    qs = qparams_struct(pkg, qp, variant, tc.TX_SCALE[ts]); qs.coeff_shape = shape
     hip.check(hip.L.svt_hip_fwd_txfm_quant_batch_dev(hip.h, ts, pix, d_src, src.shape[1], d_pred, pred.shape[1], d_desc, n,
                                                     C.byref(qs), C.byref(scans), d_co if want_coeff else None, d_q, d_dq, d_eob, d_cul, d_en), "fwd")
     out = dict(coeff=hip.to_host(d_co, (n, nk), np.int32), q=hip.to_host(d_q, (n, nk), np.int32), dq=hip.to_host(d_dq, (n, nk), np.int32),
@@ -60,15 +60,20 @@ def run_inv(hip, ts, bd, dq, pred, descs):
     return rec
 
 
-def oracle_block(orc, ts, tt, bd, src, pred, x, y, qp, variant, scan):
+def oracle_block(orc, ts, tt, bd, src, pred, x, y, qp, variant, scan, shape=0):
     w, h = tc.TXW[ts], tc.TXH[ts]
     kw, kh = min(w, 32), min(h, 32)
     res = (src[y:y + h, x:x + w].astype(np.int32) - pred[y:y + h, x:x + w].astype(np.int32)).astype(np.int16)
     res = np.ascontiguousarray(res)
-    co = tc.orc_fwd(orc, res, w, tt, ts, bd)
-    orc.orc_handle_transform.restype = C.c_uint64
-    en = orc.orc_handle_transform(ptr(co), ts)
-    co = np.ascontiguousarray(co[:kw * kh])
+    if shape:
+        orc.orc_estimate_transform.restype = C.c_uint64
+        co = np.zeros(kw * kh, np.int32)
+        en = orc.orc_estimate_transform(ptr(res), w, ptr(co), tt, ts, bd, shape)
+    else:
+        co = tc.orc_fwd(orc, res, w, tt, ts, bd)
+        orc.orc_handle_transform.restype = C.c_uint64
+        en = orc.orc_handle_transform(ptr(co), ts)
+        co = np.ascontiguousarray(co[:kw * kh])
     q, dq, eob = tc.orc_quant(orc, variant, co, qp, scan, tc.TX_SCALE[ts])
     orc.orc_cul_level.restype = C.c_int32
     cul = orc.orc_cul_level(ptr(q), ptr(scan), eob)
@@ -203,3 +208,69 @@ def test_mixed_size_launches(hip, pkg, bd):
             x, y = int(d & 0x3FFF), int((d >> 14) & 0x3FFF)
             assert np.array_equal(rec[y:y + h, x:x + w], exp["rec"][y:y + h, x:x + w]), ("rec", ts)
     hip.free(d_src, d_pred, d_rec_multi, *keep, *[v for o in outs for v in o.values()])
+
+
+@pytest.mark.parametrize("shape", [1, 2, 3])
+def test_coeff_shapes(hip, pkg, orc, shape):
+    """EB_TRANS_COEFF_SHAPE N2 / N4 / ONLY_DC of av1_estimate_transform (qp.coeff_shape) for every size and legal type: coefficients,
+    energy (0), quantized levels, eob and cul_level vs the oracle (pinned to the reference's N2 / N4 transform families in
+    tests/test_oracle_vs_ref.py::test_estimate_transform_coeff_shapes and, AVX2 / AVX-512, tests/test_ref_bench.py)."""
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]
+        rng = np.random.default_rng(500 + 19 * shape + ts)
+        for bd in (8, 10):
+            dt = np.uint8 if bd == 8 else np.uint16
+            types = tc.legal_types(ts)
+            PW, PH = 2 * 64 + 8, 2 * 64
+            src = rng.integers(0, 1 << bd, (PH, PW)).astype(dt); pred = rng.integers(0, 1 << bd, (PH, PW)).astype(dt)
+            pos = [(x, y) for y in range(0, PH - h + 1, h) for x in range(0, 128 - w + 1, w)]
+            rng.shuffle(pos); pos = pos[:max(len(types), 4)]
+            tts = [types[i % len(types)] for i in range(len(pos))]
+            descs = [pkg.tx_desc(x, y, tt) for (x, y), tt in zip(pos, tts)]
+            variant = 0 if bd == 8 else 1
+            qp = np.ascontiguousarray(T[f"qp/{bd}/60/0"])
+            g = run_fwd(hip, pkg, ts, bd, src, pred, descs, qp, variant, shape=shape)
+            for i, ((x, y), tt) in enumerate(zip(pos, tts)):
+                scan, _ = golden_scan(ts, tt)
+                co, en, q, dq, eob, cul = oracle_block(orc, ts, tt, bd, src, pred, x, y, qp, variant, scan, shape)
+                assert en == 0 and int(g["energy"][i]) == 0
+                assert np.array_equal(g["coeff"][i], co), ("coeff", ts, tt, bd, shape)
+                assert np.array_equal(g["q"][i], q) and np.array_equal(g["dq"][i], dq), ("quant", ts, tt, bd, shape)
+                assert int(g["eob"][i]) == eob and int(g["cul"][i]) == cul, ("eob/cul", ts, tt, bd, shape)
+            assert any(g["coeff"][i].any() for i in range(len(pos)))
+
+
+def test_coeff_shape_multi_and_bad_arg(hip, pkg, orc):
+    """The mixed-size launch honours the per-job shape; shape 4 is rejected."""
+    rng = np.random.default_rng(9)
+    src = rng.integers(0, 256, (64, 64)).astype(np.uint8); pred = rng.integers(0, 256, (64, 64)).astype(np.uint8)
+    d_src, d_pred = hip.to_device(src), hip.to_device(pred)
+    jobs = (pkg.FwdTxJob * 2)()
+    keep = []
+    for j, (ts, shape) in enumerate(((1, 1), (4, 2))):
+        w = tc.TXW[ts]
+        descs = np.asarray([pkg.tx_desc(x, y, 0) for y in range(0, 64, w) for x in range(0, 64, w)], np.uint32)
+        nk = min(w, 32) ** 2
+        d_desc, d_co = hip.to_device(descs), hip.empty(len(descs) * nk * 4)
+        keep += [d_desc, d_co]
+        J = jobs[j]
+        J.tx_size, J.nblk, J.d_src, J.src_stride, J.d_pred, J.pred_stride, J.d_descs = ts, len(descs), d_src.value, 64, d_pred.value, 64, d_desc.value
+        J.qp.coeff_shape = shape; J.d_coeff = d_co.value
+    hip.check(hip.L.svt_hip_fwd_txfm_quant_multi_dev(hip.h, 1, jobs, 2), "multi")
+    orc.orc_estimate_transform.restype = C.c_uint64
+    for j, (ts, shape) in enumerate(((1, 1), (4, 2))):
+        w = tc.TXW[ts]; nk = min(w, 32) ** 2
+        got = hip.to_host(keep[2 * j + 1], (jobs[j].nblk, nk), np.int32)
+        k = 0
+        for y in range(0, 64, w):
+            for x in range(0, 64, w):
+                res = np.ascontiguousarray((src[y:y + w, x:x + w].astype(np.int32) - pred[y:y + w, x:x + w]).astype(np.int16))
+                co = np.zeros(nk, np.int32)
+                orc.orc_estimate_transform(ptr(res), w, ptr(co), 0, ts, 8, shape)
+                assert np.array_equal(got[k], co), (ts, shape, k)
+                k += 1
+    jobs[0].qp.coeff_shape = 4
+    assert hip.L.svt_hip_fwd_txfm_quant_multi_dev(hip.h, 1, jobs, 2) != 0
+    qs = pkg.QuantParams(); qs.coeff_shape = -1
+    assert hip.L.svt_hip_fwd_txfm_quant_batch_dev(hip.h, 1, 1, d_src, 64, d_pred, 64, keep[0], 1, C.byref(qs), None, keep[1], None, None, None, None, None) != 0
+    hip.free(d_src, d_pred, *keep)
