@@ -272,10 +272,12 @@ typedef struct {
     uint16_t w, h;
 } SvtHipBlkPair;
 /* svt_nxm_sad_kernel / svt_aom_sad{W}x{H} / sad_16b_kernel (aom_dsp_rtcd.h:334-336, :644, :651) for a list
- * of block pairs. */
+ * of block pairs.  svt_aom_sad{W}x{H}x4d (:267-330) = four pairs that share the a block. */
 int svt_hip_block_sad_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, int a_stride, const void *d_b, int b_stride,
                                 const SvtHipBlkPair *d_pairs, int n, uint32_t *d_sad);
-/* svt_aom_variance{W}x{H} (8-bit) / svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:524, :568). */
+/* svt_aom_variance{W}x{H} (8-bit) / svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:524, :568).  svt_aom_mse16x16 (:248,
+ * Encoder/Codec/EbPsnr.c:84) is the 16x16 case: return value = d_var, *sse = d_sse; svt_aom_highbd_8_mse16x16 (:263) is the plain
+ * 16-bit SSE of svt_hip_block_sse_batch_dev. */
 int svt_hip_block_variance_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_a, int a_stride, const void *d_b,
                                      int b_stride, const SvtHipBlkPair *d_pairs, int n, uint32_t *d_var, uint32_t *d_sse);
 

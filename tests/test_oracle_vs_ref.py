@@ -362,6 +362,30 @@ def test_upsampled_pred_and_variance(orc, ref):
 
 
 # -------------------------------------------------------------------------- pyramids (HME inputs)
+def test_sad_x4d_and_mse16x16(orc, ref):
+    """svt_aom_sad{W}x{H}x4d (four references = four block pairs of the batch SAD, EbComputeSAD_C.c:118-135) and svt_aom_mse16x16 (EbPsnr.c:84) /
+    svt_aom_highbd_8_mse16x16 (C_DEFAULT/variance.c:381): the variance / sse outputs of a 16x16 pair, against the oracle's SAD / variance."""
+    rng = np.random.default_rng(61)
+    orc.orc_nxm_sad.restype = C.c_uint32; orc.orc_variance.restype = C.c_uint32
+    for (w, h) in ((4, 4), (8, 16), (16, 16), (32, 8), (64, 64), (128, 64), (64, 128), (128, 128)):
+        src = rng.integers(0, 256, (h, w + 5)).astype(np.uint8)
+        refs = [rng.integers(0, 256, (h, w + 9)).astype(np.uint8) for _ in range(4)]
+        pa = (C.c_void_p * 4)(*[r.ctypes.data for r in refs])
+        out = (C.c_uint32 * 4)()
+        getattr(ref, f"svt_aom_sad{w}x{h}x4d_c")(ptr(src), w + 5, pa, w + 9, out)
+        for k in range(4):
+            assert out[k] == orc.orc_nxm_sad(ptr(src), w + 5, ptr(refs[k]), w + 9, h, w) == getattr(ref, f"svt_aom_sad{w}x{h}_c")(ptr(src), w + 5, ptr(refs[k]), w + 9)
+    a = rng.integers(0, 256, (16, 21)).astype(np.uint8); b = rng.integers(0, 256, (16, 19)).astype(np.uint8)
+    e_sse, g_sse = C.c_uint32(), C.c_uint32()
+    ref.svt_aom_mse16x16_c.restype = C.c_uint32
+    e_var = ref.svt_aom_mse16x16_c(ptr(a), 21, ptr(b), 19, C.byref(e_sse))   # EbPsnr.c:84: a 16x16 variance; get_sse() reads *sse
+    assert orc.orc_variance(ptr(a), 21, ptr(b), 19, 16, 16, C.byref(g_sse)) == e_var
+    assert g_sse.value == e_sse.value
+    a16, b16 = a.astype(np.uint16), b.astype(np.uint16)
+    ref.svt_aom_highbd_8_mse16x16_c(C.c_void_p(a16.ctypes.data >> 1), 21, C.c_void_p(b16.ctypes.data >> 1), 19, C.byref(e_sse))   # CONVERT_TO_BYTEPTR
+    assert g_sse.value == e_sse.value
+
+
 def test_downsample_and_mean_kernels(orc, ref):
     """decimation_2d / downsample_2d and the 8x8 mean / mean-of-squares kernels behind the variance
     pyramid (/root/reference/test/compute_mean_test.cc:83-165)."""
