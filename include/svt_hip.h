@@ -358,6 +358,25 @@ int svt_hip_sgr_search_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const vo
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride,
                                 int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride,
                                 const uint8_t *d_unit_ep, const int32_t *d_unit_xqd);
+/* get_pixel_proj_error (Encoder/Codec/EbRestorationPick.c:317-351: svt_decode_xq + svt_av1_lowbd_pixel_proj_error /
+ * svt_av1_highbd_pixel_proj_error, aom_dsp_rtcd.h) for every restoration unit of a plane, every parameter set in ep_mask and ncand
+ * (1..SVT_HIP_SGR_MAX_CAND) xqd pairs per (unit, set): d_xqd[unit][16][ncand][2] -> d_err[unit][16][ncand] (cleared by the call;
+ * entries of sets outside ep_mask stay 0; a first candidate with xqd[0] == INT32_MIN skips that (unit, set), its errors stay 0).
+ * The filters are recomputed on chip, flt0 / flt1 never reach memory. */
+#define SVT_HIP_SGR_MAX_CAND 12
+int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src,
+                                     int src_stride, int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand,
+                                     const int32_t *d_xqd, int64_t *d_err);
+/* search_selfguided_restoration (EbRestorationPick.c:583-671) for every restoration unit of a plane and every parameter set in
+ * ep_mask (the reference's [start_ep, end_ep) window around the reference frames' sets, :596-607, is the caller's mask): projection
+ * sums on the GPU, svt_get_proj_subspace's 2x2 solve (:497-538) and encode_xq (:539) on the host, then
+ * finer_search_pixel_proj_error (:353-446, start step 2) replayed on the host over errors that svt_hip_sgr_proj_error_plane_dev evaluates
+ * in rounds (one launch per round for all units and sets; the walk's next points are requested speculatively, typically 2-3 rounds).
+ * HOST outputs: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched), best_ep[unit] (may be NULL) = the first set
+ * with the smallest error; *rounds_out (may be NULL) = error launches used.  Synchronous; uses library-owned device scratch. */
+int svt_hip_sgr_search_units_plane(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride,
+                                   int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out,
+                                   uint8_t *best_ep, int *rounds_out);
 /* The same frame pass with Wiener units as well (svt_av1_loop_restoration_filter_frame for all three restoration types):
  * d_unit_ep[unit] = 254 selects RESTORE_WIENER with the taps d_unit_wiener[unit][0][8] (WienerInfo::vfilter) / [unit][1][8]
  * (hfilter); wiener_filter_stripe[_highbd] -> svt_av1_[highbd_]wiener_convolve_add_src (common_dsp_rtcd.h:179-185,

@@ -229,6 +229,96 @@ void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void
     free(lim);
 }
 
+/* encode_xq (EbRestorationPick.c:539-552); SGRPROJ_PRJ_MIN0/MAX0 = -96/31, MIN1/MAX1 = -32/95 (EbRestoration.h:100-103) */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+void orc_sgr_encode_xq(const int32_t *xq, int32_t *xqd, int ep) {
+    const int32_t *prm = orc_sgr_params[ep];
+    if (prm[0] == 0) { xqd[0] = 0; xqd[1] = clampi(128 - xq[1], -32, 95); }
+    else if (prm[1] == 0) { xqd[0] = clampi(xq[0], -96, 31); xqd[1] = clampi(128 - xqd[0], -32, 95); }
+    else { xqd[0] = clampi(xq[0], -96, 31); xqd[1] = clampi(128 - xqd[0] - xq[1], -32, 95); }
+}
+
+/* get_pixel_proj_error (EbRestorationPick.c:317-351): decode the xqd pair, then the projected SSE */
+static int64_t xqd_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                         int f0_stride, const int32_t *flt1, int f1_stride, const int32_t *xqd, int ep) {
+    int32_t xq[2];
+    orc_sgr_decode_xq(xqd, xq, ep);
+    return orc_sgr_proj_error(src, src_stride, dat, dat_stride, pix_bytes, w, h, flt0, f0_stride, flt1, f1_stride, xq, ep);
+}
+
+/* finer_search_pixel_proj_error (EbRestorationPick.c:353-446): coordinate descent on the xqd pair with steps start_step, .., 1.  For each
+ * step and each active coefficient: try -step (at the largest step keep walking while the error does not increase); only when that
+ * did not help try +step the same way.  "Not worse" (err2 <= err) counts as an improvement. */
+int64_t orc_sgr_finer_search(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                             int f0_stride, const int32_t *flt1, int f1_stride, int start_step, int32_t *xqd, int ep) {
+    const int32_t *prm = orc_sgr_params[ep];
+    const int tap_min[2] = {-96, -32}, tap_max[2] = {31, 95};
+    int64_t err = xqd_error(src, src_stride, dat, dat_stride, pix_bytes, w, h, flt0, f0_stride, flt1, f1_stride, xqd, ep);
+    for (int s = start_step; s >= 1; s >>= 1) {
+        for (int p = 0; p < 2; p++) {
+            if ((prm[0] == 0 && p == 0) || (prm[1] == 0 && p == 1)) continue;
+            int skip = 0;
+            for (;;) {
+                if (xqd[p] - s >= tap_min[p]) {
+                    xqd[p] -= s;
+                    const int64_t err2 = xqd_error(src, src_stride, dat, dat_stride, pix_bytes, w, h, flt0, f0_stride, flt1, f1_stride, xqd, ep);
+                    if (err2 > err) xqd[p] += s;
+                    else { err = err2; skip = 1; if (s == start_step) continue; }
+                }
+                break;
+            }
+            if (skip) break;   /* as in the reference: leaves the loop over p for this step */
+            for (;;) {
+                if (xqd[p] + s <= tap_max[p]) {
+                    xqd[p] += s;
+                    const int64_t err2 = xqd_error(src, src_stride, dat, dat_stride, pix_bytes, w, h, flt0, f0_stride, flt1, f1_stride, xqd, ep);
+                    if (err2 > err) xqd[p] -= s;
+                    else { err = err2; if (s == start_step) continue; }
+                }
+                break;
+            }
+        }
+    }
+    return err;
+}
+
+/* search_selfguided_restoration (EbRestorationPick.c:583-671) for every restoration unit of a plane and every parameter set in ep_mask:
+ * box filters (apply_sgr :554), svt_get_proj_subspace, encode_xq, finer search with start step 2.  xqd_out[unit][16][2], err_out[unit][16]
+ * (untouched for sets outside the mask); best_ep[unit] = the first set of the mask with the smallest error (strict <, :659).  The
+ * reference's window [start_ep, end_ep) around the reference frames' sets (:596-607) is the caller's ep_mask. */
+void orc_sgr_search_units_plane(const void *dgd, int pix_bytes, int stride, const void *src, int src_stride, int pw, int ph, int ss_x, int ss_y,
+                                int unit_size, int bd, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out, uint8_t *best_ep) {
+    const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
+    int32_t *lim = (int32_t *)malloc(sizeof(int32_t) * 4 * nu);
+    orc_rest_unit_limits(pw, ph, ss_y, unit_size, lim);
+    const int puw = 64 >> ss_x, puh = 64 >> ss_y;
+    for (int u = 0; u < nu; u++) {
+        const int x0 = lim[4 * u], x1 = lim[4 * u + 1], y0 = lim[4 * u + 2], y1 = lim[4 * u + 3], w = x1 - x0, h = y1 - y0;
+        const int fs = ((w + 7) & ~7) + 8;
+        int32_t *f0 = (int32_t *)malloc(sizeof(int32_t) * 2 * fs * h), *f1 = f0 + (size_t)fs * h;
+        const uint8_t *d = (const uint8_t *)dgd + ((size_t)y0 * stride + x0) * pix_bytes;
+        const uint8_t *s = (const uint8_t *)src + ((size_t)y0 * src_stride + x0) * pix_bytes;
+        int64_t besterr = -1;
+        for (int ep = 0; ep < 16; ep++) {
+            if (!((ep_mask >> ep) & 1)) continue;
+            for (int i = 0; i < h; i += puh)
+                for (int j = 0; j < w; j += puw)
+                    orc_sgr_filter(d + ((size_t)i * stride + j) * pix_bytes, pix_bytes, w - j < puw ? w - j : puw, h - i < puh ? h - i : puh, stride,
+                                   f0 + (size_t)i * fs + j, f1 + (size_t)i * fs + j, fs, ep, bd);
+            int64_t sums[5];
+            int32_t xq[2], *xqd = xqd_out + ((size_t)u * 16 + ep) * 2;
+            orc_sgr_proj_sums(s, src_stride, d, stride, pix_bytes, w, h, f0, fs, f1, fs, ep, sums);
+            orc_sgr_solve(sums, w * h, ep, xq);
+            orc_sgr_encode_xq(xq, xqd, ep);
+            const int64_t err = orc_sgr_finer_search(s, src_stride, d, stride, pix_bytes, w, h, f0, fs, f1, fs, 2, xqd, ep);
+            err_out[(size_t)u * 16 + ep] = err;
+            if (besterr == -1 || err < besterr) { besterr = err; if (best_ep) best_ep[u] = (uint8_t)ep; }
+        }
+        free(f0);
+    }
+    free(lim);
+}
+
 /* svt_av1_loop_restoration_filter_frame for one plane (EbRestoration.c:1293-1366) = for every unit svt_av1_loop_restoration_filter_unit
  * (:1162-1249): the unit is filtered stripe by stripe (64 >> ss_y rows, the first 8 >> ss_y shorter); the 3 rows above / below a
  * stripe are replaced by the DEBLOCKED picture's rows (2 saved rows stretched to 3: get_stripe_boundary_info :321,

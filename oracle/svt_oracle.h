@@ -159,6 +159,11 @@ void orc_sgr_apply(const void *dat, int pix_bytes, int w, int h, int stride, int
 void orc_sgr_proj_sums(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                        int f0_stride, const int32_t *flt1, int f1_stride, int ep, int64_t sums[5]);
 void orc_sgr_solve(const int64_t sums[5], int size, int ep, int32_t xq[2]);
+void orc_sgr_encode_xq(const int32_t *xq, int32_t *xqd, int ep);
+int64_t orc_sgr_finer_search(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
+                             int f0_stride, const int32_t *flt1, int f1_stride, int start_step, int32_t *xqd, int ep);
+void orc_sgr_search_units_plane(const void *dgd, int pix_bytes, int stride, const void *src, int src_stride, int pw, int ph, int ss_x, int ss_y,
+                                int unit_size, int bd, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out, uint8_t *best_ep);
 int orc_rest_units(int size, int unit_size);
 int orc_rest_unit_limits(int pw, int ph, int ss_y, int unit_size, int32_t *limits);
 void orc_sgr_search_plane(const void *dgd, int pix_bytes, int stride, const void *src, int src_stride, int pw, int ph, int ss_x, int ss_y,

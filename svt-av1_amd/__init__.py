@@ -141,6 +141,8 @@ def lib():
     L.svt_hip_sgr_filter_plane_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32]
     L.svt_hip_sgr_search_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp]
     L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    L.svt_hip_sgr_proj_error_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, i32, vp, vp]
+    L.svt_hip_sgr_search_units_plane.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, vp, vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_tf_filter_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, i32, i32, i32, i32, i32, C.POINTER(TfRef), i32,

@@ -476,6 +476,92 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 #undef FA_
 #undef FB_
 
+// ---- projected error of xqd candidates: get_pixel_proj_error (EbRestorationPick.c:317-351 -> svt_av1_{lowbd,highbd}_pixel_proj_error, :174-316) for
+// every (restoration unit, parameter set in ep_mask, candidate c < ncand): err[unit][16][ncand] += sum over the unit of
+// (((u << 7) + xq0 (flt0 - u) + xq1 (flt1 - u) + 2^10) >> 11) - src)^2 with xq = svt_decode_xq(xqd[unit][16][ncand][2]).  Same tiling and filter
+// passes as the search kernel; the candidates of a (unit, set) are workgroup-uniform, so their decode is scalar work.
+constexpr int kSgrMaxCand = 12;
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(256)
+sgr_proj_error_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
+                      int units_x, int units_y, int voff, uint32_t ep_mask, int ncand, const int32_t* __restrict__ xqd,
+                      unsigned long long* __restrict__ err) {
+    __shared__ uint16_t in[S_IH * S_IW];
+    __shared__ uint32_t ab[2][S_NP];
+    __shared__ uint32_t xt[256];
+    __shared__ unsigned long long acc[16][kSgrMaxCand];
+    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;
+    const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    // a first candidate of INT32_MIN skips the (unit, set): later rounds of the host's finer search only have a few walks still open
+    for (int ep = 0; ep < 16; ep++)
+        if (((ep_mask >> ep) & 1) && xqd[((size_t)unit * 16 + ep) * ncand * 2] == INT32_MIN) ep_mask &= ~(1u << ep);
+    if (!ep_mask) return;
+    {
+        const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
+        xt[tid] = (A << 20) | (256u - A);
+        if (tid < 16 * kSgrMaxCand) acc[tid / kSgrMaxCand][tid % kSgrMaxCand] = 0ull;
+    }
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
+        [&](int i) {
+            const int r = i / S_IW, c = i - r * S_IW;
+            const int x = min(max(x0 - 3 + c, -3), pw + 2), y = min(max(y0 - 3 + r, -3), ph + 2);
+            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { in[i] = v; });
+    __syncthreads();
+    uint32_t P[S_KP], M[S_KP];
+    sgr8_precompute<BD>(in, &ab[0][0], tid, P, M);
+    const int j = tid & 63, i0 = (tid >> 6) * 8;
+    const int rlo = min(max(-(y0 + i0), 0), 8), rhi = min(max(ph - (y0 + i0), 0), 8);
+    const bool colvalid = x0 + j < pw;
+    uint32_t X[8]; int32_t BS[8], CX[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        X[r] = in[(i0 + r + 3) * S_IW + j + 3];
+        const int yy = min(max(y0 + i0 + r, 0), ph - 1), xx = min(x0 + j, pw - 1);
+        BS[r] = (int32_t)(X[r] << 11) + (1 << 10) - ((int32_t)src[(size_t)yy * src_stride + xx] << 11);   // (u << 7) + rounding - (src << 11): e = (BS + xq . D) >> 11
+        CX[r] = 256 - (int32_t)(X[r] << 13);
+    }
+    int buf = 0;
+    for (int ep = 0; ep < 16; ep++) {
+        if (!((ep_mask >> ep) & 1)) continue;
+        const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
+        uint32_t* abw = ab[buf];
+        sgr8_build(abw, xt, P, M, has0, has1, (uint32_t)kSgr[ep][2], (uint32_t)kSgr[ep][3], tid);
+        __syncthreads();
+        int32_t D0[8], D1[8];
+        if constexpr (BD == 8) sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+        else sgr10_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+        const int32_t* q = xqd + ((size_t)unit * 16 + ep) * ncand * 2;
+        for (int c = 0; c < ncand; c++) {
+            const int32_t xqd0 = q[2 * c], xqd1 = q[2 * c + 1];
+            const int32_t xq0 = has0 ? xqd0 : 0, xq1 = !has1 ? 0 : (has0 ? 128 - xqd0 - xqd1 : 128 - xqd1);   // svt_decode_xq (EbRestoration.c:707-718)
+            int32_t p0 = 0, p1 = 0;   // rows 0-3 / 4-7: |e| < 2^13 at bit depth 10, four squares stay far below 2^31
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (r >= rlo && r < rhi) {
+                    int32_t v = BS[r];
+                    if (has0) v += __mul24(xq0, D0[r]);
+                    if (has1) v += __mul24(xq1, D1[r]);
+                    const int32_t e = v >> 11;
+                    if (r < 4) p0 += __mul24(e, e); else p1 += __mul24(e, e);
+                }
+            }
+            if (!colvalid) { p0 = 0; p1 = 0; }
+            long long t;
+            if constexpr (BD == 8) t = row16_sum(p0 + p1);   // 8 px x 16 lanes x 1300^2 < 2^31
+            else t = row16_sum_wide(p0, p1);
+            if ((tid & 15) == 0) atomicAdd(&acc[ep][c], (unsigned long long)t);
+        }
+        buf ^= 1;
+    }
+    __syncthreads();
+    for (int k = tid; k < 16 * ncand; k += 256) {
+        const int ep = k / ncand, c = k - ep * ncand;
+        if ((ep_mask >> ep) & 1) atomicAdd(&err[((size_t)unit * 16 + ep) * ncand + c], acc[ep][c]);
+    }
+}
+
 // ---- frame apply (bit depth 8 and 10) on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
 // RESTORE_NONE units are copied, RESTORE_WIENER units take the 7-tap separable filter, RESTORE_SGRPROJ units the self-guided filter.
 // A tile is one stripe high at most (stripes are 64 >> ss_y rows starting 8 >> ss_y above a multiple of that), so the StripeCtx rules
@@ -595,6 +681,17 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
     if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,
+                                             int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int ncand, const int32_t* xqd, int64_t* err) {
+    const int voff = 8 >> ss_y;
+    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    unsigned long long* e = (unsigned long long*)err;
+    if (ncand < 1 || ncand > kSgrMaxCand) return (int)hipErrorInvalidValue;
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_proj_error_kernel<uint8_t, 8>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, ncand, xqd, e);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_proj_error_kernel<uint16_t, 8>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, ncand, xqd, e);
+    else hipLaunchKernelGGL((sgr_proj_error_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, ncand, xqd, e);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,

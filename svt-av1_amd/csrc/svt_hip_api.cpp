@@ -2,9 +2,11 @@
 // host-pointer convenience wrappers around the batched kernel launchers.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <limits.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "svt_hip_internal.h"
 
 struct SvtHipCtx {
@@ -550,6 +552,226 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* 
                                                        sgr_units(pw, unit_size), sgr_units(ph, unit_size), ss_y, d_dbl, dbl_stride, d_unit_ep,
                                                        d_unit_xqd, d_unit_wiener);
     if (e != hipSuccess) return fail(c, e, "sgr apply launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
+                                     int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand, const int32_t* d_xqd, int64_t* d_err) {
+    if (!c || !d_dgd || !d_src || !d_xqd || !d_err || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) || ncand < 1 ||
+        ncand > SVT_HIP_SGR_MAX_CAND || !sgr_args_ok(pix_bytes, bd, pw, ph))
+        return SVT_HIP_ERR_BAD_ARG;
+    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
+    HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int64_t) * (size_t)ux * uy * 16 * ncand, c->stream));
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_proj_error(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y,
+                                                            ep_mask & 0xFFFFu, ncand, d_xqd, d_err);
+    if (e != hipSuccess) return fail(c, e, "sgr proj error launch");
+    return SVT_HIP_OK;
+}
+
+/* ---- host side of search_selfguided_restoration (Encoder/Codec/EbRestorationPick.c:583-671) on top of the two plane kernels ---- */
+namespace {
+const int kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
+const int kTapMin[2] = {-96, -32}, kTapMax[2] = {31, 95};   // SGRPROJ_PRJ_MIN0/MAX0, MIN1/MAX1 (EbRestoration.h:100-103)
+
+struct SgrPoint { int x, y; int64_t err; };
+struct SgrItem {            // one (restoration unit, parameter set)
+    int xqd[2] = {0, 0};    // start point (encode_xq), then the result
+    int64_t err = 0;
+    bool done = false;
+    std::vector<SgrPoint> cache;
+    std::vector<std::pair<int, int>> want;
+    bool lookup(int x, int y, int64_t& e) const {
+        for (const SgrPoint& p : cache) if (p.x == x && p.y == y) { e = p.err; return true; }
+        return false;
+    }
+};
+
+// svt_get_proj_subspace_c's solve (EbRestorationPick.c:497-538) on the exact integer sums, operation order of the reference
+void sgr_solve(const int64_t* sums, int size, int ep, int xq[2]) {
+    double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    H00 /= size; H01 /= size; H11 /= size; C0 /= size; C1 /= size;
+    const double H10 = H01;
+    xq[0] = xq[1] = 0;
+    if (kSgrR[ep][0] == 0) { if (H11 < 1e-8) return; xq[1] = (int)rint((C1 / H11) * 128); }
+    else if (kSgrR[ep][1] == 0) { if (H00 < 1e-8) return; xq[0] = (int)rint((C0 / H00) * 128); }
+    else {
+        const double det = H00 * H11 - H01 * H10;
+        if (det < 1e-8) return;
+        const double x0 = (H11 * C0 - H01 * C1) / det, x1 = (H00 * C1 - H10 * C0) / det;
+        xq[0] = (int)rint(x0 * 128); xq[1] = (int)rint(x1 * 128);
+    }
+}
+int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+void sgr_encode_xq(const int xq[2], int xqd[2], int ep) {   // encode_xq, EbRestorationPick.c:539-552
+    if (kSgrR[ep][0] == 0) { xqd[0] = 0; xqd[1] = clampi(128 - xq[1], kTapMin[1], kTapMax[1]); }
+    else if (kSgrR[ep][1] == 0) { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0], kTapMin[1], kTapMax[1]); }
+    else { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0] - xq[1], kTapMin[1], kTapMax[1]); }
+}
+
+// finer_search_pixel_proj_error (EbRestorationPick.c:353-446) replayed on the cache of evaluated points.  Returns true when the walk
+// finished (it.xqd / it.err hold the result); otherwise it.want lists the missing point followed by the points the walk is most likely to ask
+// for next (the axis neighbours of the current position at the current and smaller steps), at most max_want of them.
+bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, int n_ahead) {
+    int q[2] = {it.xqd[0], it.xqd[1]};
+    int64_t err, err2;
+    it.want.clear();
+    auto stall = [&](int nx, int ny, int s) {
+        it.want.emplace_back(nx, ny);
+        // at the largest step an accepted move keeps walking in the same direction: ask for the next n_ahead points on that line too
+        if (s == start_step && (nx != q[0] || ny != q[1])) {
+            const int p = nx != q[0] ? 0 : 1, d = (p == 0 ? nx - q[0] : ny - q[1]);
+            int c[2] = {nx, ny};
+            for (int k = 0; k < n_ahead && (int)it.want.size() < max_want; k++) {
+                c[p] += d;
+                if (c[p] < kTapMin[p] || c[p] > kTapMax[p]) break;
+                it.want.emplace_back(c[0], c[1]);
+            }
+        }
+        for (int t = s; t >= 1 && (int)it.want.size() < max_want; t >>= 1)
+            for (int p = 0; p < 2 && (int)it.want.size() < max_want; p++) {
+                if (kSgrR[ep][p] == 0) continue;
+                for (int dir = -1; dir <= 1; dir += 2) {
+                    int c[2] = {q[0], q[1]};
+                    c[p] += dir * t;
+                    if (c[p] < kTapMin[p] || c[p] > kTapMax[p]) continue;
+                    int64_t dummy;
+                    bool dup = it.lookup(c[0], c[1], dummy);
+                    for (const auto& w : it.want) dup = dup || (w.first == c[0] && w.second == c[1]);
+                    if (!dup && (int)it.want.size() < max_want) it.want.emplace_back(c[0], c[1]);
+                }
+            }
+        return false;
+    };
+    if (!it.lookup(q[0], q[1], err)) return stall(q[0], q[1], start_step);
+    for (int s = start_step; s >= 1; s >>= 1) {
+        for (int p = 0; p < 2; p++) {
+            if (kSgrR[ep][p] == 0) continue;
+            bool skip = false;
+            for (;;) {
+                if (q[p] - s >= kTapMin[p]) {
+                    q[p] -= s;
+                    if (!it.lookup(q[0], q[1], err2)) { const int nx = q[0], ny = q[1]; q[p] += s; return stall(nx, ny, s); }
+                    if (err2 > err) q[p] += s;
+                    else { err = err2; skip = true; if (s == start_step) continue; }
+                }
+                break;
+            }
+            if (skip) break;
+            for (;;) {
+                if (q[p] + s <= kTapMax[p]) {
+                    q[p] += s;
+                    if (!it.lookup(q[0], q[1], err2)) { const int nx = q[0], ny = q[1]; q[p] -= s; return stall(nx, ny, s); }
+                    if (err2 > err) q[p] -= s;
+                    else { err = err2; if (s == start_step) continue; }
+                }
+                break;
+            }
+        }
+    }
+    it.xqd[0] = q[0]; it.xqd[1] = q[1]; it.err = err; it.done = true;
+    return true;
+}
+}  // namespace
+
+int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
+                                   int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep,
+                                   int* rounds_out) {
+    if (!c || !d_dgd || !d_src || !xqd_out || !err_out || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
+        !sgr_args_ok(pix_bytes, bd, pw, ph) || !(ep_mask & 0xFFFFu))
+        return SVT_HIP_ERR_BAD_ARG;
+    ep_mask &= 0xFFFFu;
+    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size), nu = ux * uy, NC = SVT_HIP_SGR_MAX_CAND;
+    const size_t sums_b = sizeof(int64_t) * nu * 16 * 5, xqd_b = sizeof(int32_t) * nu * 16 * NC * 2, err_b = sizeof(int64_t) * nu * 16 * NC;
+    const size_t need = sums_b + xqd_b + err_b;
+    if (need > c->scratch_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->scratch) HIPCHK(c, hipFree(c->scratch));
+        c->scratch = nullptr; c->scratch_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->scratch, need));
+        c->scratch_bytes = need;
+    }
+    int64_t* d_sums = (int64_t*)c->scratch;
+    int32_t* d_xqd = (int32_t*)((char*)c->scratch + sums_b);
+    int64_t* d_err = (int64_t*)((char*)c->scratch + sums_b + xqd_b);
+    // 1. the projection sums of every (unit, set)
+    HIPCHK(c, hipMemsetAsync(d_sums, 0, sums_b, c->stream));
+    int rc = svt_hip_sgr_search_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, d_sums);
+    if (rc != SVT_HIP_OK) return rc;
+    std::vector<int64_t> sums((size_t)nu * 16 * 5);
+    HIPCHK(c, hipMemcpyAsync(sums.data(), d_sums, sums_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // 2. solve + encode_xq per (unit, set); unit sizes as foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) cuts them
+    std::vector<SgrItem> items((size_t)nu * 16);
+    {
+        const int ext = unit_size * 3 / 2, voff = 8 >> ss_y;
+        int y0 = 0, i = 0;
+        while (y0 < ph) {
+            const int rem_h = ph - y0, h = rem_h < ext ? rem_h : unit_size;
+            int v_start = y0 - voff > 0 ? y0 - voff : 0, v_end = y0 + h;
+            if (v_end < ph) v_end -= voff;
+            int x0 = 0, j = 0;
+            while (x0 < pw) {
+                const int rem_w = pw - x0, w = rem_w < ext ? rem_w : unit_size;
+                const int u = i * ux + j, size = w * (v_end - v_start);
+                for (int ep = 0; ep < 16; ep++) {
+                    SgrItem& it = items[(size_t)u * 16 + ep];
+                    if (!((ep_mask >> ep) & 1)) { it.done = true; continue; }
+                    int xq[2];
+                    sgr_solve(&sums[((size_t)u * 16 + ep) * 5], size, ep, xq);
+                    sgr_encode_xq(xq, it.xqd, ep);
+                }
+                x0 += w; j++;
+            }
+            y0 += h; i++;
+        }
+    }
+    // 3. the finer search in rounds: every round evaluates up to NC new points per unfinished (unit, set) in one launch
+    std::vector<int32_t> h_xqd((size_t)nu * 16 * NC * 2);
+    std::vector<int64_t> h_err((size_t)nu * 16 * NC);
+    int rounds = 0;
+    for (;; rounds++) {
+        uint32_t round_mask = 0;
+        for (int u = 0; u < nu; u++)
+            for (int ep = 0; ep < 16; ep++) {
+                SgrItem& it = items[(size_t)u * 16 + ep];
+                if (!it.done && !sgr_replay(it, ep, 2, NC, rounds < 3 ? 2 + 3 * rounds : NC - 1)) round_mask |= 1u << ep;
+            }
+        if (!round_mask) break;
+        if (rounds >= 256) { c->err = "svt_hip_sgr_search_units_plane: finer search did not converge"; return SVT_HIP_ERR_RUNTIME; }
+        for (int u = 0; u < nu; u++)
+            for (int ep = 0; ep < 16; ep++) {
+                const SgrItem& it = items[(size_t)u * 16 + ep];
+                int32_t* q = &h_xqd[((size_t)u * 16 + ep) * NC * 2];
+                for (int k = 0; k < NC; k++) {
+                    const bool live = !it.done && k < (int)it.want.size();
+                    q[2 * k] = live ? it.want[k].first : (it.done || it.want.empty() ? INT32_MIN : it.want[0].first);   // INT32_MIN: skip this (unit, set)
+                    q[2 * k + 1] = live ? it.want[k].second : (it.done || it.want.empty() ? 0 : it.want[0].second);
+                }
+            }
+        HIPCHK(c, hipMemcpyAsync(d_xqd, h_xqd.data(), xqd_b, hipMemcpyHostToDevice, c->stream));
+        rc = svt_hip_sgr_proj_error_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, round_mask, NC, d_xqd, d_err);
+        if (rc != SVT_HIP_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(h_err.data(), d_err, err_b, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int u = 0; u < nu; u++)
+            for (int ep = 0; ep < 16; ep++) {
+                SgrItem& it = items[(size_t)u * 16 + ep];
+                if (it.done) continue;
+                for (int k = 0; k < (int)it.want.size(); k++)
+                    it.cache.push_back({it.want[k].first, it.want[k].second, h_err[((size_t)u * 16 + ep) * NC + k]});
+            }
+    }
+    for (int u = 0; u < nu; u++) {
+        int64_t besterr = -1;
+        for (int ep = 0; ep < 16; ep++) {
+            if (!((ep_mask >> ep) & 1)) continue;
+            const SgrItem& it = items[(size_t)u * 16 + ep];
+            xqd_out[((size_t)u * 16 + ep) * 2] = it.xqd[0]; xqd_out[((size_t)u * 16 + ep) * 2 + 1] = it.xqd[1];
+            err_out[(size_t)u * 16 + ep] = it.err;
+            if (besterr == -1 || it.err < besterr) { besterr = it.err; if (best_ep) best_ep[u] = (uint8_t)ep; }   // strict <, :659
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
     return SVT_HIP_OK;
 }
 

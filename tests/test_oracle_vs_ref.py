@@ -480,6 +480,47 @@ def test_sgr_tables_filter_apply_and_projection(orc, ref):
             assert np.array_equal(o1, o2), (bd, ep, "apply")
 
 
+def test_sgr_finer_search_and_unit_search(orc, ref):
+    """The per-unit self-guided search: finer_search_pixel_proj_error (EbRestorationPick.c:353) and search_selfguided_restoration (:583),
+    both static in the reference and exported by oracle/ref_shim_restpick.c, vs the oracle's restatements.  Units of several shapes
+    (luma 64-px and chroma 32-px processing units, ragged sizes), smooth + noisy content so that different sets win."""
+    if not hasattr(ref, "ref_shim_sgr_search_unit"): pytest.skip("oracle/_ref predates ref_shim_restpick.c: rebuild it")
+    orc.orc_sgr_finer_search.restype = C.c_int64; ref.ref_shim_sgr_finer_search.restype = C.c_int64
+    rng = np.random.default_rng(91)
+    rstbuf = np.zeros(ref.ref_shim_sgr_rstbuf_ints(), np.int32)
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        hb = int(bd > 8)
+        cvt = (lambda a: C.c_void_p(a >> 1)) if hb else (lambda a: C.c_void_p(a))   # CONVERT_TO_BYTEPTR
+        for it, (w, h, ss) in enumerate(((64, 64, 0), (96, 72, 0), (40, 56, 1), (128, 120, 0), (32, 32, 1), (72, 40, 1))):
+            yy, xx = np.mgrid[0:h + 6, 0:w + 6]
+            clean = (100 + 60 * np.sin(xx / (5.0 + it)) * np.cos(yy / 7.0) + 25 * (((xx + yy) // 9) % 2)) * (1 << (bd - 8))
+            src = np.clip(clean, 0, (1 << bd) - 1).astype(dt)
+            dgd = np.clip(clean + rng.normal(0, (2 + 3 * it) * (1 << (bd - 8)), clean.shape), 0, (1 << bd) - 1).astype(dt)
+            st = w + 6; off = (3 * st + 3) * dgd.itemsize
+            pd, ps = dgd.ctypes.data + off, src.ctypes.data + off
+            pu = 64 >> ss
+            # --- whole-unit search, all 16 sets (no reference-frame sets: ref_ep = -1, -1) and a window around a reference set
+            for (e0, e1, step, mask) in ((-1, -1, 16, 0xFFFF), (6, -1, 1, 0x0060), (3, 12, 4, 0x0FF8)):
+                out = (C.c_int32 * 3)()
+                ref.ref_shim_sgr_search_unit(cvt(pd), w, h, st, cvt(ps), st, hb, bd, pu, pu, ptr(rstbuf), e0, e1, step, out)
+                xqd = np.zeros((1, 16, 2), np.int32); err = np.zeros((1, 16), np.int64); best = np.zeros(1, np.uint8)
+                # a single unit: the plane-level oracle with unit_size >= the plane (one unit; rows are not shifted for a 1-unit plane top)
+                orc.orc_sgr_search_units_plane(C.c_void_p(pd), dgd.itemsize, st, C.c_void_p(ps), st, w, h, ss, ss, 256, bd, mask, ptr(xqd), ptr(err), ptr(best))
+                assert (int(best[0]), int(xqd[0, best[0], 0]), int(xqd[0, best[0], 1])) == (out[0], out[1], out[2]), (bd, it, mask, list(out), best, xqd[0, best[0]])
+            # --- the finer search on its own from arbitrary starting points (incl. the clamps of the tap range)
+            for ep in (0, 5, 9, 10, 13, 14, 15):
+                f0 = np.zeros((h, w + 8), np.int32); f1 = np.zeros_like(f0)
+                for i in range(0, h, pu):
+                    for j in range(0, w, pu):
+                        orc.orc_sgr_filter(C.c_void_p(pd + (i * st + j) * dgd.itemsize), dgd.itemsize, min(pu, w - j), min(pu, h - i), st,
+                                           C.c_void_p(f0.ctypes.data + (i * (w + 8) + j) * 4), C.c_void_p(f1.ctypes.data + (i * (w + 8) + j) * 4), w + 8, ep, bd)
+                for start in ((-96, -32), (31, 95), (-20, 40), (0, 0), (-95, 94)):
+                    a = (C.c_int32 * 2)(*start); b = (C.c_int32 * 2)(*start)
+                    e1 = ref.ref_shim_sgr_finer_search(cvt(ps), w, h, st, cvt(pd), st, hb, ptr(f0), w + 8, ptr(f1), w + 8, 2, a, ep)
+                    e2 = orc.orc_sgr_finer_search(C.c_void_p(ps), st, C.c_void_p(pd), st, dgd.itemsize, w, h, ptr(f0), w + 8, ptr(f1), w + 8, 2, b, ep)
+                    assert (e1, list(a)) == (e2, list(b)), (bd, it, ep, start)
+
+
 def test_plane_sse_kernels(orc, ref):
     """orc_plane_sse == svt_spatial_full_distortion_kernel_c (8-bit) / svt_full_distortion_kernel16_bits_c (16-bit),
     the two kernels picture_sse_calculations calls (EbDeblockingFilter.c:830-961)."""

@@ -166,3 +166,82 @@ def test_search_extreme_content(hip, orc, bd):
         hip.free(d_ext, d_src, d_sums)
         if bd == 10 and comp: assert np.abs(e_sums).max() > (1 << 31), "content must push the sums past 32 bits"
         assert np.array_equal(got, e_sums), (bd, comp, np.argwhere(got != e_sums)[:5])
+
+
+def _smooth_noisy(w, h, bd, seed, sigma):
+    """Source with textured regions; degraded picture = coarse quantisation of it (coding-like artefacts, strength per 64x64 region) plus noise
+    in some regions: different parameter sets win and the projections land inside as well as on the clamps of the tap range."""
+    rng = np.random.default_rng(seed)
+    dt = np.uint8 if bd == 8 else np.uint16
+    sc = 1 << (bd - 8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    clean = (100 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 25 * (((xx + yy) // 11) % 2) + 0.15 * xx) * sc
+    region = (xx // 64 + 2 * (yy // 64)) % 4
+    src = np.clip(clean + rng.normal(0, 1, (h, w)) * 6 * sc * (region == 1), 0, (1 << bd) - 1)
+    q = np.array([2, 6, 12, 24])[region] * sc
+    dgd = np.clip((src // q) * q + q // 2 + rng.normal(0, 1, (h, w)) * sigma * sc * (region == 3), 0, (1 << bd) - 1)
+    return np.ascontiguousarray(src.astype(dt)), np.ascontiguousarray(np.pad(dgd.astype(dt), EXT, mode="edge"))
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_proj_error_candidates(hip, orc, bd, ss):
+    """svt_hip_sgr_proj_error_plane_dev vs get_pixel_proj_error of the oracle (pinned to svt_av1_{lowbd,highbd}_pixel_proj_error): random and
+    extreme xqd pairs per (unit, set), ragged units, all 16 sets and a sparse mask, ncand 1 / 5 / 12."""
+    w, h, US = 200, 152, 64
+    src, ext = _smooth_noisy(w, h, bd, 300 + bd + ss, 4)
+    st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+    ux, uy = units(w, US), units(h, US); nu = ux * uy
+    lim = np.zeros((nu, 4), np.int32); orc.orc_rest_unit_limits(w, h, ss, US, ptr(lim))
+    d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+    rng = np.random.default_rng(5 + ss)
+    orc.orc_sgr_proj_error.restype = C.c_int64
+    pu = 64 >> ss
+    for mask, nc in ((0xFFFF, 5), (0x4401, 12), (0x8020, 1)):
+        xqd = np.stack([rng.integers(-96, 32, (nu, 16, nc)), rng.integers(-32, 96, (nu, 16, nc))], -1).astype(np.int32)
+        xqd[:, :, 0] = (-96, -32); xqd[0, :, nc - 1] = (31, 95)
+        d_xqd = hip.to_device(np.ascontiguousarray(xqd)); d_err = hip.to_device(np.full((nu, 16, nc), -1, np.int64))
+        hip.check(hip.L.svt_hip_sgr_proj_error_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, nc, d_xqd, d_err), "proj error")
+        got = hip.to_host(d_err, (nu, 16, nc), np.int64)
+        hip.free(d_xqd, d_err)
+        for u in range(nu):
+            x0, x1, y0, y1 = [int(v) for v in lim[u]]; uw, uh = x1 - x0, y1 - y0
+            fs = ((uw + 7) & ~7) + 8
+            for ep in range(16):
+                if not (mask >> ep) & 1:
+                    assert not got[u, ep].any()
+                    continue
+                f0 = np.zeros((uh, fs), np.int32); f1 = np.zeros((uh, fs), np.int32)
+                for i in range(0, uh, pu):
+                    for j in range(0, uw, pu):
+                        orc.orc_sgr_filter(C.c_void_p(ext.ctypes.data + off + ((y0 + i) * st + x0 + j) * ext.itemsize), ext.itemsize, min(pu, uw - j), min(pu, uh - i), st,
+                                           C.c_void_p(f0.ctypes.data + (i * fs + j) * 4), C.c_void_p(f1.ctypes.data + (i * fs + j) * 4), fs, ep, bd)
+                for k in range(nc):
+                    xq = (C.c_int32 * 2)()
+                    orc.orc_sgr_decode_xq(ptr(np.ascontiguousarray(xqd[u, ep, k])), xq, ep)
+                    e = orc.orc_sgr_proj_error(C.c_void_p(src.ctypes.data + (y0 * w + x0) * src.itemsize), w, C.c_void_p(ext.ctypes.data + off + (y0 * st + x0) * ext.itemsize), st,
+                                               ext.itemsize, uw, uh, ptr(f0), fs, ptr(f1), fs, xq, ep)
+                    assert got[u, ep, k] == e, (bd, ss, hex(mask), u, ep, k)
+    assert hip.L.svt_hip_sgr_proj_error_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, 1, 13, d_ext, d_ext) != 0
+    hip.free(d_ext, d_src)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_units_plane(hip, orc, bd):
+    """svt_hip_sgr_search_units_plane (sums -> solve -> encode_xq -> finer search in rounds) vs the oracle's search_selfguided_restoration
+    restatement (pinned to the reference's static functions through oracle/ref_shim_restpick.c): xqd, error and best set of every unit."""
+    for (w, h, US, ss, mask, sigma) in ((264, 200, 64, 0, 0xFFFF, 5), (168, 120, 64, 1, 0xFFFF, 9), (328, 264, 128, 0, 0x0F38, 3), (1000, 584, 256, 0, 0x4221, 4)):
+        src, ext = _smooth_noisy(w, h, bd, 400 + bd + ss, sigma)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        nu = units(w, US) * units(h, US)
+        e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+        orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+        d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+        g_xqd = np.zeros_like(e_xqd); g_err = np.zeros_like(e_err); g_best = np.zeros_like(e_best); rounds = C.c_int(0)
+        hip.check(hip.L.svt_hip_sgr_search_units_plane(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, ptr(g_xqd), ptr(g_err), ptr(g_best),
+                                                       C.byref(rounds)), "search units")
+        hip.free(d_ext, d_src)
+        assert np.array_equal(g_err, e_err), (bd, w, h, np.argwhere(g_err != e_err)[:5])
+        assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best)
+        assert 1 <= rounds.value <= 16, rounds.value
+        if mask == 0xFFFF: assert len(set(int(v) for v in e_best)) > 1, "content should make different sets win"

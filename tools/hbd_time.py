@@ -28,7 +28,11 @@ for p in range(3):
     yy, xx = np.mgrid[0:h, 0:w]
     s = (100 + 60 * np.sin(xx / 11.0 + p) * np.cos(yy / 9.0) + 30 * (((xx + 2 * yy) // 14) % 2)) * (1 << (bd - 8))
     src.append(np.clip(s, 0, (1 << bd) - 1).astype(dt))
-    rec.append(np.clip(s + rng.normal(0, 5 * (1 << (bd - 8)), (h, w)), 0, (1 << bd) - 1).astype(dt))
+    # reconstruction = coarse quantisation of the source (coding-like artefacts, strength per 64x64 region) + mild noise in some regions
+    region = (xx // 64 + 2 * (yy // 64)) % 4
+    q = np.array([2, 6, 12, 24])[region] * (1 << (bd - 8))
+    r = (np.clip(s, 0, (1 << bd) - 1) // q) * q + q // 2 + rng.normal(0, 3 * (1 << (bd - 8)), (h, w)) * (region == 3)
+    rec.append(np.clip(r, 0, (1 << bd) - 1).astype(dt))
 skip8 = (rng.random((H // 8, W // 8)) < 0.25).astype(np.uint8)
 P3, I3 = C.c_void_p * 3, C.c_int * 3
 d_src = [hip.to_device(p) for p in src]; d_rec = [hip.to_device(p) for p in rec]; d_out = [hip.to_device(p) for p in rec]
@@ -101,6 +105,19 @@ def subpel():
     hip.check(L.svt_hip_subpel_predict_batch_dev(hip.h, pb, bd, d_refp.value + (PAD * refp.shape[1] + PAD) * pb, refp.shape[1], d_pred, W, d_cb, n16), "subpel")
 
 
+def sgr_units_search():   # the complete per-unit search (sums, solve, finer search in rounds), all three planes, 16 sets
+    global rounds_used
+    rounds_used = []
+    for p in range(3):
+        st = ext[p].shape[1]
+        r = C.c_int(0)
+        hip.check(L.svt_hip_sgr_search_units_plane(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
+                                                   US[p], int(p > 0), 0xFFFF, h_xqd[p].ctypes.data, h_err[p].ctypes.data, h_best[p].ctypes.data, C.byref(r)), "sgr units search")
+        rounds_used.append(r.value)
+
+
+h_xqd = [np.zeros((n, 16, 2), np.int32) for n in units]; h_err = [np.zeros((n, 16), np.int64) for n in units]; h_best = [np.zeros(n, np.uint8) for n in units]
+rounds_used = []
 ms = C.c_float()
 for name, fn in (("deblock", deblock), ("subpel_16x16", subpel), ("cdef_search", cdef_search), ("cdef_apply", cdef_apply), ("sgr_search", sgr_search), ("sgr_apply", sgr_apply)):
     for _ in range(3): fn()
@@ -108,3 +125,10 @@ for name, fn in (("deblock", deblock), ("subpel_16x16", subpel), ("cdef_search",
     for _ in range(10): fn()
     L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
     print(f"{name:12s} {W}x{H} bd{bd}: {ms.value / 10:.3f} ms")
+import time
+sgr_units_search()
+hip.sync() if hasattr(hip, "sync") else None
+t0 = time.perf_counter()
+for _ in range(3): sgr_units_search()
+dt = (time.perf_counter() - t0) / 3
+print(f"sgr_units_search {W}x{H} bd{bd}: {dt * 1e3:.2f} ms wall per frame (synchronous host driver; error rounds per plane {rounds_used}; best sets used {sorted(set(int(v) for v in h_best[0]))})")
