@@ -377,6 +377,17 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, cons
 int svt_hip_sgr_search_units_plane(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride,
                                    int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out,
                                    uint8_t *best_ep, int *rounds_out);
+/* The same for up to three planes of a picture with shared rounds (one host synchronisation per round for the whole picture). */
+typedef struct {
+    const void *d_dgd; int32_t stride;      /* extended CDEF output plane, sample (0,0) */
+    const void *d_src; int32_t src_stride;  /* source plane */
+    int32_t pw, ph, unit_size, ss_y;
+    uint32_t ep_mask;
+    int32_t *xqd_out;   /* HOST [units][16][2] */
+    int64_t *err_out;   /* HOST [units][16] */
+    uint8_t *best_ep;   /* HOST [units] or NULL */
+} SvtHipSgrSearchPlane;
+int svt_hip_sgr_search_units_picture(SvtHipCtx *ctx, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane *planes, int *rounds_out);
 /* The same frame pass with Wiener units as well (svt_av1_loop_restoration_filter_frame for all three restoration types):
  * d_unit_ep[unit] = 254 selects RESTORE_WIENER with the taps d_unit_wiener[unit][0][8] (WienerInfo::vfilter) / [unit][1][8]
  * (hfilter); wiener_filter_stripe[_highbd] -> svt_av1_[highbd_]wiener_convolve_add_src (common_dsp_rtcd.h:179-185,

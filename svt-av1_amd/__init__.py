@@ -30,6 +30,13 @@ class QuantParams(C.Structure):
                 ("dequant", C.c_int32 * 2), ("log_scale", C.c_int32), ("variant", C.c_int32), ("coeff_shape", C.c_int32)]
 
 
+class SgrSearchPlane(C.Structure):
+    """SvtHipSgrSearchPlane (include/svt_hip.h)."""
+    _fields_ = [("d_dgd", C.c_void_p), ("stride", C.c_int32), ("d_src", C.c_void_p), ("src_stride", C.c_int32), ("pw", C.c_int32), ("ph", C.c_int32),
+                ("unit_size", C.c_int32), ("ss_y", C.c_int32), ("ep_mask", C.c_uint32), ("xqd_out", C.c_void_p), ("err_out", C.c_void_p),
+                ("best_ep", C.c_void_p)]
+
+
 class ScanTables(C.Structure):
     """SvtHipScanTables (include/svt_hip.h): device pointers."""
     _fields_ = [("iscan", C.c_void_p * 3)]
@@ -143,6 +150,7 @@ def lib():
     L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.svt_hip_sgr_proj_error_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, i32, vp, vp]
     L.svt_hip_sgr_search_units_plane.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, vp, vp]
+    L.svt_hip_sgr_search_units_picture.argtypes = [vp, i32, i32, i32, C.POINTER(SgrSearchPlane), vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_tf_filter_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, i32, i32, i32, i32, i32, C.POINTER(TfRef), i32,

@@ -15,8 +15,10 @@ struct SvtHipCtx {
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     int         me_waves = 4;   // 256 threads per SB: measured best on MI355X (tools/me_time.py)
-    void*       scratch = nullptr;   // library-owned device scratch (16-bit Wiener statistics), grown on demand
+    void*       scratch = nullptr;   // library-owned device scratch (16-bit Wiener statistics, self-guided unit search), grown on demand
     size_t      scratch_bytes = 0;
+    void*       host_scratch = nullptr;   // pinned host staging of the self-guided unit search
+    size_t      host_scratch_bytes = 0;
     std::string err;
 };
 
@@ -62,6 +64,7 @@ void svt_hip_destroy(SvtHipCtx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->host_scratch) (void)hipHostFree(c->host_scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -673,16 +676,24 @@ bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, int n_ahead) 
 }
 }  // namespace
 
-int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
-                                   int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep,
-                                   int* rounds_out) {
-    if (!c || !d_dgd || !d_src || !xqd_out || !err_out || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
-        !sgr_args_ok(pix_bytes, bd, pw, ph) || !(ep_mask & 0xFFFFu))
-        return SVT_HIP_ERR_BAD_ARG;
-    ep_mask &= 0xFFFFu;
-    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size), nu = ux * uy, NC = SVT_HIP_SGR_MAX_CAND;
-    const size_t sums_b = sizeof(int64_t) * nu * 16 * 5, xqd_b = sizeof(int32_t) * nu * 16 * NC * 2, err_b = sizeof(int64_t) * nu * 16 * NC;
-    const size_t need = sums_b + xqd_b + err_b;
+int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane* planes, int* rounds_out) {
+    if (!c || !planes || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
+    const int NC = SVT_HIP_SGR_MAX_CAND;
+    struct Job { int nu; size_t sums_o, xqd_o, err_o; std::vector<SgrItem> items; uint32_t mask; };
+    Job job[3];
+    size_t need = 0;
+    for (int k = 0; k < n_planes; k++) {
+        const SvtHipSgrSearchPlane& P = planes[k];
+        if (!P.d_dgd || !P.d_src || !P.xqd_out || !P.err_out || P.unit_size < 64 || (P.unit_size & 63) || (P.ss_y != 0 && P.ss_y != 1) ||
+            !sgr_args_ok(pix_bytes, bd, P.pw, P.ph) || !(P.ep_mask & 0xFFFFu))
+            return SVT_HIP_ERR_BAD_ARG;
+        Job& J = job[k];
+        J.nu = sgr_units(P.pw, P.unit_size) * sgr_units(P.ph, P.unit_size);
+        J.mask = P.ep_mask & 0xFFFFu;
+        J.sums_o = need; need += sizeof(int64_t) * J.nu * 16 * 5;
+        J.xqd_o = need;  need += sizeof(int32_t) * J.nu * 16 * NC * 2;
+        J.err_o = need;  need += sizeof(int64_t) * J.nu * 16 * NC;
+    }
     if (need > c->scratch_bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->scratch) HIPCHK(c, hipFree(c->scratch));
@@ -690,32 +701,43 @@ int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const vo
         HIPCHK(c, hipMalloc(&c->scratch, need));
         c->scratch_bytes = need;
     }
-    int64_t* d_sums = (int64_t*)c->scratch;
-    int32_t* d_xqd = (int32_t*)((char*)c->scratch + sums_b);
-    int64_t* d_err = (int64_t*)((char*)c->scratch + sums_b + xqd_b);
-    // 1. the projection sums of every (unit, set)
-    HIPCHK(c, hipMemsetAsync(d_sums, 0, sums_b, c->stream));
-    int rc = svt_hip_sgr_search_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, d_sums);
-    if (rc != SVT_HIP_OK) return rc;
-    std::vector<int64_t> sums((size_t)nu * 16 * 5);
-    HIPCHK(c, hipMemcpyAsync(sums.data(), d_sums, sums_b, hipMemcpyDeviceToHost, c->stream));
+    if (need > c->host_scratch_bytes) {   // pinned mirror of the device scratch: the per-round copies stay asynchronous and cheap
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->host_scratch) HIPCHK(c, hipHostFree(c->host_scratch));
+        c->host_scratch = nullptr; c->host_scratch_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->host_scratch, need, hipHostMallocDefault));
+        c->host_scratch_bytes = need;
+    }
+    char* dev = (char*)c->scratch; char* host = (char*)c->host_scratch;
+    // 1. the projection sums of every (unit, set), all planes, one synchronisation
+    for (int k = 0; k < n_planes; k++) {
+        const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
+        const size_t sums_b = sizeof(int64_t) * J.nu * 16 * 5;
+        HIPCHK(c, hipMemsetAsync(dev + J.sums_o, 0, sums_b, c->stream));
+        const int rc = svt_hip_sgr_search_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y, J.mask,
+                                                    (int64_t*)(dev + J.sums_o));
+        if (rc != SVT_HIP_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(host + J.sums_o, dev + J.sums_o, sums_b, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // 2. solve + encode_xq per (unit, set); unit sizes as foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) cuts them
-    std::vector<SgrItem> items((size_t)nu * 16);
-    {
-        const int ext = unit_size * 3 / 2, voff = 8 >> ss_y;
+    for (int k = 0; k < n_planes; k++) {
+        const SvtHipSgrSearchPlane& P = planes[k]; Job& J = job[k];
+        const int64_t* sums = (const int64_t*)(host + J.sums_o);
+        J.items.assign((size_t)J.nu * 16, SgrItem());
+        const int ux = sgr_units(P.pw, P.unit_size), ext = P.unit_size * 3 / 2, voff = 8 >> P.ss_y;
         int y0 = 0, i = 0;
-        while (y0 < ph) {
-            const int rem_h = ph - y0, h = rem_h < ext ? rem_h : unit_size;
+        while (y0 < P.ph) {
+            const int rem_h = P.ph - y0, h = rem_h < ext ? rem_h : P.unit_size;
             int v_start = y0 - voff > 0 ? y0 - voff : 0, v_end = y0 + h;
-            if (v_end < ph) v_end -= voff;
+            if (v_end < P.ph) v_end -= voff;
             int x0 = 0, j = 0;
-            while (x0 < pw) {
-                const int rem_w = pw - x0, w = rem_w < ext ? rem_w : unit_size;
+            while (x0 < P.pw) {
+                const int rem_w = P.pw - x0, w = rem_w < ext ? rem_w : P.unit_size;
                 const int u = i * ux + j, size = w * (v_end - v_start);
                 for (int ep = 0; ep < 16; ep++) {
-                    SgrItem& it = items[(size_t)u * 16 + ep];
-                    if (!((ep_mask >> ep) & 1)) { it.done = true; continue; }
+                    SgrItem& it = J.items[(size_t)u * 16 + ep];
+                    if (!((J.mask >> ep) & 1)) { it.done = true; continue; }
                     int xq[2];
                     sgr_solve(&sums[((size_t)u * 16 + ep) * 5], size, ep, xq);
                     sgr_encode_xq(xq, it.xqd, ep);
@@ -725,54 +747,79 @@ int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const vo
             y0 += h; i++;
         }
     }
-    // 3. the finer search in rounds: every round evaluates up to NC new points per unfinished (unit, set) in one launch
-    std::vector<int32_t> h_xqd((size_t)nu * 16 * NC * 2);
-    std::vector<int64_t> h_err((size_t)nu * 16 * NC);
+    // 3. the finer search in rounds: every round evaluates up to NC new points per unfinished (unit, set), one launch per plane, one
+    //    synchronisation per round for the whole picture
     int rounds = 0;
     for (;; rounds++) {
-        uint32_t round_mask = 0;
-        for (int u = 0; u < nu; u++)
-            for (int ep = 0; ep < 16; ep++) {
-                SgrItem& it = items[(size_t)u * 16 + ep];
-                if (!it.done && !sgr_replay(it, ep, 2, NC, rounds < 3 ? 2 + 3 * rounds : NC - 1)) round_mask |= 1u << ep;
-            }
-        if (!round_mask) break;
-        if (rounds >= 256) { c->err = "svt_hip_sgr_search_units_plane: finer search did not converge"; return SVT_HIP_ERR_RUNTIME; }
-        for (int u = 0; u < nu; u++)
-            for (int ep = 0; ep < 16; ep++) {
-                const SgrItem& it = items[(size_t)u * 16 + ep];
-                int32_t* q = &h_xqd[((size_t)u * 16 + ep) * NC * 2];
-                for (int k = 0; k < NC; k++) {
-                    const bool live = !it.done && k < (int)it.want.size();
-                    q[2 * k] = live ? it.want[k].first : (it.done || it.want.empty() ? INT32_MIN : it.want[0].first);   // INT32_MIN: skip this (unit, set)
-                    q[2 * k + 1] = live ? it.want[k].second : (it.done || it.want.empty() ? 0 : it.want[0].second);
+        uint32_t round_mask[3] = {0, 0, 0};
+        bool any = false;
+        for (int k = 0; k < n_planes; k++) {
+            Job& J = job[k];
+            for (int u = 0; u < J.nu; u++)
+                for (int ep = 0; ep < 16; ep++) {
+                    SgrItem& it = J.items[(size_t)u * 16 + ep];
+                    if (!it.done && !sgr_replay(it, ep, 2, NC, rounds < 3 ? 2 + 3 * rounds : NC - 1)) round_mask[k] |= 1u << ep;
                 }
-            }
-        HIPCHK(c, hipMemcpyAsync(d_xqd, h_xqd.data(), xqd_b, hipMemcpyHostToDevice, c->stream));
-        rc = svt_hip_sgr_proj_error_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, round_mask, NC, d_xqd, d_err);
-        if (rc != SVT_HIP_OK) return rc;
-        HIPCHK(c, hipMemcpyAsync(h_err.data(), d_err, err_b, hipMemcpyDeviceToHost, c->stream));
+            any = any || round_mask[k];
+        }
+        if (!any) break;
+        if (rounds >= 256) { c->err = "svt_hip_sgr_search_units: finer search did not converge"; return SVT_HIP_ERR_RUNTIME; }
+        for (int k = 0; k < n_planes; k++) {
+            if (!round_mask[k]) continue;
+            const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
+            int32_t* h_xqd = (int32_t*)(host + J.xqd_o);
+            for (int u = 0; u < J.nu; u++)
+                for (int ep = 0; ep < 16; ep++) {
+                    const SgrItem& it = J.items[(size_t)u * 16 + ep];
+                    int32_t* q = &h_xqd[((size_t)u * 16 + ep) * NC * 2];
+                    for (int n = 0; n < NC; n++) {
+                        const bool live = !it.done && n < (int)it.want.size();
+                        q[2 * n] = live ? it.want[n].first : (it.done || it.want.empty() ? INT32_MIN : it.want[0].first);   // INT32_MIN: skip this (unit, set)
+                        q[2 * n + 1] = live ? it.want[n].second : (it.done || it.want.empty() ? 0 : it.want[0].second);
+                    }
+                }
+            HIPCHK(c, hipMemcpyAsync(dev + J.xqd_o, h_xqd, sizeof(int32_t) * J.nu * 16 * NC * 2, hipMemcpyHostToDevice, c->stream));
+            const int rc = svt_hip_sgr_proj_error_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y,
+                                                            round_mask[k], NC, (const int32_t*)(dev + J.xqd_o), (int64_t*)(dev + J.err_o));
+            if (rc != SVT_HIP_OK) return rc;
+            HIPCHK(c, hipMemcpyAsync(host + J.err_o, dev + J.err_o, sizeof(int64_t) * J.nu * 16 * NC, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int u = 0; u < nu; u++)
-            for (int ep = 0; ep < 16; ep++) {
-                SgrItem& it = items[(size_t)u * 16 + ep];
-                if (it.done) continue;
-                for (int k = 0; k < (int)it.want.size(); k++)
-                    it.cache.push_back({it.want[k].first, it.want[k].second, h_err[((size_t)u * 16 + ep) * NC + k]});
-            }
+        for (int k = 0; k < n_planes; k++) {
+            if (!round_mask[k]) continue;
+            Job& J = job[k];
+            const int64_t* h_err = (const int64_t*)(host + J.err_o);
+            for (int u = 0; u < J.nu; u++)
+                for (int ep = 0; ep < 16; ep++) {
+                    SgrItem& it = J.items[(size_t)u * 16 + ep];
+                    if (it.done) continue;
+                    for (int n = 0; n < (int)it.want.size(); n++)
+                        it.cache.push_back({it.want[n].first, it.want[n].second, h_err[((size_t)u * 16 + ep) * NC + n]});
+                }
+        }
     }
-    for (int u = 0; u < nu; u++) {
-        int64_t besterr = -1;
-        for (int ep = 0; ep < 16; ep++) {
-            if (!((ep_mask >> ep) & 1)) continue;
-            const SgrItem& it = items[(size_t)u * 16 + ep];
-            xqd_out[((size_t)u * 16 + ep) * 2] = it.xqd[0]; xqd_out[((size_t)u * 16 + ep) * 2 + 1] = it.xqd[1];
-            err_out[(size_t)u * 16 + ep] = it.err;
-            if (besterr == -1 || it.err < besterr) { besterr = it.err; if (best_ep) best_ep[u] = (uint8_t)ep; }   // strict <, :659
+
+    for (int k = 0; k < n_planes; k++) {
+        const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
+        for (int u = 0; u < J.nu; u++) {
+            int64_t besterr = -1;
+            for (int ep = 0; ep < 16; ep++) {
+                if (!((J.mask >> ep) & 1)) continue;
+                const SgrItem& it = J.items[(size_t)u * 16 + ep];
+                P.xqd_out[((size_t)u * 16 + ep) * 2] = it.xqd[0]; P.xqd_out[((size_t)u * 16 + ep) * 2 + 1] = it.xqd[1];
+                P.err_out[(size_t)u * 16 + ep] = it.err;
+                if (besterr == -1 || it.err < besterr) { besterr = it.err; if (P.best_ep) P.best_ep[u] = (uint8_t)ep; }   // strict <, :659
+            }
         }
     }
     if (rounds_out) *rounds_out = rounds;
     return SVT_HIP_OK;
+}
+int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
+                                   int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep,
+                                   int* rounds_out) {
+    const SvtHipSgrSearchPlane P = {d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, xqd_out, err_out, best_ep};
+    return svt_hip_sgr_search_units_picture(c, pix_bytes, bd, 1, &P, rounds_out);
 }
 
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win, const void* d_dgd, int stride, const void* d_src, int src_stride,

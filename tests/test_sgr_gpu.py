@@ -245,3 +245,27 @@ def test_search_units_plane(hip, orc, bd):
         assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best)
         assert 1 <= rounds.value <= 16, rounds.value
         if mask == 0xFFFF: assert len(set(int(v) for v in e_best)) > 1, "content should make different sets win"
+
+
+def test_search_units_picture(hip, pkg, orc):
+    """Three planes with shared rounds (svt_hip_sgr_search_units_picture) = the per-plane results."""
+    w, h, bd = 264, 200, 8
+    planes, keep, exp = (pkg.SgrSearchPlane * 3)(), [], []
+    for p in range(3):
+        ss = int(p > 0); pw, ph = w >> ss, h >> ss
+        src, ext = _smooth_noisy(pw, ph, bd, 700 + p, 5)
+        st = ext.shape[1]; off = (EXT * st + EXT)
+        nu = units(pw, 64) * units(ph, 64)
+        mask = (0xFFFF, 0x03C0, 0x8001)[p]
+        e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+        orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), 1, st, ptr(src), pw, pw, ph, ss, ss, 64, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+        d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+        g = (np.zeros_like(e_xqd), np.zeros_like(e_err), np.zeros_like(e_best))
+        planes[p] = pkg.SgrSearchPlane(d_ext.value + off, st, d_src.value, pw, pw, ph, 64, ss, mask, g[0].ctypes.data, g[1].ctypes.data, g[2].ctypes.data)
+        keep += [d_ext, d_src]; exp.append(((e_xqd, e_err, e_best), g))
+    rounds = C.c_int(0)
+    hip.check(hip.L.svt_hip_sgr_search_units_picture(hip.h, 1, bd, 3, planes, C.byref(rounds)), "picture search")
+    for p, (e, g) in enumerate(exp):
+        assert np.array_equal(g[1], e[1]) and np.array_equal(g[0], e[0]) and np.array_equal(g[2], e[2]), p
+    assert hip.L.svt_hip_sgr_search_units_picture(hip.h, 1, bd, 4, planes, None) != 0
+    hip.free(*keep)

@@ -105,15 +105,16 @@ def subpel():
     hip.check(L.svt_hip_subpel_predict_batch_dev(hip.h, pb, bd, d_refp.value + (PAD * refp.shape[1] + PAD) * pb, refp.shape[1], d_pred, W, d_cb, n16), "subpel")
 
 
-def sgr_units_search():   # the complete per-unit search (sums, solve, finer search in rounds), all three planes, 16 sets
+def sgr_units_search():   # the complete per-unit search (sums, solve, finer search in rounds), all three planes, 16 sets, shared rounds
     global rounds_used
-    rounds_used = []
+    P = (pkg.SgrSearchPlane * 3)()
     for p in range(3):
         st = ext[p].shape[1]
-        r = C.c_int(0)
-        hip.check(L.svt_hip_sgr_search_units_plane(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
-                                                   US[p], int(p > 0), 0xFFFF, h_xqd[p].ctypes.data, h_err[p].ctypes.data, h_best[p].ctypes.data, C.byref(r)), "sgr units search")
-        rounds_used.append(r.value)
+        P[p] = pkg.SgrSearchPlane(d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p].value, rec[p].shape[1], rec[p].shape[1], rec[p].shape[0], US[p], int(p > 0), 0xFFFF,
+                                  h_xqd[p].ctypes.data, h_err[p].ctypes.data, h_best[p].ctypes.data)
+    r = C.c_int(0)
+    hip.check(L.svt_hip_sgr_search_units_picture(hip.h, pb, bd, 3, P, C.byref(r)), "sgr units search")
+    rounds_used = r.value
 
 
 h_xqd = [np.zeros((n, 16, 2), np.int32) for n in units]; h_err = [np.zeros((n, 16), np.int64) for n in units]; h_best = [np.zeros(n, np.uint8) for n in units]
@@ -125,10 +126,27 @@ for name, fn in (("deblock", deblock), ("subpel_16x16", subpel), ("cdef_search",
     for _ in range(10): fn()
     L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
     print(f"{name:12s} {W}x{H} bd{bd}: {ms.value / 10:.3f} ms")
+NCAND = 12
+d_cand = [hip.to_device(np.stack([rng.integers(-96, 32, (n, 16, NCAND)), rng.integers(-32, 96, (n, 16, NCAND))], -1).astype(np.int32)) for n in units]
+d_cerr = [hip.to_device(np.zeros((n, 16, NCAND), np.int64)) for n in units]
+
+
+def sgr_proj_error():
+    for p in range(3):
+        st = ext[p].shape[1]
+        hip.check(L.svt_hip_sgr_proj_error_plane_dev(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
+                                                     US[p], int(p > 0), 0xFFFF, NCAND, d_cand[p], d_cerr[p]), "sgr proj error")
+
+
+for _ in range(3): sgr_proj_error()
+L.svt_hip_timer_start(hip.h)
+for _ in range(10): sgr_proj_error()
+L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
+print(f"sgr_proj_error {W}x{H} bd{bd}: {ms.value / 10:.3f} ms (16 sets x {NCAND} xqd candidates per unit, all three planes)")
 import time
 sgr_units_search()
 hip.sync() if hasattr(hip, "sync") else None
 t0 = time.perf_counter()
 for _ in range(3): sgr_units_search()
 dt = (time.perf_counter() - t0) / 3
-print(f"sgr_units_search {W}x{H} bd{bd}: {dt * 1e3:.2f} ms wall per frame (synchronous host driver; error rounds per plane {rounds_used}; best sets used {sorted(set(int(v) for v in h_best[0]))})")
+print(f"sgr_units_search {W}x{H} bd{bd}: {dt * 1e3:.2f} ms wall per frame (synchronous host driver; error rounds {rounds_used}; best sets used {sorted(set(int(v) for v in h_best[0]))})")
