@@ -124,6 +124,7 @@ typedef struct SvtHipRtcd {
     SvtHipHbdWarpAffineFn  svt_av1_highbd_warp_affine;
     SvtHipComputeStatsFn   svt_av1_compute_stats;                /* aom_dsp_rtcd.h:99 */
     SvtHipHbdComputeStatsFn svt_av1_compute_stats_highbd;        /* :103 */
+    SvtHipFwdTxfmFn        svt_av1_fwd_txfm2d_N2[14], svt_av1_fwd_txfm2d_N4[14];   /* aom_dsp_rtcd.h:284-350 (squares: svt_av1_fwd_txfm2d_{N}x{N}_N2 / _N4), SVT_HIP_RTCD_FWD_SIZES order */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

@@ -182,7 +182,7 @@ CONV_WRAPPER(conv_copy_hip, convolve_2d_copy_sr, 0, 0)
 constexpr int kTxW[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
 constexpr int kTxH[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
 
-bool fwd_generic(int ts, const int16_t* in, int32_t* out, int stride, int tx_type) {
+bool fwd_generic(int ts, const int16_t* in, int32_t* out, int stride, int tx_type, int shape = 0) {
     const int w = kTxW[ts], h = kTxH[ts];
     if (!g_ctx) return false;
     // the batched entry point forms the residual itself; any residual r is src - pred with src = max(r, 0), pred = max(-r, 0)
@@ -191,14 +191,26 @@ bool fwd_generic(int ts, const int16_t* in, int32_t* out, int stride, int tx_typ
         for (int x = 0; x < w; x++) { const int r = in[y * stride + x]; hs[y * w + x] = (uint16_t)(r > 0 ? r : 0); hp[y * w + x] = (uint16_t)(r < 0 ? -r : 0); }
     uint16_t *d_s = (uint16_t*)dev(0, sizeof(hs)), *d_p = (uint16_t*)dev(1, sizeof(hp)); uint32_t* d_desc = (uint32_t*)dev(2, 16); int32_t* d_c = (int32_t*)dev(3, 32 * 32 * 4);
     const uint32_t desc = SVT_HIP_TX_DESC(0, 0, tx_type);
+    SvtHipQuantParams qp = {};
+    qp.coeff_shape = shape;   // N2 / N4 transform families = the default transform restricted to the top-left corner
     return d_s && d_p && d_desc && d_c && up(d_s, hs, (size_t)w * h * 2) && up(d_p, hp, (size_t)w * h * 2) && up(d_desc, &desc, 4) &&
-           svt_hip_fwd_txfm_quant_batch_dev(g_ctx, ts, 2, d_s, w, d_p, w, d_desc, 1, nullptr, nullptr, d_c, nullptr, nullptr, nullptr, nullptr, nullptr) == 0 &&
+           svt_hip_fwd_txfm_quant_batch_dev(g_ctx, ts, 2, d_s, w, d_p, w, d_desc, 1, &qp, nullptr, d_c, nullptr, nullptr, nullptr, nullptr, nullptr) == 0 &&
            down(out, d_c, (size_t)w * h * 4);
 }
 template <int SLOT, int TS> void fwd_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (fwd_generic(TS, in, out, (int)stride, tt)) return;
     FALLBACK("svt_av1_fwd_txfm2d_WxH", svt_av1_fwd_txfm2d[SLOT], in, out, stride, tt, bd);
+}
+template <int SLOT, int TS> void fwd_n2_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (fwd_generic(TS, in, out, (int)stride, tt, 1)) return;
+    FALLBACK("svt_av1_fwd_txfm2d_WxH_N2", svt_av1_fwd_txfm2d_N2[SLOT], in, out, stride, tt, bd);
+}
+template <int SLOT, int TS> void fwd_n4_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (fwd_generic(TS, in, out, (int)stride, tt, 2)) return;
+    FALLBACK("svt_av1_fwd_txfm2d_WxH_N4", svt_av1_fwd_txfm2d_N4[SLOT], in, out, stride, tt, bd);
 }
 bool inv_generic(int ts, const int32_t* in, uint16_t* out_r, int stride_r, uint16_t* out_w, int stride_w, int tx_type, int bd) {
     const int w = kTxW[ts], h = kTxH[ts], kw = w < 32 ? w : 32, kh = h < 32 ? h : 32;
@@ -439,5 +451,8 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_aom_highbd_blend_a64_mask = blend_mask_hbd_hip; t->svt_aom_highbd_blend_a64_hmask_8bit = blend_hmask_hbd_hip; t->svt_aom_highbd_blend_a64_vmask_8bit = blend_vmask_hbd_hip;
     t->svt_av1_warp_affine = warp_hip; t->svt_av1_highbd_warp_affine = warp_hbd_hip;
     t->svt_av1_compute_stats = stats_hip; t->svt_av1_compute_stats_highbd = stats_hbd_hip;
+#define X(I, TS, W, H) t->svt_av1_fwd_txfm2d_N2[I] = fwd_n2_hip<I, TS>; t->svt_av1_fwd_txfm2d_N4[I] = fwd_n4_hip<I, TS>;
+    SVT_HIP_RTCD_FWD_SIZES(X)
+#undef X
     return SVT_HIP_OK;
 }

@@ -70,7 +70,8 @@ class Rtcd(C.Structure):
                 ("svt_aom_obmc_sad", OBSAD * 22), ("svt_aom_obmc_variance", OBVAR * 22), ("svt_aom_obmc_sub_pixel_variance", OBSUB * 22),
                 ("svt_aom_blend_a64_mask", BLM), ("svt_aom_blend_a64_hmask", BLHV), ("svt_aom_blend_a64_vmask", BLHV),
                 ("svt_aom_highbd_blend_a64_mask", BLMH), ("svt_aom_highbd_blend_a64_hmask_8bit", BLHVH), ("svt_aom_highbd_blend_a64_vmask_8bit", BLHVH),
-                ("svt_av1_warp_affine", WARP), ("svt_av1_highbd_warp_affine", WARPH), ("svt_av1_compute_stats", STATS), ("svt_av1_compute_stats_highbd", STATSH)]
+                ("svt_av1_warp_affine", WARP), ("svt_av1_highbd_warp_affine", WARPH), ("svt_av1_compute_stats", STATS), ("svt_av1_compute_stats_highbd", STATSH),
+                ("svt_av1_fwd_txfm2d_N2", FWDF * 14), ("svt_av1_fwd_txfm2d_N4", FWDF * 14)]
 
 
 @pytest.fixture(scope="module")
@@ -137,7 +138,13 @@ def test_transform_wrappers(rtcd, orc):
                 x = rng.integers(-(1 << bd) + 1, 1 << bd, (h, stride)).astype(np.int16)
                 got = np.zeros(w * h, np.int32)
                 rtcd.svt_av1_fwd_txfm2d[slot](x.ctypes.data, got.ctypes.data, stride, tt, bd)
-                assert np.array_equal(got, tc.orc_fwd(orc, x, stride, tt, ts, bd)), ("fwd", ts, tt, bd)
+                full = tc.orc_fwd(orc, x, stride, tt, ts, bd)
+                assert np.array_equal(got, full), ("fwd", ts, tt, bd)
+                for d, tab in ((2, rtcd.svt_av1_fwd_txfm2d_N2), (4, rtcd.svt_av1_fwd_txfm2d_N4)):   # the pruned families: top-left corner of the default transform, zeros elsewhere
+                    exp = np.zeros((h, w), np.int32); exp[:h // d, :w // d] = full.reshape(h, w)[:h // d, :w // d]
+                    got = np.full(w * h, 77, np.int32)
+                    tab[slot](x.ctypes.data, got.ctypes.data, stride, tt, bd)
+                    assert np.array_equal(got.reshape(h, w), exp), ("fwd N%d" % d, ts, tt, bd)
     for ts in range(19):
         w, h = tc.TXW[ts], tc.TXH[ts]
         kw, kh = min(w, 32), min(h, 32)
