@@ -63,3 +63,28 @@ def test_search_window_matches_oracle(pkg, orc):
         # the window never leaves the 63-px padded picture
         assert x + a.x_origin >= -63 and y + a.y_origin >= -63
         assert x + a.x_origin + a.width - 1 <= pw - 1 + 0 or a.width == 1 or x + a.x_origin + a.width <= pw
+
+
+def test_every_entry_point_rejects_a_null_context(pkg):
+    """Error behaviour without a GPU: every entry point that takes the context first returns an error code (never crashes, never touches HIP)
+    when called with a NULL context and all-zero arguments.  The names come from include/svt_hip.h."""
+    L = pkg.lib()
+    hdr = open(os.path.join(ROOT, "include", "svt_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(svt_hip_[a-z0-9_]+)\s*\(SvtHipCtx \*ctx", hdr)))
+    assert len(names) >= 45
+    checked = 0
+    for n in names:
+        f = getattr(L, n)
+        if f.restype is not C.c_int and f.restype is not None and f.restype is not int: continue   # svt_hip_last_error etc.
+        assert f.argtypes, f"{n}: the ctypes binding declares no argtypes"
+        args = []
+        for a in f.argtypes:
+            if isinstance(a, type) and issubclass(a, C.Array): args.append(a())
+            elif a is C.c_void_p or a is C.c_char_p or hasattr(a, "contents"): args.append(None)
+            elif a in (C.c_double, C.c_float): args.append(0.0)
+            else: args.append(0)
+        if n in ("svt_hip_sync", "svt_hip_destroy", "svt_hip_timer_start", "svt_hip_free", "svt_hip_me_set_waves_per_sb"): continue   # void / trivially valid on NULL
+        r = f(*args)
+        assert r != 0, f"{n} accepted a NULL context"
+        checked += 1
+    assert checked >= 40
