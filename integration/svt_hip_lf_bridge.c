@@ -228,3 +228,88 @@ EbErrorType svt_hip_rest_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
     }
     return EB_ErrorNone;
 }
+
+/* rest_kernel, search half: in place of every search_sgrproj_seg call of restoration_seg_search (EbRestorationPick.c:1277-1317, per unit:
+ * search_selfguided_restoration + try_restoration_unit_seg).  One svt_hip_sgr_search_units_picture call gives the (ep, xqd) of every unit
+ * of the three planes; the units are then filtered with exactly those parameters (stripe rules as in svt_av1_loop_restoration_filter_unit)
+ * and their SSE against the source is what try_restoration_unit_seg -> sse_restoration_unit (:58-135) returns.  Results land in
+ * pcs->parent_pcs_ptr->rusi_picture[plane][unit] (sgrproj, sse[RESTORE_SGRPROJ]) and cm->sg_frame_ep_cnt, i.e. where search_sgrproj_finish (:1319) and
+ * rest_finish_search read them.  p->d_cdef must hold the CDEF output, p->d_recon the deblocked picture, p->d_src the source. */
+EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
+    Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    /* the set window of search_selfguided_restoration (:596-607) */
+    static const int8_t k_step[5] = {16, 0, 1, 4, 16};   /* get_sg_step (:693-704) */
+    const int8_t step = k_step[cm->sg_filter_mode >= 1 && cm->sg_filter_mode <= 4 ? cm->sg_filter_mode : 0];
+    const int8_t *re = cm->sg_ref_frame_ep;
+    const int none = re[0] < 0 && re[1] < 0;
+    const int mid = none ? 0 : (re[1] < 0 ? re[0] : (re[0] < 0 ? re[1] : (re[0] + re[1]) / 2));
+    const int start_ep = none ? 0 : (mid - step > 0 ? mid - step : 0), end_ep = none ? 16 : (mid + step < 16 ? mid + step : 16);
+    uint32_t mask = 0;
+    for (int ep = start_ep; ep < end_ep; ep++) mask |= 1u << ep;
+    if (!mask) return EB_ErrorBadParameter;
+
+    SvtHipSgrSearchPlane job[3];
+    int32_t *xqd[3] = {0}; int64_t *err[3] = {0}; uint8_t *best[3] = {0};
+    EbErrorType ret = EB_ErrorNone;
+    for (int pl = 0; pl < 3; pl++) {
+        const RestorationInfo *rsi = &cm->rst_info[pl];
+        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
+        xqd[pl] = (int32_t *)malloc(sizeof(int32_t) * 32 * n); err[pl] = (int64_t *)malloc(sizeof(int64_t) * 16 * n); best[pl] = (uint8_t *)malloc(n);
+        if (!xqd[pl] || !err[pl] || !best[pl]) { ret = EB_ErrorInsufficientResources; goto done; }
+        if (svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], pw, ph, LF_BORDER, LF_BORDER) != SVT_HIP_OK) { ret = EB_ErrorUndefined; goto done; }
+        job[pl].d_dgd = plane_origin(p, p->d_cdef[pl], pl); job[pl].stride = p->stride[pl];
+        job[pl].d_src = p->d_src[pl]; job[pl].src_stride = p->src_stride[pl];
+        job[pl].pw = pw; job[pl].ph = ph; job[pl].unit_size = rsi->restoration_unit_size; job[pl].ss_y = pl > 0;
+        job[pl].ep_mask = mask; job[pl].xqd_out = xqd[pl]; job[pl].err_out = err[pl]; job[pl].best_ep = best[pl];
+    }
+    if (svt_hip_sgr_search_units_picture(hip, p->pix_bytes, p->bd, 3, job, NULL) != SVT_HIP_OK) { ret = EB_ErrorUndefined; goto done; }
+
+    for (int pl = 0; pl < 3; pl++) {
+        const RestorationInfo *rsi = &cm->rst_info[pl];
+        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size;
+        RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
+        uint8_t *ep = (uint8_t *)malloc(n); int32_t *uq = (int32_t *)malloc(sizeof(int32_t) * 2 * n);
+        SvtHipBlkPair *rect = (SvtHipBlkPair *)malloc(sizeof(SvtHipBlkPair) * n); uint64_t *sse = (uint64_t *)malloc(sizeof(uint64_t) * n);
+        void *d_rect = NULL, *d_sse = NULL;
+        int ok = ep && uq && rect && sse;
+        if (ok) {
+            /* unit rectangles of foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) */
+            const int ext = us * 3 / 2, voff = 8 >> (pl > 0), hunits = rsi->horz_units_per_tile;
+            int y0 = 0, i = 0;
+            while (y0 < ph) {
+                const int rem_h = ph - y0, h = rem_h < ext ? rem_h : us;
+                int v0 = y0 - voff > 0 ? y0 - voff : 0, v1 = y0 + h;
+                if (v1 < ph) v1 -= voff;
+                int x0 = 0, j = 0;
+                while (x0 < pw) {
+                    const int rem_w = pw - x0, w = rem_w < ext ? rem_w : us, u = i * hunits + j;
+                    ep[u] = best[pl][u];
+                    uq[2 * u] = xqd[pl][(u * 16 + ep[u]) * 2]; uq[2 * u + 1] = xqd[pl][(u * 16 + ep[u]) * 2 + 1];
+                    rusi[u].sgrproj.ep = ep[u]; rusi[u].sgrproj.xqd[0] = uq[2 * u]; rusi[u].sgrproj.xqd[1] = uq[2 * u + 1];
+                    cm->sg_frame_ep_cnt[ep[u]]++;
+                    rect[u].a_x = rect[u].b_x = x0; rect[u].a_y = rect[u].b_y = v0; rect[u].w = (uint16_t)w; rect[u].h = (uint16_t)(v1 - v0);
+                    x0 += w; j++;
+                }
+                y0 += h; i++;
+            }
+            ok = svt_hip_malloc(hip, &d_rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK && svt_hip_malloc(hip, &d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK &&
+                 svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl], ep, n) == SVT_HIP_OK && svt_hip_memcpy_h2d(hip, p->d_unit_xqd[pl], uq, sizeof(int32_t) * 2 * n) == SVT_HIP_OK &&
+                 svt_hip_memcpy_h2d(hip, d_rect, rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK &&
+                 /* try_restoration_unit_seg: the unit filtered for real (stripe context from the deblocked picture), then its SSE */
+                 svt_hip_sgr_apply_plane_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
+                                             pw, ph, us, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl]) == SVT_HIP_OK &&
+                 svt_hip_block_sse_batch_dev(hip, p->pix_bytes, p->d_src[pl], p->src_stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
+                                             (const SvtHipBlkPair *)d_rect, n, (uint64_t *)d_sse) == SVT_HIP_OK &&
+                 svt_hip_memcpy_d2h(hip, sse, d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK;
+            if (ok)
+                for (int u = 0; u < n; u++) rusi[u].sse[RESTORE_SGRPROJ] = (int64_t)sse[u];
+        }
+        if (d_rect) svt_hip_free(hip, d_rect);
+        if (d_sse) svt_hip_free(hip, d_sse);
+        free(ep); free(uq); free(rect); free(sse);
+        if (!ok) { ret = EB_ErrorUndefined; goto done; }
+    }
+done:
+    for (int pl = 0; pl < 3; pl++) { free(xqd[pl]); free(err[pl]); free(best[pl]); }
+    return ret;
+}

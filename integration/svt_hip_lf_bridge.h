@@ -2,6 +2,7 @@
  * svt_hip_lf_bridge.h — reference-side glue for SURVEY 8(f) rank 1, the three in-loop filter process loops:
  *   dlf_kernel   (Source/Lib/Encoder/Codec/EbDlfProcess.c:175-216)  svt_av1_loop_filter_frame          -> svt_hip_dlf_picture()
  *   cdef_kernel  (EbCdefProcess.c:510-534)  cdef_seg_search[16bit] per segment + svt_av1_cdef_frame      -> svt_hip_cdef_search_picture(), svt_hip_cdef_apply_picture()
+ *   rest_kernel  (EbRestProcess.c:527)      restoration_seg_search: search_sgrproj_seg per unit            -> svt_hip_sgr_search_picture()
  *   rest_kernel  (EbRestProcess.c:548)      svt_av1_loop_restoration_filter_frame                        -> svt_hip_rest_apply_picture()
  * Each replaces a per-SB / per-segment loop by one batched call per picture and leaves the reference's own objects (recon picture,
  * pcs->mse_seg, cm->rst_info) exactly as the C loops leave them, so finish_cdef_search, the restoration search's host logic and the
@@ -58,5 +59,9 @@ EbErrorType svt_hip_cdef_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
 /* rest_kernel: in place of svt_av1_loop_restoration_save_boundary_lines (x2) + svt_av1_loop_restoration_filter_frame; the stripe context
  * rows come straight from the resident deblocked picture (p->d_recon).  p->d_rest receives the restored picture. */
 EbErrorType svt_hip_rest_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs);
+
+/* rest_kernel, search half: in place of the search_sgrproj_seg calls of restoration_seg_search (every unit of the three planes): fills
+ * pcs->parent_pcs_ptr->rusi_picture[plane][unit].sgrproj / .sse[RESTORE_SGRPROJ] and cm->sg_frame_ep_cnt for search_sgrproj_finish / rest_finish_search. */
+EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs);
 
 #endif
