@@ -360,7 +360,8 @@ int svt_hip_sgr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const voi
                                 const uint8_t *d_unit_ep, const int32_t *d_unit_xqd);
 /* get_pixel_proj_error (Encoder/Codec/EbRestorationPick.c:317-351: svt_decode_xq + svt_av1_lowbd_pixel_proj_error /
  * svt_av1_highbd_pixel_proj_error, aom_dsp_rtcd.h) for every restoration unit of a plane, every parameter set in ep_mask and ncand
- * (1..SVT_HIP_SGR_MAX_CAND) xqd pairs per (unit, set): d_xqd[unit][16][ncand][2] -> d_err[unit][16][ncand] (cleared by the call;
+ * (1..SVT_HIP_SGR_MAX_CAND) xqd pairs (inside the tap range: xqd[0] in [-96, 31], xqd[1] in [-32, 95], EbRestoration.h:100-103) per (unit, set):
+ * d_xqd[unit][16][ncand][2] -> d_err[unit][16][ncand] (cleared by the call;
  * entries of sets outside ep_mask stay 0; a first candidate with xqd[0] == INT32_MIN skips that (unit, set), its errors stay 0).
  * The filters are recomputed on chip, flt0 / flt1 never reach memory. */
 #define SVT_HIP_SGR_MAX_CAND 12
