@@ -362,9 +362,10 @@ int svt_hip_sgr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const voi
  * svt_av1_highbd_pixel_proj_error, aom_dsp_rtcd.h) for every restoration unit of a plane, every parameter set in ep_mask and ncand
  * (1..SVT_HIP_SGR_MAX_CAND) xqd pairs (inside the tap range: xqd[0] in [-96, 31], xqd[1] in [-32, 95], EbRestoration.h:100-103) per (unit, set):
  * d_xqd[unit][16][ncand][2] -> d_err[unit][16][ncand] (cleared by the call;
- * entries of sets outside ep_mask stay 0; a first candidate with xqd[0] == INT32_MIN skips that (unit, set), its errors stay 0).
+ * entries of sets outside ep_mask stay 0; a candidate with xqd[0] == INT32_MIN ends the list of that (unit, set) early — as the first
+ * candidate it skips the pair; the errors of the unused slots stay 0).
  * The filters are recomputed on chip, flt0 / flt1 never reach memory. */
-#define SVT_HIP_SGR_MAX_CAND 12
+#define SVT_HIP_SGR_MAX_CAND 24
 int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src,
                                      int src_stride, int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand,
                                      const int32_t *d_xqd, int64_t *d_err);
@@ -372,7 +373,8 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, cons
  * ep_mask (the reference's [start_ep, end_ep) window around the reference frames' sets, :596-607, is the caller's mask): projection
  * sums on the GPU, svt_get_proj_subspace's 2x2 solve (:497-538) and encode_xq (:539) on the host, then
  * finer_search_pixel_proj_error (:353-446, start step 2) replayed on the host over errors that svt_hip_sgr_proj_error_plane_dev evaluates
- * in rounds (one launch per round for all units and sets; the walk's next points are requested speculatively, typically 2-3 rounds).
+ * in rounds (one launch per round for all units and sets; the points the walk will visit are predicted with the quadratic model of the
+ * five sums, so a round usually covers a whole walk; a misprediction costs another round, never exactness).
  * HOST outputs: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched), best_ep[unit] (may be NULL) = the first set
  * with the smallest error; *rounds_out (may be NULL) = error launches used.  Synchronous; uses library-owned device scratch. */
 int svt_hip_sgr_search_units_plane(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride,

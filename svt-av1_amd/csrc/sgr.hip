@@ -480,7 +480,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 // every (restoration unit, parameter set in ep_mask, candidate c < ncand): err[unit][16][ncand] += sum over the unit of
 // (((u << 7) + xq0 (flt0 - u) + xq1 (flt1 - u) + 2^10) >> 11) - src)^2 with xq = svt_decode_xq(xqd[unit][16][ncand][2]).  Same tiling and filter
 // passes as the search kernel; the candidates of a (unit, set) are workgroup-uniform, so their decode is scalar work.
-constexpr int kSgrMaxCand = 12;
+constexpr int kSgrMaxCand = 24;
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
 sgr_proj_error_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
@@ -499,7 +499,7 @@ sgr_proj_error_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __rest
     {
         const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
         xt[tid] = (A << 20) | (256u - A);
-        if (tid < 16 * kSgrMaxCand) acc[tid / kSgrMaxCand][tid % kSgrMaxCand] = 0ull;
+        for (int k = tid; k < 16 * kSgrMaxCand; k += 256) acc[k / kSgrMaxCand][k % kSgrMaxCand] = 0ull;
     }
     batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
         [&](int i) {
@@ -535,6 +535,7 @@ sgr_proj_error_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __rest
         const int32_t* q = xqd + ((size_t)unit * 16 + ep) * ncand * 2;
         for (int c = 0; c < ncand; c++) {
             const int32_t xqd0 = q[2 * c], xqd1 = q[2 * c + 1];
+            if (xqd0 == INT32_MIN) break;   // end of this (unit, set)'s candidate list (workgroup-uniform)
             const int32_t xq0 = has0 ? xqd0 : 0, xq1 = !has1 ? 0 : (has0 ? 128 - xqd0 - xqd1 : 128 - xqd1);   // svt_decode_xq (EbRestoration.c:707-718)
             int32_t p0 = 0, p1 = 0;   // rows 0-3 / 4-7: |e| < 2^13 at bit depth 10, four squares stay far below 2^31
 #pragma unroll

@@ -575,6 +575,7 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
 namespace {
 const int kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
 const int kTapMin[2] = {-96, -32}, kTapMax[2] = {31, 95};   // SGRPROJ_PRJ_MIN0/MAX0, MIN1/MAX1 (EbRestoration.h:100-103)
+inline bool kSgr1(int ep) { return kSgrR[ep][1] > 0; }
 
 struct SgrPoint { int x, y; int64_t err; };
 struct SgrItem {            // one (restoration unit, parameter set)
@@ -612,66 +613,60 @@ void sgr_encode_xq(const int xq[2], int xqd[2], int ep) {   // encode_xq, EbRest
 }
 
 // finer_search_pixel_proj_error (EbRestorationPick.c:353-446) replayed on the cache of evaluated points.  Returns true when the walk
-// finished (it.xqd / it.err hold the result); otherwise it.want lists the missing point followed by the points the walk is most likely to ask
-// for next (the axis neighbours of the current position at the current and smaller steps), at most max_want of them.
-bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, int n_ahead) {
-    int q[2] = {it.xqd[0], it.xqd[1]};
-    int64_t err, err2;
-    it.want.clear();
-    auto stall = [&](int nx, int ny, int s) {
-        it.want.emplace_back(nx, ny);
-        // at the largest step an accepted move keeps walking in the same direction: ask for the next n_ahead points on that line too
-        if (s == start_step && (nx != q[0] || ny != q[1])) {
-            const int p = nx != q[0] ? 0 : 1, d = (p == 0 ? nx - q[0] : ny - q[1]);
-            int c[2] = {nx, ny};
-            for (int k = 0; k < n_ahead && (int)it.want.size() < max_want; k++) {
-                c[p] += d;
-                if (c[p] < kTapMin[p] || c[p] > kTapMax[p]) break;
-                it.want.emplace_back(c[0], c[1]);
-            }
-        }
-        for (int t = s; t >= 1 && (int)it.want.size() < max_want; t >>= 1)
-            for (int p = 0; p < 2 && (int)it.want.size() < max_want; p++) {
-                if (kSgrR[ep][p] == 0) continue;
-                for (int dir = -1; dir <= 1; dir += 2) {
-                    int c[2] = {q[0], q[1]};
-                    c[p] += dir * t;
-                    if (c[p] < kTapMin[p] || c[p] > kTapMax[p]) continue;
-                    int64_t dummy;
-                    bool dup = it.lookup(c[0], c[1], dummy);
-                    for (const auto& w : it.want) dup = dup || (w.first == c[0] && w.second == c[1]);
-                    if (!dup && (int)it.want.size() < max_want) it.want.emplace_back(c[0], c[1]);
-                }
-            }
-        return false;
+// finished on exact errors only (it.xqd / it.err hold the result).  At the first point whose error is not known yet the replay turns
+// speculative: it keeps walking, but decides with the quadratic model of the error that the five projection sums give
+// (sum e^2 = const + (xq' H xq - 256 C.xq) / 2048^2 up to the per-pixel rounding), and every point it visits goes to it.want (at most
+// max_want).  The next round evaluates those points exactly; wherever the model took the same decisions as the exact errors do, the whole
+// walk is then in the cache.  Mispredictions only cost another round, never exactness.
+bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, const int64_t* sums) {
+    const bool has0 = kSgrR[ep][0] > 0, has1 = kSgr1(ep);
+    const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    auto model = [&](int x, int y) {
+        const double xq0 = has0 ? x : 0, xq1 = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
+        return xq0 * xq0 * H00 + 2 * xq0 * xq1 * H01 + xq1 * xq1 * H11 - 256.0 * (xq0 * C0 + xq1 * C1);
     };
-    if (!it.lookup(q[0], q[1], err)) return stall(q[0], q[1], start_step);
-    for (int s = start_step; s >= 1; s >>= 1) {
-        for (int p = 0; p < 2; p++) {
+    int q[2] = {it.xqd[0], it.xqd[1]};
+    bool spec = false;
+    it.want.clear();
+    // error of point (x, y): exact while everything so far was cached, the model afterwards (cur = the walk's current point, for the switch)
+    auto value = [&](int x, int y, const int cur[2], double& cur_err) {
+        int64_t e;
+        if (!spec && it.lookup(x, y, e)) return (double)e;
+        if (!spec) { spec = true; cur_err = model(cur[0], cur[1]); }
+        if (!it.lookup(x, y, e)) {
+            bool dup = false;
+            for (const auto& w : it.want) dup = dup || (w.first == x && w.second == y);
+            if (!dup && (int)it.want.size() < max_want) it.want.emplace_back(x, y);
+        }
+        return model(x, y);
+    };
+    double err = 0, err2;
+    err = value(q[0], q[1], q, err);
+    for (int s = start_step; s >= 1 && (int)it.want.size() < max_want; s >>= 1) {
+        for (int p = 0; p < 2 && (int)it.want.size() < max_want; p++) {
             if (kSgrR[ep][p] == 0) continue;
             bool skip = false;
             for (;;) {
-                if (q[p] - s >= kTapMin[p]) {
-                    q[p] -= s;
-                    if (!it.lookup(q[0], q[1], err2)) { const int nx = q[0], ny = q[1]; q[p] += s; return stall(nx, ny, s); }
-                    if (err2 > err) q[p] += s;
-                    else { err = err2; skip = true; if (s == start_step) continue; }
+                if (q[p] - s >= kTapMin[p] && (int)it.want.size() < max_want) {
+                    int c[2] = {q[0], q[1]}; c[p] -= s;
+                    err2 = value(c[0], c[1], q, err);
+                    if (!(err2 > err)) { q[p] -= s; err = err2; skip = true; if (s == start_step) continue; }
                 }
                 break;
             }
             if (skip) break;
             for (;;) {
-                if (q[p] + s <= kTapMax[p]) {
-                    q[p] += s;
-                    if (!it.lookup(q[0], q[1], err2)) { const int nx = q[0], ny = q[1]; q[p] -= s; return stall(nx, ny, s); }
-                    if (err2 > err) q[p] -= s;
-                    else { err = err2; if (s == start_step) continue; }
+                if (q[p] + s <= kTapMax[p] && (int)it.want.size() < max_want) {
+                    int c[2] = {q[0], q[1]}; c[p] += s;
+                    err2 = value(c[0], c[1], q, err);
+                    if (!(err2 > err)) { q[p] += s; err = err2; if (s == start_step) continue; }
                 }
                 break;
             }
         }
     }
-    it.xqd[0] = q[0]; it.xqd[1] = q[1]; it.err = err; it.done = true;
+    if (spec) return false;
+    it.xqd[0] = q[0]; it.xqd[1] = q[1]; it.err = (int64_t)err; it.done = true;
     return true;
 }
 }  // namespace
@@ -758,7 +753,7 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_
             for (int u = 0; u < J.nu; u++)
                 for (int ep = 0; ep < 16; ep++) {
                     SgrItem& it = J.items[(size_t)u * 16 + ep];
-                    if (!it.done && !sgr_replay(it, ep, 2, NC, rounds < 3 ? 2 + 3 * rounds : NC - 1)) round_mask[k] |= 1u << ep;
+                    if (!it.done && !sgr_replay(it, ep, 2, NC, (const int64_t*)(host + J.sums_o) + ((size_t)u * 16 + ep) * 5)) round_mask[k] |= 1u << ep;
                 }
             any = any || round_mask[k];
         }
@@ -774,8 +769,8 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_
                     int32_t* q = &h_xqd[((size_t)u * 16 + ep) * NC * 2];
                     for (int n = 0; n < NC; n++) {
                         const bool live = !it.done && n < (int)it.want.size();
-                        q[2 * n] = live ? it.want[n].first : (it.done || it.want.empty() ? INT32_MIN : it.want[0].first);   // INT32_MIN: skip this (unit, set)
-                        q[2 * n + 1] = live ? it.want[n].second : (it.done || it.want.empty() ? 0 : it.want[0].second);
+                        q[2 * n] = live ? it.want[n].first : INT32_MIN;   // INT32_MIN ends the list (first slot: the pair is skipped)
+                        q[2 * n + 1] = live ? it.want[n].second : 0;
                     }
                 }
             HIPCHK(c, hipMemcpyAsync(dev + J.xqd_o, h_xqd, sizeof(int32_t) * J.nu * 16 * NC * 2, hipMemcpyHostToDevice, c->stream));

@@ -197,7 +197,7 @@ def test_proj_error_candidates(hip, orc, bd, ss):
     rng = np.random.default_rng(5 + ss)
     orc.orc_sgr_proj_error.restype = C.c_int64
     pu = 64 >> ss
-    for mask, nc in ((0xFFFF, 5), (0x4401, 12), (0x8020, 1)):
+    for mask, nc in ((0xFFFF, 5), (0x4401, 24), (0x8020, 1)):
         xqd = np.stack([rng.integers(-96, 32, (nu, 16, nc)), rng.integers(-32, 96, (nu, 16, nc))], -1).astype(np.int32)
         xqd[:, :, 0] = (-96, -32); xqd[0, :, nc - 1] = (31, 95)
         d_xqd = hip.to_device(np.ascontiguousarray(xqd)); d_err = hip.to_device(np.full((nu, 16, nc), -1, np.int64))
@@ -222,7 +222,7 @@ def test_proj_error_candidates(hip, orc, bd, ss):
                     e = orc.orc_sgr_proj_error(C.c_void_p(src.ctypes.data + (y0 * w + x0) * src.itemsize), w, C.c_void_p(ext.ctypes.data + off + (y0 * st + x0) * ext.itemsize), st,
                                                ext.itemsize, uw, uh, ptr(f0), fs, ptr(f1), fs, xq, ep)
                     assert got[u, ep, k] == e, (bd, ss, hex(mask), u, ep, k)
-    assert hip.L.svt_hip_sgr_proj_error_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, 1, 13, d_ext, d_ext) != 0
+    assert hip.L.svt_hip_sgr_proj_error_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, 1, 25, d_ext, d_ext) != 0
     hip.free(d_ext, d_src)
 
 

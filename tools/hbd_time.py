@@ -126,7 +126,7 @@ for name, fn in (("deblock", deblock), ("subpel_16x16", subpel), ("cdef_search",
     for _ in range(10): fn()
     L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
     print(f"{name:12s} {W}x{H} bd{bd}: {ms.value / 10:.3f} ms")
-NCAND = 12
+NCAND = 12   # of SVT_HIP_SGR_MAX_CAND = 24
 d_cand = [hip.to_device(np.stack([rng.integers(-96, 32, (n, 16, NCAND)), rng.integers(-32, 96, (n, 16, NCAND))], -1).astype(np.int32)) for n in units]
 d_cerr = [hip.to_device(np.zeros((n, 16, NCAND), np.int64)) for n in units]
 
