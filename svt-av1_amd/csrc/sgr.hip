@@ -473,8 +473,6 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         }
     }
 }
-#undef FA_
-#undef FB_
 
 // ---- projected error of xqd candidates: get_pixel_proj_error (EbRestorationPick.c:317-351 -> svt_av1_{lowbd,highbd}_pixel_proj_error, :174-316) for
 // every (restoration unit, parameter set in ep_mask, candidate c < ncand): err[unit][16][ncand] += sum over the unit of
