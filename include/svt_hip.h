@@ -55,6 +55,9 @@ int  svt_hip_free(SvtHipCtx *ctx, void *dptr);
 int  svt_hip_memcpy_h2d(SvtHipCtx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int  svt_hip_memcpy_d2h(SvtHipCtx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int  svt_hip_memcpy_d2d(SvtHipCtx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* asynchronous, stream-ordered */
+/* picture planes: `rows` rows of `width_bytes`, pitches in bytes (EbPictureBufferDesc planes keep their own strides) */
+int  svt_hip_memcpy2d_h2d(SvtHipCtx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width_bytes, size_t rows);
+int  svt_hip_memcpy2d_d2h(SvtHipCtx *ctx, void *dst_host, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes, size_t rows);
 /* HIP-event stopwatch on the context's stream (used by bench.py for per-kernel device time). */
 int  svt_hip_timer_start(SvtHipCtx *ctx);
 int  svt_hip_timer_stop_ms(SvtHipCtx *ctx, float *elapsed_ms);

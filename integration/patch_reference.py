@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Applies the reference-side hook calls of INTEGRATION.md to copies of the reference's process-loop sources.
+
+    python3 integration/patch_reference.py --ref /root/reference --out /tmp/svtav1_enc_patched
+
+The reference tree is read-only, so the patched files are written under --out with their paths relative to the reference root
+(Source/Lib/Encoder/Codec/EbDlfProcess.c ...); oracle/Makefile.enc compiles those instead of the originals and links
+integration/*.c + libsvtav1_hip.so into SvtAv1EncApp.  Nothing of the reference is copied into this repository: this script holds only
+the anchors (a few tokens of each call site) and the inserted lines — it IS the patch a maintainer would apply.
+
+Every edit is an anchored textual replacement that must match exactly once; a reference version whose call sites moved fails loudly.
+With SVT_HIP_HOOKS unset every hook reports "not handled" and the patched encoder runs the reference's own code (tests check that
+the bitstream is then identical to the unpatched build).
+"""
+import argparse
+import os
+import re
+import sys
+
+HOOK_INCLUDE = '#include "svt_hip_hooks.h"\n'
+
+
+class Patch:
+    def __init__(self, rel):
+        self.rel, self.edits = rel, []
+
+    def sub(self, pattern, repl, flags=re.S):
+        """regex with exactly one match"""
+        self.edits.append((pattern, repl, flags))
+        return self
+
+    def apply(self, text):
+        for pattern, repl, flags in self.edits:
+            found = re.findall(pattern, text, flags)
+            if len(found) != 1:
+                raise SystemExit(f"{self.rel}: anchor {pattern!r} matched {len(found)} times (expected 1)")
+            text = re.sub(pattern, repl, text, count=1, flags=flags)
+        return text
+
+
+def after_last_include(text):
+    m = list(re.finditer(r'^#include [^\n]*\n', text, re.M))
+    return text[:m[-1].end()] + HOOK_INCLUDE + text[m[-1].end():]
+
+
+PATCHES = []
+
+# ---------------------------------------------------------------------------------------------------------------- svt_av1_enc_init
+# One call after the two RTCD setups and before the tables derived from them (EbEncHandle.c:1144-1147).
+PATCHES.append(Patch("Source/Lib/Encoder/Globals/EbEncHandle.c").sub(
+    r'(setup_rtcd_internal\(enc_handle_ptr->scs_instance_array\[0\]->scs_ptr->static_config\.use_cpu_flags\);\n)',
+    r'\1    svt_hip_hooks_enc_init(); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))
+
+# ---------------------------------------------------------------------------------------------------------------- open-loop ME
+me = Patch("Source/Lib/Encoder/Codec/EbMotionEstimation.c")
+# integer_search_sb (:2130): record the window for the segment's batched launch instead of searching it now
+me.sub(r'(\n[ \t]*)(open_loop_me_fullpel_search_sblock\(context_ptr,\s*list_index,\s*ref_pic_index,\s*x_search_area_origin,\s*'
+       r'y_search_area_origin,\s*search_area_width,\s*search_area_height\);)',
+       r'\1if (!svt_hip_me_record(context_ptr, sb_origin_x, sb_origin_y, list_index, ref_pic_index, ref_pic_ptr, x_search_area_origin,'
+       r'\1                       y_search_area_origin, search_area_width, search_area_height))'
+       r'\1    \2')
+# motion_estimate_sb (:2912) becomes motion_estimate_sb_hip(..., hip_phase); the old name stays as the whole-function wrapper
+me.sub(r'EbErrorType motion_estimate_sb\(\s*PictureParentControlSet \*pcs_ptr,([^{]*?)EbPictureBufferDesc \*input_ptr\)([^{]*)\{',
+       r'EbErrorType motion_estimate_sb_hip(PictureParentControlSet *pcs_ptr,\1EbPictureBufferDesc *input_ptr, int hip_phase)\2{')
+me.sub(r'(\n[ \t]*//init hme results buffer\n)', r'\n    if (hip_phase != 1) { /* phase 1 resumes after the (batched) integer search */\1')
+me.sub(r'(\n[ \t]*integer_search_sb\(pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr, input_ptr\);\n)',
+       r'\1    if (hip_phase == 0) return return_error; /* windows recorded; results arrive with svt_hip_me_batch_flush */\n    }\n')
+PATCHES.append(me)
+ME_TAIL = '''
+EbErrorType motion_estimate_sb(PictureParentControlSet *pcs_ptr, uint32_t sb_index, uint32_t sb_origin_x, uint32_t sb_origin_y,
+                               MeContext *context_ptr, EbPictureBufferDesc *input_ptr) {
+    return motion_estimate_sb_hip(pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr, input_ptr, -1);
+}
+'''
+
+mep = Patch("Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c")
+# the SB loop of a segment (:831-963) runs twice around the batched launch when the hook is on
+mep.sub(r'(\n[ \t]*// SB Loop\n)([ \t]*for \(uint32_t y_sb_index = y_sb_start_index; y_sb_index < y_sb_end_index;\s*\+\+y_sb_index\) \{\s*'
+        r'for \(uint32_t x_sb_index = x_sb_start_index; x_sb_index < x_sb_end_index;\s*\+\+x_sb_index\) \{\s*'
+        r'uint32_t sb_index = \(uint16_t\)\(x_sb_index \+ y_sb_index \* pic_width_in_sb\);\s*uint32_t sb_origin_x = x_sb_index \* scs_ptr->sb_sz;)',
+        r'\1                SvtHipMeBatch *hip_me = svt_hip_me_batch_begin(pcs_ptr, context_ptr->me_context_ptr,\n'
+        r'                    (x_sb_end_index - x_sb_start_index) * (y_sb_end_index - y_sb_start_index));\n'
+        r'                for (int hip_pass = 0; hip_pass < (hip_me ? 2 : 1); hip_pass++) {\n'
+        r'                if (hip_pass == 1) svt_hip_me_batch_flush(hip_me, input_padded_picture_ptr);\n\2')
+mep.sub(r'(\n[ \t]*)motion_estimate_sb\(pcs_ptr,\s*sb_index,\s*sb_origin_x,\s*sb_origin_y,\s*context_ptr->me_context_ptr,\s*input_picture_ptr\);',
+        r'\1if (hip_me) {'
+        r'\1    if (!svt_hip_me_batch_sb(hip_me, hip_pass, pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr->me_context_ptr, input_picture_ptr))'
+        r'\1        continue; /* pass 0: the integer search of this SB is pending */'
+        r'\1} else'
+        r'\1    motion_estimate_sb(pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr->me_context_ptr, input_picture_ptr);')
+mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',
+        r'\1                } /* hip_pass */\n                svt_hip_me_batch_end(hip_me);\n')
+PATCHES.append(mep)
+
+TAILS = {"Source/Lib/Encoder/Codec/EbMotionEstimation.c": ME_TAIL}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--list", action="store_true", help="print the relative paths of the patched files and exit")
+    a = ap.parse_args()
+    if a.list:
+        print("\n".join(p.rel for p in PATCHES))
+        return
+    for p in PATCHES:
+        src = os.path.join(a.ref, p.rel)
+        with open(src) as f:
+            text = f.read()
+        text = after_last_include(p.apply(text)) + TAILS.get(p.rel, "")
+        dst = os.path.join(a.out, p.rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        old = open(dst).read() if os.path.exists(dst) else None
+        if old != text:   # keep timestamps when nothing changed (make)
+            with open(dst, "w") as f:
+                f.write(text)
+    print(f"patched {len(PATCHES)} files into {a.out}", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

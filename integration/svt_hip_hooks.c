@@ -1,0 +1,108 @@
+/* svt_hip_hooks.c — see svt_hip_hooks.h: run-time hook selection, the shared device context and its lock, and the per-call dispatch
+ * table entries of SVT_HIP_RTCD.  Reference-side glue (C, compiled into libSvtAv1Enc). */
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "svt_hip_hooks.h"
+#include "svt_hip_rtcd.h"
+#include "aom_dsp_rtcd.h"
+#include "common_dsp_rtcd.h"
+#include "EbLog.h"
+
+static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "hme", "dlf", "dlf_search", "cdef_search", "cdef_apply",
+                                                            "sgr_search", "wiener_stats", "rest_apply"};
+static int             g_enabled[SVT_HIP_HOOK_COUNT];
+static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
+static int             g_verbose;
+static SvtHipCtx      *g_ctx;
+static pthread_mutex_t g_lock   = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_cnt_mu = PTHREAD_MUTEX_INITIALIZER;
+static int             g_inited;
+
+static int in_list(const char *list, const char *name) {
+    if (!list) return 0;
+    const size_t n = strlen(name);
+    for (const char *p = list; *p;) {
+        const char *e = strchr(p, ',');
+        const size_t l = e ? (size_t)(e - p) : strlen(p);
+        if ((l == n && !strncmp(p, name, n)) || (l == 3 && !strncmp(p, "all", 3))) return 1;
+        if (!e) break;
+        p = e + 1;
+    }
+    return 0;
+}
+
+int svt_hip_hook_enabled(int which) { return which >= 0 && which < SVT_HIP_HOOK_COUNT && g_ctx && g_enabled[which]; }
+SvtHipCtx *svt_hip_hooks_lock(void) {
+    if (!g_ctx) return NULL;
+    pthread_mutex_lock(&g_lock);
+    return g_ctx;
+}
+void svt_hip_hooks_unlock(void) { pthread_mutex_unlock(&g_lock); }
+void svt_hip_hooks_log(const char *fmt, ...) {
+    if (!g_verbose) return;
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[svt_hip] ");
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+void svt_hip_hooks_count(int which, int handled) {
+    pthread_mutex_lock(&g_cnt_mu);
+    if (handled) g_handled[which]++; else g_fellback[which]++;
+    pthread_mutex_unlock(&g_cnt_mu);
+}
+/* one line per hook on stderr at exit: "svt_hip_hook me handled=12 fallback=0" (tests/test_encode_e2e*.py parse it) */
+void svt_hip_hooks_report(void) {
+    for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
+        if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
+}
+
+/* ---- per-call wrappers: SvtHipRtcd member <-> the reference's global pointer of the same name ---------------------------------------- */
+#define RTCD_SIMPLE(X)                                                                                                                      \
+    X(svt_sad_loop_kernel) X(svt_nxm_sad_kernel) X(svt_av1_selfguided_restoration) X(svt_apply_selfguided_restoration)                     \
+    X(svt_av1_compute_stats) X(svt_av1_compute_stats_highbd)
+
+static void install_rtcd(const char *list) {
+    SvtHipRtcd t;
+    memset(&t, 0, sizeof(t));
+    /* what is installed now (the C / SIMD kernels) becomes each wrapper's failure fallback */
+#define X(n) t.n = (void *)n;
+    RTCD_SIMPLE(X)
+#undef X
+    if (svt_hip_setup_rtcd(g_ctx, &t) != SVT_HIP_OK) {
+        SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_ctx));
+        return;
+    }
+#define X(n)                                                      \
+    if (in_list(list, #n)) {                                      \
+        n = (void *)t.n;                                          \
+        fprintf(stderr, "svt_hip_rtcd %s -> hip wrapper\n", #n);  \
+    }
+    RTCD_SIMPLE(X)
+#undef X
+}
+
+void svt_hip_hooks_enc_init(void) {
+    if (g_inited) return;
+    g_inited = 1;
+    const char *hooks = getenv("SVT_HIP_HOOKS"), *rtcd = getenv("SVT_HIP_RTCD"), *dev = getenv("SVT_HIP_DEVICE");
+    g_verbose = getenv("SVT_HIP_VERBOSE") && atoi(getenv("SVT_HIP_VERBOSE"));
+    int any = rtcd && *rtcd;
+    for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++) {
+        g_enabled[i] = in_list(hooks, k_hook_name[i]);
+        any |= g_enabled[i];
+    }
+    if (!any) return;   /* the patched encoder is the reference encoder */
+    if (svt_hip_init(dev ? atoi(dev) : 0, &g_ctx) != SVT_HIP_OK) {
+        /* error convention: never fail through the kernel surface — log, keep the C path */
+        SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");
+        g_ctx = NULL;
+        return;
+    }
+    if (rtcd && *rtcd) install_rtcd(rtcd);
+    atexit(svt_hip_hooks_report);
+}

@@ -1,0 +1,94 @@
+/*
+ * svt_hip_hooks.h — the functions the patched reference process loops call (integration/patch_reference.py shows every call site).
+ *
+ * Reference-side glue, compiled INTO libSvtAv1Enc together with svt_hip_me_bridge.c / svt_hip_lf_bridge.c; it is not part of
+ * libsvtav1_hip.so.  Every hook keeps the reference's error convention: a hook that is disabled or fails returns
+ * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
+ *
+ * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
+ *   SVT_HIP_HOOKS = comma list of  me, hme, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, rest_apply  |  all  |  none
+ *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
+ *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
+ *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
+ * Unset / empty SVT_HIP_HOOKS = none: the patched encoder then IS the reference encoder.
+ */
+#ifndef SVT_HIP_HOOKS_H
+#define SVT_HIP_HOOKS_H
+
+#include "EbDefinitions.h"
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbPictureBufferDesc.h"
+#include "EbMotionEstimationContext.h"
+#include "svt_hip.h"
+
+enum {
+    SVT_HIP_HOOK_ME = 0,       /* integer full search of every SB of an ME segment: motion_estimation_kernel (EbMotionEstimationProcess.c:831-963) */
+    SVT_HIP_HOOK_HME,          /* hme_level_0/1/2 searches of the segment (EbMotionEstimation.c:2204-2574) */
+    SVT_HIP_HOOK_DLF,          /* svt_av1_loop_filter_frame in dlf_kernel (EbDlfProcess.c:212) */
+    SVT_HIP_HOOK_DLF_SEARCH,   /* svt_av1_pick_filter_level(LPF_PICK_FROM_FULL_IMAGE) (EbDlfProcess.c:203) */
+    SVT_HIP_HOOK_CDEF_SEARCH,  /* cdef_seg_search[16bit] of every segment (EbCdefProcess.c:511-514) */
+    SVT_HIP_HOOK_CDEF_APPLY,   /* svt_av1_cdef_frame / av1_cdef_frame16bit (EbCdefProcess.c:531-533) */
+    SVT_HIP_HOOK_SGR_SEARCH,   /* search_sgrproj_seg of every unit (EbRestorationPick.c:1277, via restoration_seg_search :1537) */
+    SVT_HIP_HOOK_WIENER_STATS, /* svt_av1_compute_stats[_highbd] of every unit in search_wiener_seg (EbRestorationPick.c:1347) */
+    SVT_HIP_HOOK_REST_APPLY,   /* svt_av1_loop_restoration_filter_frame (EbRestProcess.c:548) */
+    SVT_HIP_HOOK_COUNT
+};
+
+/* svt_av1_enc_init, right after setup_common_rtcd_internal / setup_rtcd_internal (EbEncHandle.c:1144-1145) and before the derived
+ * tables (:1147): reads the environment, creates the context, installs the requested per-call wrappers. */
+void svt_hip_hooks_enc_init(void);
+int  svt_hip_hook_enabled(int which);
+/* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
+SvtHipCtx *svt_hip_hooks_lock(void);
+void       svt_hip_hooks_unlock(void);
+void       svt_hip_hooks_log(const char *fmt, ...);
+/* statistics for the tests: how many times each hook really ran on the device / fell back */
+void svt_hip_hooks_count(int which, int handled);
+void svt_hip_hooks_report(void);
+
+/* ------------------------------------------------------------------ open-loop ME (svt_hip_me_bridge.c) */
+typedef struct SvtHipMeBatch SvtHipMeBatch;
+/* motion_estimation_kernel, before the SB loop of a segment.  NULL = hook off: the caller runs its unchanged loop. */
+SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb);
+/* pass 0 (per SB): everything of motion_estimate_sb up to the integer search, whose windows are recorded instead of searched -> returns 0
+ * pass 1 (per SB, after svt_hip_me_batch_flush): results back into MeContext, the rest of motion_estimate_sb               -> returns 1 */
+int  svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
+                         uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr);
+void svt_hip_me_batch_flush(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded);
+void svt_hip_me_batch_end(SvtHipMeBatch *b);
+/* integer_search_sb, in place of open_loop_me_fullpel_search_sblock (EbMotionEstimation.c:2130): 1 = recorded for the batch, 0 = no
+ * batch is collecting on this thread (temporal-filter ME, hook off): the caller searches as before. */
+int  svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origin_y, uint32_t list_index, uint32_t ref_pic_index,
+                       const EbPictureBufferDesc *ref_pic, int16_t x_search_area_origin, int16_t y_search_area_origin,
+                       int16_t search_area_width, int16_t search_area_height);
+/* the patched motion_estimate_sb: hip_phase -1 = the whole function (what motion_estimate_sb() still is), 0 = up to and including
+ * integer_search_sb, 1 = from me_prune_ref on */
+EbErrorType motion_estimate_sb_hip(PictureParentControlSet *pcs_ptr, uint32_t sb_index, uint32_t sb_origin_x, uint32_t sb_origin_y,
+                                   MeContext *context_ptr, EbPictureBufferDesc *input_ptr, int hip_phase);
+
+/* ------------------------------------------------------------------ in-loop filters (svt_hip_lf_bridge.c)
+ * Every function returns EB_ErrorNone when the device did the work and the reference's objects hold the result; anything else =
+ * not handled, the caller runs the C code it replaces. */
+struct DlfContext;
+/* dlf_kernel: svt_av1_pick_filter_level(context, src, pcs, LPF_PICK_FROM_FULL_IMAGE) */
+EbErrorType svt_hip_hook_dlf_pick_level(PictureControlSet *pcs);
+/* dlf_kernel: svt_av1_loop_filter_frame(recon, pcs, 0, 3) */
+EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet *pcs);
+/* dlf_kernel, after the deblocked picture is final (before svt_av1_loop_restoration_save_boundary_lines): keeps it on the device for
+ * the CDEF / restoration hooks (the host overwrites it in place later). */
+void        svt_hip_hook_after_dlf(PictureControlSet *pcs);
+/* cdef_kernel, once per picture in place of all cdef_seg_search calls (when every segment has arrived) */
+EbErrorType svt_hip_hook_cdef_search(PictureControlSet *pcs);
+/* cdef_kernel: svt_av1_cdef_frame / av1_cdef_frame16bit */
+EbErrorType svt_hip_hook_cdef_apply(PictureControlSet *pcs);
+/* rest_kernel, once per picture (all segments arrived) before rest_finish_search: the search_sgrproj_seg results of every unit */
+EbErrorType svt_hip_hook_sgr_search(PictureControlSet *pcs);
+/* search_wiener_seg: M / H of one unit from the picture-level statistics pass (computed on first use per picture) */
+EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wiener_win, int unit_idx, int64_t *M, int64_t *H);
+/* rest_kernel: svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0) */
+EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs);
+/* rest_kernel, when the picture leaves the filter stages: releases its device state */
+void        svt_hip_hook_picture_done(PictureControlSet *pcs);
+
+#endif

@@ -1,0 +1,185 @@
+/*
+ * hip_mock.c — CPU test double of libsvtav1_hip.so.  TEST INFRASTRUCTURE ONLY (oracle/): it exists so that the reference-side glue in
+ * integration/ (the patched process loops, svt_hip_hooks.c, the bridges) can be exercised end to end by a real encode on a box without
+ * a GPU — tests/test_encode_e2e_cpu.py runs SvtAv1EncApp with every hook on against this library and requires the bitstream of the
+ * unpatched reference.  "Device" pointers are host pointers; every kernel entry point is answered by the oracle restatement (oracle/
+ * *_oracle.c, each pinned to the reference by tests/test_oracle_vs_ref.py).  The HOST-side logic of the product
+ * (svt-av1_amd/csrc/svt_hip_host.cpp: edge builder = set_lpf_parameters, level-search control flow) is compiled in unchanged, so this
+ * run pins exactly that code against the reference encoder.
+ *
+ * Never shipped, never loaded by the product: it is built into oracle/_ref/mock/libsvtav1_hip.so and only found when a test puts that
+ * directory on LD_LIBRARY_PATH.  On the GPU box the same encoder binary loads the real svt-av1_amd/libsvtav1_hip.so.
+ * Only the entry points the glue calls are provided.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/svt_hip.h"
+#include "../svt-av1_amd/csrc/svt_hip_host.h"
+#include "svt_oracle.h"
+
+struct SvtHipCtx { char err[256]; };
+
+int svt_hip_init(int device_id, SvtHipCtx **ctx) {
+    (void)device_id;
+    *ctx = (SvtHipCtx *)calloc(1, sizeof(SvtHipCtx));
+    fprintf(stderr, "svt_hip MOCK (oracle/hip_mock.c): CPU test double, not the product\n");
+    return *ctx ? SVT_HIP_OK : SVT_HIP_ERR_RUNTIME;
+}
+void        svt_hip_destroy(SvtHipCtx *c) { free(c); }
+const char *svt_hip_last_error(const SvtHipCtx *c) { return c ? c->err : "null context"; }
+int svt_hip_set_stream(SvtHipCtx *c, void *s) { (void)c; (void)s; return SVT_HIP_OK; }
+int svt_hip_sync(SvtHipCtx *c) { (void)c; return SVT_HIP_OK; }
+int svt_hip_malloc(SvtHipCtx *c, void **p, size_t bytes) { (void)c; *p = malloc(bytes ? bytes : 1); return *p ? SVT_HIP_OK : SVT_HIP_ERR_RUNTIME; }
+int svt_hip_free(SvtHipCtx *c, void *p) { (void)c; free(p); return SVT_HIP_OK; }
+int svt_hip_memcpy_h2d(SvtHipCtx *c, void *d, const void *h, size_t n) { (void)c; memcpy(d, h, n); return SVT_HIP_OK; }
+int svt_hip_memcpy_d2h(SvtHipCtx *c, void *h, const void *d, size_t n) { (void)c; memcpy(h, d, n); return SVT_HIP_OK; }
+int svt_hip_memcpy_d2d(SvtHipCtx *c, void *d, const void *s, size_t n) { (void)c; memmove(d, s, n); return SVT_HIP_OK; }
+int svt_hip_memcpy2d_h2d(SvtHipCtx *c, void *d, size_t dpitch, const void *h, size_t hpitch, size_t wbytes, size_t rows) {
+    (void)c;
+    for (size_t y = 0; y < rows; y++) memcpy((uint8_t *)d + y * dpitch, (const uint8_t *)h + y * hpitch, wbytes);
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy2d_d2h(SvtHipCtx *c, void *h, size_t hpitch, const void *d, size_t dpitch, size_t wbytes, size_t rows) {
+    (void)c;
+    for (size_t y = 0; y < rows; y++) memcpy((uint8_t *)h + y * hpitch, (const uint8_t *)d + y * dpitch, wbytes);
+    return SVT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ ME */
+int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int org_x, int org_y,
+                                 const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
+    (void)c;
+    orc_me_fullpel_frame(src, ref, stride, org_x, org_y, (const OrcSbSearch *)sbs, n_sb, sub_sad, best_sad, best_mv, 0, n_sb);
+    return SVT_HIP_OK;
+}
+int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,
+                             const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
+    (void)plane_rows;
+    for (int i = 0; i < n_sb; i++)
+        if ((int)sbs[i].width * sbs[i].height > 65536) return SVT_HIP_ERR_UNSUPPORTED;   /* the product's limit */
+    return svt_hip_me_fullpel_frame_dev(c, src, ref, stride, org_x, org_y, sbs, n_sb, sub_sad, best_sad, best_mv);
+}
+int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride,
+                               const SvtHipSadLoop *searches, int n, uint32_t *best_sad, int16_t *best_xy) {
+    (void)c;
+    orc_sad_loop_batch(src, src_stride, ref, ref_stride, searches, 0, n, best_sad, best_xy);
+    return SVT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ deblocking */
+int svt_hip_deblock_plane_dev(SvtHipCtx *c, void *plane, int pix_bytes, int stride, int bd, const uint16_t *ev, const uint16_t *eh,
+                              int units_w, int units_h, int sharpness) {
+    (void)c;
+    const size_t n = (size_t)units_w * units_h;
+    uint16_t    *zero = (uint16_t *)calloc(n ? n : 1, sizeof(uint16_t));
+    orc_deblock_plane(plane, pix_bytes, stride, bd, ev ? ev : zero, eh ? eh : zero, units_w, units_h, sharpness);
+    free(zero);
+    return SVT_HIP_OK;
+}
+int svt_hip_deblock_frame_dev(SvtHipCtx *c, void *const plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t *const ev[3],
+                              const uint16_t *const eh[3], const int units_w[3], const int units_h[3], int sharpness) {
+    for (int p = 0; p < 3; p++)
+        if (plane[p]) svt_hip_deblock_plane_dev(c, plane[p], pix_bytes, stride[p], bd, ev[p], eh[p], units_w[p], units_h[p], sharpness);
+    return SVT_HIP_OK;
+}
+int svt_hip_plane_sse_dev(SvtHipCtx *c, int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h, uint64_t *sse) {
+    (void)c;
+    *sse = orc_plane_sse(pix_bytes, a, a_stride, b, b_stride, w, h);
+    return SVT_HIP_OK;
+}
+typedef struct {
+    const void *recon, *src; void *tmp;
+    int pix_bytes, stride, bd, w, h, src_stride, uw, uh, sharpness;
+    const uint16_t *ev, *eh;
+} MockProbe;
+static int64_t mock_try_level(void *user, int lv_v, int lv_h) {   /* the device's level override: every edge at the probed level */
+    MockProbe   *m = (MockProbe *)user;
+    const size_t n = (size_t)m->uw * m->uh;
+    uint16_t    *v = (uint16_t *)malloc(n * 2), *h = (uint16_t *)malloc(n * 2);
+    for (size_t i = 0; i < n; i++) {
+        v[i] = (uint16_t)((m->ev[i] & 0xff) ? ((lv_v << 8) | (m->ev[i] & 0xff)) : 0);
+        h[i] = (uint16_t)((m->eh[i] & 0xff) ? ((lv_h << 8) | (m->eh[i] & 0xff)) : 0);
+    }
+    for (int y = 0; y < m->h; y++)
+        memcpy((uint8_t *)m->tmp + (size_t)y * m->stride * m->pix_bytes, (const uint8_t *)m->recon + (size_t)y * m->stride * m->pix_bytes, (size_t)m->w * m->pix_bytes);
+    orc_deblock_plane(m->tmp, m->pix_bytes, m->stride, m->bd, v, h, m->uw, m->uh, m->sharpness);
+    free(v); free(h);
+    return (int64_t)orc_plane_sse(m->pix_bytes, m->src, m->src_stride, m->tmp, m->stride, m->w, m->h);
+}
+int svt_hip_dlf_search_level_dev(SvtHipCtx *c, const SvtHipDlfSearch *p, const void *d_recon, void *d_tmp, int pix_bytes, int stride, int bd,
+                                 int plane_w, int plane_h, const void *d_src, int src_stride, const uint16_t *ev, const uint16_t *eh, int units_w,
+                                 int units_h, uint64_t *d_sse_scratch, int *best_level, int64_t *best_err) {
+    (void)c; (void)d_sse_scratch;
+    MockProbe m = {d_recon, d_src, d_tmp, pix_bytes, stride, bd, plane_w, plane_h, src_stride, units_w, units_h, p->sharpness, ev, eh};
+    return svt_hip_dlf_search_levels_host(p, mock_try_level, &m, best_level, best_err);
+}
+
+/* ------------------------------------------------------------------ CDEF */
+int svt_hip_cdef_search_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const rec[3], const int rec_stride[3], const void *const src[3],
+                                  const int src_stride[3], int w, int h, const uint8_t *skip8, int pri_damping, int bd, uint64_t *mse, uint8_t *dir,
+                                  int32_t *var) {
+    (void)c; (void)dir; (void)var;
+    const int nfb = ((w + 63) / 64) * ((h + 63) / 64);
+    orc_cdef_search_frame(rec, rec_stride, src, src_stride, pix_bytes, w, h, skip8, pri_damping, bd, 0, mse, 0, nfb);
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_apply_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const in[3], void *const out[3], const int stride[3], int w, int h,
+                                 const uint8_t *skip8, const uint8_t *ys, const uint8_t *uvs, int damping, int bd, uint8_t *dir, const int32_t *var) {
+    (void)c; (void)dir; (void)var;
+    orc_cdef_apply_frame(in, out, stride, pix_bytes, w, h, skip8, ys, uvs, damping, bd);
+    return SVT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ restoration */
+int svt_hip_generate_padding_dev(SvtHipCtx *c, void *plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
+    (void)c;
+    orc_generate_padding(plane, pix_bytes, stride, w, h, pad_w, pad_h);
+    return SVT_HIP_OK;
+}
+int svt_hip_lr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
+                               int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd,
+                               const int16_t *unit_wiener) {
+    (void)c;
+    if (!dbl) { snprintf(c->err, sizeof(c->err), "mock: lr_apply needs the deblocked plane"); return SVT_HIP_ERR_UNSUPPORTED; }
+    /* the oracle swaps the stripe context rows into the CDEF plane and back (like the reference): work on a copy of the extended plane */
+    const size_t rows = (size_t)ph + 6, bytes = rows * stride * pix_bytes;
+    uint8_t     *copy = (uint8_t *)malloc(bytes);
+    const uint8_t *base = (const uint8_t *)dgd - ((size_t)3 * stride + 3) * pix_bytes;
+    memcpy(copy, base, bytes);   /* the glue's planes are allocated as stride x (ph + 6) with sample (0,0) at (3,3) */
+    orc_lr_apply_plane(dbl, dbl_stride, copy + ((size_t)3 * stride + 3) * pix_bytes, stride, pix_bytes, pw, ph, ss_y, ss_y, unit_size, bd, unit_ep, unit_xqd,
+                       unit_wiener, dst, dst_stride);
+    free(copy);
+    return SVT_HIP_OK;
+}
+int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
+                                int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd) {
+    return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, NULL);
+}
+int svt_hip_sgr_search_units_plane(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, const void *src, int src_stride, int pw, int ph,
+                                   int unit_size, int ss_y, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out, uint8_t *best_ep, int *rounds) {
+    (void)c;
+    orc_sgr_search_units_plane(dgd, pix_bytes, stride, src, src_stride, pw, ph, ss_y, ss_y, unit_size, bd, ep_mask, xqd_out, err_out, best_ep);
+    if (rounds) *rounds = 0;
+    return SVT_HIP_OK;
+}
+int svt_hip_sgr_search_units_picture(SvtHipCtx *c, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane *pl, int *rounds) {
+    for (int i = 0; i < n_planes; i++)
+        svt_hip_sgr_search_units_plane(c, pix_bytes, bd, pl[i].d_dgd, pl[i].stride, pl[i].d_src, pl[i].src_stride, pl[i].pw, pl[i].ph, pl[i].unit_size,
+                                       pl[i].ss_y, pl[i].ep_mask, pl[i].xqd_out, pl[i].err_out, pl[i].best_ep, rounds);
+    return SVT_HIP_OK;
+}
+int svt_hip_block_sse_batch_dev(SvtHipCtx *c, int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, const SvtHipBlkPair *pairs,
+                                int n, uint64_t *sse) {
+    (void)c;
+    for (int i = 0; i < n; i++)
+        sse[i] = orc_plane_sse(pix_bytes, (const uint8_t *)a + ((size_t)pairs[i].a_y * a_stride + pairs[i].a_x) * pix_bytes, a_stride,
+                               (const uint8_t *)b + ((size_t)pairs[i].b_y * b_stride + pairs[i].b_x) * pix_bytes, b_stride, pairs[i].w, pairs[i].h);
+    return SVT_HIP_OK;
+}
+int svt_hip_wiener_stats_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, int win, const void *dgd, int stride, const void *src, int src_stride, int pw,
+                                   int ph, int unit_size, int ss_y, int64_t *M, int64_t *H) {
+    (void)c;
+    orc_wiener_stats_plane(win, dgd, stride, src, src_stride, pix_bytes, bd, pw, ph, ss_y, unit_size, M, H);
+    return SVT_HIP_OK;
+}

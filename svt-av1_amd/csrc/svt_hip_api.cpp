@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "svt_hip_internal.h"
+#include "svt_hip_host.h"
 
 struct SvtHipCtx {
     int         device = 0;
@@ -111,6 +112,22 @@ int svt_hip_memcpy_d2d(SvtHipCtx* c, void* dst, const void* src, size_t bytes) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     return SVT_HIP_OK;
 }
+int svt_hip_memcpy2d_h2d(SvtHipCtx* c, void* d, size_t dpitch, const void* h, size_t hpitch, size_t wbytes, size_t rows) {
+    if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
+    if (!wbytes || !rows) return SVT_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(d, dpitch, h, hpitch, wbytes, rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy2d_d2h(SvtHipCtx* c, void* h, size_t hpitch, const void* d, size_t dpitch, size_t wbytes, size_t rows) {
+    if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
+    if (!wbytes || !rows) return SVT_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(h, hpitch, d, dpitch, wbytes, rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
 int svt_hip_timer_start(SvtHipCtx* c) {
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -125,28 +142,6 @@ int svt_hip_timer_stop_ms(SvtHipCtx* c, float* ms) {
 }
 
 /* ------------------------------------------------------------------------------------------- ME */
-// Host-side restatement of the search-window clamp (EbMotionEstimation.c:1945-2066, unrestricted-MV
-// branch; int16 arithmetic with int intermediates, statements in the reference's order).
-SvtHipSbSearch svt_hip_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center, int sa_width,
-                                        int sa_height, int pic_width, int pic_height) {
-    const int16_t pad = 63;
-    const int16_t ox = (int16_t)sb_origin_x, oy = (int16_t)sb_origin_y, pw = (int16_t)pic_width, ph = (int16_t)pic_height;
-    int16_t w = (int16_t)sa_width, h = (int16_t)sa_height;
-    int16_t xo = (int16_t)(x_center - (w >> 1)), yo = (int16_t)(y_center - (h >> 1));
-    xo = (int16_t)((ox + xo < -pad) ? -pad - ox : xo);
-    w  = (int16_t)((ox + xo < -pad) ? w - (-pad - (ox + xo)) : w);
-    xo = (int16_t)((ox + xo > pw - 1) ? xo - ((ox + xo) - (pw - 1)) : xo);
-    if (ox + xo + w > pw) { const int v = w - ((ox + xo + w) - pw); w = (int16_t)(v > 1 ? v : 1); }
-    w  = (int16_t)((w < 8) ? w : (w & ~0x07));
-    yo = (int16_t)((oy + yo < -pad) ? -pad - oy : yo);
-    h  = (int16_t)((oy + yo < -pad) ? h - (-pad - (oy + yo)) : h);
-    yo = (int16_t)((oy + yo > ph - 1) ? yo - ((oy + yo) - (ph - 1)) : yo);
-    if (oy + yo + h > ph) { const int v = h - ((oy + yo + h) - ph); h = (int16_t)(v > 1 ? v : 1); }
-    SvtHipSbSearch s;
-    s.sb_x = sb_origin_x; s.sb_y = sb_origin_y; s.x_origin = xo; s.y_origin = yo; s.width = w; s.height = h;
-    return s;
-}
-
 int svt_hip_me_set_waves_per_sb(SvtHipCtx* c, int waves) {
     const int w = waves & 15;   // bits 4.. = KiB of LDS padding (experimental single-workgroup-per-CU mode, see me_fullpel.hip)
     if (!c || (w != 1 && w != 2 && w != 4) || (waves >> 4) > 120) return SVT_HIP_ERR_BAD_ARG;
@@ -232,46 +227,6 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int
 }
 
 /* ------------------------------------------------------------------------------- deblocking */
-// Restatement of set_lpf_parameters (Encoder/Codec/EbDeblockingFilter.c:168-319) over a plain grid.
-int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
-                            int plane_h, uint16_t* edges_v, uint16_t* edges_h) {
-    if (!mi || mi_cols <= 0 || mi_rows <= 0 || plane < 0 || plane > 2 || !edges_v || !edges_h) return SVT_HIP_ERR_BAD_ARG;
-    const int uw = (plane_w + 3) >> 2, uh = (plane_h + 3) >> 2;
-    for (int dir = 0; dir < 2; dir++) {
-        uint16_t* out = dir == 0 ? edges_v : edges_h;
-        for (int uy = 0; uy < uh; uy++)
-            for (int ux = 0; ux < uw; ux++) {
-                uint16_t v = 0;
-                const int x = 4 * ux, y = 4 * uy;
-                // chroma maps to the bottom/right mi of the co-located 8x8 (:196-197)
-                int mr = ss_y | ((y << ss_y) >> 2), mc = ss_x | ((x << ss_x) >> 2);
-                if (mr >= mi_rows) mr = mi_rows - 1;
-                if (mc >= mi_cols) mc = mi_cols - 1;
-                const SvtHipDlfModeInfo& cur = mi[mr * mi_cols + mc];
-                const int ts = plane == 0 ? (dir == 0 ? cur.tx_w_log2 : cur.tx_h_log2) : (dir == 0 ? cur.uv_tx_w_log2 : cur.uv_tx_h_log2);
-                const int coord = dir == 0 ? x : y;
-                if (!(coord & ((1 << ts) - 1)) && coord) {
-                    const int pr = dir == 0 ? mr : mr - (1 << ss_y), pc = dir == 0 ? mc - (1 << ss_x) : mc;
-                    if (pr >= 0 && pc >= 0) {
-                        const SvtHipDlfModeInfo& prv = mi[pr * mi_cols + pc];
-                        const int pts = plane == 0 ? (dir == 0 ? prv.tx_w_log2 : prv.tx_h_log2) : (dir == 0 ? prv.uv_tx_w_log2 : prv.uv_tx_h_log2);
-                        const int cl = cur.level[plane][dir], pl = prv.level[plane][dir];
-                        int bdim = dir == 0 ? cur.bw_log2 - (plane ? ss_x : 0) : cur.bh_log2 - (plane ? ss_y : 0);
-                        if (bdim < 2) bdim = 2;
-                        const bool pu_edge = !(coord & ((1 << bdim) - 1));
-                        if ((cl || pl) && (!prv.skip_inter || !cur.skip_inter || pu_edge)) {
-                            const int mts = ts < pts ? ts : pts;
-                            const int len = mts <= 2 ? 4 : (mts == 3 ? (plane ? 6 : 8) : (plane ? 6 : 14));
-                            v = (uint16_t)(((cl ? cl : pl) << 8) | len);
-                        }
-                    }
-                }
-                out[uy * uw + ux] = v;
-            }
-    }
-    return SVT_HIP_OK;
-}
-
 int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int bd, const uint16_t* d_edges_v,
                               const uint16_t* d_edges_h, int units_w, int units_h, int sharpness) {
     if (!c || !d_plane || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || units_w < 0 ||
@@ -322,14 +277,8 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
         if (c) c->err = "svt_hip_dlf_search_level_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
     }
-    const int kMaxLoopFilter = 63;   // MAX_LOOP_FILTER
-    int64_t ss_err[kMaxLoopFilter + 1];
-    for (int i = 0; i <= kMaxLoopFilter; i++) ss_err[i] = -1;
     int rc = SVT_HIP_OK;
-    auto try_level = [&](int lvl) -> int64_t {   // try_filter_frame
-        int lv_v = lvl, lv_h = lvl;
-        if (p->plane == 0 && p->dir == 0) lv_h = p->other_level;
-        if (p->plane == 0 && p->dir == 1) lv_v = p->other_level;
+    auto try_level = [&](int lv_v, int lv_h) -> int64_t {   // try_filter_frame (:966-1024) on the device
         uint64_t sse = 0;
         hipError_t e = hipMemcpy2DAsync(d_tmp, (size_t)stride * pix_bytes, d_recon, (size_t)stride * pix_bytes, (size_t)plane_w * pix_bytes,
                                         plane_h, hipMemcpyDeviceToDevice, c->stream);
@@ -338,49 +287,13 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
         if (e == hipSuccess) e = (hipError_t)svt_hip_launch_plane_sse(c->stream, pix_bytes, d_src, src_stride, d_tmp, stride, plane_w, plane_h, d_sse_scratch);
         if (e == hipSuccess) e = hipMemcpyAsync(&sse, d_sse_scratch, sizeof(sse), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { rc = fail(c, e, "dlf level probe"); return 0; }
+        if (e != hipSuccess) { rc = fail(c, e, "dlf level probe"); return -1; }
         return (int64_t)sse;
     };
-    int filt_direction = 0;
-    int filt_mid = p->start_level < 0 ? 0 : (p->start_level > kMaxLoopFilter ? kMaxLoopFilter : p->start_level);
-    int filter_step = filt_mid < 16 ? 4 : filt_mid / 4;
-    int64_t best_err = try_level(filt_mid);
-    int filt_best = filt_mid;
-    ss_err[filt_mid] = best_err;
-    const bool single = p->loop_filter_mode <= 2;
-    if (single) filter_step = 2;
-    while (rc == SVT_HIP_OK && filter_step > 0) {
-        const int filt_high = filt_mid + filter_step > kMaxLoopFilter ? kMaxLoopFilter : filt_mid + filter_step;
-        const int filt_low = filt_mid - filter_step < 0 ? 0 : filt_mid - filter_step;
-        int64_t bias = (best_err >> (15 - (filt_mid / 8))) * filter_step;   // bias against raising the level
-        if (!p->tx_mode_only_4x4) bias >>= 1;
-        if (filt_direction <= 0 && filt_low != filt_mid) {
-            if (ss_err[filt_low] < 0) ss_err[filt_low] = try_level(filt_low);
-            if (ss_err[filt_low] < best_err + bias) {
-                if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
-                filt_best = filt_low;
-            }
-        }
-        if (filt_direction >= 0 && filt_high != filt_mid) {
-            if (ss_err[filt_high] < 0) ss_err[filt_high] = try_level(filt_high);
-            if (ss_err[filt_high] < best_err - bias) {
-                if (!single) best_err = ss_err[filt_high];   // the mode <= 2 branch does not update best_err (:1121-1122)
-                filt_best = filt_high;
-            }
-        }
-        if (single) break;
-        if (filt_best == filt_mid) {
-            filter_step /= 2;
-            filt_direction = 0;
-        } else {
-            filt_direction = filt_best < filt_mid ? -1 : 1;
-            filt_mid = filt_best;
-        }
-    }
-    if (rc != SVT_HIP_OK) return rc;
-    *best_level = filt_best;
-    if (best_err_out) *best_err_out = ss_err[filt_best];
-    return SVT_HIP_OK;
+    struct Thunk { decltype(try_level)* f; } th{&try_level};
+    const int hrc = svt_hip_dlf_search_levels_host(p, [](void* u, int lv_v, int lv_h) -> int64_t { return (*((Thunk*)u)->f)(lv_v, lv_h); }, &th,
+                                                   best_level, best_err_out);
+    return rc != SVT_HIP_OK ? rc : hrc;
 }
 
 int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs) {
@@ -886,11 +799,6 @@ int svt_hip_tf_estimate_noise_dev(SvtHipCtx* c, const void* d_src, int pix_bytes
     e = (hipError_t)svt_hip_launch_tf_noise(c->stream, d_src, pix_bytes, bd, width, height, stride, (uint64_t*)d_out);
     if (e != hipSuccess) return fail(c, e, "tf noise launch");
     return SVT_HIP_OK;
-}
-
-double svt_hip_tf_noise_sigma(int64_t sum, int64_t num) {   // EbTemporalFiltering.c:2442-2447
-    if (num < 16) return -1.0;
-    return (double)sum / (6 * num) * 1.25331413732;
 }
 
 int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref0, int ref0_stride, const void* d_ref1, int ref1_stride,
