@@ -92,6 +92,46 @@ mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',
         r'\1                } /* hip_pass */\n                svt_hip_me_batch_end(hip_me);\n')
 PATCHES.append(mep)
 
+# ---------------------------------------------------------------------------------------------------------------- deblocking (dlf_kernel)
+dlf = Patch("Source/Lib/Encoder/Codec/EbDlfProcess.c")
+dlf.sub(r'(\n[ \t]*)(svt_av1_pick_filter_level\(\s*context_ptr,\s*\(EbPictureBufferDesc \*\)pcs_ptr->parent_pcs_ptr->enhanced_picture_ptr,\s*pcs_ptr,\s*'
+        r'LPF_PICK_FROM_FULL_IMAGE\);)',
+        r'\1if (svt_hip_hook_dlf_pick_level(pcs_ptr) != EB_ErrorNone) /* not handled: the reference search */\1    \2')
+dlf.sub(r'(\n[ \t]*)(svt_av1_loop_filter_frame\(recon_buffer, pcs_ptr, 0, 3\);)',
+        r'\1if (svt_hip_hook_dlf_frame(recon_buffer, pcs_ptr) != EB_ErrorNone)\1    \2')
+dlf.sub(r'(\n[ \t]*)(//pre-cdef prep\n)', r'\1svt_hip_hook_after_dlf(pcs_ptr); /* the deblocked picture is final: keep it on the device for the CDEF / restoration hooks */\1\2')
+PATCHES.append(dlf)
+
+# ---------------------------------------------------------------------------------------------------------------- CDEF (cdef_kernel)
+cdef = Patch("Source/Lib/Encoder/Codec/EbCdefProcess.c")
+cdef.sub(r'(\n[ \t]*)(if \(scs_ptr->static_config\.is_16bit_pipeline \|\| is_16bit\)\s*cdef_seg_search16bit\(pcs_ptr, scs_ptr, dlf_results_ptr->segment_index\);)',
+         r'\1if (svt_hip_hook_cdef_search(pcs_ptr) == EB_ErrorNone) {'
+         r'\1    /* the first segment to arrive searched the whole picture on the device: pcs_ptr->mse_seg is filled */'
+         r'\1} else \2')
+cdef.sub(r'(\n[ \t]*)(if \(scs_ptr->static_config\.is_16bit_pipeline \|\| is_16bit\)\s*av1_cdef_frame16bit\(0, scs_ptr, pcs_ptr\);)',
+         r'\1if (svt_hip_hook_cdef_apply(pcs_ptr) == EB_ErrorNone) {'
+         r'\1} else \2')
+PATCHES.append(cdef)
+
+# ---------------------------------------------------------------------------------------------------------------- restoration (rest_kernel)
+rest = Patch("Source/Lib/Encoder/Codec/EbRestProcess.c")
+rest.sub(r'(\n[ \t]*)(svt_av1_loop_restoration_filter_frame\(cm->frame_to_show, cm, 0\);)',
+         r'\1if (svt_hip_hook_rest_apply(pcs_ptr) != EB_ErrorNone)\1    \2')
+rest.sub(r'(\n[ \t]*)(cm->sg_frame_ep = best_ep;\n)', r'\1\2\1svt_hip_hook_picture_done(pcs_ptr); /* the picture leaves the filter stages */\n')
+PATCHES.append(rest)
+
+pick = Patch("Source/Lib/Encoder/Codec/EbRestorationPick.c")
+pick.sub(r'(\n[ \t]*SgrprojInfo sgrproj;\s*WienerInfo  wiener;\n)(\} RestSearchCtxt;)', r'\1    PictureControlSet *hip_pcs; /* for the picture-level hooks */\n\2')
+pick.sub(r'(\n[ \t]*)(rsc_p->tmpbuf = rst_tmpbuf;\n)', r'\1\2\1rsc_p->hip_pcs = pcs_ptr;\n')
+# restoration_seg_search (:1537): every search_sgrproj_seg of the picture is one picture-level search on the device
+pick.sub(r'(\n[ \t]*)(av1_foreach_rest_unit_in_frame_seg\(rsc_p->cm,\s*rsc_p->plane,\s*rsc_on_tile,\s*search_sgrproj_seg,)',
+         r'\1if (svt_hip_hook_sgr_search(pcs_ptr) != EB_ErrorNone) /* not handled: per-unit C search of this segment */\1    \2')
+# search_wiener_seg (:1359): M / H of the unit from the picture-level statistics pass
+pick.sub(r'(\n[ \t]*)(if \(cm->use_highbitdepth\)\s*svt_av1_compute_stats_highbd\(wiener_win,\s*rsc->dgd_buffer,)',
+         r'\1if (svt_hip_hook_wiener_stats(rsc->hip_pcs, rsc->plane, wiener_win, rest_unit_idx, M, H) == EB_ErrorNone) {'
+         r'\1} else \2')
+PATCHES.append(pick)
+
 TAILS = {"Source/Lib/Encoder/Codec/EbMotionEstimation.c": ME_TAIL}
 
 

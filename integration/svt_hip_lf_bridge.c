@@ -1,6 +1,8 @@
-/* svt_hip_lf_bridge.c — see svt_hip_lf_bridge.h.  Reference-side glue: host code only, every pixel operation is a batched svt_hip_* call. */
+/* svt_hip_lf_bridge.c — see svt_hip_lf_bridge.h / svt_hip_hooks.h.  Reference-side glue: host code only, every pixel operation is a batched
+ * svt_hip_* call. */
 #include <stdlib.h>
 #include <string.h>
+#include "svt_hip_hooks.h"
 #include "svt_hip_lf_bridge.h"
 #include "EbDeblockingCommon.h"
 #include "EbDeblockingFilter.h"
@@ -8,6 +10,9 @@
 #include "EbCdef.h"
 #include "EbReferenceObject.h"
 #include "EbUtility.h"
+#include "EbLog.h"
+
+int8_t get_sg_step(int8_t sg_filter_mode);   /* Encoder/Codec/EbRestorationPick.c:690 (no header declares it) */
 
 #define HIP_TRY(call) do { if ((call) != SVT_HIP_OK) return EB_ErrorUndefined; } while (0)   /* caller falls back to the C loop */
 #define LF_BORDER 3                                                                           /* RESTORATION_BORDER */
@@ -16,12 +21,19 @@ static int log2i(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 static size_t plane_bytes(const SvtHipLfPicture *p, int pl) { return (size_t)p->stride[pl] * (size_t)((p->h >> (pl > 0)) + 2 * LF_BORDER) * (size_t)p->pix_bytes; }
 static void *plane_origin(const SvtHipLfPicture *p, void *base, int pl) { return (uint8_t *)base + ((size_t)LF_BORDER * p->stride[pl] + LF_BORDER) * (size_t)p->pix_bytes; }
 
-static EbPictureBufferDesc *recon_of(PictureControlSet *pcs, int is_16bit) {
+static int is_16bit_of(const PictureControlSet *pcs) {
+    const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    return scs->static_config.encoder_bit_depth > EB_8BIT || scs->static_config.is_16bit_pipeline;
+}
+static EbPictureBufferDesc *recon_of(PictureControlSet *pcs, int is_16bit) {   /* the selection every filter stage repeats (e.g. EbDlfProcess.c:178-191) */
     if (pcs->parent_pcs_ptr->is_used_as_reference_flag == EB_TRUE) {
         EbReferenceObject *ro = (EbReferenceObject *)pcs->parent_pcs_ptr->reference_picture_wrapper_ptr->object_ptr;
         return is_16bit ? ro->reference_picture16bit : ro->reference_picture;
     }
     return is_16bit ? pcs->recon_picture16bit_ptr : pcs->recon_picture_ptr;
+}
+static EbPictureBufferDesc *source_of(PictureControlSet *pcs, int is_16bit) {   /* picture_sse_calculations :843 / :905, cdef_seg_search :136 */
+    return is_16bit ? pcs->input_frame16bit : (EbPictureBufferDesc *)pcs->parent_pcs_ptr->enhanced_picture_ptr;
 }
 
 EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, int h, int is_16bit, int bd) {
@@ -40,16 +52,18 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
             HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_edges[pl][d], sizeof(uint16_t) * p->units_w[pl] * p->units_h[pl]));
             if (!p->h_edges[pl][d]) return EB_ErrorInsufficientResources;
         }
-        const int max_units = ((pw + 31) / 32) * ((ph + 31) / 32);     /* smallest restoration unit is 64 -> count_units_in_tile rounds to nearest */
-        HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_ep[pl], max_units)); HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_xqd[pl], max_units * 8));
-        HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_wiener[pl], max_units * 32));
+        p->max_units[pl] = ((pw + 31) / 32) * ((ph + 31) / 32);     /* smallest restoration unit is 64 -> count_units_in_tile rounds to nearest */
+        HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_ep[pl], p->max_units[pl])); HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_xqd[pl], p->max_units[pl] * 8));
+        HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_unit_wiener[pl], p->max_units[pl] * 32));
     }
     p->h_skip8 = (uint8_t *)malloc((size_t)(w / 8) * (h / 8)); p->h_mi = (SvtHipDlfModeInfo *)calloc((size_t)mi_cols * mi_rows, sizeof(SvtHipDlfModeInfo));
-    if (!p->h_skip8 || !p->h_mi) return EB_ErrorInsufficientResources;
+    p->h_mse = (uint64_t *)malloc(sizeof(uint64_t) * 2 * nfb * 64);
+    if (!p->h_skip8 || !p->h_mi || !p->h_mse) return EB_ErrorInsufficientResources;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_skip8, (size_t)(w / 8) * (h / 8)));
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_mse, sizeof(uint64_t) * 2 * nfb * 64));
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_dir, (size_t)nfb * 64)); HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_var, sizeof(int32_t) * nfb * 64));
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_y_strength, nfb)); HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_uv_strength, nfb));
+    HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_sse, 64));
     return EB_ErrorNone;
 }
 
@@ -58,49 +72,93 @@ void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
         svt_hip_free(hip, p->d_recon[pl]); svt_hip_free(hip, p->d_cdef[pl]); svt_hip_free(hip, p->d_rest[pl]); svt_hip_free(hip, p->d_src[pl]);
         for (int d = 0; d < 2; d++) { free(p->h_edges[pl][d]); svt_hip_free(hip, p->d_edges[pl][d]); }
         svt_hip_free(hip, p->d_unit_ep[pl]); svt_hip_free(hip, p->d_unit_xqd[pl]); svt_hip_free(hip, p->d_unit_wiener[pl]);
+        free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
     }
-    free(p->h_skip8); free(p->h_mi);
+    free(p->h_skip8); free(p->h_mi); free(p->h_mse);
     svt_hip_free(hip, p->d_skip8); svt_hip_free(hip, p->d_mse); svt_hip_free(hip, p->d_dir); svt_hip_free(hip, p->d_var);
-    svt_hip_free(hip, p->d_y_strength); svt_hip_free(hip, p->d_uv_strength);
+    svt_hip_free(hip, p->d_y_strength); svt_hip_free(hip, p->d_uv_strength); svt_hip_free(hip, p->d_sse);
     memset(p, 0, sizeof(*p));
 }
 
+/* ---------------------------------------------------------------- per-picture state ----------------------------------------------------
+ * Pictures pass dlf_kernel -> cdef_kernel -> rest_kernel in order, several pictures can be in different stages at once.  The table is
+ * only touched with the hooks lock held.  Entries are pooled: a finished picture's device buffers serve the next one of the same size. */
+enum { ST_SRC = 1, ST_DBL = 2, ST_CDEF = 4, ST_DIRVAR = 8, ST_CDEF_SEARCHED = 16, ST_CDEF_FAILED = 32, ST_SGR_DONE = 64, ST_SGR_FAILED = 128,
+       ST_WIENER_DONE = 256, ST_WIENER_FAILED = 512, ST_PADDED = 1024 };
+typedef struct {
+    PictureControlSet *pcs;     /* NULL: free */
+    int                allocated, flags;
+    SvtHipLfPicture    pic;
+} LfState;
+#define LF_MAX_IN_FLIGHT 64
+static LfState g_state[LF_MAX_IN_FLIGHT];
+
+static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
+    for (int i = 0; i < LF_MAX_IN_FLIGHT; i++)
+        if (g_state[i].pcs == pcs) return &g_state[i];
+    if (!create) return NULL;
+    const int is_16bit = is_16bit_of(pcs);
+    const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    const EbPictureBufferDesc *rec = recon_of(pcs, is_16bit);
+    const int w = rec->width, h = rec->height, bd = scs->static_config.encoder_bit_depth;
+    if ((w & 7) || (h & 7) || (bd != 8 && bd != 10) || scs->subsampling_x != 1 || scs->subsampling_y != 1 || scs->seq_header.sb_size != BLOCK_64X64 ||
+        scs->seq_header.color_config.mono_chrome)
+        return NULL;   /* outside what the device path covers: the caller keeps its C loop */
+    LfState *s = NULL;
+    for (int i = 0; i < LF_MAX_IN_FLIGHT && !s; i++)
+        if (!g_state[i].pcs && g_state[i].allocated && g_state[i].pic.w == w && g_state[i].pic.h == h && g_state[i].pic.pix_bytes == (is_16bit ? 2 : 1) && g_state[i].pic.bd == bd)
+            s = &g_state[i];
+    for (int i = 0; i < LF_MAX_IN_FLIGHT && !s; i++)
+        if (!g_state[i].pcs && !g_state[i].allocated) s = &g_state[i];
+    if (!s) return NULL;
+    if (!s->allocated) {
+        if (svt_hip_lf_picture_ctor(hip, &s->pic, w, h, is_16bit, bd) != EB_ErrorNone) { svt_hip_lf_picture_dctor(hip, &s->pic); return NULL; }
+        s->allocated = 1;
+    }
+    s->pcs = pcs; s->flags = 0;
+    return s;
+}
+
+/* ---------------------------------------------------------------- host <-> device planes ------------------------------------------------ */
 static uint8_t *pic_plane(const EbPictureBufferDesc *pic, int pl, int pix_bytes, int *stride) {
     const int ss = pl > 0;
     uint8_t *base = pl == 0 ? pic->buffer_y : (pl == 1 ? pic->buffer_cb : pic->buffer_cr);
     *stride = pl == 0 ? pic->stride_y : (pl == 1 ? pic->stride_cb : pic->stride_cr);
     return base + ((size_t)(pic->origin_y >> ss) * *stride + (pic->origin_x >> ss)) * (size_t)pix_bytes;
 }
-
-EbErrorType svt_hip_lf_upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBufferDesc *pic, void *const d_dst[3]) {
+static EbErrorType upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBufferDesc *pic, void *const d_dst[3], int is_src) {
     for (int pl = 0; pl < 3; pl++) {
         int st;
         const uint8_t *s = pic_plane(pic, pl, p->pix_bytes, &st);
         const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
-        const int is_src = d_dst[pl] == p->d_src[pl];
         const int dstride = is_src ? p->src_stride[pl] : p->stride[pl];
         uint8_t *d = is_src ? (uint8_t *)d_dst[pl] : (uint8_t *)plane_origin(p, d_dst[pl], pl);
-        for (int y = 0; y < ph; y++)   /* row copies; a production patch pins the picture buffers and issues one 2-D copy */
-            HIP_TRY(svt_hip_memcpy_h2d(hip, d + (size_t)y * dstride * p->pix_bytes, s + (size_t)y * st * p->pix_bytes, (size_t)pw * p->pix_bytes));
+        HIP_TRY(svt_hip_memcpy2d_h2d(hip, d, (size_t)dstride * p->pix_bytes, s, (size_t)st * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
     }
     return EB_ErrorNone;
 }
-
-EbErrorType svt_hip_lf_download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *const d_src[3], EbPictureBufferDesc *pic) {
+static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *const d_src[3], EbPictureBufferDesc *pic, int plane_mask) {
     for (int pl = 0; pl < 3; pl++) {
+        if (!(plane_mask & (1 << pl))) continue;
         int st;
         uint8_t *d = pic_plane(pic, pl, p->pix_bytes, &st);
         const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
         const uint8_t *s = (const uint8_t *)plane_origin(p, d_src[pl], pl);
-        for (int y = 0; y < ph; y++)
-            HIP_TRY(svt_hip_memcpy_d2h(hip, d + (size_t)y * st * p->pix_bytes, s + (size_t)y * p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes));
+        HIP_TRY(svt_hip_memcpy2d_d2h(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
     }
+    return EB_ErrorNone;
+}
+static EbErrorType ensure_src(SvtHipCtx *hip, LfState *s) {
+    if (s->flags & ST_SRC) return EB_ErrorNone;
+    if (upload(hip, &s->pic, source_of(s->pcs, s->pic.pix_bytes == 2), s->pic.d_src, 1) != EB_ErrorNone) return EB_ErrorUndefined;
+    s->flags |= ST_SRC;
     return EB_ErrorNone;
 }
 
 /* ---------------------------------------------------------------- deblocking ---------------------------------------------------------
- * SvtHipDlfModeInfo per 4x4 unit from the mode-info grid = what set_lpf_parameters / get_transform_size read (EbDeblockingFilter.c:134-319) */
-static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs) {
+ * SvtHipDlfModeInfo per 4x4 unit from the mode-info grid = what set_lpf_parameters / get_transform_size read (EbDeblockingFilter.c:134-319).
+ * uniform_level > 0: the filter-level search only needs the edge geometry (the probed level replaces every non-zero level). */
+static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int uniform_level) {
     PictureParentControlSet *ppcs = pcs->parent_pcs_ptr;
     FrameHeader *frm_hdr = &ppcs->frm_hdr;
     const LoopFilterInfoN *lfi_n = &ppcs->lf_info;
@@ -121,30 +179,115 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs) {
             const PredictionMode mode = mbmi->block_mi.mode == INTRA_MODE_4x4 ? DC_PRED : mbmi->block_mi.mode;
             for (int pl = 0; pl < 3; pl++)
                 for (int dir = 0; dir < 2; dir++)
-                    o->level[pl][dir] = frm_hdr->delta_lf_params.delta_lf_present
+                    o->level[pl][dir] = uniform_level ? (uint8_t)uniform_level
+                        : frm_hdr->delta_lf_params.delta_lf_present
                         ? get_filter_level_delta_lf(frm_hdr, dir, pl, ppcs->curr_delta_lf, 0, mode, mbmi->block_mi.ref_frame[0])
                         : lfi_n->lvl[pl][0][dir][mbmi->block_mi.ref_frame[0]][mode_lf_lut[mode]];
         }
 }
-
-EbErrorType svt_hip_dlf_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
-    FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
-    svt_av1_loop_filter_frame_init(frm_hdr, &pcs->parent_pcs_ptr->lf_info, 0, 3);       /* svt_av1_loop_filter_frame does this first (:722) */
-    fill_mode_info(p, pcs);
-    const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4;
-    for (int pl = 0; pl < 3; pl++) {
-        /* plane skipped when its frame level is 0, like loop_filter_sb's checks (:640-655) */
-        if (pl == 0 && !frm_hdr->loop_filter_params.filter_level[0] && !frm_hdr->loop_filter_params.filter_level[1]) continue;
-        if (pl == 1 && !frm_hdr->loop_filter_params.filter_level_u) continue;
-        if (pl == 2 && !frm_hdr->loop_filter_params.filter_level_v) continue;
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
-        HIP_TRY(svt_hip_dlf_build_edges(p->h_mi, mi_cols, mi_rows, pl, pl > 0, pl > 0, pw, ph, p->h_edges[pl][0], p->h_edges[pl][1]));
-        const size_t eb = sizeof(uint16_t) * p->units_w[pl] * p->units_h[pl];
-        HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][0], p->h_edges[pl][0], eb)); HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][1], p->h_edges[pl][1], eb));
-        HIP_TRY(svt_hip_deblock_plane_dev(hip, plane_origin(p, p->d_recon[pl], pl), p->pix_bytes, p->stride[pl], p->bd, p->d_edges[pl][0], p->d_edges[pl][1],
-                                          p->units_w[pl], p->units_h[pl], frm_hdr->loop_filter_params.sharpness_level));
-    }
+static EbErrorType build_and_upload_edges(SvtHipCtx *hip, SvtHipLfPicture *p, int pl) {
+    const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4, pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
+    HIP_TRY(svt_hip_dlf_build_edges(p->h_mi, mi_cols, mi_rows, pl, pl > 0, pl > 0, pw, ph, p->h_edges[pl][0], p->h_edges[pl][1]));
+    const size_t eb = sizeof(uint16_t) * p->units_w[pl] * p->units_h[pl];
+    HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][0], p->h_edges[pl][0], eb)); HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][1], p->h_edges[pl][1], eb));
     return EB_ErrorNone;
+}
+
+/* svt_av1_pick_filter_level(.., LPF_PICK_FROM_FULL_IMAGE) (EbDeblockingFilter.c:1193, the else branch :1262-1310): three searches
+ * (luma with dir = 2, i.e. both directions at the probed level and — as the reference indexes last_frame_filter_level[dir] — started from
+ * the previous U level; then U; then V), every probe on the device. */
+static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
+    FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
+    struct LoopFilter *lf = &frm_hdr->loop_filter_params;
+    if (ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (upload(hip, p, recon_of(pcs, p->pix_bytes == 2), p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    fill_mode_info(p, pcs, 1);
+    int best[3];
+    const int last[4] = {lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v};
+    for (int pl = 0; pl < 3; pl++) {
+        if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
+        SvtHipDlfSearch q;
+        memset(&q, 0, sizeof(q));
+        q.plane = pl; q.dir = 2; q.other_level = 0;
+        q.start_level = pl == 0 ? last[2] : last[pl + 1];           /* search_filter_level :1044-1049 with dir = 2 / 0 / 0 */
+        q.loop_filter_mode = pcs->parent_pcs_ptr->loop_filter_mode;
+        q.tx_mode_only_4x4 = frm_hdr->tx_mode == ONLY_4X4;
+        q.sharpness = 0;                                            /* lf->sharpness_level = 0 (:1202) */
+        int64_t err;
+        HIP_TRY(svt_hip_dlf_search_level_dev(hip, &q, plane_origin(p, p->d_recon[pl], pl), plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->bd,
+                                             p->w >> (pl > 0), p->h >> (pl > 0), p->d_src[pl], p->src_stride[pl], p->d_edges[pl][0], p->d_edges[pl][1],
+                                             p->units_w[pl], p->units_h[pl], p->d_sse, &best[pl], &err));
+        svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, q.start_level, best[pl], (long long)err);
+    }
+    lf->sharpness_level = 0;
+    lf->filter_level[0] = lf->filter_level[1] = best[0];
+    lf->filter_level_u = best[1];
+    lf->filter_level_v = best[2];
+    return EB_ErrorNone;
+}
+
+EbErrorType svt_hip_hook_dlf_pick_level(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_DLF_SEARCH)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 1);
+    EbErrorType rc = s ? dlf_pick_level(hip, s) : EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_DLF_SEARCH, rc == EB_ErrorNone);
+    return rc;
+}
+
+/* svt_av1_loop_filter_frame(recon, pcs, 0, 3) (EbDeblockingFilter.c:711) */
+static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *recon) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
+    FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
+    const struct LoopFilter *lf = &frm_hdr->loop_filter_params;
+    svt_av1_loop_filter_frame_init(frm_hdr, &pcs->parent_pcs_ptr->lf_info, 0, 3);       /* svt_av1_loop_filter_frame does this first (:722) */
+    /* loop_filter_sb (:636-646): both luma levels 0 -> `break`, NO plane is filtered; a chroma plane with level 0 is skipped */
+    if (!lf->filter_level[0] && !lf->filter_level[1]) return EB_ErrorNone;
+    if (upload(hip, p, recon, p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    fill_mode_info(p, pcs, 0);
+    void *pl_ptr[3]; const uint16_t *ev[3], *eh[3];
+    int mask = 0;
+    for (int pl = 0; pl < 3; pl++) {
+        const int on = pl == 0 || (pl == 1 ? lf->filter_level_u : lf->filter_level_v);
+        pl_ptr[pl] = on ? plane_origin(p, p->d_recon[pl], pl) : NULL;
+        ev[pl] = p->d_edges[pl][0]; eh[pl] = p->d_edges[pl][1];
+        if (!on) continue;
+        mask |= 1 << pl;
+        if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
+    }
+    HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
+    if (download(hip, p, p->d_recon, recon, mask) != EB_ErrorNone) return EB_ErrorUndefined;
+    s->flags |= ST_DBL;
+    svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask);
+    return EB_ErrorNone;
+}
+EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_DLF)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 1);
+    EbErrorType rc = s ? dlf_frame(hip, s, recon) : EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_DLF, rc == EB_ErrorNone);
+    return rc;
+}
+
+/* dlf_kernel, when the deblocked picture is final: the later hooks need it on the device (CDEF input; the stripe context rows of the
+ * restoration filters come from the deblocked, pre-CDEF picture, which the host overwrites in place). */
+void svt_hip_hook_after_dlf(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH) && !svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH) &&
+        !svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS))
+        return;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return;
+    LfState *s = state_of(hip, pcs, 1);
+    if (s && !(s->flags & ST_DBL) && upload(hip, &s->pic, recon_of(pcs, s->pic.pix_bytes == 2), s->pic.d_recon, 0) == EB_ErrorNone) s->flags |= ST_DBL;
+    svt_hip_hooks_unlock();
 }
 
 /* ---------------------------------------------------------------- CDEF ---------------------------------------------------------------- */
@@ -158,8 +301,14 @@ static void fill_skip8(SvtHipLfPicture *p, PictureControlSet *pcs) {     /* is_8
             p->h_skip8[r * c8 + c] = (uint8_t)skip;
         }
 }
+static int cdef_geometry_ok(const SvtHipLfPicture *p) { return !(p->w % 64 > 0 && p->w % 64 < 16); }   /* include/svt_hip.h: last filter block >= 16 wide */
 
-EbErrorType svt_hip_cdef_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
+/* all cdef_seg_search[16bit] calls of the picture (EbCdefProcess.c:80-475): pcs->mse_seg[pli][fb][gi] for the strengths of the picture's
+ * pick method (gi indexes the REDUCED strength list, get_cdef_filter_strengths, Common/Codec/EbDefinitions.h:1696) */
+static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
+    if (!(s->flags & ST_DBL) || !cdef_geometry_ok(p) || ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     const int nfb = ((p->w + 63) / 64) * ((p->h + 63) / 64);
     const int pri_damping = 3 + (pcs->parent_pcs_ptr->frm_hdr.quantization_params.base_q_idx >> 6);   /* EbCdefProcess.c:121 */
     fill_skip8(p, pcs);
@@ -167,47 +316,127 @@ EbErrorType svt_hip_cdef_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pict
     const void *rec[3], *src[3];
     for (int pl = 0; pl < 3; pl++) { rec[pl] = plane_origin(p, p->d_recon[pl], pl); src[pl] = p->d_src[pl]; }
     HIP_TRY(svt_hip_cdef_search_frame_dev(hip, p->pix_bytes, rec, p->stride, src, p->src_stride, p->w, p->h, p->d_skip8, pri_damping, p->bd, p->d_mse, p->d_dir, p->d_var));
-    /* pcs->mse_seg[pli][fb][gi]: [2] arrays of nfb x TOTAL_STRENGTHS uint64, the layout of the device table */
-    HIP_TRY(svt_hip_memcpy_d2h(hip, pcs->mse_seg[0], p->d_mse, sizeof(uint64_t) * nfb * 64));
-    HIP_TRY(svt_hip_memcpy_d2h(hip, pcs->mse_seg[1], p->d_mse + (size_t)nfb * 64, sizeof(uint64_t) * nfb * 64));
+    HIP_TRY(svt_hip_memcpy_d2h(hip, p->h_mse, p->d_mse, sizeof(uint64_t) * 2 * nfb * 64));
+    const int level = pcs->parent_pcs_ptr->cdef_level;
+    const CDEF_PICK_METHOD pick = level == 2 ? CDEF_FAST_SEARCH_LVL1 : level == 3 ? CDEF_FAST_SEARCH_LVL2 : level == 4 ? CDEF_FAST_SEARCH_LVL3 : 0;
+    const int c8 = p->w / 8, nhfb = (p->w + 63) / 64;
+    for (int fb = 0; fb < nfb; fb++) {
+        /* the reference leaves the entries of an all-skip filter block untouched (svt_sb_all_skip, :199): so do we */
+        const int fbr = fb / nhfb, fbc = fb % nhfb;
+        int all_skip = 1;
+        for (int r = fbr * 8; r < fbr * 8 + 8 && r < p->h / 8 && all_skip; r++)
+            for (int c = fbc * 8; c < fbc * 8 + 8 && c < c8; c++) all_skip &= p->h_skip8[r * c8 + c];
+        if (all_skip) continue;
+        for (int gi = 0; gi < nb_cdef_strengths[pick]; gi++) {
+            int pri = gi / CDEF_SEC_STRENGTHS, sec = gi % CDEF_SEC_STRENGTHS;
+            get_cdef_filter_strengths(pick, &pri, &sec, gi);
+            pcs->mse_seg[0][fb][gi] = p->h_mse[(size_t)fb * 64 + pri * CDEF_SEC_STRENGTHS + sec];
+            pcs->mse_seg[1][fb][gi] = p->h_mse[((size_t)nfb + fb) * 64 + pri * CDEF_SEC_STRENGTHS + sec];
+        }
+    }
+    s->flags |= ST_DIRVAR;
     return EB_ErrorNone;
 }
+/* called by every segment of the picture: the first one to arrive searches the whole picture, the others find it done */
+EbErrorType svt_hip_hook_cdef_search(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = EB_ErrorUndefined;
+    if (s && (s->flags & ST_CDEF_SEARCHED)) rc = EB_ErrorNone;
+    else if (s && !(s->flags & ST_CDEF_FAILED)) {
+        rc = cdef_search(hip, s);
+        s->flags |= rc == EB_ErrorNone ? ST_CDEF_SEARCHED : ST_CDEF_FAILED;
+        svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_SEARCH, rc == EB_ErrorNone);
+    }
+    svt_hip_hooks_unlock();
+    return rc;
+}
 
-EbErrorType svt_hip_cdef_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
+/* svt_av1_cdef_frame / av1_cdef_frame16bit (EbEncCdef.c:292-1031) */
+static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
+    if (!(s->flags & ST_DBL) || !cdef_geometry_ok(p)) return EB_ErrorUndefined;
     FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
     const int nhfb = (p->w + 63) / 64, nvfb = (p->h + 63) / 64, nfb = nhfb * nvfb;
     uint8_t *ys = (uint8_t *)malloc(nfb), *uvs = (uint8_t *)malloc(nfb);
     if (!ys || !uvs) { free(ys); free(uvs); return EB_ErrorInsufficientResources; }
+    int bad = 0;
     for (int fbr = 0; fbr < nvfb; fbr++)
-        for (int fbc = 0; fbc < nhfb; fbc++) {     /* the strength index finish_cdef_search stored in the fb's first mode-info (EbEncCdef.c:415-425) */
-            const int8_t idx = pcs->mi_grid_base[MI_SIZE_64X64 * fbr * pcs->mi_stride + MI_SIZE_64X64 * fbc]->mbmi.cdef_strength;
+        for (int fbc = 0; fbc < nhfb; fbc++) {     /* the strength index finish_cdef_search stored in the fb's first mode-info (EbEncCdef.c:1292) */
+            const ModeInfo *mi = pcs->mi_grid_base[MI_SIZE_64X64 * fbr * pcs->mi_stride + MI_SIZE_64X64 * fbc];
+            const int8_t idx = mi ? mi->mbmi.cdef_strength : -1;
+            if (idx < 0 || idx >= CDEF_MAX_STRENGTHS) bad = 1;   /* the reference skips such a filter block with an error message (:370-377): leave it to the reference */
             ys[fbr * nhfb + fbc] = idx < 0 ? 0 : (uint8_t)frm_hdr->cdef_params.cdef_y_strength[idx];
             uvs[fbr * nhfb + fbc] = idx < 0 ? 0 : (uint8_t)frm_hdr->cdef_params.cdef_uv_strength[idx];
         }
-    int rc = svt_hip_memcpy_h2d(hip, p->d_y_strength, ys, nfb) | svt_hip_memcpy_h2d(hip, p->d_uv_strength, uvs, nfb);
+    int rc = bad ? SVT_HIP_ERR_UNSUPPORTED : (svt_hip_memcpy_h2d(hip, p->d_y_strength, ys, nfb) | svt_hip_memcpy_h2d(hip, p->d_uv_strength, uvs, nfb));
     free(ys); free(uvs);
     if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
+    if (!(s->flags & ST_DIRVAR)) {   /* the search hook is off: build the skip map here; directions are computed by the apply call */
+        fill_skip8(p, pcs);
+        HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_skip8, p->h_skip8, (size_t)(p->w / 8) * (p->h / 8)));
+    }
     const void *in[3]; void *out[3];
     for (int pl = 0; pl < 3; pl++) {
         in[pl] = plane_origin(p, p->d_recon[pl], pl); out[pl] = plane_origin(p, p->d_cdef[pl], pl);
         HIP_TRY(svt_hip_memcpy_d2d(hip, p->d_cdef[pl], p->d_recon[pl], plane_bytes(p, pl)));    /* unfiltered blocks keep the deblocked samples */
     }
-    /* direction / variance of the search are reused (same pre-CDEF picture) */
+    /* direction / variance of the search are reused when it ran here (same pre-CDEF picture) */
     HIP_TRY(svt_hip_cdef_apply_frame_dev(hip, p->pix_bytes, in, out, p->stride, p->w, p->h, p->d_skip8, p->d_y_strength, p->d_uv_strength,
-                                         frm_hdr->cdef_params.cdef_damping, p->bd, p->d_dir, p->d_var));
+                                         frm_hdr->cdef_params.cdef_damping, p->bd, p->d_dir, (s->flags & ST_DIRVAR) ? p->d_var : NULL));
+    if (download(hip, p, p->d_cdef, recon_of(pcs, p->pix_bytes == 2), 7) != EB_ErrorNone) return EB_ErrorUndefined;
+    s->flags |= ST_CDEF;
     return EB_ErrorNone;
+}
+EbErrorType svt_hip_hook_cdef_apply(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = s ? cdef_apply(hip, s) : EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_APPLY, rc == EB_ErrorNone);
+    return rc;
 }
 
 /* ---------------------------------------------------------------- loop restoration ---------------------------------------------------- */
-EbErrorType svt_hip_rest_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
+/* the CDEF output on the device (from the CDEF hook, or uploaded from the host picture) with its 3-sample border (svt_extend_frame) */
+static EbErrorType ensure_cdef_padded(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    if (!(s->flags & ST_CDEF)) {
+        if (upload(hip, p, recon_of(s->pcs, p->pix_bytes == 2), p->d_cdef, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+        s->flags |= ST_CDEF;
+    }
+    if (!(s->flags & ST_PADDED)) {
+        for (int pl = 0; pl < 3; pl++)
+            HIP_TRY(svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->w >> (pl > 0), p->h >> (pl > 0), LF_BORDER, LF_BORDER));
+        s->flags |= ST_PADDED;
+    }
+    return EB_ErrorNone;
+}
+static int rest_geometry_ok(const SvtHipLfPicture *p, const Av1Common *cm) {
+    for (int pl = 0; pl < 3; pl++) {
+        const RestorationInfo *rsi = &cm->rst_info[pl];
+        if (rsi->units_per_tile <= 0 || rsi->units_per_tile > p->max_units[pl] || (rsi->restoration_unit_size != 64 && rsi->restoration_unit_size != 128 && rsi->restoration_unit_size != 256))
+            return 0;
+    }
+    return 1;   /* restoration units ignore tiles (one "tile" = the frame, EbRestoration.c:1413) */
+}
+
+/* svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0) (Common/Codec/EbRestoration.c:1293) */
+static EbErrorType rest_apply(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
     Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    if (!(s->flags & ST_DBL) || !rest_geometry_ok(p, cm) || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
+    int mask = 0;
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
         const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
-        if (rsi->frame_restoration_type == RESTORE_NONE) {
-            HIP_TRY(svt_hip_memcpy_d2d(hip, p->d_rest[pl], p->d_cdef[pl], plane_bytes(p, pl)));
-            continue;
-        }
+        if (rsi->frame_restoration_type == RESTORE_NONE) continue;    /* the plane is left alone (:1322-1323) */
         uint8_t *ep = (uint8_t *)malloc(n); int32_t *xqd = (int32_t *)malloc(sizeof(int32_t) * 2 * n); int16_t *wn = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t));
         if (!ep || !xqd || !wn) { free(ep); free(xqd); free(wn); return EB_ErrorInsufficientResources; }
         for (int u = 0; u < n; u++) {
@@ -220,33 +449,42 @@ EbErrorType svt_hip_rest_apply_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
                  svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn, sizeof(int16_t) * 16 * n);
         free(ep); free(xqd); free(wn);
         if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
-        /* the CDEF picture's 3-sample border (svt_extend_frame, EbRestoration.c:1306) */
-        HIP_TRY(svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], pw, ph, LF_BORDER, LF_BORDER));
         HIP_TRY(svt_hip_lr_apply_plane_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
                                            pw, ph, rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl],
                                            p->d_unit_xqd[pl], p->d_unit_wiener[pl]));
+        mask |= 1 << pl;
     }
-    return EB_ErrorNone;
+    return download(hip, p, p->d_rest, recon_of(pcs, p->pix_bytes == 2), mask);
+}
+EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = s ? rest_apply(hip, s) : EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_REST_APPLY, rc == EB_ErrorNone);
+    return rc;
 }
 
-/* rest_kernel, search half: in place of every search_sgrproj_seg call of restoration_seg_search (EbRestorationPick.c:1277-1317, per unit:
- * search_selfguided_restoration + try_restoration_unit_seg).  One svt_hip_sgr_search_units_picture call gives the (ep, xqd) of every unit
- * of the three planes; the units are then filtered with exactly those parameters (stripe rules as in svt_av1_loop_restoration_filter_unit)
- * and their SSE against the source is what try_restoration_unit_seg -> sse_restoration_unit (:58-135) returns.  Results land in
- * pcs->parent_pcs_ptr->rusi_picture[plane][unit] (sgrproj, sse[RESTORE_SGRPROJ]) and cm->sg_frame_ep_cnt, i.e. where search_sgrproj_finish (:1319) and
- * rest_finish_search read them.  p->d_cdef must hold the CDEF output, p->d_recon the deblocked picture, p->d_src the source. */
-EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, PictureControlSet *pcs) {
+/* every search_sgrproj_seg call of the picture (EbRestorationPick.c:1277-1317, per unit: search_selfguided_restoration :583 +
+ * try_restoration_unit_seg :137).  One svt_hip_sgr_search_units_picture call gives the (ep, xqd) of every unit of the three planes; the units are
+ * then filtered with exactly those parameters (stripe rules as in svt_av1_loop_restoration_filter_unit) and their SSE against the source is what
+ * try_restoration_unit_seg -> sse_restoration_unit (:58) returns.  Results land in rusi_picture[plane][unit] (sgrproj, sse[RESTORE_SGRPROJ]) and
+ * cm->sg_frame_ep_cnt, i.e. where search_sgrproj_finish (:1319) and rest_finish_search read them. */
+static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
     Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    if (!(s->flags & ST_DBL) || !rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     /* the set window of search_selfguided_restoration (:596-607) */
-    static const int8_t k_step[5] = {16, 0, 1, 4, 16};   /* get_sg_step (:693-704) */
-    const int8_t step = k_step[cm->sg_filter_mode >= 1 && cm->sg_filter_mode <= 4 ? cm->sg_filter_mode : 0];
+    const int8_t step = get_sg_step(cm->sg_filter_mode);
     const int8_t *re = cm->sg_ref_frame_ep;
     const int none = re[0] < 0 && re[1] < 0;
     const int mid = none ? 0 : (re[1] < 0 ? re[0] : (re[0] < 0 ? re[1] : (re[0] + re[1]) / 2));
     const int start_ep = none ? 0 : (mid - step > 0 ? mid - step : 0), end_ep = none ? 16 : (mid + step < 16 ? mid + step : 16);
     uint32_t mask = 0;
     for (int ep = start_ep; ep < end_ep; ep++) mask |= 1u << ep;
-    if (!mask) return EB_ErrorBadParameter;
 
     SvtHipSgrSearchPlane job[3];
     int32_t *xqd[3] = {0}; int64_t *err[3] = {0}; uint8_t *best[3] = {0};
@@ -254,15 +492,15 @@ EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
         const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
-        xqd[pl] = (int32_t *)malloc(sizeof(int32_t) * 32 * n); err[pl] = (int64_t *)malloc(sizeof(int64_t) * 16 * n); best[pl] = (uint8_t *)malloc(n);
+        xqd[pl] = (int32_t *)calloc((size_t)32 * n, sizeof(int32_t)); err[pl] = (int64_t *)calloc((size_t)16 * n, sizeof(int64_t)); best[pl] = (uint8_t *)calloc(n, 1);
         if (!xqd[pl] || !err[pl] || !best[pl]) { ret = EB_ErrorInsufficientResources; goto done; }
-        if (svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], pw, ph, LF_BORDER, LF_BORDER) != SVT_HIP_OK) { ret = EB_ErrorUndefined; goto done; }
         job[pl].d_dgd = plane_origin(p, p->d_cdef[pl], pl); job[pl].stride = p->stride[pl];
         job[pl].d_src = p->d_src[pl]; job[pl].src_stride = p->src_stride[pl];
         job[pl].pw = pw; job[pl].ph = ph; job[pl].unit_size = rsi->restoration_unit_size; job[pl].ss_y = pl > 0;
         job[pl].ep_mask = mask; job[pl].xqd_out = xqd[pl]; job[pl].err_out = err[pl]; job[pl].best_ep = best[pl];
     }
-    if (svt_hip_sgr_search_units_picture(hip, p->pix_bytes, p->bd, 3, job, NULL) != SVT_HIP_OK) { ret = EB_ErrorUndefined; goto done; }
+    /* an empty window (step 0 with reference sets: the loop :609 never runs) leaves ep 0, xqd {0, 0} — the calloc'ed values */
+    if (mask && svt_hip_sgr_search_units_picture(hip, p->pix_bytes, p->bd, 3, job, NULL) != SVT_HIP_OK) { ret = EB_ErrorUndefined; goto done; }
 
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
@@ -283,6 +521,7 @@ EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
                 int x0 = 0, j = 0;
                 while (x0 < pw) {
                     const int rem_w = pw - x0, w = rem_w < ext ? rem_w : us, u = i * hunits + j;
+                    if (u >= n) { ok = 0; break; }
                     ep[u] = best[pl][u];
                     uq[2 * u] = xqd[pl][(u * 16 + ep[u]) * 2]; uq[2 * u + 1] = xqd[pl][(u * 16 + ep[u]) * 2 + 1];
                     rusi[u].sgrproj.ep = ep[u]; rusi[u].sgrproj.xqd[0] = uq[2 * u]; rusi[u].sgrproj.xqd[1] = uq[2 * u + 1];
@@ -292,7 +531,7 @@ EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
                 }
                 y0 += h; i++;
             }
-            ok = svt_hip_malloc(hip, &d_rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK && svt_hip_malloc(hip, &d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK &&
+            ok = ok && svt_hip_malloc(hip, &d_rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK && svt_hip_malloc(hip, &d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK &&
                  svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl], ep, n) == SVT_HIP_OK && svt_hip_memcpy_h2d(hip, p->d_unit_xqd[pl], uq, sizeof(int32_t) * 2 * n) == SVT_HIP_OK &&
                  svt_hip_memcpy_h2d(hip, d_rect, rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK &&
                  /* try_restoration_unit_seg: the unit filtered for real (stripe context from the deblocked picture), then its SSE */
@@ -312,4 +551,78 @@ EbErrorType svt_hip_sgr_search_picture(SvtHipCtx *hip, SvtHipLfPicture *p, Pictu
 done:
     for (int pl = 0; pl < 3; pl++) { free(xqd[pl]); free(err[pl]); free(best[pl]); }
     return ret;
+}
+/* called at the top of every restoration_seg_search of the picture: the first segment to arrive searches all units */
+EbErrorType svt_hip_hook_sgr_search(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = EB_ErrorUndefined;
+    if (s && (s->flags & ST_SGR_DONE)) rc = EB_ErrorNone;
+    else if (s && !(s->flags & ST_SGR_FAILED)) {
+        rc = sgr_search(hip, s);
+        s->flags |= rc == EB_ErrorNone ? ST_SGR_DONE : ST_SGR_FAILED;
+        svt_hip_hooks_count(SVT_HIP_HOOK_SGR_SEARCH, rc == EB_ErrorNone);
+    }
+    svt_hip_hooks_unlock();
+    return rc;
+}
+
+/* svt_av1_compute_stats[_highbd] of search_wiener_seg (EbRestorationPick.c:1347): the first call of a picture runs one statistics pass per
+ * plane over all units; every call copies its unit's M / H. */
+static EbErrorType wiener_stats_all(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    const Av1Common *cm = s->pcs->parent_pcs_ptr->av1_cm;
+    if (!rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
+    for (int pl = 0; pl < 3; pl++) {
+        const RestorationInfo *rsi = &cm->rst_info[pl];
+        const int wn_luma = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : cm->wn_filter_mode == 2 ? WIENER_WIN_CHROMA : WIENER_WIN;
+        const int win = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : (pl == 0 ? wn_luma : WIENER_WIN_CHROMA);   /* search_wiener_seg :1352-1358 */
+        const int n = rsi->units_per_tile, w2 = win * win;
+        free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
+        p->h_wiener_M[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2); p->h_wiener_H[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2 * w2);
+        p->wiener_win[pl] = win;
+        void *dM = NULL, *dH = NULL;
+        int ok = p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_malloc(hip, &dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
+                 svt_hip_malloc(hip, &dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK &&
+                 svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->d_src[pl], p->src_stride[pl],
+                                                p->w >> (pl > 0), p->h >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)dM, (int64_t *)dH) == SVT_HIP_OK &&
+                 svt_hip_memcpy_d2h(hip, p->h_wiener_M[pl], dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
+                 svt_hip_memcpy_d2h(hip, p->h_wiener_H[pl], dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK;
+        if (dM) svt_hip_free(hip, dM);
+        if (dH) svt_hip_free(hip, dH);
+        if (!ok) return EB_ErrorUndefined;
+    }
+    return EB_ErrorNone;
+}
+EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wiener_win, int unit_idx, int64_t *M, int64_t *H) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = EB_ErrorUndefined;
+    if (s && !(s->flags & (ST_WIENER_DONE | ST_WIENER_FAILED))) {
+        rc = wiener_stats_all(hip, s);
+        s->flags |= rc == EB_ErrorNone ? ST_WIENER_DONE : ST_WIENER_FAILED;
+        svt_hip_hooks_count(SVT_HIP_HOOK_WIENER_STATS, rc == EB_ErrorNone);
+    }
+    if (s && (s->flags & ST_WIENER_DONE) && s->pic.wiener_win[plane] == wiener_win && unit_idx >= 0 &&
+        unit_idx < pcs->parent_pcs_ptr->av1_cm->rst_info[plane].units_per_tile) {
+        const int w2 = wiener_win * wiener_win;
+        memcpy(M, s->pic.h_wiener_M[plane] + (size_t)unit_idx * w2, sizeof(int64_t) * w2);
+        memcpy(H, s->pic.h_wiener_H[plane] + (size_t)unit_idx * w2 * w2, sizeof(int64_t) * w2 * w2);
+        rc = EB_ErrorNone;
+    } else
+        rc = EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    return rc;
+}
+
+void svt_hip_hook_picture_done(PictureControlSet *pcs) {
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return;
+    LfState *s = state_of(hip, pcs, 0);
+    if (s) { s->pcs = NULL; s->flags = 0; }   /* buffers stay allocated for the next picture of this size */
+    svt_hip_hooks_unlock();
 }
