@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
+#pragma GCC visibility push(default)
 
 typedef enum {
     SVT_HIP_OK              = 0,
@@ -89,6 +91,11 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *ctx, const uint8_t *d_src, const uin
 int svt_hip_me_fullpel_frame(SvtHipCtx *ctx, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows,
                              int org_x, int org_y, const SvtHipSbSearch *sbs, int n_sb, int sub_sad,
                              uint32_t *best_sad, uint32_t *best_mv);
+/* Search areas above 65 536 candidates (the reference configures up to 750 x 750, EbMotionEstimationProcess.c:124-137) are searched by a second
+ * launch of the same kernel that walks the window strip by strip; SBs with smaller windows leave it at once.  The _dev entry point cannot see the
+ * descriptors, so that launch is always issued unless the caller declares that no window of this context exceeds 65 536 candidates (enable = 0;
+ * an oversized window then yields SVT_HIP_MAX_SAD_VALUE for every PU of its SB).  The host-pointer entry point decides per call. */
+int svt_hip_me_set_big_windows(SvtHipCtx *ctx, int enable);
 /* Tuning knob: low 4 bits = waves per SB workgroup (1, 2 or 4; default 4); bits 4.. = KiB of unused LDS added to each workgroup
  * (0 = off): with >= 56 only one ME workgroup fits a CU, which leaves half of every SIMD's registers to kernels running concurrently
  * on other streams (measured: ME alone 0.40 -> 0.63 ms, whole step unchanged -- see DESIGN.md 5). */
@@ -530,6 +537,7 @@ int svt_hip_picture_format_dev(SvtHipCtx *ctx, int mode, const void *d_in0, int 
  * reference picture, and svt_extend_frame's 3-sample border of the restoration input).  d_plane points at picture sample (0, 0). */
 int svt_hip_generate_padding_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

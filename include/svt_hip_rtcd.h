@@ -26,6 +26,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
+#pragma GCC visibility push(default)
 
 /* InterpFilterParams / ConvolveParams, Source/Lib/Common/Codec/EbDefinitions.h:493-498 / :379-392 */
 typedef struct {
@@ -131,6 +133,7 @@ typedef struct SvtHipRtcd {
  * corresponding *_hip wrapper bound to ctx; the incoming pointers are kept as the failure fallbacks. */
 int svt_hip_setup_rtcd(SvtHipCtx *ctx, SvtHipRtcd *table);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

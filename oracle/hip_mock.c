@@ -20,6 +20,13 @@
 
 struct SvtHipCtx { char err[256]; };
 
+/* SVT_HIP_MOCK_PERTURB=<stage>: deliberately wrong output of one stage, so that the end-to-end test can prove that the bitstream / the
+ * reconstruction really depend on what each hook returns (tests/test_encode_e2e.py::test_every_hook_matters) */
+static int perturb(const char *stage) {
+    const char *e = getenv("SVT_HIP_MOCK_PERTURB");
+    return e && !strcmp(e, stage);
+}
+
 int svt_hip_init(int device_id, SvtHipCtx **ctx) {
     (void)device_id;
     *ctx = (SvtHipCtx *)calloc(1, sizeof(SvtHipCtx));
@@ -51,6 +58,8 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t
                                  const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
     (void)c;
     orc_me_fullpel_frame(src, ref, stride, org_x, org_y, (const OrcSbSearch *)sbs, n_sb, sub_sad, best_sad, best_mv, 0, n_sb);
+    if (perturb("me"))
+        for (int i = 0; i < n_sb * 85; i++) best_mv[i] = (best_mv[i] & 0xffff0000u) | ((best_mv[i] + 8) & 0xffffu);   /* x_mv + 2 px */
     return SVT_HIP_OK;
 }
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,
@@ -81,6 +90,7 @@ int svt_hip_deblock_frame_dev(SvtHipCtx *c, void *const plane[3], int pix_bytes,
                               const uint16_t *const eh[3], const int units_w[3], const int units_h[3], int sharpness) {
     for (int p = 0; p < 3; p++)
         if (plane[p]) svt_hip_deblock_plane_dev(c, plane[p], pix_bytes, stride[p], bd, ev[p], eh[p], units_w[p], units_h[p], sharpness);
+    if (perturb("dlf") && plane[0]) ((uint8_t *)plane[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
 int svt_hip_plane_sse_dev(SvtHipCtx *c, int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h, uint64_t *sse) {
@@ -98,8 +108,8 @@ static int64_t mock_try_level(void *user, int lv_v, int lv_h) {   /* the device'
     const size_t n = (size_t)m->uw * m->uh;
     uint16_t    *v = (uint16_t *)malloc(n * 2), *h = (uint16_t *)malloc(n * 2);
     for (size_t i = 0; i < n; i++) {
-        v[i] = (uint16_t)((m->ev[i] & 0xff) ? ((lv_v << 8) | (m->ev[i] & 0xff)) : 0);
-        h[i] = (uint16_t)((m->eh[i] & 0xff) ? ((lv_h << 8) | (m->eh[i] & 0xff)) : 0);
+        v[i] = (uint16_t)(((m->ev[i] & 0xff) && lv_v) ? ((lv_v << 8) | (m->ev[i] & 0xff)) : 0);   /* level 0 = no filtering, like the kernel (deblock.hip) */
+        h[i] = (uint16_t)(((m->eh[i] & 0xff) && lv_h) ? ((lv_h << 8) | (m->eh[i] & 0xff)) : 0);
     }
     for (int y = 0; y < m->h; y++)
         memcpy((uint8_t *)m->tmp + (size_t)y * m->stride * m->pix_bytes, (const uint8_t *)m->recon + (size_t)y * m->stride * m->pix_bytes, (size_t)m->w * m->pix_bytes);
@@ -112,7 +122,9 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx *c, const SvtHipDlfSearch *p, const v
                                  int units_h, uint64_t *d_sse_scratch, int *best_level, int64_t *best_err) {
     (void)c; (void)d_sse_scratch;
     MockProbe m = {d_recon, d_src, d_tmp, pix_bytes, stride, bd, plane_w, plane_h, src_stride, units_w, units_h, p->sharpness, ev, eh};
-    return svt_hip_dlf_search_levels_host(p, mock_try_level, &m, best_level, best_err);
+    const int rc = svt_hip_dlf_search_levels_host(p, mock_try_level, &m, best_level, best_err);
+    if (perturb("dlf_search")) *best_level = (*best_level + 3) & 63;
+    return rc;
 }
 
 /* ------------------------------------------------------------------ CDEF */
@@ -122,12 +134,15 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const
     (void)c; (void)dir; (void)var;
     const int nfb = ((w + 63) / 64) * ((h + 63) / 64);
     orc_cdef_search_frame(rec, rec_stride, src, src_stride, pix_bytes, w, h, skip8, pri_damping, bd, 0, mse, 0, nfb);
+    if (perturb("cdef_search"))
+        for (int i = 0; i < 2 * nfb * 64; i++) mse[i] = (uint64_t)(i % 64) << 24;   /* strength 0 always "wins" */
     return SVT_HIP_OK;
 }
 int svt_hip_cdef_apply_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const in[3], void *const out[3], const int stride[3], int w, int h,
                                  const uint8_t *skip8, const uint8_t *ys, const uint8_t *uvs, int damping, int bd, uint8_t *dir, const int32_t *var) {
     (void)c; (void)dir; (void)var;
     orc_cdef_apply_frame(in, out, stride, pix_bytes, w, h, skip8, ys, uvs, damping, bd);
+    if (perturb("cdef_apply")) ((uint8_t *)out[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
 
@@ -150,6 +165,7 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *
     orc_lr_apply_plane(dbl, dbl_stride, copy + ((size_t)3 * stride + 3) * pix_bytes, stride, pix_bytes, pw, ph, ss_y, ss_y, unit_size, bd, unit_ep, unit_xqd,
                        unit_wiener, dst, dst_stride);
     free(copy);
+    if (perturb("rest_apply")) ((uint8_t *)dst)[(size_t)9 * dst_stride * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
@@ -160,6 +176,10 @@ int svt_hip_sgr_search_units_plane(SvtHipCtx *c, int pix_bytes, int bd, const vo
                                    int unit_size, int ss_y, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out, uint8_t *best_ep, int *rounds) {
     (void)c;
     orc_sgr_search_units_plane(dgd, pix_bytes, stride, src, src_stride, pw, ph, ss_y, ss_y, unit_size, bd, ep_mask, xqd_out, err_out, best_ep);
+    if (perturb("sgr_search")) {
+        const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
+        for (int i = 0; i < nu * 32; i += 2) xqd_out[i] = xqd_out[i] > -90 ? xqd_out[i] - 5 : xqd_out[i] + 5;
+    }
     if (rounds) *rounds = 0;
     return SVT_HIP_OK;
 }
@@ -181,5 +201,9 @@ int svt_hip_wiener_stats_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, int win,
                                    int ph, int unit_size, int ss_y, int64_t *M, int64_t *H) {
     (void)c;
     orc_wiener_stats_plane(win, dgd, stride, src, src_stride, pix_bytes, bd, pw, ph, ss_y, unit_size, M, H);
+    if (perturb("wiener_stats")) {
+        const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
+        for (int i = 0; i < nu * win * win; i++) M[i] = M[i] / 2;
+    }
     return SVT_HIP_OK;
 }

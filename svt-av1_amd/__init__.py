@@ -132,6 +132,7 @@ def lib():
     L.svt_hip_me_fullpel_frame_dev.argtypes = [vp, u8p, u8p, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_fullpel_frame.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
+    L.svt_hip_me_set_big_windows.argtypes = [vp, i32]
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]

@@ -205,7 +205,11 @@ __device__ __forceinline__ void search_unit(const_u32_ptr src_dw, int src_pitch_
     }
 }
 
-template <int WAVES, bool SUB>
+// BIG = false: search areas of up to 65 536 candidates (the packed keys carry a 16-bit raster index); larger ones return at once and are
+// taken by the BIG = true instance of the same code, which walks the window in strips of whole candidate rows (<= 65 536 candidates each,
+// top to bottom) and merges a strip's winners into the result with the reference's strict '<', i.e. still "first minimum in raster order"
+// (the reference configures search areas up to 750 x 750, EbMotionEstimationProcess.c:124-137).
+template <int WAVES, bool SUB, bool BIG>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PER_EU, ME_WAVES_PER_EU)))
 me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ ref, int stride, int org_x, int org_y,
                        const SvtHipSbSearch* __restrict__ sbs, uint32_t* __restrict__ best_sad,
@@ -218,8 +222,13 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
     const int sb  = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SvtHipSbSearch d = sbs[sb];
-    const int saw = d.width, sah = d.height;
+    const int saw = d.width, sah_all = d.height;
     if (saw & 7) return;  // widths 1..7 (window clamped at a picture edge) go to me_fullpel_narrow_kernel
+    if (((saw * sah_all) > 65536) != BIG) return;
+    const int strip_rows = BIG ? max(1, 65536 / max(saw, 1)) : sah_all;
+    int sy0 = 0;
+    do {
+    const int sah = BIG ? min(strip_rows, sah_all - sy0) : sah_all;   // candidate rows of this strip
 
     Keys K;
 #pragma unroll
@@ -244,7 +253,7 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
             const int tw = min(kTile, saw - tx);
             const int ng = tw >> 3;  // 8-candidate groups per candidate row (tw is a multiple of 8 here)
             __syncthreads();               // previous tile fully consumed
-            const uint8_t* ref_base = ref + (size_t)(org_y + d.sb_y + d.y_origin + ty) * stride +
+            const uint8_t* ref_base = ref + (size_t)(org_y + d.sb_y + d.y_origin + sy0 + ty) * stride +
                                       (org_x + d.sb_x + d.x_origin + tx);
             stage_rows<4>(lds_ref, kRefStrideDw, ref_base, stride, th + 63, kRefRowDw, tw + 63, tid, NT);   // 4: the 90 key registers stay live here
             __syncthreads();
@@ -316,14 +325,19 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
         if (saw > 0 && sah > 0 && bi < (uint32_t)(saw * sah)) {
             const int cy = (int)bi / saw, cx = (int)bi - cy * saw;
             // MV word of a candidate: EbMotionEstimation.c:476-478 / :253-255 (quarter-pel int16 halves)
-            const uint32_t ymv = (uint32_t)((d.y_origin + cy) * 4) & 0xFFFFu;
+            const uint32_t ymv = (uint32_t)((d.y_origin + sy0 + cy) * 4) & 0xFFFFu;
             const uint32_t xmv = (uint32_t)((d.x_origin + cx) * 4) & 0xFFFFu;
             out_sad = bs;
             out_mv  = (ymv << 16) | xmv;
         }
-        best_sad[(size_t)sb * SVT_HIP_SQUARE_PU_COUNT + pu] = out_sad;
-        best_mv[(size_t)sb * SVT_HIP_SQUARE_PU_COUNT + pu]  = out_mv;
+        // later strips only replace a strictly smaller SAD (this thread wrote the previous strips' value of this PU itself)
+        if (!BIG || sy0 == 0 || out_sad < best_sad[(size_t)sb * SVT_HIP_SQUARE_PU_COUNT + pu]) {
+            best_sad[(size_t)sb * SVT_HIP_SQUARE_PU_COUNT + pu] = out_sad;
+            best_mv[(size_t)sb * SVT_HIP_SQUARE_PU_COUNT + pu]  = out_mv;
+        }
     }
+    if (BIG) __syncthreads();   // lds_red / lds_fin are rewritten by the next strip
+    } while (BIG && (sy0 += strip_rows) < sah_all);
 }
 
 // Search areas narrower than 8 candidates (EbMotionEstimation.c:2007-2008 keeps widths 1..7 when
@@ -384,19 +398,23 @@ me_fullpel_narrow_kernel(const uint8_t* __restrict__ src, const uint8_t* __restr
 
 extern "C" int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride,
                                          int org_x, int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad,
-                                         uint32_t* d_best_sad, uint32_t* d_best_mv, int waves_per_sb) {
+                                         uint32_t* d_best_sad, uint32_t* d_best_mv, int waves_per_sb, int big_windows) {
     if (n_sb <= 0) return 0;
     dim3 grid(n_sb);
     // waves_per_sb >= 16: experimental "one workgroup per CU" mode -- (waves_per_sb >> 4) KiB of unused dynamic LDS keep a second ME
     // workgroup off the CU, leaving half of every SIMD's registers to kernels that run concurrently on other streams
     const int lds_pad = (waves_per_sb >> 4) * 1024;
     waves_per_sb &= 15;
-#define LAUNCH(W, S) hipLaunchKernelGGL((me_fullpel_85pu_kernel<W, S>), grid, dim3(64 * W), lds_pad, stream, d_src, d_ref, stride, \
+#define LAUNCH(W, S) hipLaunchKernelGGL((me_fullpel_85pu_kernel<W, S, false>), grid, dim3(64 * W), lds_pad, stream, d_src, d_ref, stride, \
                                         org_x, org_y, d_sbs, d_best_sad, d_best_mv)
     if (waves_per_sb == 1) { if (sub_sad) LAUNCH(1, true); else LAUNCH(1, false); }
     else if (waves_per_sb == 2) { if (sub_sad) LAUNCH(2, true); else LAUNCH(2, false); }
     else { if (sub_sad) LAUNCH(4, true); else LAUNCH(4, false); }
 #undef LAUNCH
+    if (big_windows) {   // search areas above 65 536 candidates: same kernel, strip by strip (SBs with smaller windows return at once)
+        if (sub_sad) hipLaunchKernelGGL((me_fullpel_85pu_kernel<4, true, true>), grid, dim3(256), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
+        else         hipLaunchKernelGGL((me_fullpel_85pu_kernel<4, false, true>), grid, dim3(256), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
+    }
     if (sub_sad) hipLaunchKernelGGL((me_fullpel_narrow_kernel<true>), grid, dim3(64), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
     else         hipLaunchKernelGGL((me_fullpel_narrow_kernel<false>), grid, dim3(64), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
     return (int)hipGetLastError();

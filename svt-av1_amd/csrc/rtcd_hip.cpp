@@ -17,6 +17,11 @@ SvtHipCtx*  g_ctx = nullptr;
 SvtHipRtcd  g_c;                 // the pointers that were installed before us (failure fallbacks)
 const int16_t h_interp[6][16][8] = SVT_HIP_INTERP_TABLE;
 
+// every wrapper: serialise on the one mutex and make the context's device current (the reference calls these pointers from many threads)
+struct Guard {
+    std::lock_guard<std::mutex> lk;
+    Guard() : lk(g_mu) { if (g_ctx) (void)hipSetDevice(svt_hip_ctx_device(g_ctx)); }
+};
 struct Slot { void* p = nullptr; size_t cap = 0; };
 Slot g_slot[8];
 
@@ -62,7 +67,7 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------- SAD
 void sad_loop_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t bh, uint32_t bw, uint64_t* best_sad,
                   int16_t* xc, int16_t* yc, uint32_t src_stride_raw, int16_t saw, int16_t sah) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     bool ok = g_ctx && src_stride_raw && bw && bh && saw > 0 && sah > 0 && (ref_stride % src_stride_raw) == 0;
     // sub-SAD convention: the caller doubles both strides and halves the height; candidate rows advance by the raw stride
     const int step = ok ? (int)(ref_stride / src_stride_raw) : 1;
@@ -103,7 +108,7 @@ bool sad_generic(const uint8_t* a, int a_stride, const uint8_t* b, int b_stride,
            svt_hip_block_sad_batch_dev(g_ctx, 1, da, (int)p, db, (int)p, (const SvtHipBlkPair*)dj, 1, dout) == 0 && down(out, dout, 4);
 }
 uint32_t nxm_sad_hip(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     uint32_t r;
     if (sad_generic(src, (int)src_stride, ref, (int)ref_stride, (int)width, (int)height, &r)) return r;
     FALLBACK("svt_nxm_sad_kernel", svt_nxm_sad_kernel, src, src_stride, ref, ref_stride, height, width);
@@ -118,19 +123,19 @@ bool var_generic(int pix_bytes, int bd, const void* a, int a_stride, const void*
     return true;
 }
 template <int IDX, int W, int H> uint32_t sad_wxh_hip(const uint8_t* a, int as, const uint8_t* b, int bs) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     uint32_t r;
     if (sad_generic(a, as, b, bs, W, H, &r)) return r;
     FALLBACK("svt_aom_sadWxH", svt_aom_sad[IDX], a, as, b, bs);
 }
 template <int IDX, int W, int H> unsigned var_wxh_hip(const uint8_t* a, int as, const uint8_t* b, int bs, unsigned* sse) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     unsigned v;
     if (var_generic(1, 8, a, as, b, bs, W, H, &v, sse)) return v;
     FALLBACK("svt_aom_varianceWxH", svt_aom_variance[IDX], a, as, b, bs, sse);
 }
 template <int IDX, int W, int H> unsigned var10_wxh_hip(const uint8_t* a8, int as, const uint8_t* b8, int bs, unsigned* sse) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     unsigned v;   // CONVERT_TO_SHORTPTR (Common/Codec/EbDefinitions.h): the byte pointer carries the uint16_t address >> 1
     if (var_generic(2, 10, (const void*)((uintptr_t)a8 << 1), as, (const void*)((uintptr_t)b8 << 1), bs, W, H, &v, sse)) return v;
     FALLBACK("svt_aom_highbd_10_varianceWxH", svt_aom_highbd_10_variance[IDX], a8, as, b8, bs, sse);
@@ -162,13 +167,13 @@ bool conv_generic(int pix_bytes, int bd, const void* src, int src_stride, void* 
 #define CONV_WRAPPER(NAME, MEMBER, SXM, SYM)                                                                                                         \
     void NAME(const uint8_t* src, int32_t ss, uint8_t* dst, int32_t ds, int32_t w, int32_t h, SvtHipInterpFilterParams* fx, SvtHipInterpFilterParams* fy, \
               const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp) {                                                                        \
-        std::lock_guard<std::mutex> lk(g_mu);                                                                                                        \
+        Guard lk;                                                                                                        \
         if (conv_generic(1, 8, src, ss, dst, ds, w, h, fx, fy, (SXM) ? sx : 0, (SYM) ? sy : 0, cp)) return;                                          \
         FALLBACK("svt_av1_" #MEMBER, svt_av1_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp);                                                                       \
     }                                                                                                                                                \
     void NAME##_hbd(const uint16_t* src, int32_t ss, uint16_t* dst, int32_t ds, int32_t w, int32_t h, const SvtHipInterpFilterParams* fx,             \
                     const SvtHipInterpFilterParams* fy, const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp, int32_t bd) {                  \
-        std::lock_guard<std::mutex> lk(g_mu);                                                                                                        \
+        Guard lk;                                                                                                        \
         if ((bd == 8 || bd == 10) && conv_generic(2, bd, src, ss, dst, ds, w, h, fx, fy, (SXM) ? sx : 0, (SYM) ? sy : 0, cp)) return;                 \
         FALLBACK("highbd " #MEMBER, svt_av1_highbd_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp, bd);                                       \
     }
@@ -198,17 +203,17 @@ bool fwd_generic(int ts, const int16_t* in, int32_t* out, int stride, int tx_typ
            down(out, d_c, (size_t)w * h * 4);
 }
 template <int SLOT, int TS> void fwd_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (fwd_generic(TS, in, out, (int)stride, tt)) return;
     FALLBACK("svt_av1_fwd_txfm2d_WxH", svt_av1_fwd_txfm2d[SLOT], in, out, stride, tt, bd);
 }
 template <int SLOT, int TS> void fwd_n2_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (fwd_generic(TS, in, out, (int)stride, tt, 1)) return;
     FALLBACK("svt_av1_fwd_txfm2d_WxH_N2", svt_av1_fwd_txfm2d_N2[SLOT], in, out, stride, tt, bd);
 }
 template <int SLOT, int TS> void fwd_n4_hip(int16_t* in, int32_t* out, uint32_t stride, uint8_t tt, uint8_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (fwd_generic(TS, in, out, (int)stride, tt, 2)) return;
     FALLBACK("svt_av1_fwd_txfm2d_WxH_N4", svt_av1_fwd_txfm2d_N4[SLOT], in, out, stride, tt, bd);
 }
@@ -222,17 +227,17 @@ bool inv_generic(int ts, const int32_t* in, uint16_t* out_r, int stride_r, uint1
            svt_hip_inv_txfm_add_batch_dev(g_ctx, ts, 2, bd, d_c, d_r, w, d_w, w, d_desc, 1) == 0 && down2d(out_w, (size_t)stride_w * 2, d_w, p, p, h);
 }
 template <int SLOT, int TS> void inv_sq_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, int32_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (inv_generic(TS, in, r, sr, wv, sw, tt, bd)) return;
     FALLBACK("svt_av1_inv_txfm2d_add (square)", svt_av1_inv_txfm2d_add_sq[SLOT], in, r, sr, wv, sw, tt, bd);
 }
 void inv_rect_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, uint8_t ts, int32_t eob, int32_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (ts < 19 && inv_generic(ts, in, r, sr, wv, sw, tt, bd)) return;
     FALLBACK("svt_av1_inv_txfm2d_add (rect)", svt_av1_inv_txfm2d_add_rect, in, r, sr, wv, sw, tt, ts, eob, bd);
 }
 void inv_rect4_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, uint8_t ts, int32_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (ts < 19 && inv_generic(ts, in, r, sr, wv, sw, tt, bd)) return;
     FALLBACK("svt_av1_inv_txfm2d_add (4xN)", svt_av1_inv_txfm2d_add_rect4, in, r, sr, wv, sw, tt, ts, bd);
 }
@@ -247,7 +252,7 @@ bool sgr_stage(const uint8_t* dat8, int highbd, int w, int h, int stride, void**
     return *d_in && up2d(*d_in, p, base - ((size_t)3 * stride + 3) * pb, (size_t)stride * pb, (size_t)(w + 6) * pb, h + 6);
 }
 void sgr_filter_hip(const uint8_t* dgd8, int32_t w, int32_t h, int32_t stride, int32_t* flt0, int32_t* flt1, int32_t fs, int32_t ep, int32_t bd, int32_t highbd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     void* d_in; size_t pp; const int pb = highbd ? 2 : 1;
     bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 64 && ep >= 0 && ep < 16 && (bd == 8 || bd == 10) && sgr_stage(dgd8, highbd, w, h, stride, &d_in, &pp);
     if (ok) {
@@ -262,7 +267,7 @@ void sgr_filter_hip(const uint8_t* dgd8, int32_t w, int32_t h, int32_t stride, i
 }
 void sgr_apply_hip(const uint8_t* dat8, int32_t w, int32_t h, int32_t stride, int32_t eps, const int32_t* xqd, uint8_t* dst8, int32_t dst_stride, int32_t* tmpbuf,
                    int32_t bd, int32_t highbd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     void* d_in; size_t pp; const int pb = highbd ? 2 : 1;
     // one call = one processing unit (<= 64 x 64) of one stripe: a single restoration unit, rows attributed from the unit's own origin
     bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 56 && eps >= 0 && eps < 16 && (bd == 8 || bd == 10) && sgr_stage(dat8, highbd, w, h, stride, &d_in, &pp);
@@ -293,19 +298,19 @@ bool obmc_generic(const uint8_t* pre, int pre_stride, const int32_t* wsrc, const
            svt_hip_obmc_cost_batch_dev(g_ctx, d_pre, (int)pp, d_w, d_m, (const SvtHipObmcBlk*)d_job, 1, d_out) == 0 && down(res, d_out, 12);
 }
 template <int IDX, int W, int H> unsigned obmc_sad_hip(const uint8_t* pre, int ps, const int32_t* wsrc, const int32_t* mask) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     uint32_t r[3];
     if (obmc_generic(pre, ps, wsrc, mask, W, H, 0, 0, r)) return r[0];
     FALLBACK("svt_aom_obmc_sadWxH", svt_aom_obmc_sad[IDX], pre, ps, wsrc, mask);
 }
 template <int IDX, int W, int H> unsigned obmc_var_hip(const uint8_t* pre, int ps, const int32_t* wsrc, const int32_t* mask, unsigned* sse) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     uint32_t r[3];
     if (obmc_generic(pre, ps, wsrc, mask, W, H, 0, 0, r)) { *sse = r[1]; return r[2]; }
     FALLBACK("svt_aom_obmc_varianceWxH", svt_aom_obmc_variance[IDX], pre, ps, wsrc, mask, sse);
 }
 template <int IDX, int W, int H> unsigned obmc_subvar_hip(const uint8_t* pre, int ps, int xo, int yo, const int32_t* wsrc, const int32_t* mask, unsigned* sse) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     uint32_t r[3];
     if (xo >= 0 && xo < 8 && yo >= 0 && yo < 8 && obmc_generic(pre, ps, wsrc, mask, W, H, xo, yo, r)) { *sse = r[1]; return r[2]; }
     FALLBACK("svt_aom_obmc_sub_pixel_varianceWxH", svt_aom_obmc_sub_pixel_variance[IDX], pre, ps, xo, yo, wsrc, mask, sse);
@@ -328,32 +333,32 @@ bool blend_generic(int pix_bytes, void* dst, int dst_stride, const void* s0, int
            down2d(dst, (size_t)dst_stride * pix_bytes, dd, p, (size_t)w * pix_bytes, h);
 }
 void blend_mask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, (int)ms, w, h, 0, subw, subh)) return;
     FALLBACK("svt_aom_blend_a64_mask", svt_aom_blend_a64_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh);
 }
 void blend_hmask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 1, 0, 0)) return;
     FALLBACK("svt_aom_blend_a64_hmask", svt_aom_blend_a64_hmask, dst, ds, s0, s0s, s1, s1s, mask, w, h);
 }
 void blend_vmask_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(1, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 2, 0, 0)) return;
     FALLBACK("svt_aom_blend_a64_vmask", svt_aom_blend_a64_vmask, dst, ds, s0, s0s, s1, s1s, mask, w, h);
 }
 void blend_mask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh, int bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, (int)ms, w, h, 0, subw, subh)) return;
     FALLBACK("svt_aom_highbd_blend_a64_mask", svt_aom_highbd_blend_a64_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, bd);
 }
 void blend_hmask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h, int bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 1, 0, 0)) return;
     FALLBACK("svt_aom_highbd_blend_a64_hmask_8bit", svt_aom_highbd_blend_a64_hmask_8bit, dst, ds, s0, s0s, s1, s1s, mask, w, h, bd);
 }
 void blend_vmask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t s0s, const uint8_t* s1, uint32_t s1s, const uint8_t* mask, int w, int h, int bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (blend_generic(2, dst, (int)ds, s0, (int)s0s, s1, (int)s1s, mask, 0, w, h, 2, 0, 0)) return;
     FALLBACK("svt_aom_highbd_blend_a64_vmask_8bit", svt_aom_highbd_blend_a64_vmask_8bit, dst, ds, s0, s0s, s1, s1s, mask, w, h, bd);
 }
@@ -380,13 +385,13 @@ bool warp_generic(int pix_bytes, int bd, const int32_t* mat, const void* ref, in
 }
 void warp_hip(const int32_t* mat, const uint8_t* ref, int width, int height, int stride, uint8_t* pred, int p_col, int p_row, int p_width, int p_height, int p_stride, int ssx,
               int ssy, SvtHipConvolveParams* cp, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (warp_generic(1, 8, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta)) return;
     FALLBACK("svt_av1_warp_affine", svt_av1_warp_affine, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta);
 }
 void warp_hbd_hip(const int32_t* mat, const uint16_t* ref, int width, int height, int stride, uint16_t* pred, int p_col, int p_row, int p_width, int p_height, int p_stride,
                   int ssx, int ssy, int bd, SvtHipConvolveParams* cp, int16_t alpha, int16_t beta, int16_t gamma, int16_t delta) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if ((bd == 8 || bd == 10 || bd == 12) && warp_generic(2, bd, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, cp, alpha, beta, gamma, delta)) return;
     FALLBACK("svt_av1_highbd_warp_affine", svt_av1_highbd_warp_affine, mat, ref, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, ssx, ssy, bd, cp, alpha, beta, gamma, delta);
 }
@@ -409,12 +414,12 @@ bool stats_generic(int pix_bytes, int bd, int win, const void* dgd, const void* 
            down(M, d_M, (size_t)w2 * 8) && down(H, d_H, (size_t)w2 * w2 * 8);
 }
 void stats_hip(int32_t win, const uint8_t* dgd, const uint8_t* src, int32_t h0, int32_t h1, int32_t v0, int32_t v1, int32_t ds, int32_t ss, int64_t* M, int64_t* H) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if (stats_generic(1, 8, win, dgd, src, h0, h1, v0, v1, ds, ss, M, H)) return;
     FALLBACK("svt_av1_compute_stats", svt_av1_compute_stats, win, dgd, src, h0, h1, v0, v1, ds, ss, M, H);
 }
 void stats_hbd_hip(int32_t win, const uint8_t* dgd8, const uint8_t* src8, int32_t h0, int32_t h1, int32_t v0, int32_t v1, int32_t ds, int32_t ss, int64_t* M, int64_t* H, int32_t bd) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     if ((bd == 8 || bd == 10 || bd == 12) &&
         stats_generic(2, bd, win, (const void*)((uintptr_t)dgd8 << 1), (const void*)((uintptr_t)src8 << 1), h0, h1, v0, v1, ds, ss, M, H)) return;
     FALLBACK("svt_av1_compute_stats_highbd", svt_av1_compute_stats_highbd, win, dgd8, src8, h0, h1, v0, v1, ds, ss, M, H, bd);
@@ -424,7 +429,7 @@ void stats_hbd_hip(int32_t win, const uint8_t* dgd8, const uint8_t* src8, int32_
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     if (!ctx || !t) return SVT_HIP_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    Guard lk;
     g_ctx = ctx;
     g_c = *t;
     t->svt_sad_loop_kernel = sad_loop_hip;

@@ -16,6 +16,7 @@ struct SvtHipCtx {
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     int         me_waves = 4;   // 256 threads per SB: measured best on MI355X (tools/me_time.py)
+    int         me_big = 1;     // also launch the strip-walking instance for search areas above 65 536 candidates
     void*       scratch = nullptr;   // library-owned device scratch (16-bit Wiener statistics, self-guided unit search), grown on demand
     size_t      scratch_bytes = 0;
     void*       host_scratch = nullptr;   // pinned host staging of the self-guided unit search
@@ -31,6 +32,13 @@ static int fail(SvtHipCtx* c, hipError_t e, const char* what) {
     do {                                                  \
         hipError_t e_ = (call);                           \
         if (e_ != hipSuccess) return fail((c), e_, #call); \
+    } while (0)
+
+// Every entry point makes the context's device current first: one encoder process may drive several GPUs, each from its own host thread
+// ("host worker i owns GPU i"); hipSetDevice is a thread-local switch.
+#define SVT_HIP_ENTER(c)                                                              \
+    do {                                                                              \
+        if ((c) && hipSetDevice((c)->device) != hipSuccess) return SVT_HIP_ERR_RUNTIME; \
     } while (0)
 
 extern "C" {
@@ -73,34 +81,41 @@ void svt_hip_destroy(SvtHipCtx* c) {
 const char* svt_hip_last_error(const SvtHipCtx* c) { return c ? c->err.c_str() : "null context"; }
 
 int svt_hip_set_stream(SvtHipCtx* c, void* s) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return SVT_HIP_OK;
 }
 void* svt_hip_ctx_stream(SvtHipCtx* c) { return c ? (void*)c->stream : nullptr; }
+int   svt_hip_ctx_device(SvtHipCtx* c) { return c ? c->device : 0; }
 int svt_hip_sync(SvtHipCtx* c) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SVT_HIP_OK;
 }
 int svt_hip_malloc(SvtHipCtx* c, void** p, size_t bytes) {
+    SVT_HIP_ENTER(c);
     if (!c || !p) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(p, bytes ? bytes : 4));
     return SVT_HIP_OK;
 }
 int svt_hip_free(SvtHipCtx* c, void* p) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipFree(p));
     return SVT_HIP_OK;
 }
 int svt_hip_memcpy_h2d(SvtHipCtx* c, void* d, const void* h, size_t bytes) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SVT_HIP_OK;
 }
 int svt_hip_memcpy_d2h(SvtHipCtx* c, void* h, const void* d, size_t bytes) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -113,6 +128,8 @@ int svt_hip_memcpy_d2d(SvtHipCtx* c, void* dst, const void* src, size_t bytes) {
     return SVT_HIP_OK;
 }
 int svt_hip_memcpy2d_h2d(SvtHipCtx* c, void* d, size_t dpitch, const void* h, size_t hpitch, size_t wbytes, size_t rows) {
+    SVT_HIP_ENTER(c);
+    SVT_HIP_ENTER(c);
     if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
     if (!wbytes || !rows) return SVT_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -121,6 +138,7 @@ int svt_hip_memcpy2d_h2d(SvtHipCtx* c, void* d, size_t dpitch, const void* h, si
     return SVT_HIP_OK;
 }
 int svt_hip_memcpy2d_d2h(SvtHipCtx* c, void* h, size_t hpitch, const void* d, size_t dpitch, size_t wbytes, size_t rows) {
+    SVT_HIP_ENTER(c);
     if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
     if (!wbytes || !rows) return SVT_HIP_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -129,11 +147,13 @@ int svt_hip_memcpy2d_d2h(SvtHipCtx* c, void* h, size_t hpitch, const void* d, si
     return SVT_HIP_OK;
 }
 int svt_hip_timer_start(SvtHipCtx* c) {
+    SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return SVT_HIP_OK;
 }
 int svt_hip_timer_stop_ms(SvtHipCtx* c, float* ms) {
+    SVT_HIP_ENTER(c);
     if (!c || !ms) return SVT_HIP_ERR_BAD_ARG;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -143,21 +163,30 @@ int svt_hip_timer_stop_ms(SvtHipCtx* c, float* ms) {
 
 /* ------------------------------------------------------------------------------------------- ME */
 int svt_hip_me_set_waves_per_sb(SvtHipCtx* c, int waves) {
+    SVT_HIP_ENTER(c);
     const int w = waves & 15;   // bits 4.. = KiB of LDS padding (experimental single-workgroup-per-CU mode, see me_fullpel.hip)
     if (!c || (w != 1 && w != 2 && w != 4) || (waves >> 4) > 120) return SVT_HIP_ERR_BAD_ARG;
     c->me_waves = waves;
     return SVT_HIP_OK;
 }
 
+int svt_hip_me_set_big_windows(SvtHipCtx* c, int enable) {
+    SVT_HIP_ENTER(c);
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    c->me_big = enable != 0;
+    return SVT_HIP_OK;
+}
+
 int svt_hip_me_fullpel_frame_dev(SvtHipCtx* c, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                                  int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
                                  uint32_t* d_best_mv) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_src || !d_ref || !d_sbs || !d_best_sad || !d_best_mv || n_sb < 0 || (stride & 3)) {
         if (c) c->err = "svt_hip_me_fullpel_frame_dev: bad argument (stride must be a multiple of 4)";
         return SVT_HIP_ERR_BAD_ARG;
     }
     hipError_t e = (hipError_t)svt_hip_launch_me_fullpel(c->stream, d_src, d_ref, stride, org_x, org_y, d_sbs, n_sb,
-                                                        sub_sad, d_best_sad, d_best_mv, c->me_waves);
+                                                        sub_sad, d_best_sad, d_best_mv, c->me_waves, c->me_big);
     if (e != hipSuccess) return fail(c, e, "me_fullpel launch");
     return SVT_HIP_OK;
 }
@@ -165,12 +194,18 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx* c, const uint8_t* d_src, const uint8
 int svt_hip_me_fullpel_frame(SvtHipCtx* c, const uint8_t* src, const uint8_t* ref, int stride, int plane_rows, int org_x,
                              int org_y, const SvtHipSbSearch* sbs, int n_sb, int sub_sad, uint32_t* best_sad,
                              uint32_t* best_mv) {
+    SVT_HIP_ENTER(c);
     if (!c || !src || !ref || !sbs || !best_sad || !best_mv || n_sb < 0 || plane_rows <= 0) return SVT_HIP_ERR_BAD_ARG;
-    for (int i = 0; i < n_sb; i++)
-        if ((int)sbs[i].width * (int)sbs[i].height > 65536 || sbs[i].width < 0 || sbs[i].height < 0) {
-            c->err = "svt_hip_me_fullpel_frame: search area larger than 65536 candidates";
-            return SVT_HIP_ERR_UNSUPPORTED;
+    int big = 0;
+    for (int i = 0; i < n_sb; i++) {
+        if (sbs[i].width < 0 || sbs[i].height < 0) {
+            c->err = "svt_hip_me_fullpel_frame: negative search area";
+            return SVT_HIP_ERR_BAD_ARG;
         }
+        big |= (int)sbs[i].width * (int)sbs[i].height > 65536;
+    }
+    const int saved_big = c->me_big;
+    c->me_big = big;   // the windows are known here: launch the strip-walking instance only when one needs it
     const size_t plane = (size_t)stride * plane_rows, nres = (size_t)n_sb * SVT_HIP_SQUARE_PU_COUNT * 4;
     uint8_t *d_src = nullptr, *d_ref = nullptr;
     SvtHipSbSearch* d_sbs = nullptr;
@@ -186,6 +221,7 @@ int svt_hip_me_fullpel_frame(SvtHipCtx* c, const uint8_t* src, const uint8_t* re
     if ((rc = svt_hip_me_fullpel_frame_dev(c, d_src, d_ref, stride, org_x, org_y, d_sbs, n_sb, sub_sad, d_sad, d_mv))) goto done;
     if ((rc = svt_hip_memcpy_d2h(c, best_sad, d_sad, nres)) || (rc = svt_hip_memcpy_d2h(c, best_mv, d_mv, nres))) goto done;
 done:
+    c->me_big = saved_big;
     if (d_src) (void)hipFree(d_src);
     if (d_ref) (void)hipFree(d_ref);
     if (d_sbs) (void)hipFree(d_sbs);
@@ -200,6 +236,7 @@ int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, c
                                      const SvtHipQuantParams* qp, const SvtHipScanTables* scans, int32_t* d_coeff,
                                      int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob, int32_t* d_cul_level,
                                      uint64_t* d_energy) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_src || !d_pred || !d_descs || nblk < 0 || tx_size < 0 || tx_size > 18 || (pix_bytes != 1 && pix_bytes != 2) ||
         ((d_qcoeff != nullptr) != (d_dqcoeff != nullptr)) || (d_qcoeff && (!qp || !scans || !scans->iscan[0])) ||
         (qp && (qp->variant < 0 || qp->variant > 3 || qp->log_scale < 0 || qp->log_scale > 2 || qp->coeff_shape < 0 || qp->coeff_shape > 3))) {
@@ -215,6 +252,7 @@ int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, c
 
 int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int bd, const int32_t* d_dqcoeff, const void* d_pred,
                                    int pred_stride, void* d_recon, int recon_stride, const uint32_t* d_descs, int nblk) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_dqcoeff || !d_pred || !d_recon || !d_descs || nblk < 0 || tx_size < 0 || tx_size > 18 ||
         (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) {
         if (c) c->err = "svt_hip_inv_txfm_add_batch_dev: bad argument";
@@ -229,6 +267,7 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int
 /* ------------------------------------------------------------------------------- deblocking */
 int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int bd, const uint16_t* d_edges_v,
                               const uint16_t* d_edges_h, int units_w, int units_h, int sharpness) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_plane || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || units_w < 0 ||
         units_h < 0 || sharpness < 0 || sharpness > 7 || (!d_edges_v && !d_edges_h)) {
         if (c) c->err = "svt_hip_deblock_plane_dev: bad argument";
@@ -242,6 +281,7 @@ int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int st
 
 int svt_hip_deblock_frame_dev(SvtHipCtx* c, void* const d_plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t* const d_edges_v[3],
                               const uint16_t* const d_edges_h[3], const int units_w[3], const int units_h[3], int sharpness) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_plane || !stride || !d_edges_v || !d_edges_h || !units_w || !units_h || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) ||
         (pix_bytes == 1 && bd != 8) || sharpness < 0 || sharpness > 7) {
         if (c) c->err = "svt_hip_deblock_frame_dev: bad argument";
@@ -256,6 +296,7 @@ int svt_hip_deblock_frame_dev(SvtHipCtx* c, void* const d_plane[3], int pix_byte
 
 int svt_hip_plane_sse_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, int w, int h,
                           uint64_t* d_sse) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_a || !d_b || !d_sse || (pix_bytes != 1 && pix_bytes != 2) || w <= 0 || h <= 0) {
         if (c) c->err = "svt_hip_plane_sse_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
@@ -271,6 +312,7 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
                                  int bd, int plane_w, int plane_h, const void* d_src, int src_stride, const uint16_t* d_edges_v,
                                  const uint16_t* d_edges_h, int units_w, int units_h, uint64_t* d_sse_scratch, int* best_level,
                                  int64_t* best_err_out) {
+    SVT_HIP_ENTER(c);
     if (!c || !p || !d_recon || !d_tmp || !d_src || !d_edges_v || !d_edges_h || !d_sse_scratch || !best_level || p->plane < 0 ||
         p->plane > 2 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || plane_w <= 0 ||
         plane_h <= 0 || units_w != (plane_w + 3) / 4 || units_h != (plane_h + 3) / 4 || p->sharpness < 0 || p->sharpness > 7) {
@@ -297,6 +339,7 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
 }
 
 int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs) {
+    SVT_HIP_ENTER(c);
     if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
     for (int j = 0; j < njobs; j++) {
         const SvtHipFwdTxJob& J = jobs[j];
@@ -312,6 +355,7 @@ int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFw
     return SVT_HIP_OK;
 }
 int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx* c, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs) {
+    SVT_HIP_ENTER(c);
     if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8))
         return SVT_HIP_ERR_BAD_ARG;
     for (int j = 0; j < njobs; j++) {
@@ -330,6 +374,7 @@ int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx* c, int pix_bytes, int bd, const Sv
 int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_rec[3], const int rec_stride[3],
                                   const void* const d_src[3], const int src_stride[3], int w, int h, const uint8_t* d_skip8,
                                   int pri_damping, int bd, uint64_t* d_mse, uint8_t* d_dir, int32_t* d_var) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_rec || !d_src || !rec_stride || !src_stride || !d_skip8 || !d_mse || !d_dir || !d_var || (pix_bytes != 1 && pix_bytes != 2) ||
         (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7) || ((w & 63) && (w & 63) < 16) ||
         ((h & 63) && (h & 63) < 16)) {
@@ -344,6 +389,7 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const
 int svt_hip_cdef_apply_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const d_in[3], void* const d_out[3], const int stride[3], int w,
                                  int h, const uint8_t* d_skip8, const uint8_t* d_y_strength, const uint8_t* d_uv_strength, int damping,
                                  int bd, uint8_t* d_dir, const int32_t* d_var) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_in || !d_out || !stride || !d_skip8 || !d_y_strength || !d_uv_strength || !d_dir || (pix_bytes != 1 && pix_bytes != 2) ||
         (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7)) {
         if (c) c->err = "svt_hip_cdef_apply_frame_dev: bad argument";
@@ -358,6 +404,7 @@ int svt_hip_cdef_apply_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const 
 /* -------------------------------------------------------------- sub-pel predict / SAD / variance */
 int svt_hip_subpel_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref, int ref_stride, void* d_dst, int dst_stride,
                                      const SvtHipConvBlk* d_blks, int nblk) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_ref || !d_dst || !d_blks || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) {
         if (c) c->err = "svt_hip_subpel_predict_batch_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
@@ -368,12 +415,14 @@ int svt_hip_subpel_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
 }
 int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride,
                                 const SvtHipBlkPair* d_pairs, int n, uint32_t* d_sad) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_a || !d_b || !d_pairs || !d_sad || n < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_block_sad(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, d_pairs, n, d_sad);
     if (e != hipSuccess) return fail(c, e, "block sad launch");
     return SVT_HIP_OK;
 }
 int svt_hip_coeff_distortion_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, const int32_t* d_recon_coeff, int n_per_block, int nblk, uint64_t* d_out) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_coeff || !d_out || n_per_block <= 0 || nblk < 0) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_coeff_distortion(c->stream, d_coeff, d_recon_coeff, n_per_block, nblk, d_out);
     if (e != hipSuccess) return fail(c, e, "coeff distortion launch");
@@ -381,6 +430,7 @@ int svt_hip_coeff_distortion_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, con
 }
 int svt_hip_block_sse_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, const SvtHipBlkPair* d_pairs,
                                 int n, uint64_t* d_sse) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_a || !d_b || !d_pairs || !d_sse || n < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_block_sse(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, d_pairs, n, d_sse);
     if (e != hipSuccess) return fail(c, e, "block sse launch");
@@ -388,6 +438,7 @@ int svt_hip_block_sse_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, in
 }
 int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_a, int a_stride, const void* d_b, int b_stride,
                                      const SvtHipBlkPair* d_pairs, int n, uint32_t* d_var, uint32_t* d_sse) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_a || !d_b || !d_pairs || !d_var || n < 0 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd == 10))) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_block_variance(c->stream, pix_bytes, bd, d_a, a_stride, d_b, b_stride, d_pairs, n, d_var, d_sse);
     if (e != hipSuccess) return fail(c, e, "block variance launch");
@@ -397,6 +448,7 @@ int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
 /* ------------------------------------------------------------------- pyramids / HME search */
 int svt_hip_downsample_2d_dev(SvtHipCtx* c, const uint8_t* d_in, int in_stride, int w, int h, uint8_t* d_out, int out_stride, int step,
                               int filtered) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_in || !d_out || (step != 2 && step != 4) || w < step || h < step) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_downsample(c->stream, d_in, in_stride, w, h, d_out, out_stride, step, filtered);
     if (e != hipSuccess) return fail(c, e, "downsample launch");
@@ -404,6 +456,7 @@ int svt_hip_downsample_2d_dev(SvtHipCtx* c, const uint8_t* d_in, int in_stride, 
 }
 int svt_hip_variance_pyramid_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, int sb_cols, int n_sb, int full_precision,
                                  uint8_t* d_mean, uint16_t* d_var) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_plane || !d_mean || !d_var || sb_cols <= 0 || n_sb < 0 || (stride & 7) || ((uintptr_t)d_plane & 7)) {
         if (c) c->err = "svt_hip_variance_pyramid_dev: bad argument (plane and stride must be 8-byte aligned)";
         return SVT_HIP_ERR_BAD_ARG;
@@ -414,6 +467,7 @@ int svt_hip_variance_pyramid_dev(SvtHipCtx* c, const uint8_t* d_plane, int strid
 }
 int svt_hip_sad_loop_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, const uint8_t* d_ref, int ref_stride,
                                const SvtHipSadLoop* d_searches, int n, uint32_t* d_best_sad, int16_t* d_best_xy) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_src || !d_ref || !d_searches || !d_best_sad || !d_best_xy || n < 0) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sad_loop(c->stream, d_src, src_stride, d_ref, ref_stride, d_searches, n, d_best_sad, d_best_xy);
     if (e != hipSuccess) return fail(c, e, "sad loop launch");
@@ -422,6 +476,7 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_strid
 
 int svt_hip_sad_loop16_batch_dev(SvtHipCtx* c, const uint16_t* d_src, int src_stride, const uint16_t* d_ref, int ref_stride, const SvtHipSadLoop* d_searches, int n,
                                  uint32_t* d_best_sad, int16_t* d_best_xy) {
+    SVT_HIP_ENTER(c);
     if (!c || n < 0) return SVT_HIP_ERR_BAD_ARG;
     if (n == 0) return SVT_HIP_OK;
     if (!d_src || !d_ref || !d_searches || !d_best_sad || !d_best_xy) return SVT_HIP_ERR_BAD_ARG;
@@ -438,6 +493,7 @@ static int sgr_units(int size, int unit) { const int n = (size + unit / 2) / uni
 
 int svt_hip_sgr_filter_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_plane, int stride, int pw, int ph, int ep,
                                  int32_t* d_flt0, int32_t* d_flt1, int flt_stride) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_plane || !d_flt0 || !d_flt1 || ep < 0 || ep > 15 || !sgr_args_ok(pix_bytes, bd, pw, ph)) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sgr_filter(c->stream, pix_bytes, bd, d_plane, stride, pw, ph, ep, d_flt0, d_flt1, flt_stride);
     if (e != hipSuccess) return fail(c, e, "sgr filter launch");
@@ -445,6 +501,7 @@ int svt_hip_sgr_filter_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void
 }
 int svt_hip_sgr_search_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                  int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int64_t* d_sums) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_dgd || !d_src || !d_sums || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) || !sgr_args_ok(pix_bytes, bd, pw, ph))
         return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size,
@@ -455,12 +512,14 @@ int svt_hip_sgr_search_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw,
                                 int ph, int unit_size, int ss_y, const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep,
                                 const int32_t* d_unit_xqd) {
+    SVT_HIP_ENTER(c);
     return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size, ss_y, d_dbl, dbl_stride, d_unit_ep,
                                       d_unit_xqd, nullptr);
 }
 int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw, int ph,
                                int unit_size, int ss_y, const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd,
                                const int16_t* d_unit_wiener) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
         !sgr_args_ok(pix_bytes, bd, pw, ph))
         return SVT_HIP_ERR_BAD_ARG;
@@ -473,6 +532,7 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* 
 
 int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                      int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand, const int32_t* d_xqd, int64_t* d_err) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_dgd || !d_src || !d_xqd || !d_err || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) || ncand < 1 ||
         ncand > SVT_HIP_SGR_MAX_CAND || !sgr_args_ok(pix_bytes, bd, pw, ph))
         return SVT_HIP_ERR_BAD_ARG;
@@ -585,6 +645,7 @@ bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, const int64_t
 }  // namespace
 
 int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane* planes, int* rounds_out) {
+    SVT_HIP_ENTER(c);
     if (!c || !planes || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
     const int NC = SVT_HIP_SGR_MAX_CAND;
     struct Job { int nu; size_t sums_o, xqd_o, err_o; std::vector<SgrItem> items; uint32_t mask; };
@@ -726,12 +787,14 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_
 int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
                                    int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep,
                                    int* rounds_out) {
+    SVT_HIP_ENTER(c);
     const SvtHipSgrSearchPlane P = {d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, xqd_out, err_out, best_ep};
     return svt_hip_sgr_search_units_picture(c, pix_bytes, bd, 1, &P, rounds_out);
 }
 
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                    int pw, int ph, int unit_size, int ss_y, int64_t* d_M, int64_t* d_H) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_dgd || !d_src || !d_M || !d_H || (win != 7 && win != 5 && win != 3) || unit_size < 64 || (unit_size & 63) || unit_size > 256 ||
         (ss_y != 0 && ss_y != 1) || pw <= 0 || ph <= 0)
         return SVT_HIP_ERR_BAD_ARG;
@@ -763,6 +826,7 @@ int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win,
 int svt_hip_tf_filter_frame_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* const d_src[3], const int src_stride[3], void* const d_dst[3],
                                 const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef* refs, int n_refs,
                                 const double noise_levels[3], int decay_control, int min_frame_size, uint64_t* d_sse) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_src || !src_stride || !d_dst || !dst_stride || !refs || !noise_levels || !d_sse || (pix_bytes != 1 && pix_bytes != 2) ||
         (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && (bd < 8 || bd > 12)) || w <= 0 || h <= 0 || (w & 63) || (h & 63) || n_refs < 1 ||
         n_refs > SVT_HIP_TF_MAX_REFS || (ss_x != 0 && ss_x != 1) || (ss_y != 0 && ss_y != 1) || (ss_y == 1 && ss_x == 0) || decay_control <= 0) {
@@ -791,6 +855,7 @@ int svt_hip_tf_filter_frame_dev(SvtHipCtx* c, int pix_bytes, int bd, const void*
 }
 
 int svt_hip_tf_estimate_noise_dev(SvtHipCtx* c, const void* d_src, int pix_bytes, int bd, int width, int height, int stride, int64_t* d_out) {
+    SVT_HIP_ENTER(c);
     if (!c || !d_src || !d_out || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && (bd < 8 || bd > 12)) ||
         width <= 0 || height <= 0 || stride < width)
         return SVT_HIP_ERR_BAD_ARG;
@@ -803,6 +868,7 @@ int svt_hip_tf_estimate_noise_dev(SvtHipCtx* c, const void* d_src, int pix_bytes
 
 int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref0, int ref0_stride, const void* d_ref1, int ref1_stride,
                                        void* d_dst, int dst_stride, uint8_t* d_masks, const SvtHipCompBlk* d_blks, int nblk) {
+    SVT_HIP_ENTER(c);
     if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10 && bd != 12)) {
         if (c) c->err = "svt_hip_compound_predict_batch_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
@@ -816,6 +882,7 @@ int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
 
 int svt_hip_obmc_cost_batch_dev(SvtHipCtx* c, const uint8_t* d_pre, int pre_stride, const int32_t* d_wsrc, const int32_t* d_mask, const SvtHipObmcBlk* d_blks,
                                 int nblk, uint32_t* d_out) {
+    SVT_HIP_ENTER(c);
     if (!c || nblk < 0) return SVT_HIP_ERR_BAD_ARG;
     if (nblk == 0) return SVT_HIP_OK;
     if (!d_pre || !d_wsrc || !d_mask || !d_blks || !d_out) return SVT_HIP_ERR_BAD_ARG;
@@ -826,6 +893,7 @@ int svt_hip_obmc_cost_batch_dev(SvtHipCtx* c, const uint8_t* d_pre, int pre_stri
 
 int svt_hip_warp_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref, int width, int height, int stride, void* d_dst, int dst_stride,
                                    int ss_x, int ss_y, const SvtHipWarpBlk* d_blks, int nblk) {
+    SVT_HIP_ENTER(c);
     if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10 && bd != 12) ||
         (ss_x != 0 && ss_x != 1) || (ss_y != 0 && ss_y != 1)) {
         if (c) c->err = "svt_hip_warp_predict_batch_dev: bad argument";
@@ -840,6 +908,7 @@ int svt_hip_warp_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const vo
 
 int svt_hip_blend_a64_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_src0, int src0_stride, const void* d_src1, int src1_stride, void* d_dst, int dst_stride,
                                 const uint8_t* d_masks, const SvtHipBlendBlk* d_blks, int nblk) {
+    SVT_HIP_ENTER(c);
     if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
     if (nblk == 0) return SVT_HIP_OK;
     if (!d_src0 || !d_src1 || !d_dst || !d_masks || !d_blks) return SVT_HIP_ERR_BAD_ARG;
@@ -850,6 +919,7 @@ int svt_hip_blend_a64_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_src0,
 
 int svt_hip_picture_format_dev(SvtHipCtx* c, int mode, const void* d_in0, int in0_stride, const void* d_in1, int in1_stride, void* d_out0, int out0_stride,
                                void* d_out1, int out1_stride, int w, int h) {
+    SVT_HIP_ENTER(c);
     const bool two_in = mode == 0 || mode == 1 || mode == 6;
     if (!c || mode < 0 || mode > 6 || w < 0 || h < 0 || ((mode == 1 || mode == 5) && (w & 3))) {
         if (c) c->err = "svt_hip_picture_format_dev: bad argument";
@@ -863,6 +933,7 @@ int svt_hip_picture_format_dev(SvtHipCtx* c, int mode, const void* d_in0, int in
 }
 
 int svt_hip_generate_padding_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
+    SVT_HIP_ENTER(c);
     if (!c || (pix_bytes != 1 && pix_bytes != 2) || w < 0 || h < 0 || pad_w < 0 || pad_h < 0) return SVT_HIP_ERR_BAD_ARG;
     if (w == 0 || h == 0 || (pad_w == 0 && pad_h == 0)) return SVT_HIP_OK;
     if (!d_plane || stride < w + pad_w) return SVT_HIP_ERR_BAD_ARG;

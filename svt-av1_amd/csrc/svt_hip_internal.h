@@ -6,10 +6,11 @@
 #include "../../include/svt_hip.h"
 
 extern "C" {
-void* svt_hip_ctx_stream(SvtHipCtx* c);   /* the stream the context launches on (rtcd_hip.cpp) */
+void* svt_hip_ctx_stream(SvtHipCtx* c);
+int   svt_hip_ctx_device(SvtHipCtx* c);   /* the stream the context launches on (rtcd_hip.cpp) */
 int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                               int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
-                              uint32_t* d_best_mv, int waves_per_sb);
+                              uint32_t* d_best_mv, int waves_per_sb, int big_windows);
 int svt_hip_launch_fwd_txfm_quant(hipStream_t st, int tx_size, int pix_bytes, const void* src, int src_stride, const void* pred,
                                   int pred_stride, const uint32_t* descs, int nblk, const SvtHipQuantParams* qp,
                                   const SvtHipScanTables* scans, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,

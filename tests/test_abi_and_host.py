@@ -16,7 +16,7 @@ def _declared_symbols():
     for hdr in ("svt_hip.h", "svt_hip_rtcd.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        syms |= set(re.findall(r"^(?:int|void|const char \*|SvtHipSbSearch)\s*\*?\s*(svt_hip_[a-z0-9_]+)\s*\(", txt, flags=re.M))
+        syms |= set(re.findall(r"^(?:int|void|double|const char \*|SvtHipSbSearch)\s*\*?\s*(svt_hip_[a-z0-9_]+)\s*\(", txt, flags=re.M))
     return sorted(syms)
 
 
@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/*.h but not exported"
+
+
+def test_library_exports_nothing_else(pkg):
+    """-fvisibility=hidden: the dynamic symbol table holds exactly the functions the two public headers declare (no launchers, no helpers)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtWwBbDd" and ln.split()[1].isupper()}
+    exported = {s for s in exported if not s.startswith(("_init", "_fini", "__"))}
+    extra = sorted(exported - set(_declared_symbols()))
+    assert not extra, f"exported but not declared in include/*.h: {extra[:20]}"
 
 
 def test_no_cpu_fallback(pkg):

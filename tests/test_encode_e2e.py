@@ -1,0 +1,106 @@
+"""End-to-end: the reference encoder with the process-loop hooks of integration/ must produce the SAME bitstream and the SAME reconstruction
+as the unpatched reference encoder (BASELINE.json north_star: "drop-in replacement behind the existing C dispatch tables").
+
+* CPU (`-m "not gpu"`): SvtAv1EncApp_hip runs against the CPU test double of the library (oracle/_ref/mock/libsvtav1_hip.so = the oracle
+  kernels + the product's own host logic, svt-av1_amd/csrc/svt_hip_host.cpp).  This pins the glue — patched loops, bridges, the edge
+  builder (set_lpf_parameters), the filter-level search control flow, the CDEF / restoration drivers — against the real encoder.
+* GPU (`-m gpu`): the same binary loads svt-av1_amd/libsvtav1_hip.so; every hooked stage runs on the MI355X.
+Every hook must report handled > 0 and fallback == 0 where the preset uses the stage: a silent fallback to the C loop would pass trivially.
+"""
+import os
+
+import pytest
+
+import e2e_common as E
+
+pytestmark = pytest.mark.skipif(not E.have_apps(), reason="oracle/_ref/SvtAv1EncApp_{ref,hip} not built (make -f oracle/Makefile.enc; needs /root/reference)")
+
+# name: (w, h, frames, bit depth, preset, qp, hooks that must have run)
+ALL = set(E.HOOKS)
+NO_DLF_REST = {"me", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
+CASES = {
+    "cif_8bit_m6": (352, 288, 8, 8, 6, 35, ALL),
+    "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),
+    "360p_8bit_m7": (640, 360, 5, 8, 7, 40, NO_DLF_REST),     # 40 SBs in many ME segments; width % 64 == 0, height % 64 == 40
+    "cif_8bit_m4": (352, 288, 5, 8, 4, 45, ALL),              # full filter-level step search, chroma levels searched on their own
+}
+GPU_ONLY_CASES = {
+    "720p_8bit_m6": (1280, 720, 4, 8, 6, 38, ALL),
+    "720p_10bit_m5": (1280, 720, 3, 10, 5, 32, ALL),
+}
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("e2e"))
+
+
+_ref_cache = {}
+
+
+def _reference(case, spec, workdir):
+    """clip + the unpatched reference encode (cached per module run)"""
+    if case not in _ref_cache:
+        w, h, n, bd, preset, q, _ = spec
+        clip = os.path.join(workdir, case + ".src.yuv")
+        E.make_clip(clip, w, h, n, seed=len(case) * 7 + w, bd=bd)
+        _ref_cache[case] = (clip, E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".ref")))
+    return _ref_cache[case]
+
+
+def _check(case, spec, workdir, env, tag):
+    w, h, n, bd, preset, q, must = spec
+    clip, ref = _reference(case, spec, workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.{tag}"), env_extra=env)
+    assert got["ivf"] == ref["ivf"], f"{case}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
+    assert got["recon"] == ref["recon"], f"{case}: reconstruction differs from the reference encoder"
+    for hk in must:
+        handled, fallback = got["hooks"].get(hk, (0, 0))
+        assert handled > 0 and fallback == 0, f"{case}: hook {hk} handled={handled} fallback={fallback}\n" + got["log"][-2000:]
+    return got
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_patched_encoder_without_hooks_is_the_reference(case, workdir):
+    """SVT_HIP_HOOKS unset: the patch itself changes nothing."""
+    w, h, n, bd, preset, q, _ = CASES[case]
+    if case != "cif_8bit_m6":
+        pytest.skip("one case is enough for the no-op check")
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".nohook"), env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR})
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"]) and not got["hooks"]
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_hooked_encode_on_cpu_test_double(case, workdir):
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+    assert "svt_hip MOCK" in got["log"]
+
+
+@pytest.mark.parametrize("stage", E.HOOKS)
+def test_every_hook_matters(stage, workdir):
+    """A deliberately wrong answer of ONE stage (SVT_HIP_MOCK_PERTURB) must change the bitstream or the reconstruction: the comparison above
+    is sensitive to every hook's output, none of them is dead weight."""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_{stage}"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_MOCK_PERTURB": stage})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"]), f"perturbing {stage} went unnoticed"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES) + list(GPU_ONLY_CASES))
+def test_hooked_encode_on_gpu(case, workdir):
+    spec = CASES.get(case) or GPU_ONLY_CASES[case]
+    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+    assert "svt_hip MOCK" not in got["log"], "the GPU test must load svt-av1_amd/libsvtav1_hip.so, not the CPU test double"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", E.HOOKS)
+def test_single_hook_on_gpu(hook, workdir):
+    """Each hook alone (the others on the C path): a mismatch bisects to a stage."""
+    case = "cif_8bit_m6"
+    spec = CASES[case][:6] + ({hook},)
+    _check(case, spec, workdir, {"SVT_HIP_HOOKS": hook}, "hip_" + hook)

@@ -114,3 +114,25 @@ def test_maximum_search_area(hip, orc):
     cur[64:128, 64:192] = 90; refp[:, :96] = 90; refp[40:200, 150:300] = 90   # large flat areas -> ties
     _run(hip, orc, cur, refp, w, h, 256, 256, 0)
     _run(hip, orc, cur, refp, w, h, 256, 256, 1)
+
+
+@pytest.mark.parametrize("sub", [0, 1])
+def test_search_area_above_65536_candidates(hip, orc, sub):
+    """Search areas larger than the 16-bit raster index of the packed keys (the reference configures up to 750 x 750,
+    EbMotionEstimationProcess.c:124-137) take the strip-walking instance of the kernel: strips of whole candidate rows merged with the strict
+    '<' of the reference.  336 x 200 = 67 200 candidates -> a 195-row strip and a 5-row strip; flat content makes exact ties across the
+    strip boundary common.  Mixed with ordinary 64 x 64 windows in the same call (the small ones must be left to the ordinary instance)."""
+    w, h = 384, 320
+    cur, refp = mc.synth.make_luma_pair(w, h, seed=23)
+    cur[100:180, 60:300] = 77; refp[:, 40:340] = 77   # ties everywhere in the middle band, across the strip boundary
+    pad = mc.synth.PAD
+    cur_p, ref_p = mc.synth.pad_plane(cur), mc.synth.pad_plane(refp)
+    stride = cur_p.shape[1]
+    big = mc.windows(orc, w, h, 336, 200)
+    small = mc.windows(orc, w, h, 64, 64)
+    pick = [7, 8, 14, 15]                                  # inner SBs: the clamp leaves the whole 336 x 200 window
+    sbs = (type(big[0]) * 8)(*([big[i] for i in pick] + [small[i] for i in pick]))
+    assert all(sbs[i].width * sbs[i].height > 65536 for i in range(4))
+    o_sad, o_mv = mc.oracle_frame(orc, cur_p, ref_p, stride, pad, sbs, sub)
+    g_sad, g_mv = mc.hip_frame(hip, cur_p, ref_p, stride, pad, sbs, sub)
+    assert np.array_equal(g_sad, o_sad) and np.array_equal(g_mv, o_mv)
