@@ -380,17 +380,27 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, cons
                                      int src_stride, int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand,
                                      const int32_t *d_xqd, int64_t *d_err);
 /* search_selfguided_restoration (EbRestorationPick.c:583-671) for every restoration unit of a plane and every parameter set in
- * ep_mask (the reference's [start_ep, end_ep) window around the reference frames' sets, :596-607, is the caller's mask): projection
- * sums on the GPU, svt_get_proj_subspace's 2x2 solve (:497-538) and encode_xq (:539) on the host, then
- * finer_search_pixel_proj_error (:353-446, start step 2) replayed on the host over errors that svt_hip_sgr_proj_error_plane_dev evaluates
- * in rounds (one launch per round for all units and sets; the points the walk will visit are predicted with the quadratic model of the
- * five sums, so a round usually covers a whole walk; a misprediction costs another round, never exactness).
- * HOST outputs: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched), best_ep[unit] (may be NULL) = the first set
- * with the smallest error; *rounds_out (may be NULL) = error launches used.  Synchronous; uses library-owned device scratch. */
+ * ep_mask (the reference's [start_ep, end_ep) window around the reference frames' sets, :596-607, is the caller's mask), ENTIRELY ON THE DEVICE:
+ * the projection sums, svt_get_proj_subspace's 2x2 solve in IEEE double (:497-538), encode_xq (:539) and the coordinate descent of
+ * finer_search_pixel_proj_error (:353-446, start step 2) — one workgroup per (unit, set) replays the reference's walk on exactly evaluated
+ * errors (speculating ahead on the quadratic model of the five sums; a misprediction costs another pass over the unit, never exactness) — and the
+ * unit's best set.  Two launches, no host synchronisation; stream-ordered like every _dev call.
+ *   d_xqd [units][16][2], d_err [units][16] (entries of sets outside the mask are not written),
+ *   d_best_ep [units] (may be NULL) = the first set with the smallest error, d_best_xqd [units][2] (may be NULL) = its xqd: exactly the
+ *   d_unit_ep / d_unit_xqd arrays svt_hip_sgr_apply_plane_dev takes, so search -> trial filter -> SSE chains on the device.
+ *   d_scratch: svt_hip_sgr_search_units_scratch_bytes(pw, ph, unit_size) bytes, 16-byte aligned, private to this call until it has completed
+ *   (sums, arrival counters, and 33 int16 planes: flt0 - u and flt1 - u per filter, dat - src). */
+size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size);
+int svt_hip_sgr_search_units_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride, int pw,
+                                       int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *d_xqd, int64_t *d_err, uint8_t *d_best_ep,
+                                       int32_t *d_best_xqd, void *d_scratch, size_t scratch_bytes);
+/* HOST-output convenience form on library-owned device scratch: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched),
+ * best_ep[unit] (may be NULL); *rounds_out (may be NULL) is always 0 (kept from the host-driven search of earlier versions).  Synchronous: one
+ * stream synchronisation at the end to hand the results over. */
 int svt_hip_sgr_search_units_plane(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride,
                                    int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *xqd_out, int64_t *err_out,
                                    uint8_t *best_ep, int *rounds_out);
-/* The same for up to three planes of a picture with shared rounds (one host synchronisation per round for the whole picture). */
+/* The same for up to three planes of a picture (all launches first, then one hand-over per plane). */
 typedef struct {
     const void *d_dgd; int32_t stride;      /* extended CDEF output plane, sample (0,0) */
     const void *d_src; int32_t src_stride;  /* source plane */

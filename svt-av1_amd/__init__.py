@@ -153,6 +153,9 @@ def lib():
     L.svt_hip_sgr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     L.svt_hip_sgr_proj_error_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, i32, vp, vp]
     L.svt_hip_sgr_search_units_plane.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, vp, vp]
+    L.svt_hip_sgr_search_units_scratch_bytes.argtypes = [i32, i32, i32]
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    L.svt_hip_sgr_search_units_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t]
     L.svt_hip_sgr_search_units_picture.argtypes = [vp, i32, i32, i32, C.POINTER(SgrSearchPlane), vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]

@@ -55,12 +55,17 @@ bool down(void* h, const void* d, size_t bytes) {
                  g_ctx ? svt_hip_last_error(g_ctx) : "no context");
     std::abort();
 }
-#define FALLBACK(name, member, ...)                                                                    \
-    do {                                                                                               \
-        std::fprintf(stderr, "libsvtav1_hip: %s fell back to the installed C pointer (%s)\n", name,    \
-                     g_ctx ? svt_hip_last_error(g_ctx) : "no context");                                 \
-        if (!g_c.member) die(name);                                                                    \
-        return g_c.member(__VA_ARGS__);                                                                \
+// A call the wrapper does not cover (an argument outside the batched entry point's domain) or a device failure is delegated to the pointer
+// that was installed before: quietly — the first delegation of each wrapper is logged once, a flood of identical lines would only hide it.
+#define FALLBACK(name, member, ...)                                                                              \
+    do {                                                                                                         \
+        static bool logged_ = false;                                                                             \
+        if (!logged_) {                                                                                          \
+            logged_ = true;                                                                                      \
+            std::fprintf(stderr, "libsvtav1_hip: %s delegated to the installed C pointer (first occurrence)\n", name); \
+        }                                                                                                        \
+        if (!g_c.member) die(name);                                                                              \
+        return g_c.member(__VA_ARGS__);                                                                          \
     } while (0)
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -270,7 +275,7 @@ void sgr_apply_hip(const uint8_t* dat8, int32_t w, int32_t h, int32_t stride, in
     Guard lk;
     void* d_in; size_t pp; const int pb = highbd ? 2 : 1;
     // one call = one processing unit (<= 64 x 64) of one stripe: a single restoration unit, rows attributed from the unit's own origin
-    bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 56 && eps >= 0 && eps < 16 && (bd == 8 || bd == 10) && sgr_stage(dat8, highbd, w, h, stride, &d_in, &pp);
+    bool ok = g_ctx && w > 0 && h > 0 && w <= 64 && h <= 64 && eps >= 0 && eps < 16 && (bd == 8 || bd == 10) && sgr_stage(dat8, highbd, w, h, stride, &d_in, &pp);
     if (ok) {
         const size_t dp = rup((size_t)w * pb, 4);
         uint8_t* d_dst = (uint8_t*)dev(1, dp * h + 64); uint8_t* d_ep = (uint8_t*)dev(2, 16); int32_t* d_xqd = (int32_t*)dev(3, 16);

@@ -359,10 +359,15 @@ __device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
     return (long long)hi * 65536 + lo;
 }
 
-template <typename PIX, int BD = 8>
+// STORE: additionally leaves flt0 - u (diff0[ep]), flt1 - u (diff1[ep]; sets 11 / 12 / 13 share the plane of 2 / 5 / 8) and dat - src (sd) of every pixel
+// as int16 planes (stride dstride, plane pitch dplane) for the on-device unit search (sgr_walk.hip): the walk then re-reads 6 bytes per pixel and probe
+// batch instead of re-running the filters.
+template <typename PIX, int BD = 8, bool STORE = false>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums) {
+                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums,
+                   int16_t* __restrict__ diff0 = nullptr, int16_t* __restrict__ diff1 = nullptr, int16_t* __restrict__ sd = nullptr, int dstride = 0,
+                   size_t dplane = 0) {
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
@@ -398,6 +403,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         const int yy = min(max(y0 + i0 + r, 0), ph - 1), xx = min(x0 + j, pw - 1);
         SV[r] = ((int32_t)src[(size_t)yy * src_stride + xx] - (int32_t)X[r]) << 4;     // (src << 4) - u
         CX[r] = 256 - (int32_t)(X[r] << 13);                                           // rounding - (u << 9)
+        if (STORE && colvalid && r >= rlo && r < rhi) sd[(size_t)(y0 + i0 + r) * dstride + x0 + j] = (int16_t)(-(SV[r] >> 4));   // dat - src
     }
 
     // parameter sets that must be filtered: the masked ones, 11/12/13 folded onto 2/5/8
@@ -418,6 +424,15 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         if (BD == 8) {
             int32_t D0[8], D1[8];
             sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+            if (STORE && colvalid) {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (r >= rlo && r < rhi) {
+                        const size_t o = (size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j;
+                        if (has0) diff0[o] = (int16_t)D0[r];
+                        if (has1) diff1[o] = (int16_t)D1[r];
+                    }
+            }
             int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
     #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -440,6 +455,15 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
             // bit depth 10: |flt - u| < 2^14.1, a product < 2^28.1 -> four rows per int32 partial, 64-bit from the row reduction on
             int32_t D0[8], D1[8];
             sgr10_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
+            if (STORE && colvalid) {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (r >= rlo && r < rhi) {
+                        const size_t o = (size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j;
+                        if (has0) diff0[o] = (int16_t)D0[r];
+                        if (has1) diff1[o] = (int16_t)D1[r];
+                    }
+            }
             int32_t h00[2] = {0, 0}, h01[2] = {0, 0}, h11[2] = {0, 0}, c0[2] = {0, 0}, c1[2] = {0, 0};
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -680,6 +704,18 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
     if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
     else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+    return (int)hipGetLastError();
+}
+// the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip)
+extern "C" int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
+                                               int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums,
+                                               int16_t* diff0, int16_t* diff1, int16_t* sd, int dstride, size_t dplane) {
+    const int voff = 8 >> ss_y;
+    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    unsigned long long* s = (unsigned long long*)sums;
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, true>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
+    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,

@@ -544,251 +544,122 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
     return SVT_HIP_OK;
 }
 
-/* ---- host side of search_selfguided_restoration (Encoder/Codec/EbRestorationPick.c:583-671) on top of the two plane kernels ---- */
+/* ---- search_selfguided_restoration (Encoder/Codec/EbRestorationPick.c:583-671) for every unit of a plane, entirely on the device ----
+ * launch 1: sgr_search8_kernel<STORE>: the five projection sums of every (unit, set) + the int16 planes flt0 - u, flt1 - u, dat - src
+ * launch 2: sgr_walk_kernel: per (unit, set) the 2x2 solve, encode_xq and finer_search_pixel_proj_error; the unit's best set
+ * No host synchronisation in between; the scratch (sums, arrival counters, difference planes) is the caller's. */
 namespace {
-const int kSgrR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
-const int kTapMin[2] = {-96, -32}, kTapMax[2] = {31, 95};   // SGRPROJ_PRJ_MIN0/MAX0, MIN1/MAX1 (EbRestoration.h:100-103)
-inline bool kSgr1(int ep) { return kSgrR[ep][1] > 0; }
-
-struct SgrPoint { int x, y; int64_t err; };
-struct SgrItem {            // one (restoration unit, parameter set)
-    int xqd[2] = {0, 0};    // start point (encode_xq), then the result
-    int64_t err = 0;
-    bool done = false;
-    std::vector<SgrPoint> cache;
-    std::vector<std::pair<int, int>> want;
-    bool lookup(int x, int y, int64_t& e) const {
-        for (const SgrPoint& p : cache) if (p.x == x && p.y == y) { e = p.err; return true; }
-        return false;
-    }
-};
-
-// svt_get_proj_subspace_c's solve (EbRestorationPick.c:497-538) on the exact integer sums, operation order of the reference
-void sgr_solve(const int64_t* sums, int size, int ep, int xq[2]) {
-    double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
-    H00 /= size; H01 /= size; H11 /= size; C0 /= size; C1 /= size;
-    const double H10 = H01;
-    xq[0] = xq[1] = 0;
-    if (kSgrR[ep][0] == 0) { if (H11 < 1e-8) return; xq[1] = (int)rint((C1 / H11) * 128); }
-    else if (kSgrR[ep][1] == 0) { if (H00 < 1e-8) return; xq[0] = (int)rint((C0 / H00) * 128); }
-    else {
-        const double det = H00 * H11 - H01 * H10;
-        if (det < 1e-8) return;
-        const double x0 = (H11 * C0 - H01 * C1) / det, x1 = (H00 * C1 - H10 * C0) / det;
-        xq[0] = (int)rint(x0 * 128); xq[1] = (int)rint(x1 * 128);
-    }
-}
-int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-void sgr_encode_xq(const int xq[2], int xqd[2], int ep) {   // encode_xq, EbRestorationPick.c:539-552
-    if (kSgrR[ep][0] == 0) { xqd[0] = 0; xqd[1] = clampi(128 - xq[1], kTapMin[1], kTapMax[1]); }
-    else if (kSgrR[ep][1] == 0) { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0], kTapMin[1], kTapMax[1]); }
-    else { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0] - xq[1], kTapMin[1], kTapMax[1]); }
-}
-
-// finer_search_pixel_proj_error (EbRestorationPick.c:353-446) replayed on the cache of evaluated points.  Returns true when the walk
-// finished on exact errors only (it.xqd / it.err hold the result).  At the first point whose error is not known yet the replay turns
-// speculative: it keeps walking, but decides with the quadratic model of the error that the five projection sums give
-// (sum e^2 = const + (xq' H xq - 256 C.xq) / 2048^2 up to the per-pixel rounding), and every point it visits goes to it.want (at most
-// max_want).  The next round evaluates those points exactly; wherever the model took the same decisions as the exact errors do, the whole
-// walk is then in the cache.  Mispredictions only cost another round, never exactness.
-bool sgr_replay(SgrItem& it, int ep, int start_step, int max_want, const int64_t* sums) {
-    const bool has0 = kSgrR[ep][0] > 0, has1 = kSgr1(ep);
-    const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
-    auto model = [&](int x, int y) {
-        const double xq0 = has0 ? x : 0, xq1 = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
-        return xq0 * xq0 * H00 + 2 * xq0 * xq1 * H01 + xq1 * xq1 * H11 - 256.0 * (xq0 * C0 + xq1 * C1);
-    };
-    int q[2] = {it.xqd[0], it.xqd[1]};
-    bool spec = false;
-    it.want.clear();
-    // error of point (x, y): exact while everything so far was cached, the model afterwards (cur = the walk's current point, for the switch)
-    auto value = [&](int x, int y, const int cur[2], double& cur_err) {
-        int64_t e;
-        if (!spec && it.lookup(x, y, e)) return (double)e;
-        if (!spec) { spec = true; cur_err = model(cur[0], cur[1]); }
-        if (!it.lookup(x, y, e)) {
-            bool dup = false;
-            for (const auto& w : it.want) dup = dup || (w.first == x && w.second == y);
-            if (!dup && (int)it.want.size() < max_want) it.want.emplace_back(x, y);
-        }
-        return model(x, y);
-    };
-    double err = 0, err2;
-    err = value(q[0], q[1], q, err);
-    for (int s = start_step; s >= 1 && (int)it.want.size() < max_want; s >>= 1) {
-        for (int p = 0; p < 2 && (int)it.want.size() < max_want; p++) {
-            if (kSgrR[ep][p] == 0) continue;
-            bool skip = false;
-            for (;;) {
-                if (q[p] - s >= kTapMin[p] && (int)it.want.size() < max_want) {
-                    int c[2] = {q[0], q[1]}; c[p] -= s;
-                    err2 = value(c[0], c[1], q, err);
-                    if (!(err2 > err)) { q[p] -= s; err = err2; skip = true; if (s == start_step) continue; }
-                }
-                break;
-            }
-            if (skip) break;
-            for (;;) {
-                if (q[p] + s <= kTapMax[p] && (int)it.want.size() < max_want) {
-                    int c[2] = {q[0], q[1]}; c[p] += s;
-                    err2 = value(c[0], c[1], q, err);
-                    if (!(err2 > err)) { q[p] += s; err = err2; if (s == start_step) continue; }
-                }
-                break;
-            }
-        }
-    }
-    if (spec) return false;
-    it.xqd[0] = q[0]; it.xqd[1] = q[1]; it.err = (int64_t)err; it.done = true;
-    return true;
+struct SgrScratch { size_t sums, counters, sd, d0, d1, total, dplane; int dstride, nu; };
+SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
+    SgrScratch L;
+    L.nu = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
+    L.dstride = (pw + 63) & ~63;
+    L.dplane = (size_t)L.dstride * (size_t)ph;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    L.sums = o;     o = al(o + sizeof(int64_t) * (size_t)L.nu * 16 * 5);
+    L.counters = o; o = al(o + sizeof(uint32_t) * (size_t)L.nu);
+    L.sd = o;       o = al(o + sizeof(int16_t) * L.dplane);
+    L.d0 = o;       o = al(o + sizeof(int16_t) * L.dplane * 16);
+    L.d1 = o;       o = al(o + sizeof(int16_t) * L.dplane * 16);
+    L.total = o;
+    return L;
 }
 }  // namespace
 
+size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size) {
+    if (pw <= 0 || ph <= 0 || unit_size < 64 || (unit_size & 63)) return 0;
+    return sgr_scratch_layout(pw, ph, unit_size).total;
+}
+
+int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
+                                       int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* d_xqd, int64_t* d_err, uint8_t* d_best_ep,
+                                       int32_t* d_best_xqd, void* d_scratch, size_t scratch_bytes) {
+    SVT_HIP_ENTER(c);
+    ep_mask &= 0xFFFFu;
+    if (!c || !d_dgd || !d_src || !d_xqd || !d_err || !d_scratch || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
+        !sgr_args_ok(pix_bytes, bd, pw, ph) || !ep_mask || ((uintptr_t)d_scratch & 15)) {
+        if (c) c->err = "svt_hip_sgr_search_units_plane_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    const SgrScratch L = sgr_scratch_layout(pw, ph, unit_size);
+    if (scratch_bytes < L.total) {
+        c->err = "svt_hip_sgr_search_units_plane_dev: scratch smaller than svt_hip_sgr_search_units_scratch_bytes()";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    char* base = (char*)d_scratch;
+    HIPCHK(c, hipMemsetAsync(base + L.sums, 0, L.sd - L.sums, c->stream));   // sums + arrival counters
+    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y, ep_mask,
+                                                              (int64_t*)(base + L.sums), (int16_t*)(base + L.d0), (int16_t*)(base + L.d1), (int16_t*)(base + L.sd),
+                                                              L.dstride, L.dplane);
+    if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
+    e = (hipError_t)svt_hip_launch_sgr_walk(c->stream, bd, (const int16_t*)(base + L.d0), (const int16_t*)(base + L.d1), (const int16_t*)(base + L.sd), L.dstride, L.dplane,
+                                            (const int64_t*)(base + L.sums), pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd, d_err, (uint32_t*)(base + L.counters),
+                                            d_best_ep, d_best_xqd);
+    if (e != hipSuccess) return fail(c, e, "sgr walk launch");
+    return SVT_HIP_OK;
+}
+
+// HOST-output convenience forms: the library's own scratch, one synchronisation at the very end (to hand the results over).
 int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane* planes, int* rounds_out) {
     SVT_HIP_ENTER(c);
     if (!c || !planes || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
-    const int NC = SVT_HIP_SGR_MAX_CAND;
-    struct Job { int nu; size_t sums_o, xqd_o, err_o; std::vector<SgrItem> items; uint32_t mask; };
-    Job job[3];
+    struct Off { size_t scratch, xqd, err, best; int nu; } off[3];
     size_t need = 0;
     for (int k = 0; k < n_planes; k++) {
         const SvtHipSgrSearchPlane& P = planes[k];
         if (!P.d_dgd || !P.d_src || !P.xqd_out || !P.err_out || P.unit_size < 64 || (P.unit_size & 63) || (P.ss_y != 0 && P.ss_y != 1) ||
             !sgr_args_ok(pix_bytes, bd, P.pw, P.ph) || !(P.ep_mask & 0xFFFFu))
             return SVT_HIP_ERR_BAD_ARG;
-        Job& J = job[k];
-        J.nu = sgr_units(P.pw, P.unit_size) * sgr_units(P.ph, P.unit_size);
-        J.mask = P.ep_mask & 0xFFFFu;
-        J.sums_o = need; need += sizeof(int64_t) * J.nu * 16 * 5;
-        J.xqd_o = need;  need += sizeof(int32_t) * J.nu * 16 * NC * 2;
-        J.err_o = need;  need += sizeof(int64_t) * J.nu * 16 * NC;
+        const SgrScratch L = sgr_scratch_layout(P.pw, P.ph, P.unit_size);
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        off[k].nu = L.nu;
+        off[k].scratch = need; need = al(need + L.total);
+        off[k].xqd = need;     need = al(need + sizeof(int32_t) * (size_t)L.nu * 32);
+        off[k].err = need;     need = al(need + sizeof(int64_t) * (size_t)L.nu * 16);
+        off[k].best = need;    need = al(need + (size_t)L.nu);
     }
-    if (need > c->scratch_bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (need > c->scratch_bytes) {   // the scratch may still be in use by work queued on ANY stream this context was pointed at
+        HIPCHK(c, hipDeviceSynchronize());
         if (c->scratch) HIPCHK(c, hipFree(c->scratch));
         c->scratch = nullptr; c->scratch_bytes = 0;
         HIPCHK(c, hipMalloc(&c->scratch, need));
         c->scratch_bytes = need;
     }
-    if (need > c->host_scratch_bytes) {   // pinned mirror of the device scratch: the per-round copies stay asynchronous and cheap
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->host_scratch) HIPCHK(c, hipHostFree(c->host_scratch));
-        c->host_scratch = nullptr; c->host_scratch_bytes = 0;
-        HIPCHK(c, hipHostMalloc(&c->host_scratch, need, hipHostMallocDefault));
-        c->host_scratch_bytes = need;
-    }
-    char* dev = (char*)c->scratch; char* host = (char*)c->host_scratch;
-    // 1. the projection sums of every (unit, set), all planes, one synchronisation
+    char* dev = (char*)c->scratch;
     for (int k = 0; k < n_planes; k++) {
-        const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
-        const size_t sums_b = sizeof(int64_t) * J.nu * 16 * 5;
-        HIPCHK(c, hipMemsetAsync(dev + J.sums_o, 0, sums_b, c->stream));
-        const int rc = svt_hip_sgr_search_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y, J.mask,
-                                                    (int64_t*)(dev + J.sums_o));
+        const SvtHipSgrSearchPlane& P = planes[k];
+        const int rc = svt_hip_sgr_search_units_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y, P.ep_mask,
+                                                          (int32_t*)(dev + off[k].xqd), (int64_t*)(dev + off[k].err), (uint8_t*)(dev + off[k].best), nullptr,
+                                                          dev + off[k].scratch, sgr_scratch_layout(P.pw, P.ph, P.unit_size).total);
         if (rc != SVT_HIP_OK) return rc;
-        HIPCHK(c, hipMemcpyAsync(host + J.sums_o, dev + J.sums_o, sums_b, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // 2. solve + encode_xq per (unit, set); unit sizes as foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) cuts them
     for (int k = 0; k < n_planes; k++) {
-        const SvtHipSgrSearchPlane& P = planes[k]; Job& J = job[k];
-        const int64_t* sums = (const int64_t*)(host + J.sums_o);
-        J.items.assign((size_t)J.nu * 16, SgrItem());
-        const int ux = sgr_units(P.pw, P.unit_size), ext = P.unit_size * 3 / 2, voff = 8 >> P.ss_y;
-        int y0 = 0, i = 0;
-        while (y0 < P.ph) {
-            const int rem_h = P.ph - y0, h = rem_h < ext ? rem_h : P.unit_size;
-            int v_start = y0 - voff > 0 ? y0 - voff : 0, v_end = y0 + h;
-            if (v_end < P.ph) v_end -= voff;
-            int x0 = 0, j = 0;
-            while (x0 < P.pw) {
-                const int rem_w = P.pw - x0, w = rem_w < ext ? rem_w : P.unit_size;
-                const int u = i * ux + j, size = w * (v_end - v_start);
-                for (int ep = 0; ep < 16; ep++) {
-                    SgrItem& it = J.items[(size_t)u * 16 + ep];
-                    if (!((J.mask >> ep) & 1)) { it.done = true; continue; }
-                    int xq[2];
-                    sgr_solve(&sums[((size_t)u * 16 + ep) * 5], size, ep, xq);
-                    sgr_encode_xq(xq, it.xqd, ep);
-                }
-                x0 += w; j++;
-            }
-            y0 += h; i++;
-        }
-    }
-    // 3. the finer search in rounds: every round evaluates up to NC new points per unfinished (unit, set), one launch per plane, one
-    //    synchronisation per round for the whole picture
-    int rounds = 0;
-    for (;; rounds++) {
-        uint32_t round_mask[3] = {0, 0, 0};
-        bool any = false;
-        for (int k = 0; k < n_planes; k++) {
-            Job& J = job[k];
-            for (int u = 0; u < J.nu; u++)
-                for (int ep = 0; ep < 16; ep++) {
-                    SgrItem& it = J.items[(size_t)u * 16 + ep];
-                    if (!it.done && !sgr_replay(it, ep, 2, NC, (const int64_t*)(host + J.sums_o) + ((size_t)u * 16 + ep) * 5)) round_mask[k] |= 1u << ep;
-                }
-            any = any || round_mask[k];
-        }
-        if (!any) break;
-        if (rounds >= 256) { c->err = "svt_hip_sgr_search_units: finer search did not converge"; return SVT_HIP_ERR_RUNTIME; }
-        for (int k = 0; k < n_planes; k++) {
-            if (!round_mask[k]) continue;
-            const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
-            int32_t* h_xqd = (int32_t*)(host + J.xqd_o);
-            for (int u = 0; u < J.nu; u++)
-                for (int ep = 0; ep < 16; ep++) {
-                    const SgrItem& it = J.items[(size_t)u * 16 + ep];
-                    int32_t* q = &h_xqd[((size_t)u * 16 + ep) * NC * 2];
-                    for (int n = 0; n < NC; n++) {
-                        const bool live = !it.done && n < (int)it.want.size();
-                        q[2 * n] = live ? it.want[n].first : INT32_MIN;   // INT32_MIN ends the list (first slot: the pair is skipped)
-                        q[2 * n + 1] = live ? it.want[n].second : 0;
-                    }
-                }
-            HIPCHK(c, hipMemcpyAsync(dev + J.xqd_o, h_xqd, sizeof(int32_t) * J.nu * 16 * NC * 2, hipMemcpyHostToDevice, c->stream));
-            const int rc = svt_hip_sgr_proj_error_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y,
-                                                            round_mask[k], NC, (const int32_t*)(dev + J.xqd_o), (int64_t*)(dev + J.err_o));
-            if (rc != SVT_HIP_OK) return rc;
-            HIPCHK(c, hipMemcpyAsync(host + J.err_o, dev + J.err_o, sizeof(int64_t) * J.nu * 16 * NC, hipMemcpyDeviceToHost, c->stream));
-        }
+        const SvtHipSgrSearchPlane& P = planes[k];
+        const size_t nu = (size_t)off[k].nu;
+        std::vector<int32_t> xqd(nu * 32);
+        std::vector<int64_t> err(nu * 16);
+        HIPCHK(c, hipMemcpyAsync(xqd.data(), dev + off[k].xqd, sizeof(int32_t) * nu * 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(err.data(), dev + off[k].err, sizeof(int64_t) * nu * 16, hipMemcpyDeviceToHost, c->stream));
+        if (P.best_ep) HIPCHK(c, hipMemcpyAsync(P.best_ep, dev + off[k].best, nu, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < n_planes; k++) {
-            if (!round_mask[k]) continue;
-            Job& J = job[k];
-            const int64_t* h_err = (const int64_t*)(host + J.err_o);
-            for (int u = 0; u < J.nu; u++)
-                for (int ep = 0; ep < 16; ep++) {
-                    SgrItem& it = J.items[(size_t)u * 16 + ep];
-                    if (it.done) continue;
-                    for (int n = 0; n < (int)it.want.size(); n++)
-                        it.cache.push_back({it.want[n].first, it.want[n].second, h_err[((size_t)u * 16 + ep) * NC + n]});
-                }
-        }
-    }
-
-    for (int k = 0; k < n_planes; k++) {
-        const SvtHipSgrSearchPlane& P = planes[k]; const Job& J = job[k];
-        for (int u = 0; u < J.nu; u++) {
-            int64_t besterr = -1;
+        for (size_t u = 0; u < nu; u++)
             for (int ep = 0; ep < 16; ep++) {
-                if (!((J.mask >> ep) & 1)) continue;
-                const SgrItem& it = J.items[(size_t)u * 16 + ep];
-                P.xqd_out[((size_t)u * 16 + ep) * 2] = it.xqd[0]; P.xqd_out[((size_t)u * 16 + ep) * 2 + 1] = it.xqd[1];
-                P.err_out[(size_t)u * 16 + ep] = it.err;
-                if (besterr == -1 || it.err < besterr) { besterr = it.err; if (P.best_ep) P.best_ep[u] = (uint8_t)ep; }   // strict <, :659
+                if (!((P.ep_mask >> ep) & 1)) continue;   // sets outside the mask stay untouched
+                if (err[u * 16 + ep] < 0) { c->err = "svt_hip_sgr_search_units: a walk did not finish within the pass budget"; return SVT_HIP_ERR_RUNTIME; }
+                P.xqd_out[(u * 16 + ep) * 2] = xqd[(u * 16 + ep) * 2]; P.xqd_out[(u * 16 + ep) * 2 + 1] = xqd[(u * 16 + ep) * 2 + 1];
+                P.err_out[u * 16 + ep] = err[u * 16 + ep];
             }
-        }
     }
-    if (rounds_out) *rounds_out = rounds;
+    if (rounds_out) *rounds_out = 0;   // kept for source compatibility: there are no host rounds any more
     return SVT_HIP_OK;
 }
+
 int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
-                                   int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep,
-                                   int* rounds_out) {
+                                   int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep, int* rounds_out) {
     SVT_HIP_ENTER(c);
-    const SvtHipSgrSearchPlane P = {d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, xqd_out, err_out, best_ep};
+    SvtHipSgrSearchPlane P = {d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ss_y, ep_mask, xqd_out, err_out, best_ep};
     return svt_hip_sgr_search_units_picture(c, pix_bytes, bd, 1, &P, rounds_out);
 }
 

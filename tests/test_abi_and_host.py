@@ -16,7 +16,7 @@ def _declared_symbols():
     for hdr in ("svt_hip.h", "svt_hip_rtcd.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        syms |= set(re.findall(r"^(?:int|void|double|const char \*|SvtHipSbSearch)\s*\*?\s*(svt_hip_[a-z0-9_]+)\s*\(", txt, flags=re.M))
+        syms |= set(re.findall(r"^(?:int|void|double|size_t|const char \*|SvtHipSbSearch)\s*\*?\s*(svt_hip_[a-z0-9_]+)\s*\(", txt, flags=re.M))
     return sorted(syms)
 
 

@@ -104,3 +104,20 @@ def test_single_hook_on_gpu(hook, workdir):
     case = "cif_8bit_m6"
     spec = CASES[case][:6] + ({hook},)
     _check(case, spec, workdir, {"SVT_HIP_HOOKS": hook}, "hip_" + hook)
+
+
+@pytest.mark.gpu
+def test_per_call_wrappers_in_a_real_encode_on_gpu(workdir):
+    """SVT_HIP_RTCD: the reference's dispatch-table entries themselves point at the svt_*_hip wrappers (include/svt_hip_rtcd.h) while the encoder
+    runs its unchanged per-block loops: HME (svt_sad_loop_kernel), the self-guided filter of the restoration search and of the frame filter,
+    the Wiener statistics.  Slow (one launch per call) but it is the literal "drop-in behind the dispatch table" statement on a real encode."""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    names = "svt_sad_loop_kernel,svt_av1_selfguided_restoration,svt_apply_selfguided_restoration,svt_av1_compute_stats"
+    got = E.encode(E.APP_HIP, clip, w, h, 4, preset, q, bd, os.path.join(workdir, case + ".rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1200)
+    ref4 = E.encode(E.APP_REF, clip, w, h, 4, preset, q, bd, os.path.join(workdir, case + ".ref4"))
+    assert (got["ivf"], got["recon"]) == (ref4["ivf"], ref4["recon"])
+    for nme in names.split(","):
+        assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"]
+    assert "delegated to the installed C pointer" not in got["log"], got["log"][-1500:]

@@ -167,7 +167,7 @@ def test_selfguided_wrappers(rtcd, orc):
     rng = np.random.default_rng(4)
     for bd, dt in ((8, np.uint8), (10, np.uint16)):
         img = np.clip(rng.normal(120, 40, (90, 100)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(dt)
-        for (w, h) in ((64, 56), (40, 24), (7, 10)):
+        for (w, h) in ((64, 64), (64, 56), (40, 24), (7, 10)):   # 64 x 64: a full luma processing unit of a 64-row stripe
             org = (9 * 100 + 11) * img.itemsize
             p = img.ctypes.data + org
             p_ref = p >> 1 if bd > 8 else p   # CONVERT_TO_BYTEPTR

@@ -228,7 +228,7 @@ def test_proj_error_candidates(hip, orc, bd, ss):
 
 @pytest.mark.parametrize("bd", [8, 10])
 def test_search_units_plane(hip, orc, bd):
-    """svt_hip_sgr_search_units_plane (sums -> solve -> encode_xq -> finer search in rounds) vs the oracle's search_selfguided_restoration
+    """svt_hip_sgr_search_units_plane (sums -> solve -> encode_xq -> finer search, all on the device) vs the oracle's search_selfguided_restoration
     restatement (pinned to the reference's static functions through oracle/ref_shim_restpick.c): xqd, error and best set of every unit."""
     for (w, h, US, ss, mask, sigma) in ((264, 200, 64, 0, 0xFFFF, 5), (168, 120, 64, 1, 0xFFFF, 9), (328, 264, 128, 0, 0x0F38, 3), (1000, 584, 256, 0, 0x4221, 4)):
         src, ext = _smooth_noisy(w, h, bd, 400 + bd + ss, sigma)
@@ -243,12 +243,12 @@ def test_search_units_plane(hip, orc, bd):
         hip.free(d_ext, d_src)
         assert np.array_equal(g_err, e_err), (bd, w, h, np.argwhere(g_err != e_err)[:5])
         assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best)
-        assert 1 <= rounds.value <= 16, rounds.value
+        assert rounds.value == 0   # no host rounds: the whole search runs on the device
         if mask == 0xFFFF: assert len(set(int(v) for v in e_best)) > 1, "content should make different sets win"
 
 
 def test_search_units_picture(hip, pkg, orc):
-    """Three planes with shared rounds (svt_hip_sgr_search_units_picture) = the per-plane results."""
+    """Three planes in one call (svt_hip_sgr_search_units_picture) = the per-plane results."""
     w, h, bd = 264, 200, 8
     planes, keep, exp = (pkg.SgrSearchPlane * 3)(), [], []
     for p in range(3):
@@ -269,3 +269,36 @@ def test_search_units_picture(hip, pkg, orc):
         assert np.array_equal(g[1], e[1]) and np.array_equal(g[0], e[0]) and np.array_equal(g[2], e[2]), p
     assert hip.L.svt_hip_sgr_search_units_picture(hip.h, 1, bd, 4, planes, None) != 0
     hip.free(*keep)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_units_plane_dev_chain(hip, orc, bd):
+    """The device-output form: results stay in HBM, d_best_ep / d_best_xqd are exactly the per-unit arrays svt_hip_sgr_apply_plane_dev takes, so the
+    search -> trial filter chain needs no host round trip.  Checked: every (unit, set) result, the best set, and the plane filtered with the winners."""
+    w, h, US, ss, mask = 328, 264, 128, 0, 0xFFFF
+    src, ext = _smooth_noisy(w, h, bd, 900 + bd, 6)
+    st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+    nu = units(w, US) * units(h, US)
+    e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+    orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+    L = hip.L
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    nbytes = L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+    assert nbytes > 33 * 2 * w * h
+    d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+    d_scr = hip.empty(nbytes); d_xqd = hip.empty(nu * 16 * 8); d_err = hip.empty(nu * 16 * 8); d_best = hip.empty(nu); d_bx = hip.empty(nu * 8)
+    hip.check(L.svt_hip_sgr_search_units_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_xqd, d_err, d_best, d_bx, d_scr, nbytes), "units dev")
+    # chained apply with the winners, still on the device (stripe context rows taken from the same plane)
+    d_out = hip.empty(h * w * ext.itemsize)
+    hip.check(L.svt_hip_sgr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_out, w, w, h, US, ss, d_ext.value + off, st, d_best, d_bx), "apply")
+    g_xqd = hip.to_host(d_xqd, e_xqd.shape, np.int32); g_err = hip.to_host(d_err, e_err.shape, np.int64); g_best = hip.to_host(d_best, e_best.shape, np.uint8)
+    g_bx = hip.to_host(d_bx, (nu, 2), np.int32); out = hip.to_host(d_out, (h, w), ext.dtype)
+    assert np.array_equal(g_err, e_err) and np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best)
+    assert np.array_equal(g_bx, e_xqd[np.arange(nu), e_best])
+    exp = np.zeros((h, w), ext.dtype)
+    work = ext.copy(); dbl = ext.copy()
+    orc.orc_sgr_apply_plane(C.c_void_p(dbl.ctypes.data + off), st, C.c_void_p(work.ctypes.data + off), st, ext.itemsize, w, h, ss, ss, US, bd, ptr(e_best), ptr(np.ascontiguousarray(g_bx)), ptr(exp), w)
+    assert np.array_equal(out, exp)
+    # a scratch that is too small is rejected
+    assert L.svt_hip_sgr_search_units_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_xqd, d_err, d_best, d_bx, d_scr, nbytes - 1) != 0
+    hip.free(d_ext, d_src, d_scr, d_xqd, d_err, d_best, d_bx, d_out)
