@@ -389,7 +389,8 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, cons
  *   d_best_ep [units] (may be NULL) = the first set with the smallest error, d_best_xqd [units][2] (may be NULL) = its xqd: exactly the
  *   d_unit_ep / d_unit_xqd arrays svt_hip_sgr_apply_plane_dev takes, so search -> trial filter -> SSE chains on the device.
  *   d_scratch: svt_hip_sgr_search_units_scratch_bytes(pw, ph, unit_size) bytes, 16-byte aligned, private to this call until it has completed
- *   (sums, arrival counters, and 33 int16 planes: flt0 - u and flt1 - u per filter, dat - src). */
+ *   (sums, arrival counters, and 33 int16 planes: flt0 - u and flt1 - u per filter, dat - src).  Its first three uint32 receive diagnostics of the call:
+ *   evaluation passes and evaluated points summed over all (unit, set) walks, and the number of walks that did not finish (always 0). */
 size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size);
 int svt_hip_sgr_search_units_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride, int pw,
                                        int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *d_xqd, int64_t *d_err, uint8_t *d_best_ep,

@@ -85,7 +85,7 @@ void sad_loop_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_
         void* d_job = dev(2, sizeof(job)); uint32_t* d_out = (uint32_t*)dev(3, 16);
         const uint32_t init[4] = {0xffffffu, 0, 0, 0};
         struct { uint32_t sad; int16_t xy[2]; uint32_t pad[2]; } res;
-        ok = d_src && d_ref && d_job && d_out && up2d(d_src, sp, src, src_stride / step, bw, srows) &&
+        ok = d_src && d_ref && d_job && d_out && up2d(d_src, sp * step, src, src_stride, bw, bh) &&
              up2d(d_ref, rp, ref, src_stride_raw, rw, rrows) && up(d_job, &job, sizeof(job)) && up(d_out, init, sizeof(init)) &&
              svt_hip_sad_loop_batch_dev(g_ctx, d_src, (int)sp, d_ref, (int)rp, (const SvtHipSadLoop*)d_job, 1, d_out, (int16_t*)(d_out + 1)) == 0 &&
              down(&res, d_out, 8);
@@ -93,6 +93,14 @@ void sad_loop_hip(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_
             *best_sad = res.sad;   // EbComputeSAD_C.c:73: 0xffffff when nothing beat it (centres untouched)
             if (res.sad != 0xffffffu) { *xc = res.xy[0]; *yc = res.xy[1]; }
             return;
+        }
+    }
+    {
+        static bool once = false;   // which call shape was not covered (diagnostic, printed once)
+        if (!once) {
+            once = true;
+            std::fprintf(stderr, "libsvtav1_hip: svt_sad_loop_kernel(src_stride %u ref_stride %u h %u w %u raw %u sa %d x %d) not covered: %s\n", src_stride, ref_stride, bh, bw,
+                         src_stride_raw, (int)saw, (int)sah, g_ctx ? svt_hip_last_error(g_ctx) : "no context");
         }
     }
     FALLBACK("svt_sad_loop_kernel", svt_sad_loop_kernel, src, src_stride, ref, ref_stride, bh, bw, best_sad, xc, yc, src_stride_raw, saw, sah);

@@ -17,6 +17,7 @@
 // workgroup of a unit to finish picks the unit's best set.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "svt_hip_internal.h"
 
 namespace {
@@ -24,8 +25,8 @@ namespace {
 constexpr int kMaxCand = 10;     // points evaluated per pass
 constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
 
-__device__ __constant__ int kR[16][2] = {{2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {2, 0}, {2, 0}};
-__device__ __constant__ int kTapMin[2] = {-96, -32}, kTapMax[2] = {31, 95};   // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1 (EbRestoration.h:100-103)
+// eb_sgr_params (Common/Codec/EbRestoration.c:136-153): r0 > 0 for sets 0-9, 14, 15; r1 > 0 for sets 0-13.  Tap ranges: SGRPROJ_PRJ_MIN0 / MAX0 = -96 / 31,
+// MIN1 / MAX1 = -32 / 95 (EbRestoration.h:100-103).  Both are spelled out as arithmetic where they are used: no table loads on the serial path.
 
 struct WalkLds {
     int       cx[kCache], cy[kCache];   // evaluated points
@@ -49,8 +50,9 @@ __device__ void solve_and_encode(const long long* sums, int size, int ep, int xq
     H00 /= dsize; H01 /= dsize; H11 /= dsize; C0 /= dsize; C1 /= dsize;
     const double H10 = H01;
     int xq[2] = {0, 0};
-    if (kR[ep][0] == 0) { if (!(H11 < 1e-8)) xq[1] = (int)rint((C1 / H11) * 128.0); }
-    else if (kR[ep][1] == 0) { if (!(H00 < 1e-8)) xq[0] = (int)rint((C0 / H00) * 128.0); }
+    const bool has0 = ep < 10 || ep >= 14, has1 = ep < 14;   // eb_sgr_params r0 / r1 > 0
+    if (!has0) { if (!(H11 < 1e-8)) xq[1] = (int)rint((C1 / H11) * 128.0); }
+    else if (!has1) { if (!(H00 < 1e-8)) xq[0] = (int)rint((C0 / H00) * 128.0); }
     else {
         const double det = H00 * H11 - H01 * H10;
         if (!(det < 1e-8)) {
@@ -58,69 +60,80 @@ __device__ void solve_and_encode(const long long* sums, int size, int ep, int xq
             xq[0] = (int)rint(x0 * 128.0); xq[1] = (int)rint(x1 * 128.0);
         }
     }
-    if (kR[ep][0] == 0) { xqd[0] = 0; xqd[1] = clampi(128 - xq[1], kTapMin[1], kTapMax[1]); }
-    else if (kR[ep][1] == 0) { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0], kTapMin[1], kTapMax[1]); }
-    else { xqd[0] = clampi(xq[0], kTapMin[0], kTapMax[0]); xqd[1] = clampi(128 - xqd[0] - xq[1], kTapMin[1], kTapMax[1]); }
+    if (!has0) { xqd[0] = 0; xqd[1] = clampi(128 - xq[1], -32, 95); }
+    else if (!has1) { xqd[0] = clampi(xq[0], -96, 31); xqd[1] = clampi(128 - xqd[0], -32, 95); }
+    else { xqd[0] = clampi(xq[0], -96, 31); xqd[1] = clampi(128 - xqd[0] - xq[1], -32, 95); }
 }
 
 // finer_search_pixel_proj_error replayed on the cache.  Returns true when the walk finished on exact errors only.
-__device__ bool replay(WalkLds& L, int ep, const int start[2], const long long* sums) {
-    const bool   has0 = kR[ep][0] > 0, has1 = kR[ep][1] > 0;
+// Executed by ALL 64 lanes of wave 0 with identical values (uniform control flow): the scalar walk logic runs as before, but the two
+// searches it performs over and over — "is this point in the cache?", "is it already wanted?" — compare 64 entries at a time across the
+// lanes (one LDS read per lane + a ballot) instead of looping over them.  Parameter-set constants are arithmetic (no table loads).
+__device__ bool replay(WalkLds& L, int ep, const int start[2], const long long* sums, int lane) {
+    const bool   has0 = ep < 10 || ep >= 14, has1 = ep < 14;
     const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
     auto model = [&](int x, int y) {
         const double a = has0 ? x : 0, b = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
         return a * a * H00 + 2 * a * b * H01 + b * b * H11 - 256.0 * (a * C0 + b * C1);
     };
+    const int n_cache = L.n_cache;
     auto lookup = [&](int x, int y, long long& e) {
-        for (int i = 0; i < L.n_cache; i++)
-            if (L.cx[i] == x && L.cy[i] == y) { e = L.ce[i]; return true; }
+        for (int base = 0; base < n_cache; base += 64) {
+            const int  i = base + lane;
+            const bool hit = i < n_cache && L.cx[i] == x && L.cy[i] == y;
+            const unsigned long long m = __ballot(hit);
+            if (m) { e = L.ce[base + __ffsll((long long)m) - 1]; return true; }
+        }
         return false;
     };
     bool spec = false;
     int  nw = 0;
     // value of a point: its exact error while everything so far was cached, the model afterwards (cur = the walk's current point, whose
     // value is switched to the model at that moment so that comparisons stay like with like)
-    auto value = [&](int x, int y, const int cur[2], double& cur_err) {
+    auto value = [&](int x, int y, int curx, int cury, double& cur_err) {
         long long e;
         if (!spec && lookup(x, y, e)) return (double)e;
-        if (!spec) { spec = true; cur_err = model(cur[0], cur[1]); }
+        if (!spec) { spec = true; cur_err = model(curx, cury); }
         if (!lookup(x, y, e)) {
-            bool dup = false;
-            for (int i = 0; i < nw; i++) dup = dup || (L.wx[i] == x && L.wy[i] == y);
-            if (!dup && nw < kMaxCand) { L.wx[nw] = x; L.wy[nw] = y; nw++; }
+            const bool dup = __ballot(lane < nw && ((volatile int*)L.wx)[lane] == x && ((volatile int*)L.wy)[lane] == y) != 0;   // kMaxCand <= 64; lane 0 wrote the list
+            if (!dup && nw < kMaxCand) { if (lane == 0) { L.wx[nw] = x; L.wy[nw] = y; } nw++; }
         }
         return model(x, y);
     };
-    int    q[2] = {start[0], start[1]};
+    int    q0 = start[0], q1 = start[1];
     double err = 0, err2;
-    err = value(q[0], q[1], q, err);
+    err = value(q0, q1, q0, q1, err);
     for (int s = 2; s >= 1 && nw < kMaxCand; s >>= 1) {
         for (int p = 0; p < 2 && nw < kMaxCand; p++) {
-            if (kR[ep][p] == 0) continue;
+            if (p == 0 ? !has0 : !has1) continue;
+            const int tmin = p == 0 ? -96 : -32, tmax = p == 0 ? 31 : 95;   // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1 (EbRestoration.h:100-103)
             bool skip = false;
             for (;;) {
-                if (q[p] - s >= kTapMin[p] && nw < kMaxCand) {
-                    int c[2] = {q[0], q[1]}; c[p] -= s;
-                    err2 = value(c[0], c[1], q, err);
-                    if (!(err2 > err)) { q[p] -= s; err = err2; skip = true; if (s == 2) continue; }
+                const int qp = p == 0 ? q0 : q1;
+                if (qp - s >= tmin && nw < kMaxCand) {
+                    const int c0 = p == 0 ? q0 - s : q0, c1 = p == 0 ? q1 : q1 - s;
+                    err2 = value(c0, c1, q0, q1, err);
+                    if (!(err2 > err)) { q0 = c0; q1 = c1; err = err2; skip = true; if (s == 2) continue; }
                 }
                 break;
             }
             if (skip) break;   // EbRestorationPick.c:406-407: leaves the parameter loop of this step size
             for (;;) {
-                if (q[p] + s <= kTapMax[p] && nw < kMaxCand) {
-                    int c[2] = {q[0], q[1]}; c[p] += s;
-                    err2 = value(c[0], c[1], q, err);
-                    if (!(err2 > err)) { q[p] += s; err = err2; if (s == 2) continue; }
+                const int qp = p == 0 ? q0 : q1;
+                if (qp + s <= tmax && nw < kMaxCand) {
+                    const int c0 = p == 0 ? q0 + s : q0, c1 = p == 0 ? q1 : q1 + s;
+                    err2 = value(c0, c1, q0, q1, err);
+                    if (!(err2 > err)) { q0 = c0; q1 = c1; err = err2; if (s == 2) continue; }
                 }
                 break;
             }
         }
     }
-    L.n_want = nw;
-    if (spec) return false;
-    L.res_x = q[0]; L.res_y = q[1]; L.res_err = (long long)err;
-    return true;
+    if (lane == 0) {
+        L.n_want = nw;
+        if (!spec) { L.res_x = q0; L.res_y = q1; L.res_err = (long long)err; }
+    }
+    return !spec;
 }
 
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
@@ -135,7 +148,7 @@ __global__ void __launch_bounds__(256)
 sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ diff1, const int16_t* __restrict__ sd, int dstride, size_t dplane,
                 const long long* __restrict__ sums, int pw, int ph, int unit_size, int units_x, int units_y, int voff, uint32_t ep_mask,
                 int32_t* __restrict__ xqd_out, long long* __restrict__ err_out, uint32_t* __restrict__ counters, uint8_t* __restrict__ best_ep,
-                int32_t* __restrict__ best_xqd) {
+                int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats) {
     __shared__ WalkLds L;
     const int unit = blockIdx.x, ep = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!((ep_mask >> ep) & 1)) return;
@@ -144,31 +157,38 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
     const int x0 = uj * unit_size, w = uj == units_x - 1 ? pw - x0 : unit_size;
     const int y0 = ui * unit_size, h = ui == units_y - 1 ? ph - y0 : unit_size;
     const int v0 = max(y0 - voff, 0), v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
-    const bool has0 = kR[ep][0] > 0, has1 = kR[ep][1] > 0;
+    const bool has0 = ep < 10 || ep >= 14, has1 = ep < 14;
     const int  ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
     const int16_t* __restrict__ D0 = diff0 + (size_t)ep * dplane;
     const int16_t* __restrict__ D1 = diff1 + (size_t)ce * dplane;
     const long long* S = sums + ((size_t)unit * 16 + ep) * 5;
 
-    int start[2];
-    if (tid == 0) {
+    int start[2] = {0, 0};
+    if (wave == 0) {   // all lanes of wave 0 carry the same values
         solve_and_encode(S, w * (v1 - v0), ep, start);
-        L.n_cache = 0; L.done = 0; L.last = 0; L.n_want = 0;
-        L.res_x = start[0]; L.res_y = start[1]; L.res_err = -1;
+        if (lane == 0) {
+            L.n_cache = 0; L.done = 0; L.last = 0; L.n_want = 0;
+            L.res_x = start[0]; L.res_y = start[1]; L.res_err = -1;
+        }
     }
     __syncthreads();
     const int cw = (w + 7) >> 3, nchunk = cw * (v1 - v0);
+    int n_pass = 0, n_eval = 0;
     for (int pass = 0; pass < 64; pass++) {
-        if (tid == 0) {
-            L.done = replay(L, ep, start, S) ? 1 : 0;
-            for (int c = 0; c < L.n_want; c++) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718)
-                L.xq0[c] = has0 ? L.wx[c] : 0;
-                L.xq1[c] = !has1 ? 0 : (has0 ? 128 - L.wx[c] - L.wy[c] : 128 - L.wy[c]);
+        if (wave == 0) {
+            const bool fin = replay(L, ep, start, S, lane);
+            if (lane == 0) L.done = fin ? 1 : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kMaxCand) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718); entries past n_want are not read
+                const int x = L.wx[lane], y = L.wy[lane];
+                L.xq0[lane] = has0 ? x : 0;
+                L.xq1[lane] = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);
             }
         }
         __syncthreads();
         if (L.done) break;
         const int nc = L.n_want;
+        n_pass++; n_eval += nc;
         int xq0[kMaxCand], xq1[kMaxCand];
         long long acc[kMaxCand];
 #pragma unroll
@@ -226,6 +246,7 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
         xqd_out[((size_t)unit * 16 + ep) * 2] = L.res_x;
         xqd_out[((size_t)unit * 16 + ep) * 2 + 1] = L.res_y;
         err_out[(size_t)unit * 16 + ep] = L.done ? L.res_err : -1;   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+        atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!L.done) atomicAdd(&stats[2], 1u);   // diagnostics
         __threadfence();
         const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
         if (arrived == (uint32_t)__popc(ep_mask)) {
@@ -249,14 +270,17 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
 
 extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const int16_t* diff0, const int16_t* diff1, const int16_t* sd, int dstride, size_t dplane,
                                        const int64_t* sums, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int32_t* xqd_out,
-                                       int64_t* err_out, uint32_t* counters, uint8_t* best_ep, int32_t* best_xqd) {
+                                       int64_t* err_out, uint32_t* counters, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats) {
     const int voff = 8 >> ss_y;
     dim3 grid(units_x * units_y, 16);
+    // tuning knob (tools/hbd_time.py): unused dynamic LDS per workgroup limits how many (unit, set) walks are in flight, i.e. how much of the
+    // difference planes has to stay cached between a walk's first and second pass
+    static const int lds_pad = getenv("SVT_HIP_SGR_WALK_LDS_PAD") ? atoi(getenv("SVT_HIP_SGR_WALK_LDS_PAD")) * 1024 : 0;
     if (bd == 8)
-        hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), 0, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
-                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd);
+        hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), lds_pad, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
+                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
     else
-        hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), 0, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
-                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd);
+        hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), lds_pad, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
+                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
     return (int)hipGetLastError();
 }

@@ -549,7 +549,7 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
  * launch 2: sgr_walk_kernel: per (unit, set) the 2x2 solve, encode_xq and finer_search_pixel_proj_error; the unit's best set
  * No host synchronisation in between; the scratch (sums, arrival counters, difference planes) is the caller's. */
 namespace {
-struct SgrScratch { size_t sums, counters, sd, d0, d1, total, dplane; int dstride, nu; };
+struct SgrScratch { size_t stats, sums, counters, sd, d0, d1, total, dplane; int dstride, nu; };
 SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     SgrScratch L;
     L.nu = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
@@ -557,6 +557,7 @@ SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     L.dplane = (size_t)L.dstride * (size_t)ph;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
+    L.stats = o;    o = al(o + 16);   // {evaluation passes, evaluated points, unfinished walks, -} over the plane: diagnostics
     L.sums = o;     o = al(o + sizeof(int64_t) * (size_t)L.nu * 16 * 5);
     L.counters = o; o = al(o + sizeof(uint32_t) * (size_t)L.nu);
     L.sd = o;       o = al(o + sizeof(int16_t) * L.dplane);
@@ -588,7 +589,7 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
         return SVT_HIP_ERR_BAD_ARG;
     }
     char* base = (char*)d_scratch;
-    HIPCHK(c, hipMemsetAsync(base + L.sums, 0, L.sd - L.sums, c->stream));   // sums + arrival counters
+    HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // statistics, sums, arrival counters
     const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y, ep_mask,
                                                               (int64_t*)(base + L.sums), (int16_t*)(base + L.d0), (int16_t*)(base + L.d1), (int16_t*)(base + L.sd),
@@ -596,7 +597,7 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
     if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
     e = (hipError_t)svt_hip_launch_sgr_walk(c->stream, bd, (const int16_t*)(base + L.d0), (const int16_t*)(base + L.d1), (const int16_t*)(base + L.sd), L.dstride, L.dplane,
                                             (const int64_t*)(base + L.sums), pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd, d_err, (uint32_t*)(base + L.counters),
-                                            d_best_ep, d_best_xqd);
+                                            d_best_ep, d_best_xqd, (uint32_t*)(base + L.stats));
     if (e != hipSuccess) return fail(c, e, "sgr walk launch");
     return SVT_HIP_OK;
 }

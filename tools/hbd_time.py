@@ -105,7 +105,7 @@ def subpel():
     hip.check(L.svt_hip_subpel_predict_batch_dev(hip.h, pb, bd, d_refp.value + (PAD * refp.shape[1] + PAD) * pb, refp.shape[1], d_pred, W, d_cb, n16), "subpel")
 
 
-def sgr_units_search():   # the complete per-unit search (sums, solve, finer search in rounds), all three planes, 16 sets, shared rounds
+def sgr_units_search():   # the complete per-unit search, host-output form, all three planes, 16 sets
     global rounds_used
     P = (pkg.SgrSearchPlane * 3)()
     for p in range(3):
@@ -149,4 +149,30 @@ hip.sync() if hasattr(hip, "sync") else None
 t0 = time.perf_counter()
 for _ in range(3): sgr_units_search()
 dt = (time.perf_counter() - t0) / 3
-print(f"sgr_units_search {W}x{H} bd{bd}: {dt * 1e3:.2f} ms wall per frame (synchronous host driver; error rounds {rounds_used}; best sets used {sorted(set(int(v) for v in h_best[0]))})")
+print(f"sgr_units_search {W}x{H} bd{bd}: {dt * 1e3:.2f} ms wall per frame (host-output form incl. the result copies; best sets used {sorted(set(int(v) for v in h_best[0]))})")
+
+# the device-output form: two launches per plane, nothing crosses PCIe -- HIP-event time of the whole search
+L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+scr = [L.svt_hip_sgr_search_units_scratch_bytes(rec[p].shape[1], rec[p].shape[0], US[p]) for p in range(3)]
+d_scr = [hip.empty(n) for n in scr]
+d_uxqd = [hip.empty(n * 16 * 8) for n in units]; d_uerr = [hip.empty(n * 16 * 8) for n in units]; d_ubest = [hip.empty(n) for n in units]; d_ubx = [hip.empty(n * 8) for n in units]
+
+
+def sgr_units_dev(mask=0xFFFF):
+    for p in range(3):
+        st = ext[p].shape[1]
+        hip.check(L.svt_hip_sgr_search_units_plane_dev(hip.h, pb, bd, d_ext[p].value + (EXT * st + EXT) * pb, st, d_src[p], rec[p].shape[1], rec[p].shape[1], rec[p].shape[0],
+                                                       US[p], int(p > 0), mask, d_uxqd[p], d_uerr[p], d_ubest[p], d_ubx[p], d_scr[p], scr[p]), "sgr units dev")
+
+
+for mask in (0xFFFF, 0x0038):
+    for _ in range(3): sgr_units_dev(mask)
+    L.svt_hip_timer_start(hip.h)
+    for _ in range(10): sgr_units_dev(mask)
+    L.svt_hip_timer_stop_ms(hip.h, C.byref(ms))
+    print(f"sgr_units_dev  {W}x{H} bd{bd}: {ms.value / 10:.3f} ms device time per frame, ep mask {mask:#06x} (sums + difference planes + walk, all three planes, no host sync; scratch {sum(scr) / 1e6:.0f} MB)")
+sgr_units_dev(0xFFFF)
+for p in range(3):
+    st3 = hip.to_host(d_scr[p], (3,), np.uint32)
+    print(f"  plane {p}: {units[p]} units x 16 sets: {st3[0] / (units[p] * 16):.2f} evaluation passes, {st3[1] / (units[p] * 16):.2f} evaluated points per walk, unfinished {st3[2]}")
+
