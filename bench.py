@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X SVT-AV1 hot path (BASELINE.json metric).
 
-One "step" = one pass of every implemented kernel class of the hot path over ONE synthetic
-4K (3840x2160) 8-bit 4:2:0 frame = 2040 superblocks, inputs resident in
-HBM before the timed region:
-    HME pyramids + variance pyramid -> HME L0/L1/L2 -> integer ME (85 PUs, 64x64 search area, 1 ref) ->
-    sub-pel convolve (every 16x16 luma block) -> residual + fwd txfm + quantize (all planes, per-SB
-    square tiling 4..64) -> inverse txfm + recon -> deblock (3 planes, V then H) -> CDEF strength
-    search (64 strengths, 3 planes) -> CDEF apply -> SGR search (16 parameter sets, 3 planes) -> SGR apply.
-`value` = superblocks per second over the whole job (all ranks).
+One "step" = one pass of every kernel class of the hot path over ONE BATCH of `--frames` (default 4) distinct synthetic 4K (3840x2160)
+8-bit 4:2:0 frames = 2040 superblocks each, inputs resident in HBM before the timed region.  north_star batches
+"all 64x64 superblocks of one (or many concurrent) frames": the frames of a batch are independent pictures (different streams / different
+pictures of the open-loop stages), every kernel class still runs once per frame, the frames' launches are parallel branches of one HIP
+graph.  `--frames 1` is the single-frame step; the JSON line carries the F = 1 / 4 / 8 sweep.  Consecutive steps rotate over
+`--groups` batches of different frames, so the 256 MB Infinity Cache cannot hold a step's working set.
 
-Multi-GPU: frames/streams are independent, so rank i processes its own frame on
-GPU i — no data-path collective; torch.distributed (RCCL) is used only for the barrier and the
-max-over-ranks time.  Scaling is "weak" (per-GPU work fixed).
+Per frame, in the encoder's data flow:
+    source side (open loop, runs ahead of the coding loop):  HME pyramids + variance pyramid -> HME L0/L1/L2 -> integer ME (85 PUs, 64x64
+        search area, 1 reference)
+    reconstruction side: sub-pel prediction of every 16x16 luma block (eighth-pel MVs; decoupled from this frame's ME output as in SURVEY 8(d)
+        config 3 ii) -> residual + fwd txfm + quantize against THAT prediction (luma; chroma predicts from the co-located reference) ->
+        inverse txfm + recon -> deblock (3 planes, V then H) -> CDEF 64-strength search -> CDEF apply (per-fb strengths from the workload:
+        the strength *decision* is host logic of the reference) -> the COMPLETE self-guided search of every restoration unit, 16 sets
+        (sums, 2x2 solve, encode_xq, finer search, best set — all on the device) -> restoration apply with the sets / xqd that search chose.
+`value` = superblocks per second over the whole job (all ranks, all frames of a step).
 
-PyTorch is plumbing only (device memory, streams, distributed); every kernel is launched through the
-C ABI of libsvtav1_hip.so (include/svt_hip.h) on torch's current stream.
+Multi-GPU: frames/streams are independent, so rank i processes its own frames on GPU i — no data-path collective;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.  Scaling is "weak" (per-GPU work fixed).
+
+PyTorch is plumbing only (device memory, streams, graph capture, distributed); every kernel is launched through the C ABI of
+libsvtav1_hip.so (include/svt_hip.h).
 """
 import argparse
 import ctypes as C
@@ -41,34 +48,210 @@ BYTES_PER_SB = {
     "inv_txfm_recon": 36864,                 # dqcoeff 4*6144 + pred 6144 + recon 6144
     "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
     "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
-    "cdef_apply": 12288,                     # 6144 R + 6144 W
+    "cdef_apply": 12288 + 12288,             # 6144 R + 6144 W, plus the device-to-device copy that initialises the destination (R + W)
     "pyramids": 5376 + 4351,                 # decimation 4096 R + 1024 + 256 W ; variance pyramid 4096 R + 85*3 W
     "hme_l0_l1_l2": 256 + 1024 + 4096 + 3 * 12,   # source blocks of the three levels + results (windows are cache-resident)
     "subpel_convolve": 12560,                # 16 blocks x (16+7)^2 R + 4096 W (luma)
-    "sgr_search": 12288 + 640,               # dgd 6144 + source 6144 R + sums
+    "sgr_units_search": 12288 + 640,         # dgd 6144 + source 6144 R + results: the minimum if everything in between stayed on chip
     "sgr_apply": 12288,                      # 6144 R + 6144 W
 }
+STAGE_KERNELS = {
+    "pyramids": "downsample_kernel+variance_pyramid_kernel", "hme_l0_l1_l2": "sad_loop_kernel", "me_fullpel_85pu": "me_fullpel_85pu_kernel",
+    "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel",
+    "deblock": "deblock_frame_pass_kernel", "cdef_search": "cdef_search_luma_kernel+cdef_search_chroma_kernel", "cdef_apply": "cdef_apply_kernel",
+    "sgr_units_search": "sgr_search8_kernel+sgr_walk_kernel", "sgr_apply": "lr_apply8_kernel",
+}
+SOURCE_SIDE = ("pyr", "hme", "me")   # read only source pictures: the open-loop chain, parallel to the reconstruction chain
+EXT = 3                              # RESTORATION_BORDER: recon / CDEF / restoration planes carry a 3-sample border
+
+
+class Env:
+    pass
+
+
+class Pipeline:
+    """The device-resident buffers of ONE frame and the launches of its stages (all through the C ABI)."""
+
+    def __init__(self, E, F, rank):
+        import torch
+        self.E, self.F = E, F
+        ctx, L, pkg, dev, tc, mc, workload = E.ctx, E.L, E.pkg, E.dev, E.tc, E.mc, E.workload
+        W, H = F.w, F.h
+        self.n_sb, PAD = F.n_sb, F.pad
+
+        def T(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.T = T
+        self.d_cur_p, self.d_ref_p = T(F.cur_y_p), T(F.ref_y_p)
+        self.sbs = mc.windows_product(L, W, H, 64, 64)   # the product's own restatement of integer_search_sb's window clamp
+        self.d_sbs = T(np.frombuffer(bytes(self.sbs), dtype=np.uint8).copy())
+        self.d_sad = torch.zeros((self.n_sb, 85), dtype=torch.int32, device=dev)
+        self.d_mv = torch.zeros((self.n_sb, 85), dtype=torch.int32, device=dev)
+        self.d_cur = [T(p) for p in F.cur]
+        self.strides = [p.shape[1] for p in F.cur]
+        self.d_subpel = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+        # prediction of the transform chain: luma = this frame's sub-pel prediction plane, chroma = co-located reference
+        self.d_pred = [self.d_subpel, T(F.ref[1]), T(F.ref[2])]
+        # reconstruction / CDEF output / restoration output: one geometry (stride, 3-sample border) so that whole-buffer copies and the
+        # in-place border extension need no repacking
+        self.xs = [((p.shape[1] + 2 * EXT + 63) // 64) * 64 for p in F.cur]
+        mk = lambda: [torch.zeros((p.shape[0] + 2 * EXT, self.xs[i]), dtype=torch.uint8, device=dev) for i, p in enumerate(F.cur)]
+        self.b_recon, self.b_cdef, self.b_rest = mk(), mk(), mk()
+        org = lambda b, i: b[i].data_ptr() + EXT * self.xs[i] + EXT
+        self.p_recon = [org(self.b_recon, i) for i in range(3)]
+        self.p_cdef = [org(self.b_cdef, i) for i in range(3)]
+        self.p_rest = [org(self.b_rest, i) for i in range(3)]
+        self.tx_jobs, self.keep = [], []
+        for (kind, ts), descs in sorted(F.descs.items()):
+            nk = min(tc.TXW[ts], 32) * min(tc.TXH[ts], 32)
+            d_desc = T(descs)
+            isc = [T(s) if s is not None else None for s in F.scan_tables(ts)]
+            self.keep.append(isc)
+            st = pkg.ScanTables()
+            for c in range(3):
+                st.iscan[c] = isc[c].data_ptr() if isc[c] is not None else None
+            for plane in ([0] if kind == 0 else [1, 2]):
+                qs = pkg.QuantParams()
+                qp = F.qp[plane]
+                for name, row in (("zbin", qp[0]), ("round", qp[1]), ("quant", qp[2]), ("quant_shift", qp[3]), ("dequant", qp[4])):
+                    getattr(qs, name)[0] = int(row[0]); getattr(qs, name)[1] = int(row[1])
+                qs.log_scale = tc.TX_SCALE[ts]; qs.variant = 0
+                n = len(descs)
+                self.tx_jobs.append(dict(ts=ts, plane=plane, n=n, desc=d_desc, qs=qs, st=st,
+                                         q=torch.zeros(n * nk, dtype=torch.int32, device=dev), dq=torch.zeros(n * nk, dtype=torch.int32, device=dev),
+                                         eob=torch.zeros(n, dtype=torch.int16, device=dev), cul=torch.zeros(n, dtype=torch.int32, device=dev)))
+        self.FJ = (pkg.FwdTxJob * len(self.tx_jobs))(); self.IJ = (pkg.InvTxJob * len(self.tx_jobs))()
+        for k, j in enumerate(self.tx_jobs):
+            p = j["plane"]
+            self.FJ[k] = pkg.FwdTxJob(j["ts"], j["n"], self.d_cur[p].data_ptr(), self.strides[p], self.d_pred[p].data_ptr(), self.strides[p], j["desc"].data_ptr(), j["qs"], j["st"],
+                                      None, j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None)
+            self.IJ[k] = pkg.InvTxJob(j["ts"], j["n"], j["dq"].data_ptr(), self.d_pred[p].data_ptr(), self.strides[p], self.p_recon[p], self.xs[p], j["desc"].data_ptr())
+        self.d_edges = [(T(ev), T(eh), ev.shape[1], ev.shape[0]) for ev, eh in F.edges]
+        self.d_skip8 = T(F.skip8)
+        self.d_mse = torch.zeros((2, self.n_sb, 64), dtype=torch.int64, device=dev)
+        self.d_dir = torch.zeros(self.n_sb * 64, dtype=torch.uint8, device=dev)
+        self.d_var = torch.zeros(self.n_sb * 64, dtype=torch.int32, device=dev)
+        self.d_cy, self.d_cuv = T(F.cdef_y), T(F.cdef_uv)
+        # pyramids / HME (SURVEY 8(d) config 3 (i)): 1/4 and 1/16 resolution source + reference, variance pyramid
+        PADQ, PADS = workload.PADQ, workload.PADS
+        qw, qh, sw_, sh_ = W // 2, H // 2, W // 4, H // 4
+        self.d_cur_q = torch.zeros((qh + 2 * PADQ, qw + 2 * PADQ), dtype=torch.uint8, device=dev); self.d_ref_q = torch.zeros_like(self.d_cur_q)
+        self.d_cur_s = torch.zeros((sh_ + 2 * PADS, sw_ + 2 * PADS), dtype=torch.uint8, device=dev); self.d_ref_s = torch.zeros_like(self.d_cur_s)
+        self.d_ymean = torch.zeros((self.n_sb, 85), dtype=torch.uint8, device=dev); self.d_yvar = torch.zeros((self.n_sb, 85), dtype=torch.int16, device=dev)
+        # aligned copy of the current luma for the variance pyramid (needs an 8-byte aligned origin/stride and 64 px of slack)
+        vp = np.zeros((F.sb_rows * 64 + 64, F.sb_cols * 64 + 64), np.uint8); vp[:H, :W] = F.cur[0]
+        self.d_vp = T(vp)
+        self.hme_host = workload.hme_jobs(F)
+        self.hme = [dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(self.n_sb, dtype=torch.int32, device=dev),
+                         xy=torch.zeros((self.n_sb, 2), dtype=torch.int16, device=dev)) for S in self.hme_host]
+        # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into the prediction plane
+        self.CB, self.nblk16 = workload.conv_jobs(F, 14 + rank)
+        self.d_cb = T(np.frombuffer(bytes(self.CB), np.uint8)[:self.nblk16 * C.sizeof(pkg.ConvBlk)].copy())
+        # restoration: the complete per-unit self-guided search (device scratch from the library's own size query) and the apply fed by it
+        self.US = [256, 256, 256]   # restoration unit size per plane: what the reference picks above CIF (set_restoration_unit_size, EbPictureControlSet.c:31-47)
+        self.n_units = [max((F.cur[p].shape[1] + self.US[p] // 2) // self.US[p], 1) * max((F.cur[p].shape[0] + self.US[p] // 2) // self.US[p], 1) for p in range(3)]
+        L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+        self.scr_bytes = [L.svt_hip_sgr_search_units_scratch_bytes(F.cur[p].shape[1], F.cur[p].shape[0], self.US[p]) for p in range(3)]
+        self.d_scr = [torch.zeros(n, dtype=torch.uint8, device=dev) for n in self.scr_bytes]
+        self.d_uxqd = [torch.zeros((n, 16, 2), dtype=torch.int32, device=dev) for n in self.n_units]
+        self.d_uerr = [torch.zeros((n, 16), dtype=torch.int64, device=dev) for n in self.n_units]
+        self.d_ubest = [torch.zeros(n, dtype=torch.uint8, device=dev) for n in self.n_units]
+        self.d_ubx = [torch.zeros((n, 2), dtype=torch.int32, device=dev) for n in self.n_units]
+        self.stage_fns = dict(pyr=self.run_pyramids, hme=self.run_hme, me=self.run_me, subpel=self.run_subpel, txfm=self.run_txfm, inv=self.run_inv, dlf=self.run_dlf,
+                              cdef_search=self.run_cdef_search, cdef_apply=self.run_cdef_apply, sgr_units=self.run_sgr_units, sgr_apply=self.run_sgr_apply)
+
+    # ---------------------------------------------------------------- the kernel classes of a step
+    def chk(self, rc, what):
+        self.E.ctx.check(rc, what)
+
+    def run_me(self):
+        E, F = self.E, self.F
+        self.chk(E.L.svt_hip_me_fullpel_frame_dev(E.ctx.h, self.d_cur_p.data_ptr(), self.d_ref_p.data_ptr(), F.cur_y_p.shape[1], F.pad, F.pad,
+                                                  self.d_sbs.data_ptr(), self.n_sb, 0, self.d_sad.data_ptr(), self.d_mv.data_ptr()), "me")
+
+    def run_txfm(self):   # one mixed-size launch per 16 (size, plane) job lists: the 19 lists of a frame are 400-4000 blocks each
+        self.chk(self.E.L.svt_hip_fwd_txfm_quant_multi_dev(self.E.ctx.h, 1, self.FJ, len(self.tx_jobs)), "fwd")
+
+    def run_inv(self):
+        self.chk(self.E.L.svt_hip_inv_txfm_add_multi_dev(self.E.ctx.h, 1, 8, self.IJ, len(self.tx_jobs)), "inv")
+
+    def run_dlf(self):   # all three planes: one launch per direction
+        e = self.d_edges
+        self.chk(self.E.L.svt_hip_deblock_frame_dev(self.E.ctx.h, P3(*self.p_recon), 1, I3(*self.xs), 8, P3(*[e[p][0].data_ptr() for p in range(3)]),
+                                                    P3(*[e[p][1].data_ptr() for p in range(3)]), I3(*[e[p][2] for p in range(3)]), I3(*[e[p][3] for p in range(3)]), 0), "dlf")
+
+    def run_cdef_search(self):
+        F = self.F
+        self.chk(self.E.L.svt_hip_cdef_search_frame_dev(self.E.ctx.h, 1, P3(*self.p_recon), I3(*self.xs), P3(*[p.data_ptr() for p in self.d_cur]), I3(*self.strides), F.w, F.h,
+                                                        self.d_skip8.data_ptr(), F.cdef_damping, 8, self.d_mse.data_ptr(), self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef search")
+
+    def run_cdef_apply(self):
+        F, L, h = self.F, self.E.L, self.E.ctx.h
+        for p in range(3):   # the destination starts as a copy of the pre-CDEF picture (skipped blocks keep it): stream-ordered device-to-device copies
+            self.chk(L.svt_hip_memcpy_d2d(h, self.b_cdef[p].data_ptr(), self.b_recon[p].data_ptr(), self.b_recon[p].numel()), "d2d")
+        self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_recon), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
+                                                self.d_cuv.data_ptr(), F.cdef_damping, 8, self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef apply")
+
+    def run_pyramids(self):
+        E, F = self.E, self.F
+        PAD, st = F.pad, F.cur_y_p.shape[1]
+        for src_p, dst_t, pad_, step_ in ((self.d_cur_p, self.d_cur_q, E.workload.PADQ, 2), (self.d_cur_p, self.d_cur_s, E.workload.PADS, 4),
+                                          (self.d_ref_p, self.d_ref_q, E.workload.PADQ, 2), (self.d_ref_p, self.d_ref_s, E.workload.PADS, 4)):
+            self.chk(E.L.svt_hip_downsample_2d_dev(E.ctx.h, src_p.data_ptr() + PAD * st + PAD, st, F.w, F.h, dst_t.data_ptr() + pad_ * dst_t.shape[1] + pad_, dst_t.shape[1], step_, 1), "ds")
+        self.chk(E.L.svt_hip_variance_pyramid_dev(E.ctx.h, self.d_vp.data_ptr(), self.d_vp.shape[1], F.sb_cols, self.n_sb, 0, self.d_ymean.data_ptr(), self.d_yvar.data_ptr()), "varpyr")
+
+    def run_hme(self):
+        for lvl, (cur_t, ref_t) in enumerate(((self.d_cur_s, self.d_ref_s), (self.d_cur_q, self.d_ref_q), (self.d_cur_p, self.d_ref_p))):
+            j = self.hme[lvl]
+            self.chk(self.E.L.svt_hip_sad_loop_batch_dev(self.E.ctx.h, cur_t.data_ptr(), cur_t.shape[1], ref_t.data_ptr(), ref_t.shape[1], j["S"].data_ptr(), self.n_sb,
+                                                         j["sad"].data_ptr(), j["xy"].data_ptr()), "hme")
+
+    def run_subpel(self):
+        F = self.F
+        self.chk(self.E.L.svt_hip_subpel_predict_batch_dev(self.E.ctx.h, 1, 8, self.d_ref_p.data_ptr() + F.pad * F.ref_y_p.shape[1] + F.pad, F.ref_y_p.shape[1],
+                                                           self.d_subpel.data_ptr(), F.w, self.d_cb.data_ptr(), self.nblk16), "subpel")
+
+    def run_sgr_units(self):
+        """svt_extend_frame of the CDEF output (in place: the planes carry the border) + search_selfguided_restoration of every unit"""
+        L, h, F = self.E.L, self.E.ctx.h, self.F
+        for p in range(3):
+            ph, pw = F.cur[p].shape
+            self.chk(L.svt_hip_generate_padding_dev(h, self.p_cdef[p], 1, self.xs[p], pw, ph, EXT, EXT), "extend")
+            self.chk(L.svt_hip_sgr_search_units_plane_dev(h, 1, 8, self.p_cdef[p], self.xs[p], self.d_cur[p].data_ptr(), self.strides[p], pw, ph, self.US[p], int(p > 0), 0xFFFF,
+                                                          self.d_uxqd[p].data_ptr(), self.d_uerr[p].data_ptr(), self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr(),
+                                                          self.d_scr[p].data_ptr(), self.scr_bytes[p]), "sgr units")
+
+    def run_sgr_apply(self):   # every unit filtered with the set / xqd its search chose (device arrays), stripe context rows from the deblocked picture
+        L, h, F = self.E.L, self.E.ctx.h, self.F
+        for p in range(3):
+            ph, pw = F.cur[p].shape
+            self.chk(L.svt_hip_sgr_apply_plane_dev(h, 1, 8, self.p_cdef[p], self.xs[p], self.p_rest[p], self.xs[p], pw, ph, self.US[p], int(p > 0), self.p_recon[p], self.xs[p],
+                                                   self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr()), "sgr apply")
+
+
+ALL_STAGES = [("pyr", "pyramids"), ("hme", "hme_l0_l1_l2"), ("me", "me_fullpel_85pu"), ("subpel", "subpel_convolve"), ("txfm", "fwd_txfm_quant"),
+              ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
+              ("sgr_apply", "sgr_apply")]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=4, help="independent frames per step (their launches are parallel branches of one HIP graph)")
+    ap.add_argument("--groups", type=int, default=0, help="distinct batches the steps rotate over (default: enough for >= 4 distinct frames)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-sweep", action="store_true", help="skip the F = 1 / 4 / 8 sweep")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
                     help="reference = the reference's own SIMD kernels (oracle/_ref SIMD flavour); port = the oracle's scalar C; auto = reference when built")
-    ap.add_argument("--cpu-port-too", action="store_true", help="with the reference baseline, also time the scalar port")
-    ap.add_argument("--serial", action="store_true", help="issue every launch on one stream (no intra-step concurrency)")
-    ap.add_argument("--lanes", type=int, default=3, help="streams for the independent launches of a stage (debug)")
-    ap.add_argument("--tx-multi", default="inv", help="which transform stages use the mixed-size launch (debug): fwd,inv / fwd / inv / none")
-    ap.add_argument("--side-keys", default="pyr,hme,me,subpel", help="stages issued on the side stream (debug; must be source-side stages)")
     ap.add_argument("--me-waves", type=int, default=4, help="svt_hip_me_set_waves_per_sb value (debug)")
-    ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the main stream (debug)")
+    ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the frame's main stream (debug)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
-    ap.add_argument("--stages", default="all", help="comma list (debug): pyr,hme,me,subpel,txfm,inv,dlf,cdef_search,cdef_apply,sgr_search,sgr_apply")
+    ap.add_argument("--stages", default="all", help="comma list (debug): " + ",".join(k for k, _ in ALL_STAGES))
     args = ap.parse_args()
 
     import torch
@@ -84,341 +267,343 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from conftest import load_package, ptr
+    from conftest import load_package
     import importlib
     import me_common as mc
     import workload
     import txfm_common as tc
-    pkg = load_package()
+    E = Env()
+    E.pkg = load_package()
     shard = importlib.import_module("svt_av1_amd.shard")
-    orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    ctx = pkg.Context(local_rank)
-    L = ctx.L
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))   # the checker: parity spot check and (port) CPU baseline only, after the timed region
+    E.ctx = E.pkg.Context(local_rank)
+    E.L, E.mc, E.tc, E.workload = E.ctx.L, mc, tc, workload
+    L, ctx = E.L, E.ctx
     stream = torch.cuda.current_stream()
     ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
-    dev = torch.device("cuda", local_rank)
+    E.dev = dev = torch.device("cuda", local_rank)
     ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, args.me_waves))
+    ctx.check(L.svt_hip_me_set_big_windows(ctx.h, 0))   # every window of this workload is 64 x 64 candidates: no strip-walking launch needed
 
     W, H = args.width, args.height
-    F = workload.Frame(W, H, seed=11 + 100 * rank)   # one stream per rank
-    n_sb, PAD = F.n_sb, F.pad
+    nF = max(1, args.frames)
+    sweep_fs = [f for f in (1, 4, 8) if not args.no_sweep or f == nF]
+    n_groups = args.groups if args.groups > 0 else max(2, (4 + nF - 1) // nF)
+    n_pipes = max(nF * n_groups, 8 if (8 in sweep_fs and not args.no_sweep) else 0, 4)
+    frames = [workload.Frame(W, H, seed=11 + 100 * rank + 7 * i) for i in range(n_pipes)]   # distinct pictures
+    pipes = [Pipeline(E, F, rank) for F in frames]
+    n_sb = pipes[0].n_sb
+    want = None if args.stages == "all" else set(args.stages.split(","))
+    stages = [(k, n) for k, n in ALL_STAGES if want is None or k in want]
 
-    def T(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
-    # ---------------------------------------------------------------- device-resident inputs / outputs
-    d_cur_p, d_ref_p = T(F.cur_y_p), T(F.ref_y_p)
-    sbs = mc.windows_product(L, W, H, 64, 64)   # the product's own restatement of integer_search_sb's window clamp
-    d_sbs = T(np.frombuffer(bytes(sbs), dtype=np.uint8).copy())
-    d_sad = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)
-    d_mv = torch.zeros((n_sb, 85), dtype=torch.int32, device=dev)
-    d_cur = [T(p) for p in F.cur]
-    d_pred = [T(p) for p in F.ref]                       # prediction = co-located reference (zero MV)
-    d_recon = [torch.zeros_like(p) for p in d_pred]
-    d_cdef_out = [torch.zeros_like(p) for p in d_pred]
-    strides = [p.shape[1] for p in F.cur]
-    tx_jobs = []   # one launch per (plane, tx size)
-    keep = []
-    for (kind, ts), descs in sorted(F.descs.items()):
-        nk = min(tc.TXW[ts], 32) * min(tc.TXH[ts], 32)
-        d_desc = T(descs)
-        isc = [T(s) if s is not None else None for s in F.scan_tables(ts)]
-        keep.append(isc)
-        st = pkg.ScanTables()
-        for c in range(3):
-            st.iscan[c] = isc[c].data_ptr() if isc[c] is not None else None
-        for plane in ([0] if kind == 0 else [1, 2]):
-            qs = pkg.QuantParams()
-            qp = F.qp[plane]
-            for name, row in (("zbin", qp[0]), ("round", qp[1]), ("quant", qp[2]), ("quant_shift", qp[3]), ("dequant", qp[4])):
-                getattr(qs, name)[0] = int(row[0]); getattr(qs, name)[1] = int(row[1])
-            qs.log_scale = tc.TX_SCALE[ts]; qs.variant = 0
-            n = len(descs)
-            tx_jobs.append(dict(ts=ts, plane=plane, n=n, desc=d_desc, qs=qs, st=st,
-                                q=torch.zeros(n * nk, dtype=torch.int32, device=dev), dq=torch.zeros(n * nk, dtype=torch.int32, device=dev),
-                                eob=torch.zeros(n, dtype=torch.int16, device=dev), cul=torch.zeros(n, dtype=torch.int32, device=dev)))
-    d_edges = [(T(ev), T(eh), ev.shape[1], ev.shape[0]) for ev, eh in F.edges]
-    d_skip8 = T(F.skip8)
-    d_mse = torch.zeros((2, n_sb, 64), dtype=torch.int64, device=dev)
-    d_dir = torch.zeros(n_sb * 64, dtype=torch.uint8, device=dev)
-    d_var = torch.zeros(n_sb * 64, dtype=torch.int32, device=dev)
-    d_cy, d_cuv = T(F.cdef_y), T(F.cdef_uv)
-    # pyramids / HME: 1/4 and 1/16 resolution source + reference, variance pyramid
-    PADQ, PADS = 32, 16
-    qw, qh, sw_, sh_ = W // 2, H // 2, W // 4, H // 4
-    d_cur_q = torch.zeros((qh + 2 * PADQ, qw + 2 * PADQ), dtype=torch.uint8, device=dev); d_ref_q = torch.zeros_like(d_cur_q)
-    d_cur_s = torch.zeros((sh_ + 2 * PADS, sw_ + 2 * PADS), dtype=torch.uint8, device=dev); d_ref_s = torch.zeros_like(d_cur_s)
-    d_ymean = torch.zeros((n_sb, 85), dtype=torch.uint8, device=dev); d_yvar = torch.zeros((n_sb, 85), dtype=torch.int16, device=dev)
-    # aligned copy of the current luma for the variance pyramid (needs an 8-byte aligned origin/stride and 64 px of slack)
-    vp = np.zeros((F.sb_rows * 64 + 64, F.sb_cols * 64 + 64), np.uint8); vp[:H, :W] = F.cur[0]
-    d_vp = T(vp)
-    hme_host = workload.hme_jobs(F)
-    hme = [dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(n_sb, dtype=torch.int32, device=dev),
-                xy=torch.zeros((n_sb, 2), dtype=torch.int16, device=dev)) for S in hme_host]
-    # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into a prediction plane
-    CB, nblk16 = workload.conv_jobs(F, 14 + rank)
-    k = nblk16
-    rng = np.random.default_rng(15 + rank)
-    d_cb = T(np.frombuffer(bytes(CB), np.uint8)[:k * C.sizeof(pkg.ConvBlk)].copy())
-    d_subpel = torch.zeros((H, W), dtype=torch.uint8, device=dev)
-    # SGR: 3-px extended copies of the CDEF output, projection sums for all 16 sets, apply with fixed per-unit sets
-    EXT = 3
-    d_ext = [torch.zeros((p.shape[0] + 2 * EXT, p.shape[1] + 2 * EXT + ((-(p.shape[1] + 2 * EXT)) % 4), ), dtype=torch.uint8, device=dev) for p in d_pred]
-    US = [256, 256, 256]   # restoration unit size per plane: what the reference picks above CIF (set_restoration_unit_size, EbPictureControlSet.c:31-47)
-    n_units = [max((F.cur[p].shape[1] + US[p] // 2) // US[p], 1) * max((F.cur[p].shape[0] + US[p] // 2) // US[p], 1) for p in range(3)]
-    d_sgr_sums = [torch.zeros((n_units[p], 16, 5), dtype=torch.int64, device=dev) for p in range(3)]
-    d_unit_ep = [T(rng.integers(0, 16, n_units[p]).astype(np.uint8)) for p in range(3)]
-    d_unit_xqd = [T(np.stack([rng.integers(-96, 32, n_units[p]), rng.integers(-32, 96, n_units[p])], 1).astype(np.int32)) for p in range(3)]
-    d_sgr_out = [torch.zeros_like(p) for p in d_pred]
-
-    # ---------------------------------------------------------------- streams
-    # Independent launches of a stage (planes, transform sizes) and the two data-independent halves of a step (the source-side
-    # chain pyramids -> HME -> ME -> sub-pel, and the reconstruction-side chain transform -> deblock -> CDEF -> restoration) are
-    # issued on separate HIP streams, forked from and joined back into the stream that carries the step; inside a captured graph
-    # these become parallel branches, so short kernels fill each other's tails and the VALU-bound search kernels overlap the
-    # HBM-bound transform / filter passes.  --serial keeps everything on one stream.
-    S = {"cur": stream}
-    n_lanes = 1 if args.serial else args.lanes
-    lanes = [torch.cuda.Stream() for _ in range(n_lanes)] if n_lanes > 1 else []
-    side = torch.cuda.Stream() if not (args.serial or args.no_side) else None
+    # ---------------------------------------------------------------- streams / graphs
+    # A frame's step is two chains: the source side (pyramids -> HME -> ME; open loop, reads source pictures only) and the reconstruction side
+    # (sub-pel -> transform -> inverse -> deblock -> CDEF -> restoration).  Each chain of each frame of the batch gets its own HIP stream, forked
+    # from and joined back into the stream that carries the step; inside a captured graph these are parallel branches, so the short
+    # memory-side kernels of one frame fill the gaps next to the VALU-bound searches of another.
+    cur = {"s": stream}
 
     class on:
         def __init__(self, st):
             self.st = st
 
         def __enter__(self):
-            self.prev = S["cur"]
-            S["cur"] = self.st
+            self.prev = cur["s"]
+            cur["s"] = self.st
             ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(self.st.cuda_stream)))
             self.t = torch.cuda.stream(self.st)
             self.t.__enter__()
 
         def __exit__(self, *a):
             self.t.__exit__(*a)
-            S["cur"] = self.prev
+            cur["s"] = self.prev
             ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(self.prev.cuda_stream)))
 
-    def parallel(jobs):
-        """Run the callables round-robin on the lane streams, forked from / joined into the current stream."""
-        if not lanes or len(jobs) < 2 or S["cur"] is side:   # the lanes belong to the main chain
-            for j in jobs:
-                j()
-            return
-        base = S["cur"]
-        used = lanes[:min(len(lanes), len(jobs))]
-        for ln in used:
-            ln.wait_stream(base)
-        for i, j in enumerate(jobs):
-            with on(used[i % len(used)]):
-                j()
-        for ln in used:
-            base.wait_stream(ln)
+    max_f = max([nF] + (sweep_fs if not args.no_sweep else []))
+    main_streams = [torch.cuda.Stream() for _ in range(max_f)]
+    side_streams = [torch.cuda.Stream() for _ in range(max_f)] if not args.no_side else None
 
-    # ---------------------------------------------------------------- the kernel classes of a step
-    def run_me():
-        ctx.check(L.svt_hip_me_fullpel_frame_dev(ctx.h, d_cur_p.data_ptr(), d_ref_p.data_ptr(), F.cur_y_p.shape[1], PAD, PAD,
-                                                 d_sbs.data_ptr(), n_sb, 0, d_sad.data_ptr(), d_mv.data_ptr()), "me")
-
-    # one mixed-size launch per 16 (size, plane) job lists (svt_hip_*_multi_dev): the 19 lists of a frame are 400-4000 blocks each
-    FJ = (pkg.FwdTxJob * len(tx_jobs))(); IJ = (pkg.InvTxJob * len(tx_jobs))()
-    for k, j in enumerate(tx_jobs):
-        p = j["plane"]
-        FJ[k] = pkg.FwdTxJob(j["ts"], j["n"], d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["qs"], j["st"],
-                             None, j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None)
-        IJ[k] = pkg.InvTxJob(j["ts"], j["n"], j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p], d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr())
-
-    def txfm_job(j):
-        p = j["plane"]
-        ctx.check(L.svt_hip_fwd_txfm_quant_batch_dev(ctx.h, j["ts"], 1, d_cur[p].data_ptr(), strides[p], d_pred[p].data_ptr(), strides[p],
-                                                     j["desc"].data_ptr(), j["n"], C.byref(j["qs"]), C.byref(j["st"]), None,
-                                                     j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None), "fwd")
-
-    def inv_job(j):
-        p = j["plane"]
-        ctx.check(L.svt_hip_inv_txfm_add_batch_dev(ctx.h, j["ts"], 1, 8, j["dq"].data_ptr(), d_pred[p].data_ptr(), strides[p],
-                                                   d_recon[p].data_ptr(), strides[p], j["desc"].data_ptr(), j["n"]), "inv")
-
-    def run_txfm():
-        if "fwd" in args.tx_multi:
-            ctx.check(L.svt_hip_fwd_txfm_quant_multi_dev(ctx.h, 1, FJ, len(tx_jobs)), "fwd")
-        else:
-            parallel([lambda j=j: txfm_job(j) for j in tx_jobs])
-
-    def run_inv():
-        if "inv" in args.tx_multi:
-            ctx.check(L.svt_hip_inv_txfm_add_multi_dev(ctx.h, 1, 8, IJ, len(tx_jobs)), "inv")
-        else:
-            parallel([lambda j=j: inv_job(j) for j in tx_jobs])
-
-    def run_dlf():   # all three planes: one launch per direction
-        ctx.check(L.svt_hip_deblock_frame_dev(ctx.h, P3(*[p.data_ptr() for p in d_recon]), 1, I3(*strides), 8, P3(*[d_edges[p][0].data_ptr() for p in range(3)]),
-                                              P3(*[d_edges[p][1].data_ptr() for p in range(3)]), I3(*[d_edges[p][2] for p in range(3)]),
-                                              I3(*[d_edges[p][3] for p in range(3)]), 0), "dlf")
-
-    def dlf_plane(p):
-        if True:
-            ev, eh, uw, uh = d_edges[p]
-            ctx.check(L.svt_hip_deblock_plane_dev(ctx.h, d_recon[p].data_ptr(), 1, strides[p], 8, ev.data_ptr(), eh.data_ptr(), uw, uh, 0), "dlf")
-
-    def run_cdef_search():
-        ctx.check(L.svt_hip_cdef_search_frame_dev(ctx.h, 1, P3(*[p.data_ptr() for p in d_recon]), I3(*strides), P3(*[p.data_ptr() for p in d_cur]),
-                                                  I3(*strides), W, H, d_skip8.data_ptr(), F.cdef_damping, 8, d_mse.data_ptr(), d_dir.data_ptr(),
-                                                  d_var.data_ptr()), "cdef search")
-
-    def run_cdef_apply():
-        for p in range(3):
-            d_cdef_out[p].copy_(d_recon[p])   # destination starts as a copy of the pre-CDEF picture (device-to-device)
-        ctx.check(L.svt_hip_cdef_apply_frame_dev(ctx.h, 1, P3(*[p.data_ptr() for p in d_recon]), P3(*[p.data_ptr() for p in d_cdef_out]),
-                                                 I3(*strides), W, H, d_skip8.data_ptr(), d_cy.data_ptr(), d_cuv.data_ptr(), F.cdef_damping, 8,
-                                                 d_dir.data_ptr(), d_var.data_ptr()), "cdef apply")
-
-    def pyr_job(src_p, dst_t, pad_, step_):
-        org = src_p.data_ptr() + PAD * F.cur_y_p.shape[1] + PAD
-        ctx.check(L.svt_hip_downsample_2d_dev(ctx.h, org, F.cur_y_p.shape[1], W, H, dst_t.data_ptr() + pad_ * dst_t.shape[1] + pad_, dst_t.shape[1], step_, 1), "ds")
-
-    def run_pyramids():
-        parallel([lambda: pyr_job(d_cur_p, d_cur_q, PADQ, 2), lambda: pyr_job(d_cur_p, d_cur_s, PADS, 4),
-                  lambda: pyr_job(d_ref_p, d_ref_q, PADQ, 2), lambda: pyr_job(d_ref_p, d_ref_s, PADS, 4),
-                  lambda: ctx.check(L.svt_hip_variance_pyramid_dev(ctx.h, d_vp.data_ptr(), d_vp.shape[1], F.sb_cols, n_sb, 0, d_ymean.data_ptr(), d_yvar.data_ptr()), "varpyr")])
-
-    def run_hme():
-        for lvl, (cur_t, ref_t) in enumerate(((d_cur_s, d_ref_s), (d_cur_q, d_ref_q), (d_cur_p, d_ref_p))):
-            j = hme[lvl]
-            ctx.check(L.svt_hip_sad_loop_batch_dev(ctx.h, cur_t.data_ptr(), cur_t.shape[1], ref_t.data_ptr(), ref_t.shape[1], j["S"].data_ptr(), n_sb,
-                                                   j["sad"].data_ptr(), j["xy"].data_ptr()), "hme")
-
-    def run_subpel():
-        ctx.check(L.svt_hip_subpel_predict_batch_dev(ctx.h, 1, 8, d_ref_p.data_ptr() + PAD * F.ref_y_p.shape[1] + PAD, F.ref_y_p.shape[1],
-                                                     d_subpel.data_ptr(), W, d_cb.data_ptr(), nblk16), "subpel")
-
-    def sgr_extend(p):
-        # svt_extend_frame equivalent (device-to-device, torch slicing = plumbing): 3-px edge replication of the CDEF output
-        h_, w_ = d_cdef_out[p].shape
-        e = d_ext[p]
-        e[EXT:EXT + h_, EXT:EXT + w_] = d_cdef_out[p]
-        e[EXT:EXT + h_, :EXT] = d_cdef_out[p][:, :1]; e[EXT:EXT + h_, EXT + w_:EXT + w_ + EXT] = d_cdef_out[p][:, -1:]
-        e[:EXT, :] = e[EXT:EXT + 1, :]; e[EXT + h_:EXT + h_ + EXT, :] = e[EXT + h_ - 1:EXT + h_, :]
-
-    def sgr_search_plane(p):
-        sgr_extend(p)
-        d_sgr_sums[p].zero_()
-        h_, w_ = d_cdef_out[p].shape
-        ctx.check(L.svt_hip_sgr_search_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_cur[p].data_ptr(),
-                                                 strides[p], w_, h_, US[p], int(p > 0), 0xFFFF, d_sgr_sums[p].data_ptr()), "sgr search")
-
-    def run_sgr_search():
-        parallel([lambda p=p: sgr_search_plane(p) for p in range(3)])
-
-    def sgr_apply_plane(p):
-        h_, w_ = d_cdef_out[p].shape
-        ctx.check(L.svt_hip_sgr_apply_plane_dev(ctx.h, 1, 8, d_ext[p].data_ptr() + EXT * d_ext[p].shape[1] + EXT, d_ext[p].shape[1], d_sgr_out[p].data_ptr(),
-                                                strides[p], w_, h_, US[p], int(p > 0), d_recon[p].data_ptr(), strides[p],   # stripe context rows from the deblocked picture
-                                                d_unit_ep[p].data_ptr(), d_unit_xqd[p].data_ptr()), "sgr apply")
-
-    def run_sgr_apply():
-        parallel([lambda p=p: sgr_apply_plane(p) for p in range(3)])
-
-    all_stages = [
-        dict(key="pyr", name="pyramids", run=run_pyramids, kernel="downsample_kernel+variance_pyramid_kernel"),
-        dict(key="hme", name="hme_l0_l1_l2", run=run_hme, kernel="sad_loop_kernel"),
-        dict(key="me", name="me_fullpel_85pu", run=run_me, kernel="me_fullpel_85pu_kernel"),
-        dict(key="subpel", name="subpel_convolve", run=run_subpel, kernel="subpel_predict_kernel"),
-        dict(key="txfm", name="fwd_txfm_quant", run=run_txfm, kernel="fwd_txfm_quant_multi_kernel"),
-        dict(key="inv", name="inv_txfm_recon", run=run_inv, kernel="inv_txfm_add_multi_kernel"),
-        dict(key="dlf", name="deblock", run=run_dlf, kernel="deblock_pass_kernel"),
-        dict(key="cdef_search", name="cdef_search", run=run_cdef_search, kernel="cdef_search_luma_kernel"),
-        dict(key="cdef_apply", name="cdef_apply", run=run_cdef_apply, kernel="cdef_apply_kernel"),
-        dict(key="sgr_search", name="sgr_search", run=run_sgr_search, kernel="sgr_search8_kernel"),
-        dict(key="sgr_apply", name="sgr_apply", run=run_sgr_apply, kernel="lr_apply8_kernel"),
-    ]
-    want = None if args.stages == "all" else set(args.stages.split(","))
-    stages = [s for s in all_stages if want is None or s["key"] in want]
-
-    # read only the source / reference pictures: independent of the reconstruction chain
-    SOURCE_SIDE = tuple(k for k in args.side_keys.split(",") if k in ("pyr", "hme", "me", "subpel"))
-
-    def step():
-        if side is None:
-            for st in stages:
-                st["run"]()
-            return
-        base = S["cur"]
-        side.wait_stream(base)
-        with on(side):
-            for st in stages:
-                if st["key"] in SOURCE_SIDE:
-                    st["run"]()
-        for st in stages:
-            if st["key"] not in SOURCE_SIDE:
-                st["run"]()
-        base.wait_stream(side)
+    def batch_step(batch):
+        base = cur["s"]
+        used = []
+        for i, P in enumerate(batch):
+            ms = main_streams[i]
+            ms.wait_stream(base)
+            used.append(ms)
+            if side_streams is not None:
+                ss = side_streams[i]
+                ss.wait_stream(base)
+                used.append(ss)
+                with on(ss):
+                    for k, _ in stages:
+                        if k in SOURCE_SIDE:
+                            P.stage_fns[k]()
+            with on(ms):
+                for k, _ in stages:
+                    if side_streams is None or k not in SOURCE_SIDE:
+                        P.stage_fns[k]()
+        for st in used:
+            base.wait_stream(st)
 
     def capture(fn, reps=1):
-        """One HIP graph of `reps` back-to-back calls of fn(): a frame step is ~80 short launches, replaying a captured
-        graph takes the host (Python, ctypes) out of the timed region.  The library's _dev entry points only enqueue
-        work on the context's stream, so they are capture-safe; the context is pointed at the capture stream meanwhile."""
+        """One HIP graph of `reps` back-to-back calls of fn(): a step is a few hundred short launches, replaying a captured graph takes the host
+        (Python, ctypes) out of the timed region.  The library's _dev entry points only enqueue work on the context's stream, so they are
+        capture-safe; the context is pointed at the capture stream meanwhile."""
         g = torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream()
         cap.wait_stream(stream)
         ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(cap.cuda_stream)))
-        S["cur"] = cap
+        cur["s"] = cap
         try:
             with torch.cuda.graph(g, stream=cap):
                 for _ in range(reps):
                     fn()
         finally:
-            S["cur"] = stream
+            cur["s"] = stream
             ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
         return g
 
-    step()                      # eager once: first-touch, lazy module loads
-    torch.cuda.synchronize()
     use_graph = not args.no_graph
-    if use_graph:
-        g_step = capture(step)
-        do_step = g_step.replay
-    else:
-        do_step = step
-    for _ in range(args.warmup):
-        do_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        do_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
 
-    # ---- per-stage device time with HIP events on the launch stream (outside the headline timing): `reps` back-to-back
-    #      passes of one stage (one captured graph unless --no-graph), so the figure is kernel time, not launch gaps
-    per_stage = {}
-    for st in stages:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(5, args.steps)
+    def make_steps(f):
+        """the rotating step functions for batches of f frames over all pipelines"""
+        batches = [pipes[i:i + f] for i in range(0, len(pipes) - f + 1, f)]
+        for b in batches:
+            batch_step(b)           # eager once: first-touch, lazy module loads
+        torch.cuda.synchronize()
         if use_graph:
-            g = capture(st["run"], reps)
+            return [capture(lambda b=b: batch_step(b)).replay for b in batches]
+        return [lambda b=b: batch_step(b) for b in batches]
+
+    def timed(fns, steps, warmup, barrier):
+        for i in range(warmup):
+            fns[i % len(fns)]()
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fns[i % len(fns)]()
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    step_fns = make_steps(nF)
+    elapsed = shard.max_over_ranks(timed(step_fns, args.steps, args.warmup, True), dist if world > 1 else None, dev)
+
+    # ---- the same step at other batch sizes (rank 0 reports; a few dozen steps each)
+    sweep = {str(nF): {"ms_per_step": elapsed / args.steps * 1e3, "sb_per_s": nF * n_sb * args.steps / elapsed}}
+    if not args.no_sweep:
+        for f in sweep_fs:
+            if f == nF or f > len(pipes):
+                continue
+            fns = make_steps(f)
+            n = max(10, min(args.steps, 40))
+            t = timed(fns, n, 3, False)
+            sweep[str(f)] = {"ms_per_step": t / n * 1e3, "sb_per_s": f * n_sb * n / t}
+            del fns
+
+    # ---- per-stage device time with HIP events on the launch stream (outside the headline timing): `reps` back-to-back passes of one stage of
+    #      ONE frame (one captured graph unless --no-graph), so the figure is that stage's kernel time alone on an otherwise idle GPU
+    per_stage = {}
+    P0 = pipes[0]
+    for k, name in stages:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        fn = P0.stage_fns[k]
+        if use_graph:
+            g = capture(fn, reps)
             g.replay()
             torch.cuda.synchronize()
             e0.record(stream)
             g.replay()
             e1.record(stream)
         else:
+            fn()
+            torch.cuda.synchronize()
             e0.record(stream)
             for _ in range(reps):
-                st["run"]()
+                fn()
             e1.record(stream)
         e1.synchronize()
-        per_stage[st["name"]] = e0.elapsed_time(e1) / reps  # ms per frame
-    dominant = max(stages, key=lambda s: per_stage[s["name"]])
-    dom_ms = per_stage[dominant["name"]]
-    achieved_gbs = BYTES_PER_SB[dominant["name"]] * n_sb / (dom_ms * 1e-3) / 1e9
-    # HBM traffic of the dominant stage per frame from the PMC passes of the latest profiled round (tools/collect_profiles.sh:
-    # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs; summary committed as profiles/<round>/pmc_traffic.json)
+        per_stage[name] = e0.elapsed_time(e1) / reps  # ms per frame
+
+    # ---- PCIe-inclusive rate (SURVEY 8(d) "with and without transfers"): every step additionally uploads its batch's source pictures from pinned
+    #      host memory (padded luma + U + V = what a new input picture is; references are earlier inputs and already resident) and downloads its
+    #      results (ME SAD / MV tables, CDEF distortion table, restoration search results, the restored picture) on a copy stream; uploads of batch
+    #      i+1 and downloads of batch i-1 overlap the compute of batch i
+    with_transfers = None
+    if not args.no_transfers and world == 1 and len(step_fns) >= 2:
+        with_transfers = measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, max(10, min(args.steps, 40)))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- parity spot check of what was just timed — the checker, not the product
+    parity_ok = None
+    F0 = frames[0]
+    if any(k == "me" for k, _ in stages):
+        g_sad = P0.d_sad.cpu().numpy().view(np.uint32); g_mv = P0.d_mv.cpu().numpy().view(np.uint32)
+        k8 = min(F0.sb_cols, 8)
+        o_sad, o_mv = mc.oracle_frame(orc, F0.cur_y_p, F0.ref_y_p, F0.cur_y_p.shape[1], F0.pad, P0.sbs, 0, 0, k8)
+        parity_ok = bool(np.array_equal(o_sad[:k8], g_sad[:k8]) and np.array_equal(o_mv[:k8], g_mv[:k8]))
+        simd_lib = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
+        if os.path.exists(simd_lib) and world == 1:   # the whole frame against the reference's own (SIMD) kernels: 2040 SBs x 85 PUs
+            refb = C.CDLL(simd_lib)
+            refb.refb_setup.restype = C.c_uint64; refb.refb_setup.argtypes = [C.c_uint64]; refb.refb_setup(0xFFFFFFFFFFFFFFFF)
+            refb.refb_parallel.restype = C.c_double; refb.refb_parallel.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+            r_sad = np.zeros((n_sb, 85), np.uint32); r_mv = np.zeros((n_sb, 85), np.uint32)
+            slots = (C.c_int64 * 10)(F0.cur_y_p.ctypes.data, F0.ref_y_p.ctypes.data, F0.cur_y_p.shape[1], F0.pad, F0.pad, C.addressof(P0.sbs), n_sb, 0, r_sad.ctypes.data, r_mv.ctypes.data)
+            refb.refb_parallel(0, C.addressof(slots), n_sb, 8, min(len(os.sched_getaffinity(0)), 128), 1)
+            parity_ok = bool(parity_ok and np.array_equal(r_sad, g_sad) and np.array_equal(r_mv, g_mv))
+    walk_stats = None
+    if any(k == "sgr_units" for k, _ in stages):   # diagnostics the search leaves at the start of its scratch: passes / points per walk, unfinished walks
+        st3 = [P0.d_scr[p][:96].cpu().numpy().view(np.uint32) for p in range(3)]
+        nw = 16 * sum(P0.n_units)
+        walk_stats = {"passes_per_walk": float(sum(int(s[0]) for s in st3)) / nw, "points_per_walk": float(sum(int(s[1]) for s in st3)) / nw,
+                      "unfinished": int(sum(int(s[2]) for s in st3)), "passes_histogram": [int(sum(int(s[8 + i]) for s in st3)) for i in range(16)]}
+        parity_ok = bool(parity_ok is not False and walk_stats["unfinished"] == 0)
+
+    # ---- CPU baseline: the reference's own kernels over the same job lists (or the oracle port), all hardware threads and one thread
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        stage_keys = [dict(key=k, name=n) for k, n in stages]
+        jobs = dict(hme=P0.hme_host, conv=(P0.CB, P0.nblk16), unit=P0.US[0])
+        simd = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
+        if args.cpu_baseline in ("auto", "reference") and os.path.exists(simd):
+            cpu = cpu_baseline_reference(C.CDLL(simd), orc, F0, P0.sbs, mc, tc, stage_keys, jobs)
+        elif args.cpu_baseline == "reference":
+            raise SystemExit("oracle/_ref/libsvtav1_ref_simd.so is not built (make -f oracle/Makefile.ref simd)")
+        else:
+            cpu = cpu_baseline(orc, F0, P0.sbs, mc, tc, stage_keys, jobs)
+
+    out = {
+        "metric": METRIC, "value": nF * n_sb * args.steps * world / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step x 2 forked streams (source side / reconstruction side), "
+                  f"steps rotate over {len(step_fns)} batches = {len(step_fns) * nF} distinct frames",
+        "value_with_transfers": with_transfers,
+        "frames_per_step_sweep": sweep,
+        "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frames, {n_sb} SBs/frame, {nF} independent frames per step per GPU (F = 1 / 4 / 8 in frames_per_step_sweep); "
+                               "stages per frame: " + ",".join(n for _, n in stages)
+                               + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16 at random eighth-pel MVs (decoupled from this "
+                                 "frame's ME result, SURVEY 8(d) config 3 ii); transform: luma residual against THAT sub-pel prediction, chroma against the co-located reference, "
+                                 "square tx tiling 4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12) on the reconstruction; CDEF full 64-strength search on the "
+                                 "deblocked picture, apply with workload strengths (strength decision = host logic); restoration: complete search_selfguided_restoration of "
+                                 "every unit (16 sets, units 256, solve + finer search on the device) on the CDEF output, apply with the sets it chose",
+                   "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes)",
+                   "parity_spot_check": parity_ok, "sgr_walk": walk_stats},
+        "cpu_baseline": cpu,
+    }
+    out["roofline"] = roofline(per_stage, stages, n_sb)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
+    batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
+    copy_s = torch.cuda.Stream()
+    pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host = []
+    up_bytes = down_bytes = 0
+    for P in pipes:
+        ups = [(P.d_cur_p, pin(P.d_cur_p).copy_(P.d_cur_p.cpu())), (P.d_cur[1], pin(P.d_cur[1]).copy_(P.d_cur[1].cpu())), (P.d_cur[2], pin(P.d_cur[2]).copy_(P.d_cur[2].cpu()))]
+        downs = [(P.d_sad, pin(P.d_sad)), (P.d_mv, pin(P.d_mv)), (P.d_mse, pin(P.d_mse))] + [(t, pin(t)) for t in P.d_ubest + P.d_ubx] + [(t, pin(t)) for t in P.b_rest]
+        host.append((ups, downs))
+        up_bytes = sum(d.numel() * d.element_size() for d, _ in ups); down_bytes = sum(d.numel() * d.element_size() for d, _ in downs)
+    idx = {id(P): i for i, P in enumerate(pipes)}
+    up_done = [torch.cuda.Event() for _ in batches]
+    comp_done = [torch.cuda.Event() for _ in batches]
+    down_done = [torch.cuda.Event() for _ in batches]
+
+    def upload(b):
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(comp_done[b])          # the previous compute on these buffers has finished
+            for P in batches[b]:
+                for d, h in host[idx[id(P)]][0]:
+                    d.copy_(h, non_blocking=True)
+                P.d_cur[0].copy_(P.d_cur_p[P.F.pad:P.F.pad + P.F.h, P.F.pad:P.F.pad + P.F.w], non_blocking=True)   # un-padded view of the luma for the transform / filter stages (device-to-device)
+                P.d_vp[:P.F.h, :P.F.w].copy_(P.d_cur[0], non_blocking=True)
+            up_done[b].record(copy_s)
+
+    def download(b):
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(comp_done[b])
+            for P in batches[b]:
+                for d, h in host[idx[id(P)]][1]:
+                    h.copy_(d, non_blocking=True)
+            down_done[b].record(copy_s)
+
+    nb = len(batches)
+    for b in range(nb):
+        comp_done[b].record(stream)
+    torch.cuda.synchronize()
+
+    def run(n):
+        upload(0)
+        for i in range(n):
+            b = i % nb
+            stream.wait_event(up_done[b])
+            step_fns[b]()
+            comp_done[b].record(stream)
+            download(b)
+            if i + 1 < n:
+                upload((i + 1) % nb)      # waits (on the copy stream) for the step that last used those buffers; overlaps the step just launched
+        torch.cuda.synchronize()
+
+    run(3)
+    t0 = time.perf_counter()
+    run(steps)
+    t = time.perf_counter() - t0
+    return {"value": nF * n_sb * steps / t, "unit": "SB/s", "ms_per_step": t / steps * 1e3, "h2d_bytes_per_frame": up_bytes, "d2h_bytes_per_frame": down_bytes,
+            "note": "every step uploads its frames' source pictures (padded luma, U, V) from pinned host memory and downloads ME tables, CDEF distortion table, restoration "
+                    "search results and the restored picture, on a copy stream overlapped with the neighbouring steps' compute"}
+
+
+def roofline(per_stage, stages, n_sb):
+    """The dominant kernel class of the step and what bounds it.  The three searches are integer-VALU bound by construction (4096 candidates, 64
+    strength pairs, 16 parameter sets per sample), so their fraction is work-based: useful operations per second against the issue peak of the
+    instruction that carries the work."""
+    names = [n for _, n in stages]
+    dom = max(names, key=lambda n: per_stage[n])
+    r = {"kernel": STAGE_KERNELS[dom], "stage": dom}
+    per_stage_gbs = {n: BYTES_PER_SB[n] * n_sb / (per_stage[n] * 1e-3) / 1e9 for n in names}
+    valu = {}
+    if "me_fullpel_85pu" in per_stage:
+        ms = per_stage["me_fullpel_85pu"]
+        ach = 4096 * 4096 * n_sb / (ms * 1e-3) / 1e12
+        peak = 1024 * 64 * 16 / 16.0 * 2.4e9 / 1e12
+        valu["me_fullpel_85pu"] = {"achieved": ach, "peak": peak, "unit": "T px-SAD/s", "frac": ach / peak,
+                                   "note": "4096 px x 4096 candidates per SB; peak = 1024 SIMDs x 64 lanes x 16 abs-diff per v_qsad_pk_u16_u8 / 16 cycles x 2.4 GHz (issue rate measured: "
+                                           "profiles/r01/ubench_sad_rate.txt)"}
+    if "cdef_search" in per_stage:
+        ms = per_stage["cdef_search"]
+        # minimum per pixel and strength pair (luma 64, chroma 2 x 64 on quarter-size planes): combine + round + clamp + squared error on packed 16-bit pairs
+        work = 6144 * 64 * 4.0 * n_sb          # 4 lane-operations per (pixel, strength): add primary+secondary, round/shift, clamp, accumulate (d - s)^2
+        valu["cdef_search"] = {"achieved": work / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 2.4e9 / 4.0 / 1e12 * 2, "unit": "T lane-op/s",
+                               "note": "work = 6144 px x 64 strengths x 4 ops per SB (the strength-dependent minimum: combine, round, clamp, squared error); peak = 1024 SIMDs x 64 "
+                                       "lanes x 2 packed 16-bit results per instruction / 4 cycles x 2.4 GHz"}
+        valu["cdef_search"]["frac"] = valu["cdef_search"]["achieved"] / valu["cdef_search"]["peak"]
+    if "sgr_units_search" in per_stage:
+        ms = per_stage["sgr_units_search"]
+        work = 6144 * (23 * 30.0 + 16 * 9.2 * 4.0) * n_sb   # 23 distinct box filters x ~30 ops per pixel + 16 sets x ~9.2 probes x 4 ops per pixel
+        valu["sgr_units_search"] = {"achieved": work / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 2.4e9 / 4.0 / 1e12, "unit": "T lane-op/s",
+                                    "note": "work = per pixel 23 distinct (radius, strength) filters x ~30 ops (A/B lookup, 3x3 weighting, projection) + 16 sets x ~9.2 error probes x 4 "
+                                            "ops; peak = 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz; the probe passes re-read 4-6 B per pixel and set from HBM (821 MB scratch)"}
+        valu["sgr_units_search"]["frac"] = valu["sgr_units_search"]["achieved"] / valu["sgr_units_search"]["peak"]
+    if dom in valu:
+        r.update({"bound": "valu", "achieved": valu[dom]["achieved"], "peak": valu[dom]["peak"], "unit": valu[dom]["unit"], "frac": valu[dom]["frac"]})
+    else:
+        r.update({"bound": "hbm", "achieved": per_stage_gbs[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_stage_gbs[dom] / HBM_PEAK_GBS})
+    # HBM traffic of the dominant stage per frame from the PMC passes of the latest profiled round (tools/collect_profiles.sh: FETCH_SIZE and
+    # WRITE_SIZE in separate rocprofv3 --pmc runs; summary committed as profiles/<round>/pmc_traffic.json)
     traffic, traffic_src, valu_busy = None, None, None
     try:
         rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
@@ -426,82 +611,22 @@ def main():
             traffic_src = f"profiles/{rounds[-1]}/pmc_traffic.json"
             pt = json.load(open(os.path.join(ROOT, traffic_src)))
             frames = max((e["launches"] for k, e in pt.items() if k.startswith("me_fullpel_85pu_kernel")), default=0)
-            names = dominant["kernel"].split("+")
-            tot = sum((e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)) * e["launches"]
-                      for k, e in pt.items() if any(k.startswith(nm) for nm in names))
+            knames = STAGE_KERNELS[dom].split("+")
+            sel = [e for k, e in pt.items() if any(k.startswith(nm) for nm in knames)]
+            tot = sum((e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)) * e["launches"] for e in sel)
             traffic = tot / frames if frames and tot else None
-            # VALU issue utilisation of the same launches: SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs
-            act = sum(e.get("sq", {}).get("SQ_ACTIVE_INST_VALU", 0.0) * e["launches"] for k, e in pt.items() if any(k.startswith(nm) for nm in names))
-            dur = sum(e["avg_us"] * e["launches"] for k, e in pt.items() if any(k.startswith(nm) for nm in names))
+            act = sum(e.get("sq", {}).get("SQ_ACTIVE_INST_VALU", 0.0) * e["launches"] for e in sel)
+            dur = sum(e["avg_us"] * e["launches"] for e in sel)
             valu_busy = (act * 4.0) / (1024 * dur * 1e-6 * 2.4e9) if dur else None
     except (OSError, ValueError, KeyError):
         traffic = None
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    # ---- parity spot check of what was just timed (first SB row of ME) — the checker, not the product
-    parity_ok = None
-    if any(s["key"] == "me" for s in stages):
-        g_sad = d_sad.cpu().numpy().view(np.uint32); g_mv = d_mv.cpu().numpy().view(np.uint32)
-        k = min(F.sb_cols, 8)
-        o_sad, o_mv = mc.oracle_frame(orc, F.cur_y_p, F.ref_y_p, F.cur_y_p.shape[1], PAD, sbs, 0, 0, k)
-        parity_ok = bool(np.array_equal(o_sad[:k], g_sad[:k]) and np.array_equal(o_mv[:k], g_mv[:k]))
-        simd_lib = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
-        if os.path.exists(simd_lib) and world == 1:   # the whole frame against the reference's own (SIMD) kernels: 2040 SBs x 85 PUs
-            refb = C.CDLL(simd_lib)
-            refb.refb_setup.restype = C.c_uint64; refb.refb_setup.argtypes = [C.c_uint64]; refb.refb_setup(0xFFFFFFFFFFFFFFFF)
-            refb.refb_parallel.restype = C.c_double; refb.refb_parallel.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-            r_sad = np.zeros((n_sb, 85), np.uint32); r_mv = np.zeros((n_sb, 85), np.uint32)
-            slots = (C.c_int64 * 10)(F.cur_y_p.ctypes.data, F.ref_y_p.ctypes.data, F.cur_y_p.shape[1], PAD, PAD, C.addressof(sbs), n_sb, 0, r_sad.ctypes.data, r_mv.ctypes.data)
-            refb.refb_parallel(0, C.addressof(slots), n_sb, 1, min(len(os.sched_getaffinity(0)), 128), 1)
-            parity_ok = bool(parity_ok and np.array_equal(r_sad, g_sad) and np.array_equal(r_mv, g_mv))
-
-    # ---- CPU baseline: the oracle C port of the same stage chain, every host core, on a bounded sample of the
-    #      same frame; composite SB/s = 1 / sum_k (seconds per SB of stage k)
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        jobs = dict(hme=hme_host, conv=(CB, nblk16), unit=US[0])
-        simd = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
-        if args.cpu_baseline in ("auto", "reference") and os.path.exists(simd):
-            cpu = cpu_baseline_reference(C.CDLL(simd), orc, F, sbs, mc, tc, stages, jobs)
-            if args.cpu_baseline == "auto" and args.cpu_port_too:
-                cpu["port"] = cpu_baseline(orc, F, sbs, mc, tc, stages, jobs)
-        elif args.cpu_baseline == "reference":
-            raise SystemExit("oracle/_ref/libsvtav1_ref_simd.so is not built (make -f oracle/Makefile.ref simd)")
-        else:
-            cpu = cpu_baseline(orc, F, sbs, mc, tc, stages, jobs)
-
-    total_sb = n_sb * args.steps * world
-    out = {
-        "metric": METRIC, "value": total_sb / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "launch": ("eager" if not use_graph else "hip_graph_replay") + (", single stream" if args.serial else f", 1+1+{n_lanes} forked streams per step"),
-        "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frame, {n_sb} SBs/frame/GPU; stages: " + ",".join(s["name"] for s in stages)
-                               + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16; square tx tiling "
-                                 "4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12); CDEF full 64-strength search; SGR 16 sets, restoration units 256",
-                   "stages_ms": per_stage, "parity_spot_check": parity_ok},   # ME: first SB row vs the oracle + (when oracle/_ref is present) the whole frame vs the reference's SIMD kernels
-        "roofline": {"bound": "hbm", "kernel": dominant["kernel"], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "valu_busy": valu_busy,   # fraction of VALU issue cycles used by the dominant stage's kernels (profiled round, 2.4 GHz)
-                     "traffic_note": None if traffic is None else f"bytes per frame of the stage's launches, FETCH_SIZE + WRITE_SIZE from {traffic_src} "
-                                     "(raw counters x 1024; narrow loads are uncalibrated on gfx950, Infinity-Cache hits included)",
-                     "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / HIP-event stage time of the slowest stage; the ME and CDEF-search "
-                             "kernels are integer-VALU bound (DESIGN.md), see per_stage_gbs for the HBM-bound ones",
-                     "per_stage_gbs": {s["name"]: BYTES_PER_SB[s["name"]] * n_sb / (per_stage[s["name"]] * 1e-3) / 1e9 for s in stages}},
-        "cpu_baseline": cpu,
-    }
-    if any(s["key"] == "me" for s in stages):
-        ms = per_stage["me_fullpel_85pu"]
-        out["roofline"]["valu_me"] = {"achieved": 4096 * 4096 * n_sb / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 16 / 16.0 * 2.4e9 / 1e12,
-                                      "unit": "T px-SAD/s", "note": "peak = 1024 SIMDs x 64 lanes x 16 abs-diff per v_qsad_pk_u16_u8 / 16 cyc x 2.4 GHz"}
-        out["roofline"]["valu_me"]["frac"] = out["roofline"]["valu_me"]["achieved"] / out["roofline"]["valu_me"]["peak"]
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    r.update({"traffic": traffic, "valu_busy": valu_busy,
+              "traffic_note": None if traffic is None else f"bytes per frame of the stage's launches, FETCH_SIZE + WRITE_SIZE from {traffic_src} (raw counters x 1024; narrow loads are "
+                              "uncalibrated on gfx950, Infinity-Cache hits included)",
+              "hbm_view": {"per_stage_gbs": per_stage_gbs, "peak": HBM_PEAK_GBS, "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / isolated stage time: the memory-side stages of ONE 4K "
+                           "frame move 25-125 MB each, i.e. 3-15 us at peak — alone on the GPU they are launch/latency bound, which is what batching frames per step addresses"},
+              "valu": valu})
+    return r
 
 
 def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
@@ -612,7 +737,7 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
         dst = np.zeros((F.h, F.w), np.uint8)
         t = par(lambda be: orc.orc_subpel_predict_batch(1, 8, C.c_void_p(F.ref_y_p.ctypes.data + F.pad * st + F.pad), st, ptr(dst), F.w, CB_, be[0], be[1]), split(n))
         sec_per_sb["subpel_convolve"] = t / (n / 16.0)
-    if "sgr_search" in keys or "sgr_apply" in keys:
+    if "sgr_units" in keys or "sgr_apply" in keys:
         # luma band of 4 unit rows, one unit column per work item; chroma adds half as many samples (x 1.5)
         EXT_ = 3
         rows = min(F.h, 256)
@@ -620,11 +745,13 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
         eoff = EXT_ * est + EXT_
         ncol = F.w // 64
         nunit = ncol * (rows // 64)
-        if "sgr_search" in keys:
+        if "sgr_units" in keys:   # the complete unit search (64 x 64 units here: same work per sample)
             def work(c):
-                sums = np.zeros((rows // 64, 16, 5), np.int64)
-                orc.orc_sgr_search_plane(C.c_void_p(ext.ctypes.data + eoff + 64 * c), 1, est, C.c_void_p(F.cur[0].ctypes.data + 64 * c), F.cur[0].shape[1], 64, rows, 0, 0, 64, 8, 0xFFFF, ptr(sums))
-            sec_per_sb["sgr_search"] = par(work, list(range(ncol))) / nunit * 1.5
+                nu_ = rows // 64
+                xqd = np.zeros((nu_, 16, 2), np.int32); err = np.zeros((nu_, 16), np.int64); best = np.zeros(nu_, np.uint8)
+                orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + eoff + 64 * c), 1, est, C.c_void_p(F.cur[0].ctypes.data + 64 * c), F.cur[0].shape[1], 64, rows, 0, 0, 64, 8,
+                                               0xFFFF, ptr(xqd), ptr(err), ptr(best))
+            sec_per_sb["sgr_units_search"] = par(work, list(range(ncol))) / nunit * 1.5
         if "sgr_apply" in keys:
             uep = np.full(rows // 64, 3, np.uint8); uxqd = np.tile(np.array([-30, 40], np.int32), (rows // 64, 1)).copy()
             dst = np.zeros((rows, F.w), np.uint8)
@@ -669,16 +796,22 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
         keep.append(x)
         return C.addressof(x)
 
-    def run(stage, slots, n, chunk, reps=3):
+    sec1 = {}   # the same on ONE thread (BASELINE.md asks for T in {1, nproc})
+
+    def run(stage, slots, n, chunk, reps=3, name=None, one_thread_items=None):
         a = (C.c_int64 * len(slots))(*[adr(v) for v in slots])
-        return refb.refb_parallel(stage, C.addressof(a), n, chunk, cores, reps)
+        t = refb.refb_parallel(stage, C.addressof(a), n, chunk, cores, reps)
+        if name is not None:   # one thread, a bounded prefix of the same items, scaled to the whole frame
+            n1 = min(n, one_thread_items or n)
+            sec1[name] = sec1.get(name, 0.0) + refb.refb_parallel(stage, C.addressof(a), n1, chunk, 1, 1) * (n / n1)
+        return t
 
     W_, H_, n_sb = F.w, F.h, F.n_sb
     st = F.cur_y_p.shape[1]
     org = F.pad * st + F.pad
     if "me" in keys:
         sad = np.zeros((n_sb, 85), np.uint32); mv = np.zeros((n_sb, 85), np.uint32)
-        sec["me_fullpel_85pu"] = run(0, [F.cur_y_p, F.ref_y_p, st, F.pad, F.pad, sbs, n_sb, 0, sad, mv], n_sb, 1) / n_sb
+        sec["me_fullpel_85pu"] = run(0, [F.cur_y_p, F.ref_y_p, st, F.pad, F.pad, sbs, n_sb, 0, sad, mv], n_sb, 8, name="me_fullpel_85pu", one_thread_items=512) / n_sb   # 8 SBs per work item
     if "pyr" in keys or "hme" in keys:
         PQ, PS = 32, 16
         planes = {}
@@ -702,12 +835,12 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
             for lvl in range(3):
                 cur_t, ref_t = planes["cur"][lvl], planes["ref"][lvl]
                 sad_o = np.zeros(n_sb, np.uint32); xy_o = np.zeros((n_sb, 2), np.int16)
-                t += run(1, [cur_t, cur_t.shape[1], ref_t, ref_t.shape[1], jobs["hme"][lvl], sad_o, xy_o], n_sb, 2)
+                t += run(1, [cur_t, cur_t.shape[1], ref_t, ref_t.shape[1], jobs["hme"][lvl], sad_o, xy_o], n_sb, 8, name="hme_l0_l1_l2", one_thread_items=512)
             sec["hme_l0_l1_l2"] = t / n_sb
     if "subpel" in keys:
         CB_, nb = jobs["conv"]
         dst = np.zeros((H_, W_), np.uint8)
-        sec["subpel_convolve"] = run(2, [F.ref_y_p.ctypes.data + org, st, dst, W_, CB_], nb, 32) / n_sb
+        sec["subpel_convolve"] = run(2, [F.ref_y_p.ctypes.data + org, st, dst, W_, CB_], nb, 64, name="subpel_convolve", one_thread_items=16 * 512) / n_sb
     if "txfm" in keys or "inv" in keys:
         recon = [np.zeros_like(p) for p in F.ref]
         t_sum = 0.0
@@ -716,7 +849,8 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
             px = tc.TXW[ts] * tc.TXH[ts]
             for plane in ([0] if kind == 0 else [1, 2]):
                 t_sum += run(3, [F.cur[plane], F.cur[plane].shape[1], F.ref[plane], F.ref[plane].shape[1], recon[plane], recon[plane].shape[1], descs, ts, F.qp[plane],
-                                 tc.TX_SCALE[ts], sc[0], sc[1], sc[2], isc[0], isc[1], isc[2]], len(descs), max(1, 4096 // px))
+                                 tc.TX_SCALE[ts], sc[0], sc[1], sc[2], isc[0], isc[1], isc[2]], len(descs), max(1, 4096 // px), name="fwd_txfm_quant+inv_txfm_recon",
+                             one_thread_items=max(64, len(descs) // 4))
         sec["fwd_txfm_quant+inv_txfm_recon"] = t_sum / n_sb
     if "dlf" in keys:
         t = 0.0
@@ -730,29 +864,30 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
                 r0, r1 = max(4 * u0 - 8, 0), min(4 * u1 + 8, F.ref[p].shape[0])
                 img = np.ascontiguousarray(F.ref[p][r0:r1]); keep.append(img)
                 slots += [img.ctypes.data + (4 * u0 - r0) * img.shape[1], img.shape[1], np.ascontiguousarray(ev[u0:u1]), np.ascontiguousarray(eh[u0:u1]), uw, u1 - u0] + [0] * 10
-            t += run(4, slots, nb_, 1, reps=1)
+            t += run(4, slots, nb_, 1, reps=1, name="deblock", one_thread_items=max(1, nb_ // 8))
         sec["deblock"] = t / n_sb
     if "cdef_search" in keys:
         mse = np.zeros((2, n_sb, 64), np.uint64)
         sec["cdef_search"] = run(5, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + [F.cur[0], F.cur[1], F.cur[2]] + [p.shape[1] for p in F.cur]
-                                 + [W_, H_, F.skip8, F.cdef_damping, mse], n_sb, 1) / n_sb
+                                 + [W_, H_, F.skip8, F.cdef_damping, mse], n_sb, 4, name="cdef_search", one_thread_items=256) / n_sb
     if "cdef_apply" in keys:
         outs = [p.copy() for p in F.ref]
-        sec["cdef_apply"] = run(6, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + outs + [W_, H_, F.skip8, F.cdef_y, F.cdef_uv, F.cdef_damping], n_sb, 2) / n_sb
-    if "sgr_search" in keys or "sgr_apply" in keys:
+        sec["cdef_apply"] = run(6, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + outs + [W_, H_, F.skip8, F.cdef_y, F.cdef_uv, F.cdef_damping], n_sb, 4, name="cdef_apply", one_thread_items=256) / n_sb
+    if "sgr_units" in keys or "sgr_apply" in keys:
         US = jobs.get("unit", 256)
         EXT_ = 3
         t_search = t_apply = 0.0
         for p in range(3):
             ssub = int(p > 0)
             ph, pw = F.ref[p].shape
-            if "sgr_search" in keys:
+            if "sgr_units" in keys:   # the reference's complete search_selfguided_restoration per unit (oracle/ref_shim_restpick.c), 16 sets
                 ext = np.ascontiguousarray(np.pad(F.ref[p], EXT_, mode="edge")); est = ext.shape[1]; eoff = EXT_ * est + EXT_
                 nu = max((pw + US // 2) // US, 1) * max((ph + US // 2) // US, 1)
                 lim = np.zeros((nu, 4), np.int32)
                 orc.orc_rest_unit_limits(pw, ph, ssub, US, ptr(lim))
-                xq = np.zeros((nu, 16, 2), np.int32)
-                t_search += run(7, [ext.ctypes.data + eoff, est, F.cur[p], F.cur[p].shape[1], lim, 64 >> ssub, 64 >> ssub, 0xFFFF, xq], nu, 1, reps=2)
+                res = np.zeros((nu, 3), np.int32)
+                t_search += run(9, [ext.ctypes.data + eoff, est, F.cur[p], F.cur[p].shape[1], lim, 64 >> ssub, 64 >> ssub, res], nu, 1, reps=1, name="sgr_units_search",
+                                one_thread_items=4)
                 keep.append(ext)
             if "sgr_apply" in keys:
                 # horizontal bands of the plane, each filtered as a picture of its own by the reference's frame-level restoration
@@ -770,14 +905,19 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
                     keep.append(cdef_b)
                     nbands += 1
                     y0 = y1
-                t_apply += run(8, slots, nbands, 1, reps=1)
-        if "sgr_search" in keys: sec["sgr_search"] = t_search / n_sb
+                t_apply += run(8, slots, nbands, 1, reps=1, name="sgr_apply", one_thread_items=2)
+        if "sgr_units" in keys: sec["sgr_units_search"] = t_search / n_sb
         if "sgr_apply" in keys: sec["sgr_apply"] = t_apply / n_sb
     total = sum(sec.values())
+    total1 = sum(sec1.values()) / n_sb + sec.get("pyramids", 0.0) * cores
     return dict(value=1.0 / total if total > 0 else None, unit="SB/s", cores=cores, kind="reference",
+                value_one_thread=1.0 / total1 if total1 > 0 else None,
+                one_thread_note="the same drivers on 1 thread over a bounded prefix of each stage's work items, scaled to the frame; seconds per SB per stage: "
+                                + ", ".join(f"{k}={v / n_sb:.2e}" for k, v in sec1.items()),
                 sample="the reference's own kernels as its x86 build dispatches them on this host (cpu flags 0x%x: SSE2..AVX2%s; oracle/_ref SIMD flavour built by "
                        "oracle/Makefile.ref from the reference sources, NASM-only helpers stubbed in C and not on this path), driven by oracle/ref_bench.c over the "
-                       "same job lists as the HIP stages, whole frame per stage, %d pthreads (all hardware threads), best of 3; seconds per SB per stage: " % (
+                       "same job lists as the HIP stages (the restoration search is the complete search_selfguided_restoration per unit), whole frame per stage, %d pthreads (all hardware "
+                       "threads; ME and HME in work items of 8 SBs), best of 3; seconds per SB per stage: " % (
                            flags, " + AVX-512" if flags & (1 << 9) else "", cores)
                        + ", ".join(f"{k}={v:.2e}" for k, v in sec.items())
                        + " (pyramids: the oracle's scalar C / threads; deblock and restoration apply run on independent row bands; restoration search is "

@@ -384,13 +384,15 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, cons
  * the projection sums, svt_get_proj_subspace's 2x2 solve in IEEE double (:497-538), encode_xq (:539) and the coordinate descent of
  * finer_search_pixel_proj_error (:353-446, start step 2) — one workgroup per (unit, set) replays the reference's walk on exactly evaluated
  * errors (speculating ahead on the quadratic model of the five sums; a misprediction costs another pass over the unit, never exactness) — and the
- * unit's best set.  Two launches, no host synchronisation; stream-ordered like every _dev call.
+ * unit's best set.  A fixed sequence of launches (sums + difference planes, then replay / evaluate rounds: walks that are done return at once), no host
+ * synchronisation; stream-ordered like every _dev call.
  *   d_xqd [units][16][2], d_err [units][16] (entries of sets outside the mask are not written),
  *   d_best_ep [units] (may be NULL) = the first set with the smallest error, d_best_xqd [units][2] (may be NULL) = its xqd: exactly the
  *   d_unit_ep / d_unit_xqd arrays svt_hip_sgr_apply_plane_dev takes, so search -> trial filter -> SSE chains on the device.
  *   d_scratch: svt_hip_sgr_search_units_scratch_bytes(pw, ph, unit_size) bytes, 16-byte aligned, private to this call until it has completed
- *   (sums, arrival counters, and 33 int16 planes: flt0 - u and flt1 - u per filter, dat - src).  Its first three uint32 receive diagnostics of the call:
- *   evaluation passes and evaluated points summed over all (unit, set) walks, and the number of walks that did not finish (always 0). */
+ *   (sums, per-walk state, 16 planes of (flt0 - u, flt1 - u) int16 pairs, one of dat - src).  Its first three uint32 receive diagnostics of the call:
+ *   evaluation passes and evaluated points summed over all (unit, set) walks, and the number of walks that did not finish within the launched rounds (a
+ *   failure: their error entry is -1; never observed). */
 size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size);
 int svt_hip_sgr_search_units_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride, int pw,
                                        int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *d_xqd, int64_t *d_err, uint8_t *d_best_ep,

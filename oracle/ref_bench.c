@@ -281,6 +281,24 @@ void refb_sgr_search_plane(const uint8_t *dgd, int stride, const uint8_t *src, i
     svt_aom_free(flt0);
 }
 
+/* The COMPLETE per-unit search: search_selfguided_restoration (EbRestorationPick.c:583-671: filters, svt_get_proj_subspace, encode_xq and
+ * finer_search_pixel_proj_error for every parameter set, best set) through the exported wrapper of oracle/ref_shim_restpick.c.
+ * out[unit][3] = {ep, xqd0, xqd1}.  ref_ep = {-1, -1}: all 16 sets, like the first picture of a sequence. */
+void ref_shim_sgr_search_unit(const uint8_t *dat8, int32_t width, int32_t height, int32_t dat_stride, const uint8_t *src8, int32_t src_stride,
+                              int32_t use_highbitdepth, int32_t bit_depth, int32_t pu_width, int32_t pu_height, int32_t *rstbuf, int32_t ref_ep0,
+                              int32_t ref_ep1, int32_t step, int32_t *out);
+int32_t ref_shim_sgr_rstbuf_ints(void);
+void refb_sgr_search_units_plane(const uint8_t *dgd, int stride, const uint8_t *src, int src_stride, const int32_t *limits, int unit_begin, int unit_end,
+                                 int pu_w, int pu_h, int32_t *out) {
+    int32_t *rstbuf = (int32_t *)svt_aom_memalign(32, sizeof(int32_t) * (size_t)ref_shim_sgr_rstbuf_ints());
+    for (int u = unit_begin; u < unit_end; u++) {
+        const int x0 = limits[4 * u], x1 = limits[4 * u + 1], y0 = limits[4 * u + 2], y1 = limits[4 * u + 3];
+        ref_shim_sgr_search_unit(dgd + (size_t)y0 * stride + x0, x1 - x0, y1 - y0, stride, src + (size_t)y0 * src_stride + x0, src_stride, 0, 8, pu_w, pu_h, rstbuf,
+                                 -1, -1, 16, out + 3 * (size_t)u);
+    }
+    svt_aom_free(rstbuf);
+}
+
 /* ---------------------------------------------------------------- thread pool for bench.py's cpu_baseline ---------------------------
  * refb_parallel runs one of the drivers above over n items on n_threads pthreads (dynamic chunks from an atomic counter, so threads of
  * uneven speed stay busy), `reps` times, and returns the best wall time in seconds.  Arguments travel as an array of 64-bit slots
@@ -322,6 +340,7 @@ static void run_range(int stage, const int64_t *a, int b, int e) {
             ref_shim_lr_apply_plane((int)r[0], 8, 0, (int)r[1], (int)r[2], (void *)(uintptr_t)r[3], (int)r[4], (void *)(uintptr_t)r[5], (int)r[6], (void *)(uintptr_t)r[7], (int)r[8], (int)r[9],
                                     (const uint8_t *)(uintptr_t)r[10], (const int32_t *)(uintptr_t)r[11]);
         } break;
+    case 9: refb_sgr_search_units_plane(P(0, const uint8_t *), I(1), P(2, const uint8_t *), I(3), P(4, const int32_t *), b, e, I(5), I(6), P(7, int32_t *)); break;
     default: break;
     }
 }

@@ -359,19 +359,20 @@ __device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
     return (long long)hi * 65536 + lo;
 }
 
-// STORE: additionally leaves flt0 - u (diff0[ep]), flt1 - u (diff1[ep]; sets 11 / 12 / 13 share the plane of 2 / 5 / 8) and dat - src (sd) of every pixel
-// as int16 planes (stride dstride, plane pitch dplane) for the on-device unit search (sgr_walk.hip): the walk then re-reads 6 bytes per pixel and probe
-// batch instead of re-running the filters.
+// STORE: additionally leaves, per pixel, (flt0 - u) | (flt1 - u) << 16 (pairs[ep], int16 halves; sets 11 / 12 / 13 use the plane of 2 / 5 / 8), dat - src (sd,
+// int16) and per unit the sum of (dat - src)^2 (d2) for the on-device unit search (sgr_walk.hip): a probe pass then re-reads 6 bytes per pixel instead of
+// re-running the filters.
 template <typename PIX, int BD = 8, bool STORE = false>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
                    int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums,
-                   int16_t* __restrict__ diff0 = nullptr, int16_t* __restrict__ diff1 = nullptr, int16_t* __restrict__ sd = nullptr, int dstride = 0,
-                   size_t dplane = 0) {
+                   uint32_t* __restrict__ pairs = nullptr, int16_t* __restrict__ sd = nullptr, int dstride = 0, size_t dplane = 0,
+                   unsigned long long* __restrict__ d2 = nullptr) {
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
     __shared__ unsigned long long acc[16][5];
+    __shared__ unsigned long long acc_d2;
     const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
 
@@ -379,6 +380,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
         xt[tid] = (A << 20) | (256u - A);
         if (tid < 80) acc[tid / 5][tid % 5] = 0ull;
+        if (tid == 80) acc_d2 = 0ull;
     }
     batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
         [&](int i) {
@@ -405,6 +407,14 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         CX[r] = 256 - (int32_t)(X[r] << 13);                                           // rounding - (u << 9)
         if (STORE && colvalid && r >= rlo && r < rhi) sd[(size_t)(y0 + i0 + r) * dstride + x0 + j] = (int16_t)(-(SV[r] >> 4));   // dat - src
     }
+    if (STORE) {   // sum of (dat - src)^2 over the unit: the constant term of the quadratic error model the walk speculates on
+        int32_t q = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            if (colvalid && r >= rlo && r < rhi) { const int32_t d = SV[r] >> 4; q += d * d; }   // <= 8 x 1023^2 < 2^24
+        q = row16_sum(q);
+        if ((tid & 15) == 0 && q) atomicAdd(&acc_d2, (unsigned long long)q);
+    }
 
     // parameter sets that must be filtered: the masked ones, 11/12/13 folded onto 2/5/8
     uint32_t cmask = ep_mask & 0xC7FFu;
@@ -424,14 +434,11 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         if (BD == 8) {
             int32_t D0[8], D1[8];
             sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
-            if (STORE && colvalid) {
+            if (STORE && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
 #pragma unroll
                 for (int r = 0; r < 8; r++)
-                    if (r >= rlo && r < rhi) {
-                        const size_t o = (size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j;
-                        if (has0) diff0[o] = (int16_t)D0[r];
-                        if (has1) diff1[o] = (int16_t)D1[r];
-                    }
+                    if (r >= rlo && r < rhi)
+                        pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j] = ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16);
             }
             int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
     #pragma unroll
@@ -455,14 +462,11 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
             // bit depth 10: |flt - u| < 2^14.1, a product < 2^28.1 -> four rows per int32 partial, 64-bit from the row reduction on
             int32_t D0[8], D1[8];
             sgr10_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
-            if (STORE && colvalid) {
+            if (STORE && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
 #pragma unroll
                 for (int r = 0; r < 8; r++)
-                    if (r >= rlo && r < rhi) {
-                        const size_t o = (size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j;
-                        if (has0) diff0[o] = (int16_t)D0[r];
-                        if (has1) diff1[o] = (int16_t)D1[r];
-                    }
+                    if (r >= rlo && r < rhi)
+                        pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j] = ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16);
             }
             int32_t h00[2] = {0, 0}, h01[2] = {0, 0}, h11[2] = {0, 0}, c0[2] = {0, 0}, c1[2] = {0, 0};
 #pragma unroll
@@ -496,6 +500,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
             if (used) atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + q], acc[ce][q]);
         }
     }
+    if (STORE && tid == 80 && acc_d2) atomicAdd(&d2[unit], acc_d2);
 }
 
 // ---- projected error of xqd candidates: get_pixel_proj_error (EbRestorationPick.c:317-351 -> svt_av1_{lowbd,highbd}_pixel_proj_error, :174-316) for
@@ -709,13 +714,13 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
 // the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip)
 extern "C" int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
                                                int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums,
-                                               int16_t* diff0, int16_t* diff1, int16_t* sd, int dstride, size_t dplane) {
+                                               uint32_t* pairs, int16_t* sd, int dstride, size_t dplane, int64_t* d2) {
     const int voff = 8 >> ss_y;
     dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
     unsigned long long* s = (unsigned long long*)sums;
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, true>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
-    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, diff0, diff1, sd, dstride, dplane);
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, true>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
+    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,

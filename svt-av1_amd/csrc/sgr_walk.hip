@@ -6,15 +6,20 @@
 //   EbRestorationPick.c:353-446  finer_search_pixel_proj_error   (coordinate descent; every probe = get_pixel_proj_error :317 over the unit)
 //   EbRestorationPick.c:583-671  search_selfguided_restoration    (best parameter set of the unit: first set with the smallest error)
 //
-// Data flow.  sgr_search8_kernel<.., STORE> (sgr.hip) has left, per plane, the five projection sums of every (unit, set) and three kinds of
-// int16 planes: flt0 - u per r0-filter, flt1 - u per r1-filter (|.| <= 4084 at bit depth 8, < 2^14.1 at 10) and dat - src.  One workgroup owns one
-// (unit, set): lane 0 solves and encodes the start point, then the workgroup alternates between
-//   * REPLAY (lane 0): the reference's walk, decision by decision, on a cache of exactly evaluated points; at the first unknown point it
-//     turns speculative and keeps walking on the quadratic model the five sums give (exact up to the per-pixel rounding), collecting the
-//     points it visits (up to kMaxCand);
-//   * EVALUATE (all lanes): one pass over the unit's three int16 planes gives the exact 64-bit error of all collected points.
-// The result is the reference's by construction (a misprediction only costs another pass); no host round trip anywhere.  The last
-// workgroup of a unit to finish picks the unit's best set.
+// Data flow.  sgr_search8_kernel<.., STORE> (sgr.hip) has left, per plane, the five projection sums of every (unit, set) and, per pixel, one 32-bit word per
+// filter pair = (flt0 - u) | (flt1 - u) << 16 (int16 halves: |.| <= 4084 at bit depth 8, < 2^14.1 at 10) plus dat - src (int16).  One workgroup owns one
+// (unit, set): wave 0 solves and encodes the start point, then the workgroup alternates between
+//   * REPLAY (wave 0, all lanes with identical values): the reference's walk, decision by decision, on a cache of exactly evaluated points; at the
+//     first unknown point it turns speculative and keeps walking on the quadratic model the five sums give (exact up to the per-pixel rounding),
+//     collecting the points it visits (up to kMaxCand);
+//   * EVALUATE (all lanes): one pass over the unit's planes gives the exact 64-bit error of all collected points — v_dot2_i32_i16 forms
+//     xq0 (flt0 - u) + xq1 (flt1 - u) + ((dat - src) << 11 | rounding) of a pixel in one instruction (scaled by 32, so that the >> 11 of the reference is
+//     "take the high half"), a second one squares and accumulates two pixels' errors.
+// The result is the reference's by construction (a misprediction only costs another pass); no host round trip anywhere.  The last workgroup of a unit
+// to finish picks the unit's best set.
+// Measured alternatives (MI355X, 4K, 16 sets; profiles/r02/sgr_walk_notes.md): one wave per walk replaying all walks at once + separate evaluation
+// launches, best-first hedging of close decisions with 16 / 32 points per pass, 1024-thread workgroups — all slower than this form, whose evaluation of
+// one walk overlaps the serial replay of the three others on the same CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -23,6 +28,7 @@
 namespace {
 
 constexpr int kMaxCand = 10;     // points evaluated per pass
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
 
 // eb_sgr_params (Common/Codec/EbRestoration.c:136-153): r0 > 0 for sets 0-9, 14, 15; r1 > 0 for sets 0-13.  Tap ranges: SGRPROJ_PRJ_MIN0 / MAX0 = -96 / 31,
@@ -142,10 +148,11 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     return v;
 }
 
-// grid: (units, 16); block 256.  diff0 / diff1: [16] planes each (plane `ep`; sets 11 / 12 / 13 read the r1 plane of 2 / 5 / 8), sd: one plane.
+// grid: (units, 16); block 256.  pairs: [16] planes of (flt0 - u) | (flt1 - u) << 16 (plane `ep`; sets 11 / 12 / 13 read the plane of 2 / 5 / 8 — their
+// xq0 is 0, so the r0 half does not matter), sd: one int16 plane of dat - src.
 template <int BD>
 __global__ void __launch_bounds__(256)
-sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ diff1, const int16_t* __restrict__ sd, int dstride, size_t dplane,
+sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ sd, int dstride, size_t dplane,
                 const long long* __restrict__ sums, int pw, int ph, int unit_size, int units_x, int units_y, int voff, uint32_t ep_mask,
                 int32_t* __restrict__ xqd_out, long long* __restrict__ err_out, uint32_t* __restrict__ counters, uint8_t* __restrict__ best_ep,
                 int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats) {
@@ -159,8 +166,7 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
     const int v0 = max(y0 - voff, 0), v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
     const bool has0 = ep < 10 || ep >= 14, has1 = ep < 14;
     const int  ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
-    const int16_t* __restrict__ D0 = diff0 + (size_t)ep * dplane;
-    const int16_t* __restrict__ D1 = diff1 + (size_t)ce * dplane;
+    const uint32_t* __restrict__ PP = pairs + (size_t)ce * dplane;
     const long long* S = sums + ((size_t)unit * 16 + ep) * 5;
 
     int start[2] = {0, 0};
@@ -189,37 +195,40 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
         if (L.done) break;
         const int nc = L.n_want;
         n_pass++; n_eval += nc;
-        int xq0[kMaxCand], xq1[kMaxCand];
+        int xq[kMaxCand];   // both taps scaled by 32 and packed for v_dot2_i32_i16 (|32 xq| <= 8192)
         long long acc[kMaxCand];
 #pragma unroll
-        for (int c = 0; c < kMaxCand; c++) { xq0[c] = c < nc ? L.xq0[c] : 0; xq1[c] = c < nc ? L.xq1[c] : 0; acc[c] = 0; }
-        // ---- one pass over the unit: e = ((dat - src) << 11 | rounding) + xq0 (flt0 - u) + xq1 (flt1 - u)) >> 11   (svt_av1_{lowbd,highbd}_pixel_proj_error, :174-316)
+        for (int c = 0; c < kMaxCand; c++) {
+            xq[c] = c < nc ? (int)(((uint32_t)(L.xq0[c] * 32) & 0xFFFFu) | ((uint32_t)(L.xq1[c] * 32) << 16)) : 0;
+            acc[c] = 0;
+        }
+        // ---- one pass over the unit: e = ((dat - src) << 11 | rounding) + xq0 (flt0 - u) + xq1 (flt1 - u)) >> 11   (svt_av1_{lowbd,highbd}_pixel_proj_error, :174-316).
+        // Everything is scaled by 32 so that the >> 11 becomes "take the high half": one v_dot2_i32_i16 forms a pixel's sum, v_perm_b32 packs the high halves
+        // of two of them, a second v_dot2_i32_i16 squares and accumulates both errors.
         for (int k = tid; k < nchunk; k += 256) {
             const int row = k / cw, cx = k - row * cw;
             const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-            const int4 a = has0 ? *(const int4*)(D0 + off) : make_int4(0, 0, 0, 0);
-            const int4 b = has1 ? *(const int4*)(D1 + off) : make_int4(0, 0, 0, 0);
+            const int4 a0 = *(const int4*)(PP + off), a1 = *(const int4*)(PP + off + 4);
             const int4 s = *(const int4*)(sd + off);
             const int  n = min(8, w - 8 * cx);
-            int d0[8], d1[8], bs[8];
-            const int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, sw[4] = {s.x, s.y, s.z, s.w};
+            int pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bs[8];
+            const int sw[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                d0[2 * i] = (int)(int16_t)aw[i]; d0[2 * i + 1] = aw[i] >> 16;
-                d1[2 * i] = (int)(int16_t)bw[i]; d1[2 * i + 1] = bw[i] >> 16;
-                bs[2 * i] = ((int)(int16_t)sw[i] << 11) + 1024; bs[2 * i + 1] = ((sw[i] >> 16) << 11) + 1024;
-            }
+            for (int i = 0; i < 4; i++) { bs[2 * i] = (sw[i] << 16) + 32768; bs[2 * i + 1] = (int)((uint32_t)sw[i] & 0xFFFF0000u) + 32768; }   // 32 x (((dat - src) << 11) + 2^10)
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                if (i >= n) { d0[i] = 0; d1[i] = 0; bs[i] = 0; }   // columns past the unit: e = 0
+                if (i >= n) { pr[i] = 0; bs[i] = 0; }   // columns past the unit: e = 0
 #pragma unroll
             for (int c = 0; c < kMaxCand; c++) {
                 if (c < nc) {   // workgroup-uniform
+                    const s16x2 q = __builtin_bit_cast(s16x2, xq[c]);
                     int p = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int e = (bs[i] + __mul24(xq0[c], d0[i]) + __mul24(xq1[c], d1[i])) >> 11;
-                        p += __mul24(e, e);   // |e| < 2^13 at bit depth 10: eight squares stay below 2^31
+                    for (int i = 0; i < 8; i += 2) {
+                        const int t0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[i]), q, bs[i], false);
+                        const int t1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[i + 1]), q, bs[i + 1], false);
+                        const int ee = (int)__builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x07060302u);   // (t0 >> 16) | (t1 & 0xffff0000): the two errors, int16 each
+                        p = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, ee), __builtin_bit_cast(s16x2, ee), p, false);   // |e| < 2^13 at bit depth 10: eight squares stay below 2^31
                     }
                     acc[c] += p;
                 }
@@ -268,19 +277,23 @@ sgr_walk_kernel(const int16_t* __restrict__ diff0, const int16_t* __restrict__ d
 
 }  // namespace
 
-extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const int16_t* diff0, const int16_t* diff1, const int16_t* sd, int dstride, size_t dplane,
-                                       const int64_t* sums, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int32_t* xqd_out,
-                                       int64_t* err_out, uint32_t* counters, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats) {
+extern "C" size_t svt_hip_sgr_walk_state_bytes(int n_units) { return sizeof(uint32_t) * (size_t)n_units; }   // arrival counter per unit
+
+extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums,
+                                       const int64_t* d2, void* states, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask,
+                                       int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats) {
+    (void)d2;
     const int voff = 8 >> ss_y;
     dim3 grid(units_x * units_y, 16);
-    // tuning knob (tools/hbd_time.py): unused dynamic LDS per workgroup limits how many (unit, set) walks are in flight, i.e. how much of the
-    // difference planes has to stay cached between a walk's first and second pass
+    uint32_t* counters = (uint32_t*)states;
+    (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)units_x * units_y, st);
+    // tuning knob (tools/hbd_time.py): unused dynamic LDS per workgroup limits how many (unit, set) walks are in flight
     static const int lds_pad = getenv("SVT_HIP_SGR_WALK_LDS_PAD") ? atoi(getenv("SVT_HIP_SGR_WALK_LDS_PAD")) * 1024 : 0;
     if (bd == 8)
-        hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), lds_pad, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
+        hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), lds_pad, st, pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
                            ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
     else
-        hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), lds_pad, st, diff0, diff1, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
+        hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), lds_pad, st, pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
                            ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
     return (int)hipGetLastError();
 }

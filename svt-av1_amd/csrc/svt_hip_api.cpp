@@ -546,10 +546,11 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
 
 /* ---- search_selfguided_restoration (Encoder/Codec/EbRestorationPick.c:583-671) for every unit of a plane, entirely on the device ----
  * launch 1: sgr_search8_kernel<STORE>: the five projection sums of every (unit, set) + the int16 planes flt0 - u, flt1 - u, dat - src
- * launch 2: sgr_walk_kernel: per (unit, set) the 2x2 solve, encode_xq and finer_search_pixel_proj_error; the unit's best set
+ * then sgr_walk.hip: replay (one wave per (unit, set): solve, encode_xq, the walk on exact errors, best-first speculation) and evaluate launches alternate a
+ * fixed number of times, a last launch writes the results and every unit's best set
  * No host synchronisation in between; the scratch (sums, arrival counters, difference planes) is the caller's. */
 namespace {
-struct SgrScratch { size_t stats, sums, counters, sd, d0, d1, total, dplane; int dstride, nu; };
+struct SgrScratch { size_t stats, sums, d2, states, sd, pairs, total, dplane; int dstride, nu; };
 SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     SgrScratch L;
     L.nu = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
@@ -557,12 +558,12 @@ SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     L.dplane = (size_t)L.dstride * (size_t)ph;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
-    L.stats = o;    o = al(o + 16);   // {evaluation passes, evaluated points, unfinished walks, -} over the plane: diagnostics
+    L.stats = o;    o = al(o + 128);   // [0] passes, [1] points, [2] unfinished, [3] flat walks, [8..23] histogram of passes per finished walk   // {evaluation passes, evaluated points, unfinished walks, -} over the plane: diagnostics
     L.sums = o;     o = al(o + sizeof(int64_t) * (size_t)L.nu * 16 * 5);
-    L.counters = o; o = al(o + sizeof(uint32_t) * (size_t)L.nu);
+    L.d2 = o;       o = al(o + sizeof(int64_t) * (size_t)L.nu);   // sum (dat - src)^2 per unit
+    L.states = o;   o = al(o + svt_hip_sgr_walk_state_bytes(L.nu));   // per (unit, set): cache of evaluated points, points wanted next, result
     L.sd = o;       o = al(o + sizeof(int16_t) * L.dplane);
-    L.d0 = o;       o = al(o + sizeof(int16_t) * L.dplane * 16);
-    L.d1 = o;       o = al(o + sizeof(int16_t) * L.dplane * 16);
+    L.pairs = o;    o = al(o + sizeof(uint32_t) * L.dplane * 16);
     L.total = o;
     return L;
 }
@@ -589,15 +590,15 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
         return SVT_HIP_ERR_BAD_ARG;
     }
     char* base = (char*)d_scratch;
-    HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // statistics, sums, arrival counters
+    HIPCHK(c, hipMemsetAsync(base, 0, L.states, c->stream));   // statistics, sums, per-unit squared differences
     const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y, ep_mask,
-                                                              (int64_t*)(base + L.sums), (int16_t*)(base + L.d0), (int16_t*)(base + L.d1), (int16_t*)(base + L.sd),
-                                                              L.dstride, L.dplane);
+                                                              (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
+                                                              (int64_t*)(base + L.d2));
     if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
-    e = (hipError_t)svt_hip_launch_sgr_walk(c->stream, bd, (const int16_t*)(base + L.d0), (const int16_t*)(base + L.d1), (const int16_t*)(base + L.sd), L.dstride, L.dplane,
-                                            (const int64_t*)(base + L.sums), pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd, d_err, (uint32_t*)(base + L.counters),
-                                            d_best_ep, d_best_xqd, (uint32_t*)(base + L.stats));
+    e = (hipError_t)svt_hip_launch_sgr_walk(c->stream, bd, (const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), L.dstride, L.dplane,
+                                            (const int64_t*)(base + L.sums), (const int64_t*)(base + L.d2), base + L.states, pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd,
+                                            d_err, d_best_ep, d_best_xqd, (uint32_t*)(base + L.stats));
     if (e != hipSuccess) return fail(c, e, "sgr walk launch");
     return SVT_HIP_OK;
 }

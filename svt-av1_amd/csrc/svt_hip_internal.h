@@ -72,11 +72,12 @@ int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, const void*
 int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
                               int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums);
 int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
-                                    int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, int16_t* diff0, int16_t* diff1,
-                                    int16_t* sd, int dstride, size_t dplane);
-int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const int16_t* diff0, const int16_t* diff1, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums,
-                            int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out,
-                            uint32_t* counters, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats);
+                                    int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
+                                    int dstride, size_t dplane, int64_t* d2);
+size_t svt_hip_sgr_walk_state_bytes(int n_units);
+int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums, const int64_t* d2,
+                            void* states, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out,
+                            uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats);
 int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph,
                              int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride, const uint8_t* unit_ep,
                              const int32_t* unit_xqd, const int16_t* unit_wiener);

@@ -8,13 +8,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# --serial: one stream, so that a kernel's trace duration is its own (the default bench overlaps kernels on forked streams)
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --serial"
+# one frame per step on one stream, so that a kernel's trace duration is its own (the default bench overlaps the kernels of several frames on forked streams)
+BENCH="python $R/bench.py --steps 12 --warmup 2 --frames 1 --groups 4 --no-side --no-sweep --no-transfers --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1
-cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # kernels outside the bench step: HIP-event timings
 (python tools/wiener_time.py; python tools/tf_time.py; python tools/tf_time.py --bd 10; python tools/compound_time.py; python tools/hbd_time.py --bd 8; python tools/hbd_time.py --bd 10) > $OUT/extra_kernels.txt 2>&1
 # ... and their rocprofv3 kernel statistics (one trace over the three timing tools)

@@ -23,7 +23,7 @@ orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
 F = workload.Frame(args.w, args.h, seed=11)
 sbs = mc.windows(orc, args.w, args.h, 64, 64)
 CB, nb = workload.conv_jobs(F, 14)
-stages = [dict(key=k) for k in "pyr hme me subpel txfm inv dlf cdef_search cdef_apply sgr_search sgr_apply".split()]
+stages = [dict(key=k) for k in "pyr hme me subpel txfm inv dlf cdef_search cdef_apply sgr_units sgr_apply".split()]
 jobs = dict(hme=workload.hme_jobs(F), conv=(CB, nb), unit=256)
 refb = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so"))
 if args.threads_check:   # does a ctypes call scale over Python threads on this host?

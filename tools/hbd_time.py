@@ -173,6 +173,7 @@ for mask in (0xFFFF, 0x0038):
     print(f"sgr_units_dev  {W}x{H} bd{bd}: {ms.value / 10:.3f} ms device time per frame, ep mask {mask:#06x} (sums + difference planes + walk, all three planes, no host sync; scratch {sum(scr) / 1e6:.0f} MB)")
 sgr_units_dev(0xFFFF)
 for p in range(3):
-    st3 = hip.to_host(d_scr[p], (3,), np.uint32)
-    print(f"  plane {p}: {units[p]} units x 16 sets: {st3[0] / (units[p] * 16):.2f} evaluation passes, {st3[1] / (units[p] * 16):.2f} evaluated points per walk, unfinished {st3[2]}")
+    st3 = hip.to_host(d_scr[p], (24,), np.uint32)
+    print(f"  plane {p}: {units[p]} units x 16 sets: {st3[0] / (units[p] * 16):.2f} evaluation passes, {st3[1] / (units[p] * 16):.2f} evaluated points per walk, unfinished {st3[2]}, "
+          f"flat {st3[3]}, passes histogram {list(st3[8:24])}")
 
