@@ -550,6 +550,57 @@ int svt_hip_picture_format_dev(SvtHipCtx *ctx, int mode, const void *d_in0, int 
  * reference picture, and svt_extend_frame's 3-sample border of the restoration input).  d_plane points at picture sample (0, 0). */
 int svt_hip_generate_padding_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h);
 
+/* ------------------------------------------------------------------ per-call forms ------------- */
+/* Operations that the frame entry points above run fused inside larger kernels, exposed on their own for a list of units, so that every
+ * pointer of the reference's dispatch table on this path has a device form (include/svt_hip_rtcd.h launches these with a list of one).
+ * All pointers are device pointers; lists are device arrays. */
+
+/* The quantizer stage alone: nblk blocks of n_coeffs coefficients each (packed, block after block), quantizer variants and parameters as in
+ * SvtHipQuantParams (flat quant matrix), d_iscan = inverse scan of the transform size (eob = 1 + last scan position with a non-zero level).
+ * Replaces svt_aom_quantize_b / svt_aom_highbd_quantize_b / svt_av1_quantize_fp[_32x32|_64x64] / svt_av1_highbd_quantize_fp
+ * (aom_dsp_rtcd.h:250-262). */
+int svt_hip_quantize_batch_dev(SvtHipCtx *ctx, const int32_t *d_coeff, int n_coeffs, int nblk, const SvtHipQuantParams *qp,
+                               const int16_t *d_iscan, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+/* residual = src - pred over a w x h area: svt_residual_kernel8bit / 16bit (common_dsp_rtcd.h:168, :180).  Strides in samples. */
+int svt_hip_residual_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_src, int src_stride, const void *d_pred, int pred_stride,
+                         int16_t *d_residual, int residual_stride, int w, int h);
+/* svt_ext_all_sad_calculation_8x8_16x16 (aom_dsp_rtcd.h:640; EbMotionEstimation.c:356): for each job the 64 8x8 and 16 16x16 SADs of a 64x64
+ * source block against 8 horizontally consecutive candidates, and the running bests updated in candidate order.
+ * d_state: 800 uint32 per job = best_sad8x8[64] best_sad16x16[16] best_mv8x8[64] best_mv16x16[16] (in/out) eight_sad16x16[16][8]
+ * eight_sad8x8[64][8] (out), block indices in the reference's z-order. */
+typedef struct { int32_t src_off, ref_off; uint32_t mv; int32_t sub_sad; } SvtHipExtSadJob;
+int svt_hip_ext_all_sad_8x8_16x16_batch_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, const uint8_t *d_ref, int ref_stride,
+                                            const SvtHipExtSadJob *d_jobs, int n, uint32_t *d_state);
+/* svt_ext_eight_sad_calculation_32x32_64x64 (aom_dsp_rtcd.h:641; EbMotionEstimation.c:394).  d_state: 170 uint32 per job =
+ * sad16x16[16][8] (in) best_sad32x32[4] best_sad64x64 best_mv32x32[4] best_mv64x64 (in/out) sad32x32[4][8] (out); d_mv[n]. */
+int svt_hip_ext_eight_sad_32x32_64x64_batch_dev(SvtHipCtx *ctx, const uint32_t *d_mv, int n, uint32_t *d_state);
+/* svt_compute_interm_var_four8x8 (aom_dsp_rtcd.h:650; EbPictureAnalysisProcess.c:352): for each offset (top-left sample of four
+ * horizontally adjacent 8x8 blocks) 4 means and 4 means of squares with the reference's fixed-point scaling. */
+int svt_hip_interm_var_four8x8_batch_dev(SvtHipCtx *ctx, const uint8_t *d_plane, int stride, const int32_t *d_offs, int n,
+                                         uint64_t *d_mean, uint64_t *d_mean_sq);
+/* svt_handle_transform64x64 / 64x32 / 32x64 / 64x16 / 16x64 (aom_dsp_rtcd.h:221-230) in place on nblk blocks of W*H coefficients:
+ * energy of the coefficients outside the top-left 32x32, zero them, pack the kept rows to stride min(W,32). tx_size = TxSize (4, 12, 11, 18, 17). */
+int svt_hip_handle_transform64_batch_dev(SvtHipCtx *ctx, int tx_size, int32_t *d_coeff, int nblk, uint64_t *d_energy);
+/* svt_aom_upsampled_pred (aom_dsp_rtcd.h:353; C_DEFAULT/variance.c:212): sub-pel prediction of the OBMC / sub-pel refinement searches, two
+ * 8-tap passes with an 8-bit clip after each.  bank = filter family as in SvtHipConvBlk (3 bilinear = USE_2_TAPS, 4 = USE_4_TAPS, 0 = USE_8_TAPS).
+ * Output is packed (stride = w) at dst_off. */
+typedef struct { int32_t ref_off, dst_off; uint8_t w, h, subpel_x_q3, subpel_y_q3, bank, reserved[3]; } SvtHipUpsampledBlk;
+int svt_hip_upsampled_pred_batch_dev(SvtHipCtx *ctx, const uint8_t *d_ref, int ref_stride, uint8_t *d_dst, const SvtHipUpsampledBlk *d_blks, int n);
+/* svt_cdef_find_dir (common_dsp_rtcd.h:1031) for a list of 8x8 blocks of a 16-bit image (offsets in samples). */
+int svt_hip_cdef_find_dir_batch_dev(SvtHipCtx *ctx, const uint16_t *d_img, int stride, const int32_t *d_offs, int n, int coeff_shift,
+                                    int32_t *d_dir, int32_t *d_var);
+/* svt_cdef_filter_block (common_dsp_rtcd.h:1033) for a list of blocks of the 16-bit staging image (CDEF_VERY_LARGE outside the picture);
+ * strengths as the reference passes them (already scaled by coeff_shift), block 4 or 8 samples wide / high (log2 2 or 3).
+ * Exactly one of d_dst8 / d_dst16 is non-NULL. */
+typedef struct { int32_t in_off, dst_off, pri_strength, sec_strength, dir, pri_damping, sec_damping, bw_log2, bh_log2, coeff_shift; } SvtHipCdefBlk;
+int svt_hip_cdef_filter_block_batch_dev(SvtHipCtx *ctx, const uint16_t *d_in, int in_stride, const SvtHipCdefBlk *d_blks, int n,
+                                        uint8_t *d_dst8, uint16_t *d_dst16, int dst_stride);
+/* svt_aom_[highbd_]lpf_{vertical,horizontal}_{4,6,8,14} (common_dsp_rtcd.h:1044-1075) for a list of 4-sample edge segments with explicit
+ * thresholds.  off = sample index of the first q0 sample; dir 0 = vertical edge (filter taps run along x, the 4 samples along y), 1 =
+ * horizontal edge.  The segments of one call must not touch each other's samples (they are filtered concurrently). */
+typedef struct { int32_t off; uint8_t dir, len, blimit, limit, thresh, reserved[3]; } SvtHipLpfEdge;
+int svt_hip_lpf_edges_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, void *d_plane, int stride, const SvtHipLpfEdge *d_edges, int n);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

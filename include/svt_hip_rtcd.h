@@ -90,6 +90,45 @@ typedef void (*SvtHipHbdComputeStatsFn)(int32_t wiener_win, const uint8_t *dgd8,
                                         int32_t v_start, int32_t v_end, int32_t dgd_stride, int32_t src_stride, int64_t *M, int64_t *H,
                                         int32_t bit_depth /* AomBitDepth */);
 
+typedef void (*SvtHipExtAllSadFn)(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
+                                  uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
+                                  uint32_t p_eight_sad8x8[64][8], uint8_t sub_sad /* EbBool */);
+typedef void (*SvtHipExtEightSadFn)(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                    uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]);
+/* TranLow = int32_t, QmVal = uint8_t (EbDefinitions.h:668) */
+typedef void (*SvtHipQuantizeBFn)(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                  const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                  const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale);
+typedef void (*SvtHipQuantizeFpFn)(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                   const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                   const int16_t *scan, const int16_t *iscan);
+typedef void (*SvtHipHbdQuantizeFpFn)(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr,
+                                      const int16_t *quant_ptr, const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr,
+                                      const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan, int16_t log_scale);
+typedef void (*SvtHipLpfFn)(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);
+typedef void (*SvtHipHbdLpfFn)(uint16_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int32_t bd);
+typedef int32_t (*SvtHipCdefFindDirFn)(const uint16_t *img, int32_t stride, int32_t *var, int32_t coeff_shift);
+typedef void (*SvtHipCdefFilterBlockFn)(uint8_t *dst8, uint16_t *dst16, int32_t dstride, const uint16_t *in, int32_t pri_strength, int32_t sec_strength,
+                                        int32_t dir, int32_t pri_damping, int32_t sec_damping, int32_t bsize, int32_t coeff_shift);
+typedef void (*SvtHipResidual8Fn)(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                  uint32_t area_width, uint32_t area_height);
+typedef void (*SvtHipResidual16Fn)(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                   uint32_t area_width, uint32_t area_height);
+typedef void (*SvtHipSadx4dFn)(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[], int ref_stride, uint32_t *sad_array);
+/* MacroBlockD*, AV1Common*, MV* are unused by the reference's function (C_DEFAULT/variance.c:218-222) and opaque here */
+typedef void (*SvtHipUpsampledPredFn)(void *xd, const void *cm, int mi_row, int mi_col, const void *mv, uint8_t *comp_pred, int width, int height,
+                                      int subpel_x_q3, int subpel_y_q3, const uint8_t *ref, int ref_stride, int subpel_search);
+typedef void (*SvtHipIntermVarFn)(uint8_t *input_samples, uint16_t input_stride, uint64_t *mean_of8x8_blocks, uint64_t *mean_of_squared8x8_blocks);
+typedef uint64_t (*SvtHipHandleTransformFn)(int32_t *output);
+/* TxfmParam, EbDefinitions.h:779-791 (TxType / TxSize / TxSetType are one-byte enums) */
+typedef struct {
+    uint8_t tx_type, tx_size;
+    int32_t lossless, bd, is_hbd;
+    uint8_t tx_set_type;
+    int32_t eob;
+} SvtHipTxfmParam;
+typedef void (*SvtHipInvTxfmAddFn)(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+
 /* The 22 block sizes of svt_aom_sad{W}x{H} / svt_aom_variance{W}x{H} in BlockSize order
  * (aom_dsp_rtcd.h:334-336, :524): index = position in this list. */
 #define SVT_HIP_RTCD_BLOCK_SIZES(X) /* X(index, W, H) */ \
@@ -127,6 +166,23 @@ typedef struct SvtHipRtcd {
     SvtHipComputeStatsFn   svt_av1_compute_stats;                /* aom_dsp_rtcd.h:99 */
     SvtHipHbdComputeStatsFn svt_av1_compute_stats_highbd;        /* :103 */
     SvtHipFwdTxfmFn        svt_av1_fwd_txfm2d_N2[14], svt_av1_fwd_txfm2d_N4[14];   /* aom_dsp_rtcd.h:284-350 (squares: svt_av1_fwd_txfm2d_{N}x{N}_N2 / _N4), SVT_HIP_RTCD_FWD_SIZES order */
+    /* --- per-call forms of the remaining pointers on the hot path */
+    SvtHipExtAllSadFn      svt_ext_all_sad_calculation_8x8_16x16;     /* aom_dsp_rtcd.h:640 */
+    SvtHipExtEightSadFn    svt_ext_eight_sad_calculation_32x32_64x64; /* :641 */
+    SvtHipQuantizeBFn      svt_aom_quantize_b, svt_aom_highbd_quantize_b;                             /* :252, :254 */
+    SvtHipQuantizeFpFn     svt_av1_quantize_fp, svt_av1_quantize_fp_32x32, svt_av1_quantize_fp_64x64; /* :256, :260, :262 */
+    SvtHipHbdQuantizeFpFn  svt_av1_highbd_quantize_fp;                                                /* :258 */
+    SvtHipLpfFn            svt_aom_lpf_horizontal[4], svt_aom_lpf_vertical[4];               /* common_dsp_rtcd.h:1060-1075, filter lengths 4, 6, 8, 14 */
+    SvtHipHbdLpfFn         svt_aom_highbd_lpf_horizontal[4], svt_aom_highbd_lpf_vertical[4]; /* :1044-1059 */
+    SvtHipCdefFindDirFn    svt_cdef_find_dir;                  /* :1032 */
+    SvtHipCdefFilterBlockFn svt_cdef_filter_block;             /* :1034 */
+    SvtHipResidual8Fn      svt_residual_kernel8bit;            /* :169 */
+    SvtHipResidual16Fn     svt_residual_kernel16bit;           /* :180 */
+    SvtHipSadx4dFn         svt_aom_sadx4d[22];                 /* aom_dsp_rtcd.h:336 svt_aom_sad{W}x{H}x4d, SVT_HIP_RTCD_BLOCK_SIZES order */
+    SvtHipUpsampledPredFn  svt_aom_upsampled_pred;             /* :354 */
+    SvtHipIntermVarFn      svt_compute_interm_var_four8x8;     /* :650 */
+    SvtHipHandleTransformFn svt_handle_transform64[5];         /* :221-230 in header order: 16x64, 32x64, 64x16, 64x32, 64x64 */
+    SvtHipInvTxfmAddFn     svt_av1_inv_txfm_add;               /* common_dsp_rtcd.h:156 */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

@@ -64,7 +64,26 @@ void svt_hip_hooks_report(void) {
 /* ---- per-call wrappers: SvtHipRtcd member <-> the reference's global pointer of the same name ---------------------------------------- */
 #define RTCD_SIMPLE(X)                                                                                                                      \
     X(svt_sad_loop_kernel) X(svt_nxm_sad_kernel) X(svt_av1_selfguided_restoration) X(svt_apply_selfguided_restoration)                     \
-    X(svt_av1_compute_stats) X(svt_av1_compute_stats_highbd)
+    X(svt_av1_compute_stats) X(svt_av1_compute_stats_highbd)                                                                                \
+    X(svt_ext_all_sad_calculation_8x8_16x16) X(svt_ext_eight_sad_calculation_32x32_64x64)                                                   \
+    X(svt_aom_quantize_b) X(svt_aom_highbd_quantize_b) X(svt_av1_quantize_fp) X(svt_av1_quantize_fp_32x32) X(svt_av1_quantize_fp_64x64)    \
+    X(svt_av1_highbd_quantize_fp) X(svt_cdef_find_dir) X(svt_cdef_filter_block) X(svt_residual_kernel8bit) X(svt_residual_kernel16bit)     \
+    X(svt_aom_upsampled_pred) X(svt_compute_interm_var_four8x8) X(svt_av1_inv_txfm_add)                                                     \
+    X(svt_av1_convolve_2d_sr) X(svt_av1_convolve_x_sr) X(svt_av1_convolve_y_sr) X(svt_av1_convolve_2d_copy_sr)                              \
+    X(svt_av1_highbd_convolve_2d_sr) X(svt_av1_highbd_convolve_x_sr) X(svt_av1_highbd_convolve_y_sr) X(svt_av1_highbd_convolve_2d_copy_sr)
+/* array members <-> the reference's individually named pointers */
+#define RTCD_INDEXED(X)                                                                                                                      \
+    X(svt_aom_lpf_horizontal, 0, svt_aom_lpf_horizontal_4) X(svt_aom_lpf_horizontal, 1, svt_aom_lpf_horizontal_6)                           \
+    X(svt_aom_lpf_horizontal, 2, svt_aom_lpf_horizontal_8) X(svt_aom_lpf_horizontal, 3, svt_aom_lpf_horizontal_14)                          \
+    X(svt_aom_lpf_vertical, 0, svt_aom_lpf_vertical_4) X(svt_aom_lpf_vertical, 1, svt_aom_lpf_vertical_6)                                   \
+    X(svt_aom_lpf_vertical, 2, svt_aom_lpf_vertical_8) X(svt_aom_lpf_vertical, 3, svt_aom_lpf_vertical_14)                                  \
+    X(svt_aom_highbd_lpf_horizontal, 0, svt_aom_highbd_lpf_horizontal_4) X(svt_aom_highbd_lpf_horizontal, 1, svt_aom_highbd_lpf_horizontal_6) \
+    X(svt_aom_highbd_lpf_horizontal, 2, svt_aom_highbd_lpf_horizontal_8) X(svt_aom_highbd_lpf_horizontal, 3, svt_aom_highbd_lpf_horizontal_14) \
+    X(svt_aom_highbd_lpf_vertical, 0, svt_aom_highbd_lpf_vertical_4) X(svt_aom_highbd_lpf_vertical, 1, svt_aom_highbd_lpf_vertical_6)       \
+    X(svt_aom_highbd_lpf_vertical, 2, svt_aom_highbd_lpf_vertical_8) X(svt_aom_highbd_lpf_vertical, 3, svt_aom_highbd_lpf_vertical_14)      \
+    X(svt_handle_transform64, 0, svt_handle_transform16x64) X(svt_handle_transform64, 1, svt_handle_transform32x64)                         \
+    X(svt_handle_transform64, 2, svt_handle_transform64x16) X(svt_handle_transform64, 3, svt_handle_transform64x32)                         \
+    X(svt_handle_transform64, 4, svt_handle_transform64x64)
 
 static void install_rtcd(const char *list) {
     SvtHipRtcd t;
@@ -72,6 +91,9 @@ static void install_rtcd(const char *list) {
     /* what is installed now (the C / SIMD kernels) becomes each wrapper's failure fallback */
 #define X(n) t.n = (void *)n;
     RTCD_SIMPLE(X)
+#undef X
+#define X(m, i, n) t.m[i] = (void *)n;
+    RTCD_INDEXED(X)
 #undef X
     if (svt_hip_setup_rtcd(g_ctx, &t) != SVT_HIP_OK) {
         SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_ctx));
@@ -83,6 +105,13 @@ static void install_rtcd(const char *list) {
         fprintf(stderr, "svt_hip_rtcd %s -> hip wrapper\n", #n);  \
     }
     RTCD_SIMPLE(X)
+#undef X
+#define X(m, i, n)                                                \
+    if (in_list(list, #n)) {                                      \
+        n = (void *)t.m[i];                                       \
+        fprintf(stderr, "svt_hip_rtcd %s -> hip wrapper\n", #n);  \
+    }
+    RTCD_INDEXED(X)
 #undef X
 }
 

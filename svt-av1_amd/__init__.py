@@ -173,6 +173,17 @@ def lib():
     L.svt_hip_tf_noise_sigma.argtypes = [C.c_int64, C.c_int64]
     L.svt_hip_tf_noise_sigma.restype = C.c_double
     L.svt_hip_plane_sse_dev.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp]
+    # per-call forms
+    L.svt_hip_quantize_batch_dev.argtypes = [vp, vp, i32, i32, C.POINTER(QuantParams), vp, vp, vp, vp]
+    L.svt_hip_residual_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32]
+    L.svt_hip_ext_all_sad_8x8_16x16_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    L.svt_hip_ext_eight_sad_32x32_64x64_batch_dev.argtypes = [vp, vp, i32, vp]
+    L.svt_hip_interm_var_four8x8_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.svt_hip_handle_transform64_batch_dev.argtypes = [vp, i32, vp, i32, vp]
+    L.svt_hip_upsampled_pred_batch_dev.argtypes = [vp, vp, i32, vp, vp, i32]
+    L.svt_hip_cdef_find_dir_batch_dev.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+    L.svt_hip_cdef_filter_block_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32]
+    L.svt_hip_lpf_edges_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32]
     L.svt_hip_dlf_search_level_dev.argtypes = [vp, C.POINTER(DlfSearch), vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.svt_hip_setup_rtcd.argtypes = [vp, vp]

@@ -239,12 +239,12 @@ __device__ __forceinline__ void tap_minmax(int v, int& mn, int& mx) {
 
 // One pixel, one (pri, sec, dir): svt_cdef_filter_block_c (EbCdef.c:202-257).  The two mirrored taps of every (direction, distance) share a weight,
 // so they are handled as a packed pair with the search's helpers (|d|, constrain and the weighted sum of both taps in ~9 instructions).
-__device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride, int pri, int sec, int dir, int cs, int damping) {
+__device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride, int pri, int sec, int dir, int cs, int damping, int sec_damping = -1) {
     const int x = (int)(int16_t)px[0];
     const s16x2 x2 = dup2(x);
     s16x2 mn = x2, mx = x2;
     int sum = 0;
-    const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
+    const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, (sec_damping < 0 ? damping : sec_damping) - msb(sec)) : 0;
     const int w0 = ((pri >> cs) & 1) ? 3 : 4, w1 = ((pri >> cs) & 1) ? 3 : 2;
     const int d2 = (dir + 2) & 7, d6 = (dir + 6) & 7;
 #pragma unroll
@@ -518,7 +518,41 @@ int apply_t(hipStream_t st, const void* const in[3], void* const out[3], const i
     return (int)hipGetLastError();
 }
 
+// ---- per-call forms (include/svt_hip_rtcd.h): svt_cdef_find_dir for a list of 8x8 blocks, svt_cdef_filter_block for a list of blocks, on the
+// 16-bit staging layout of the reference (CDEF_BSTRIDE rows, CDEF_VERY_LARGE outside the picture).  Same device functions as the frame kernels.
+__global__ void __launch_bounds__(64)
+cdef_find_dir_list_kernel(const uint16_t* __restrict__ img, const int32_t* __restrict__ offs, int stride, int coeff_shift, int32_t* __restrict__ dir_out, int32_t* __restrict__ var_out) {
+    __shared__ int xs[64];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const uint16_t* p = img + offs[b];
+    int var;
+    const int dir = find_dir_wave((int)p[(lane >> 3) * stride + (lane & 7)] >> coeff_shift, lane, xs, var);
+    if (lane == 0) { dir_out[b] = dir; var_out[b] = var; }
+}
+// dst8 != nullptr: 8-bit destination (stride dstride), else dst16
+__global__ void __launch_bounds__(64)
+cdef_filter_block_list_kernel(const uint16_t* __restrict__ in, int istride, const SvtHipCdefBlk* __restrict__ jobs, uint8_t* __restrict__ dst8, uint16_t* __restrict__ dst16, int dstride) {
+    const SvtHipCdefBlk j = jobs[blockIdx.x];
+    const int bw = 1 << j.bw_log2, bh = 1 << j.bh_log2, lane = threadIdx.x;
+    if (lane >= bw * bh) return;
+    const int y = lane >> j.bw_log2, x = lane & (bw - 1);
+    const int v = filter_px_single(in + j.in_off + y * istride + x, istride, j.pri_strength, j.sec_strength, j.dir, j.coeff_shift, j.pri_damping, j.sec_damping);
+    if (dst8) dst8[j.dst_off + y * dstride + x] = (uint8_t)v; else dst16[j.dst_off + y * dstride + x] = (uint16_t)v;
+}
+
 }  // namespace
+
+extern "C" int svt_hip_launch_cdef_find_dir_list(hipStream_t st, const uint16_t* img, const int32_t* offs, int n, int stride, int coeff_shift, int32_t* dir_out, int32_t* var_out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cdef_find_dir_list_kernel, dim3(n), dim3(64), 0, st, img, offs, stride, coeff_shift, dir_out, var_out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_cdef_filter_block_list(hipStream_t st, const uint16_t* in, int istride, const void* jobs, int n, uint8_t* dst8, uint16_t* dst16, int dstride) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cdef_filter_block_list_kernel, dim3(n), dim3(64), 0, st, in, istride, (const SvtHipCdefBlk*)jobs, dst8, dst16, dstride);
+    return (int)hipGetLastError();
+}
+
 
 extern "C" int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const rec[3], const int rec_stride[3],
                                           const void* const src[3], const int src_stride[3], int w, int h, const uint8_t* skip8,

@@ -22,14 +22,11 @@ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // px[0..13] = p6..p0 q0..q6; returns how many samples on each side may have changed
+// lim8 / blim8 / thr8: the 8-bit-scale thresholds the reference's filters take (*limit, *blimit, *thresh); scaled by the bit depth here
 template <int BD>
-__device__ __forceinline__ int lpf_core(int (&px)[14], int len, int level, int sharpness) {
+__device__ __forceinline__ int lpf_core_thr(int (&px)[14], int len, int lim8, int blim8, int thr8) {
     constexpr int sh = BD - 8, t80 = 0x80 << sh, lo = -t80, hi = t80 - 1, one = 1 << sh;
-    // limits of the level: update_sharpness (EbDeblockingCommon.c:587-606), hev_thr = lvl >> 4 (EbDeblockingFilter.c:38)
-    int inside = level >> ((sharpness > 0) + (sharpness > 4));
-    if (sharpness > 0) inside = min(inside, 9 - sharpness);
-    inside = max(inside, 1);
-    const int lim = inside << sh, blim = (2 * (level + 2) + inside) << sh, thr = (level >> 4) << sh;
+    const int lim = lim8 << sh, blim = blim8 << sh, thr = thr8 << sh;
 #define p(i) px[6 - (i)]
 #define q(i) px[7 + (i)]
     bool m = (iabs(p(1) - p(0)) > lim) | (iabs(q(1) - q(0)) > lim) | ((iabs(p(0) - q(0)) * 2 + iabs(p(1) - q(1)) / 2) > blim);
@@ -97,6 +94,37 @@ __device__ __forceinline__ int lpf_core(int (&px)[14], int len, int level, int s
 #undef q
 #undef RP2
 }
+template <int BD>
+__device__ __forceinline__ int lpf_core(int (&px)[14], int len, int level, int sharpness) {
+    // limits of the level: update_sharpness (EbDeblockingCommon.c:587-606), hev_thr = lvl >> 4 (EbDeblockingFilter.c:38)
+    int inside = level >> ((sharpness > 0) + (sharpness > 4));
+    if (sharpness > 0) inside = min(inside, 9 - sharpness);
+    inside = max(inside, 1);
+    return lpf_core_thr<BD>(px, len, inside, 2 * (level + 2) + inside, level >> 4);
+}
+
+// ---- per-call form (include/svt_hip_rtcd.h): a list of 4-sample edge segments with explicit thresholds = svt_aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(64)
+lpf_edge_list_kernel(PIX* __restrict__ plane, int stride, const SvtHipLpfEdge* __restrict__ jobs, int n) {
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 2), k = threadIdx.x & 3;
+    if (e >= n) return;
+    const SvtHipLpfEdge j = jobs[e];
+    const int half = j.len == 4 ? 2 : (j.len == 6 ? 3 : (j.len == 8 ? 4 : 7));
+    const ptrdiff_t tap = j.dir == 0 ? 1 : stride, step = j.dir == 0 ? stride : 1;   // dir 0: vertical edge (taps along x, the 4 samples along y)
+    PIX* s = plane + j.off + (ptrdiff_t)k * step;
+    int px[14];
+#pragma unroll
+    for (int t = 1; t <= 7; t++) {
+        px[7 - t] = (t <= half) ? (int)s[-(ptrdiff_t)t * tap] : 0;
+        px[6 + t] = (t <= half) ? (int)s[(ptrdiff_t)(t - 1) * tap] : 0;
+    }
+    const int changed = lpf_core_thr<BD>(px, j.len, j.limit, j.blimit, j.thresh);
+#pragma unroll
+    for (int t = 1; t <= 6; t++)
+        if (t <= changed) { s[-(ptrdiff_t)t * tap] = (PIX)px[7 - t]; s[(ptrdiff_t)(t - 1) * tap] = (PIX)px[6 + t]; }
+}
+
 
 // DIR 0: vertical edges (taps along x); DIR 1: horizontal edges (taps along y)
 template <typename PIX, int BD, int DIR>
@@ -216,6 +244,16 @@ plane_sse_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __restrict_
 }
 
 }  // namespace
+
+extern "C" int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n) {
+    if (n <= 0) return 0;
+    dim3 grid((n + 15) / 16);
+    if (pix_bytes == 1) hipLaunchKernelGGL((lpf_edge_list_kernel<uint8_t, 8>), grid, dim3(64), 0, st, (uint8_t*)plane, stride, (const SvtHipLpfEdge*)jobs, n);
+    else if (bd == 8) hipLaunchKernelGGL((lpf_edge_list_kernel<uint16_t, 8>), grid, dim3(64), 0, st, (uint16_t*)plane, stride, (const SvtHipLpfEdge*)jobs, n);
+    else hipLaunchKernelGGL((lpf_edge_list_kernel<uint16_t, 10>), grid, dim3(64), 0, st, (uint16_t*)plane, stride, (const SvtHipLpfEdge*)jobs, n);
+    return (int)hipGetLastError();
+}
+
 
 extern "C" int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
                                             const uint16_t* edges_h, int units_w, int units_h, int sharpness, int level_v, int level_h) {

@@ -230,14 +230,20 @@ template <int SLOT, int TS> void fwd_n4_hip(int16_t* in, int32_t* out, uint32_t 
     if (fwd_generic(TS, in, out, (int)stride, tt, 2)) return;
     FALLBACK("svt_av1_fwd_txfm2d_WxH_N4", svt_av1_fwd_txfm2d_N4[SLOT], in, out, stride, tt, bd);
 }
-bool inv_generic(int ts, const int32_t* in, uint16_t* out_r, int stride_r, uint16_t* out_w, int stride_w, int tx_type, int bd) {
+bool inv_generic(int ts, const int32_t* in, void* out_r, int stride_r, void* out_w, int stride_w, int tx_type, int bd, int pb = 2) {
     const int w = kTxW[ts], h = kTxH[ts], kw = w < 32 ? w : 32, kh = h < 32 ? h : 32;
-    if (!g_ctx || (bd != 8 && bd != 10)) return false;
-    const size_t p = (size_t)w * 2;
-    int32_t* d_c = (int32_t*)dev(0, (size_t)kw * kh * 4); uint16_t *d_r = (uint16_t*)dev(1, p * h), *d_w = (uint16_t*)dev(3, p * h); uint32_t* d_desc = (uint32_t*)dev(2, 16);
+    if (!g_ctx || (bd != 8 && bd != 10) || (pb == 1 && bd != 8)) return false;
+    const size_t p = (size_t)w * pb, pitch = rup(p, 4);
+    int32_t* d_c = (int32_t*)dev(0, (size_t)kw * kh * 4); uint8_t *d_r = (uint8_t*)dev(1, pitch * h), *d_w = (uint8_t*)dev(3, pitch * h); uint32_t* d_desc = (uint32_t*)dev(2, 16);
     const uint32_t desc = SVT_HIP_TX_DESC(0, 0, tx_type);
-    return d_c && d_r && d_w && d_desc && up(d_c, in, (size_t)kw * kh * 4) && up2d(d_r, p, out_r, (size_t)stride_r * 2, p, h) && up(d_desc, &desc, 4) &&
-           svt_hip_inv_txfm_add_batch_dev(g_ctx, ts, 2, bd, d_c, d_r, w, d_w, w, d_desc, 1) == 0 && down2d(out_w, (size_t)stride_w * 2, d_w, p, p, h);
+    return d_c && d_r && d_w && d_desc && up(d_c, in, (size_t)kw * kh * 4) && up2d(d_r, pitch, out_r, (size_t)stride_r * pb, p, h) && up(d_desc, &desc, 4) &&
+           svt_hip_inv_txfm_add_batch_dev(g_ctx, ts, pb, bd, d_c, d_r, (int)(pitch / pb), d_w, (int)(pitch / pb), d_desc, 1) == 0 &&
+           down2d(out_w, (size_t)stride_w * pb, d_w, pitch, p, h);
+}
+void inv_txfm_add_hip(const int32_t* dq, uint8_t* dst_r, int32_t sr, uint8_t* dst_w, int32_t sw, const SvtHipTxfmParam* tp) {
+    Guard lk;   // svt_av1_inv_txfm_add_c (EbInvTransforms.c:3302): 8-bit destination through the high bit-depth inverse at bd = tp->bd
+    if (tp && !tp->lossless && tp->tx_size < 19 && tp->tx_type < 16 && inv_generic(tp->tx_size, dq, dst_r, sr, dst_w, sw, tp->tx_type, tp->bd, 1)) return;
+    FALLBACK("svt_av1_inv_txfm_add", svt_av1_inv_txfm_add, dq, dst_r, sr, dst_w, sw, tp);
 }
 template <int SLOT, int TS> void inv_sq_hip(const int32_t* in, uint16_t* r, int32_t sr, uint16_t* wv, int32_t sw, uint8_t tt, int32_t bd) {
     Guard lk;
@@ -438,6 +444,220 @@ void stats_hbd_hip(int32_t win, const uint8_t* dgd8, const uint8_t* src8, int32_
     FALLBACK("svt_av1_compute_stats_highbd", svt_av1_compute_stats_highbd, win, dgd8, src8, h0, h1, v0, v1, ds, ss, M, H, bd);
 }
 
+
+// ----------------------------------------------------------------------------------- 8-candidate SAD ladders of the open-loop search
+void ext_all_sad_hip(uint8_t* src, uint32_t ss, uint8_t* ref, uint32_t rs, uint32_t mv, uint32_t* bs8, uint32_t* bs16, uint32_t* bm8, uint32_t* bm16, uint32_t e16[16][8],
+                     uint32_t e8[64][8], uint8_t sub_sad) {
+    Guard lk;
+    if (g_ctx) {
+        uint8_t *d_src = (uint8_t*)dev(0, 64 * 64), *d_ref = (uint8_t*)dev(1, 72 * 64 + 64); void* d_job = dev(2, sizeof(SvtHipExtSadJob)); uint32_t* d_st = (uint32_t*)dev(3, 800 * 4);
+        const SvtHipExtSadJob job = {0, 0, mv, sub_sad ? 1 : 0};
+        static thread_local uint32_t st[800];
+        std::memcpy(st, bs8, 256); std::memcpy(st + 64, bs16, 64); std::memcpy(st + 80, bm8, 256); std::memcpy(st + 144, bm16, 64);
+        const int rows = sub_sad ? 63 : 64;   // the sub-sampled form never reads the last row
+        if (d_src && d_ref && d_job && d_st && up2d(d_src, 64, src, ss, 64, rows) && up2d(d_ref, 72, ref, rs, 71, rows) && up(d_job, &job, sizeof(job)) && up(d_st, st, 640) &&
+            svt_hip_ext_all_sad_8x8_16x16_batch_dev(g_ctx, d_src, 64, d_ref, 72, (const SvtHipExtSadJob*)d_job, 1, d_st) == 0 && down(st, d_st, sizeof(st))) {
+            std::memcpy(bs8, st, 256); std::memcpy(bs16, st + 64, 64); std::memcpy(bm8, st + 80, 256); std::memcpy(bm16, st + 144, 64);
+            std::memcpy(e16, st + 160, 512); std::memcpy(e8, st + 288, 2048);
+            return;
+        }
+    }
+    FALLBACK("svt_ext_all_sad_calculation_8x8_16x16", svt_ext_all_sad_calculation_8x8_16x16, src, ss, ref, rs, mv, bs8, bs16, bm8, bm16, e16, e8, sub_sad);
+}
+void ext_eight_sad_hip(uint32_t s16[16][8], uint32_t* bs32, uint32_t* bs64, uint32_t* bm32, uint32_t* bm64, uint32_t mv, uint32_t s32[4][8]) {
+    Guard lk;
+    if (g_ctx) {
+        uint32_t* d_st = (uint32_t*)dev(0, 170 * 4); uint32_t* d_mv = (uint32_t*)dev(1, 16);
+        uint32_t st[170];
+        std::memcpy(st, s16, 512); std::memcpy(st + 128, bs32, 16); st[132] = *bs64; std::memcpy(st + 133, bm32, 16); st[137] = *bm64;
+        if (d_st && d_mv && up(d_st, st, 138 * 4) && up(d_mv, &mv, 4) && svt_hip_ext_eight_sad_32x32_64x64_batch_dev(g_ctx, d_mv, 1, d_st) == 0 && down(st, d_st, sizeof(st))) {
+            std::memcpy(bs32, st + 128, 16); *bs64 = st[132]; std::memcpy(bm32, st + 133, 16); *bm64 = st[137]; std::memcpy(s32, st + 138, 128);
+            return;
+        }
+    }
+    FALLBACK("svt_ext_eight_sad_calculation_32x32_64x64", svt_ext_eight_sad_calculation_32x32_64x64, s16, bs32, bs64, bm32, bm64, mv, s32);
+}
+
+// ----------------------------------------------------------------------------------- quantizers
+bool flat_qm(const uint8_t* qm, intptr_t n) {
+    if (!qm) return true;
+    for (intptr_t i = 0; i < n; i++)
+        if (qm[i] != 32) return false;   // 1 << AOM_QM_BITS: the only matrix the device quantizer covers
+    return true;
+}
+bool quant_generic(int variant, const int32_t* coeff, intptr_t n, const int16_t* zbin, const int16_t* round, const int16_t* quant, const int16_t* shift, int32_t* q, int32_t* dq,
+                   const int16_t* dequant, uint16_t* eob, const int16_t* iscan, const uint8_t* qm, const uint8_t* iqm, int log_scale) {
+    if (!g_ctx || n <= 0 || n > 4096 || log_scale < 0 || log_scale > 2 || !iscan || !flat_qm(qm, n) || !flat_qm(iqm, n)) return false;
+    SvtHipQuantParams qp = {};
+    for (int i = 0; i < 2; i++) {
+        qp.zbin[i] = zbin ? zbin[i] : 0; qp.round[i] = round[i]; qp.quant[i] = quant[i]; qp.quant_shift[i] = shift ? shift[i] : 0; qp.dequant[i] = dequant[i];
+    }
+    qp.log_scale = log_scale; qp.variant = variant;
+    int32_t *d_c = (int32_t*)dev(0, (size_t)n * 4), *d_q = (int32_t*)dev(1, (size_t)n * 4), *d_dq = (int32_t*)dev(3, (size_t)n * 4); int16_t* d_is = (int16_t*)dev(2, (size_t)n * 2);
+    uint16_t* d_eob = (uint16_t*)dev(4, 16);
+    return d_c && d_q && d_dq && d_is && d_eob && up(d_c, coeff, (size_t)n * 4) && up(d_is, iscan, (size_t)n * 2) &&
+           svt_hip_quantize_batch_dev(g_ctx, d_c, (int)n, 1, &qp, d_is, d_q, d_dq, d_eob) == 0 && down(q, d_q, (size_t)n * 4) && down(dq, d_dq, (size_t)n * 4) && down(eob, d_eob, 2);
+}
+void quantize_b_hip(const int32_t* c, intptr_t n, const int16_t* zb, const int16_t* rd, const int16_t* qt, const int16_t* qs, int32_t* q, int32_t* dq, const int16_t* deq,
+                    uint16_t* eob, const int16_t* scan, const int16_t* iscan, const uint8_t* qm, const uint8_t* iqm, const int32_t ls) {
+    Guard lk;
+    if (zb && qs && quant_generic(0, c, n, zb, rd, qt, qs, q, dq, deq, eob, iscan, qm, iqm, ls)) return;
+    FALLBACK("svt_aom_quantize_b", svt_aom_quantize_b, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan, qm, iqm, ls);
+}
+void quantize_b_hbd_hip(const int32_t* c, intptr_t n, const int16_t* zb, const int16_t* rd, const int16_t* qt, const int16_t* qs, int32_t* q, int32_t* dq, const int16_t* deq,
+                        uint16_t* eob, const int16_t* scan, const int16_t* iscan, const uint8_t* qm, const uint8_t* iqm, const int32_t ls) {
+    Guard lk;
+    if (zb && qs && quant_generic(1, c, n, zb, rd, qt, qs, q, dq, deq, eob, iscan, qm, iqm, ls)) return;
+    FALLBACK("svt_aom_highbd_quantize_b", svt_aom_highbd_quantize_b, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan, qm, iqm, ls);
+}
+template <int LS> void quantize_fp_hip(const int32_t* c, intptr_t n, const int16_t* zb, const int16_t* rd, const int16_t* qt, const int16_t* qs, int32_t* q, int32_t* dq,
+                                       const int16_t* deq, uint16_t* eob, const int16_t* scan, const int16_t* iscan) {
+    Guard lk;
+    if (quant_generic(2, c, n, zb, rd, qt, qs, q, dq, deq, eob, iscan, nullptr, nullptr, LS)) return;
+    if (LS == 0) FALLBACK("svt_av1_quantize_fp", svt_av1_quantize_fp, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan);
+    if (LS == 1) FALLBACK("svt_av1_quantize_fp_32x32", svt_av1_quantize_fp_32x32, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan);
+    FALLBACK("svt_av1_quantize_fp_64x64", svt_av1_quantize_fp_64x64, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan);
+}
+void quantize_fp_hbd_hip(const int32_t* c, intptr_t n, const int16_t* zb, const int16_t* rd, const int16_t* qt, const int16_t* qs, int32_t* q, int32_t* dq, const int16_t* deq,
+                         uint16_t* eob, const int16_t* scan, const int16_t* iscan, int16_t ls) {
+    Guard lk;
+    if (quant_generic(3, c, n, zb, rd, qt, qs, q, dq, deq, eob, iscan, nullptr, nullptr, ls)) return;
+    FALLBACK("svt_av1_highbd_quantize_fp", svt_av1_highbd_quantize_fp, c, n, zb, rd, qt, qs, q, dq, deq, eob, scan, iscan, ls);
+}
+
+// ----------------------------------------------------------------------------------- deblocking: one 4-sample edge segment
+constexpr int kLpfLen[4] = {4, 6, 8, 14};
+bool lpf_generic(int pb, int bd, void* s, int pitch, bool vertical_edge, int len, const uint8_t* blimit, const uint8_t* limit, const uint8_t* thresh) {
+    if (!g_ctx || !s || !blimit || !limit || !thresh || (bd != 8 && bd != 10)) return false;
+    const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+    const int rw = vertical_edge ? 2 * half : 4, rh = vertical_edge ? 4 : 2 * half;      // exactly the samples the C function reads
+    const size_t p = rup((size_t)rw * pb, 4);
+    uint8_t* d = (uint8_t*)dev(0, p * rh + 64); void* d_job = dev(2, sizeof(SvtHipLpfEdge));
+    uint8_t* origin = (uint8_t*)s - (vertical_edge ? (size_t)half : (size_t)half * pitch) * pb;
+    SvtHipLpfEdge e = {};
+    e.off = vertical_edge ? half : half * (int)(p / pb);
+    e.dir = vertical_edge ? 0 : 1; e.len = (uint8_t)len; e.blimit = *blimit; e.limit = *limit; e.thresh = *thresh;
+    return d && d_job && up2d(d, p, origin, (size_t)pitch * pb, (size_t)rw * pb, rh) && up(d_job, &e, sizeof(e)) &&
+           svt_hip_lpf_edges_batch_dev(g_ctx, pb, bd, d, (int)(p / pb), (const SvtHipLpfEdge*)d_job, 1) == 0 && down2d(origin, (size_t)pitch * pb, d, p, (size_t)rw * pb, rh);
+}
+template <int V, int LI> void lpf_hip(uint8_t* s, int32_t pitch, const uint8_t* bl, const uint8_t* l, const uint8_t* t) {
+    Guard lk;
+    if (lpf_generic(1, 8, s, pitch, V, kLpfLen[LI], bl, l, t)) return;
+    if (V) FALLBACK("svt_aom_lpf_vertical_N", svt_aom_lpf_vertical[LI], s, pitch, bl, l, t);
+    FALLBACK("svt_aom_lpf_horizontal_N", svt_aom_lpf_horizontal[LI], s, pitch, bl, l, t);
+}
+template <int V, int LI> void lpf_hbd_hip(uint16_t* s, int32_t pitch, const uint8_t* bl, const uint8_t* l, const uint8_t* t, int32_t bd) {
+    Guard lk;
+    if (lpf_generic(2, bd, s, pitch, V, kLpfLen[LI], bl, l, t)) return;
+    if (V) FALLBACK("svt_aom_highbd_lpf_vertical_N", svt_aom_highbd_lpf_vertical[LI], s, pitch, bl, l, t, bd);
+    FALLBACK("svt_aom_highbd_lpf_horizontal_N", svt_aom_highbd_lpf_horizontal[LI], s, pitch, bl, l, t, bd);
+}
+
+// ----------------------------------------------------------------------------------- CDEF: one block
+int32_t cdef_find_dir_hip(const uint16_t* img, int32_t stride, int32_t* var, int32_t coeff_shift) {
+    Guard lk;
+    if (g_ctx && coeff_shift >= 0 && coeff_shift <= 4) {
+        uint16_t* d_img = (uint16_t*)dev(0, 8 * 8 * 2); int32_t* d_off = (int32_t*)dev(2, 16); int32_t* d_out = (int32_t*)dev(3, 16);
+        const int32_t zero = 0; int32_t res[2];
+        if (d_img && d_off && d_out && up2d(d_img, 16, img, (size_t)stride * 2, 16, 8) && up(d_off, &zero, 4) &&
+            svt_hip_cdef_find_dir_batch_dev(g_ctx, d_img, 8, d_off, 1, coeff_shift, d_out, d_out + 1) == 0 && down(res, d_out, 8)) {
+            *var = res[1];
+            return res[0];
+        }
+    }
+    FALLBACK("svt_cdef_find_dir", svt_cdef_find_dir, img, stride, var, coeff_shift);
+}
+void cdef_filter_block_hip(uint8_t* dst8, uint16_t* dst16, int32_t dstride, const uint16_t* in, int32_t pri, int32_t sec, int32_t dir, int32_t pdamp, int32_t sdamp, int32_t bsize,
+                           int32_t cs) {
+    Guard lk;
+    // BLOCK_4X4 0, BLOCK_4X8 1, BLOCK_8X4 2, BLOCK_8X8 3 (EbCdef.c:211-212); the staging image has stride CDEF_BSTRIDE = 144 (EbCdef.h:35) and the taps reach 2 samples out
+    if (g_ctx && bsize >= 0 && bsize <= 3 && dir >= 0 && dir < 8 && (dst8 || dst16)) {
+        const int bw = (bsize == 3 || bsize == 2) ? 8 : 4, bh = (bsize == 3 || bsize == 1) ? 8 : 4, pb = dst8 ? 1 : 2;
+        const int iw = bw + 4, ih = bh + 4, ip = 12;
+        uint16_t* d_in = (uint16_t*)dev(0, (size_t)ip * ih * 2); void* d_job = dev(2, sizeof(SvtHipCdefBlk)); uint8_t* d_dst = (uint8_t*)dev(1, 8 * 8 * 2);
+        const SvtHipCdefBlk job = {2 * ip + 2, 0, pri, sec, dir, pdamp, sdamp, bw == 8 ? 3 : 2, bh == 8 ? 3 : 2, cs};
+        if (d_in && d_job && d_dst && up2d(d_in, (size_t)ip * 2, in - 2 * 144 - 2, 144 * 2, (size_t)iw * 2, ih) && up(d_job, &job, sizeof(job)) &&
+            svt_hip_cdef_filter_block_batch_dev(g_ctx, d_in, ip, (const SvtHipCdefBlk*)d_job, 1, dst8 ? d_dst : nullptr, dst8 ? nullptr : (uint16_t*)d_dst, 8) == 0 &&
+            down2d(dst8 ? (void*)dst8 : (void*)dst16, (size_t)dstride * pb, d_dst, (size_t)8 * pb, (size_t)bw * pb, bh))
+            return;
+    }
+    FALLBACK("svt_cdef_filter_block", svt_cdef_filter_block, dst8, dst16, dstride, in, pri, sec, dir, pdamp, sdamp, bsize, cs);
+}
+
+// ----------------------------------------------------------------------------------- residual, 4-reference SAD, OBMC sub-pel prediction, variance intermediates
+bool residual_generic(int pb, const void* in, uint32_t is, const void* pred, uint32_t ps, int16_t* res, uint32_t rs, uint32_t w, uint32_t h) {
+    if (!g_ctx || !w || !h || w > 128 || h > 128) return false;
+    const size_t p = rup((size_t)w * pb, 4), rp = rup((size_t)w * 2, 4);
+    uint8_t *d_a = (uint8_t*)dev(0, p * h), *d_b = (uint8_t*)dev(1, p * h); int16_t* d_r = (int16_t*)dev(3, rp * h);
+    return d_a && d_b && d_r && up2d(d_a, p, in, (size_t)is * pb, (size_t)w * pb, h) && up2d(d_b, p, pred, (size_t)ps * pb, (size_t)w * pb, h) &&
+           svt_hip_residual_dev(g_ctx, pb, d_a, (int)(p / pb), d_b, (int)(p / pb), d_r, (int)(rp / 2), (int)w, (int)h) == 0 && down2d(res, (size_t)rs * 2, d_r, rp, (size_t)w * 2, h);
+}
+void residual8_hip(uint8_t* in, uint32_t is, uint8_t* pred, uint32_t ps, int16_t* res, uint32_t rs, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (residual_generic(1, in, is, pred, ps, res, rs, w, h)) return;
+    FALLBACK("svt_residual_kernel8bit", svt_residual_kernel8bit, in, is, pred, ps, res, rs, w, h);
+}
+void residual16_hip(uint16_t* in, uint32_t is, uint16_t* pred, uint32_t ps, int16_t* res, uint32_t rs, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (residual_generic(2, in, is, pred, ps, res, rs, w, h)) return;
+    FALLBACK("svt_residual_kernel16bit", svt_residual_kernel16bit, in, is, pred, ps, res, rs, w, h);
+}
+template <int IDX, int W, int H> void sadx4d_hip(const uint8_t* src, int ss, const uint8_t* const ref[], int rs, uint32_t* out) {
+    Guard lk;
+    if (g_ctx) {
+        const size_t p = rup((size_t)W, 4);
+        uint8_t *d_a = (uint8_t*)dev(0, p * H + 64), *d_b = (uint8_t*)dev(1, p * H * 4 + 64); SvtHipBlkPair* d_j = (SvtHipBlkPair*)dev(2, 4 * sizeof(SvtHipBlkPair)); uint32_t* d_o = (uint32_t*)dev(3, 16);
+        SvtHipBlkPair jobs[4];
+        bool ok = d_a && d_b && d_j && d_o && up2d(d_a, p, src, (size_t)ss, W, H);
+        for (int k = 0; k < 4 && ok; k++) {
+            jobs[k] = SvtHipBlkPair{0, 0, 0, k * H, (uint16_t)W, (uint16_t)H};
+            ok = up2d(d_b + (size_t)k * H * p, p, ref[k], (size_t)rs, W, H);
+        }
+        if (ok && up(d_j, jobs, sizeof(jobs)) && svt_hip_block_sad_batch_dev(g_ctx, 1, d_a, (int)p, d_b, (int)p, d_j, 4, d_o) == 0 && down(out, d_o, 16)) return;
+    }
+    FALLBACK("svt_aom_sadWxHx4d", svt_aom_sadx4d[IDX], src, ss, ref, rs, out);
+}
+void upsampled_pred_hip(void* xd, const void* cm, int mi_row, int mi_col, const void* mv, uint8_t* comp_pred, int w, int h, int sx, int sy, const uint8_t* ref, int rs, int search) {
+    Guard lk;
+    // USE_2_TAPS 1 -> bilinear, USE_4_TAPS 2 -> the 4-tap regular family, USE_8_TAPS 3 -> 8-tap regular (EbDefinitions.h:487-490, variance.c:200-209)
+    const int bank = search == 1 ? 3 : (search == 2 ? 4 : (search == 3 ? 0 : -1));
+    if (g_ctx && bank >= 0 && w > 0 && h > 0 && w <= 128 && h <= 128 && sx >= 0 && sx < 8 && sy >= 0 && sy < 8) {
+        // only the window the C function reads is staged: 3 samples before and 4 after in each direction that is interpolated
+        const int x0 = sx ? 3 : 0, x1 = sx ? 4 : 0, y0 = sy ? 3 : 0, y1 = sy ? 4 : 0, rw = w + x0 + x1, rh = h + y0 + y1;
+        const size_t p = rup((size_t)rw, 4);
+        uint8_t *d_ref = (uint8_t*)dev(0, p * rh + 64), *d_dst = (uint8_t*)dev(1, (size_t)w * h + 64); void* d_job = dev(2, sizeof(SvtHipUpsampledBlk));
+        SvtHipUpsampledBlk job = {};
+        job.ref_off = (int32_t)(y0 * p + x0); job.w = (uint8_t)w; job.h = (uint8_t)h; job.subpel_x_q3 = (uint8_t)sx; job.subpel_y_q3 = (uint8_t)sy; job.bank = (uint8_t)bank;
+        if (d_ref && d_dst && d_job && up2d(d_ref, p, ref - (ptrdiff_t)y0 * rs - x0, (size_t)rs, rw, rh) && up(d_job, &job, sizeof(job)) &&
+            svt_hip_upsampled_pred_batch_dev(g_ctx, d_ref, (int)p, d_dst, (const SvtHipUpsampledBlk*)d_job, 1) == 0 && down(comp_pred, d_dst, (size_t)w * h))
+            return;
+    }
+    FALLBACK("svt_aom_upsampled_pred", svt_aom_upsampled_pred, xd, cm, mi_row, mi_col, mv, comp_pred, w, h, sx, sy, ref, rs, search);
+}
+void interm_var_hip(uint8_t* in, uint16_t stride, uint64_t* mean, uint64_t* mean_sq) {
+    Guard lk;
+    if (g_ctx) {
+        uint8_t* d_in = (uint8_t*)dev(0, 32 * 8); int32_t* d_off = (int32_t*)dev(2, 16); uint64_t* d_o = (uint64_t*)dev(3, 64);
+        const int32_t zero = 0;
+        uint64_t res[8];
+        if (d_in && d_off && d_o && up2d(d_in, 32, in, stride, 32, 7) && up(d_off, &zero, 4) && svt_hip_interm_var_four8x8_batch_dev(g_ctx, d_in, 32, d_off, 1, d_o, d_o + 4) == 0 &&
+            down(res, d_o, 64)) {
+            std::memcpy(mean, res, 32); std::memcpy(mean_sq, res + 4, 32);
+            return;
+        }
+    }
+    FALLBACK("svt_compute_interm_var_four8x8", svt_compute_interm_var_four8x8, in, stride, mean, mean_sq);
+}
+template <int SLOT, int TS> uint64_t handle_transform_hip(int32_t* output) {
+    Guard lk;
+    if (g_ctx) {
+        const size_t n = (size_t)kTxW[TS] * kTxH[TS];
+        int32_t* d_c = (int32_t*)dev(0, n * 4); uint64_t* d_e = (uint64_t*)dev(3, 16);
+        uint64_t e;
+        if (d_c && d_e && up(d_c, output, n * 4) && svt_hip_handle_transform64_batch_dev(g_ctx, TS, d_c, 1, d_e) == 0 && down(output, d_c, n * 4) && down(&e, d_e, 8)) return e;
+    }
+    FALLBACK("svt_handle_transform64xN", svt_handle_transform64[SLOT], output);
+}
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -472,5 +692,23 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
 #define X(I, TS, W, H) t->svt_av1_fwd_txfm2d_N2[I] = fwd_n2_hip<I, TS>; t->svt_av1_fwd_txfm2d_N4[I] = fwd_n4_hip<I, TS>;
     SVT_HIP_RTCD_FWD_SIZES(X)
 #undef X
+    t->svt_ext_all_sad_calculation_8x8_16x16 = ext_all_sad_hip; t->svt_ext_eight_sad_calculation_32x32_64x64 = ext_eight_sad_hip;
+    t->svt_aom_quantize_b = quantize_b_hip; t->svt_aom_highbd_quantize_b = quantize_b_hbd_hip;
+    t->svt_av1_quantize_fp = quantize_fp_hip<0>; t->svt_av1_quantize_fp_32x32 = quantize_fp_hip<1>; t->svt_av1_quantize_fp_64x64 = quantize_fp_hip<2>;
+    t->svt_av1_highbd_quantize_fp = quantize_fp_hbd_hip;
+#define X(LI) t->svt_aom_lpf_horizontal[LI] = lpf_hip<0, LI>; t->svt_aom_lpf_vertical[LI] = lpf_hip<1, LI>; \
+              t->svt_aom_highbd_lpf_horizontal[LI] = lpf_hbd_hip<0, LI>; t->svt_aom_highbd_lpf_vertical[LI] = lpf_hbd_hip<1, LI>;
+    X(0) X(1) X(2) X(3)
+#undef X
+    t->svt_cdef_find_dir = cdef_find_dir_hip; t->svt_cdef_filter_block = cdef_filter_block_hip;
+    t->svt_residual_kernel8bit = residual8_hip; t->svt_residual_kernel16bit = residual16_hip;
+#define X(I, W, H) t->svt_aom_sadx4d[I] = sadx4d_hip<I, W, H>;
+    SVT_HIP_RTCD_BLOCK_SIZES(X)
+#undef X
+    t->svt_aom_upsampled_pred = upsampled_pred_hip;
+    t->svt_compute_interm_var_four8x8 = interm_var_hip;
+    t->svt_handle_transform64[0] = handle_transform_hip<0, 17>; t->svt_handle_transform64[1] = handle_transform_hip<1, 11>; t->svt_handle_transform64[2] = handle_transform_hip<2, 18>;
+    t->svt_handle_transform64[3] = handle_transform_hip<3, 12>; t->svt_handle_transform64[4] = handle_transform_hip<4, 4>;
+    t->svt_av1_inv_txfm_add = inv_txfm_add_hip;
     return SVT_HIP_OK;
 }

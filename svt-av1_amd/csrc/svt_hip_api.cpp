@@ -815,4 +815,85 @@ int svt_hip_generate_padding_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int
     return SVT_HIP_OK;
 }
 
+
+/* ------------------------------------------------------------------ per-call forms (percall.hip, cdef.hip, deblock.hip) */
+int svt_hip_quantize_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, int n_coeffs, int nblk, const SvtHipQuantParams* qp, const int16_t* d_iscan,
+                               int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_coeff || !qp || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob || n_coeffs <= 0 || n_coeffs > 4096 || nblk < 0 || qp->variant < 0 || qp->variant > 3 ||
+        qp->log_scale < 0 || qp->log_scale > 2)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_quantize_blocks(c->stream, d_coeff, n_coeffs, nblk, qp, d_iscan, d_qcoeff, d_dqcoeff, d_eob);
+    if (e != hipSuccess) return fail(c, e, "quantize launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_residual_dev(SvtHipCtx* c, int pix_bytes, const void* d_src, int src_stride, const void* d_pred, int pred_stride, int16_t* d_residual,
+                         int residual_stride, int w, int h) {
+    SVT_HIP_ENTER(c);
+    if (!c || (pix_bytes != 1 && pix_bytes != 2) || w < 0 || h < 0) return SVT_HIP_ERR_BAD_ARG;
+    if (w == 0 || h == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_residual) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_residual(c->stream, pix_bytes, d_src, src_stride, d_pred, pred_stride, d_residual, residual_stride, w, h);
+    if (e != hipSuccess) return fail(c, e, "residual launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_ext_all_sad_8x8_16x16_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, const uint8_t* d_ref, int ref_stride,
+                                            const SvtHipExtSadJob* d_jobs, int n, uint32_t* d_state) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_ref || !d_jobs || !d_state || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_ext_all_sad(c->stream, d_src, src_stride, d_ref, ref_stride, d_jobs, n, d_state);
+    if (e != hipSuccess) return fail(c, e, "ext all sad launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_ext_eight_sad_32x32_64x64_batch_dev(SvtHipCtx* c, const uint32_t* d_mv, int n, uint32_t* d_state) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mv || !d_state || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_ext_eight_sad_32_64(c->stream, d_mv, n, d_state);
+    if (e != hipSuccess) return fail(c, e, "ext eight sad launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_interm_var_four8x8_batch_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, const int32_t* d_offs, int n, uint64_t* d_mean, uint64_t* d_mean_sq) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_plane || !d_offs || !d_mean || !d_mean_sq || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_interm_var(c->stream, d_plane, stride, d_offs, n, d_mean, d_mean_sq);
+    if (e != hipSuccess) return fail(c, e, "interm var launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_handle_transform64_batch_dev(SvtHipCtx* c, int tx_size, int32_t* d_coeff, int nblk, uint64_t* d_energy) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_coeff || !d_energy || nblk < 0 || (tx_size != 4 && tx_size != 11 && tx_size != 12 && tx_size != 17 && tx_size != 18)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_handle_transform64(c->stream, tx_size, d_coeff, nblk, d_energy);
+    if (e != hipSuccess) return fail(c, e, "handle transform64 launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_upsampled_pred_batch_dev(SvtHipCtx* c, const uint8_t* d_ref, int ref_stride, uint8_t* d_dst, const SvtHipUpsampledBlk* d_blks, int n) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_ref || !d_dst || !d_blks || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_upsampled_pred(c->stream, d_ref, ref_stride, d_dst, d_blks, n);
+    if (e != hipSuccess) return fail(c, e, "upsampled pred launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_find_dir_batch_dev(SvtHipCtx* c, const uint16_t* d_img, int stride, const int32_t* d_offs, int n, int coeff_shift, int32_t* d_dir, int32_t* d_var) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_img || !d_offs || !d_dir || !d_var || n < 0 || coeff_shift < 0 || coeff_shift > 4) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_find_dir_list(c->stream, d_img, d_offs, n, stride, coeff_shift, d_dir, d_var);
+    if (e != hipSuccess) return fail(c, e, "cdef find dir launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_filter_block_batch_dev(SvtHipCtx* c, const uint16_t* d_in, int in_stride, const SvtHipCdefBlk* d_blks, int n, uint8_t* d_dst8, uint16_t* d_dst16,
+                                        int dst_stride) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_in || !d_blks || n < 0 || (!d_dst8) == (!d_dst16)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_filter_block_list(c->stream, d_in, in_stride, d_blks, n, d_dst8, d_dst16, dst_stride);
+    if (e != hipSuccess) return fail(c, e, "cdef filter block launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_lpf_edges_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, void* d_plane, int stride, const SvtHipLpfEdge* d_edges, int n) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_plane || !d_edges || n < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_lpf_edge_list(c->stream, d_plane, pix_bytes, stride, bd, d_edges, n);
+    if (e != hipSuccess) return fail(c, e, "lpf edges launch");
+    return SVT_HIP_OK;
+}
+
 }  // extern "C"

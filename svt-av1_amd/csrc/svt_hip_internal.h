@@ -81,4 +81,16 @@ int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const
 int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph,
                              int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride, const uint8_t* unit_ep,
                              const int32_t* unit_xqd, const int16_t* unit_wiener);
+/* per-call forms (percall.hip, cdef.hip, deblock.hip) */
+int svt_hip_launch_quantize_blocks(hipStream_t st, const int32_t* coeff, int n, int nblk, const SvtHipQuantParams* qp, const int16_t* iscan, int32_t* qcoeff,
+                                   int32_t* dqcoeff, uint16_t* eob);
+int svt_hip_launch_residual(hipStream_t st, int pix_bytes, const void* src, int ss, const void* pred, int ps, int16_t* res, int rs, int w, int h);
+int svt_hip_launch_ext_all_sad(hipStream_t st, const uint8_t* src, int ss, const uint8_t* ref, int rs, const void* jobs, int n, uint32_t* state);
+int svt_hip_launch_ext_eight_sad_32_64(hipStream_t st, const uint32_t* mvs, int n, uint32_t* state);
+int svt_hip_launch_interm_var(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, uint64_t* mean, uint64_t* mean_sq);
+int svt_hip_launch_handle_transform64(hipStream_t st, int tx_size, int32_t* coeff, int nblk, uint64_t* energy);
+int svt_hip_launch_upsampled_pred(hipStream_t st, const uint8_t* ref, int rs, uint8_t* dst, const void* blks, int n);
+int svt_hip_launch_cdef_find_dir_list(hipStream_t st, const uint16_t* img, const int32_t* offs, int n, int stride, int coeff_shift, int32_t* dir_out, int32_t* var_out);
+int svt_hip_launch_cdef_filter_block_list(hipStream_t st, const uint16_t* in, int istride, const void* jobs, int n, uint8_t* dst8, uint16_t* dst16, int dstride);
+int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n);
 }

@@ -121,3 +121,23 @@ def test_per_call_wrappers_in_a_real_encode_on_gpu(workdir):
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"]
     assert "delegated to the installed C pointer" not in got["log"], got["log"][-1500:]
+
+
+@pytest.mark.gpu
+def test_block_level_wrappers_in_a_real_encode_on_gpu(workdir):
+    """The block-level pointers (residual, quantizers, inverse transform + add, the 16 loop filters, CDEF direction / block filter, the 8-candidate
+    SAD ladders, variance intermediates) behind SVT_HIP_RTCD on a small clip: the mode-decision and encode loops call them hundreds of thousands of
+    times, each call a launch of its own.  Bitstream and reconstruction must not change."""
+    w, h, n, bd, preset, q = 176, 144, 2, 8, 6, 32
+    clip = os.path.join(workdir, "qcif.yuv")
+    E.make_clip(clip, w, h, n, seed=5, bd=bd)
+    lpf = ",".join(f"svt_aom_lpf_{d}_{k}" for d in ("horizontal", "vertical") for k in (4, 6, 8, 14))
+    names = ("svt_residual_kernel8bit,svt_aom_quantize_b,svt_av1_quantize_fp,svt_av1_quantize_fp_32x32,svt_av1_quantize_fp_64x64,svt_av1_inv_txfm_add,"
+             "svt_cdef_find_dir,svt_cdef_filter_block,svt_ext_all_sad_calculation_8x8_16x16,svt_ext_eight_sad_calculation_32x32_64x64,"
+             "svt_compute_interm_var_four8x8,svt_handle_transform64x64," + lpf)
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif.ref"))
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1500)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    for nme in names.split(","):
+        assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
+    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))

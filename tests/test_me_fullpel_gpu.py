@@ -136,3 +136,26 @@ def test_search_area_above_65536_candidates(hip, orc, sub):
     o_sad, o_mv = mc.oracle_frame(orc, cur_p, ref_p, stride, pad, sbs, sub)
     g_sad, g_mv = mc.hip_frame(hip, cur_p, ref_p, stride, pad, sbs, sub)
     assert np.array_equal(g_sad, o_sad) and np.array_equal(g_mv, o_mv)
+
+
+def test_256x256_search_area_on_a_4k_frame(hip, orc):
+    """SURVEY 8(c) row B6 at the reference's high-resolution search area: 3840 x 2160, 256 x 256 window (65 536 candidates, the largest the packed-key
+    instance takes), SBs in the picture corners (clamped windows), on the edges and in the interior, a non-zero HME centre on some.  The oracle
+    runs only the chosen SBs (a whole 4K frame at this area is minutes of scalar C)."""
+    w, h = 3840, 2160
+    cur, refp = mc.synth.make_luma_pair(w, h, seed=31)
+    pad = mc.synth.PAD
+    cur_p, ref_p = mc.synth.pad_plane(cur), mc.synth.pad_plane(refp)
+    stride = cur_p.shape[1]
+    cols, rows = (w + 63) // 64, (h + 63) // 64
+    n = cols * rows
+    centers = [(0, 0)] * n
+    pick = [0, cols - 1, (rows - 1) * cols, n - 1, 5 * cols, 7 * cols + 23, 16 * cols + 30, rows // 2 * cols + cols - 1, 20 * cols + 31]
+    for k, i in enumerate(pick[5:]):
+        centers[i] = ((-37, 22), (64, -40), (15, 9), (-120, 80))[k]
+    allw = mc.windows(orc, w, h, 256, 256, centers)
+    sbs = (type(allw[0]) * len(pick))(*[allw[i] for i in pick])
+    assert max(s.width * s.height for s in sbs) == 65536
+    o_sad, o_mv = mc.oracle_frame(orc, cur_p, ref_p, stride, pad, sbs, 0)
+    g_sad, g_mv = mc.hip_frame(hip, cur_p, ref_p, stride, pad, sbs, 0)
+    assert np.array_equal(g_sad, o_sad) and np.array_equal(g_mv, o_mv)

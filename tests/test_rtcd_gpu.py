@@ -58,6 +58,29 @@ WARPH = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_in
 STATS = C.CFUNCTYPE(None, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP)
 STATSH = C.CFUNCTYPE(None, C.c_int32, VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, VP, VP, C.c_int32)
 
+EXTALL = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_uint8)
+EXT8 = C.CFUNCTYPE(None, VP, VP, VP, VP, VP, C.c_uint32, VP)
+QB = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int32)
+QFP = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP)
+QFPH = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int16)
+LPF = C.CFUNCTYPE(None, VP, C.c_int32, VP, VP, VP)
+LPFH = C.CFUNCTYPE(None, VP, C.c_int32, VP, VP, VP, C.c_int32)
+CDIR = C.CFUNCTYPE(C.c_int32, VP, C.c_int32, VP, C.c_int32)
+CFB = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
+RESID = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+SADX4 = C.CFUNCTYPE(None, VP, C.c_int, VP, C.c_int, VP)
+UPS = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int)
+IVAR = C.CFUNCTYPE(None, VP, C.c_uint16, VP, VP)
+HT64 = C.CFUNCTYPE(C.c_uint64, VP)
+
+
+class TxfmParam(C.Structure):   # EbDefinitions.h:779-791 (one-byte enums)
+    _fields_ = [("tx_type", C.c_uint8), ("tx_size", C.c_uint8), ("lossless", C.c_int32), ("bd", C.c_int32), ("is_hbd", C.c_int32), ("tx_set_type", C.c_uint8),
+                ("eob", C.c_int32)]
+
+
+INVADD = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.POINTER(TxfmParam))
+
 
 class Rtcd(C.Structure):
     _fields_ = [("svt_sad_loop_kernel", SADLOOP), ("svt_nxm_sad_kernel", NXM), ("svt_aom_sad", SADWH * 22), ("svt_aom_variance", VARWH * 22),
@@ -71,7 +94,14 @@ class Rtcd(C.Structure):
                 ("svt_aom_blend_a64_mask", BLM), ("svt_aom_blend_a64_hmask", BLHV), ("svt_aom_blend_a64_vmask", BLHV),
                 ("svt_aom_highbd_blend_a64_mask", BLMH), ("svt_aom_highbd_blend_a64_hmask_8bit", BLHVH), ("svt_aom_highbd_blend_a64_vmask_8bit", BLHVH),
                 ("svt_av1_warp_affine", WARP), ("svt_av1_highbd_warp_affine", WARPH), ("svt_av1_compute_stats", STATS), ("svt_av1_compute_stats_highbd", STATSH),
-                ("svt_av1_fwd_txfm2d_N2", FWDF * 14), ("svt_av1_fwd_txfm2d_N4", FWDF * 14)]
+                ("svt_av1_fwd_txfm2d_N2", FWDF * 14), ("svt_av1_fwd_txfm2d_N4", FWDF * 14),
+                ("svt_ext_all_sad_calculation_8x8_16x16", EXTALL), ("svt_ext_eight_sad_calculation_32x32_64x64", EXT8),
+                ("svt_aom_quantize_b", QB), ("svt_aom_highbd_quantize_b", QB), ("svt_av1_quantize_fp", QFP), ("svt_av1_quantize_fp_32x32", QFP),
+                ("svt_av1_quantize_fp_64x64", QFP), ("svt_av1_highbd_quantize_fp", QFPH),
+                ("svt_aom_lpf_horizontal", LPF * 4), ("svt_aom_lpf_vertical", LPF * 4), ("svt_aom_highbd_lpf_horizontal", LPFH * 4),
+                ("svt_aom_highbd_lpf_vertical", LPFH * 4), ("svt_cdef_find_dir", CDIR), ("svt_cdef_filter_block", CFB),
+                ("svt_residual_kernel8bit", RESID), ("svt_residual_kernel16bit", RESID), ("svt_aom_sadx4d", SADX4 * 22), ("svt_aom_upsampled_pred", UPS),
+                ("svt_compute_interm_var_four8x8", IVAR), ("svt_handle_transform64", HT64 * 5), ("svt_av1_inv_txfm_add", INVADD)]
 
 
 @pytest.fixture(scope="module")
@@ -303,3 +333,133 @@ def test_next_row_wrappers(rtcd, orc):
             if bd == 8: rtcd.svt_av1_compute_stats(win, dgd.ctypes.data, src.ctypes.data, h0, h1, v0, v1, 140, 140, Mg.ctypes.data, Hg.ctypes.data)
             else: rtcd.svt_av1_compute_stats_highbd(win, dgd.ctypes.data >> 1, src.ctypes.data >> 1, h0, h1, v0, v1, 140, 140, Mg.ctypes.data, Hg.ctypes.data, bd)
             assert np.array_equal(Mg, Me) and np.array_equal(Hg, He), (bd, win)
+
+
+def _vp(a, off=0):
+    return C.c_void_p(a.ctypes.data + off)
+
+
+def test_per_call_forms_vs_reference_c(rtcd, ref):
+    """The pointers that only existed fused inside the frame kernels (SAD ladders, quantizers, the 16 loop filters, CDEF direction / block filter,
+    residual, 4-reference SAD, up-sampled prediction, variance intermediates, 64-point re-pack, svt_av1_inv_txfm_add): same arguments to the
+    reference's `*_c` function and to the wrapper in the same slot, identical outputs."""
+    rng = np.random.default_rng(77)
+    # --- svt_ext_all_sad_calculation_8x8_16x16 + svt_ext_eight_sad_calculation_32x32_64x64 (running bests carried across three 8-candidate groups)
+    src = rng.integers(0, 256, (64, 80)).astype(np.uint8)
+    refp = np.clip(np.pad(src[:, :64], ((0, 8), (8, 40)), mode="edge").astype(np.int32) + rng.integers(-6, 7, (72, 112)), 0, 255).astype(np.uint8)
+    for sub in (0, 1):
+        st = [dict(bs8=np.full(64, 0xffffffff, np.uint32), bs16=np.full(16, 0xffffffff, np.uint32), bm8=np.zeros(64, np.uint32), bm16=np.zeros(16, np.uint32),
+                   e16=np.zeros((16, 8), np.uint32), e8=np.zeros((64, 8), np.uint32), bs32=np.full(4, 0xffffffff, np.uint32), bs64=np.full(1, 0xffffffff, np.uint32),
+                   bm32=np.zeros(4, np.uint32), bm64=np.zeros(1, np.uint32), s32=np.zeros((4, 8), np.uint32)) for _ in range(2)]
+        for grp, xoff in enumerate((16, 0, 8)):   # the exact match (offset 8) arrives last, an equal-SAD earlier candidate must keep its vector
+            mv = ((((-3) & 0xffff) << 16) | ((4 * (xoff - 8)) & 0xffff))
+            for d, fa, fe in ((st[0], ref.svt_ext_all_sad_calculation_8x8_16x16_c, ref.svt_ext_eight_sad_calculation_32x32_64x64_c),
+                              (st[1], rtcd.svt_ext_all_sad_calculation_8x8_16x16, rtcd.svt_ext_eight_sad_calculation_32x32_64x64)):
+                fa(_vp(src), 80, _vp(refp, xoff), 112, mv, _vp(d["bs8"]), _vp(d["bs16"]), _vp(d["bm8"]), _vp(d["bm16"]), _vp(d["e16"]), _vp(d["e8"]), sub)
+                fe(_vp(d["e16"]), _vp(d["bs32"]), _vp(d["bs64"]), _vp(d["bm32"]), _vp(d["bm64"]), mv, _vp(d["s32"]))
+            for k in st[0]:
+                assert np.array_equal(st[0][k], st[1][k]), ("ext sad", sub, grp, k)
+        assert st[0]["bs64"][0] < 64 * 64 * 7
+    # --- quantizers: every variant, the three log scales, a random scan
+    for n, ls in ((16, 0), (64, 0), (256, 0), (1024, 1), (1024, 2), (512, 1)):
+        scan = rng.permutation(n).astype(np.int16); iscan = np.zeros(n, np.int16); iscan[scan] = np.arange(n, dtype=np.int16)
+        coeff = (rng.integers(-3000, 3000, n) * (rng.random(n) < 0.4)).astype(np.int32)
+        coeff[rng.integers(0, n, 3)] = (40000, -40000, 32767)     # the int16 clamp of the 8-bit variants
+        zbin = np.array([37, 45], np.int16); rnd = np.array([20, 26], np.int16); quant = np.array([-21846, 18724], np.int16); shift = np.array([64, 128], np.int16)
+        deq = np.array([48, 56], np.int16); rfp = np.array([24, 28], np.int16); qfp = np.array([1365, 1170], np.int16)
+        flat = np.full(n, 32, np.uint8)
+        def run(fn, *extra, fp=False):
+            q = np.full(n, 99, np.int32); dq = np.full(n, 99, np.int32); eob = np.zeros(1, np.uint16)
+            fn(_vp(coeff), n, _vp(zbin), _vp(rfp if fp else rnd), _vp(qfp if fp else quant), _vp(shift), _vp(q), _vp(dq), _vp(deq), _vp(eob), _vp(scan), _vp(iscan), *extra)
+            return q, dq, int(eob[0])
+        cases = [("b", ref.svt_aom_quantize_b_c_ii, rtcd.svt_aom_quantize_b, (None, None, ls), False),
+                 ("b flat qm", ref.svt_aom_quantize_b_c_ii, rtcd.svt_aom_quantize_b, (_vp(flat), _vp(flat), ls), False),
+                 ("b hbd", ref.svt_aom_highbd_quantize_b_c, rtcd.svt_aom_highbd_quantize_b, (None, None, ls), False),
+                 ("fp hbd", ref.svt_av1_highbd_quantize_fp_c, rtcd.svt_av1_highbd_quantize_fp, (ls,), True),
+                 ("fp", (ref.svt_av1_quantize_fp_c, ref.svt_av1_quantize_fp_32x32_c, ref.svt_av1_quantize_fp_64x64_c)[ls],
+                  (rtcd.svt_av1_quantize_fp, rtcd.svt_av1_quantize_fp_32x32, rtcd.svt_av1_quantize_fp_64x64)[ls], (), True)]
+        for name, fr, fh, extra, fp in cases:
+            e = run(fr, *extra, fp=fp); g = run(fh, *extra, fp=fp)
+            assert np.array_equal(e[0], g[0]) and np.array_equal(e[1], g[1]) and e[2] == g[2], (name, n, ls, e[2], g[2])
+    # --- the 16 loop filters: smooth, stepped and noisy neighbourhoods x random thresholds
+    for bd, dt, names in ((8, np.uint8, ("svt_aom_lpf", rtcd.svt_aom_lpf_horizontal, rtcd.svt_aom_lpf_vertical)),
+                          (10, np.uint16, ("svt_aom_highbd_lpf", rtcd.svt_aom_highbd_lpf_horizontal, rtcd.svt_aom_highbd_lpf_vertical))):
+        for li, ln in enumerate((4, 6, 8, 14)):
+            for trial in range(24):
+                base = int(rng.integers(20, (1 << bd) - 20))
+                img = np.full((32, 32), base, np.int32) + rng.integers(-2, 3, (32, 32)) * (trial % 3)
+                img[16:, :] += int(rng.integers(-12, 13)) << (bd - 8); img[:, 16:] += int(rng.integers(-12, 13)) << (bd - 8)
+                if trial % 4 == 3: img = rng.integers(0, 1 << bd, (32, 32))
+                img = np.clip(img, 0, (1 << bd) - 1).astype(dt)
+                bl, lim, th = (np.array([int(v)], np.uint8) for v in (rng.integers(1, 80), rng.integers(1, 20), rng.integers(0, 5)))
+                for vert in (0, 1):
+                    e = img.copy(); g = img.copy()
+                    fr = getattr(ref, f"{names[0]}_{'vertical' if vert else 'horizontal'}_{ln}_c")
+                    fh = (names[2] if vert else names[1])[li]
+                    off = (16 * 32 + 16 + (9 * 32 if vert else 9)) * img.itemsize
+                    extra = (bd,) if bd > 8 else ()
+                    fr(_vp(e, off), 32, _vp(bl), _vp(lim), _vp(th), *extra); fh(_vp(g, off), 32, _vp(bl), _vp(lim), _vp(th), *extra)
+                    assert np.array_equal(e, g), ("lpf", bd, ln, vert, trial)
+    # --- svt_cdef_find_dir / svt_cdef_filter_block on the 144-stride staging image with CDEF_VERY_LARGE borders
+    for cs in (0, 2):
+        stage = np.clip(rng.normal(100 << cs, 30 << cs, (40, 144)), 0, (256 << cs) - 1).astype(np.uint16)
+        stage[:, :6] = 16384; stage[:5, :] = 16384     # the picture edge runs through the blocks' tap footprint
+        for (y, x) in ((8, 8), (5, 6), (20, 40)):
+            ve, vg = C.c_int32(), C.c_int32()
+            off = (y * 144 + x) * 2
+            de = ref.svt_cdef_find_dir_c(_vp(stage, off), 144, C.byref(ve), cs); dg = rtcd.svt_cdef_find_dir(_vp(stage, off), 144, C.byref(vg), cs)
+            assert (de, ve.value) == (dg, vg.value), ("find_dir", cs, y, x)
+            for bsize, (bw, bh) in enumerate(((4, 4), (4, 8), (8, 4), (8, 8))):
+                for (pri, sec, pd, sd) in ((0, 0, 3, 3), (4 << cs, 2 << cs, 6 + cs, 5 + cs), (15 << cs, 4 << cs, 5 + cs, 5 + cs), (0, 1 << cs, 4 + cs, 3 + cs), (7 << cs, 0, 3 + cs, 3 + cs)):
+                    for d8 in ((True, False) if cs == 0 else (False,)):
+                        e = np.zeros((8, 12), np.uint8 if d8 else np.uint16); g = e.copy()
+                        for fn, o in ((ref.svt_cdef_filter_block_c, e), (rtcd.svt_cdef_filter_block, g)):
+                            fn(_vp(o) if d8 else None, None if d8 else _vp(o), 12, _vp(stage, off), pri, sec, de, pd, sd, bsize, cs)
+                        assert np.array_equal(e, g), ("filter_block", cs, y, x, bsize, pri, sec, d8)
+    # --- residual
+    for dt, fr, fh in ((np.uint8, ref.svt_residual_kernel8bit_c, rtcd.svt_residual_kernel8bit), (np.uint16, ref.svt_residual_kernel16bit_c, rtcd.svt_residual_kernel16bit)):
+        a = rng.integers(0, 256 if dt == np.uint8 else 1024, (70, 90)).astype(dt); b = rng.integers(0, 256 if dt == np.uint8 else 1024, (70, 100)).astype(dt)
+        for (w, h) in ((64, 64), (4, 4), (32, 8), (7, 5), (128, 2)):
+            if w > 90: a = rng.integers(0, 255, (4, 140)).astype(dt); b = rng.integers(0, 255, (4, 150)).astype(dt)
+            e = np.zeros((h, w + 3), np.int16); g = e.copy()
+            fr(_vp(a), a.shape[1], _vp(b), b.shape[1], _vp(e), w + 3, w, h); fh(_vp(a), a.shape[1], _vp(b), b.shape[1], _vp(g), w + 3, w, h)
+            assert np.array_equal(e, g), ("residual", dt, w, h)
+    # --- svt_aom_sad{W}x{H}x4d
+    a = rng.integers(0, 256, (140, 150)).astype(np.uint8); b = rng.integers(0, 256, (150, 170)).astype(np.uint8)
+    for i, (w, h) in enumerate(SIZES):
+        offs = [int(v) for v in rng.integers(0, 10 * 170, 4)]
+        arr = (C.c_void_p * 4)(*[b.ctypes.data + o for o in offs])
+        e = np.zeros(4, np.uint32); g = np.zeros(4, np.uint32)
+        getattr(ref, f"svt_aom_sad{w}x{h}x4d_c")(_vp(a), 150, arr, 170, _vp(e)); rtcd.svt_aom_sadx4d[i](_vp(a), 150, arr, 170, _vp(g))
+        assert np.array_equal(e, g), ("x4d", w, h)
+    # --- svt_aom_upsampled_pred: the three tap families, every phase class
+    img = rng.integers(0, 256, (160, 180)).astype(np.uint8)
+    for search in (1, 2, 3):
+        for (w, h, sx, sy) in ((16, 16, 0, 0), (8, 8, 3, 0), (8, 16, 0, 5), (32, 32, 7, 1), (128, 128, 4, 4), (4, 4, 1, 7), (64, 8, 2, 6)):
+            e = np.zeros(w * h, np.uint8); g = e.copy()
+            off = 12 * 180 + 14
+            ref.svt_aom_upsampled_pred_c(None, None, 0, 0, None, _vp(e), w, h, sx, sy, _vp(img, off), 180, search)
+            rtcd.svt_aom_upsampled_pred(None, None, 0, 0, None, _vp(g), w, h, sx, sy, _vp(img, off), 180, search)
+            assert np.array_equal(e, g), ("upsampled_pred", search, w, h, sx, sy)
+    # --- svt_compute_interm_var_four8x8
+    img = rng.integers(0, 256, (16, 80)).astype(np.uint8)
+    for off in (0, 5, 80 * 3 + 17):
+        e = np.zeros(8, np.uint64); g = np.zeros(8, np.uint64)
+        ref.svt_compute_interm_var_four8x8_c(_vp(img, off), 80, _vp(e), _vp(e, 32)); rtcd.svt_compute_interm_var_four8x8(_vp(img, off), 80, _vp(g), _vp(g, 32))
+        assert np.array_equal(e, g), ("interm_var", off)
+    # --- svt_handle_transform64x*: energy and the whole buffer afterwards
+    for slot, (name, n) in enumerate((("16x64", 1024), ("32x64", 2048), ("64x16", 1024), ("64x32", 2048), ("64x64", 4096))):
+        x = rng.integers(-(1 << 20), 1 << 20, n).astype(np.int32)
+        e = x.copy(); g = x.copy()
+        f = getattr(ref, f"svt_handle_transform{name}_c"); f.restype = C.c_uint64
+        assert f(_vp(e)) == rtcd.svt_handle_transform64[slot](_vp(g)) and np.array_equal(e, g), ("handle_transform", name)
+    # --- svt_av1_inv_txfm_add (8-bit destination)
+    for ts in range(19):
+        w, h = tc.TXW[ts], tc.TXH[ts]; kw, kh = min(w, 32), min(h, 32)
+        tt = tc.legal_types(ts)[-1]
+        cfull = np.zeros(w * h, np.int32); cfull[:kw * kh] = (rng.integers(-400, 400, kw * kh) * (rng.random(kw * kh) < 0.3)).astype(np.int32)
+        pred = rng.integers(0, 256, (h, w + 5)).astype(np.uint8)
+        e = np.zeros((h, w + 2), np.uint8); g = e.copy()
+        tp = TxfmParam(tt, ts, 0, 8, 0, 0, kw * kh)
+        ref.svt_av1_inv_txfm_add_c(_vp(cfull), _vp(pred), w + 5, _vp(e), w + 2, C.byref(tp)); rtcd.svt_av1_inv_txfm_add(_vp(cfull), _vp(pred), w + 5, _vp(g), w + 2, C.byref(tp))
+        assert np.array_equal(e, g), ("inv_txfm_add", ts)

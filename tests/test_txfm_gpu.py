@@ -274,3 +274,39 @@ def test_coeff_shape_multi_and_bad_arg(hip, pkg, orc):
     qs = pkg.QuantParams(); qs.coeff_shape = -1
     assert hip.L.svt_hip_fwd_txfm_quant_batch_dev(hip.h, 1, 1, d_src, 64, d_pred, 64, keep[0], 1, C.byref(qs), None, keep[1], None, None, None, None, None) != 0
     hip.free(d_src, d_pred, *keep)
+
+
+@pytest.mark.parametrize("ts", range(19), ids=tc.TX_NAMES)
+def test_inverse_full_range_vs_reference_c(hip, pkg, ref, ts):
+    """The input domain of the reference's own inverse-transform test (test/InvTxfm2dAsmTest.cc:654-675: coefficients = the C forward transform of
+    a residual drawn from the full +-(2^bd - 1) range, re-packed for the 64-point sizes), plus saturated residuals (constant, checkerboard, stripes)
+    and coefficient buffers saturated at the +-2^(bd+8) input clamp, against the reference's C inverse itself.  This is where a 32-bit butterfly sum
+    would leave the reference's 64-bit one (EbInvTransforms.c half_btf) if it ever did."""
+    w, h = tc.TXW[ts], tc.TXH[ts]; kw, kh = min(w, 32), min(h, 32)
+    rng = np.random.default_rng(500 + ts)
+    for bd in (8, 10):
+        top = (1 << bd) - 1
+        yy, xx = np.mgrid[0:h, 0:w]
+        residuals = [rng.integers(-top, top + 1, (h, w)) for _ in range(3)] + [np.full((h, w), top), np.full((h, w), -top), np.where((xx + yy) & 1, top, -top),
+                                                                              np.where(xx & 1, top, -top), np.where(yy & 2, top, -top),
+                                                                              rng.choice([-top, top], (h, w))]
+        lim = (1 << (bd + 8)) - 1
+        for tt in tc.legal_types(ts):
+            blocks = []
+            for r in residuals:
+                co = tc.ref_fwd(ref, np.ascontiguousarray(r.astype(np.int16)), w, tt, ts, bd)
+                if max(w, h) == 64: tc.ref_handle(ref, co, ts)
+                blocks.append(co[:kw * kh].copy())
+            sat = rng.choice([-lim, lim], kw * kh).astype(np.int32); blocks.append(sat)
+            blocks.append(np.full(kw * kh, lim, np.int32)); blocks.append((rng.integers(-lim, lim + 1, kw * kh)).astype(np.int32))
+            one = np.zeros(kw * kh, np.int32); one[0] = lim; blocks.append(one)
+            n = len(blocks)
+            dt = np.uint8 if bd == 8 else np.uint16
+            pred = rng.integers(0, top + 1, (h, w * n)).astype(dt)
+            descs = [pkg.tx_desc(i * w, 0, tt) for i in range(n)]
+            rec = run_inv(hip, ts, bd, np.ascontiguousarray(np.stack(blocks)), pred, descs)
+            for i, co in enumerate(blocks):
+                cfull = np.zeros(w * h, np.int32); cfull[:kw * kh] = co
+                p16 = np.ascontiguousarray(pred[:, i * w:(i + 1) * w].astype(np.uint16)); exp = np.zeros((h, w), np.uint16)
+                tc.ref_inv(ref, cfull, p16, w, exp, w, tt, ts, bd)
+                assert np.array_equal(rec[:, i * w:(i + 1) * w].astype(np.uint16), exp), ("inverse full range", ts, tt, bd, i)
