@@ -463,10 +463,13 @@ def main():
             parity_ok = bool(parity_ok and np.array_equal(r_sad, g_sad) and np.array_equal(r_mv, g_mv))
     walk_stats = None
     if any(k == "sgr_units" for k, _ in stages):   # diagnostics the search leaves at the start of its scratch: passes / points per walk, unfinished walks
-        st3 = [P0.d_scr[p][:96].cpu().numpy().view(np.uint32) for p in range(3)]
+        st3 = [P0.d_scr[p][:128].cpu().numpy().view(np.uint32) for p in range(3)]
         nw = 16 * sum(P0.n_units)
         walk_stats = {"passes_per_walk": float(sum(int(s[0]) for s in st3)) / nw, "points_per_walk": float(sum(int(s[1]) for s in st3)) / nw,
-                      "unfinished": int(sum(int(s[2]) for s in st3)), "passes_histogram": [int(sum(int(s[8 + i]) for s in st3)) for i in range(16)]}
+                      "unfinished": int(sum(int(s[2]) for s in st3)),
+                      # shader cycles per walk and plane as the walking wave sees them: solve, replay, wait for the unit to become resident, evaluation, total
+                      "phase_cycles_per_walk": [{k: round(64.0 * int(s[24 + i]) / (16 * P0.n_units[p])) for i, k in enumerate(("solve", "replay", "load_wait", "evaluate", "total"))}
+                                                | {"passes": round(int(s[0]) / (16 * P0.n_units[p]), 2), "points": round(int(s[1]) / (16 * P0.n_units[p]), 2)} for p, s in enumerate(st3)]}
         parity_ok = bool(parity_ok is not False and walk_stats["unfinished"] == 0)
 
     # ---- CPU baseline: the reference's own kernels over the same job lists (or the oracle port), all hardware threads and one thread

@@ -23,11 +23,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "svt_hip_internal.h"
 
 namespace {
 
-constexpr int kMaxCand = 10;     // points evaluated per pass
+constexpr int kStreamCand = 10;  // the streamed form keeps one accumulator per candidate in registers
+constexpr int kMaxCand = 16;     // capacity of the per-pass candidate list (the launch's `cap` <= this is the number actually used)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
 
@@ -40,7 +42,7 @@ struct WalkLds {
     int       n_cache;
     int       wx[kMaxCand], wy[kMaxCand], n_want;
     int       xq0[kMaxCand], xq1[kMaxCand];
-    long long part[4][kMaxCand];        // per-wave partial sums
+    long long part[16][kMaxCand];       // per-wave partial sums
     int       done, res_x, res_y;
     long long res_err;
     int       last;
@@ -74,16 +76,12 @@ __device__ void solve_and_encode(const long long* sums, int size, int ep, int xq
 // finer_search_pixel_proj_error replayed on the cache.  Returns true when the walk finished on exact errors only.
 // Executed by ALL 64 lanes of wave 0 with identical values (uniform control flow): the scalar walk logic runs as before, but the two
 // searches it performs over and over — "is this point in the cache?", "is it already wanted?" — compare 64 entries at a time across the
-// lanes (one LDS read per lane + a ballot) instead of looping over them.  Parameter-set constants are arithmetic (no table loads).
-__device__ bool replay(WalkLds& L, int ep, const int start[2], const long long* sums, int lane) {
-    const bool   has0 = ep < 10 || ep >= 14, has1 = ep < 14;
-    const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
-    auto model = [&](int x, int y) {
-        const double a = has0 ? x : 0, b = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
-        return a * a * H00 + 2 * a * b * H01 + b * b * H11 - 256.0 * (a * C0 + b * C1);
-    };
-    const int n_cache = L.n_cache;
-    auto lookup = [&](int x, int y, long long& e) {
+// lanes (a ballot) instead of looping over them.  Parameter-set constants are arithmetic (no table loads).  The store of evaluated and wanted
+// points is a policy: LdsStore keeps them in the workgroup's LDS (streamed form), RegStore in the registers of the walking wave (resident form).
+struct LdsStore {
+    WalkLds& L; int lane, n_cache, nw, cap;
+    __device__ LdsStore(WalkLds& l, int ln, int cp) : L(l), lane(ln), n_cache(l.n_cache), nw(0), cap(cp) {}
+    __device__ bool lookup(int x, int y, long long& e) const {
         for (int base = 0; base < n_cache; base += 64) {
             const int  i = base + lane;
             const bool hit = i < n_cache && L.cx[i] == x && L.cy[i] == y;
@@ -91,57 +89,123 @@ __device__ bool replay(WalkLds& L, int ep, const int start[2], const long long* 
             if (m) { e = L.ce[base + __ffsll((long long)m) - 1]; return true; }
         }
         return false;
+    }
+    __device__ void want(int x, int y) {
+        const bool dup = __ballot(lane < nw && ((volatile int*)L.wx)[lane] == x && ((volatile int*)L.wy)[lane] == y) != 0;   // kMaxCand <= 64; lane 0 wrote the list
+        if (!dup && nw < cap) { if (lane == 0) { L.wx[nw] = x; L.wy[nw] = y; } nw++; }
+    }
+    __device__ void finish(bool exact, int q0, int q1, double err) {
+        if (lane == 0) {
+            L.n_want = nw;
+            if (exact) { L.res_x = q0; L.res_y = q1; L.res_err = (long long)err; }
+        }
+    }
+};
+// lane i of bank b holds evaluated point 64 b + i: a lookup is one compare + ballot + two v_readlane per bank in use, no memory on the serial path
+constexpr int kBanks = kCache / 64;
+__device__ __forceinline__ int point_key(int x, int y) { return (x + 128) | ((y + 128) << 8); }   // taps lie in [-96, 95]
+struct RegStore {
+    int key[kBanks]; long long err[kBanks];   // the cache, one entry per lane and bank
+    int wkey;                                   // lane i: wanted point i
+    int lane, n_cache, nw, cap;
+    int res_x, res_y; long long res_err;
+    __device__ bool lookup(int x, int y, long long& e) const {
+        const int k = point_key(x, y);
+        bool found = false;
+#pragma unroll
+        for (int b = 0; b < kBanks; b++) {   // no early exit: the bank index must stay a compile-time constant (registers, not scratch)
+            if (!found && 64 * b < n_cache) {
+                const unsigned long long m = __ballot(64 * b + lane < n_cache && key[b] == k);
+                if (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)err[b], src);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)err[b] >> 32), src);
+                    e = (long long)(((unsigned long long)hi << 32) | lo);
+                    found = true;
+                }
+            }
+        }
+        return found;
+    }
+    __device__ void want(int x, int y) {
+        const int k = point_key(x, y);
+        const bool dup = __ballot(lane < nw && wkey == k) != 0;
+        if (!dup && nw < cap) { if (lane == nw) wkey = k; nw++; }
+    }
+    __device__ void finish(bool exact, int q0, int q1, double e) {
+        if (exact) { res_x = q0; res_y = q1; res_err = (long long)e; }
+    }
+};
+
+// The walk as a state machine, so that a replay can RESUME where the previous one turned speculative instead of re-deciding the exact prefix:
+//   s = step (2, then 1), p = parameter (0, 1; 2 = this step size is finished), up = 0 probing q - s / 1 probing q + s, (q0, q1) = current point,
+//   err = its error, moved = "the downward probe of this parameter was accepted" (EbRestorationPick.c:406-407 then leaves the parameter loop).
+struct WalkState { int s, p, up, q0, q1, moved, have_err; double err; };
+__device__ __forceinline__ void walk_begin(WalkState& W, const int start[2]) { W.s = 2; W.p = 0; W.up = 0; W.q0 = start[0]; W.q1 = start[1]; W.moved = 0; W.have_err = 0; W.err = 0; }
+
+// One replay: continues from W on exact errors; at the first unknown point it freezes W there (the next replay resumes from it) and keeps walking on
+// the quadratic model, collecting up to K.cap unknown points.  Returns true when the walk finished on exact errors only (W.q0, W.q1, W.err = result).
+template <class Store>
+__device__ bool replay(Store& K, WalkState& W, int ep, const long long* sums) {
+    const bool   has0 = ep < 10 || ep >= 14, has1 = ep < 14;
+    const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    auto model = [&](int x, int y) {
+        const double a = has0 ? x : 0, b = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
+        return a * a * H00 + 2 * a * b * H01 + b * b * H11 - 256.0 * (a * C0 + b * C1);
     };
     bool spec = false;
-    int  nw = 0;
-    // value of a point: its exact error while everything so far was cached, the model afterwards (cur = the walk's current point, whose
+    K.nw = 0;
+    WalkState T = W;   // the running state; W follows it while everything is exact
+    // value of a point: its exact error while everything so far was cached, the model afterwards (the current point's
     // value is switched to the model at that moment so that comparisons stay like with like)
-    auto value = [&](int x, int y, int curx, int cury, double& cur_err) {
+    auto value = [&](int x, int y) {
         long long e;
-        if (!spec && lookup(x, y, e)) return (double)e;
-        if (!spec) { spec = true; cur_err = model(curx, cury); }
-        if (!lookup(x, y, e)) {
-            const bool dup = __ballot(lane < nw && ((volatile int*)L.wx)[lane] == x && ((volatile int*)L.wy)[lane] == y) != 0;   // kMaxCand <= 64; lane 0 wrote the list
-            if (!dup && nw < kMaxCand) { if (lane == 0) { L.wx[nw] = x; L.wy[nw] = y; } nw++; }
-        }
+        if (!spec && K.lookup(x, y, e)) return (double)e;
+        if (!spec) { spec = true; T.err = model(T.q0, T.q1); }
+        if (!K.lookup(x, y, e)) K.want(x, y);
         return model(x, y);
     };
-    int    q0 = start[0], q1 = start[1];
-    double err = 0, err2;
-    err = value(q0, q1, q0, q1, err);
-    for (int s = 2; s >= 1 && nw < kMaxCand; s >>= 1) {
-        for (int p = 0; p < 2 && nw < kMaxCand; p++) {
-            if (p == 0 ? !has0 : !has1) continue;
-            const int tmin = p == 0 ? -96 : -32, tmax = p == 0 ? 31 : 95;   // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1 (EbRestoration.h:100-103)
-            bool skip = false;
-            for (;;) {
-                const int qp = p == 0 ? q0 : q1;
-                if (qp - s >= tmin && nw < kMaxCand) {
-                    const int c0 = p == 0 ? q0 - s : q0, c1 = p == 0 ? q1 : q1 - s;
-                    err2 = value(c0, c1, q0, q1, err);
-                    if (!(err2 > err)) { q0 = c0; q1 = c1; err = err2; skip = true; if (s == 2) continue; }
-                }
-                break;
-            }
-            if (skip) break;   // EbRestorationPick.c:406-407: leaves the parameter loop of this step size
-            for (;;) {
-                const int qp = p == 0 ? q0 : q1;
-                if (qp + s <= tmax && nw < kMaxCand) {
-                    const int c0 = p == 0 ? q0 + s : q0, c1 = p == 0 ? q1 : q1 + s;
-                    err2 = value(c0, c1, q0, q1, err);
-                    if (!(err2 > err)) { q0 = c0; q1 = c1; err = err2; if (s == 2) continue; }
-                }
-                break;
-            }
+    if (!T.have_err) {
+        T.err = value(T.q0, T.q1);
+        T.have_err = 1;
+        if (!spec) W = T;
+    }
+    while (T.s >= 1 && K.nw < K.cap) {
+        if (T.p >= 2) { T.s >>= 1; T.p = 0; T.up = 0; T.moved = 0; if (!spec) W = T; continue; }
+        if (T.p == 0 ? !has0 : !has1) { T.p++; T.up = 0; T.moved = 0; if (!spec) W = T; continue; }
+        const int tmin = T.p == 0 ? -96 : -32, tmax = T.p == 0 ? 31 : 95;   // SGRPROJ_PRJ_MIN0 / MAX0, MIN1 / MAX1 (EbRestoration.h:100-103)
+        const int qp = T.p == 0 ? T.q0 : T.q1, d = T.up ? T.s : -T.s;
+        bool again = false;
+        if (T.up ? qp + T.s <= tmax : qp - T.s >= tmin) {
+            const int c0 = T.p == 0 ? T.q0 + d : T.q0, c1 = T.p == 0 ? T.q1 : T.q1 + d;
+            const double err2 = value(c0, c1);
+            if (!(err2 > T.err)) { T.q0 = c0; T.q1 = c1; T.err = err2; if (!T.up) T.moved = 1; again = T.s == 2; }
         }
+        if (!again) {
+            if (!T.up) { if (T.moved) T.p = 2; else T.up = 1; }   // an accepted downward probe ends this step size (the reference's `if (skip) break`)
+            else { T.p++; T.up = 0; T.moved = 0; }
+        }
+        if (!spec) W = T;   // still exact: this decision is final
     }
-    if (lane == 0) {
-        L.n_want = nw;
-        if (!spec) { L.res_x = q0; L.res_y = q1; L.res_err = (long long)err; }
-    }
+    K.finish(!spec, T.q0, T.q1, T.err);
     return !spec;
 }
 
+// sum of a non-negative value below 2^48 over the wave, without LDS traffic: two 24-bit limbs, each reduced with four DPP adds (within a row of 16
+// lanes) and four v_readlane.  Uniform result.
+__device__ __forceinline__ int row_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1 0 3 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2 3 0 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_u48(long long v) {
+    const int lo = row_sum_dpp((int)(v & 0xFFFFFF)), hi = row_sum_dpp((int)(v >> 24));
+    const long long slo = (long long)__builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
+    const long long shi = (long long)__builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
+    return slo + (shi << 24);
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -155,7 +219,7 @@ __global__ void __launch_bounds__(256)
 sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ sd, int dstride, size_t dplane,
                 const long long* __restrict__ sums, int pw, int ph, int unit_size, int units_x, int units_y, int voff, uint32_t ep_mask,
                 int32_t* __restrict__ xqd_out, long long* __restrict__ err_out, uint32_t* __restrict__ counters, uint8_t* __restrict__ best_ep,
-                int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats) {
+                int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats, int cap) {
     __shared__ WalkLds L;
     const int unit = blockIdx.x, ep = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!((ep_mask >> ep) & 1)) return;
@@ -182,10 +246,12 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
     int n_pass = 0, n_eval = 0;
     for (int pass = 0; pass < 64; pass++) {
         if (wave == 0) {
-            const bool fin = replay(L, ep, start, S, lane);
+            LdsStore K(L, lane, cap);
+            WalkState W0; walk_begin(W0, start);   // the streamed form re-decides the whole walk every pass
+            const bool fin = replay(K, W0, ep, S);
             if (lane == 0) L.done = fin ? 1 : 0;
             __builtin_amdgcn_wave_barrier();
-            if (lane < kMaxCand) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718); entries past n_want are not read
+            if (lane < kStreamCand) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718); entries past n_want are not read
                 const int x = L.wx[lane], y = L.wy[lane];
                 L.xq0[lane] = has0 ? x : 0;
                 L.xq1[lane] = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);
@@ -195,10 +261,10 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
         if (L.done) break;
         const int nc = L.n_want;
         n_pass++; n_eval += nc;
-        int xq[kMaxCand];   // both taps scaled by 32 and packed for v_dot2_i32_i16 (|32 xq| <= 8192)
-        long long acc[kMaxCand];
+        int xq[kStreamCand];   // both taps scaled by 32 and packed for v_dot2_i32_i16 (|32 xq| <= 8192)
+        long long acc[kStreamCand];
 #pragma unroll
-        for (int c = 0; c < kMaxCand; c++) {
+        for (int c = 0; c < kStreamCand; c++) {
             xq[c] = c < nc ? (int)(((uint32_t)(L.xq0[c] * 32) & 0xFFFFu) | ((uint32_t)(L.xq1[c] * 32) << 16)) : 0;
             acc[c] = 0;
         }
@@ -275,6 +341,219 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// The same search with the unit RESIDENT on the compute unit: one 1024-thread workgroup per (unit, set).  Waves 1-15 load the unit's difference planes
+// once — the (flt0 - u, flt1 - u) words into registers (9 chunks of 8 pixels per thread x 960 threads = 69 120 pixels, a whole 256 x 256 unit), dat - src
+// into 135 KB of LDS — and every later pass of the walk is arithmetic on resident data; wave 0 holds no pixels and runs the solve and the replay (its
+// registers are the replay's: the two roles are separate code paths that meet at the workgroup barriers, so neither spills).  The streamed form above
+// re-reads 6 bytes per pixel and pass (3.3 passes per walk on coded content): 4 GB per 4K frame against 1.2 GB here.  Units larger than 69 120 pixels
+// (the last row / column may be up to 1.5 x the unit size) keep the excess in memory and stream it per pass like the form above.  Per candidate and
+// pixel pair: 2 v_dot2_i32_i16 (weighted sum, rounding constant as the accumulator), v_perm_b32 (high halves), v_pk_add_i16 (+ dat - src),
+// v_dot2_i32_i16 (square-accumulate).
+constexpr int kResT = 1024, kResD = kResT - 64, kResJ = 9;   // threads, data threads, resident chunks per data thread
+struct ResLds {
+    WalkLds W;
+    int4    sd[kResJ * kResD];   // [chunk slot][data thread]: eight dat - src values
+};
+
+// Eight pixels of one candidate: 20 vector instructions, written out because the order matters on this pipeline — a dot product's result may
+// not be read by a different opcode for three issue slots, so the eight weighted sums go first (the three-operand v_dot2_i32_i16 takes the rounding
+// constant 2^15 from a scalar register; the compiler's own choice, the accumulate-in-place form, costs a v_mov per pixel), then the four
+// v_perm_b32 that pack the high halves (= the rounded >> 11), the four v_pk_add_u16 that add dat - src, and four squaring dots that accumulate
+// into p0 / p1 (a dot may feed the accumulator of the next dot back to back).  The caller waits three slots before reading p0 / p1 (dot_drain).
+__device__ __forceinline__ void eval_chunk(const int4& a0, const int4& a1, const int4& s, int q, int rnd, int sel, int& p0, int& p1) {
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_dot2_i32_i16 %[t0], %[a0], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t1], %[a1], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t2], %[a2], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t3], %[a3], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t4], %[a4], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t5], %[a5], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t6], %[a6], %[q], %[r]\n\t"
+        "v_dot2_i32_i16 %[t7], %[a7], %[q], %[r]\n\t"
+        "v_perm_b32 %[t0], %[t1], %[t0], %[sel]\n\t"
+        "v_perm_b32 %[t2], %[t3], %[t2], %[sel]\n\t"
+        "v_perm_b32 %[t4], %[t5], %[t4], %[sel]\n\t"
+        "v_perm_b32 %[t6], %[t7], %[t6], %[sel]\n\t"
+        "v_pk_add_u16 %[t0], %[t0], %[s0]\n\t"
+        "v_pk_add_u16 %[t2], %[t2], %[s1]\n\t"
+        "v_pk_add_u16 %[t4], %[t4], %[s2]\n\t"
+        "v_pk_add_u16 %[t6], %[t6], %[s3]\n\t"
+        "v_dot2_i32_i16 %[p0], %[t0], %[t0], %[p0]\n\t"
+        "v_dot2_i32_i16 %[p1], %[t2], %[t2], %[p1]\n\t"
+        "v_dot2_i32_i16 %[p0], %[t4], %[t4], %[p0]\n\t"
+        "v_dot2_i32_i16 %[p1], %[t6], %[t6], %[p1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [p0] "+v"(p0), [p1] "+v"(p1)
+        : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [s0] "v"(s.x), [s1] "v"(s.y),
+          [s2] "v"(s.z), [s3] "v"(s.w), [q] "v"(q), [r] "s"(rnd), [sel] "s"(sel));
+}
+__device__ __forceinline__ void dot_drain() { asm volatile("s_nop 2"); }
+// zero the pixels of a chunk at or past column n (n < 8): their error is then 0 for every candidate
+__device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
+    int pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    int sw[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (i >= n) { pr[i] = 0; sw[i >> 1] &= (i & 1) ? 0x0000FFFF : 0; }
+    a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]); s = make_int4(sw[0], sw[1], sw[2], sw[3]);
+}
+
+template <int BD>
+__global__ void __launch_bounds__(kResT)
+sgr_walk_resident_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ sd, int dstride, size_t dplane,
+                         const long long* __restrict__ sums, int pw, int ph, int unit_size, int units_x, int units_y, int voff, uint32_t ep_mask,
+                         int32_t* __restrict__ xqd_out, long long* __restrict__ err_out, uint32_t* __restrict__ counters, uint8_t* __restrict__ best_ep,
+                         int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats, int cap) {
+    __shared__ ResLds R;
+    WalkLds& L = R.W;
+    const int unit = blockIdx.x, ep = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!((ep_mask >> ep) & 1)) return;
+    const int uj = unit % units_x, ui = unit / units_x;
+    const int x0 = uj * unit_size, w = uj == units_x - 1 ? pw - x0 : unit_size;
+    const int y0 = ui * unit_size, h = ui == units_y - 1 ? ph - y0 : unit_size;
+    const int v0 = max(y0 - voff, 0), v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
+    const bool has0 = ep < 10 || ep >= 14, has1 = ep < 14;
+    const int  ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
+    const uint32_t* __restrict__ PP = pairs + (size_t)ce * dplane;
+    const long long* S = sums + ((size_t)unit * 16 + ep) * 5;
+
+    if (wave == 0) {
+        // =================================== the walk: solve, replay, cache ===================================
+        int start[2] = {0, 0};
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        unsigned long long c_replay = 0, c_load = 0, c_eval = 0;
+        solve_and_encode(S, w * (v1 - v0), ep, start);
+        RegStore K;
+#pragma unroll
+        for (int b = 0; b < kBanks; b++) { K.key[b] = -1; K.err[b] = 0; }
+        K.wkey = -1; K.lane = lane; K.n_cache = 0; K.nw = 0; K.cap = cap; K.res_x = start[0]; K.res_y = start[1]; K.res_err = -1;
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        int n_pass = 0, n_eval = 0;
+        bool fin = false;
+        WalkState W; walk_begin(W, start);
+        for (int pass = 0; pass < 64; pass++) {
+            const unsigned long long r0 = __builtin_readcyclecounter();
+            fin = replay(K, W, ep, S);
+            c_replay += __builtin_readcyclecounter() - r0;
+            const int nc = K.nw;
+            if (lane == 0) { L.done = fin ? 1 : 0; L.n_want = nc; }
+            if (lane < nc) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718)
+                const int x = (K.wkey & 255) - 128, y = (K.wkey >> 8) - 128;
+                L.xq0[lane] = has0 ? x : 0;
+                L.xq1[lane] = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);
+            }
+            const unsigned long long a0 = __builtin_readcyclecounter();
+            __syncthreads();   // A: the candidate list is published (or the walk is over)
+            const unsigned long long a1 = __builtin_readcyclecounter();
+            if (pass == 0) c_load = a1 - a0;
+            if (fin) break;
+            n_pass++; n_eval += nc;
+            __syncthreads();   // B: every data wave has left its partial sums
+            c_eval += __builtin_readcyclecounter() - a1;
+            // the new exact points join the cache: point c goes to entry n_cache + c = lane (n_cache + c) & 63 of bank (n_cache + c) >> 6
+#pragma unroll
+            for (int b = 0; b < kBanks; b++) {
+                const int c = 64 * b + lane - K.n_cache;
+                const int k = __shfl(K.wkey, c & 63, 64);
+                if (c >= 0 && c < nc) {
+                    long long e = 0;
+#pragma unroll
+                    for (int v = 1; v < kResT / 64; v++) e += L.part[v][c];
+                    K.key[b] = k; K.err[b] = e;
+                }
+            }
+            K.n_cache = min(K.n_cache + nc, kCache);   // kCache is never reached: a walk visits < 200 points
+        }
+        // ---- results, and the unit's best set once all of its sets are in: search_selfguided_restoration :661-665 (first set with the smallest error)
+        if (lane == 0) {
+            xqd_out[((size_t)unit * 16 + ep) * 2] = K.res_x;
+            xqd_out[((size_t)unit * 16 + ep) * 2 + 1] = K.res_y;
+            err_out[(size_t)unit * 16 + ep] = fin ? K.res_err : -1;   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+            atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
+            // phase clocks of the walk, in units of 64 shader cycles (diagnostics: tools/hbd_time.py)
+            atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
+            atomicAdd(&stats[27], (uint32_t)(c_eval >> 6)); atomicAdd(&stats[28], (uint32_t)((__builtin_readcyclecounter() - c0) >> 6));
+            __threadfence();
+            const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
+            if (arrived == (uint32_t)__popc(ep_mask)) {
+                __threadfence();
+                int be = -1; long long berr = -1;
+                for (int e2 = 0; e2 < 16; e2++) {
+                    if (!((ep_mask >> e2) & 1)) continue;
+                    const long long v = ((volatile long long*)err_out)[(size_t)unit * 16 + e2];
+                    if (be < 0 || v < berr) { be = e2; berr = v; }
+                }
+                if (best_ep) best_ep[unit] = (uint8_t)be;
+                if (best_xqd) {
+                    best_xqd[2 * unit] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2];
+                    best_xqd[2 * unit + 1] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2 + 1];
+                }
+            }
+        }
+        return;
+    }
+    // =================================== the pixels: load once, evaluate every pass ===================================
+    const int t = tid - 64;
+    const int cw = (w + 7) >> 3, nchunk = cw * (v1 - v0);
+    int4 pa[kResJ], pb[kResJ];
+#pragma unroll
+    for (int j = 0; j < kResJ; j++) {
+        const int k = t + j * kResD;
+        int4 s = make_int4(0, 0, 0, 0);
+        pa[j] = pb[j] = s;
+        if (k < nchunk) {
+            const int row = k / cw, cx = k - row * cw;
+            const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+            pa[j] = *(const int4*)(PP + off); pb[j] = *(const int4*)(PP + off + 4);
+            s = *(const int4*)(sd + off);
+            const int n = w - 8 * cx;
+            if (n < 8) mask_chunk(pa[j], pb[j], s, n);
+        }
+        R.sd[j * kResD + t] = s;   // read back by this thread only
+    }
+    int rnd, sel;
+    asm volatile("s_mov_b32 %0, 0x8000\n\ts_mov_b32 %1, 0x07060302" : "=s"(rnd), "=s"(sel));   // opaque: kept in scalar registers
+    for (int pass = 0; pass < 64; pass++) {
+        __syncthreads();   // A
+        if (L.done) break;
+        const int nc = L.n_want;
+        const int qv = lane < nc ? (int)(((uint32_t)(L.xq0[lane] * 32) & 0xFFFFu) | ((uint32_t)(L.xq1[lane] * 32) << 16)) : 0;   // lane c: both taps of candidate c, scaled by 32 (|32 xq| <= 8192)
+        const unsigned long long e0 = __builtin_readcyclecounter();
+        for (int c = 0; c < nc; c++) {
+            const int q = __builtin_amdgcn_readlane(qv, c);
+            long long acc = 0;
+            int p0 = 0, p1 = 0;
+            int4 sn = R.sd[t];
+#pragma unroll
+            for (int j = 0; j < kResJ; j++) {   // dat - src of the next chunk is fetched while this one is evaluated; the fence keeps the scheduler from
+                if (j * kResD < nchunk) {       // hoisting all nine LDS reads (36 registers on top of the 72 resident ones); unused slots (small units) are skipped
+                    const int4 sc = sn;
+                    if (j + 1 < kResJ) sn = R.sd[(j + 1) * kResD + t];
+                    eval_chunk(pa[j], pb[j], sc, q, rnd, sel, p0, p1);
+                    if (BD > 8) { dot_drain(); acc += p0 + p1; p0 = p1 = 0; }   // |e| < 2^13 at bit depth 10: eight squares per accumulator stay below 2^31; at 8 (|e| < 2^10) all 72 do
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (BD == 8) { dot_drain(); acc += p0 + p1; p0 = p1 = 0; }
+            for (int k = t + kResJ * kResD; k < nchunk; k += kResD) {   // the part of an over-sized unit that is not resident
+                const int row = k / cw, cx = k - row * cw;
+                const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+                int4 a0 = *(const int4*)(PP + off), a1 = *(const int4*)(PP + off + 4), s = *(const int4*)(sd + off);
+                const int n = w - 8 * cx;
+                if (n < 8) mask_chunk(a0, a1, s, n);
+                eval_chunk(a0, a1, s, q, rnd, sel, p0, p1);
+                dot_drain(); acc += p0 + p1; p0 = p1 = 0;
+            }
+            const long long sum = wave_sum_u48(acc);   // acc < 72 x 2^26
+            if (lane == 0) L.part[wave][c] = sum;
+        }
+        if (tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); }   // diagnostics: the candidate loop as wave 1 sees it
+        __syncthreads();   // B
+    }
+}
+
 }  // namespace
 
 extern "C" size_t svt_hip_sgr_walk_state_bytes(int n_units) { return sizeof(uint32_t) * (size_t)n_units; }   // arrival counter per unit
@@ -287,13 +566,19 @@ extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* p
     dim3 grid(units_x * units_y, 16);
     uint32_t* counters = (uint32_t*)states;
     (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)units_x * units_y, st);
-    // tuning knob (tools/hbd_time.py): unused dynamic LDS per workgroup limits how many (unit, set) walks are in flight
-    static const int lds_pad = getenv("SVT_HIP_SGR_WALK_LDS_PAD") ? atoi(getenv("SVT_HIP_SGR_WALK_LDS_PAD")) * 1024 : 0;
-    if (bd == 8)
-        hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), lds_pad, st, pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
-                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
-    else
-        hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), lds_pad, st, pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff,
-                           ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats);
+    // SVT_HIP_SGR_WALK=stream selects the streamed form (A/B measurements, tools/hbd_time.py); the resident form is the product path
+    static const bool stream_form = getenv("SVT_HIP_SGR_WALK") && !strcmp(getenv("SVT_HIP_SGR_WALK"), "stream");
+    static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
+    const int cap = cap_env >= 1 && cap_env <= kMaxCand ? cap_env : (stream_form ? kStreamCand : 12);   // candidates per pass
+    if (stream_form && cap > kStreamCand) return (int)hipErrorInvalidValue;
+#define WALK_ARGS pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff, ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats, cap
+    if (stream_form) {
+        if (bd == 8) hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), 0, st, WALK_ARGS);
+        else hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), 0, st, WALK_ARGS);
+    } else {
+        if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8>), grid, dim3(kResT), 0, st, WALK_ARGS);
+        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10>), grid, dim3(kResT), 0, st, WALK_ARGS);
+    }
+#undef WALK_ARGS
     return (int)hipGetLastError();
 }

@@ -558,7 +558,7 @@ SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     L.dplane = (size_t)L.dstride * (size_t)ph;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
-    L.stats = o;    o = al(o + 128);   // [0] passes, [1] points, [2] unfinished, [3] flat walks, [8..23] histogram of passes per finished walk   // {evaluation passes, evaluated points, unfinished walks, -} over the plane: diagnostics
+    L.stats = o;    o = al(o + 128);   // diagnostics over the plane: [0] evaluation passes, [1] evaluated points, [2] unfinished walks, [24..30] phase clocks of the walks (sgr_walk.hip)
     L.sums = o;     o = al(o + sizeof(int64_t) * (size_t)L.nu * 16 * 5);
     L.d2 = o;       o = al(o + sizeof(int64_t) * (size_t)L.nu);   // sum (dat - src)^2 per unit
     L.states = o;   o = al(o + svt_hip_sgr_walk_state_bytes(L.nu));   // per (unit, set): cache of evaluated points, points wanted next, result
