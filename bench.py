@@ -59,7 +59,7 @@ STAGE_KERNELS = {
     "pyramids": "downsample_kernel+variance_pyramid_kernel", "hme_l0_l1_l2": "sad_loop_kernel", "me_fullpel_85pu": "me_fullpel_85pu_kernel",
     "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel",
     "deblock": "deblock_frame_pass_kernel", "cdef_search": "cdef_search_luma_kernel+cdef_search_chroma_kernel", "cdef_apply": "cdef_apply_kernel",
-    "sgr_units_search": "sgr_search8_kernel+sgr_walk_kernel", "sgr_apply": "lr_apply8_kernel",
+    "sgr_units_search": "sgr_search8_kernel+sgr_walk_resident_kernel", "sgr_apply": "lr_apply8_kernel",
 }
 SOURCE_SIDE = ("pyr", "hme", "me")   # read only source pictures: the open-loop chain, parallel to the reconstruction chain
 EXT = 3                              # RESTORATION_BORDER: recon / CDEF / restoration planes carry a 3-sample border
@@ -599,7 +599,7 @@ def roofline(per_stage, stages, n_sb):
         work = 6144 * (23 * 30.0 + 16 * 9.2 * 4.0) * n_sb   # 23 distinct box filters x ~30 ops per pixel + 16 sets x ~9.2 probes x 4 ops per pixel
         valu["sgr_units_search"] = {"achieved": work / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 2.4e9 / 4.0 / 1e12, "unit": "T lane-op/s",
                                     "note": "work = per pixel 23 distinct (radius, strength) filters x ~30 ops (A/B lookup, 3x3 weighting, projection) + 16 sets x ~9.2 error probes x 4 "
-                                            "ops; peak = 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz; the probe passes re-read 4-6 B per pixel and set from HBM (821 MB scratch)"}
+                                            "ops; peak = 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz; every (unit, set) loads its 6 B per pixel once (resident walk), 1.2 GB per frame"}
         valu["sgr_units_search"]["frac"] = valu["sgr_units_search"]["achieved"] / valu["sgr_units_search"]["peak"]
     if dom in valu:
         r.update({"bound": "valu", "achieved": valu[dom]["achieved"], "peak": valu[dom]["peak"], "unit": valu[dom]["unit"], "frac": valu[dom]["frac"]})
@@ -621,6 +621,21 @@ def roofline(per_stage, stages, n_sb):
             act = sum(e.get("sq", {}).get("SQ_ACTIVE_INST_VALU", 0.0) * e["launches"] for e in sel)
             dur = sum(e["avg_us"] * e["launches"] for e in sel)
             valu_busy = (act * 4.0) / (1024 * dur * 1e-6 * 2.4e9) if dur else None
+
+            def lane_ops(prefixes):   # vector instructions the ISA actually issued per frame (SQ_INSTS_VALU counts wave-instructions), as lane operations
+                return 64.0 * sum(e.get("sq", {}).get("SQ_INSTS_VALU", 0.0) * e["launches"] for k, e in pt.items() if any(k.startswith(x) for x in prefixes)) / frames if frames else None
+            px = 6144.0 * n_sb   # luma + 2 chroma samples of a 4:2:0 frame
+            c_ops, s_ops = lane_ops(("cdef_search_",)), lane_ops(("sgr_search8_kernel", "sgr_walk_"))
+            if c_ops:
+                r["valu_cdef"] = {"isa_lane_ops_per_sample_and_strength": c_ops / (px * 64), "argued_minimum": 2.0, "source": traffic_src,
+                                  "note": "SQ_INSTS_VALU x 64 of cdef_search_luma/chroma per frame / (samples x 64 strength pairs); minimum: the strength-dependent part is combine, "
+                                          "round, clamp, squared error = 4 operations on packed 16-bit pairs = 2 per sample; everything above it is the direction search, the 21 "
+                                          "tap sums computed once per sample (amortised over 64 strengths), tile staging and the reductions"}
+            if s_ops:
+                r["valu_sgr"] = {"isa_lane_ops_per_sample_and_set": s_ops / (px * 16), "argued_minimum": 23 * 30.0 / 16 + 13.0 * 2.5, "source": traffic_src,
+                                 "note": "SQ_INSTS_VALU x 64 of sgr_search8 + sgr_walk per frame / (samples x 16 sets); minimum: 23 distinct (radius, strength) filters x ~30 operations "
+                                         "per sample shared by the 16 sets + ~13 evaluated points per walk x 2.5 operations per sample (two dot products, half a permute, half a "
+                                         "packed add, half a squaring dot product)"}
     except (OSError, ValueError, KeyError):
         traffic = None
     r.update({"traffic": traffic, "valu_busy": valu_busy,
