@@ -301,17 +301,17 @@ static void fill_skip8(SvtHipLfPicture *p, PictureControlSet *pcs) {     /* is_8
             p->h_skip8[r * c8 + c] = (uint8_t)skip;
         }
 }
-static int cdef_geometry_ok(const SvtHipLfPicture *p) { return !(p->w % 64 > 0 && p->w % 64 < 16); }   /* include/svt_hip.h: last filter block >= 16 wide */
 
 /* all cdef_seg_search[16bit] calls of the picture (EbCdefProcess.c:80-475): pcs->mse_seg[pli][fb][gi] for the strengths of the picture's
  * pick method (gi indexes the REDUCED strength list, get_cdef_filter_strengths, Common/Codec/EbDefinitions.h:1696) */
 static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
     PictureControlSet *pcs = s->pcs;
-    if (!(s->flags & ST_DBL) || !cdef_geometry_ok(p) || ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (!(s->flags & ST_DBL) || ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     const int nfb = ((p->w + 63) / 64) * ((p->h + 63) / 64);
     const int pri_damping = 3 + (pcs->parent_pcs_ptr->frm_hdr.quantization_params.base_q_idx >> 6);   /* EbCdefProcess.c:121 */
     fill_skip8(p, pcs);
+    svt_hip_hooks_log("cdef_search: %d x %d, %d filter blocks, primary damping %d", p->w, p->h, nfb, pri_damping);
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_skip8, p->h_skip8, (size_t)(p->w / 8) * (p->h / 8)));
     const void *rec[3], *src[3];
     for (int pl = 0; pl < 3; pl++) { rec[pl] = plane_origin(p, p->d_recon[pl], pl); src[pl] = p->d_src[pl]; }
@@ -335,6 +335,7 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
         }
     }
     s->flags |= ST_DIRVAR;
+    svt_hip_hooks_log("cdef_search: distortion table of the picture is in pcs->mse_seg");
     return EB_ErrorNone;
 }
 /* called by every segment of the picture: the first one to arrive searches the whole picture, the others find it done */
@@ -358,7 +359,7 @@ EbErrorType svt_hip_hook_cdef_search(PictureControlSet *pcs) {
 static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
     PictureControlSet *pcs = s->pcs;
-    if (!(s->flags & ST_DBL) || !cdef_geometry_ok(p)) return EB_ErrorUndefined;
+    if (!(s->flags & ST_DBL)) return EB_ErrorUndefined;
     FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
     const int nhfb = (p->w + 63) / 64, nvfb = (p->h + 63) / 64, nfb = nhfb * nvfb;
     uint8_t *ys = (uint8_t *)malloc(nfb), *uvs = (uint8_t *)malloc(nfb);

@@ -376,8 +376,7 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx* c, int pix_bytes, const void* const
                                   int pri_damping, int bd, uint64_t* d_mse, uint8_t* d_dir, int32_t* d_var) {
     SVT_HIP_ENTER(c);
     if (!c || !d_rec || !d_src || !rec_stride || !src_stride || !d_skip8 || !d_mse || !d_dir || !d_var || (pix_bytes != 1 && pix_bytes != 2) ||
-        (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7) || ((w & 63) && (w & 63) < 16) ||
-        ((h & 63) && (h & 63) < 16)) {
+        (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || w <= 0 || h <= 0 || (w & 7) || (h & 7)) {
         if (c) c->err = "svt_hip_cdef_search_frame_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
     }

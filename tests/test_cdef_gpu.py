@@ -30,8 +30,12 @@ def gpu_search(hip, rec, src, bd, skip8, pri_damping):
 
 @pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("smooth", [True, False])
-def test_search_table(hip, orc, bd, smooth):
-    src, rec, skip8 = cc.make_frame(208, 144, bd, seed=3 + bd, smooth=smooth)   # 4 x 3 fbs, last ones 16 px
+@pytest.mark.parametrize("size", [(208, 144), (200, 136)])
+def test_search_table(hip, orc, bd, smooth, size):
+    # 4 x 3 filter blocks; 208 x 144: the last ones 16 samples, 200 x 136: 8 luma / 4 chroma samples — narrower than the 8-sample halo the
+    # reference stages for their left / upper neighbours (EbCdefProcess.c:210-226: the halo then extends into the picture padding, but no filter
+    # tap reaches further than 2 samples, so the padding is never read)
+    src, rec, skip8 = cc.make_frame(size[0], size[1], bd, seed=3 + bd, smooth=smooth)
     skip8[0:8, 8:16] = 1          # one all-skip filter block: its entries stay untouched (zero)
     for damping in (3, 5, 6):
         exp = cc.orc_search(orc, rec, src, bd, skip8, damping)
@@ -42,8 +46,9 @@ def test_search_table(hip, orc, bd, smooth):
 
 
 @pytest.mark.parametrize("bd", [8, 10])
-def test_apply_frame(hip, orc, bd):
-    src, rec, skip8 = cc.make_frame(208, 144, bd, seed=30 + bd)
+@pytest.mark.parametrize("size", [(208, 144), (200, 136)])
+def test_apply_frame(hip, orc, bd, size):
+    src, rec, skip8 = cc.make_frame(size[0], size[1], bd, seed=30 + bd)
     h, w = rec[0].shape
     nfb = 12
     rng = np.random.default_rng(1)

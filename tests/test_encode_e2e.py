@@ -23,6 +23,7 @@ CASES = {
     "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),
     "360p_8bit_m7": (640, 360, 5, 8, 7, 40, NO_DLF_REST),     # 40 SBs in many ME segments; width % 64 == 0, height % 64 == 40
     "cif_8bit_m4": (352, 288, 5, 8, 4, 45, ALL),              # full filter-level step search, chroma levels searched on their own
+    "328x200_8bit_m6": (328, 200, 4, 8, 6, 33, ALL),          # width % 64 == height % 64 == 8: last filter blocks / restoration stripes narrower than the CDEF halo
 }
 GPU_ONLY_CASES = {
     "720p_8bit_m6": (1280, 720, 4, 8, 6, 38, ALL),
