@@ -632,10 +632,10 @@ def roofline(per_stage, stages, n_sb):
                                           "round, clamp, squared error = 4 operations on packed 16-bit pairs = 2 per sample; everything above it is the direction search, the 21 "
                                           "tap sums computed once per sample (amortised over 64 strengths), tile staging and the reductions"}
             if s_ops:
-                r["valu_sgr"] = {"isa_lane_ops_per_sample_and_set": s_ops / (px * 16), "argued_minimum": 23 * 30.0 / 16 + 13.0 * 2.5, "source": traffic_src,
-                                 "note": "SQ_INSTS_VALU x 64 of sgr_search8 + sgr_walk per frame / (samples x 16 sets); minimum: 23 distinct (radius, strength) filters x ~30 operations "
-                                         "per sample shared by the 16 sets + ~13 evaluated points per walk x 2.5 operations per sample (two dot products, half a permute, half a "
-                                         "packed add, half a squaring dot product)"}
+                r["valu_sgr"] = {"isa_lane_ops_per_sample_and_set": s_ops / (px * 16), "argued_minimum": 13.0 * 2.5 + 5.0, "source": traffic_src,
+                                 "note": "SQ_INSTS_VALU x 64 of sgr_search8 + sgr_walk per frame / (samples x 16 sets); minimum of the set-dependent part: ~13 evaluated points per "
+                                         "walk x 2.5 operations per sample (two dot products, half a permute, half a packed add, half a squaring dot product) + the five projection "
+                                         "products; the box filters themselves (23 distinct radius / strength pairs) are shared between sets"}
     except (OSError, ValueError, KeyError):
         traffic = None
     r.update({"traffic": traffic, "valu_busy": valu_busy,
