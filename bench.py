@@ -512,7 +512,7 @@ def main():
 
 def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
-    copy_s = torch.cuda.Stream()
+    up_s, down_s = torch.cuda.Stream(), torch.cuda.Stream()   # PCIe is full duplex: uploads and downloads get a stream (a DMA queue) each
     pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host = []
     up_bytes = down_bytes = 0
@@ -527,22 +527,22 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     down_done = [torch.cuda.Event() for _ in batches]
 
     def upload(b):
-        with torch.cuda.stream(copy_s):
-            copy_s.wait_event(comp_done[b])          # the previous compute on these buffers has finished
+        with torch.cuda.stream(up_s):
+            up_s.wait_event(comp_done[b])          # the previous compute on these buffers has finished (the downloads only read result buffers)
             for P in batches[b]:
                 for d, h in host[idx[id(P)]][0]:
                     d.copy_(h, non_blocking=True)
                 P.d_cur[0].copy_(P.d_cur_p[P.F.pad:P.F.pad + P.F.h, P.F.pad:P.F.pad + P.F.w], non_blocking=True)   # un-padded view of the luma for the transform / filter stages (device-to-device)
                 P.d_vp[:P.F.h, :P.F.w].copy_(P.d_cur[0], non_blocking=True)
-            up_done[b].record(copy_s)
+            up_done[b].record(up_s)
 
     def download(b):
-        with torch.cuda.stream(copy_s):
-            copy_s.wait_event(comp_done[b])
+        with torch.cuda.stream(down_s):
+            down_s.wait_event(comp_done[b])
             for P in batches[b]:
                 for d, h in host[idx[id(P)]][1]:
                     h.copy_(d, non_blocking=True)
-            down_done[b].record(copy_s)
+            down_done[b].record(down_s)
 
     nb = len(batches)
     for b in range(nb):
@@ -554,6 +554,7 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
         for i in range(n):
             b = i % nb
             stream.wait_event(up_done[b])
+            if i >= nb: stream.wait_event(down_done[b])   # the results of this batch's previous step have left the device
             step_fns[b]()
             comp_done[b].record(stream)
             download(b)
@@ -567,7 +568,7 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     t = time.perf_counter() - t0
     return {"value": nF * n_sb * steps / t, "unit": "SB/s", "ms_per_step": t / steps * 1e3, "h2d_bytes_per_frame": up_bytes, "d2h_bytes_per_frame": down_bytes,
             "note": "every step uploads its frames' source pictures (padded luma, U, V) from pinned host memory and downloads ME tables, CDEF distortion table, restoration "
-                    "search results and the restored picture, on a copy stream overlapped with the neighbouring steps' compute"}
+                    "search results and the restored picture, on an upload and a download stream overlapped with the neighbouring steps' compute"}
 
 
 def roofline(per_stage, stages, n_sb):
