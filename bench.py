@@ -187,8 +187,6 @@ class Pipeline:
 
     def run_cdef_apply(self):
         F, L, h = self.F, self.E.L, self.E.ctx.h
-        for p in range(3):   # the destination starts as a copy of the pre-CDEF picture (skipped blocks keep it): stream-ordered device-to-device copies
-            self.chk(L.svt_hip_memcpy_d2d(h, self.b_cdef[p].data_ptr(), self.b_recon[p].data_ptr(), self.b_recon[p].numel()), "d2d")
         self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_recon), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
                                                 self.d_cuv.data_ptr(), F.cdef_damping, 8, self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef apply")
 

@@ -247,8 +247,8 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx *ctx, int pix_bytes, const void *con
                                   const uint8_t *d_skip8, int pri_damping, int bd, uint64_t *d_mse, uint8_t *d_dir,
                                   int32_t *d_var);
 /* Frame application of svt_av1_cdef_frame / av1_cdef_frame16bit (Encoder/Codec/EbEncCdef.c:292-1031).
- * d_in = pre-CDEF planes, d_out = destination planes that must already hold a copy of d_in (blocks
- * that are skipped or belong to an unfiltered fb are not touched); y/uv_strength[nfb] = the frame
+ * d_in = pre-CDEF planes, d_out = destination planes (distinct from d_in); every sample of the picture is written — samples of skipped
+ * blocks and of unfiltered filter blocks are passed through — so d_out needs no initial copy of d_in; y/uv_strength[nfb] = the frame
  * header strength value (pri*4 + sec_idx) selected for each filter block.  d_var == NULL: the directions are computed here and left in
  * d_dir; d_var != NULL: d_dir / d_var are the per-8x8 direction and variance svt_hip_cdef_search_frame_dev produced for the same
  * pre-CDEF picture (svt_cdef_find_dir is deterministic in the picture, so the reference recomputes the same values) and are reused. */
@@ -519,6 +519,17 @@ typedef struct {
 } SvtHipWarpBlk;
 int svt_hip_warp_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int width, int height, int stride, void *d_dst,
                                    int dst_stride, int ss_x, int ss_y, const SvtHipWarpBlk *d_blks, int nblk);
+/* The is_compound branches of the same two functions (EbWarpedMotion.c:660-683, :812-835): do_average = 0 — the block's prediction from the FIRST
+ * reference goes to the 16-bit compound buffer (ConvolveParams::dst) at cb_off with stride cb_stride, d_dst is not touched; do_average = 1 —
+ * the prediction from the SECOND reference is averaged with the buffer ((a + b) >> 1, or (a * fwd_offset + b * bck_offset) >> 4 when
+ * use_jnt_comp_avg) and written to d_dst as pixels.  round_0 / round_1 are the values av1 uses for compound prediction (3 or 5 at 12 bits / 7). */
+typedef struct {
+    SvtHipWarpBlk blk;
+    int32_t cb_off, cb_stride;
+    uint8_t do_average, use_jnt_comp_avg, fwd_offset, bck_offset;
+} SvtHipWarpCompBlk;
+int svt_hip_warp_compound_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int width, int height, int stride, void *d_dst,
+                                    int dst_stride, int ss_x, int ss_y, uint16_t *d_convbuf, const SvtHipWarpCompBlk *d_blks, int nblk);
 
 /* Pixel-domain mask blends of a list of blocks: svt_aom_[highbd_]blend_a64_mask (mode 0: 2-D mask at d_masks + mask_off with mask_stride, subw / subh = the
  * mask is at twice the block's resolution in that direction), _hmask (mode 1: one mask value per column) and _vmask (mode 2: per row)

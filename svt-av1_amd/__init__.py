@@ -164,6 +164,7 @@ def lib():
     L.svt_hip_compound_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_obmc_cost_batch_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     L.svt_hip_warp_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32]
+    L.svt_hip_warp_compound_batch_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, i32]
     L.svt_hip_blend_a64_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_deblock_frame_dev.argtypes = [vp, P3, i32, I3, i32, P3, P3, I3, I3, i32]
     L.svt_hip_picture_format_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32]

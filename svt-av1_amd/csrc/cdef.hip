@@ -447,8 +447,9 @@ cdef_search_chroma_kernel(const PIX* __restrict__ rec_u, const PIX* __restrict__
 }
 
 // ---------------------------------------------------------------------------------- apply -------
-// One workgroup per (filter block, plane).  in = pre-CDEF plane, out = result plane (pre-initialised
-// with a copy of `in`).  strength[fb] = frame-header value pri*4 + sec_idx chosen for the fb.
+// One workgroup per (filter block, plane).  in = pre-CDEF plane, out = result plane: every sample of the picture is written (samples of
+// unfiltered filter blocks and of skipped 8x8 blocks are passed through), so `out` needs no initial copy of `in`.
+// strength[fb] = frame-header value pri*4 + sec_idx chosen for the fb.
 template <typename PIX, int PLANE_KIND>  // 0 luma, 1 chroma
 __global__ void __launch_bounds__(256)
 cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride, int w, int h, const uint8_t* __restrict__ skip8,
@@ -462,7 +463,15 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ly = y_strength[fb] >> 2, sy = y_strength[fb] & 3, lu = uv_strength[fb] >> 2, su = uv_strength[fb] & 3;
     sy += sy == 3; su += su == 3;
-    if (ly == 0 && sy == 0 && lu == 0 && su == 0) return;  // EbEncCdef.c:434-441
+    if (ly == 0 && sy == 0 && lu == 0 && su == 0) {  // EbEncCdef.c:434-441: the filter block keeps the pre-CDEF samples
+        const int fw = min(FBS, (w >> DEC) - FBS * fbc), fh = min(FBS, (h >> DEC) - FBS * fbr);
+        for (int i = tid; i < fw * fh; i += 256) {
+            const int y = i / fw, x = i - y * fw;
+            const size_t o = (size_t)(FBS * fbr + y) * stride + FBS * fbc + x;
+            out[o] = in[o];
+        }
+        return;
+    }
     const int level = PLANE_KIND ? lu : ly, sec = (PLANE_KIND ? su : sy) << cs;
     stage_tile(tile, TS, in, stride, w >> DEC, h >> DEC, FBS * fbc, FBS * fbr, FBS, FBS, tid, 256);
     __syncthreads();
@@ -471,8 +480,12 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
         const int i = lane >> 3, j = lane & 7;
         for (int b = wave; b < 64; b += 4) {
             const int by = b >> 3, bx = b & 7;
-            if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) continue;
+            if (by >= nby || bx >= nbx) continue;
             const uint16_t* px = tile + (8 * by + i + kVB) * TS + 8 * bx + j + kHB;
+            if (skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) {   // skipped block: passed through
+                out[(size_t)(64 * fbr + 8 * by + i) * stride + 64 * fbc + 8 * bx + j] = (PIX)px[0];
+                continue;
+            }
             int var, dir;
             if (var_in) {   // the strength search already ran svt_cdef_find_dir on this picture: reuse its direction / variance
                 dir = dir_buf[fb * 64 + b]; var = var_in[fb * 64 + b];
@@ -488,8 +501,12 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
         const int q = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
         for (int strip = wave; strip < 16; strip += 4) {
             const int by = strip >> 1, bx = (strip & 1) * 4 + q;
-            if (by >= nby || bx >= nbx || skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) continue;
+            if (by >= nby || bx >= nbx) continue;
             const uint16_t* px = tile + (4 * by + i + kVB) * TS + 4 * bx + j + kHB;
+            if (skip8[(8 * fbr + by) * c8 + 8 * fbc + bx]) {
+                out[(size_t)(32 * fbr + 4 * by + i) * stride + 32 * fbc + 4 * bx + j] = (PIX)px[0];
+                continue;
+            }
             const int t = level << cs;
             const int dir = t ? dir_buf[fb * 64 + by * 8 + bx] : 0;
             const int y = filter_px_single(px, TS, t, sec, dir, cs, damping);

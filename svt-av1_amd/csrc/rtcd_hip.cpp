@@ -385,8 +385,10 @@ void blend_vmask_hbd_hip(uint8_t* dst, uint32_t ds, const uint8_t* s0, uint32_t 
 // ----------------------------------------------------------------------------------- warped prediction
 bool warp_generic(int pix_bytes, int bd, const int32_t* mat, const void* ref, int width, int height, int stride, void* pred, int p_col, int p_row, int p_width, int p_height,
                   int p_stride, int ss_x, int ss_y, const SvtHipConvolveParams* cp, int alpha, int beta, int gamma, int delta) {
-    if (!g_ctx || (cp && (cp->is_compound || cp->do_average)) || p_width < 8 || p_height < 8 || p_width > 128 || p_height > 128 || (p_width & 7) || (p_height & 7) ||
-        ss_x != ss_y || width <= 0 || height <= 0)
+    const bool comp = cp && cp->is_compound;
+    // the compound branches use av1's fixed rounding for compound prediction (round_0 3, 5 at 12 bits; round_1 = COMPOUND_ROUND1_BITS)
+    if (!g_ctx || (cp && !comp && cp->do_average) || (comp && (!cp->dst || cp->round_1 != 7 || cp->round_0 != (bd == 12 ? 5 : 3) || cp->dst_stride < p_width)) || p_width < 8 ||
+        p_height < 8 || p_width > 128 || p_height > 128 || (p_width & 7) || (p_height & 7) || ss_x != ss_y || width <= 0 || height <= 0)
         return false;
     // the whole reference plane is uploaded (the model decides which part is read); a production caller keeps it resident and uses the batched entry
     const size_t rp = rup((size_t)width * pix_bytes, 4), dp = rup((size_t)p_width * pix_bytes, 4);
@@ -398,6 +400,20 @@ bool warp_generic(int pix_bytes, int bd, const int32_t* mat, const void* ref, in
     job.p_col = p_col; job.p_row = p_row; job.p_width = (uint8_t)p_width; job.p_height = (uint8_t)p_height; job.reserved[0] = job.reserved[1] = 0;
     // destination pointer is biased so that (p_col, p_row) of the "plane" is element 0 of the packed block buffer
     uint8_t* d_plane0 = d_dst - ((ptrdiff_t)p_row * (ptrdiff_t)(dp / pix_bytes) + p_col) * pix_bytes;
+    if (comp) {   // first reference: the 16-bit compound buffer comes back; second reference: it goes up and the averaged pixels come back
+        const size_t cbp = rup((size_t)p_width * 2, 4);
+        uint16_t* d_cb = (uint16_t*)dev(3, cbp * p_height); void* d_cjob = dev(4, sizeof(SvtHipWarpCompBlk));
+        SvtHipWarpCompBlk cj = {};
+        cj.blk = job; cj.cb_off = 0; cj.cb_stride = (int32_t)(cbp / 2); cj.do_average = cp->do_average ? 1 : 0; cj.use_jnt_comp_avg = cp->use_jnt_comp_avg ? 1 : 0;
+        cj.fwd_offset = (uint8_t)cp->fwd_offset; cj.bck_offset = (uint8_t)cp->bck_offset;
+        if (!d_cb || !d_cjob || !up2d(d_ref, rp, ref, (size_t)stride * pix_bytes, (size_t)width * pix_bytes, height) || !up(d_cjob, &cj, sizeof(cj))) return false;
+        if (cp->do_average && !up2d(d_cb, cbp, cp->dst, (size_t)cp->dst_stride * 2, (size_t)p_width * 2, p_height)) return false;
+        if (svt_hip_warp_compound_batch_dev(g_ctx, pix_bytes, bd, d_ref, width, height, (int)(rp / pix_bytes), d_plane0, (int)(dp / pix_bytes), ss_x, ss_y, d_cb,
+                                            (const SvtHipWarpCompBlk*)d_cjob, 1) != 0)
+            return false;
+        return cp->do_average ? down2d(pred, (size_t)p_stride * pix_bytes, d_dst, dp, (size_t)p_width * pix_bytes, p_height)
+                              : down2d(cp->dst, (size_t)cp->dst_stride * 2, d_cb, cbp, (size_t)p_width * 2, p_height);
+    }
     return up2d(d_ref, rp, ref, (size_t)stride * pix_bytes, (size_t)width * pix_bytes, height) && up(d_job, &job, sizeof(job)) &&
            svt_hip_warp_predict_batch_dev(g_ctx, pix_bytes, bd, d_ref, width, height, (int)(rp / pix_bytes), d_plane0, (int)(dp / pix_bytes), ss_x, ss_y, (const SvtHipWarpBlk*)d_job, 1) == 0 &&
            down2d(pred, (size_t)p_stride * pix_bytes, d_dst, dp, (size_t)p_width * pix_bytes, p_height);

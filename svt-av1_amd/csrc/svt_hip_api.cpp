@@ -777,6 +777,20 @@ int svt_hip_warp_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const vo
     if (e != hipSuccess) return fail(c, e, "warp predict launch");
     return SVT_HIP_OK;
 }
+int svt_hip_warp_compound_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref, int width, int height, int stride, void* d_dst, int dst_stride,
+                                    int ss_x, int ss_y, uint16_t* d_convbuf, const SvtHipWarpCompBlk* d_blks, int nblk) {
+    SVT_HIP_ENTER(c);
+    if (!c || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10 && bd != 12) ||
+        (ss_x != 0 && ss_x != 1) || (ss_y != 0 && ss_y != 1)) {
+        if (c) c->err = "svt_hip_warp_compound_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    if (nblk == 0) return SVT_HIP_OK;
+    if (!d_ref || !d_convbuf || !d_blks || width <= 0 || height <= 0) return SVT_HIP_ERR_BAD_ARG;   // d_dst may be NULL when no block averages
+    hipError_t e = (hipError_t)svt_hip_launch_warp_compound(c->stream, pix_bytes, bd, d_ref, width, height, stride, d_dst, dst_stride, ss_x, ss_y, d_convbuf, d_blks, nblk);
+    if (e != hipSuccess) return fail(c, e, "warp compound launch");
+    return SVT_HIP_OK;
+}
 
 int svt_hip_blend_a64_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_src0, int src0_stride, const void* d_src1, int src1_stride, void* d_dst, int dst_stride,
                                 const uint8_t* d_masks, const SvtHipBlendBlk* d_blks, int nblk) {

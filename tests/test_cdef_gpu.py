@@ -58,7 +58,7 @@ def test_apply_frame(hip, orc, bd, size):
     exp = [p.copy() for p in rec]
     orc.orc_cdef_apply_frame(P3(*[p.ctypes.data for p in rec]), P3(*[p.ctypes.data for p in exp]), I3(*[p.shape[1] for p in rec]),
                              rec[0].itemsize, w, h, ptr(skip8), ptr(ys), ptr(uvs), 5, bd)
-    d_in = [hip.to_device(p) for p in rec]; d_out = [hip.to_device(p) for p in rec]
+    d_in = [hip.to_device(p) for p in rec]; d_out = [hip.to_device(np.full_like(p, 77)) for p in rec]   # every sample must be written: no initial copy
     d_skip, d_ys, d_uvs, d_dir = hip.to_device(skip8), hip.to_device(ys), hip.to_device(uvs), hip.empty(nfb * 64)
     hip.check(hip.L.svt_hip_cdef_apply_frame_dev(hip.h, rec[0].itemsize, P3(*[p.value for p in d_in]), P3(*[p.value for p in d_out]),
                                                 I3(*[p.shape[1] for p in rec]), w, h, d_skip, d_ys, d_uvs, 5, bd, d_dir, None), "cdef apply")

@@ -463,3 +463,30 @@ def test_per_call_forms_vs_reference_c(rtcd, ref):
         tp = TxfmParam(tt, ts, 0, 8, 0, 0, kw * kh)
         ref.svt_av1_inv_txfm_add_c(_vp(cfull), _vp(pred), w + 5, _vp(e), w + 2, C.byref(tp)); rtcd.svt_av1_inv_txfm_add(_vp(cfull), _vp(pred), w + 5, _vp(g), w + 2, C.byref(tp))
         assert np.array_equal(e, g), ("inv_txfm_add", ts)
+
+
+def test_compound_warp_vs_reference_c(rtcd, ref):
+    """The is_compound branches of svt_av1_warp_affine / svt_av1_highbd_warp_affine (Common/Codec/EbWarpedMotion.c:660-683, :812-835): first
+    reference into the 16-bit compound buffer, second reference averaged (plain and distance-weighted) into pixels — same calls to the reference's
+    `_c` function and to the wrapper."""
+    import comp_common as cmc
+    rng = np.random.default_rng(321)
+    W, H = 320, 200
+    for bd, dt in ((8, np.uint8), (10, np.uint16), (12, np.uint16)):
+        plane0 = rng.integers(0, 1 << bd, (H, W + 8)).astype(dt); plane1 = rng.integers(0, 1 << bd, (H, W + 8)).astype(dt)
+        for it, (pw, ph, pc, pr, ss) in enumerate(((8, 8, 0, 0, 0), (32, 16, 64, 40, 0), (64, 64, 128, 96, 1), (16, 32, 296, 160, 0), (128, 128, 64, 32, 0))):
+            for jnt, (fwd, bck) in ((0, (0, 0)), (1, (9, 7)), (1, (13, 3))):
+                m0 = cmc.warp_model(rng, extreme=(it == 3)); m1 = cmc.warp_model(rng)
+                res = []
+                for fns in ((ref.svt_av1_warp_affine_c, ref.svt_av1_highbd_warp_affine_c), (rtcd.svt_av1_warp_affine, rtcd.svt_av1_highbd_warp_affine)):
+                    cbuf = np.full((ph, pw + 6), 0xABCD, np.uint16); pred = np.full((ph, pw + 4), 5, dt)
+                    for second, (plane, (mat, a, b_, g, d)) in enumerate(((plane0, m0), (plane1, m1))):
+                        cp = ConvParams(0, second, cbuf.ctypes.data, pw + 6, 5 if bd == 12 else 3, 7, 0, 1, jnt, fwd, bck, jnt)
+                        m8 = (C.c_int32 * 8)(*mat, 0, 0)
+                        args = (m8, _vp(plane), W, H, plane.shape[1], _vp(pred), pc, pr, pw, ph, pw + 4, ss, ss)
+                        if bd == 8 and dt == np.uint8: fns[0](*args, C.byref(cp), a, b_, g, d)
+                        else: fns[1](*args, bd, C.byref(cp), a, b_, g, d)
+                        if second == 0: first = cbuf.copy()
+                    res.append((first, pred.copy()))
+                assert np.array_equal(res[0][0], res[1][0]), ("compound buffer", bd, it, jnt)
+                assert np.array_equal(res[0][1], res[1][1]) and (res[0][1][:, :pw] != 5).any(), ("averaged prediction", bd, it, jnt, fwd)
