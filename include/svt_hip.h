@@ -421,6 +421,13 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx *ctx, int pix_bytes, int bd, int 
 int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride,
                                int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep,
                                const int32_t *d_unit_xqd, const int16_t *d_unit_wiener);
+/* try_restoration_unit_seg (Encoder/Codec/EbRestorationPick.c:137-172): ONE restoration unit (index `unit` of the plane's unit grid) filtered with the
+ * type / parameters its entries of d_unit_ep / d_unit_xqd / d_unit_wiener hold — same rules, stripe handling and arguments as
+ * svt_hip_lr_apply_plane_dev, only the tiles of that unit are launched — and the unit's SSE against the source (sse_restoration_unit, :58) left in
+ * *d_sse (device).  This is the probe of finer_tile_search_wiener_seg (:1092) and of search_sgrproj_seg's final check. */
+int svt_hip_lr_try_unit_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride, int pw, int ph,
+                            int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep, const int32_t *d_unit_xqd,
+                            const int16_t *d_unit_wiener, const void *d_src, int src_stride, int unit, uint64_t *d_sse);
 
 /* ------------------------------------------------------------------ Wiener restoration search ---- */
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as

@@ -130,6 +130,13 @@ pick.sub(r'(\n[ \t]*)(av1_foreach_rest_unit_in_frame_seg\(rsc_p->cm,\s*rsc_p->pl
 pick.sub(r'(\n[ \t]*)(if \(cm->use_highbitdepth\)\s*svt_av1_compute_stats_highbd\(wiener_win,\s*rsc->dgd_buffer,)',
          r'\1if (svt_hip_hook_wiener_stats(rsc->hip_pcs, rsc->plane, wiener_win, rest_unit_idx, M, H) == EB_ErrorNone) {'
          r'\1} else \2')
+# try_restoration_unit_seg (:137): a RESTORE_WIENER probe (finer_tile_search_wiener_seg, :1092) is filtered and measured on the device
+pick.sub(r'(\n[ \t]*)(const int32_t optimized_lr = 0;\n)',
+         r'\1\2\1if (rui->restoration_type == RESTORE_WIENER) {'
+         r'\1    int64_t hip_err;'
+         r'\1    if (svt_hip_hook_wiener_try(rsc->hip_pcs, plane, limits->h_start, limits->h_end, limits->v_start, limits->v_end, &rui->wiener_info, &hip_err) == EB_ErrorNone)'
+         r'\1        return hip_err;'
+         r'\1}\n')
 PATCHES.append(pick)
 
 TAILS = {"Source/Lib/Encoder/Codec/EbMotionEstimation.c": ME_TAIL}

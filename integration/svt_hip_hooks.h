@@ -32,6 +32,7 @@ enum {
     SVT_HIP_HOOK_SGR_SEARCH,   /* search_sgrproj_seg of every unit (EbRestorationPick.c:1277, via restoration_seg_search :1537) */
     SVT_HIP_HOOK_WIENER_STATS, /* svt_av1_compute_stats[_highbd] of every unit in search_wiener_seg (EbRestorationPick.c:1347) */
     SVT_HIP_HOOK_REST_APPLY,   /* svt_av1_loop_restoration_filter_frame (EbRestProcess.c:548) */
+    SVT_HIP_HOOK_WIENER_TRY,   /* every try_restoration_unit_seg probe of finer_tile_search_wiener_seg (EbRestorationPick.c:1092, :137) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -88,6 +89,8 @@ EbErrorType svt_hip_hook_sgr_search(PictureControlSet *pcs);
 EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wiener_win, int unit_idx, int64_t *M, int64_t *H);
 /* rest_kernel: svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0) */
 EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs);
+/* one probe of the Wiener tap refinement: the unit [h_start, h_end) x [v_start, v_end) of `plane` filtered with `wi`, *err = its SSE against the source */
+EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err);
 /* rest_kernel, when the picture leaves the filter stages: releases its device state */
 void        svt_hip_hook_picture_done(PictureControlSet *pcs);
 

@@ -281,7 +281,7 @@ EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet
  * restoration filters come from the deblocked, pre-CDEF picture, which the host overwrites in place). */
 void svt_hip_hook_after_dlf(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH) && !svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH) &&
-        !svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS))
+        !svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_TRY))
         return;
     SvtHipCtx *hip = svt_hip_hooks_lock();
     if (!hip) return;
@@ -617,6 +617,41 @@ EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wie
     } else
         rc = EB_ErrorUndefined;
     svt_hip_hooks_unlock();
+    return rc;
+}
+
+/* try_restoration_unit_seg for a RESTORE_WIENER candidate (EbRestorationPick.c:137; the probe of finer_tile_search_wiener_seg, :1092): the unit is filtered
+ * on the device with the probed taps (stripe context rows from the deblocked picture kept there) and only its SSE comes back. */
+static EbErrorType wiener_try(SvtHipCtx *hip, LfState *s, int pl, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err) {
+    SvtHipLfPicture *p = &s->pic;
+    const Av1Common *cm = s->pcs->parent_pcs_ptr->av1_cm;
+    if (!(s->flags & ST_DBL) || !rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
+    const RestorationInfo *rsi = &cm->rst_info[pl];
+    const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), us = rsi->restoration_unit_size, n = rsi->units_per_tile, voff = 8 >> (pl > 0);
+    /* unit index from its rectangle: columns start at j * us, rows at i * us - voff (0 for the first row), EbRestoration.c:1369-1411 */
+    const int j = h_start / us, i = v_start > 0 ? (v_start + voff) / us : 0, u = i * rsi->horz_units_per_tile + j;
+    if (u < 0 || u >= n || h_end <= h_start || v_end <= v_start) return EB_ErrorUndefined;
+    uint8_t ep = 254;   /* RESTORE_WIENER */
+    int16_t wn[16];
+    memcpy(wn, wi->vfilter, 8 * sizeof(int16_t)); memcpy(wn + 8, wi->hfilter, 8 * sizeof(int16_t));
+    uint64_t sse = 0;
+    HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl] + u, &ep, 1));
+    HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl] + 16 * u, wn, sizeof(wn)));
+    HIP_TRY(svt_hip_lr_try_unit_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl], pw, ph, us,
+                                    pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl], p->d_unit_wiener[pl], p->d_src[pl],
+                                    p->src_stride[pl], u, p->d_sse));
+    HIP_TRY(svt_hip_memcpy_d2h(hip, &sse, p->d_sse, sizeof(sse)));
+    *err = (int64_t)sse;
+    return EB_ErrorNone;
+}
+EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_TRY)) return EB_ErrorUndefined;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return EB_ErrorUndefined;
+    LfState    *s = state_of(hip, pcs, 0);
+    EbErrorType rc = s ? wiener_try(hip, s, plane, h_start, h_end, v_start, v_end, wi, err) : EB_ErrorUndefined;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_WIENER_TRY, rc == EB_ErrorNone);
     return rc;
 }
 

@@ -168,6 +168,26 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *
     if (perturb("rest_apply")) ((uint8_t *)dst)[(size_t)9 * dst_stride * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
+int svt_hip_lr_try_unit_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph, int unit_size, int ss_y,
+                            const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener, const void *src, int src_stride,
+                            int unit, uint64_t *sse) {
+    /* the double filters the whole plane (the units other than `unit` are whatever their entries say) and measures the unit's rectangle */
+    const int ux = orc_rest_units(pw, unit_size), uy = orc_rest_units(ph, unit_size), voff = 8 >> ss_y;
+    if (unit < 0 || unit >= ux * uy) return SVT_HIP_ERR_BAD_ARG;
+    uint8_t *ep1 = (uint8_t *)malloc((size_t)ux * uy);   /* only `unit` is filtered: every other unit is RESTORE_NONE here (their entries may be unset) */
+    if (!ep1) return SVT_HIP_ERR_RUNTIME;
+    memset(ep1, 255, (size_t)ux * uy);
+    ep1[unit] = unit_ep[unit];
+    const int rc = svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, ep1, unit_xqd, unit_wiener);
+    free(ep1);
+    if (rc != SVT_HIP_OK) return rc;
+    const int uj = unit % ux, ui = unit / ux, x0 = uj * unit_size, w = uj == ux - 1 ? pw - x0 : unit_size, y0 = ui * unit_size, h = ui == uy - 1 ? ph - y0 : unit_size;
+    const int v0 = y0 - voff > 0 ? y0 - voff : 0, v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
+    *sse = orc_plane_sse(pix_bytes, (const uint8_t *)src + ((size_t)v0 * src_stride + x0) * pix_bytes, src_stride,
+                         (const uint8_t *)dst + ((size_t)v0 * dst_stride + x0) * pix_bytes, dst_stride, w, v1 - v0);
+    if (perturb("wiener_try")) { static unsigned n_call; *sse += (uint64_t)((n_call++ * 2654435761u) >> 20); }   /* a different wrong answer per probe: comparisons flip */
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
                                 int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd) {
     return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, NULL);

@@ -598,11 +598,11 @@ template <typename PIX, int BD = 8>
 __global__ void __launch_bounds__(256)
 lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
                  int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
-                 const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener) {
+                 const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener, int tile_x0, int tile_y0) {
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];
     __shared__ uint32_t xt[256];
-    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;
+    const int x0 = (blockIdx.x + tile_x0) * S_TW, y0 = (blockIdx.y + tile_y0) * S_TH - voff, tid = threadIdx.x;   // (tile_x0, tile_y0): first tile of a partial launch
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     const int ep = unit_ep[unit];
     const bool wiener = ep == 254 && unit_wiener != nullptr;
@@ -734,13 +734,21 @@ extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int 
     else hipLaunchKernelGGL((sgr_proj_error_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, ncand, xqd, e);
     return (int)hipGetLastError();
 }
+extern "C" int svt_hip_launch_sgr_apply_tiles(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,
+                                              int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
+                                              const uint8_t* unit_ep, const int32_t* unit_xqd, const int16_t* unit_wiener, int tx0, int ty0, int ntx, int nty) {
+    const int voff = 8 >> ss_y, sh = 64 >> ss_y;
+    if (ntx <= 0 || nty <= 0) return 0;
+    dim3 grid8(ntx, nty);
+    if (pix_bytes == 1) hipLaunchKernelGGL((lr_apply8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener, tx0, ty0);
+    else if (bd == 8) hipLaunchKernelGGL((lr_apply8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener, tx0, ty0);
+    else hipLaunchKernelGGL((lr_apply8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener, tx0, ty0);
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw,
                                         int ph, int unit_size, int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride,
                                         const uint8_t* unit_ep, const int32_t* unit_xqd, const int16_t* unit_wiener) {
-    const int voff = 8 >> ss_y, sh = 64 >> ss_y;
-    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
-    if (pix_bytes == 1) hipLaunchKernelGGL((lr_apply8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (uint8_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
-    else if (bd == 8) hipLaunchKernelGGL((lr_apply8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
-    else hipLaunchKernelGGL((lr_apply8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (uint16_t*)dst, dst_stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
-    return (int)hipGetLastError();
+    const int voff = 8 >> ss_y;
+    return svt_hip_launch_sgr_apply_tiles(st, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, units_x, units_y, ss_y, dbl, dbl_stride, unit_ep, unit_xqd,
+                                          unit_wiener, 0, 0, (pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
 }

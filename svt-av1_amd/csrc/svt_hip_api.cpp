@@ -528,6 +528,32 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* 
     if (e != hipSuccess) return fail(c, e, "sgr apply launch");
     return SVT_HIP_OK;
 }
+int svt_hip_lr_try_unit_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw, int ph, int unit_size, int ss_y,
+                            const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd, const int16_t* d_unit_wiener, const void* d_src,
+                            int src_stride, int unit, uint64_t* d_sse) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_dgd || !d_dst || !d_unit_ep || !d_unit_xqd || !d_src || !d_sse || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
+        !sgr_args_ok(pix_bytes, bd, pw, ph))
+        return SVT_HIP_ERR_BAD_ARG;
+    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
+    if (unit < 0 || unit >= ux * uy) return SVT_HIP_ERR_BAD_ARG;
+    // the unit's rectangle: foreach_rest_unit_in_tile (Common/Codec/EbRestoration.c:1369-1411) — the last unit of a row / column takes the remainder
+    const int uj = unit % ux, ui = unit / ux, voff = 8 >> ss_y;
+    const int x0 = uj * unit_size, w = uj == ux - 1 ? pw - x0 : unit_size;
+    const int y0 = ui * unit_size, h = ui == uy - 1 ? ph - y0 : unit_size;
+    const int v0 = y0 - voff > 0 ? y0 - voff : 0, v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
+    // tiles are 64 x 32 starting at (0, -voff): unit boundaries fall on tile boundaries
+    const int tx0 = x0 / 64, tx1 = (x0 + w + 63) / 64, ty0 = (v0 + voff) / 32, ty1 = (v1 + voff + 31) / 32;
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_apply_tiles(c->stream, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size, ux, uy, ss_y, d_dbl, dbl_stride,
+                                                             d_unit_ep, d_unit_xqd, d_unit_wiener, tx0, ty0, tx1 - tx0, ty1 - ty0);
+    if (e != hipSuccess) return fail(c, e, "restoration unit launch");
+    HIPCHK(c, hipMemsetAsync(d_sse, 0, sizeof(uint64_t), c->stream));
+    const uint8_t* a = (const uint8_t*)d_src + ((size_t)v0 * src_stride + x0) * pix_bytes;
+    const uint8_t* b = (const uint8_t*)d_dst + ((size_t)v0 * dst_stride + x0) * pix_bytes;
+    e = (hipError_t)svt_hip_launch_plane_sse(c->stream, pix_bytes, a, src_stride, b, dst_stride, w, v1 - v0, d_sse);
+    if (e != hipSuccess) return fail(c, e, "restoration unit sse launch");
+    return SVT_HIP_OK;
+}
 
 int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                      int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand, const int32_t* d_xqd, int64_t* d_err) {

@@ -40,6 +40,9 @@ int svt_hip_launch_compound_predict(hipStream_t st, int pix_bytes, int bd, const
 int svt_hip_launch_obmc_cost(hipStream_t st, const uint8_t* pre, int pre_stride, const int32_t* wsrc, const int32_t* mask, const SvtHipObmcBlk* blks, int n, uint32_t* out);
 int svt_hip_launch_warp_predict(hipStream_t st, int pix_bytes, int bd, const void* ref, int width, int height, int stride, void* dst, int dst_stride, int ss_x,
                                 int ss_y, const SvtHipWarpBlk* blks, int n);
+int svt_hip_launch_sgr_apply_tiles(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, void* dst, int dst_stride, int pw, int ph, int unit_size,
+                                   int units_x, int units_y, int ss_y, const void* dbl, int dbl_stride, const uint8_t* unit_ep, const int32_t* unit_xqd,
+                                   const int16_t* unit_wiener, int tx0, int ty0, int ntx, int nty);
 int svt_hip_launch_warp_compound(hipStream_t st, int pix_bytes, int bd, const void* ref, int width, int height, int stride, void* dst, int dst_stride, int ss_x,
                                  int ss_y, uint16_t* convbuf, const SvtHipWarpCompBlk* blks, int n);
 int svt_hip_launch_blend_a64(hipStream_t st, int pix_bytes, const void* src0, int src0_stride, const void* src1, int src1_stride, void* dst, int dst_stride,

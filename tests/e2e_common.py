@@ -14,7 +14,7 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 APP_REF = os.path.join(REFDIR, "SvtAv1EncApp_ref")
 APP_HIP = os.path.join(REFDIR, "SvtAv1EncApp_hip")
 MOCK_DIR = os.path.join(REFDIR, "mock")
-HOOKS = ["me", "dlf", "dlf_search", "cdef_search", "cdef_apply", "sgr_search", "wiener_stats", "rest_apply"]
+HOOKS = ["me", "dlf", "dlf_search", "cdef_search", "cdef_apply", "sgr_search", "wiener_stats", "rest_apply", "wiener_try"]
 
 
 def have_apps():

@@ -134,8 +134,26 @@ def test_mixed_wiener_sgr_apply(hip, orc, bd, ss):
         d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst = hip.to_device(ext), hip.to_device(dbl), hip.to_device(u_ep), hip.to_device(u_xqd), hip.to_device(u_wn), hip.to_device(np.zeros_like(exp))
         hip.check(hip.L.svt_hip_lr_apply_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_dst, w, w, h, US, ss, d_dbl, w, d_ep, d_xqd, d_wn), "lr apply")
         got = hip.to_host(d_dst, (h, w), ext.dtype)
-        hip.free(d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst)
         assert np.array_equal(got, exp), (bd, ss, w, h, US, np.argwhere(got != exp)[:5])
+        # svt_hip_lr_try_unit_dev = try_restoration_unit_seg: ONE unit filtered (only its tiles are launched: the rest of the destination keeps the
+        # marker) and its SSE against the source, for every unit of the plane incl. the over-sized last row / column
+        d_src2, d_sse = hip.to_device(src), hip.to_device(np.zeros(1, np.uint64))
+        voff = 8 >> ss; ux, uy = units(w, US), units(h, US)
+        for u in range(nu):
+            d_one = hip.to_device(np.full_like(exp, 7))
+            hip.check(hip.L.svt_hip_lr_try_unit_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_one, w, w, h, US, ss, d_dbl, w, d_ep, d_xqd, d_wn, d_src2, w, u, d_sse), "try unit")
+            one = hip.to_host(d_one, (h, w), ext.dtype); sse = int(hip.to_host(d_sse, (1,), np.uint64)[0])
+            uj, ui = u % ux, u // ux
+            x0 = uj * US; x1 = w if uj == ux - 1 else x0 + US
+            y0 = ui * US; y1 = h if ui == uy - 1 else y0 + US
+            v0 = max(y0 - voff, 0); v1 = y1 - voff if y1 < h else y1
+            ref_rect = exp[v0:v1, x0:x1].astype(np.int64); src_rect = src[v0:v1, x0:x1].astype(np.int64)
+            assert np.array_equal(one[v0:v1, x0:x1], exp[v0:v1, x0:x1]), ("try unit pixels", bd, ss, US, u)
+            mask = np.ones((h, w), bool); mask[v0:v1, x0:x1] = False
+            assert (one[mask] == 7).all(), ("try unit touched samples outside its unit", bd, ss, US, u)
+            assert sse == int(((ref_rect - src_rect) ** 2).sum()), ("try unit sse", bd, ss, US, u)
+            hip.free(d_one)
+        hip.free(d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst, d_src2, d_sse)
 
 
 @pytest.mark.parametrize("bd", [8, 10])
