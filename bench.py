@@ -46,6 +46,7 @@ BYTES_PER_SB = {
     "me_fullpel_85pu": 8872,                 # 4096 src + 4096 ref (amortised) + 85*8 out
     "fwd_txfm_quant": 61440 + 128,           # (src+pred 2*6144) + qcoeff+dqcoeff 2*4*6144 + eob   (luma+chroma)
     "inv_txfm_recon": 36864,                 # dqcoeff 4*6144 + pred 6144 + recon 6144
+    "fwd_quant_inv_recon": 2 * 6144 + 4 * 6144 + 6144 + 128,   # fused: src + pred in, levels + recon out (the dequantised coefficients stay in registers)
     "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
     "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
     "cdef_apply": 12288 + 12288,             # 6144 R + 6144 W, plus the device-to-device copy that initialises the destination (R + W)
@@ -57,7 +58,7 @@ BYTES_PER_SB = {
 }
 STAGE_KERNELS = {
     "pyramids": "downsample_kernel+variance_pyramid_kernel", "hme_l0_l1_l2": "sad_loop_kernel", "me_fullpel_85pu": "me_fullpel_85pu_kernel",
-    "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel",
+    "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel", "fwd_quant_inv_recon": "enc_txfm_multi_kernel",
     "deblock": "deblock_frame_pass_kernel", "cdef_search": "cdef_search_luma_kernel+cdef_search_chroma_kernel", "cdef_apply": "cdef_apply_kernel",
     "sgr_units_search": "sgr_search8_kernel+sgr_walk_resident_kernel", "sgr_apply": "lr_apply8_kernel",
 }
@@ -126,6 +127,12 @@ class Pipeline:
             self.FJ[k] = pkg.FwdTxJob(j["ts"], j["n"], self.d_cur[p].data_ptr(), self.strides[p], self.d_pred[p].data_ptr(), self.strides[p], j["desc"].data_ptr(), j["qs"], j["st"],
                                       None, j["q"].data_ptr(), j["dq"].data_ptr(), j["eob"].data_ptr(), j["cul"].data_ptr(), None)
             self.IJ[k] = pkg.InvTxJob(j["ts"], j["n"], j["dq"].data_ptr(), self.d_pred[p].data_ptr(), self.strides[p], self.p_recon[p], self.xs[p], j["desc"].data_ptr())
+        self.EJ = (pkg.EncTxJob * len(self.tx_jobs))()   # the fused form: no dequantised coefficients in memory
+        for k, j in enumerate(self.tx_jobs):
+            p = j["plane"]
+            self.EJ[k].fwd = pkg.FwdTxJob(j["ts"], j["n"], self.d_cur[p].data_ptr(), self.strides[p], self.d_pred[p].data_ptr(), self.strides[p], j["desc"].data_ptr(), j["qs"],
+                                          j["st"], None, j["q"].data_ptr(), None, j["eob"].data_ptr(), j["cul"].data_ptr(), None)
+            self.EJ[k].d_recon = self.p_recon[p]; self.EJ[k].recon_stride = self.xs[p]
         self.d_edges = [(T(ev), T(eh), ev.shape[1], ev.shape[0]) for ev, eh in F.edges]
         self.d_skip8 = T(F.skip8)
         self.d_mse = torch.zeros((2, self.n_sb, 64), dtype=torch.int64, device=dev)
@@ -157,7 +164,8 @@ class Pipeline:
         self.d_uerr = [torch.zeros((n, 16), dtype=torch.int64, device=dev) for n in self.n_units]
         self.d_ubest = [torch.zeros(n, dtype=torch.uint8, device=dev) for n in self.n_units]
         self.d_ubx = [torch.zeros((n, 2), dtype=torch.int32, device=dev) for n in self.n_units]
-        self.stage_fns = dict(pyr=self.run_pyramids, hme=self.run_hme, me=self.run_me, subpel=self.run_subpel, txfm=self.run_txfm, inv=self.run_inv, dlf=self.run_dlf,
+        self.stage_fns = dict(pyr=self.run_pyramids, hme=self.run_hme, me=self.run_me, subpel=self.run_subpel, txfm=self.run_txfm, inv=self.run_inv, enc_txfm=self.run_enc_txfm,
+                              dlf=self.run_dlf,
                               cdef_search=self.run_cdef_search, cdef_apply=self.run_cdef_apply, sgr_units=self.run_sgr_units, sgr_apply=self.run_sgr_apply)
 
     # ---------------------------------------------------------------- the kernel classes of a step
@@ -171,6 +179,9 @@ class Pipeline:
 
     def run_txfm(self):   # one mixed-size launch per 16 (size, plane) job lists: the 19 lists of a frame are 400-4000 blocks each
         self.chk(self.E.L.svt_hip_fwd_txfm_quant_multi_dev(self.E.ctx.h, 1, self.FJ, len(self.tx_jobs)), "fwd")
+
+    def run_enc_txfm(self):   # residual -> forward -> quantize -> inverse -> reconstruction, one launch per 16 job lists
+        self.chk(self.E.L.svt_hip_enc_txfm_multi_dev(self.E.ctx.h, 1, 8, self.EJ, len(self.tx_jobs)), "enc txfm")
 
     def run_inv(self):
         self.chk(self.E.L.svt_hip_inv_txfm_add_multi_dev(self.E.ctx.h, 1, 8, self.IJ, len(self.tx_jobs)), "inv")
@@ -227,8 +238,8 @@ class Pipeline:
                                                    self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr()), "sgr apply")
 
 
-ALL_STAGES = [("pyr", "pyramids"), ("hme", "hme_l0_l1_l2"), ("me", "me_fullpel_85pu"), ("subpel", "subpel_convolve"), ("txfm", "fwd_txfm_quant"),
-              ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
+ALL_STAGES = [("pyr", "pyramids"), ("hme", "hme_l0_l1_l2"), ("me", "me_fullpel_85pu"), ("subpel", "subpel_convolve"), ("enc_txfm", "fwd_quant_inv_recon"),
+              ("txfm", "fwd_txfm_quant"), ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
               ("sgr_apply", "sgr_apply")]
 
 
@@ -292,7 +303,8 @@ def main():
     pipes = [Pipeline(E, F, rank) for F in frames]
     n_sb = pipes[0].n_sb
     want = None if args.stages == "all" else set(args.stages.split(","))
-    stages = [(k, n) for k, n in ALL_STAGES if want is None or k in want]
+    # default: the fused transform stage; the separate forward / inverse launches remain selectable (--stages ...,txfm,inv,...)
+    stages = [(k, n) for k, n in ALL_STAGES if (k not in ("txfm", "inv") if want is None else k in want)]
 
     # ---------------------------------------------------------------- streams / graphs
     # A frame's step is two chains: the source side (pyramids -> HME -> ME; open loop, reads source pictures only) and the reconstruction side
@@ -666,7 +678,7 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
         n = min(F.n_sb, cores * 8)
         t = par(lambda be: mc.oracle_frame(orc, F.cur_y_p, F.ref_y_p, F.cur_y_p.shape[1], F.pad, sbs, 0, be[0], be[1]), split(n))
         sec_per_sb["me_fullpel_85pu"] = t / n
-    if "txfm" in keys or "inv" in keys:
+    if "txfm" in keys or "inv" in keys or "enc_txfm" in keys:
         # forward + quant + inverse chain on every block list, first `frac` of each list
         recon = [np.zeros_like(p) for p in F.ref]
         total_blocks_px, t_sum = 0, 0.0
@@ -858,7 +870,7 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
         CB_, nb = jobs["conv"]
         dst = np.zeros((H_, W_), np.uint8)
         sec["subpel_convolve"] = run(2, [F.ref_y_p.ctypes.data + org, st, dst, W_, CB_], nb, 64, name="subpel_convolve", one_thread_items=16 * 512) / n_sb
-    if "txfm" in keys or "inv" in keys:
+    if "txfm" in keys or "inv" in keys or "enc_txfm" in keys:
         recon = [np.zeros_like(p) for p in F.ref]
         t_sum = 0.0
         for (kind, ts), descs in sorted(F.descs.items()):

@@ -173,6 +173,15 @@ typedef struct {
     const uint32_t *d_descs;
 } SvtHipInvTxJob;
 int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx *ctx, int pix_bytes, const SvtHipFwdTxJob *jobs, int njobs);
+/* The encode loop's per-block chain in ONE launch (Encoder/Codec/EbCodingLoop.c:379-596: residual -> forward transform -> quantize -> inverse
+ * quantize -> inverse transform -> reconstruction): the job lists of svt_hip_fwd_txfm_quant_multi_dev with the reconstruction plane of each job.
+ * The dequantised coefficients go from the quantizer to the inverse transform in registers; fwd.d_qcoeff is required, fwd.d_dqcoeff may be NULL
+ * (then they are never written).  d_recon may be the prediction plane itself (in-place reconstruction) when no two blocks of a job overlap. */
+typedef struct {
+    SvtHipFwdTxJob fwd;
+    void *d_recon; int32_t recon_stride;
+} SvtHipEncTxJob;
+int svt_hip_enc_txfm_multi_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const SvtHipEncTxJob *jobs, int njobs);
 int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const SvtHipInvTxJob *jobs, int njobs);
 
 /* ------------------------------------------------------------------ deblocking loop filter ------ */

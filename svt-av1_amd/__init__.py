@@ -73,6 +73,11 @@ class FwdTxJob(C.Structure):
                 ("d_qcoeff", C.c_void_p), ("d_dqcoeff", C.c_void_p), ("d_eob", C.c_void_p), ("d_cul_level", C.c_void_p), ("d_energy", C.c_void_p)]
 
 
+class EncTxJob(C.Structure):
+    """SvtHipEncTxJob (include/svt_hip.h)."""
+    _fields_ = [("fwd", FwdTxJob), ("d_recon", C.c_void_p), ("recon_stride", C.c_int32)]
+
+
 class InvTxJob(C.Structure):
     """SvtHipInvTxJob (include/svt_hip.h)."""
     _fields_ = [("tx_size", C.c_int32), ("nblk", C.c_int32), ("d_dqcoeff", C.c_void_p), ("d_pred", C.c_void_p), ("pred_stride", C.c_int32),
@@ -137,6 +142,7 @@ def lib():
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     L.svt_hip_fwd_txfm_quant_multi_dev.argtypes = [vp, i32, vp, i32]
+    L.svt_hip_enc_txfm_multi_dev.argtypes = [vp, i32, i32, C.POINTER(EncTxJob), i32]
     L.svt_hip_inv_txfm_add_multi_dev.argtypes = [vp, i32, i32, vp, i32]
     L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]

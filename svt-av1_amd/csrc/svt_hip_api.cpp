@@ -354,6 +354,21 @@ int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFw
     if (e != hipSuccess) return fail(c, e, "fwd_txfm_quant multi launch");
     return SVT_HIP_OK;
 }
+int svt_hip_enc_txfm_multi_dev(SvtHipCtx* c, int pix_bytes, int bd, const SvtHipEncTxJob* jobs, int njobs) {
+    SVT_HIP_ENTER(c);
+    if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8)) return SVT_HIP_ERR_BAD_ARG;
+    for (int j = 0; j < njobs; j++) {
+        const SvtHipFwdTxJob& J = jobs[j].fwd;
+        if (J.nblk < 0 || J.tx_size < 0 || J.tx_size > 18 || (J.nblk && (!J.d_src || !J.d_pred || !J.d_descs || !J.d_qcoeff || !jobs[j].d_recon || !J.scans.iscan[0])) ||
+            J.qp.variant < 0 || J.qp.variant > 3 || J.qp.log_scale < 0 || J.qp.log_scale > 2 || J.qp.coeff_shape < 0 || J.qp.coeff_shape > 3) {
+            c->err = "svt_hip_enc_txfm_multi_dev: bad job";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_enc_txfm_multi(c->stream, pix_bytes, bd, jobs, njobs);
+    if (e != hipSuccess) return fail(c, e, "encode transform multi launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_inv_txfm_add_multi_dev(SvtHipCtx* c, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs) {
     SVT_HIP_ENTER(c);
     if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8))

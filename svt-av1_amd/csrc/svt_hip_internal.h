@@ -18,6 +18,7 @@ int svt_hip_launch_fwd_txfm_quant(hipStream_t st, int tx_size, int pix_bytes, co
 int svt_hip_launch_inv_txfm_add(hipStream_t st, int tx_size, int pix_bytes, int bd, const int32_t* dqcoeff, const void* pred,
                                 int pred_stride, void* recon, int recon_stride, const uint32_t* descs, int nblk);
 int svt_hip_launch_fwd_txfm_quant_multi(hipStream_t st, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs);
+int svt_hip_launch_enc_txfm_multi(hipStream_t st, int pix_bytes, int bd, const SvtHipEncTxJob* jobs, int njobs);
 int svt_hip_launch_inv_txfm_add_multi(hipStream_t st, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs);
 int svt_hip_launch_deblock_frame(hipStream_t st, void* const plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t* const ev[3],
                                  const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness);

@@ -102,16 +102,72 @@ template <int L> __device__ __forceinline__ uint64_t team_add64(uint64_t v) {
     return v;
 }
 
+// ================================================================== inverse passes (shared by inv_block and the fused encode block) =====
+// Row pass of the inverse for row t of a block: `row` = the KW kept dequantised coefficients of the row (registers), written transformed to `tile_row`.
+template <int W, int H, int BD>
+__device__ __forceinline__ void inv_row_pass(int kr, int t, const int32_t* row, int32_t* __restrict__ tile_row) {
+    constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H;
+    constexpr int S0 = -inv_shift0_of(W, H);
+    constexpr bool RECT2 = (W == 2 * H) || (H == 2 * W);
+    constexpr int RNG_ROW = BD == 8 ? 16 : 18;     // svt_av1_gen_inv_stage_range, EbInvTransforms.c:23-60
+    constexpr int IN_CLAMP = BD + 8;
+    int32_t out[W];
+    if (t < KH) {
+        int32_t in[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t v = 0;
+            if (c < KW) v = row[c];
+            if (RECT2) v = mul_inv_sqrt2(v);
+            in[c] = clampv<IN_CLAMP>(v);
+        }
+        inv_1d<W, 12, RNG_ROW>(kr, in, out);
+#pragma unroll
+        for (int c = 0; c < W; c++) out[c] = S0 ? rshift_round(out[c], S0 ? S0 : 1) : out[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) out[c] = 0;  // rows beyond the kept 32 are zero in, zero out
+    }
+#pragma unroll
+    for (int c = 0; c < W; c++) tile_row[c] = out[c];
+}
+// Column pass for column t + add to the prediction + clip: tile_team = the team's H x (W + 1) tile of row-pass outputs.
+template <int W, int H, int BD, typename PIX>
+__device__ __forceinline__ void inv_col_pass(const int32_t* __restrict__ tile_team, int t, int kc, int kr, const PIX* pred, int pred_stride, PIX* recon,
+                                             int recon_stride, int bx, int by) {
+    constexpr int RNG_COL = 16, COL_CLAMP = (BD + 6 > 16) ? BD + 6 : 16, S1 = 4, LS = W + 1;
+    int32_t in[H], out[H];
+    const int cs = (kr == 2) ? W - 1 - t : t;
+#pragma unroll
+    for (int r = 0; r < H; r++) in[r] = clampv<COL_CLAMP>(tile_team[r * LS + cs]);
+    inv_1d<H, 12, RNG_COL>(kc, in, out);
+    constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), res_min = -res_max - 1;  // check_range, :2398-2411
+    constexpr int32_t pix_max = (1 << BD) - 1;
+    const PIX* p = pred + (size_t)by * pred_stride + bx + t;
+    PIX* w = recon + (size_t)by * recon_stride + bx + t;
+#pragma unroll
+    for (int r = 0; r < H; r++) {
+        const int rr = (kc == 2) ? H - 1 - r : r;
+        int32_t v = rshift_round(out[rr], S1);
+        v = min(max(v, res_min), res_max);
+        const int32_t px = (int32_t)p[(size_t)r * pred_stride] + v;
+        w[(size_t)r * recon_stride] = (PIX)min(max(px, 0), pix_max);
+    }
+}
+
 // ================================================================== forward + quantize ==========
 // One workgroup's share of a forward launch: blocks [wg * TEAMS, (wg + 1) * TEAMS) of the list.  `tile` is TEAMS * H * (W + 1) dwords of
 // LDS.  Called by the single-size kernel and by the mixed-size kernel (where the workgroup always has 256 threads: threads beyond
 // threads_of(W, H) only take part in the barrier and the shuffles).
-template <int W, int H, typename PIX>
+// FBD = 0: forward + quantize only.  FBD = 8 / 10: the block is also reconstructed (the encode loop's fwd -> quant -> inverse -> recon per block,
+// EbCodingLoop.c:379-596): the forward pass ends with thread t holding row t of the dequantised coefficients, which is exactly what the inverse's row
+// pass of thread t starts from, so they never leave registers; qcoeff is required, dqcoeff may be NULL.
+template <int W, int H, typename PIX, int FBD = 0>
 __device__ __forceinline__ void fwd_block(int32_t* __restrict__ tile, int wg, int tid, const PIX* __restrict__ src, int src_stride,
                                           const PIX* __restrict__ pred, int pred_stride, const uint32_t* __restrict__ descs, int nblk,
                                           const SvtHipQuantParams& qp, const SvtHipScanTables& scans, int32_t* __restrict__ coeff_out,
                                           int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob_out,
-                                          int32_t* __restrict__ cul_out, uint64_t* __restrict__ energy_out) {
+                                          int32_t* __restrict__ cul_out, uint64_t* __restrict__ energy_out, PIX* recon = nullptr, int recon_stride = 0) {
     constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
     constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H, NK = KW * KH;
     constexpr int S0 = fwd_shift_of(W, H, 0), S1 = -fwd_shift_of(W, H, 1), S2 = -fwd_shift_of(W, H, 2);
@@ -194,9 +250,13 @@ __device__ __forceinline__ void fwd_block(int32_t* __restrict__ tile, int wg, in
 #pragma unroll
                 for (int c = 0; c < KW; c += 4) {
                     *(int4*)(qcoeff + base + c)  = make_int4(qv[c], qv[c + 1], qv[c + 2], qv[c + 3]);
-                    *(int4*)(dqcoeff + base + c) = make_int4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+                    if (!FBD || dqcoeff) *(int4*)(dqcoeff + base + c) = make_int4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
                 }
+                if constexpr (FBD != 0) inv_row_pass<W, H, FBD>(kr, t, dv, tile + team * TS + t * LS);   // row t of the tile was only ever read by this thread
             }
+        }
+        if constexpr (FBD != 0) {
+            if (t >= KH) { const int32_t none[1] = {0}; inv_row_pass<W, H, FBD>(kr, t, none, tile + team * TS + t * LS); }
         }
     }
     // team reductions (all 64 lanes of each wave execute the shuffles)
@@ -211,6 +271,10 @@ __device__ __forceinline__ void fwd_block(int32_t* __restrict__ tile, int wg, in
             cul_out[blk] = cul;
         }
         if (energy_out) energy_out[blk] = energy;
+    }
+    if constexpr (FBD != 0) {
+        __syncthreads();
+        if (live && t < W) inv_col_pass<W, H, FBD, PIX>(tile + team * TS, t, kc, kr, pred, pred_stride, recon, recon_stride, bx, by);
     }
 }
 
@@ -232,10 +296,6 @@ __device__ __forceinline__ void inv_block(int32_t* __restrict__ tile, int wg, in
                                           int pred_stride, PIX* recon, int recon_stride, const uint32_t* __restrict__ descs, int nblk) {
     constexpr int L = W > H ? W : H, TEAMS = threads_of(W, H) / L;
     constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H, NK = KW * KH;
-    constexpr int S0 = -inv_shift0_of(W, H), S1 = 4;
-    constexpr bool RECT2 = (W == 2 * H) || (H == 2 * W);
-    constexpr int RNG_ROW = BD == 8 ? 16 : 18, RNG_COL = 16;     // svt_av1_gen_inv_stage_range, EbInvTransforms.c:23-60
-    constexpr int IN_CLAMP = BD + 8, COL_CLAMP = (BD + 6 > 16) ? BD + 6 : 16;
     constexpr int LS = W + 1;
     constexpr int TS = H * LS;
 
@@ -247,47 +307,16 @@ __device__ __forceinline__ void inv_block(int32_t* __restrict__ tile, int wg, in
     const int kc = kVtx[tt], kr = kHtx[tt];
 
     if (live && t < H) {
-        int32_t out[W];
+        int32_t row[KW];
         if (t < KH) {
-            int32_t in[W];
             const int32_t* src = dqcoeff + (size_t)blk * NK + (size_t)t * KW;
 #pragma unroll
-            for (int c = 0; c < W; c++) {
-                int32_t v = 0;
-                if (c < KW) v = src[c];
-                if (RECT2) v = mul_inv_sqrt2(v);
-                in[c] = clampv<IN_CLAMP>(v);
-            }
-            inv_1d<W, 12, RNG_ROW>(kr, in, out);
-#pragma unroll
-            for (int c = 0; c < W; c++) out[c] = S0 ? rshift_round(out[c], S0 ? S0 : 1) : out[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < W; c++) out[c] = 0;  // rows beyond the kept 32 are zero in, zero out
+            for (int c = 0; c < KW; c++) row[c] = src[c];
         }
-#pragma unroll
-        for (int c = 0; c < W; c++) tile[team * TS + t * LS + c] = out[c];
+        inv_row_pass<W, H, BD>(kr, t, row, tile + team * TS + t * LS);
     }
     __syncthreads();
-    if (live && t < W) {
-        int32_t in[H], out[H];
-        const int cs = (kr == 2) ? W - 1 - t : t;
-#pragma unroll
-        for (int r = 0; r < H; r++) in[r] = clampv<COL_CLAMP>(tile[team * TS + r * LS + cs]);
-        inv_1d<H, 12, RNG_COL>(kc, in, out);
-        constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), res_min = -res_max - 1;  // check_range, :2398-2411
-        constexpr int32_t pix_max = (1 << BD) - 1;
-        const PIX* p = pred + (size_t)by * pred_stride + bx + t;
-        PIX* w = recon + (size_t)by * recon_stride + bx + t;
-#pragma unroll
-        for (int r = 0; r < H; r++) {
-            const int rr = (kc == 2) ? H - 1 - r : r;
-            int32_t v = rshift_round(out[rr], S1);
-            v = min(max(v, res_min), res_max);
-            const int32_t px = (int32_t)p[(size_t)r * pred_stride] + v;
-            w[(size_t)r * recon_stride] = (PIX)min(max(px, 0), pix_max);
-        }
-    }
+    if (live && t < W) inv_col_pass<W, H, BD, PIX>(tile + team * TS, t, kc, kr, pred, pred_stride, recon, recon_stride, bx, by);
 }
 
 template <int W, int H, int BD, typename PIX>
@@ -331,6 +360,33 @@ fwd_txfm_quant_multi_kernel(const FwdMulti a) {
     case id:                                                                                                                                   \
         fwd_block<w, h, PIX>(tile, wg, threadIdx.x, src, src_stride, pred, pred_stride, descs, nblk, qp, scans, coeff, qcoeff, dqcoeff, eob,  \
                              cul, energy);                                                                                                     \
+        break;
+        FOR_ALL_TX_SIZES_DEV(X)
+#undef X
+    default: break;
+    }
+}
+// the same job lists with the reconstruction fused in (FBD = bit depth): recon[j] / recon_stride[j] per job
+struct EncMulti { FwdMulti f; void* recon[kMultiJobs]; int recon_stride[kMultiJobs]; };
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(256)
+enc_txfm_multi_kernel(const EncMulti e) {
+    __shared__ int32_t tile[kMultiTileDw];
+    int j = 0;
+    while (j + 1 < e.f.njobs && (int)blockIdx.x >= e.f.first_wg[j + 1]) j++;
+    const int wg = (int)blockIdx.x - e.f.first_wg[j];
+    const int tx_size = e.f.job[j].tx_size, nblk = e.f.job[j].nblk, src_stride = e.f.job[j].src_stride, pred_stride = e.f.job[j].pred_stride, recon_stride = e.recon_stride[j];
+    const PIX* src = (const PIX*)e.f.job[j].d_src; const PIX* pred = (const PIX*)e.f.job[j].d_pred; PIX* recon = (PIX*)e.recon[j];
+    const uint32_t* descs = e.f.job[j].d_descs;
+    const SvtHipQuantParams qp = e.f.job[j].qp;
+    const SvtHipScanTables scans = e.f.job[j].scans;
+    int32_t *coeff = e.f.job[j].d_coeff, *qcoeff = e.f.job[j].d_qcoeff, *dqcoeff = e.f.job[j].d_dqcoeff, *cul = e.f.job[j].d_cul_level;
+    uint16_t* eob = e.f.job[j].d_eob; uint64_t* energy = e.f.job[j].d_energy;
+    switch (tx_size) {
+#define X(id, w, h)                                                                                                                                  \
+    case id:                                                                                                                                         \
+        fwd_block<w, h, PIX, BD>(tile, wg, threadIdx.x, src, src_stride, pred, pred_stride, descs, nblk, qp, scans, coeff, qcoeff, dqcoeff, eob, cul, \
+                                 energy, recon, recon_stride);                                                                                       \
         break;
         FOR_ALL_TX_SIZES_DEV(X)
 #undef X
@@ -441,6 +497,26 @@ extern "C" int svt_hip_launch_fwd_txfm_quant_multi(hipStream_t st, int pix_bytes
         if (!wg) continue;
         if (pix_bytes == 1) hipLaunchKernelGGL((fwd_txfm_quant_multi_kernel<uint8_t>), dim3(wg), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((fwd_txfm_quant_multi_kernel<uint16_t>), dim3(wg), dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_enc_txfm_multi(hipStream_t st, int pix_bytes, int bd, const SvtHipEncTxJob* jobs, int njobs) {
+    for (int j0 = 0; j0 < njobs; j0 += kMultiJobs) {
+        EncMulti e = {};
+        int wg = 0;
+        for (int j = j0; j < njobs && j < j0 + kMultiJobs; j++) {
+            if (jobs[j].fwd.nblk <= 0) continue;
+            const int t = teams_of(jobs[j].fwd.tx_size);
+            e.f.first_wg[e.f.njobs] = wg;
+            e.recon[e.f.njobs] = jobs[j].d_recon; e.recon_stride[e.f.njobs] = jobs[j].recon_stride;
+            e.f.job[e.f.njobs++] = jobs[j].fwd;
+            wg += (jobs[j].fwd.nblk + t - 1) / t;
+        }
+        e.f.first_wg[e.f.njobs] = wg;
+        if (!wg) continue;
+        if (pix_bytes == 1) hipLaunchKernelGGL((enc_txfm_multi_kernel<uint8_t, 8>), dim3(wg), dim3(256), 0, st, e);
+        else if (bd == 8) hipLaunchKernelGGL((enc_txfm_multi_kernel<uint16_t, 8>), dim3(wg), dim3(256), 0, st, e);
+        else hipLaunchKernelGGL((enc_txfm_multi_kernel<uint16_t, 10>), dim3(wg), dim3(256), 0, st, e);
     }
     return (int)hipGetLastError();
 }

@@ -207,6 +207,34 @@ def test_mixed_size_launches(hip, pkg, bd):
         for d in descs:
             x, y = int(d & 0x3FFF), int((d >> 14) & 0x3FFF)
             assert np.array_equal(rec[y:y + h, x:x + w], exp["rec"][y:y + h, x:x + w]), ("rec", ts)
+    # svt_hip_enc_txfm_multi_dev: the same jobs with the reconstruction fused in (dequantised coefficients stay in registers) — identical
+    # levels, eobs and reconstruction, with the dq output (pass 0) and without it (pass 1)
+    for drop_dq in (0, 1):
+        ej = (pkg.EncTxJob * 20)()
+        d_rec_f = hip.to_device(np.zeros_like(pred))
+        outs2 = []
+        for j in range(20):
+            if not fj[j].nblk: continue
+            n = fj[j].nblk; nk = min(tc.TXW[fj[j].tx_size], 32) * min(tc.TXH[fj[j].tx_size], 32)
+            o = dict(q=hip.empty(n * nk * 4), dq=hip.empty(n * nk * 4), eob=hip.empty(n * 2), cul=hip.empty(n * 4))
+            outs2.append((j, o))
+            f = fj[j]
+            ej[j].fwd = pkg.FwdTxJob(f.tx_size, f.nblk, f.d_src, f.src_stride, f.d_pred, f.pred_stride, f.d_descs, f.qp, f.scans, None, o["q"].value,
+                                     None if drop_dq else o["dq"].value, o["eob"].value, o["cul"].value, None)
+            ej[j].d_recon = d_rec_f.value; ej[j].recon_stride = Wp
+        hip.check(hip.L.svt_hip_enc_txfm_multi_dev(hip.h, src.itemsize, bd, ej, 20), "enc multi")
+        rec_f = hip.to_host(d_rec_f, pred.shape, dt)
+        by_ts = {ts: (descs, exp) for ts, descs, exp in expect}
+        for j, o in outs2:
+            ts = fj[j].tx_size; descs, exp = by_ts[ts]
+            n = len(descs); nk = min(tc.TXW[ts], 32) * min(tc.TXH[ts], 32); w, h = tc.TXW[ts], tc.TXH[ts]
+            assert np.array_equal(hip.to_host(o["q"], (n, nk), np.int32), exp["q"]), ("fused q", ts, drop_dq)
+            if not drop_dq: assert np.array_equal(hip.to_host(o["dq"], (n, nk), np.int32), exp["dq"]), ("fused dq", ts)
+            assert np.array_equal(hip.to_host(o["eob"], (n,), np.uint16), exp["eob"]) and np.array_equal(hip.to_host(o["cul"], (n,), np.int32), exp["cul"]), ("fused eob", ts)
+            for d in descs:
+                x, y = int(d & 0x3FFF), int((d >> 14) & 0x3FFF)
+                assert np.array_equal(rec_f[y:y + h, x:x + w], exp["rec"][y:y + h, x:x + w]), ("fused rec", ts, drop_dq)
+        hip.free(d_rec_f, *[v for _, o in outs2 for v in o.values()])
     hip.free(d_src, d_pred, d_rec_multi, *keep, *[v for o in outs for v in o.values()])
 
 
