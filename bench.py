@@ -164,6 +164,12 @@ class Pipeline:
         self.d_uerr = [torch.zeros((n, 16), dtype=torch.int64, device=dev) for n in self.n_units]
         self.d_ubest = [torch.zeros(n, dtype=torch.uint8, device=dev) for n in self.n_units]
         self.d_ubx = [torch.zeros((n, 2), dtype=torch.int32, device=dev) for n in self.n_units]
+        self.SGRJ = (pkg.SgrUnitsPlaneDev * 3)()
+        for p in range(3):
+            ph_, pw_ = F.cur[p].shape
+            self.SGRJ[p] = pkg.SgrUnitsPlaneDev(self.p_cdef[p], self.xs[p], self.d_cur[p].data_ptr(), self.strides[p], pw_, ph_, self.US[p], int(p > 0), 0xFFFF,
+                                                self.d_uxqd[p].data_ptr(), self.d_uerr[p].data_ptr(), self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr(),
+                                                self.d_scr[p].data_ptr(), self.scr_bytes[p])
         self.stage_fns = dict(pyr=self.run_pyramids, hme=self.run_hme, me=self.run_me, subpel=self.run_subpel, txfm=self.run_txfm, inv=self.run_inv, enc_txfm=self.run_enc_txfm,
                               dlf=self.run_dlf,
                               cdef_search=self.run_cdef_search, cdef_apply=self.run_cdef_apply, sgr_units=self.run_sgr_units, sgr_apply=self.run_sgr_apply)
@@ -226,9 +232,7 @@ class Pipeline:
         for p in range(3):
             ph, pw = F.cur[p].shape
             self.chk(L.svt_hip_generate_padding_dev(h, self.p_cdef[p], 1, self.xs[p], pw, ph, EXT, EXT), "extend")
-            self.chk(L.svt_hip_sgr_search_units_plane_dev(h, 1, 8, self.p_cdef[p], self.xs[p], self.d_cur[p].data_ptr(), self.strides[p], pw, ph, self.US[p], int(p > 0), 0xFFFF,
-                                                          self.d_uxqd[p].data_ptr(), self.d_uerr[p].data_ptr(), self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr(),
-                                                          self.d_scr[p].data_ptr(), self.scr_bytes[p]), "sgr units")
+        self.chk(L.svt_hip_sgr_search_units_picture_dev(h, 1, 8, 3, self.SGRJ), "sgr units")   # one sums launch per plane, one walk launch for the picture
 
     def run_sgr_apply(self):   # every unit filtered with the set / xqd its search chose (device arrays), stripe context rows from the deblocked picture
         L, h, F = self.E.L, self.E.ctx.h, self.F

@@ -406,6 +406,20 @@ size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size);
 int svt_hip_sgr_search_units_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, const void *d_src, int src_stride, int pw,
                                        int ph, int unit_size, int ss_y, uint32_t ep_mask, int32_t *d_xqd, int64_t *d_err, uint8_t *d_best_ep,
                                        int32_t *d_best_xqd, void *d_scratch, size_t scratch_bytes);
+/* The same for all planes of a picture in one call: one sums / difference-plane launch per plane, then ONE walk launch over every
+ * (plane, unit, set) — the long walks of one plane overlap the other planes' work instead of ending a launch each. */
+typedef struct {
+    const void *d_dgd; int32_t stride;      /* (0,0) of the 3-sample-extended CDEF output */
+    const void *d_src; int32_t src_stride;
+    int32_t pw, ph, unit_size, ss_y;
+    uint32_t ep_mask;
+    int32_t *d_xqd;       /* device [units][16][2] */
+    int64_t *d_err;       /* device [units][16] */
+    uint8_t *d_best_ep;   /* device [units] or NULL */
+    int32_t *d_best_xqd;  /* device [units][2] or NULL */
+    void *d_scratch; size_t scratch_bytes;   /* svt_hip_sgr_search_units_scratch_bytes(pw, ph, unit_size) */
+} SvtHipSgrUnitsPlaneDev;
+int svt_hip_sgr_search_units_picture_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int n_planes, const SvtHipSgrUnitsPlaneDev *planes);
 /* HOST-output convenience form on library-owned device scratch: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched),
  * best_ep[unit] (may be NULL); *rounds_out (may be NULL) is always 0 (kept from the host-driven search of earlier versions).  Synchronous: one
  * stream synchronisation at the end to hand the results over. */

@@ -84,6 +84,12 @@ class InvTxJob(C.Structure):
                 ("d_recon", C.c_void_p), ("recon_stride", C.c_int32), ("d_descs", C.c_void_p)]
 
 
+class SgrUnitsPlaneDev(C.Structure):   # SvtHipSgrUnitsPlaneDev
+    _fields_ = [("d_dgd", C.c_void_p), ("stride", C.c_int32), ("d_src", C.c_void_p), ("src_stride", C.c_int32), ("pw", C.c_int32), ("ph", C.c_int32),
+                ("unit_size", C.c_int32), ("ss_y", C.c_int32), ("ep_mask", C.c_uint32), ("d_xqd", C.c_void_p), ("d_err", C.c_void_p), ("d_best_ep", C.c_void_p),
+                ("d_best_xqd", C.c_void_p), ("d_scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
+
+
 class TfBlk64(C.Structure):   # SvtHipTfBlk64
     _fields_ = [("mv16_x", C.c_int16 * 16), ("mv16_y", C.c_int16 * 16), ("err16", C.c_uint64 * 16),
                 ("mv32_x", C.c_int16 * 4), ("mv32_y", C.c_int16 * 4), ("err32", C.c_uint64 * 4), ("split", C.c_int32 * 4)]
@@ -162,6 +168,7 @@ def lib():
     L.svt_hip_sgr_search_units_scratch_bytes.argtypes = [i32, i32, i32]
     L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
     L.svt_hip_sgr_search_units_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t]
+    L.svt_hip_sgr_search_units_picture_dev.argtypes = [vp, i32, i32, i32, C.POINTER(SgrUnitsPlaneDev)]
     L.svt_hip_sgr_search_units_picture.argtypes = [vp, i32, i32, i32, C.POINTER(SgrSearchPlane), vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_lr_try_unit_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp]

@@ -31,6 +31,12 @@ namespace {
 constexpr int kStreamCand = 10;  // the streamed form keeps one accumulator per candidate in registers
 constexpr int kMaxCand = 16;     // capacity of the per-pass candidate list (the launch's `cap` <= this is the number actually used)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+struct WalkPlane {   // one plane's arguments of a walk launch
+    const uint32_t* pairs; const int16_t* sd; const int64_t* sums; size_t dplane;
+    int dstride, pw, ph, unit_size, units_x, units_y, voff; uint32_t ep_mask;
+    int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
+};
+struct WalkPic { WalkPlane p[3]; int cap; };
 constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
 
 // eb_sgr_params (Common/Codec/EbRestoration.c:136-153): r0 > 0 for sets 0-9, 14, 15; r1 > 0 for sets 0-13.  Tap ranges: SGRPROJ_PRJ_MIN0 / MAX0 = -96 / 31,
@@ -351,10 +357,14 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
 // (the last row / column may be up to 1.5 x the unit size) keep the excess in memory and stream it per pass like the form above.  Per candidate and
 // pixel pair: 2 v_dot2_i32_i16 (weighted sum, rounding constant as the accumulator), v_perm_b32 (high halves), v_pk_add_i16 (+ dat - src),
 // v_dot2_i32_i16 (square-accumulate).
-constexpr int kResT = 1024, kResD = kResT - 64, kResJ = 9;   // threads, data threads, resident chunks per data thread
-struct ResLds {
+constexpr int kResT = 1024, kResJ = 9;   // full residency: threads, resident chunks per data thread
+// The HYBRID instance (T = 512, J = 7, NA = 8): two workgroups share a compute unit, each keeps 7 x 448 chunks (38 % of a 256 x 256 unit) resident and
+// streams the rest of the unit on every pass, chunk-outer with NA candidate accumulators — one workgroup's loads and replays overlap the other's
+// evaluation (a compute unit streams only ~10 B per cycle from HBM, and with full residency nothing else can run beside the 1024 threads).
+template <int T, int J>
+struct ResLdsT {
     WalkLds W;
-    int4    sd[kResJ * kResD];   // [chunk slot][data thread]: eight dat - src values
+    int4    sd[J * (T - 64)];   // [chunk slot][data thread]: eight dat - src values
 };
 
 // Eight pixels of one candidate: 20 vector instructions, written out because the order matters on this pipeline — a dot product's result may
@@ -400,16 +410,24 @@ __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
     a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]); s = make_int4(sw[0], sw[1], sw[2], sw[3]);
 }
 
-template <int BD>
-__global__ void __launch_bounds__(kResT)
-sgr_walk_resident_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ sd, int dstride, size_t dplane,
-                         const long long* __restrict__ sums, int pw, int ph, int unit_size, int units_x, int units_y, int voff, uint32_t ep_mask,
-                         int32_t* __restrict__ xqd_out, long long* __restrict__ err_out, uint32_t* __restrict__ counters, uint8_t* __restrict__ best_ep,
-                         int32_t* __restrict__ best_xqd, uint32_t* __restrict__ stats, int cap) {
-    __shared__ ResLds R;
+template <int BD, int kT, int kJ, int NA>   // NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own
+__global__ void __launch_bounds__(kT)
+sgr_walk_resident_kernel(const WalkPic a) {
+    constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
+    __shared__ ResLdsT<kT, kJ> R;
     WalkLds& L = R.W;
+    // the planes of a picture share one launch (grid.z): one tail instead of three.  Scalar copies of the plane's arguments (a reference into the
+    // kernel-argument struct with a run-time index would force a private copy of the whole struct)
+    const int z = blockIdx.z;
+    const uint32_t* __restrict__ pairs = a.p[z].pairs; const int16_t* __restrict__ sd = a.p[z].sd; const long long* __restrict__ sums = (const long long*)a.p[z].sums;
+    const int dstride = a.p[z].dstride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff;
+    const size_t dplane = a.p[z].dplane;
+    const uint32_t ep_mask = a.p[z].ep_mask;
+    int32_t* __restrict__ xqd_out = a.p[z].xqd_out; long long* __restrict__ err_out = (long long*)a.p[z].err_out; uint32_t* __restrict__ counters = a.p[z].counters;
+    uint8_t* __restrict__ best_ep = a.p[z].best_ep; int32_t* __restrict__ best_xqd = a.p[z].best_xqd; uint32_t* __restrict__ stats = a.p[z].stats;
+    const int cap = a.cap;
     const int unit = blockIdx.x, ep = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!((ep_mask >> ep) & 1)) return;
+    if (unit >= units_x * units_y || !((ep_mask >> ep) & 1)) return;
     const int uj = unit % units_x, ui = unit / units_x;
     const int x0 = uj * unit_size, w = uj == units_x - 1 ? pw - x0 : unit_size;
     const int y0 = ui * unit_size, h = ui == units_y - 1 ? ph - y0 : unit_size;
@@ -521,6 +539,57 @@ sgr_walk_resident_kernel(const uint32_t* __restrict__ pairs, const int16_t* __re
         const int nc = L.n_want;
         const int qv = lane < nc ? (int)(((uint32_t)(L.xq0[lane] * 32) & 0xFFFFu) | ((uint32_t)(L.xq1[lane] * 32) << 16)) : 0;   // lane c: both taps of candidate c, scaled by 32 (|32 xq| <= 8192)
         const unsigned long long e0 = __builtin_readcyclecounter();
+        if constexpr (NA > 0) {
+            // ---- hybrid: the streamed part of the unit first (its loads are in flight while the resident part is evaluated), one pass over it for all
+            // candidates; per candidate two int32 accumulators (bit depth 8: |e| < 2^10, < 160 samples per thread) or a 64-bit one (bit depth 10)
+            int pp0[NA], pp1[NA]; long long acc[NA];
+            int qq[NA];
+#pragma unroll
+            for (int c = 0; c < NA; c++) { pp0[c] = pp1[c] = 0; acc[c] = 0; qq[c] = __builtin_amdgcn_readlane(qv, c); }
+            int k = t + kResJ * kResD;
+            int4 a0 = make_int4(0, 0, 0, 0), a1 = a0, s4 = a0;
+            auto fetch = [&](int kk, int4& x0v, int4& x1v, int4& sv) {
+                const int row = kk / cw, cx = kk - row * cw;
+                const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+                x0v = *(const int4*)(PP + off); x1v = *(const int4*)(PP + off + 4); sv = *(const int4*)(sd + off);
+                const int n = w - 8 * cx;
+                if (n < 8) mask_chunk(x0v, x1v, sv, n);
+            };
+            if (k < nchunk) fetch(k, a0, a1, s4);
+            while (k < nchunk) {
+                const int kn = k + kResD;
+                int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
+                if (kn < nchunk) fetch(kn, b0, b1, t4);   // next chunk's loads before this chunk's arithmetic
+#pragma unroll
+                for (int c = 0; c < NA; c++)
+                    if (c < nc) {
+                        eval_chunk(a0, a1, s4, qq[c], rnd, sel, pp0[c], pp1[c]);
+                        if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                    }
+                a0 = b0; a1 = b1; s4 = t4; k = kn;
+            }
+            // ---- the resident chunks, slot by slot for all candidates (one LDS read of dat - src per slot)
+#pragma unroll
+            for (int j = 0; j < kResJ; j++) {
+                if (j * kResD < nchunk) {
+                    const int4 sc = R.sd[j * kResD + t];
+#pragma unroll
+                    for (int c = 0; c < NA; c++)
+                        if (c < nc) {
+                            eval_chunk(pa[j], pb[j], sc, qq[c], rnd, sel, pp0[c], pp1[c]);
+                            if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (BD == 8) dot_drain();
+#pragma unroll
+            for (int c = 0; c < NA; c++)
+                if (c < nc) {
+                    const long long sum = wave_sum_u48(acc[c] + pp0[c] + pp1[c]);
+                    if (lane == 0) L.part[wave][c] = sum;
+                }
+        } else
         for (int c = 0; c < nc; c++) {
             const int q = __builtin_amdgcn_readlane(qv, c);
             long long acc = 0;
@@ -558,27 +627,54 @@ sgr_walk_resident_kernel(const uint32_t* __restrict__ pairs, const int16_t* __re
 
 extern "C" size_t svt_hip_sgr_walk_state_bytes(int n_units) { return sizeof(uint32_t) * (size_t)n_units; }   // arrival counter per unit
 
+// planes[i]: the arguments of svt_hip_launch_sgr_walk for plane i; one launch for all of them (resident / hybrid forms), one per plane (streamed form)
+extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_planes, const SvtHipSgrWalkPlane* planes) {
+    if (n_planes < 1 || n_planes > 3) return (int)hipErrorInvalidValue;
+    // SVT_HIP_SGR_WALK = stream | resident | hybrid selects the form (A/B measurements, tools/hbd_time.py); default: hybrid
+    static const char* form_env = getenv("SVT_HIP_SGR_WALK");
+    const bool stream_form = form_env && !strcmp(form_env, "stream"), resident_form = form_env && !strcmp(form_env, "resident");
+    static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
+    constexpr int kHybT = 512, kHybJ = 7, kHybNA = 8;
+    constexpr int kHybNA10 = 5;   // bit depth 10 keeps 64-bit accumulators: fewer of them fit the 128-register budget of two workgroups per compute unit
+    const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? kHybNA : kHybNA10));
+    const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
+    WalkPic a = {};
+    a.cap = cap;
+    int max_units = 0;
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipSgrWalkPlane& P = planes[i];
+        const int nu = P.units_x * P.units_y;
+        uint32_t* counters = (uint32_t*)P.states;
+        (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)nu, st);
+        a.p[i] = WalkPlane{P.pairs, P.sd, P.sums, P.dplane, P.dstride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, 8 >> P.ss_y, P.ep_mask,
+                           P.xqd_out, P.err_out, counters, P.best_ep, P.best_xqd, P.stats};
+        max_units = nu > max_units ? nu : max_units;
+    }
+    if (stream_form) {
+        for (int i = 0; i < n_planes; i++) {
+            const WalkPlane& W = a.p[i];
+            dim3 grid(W.units_x * W.units_y, 16);
+#define WALK_ARGS W.pairs, W.sd, W.dstride, W.dplane, (const long long*)W.sums, W.pw, W.ph, W.unit_size, W.units_x, W.units_y, W.voff, W.ep_mask, W.xqd_out, (long long*)W.err_out, W.counters, W.best_ep, W.best_xqd, W.stats, cap
+            if (bd == 8) hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), 0, st, WALK_ARGS);
+            else hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), 0, st, WALK_ARGS);
+#undef WALK_ARGS
+        }
+        return (int)hipGetLastError();
+    }
+    dim3 grid(max_units, 16, n_planes);
+    if (resident_form) {
+        if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);
+        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);
+    } else {
+        if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, kHybJ, kHybNA>), grid, dim3(kHybT), 0, st, a);
+        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, kHybNA10>), grid, dim3(kHybT), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums,
                                        const int64_t* d2, void* states, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask,
                                        int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats) {
     (void)d2;
-    const int voff = 8 >> ss_y;
-    dim3 grid(units_x * units_y, 16);
-    uint32_t* counters = (uint32_t*)states;
-    (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)units_x * units_y, st);
-    // SVT_HIP_SGR_WALK=stream selects the streamed form (A/B measurements, tools/hbd_time.py); the resident form is the product path
-    static const bool stream_form = getenv("SVT_HIP_SGR_WALK") && !strcmp(getenv("SVT_HIP_SGR_WALK"), "stream");
-    static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
-    const int cap = cap_env >= 1 && cap_env <= kMaxCand ? cap_env : (stream_form ? kStreamCand : 12);   // candidates per pass
-    if (stream_form && cap > kStreamCand) return (int)hipErrorInvalidValue;
-#define WALK_ARGS pairs, sd, dstride, dplane, (const long long*)sums, pw, ph, unit_size, units_x, units_y, voff, ep_mask, xqd_out, (long long*)err_out, counters, best_ep, best_xqd, stats, cap
-    if (stream_form) {
-        if (bd == 8) hipLaunchKernelGGL((sgr_walk_kernel<8>), grid, dim3(256), 0, st, WALK_ARGS);
-        else hipLaunchKernelGGL((sgr_walk_kernel<10>), grid, dim3(256), 0, st, WALK_ARGS);
-    } else {
-        if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8>), grid, dim3(kResT), 0, st, WALK_ARGS);
-        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10>), grid, dim3(kResT), 0, st, WALK_ARGS);
-    }
-#undef WALK_ARGS
-    return (int)hipGetLastError();
+    const SvtHipSgrWalkPlane P = {pairs, sd, sums, states, dplane, dstride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, xqd_out, err_out, best_ep, best_xqd, stats};
+    return svt_hip_launch_sgr_walk_multi(st, bd, 1, &P);
 }

@@ -643,6 +643,39 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
     return SVT_HIP_OK;
 }
 
+// All planes of a picture: the sums / difference-plane kernel per plane, then ONE walk launch for every (plane, unit, set) — one tail instead of three.
+int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrUnitsPlaneDev* pl) {
+    SVT_HIP_ENTER(c);
+    if (!c || !pl || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
+    SvtHipSgrWalkPlane wp[3];
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipSgrUnitsPlaneDev& P = pl[i];
+        const uint32_t ep_mask = P.ep_mask & 0xFFFFu;
+        if (!P.d_dgd || !P.d_src || !P.d_xqd || !P.d_err || !P.d_scratch || P.unit_size < 64 || (P.unit_size & 63) || (P.ss_y != 0 && P.ss_y != 1) ||
+            !sgr_args_ok(pix_bytes, bd, P.pw, P.ph) || !ep_mask || ((uintptr_t)P.d_scratch & 15)) {
+            c->err = "svt_hip_sgr_search_units_picture_dev: bad plane";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+        const SgrScratch L = sgr_scratch_layout(P.pw, P.ph, P.unit_size);
+        if (P.scratch_bytes < L.total) {
+            c->err = "svt_hip_sgr_search_units_picture_dev: scratch smaller than svt_hip_sgr_search_units_scratch_bytes()";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+        char* base = (char*)P.d_scratch;
+        HIPCHK(c, hipMemsetAsync(base, 0, L.states, c->stream));
+        const int ux = sgr_units(P.pw, P.unit_size), uy = sgr_units(P.ph, P.unit_size);
+        hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, ux, uy, P.ss_y,
+                                                                  ep_mask, (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
+                                                                  (int64_t*)(base + L.d2));
+        if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
+        wp[i] = SvtHipSgrWalkPlane{(const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), (const int64_t*)(base + L.sums), base + L.states, L.dplane, L.dstride,
+                                   P.pw, P.ph, P.unit_size, ux, uy, P.ss_y, ep_mask, P.d_xqd, P.d_err, P.d_best_ep, P.d_best_xqd, (uint32_t*)(base + L.stats)};
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_walk_multi(c->stream, bd, n_planes, wp);
+    if (e != hipSuccess) return fail(c, e, "sgr walk launch");
+    return SVT_HIP_OK;
+}
+
 // HOST-output convenience forms: the library's own scratch, one synchronisation at the very end (to hand the results over).
 int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchPlane* planes, int* rounds_out) {
     SVT_HIP_ENTER(c);

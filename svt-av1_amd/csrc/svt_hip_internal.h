@@ -81,6 +81,12 @@ int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const
                                     int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
                                     int dstride, size_t dplane, int64_t* d2);
 size_t svt_hip_sgr_walk_state_bytes(int n_units);
+typedef struct {
+    const uint32_t* pairs; const int16_t* sd; const int64_t* sums; void* states; size_t dplane;
+    int dstride, pw, ph, unit_size, units_x, units_y, ss_y; uint32_t ep_mask;
+    int32_t* xqd_out; int64_t* err_out; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
+} SvtHipSgrWalkPlane;
+int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_planes, const SvtHipSgrWalkPlane* planes);
 int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums, const int64_t* d2,
                             void* states, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int32_t* xqd_out, int64_t* err_out,
                             uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats);

@@ -320,3 +320,32 @@ def test_search_units_plane_dev_chain(hip, orc, bd):
     # a scratch that is too small is rejected
     assert L.svt_hip_sgr_search_units_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_xqd, d_err, d_best, d_bx, d_scr, nbytes - 1) != 0
     hip.free(d_ext, d_src, d_scr, d_xqd, d_err, d_best, d_bx, d_out)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_units_picture_dev(hip, pkg, orc, bd):
+    """svt_hip_sgr_search_units_picture_dev: three planes of different sizes / unit sizes / set masks in one call (one walk launch for the picture:
+    grid.z = plane, a plane with fewer units than the widest one leaves workgroups without work) against the oracle's per-plane search."""
+    planes = [(328, 264, 128, 0, 0xFFFF), (168, 136, 64, 1, 0x0F3C), (200, 96, 64, 1, 0x8001)]
+    L = hip.L
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    jobs = (pkg.SgrUnitsPlaneDev * 3)()
+    keep, expect = [], []
+    for i, (w, h, US, ss, mask) in enumerate(planes):
+        src, ext = _smooth_noisy(w, h, bd, 1500 + 10 * i + bd, 5 + i)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        nu = units(w, US) * units(h, US)
+        e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+        orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+        nbytes = L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+        d = dict(ext=hip.to_device(ext), src=hip.to_device(src), scr=hip.empty(nbytes), xqd=hip.to_device(np.zeros_like(e_xqd)), err=hip.to_device(np.zeros_like(e_err)),
+                 best=hip.empty(nu), bx=hip.empty(nu * 8))
+        keep.append(d); expect.append((nu, mask, e_xqd, e_err, e_best))
+        jobs[i] = pkg.SgrUnitsPlaneDev(d["ext"].value + off, st, d["src"].value, w, w, h, US, ss, mask, d["xqd"].value, d["err"].value, d["best"].value, d["bx"].value,
+                                       d["scr"].value, nbytes)
+    hip.check(L.svt_hip_sgr_search_units_picture_dev(hip.h, 1 if bd == 8 else 2, bd, 3, jobs), "units picture dev")
+    for d, (nu, mask, e_xqd, e_err, e_best) in zip(keep, expect):
+        g_xqd = hip.to_host(d["xqd"], e_xqd.shape, np.int32); g_err = hip.to_host(d["err"], e_err.shape, np.int64); g_best = hip.to_host(d["best"], e_best.shape, np.uint8)
+        on = np.array([(mask >> e) & 1 for e in range(16)], bool)
+        assert np.array_equal(g_err[:, on], e_err[:, on]) and np.array_equal(g_xqd[:, on], e_xqd[:, on]) and np.array_equal(g_best, e_best), (bd, nu, hex(mask))
+        hip.free(*d.values())
