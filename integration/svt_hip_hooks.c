@@ -11,7 +11,7 @@
 #include "common_dsp_rtcd.h"
 #include "EbLog.h"
 
-static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "hme", "dlf", "dlf_search", "cdef_search", "cdef_apply",
+static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
                                                             "sgr_search", "wiener_stats", "rest_apply", "wiener_try"};
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];

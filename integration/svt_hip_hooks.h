@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  me, hme, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -24,7 +24,6 @@
 
 enum {
     SVT_HIP_HOOK_ME = 0,       /* integer full search of every SB of an ME segment: motion_estimation_kernel (EbMotionEstimationProcess.c:831-963) */
-    SVT_HIP_HOOK_HME,          /* hme_level_0/1/2 searches of the segment (EbMotionEstimation.c:2204-2574) */
     SVT_HIP_HOOK_DLF,          /* svt_av1_loop_filter_frame in dlf_kernel (EbDlfProcess.c:212) */
     SVT_HIP_HOOK_DLF_SEARCH,   /* svt_av1_pick_filter_level(LPF_PICK_FROM_FULL_IMAGE) (EbDlfProcess.c:203) */
     SVT_HIP_HOOK_CDEF_SEARCH,  /* cdef_seg_search[16bit] of every segment (EbCdefProcess.c:511-514) */
