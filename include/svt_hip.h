@@ -458,7 +458,8 @@ int svt_hip_lr_try_unit_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d
  * + (dy + win/2)).  win = 7 (luma), 5 (chroma) or 3.  The plane must be extended by 3 samples like for the self-guided calls.  The linear
  * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090) stay on the host.  8-bit planes, and
  * 16-bit planes (bd 8 / 10 / 12) = svt_av1_compute_stats_highbd (:741) incl. its bit_depth_divider; the 16-bit path keeps a library-owned
- * device scratch buffer inside the context (allocated on first use, freed by svt_hip_destroy). */
+ * device scratch buffer inside the context (allocated on first use — growing it waits for the whole device —, freed by svt_hip_destroy): calls
+ * of the 16-bit path through ONE context must not overlap on different streams (use one context per stream for that). */
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int win, const void *d_dgd, int stride, const void *d_src,
                                    int src_stride, int pw, int ph, int unit_size, int ss_y, int64_t *d_M, int64_t *d_H);
 

@@ -751,8 +751,8 @@ int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win,
     if (pix_bytes == 2) {
         const int n_units = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
         const size_t need = svt_hip_wiener_stats16_scratch(win, pw, ph, n_units);
-        if (need > c->scratch_bytes) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (need > c->scratch_bytes) {   // the scratch may still be in use by work queued on ANY stream this context was pointed at
+            HIPCHK(c, hipDeviceSynchronize());
             if (c->scratch) HIPCHK(c, hipFree(c->scratch));
             c->scratch = nullptr; c->scratch_bytes = 0;
             HIPCHK(c, hipMalloc(&c->scratch, need));
