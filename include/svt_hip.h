@@ -451,6 +451,14 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void
 int svt_hip_lr_try_unit_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride, int pw, int ph,
                             int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep, const int32_t *d_unit_xqd,
                             const int16_t *d_unit_wiener, const void *d_src, int src_stride, int unit, uint64_t *d_sse);
+/* The list form: the whole plane filtered with the per-unit entries (units that are not being probed hold 255 = RESTORE_NONE and are passed
+ * through) and the SSE of every rectangle of d_rects (a = source plane coordinates, b = destination plane coordinates; normally one rectangle
+ * per restoration unit) in d_sse[n_rects] — one round of a refinement that walks all units of a plane in lockstep
+ * (finer_tile_search_wiener_seg, EbRestorationPick.c:1092, for every unit at once). */
+int svt_hip_lr_try_units_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, void *d_dst, int dst_stride, int pw, int ph,
+                             int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep, const int32_t *d_unit_xqd,
+                             const int16_t *d_unit_wiener, const void *d_src, int src_stride, const SvtHipBlkPair *d_rects, int n_rects,
+                             uint64_t *d_sse);
 
 /* ------------------------------------------------------------------ Wiener restoration search ---- */
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as

@@ -137,9 +137,23 @@ pick.sub(r'(\n[ \t]*)(const int32_t optimized_lr = 0;\n)',
          r'\1    if (svt_hip_hook_wiener_try(rsc->hip_pcs, plane, limits->h_start, limits->h_end, limits->v_start, limits->v_end, &rui->wiener_info, &hip_err) == EB_ErrorNone)'
          r'\1        return hip_err;'
          r'\1}\n')
+# restoration_seg_search (:1552): every search_wiener_seg of the picture in one device-side lockstep search
+pick.sub(r'(\n[ \t]*)(if \(cm->wn_filter_mode\)\s*)(av1_foreach_rest_unit_in_frame_seg\(rsc_p->cm,\s*rsc_p->plane,\s*rsc_on_tile,\s*search_wiener_seg,)',
+         r'\1if (cm->wn_filter_mode && svt_hip_hook_wiener_search(pcs_ptr) != EB_ErrorNone) /* not handled: the per-unit C search of this segment */\1    \3')
 PATCHES.append(pick)
+PICK_TAIL = '''
+/* search_wiener_seg (:1388-1407) between the statistics and the refinement, for the picture-level hook: 0 = the decomposition failed,
+ * 1 = *wi holds the initial filter and it beats the identity filter (refine it), 2 = it does not (the unit gets no Wiener filter) */
+int svt_hip_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, WienerInfo *wi) {
+    int32_t vfilterd[WIENER_WIN], hfilterd[WIENER_WIN];
+    if (!wiener_decompose_sep_sym(wiener_win, M, H, vfilterd, hfilterd)) return 0;
+    finalize_sym_filter(wiener_win, vfilterd, wi->vfilter);
+    finalize_sym_filter(wiener_win, hfilterd, wi->hfilter);
+    return compute_score(wiener_win, M, H, wi->vfilter, wi->hfilter) > 0 ? 2 : 1;
+}
+'''
 
-TAILS = {"Source/Lib/Encoder/Codec/EbMotionEstimation.c": ME_TAIL}
+TAILS = {"Source/Lib/Encoder/Codec/EbMotionEstimation.c": ME_TAIL, "Source/Lib/Encoder/Codec/EbRestorationPick.c": PICK_TAIL}
 
 
 def main():

@@ -32,6 +32,8 @@ enum {
     SVT_HIP_HOOK_WIENER_STATS, /* svt_av1_compute_stats[_highbd] of every unit in search_wiener_seg (EbRestorationPick.c:1347) */
     SVT_HIP_HOOK_REST_APPLY,   /* svt_av1_loop_restoration_filter_frame (EbRestProcess.c:548) */
     SVT_HIP_HOOK_WIENER_TRY,   /* every try_restoration_unit_seg probe of finer_tile_search_wiener_seg (EbRestorationPick.c:1092, :137) */
+    SVT_HIP_HOOK_WIENER_SEARCH, /* every search_wiener_seg of the picture at once: statistics, initial filters, the tap refinement of all units in lockstep (:1347);
+                                 * takes precedence over wiener_stats / wiener_try (those hook the same work unit by unit) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -89,6 +91,10 @@ EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wie
 /* rest_kernel: svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0) */
 EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs);
 /* one probe of the Wiener tap refinement: the unit [h_start, h_end) x [v_start, v_end) of `plane` filtered with `wi`, *err = its SSE against the source */
+/* called before the search_wiener_seg loop of every segment and plane: the first one to arrive searches the whole picture */
+EbErrorType svt_hip_hook_wiener_search(PictureControlSet *pcs);
+/* in the patched EbRestorationPick.c (its static helpers): 0 = decomposition failed, 1 = initial filter in *wi, refine it, 2 = the filter does not beat identity */
+int svt_hip_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, WienerInfo *wi);
 EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err);
 /* rest_kernel, when the picture leaves the filter stages: releases its device state */
 void        svt_hip_hook_picture_done(PictureControlSet *pcs);

@@ -188,6 +188,18 @@ int svt_hip_lr_try_unit_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd
     if (perturb("wiener_try")) { static unsigned n_call; *sse += (uint64_t)((n_call++ * 2654435761u) >> 20); }   /* a different wrong answer per probe: comparisons flip */
     return SVT_HIP_OK;
 }
+int svt_hip_lr_try_units_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph, int unit_size, int ss_y,
+                             const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd, const int16_t *unit_wiener, const void *src, int src_stride,
+                             const SvtHipBlkPair *rects, int n_rects, uint64_t *sse) {
+    const int rc = svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, unit_wiener);
+    if (rc != SVT_HIP_OK) return rc;
+    for (int i = 0; i < n_rects; i++) {
+        sse[i] = orc_plane_sse(pix_bytes, (const uint8_t *)src + ((size_t)rects[i].a_y * src_stride + rects[i].a_x) * pix_bytes, src_stride,
+                               (const uint8_t *)dst + ((size_t)rects[i].b_y * dst_stride + rects[i].b_x) * pix_bytes, dst_stride, rects[i].w, rects[i].h);
+        if (perturb("wiener_search")) { static unsigned n_call; sse[i] += (uint64_t)((n_call++ * 2654435761u) >> 20); }
+    }
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
                                 int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd) {
     return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, NULL);

@@ -171,6 +171,7 @@ def lib():
     L.svt_hip_sgr_search_units_picture_dev.argtypes = [vp, i32, i32, i32, C.POINTER(SgrUnitsPlaneDev)]
     L.svt_hip_sgr_search_units_picture.argtypes = [vp, i32, i32, i32, C.POINTER(SgrSearchPlane), vp]
     L.svt_hip_lr_apply_plane_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
+    L.svt_hip_lr_try_units_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp]
     L.svt_hip_lr_try_unit_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp]
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_tf_filter_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, i32, i32, i32, i32, i32, C.POINTER(TfRef), i32,

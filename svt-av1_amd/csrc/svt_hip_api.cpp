@@ -569,6 +569,15 @@ int svt_hip_lr_try_unit_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_d
     if (e != hipSuccess) return fail(c, e, "restoration unit sse launch");
     return SVT_HIP_OK;
 }
+int svt_hip_lr_try_units_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, void* d_dst, int dst_stride, int pw, int ph, int unit_size, int ss_y,
+                             const void* d_dbl, int dbl_stride, const uint8_t* d_unit_ep, const int32_t* d_unit_xqd, const int16_t* d_unit_wiener, const void* d_src,
+                             int src_stride, const SvtHipBlkPair* d_rects, int n_rects, uint64_t* d_sse) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_rects || !d_sse || n_rects < 0) return SVT_HIP_ERR_BAD_ARG;
+    int rc = svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, d_dgd, stride, d_dst, dst_stride, pw, ph, unit_size, ss_y, d_dbl, dbl_stride, d_unit_ep, d_unit_xqd, d_unit_wiener);
+    if (rc != SVT_HIP_OK) return rc;
+    return svt_hip_block_sse_batch_dev(c, pix_bytes, d_src, src_stride, d_dst, dst_stride, d_rects, n_rects, d_sse);
+}
 
 int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                      int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand, const int32_t* d_xqd, int64_t* d_err) {

@@ -16,7 +16,8 @@ import e2e_common as E
 pytestmark = pytest.mark.skipif(not E.have_apps(), reason="oracle/_ref/SvtAv1EncApp_{ref,hip} not built (make -f oracle/Makefile.enc; needs /root/reference)")
 
 # name: (w, h, frames, bit depth, preset, qp, hooks that must have run)
-ALL = set(E.HOOKS)
+ALL = set(E.HOOKS) - E.PER_UNIT_WIENER   # SVT_HIP_HOOKS=all: the picture-level Wiener search takes the place of the per-unit hooks
+ALL_UNIT = set(E.HOOKS) - {"wiener_search"}
 NO_DLF_REST = {"me", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
 CASES = {
     "cif_8bit_m6": (352, 288, 8, 8, 6, 35, ALL),
@@ -78,6 +79,13 @@ def test_hooked_encode_on_cpu_test_double(case, workdir):
     assert "svt_hip MOCK" in got["log"]
 
 
+def test_per_unit_wiener_hooks_on_cpu_test_double(workdir):
+    """The per-unit path (statistics per unit from the picture-level pass, every refinement probe on the device) with the picture-level search off."""
+    case = "cif_8bit_m6"
+    spec = CASES[case][:6] + (ALL_UNIT,)
+    _check(case, spec, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": E.ALL_PER_UNIT}, "mock_unit")
+
+
 @pytest.mark.parametrize("stage", E.HOOKS)
 def test_every_hook_matters(stage, workdir):
     """A deliberately wrong answer of ONE stage (SVT_HIP_MOCK_PERTURB) must change the bitstream or the reconstruction: the comparison above
@@ -86,7 +94,7 @@ def test_every_hook_matters(stage, workdir):
     w, h, n, bd, preset, q, _ = CASES[case]
     clip, ref = _reference(case, CASES[case], workdir)
     got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_{stage}"),
-                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_MOCK_PERTURB": stage})
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": E.ALL_PER_UNIT if stage in E.PER_UNIT_WIENER else "all", "SVT_HIP_MOCK_PERTURB": stage})
     assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"]), f"perturbing {stage} went unnoticed"
 
 
