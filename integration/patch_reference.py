@@ -59,12 +59,33 @@ me.sub(r'(\n[ \t]*)(open_loop_me_fullpel_search_sblock\(context_ptr,\s*list_inde
        r'\1if (!svt_hip_me_record(context_ptr, sb_origin_x, sb_origin_y, list_index, ref_pic_index, ref_pic_ptr, x_search_area_origin,'
        r'\1                       y_search_area_origin, search_area_width, search_area_height))'
        r'\1    \2')
-# motion_estimate_sb (:2912) becomes motion_estimate_sb_hip(..., hip_phase); the old name stays as the whole-function wrapper
+# hme_level_0 / 1 / 2 (:998, :1146, :1291): the exhaustive search of one region is recorded for the segment's batched launch of its level;
+# the SAD doubling / centre scaling after the call (:1016-1023 ...) is applied to the batched results by the bridge
+for level, first_arg, ref_desc in ((0, r'&context_ptr->sixteenth_sb_buffer\[0\],', 'sixteenth_ref_pic_ptr'),
+                                   (1, r'&context_ptr->quarter_sb_buffer\[0\],', 'quarter_ref_pic_ptr'),
+                                   (2, r'context_ptr->sb_src_ptr,', 'ref_pic_ptr')):
+    me.sub(r'(\n[ \t]*)svt_sad_loop_kernel\(\s*(' + first_arg + r'.*?search_area_height)\);',
+           r'\1if (svt_hip_hme_sad_loop(%d, %s, x_search_area_origin, y_search_area_origin, \2)) return; /* recorded */'
+           r'\1svt_sad_loop_kernel(\2);' % (level, ref_desc))
+# motion_estimate_sb (:2912) becomes motion_estimate_sb_hip(..., hip_phase); the old name stays as the whole-function wrapper.
+# hip_phase: -1 everything | 0 up to and including integer_search_sb | 1 from me_prune_ref on | 10 / 11 / 12 one HME level only |
+#            2 set_final_seach_centre_sb .. integer_search_sb | 3 set_final_seach_centre_sb .. end
 me.sub(r'EbErrorType motion_estimate_sb\(\s*PictureParentControlSet \*pcs_ptr,([^{]*?)EbPictureBufferDesc \*input_ptr\)([^{]*)\{',
        r'EbErrorType motion_estimate_sb_hip(PictureParentControlSet *pcs_ptr,\1EbPictureBufferDesc *input_ptr, int hip_phase)\2{')
-me.sub(r'(\n[ \t]*//init hme results buffer\n)', r'\n    if (hip_phase != 1) { /* phase 1 resumes after the (batched) integer search */\1')
+me.sub(r'(\n[ \t]*//init hme results buffer\n)',
+       r'\n    if (hip_phase != 1) { /* phase 1 resumes after the (batched) integer search */\n    if (hip_phase < 10) {\1')
+me.sub(r'(\n[ \t]*// HME: Perform Hierachical Motion Estimation for all refrence frames.\n)([ \t]*)(hme_sb\(pcs_ptr, sb_origin_x, sb_origin_y, context_ptr, input_ptr\);)',
+       r'\n    }\1'
+       r'\2if (hip_phase >= 10) { /* one level of the hierarchy, its searches recorded (svt_hip_hme_sad_loop) */\n'
+       r'\2    if (hip_phase == 10) hme_level0_sb(pcs_ptr, sb_origin_x, sb_origin_y, context_ptr, input_ptr);\n'
+       r'\2    else if (hip_phase == 11) hme_level1_sb(pcs_ptr, sb_origin_x, sb_origin_y, context_ptr, input_ptr);\n'
+       r'\2    else hme_level2_sb(pcs_ptr, sb_origin_x, sb_origin_y, context_ptr, input_ptr);\n'
+       r'\2    return return_error;\n'
+       r'\2}\n'
+       r'\2if (hip_phase >= 2) set_final_seach_centre_sb(pcs_ptr, context_ptr); /* the three levels arrived with svt_hip_me_batch_flush */\n'
+       r'\2else \3')
 me.sub(r'(\n[ \t]*integer_search_sb\(pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr, input_ptr\);\n)',
-       r'\1    if (hip_phase == 0) return return_error; /* windows recorded; results arrive with svt_hip_me_batch_flush */\n    }\n')
+       r'\1    if (hip_phase == 0 || hip_phase == 2) return return_error; /* windows recorded; results arrive with svt_hip_me_batch_flush */\n    }\n')
 PATCHES.append(me)
 ME_TAIL = '''
 EbErrorType motion_estimate_sb(PictureParentControlSet *pcs_ptr, uint32_t sb_index, uint32_t sb_origin_x, uint32_t sb_origin_y,
@@ -80,12 +101,12 @@ mep.sub(r'(\n[ \t]*// SB Loop\n)([ \t]*for \(uint32_t y_sb_index = y_sb_start_in
         r'uint32_t sb_index = \(uint16_t\)\(x_sb_index \+ y_sb_index \* pic_width_in_sb\);\s*uint32_t sb_origin_x = x_sb_index \* scs_ptr->sb_sz;)',
         r'\1                SvtHipMeBatch *hip_me = svt_hip_me_batch_begin(pcs_ptr, context_ptr->me_context_ptr,\n'
         r'                    (x_sb_end_index - x_sb_start_index) * (y_sb_end_index - y_sb_start_index));\n'
-        r'                for (int hip_pass = 0; hip_pass < (hip_me ? 2 : 1); hip_pass++) {\n'
-        r'                if (hip_pass == 1) svt_hip_me_batch_flush(hip_me, input_padded_picture_ptr);\n\2')
+        r'                for (int hip_pass = 0; hip_pass < svt_hip_me_batch_passes(hip_me); hip_pass++) {\n'
+        r'                if (hip_pass) svt_hip_me_batch_flush(hip_me, hip_pass, input_padded_picture_ptr); /* what pass hip_pass - 1 recorded */\n\2')
 mep.sub(r'(\n[ \t]*)motion_estimate_sb\(pcs_ptr,\s*sb_index,\s*sb_origin_x,\s*sb_origin_y,\s*context_ptr->me_context_ptr,\s*input_picture_ptr\);',
         r'\1if (hip_me) {'
         r'\1    if (!svt_hip_me_batch_sb(hip_me, hip_pass, pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr->me_context_ptr, input_picture_ptr))'
-        r'\1        continue; /* pass 0: the integer search of this SB is pending */'
+        r'\1        continue; /* not the last pass: searches of this SB are pending */'
         r'\1} else'
         r'\1    motion_estimate_sb(pcs_ptr, sb_index, sb_origin_x, sb_origin_y, context_ptr->me_context_ptr, input_picture_ptr);')
 mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',

@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -34,6 +34,8 @@ enum {
     SVT_HIP_HOOK_WIENER_TRY,   /* every try_restoration_unit_seg probe of finer_tile_search_wiener_seg (EbRestorationPick.c:1092, :137) */
     SVT_HIP_HOOK_WIENER_SEARCH, /* every search_wiener_seg of the picture at once: statistics, initial filters, the tap refinement of all units in lockstep (:1347);
                                  * takes precedence over wiener_stats / wiener_try (those hook the same work unit by unit) */
+    SVT_HIP_HOOK_HME,          /* every svt_sad_loop_kernel search of hme_level_0 / 1 / 2 of an ME segment, one launch per level and reference picture
+                                * (EbMotionEstimation.c:998, :1146, :1291) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -51,21 +53,31 @@ void svt_hip_hooks_report(void);
 
 /* ------------------------------------------------------------------ open-loop ME (svt_hip_me_bridge.c) */
 typedef struct SvtHipMeBatch SvtHipMeBatch;
-/* motion_estimation_kernel, before the SB loop of a segment.  NULL = hook off: the caller runs its unchanged loop. */
+/* motion_estimation_kernel, before the SB loop of a segment.  NULL = hooks "hme" and "me" off: the caller runs its unchanged loop. */
 SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb);
-/* pass 0 (per SB): everything of motion_estimate_sb up to the integer search, whose windows are recorded instead of searched -> returns 0
- * pass 1 (per SB, after svt_hip_me_batch_flush): results back into MeContext, the rest of motion_estimate_sb               -> returns 1 */
+/* The SB loop runs svt_hip_me_batch_passes() times (1 for NULL); before every pass but the first svt_hip_me_batch_flush launches what the
+ * previous pass recorded (one hierarchical-ME level, or the integer-search windows).  svt_hip_me_batch_sb runs this pass's part of
+ * motion_estimate_sb for one SB and returns 1 when the SB is complete (last pass), 0 when more passes follow (svt_hip_me_bridge.c). */
+int  svt_hip_me_batch_passes(const SvtHipMeBatch *b);
 int  svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
                          uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr);
-void svt_hip_me_batch_flush(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded);
+void svt_hip_me_batch_flush(SvtHipMeBatch *b, int next_pass, const EbPictureBufferDesc *src_padded);
 void svt_hip_me_batch_end(SvtHipMeBatch *b);
+/* hme_level_0 / 1 / 2, in front of their svt_sad_loop_kernel call, whose twelve arguments follow the four describing the call site:
+ * 1 = recorded for the batch (the caller returns; the bridge applies the SAD doubling / centre scaling that follows the call),
+ * 0 = no batch is collecting on this thread (temporal-filter ME, hook off, a failed batch): the caller searches as before. */
+int  svt_hip_hme_sad_loop(int level, const EbPictureBufferDesc *ref_pic, int16_t x_search_area_origin, int16_t y_search_area_origin,
+                          uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width,
+                          uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw,
+                          int16_t search_area_width, int16_t search_area_height);
 /* integer_search_sb, in place of open_loop_me_fullpel_search_sblock (EbMotionEstimation.c:2130): 1 = recorded for the batch, 0 = no
  * batch is collecting on this thread (temporal-filter ME, hook off): the caller searches as before. */
 int  svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origin_y, uint32_t list_index, uint32_t ref_pic_index,
                        const EbPictureBufferDesc *ref_pic, int16_t x_search_area_origin, int16_t y_search_area_origin,
                        int16_t search_area_width, int16_t search_area_height);
 /* the patched motion_estimate_sb: hip_phase -1 = the whole function (what motion_estimate_sb() still is), 0 = up to and including
- * integer_search_sb, 1 = from me_prune_ref on */
+ * integer_search_sb, 1 = from me_prune_ref on, 10 / 11 / 12 = hme_level0 / 1 / 2_sb only, 2 = set_final_seach_centre_sb up to and including
+ * integer_search_sb, 3 = set_final_seach_centre_sb to the end */
 EbErrorType motion_estimate_sb_hip(PictureParentControlSet *pcs_ptr, uint32_t sb_index, uint32_t sb_origin_x, uint32_t sb_origin_y,
                                    MeContext *context_ptr, EbPictureBufferDesc *input_ptr, int hip_phase);
 

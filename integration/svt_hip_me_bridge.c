@@ -1,17 +1,27 @@
 /* svt_hip_me_bridge.c — open-loop ME glue: the SB loop of motion_estimation_kernel
- * (Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c:831-963) run in two passes around ONE svt_hip_me_fullpel_frame launch per
- * (reference list, reference picture) of the segment.  Host orchestration only — every SAD is computed by libsvtav1_hip.so.
+ * (Source/Lib/Encoder/Codec/EbMotionEstimationProcess.c:831-963) run in passes around batched launches: one svt_hip_sad_loop_batch launch
+ * per hierarchical-ME level and reference picture, one svt_hip_me_fullpel_frame launch per (reference list, reference picture) of the
+ * segment.  Host orchestration only — every SAD is computed by libsvtav1_hip.so.
  *
- *   pass 0, per SB : motion_estimate_sb up to and including integer_search_sb (EbMotionEstimation.c:2912-2953): HME, reference pruning,
- *                    the search-window arithmetic (:1922-2066) and check_00_center stay the reference's code; where integer_search_sb
- *                    would call open_loop_me_fullpel_search_sblock (:2130) it calls svt_hip_me_record() instead.  The only per-SB state
- *                    the rest of motion_estimate_sb reads is MeContext::hme_results (me_prune_ref :2145, construct_me_candidate_array
- *                    :2825) and p_sb_best_sad / p_sb_best_mv, so hme_results is saved per SB.
- *   flush          : the recorded windows of one (list, ref) = one launch; results [n][85] SAD / MV words.
- *   pass 1, per SB : hme_results restored, the 85 SADs / MVs copied into p_sb_best_sad / p_sb_best_mv[list][ref] — exactly the arrays the C
+ * Passes over the SBs of a segment (hook "hme" on, hook "me" on; motion_estimate_sb_hip's hip_phase in brackets):
+ *   L0 [10], L1 [11], L2 [12] : hme_level0/1/2_sb (EbMotionEstimation.c:2204, :2333, :2444) with the reference's own search-region arithmetic;
+ *                    where hme_level_0/1/2 would call svt_sad_loop_kernel (:998, :1146, :1291) the call is recorded (svt_hip_hme_sad_loop).
+ *                    The flush before the next pass runs every recorded search of the level in one launch per reference picture and applies
+ *                    what the reference does after the call (SAD doubling of the sub-sampled search, centre + window origin, x4 / x2 / x1).
+ *                    MeContext is shared by the SBs of the segment, so the results stay in the batch and are written to the context's
+ *                    x/y_hme_levelN_search_center / hme_levelN_sad entries of an SB right before that SB's next pass.
+ *   centre + integer windows [2] : set_final_seach_centre_sb (:2575), hme_prune_ref_and_adjust_sr, integer_search_sb (:1922-2066) with
+ *                    check_00_center etc. unchanged; where integer_search_sb would call open_loop_me_fullpel_search_sblock (:2130) it
+ *                    calls svt_hip_me_record().  The only per-SB state the rest of motion_estimate_sb reads is MeContext::hme_results
+ *                    (me_prune_ref :2145, construct_me_candidate_array :2825) and p_sb_best_sad / p_sb_best_mv, so hme_results is saved.
+ *   tail [1]       : hme_results restored, the 85 SADs / MVs copied into p_sb_best_sad / p_sb_best_mv[list][ref] — exactly the arrays the C
  *                    kernels update in place — then motion_estimate_sb from me_prune_ref on (:2955-3040), unchanged.
- * A HIP failure marks the batch failed and pass 1 simply runs the whole unchanged motion_estimate_sb per SB (error convention).
+ * With only "me" on the passes are [0] (everything up to the integer windows) and [1]; with only "hme" on they are L0, L1, L2 and [3]
+ * (set_final_seach_centre_sb to the end, integer search by the reference's kernels).
+ * A HIP failure marks the batch failed and the last pass simply runs the whole unchanged motion_estimate_sb per SB (error convention,
+ * SURVEY 8(b)).
  */
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 #include "svt_hip_hooks.h"
@@ -22,32 +32,71 @@ typedef struct {
     HmeResults hme[MAX_NUM_OF_REF_PIC_LIST][REF_LIST_MAX_DEPTH];
 } MeSbState;
 
+typedef struct {
+    const EbPictureBufferDesc *ref;        /* the (decimated) reference picture the window lies in */
+    SvtHipSadLoop              job;        /* src_* in the packed source blocks of the level, ref_* in samples of ref->buffer_y */
+    uint8_t                    sub, shift; /* sub-sampled search (SAD doubled); centres scaled by 1 << shift */
+    int16_t                    x_origin, y_origin, x0, y0; /* window origin; the centre before the call (kept when no candidate wins) */
+    uint64_t                  *out_sad;    /* into MeContext: hme_levelN_sad / x,y_hme_levelN_search_center[list][ref][region] */
+    int16_t                   *out_x, *out_y;
+    uint64_t                   sad;        /* results, post-processed */
+    int16_t                    x, y;
+} HmeJob;
+
+#define MAX_PASSES 5
 struct SvtHipMeBatch {
-    uint32_t                   cap, n0, n1;    /* SB slots, SBs seen in pass 0 / pass 1 */
+    uint32_t                   cap, n0, cur;   /* SB slots, SBs seen in the first pass, slot of the SB being processed */
+    uint32_t                   seen[MAX_PASSES];
+    int                        n_pass, phase[MAX_PASSES];
     int                        failed, sub_sad;
     MeSbState                 *sb;             /* [cap] */
     const EbPictureBufferDesc *ref_pic[MAX_NUM_OF_REF_PIC_LIST][MAX_REF_IDX];
     uint8_t                   *has;            /* [list][ref][cap]: a window was recorded */
     SvtHipSbSearch            *win;            /* [list][ref][cap] */
     uint32_t                  *best_sad, *best_mv; /* [list][ref][cap][85] */
+    /* hierarchical ME */
+    HmeJob                    *job;
+    uint32_t                   n_job, job_cap, level_first[4]; /* jobs of level L: [level_first[L], level_first[L + 1]) */
+    uint32_t                  *sb_first[3], *sb_count[3];     /* [level][slot]: the jobs of one SB are contiguous */
+    uint8_t                   *src[3];         /* [level][cap][64][64]: the source block of every SB as the calls read it */
+    int                        hme_launches;
+    void                      *d_src, *d_ref, *d_job, *d_sad, *d_xy;
+    size_t                     d_cap[5];
 };
 #define SLOT(b, l, r) ((((size_t)(l)) * MAX_REF_IDX + (r)) * (b)->cap)
 
-static __thread SvtHipMeBatch *tls_batch; /* the batch that is collecting windows on this thread (pass 0 only) */
+static __thread SvtHipMeBatch *tls_batch; /* the batch that is collecting integer-search windows on this thread */
+static __thread SvtHipMeBatch *tls_hme;   /* the batch that is collecting hierarchical-ME searches on this thread */
+
+int svt_hip_me_batch_passes(const SvtHipMeBatch *b) { return b ? b->n_pass : 1; }
 
 SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb) {
     (void)pcs;
-    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ME) || !n_sb || me_ctx->me_type == ME_MCTF) return NULL;
+    const int me = svt_hip_hook_enabled(SVT_HIP_HOOK_ME), hme = svt_hip_hook_enabled(SVT_HIP_HOOK_HME) && me_ctx->enable_hme_flag;
+    if ((!me && !hme) || !n_sb || me_ctx->me_type == ME_MCTF) return NULL;
     SvtHipMeBatch *b = (SvtHipMeBatch *)calloc(1, sizeof(*b));
     if (!b) return NULL;
     b->cap = n_sb;
+    if (hme) { b->phase[0] = 10; b->phase[1] = 11; b->phase[2] = 12; b->n_pass = 3; }
+    if (me) { b->phase[b->n_pass++] = hme ? 2 : 0; b->phase[b->n_pass++] = 1; }
+    else b->phase[b->n_pass++] = 3;
     const size_t slots = (size_t)MAX_NUM_OF_REF_PIC_LIST * MAX_REF_IDX * n_sb;
     b->sb = (MeSbState *)calloc(n_sb, sizeof(MeSbState));
-    b->has = (uint8_t *)calloc(slots, 1);
-    b->win = (SvtHipSbSearch *)calloc(slots, sizeof(SvtHipSbSearch));
-    b->best_sad = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
-    b->best_mv = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
-    if (!b->sb || !b->has || !b->win || !b->best_sad || !b->best_mv) {
+    int ok = b->sb != NULL;
+    if (me) {
+        b->has = (uint8_t *)calloc(slots, 1);
+        b->win = (SvtHipSbSearch *)calloc(slots, sizeof(SvtHipSbSearch));
+        b->best_sad = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
+        b->best_mv = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
+        ok = ok && b->has && b->win && b->best_sad && b->best_mv;
+    }
+    for (int l = 0; l < 3 && hme; l++) {
+        b->sb_first[l] = (uint32_t *)calloc(n_sb, sizeof(uint32_t));
+        b->sb_count[l] = (uint32_t *)calloc(n_sb, sizeof(uint32_t));
+        b->src[l] = (uint8_t *)calloc((size_t)n_sb * 64 * 64, 1);
+        ok = ok && b->sb_first[l] && b->sb_count[l] && b->src[l];
+    }
+    if (!ok) {
         svt_hip_me_batch_end(b);
         return NULL;
     }
@@ -56,16 +105,26 @@ SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *m
 
 void svt_hip_me_batch_end(SvtHipMeBatch *b) {
     if (!b) return;
+    if (b->d_src || b->d_ref || b->d_job || b->d_sad || b->d_xy) {
+        SvtHipCtx *hip = svt_hip_hooks_lock();
+        if (hip) {
+            svt_hip_free(hip, b->d_src); svt_hip_free(hip, b->d_ref); svt_hip_free(hip, b->d_job); svt_hip_free(hip, b->d_sad); svt_hip_free(hip, b->d_xy);
+            svt_hip_hooks_unlock();
+        }
+    }
+    for (int l = 0; l < 3; l++) { free(b->sb_first[l]); free(b->sb_count[l]); free(b->src[l]); }
+    free(b->job);
     free(b->sb); free(b->has); free(b->win); free(b->best_sad); free(b->best_mv);
     free(b);
 }
 
+/* ------------------------------------------------------------------ integer search windows */
 int svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origin_y, uint32_t list_index, uint32_t ref_pic_index,
                       const EbPictureBufferDesc *ref_pic, int16_t x_search_area_origin, int16_t y_search_area_origin,
                       int16_t search_area_width, int16_t search_area_height) {
     SvtHipMeBatch *b = tls_batch;
     if (!b) return 0;
-    const size_t    s = SLOT(b, list_index, ref_pic_index) + b->n0;
+    const size_t    s = SLOT(b, list_index, ref_pic_index) + b->cur;
     SvtHipSbSearch *w = &b->win[s];
     w->sb_x = (int32_t)sb_origin_x;
     w->sb_y = (int32_t)sb_origin_y;
@@ -79,7 +138,7 @@ int svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origi
     return 1;
 }
 
-void svt_hip_me_batch_flush(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded) {
+static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded) {
     SvtHipSbSearch *wins = (SvtHipSbSearch *)malloc(sizeof(SvtHipSbSearch) * b->cap);
     uint32_t       *idx = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
     uint32_t       *sad = (uint32_t *)malloc(sizeof(uint32_t) * SQUARE_PU_COUNT * b->cap);
@@ -115,32 +174,188 @@ void svt_hip_me_batch_flush(SvtHipMeBatch *b, const EbPictureBufferDesc *src_pad
     svt_hip_hooks_count(SVT_HIP_HOOK_ME, !b->failed);
 }
 
-int svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
-                        uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
-    if (pass == 0) {
-        if (b->n0 >= b->cap) { b->failed = 1; return 0; }
-        b->sb[b->n0].sb_index = sb_index;
-        tls_batch = b;
-        motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, 0);
-        tls_batch = NULL;
-        memcpy(b->sb[b->n0].hme, me_ctx->hme_results, sizeof(b->sb[b->n0].hme));
-        b->n0++;
+/* ------------------------------------------------------------------ hierarchical ME */
+int svt_hip_hme_sad_loop(int level, const EbPictureBufferDesc *ref_pic, int16_t x_search_area_origin, int16_t y_search_area_origin,
+                         uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height, uint32_t block_width,
+                         uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center, uint32_t src_stride_raw,
+                         int16_t search_area_width, int16_t search_area_height) {
+    SvtHipMeBatch *b = tls_hme;
+    if (!b || b->failed) return 0;
+    const uint32_t step = src_stride_raw ? ref_stride / src_stride_raw : 0; /* 2 = every other line (hme_search_method != FULL_SAD_SEARCH) */
+    const size_t   off = (size_t)(ref - ref_pic->buffer_y);
+    if ((step != 1 && step != 2) || step * src_stride_raw != ref_stride || src_stride_raw != ref_pic->stride_y || block_width > 64 ||
+        block_height * step > 64 || !block_width || !block_height || search_area_width < 1 || search_area_height < 1 || ref < ref_pic->buffer_y) {
+        b->failed = 1; /* a call shape the batch does not describe: the whole segment goes back to the C path */
         return 0;
     }
-    const uint32_t i = b->n1++;
-    if (b->failed || i >= b->n0 || b->sb[i].sb_index != sb_index) {
-        motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, -1); /* the unchanged C path */
-        return 1;
+    if (b->n_job == b->job_cap) {
+        const uint32_t cap = b->job_cap ? 2 * b->job_cap : 16 * b->cap + 64;
+        HmeJob        *j = (HmeJob *)realloc(b->job, sizeof(HmeJob) * cap);
+        if (!j) { b->failed = 1; return 0; }
+        b->job = j;
+        b->job_cap = cap;
     }
-    memcpy(me_ctx->hme_results, b->sb[i].hme, sizeof(b->sb[i].hme));
-    memset(me_ctx->p_sb_best_mv, 0, sizeof(me_ctx->p_sb_best_mv)); /* motion_estimate_sb's initialisation (:2938-2939) */
-    for (uint32_t l = 0; l < MAX_NUM_OF_REF_PIC_LIST; l++)
-        for (uint32_t r = 0; r < MAX_REF_IDX; r++) {
-            const size_t s = SLOT(b, l, r) + i;
-            if (!b->has[s]) continue;
-            memcpy(me_ctx->p_sb_best_sad[l][r], &b->best_sad[s * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
-            memcpy(me_ctx->p_sb_best_mv[l][r], &b->best_mv[s * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
-        }
-    motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, 1);
+    const uint32_t i = b->cur;
+    if (!b->sb_count[level][i]) {
+        /* the block as this call reads it: row r of the call at row r * step of the slot, so that row_step = step addresses both operands alike */
+        uint8_t *dst = b->src[level] + (size_t)i * 64 * 64;
+        for (uint32_t r = 0; r < block_height; r++) memcpy(dst + (size_t)r * step * 64, src + (size_t)r * src_stride, block_width);
+        b->sb_first[level][i] = b->n_job;
+    }
+    b->sb_count[level][i]++;
+    HmeJob *j = &b->job[b->n_job++];
+    memset(j, 0, sizeof(*j));
+    j->ref = ref_pic;
+    j->job.src_x = 0;
+    j->job.src_y = (int32_t)i * 64;
+    j->job.ref_x = (int32_t)(off % ref_pic->stride_y);
+    j->job.ref_y = (int32_t)(off / ref_pic->stride_y);
+    j->job.bw = (int16_t)block_width;
+    j->job.bh = (int16_t)(block_height * step);
+    j->job.sa_w = search_area_width;
+    j->job.sa_h = search_area_height;
+    j->job.row_step = (int16_t)step;
+    j->sub = step == 2;
+    j->shift = (uint8_t)(2 - level);
+    j->x_origin = x_search_area_origin;
+    j->y_origin = y_search_area_origin;
+    j->x0 = *x_search_center;
+    j->y0 = *y_search_center;
+    j->out_sad = best_sad;
+    j->out_x = x_search_center;
+    j->out_y = y_search_center;
     return 1;
+}
+
+static int dev_need(SvtHipCtx *hip, void **d, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return SVT_HIP_OK;
+    if (*d) svt_hip_free(hip, *d);
+    *d = NULL;
+    *cap = 0;
+    const int rc = svt_hip_malloc(hip, d, bytes + bytes / 4);
+    if (rc == SVT_HIP_OK) *cap = bytes + bytes / 4;
+    return rc;
+}
+
+#define HME_TRY(x) do { if (rc == SVT_HIP_OK) rc = (x); } while (0)
+static void flush_hme_level(SvtHipMeBatch *b, int level) {
+    const uint32_t first = b->level_first[level], end = b->level_first[level + 1];
+    if (first == end || b->failed) return;
+    const uint32_t n_all = end - first;
+    SvtHipSadLoop *jobs = (SvtHipSadLoop *)malloc(sizeof(SvtHipSadLoop) * n_all);
+    uint32_t      *sel = (uint32_t *)malloc(sizeof(uint32_t) * n_all), *sad = (uint32_t *)malloc(sizeof(uint32_t) * n_all);
+    int16_t       *xy = (int16_t *)malloc(sizeof(int16_t) * 2 * n_all);
+    uint8_t       *done = (uint8_t *)calloc(n_all, 1);
+    SvtHipCtx     *hip = (jobs && sel && sad && xy && done) ? svt_hip_hooks_lock() : NULL;
+    int            rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
+    HME_TRY(dev_need(hip, &b->d_src, &b->d_cap[0], (size_t)b->n0 * 64 * 64 + 64));
+    HME_TRY(svt_hip_memcpy_h2d(hip, b->d_src, b->src[level], (size_t)b->n0 * 64 * 64));
+    for (uint32_t g = 0; g < n_all && rc == SVT_HIP_OK; g++) {
+        if (done[g]) continue;
+        const EbPictureBufferDesc *ref = b->job[first + g].ref; /* one launch per reference picture */
+        const int                  rows_total = ref->height + 2 * ref->origin_y;
+        uint32_t                   n = 0;
+        int                        y_lo = INT_MAX, y_hi = -1;
+        for (uint32_t k = g; k < n_all; k++) {
+            const HmeJob *j = &b->job[first + k];
+            if (j->ref != ref) continue;
+            done[k] = 1;
+            sel[n] = k;
+            jobs[n++] = j->job;
+            if (j->job.ref_y < y_lo) y_lo = j->job.ref_y;
+            const int last = j->job.ref_y + j->job.sa_h - 1 + j->job.bh - 1;
+            if (last > y_hi) y_hi = last;
+        }
+        if (y_hi >= rows_total) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
+        for (uint32_t k = 0; k < n; k++) { jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
+        /* only the rows the segment's windows touch travel (a segment is a band of SB rows) */
+        const size_t ref_bytes = (size_t)(y_hi - y_lo + 1) * ref->stride_y;
+        HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
+        HME_TRY(dev_need(hip, &b->d_job, &b->d_cap[2], sizeof(SvtHipSadLoop) * n));
+        HME_TRY(dev_need(hip, &b->d_sad, &b->d_cap[3], sizeof(uint32_t) * n));
+        HME_TRY(dev_need(hip, &b->d_xy, &b->d_cap[4], sizeof(int16_t) * 2 * n));
+        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, ref->buffer_y + (size_t)y_lo * ref->stride_y, ref_bytes));
+        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_job, jobs, sizeof(SvtHipSadLoop) * n));
+        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_sad, sad, sizeof(uint32_t) * n));
+        HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
+                                           (int)n, (uint32_t *)b->d_sad, (int16_t *)b->d_xy));
+        HME_TRY(svt_hip_memcpy_d2h(hip, sad, b->d_sad, sizeof(uint32_t) * n));
+        HME_TRY(svt_hip_memcpy_d2h(hip, xy, b->d_xy, sizeof(int16_t) * 2 * n));
+        if (rc != SVT_HIP_OK) break;
+        for (uint32_t k = 0; k < n; k++) {
+            HmeJob       *j = &b->job[first + sel[k]];
+            const int     found = sad[k] != 0xffffffu; /* EbComputeSAD_C.c:73: the centres are written only when a candidate wins */
+            const int16_t x = found ? xy[2 * k] : j->x0, y = found ? xy[2 * k + 1] : j->y0;
+            /* hme_level_0 (:1016-1023), hme_level_1 (:1165-1172), hme_level_2 (:1309-1314), in the reference's int16 arithmetic */
+            j->sad = j->sub ? (uint64_t)sad[k] * 2 : sad[k];
+            j->x = (int16_t)((int16_t)(x + j->x_origin) * (1 << j->shift));
+            j->y = (int16_t)((int16_t)(y + j->y_origin) * (1 << j->shift));
+        }
+        b->hme_launches++;
+        svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows uploaded)", level, n, y_hi - y_lo + 1);
+    }
+    if (rc != SVT_HIP_OK) {
+        SVT_LOG("hierarchical ME level %d on the device failed (%s): C search for this segment\n", level, hip ? svt_hip_last_error(hip) : "no context");
+        b->failed = 1;
+    }
+    if (hip) svt_hip_hooks_unlock();
+    free(jobs); free(sel); free(sad); free(xy); free(done);
+}
+
+/* the level results of SB slot i into the (shared) context, as the reference's calls would have left them */
+static void apply_hme(const SvtHipMeBatch *b, uint32_t i, int levels) {
+    for (int l = 0; l < levels; l++)
+        for (uint32_t k = 0; k < b->sb_count[l][i]; k++) {
+            const HmeJob *j = &b->job[b->sb_first[l][i] + k];
+            *j->out_sad = j->sad;
+            *j->out_x = j->x;
+            *j->out_y = j->y;
+        }
+}
+
+void svt_hip_me_batch_flush(SvtHipMeBatch *b, int next_pass, const EbPictureBufferDesc *src_padded) {
+    if (!b || next_pass < 1 || next_pass >= b->n_pass) return;
+    const int prev = b->phase[next_pass - 1];
+    if (prev >= 10) {
+        b->level_first[prev - 10 + 1] = b->n_job;
+        flush_hme_level(b, prev - 10);
+        if (prev == 12 && b->n_job) svt_hip_hooks_count(SVT_HIP_HOOK_HME, !b->failed);
+    } else if (prev == 0 || prev == 2)
+        flush_integer(b, src_padded);
+}
+
+int svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
+                        uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
+    const int      ph = b->phase[pass], last = pass == b->n_pass - 1;
+    const uint32_t i = b->seen[pass]++;
+    if (pass == 0) {
+        if (i >= b->cap) b->failed = 1;
+        else { b->sb[i].sb_index = sb_index; b->n0 = i + 1; }
+    } else if (i >= b->n0 || b->sb[i].sb_index != sb_index)
+        b->failed = 1;
+    if (b->failed) {
+        if (last) motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, -1); /* the unchanged C path */
+        return last;
+    }
+    b->cur = i;
+    if (ph == 11) apply_hme(b, i, 1);
+    else if (ph == 12) apply_hme(b, i, 2);
+    else if (ph == 2 || ph == 3) apply_hme(b, i, 3);
+    else if (ph == 1) {
+        memcpy(me_ctx->hme_results, b->sb[i].hme, sizeof(b->sb[i].hme));
+        memset(me_ctx->p_sb_best_mv, 0, sizeof(me_ctx->p_sb_best_mv)); /* motion_estimate_sb's initialisation (:2938-2939) */
+        for (uint32_t l = 0; l < MAX_NUM_OF_REF_PIC_LIST; l++)
+            for (uint32_t r = 0; r < MAX_REF_IDX; r++) {
+                const size_t s = SLOT(b, l, r) + i;
+                if (!b->has[s]) continue;
+                memcpy(me_ctx->p_sb_best_sad[l][r], &b->best_sad[s * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
+                memcpy(me_ctx->p_sb_best_mv[l][r], &b->best_mv[s * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
+            }
+    }
+    tls_hme = ph >= 10 ? b : NULL;
+    tls_batch = (ph == 0 || ph == 2) ? b : NULL;
+    motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, ph);
+    tls_hme = tls_batch = NULL;
+    if (ph == 0 || ph == 2) memcpy(b->sb[i].hme, me_ctx->hme_results, sizeof(b->sb[i].hme));
+    return last;
 }

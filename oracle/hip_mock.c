@@ -73,6 +73,8 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride,
                                const SvtHipSadLoop *searches, int n, uint32_t *best_sad, int16_t *best_xy) {
     (void)c;
     orc_sad_loop_batch(src, src_stride, ref, ref_stride, searches, 0, n, best_sad, best_xy);
+    if (perturb("hme"))
+        for (int i = 0; i < n; i++) { best_xy[2 * i] = (int16_t)(best_xy[2 * i] + 24); best_xy[2 * i + 1] = (int16_t)(best_xy[2 * i + 1] - 16); }   /* every search lands far off */
     return SVT_HIP_OK;
 }
 

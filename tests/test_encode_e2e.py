@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not E.have_apps(), reason="oracle/_ref/SvtAv1Enc
 # name: (w, h, frames, bit depth, preset, qp, hooks that must have run)
 ALL = set(E.HOOKS) - E.PER_UNIT_WIENER   # SVT_HIP_HOOKS=all: the picture-level Wiener search takes the place of the per-unit hooks
 ALL_UNIT = set(E.HOOKS) - {"wiener_search"}
-NO_DLF_REST = {"me", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
+NO_DLF_REST = {"hme", "me", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
 CASES = {
     "cif_8bit_m6": (352, 288, 8, 8, 6, 35, ALL),
     "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),
@@ -84,6 +84,15 @@ def test_per_unit_wiener_hooks_on_cpu_test_double(workdir):
     case = "cif_8bit_m6"
     spec = CASES[case][:6] + (ALL_UNIT,)
     _check(case, spec, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": E.ALL_PER_UNIT}, "mock_unit")
+
+
+@pytest.mark.parametrize("hooks", ["hme", "me"])
+def test_motion_estimation_hooks_one_at_a_time_on_cpu_test_double(hooks, workdir):
+    """The segment's SB loop runs a different pass sequence for every combination of the two ME hooks (svt_hip_me_bridge.c): "hme" alone = three
+    level passes + the rest of motion_estimate_sb with the reference's integer search; "me" alone = the reference's HME inside the first pass.
+    Both together are what every SVT_HIP_HOOKS=all case above runs.  40 SBs in many ME segments."""
+    case = "360p_8bit_m7"
+    _check(case, CASES[case][:6] + ({hooks},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": hooks}, "mock_" + hooks)
 
 
 @pytest.mark.parametrize("stage", E.HOOKS)
