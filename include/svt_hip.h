@@ -294,7 +294,8 @@ typedef struct {
  * of block pairs.  svt_aom_sad{W}x{H}x4d (:267-330) = four pairs that share the a block. */
 int svt_hip_block_sad_batch_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_a, int a_stride, const void *d_b, int b_stride,
                                 const SvtHipBlkPair *d_pairs, int n, uint32_t *d_sad);
-/* svt_aom_variance{W}x{H} (8-bit) / svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:524, :568).  svt_aom_mse16x16 (:248,
+/* svt_aom_variance{W}x{H} (8-bit) / svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:524, :568); pix_bytes 2 with bd = 16 selects the rule of
+ * variance_highbd (aom_dsp_rtcd.h:653; EbComputeVariance_C.c:34: 32-bit sums, no bit-depth scaling).  svt_aom_mse16x16 (:248,
  * Encoder/Codec/EbPsnr.c:84) is the 16x16 case: return value = d_var, *sse = d_sse; svt_aom_highbd_8_mse16x16 (:263) is the plain
  * 16-bit SSE of svt_hip_block_sse_batch_dev. */
 int svt_hip_block_variance_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_a, int a_stride, const void *d_b,
@@ -636,6 +637,44 @@ int svt_hip_handle_transform64_batch_dev(SvtHipCtx *ctx, int tx_size, int32_t *d
  * Output is packed (stride = w) at dst_off. */
 typedef struct { int32_t ref_off, dst_off; uint8_t w, h, subpel_x_q3, subpel_y_q3, bank, reserved[3]; } SvtHipUpsampledBlk;
 int svt_hip_upsampled_pred_batch_dev(SvtHipCtx *ctx, const uint8_t *d_ref, int ref_stride, uint8_t *d_dst, const SvtHipUpsampledBlk *d_blks, int n);
+/* svt_compute_mean_square_values_8x8 (aom_dsp_rtcd.h; EbPictureAnalysisProcess.c:287: mode 0, (sum of squares << 16) / (w * h) over a w x h
+ * area) and svt_compute_sub_mean_8x8 (:310: mode 1, rows 0 / 2 / 4 / 6 of an 8x8 block, sum << 3) for a list of block offsets. */
+int svt_hip_block_mean_batch_dev(SvtHipCtx *ctx, const uint8_t *d_plane, int stride, const int32_t *d_offs, int n, int mode, int w, int h,
+                                 uint64_t *d_out);
+/* svt_ext_sad_calculation_8x8_16x16 (aom_dsp_rtcd.h:630; EbMotionEstimation.c:122): one candidate of one 16x16 block per job.  d_state: 15 uint32
+ * per job = best_sad8x8[4] best_sad16x16 best_mv8x8[4] best_mv16x16 (in/out) sad16x16 sad8x8[4] (out). */
+int svt_hip_ext_sad_16x16_batch_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, const uint8_t *d_ref, int ref_stride,
+                                    const SvtHipExtSadJob *d_jobs, int n, uint32_t *d_state);
+/* svt_ext_sad_calculation_32x32_64x64 (aom_dsp_rtcd.h:636; EbMotionEstimation.c:189).  d_state: 30 uint32 per job = sad16x16[16] (in)
+ * best_sad32x32[4] best_sad64x64 best_mv32x32[4] best_mv64x64 (in/out) sad32x32[4] (out); d_mv[n]. */
+int svt_hip_ext_sad_32x32_64x64_batch_dev(SvtHipCtx *ctx, uint32_t *d_state, const uint32_t *d_mv, int n);
+/* svt_compute_cdef_dist_8bit / _16bit (aom_dsp_rtcd.c:97-98; EbEncCdef.c:134, :178) of one filter block: d_dst = the source plane at the filter
+ * block's origin (the reference's argument name), d_src = the n filtered blocks packed one after the other, d_list[n][3] = (by, bx, skip) in units of
+ * the block size (the reference's CdefList, EbDefinitions.h:77-81), block = (1 << bw_log2) x (1 << bh_log2); 8x8 luma (pli 0) uses the perceptual metric in FP64.  d_out[0] = the sum. */
+int svt_hip_cdef_dist_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_dst, int dstride, const void *d_src, const uint8_t *d_list, int n, int bw_log2,
+                          int bh_log2, int coeff_shift, int pli, uint64_t *d_out);
+/* svt_search_one_dual (aom_dsp_rtcd.c:363; EbEncCdef.c:1070): one greedy step of joint_strength_search_dual over d_mse0 / d_mse1[sb_count][64]:
+ * the (luma, chroma) strength pair in [start_gi, end_gi)^2 that, added to the nb_strengths pairs already in d_lev0 / d_lev1, minimises the total;
+ * written to d_lev0 / d_lev1[nb_strengths], total to d_work[0].  d_work: 4097 + sb_count uint64 of scratch. */
+int svt_hip_cdef_search_one_dual_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
+                                     int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
+/* The self-guided projection on MATERIALISED filter planes (the form the reference's pointers have; the frame kernels never write flt0 / flt1):
+ * mode 0 = svt_get_proj_subspace (common_dsp_rtcd.h; EbRestorationPick.c:448): d_acc[5] = {H00, H01, H11, C0, C1} as exact integers, d_xq[2] = the
+ * solved pair; mode 1 = svt_av1_lowbd_pixel_proj_error / svt_av1_highbd_pixel_proj_error (:174, :244): d_acc[0] = the squared error of the
+ * projection with xq[2] (host array).  r0 / r1 = the radii of the parameter set (0 = filter absent). */
+int svt_hip_sgr_flt_proj_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_src, int src_stride, const void *d_dat, int dat_stride, const int32_t *d_flt0,
+                             int flt0_stride, const int32_t *d_flt1, int flt1_stride, int w, int h, int r0, int r1, int mode, const int32_t *xq,
+                             int64_t *d_acc, int32_t *d_xq);
+/* svt_aom_convolve8_horiz / _vert (common_dsp_rtcd.h:231; Common/Codec/convolve.c:286, :298): d_filters = the 16 x 8 kernel table the reference
+ * derives from its filter pointer (get_filter_base), q0 = the first phase (get_filter_offset), step_q4 = phase advance per output sample
+ * (16 = unscaled).  d_src addresses the first output sample's position (taps reach 3 samples before, 4 + scaling after). */
+int svt_hip_convolve8_dev(SvtHipCtx *ctx, int vert, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, const int16_t *d_filters, int q0,
+                          int step_q4, int w, int h);
+/* svt_av1_wiener_convolve_add_src / svt_av1_highbd_wiener_convolve_add_src (common_dsp_rtcd.h; Common/Codec/convolve.c:105, :205) of one w x h
+ * processing unit: d_taps[16] = the horizontal and the vertical 8-tap kernel, round_0 / round_1 = ConvolveParams; d_src needs 3 samples of
+ * context on every side (4 after). */
+int svt_hip_wiener_convolve_add_src_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_src, int src_stride, void *d_dst, int dst_stride,
+                                        const int16_t *d_taps, int w, int h, int round_0, int round_1);
 /* svt_cdef_find_dir (common_dsp_rtcd.h:1031) for a list of 8x8 blocks of a 16-bit image (offsets in samples). */
 int svt_hip_cdef_find_dir_batch_dev(SvtHipCtx *ctx, const uint16_t *d_img, int stride, const int32_t *d_offs, int n, int coeff_shift,
                                     int32_t *d_dir, int32_t *d_var);

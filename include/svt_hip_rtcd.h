@@ -21,6 +21,7 @@
  */
 #ifndef SVT_HIP_RTCD_H
 #define SVT_HIP_RTCD_H
+#include <stddef.h>
 #include <stdint.h>
 #include "svt_hip.h"
 #ifdef __cplusplus
@@ -128,6 +129,45 @@ typedef struct {
     int32_t eob;
 } SvtHipTxfmParam;
 typedef void (*SvtHipInvTxfmAddFn)(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+typedef void (*SvtHipSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
+                                      const uint8_t *pred_ptr, ptrdiff_t pred_stride);
+typedef void (*SvtHipHbdSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
+                                         const uint8_t *pred_ptr, ptrdiff_t pred_stride, int bd);
+typedef uint32_t (*SvtHipSad16bFn)(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+typedef uint32_t (*SvtHipVarianceHbdFn)(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
+typedef void (*SvtHipExtSad16Fn)(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16,
+                                 uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8, uint8_t sub_sad);
+typedef void (*SvtHipExtSad3264Fn)(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                   uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32);
+typedef void (*SvtHipCopyRect8To16Fn)(uint16_t *dst, int32_t dstride, const uint8_t *src, int32_t sstride, int32_t v, int32_t h);
+typedef struct { uint8_t by, bx, skip; } SvtHipCdefList; /* CdefList, EbDefinitions.h:77-81 */
+/* bsize: BlockSize, a one-byte enum (BLOCK_4X4 0, BLOCK_4X8 1, BLOCK_8X4 2, BLOCK_8X8 3) */
+typedef uint64_t (*SvtHipCdefDist8Fn)(const uint8_t *dst8, int32_t dstride, const uint8_t *src8, const SvtHipCdefList *dlist, int32_t cdef_count, uint8_t bsize,
+                                      int32_t coeff_shift, int32_t pli);
+typedef uint64_t (*SvtHipCdefDist16Fn)(const uint16_t *dst, int32_t dstride, const uint16_t *src, const SvtHipCdefList *dlist, int32_t cdef_count, uint8_t bsize,
+                                       int32_t coeff_shift, int32_t pli);
+typedef uint64_t (*SvtHipSearchOneDualFn)(int *lev0, int *lev1, int nb_strengths, uint64_t (**mse)[64], int sb_count, int start_gi, int end_gi);
+typedef void (*SvtHipFullDist32Fn)(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                   uint32_t area_width, uint32_t area_height);
+typedef void (*SvtHipFullDistCbfZero32Fn)(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height);
+typedef uint64_t (*SvtHipSpatialDistFn)(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset, uint32_t recon_stride,
+                                        uint32_t area_width, uint32_t area_height);
+typedef int64_t (*SvtHipSseFn)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
+typedef int (*SvtHipSatdFn)(const int32_t *coeff, int length);
+typedef int64_t (*SvtHipBlockErrorFn)(const int32_t *coeff, const int32_t *dqcoeff, intptr_t block_size, int64_t *ssz);
+typedef struct { int32_t r[2], s[2]; } SvtHipSgrParamsType; /* SgrParamsType, EbDefinitions.h:1483-1486 */
+typedef void (*SvtHipGetProjSubspaceFn)(const uint8_t *src8, int width, int height, int src_stride, const uint8_t *dat8, int dat_stride, int use_highbitdepth,
+                                        int32_t *flt0, int flt0_stride, int32_t *flt1, int flt1_stride, int *xq, const SvtHipSgrParamsType *params);
+typedef int64_t (*SvtHipPixelProjErrorFn)(const uint8_t *src8, int32_t width, int32_t height, int32_t src_stride, const uint8_t *dat8, int32_t dat_stride,
+                                          int32_t *flt0, int32_t flt0_stride, int32_t *flt1, int32_t flt1_stride, int32_t xq[2], const SvtHipSgrParamsType *params);
+typedef uint64_t (*SvtHipMeanSq8x8Fn)(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height);
+typedef uint64_t (*SvtHipSubMean8x8Fn)(uint8_t *input_samples, uint16_t input_stride);
+typedef void (*SvtHipConvolve8Fn)(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x, int x_step_q4,
+                                  const int16_t *filter_y, int y_step_q4, int w, int h);
+typedef void (*SvtHipWienerConvolveFn)(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,
+                                       const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params);
+typedef void (*SvtHipHbdWienerConvolveFn)(const uint8_t *src, ptrdiff_t src_stride, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *filter_x,
+                                          const int16_t *filter_y, int32_t w, int32_t h, const SvtHipConvolveParams *conv_params, int32_t bd);
 
 /* The 22 block sizes of svt_aom_sad{W}x{H} / svt_aom_variance{W}x{H} in BlockSize order
  * (aom_dsp_rtcd.h:334-336, :524): index = position in this list. */
@@ -183,6 +223,32 @@ typedef struct SvtHipRtcd {
     SvtHipIntermVarFn      svt_compute_interm_var_four8x8;     /* :650 */
     SvtHipHandleTransformFn svt_handle_transform64[5];         /* :221-230 in header order: 16x64, 32x64, 64x16, 64x32, 64x64 */
     SvtHipInvTxfmAddFn     svt_av1_inv_txfm_add;               /* common_dsp_rtcd.h:156 */
+    /* --- the small helpers of the same kernel classes (SURVEY 2's dispatch-table rows) */
+    SvtHipSubtractBlockFn    svt_aom_subtract_block;           /* common_dsp_rtcd.h:241 */
+    SvtHipHbdSubtractBlockFn svt_aom_highbd_subtract_block;    /* the uint8_t* arguments are plain casts of uint16_t* (EbInterPrediction.c:52) */
+    SvtHipSad16bFn         sad_16b_kernel;                     /* aom_dsp_rtcd.h:651 */
+    SvtHipVarianceHbdFn    variance_highbd;                    /* :653 */
+    SvtHipNxmSadFn         svt_nxm_sad_kernel_sub_sampled;     /* :642 (the same function as svt_nxm_sad_kernel in the C table) */
+    SvtHipExtSad16Fn       svt_ext_sad_calculation_8x8_16x16;  /* :630 */
+    SvtHipExtSad3264Fn     svt_ext_sad_calculation_32x32_64x64; /* :636 */
+    SvtHipCopyRect8To16Fn  svt_copy_rect8_8bit_to_16bit;       /* common_dsp_rtcd.h:1037 */
+    SvtHipCdefDist8Fn      svt_compute_cdef_dist_8bit;         /* aom_dsp_rtcd.c:98 */
+    SvtHipCdefDist16Fn     svt_compute_cdef_dist_16bit;        /* aom_dsp_rtcd.c:97 */
+    SvtHipSearchOneDualFn  svt_search_one_dual;                /* aom_dsp_rtcd.c:363 */
+    SvtHipFullDist32Fn     svt_full_distortion_kernel32_bits;  /* common_dsp_rtcd.h; EbPictureOperators.c:156 */
+    SvtHipFullDistCbfZero32Fn svt_full_distortion_kernel_cbf_zero32_bits; /* EbPictureOperators.c:212 */
+    SvtHipSpatialDistFn    svt_spatial_full_distortion_kernel; /* 8-bit planes */
+    SvtHipSpatialDistFn    svt_full_distortion_kernel16_bits;  /* the uint8_t* arguments are uint16_t planes (EbPictureOperators.c:182-207) */
+    SvtHipSseFn            svt_aom_sse, svt_aom_highbd_sse;    /* aom_dsp_rtcd.h:93-94 (highbd: plain casts of uint16_t*, EbEncInterPrediction.c:789) */
+    SvtHipSatdFn           svt_aom_satd;                       /* common_dsp_rtcd.c:47 */
+    SvtHipBlockErrorFn     svt_av1_block_error;                /* common_dsp_rtcd.c:56; exact sums (the C function's `int` products are undefined beyond |coeff| = 46340) */
+    SvtHipGetProjSubspaceFn svt_get_proj_subspace;             /* EbRestorationPick.c:448 */
+    SvtHipPixelProjErrorFn svt_av1_lowbd_pixel_proj_error, svt_av1_highbd_pixel_proj_error; /* :174, :244 */
+    SvtHipMeanSq8x8Fn      svt_compute_mean_square_values_8x8; /* EbPictureAnalysisProcess.c:287 */
+    SvtHipSubMean8x8Fn     svt_compute_sub_mean_8x8;           /* :310 */
+    SvtHipConvolve8Fn      svt_aom_convolve8_horiz, svt_aom_convolve8_vert; /* common_dsp_rtcd.h:231; convolve.c:286, :298 */
+    SvtHipWienerConvolveFn svt_av1_wiener_convolve_add_src;    /* convolve.c:105 */
+    SvtHipHbdWienerConvolveFn svt_av1_highbd_wiener_convolve_add_src; /* convolve.c:205 */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

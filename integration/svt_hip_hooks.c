@@ -70,7 +70,15 @@ void svt_hip_hooks_report(void) {
     X(svt_av1_highbd_quantize_fp) X(svt_cdef_find_dir) X(svt_cdef_filter_block) X(svt_residual_kernel8bit) X(svt_residual_kernel16bit)     \
     X(svt_aom_upsampled_pred) X(svt_compute_interm_var_four8x8) X(svt_av1_inv_txfm_add)                                                     \
     X(svt_av1_convolve_2d_sr) X(svt_av1_convolve_x_sr) X(svt_av1_convolve_y_sr) X(svt_av1_convolve_2d_copy_sr)                              \
-    X(svt_av1_highbd_convolve_2d_sr) X(svt_av1_highbd_convolve_x_sr) X(svt_av1_highbd_convolve_y_sr) X(svt_av1_highbd_convolve_2d_copy_sr)
+    X(svt_av1_highbd_convolve_2d_sr) X(svt_av1_highbd_convolve_x_sr) X(svt_av1_highbd_convolve_y_sr) X(svt_av1_highbd_convolve_2d_copy_sr) \
+    X(svt_aom_subtract_block) X(svt_aom_highbd_subtract_block) X(sad_16b_kernel) X(variance_highbd) X(svt_nxm_sad_kernel_sub_sampled)       \
+    X(svt_ext_sad_calculation_8x8_16x16) X(svt_ext_sad_calculation_32x32_64x64) X(svt_copy_rect8_8bit_to_16bit)                             \
+    X(svt_compute_cdef_dist_8bit) X(svt_compute_cdef_dist_16bit) X(svt_search_one_dual)                                                     \
+    X(svt_full_distortion_kernel32_bits) X(svt_full_distortion_kernel_cbf_zero32_bits) X(svt_spatial_full_distortion_kernel)                \
+    X(svt_full_distortion_kernel16_bits) X(svt_aom_sse) X(svt_aom_highbd_sse) X(svt_aom_satd) X(svt_av1_block_error)                        \
+    X(svt_get_proj_subspace) X(svt_av1_lowbd_pixel_proj_error) X(svt_av1_highbd_pixel_proj_error)                                           \
+    X(svt_compute_mean_square_values_8x8) X(svt_compute_sub_mean_8x8) X(svt_aom_convolve8_horiz) X(svt_aom_convolve8_vert)                  \
+    X(svt_av1_wiener_convolve_add_src) X(svt_av1_highbd_wiener_convolve_add_src)
 /* array members <-> the reference's individually named pointers */
 #define RTCD_INDEXED(X)                                                                                                                      \
     X(svt_aom_lpf_horizontal, 0, svt_aom_lpf_horizontal_4) X(svt_aom_lpf_horizontal, 1, svt_aom_lpf_horizontal_6)                           \

@@ -197,6 +197,14 @@ def lib():
     L.svt_hip_interm_var_four8x8_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.svt_hip_handle_transform64_batch_dev.argtypes = [vp, i32, vp, i32, vp]
     L.svt_hip_upsampled_pred_batch_dev.argtypes = [vp, vp, i32, vp, vp, i32]
+    L.svt_hip_block_mean_batch_dev.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, vp]
+    L.svt_hip_ext_sad_16x16_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    L.svt_hip_ext_sad_32x32_64x64_batch_dev.argtypes = [vp, vp, vp, i32]
+    L.svt_hip_cdef_dist_dev.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.svt_hip_cdef_search_one_dual_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    L.svt_hip_sgr_flt_proj_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.svt_hip_convolve8_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32]
+    L.svt_hip_wiener_convolve_add_src_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32]
     L.svt_hip_cdef_find_dir_batch_dev.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.svt_hip_cdef_filter_block_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_lpf_edges_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32]

@@ -133,6 +133,10 @@ block_variance_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __rest
         if (BD == 8) {   // svt_aom_variance{W}x{H}_c
             s2 = (uint32_t)sse;
             v = s2 - (uint32_t)((sum * sum) / n);
+        } else if (BD == 16) {   // variance_highbd_c (EbComputeVariance_C.c:34-52): 32-bit sums, int arithmetic for sum * sum / n
+            s2 = (uint32_t)sse;
+            const int sm = (int)sum;
+            v = s2 - (uint32_t)((int)((unsigned)sm * (unsigned)sm) / n);
         } else {         // svt_aom_highbd_10_variance{W}x{H}_c: sse >> 4, sum >> 2 with rounding, clamp at 0
             s2 = (uint32_t)((sse + 8) >> 4);
             const int sm = (int)((sum + 2) >> 2);
@@ -165,6 +169,7 @@ extern "C" int svt_hip_launch_block_variance(hipStream_t st, int pix_bytes, int 
                                              const SvtHipBlkPair* d, int n, uint32_t* var_out, uint32_t* sse_out) {
     if (n <= 0) return 0;
     if (pix_bytes == 1) hipLaunchKernelGGL((block_variance_kernel<uint8_t, 8>), dim3(n), dim3(64), 0, st, (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, d, var_out, sse_out);
+    else if (bd == 16) hipLaunchKernelGGL((block_variance_kernel<uint16_t, 16>), dim3(n), dim3(64), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, d, var_out, sse_out);
     else hipLaunchKernelGGL((block_variance_kernel<uint16_t, 10>), dim3(n), dim3(64), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, d, var_out, sse_out);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,327 @@
+// percall2.hip — the remaining stand-alone forms behind the per-call table of include/svt_hip_rtcd.h: the small helpers of the reference's
+// dispatch table on this path whose work is otherwise fused into the frame kernels (picture-analysis block means, the single-candidate
+// SAD ladders, CDEF's distortion of one filter block and its strength-pair selection step, the self-guided projection on materialised
+// flt0 / flt1 planes, the 8-tap scaled convolution of svt_aom_upsampled_pred and the Wiener convolution of one stripe).
+// Bit-exact restatements of (paths under /root/reference/Source/Lib):
+//   block_mean            Encoder/Codec/EbPictureAnalysisProcess.c:287-326   svt_compute_mean_squared_values_c, svt_compute_sub_mean_8x8_c
+//   ext_sad_16 / _32_64   Encoder/Codec/EbMotionEstimation.c:122-228         svt_ext_sad_calculation_8x8_16x16_c, _32x32_64x64_c
+//   cdef_dist             Encoder/Codec/EbEncCdef.c:25-220                   compute_cdef_dist_c / _8bit_c
+//   search_one_dual       Encoder/Codec/EbEncCdef.c:1070-1118                svt_search_one_dual_c
+//   sgr_flt_proj          Encoder/Codec/EbRestorationPick.c:174-316, :448-538  svt_av1_{lowbd,highbd}_pixel_proj_error_c, svt_get_proj_subspace_c
+//   convolve8             Common/Codec/convolve.c:249-307                    svt_aom_convolve8_horiz_c / _vert_c
+//   wiener_convolve       Common/Codec/convolve.c:57-242                     svt_av1_[highbd_]wiener_convolve_add_src_c
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "svt_hip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1)
+        v += ((unsigned long long)(unsigned)__shfl_xor((int)(v >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)v, m, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) { return (long long)wave_sum_u64((unsigned long long)v); }
+__device__ __forceinline__ int clip_px(int v, int bd) { const int mx = (1 << bd) - 1; return v < 0 ? 0 : (v > mx ? mx : v); }
+
+// ------------------------------------------------------------------------------------------------ picture-analysis block means
+// mode 0: (sum of squares << 16) / (w * h) over a w x h area; mode 1: sum over rows 0, 2, 4, 6 of an 8 x 8 block, << 3.  One wave per block.
+__global__ void __launch_bounds__(64)
+block_mean_kernel(const uint8_t* __restrict__ plane, int stride, const int32_t* __restrict__ offs, int mode, int w, int h, uint64_t* __restrict__ out) {
+    const uint8_t* p = plane + offs[blockIdx.x];
+    unsigned long long acc = 0;
+    if (mode == 0) {
+        for (int i = threadIdx.x; i < w * h; i += 64) { const int y = i / w, x = i - y * w; const unsigned v = p[(size_t)y * stride + x]; acc += v * v; }
+    } else if (threadIdx.x < 32) {
+        const int y = 2 * (threadIdx.x >> 3), x = threadIdx.x & 7;
+        acc = p[(size_t)y * stride + x];
+    }
+    acc = wave_sum_u64(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = mode == 0 ? (acc << 16) / (unsigned long long)(w * h) : acc << 3;
+}
+
+// ------------------------------------------------------------------------------------------------ single-candidate SAD ladders
+// state of one 16x16 job (uint32): best_sad8x8[4] best_sad16x16 best_mv8x8[4] best_mv16x16 | sad16x16 sad8x8[4]   (15 words, the last five are outputs)
+__global__ void __launch_bounds__(64)
+ext_sad_16_kernel(const uint8_t* __restrict__ src, int ss, const uint8_t* __restrict__ ref, int rs, const SvtHipExtSadJob* __restrict__ jobs, uint32_t* __restrict__ state) {
+    const SvtHipExtSadJob j = jobs[blockIdx.x];
+    const uint8_t *s = src + j.src_off, *r = ref + j.ref_off;
+    const int      lane = threadIdx.x, q = lane >> 4, l16 = lane & 15;   // quadrant q: 8x8 block (q >> 1, q & 1); 16 lanes x 4 pixels
+    const int      qy = 8 * (q >> 1), qx = 8 * (q & 1);
+    unsigned       acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = l16 * 4 + k, y = p >> 3, x = p & 7;
+        if (!j.sub_sad || !(y & 1)) acc += (unsigned)abs((int)s[(size_t)(qy + y) * ss + qx + x] - (int)r[(size_t)(qy + y) * rs + qx + x]);
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) acc += (unsigned)__shfl_xor((int)acc, m, 64);
+    if (j.sub_sad) acc <<= 1;   // compute8x4_sad_kernel on every other row, doubled
+    const unsigned s0 = (unsigned)__shfl((int)acc, 0, 64), s1 = (unsigned)__shfl((int)acc, 16, 64), s2 = (unsigned)__shfl((int)acc, 32, 64), s3 = (unsigned)__shfl((int)acc, 48, 64);
+    if (lane == 0) {
+        uint32_t*      st = state + (size_t)blockIdx.x * 15;
+        const unsigned sad8[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            st[11 + k] = sad8[k];
+            if (sad8[k] < st[k]) { st[k] = sad8[k]; st[5 + k] = j.mv; }
+        }
+        const unsigned sad16 = s0 + s1 + s2 + s3;
+        if (sad16 < st[4]) { st[4] = sad16; st[9] = j.mv; }
+        st[10] = sad16;
+    }
+}
+// state of one 64x64 job (uint32): sad16x16[16] (input) best_sad32x32[4] best_sad64x64 best_mv32x32[4] best_mv64x64 | sad32x32[4]   (30 words)
+__global__ void __launch_bounds__(64)
+ext_sad_32_64_kernel(uint32_t* __restrict__ state, const uint32_t* __restrict__ mv, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* st = state + (size_t)i * 30;
+    uint32_t  s64 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t s32 = st[4 * k] + st[4 * k + 1] + st[4 * k + 2] + st[4 * k + 3];
+        st[26 + k] = s32;
+        if (s32 < st[16 + k]) { st[16 + k] = s32; st[21 + k] = mv[i]; }
+        s64 += s32;
+    }
+    if (s64 < st[20]) { st[20] = s64; st[25] = mv[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------ CDEF: distortion of one filter block
+// dst: the picture plane (source pixels), src: the filtered blocks packed one after the other (bw x bh each) — the reference's argument names.
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+cdef_dist_kernel(const PIX* __restrict__ dst, int dstride, const PIX* __restrict__ src, const uint8_t* __restrict__ list, int n, int bw_log2, int bh_log2, int cs,
+                 int pli, uint64_t* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bw = 1 << bw_log2, npx = 1 << (bw_log2 + bh_log2);
+    unsigned long long acc = 0;
+    for (int bi = wave; bi < n; bi += 4) {
+        const int by = list[3 * bi], bx = list[3 * bi + 1];   // CdefList {by, bx, skip}
+        const bool on = lane < npx;
+        const int  i = lane >> bw_log2, jx = lane & (bw - 1);
+        const unsigned s = on ? src[((size_t)bi << (bw_log2 + bh_log2)) + lane] : 0u;
+        const unsigned d = on ? dst[(size_t)((by << bh_log2) + i) * dstride + (bx << bw_log2) + jx] : 0u;
+        if (pli == 0 && bw_log2 == 3 && bh_log2 == 3) {   // dist_8x8_*: the perceptual luma metric
+            const unsigned long long sum_s = wave_sum_u64(s), sum_d = wave_sum_u64(d), sum_s2 = wave_sum_u64((unsigned long long)s * s),
+                                     sum_d2 = wave_sum_u64((unsigned long long)d * d), sum_sd = wave_sum_u64((unsigned long long)s * d);
+            const uint64_t svar = sum_s2 - ((sum_s * sum_s + 32) >> 6);
+            const uint64_t dvar = sum_d2 - ((sum_d * sum_d + 32) >> 6);
+            const double   num = (double)(sum_d2 + sum_s2 - 2 * sum_sd) * .5 * (double)(svar + dvar + (uint64_t)(400 << 2 * cs));
+            const double   den = sqrt((double)(20000 << 4 * cs) + (double)svar * (double)dvar);
+            acc += (unsigned long long)floor(.5 + num / den);
+        } else {
+            const int e = (int)d - (int)s;
+            acc += wave_sum_u64((unsigned long long)(unsigned)(e * e));
+        }
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) >> (2 * cs);
+}
+
+// ------------------------------------------------------------------------------------------------ CDEF: one step of the strength-pair selection
+__global__ void __launch_bounds__(256)
+one_dual_best_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const int* __restrict__ lev0, const int* __restrict__ lev1,
+                     int nb, uint64_t* __restrict__ best) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sb_count) return;
+    uint64_t b = (uint64_t)1 << 63;
+    for (int g = 0; g < nb; g++) {
+        const uint64_t c = mse0[(size_t)i * 64 + lev0[g]] + mse1[(size_t)i * 64 + lev1[g]];
+        if (c < b) b = c;
+    }
+    best[i] = b;
+}
+__global__ void __launch_bounds__(256)
+one_dual_total_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const uint64_t* __restrict__ best, int start_gi, int ng,
+                      uint64_t* __restrict__ tot) {
+    __shared__ unsigned long long part[4];
+    const int j = start_gi + blockIdx.x / ng, k = start_gi + blockIdx.x % ng;
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < sb_count; i += 256) {
+        const uint64_t c = mse0[(size_t)i * 64 + j] + mse1[(size_t)i * 64 + k], b = best[i];
+        acc += c < b ? c : b;
+    }
+    acc = wave_sum_u64(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tot[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// the first minimum in (j, k) raster order; out[0] = its total, lev0[nb] / lev1[nb] = the pair
+__global__ void __launch_bounds__(64)
+one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out) {
+    const int lane = threadIdx.x;
+    uint64_t  bv = (uint64_t)1 << 63;
+    int       bi = 0x7fffffff;
+    for (int i = lane; i < ng * ng; i += 64)
+        if (tot[i] < bv) { bv = tot[i]; bi = i; }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t ov = ((uint64_t)(unsigned)__shfl_xor((int)(bv >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)bv, m, 64);
+        const int      oi = __shfl_xor(bi, m, 64);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const bool any = bi != 0x7fffffff;   // nothing below 1 << 63: the reference keeps (0, 0)
+        lev0[nb] = any ? start_gi + bi / ng : 0;
+        lev1[nb] = any ? start_gi + bi % ng : 0;
+        out[0] = bv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ self-guided projection on materialised filters
+// mode 0: acc[0..4] += {H00, H01, H11, C0, C1} (exact integers; the reference accumulates the same integers in doubles, exact below 2^53)
+// mode 1: acc[0] += squared error of the projection with xq
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+sgr_flt_proj_kernel(const PIX* __restrict__ src, int ss, const PIX* __restrict__ dat, int ds, const int32_t* __restrict__ f0, int f0s, const int32_t* __restrict__ f1,
+                    int f1s, int w, int h, int r0, int r1, int mode, int xq0, int xq1, long long* __restrict__ acc) {
+    long long a[5] = {0, 0, 0, 0, 0};
+    for (int y = blockIdx.x; y < h; y += gridDim.x)
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const int d = dat[(size_t)y * ds + x], s = src[(size_t)y * ss + x];
+            const int u = d << 4;
+            if (mode == 0) {
+                const long long sv = (long long)((s << 4) - u);
+                const long long v1 = r0 > 0 ? (long long)f0[(size_t)y * f0s + x] - u : 0, v2 = r1 > 0 ? (long long)f1[(size_t)y * f1s + x] - u : 0;
+                a[0] += v1 * v1; a[1] += v1 * v2; a[2] += v2 * v2; a[3] += v1 * sv; a[4] += v2 * sv;
+            } else {
+                int e;
+                if (r0 > 0 || r1 > 0) {
+                    int v = u << 7;
+                    if (r0 > 0) v += xq0 * (f0[(size_t)y * f0s + x] - u);
+                    if (r1 > 0) v += xq1 * (f1[(size_t)y * f1s + x] - u);
+                    e = ((v + (1 << 10)) >> 11) - s;
+                } else
+                    e = d - s;
+                a[0] += (long long)e * e;
+            }
+        }
+    __shared__ long long part[4][5];
+    const int nacc = mode == 0 ? 5 : 1;
+    for (int k = 0; k < nacc; k++) {
+        const long long t = wave_sum_i64(a[k]);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nacc)
+        atomicAdd((unsigned long long*)&acc[threadIdx.x],
+                  (unsigned long long)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+// svt_get_proj_subspace_c's solve: every operation an IEEE double operation in the reference's order (-ffp-contract=off)
+__global__ void sgr_flt_solve_kernel(const long long* __restrict__ sums, int size, int r0, int r1, int32_t* __restrict__ xq) {
+    double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    const double dsize = (double)size;
+    H00 /= dsize; H01 /= dsize; H11 /= dsize; C0 /= dsize; C1 /= dsize;
+    const double H10 = H01;
+    int q0 = 0, q1 = 0;
+    if (r0 == 0) { if (!(H11 < 1e-8)) q1 = (int)rint((C1 / H11) * 128.0); }
+    else if (r1 == 0) { if (!(H00 < 1e-8)) q0 = (int)rint((C0 / H00) * 128.0); }
+    else {
+        const double det = H00 * H11 - H01 * H10;
+        if (!(det < 1e-8)) {
+            const double x0 = (H11 * C0 - H01 * C1) / det, x1 = (H00 * C1 - H10 * C0) / det;
+            q0 = (int)rint(x0 * 128.0); q1 = (int)rint(x1 * 128.0);
+        }
+    }
+    xq[0] = q0; xq[1] = q1;
+}
+
+// ------------------------------------------------------------------------------------------------ 8-tap convolution with a phase table (scaling allowed)
+// filters[16][8]: the 256-byte-aligned kernel table the reference derives from its filter pointer; q0 = first phase, step = phase advance per sample
+template <bool VERT>
+__global__ void __launch_bounds__(256)
+convolve8_kernel(const uint8_t* __restrict__ src, int ss, uint8_t* __restrict__ dst, int ds, const int16_t* __restrict__ filters, int q0, int step, int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int      q = q0 + (VERT ? y : x) * step, base = (q >> 4) - 3;
+    const int16_t* f = filters + 8 * (q & 15);
+    int            sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += (int)(VERT ? src[(ptrdiff_t)(base + k) * ss + x] : src[(ptrdiff_t)y * ss + base + k]) * f[k];
+    dst[(size_t)y * ds + x] = (uint8_t)clip_px((sum + 64) >> 7, 8);
+}
+
+// ------------------------------------------------------------------------------------------------ Wiener convolution of one processing unit
+// horizontal pass with the source added and the intermediate clamp, vertical pass on the clamped rows; step 16 (no scaling), taps fx / fy.
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+wiener_convolve_kernel(const PIX* __restrict__ src, int ss, PIX* __restrict__ dst, int ds, const int16_t* __restrict__ taps, int w, int h, int round0, int round1, int bd) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int16_t *fx = taps, *fy = taps + 8;
+    const int      lim = (1 << (bd + 1 + 7 - round0)) - 1;
+    int            mid[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const PIX* row = src + (ptrdiff_t)(y + k - 3) * ss + x - 3;
+        int        sum = ((int)row[3] << 7) + (1 << (bd + 7 - 1));
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += (int)row[t] * fx[t];
+        const int v = (sum + ((1 << round0) >> 1)) >> round0;
+        mid[k] = v < 0 ? 0 : (v > lim ? lim : v);
+    }
+    int sum = (mid[3] << 7) - (1 << (bd + round1 - 1));
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += mid[k] * fy[k];
+    dst[(size_t)y * ds + x] = (PIX)clip_px((sum + ((1 << round1) >> 1)) >> round1, bd);
+}
+
+}  // namespace
+
+extern "C" int svt_hip_launch_block_mean(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, int mode, int w, int h, uint64_t* out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(block_mean_kernel, dim3(n), dim3(64), 0, st, plane, stride, offs, mode, w, h, out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_ext_sad_16(hipStream_t st, const uint8_t* src, int ss, const uint8_t* ref, int rs, const SvtHipExtSadJob* jobs, int n, uint32_t* state) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ext_sad_16_kernel, dim3(n), dim3(64), 0, st, src, ss, ref, rs, jobs, state);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_ext_sad_32_64(hipStream_t st, uint32_t* state, const uint32_t* mv, int n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ext_sad_32_64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, state, mv, n);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_cdef_dist(hipStream_t st, int pix_bytes, const void* dst, int dstride, const void* src, const uint8_t* list, int n, int bw_log2, int bh_log2,
+                                        int cs, int pli, uint64_t* out) {
+    if (pix_bytes == 1) hipLaunchKernelGGL(cdef_dist_kernel<uint8_t>, dim3(1), dim3(256), 0, st, (const uint8_t*)dst, dstride, (const uint8_t*)src, list, n, bw_log2, bh_log2, cs, pli, out);
+    else hipLaunchKernelGGL(cdef_dist_kernel<uint16_t>, dim3(1), dim3(256), 0, st, (const uint16_t*)dst, dstride, (const uint16_t*)src, list, n, bw_log2, bh_log2, cs, pli, out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
+                                              uint64_t* best, uint64_t* tot, uint64_t* out) {
+    const int ng = end_gi - start_gi;
+    if (sb_count > 0) hipLaunchKernelGGL(one_dual_best_kernel, dim3((sb_count + 255) / 256), dim3(256), 0, st, mse0, mse1, sb_count, lev0, lev1, nb, best);
+    if (ng > 0) hipLaunchKernelGGL(one_dual_total_kernel, dim3(ng * ng), dim3(256), 0, st, mse0, mse1, sb_count, best, start_gi, ng, tot);
+    hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(64), 0, st, tot, start_gi, ng > 0 ? ng : 0, nb, lev0, lev1, out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,
+                                           int w, int h, int r0, int r1, int mode, int xq0, int xq1, long long* acc, int32_t* xq_out) {
+    const int blocks = h < 256 ? h : 256;
+    if (pix_bytes == 1)
+        hipLaunchKernelGGL(sgr_flt_proj_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)src, ss, (const uint8_t*)dat, ds, f0, f0s, f1, f1s, w, h, r0, r1, mode, xq0, xq1, acc);
+    else
+        hipLaunchKernelGGL(sgr_flt_proj_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)src, ss, (const uint16_t*)dat, ds, f0, f0s, f1, f1s, w, h, r0, r1, mode, xq0, xq1, acc);
+    if (mode == 0) hipLaunchKernelGGL(sgr_flt_solve_kernel, dim3(1), dim3(1), 0, st, acc, w * h, r0, r1, xq_out);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_convolve8(hipStream_t st, int vert, const uint8_t* src, int ss, uint8_t* dst, int ds, const int16_t* filters, int q0, int step, int w, int h) {
+    const dim3 grid((w + 63) / 64, (h + 3) / 4);
+    if (vert) hipLaunchKernelGGL(convolve8_kernel<true>, grid, dim3(256), 0, st, src, ss, dst, ds, filters, q0, step, w, h);
+    else hipLaunchKernelGGL(convolve8_kernel<false>, grid, dim3(256), 0, st, src, ss, dst, ds, filters, q0, step, w, h);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_wiener_convolve(hipStream_t st, int pix_bytes, int bd, const void* src, int ss, void* dst, int ds, const int16_t* taps, int w, int h, int round0,
+                                              int round1) {
+    const dim3 grid((w + 63) / 64, (h + 3) / 4);
+    if (pix_bytes == 1) hipLaunchKernelGGL(wiener_convolve_kernel<uint8_t>, grid, dim3(256), 0, st, (const uint8_t*)src, ss, (uint8_t*)dst, ds, taps, w, h, round0, round1, 8);
+    else hipLaunchKernelGGL(wiener_convolve_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, ss, (uint16_t*)dst, ds, taps, w, h, round0, round1, bd);
+    return (int)hipGetLastError();
+}

@@ -674,6 +674,302 @@ template <int SLOT, int TS> uint64_t handle_transform_hip(int32_t* output) {
     }
     FALLBACK("svt_handle_transform64xN", svt_handle_transform64[SLOT], output);
 }
+
+// ----------------------------------------------------------------------------------- the small helpers of the same kernel classes
+void subtract_block_hip(int rows, int cols, int16_t* diff, ptrdiff_t ds, const uint8_t* src, ptrdiff_t ss, const uint8_t* pred, ptrdiff_t ps) {
+    Guard lk;
+    if (rows > 0 && cols > 0 && residual_generic(1, src, (uint32_t)ss, pred, (uint32_t)ps, diff, (uint32_t)ds, (uint32_t)cols, (uint32_t)rows)) return;
+    FALLBACK("svt_aom_subtract_block", svt_aom_subtract_block, rows, cols, diff, ds, src, ss, pred, ps);
+}
+void subtract_block_hbd_hip(int rows, int cols, int16_t* diff, ptrdiff_t ds, const uint8_t* src8, ptrdiff_t ss, const uint8_t* pred8, ptrdiff_t ps, int bd) {
+    Guard lk;   // the byte pointers are plain casts of uint16_t pointers here (EbInterPrediction.c:52-53), not CONVERT_TO_BYTEPTR values
+    if (rows > 0 && cols > 0 && residual_generic(2, src8, (uint32_t)ss, pred8, (uint32_t)ps, diff, (uint32_t)ds, (uint32_t)cols, (uint32_t)rows)) return;
+    FALLBACK("svt_aom_highbd_subtract_block", svt_aom_highbd_subtract_block, rows, cols, diff, ds, src8, ss, pred8, ps, bd);
+}
+uint32_t sad_16b_hip(uint16_t* src, uint32_t ss, uint16_t* ref, uint32_t rs, uint32_t h, uint32_t w) {
+    Guard lk;
+    void *da, *db, *dj; uint32_t* dout; size_t p; uint32_t r;
+    if (g_ctx && w && h && pair_stage(2, src, (int)ss, ref, (int)rs, (int)w, (int)h, &da, &db, &dj, &dout, &p) &&
+        svt_hip_block_sad_batch_dev(g_ctx, 2, da, (int)(p / 2), db, (int)(p / 2), (const SvtHipBlkPair*)dj, 1, dout) == 0 && down(&r, dout, 4))
+        return r;
+    FALLBACK("sad_16b_kernel", sad_16b_kernel, src, ss, ref, rs, h, w);
+}
+uint32_t variance_highbd_hip(const uint16_t* a, int as, const uint16_t* b, int bs, int w, int h, uint32_t* sse) {
+    Guard lk;
+    unsigned v;
+    if (w > 0 && h > 0 && var_generic(2, 16, a, as, b, bs, w, h, &v, sse)) return v;
+    FALLBACK("variance_highbd", variance_highbd, a, as, b, bs, w, h, sse);
+}
+uint32_t nxm_sad_sub_hip(const uint8_t* src, uint32_t ss, const uint8_t* ref, uint32_t rs, uint32_t h, uint32_t w) {
+    Guard lk;
+    uint32_t r;
+    if (sad_generic(src, (int)ss, ref, (int)rs, (int)w, (int)h, &r)) return r;
+    FALLBACK("svt_nxm_sad_kernel_sub_sampled", svt_nxm_sad_kernel_sub_sampled, src, ss, ref, rs, h, w);
+}
+void ext_sad_16_hip(uint8_t* src, uint32_t ss, uint8_t* ref, uint32_t rs, uint32_t* bs8, uint32_t* bs16, uint32_t* bm8, uint32_t* bm16, uint32_t mv, uint32_t* s16, uint32_t* s8,
+                    uint8_t sub) {
+    Guard lk;
+    if (g_ctx) {
+        uint8_t *d_s = (uint8_t*)dev(0, 16 * 16), *d_r = (uint8_t*)dev(1, 16 * 16); SvtHipExtSadJob* d_j = (SvtHipExtSadJob*)dev(2, sizeof(SvtHipExtSadJob));
+        uint32_t* d_st = (uint32_t*)dev(3, 15 * 4);
+        const SvtHipExtSadJob job = {0, 0, mv, sub ? 1 : 0};
+        uint32_t st[15];
+        std::memcpy(st, bs8, 16); st[4] = *bs16; std::memcpy(st + 5, bm8, 16); st[9] = *bm16;
+        std::memset(st + 10, 0, 20);
+        if (d_s && d_r && d_j && d_st && up2d(d_s, 16, src, ss, 16, 16) && up2d(d_r, 16, ref, rs, 16, 16) && up(d_j, &job, sizeof(job)) && up(d_st, st, sizeof(st)) &&
+            svt_hip_ext_sad_16x16_batch_dev(g_ctx, d_s, 16, d_r, 16, d_j, 1, d_st) == 0 && down(st, d_st, sizeof(st))) {
+            std::memcpy(bs8, st, 16); *bs16 = st[4]; std::memcpy(bm8, st + 5, 16); *bm16 = st[9]; *s16 = st[10]; std::memcpy(s8, st + 11, 16);
+            return;
+        }
+    }
+    FALLBACK("svt_ext_sad_calculation_8x8_16x16", svt_ext_sad_calculation_8x8_16x16, src, ss, ref, rs, bs8, bs16, bm8, bm16, mv, s16, s8, sub);
+}
+void ext_sad_32_64_hip(uint32_t* s16, uint32_t* bs32, uint32_t* bs64, uint32_t* bm32, uint32_t* bm64, uint32_t mv, uint32_t* s32) {
+    Guard lk;
+    if (g_ctx) {
+        uint32_t* d_st = (uint32_t*)dev(3, 30 * 4); uint32_t* d_mv = (uint32_t*)dev(2, 4);
+        uint32_t st[30];
+        std::memcpy(st, s16, 64); std::memcpy(st + 16, bs32, 16); st[20] = *bs64; std::memcpy(st + 21, bm32, 16); st[25] = *bm64;
+        std::memset(st + 26, 0, 16);
+        if (d_st && d_mv && up(d_st, st, sizeof(st)) && up(d_mv, &mv, 4) && svt_hip_ext_sad_32x32_64x64_batch_dev(g_ctx, d_st, d_mv, 1) == 0 && down(st, d_st, sizeof(st))) {
+            std::memcpy(bs32, st + 16, 16); *bs64 = st[20]; std::memcpy(bm32, st + 21, 16); *bm64 = st[25]; std::memcpy(s32, st + 26, 16);
+            return;
+        }
+    }
+    FALLBACK("svt_ext_sad_calculation_32x32_64x64", svt_ext_sad_calculation_32x32_64x64, s16, bs32, bs64, bm32, bm64, mv, s32);
+}
+void copy_rect8_hip(uint16_t* dst, int32_t ds, const uint8_t* src, int32_t ss, int32_t v, int32_t h) {
+    Guard lk;   // v rows of h samples (the reference's argument order)
+    if (g_ctx && v > 0 && h > 0) {
+        const size_t ip = rup((size_t)h, 4), op = rup((size_t)h * 2, 4);
+        uint8_t* d_i = (uint8_t*)dev(0, ip * v); uint16_t* d_o = (uint16_t*)dev(1, op * v);
+        if (d_i && d_o && up2d(d_i, ip, src, (size_t)ss, (size_t)h, v) &&
+            svt_hip_picture_format_dev(g_ctx, 3, d_i, (int)ip, nullptr, 0, d_o, (int)(op / 2), nullptr, 0, h, v) == 0 && down2d(dst, (size_t)ds * 2, d_o, op, (size_t)h * 2, v))
+            return;
+    }
+    FALLBACK("svt_copy_rect8_8bit_to_16bit", svt_copy_rect8_8bit_to_16bit, dst, ds, src, ss, v, h);
+}
+// BlockSize -> log2 of the block's width / height; only the four sizes compute_cdef_dist handles
+bool cdef_bsize(int bsize, int* bwl, int* bhl) {
+    if (bsize < 0 || bsize > 3) return false;
+    *bwl = (bsize == 2 || bsize == 3) ? 3 : 2;   // BLOCK_4X4 0, BLOCK_4X8 1, BLOCK_8X4 2, BLOCK_8X8 3
+    *bhl = (bsize == 1 || bsize == 3) ? 3 : 2;
+    return true;
+}
+bool cdef_dist_generic(int pb, const void* dst, int32_t dstride, const void* src, const SvtHipCdefList* dlist, int32_t n, int bsize, int32_t cs, int32_t pli, uint64_t* out) {
+    int bwl, bhl;
+    if (!g_ctx || n < 0 || n > 64 || !cdef_bsize(bsize, &bwl, &bhl)) return false;
+    if (n == 0) { *out = 0; return true; }
+    int max_by = 0, max_bx = 0;
+    for (int i = 0; i < n; i++) { if (dlist[i].by > max_by) max_by = dlist[i].by; if (dlist[i].bx > max_bx) max_bx = dlist[i].bx; }
+    const int    w = (max_bx + 1) << bwl, h = (max_by + 1) << bhl;   // the part of the plane the listed blocks cover
+    const size_t p = rup((size_t)w * pb, 4), sb = ((size_t)n << (bwl + bhl)) * pb;
+    uint8_t *d_d = (uint8_t*)dev(0, p * h), *d_s = (uint8_t*)dev(1, sb), *d_l = (uint8_t*)dev(2, 3 * (size_t)n); uint64_t* d_o = (uint64_t*)dev(3, 8);
+    return d_d && d_s && d_l && d_o && up2d(d_d, p, dst, (size_t)dstride * pb, (size_t)w * pb, h) && up(d_s, src, sb) && up(d_l, dlist, 3 * (size_t)n) &&
+           svt_hip_cdef_dist_dev(g_ctx, pb, d_d, (int)(p / pb), d_s, d_l, n, bwl, bhl, cs, pli, d_o) == 0 && down(out, d_o, 8);
+}
+uint64_t cdef_dist8_hip(const uint8_t* dst, int32_t dstride, const uint8_t* src, const SvtHipCdefList* dlist, int32_t n, uint8_t bsize, int32_t cs, int32_t pli) {
+    Guard lk;
+    uint64_t r;
+    if (cdef_dist_generic(1, dst, dstride, src, dlist, n, bsize, cs, pli, &r)) return r;
+    FALLBACK("svt_compute_cdef_dist_8bit", svt_compute_cdef_dist_8bit, dst, dstride, src, dlist, n, bsize, cs, pli);
+}
+uint64_t cdef_dist16_hip(const uint16_t* dst, int32_t dstride, const uint16_t* src, const SvtHipCdefList* dlist, int32_t n, uint8_t bsize, int32_t cs, int32_t pli) {
+    Guard lk;
+    uint64_t r;
+    if (cdef_dist_generic(2, dst, dstride, src, dlist, n, bsize, cs, pli, &r)) return r;
+    FALLBACK("svt_compute_cdef_dist_16bit", svt_compute_cdef_dist_16bit, dst, dstride, src, dlist, n, bsize, cs, pli);
+}
+uint64_t search_one_dual_hip(int* lev0, int* lev1, int nb, uint64_t (**mse)[64], int sb_count, int start_gi, int end_gi) {
+    Guard lk;
+    if (g_ctx && sb_count >= 0 && nb >= 0 && nb < 8 && start_gi >= 0 && end_gi <= 64 && start_gi <= end_gi) {
+        const size_t mb = (size_t)sb_count * 64 * 8;
+        uint64_t *d_m0 = (uint64_t*)dev(0, mb + 8), *d_m1 = (uint64_t*)dev(1, mb + 8), *d_w = (uint64_t*)dev(3, (4097 + (size_t)sb_count) * 8);
+        int* d_lev = (int*)dev(2, 16 * sizeof(int));
+        int lev[16];
+        std::memcpy(lev, lev0, 8 * sizeof(int)); std::memcpy(lev + 8, lev1, 8 * sizeof(int));
+        uint64_t r;
+        if (d_m0 && d_m1 && d_w && d_lev && (!mb || (up(d_m0, mse[0], mb) && up(d_m1, mse[1], mb))) && up(d_lev, lev, sizeof(lev)) &&
+            svt_hip_cdef_search_one_dual_dev(g_ctx, d_m0, d_m1, sb_count, d_lev, d_lev + 8, nb, start_gi, end_gi, d_w) == 0 && down(lev, d_lev, sizeof(lev)) && down(&r, d_w, 8)) {
+            lev0[nb] = lev[nb]; lev1[nb] = lev[8 + nb];
+            return r;
+        }
+    }
+    FALLBACK("svt_search_one_dual", svt_search_one_dual, lev0, lev1, nb, mse, sb_count, start_gi, end_gi);
+}
+// coefficient-domain sums of one w x h block with strides: packed on the way up, then the batched entry point with one block
+bool coeff_dist_generic(const int32_t* coeff, uint32_t cs, const int32_t* recon, uint32_t rs, uint32_t w, uint32_t h, uint64_t out[3]) {
+    if (!g_ctx || !w || !h || (size_t)w * h > 128 * 128) return false;
+    const size_t n = (size_t)w * h;
+    int32_t *d_c = (int32_t*)dev(0, n * 4), *d_r = recon ? (int32_t*)dev(1, n * 4) : nullptr; uint64_t* d_o = (uint64_t*)dev(3, 24);
+    return d_c && (!recon || d_r) && d_o && up2d(d_c, (size_t)w * 4, coeff, (size_t)cs * 4, (size_t)w * 4, h) &&
+           (!recon || up2d(d_r, (size_t)w * 4, recon, (size_t)rs * 4, (size_t)w * 4, h)) && svt_hip_coeff_distortion_batch_dev(g_ctx, d_c, d_r, (int)n, 1, d_o) == 0 &&
+           down(out, d_o, 24);
+}
+void full_dist32_hip(int32_t* coeff, uint32_t cs, int32_t* recon, uint32_t rs, uint64_t res[2], uint32_t w, uint32_t h) {
+    Guard lk;
+    uint64_t o[3];
+    if (coeff_dist_generic(coeff, cs, recon, rs, w, h, o)) { res[0] = o[0]; res[1] = o[1]; return; }
+    FALLBACK("svt_full_distortion_kernel32_bits", svt_full_distortion_kernel32_bits, coeff, cs, recon, rs, res, w, h);
+}
+void full_dist_cbf_zero32_hip(int32_t* coeff, uint32_t cs, uint64_t res[2], uint32_t w, uint32_t h) {
+    Guard lk;
+    uint64_t o[3];
+    if (coeff_dist_generic(coeff, cs, nullptr, 0, w, h, o)) { res[0] = o[1]; res[1] = o[1]; return; }
+    FALLBACK("svt_full_distortion_kernel_cbf_zero32_bits", svt_full_distortion_kernel_cbf_zero32_bits, coeff, cs, res, w, h);
+}
+bool sse_generic(int pb, const void* a, int as, const void* b, int bs, int w, int h, uint64_t* out) {
+    void *da, *db, *dj; uint32_t* dout; size_t p;
+    return g_ctx && w > 0 && h > 0 && pair_stage(pb, a, as, b, bs, w, h, &da, &db, &dj, &dout, &p) &&
+           svt_hip_block_sse_batch_dev(g_ctx, pb, da, (int)(p / pb), db, (int)(p / pb), (const SvtHipBlkPair*)dj, 1, (uint64_t*)dout) == 0 && down(out, dout, 8);
+}
+uint64_t spatial_dist_hip(uint8_t* in, uint32_t io, uint32_t is, uint8_t* rec, int32_t ro, uint32_t rs, uint32_t w, uint32_t h) {
+    Guard lk;
+    uint64_t r;
+    if (sse_generic(1, in + io, (int)is, rec + ro, (int)rs, (int)w, (int)h, &r)) return r;
+    FALLBACK("svt_spatial_full_distortion_kernel", svt_spatial_full_distortion_kernel, in, io, is, rec, ro, rs, w, h);
+}
+uint64_t full_dist16_hip(uint8_t* in, uint32_t io, uint32_t is, uint8_t* rec, int32_t ro, uint32_t rs, uint32_t w, uint32_t h) {
+    Guard lk;   // 16-bit planes behind uint8_t* (a plain cast in the reference, offsets in samples)
+    uint64_t r;
+    if (sse_generic(2, (const uint16_t*)in + io, (int)is, (const uint16_t*)rec + ro, (int)rs, (int)w, (int)h, &r)) return r;
+    FALLBACK("svt_full_distortion_kernel16_bits", svt_full_distortion_kernel16_bits, in, io, is, rec, ro, rs, w, h);
+}
+int64_t sse_hip(const uint8_t* a, int as, const uint8_t* b, int bs, int w, int h) {
+    Guard lk;
+    uint64_t r;
+    if (sse_generic(1, a, as, b, bs, w, h, &r)) return (int64_t)r;
+    FALLBACK("svt_aom_sse", svt_aom_sse, a, as, b, bs, w, h);
+}
+int64_t sse_hbd_hip(const uint8_t* a8, int as, const uint8_t* b8, int bs, int w, int h) {
+    Guard lk;
+    uint64_t r;
+    if (sse_generic(2, a8, as, b8, bs, w, h, &r)) return (int64_t)r;   // plain casts of uint16_t pointers (EbEncInterPrediction.c:789-790)
+    FALLBACK("svt_aom_highbd_sse", svt_aom_highbd_sse, a8, as, b8, bs, w, h);
+}
+int satd_hip(const int32_t* coeff, int length) {
+    Guard lk;
+    uint64_t o[3];
+    if (length > 0 && coeff_dist_generic(coeff, (uint32_t)length, nullptr, 0, (uint32_t)length, 1, o)) return (int)o[2];
+    FALLBACK("svt_aom_satd", svt_aom_satd, coeff, length);
+}
+int64_t block_error_hip(const int32_t* coeff, const int32_t* dq, intptr_t n, int64_t* ssz) {
+    Guard lk;
+    uint64_t o[3];
+    if (n > 0 && n <= 128 * 128 && coeff_dist_generic(coeff, (uint32_t)n, dq, (uint32_t)n, (uint32_t)n, 1, o)) { *ssz = (int64_t)o[1]; return (int64_t)o[0]; }
+    FALLBACK("svt_av1_block_error", svt_av1_block_error, coeff, dq, n, ssz);
+}
+// materialised flt0 / flt1: stage the unit's four planes; mode 0 returns the solved pair, mode 1 the error
+bool sgr_flt_generic(int pb, const void* src, int w, int h, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s, const SvtHipSgrParamsType* prm,
+                     int mode, const int32_t* xq_in, int32_t* xq_out, int64_t* err) {
+    if (!g_ctx || w < 1 || h < 1 || !prm) return false;
+    const int    r0 = prm->r[0], r1 = prm->r[1];
+    const size_t p = rup((size_t)w * pb, 4), fp = (size_t)w * 4;
+    uint8_t *d_s = (uint8_t*)dev(0, p * h), *d_d = (uint8_t*)dev(1, p * h); int64_t* d_acc = (int64_t*)dev(3, 48);
+    int32_t *d_f0 = r0 > 0 ? (int32_t*)dev(4, fp * h) : nullptr, *d_f1 = r1 > 0 ? (int32_t*)dev(5, fp * h) : nullptr;
+    int64_t acc[6];
+    if (!(d_s && d_d && d_acc && (r0 <= 0 || d_f0) && (r1 <= 0 || d_f1) && up2d(d_s, p, src, (size_t)ss * pb, (size_t)w * pb, h) && up2d(d_d, p, dat, (size_t)ds * pb, (size_t)w * pb, h) &&
+          (r0 <= 0 || up2d(d_f0, fp, f0, (size_t)f0s * 4, fp, h)) && (r1 <= 0 || up2d(d_f1, fp, f1, (size_t)f1s * 4, fp, h)) &&
+          svt_hip_sgr_flt_proj_dev(g_ctx, pb, d_s, (int)(p / pb), d_d, (int)(p / pb), d_f0, w, d_f1, w, w, h, r0, r1, mode, xq_in, d_acc, (int32_t*)(d_acc + 5)) == 0 &&
+          down(acc, d_acc, sizeof(acc))))
+        return false;
+    if (mode == 0) std::memcpy(xq_out, &acc[5], 8);
+    else *err = acc[0];
+    return true;
+}
+void get_proj_subspace_hip(const uint8_t* src8, int w, int h, int ss, const uint8_t* dat8, int ds, int hbd, int32_t* f0, int f0s, int32_t* f1, int f1s, int* xq,
+                           const SvtHipSgrParamsType* prm) {
+    Guard lk;
+    const void *s = hbd ? (const void*)((uintptr_t)src8 << 1) : (const void*)src8, *d = hbd ? (const void*)((uintptr_t)dat8 << 1) : (const void*)dat8;
+    int32_t q[2];
+    if (sgr_flt_generic(hbd ? 2 : 1, s, w, h, ss, d, ds, f0, f0s, f1, f1s, prm, 0, nullptr, q, nullptr)) { xq[0] = q[0]; xq[1] = q[1]; return; }
+    FALLBACK("svt_get_proj_subspace", svt_get_proj_subspace, src8, w, h, ss, dat8, ds, hbd, f0, f0s, f1, f1s, xq, prm);
+}
+int64_t pixel_proj_error_hip(const uint8_t* src8, int32_t w, int32_t h, int32_t ss, const uint8_t* dat8, int32_t ds, int32_t* f0, int32_t f0s, int32_t* f1, int32_t f1s, int32_t xq[2],
+                             const SvtHipSgrParamsType* prm) {
+    Guard lk;
+    int64_t e;
+    if (sgr_flt_generic(1, src8, w, h, ss, dat8, ds, f0, f0s, f1, f1s, prm, 1, xq, nullptr, &e)) return e;
+    FALLBACK("svt_av1_lowbd_pixel_proj_error", svt_av1_lowbd_pixel_proj_error, src8, w, h, ss, dat8, ds, f0, f0s, f1, f1s, xq, prm);
+}
+int64_t pixel_proj_error_hbd_hip(const uint8_t* src8, int32_t w, int32_t h, int32_t ss, const uint8_t* dat8, int32_t ds, int32_t* f0, int32_t f0s, int32_t* f1, int32_t f1s,
+                                 int32_t xq[2], const SvtHipSgrParamsType* prm) {
+    Guard lk;
+    int64_t e;
+    if (sgr_flt_generic(2, (const void*)((uintptr_t)src8 << 1), w, h, ss, (const void*)((uintptr_t)dat8 << 1), ds, f0, f0s, f1, f1s, prm, 1, xq, nullptr, &e)) return e;
+    FALLBACK("svt_av1_highbd_pixel_proj_error", svt_av1_highbd_pixel_proj_error, src8, w, h, ss, dat8, ds, f0, f0s, f1, f1s, xq, prm);
+}
+uint64_t mean_sq_8x8_hip(uint8_t* in, uint32_t stride, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (g_ctx && w && h && w <= 64 && h <= 64) {
+        const size_t p = rup(w, 4);
+        uint8_t* d_in = (uint8_t*)dev(0, p * h); int32_t* d_off = (int32_t*)dev(2, 16); uint64_t* d_o = (uint64_t*)dev(3, 16);
+        const int32_t zero = 0;
+        uint64_t r;
+        if (d_in && d_off && d_o && up2d(d_in, p, in, stride, w, h) && up(d_off, &zero, 4) && svt_hip_block_mean_batch_dev(g_ctx, d_in, (int)p, d_off, 1, 0, (int)w, (int)h, d_o) == 0 &&
+            down(&r, d_o, 8))
+            return r;
+    }
+    FALLBACK("svt_compute_mean_square_values_8x8", svt_compute_mean_square_values_8x8, in, stride, w, h);
+}
+uint64_t sub_mean_8x8_hip(uint8_t* in, uint16_t stride) {
+    Guard lk;
+    if (g_ctx) {
+        uint8_t* d_in = (uint8_t*)dev(0, 8 * 8); int32_t* d_off = (int32_t*)dev(2, 16); uint64_t* d_o = (uint64_t*)dev(3, 16);
+        const int32_t zero = 0;
+        uint64_t r;
+        if (d_in && d_off && d_o && up2d(d_in, 8, in, stride, 8, 7) && up(d_off, &zero, 4) && svt_hip_block_mean_batch_dev(g_ctx, d_in, 8, d_off, 1, 1, 8, 8, d_o) == 0 && down(&r, d_o, 8))
+            return r;
+    }
+    FALLBACK("svt_compute_sub_mean_8x8", svt_compute_sub_mean_8x8, in, stride);
+}
+// the reference finds the 16-kernel table by aligning the filter pointer down to 256 bytes (convolve.c:49-57); the table travels as it is
+bool convolve8_generic(bool vert, const uint8_t* src, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds, const int16_t* filter, int step, int w, int h) {
+    if (!g_ctx || w < 1 || h < 1 || w > 128 || h > 128 || step < 1 || step > 64 || !filter) return false;
+    const int16_t* base = (const int16_t*)((uintptr_t)filter & ~(uintptr_t)0xff);
+    const int      q0 = (int)((filter - base) / 8);
+    const int      span = (((vert ? h : w) - 1) * step + q0) / 16 + 8;   // samples touched along the filtered axis, starting 3 before the first output
+    const int      cw = vert ? w : span, ch = vert ? span : h;
+    const size_t   ip = rup((size_t)cw, 4), op = rup((size_t)w, 4);
+    uint8_t *d_i = (uint8_t*)dev(0, ip * ch + 64), *d_o = (uint8_t*)dev(1, op * h); int16_t* d_f = (int16_t*)dev(2, 256);
+    const uint8_t* s0 = vert ? src - 3 * ss : src - 3;
+    return d_i && d_o && d_f && up2d(d_i, ip, s0, (size_t)ss, (size_t)cw, ch) && up(d_f, base, 256) &&
+           svt_hip_convolve8_dev(g_ctx, vert, vert ? d_i + 3 * ip : d_i + 3, (int)ip, d_o, (int)op, d_f, q0, step, w, h) == 0 && down2d(dst, (size_t)ds, d_o, op, (size_t)w, h);
+}
+void convolve8_horiz_hip(const uint8_t* src, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds, const int16_t* fx, int xs, const int16_t* fy, int ys, int w, int h) {
+    Guard lk;
+    if (convolve8_generic(false, src, ss, dst, ds, fx, xs, w, h)) return;
+    FALLBACK("svt_aom_convolve8_horiz", svt_aom_convolve8_horiz, src, ss, dst, ds, fx, xs, fy, ys, w, h);
+}
+void convolve8_vert_hip(const uint8_t* src, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds, const int16_t* fx, int xs, const int16_t* fy, int ys, int w, int h) {
+    Guard lk;
+    if (convolve8_generic(true, src, ss, dst, ds, fy, ys, w, h)) return;
+    FALLBACK("svt_aom_convolve8_vert", svt_aom_convolve8_vert, src, ss, dst, ds, fx, xs, fy, ys, w, h);
+}
+bool wiener_generic(int pb, int bd, const void* src, ptrdiff_t ss, void* dst, ptrdiff_t ds, const int16_t* fx, const int16_t* fy, int w, int h, const SvtHipConvolveParams* cp) {
+    if (!g_ctx || w < 1 || h < 1 || w > 128 || h > 128 || !cp || !fx || !fy) return false;
+    const int    cw = w + 7, ch = h + 7;
+    const size_t ip = rup((size_t)cw * pb, 4), op = rup((size_t)w * pb, 4);
+    uint8_t *d_i = (uint8_t*)dev(0, ip * ch + 64), *d_o = (uint8_t*)dev(1, op * h); int16_t* d_t = (int16_t*)dev(2, 32);
+    int16_t taps[16];
+    std::memcpy(taps, fx, 16); std::memcpy(taps + 8, fy, 16);
+    const uint8_t* s0 = (const uint8_t*)src - (3 * ss + 3) * pb;
+    return d_i && d_o && d_t && up2d(d_i, ip, s0, (size_t)ss * pb, (size_t)cw * pb, ch) && up(d_t, taps, 32) &&
+           svt_hip_wiener_convolve_add_src_dev(g_ctx, pb, bd, d_i + 3 * ip + 3 * pb, (int)(ip / pb), d_o, (int)(op / pb), d_t, w, h, cp->round_0, cp->round_1) == 0 &&
+           down2d(dst, (size_t)ds * pb, d_o, op, (size_t)w * pb, h);
+}
+void wiener_convolve_hip(const uint8_t* src, ptrdiff_t ss, uint8_t* dst, ptrdiff_t ds, const int16_t* fx, const int16_t* fy, int32_t w, int32_t h, const SvtHipConvolveParams* cp) {
+    Guard lk;
+    if (wiener_generic(1, 8, src, ss, dst, ds, fx, fy, w, h, cp)) return;
+    FALLBACK("svt_av1_wiener_convolve_add_src", svt_av1_wiener_convolve_add_src, src, ss, dst, ds, fx, fy, w, h, cp);
+}
+void wiener_convolve_hbd_hip(const uint8_t* src8, ptrdiff_t ss, uint8_t* dst8, ptrdiff_t ds, const int16_t* fx, const int16_t* fy, int32_t w, int32_t h, const SvtHipConvolveParams* cp,
+                             int32_t bd) {
+    Guard lk;
+    if (wiener_generic(2, bd, (const void*)((uintptr_t)src8 << 1), ss, (void*)((uintptr_t)dst8 << 1), ds, fx, fy, w, h, cp)) return;
+    FALLBACK("svt_av1_highbd_wiener_convolve_add_src", svt_av1_highbd_wiener_convolve_add_src, src8, ss, dst8, ds, fx, fy, w, h, cp, bd);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -726,5 +1022,17 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_handle_transform64[0] = handle_transform_hip<0, 17>; t->svt_handle_transform64[1] = handle_transform_hip<1, 11>; t->svt_handle_transform64[2] = handle_transform_hip<2, 18>;
     t->svt_handle_transform64[3] = handle_transform_hip<3, 12>; t->svt_handle_transform64[4] = handle_transform_hip<4, 4>;
     t->svt_av1_inv_txfm_add = inv_txfm_add_hip;
+    t->svt_aom_subtract_block = subtract_block_hip; t->svt_aom_highbd_subtract_block = subtract_block_hbd_hip;
+    t->sad_16b_kernel = sad_16b_hip; t->variance_highbd = variance_highbd_hip; t->svt_nxm_sad_kernel_sub_sampled = nxm_sad_sub_hip;
+    t->svt_ext_sad_calculation_8x8_16x16 = ext_sad_16_hip; t->svt_ext_sad_calculation_32x32_64x64 = ext_sad_32_64_hip;
+    t->svt_copy_rect8_8bit_to_16bit = copy_rect8_hip;
+    t->svt_compute_cdef_dist_8bit = cdef_dist8_hip; t->svt_compute_cdef_dist_16bit = cdef_dist16_hip; t->svt_search_one_dual = search_one_dual_hip;
+    t->svt_full_distortion_kernel32_bits = full_dist32_hip; t->svt_full_distortion_kernel_cbf_zero32_bits = full_dist_cbf_zero32_hip;
+    t->svt_spatial_full_distortion_kernel = spatial_dist_hip; t->svt_full_distortion_kernel16_bits = full_dist16_hip;
+    t->svt_aom_sse = sse_hip; t->svt_aom_highbd_sse = sse_hbd_hip; t->svt_aom_satd = satd_hip; t->svt_av1_block_error = block_error_hip;
+    t->svt_get_proj_subspace = get_proj_subspace_hip; t->svt_av1_lowbd_pixel_proj_error = pixel_proj_error_hip; t->svt_av1_highbd_pixel_proj_error = pixel_proj_error_hbd_hip;
+    t->svt_compute_mean_square_values_8x8 = mean_sq_8x8_hip; t->svt_compute_sub_mean_8x8 = sub_mean_8x8_hip;
+    t->svt_aom_convolve8_horiz = convolve8_horiz_hip; t->svt_aom_convolve8_vert = convolve8_vert_hip;
+    t->svt_av1_wiener_convolve_add_src = wiener_convolve_hip; t->svt_av1_highbd_wiener_convolve_add_src = wiener_convolve_hbd_hip;
     return SVT_HIP_OK;
 }

@@ -453,7 +453,7 @@ int svt_hip_block_sse_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, in
 int svt_hip_block_variance_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_a, int a_stride, const void* d_b, int b_stride,
                                      const SvtHipBlkPair* d_pairs, int n, uint32_t* d_var, uint32_t* d_sse) {
     SVT_HIP_ENTER(c);
-    if (!c || !d_a || !d_b || !d_pairs || !d_var || n < 0 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd == 10))) return SVT_HIP_ERR_BAD_ARG;
+    if (!c || !d_a || !d_b || !d_pairs || !d_var || n < 0 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && (bd == 10 || bd == 16)))) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_block_variance(c->stream, pix_bytes, bd, d_a, a_stride, d_b, b_stride, d_pairs, n, d_var, d_sse);
     if (e != hipSuccess) return fail(c, e, "block variance launch");
     return SVT_HIP_OK;
@@ -967,6 +967,79 @@ int svt_hip_upsampled_pred_batch_dev(SvtHipCtx* c, const uint8_t* d_ref, int ref
     if (!c || !d_ref || !d_dst || !d_blks || n < 0) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_upsampled_pred(c->stream, d_ref, ref_stride, d_dst, d_blks, n);
     if (e != hipSuccess) return fail(c, e, "upsampled pred launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_block_mean_batch_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, const int32_t* d_offs, int n, int mode, int w, int h, uint64_t* d_out) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_plane || !d_offs || !d_out || n < 0 || (mode != 0 && mode != 1) || (mode == 0 && (w < 1 || h < 1))) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_block_mean(c->stream, d_plane, stride, d_offs, n, mode, w, h, d_out);
+    if (e != hipSuccess) return fail(c, e, "block mean launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_ext_sad_16x16_batch_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, const uint8_t* d_ref, int ref_stride, const SvtHipExtSadJob* d_jobs, int n,
+                                    uint32_t* d_state) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_ref || !d_jobs || !d_state || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_ext_sad_16(c->stream, d_src, src_stride, d_ref, ref_stride, d_jobs, n, d_state);
+    if (e != hipSuccess) return fail(c, e, "ext sad 16x16 launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_ext_sad_32x32_64x64_batch_dev(SvtHipCtx* c, uint32_t* d_state, const uint32_t* d_mv, int n) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_state || !d_mv || n < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_ext_sad_32_64(c->stream, d_state, d_mv, n);
+    if (e != hipSuccess) return fail(c, e, "ext sad 32x32 / 64x64 launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_dist_dev(SvtHipCtx* c, int pix_bytes, const void* d_dst, int dstride, const void* d_src, const uint8_t* d_list, int n, int bw_log2, int bh_log2,
+                          int coeff_shift, int pli, uint64_t* d_out) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_dst || !d_src || !d_list || !d_out || n < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bw_log2 != 2 && bw_log2 != 3) || (bh_log2 != 2 && bh_log2 != 3) ||
+        coeff_shift < 0 || coeff_shift > 4)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_dist(c->stream, pix_bytes, d_dst, dstride, d_src, d_list, n, bw_log2, bh_log2, coeff_shift, pli, d_out);
+    if (e != hipSuccess) return fail(c, e, "cdef dist launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_cdef_search_one_dual_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, int* d_lev0, int* d_lev1, int nb_strengths, int start_gi,
+                                     int end_gi, uint64_t* d_work) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mse0 || !d_mse1 || !d_lev0 || !d_lev1 || !d_work || sb_count < 0 || nb_strengths < 0 || nb_strengths > 7 || start_gi < 0 || end_gi > 64 || start_gi > end_gi)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_search_one_dual(c->stream, d_mse0, d_mse1, sb_count, d_lev0, d_lev1, nb_strengths, start_gi, end_gi, d_work + 1 + 4096, d_work + 1,
+                                                              d_work);
+    if (e != hipSuccess) return fail(c, e, "search one dual launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_sgr_flt_proj_dev(SvtHipCtx* c, int pix_bytes, const void* d_src, int src_stride, const void* d_dat, int dat_stride, const int32_t* d_flt0, int flt0_stride,
+                             const int32_t* d_flt1, int flt1_stride, int w, int h, int r0, int r1, int mode, const int32_t* xq, int64_t* d_acc, int32_t* d_xq) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_dat || !d_acc || w < 1 || h < 1 || (pix_bytes != 1 && pix_bytes != 2) || (mode != 0 && mode != 1) || (r0 > 0 && !d_flt0) || (r1 > 0 && !d_flt1) ||
+        (mode == 0 && !d_xq) || (mode == 1 && !xq))
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = hipMemsetAsync(d_acc, 0, 5 * sizeof(int64_t), c->stream);
+    if (e != hipSuccess) return fail(c, e, "sgr flt proj clear");
+    e = (hipError_t)svt_hip_launch_sgr_flt_proj(c->stream, pix_bytes, d_src, src_stride, d_dat, dat_stride, d_flt0, flt0_stride, d_flt1, flt1_stride, w, h, r0, r1, mode,
+                                                mode ? xq[0] : 0, mode ? xq[1] : 0, (long long*)d_acc, d_xq);
+    if (e != hipSuccess) return fail(c, e, "sgr flt proj launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_convolve8_dev(SvtHipCtx* c, int vert, const uint8_t* d_src, int src_stride, uint8_t* d_dst, int dst_stride, const int16_t* d_filters, int q0, int step_q4, int w,
+                          int h) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_dst || !d_filters || w < 1 || h < 1 || q0 < 0 || q0 > 15 || step_q4 < 1 || step_q4 > 64) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_convolve8(c->stream, vert, d_src, src_stride, d_dst, dst_stride, d_filters, q0, step_q4, w, h);
+    if (e != hipSuccess) return fail(c, e, "convolve8 launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_wiener_convolve_add_src_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_src, int src_stride, void* d_dst, int dst_stride, const int16_t* d_taps, int w, int h,
+                                        int round_0, int round_1) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_dst || !d_taps || w < 1 || h < 1 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd >= 8 && bd <= 12)) || round_0 < 1 || round_0 > 7 ||
+        round_1 < 1 || round_1 > 14)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_convolve(c->stream, pix_bytes, bd, d_src, src_stride, d_dst, dst_stride, d_taps, w, h, round_0, round_1);
+    if (e != hipSuccess) return fail(c, e, "wiener convolve launch");
     return SVT_HIP_OK;
 }
 int svt_hip_cdef_find_dir_batch_dev(SvtHipCtx* c, const uint16_t* d_img, int stride, const int32_t* d_offs, int n, int coeff_shift, int32_t* d_dir, int32_t* d_var) {

@@ -105,4 +105,17 @@ int svt_hip_launch_upsampled_pred(hipStream_t st, const uint8_t* ref, int rs, ui
 int svt_hip_launch_cdef_find_dir_list(hipStream_t st, const uint16_t* img, const int32_t* offs, int n, int stride, int coeff_shift, int32_t* dir_out, int32_t* var_out);
 int svt_hip_launch_cdef_filter_block_list(hipStream_t st, const uint16_t* in, int istride, const void* jobs, int n, uint8_t* dst8, uint16_t* dst16, int dstride);
 int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n);
+/* per-call forms (percall2.hip) */
+int svt_hip_launch_block_mean(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, int mode, int w, int h, uint64_t* out);
+int svt_hip_launch_ext_sad_16(hipStream_t st, const uint8_t* src, int ss, const uint8_t* ref, int rs, const SvtHipExtSadJob* jobs, int n, uint32_t* state);
+int svt_hip_launch_ext_sad_32_64(hipStream_t st, uint32_t* state, const uint32_t* mv, int n);
+int svt_hip_launch_cdef_dist(hipStream_t st, int pix_bytes, const void* dst, int dstride, const void* src, const uint8_t* list, int n, int bw_log2, int bh_log2, int cs,
+                             int pli, uint64_t* out);
+int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
+                                   uint64_t* best, uint64_t* tot, uint64_t* out);
+int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s, int w,
+                                int h, int r0, int r1, int mode, int xq0, int xq1, long long* acc, int32_t* xq_out);
+int svt_hip_launch_convolve8(hipStream_t st, int vert, const uint8_t* src, int ss, uint8_t* dst, int ds, const int16_t* filters, int q0, int step, int w, int h);
+int svt_hip_launch_wiener_convolve(hipStream_t st, int pix_bytes, int bd, const void* src, int ss, void* dst, int ds, const int16_t* taps, int w, int h, int round0,
+                                   int round1);
 }

@@ -159,3 +159,24 @@ def test_block_level_wrappers_in_a_real_encode_on_gpu(workdir):
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
     print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
+
+
+@pytest.mark.gpu
+def test_helper_pointers_in_a_real_encode_on_gpu(workdir):
+    """The small helpers of the same dispatch-table rows behind SVT_HIP_RTCD in a real encode: picture-analysis block means, the single-candidate
+    SAD ladders, subtract, the distortion sums of mode decision, CDEF's rectangle copy / filter-block distortion / strength-pair step, the
+    self-guided projection on materialised filters, the Wiener convolution, svt_aom_convolve8_*.  Bitstream and reconstruction must not change."""
+    w, h, n, bd, preset, q = 176, 144, 2, 8, 6, 32
+    clip = os.path.join(workdir, "qcif2.yuv")
+    E.make_clip(clip, w, h, n, seed=9, bd=bd)
+    names = ("svt_aom_subtract_block,svt_nxm_sad_kernel_sub_sampled,svt_ext_sad_calculation_8x8_16x16,svt_ext_sad_calculation_32x32_64x64,"
+             "svt_copy_rect8_8bit_to_16bit,svt_compute_cdef_dist_8bit,svt_search_one_dual,svt_full_distortion_kernel32_bits,"
+             "svt_full_distortion_kernel_cbf_zero32_bits,svt_spatial_full_distortion_kernel,svt_aom_sse,svt_aom_satd,svt_av1_block_error,"
+             "svt_get_proj_subspace,svt_av1_lowbd_pixel_proj_error,svt_compute_mean_square_values_8x8,svt_compute_sub_mean_8x8,"
+             "svt_aom_convolve8_horiz,svt_aom_convolve8_vert,svt_av1_wiener_convolve_add_src")
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif2.ref"))
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif2.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1500)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    for nme in names.split(","):
+        assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
+    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))

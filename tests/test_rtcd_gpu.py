@@ -80,6 +80,28 @@ class TxfmParam(C.Structure):   # EbDefinitions.h:779-791 (one-byte enums)
 
 
 INVADD = C.CFUNCTYPE(None, VP, VP, C.c_int32, VP, C.c_int32, C.POINTER(TxfmParam))
+SUBBLK = C.CFUNCTYPE(None, C.c_int, C.c_int, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_ssize_t)
+SUBBLKH = C.CFUNCTYPE(None, C.c_int, C.c_int, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_ssize_t, C.c_int)
+SAD16B = C.CFUNCTYPE(C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+VARHBD = C.CFUNCTYPE(C.c_uint32, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP)
+EXT16 = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, VP, VP, VP, C.c_uint32, VP, VP, C.c_uint8)
+EXT3264 = C.CFUNCTYPE(None, VP, VP, VP, VP, VP, C.c_uint32, VP)
+CPRECT = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, C.c_int32, C.c_int32)
+CDIST = C.CFUNCTYPE(C.c_uint64, VP, C.c_int32, VP, VP, C.c_int32, C.c_uint8, C.c_int32, C.c_int32)
+ONEDUAL = C.CFUNCTYPE(C.c_uint64, VP, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
+FD32 = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32)
+FDZ32 = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32)
+SPDIST = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint32, C.c_uint32, VP, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32)
+SSE = C.CFUNCTYPE(C.c_int64, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
+SATD = C.CFUNCTYPE(C.c_int, VP, C.c_int)
+BLKERR = C.CFUNCTYPE(C.c_int64, VP, VP, C.c_ssize_t, VP)
+PROJSUB = C.CFUNCTYPE(None, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, VP, C.c_int, VP, VP)
+PROJERR = C.CFUNCTYPE(C.c_int64, VP, C.c_int32, C.c_int32, C.c_int32, VP, C.c_int32, VP, C.c_int32, VP, C.c_int32, VP, VP)
+MSQ8 = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+SUBMEAN = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint16)
+CONV8 = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
+WIENER = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams))
+WIENERH = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams), C.c_int32)
 
 
 class Rtcd(C.Structure):
@@ -101,7 +123,16 @@ class Rtcd(C.Structure):
                 ("svt_aom_lpf_horizontal", LPF * 4), ("svt_aom_lpf_vertical", LPF * 4), ("svt_aom_highbd_lpf_horizontal", LPFH * 4),
                 ("svt_aom_highbd_lpf_vertical", LPFH * 4), ("svt_cdef_find_dir", CDIR), ("svt_cdef_filter_block", CFB),
                 ("svt_residual_kernel8bit", RESID), ("svt_residual_kernel16bit", RESID), ("svt_aom_sadx4d", SADX4 * 22), ("svt_aom_upsampled_pred", UPS),
-                ("svt_compute_interm_var_four8x8", IVAR), ("svt_handle_transform64", HT64 * 5), ("svt_av1_inv_txfm_add", INVADD)]
+                ("svt_compute_interm_var_four8x8", IVAR), ("svt_handle_transform64", HT64 * 5), ("svt_av1_inv_txfm_add", INVADD),
+                ("svt_aom_subtract_block", SUBBLK), ("svt_aom_highbd_subtract_block", SUBBLKH), ("sad_16b_kernel", SAD16B), ("variance_highbd", VARHBD),
+                ("svt_nxm_sad_kernel_sub_sampled", NXM), ("svt_ext_sad_calculation_8x8_16x16", EXT16), ("svt_ext_sad_calculation_32x32_64x64", EXT3264),
+                ("svt_copy_rect8_8bit_to_16bit", CPRECT), ("svt_compute_cdef_dist_8bit", CDIST), ("svt_compute_cdef_dist_16bit", CDIST),
+                ("svt_search_one_dual", ONEDUAL), ("svt_full_distortion_kernel32_bits", FD32), ("svt_full_distortion_kernel_cbf_zero32_bits", FDZ32),
+                ("svt_spatial_full_distortion_kernel", SPDIST), ("svt_full_distortion_kernel16_bits", SPDIST), ("svt_aom_sse", SSE), ("svt_aom_highbd_sse", SSE),
+                ("svt_aom_satd", SATD), ("svt_av1_block_error", BLKERR), ("svt_get_proj_subspace", PROJSUB), ("svt_av1_lowbd_pixel_proj_error", PROJERR),
+                ("svt_av1_highbd_pixel_proj_error", PROJERR), ("svt_compute_mean_square_values_8x8", MSQ8), ("svt_compute_sub_mean_8x8", SUBMEAN),
+                ("svt_aom_convolve8_horiz", CONV8), ("svt_aom_convolve8_vert", CONV8), ("svt_av1_wiener_convolve_add_src", WIENER),
+                ("svt_av1_highbd_wiener_convolve_add_src", WIENERH)]
 
 
 @pytest.fixture(scope="module")
@@ -490,3 +521,166 @@ def test_compound_warp_vs_reference_c(rtcd, ref):
                     res.append((first, pred.copy()))
                 assert np.array_equal(res[0][0], res[1][0]), ("compound buffer", bd, it, jnt)
                 assert np.array_equal(res[0][1], res[1][1]) and (res[0][1][:, :pw] != 5).any(), ("averaged prediction", bd, it, jnt, fwd)
+
+
+def _as(T, fn):
+    """the reference's `*_c` function behind the same ctypes prototype as the wrapper in that slot"""
+    return T(C.cast(fn, C.c_void_p).value)
+
+
+def _aligned(shape, dtype, align=256):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape), raw
+
+
+def test_helper_pointers_vs_reference_c(rtcd, ref):
+    """The small helpers of the same dispatch-table rows: subtract, 16-bit SAD / variance, single-candidate SAD ladders, CDEF's
+    rectangle copy, filter-block distortion and strength-pair step, the distortion sums, the self-guided projection on materialised filters, the
+    picture-analysis block means, svt_aom_convolve8_*, the Wiener convolution.  Same arguments to the reference's `*_c` function and to the wrapper."""
+    rng = np.random.default_rng(2024)
+    # --- svt_aom_subtract_block / highbd
+    for (w, h) in ((4, 4), (16, 8), (64, 64), (12, 7), (128, 128)):
+        a = rng.integers(0, 256, (h + 2, w + 9)).astype(np.uint8); b = rng.integers(0, 256, (h + 1, w + 5)).astype(np.uint8)
+        e = np.full((h, w + 3), 77, np.int16); g = e.copy()
+        _as(SUBBLK, ref.svt_aom_subtract_block_c)(h, w, _vp(e), w + 3, _vp(a, 3), w + 9, _vp(b, 1), w + 5); rtcd.svt_aom_subtract_block(h, w, _vp(g), w + 3, _vp(a, 3), w + 9, _vp(b, 1), w + 5)
+        assert np.array_equal(e, g), ("subtract", w, h)
+        a16 = rng.integers(0, 1024, (h + 2, w + 9)).astype(np.uint16); b16 = rng.integers(0, 1024, (h + 1, w + 5)).astype(np.uint16)
+        e[:] = 77; g[:] = 77
+        for fn, o in ((_as(SUBBLKH, ref.svt_aom_highbd_subtract_block_c), e), (rtcd.svt_aom_highbd_subtract_block, g)):
+            fn(h, w, _vp(o), w + 3, _vp(a16, 6), w + 9, _vp(b16, 2), w + 5, 10)   # plain casts of uint16_t* in this function
+        assert np.array_equal(e, g), ("subtract hbd", w, h)
+        # --- sad_16b_kernel, variance_highbd, svt_nxm_sad_kernel_sub_sampled, the SSE family
+        assert _as(SAD16B, ref.sad_16b_kernel_c)(_vp(a16, 6), w + 9, _vp(b16, 2), w + 5, h, w) == rtcd.sad_16b_kernel(_vp(a16, 6), w + 9, _vp(b16, 2), w + 5, h, w)
+        near = np.clip(a16[:h + 1, :w + 5].astype(np.int32) + rng.integers(-9, 10, (h + 1, w + 5)), 0, 1023).astype(np.uint16)
+        se, sg = C.c_uint32(), C.c_uint32()
+        ve = _as(VARHBD, ref.variance_highbd_c)(_vp(a16), w + 9, _vp(near), w + 5, w, h, C.byref(se)); vg = rtcd.variance_highbd(_vp(a16), w + 9, _vp(near), w + 5, w, h, C.byref(sg))
+        assert (ve, se.value) == (vg, sg.value), ("variance_highbd", w, h)
+        assert _as(NXM, ref.svt_nxm_sad_kernel_helper_c)(_vp(a, 3), w + 9, _vp(b, 1), w + 5, h, w) == rtcd.svt_nxm_sad_kernel_sub_sampled(_vp(a, 3), w + 9, _vp(b, 1), w + 5, h, w)
+        assert _as(SSE, ref.svt_aom_sse_c)(_vp(a, 3), w + 9, _vp(b, 1), w + 5, w, h) == rtcd.svt_aom_sse(_vp(a, 3), w + 9, _vp(b, 1), w + 5, w, h)
+        assert _as(SSE, ref.svt_aom_highbd_sse_c)(_vp(a16, 6), w + 9, _vp(b16, 2), w + 5, w, h) == rtcd.svt_aom_highbd_sse(_vp(a16, 6), w + 9, _vp(b16, 2), w + 5, w, h)
+        assert _as(SPDIST, ref.svt_spatial_full_distortion_kernel_c)(_vp(a), 3, w + 9, _vp(b), 1, w + 5, w, h) == rtcd.svt_spatial_full_distortion_kernel(_vp(a), 3, w + 9, _vp(b), 1, w + 5, w, h)
+        assert _as(SPDIST, ref.svt_full_distortion_kernel16_bits_c)(_vp(a16), 3, w + 9, _vp(b16), 1, w + 5, w, h) == rtcd.svt_full_distortion_kernel16_bits(_vp(a16), 3, w + 9, _vp(b16), 1, w + 5, w, h)
+        # --- coefficient-domain sums
+        if w * h <= 64 * 64:
+            co = rng.integers(-(1 << 17), 1 << 17, (h, w + 2)).astype(np.int32); rc = (co + rng.integers(-300, 300, co.shape)).astype(np.int32)
+            de = np.zeros(2, np.uint64); dg = np.zeros(2, np.uint64)
+            _as(FD32, ref.svt_full_distortion_kernel32_bits_c)(_vp(co), w + 2, _vp(rc), w + 2, _vp(de), w, h); rtcd.svt_full_distortion_kernel32_bits(_vp(co), w + 2, _vp(rc), w + 2, _vp(dg), w, h)
+            assert np.array_equal(de, dg), ("full distortion", w, h)
+            _as(FDZ32, ref.svt_full_distortion_kernel_cbf_zero32_bits_c)(_vp(co), w + 2, _vp(de), w, h); rtcd.svt_full_distortion_kernel_cbf_zero32_bits(_vp(co), w + 2, _vp(dg), w, h)
+            assert np.array_equal(de, dg), ("cbf zero", w, h)
+            # svt_av1_block_error_c multiplies in `int`: defined up to |coeff| = 46340 (the coefficient range of 8-bit content is 2^15)
+            flat = np.clip(np.ascontiguousarray(co[:, :w]).ravel(), -46000, 46000); dq = np.clip(np.ascontiguousarray(rc[:, :w]).ravel(), -46000, 46000)
+            assert _as(SATD, ref.svt_aom_satd_c)(_vp(flat), flat.size) == rtcd.svt_aom_satd(_vp(flat), flat.size)
+            ze, zg = C.c_int64(), C.c_int64()
+            assert _as(BLKERR, ref.svt_av1_block_error_c)(_vp(flat), _vp(dq), flat.size, C.byref(ze)) == rtcd.svt_av1_block_error(_vp(flat), _vp(dq), flat.size, C.byref(zg))
+            assert ze.value == zg.value
+    # --- single-candidate SAD ladders, running bests carried across candidates
+    src = rng.integers(0, 256, (64, 70)).astype(np.uint8)
+    refp = np.clip(np.pad(src[:, :64], ((0, 0), (4, 12)), mode="edge").astype(np.int32) + rng.integers(-5, 6, (64, 80)), 0, 255).astype(np.uint8)
+    for sub in (0, 1):
+        st = [dict(bs8=np.full(64, 0xffffffff, np.uint32), bs16=np.full(16, 0xffffffff, np.uint32), bm8=np.zeros(64, np.uint32), bm16=np.zeros(16, np.uint32),
+                   s16=np.zeros(16, np.uint32), s8=np.zeros(64, np.uint32), bs32=np.full(4, 0xffffffff, np.uint32), bs64=np.full(1, 0xffffffff, np.uint32),
+                   bm32=np.zeros(4, np.uint32), bm64=np.zeros(1, np.uint32), s32=np.zeros(4, np.uint32)) for _ in range(2)]
+        for xoff in (6, 4, 5, 4):   # the exact match (offset 4) twice: the second visit must not replace the first (strict <)
+            mv = (((7) & 0xffff) << 16) | ((4 * xoff) & 0xffff)
+            for d, f16, f64 in ((st[0], _as(EXT16, ref.svt_ext_sad_calculation_8x8_16x16_c), _as(EXT3264, ref.svt_ext_sad_calculation_32x32_64x64_c)),
+                                (st[1], rtcd.svt_ext_sad_calculation_8x8_16x16, rtcd.svt_ext_sad_calculation_32x32_64x64)):
+                for blk in range(16):
+                    by, bx = 16 * (blk // 4), 16 * (blk % 4)
+                    f16(_vp(src, by * 70 + bx), 70, _vp(refp, by * 80 + bx + xoff), 80, _vp(d["bs8"], 16 * blk), _vp(d["bs16"], 4 * blk), _vp(d["bm8"], 16 * blk), _vp(d["bm16"], 4 * blk),
+                        mv, _vp(d["s16"], 4 * blk), _vp(d["s8"], 16 * blk), sub)
+                f64(_vp(d["s16"]), _vp(d["bs32"]), _vp(d["bs64"]), _vp(d["bm32"]), _vp(d["bm64"]), mv, _vp(d["s32"]))
+            for k in st[0]:
+                assert np.array_equal(st[0][k], st[1][k]), ("single-candidate ladders", sub, xoff, k)
+    # --- svt_copy_rect8_8bit_to_16bit
+    a = rng.integers(0, 256, (30, 50)).astype(np.uint8)
+    for (v, hh) in ((8, 8), (13, 37), (30, 50)):
+        e = np.full((v, hh + 4), 999, np.uint16); g = e.copy()
+        _as(CPRECT, ref.svt_copy_rect8_8bit_to_16bit_c)(_vp(e), hh + 4, _vp(a), 50, v, hh); rtcd.svt_copy_rect8_8bit_to_16bit(_vp(g), hh + 4, _vp(a), 50, v, hh)
+        assert np.array_equal(e, g), ("copy_rect", v, hh)
+    # --- svt_compute_cdef_dist_8bit / _16bit: every block size, luma (perceptual metric) and chroma, coefficient shifts 0 and 2
+    for cs, dt, fr, fh in ((0, np.uint8, ref.compute_cdef_dist_8bit_c, rtcd.svt_compute_cdef_dist_8bit), (0, np.uint16, ref.compute_cdef_dist_c, rtcd.svt_compute_cdef_dist_16bit),
+                           (2, np.uint16, ref.compute_cdef_dist_c, rtcd.svt_compute_cdef_dist_16bit)):
+        plane = np.clip(rng.normal(120 << cs, 40 << cs, (64, 80)), 0, (256 << cs) - 1).astype(dt)
+        for bsize, (bw, bh) in enumerate(((4, 4), (4, 8), (8, 4), (8, 8))):
+            for n in (1, 7, 64 if (bw, bh) == (8, 8) else 40):
+                cells = rng.permutation((64 // bh) * (64 // bw))[:n]
+                dlist = np.zeros((n, 3), np.uint8); dlist[:, 0] = cells // (64 // bw); dlist[:, 1] = cells % (64 // bw)
+                filt = np.zeros((n, bh, bw), dt)
+                for i, (by, bx, _) in enumerate(dlist):
+                    blk = plane[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw].astype(np.int32)
+                    filt[i] = np.clip(blk + rng.integers(-6 << cs, (6 << cs) + 1, blk.shape), 0, (256 << cs) - 1)
+                for pli in (0, 1):
+                    e = _as(CDIST, fr)(_vp(plane), 80, _vp(filt), _vp(dlist), n, bsize, cs, pli); g = fh(_vp(plane), 80, _vp(filt), _vp(dlist), n, bsize, cs, pli)
+                    assert e == g and e > 0, ("cdef dist", dt.__name__, cs, bw, bh, n, pli, e, g)
+    # --- svt_search_one_dual: the greedy selection of up to 8 strength pairs, step by step
+    for sb_count, (start, end) in ((1, (0, 64)), (37, (0, 64)), (300, (0, 16)), (90, (2, 40))):
+        m0 = rng.integers(1000, 1 << 22, (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << 21, (sb_count, 64)).astype(np.uint64)
+        m0[:, 7] = m0[:, 3]; m1[:, 9] = m1[:, 5]   # equal totals: the first pair in raster order wins
+        ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
+        le = [np.zeros(8, np.int32), np.zeros(8, np.int32)]; lg = [np.zeros(8, np.int32), np.zeros(8, np.int32)]
+        for nb in range(4):
+            e = _as(ONEDUAL, ref.svt_search_one_dual_c)(_vp(le[0]), _vp(le[1]), nb, C.cast(ptrs, C.c_void_p), sb_count, start, end)
+            g = rtcd.svt_search_one_dual(_vp(lg[0]), _vp(lg[1]), nb, C.cast(ptrs, C.c_void_p), sb_count, start, end)
+            assert e == g and np.array_equal(le[0], lg[0]) and np.array_equal(le[1], lg[1]), ("search_one_dual", sb_count, nb, e, g, le, lg)
+    # --- the self-guided projection on materialised filters
+    class SgrParams(C.Structure):
+        _fields_ = [("r", C.c_int32 * 2), ("s", C.c_int32 * 2)]
+    for bd, dt in ((8, np.uint8), (10, np.uint16)):
+        for (w, h) in ((64, 48), (70, 50), (256, 200)):
+            src = np.clip(rng.normal(100 << (bd - 8), 30 << (bd - 8), (h, w + 6)), 0, (1 << bd) - 1).astype(dt)
+            dat = np.clip(src.astype(np.int32) + rng.integers(-8, 9, src.shape) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(dt)
+            f0 = ((dat.astype(np.int32) << 4) + rng.integers(-200, 201, dat.shape)).astype(np.int32)
+            f1 = ((src.astype(np.int32) << 4) + rng.integers(-120, 121, dat.shape)).astype(np.int32)
+            sp = lambda a: (a.ctypes.data >> 1) if bd > 8 else a.ctypes.data   # CONVERT_TO_BYTEPTR
+            for r in ((2, 1), (0, 1), (2, 0)):
+                prm = SgrParams((C.c_int32 * 2)(*r), (C.c_int32 * 2)(140, 3236))
+                xe = np.zeros(2, np.int32); xg = np.zeros(2, np.int32)
+                _as(PROJSUB, ref.svt_get_proj_subspace_c)(sp(src), w, h, w + 6, sp(dat), w + 6, int(bd > 8), _vp(f0), w + 6, _vp(f1), w + 6, _vp(xe), C.byref(prm))
+                rtcd.svt_get_proj_subspace(sp(src), w, h, w + 6, sp(dat), w + 6, int(bd > 8), _vp(f0), w + 6, _vp(f1), w + 6, _vp(xg), C.byref(prm))
+                assert np.array_equal(xe, xg), ("get_proj_subspace", bd, w, h, r, xe, xg)
+                for xq in (xe.copy(), np.array([-37, 61], np.int32), np.array([0, 0], np.int32)):
+                    fr, fh = (ref.svt_av1_highbd_pixel_proj_error_c, rtcd.svt_av1_highbd_pixel_proj_error) if bd > 8 else (ref.svt_av1_lowbd_pixel_proj_error_c, rtcd.svt_av1_lowbd_pixel_proj_error)
+                    e = _as(PROJERR, fr)(sp(src), w, h, w + 6, sp(dat), w + 6, _vp(f0), w + 6, _vp(f1), w + 6, _vp(xq), C.byref(prm))
+                    g = fh(sp(src), w, h, w + 6, sp(dat), w + 6, _vp(f0), w + 6, _vp(f1), w + 6, _vp(xq), C.byref(prm))
+                    assert e == g, ("pixel_proj_error", bd, w, h, r, xq, e, g)
+        prm = SgrParams((C.c_int32 * 2)(0, 0), (C.c_int32 * 2)(0, 0))   # both filters off: the plain SSE branch
+        fr, fh = (ref.svt_av1_highbd_pixel_proj_error_c, rtcd.svt_av1_highbd_pixel_proj_error) if bd > 8 else (ref.svt_av1_lowbd_pixel_proj_error_c, rtcd.svt_av1_lowbd_pixel_proj_error)
+        xq = np.array([5, 5], np.int32)
+        assert _as(PROJERR, fr)(sp(src), w, h, w + 6, sp(dat), w + 6, None, 0, None, 0, _vp(xq), C.byref(prm)) == fh(sp(src), w, h, w + 6, sp(dat), w + 6, None, 0, None, 0, _vp(xq), C.byref(prm))
+    # --- picture-analysis block means
+    img = rng.integers(0, 256, (20, 40)).astype(np.uint8)
+    for (w, h) in ((8, 8), (16, 4), (5, 3)):
+        assert _as(MSQ8, ref.svt_compute_mean_squared_values_c)(_vp(img, 43), 40, w, h) == rtcd.svt_compute_mean_square_values_8x8(_vp(img, 43), 40, w, h)
+    assert _as(SUBMEAN, ref.svt_compute_sub_mean_8x8_c)(_vp(img, 85), 40) == rtcd.svt_compute_sub_mean_8x8(_vp(img, 85), 40)
+    # --- svt_aom_convolve8_horiz / _vert: a 256-byte aligned 16-kernel table, every start phase, unscaled and scaled steps
+    table, _keep = _aligned((16, 8), np.int16)
+    for p in range(16):
+        t = rng.integers(-20, 40, 8); t[3] += 128 - t.sum()
+        table[p] = t
+    img = rng.integers(0, 256, (120, 140)).astype(np.uint8)
+    for (w, h, phase, step) in ((16, 16, 0, 16), (64, 8, 5, 16), (8, 64, 15, 16), (33, 17, 3, 24), (20, 20, 9, 32), (7, 5, 12, 11)):
+        for vert, name in ((0, "horiz"), (1, "vert")):
+            e = np.full((h, w + 2), 55, np.uint8); g = e.copy()
+            fx = _vp(table, 16 * phase)
+            args = (_vp(img, 20 * 140 + 20), 140, None, w + 2, fx, step, fx, step, w, h)
+            _as(CONV8, getattr(ref, f"svt_aom_convolve8_{name}_c"))(args[0], args[1], _vp(e), *args[3:]); getattr(rtcd, f"svt_aom_convolve8_{name}")(args[0], args[1], _vp(g), *args[3:])
+            assert np.array_equal(e, g), ("convolve8", name, w, h, phase, step)
+    # --- Wiener convolution of one processing unit (8-bit, 10-bit and 12-bit rounding)
+    taps, _keep2 = _aligned((16, 8), np.int16)
+    taps[2] = (3, -7, 15, -22, 15, -7, 3, 0); taps[5] = (-5, 4, 30, -58, 30, 4, -5, 0); taps[9] = (0, 0, 0, 0, 0, 0, 0, 0)
+    for bd, dt, r0, r1 in ((8, np.uint8, 3, 11), (10, np.uint16, 3, 11), (12, np.uint16, 5, 9)):
+        img = np.clip(rng.normal(110 << (bd - 8), 45 << (bd - 8), (90, 100)), 0, (1 << bd) - 1).astype(dt)
+        cp = ConvParams(0, 0, None, 0, r0, r1, 0, 0, 0, 0, 0, 0)
+        for (w, h, ix, iy) in ((64, 64, 2, 5), (32, 20, 5, 2), (56, 7, 9, 9), (8, 8, 2, 2)):
+            e = np.full((h, w + 3), 7, dt); g = e.copy()
+            off = (8 * 100 + 9) * img.itemsize
+            if bd == 8:
+                _as(WIENER, ref.svt_av1_wiener_convolve_add_src_c)(_vp(img, off), 100, _vp(e), w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp))
+                rtcd.svt_av1_wiener_convolve_add_src(_vp(img, off), 100, _vp(g), w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp))
+            else:
+                _as(WIENERH, ref.svt_av1_highbd_wiener_convolve_add_src_c)((img.ctypes.data + off) >> 1, 100, e.ctypes.data >> 1, w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp), bd)
+                rtcd.svt_av1_highbd_wiener_convolve_add_src((img.ctypes.data + off) >> 1, 100, g.ctypes.data >> 1, w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp), bd)
+            assert np.array_equal(e, g), ("wiener convolve", bd, w, h, ix, iy)
