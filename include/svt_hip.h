@@ -632,6 +632,9 @@ int svt_hip_interm_var_four8x8_batch_dev(SvtHipCtx *ctx, const uint8_t *d_plane,
 /* svt_handle_transform64x64 / 64x32 / 32x64 / 64x16 / 16x64 (aom_dsp_rtcd.h:221-230) in place on nblk blocks of W*H coefficients:
  * energy of the coefficients outside the top-left 32x32, zero them, pack the kept rows to stride min(W,32). tx_size = TxSize (4, 12, 11, 18, 17). */
 int svt_hip_handle_transform64_batch_dev(SvtHipCtx *ctx, int tx_size, int32_t *d_coeff, int nblk, uint64_t *d_energy);
+/* handle_transform64x64_N2_N4 / 64x32 / 32x64 / 64x16 / 16x64 (aom_dsp_rtcd.h:237-245; EbTransforms.c:2933-2969), the re-pack that follows the
+ * N2 / N4 forward transforms: the kept rows move from stride 64 to stride 32 in place (nothing is zeroed, the energy is 0); blocks of W*H coefficients. */
+int svt_hip_handle_transform64_n2n4_batch_dev(SvtHipCtx *ctx, int tx_size, int32_t *d_coeff, int nblk);
 /* svt_aom_upsampled_pred (aom_dsp_rtcd.h:353; C_DEFAULT/variance.c:212): sub-pel prediction of the OBMC / sub-pel refinement searches, two
  * 8-tap passes with an 8-bit clip after each.  bank = filter family as in SvtHipConvBlk (3 bilinear = USE_2_TAPS, 4 = USE_4_TAPS, 0 = USE_8_TAPS).
  * Output is packed (stride = w) at dst_off. */

@@ -129,6 +129,7 @@ typedef struct {
     int32_t eob;
 } SvtHipTxfmParam;
 typedef void (*SvtHipInvTxfmAddFn)(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+typedef void (*SvtHipHbdMseFn)(const uint8_t *src_ptr, int32_t source_stride, const uint8_t *ref_ptr, int32_t recon_stride, uint32_t *sse);
 typedef void (*SvtHipSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
                                       const uint8_t *pred_ptr, ptrdiff_t pred_stride);
 typedef void (*SvtHipHbdSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
@@ -249,6 +250,9 @@ typedef struct SvtHipRtcd {
     SvtHipConvolve8Fn      svt_aom_convolve8_horiz, svt_aom_convolve8_vert; /* common_dsp_rtcd.h:231; convolve.c:286, :298 */
     SvtHipWienerConvolveFn svt_av1_wiener_convolve_add_src;    /* convolve.c:105 */
     SvtHipHbdWienerConvolveFn svt_av1_highbd_wiener_convolve_add_src; /* convolve.c:205 */
+    SvtHipHandleTransformFn handle_transform64_N2_N4[5];       /* aom_dsp_rtcd.h:237-245 in header order: 16x64, 32x64, 64x16, 64x32, 64x64 */
+    SvtHipVarWxHFn         svt_aom_mse16x16;                   /* :248 (EbPsnr.c:84) */
+    SvtHipHbdMseFn         svt_aom_highbd_8_mse16x16;          /* :264 (uint8_t* = CONVERT_TO_BYTEPTR(uint16_t*)) */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

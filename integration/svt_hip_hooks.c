@@ -78,7 +78,7 @@ void svt_hip_hooks_report(void) {
     X(svt_full_distortion_kernel16_bits) X(svt_aom_sse) X(svt_aom_highbd_sse) X(svt_aom_satd) X(svt_av1_block_error)                        \
     X(svt_get_proj_subspace) X(svt_av1_lowbd_pixel_proj_error) X(svt_av1_highbd_pixel_proj_error)                                           \
     X(svt_compute_mean_square_values_8x8) X(svt_compute_sub_mean_8x8) X(svt_aom_convolve8_horiz) X(svt_aom_convolve8_vert)                  \
-    X(svt_av1_wiener_convolve_add_src) X(svt_av1_highbd_wiener_convolve_add_src)
+    X(svt_av1_wiener_convolve_add_src) X(svt_av1_highbd_wiener_convolve_add_src) X(svt_aom_mse16x16) X(svt_aom_highbd_8_mse16x16)
 /* array members <-> the reference's individually named pointers */
 #define RTCD_INDEXED(X)                                                                                                                      \
     X(svt_aom_lpf_horizontal, 0, svt_aom_lpf_horizontal_4) X(svt_aom_lpf_horizontal, 1, svt_aom_lpf_horizontal_6)                           \
@@ -91,7 +91,10 @@ void svt_hip_hooks_report(void) {
     X(svt_aom_highbd_lpf_vertical, 2, svt_aom_highbd_lpf_vertical_8) X(svt_aom_highbd_lpf_vertical, 3, svt_aom_highbd_lpf_vertical_14)      \
     X(svt_handle_transform64, 0, svt_handle_transform16x64) X(svt_handle_transform64, 1, svt_handle_transform32x64)                         \
     X(svt_handle_transform64, 2, svt_handle_transform64x16) X(svt_handle_transform64, 3, svt_handle_transform64x32)                         \
-    X(svt_handle_transform64, 4, svt_handle_transform64x64)
+    X(svt_handle_transform64, 4, svt_handle_transform64x64)                                                                                  \
+    X(handle_transform64_N2_N4, 0, handle_transform16x64_N2_N4) X(handle_transform64_N2_N4, 1, handle_transform32x64_N2_N4)                 \
+    X(handle_transform64_N2_N4, 2, handle_transform64x16_N2_N4) X(handle_transform64_N2_N4, 3, handle_transform64x32_N2_N4)                 \
+    X(handle_transform64_N2_N4, 4, handle_transform64x64_N2_N4)
 
 static void install_rtcd(const char *list) {
     SvtHipRtcd t;

@@ -10,6 +10,7 @@
 //   sgr_flt_proj          Encoder/Codec/EbRestorationPick.c:174-316, :448-538  svt_av1_{lowbd,highbd}_pixel_proj_error_c, svt_get_proj_subspace_c
 //   convolve8             Common/Codec/convolve.c:249-307                    svt_aom_convolve8_horiz_c / _vert_c
 //   wiener_convolve       Common/Codec/convolve.c:57-242                     svt_av1_[highbd_]wiener_convolve_add_src_c
+//   repack64              Encoder/Codec/EbTransforms.c:2933-2969             handle_transform*_N2_N4_c
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
@@ -271,8 +272,24 @@ wiener_convolve_kernel(const PIX* __restrict__ src, int ss, PIX* __restrict__ ds
     dst[(size_t)y * ds + x] = (PIX)clip_px((sum + ((1 << round1) >> 1)) >> round1, bd);
 }
 
+// ------------------------------------------------------------------------------------------------ 64-point re-pack of the N2 / N4 coefficient shapes
+// handle_transform64x{16,32,64}_N2_N4_c (EbTransforms.c:2947-2969): rows 1 .. rows-1 move from stride 64 to stride 32, nothing is zeroed, no energy
+__global__ void __launch_bounds__(1024)
+repack64_kernel(int32_t* __restrict__ coeff, int rows, int per_block) {
+    int32_t* c = coeff + (size_t)blockIdx.x * per_block;
+    const int r = threadIdx.x >> 5, x = threadIdx.x & 31;
+    const int32_t v = r < rows ? c[r * 64 + x] : 0;
+    __syncthreads();
+    if (r < rows) c[r * 32 + x] = v;
+}
+
 }  // namespace
 
+extern "C" int svt_hip_launch_repack64(hipStream_t st, int32_t* coeff, int rows, int per_block, int nblk) {
+    if (nblk <= 0) return 0;
+    hipLaunchKernelGGL(repack64_kernel, dim3(nblk), dim3(1024), 0, st, coeff, rows, per_block);
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_block_mean(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, int mode, int w, int h, uint64_t* out) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(block_mean_kernel, dim3(n), dim3(64), 0, st, plane, stride, offs, mode, w, h, out);

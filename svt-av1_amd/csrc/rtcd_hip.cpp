@@ -970,6 +970,28 @@ void wiener_convolve_hbd_hip(const uint8_t* src8, ptrdiff_t ss, uint8_t* dst8, p
     FALLBACK("svt_av1_highbd_wiener_convolve_add_src", svt_av1_highbd_wiener_convolve_add_src, src8, ss, dst8, ds, fx, fy, w, h, cp, bd);
 }
 
+template <int SLOT, int TS> uint64_t handle_transform_n2n4_hip(int32_t* output) {
+    Guard lk;
+    if (g_ctx) {
+        const size_t n = (size_t)kTxW[TS] * kTxH[TS];
+        int32_t* d_c = (int32_t*)dev(0, n * 4);
+        if (d_c && up(d_c, output, n * 4) && svt_hip_handle_transform64_n2n4_batch_dev(g_ctx, TS, d_c, 1) == 0 && down(output, d_c, n * 4)) return 0;
+    }
+    FALLBACK("handle_transform64xN_N2_N4", handle_transform64_N2_N4[SLOT], output);
+}
+unsigned mse16x16_hip(const uint8_t* a, int as, const uint8_t* b, int bs, unsigned* sse) {
+    Guard lk;
+    unsigned v;
+    if (var_generic(1, 8, a, as, b, bs, 16, 16, &v, sse)) return v;
+    FALLBACK("svt_aom_mse16x16", svt_aom_mse16x16, a, as, b, bs, sse);
+}
+void mse16x16_hbd8_hip(const uint8_t* a8, int32_t as, const uint8_t* b8, int32_t bs, uint32_t* sse) {
+    Guard lk;
+    uint64_t r;
+    if (sse_generic(2, (const void*)((uintptr_t)a8 << 1), as, (const void*)((uintptr_t)b8 << 1), bs, 16, 16, &r)) { *sse = (uint32_t)r; return; }
+    FALLBACK("svt_aom_highbd_8_mse16x16", svt_aom_highbd_8_mse16x16, a8, as, b8, bs, sse);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -1034,5 +1056,9 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_compute_mean_square_values_8x8 = mean_sq_8x8_hip; t->svt_compute_sub_mean_8x8 = sub_mean_8x8_hip;
     t->svt_aom_convolve8_horiz = convolve8_horiz_hip; t->svt_aom_convolve8_vert = convolve8_vert_hip;
     t->svt_av1_wiener_convolve_add_src = wiener_convolve_hip; t->svt_av1_highbd_wiener_convolve_add_src = wiener_convolve_hbd_hip;
+    t->handle_transform64_N2_N4[0] = handle_transform_n2n4_hip<0, 17>; t->handle_transform64_N2_N4[1] = handle_transform_n2n4_hip<1, 11>;
+    t->handle_transform64_N2_N4[2] = handle_transform_n2n4_hip<2, 18>; t->handle_transform64_N2_N4[3] = handle_transform_n2n4_hip<3, 12>;
+    t->handle_transform64_N2_N4[4] = handle_transform_n2n4_hip<4, 4>;
+    t->svt_aom_mse16x16 = mse16x16_hip; t->svt_aom_highbd_8_mse16x16 = mse16x16_hbd8_hip;
     return SVT_HIP_OK;
 }

@@ -969,6 +969,15 @@ int svt_hip_upsampled_pred_batch_dev(SvtHipCtx* c, const uint8_t* d_ref, int ref
     if (e != hipSuccess) return fail(c, e, "upsampled pred launch");
     return SVT_HIP_OK;
 }
+int svt_hip_handle_transform64_n2n4_batch_dev(SvtHipCtx* c, int tx_size, int32_t* d_coeff, int nblk) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_coeff || nblk < 0 || (tx_size != 4 && tx_size != 11 && tx_size != 12 && tx_size != 17 && tx_size != 18)) return SVT_HIP_ERR_BAD_ARG;
+    if (tx_size == 11 || tx_size == 17) return SVT_HIP_OK;   // 32x64 / 16x64: the reference's functions do nothing
+    const int rows = tx_size == 18 ? 16 : 32;
+    hipError_t e = (hipError_t)svt_hip_launch_repack64(c->stream, d_coeff, rows, 64 * (tx_size == 4 ? 64 : rows), nblk);
+    if (e != hipSuccess) return fail(c, e, "handle transform64 N2 / N4 launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_block_mean_batch_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, const int32_t* d_offs, int n, int mode, int w, int h, uint64_t* d_out) {
     SVT_HIP_ENTER(c);
     if (!c || !d_plane || !d_offs || !d_out || n < 0 || (mode != 0 && mode != 1) || (mode == 0 && (w < 1 || h < 1))) return SVT_HIP_ERR_BAD_ARG;

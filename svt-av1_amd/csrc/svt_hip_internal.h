@@ -106,6 +106,7 @@ int svt_hip_launch_cdef_find_dir_list(hipStream_t st, const uint16_t* img, const
 int svt_hip_launch_cdef_filter_block_list(hipStream_t st, const uint16_t* in, int istride, const void* jobs, int n, uint8_t* dst8, uint16_t* dst16, int dstride);
 int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n);
 /* per-call forms (percall2.hip) */
+int svt_hip_launch_repack64(hipStream_t st, int32_t* coeff, int rows, int per_block, int nblk);
 int svt_hip_launch_block_mean(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, int mode, int w, int h, uint64_t* out);
 int svt_hip_launch_ext_sad_16(hipStream_t st, const uint8_t* src, int ss, const uint8_t* ref, int rs, const SvtHipExtSadJob* jobs, int n, uint32_t* state);
 int svt_hip_launch_ext_sad_32_64(hipStream_t st, uint32_t* state, const uint32_t* mv, int n);

@@ -101,6 +101,7 @@ MSQ8 = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint32, C.c_uint32, C.c_uint32)
 SUBMEAN = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint16)
 CONV8 = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
 WIENER = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams))
+HBDMSE = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, VP)
 WIENERH = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams), C.c_int32)
 
 
@@ -132,7 +133,8 @@ class Rtcd(C.Structure):
                 ("svt_aom_satd", SATD), ("svt_av1_block_error", BLKERR), ("svt_get_proj_subspace", PROJSUB), ("svt_av1_lowbd_pixel_proj_error", PROJERR),
                 ("svt_av1_highbd_pixel_proj_error", PROJERR), ("svt_compute_mean_square_values_8x8", MSQ8), ("svt_compute_sub_mean_8x8", SUBMEAN),
                 ("svt_aom_convolve8_horiz", CONV8), ("svt_aom_convolve8_vert", CONV8), ("svt_av1_wiener_convolve_add_src", WIENER),
-                ("svt_av1_highbd_wiener_convolve_add_src", WIENERH)]
+                ("svt_av1_highbd_wiener_convolve_add_src", WIENERH), ("handle_transform64_N2_N4", HT64 * 5), ("svt_aom_mse16x16", VARWH),
+                ("svt_aom_highbd_8_mse16x16", HBDMSE)]
 
 
 @pytest.fixture(scope="module")
@@ -684,3 +686,15 @@ def test_helper_pointers_vs_reference_c(rtcd, ref):
                 _as(WIENERH, ref.svt_av1_highbd_wiener_convolve_add_src_c)((img.ctypes.data + off) >> 1, 100, e.ctypes.data >> 1, w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp), bd)
                 rtcd.svt_av1_highbd_wiener_convolve_add_src((img.ctypes.data + off) >> 1, 100, g.ctypes.data >> 1, w + 3, _vp(taps, 16 * ix), _vp(taps, 16 * iy), w, h, C.byref(cp), bd)
             assert np.array_equal(e, g), ("wiener convolve", bd, w, h, ix, iy)
+    # --- the re-pack after the N2 / N4 forward transforms, and the two 16x16 MSE pointers
+    for slot, (name, n) in enumerate((("16x64", 16 * 64), ("32x64", 32 * 64), ("64x16", 64 * 16), ("64x32", 64 * 32), ("64x64", 64 * 64))):
+        e = rng.integers(-(1 << 20), 1 << 20, n).astype(np.int32); g = e.copy()
+        assert _as(HT64, getattr(ref, f"handle_transform{name}_N2_N4_c"))(_vp(e)) == rtcd.handle_transform64_N2_N4[slot](_vp(g)) == 0
+        assert np.array_equal(e, g), ("N2 / N4 re-pack", name)
+    a = rng.integers(0, 256, (20, 30)).astype(np.uint8); b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    se, sg = C.c_uint(), C.c_uint()
+    assert _as(VARWH, ref.svt_aom_mse16x16_c)(_vp(a, 33), 30, _vp(b, 2), 30, C.byref(se)) == rtcd.svt_aom_mse16x16(_vp(a, 33), 30, _vp(b, 2), 30, C.byref(sg)) and se.value == sg.value
+    a16 = rng.integers(0, 1024, (20, 30)).astype(np.uint16); b16 = rng.integers(0, 1024, (20, 30)).astype(np.uint16)
+    _as(HBDMSE, ref.svt_aom_highbd_8_mse16x16_c)((a16.ctypes.data + 4) >> 1, 30, (b16.ctypes.data + 66) >> 1, 30, C.byref(se))
+    rtcd.svt_aom_highbd_8_mse16x16((a16.ctypes.data + 4) >> 1, 30, (b16.ctypes.data + 66) >> 1, 30, C.byref(sg))
+    assert se.value == sg.value and se.value > 0
