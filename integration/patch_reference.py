@@ -113,6 +113,31 @@ mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',
         r'\1                } /* hip_pass */\n                svt_hip_me_batch_end(hip_me);\n')
 PATCHES.append(mep)
 
+# ---------------------------------------------------------------------------------------------------------------- alt-ref temporal filter
+# produce_temporally_filtered_pic (:2038): the block loop of a TF segment keeps its motion search and tf_inter_prediction; Step 2 (the central /
+# plane-wise filter) and get_final_filtered_pixels are replaced by one device launch per segment (svt_hip_tf_bridge.c).  The loop is wrapped so
+# that a failed flush reruns it unchanged — the central picture is only written by a successful flush.
+tf = Patch("Source/Lib/Encoder/Codec/EbTemporalFiltering.c")
+tf.sub(r'(\n    \*filtered_sse    = 0;\n    \*filtered_sse_uv = 0;\n)',
+       r'\n    for (int hip_try = 0; hip_try < 2; hip_try++) {\n'
+       r'    SvtHipTfSeg *hip_tf = hip_try ? NULL : svt_hip_tf_seg_begin(picture_control_set_ptr_central->past_altref_nframes +\n'
+       r'        picture_control_set_ptr_central->future_altref_nframes + 1, index_center, x_b64_start_idx, x_b64_end_idx, y_b64_start_idx, y_b64_end_idx,\n'
+       r'        is_highbd, ss_x, ss_y);\1')
+tf.sub(r'(\n[ \t]*if \(picture_control_set_ptr_central->scs_ptr->static_config\.qp <= ALT_REF_QP_THRESH\)\s*decay_control--;\n)',
+       r'\1                if (hip_tf) { /* Step 2 of this (frame, block) happens in svt_hip_tf_seg_flush */\n'
+       r'                    svt_hip_tf_seg_block(hip_tf, frame_index, blk_row, blk_col, context_ptr, pred, pred_16bit, stride_pred, decay_control);\n'
+       r'                    continue;\n'
+       r'                }\n')
+tf.sub(r'(\n[ \t]*)(get_final_filtered_pixels\(context_ptr,\s*src_center_ptr_start,)', r'\1if (!hip_tf) \2')
+tf.sub(r'(\n    if \(!is_highbd\)\n        EB_FREE_ALIGNED_ARRAY\(predictor\);)',
+       r'\n    if (!hip_tf) break;\n'
+       r'    const EbErrorType hip_ret = svt_hip_tf_seg_flush(hip_tf, context_ptr, src_center_ptr_start, altref_buffer_highbd_start, stride, encoder_bit_depth,\n'
+       r'                                                     noise_levels, filtered_sse, filtered_sse_uv);\n'
+       r'    svt_hip_tf_seg_end(hip_tf);\n'
+       r'    if (hip_ret == EB_ErrorNone) break;\n'
+       r'    } /* hip_try */\1')
+PATCHES.append(tf)
+
 # ---------------------------------------------------------------------------------------------------------------- deblocking (dlf_kernel)
 dlf = Patch("Source/Lib/Encoder/Codec/EbDlfProcess.c")
 dlf.sub(r'(\n[ \t]*)(svt_av1_pick_filter_level\(\s*context_ptr,\s*\(EbPictureBufferDesc \*\)pcs_ptr->parent_pcs_ptr->enhanced_picture_ptr,\s*pcs_ptr,\s*'

@@ -2,6 +2,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include "svt_hip_tf_bridge.h"
+#include "svt_hip_hooks.h"
+#include "EbLog.h"
 
 #define HIP_TRY(call) do { if ((call) != SVT_HIP_OK) return EB_ErrorUndefined; } while (0)   /* caller falls back to the C loop */
 
@@ -64,4 +66,110 @@ EbErrorType svt_hip_tf_flush_picture(SvtHipCtx *hip, SvtHipTfWindow *w, const Me
     HIP_TRY(svt_hip_memcpy_d2h(hip, sse, w->d_sse, sizeof(sse)));
     *filtered_sse = sse[0]; *filtered_sse_uv = sse[1];
     return EB_ErrorNone;
+}
+
+/* ------------------------------------------------------------------ hook "tf": one TF segment */
+struct SvtHipTfSeg {
+    SvtHipTfWindow w;                 /* geometry of the segment's rectangle (blk_cols x blk_rows), block records per frame */
+    uint32_t       col0, row0;
+    int            is_highbd, ss_x, ss_y, decay_control, ctor_done;
+    uint8_t       *h_pred[SVT_HIP_TF_MAX_REFS][3]; /* host staging of the predictor pictures (the reference's tf_inter_prediction output) */
+    size_t         plane_bytes[3];
+};
+
+SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0, uint32_t col1, uint32_t row0, uint32_t row1, int is_highbd, int ss_x, int ss_y) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_TF) || n_frames < 1 || n_frames > SVT_HIP_TF_MAX_REFS || col1 <= col0 || row1 <= row0) return NULL;
+    SvtHipTfSeg *s = (SvtHipTfSeg *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->col0 = col0; s->row0 = row0; s->is_highbd = is_highbd; s->ss_x = ss_x; s->ss_y = ss_y;
+    SvtHipTfWindow *w = &s->w;
+    w->n_frames = n_frames; w->index_center = index_center;
+    w->blk_cols = (int)(col1 - col0); w->blk_rows = (int)(row1 - row0);
+    w->pred_stride[0] = w->blk_cols * 64; w->pred_stride[1] = w->pred_stride[2] = (w->blk_cols * 64) >> ss_x;
+    const size_t nblk = (size_t)w->blk_cols * w->blk_rows;
+    const int    pb = is_highbd ? 2 : 1;
+    for (int p = 0; p < 3; p++) s->plane_bytes[p] = (size_t)w->pred_stride[p] * ((size_t)(w->blk_rows * 64) >> (p ? ss_y : 0)) * pb;
+    for (int f = 0; f < n_frames; f++) {
+        if (f == index_center) continue;
+        w->h_blocks[f] = (SvtHipTfBlk64 *)calloc(nblk, sizeof(SvtHipTfBlk64));
+        int ok = w->h_blocks[f] != NULL;
+        for (int p = 0; p < 3 && ok; p++) ok = (s->h_pred[f][p] = (uint8_t *)calloc(1, s->plane_bytes[p])) != NULL;
+        if (!ok) { svt_hip_tf_seg_end(s); return NULL; }
+    }
+    return s;
+}
+
+void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
+    if (!s) return;
+    SvtHipCtx *hip = s->ctor_done ? svt_hip_hooks_lock() : NULL;
+    for (int f = 0; f < SVT_HIP_TF_MAX_REFS; f++) {
+        free(s->w.h_blocks[f]);
+        for (int p = 0; p < 3; p++) free(s->h_pred[f][p]);
+        if (hip) {
+            svt_hip_free(hip, s->w.d_blocks[f]);
+            for (int p = 0; p < 3; p++) svt_hip_free(hip, s->w.d_pred[f][p]);
+        }
+    }
+    if (hip) { svt_hip_free(hip, s->w.d_sse); svt_hip_hooks_unlock(); }
+    free(s);
+}
+
+void svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *c, EbByte *pred, uint16_t **pred_16bit,
+                          const uint32_t *stride_pred, int decay_control) {
+    s->decay_control = decay_control;   /* the same for every block of the picture (resolution class and QP, EbTemporalFiltering.c:2313-2320) */
+    if (frame_index == s->w.index_center) return;   /* apply_filtering_central reads the central picture itself */
+    const uint32_t r = blk_row - s->row0, col = blk_col - s->col0;
+    svt_hip_tf_record_block(&s->w, frame_index, r, col, c);
+    const int pb = s->is_highbd ? 2 : 1;
+    for (int p = 0; p < (c->tf_chroma ? 3 : 1); p++) {
+        const int      bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
+        const uint8_t *src = s->is_highbd ? (const uint8_t *)pred_16bit[p] : pred[p];
+        uint8_t       *dst = s->h_pred[frame_index][p] + ((size_t)r * bh * s->w.pred_stride[p] + (size_t)col * bw) * pb;
+        for (int y = 0; y < bh; y++) memcpy(dst + (size_t)y * s->w.pred_stride[p] * pb, src + (size_t)y * stride_pred[p] * pb, (size_t)bw * pb);
+    }
+}
+
+#define TF_TRY(x) do { if (ret == EB_ErrorNone && (x) != SVT_HIP_OK) ret = EB_ErrorUndefined; } while (0)
+EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src_start, uint16_t **src16_start, const uint32_t *stride, int bd, const double *noise_levels,
+                                 uint64_t *filtered_sse, uint64_t *filtered_sse_uv) {
+    SvtHipTfWindow *w = &s->w;
+    const int       pb = s->is_highbd ? 2 : 1, np = c->tf_chroma ? 3 : 1;
+    const size_t    nblk = (size_t)w->blk_cols * w->blk_rows;
+    SvtHipCtx      *hip = svt_hip_hooks_lock();
+    if (!hip) { svt_hip_hooks_count(SVT_HIP_HOOK_TF, 0); return EB_ErrorUndefined; }
+    EbErrorType ret = EB_ErrorNone;
+    void       *d_src[3] = {NULL, NULL, NULL};
+    uint8_t    *host[3];
+    int         sstride[3];
+    s->ctor_done = 1;
+    for (int f = 0; f < w->n_frames && ret == EB_ErrorNone; f++) {
+        if (f == w->index_center) continue;
+        TF_TRY(svt_hip_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
+        for (int p = 0; p < 3; p++) {
+            TF_TRY(svt_hip_malloc(hip, &w->d_pred[f][p], s->plane_bytes[p]));
+            if (p < np) TF_TRY(svt_hip_memcpy_h2d(hip, w->d_pred[f][p], s->h_pred[f][p], s->plane_bytes[p]));
+        }
+    }
+    TF_TRY(svt_hip_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
+    /* the segment's rectangle of the central picture (chroma is only read when tf_chroma is on) */
+    for (int p = 0; p < 3; p++) {
+        const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
+        host[p] = (s->is_highbd ? (uint8_t *)src16_start[p] : src_start[p]) + ((size_t)s->row0 * bh * stride[p] + (size_t)s->col0 * bw) * pb;
+        sstride[p] = w->pred_stride[p];
+        TF_TRY(svt_hip_malloc(hip, &d_src[p], s->plane_bytes[p]));
+        TF_TRY(svt_hip_memcpy2d_h2d(hip, d_src[p], (size_t)sstride[p] * pb, host[p], (size_t)stride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
+    }
+    if (ret == EB_ErrorNone)
+        ret = svt_hip_tf_flush_picture(hip, w, c, s->is_highbd, bd, d_src, sstride, d_src, sstride, s->ss_x, s->ss_y, noise_levels, s->decay_control, filtered_sse,
+                                       filtered_sse_uv);
+    for (int p = 0; p < np; p++) {   /* get_final_filtered_pixels writes chroma only when tf_chroma is on (:1969, :2011) */
+        const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
+        TF_TRY(svt_hip_memcpy2d_d2h(hip, host[p], (size_t)stride[p] * pb, d_src[p], (size_t)sstride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
+    }
+    for (int p = 0; p < 3; p++) svt_hip_free(hip, d_src[p]);
+    if (ret != EB_ErrorNone) SVT_LOG("temporal filter segment on the device failed (%s): C loop for this segment\n", svt_hip_last_error(hip));
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_log("tf: segment of %d x %d blocks, %d frames, one launch", w->blk_cols, w->blk_rows, w->n_frames);
+    svt_hip_hooks_count(SVT_HIP_HOOK_TF, ret == EB_ErrorNone);
+    return ret;
 }

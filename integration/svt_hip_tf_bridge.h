@@ -2,7 +2,10 @@
  * svt_hip_tf_bridge.h — reference-side glue for the alt-ref temporal filter: produce_temporally_filtered_pic
  * (Source/Lib/Encoder/Codec/EbTemporalFiltering.c:2012-2412) driven through svt_hip_tf_filter_frame_dev.
  *
- * Compiled INTO libSvtAv1Enc (includes the reference's headers); tests/test_integration_compiles.py syntax-checks it.
+ * Compiled INTO libSvtAv1Enc (includes the reference's headers).  Two users:
+ *   - the hooked encoder (hook "tf", integration/patch_reference.py): svt_hip_tf_seg_* below — one TF segment at a time, the reference's own
+ *     motion search and tf_inter_prediction, the pixel side (central / plane-wise filter, normalisation) in one launch per segment;
+ *   - a picture-level driver with device-side prediction (svt_hip_tf_window_* / record_block / flush_picture), the form a resident pipeline uses.
  *
  * The per-64x64-block loop keeps its motion search (motion_estimate_sb, tf_32x32 / tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag:
  * host logic on top of the ME / sub-pel entry points) but
@@ -40,5 +43,22 @@ void svt_hip_tf_record_block(SvtHipTfWindow *w, int frame_index, uint32_t blk_ro
 EbErrorType svt_hip_tf_flush_picture(SvtHipCtx *hip, SvtHipTfWindow *w, const MeContext *context_ptr, int is_16bit, int bd, void *const d_src[3],
                                      const int src_stride[3], void *const d_dst[3], const int dst_stride[3], int ss_x, int ss_y, const double *noise_levels,
                                      int decay_control, uint64_t *filtered_sse, uint64_t *filtered_sse_uv);
+
+
+/* ------------------------------------------------------------------ hook "tf": one TF segment of produce_temporally_filtered_pic
+ * (Source/Lib/Encoder/Codec/EbTemporalFiltering.c:2038-2412).  The block loop keeps Step 1 (motion_estimate_sb, tf_32x32 / tf_16x16_sub_pel_search,
+ * derive_tf_32x32_block_split_flag, tf_inter_prediction) and hands every (frame, 64x64 block) predictor + the MeContext TF fields to
+ * svt_hip_tf_seg_block instead of running Step 2 (apply_filtering_central / apply_filtering_block_plane_wise) and get_final_filtered_pixels;
+ * svt_hip_tf_seg_flush then filters the segment's rectangle over the whole window on the device and writes it into the central picture.
+ * Nothing of the central picture changes before the flush succeeded, so a failure simply reruns the segment's unchanged C loop. */
+typedef struct SvtHipTfSeg SvtHipTfSeg;
+/* NULL = hook off (or no memory): the caller runs its unchanged loop.  [col0, col1) x [row0, row1) = the segment's 64x64 blocks. */
+SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0, uint32_t col1, uint32_t row0, uint32_t row1, int is_highbd, int ss_x, int ss_y);
+void         svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *context_ptr, EbByte *pred,
+                                  uint16_t **pred_16bit, const uint32_t *stride_pred, int decay_control);
+/* src_start / src16_start: the central picture's planes at sample (0, 0) (8-bit planes, or altref_buffer_highbd), stride[] in samples */
+EbErrorType  svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *context_ptr, EbByte *src_start, uint16_t **src16_start, const uint32_t *stride, int bd,
+                                  const double *noise_levels, uint64_t *filtered_sse, uint64_t *filtered_sse_uv);
+void         svt_hip_tf_seg_end(SvtHipTfSeg *s);
 
 #endif

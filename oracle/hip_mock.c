@@ -78,6 +78,21 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride,
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------ alt-ref temporal filter */
+int svt_hip_tf_filter_frame_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *const src[3], const int src_stride[3], void *const dst[3],
+                                const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef *refs, int n_refs,
+                                const double noise_levels[3], int decay_control, int min_frame_size, uint64_t *sse) {
+    (void)c;
+    OrcTfRef r[SVT_HIP_TF_MAX_REFS];
+    for (int f = 0; f < n_refs; f++) {
+        for (int p = 0; p < 3; p++) { r[f].pred[p] = refs[f].pred[p]; r[f].pred_stride[p] = refs[f].pred_stride[p]; }
+        r[f].blocks = (const OrcTfBlk64 *)refs[f].blocks;   /* the same layout (svt_oracle.h / svt_hip.h) */
+    }
+    orc_tf_filter_frame(pix_bytes, bd, src, src_stride, dst, dst_stride, w, h, ss_x, ss_y, tf_chroma, r, n_refs, noise_levels, decay_control, min_frame_size, sse);
+    if (perturb("tf")) { ((uint8_t *)dst[0])[(size_t)9 * dst_stride[0] * pix_bytes + 9 * pix_bytes] ^= 4; ((uint8_t *)dst[0])[(size_t)30 * dst_stride[0] * pix_bytes + 41 * pix_bytes] ^= 8; }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ deblocking */
 int svt_hip_deblock_plane_dev(SvtHipCtx *c, void *plane, int pix_bytes, int stride, int bd, const uint16_t *ev, const uint16_t *eh,
                               int units_w, int units_h, int sharpness) {
