@@ -136,6 +136,11 @@ tf.sub(r'(\n    if \(!is_highbd\)\n        EB_FREE_ALIGNED_ARRAY\(predictor\);)'
        r'    svt_hip_tf_seg_end(hip_tf);\n'
        r'    if (hip_ret == EB_ErrorNone) break;\n'
        r'    } /* hip_try */\1')
+# estimate_noise / estimate_noise_highbd (:2416, :2451): the Laplacian sums on the device, sigma by the library's host helper
+tf.sub(r'(double estimate_noise\(const uint8_t \*src, uint16_t width, uint16_t height, uint16_t stride_y\) \{\n)',
+       r'\1    { double hip_sigma; if (svt_hip_tf_hook_noise(src, 1, 8, width, height, stride_y, &hip_sigma)) return hip_sigma; }\n')
+tf.sub(r'(double estimate_noise_highbd\(const uint16_t \*src, int width, int height, int stride, int bd\) \{\n)',
+       r'\1    { double hip_sigma; if (svt_hip_tf_hook_noise(src, 2, bd, width, height, stride, &hip_sigma)) return hip_sigma; }\n')
 PATCHES.append(tf)
 
 # ---------------------------------------------------------------------------------------------------------------- deblocking (dlf_kernel)

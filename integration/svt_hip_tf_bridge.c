@@ -173,3 +173,22 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     svt_hip_hooks_count(SVT_HIP_HOOK_TF, ret == EB_ErrorNone);
     return ret;
 }
+
+int svt_hip_tf_hook_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, double *sigma) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_TF) || width < 3 || height < 3) return 0;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return 0;
+    void   *d_plane = NULL, *d_out = NULL;
+    int64_t out[2] = {0, 0};
+    int     rc = svt_hip_malloc(hip, &d_plane, (size_t)width * height * pix_bytes);
+    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_out, sizeof(out));
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy2d_h2d(hip, d_plane, (size_t)width * pix_bytes, src, (size_t)stride * pix_bytes, (size_t)width * pix_bytes, (size_t)height);
+    if (rc == SVT_HIP_OK) rc = svt_hip_tf_estimate_noise_dev(hip, d_plane, pix_bytes, bd, width, height, width, (int64_t *)d_out);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, out, d_out, sizeof(out));
+    svt_hip_free(hip, d_plane); svt_hip_free(hip, d_out);
+    svt_hip_hooks_unlock();
+    if (rc != SVT_HIP_OK) return 0;
+    *sigma = svt_hip_tf_noise_sigma(out[0], out[1]);
+    svt_hip_hooks_log("tf: noise of a %d x %d plane = %f", width, height, *sigma);
+    return 1;
+}

@@ -60,5 +60,8 @@ void         svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_
 EbErrorType  svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *context_ptr, EbByte *src_start, uint16_t **src16_start, const uint32_t *stride, int bd,
                                   const double *noise_levels, uint64_t *filtered_sse, uint64_t *filtered_sse_uv);
 void         svt_hip_tf_seg_end(SvtHipTfSeg *s);
+/* estimate_noise / estimate_noise_highbd (EbTemporalFiltering.c:2416, :2451), first statement of both: 1 = *sigma holds the result of
+ * svt_hip_tf_estimate_noise_dev + svt_hip_tf_noise_sigma, 0 = hook off or a failure (the function continues with its own loop). */
+int          svt_hip_tf_hook_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, double *sigma);
 
 #endif

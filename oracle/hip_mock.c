@@ -93,6 +93,12 @@ int svt_hip_tf_filter_frame_dev(SvtHipCtx *c, int pix_bytes, int bd, const void 
     return SVT_HIP_OK;
 }
 
+int svt_hip_tf_estimate_noise_dev(SvtHipCtx *c, const void *src, int pix_bytes, int bd, int width, int height, int stride, int64_t *out) {
+    (void)c;
+    orc_tf_estimate_noise(src, pix_bytes, bd, width, height, stride, out);
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ deblocking */
 int svt_hip_deblock_plane_dev(SvtHipCtx *c, void *plane, int pix_bytes, int stride, int bd, const uint16_t *ev, const uint16_t *eh,
                               int units_w, int units_h, int sharpness) {
