@@ -113,6 +113,20 @@ mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',
         r'\1                } /* hip_pass */\n                svt_hip_me_batch_end(hip_me);\n')
 PATCHES.append(mep)
 
+# ---------------------------------------------------------------------------------------------------------------- picture analysis
+# the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)
+pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")
+pa.sub(r'(void downsample_decimation_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',
+       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 0) == EB_ErrorNone)\n'
+       r'        return;\n')
+pa.sub(r'(void downsample_filtering_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',
+       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_picture_ptr, sixteenth_picture_ptr, 1) == EB_ErrorNone) return;\n')
+pa.sub(r'(\n[ \t]*// Variance\n[ \t]*uint64_t pic_tot_variance = 0;\n)',
+       r'\1    const int hip_var = svt_hip_hook_pa_variance(scs_ptr, pcs_ptr, input_padded_picture_ptr) == EB_ErrorNone; /* y_mean / variance of every SB */\n')
+pa.sub(r'(\n[ \t]*)(compute_block_mean_compute_variance\(\s*scs_ptr, pcs_ptr, input_padded_picture_ptr, sb_index, input_luma_origin_index\);)',
+       r'\1if (!hip_var)\1    \2')
+PATCHES.append(pa)
+
 # ---------------------------------------------------------------------------------------------------------------- alt-ref temporal filter
 # produce_temporally_filtered_pic (:2038): the block loop of a TF segment keeps its motion search and tf_inter_prediction; Step 2 (the central /
 # plane-wise filter) and get_final_filtered_pixels are replaced by one device launch per segment (svt_hip_tf_bridge.c).  The loop is wrapped so

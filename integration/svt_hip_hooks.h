@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  tf, hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  pa, tf, hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -38,6 +38,7 @@ enum {
                                 * (EbMotionEstimation.c:998, :1146, :1291) */
     SVT_HIP_HOOK_TF,           /* Step 2 + get_final_filtered_pixels of every TF segment: produce_temporally_filtered_pic (EbTemporalFiltering.c:2038-2412),
                                 * glue in svt_hip_tf_bridge.c */
+    SVT_HIP_HOOK_PA,           /* picture analysis: the HME pyramids and the per-SB mean / variance pyramid (EbPictureAnalysisProcess.c:3312, :3606, :2929) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -112,6 +113,11 @@ int svt_hip_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, WienerI
 EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err);
 /* rest_kernel, when the picture leaves the filter stages: releases its device state */
 void        svt_hip_hook_picture_done(PictureControlSet *pcs);
+
+/* ------------------------------------------------------------------ picture analysis (svt_hip_pa_bridge.c); EB_ErrorNone = handled */
+EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,
+                                       int filtered);
+EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentControlSet *pcs, EbPictureBufferDesc *padded);
 
 /* the temporal-filter hook's declarations (svt_hip_tf_seg_*) */
 #include "svt_hip_tf_bridge.h"

@@ -78,6 +78,20 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride,
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------ picture analysis */
+int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
+    (void)c;
+    orc_downsample_2d(in, in_stride, w, h, out, out_stride, step, filtered);
+    if (perturb("pa")) out[(size_t)5 * out_stride + 7] ^= 0x10;
+    return SVT_HIP_OK;
+}
+int svt_hip_variance_pyramid_dev(SvtHipCtx *c, const uint8_t *plane, int stride, int sb_cols, int n_sb, int full_precision, uint8_t *mean, uint16_t *var) {
+    (void)c;
+    for (int i = 0; i < n_sb; i++)
+        orc_variance_pyramid_sb(plane + (size_t)(i / sb_cols) * 64 * stride + (size_t)(i % sb_cols) * 64, stride, full_precision, mean + (size_t)i * 85, var + (size_t)i * 85);
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ alt-ref temporal filter */
 int svt_hip_tf_filter_frame_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *const src[3], const int src_stride[3], void *const dst[3],
                                 const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef *refs, int n_refs,
