@@ -14,6 +14,7 @@
 #include "svt_hip_hooks.h"
 #include "EbLog.h"
 #include "EbPictureAnalysisProcess.h"
+#include "EbMcp.h"
 
 #define PA_TRY(x) do { if (rc == SVT_HIP_OK) rc = (x); } while (0)
 
