@@ -263,7 +263,9 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
                     help="reference = the reference's own SIMD kernels (oracle/_ref SIMD flavour); port = the oracle's scalar C; auto = reference when built")
     ap.add_argument("--me-waves", type=int, default=4, help="svt_hip_me_set_waves_per_sb value (debug)")
-    ap.add_argument("--no-side", action="store_true", help="keep the source-side chain on the frame's main stream (debug)")
+    ap.add_argument("--side", action="store_true", help="run each frame's source-side chain (pyramids, HME, ME) on a second stream (slower on MI355X: 8 streams "
+                                                         "share 4 hardware queues; measured 8.60 vs 8.26 ms per 4-frame step)")
+    ap.add_argument("--no-side", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--stages", default="all", help="comma list (debug): " + ",".join(k for k, _ in ALL_STAGES))
     args = ap.parse_args()
@@ -312,10 +314,10 @@ def main():
     stages = [(k, n) for k, n in ALL_STAGES if (k not in ("txfm", "inv") if want is None else k in want)]
 
     # ---------------------------------------------------------------- streams / graphs
-    # A frame's step is two chains: the source side (pyramids -> HME -> ME; open loop, reads source pictures only) and the reconstruction side
-    # (sub-pel -> transform -> inverse -> deblock -> CDEF -> restoration).  Each chain of each frame of the batch gets its own HIP stream, forked
-    # from and joined back into the stream that carries the step; inside a captured graph these are parallel branches, so the short
-    # memory-side kernels of one frame fill the gaps next to the VALU-bound searches of another.
+    # Each frame of the batch gets its own HIP stream, forked from and joined back into the stream that carries the step; inside a captured graph
+    # these are parallel branches, so the short memory-side kernels of one frame fill the gaps next to the VALU-bound searches of another.
+    # (--side splits a frame further into its source side — pyramids -> HME -> ME, open loop — and its reconstruction side on two streams; with
+    # four frames that is eight streams on the four hardware queues ROCm multiplexes them onto, and measurably slower.)
     cur = {"s": stream}
 
     class on:
@@ -336,7 +338,7 @@ def main():
 
     max_f = max([nF] + (sweep_fs if not args.no_sweep else []))
     main_streams = [torch.cuda.Stream() for _ in range(max_f)]
-    side_streams = [torch.cuda.Stream() for _ in range(max_f)] if not args.no_side else None
+    side_streams = [torch.cuda.Stream() for _ in range(max_f)] if args.side else None
 
     def batch_step(batch, stages=stages):
         base = cur["s"]
@@ -528,7 +530,7 @@ def main():
         "metric": METRIC, "value": nF * n_sb * args.steps * world / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step x 2 forked streams (source side / reconstruction side), "
+        "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame" + (" x 2 (source side / reconstruction side)" if side_streams is not None else "") + ", "
                   f"steps rotate over {len(step_fns)} batches = {len(step_fns) * nF} distinct frames",
         "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p,
         "frames_per_step_sweep": sweep,
@@ -551,7 +553,7 @@ def main():
 
 def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
-    up_s, down_s = torch.cuda.Stream(), torch.cuda.Stream()   # PCIe is full duplex: uploads and downloads get a stream (a DMA queue) each
+    up_s, down_s = torch.cuda.Stream(), torch.cuda.Stream()   # PCIe is full duplex: uploads and downloads get a stream each
     pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host = []
     up_bytes = down_bytes = 0
@@ -588,17 +590,20 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
         comp_done[b].record(stream)
     torch.cuda.synchronize()
 
+    mode = os.environ.get("SVT_BENCH_XFER", "both")   # diagnosis: up | down | both | none
+    do_up, do_down = mode in ("up", "both"), mode in ("down", "both")
+
     def run(n):
-        upload(0)
+        if do_up: upload(0)
         for i in range(n):
             b = i % nb
-            stream.wait_event(up_done[b])
-            if i >= nb: stream.wait_event(down_done[b])   # the results of this batch's previous step have left the device
+            if do_up: stream.wait_event(up_done[b])
+            if do_down and i >= nb: stream.wait_event(down_done[b])   # the results of this batch's previous step have left the device
             step_fns[b]()
             comp_done[b].record(stream)
-            download(b)
-            if i + 1 < n:
-                upload((i + 1) % nb)      # waits (on the copy stream) for the step that last used those buffers; overlaps the step just launched
+            if do_down: download(b)
+            if do_up and i + 1 < n:
+                upload((i + 1) % nb)      # waits (on the copy stream) for the step that last used those buffers
         torch.cuda.synchronize()
 
     run(3)
