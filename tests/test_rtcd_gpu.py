@@ -698,3 +698,67 @@ def test_helper_pointers_vs_reference_c(rtcd, ref):
     _as(HBDMSE, ref.svt_aom_highbd_8_mse16x16_c)((a16.ctypes.data + 4) >> 1, 30, (b16.ctypes.data + 66) >> 1, 30, C.byref(se))
     rtcd.svt_aom_highbd_8_mse16x16((a16.ctypes.data + 4) >> 1, 30, (b16.ctypes.data + 66) >> 1, 30, C.byref(sg))
     assert se.value == sg.value and se.value > 0
+
+
+def test_helper_list_forms_with_many_units(hip, ref):
+    """The list forms behind the helpers (one launch over n units): block means, single-candidate SAD ladders, the N2 / N4 re-pack — each unit against the
+    reference's `*_c` function."""
+    rng = np.random.default_rng(99)
+    L = hip.L
+    img = rng.integers(0, 256, (96, 160)).astype(np.uint8)
+    offs = np.array([y * 160 + x for y in range(0, 88, 8) for x in range(0, 152, 8)], np.int32)
+    d_img, d_off = hip.to_device(img), hip.to_device(offs)
+    for mode, (w, h) in ((0, (8, 8)), (0, (8, 4)), (1, (8, 8))):
+        d_out = hip.empty(8 * len(offs))
+        hip.check(L.svt_hip_block_mean_batch_dev(hip.h, d_img, 160, d_off, len(offs), mode, w, h, d_out), "block mean")
+        got = hip.to_host(d_out, (len(offs),), np.uint64)
+        exp = [(_as(MSQ8, ref.svt_compute_mean_squared_values_c)(_vp(img, int(o)), 160, w, h) if mode == 0 else _as(SUBMEAN, ref.svt_compute_sub_mean_8x8_c)(_vp(img, int(o)), 160))
+               for o in offs]
+        assert np.array_equal(got, np.array(exp, np.uint64)), ("block mean list", mode, w, h)
+        hip.free(d_out)
+    # --- every 16x16 block of a 64x64 SB at 7 candidates, 2 SBs, both SAD flavours: 2 * 16 jobs per launch, running bests carried on the device
+    src = rng.integers(0, 256, (64, 140)).astype(np.uint8)
+    refp = np.clip(np.pad(src, ((0, 0), (3, 9)), mode="edge").astype(np.int32) + rng.integers(-4, 5, (64, 152)), 0, 255).astype(np.uint8)
+    d_src, d_ref = hip.to_device(src), hip.to_device(refp)
+    for sub in (0, 1):
+        n = 32
+        state = np.zeros((n, 15), np.uint32); state[:, :5] = 0xffffffff
+        exp = state.copy()
+        d_state = hip.to_device(state)
+        for cand in (5, 3, 4, 3, 0, 6, 2):
+            mv = ((9 & 0xffff) << 16) | ((4 * cand) & 0xffff)
+            jobs = np.zeros((n, 4), np.int32)
+            for j in range(n):
+                sb, blk = j // 16, j % 16
+                by, bx = 16 * (blk // 4), 64 * sb + 16 * (blk % 4)
+                jobs[j] = (by * 140 + bx, by * 152 + bx + cand, mv, sub)
+                e = exp[j]
+                _as(EXT16, ref.svt_ext_sad_calculation_8x8_16x16_c)(_vp(src, by * 140 + bx), 140, _vp(refp, by * 152 + bx + cand), 152, _vp(e, 0), _vp(e, 16), _vp(e, 20), _vp(e, 36), mv,
+                                                                   _vp(e, 40), _vp(e, 44), sub)
+            d_jobs = hip.to_device(jobs)
+            hip.check(L.svt_hip_ext_sad_16x16_batch_dev(hip.h, d_src, 140, d_ref, 152, d_jobs, n, d_state), "ext sad 16x16 list")
+            hip.free(d_jobs)
+            got = hip.to_host(d_state, (n, 15), np.uint32)
+            assert np.array_equal(got, exp), ("single-candidate ladder list", sub, cand)
+        # 32x32 / 64x64 from the 16x16 SADs of the last candidate, 2 jobs
+        st2 = np.zeros((2, 30), np.uint32); st2[:, 16:21] = 0xffffffff
+        for sb in range(2): st2[sb, :16] = got[16 * sb:16 * sb + 16, 10]
+        exp2 = st2.copy()
+        mvs = np.array([mv, mv ^ 0x40004], np.uint32)
+        for sb in range(2):
+            e = exp2[sb]
+            _as(EXT3264, ref.svt_ext_sad_calculation_32x32_64x64_c)(_vp(e, 0), _vp(e, 64), _vp(e, 80), _vp(e, 84), _vp(e, 100), int(mvs[sb]), _vp(e, 104))
+        d_st2, d_mv = hip.to_device(st2), hip.to_device(mvs)
+        hip.check(L.svt_hip_ext_sad_32x32_64x64_batch_dev(hip.h, d_st2, d_mv, 2), "ext sad 32 / 64 list")
+        assert np.array_equal(hip.to_host(d_st2, (2, 30), np.uint32), exp2), ("32x32 / 64x64 list", sub)
+        hip.free(d_state, d_st2, d_mv)
+    # --- N2 / N4 re-pack of 5 blocks per launch
+    for ts, name, n in ((4, "64x64", 4096), (12, "64x32", 2048), (18, "64x16", 1024), (11, "32x64", 2048), (17, "16x64", 1024)):
+        blocks = rng.integers(-(1 << 20), 1 << 20, (5, n)).astype(np.int32)
+        exp = blocks.copy()
+        for b in range(5): _as(HT64, getattr(ref, f"handle_transform{name}_N2_N4_c"))(_vp(exp, 4 * n * b))
+        d_b = hip.to_device(blocks)
+        hip.check(L.svt_hip_handle_transform64_n2n4_batch_dev(hip.h, ts, d_b, 5), "N2 / N4 re-pack list")
+        assert np.array_equal(hip.to_host(d_b, (5, n), np.int32), exp), ("N2 / N4 re-pack list", name)
+        hip.free(d_b)
+    hip.free(d_img, d_off, d_src, d_ref)
