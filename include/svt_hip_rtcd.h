@@ -129,6 +129,17 @@ typedef struct {
     int32_t eob;
 } SvtHipTxfmParam;
 typedef void (*SvtHipInvTxfmAddFn)(const int32_t *dqcoeff, uint8_t *dst_r, int32_t stride_r, uint8_t *dst_w, int32_t stride_w, const SvtHipTxfmParam *txfm_param);
+typedef void (*SvtHipConvert8To16Fn)(uint8_t *src, uint32_t src_stride, uint16_t *dst, uint32_t dst_stride, uint32_t width, uint32_t height);
+typedef void (*SvtHipConvert16To8Fn)(uint16_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t width, uint32_t height);
+typedef void (*SvtHipCPackFn)(const uint8_t *inn_bit_buffer, uint32_t inn_stride, uint8_t *in_compn_bit_buffer, uint32_t out_stride, uint8_t *local_cache,
+                              uint32_t width, uint32_t height);
+typedef void (*SvtHipPackMsbFn)(uint8_t *in8_bit_buffer, uint32_t in8_stride, uint8_t *inn_bit_buffer, uint16_t *out16_bit_buffer, uint32_t inn_stride,
+                                uint32_t out_stride, uint32_t width, uint32_t height);
+typedef void (*SvtHipUnpackAvgFn)(uint16_t *ref16_l0, uint32_t ref_l0_stride, uint16_t *ref16_l1, uint32_t ref_l1_stride, uint8_t *dst_ptr, uint32_t dst_stride,
+                                  uint32_t width, uint32_t height);
+typedef void (*SvtHipUnPack2dFn)(uint16_t *in16_bit_buffer, uint32_t in_stride, uint8_t *out8_bit_buffer, uint8_t *outn_bit_buffer, uint32_t out8_stride,
+                                 uint32_t outn_stride, uint32_t width, uint32_t height);
+typedef void (*SvtHipUnPack8Fn)(uint16_t *in16_bit_buffer, uint32_t in_stride, uint8_t *out8_bit_buffer, uint32_t out8_stride, uint32_t width, uint32_t height);
 typedef void (*SvtHipHbdMseFn)(const uint8_t *src_ptr, int32_t source_stride, const uint8_t *ref_ptr, int32_t recon_stride, uint32_t *sse);
 typedef void (*SvtHipSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
                                       const uint8_t *pred_ptr, ptrdiff_t pred_stride);
@@ -253,6 +264,14 @@ typedef struct SvtHipRtcd {
     SvtHipHandleTransformFn handle_transform64_N2_N4[5];       /* aom_dsp_rtcd.h:237-245 in header order: 16x64, 32x64, 64x16, 64x32, 64x64 */
     SvtHipVarWxHFn         svt_aom_mse16x16;                   /* :248 (EbPsnr.c:84) */
     SvtHipHbdMseFn         svt_aom_highbd_8_mse16x16;          /* :264 (uint8_t* = CONVERT_TO_BYTEPTR(uint16_t*)) */
+    /* --- the picture formats either side of the high-bit-depth path (Common/C_DEFAULT/EbPackUnPack_C.c; svt_hip_picture_format_dev) */
+    SvtHipConvert8To16Fn   svt_convert_8bit_to_16bit;
+    SvtHipConvert16To8Fn   svt_convert_16bit_to_8bit;
+    SvtHipCPackFn          svt_c_pack;                         /* local_cache is not used */
+    SvtHipPackMsbFn        svt_compressed_packmsb, svt_pack2d_16_bit_src_mul4;   /* = svt_enc_msb_pack2_d */
+    SvtHipUnpackAvgFn      svt_unpack_avg;
+    SvtHipUnPack2dFn       svt_un_pack2d_16_bit_src_mul4;      /* = svt_enc_msb_un_pack2_d */
+    SvtHipUnPack8Fn        svt_un_pack8_bit_data;
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

@@ -992,6 +992,58 @@ void mse16x16_hbd8_hip(const uint8_t* a8, int32_t as, const uint8_t* b8, int32_t
     FALLBACK("svt_aom_highbd_8_mse16x16", svt_aom_highbd_8_mse16x16, a8, as, b8, bs, sse);
 }
 
+// ----------------------------------------------------------------------------------- picture formats (svt_hip_picture_format_dev, one rectangle)
+// in / out planes: pointer, stride and width in BYTES per row as the host sees them, and the stride the device call takes (samples of that plane)
+struct FmtPlane { const void* h; size_t hpitch, wbytes; int dev_stride_div; };
+bool format_generic(int mode, const FmtPlane& i0, const FmtPlane& i1, void* o0, size_t o0pitch, size_t o0w, int o0div, void* o1, size_t o1pitch, size_t o1w, int w, int h) {
+    if (!g_ctx || w < 1 || h < 1) return false;
+    const size_t p0 = rup(i0.wbytes, 4), p1 = i1.h ? rup(i1.wbytes, 4) : 0, q0 = rup(o0w, 4), q1 = o1 ? rup(o1w, 4) : 0;
+    uint8_t *d_i0 = (uint8_t*)dev(0, p0 * h), *d_i1 = i1.h ? (uint8_t*)dev(1, p1 * h) : nullptr, *d_o0 = (uint8_t*)dev(4, q0 * h), *d_o1 = o1 ? (uint8_t*)dev(5, q1 * h) : nullptr;
+    return d_i0 && (!i1.h || d_i1) && d_o0 && (!o1 || d_o1) && up2d(d_i0, p0, i0.h, i0.hpitch, i0.wbytes, h) && (!i1.h || up2d(d_i1, p1, i1.h, i1.hpitch, i1.wbytes, h)) &&
+           svt_hip_picture_format_dev(g_ctx, mode, d_i0, (int)(p0 / i0.dev_stride_div), d_i1, i1.h ? (int)(p1 / i1.dev_stride_div) : 0, d_o0, (int)(q0 / o0div), d_o1, (int)q1, w, h) == 0 &&
+           down2d(o0, o0pitch, d_o0, q0, o0w, h) && (!o1 || down2d(o1, o1pitch, d_o1, q1, o1w, h));
+}
+void convert_8_to_16_hip(uint8_t* src, uint32_t ss, uint16_t* dst, uint32_t ds, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(3, {src, ss, w, 1}, {nullptr, 0, 0, 1}, dst, (size_t)ds * 2, (size_t)w * 2, 2, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_convert_8bit_to_16bit", svt_convert_8bit_to_16bit, src, ss, dst, ds, w, h);
+}
+void convert_16_to_8_hip(uint16_t* src, uint32_t ss, uint8_t* dst, uint32_t ds, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(4, {src, (size_t)ss * 2, (size_t)w * 2, 2}, {nullptr, 0, 0, 1}, dst, ds, w, 1, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_convert_16bit_to_8bit", svt_convert_16bit_to_8bit, src, ss, dst, ds, w, h);
+}
+void c_pack_hip(const uint8_t* inn, uint32_t is, uint8_t* out, uint32_t os, uint8_t* cache, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (!(w & 3) && format_generic(5, {inn, is, w, 1}, {nullptr, 0, 0, 1}, out, os, w / 4, 1, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_c_pack", svt_c_pack, inn, is, out, os, cache, w, h);
+}
+void compressed_packmsb_hip(uint8_t* in8, uint32_t s8, uint8_t* inn, uint16_t* out, uint32_t sn, uint32_t os, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (!(w & 3) && format_generic(1, {in8, s8, w, 1}, {inn, sn, w / 4, 1}, out, (size_t)os * 2, (size_t)w * 2, 2, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_compressed_packmsb", svt_compressed_packmsb, in8, s8, inn, out, sn, os, w, h);
+}
+void pack2d_hip(uint8_t* in8, uint32_t s8, uint8_t* inn, uint16_t* out, uint32_t sn, uint32_t os, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(0, {in8, s8, w, 1}, {inn, sn, w, 1}, out, (size_t)os * 2, (size_t)w * 2, 2, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_pack2d_16_bit_src_mul4", svt_pack2d_16_bit_src_mul4, in8, s8, inn, out, sn, os, w, h);
+}
+void unpack_avg_hip(uint16_t* l0, uint32_t s0, uint16_t* l1, uint32_t s1, uint8_t* dst, uint32_t ds, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(6, {l0, (size_t)s0 * 2, (size_t)w * 2, 2}, {l1, (size_t)s1 * 2, (size_t)w * 2, 2}, dst, ds, w, 1, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_unpack_avg", svt_unpack_avg, l0, s0, l1, s1, dst, ds, w, h);
+}
+void un_pack2d_hip(uint16_t* in, uint32_t is, uint8_t* o8, uint8_t* on, uint32_t s8, uint32_t sn, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(2, {in, (size_t)is * 2, (size_t)w * 2, 2}, {nullptr, 0, 0, 1}, o8, s8, w, 1, on, sn, w, (int)w, (int)h)) return;
+    FALLBACK("svt_un_pack2d_16_bit_src_mul4", svt_un_pack2d_16_bit_src_mul4, in, is, o8, on, s8, sn, w, h);
+}
+void un_pack8_hip(uint16_t* in, uint32_t is, uint8_t* o8, uint32_t s8, uint32_t w, uint32_t h) {
+    Guard lk;
+    if (format_generic(2, {in, (size_t)is * 2, (size_t)w * 2, 2}, {nullptr, 0, 0, 1}, o8, s8, w, 1, nullptr, 0, 0, (int)w, (int)h)) return;
+    FALLBACK("svt_un_pack8_bit_data", svt_un_pack8_bit_data, in, is, o8, s8, w, h);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -1060,5 +1112,8 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->handle_transform64_N2_N4[2] = handle_transform_n2n4_hip<2, 18>; t->handle_transform64_N2_N4[3] = handle_transform_n2n4_hip<3, 12>;
     t->handle_transform64_N2_N4[4] = handle_transform_n2n4_hip<4, 4>;
     t->svt_aom_mse16x16 = mse16x16_hip; t->svt_aom_highbd_8_mse16x16 = mse16x16_hbd8_hip;
+    t->svt_convert_8bit_to_16bit = convert_8_to_16_hip; t->svt_convert_16bit_to_8bit = convert_16_to_8_hip; t->svt_c_pack = c_pack_hip;
+    t->svt_compressed_packmsb = compressed_packmsb_hip; t->svt_pack2d_16_bit_src_mul4 = pack2d_hip; t->svt_unpack_avg = unpack_avg_hip;
+    t->svt_un_pack2d_16_bit_src_mul4 = un_pack2d_hip; t->svt_un_pack8_bit_data = un_pack8_hip;
     return SVT_HIP_OK;
 }

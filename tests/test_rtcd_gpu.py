@@ -102,6 +102,12 @@ SUBMEAN = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint16)
 CONV8 = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
 WIENER = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams))
 HBDMSE = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, VP)
+CVT = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+CPACK = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32)
+PACKMSB = C.CFUNCTYPE(None, VP, C.c_uint32, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+UNPAVG = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
+UNPACK2D = C.CFUNCTYPE(None, VP, C.c_uint32, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+UNPACK8 = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
 WIENERH = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams), C.c_int32)
 
 
@@ -134,7 +140,9 @@ class Rtcd(C.Structure):
                 ("svt_av1_highbd_pixel_proj_error", PROJERR), ("svt_compute_mean_square_values_8x8", MSQ8), ("svt_compute_sub_mean_8x8", SUBMEAN),
                 ("svt_aom_convolve8_horiz", CONV8), ("svt_aom_convolve8_vert", CONV8), ("svt_av1_wiener_convolve_add_src", WIENER),
                 ("svt_av1_highbd_wiener_convolve_add_src", WIENERH), ("handle_transform64_N2_N4", HT64 * 5), ("svt_aom_mse16x16", VARWH),
-                ("svt_aom_highbd_8_mse16x16", HBDMSE)]
+                ("svt_aom_highbd_8_mse16x16", HBDMSE), ("svt_convert_8bit_to_16bit", CVT), ("svt_convert_16bit_to_8bit", CVT), ("svt_c_pack", CPACK),
+                ("svt_compressed_packmsb", PACKMSB), ("svt_pack2d_16_bit_src_mul4", PACKMSB), ("svt_unpack_avg", UNPAVG), ("svt_un_pack2d_16_bit_src_mul4", UNPACK2D),
+                ("svt_un_pack8_bit_data", UNPACK8)]
 
 
 @pytest.fixture(scope="module")
@@ -762,3 +770,38 @@ def test_helper_list_forms_with_many_units(hip, ref):
         assert np.array_equal(hip.to_host(d_b, (5, n), np.int32), exp), ("N2 / N4 re-pack list", name)
         hip.free(d_b)
     hip.free(d_img, d_off, d_src, d_ref)
+
+
+def test_format_pointers_vs_reference_c(rtcd, ref):
+    """The picture-format conversions either side of the high-bit-depth path (Common/C_DEFAULT/EbPackUnPack_C.c) through their per-call pointers."""
+    rng = np.random.default_rng(31)
+    for (w, h) in ((64, 9), (36, 5), (128, 64), (8, 3)):
+        a8 = rng.integers(0, 256, (h, w + 5)).astype(np.uint8); a16 = rng.integers(0, 1024, (h, w + 7)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 3)).astype(np.uint16)
+        nbit = (rng.integers(0, 4, (h, w + 2)) << 6).astype(np.uint8)           # one byte per sample, the two bits on top
+        packed = rng.integers(0, 256, (h, w // 4 + 3)).astype(np.uint8)         # four samples per byte
+        e = np.full((h, w + 4), 999, np.uint16); g = e.copy()
+        _as(CVT, ref.svt_convert_8bit_to_16bit_c)(_vp(a8), w + 5, _vp(e), w + 4, w, h); rtcd.svt_convert_8bit_to_16bit(_vp(a8), w + 5, _vp(g), w + 4, w, h)
+        assert np.array_equal(e, g), ("8 -> 16", w, h)
+        e8 = np.full((h, w + 6), 99, np.uint8); g8 = e8.copy()
+        _as(CVT, ref.svt_convert_16bit_to_8bit_c)(_vp(a16), w + 7, _vp(e8), w + 6, w, h); rtcd.svt_convert_16bit_to_8bit(_vp(a16), w + 7, _vp(g8), w + 6, w, h)
+        assert np.array_equal(e8, g8), ("16 -> 8", w, h)
+        e[:] = 999; g[:] = 999
+        _as(PACKMSB, ref.svt_enc_msb_pack2_d)(_vp(a8), w + 5, _vp(nbit), _vp(e), w + 2, w + 4, w, h); rtcd.svt_pack2d_16_bit_src_mul4(_vp(a8), w + 5, _vp(nbit), _vp(g), w + 2, w + 4, w, h)
+        assert np.array_equal(e, g), ("pack2d", w, h)
+        e[:] = 999; g[:] = 999
+        _as(PACKMSB, ref.svt_compressed_packmsb_c)(_vp(a8), w + 5, _vp(packed), _vp(e), w // 4 + 3, w + 4, w, h); rtcd.svt_compressed_packmsb(_vp(a8), w + 5, _vp(packed), _vp(g), w // 4 + 3, w + 4, w, h)
+        assert np.array_equal(e, g), ("compressed_packmsb", w, h)
+        ep = np.full((h, w // 4 + 2), 77, np.uint8); gp = ep.copy(); cache = np.zeros(256, np.uint8)
+        _as(CPACK, ref.svt_c_pack_c)(_vp(nbit), w + 2, _vp(ep), w // 4 + 2, _vp(cache), w, h); rtcd.svt_c_pack(_vp(nbit), w + 2, _vp(gp), w // 4 + 2, _vp(cache), w, h)
+        assert np.array_equal(ep, gp), ("c_pack", w, h)
+        e8[:] = 99; g8[:] = 99
+        _as(UNPAVG, ref.svt_unpack_avg_c)(_vp(a16), w + 7, _vp(b16), w + 3, _vp(e8), w + 6, w, h); rtcd.svt_unpack_avg(_vp(a16), w + 7, _vp(b16), w + 3, _vp(g8), w + 6, w, h)
+        assert np.array_equal(e8, g8), ("unpack_avg", w, h)
+        for with_n in (True, False):
+            e8[:] = 99; g8[:] = 99; en = np.full((h, w + 1), 55, np.uint8); gn = en.copy()
+            _as(UNPACK2D, ref.svt_enc_msb_un_pack2_d)(_vp(a16), w + 7, _vp(e8), _vp(en) if with_n else None, w + 6, w + 1, w, h)
+            rtcd.svt_un_pack2d_16_bit_src_mul4(_vp(a16), w + 7, _vp(g8), _vp(gn) if with_n else None, w + 6, w + 1, w, h)
+            assert np.array_equal(e8, g8) and np.array_equal(en, gn), ("un_pack2d", w, h, with_n)
+        e8[:] = 99; g8[:] = 99
+        _as(UNPACK8, ref.svt_un_pack8_bit_data_c)(_vp(a16), w + 7, _vp(e8), w + 6, w, h); rtcd.svt_un_pack8_bit_data(_vp(a16), w + 7, _vp(g8), w + 6, w, h)
+        assert np.array_equal(e8, g8), ("un_pack8", w, h)
