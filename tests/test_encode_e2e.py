@@ -180,3 +180,21 @@ def test_helper_pointers_in_a_real_encode_on_gpu(workdir):
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
     print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
+
+
+@pytest.mark.gpu
+def test_high_bit_depth_pointers_in_a_real_encode_on_gpu(workdir):
+    """The 16-bit flavours and the picture-format conversions behind SVT_HIP_RTCD in a 10-bit encode."""
+    w, h, n, bd, preset, q = 176, 144, 2, 10, 6, 32
+    clip = os.path.join(workdir, "qcif10.yuv")
+    E.make_clip(clip, w, h, n, seed=11, bd=bd)
+    names = ("svt_compressed_packmsb,svt_c_pack,svt_convert_8bit_to_16bit,svt_convert_16bit_to_8bit,svt_pack2d_16_bit_src_mul4,svt_un_pack2d_16_bit_src_mul4,"
+             "svt_un_pack8_bit_data,svt_unpack_avg,svt_aom_highbd_subtract_block,svt_full_distortion_kernel16_bits,svt_aom_highbd_8_mse16x16,"
+             "svt_av1_highbd_wiener_convolve_add_src,svt_av1_highbd_pixel_proj_error,variance_highbd,sad_16b_kernel,svt_compute_cdef_dist_16bit,"
+             "svt_residual_kernel16bit,svt_aom_highbd_quantize_b,svt_av1_highbd_quantize_fp,svt_get_proj_subspace,svt_aom_highbd_sse")
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10.ref"))
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1500)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    for nme in names.split(","):
+        assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
+    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
