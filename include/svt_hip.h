@@ -640,6 +640,14 @@ int svt_hip_handle_transform64_n2n4_batch_dev(SvtHipCtx *ctx, int tx_size, int32
  * Output is packed (stride = w) at dst_off. */
 typedef struct { int32_t ref_off, dst_off; uint8_t w, h, subpel_x_q3, subpel_y_q3, bank, reserved[3]; } SvtHipUpsampledBlk;
 int svt_hip_upsampled_pred_batch_dev(SvtHipCtx *ctx, const uint8_t *d_ref, int ref_stride, uint8_t *d_dst, const SvtHipUpsampledBlk *d_blks, int n);
+/* ONE reference of a compound prediction, the form the reference's pointers have: svt_av1_[highbd_]jnt_convolve_{2d, x, y, 2d_copy} (variant 0..3;
+ * common_dsp_rtcd.h:211-243; Common/Codec/EbInterPrediction.c:552-741, :868-1143).  do_average = 0: the 16-bit result goes to d_convbuf
+ * (ConvolveParams::dst), d_dst is not touched; do_average = 1: it is combined with d_convbuf (plain average, or fwd_offset / bck_offset when
+ * use_jnt_comp_avg) and written to d_dst as pixels.  d_taps[16] = the horizontal and the vertical 8-tap kernel of the block's phases; d_src needs 3
+ * samples of context before and 4 after in the filtered directions.  (svt_hip_compound_predict_batch_dev is the fused two-reference form.) */
+int svt_hip_jnt_convolve_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int variant, const void *d_src, int src_stride, void *d_dst, int dst_stride,
+                             uint16_t *d_convbuf, int convbuf_stride, const int16_t *d_taps, int w, int h, int round_0, int round_1, int do_average,
+                             int use_jnt_comp_avg, int fwd_offset, int bck_offset);
 /* svt_compute_mean_square_values_8x8 (aom_dsp_rtcd.h; EbPictureAnalysisProcess.c:287: mode 0, (sum of squares << 16) / (w * h) over a w x h
  * area) and svt_compute_sub_mean_8x8 (:310: mode 1, rows 0 / 2 / 4 / 6 of an 8x8 block, sum << 3) for a list of block offsets. */
 int svt_hip_block_mean_batch_dev(SvtHipCtx *ctx, const uint8_t *d_plane, int stride, const int32_t *d_offs, int n, int mode, int w, int h,

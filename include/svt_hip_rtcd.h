@@ -272,6 +272,9 @@ typedef struct SvtHipRtcd {
     SvtHipUnpackAvgFn      svt_unpack_avg;
     SvtHipUnPack2dFn       svt_un_pack2d_16_bit_src_mul4;      /* = svt_enc_msb_un_pack2_d */
     SvtHipUnPack8Fn        svt_un_pack8_bit_data;
+    /* --- one reference of a compound prediction (common_dsp_rtcd.h:211-243): do_average = 0 writes ConvolveParams::dst, 1 averages with it */
+    SvtHipConvolveSrFn     svt_av1_jnt_convolve_2d, svt_av1_jnt_convolve_x, svt_av1_jnt_convolve_y, svt_av1_jnt_convolve_2d_copy;
+    SvtHipHbdConvolveSrFn  svt_av1_highbd_jnt_convolve_2d, svt_av1_highbd_jnt_convolve_x, svt_av1_highbd_jnt_convolve_y, svt_av1_highbd_jnt_convolve_2d_copy;
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

@@ -80,7 +80,9 @@ void svt_hip_hooks_report(void) {
     X(svt_compute_mean_square_values_8x8) X(svt_compute_sub_mean_8x8) X(svt_aom_convolve8_horiz) X(svt_aom_convolve8_vert)                  \
     X(svt_av1_wiener_convolve_add_src) X(svt_av1_highbd_wiener_convolve_add_src) X(svt_aom_mse16x16) X(svt_aom_highbd_8_mse16x16) \
     X(svt_convert_8bit_to_16bit) X(svt_convert_16bit_to_8bit) X(svt_c_pack) X(svt_compressed_packmsb) X(svt_pack2d_16_bit_src_mul4) X(svt_unpack_avg)   \
-    X(svt_un_pack2d_16_bit_src_mul4) X(svt_un_pack8_bit_data)
+    X(svt_un_pack2d_16_bit_src_mul4) X(svt_un_pack8_bit_data)                                                                              \
+    X(svt_av1_jnt_convolve_2d) X(svt_av1_jnt_convolve_x) X(svt_av1_jnt_convolve_y) X(svt_av1_jnt_convolve_2d_copy)                          \
+    X(svt_av1_highbd_jnt_convolve_2d) X(svt_av1_highbd_jnt_convolve_x) X(svt_av1_highbd_jnt_convolve_y) X(svt_av1_highbd_jnt_convolve_2d_copy)
 /* array members <-> the reference's individually named pointers */
 #define RTCD_INDEXED(X)                                                                                                                      \
     X(svt_aom_lpf_horizontal, 0, svt_aom_lpf_horizontal_4) X(svt_aom_lpf_horizontal, 1, svt_aom_lpf_horizontal_6)                           \

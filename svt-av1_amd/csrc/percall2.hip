@@ -11,6 +11,7 @@
 //   convolve8             Common/Codec/convolve.c:249-307                    svt_aom_convolve8_horiz_c / _vert_c
 //   wiener_convolve       Common/Codec/convolve.c:57-242                     svt_av1_[highbd_]wiener_convolve_add_src_c
 //   repack64              Encoder/Codec/EbTransforms.c:2933-2969             handle_transform*_N2_N4_c
+//   jnt_convolve          Common/Codec/EbInterPrediction.c:552-741, :868-1143  svt_av1_[highbd_]jnt_convolve_{2d,x,y,2d_copy}_c
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
@@ -283,8 +284,60 @@ repack64_kernel(int32_t* __restrict__ coeff, int rows, int per_block) {
     if (r < rows) c[r * 32 + x] = v;
 }
 
+// ------------------------------------------------------------------------------------------------ one reference of a compound prediction
+// variant 0 = 2d, 1 = x, 2 = y, 3 = 2d_copy.  do_average = 0: the 16-bit result goes to the compound buffer; 1: it is combined with the buffer
+// (plain or distance-weighted average) and written to dst as pixels.  taps[0..7] horizontal, taps[8..15] vertical kernel.
+struct JntArgs { int variant, w, h, round0, round1, do_average, use_jnt, fwd, bck, bd; };
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+jnt_convolve_kernel(const PIX* __restrict__ src, int ss, PIX* __restrict__ dst, int ds, uint16_t* __restrict__ cb, int cbs, const int16_t* __restrict__ taps, JntArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.w || y >= a.h) return;
+    const int16_t *fx = taps, *fy = taps + 8;
+    const int      offset_bits = a.bd + 14 - a.round0, round_offset = (1 << (offset_bits - a.round1)) + (1 << (offset_bits - a.round1 - 1));
+    const int      round_bits = 14 - a.round0 - a.round1;
+    int            res;
+    if (a.variant == 0) {
+        int sum = 1 << offset_bits;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const PIX* row = src + (ptrdiff_t)(y + k - 3) * ss + x - 3;
+            int        hs = 1 << (a.bd + 6);
+#pragma unroll
+            for (int t = 0; t < 8; t++) hs += fx[t] * (int)row[t];
+            sum += fy[k] * (int)(int16_t)((hs + ((1 << a.round0) >> 1)) >> a.round0);
+        }
+        res = (int)(uint16_t)((sum + ((1 << a.round1) >> 1)) >> a.round1);
+    } else if (a.variant == 1) {
+        int hs = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) hs += fx[t] * (int)src[(ptrdiff_t)y * ss + x - 3 + t];
+        res = (1 << (7 - a.round1)) * ((hs + ((1 << a.round0) >> 1)) >> a.round0) + round_offset;
+    } else if (a.variant == 2) {
+        int vs = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) vs += fy[k] * (int)src[(ptrdiff_t)(y + k - 3) * ss + x];
+        vs *= 1 << (7 - a.round0);
+        res = ((vs + ((1 << a.round1) >> 1)) >> a.round1) + round_offset;
+    } else
+        res = (int)(uint16_t)(((int)src[(ptrdiff_t)y * ss + x] << round_bits) + round_offset);
+    if (!a.do_average) { cb[(size_t)y * cbs + x] = (uint16_t)res; return; }
+    int tmp = cb[(size_t)y * cbs + x];
+    tmp = a.use_jnt ? (tmp * a.fwd + res * a.bck) >> 4 : (tmp + res) >> 1;
+    tmp -= round_offset;
+    dst[(size_t)y * ds + x] = (PIX)clip_px((tmp + ((1 << round_bits) >> 1)) >> round_bits, a.bd);
+}
+
 }  // namespace
 
+extern "C" int svt_hip_launch_jnt_convolve(hipStream_t st, int pix_bytes, int bd, int variant, const void* src, int ss, void* dst, int ds, uint16_t* cb, int cbs,
+                                           const int16_t* taps, int w, int h, int round0, int round1, int do_average, int use_jnt, int fwd, int bck) {
+    const dim3    grid((w + 63) / 64, (h + 3) / 4);
+    const JntArgs a = {variant, w, h, round0, round1, do_average, use_jnt, fwd, bck, pix_bytes == 1 ? 8 : bd};
+    if (pix_bytes == 1) hipLaunchKernelGGL(jnt_convolve_kernel<uint8_t>, grid, dim3(256), 0, st, (const uint8_t*)src, ss, (uint8_t*)dst, ds, cb, cbs, taps, a);
+    else hipLaunchKernelGGL(jnt_convolve_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, ss, (uint16_t*)dst, ds, cb, cbs, taps, a);
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_repack64(hipStream_t st, int32_t* coeff, int rows, int per_block, int nblk) {
     if (nblk <= 0) return 0;
     hipLaunchKernelGGL(repack64_kernel, dim3(nblk), dim3(1024), 0, st, coeff, rows, per_block);

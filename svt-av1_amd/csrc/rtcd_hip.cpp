@@ -1044,6 +1044,43 @@ void un_pack8_hip(uint16_t* in, uint32_t is, uint8_t* o8, uint32_t s8, uint32_t 
     FALLBACK("svt_un_pack8_bit_data", svt_un_pack8_bit_data, in, is, o8, s8, w, h);
 }
 
+// ----------------------------------------------------------------------------------- one reference of a compound prediction
+// variant 0 = 2d, 1 = x, 2 = y, 3 = 2d_copy.  The compound buffer (ConvolveParams::dst) travels both ways: written when do_average = 0, read otherwise.
+bool jnt_generic(int pb, int bd, int variant, const void* src, int ss, void* dst, int ds, int w, int h, const SvtHipInterpFilterParams* fx, const SvtHipInterpFilterParams* fy, int sx,
+                 int sy, const SvtHipConvolveParams* cp) {
+    if (!g_ctx || !cp || !cp->dst || w < 1 || h < 1 || w > 128 || h > 128 || !fx || !fy || !fx->filter_ptr || !fy->filter_ptr || fx->taps != 8 || fy->taps != 8) return false;
+    const bool   fh = variant == 0 || variant == 1, fv = variant == 0 || variant == 2;
+    const int    cw = w + (fh ? 7 : 0), ch = h + (fv ? 7 : 0), ox = fh ? 3 : 0, oy = fv ? 3 : 0;
+    const size_t ip = rup((size_t)cw * pb, 4), op = rup((size_t)w * pb, 4), cp_pitch = (size_t)w * 2;
+    uint8_t *d_i = (uint8_t*)dev(0, ip * ch + 64), *d_o = (uint8_t*)dev(1, op * h); uint16_t* d_cb = (uint16_t*)dev(4, cp_pitch * h); int16_t* d_t = (int16_t*)dev(2, 32);
+    int16_t taps[16];
+    std::memcpy(taps, fx->filter_ptr + 8 * (sx & 15), 16); std::memcpy(taps + 8, fy->filter_ptr + 8 * (sy & 15), 16);
+    const uint8_t* s0 = (const uint8_t*)src - ((size_t)oy * ss + ox) * pb;
+    if (!(d_i && d_o && d_cb && d_t && up2d(d_i, ip, s0, (size_t)ss * pb, (size_t)cw * pb, ch) && up(d_t, taps, 32))) return false;
+    if (cp->do_average && !up2d(d_cb, cp_pitch, cp->dst, (size_t)cp->dst_stride * 2, (size_t)w * 2, h)) return false;
+    if (svt_hip_jnt_convolve_dev(g_ctx, pb, bd, variant, d_i + oy * ip + (size_t)ox * pb, (int)(ip / pb), d_o, (int)(op / pb), d_cb, w, d_t, w, h, cp->round_0, cp->round_1,
+                                 cp->do_average, cp->use_jnt_comp_avg, cp->fwd_offset, cp->bck_offset) != 0)
+        return false;
+    return cp->do_average ? down2d(dst, (size_t)ds * pb, d_o, op, (size_t)w * pb, h) : down2d(cp->dst, (size_t)cp->dst_stride * 2, d_cb, cp_pitch, (size_t)w * 2, h);
+}
+#define JNT_WRAPPER(NAME, MEMBER, VARIANT)                                                                                                            \
+    void NAME(const uint8_t* src, int32_t ss, uint8_t* dst, int32_t ds, int32_t w, int32_t h, SvtHipInterpFilterParams* fx, SvtHipInterpFilterParams* fy, \
+              const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp) {                                                                         \
+        Guard lk;                                                                                                                                     \
+        if (jnt_generic(1, 8, VARIANT, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp)) return;                                                          \
+        FALLBACK("svt_av1_" #MEMBER, svt_av1_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp);                                                 \
+    }                                                                                                                                                 \
+    void NAME##_hbd(const uint16_t* src, int32_t ss, uint16_t* dst, int32_t ds, int32_t w, int32_t h, const SvtHipInterpFilterParams* fx,              \
+                    const SvtHipInterpFilterParams* fy, const int32_t sx, const int32_t sy, SvtHipConvolveParams* cp, int32_t bd) {                   \
+        Guard lk;                                                                                                                                     \
+        if (bd >= 8 && bd <= 12 && jnt_generic(2, bd, VARIANT, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp)) return;                                  \
+        FALLBACK("highbd " #MEMBER, svt_av1_highbd_##MEMBER, src, ss, dst, ds, w, h, fx, fy, sx, sy, cp, bd);                                       \
+    }
+JNT_WRAPPER(jnt_2d_hip, jnt_convolve_2d, 0)
+JNT_WRAPPER(jnt_x_hip, jnt_convolve_x, 1)
+JNT_WRAPPER(jnt_y_hip, jnt_convolve_y, 2)
+JNT_WRAPPER(jnt_copy_hip, jnt_convolve_2d_copy, 3)
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -1115,5 +1152,8 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_convert_8bit_to_16bit = convert_8_to_16_hip; t->svt_convert_16bit_to_8bit = convert_16_to_8_hip; t->svt_c_pack = c_pack_hip;
     t->svt_compressed_packmsb = compressed_packmsb_hip; t->svt_pack2d_16_bit_src_mul4 = pack2d_hip; t->svt_unpack_avg = unpack_avg_hip;
     t->svt_un_pack2d_16_bit_src_mul4 = un_pack2d_hip; t->svt_un_pack8_bit_data = un_pack8_hip;
+    t->svt_av1_jnt_convolve_2d = jnt_2d_hip; t->svt_av1_jnt_convolve_x = jnt_x_hip; t->svt_av1_jnt_convolve_y = jnt_y_hip; t->svt_av1_jnt_convolve_2d_copy = jnt_copy_hip;
+    t->svt_av1_highbd_jnt_convolve_2d = jnt_2d_hip_hbd; t->svt_av1_highbd_jnt_convolve_x = jnt_x_hip_hbd; t->svt_av1_highbd_jnt_convolve_y = jnt_y_hip_hbd;
+    t->svt_av1_highbd_jnt_convolve_2d_copy = jnt_copy_hip_hbd;
     return SVT_HIP_OK;
 }

@@ -978,6 +978,18 @@ int svt_hip_handle_transform64_n2n4_batch_dev(SvtHipCtx* c, int tx_size, int32_t
     if (e != hipSuccess) return fail(c, e, "handle transform64 N2 / N4 launch");
     return SVT_HIP_OK;
 }
+int svt_hip_jnt_convolve_dev(SvtHipCtx* c, int pix_bytes, int bd, int variant, const void* d_src, int src_stride, void* d_dst, int dst_stride, uint16_t* d_convbuf,
+                             int convbuf_stride, const int16_t* d_taps, int w, int h, int round_0, int round_1, int do_average, int use_jnt_comp_avg, int fwd_offset,
+                             int bck_offset) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_convbuf || !d_taps || (do_average && !d_dst) || w < 1 || h < 1 || variant < 0 || variant > 3 ||
+        !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd >= 8 && bd <= 12)) || round_0 < 3 || round_0 > 5 || round_1 < 1 || 14 - round_0 - round_1 < 0)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_jnt_convolve(c->stream, pix_bytes, bd, variant, d_src, src_stride, d_dst, dst_stride, d_convbuf, convbuf_stride, d_taps, w, h,
+                                                           round_0, round_1, do_average, use_jnt_comp_avg, fwd_offset, bck_offset);
+    if (e != hipSuccess) return fail(c, e, "jnt convolve launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_block_mean_batch_dev(SvtHipCtx* c, const uint8_t* d_plane, int stride, const int32_t* d_offs, int n, int mode, int w, int h, uint64_t* d_out) {
     SVT_HIP_ENTER(c);
     if (!c || !d_plane || !d_offs || !d_out || n < 0 || (mode != 0 && mode != 1) || (mode == 0 && (w < 1 || h < 1))) return SVT_HIP_ERR_BAD_ARG;

@@ -142,7 +142,10 @@ class Rtcd(C.Structure):
                 ("svt_av1_highbd_wiener_convolve_add_src", WIENERH), ("handle_transform64_N2_N4", HT64 * 5), ("svt_aom_mse16x16", VARWH),
                 ("svt_aom_highbd_8_mse16x16", HBDMSE), ("svt_convert_8bit_to_16bit", CVT), ("svt_convert_16bit_to_8bit", CVT), ("svt_c_pack", CPACK),
                 ("svt_compressed_packmsb", PACKMSB), ("svt_pack2d_16_bit_src_mul4", PACKMSB), ("svt_unpack_avg", UNPAVG), ("svt_un_pack2d_16_bit_src_mul4", UNPACK2D),
-                ("svt_un_pack8_bit_data", UNPACK8)]
+                ("svt_un_pack8_bit_data", UNPACK8),
+                ("svt_av1_jnt_convolve_2d", CONV), ("svt_av1_jnt_convolve_x", CONV), ("svt_av1_jnt_convolve_y", CONV), ("svt_av1_jnt_convolve_2d_copy", CONV),
+                ("svt_av1_highbd_jnt_convolve_2d", CONVH), ("svt_av1_highbd_jnt_convolve_x", CONVH), ("svt_av1_highbd_jnt_convolve_y", CONVH),
+                ("svt_av1_highbd_jnt_convolve_2d_copy", CONVH)]
 
 
 @pytest.fixture(scope="module")
@@ -805,3 +808,29 @@ def test_format_pointers_vs_reference_c(rtcd, ref):
         e8[:] = 99; g8[:] = 99
         _as(UNPACK8, ref.svt_un_pack8_bit_data_c)(_vp(a16), w + 7, _vp(e8), w + 6, w, h); rtcd.svt_un_pack8_bit_data(_vp(a16), w + 7, _vp(g8), w + 6, w, h)
         assert np.array_equal(e8, g8), ("un_pack8", w, h)
+
+
+def test_jnt_convolve_pointers_vs_reference_c(rtcd, ref, orc):
+    """One reference of a compound prediction through svt_av1_[highbd_]jnt_convolve_{2d, x, y, 2d_copy}: the first call fills the compound buffer
+    (do_average = 0), the second averages with it — plain and distance-weighted — like av1_make_inter_predictor drives them."""
+    rng = np.random.default_rng(8)
+    banks = np.ctypeslib.as_array((C.c_int16 * 8 * 16 * 6).in_dll(orc, "orc_interp_kernels")).copy()
+    for bd, dt in ((8, np.uint8), (10, np.uint16), (12, np.uint16)):
+        img0 = rng.integers(0, 1 << bd, (100, 120)).astype(dt); img1 = np.clip(img0.astype(np.int32) + rng.integers(-30, 31, img0.shape), 0, (1 << bd) - 1).astype(dt)
+        r0 = 5 if bd == 12 else 3
+        for (w, h, bx, by, sx, sy) in ((16, 16, 0, 0, 5, 11), (64, 32, 2, 1, 8, 3), (4, 8, 4, 5, 9, 14), (8, 4, 3, 3, 7, 7), (32, 64, 1, 0, 15, 1)):
+            fx = FilterParams(banks[bx].ctypes.data, 8, 16, bx % 4); fy = FilterParams(banks[by].ctypes.data, 8, 16, by % 4)
+            off = (12 * 120 + 14) * img0.itemsize
+            for name in ("2d", "x", "y", "2d_copy"):
+                for jnt, fwd, bck in ((0, 0, 0), (1, 9, 7), (1, 13, 3)):
+                    res = []
+                    for fn_ref, fn_hip in (((getattr(ref, f"svt_av1_jnt_convolve_{name}_c") if bd == 8 else getattr(ref, f"svt_av1_highbd_jnt_convolve_{name}_c")), None),
+                                           (None, getattr(rtcd, f"svt_av1_jnt_convolve_{name}" if bd == 8 else f"svt_av1_highbd_jnt_convolve_{name}"))):
+                        f = _as(CONV if bd == 8 else CONVH, fn_ref) if fn_ref is not None else fn_hip
+                        cb = np.full((h, w + 6), 4321, np.uint16); out = np.full((h, w + 3), 77, dt)
+                        extra = (bd,) if bd > 8 else ()
+                        for do_avg, img in ((0, img0), (1, img1)):
+                            cp = ConvParams(0, do_avg, cb.ctypes.data, w + 6, r0, 7, 0, 1, jnt, fwd, bck, jnt)
+                            f(img.ctypes.data + off, 120, out.ctypes.data, w + 3, w, h, C.byref(fx), C.byref(fy), sx, sy, C.byref(cp), *extra)
+                        res.append((cb, out))
+                    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), ("jnt convolve", bd, name, w, h, bx, by, sx, sy, jnt, fwd, bck)
