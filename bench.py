@@ -295,7 +295,9 @@ def main():
     E.ctx = E.pkg.Context(local_rank)
     E.L, E.mc, E.tc, E.workload = E.ctx.L, mc, tc, workload
     L, ctx = E.L, E.ctx
-    stream = torch.cuda.current_stream()
+    # the step runs on a stream of its own, not on the (legacy, implicitly synchronising) default stream: copies queued on other streams overlap it
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
     ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
     E.dev = dev = torch.device("cuda", local_rank)
     ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, args.me_waves))

@@ -52,3 +52,33 @@ def pipeline(n, xfer):
 b_ = b
 pipeline(4, True)
 print(f"pipeline without transfers {pipeline(20, False):.3f} ms, with {pipeline(20, True):.3f} ms per step")
+
+# the same pipeline with the step forked onto K streams and joined (bench.py's batch_step): does the copy overlap survive more streams than hardware queues?
+def forked_step(K):
+    base = torch.cuda.current_stream()
+    for k in range(K):
+        fs[k].wait_stream(base)
+        with torch.cuda.stream(fs[k]):
+            torch.matmul(a, b_)
+    for k in range(K): base.wait_stream(fs[k])
+fs = [torch.cuda.Stream() for _ in range(8)]
+def pipeline_forked(n, xfer, K):
+    for b in range(nb): comp_done[b].record(sk)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    if xfer: upload(0)
+    for i in range(n):
+        b = i % nb
+        if xfer:
+            sk.wait_event(up_done[b])
+            if i >= nb: sk.wait_event(down_done[b])
+        with torch.cuda.stream(sk):
+            forked_step(K)
+        comp_done[b].record(sk)
+        if xfer:
+            download(b)
+            if i + 1 < n: upload((i + 1) % nb)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+for K in (1, 2, 4, 8):
+    pipeline_forked(4, True, K)
+    print(f"forked onto {K} streams: without transfers {pipeline_forked(20, False, K):.3f} ms, with {pipeline_forked(20, True, K):.3f} ms per step")
