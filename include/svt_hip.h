@@ -648,6 +648,16 @@ int svt_hip_upsampled_pred_batch_dev(SvtHipCtx *ctx, const uint8_t *d_ref, int r
 int svt_hip_jnt_convolve_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int variant, const void *d_src, int src_stride, void *d_dst, int dst_stride,
                              uint16_t *d_convbuf, int convbuf_stride, const int16_t *d_taps, int w, int h, int round_0, int round_1, int do_average,
                              int use_jnt_comp_avg, int fwd_offset, int bck_offset);
+/* svt_av1_build_compound_diffwtd_mask (elem_bytes 1: 8-bit pixels), _highbd (elem_bytes 2, shift = bd - 8) and _d16 (elem_bytes 2 on the compound
+ * buffers, round = 14 - round_0 - round_1 + bd - 8) — common_dsp_rtcd.h:113-117; EbInterPrediction.c:78-175, C_DEFAULT/EbInterPrediction_c.c:15-45:
+ * d_mask[h][w] (packed) = 38 + |a - b| / 16 after the rounding / shift, clamped to [0, 64]; inverse = DIFFWTD_38_INV. */
+int svt_hip_diffwtd_mask_dev(SvtHipCtx *ctx, int elem_bytes, uint8_t *d_mask, const void *d_src0, int src0_stride, const void *d_src1, int src1_stride, int w,
+                             int h, int inverse, int round, int shift);
+/* svt_aom_lowbd_blend_a64_d16_mask / svt_aom_highbd_blend_a64_d16_mask (common_dsp_rtcd.h; EbBlend_a64_mask.c:34, :116): the two compound buffers
+ * blended under a mask (at the block's resolution, or twice it in the directions subw / subh say) into pixels. */
+int svt_hip_blend_a64_d16_dev(SvtHipCtx *ctx, int pix_bytes, int bd, void *d_dst, int dst_stride, const uint16_t *d_src0, int src0_stride,
+                              const uint16_t *d_src1, int src1_stride, const uint8_t *d_mask, int mask_stride, int w, int h, int subw, int subh,
+                              int round_0, int round_1);
 /* svt_compute_mean_square_values_8x8 (aom_dsp_rtcd.h; EbPictureAnalysisProcess.c:287: mode 0, (sum of squares << 16) / (w * h) over a w x h
  * area) and svt_compute_sub_mean_8x8 (:310: mode 1, rows 0 / 2 / 4 / 6 of an 8x8 block, sum << 3) for a list of block offsets. */
 int svt_hip_block_mean_batch_dev(SvtHipCtx *ctx, const uint8_t *d_plane, int stride, const int32_t *d_offs, int n, int mode, int w, int h,

@@ -140,6 +140,14 @@ typedef void (*SvtHipUnpackAvgFn)(uint16_t *ref16_l0, uint32_t ref_l0_stride, ui
 typedef void (*SvtHipUnPack2dFn)(uint16_t *in16_bit_buffer, uint32_t in_stride, uint8_t *out8_bit_buffer, uint8_t *outn_bit_buffer, uint32_t out8_stride,
                                  uint32_t outn_stride, uint32_t width, uint32_t height);
 typedef void (*SvtHipUnPack8Fn)(uint16_t *in16_bit_buffer, uint32_t in_stride, uint8_t *out8_bit_buffer, uint32_t out8_stride, uint32_t width, uint32_t height);
+typedef void (*SvtHipDiffwtdMaskFn)(uint8_t *mask, uint8_t mask_type, const uint8_t *src0, int src0_stride, const uint8_t *src1, int src1_stride, int h, int w);
+typedef void (*SvtHipDiffwtdMaskHbdFn)(uint8_t *mask, uint8_t mask_type, const uint8_t *src0, int src0_stride, const uint8_t *src1, int src1_stride, int h, int w, int bd);
+typedef void (*SvtHipDiffwtdMaskD16Fn)(uint8_t *mask, uint8_t mask_type, const uint16_t *src0, int src0_stride, const uint16_t *src1, int src1_stride, int h, int w,
+                                       SvtHipConvolveParams *conv_params, int bd);
+typedef void (*SvtHipBlendD16Fn)(uint8_t *dst, uint32_t dst_stride, const uint16_t *src0, uint32_t src0_stride, const uint16_t *src1, uint32_t src1_stride,
+                                 const uint8_t *mask, uint32_t mask_stride, int w, int h, int subw, int subh, SvtHipConvolveParams *conv_params);
+typedef void (*SvtHipHbdBlendD16Fn)(uint8_t *dst, uint32_t dst_stride, const uint16_t *src0, uint32_t src0_stride, const uint16_t *src1, uint32_t src1_stride,
+                                    const uint8_t *mask, uint32_t mask_stride, int w, int h, int subw, int subh, SvtHipConvolveParams *conv_params, int bd);
 typedef void (*SvtHipHbdMseFn)(const uint8_t *src_ptr, int32_t source_stride, const uint8_t *ref_ptr, int32_t recon_stride, uint32_t *sse);
 typedef void (*SvtHipSubtractBlockFn)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
                                       const uint8_t *pred_ptr, ptrdiff_t pred_stride);
@@ -275,6 +283,12 @@ typedef struct SvtHipRtcd {
     /* --- one reference of a compound prediction (common_dsp_rtcd.h:211-243): do_average = 0 writes ConvolveParams::dst, 1 averages with it */
     SvtHipConvolveSrFn     svt_av1_jnt_convolve_2d, svt_av1_jnt_convolve_x, svt_av1_jnt_convolve_y, svt_av1_jnt_convolve_2d_copy;
     SvtHipHbdConvolveSrFn  svt_av1_highbd_jnt_convolve_2d, svt_av1_highbd_jnt_convolve_x, svt_av1_highbd_jnt_convolve_y, svt_av1_highbd_jnt_convolve_2d_copy;
+    /* --- masked compound: the difference-weighted mask and the blend of the two compound buffers (common_dsp_rtcd.h:113-117; DIFFWTD_MASK_TYPE is a one-byte enum) */
+    SvtHipDiffwtdMaskFn    svt_av1_build_compound_diffwtd_mask;
+    SvtHipDiffwtdMaskHbdFn svt_av1_build_compound_diffwtd_mask_highbd;   /* the uint8_t* arguments are plain casts of uint16_t* (EbInterPrediction.c:155) */
+    SvtHipDiffwtdMaskD16Fn svt_av1_build_compound_diffwtd_mask_d16;
+    SvtHipBlendD16Fn       svt_aom_lowbd_blend_a64_d16_mask;
+    SvtHipHbdBlendD16Fn    svt_aom_highbd_blend_a64_d16_mask;            /* dst: a plain cast of uint16_t* (EbBlend_a64_mask.c:126) */
 } SvtHipRtcd;
 
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the

@@ -82,7 +82,9 @@ void svt_hip_hooks_report(void) {
     X(svt_convert_8bit_to_16bit) X(svt_convert_16bit_to_8bit) X(svt_c_pack) X(svt_compressed_packmsb) X(svt_pack2d_16_bit_src_mul4) X(svt_unpack_avg)   \
     X(svt_un_pack2d_16_bit_src_mul4) X(svt_un_pack8_bit_data)                                                                              \
     X(svt_av1_jnt_convolve_2d) X(svt_av1_jnt_convolve_x) X(svt_av1_jnt_convolve_y) X(svt_av1_jnt_convolve_2d_copy)                          \
-    X(svt_av1_highbd_jnt_convolve_2d) X(svt_av1_highbd_jnt_convolve_x) X(svt_av1_highbd_jnt_convolve_y) X(svt_av1_highbd_jnt_convolve_2d_copy)
+    X(svt_av1_highbd_jnt_convolve_2d) X(svt_av1_highbd_jnt_convolve_x) X(svt_av1_highbd_jnt_convolve_y) X(svt_av1_highbd_jnt_convolve_2d_copy) \
+    X(svt_av1_build_compound_diffwtd_mask) X(svt_av1_build_compound_diffwtd_mask_highbd) X(svt_av1_build_compound_diffwtd_mask_d16)          \
+    X(svt_aom_lowbd_blend_a64_d16_mask) X(svt_aom_highbd_blend_a64_d16_mask)
 /* array members <-> the reference's individually named pointers */
 #define RTCD_INDEXED(X)                                                                                                                      \
     X(svt_aom_lpf_horizontal, 0, svt_aom_lpf_horizontal_4) X(svt_aom_lpf_horizontal, 1, svt_aom_lpf_horizontal_6)                           \

@@ -198,6 +198,8 @@ def lib():
     L.svt_hip_handle_transform64_batch_dev.argtypes = [vp, i32, vp, i32, vp]
     L.svt_hip_upsampled_pred_batch_dev.argtypes = [vp, vp, i32, vp, vp, i32]
     L.svt_hip_handle_transform64_n2n4_batch_dev.argtypes = [vp, i32, vp, i32]
+    L.svt_hip_diffwtd_mask_dev.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32]
+    L.svt_hip_blend_a64_d16_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32]
     L.svt_hip_jnt_convolve_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32]
     L.svt_hip_block_mean_batch_dev.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.svt_hip_ext_sad_16x16_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]

@@ -12,6 +12,8 @@
 //   wiener_convolve       Common/Codec/convolve.c:57-242                     svt_av1_[highbd_]wiener_convolve_add_src_c
 //   repack64              Encoder/Codec/EbTransforms.c:2933-2969             handle_transform*_N2_N4_c
 //   jnt_convolve          Common/Codec/EbInterPrediction.c:552-741, :868-1143  svt_av1_[highbd_]jnt_convolve_{2d,x,y,2d_copy}_c
+//   diffwtd_mask          Common/Codec/EbInterPrediction.c:78-175; Common/C_DEFAULT/EbInterPrediction_c.c:15-45  svt_av1_build_compound_diffwtd_mask[_highbd|_d16]_c
+//   blend_d16             Common/Codec/EbBlend_a64_mask.c:34-215            svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
@@ -328,8 +330,53 @@ jnt_convolve_kernel(const PIX* __restrict__ src, int ss, PIX* __restrict__ dst, 
     dst[(size_t)y * ds + x] = (PIX)clip_px((tmp + ((1 << round_bits) >> 1)) >> round_bits, a.bd);
 }
 
+// ------------------------------------------------------------------------------------------------ difference-weighted compound mask, d16 blend
+// mask[i * w + j] = 38 + (|a - b| rounded by `round`, shifted by `shift`) / 16, clamped to [0, 64], inverted for DIFFWTD_38_INV
+template <typename T>
+__global__ void __launch_bounds__(256)
+diffwtd_mask_kernel(uint8_t* __restrict__ mask, const T* __restrict__ a, int as, const T* __restrict__ b, int bs, int w, int h, int inverse, int round, int shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    int d = abs((int)a[(size_t)y * as + x] - (int)b[(size_t)y * bs + x]);
+    if (round > 0) d = (d + (1 << (round - 1))) >> round;
+    d >>= shift;
+    const int m = min(max(38 + d / 16, 0), 64);
+    mask[i] = (uint8_t)(inverse ? 64 - m : m);
+}
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+blend_d16_kernel(PIX* __restrict__ dst, int ds, const uint16_t* __restrict__ s0, int s0s, const uint16_t* __restrict__ s1, int s1s, const uint8_t* __restrict__ mask, int ms, int w,
+                 int h, int subw, int subh, int round_offset, int round_bits, int bd) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    int m;
+    if (!subw && !subh) m = mask[(size_t)y * ms + x];
+    else if (subw && subh) m = (mask[(size_t)(2 * y) * ms + 2 * x] + mask[(size_t)(2 * y + 1) * ms + 2 * x] + mask[(size_t)(2 * y) * ms + 2 * x + 1] + mask[(size_t)(2 * y + 1) * ms + 2 * x + 1] + 2) >> 2;
+    else if (subw) m = (mask[(size_t)y * ms + 2 * x] + mask[(size_t)y * ms + 2 * x + 1] + 1) >> 1;
+    else m = (mask[(size_t)(2 * y) * ms + x] + mask[(size_t)(2 * y + 1) * ms + x] + 1) >> 1;
+    int res = (m * (int)s0[(size_t)y * s0s + x] + (64 - m) * (int)s1[(size_t)y * s1s + x]) >> 6;
+    res -= round_offset;
+    dst[(size_t)y * ds + x] = (PIX)clip_px((res + ((1 << round_bits) >> 1)) >> round_bits, bd);
+}
+
 }  // namespace
 
+extern "C" int svt_hip_launch_diffwtd_mask(hipStream_t st, int elem_bytes, uint8_t* mask, const void* a, int as, const void* b, int bs, int w, int h, int inverse, int round,
+                                           int shift) {
+    const dim3 grid((w * h + 255) / 256);
+    if (elem_bytes == 1) hipLaunchKernelGGL(diffwtd_mask_kernel<uint8_t>, grid, dim3(256), 0, st, mask, (const uint8_t*)a, as, (const uint8_t*)b, bs, w, h, inverse, round, shift);
+    else hipLaunchKernelGGL(diffwtd_mask_kernel<uint16_t>, grid, dim3(256), 0, st, mask, (const uint16_t*)a, as, (const uint16_t*)b, bs, w, h, inverse, round, shift);
+    return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_blend_d16(hipStream_t st, int pix_bytes, int bd, void* dst, int ds, const uint16_t* s0, int s0s, const uint16_t* s1, int s1s, const uint8_t* mask,
+                                        int ms, int w, int h, int subw, int subh, int round0, int round1) {
+    const dim3 grid((w + 63) / 64, (h + 3) / 4);
+    const int  b = pix_bytes == 1 ? 8 : bd, offset_bits = b + 14 - round0, round_offset = (1 << (offset_bits - round1)) + (1 << (offset_bits - round1 - 1));
+    if (pix_bytes == 1) hipLaunchKernelGGL(blend_d16_kernel<uint8_t>, grid, dim3(256), 0, st, (uint8_t*)dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, round_offset, 14 - round0 - round1, b);
+    else hipLaunchKernelGGL(blend_d16_kernel<uint16_t>, grid, dim3(256), 0, st, (uint16_t*)dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, round_offset, 14 - round0 - round1, b);
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_jnt_convolve(hipStream_t st, int pix_bytes, int bd, int variant, const void* src, int ss, void* dst, int ds, uint16_t* cb, int cbs,
                                            const int16_t* taps, int w, int h, int round0, int round1, int do_average, int use_jnt, int fwd, int bck) {
     const dim3    grid((w + 63) / 64, (h + 3) / 4);

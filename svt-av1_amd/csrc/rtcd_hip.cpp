@@ -1081,6 +1081,53 @@ JNT_WRAPPER(jnt_x_hip, jnt_convolve_x, 1)
 JNT_WRAPPER(jnt_y_hip, jnt_convolve_y, 2)
 JNT_WRAPPER(jnt_copy_hip, jnt_convolve_2d_copy, 3)
 
+// ----------------------------------------------------------------------------------- masked compound
+bool diffwtd_generic(int eb, uint8_t* mask, int type, const void* s0, int s0s, const void* s1, int s1s, int h, int w, int round, int shift) {
+    if (!g_ctx || w < 1 || h < 1 || w > 128 || h > 128 || type < 0 || type > 1) return false;
+    const size_t p = rup((size_t)w * eb, 4);
+    uint8_t *d_a = (uint8_t*)dev(0, p * h), *d_b = (uint8_t*)dev(1, p * h), *d_m = (uint8_t*)dev(3, (size_t)w * h);
+    return d_a && d_b && d_m && up2d(d_a, p, s0, (size_t)s0s * eb, (size_t)w * eb, h) && up2d(d_b, p, s1, (size_t)s1s * eb, (size_t)w * eb, h) &&
+           svt_hip_diffwtd_mask_dev(g_ctx, eb, d_m, d_a, (int)(p / eb), d_b, (int)(p / eb), w, h, type, round, shift) == 0 && down(mask, d_m, (size_t)w * h);
+}
+void diffwtd_mask_hip(uint8_t* mask, uint8_t type, const uint8_t* s0, int s0s, const uint8_t* s1, int s1s, int h, int w) {
+    Guard lk;
+    if (diffwtd_generic(1, mask, type, s0, s0s, s1, s1s, h, w, 0, 0)) return;
+    FALLBACK("svt_av1_build_compound_diffwtd_mask", svt_av1_build_compound_diffwtd_mask, mask, type, s0, s0s, s1, s1s, h, w);
+}
+void diffwtd_mask_hbd_hip(uint8_t* mask, uint8_t type, const uint8_t* s0, int s0s, const uint8_t* s1, int s1s, int h, int w, int bd) {
+    Guard lk;
+    if (bd >= 8 && bd <= 12 && diffwtd_generic(2, mask, type, s0, s0s, s1, s1s, h, w, 0, bd - 8)) return;
+    FALLBACK("svt_av1_build_compound_diffwtd_mask_highbd", svt_av1_build_compound_diffwtd_mask_highbd, mask, type, s0, s0s, s1, s1s, h, w, bd);
+}
+void diffwtd_mask_d16_hip(uint8_t* mask, uint8_t type, const uint16_t* s0, int s0s, const uint16_t* s1, int s1s, int h, int w, SvtHipConvolveParams* cp, int bd) {
+    Guard lk;
+    if (cp && bd >= 8 && bd <= 12 && diffwtd_generic(2, mask, type, s0, s0s, s1, s1s, h, w, 14 - cp->round_0 - cp->round_1 + bd - 8, 0)) return;
+    FALLBACK("svt_av1_build_compound_diffwtd_mask_d16", svt_av1_build_compound_diffwtd_mask_d16, mask, type, s0, s0s, s1, s1s, h, w, cp, bd);
+}
+bool blend_d16_generic(int pb, int bd, void* dst, uint32_t ds, const uint16_t* s0, uint32_t s0s, const uint16_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw,
+                       int subh, const SvtHipConvolveParams* cp) {
+    if (!g_ctx || !cp || w < 1 || h < 1 || w > 128 || h > 128) return false;
+    const int    mw = w << (subw ? 1 : 0), mh = h << (subh ? 1 : 0);
+    const size_t sp = (size_t)w * 2, mp = rup((size_t)mw, 4), dp = rup((size_t)w * pb, 4);
+    uint16_t *d_0 = (uint16_t*)dev(0, sp * h), *d_1 = (uint16_t*)dev(1, sp * h); uint8_t *d_m = (uint8_t*)dev(4, mp * mh), *d_d = (uint8_t*)dev(5, dp * h);
+    // src0 / src1 may alias dst in the reference's callers (it reads each sample before it writes it): both are uploaded before anything is written
+    return d_0 && d_1 && d_m && d_d && up2d(d_0, sp, s0, (size_t)s0s * 2, sp, h) && up2d(d_1, sp, s1, (size_t)s1s * 2, sp, h) && up2d(d_m, mp, mask, ms, (size_t)mw, mh) &&
+           svt_hip_blend_a64_d16_dev(g_ctx, pb, bd, d_d, (int)(dp / pb), d_0, w, d_1, w, d_m, (int)mp, w, h, subw, subh, cp->round_0, cp->round_1) == 0 &&
+           down2d(dst, (size_t)ds * pb, d_d, dp, (size_t)w * pb, h);
+}
+void blend_d16_hip(uint8_t* dst, uint32_t ds, const uint16_t* s0, uint32_t s0s, const uint16_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh,
+                   SvtHipConvolveParams* cp) {
+    Guard lk;
+    if (blend_d16_generic(1, 8, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, cp)) return;
+    FALLBACK("svt_aom_lowbd_blend_a64_d16_mask", svt_aom_lowbd_blend_a64_d16_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, cp);
+}
+void blend_d16_hbd_hip(uint8_t* dst, uint32_t ds, const uint16_t* s0, uint32_t s0s, const uint16_t* s1, uint32_t s1s, const uint8_t* mask, uint32_t ms, int w, int h, int subw, int subh,
+                       SvtHipConvolveParams* cp, int bd) {
+    Guard lk;
+    if ((bd == 8 || bd == 10 || bd == 12) && blend_d16_generic(2, bd, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, cp)) return;
+    FALLBACK("svt_aom_highbd_blend_a64_d16_mask", svt_aom_highbd_blend_a64_d16_mask, dst, ds, s0, s0s, s1, s1s, mask, ms, w, h, subw, subh, cp, bd);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
@@ -1155,5 +1202,7 @@ extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     t->svt_av1_jnt_convolve_2d = jnt_2d_hip; t->svt_av1_jnt_convolve_x = jnt_x_hip; t->svt_av1_jnt_convolve_y = jnt_y_hip; t->svt_av1_jnt_convolve_2d_copy = jnt_copy_hip;
     t->svt_av1_highbd_jnt_convolve_2d = jnt_2d_hip_hbd; t->svt_av1_highbd_jnt_convolve_x = jnt_x_hip_hbd; t->svt_av1_highbd_jnt_convolve_y = jnt_y_hip_hbd;
     t->svt_av1_highbd_jnt_convolve_2d_copy = jnt_copy_hip_hbd;
+    t->svt_av1_build_compound_diffwtd_mask = diffwtd_mask_hip; t->svt_av1_build_compound_diffwtd_mask_highbd = diffwtd_mask_hbd_hip;
+    t->svt_av1_build_compound_diffwtd_mask_d16 = diffwtd_mask_d16_hip; t->svt_aom_lowbd_blend_a64_d16_mask = blend_d16_hip; t->svt_aom_highbd_blend_a64_d16_mask = blend_d16_hbd_hip;
     return SVT_HIP_OK;
 }

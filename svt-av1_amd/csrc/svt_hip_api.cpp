@@ -978,6 +978,25 @@ int svt_hip_handle_transform64_n2n4_batch_dev(SvtHipCtx* c, int tx_size, int32_t
     if (e != hipSuccess) return fail(c, e, "handle transform64 N2 / N4 launch");
     return SVT_HIP_OK;
 }
+int svt_hip_diffwtd_mask_dev(SvtHipCtx* c, int elem_bytes, uint8_t* d_mask, const void* d_src0, int src0_stride, const void* d_src1, int src1_stride, int w, int h, int inverse,
+                             int round, int shift) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mask || !d_src0 || !d_src1 || w < 1 || h < 1 || (elem_bytes != 1 && elem_bytes != 2) || round < 0 || round > 15 || shift < 0 || shift > 8) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_diffwtd_mask(c->stream, elem_bytes, d_mask, d_src0, src0_stride, d_src1, src1_stride, w, h, inverse, round, shift);
+    if (e != hipSuccess) return fail(c, e, "diffwtd mask launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_blend_a64_d16_dev(SvtHipCtx* c, int pix_bytes, int bd, void* d_dst, int dst_stride, const uint16_t* d_src0, int src0_stride, const uint16_t* d_src1, int src1_stride,
+                              const uint8_t* d_mask, int mask_stride, int w, int h, int subw, int subh, int round_0, int round_1) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_dst || !d_src0 || !d_src1 || !d_mask || w < 1 || h < 1 || !((pix_bytes == 1 && bd == 8) || (pix_bytes == 2 && bd >= 8 && bd <= 12)) || round_0 < 3 || round_0 > 5 ||
+        round_1 < 1 || 14 - round_0 - round_1 < 0)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_blend_d16(c->stream, pix_bytes, bd, d_dst, dst_stride, d_src0, src0_stride, d_src1, src1_stride, d_mask, mask_stride, w, h, subw != 0,
+                                                        subh != 0, round_0, round_1);
+    if (e != hipSuccess) return fail(c, e, "blend a64 d16 launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_jnt_convolve_dev(SvtHipCtx* c, int pix_bytes, int bd, int variant, const void* d_src, int src_stride, void* d_dst, int dst_stride, uint16_t* d_convbuf,
                              int convbuf_stride, const int16_t* d_taps, int w, int h, int round_0, int round_1, int do_average, int use_jnt_comp_avg, int fwd_offset,
                              int bck_offset) {

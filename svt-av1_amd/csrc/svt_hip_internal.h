@@ -106,6 +106,9 @@ int svt_hip_launch_cdef_find_dir_list(hipStream_t st, const uint16_t* img, const
 int svt_hip_launch_cdef_filter_block_list(hipStream_t st, const uint16_t* in, int istride, const void* jobs, int n, uint8_t* dst8, uint16_t* dst16, int dstride);
 int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n);
 /* per-call forms (percall2.hip) */
+int svt_hip_launch_diffwtd_mask(hipStream_t st, int elem_bytes, uint8_t* mask, const void* a, int as, const void* b, int bs, int w, int h, int inverse, int round, int shift);
+int svt_hip_launch_blend_d16(hipStream_t st, int pix_bytes, int bd, void* dst, int ds, const uint16_t* s0, int s0s, const uint16_t* s1, int s1s, const uint8_t* mask, int ms, int w,
+                             int h, int subw, int subh, int round0, int round1);
 int svt_hip_launch_jnt_convolve(hipStream_t st, int pix_bytes, int bd, int variant, const void* src, int ss, void* dst, int ds, uint16_t* cb, int cbs, const int16_t* taps,
                                 int w, int h, int round0, int round1, int do_average, int use_jnt, int fwd, int bck);
 int svt_hip_launch_repack64(hipStream_t st, int32_t* coeff, int rows, int per_block, int nblk);

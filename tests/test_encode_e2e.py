@@ -174,7 +174,8 @@ def test_helper_pointers_in_a_real_encode_on_gpu(workdir):
              "svt_full_distortion_kernel_cbf_zero32_bits,svt_spatial_full_distortion_kernel,svt_aom_sse,svt_aom_satd,svt_av1_block_error,"
              "svt_get_proj_subspace,svt_av1_lowbd_pixel_proj_error,svt_compute_mean_square_values_8x8,svt_compute_sub_mean_8x8,"
              "svt_aom_convolve8_horiz,svt_aom_convolve8_vert,svt_av1_wiener_convolve_add_src,"
-             "svt_av1_jnt_convolve_2d,svt_av1_jnt_convolve_x,svt_av1_jnt_convolve_y,svt_av1_jnt_convolve_2d_copy")
+             "svt_av1_jnt_convolve_2d,svt_av1_jnt_convolve_x,svt_av1_jnt_convolve_y,svt_av1_jnt_convolve_2d_copy,"
+             "svt_av1_build_compound_diffwtd_mask,svt_av1_build_compound_diffwtd_mask_d16,svt_aom_lowbd_blend_a64_d16_mask")
     ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif2.ref"))
     got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif2.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1500)
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
@@ -193,7 +194,8 @@ def test_high_bit_depth_pointers_in_a_real_encode_on_gpu(workdir):
              "svt_un_pack8_bit_data,svt_unpack_avg,svt_aom_highbd_subtract_block,svt_full_distortion_kernel16_bits,svt_aom_highbd_8_mse16x16,"
              "svt_av1_highbd_wiener_convolve_add_src,svt_av1_highbd_pixel_proj_error,variance_highbd,sad_16b_kernel,svt_compute_cdef_dist_16bit,"
              "svt_residual_kernel16bit,svt_aom_highbd_quantize_b,svt_av1_highbd_quantize_fp,svt_get_proj_subspace,svt_aom_highbd_sse,"
-             "svt_av1_highbd_jnt_convolve_2d,svt_av1_highbd_jnt_convolve_x,svt_av1_highbd_jnt_convolve_y,svt_av1_highbd_jnt_convolve_2d_copy")
+             "svt_av1_highbd_jnt_convolve_2d,svt_av1_highbd_jnt_convolve_x,svt_av1_highbd_jnt_convolve_y,svt_av1_highbd_jnt_convolve_2d_copy,"
+             "svt_av1_build_compound_diffwtd_mask_highbd,svt_av1_build_compound_diffwtd_mask_d16,svt_aom_highbd_blend_a64_d16_mask")
     ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10.ref"))
     got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=1500)
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])

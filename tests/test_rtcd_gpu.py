@@ -102,6 +102,11 @@ SUBMEAN = C.CFUNCTYPE(C.c_uint64, VP, C.c_uint16)
 CONV8 = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
 WIENER = C.CFUNCTYPE(None, VP, C.c_ssize_t, VP, C.c_ssize_t, VP, VP, C.c_int32, C.c_int32, C.POINTER(ConvParams))
 HBDMSE = C.CFUNCTYPE(None, VP, C.c_int32, VP, C.c_int32, VP)
+DWM = C.CFUNCTYPE(None, VP, C.c_uint8, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int)
+DWMH = C.CFUNCTYPE(None, VP, C.c_uint8, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int)
+DWM16 = C.CFUNCTYPE(None, VP, C.c_uint8, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.POINTER(ConvParams), C.c_int)
+BLD16 = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvParams))
+BLD16H = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvParams), C.c_int)
 CVT = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32, C.c_uint32)
 CPACK = C.CFUNCTYPE(None, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_uint32)
 PACKMSB = C.CFUNCTYPE(None, VP, C.c_uint32, VP, VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
@@ -145,7 +150,9 @@ class Rtcd(C.Structure):
                 ("svt_un_pack8_bit_data", UNPACK8),
                 ("svt_av1_jnt_convolve_2d", CONV), ("svt_av1_jnt_convolve_x", CONV), ("svt_av1_jnt_convolve_y", CONV), ("svt_av1_jnt_convolve_2d_copy", CONV),
                 ("svt_av1_highbd_jnt_convolve_2d", CONVH), ("svt_av1_highbd_jnt_convolve_x", CONVH), ("svt_av1_highbd_jnt_convolve_y", CONVH),
-                ("svt_av1_highbd_jnt_convolve_2d_copy", CONVH)]
+                ("svt_av1_highbd_jnt_convolve_2d_copy", CONVH),
+                ("svt_av1_build_compound_diffwtd_mask", DWM), ("svt_av1_build_compound_diffwtd_mask_highbd", DWMH), ("svt_av1_build_compound_diffwtd_mask_d16", DWM16),
+                ("svt_aom_lowbd_blend_a64_d16_mask", BLD16), ("svt_aom_highbd_blend_a64_d16_mask", BLD16H)]
 
 
 @pytest.fixture(scope="module")
@@ -834,3 +841,40 @@ def test_jnt_convolve_pointers_vs_reference_c(rtcd, ref, orc):
                             f(img.ctypes.data + off, 120, out.ctypes.data, w + 3, w, h, C.byref(fx), C.byref(fy), sx, sy, C.byref(cp), *extra)
                         res.append((cb, out))
                     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), ("jnt convolve", bd, name, w, h, bx, by, sx, sy, jnt, fwd, bck)
+
+
+def test_masked_compound_pointers_vs_reference_c(rtcd, ref):
+    """The difference-weighted compound mask (pixels, 16-bit pixels, compound buffers) and the blend of two compound buffers under a mask."""
+    rng = np.random.default_rng(17)
+    for (w, h) in ((8, 8), (16, 32), (64, 64), (128, 32), (4, 16)):
+        for mtype in (0, 1):
+            a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8); b = np.clip(a.astype(np.int32) + rng.integers(-120, 121, a.shape), 0, 255).astype(np.uint8)
+            e = np.full(w * h + 8, 99, np.uint8); g = e.copy()
+            _as(DWM, ref.svt_av1_build_compound_diffwtd_mask_c)(_vp(e), mtype, _vp(a), w + 3, _vp(b), w + 3, h, w); rtcd.svt_av1_build_compound_diffwtd_mask(_vp(g), mtype, _vp(a), w + 3, _vp(b), w + 3, h, w)
+            assert np.array_equal(e, g), ("diffwtd mask", w, h, mtype)
+            for bd in (8, 10, 12):
+                a16 = rng.integers(0, 1 << bd, (h, w + 5)).astype(np.uint16); b16 = np.clip(a16.astype(np.int32) + rng.integers(-(60 << (bd - 8)), (60 << (bd - 8)) + 1, a16.shape), 0, (1 << bd) - 1).astype(np.uint16)
+                e[:] = 99; g[:] = 99
+                _as(DWMH, ref.svt_av1_build_compound_diffwtd_mask_highbd_c)(_vp(e), mtype, _vp(a16), w + 5, _vp(b16), w + 5, h, w, bd)
+                rtcd.svt_av1_build_compound_diffwtd_mask_highbd(_vp(g), mtype, _vp(a16), w + 5, _vp(b16), w + 5, h, w, bd)
+                assert np.array_equal(e, g), ("diffwtd mask highbd", w, h, mtype, bd)
+                # compound buffers: the offset-carrying 16-bit intermediates of the jnt convolves
+                r0 = 5 if bd == 12 else 3
+                off = (1 << (bd + 14 - r0 - 7)) + (1 << (bd + 14 - r0 - 8))
+                c0 = (off + rng.integers(0, 1 << (bd + 4), (h, w + 2))).astype(np.uint16); c1 = np.clip(c0.astype(np.int32) + rng.integers(-(900 << (bd - 8)), (900 << (bd - 8)) + 1, c0.shape), 0, 65535).astype(np.uint16)
+                cp = ConvParams(0, 0, None, 0, r0, 7, 0, 1, 0, 0, 0, 0)
+                e[:] = 99; g[:] = 99
+                _as(DWM16, ref.svt_av1_build_compound_diffwtd_mask_d16_c)(_vp(e), mtype, _vp(c0), w + 2, _vp(c1), w + 2, h, w, C.byref(cp), bd)
+                rtcd.svt_av1_build_compound_diffwtd_mask_d16(_vp(g), mtype, _vp(c0), w + 2, _vp(c1), w + 2, h, w, C.byref(cp), bd)
+                assert np.array_equal(e, g), ("diffwtd mask d16", w, h, mtype, bd)
+                for subw, subh in ((0, 0), (1, 1), (1, 0), (0, 1)):
+                    mk = rng.integers(0, 65, (h << subh, (w << subw) + 6)).astype(np.uint8)
+                    dt = np.uint8 if bd == 8 else np.uint16
+                    de = np.full((h, w + 4), 7, dt); dg = de.copy()
+                    if bd == 8:
+                        _as(BLD16, ref.svt_aom_lowbd_blend_a64_d16_mask_c)(_vp(de), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp))
+                        rtcd.svt_aom_lowbd_blend_a64_d16_mask(_vp(dg), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp))
+                    else:
+                        _as(BLD16H, ref.svt_aom_highbd_blend_a64_d16_mask_c)(_vp(de), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp), bd)
+                        rtcd.svt_aom_highbd_blend_a64_d16_mask(_vp(dg), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp), bd)
+                    assert np.array_equal(de, dg), ("blend d16", w, h, bd, subw, subh)
