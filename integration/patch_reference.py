@@ -134,17 +134,36 @@ PATCHES.append(pa)
 tf = Patch("Source/Lib/Encoder/Codec/EbTemporalFiltering.c")
 tf.sub(r'(\n    \*filtered_sse    = 0;\n    \*filtered_sse_uv = 0;\n)',
        r'\n    for (int hip_try = 0; hip_try < 2; hip_try++) {\n'
-       r'    SvtHipTfSeg *hip_tf = hip_try ? NULL : svt_hip_tf_seg_begin(picture_control_set_ptr_central->past_altref_nframes +\n'
-       r'        picture_control_set_ptr_central->future_altref_nframes + 1, index_center, x_b64_start_idx, x_b64_end_idx, y_b64_start_idx, y_b64_end_idx,\n'
-       r'        is_highbd, ss_x, ss_y);\1')
+       r'    const int hip_nframes = picture_control_set_ptr_central->past_altref_nframes + picture_control_set_ptr_central->future_altref_nframes + 1;\n'
+       r'    SvtHipTfSeg *hip_tf = hip_try ? NULL : svt_hip_tf_seg_begin(hip_nframes, index_center, x_b64_start_idx, x_b64_end_idx, y_b64_start_idx, y_b64_end_idx,\n'
+       r'        is_highbd, ss_x, ss_y);\n'
+       r'    /* hook "tf_me": the block loop runs once per pass of the batched motion search (svt_hip_me_bridge.c), everything after the search in the last */\n'
+       r'    SvtHipMeBatch *hip_tfme = (hip_try || scs_ptr->in_loop_me) ? NULL : svt_hip_me_batch_begin_tf(context_ptr->enable_hme_flag,\n'
+       r'        (x_b64_end_idx - x_b64_start_idx) * (y_b64_end_idx - y_b64_start_idx) * (uint32_t)(hip_nframes - 1));\n'
+       r'    const int hip_passes = svt_hip_me_batch_passes(hip_tfme);\n\1'
+       r'    for (int hip_pass = 0; hip_pass < hip_passes; hip_pass++) {\n'
+       r'    const int hip_last = hip_pass + 1 == hip_passes;\n'
+       r'    if (hip_pass) svt_hip_me_batch_flush(hip_tfme, hip_pass, ((EbPaReferenceObject *)picture_control_set_ptr_central->pa_reference_picture_wrapper_ptr->object_ptr)\n'
+       r'        ->input_padded_picture_ptr);\n')
+tf.sub(r'(\n[ \t]*if \(frame_index == index_center\) \{\n[ \t]*// skip MC \(central frame\)\n)', r'\1                    if (!hip_last) continue;\n')
+tf.sub(r'(\n[ \t]*)(motion_estimate_sb\(\s*picture_control_set_ptr_central, // source picture control set -> references come from here\s*'
+       r'\(uint32_t\)blk_row \* blk_cols \+ blk_col,.*?input_picture_ptr_central\); // source picture)',
+       r'\1if (hip_tfme) {'
+       r'\1    if (!svt_hip_me_batch_slot(hip_tfme, hip_pass, picture_control_set_ptr_central, ((uint32_t)blk_row * blk_cols + blk_col) * 16 + frame_index,'
+       r'\1                               (uint32_t)blk_row * blk_cols + blk_col, (uint32_t)blk_col * BW, (uint32_t)blk_row * BH, context_ptr, input_picture_ptr_central))'
+       r'\1        continue; /* not the last pass: the searches of this (block, frame) are pending */'
+       r'\1} else'
+       r'\1\2')
 tf.sub(r'(\n[ \t]*if \(picture_control_set_ptr_central->scs_ptr->static_config\.qp <= ALT_REF_QP_THRESH\)\s*decay_control--;\n)',
        r'\1                if (hip_tf) { /* Step 2 of this (frame, block) happens in svt_hip_tf_seg_flush */\n'
        r'                    svt_hip_tf_seg_block(hip_tf, frame_index, blk_row, blk_col, context_ptr, pred, pred_16bit, stride_pred, decay_control);\n'
        r'                    continue;\n'
        r'                }\n')
-tf.sub(r'(\n[ \t]*)(get_final_filtered_pixels\(context_ptr,\s*src_center_ptr_start,)', r'\1if (!hip_tf) \2')
+tf.sub(r'(\n[ \t]*)(get_final_filtered_pixels\(context_ptr,\s*src_center_ptr_start,)', r'\1if (hip_last && !hip_tf) \2')
 tf.sub(r'(\n    if \(!is_highbd\)\n        EB_FREE_ALIGNED_ARRAY\(predictor\);)',
-       r'\n    if (!hip_tf) break;\n'
+       r'\n    } /* hip_pass */\n'
+       r'    svt_hip_me_batch_end(hip_tfme);\n'
+       r'    if (!hip_tf) break;\n'
        r'    const EbErrorType hip_ret = svt_hip_tf_seg_flush(hip_tf, context_ptr, src_center_ptr_start, altref_buffer_highbd_start, stride, encoder_bit_depth,\n'
        r'                                                     noise_levels, filtered_sse, filtered_sse_uv);\n'
        r'    svt_hip_tf_seg_end(hip_tf);\n'

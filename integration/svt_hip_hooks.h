@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  pa, tf, hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -39,6 +39,8 @@ enum {
     SVT_HIP_HOOK_TF,           /* Step 2 + get_final_filtered_pixels of every TF segment: produce_temporally_filtered_pic (EbTemporalFiltering.c:2038-2412),
                                 * glue in svt_hip_tf_bridge.c */
     SVT_HIP_HOOK_PA,           /* picture analysis: the HME pyramids and the per-SB mean / variance pyramid (EbPictureAnalysisProcess.c:3312, :3606, :2929) */
+    SVT_HIP_HOOK_TF_ME,        /* the motion search of the temporal filter: HME levels and integer search of every (block, frame) of a TF segment batched like
+                                * the open-loop ME (EbTemporalFiltering.c:2264, motion_estimate_sb with ME_MCTF) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -58,12 +60,16 @@ void svt_hip_hooks_report(void);
 typedef struct SvtHipMeBatch SvtHipMeBatch;
 /* motion_estimation_kernel, before the SB loop of a segment.  NULL = hooks "hme" and "me" off: the caller runs its unchanged loop. */
 SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb);
+/* the same for the temporal filter's block loop (hook "tf_me"): one slot per (64x64 block, window frame) of the TF segment */
+SvtHipMeBatch *svt_hip_me_batch_begin_tf(int enable_hme, uint32_t n_slots);
 /* The SB loop runs svt_hip_me_batch_passes() times (1 for NULL); before every pass but the first svt_hip_me_batch_flush launches what the
  * previous pass recorded (one hierarchical-ME level, or the integer-search windows).  svt_hip_me_batch_sb runs this pass's part of
  * motion_estimate_sb for one SB and returns 1 when the SB is complete (last pass), 0 when more passes follow (svt_hip_me_bridge.c). */
 int  svt_hip_me_batch_passes(const SvtHipMeBatch *b);
 int  svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
                          uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr);
+int  svt_hip_me_batch_slot(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t key, uint32_t sb_index, uint32_t sb_origin_x,
+                           uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr);
 void svt_hip_me_batch_flush(SvtHipMeBatch *b, int next_pass, const EbPictureBufferDesc *src_padded);
 void svt_hip_me_batch_end(SvtHipMeBatch *b);
 /* hme_level_0 / 1 / 2, in front of their svt_sad_loop_kernel call, whose twelve arguments follow the four describing the call site:

@@ -50,7 +50,8 @@ struct SvtHipMeBatch {
     int                        n_pass, phase[MAX_PASSES];
     int                        failed, sub_sad;
     MeSbState                 *sb;             /* [cap] */
-    const EbPictureBufferDesc *ref_pic[MAX_NUM_OF_REF_PIC_LIST][MAX_REF_IDX];
+    const EbPictureBufferDesc **win_ref;       /* [list][ref][cap]: the reference picture of each recorded window (the TF loop's slots differ in it) */
+    int                        hook_me, hook_hme; /* which counters the flushes feed (SVT_HIP_HOOK_ME / _HME, or SVT_HIP_HOOK_TF_ME for both) */
     uint8_t                   *has;            /* [list][ref][cap]: a window was recorded */
     SvtHipSbSearch            *win;            /* [list][ref][cap] */
     uint32_t                  *best_sad, *best_mv; /* [list][ref][cap][85] */
@@ -70,13 +71,11 @@ static __thread SvtHipMeBatch *tls_hme;   /* the batch that is collecting hierar
 
 int svt_hip_me_batch_passes(const SvtHipMeBatch *b) { return b ? b->n_pass : 1; }
 
-SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb) {
-    (void)pcs;
-    const int me = svt_hip_hook_enabled(SVT_HIP_HOOK_ME), hme = svt_hip_hook_enabled(SVT_HIP_HOOK_HME) && me_ctx->enable_hme_flag;
-    if ((!me && !hme) || !n_sb || me_ctx->me_type == ME_MCTF) return NULL;
+static SvtHipMeBatch *batch_new(uint32_t n_sb, int me, int hme, int hook_me, int hook_hme) {
     SvtHipMeBatch *b = (SvtHipMeBatch *)calloc(1, sizeof(*b));
     if (!b) return NULL;
     b->cap = n_sb;
+    b->hook_me = hook_me; b->hook_hme = hook_hme;
     if (hme) { b->phase[0] = 10; b->phase[1] = 11; b->phase[2] = 12; b->n_pass = 3; }
     if (me) { b->phase[b->n_pass++] = hme ? 2 : 0; b->phase[b->n_pass++] = 1; }
     else b->phase[b->n_pass++] = 3;
@@ -86,9 +85,10 @@ SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *m
     if (me) {
         b->has = (uint8_t *)calloc(slots, 1);
         b->win = (SvtHipSbSearch *)calloc(slots, sizeof(SvtHipSbSearch));
+        b->win_ref = (const EbPictureBufferDesc **)calloc(slots, sizeof(*b->win_ref));
         b->best_sad = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
         b->best_mv = (uint32_t *)malloc(slots * SQUARE_PU_COUNT * sizeof(uint32_t));
-        ok = ok && b->has && b->win && b->best_sad && b->best_mv;
+        ok = ok && b->has && b->win && b->win_ref && b->best_sad && b->best_mv;
     }
     for (int l = 0; l < 3 && hme; l++) {
         b->sb_first[l] = (uint32_t *)calloc(n_sb, sizeof(uint32_t));
@@ -103,6 +103,20 @@ SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *m
     return b;
 }
 
+SvtHipMeBatch *svt_hip_me_batch_begin(PictureParentControlSet *pcs, MeContext *me_ctx, uint32_t n_sb) {
+    (void)pcs;
+    const int me = svt_hip_hook_enabled(SVT_HIP_HOOK_ME), hme = svt_hip_hook_enabled(SVT_HIP_HOOK_HME) && me_ctx->enable_hme_flag;
+    if ((!me && !hme) || !n_sb || me_ctx->me_type == ME_MCTF) return NULL;
+    return batch_new(n_sb, me, hme, SVT_HIP_HOOK_ME, SVT_HIP_HOOK_HME);
+}
+
+/* The temporal filter's motion search (hook "tf_me"): the slots are the (64x64 block, window frame) pairs of a TF segment, each with its own
+ * reference picture; hierarchical levels and integer search are both batched.  enable_hme: MeContext::enable_hme_flag as the TF loop sets it. */
+SvtHipMeBatch *svt_hip_me_batch_begin_tf(int enable_hme, uint32_t n_slots) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_TF_ME) || !n_slots) return NULL;
+    return batch_new(n_slots, 1, enable_hme != 0, SVT_HIP_HOOK_TF_ME, SVT_HIP_HOOK_TF_ME);
+}
+
 void svt_hip_me_batch_end(SvtHipMeBatch *b) {
     if (!b) return;
     if (b->d_src || b->d_ref || b->d_job || b->d_sad || b->d_xy) {
@@ -114,7 +128,7 @@ void svt_hip_me_batch_end(SvtHipMeBatch *b) {
     }
     for (int l = 0; l < 3; l++) { free(b->sb_first[l]); free(b->sb_count[l]); free(b->src[l]); }
     free(b->job);
-    free(b->sb); free(b->has); free(b->win); free(b->best_sad); free(b->best_mv);
+    free(b->sb); free(b->has); free(b->win); free((void *)b->win_ref); free(b->best_sad); free(b->best_mv);
     free(b);
 }
 
@@ -133,7 +147,7 @@ int svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origi
     w->width = search_area_width;
     w->height = search_area_height;
     b->has[s] = 1;
-    b->ref_pic[list_index][ref_pic_index] = ref_pic;
+    b->win_ref[s] = ref_pic;
     b->sub_sad = me_ctx->me_search_method == SUB_SAD_SEARCH;
     return 1;
 }
@@ -147,31 +161,35 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
     for (uint32_t l = 0; l < MAX_NUM_OF_REF_PIC_LIST && !b->failed; l++)
         for (uint32_t r = 0; r < MAX_REF_IDX && !b->failed; r++) {
             const size_t s = SLOT(b, l, r);
-            uint32_t     n = 0;
-            for (uint32_t i = 0; i < b->n0; i++)
-                if (b->has[s + i]) { wins[n] = b->win[s + i]; idx[n++] = i; }
-            if (!n) continue;
-            const EbPictureBufferDesc *ref = b->ref_pic[l][r];
-            /* source and reference are the padded luma pictures of two EbPaReferenceObjects of the same sequence: same geometry */
-            if (!ref || ref->stride_y != src_padded->stride_y || ref->origin_x != src_padded->origin_x || ref->origin_y != src_padded->origin_y ||
-                (src_padded->stride_y & 3)) { b->failed = 1; break; }
-            SvtHipCtx *hip = svt_hip_hooks_lock();
-            int        rc = hip ? svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
-                                                           src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x,
-                                                           src_padded->origin_y, wins, (int)n, b->sub_sad, sad, mv)
-                                : SVT_HIP_ERR_NO_DEVICE;
-            if (rc != SVT_HIP_OK)
-                SVT_LOG("svt_hip_me_fullpel_frame failed (%s): C search for this segment\n", hip ? svt_hip_last_error(hip) : "no context");
-            if (hip) svt_hip_hooks_unlock();
-            if (rc != SVT_HIP_OK) { b->failed = 1; break; }
-            for (uint32_t k = 0; k < n; k++) {
-                memcpy(&b->best_sad[(s + idx[k]) * SQUARE_PU_COUNT], &sad[(size_t)k * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
-                memcpy(&b->best_mv[(s + idx[k]) * SQUARE_PU_COUNT], &mv[(size_t)k * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
+            for (uint32_t first = 0; first < b->n0 && !b->failed; first++) {   /* one launch per distinct reference picture among the slots */
+                if (!b->has[s + first]) continue;
+                const EbPictureBufferDesc *ref = b->win_ref[s + first];
+                uint32_t                   n = 0, seen = 0;
+                for (uint32_t i = 0; i < first; i++) seen |= b->has[s + i] && b->win_ref[s + i] == ref;
+                if (seen) continue;
+                for (uint32_t i = first; i < b->n0; i++)
+                    if (b->has[s + i] && b->win_ref[s + i] == ref) { wins[n] = b->win[s + i]; idx[n++] = i; }
+                /* source and reference are the padded luma pictures of two EbPaReferenceObjects of the same sequence: same geometry */
+                if (!ref || ref->stride_y != src_padded->stride_y || ref->origin_x != src_padded->origin_x || ref->origin_y != src_padded->origin_y ||
+                    (src_padded->stride_y & 3)) { b->failed = 1; break; }
+                SvtHipCtx *hip = svt_hip_hooks_lock();
+                int        rc = hip ? svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
+                                                               src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x,
+                                                               src_padded->origin_y, wins, (int)n, b->sub_sad, sad, mv)
+                                    : SVT_HIP_ERR_NO_DEVICE;
+                if (rc != SVT_HIP_OK)
+                    SVT_LOG("svt_hip_me_fullpel_frame failed (%s): C search for this segment\n", hip ? svt_hip_last_error(hip) : "no context");
+                if (hip) svt_hip_hooks_unlock();
+                if (rc != SVT_HIP_OK) { b->failed = 1; break; }
+                for (uint32_t k = 0; k < n; k++) {
+                    memcpy(&b->best_sad[(s + idx[k]) * SQUARE_PU_COUNT], &sad[(size_t)k * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
+                    memcpy(&b->best_mv[(s + idx[k]) * SQUARE_PU_COUNT], &mv[(size_t)k * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
+                }
+                svt_hip_hooks_log("me: list %u ref %u, %u windows of one reference picture in one launch", l, r, n);
             }
-            svt_hip_hooks_log("me: list %u ref %u, %u SB windows in one launch", l, r, n);
         }
     free(wins); free(idx); free(sad); free(mv);
-    svt_hip_hooks_count(SVT_HIP_HOOK_ME, !b->failed);
+    svt_hip_hooks_count(b->hook_me, !b->failed);
 }
 
 /* ------------------------------------------------------------------ hierarchical ME */
@@ -319,19 +337,25 @@ void svt_hip_me_batch_flush(SvtHipMeBatch *b, int next_pass, const EbPictureBuff
     if (prev >= 10) {
         b->level_first[prev - 10 + 1] = b->n_job;
         flush_hme_level(b, prev - 10);
-        if (prev == 12 && b->n_job) svt_hip_hooks_count(SVT_HIP_HOOK_HME, !b->failed);
+        if (prev == 12 && b->n_job && b->hook_hme != b->hook_me) svt_hip_hooks_count(b->hook_hme, !b->failed);
     } else if (prev == 0 || prev == 2)
         flush_integer(b, src_padded);
 }
 
 int svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,
                         uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
+    return svt_hip_me_batch_slot(b, pass, pcs, sb_index, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr);
+}
+
+/* key identifies the slot across the passes (the SB index in the ME loop; block and frame in the TF loop), sb_index is motion_estimate_sb's argument */
+int svt_hip_me_batch_slot(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t key, uint32_t sb_index, uint32_t sb_origin_x,
+                          uint32_t sb_origin_y, MeContext *me_ctx, EbPictureBufferDesc *input_ptr) {
     const int      ph = b->phase[pass], last = pass == b->n_pass - 1;
     const uint32_t i = b->seen[pass]++;
     if (pass == 0) {
         if (i >= b->cap) b->failed = 1;
-        else { b->sb[i].sb_index = sb_index; b->n0 = i + 1; }
-    } else if (i >= b->n0 || b->sb[i].sb_index != sb_index)
+        else { b->sb[i].sb_index = key; b->n0 = i + 1; }
+    } else if (i >= b->n0 || b->sb[i].sb_index != key)
         b->failed = 1;
     if (b->failed) {
         if (last) motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, -1); /* the unchanged C path */

@@ -58,7 +58,7 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t
                                  const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
     (void)c;
     orc_me_fullpel_frame(src, ref, stride, org_x, org_y, (const OrcSbSearch *)sbs, n_sb, sub_sad, best_sad, best_mv, 0, n_sb);
-    if (perturb("me"))
+    if (perturb("me") || perturb("tf_me"))   /* the temporal filter's search uses the same entry point */
         for (int i = 0; i < n_sb * 85; i++) best_mv[i] = (best_mv[i] & 0xffff0000u) | ((best_mv[i] + 8) & 0xffffu);   /* x_mv + 2 px */
     return SVT_HIP_OK;
 }
