@@ -679,6 +679,11 @@ int svt_hip_cdef_dist_dev(SvtHipCtx *ctx, int pix_bytes, const void *d_dst, int 
  * written to d_lev0 / d_lev1[nb_strengths], total to d_work[0].  d_work: 4097 + sb_count uint64 of scratch. */
 int svt_hip_cdef_search_one_dual_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
                                      int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
+/* joint_strength_search_dual (EbEncCdef.c:1140-1164), the strength-pair selection of finish_cdef_search for one count nb_strengths (1, 2, 4, 8): the
+ * greedy steps and the 4 * nb_strengths refinement steps of svt_search_one_dual queued back to back, no host round trip in between.  d_lev0 / d_lev1
+ * [8] receive the selected pairs, d_work[0] the total; d_work: 4097 + sb_count uint64 of scratch. */
+int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
+                                           int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
 /* The self-guided projection on MATERIALISED filter planes (the form the reference's pointers have; the frame kernels never write flt0 / flt1):
  * mode 0 = svt_get_proj_subspace (common_dsp_rtcd.h; EbRestorationPick.c:448): d_acc[5] = {H00, H01, H11, C0, C1} as exact integers, d_xq[2] = the
  * solved pair; mode 1 = svt_av1_lowbd_pixel_proj_error / svt_av1_highbd_pixel_proj_error (:174, :244): d_acc[0] = the squared error of the

@@ -113,6 +113,14 @@ mep.sub(r'(svt_release_mutex\(pcs_ptr->me_processed_sb_mutex\);\s*\}\s*\}\n)',
         r'\1                } /* hip_pass */\n                svt_hip_me_batch_end(hip_me);\n')
 PATCHES.append(mep)
 
+# ---------------------------------------------------------------------------------------------------------------- CDEF strength selection
+# finish_cdef_search (:1258): the four joint_strength_search_dual calls (greedy + refinement steps of svt_search_one_dual) run on the device
+enccdef = Patch("Source/Lib/Encoder/Codec/EbEncCdef.c")
+enccdef.sub(r'(uint64_t tot_mse\s*=\s*)(joint_strength_search_dual\(\s*best_lev0, best_lev1, nb_strengths, mse, sb_count, start_gi, end_gi\);)',
+            r'uint64_t tot_mse = 0;\n        if (!svt_hip_hook_cdef_joint_search(best_lev0, best_lev1, nb_strengths, mse, sb_count, start_gi, end_gi, &tot_mse))\n'
+            r'            tot_mse = \2')
+PATCHES.append(enccdef)
+
 # ---------------------------------------------------------------------------------------------------------------- picture analysis
 # the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)
 pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")

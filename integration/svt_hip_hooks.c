@@ -12,7 +12,7 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me"};
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish"};
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;

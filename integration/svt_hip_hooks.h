@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, hme, me, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, hme, me, cdef_finish, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -41,6 +41,7 @@ enum {
     SVT_HIP_HOOK_PA,           /* picture analysis: the HME pyramids and the per-SB mean / variance pyramid (EbPictureAnalysisProcess.c:3312, :3606, :2929) */
     SVT_HIP_HOOK_TF_ME,        /* the motion search of the temporal filter: HME levels and integer search of every (block, frame) of a TF segment batched like
                                 * the open-loop ME (EbTemporalFiltering.c:2264, motion_estimate_sb with ME_MCTF) */
+    SVT_HIP_HOOK_CDEF_FINISH,  /* joint_strength_search_dual of finish_cdef_search: the strength-pair selection steps back to back on the device (EbEncCdef.c:1140, :1258) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -119,6 +120,10 @@ int svt_hip_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, WienerI
 EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err);
 /* rest_kernel, when the picture leaves the filter stages: releases its device state */
 void        svt_hip_hook_picture_done(PictureControlSet *pcs);
+
+/* finish_cdef_search, in place of joint_strength_search_dual (svt_hip_lf_bridge.c): 1 = best_lev0 / best_lev1 / *tot_mse hold the device result */
+int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32_t nb_strengths, uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi,
+                                   int32_t end_gi, uint64_t *tot_mse);
 
 /* ------------------------------------------------------------------ picture analysis (svt_hip_pa_bridge.c); EB_ErrorNone = handled */
 EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,

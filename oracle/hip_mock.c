@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "../include/svt_hip.h"
 #include "../svt-av1_amd/csrc/svt_hip_host.h"
 #include "svt_oracle.h"
@@ -75,6 +76,41 @@ int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride,
     orc_sad_loop_batch(src, src_stride, ref, ref_stride, searches, 0, n, best_sad, best_xy);
     if (perturb("hme"))
         for (int i = 0; i < n; i++) { best_xy[2 * i] = (int16_t)(best_xy[2 * i] + 24); best_xy[2 * i + 1] = (int16_t)(best_xy[2 * i + 1] - 16); }   /* every search lands far off */
+    return SVT_HIP_OK;
+}
+
+/* joint_strength_search_dual (Encoder/Codec/EbEncCdef.c:1140-1164) on top of svt_search_one_dual_c (:1070-1118), restated */
+static uint64_t mock_search_one_dual(int *lev0, int *lev1, int nb, const uint64_t *m0, const uint64_t *m1, int sb_count, int start_gi, int end_gi) {
+    static uint64_t tot[64][64];
+    uint64_t        best_tot = (uint64_t)1 << 63;
+    int             b0 = 0, b1 = 0;
+    memset(tot, 0, sizeof(tot));
+    for (int i = 0; i < sb_count; i++) {
+        uint64_t best = (uint64_t)1 << 63;
+        for (int g = 0; g < nb; g++) { const uint64_t c = m0[(size_t)i * 64 + lev0[g]] + m1[(size_t)i * 64 + lev1[g]]; if (c < best) best = c; }
+        for (int j = start_gi; j < end_gi; j++)
+            for (int k = start_gi; k < end_gi; k++) { const uint64_t c = m0[(size_t)i * 64 + j] + m1[(size_t)i * 64 + k]; tot[j][k] += c < best ? c : best; }
+    }
+    for (int j = start_gi; j < end_gi; j++)
+        for (int k = start_gi; k < end_gi; k++)
+            if (tot[j][k] < best_tot) { best_tot = tot[j][k]; b0 = j; b1 = k; }
+    lev0[nb] = b0; lev1[nb] = b1;
+    return best_tot;
+}
+int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *c, const uint64_t *m0, const uint64_t *m1, int sb_count, int *lev0, int *lev1, int nb, int start_gi, int end_gi,
+                                           uint64_t *work) {
+    (void)c;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;   /* the static table above */
+    pthread_mutex_lock(&mu);
+    uint64_t tot = (uint64_t)1 << 63;
+    for (int i = 0; i < nb; i++) tot = mock_search_one_dual(lev0, lev1, i, m0, m1, sb_count, start_gi, end_gi);
+    for (int i = 0; i < 4 * nb; i++) {
+        for (int j = 0; j < nb - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+        tot = mock_search_one_dual(lev0, lev1, nb - 1, m0, m1, sb_count, start_gi, end_gi);
+    }
+    pthread_mutex_unlock(&mu);
+    if (perturb("cdef_finish")) { lev0[0] = (lev0[0] + 5) % (end_gi > 0 ? end_gi : 1); tot += 12345; }
+    work[0] = tot;
     return SVT_HIP_OK;
 }
 

@@ -155,6 +155,11 @@ one_dual_total_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) tot[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
+// joint_strength_search_dual's refinement step: drop the oldest pair (lev[j] = lev[j + 1]) before the next search fills slot nb - 1
+__global__ void one_dual_shift_kernel(int* __restrict__ lev0, int* __restrict__ lev1, int nb) {
+    if (threadIdx.x == 0)
+        for (int j = 0; j < nb - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+}
 // the first minimum in (j, k) raster order; out[0] = its total, lev0[nb] / lev1[nb] = the pair
 __global__ void __launch_bounds__(64)
 one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out) {
@@ -417,6 +422,20 @@ extern "C" int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* ms
     if (sb_count > 0) hipLaunchKernelGGL(one_dual_best_kernel, dim3((sb_count + 255) / 256), dim3(256), 0, st, mse0, mse1, sb_count, lev0, lev1, nb, best);
     if (ng > 0) hipLaunchKernelGGL(one_dual_total_kernel, dim3(ng * ng), dim3(256), 0, st, mse0, mse1, sb_count, best, start_gi, ng, tot);
     hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(64), 0, st, tot, start_gi, ng > 0 ? ng : 0, nb, lev0, lev1, out);
+    return (int)hipGetLastError();
+}
+// joint_strength_search_dual (EbEncCdef.c:1140-1164): nb greedy steps, then 4 * nb refinement steps, all queued back to back
+extern "C" int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi,
+                                                    int end_gi, uint64_t* best, uint64_t* tot, uint64_t* out) {
+    for (int i = 0; i < nb; i++) {
+        const int rc = svt_hip_launch_search_one_dual(st, mse0, mse1, sb_count, lev0, lev1, i, start_gi, end_gi, best, tot, out);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < 4 * nb; i++) {
+        hipLaunchKernelGGL(one_dual_shift_kernel, dim3(1), dim3(64), 0, st, lev0, lev1, nb);
+        const int rc = svt_hip_launch_search_one_dual(st, mse0, mse1, sb_count, lev0, lev1, nb - 1, start_gi, end_gi, best, tot, out);
+        if (rc) return rc;
+    }
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,

@@ -1051,6 +1051,16 @@ int svt_hip_cdef_search_one_dual_dev(SvtHipCtx* c, const uint64_t* d_mse0, const
     if (e != hipSuccess) return fail(c, e, "search one dual launch");
     return SVT_HIP_OK;
 }
+int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, int* d_lev0, int* d_lev1, int nb_strengths, int start_gi,
+                                           int end_gi, uint64_t* d_work) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mse0 || !d_mse1 || !d_lev0 || !d_lev1 || !d_work || sb_count < 0 || nb_strengths < 1 || nb_strengths > 8 || start_gi < 0 || end_gi > 64 || start_gi > end_gi)
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_joint_strength_search(c->stream, d_mse0, d_mse1, sb_count, d_lev0, d_lev1, nb_strengths, start_gi, end_gi, d_work + 1 + 4096,
+                                                                    d_work + 1, d_work);
+    if (e != hipSuccess) return fail(c, e, "joint strength search launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_flt_proj_dev(SvtHipCtx* c, int pix_bytes, const void* d_src, int src_stride, const void* d_dat, int dat_stride, const int32_t* d_flt0, int flt0_stride,
                              const int32_t* d_flt1, int flt1_stride, int w, int h, int r0, int r1, int mode, const int32_t* xq, int64_t* d_acc, int32_t* d_xq) {
     SVT_HIP_ENTER(c);

@@ -119,6 +119,8 @@ int svt_hip_launch_cdef_dist(hipStream_t st, int pix_bytes, const void* dst, int
                              int pli, uint64_t* out);
 int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
                                    uint64_t* best, uint64_t* tot, uint64_t* out);
+int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
+                                         uint64_t* best, uint64_t* tot, uint64_t* out);
 int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s, int w,
                                 int h, int r0, int r1, int mode, int xq0, int xq1, long long* acc, int32_t* xq_out);
 int svt_hip_launch_convolve8(hipStream_t st, int vert, const uint8_t* src, int ss, uint8_t* dst, int ds, const int16_t* filters, int q0, int step, int w, int h);

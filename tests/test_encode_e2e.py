@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not E.have_apps(), reason="oracle/_ref/SvtAv1Enc
 # name: (w, h, frames, bit depth, preset, qp, hooks that must have run)
 ALL = set(E.HOOKS) - E.PER_UNIT_WIENER   # SVT_HIP_HOOKS=all: the picture-level Wiener search takes the place of the per-unit hooks
 ALL_UNIT = set(E.HOOKS) - {"wiener_search"}
-NO_DLF_REST = {"pa", "tf", "tf_me", "hme", "me", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
+NO_DLF_REST = {"pa", "tf", "tf_me", "hme", "me", "cdef_finish", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
 CASES = {
     "cif_8bit_m6": (352, 288, 8, 8, 6, 35, ALL),
     "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),

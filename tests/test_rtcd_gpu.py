@@ -878,3 +878,28 @@ def test_masked_compound_pointers_vs_reference_c(rtcd, ref):
                         _as(BLD16H, ref.svt_aom_highbd_blend_a64_d16_mask_c)(_vp(de), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp), bd)
                         rtcd.svt_aom_highbd_blend_a64_d16_mask(_vp(dg), w + 4, _vp(c0), w + 2, _vp(c1), w + 2, _vp(mk), mk.shape[1], w, h, subw, subh, C.byref(cp), bd)
                     assert np.array_equal(de, dg), ("blend d16", w, h, bd, subw, subh)
+
+
+def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
+    """svt_hip_cdef_joint_strength_search_dev = joint_strength_search_dual (EbEncCdef.c:1140-1164, a static function): the same greedy + refinement
+    sequence driven step by step through the reference's svt_search_one_dual_c."""
+    rng = np.random.default_rng(5)
+    L = hip.L
+    for sb_count, (start, end) in ((1, (0, 64)), (40, (0, 64)), (510, (0, 64)), (77, (0, 16))):
+        m0 = rng.integers(1000, 1 << 22, (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << 21, (sb_count, 64)).astype(np.uint64)
+        m0[:, 11] = m0[:, 2]; m1[:, 9] = m1[:, 4]
+        ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
+        d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
+        for nb in (1, 2, 4, 8):
+            l0 = np.zeros(8, np.int32); l1 = np.zeros(8, np.int32)
+            f = _as(ONEDUAL, ref.svt_search_one_dual_c)
+            for i in range(nb): tot = f(_vp(l0), _vp(l1), i, C.cast(ptrs, C.c_void_p), sb_count, start, end)
+            for i in range(4 * nb):
+                l0[:nb - 1] = l0[1:nb].copy(); l1[:nb - 1] = l1[1:nb].copy()
+                tot = f(_vp(l0), _vp(l1), nb - 1, C.cast(ptrs, C.c_void_p), sb_count, start, end)
+            d_lev = hip.to_device(np.zeros(16, np.int32)); d_work = hip.empty(8 * (4097 + sb_count))
+            hip.check(L.svt_hip_cdef_joint_strength_search_dev(hip.h, d_m0, d_m1, sb_count, d_lev, C.c_void_p(d_lev.value + 32), nb, start, end, d_work), "joint strength search")
+            lev = hip.to_host(d_lev, (16,), np.int32); got_tot = int(hip.to_host(d_work, (1,), np.uint64)[0])
+            assert got_tot == tot and np.array_equal(lev[:nb], l0[:nb]) and np.array_equal(lev[8:8 + nb], l1[:nb]), ("joint search", sb_count, nb, got_tot, tot, lev, l0, l1)
+            hip.free(d_lev, d_work)
+        hip.free(d_m0, d_m1)
