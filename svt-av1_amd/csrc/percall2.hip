@@ -130,8 +130,9 @@ cdef_dist_kernel(const PIX* __restrict__ dst, int dstride, const PIX* __restrict
 // ------------------------------------------------------------------------------------------------ CDEF: one step of the strength-pair selection
 __global__ void __launch_bounds__(256)
 one_dual_best_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const int* __restrict__ lev0, const int* __restrict__ lev1,
-                     int nb, uint64_t* __restrict__ best) {
+                     int nb, uint64_t* __restrict__ best, uint64_t* __restrict__ tot, int n_tot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    for (int t = i; t < n_tot; t += gridDim.x * 256) tot[t] = 0;   // the totals this step accumulates into
     if (i >= sb_count) return;
     uint64_t b = (uint64_t)1 << 63;
     for (int g = 0; g < nb; g++) {
@@ -140,29 +141,29 @@ one_dual_best_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restri
     }
     best[i] = b;
 }
+// tot[j][k] += sum over a chunk of filter blocks of min(best, mse0[i][j] + mse1[i][k]): one workgroup per (j, chunk), lanes along k so that the
+// mse1 rows are read as whole 512-byte lines and mse0[i][j] is a broadcast; the totals are accumulated with 64-bit atomics (integers: any order)
+constexpr int kDualChunk = 128;
 __global__ void __launch_bounds__(256)
 one_dual_total_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const uint64_t* __restrict__ best, int start_gi, int ng,
-                      uint64_t* __restrict__ tot) {
-    __shared__ unsigned long long part[4];
-    const int j = start_gi + blockIdx.x / ng, k = start_gi + blockIdx.x % ng;
+                      unsigned long long* __restrict__ tot) {
+    __shared__ unsigned long long part[4][64];
+    const int j = start_gi + blockIdx.x, kk = threadIdx.x & 63, r = threadIdx.x >> 6, k = start_gi + kk;
+    const int i0 = blockIdx.y * kDualChunk, i1 = min(i0 + kDualChunk, sb_count);
     unsigned long long acc = 0;
-    for (int i = threadIdx.x; i < sb_count; i += 256) {
-        const uint64_t c = mse0[(size_t)i * 64 + j] + mse1[(size_t)i * 64 + k], b = best[i];
-        acc += c < b ? c : b;
-    }
-    acc = wave_sum_u64(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if (kk < ng)
+        for (int i = i0 + r; i < i1; i += 4) {
+            const uint64_t c = mse0[(size_t)i * 64 + j] + mse1[(size_t)i * 64 + k], b = best[i];
+            acc += c < b ? c : b;
+        }
+    part[r][kk] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) tot[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-}
-// joint_strength_search_dual's refinement step: drop the oldest pair (lev[j] = lev[j + 1]) before the next search fills slot nb - 1
-__global__ void one_dual_shift_kernel(int* __restrict__ lev0, int* __restrict__ lev1, int nb) {
-    if (threadIdx.x == 0)
-        for (int j = 0; j < nb - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+    if (r == 0 && kk < ng) atomicAdd(&tot[blockIdx.x * ng + kk], part[0][kk] + part[1][kk] + part[2][kk] + part[3][kk]);
 }
 // the first minimum in (j, k) raster order; out[0] = its total, lev0[nb] / lev1[nb] = the pair
+// shift_after: joint_strength_search_dual's refinement drops the oldest pair before its next search (lev[j] = lev[j + 1], j < n_shift - 1)
 __global__ void __launch_bounds__(64)
-one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out) {
+one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out, int n_shift) {
     const int lane = threadIdx.x;
     uint64_t  bv = (uint64_t)1 << 63;
     int       bi = 0x7fffffff;
@@ -179,6 +180,7 @@ one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int
         lev0[nb] = any ? start_gi + bi / ng : 0;
         lev1[nb] = any ? start_gi + bi % ng : 0;
         out[0] = bv;
+        for (int j = 0; j < n_shift - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
     }
 }
 
@@ -416,24 +418,30 @@ extern "C" int svt_hip_launch_cdef_dist(hipStream_t st, int pix_bytes, const voi
     else hipLaunchKernelGGL(cdef_dist_kernel<uint16_t>, dim3(1), dim3(256), 0, st, (const uint16_t*)dst, dstride, (const uint16_t*)src, list, n, bw_log2, bh_log2, cs, pli, out);
     return (int)hipGetLastError();
 }
-extern "C" int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
-                                              uint64_t* best, uint64_t* tot, uint64_t* out) {
-    const int ng = end_gi - start_gi;
-    if (sb_count > 0) hipLaunchKernelGGL(one_dual_best_kernel, dim3((sb_count + 255) / 256), dim3(256), 0, st, mse0, mse1, sb_count, lev0, lev1, nb, best);
-    if (ng > 0) hipLaunchKernelGGL(one_dual_total_kernel, dim3(ng * ng), dim3(256), 0, st, mse0, mse1, sb_count, best, start_gi, ng, tot);
-    hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(64), 0, st, tot, start_gi, ng > 0 ? ng : 0, nb, lev0, lev1, out);
+static int one_dual_step(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi, uint64_t* best,
+                         uint64_t* tot, uint64_t* out, int n_shift) {
+    const int ng = end_gi - start_gi > 0 ? end_gi - start_gi : 0;
+    hipLaunchKernelGGL(one_dual_best_kernel, dim3(sb_count > 0 ? (sb_count + 255) / 256 : 1), dim3(256), 0, st, mse0, mse1, sb_count, lev0, lev1, nb, best, tot, ng * ng);
+    if (ng > 0 && sb_count > 0)
+        hipLaunchKernelGGL(one_dual_total_kernel, dim3(ng, (sb_count + kDualChunk - 1) / kDualChunk), dim3(256), 0, st, mse0, mse1, sb_count, best, start_gi, ng,
+                           (unsigned long long*)tot);
+    hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(64), 0, st, tot, start_gi, ng, nb, lev0, lev1, out, n_shift);
     return (int)hipGetLastError();
 }
-// joint_strength_search_dual (EbEncCdef.c:1140-1164): nb greedy steps, then 4 * nb refinement steps, all queued back to back
+extern "C" int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
+                                              uint64_t* best, uint64_t* tot, uint64_t* out) {
+    return one_dual_step(st, mse0, mse1, sb_count, lev0, lev1, nb, start_gi, end_gi, best, tot, out, 0);
+}
+// joint_strength_search_dual (EbEncCdef.c:1140-1164): nb greedy steps, then 4 * nb refinement steps (each preceded by the shift, which the previous
+// step's last kernel performs), all queued back to back: three launches per step
 extern "C" int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi,
                                                     int end_gi, uint64_t* best, uint64_t* tot, uint64_t* out) {
     for (int i = 0; i < nb; i++) {
-        const int rc = svt_hip_launch_search_one_dual(st, mse0, mse1, sb_count, lev0, lev1, i, start_gi, end_gi, best, tot, out);
+        const int rc = one_dual_step(st, mse0, mse1, sb_count, lev0, lev1, i, start_gi, end_gi, best, tot, out, i == nb - 1 ? nb : 0);
         if (rc) return rc;
     }
     for (int i = 0; i < 4 * nb; i++) {
-        hipLaunchKernelGGL(one_dual_shift_kernel, dim3(1), dim3(64), 0, st, lev0, lev1, nb);
-        const int rc = svt_hip_launch_search_one_dual(st, mse0, mse1, sb_count, lev0, lev1, nb - 1, start_gi, end_gi, best, tot, out);
+        const int rc = one_dual_step(st, mse0, mse1, sb_count, lev0, lev1, nb - 1, start_gi, end_gi, best, tot, out, i == 4 * nb - 1 ? 0 : nb);
         if (rc) return rc;
     }
     return (int)hipGetLastError();
