@@ -342,7 +342,7 @@ def main():
     main_streams = [torch.cuda.Stream() for _ in range(max_f)]
     side_streams = [torch.cuda.Stream() for _ in range(max_f)] if args.side else None
 
-    def batch_step(batch, stages=stages):
+    def batch_step(batch, stages=stages, pre=None):
         base = cur["s"]
         used = []
         for i, P in enumerate(batch):
@@ -358,6 +358,7 @@ def main():
                         if k in SOURCE_SIDE:
                             P.stage_fns[k]()
             with on(ms):
+                if pre is not None: pre(P)
                 for k, _ in stages:
                     if side_streams is None or k not in SOURCE_SIDE:
                         P.stage_fns[k]()
@@ -384,15 +385,15 @@ def main():
 
     use_graph = not args.no_graph
 
-    def make_steps(f, stage_list=stages):
-        """the rotating step functions for batches of f frames over all pipelines"""
+    def make_steps(f, stage_list=stages, pre=None):
+        """the rotating step functions for batches of f frames over all pipelines (pre(P): extra launches at the head of a frame's chain)"""
         batches = [pipes[i:i + f] for i in range(0, len(pipes) - f + 1, f)]
         for b in batches:
-            batch_step(b, stage_list)           # eager once: first-touch, lazy module loads
+            batch_step(b, stage_list, pre)      # eager once: first-touch, lazy module loads
         torch.cuda.synchronize()
         if use_graph:
-            return [capture(lambda b=b: batch_step(b, stage_list)).replay for b in batches]
-        return [lambda b=b: batch_step(b, stage_list) for b in batches]
+            return [capture(lambda b=b: batch_step(b, stage_list, pre)).replay for b in batches]
+        return [lambda b=b: batch_step(b, stage_list, pre) for b in batches]
 
     def timed(fns, steps, warmup, barrier):
         for i in range(warmup):
@@ -480,7 +481,11 @@ def main():
     #      i+1 and downloads of batch i-1 overlap the compute of batch i
     with_transfers = None
     if not args.no_transfers and world == 1 and len(step_fns) >= 2:
-        with_transfers = measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, max(10, min(args.steps, 40)))
+        def unpad(P):   # the un-padded views the transform / filter stages read: device-to-device, at the head of the frame's own chain (a kernel on the
+            # copy stream would queue behind a whole step's launches: ROCm runs the streams on a few in-order hardware queues)
+            P.d_cur[0].copy_(P.d_cur_p[P.F.pad:P.F.pad + P.F.h, P.F.pad:P.F.pad + P.F.w], non_blocking=True)
+            P.d_vp[:P.F.h, :P.F.w].copy_(P.d_cur[0], non_blocking=True)
+        with_transfers = measure_with_transfers(torch, stream, pipes, nF, make_steps(nF, stages, unpad), n_sb, max(10, min(args.steps, 40)))
 
     if rank != 0:
         if world > 1:
@@ -555,7 +560,7 @@ def main():
 
 def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
-    up_s, down_s = torch.cuda.Stream(), torch.cuda.Stream()   # PCIe is full duplex: uploads and downloads get a stream each
+    up_s = down_s = torch.cuda.Stream()   # one in-order copy stream (see run())
     pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host = []
     up_bytes = down_bytes = 0
@@ -575,8 +580,6 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
             for P in batches[b]:
                 for d, h in host[idx[id(P)]][0]:
                     d.copy_(h, non_blocking=True)
-                P.d_cur[0].copy_(P.d_cur_p[P.F.pad:P.F.pad + P.F.h, P.F.pad:P.F.pad + P.F.w], non_blocking=True)   # un-padded view of the luma for the transform / filter stages (device-to-device)
-                P.d_vp[:P.F.h, :P.F.w].copy_(P.d_cur[0], non_blocking=True)
             up_done[b].record(up_s)
 
     def download(b):
@@ -596,6 +599,8 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     do_up, do_down = mode in ("up", "both"), mode in ("down", "both")
 
     def run(n):
+        # ONE copy stream, commands in the order they can run: the next batch's upload (it only waits for the step before this one) goes in ahead of
+        # this step's download (which waits for this step), so the upload is never queued behind a wait it does not depend on
         if do_up: upload(0)
         for i in range(n):
             b = i % nb
@@ -603,9 +608,8 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
             if do_down and i >= nb: stream.wait_event(down_done[b])   # the results of this batch's previous step have left the device
             step_fns[b]()
             comp_done[b].record(stream)
+            if do_up and i + 1 < n: upload((i + 1) % nb)
             if do_down: download(b)
-            if do_up and i + 1 < n:
-                upload((i + 1) % nb)      # waits (on the copy stream) for the step that last used those buffers
         torch.cuda.synchronize()
 
     run(3)
@@ -614,7 +618,7 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     t = time.perf_counter() - t0
     return {"value": nF * n_sb * steps / t, "unit": "SB/s", "ms_per_step": t / steps * 1e3, "h2d_bytes_per_frame": up_bytes, "d2h_bytes_per_frame": down_bytes,
             "note": "every step uploads its frames' source pictures (padded luma, U, V) from pinned host memory and downloads ME tables, CDEF distortion table, restoration "
-                    "search results and the restored picture, on an upload and a download stream overlapped with the neighbouring steps' compute"}
+                    "search results and the restored picture, on one copy stream (next batch's upload, then this batch's download) next to the neighbouring steps' compute"}
 
 
 def roofline(per_stage, stages, n_sb):
