@@ -684,6 +684,17 @@ int svt_hip_cdef_search_one_dual_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, con
  * [8] receive the selected pairs, d_work[0] the total; d_work: 4097 + sb_count uint64 of scratch. */
 int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
                                            int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
+/* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once: the chains are independent, one
+ * launch per step index advances all that are still running (40 launches instead of 225).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
+ * cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each count and the totals). */
+typedef struct {
+    int32_t  lev0[4][8], lev1[4][8]; /* [log2 nb_strengths][pair]: cdef_y_strength / cdef_uv_strength indices */
+    uint32_t reserved[4];
+    uint64_t tot_mse[4];
+} SvtHipCdefSelectResult;
+#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)4 * 2 * 4096 * 8)
+int svt_hip_cdef_strength_select_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int start_gi, int end_gi, void *d_state,
+                                     size_t state_bytes);
 /* The self-guided projection on MATERIALISED filter planes (the form the reference's pointers have; the frame kernels never write flt0 / flt1):
  * mode 0 = svt_get_proj_subspace (common_dsp_rtcd.h; EbRestorationPick.c:448): d_acc[5] = {H00, H01, H11, C0, C1} as exact integers, d_xq[2] = the
  * solved pair; mode 1 = svt_av1_lowbd_pixel_proj_error / svt_av1_highbd_pixel_proj_error (:174, :244): d_acc[0] = the squared error of the

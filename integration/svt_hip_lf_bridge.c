@@ -819,34 +819,47 @@ void svt_hip_hook_picture_done(PictureControlSet *pcs) {
 }
 
 /* ------------------------------------------------------------------ hook "cdef_finish": joint_strength_search_dual inside finish_cdef_search
- * (EbEncCdef.c:1258: four calls per picture, nb_strengths = 1, 2, 4, 8).  The two distortion tables of the non-skipped filter blocks travel once per
- * call; the greedy + refinement steps run back to back on the device; 16 strengths indices and the total come back.  1 = handled. */
+ * (EbEncCdef.c:1258: four calls per picture, nb_strengths = 1, 2, 4, 8).  The first call of a picture sends the two distortion tables of the non-skipped
+ * filter blocks and runs all four independent searches side by side (svt_hip_cdef_strength_select_dev: one launch per step index, no host round trip);
+ * the three calls that follow read their result from the same download.  1 = handled. */
+static __thread struct {
+    const void            *key0, *key1; /* the tables the cached result belongs to */
+    int32_t                sb_count, start_gi, end_gi;
+    int                    valid;
+    SvtHipCdefSelectResult res;
+} tls_sel;
+
 int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32_t nb_strengths, uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi,
                                    int32_t end_gi, uint64_t *tot_mse) {
-    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_FINISH) || sb_count < 0 || nb_strengths < 1 || nb_strengths > 8) return 0;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return 0;
-    const size_t mb = (size_t)sb_count * 64 * sizeof(uint64_t);
-    void        *d_m0 = NULL, *d_m1 = NULL, *d_lev = NULL, *d_work = NULL;
-    int32_t      lev[16] = {0};
-    int          rc = svt_hip_malloc(hip, &d_m0, mb + 8);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_m1, mb + 8);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_lev, sizeof(lev));
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_work, (4097 + (size_t)sb_count) * sizeof(uint64_t));
-    if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m0, mse[0], mb);
-    if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m1, mse[1], mb);
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_lev, lev, sizeof(lev));
-    if (rc == SVT_HIP_OK)
-        rc = svt_hip_cdef_joint_strength_search_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, (int *)d_lev, (int *)d_lev + 8, nb_strengths, start_gi, end_gi,
-                                                    (uint64_t *)d_work);
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, lev, d_lev, sizeof(lev));
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, tot_mse, d_work, sizeof(uint64_t));
-    svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_lev); svt_hip_free(hip, d_work);
-    if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength selection on the device failed (%s): C search\n", svt_hip_last_error(hip));
-    svt_hip_hooks_unlock();
-    svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_FINISH, rc == SVT_HIP_OK);
-    if (rc != SVT_HIP_OK) return 0;
-    for (int i = 0; i < nb_strengths; i++) { best_lev0[i] = lev[i]; best_lev1[i] = lev[8 + i]; }
-    svt_hip_hooks_log("cdef_finish: %d strength pairs over %d filter blocks, total %llu", nb_strengths, sb_count, (unsigned long long)*tot_mse);
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_FINISH) || sb_count < 0 || (nb_strengths != 1 && nb_strengths != 2 && nb_strengths != 4 && nb_strengths != 8)) return 0;
+    const int ci = nb_strengths == 1 ? 0 : (nb_strengths == 2 ? 1 : (nb_strengths == 4 ? 2 : 3));
+    if (nb_strengths == 1 || !tls_sel.valid || tls_sel.key0 != (const void *)mse[0] || tls_sel.key1 != (const void *)mse[1] || tls_sel.sb_count != sb_count ||
+        tls_sel.start_gi != start_gi || tls_sel.end_gi != end_gi) {
+        tls_sel.valid = 0;
+        SvtHipCtx *hip = svt_hip_hooks_lock();
+        if (!hip) return 0;
+        const size_t mb = (size_t)sb_count * 64 * sizeof(uint64_t);
+        void        *d_m0 = NULL, *d_m1 = NULL, *d_state = NULL;
+        int          rc = svt_hip_malloc(hip, &d_m0, mb + 8);
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_m1, mb + 8);
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+        if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m0, mse[0], mb);
+        if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m1, mse[1], mb);
+        if (rc == SVT_HIP_OK)
+            rc = svt_hip_cdef_strength_select_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, start_gi, end_gi, d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+        if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &tls_sel.res, d_state, sizeof(tls_sel.res));
+        svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state);
+        if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength selection on the device failed (%s): C search\n", svt_hip_last_error(hip));
+        svt_hip_hooks_unlock();
+        svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_FINISH, rc == SVT_HIP_OK);
+        if (rc != SVT_HIP_OK) return 0;
+        tls_sel.key0 = mse[0]; tls_sel.key1 = mse[1]; tls_sel.sb_count = sb_count; tls_sel.start_gi = start_gi; tls_sel.end_gi = end_gi; tls_sel.valid = 1;
+        svt_hip_hooks_log("cdef_finish: strength pairs for 1 / 2 / 4 / 8 over %d filter blocks in one pass, totals %llu %llu %llu %llu", sb_count,
+                          (unsigned long long)tls_sel.res.tot_mse[0], (unsigned long long)tls_sel.res.tot_mse[1], (unsigned long long)tls_sel.res.tot_mse[2],
+                          (unsigned long long)tls_sel.res.tot_mse[3]);
+    }
+    for (int i = 0; i < nb_strengths; i++) { best_lev0[i] = tls_sel.res.lev0[ci][i]; best_lev1[i] = tls_sel.res.lev1[ci][i]; }
+    *tot_mse = tls_sel.res.tot_mse[ci];
+    if (nb_strengths == 8) tls_sel.valid = 0;   /* the picture's last call */
     return 1;
 }

@@ -114,6 +114,20 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *c, const uint64_t *m0, con
     return SVT_HIP_OK;
 }
 
+int svt_hip_cdef_strength_select_dev(SvtHipCtx *c, const uint64_t *m0, const uint64_t *m1, int sb_count, int start_gi, int end_gi, void *state, size_t state_bytes) {
+    if (state_bytes < sizeof(SvtHipCdefSelectResult)) return SVT_HIP_ERR_BAD_ARG;
+    SvtHipCdefSelectResult *r = (SvtHipCdefSelectResult *)state;
+    memset(r, 0, sizeof(*r));
+    for (int ci = 0; ci < 4; ci++) {
+        int      lev0[8] = {0}, lev1[8] = {0};
+        uint64_t work[1];
+        svt_hip_cdef_joint_strength_search_dev(c, m0, m1, sb_count, lev0, lev1, 1 << ci, start_gi, end_gi, work);
+        for (int i = 0; i < 8; i++) { r->lev0[ci][i] = lev0[i]; r->lev1[ci][i] = lev1[i]; }
+        r->tot_mse[ci] = work[0];
+    }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ picture analysis */
 int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
     (void)c;

@@ -207,6 +207,7 @@ def lib():
     L.svt_hip_cdef_dist_dev.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svt_hip_cdef_search_one_dual_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     L.svt_hip_cdef_joint_strength_search_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    L.svt_hip_cdef_strength_select_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_size_t]
     L.svt_hip_sgr_flt_proj_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.svt_hip_convolve8_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32]
     L.svt_hip_wiener_convolve_add_src_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32]

@@ -161,26 +161,115 @@ one_dual_total_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restr
     if (r == 0 && kk < ng) atomicAdd(&tot[blockIdx.x * ng + kk], part[0][kk] + part[1][kk] + part[2][kk] + part[3][kk]);
 }
 // the first minimum in (j, k) raster order; out[0] = its total, lev0[nb] / lev1[nb] = the pair
-// shift_after: joint_strength_search_dual's refinement drops the oldest pair before its next search (lev[j] = lev[j + 1], j < n_shift - 1)
-__global__ void __launch_bounds__(64)
-one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out, int n_shift) {
-    const int lane = threadIdx.x;
-    uint64_t  bv = (uint64_t)1 << 63;
-    int       bi = 0x7fffffff;
-    for (int i = lane; i < ng * ng; i += 64)
-        if (tot[i] < bv) { bv = tot[i]; bi = i; }
+// first minimum of tot[0..n) in index order, by the 256 threads of a workgroup (result valid in thread 0); loads issued back to back
+__device__ __forceinline__ void block_argmin_first(const unsigned long long* tot, int n, unsigned long long& bv, int& bi) {
+    __shared__ unsigned long long s_v[256];
+    __shared__ int                s_i[256];
+    unsigned long long v[16];
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint64_t ov = ((uint64_t)(unsigned)__shfl_xor((int)(bv >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)bv, m, 64);
-        const int      oi = __shfl_xor(bi, m, 64);
-        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int t = 0; t < 16; t++) { const int i = threadIdx.x + 256 * t; v[t] = i < n ? ((const volatile unsigned long long*)tot)[i] : ~0ull; }
+    bv = (unsigned long long)1 << 63; bi = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < 16; t++) { const int i = threadIdx.x + 256 * t; if (i < n && v[t] < bv) { bv = v[t]; bi = i; } }
+    s_v[threadIdx.x] = bv; s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            const unsigned long long ov = s_v[threadIdx.x + m];
+            const int                oi = s_i[threadIdx.x + m];
+            if (ov < s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
     }
-    if (lane == 0) {
+    bv = s_v[0]; bi = s_i[0];
+}
+// shift_after: joint_strength_search_dual's refinement drops the oldest pair before its next search (lev[j] = lev[j + 1], j < n_shift - 1)
+// the first minimum in (j, k) raster order; out[0] = its total, lev0[nb] / lev1[nb] = the pair
+__global__ void __launch_bounds__(256)
+one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int nb, int* __restrict__ lev0, int* __restrict__ lev1, uint64_t* __restrict__ out, int n_shift) {
+    unsigned long long bv;
+    int                bi;
+    block_argmin_first((const unsigned long long*)tot, ng * ng, bv, bi);
+    if (threadIdx.x == 0) {
         const bool any = bi != 0x7fffffff;   // nothing below 1 << 63: the reference keeps (0, 0)
         lev0[nb] = any ? start_gi + bi / ng : 0;
         lev1[nb] = any ? start_gi + bi % ng : 0;
         out[0] = bv;
         for (int j = 0; j < n_shift - 1; j++) { lev0[j] = lev0[j + 1]; lev1[j] = lev1[j + 1]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ CDEF: the whole strength-pair selection of a picture
+// finish_cdef_search runs joint_strength_search_dual for 1, 2, 4 and 8 pairs (EbEncCdef.c:1258): four independent chains of 5, 10, 20 and 40
+// svt_search_one_dual steps.  One launch per step index advances every chain that is still running (blockIdx.z = chain); a step is ONE kernel: the
+// workgroups form the running best of their filter blocks on the fly, accumulate the totals with 64-bit atomics, and the workgroup that finishes
+// last picks the pair, shifts the list when the next step is a refinement step, clears the totals of the next step and resets the counter.
+struct JointState {
+    int lev0[4][8], lev1[4][8];
+    unsigned int counter[4];
+    unsigned long long result[4];          // total of the chain's last step
+    unsigned long long tot[4][2][4096];    // double-buffered by step parity
+};
+constexpr int kJointRows = 32;   // filter blocks per workgroup
+__global__ void __launch_bounds__(256)
+joint_step_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, int step, JointState* __restrict__ S) {
+    const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
+    if (step >= total_steps) return;
+    const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
+    __shared__ int s_l0[8], s_l1[8];
+    __shared__ bool s_last;
+    __shared__ unsigned long long s_best[kJointRows];
+    if (threadIdx.x < 8) { s_l0[threadIdx.x] = S->lev0[c][threadIdx.x]; s_l1[threadIdx.x] = S->lev1[c][threadIdx.x]; }
+    __syncthreads();
+    const int i0 = blockIdx.x * kJointRows, i1 = min(i0 + kJointRows, sb_count);
+    unsigned long long* tot = S->tot[c][step & 1];
+    // the running best of this workgroup's filter blocks over the pairs selected so far
+    if ((int)threadIdx.x < kJointRows && i0 + (int)threadIdx.x < i1) {
+        const uint64_t *a = mse0 + (size_t)(i0 + threadIdx.x) * 64, *b = mse1 + (size_t)(i0 + threadIdx.x) * 64;
+        uint64_t best = (uint64_t)1 << 63;
+        for (int g = 0; g < idx; g++) { const uint64_t v = a[s_l0[g]] + b[s_l1[g]]; best = v < best ? v : best; }
+        s_best[threadIdx.x] = best;
+    }
+    __syncthreads();
+    // lane = chroma strength k, wave = 16 consecutive luma strengths j: mse1[i][k] is loaded once per row and reused for the wave's 16 totals
+    const int kk = threadIdx.x & 63, jg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 16;
+    unsigned long long acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) acc[t] = 0;
+    if (kk < ng)
+        for (int i = i0; i < i1; i++) {
+            const uint64_t bk = mse1[(size_t)i * 64 + start_gi + kk], best = s_best[i - i0];
+            const uint64_t* a = mse0 + (size_t)i * 64 + start_gi + jg;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (jg + t < ng) { const uint64_t v = a[t] + bk; acc[t] += v < best ? v : best; }
+            }
+        }
+    if (kk < ng) {
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (jg + t < ng) atomicAdd(&tot[(jg + t) * ng + kk], acc[t]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&S->counter[c], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // the last workgroup of this chain's step: first minimum in (j, k) raster order
+    unsigned long long bv;
+    int                bi;
+    block_argmin_first(tot, ng * ng, bv, bi);
+    unsigned long long* next = S->tot[c][(step + 1) & 1];
+    for (int t = threadIdx.x; t < ng * ng; t += 256) next[t] = 0;
+    if (threadIdx.x == 0) {
+        const bool any = bi != 0x7fffffff;
+        S->lev0[c][idx] = any ? start_gi + bi / ng : 0;
+        S->lev1[c][idx] = any ? start_gi + bi % ng : 0;
+        S->result[c] = bv;
+        if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
+            for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
+        S->counter[c] = 0;
     }
 }
 
@@ -425,7 +514,7 @@ static int one_dual_step(hipStream_t st, const uint64_t* mse0, const uint64_t* m
     if (ng > 0 && sb_count > 0)
         hipLaunchKernelGGL(one_dual_total_kernel, dim3(ng, (sb_count + kDualChunk - 1) / kDualChunk), dim3(256), 0, st, mse0, mse1, sb_count, best, start_gi, ng,
                            (unsigned long long*)tot);
-    hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(64), 0, st, tot, start_gi, ng, nb, lev0, lev1, out, n_shift);
+    hipLaunchKernelGGL(one_dual_pick_kernel, dim3(1), dim3(256), 0, st, tot, start_gi, ng, nb, lev0, lev1, out, n_shift);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
@@ -444,6 +533,16 @@ extern "C" int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64
         const int rc = one_dual_step(st, mse0, mse1, sb_count, lev0, lev1, nb - 1, start_gi, end_gi, best, tot, out, i == 4 * nb - 1 ? 0 : nb);
         if (rc) return rc;
     }
+    return (int)hipGetLastError();
+}
+extern "C" size_t svt_hip_joint_state_bytes(void) { return sizeof(JointState); }
+// out[c] = {total, lev0[8], lev1[8]} as 64-bit words (17 per chain) is assembled by the caller from the state; here: clear, 40 steps
+extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state) {
+    const int ng = end_gi - start_gi;
+    if (hipMemsetAsync(state, 0, sizeof(JointState), st) != hipSuccess) return (int)hipGetLastError();
+    if (ng <= 0) return 0;
+    const dim3 grid(sb_count > 0 ? (sb_count + kJointRows - 1) / kJointRows : 1, 1, 4);
+    for (int step = 0; step < 40; step++) hipLaunchKernelGGL(joint_step_kernel, grid, dim3(256), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,

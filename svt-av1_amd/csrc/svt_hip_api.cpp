@@ -1061,6 +1061,14 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx* c, const uint64_t* d_mse0,
     if (e != hipSuccess) return fail(c, e, "joint strength search launch");
     return SVT_HIP_OK;
 }
+int svt_hip_cdef_strength_select_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, int start_gi, int end_gi, void* d_state, size_t state_bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mse0 || !d_mse1 || !d_state || sb_count < 0 || start_gi < 0 || end_gi > 64 || start_gi > end_gi || state_bytes < svt_hip_joint_state_bytes())
+        return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_strength_select(c->stream, d_mse0, d_mse1, sb_count, start_gi, end_gi, d_state);
+    if (e != hipSuccess) return fail(c, e, "strength select launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_flt_proj_dev(SvtHipCtx* c, int pix_bytes, const void* d_src, int src_stride, const void* d_dat, int dat_stride, const int32_t* d_flt0, int flt0_stride,
                              const int32_t* d_flt1, int flt1_stride, int w, int h, int r0, int r1, int mode, const int32_t* xq, int64_t* d_acc, int32_t* d_xq) {
     SVT_HIP_ENTER(c);

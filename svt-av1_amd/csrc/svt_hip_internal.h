@@ -119,6 +119,8 @@ int svt_hip_launch_cdef_dist(hipStream_t st, int pix_bytes, const void* dst, int
                              int pli, uint64_t* out);
 int svt_hip_launch_search_one_dual(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
                                    uint64_t* best, uint64_t* tot, uint64_t* out);
+size_t svt_hip_joint_state_bytes(void);
+int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state);
 int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
                                          uint64_t* best, uint64_t* tot, uint64_t* out);
 int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s, int w,

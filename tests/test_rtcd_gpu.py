@@ -890,7 +890,12 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         m0[:, 11] = m0[:, 2]; m1[:, 9] = m1[:, 4]
         ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
         d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
-        for nb in (1, 2, 4, 8):
+        state_bytes = 304 + 4 * 2 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+        d_state = hip.empty(state_bytes)
+        hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
+        sel = hip.to_host(d_state, (304,), np.uint8)
+        sel_lev0 = sel[:128].view(np.int32).reshape(4, 8); sel_lev1 = sel[128:256].view(np.int32).reshape(4, 8); sel_tot = sel[272:304].view(np.uint64)
+        for ci, nb in enumerate((1, 2, 4, 8)):
             l0 = np.zeros(8, np.int32); l1 = np.zeros(8, np.int32)
             f = _as(ONEDUAL, ref.svt_search_one_dual_c)
             for i in range(nb): tot = f(_vp(l0), _vp(l1), i, C.cast(ptrs, C.c_void_p), sb_count, start, end)
@@ -901,5 +906,9 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
             hip.check(L.svt_hip_cdef_joint_strength_search_dev(hip.h, d_m0, d_m1, sb_count, d_lev, C.c_void_p(d_lev.value + 32), nb, start, end, d_work), "joint strength search")
             lev = hip.to_host(d_lev, (16,), np.int32); got_tot = int(hip.to_host(d_work, (1,), np.uint64)[0])
             assert got_tot == tot and np.array_equal(lev[:nb], l0[:nb]) and np.array_equal(lev[8:8 + nb], l1[:nb]), ("joint search", sb_count, nb, got_tot, tot, lev, l0, l1)
+            # ... and the four chains of the picture-level call
+            assert int(sel_tot[ci]) == tot and np.array_equal(sel_lev0[ci, :nb], l0[:nb]) and np.array_equal(sel_lev1[ci, :nb], l1[:nb]), \
+                ("strength select", sb_count, nb, int(sel_tot[ci]), tot, sel_lev0[ci], l0, sel_lev1[ci], l1)
             hip.free(d_lev, d_work)
+        hip.free(d_state)
         hip.free(d_m0, d_m1)

@@ -31,4 +31,13 @@ with torch.cuda.stream(st):
     for _ in range(5): g.replay()
     g1.record(st); torch.cuda.synchronize()
 print(f"the same as one captured HIP graph: {g0.elapsed_time(g1) / 5:.3f} ms per frame")
+d_state = hip.empty(304 + 4 * 2 * 4096 * 8)
+def run2(): hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, n, 0, 64, d_state, 304 + 4 * 2 * 4096 * 8), "select")
+with torch.cuda.stream(st):
+    run2(); torch.cuda.synchronize()
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record(st)
+    for _ in range(5): run2()
+    s1.record(st); torch.cuda.synchronize()
+print(f"svt_hip_cdef_strength_select_dev (the four chains side by side, one launch per step index, 40 launches): {s0.elapsed_time(s1) / 5:.3f} ms per frame")
 print(f"cdef strength-pair selection, 2040 filter blocks, nb = 1 + 2 + 4 + 8 (75 steps): {e0.elapsed_time(e1) / 5:.3f} ms per frame (eager launches)")
