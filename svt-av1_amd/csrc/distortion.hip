@@ -54,6 +54,25 @@ block_sse_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __restrict_
     if (lane == 0) out[blk] = s;
 }
 
+// The same sums for lists of LARGE rectangles (restoration units, whole stripes): blockIdx.x = pair, blockIdx.y = a slice of 32 rows repeating every
+// 32 * gridDim.y rows; a wave takes 8 rows of the slice, lanes run along x; partial sums meet in out[pair] by 64-bit atomics (out cleared before).
+template <typename PIX>
+__global__ void __launch_bounds__(256)
+block_sse_rows_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __restrict__ b, int b_stride, const SvtHipBlkPair* __restrict__ pairs,
+                      unsigned long long* __restrict__ out) {
+    const SvtHipBlkPair p = pairs[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long s = 0;
+    for (int row0 = blockIdx.y * 32 + wave * 8; row0 < p.h; row0 += gridDim.y * 32)
+        for (int y = row0; y < min(row0 + 8, (int)p.h); y++) {
+            const PIX* ra = a + (size_t)(p.a_y + y) * a_stride + p.a_x;
+            const PIX* rb = b + (size_t)(p.b_y + y) * b_stride + p.b_x;
+            for (int x = lane; x < p.w; x += 64) { const long long d = (long long)ra[x] - (long long)rb[x]; s += (unsigned long long)(d * d); }
+        }
+    s = wave_sum_u64(s);
+    if (lane == 0 && s) atomicAdd(&out[blockIdx.x], s);
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_coeff_distortion(hipStream_t st, const int32_t* coeff, const int32_t* recon, int n, int nblk, uint64_t* out) {
@@ -64,6 +83,12 @@ extern "C" int svt_hip_launch_coeff_distortion(hipStream_t st, const int32_t* co
 extern "C" int svt_hip_launch_block_sse(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,
                                         const SvtHipBlkPair* pairs, int n, uint64_t* out) {
     if (n <= 0) return 0;
+    if (n <= 2048) {   // few pairs: probably large rectangles (restoration units) — row-sliced form; long lists are small blocks, one wave each
+        if (hipMemsetAsync(out, 0, sizeof(uint64_t) * n, st) != hipSuccess) return (int)hipGetLastError();
+        if (pix_bytes == 1) hipLaunchKernelGGL((block_sse_rows_kernel<uint8_t>), dim3(n, 8), dim3(256), 0, st, (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, pairs, (unsigned long long*)out);
+        else hipLaunchKernelGGL((block_sse_rows_kernel<uint16_t>), dim3(n, 8), dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, pairs, (unsigned long long*)out);
+        return (int)hipGetLastError();
+    }
     if (pix_bytes == 1) hipLaunchKernelGGL((block_sse_kernel<uint8_t>), dim3((n + 3) / 4), dim3(256), 0, st, (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, pairs, n, (unsigned long long*)out);
     else hipLaunchKernelGGL((block_sse_kernel<uint16_t>), dim3((n + 3) / 4), dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, pairs, n, (unsigned long long*)out);
     return (int)hipGetLastError();
