@@ -24,11 +24,14 @@ CASES = {
     "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),
     "360p_8bit_m7": (640, 360, 5, 8, 7, 40, NO_DLF_REST),     # 40 SBs in many ME segments; width % 64 == 0, height % 64 == 40
     "cif_8bit_m4": (352, 288, 5, 8, 4, 45, ALL),              # full filter-level step search, chroma levels searched on their own
-    "328x200_8bit_m6": (328, 200, 4, 8, 6, 33, ALL),          # width % 64 == height % 64 == 8: last filter blocks / restoration stripes narrower than the CDEF halo
+    "328x200_8bit_m6": (328, 200, 4, 8, 6, 33, ALL),
+    "cif_10bit_m8": (352, 288, 5, 10, 8, 36, NO_DLF_REST),    # the fastest preset of this version, 10-bit          # width % 64 == height % 64 == 8: last filter blocks / restoration stripes narrower than the CDEF halo
 }
 GPU_ONLY_CASES = {
     "720p_8bit_m6": (1280, 720, 4, 8, 6, 38, ALL),
     "720p_10bit_m5": (1280, 720, 3, 10, 5, 32, ALL),
+    "cif_8bit_m2": (352, 288, 4, 8, 2, 40, ALL),              # slow presets: several reference pictures per list in ME, wider searches
+    "qcif_8bit_m0": (176, 144, 3, 8, 0, 40, ALL - {"tf_me"}), # 3 frames: the alt-ref filter has a single neighbour pair, its ME batch stays empty
 }
 
 
