@@ -171,7 +171,11 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                     if (b->has[s + i] && b->win_ref[s + i] == ref) { wins[n] = b->win[s + i]; idx[n++] = i; }
                 /* source and reference are the padded luma pictures of two EbPaReferenceObjects of the same sequence: same geometry */
                 if (!ref || ref->stride_y != src_padded->stride_y || ref->origin_x != src_padded->origin_x || ref->origin_y != src_padded->origin_y ||
-                    (src_padded->stride_y & 3)) { b->failed = 1; break; }
+                    (src_padded->stride_y & 3)) {
+                    svt_hip_hooks_log("me: reference picture geometry differs from the source picture: C path for this segment");
+                    b->failed = 1;
+                    break;
+                }
                 SvtHipCtx *hip = svt_hip_hooks_lock();
                 int        rc = hip ? svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
                                                                src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x,
@@ -202,8 +206,10 @@ int svt_hip_hme_sad_loop(int level, const EbPictureBufferDesc *ref_pic, int16_t 
     const uint32_t step = src_stride_raw ? ref_stride / src_stride_raw : 0; /* 2 = every other line (hme_search_method != FULL_SAD_SEARCH) */
     const size_t   off = (size_t)(ref - ref_pic->buffer_y);
     if ((step != 1 && step != 2) || step * src_stride_raw != ref_stride || src_stride_raw != ref_pic->stride_y || block_width > 64 ||
-        block_height * step > 64 || !block_width || !block_height || search_area_width < 1 || search_area_height < 1 || ref < ref_pic->buffer_y) {
+        block_height * step > 64 || !block_width || !block_height || search_area_width < 0 || search_area_height < 0 || ref < ref_pic->buffer_y) {
         b->failed = 1; /* a call shape the batch does not describe: the whole segment goes back to the C path */
+        svt_hip_hooks_log("hme: level %d call shape outside the batch (block %u x %u, strides %u / %u / %u, area %d x %d): C path for this segment",
+                          level, block_width, block_height, src_stride, ref_stride, src_stride_raw, search_area_width, search_area_height);
         return 0;
     }
     if (b->n_job == b->job_cap) {
@@ -255,6 +261,15 @@ static int dev_need(SvtHipCtx *hip, void **d, size_t *cap, size_t bytes) {
     return rc;
 }
 
+/* what hme_level_0 (:1016-1023), hme_level_1 (:1165-1172) and hme_level_2 (:1309-1314) do with svt_sad_loop_kernel's outputs, in the
+ * reference's int16 arithmetic; the centres are written only when a candidate wins (EbComputeSAD_C.c:73) */
+static void hme_finish(HmeJob *j, uint32_t sad, int found, int16_t fx, int16_t fy) {
+    const int16_t x = found ? fx : j->x0, y = found ? fy : j->y0;
+    j->sad = j->sub ? (uint64_t)sad * 2 : sad;
+    j->x = (int16_t)((int16_t)(x + j->x_origin) * (1 << j->shift));
+    j->y = (int16_t)((int16_t)(y + j->y_origin) * (1 << j->shift));
+}
+
 #define HME_TRY(x) do { if (rc == SVT_HIP_OK) rc = (x); } while (0)
 static void flush_hme_level(SvtHipMeBatch *b, int level) {
     const uint32_t first = b->level_first[level], end = b->level_first[level + 1];
@@ -275,15 +290,17 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         uint32_t                   n = 0;
         int                        y_lo = INT_MAX, y_hi = -1;
         for (uint32_t k = g; k < n_all; k++) {
-            const HmeJob *j = &b->job[first + k];
+            HmeJob *j = &b->job[first + k];
             if (j->ref != ref) continue;
             done[k] = 1;
+            if (j->job.sa_w < 1 || j->job.sa_h < 1) continue;   /* an empty search area: no candidate, resolved below */
             sel[n] = k;
             jobs[n++] = j->job;
             if (j->job.ref_y < y_lo) y_lo = j->job.ref_y;
             const int last = j->job.ref_y + j->job.sa_h - 1 + j->job.bh - 1;
             if (last > y_hi) y_hi = last;
         }
+        if (!n) continue;
         if (y_hi >= rows_total) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
         for (uint32_t k = 0; k < n; k++) { jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
         /* only the rows the segment's windows touch travel (a segment is a band of SB rows) */
@@ -301,16 +318,20 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         HME_TRY(svt_hip_memcpy_d2h(hip, xy, b->d_xy, sizeof(int16_t) * 2 * n));
         if (rc != SVT_HIP_OK) break;
         for (uint32_t k = 0; k < n; k++) {
-            HmeJob       *j = &b->job[first + sel[k]];
-            const int     found = sad[k] != 0xffffffu; /* EbComputeSAD_C.c:73: the centres are written only when a candidate wins */
-            const int16_t x = found ? xy[2 * k] : j->x0, y = found ? xy[2 * k + 1] : j->y0;
-            /* hme_level_0 (:1016-1023), hme_level_1 (:1165-1172), hme_level_2 (:1309-1314), in the reference's int16 arithmetic */
-            j->sad = j->sub ? (uint64_t)sad[k] * 2 : sad[k];
-            j->x = (int16_t)((int16_t)(x + j->x_origin) * (1 << j->shift));
-            j->y = (int16_t)((int16_t)(y + j->y_origin) * (1 << j->shift));
+            hme_finish(&b->job[first + sel[k]], sad[k], sad[k] != 0xffffffu, xy[2 * k], xy[2 * k + 1]);
         }
         b->hme_launches++;
         svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows uploaded)", level, n, y_hi - y_lo + 1);
+    }
+    /* A level whose search area the configuration switched down to 0 x 0: svt_sad_loop_kernel leaves the centres as they are, so the level's
+     * arithmetic runs on what the previous search through the same pointers left there -- the previous block of this segment, in the reference's
+     * block-by-block order; for the segment's first block, what was in the context when the block was recorded. */
+    for (uint32_t k = 0; k < n_all && rc == SVT_HIP_OK; k++) {
+        HmeJob *j = &b->job[first + k];
+        if (j->job.sa_w >= 1 && j->job.sa_h >= 1) continue;
+        for (uint32_t p = k; p-- > 0;)
+            if (b->job[first + p].out_x == j->out_x) { j->x0 = b->job[first + p].x; j->y0 = b->job[first + p].y; break; }
+        hme_finish(j, 0xffffffu, 0, 0, 0);
     }
     if (rc != SVT_HIP_OK) {
         SVT_LOG("hierarchical ME level %d on the device failed (%s): C search for this segment\n", level, hip ? svt_hip_last_error(hip) : "no context");
@@ -353,10 +374,12 @@ int svt_hip_me_batch_slot(SvtHipMeBatch *b, int pass, PictureParentControlSet *p
     const int      ph = b->phase[pass], last = pass == b->n_pass - 1;
     const uint32_t i = b->seen[pass]++;
     if (pass == 0) {
-        if (i >= b->cap) b->failed = 1;
+        if (i >= b->cap) { b->failed = 1; svt_hip_hooks_log("me: more blocks than the batch was opened for (%u): C path", b->cap); }
         else { b->sb[i].sb_index = key; b->n0 = i + 1; }
-    } else if (i >= b->n0 || b->sb[i].sb_index != key)
+    } else if (i >= b->n0 || b->sb[i].sb_index != key) {
+        if (!b->failed) svt_hip_hooks_log("me: pass %d visits block %u out of order: C path", pass, key);
         b->failed = 1;
+    }
     if (b->failed) {
         if (last) motion_estimate_sb_hip(pcs, sb_index, sb_origin_x, sb_origin_y, me_ctx, input_ptr, -1); /* the unchanged C path */
         return last;

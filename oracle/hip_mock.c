@@ -65,9 +65,7 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t
 }
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,
                              const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
-    (void)plane_rows;
-    for (int i = 0; i < n_sb; i++)
-        if ((int)sbs[i].width * sbs[i].height > 65536) return SVT_HIP_ERR_UNSUPPORTED;   /* the product's limit */
+    (void)plane_rows;   /* search areas above 65 536 candidates: the product takes its strip kernel, the same results */
     return svt_hip_me_fullpel_frame_dev(c, src, ref, stride, org_x, org_y, sbs, n_sb, sub_sad, best_sad, best_mv);
 }
 int svt_hip_sad_loop_batch_dev(SvtHipCtx *c, const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride,

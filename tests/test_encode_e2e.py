@@ -110,6 +110,56 @@ def test_every_hook_matters(stage, workdir):
     assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"]), f"perturbing {stage} went unnoticed"
 
 
+# Encoder options that change what reaches the hooks.  (extra arguments, --lp): one thread where the unpatched reference itself is not
+# repeatable with eight (segment-based adaptive quantisation; VBR; a 0 x 0 HME level-2 area, whose centres are whatever the thread's previous
+# search left behind -- the bridge reproduces that in the reference's block order).
+OPTION_VARIANTS = {
+    "tiles_2x2": (["-tile-columns", "1", "-tile-rows", "1"], 8),
+    "hme_off": (["-hme", "0"], 8),
+    "hme_level0_only": (["-hme-l1", "0", "-hme-l2", "0"], 8),
+    "search_area_128x48_user_hme": (["-use-default-me-hme", "0", "-search-w", "128", "-search-h", "48"], 1),
+    "screen_content": (["-scm", "1"], 8),             # ME search areas above 65 536 candidates
+    "low_delay_p": (["-pred-struct", "0"], 8),
+    "three_layers": (["-hierarchical-levels", "3"], 8),
+    "altref_7_frames": (["-altref-nframes", "7", "-altref-strength", "6"], 8),
+    "film_grain": (["-film-grain", "8"], 8),          # noise estimation + denoised source
+    "segment_aq": (["-adaptive-quantization", "1"], 1),
+    "sg_mode_1_wiener_mode_1_cdef_level_1": (["-sg-filter-mode", "1", "-wn-filter-mode", "1", "-cdef-level", "1"], 8),
+    "sg_mode_4_wiener_mode_3_cdef_level_4": (["-sg-filter-mode", "4", "-wn-filter-mode", "3", "-cdef-level", "4"], 8),
+    "vbr": (["-rc", "1", "-tbr", "400"], 1),         # with eight threads the rate-control feedback arrives when the pipeline's timing lets it
+}
+
+
+def _check_variant(name, workdir, env, tag):
+    extra, lp = OPTION_VARIANTS[name]
+    w, h, n, bd, preset, q = 352, 288, 6, 8, 6, 38
+    clip = os.path.join(workdir, "variants.src.yuv")
+    if not os.path.exists(clip):
+        E.make_clip(clip, w, h, n, seed=5, bd=bd)
+    key = "variant_" + name
+    if key not in _ref_cache:
+        _ref_cache[key] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, key + ".ref"), extra_args=extra, lp=lp)
+    ref = _ref_cache[key]
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{key}.{tag}"), env_extra=env, extra_args=extra, lp=lp)
+    assert got["ivf"] == ref["ivf"], f"{name}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
+    assert got["recon"] == ref["recon"], f"{name}: reconstruction differs from the reference encoder"
+    assert sum(v[0] for v in got["hooks"].values()) > 20, got["hooks"]
+    assert all(v[1] == 0 for v in got["hooks"].values()), f"{name}: a hook fell back to the C path: {got['hooks']}\n" + got["log"][-2000:]
+    return got
+
+
+@pytest.mark.parametrize("name", list(OPTION_VARIANTS))
+def test_encoder_option_variants_on_cpu_test_double(name, workdir):
+    _check_variant(name, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(OPTION_VARIANTS))
+def test_encoder_option_variants_on_gpu(name, workdir):
+    got = _check_variant(name, workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", list(CASES) + list(GPU_ONLY_CASES))
 def test_hooked_encode_on_gpu(case, workdir):
