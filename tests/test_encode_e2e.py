@@ -148,6 +148,34 @@ def _check_variant(name, workdir, env, tag):
     return got
 
 
+def _check_padded_size(workdir, env, tag):
+    """Source sizes that are not multiples of 8 are coded padded while the reference deblocks, measures and restores on the unpadded extent:
+    the loop-filter hooks hand such pictures back to the C loops (counted as fallbacks), the source-side hooks (picture analysis, temporal filter,
+    HME, ME) work on the padded input exactly like the reference.  Identical output either way."""
+    w, h, n, bd, preset, q = 130, 66, 5, 8, 6, 38
+    clip = os.path.join(workdir, "padded.src.yuv")
+    if not os.path.exists(clip):
+        E.make_clip(clip, w, h, n, seed=11, bd=bd)
+    if "padded" not in _ref_cache:
+        _ref_cache["padded"] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "padded.ref"))
+    ref = _ref_cache["padded"]
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "padded." + tag), env_extra=env)
+    assert got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"], got["log"][-2000:]
+    for hk in ("pa", "hme", "me"):
+        assert got["hooks"][hk][0] > 0 and got["hooks"][hk][1] == 0, got["hooks"]
+    for hk in ("dlf", "dlf_search", "cdef_apply", "rest_apply"):
+        assert got["hooks"][hk][0] == 0 and got["hooks"][hk][1] > 0, got["hooks"]
+
+
+def test_padded_source_size_on_cpu_test_double(workdir):
+    _check_padded_size(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_padded_source_size_on_gpu(workdir):
+    _check_padded_size(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
 @pytest.mark.parametrize("name", list(OPTION_VARIANTS))
 def test_encoder_option_variants_on_cpu_test_double(name, workdir):
     _check_variant(name, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
