@@ -30,6 +30,9 @@ CASES = {
 GPU_ONLY_CASES = {
     "720p_8bit_m6": (1280, 720, 4, 8, 6, 38, ALL),
     "720p_10bit_m5": (1280, 720, 3, 10, 5, 32, ALL),
+    "cif_8bit_q2": (352, 288, 4, 8, 6, 2, ALL - {"rest_apply"}),   # near-lossless: the largest coefficients; no unit picks a restoration filter
+    "cif_10bit_q60": (352, 288, 4, 10, 6, 60, ALL),           # strongest filtering
+    "cif_8bit_18_frames": (352, 288, 18, 8, 6, 42, ALL),      # more than one mini-GOP
     "cif_8bit_m2": (352, 288, 4, 8, 2, 40, ALL),              # slow presets: several reference pictures per list in ME, wider searches
     "qcif_8bit_m0": (176, 144, 3, 8, 0, 40, ALL - {"tf_me"}), # 3 frames: the alt-ref filter has a single neighbour pair, its ME batch stays empty
 }
