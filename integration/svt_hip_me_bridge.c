@@ -275,11 +275,12 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
     const uint32_t first = b->level_first[level], end = b->level_first[level + 1];
     if (first == end || b->failed) return;
     const uint32_t n_all = end - first;
-    SvtHipSadLoop *jobs = (SvtHipSadLoop *)malloc(sizeof(SvtHipSadLoop) * n_all);
+    SvtHipSadLoop *jobs = (SvtHipSadLoop *)malloc((sizeof(SvtHipSadLoop) + sizeof(uint32_t)) * n_all);
+    uint8_t       *back = (uint8_t *)malloc((sizeof(uint32_t) + 2 * sizeof(int16_t)) * n_all);
     uint32_t      *sel = (uint32_t *)malloc(sizeof(uint32_t) * n_all), *sad = (uint32_t *)malloc(sizeof(uint32_t) * n_all);
     int16_t       *xy = (int16_t *)malloc(sizeof(int16_t) * 2 * n_all);
     uint8_t       *done = (uint8_t *)calloc(n_all, 1);
-    SvtHipCtx     *hip = (jobs && sel && sad && xy && done) ? svt_hip_hooks_lock() : NULL;
+    SvtHipCtx     *hip = (jobs && back && sel && sad && xy && done) ? svt_hip_hooks_lock() : NULL;
     int            rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
     HME_TRY(dev_need(hip, &b->d_src, &b->d_cap[0], (size_t)b->n0 * 64 * 64 + 64));
     HME_TRY(svt_hip_memcpy_h2d(hip, b->d_src, b->src[level], (size_t)b->n0 * 64 * 64));
@@ -306,16 +307,17 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         /* only the rows the segment's windows touch travel (a segment is a band of SB rows) */
         const size_t ref_bytes = (size_t)(y_hi - y_lo + 1) * ref->stride_y;
         HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
-        HME_TRY(dev_need(hip, &b->d_job, &b->d_cap[2], sizeof(SvtHipSadLoop) * n));
-        HME_TRY(dev_need(hip, &b->d_sad, &b->d_cap[3], sizeof(uint32_t) * n));
-        HME_TRY(dev_need(hip, &b->d_xy, &b->d_cap[4], sizeof(int16_t) * 2 * n));
+        /* one upload [searches | initial SADs] and one download [SADs | centres] per launch */
+        const size_t job_bytes = sizeof(SvtHipSadLoop) * n, sad_bytes = sizeof(uint32_t) * n, xy_bytes = sizeof(int16_t) * 2 * n;
+        memcpy((uint8_t *)jobs + job_bytes, sad, sad_bytes);   /* jobs has room for n_all >= n entries of 28 bytes plus their SADs: see the allocation */
+        HME_TRY(dev_need(hip, &b->d_job, &b->d_cap[2], job_bytes + sad_bytes + xy_bytes));
+        uint8_t *d_sad = (uint8_t *)b->d_job + job_bytes, *d_xy = d_sad + sad_bytes;
         HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, ref->buffer_y + (size_t)y_lo * ref->stride_y, ref_bytes));
-        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_job, jobs, sizeof(SvtHipSadLoop) * n));
-        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_sad, sad, sizeof(uint32_t) * n));
+        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_job, jobs, job_bytes + sad_bytes));
         HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
-                                           (int)n, (uint32_t *)b->d_sad, (int16_t *)b->d_xy));
-        HME_TRY(svt_hip_memcpy_d2h(hip, sad, b->d_sad, sizeof(uint32_t) * n));
-        HME_TRY(svt_hip_memcpy_d2h(hip, xy, b->d_xy, sizeof(int16_t) * 2 * n));
+                                           (int)n, (uint32_t *)d_sad, (int16_t *)d_xy));
+        HME_TRY(svt_hip_memcpy_d2h(hip, back, d_sad, sad_bytes + xy_bytes));
+        if (rc == SVT_HIP_OK) { memcpy(sad, back, sad_bytes); memcpy(xy, back + sad_bytes, xy_bytes); }
         if (rc != SVT_HIP_OK) break;
         for (uint32_t k = 0; k < n; k++) {
             hme_finish(&b->job[first + sel[k]], sad[k], sad[k] != 0xffffffu, xy[2 * k], xy[2 * k + 1]);
@@ -338,7 +340,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         b->failed = 1;
     }
     if (hip) svt_hip_hooks_unlock();
-    free(jobs); free(sel); free(sad); free(xy); free(done);
+    free(jobs); free(back); free(sel); free(sad); free(xy); free(done);
 }
 
 /* the level results of SB slot i into the (shared) context, as the reference's calls would have left them */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <limits.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -21,6 +22,8 @@ struct SvtHipCtx {
     size_t      scratch_bytes = 0;
     void*       host_scratch = nullptr;   // pinned host staging of the self-guided unit search
     size_t      host_scratch_bytes = 0;
+    void*       me_buf = nullptr;         // device staging of svt_hip_me_fullpel_frame (host-pointer form), grown on demand
+    size_t      me_buf_bytes = 0;
     std::string err;
 };
 
@@ -74,6 +77,7 @@ void svt_hip_destroy(SvtHipCtx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->host_scratch) (void)hipHostFree(c->host_scratch);
+    if (c->me_buf) (void)hipFree(c->me_buf);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -204,29 +208,42 @@ int svt_hip_me_fullpel_frame(SvtHipCtx* c, const uint8_t* src, const uint8_t* re
         }
         big |= (int)sbs[i].width * (int)sbs[i].height > 65536;
     }
+    if (!n_sb) return SVT_HIP_OK;
+    // Only the rows the windows touch travel (an ME segment is a band of superblock rows), into one staging buffer the context keeps:
+    // [source rows | reference rows | windows | SADs | MVs].  Both planes are uploaded over the same row range so that one origin serves both.
+    int lo = plane_rows, hi = 0;
+    for (int i = 0; i < n_sb; i++) {
+        const int s0 = org_y + sbs[i].sb_y, r0 = s0 + sbs[i].y_origin;
+        lo = std::min(lo, std::min(s0, r0));
+        hi = std::max(hi, std::max(s0 + 64, r0 + (int)sbs[i].height + 63));
+    }
+    lo = std::max(lo, 0);
+    hi = std::min(hi, plane_rows);
+    if (lo >= hi) { lo = 0; hi = plane_rows; }
+    const size_t band = (size_t)stride * (size_t)(hi - lo), nres = (size_t)n_sb * SVT_HIP_SQUARE_PU_COUNT * 4;
+    const size_t off_ref = (band + 256 + 255) & ~(size_t)255 /* slack: dword-aligned window loads may run a few bytes past a row */, off_sbs = 2 * off_ref, off_sad = off_sbs + ((sizeof(SvtHipSbSearch) * (size_t)n_sb + 255) & ~(size_t)255);
+    const size_t off_mv = off_sad + ((nres + 255) & ~(size_t)255), total = off_mv + nres + 256;
+    if (c->me_buf_bytes < total) {
+        if (c->me_buf) (void)hipFree(c->me_buf);
+        c->me_buf = nullptr;
+        c->me_buf_bytes = 0;
+        const hipError_t e = hipMalloc(&c->me_buf, total + total / 4);
+        if (e != hipSuccess) return fail(c, e, "svt_hip_me_fullpel_frame: staging buffer");
+        c->me_buf_bytes = total + total / 4;
+    }
+    uint8_t* const base = (uint8_t*)c->me_buf;
     const int saved_big = c->me_big;
     c->me_big = big;   // the windows are known here: launch the strip-walking instance only when one needs it
-    const size_t plane = (size_t)stride * plane_rows, nres = (size_t)n_sb * SVT_HIP_SQUARE_PU_COUNT * 4;
-    uint8_t *d_src = nullptr, *d_ref = nullptr;
-    SvtHipSbSearch* d_sbs = nullptr;
-    uint32_t *d_sad = nullptr, *d_mv = nullptr;
     int rc = SVT_HIP_OK;
-    if ((rc = svt_hip_malloc(c, (void**)&d_src, plane)) || (rc = svt_hip_malloc(c, (void**)&d_ref, plane)) ||
-        (rc = svt_hip_malloc(c, (void**)&d_sbs, sizeof(SvtHipSbSearch) * (size_t)(n_sb ? n_sb : 1))) ||
-        (rc = svt_hip_malloc(c, (void**)&d_sad, nres)) || (rc = svt_hip_malloc(c, (void**)&d_mv, nres)))
+    if ((rc = svt_hip_memcpy_h2d(c, base, src + (size_t)lo * stride, band)) || (rc = svt_hip_memcpy_h2d(c, base + off_ref, ref + (size_t)lo * stride, band)) ||
+        (rc = svt_hip_memcpy_h2d(c, base + off_sbs, sbs, sizeof(SvtHipSbSearch) * (size_t)n_sb)))
         goto done;
-    if ((rc = svt_hip_memcpy_h2d(c, d_src, src, plane)) || (rc = svt_hip_memcpy_h2d(c, d_ref, ref, plane)) ||
-        (rc = svt_hip_memcpy_h2d(c, d_sbs, sbs, sizeof(SvtHipSbSearch) * (size_t)n_sb)))
+    if ((rc = svt_hip_me_fullpel_frame_dev(c, base, base + off_ref, stride, org_x, org_y - lo, (const SvtHipSbSearch*)(base + off_sbs), n_sb, sub_sad,
+                                           (uint32_t*)(base + off_sad), (uint32_t*)(base + off_mv))))
         goto done;
-    if ((rc = svt_hip_me_fullpel_frame_dev(c, d_src, d_ref, stride, org_x, org_y, d_sbs, n_sb, sub_sad, d_sad, d_mv))) goto done;
-    if ((rc = svt_hip_memcpy_d2h(c, best_sad, d_sad, nres)) || (rc = svt_hip_memcpy_d2h(c, best_mv, d_mv, nres))) goto done;
+    if ((rc = svt_hip_memcpy_d2h(c, best_sad, base + off_sad, nres)) || (rc = svt_hip_memcpy_d2h(c, best_mv, base + off_mv, nres))) goto done;
 done:
     c->me_big = saved_big;
-    if (d_src) (void)hipFree(d_src);
-    if (d_ref) (void)hipFree(d_ref);
-    if (d_sbs) (void)hipFree(d_sbs);
-    if (d_sad) (void)hipFree(d_sad);
-    if (d_mv) (void)hipFree(d_mv);
     return rc;
 }
 
