@@ -102,10 +102,14 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
     const EbPictureBufferDesc *rec = recon_of(pcs, is_16bit);
     const int w = rec->width, h = rec->height, bd = scs->static_config.encoder_bit_depth;
     if ((w & 7) || (h & 7) || (bd != 8 && bd != 10) || scs->subsampling_x != 1 || scs->subsampling_y != 1 || scs->seq_header.sb_size != BLOCK_64X64 ||
-        scs->seq_header.color_config.mono_chrome || scs->max_input_pad_right || scs->max_input_pad_bottom)
+        scs->seq_header.color_config.mono_chrome || scs->max_input_pad_right || scs->max_input_pad_bottom) {
+        svt_hip_hooks_log("loop filter stages: %d x %d (source padded by %d x %d), %d-bit, subsampling %d/%d, superblock %s: not covered, C loops",
+                          w, h, scs->max_input_pad_right, scs->max_input_pad_bottom, bd, scs->subsampling_x, scs->subsampling_y,
+                          scs->seq_header.sb_size == BLOCK_64X64 ? "64" : "128");
         return NULL;   /* outside what the device path covers: the caller keeps its C loop.  Source sizes that are not multiples of 8 are coded
                         * padded, but the reference deblocks (EbDeblockingFilter.c:343-367), measures (picture_sse_calculations: the input picture's
                         * size) and restores (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251: the cropped size) on the unpadded extent */
+    }
     LfState *s = NULL;
     for (int i = 0; i < LF_MAX_IN_FLIGHT && !s; i++)
         if (!g_state[i].pcs && g_state[i].allocated && g_state[i].pic.w == w && g_state[i].pic.h == h && g_state[i].pic.pix_bytes == (is_16bit ? 2 : 1) && g_state[i].pic.bd == bd)
