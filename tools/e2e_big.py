@@ -1,0 +1,23 @@
+"""Run ON THE GPU BOX: the hooked reference encoder against the unpatched one on large pictures (1080p 10-bit, 4K 8-bit), all hooks.
+Too slow for the test suite (the reference side is the C-kernel build); prints one line per case."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_common as E  # noqa: E402
+
+wd = os.path.join(ROOT, "gpurun_out", "e2e_big")
+os.makedirs(wd, exist_ok=True)
+CASES = {"1080p_10bit_m6": (1920, 1080, 3, 10, 6, 34), "2160p_8bit_m8": (3840, 2160, 3, 8, 8, 40), "2160p_8bit_m6": (3840, 2160, 2, 8, 6, 36)}
+for name in sys.argv[1:] or list(CASES):
+    w, h, n, bd, preset, q = CASES[name]
+    clip = os.path.join(wd, name + ".yuv")
+    E.make_clip(clip, w, h, n, seed=17, bd=bd)
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(wd, name + ".ref"), timeout=1200)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(wd, name + ".hip"), env_extra={"SVT_HIP_HOOKS": "all"}, timeout=1200)
+    same = got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"]
+    print(name, "identical" if same else "MISMATCH", "mock!" if "svt_hip MOCK" in got["log"] else "", {k: v for k, v in got["hooks"].items() if v != (0, 0)}, flush=True)
+    for f in os.listdir(wd):
+        if f.startswith(name) and not f.endswith(".txt"):
+            os.remove(os.path.join(wd, f))
