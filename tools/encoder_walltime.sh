@@ -5,7 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/enc_wall
 mkdir -p $OUT
 cd $R
-for geo in "1280 720 8" "1920 1080 8"; do
+IFS=, read -ra GEO_LIST <<< "${GEOS:-1280 720 8,1920 1080 8}"   # GEOS="3840 2160 4" for other sizes
+for geo in "${GEO_LIST[@]}"; do
   set -- $geo; W=$1; H=$2; N=$3
   python - $W $H $N <<'PY'
 import sys; sys.path.insert(0, "tests")
