@@ -129,6 +129,7 @@ OPTION_VARIANTS = {
     "segment_aq": (["-adaptive-quantization", "1"], 1),
     "sg_mode_1_wiener_mode_1_cdef_level_1": (["-sg-filter-mode", "1", "-wn-filter-mode", "1", "-cdef-level", "1"], 8),
     "sg_mode_4_wiener_mode_3_cdef_level_4": (["-sg-filter-mode", "4", "-wn-filter-mode", "3", "-cdef-level", "4"], 8),
+    "two_pass_vbr": (["--passes", "2", "--stats", "{stats}", "--rc", "1", "--tbr", "500"], 1),   # the first pass drives the same hooks
     "vbr": (["-rc", "1", "-tbr", "400"], 1),         # with eight threads the rate-control feedback arrives when the pipeline's timing lets it
 }
 
@@ -141,9 +142,11 @@ def _check_variant(name, workdir, env, tag):
         E.make_clip(clip, w, h, n, seed=5, bd=bd)
     key = "variant_" + name
     if key not in _ref_cache:
-        _ref_cache[key] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, key + ".ref"), extra_args=extra, lp=lp)
+        _ref_cache[key] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, key + ".ref"),
+                                   extra_args=[a.replace("{stats}", os.path.join(workdir, key + ".ref.stat")) for a in extra], lp=lp)
     ref = _ref_cache[key]
-    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{key}.{tag}"), env_extra=env, extra_args=extra, lp=lp)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{key}.{tag}"), env_extra=env,
+                   extra_args=[a.replace("{stats}", os.path.join(workdir, f"{key}.{tag}.stat")) for a in extra], lp=lp)
     assert got["ivf"] == ref["ivf"], f"{name}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
     assert got["recon"] == ref["recon"], f"{name}: reconstruction differs from the reference encoder"
     assert sum(v[0] for v in got["hooks"].values()) > 20, got["hooks"]
