@@ -154,6 +154,32 @@ def _check_variant(name, workdir, env, tag):
     return got
 
 
+def _check_sb128(workdir, env, tag):
+    """Presets <= M4 code with 128 x 128 superblocks above the 240p range (EbEncHandle.c:2105-2111): the source-side hooks work on their own
+    64 x 64 grid as in the reference, the loop-filter hooks hand the pictures back to the C loops.  Identical output."""
+    w, h, n, bd, preset, q = 640, 360, 3, 8, 4, 42
+    clip = os.path.join(workdir, "sb128.src.yuv")
+    if not os.path.exists(clip):
+        E.make_clip(clip, w, h, n, seed=13, bd=bd)
+    if "sb128" not in _ref_cache:
+        _ref_cache["sb128"] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "sb128.ref"))
+    ref = _ref_cache["sb128"]
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "sb128." + tag), env_extra=env)
+    assert got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"], got["log"][-2000:]
+    for hk in ("pa", "hme", "me"):
+        assert got["hooks"][hk][0] > 0 and got["hooks"][hk][1] == 0, got["hooks"]
+    assert got["hooks"]["dlf"][0] == 0 and got["hooks"]["dlf"][1] > 0, got["hooks"]
+
+
+def test_128_superblocks_on_cpu_test_double(workdir):
+    _check_sb128(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_128_superblocks_on_gpu(workdir):
+    _check_sb128(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
 def _check_padded_size(workdir, env, tag):
     """Source sizes that are not multiples of 8 are coded padded while the reference deblocks, measures and restores on the unpadded extent:
     the loop-filter hooks hand such pictures back to the C loops (counted as fallbacks), the source-side hooks (picture analysis, temporal filter,

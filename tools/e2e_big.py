@@ -9,7 +9,7 @@ import e2e_common as E  # noqa: E402
 
 wd = os.path.join(ROOT, "gpurun_out", "e2e_big")
 os.makedirs(wd, exist_ok=True)
-CASES = {"1080p_10bit_m6": (1920, 1080, 3, 10, 6, 34), "2160p_8bit_m8": (3840, 2160, 3, 8, 8, 40), "2160p_8bit_m6": (3840, 2160, 2, 8, 6, 36)}
+CASES = {"1080p_10bit_m6": (1920, 1080, 3, 10, 6, 34), "2160p_8bit_m8": (3840, 2160, 3, 8, 8, 40), "2160p_8bit_m6": (3840, 2160, 2, 8, 6, 36), "2160p_10bit_m6": (3840, 2160, 2, 10, 6, 34), "1080p_8bit_m4": (1920, 1080, 3, 8, 4, 40)}
 for name in sys.argv[1:] or list(CASES):
     w, h, n, bd, preset, q = CASES[name]
     clip = os.path.join(wd, name + ".yuv")
