@@ -201,6 +201,14 @@ typedef struct {
  * edge on the left / top of each 4x4 unit of the plane; units = ceil(plane dim / 4). */
 int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y,
                             int plane_w, int plane_h, uint16_t *edges_v, uint16_t *edges_h);
+/* The same for a coded picture that contains padding (a source size that is not a multiple of 8 is coded padded): the reference's loops
+ * (svt_av1_filter_block_plane_vert / _horz, EbDeblockingFilter.c:338-367, :479-508) stop at the unpadded extent in the last superblock row /
+ * column, so units with x >= filt_units_w or y >= filt_units_h carry no edge.  svt_hip_dlf_filtered_units gives that extent along one axis:
+ * coded_luma = the coded (padded) luma size, pad = scs->max_input_pad_right / _bottom, sb_size = 64 or 128, ss = the plane's subsampling;
+ * -1 for arguments outside that domain. */
+int svt_hip_dlf_filtered_units(int coded_luma, int pad, int sb_size, int ss);
+int svt_hip_dlf_build_edges_crop(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
+                                 int plane_h, int filt_units_w, int filt_units_h, uint16_t *edges_v, uint16_t *edges_h);
 /* Deblock one plane in place: all vertical edges, then all horizontal edges (normative order;
  * replaces svt_av1_loop_filter_frame for that plane, EbDeblockingFilter.c:711, and the 16 edge
  * kernels svt_aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}, common_dsp_rtcd.h:1051-1081).

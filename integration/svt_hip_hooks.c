@@ -17,6 +17,9 @@ static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;
 static SvtHipCtx      *g_ctx;
+static SvtHipCtx      *g_rtcd_ctx;   /* the per-call wrappers run on a context of their own: they serialise on the library's wrapper mutex, the hooks on
+                                      * g_lock, and a context (error string, library-owned scratch, stream) must not be driven from both at once */
+static int             g_rtcd_installed;
 static pthread_mutex_t g_lock   = PTHREAD_MUTEX_INITIALIZER;
 static pthread_mutex_t g_cnt_mu = PTHREAD_MUTEX_INITIALIZER;
 static int             g_inited;
@@ -59,6 +62,7 @@ void svt_hip_hooks_count(int which, int handled) {
 void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
+    if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }
 
 /* ---- per-call wrappers: SvtHipRtcd member <-> the reference's global pointer of the same name ---------------------------------------- */
@@ -112,10 +116,11 @@ static void install_rtcd(const char *list) {
 #define X(m, i, n) t.m[i] = (void *)n;
     RTCD_INDEXED(X)
 #undef X
-    if (svt_hip_setup_rtcd(g_ctx, &t) != SVT_HIP_OK) {
-        SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_ctx));
+    if (svt_hip_setup_rtcd(g_rtcd_ctx, &t) != SVT_HIP_OK) {
+        SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_rtcd_ctx));
         return;
     }
+    g_rtcd_installed = 1;
 #define X(n)                                                      \
     if (in_list(list, #n)) {                                      \
         n = (void *)t.n;                                          \
@@ -149,6 +154,9 @@ void svt_hip_hooks_enc_init(void) {
         g_ctx = NULL;
         return;
     }
-    if (rtcd && *rtcd) install_rtcd(rtcd);
+    if (rtcd && *rtcd) {
+        if (svt_hip_init(dev ? atoi(dev) : 0, &g_rtcd_ctx) == SVT_HIP_OK) install_rtcd(rtcd);
+        else SVT_LOG("svt_hip_init (per-call wrappers) failed - SVT_HIP_RTCD ignored, keeping the C kernels\n");
+    }
     atexit(svt_hip_hooks_report);
 }

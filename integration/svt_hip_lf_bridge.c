@@ -101,14 +101,13 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
     const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
     const EbPictureBufferDesc *rec = recon_of(pcs, is_16bit);
     const int w = rec->width, h = rec->height, bd = scs->static_config.encoder_bit_depth;
-    if ((w & 7) || (h & 7) || (bd != 8 && bd != 10) || scs->subsampling_x != 1 || scs->subsampling_y != 1 || scs->seq_header.sb_size != BLOCK_64X64 ||
-        scs->seq_header.color_config.mono_chrome || scs->max_input_pad_right || scs->max_input_pad_bottom) {
-        svt_hip_hooks_log("loop filter stages: %d x %d (source padded by %d x %d), %d-bit, subsampling %d/%d, superblock %s: not covered, C loops",
-                          w, h, scs->max_input_pad_right, scs->max_input_pad_bottom, bd, scs->subsampling_x, scs->subsampling_y,
-                          scs->seq_header.sb_size == BLOCK_64X64 ? "64" : "128");
-        return NULL;   /* outside what the device path covers: the caller keeps its C loop.  Source sizes that are not multiples of 8 are coded
-                        * padded, but the reference deblocks (EbDeblockingFilter.c:343-367), measures (picture_sse_calculations: the input picture's
-                        * size) and restores (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251: the cropped size) on the unpadded extent */
+    const int pad_r = scs->max_input_pad_right, pad_b = scs->max_input_pad_bottom;
+    const int sb_size = scs->seq_header.sb_size == BLOCK_128X128 ? 128 : 64;
+    if ((w & 7) || (h & 7) || (bd != 8 && bd != 10) || scs->subsampling_x != 1 || scs->subsampling_y != 1 || scs->seq_header.color_config.mono_chrome ||
+        pad_r < 0 || pad_r >= 8 || pad_b < 0 || pad_b >= 8 || ((w - pad_r) & 1) || ((h - pad_b) & 1) || w != scs->max_input_luma_width || h != scs->max_input_luma_height) {
+        svt_hip_hooks_log("loop filter stages: %d x %d (source padded by %d x %d), %d-bit, subsampling %d/%d: not covered, C loops",
+                          w, h, pad_r, pad_b, bd, scs->subsampling_x, scs->subsampling_y);
+        return NULL;   /* outside what the device path covers (monochrome, 4:2:2 / 4:4:4, 12-bit): the caller keeps its C loop */
     }
     LfState *s = NULL;
     for (int i = 0; i < LF_MAX_IN_FLIGHT && !s; i++)
@@ -122,6 +121,10 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
         s->allocated = 1;
     }
     s->pcs = pcs; s->flags = 0;
+    /* A source size that is not a multiple of 8 is coded padded (w, h), but the reference deblocks the last superblock row / column only up to the
+     * unpadded extent (EbDeblockingFilter.c:343-367) and restores the cropped frame (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251; the
+     * restoration units, stripes and the 3-sample extension all follow the crop size); CDEF and the level search's SSE use the coded size. */
+    s->pic.cw = w - pad_r; s->pic.ch = h - pad_b; s->pic.sb_size = sb_size;
     return s;
 }
 
@@ -143,12 +146,13 @@ static EbErrorType upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBuf
     }
     return EB_ErrorNone;
 }
-static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *const d_src[3], EbPictureBufferDesc *pic, int plane_mask) {
+/* crop: only the unpadded extent comes back (the restoration filter writes the cropped frame, EbRestoration.c:1330-1350) */
+static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *const d_src[3], EbPictureBufferDesc *pic, int plane_mask, int crop) {
     for (int pl = 0; pl < 3; pl++) {
         if (!(plane_mask & (1 << pl))) continue;
         int st;
         uint8_t *d = pic_plane(pic, pl, p->pix_bytes, &st);
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
+        const int pw = (crop ? p->cw : p->w) >> (pl > 0), ph = (crop ? p->ch : p->h) >> (pl > 0);
         const uint8_t *s = (const uint8_t *)plane_origin(p, d_src[pl], pl);
         HIP_TRY(svt_hip_memcpy2d_d2h(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
     }
@@ -193,7 +197,9 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
 }
 static EbErrorType build_and_upload_edges(SvtHipCtx *hip, SvtHipLfPicture *p, int pl) {
     const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4, pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
-    HIP_TRY(svt_hip_dlf_build_edges(p->h_mi, mi_cols, mi_rows, pl, pl > 0, pl > 0, pw, ph, p->h_edges[pl][0], p->h_edges[pl][1]));
+    const int fw = svt_hip_dlf_filtered_units(p->w, p->w - p->cw, p->sb_size, pl > 0), fh = svt_hip_dlf_filtered_units(p->h, p->h - p->ch, p->sb_size, pl > 0);
+    if (fw < 0 || fh < 0) return EB_ErrorUndefined;
+    HIP_TRY(svt_hip_dlf_build_edges_crop(p->h_mi, mi_cols, mi_rows, pl, pl > 0, pl > 0, pw, ph, fw, fh, p->h_edges[pl][0], p->h_edges[pl][1]));
     const size_t eb = sizeof(uint16_t) * p->units_w[pl] * p->units_h[pl];
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][0], p->h_edges[pl][0], eb)); HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][1], p->h_edges[pl][1], eb));
     return EB_ErrorNone;
@@ -267,7 +273,7 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
         if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
     }
     HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
-    if (download(hip, p, p->d_recon, recon, mask) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_DBL;
     svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask);
     return EB_ErrorNone;
@@ -325,10 +331,18 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
     HIP_TRY(svt_hip_memcpy_d2h(hip, p->h_mse, p->d_mse, sizeof(uint64_t) * 2 * nfb * 64));
     const int level = pcs->parent_pcs_ptr->cdef_level;
     const CDEF_PICK_METHOD pick = level == 2 ? CDEF_FAST_SEARCH_LVL1 : level == 3 ? CDEF_FAST_SEARCH_LVL2 : level == 4 ? CDEF_FAST_SEARCH_LVL3 : 0;
-    const int c8 = p->w / 8, nhfb = (p->w + 63) / 64;
+    const int c8 = p->w / 8, nhfb = (p->w + 63) / 64, nvfb = (p->h + 63) / 64;
     for (int fb = 0; fb < nfb; fb++) {
-        /* the reference leaves the entries of an all-skip filter block untouched (svt_sb_all_skip, :199): so do we */
         const int fbr = fb / nhfb, fbc = fb % nhfb;
+        /* 128 x 128 superblocks: a filter block whose first mode-info belongs to an unsplit 128-wide / 128-high block is searched together with its
+         * right / lower neighbour -- one distortion entry, kept in the first of them, for the blocks of the whole 128 x 128 (128 x 64, 64 x 128) area,
+         * and the others are passed over (cdef_seg_search, EbCdefProcess.c:181-199; svt_sb_compute_cdef_list with that block size).  The distortion
+         * of a list of 8 x 8 blocks is the sum over its blocks, so the merged entry is the sum of the device table's 64 x 64 entries. */
+        const ModeInfo *mi0 = pcs->mi_grid_base[MI_SIZE_64X64 * fbr * pcs->mi_stride + MI_SIZE_64X64 * fbc];
+        const BlockSize bt = mi0->mbmi.block_mi.sb_type;
+        if (((fbc & 1) && (bt == BLOCK_128X128 || bt == BLOCK_128X64)) || ((fbr & 1) && (bt == BLOCK_128X128 || bt == BLOCK_64X128))) continue;
+        const int hb_step = (bt == BLOCK_128X128 || bt == BLOCK_128X64) ? 2 : 1, vb_step = (bt == BLOCK_128X128 || bt == BLOCK_64X128) ? 2 : 1;
+        /* the reference leaves the entries of an all-skip filter block untouched (svt_sb_all_skip of the FIRST 64 x 64, :201): so do we */
         int all_skip = 1;
         for (int r = fbr * 8; r < fbr * 8 + 8 && r < p->h / 8 && all_skip; r++)
             for (int c = fbc * 8; c < fbc * 8 + 8 && c < c8; c++) all_skip &= p->h_skip8[r * c8 + c];
@@ -336,8 +350,15 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
         for (int gi = 0; gi < nb_cdef_strengths[pick]; gi++) {
             int pri = gi / CDEF_SEC_STRENGTHS, sec = gi % CDEF_SEC_STRENGTHS;
             get_cdef_filter_strengths(pick, &pri, &sec, gi);
-            pcs->mse_seg[0][fb][gi] = p->h_mse[(size_t)fb * 64 + pri * CDEF_SEC_STRENGTHS + sec];
-            pcs->mse_seg[1][fb][gi] = p->h_mse[((size_t)nfb + fb) * 64 + pri * CDEF_SEC_STRENGTHS + sec];
+            uint64_t m0 = 0, m1 = 0;
+            for (int dy = 0; dy < vb_step && fbr + dy < nvfb; dy++)
+                for (int dx = 0; dx < hb_step && fbc + dx < nhfb; dx++) {
+                    const size_t q = (size_t)(fbr + dy) * nhfb + fbc + dx;
+                    m0 += p->h_mse[q * 64 + pri * CDEF_SEC_STRENGTHS + sec];
+                    m1 += p->h_mse[((size_t)nfb + q) * 64 + pri * CDEF_SEC_STRENGTHS + sec];
+                }
+            pcs->mse_seg[0][fb][gi] = m0;
+            pcs->mse_seg[1][fb][gi] = m1;
         }
     }
     s->flags |= ST_DIRVAR;
@@ -394,7 +415,7 @@ static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
     /* direction / variance of the search are reused when it ran here (same pre-CDEF picture) */
     HIP_TRY(svt_hip_cdef_apply_frame_dev(hip, p->pix_bytes, in, out, p->stride, p->w, p->h, p->d_skip8, p->d_y_strength, p->d_uv_strength,
                                          frm_hdr->cdef_params.cdef_damping, p->bd, p->d_dir, (s->flags & ST_DIRVAR) ? p->d_var : NULL));
-    if (download(hip, p, p->d_cdef, recon_of(pcs, p->pix_bytes == 2), 7) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (download(hip, p, p->d_cdef, recon_of(pcs, p->pix_bytes == 2), 7, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_CDEF;
     return EB_ErrorNone;
 }
@@ -419,7 +440,7 @@ static EbErrorType ensure_cdef_padded(SvtHipCtx *hip, LfState *s) {
     }
     if (!(s->flags & ST_PADDED)) {
         for (int pl = 0; pl < 3; pl++)
-            HIP_TRY(svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->w >> (pl > 0), p->h >> (pl > 0), LF_BORDER, LF_BORDER));
+            HIP_TRY(svt_hip_generate_padding_dev(hip, plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->cw >> (pl > 0), p->ch >> (pl > 0), LF_BORDER, LF_BORDER));   /* svt_extend_frame of the CROPPED frame (EbCdefProcess.c:552-572): inside a padded picture it overwrites coded samples, on the host as well */
         s->flags |= ST_PADDED;
     }
     return EB_ErrorNone;
@@ -442,7 +463,7 @@ static EbErrorType rest_apply(SvtHipCtx *hip, LfState *s) {
     int mask = 0;
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile;
         if (rsi->frame_restoration_type == RESTORE_NONE) continue;    /* the plane is left alone (:1322-1323) */
         uint8_t *ep = (uint8_t *)malloc(n); int32_t *xqd = (int32_t *)malloc(sizeof(int32_t) * 2 * n); int16_t *wn = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t));
         if (!ep || !xqd || !wn) { free(ep); free(xqd); free(wn); return EB_ErrorInsufficientResources; }
@@ -461,7 +482,7 @@ static EbErrorType rest_apply(SvtHipCtx *hip, LfState *s) {
                                            p->d_unit_xqd[pl], p->d_unit_wiener[pl]));
         mask |= 1 << pl;
     }
-    return download(hip, p, p->d_rest, recon_of(pcs, p->pix_bytes == 2), mask);
+    return download(hip, p, p->d_rest, recon_of(pcs, p->pix_bytes == 2), mask, 1);
 }
 EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY)) return EB_ErrorUndefined;
@@ -498,7 +519,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
     EbErrorType ret = EB_ErrorNone;
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile;
         xqd[pl] = (int32_t *)calloc((size_t)32 * n, sizeof(int32_t)); err[pl] = (int64_t *)calloc((size_t)16 * n, sizeof(int64_t)); best[pl] = (uint8_t *)calloc(n, 1);
         if (!xqd[pl] || !err[pl] || !best[pl]) { ret = EB_ErrorInsufficientResources; goto done; }
         job[pl].d_dgd = plane_origin(p, p->d_cdef[pl], pl); job[pl].stride = p->stride[pl];
@@ -511,7 +532,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
 
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size;
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size;
         RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
         uint8_t *ep = (uint8_t *)malloc(n); int32_t *uq = (int32_t *)malloc(sizeof(int32_t) * 2 * n);
         SvtHipBlkPair *rect = (SvtHipBlkPair *)malloc(sizeof(SvtHipBlkPair) * n); uint64_t *sse = (uint64_t *)malloc(sizeof(uint64_t) * n);
@@ -594,7 +615,7 @@ static EbErrorType wiener_stats_all(SvtHipCtx *hip, LfState *s) {
         int ok = p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_malloc(hip, &dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
                  svt_hip_malloc(hip, &dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK &&
                  svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->d_src[pl], p->src_stride[pl],
-                                                p->w >> (pl > 0), p->h >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)dM, (int64_t *)dH) == SVT_HIP_OK &&
+                                                p->cw >> (pl > 0), p->ch >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)dM, (int64_t *)dH) == SVT_HIP_OK &&
                  svt_hip_memcpy_d2h(hip, p->h_wiener_M[pl], dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
                  svt_hip_memcpy_d2h(hip, p->h_wiener_H[pl], dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK;
         if (dM) svt_hip_free(hip, dM);
@@ -633,7 +654,7 @@ static EbErrorType wiener_try(SvtHipCtx *hip, LfState *s, int pl, int h_start, i
     const Av1Common *cm = s->pcs->parent_pcs_ptr->av1_cm;
     if (!(s->flags & ST_DBL) || !rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     const RestorationInfo *rsi = &cm->rst_info[pl];
-    const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), us = rsi->restoration_unit_size, n = rsi->units_per_tile, voff = 8 >> (pl > 0);
+    const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), us = rsi->restoration_unit_size, n = rsi->units_per_tile, voff = 8 >> (pl > 0);
     /* unit index from its rectangle: columns start at j * us, rows at i * us - voff (0 for the first row), EbRestoration.c:1369-1411 */
     const int j = h_start / us, i = v_start > 0 ? (v_start + voff) / us : 0, u = i * rsi->horz_units_per_tile + j;
     if (u < 0 || u >= n || h_end <= h_start || v_end <= v_start) return EB_ErrorUndefined;
@@ -721,7 +742,7 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     int n_active = 0;
     for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size, win = p->wiener_win[pl], w2 = win * win;
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size, win = p->wiener_win[pl], w2 = win * win;
         RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
         walk[pl] = (WnWalk *)calloc(n, sizeof(WnWalk)); rect[pl] = (SvtHipBlkPair *)calloc(n, sizeof(SvtHipBlkPair));
         ep[pl] = (uint8_t *)malloc(n); wn[pl] = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t)); sse[pl] = (uint64_t *)calloc(n, sizeof(uint64_t));
@@ -758,7 +779,7 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     while (ret == EB_ErrorNone && n_active > 0) {
         for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
             const RestorationInfo *rsi = &cm->rst_info[pl];
-            const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0), n = rsi->units_per_tile;
+            const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile;
             int any = 0;
             for (int u = 0; u < n; u++) {
                 const WnWalk *w = &walk[pl][u];

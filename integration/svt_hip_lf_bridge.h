@@ -26,7 +26,10 @@
 #include "svt_hip.h"
 
 typedef struct SvtHipLfPicture {
-    int   pix_bytes, bd, w, h;           /* luma size, multiples of 8 */
+    int   pix_bytes, bd, w, h;           /* coded luma size, multiples of 8 */
+    int   cw, ch;                        /* luma size without the padding of a source that is not a multiple of 8 (w - max_input_pad_right, h - _bottom):
+                                          * what the restoration stages work on (link_eb_to_aom_buffer_desc's crop size) */
+    int   sb_size;                       /* 64 / 128: superblock size of the sequence (deblocking range of the last superblock row / column) */
     void *d_recon[3], *d_cdef[3], *d_rest[3], *d_src[3];
     int   stride[3];                     /* recon / cdef / rest share one stride per plane; the planes carry a 3-sample border */
     int   src_stride[3];

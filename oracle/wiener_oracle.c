@@ -49,13 +49,14 @@ void orc_wiener_compute_stats(int win, const void *dgd, const void *src, int pix
  * filter_x / filter_y: 8 int16 (tap 7 = 0), round_0 = 3, round_1 = 11 for 8 / 10 bit (get_conv_params_wiener, convolve.h:78-95). */
 void orc_wiener_convolve_add_src(const void *src, int src_stride, void *dst, int dst_stride, int pix_bytes, const int16_t *filter_x,
                                  const int16_t *filter_y, int w, int h, int bd) {
-    const int r0 = 3, r1 = 11, ih = h + 7;
+    const int r0 = 3, r1 = 11, ih = h + 6;   /* tap 7 is 0 (the reference still reads row h + 3 / column w + 3 for it, its pictures have wide
+                                               * borders; here nothing outside the 3-sample context is touched) */
     const int lim = (1 << (bd + 1 + 7 - r0)) - 1;   /* WIENER_CLAMP_LIMIT - 1 */
     uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * ih);
-    for (int y = 0; y < ih; y++)           /* rows -3 .. h+3 */
+    for (int y = 0; y < ih; y++)           /* rows -3 .. h+2 */
         for (int x = 0; x < w; x++) {
             int32_t sum = 0;
-            for (int k = 0; k < 8; k++) sum += rdp(src, pix_bytes, (ptrdiff_t)(y - 3) * src_stride + x - 3 + k) * filter_x[k];
+            for (int k = 0; k < 7; k++) sum += rdp(src, pix_bytes, (ptrdiff_t)(y - 3) * src_stride + x - 3 + k) * filter_x[k];
             sum += (rdp(src, pix_bytes, (ptrdiff_t)(y - 3) * src_stride + x) << 7) + (1 << (bd + 7 - 1));
             int32_t v = (sum + (1 << (r0 - 1))) >> r0;
             tmp[y * w + x] = (uint16_t)(v < 0 ? 0 : (v > lim ? lim : v));
@@ -63,7 +64,7 @@ void orc_wiener_convolve_add_src(const void *src, int src_stride, void *dst, int
     for (int x = 0; x < w; x++)
         for (int y = 0; y < h; y++) {
             int32_t sum = 0;
-            for (int k = 0; k < 8; k++) sum += tmp[(y + k) * w + x] * filter_y[k];
+            for (int k = 0; k < 7; k++) sum += tmp[(y + k) * w + x] * filter_y[k];
             sum += ((int32_t)tmp[(y + 3) * w + x] << 7) - (1 << (bd + r1 - 1));
             int32_t v = (sum + (1 << (r1 - 1))) >> r1;
             const int mx = (1 << bd) - 1;

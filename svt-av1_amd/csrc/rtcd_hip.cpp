@@ -17,10 +17,25 @@ SvtHipCtx*  g_ctx = nullptr;
 SvtHipRtcd  g_c;                 // the pointers that were installed before us (failure fallbacks)
 const int16_t h_interp[6][16][8] = SVT_HIP_INTERP_TABLE;
 
+// per-wrapper bookkeeping for svt_hip_rtcd_report: calls by wrapper function, delegations by dispatch-table name (both touched with g_mu held)
+struct Tally { const char* key; long n, device_failures; };
+Tally g_calls[512], g_deleg[512];
+int   g_ncalls = 0, g_ndeleg = 0;
+Tally* tally(Tally* tab, int* n, const char* key) {
+    for (int i = 0; i < *n; i++)
+        if (tab[i].key == key || !std::strcmp(tab[i].key, key)) return &tab[i];
+    if (*n >= 512) return &tab[511];
+    tab[*n] = Tally{key, 0, 0};
+    return &tab[(*n)++];
+}
+
 // every wrapper: serialise on the one mutex and make the context's device current (the reference calls these pointers from many threads)
 struct Guard {
     std::lock_guard<std::mutex> lk;
-    Guard() : lk(g_mu) { if (g_ctx) (void)hipSetDevice(svt_hip_ctx_device(g_ctx)); }
+    Guard(const char* fn = __builtin_FUNCTION()) : lk(g_mu) {
+        tally(g_calls, &g_ncalls, fn)->n++;
+        if (g_ctx) { (void)hipSetDevice(svt_hip_ctx_device(g_ctx)); svt_hip_ctx_clear_error(g_ctx); }
+    }
 };
 struct Slot { void* p = nullptr; size_t cap = 0; };
 Slot g_slot[8];
@@ -56,14 +71,23 @@ bool down(void* h, const void* d, size_t bytes) {
     std::abort();
 }
 // A call the wrapper does not cover (an argument outside the batched entry point's domain) or a device failure is delegated to the pointer
-// that was installed before: quietly — the first delegation of each wrapper is logged once, a flood of identical lines would only hide it.
+// that was installed before.  Every delegation is counted per table entry (svt_hip_rtcd_report); a domain delegation is logged on its first
+// occurrence only (a flood of identical lines would only hide it), a delegation that follows a failed device call is logged every time with
+// the context's error string -- the two must not look alike.  Called with g_mu held (the wrapper's Guard).
+void note_delegation(const char* name) {
+    Tally* t = tally(g_deleg, &g_ndeleg, name);
+    const char* err = g_ctx ? svt_hip_last_error(g_ctx) : "no context";
+    const bool device = !g_ctx || (err && *err);
+    if (device) {
+        t->device_failures++;
+        std::fprintf(stderr, "libsvtav1_hip: %s DEVICE FAILURE (%s), delegated to the installed C pointer\n", name, err);
+    } else if (!t->n)
+        std::fprintf(stderr, "libsvtav1_hip: %s delegated to the installed C pointer (first occurrence)\n", name);
+    t->n++;
+}
 #define FALLBACK(name, member, ...)                                                                              \
     do {                                                                                                         \
-        static bool logged_ = false;                                                                             \
-        if (!logged_) {                                                                                          \
-            logged_ = true;                                                                                      \
-            std::fprintf(stderr, "libsvtav1_hip: %s delegated to the installed C pointer (first occurrence)\n", name); \
-        }                                                                                                        \
+        note_delegation(name);                                                                                   \
         if (!g_c.member) die(name);                                                                              \
         return g_c.member(__VA_ARGS__);                                                                          \
     } while (0)
@@ -1129,6 +1153,21 @@ void blend_d16_hbd_hip(uint8_t* dst, uint32_t ds, const uint16_t* s0, uint32_t s
 }
 
 }  // namespace
+
+// One line per wrapper that was called and per table entry that was delegated, e.g.
+//   svt_hip_rtcd_calls quantize_b_hip calls=1234
+//   svt_hip_rtcd_delegated svt_aom_quantize_b count=3 device_failures=0
+// (the hooked encoder prints it at exit; tests/test_encode_e2e.py pins the delegated set).  Returns the number of delegations.
+extern "C" long svt_hip_rtcd_report(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    long total = 0;
+    for (int i = 0; i < g_ncalls; i++) std::fprintf(stderr, "svt_hip_rtcd_calls %s calls=%ld\n", g_calls[i].key, g_calls[i].n);
+    for (int i = 0; i < g_ndeleg; i++) {
+        std::fprintf(stderr, "svt_hip_rtcd_delegated %s count=%ld device_failures=%ld\n", g_deleg[i].key, g_deleg[i].n, g_deleg[i].device_failures);
+        total += g_deleg[i].n;
+    }
+    return total;
+}
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     if (!ctx || !t) return SVT_HIP_ERR_BAD_ARG;

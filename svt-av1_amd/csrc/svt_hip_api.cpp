@@ -92,6 +92,7 @@ int svt_hip_set_stream(SvtHipCtx* c, void* s) {
 }
 void* svt_hip_ctx_stream(SvtHipCtx* c) { return c ? (void*)c->stream : nullptr; }
 int   svt_hip_ctx_device(SvtHipCtx* c) { return c ? c->device : 0; }
+void  svt_hip_ctx_clear_error(SvtHipCtx* c) { if (c) c->err.clear(); }
 int svt_hip_sync(SvtHipCtx* c) {
     SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;

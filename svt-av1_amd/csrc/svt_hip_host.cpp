@@ -33,15 +33,34 @@ SvtHipSbSearch svt_hip_me_search_window(int sb_origin_x, int sb_origin_y, int x_
 
 /* ------------------------------------------------------------------------------- deblocking */
 // Restatement of set_lpf_parameters (Encoder/Codec/EbDeblockingFilter.c:168-319) over a plain grid.
+// svt_av1_filter_block_plane_vert / _horz (Encoder/Codec/EbDeblockingFilter.c:338-367, :479-508): the 4x4 units of a plane the reference's loops
+// visit along one axis.  Every superblock covers sb_size >> ss samples, except that the LAST superblock row / column of a coded size that is
+// not a multiple of the superblock size stops at the unpadded source extent (rounded up to 4 samples).  A coded size that IS a multiple of the
+// superblock size is filtered completely even when it contains padding (the reference's `mi_row ==` test then never fires).
+int svt_hip_dlf_filtered_units(int coded_luma, int pad, int sb_size, int ss) {
+    if (coded_luma <= 0 || pad < 0 || pad >= coded_luma || (sb_size != 64 && sb_size != 128) || ss < 0 || ss > 1) return -1;
+    const int full = ((coded_luma >> ss) + 3) >> 2;
+    if (coded_luma % sb_size == 0) return full;
+    const int last = coded_luma / sb_size * sb_size, rem = (coded_luma - pad) % sb_size;
+    const int units = ((last >> ss) >> 2) + (((rem >> ss) + 3) >> 2);
+    return units < full ? units : full;
+}
+
 int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
                             int plane_h, uint16_t* edges_v, uint16_t* edges_h) {
-    if (!mi || mi_cols <= 0 || mi_rows <= 0 || plane < 0 || plane > 2 || !edges_v || !edges_h) return SVT_HIP_ERR_BAD_ARG;
+    return svt_hip_dlf_build_edges_crop(mi, mi_cols, mi_rows, plane, ss_x, ss_y, plane_w, plane_h, (plane_w + 3) >> 2, (plane_h + 3) >> 2, edges_v, edges_h);
+}
+
+int svt_hip_dlf_build_edges_crop(const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
+                                 int plane_h, int filt_units_w, int filt_units_h, uint16_t* edges_v, uint16_t* edges_h) {
+    if (!mi || mi_cols <= 0 || mi_rows <= 0 || plane < 0 || plane > 2 || !edges_v || !edges_h || filt_units_w < 0 || filt_units_h < 0) return SVT_HIP_ERR_BAD_ARG;
     const int uw = (plane_w + 3) >> 2, uh = (plane_h + 3) >> 2;
     for (int dir = 0; dir < 2; dir++) {
         uint16_t* out = dir == 0 ? edges_v : edges_h;
         for (int uy = 0; uy < uh; uy++)
             for (int ux = 0; ux < uw; ux++) {
                 uint16_t v = 0;
+                if (ux >= filt_units_w || uy >= filt_units_h) { out[uy * uw + ux] = 0; continue; }   // outside the loops' range: never visited
                 const int x = 4 * ux, y = 4 * uy;
                 // chroma maps to the bottom/right mi of the co-located 8x8 (:196-197)
                 int mr = ss_y | ((y << ss_y) >> 2), mc = ss_x | ((x << ss_x) >> 2);

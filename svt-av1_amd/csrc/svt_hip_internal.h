@@ -7,6 +7,7 @@
 
 extern "C" {
 void* svt_hip_ctx_stream(SvtHipCtx* c);
+void  svt_hip_ctx_clear_error(SvtHipCtx* c);   /* rtcd_hip.cpp: a wrapper's delegation is a device failure iff an entry point left an error string */
 int   svt_hip_ctx_device(SvtHipCtx* c);   /* the stream the context launches on (rtcd_hip.cpp) */
 int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                               int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,

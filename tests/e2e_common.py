@@ -74,4 +74,7 @@ def encode(app, clip, w, h, n, preset, q, bd, out_prefix, env_extra=None, lp=8, 
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     hooks = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"svt_hip_hook (\w+) handled=(\d+) fallback=(\d+)", log)}
-    return {"ivf": _md5(out_prefix + ".ivf"), "recon": _md5(out_prefix + ".yuv"), "hooks": hooks, "log": log}
+    # per-call wrappers (SVT_HIP_RTCD): calls per wrapper function, delegations per dispatch-table entry (svt_hip_rtcd_report)
+    calls = {m.group(1): int(m.group(2)) for m in re.finditer(r"svt_hip_rtcd_calls (\w+) calls=(\d+)", log)}
+    deleg = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"svt_hip_rtcd_delegated (\w+) count=(\d+) device_failures=(\d+)", log)}
+    return {"ivf": _md5(out_prefix + ".ivf"), "recon": _md5(out_prefix + ".yuv"), "hooks": hooks, "log": log, "rtcd_calls": calls, "rtcd_delegated": deleg}

@@ -154,21 +154,35 @@ def _check_variant(name, workdir, env, tag):
     return got
 
 
+def _check_geometry(name, w, h, n, bd, preset, q, seed, workdir, env, tag, must=None):
+    """hooked vs unpatched encoder on one more picture geometry: identical output, every hook the preset uses handled, nothing handed back"""
+    clip = os.path.join(workdir, name + ".src.yuv")
+    if not os.path.exists(clip):
+        E.make_clip(clip, w, h, n, seed=seed, bd=bd)
+    if name not in _ref_cache:
+        _ref_cache[name] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".ref"))
+    ref = _ref_cache[name]
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{name}.{tag}"), env_extra=env)
+    assert got["ivf"] == ref["ivf"], f"{name}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
+    assert got["recon"] == ref["recon"], f"{name}: reconstruction differs from the reference encoder"
+    for hk in (ALL if must is None else must):
+        handled, fallback = got["hooks"].get(hk, (0, 0))
+        assert handled > 0 and fallback == 0, f"{name}: hook {hk} handled={handled} fallback={fallback}\n" + got["log"][-2000:]
+    assert all(v[1] == 0 for v in got["hooks"].values()), f"{name}: a hook handed a picture back to the C loops: {got['hooks']}"
+    return got
+
+
 def _check_sb128(workdir, env, tag):
     """Presets <= M4 code with 128 x 128 superblocks above the 240p range (EbEncHandle.c:2105-2111): the source-side hooks work on their own
-    64 x 64 grid as in the reference, the loop-filter hooks hand the pictures back to the C loops.  Identical output."""
-    w, h, n, bd, preset, q = 640, 360, 3, 8, 4, 42
-    clip = os.path.join(workdir, "sb128.src.yuv")
-    if not os.path.exists(clip):
-        E.make_clip(clip, w, h, n, seed=13, bd=bd)
-    if "sb128" not in _ref_cache:
-        _ref_cache["sb128"] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "sb128.ref"))
-    ref = _ref_cache["sb128"]
-    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "sb128." + tag), env_extra=env)
-    assert got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"], got["log"][-2000:]
-    for hk in ("pa", "hme", "me"):
-        assert got["hooks"][hk][0] > 0 and got["hooks"][hk][1] == 0, got["hooks"]
-    assert got["hooks"]["dlf"][0] == 0 and got["hooks"]["dlf"][1] > 0, got["hooks"]
+    64 x 64 grid as in the reference; deblocking takes the last superblock row / column of the 128 grid, the CDEF search merges the filter blocks
+    of unsplit 128-wide / 128-high blocks (cdef_seg_search), restoration units are independent of the superblock size.  640 x 360: the last
+    superblock row is 104 rows high, the last column is complete."""
+    return _check_geometry("sb128", 640, 360, 3, 8, 4, 42, 13, workdir, env, tag)
+
+
+def _check_sb128_10bit(workdir, env, tag):
+    """the same with the 16-bit pipeline, a width that ends inside a 128-wide superblock (480 = 3 x 128 + 96) and a padded height (270 -> 272)"""
+    return _check_geometry("sb128_10bit", 480, 270, 3, 10, 4, 36, 17, workdir, env, tag)
 
 
 def test_128_superblocks_on_cpu_test_double(workdir):
@@ -181,22 +195,17 @@ def test_128_superblocks_on_gpu(workdir):
 
 
 def _check_padded_size(workdir, env, tag):
-    """Source sizes that are not multiples of 8 are coded padded while the reference deblocks, measures and restores on the unpadded extent:
-    the loop-filter hooks hand such pictures back to the C loops (counted as fallbacks), the source-side hooks (picture analysis, temporal filter,
-    HME, ME) work on the padded input exactly like the reference.  Identical output either way."""
-    w, h, n, bd, preset, q = 130, 66, 5, 8, 6, 38
-    clip = os.path.join(workdir, "padded.src.yuv")
-    if not os.path.exists(clip):
-        E.make_clip(clip, w, h, n, seed=11, bd=bd)
-    if "padded" not in _ref_cache:
-        _ref_cache["padded"] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "padded.ref"))
-    ref = _ref_cache["padded"]
-    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "padded." + tag), env_extra=env)
-    assert got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"], got["log"][-2000:]
-    for hk in ("pa", "hme", "me"):
-        assert got["hooks"][hk][0] > 0 and got["hooks"][hk][1] == 0, got["hooks"]
-    for hk in ("dlf", "dlf_search", "cdef_apply", "rest_apply"):
-        assert got["hooks"][hk][0] == 0 and got["hooks"][hk][1] > 0, got["hooks"]
+    """Source sizes that are not multiples of 8 are coded padded (130 x 66 -> 136 x 72) while the reference deblocks the last superblock row / column
+    only up to the unpadded extent (EbDeblockingFilter.c:343-367), searches CDEF and the filter level on the coded size, and runs the restoration
+    search and filter on the cropped frame, whose 3-sample extension overwrites coded samples (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251;
+    svt_extend_frame, EbCdefProcess.c:552-572).  Every loop-filter hook takes such pictures."""
+    return _check_geometry("padded", 130, 66, 5, 8, 6, 38, 11, workdir, env, tag, must=ALL - {"tf_me"})   # the alt-ref window of so small a picture is the central frame alone
+
+
+def _check_padded_size_64(workdir, env, tag):
+    """a padded size whose coded size IS a multiple of the superblock size (186 x 122 -> 192 x 128): the reference's crop test never fires and the
+    padding is deblocked like picture content (the quirk svt_hip_dlf_filtered_units restates); restoration still works on the cropped 186 x 122"""
+    return _check_geometry("padded64", 186, 122, 4, 10, 6, 34, 19, workdir, env, tag, must=ALL - {"tf_me"})   # the alt-ref window of so small a picture is the central frame alone
 
 
 def test_padded_source_size_on_cpu_test_double(workdir):
@@ -206,6 +215,24 @@ def test_padded_source_size_on_cpu_test_double(workdir):
 @pytest.mark.gpu
 def test_padded_source_size_on_gpu(workdir):
     _check_padded_size(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
+def test_padded_source_size_multiple_of_64_on_cpu_test_double(workdir):
+    _check_padded_size_64(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_padded_source_size_multiple_of_64_on_gpu(workdir):
+    _check_padded_size_64(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
+def test_128_superblocks_10bit_padded_on_cpu_test_double(workdir):
+    _check_sb128_10bit(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_128_superblocks_10bit_padded_on_gpu(workdir):
+    _check_sb128_10bit(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
 
 
 @pytest.mark.parametrize("name", list(OPTION_VARIANTS))
@@ -237,6 +264,28 @@ def test_single_hook_on_gpu(hook, workdir):
     _check(case, spec, workdir, {"SVT_HIP_HOOKS": hook}, "hip_" + hook)
 
 
+# Dispatch-table entries that hand SOME of their calls to the saved C pointer in the encodes below, and why (everything else must stay on the device):
+EXPECTED_DELEGATIONS = {
+    "per_call": set(),
+    "block_level": set(),
+    "helpers": set(),
+    "hbd": set(),
+    "both": set(),
+}
+
+
+def _check_delegations(got, expected, tag):
+    """The wrappers' own bookkeeping (svt_hip_rtcd_report at exit): exactly the table entries listed in `expected` may have handed calls to the saved C
+    pointer (calls outside a kernel's domain -- each one explained next to the list), none because a device call failed, and wrappers did run."""
+    dump = os.environ.get("SVT_E2E_DUMP")
+    if dump:
+        with open(dump, "a") as f:
+            f.write(f"{tag}: delegated={got['rtcd_delegated']} calls={got['rtcd_calls']}\n")
+    assert got["rtcd_calls"] and sum(got["rtcd_calls"].values()) > 0, "no per-call wrapper ran"
+    assert all(v[1] == 0 for v in got["rtcd_delegated"].values()), f"{tag}: a wrapper delegated after a DEVICE failure: {got['rtcd_delegated']}\n" + got["log"][-1500:]
+    assert set(got["rtcd_delegated"]) == set(expected), f"{tag}: delegated entries {sorted(got['rtcd_delegated'])}, expected {sorted(expected)}"
+
+
 @pytest.mark.gpu
 def test_per_call_wrappers_in_a_real_encode_on_gpu(workdir):
     """SVT_HIP_RTCD: the reference's dispatch-table entries themselves point at the svt_*_hip wrappers (include/svt_hip_rtcd.h) while the encoder
@@ -252,6 +301,7 @@ def test_per_call_wrappers_in_a_real_encode_on_gpu(workdir):
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"]
     assert "delegated to the installed C pointer" not in got["log"], got["log"][-1500:]
+    _check_delegations(got, EXPECTED_DELEGATIONS["per_call"], "per_call")
 
 
 @pytest.mark.gpu
@@ -271,7 +321,7 @@ def test_block_level_wrappers_in_a_real_encode_on_gpu(workdir):
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
-    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
+    _check_delegations(got, EXPECTED_DELEGATIONS["block_level"], "block_level")
 
 
 @pytest.mark.gpu
@@ -294,7 +344,7 @@ def test_helper_pointers_in_a_real_encode_on_gpu(workdir):
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
-    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
+    _check_delegations(got, EXPECTED_DELEGATIONS["helpers"], "helpers")
 
 
 @pytest.mark.gpu
@@ -314,4 +364,21 @@ def test_high_bit_depth_pointers_in_a_real_encode_on_gpu(workdir):
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
     for nme in names.split(","):
         assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
-    print("\n".join(l for l in got["log"].splitlines() if "delegated" in l or "not covered" in l))
+    _check_delegations(got, EXPECTED_DELEGATIONS["hbd"], "hbd")
+
+
+@pytest.mark.gpu
+def test_hooks_and_wrappers_together_10bit_on_gpu(workdir):
+    """SVT_HIP_HOOKS and SVT_HIP_RTCD in one 10-bit encode: the picture-level hooks (one context behind the hooks' lock) and per-call wrappers that use
+    the library-owned scratch at 16 bits (the Wiener statistics, the self-guided filter) run from different process threads at the same time -- the
+    wrappers own a second context, so neither side can free or overwrite the other's scratch."""
+    w, h, n, bd, preset, q = 176, 144, 3, 10, 6, 34
+    clip = os.path.join(workdir, "qcif10b.yuv")
+    E.make_clip(clip, w, h, n, seed=21, bd=bd)
+    names = "svt_av1_compute_stats_highbd,svt_av1_selfguided_restoration,svt_apply_selfguided_restoration,svt_aom_highbd_quantize_b,svt_residual_kernel16bit"
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10b.ref"))
+    hooks = "pa,tf,tf_me,hme,me,cdef_finish,dlf,dlf_search,cdef_search,cdef_apply,sgr_search,rest_apply"   # the Wiener search stays the reference's loop: it calls svt_av1_compute_stats_highbd
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10b.both"), env_extra={"SVT_HIP_HOOKS": hooks, "SVT_HIP_RTCD": names}, timeout=1500)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    assert all(v[1] == 0 for v in got["hooks"].values()) and sum(v[0] for v in got["hooks"].values()) > 10, got["hooks"]
+    _check_delegations(got, EXPECTED_DELEGATIONS["both"], "both")
