@@ -270,14 +270,22 @@ def main():
     ap.add_argument("--stages", default="all", help="comma list (debug): " + ",".join(k for k, _ in ALL_STAGES))
     args = ap.parse_args()
 
+    # --gpus N without a launcher: spawn the N ranks here (one process per GPU, torch.distributed.run on 127.0.0.1) and relay rank 0's JSON line.
+    # Under a launcher (WORLD_SIZE set) the two must agree: a silent 1-GPU measurement labelled N would be worse than no number.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}) or drop the launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in the product path)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -556,6 +564,17 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N: N ranks on this node through torch.distributed.run (RCCL only carries the barrier and the max-over-ranks time)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):

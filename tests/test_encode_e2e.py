@@ -217,6 +217,27 @@ def test_padded_source_size_on_gpu(workdir):
     _check_padded_size(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
 
 
+def _check_480p_m4(workdir, env, tag):
+    """854 x 480, preset 4: 128 x 128 superblocks AND a padded width (854 -> 856, the last superblock column is 88 samples of which 2 are padding)"""
+    return _check_geometry("480p_m4", 854, 480, 3, 8, 4, 40, 23, workdir, env, tag)
+
+
+def test_854x480_preset_4_on_cpu_test_double(workdir):
+    _check_480p_m4(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_854x480_preset_4_on_gpu(workdir):
+    _check_480p_m4(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
+@pytest.mark.gpu
+def test_1080p_preset_4_on_gpu(workdir):
+    """1920 x 1080 at a slow preset: 128 x 128 superblocks, the last superblock row 56 rows high -- the loop-filter hooks on the geometry the slow presets
+    use at every practical resolution"""
+    _check_geometry("1080p_m4", 1920, 1080, 2, 8, 4, 40, 29, workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
 def test_padded_source_size_multiple_of_64_on_cpu_test_double(workdir):
     _check_padded_size_64(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
 
