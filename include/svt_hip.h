@@ -693,16 +693,31 @@ int svt_hip_cdef_search_one_dual_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, con
 int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
                                            int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
 /* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once: the chains are independent, one
- * launch per step index advances all that are still running (40 launches instead of 225).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
+ * launch per step index advances all that are still running (40 launches instead of 225; every workgroup reduces 1/8 of the filter blocks for 16 luma
+ * strengths on chip before it touches the totals).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
  * cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each count and the totals). */
 typedef struct {
     int32_t  lev0[4][8], lev1[4][8]; /* [log2 nb_strengths][pair]: cdef_y_strength / cdef_uv_strength indices */
     uint32_t reserved[4];
     uint64_t tot_mse[4];
 } SvtHipCdefSelectResult;
-#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)4 * 2 * 4096 * 8)
+#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)4 * 3 * 4096 * 8 + 64)
 int svt_hip_cdef_strength_select_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int start_gi, int end_gi, void *d_state,
                                      size_t state_bytes);
+/* finish_cdef_search after its four searches (EbEncCdef.c:1258-1298): the number of signalled strength pairs by rate-distortion cost
+ * (RDCOST(lambda, av1_cost_literal(sb_count * bits + nb * CDEF_STRENGTH_BITS * 2), tot_mse * 16), the first minimum over bits = 0..3), then every filter
+ * block's pair (first minimum of mse0[i][y[gi]] + mse1[i][uv[gi]]).  d_state = what svt_hip_cdef_strength_select_dev left; d_sel_gi[sb_count] = the
+ * index the reference stores in mbmi.cdef_strength; d_fb_y / d_fb_uv (may be NULL) receive the strength values per filter block in the layout
+ * svt_hip_cdef_apply_frame_dev reads, at d_sb_fb[i] (NULL: i) -- the distortion tables only list the filter blocks that are not all-skip.  The
+ * strength values are positions in the caller's strength list: the reduced lists of the fast pick methods are mapped by the caller
+ * (get_cdef_filter_strengths), as finish_cdef_search does after this point. */
+typedef struct {
+    int32_t  cdef_bits, nb_strengths;
+    int32_t  y_strength[8], uv_strength[8];
+    uint64_t best_cost;
+} SvtHipCdefFinish;
+int svt_hip_cdef_finish_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, const void *d_state, uint64_t lambda,
+                            const int32_t *d_sb_fb, SvtHipCdefFinish *d_out, int32_t *d_sel_gi, uint8_t *d_fb_y, uint8_t *d_fb_uv);
 /* The self-guided projection on MATERIALISED filter planes (the form the reference's pointers have; the frame kernels never write flt0 / flt1):
  * mode 0 = svt_get_proj_subspace (common_dsp_rtcd.h; EbRestorationPick.c:448): d_acc[5] = {H00, H01, H11, C0, C1} as exact integers, d_xq[2] = the
  * solved pair; mode 1 = svt_av1_lowbd_pixel_proj_error / svt_av1_highbd_pixel_proj_error (:174, :244): d_acc[0] = the squared error of the

@@ -297,7 +297,7 @@ int svt_hip_setup_rtcd(SvtHipCtx *ctx, SvtHipRtcd *table);
 /* Per-wrapper bookkeeping on stderr: "svt_hip_rtcd_calls <wrapper> calls=N" for every wrapper that ran and
  * "svt_hip_rtcd_delegated <table entry> count=N device_failures=M" for every entry that handed a call to the saved pointer (a call outside the
  * kernel's domain, or -- counted separately and logged every time with the error string -- a failed device call).  Returns the delegation total. */
-long svt_hip_rtcd_report(void);
+int svt_hip_rtcd_report(void);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -119,6 +119,17 @@ enccdef = Patch("Source/Lib/Encoder/Codec/EbEncCdef.c")
 enccdef.sub(r'(uint64_t tot_mse\s*=\s*)(joint_strength_search_dual\(\s*best_lev0, best_lev1, nb_strengths, mse, sb_count, start_gi, end_gi\);)',
             r'uint64_t tot_mse = 0;\n        if (!svt_hip_hook_cdef_joint_search(best_lev0, best_lev1, nb_strengths, mse, sb_count, start_gi, end_gi, &tot_mse))\n'
             r'            tot_mse = \2')
+# ... and with them the rest of the decision (:1258-1298): the count of strength pairs by RDCOST and every filter block's pair come back from the device in
+# one go (svt_hip_hook_cdef_finish); the reference keeps writing them into the frame header and the mode-info grid.  Not handled: the loops run as they are.
+enccdef.sub(r'(\n    nb_strength_bits = 0;\n)(    /\* Search for different number of signalling bits\. \*/\n    for \(i = 0; i <= 3)(; i\+\+\) \{)',
+            r'\1    int32_t hip_lev0[CDEF_MAX_STRENGTHS], hip_lev1[CDEF_MAX_STRENGTHS];\n'
+            r'    const int hip_fin = svt_hip_hook_cdef_finish(mse, sb_count, start_gi, end_gi, lambda, &nb_strength_bits, hip_lev0, hip_lev1, selected_strength);\n'
+            r'    for (int hip_j = 0; hip_fin && hip_j < (1 << nb_strength_bits); hip_j++) {\n'
+            r'        frm_hdr->cdef_params.cdef_y_strength[hip_j]  = hip_lev0[hip_j];\n'
+            r'        frm_hdr->cdef_params.cdef_uv_strength[hip_j] = hip_lev1[hip_j];\n'
+            r'    }\n\2 && !hip_fin\3')
+enccdef.sub(r'(for \(gi = 0; gi < ppcs->nb_cdef_strengths)(; gi\+\+\) \{\n\s*uint64_t curr = mse\[0\]\[i\]\[frm_hdr->cdef_params\.cdef_y_strength\[gi\]\];)', r'\1 && !hip_fin\2')
+enccdef.sub(r'(\n[ \t]*)(selected_strength\[i\] = best_gi;)', r'\1if (hip_fin) best_gi = selected_strength[i];\1\2')
 PATCHES.append(enccdef)
 
 # ---------------------------------------------------------------------------------------------------------------- picture analysis

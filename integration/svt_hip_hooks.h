@@ -125,6 +125,11 @@ void        svt_hip_hook_picture_done(PictureControlSet *pcs);
 int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32_t nb_strengths, uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi,
                                    int32_t end_gi, uint64_t *tot_mse);
 
+/* finish_cdef_search, in place of everything it does with the two distortion tables (the four searches, the count of strength pairs by RDCOST, every filter
+ * block's pair; EbEncCdef.c:1258-1298): 1 = *nb_strength_bits, y_strength / uv_strength [1 << bits] and selected[sb_count] hold the device result */
+int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi, int32_t end_gi, uint64_t lambda, int32_t *nb_strength_bits, int32_t *y_strength,
+                             int32_t *uv_strength, int32_t *selected);
+
 /* ------------------------------------------------------------------ picture analysis (svt_hip_pa_bridge.c); EB_ErrorNone = handled */
 EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,
                                        int filtered);

@@ -890,3 +890,38 @@ int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32
     if (nb_strengths == 8) tls_sel.valid = 0;   /* the picture's last call */
     return 1;
 }
+
+/* ------------------------------------------------------------------ hook "cdef_finish", whole: everything finish_cdef_search does with the two distortion tables
+ * (EbEncCdef.c:1258-1298) -- the four joint_strength_search_dual searches, the count of strength pairs by RDCOST, every filter block's pair -- in one
+ * upload, 42 launches and one download.  1 = handled: *nb_strength_bits, y / uv strengths [8] and selected[sb_count] are filled in; the reference then only
+ * copies them into the frame header and the mode-info grid.  0: the reference's own loops run (with the per-search hook above). */
+int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi, int32_t end_gi, uint64_t lambda, int32_t *nb_strength_bits, int32_t *y_strength,
+                             int32_t *uv_strength, int32_t *selected) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_FINISH) || sb_count < 0) return 0;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return 0;
+    const size_t mb = (size_t)sb_count * 64 * sizeof(uint64_t);
+    void *d_m0 = NULL, *d_m1 = NULL, *d_state = NULL, *d_out = NULL, *d_sel = NULL;
+    SvtHipCdefFinish fin;
+    int rc = svt_hip_malloc(hip, &d_m0, mb + 8);
+    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_m1, mb + 8);
+    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_out, sizeof(fin));
+    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sel, sizeof(int32_t) * (size_t)(sb_count + 1));
+    if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m0, mse[0], mb);
+    if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m1, mse[1], mb);
+    if (rc == SVT_HIP_OK) rc = svt_hip_cdef_strength_select_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, start_gi, end_gi, d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+    if (rc == SVT_HIP_OK)
+        rc = svt_hip_cdef_finish_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, d_state, lambda, NULL, (SvtHipCdefFinish *)d_out, (int32_t *)d_sel, NULL, NULL);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &fin, d_out, sizeof(fin));
+    if (rc == SVT_HIP_OK && sb_count) rc = svt_hip_memcpy_d2h(hip, selected, d_sel, sizeof(int32_t) * (size_t)sb_count);
+    svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state); svt_hip_free(hip, d_out); svt_hip_free(hip, d_sel);
+    if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength decision on the device failed (%s): C loops\n", svt_hip_last_error(hip));
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_FINISH, rc == SVT_HIP_OK);
+    if (rc != SVT_HIP_OK) return 0;
+    *nb_strength_bits = fin.cdef_bits;
+    for (int j = 0; j < fin.nb_strengths; j++) { y_strength[j] = fin.y_strength[j]; uv_strength[j] = fin.uv_strength[j]; }
+    svt_hip_hooks_log("cdef_finish: %d filter blocks, %d strength pair(s), first (%d, %d)", sb_count, fin.nb_strengths, fin.y_strength[0], fin.uv_strength[0]);
+    return 1;
+}

@@ -246,3 +246,33 @@ void orc_cdef_apply_frame(const void *const in[3], void *const out[3], const int
         }
     }
 }
+
+/* finish_cdef_search after its four joint_strength_search_dual calls (Encoder/Codec/EbEncCdef.c:1258-1298): the count of signalled strength pairs by
+ * RDCOST (EbRateDistortionCost.h:106, av1_cost_literal EbMdRateEstimation.h:35), then every filter block's pair index.  lev0 / lev1 / tot: [4][8] / [4]
+ * = the searches' results for 1, 2, 4, 8 pairs.  Returns the chosen log2 count; y / uv [8] = its pairs; sel[sb_count] = the index per filter block. */
+int orc_cdef_finish(const uint64_t *mse0, const uint64_t *mse1, int sb_count, const int32_t (*lev0)[8], const int32_t (*lev1)[8], const uint64_t *tot, uint64_t lambda,
+                    int32_t *y, int32_t *uv, int32_t *sel, uint64_t *best_cost) {
+    uint64_t best = (uint64_t)1 << 63;
+    int bits = 0;
+    for (int i = 0; i <= 3; i++) {
+        const int nb = 1 << i;
+        const int total_bits = sb_count * i + nb * 6 * 2;   /* CDEF_STRENGTH_BITS */
+        const int rate_cost = total_bits * (1 << 9);
+        const uint64_t dist = tot[i] * 16;
+        const uint64_t cost = ((((uint64_t)rate_cost) * lambda + 256) >> 9) + dist * (1 << 7);
+        if (cost < best) { best = cost; bits = i; }
+    }
+    const int nb = 1 << bits;
+    for (int g = 0; g < 8; g++) { y[g] = g < nb ? lev0[bits][g] : 0; uv[g] = g < nb ? lev1[bits][g] : 0; }
+    for (int i = 0; i < sb_count; i++) {
+        uint64_t bm = (uint64_t)1 << 63;
+        int bg = 0;
+        for (int g = 0; g < nb; g++) {
+            const uint64_t c = mse0[(size_t)i * 64 + y[g]] + mse1[(size_t)i * 64 + uv[g]];
+            if (c < bm) { bm = c; bg = g; }
+        }
+        sel[i] = bg;
+    }
+    if (best_cost) *best_cost = best;
+    return bits;
+}

@@ -126,6 +126,23 @@ int svt_hip_cdef_strength_select_dev(SvtHipCtx *c, const uint64_t *m0, const uin
     return SVT_HIP_OK;
 }
 
+int svt_hip_cdef_finish_dev(SvtHipCtx *c, const uint64_t *m0, const uint64_t *m1, int sb_count, const void *state, uint64_t lambda, const int32_t *sb_fb, SvtHipCdefFinish *out,
+                            int32_t *sel_gi, uint8_t *fb_y, uint8_t *fb_uv) {
+    (void)c;
+    const SvtHipCdefSelectResult *r = (const SvtHipCdefSelectResult *)state;
+    int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (sb_count > 0 ? sb_count : 1));
+    out->cdef_bits = orc_cdef_finish(m0, m1, sb_count, r->lev0, r->lev1, r->tot_mse, lambda, out->y_strength, out->uv_strength, sel, &out->best_cost);
+    out->nb_strengths = 1 << out->cdef_bits;
+    for (int i = 0; i < sb_count; i++) {
+        if (sel_gi) sel_gi[i] = sel[i];
+        const int fb = sb_fb ? sb_fb[i] : i;
+        if (fb_y) fb_y[fb] = (uint8_t)out->y_strength[sel[i]];
+        if (fb_uv) fb_uv[fb] = (uint8_t)out->uv_strength[sel[i]];
+    }
+    free(sel);
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ picture analysis */
 int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
     (void)c;

@@ -240,4 +240,6 @@ void orc_sad_loop16_batch(const uint16_t *src, int src_stride, const uint16_t *r
 #ifdef __cplusplus
 }
 #endif
+int orc_cdef_finish(const uint64_t *mse0, const uint64_t *mse1, int sb_count, const int32_t (*lev0)[8], const int32_t (*lev1)[8], const uint64_t *tot, uint64_t lambda,
+                    int32_t *y, int32_t *uv, int32_t *sel, uint64_t *best_cost);
 #endif

@@ -112,6 +112,9 @@ def tx_desc(x, y, tx_type):
 _lib = None
 
 
+CDEF_SELECT_STATE_BYTES = 304 + 4 * 3 * 4096 * 8 + 64   # SVT_HIP_CDEF_SELECT_STATE_BYTES (include/svt_hip.h)
+
+
 def lib():
     """Load libsvtav1_hip.so (once) and attach prototypes. Raises if the library was not built."""
     global _lib
@@ -144,6 +147,9 @@ def lib():
     L.svt_hip_me_fullpel_frame.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
     L.svt_hip_me_set_big_windows.argtypes = [vp, i32]
+    L.svt_hip_cdef_strength_select_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_size_t]
+    L.svt_hip_cdef_finish_dev.argtypes = [vp, vp, vp, i32, vp, C.c_uint64, vp, vp, vp, vp, vp]
+    L.svt_hip_dlf_filtered_units.argtypes = [i32, i32, i32, i32]
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]

@@ -15,6 +15,7 @@
 //   diffwtd_mask          Common/Codec/EbInterPrediction.c:78-175; Common/C_DEFAULT/EbInterPrediction_c.c:15-45  svt_av1_build_compound_diffwtd_mask[_highbd|_d16]_c
 //   blend_d16             Common/Codec/EbBlend_a64_mask.c:34-215            svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "svt_hip_internal.h"
 
@@ -201,54 +202,92 @@ one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int
 
 // ------------------------------------------------------------------------------------------------ CDEF: the whole strength-pair selection of a picture
 // finish_cdef_search runs joint_strength_search_dual for 1, 2, 4 and 8 pairs (EbEncCdef.c:1258): four independent chains of 5, 10, 20 and 40
-// svt_search_one_dual steps.  One launch per step index advances every chain that is still running (blockIdx.z = chain); a step is ONE kernel: the
-// workgroups form the running best of their filter blocks on the fly, accumulate the totals with 64-bit atomics, and the workgroup that finishes
-// last picks the pair, shifts the list when the next step is a refinement step, clears the totals of the next step and resets the counter.
+// svt_search_one_dual steps.  One launch per step index advances every chain that is still running (blockIdx.z = chain); a step is ONE kernel.
+// A workgroup of 16 waves owns (chain, 16 luma strengths, one of kJointParts slices of the filter blocks): lane = chroma strength, a wave walks 1/16 of
+// the slice with 16 running totals in registers (the luma distortions and the running best of a filter block are wave-uniform: scalar loads), the 16
+// waves add into one LDS table and the workgroup issues ONE 64-bit atomic per (pair, slice) -- kJointParts x 4096 per chain and step instead of one
+// per (pair, 32 filter blocks).  When every per-block distortion is below 2^27 (joint_init_kernel looks) the per-lane arithmetic is 32-bit: add, min, add.
+// The workgroup that finishes last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next step is a refinement
+// step and resets the counter; the totals are triple-buffered and every workgroup clears its share of the buffer of step + 2 on the way.
 struct JointState {
     int lev0[4][8], lev1[4][8];
     unsigned int counter[4];
     unsigned long long result[4];          // total of the chain's last step
-    unsigned long long tot[4][2][4096];    // double-buffered by step parity
+    unsigned long long tot[4][3][4096];    // by step % 3
+    unsigned long long max0, max1;         // largest entry of each table (joint_init_kernel)
 };
-constexpr int kJointRows = 32;   // filter blocks per workgroup
+constexpr int kJointParts = 8;
 __global__ void __launch_bounds__(256)
+joint_init_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int n, JointState* __restrict__ S) {
+    unsigned long long m0 = 0, m1 = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { m0 = max(m0, (unsigned long long)mse0[i]); m1 = max(m1, (unsigned long long)mse1[i]); }
+    for (int o = 32; o > 0; o >>= 1) { m0 = max(m0, (unsigned long long)__shfl_xor((long long)m0, o)); m1 = max(m1, (unsigned long long)__shfl_xor((long long)m1, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&S->max0, m0); atomicMax(&S->max1, m1); }
+}
+template <bool NARROW>
+__device__ __forceinline__ void joint_accumulate(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int ia, int ib, int start_gi, int ng, int jg, int kk,
+                                                 int idx, const int* l0, const int* l1, unsigned long long (&acc)[16]) {
+    typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type T;
+    T a32[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) a32[t] = 0;
+    const bool lane_on = kk < ng;
+    for (int i = ia; i < ib; i++) {                      // i is wave-uniform
+        const uint64_t* a = mse0 + (size_t)i * 64;       // uniform address: scalar loads
+        const uint64_t* b = mse1 + (size_t)i * 64;
+        uint64_t best = (uint64_t)1 << 63;
+        for (int g = 0; g < idx; g++) { const uint64_t v = a[l0[g]] + b[l1[g]]; best = v < best ? v : best; }
+        const T bk = lane_on ? (T)b[start_gi + kk] : (T)0;
+        const T bb = NARROW ? (T)(best > 0xffffffffull ? 0xffffffffull : best) : (T)best;   // every candidate is below 2^28: clamping the initial 1 << 63 changes nothing
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const T v = (T)a[start_gi + min(jg + t, ng - 1)] + bk;
+            a32[t] += v < bb ? v : bb;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) acc[t] = a32[t];
+}
+__global__ void __launch_bounds__(1024)
 joint_step_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, int step, JointState* __restrict__ S) {
     const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
     if (step >= total_steps) return;
     const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
     __shared__ int s_l0[8], s_l1[8];
     __shared__ bool s_last;
-    __shared__ unsigned long long s_best[kJointRows];
+    __shared__ unsigned long long s_tot[16][64];
     if (threadIdx.x < 8) { s_l0[threadIdx.x] = S->lev0[c][threadIdx.x]; s_l1[threadIdx.x] = S->lev1[c][threadIdx.x]; }
-    __syncthreads();
-    const int i0 = blockIdx.x * kJointRows, i1 = min(i0 + kJointRows, sb_count);
-    unsigned long long* tot = S->tot[c][step & 1];
-    // the running best of this workgroup's filter blocks over the pairs selected so far
-    if ((int)threadIdx.x < kJointRows && i0 + (int)threadIdx.x < i1) {
-        const uint64_t *a = mse0 + (size_t)(i0 + threadIdx.x) * 64, *b = mse1 + (size_t)(i0 + threadIdx.x) * 64;
-        uint64_t best = (uint64_t)1 << 63;
-        for (int g = 0; g < idx; g++) { const uint64_t v = a[s_l0[g]] + b[s_l1[g]]; best = v < best ? v : best; }
-        s_best[threadIdx.x] = best;
+    s_tot[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+    const int part = blockIdx.x % kJointParts, jq = blockIdx.x / kJointParts;   // jq: which 16 luma strengths
+    {   // this workgroup's share of the totals of step + 2 (nobody reads or adds to that buffer before the launch after next)
+        unsigned long long* clr = S->tot[c][(step + 2) % 3];
+        const int wg = blockIdx.x, nwg = gridDim.x;
+        for (int t = wg * 1024 + threadIdx.x; t < 4096; t += nwg * 1024) clr[t] = 0;
     }
     __syncthreads();
-    // lane = chroma strength k, wave = 16 consecutive luma strengths j: mse1[i][k] is loaded once per row and reused for the wave's 16 totals
-    const int kk = threadIdx.x & 63, jg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 16;
-    unsigned long long acc[16];
+    unsigned long long* tot = S->tot[c][step % 3];
+    const int kk = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), jg = jq * 16;
+    // slice `part` of the filter blocks, split again over the 16 waves
+    const int p0 = (int)((long long)sb_count * part / kJointParts), p1 = (int)((long long)sb_count * (part + 1) / kJointParts);
+    const int ia = p0 + (int)((long long)(p1 - p0) * w / 16), ib = p0 + (int)((long long)(p1 - p0) * (w + 1) / 16);
+    if (jg < ng) {
+        int l0[8], l1[8];
 #pragma unroll
-    for (int t = 0; t < 16; t++) acc[t] = 0;
-    if (kk < ng)
-        for (int i = i0; i < i1; i++) {
-            const uint64_t bk = mse1[(size_t)i * 64 + start_gi + kk], best = s_best[i - i0];
-            const uint64_t* a = mse0 + (size_t)i * 64 + start_gi + jg;
+        for (int g = 0; g < 8; g++) { l0[g] = __builtin_amdgcn_readfirstlane(s_l0[g]); l1[g] = __builtin_amdgcn_readfirstlane(s_l1[g]); }
+        unsigned long long acc[16];
+        const bool narrow = S->max0 < (1ull << 27) && S->max1 < (1ull << 27) && (ib - ia) <= 16;   // 16 blocks x 2^28 < 2^32
+        if (narrow) joint_accumulate<true>(mse0, mse1, ia, ib, start_gi, ng, jg, kk, idx, l0, l1, acc);
+        else joint_accumulate<false>(mse0, mse1, ia, ib, start_gi, ng, jg, kk, idx, l0, l1, acc);
+        if (kk < ng) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                if (jg + t < ng) { const uint64_t v = a[t] + bk; acc[t] += v < best ? v : best; }
-            }
+            for (int t = 0; t < 16; t++)
+                if (jg + t < ng && acc[t]) atomicAdd(&s_tot[t][kk], acc[t]);
         }
-    if (kk < ng) {
-#pragma unroll
-        for (int t = 0; t < 16; t++)
-            if (jg + t < ng) atomicAdd(&tot[(jg + t) * ng + kk], acc[t]);
+    }
+    __syncthreads();
+    {
+        const int t = threadIdx.x >> 6;
+        if (jg + t < ng && kk < ng && s_tot[t][kk]) atomicAdd(&tot[(jg + t) * ng + kk], s_tot[t][kk]);
     }
     __threadfence();
     __syncthreads();
@@ -257,12 +296,29 @@ joint_step_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict_
     if (!s_last) return;
     __threadfence();
     // the last workgroup of this chain's step: first minimum in (j, k) raster order
-    unsigned long long bv;
-    int                bi;
-    block_argmin_first(tot, ng * ng, bv, bi);
-    unsigned long long* next = S->tot[c][(step + 1) & 1];
-    for (int t = threadIdx.x; t < ng * ng; t += 256) next[t] = 0;
+    __shared__ unsigned long long r_v[1024];
+    __shared__ int                r_i[1024];
+    unsigned long long bv = (unsigned long long)1 << 63;
+    int                bi = 0x7fffffff;
+    {
+        unsigned long long v[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const int i = threadIdx.x + 1024 * t; v[t] = i < ng * ng ? ((const volatile unsigned long long*)tot)[i] : ~0ull; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const int i = threadIdx.x + 1024 * t; if (i < ng * ng && v[t] < bv) { bv = v[t]; bi = i; } }
+    }
+    r_v[threadIdx.x] = bv; r_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int m = 512; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            const unsigned long long ov = r_v[threadIdx.x + m];
+            const int                oi = r_i[threadIdx.x + m];
+            if (ov < r_v[threadIdx.x] || (ov == r_v[threadIdx.x] && oi < r_i[threadIdx.x])) { r_v[threadIdx.x] = ov; r_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
+        bv = r_v[0]; bi = r_i[0];
         const bool any = bi != 0x7fffffff;
         S->lev0[c][idx] = any ? start_gi + bi / ng : 0;
         S->lev1[c][idx] = any ? start_gi + bi % ng : 0;
@@ -271,6 +327,46 @@ joint_step_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict_
             for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
         S->counter[c] = 0;
     }
+}
+
+// finish_cdef_search after the four searches (EbEncCdef.c:1258-1298): the count of strength pairs by rate-distortion cost, then every filter block's
+// pair.  One thread per filter block; every workgroup redoes the four-way cost comparison (a handful of scalar operations).
+struct CdefFinishOut { int cdef_bits, nb_strengths, y_strength[8], uv_strength[8]; unsigned long long best_cost; };
+__global__ void __launch_bounds__(256)
+cdef_finish_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const JointState* __restrict__ S, unsigned long long lambda,
+                   const int* __restrict__ sb_fb, CdefFinishOut* __restrict__ out, int* __restrict__ sel_gi, uint8_t* __restrict__ fb_y, uint8_t* __restrict__ fb_uv) {
+    unsigned long long best = (unsigned long long)1 << 63;
+    int bits = 0;
+    for (int i = 0; i <= 3; i++) {
+        const int nb = 1 << i;
+        const long long total_bits = (long long)sb_count * i + nb * 6 * 2;                       // CDEF_STRENGTH_BITS = 6
+        const unsigned long long rate = (unsigned long long)total_bits << 9, dist = S->result[i] * 16;   // av1_cost_literal
+        const unsigned long long cost = ((rate * lambda + 256) >> 9) + dist * 128;              // RDCOST: AV1_PROB_COST_SHIFT 9, RDDIV_BITS 7
+        if (cost < best) { best = cost; bits = i; }
+    }
+    const int nb = 1 << bits;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out->cdef_bits = bits; out->nb_strengths = nb; out->best_cost = best;
+        for (int g = 0; g < 8; g++) { out->y_strength[g] = g < nb ? S->lev0[bits][g] : 0; out->uv_strength[g] = g < nb ? S->lev1[bits][g] : 0; }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sb_count) return;
+    unsigned long long bm = (unsigned long long)1 << 63;
+    int bg = 0;
+    for (int g = 0; g < nb; g++) {
+        const unsigned long long c = mse0[(size_t)i * 64 + S->lev0[bits][g]] + mse1[(size_t)i * 64 + S->lev1[bits][g]];
+        if (c < bm) { bm = c; bg = g; }
+    }
+    if (sel_gi) sel_gi[i] = bg;
+    const int fb = sb_fb ? sb_fb[i] : i;
+    if (fb_y) fb_y[fb] = (uint8_t)S->lev0[bits][bg];
+    if (fb_uv) fb_uv[fb] = (uint8_t)S->lev1[bits][bg];
+}
+extern "C" int svt_hip_launch_cdef_finish(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, const void* state, unsigned long long lambda, const int* sb_fb,
+                                          void* out, int* sel_gi, uint8_t* fb_y, uint8_t* fb_uv) {
+    hipLaunchKernelGGL(cdef_finish_kernel, dim3(sb_count > 0 ? (sb_count + 255) / 256 : 1), dim3(256), 0, st, mse0, mse1, sb_count, (const JointState*)state, lambda, sb_fb,
+                       (CdefFinishOut*)out, sel_gi, fb_y, fb_uv);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ self-guided projection on materialised filters
@@ -541,8 +637,9 @@ extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* ms
     const int ng = end_gi - start_gi;
     if (hipMemsetAsync(state, 0, sizeof(JointState), st) != hipSuccess) return (int)hipGetLastError();
     if (ng <= 0) return 0;
-    const dim3 grid(sb_count > 0 ? (sb_count + kJointRows - 1) / kJointRows : 1, 1, 4);
-    for (int step = 0; step < 40; step++) hipLaunchKernelGGL(joint_step_kernel, grid, dim3(256), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
+    if (sb_count > 0) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 256)), dim3(256), 0, st, mse0, mse1, sb_count * 64, (JointState*)state);
+    const dim3 grid(kJointParts * ((ng + 15) / 16), 1, 4);
+    for (int step = 0; step < 40; step++) hipLaunchKernelGGL(joint_step_kernel, grid, dim3(1024), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,

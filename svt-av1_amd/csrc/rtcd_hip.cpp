@@ -1158,7 +1158,7 @@ void blend_d16_hbd_hip(uint8_t* dst, uint32_t ds, const uint16_t* s0, uint32_t s
 //   svt_hip_rtcd_calls quantize_b_hip calls=1234
 //   svt_hip_rtcd_delegated svt_aom_quantize_b count=3 device_failures=0
 // (the hooked encoder prints it at exit; tests/test_encode_e2e.py pins the delegated set).  Returns the number of delegations.
-extern "C" long svt_hip_rtcd_report(void) {
+extern "C" int svt_hip_rtcd_report(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     long total = 0;
     for (int i = 0; i < g_ncalls; i++) std::fprintf(stderr, "svt_hip_rtcd_calls %s calls=%ld\n", g_calls[i].key, g_calls[i].n);
@@ -1166,7 +1166,7 @@ extern "C" long svt_hip_rtcd_report(void) {
         std::fprintf(stderr, "svt_hip_rtcd_delegated %s count=%ld device_failures=%ld\n", g_deleg[i].key, g_deleg[i].n, g_deleg[i].device_failures);
         total += g_deleg[i].n;
     }
-    return total;
+    return (int)(total > 0x7fffffff ? 0x7fffffff : total);
 }
 
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {

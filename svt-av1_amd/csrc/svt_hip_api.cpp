@@ -1087,6 +1087,14 @@ int svt_hip_cdef_strength_select_dev(SvtHipCtx* c, const uint64_t* d_mse0, const
     if (e != hipSuccess) return fail(c, e, "strength select launch");
     return SVT_HIP_OK;
 }
+int svt_hip_cdef_finish_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, const void* d_state, uint64_t lambda, const int32_t* d_sb_fb,
+                            SvtHipCdefFinish* d_out, int32_t* d_sel_gi, uint8_t* d_fb_y, uint8_t* d_fb_uv) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mse0 || !d_mse1 || !d_state || !d_out || sb_count < 0) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_cdef_finish(c->stream, d_mse0, d_mse1, sb_count, d_state, lambda, d_sb_fb, d_out, d_sel_gi, d_fb_y, d_fb_uv);
+    if (e != hipSuccess) return fail(c, e, "cdef finish launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_flt_proj_dev(SvtHipCtx* c, int pix_bytes, const void* d_src, int src_stride, const void* d_dat, int dat_stride, const int32_t* d_flt0, int flt0_stride,
                              const int32_t* d_flt1, int flt1_stride, int w, int h, int r0, int r1, int mode, const int32_t* xq, int64_t* d_acc, int32_t* d_xq) {
     SVT_HIP_ENTER(c);

@@ -7,7 +7,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import ptr
+import os
+
+from conftest import ROOT, ptr
 import txfm_common as tc
 
 pytestmark = pytest.mark.gpu
@@ -885,12 +887,16 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
     sequence driven step by step through the reference's svt_search_one_dual_c."""
     rng = np.random.default_rng(5)
     L = hip.L
-    for sb_count, (start, end) in ((1, (0, 64)), (40, (0, 64)), (510, (0, 64)), (77, (0, 16))):
-        m0 = rng.integers(1000, 1 << 22, (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << 21, (sb_count, 64)).astype(np.uint64)
+    # (filter blocks, strength range, magnitude): 2^22 keeps the 32-bit lanes of the picture-level call, 2^40 forces its 64-bit path, 2^27 sits on the switch;
+    # ranges that are not multiples of 16 leave part of a workgroup's 16 luma strengths masked
+    for sb_count, (start, end), mag in ((1, (0, 64), 22), (40, (0, 64), 22), (510, (0, 64), 22), (77, (0, 16), 22), (2040, (0, 64), 22), (2040, (0, 64), 40), (300, (0, 20), 27),
+                                        (1000, (3, 40), 33), (9, (0, 1), 22)):
+        m0 = rng.integers(1000, 1 << mag, (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << (mag - 1), (sb_count, 64)).astype(np.uint64)
         m0[:, 11] = m0[:, 2]; m1[:, 9] = m1[:, 4]
+        if mag == 27: m0[sb_count // 2, 5] = (1 << 27) - 1
         ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
         d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
-        state_bytes = 304 + 4 * 2 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+        state_bytes = 304 + 4 * 3 * 4096 * 8 + 64   # SVT_HIP_CDEF_SELECT_STATE_BYTES
         d_state = hip.empty(state_bytes)
         hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
         sel = hip.to_host(d_state, (304,), np.uint8)
@@ -910,5 +916,24 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
             assert int(sel_tot[ci]) == tot and np.array_equal(sel_lev0[ci, :nb], l0[:nb]) and np.array_equal(sel_lev1[ci, :nb], l1[:nb]), \
                 ("strength select", sb_count, nb, int(sel_tot[ci]), tot, sel_lev0[ci], l0, sel_lev1[ci], l1)
             hip.free(d_lev, d_work)
+        # ... and the decision finish_cdef_search builds on them (the count of pairs by RDCOST, every filter block's pair) against the oracle's restatement,
+        # at lambdas either side of the switch between counts
+        orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        for lam in (1, 3000, 70000, 5_000_000, 1 << 33):
+            d_out = hip.empty(88); d_sel = hip.empty(4 * (sb_count + 1)); d_fy = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8)); d_fuv = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8))
+            fbmap = (np.arange(sb_count, dtype=np.int32) * 2 + 1)
+            d_map = hip.to_device(fbmap)
+            hip.check(L.svt_hip_cdef_finish_dev(hip.h, d_m0, d_m1, sb_count, d_state, lam, d_map, d_out, d_sel, d_fy, d_fuv), "cdef finish")
+            out = hip.to_host(d_out, (88,), np.uint8); g_sel = hip.to_host(d_sel, (sb_count,), np.int32)
+            g_bits, g_nb = out[:8].view(np.int32); g_y = out[8:40].view(np.int32); g_uv = out[40:72].view(np.int32); g_cost = int(out[80:88].view(np.uint64)[0])
+            y = np.zeros(8, np.int32); uv = np.zeros(8, np.int32); o_sel = np.zeros(max(sb_count, 1), np.int32); cost = C.c_uint64(0)
+            orc.orc_cdef_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            bits = orc.orc_cdef_finish(_vp(m0), _vp(m1), sb_count, _vp(np.ascontiguousarray(sel_lev0)), _vp(np.ascontiguousarray(sel_lev1)), _vp(np.ascontiguousarray(sel_tot)), lam,
+                                       _vp(y), _vp(uv), _vp(o_sel), C.byref(cost))
+            assert (g_bits, g_nb, g_cost) == (bits, 1 << bits, cost.value) and np.array_equal(g_y, y) and np.array_equal(g_uv, uv) and np.array_equal(g_sel, o_sel[:sb_count]), \
+                ("cdef finish", sb_count, lam, g_bits, bits, g_y, y)
+            fy = hip.to_host(d_fy, (2 * sb_count + 3,), np.uint8); fuv = hip.to_host(d_fuv, (2 * sb_count + 3,), np.uint8)
+            assert np.array_equal(fy[fbmap], y[o_sel[:sb_count]].astype(np.uint8)) and np.array_equal(fuv[fbmap], uv[o_sel[:sb_count]].astype(np.uint8)) and np.all(fy[::2] == 77)
+            hip.free(d_out, d_sel, d_fy, d_fuv, d_map)
         hip.free(d_state)
         hip.free(d_m0, d_m1)

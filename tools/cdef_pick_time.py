@@ -31,8 +31,8 @@ with torch.cuda.stream(st):
     for _ in range(5): g.replay()
     g1.record(st); torch.cuda.synchronize()
 print(f"the same as one captured HIP graph: {g0.elapsed_time(g1) / 5:.3f} ms per frame")
-d_state = hip.empty(304 + 4 * 2 * 4096 * 8)
-def run2(): hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, n, 0, 64, d_state, 304 + 4 * 2 * 4096 * 8), "select")
+d_state = hip.empty(304 + 4 * 3 * 4096 * 8 + 64)
+def run2(): hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, n, 0, 64, d_state, 304 + 4 * 3 * 4096 * 8 + 64), "select")
 with torch.cuda.stream(st):
     run2(); torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,3 +41,16 @@ with torch.cuda.stream(st):
     s1.record(st); torch.cuda.synchronize()
 print(f"svt_hip_cdef_strength_select_dev (the four chains side by side, one launch per step index, 40 launches): {s0.elapsed_time(s1) / 5:.3f} ms per frame")
 print(f"cdef strength-pair selection, 2040 filter blocks, nb = 1 + 2 + 4 + 8 (75 steps): {e0.elapsed_time(e1) / 5:.3f} ms per frame (eager launches)")
+g2 = torch.cuda.CUDAGraph()
+cap2 = torch.cuda.Stream(); cap2.wait_stream(st)
+L.svt_hip_set_stream(hip.h, C.c_void_p(cap2.cuda_stream))
+with torch.cuda.graph(g2, stream=cap2):
+    run2()
+L.svt_hip_set_stream(hip.h, C.c_void_p(st.cuda_stream))
+with torch.cuda.stream(st):
+    g2.replay(); torch.cuda.synchronize()
+    h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h0.record(st)
+    for _ in range(10): g2.replay()
+    h1.record(st); torch.cuda.synchronize()
+print(f"svt_hip_cdef_strength_select_dev as one captured HIP graph: {h0.elapsed_time(h1) / 10:.3f} ms per frame")
