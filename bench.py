@@ -11,10 +11,11 @@ graph.  `--frames 1` is the single-frame step; the JSON line carries the F = 1 /
 Per frame, in the encoder's data flow:
     source side (open loop, runs ahead of the coding loop):  HME pyramids + variance pyramid -> HME L0/L1/L2 -> integer ME (85 PUs, 64x64
         search area, 1 reference)
-    reconstruction side: sub-pel prediction of every 16x16 luma block (eighth-pel MVs; decoupled from this frame's ME output as in SURVEY 8(d)
-        config 3 ii) -> residual + fwd txfm + quantize against THAT prediction (luma; chroma predicts from the co-located reference) ->
-        inverse txfm + recon -> deblock (3 planes, V then H) -> CDEF 64-strength search -> CDEF apply (per-fb strengths from the workload:
-        the strength *decision* is host logic of the reference) -> the COMPLETE self-guided search of every restoration unit, 16 sets
+    reconstruction side: sub-pel prediction of every 16x16 luma block at THIS frame's integer ME vector of the block + a random eighth-pel phase
+        (SURVEY 8(d) config 3 ii; the job list is built on the device from the ME table) -> residual + fwd txfm + quantize against THAT prediction
+        (luma; chroma predicts from the co-located reference) -> inverse txfm + recon -> deblock (3 planes, V then H) -> CDEF 64-strength search
+        -> finish_cdef_search's decision on the device (four strength-pair searches, count of pairs by RDCOST, every filter block's pair) -> CDEF
+        apply with exactly those strengths -> the COMPLETE self-guided search of every restoration unit, 16 sets
         (sums, 2x2 solve, encode_xq, finer search, best set — all on the device) -> restoration apply with the sets / xqd that search chose.
 `value` = superblocks per second over the whole job (all ranks, all frames of a step).
 
@@ -50,6 +51,7 @@ BYTES_PER_SB = {
     "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
     "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
     "cdef_apply": 12288 + 12288,             # 6144 R + 6144 W, plus the device-to-device copy that initialises the destination (R + W)
+    "cdef_strength_select": 2 * 64 * 8 + 2,  # the two distortion rows of the filter block R (once, if they stayed on chip over the 75 steps) + its strength pair W
     "pyramids": 5376 + 4351,                 # decimation 4096 R + 1024 + 256 W ; variance pyramid 4096 R + 85*3 W
     "hme_l0_l1_l2": 256 + 1024 + 4096 + 3 * 12,   # source blocks of the three levels + results (windows are cache-resident)
     "subpel_convolve": 12560,                # 16 blocks x (16+7)^2 R + 4096 W (luma)
@@ -60,9 +62,10 @@ STAGE_KERNELS = {
     "pyramids": "downsample_kernel+variance_pyramid_kernel", "hme_l0_l1_l2": "sad_loop_kernel", "me_fullpel_85pu": "me_fullpel_85pu_kernel",
     "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel", "fwd_quant_inv_recon": "enc_txfm_multi_kernel",
     "deblock": "deblock_frame_pass_kernel", "cdef_search": "cdef_search_luma_kernel+cdef_search_chroma_kernel", "cdef_apply": "cdef_apply_kernel",
+    "cdef_strength_select": "joint_init_kernel+joint_step_kernel+cdef_finish_kernel",
     "sgr_units_search": "sgr_search8_kernel+sgr_walk_resident_kernel", "sgr_apply": "lr_apply8_kernel",
 }
-SOURCE_SIDE = ("pyr", "hme", "me")   # read only source pictures: the open-loop chain, parallel to the reconstruction chain
+CDEF_LAMBDA = 55473                  # av1_lambda_mode_decision8_bit_sse[120] (EbLambdaRateTables.h:227): full lambda of a key frame at the workload's base_q_idx
 EXT = 3                              # RESTORATION_BORDER: recon / CDEF / restoration planes carry a 3-sample border
 
 
@@ -138,7 +141,10 @@ class Pipeline:
         self.d_mse = torch.zeros((2, self.n_sb, 64), dtype=torch.int64, device=dev)
         self.d_dir = torch.zeros(self.n_sb * 64, dtype=torch.uint8, device=dev)
         self.d_var = torch.zeros(self.n_sb * 64, dtype=torch.int32, device=dev)
-        self.d_cy, self.d_cuv = T(F.cdef_y), T(F.cdef_uv)
+        # CDEF strengths per filter block: written by the strength decision of THIS step (finish_cdef_search on the device), read by the apply
+        self.d_cy = torch.zeros(self.n_sb, dtype=torch.uint8, device=dev); self.d_cuv = torch.zeros(self.n_sb, dtype=torch.uint8, device=dev)
+        self.d_sel_state = torch.zeros(pkg.CDEF_SELECT_STATE_BYTES, dtype=torch.uint8, device=dev)
+        self.d_fin = torch.zeros(88, dtype=torch.uint8, device=dev); self.d_sel_gi = torch.zeros(self.n_sb, dtype=torch.int32, device=dev)
         # pyramids / HME: 1/4 and 1/16 resolution source + reference, variance pyramid
         PADQ, PADS = workload.PADQ, workload.PADS
         qw, qh, sw_, sh_ = W // 2, H // 2, W // 4, H // 4
@@ -151,9 +157,11 @@ class Pipeline:
         self.hme_host = workload.hme_jobs(F)
         self.hme = [dict(S=T(np.frombuffer(bytes(S), np.uint8).copy()), sad=torch.zeros(self.n_sb, dtype=torch.int32, device=dev),
                          xy=torch.zeros((self.n_sb, 2), dtype=torch.int16, device=dev)) for S in self.hme_host]
-        # sub-pel: every 16x16 luma block at an eighth-pel MV (EIGHTTAP_REGULAR), written into the prediction plane
-        self.CB, self.nblk16 = workload.conv_jobs(F, 14 + rank)
-        self.d_cb = T(np.frombuffer(bytes(self.CB), np.uint8)[:self.nblk16 * C.sizeof(pkg.ConvBlk)].copy())
+        # sub-pel: every whole 16x16 luma block at its integer ME vector + a random eighth-pel phase (EIGHTTAP_REGULAR), written into the prediction
+        # plane; the SvtHipConvBlk list is built on the device from this step's ME table
+        self.nblk16 = (W // 16) * (H // 16)
+        self.d_frac = T(np.random.default_rng(14 + rank + 1000 * F.seed).integers(0, 16, (self.nblk16, 2)).astype(np.uint8))
+        self.d_cb = torch.zeros(self.nblk16 * C.sizeof(pkg.ConvBlk), dtype=torch.uint8, device=dev)
         # restoration: the complete per-unit self-guided search (device scratch from the library's own size query) and the apply fed by it
         self.US = [256, 256, 256]   # restoration unit size per plane: what the reference picks above CIF (set_restoration_unit_size, EbPictureControlSet.c:31-47)
         self.n_units = [max((F.cur[p].shape[1] + self.US[p] // 2) // self.US[p], 1) * max((F.cur[p].shape[0] + self.US[p] // 2) // self.US[p], 1) for p in range(3)]
@@ -172,7 +180,7 @@ class Pipeline:
                                                 self.d_scr[p].data_ptr(), self.scr_bytes[p])
         self.stage_fns = dict(pyr=self.run_pyramids, hme=self.run_hme, me=self.run_me, subpel=self.run_subpel, txfm=self.run_txfm, inv=self.run_inv, enc_txfm=self.run_enc_txfm,
                               dlf=self.run_dlf,
-                              cdef_search=self.run_cdef_search, cdef_apply=self.run_cdef_apply, sgr_units=self.run_sgr_units, sgr_apply=self.run_sgr_apply)
+                              cdef_search=self.run_cdef_search, cdef_pick=self.run_cdef_pick, cdef_apply=self.run_cdef_apply, sgr_units=self.run_sgr_units, sgr_apply=self.run_sgr_apply)
 
     # ---------------------------------------------------------------- the kernel classes of a step
     def chk(self, rc, what):
@@ -202,6 +210,14 @@ class Pipeline:
         self.chk(self.E.L.svt_hip_cdef_search_frame_dev(self.E.ctx.h, 1, P3(*self.p_recon), I3(*self.xs), P3(*[p.data_ptr() for p in self.d_cur]), I3(*self.strides), F.w, F.h,
                                                         self.d_skip8.data_ptr(), F.cdef_damping, 8, self.d_mse.data_ptr(), self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef search")
 
+    def run_cdef_pick(self):
+        """finish_cdef_search on the distortion table of the search that just ran: 1 + 40 + 1 launches, no host step; every filter block is listed (none is all-skip here)"""
+        L, h, n = self.E.L, self.E.ctx.h, self.n_sb
+        m0, m1 = self.d_mse.data_ptr(), self.d_mse.data_ptr() + n * 64 * 8
+        self.chk(L.svt_hip_cdef_strength_select_dev(h, m0, m1, n, 0, 64, self.d_sel_state.data_ptr(), self.E.pkg.CDEF_SELECT_STATE_BYTES), "cdef select")
+        self.chk(L.svt_hip_cdef_finish_dev(h, m0, m1, n, self.d_sel_state.data_ptr(), CDEF_LAMBDA, None, self.d_fin.data_ptr(), self.d_sel_gi.data_ptr(), self.d_cy.data_ptr(),
+                                           self.d_cuv.data_ptr()), "cdef finish")
+
     def run_cdef_apply(self):
         F, L, h = self.F, self.E.L, self.E.ctx.h
         self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_recon), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
@@ -223,6 +239,7 @@ class Pipeline:
 
     def run_subpel(self):
         F = self.F
+        self.chk(self.E.L.svt_hip_subpel_jobs_from_me_dev(self.E.ctx.h, self.d_mv.data_ptr(), F.sb_cols, F.w, F.h, self.d_frac.data_ptr(), self.d_cb.data_ptr()), "subpel jobs")
         self.chk(self.E.L.svt_hip_subpel_predict_batch_dev(self.E.ctx.h, 1, 8, self.d_ref_p.data_ptr() + F.pad * F.ref_y_p.shape[1] + F.pad, F.ref_y_p.shape[1],
                                                            self.d_subpel.data_ptr(), F.w, self.d_cb.data_ptr(), self.nblk16), "subpel")
 
@@ -243,7 +260,7 @@ class Pipeline:
 
 
 ALL_STAGES = [("pyr", "pyramids"), ("hme", "hme_l0_l1_l2"), ("me", "me_fullpel_85pu"), ("subpel", "subpel_convolve"), ("enc_txfm", "fwd_quant_inv_recon"),
-              ("txfm", "fwd_txfm_quant"), ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
+              ("txfm", "fwd_txfm_quant"), ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_pick", "cdef_strength_select"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
               ("sgr_apply", "sgr_apply")]
 
 
@@ -259,13 +276,13 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the F = 1 / 4 / 8 sweep")
     ap.add_argument("--no-transfers", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-1080p", action="store_true", help="skip the extra 1920x1080 measurement (a second, short run of this script)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the configs[1] / configs[3] sub-lines (tools/bench_variants.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
                     help="reference = the reference's own SIMD kernels (oracle/_ref SIMD flavour); port = the oracle's scalar C; auto = reference when built")
     ap.add_argument("--me-waves", type=int, default=4, help="svt_hip_me_set_waves_per_sb value (debug)")
-    ap.add_argument("--side", action="store_true", help="run each frame's source-side chain (pyramids, HME, ME) on a second stream (slower on MI355X: 8 streams "
-                                                         "share 4 hardware queues; measured 8.60 vs 8.26 ms per 4-frame step)")
-    ap.add_argument("--no-side", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-side", action="store_true", help="(ignored; kept for older command lines: a frame's chain is one stream -- the sub-pel stage reads this step's ME "
+                                                            "table, and a second stream per frame for the source side measured slower anyway, 8.60 vs 8.26 ms)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--stages", default="all", help="comma list (debug): " + ",".join(k for k, _ in ALL_STAGES))
     args = ap.parse_args()
@@ -326,8 +343,6 @@ def main():
     # ---------------------------------------------------------------- streams / graphs
     # Each frame of the batch gets its own HIP stream, forked from and joined back into the stream that carries the step; inside a captured graph
     # these are parallel branches, so the short memory-side kernels of one frame fill the gaps next to the VALU-bound searches of another.
-    # (--side splits a frame further into its source side — pyramids -> HME -> ME, open loop — and its reconstruction side on two streams; with
-    # four frames that is eight streams on the four hardware queues ROCm multiplexes them onto, and measurably slower.)
     cur = {"s": stream}
 
     class on:
@@ -348,7 +363,6 @@ def main():
 
     max_f = max([nF] + (sweep_fs if not args.no_sweep else []))
     main_streams = [torch.cuda.Stream() for _ in range(max_f)]
-    side_streams = [torch.cuda.Stream() for _ in range(max_f)] if args.side else None
 
     def batch_step(batch, stages=stages, pre=None):
         base = cur["s"]
@@ -357,19 +371,10 @@ def main():
             ms = main_streams[i]
             ms.wait_stream(base)
             used.append(ms)
-            if side_streams is not None:
-                ss = side_streams[i]
-                ss.wait_stream(base)
-                used.append(ss)
-                with on(ss):
-                    for k, _ in stages:
-                        if k in SOURCE_SIDE:
-                            P.stage_fns[k]()
             with on(ms):
                 if pre is not None: pre(P)
                 for k, _ in stages:
-                    if side_streams is None or k not in SOURCE_SIDE:
-                        P.stage_fns[k]()
+                    P.stage_fns[k]()
         for st in used:
             base.wait_stream(st)
 
@@ -451,12 +456,27 @@ def main():
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--width", "1920", "--height", "1080", "--frames", str(4 * nF), "--steps", "30", "--warmup", "3", "--no-sweep",
-                                "--no-transfers", "--no-cpu-baseline", "--no-1080p"], capture_output=True, text=True, timeout=300)
+                                "--no-transfers", "--no-cpu-baseline", "--no-1080p", "--no-variants"], capture_output=True, text=True, timeout=300)
             d2 = json.loads(r.stdout.strip().splitlines()[-1])
             also_1080p = {"value": d2["value"], "unit": d2["unit"], "ms_per_step": d2["ms_per_step"], "frames_per_step": 4 * nF, "workload": d2["config"]["workload"].split(";")[0],
                           "stages_ms": d2["config"]["stages_ms"]}
         except Exception as ex:   # the headline run must not depend on it
             also_1080p = {"error": str(ex)[:200]}
+
+    # ---- the BASELINE.json configurations the headline step does not cover, as sub-lines (tools/bench_variants.py, one short subprocess each):
+    #      configs[1] (1080p: ME with FULL / SUB_SAD search, transform chain 4..32 with quantize_b / quantize_fp at four q-indices) and configs[3] (4K 10-bit:
+    #      HBD SAD / variance, the 64-point transform chain, the self-guided search and filter on 16-bit planes)
+    also_10bit = config1_variants = None
+    if world == 1 and not args.no_variants and not args.no_sweep and (args.width, args.height) == (3840, 2160):
+        import subprocess
+        for which in ("10bit", "config1"):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_variants.py"), "--which", which], capture_output=True, text=True, timeout=420)
+                d2 = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as ex:   # the headline run must not depend on it
+                d2 = {"error": str(ex)[:200]}
+            if which == "10bit": also_10bit = d2
+            else: config1_variants = d2
 
     # ---- per-stage device time with HIP events on the launch stream (outside the headline timing): `reps` back-to-back passes of one stage of
     #      ONE frame (one captured graph unless --no-graph), so the figure is that stage's kernel time alone on an otherwise idle GPU
@@ -532,7 +552,9 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         stage_keys = [dict(key=k, name=n) for k, n in stages]
-        jobs = dict(hme=P0.hme_host, conv=(P0.CB, P0.nblk16), unit=P0.US[0])
+        CB0 = (E.pkg.ConvBlk * P0.nblk16).from_buffer_copy(P0.d_cb.cpu().numpy().tobytes())   # the job list the device built from frame 0's ME table
+        jobs = dict(hme=P0.hme_host, conv=(CB0, P0.nblk16), unit=P0.US[0], cdef_mse=P0.d_mse.cpu().numpy().view(np.uint64), cdef_lambda=CDEF_LAMBDA,
+                    cdef_strengths=(P0.d_cy.cpu().numpy(), P0.d_cuv.cpu().numpy()))
         simd = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
         if args.cpu_baseline in ("auto", "reference") and os.path.exists(simd):
             cpu = cpu_baseline_reference(C.CDLL(simd), orc, F0, P0.sbs, mc, tc, stage_keys, jobs)
@@ -540,22 +562,29 @@ def main():
             raise SystemExit("oracle/_ref/libsvtav1_ref_simd.so is not built (make -f oracle/Makefile.ref simd)")
         else:
             cpu = cpu_baseline(orc, F0, P0.sbs, mc, tc, stage_keys, jobs)
+        if "cdef_fin_ref" in jobs:   # the strength decision of frame 0 against the reference's (dispatched svt_search_one_dual x 75 + the RDCOST choice) on the same table
+            r_fin, r_sel = jobs["cdef_fin_ref"]
+            g_fin = P0.d_fin.cpu().numpy()
+            g_bits = int(g_fin[:4].view(np.int32)[0]); g_y = g_fin[8:40].view(np.int32); g_uv = g_fin[40:72].view(np.int32)
+            same = g_bits == int(r_fin[0]) and np.array_equal(g_y, r_fin[1:9]) and np.array_equal(g_uv, r_fin[9:17]) and np.array_equal(P0.d_sel_gi.cpu().numpy(), r_sel)
+            parity_ok = bool(parity_ok is not False and same)
 
     out = {
         "metric": METRIC, "value": nF * n_sb * args.steps * world / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame" + (" x 2 (source side / reconstruction side)" if side_streams is not None else "") + ", "
+        "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame, "
                   f"steps rotate over {len(step_fns)} batches = {len(step_fns) * nF} distinct frames",
-        "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p,
+        "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p, "also_10bit": also_10bit, "config1_variants": config1_variants,
         "frames_per_step_sweep": sweep,
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frames, {n_sb} SBs/frame, {nF} independent frames per step per GPU (F = 1 / 4 / 8 in frames_per_step_sweep); "
                                "stages per frame: " + ",".join(n for _, n in stages)
-                               + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16 at random eighth-pel MVs (decoupled from this "
-                                 "frame's ME result, SURVEY 8(d) config 3 ii); transform: luma residual against THAT sub-pel prediction, chroma against the co-located reference, "
+                               + "; HME L0 64x32 / L1,L2 16x16 windows; ME 1 ref 64x64 search area; sub-pel 2d_sr on every 16x16 at this step's ME vector of the block + a random "
+                                 "eighth-pel phase; transform: luma residual against THAT sub-pel prediction, chroma against the co-located reference, "
                                  "square tx tiling 4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12) on the reconstruction; CDEF full 64-strength search on the "
-                                 "deblocked picture, apply with workload strengths (strength decision = host logic); restoration: complete search_selfguided_restoration of "
-                                 "every unit (16 sets, units 256, solve + finer search on the device) on the CDEF output, apply with the sets it chose",
+                                 "deblocked picture, finish_cdef_search's strength decision on that table (lambda of base_q_idx 120), apply with the strengths it chose; "
+                                 "restoration: complete search_selfguided_restoration of every unit (16 sets, units 256, solve + finer search on the device) on the CDEF "
+                                 "output, apply with the sets it chose",
                    "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes)",
                    "parity_spot_check": parity_ok, "sgr_walk": walk_stats},
         "cpu_baseline": cpu,
@@ -785,7 +814,7 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
         nfb = F.sb_cols * (rows // 64)
         t0 = time.perf_counter()
         orc.orc_cdef_apply_frame(P3(*[a.ctypes.data for a in ins]), P3(*[a.ctypes.data for a in outs]), I3(*[a.shape[1] for a in ins]), 1, F.w, rows,
-                                 ptr(np.ascontiguousarray(F.skip8[:(rows // 8) * (F.w // 8)])), ptr(F.cdef_y[:nfb].copy()), ptr(F.cdef_uv[:nfb].copy()), F.cdef_damping, 8)
+                                 ptr(np.ascontiguousarray(F.skip8[:(rows // 8) * (F.w // 8)])), ptr(jobs["cdef_strengths"][0][:nfb].copy()), ptr(jobs["cdef_strengths"][1][:nfb].copy()), F.cdef_damping, 8)
         sec_per_sb["cdef_apply"] = (time.perf_counter() - t0) / nfb / cores
     if "pyr" in keys or "hme" in keys:
         W_, H_, st = F.w, F.h, F.cur_y_p.shape[1]
@@ -958,9 +987,20 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
         mse = np.zeros((2, n_sb, 64), np.uint64)
         sec["cdef_search"] = run(5, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + [F.cur[0], F.cur[1], F.cur[2]] + [p.shape[1] for p in F.cur]
                                  + [W_, H_, F.skip8, F.cdef_damping, mse], n_sb, 4, name="cdef_search", one_thread_items=256) / n_sb
+    if "cdef_pick" in keys:
+        # finish_cdef_search's decision is ONE thread's work per picture in the reference (75 dispatched svt_search_one_dual steps + the RDCOST choice): timed as
+        # `cores` pictures side by side (the device's own distortion table of frame 0 for each), i.e. as if the encoder kept that many pictures in flight
+        m = np.ascontiguousarray(jobs["cdef_mse"]).reshape(2, n_sb, 64)
+        npic = cores
+        fin = np.zeros((npic, 17), np.int32); sel = np.zeros((npic, n_sb), np.int32)
+        t = run(10, [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel], npic, 1, reps=1)
+        sec["cdef_strength_select"] = t / npic / n_sb   # one picture per thread, all threads busy
+        sec1["cdef_strength_select"] = refb.refb_parallel(10, C.addressof((C.c_int64 * 6)(*[adr(v) for v in [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel]])), 1, 1, 1, 1)
+        jobs["cdef_fin_ref"] = (fin[0].copy(), sel[0].copy())
     if "cdef_apply" in keys:
         outs = [p.copy() for p in F.ref]
-        sec["cdef_apply"] = run(6, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + outs + [W_, H_, F.skip8, F.cdef_y, F.cdef_uv, F.cdef_damping], n_sb, 4, name="cdef_apply", one_thread_items=256) / n_sb
+        cy_, cuv_ = jobs["cdef_strengths"]
+        sec["cdef_apply"] = run(6, [F.ref[0], F.ref[1], F.ref[2]] + [p.shape[1] for p in F.ref] + outs + [W_, H_, F.skip8, cy_, cuv_, F.cdef_damping], n_sb, 4, name="cdef_apply", one_thread_items=256) / n_sb
     if "sgr_units" in keys or "sgr_apply" in keys:
         US = jobs.get("unit", 256)
         EXT_ = 3

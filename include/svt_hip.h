@@ -293,6 +293,12 @@ typedef struct {
  * every block (the reference's padded pictures are).  strides in pixels. */
 int svt_hip_subpel_predict_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_ref, int ref_stride, void *d_dst,
                                      int dst_stride, const SvtHipConvBlk *d_blks, int nblk);
+/* The job list of the sub-pel stage straight from the open-loop ME table, on the device: one mode-0 SvtHipConvBlk (EIGHTTAP_REGULAR both ways) per
+ * whole 16x16 luma block of a w x h picture, in raster order -- (w / 16) * (h / 16) entries -- whose integer position is the block's position plus the
+ * full-pel vector of its 16x16 PU in d_best_mv (the [n_sb][85] MV table of svt_hip_me_fullpel_frame_dev: EbMeTierZeroPu order, 16x16 PUs at 5 + the
+ * z-order index inside the superblock), and whose q4 phases are d_frac_q4[2 * k], [2 * k + 1] (NULL: 0).  This is how md_subpel_search starts: the
+ * sub-pel refinement of a block begins at its open-loop ME vector (EbProductCodingLoop.c:2063-2160). */
+int svt_hip_subpel_jobs_from_me_dev(SvtHipCtx *ctx, const uint32_t *d_best_mv, int sb_cols, int w, int h, const uint8_t *d_frac_q4, SvtHipConvBlk *d_blks);
 
 typedef struct {
     int32_t a_x, a_y, b_x, b_y;

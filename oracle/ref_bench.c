@@ -299,6 +299,51 @@ void refb_sgr_search_units_plane(const uint8_t *dgd, int stride, const uint8_t *
     svt_aom_free(rstbuf);
 }
 
+/* finish_cdef_search's decision on ONE picture's two distortion tables (EbEncCdef.c:1258-1298): the four joint_strength_search_dual sequences (a static
+ * function: restated here as the greedy + refinement loop it is, every step through the dispatched svt_search_one_dual pointer, i.e. the reference's
+ * AVX2 / AVX-512 kernel where the host has it), then the count of pairs by RDCOST and every filter block's pair (the oracle's restatement of that
+ * arithmetic).  out: [0] = bits, [1..8] y strengths, [9..16] uv strengths; sel[sb_count].  One picture is one thread's work in the reference. */
+static int refb_finish_tail(const uint64_t *mse0, const uint64_t *mse1, int sb_count, const int32_t (*lev0)[8], const int32_t (*lev1)[8], const uint64_t *tot, uint64_t lambda,
+                            int32_t *y, int32_t *uv, int32_t *sel) {   /* EbEncCdef.c:1258-1298 (the same lines orc_cdef_finish restates; this library does not link the oracle) */
+    uint64_t best = (uint64_t)1 << 63;
+    int bits = 0;
+    for (int i = 0; i <= 3; i++) {
+        const int nb = 1 << i, total_bits = sb_count * i + nb * CDEF_STRENGTH_BITS * 2, rate_cost = total_bits * (1 << 9);
+        const uint64_t dist = tot[i] * 16, cost = ((((uint64_t)rate_cost) * lambda + 256) >> 9) + dist * (1 << 7);
+        if (cost < best) { best = cost; bits = i; }
+    }
+    const int nb = 1 << bits;
+    for (int g = 0; g < 8; g++) { y[g] = g < nb ? lev0[bits][g] : 0; uv[g] = g < nb ? lev1[bits][g] : 0; }
+    for (int i = 0; i < sb_count; i++) {
+        uint64_t bm = (uint64_t)1 << 63;
+        int bg = 0;
+        for (int g = 0; g < nb; g++) {
+            const uint64_t c = mse0[(size_t)i * 64 + y[g]] + mse1[(size_t)i * 64 + uv[g]];
+            if (c < bm) { bm = c; bg = g; }
+        }
+        sel[i] = bg;
+    }
+    return bits;
+}
+void refb_cdef_finish(const uint64_t *mse0, const uint64_t *mse1, int sb_count, uint64_t lambda, int32_t *out, int32_t *sel) {
+    uint64_t(*mse[2])[64] = {(uint64_t(*)[64])(uintptr_t)mse0, (uint64_t(*)[64])(uintptr_t)mse1};
+    int32_t lev0[4][8] = {{0}}, lev1[4][8] = {{0}};
+    uint64_t tot[4];
+    for (int c = 0; c < 4; c++) {
+        const int nb = 1 << c;
+        int l0[8] = {0}, l1[8] = {0};
+        uint64_t t = (uint64_t)1 << 63;
+        for (int i = 0; i < nb; i++) t = svt_search_one_dual(l0, l1, i, mse, sb_count, 0, 64);
+        for (int i = 0; i < 4 * nb; i++) {
+            for (int j = 0; j < nb - 1; j++) { l0[j] = l0[j + 1]; l1[j] = l1[j + 1]; }
+            t = svt_search_one_dual(l0, l1, nb - 1, mse, sb_count, 0, 64);
+        }
+        for (int i = 0; i < 8; i++) { lev0[c][i] = l0[i]; lev1[c][i] = l1[i]; }
+        tot[c] = t;
+    }
+    out[0] = refb_finish_tail(mse0, mse1, sb_count, (const int32_t(*)[8])lev0, (const int32_t(*)[8])lev1, tot, lambda, out + 1, out + 9, sel);
+}
+
 /* ---------------------------------------------------------------- thread pool for bench.py's cpu_baseline ---------------------------
  * refb_parallel runs one of the drivers above over n items on n_threads pthreads (dynamic chunks from an atomic counter, so threads of
  * uneven speed stay busy), `reps` times, and returns the best wall time in seconds.  Arguments travel as an array of 64-bit slots
@@ -340,6 +385,7 @@ static void run_range(int stage, const int64_t *a, int b, int e) {
             ref_shim_lr_apply_plane((int)r[0], 8, 0, (int)r[1], (int)r[2], (void *)(uintptr_t)r[3], (int)r[4], (void *)(uintptr_t)r[5], (int)r[6], (void *)(uintptr_t)r[7], (int)r[8], (int)r[9],
                                     (const uint8_t *)(uintptr_t)r[10], (const int32_t *)(uintptr_t)r[11]);
         } break;
+    case 10: for (int k = b; k < e; k++) refb_cdef_finish(P(0, const uint64_t *), P(1, const uint64_t *), I(2), (uint64_t)a[3], P(4, int32_t *) + 17 * k, P(5, int32_t *) + (size_t)I(2) * k); break;   /* item = one picture */
     case 9: refb_sgr_search_units_plane(P(0, const uint8_t *), I(1), P(2, const uint8_t *), I(3), P(4, const int32_t *), b, e, I(5), I(6), P(7, int32_t *)); break;
     default: break;
     }

@@ -150,6 +150,7 @@ def lib():
     L.svt_hip_cdef_strength_select_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_size_t]
     L.svt_hip_cdef_finish_dev.argtypes = [vp, vp, vp, i32, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.svt_hip_dlf_filtered_units.argtypes = [i32, i32, i32, i32]
+    L.svt_hip_subpel_jobs_from_me_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]

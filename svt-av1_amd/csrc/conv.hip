@@ -158,6 +158,29 @@ extern "C" int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int 
     else hipLaunchKernelGGL((subpel_predict_kernel<uint16_t, 10>), dim3(n), dim3(256), 0, st, (const uint16_t*)ref, ref_stride, (uint16_t*)dst, dst_stride, blks);
     return (int)hipGetLastError();
 }
+// The SvtHipConvBlk list of every whole 16x16 luma block from the open-loop ME table: block (bx, by) of the picture reads its integer vector from
+// its superblock's 16x16 PU (EbMeTierZeroPu order: 5 + z-order index of the 16x16 inside the 64x64; MV word = y << 16 | x in quarter-pel, full-pel
+// vectors) and gets the eighth-pel phase pair frac[2 * k] / frac[2 * k + 1] (q4, 0..15; NULL: full-pel).  k = raster index over whole blocks.
+__global__ void __launch_bounds__(256)
+subpel_jobs_from_me_kernel(const uint32_t* __restrict__ mv, int sb_cols, int w, int h, const uint8_t* __restrict__ frac, SvtHipConvBlk* __restrict__ out) {
+    const int bw = w >> 4, bh = h >> 4, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= bw * bh) return;
+    const int bx = k % bw, by = k / bw, sb = (by >> 2) * sb_cols + (bx >> 2), qx = bx & 3, qy = by & 3;
+    const int z = ((qy >> 1) * 2 + (qx >> 1)) * 4 + (qy & 1) * 2 + (qx & 1);
+    const uint32_t word = mv[(size_t)sb * 85 + 5 + z];
+    const int mx = (int)(int16_t)(word & 0xffff) >> 2, my = (int)(int16_t)(word >> 16) >> 2;
+    SvtHipConvBlk b;
+    b.src_x = bx * 16 + mx; b.src_y = by * 16 + my; b.dst_x = bx * 16; b.dst_y = by * 16;
+    b.w = 16; b.h = 16; b.bank_x = 0; b.bank_y = 0;
+    b.subpel_x = frac ? frac[2 * k] & 15 : 0; b.subpel_y = frac ? frac[2 * k + 1] & 15 : 0;
+    b.mode = 0; b.reserved = 0;
+    out[k] = b;
+}
+extern "C" int svt_hip_launch_subpel_jobs_from_me(hipStream_t st, const uint32_t* mv, int sb_cols, int w, int h, const uint8_t* frac, SvtHipConvBlk* out) {
+    const int n = (w >> 4) * (h >> 4);
+    if (n > 0) hipLaunchKernelGGL(subpel_jobs_from_me_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mv, sb_cols, w, h, frac, out);
+    return (int)hipGetLastError();
+}
 extern "C" int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,
                                         const SvtHipBlkPair* d, int n, uint32_t* out) {
     if (n <= 0) return 0;

@@ -445,6 +445,13 @@ int svt_hip_subpel_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
     if (e != hipSuccess) return fail(c, e, "subpel predict launch");
     return SVT_HIP_OK;
 }
+int svt_hip_subpel_jobs_from_me_dev(SvtHipCtx* c, const uint32_t* d_best_mv, int sb_cols, int w, int h, const uint8_t* d_frac_q4, SvtHipConvBlk* d_blks) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_best_mv || !d_blks || sb_cols < 1 || w < 16 || h < 16 || (w + 63) / 64 > sb_cols) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_subpel_jobs_from_me(c->stream, d_best_mv, sb_cols, w, h, d_frac_q4, d_blks);
+    if (e != hipSuccess) return fail(c, e, "subpel jobs launch");
+    return SVT_HIP_OK;
+}
 int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride,
                                 const SvtHipBlkPair* d_pairs, int n, uint32_t* d_sad) {
     SVT_HIP_ENTER(c);

@@ -63,6 +63,7 @@ int svt_hip_launch_cdef_search(hipStream_t st, int pix_bytes, const void* const 
 int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const in[3], void* const out[3], const int stride[3], int w, int h,
                               const uint8_t* skip8, const uint8_t* y_strength, const uint8_t* uv_strength, int damping, int bd,
                               uint8_t* dir_buf, const int32_t* var_in);
+int svt_hip_launch_subpel_jobs_from_me(hipStream_t st, const uint32_t* mv, int sb_cols, int w, int h, const uint8_t* frac, SvtHipConvBlk* out);
 int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int bd, const void* ref, int ref_stride, void* dst, int dst_stride,
                                   const SvtHipConvBlk* blks, int n);
 int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,

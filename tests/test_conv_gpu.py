@@ -87,3 +87,32 @@ def test_block_sad_and_variance(hip, pkg, orc, bd):
     assert np.array_equal(hip.to_host(d_v, (n,), np.uint32), e_var)
     assert np.array_equal(hip.to_host(d_e, (n,), np.uint32), e_sse)
     hip.free(d_a, d_b, d_p, d_s, d_v, d_e)
+
+
+@pytest.mark.gpu
+def test_subpel_jobs_from_me_table(hip, pkg):
+    """svt_hip_subpel_jobs_from_me_dev: the sub-pel job list of every whole 16x16 block from the [n_sb][85] ME table (16x16 PUs at 5 + z-order index,
+    EbMeTierZeroPu; MV word y << 16 | x in quarter-pel) plus q4 phases, against the same arithmetic spelled out here.  A picture whose last superblock
+    row / column is partial (200 x 152: 13 x 10 blocks... 12 x 9 whole)."""
+    rng = np.random.default_rng(77)
+    w, h = 200, 152
+    sb_cols, sb_rows = (w + 63) // 64, (h + 63) // 64
+    n_sb = sb_cols * sb_rows
+    mvx = rng.integers(-32, 32, (n_sb, 85)).astype(np.int16) * 4; mvy = rng.integers(-32, 32, (n_sb, 85)).astype(np.int16) * 4
+    word = (mvy.astype(np.uint16).astype(np.uint32) << 16) | mvx.astype(np.uint16).astype(np.uint32)
+    bw, bh = w // 16, h // 16
+    frac = rng.integers(0, 16, (bw * bh, 2)).astype(np.uint8)
+    d_mv, d_frac = hip.to_device(word), hip.to_device(frac)
+    d_out = hip.empty(C.sizeof(pkg.ConvBlk) * bw * bh)
+    hip.check(hip.L.svt_hip_subpel_jobs_from_me_dev(hip.h, d_mv, sb_cols, w, h, d_frac, d_out), "jobs from me")
+    raw = hip.to_host(d_out, (C.sizeof(pkg.ConvBlk) * bw * bh,), np.uint8)
+    got = (pkg.ConvBlk * (bw * bh)).from_buffer_copy(raw.tobytes())
+    for k in range(bw * bh):
+        bx, by = k % bw, k // bw
+        sb = (by // 4) * sb_cols + bx // 4
+        qx, qy = bx % 4, by % 4
+        z = ((qy // 2) * 2 + qx // 2) * 4 + (qy % 2) * 2 + qx % 2
+        g = got[k]
+        assert (g.src_x, g.src_y, g.dst_x, g.dst_y, g.w, g.h, g.bank_x, g.bank_y, g.subpel_x, g.subpel_y, g.mode) == \
+            (bx * 16 + int(mvx[sb, 5 + z]) // 4, by * 16 + int(mvy[sb, 5 + z]) // 4, bx * 16, by * 16, 16, 16, 0, 0, int(frac[k, 0]), int(frac[k, 1]), 0), k
+    hip.free(d_mv, d_frac, d_out)
