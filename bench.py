@@ -537,6 +537,7 @@ def main():
             slots = (C.c_int64 * 10)(F0.cur_y_p.ctypes.data, F0.ref_y_p.ctypes.data, F0.cur_y_p.shape[1], F0.pad, F0.pad, C.addressof(P0.sbs), n_sb, 0, r_sad.ctypes.data, r_mv.ctypes.data)
             refb.refb_parallel(0, C.addressof(slots), n_sb, 8, min(len(os.sched_getaffinity(0)), 128), 1)
             parity_ok = bool(parity_ok and np.array_equal(r_sad, g_sad) and np.array_equal(r_mv, g_mv))
+    me_ok = parity_ok
     walk_stats = None
     if any(k == "sgr_units" for k, _ in stages):   # diagnostics the search leaves at the start of its scratch: passes / points per walk, unfinished walks
         st3 = [P0.d_scr[p][:128].cpu().numpy().view(np.uint32) for p in range(3)]
@@ -562,12 +563,29 @@ def main():
             raise SystemExit("oracle/_ref/libsvtav1_ref_simd.so is not built (make -f oracle/Makefile.ref simd)")
         else:
             cpu = cpu_baseline(orc, F0, P0.sbs, mc, tc, stage_keys, jobs)
-        if "cdef_fin_ref" in jobs:   # the strength decision of frame 0 against the reference's (dispatched svt_search_one_dual x 75 + the RDCOST choice) on the same table
-            r_fin, r_sel = jobs["cdef_fin_ref"]
-            g_fin = P0.d_fin.cpu().numpy()
-            g_bits = int(g_fin[:4].view(np.int32)[0]); g_y = g_fin[8:40].view(np.int32); g_uv = g_fin[40:72].view(np.int32)
-            same = g_bits == int(r_fin[0]) and np.array_equal(g_y, r_fin[1:9]) and np.array_equal(g_uv, r_fin[9:17]) and np.array_equal(P0.d_sel_gi.cpu().numpy(), r_sel)
-            parity_ok = bool(parity_ok is not False and same)
+    # the strength decision of frame 0 against the reference's (svt_search_one_dual x 75 + the RDCOST choice) on the same distortion table: the C functions decide
+    # parity ("bit-exact vs C ref"); the dispatched SIMD kernels are compared as well and reported
+    parity_detail = {"me_85pu_vs_reference": me_ok, "sgr_walks_unfinished": None if walk_stats is None else walk_stats["unfinished"]}
+    if world == 1 and any(k == "cdef_pick" for k, _ in stages):
+        m = np.ascontiguousarray(P0.d_mse.cpu().numpy().view(np.uint64)).reshape(2, n_sb, 64)
+        g_fin = P0.d_fin.cpu().numpy(); g_sel = P0.d_sel_gi.cpu().numpy()
+        g_bits = int(g_fin[:4].view(np.int32)[0]); g_y = g_fin[8:40].view(np.int32); g_uv = g_fin[40:72].view(np.int32)
+        for flavour, libname in (("c", "libsvtav1_ref.so"), ("simd", "libsvtav1_ref_simd.so")):
+            path = os.path.join(ROOT, "oracle", "_ref", libname)
+            if not os.path.exists(path):
+                continue
+            rl = C.CDLL(path)
+            rl.refb_setup.restype = C.c_uint64; rl.refb_setup.argtypes = [C.c_uint64]; rl.refb_setup(0xFFFFFFFFFFFFFFFF)
+            rl.refb_cdef_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+            r_fin = np.zeros(17, np.int32); r_sel = np.zeros(n_sb, np.int32)
+            rl.refb_cdef_finish(m[0].ctypes.data, m[1].ctypes.data, n_sb, CDEF_LAMBDA, r_fin.ctypes.data, r_sel.ctypes.data)
+            same = bool(g_bits == int(r_fin[0]) and np.array_equal(g_y, r_fin[1:9]) and np.array_equal(g_uv, r_fin[9:17]) and np.array_equal(g_sel, r_sel))
+            parity_detail["cdef_strength_decision_vs_reference_" + flavour] = same
+            if not same:
+                parity_detail["cdef_decision_" + flavour + "_diff"] = {"device": [g_bits] + g_y.tolist() + g_uv.tolist(), "reference": r_fin.tolist(),
+                                                                    "per_block_differences": int(np.count_nonzero(g_sel != r_sel))}
+            if flavour == "c":
+                parity_ok = bool(parity_ok is not False and same)
 
     out = {
         "metric": METRIC, "value": nF * n_sb * args.steps * world / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
@@ -586,7 +604,7 @@ def main():
                                  "restoration: complete search_selfguided_restoration of every unit (16 sets, units 256, solve + finer search on the device) on the CDEF "
                                  "output, apply with the sets it chose",
                    "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes)",
-                   "parity_spot_check": parity_ok, "sgr_walk": walk_stats},
+                   "parity_spot_check": parity_ok, "parity_detail": parity_detail, "sgr_walk": walk_stats},
         "cpu_baseline": cpu,
     }
     out["roofline"] = roofline(per_stage, stages, n_sb)
@@ -996,7 +1014,6 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
         t = run(10, [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel], npic, 1, reps=1)
         sec["cdef_strength_select"] = t / npic / n_sb   # one picture per thread, all threads busy
         sec1["cdef_strength_select"] = refb.refb_parallel(10, C.addressof((C.c_int64 * 6)(*[adr(v) for v in [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel]])), 1, 1, 1, 1)
-        jobs["cdef_fin_ref"] = (fin[0].copy(), sel[0].copy())
     if "cdef_apply" in keys:
         outs = [p.copy() for p in F.ref]
         cy_, cuv_ = jobs["cdef_strengths"]

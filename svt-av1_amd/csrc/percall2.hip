@@ -16,6 +16,7 @@
 //   blend_d16             Common/Codec/EbBlend_a64_mask.c:34-215            svt_aom_{lowbd,highbd}_blend_a64_d16_mask_c
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstddef>
 #include <stdint.h>
 #include "svt_hip_internal.h"
 
@@ -202,131 +203,152 @@ one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int
 
 // ------------------------------------------------------------------------------------------------ CDEF: the whole strength-pair selection of a picture
 // finish_cdef_search runs joint_strength_search_dual for 1, 2, 4 and 8 pairs (EbEncCdef.c:1258): four independent chains of 5, 10, 20 and 40
-// svt_search_one_dual steps.  One launch per step index advances every chain that is still running (blockIdx.z = chain); a step is ONE kernel.
-// A workgroup of 16 waves owns (chain, 16 luma strengths, one of kJointParts slices of the filter blocks): lane = chroma strength, a wave walks 1/16 of
-// the slice with 16 running totals in registers (the luma distortions and the running best of a filter block are wave-uniform: scalar loads), the 16
-// waves add into one LDS table and the workgroup issues ONE 64-bit atomic per (pair, slice) -- kJointParts x 4096 per chain and step instead of one
-// per (pair, 32 filter blocks).  When every per-block distortion is below 2^27 (joint_init_kernel looks) the per-lane arithmetic is 32-bit: add, min, add.
-// The workgroup that finishes last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next step is a refinement
-// step and resets the counter; the totals are triple-buffered and every workgroup clears its share of the buffer of step + 2 on the way.
+// svt_search_one_dual steps.  One launch per step index advances every chain that is still running (blockIdx.z = chain); a step is ONE kernel
+// (joint_step_kernel below).  The workgroup that finishes last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next
+// step is a refinement step and resets the counter; the totals are triple-buffered and every workgroup clears its share of the buffer of step + 2 on the way.
+constexpr int kJointMaxSlices = 64;
 struct JointState {
     int lev0[4][8], lev1[4][8];
     unsigned int counter[4];
     unsigned long long result[4];          // total of the chain's last step
-    unsigned long long tot[4][3][4096];    // by step % 3
     unsigned long long max0, max1;         // largest entry of each table (joint_init_kernel)
+    unsigned long long cand_v[4][64];      // per reduce workgroup: its first minimum ...
+    int                cand_i[4][64];      // ... and where
+    unsigned long long partial[4][kJointMaxSlices][4096];   // totals of one slice of the filter blocks, [j][k] with row stride 64
 };
-constexpr int kJointParts = 8;
 __global__ void __launch_bounds__(256)
 joint_init_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int n, JointState* __restrict__ S) {
     unsigned long long m0 = 0, m1 = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { m0 = max(m0, (unsigned long long)mse0[i]); m1 = max(m1, (unsigned long long)mse1[i]); }
     for (int o = 32; o > 0; o >>= 1) { m0 = max(m0, (unsigned long long)__shfl_xor((long long)m0, o)); m1 = max(m1, (unsigned long long)__shfl_xor((long long)m1, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&S->max0, m0); atomicMax(&S->max1, m1); }
+    __shared__ unsigned long long w0[4], w1[4];
+    if ((threadIdx.x & 63) == 0) { w0[threadIdx.x >> 6] = m0; w1[threadIdx.x >> 6] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic pair per workgroup: same-address 64-bit atomics serialise at ~25 ns each
+        atomicMax(&S->max0, max(max(w0[0], w0[1]), max(w0[2], w0[3])));
+        atomicMax(&S->max1, max(max(w1[0], w1[1]), max(w1[2], w1[3])));
+    }
 }
-template <bool NARROW>
-__device__ __forceinline__ void joint_accumulate(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int ia, int ib, int start_gi, int ng, int jg, int kk,
-                                                 int idx, const int* l0, const int* l1, unsigned long long (&acc)[16]) {
-    typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type T;
-    T a32[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) a32[t] = 0;
-    const bool lane_on = kk < ng;
-    for (int i = ia; i < ib; i++) {                      // i is wave-uniform
-        const uint64_t* a = mse0 + (size_t)i * 64;       // uniform address: scalar loads
-        const uint64_t* b = mse1 + (size_t)i * 64;
-        uint64_t best = (uint64_t)1 << 63;
-        for (int g = 0; g < idx; g++) { const uint64_t v = a[l0[g]] + b[l1[g]]; best = v < best ? v : best; }
-        const T bk = lane_on ? (T)b[start_gi + kk] : (T)0;
-        const T bb = NARROW ? (T)(best > 0xffffffffull ? 0xffffffffull : best) : (T)best;   // every candidate is below 2^28: clamping the initial 1 << 63 changes nothing
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const T v = (T)a[start_gi + min(jg + t, ng - 1)] + bk;
-            a32[t] += v < bb ? v : bb;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 16; t++) acc[t] = a32[t];
-}
-__global__ void __launch_bounds__(1024)
-joint_step_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, int step, JointState* __restrict__ S) {
-    const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
-    if (step >= total_steps) return;
-    const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
-    __shared__ int s_l0[8], s_l1[8];
-    __shared__ bool s_last;
-    __shared__ unsigned long long s_tot[16][64];
-    if (threadIdx.x < 8) { s_l0[threadIdx.x] = S->lev0[c][threadIdx.x]; s_l1[threadIdx.x] = S->lev1[c][threadIdx.x]; }
-    s_tot[threadIdx.x >> 6][threadIdx.x & 63] = 0;
-    const int part = blockIdx.x % kJointParts, jq = blockIdx.x / kJointParts;   // jq: which 16 luma strengths
-    {   // this workgroup's share of the totals of step + 2 (nobody reads or adds to that buffer before the launch after next)
-        unsigned long long* clr = S->tot[c][(step + 2) % 3];
-        const int wg = blockIdx.x, nwg = gridDim.x;
-        for (int t = wg * 1024 + threadIdx.x; t < 4096; t += nwg * 1024) clr[t] = 0;
-    }
-    __syncthreads();
-    unsigned long long* tot = S->tot[c][step % 3];
-    const int kk = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), jg = jq * 16;
-    // slice `part` of the filter blocks, split again over the 16 waves
-    const int p0 = (int)((long long)sb_count * part / kJointParts), p1 = (int)((long long)sb_count * (part + 1) / kJointParts);
-    const int ia = p0 + (int)((long long)(p1 - p0) * w / 16), ib = p0 + (int)((long long)(p1 - p0) * (w + 1) / 16);
-    if (jg < ng) {
-        int l0[8], l1[8];
-#pragma unroll
-        for (int g = 0; g < 8; g++) { l0[g] = __builtin_amdgcn_readfirstlane(s_l0[g]); l1[g] = __builtin_amdgcn_readfirstlane(s_l1[g]); }
-        unsigned long long acc[16];
-        const bool narrow = S->max0 < (1ull << 27) && S->max1 < (1ull << 27) && (ib - ia) <= 16;   // 16 blocks x 2^28 < 2^32
-        if (narrow) joint_accumulate<true>(mse0, mse1, ia, ib, start_gi, ng, jg, kk, idx, l0, l1, acc);
-        else joint_accumulate<false>(mse0, mse1, ia, ib, start_gi, ng, jg, kk, idx, l0, l1, acc);
-        if (kk < ng) {
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-                if (jg + t < ng && acc[t]) atomicAdd(&s_tot[t][kk], acc[t]);
-        }
-    }
-    __syncthreads();
-    {
-        const int t = threadIdx.x >> 6;
-        if (jg + t < ng && kk < ng && s_tot[t][kk]) atomicAdd(&tot[(jg + t) * ng + kk], s_tot[t][kk]);
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&S->counter[c], 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    // the last workgroup of this chain's step: first minimum in (j, k) raster order
-    __shared__ unsigned long long r_v[1024];
-    __shared__ int                r_i[1024];
-    unsigned long long bv = (unsigned long long)1 << 63;
-    int                bi = 0x7fffffff;
-    {
-        unsigned long long v[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) { const int i = threadIdx.x + 1024 * t; v[t] = i < ng * ng ? ((const volatile unsigned long long*)tot)[i] : ~0ull; }
-#pragma unroll
-        for (int t = 0; t < 4; t++) { const int i = threadIdx.x + 1024 * t; if (i < ng * ng && v[t] < bv) { bv = v[t]; bi = i; } }
-    }
-    r_v[threadIdx.x] = bv; r_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int m = 512; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) {
-            const unsigned long long ov = r_v[threadIdx.x + m];
-            const int                oi = r_i[threadIdx.x + m];
-            if (ov < r_v[threadIdx.x] || (ov == r_v[threadIdx.x] && oi < r_i[threadIdx.x])) { r_v[threadIdx.x] = ov; r_i[threadIdx.x] = oi; }
+// A step of all running chains is two launches.  The totals are a (min, +) product, tot[j][k] = sum_i min(best_i, a[i][j] + b[i][k]), laid out like a small GEMM:
+// joint_partial_kernel -- a workgroup (1024 threads) takes a slice of the filter blocks, stages their two distortion rows through LDS in bulk (every load of a
+// stage is in flight at once: the tables live in L2, and a per-block dependent load chain is what bounded the earlier forms), forms the running best of each
+// staged block once, and every thread accumulates a 2 x 2 tile of pairs over the slice (T = uint32_t when every distortion is below 2^27: add, min, and a
+// 64-bit accumulate); the slice's 4096 totals go to its own row of `partial` -- no atomics (64-bit device-scope atomics ran at ~30 G/s here, 18 us per step).
+// joint_reduce_kernel -- 64 workgroups per chain add the slices' rows (coalesced), each finds the first minimum of its 64 pairs, and the one that finishes
+// last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next step is a refinement step and resets the counter.
+constexpr int kJointStage = 64;   // filter blocks per LDS stage
+template <typename T>
+__device__ __forceinline__ void joint_tile(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int p0, int p1, int start_gi, int ng, int idx, const int* s_l0,
+                                           const int* s_l1, unsigned char* lds, unsigned long long* __restrict__ out) {
+    T* A = (T*)lds;                          // [kJointStage][64]
+    T* B = A + kJointStage * 64;             // [kJointStage][64]
+    T* best = B + kJointStage * 64;          // [kJointStage]
+    const int tid = threadIdx.x, tj = (tid >> 5) * 2, tk = (tid & 31) * 2;
+    const int ja = start_gi + min(tj, ng - 1), jb = start_gi + min(tj + 1, ng - 1), ka = start_gi + min(tk, ng - 1), kb = start_gi + min(tk + 1, ng - 1);
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    for (int s0 = p0; s0 < p1; s0 += kJointStage) {
+        const int ns = min(kJointStage, p1 - s0);
+        __syncthreads();
+        for (int e = tid; e < ns * 64; e += 1024) {   // whole rows: entries outside [start_gi, start_gi + ng) are staged but never used
+            A[e] = (T)mse0[(size_t)s0 * 64 + e];
+            B[e] = (T)mse1[(size_t)s0 * 64 + e];
         }
         __syncthreads();
+        if (tid < ns) {
+            T bm = sizeof(T) == 4 ? (T)0xffffffffu : (T)((unsigned long long)1 << 63);   // narrow: every candidate is below 2^28, so this start value never wins
+            for (int g = 0; g < idx; g++) { const T v = A[tid * 64 + s_l0[g]] + B[tid * 64 + s_l1[g]]; bm = v < bm ? v : bm; }
+            best[tid] = bm;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < ns; i++) {
+            const T a0 = A[i * 64 + ja], a1 = A[i * 64 + jb], b0 = B[i * 64 + ka], b1 = B[i * 64 + kb], bb = best[i];
+            T v;
+            v = a0 + b0; acc[0] += v < bb ? v : bb;
+            v = a0 + b1; acc[1] += v < bb ? v : bb;
+            v = a1 + b0; acc[2] += v < bb ? v : bb;
+            v = a1 + b1; acc[3] += v < bb ? v : bb;
+        }
     }
-    if (threadIdx.x == 0) {
-        bv = r_v[0]; bi = r_i[0];
-        const bool any = bi != 0x7fffffff;
-        S->lev0[c][idx] = any ? start_gi + bi / ng : 0;
-        S->lev1[c][idx] = any ? start_gi + bi % ng : 0;
-        S->result[c] = bv;
-        if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
-            for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
-        S->counter[c] = 0;
+    // [j][k], row stride 64: a thread's two k are adjacent, a wave writes two whole rows
+    *(ulonglong2*)&out[tj * 64 + tk] = make_ulonglong2(acc[0], acc[1]);
+    *(ulonglong2*)&out[(tj + 1) * 64 + tk] = make_ulonglong2(acc[2], acc[3]);
+}
+__global__ void __launch_bounds__(1024)
+joint_partial_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, int step, JointState* __restrict__ S) {
+    const int c = blockIdx.z, nb = 1 << c;
+    if (step >= 5 * nb) return;
+    const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
+    __shared__ int s_l0[8], s_l1[8];
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[(2 * kJointStage * 64 + kJointStage) * 8];
+    // the selected pairs are only needed after the first stage is in LDS (joint_tile's barrier orders this store before their first use): their load
+    // latency overlaps the staging loads instead of preceding them
+    if (threadIdx.x < 8) { s_l0[threadIdx.x] = S->lev0[c][threadIdx.x]; s_l1[threadIdx.x] = S->lev1[c][threadIdx.x]; }
+    const int p0 = (int)((long long)sb_count * blockIdx.x / gridDim.x), p1 = (int)((long long)sb_count * (blockIdx.x + 1) / gridDim.x);
+    const bool narrow = S->max0 < (1ull << 27) && S->max1 < (1ull << 27);
+    if (narrow) joint_tile<uint32_t>(mse0, mse1, p0, p1, start_gi, ng, idx, s_l0, s_l1, s_stage, S->partial[c][blockIdx.x]);
+    else joint_tile<unsigned long long>(mse0, mse1, p0, p1, start_gi, ng, idx, s_l0, s_l1, s_stage, S->partial[c][blockIdx.x]);
+}
+__global__ void __launch_bounds__(256)
+joint_reduce_kernel(int slices, int start_gi, int ng, int step, JointState* __restrict__ S) {
+    const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
+    if (step >= total_steps) return;
+    const int idx = step < nb ? step : nb - 1;
+    __shared__ unsigned long long r_v[256];
+    __shared__ int                r_i[64];
+    __shared__ bool               s_last;
+    // 64 pairs per workgroup, four threads per pair: thread (pair, q) adds the slices s = q, q + 4, ... -- at most 16 loads, all in flight at once (the rows
+    // were written by other XCDs: every load is a memory-side round trip, so batches of dependent loads were what this kernel's time consisted of)
+    const int q = threadIdx.x >> 6, p = blockIdx.x * 64 + (threadIdx.x & 63), j = p >> 6, k = p & 63;
+    unsigned long long v = 0;
+    const unsigned long long* src = &S->partial[c][0][p];
+#pragma unroll
+    for (int t = 0; t < kJointMaxSlices / 4; t++) {
+        const int sl = q + 4 * t;
+        v += sl < slices ? src[(size_t)sl * 4096] : 0ull;
     }
+    r_v[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const bool on = j < ng && k < ng;
+        unsigned long long bv = on ? r_v[threadIdx.x] + r_v[threadIdx.x + 64] + r_v[threadIdx.x + 128] + r_v[threadIdx.x + 192] : ~0ull;
+        int                bi = on ? j * ng + k : 0x7fffffff;          // the reference's raster index over the ng x ng table
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
+            const int                oi = __shfl_xor(bi, o);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (threadIdx.x == 0) {
+            S->cand_v[c][blockIdx.x] = bv; S->cand_i[c][blockIdx.x] = bi;
+            __threadfence();
+            s_last = atomicAdd(&S->counter[c], 1u) == gridDim.x - 1;
+        }
+    }
+    (void)r_i;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    __threadfence();
+    // the last workgroup of the chain: its first wave reads the 16 candidates side by side (a serial loop of dependent device loads cost ~1 us each)
+    unsigned long long bv = (unsigned long long)1 << 63;   // "tot < best" with best = 1 << 63 (EbEncCdef.c:1104): nothing below it keeps (0, 0)
+    int                bi = 0x7fffffff;
+    if (threadIdx.x < gridDim.x) {
+        const unsigned long long ov = ((const volatile unsigned long long*)S->cand_v[c])[threadIdx.x];
+        const int                oi = ((const volatile int*)S->cand_i[c])[threadIdx.x];
+        if (oi != 0x7fffffff && ov < bv) { bv = ov; bi = oi; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
+        const int                oi = __shfl_xor(bi, o);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (threadIdx.x != 0) return;
+    const bool any = bi != 0x7fffffff;
+    S->lev0[c][idx] = any ? start_gi + bi / ng : 0;
+    S->lev1[c][idx] = any ? start_gi + bi % ng : 0;
+    S->result[c] = bv;
+    if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
+        for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
+    S->counter[c] = 0;
 }
 
 // finish_cdef_search after the four searches (EbEncCdef.c:1258-1298): the count of strength pairs by rate-distortion cost, then every filter block's
@@ -635,11 +657,17 @@ extern "C" size_t svt_hip_joint_state_bytes(void) { return sizeof(JointState); }
 // out[c] = {total, lev0[8], lev1[8]} as 64-bit words (17 per chain) is assembled by the caller from the state; here: clear, 40 steps
 extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state) {
     const int ng = end_gi - start_gi;
-    if (hipMemsetAsync(state, 0, sizeof(JointState), st) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(state, 0, offsetof(JointState, partial), st) != hipSuccess) return (int)hipGetLastError();
     if (ng <= 0) return 0;
-    if (sb_count > 0) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 256)), dim3(256), 0, st, mse0, mse1, sb_count * 64, (JointState*)state);
-    const dim3 grid(kJointParts * ((ng + 15) / 16), 1, 4);
-    for (int step = 0; step < 40; step++) hipLaunchKernelGGL(joint_step_kernel, grid, dim3(1024), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
+    if (sb_count > 0) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 64)), dim3(256), 0, st, mse0, mse1, sb_count * 64, (JointState*)state);
+    static int forced = -1;   // debug: SVT_HIP_CDEF_SELECT_SLICES
+    if (forced < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT_SLICES"); forced = e ? atoi(e) : 0; }
+    int slices = forced > 0 ? forced : (sb_count + 31) / 32;
+    slices = slices < 1 ? 1 : (slices > kJointMaxSlices ? kJointMaxSlices : slices);
+    for (int step = 0; step < 40; step++) {
+        hipLaunchKernelGGL(joint_partial_kernel, dim3(slices, 1, 4), dim3(1024), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
+        hipLaunchKernelGGL(joint_reduce_kernel, dim3(64, 1, 4), dim3(256), 0, st, slices, start_gi, ng, step, (JointState*)state);
+    }
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,

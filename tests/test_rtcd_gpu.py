@@ -896,7 +896,7 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         if mag == 27: m0[sb_count // 2, 5] = (1 << 27) - 1
         ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
         d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
-        state_bytes = 304 + 4 * 3 * 4096 * 8 + 64   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+        state_bytes = 304 + 4096 + 4 * 64 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
         d_state = hip.empty(state_bytes)
         hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
         sel = hip.to_host(d_state, (304,), np.uint8)
@@ -920,12 +920,12 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         # at lambdas either side of the switch between counts
         orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         for lam in (1, 3000, 70000, 5_000_000, 1 << 33):
-            d_out = hip.empty(88); d_sel = hip.empty(4 * (sb_count + 1)); d_fy = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8)); d_fuv = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8))
+            d_out = hip.empty(80); d_sel = hip.empty(4 * (sb_count + 1)); d_fy = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8)); d_fuv = hip.to_device(np.full(2 * sb_count + 3, 77, np.uint8))
             fbmap = (np.arange(sb_count, dtype=np.int32) * 2 + 1)
             d_map = hip.to_device(fbmap)
             hip.check(L.svt_hip_cdef_finish_dev(hip.h, d_m0, d_m1, sb_count, d_state, lam, d_map, d_out, d_sel, d_fy, d_fuv), "cdef finish")
-            out = hip.to_host(d_out, (88,), np.uint8); g_sel = hip.to_host(d_sel, (sb_count,), np.int32)
-            g_bits, g_nb = out[:8].view(np.int32); g_y = out[8:40].view(np.int32); g_uv = out[40:72].view(np.int32); g_cost = int(out[80:88].view(np.uint64)[0])
+            out = hip.to_host(d_out, (80,), np.uint8); g_sel = hip.to_host(d_sel, (sb_count,), np.int32)
+            g_bits, g_nb = out[:8].view(np.int32); g_y = out[8:40].view(np.int32); g_uv = out[40:72].view(np.int32); g_cost = int(out[72:80].view(np.uint64)[0])
             y = np.zeros(8, np.int32); uv = np.zeros(8, np.int32); o_sel = np.zeros(max(sb_count, 1), np.int32); cost = C.c_uint64(0)
             orc.orc_cdef_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             bits = orc.orc_cdef_finish(_vp(m0), _vp(m1), sb_count, _vp(np.ascontiguousarray(sel_lev0)), _vp(np.ascontiguousarray(sel_lev1)), _vp(np.ascontiguousarray(sel_tot)), lam,
