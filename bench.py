@@ -39,32 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "encoded 4K 8-bit SB/s (ME+txfm+quant+loopfilter) per GPU; bit-exact vs C ref"
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-P3, I3 = C.c_void_p * 3, C.c_int * 3
-
-# algorithmic HBM bytes per SB of each kernel class (8-bit 4:2:0, luma + chroma where the stage covers chroma)
-BYTES_PER_SB = {
-    "me_fullpel_85pu": 8872,                 # 4096 src + 4096 ref (amortised) + 85*8 out
-    "fwd_txfm_quant": 61440 + 128,           # (src+pred 2*6144) + qcoeff+dqcoeff 2*4*6144 + eob   (luma+chroma)
-    "inv_txfm_recon": 36864,                 # dqcoeff 4*6144 + pred 6144 + recon 6144
-    "fwd_quant_inv_recon": 2 * 6144 + 4 * 6144 + 6144 + 128,   # fused: src + pred in, levels + recon out (the dequantised coefficients stay in registers)
-    "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
-    "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
-    "cdef_apply": 12288 + 12288,             # 6144 R + 6144 W, plus the device-to-device copy that initialises the destination (R + W)
-    "cdef_strength_select": 2 * 64 * 8 + 2,  # the two distortion rows of the filter block R (once, if they stayed on chip over the 75 steps) + its strength pair W
-    "pyramids": 5376 + 4351,                 # decimation 4096 R + 1024 + 256 W ; variance pyramid 4096 R + 85*3 W
-    "hme_l0_l1_l2": 256 + 1024 + 4096 + 3 * 12,   # source blocks of the three levels + results (windows are cache-resident)
-    "subpel_convolve": 12560,                # 16 blocks x (16+7)^2 R + 4096 W (luma)
-    "sgr_units_search": 12288 + 640,         # dgd 6144 + source 6144 R + results: the minimum if everything in between stayed on chip
-    "sgr_apply": 12288,                      # 6144 R + 6144 W
-}
-STAGE_KERNELS = {
-    "pyramids": "downsample_kernel+variance_pyramid_kernel", "hme_l0_l1_l2": "sad_loop_kernel", "me_fullpel_85pu": "me_fullpel_85pu_kernel",
-    "subpel_convolve": "subpel_predict_kernel", "fwd_txfm_quant": "fwd_txfm_quant_multi_kernel", "inv_txfm_recon": "inv_txfm_add_multi_kernel", "fwd_quant_inv_recon": "enc_txfm_multi_kernel",
-    "deblock": "deblock_frame_pass_kernel", "cdef_search": "cdef_search_luma_kernel+cdef_search_chroma_kernel", "cdef_apply": "cdef_apply_kernel",
-    "cdef_strength_select": "joint_init_kernel+joint_step_kernel+cdef_finish_kernel",
-    "sgr_units_search": "sgr_search8_kernel+sgr_walk_resident_kernel", "sgr_apply": "lr_apply8_kernel",
-}
+# algorithmic bytes per SB, kernel names per stage and the roofline arithmetic: tools/roofline_defs.py (shared with tools/summarize_profiles.py)
 CDEF_LAMBDA = 55473                  # av1_lambda_mode_decision8_bit_sse[120] (EbLambdaRateTables.h:227): full lambda of a key frame at the workload's base_q_idx
 EXT = 3                              # RESTORATION_BORDER: recon / CDEF / restoration planes carry a 3-sample border
 
@@ -688,80 +663,20 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
 
 
 def roofline(per_stage, stages, n_sb):
-    """The dominant kernel class of the step and what bounds it.  The three searches are integer-VALU bound by construction (4096 candidates, 64
-    strength pairs, 16 parameter sets per sample), so their fraction is work-based: useful operations per second against the issue peak of the
-    instruction that carries the work."""
-    names = [n for _, n in stages]
-    dom = max(names, key=lambda n: per_stage[n])
-    r = {"kernel": STAGE_KERNELS[dom], "stage": dom}
-    per_stage_gbs = {n: BYTES_PER_SB[n] * n_sb / (per_stage[n] * 1e-3) / 1e9 for n in names}
-    valu = {}
-    if "me_fullpel_85pu" in per_stage:
-        ms = per_stage["me_fullpel_85pu"]
-        ach = 4096 * 4096 * n_sb / (ms * 1e-3) / 1e12
-        peak = 1024 * 64 * 16 / 16.0 * 2.4e9 / 1e12
-        valu["me_fullpel_85pu"] = {"achieved": ach, "peak": peak, "unit": "T px-SAD/s", "frac": ach / peak,
-                                   "note": "4096 px x 4096 candidates per SB; peak = 1024 SIMDs x 64 lanes x 16 abs-diff per v_qsad_pk_u16_u8 / 16 cycles x 2.4 GHz (issue rate measured: "
-                                           "profiles/r01/ubench_sad_rate.txt)"}
-    if "cdef_search" in per_stage:
-        ms = per_stage["cdef_search"]
-        # minimum per pixel and strength pair (luma 64, chroma 2 x 64 on quarter-size planes): combine + round + clamp + squared error on packed 16-bit pairs
-        work = 6144 * 64 * 4.0 * n_sb          # 4 lane-operations per (pixel, strength): add primary+secondary, round/shift, clamp, accumulate (d - s)^2
-        valu["cdef_search"] = {"achieved": work / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 2.4e9 / 4.0 / 1e12 * 2, "unit": "T lane-op/s",
-                               "note": "work = 6144 px x 64 strengths x 4 ops per SB (the strength-dependent minimum: combine, round, clamp, squared error); peak = 1024 SIMDs x 64 "
-                                       "lanes x 2 packed 16-bit results per instruction / 4 cycles x 2.4 GHz"}
-        valu["cdef_search"]["frac"] = valu["cdef_search"]["achieved"] / valu["cdef_search"]["peak"]
-    if "sgr_units_search" in per_stage:
-        ms = per_stage["sgr_units_search"]
-        work = 6144 * (23 * 30.0 + 16 * 9.2 * 4.0) * n_sb   # 23 distinct box filters x ~30 ops per pixel + 16 sets x ~9.2 probes x 4 ops per pixel
-        valu["sgr_units_search"] = {"achieved": work / (ms * 1e-3) / 1e12, "peak": 1024 * 64 * 2.4e9 / 4.0 / 1e12, "unit": "T lane-op/s",
-                                    "note": "work = per pixel 23 distinct (radius, strength) filters x ~30 ops (A/B lookup, 3x3 weighting, projection) + 16 sets x ~9.2 error probes x 4 "
-                                            "ops; peak = 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz; every (unit, set) loads its 6 B per pixel once (resident walk), 1.2 GB per frame"}
-        valu["sgr_units_search"]["frac"] = valu["sgr_units_search"]["achieved"] / valu["sgr_units_search"]["peak"]
-    if dom in valu:
-        r.update({"bound": "valu", "achieved": valu[dom]["achieved"], "peak": valu[dom]["peak"], "unit": valu[dom]["unit"], "frac": valu[dom]["frac"]})
-    else:
-        r.update({"bound": "hbm", "achieved": per_stage_gbs[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_stage_gbs[dom] / HBM_PEAK_GBS})
-    # HBM traffic of the dominant stage per frame from the PMC passes of the latest profiled round (tools/collect_profiles.sh: FETCH_SIZE and
-    # WRITE_SIZE in separate rocprofv3 --pmc runs; summary committed as profiles/<round>/pmc_traffic.json)
-    traffic, traffic_src, valu_busy = None, None, None
+    """tools/roofline_defs.py holds the arithmetic (shared with tools/summarize_profiles.py, which recomputes the same object from the committed profile): the
+    dominant stage against the integer-VALU peak by what the ISA issued (SQ_INSTS_VALU x 64 from the latest profiles/<round>/pmc_traffic.json) and by the useful
+    work count, plus algorithmic GB/s, counter traffic and traffic / algorithmic for every stage."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_defs as rd
+    pmc, src = None, None
     try:
         rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
         if rounds:
-            traffic_src = f"profiles/{rounds[-1]}/pmc_traffic.json"
-            pt = json.load(open(os.path.join(ROOT, traffic_src)))
-            frames = max((e["launches"] for k, e in pt.items() if k.startswith("me_fullpel_85pu_kernel")), default=0)
-            knames = STAGE_KERNELS[dom].split("+")
-            sel = [e for k, e in pt.items() if any(k.startswith(nm) for nm in knames)]
-            tot = sum((e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)) * e["launches"] for e in sel)
-            traffic = tot / frames if frames and tot else None
-            act = sum(e.get("sq", {}).get("SQ_ACTIVE_INST_VALU", 0.0) * e["launches"] for e in sel)
-            dur = sum(e["avg_us"] * e["launches"] for e in sel)
-            valu_busy = (act * 4.0) / (1024 * dur * 1e-6 * 2.4e9) if dur else None
-
-            def lane_ops(prefixes):   # vector instructions the ISA actually issued per frame (SQ_INSTS_VALU counts wave-instructions), as lane operations
-                return 64.0 * sum(e.get("sq", {}).get("SQ_INSTS_VALU", 0.0) * e["launches"] for k, e in pt.items() if any(k.startswith(x) for x in prefixes)) / frames if frames else None
-            px = 6144.0 * n_sb   # luma + 2 chroma samples of a 4:2:0 frame
-            c_ops, s_ops = lane_ops(("cdef_search_",)), lane_ops(("sgr_search8_kernel", "sgr_walk_"))
-            if c_ops:
-                r["valu_cdef"] = {"isa_lane_ops_per_sample_and_strength": c_ops / (px * 64), "argued_minimum": 2.0, "source": traffic_src,
-                                  "note": "SQ_INSTS_VALU x 64 of cdef_search_luma/chroma per frame / (samples x 64 strength pairs); minimum: the strength-dependent part is combine, "
-                                          "round, clamp, squared error = 4 operations on packed 16-bit pairs = 2 per sample; everything above it is the direction search, the 21 "
-                                          "tap sums computed once per sample (amortised over 64 strengths), tile staging and the reductions"}
-            if s_ops:
-                r["valu_sgr"] = {"isa_lane_ops_per_sample_and_set": s_ops / (px * 16), "argued_minimum": 13.0 * 2.5 + 5.0, "source": traffic_src,
-                                 "note": "SQ_INSTS_VALU x 64 of sgr_search8 + sgr_walk per frame / (samples x 16 sets); minimum of the set-dependent part: ~13 evaluated points per "
-                                         "walk x 2.5 operations per sample (two dot products, half a permute, half a packed add, half a squaring dot product) + the five projection "
-                                         "products; the box filters themselves (23 distinct radius / strength pairs) are shared between sets"}
-    except (OSError, ValueError, KeyError):
-        traffic = None
-    r.update({"traffic": traffic, "valu_busy": valu_busy,
-              "traffic_note": None if traffic is None else f"bytes per frame of the stage's launches, FETCH_SIZE + WRITE_SIZE from {traffic_src} (raw counters x 1024; narrow loads are "
-                              "uncalibrated on gfx950, Infinity-Cache hits included)",
-              "hbm_view": {"per_stage_gbs": per_stage_gbs, "peak": HBM_PEAK_GBS, "note": "algorithmic bytes/SB (SURVEY 8d) x SBs / isolated stage time: the memory-side stages of ONE 4K "
-                           "frame move 25-125 MB each, i.e. 3-15 us at peak — alone on the GPU they are launch/latency bound, which is what batching frames per step addresses"},
-              "valu": valu})
-    return r
+            src = f"profiles/{rounds[-1]}/pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, src)))
+    except (OSError, ValueError):
+        pmc = None
+    return rd.roofline({n: per_stage[n] for _, n in stages}, n_sb, pmc, src)
 
 
 def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):

@@ -3,13 +3,13 @@
 # HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC passes carry no API trace domains).
 # Output: gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}/..., summarised by tools/summarize_profiles.py into profiles/<tag>/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # one frame per step on one stream, so that a kernel's trace duration is its own (the default bench overlaps the kernels of several frames on forked streams)
-BENCH="python $R/bench.py --steps 12 --warmup 2 --frames 1 --groups 4 --no-side --no-sweep --no-transfers --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 12 --warmup 2 --frames 1 --groups 4 --no-sweep --no-transfers --no-cpu-baseline --no-variants"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -3,7 +3,10 @@
   pmc_traffic.json   per kernel: launches, average duration (us), FETCH_SIZE / WRITE_SIZE per launch in bytes (raw counter x 1024;
                      the gfx950 caveats of /opt/skills/guides/MI355X_MICROARCH.md 'HBM' apply: wide coalesced reads are under-counted 2x,
                      Infinity-Cache hits are included) and the SQ counters of the same step
-  bench.json         the bench line of the same build without the profiler"""
+  bench.json         the bench line of the same build without the profiler
+  roofline.json      the bench line's `roofline` object recomputed from THESE files alone (tools/roofline_defs.py: stage time = summed rocprofv3 durations of
+                     its kernels per frame; issued lane-operations = SQ_INSTS_VALU x 64; traffic = FETCH_SIZE + WRITE_SIZE) -- bench.py's live object uses
+                     the same functions with HIP-event stage times"""
 import collections
 import csv
 import glob
@@ -65,3 +68,20 @@ if os.path.exists(os.path.join(src, "extra_kernels.txt")):
     shutil.copy(os.path.join(src, "extra_kernels.txt"), os.path.join(dst, "extra_kernels.txt"))
 for f in glob.glob(os.path.join(src, "extra_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "extra_kernel_stats.csv"))
+
+# ---- the roofline object from the profile alone
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import roofline_defs as rd  # noqa: E402
+frames = rd.frames_of(res)
+if frames:
+    n_sb = 2040   # the profiled workload: 3840 x 2160
+    stage_ms = {}
+    for st in rd.ALG_BYTES_PER_SB:
+        us, _, _, _ = rd.stage_counters(res, st, frames)
+        if us > 0 and st not in ("fwd_txfm_quant", "inv_txfm_recon"):
+            stage_ms[st] = us * 1e-3
+    roof = rd.roofline(stage_ms, n_sb, res, f"profiles/{tag}/pmc_traffic.json")
+    json.dump(roof, open(os.path.join(dst, "roofline.json"), "w"), indent=1)
+    print("roofline:", {k: roof[k] for k in ("stage", "bound", "achieved", "peak", "frac", "useful_frac", "traffic_over_algorithmic")})
+    for st, e in roof["stages"].items():
+        print(f"  {st:22s} {e['ms']:7.3f} ms  alg {e['algorithmic_GBps']:7.0f} GB/s  traffic/alg {e.get('traffic_over_algorithmic', float('nan')):6.1f}  issued {e.get('issued_frac', float('nan')):5.2f}  useful {e.get('useful_frac', float('nan')):5.2f}")
