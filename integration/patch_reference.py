@@ -49,7 +49,7 @@ PATCHES = []
 # One call after the two RTCD setups and before the tables derived from them (EbEncHandle.c:1144-1147).
 PATCHES.append(Patch("Source/Lib/Encoder/Globals/EbEncHandle.c").sub(
     r'(setup_rtcd_internal\(enc_handle_ptr->scs_instance_array\[0\]->scs_ptr->static_config\.use_cpu_flags\);\n)',
-    r'\1    svt_hip_hooks_enc_init(); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))
+    r'\1    svt_hip_hooks_enc_init(enc_handle_ptr->scs_instance_array[0]->scs_ptr->static_config.target_socket); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))
 
 # ---------------------------------------------------------------------------------------------------------------- open-loop ME
 me = Patch("Source/Lib/Encoder/Codec/EbMotionEstimation.c")

@@ -137,7 +137,7 @@ static void install_rtcd(const char *list) {
 #undef X
 }
 
-void svt_hip_hooks_enc_init(void) {
+void svt_hip_hooks_enc_init(int target_socket) {
     if (g_inited) return;
     g_inited = 1;
     const char *hooks = getenv("SVT_HIP_HOOKS"), *rtcd = getenv("SVT_HIP_RTCD"), *dev = getenv("SVT_HIP_DEVICE");
@@ -148,14 +148,15 @@ void svt_hip_hooks_enc_init(void) {
         any |= g_enabled[i];
     }
     if (!any) return;   /* the patched encoder is the reference encoder */
-    if (svt_hip_init(dev ? atoi(dev) : 0, &g_ctx) != SVT_HIP_OK) {
+    const int device = dev ? atoi(dev) : (target_socket >= 0 ? target_socket : 0);
+    if (svt_hip_init(device, &g_ctx) != SVT_HIP_OK) {
         /* error convention: never fail through the kernel surface — log, keep the C path */
         SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");
         g_ctx = NULL;
         return;
     }
     if (rtcd && *rtcd) {
-        if (svt_hip_init(dev ? atoi(dev) : 0, &g_rtcd_ctx) == SVT_HIP_OK) install_rtcd(rtcd);
+        if (svt_hip_init(device, &g_rtcd_ctx) == SVT_HIP_OK) install_rtcd(rtcd);
         else SVT_LOG("svt_hip_init (per-call wrappers) failed - SVT_HIP_RTCD ignored, keeping the C kernels\n");
     }
     atexit(svt_hip_hooks_report);

@@ -47,7 +47,9 @@ enum {
 
 /* svt_av1_enc_init, right after setup_common_rtcd_internal / setup_rtcd_internal (EbEncHandle.c:1144-1145) and before the derived
  * tables (:1147): reads the environment, creates the context, installs the requested per-call wrappers. */
-void svt_hip_hooks_enc_init(void);
+/* target_socket: EbSvtAv1EncConfiguration::target_socket of the instance (EbSvtAv1Enc.h:648; -1 = no preference).  The GPU ordinal is SVT_HIP_DEVICE when
+ * set, else target_socket when >= 0 (eight encoder instances started with --socket 0..7 land on eight GPUs), else 0. */
+void svt_hip_hooks_enc_init(int target_socket);
 int  svt_hip_hook_enabled(int which);
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
 SvtHipCtx *svt_hip_hooks_lock(void);
