@@ -132,6 +132,38 @@ enccdef.sub(r'(for \(gi = 0; gi < ppcs->nb_cdef_strengths)(; gi\+\+\) \{\n\s*uin
 enccdef.sub(r'(\n[ \t]*)(selected_strength\[i\] = best_gi;)', r'\1if (hip_fin) best_gi = selected_strength[i];\1\2')
 PATCHES.append(enccdef)
 
+# ---------------------------------------------------------------------------------------------------------------- mode decision: tx_type_search
+# (:4258) the forward transforms of the block for every transform type the loop below can reach, in one launch (svt_hip_md_bridge.c, hook "md_tx"); the
+# loop's av1_estimate_transform call reads the cached coefficients.  The type list is the loop's own filter, evaluated up front (the statistics-based bypass
+# may skip some of them later: an unused transform costs nothing here).
+mdtx = Patch("Source/Lib/Encoder/Codec/EbProductCodingLoop.c")
+mdtx.sub(r'(    int tx_type_tot_group = get_tx_type_group\(context_ptr, candidate_buffer, only_dct_dct\);\n)',
+         r'\1    {\n'
+         r'        uint32_t hip_mask = 0;\n'
+         r'        const int hip_w = context_ptr->blk_geom->tx_width[context_ptr->tx_depth][context_ptr->txb_itr], hip_h = context_ptr->blk_geom->tx_height[context_ptr->tx_depth][context_ptr->txb_itr];\n'
+         r'        for (int hip_g = 0; hip_g < tx_type_tot_group; ++hip_g)\n'
+         r'            for (int hip_i = 0; hip_i < TX_TYPES; ++hip_i) {\n'
+         r'                const int hip_t = pcs_ptr->parent_pcs_ptr->sc_content_detected ? tx_type_group_sc[hip_g][hip_i] : tx_type_group[hip_g][hip_i];\n'
+         r'                if (hip_t == INVALID_TX_TYPE) break;\n'
+         r'                if (only_dct_dct && hip_t != DCT_DCT) continue;\n'
+         r'                if (hip_t != DCT_DCT) {\n'
+         r'                    if (is_inter) {\n'
+         r'                        const TxSize hip_max = context_ptr->blk_geom->txsize[0][0];\n'
+         r'                        if (get_ext_tx_set(hip_max, is_inter, pcs_ptr->parent_pcs_ptr->frm_hdr.reduced_tx_set) <= 0 ||\n'
+         r'                            av1_ext_tx_used[get_ext_tx_set_type(hip_max, is_inter, pcs_ptr->parent_pcs_ptr->frm_hdr.reduced_tx_set)][hip_t] == 0) continue;\n'
+         r'                    }\n'
+         r'                    if (get_ext_tx_set(tx_size, is_inter, pcs_ptr->parent_pcs_ptr->frm_hdr.reduced_tx_set) <= 0 || av1_ext_tx_used[tx_set_type][hip_t] == 0 || hip_w > 32 || hip_h > 32) continue;\n'
+         r'                }\n'
+         r'                hip_mask |= 1u << hip_t;\n'
+         r'            }\n'
+         r'        svt_hip_hook_md_tx_begin(&(((int16_t *)candidate_buffer->residual_ptr->buffer_y)[txb_origin_index]), candidate_buffer->residual_ptr->stride_y, tx_size,\n'
+         r'                                 context_ptr->pf_ctrls.pf_shape, hip_mask);\n'
+         r'    }\n')
+mdtx.sub(r'(\n        // Y: T Q i_q\n)(        av1_estimate_transform\(\n            &\(\(\(int16_t \*\)candidate_buffer->residual_ptr->buffer_y\)\[txb_origin_index\]\),.*?context_ptr->pf_ctrls\.pf_shape\);\n)(\n        quantized_dc_txt\[tx_type\] = av1_quantize_inv_quantize\()',
+         r'\1        if (!svt_hip_hook_md_tx_fetch(tx_size, tx_type, &(((int32_t *)context_ptr->trans_quant_buffers_ptr->txb_trans_coeff2_nx2_n_ptr->buffer_y)[context_ptr->txb_1d_offset])))\n\2\3')
+mdtx.sub(r'(\n    context_ptr->md_staging_spatial_sse_full_loop_level = default_md_staging_spatial_sse_full_loop;\n    //  Best Tx Type Pass\n)', r'\n    svt_hip_hook_md_tx_end();\1')
+PATCHES.append(mdtx)
+
 # ---------------------------------------------------------------------------------------------------------------- picture analysis
 # the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)
 pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")

@@ -12,7 +12,8 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish"};
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx"};
+static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1};   /* not selected by "all": must be named */
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;
@@ -31,6 +32,19 @@ static int in_list(const char *list, const char *name) {
         const char *e = strchr(p, ',');
         const size_t l = e ? (size_t)(e - p) : strlen(p);
         if ((l == n && !strncmp(p, name, n)) || (l == 3 && !strncmp(p, "all", 3))) return 1;
+        if (!e) break;
+        p = e + 1;
+    }
+    return 0;
+}
+
+static int in_list_exact(const char *list, const char *name) {   /* like in_list, but "all" does not match */
+    if (!list) return 0;
+    const size_t n = strlen(name);
+    for (const char *p = list; *p;) {
+        const char *e = strchr(p, ',');
+        const size_t l = e ? (size_t)(e - p) : strlen(p);
+        if (l == n && !strncmp(p, name, n)) return 1;
         if (!e) break;
         p = e + 1;
     }
@@ -144,7 +158,7 @@ void svt_hip_hooks_enc_init(int target_socket) {
     g_verbose = getenv("SVT_HIP_VERBOSE") && atoi(getenv("SVT_HIP_VERBOSE"));
     int any = rtcd && *rtcd;
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++) {
-        g_enabled[i] = in_list(hooks, k_hook_name[i]);
+        g_enabled[i] = k_hook_opt_in[i] ? in_list_exact(hooks, k_hook_name[i]) : in_list(hooks, k_hook_name[i]);
         any |= g_enabled[i];
     }
     if (!any) return;   /* the patched encoder is the reference encoder */

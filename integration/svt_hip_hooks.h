@@ -42,6 +42,9 @@ enum {
     SVT_HIP_HOOK_TF_ME,        /* the motion search of the temporal filter: HME levels and integer search of every (block, frame) of a TF segment batched like
                                 * the open-loop ME (EbTemporalFiltering.c:2264, motion_estimate_sb with ME_MCTF) */
     SVT_HIP_HOOK_CDEF_FINISH,  /* joint_strength_search_dual of finish_cdef_search: the strength-pair selection steps back to back on the device (EbEncCdef.c:1140, :1258) */
+    SVT_HIP_HOOK_MD_TX,        /* mode decision: the forward transforms of a transform block for every type tx_type_search tries, one launch (EbProductCodingLoop.c:4258).
+                                * Opt-in: not part of SVT_HIP_HOOKS=all (a launch per transform block of every candidate is the slow way to use a GPU; it exists to
+                                * put the mode-decision side of the path behind the batched ABI, bit-identically) */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -131,6 +134,11 @@ int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32
  * block's pair; EbEncCdef.c:1258-1298): 1 = *nb_strength_bits, y_strength / uv_strength [1 << bits] and selected[sb_count] hold the device result */
 int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi, int32_t end_gi, uint64_t lambda, int32_t *nb_strength_bits, int32_t *y_strength,
                              int32_t *uv_strength, int32_t *selected);
+
+/* ------------------------------------------------------------------ mode decision (svt_hip_md_bridge.c): tx_type_search's forward transforms, one launch per block */
+int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);
+int  svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff);
+void svt_hip_hook_md_tx_end(void);
 
 /* ------------------------------------------------------------------ picture analysis (svt_hip_pa_bridge.c); EB_ErrorNone = handled */
 EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,

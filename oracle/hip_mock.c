@@ -143,6 +143,29 @@ int svt_hip_cdef_finish_dev(SvtHipCtx *c, const uint64_t *m0, const uint64_t *m1
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------ mode decision (hook "md_tx"): coefficients only, 16-bit planes, blocks up to 32 x 32 */
+int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx *c, int tx_size, int pix_bytes, const void *src, int src_stride, const void *pred, int pred_stride, const uint32_t *descs, int nblk,
+                                     const SvtHipQuantParams *qp, const SvtHipScanTables *scans, int32_t *coeff, int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, int32_t *cul,
+                                     uint64_t *energy) {
+    (void)scans;
+    static const uint8_t tw[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64}, th[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+    if (pix_bytes != 2 || !coeff || qcoeff || dqcoeff || eob || cul || energy || tx_size < 0 || tx_size > 18 || tw[tx_size] > 32 || th[tx_size] > 32) {
+        snprintf(c->err, sizeof(c->err), "mock: svt_hip_fwd_txfm_quant_batch_dev is only built for the coefficient-only form of the md_tx hook");
+        return SVT_HIP_ERR_UNSUPPORTED;
+    }
+    const int w = tw[tx_size], h = th[tx_size];
+    for (int b = 0; b < nblk; b++) {
+        const int x = (int)(descs[b] & 0x3FFF), y = (int)((descs[b] >> 14) & 0x3FFF), tt = (int)(descs[b] >> 28);
+        int16_t r[32 * 32];
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++)
+                r[i * w + j] = (int16_t)((int)((const uint16_t *)src)[(size_t)(y + i) * src_stride + x + j] - (int)((const uint16_t *)pred)[(size_t)(y + i) * pred_stride + x + j]);
+        orc_estimate_transform(r, (uint32_t)w, coeff + (size_t)b * w * h, tt, tx_size, 10, qp ? qp->coeff_shape : 0);
+        if (perturb("md_tx") && b == 1) coeff[(size_t)b * w * h] += 64;
+    }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ picture analysis */
 int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
     (void)c;

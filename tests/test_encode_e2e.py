@@ -92,6 +92,41 @@ def test_per_unit_wiener_hooks_on_cpu_test_double(workdir):
     _check(case, spec, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": E.ALL_PER_UNIT}, "mock_unit")
 
 
+def _check_md_tx(workdir, env, tag, case="cif_8bit_m4"):
+    """hook "md_tx" (opt-in, not part of "all"): mode decision's transform-type search takes the forward transforms of a block for all its candidate types
+    from ONE batched launch (svt_hip_md_bridge.c).  Preset 4 searches several types per block."""
+    spec = CASES[case][:6] + ({"md_tx"},)
+    return _check(case, spec, workdir, env, tag)
+
+
+def test_md_tx_type_search_hook_on_cpu_test_double(workdir):
+    got = _check_md_tx(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_tx"}, "mock_mdtx")
+    assert got["hooks"]["md_tx"][0] > 100, got["hooks"]
+    # together with the picture-level hooks
+    both = _check("cif_8bit_m4", CASES["cif_8bit_m4"][:6] + (ALL | {"md_tx"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all,md_tx"}, "mock_all_mdtx")
+    assert both["hooks"]["md_tx"][0] > 100
+    # "all" alone does not switch it on
+    plain = E.encode(E.APP_HIP, os.path.join(workdir, "cif_8bit_m4.src.yuv"), 352, 288, 2, 4, 45, 8, os.path.join(workdir, "mdtx_off"),
+                     env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"})
+    assert "md_tx" not in plain["hooks"]
+
+
+def test_md_tx_hook_matters(workdir):
+    """a wrong coefficient out of the batched transforms changes the encode: the search really consumes them"""
+    case = "cif_8bit_m4"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_mdtx"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_tx", "SVT_HIP_MOCK_PERTURB": "md_tx"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+
+
+@pytest.mark.gpu
+def test_md_tx_type_search_hook_on_gpu(workdir):
+    got = _check_md_tx(workdir, {"SVT_HIP_HOOKS": "md_tx"}, "hip_mdtx")
+    assert "svt_hip MOCK" not in got["log"] and got["hooks"]["md_tx"][0] > 100, got["hooks"]
+
+
 @pytest.mark.parametrize("hooks", ["hme", "me"])
 def test_motion_estimation_hooks_one_at_a_time_on_cpu_test_double(hooks, workdir):
     """The segment's SB loop runs a different pass sequence for every combination of the two ME hooks (svt_hip_me_bridge.c): "hme" alone = three
