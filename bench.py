@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "encoded 4K 8-bit SB/s (ME+txfm+quant+loopfilter) per GPU; bit-exact vs C ref"
+P3, I3 = C.c_void_p * 3, C.c_int * 3
 # algorithmic bytes per SB, kernel names per stage and the roofline arithmetic: tools/roofline_defs.py (shared with tools/summarize_profiles.py)
 CDEF_LAMBDA = 55473                  # av1_lambda_mode_decision8_bit_sse[120] (EbLambdaRateTables.h:227): full lambda of a key frame at the workload's base_q_idx
 EXT = 3                              # RESTORATION_BORDER: recon / CDEF / restoration planes carry a 3-sample border
