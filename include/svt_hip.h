@@ -524,6 +524,32 @@ int svt_hip_tf_estimate_noise_dev(SvtHipCtx *ctx, const void *d_src, int pix_byt
                                   int64_t *d_out);
 double svt_hip_tf_noise_sigma(int64_t sum, int64_t num);
 
+/* One (64x64 block, window frame) pair of the temporal filter's sub-pel stage. */
+typedef struct SvtHipTfSubpelBlk {
+    int32_t  x, y;          /* luma position of the block in the picture (sb_origin_x / sb_origin_y of the reference's calls) */
+    int32_t  dst_x, dst_y;  /* luma position of the block in the central / predictor planes handed to the call */
+    int32_t  blk_index;     /* its entry of d_blocks */
+    uint32_t mv32[4];       /* MeContext::p_best_mv32x32[0..3] after motion_estimate_sb: (y << 16) | x, quarter-pel (integer vectors) */
+    uint32_t mv16[16];      /* MeContext::p_best_mv16x16[0..15], z-order like the ME table */
+} SvtHipTfSubpelBlk;
+/* tf_32x32_sub_pel_search, tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag and tf_inter_prediction
+ * (Encoder/Codec/EbTemporalFiltering.c:1469, :1133, :284, :1768; call sites :2272-2315) for every listed (block, frame) pair of ONE reference
+ * picture, in one launch: per 32x32 block the half / quarter / (tf_hp) eighth-pel rounds of nine candidates each — EIGHTTAP_REGULAR prediction
+ * through av1_inter_prediction's single-reference path (clamp_mv_to_umv_border_sb against the mi_cols x mi_rows picture, Encoder/Codec/
+ * EbEncInterPrediction.c:24, :3593) scored with svt_aom_variance{32x32,16x16} (8-bit) / variance_highbd (16-bit planes) against the central
+ * picture, first strictly smaller distortion wins —, the 16x16 rounds of the 32x32 blocks whose error reaches `th16`
+ * (MeContext::tf_block_32x32_16x16_th), the split decision, and the MULTITAP_SHARP prediction of luma and (tf_chroma, 4:2:0) chroma with the
+ * chosen vectors.  d_src: the central picture's planes, d_pred: the predictor planes (both addressed with dst_x / dst_y), d_ref: the
+ * reference picture's planes with the pointer at picture sample (0, 0) (padded like the reference's pictures: the search reads up to
+ * 4 + 32 + 4 samples outside the picture; only the rows the vectors reach have to be resident).  d_blocks[blk_index] receives the block's
+ * SvtHipTfBlk64, which svt_hip_tf_filter_frame_dev then reads together with d_pred: the predictors never leave the device.
+ * 16x16 fields of 32x32 blocks that skipped the 16x16 rounds are written as 0 (the reference leaves the previous block's values there and
+ * never reads them: split is 0). */
+int svt_hip_tf_subpel_frame_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *const d_src[3], const int src_stride[3],
+                                const void *const d_ref[3], const int ref_stride[3], void *const d_pred[3], const int pred_stride[3],
+                                int mi_cols, int mi_rows, uint64_t th16, int tf_hp, int tf_chroma, const SvtHipTfSubpelBlk *d_jobs, int n_jobs,
+                                SvtHipTfBlk64 *d_blocks);
+
 /* ------------------------------------------------------------------ compound inter prediction ---- */
 /* One two-reference block.  Both references are predicted like svt_av1_[highbd_]jnt_convolve_{2d_copy,x,y,2d} (common_dsp_rtcd.h:221-243;
  * Common/Codec/EbInterPrediction.c:552-741, :944-1143; round_0 = 3 (5 at 12 bits), round_1 = COMPOUND_ROUND1_BITS) and combined by `type`:

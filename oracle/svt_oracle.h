@@ -209,6 +209,11 @@ void orc_tf_filter_frame(int pix_bytes, int bd, const void *const src[3], const 
 /* Encoder/Codec/EbTemporalFiltering.c:2414 / :2451 (estimate_noise / estimate_noise_highbd); out = {sum, num} */
 double orc_tf_estimate_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, int64_t out[2]);
 
+/* Encoder/Codec/EbTemporalFiltering.c:1469, :1133, :284, :1768 (the TF sub-pel searches, split decision and final prediction); jobs = SvtHipTfSubpelBlk[] */
+void orc_tf_subpel_frame(int pix_bytes, int bd, const void *const src[3], const int src_stride[3], const void *const ref[3], const int ref_stride[3],
+                         void *const pred[3], const int pred_stride[3], int mi_cols, int mi_rows, uint64_t th16, int tf_hp, int tf_chroma, const void *jobs,
+                         int n_jobs, OrcTfBlk64 *blocks);
+
 /* ---------------------------------------------------------------- compound prediction (8(f) rank 4, conv_oracle.c) */
 void orc_jnt_convolve_d16(const void *src, int src_stride, int pix_bytes, int w, int h, int bank_x, int bank_y, int subpel_x_q4, int subpel_y_q4, int bd,
                           uint16_t *out, int out_stride);

@@ -233,3 +233,117 @@ double orc_tf_estimate_noise(const void *src, int pix_bytes, int bd, int width, 
     if (num < 16) return -1.0;
     return (double)sum / (6 * num) * 1.25331413732;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * The sub-pel stage of the temporal filter: tf_32x32_sub_pel_search (Encoder/Codec/EbTemporalFiltering.c:1469), tf_16x16_sub_pel_search
+ * (:1133), derive_tf_32x32_block_split_flag (:284), tf_inter_prediction (:1768) for a list of (64x64 block, frame) pairs of one reference
+ * picture.  A candidate = av1_inter_prediction's single-reference unscaled path (Encoder/Codec/EbEncInterPrediction.c:4040 ->
+ * enc_make_inter_predictor :3663 -> compute_subpel_params :3593 with clamp_mv_to_umv_border_sb :24) + svt_aom_variance{W}x{H}_c /
+ * variance_highbd_c (Encoder/C_DEFAULT/EbComputeVariance_C.c:54 / :34).  Pinned by the end-to-end encodes (tests/test_encode_e2e.py, hook
+ * "tf_subpel" on the CPU test double against the unpatched reference encoder): the reference's functions are static and need a whole
+ * PictureParentControlSet. */
+typedef struct {   /* SvtHipTfSubpelBlk of include/svt_hip.h */
+    int32_t  x, y, dst_x, dst_y, blk_index;
+    uint32_t mv32[4], mv16[16];
+} OrcTfSubpelBlk;
+typedef struct {
+    int pix_bytes, bd, mi_cols, mi_rows, tf_hp, tf_chroma;
+    const void *const *src; const int *src_stride; const void *const *ref; const int *ref_stride; void *const *pred; const int *pred_stride;
+} TfSp;
+
+/* clamp_mv_to_umv_border_sb + the position arithmetic of compute_subpel_params' unscaled branch; mv in 1/8 luma pel, (px, py) the block's luma
+ * position, bs its luma size, (bw, bh) its size in the plane with subsampling ss, (pre_x, pre_y) its position there */
+static void tf_sp_params(const TfSp *t, int mvx, int mvy, int px, int py, int bs, int bw, int bh, int ss, int pre_x, int pre_y, int *pos_x, int *pos_y, int *sx, int *sy) {
+    const int mirow = py >> 2, micol = px >> 2, mi = bs >> 2;
+    const int to_top = -((mirow * 4) * 8), to_bottom = ((t->mi_rows - mi - mirow) * 4) * 8, to_left = -((micol * 4) * 8), to_right = ((t->mi_cols - mi - micol) * 4) * 8;
+    const int spel_left = (4 + bw) << 4, spel_right = spel_left - 16, spel_top = (4 + bh) << 4, spel_bottom = spel_top - 16;
+    int16_t row = (int16_t)(mvy * (1 << (1 - ss))), col = (int16_t)(mvx * (1 << (1 - ss)));
+    col = (int16_t)clampi(col, to_left * (1 << (1 - ss)) - spel_left, to_right * (1 << (1 - ss)) + spel_right);
+    row = (int16_t)clampi(row, to_top * (1 << (1 - ss)) - spel_top, to_bottom * (1 << (1 - ss)) + spel_bottom);
+    *sx = col & 15; *sy = row & 15;
+    *pos_x = ((pre_x << 4) + col) >> 4; *pos_y = ((pre_y << 4) + row) >> 4;
+}
+static void tf_sp_predict(const TfSp *t, int plane, int pos_x, int pos_y, int sx, int sy, int bank, int bw, int bh, void *dst, int dst_stride) {
+    const uint8_t *r = (const uint8_t *)t->ref[plane] + ((ptrdiff_t)pos_y * t->ref_stride[plane] + pos_x) * t->pix_bytes;
+    orc_convolve_sr(r, t->ref_stride[plane], dst, dst_stride, t->pix_bytes, bw, bh, bank, bank, sx, sy, t->bd);
+}
+static uint64_t tf_sp_distortion(const TfSp *t, const void *pred, int bs, int lx, int ly) {
+    const int n = bs * bs;
+    if (t->pix_bytes == 1) {
+        const uint8_t *s = (const uint8_t *)t->src[0] + (ptrdiff_t)ly * t->src_stride[0] + lx, *p = (const uint8_t *)pred;
+        int sum = 0; uint32_t sse = 0;
+        for (int y = 0; y < bs; y++) for (int x = 0; x < bs; x++) { const int d = p[y * bs + x] - s[(ptrdiff_t)y * t->src_stride[0] + x]; sum += d; sse += (uint32_t)(d * d); }
+        return sse - (uint32_t)(((int64_t)sum * sum) / n);
+    }
+    const uint16_t *s = (const uint16_t *)t->src[0] + (ptrdiff_t)ly * t->src_stride[0] + lx, *p = (const uint16_t *)pred;
+    int sad = 0; uint32_t sse = 0;
+    for (int y = 0; y < bs; y++) for (int x = 0; x < bs; x++) { const int d = p[y * bs + x] - s[(ptrdiff_t)y * t->src_stride[0] + x]; sad += d; sse += (uint32_t)(d * d); }
+    return (uint32_t)(sse - (uint32_t)((int)((unsigned)sad * (unsigned)sad) / n));   /* `sad * sad` in int: wraps like the compiled C */
+}
+static void tf_sp_search(const TfSp *t, int bs, int px, int py, int lx, int ly, uint32_t word, int16_t *out_x, int16_t *out_y, uint64_t *out_err) {
+    uint16_t pred[32 * 32];
+    int16_t  mv_x = (int16_t)((int16_t)(word & 0xffff) << 1), mv_y = (int16_t)((int16_t)(word >> 16) << 1), best_x = mv_x, best_y = mv_y;
+    uint64_t best = 0x7fffffff;   /* INT_MAX */
+    for (int round = 0; round < (t->tf_hp ? 3 : 2); round++) {
+        const int step = 4 >> round;
+        for (int i = -step; i <= step; i += step)
+            for (int j = -step; j <= step; j += step) {
+                const int16_t cx = (int16_t)(mv_x + i), cy = (int16_t)(mv_y + j);
+                int pos_x, pos_y, sx, sy;
+                tf_sp_params(t, cx, cy, px, py, bs, bs, bs, 0, px, py, &pos_x, &pos_y, &sx, &sy);
+                tf_sp_predict(t, 0, pos_x, pos_y, sx, sy, 0, bs, bs, pred, bs);   /* EIGHTTAP_REGULAR */
+                const uint64_t d = tf_sp_distortion(t, pred, bs, lx, ly);
+                if (d < best) { best = d; best_x = cx; best_y = cy; }
+            }
+        mv_x = best_x; mv_y = best_y;
+    }
+    *out_x = best_x; *out_y = best_y; *out_err = best;
+}
+static void tf_sp_final(const TfSp *t, int bs, int px, int py, int lx, int ly, int mvx, int mvy) {
+    int pos_x, pos_y, sx, sy;
+    tf_sp_params(t, mvx, mvy, px, py, bs, bs, bs, 0, px, py, &pos_x, &pos_y, &sx, &sy);
+    tf_sp_predict(t, 0, pos_x, pos_y, sx, sy, 2, bs, bs, (uint8_t *)t->pred[0] + ((ptrdiff_t)ly * t->pred_stride[0] + lx) * t->pix_bytes, t->pred_stride[0]);   /* MULTITAP_SHARP */
+    if (!t->tf_chroma) return;
+    const int cb = bs >> 1, cpx = ((px >> 3) << 3) / 2, cpy = ((py >> 3) << 3) / 2, clx = ((lx >> 3) << 3) / 2, cly = ((ly >> 3) << 3) / 2;
+    tf_sp_params(t, mvx, mvy, px, py, bs, cb, cb, 1, cpx, cpy, &pos_x, &pos_y, &sx, &sy);
+    for (int p = 1; p < 3; p++)
+        tf_sp_predict(t, p, pos_x, pos_y, sx, sy, 2, cb, cb, (uint8_t *)t->pred[p] + ((ptrdiff_t)cly * t->pred_stride[p] + clx) * t->pix_bytes, t->pred_stride[p]);
+}
+void orc_tf_subpel_frame(int pix_bytes, int bd, const void *const src[3], const int src_stride[3], const void *const ref[3], const int ref_stride[3],
+                         void *const pred[3], const int pred_stride[3], int mi_cols, int mi_rows, uint64_t th16, int tf_hp, int tf_chroma, const void *jobs_,
+                         int n_jobs, OrcTfBlk64 *blocks) {
+    const OrcTfSubpelBlk *jobs = (const OrcTfSubpelBlk *)jobs_;
+    const TfSp t = {pix_bytes, bd, mi_cols, mi_rows, tf_hp, tf_chroma, src, src_stride, ref, ref_stride, pred, pred_stride};
+    for (int n = 0; n < n_jobs; n++) {
+        const OrcTfSubpelBlk *J = &jobs[n];
+        OrcTfBlk64           *B = &blocks[J->blk_index];
+        int                   search_do[4];
+        for (int q = 0; q < 4; q++)   /* tf_32x32_sub_pel_search */
+            tf_sp_search(&t, 32, J->x + 32 * (q & 1), J->y + 32 * (q >> 1), J->dst_x + 32 * (q & 1), J->dst_y + 32 * (q >> 1), J->mv32[q], &B->mv32_x[q], &B->mv32_y[q],
+                         &B->err32[q]);
+        for (int q = 0; q < 4; q++) {   /* tf_16x16_sub_pel_search; 16x16 k of quadrant q sits at raster (2 (q >> 1) + (k >> 1), 2 (q & 1) + (k & 1)) */
+            search_do[q] = B->err32[q] < th16 ? 0 : 1;
+            for (int k = 0; k < 4; k++) {
+                const int ox = 32 * (q & 1) + 16 * (k & 1), oy = 32 * (q >> 1) + 16 * (k >> 1);
+                if (search_do[q]) tf_sp_search(&t, 16, J->x + ox, J->y + oy, J->dst_x + ox, J->dst_y + oy, J->mv16[4 * q + k], &B->mv16_x[4 * q + k], &B->mv16_y[4 * q + k], &B->err16[4 * q + k]);
+                else { B->mv16_x[4 * q + k] = B->mv16_y[4 * q + k] = 0; B->err16[4 * q + k] = 0; }   /* never read: split = 0 */
+            }
+        }
+        for (int q = 0; q < 4; q++) {   /* derive_tf_32x32_block_split_flag */
+            if (!search_do[q]) { B->split[q] = 0; continue; }
+            const int block_error = (int)B->err32[q];
+            int       mn = 0x7fffffff, mx = (int)0x80000000, sum = 0;
+            for (int k = 0; k < 4; k++) { const int e = (int)B->err16[4 * q + k]; sum = (int)((unsigned)sum + (unsigned)e); mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+            const int b15 = (int)((unsigned)block_error * 15u), b14 = (int)((unsigned)block_error * 14u), s16 = (int)((unsigned)sum * 16u);
+            B->split[q] = ((b15 < s16 && mx - mn < 12000) || (b14 < s16 && mx - mn < 6000)) ? 0 : 1;
+        }
+        for (int q = 0; q < 4; q++) {   /* tf_inter_prediction */
+            if (B->split[q])
+                for (int k = 0; k < 4; k++) {
+                    const int ox = 32 * (q & 1) + 16 * (k & 1), oy = 32 * (q >> 1) + 16 * (k >> 1);
+                    tf_sp_final(&t, 16, J->x + ox, J->y + oy, J->dst_x + ox, J->dst_y + oy, B->mv16_x[4 * q + k], B->mv16_y[4 * q + k]);
+                }
+            else tf_sp_final(&t, 32, J->x + 32 * (q & 1), J->y + 32 * (q >> 1), J->dst_x + 32 * (q & 1), J->dst_y + 32 * (q >> 1), B->mv32_x[q], B->mv32_y[q]);
+        }
+    }
+}

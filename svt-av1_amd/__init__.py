@@ -95,6 +95,11 @@ class TfBlk64(C.Structure):   # SvtHipTfBlk64
                 ("mv32_x", C.c_int16 * 4), ("mv32_y", C.c_int16 * 4), ("err32", C.c_uint64 * 4), ("split", C.c_int32 * 4)]
 
 
+class TfSubpelBlk(C.Structure):   # SvtHipTfSubpelBlk
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("dst_x", C.c_int32), ("dst_y", C.c_int32), ("blk_index", C.c_int32),
+                ("mv32", C.c_uint32 * 4), ("mv16", C.c_uint32 * 16)]
+
+
 class TfRef(C.Structure):     # SvtHipTfRef
     _fields_ = [("pred", C.c_void_p * 3), ("pred_stride", C.c_int * 3), ("blocks", C.c_void_p)]
 
@@ -183,6 +188,7 @@ def lib():
     L.svt_hip_wiener_stats_plane_dev.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     L.svt_hip_tf_filter_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, i32, i32, i32, i32, i32, C.POINTER(TfRef), i32,
                                               C.POINTER(C.c_double), i32, i32, vp]
+    L.svt_hip_tf_subpel_frame_dev.argtypes = [vp, i32, i32, P3, I3, P3, I3, P3, I3, i32, i32, C.c_uint64, i32, i32, vp, i32, vp]
     L.svt_hip_compound_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_obmc_cost_batch_dev.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     L.svt_hip_warp_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32]

@@ -846,6 +846,23 @@ int svt_hip_tf_estimate_noise_dev(SvtHipCtx* c, const void* d_src, int pix_bytes
     return SVT_HIP_OK;
 }
 
+int svt_hip_tf_subpel_frame_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* const d_src[3], const int src_stride[3], const void* const d_ref[3],
+                                const int ref_stride[3], void* const d_pred[3], const int pred_stride[3], int mi_cols, int mi_rows, uint64_t th16, int tf_hp,
+                                int tf_chroma, const SvtHipTfSubpelBlk* d_jobs, int n_jobs, SvtHipTfBlk64* d_blocks) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !src_stride || !d_ref || !ref_stride || !d_pred || !pred_stride || !d_jobs || !d_blocks || n_jobs < 0 || mi_cols <= 0 || mi_rows <= 0 ||
+        (pix_bytes != 1 && pix_bytes != 2) || (pix_bytes == 1 && bd != 8) || (pix_bytes == 2 && bd != 8 && bd != 10)) {
+        if (c) c->err = "svt_hip_tf_subpel_frame_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    for (int p = 0; p < (tf_chroma ? 3 : 1); p++)
+        if (!d_src[p] || !d_ref[p] || !d_pred[p]) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_tf_subpel(c->stream, pix_bytes, bd, d_src, src_stride, d_ref, ref_stride, d_pred, pred_stride, mi_cols, mi_rows, th16,
+                                                        tf_hp != 0, tf_chroma != 0, d_jobs, n_jobs, d_blocks);
+    if (e != hipSuccess) return fail(c, e, "tf sub-pel launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_compound_predict_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_ref0, int ref0_stride, const void* d_ref1, int ref1_stride,
                                        void* d_dst, int dst_stride, uint8_t* d_masks, const SvtHipCompBlk* d_blks, int nblk) {
     SVT_HIP_ENTER(c);

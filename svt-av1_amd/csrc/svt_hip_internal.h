@@ -32,6 +32,9 @@ int svt_hip_launch_tf_filter(hipStream_t st, int pix_bytes, int bd, const void* 
                              const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef* refs, int n_refs,
                              const double den[3], double dist_thr, uint64_t* sse);
 int svt_hip_launch_tf_noise(hipStream_t st, const void* src, int pix_bytes, int bd, int width, int height, int stride, uint64_t* out);
+int svt_hip_launch_tf_subpel(hipStream_t st, int pix_bytes, int bd, const void* const src[3], const int src_stride[3], const void* const ref[3],
+                             const int ref_stride[3], void* const pred[3], const int pred_stride[3], int mi_cols, int mi_rows, uint64_t th16,
+                             int tf_hp, int tf_chroma, const SvtHipTfSubpelBlk* jobs, int n_jobs, SvtHipTfBlk64* blocks);
 int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,
                                   int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int ncand, const int32_t* xqd, int64_t* err);
 size_t svt_hip_wiener_stats16_scratch(int win, int pw, int ph, int n_units);

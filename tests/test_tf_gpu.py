@@ -177,3 +177,57 @@ def test_filter_4k_window7(hip, orc, pkg):
     out3, sse3 = run([0] * n_refs, 2, pred_src=[d_src], blk_src=[d_zero])
     assert all(np.array_equal(a, b) for a, b in zip(out3, src)) and not sse3.any()
     hip.free(*d_src, *[x for pr in d_pred for x in pr], *d_blk, d_zero)
+
+
+# ------------------------------------------------------------------------------------------------ the sub-pel stage (hook "tf_subpel")
+def run_subpel(hip, orc, pkg, w, h, bd, th16, tf_hp, tf_chroma, seed, pad=80, max_mv=9):
+    rng = np.random.default_rng(seed)
+    src, ref, jobs = tfc.make_subpel_case(rng, w, h, bd, pad, max_mv=max_mv)
+    pb = src[0].itemsize
+    nb = len(jobs)
+    pads = [pad, pad >> 1, pad >> 1]
+    # the reference planes are handed over with the pointer at picture sample (0, 0)
+    r_off = [(pads[p] * ref[p].shape[1] + pads[p]) * pb for p in range(3)]
+    e_pred = [np.zeros_like(p) for p in src]; e_blk = np.zeros(nb, tfc.BLK_DTYPE)
+    orc.orc_tf_subpel_frame.argtypes = [C.c_int, C.c_int, P3, I3, P3, I3, P3, I3, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    orc.orc_tf_subpel_frame(pb, bd, P3(*[p.ctypes.data for p in src]), I3(*[p.shape[1] for p in src]), P3(*[ref[p].ctypes.data + r_off[p] for p in range(3)]),
+                            I3(*[p.shape[1] for p in ref]), P3(*[p.ctypes.data for p in e_pred]), I3(*[p.shape[1] for p in e_pred]), w // 4, h // 4, th16, tf_hp,
+                            tf_chroma, jobs.ctypes.data, nb, e_blk.ctypes.data)
+    d_src = [hip.to_device(p) for p in src]; d_ref = [hip.to_device(p) for p in ref]; d_pred = [hip.to_device(np.zeros_like(p)) for p in src]
+    d_jobs = hip.to_device(jobs); d_blk = hip.to_device(np.zeros(nb, tfc.BLK_DTYPE))
+    hip.check(hip.L.svt_hip_tf_subpel_frame_dev(hip.h, pb, bd, P3(*[p.value for p in d_src]), I3(*[p.shape[1] for p in src]),
+                                               P3(*[d_ref[p].value + r_off[p] for p in range(3)]), I3(*[p.shape[1] for p in ref]), P3(*[p.value for p in d_pred]),
+                                               I3(*[p.shape[1] for p in src]), w // 4, h // 4, th16, tf_hp, tf_chroma, d_jobs, nb, d_blk), "tf subpel")
+    g_blk = hip.to_host(d_blk, (nb,), tfc.BLK_DTYPE)
+    for k in ("mv32_x", "mv32_y", "err32", "split", "mv16_x", "mv16_y", "err16"):
+        assert np.array_equal(g_blk[k], e_blk[k]), (k, np.argwhere(g_blk[k] != e_blk[k])[:4], g_blk[k][g_blk[k] != e_blk[k]][:4], e_blk[k][g_blk[k] != e_blk[k]][:4])
+    for p in range(3 if tf_chroma else 1):
+        got = hip.to_host(d_pred[p], src[p].shape, src[p].dtype)
+        assert np.array_equal(got, e_pred[p]), (p, np.argwhere(got != e_pred[p])[:4])
+    hip.free(*d_src, *d_ref, *d_pred, d_jobs, d_blk)
+    return e_blk, e_pred, src
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_subpel_search_and_prediction(hip, orc, pkg, bd):
+    """tf_32x32 / tf_16x16_sub_pel_search + split decision + tf_inter_prediction, every (block, frame) pair in one launch, vs the oracle; the threshold
+    is set so that both kinds of 32x32 block occur (with and without the 16x16 rounds), vectors of border blocks run into the clamp"""
+    blk, _, _ = run_subpel(hip, orc, pkg, 256, 192, bd, th16=1 << 40, tf_hp=1, tf_chroma=1, seed=5)     # no 16x16 rounds: the 32x32 errors of this content
+    th = int(np.median(blk["err32"]))
+    blk, _, _ = run_subpel(hip, orc, pkg, 256, 192, bd, th16=th, tf_hp=1, tf_chroma=1, seed=5)
+    assert 0 < np.count_nonzero(blk["err32"] >= th) < blk["err32"].size
+    assert blk["split"].any() and not blk["split"].all()
+    run_subpel(hip, orc, pkg, 128, 128, bd, th16=0, tf_hp=0, tf_chroma=0, seed=6)              # every block searched at 16x16, no eighth-pel round, luma only
+    run_subpel(hip, orc, pkg, 128, 64, bd, th16=1 << 40, tf_hp=1, tf_chroma=1, seed=7)         # no 16x16 rounds at all
+
+
+def test_subpel_finds_the_motion(hip, orc, pkg):
+    """size-independent property: with the reference = the central picture shifted by (+2.3, -1.6) samples the chosen 32x32 vectors of interior blocks land
+    within an eighth of a sample of that shift when the integer vector starts at the nearest full-pel position"""
+    rng = np.random.default_rng(11)
+    blk, _, _ = run_subpel(hip, orc, pkg, 256, 256, 8, th16=1 << 40, tf_hp=1, tf_chroma=1, seed=11, max_mv=0)
+    # interior blocks only (border vectors are pushed out on purpose)
+    inner = [r * 4 + c for r in range(1, 3) for c in range(1, 3)]
+    # the reference texture is offset by (-2.3, +1.6): block at x in the central picture sits at x - 2.3 in the reference -> vector ~ (-2.3, +1.6) * 8
+    mvx = blk["mv32_x"][inner].astype(np.int32); mvy = blk["mv32_y"][inner].astype(np.int32)
+    assert np.all(np.abs(mvx - round(-2.3 * 8)) <= 12) and np.all(np.abs(mvy - round(1.6 * 8)) <= 12), (mvx, mvy)

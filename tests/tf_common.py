@@ -51,3 +51,49 @@ def make_pictures(rng, w, h, bd, ss_x, ss_y, n_refs, noise=6.0):
         if f == 0: pr[0][:32, :32] = 0                     # maximum squared differences in one 32x32 block
         preds.append(pr)
     return src, preds
+
+
+# SvtHipTfSubpelBlk (include/svt_hip.h): one (64x64 block, frame) pair of the TF sub-pel stage
+SUBPEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("dst_x", np.int32), ("dst_y", np.int32), ("blk_index", np.int32),
+                         ("mv32", np.uint32, 4), ("mv16", np.uint32, 16)], align=True)
+assert SUBPEL_DTYPE.itemsize == 100
+
+
+def mv_word(mx, my):
+    """the ME table's vector word: (y << 16) | x, quarter-pel int16 halves of an integer vector"""
+    return ((np.asarray(my, np.int64) * 4 & 0xffff) << 16 | (np.asarray(mx, np.int64) * 4 & 0xffff)).astype(np.uint32)
+
+
+def make_subpel_case(rng, w, h, bd, pad, max_mv=9, noise=3.0, edge_mv=True):
+    """A central picture and a padded reference picture (the central one shifted by a smooth sub-pel field + noise), 4:2:0, and one job per 64x64 block
+    whose integer vectors point near the true motion; blocks on the picture border get vectors that push the clamp of clamp_mv_to_umv_border_sb."""
+    dt = np.uint8 if bd == 8 else np.uint16
+    mx = (1 << bd) - 1
+    sc = 1 << (bd - 8)
+
+    def tex(hh, ww, ox, oy, k):
+        yy, xx = np.mgrid[0:hh, 0:ww].astype(np.float64)
+        xx = xx + ox; yy = yy + oy
+        return (120 + 60 * np.sin(xx / (7.0 + k)) * np.cos(yy / (5.0 + k)) + 30 * np.sin((xx + 2 * yy) / 3.1)) * sc
+
+    src, ref = [], []
+    for p in range(3):
+        s = 0 if p == 0 else 1
+        ww, hh, pd = w >> s, h >> s, pad >> s
+        src.append(np.ascontiguousarray(np.clip(tex(hh, ww, 0, 0, p) + rng.normal(0, noise * sc, (hh, ww)), 0, mx).astype(dt)))
+        full = np.clip(tex(hh + 2 * pd, ww + 2 * pd, -pd + 2.3 / (1 + s), -pd - 1.6 / (1 + s), p) + rng.normal(0, noise * sc, (hh + 2 * pd, ww + 2 * pd)), 0, mx).astype(dt)
+        ref.append(np.ascontiguousarray(full))
+    bc, br = w // 64, h // 64
+    jobs = np.zeros(bc * br, SUBPEL_DTYPE)
+    for r in range(br):
+        for c in range(bc):
+            j = jobs[r * bc + c]
+            j["x"], j["y"], j["dst_x"], j["dst_y"], j["blk_index"] = c * 64, r * 64, c * 64, r * 64, r * bc + c
+            m32x = rng.integers(-max_mv, max_mv + 1, 4); m32y = rng.integers(-max_mv, max_mv + 1, 4)
+            m16x = rng.integers(-max_mv, max_mv + 1, 16); m16y = rng.integers(-max_mv, max_mv + 1, 16)
+            if edge_mv and (r == 0 or c == 0 or r == br - 1 or c == bc - 1):   # far outside the picture: the clamp decides
+                far = pad - 8
+                m32x[:] = -far if c == 0 else (far if c == bc - 1 else m32x); m32y[:] = -far if r == 0 else (far if r == br - 1 else m32y)
+                m16x[:8] = m32x[0]; m16y[:8] = m32y[0]
+            j["mv32"] = mv_word(m32x, m32y); j["mv16"] = mv_word(m16x, m16y)
+    return src, ref, jobs
