@@ -205,6 +205,12 @@ tf.sub(r'(\n[ \t]*)(motion_estimate_sb\(\s*picture_control_set_ptr_central, // s
        r'\1        continue; /* not the last pass: the searches of this (block, frame) are pending */'
        r'\1} else'
        r'\1\2')
+# hook "tf_subpel": the two sub-pel searches, the split decision and tf_inter_prediction of this (block, frame) are recorded for the segment's flush
+tf.sub(r'(\n[ \t]*)(// Perform TF sub-pel search for 32x32 blocks\n)',
+       r'\1if (!svt_hip_tf_seg_subpel(hip_tf, frame_index, blk_row, blk_col, context_ptr, picture_control_set_ptr_central, list_picture_control_set_ptr[frame_index],'
+       r'\1                           list_input_picture_ptr[frame_index], (uint32_t)blk_col * BW, (uint32_t)blk_row * BH)) {\1\2')
+tf.sub(r'(\n[ \t]*tf_inter_prediction\(picture_control_set_ptr_central,\s*context_ptr,\s*list_picture_control_set_ptr\[frame_index\],.*?encoder_bit_depth\);\n)',
+       r'\1                    } /* svt_hip_tf_seg_subpel */\n')
 tf.sub(r'(\n[ \t]*if \(picture_control_set_ptr_central->scs_ptr->static_config\.qp <= ALT_REF_QP_THRESH\)\s*decay_control--;\n)',
        r'\1                if (hip_tf) { /* Step 2 of this (frame, block) happens in svt_hip_tf_seg_flush */\n'
        r'                    svt_hip_tf_seg_block(hip_tf, frame_index, blk_row, blk_col, context_ptr, pred, pred_16bit, stride_pred, decay_control);\n'

@@ -12,7 +12,7 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx"};
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel"};
 static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1};   /* not selected by "all": must be named */
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
@@ -120,6 +120,32 @@ void svt_hip_hooks_report(void) {
     X(handle_transform64_N2_N4, 2, handle_transform64x16_N2_N4) X(handle_transform64_N2_N4, 3, handle_transform64x32_N2_N4)                 \
     X(handle_transform64_N2_N4, 4, handle_transform64x64_N2_N4)
 
+/* the families with one pointer per block size (22 sizes, SVT_HIP_RTCD_BLOCK_SIZES order): what the sub-pel searches of mode decision / the temporal filter
+ * call through mefn_ptr[] (svt_aom_variance{W}x{H}, svt_aom_sad{W}x{H}[x4d], the OBMC costs) — mefn_ptr is built from these pointers after this init
+ * (EbEncHandle.c:1147), so replacing them here reaches every caller */
+#define RTCD_BY_SIZE(X)                                                                                                                 \
+    SVT_HIP_RTCD_BLOCK_SIZES(X##_sad) SVT_HIP_RTCD_BLOCK_SIZES(X##_sadx4d) SVT_HIP_RTCD_BLOCK_SIZES(X##_var) SVT_HIP_RTCD_BLOCK_SIZES(X##_var10) \
+    SVT_HIP_RTCD_BLOCK_SIZES(X##_osad) SVT_HIP_RTCD_BLOCK_SIZES(X##_ovar) SVT_HIP_RTCD_BLOCK_SIZES(X##_osvar)
+#define SAVE_sad(I, W, H)    t.svt_aom_sad[I] = (void *)svt_aom_sad##W##x##H;
+#define SAVE_sadx4d(I, W, H) t.svt_aom_sadx4d[I] = (void *)svt_aom_sad##W##x##H##x4d;
+#define SAVE_var(I, W, H)    t.svt_aom_variance[I] = (void *)svt_aom_variance##W##x##H;
+#define SAVE_var10(I, W, H)  t.svt_aom_highbd_10_variance[I] = (void *)svt_aom_highbd_10_variance##W##x##H;
+#define SAVE_osad(I, W, H)   t.svt_aom_obmc_sad[I] = (void *)svt_aom_obmc_sad##W##x##H;
+#define SAVE_ovar(I, W, H)   t.svt_aom_obmc_variance[I] = (void *)svt_aom_obmc_variance##W##x##H;
+#define SAVE_osvar(I, W, H)  t.svt_aom_obmc_sub_pixel_variance[I] = (void *)svt_aom_obmc_sub_pixel_variance##W##x##H;
+#define PUT(member, I, name)                                              \
+    if (in_list(list, #name)) {                                           \
+        name = (void *)t.member[I];                                       \
+        fprintf(stderr, "svt_hip_rtcd %s -> hip wrapper\n", #name);       \
+    }
+#define PUT_sad(I, W, H)    PUT(svt_aom_sad, I, svt_aom_sad##W##x##H)
+#define PUT_sadx4d(I, W, H) PUT(svt_aom_sadx4d, I, svt_aom_sad##W##x##H##x4d)
+#define PUT_var(I, W, H)    PUT(svt_aom_variance, I, svt_aom_variance##W##x##H)
+#define PUT_var10(I, W, H)  PUT(svt_aom_highbd_10_variance, I, svt_aom_highbd_10_variance##W##x##H)
+#define PUT_osad(I, W, H)   PUT(svt_aom_obmc_sad, I, svt_aom_obmc_sad##W##x##H)
+#define PUT_ovar(I, W, H)   PUT(svt_aom_obmc_variance, I, svt_aom_obmc_variance##W##x##H)
+#define PUT_osvar(I, W, H)  PUT(svt_aom_obmc_sub_pixel_variance, I, svt_aom_obmc_sub_pixel_variance##W##x##H)
+
 static void install_rtcd(const char *list) {
     SvtHipRtcd t;
     memset(&t, 0, sizeof(t));
@@ -130,6 +156,7 @@ static void install_rtcd(const char *list) {
 #define X(m, i, n) t.m[i] = (void *)n;
     RTCD_INDEXED(X)
 #undef X
+    RTCD_BY_SIZE(SAVE)
     if (svt_hip_setup_rtcd(g_rtcd_ctx, &t) != SVT_HIP_OK) {
         SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_rtcd_ctx));
         return;
@@ -149,6 +176,7 @@ static void install_rtcd(const char *list) {
     }
     RTCD_INDEXED(X)
 #undef X
+    RTCD_BY_SIZE(PUT)
 }
 
 void svt_hip_hooks_enc_init(int target_socket) {

@@ -6,7 +6,7 @@
  * "not handled" and the caller runs its unchanged C loop, so a HIP failure can never surface through a kernel pointer.
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
- *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, hme, me, cdef_finish, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, tf_subpel, hme, me, cdef_finish, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -45,6 +45,9 @@ enum {
     SVT_HIP_HOOK_MD_TX,        /* mode decision: the forward transforms of a transform block for every type tx_type_search tries, one launch (EbProductCodingLoop.c:4258).
                                 * Opt-in: not part of SVT_HIP_HOOKS=all (a launch per transform block of every candidate is the slow way to use a GPU; it exists to
                                 * put the mode-decision side of the path behind the batched ABI, bit-identically) */
+    SVT_HIP_HOOK_TF_SUBPEL,    /* the temporal filter's sub-pel stage: tf_32x32 / tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag and tf_inter_prediction of every
+                                * (block, frame) pair of a TF segment, one launch per window frame (EbTemporalFiltering.c:2272-2315); the predictors stay on the device for
+                                * hook "tf", which it needs (without "tf" the reference's C code runs) */
     SVT_HIP_HOOK_COUNT
 };
 

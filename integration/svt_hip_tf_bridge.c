@@ -1,4 +1,6 @@
 /* svt_hip_tf_bridge.c — see svt_hip_tf_bridge.h.  Host code only; the pixel work is one svt_hip_tf_filter_frame_dev launch per central picture. */
+#include <stdint.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include "svt_hip_tf_bridge.h"
@@ -56,7 +58,7 @@ EbErrorType svt_hip_tf_flush_picture(SvtHipCtx *hip, SvtHipTfWindow *w, const Me
     const size_t nblk = (size_t)w->blk_cols * w->blk_rows;
     for (int f = 0; f < w->n_frames; f++) {
         if (f == w->index_center) continue;                      /* blocks == NULL: apply_filtering_central */
-        HIP_TRY(svt_hip_memcpy_h2d(hip, w->d_blocks[f], w->h_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
+        if (!w->blocks_on_device[f]) HIP_TRY(svt_hip_memcpy_h2d(hip, w->d_blocks[f], w->h_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
         for (int p = 0; p < 3; p++) { refs[f].pred[p] = w->d_pred[f][p]; refs[f].pred_stride[p] = w->pred_stride[p]; }
         refs[f].blocks = w->d_blocks[f];
     }
@@ -73,8 +75,15 @@ struct SvtHipTfSeg {
     SvtHipTfWindow w;                 /* geometry of the segment's rectangle (blk_cols x blk_rows), block records per frame */
     uint32_t       col0, row0;
     int            is_highbd, ss_x, ss_y, decay_control, ctor_done;
-    uint8_t       *h_pred[SVT_HIP_TF_MAX_REFS][3]; /* host staging of the predictor pictures (the reference's tf_inter_prediction output) */
+    uint8_t       *h_pred[SVT_HIP_TF_MAX_REFS][3]; /* host staging of the predictor pictures (the reference's tf_inter_prediction output); hook "tf_subpel": unused */
     size_t         plane_bytes[3];
+    /* hook "tf_subpel": the (block, frame) pairs whose sub-pel searches and prediction run on the device at the flush */
+    int                        subpel, mi_cols, mi_rows, tf_hp;
+    uint64_t                   th16;
+    SvtHipTfSubpelBlk         *jobs[SVT_HIP_TF_MAX_REFS];
+    int                        n_jobs[SVT_HIP_TF_MAX_REFS], n_host[SVT_HIP_TF_MAX_REFS];   /* pairs recorded for the device / predicted by the reference's C */
+    const EbPictureBufferDesc *ref_pic[SVT_HIP_TF_MAX_REFS];                                /* geometry of the frame's reference picture */
+    const uint8_t             *ref_plane[SVT_HIP_TF_MAX_REFS][3];                           /* its planes (8-bit buffers, or altref_buffer_highbd) */
 };
 
 SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0, uint32_t col1, uint32_t row0, uint32_t row1, int is_highbd, int ss_x, int ss_y) {
@@ -82,6 +91,7 @@ SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0,
     SvtHipTfSeg *s = (SvtHipTfSeg *)calloc(1, sizeof(*s));
     if (!s) return NULL;
     s->col0 = col0; s->row0 = row0; s->is_highbd = is_highbd; s->ss_x = ss_x; s->ss_y = ss_y;
+    s->subpel = svt_hip_hook_enabled(SVT_HIP_HOOK_TF_SUBPEL) && ss_x == 1 && ss_y == 1;   /* av1_inter_prediction's chroma path is 4:2:0 */
     SvtHipTfWindow *w = &s->w;
     w->n_frames = n_frames; w->index_center = index_center;
     w->blk_cols = (int)(col1 - col0); w->blk_rows = (int)(row1 - row0);
@@ -94,6 +104,7 @@ SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0,
         w->h_blocks[f] = (SvtHipTfBlk64 *)calloc(nblk, sizeof(SvtHipTfBlk64));
         int ok = w->h_blocks[f] != NULL;
         for (int p = 0; p < 3 && ok; p++) ok = (s->h_pred[f][p] = (uint8_t *)calloc(1, s->plane_bytes[p])) != NULL;
+        if (ok && s->subpel) ok = (s->jobs[f] = (SvtHipTfSubpelBlk *)calloc(nblk, sizeof(SvtHipTfSubpelBlk))) != NULL;
         if (!ok) { svt_hip_tf_seg_end(s); return NULL; }
     }
     return s;
@@ -103,7 +114,7 @@ void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
     if (!s) return;
     SvtHipCtx *hip = s->ctor_done ? svt_hip_hooks_lock() : NULL;
     for (int f = 0; f < SVT_HIP_TF_MAX_REFS; f++) {
-        free(s->w.h_blocks[f]);
+        free(s->w.h_blocks[f]); free(s->jobs[f]);
         for (int p = 0; p < 3; p++) free(s->h_pred[f][p]);
         if (hip) {
             svt_hip_free(hip, s->w.d_blocks[f]);
@@ -114,10 +125,35 @@ void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
     free(s);
 }
 
+/* hook "tf_subpel", after the motion search of (frame, block): 1 = the pair is recorded — tf_32x32 / tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag and
+ * tf_inter_prediction of it run on the device in svt_hip_tf_seg_flush (one launch per window frame), the caller skips them */
+int svt_hip_tf_seg_subpel(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *c, const PictureParentControlSet *pcs_central,
+                          const PictureParentControlSet *pcs_ref, const EbPictureBufferDesc *pic_ref, uint32_t sb_origin_x, uint32_t sb_origin_y) {
+    if (!s || !s->subpel || frame_index == s->w.index_center || !s->jobs[frame_index] || !c->p_best_mv32x32 || !c->p_best_mv16x16) return 0;
+    const uint32_t r = blk_row - s->row0, col = blk_col - s->col0;
+    if (s->n_host[frame_index]) return 0;   /* one frame is predicted either here or by the C code, not both */
+    SvtHipTfSubpelBlk *j = &s->jobs[frame_index][s->n_jobs[frame_index]++];
+    j->x = (int32_t)sb_origin_x; j->y = (int32_t)sb_origin_y;
+    j->dst_x = (int32_t)col * 64; j->dst_y = (int32_t)r * 64;
+    j->blk_index = (int32_t)(r * (uint32_t)s->w.blk_cols + col);
+    for (int i = 0; i < 4; i++) j->mv32[i] = c->p_best_mv32x32[i];
+    for (int i = 0; i < 16; i++) j->mv16[i] = c->p_best_mv16x16[i];
+    s->mi_cols = pcs_central->av1_cm->mi_cols; s->mi_rows = pcs_central->av1_cm->mi_rows;
+    s->th16 = c->tf_block_32x32_16x16_th; s->tf_hp = c->tf_hp;
+    s->ref_pic[frame_index] = pic_ref;
+    for (int p = 0; p < 3; p++) {
+        const uint8_t *b = p == 0 ? pic_ref->buffer_y : (p == 1 ? pic_ref->buffer_cb : pic_ref->buffer_cr);
+        s->ref_plane[frame_index][p] = s->is_highbd ? (const uint8_t *)pcs_ref->altref_buffer_highbd[p] : b;
+    }
+    return 1;
+}
+
 void svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *c, EbByte *pred, uint16_t **pred_16bit,
                           const uint32_t *stride_pred, int decay_control) {
     s->decay_control = decay_control;   /* the same for every block of the picture (resolution class and QP, EbTemporalFiltering.c:2313-2320) */
     if (frame_index == s->w.index_center) return;   /* apply_filtering_central reads the central picture itself */
+    if (s->n_jobs[frame_index]) return;             /* recorded by svt_hip_tf_seg_subpel: predictor and TF fields are produced on the device */
+    s->n_host[frame_index]++;
     const uint32_t r = blk_row - s->row0, col = blk_col - s->col0;
     svt_hip_tf_record_block(&s->w, frame_index, r, col, c);
     const int pb = s->is_highbd ? 2 : 1;
@@ -130,6 +166,49 @@ void svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uin
 }
 
 #define TF_TRY(x) do { if (ret == EB_ErrorNone && (x) != SVT_HIP_OK) ret = EB_ErrorUndefined; } while (0)
+/* The reference picture of window frame f: only the rows the recorded vectors can reach travel (a segment is a band of block rows), every plane with its
+ * full padded width; the entry point gets the planes' pointers at picture sample (0, 0). */
+static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const MeContext *c, void *const d_src[3], const int sstride[3], int bd) {
+    const EbPictureBufferDesc *rp = s->ref_pic[f];
+    const int                  pb = s->is_highbd ? 2 : 1, np = c->tf_chroma ? 3 : 1, n = s->n_jobs[f];
+    EbErrorType                ret = EB_ErrorNone;
+    /* luma rows: the block displaced by its integer vectors, +- (7/8 sample of refinement + the 8-tap support), and the block's own rows (the clamp of
+     * clamp_mv_to_umv_border_sb pulls a vector towards the picture, never away from it) */
+    int y_lo = INT32_MAX, y_hi = INT32_MIN;
+    for (int k = 0; k < n; k++) {
+        const SvtHipTfSubpelBlk *j = &s->jobs[f][k];
+        for (int i = 0; i < 20; i++) {
+            const uint32_t word = i < 4 ? j->mv32[i] : j->mv16[i - 4];
+            const int      my = (int16_t)(word >> 16) >> 2;   /* quarter-pel word of an integer vector */
+            const int      lo = j->y + (my < 0 ? my : 0) - 8, hi = j->y + 63 + (my > 0 ? my : 0) + 8;
+            if (lo < y_lo) y_lo = lo;
+            if (hi > y_hi) y_hi = hi;
+        }
+    }
+    const int stride3[3] = {rp->stride_y, rp->stride_cb, rp->stride_cr};
+    void     *d_band[3] = {NULL, NULL, NULL}, *d_jobs = NULL;
+    const void *d_ref[3] = {NULL, NULL, NULL};
+    for (int p = 0; p < np; p++) {
+        const int ss = p ? 1 : 0, org_x = rp->origin_x >> ss, org_y = rp->origin_y >> ss, rows = (rp->height >> ss) + 2 * org_y;
+        int lo = (y_lo >> ss) - 2, hi = (y_hi >> ss) + 2;   /* chroma: the halved range with a margin for the halved-position rounding */
+        if (lo < -org_y) lo = -org_y;
+        if (hi > rows - org_y - 1) hi = rows - org_y - 1;
+        if (hi < lo) return EB_ErrorUndefined;
+        const size_t bytes = (size_t)(hi - lo + 1) * stride3[p] * pb;
+        TF_TRY(svt_hip_malloc(hip, &d_band[p], bytes + 64));
+        TF_TRY(svt_hip_memcpy_h2d(hip, d_band[p], s->ref_plane[f][p] + (size_t)(org_y + lo) * stride3[p] * pb, bytes));
+        if (ret == EB_ErrorNone) d_ref[p] = (const uint8_t *)d_band[p] + ((ptrdiff_t)(-lo) * stride3[p] + org_x) * pb;
+    }
+    TF_TRY(svt_hip_malloc(hip, &d_jobs, sizeof(SvtHipTfSubpelBlk) * (size_t)n));
+    TF_TRY(svt_hip_memcpy_h2d(hip, d_jobs, s->jobs[f], sizeof(SvtHipTfSubpelBlk) * (size_t)n));
+    TF_TRY(svt_hip_tf_subpel_frame_dev(hip, pb, bd, (const void *const *)d_src, sstride, d_ref, stride3, s->w.d_pred[f], s->w.pred_stride, s->mi_cols, s->mi_rows,
+                                       s->th16, s->tf_hp, c->tf_chroma, (const SvtHipTfSubpelBlk *)d_jobs, n, s->w.d_blocks[f]));
+    if (ret == EB_ErrorNone && svt_hip_memcpy_d2h(hip, &s->w.h_blocks[f][0], s->w.d_blocks[f], sizeof(SvtHipTfBlk64)) != SVT_HIP_OK) ret = EB_ErrorUndefined;   /* completes the launch before the band is freed */
+    for (int p = 0; p < 3; p++) svt_hip_free(hip, d_band[p]);
+    svt_hip_free(hip, d_jobs);
+    return ret;
+}
+
 EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src_start, uint16_t **src16_start, const uint32_t *stride, int bd, const double *noise_levels,
                                  uint64_t *filtered_sse, uint64_t *filtered_sse_uv) {
     SvtHipTfWindow *w = &s->w;
@@ -142,14 +221,6 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     uint8_t    *host[3];
     int         sstride[3];
     s->ctor_done = 1;
-    for (int f = 0; f < w->n_frames && ret == EB_ErrorNone; f++) {
-        if (f == w->index_center) continue;
-        TF_TRY(svt_hip_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
-        for (int p = 0; p < 3; p++) {
-            TF_TRY(svt_hip_malloc(hip, &w->d_pred[f][p], s->plane_bytes[p]));
-            if (p < np) TF_TRY(svt_hip_memcpy_h2d(hip, w->d_pred[f][p], s->h_pred[f][p], s->plane_bytes[p]));
-        }
-    }
     TF_TRY(svt_hip_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
     /* the segment's rectangle of the central picture (chroma is only read when tf_chroma is on) */
     for (int p = 0; p < 3; p++) {
@@ -158,6 +229,21 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
         sstride[p] = w->pred_stride[p];
         TF_TRY(svt_hip_malloc(hip, &d_src[p], s->plane_bytes[p]));
         TF_TRY(svt_hip_memcpy2d_h2d(hip, d_src[p], (size_t)sstride[p] * pb, host[p], (size_t)stride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
+    }
+    int n_subpel = 0;
+    for (int f = 0; f < w->n_frames && ret == EB_ErrorNone; f++) {
+        if (f == w->index_center) continue;
+        TF_TRY(svt_hip_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
+        for (int p = 0; p < 3; p++) {
+            TF_TRY(svt_hip_malloc(hip, &w->d_pred[f][p], s->plane_bytes[p]));
+            if (p < np && !s->n_jobs[f]) TF_TRY(svt_hip_memcpy_h2d(hip, w->d_pred[f][p], s->h_pred[f][p], s->plane_bytes[p]));
+        }
+        if (s->n_jobs[f] && ret == EB_ErrorNone) {   /* hook "tf_subpel": sub-pel searches + prediction of this frame's blocks, on the device */
+            if ((size_t)s->n_jobs[f] != nblk) { ret = EB_ErrorUndefined; break; }   /* every block of the segment visits every frame once */
+            ret = tf_subpel_frame(hip, s, f, c, d_src, sstride, bd);
+            w->blocks_on_device[f] = 1;
+            n_subpel++;
+        }
     }
     if (ret == EB_ErrorNone)
         ret = svt_hip_tf_flush_picture(hip, w, c, s->is_highbd, bd, d_src, sstride, d_src, sstride, s->ss_x, s->ss_y, noise_levels, s->decay_control, filtered_sse,
@@ -170,6 +256,10 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     if (ret != EB_ErrorNone) SVT_LOG("temporal filter segment on the device failed (%s): C loop for this segment\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock();
     svt_hip_hooks_log("tf: segment of %d x %d blocks, %d frames, one launch", w->blk_cols, w->blk_rows, w->n_frames);
+    if (n_subpel) {
+        svt_hip_hooks_log("tf_subpel: sub-pel searches and prediction of %d window frames on the device, %d blocks each (no predictor upload)", n_subpel, (int)nblk);
+        svt_hip_hooks_count(SVT_HIP_HOOK_TF_SUBPEL, ret == EB_ErrorNone);
+    }
     svt_hip_hooks_count(SVT_HIP_HOOK_TF, ret == EB_ErrorNone);
     return ret;
 }

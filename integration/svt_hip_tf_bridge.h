@@ -30,6 +30,7 @@ typedef struct SvtHipTfWindow {
     void          *d_pred[SVT_HIP_TF_MAX_REFS][3]; /* predictor pictures (device), same geometry as the central picture */
     int            pred_stride[3];
     uint64_t      *d_sse;                          /* filtered_sse, filtered_sse_uv */
+    uint8_t        blocks_on_device[SVT_HIP_TF_MAX_REFS]; /* d_blocks[f] was written by svt_hip_tf_subpel_frame_dev: h_blocks[f] is not uploaded */
 } SvtHipTfWindow;
 
 EbErrorType svt_hip_tf_window_ctor(SvtHipCtx *hip, SvtHipTfWindow *w, int n_frames, int index_center, int width, int height, int is_16bit, int ss_x, int ss_y);
@@ -56,6 +57,14 @@ typedef struct SvtHipTfSeg SvtHipTfSeg;
 SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0, uint32_t col1, uint32_t row0, uint32_t row1, int is_highbd, int ss_x, int ss_y);
 void         svt_hip_tf_seg_block(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *context_ptr, EbByte *pred,
                                   uint16_t **pred_16bit, const uint32_t *stride_pred, int decay_control);
+/* hook "tf_subpel", right after the motion search of (frame, block) — motion_estimate_sb or the last pass of the batched search: 1 = recorded, the caller skips
+ * tf_32x32_sub_pel_search, tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag and tf_inter_prediction (EbTemporalFiltering.c:2272-2315), which then run
+ * on the device inside svt_hip_tf_seg_flush — one svt_hip_tf_subpel_frame_dev launch per window frame — and leave predictor and TF fields where the filter
+ * launch reads them; 0 = hook off / not 4:2:0: the caller runs them as before.  pcs_ref / pic_ref: list_picture_control_set_ptr / list_input_picture_ptr
+ * [frame_index]. */
+int          svt_hip_tf_seg_subpel(SvtHipTfSeg *s, int frame_index, uint32_t blk_row, uint32_t blk_col, const MeContext *context_ptr,
+                                   const PictureParentControlSet *pcs_central, const PictureParentControlSet *pcs_ref, const EbPictureBufferDesc *pic_ref,
+                                   uint32_t sb_origin_x, uint32_t sb_origin_y);
 /* src_start / src16_start: the central picture's planes at sample (0, 0) (8-bit planes, or altref_buffer_highbd), stride[] in samples */
 EbErrorType  svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *context_ptr, EbByte *src_start, uint16_t **src16_start, const uint32_t *stride, int bd,
                                   const double *noise_levels, uint64_t *filtered_sse, uint64_t *filtered_sse_uv);

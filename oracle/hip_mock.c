@@ -195,6 +195,18 @@ int svt_hip_tf_filter_frame_dev(SvtHipCtx *c, int pix_bytes, int bd, const void 
     return SVT_HIP_OK;
 }
 
+int svt_hip_tf_subpel_frame_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *const src[3], const int src_stride[3], const void *const ref[3],
+                                const int ref_stride[3], void *const pred[3], const int pred_stride[3], int mi_cols, int mi_rows, uint64_t th16, int tf_hp,
+                                int tf_chroma, const SvtHipTfSubpelBlk *jobs, int n_jobs, SvtHipTfBlk64 *blocks) {
+    (void)c;
+    orc_tf_subpel_frame(pix_bytes, bd, src, src_stride, ref, ref_stride, pred, pred_stride, mi_cols, mi_rows, th16, tf_hp, tf_chroma, jobs, n_jobs, (OrcTfBlk64 *)blocks);
+    if (perturb("tf_subpel") && n_jobs > 0) {   /* a visibly wrong predictor block and error */
+        blocks[jobs[0].blk_index].err32[0] += 4096;
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16 * pix_bytes; x++) ((uint8_t *)pred[0])[((size_t)(jobs[0].dst_y + 8 + y) * pred_stride[0] + jobs[0].dst_x + 8) * pix_bytes + x] ^= 0x10;
+    }
+    return SVT_HIP_OK;
+}
+
 int svt_hip_tf_estimate_noise_dev(SvtHipCtx *c, const void *src, int pix_bytes, int bd, int width, int height, int stride, int64_t *out) {
     (void)c;
     orc_tf_estimate_noise(src, pix_bytes, bd, width, height, stride, out);

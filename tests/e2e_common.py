@@ -14,7 +14,7 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 APP_REF = os.path.join(REFDIR, "SvtAv1EncApp_ref")
 APP_HIP = os.path.join(REFDIR, "SvtAv1EncApp_hip")
 MOCK_DIR = os.path.join(REFDIR, "mock")
-HOOKS = ["pa", "tf", "tf_me", "hme", "me", "cdef_finish", "dlf", "dlf_search", "cdef_search", "cdef_apply", "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search"]
+HOOKS = ["pa", "tf", "tf_me", "tf_subpel", "hme", "me", "cdef_finish", "dlf", "dlf_search", "cdef_search", "cdef_apply", "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search"]
 OPT_IN_HOOKS = ["md_tx"]   # not selected by SVT_HIP_HOOKS=all: named explicitly (one launch per transform block of every mode-decision candidate)
 # wiener_search hooks the whole Wiener search of a picture and takes precedence over the two hooks of the per-unit path
 PER_UNIT_WIENER = {"wiener_stats", "wiener_try"}

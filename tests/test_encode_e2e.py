@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not E.have_apps(), reason="oracle/_ref/SvtAv1Enc
 # name: (w, h, frames, bit depth, preset, qp, hooks that must have run)
 ALL = set(E.HOOKS) - E.PER_UNIT_WIENER   # SVT_HIP_HOOKS=all: the picture-level Wiener search takes the place of the per-unit hooks
 ALL_UNIT = set(E.HOOKS) - {"wiener_search"}
-NO_DLF_REST = {"pa", "tf", "tf_me", "hme", "me", "cdef_finish", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
+NO_DLF_REST = {"pa", "tf", "tf_me", "tf_subpel", "hme", "me", "cdef_finish", "cdef_search", "cdef_apply"}        # presets > M6: deblocking inside EncDec (loop_filter_mode 1), restoration off
 CASES = {
     "cif_8bit_m6": (352, 288, 8, 8, 6, 35, ALL),
     "cif_10bit_m6": (352, 288, 6, 10, 6, 30, ALL),
@@ -34,7 +34,7 @@ GPU_ONLY_CASES = {
     "cif_10bit_q60": (352, 288, 4, 10, 6, 60, ALL),           # strongest filtering
     "cif_8bit_18_frames": (352, 288, 18, 8, 6, 42, ALL),      # more than one mini-GOP
     "cif_8bit_m2": (352, 288, 4, 8, 2, 40, ALL),              # slow presets: several reference pictures per list in ME, wider searches
-    "qcif_8bit_m0": (176, 144, 3, 8, 0, 40, ALL - {"tf_me"}), # 3 frames: the alt-ref filter has a single neighbour pair, its ME batch stays empty
+    "qcif_8bit_m0": (176, 144, 3, 8, 0, 40, ALL - {"tf_me", "tf_subpel"}), # 3 frames: the alt-ref filter has a single neighbour pair, its ME batch stays empty
 }
 
 
@@ -234,13 +234,13 @@ def _check_padded_size(workdir, env, tag):
     only up to the unpadded extent (EbDeblockingFilter.c:343-367), searches CDEF and the filter level on the coded size, and runs the restoration
     search and filter on the cropped frame, whose 3-sample extension overwrites coded samples (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251;
     svt_extend_frame, EbCdefProcess.c:552-572).  Every loop-filter hook takes such pictures."""
-    return _check_geometry("padded", 130, 66, 5, 8, 6, 38, 11, workdir, env, tag, must=ALL - {"tf_me"})   # the alt-ref window of so small a picture is the central frame alone
+    return _check_geometry("padded", 130, 66, 5, 8, 6, 38, 11, workdir, env, tag, must=ALL - {"tf_me", "tf_subpel"})   # the alt-ref window of so small a picture is the central frame alone
 
 
 def _check_padded_size_64(workdir, env, tag):
     """a padded size whose coded size IS a multiple of the superblock size (186 x 122 -> 192 x 128): the reference's crop test never fires and the
     padding is deblocked like picture content (the quirk svt_hip_dlf_filtered_units restates); restoration still works on the cropped 186 x 122"""
-    return _check_geometry("padded64", 186, 122, 4, 10, 6, 34, 19, workdir, env, tag, must=ALL - {"tf_me"})   # the alt-ref window of so small a picture is the central frame alone
+    return _check_geometry("padded64", 186, 122, 4, 10, 6, 34, 19, workdir, env, tag, must=ALL - {"tf_me", "tf_subpel"})   # the alt-ref window of so small a picture is the central frame alone
 
 
 def test_padded_source_size_on_cpu_test_double(workdir):
@@ -316,8 +316,9 @@ def test_hooked_encode_on_gpu(case, workdir):
 def test_single_hook_on_gpu(hook, workdir):
     """Each hook alone (the others on the C path): a mismatch bisects to a stage."""
     case = "cif_8bit_m6"
-    spec = CASES[case][:6] + ({hook},)
-    _check(case, spec, workdir, {"SVT_HIP_HOOKS": hook}, "hip_" + hook)
+    hooks = {hook, "tf"} if hook == "tf_subpel" else {hook}   # the sub-pel stage leaves its predictors on the device for hook "tf": it needs it
+    spec = CASES[case][:6] + (hooks,)
+    _check(case, spec, workdir, {"SVT_HIP_HOOKS": ",".join(sorted(hooks))}, "hip_" + hook)
 
 
 # Dispatch-table entries that hand SOME of their calls to the saved C pointer in the encodes below, and why (everything else must stay on the device):
@@ -327,6 +328,7 @@ EXPECTED_DELEGATIONS = {
     "helpers": set(),
     "hbd": set(),
     "both": set(),
+    "subpel": set(),
 }
 
 
@@ -423,6 +425,33 @@ def test_high_bit_depth_pointers_in_a_real_encode_on_gpu(workdir):
     _check_delegations(got, EXPECTED_DELEGATIONS["hbd"], "hbd")
 
 
+BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128),
+               (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+@pytest.mark.gpu
+def test_subpel_search_pointers_in_a_real_encode_on_gpu(workdir):
+    """the sub-pel search trees (md_subpel_search -> svt_av1_find_best_sub_pixel_tree, Encoder/Codec/mcomp.c:350; the temporal filter's rounds) are
+    host control flow of the reference; every kernel they evaluate a candidate with -- svt_aom_upsampled_pred, svt_aom_variance{W}x{H}, svt_aom_sad{W}x{H} and
+    its x4d form (through mefn_ptr[], which is built from these pointers), the four *_sr convolves behind av1_inter_prediction -- runs on the device here,
+    inside a real encode, one launch per call.  Bitstream and reconstruction must not change, and the wrappers must really have been called."""
+    w, h, n, bd, preset, q = 176, 144, 3, 8, 4, 36
+    clip = os.path.join(workdir, "qcif_sp.yuv")
+    E.make_clip(clip, w, h, n, seed=31, bd=bd)
+    fam = [f"svt_aom_variance{a}x{b}" for a, b in BLOCK_SIZES] + [f"svt_aom_sad{a}x{b}" for a, b in BLOCK_SIZES] + [f"svt_aom_sad{a}x{b}x4d" for a, b in BLOCK_SIZES]
+    names = ",".join(["svt_aom_upsampled_pred", "svt_av1_convolve_2d_sr", "svt_av1_convolve_x_sr", "svt_av1_convolve_y_sr", "svt_av1_convolve_2d_copy_sr"] + fam)
+    ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif_sp.ref"))
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif_sp.rtcd"), env_extra={"SVT_HIP_RTCD": names}, timeout=2400)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    for nme in names.split(","):
+        assert f"svt_hip_rtcd {nme} -> hip wrapper" in got["log"], nme
+    calls = got["rtcd_calls"]
+    print("sub-pel pointers, calls per wrapper:", {k: v for k, v in sorted(calls.items())})
+    assert any("upsampled_pred" in k and v > 0 for k, v in calls.items()), calls
+    assert any("var" in k and v > 0 for k, v in calls.items()) and any("conv" in k and v > 0 for k, v in calls.items()), calls
+    _check_delegations(got, EXPECTED_DELEGATIONS["subpel"], "subpel")
+
+
 @pytest.mark.gpu
 def test_hooks_and_wrappers_together_10bit_on_gpu(workdir):
     """SVT_HIP_HOOKS and SVT_HIP_RTCD in one 10-bit encode: the picture-level hooks (one context behind the hooks' lock) and per-call wrappers that use
@@ -433,7 +462,7 @@ def test_hooks_and_wrappers_together_10bit_on_gpu(workdir):
     E.make_clip(clip, w, h, n, seed=21, bd=bd)
     names = "svt_av1_compute_stats_highbd,svt_av1_selfguided_restoration,svt_apply_selfguided_restoration,svt_aom_highbd_quantize_b,svt_residual_kernel16bit"
     ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10b.ref"))
-    hooks = "pa,tf,tf_me,hme,me,cdef_finish,dlf,dlf_search,cdef_search,cdef_apply,sgr_search,rest_apply"   # the Wiener search stays the reference's loop: it calls svt_av1_compute_stats_highbd
+    hooks = "pa,tf,tf_me,tf_subpel,hme,me,cdef_finish,dlf,dlf_search,cdef_search,cdef_apply,sgr_search,rest_apply"   # the Wiener search stays the reference's loop: it calls svt_av1_compute_stats_highbd
     got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, "qcif10b.both"), env_extra={"SVT_HIP_HOOKS": hooks, "SVT_HIP_RTCD": names}, timeout=1500)
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
     assert all(v[1] == 0 for v in got["hooks"].values()) and sum(v[0] for v in got["hooks"].values()) > 10, got["hooks"]
