@@ -29,12 +29,18 @@ class Patch:
         self.edits.append((pattern, repl, flags))
         return self
 
+    def sub_n(self, pattern, repl, n, flags=re.S):
+        """regex with exactly n matches, all replaced (repl may be a function of the match)"""
+        self.edits.append((pattern, repl, flags, n))
+        return self
+
     def apply(self, text):
-        for pattern, repl, flags in self.edits:
+        for pattern, repl, flags, *rest in self.edits:
+            want = rest[0] if rest else 1
             found = re.findall(pattern, text, flags)
-            if len(found) != 1:
-                raise SystemExit(f"{self.rel}: anchor {pattern!r} matched {len(found)} times (expected 1)")
-            text = re.sub(pattern, repl, text, count=1, flags=flags)
+            if len(found) != want:
+                raise SystemExit(f"{self.rel}: anchor {pattern!r} matched {len(found)} times (expected {want})")
+            text = re.sub(pattern, repl, text, count=want, flags=flags)
         return text
 
 
@@ -163,6 +169,28 @@ mdtx.sub(r'(\n        // Y: T Q i_q\n)(        av1_estimate_transform\(\n       
          r'\1        if (!svt_hip_hook_md_tx_fetch(tx_size, tx_type, &(((int32_t *)context_ptr->trans_quant_buffers_ptr->txb_trans_coeff2_nx2_n_ptr->buffer_y)[context_ptr->txb_1d_offset])))\n\2\3')
 mdtx.sub(r'(\n    context_ptr->md_staging_spatial_sse_full_loop_level = default_md_staging_spatial_sse_full_loop;\n    //  Best Tx Type Pass\n)', r'\n    svt_hip_hook_md_tx_end();\1')
 PATCHES.append(mdtx)
+
+# ---------------------------------------------------------------------------------------------------------------- encode pass: inter blocks
+# av1_encode_decode (:1987): before the transform loops of an inter-coded block (:2997) every forward transform of the block is computed in one launch
+# (svt_hip_md_bridge.c, hook "encdec_tx"); the six av1_estimate_transform calls of av1_encode_loop / av1_encode_loop_16bit (:379, :533, :585, :760, :913, :965) read
+# the cached coefficients; the cache is dropped after the second loop (:3560).
+ed = Patch("Source/Lib/Encoder/Codec/EbCodingLoop.c")
+ed.sub(r'(\n[ \t]*// Transform Loop\n[ \t]*context_ptr->md_context->md_local_blk_unit\[context_ptr->blk_geom->blkidx_mds\]\.y_has_coeff\[0\] = EB_FALSE;)',
+       r'\n                    svt_hip_hook_encdec_tx_begin(context_ptr, recon_buffer, is_16bit);\1')
+ed.sub(r'(\n[ \t]*// Force Skip if MergeFlag == TRUE && RootCbf == 0\n)', r'\n                    svt_hip_hook_encdec_tx_end();\1')
+
+
+def _ed_fetch(m):
+    plane = {"y": 0, "cb": 1, "cr": 2}[m.group(3)]
+    return (f"{m.group(1)}if (!svt_hip_hook_encdec_tx_fetch({plane}, context_ptr->txb_itr, {m.group(5)}, {m.group(7)}, {m.group(4)}))"
+            f"{m.group(1)}    {m.group(2)}")
+
+
+ed.sub_n(r'(\n[ \t]*)(av1_estimate_transform\(\s*\(\(int16_t \*\)residual16bit->buffer_(y|cb|cr)\) \+ scratch_\w+,\s*residual16bit->stride_\w+,\s*'
+         r'(\(\(TranLow \*\)transform16bit->buffer_\w+\) \+ [\w>\-]+),\s*NOT_USED_VALUE,\s*'
+         r'(context_ptr->blk_geom->txsize\w*\[blk_ptr->tx_depth\]\[context_ptr->txb_itr\]),\s*&context_ptr->three_quad_energy,\s*(EB_8BIT|bit_depth),\s*'
+         r'(txb_ptr->transform_type\[PLANE_TYPE_\w+\]),\s*PLANE_TYPE_\w+,\s*context_ptr->md_context->pf_ctrls\.pf_shape\);)', _ed_fetch, 6)
+PATCHES.append(ed)
 
 # ---------------------------------------------------------------------------------------------------------------- picture analysis
 # the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)

@@ -12,8 +12,8 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel"};
-static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1};   /* not selected by "all": must be named */
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel", "encdec_tx"};
+static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1, [SVT_HIP_HOOK_ENCDEC_TX] = 1};   /* not selected by "all": must be named */
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;
@@ -76,6 +76,11 @@ void svt_hip_hooks_count(int which, int handled) {
 void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
+    if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
+        long blocks, calls;
+        svt_hip_hook_encdec_tx_stats(&blocks, &calls);
+        fprintf(stderr, "svt_hip_encdec_tx inter_blocks=%ld estimate_transform_calls_replaced=%ld\n", blocks, calls);
+    }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }
 

@@ -48,6 +48,9 @@ enum {
     SVT_HIP_HOOK_TF_SUBPEL,    /* the temporal filter's sub-pel stage: tf_32x32 / tf_16x16_sub_pel_search, derive_tf_32x32_block_split_flag and tf_inter_prediction of every
                                 * (block, frame) pair of a TF segment, one launch per window frame (EbTemporalFiltering.c:2272-2315); the predictors stay on the device for
                                 * hook "tf", which it needs (without "tf" the reference's C code runs) */
+    SVT_HIP_HOOK_ENCDEC_TX,    /* encode pass: the forward transforms of every transform block (luma + chroma) of an inter-coded block in one launch, ahead of the block's
+                                * transform loops (av1_encode_decode, EbCodingLoop.c:2997-3560; av1_encode_loop's av1_estimate_transform calls :379, :533, :585 read the
+                                * results).  Opt-in like md_tx: a launch per coded block */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -139,6 +142,11 @@ int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t sta
                              int32_t *uv_strength, int32_t *selected);
 
 /* ------------------------------------------------------------------ mode decision (svt_hip_md_bridge.c): tx_type_search's forward transforms, one launch per block */
+struct EncDecContext;
+int  svt_hip_hook_encdec_tx_begin(struct EncDecContext *ctx, const EbPictureBufferDesc *pred, int is_16bit);
+int  svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff);
+void svt_hip_hook_encdec_tx_end(void);
+void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls);
 int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);
 int  svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff);
 void svt_hip_hook_md_tx_end(void);

@@ -76,3 +76,139 @@ int svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff) {
     return 1;
 }
 void svt_hip_hook_md_tx_end(void) { tls_tx.valid = 0; }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Encode pass, hook "encdec_tx": the forward transforms of EVERY transform block of one inter-coded block — luma and both chroma planes, all
+ * transform blocks of the block's depth — in one launch, before the block's transform loops run (av1_encode_decode, EbCodingLoop.c:2997-3560, whose
+ * av1_encode_loop / av1_encode_loop_16bit calls :3069, :3393 do residual -> av1_estimate_transform -> av1_quantize_inv_quantize per transform block, :379-596 /
+ * :760-975).  The prediction of an inter block is complete before its first transform block and the reconstruction of one transform block never touches the
+ * samples of another, so every residual is known up front; quantisation (RDOQ, entropy contexts) stays the reference's, block by block.  A transform block
+ * whose luma ends up without coefficients switches its type to DCT_DCT (luma in the second loop, chroma right away, :441-449), so both the chosen type and
+ * DCT_DCT are computed where they differ.  Transform blocks with a 64-sample side keep the reference's call (they come with the discarded-energy sum and a
+ * re-packed layout); the cache is keyed by (plane, transform block, size, type) and dropped at the end of the block. */
+#include "EbEncDecProcess.h"
+#include "EbCodingUnit.h"
+
+#define ED_MAX_JOBS (3 * MAX_TXB_COUNT * 2)
+#define ED_MAX_COEFF (128 * 128 * 3)   /* a 128x128 block, luma + chroma, both types: well below this with sides <= 32 */
+static __thread struct {
+    int      valid, n;
+    struct { int8_t plane, txb, tx_size, tx_type; int32_t off, count; } e[ED_MAX_JOBS];
+    int32_t  coeff[ED_MAX_COEFF];
+} tls_ed;
+static void *d_ed_src, *d_ed_pred, *d_ed_desc, *d_ed_coeff;   /* shared staging, hooks lock held */
+static long  g_ed_blocks, g_ed_tx;                            /* inter blocks batched / av1_estimate_transform calls they replaced (svt_hip_hooks_report) */
+
+void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls) { *blocks = g_ed_blocks; *calls = g_ed_tx; }
+
+int svt_hip_hook_encdec_tx_begin(EncDecContext *ctx, const EbPictureBufferDesc *pred, int is_16bit) {
+    tls_ed.valid = 0;
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ENCDEC_TX)) return 0;
+    const BlkStruct *blk = ctx->blk_ptr;
+    const BlockGeom *g = ctx->blk_geom;
+    const int        d = blk->tx_depth, tot = g->txb_count[d], is_inter = 1;
+    /* the residual of every transform block, as the encode loops form it (8-bit: input picture vs the prediction in the reconstruction buffer, :315-338;
+     * 16-bit: the superblock's 16-bit input buffer, :677-700), split into two non-negative planes for the batched entry point (src - pred) */
+    static __thread uint16_t hs[ED_MAX_COEFF / 2], hp[ED_MAX_COEFF / 2];
+    uint32_t desc[ED_MAX_JOBS];
+    SvtHipFwdTxJob jobs[ED_MAX_JOBS];
+    int      n = 0, n_pix = 0, n_coeff = 0;
+    for (int t = 0; t < tot; t++) {
+        const int uv_pass = d && t ? 0 : 1;
+        const uint32_t ox = ctx->blk_origin_x + g->tx_org_x[is_inter][d][t] - g->origin_x, oy = ctx->blk_origin_y + g->tx_org_y[is_inter][d][t] - g->origin_y;
+        const uint32_t rx = (ox >> 3) << 3, ry = (oy >> 3) << 3;
+        for (int p = 0; p < ((g->has_uv && uv_pass) ? 3 : 1); p++) {
+            const int w = p ? g->tx_width_uv[d][t] : g->tx_width[d][t], h = p ? g->tx_height_uv[d][t] : g->tx_height[d][t];
+            const int tx_size = p ? g->txsize_uv[d][t] : g->txsize[d][t];
+            if (w > 32 || h > 32) continue;
+            if (n_pix + w * h > ED_MAX_COEFF / 2) return 0;
+            /* sample (x, y) of source and prediction */
+            uint16_t *ps = hs + n_pix, *pp = hp + n_pix;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int s, q;
+                    if (!is_16bit) {
+                        const EbPictureBufferDesc *in = ctx->input_samples;
+                        if (p == 0) {
+                            s = in->buffer_y[(size_t)(oy + in->origin_y + y) * in->stride_y + ox + in->origin_x + x];
+                            q = pred->buffer_y[(size_t)(pred->origin_y + oy + y) * pred->stride_y + pred->origin_x + ox + x];
+                        } else {
+                            const uint8_t *ib = p == 1 ? in->buffer_cb : in->buffer_cr, *pb = p == 1 ? pred->buffer_cb : pred->buffer_cr;
+                            const uint32_t is = p == 1 ? in->stride_cb : in->stride_cr, pst = p == 1 ? pred->stride_cb : pred->stride_cr;
+                            s = ib[(size_t)(((ry + in->origin_y) >> 1) + y) * is + ((rx + in->origin_x) >> 1) + x];
+                            q = pb[(size_t)(((pred->origin_y + ry) >> 1) + y) * pst + ((pred->origin_x + rx) >> 1) + x];
+                        }
+                    } else {
+                        const EbPictureBufferDesc *in = ctx->input_sample16bit_buffer;
+                        const uint32_t tx = g->tx_org_x[is_inter][d][t], ty = g->tx_org_y[is_inter][d][t];
+                        if (p == 0) {
+                            s = ((const uint16_t *)in->buffer_y)[(size_t)(ty + y) * in->stride_y + tx + x];
+                            q = ((const uint16_t *)pred->buffer_y)[(size_t)(pred->origin_y + oy + y) * pred->stride_y + pred->origin_x + ox + x];
+                        } else {
+                            const uint16_t *ib = (const uint16_t *)(p == 1 ? in->buffer_cb : in->buffer_cr), *pb = (const uint16_t *)(p == 1 ? pred->buffer_cb : pred->buffer_cr);
+                            const uint32_t is = p == 1 ? in->stride_cb : in->stride_cr, pst = p == 1 ? pred->stride_cb : pred->stride_cr;
+                            s = ib[(size_t)(ROUND_UV(ty) / 2 + y) * is + ROUND_UV(tx) / 2 + x];
+                            q = pb[(size_t)(((pred->origin_y + ry) >> 1) + y) * pst + ((pred->origin_x + rx) >> 1) + x];
+                        }
+                    }
+                    ps[y * w + x] = (uint16_t)s; pp[y * w + x] = (uint16_t)q;
+                }
+            const int type0 = blk->txb_array[t].transform_type[p ? PLANE_TYPE_UV : PLANE_TYPE_Y];
+            for (int k = 0; k < 2; k++) {
+                const int type = k ? DCT_DCT : type0;
+                if (k && type0 == DCT_DCT) break;
+                if (n >= ED_MAX_JOBS || n_coeff + w * h > ED_MAX_COEFF) return 0;
+                tls_ed.e[n].plane = (int8_t)p; tls_ed.e[n].txb = (int8_t)t; tls_ed.e[n].tx_size = (int8_t)tx_size; tls_ed.e[n].tx_type = (int8_t)type;
+                tls_ed.e[n].off = n_coeff; tls_ed.e[n].count = w * h;
+                desc[n] = SVT_HIP_TX_DESC(0, 0, type);
+                memset(&jobs[n], 0, sizeof(jobs[n]));
+                jobs[n].tx_size = tx_size; jobs[n].nblk = 1; jobs[n].src_stride = w; jobs[n].pred_stride = w;
+                jobs[n].d_src = (const void *)(size_t)n_pix;      /* offsets for now: the device base is added under the lock */
+                jobs[n].d_coeff = (int32_t *)(size_t)n_coeff;
+                jobs[n].qp.coeff_shape = ctx->md_context->pf_ctrls.pf_shape;
+                n++; n_coeff += w * h;
+            }
+            n_pix += w * h;
+        }
+    }
+    if (!n) return 0;
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return 0;
+    int rc = SVT_HIP_OK;
+    if (!d_ed_src) {
+        rc = svt_hip_malloc(hip, &d_ed_src, sizeof(hs));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_pred, sizeof(hp));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_desc, sizeof(desc));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_coeff, sizeof(tls_ed.coeff));
+        if (rc != SVT_HIP_OK) { svt_hip_free(hip, d_ed_src); svt_hip_free(hip, d_ed_pred); svt_hip_free(hip, d_ed_desc); svt_hip_free(hip, d_ed_coeff); d_ed_src = d_ed_pred = d_ed_desc = d_ed_coeff = NULL; }
+    }
+    for (int i = 0; i < n && rc == SVT_HIP_OK; i++) {
+        const size_t po = (size_t)jobs[i].d_src, co = (size_t)jobs[i].d_coeff;
+        jobs[i].d_src = (const uint16_t *)d_ed_src + po; jobs[i].d_pred = (const uint16_t *)d_ed_pred + po;
+        jobs[i].d_descs = (const uint32_t *)d_ed_desc + i; jobs[i].d_coeff = (int32_t *)d_ed_coeff + co;
+    }
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_src, hs, sizeof(uint16_t) * (size_t)n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_pred, hp, sizeof(uint16_t) * (size_t)n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_desc, desc, sizeof(uint32_t) * (size_t)n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_fwd_txfm_quant_multi_dev(hip, 2, jobs, n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, tls_ed.coeff, d_ed_coeff, sizeof(int32_t) * (size_t)n_coeff);
+    if (rc == SVT_HIP_OK) g_ed_blocks++;
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_ENCDEC_TX, rc == SVT_HIP_OK);
+    if (rc != SVT_HIP_OK) return 0;
+    tls_ed.n = n; tls_ed.valid = 1;
+    return 1;
+}
+
+/* av1_estimate_transform of transform block `txb` of plane `plane` inside av1_encode_loop[_16bit]: 1 = coeff holds the device result */
+int svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff) {
+    if (!tls_ed.valid) return 0;
+    for (int i = 0; i < tls_ed.n; i++)
+        if (tls_ed.e[i].plane == plane && tls_ed.e[i].txb == txb && tls_ed.e[i].tx_size == tx_size && tls_ed.e[i].tx_type == tx_type) {
+            memcpy(coeff, tls_ed.coeff + tls_ed.e[i].off, sizeof(int32_t) * (size_t)tls_ed.e[i].count);
+            __sync_fetch_and_add(&g_ed_tx, 1);
+            return 1;
+        }
+    return 0;
+}
+void svt_hip_hook_encdec_tx_end(void) { tls_ed.valid = 0; }

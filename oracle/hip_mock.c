@@ -166,6 +166,18 @@ int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx *c, int tx_size, int pix_bytes, c
     return SVT_HIP_OK;
 }
 
+/* the mixed-size form the encode pass's hook "encdec_tx" uses: the job lists one after the other (coefficient-only jobs) */
+int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx *c, int pix_bytes, const SvtHipFwdTxJob *jobs, int njobs) {
+    for (int j = 0; j < njobs; j++) {
+        const SvtHipFwdTxJob *J = &jobs[j];
+        const int rc = svt_hip_fwd_txfm_quant_batch_dev(c, J->tx_size, pix_bytes, J->d_src, J->src_stride, J->d_pred, J->pred_stride, J->d_descs, J->nblk, &J->qp, NULL, J->d_coeff,
+                                                        J->d_qcoeff, J->d_dqcoeff, J->d_eob, J->d_cul_level, J->d_energy);
+        if (rc != SVT_HIP_OK) return rc;
+        if (perturb("encdec_tx") && j == 0) J->d_coeff[0] += 96;
+    }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ picture analysis */
 int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
     (void)c;

@@ -121,6 +121,46 @@ def test_md_tx_hook_matters(workdir):
     assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
 
 
+def _check_encdec_tx(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6")):
+    """hook "encdec_tx" (opt-in): the encode pass takes the forward transforms of every transform block of an inter-coded block from one batched launch; the
+    bitstream must not change, blocks must really have been batched, and the number of av1_estimate_transform calls it replaced is reported"""
+    out = {}
+    for case in cases:
+        got = _check(case, {**CASES, **GPU_ONLY_CASES}[case][:6] + ({"encdec_tx"},), workdir, env, tag + "_" + case)
+        import re
+        m = re.search(r"svt_hip_encdec_tx inter_blocks=(\d+) estimate_transform_calls_replaced=(\d+)", got["log"])
+        assert m, got["log"][-800:]
+        blocks, calls = int(m.group(1)), int(m.group(2))
+        print(f"encdec_tx {case}: {blocks} inter blocks batched, {calls} av1_estimate_transform calls replaced")
+        assert blocks > 50 and calls >= blocks, (blocks, calls)
+        out[case] = got
+    return out
+
+
+def test_encdec_tx_hook_on_cpu_test_double(workdir):
+    _check_encdec_tx(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "encdec_tx"}, "mock_edtx")
+    # together with every picture-level hook and the mode-decision one
+    case = "cif_8bit_m4"
+    both = _check(case, CASES[case][:6] + (ALL | {"md_tx", "encdec_tx"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all,md_tx,encdec_tx"}, "mock_all_edtx")
+    assert both["hooks"]["encdec_tx"][0] > 50
+
+
+def test_encdec_tx_hook_matters(workdir):
+    """a wrong coefficient out of the batched transforms changes the encode: the encode pass really consumes them"""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_edtx"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "encdec_tx", "SVT_HIP_MOCK_PERTURB": "encdec_tx"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+
+
+@pytest.mark.gpu
+def test_encdec_tx_hook_on_gpu(workdir):
+    got = _check_encdec_tx(workdir, {"SVT_HIP_HOOKS": "encdec_tx"}, "hip_edtx", cases=("cif_8bit_m6", "cif_10bit_m6", "cif_8bit_m2"))
+    assert all("svt_hip MOCK" not in g["log"] for g in got.values())
+
+
 @pytest.mark.gpu
 def test_md_tx_type_search_hook_on_gpu(workdir):
     got = _check_md_tx(workdir, {"SVT_HIP_HOOKS": "md_tx"}, "hip_mdtx")
