@@ -1,6 +1,7 @@
 /* svt_hip_hooks.c — see svt_hip_hooks.h: run-time hook selection, the shared device context and its lock, and the per-call dispatch
  * table entries of SVT_HIP_RTCD.  Reference-side glue (C, compiled into libSvtAv1Enc). */
 #include <pthread.h>
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,12 +53,22 @@ static int in_list_exact(const char *list, const char *name) {   /* like in_list
 }
 
 int svt_hip_hook_enabled(int which) { return which >= 0 && which < SVT_HIP_HOOK_COUNT && g_ctx && g_enabled[which]; }
+/* how long process threads waited for the context and how long they held it (nanoseconds; reported at exit: the serial share of the hooks) */
+static long long g_lock_wait_ns, g_lock_held_ns, g_lock_t0, g_lock_n;
+static long long now_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (long long)t.tv_sec * 1000000000ll + t.tv_nsec; }
 SvtHipCtx *svt_hip_hooks_lock(void) {
     if (!g_ctx) return NULL;
+    const long long t0 = now_ns();
     pthread_mutex_lock(&g_lock);
+    g_lock_t0 = now_ns();
+    g_lock_wait_ns += g_lock_t0 - t0;
+    g_lock_n++;
     return g_ctx;
 }
-void svt_hip_hooks_unlock(void) { pthread_mutex_unlock(&g_lock); }
+void svt_hip_hooks_unlock(void) {
+    g_lock_held_ns += now_ns() - g_lock_t0;
+    pthread_mutex_unlock(&g_lock);
+}
 void svt_hip_hooks_log(const char *fmt, ...) {
     if (!g_verbose) return;
     va_list ap;
@@ -76,6 +87,7 @@ void svt_hip_hooks_count(int which, int handled) {
 void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
+    fprintf(stderr, "svt_hip_context locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_lock_n, g_lock_held_ns / 1e6, g_lock_wait_ns / 1e6);
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
         long blocks, calls;
         svt_hip_hook_encdec_tx_stats(&blocks, &calls);

@@ -1,11 +1,16 @@
 #!/bin/bash
-# Run ON THE GPU BOX: wall time of the unpatched reference encoder and of the hooked one (all hooks) on the same synthetic clips -> gpurun_out/enc_wall/
+# Run ON THE GPU BOX: wall time of the reference encoder and of the hooked one (all hooks) on the same synthetic clips -> gpurun_out/enc_wall/
+# Four applications (oracle/Makefile.enc): ref = unpatched reference, C kernels; hip = hooks on the C build; simd = unpatched reference as its x86 build
+# dispatches it (SSE2 .. AVX-512); hip_simd = hooks on the SIMD build.  The hooked ones run twice (the second run has warm module loads).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/enc_wall
 mkdir -p $OUT
 cd $R
+PRESET=${PRESET:-6}
+LP=${LP:-8}
 IFS=, read -ra GEO_LIST <<< "${GEOS:-1280 720 8,1920 1080 8}"   # GEOS="3840 2160 4" for other sizes
+APPS=${APPS:-"ref hip hip simd hip_simd hip_simd"}
 for geo in "${GEO_LIST[@]}"; do
   set -- $geo; W=$1; H=$2; N=$3
   python - $W $H $N <<'PY'
@@ -14,16 +19,23 @@ import e2e_common as E
 w, h, n = map(int, sys.argv[1:4])
 E.make_clip("gpurun_out/enc_wall/clip.yuv", w, h, n, seed=3, bd=8)
 PY
-  ARGS="-i $OUT/clip.yuv -w $W -h $H -n $N --preset 6 --fps 30 -q 36 --lp 8"
-  for app in ref hip hip; do
+  ARGS="-i $OUT/clip.yuv -w $W -h $H -n $N --preset $PRESET --fps 30 -q 36 --lp $LP"
+  for app in $APPS; do
+    [ -x $R/oracle/_ref/SvtAv1EncApp_$app ] || { echo "${W}x${H} $app: not built" | tee -a $OUT/wall.txt; continue; }
     s=$(date +%s.%N)
-    if [ $app = ref ]; then timeout 600 $R/oracle/_ref/SvtAv1EncApp_ref $ARGS -b $OUT/ref.ivf > $OUT/ref_$W.log 2>&1
-    else SVT_HIP_HOOKS=all timeout 600 $R/oracle/_ref/SvtAv1EncApp_hip $ARGS -b $OUT/hip.ivf > $OUT/hip_$W.log 2>&1; fi
+    case $app in
+      ref|simd) timeout 900 $R/oracle/_ref/SvtAv1EncApp_$app $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
+      *) SVT_HIP_HOOKS=${HOOKS:-all} timeout 900 $R/oracle/_ref/SvtAv1EncApp_$app $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
+    esac
     e=$(date +%s.%N)
     log=$OUT/${app}_$W.log
-    echo "${W}x${H} n=$N $app wall_s=$(python -c "print(round($e - $s, 2))") $(grep -h 'Total Encoding Time\|Average Speed' $log | tr -s '\t\n' '  ')" | tee -a $OUT/wall.txt
+    echo "${W}x${H} n=$N preset=$PRESET lp=$LP $app wall_s=$(python -c "print(round($e - $s, 2))") $(grep -h 'Total Encoding Time\|Average Speed' $log | tr -s '\t\n' '  ')" | tee -a $OUT/wall.txt
   done
-  cmp $OUT/ref.ivf $OUT/hip.ivf && echo "${W}x${H} bitstreams identical" | tee -a $OUT/wall.txt
-  grep -h "svt_hip_hook" $OUT/hip_$W.log | awk '{f+=substr($4,10)} END {print "fallbacks:", f}' | tee -a $OUT/wall.txt
-  rm -f $OUT/clip.yuv $OUT/ref.ivf $OUT/hip.ivf
+  for app in hip simd hip_simd; do
+    [ -f $OUT/$app.ivf ] && { cmp -s $OUT/ref.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to ref" || echo "${W}x${H} $app BITSTREAM DIFFERS from ref"; } | tee -a $OUT/wall.txt
+  done
+  for app in hip hip_simd; do
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook" $OUT/${app}_$W.log | awk -v a=$app '{h+=substr($3,9); f+=substr($4,10)} END {print a, "hook launches:", h, "fallbacks:", f}' | tee -a $OUT/wall.txt
+  done
+  rm -f $OUT/clip.yuv $OUT/*.ivf
 done
