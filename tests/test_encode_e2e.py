@@ -465,6 +465,36 @@ def test_high_bit_depth_pointers_in_a_real_encode_on_gpu(workdir):
     _check_delegations(got, EXPECTED_DELEGATIONS["hbd"], "hbd")
 
 
+APP_SIMD, APP_HIP_SIMD = os.path.join(E.REFDIR, "SvtAv1EncApp_simd"), os.path.join(E.REFDIR, "SvtAv1EncApp_hip_simd")
+need_simd = pytest.mark.skipif(not (os.path.exists(APP_SIMD) and os.path.exists(APP_HIP_SIMD)), reason="SIMD-build applications not built (make -f oracle/Makefile.enc simd)")
+
+
+@need_simd
+@pytest.mark.parametrize("case", ["cif_8bit_m6", "cif_10bit_m6", "cif_8bit_m4"])
+def test_simd_build_of_the_reference_and_hooks_on_top_of_it(case, workdir):
+    """The reference as its x86 build dispatches it (SSE2 .. AVX-512 intrinsics, the NASM entry points as C stand-ins of oracle/ref_asm_stubs.c) codes the same
+    bitstream as its C build -- which pins the stand-ins --, and so does the hooked encoder built on top of the SIMD objects (CPU test double): the applications of
+    the wall-clock comparison (tools/encoder_walltime.sh) are the same encoder."""
+    w, h, n, bd, preset, q, must = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    simd = E.encode(APP_SIMD, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".simd"))
+    assert (simd["ivf"], simd["recon"]) == (ref["ivf"], ref["recon"])
+    got = E.encode(APP_HIP_SIMD, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".hipsimd"), env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"})
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    assert all(got["hooks"].get(hk, (0, 0))[0] > 0 and got["hooks"][hk][1] == 0 for hk in must), got["hooks"]
+
+
+@need_simd
+@pytest.mark.gpu
+def test_hooks_on_the_simd_build_on_gpu(workdir):
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, must = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(APP_HIP_SIMD, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".hipsimd_gpu"), env_extra={"SVT_HIP_HOOKS": "all"})
+    assert "svt_hip MOCK" not in got["log"] and (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
+    assert all(got["hooks"].get(hk, (0, 0))[0] > 0 and got["hooks"][hk][1] == 0 for hk in must), got["hooks"]
+
+
 BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128),
                (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
 
