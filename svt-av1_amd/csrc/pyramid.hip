@@ -194,12 +194,8 @@ sad_loop_kernel(const uint8_t* __restrict__ src, int src_stride, const uint8_t* 
 // 16-bit twin of the search above for the high-bit-depth path: sad_16b_kernel (Encoder/C_DEFAULT/EbComputeSAD_C.c:39) over a window, with
 // svt_sad_loop_kernel's candidate order and update rule (first minimum in raster order, initial best 0xffffff).  One workgroup per search:
 // the source block sits in LDS, a lane owns candidates c, c + 256, ...; two samples per v_sad_u16.
-__global__ void __launch_bounds__(256)
-sad_loop16_kernel(const uint16_t* __restrict__ src, int src_stride, const uint16_t* __restrict__ ref, int ref_stride,
-                  const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
-    __shared__ uint16_t s_blk[64 * 64];
-    __shared__ unsigned long long s_best[4];
-    const SvtHipSadLoop d = searches[blockIdx.x];
+__device__ void sad_loop16_generic(uint16_t* __restrict__ s_blk, unsigned long long* __restrict__ s_best, const uint16_t* __restrict__ src, int src_stride,
+                                   const uint16_t* __restrict__ ref, int ref_stride, const SvtHipSadLoop d, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
     const int tid = threadIdx.x;
     unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;
     const int ncand = d.sa_w * d.sa_h, rstep = d.row_step, rows = d.bh / rstep;
@@ -235,6 +231,86 @@ sad_loop16_kernel(const uint16_t* __restrict__ src, int src_stride, const uint16
     }
 }
 
+// The same search for the shapes configs[3] of BASELINE.json asks for (block 16..64 wide in multiples of 16, search area a multiple of 8 wide, every row of
+// the block): the reference window goes through LDS once, in TWO copies -- copy 0 as it lies, copy 1 shifted by one sample -- so that a candidate at an odd
+// column reads its sample pairs as aligned dwords too; a lane owns 8 horizontally adjacent candidates of one candidate row and feeds v_sad_u16 (two samples
+// per instruction) from 128-bit LDS reads: per 8 source pairs 6 reads for 64 SAD instructions.  Keys sad << 32 | candidate index keep the reference's first
+// minimum in raster order.  16.8 M absolute differences per 64x64 / 64x64 search = 131 k wave instructions.
+constexpr int kS16 = 68;   // row stride of a window copy in dwords (272 B: 16-byte aligned rows, consecutive rows 4 banks apart)
+__global__ void __launch_bounds__(256)
+sad_loop16_lds_kernel(const uint16_t* __restrict__ src, int src_stride, const uint16_t* __restrict__ ref, int ref_stride,
+                      const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    __shared__ unsigned long long s_best[4];
+    const SvtHipSadLoop d = searches[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lds_form = d.row_step == 1 && d.bw >= 16 && d.bw <= 64 && (d.bw & 15) == 0 && d.bh >= 1 && d.bh <= 64 && d.sa_w >= 8 && d.sa_w <= 64 && (d.sa_w & 7) == 0 &&
+                          d.sa_h >= 1 && d.sa_h <= 64;
+    if (!lds_form) {   // any other shape (sub-sampled rows, odd widths, large areas): a lane per candidate straight from memory (workgroup-uniform branch)
+        sad_loop16_generic((uint16_t*)s_dyn, s_best, src, src_stride, ref, ref_stride, d, best_sad, best_xy);
+        return;
+    }
+    const int bw = d.bw, bh = d.bh, sa_w = d.sa_w, sa_h = d.sa_h, wr = bh + sa_h - 1, ww = bw + sa_w - 1;
+    uint32_t* __restrict__ s_src = s_dyn;                      // [bh][32] dwords (row stride 32: bw <= 64)
+    uint32_t* __restrict__ s_w0 = s_dyn + 64 * 32;              // [wr][kS16]
+    uint32_t* __restrict__ s_w1 = s_w0 + 127 * kS16;
+    for (int i = tid; i < bh * (bw >> 1); i += 256) {
+        const int y = i / (bw >> 1), x = i - y * (bw >> 1);
+        const uint16_t* p = src + (size_t)(d.src_y + y) * src_stride + d.src_x + 2 * x;
+        s_src[y * 32 + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+    }
+    for (int i = tid; i < wr * 64; i += 256) {   // dword i of a window row: samples 2i, 2i + 1 (copy 0) / 2i + 1, 2i + 2 (copy 1); zero past the window
+        const int y = i >> 6, x = i & 63;
+        const uint16_t* p = ref + (size_t)(d.ref_y + y) * ref_stride + d.ref_x;
+        const uint32_t a = 2 * x < ww ? p[2 * x] : 0u, b = 2 * x + 1 < ww ? p[2 * x + 1] : 0u, c = 2 * x + 2 < ww ? p[2 * x + 2] : 0u;
+        s_w0[y * kS16 + x] = a | (b << 16);
+        s_w1[y * kS16 + x] = b | (c << 16);
+    }
+    __syncthreads();
+    unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;
+    const int g = lane & 7, r = lane >> 3, cx = 8 * g;
+    for (int cy0 = 0; cy0 < sa_h; cy0 += 32) {
+        const int cy = cy0 + 8 * wave + r;
+        if (cx < sa_w && cy < sa_h) {   // sa_w is a multiple of 8: a lane's eight candidates are all inside or all outside
+            uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int y = 0; y < bh; y++) {
+                const uint4* __restrict__ q0 = (const uint4*)(s_w0 + (cy + y) * kS16 + (cx >> 1));
+                const uint4* __restrict__ q1 = (const uint4*)(s_w1 + (cy + y) * kS16 + (cx >> 1));
+                const uint4* __restrict__ qs = (const uint4*)(s_src + y * 32);
+                for (int c = 0; c < (bw >> 4); c++) {   // 8 source pairs (16 samples) at a time
+                    const uint4 a0 = q0[2 * c], a1 = q0[2 * c + 1], a2 = q0[2 * c + 2], b0 = q1[2 * c], b1 = q1[2 * c + 1], b2 = q1[2 * c + 2];
+                    const uint4 s0 = qs[2 * c], s1 = qs[2 * c + 1];
+                    const uint32_t w0[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+                    const uint32_t w1[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                    const uint32_t sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                    for (int p = 0; p < 8; p++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            acc[j] = __builtin_amdgcn_sad_u16((j & 1) ? w1[p + (j >> 1)] : w0[p + (j >> 1)], sv[p], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned long long key = ((unsigned long long)acc[j] << 32) | (uint32_t)(cy * sa_w + cx + j);
+                best = key < best ? key : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long o = shfl_xor64(best, m); best = o < best ? o : best; }
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) best = s_best[w] < best ? s_best[w] : best;
+        const uint32_t sad = (uint32_t)(best >> 32), c = (uint32_t)best;
+        best_sad[blockIdx.x] = sad;
+        if (sad < 0xffffffu && c < (uint32_t)(sa_w * sa_h)) {
+            best_xy[2 * blockIdx.x] = (int16_t)(c % sa_w);
+            best_xy[2 * blockIdx.x + 1] = (int16_t)(c / sa_w);
+        }
+    }
+}
 }  // namespace
 
 extern "C" int svt_hip_launch_downsample(hipStream_t st, const uint8_t* in, int in_stride, int w, int h, uint8_t* out, int out_stride, int step, int filtered) {
@@ -254,8 +330,11 @@ extern "C" int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int s
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sad_loop16(hipStream_t st, const uint16_t* src, int src_stride, const uint16_t* ref, int ref_stride, const SvtHipSadLoop* searches, int n,
-                                         uint32_t* best_sad, int16_t* best_xy) {
+                                             uint32_t* best_sad, int16_t* best_xy) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(sad_loop16_kernel, dim3(n), dim3(256), 0, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
+    constexpr size_t lds = sizeof(uint32_t) * (64 * 32 + 2 * 127 * kS16);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)sad_loop16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    hipLaunchKernelGGL(sad_loop16_lds_kernel, dim3(n), dim3(256), lds, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
     return (int)hipGetLastError();
 }
