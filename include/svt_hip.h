@@ -726,14 +726,15 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse
                                            int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
 /* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once: the chains are independent, one
  * pair of launches per step index advances all that are still running (80 launches instead of 225: slices of the filter blocks into per-slice totals,
- * then the sum over slices and the first minimum -- no atomics on the totals).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
+ * then the sum over slices and the first minimum -- no atomics on the totals; SVT_HIP_CDEF_SELECT=persistent runs the 40 step indices in one resident launch
+ * with grid barriers instead, which measured slower on MI355X).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
  * cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each count and the totals). */
 typedef struct {
     int32_t  lev0[4][8], lev1[4][8]; /* [log2 nb_strengths][pair]: cdef_y_strength / cdef_uv_strength indices */
     uint32_t reserved[4];
     uint64_t tot_mse[4];
 } SvtHipCdefSelectResult;
-#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)4096 + (size_t)4 * 64 * 4096 * 8)   /* + per-slice totals of the four chains */
+#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)8192 + (size_t)4 * 128 * 4096 * 8)   /* + per-slice totals of the four chains */
 int svt_hip_cdef_strength_select_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int start_gi, int end_gi, void *d_state,
                                      size_t state_bytes);
 /* finish_cdef_search after its four searches (EbEncCdef.c:1258-1298): the number of signalled strength pairs by rate-distortion cost

@@ -117,7 +117,7 @@ def tx_desc(x, y, tx_type):
 _lib = None
 
 
-CDEF_SELECT_STATE_BYTES = 304 + 4096 + 4 * 64 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES (include/svt_hip.h)
+CDEF_SELECT_STATE_BYTES = 304 + 8192 + 4 * 128 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES (include/svt_hip.h)
 
 
 def lib():

@@ -18,6 +18,8 @@
 #include <type_traits>
 #include <cstddef>
 #include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
 #include "svt_hip_internal.h"
 
 namespace {
@@ -207,14 +209,16 @@ one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int
 // (joint_step_kernel below).  The workgroup that finishes last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next
 // step is a refinement step and resets the counter; the totals are triple-buffered and every workgroup clears its share of the buffer of step + 2 on the way.
 constexpr int kJointMaxSlices = 64;
+constexpr int kPersistWgs = 128;          // workgroups of the one-launch form (joint_persistent_kernel)
 struct JointState {
     int lev0[4][8], lev1[4][8];
     unsigned int counter[4];
     unsigned long long result[4];          // total of the chain's last step
     unsigned long long max0, max1;         // largest entry of each table (joint_init_kernel)
-    unsigned long long cand_v[4][64];      // per reduce workgroup: its first minimum ...
-    int                cand_i[4][64];      // ... and where
-    unsigned long long partial[4][kJointMaxSlices][4096];   // totals of one slice of the filter blocks, [j][k] with row stride 64
+    unsigned long long cand_v[4][kPersistWgs];   // per reduce workgroup: its first minimum ...
+    int                cand_i[4][kPersistWgs];   // ... and where
+    unsigned int       bar, err;           // one-launch form: arrivals at the grid barrier, "a barrier timed out" flag
+    unsigned long long partial[4][kPersistWgs][4096];   // totals of one slice of the filter blocks, [j][k] with row stride 64 (the two-launch form uses 64 slices of it)
 };
 __global__ void __launch_bounds__(256)
 joint_init_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int n, JointState* __restrict__ S) {
@@ -349,6 +353,169 @@ joint_reduce_kernel(int slices, int start_gi, int ng, int step, JointState* __re
     if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
         for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
     S->counter[c] = 0;
+}
+
+// ---- the same selection in ONE launch (experiment, not the default: see svt_hip_launch_strength_select for what it measured).  The step-by-step form spends its
+// time between launches, not on arithmetic (~60 us of the chip per frame against 0.69 ms).  Here kPersistWgs workgroups of 256 threads stay resident for all 40 step indices: workgroup w keeps ITS
+// slice of the filter blocks (<= 16 of them, both distortion rows) in LDS for the whole selection — the tables are read once —, a thread owns a 4 x 4 tile of
+// strength pairs, and the steps are separated by a grid barrier (arrival counter in the state, agent-scope fences; the spin is bounded and raises `err`
+// instead of hanging).  Per step and running chain: slice totals -> barrier -> every workgroup sums 32 pairs over the slices and posts its first minimum ->
+// barrier -> every workgroup reads the 128 candidates and advances its own copy of the chain's list (no broadcast needed).  256 threads and 17 KB of LDS: eight
+// such workgroups fit a compute unit, so sixteen pictures' selections can be resident at once — the barrier cannot starve for residency.
+__device__ __forceinline__ void grid_barrier(JointState* __restrict__ S, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(&S->bar, 1u);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&S->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // relaxed: an acquire here would invalidate the L2 on every poll
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22) || __hip_atomic_load(&S->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicExch(&S->err, 1u); break; }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+template <typename T>
+__device__ void joint_persistent(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, JointState* __restrict__ S,
+                                 unsigned char* lds) {
+    constexpr int kBlk = 16;
+    T* A = (T*)lds;                 // [kBlk][64]
+    T* B = A + kBlk * 64;           // [kBlk][64]
+    T* best = B + kBlk * 64;        // [4][kBlk]
+    __shared__ int                s_l0[4][8], s_l1[4][8];
+    __shared__ unsigned long long r_v[256];
+    __shared__ int                r_i[4];
+    __shared__ unsigned long long r_w[4];
+    const int tid = threadIdx.x, w = blockIdx.x, C = gridDim.x;
+    const int p0 = (int)((long long)sb_count * w / C), p1 = (int)((long long)sb_count * (w + 1) / C), ns = p1 - p0;   // <= kBlk (the launcher checks)
+    for (int e = tid; e < ns * 64; e += 256) { A[e] = (T)mse0[(size_t)p0 * 64 + e]; B[e] = (T)mse1[(size_t)p0 * 64 + e]; }
+    if (tid < 32) { s_l0[tid >> 3][tid & 7] = 0; s_l1[tid >> 3][tid & 7] = 0; }
+    const int tj = (tid >> 4) * 4, tk = (tid & 15) * 4;
+    int ja[4], ka[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { ja[u] = start_gi + min(tj + u, ng - 1); ka[u] = start_gi + min(tk + u, ng - 1); }
+    const int pairs_per_wg = (4096 + C - 1) / C;   // 32 for 128 workgroups
+    unsigned bar_target = 0;
+    __syncthreads();
+    for (int step = 0; step < 40; step++) {
+        // ---- slice totals of every running chain
+        for (int c = 0; c < 4; c++) {
+            const int nb = 1 << c;
+            if (step >= 5 * nb) continue;
+            const int idx = step < nb ? step : nb - 1;
+            if (tid < ns) {
+                T bm = sizeof(T) == 4 ? (T)0xffffffffu : (T)((unsigned long long)1 << 63);
+                for (int g = 0; g < idx; g++) { const T v = A[tid * 64 + s_l0[c][g]] + B[tid * 64 + s_l1[c][g]]; bm = v < bm ? v : bm; }
+                best[c * kBlk + tid] = bm;
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < 4; c++) {
+            const int nb = 1 << c;
+            if (step >= 5 * nb) continue;
+            T acc[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc[u] = 0;
+            for (int i = 0; i < ns; i++) {
+                const T bb = best[c * kBlk + i];
+                T a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a[u] = A[i * 64 + ja[u]]; b[u] = B[i * 64 + ka[u]]; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const T v = a[u >> 2] + b[u & 3]; acc[u] += v < bb ? v : bb; }
+            }
+            T* out = (T*)&S->partial[c][w][0];   // narrow: 32-bit totals (16 blocks x 2^28 < 2^32), same [j][k] layout
+#pragma unroll
+            for (int u = 0; u < 16; u++) out[(tj + (u >> 2)) * 64 + tk + (u & 3)] = acc[u];
+        }
+        bar_target += (unsigned)C;
+        grid_barrier(S, bar_target);
+        // ---- this workgroup's share of the pairs, summed over the slices; its first minimum
+        for (int c = 0; c < 4; c++) {
+            const int nb = 1 << c;
+            if (step >= 5 * nb) continue;
+            const int q = tid >> 5, pl = tid & 31;   // 8 slice groups x 32 pairs at a time
+            unsigned long long bv = ~0ull;           // lanes 0..31 of wave 0: running first minimum of the pairs they have seen
+            int                bi = 0x7fffffff;
+            for (int base = 0; base < pairs_per_wg; base += 32) {
+                const int  p = w * pairs_per_wg + base + pl;
+                const bool mine = base + pl < pairs_per_wg && p < 4096;
+                unsigned long long v = 0;
+                if (mine) {   // the rows were written by other XCDs: every load is a memory-side round trip, so all sixteen are issued before the first add
+                    T rows[kPersistWgs / 8];
+#pragma unroll
+                    for (int t = 0; t < kPersistWgs / 8; t++) { const int sl = q + 8 * t; rows[t] = sl < C ? ((const T*)&S->partial[c][sl][0])[p] : (T)0; }
+#pragma unroll
+                    for (int t = 0; t < kPersistWgs / 8; t++) v += (unsigned long long)rows[t];
+                }
+                __syncthreads();
+                r_v[tid] = v;
+                __syncthreads();
+                if (tid < 32 && mine) {
+                    const int j = p >> 6, k = p & 63;
+                    if (j < ng && k < ng) {
+                        unsigned long long t = 0;
+#pragma unroll
+                        for (int g = 0; g < 8; g++) t += r_v[pl + 32 * g];
+                        const int ti = j * ng + k;
+                        if (t < bv || (t == bv && ti < bi)) { bv = t; bi = ti; }
+                    }
+                }
+            }
+            if (tid < 64) {
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
+                    const int                oi = __shfl_xor(bi, o);
+                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (tid == 0) { S->cand_v[c][w] = bv; S->cand_i[c][w] = bi; }
+            }
+        }
+        bar_target += (unsigned)C;
+        grid_barrier(S, bar_target);
+        // ---- every workgroup picks the chain's pair from the candidates (first minimum in (j, k) raster order) and advances its copy of the list
+        for (int c = 0; c < 4; c++) {
+            const int nb = 1 << c, total_steps = 5 * nb;
+            if (step >= total_steps) continue;
+            const int idx = step < nb ? step : nb - 1;
+            unsigned long long bv = (unsigned long long)1 << 63;   // "tot < best" with best = 1 << 63 (EbEncCdef.c:1104): nothing below it keeps (0, 0)
+            int                bi = 0x7fffffff;
+            if (tid < C) {
+                const unsigned long long ov = ((const volatile unsigned long long*)S->cand_v[c])[tid];
+                const int                oi = ((const volatile int*)S->cand_i[c])[tid];
+                if (oi != 0x7fffffff && ov < bv) { bv = ov; bi = oi; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
+                const int                oi = __shfl_xor(bi, o);
+                if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((tid & 63) == 0) { r_w[tid >> 6] = bv; r_i[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int x = 1; x < 4; x++)
+                    if (r_w[x] < bv || (r_w[x] == bv && r_i[x] < bi)) { bv = r_w[x]; bi = r_i[x]; }
+                const bool any = bi != 0x7fffffff;
+                s_l0[c][idx] = any ? start_gi + bi / ng : 0;
+                s_l1[c][idx] = any ? start_gi + bi % ng : 0;
+                if (w == 0 && step + 1 == total_steps) {   // the chain is complete: its pairs and total
+                    for (int g = 0; g < 8; g++) { S->lev0[c][g] = s_l0[c][g]; S->lev1[c][g] = s_l1[c][g]; }
+                    S->result[c] = bv;
+                }
+                if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
+                    for (int g = 0; g < nb - 1; g++) { s_l0[c][g] = s_l0[c][g + 1]; s_l1[c][g] = s_l1[c][g + 1]; }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+joint_persistent_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, JointState* __restrict__ S) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[(2 * 16 * 64 + 4 * 16) * 8];
+    const bool narrow = S->max0 < (1ull << 27) && S->max1 < (1ull << 27);
+    if (narrow) joint_persistent<uint32_t>(mse0, mse1, sb_count, start_gi, ng, S, s_tab);
+    else joint_persistent<unsigned long long>(mse0, mse1, sb_count, start_gi, ng, S, s_tab);
 }
 
 // finish_cdef_search after the four searches (EbEncCdef.c:1258-1298): the count of strength pairs by rate-distortion cost, then every filter block's
@@ -660,6 +827,18 @@ extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* ms
     if (hipMemsetAsync(state, 0, offsetof(JointState, partial), st) != hipSuccess) return (int)hipGetLastError();
     if (ng <= 0) return 0;
     if (sb_count > 0) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 64)), dim3(256), 0, st, mse0, mse1, sb_count * 64, (JointState*)state);
+    // SVT_HIP_CDEF_SELECT=persistent selects the one-launch form (pictures of up to 16 filter blocks per workgroup).  Measured on MI355X (4K, 2040 filter blocks):
+    // 1.35 ms against 0.69 ms for the launch-per-step form below — a step costs ~8 memory-side round trips (the workgroups sit on eight XCDs whose L2s are not
+    // coherent: arrival counter, poll, the other slices' totals, the candidates), ~2 us each, which is more than the ~8 us a pair of launches costs; and with
+    // four frames in flight the step is bound by this stage's latency, not by the launch count (bench.py: 12.5 ms against 9.4 ms per four-frame step).  Kept for
+    // A/B runs; the default stays the launch-per-step form.
+    static int form = -1;
+    if (form < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT"); form = e && !strcmp(e, "persistent") ? 1 : 0; }
+    if (form == 1 && sb_count > 0 && sb_count <= 16 * kPersistWgs) {
+        const int wgs = min(kPersistWgs, (sb_count + 15) / 16);
+        hipLaunchKernelGGL(joint_persistent_kernel, dim3(wgs), dim3(256), 0, st, mse0, mse1, sb_count, start_gi, ng, (JointState*)state);
+        return (int)hipGetLastError();
+    }
     static int forced = -1;   // debug: SVT_HIP_CDEF_SELECT_SLICES
     if (forced < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT_SLICES"); forced = e ? atoi(e) : 0; }
     int slices = forced > 0 ? forced : (sb_count + 31) / 32;

@@ -662,6 +662,17 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
         return (int)hipGetLastError();
     }
     dim3 grid(max_units, 16, n_planes);
+    static const bool hyb256 = form_env && !strcmp(form_env, "hybrid256"), hyb256j = form_env && !strcmp(form_env, "hybrid256j");
+    if (hyb256 || hyb256j) {   // experiment: four smaller workgroups per compute unit (one walker + three data waves each)
+        if (hyb256) {
+            if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, 256, kHybJ, kHybNA>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, kHybJ, kHybNA10>), grid, dim3(256), 0, st, a);
+        } else {
+            if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, 256, 9, kHybNA>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, 9, kHybNA10>), grid, dim3(256), 0, st, a);
+        }
+        return (int)hipGetLastError();
+    }
     if (resident_form) {
         if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);
         else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);

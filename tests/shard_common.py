@@ -10,7 +10,7 @@ import numpy as np
 from conftest import ROOT
 
 MOCK_LIB = os.path.join(ROOT, "oracle", "_ref", "mock", "libsvtav1_hip.so")
-STATE_BYTES = 304 + 4096 + 4 * 64 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+STATE_BYTES = 304 + 8192 + 4 * 128 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
 vp, i32 = C.c_void_p, C.c_int32
 P3, I3 = C.c_void_p * 3, C.c_int * 3
 

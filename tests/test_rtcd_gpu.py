@@ -896,7 +896,7 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         if mag == 27: m0[sb_count // 2, 5] = (1 << 27) - 1
         ptrs = (C.c_void_p * 2)(m0.ctypes.data, m1.ctypes.data)
         d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
-        state_bytes = 304 + 4096 + 4 * 64 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+        state_bytes = 304 + 8192 + 4 * 128 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
         d_state = hip.empty(state_bytes)
         hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
         sel = hip.to_host(d_state, (304,), np.uint8)

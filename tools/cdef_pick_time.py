@@ -31,8 +31,8 @@ with torch.cuda.stream(st):
     for _ in range(5): g.replay()
     g1.record(st); torch.cuda.synchronize()
 print(f"the same as one captured HIP graph: {g0.elapsed_time(g1) / 5:.3f} ms per frame")
-d_state = hip.empty(304 + 4096 + 4 * 64 * 4096 * 8)
-def run2(): hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, n, 0, 64, d_state, 304 + 4096 + 4 * 64 * 4096 * 8), "select")
+d_state = hip.empty(304 + 8192 + 4 * 128 * 4096 * 8)
+def run2(): hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, n, 0, 64, d_state, 304 + 8192 + 4 * 128 * 4096 * 8), "select")
 with torch.cuda.stream(st):
     run2(); torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
