@@ -69,6 +69,43 @@ void svt_hip_hooks_unlock(void) {
     g_lock_held_ns += now_ns() - g_lock_t0;
     pthread_mutex_unlock(&g_lock);
 }
+/* The source-side bridges (picture analysis, open-loop ME / HME, the temporal filter) keep no device state between two calls — every call allocates, uploads,
+ * launches, downloads and frees under the lock — so they do not need THE context, only A context: a small pool (SVT_HIP_CONTEXTS, default 4), each with its own
+ * stream, lets the reference's N motion-estimation / TF threads run their segments side by side instead of queueing behind one mutex.  The loop-filter bridge keeps
+ * the main context and its lock: its per-picture state table and the "first segment searches the whole picture" rule rely on that mutual exclusion.  A context is
+ * drained (svt_hip_sync) before it is handed back, so whichever context a later call gets sees the device memory complete. */
+#define SVT_HIP_POOL_MAX 8
+static SvtHipCtx      *g_pool[SVT_HIP_POOL_MAX];
+static pthread_mutex_t g_pool_mu[SVT_HIP_POOL_MAX];
+static int             g_pool_n, g_pool_next;
+static long long       g_pool_wait_ns, g_pool_held_ns, g_pool_locks;
+static __thread int       tls_slot = -1, tls_pref = -1;
+static __thread long long tls_t0;
+SvtHipCtx *svt_hip_hooks_lock_any(void) {
+    if (!g_ctx) return NULL;
+    if (!g_pool_n) { tls_slot = -1; return svt_hip_hooks_lock(); }
+    if (tls_pref < 0) tls_pref = __sync_fetch_and_add(&g_pool_next, 1) % g_pool_n;
+    const long long t0 = now_ns();
+    int got = -1;
+    for (int i = 0; i < g_pool_n && got < 0; i++) {
+        const int k = (tls_pref + i) % g_pool_n;
+        if (pthread_mutex_trylock(&g_pool_mu[k]) == 0) got = k;
+    }
+    if (got < 0) { got = tls_pref; pthread_mutex_lock(&g_pool_mu[got]); }
+    tls_slot = got;
+    tls_t0 = now_ns();
+    __sync_fetch_and_add(&g_pool_wait_ns, tls_t0 - t0);
+    __sync_fetch_and_add(&g_pool_locks, 1);
+    return g_pool[got];
+}
+void svt_hip_hooks_unlock_any(void) {
+    if (tls_slot < 0) { svt_hip_hooks_unlock(); return; }
+    (void)svt_hip_sync(g_pool[tls_slot]);
+    __sync_fetch_and_add(&g_pool_held_ns, now_ns() - tls_t0);
+    const int k = tls_slot;
+    tls_slot = -1;
+    pthread_mutex_unlock(&g_pool_mu[k]);
+}
 void svt_hip_hooks_log(const char *fmt, ...) {
     if (!g_verbose) return;
     va_list ap;
@@ -88,6 +125,8 @@ void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
     fprintf(stderr, "svt_hip_context locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_lock_n, g_lock_held_ns / 1e6, g_lock_wait_ns / 1e6);
+    if (g_pool_n)
+        fprintf(stderr, "svt_hip_context_pool contexts=%d locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_pool_n, g_pool_locks, g_pool_held_ns / 1e6, g_pool_wait_ns / 1e6);
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
         long blocks, calls;
         svt_hip_hook_encdec_tx_stats(&blocks, &calls);
@@ -213,6 +252,16 @@ void svt_hip_hooks_enc_init(int target_socket) {
         SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");
         g_ctx = NULL;
         return;
+    }
+    {   /* the pool of the source-side bridges; 0 = everything on the main context (the round-2 behaviour) */
+        const char *pc = getenv("SVT_HIP_CONTEXTS");
+        int         n = pc ? atoi(pc) : 4;
+        n = n < 0 ? 0 : (n > SVT_HIP_POOL_MAX ? SVT_HIP_POOL_MAX : n);
+        for (int i = 0; i < n; i++) {
+            if (svt_hip_init(device, &g_pool[i]) != SVT_HIP_OK) { g_pool[i] = NULL; break; }
+            pthread_mutex_init(&g_pool_mu[i], NULL);
+            g_pool_n = i + 1;
+        }
     }
     if (rtcd && *rtcd) {
         if (svt_hip_init(device, &g_rtcd_ctx) == SVT_HIP_OK) install_rtcd(rtcd);

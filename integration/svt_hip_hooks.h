@@ -63,6 +63,10 @@ int  svt_hip_hook_enabled(int which);
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
 SvtHipCtx *svt_hip_hooks_lock(void);
 void       svt_hip_hooks_unlock(void);
+/* a context of the pool the source-side bridges share (SVT_HIP_CONTEXTS, default 4; 0 = the main context): for calls that keep no device state between two
+ * calls.  lock_any / unlock_any pair up on one thread; unlock_any drains the context's stream first */
+SvtHipCtx *svt_hip_hooks_lock_any(void);
+void       svt_hip_hooks_unlock_any(void);
 void       svt_hip_hooks_log(const char *fmt, ...);
 /* statistics for the tests: how many times each hook really ran on the device / fell back */
 void svt_hip_hooks_count(int which, int handled);

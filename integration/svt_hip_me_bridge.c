@@ -120,10 +120,10 @@ SvtHipMeBatch *svt_hip_me_batch_begin_tf(int enable_hme, uint32_t n_slots) {
 void svt_hip_me_batch_end(SvtHipMeBatch *b) {
     if (!b) return;
     if (b->d_src || b->d_ref || b->d_job || b->d_sad || b->d_xy) {
-        SvtHipCtx *hip = svt_hip_hooks_lock();
+        SvtHipCtx *hip = svt_hip_hooks_lock_any();
         if (hip) {
             svt_hip_free(hip, b->d_src); svt_hip_free(hip, b->d_ref); svt_hip_free(hip, b->d_job); svt_hip_free(hip, b->d_sad); svt_hip_free(hip, b->d_xy);
-            svt_hip_hooks_unlock();
+            svt_hip_hooks_unlock_any();
         }
     }
     for (int l = 0; l < 3; l++) { free(b->sb_first[l]); free(b->sb_count[l]); free(b->src[l]); }
@@ -176,14 +176,14 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                     b->failed = 1;
                     break;
                 }
-                SvtHipCtx *hip = svt_hip_hooks_lock();
+                SvtHipCtx *hip = svt_hip_hooks_lock_any();
                 int        rc = hip ? svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
                                                                src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x,
                                                                src_padded->origin_y, wins, (int)n, b->sub_sad, sad, mv)
                                     : SVT_HIP_ERR_NO_DEVICE;
                 if (rc != SVT_HIP_OK)
                     SVT_LOG("svt_hip_me_fullpel_frame failed (%s): C search for this segment\n", hip ? svt_hip_last_error(hip) : "no context");
-                if (hip) svt_hip_hooks_unlock();
+                if (hip) svt_hip_hooks_unlock_any();
                 if (rc != SVT_HIP_OK) { b->failed = 1; break; }
                 for (uint32_t k = 0; k < n; k++) {
                     memcpy(&b->best_sad[(s + idx[k]) * SQUARE_PU_COUNT], &sad[(size_t)k * SQUARE_PU_COUNT], SQUARE_PU_COUNT * sizeof(uint32_t));
@@ -280,7 +280,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
     uint32_t      *sel = (uint32_t *)malloc(sizeof(uint32_t) * n_all), *sad = (uint32_t *)malloc(sizeof(uint32_t) * n_all);
     int16_t       *xy = (int16_t *)malloc(sizeof(int16_t) * 2 * n_all);
     uint8_t       *done = (uint8_t *)calloc(n_all, 1);
-    SvtHipCtx     *hip = (jobs && back && sel && sad && xy && done) ? svt_hip_hooks_lock() : NULL;
+    SvtHipCtx     *hip = (jobs && back && sel && sad && xy && done) ? svt_hip_hooks_lock_any() : NULL;
     int            rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
     HME_TRY(dev_need(hip, &b->d_src, &b->d_cap[0], (size_t)b->n0 * 64 * 64 + 64));
     HME_TRY(svt_hip_memcpy_h2d(hip, b->d_src, b->src[level], (size_t)b->n0 * 64 * 64));
@@ -339,7 +339,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         SVT_LOG("hierarchical ME level %d on the device failed (%s): C search for this segment\n", level, hip ? svt_hip_last_error(hip) : "no context");
         b->failed = 1;
     }
-    if (hip) svt_hip_hooks_unlock();
+    if (hip) svt_hip_hooks_unlock_any();
     free(jobs); free(back); free(sel); free(sad); free(xy); free(done);
 }
 

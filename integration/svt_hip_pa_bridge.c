@@ -27,7 +27,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     const int do_q = hme && lvl1, do_s = filtered ? (hme && lvl0) : 1;
     if (!do_q && !do_s) return EB_ErrorNone;
     const int  w = padded->width, h = padded->height;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return EB_ErrorUndefined;
     void *d_in = NULL, *d_q = NULL, *d_s = NULL;
     int   rc = svt_hip_malloc(hip, &d_in, (size_t)w * h);
@@ -50,7 +50,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     }
     svt_hip_free(hip, d_in); svt_hip_free(hip, d_q); svt_hip_free(hip, d_s);
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
-    svt_hip_hooks_unlock();
+    svt_hip_hooks_unlock_any();
     svt_hip_hooks_count(SVT_HIP_HOOK_PA, rc == SVT_HIP_OK);
     if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
     if (do_q) generate_padding(&quarter->buffer_y[0], quarter->stride_y, quarter->width, quarter->height, quarter->origin_x, quarter->origin_y);
@@ -73,7 +73,7 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     if (padded->origin_x + pw > padded->stride_y || padded->origin_y + ph > (int)(padded->height + 2 * padded->origin_y)) return EB_ErrorUndefined;
     uint8_t  *mean = (uint8_t *)malloc((size_t)n_sb * 85);
     uint16_t *var = (uint16_t *)malloc((size_t)n_sb * 85 * sizeof(uint16_t));
-    SvtHipCtx *hip = (mean && var) ? svt_hip_hooks_lock() : NULL;
+    SvtHipCtx *hip = (mean && var) ? svt_hip_hooks_lock_any() : NULL;
     int        rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
     void      *d_in = NULL, *d_mean = NULL, *d_var = NULL;
     PA_TRY(svt_hip_malloc(hip, &d_in, (size_t)stride * ph));
@@ -88,7 +88,7 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     if (hip) {
         svt_hip_free(hip, d_in); svt_hip_free(hip, d_mean); svt_hip_free(hip, d_var);
         if (rc != SVT_HIP_OK) SVT_LOG("variance pyramid on the device failed (%s): C path\n", svt_hip_last_error(hip));
-        svt_hip_hooks_unlock();
+        svt_hip_hooks_unlock_any();
     }
     if (rc == SVT_HIP_OK)
         for (uint32_t i = 0; i < n_sb; i++) {   /* [0] 64x64, [1..4] 32x32, [5..20] 16x16, [21..84] 8x8: the raster-scan indices of pcs->y_mean / variance */

@@ -112,7 +112,7 @@ SvtHipTfSeg *svt_hip_tf_seg_begin(int n_frames, int index_center, uint32_t col0,
 
 void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
     if (!s) return;
-    SvtHipCtx *hip = s->ctor_done ? svt_hip_hooks_lock() : NULL;
+    SvtHipCtx *hip = s->ctor_done ? svt_hip_hooks_lock_any() : NULL;
     for (int f = 0; f < SVT_HIP_TF_MAX_REFS; f++) {
         free(s->w.h_blocks[f]); free(s->jobs[f]);
         for (int p = 0; p < 3; p++) free(s->h_pred[f][p]);
@@ -121,7 +121,7 @@ void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
             for (int p = 0; p < 3; p++) svt_hip_free(hip, s->w.d_pred[f][p]);
         }
     }
-    if (hip) { svt_hip_free(hip, s->w.d_sse); svt_hip_hooks_unlock(); }
+    if (hip) { svt_hip_free(hip, s->w.d_sse); svt_hip_hooks_unlock_any(); }
     free(s);
 }
 
@@ -214,7 +214,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     SvtHipTfWindow *w = &s->w;
     const int       pb = s->is_highbd ? 2 : 1, np = c->tf_chroma ? 3 : 1;
     const size_t    nblk = (size_t)w->blk_cols * w->blk_rows;
-    SvtHipCtx      *hip = svt_hip_hooks_lock();
+    SvtHipCtx      *hip = svt_hip_hooks_lock_any();
     if (!hip) { svt_hip_hooks_count(SVT_HIP_HOOK_TF, 0); return EB_ErrorUndefined; }
     EbErrorType ret = EB_ErrorNone;
     void       *d_src[3] = {NULL, NULL, NULL};
@@ -254,7 +254,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     }
     for (int p = 0; p < 3; p++) svt_hip_free(hip, d_src[p]);
     if (ret != EB_ErrorNone) SVT_LOG("temporal filter segment on the device failed (%s): C loop for this segment\n", svt_hip_last_error(hip));
-    svt_hip_hooks_unlock();
+    svt_hip_hooks_unlock_any();
     svt_hip_hooks_log("tf: segment of %d x %d blocks, %d frames, one launch", w->blk_cols, w->blk_rows, w->n_frames);
     if (n_subpel) {
         svt_hip_hooks_log("tf_subpel: sub-pel searches and prediction of %d window frames on the device, %d blocks each (no predictor upload)", n_subpel, (int)nblk);
@@ -266,7 +266,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
 
 int svt_hip_tf_hook_noise(const void *src, int pix_bytes, int bd, int width, int height, int stride, double *sigma) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_TF) || width < 3 || height < 3) return 0;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return 0;
     void   *d_plane = NULL, *d_out = NULL;
     int64_t out[2] = {0, 0};
@@ -276,7 +276,7 @@ int svt_hip_tf_hook_noise(const void *src, int pix_bytes, int bd, int width, int
     if (rc == SVT_HIP_OK) rc = svt_hip_tf_estimate_noise_dev(hip, d_plane, pix_bytes, bd, width, height, width, (int64_t *)d_out);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, out, d_out, sizeof(out));
     svt_hip_free(hip, d_plane); svt_hip_free(hip, d_out);
-    svt_hip_hooks_unlock();
+    svt_hip_hooks_unlock_any();
     if (rc != SVT_HIP_OK) return 0;
     *sigma = svt_hip_tf_noise_sigma(out[0], out[1]);
     svt_hip_hooks_log("tf: noise of a %d x %d plane = %f", width, height, *sigma);

@@ -442,7 +442,9 @@ sgr_walk_resident_kernel(const WalkPic a) {
         int start[2] = {0, 0};
         const unsigned long long c0 = __builtin_readcyclecounter();
         unsigned long long c_replay = 0, c_load = 0, c_eval = 0;
+        __builtin_amdgcn_s_setprio(3);
         solve_and_encode(S, w * (v1 - v0), ep, start);
+        __builtin_amdgcn_s_setprio(0);
         RegStore K;
 #pragma unroll
         for (int b = 0; b < kBanks; b++) { K.key[b] = -1; K.err[b] = 0; }
@@ -453,7 +455,9 @@ sgr_walk_resident_kernel(const WalkPic a) {
         WalkState W; walk_begin(W, start);
         for (int pass = 0; pass < 64; pass++) {
             const unsigned long long r0 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_setprio(3);   // the replay is the serial part of the walk: it goes ahead of the other workgroup's evaluation waves on this SIMD
             fin = replay(K, W, ep, S);
+            __builtin_amdgcn_s_setprio(0);
             c_replay += __builtin_readcyclecounter() - r0;
             const int nc = K.nw;
             if (lane == 0) { L.done = fin ? 1 : 0; L.n_want = nc; }
