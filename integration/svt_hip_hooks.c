@@ -74,6 +74,65 @@ void svt_hip_hooks_unlock(void) {
  * stream, lets the reference's N motion-estimation / TF threads run their segments side by side instead of queueing behind one mutex.  The loop-filter bridge keeps
  * the main context and its lock: its per-picture state table and the "first segment searches the whole picture" rule rely on that mutual exclusion.  A context is
  * drained (svt_hip_sync) before it is handed back, so whichever context a later call gets sees the device memory complete. */
+/* Device memory of the per-call bridges comes from a small cache: hipMalloc / hipFree cost tens of microseconds each and hipFree waits for the whole device, which
+ * with several contexts at work turns every free into a global synchronisation point.  Blocks are kept by power-of-two size class (SVT_HIP_ALLOC_CACHE_MB in total,
+ * default 1024; 0 = off); a block is only ever reused after the context that used it was drained (svt_hip_hooks_unlock_any / the synchronous copies), like a free. */
+#define ALLOC_CLASSES 40
+#define ALLOC_PER_CLASS 32
+#define ALLOC_LIVE 2048
+static pthread_mutex_t g_alloc_mu = PTHREAD_MUTEX_INITIALIZER;
+static void           *g_alloc_free[ALLOC_CLASSES][ALLOC_PER_CLASS];
+static int             g_alloc_n[ALLOC_CLASSES];
+static struct { void *p; int c; } g_alloc_live[ALLOC_LIVE];   /* blocks handed out: pointer -> size class */
+static size_t          g_alloc_cached, g_alloc_limit = (size_t)1024 << 20;
+static long            g_alloc_hits, g_alloc_misses;
+static int alloc_class(size_t bytes) { int c = 8; while (((size_t)1 << c) < bytes && c < ALLOC_CLASSES - 1) c++; return c; }
+static int alloc_note(void *p, int c) {   /* g_alloc_mu held */
+    for (int i = 0; i < ALLOC_LIVE; i++)
+        if (!g_alloc_live[i].p) { g_alloc_live[i].p = p; g_alloc_live[i].c = c; return 1; }
+    return 0;
+}
+int svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes) {
+    const int c = alloc_class(bytes ? bytes : 1);
+    if (!g_alloc_limit || ((size_t)1 << c) < bytes) return svt_hip_malloc(hip, p, bytes);
+    pthread_mutex_lock(&g_alloc_mu);
+    if (g_alloc_n[c]) {
+        void *q = g_alloc_free[c][g_alloc_n[c] - 1];
+        if (alloc_note(q, c)) {
+            g_alloc_n[c]--;
+            g_alloc_cached -= (size_t)1 << c;
+            g_alloc_hits++;
+            pthread_mutex_unlock(&g_alloc_mu);
+            *p = q;
+            return SVT_HIP_OK;
+        }
+    }
+    g_alloc_misses++;
+    pthread_mutex_unlock(&g_alloc_mu);
+    const int rc = svt_hip_malloc(hip, p, (size_t)1 << c);   /* the whole class: the block can serve any request of it later */
+    if (rc == SVT_HIP_OK) {
+        pthread_mutex_lock(&g_alloc_mu);
+        (void)alloc_note(*p, c);   /* table full: the block is simply freed for real later */
+        pthread_mutex_unlock(&g_alloc_mu);
+    }
+    return rc;
+}
+void svt_hip_hooks_free(SvtHipCtx *hip, void *p) {
+    if (!p) return;
+    int c = -1;
+    pthread_mutex_lock(&g_alloc_mu);
+    for (int i = 0; i < ALLOC_LIVE; i++)
+        if (g_alloc_live[i].p == p) { c = g_alloc_live[i].c; g_alloc_live[i].p = NULL; break; }
+    if (c >= 0 && g_alloc_n[c] < ALLOC_PER_CLASS && g_alloc_cached + ((size_t)1 << c) <= g_alloc_limit) {
+        g_alloc_free[c][g_alloc_n[c]++] = p;
+        g_alloc_cached += (size_t)1 << c;
+        pthread_mutex_unlock(&g_alloc_mu);
+        return;
+    }
+    pthread_mutex_unlock(&g_alloc_mu);
+    svt_hip_free(hip, p);
+}
+
 #define SVT_HIP_POOL_MAX 8
 static SvtHipCtx      *g_pool[SVT_HIP_POOL_MAX];
 static pthread_mutex_t g_pool_mu[SVT_HIP_POOL_MAX];
@@ -125,6 +184,7 @@ void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
     fprintf(stderr, "svt_hip_context locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_lock_n, g_lock_held_ns / 1e6, g_lock_wait_ns / 1e6);
+    if (g_alloc_hits + g_alloc_misses) fprintf(stderr, "svt_hip_alloc_cache hits=%ld misses=%ld cached_mb=%.1f\n", g_alloc_hits, g_alloc_misses, g_alloc_cached / 1048576.0);
     if (g_pool_n)
         fprintf(stderr, "svt_hip_context_pool contexts=%d locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_pool_n, g_pool_locks, g_pool_held_ns / 1e6, g_pool_wait_ns / 1e6);
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
@@ -253,6 +313,7 @@ void svt_hip_hooks_enc_init(int target_socket) {
         g_ctx = NULL;
         return;
     }
+    if (getenv("SVT_HIP_ALLOC_CACHE_MB")) g_alloc_limit = (size_t)atol(getenv("SVT_HIP_ALLOC_CACHE_MB")) << 20;
     {   /* the pool of the source-side bridges; 0 = everything on the main context (the round-2 behaviour) */
         const char *pc = getenv("SVT_HIP_CONTEXTS");
         int         n = pc ? atoi(pc) : 4;

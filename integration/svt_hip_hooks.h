@@ -65,6 +65,9 @@ SvtHipCtx *svt_hip_hooks_lock(void);
 void       svt_hip_hooks_unlock(void);
 /* a context of the pool the source-side bridges share (SVT_HIP_CONTEXTS, default 4; 0 = the main context): for calls that keep no device state between two
  * calls.  lock_any / unlock_any pair up on one thread; unlock_any drains the context's stream first */
+/* device memory through the hooks' block cache (power-of-two size classes, SVT_HIP_ALLOC_CACHE_MB); pointers of svt_hip_malloc may be passed to the free too */
+int        svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes);
+void       svt_hip_hooks_free(SvtHipCtx *hip, void *p);
 SvtHipCtx *svt_hip_hooks_lock_any(void);
 void       svt_hip_hooks_unlock_any(void);
 void       svt_hip_hooks_log(const char *fmt, ...);

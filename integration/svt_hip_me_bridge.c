@@ -122,7 +122,7 @@ void svt_hip_me_batch_end(SvtHipMeBatch *b) {
     if (b->d_src || b->d_ref || b->d_job || b->d_sad || b->d_xy) {
         SvtHipCtx *hip = svt_hip_hooks_lock_any();
         if (hip) {
-            svt_hip_free(hip, b->d_src); svt_hip_free(hip, b->d_ref); svt_hip_free(hip, b->d_job); svt_hip_free(hip, b->d_sad); svt_hip_free(hip, b->d_xy);
+            svt_hip_hooks_free(hip, b->d_src); svt_hip_hooks_free(hip, b->d_ref); svt_hip_hooks_free(hip, b->d_job); svt_hip_hooks_free(hip, b->d_sad); svt_hip_hooks_free(hip, b->d_xy);
             svt_hip_hooks_unlock_any();
         }
     }
@@ -253,10 +253,10 @@ int svt_hip_hme_sad_loop(int level, const EbPictureBufferDesc *ref_pic, int16_t 
 
 static int dev_need(SvtHipCtx *hip, void **d, size_t *cap, size_t bytes) {
     if (*cap >= bytes) return SVT_HIP_OK;
-    if (*d) svt_hip_free(hip, *d);
+    if (*d) svt_hip_hooks_free(hip, *d);
     *d = NULL;
     *cap = 0;
-    const int rc = svt_hip_malloc(hip, d, bytes + bytes / 4);
+    const int rc = svt_hip_hooks_malloc(hip, d, bytes + bytes / 4);
     if (rc == SVT_HIP_OK) *cap = bytes + bytes / 4;
     return rc;
 }

@@ -30,9 +30,9 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return EB_ErrorUndefined;
     void *d_in = NULL, *d_q = NULL, *d_s = NULL;
-    int   rc = svt_hip_malloc(hip, &d_in, (size_t)w * h);
-    PA_TRY(svt_hip_malloc(hip, &d_q, (size_t)(w / 2) * (h / 2) + 64));
-    PA_TRY(svt_hip_malloc(hip, &d_s, (size_t)(w / 4) * (h / 4) + 64));
+    int   rc = svt_hip_hooks_malloc(hip, &d_in, (size_t)w * h);
+    PA_TRY(svt_hip_hooks_malloc(hip, &d_q, (size_t)(w / 2) * (h / 2) + 64));
+    PA_TRY(svt_hip_hooks_malloc(hip, &d_s, (size_t)(w / 4) * (h / 4) + 64));
     PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)w, padded->buffer_y + padded->origin_x + (size_t)padded->origin_y * padded->stride_y, padded->stride_y, (size_t)w, (size_t)h));
     /* the destination offset is the reference's own expression (origin_x for the row as well, :3327-3329) */
     if (do_q) {
@@ -48,7 +48,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
         PA_TRY(svt_hip_memcpy2d_d2h(hip, sixteenth->buffer_y + sixteenth->origin_x + (size_t)sixteenth->origin_x * sixteenth->stride_y, sixteenth->stride_y, d_s,
                                     (size_t)(w / 4), (size_t)(w / 4), (size_t)(h / 4)));
     }
-    svt_hip_free(hip, d_in); svt_hip_free(hip, d_q); svt_hip_free(hip, d_s);
+    svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_q); svt_hip_hooks_free(hip, d_s);
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
     svt_hip_hooks_count(SVT_HIP_HOOK_PA, rc == SVT_HIP_OK);
@@ -76,9 +76,9 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     SvtHipCtx *hip = (mean && var) ? svt_hip_hooks_lock_any() : NULL;
     int        rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
     void      *d_in = NULL, *d_mean = NULL, *d_var = NULL;
-    PA_TRY(svt_hip_malloc(hip, &d_in, (size_t)stride * ph));
-    PA_TRY(svt_hip_malloc(hip, &d_mean, (size_t)n_sb * 85));
-    PA_TRY(svt_hip_malloc(hip, &d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
+    PA_TRY(svt_hip_hooks_malloc(hip, &d_in, (size_t)stride * ph));
+    PA_TRY(svt_hip_hooks_malloc(hip, &d_mean, (size_t)n_sb * 85));
+    PA_TRY(svt_hip_hooks_malloc(hip, &d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
     PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)stride, padded->buffer_y + padded->origin_x + (size_t)padded->origin_y * padded->stride_y, padded->stride_y, (size_t)pw,
                                 (size_t)ph));
     PA_TRY(svt_hip_variance_pyramid_dev(hip, (const uint8_t *)d_in, stride, sb_cols, (int)n_sb, scs->block_mean_calc_prec == BLOCK_MEAN_PREC_FULL, (uint8_t *)d_mean,
@@ -86,7 +86,7 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     PA_TRY(svt_hip_memcpy_d2h(hip, mean, d_mean, (size_t)n_sb * 85));
     PA_TRY(svt_hip_memcpy_d2h(hip, var, d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
     if (hip) {
-        svt_hip_free(hip, d_in); svt_hip_free(hip, d_mean); svt_hip_free(hip, d_var);
+        svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_mean); svt_hip_hooks_free(hip, d_var);
         if (rc != SVT_HIP_OK) SVT_LOG("variance pyramid on the device failed (%s): C path\n", svt_hip_last_error(hip));
         svt_hip_hooks_unlock_any();
     }

@@ -21,23 +21,23 @@ EbErrorType svt_hip_tf_window_ctor(SvtHipCtx *hip, SvtHipTfWindow *w, int n_fram
         if (f == index_center) continue;
         w->h_blocks[f] = (SvtHipTfBlk64 *)calloc(nblk, sizeof(SvtHipTfBlk64));
         if (!w->h_blocks[f]) return EB_ErrorInsufficientResources;
-        HIP_TRY(svt_hip_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
+        HIP_TRY(svt_hip_hooks_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
         for (int p = 0; p < 3; p++) {
             const size_t rows = (size_t)(w->blk_rows * 64) >> (p ? ss_y : 0);
-            HIP_TRY(svt_hip_malloc(hip, &w->d_pred[f][p], (size_t)w->pred_stride[p] * rows * pb));
+            HIP_TRY(svt_hip_hooks_malloc(hip, &w->d_pred[f][p], (size_t)w->pred_stride[p] * rows * pb));
         }
     }
-    HIP_TRY(svt_hip_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
+    HIP_TRY(svt_hip_hooks_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
     return EB_ErrorNone;
 }
 
 void svt_hip_tf_window_dctor(SvtHipCtx *hip, SvtHipTfWindow *w) {
     for (int f = 0; f < SVT_HIP_TF_MAX_REFS; f++) {
         free(w->h_blocks[f]);
-        svt_hip_free(hip, w->d_blocks[f]);
-        for (int p = 0; p < 3; p++) svt_hip_free(hip, w->d_pred[f][p]);
+        svt_hip_hooks_free(hip, w->d_blocks[f]);
+        for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, w->d_pred[f][p]);
     }
-    svt_hip_free(hip, w->d_sse);
+    svt_hip_hooks_free(hip, w->d_sse);
     memset(w, 0, sizeof(*w));
 }
 
@@ -117,11 +117,11 @@ void svt_hip_tf_seg_end(SvtHipTfSeg *s) {
         free(s->w.h_blocks[f]); free(s->jobs[f]);
         for (int p = 0; p < 3; p++) free(s->h_pred[f][p]);
         if (hip) {
-            svt_hip_free(hip, s->w.d_blocks[f]);
-            for (int p = 0; p < 3; p++) svt_hip_free(hip, s->w.d_pred[f][p]);
+            svt_hip_hooks_free(hip, s->w.d_blocks[f]);
+            for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, s->w.d_pred[f][p]);
         }
     }
-    if (hip) { svt_hip_free(hip, s->w.d_sse); svt_hip_hooks_unlock_any(); }
+    if (hip) { svt_hip_hooks_free(hip, s->w.d_sse); svt_hip_hooks_unlock_any(); }
     free(s);
 }
 
@@ -195,17 +195,17 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
         if (hi > rows - org_y - 1) hi = rows - org_y - 1;
         if (hi < lo) return EB_ErrorUndefined;
         const size_t bytes = (size_t)(hi - lo + 1) * stride3[p] * pb;
-        TF_TRY(svt_hip_malloc(hip, &d_band[p], bytes + 64));
+        TF_TRY(svt_hip_hooks_malloc(hip, &d_band[p], bytes + 64));
         TF_TRY(svt_hip_memcpy_h2d(hip, d_band[p], s->ref_plane[f][p] + (size_t)(org_y + lo) * stride3[p] * pb, bytes));
         if (ret == EB_ErrorNone) d_ref[p] = (const uint8_t *)d_band[p] + ((ptrdiff_t)(-lo) * stride3[p] + org_x) * pb;
     }
-    TF_TRY(svt_hip_malloc(hip, &d_jobs, sizeof(SvtHipTfSubpelBlk) * (size_t)n));
+    TF_TRY(svt_hip_hooks_malloc(hip, &d_jobs, sizeof(SvtHipTfSubpelBlk) * (size_t)n));
     TF_TRY(svt_hip_memcpy_h2d(hip, d_jobs, s->jobs[f], sizeof(SvtHipTfSubpelBlk) * (size_t)n));
     TF_TRY(svt_hip_tf_subpel_frame_dev(hip, pb, bd, (const void *const *)d_src, sstride, d_ref, stride3, s->w.d_pred[f], s->w.pred_stride, s->mi_cols, s->mi_rows,
                                        s->th16, s->tf_hp, c->tf_chroma, (const SvtHipTfSubpelBlk *)d_jobs, n, s->w.d_blocks[f]));
     if (ret == EB_ErrorNone && svt_hip_memcpy_d2h(hip, &s->w.h_blocks[f][0], s->w.d_blocks[f], sizeof(SvtHipTfBlk64)) != SVT_HIP_OK) ret = EB_ErrorUndefined;   /* completes the launch before the band is freed */
-    for (int p = 0; p < 3; p++) svt_hip_free(hip, d_band[p]);
-    svt_hip_free(hip, d_jobs);
+    for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, d_band[p]);
+    svt_hip_hooks_free(hip, d_jobs);
     return ret;
 }
 
@@ -221,21 +221,21 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     uint8_t    *host[3];
     int         sstride[3];
     s->ctor_done = 1;
-    TF_TRY(svt_hip_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
+    TF_TRY(svt_hip_hooks_malloc(hip, (void **)&w->d_sse, 2 * sizeof(uint64_t)));
     /* the segment's rectangle of the central picture (chroma is only read when tf_chroma is on) */
     for (int p = 0; p < 3; p++) {
         const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
         host[p] = (s->is_highbd ? (uint8_t *)src16_start[p] : src_start[p]) + ((size_t)s->row0 * bh * stride[p] + (size_t)s->col0 * bw) * pb;
         sstride[p] = w->pred_stride[p];
-        TF_TRY(svt_hip_malloc(hip, &d_src[p], s->plane_bytes[p]));
+        TF_TRY(svt_hip_hooks_malloc(hip, &d_src[p], s->plane_bytes[p]));
         TF_TRY(svt_hip_memcpy2d_h2d(hip, d_src[p], (size_t)sstride[p] * pb, host[p], (size_t)stride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
     }
     int n_subpel = 0;
     for (int f = 0; f < w->n_frames && ret == EB_ErrorNone; f++) {
         if (f == w->index_center) continue;
-        TF_TRY(svt_hip_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
+        TF_TRY(svt_hip_hooks_malloc(hip, (void **)&w->d_blocks[f], nblk * sizeof(SvtHipTfBlk64)));
         for (int p = 0; p < 3; p++) {
-            TF_TRY(svt_hip_malloc(hip, &w->d_pred[f][p], s->plane_bytes[p]));
+            TF_TRY(svt_hip_hooks_malloc(hip, &w->d_pred[f][p], s->plane_bytes[p]));
             if (p < np && !s->n_jobs[f]) TF_TRY(svt_hip_memcpy_h2d(hip, w->d_pred[f][p], s->h_pred[f][p], s->plane_bytes[p]));
         }
         if (s->n_jobs[f] && ret == EB_ErrorNone) {   /* hook "tf_subpel": sub-pel searches + prediction of this frame's blocks, on the device */
@@ -252,7 +252,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
         const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
         TF_TRY(svt_hip_memcpy2d_d2h(hip, host[p], (size_t)stride[p] * pb, d_src[p], (size_t)sstride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
     }
-    for (int p = 0; p < 3; p++) svt_hip_free(hip, d_src[p]);
+    for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, d_src[p]);
     if (ret != EB_ErrorNone) SVT_LOG("temporal filter segment on the device failed (%s): C loop for this segment\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
     svt_hip_hooks_log("tf: segment of %d x %d blocks, %d frames, one launch", w->blk_cols, w->blk_rows, w->n_frames);
@@ -270,12 +270,12 @@ int svt_hip_tf_hook_noise(const void *src, int pix_bytes, int bd, int width, int
     if (!hip) return 0;
     void   *d_plane = NULL, *d_out = NULL;
     int64_t out[2] = {0, 0};
-    int     rc = svt_hip_malloc(hip, &d_plane, (size_t)width * height * pix_bytes);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_out, sizeof(out));
+    int     rc = svt_hip_hooks_malloc(hip, &d_plane, (size_t)width * height * pix_bytes);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_out, sizeof(out));
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy2d_h2d(hip, d_plane, (size_t)width * pix_bytes, src, (size_t)stride * pix_bytes, (size_t)width * pix_bytes, (size_t)height);
     if (rc == SVT_HIP_OK) rc = svt_hip_tf_estimate_noise_dev(hip, d_plane, pix_bytes, bd, width, height, width, (int64_t *)d_out);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, out, d_out, sizeof(out));
-    svt_hip_free(hip, d_plane); svt_hip_free(hip, d_out);
+    svt_hip_hooks_free(hip, d_plane); svt_hip_hooks_free(hip, d_out);
     svt_hip_hooks_unlock_any();
     if (rc != SVT_HIP_OK) return 0;
     *sigma = svt_hip_tf_noise_sigma(out[0], out[1]);
