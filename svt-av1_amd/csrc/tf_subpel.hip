@@ -8,10 +8,10 @@
 // Each candidate is av1_inter_prediction's single-reference, unscaled path (EbEncInterPrediction.c:4040 -> enc_make_inter_predictor :3663 ->
 // compute_subpel_params :3593 -> clamp_mv_to_umv_border_sb :24 -> convolve[sx != 0][sy != 0][0], round_0 = 3, round_1 = 11) followed by
 // svt_aom_variance{W}x{H} (C_DEFAULT/EbComputeVariance_C.c:54) or variance_highbd (:34; 32-bit sums, wrapping like the C) against the central picture.
-// One workgroup owns one 32x32 quadrant of one pair from the first half-pel candidate to the final predictor: a candidate's window goes through
-// LDS once (horizontal pass -> 16-bit intermediate -> vertical pass, every rounding step of the reference kept), the source samples of a thread stay
-// in registers, and the rounds are sequential inside the workgroup — no host round trip between rounds, the predictors are written straight into
-// the planes svt_hip_tf_filter_frame_dev reads.
+// One workgroup (nine waves) owns one 32x32 quadrant of one pair from the first half-pel candidate to the final predictor: wave c evaluates candidate c of a
+// round in its own LDS region (window -> horizontal pass -> 16-bit intermediate -> vertical pass, every rounding step of the reference kept; the source samples
+// of a lane stay in registers), the rounds are sequential inside the workgroup — 3 + 12 of them instead of 27 + 108 candidate evaluations one after the other —,
+// no host round trip between rounds, and the predictors are written straight into the planes svt_hip_tf_filter_frame_dev reads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
@@ -30,12 +30,14 @@ struct TfSubpelArgs {
     const SvtHipTfSubpelBlk* jobs; SvtHipTfBlk64* blocks;
 };
 
-struct Lds {
+constexpr int kWaves = 9;   // one wave per candidate of a round
+struct WaveLds {
     short src[(32 + 7) * 40];   // the candidate's window, rows -3 .. bs + 3, row stride bs + 8
     short im[(32 + 7) * 32];    // horizontal pass
-    int   red[2][4];            // per-wave partial sums
-    int   best_x, best_y;       // broadcast of a round's result
-    unsigned long long best_err;
+};
+struct Lds {
+    WaveLds w[kWaves];
+    unsigned dist[kWaves];
 };
 
 // compute_subpel_params (EbEncInterPrediction.c:3593-3660), unscaled branch: the vector (1/8 pel, luma units) of a bw x bh block of the plane with
@@ -54,36 +56,37 @@ __device__ __forceinline__ void subpel_params(int mvx, int mvy, int px, int py, 
     pos_x = ((pre_x << 4) + col) >> 4; pos_y = ((pre_y << 4) + row) >> 4;
 }
 
-// One bw x bh prediction (bw, bh <= 32) of the workgroup: thread t owns outputs t, t + 256, ... (raster).  out[u] receives them.
+// One bw x bh prediction (bw, bh <= 32) by ONE wave in its own LDS region: lane l owns outputs l, l + 64, ... (raster), out[u] receives them.  `on` = this wave
+// has a block to predict; every wave of the workgroup passes the two barriers whatever it does in between (the candidates of a round differ in their phases).
 template <typename PIX, int BD>
-__device__ void predict(Lds& L, const PIX* __restrict__ ref, int ref_stride, int pos_x, int pos_y, int sx, int sy, int bank, int bw, int bh, int out[4]) {
-    const int tid = threadIdx.x, ws = bw + 8;
+__device__ void predict(WaveLds& L, bool on, const PIX* __restrict__ ref, int ref_stride, int pos_x, int pos_y, int sx, int sy, int bank, int bw, int bh, int out[16]) {
+    const int lane = threadIdx.x & 63, ws = bw + 8;
     constexpr int pix_max = (1 << BD) - 1;
-    __syncthreads();   // the previous user of the LDS window is done
-    for (int i = tid; i < (bh + 7) * (bw + 7); i += 256) {
-        const int r = i / (bw + 7), c = i - r * (bw + 7);
-        L.src[r * ws + c] = (short)ref[(ptrdiff_t)(pos_y + r - 3) * ref_stride + (pos_x + c - 3)];
-    }
+    __syncthreads();   // the previous users of the LDS windows are done
+    if (on)
+        for (int i = lane; i < (bh + 7) * (bw + 7); i += 64) {
+            const int r = i / (bw + 7), c = i - r * (bw + 7);
+            L.src[r * ws + c] = (short)ref[(ptrdiff_t)(pos_y + r - 3) * ref_stride + (pos_x + c - 3)];
+        }
     __syncthreads();
     int xf[8], yf[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { xf[k] = kInterp[bank][sx][k]; yf[k] = kInterp[bank][sy][k]; }
     const int n = bw * bh;
-    if (sx && sy) {
-        for (int i = tid; i < (bh + 7) * bw; i += 256) {   // horizontal pass over bh + 7 rows (im_block, EbInterPrediction.c:366-374)
+    if (on && sx && sy)
+        for (int i = lane; i < (bh + 7) * bw; i += 64) {   // horizontal pass over bh + 7 rows (im_block, EbInterPrediction.c:366-374)
             const int r = i / bw, c = i - r * bw;
             int sum = 1 << (BD + 6);
 #pragma unroll
             for (int k = 0; k < 8; k++) sum += xf[k] * L.src[r * ws + c + k];
             L.im[i] = (short)rp2(sum, 3);
         }
-        __syncthreads();
-    }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int i = tid + 256 * u;
+    for (int u = 0; u < 16; u++) {
+        const int i = lane + 64 * u;
         int o = 0;
-        if (i < n) {
+        if (on && i < n) {
             const int y = i / bw, x = i - y * bw;
             if (!sx && !sy) o = L.src[(y + 3) * ws + x + 3];
             else if (!sy) {
@@ -110,28 +113,17 @@ __device__ void predict(Lds& L, const PIX* __restrict__ ref, int ref_stride, int
     }
 }
 
-// sum of (a, b) over the workgroup, the result in every thread
-__device__ __forceinline__ void block_sum2(Lds& L, int& a, int& b) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { L.red[0][w] = a; L.red[1][w] = b; }
-    __syncthreads();
-    a = L.red[0][0] + L.red[0][1] + L.red[0][2] + L.red[0][3];
-    b = L.red[1][0] + L.red[1][1] + L.red[1][2] + L.red[1][3];
-}
-
-// the three rounds of one bs x bs block at luma position (px, py) (picture) / (lx, ly) (central and predictor planes); word = the open-loop ME vector
+// the three rounds of one bs x bs block at luma position (px, py) (picture) / (lx, ly) (central and predictor planes); word = the open-loop ME vector.
+// Wave c of the workgroup evaluates candidate c of the round (i outer, j inner: the reference's order); the first strictly smaller distortion wins.
 template <typename PIX, int BD>
 __device__ void search(Lds& L, const TfSubpelArgs& a, int bs, int px, int py, int lx, int ly, uint32_t word, int& best_x, int& best_y, unsigned long long& best_err) {
     const PIX* __restrict__ src = (const PIX*)a.src[0];
     const PIX* __restrict__ ref = (const PIX*)a.ref[0];
-    const int tid = threadIdx.x, n = bs * bs;
-    int s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = bs * bs;
+    int s[16];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int i = tid + 256 * u, y = i / bs, x = i - y * bs;
+    for (int u = 0; u < 16; u++) {
+        const int i = lane + 64 * u, y = i / bs, x = i - y * bs;
         s[u] = i < n ? (int)src[(ptrdiff_t)(ly + y) * a.src_stride[0] + lx + x] : 0;
     }
     short mv_x = (short)((short)(word & 0xffff) << 1), mv_y = (short)((short)(word >> 16) << 1);   // AV1 vectors are 1/8 pel (:1225-1232)
@@ -139,54 +131,62 @@ __device__ void search(Lds& L, const TfSubpelArgs& a, int bs, int px, int py, in
     unsigned long long berr = 0x7fffffffull;   // INT_MAX
     for (int round = 0; round < (a.tf_hp ? 3 : 2); round++) {
         const int step = 4 >> round;
-        for (int i = -step; i <= step; i += step)
-            for (int j = -step; j <= step; j += step) {
-                const short cx = (short)(mv_x + i), cy = (short)(mv_y + j);
-                int pos_x, pos_y, sx, sy, o[4];
-                subpel_params(cx, cy, px, py, bs, bs, bs, 0, a.mi_cols, a.mi_rows, px, py, pos_x, pos_y, sx, sy);
-                predict<PIX, BD>(L, ref, a.ref_stride[0], pos_x, pos_y, sx, sy, 0, bs, bs, o);
-                int sum = 0, sse = 0;   // sse < 2^31: 1024 x 1023^2
+        const short cx = (short)(mv_x + (wave / 3 - 1) * step), cy = (short)(mv_y + (wave % 3 - 1) * step);
+        int pos_x, pos_y, sx, sy, o[16];
+        subpel_params(cx, cy, px, py, bs, bs, bs, 0, a.mi_cols, a.mi_rows, px, py, pos_x, pos_y, sx, sy);
+        predict<PIX, BD>(L.w[wave], true, ref, a.ref_stride[0], pos_x, pos_y, sx, sy, 0, bs, bs, o);
+        int sum = 0, sse = 0;   // sse < 2^31: 1024 x 1023^2
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (tid + 256 * u < n) { const int d = o[u] - s[u]; sum += d; sse += d * d; }
-                block_sum2(L, sum, sse);
-                uint32_t dist;
-                if (sizeof(PIX) == 1) dist = (uint32_t)sse - (uint32_t)(((long long)sum * sum) / n);
-                else dist = (uint32_t)sse - (uint32_t)((int)((unsigned)sum * (unsigned)sum) / n);   // variance_highbd_c: int arithmetic
-                if ((unsigned long long)dist < berr) { berr = dist; bx = cx; by = cy; }
-            }
+        for (int u = 0; u < 16; u++)
+            if (lane + 64 * u < n) { const int d = o[u] - s[u]; sum += d; sse += d * d; }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { sum += __shfl_xor(sum, m, 64); sse += __shfl_xor(sse, m, 64); }
+        uint32_t dist;
+        if (sizeof(PIX) == 1) dist = (uint32_t)sse - (uint32_t)(((long long)sum * sum) / n);
+        else dist = (uint32_t)sse - (uint32_t)((int)((unsigned)sum * (unsigned)sum) / n);   // variance_highbd_c: int arithmetic
+        if (lane == 0) L.dist[wave] = dist;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kWaves; c++) {
+            const unsigned long long d = L.dist[c];
+            if (d < berr) { berr = d; bx = (short)(mv_x + (c / 3 - 1) * step); by = (short)(mv_y + (c % 3 - 1) * step); }
+        }
         mv_x = bx; mv_y = by;
     }
     best_x = bx; best_y = by; best_err = berr;
 }
 
-// tf_inter_prediction of one bs x bs block: luma and, with tf_chroma, the (bs / 2)^2 chroma blocks (4:2:0), MULTITAP_SHARP
+// tf_inter_prediction: the workgroup's waves share the quadrant's final predictions — job j of `njobs` luma blocks (bs x bs at (ox[j], oy[j]) inside the 64x64
+// block) goes to wave j, its two chroma blocks (tf_chroma, 4:2:0) to waves njobs + 2 j and njobs + 2 j + 1; jobs beyond the ninth wave take a second turn.
 template <typename PIX, int BD>
-__device__ void final_predict(Lds& L, const TfSubpelArgs& a, int bs, int px, int py, int lx, int ly, int mvx, int mvy) {
-    const int tid = threadIdx.x;
-    int pos_x, pos_y, sx, sy, o[4];
-    subpel_params(mvx, mvy, px, py, bs, bs, bs, 0, a.mi_cols, a.mi_rows, px, py, pos_x, pos_y, sx, sy);
-    predict<PIX, BD>(L, (const PIX*)a.ref[0], a.ref_stride[0], pos_x, pos_y, sx, sy, 2, bs, bs, o);
-    PIX* __restrict__ d0 = (PIX*)a.pred[0];
+__device__ void final_predict(Lds& L, const TfSubpelArgs& a, const SvtHipTfSubpelBlk& J, int bs, int njobs, const int* ox, const int* oy, const int* mvx, const int* mvy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = njobs * (a.tf_chroma ? 3 : 1);
+    for (int base = 0; base < total; base += kWaves) {
+        const int  t = base + wave;
+        const bool on = t < total;
+        const int  j = !on ? 0 : (t < njobs ? t : (t - njobs) >> 1), plane = !on || t < njobs ? 0 : 1 + ((t - njobs) & 1);
+        const int  px = J.x + ox[j], py = J.y + oy[j], lx = J.dst_x + ox[j], ly = J.dst_y + oy[j];
+        const int  bw = plane ? bs >> 1 : bs;
+        const int  pre_x = plane ? ((px >> 3) << 3) / 2 : px, pre_y = plane ? ((py >> 3) << 3) / 2 : py;
+        const int  dx = plane ? ((lx >> 3) << 3) / 2 : lx, dy = plane ? ((ly >> 3) << 3) / 2 : ly;
+        int pos_x, pos_y, sx, sy, o[16];
+        subpel_params(mvx[j], mvy[j], px, py, bs, bw, bw, plane ? 1 : 0, a.mi_cols, a.mi_rows, pre_x, pre_y, pos_x, pos_y, sx, sy);
+        predict<PIX, BD>(L.w[wave], on, (const PIX*)a.ref[plane], a.ref_stride[plane], pos_x, pos_y, sx, sy, 2, bw, bw, o);   // MULTITAP_SHARP
+        if (on) {
+            PIX* __restrict__ d = (PIX*)a.pred[plane];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int i = tid + 256 * u, y = i / bs, x = i - y * bs;
-        if (i < bs * bs) d0[(ptrdiff_t)(ly + y) * a.pred_stride[0] + lx + x] = (PIX)o[u];
-    }
-    if (!a.tf_chroma) return;
-    const int cb = bs >> 1, cpx = ((px >> 3) << 3) / 2, cpy = ((py >> 3) << 3) / 2, clx = ((lx >> 3) << 3) / 2, cly = ((ly >> 3) << 3) / 2;
-    subpel_params(mvx, mvy, px, py, bs, cb, cb, 1, a.mi_cols, a.mi_rows, cpx, cpy, pos_x, pos_y, sx, sy);
-    for (int p = 1; p < 3; p++) {
-        predict<PIX, BD>(L, (const PIX*)a.ref[p], a.ref_stride[p], pos_x, pos_y, sx, sy, 2, cb, cb, o);
-        PIX* __restrict__ d = (PIX*)a.pred[p];
-        const int i = tid, y = i / cb, x = i - y * cb;   // cb * cb <= 256
-        if (i < cb * cb) d[(ptrdiff_t)(cly + y) * a.pred_stride[p] + clx + x] = (PIX)o[0];
+            for (int u = 0; u < 16; u++) {
+                const int i = lane + 64 * u, y = i / bw, x = i - y * bw;
+                if (i < bw * bw) d[(ptrdiff_t)(dy + y) * a.pred_stride[plane] + dx + x] = (PIX)o[u];
+            }
+        }
     }
 }
 
-// grid: 4 x n_jobs (quadrant = blockIdx.x & 3); block 256
+// grid: 4 x n_jobs (quadrant = blockIdx.x & 3); block 9 waves
 template <typename PIX, int BD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kWaves)
 tf_subpel_kernel(const TfSubpelArgs a) {
     __shared__ Lds L;
     const SvtHipTfSubpelBlk J = a.jobs[blockIdx.x >> 2];
@@ -196,12 +196,11 @@ tf_subpel_kernel(const TfSubpelArgs a) {
     search<PIX, BD>(L, a, 32, J.x + 32 * qx, J.y + 32 * qy, J.dst_x + 32 * qx, J.dst_y + 32 * qy, J.mv32[q], mv32x, mv32y, err32);
     const bool do16 = !(err32 < a.th16);   // tf_16x16_search_do (:1190-1193)
     int mv16x[4] = {0, 0, 0, 0}, mv16y[4] = {0, 0, 0, 0}; unsigned long long err16[4] = {0, 0, 0, 0};
+    int ox[4], oy[4];
+    for (int k = 0; k < 4; k++) { ox[k] = 32 * qx + 16 * (k & 1); oy[k] = 32 * qy + 16 * (k >> 1); }   // z-order inside the quadrant = index_16x16_from_subindexes / tab16x16 (:54, EbMotionEstimation.h:108)
     int split = 0;
     if (do16) {
-        for (int k = 0; k < 4; k++) {   // z-order inside the quadrant = index_16x16_from_subindexes / tab16x16 (:54, EbMotionEstimation.h:108)
-            const int ox = 32 * qx + 16 * (k & 1), oy = 32 * qy + 16 * (k >> 1);
-            search<PIX, BD>(L, a, 16, J.x + ox, J.y + oy, J.dst_x + ox, J.dst_y + oy, J.mv16[4 * q + k], mv16x[k], mv16y[k], err16[k]);
-        }
+        for (int k = 0; k < 4; k++) search<PIX, BD>(L, a, 16, J.x + ox[k], J.y + oy[k], J.dst_x + ox[k], J.dst_y + oy[k], J.mv16[4 * q + k], mv16x[k], mv16y[k], err16[k]);
         // derive_tf_32x32_block_split_flag (:284-324), int arithmetic
         const int block_error = (int)err32;
         int mn = 0x7fffffff, mx = (int)0x80000000, sum = 0;
@@ -213,13 +212,11 @@ tf_subpel_kernel(const TfSubpelArgs a) {
         B->mv32_x[q] = (int16_t)mv32x; B->mv32_y[q] = (int16_t)mv32y; B->err32[q] = err32; B->split[q] = split;
         for (int k = 0; k < 4; k++) { B->mv16_x[4 * q + k] = (int16_t)mv16x[k]; B->mv16_y[4 * q + k] = (int16_t)mv16y[k]; B->err16[4 * q + k] = err16[k]; }
     }
-    if (split) {
-        for (int k = 0; k < 4; k++) {
-            const int ox = 32 * qx + 16 * (k & 1), oy = 32 * qy + 16 * (k >> 1);
-            final_predict<PIX, BD>(L, a, 16, J.x + ox, J.y + oy, J.dst_x + ox, J.dst_y + oy, mv16x[k], mv16y[k]);
-        }
-    } else
-        final_predict<PIX, BD>(L, a, 32, J.x + 32 * qx, J.y + 32 * qy, J.dst_x + 32 * qx, J.dst_y + 32 * qy, mv32x, mv32y);
+    if (split) final_predict<PIX, BD>(L, a, J, 16, 4, ox, oy, mv16x, mv16y);
+    else {
+        const int o32x = 32 * qx, o32y = 32 * qy;
+        final_predict<PIX, BD>(L, a, J, 32, 1, &o32x, &o32y, &mv32x, &mv32y);
+    }
 }
 
 }  // namespace
@@ -234,7 +231,7 @@ extern "C" int svt_hip_launch_tf_subpel(hipStream_t st, int pix_bytes, int bd, c
         a.src_stride[p] = src_stride[p]; a.ref_stride[p] = ref_stride[p]; a.pred_stride[p] = pred_stride[p];
     }
     a.mi_cols = mi_cols; a.mi_rows = mi_rows; a.tf_hp = tf_hp; a.tf_chroma = tf_chroma; a.th16 = th16; a.jobs = jobs; a.blocks = blocks;
-    const dim3 grid(4 * n_jobs), block(256);
+    const dim3 grid(4 * n_jobs), block(64 * kWaves);
     if (pix_bytes == 1) hipLaunchKernelGGL((tf_subpel_kernel<uint8_t, 8>), grid, block, 0, st, a);
     else if (bd == 8) hipLaunchKernelGGL((tf_subpel_kernel<uint16_t, 8>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((tf_subpel_kernel<uint16_t, 10>), grid, block, 0, st, a);
