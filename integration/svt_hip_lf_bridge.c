@@ -516,6 +516,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
 
     SvtHipSgrSearchPlane job[3];
     int32_t *xqd[3] = {0}; int64_t *err[3] = {0}; uint8_t *best[3] = {0};
+    uint8_t *c_ep[3] = {0}; int32_t *c_uq[3] = {0}; uint64_t *c_sse[3] = {0};   /* per plane: the chosen set / taps / SSE of every unit, committed at the end */
     EbErrorType ret = EB_ErrorNone;
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
@@ -552,8 +553,6 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
                     if (u >= n) { ok = 0; break; }
                     ep[u] = best[pl][u];
                     uq[2 * u] = xqd[pl][(u * 16 + ep[u]) * 2]; uq[2 * u + 1] = xqd[pl][(u * 16 + ep[u]) * 2 + 1];
-                    rusi[u].sgrproj.ep = ep[u]; rusi[u].sgrproj.xqd[0] = uq[2 * u]; rusi[u].sgrproj.xqd[1] = uq[2 * u + 1];
-                    cm->sg_frame_ep_cnt[ep[u]]++;
                     rect[u].a_x = rect[u].b_x = x0; rect[u].a_y = rect[u].b_y = v0; rect[u].w = (uint16_t)w; rect[u].h = (uint16_t)(v1 - v0);
                     x0 += w; j++;
                 }
@@ -568,16 +567,26 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
                  svt_hip_block_sse_batch_dev(hip, p->pix_bytes, p->d_src[pl], p->src_stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
                                              (const SvtHipBlkPair *)d_rect, n, (uint64_t *)d_sse) == SVT_HIP_OK &&
                  svt_hip_memcpy_d2h(hip, sse, d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK;
-            if (ok)
-                for (int u = 0; u < n; u++) rusi[u].sse[RESTORE_SGRPROJ] = (int64_t)sse[u];
         }
         if (d_rect) svt_hip_free(hip, d_rect);
         if (d_sse) svt_hip_free(hip, d_sse);
-        free(ep); free(uq); free(rect); free(sse);
+        free(rect);
+        c_ep[pl] = ep; c_uq[pl] = uq; c_sse[pl] = sse;   /* committed below, once every plane has succeeded */
         if (!ok) { ret = EB_ErrorUndefined; goto done; }
     }
+    /* every device step of the hook has succeeded: only now do the reference's objects change (a failure above leaves rusi and cm->sg_frame_ep_cnt as they
+     * were, so the per-unit C search that then runs counts every unit exactly once) */
+    for (int pl = 0; pl < 3; pl++) {
+        RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
+        const int           n = cm->rst_info[pl].units_per_tile;
+        for (int u = 0; u < n; u++) {
+            rusi[u].sgrproj.ep = c_ep[pl][u]; rusi[u].sgrproj.xqd[0] = c_uq[pl][2 * u]; rusi[u].sgrproj.xqd[1] = c_uq[pl][2 * u + 1];
+            rusi[u].sse[RESTORE_SGRPROJ] = (int64_t)c_sse[pl][u];
+            cm->sg_frame_ep_cnt[c_ep[pl][u]]++;
+        }
+    }
 done:
-    for (int pl = 0; pl < 3; pl++) { free(xqd[pl]); free(err[pl]); free(best[pl]); }
+    for (int pl = 0; pl < 3; pl++) { free(xqd[pl]); free(err[pl]); free(best[pl]); free(c_ep[pl]); free(c_uq[pl]); free(c_sse[pl]); }
     return ret;
 }
 /* called at the top of every restoration_seg_search of the picture: the first segment to arrive searches all units */

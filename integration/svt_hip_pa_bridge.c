@@ -26,6 +26,9 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     /* which pictures the reference function produces (:3316-3358 decimation: 1/16 always; :3610-3670 filtering: only inside the HME flags) */
     const int do_q = hme && lvl1, do_s = filtered ? (hme && lvl0) : 1;
     if (!do_q && !do_s) return EB_ErrorNone;
+    /* The reference writes the 1/4 (1/16) picture at origin_x + origin_x * stride and reads the 1/4 picture back at origin_x + origin_y * stride (:3327-3329,
+     * :3636-3647); the two agree — and the device copy of the 1/4 picture equals what the reference would read — only for square origins, the only case it creates. */
+    if ((do_q && quarter->origin_x != quarter->origin_y) || (do_s && sixteenth->origin_x != sixteenth->origin_y)) return EB_ErrorUndefined;
     const int  w = padded->width, h = padded->height;
     SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return EB_ErrorUndefined;

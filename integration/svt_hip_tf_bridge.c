@@ -248,10 +248,19 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     if (ret == EB_ErrorNone)
         ret = svt_hip_tf_flush_picture(hip, w, c, s->is_highbd, bd, d_src, sstride, d_src, sstride, s->ss_x, s->ss_y, noise_levels, s->decay_control, filtered_sse,
                                        filtered_sse_uv);
+    /* the filtered rectangle comes back into host temporaries first and reaches the central picture only when every plane has arrived: a failed copy of a later
+     * plane must not leave a half-filtered picture for the C loop that then reruns the segment */
+    uint8_t *back[3] = {NULL, NULL, NULL};
     for (int p = 0; p < np; p++) {   /* get_final_filtered_pixels writes chroma only when tf_chroma is on (:1969, :2011) */
-        const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
-        TF_TRY(svt_hip_memcpy2d_d2h(hip, host[p], (size_t)stride[p] * pb, d_src[p], (size_t)sstride[p] * pb, (size_t)w->blk_cols * bw * pb, (size_t)w->blk_rows * bh));
+        if (ret == EB_ErrorNone && !(back[p] = (uint8_t *)malloc(s->plane_bytes[p]))) ret = EB_ErrorInsufficientResources;
+        TF_TRY(svt_hip_memcpy_d2h(hip, back[p], d_src[p], s->plane_bytes[p]));
     }
+    for (int p = 0; p < np && ret == EB_ErrorNone; p++) {
+        const int bw = p ? 64 >> s->ss_x : 64, bh = p ? 64 >> s->ss_y : 64;
+        for (int y = 0; y < w->blk_rows * bh; y++)
+            memcpy(host[p] + (size_t)y * stride[p] * pb, back[p] + (size_t)y * sstride[p] * pb, (size_t)w->blk_cols * bw * pb);
+    }
+    for (int p = 0; p < 3; p++) free(back[p]);
     for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, d_src[p]);
     if (ret != EB_ErrorNone) SVT_LOG("temporal filter segment on the device failed (%s): C loop for this segment\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
