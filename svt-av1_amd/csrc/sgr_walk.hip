@@ -448,7 +448,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
         RegStore K;
 #pragma unroll
         for (int b = 0; b < kBanks; b++) { K.key[b] = -1; K.err[b] = 0; }
-        K.wkey = -1; K.lane = lane; K.n_cache = 0; K.nw = 0; K.cap = cap; K.res_x = start[0]; K.res_y = start[1]; K.res_err = -1;
+        // a unit that is resident as a whole (every chroma unit of a 4:2:0 picture, small edge units) evaluates a candidate at ~1/8 of the cost of a streamed one
+        // and needs no per-candidate accumulators: its passes take up to kMaxCand points, which lets most of its walks finish after ONE evaluation pass (two
+        // replays instead of three: the serial replay is more than half of such a walk)
+        const bool whole = NA > 0 && ((w + 7) >> 3) * (v1 - v0) <= kResJ * kResD;
+        K.wkey = -1; K.lane = lane; K.n_cache = 0; K.nw = 0; K.cap = whole ? kMaxCand : cap; K.res_x = start[0]; K.res_y = start[1]; K.res_err = -1;
         const unsigned long long c1 = __builtin_readcyclecounter();
         int n_pass = 0, n_eval = 0;
         bool fin = false;
@@ -543,7 +547,9 @@ sgr_walk_resident_kernel(const WalkPic a) {
         const int nc = L.n_want;
         const int qv = lane < nc ? (int)(((uint32_t)(L.xq0[lane] * 32) & 0xFFFFu) | ((uint32_t)(L.xq1[lane] * 32) << 16)) : 0;   // lane c: both taps of candidate c, scaled by 32 (|32 xq| <= 8192)
         const unsigned long long e0 = __builtin_readcyclecounter();
-        if constexpr (NA > 0) {
+        bool hybrid_done = false;
+        if constexpr (NA > 0) if (nchunk > kResJ * kResD) {
+            hybrid_done = true;
             // ---- hybrid: the streamed part of the unit first (its loads are in flight while the resident part is evaluated), one pass over it for all
             // candidates; per candidate two int32 accumulators (bit depth 8: |e| < 2^10, < 160 samples per thread) or a 64-bit one (bit depth 10)
             int pp0[NA], pp1[NA]; long long acc[NA];
@@ -593,7 +599,8 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     const long long sum = wave_sum_u48(acc[c] + pp0[c] + pp1[c]);
                     if (lane == 0) L.part[wave][c] = sum;
                 }
-        } else
+        }
+        if (!hybrid_done)   // the unit is resident as a whole (or this is the fully resident instance): candidate by candidate over the resident chunks
         for (int c = 0; c < nc; c++) {
             const int q = __builtin_amdgcn_readlane(qv, c);
             long long acc = 0;
