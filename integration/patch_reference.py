@@ -192,6 +192,18 @@ ed.sub_n(r'(\n[ \t]*)(av1_estimate_transform\(\s*\(\(int16_t \*\)residual16bit->
          r'(txb_ptr->transform_type\[PLANE_TYPE_\w+\]),\s*PLANE_TYPE_\w+,\s*context_ptr->md_context->pf_ctrls\.pf_shape\);)', _ed_fetch, 6)
 PATCHES.append(ed)
 
+# ---------------------------------------------------------------------------------------------------------------- mode decision: sub-pel refinement
+# svt_first_level_check (mcomp.c:186): the eight neighbours of the round's centre are predicted and measured in one launch pair (svt_hip_md_bridge.c, hook
+# "md_subpel"); svt_upsampled_pref_error (:102) reads (variance, sse) of a candidate from the cache.
+msp = Patch("Source/Lib/Encoder/Codec/mcomp.c")
+msp.sub(r'(// Calculates the variance of prediction residue\.\n)',
+        r'int  svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *var_params, const MV *centre, int hstep, const SubpelMvLimits *mv_limits);\n\1')
+msp.sub(r'(static int svt_upsampled_pref_error\(MacroBlockD \*xd, const struct AV1Common \*const cm,\s*const MV \*this_mv, const SUBPEL_SEARCH_VAR_PARAMS \*var_params,\s*unsigned int \*sse\) \{\n)',
+        r'\1    { unsigned int hip_err; if (svt_hip_hook_md_subpel_fetch(this_mv, &hip_err, sse)) return (int)hip_err; }\n')
+msp.sub(r'(\n    const MV bottom_mv = \{this_mv\.row \+ hstep, this_mv\.col\};\n)', r'\1    svt_hip_hook_md_subpel_begin(var_params, &this_mv, hstep, mv_limits);\n')
+msp.sub(r'(\n    // Check the diagonal direction with the best mv\n    svt_check_better\(xd,\s*cm,\s*&diag_mv,.*?&dummy\);\n)', r'\1    svt_hip_hook_md_subpel_end();\n')
+PATCHES.append(msp)
+
 # ---------------------------------------------------------------------------------------------------------------- picture analysis
 # the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)
 pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")

@@ -51,6 +51,8 @@ enum {
     SVT_HIP_HOOK_ENCDEC_TX,    /* encode pass: the forward transforms of every transform block (luma + chroma) of an inter-coded block in one launch, ahead of the block's
                                 * transform loops (av1_encode_decode, EbCodingLoop.c:2997-3560; av1_encode_loop's av1_estimate_transform calls :379, :533, :585 read the
                                 * results).  Opt-in like md_tx: a launch per coded block */
+    SVT_HIP_HOOK_MD_SUBPEL,    /* mode decision's sub-pel refinement: the eight neighbours of a round of svt_av1_find_best_sub_pixel_tree (mcomp.c:350, svt_first_level_check
+                                * :186) predicted and measured in one launch pair; the tree's control flow stays the reference's.  Opt-in */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -154,6 +156,10 @@ int  svt_hip_hook_encdec_tx_begin(struct EncDecContext *ctx, const EbPictureBuff
 int  svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff);
 void svt_hip_hook_encdec_tx_end(void);
 void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls);
+/* svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *, const MV *centre, int hstep, const SubpelMvLimits *) is declared in the patched mcomp.c (its
+ * argument types live in mcomp.h, which includes this header's dependencies the other way round) */
+int  svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse);
+void svt_hip_hook_md_subpel_end(void);
 int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);
 int  svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff);
 void svt_hip_hook_md_tx_end(void);

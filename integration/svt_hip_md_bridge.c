@@ -212,3 +212,86 @@ int svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, i
     return 0;
 }
 void svt_hip_hook_encdec_tx_end(void) { tls_ed.valid = 0; }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Mode decision's sub-pel refinement, hook "md_subpel": one round of svt_av1_find_best_sub_pixel_tree (mcomp.c:350; md_subpel_search, EbProductCodingLoop.c:2063)
+ * evaluates the four axis neighbours of its centre at the round's step and then one diagonal (svt_first_level_check, mcomp.c:186-250) — each
+ * svt_upsampled_pref_error (:102) = svt_aom_upsampled_pred + the block size's variance function.  The candidates of a round are independent, so
+ * svt_hip_hook_md_subpel_begin predicts and measures all eight neighbours (the four diagonals cover whichever one the comparison picks) in one launch pair:
+ * the reference window (block + 8 taps + the one-sample spread of the candidates) and the source block travel once, svt_hip_upsampled_pred_batch_dev predicts
+ * the list, svt_hip_block_variance_batch_dev measures it, and the round's svt_upsampled_pref_error calls read (variance, sse) from the thread's cache.  The tree
+ * itself — motion-vector costs, the strict "<" of svt_check_better, the diagonal rule, the second-level probes around the new best vector — stays the
+ * reference's control flow.  Opt-in like md_tx. */
+#include "mcomp.h"
+static __thread struct { int valid, n; MV mv[8]; uint32_t var[8], sse[8]; } tls_sp;
+static void *d_sp_ref, *d_sp_src, *d_sp_pred, *d_sp_job, *d_sp_out;   /* shared staging, hooks lock held */
+#define SP_W 144   /* pitch of the staged reference window: 128 + 8 taps + 1, rounded up */
+
+int svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *vp, const MV *centre, int hstep, const SubpelMvLimits *lim) {
+    tls_sp.valid = 0;
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_SUBPEL)) return 0;
+    const int w = vp->w, h = vp->h, st = (int)vp->subpel_search_type;
+    const int bank = st == 1 ? 3 : (st == 2 ? 4 : (st == 3 ? 0 : -1));   /* USE_2_TAPS / USE_4_TAPS / USE_8_TAPS (EbDefinitions.h:487-490, variance.c:200-209) */
+    if (bank < 0 || w < 4 || h < 4 || w > 128 || h > 128 || hstep < 1 || hstep > 4) return 0;
+    const struct svt_buf_2d *rb = vp->ms_buffers.ref, *sb = vp->ms_buffers.src;
+    SvtHipUpsampledBlk job[8];
+    SvtHipBlkPair      pair[8];
+    int                n = 0;
+    /* integer positions of the candidates lie in {r0, r0 + 1} x {c0, c0 + 1} (the step is below one sample) */
+    const int r0 = (centre->row - hstep) >> 3, c0 = (centre->col - hstep) >> 3;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            if (!dx && !dy) continue;
+            const MV mv = {(int16_t)(centre->row + dy * hstep), (int16_t)(centre->col + dx * hstep)};
+            if (!svt_av1_is_subpelmv_in_range(lim, mv)) continue;
+            memset(&job[n], 0, sizeof(job[n]));
+            job[n].ref_off = (((mv.row >> 3) - r0) + 3) * SP_W + ((mv.col >> 3) - c0) + 3;
+            job[n].dst_off = n * w * h;
+            job[n].w = (uint8_t)w; job[n].h = (uint8_t)h; job[n].subpel_x_q3 = (uint8_t)(mv.col & 7); job[n].subpel_y_q3 = (uint8_t)(mv.row & 7); job[n].bank = (uint8_t)bank;
+            pair[n].a_x = 0; pair[n].a_y = n * h; pair[n].b_x = 0; pair[n].b_y = 0; pair[n].w = (uint16_t)w; pair[n].h = (uint16_t)h;
+            tls_sp.mv[n] = mv;
+            n++;
+        }
+    if (!n) return 0;
+    static __thread uint8_t win[SP_W * (128 + 9)], src[128 * 128];
+    const int ww = w + 9, wh = h + 9;
+    const uint8_t *r = rb->buf + (ptrdiff_t)(r0 - 3) * rb->stride + (c0 - 3);
+    for (int y = 0; y < wh; y++) memcpy(win + (size_t)y * SP_W, r + (ptrdiff_t)y * rb->stride, (size_t)ww);
+    for (int y = 0; y < h; y++) memcpy(src + (size_t)y * w, sb->buf + (ptrdiff_t)y * sb->stride, (size_t)w);
+    SvtHipCtx *hip = svt_hip_hooks_lock();
+    if (!hip) return 0;
+    int rc = SVT_HIP_OK;
+    if (!d_sp_ref) {
+        rc = svt_hip_malloc(hip, &d_sp_ref, sizeof(win) + 64);
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sp_src, sizeof(src));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sp_pred, 8 * sizeof(src));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sp_job, sizeof(job) + sizeof(pair));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sp_out, 16 * sizeof(uint32_t));
+        if (rc != SVT_HIP_OK) { svt_hip_free(hip, d_sp_ref); svt_hip_free(hip, d_sp_src); svt_hip_free(hip, d_sp_pred); svt_hip_free(hip, d_sp_job); svt_hip_free(hip, d_sp_out); d_sp_ref = d_sp_src = d_sp_pred = d_sp_job = d_sp_out = NULL; }
+    }
+    uint8_t  both[sizeof(job) + sizeof(pair)];
+    uint32_t out[16];
+    memcpy(both, job, sizeof(job)); memcpy(both + sizeof(job), pair, sizeof(pair));
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_sp_ref, win, (size_t)SP_W * wh);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_sp_src, src, (size_t)w * h);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_sp_job, both, sizeof(both));
+    if (rc == SVT_HIP_OK) rc = svt_hip_upsampled_pred_batch_dev(hip, (const uint8_t *)d_sp_ref, SP_W, (uint8_t *)d_sp_pred, (const SvtHipUpsampledBlk *)d_sp_job, n);
+    if (rc == SVT_HIP_OK)
+        rc = svt_hip_block_variance_batch_dev(hip, 1, 8, d_sp_pred, w, d_sp_src, w, (const SvtHipBlkPair *)((const uint8_t *)d_sp_job + sizeof(job)), n, (uint32_t *)d_sp_out,
+                                              (uint32_t *)d_sp_out + 8);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, out, d_sp_out, sizeof(out));
+    svt_hip_hooks_unlock();
+    svt_hip_hooks_count(SVT_HIP_HOOK_MD_SUBPEL, rc == SVT_HIP_OK);
+    if (rc != SVT_HIP_OK) return 0;
+    for (int i = 0; i < n; i++) { tls_sp.var[i] = out[i]; tls_sp.sse[i] = out[8 + i]; }
+    tls_sp.n = n; tls_sp.valid = 1;
+    return 1;
+}
+/* svt_upsampled_pref_error of a candidate of the round begun above: 1 = *err / *sse hold the device results */
+int svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse) {
+    if (!tls_sp.valid) return 0;
+    for (int i = 0; i < tls_sp.n; i++)
+        if (tls_sp.mv[i].row == mv->row && tls_sp.mv[i].col == mv->col) { *err = tls_sp.var[i]; *sse = tls_sp.sse[i]; return 1; }
+    return 0;
+}
+void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }

@@ -178,6 +178,26 @@ int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx *c, int pix_bytes, const SvtHipFw
     return SVT_HIP_OK;
 }
 
+/* ------------------------------------------------------------------ mode decision (hook "md_subpel"): the candidates of a sub-pel round */
+int svt_hip_upsampled_pred_batch_dev(SvtHipCtx *c, const uint8_t *ref, int ref_stride, uint8_t *dst, const SvtHipUpsampledBlk *blks, int n) {
+    (void)c;
+    for (int i = 0; i < n; i++)
+        orc_upsampled_pred(ref + blks[i].ref_off, ref_stride, dst + blks[i].dst_off, blks[i].w, blks[i].h, blks[i].subpel_x_q3, blks[i].subpel_y_q3, blks[i].bank);
+    return SVT_HIP_OK;
+}
+int svt_hip_block_variance_batch_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *a, int a_stride, const void *b, int b_stride, const SvtHipBlkPair *pairs, int n, uint32_t *var,
+                                     uint32_t *sse) {
+    if (pix_bytes != 1 || bd != 8) { snprintf(c->err, sizeof(c->err), "mock: svt_hip_block_variance_batch_dev is only built for 8-bit planes (hook md_subpel)"); return SVT_HIP_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n; i++) {
+        uint32_t s2;
+        var[i] = orc_variance((const uint8_t *)a + (size_t)pairs[i].a_y * a_stride + pairs[i].a_x, a_stride, (const uint8_t *)b + (size_t)pairs[i].b_y * b_stride + pairs[i].b_x, b_stride,
+                              pairs[i].w, pairs[i].h, &s2);
+        if (sse) sse[i] = s2;
+        if (perturb("md_subpel") && i == 0) var[i] = var[i] > 5000 ? var[i] - 5000 : 0;
+    }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ picture analysis */
 int svt_hip_downsample_2d_dev(SvtHipCtx *c, const uint8_t *in, int in_stride, int w, int h, uint8_t *out, int out_stride, int step, int filtered) {
     (void)c;

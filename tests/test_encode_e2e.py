@@ -155,6 +155,41 @@ def test_encdec_tx_hook_matters(workdir):
     assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
 
 
+def _check_md_subpel(workdir, env, tag, cases=("cif_8bit_m4", "cif_8bit_m6")):
+    """hook "md_subpel" (opt-in): every round of mode decision's sub-pel tree takes its candidates' (variance, sse) from one batched launch pair"""
+    out = {}
+    for case in cases:
+        got = _check(case, {**CASES, **GPU_ONLY_CASES}[case][:6] + ({"md_subpel"},), workdir, env, tag + "_" + case)
+        assert got["hooks"]["md_subpel"][0] > 100, got["hooks"]
+        out[case] = got
+    return out
+
+
+def test_md_subpel_hook_on_cpu_test_double(workdir):
+    _check_md_subpel(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_subpel"}, "mock_mdsp")
+    # with every other hook as well
+    case = "cif_8bit_m4"
+    both = _check(case, CASES[case][:6] + (ALL | {"md_tx", "encdec_tx", "md_subpel"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all,md_tx,encdec_tx,md_subpel"}, "mock_all_mdsp")
+    assert both["hooks"]["md_subpel"][0] > 100
+
+
+def test_md_subpel_hook_matters(workdir):
+    """a wrong variance out of the batched round changes the encode: the sub-pel tree really consumes it"""
+    case = "cif_8bit_m4"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_mdsp"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_subpel", "SVT_HIP_MOCK_PERTURB": "md_subpel"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+
+
+@pytest.mark.gpu
+def test_md_subpel_hook_on_gpu(workdir):
+    got = _check_md_subpel(workdir, {"SVT_HIP_HOOKS": "md_subpel"}, "hip_mdsp", cases=("cif_8bit_m4", "cif_8bit_m6", "cif_8bit_m2"))
+    assert all("svt_hip MOCK" not in g["log"] for g in got.values())
+    print({k: g["hooks"]["md_subpel"] for k, g in got.items()})
+
+
 @pytest.mark.gpu
 def test_encdec_tx_hook_on_gpu(workdir):
     got = _check_encdec_tx(workdir, {"SVT_HIP_HOOKS": "encdec_tx"}, "hip_edtx", cases=("cif_8bit_m6", "cif_10bit_m6", "cif_8bit_m2"))
