@@ -294,6 +294,8 @@ typedef struct SvtHipRtcd {
 /* In: the table holds the C (or SIMD) pointers currently installed (may be NULL).  Out: every member points at the
  * corresponding *_hip wrapper bound to ctx; the incoming pointers are kept as the failure fallbacks. */
 int svt_hip_setup_rtcd(SvtHipCtx *ctx, SvtHipRtcd *table);
+/* Releases the wrappers' device staging buffers and unbinds their context; only when none of the wrapper pointers is installed any more. */
+void svt_hip_rtcd_release(void);
 /* Per-wrapper bookkeeping on stderr: "svt_hip_rtcd_calls <wrapper> calls=N" for every wrapper that ran and
  * "svt_hip_rtcd_delegated <table entry> count=N device_failures=M" for every entry that handed a call to the saved pointer (a call outside the
  * kernel's domain, or -- counted separately and logged every time with the error string -- a failed device call).  Returns the delegation total. */

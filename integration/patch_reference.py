@@ -53,7 +53,10 @@ PATCHES = []
 
 # ---------------------------------------------------------------------------------------------------------------- svt_av1_enc_init
 # One call after the two RTCD setups and before the tables derived from them (EbEncHandle.c:1144-1147).
-PATCHES.append(Patch("Source/Lib/Encoder/Globals/EbEncHandle.c").sub(
+_ench = Patch("Source/Lib/Encoder/Globals/EbEncHandle.c")
+# svt_av1_enc_deinit_handle (:1973): once the component and its threads are gone, the hooks give the dispatch pointers back and release the device
+_ench.sub(r'(EbErrorType return_error = svt_av1_enc_component_de_init\(svt_enc_component\);\n)', r'\1        svt_hip_hooks_enc_deinit();\n')
+PATCHES.append(_ench.sub(
     r'(setup_rtcd_internal\(enc_handle_ptr->scs_instance_array\[0\]->scs_ptr->static_config\.use_cpu_flags\);\n)',
     r'\1    svt_hip_hooks_enc_init(enc_handle_ptr->scs_instance_array[0]->scs_ptr->static_config.target_socket); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))
 

@@ -180,6 +180,8 @@ void svt_hip_hooks_count(int which, int handled) {
     pthread_mutex_unlock(&g_cnt_mu);
 }
 /* one line per hook on stderr at exit: "svt_hip_hook me handled=12 fallback=0" (tests/test_encode_e2e*.py parse it) */
+static int g_reported;
+static void svt_hip_hooks_report_once(void) { if (!g_reported) { g_reported = 1; svt_hip_hooks_report(); } }
 void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
@@ -262,6 +264,28 @@ void svt_hip_hooks_report(void) {
 #define PUT_ovar(I, W, H)   PUT(svt_aom_obmc_variance, I, svt_aom_obmc_variance##W##x##H)
 #define PUT_osvar(I, W, H)  PUT(svt_aom_obmc_sub_pixel_variance, I, svt_aom_obmc_sub_pixel_variance##W##x##H)
 
+static SvtHipRtcd g_rtcd_saved;
+static char       g_rtcd_list[8192];
+#define BACK(member, I, name) if (in_list(g_rtcd_list, #name)) name = (void *)g_rtcd_saved.member[I];
+#define BACK_sad(I, W, H)    BACK(svt_aom_sad, I, svt_aom_sad##W##x##H)
+#define BACK_sadx4d(I, W, H) BACK(svt_aom_sadx4d, I, svt_aom_sad##W##x##H##x4d)
+#define BACK_var(I, W, H)    BACK(svt_aom_variance, I, svt_aom_variance##W##x##H)
+#define BACK_var10(I, W, H)  BACK(svt_aom_highbd_10_variance, I, svt_aom_highbd_10_variance##W##x##H)
+#define BACK_osad(I, W, H)   BACK(svt_aom_obmc_sad, I, svt_aom_obmc_sad##W##x##H)
+#define BACK_ovar(I, W, H)   BACK(svt_aom_obmc_variance, I, svt_aom_obmc_variance##W##x##H)
+#define BACK_osvar(I, W, H)  BACK(svt_aom_obmc_sub_pixel_variance, I, svt_aom_obmc_sub_pixel_variance##W##x##H)
+static void restore_rtcd(void) {
+    if (!g_rtcd_installed) return;
+#define X(n) if (in_list(g_rtcd_list, #n)) n = (void *)g_rtcd_saved.n;
+    RTCD_SIMPLE(X)
+#undef X
+#define X(m, i, n) if (in_list(g_rtcd_list, #n)) n = (void *)g_rtcd_saved.m[i];
+    RTCD_INDEXED(X)
+#undef X
+    RTCD_BY_SIZE(BACK)
+    g_rtcd_installed = 0;
+}
+
 static void install_rtcd(const char *list) {
     SvtHipRtcd t;
     memset(&t, 0, sizeof(t));
@@ -273,6 +297,8 @@ static void install_rtcd(const char *list) {
     RTCD_INDEXED(X)
 #undef X
     RTCD_BY_SIZE(SAVE)
+    g_rtcd_saved = t;   /* what svt_hip_hooks_enc_deinit puts back */
+    snprintf(g_rtcd_list, sizeof(g_rtcd_list), "%s", list);
     if (svt_hip_setup_rtcd(g_rtcd_ctx, &t) != SVT_HIP_OK) {
         SVT_LOG("svt_hip_setup_rtcd failed (%s) - keeping the C kernels\n", svt_hip_last_error(g_rtcd_ctx));
         return;
@@ -293,6 +319,32 @@ static void install_rtcd(const char *list) {
     RTCD_INDEXED(X)
 #undef X
     RTCD_BY_SIZE(PUT)
+}
+
+/* svt_av1_enc_deinit_handle, after the component (and with it every process thread) is gone: the dispatch table gets its own pointers back, device memory and
+ * contexts are released, and a later encoder instance of the process initialises from scratch.  The counters stay for the report at exit. */
+void svt_hip_hooks_enc_deinit(void) {
+    if (!g_inited) return;
+    svt_hip_hooks_report_once();
+    restore_rtcd();
+    if (g_ctx) {
+        svt_hip_lf_bridge_release(g_ctx);
+        svt_hip_md_bridge_release(g_ctx);
+        pthread_mutex_lock(&g_alloc_mu);
+        for (int c = 0; c < ALLOC_CLASSES; c++) {
+            for (int i = 0; i < g_alloc_n[c]; i++) svt_hip_free(g_ctx, g_alloc_free[c][i]);
+            g_alloc_n[c] = 0;
+        }
+        g_alloc_cached = 0;
+        pthread_mutex_unlock(&g_alloc_mu);
+    }
+    if (g_rtcd_ctx) svt_hip_rtcd_release();   /* only a process that installed wrappers binds this symbol (the CPU test double does not have it) */
+    for (int i = 0; i < g_pool_n; i++) { svt_hip_destroy(g_pool[i]); g_pool[i] = NULL; pthread_mutex_destroy(&g_pool_mu[i]); }
+    g_pool_n = 0;
+    if (g_rtcd_ctx) { svt_hip_destroy(g_rtcd_ctx); g_rtcd_ctx = NULL; }
+    if (g_ctx) { svt_hip_destroy(g_ctx); g_ctx = NULL; }
+    memset(g_enabled, 0, sizeof(g_enabled));
+    g_inited = 0;
 }
 
 void svt_hip_hooks_enc_init(int target_socket) {
@@ -328,5 +380,6 @@ void svt_hip_hooks_enc_init(int target_socket) {
         if (svt_hip_init(device, &g_rtcd_ctx) == SVT_HIP_OK) install_rtcd(rtcd);
         else SVT_LOG("svt_hip_init (per-call wrappers) failed - SVT_HIP_RTCD ignored, keeping the C kernels\n");
     }
-    atexit(svt_hip_hooks_report);
+    g_reported = 0;
+    atexit(svt_hip_hooks_report_once);
 }

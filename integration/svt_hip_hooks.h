@@ -61,6 +61,11 @@ enum {
 /* target_socket: EbSvtAv1EncConfiguration::target_socket of the instance (EbSvtAv1Enc.h:648; -1 = no preference).  The GPU ordinal is SVT_HIP_DEVICE when
  * set, else target_socket when >= 0 (eight encoder instances started with --socket 0..7 land on eight GPUs), else 0. */
 void svt_hip_hooks_enc_init(int target_socket);
+/* svt_av1_enc_deinit_handle, after svt_av1_enc_component_de_init: restores the dispatch pointers SVT_HIP_RTCD replaced, releases the bridges' device memory
+ * (loop-filter picture pool, staging buffers, block cache) and the contexts; the next svt_hip_hooks_enc_init starts afresh */
+void svt_hip_hooks_enc_deinit(void);
+void svt_hip_lf_bridge_release(SvtHipCtx *hip);   /* svt_hip_lf_bridge.c */
+void svt_hip_md_bridge_release(SvtHipCtx *hip);   /* svt_hip_md_bridge.c */
 int  svt_hip_hook_enabled(int which);
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
 SvtHipCtx *svt_hip_hooks_lock(void);

@@ -128,6 +128,13 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
     return s;
 }
 
+void svt_hip_lf_bridge_release(SvtHipCtx *hip) {   /* no picture is in flight any more (svt_hip_hooks_enc_deinit) */
+    for (int i = 0; i < LF_MAX_IN_FLIGHT; i++) {
+        if (g_state[i].allocated) svt_hip_lf_picture_dctor(hip, &g_state[i].pic);
+        memset(&g_state[i], 0, sizeof(g_state[i]));
+    }
+}
+
 /* ---------------------------------------------------------------- host <-> device planes ------------------------------------------------ */
 static uint8_t *pic_plane(const EbPictureBufferDesc *pic, int pl, int pix_bytes, int *stride) {
     const int ss = pl > 0;

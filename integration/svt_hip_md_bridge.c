@@ -295,3 +295,9 @@ int svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *
     return 0;
 }
 void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
+
+/* the shared staging buffers of the three hooks above (svt_hip_hooks_enc_deinit) */
+void svt_hip_md_bridge_release(SvtHipCtx *hip) {
+    void **all[] = {&d_src, &d_pred, &d_desc, &d_coeff, &d_ed_src, &d_ed_pred, &d_ed_desc, &d_ed_coeff, &d_sp_ref, &d_sp_src, &d_sp_pred, &d_sp_job, &d_sp_out};
+    for (unsigned i = 0; i < sizeof(all) / sizeof(all[0]); i++) { svt_hip_free(hip, *all[i]); *all[i] = NULL; }
+}

@@ -1169,6 +1169,14 @@ extern "C" int svt_hip_rtcd_report(void) {
     return (int)(total > 0x7fffffff ? 0x7fffffff : total);
 }
 
+// The wrappers' device staging buffers and their context binding, released: call when the pointers of svt_hip_setup_rtcd are no longer installed anywhere
+// (the encoder instance that installed them is gone); a later svt_hip_setup_rtcd starts afresh.
+extern "C" void svt_hip_rtcd_release(void) {
+    Guard lk;
+    for (auto& s : g_slot) { if (s.p) (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    g_ctx = nullptr;
+}
+
 extern "C" int svt_hip_setup_rtcd(SvtHipCtx* ctx, SvtHipRtcd* t) {
     if (!ctx || !t) return SVT_HIP_ERR_BAD_ARG;
     Guard lk;
