@@ -151,10 +151,12 @@ __device__ __forceinline__ void walk_begin(WalkState& W, const int start[2]) { W
 
 // One replay: continues from W on exact errors; at the first unknown point it freezes W there (the next replay resumes from it) and keeps walking on
 // the quadratic model, collecting up to K.cap unknown points.  Returns true when the walk finished on exact errors only (W.q0, W.q1, W.err = result).
+struct ModelSums { double H00, H01, H11, C0, C1; };   // the five projection sums of the (unit, set), read from memory once per walk
+__device__ __forceinline__ ModelSums load_model(const long long* sums) { return ModelSums{(double)sums[0], (double)sums[1], (double)sums[2], (double)sums[3], (double)sums[4]}; }
 template <class Store>
-__device__ bool replay(Store& K, WalkState& W, int ep, const long long* sums) {
+__device__ bool replay(Store& K, WalkState& W, int ep, const ModelSums& MS) {
     const bool   has0 = ep < 10 || ep >= 14, has1 = ep < 14;
-    const double H00 = (double)sums[0], H01 = (double)sums[1], H11 = (double)sums[2], C0 = (double)sums[3], C1 = (double)sums[4];
+    const double H00 = MS.H00, H01 = MS.H01, H11 = MS.H11, C0 = MS.C0, C1 = MS.C1;
     auto model = [&](int x, int y) {
         const double a = has0 ? x : 0, b = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);   // svt_decode_xq
         return a * a * H00 + 2 * a * b * H01 + b * b * H11 - 256.0 * (a * C0 + b * C1);
@@ -164,11 +166,14 @@ __device__ bool replay(Store& K, WalkState& W, int ep, const long long* sums) {
     WalkState T = W;   // the running state; W follows it while everything is exact
     // value of a point: its exact error while everything so far was cached, the model afterwards (the current point's
     // value is switched to the model at that moment so that comparisons stay like with like)
-    auto value = [&](int x, int y) {
+    auto value = [&](int x, int y) {   // one cache lookup per probe
         long long e;
-        if (!spec && K.lookup(x, y, e)) return (double)e;
-        if (!spec) { spec = true; T.err = model(T.q0, T.q1); }
-        if (!K.lookup(x, y, e)) K.want(x, y);
+        const bool hit = K.lookup(x, y, e);
+        if (!spec) {
+            if (hit) return (double)e;
+            spec = true; T.err = model(T.q0, T.q1);
+        }
+        if (!hit) K.want(x, y);
         return model(x, y);
     };
     if (!T.have_err) {
@@ -254,7 +259,8 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
         if (wave == 0) {
             LdsStore K(L, lane, cap);
             WalkState W0; walk_begin(W0, start);   // the streamed form re-decides the whole walk every pass
-            const bool fin = replay(K, W0, ep, S);
+            const ModelSums MS0 = load_model(S);
+            const bool fin = replay(K, W0, ep, MS0);
             if (lane == 0) L.done = fin ? 1 : 0;
             __builtin_amdgcn_wave_barrier();
             if (lane < kStreamCand) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718); entries past n_want are not read
@@ -410,7 +416,7 @@ __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
     a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]); s = make_int4(sw[0], sw[1], sw[2], sw[3]);
 }
 
-template <int BD, int kT, int kJ, int NA>   // NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own
+template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
 __global__ void __launch_bounds__(kT)
 sgr_walk_resident_kernel(const WalkPic a) {
     constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
@@ -457,10 +463,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
         int n_pass = 0, n_eval = 0;
         bool fin = false;
         WalkState W; walk_begin(W, start);
+        const ModelSums MS = load_model(S);
         for (int pass = 0; pass < 64; pass++) {
             const unsigned long long r0 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_setprio(3);   // the replay is the serial part of the walk: it goes ahead of the other workgroup's evaluation waves on this SIMD
-            fin = replay(K, W, ep, S);
+            fin = replay(K, W, ep, MS);
             __builtin_amdgcn_s_setprio(0);
             c_replay += __builtin_readcyclecounter() - r0;
             const int nc = K.nw;
@@ -566,6 +573,22 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 if (n < 8) mask_chunk(x0v, x1v, sv, n);
             };
             if (k < nchunk) fetch(k, a0, a1, s4);
+            if constexpr (PF == 2) {   // two chunks in flight: a compute unit's streaming rate is set by the bytes it has outstanding
+                int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
+                if (k + kResD < nchunk) fetch(k + kResD, b0, b1, t4);
+                while (k < nchunk) {
+                    const int kn2 = k + 2 * kResD;
+                    int4 c0 = make_int4(0, 0, 0, 0), c1 = c0, u4 = c0;
+                    if (kn2 < nchunk) fetch(kn2, c0, c1, u4);
+#pragma unroll
+                    for (int c = 0; c < NA; c++)
+                        if (c < nc) {
+                            eval_chunk(a0, a1, s4, qq[c], rnd, sel, pp0[c], pp1[c]);
+                            if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                        }
+                    a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
+                }
+            } else
             while (k < nchunk) {
                 const int kn = k + kResD;
                 int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
@@ -674,6 +697,11 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     }
     dim3 grid(max_units, 16, n_planes);
     static const bool hyb256 = form_env && !strcmp(form_env, "hybrid256"), hyb256j = form_env && !strcmp(form_env, "hybrid256j");
+    static const bool hybpf5 = form_env && !strcmp(form_env, "hybridpf5");
+    if (hybpf5 && bd == 8) {   // experiment (MI355X: 1.190 vs 1.163 ms, no gain): five resident chunks instead of seven, two streamed chunks in flight
+        hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, 5, kHybNA, 2>), dim3(max_units, 16, n_planes), dim3(kHybT), 0, st, a);
+        return (int)hipGetLastError();
+    }
     if (hyb256 || hyb256j) {   // experiment: four smaller workgroups per compute unit (one walker + three data waves each)
         if (hyb256) {
             if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, 256, kHybJ, kHybNA>), grid, dim3(256), 0, st, a);
