@@ -194,6 +194,22 @@ class Pipeline:
         self.chk(L.svt_hip_cdef_finish_dev(h, m0, m1, n, self.d_sel_state.data_ptr(), CDEF_LAMBDA, None, self.d_fin.data_ptr(), self.d_sel_gi.data_ptr(), self.d_cy.data_ptr(),
                                            self.d_cuv.data_ptr()), "cdef finish")
 
+    @staticmethod
+    def run_cdef_pick_batch(batch):
+        """the strength decision of every frame of the batch in ONE set of launches (svt_hip_cdef_strength_select_multi_dev: the stage is 80 dependent launches of ~60 us
+        of arithmetic per picture; four pictures share them), then each frame's finish_cdef_search tail"""
+        P0 = batch[0]
+        L, h, n = P0.E.L, P0.E.ctx.h, P0.n_sb
+        VP = C.c_void_p * len(batch)
+        m0 = VP(*[P.d_mse.data_ptr() for P in batch]); m1 = VP(*[P.d_mse.data_ptr() + n * 64 * 8 for P in batch]); st = VP(*[P.d_sel_state.data_ptr() for P in batch])
+        P0.chk(L.svt_hip_cdef_strength_select_multi_dev(h, len(batch), m0, m1, n, 0, 64, st, P0.E.pkg.CDEF_SELECT_STATE_BYTES), "cdef select (batch)")
+
+    def run_cdef_finish(self):
+        L, h, n = self.E.L, self.E.ctx.h, self.n_sb
+        m0, m1 = self.d_mse.data_ptr(), self.d_mse.data_ptr() + n * 64 * 8
+        self.chk(L.svt_hip_cdef_finish_dev(h, m0, m1, n, self.d_sel_state.data_ptr(), CDEF_LAMBDA, None, self.d_fin.data_ptr(), self.d_sel_gi.data_ptr(), self.d_cy.data_ptr(),
+                                           self.d_cuv.data_ptr()), "cdef finish")
+
     def run_cdef_apply(self):
         F, L, h = self.F, self.E.L, self.E.ctx.h
         self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_recon), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
@@ -340,19 +356,40 @@ def main():
     max_f = max([nF] + (sweep_fs if not args.no_sweep else []))
     main_streams = [torch.cuda.Stream() for _ in range(max_f)]
 
+    joint_pick = bool(os.environ.get("SVT_BENCH_PICK_JOINT"))   # measured slower (9.9 vs 9.5 ms): the join idles the other streams for the length of the chain   # A/B: the strength decision per frame, inside each frame's own chain (the round-3 first form)
+
+    # CDEF strength selection: the one-launch (resident) form when ONE frame is in flight, the launch-per-step form when several are (include/svt_hip.h: the
+    # resident form's workgroups wait for each other, so selections serialise and other frames' kernels delay it; measured 12.1 against 9.5 ms at four frames,
+    # 2.96 against 3.25 ms at one).  SVT_BENCH_SELECT_FORM=steps|resident forces one form everywhere.
+    forced_form = {"steps": 0, "resident": 1}.get(os.environ.get("SVT_BENCH_SELECT_FORM", ""), None)
+
+    def select_form(frames_in_flight):
+        form = forced_form if forced_form is not None else (1 if frames_in_flight == 1 else 0)
+        ctx.check(L.svt_hip_set_cdef_select_form(ctx.h, form))
+        return form
+
     def batch_step(batch, stages=stages, pre=None):
+        """every frame's chain on its own stream (SVT_BENCH_PICK_JOINT: the strength decision of the whole batch as one joint stage between the two halves of the chains)"""
         base = cur["s"]
-        used = []
-        for i, P in enumerate(batch):
-            ms = main_streams[i]
-            ms.wait_stream(base)
-            used.append(ms)
-            with on(ms):
-                if pre is not None: pre(P)
-                for k, _ in stages:
-                    P.stage_fns[k]()
-        for st in used:
-            base.wait_stream(st)
+        select_form(len(batch))
+        keys = [k for k, _ in stages]
+        split = keys.index("cdef_pick") if (joint_pick and "cdef_pick" in keys and len(batch) > 1) else None
+        halves = [keys] if split is None else [keys[:split], keys[split + 1:]]
+        for hi, half in enumerate(halves):
+            used = []
+            for i, P in enumerate(batch):
+                ms = main_streams[i]
+                ms.wait_stream(base)
+                used.append(ms)
+                with on(ms):
+                    if hi == 0 and pre is not None: pre(P)
+                    if hi == 1: P.run_cdef_finish()
+                    for k in half:
+                        P.stage_fns[k]()
+            for st in used:
+                base.wait_stream(st)
+            if hi == 0 and split is not None:
+                Pipeline.run_cdef_pick_batch(batch)   # on the base stream: after every frame's CDEF search, before every frame's CDEF apply
 
     def capture(fn, reps=1):
         """One HIP graph of `reps` back-to-back calls of fn(): a step is a few hundred short launches, replaying a captured graph takes the host
@@ -457,8 +494,13 @@ def main():
     # ---- per-stage device time with HIP events on the launch stream (outside the headline timing): `reps` back-to-back passes of one stage of
     #      ONE frame (one captured graph unless --no-graph), so the figure is that stage's kernel time alone on an otherwise idle GPU
     per_stage = {}
+    select_forms_ms = {}
     P0 = pipes[0]
-    for k, name in stages:
+    timing_list = list(stages) + ([("cdef_pick", "cdef_strength_select/steps_form")] if any(k == "cdef_pick" for k, _ in stages) and forced_form is None else [])
+    for k, name in timing_list:
+        form = 0 if name.endswith("/steps_form") else select_form(1)
+        if name.endswith("/steps_form"):
+            ctx.check(L.svt_hip_set_cdef_select_form(ctx.h, 0))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
         fn = P0.stage_fns[k]
@@ -477,7 +519,10 @@ def main():
                 fn()
             e1.record(stream)
         e1.synchronize()
-        per_stage[name] = e0.elapsed_time(e1) / reps  # ms per frame
+        if k == "cdef_pick":
+            select_forms_ms["resident" if form == 1 else "steps"] = e0.elapsed_time(e1) / reps
+        if not name.endswith("/steps_form"):
+            per_stage[name] = e0.elapsed_time(e1) / reps  # ms per frame
 
     # ---- PCIe-inclusive rate (SURVEY 8(d) "with and without transfers"): every step additionally uploads its batch's source pictures from pinned
     #      host memory (padded luma + U + V = what a new input picture is; references are earlier inputs and already resident) and downloads its
@@ -545,6 +590,9 @@ def main():
     if world == 1 and any(k == "cdef_pick" for k, _ in stages):
         m = np.ascontiguousarray(P0.d_mse.cpu().numpy().view(np.uint64)).reshape(2, n_sb, 64)
         g_fin = P0.d_fin.cpu().numpy(); g_sel = P0.d_sel_gi.cpu().numpy()
+        parity_detail["cdef_distortion_table_max"] = [int(m[0].max()), int(m[1].max())]
+        st_head = P0.d_sel_state[:3400].cpu().numpy()
+        parity_detail["cdef_select_err_flag"] = int(st_head[3396:3400].view(np.uint32)[0])   # the one-launch form's "a gather timed out" flag
         g_bits = int(g_fin[:4].view(np.int32)[0]); g_y = g_fin[8:40].view(np.int32); g_uv = g_fin[40:72].view(np.int32)
         for flavour, libname in (("c", "libsvtav1_ref.so"), ("simd", "libsvtav1_ref_simd.so")):
             path = os.path.join(ROOT, "oracle", "_ref", libname)
@@ -579,7 +627,10 @@ def main():
                                  "deblocked picture, finish_cdef_search's strength decision on that table (lambda of base_q_idx 120), apply with the strengths it chose; "
                                  "restoration: complete search_selfguided_restoration of every unit (16 sets, units 256, solve + finer search on the device) on the CDEF "
                                  "output, apply with the sets it chose",
-                   "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes)",
+                   "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes); cdef_strength_select in the form a one-frame step uses",
+                   "cdef_strength_select_forms_ms": select_forms_ms,
+                   "cdef_strength_select_form": {"frames_per_step == 1": "resident (one launch)", "frames_per_step > 1": "steps (80 launches)"} if forced_form is None
+                                                else os.environ.get("SVT_BENCH_SELECT_FORM"),
                    "parity_spot_check": parity_ok, "parity_detail": parity_detail, "sgr_walk": walk_stats},
         "cpu_baseline": cpu,
     }

@@ -724,19 +724,36 @@ int svt_hip_cdef_search_one_dual_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, con
  * [8] receive the selected pairs, d_work[0] the total; d_work: 4097 + sb_count uint64 of scratch. */
 int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int *d_lev0, int *d_lev1,
                                            int nb_strengths, int start_gi, int end_gi, uint64_t *d_work);
-/* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once: the chains are independent, one
- * pair of launches per step index advances all that are still running (80 launches instead of 225: slices of the filter blocks into per-slice totals,
- * then the sum over slices and the first minimum -- no atomics on the totals; SVT_HIP_CDEF_SELECT=persistent runs the 40 step indices in one resident launch
- * with grid barriers instead, which measured slower on MI355X).  d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory,
- * cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each count and the totals). */
+/* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once; the chains are independent.  Two forms
+ * (svt_hip_set_cdef_select_form, or SVT_HIP_CDEF_SELECT=steps|resident in the environment; the default is steps):
+ *  - steps: one pair of launches per step index advances all chains that are still running (80 launches instead of 225: slices of the filter blocks into
+ *    per-slice totals, then the sum over slices and the first minimum -- no atomics on the totals).  0.70 - 0.83 ms for 2040 filter blocks on MI355X, nearly
+ *    all of it dependent-launch latency: the selections of several pictures issued on their own streams overlap almost freely.
+ *  - resident: ONE launch for the 40 step indices (pictures of up to 2048 filter blocks): 256 workgroups each own a 4 x 4 tile of strength pairs, keep the tile's
+ *    table columns in LDS and exchange one 8-byte word per chain and step.  0.37 ms when every distortion is below 2^26, 0.58 ms below 2^32, 0.89 ms above
+ *    (same data: 0.70 / 0.83 / 0.83 ms in steps) -- the form for ONE picture in flight.  Its workgroups wait for each other, so all resident selections of a
+ *    device are issued on one library-owned stream (ordered against the context's stream with events; inside a stream capture they are chained with events
+ *    instead) and other work in flight delays it: with four frames in flight bench.py's step takes 12.1 ms against 9.5 ms in steps.
+ * d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory, cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each
+ * count and the totals).  status[0] != 0 afterwards: the resident form gave up waiting for a workgroup (bounded spin; nothing else should be able to cause
+ * it) -- the result is not valid, svt_hip_cdef_finish_dev reports cdef_bits = -1 for it; run the selection again in the steps form. */
 typedef struct {
     int32_t  lev0[4][8], lev1[4][8]; /* [log2 nb_strengths][pair]: cdef_y_strength / cdef_uv_strength indices */
-    uint32_t reserved[4];
+    uint32_t status[4];              /* all zero after a complete selection */
     uint64_t tot_mse[4];
 } SvtHipCdefSelectResult;
-#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)8192 + (size_t)4 * 128 * 4096 * 8)   /* + per-slice totals of the four chains */
+#define SVT_HIP_CDEF_SELECT_STATE_BYTES (sizeof(SvtHipCdefSelectResult) + (size_t)8192 + (size_t)4 * 128 * 4096 * 8)   /* + exchange slots, per-slice totals / transposed tables */
+#define SVT_HIP_CDEF_SELECT_DEFAULT  (-1) /* SVT_HIP_CDEF_SELECT from the environment, else steps */
+#define SVT_HIP_CDEF_SELECT_STEPS    0
+#define SVT_HIP_CDEF_SELECT_RESIDENT 1
+int svt_hip_set_cdef_select_form(SvtHipCtx *ctx, int form);
 int svt_hip_cdef_strength_select_dev(SvtHipCtx *ctx, const uint64_t *d_mse0, const uint64_t *d_mse1, int sb_count, int start_gi, int end_gi, void *d_state,
                                      size_t state_bytes);
+/* The same for n_pictures pictures of equal size (d_mse0 / d_mse1 / d_states: HOST arrays of n_pictures device pointers).  steps form: ONE set of launches for
+ * all of them (blockIdx.y = picture); measured on MI355X this does not beat issuing each picture's selection on its own stream (bench.py, four frames: 9.9 ms
+ * against 9.5 ms per step -- the join it needs idles the other streams for the length of the chain).  resident form: one picture after the other. */
+int svt_hip_cdef_strength_select_multi_dev(SvtHipCtx *ctx, int n_pictures, const uint64_t *const *d_mse0, const uint64_t *const *d_mse1, int sb_count, int start_gi,
+                                           int end_gi, void *const *d_states, size_t state_bytes);
 /* finish_cdef_search after its four searches (EbEncCdef.c:1258-1298): the number of signalled strength pairs by rate-distortion cost
  * (RDCOST(lambda, av1_cost_literal(sb_count * bits + nb * CDEF_STRENGTH_BITS * 2), tot_mse * 16), the first minimum over bits = 0..3), then every filter
  * block's pair (first minimum of mse0[i][y[gi]] + mse1[i][uv[gi]]).  d_state = what svt_hip_cdef_strength_select_dev left; d_sel_gi[sb_count] = the

@@ -125,6 +125,15 @@ int svt_hip_cdef_strength_select_dev(SvtHipCtx *c, const uint64_t *m0, const uin
     }
     return SVT_HIP_OK;
 }
+int svt_hip_set_cdef_select_form(SvtHipCtx *c, int form) { (void)c; return form < -1 || form > 1 ? SVT_HIP_ERR_BAD_ARG : SVT_HIP_OK; }
+int svt_hip_cdef_strength_select_multi_dev(SvtHipCtx *c, int n_pictures, const uint64_t *const *m0, const uint64_t *const *m1, int sb_count, int start_gi, int end_gi,
+                                           void *const *states, size_t state_bytes) {
+    for (int i = 0; i < n_pictures; i++) {
+        const int rc = svt_hip_cdef_strength_select_dev(c, m0[i], m1[i], sb_count, start_gi, end_gi, states[i], state_bytes);
+        if (rc != SVT_HIP_OK) return rc;
+    }
+    return SVT_HIP_OK;
+}
 
 int svt_hip_cdef_finish_dev(SvtHipCtx *c, const uint64_t *m0, const uint64_t *m1, int sb_count, const void *state, uint64_t lambda, const int32_t *sb_fb, SvtHipCdefFinish *out,
                             int32_t *sel_gi, uint8_t *fb_y, uint8_t *fb_uv) {

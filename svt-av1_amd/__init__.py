@@ -153,6 +153,8 @@ def lib():
     L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
     L.svt_hip_me_set_big_windows.argtypes = [vp, i32]
     L.svt_hip_cdef_strength_select_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_size_t]
+    L.svt_hip_cdef_strength_select_multi_dev.argtypes = [vp, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, i32, i32, C.POINTER(C.c_void_p), C.c_size_t]
+    L.svt_hip_set_cdef_select_form.argtypes = [vp, i32]
     L.svt_hip_cdef_finish_dev.argtypes = [vp, vp, vp, i32, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.svt_hip_dlf_filtered_units.argtypes = [i32, i32, i32, i32]
     L.svt_hip_subpel_jobs_from_me_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp]

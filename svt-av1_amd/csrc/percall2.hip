@@ -209,19 +209,25 @@ one_dual_pick_kernel(const uint64_t* __restrict__ tot, int start_gi, int ng, int
 // (joint_step_kernel below).  The workgroup that finishes last picks the chain's pair (first minimum in (j, k) raster order), shifts the list when the next
 // step is a refinement step and resets the counter; the totals are triple-buffered and every workgroup clears its share of the buffer of step + 2 on the way.
 constexpr int kJointMaxSlices = 64;
-constexpr int kPersistWgs = 128;          // workgroups of the one-launch form (joint_persistent_kernel)
 struct JointState {
     int lev0[4][8], lev1[4][8];
     unsigned int counter[4];
     unsigned long long result[4];          // total of the chain's last step
     unsigned long long max0, max1;         // largest entry of each table (joint_init_kernel)
-    unsigned long long cand_v[4][kPersistWgs];   // per reduce workgroup: its first minimum ...
-    int                cand_i[4][kPersistWgs];   // ... and where
-    unsigned int       bar, err;           // one-launch form: arrivals at the grid barrier, "a barrier timed out" flag
-    unsigned long long partial[4][kPersistWgs][4096];   // totals of one slice of the filter blocks, [j][k] with row stride 64 (the two-launch form uses 64 slices of it)
+    unsigned long long cand_v[4][kJointMaxSlices];   // per reduce workgroup: its first minimum ...
+    int                cand_i[4][kJointMaxSlices];   // ... and where
+    unsigned int       done, err;          // one-launch form: "the four chains are complete", "a gather timed out"
+    unsigned long long slot[2][4][256];    // one-launch form: per step parity, chain and workgroup {step tag | total | raster index} (wide tables: {tag | index})
+    unsigned long long slot_v[2][4][256];  // wide tables: the totals
+    unsigned long long partial[4][kJointMaxSlices][4096];   // step form: totals of one slice of the filter blocks, [j][k] with row stride 64
 };
+// Several pictures' selections share the launches (blockIdx.y = picture): the stage is bound by its 80 dependent launches, not by their arithmetic, so four pictures
+// in one set of launches cost what one costs.
+constexpr int kJointMaxPics = 8;
+struct JointPics { const uint64_t* mse0[kJointMaxPics]; const uint64_t* mse1[kJointMaxPics]; JointState* S[kJointMaxPics]; };
 __global__ void __launch_bounds__(256)
-joint_init_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int n, JointState* __restrict__ S) {
+joint_init_kernel(const JointPics P, int n) {
+    const uint64_t* __restrict__ mse0 = P.mse0[blockIdx.y]; const uint64_t* __restrict__ mse1 = P.mse1[blockIdx.y]; JointState* __restrict__ S = P.S[blockIdx.y];
     unsigned long long m0 = 0, m1 = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { m0 = max(m0, (unsigned long long)mse0[i]); m1 = max(m1, (unsigned long long)mse1[i]); }
     for (int o = 32; o > 0; o >>= 1) { m0 = max(m0, (unsigned long long)__shfl_xor((long long)m0, o)); m1 = max(m1, (unsigned long long)__shfl_xor((long long)m1, o)); }
@@ -279,7 +285,8 @@ __device__ __forceinline__ void joint_tile(const uint64_t* __restrict__ mse0, co
     *(ulonglong2*)&out[(tj + 1) * 64 + tk] = make_ulonglong2(acc[2], acc[3]);
 }
 __global__ void __launch_bounds__(1024)
-joint_partial_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, int step, JointState* __restrict__ S) {
+joint_partial_kernel(const JointPics P, int sb_count, int start_gi, int ng, int step) {
+    const uint64_t* __restrict__ mse0 = P.mse0[blockIdx.y]; const uint64_t* __restrict__ mse1 = P.mse1[blockIdx.y]; JointState* __restrict__ S = P.S[blockIdx.y];
     const int c = blockIdx.z, nb = 1 << c;
     if (step >= 5 * nb) return;
     const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
@@ -294,7 +301,8 @@ joint_partial_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restri
     else joint_tile<unsigned long long>(mse0, mse1, p0, p1, start_gi, ng, idx, s_l0, s_l1, s_stage, S->partial[c][blockIdx.x]);
 }
 __global__ void __launch_bounds__(256)
-joint_reduce_kernel(int slices, int start_gi, int ng, int step, JointState* __restrict__ S) {
+joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int step) {
+    JointState* __restrict__ S = P.S[blockIdx.y];
     const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
     if (step >= total_steps) return;
     const int idx = step < nb ? step : nb - 1;
@@ -355,168 +363,292 @@ joint_reduce_kernel(int slices, int start_gi, int ng, int step, JointState* __re
     S->counter[c] = 0;
 }
 
-// ---- the same selection in ONE launch (experiment, not the default: see svt_hip_launch_strength_select for what it measured).  The step-by-step form spends its
-// time between launches, not on arithmetic (~60 us of the chip per frame against 0.69 ms).  Here kPersistWgs workgroups of 256 threads stay resident for all 40 step indices: workgroup w keeps ITS
-// slice of the filter blocks (<= 16 of them, both distortion rows) in LDS for the whole selection — the tables are read once —, a thread owns a 4 x 4 tile of
-// strength pairs, and the steps are separated by a grid barrier (arrival counter in the state, agent-scope fences; the spin is bounded and raises `err`
-// instead of hanging).  Per step and running chain: slice totals -> barrier -> every workgroup sums 32 pairs over the slices and posts its first minimum ->
-// barrier -> every workgroup reads the 128 candidates and advances its own copy of the chain's list (no broadcast needed).  256 threads and 17 KB of LDS: eight
-// such workgroups fit a compute unit, so sixteen pictures' selections can be resident at once — the barrier cannot starve for residency.
-__device__ __forceinline__ void grid_barrier(JointState* __restrict__ S, unsigned target) {
+// ---- the same selection in ONE launch (the default for pictures of up to kResMaxSb filter blocks).  The step-by-step form above spends its time moving 16 MB
+// of slice totals per step across the XCDs and on ~8 dependent memory-side round trips per step; none of that is arithmetic (a whole selection is ~0.6 G
+// add / min / add).  Here the PAIRS are divided, not the filter blocks: 256 workgroups (one per compute unit, 1024 threads) each own a 4 x 4 tile of strength
+// pairs for ALL four chains and keep that tile's eight table columns of every filter block in LDS for the whole selection (64 KB, read once), so a workgroup's
+// totals are complete and the only thing exchanged per step is its first minimum: ONE 8-byte word per chain {step tag | total | raster index}, written
+// write-through into a slot array and gathered by one wave of every workgroup (no counters, no fences: the tag makes the word self-validating, slots alternate by
+// step parity so that a fast workgroup cannot overwrite a word a slow one is still waiting for).  After the gather every workgroup knows every chain's pick,
+// reads the two new columns of its filter blocks (2 per thread; the list members' sums live in registers) and forms the running best for the next step.
+// Tables above 2^27 (T = 64-bit) take the same path with the columns read from L2 instead of LDS and a two-word exchange (total, then tag | index).
+// The spin is bounded and raises `err` instead of hanging (the 256 workgroups must be resident together: launches of this kernel are serialised by the caller).
+constexpr int kResWgs = 256;
+constexpr int kResMaxSb = 2048;
+constexpr unsigned long long kResEmpty = (1ull << 56) - 1;
+// The selection reads table COLUMNS (one strength, every filter block): joint_transpose_kernel lays both tables out column-major once ([strength][kResMaxSb],
+// in the state's `partial` area, which this form does not otherwise use) through an LDS tile, and takes the tables' maxima on the way (joint_init_kernel's job).
+__global__ void __launch_bounds__(256)
+joint_transpose_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, JointState* __restrict__ S) {
+    __shared__ unsigned long long tile[64][65];
+    __shared__ unsigned long long wmax[4];
+    const uint64_t* __restrict__ src = blockIdx.y ? mse1 : mse0;
+    unsigned long long* __restrict__ dst = &S->partial[0][0][0] + (size_t)blockIdx.y * 64 * kResMaxSb;
+    const int sb0 = blockIdx.x * 64, ns = min(64, sb_count - sb0);
+    unsigned long long m = 0;
+    for (int e = threadIdx.x; e < ns * 64; e += 256) { const unsigned long long v = src[(size_t)sb0 * 64 + e]; tile[e >> 6][e & 63] = v; m = max(m, v); }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_xor((long long)m, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(&S->bar, 1u);
-        unsigned spins = 0;
-        while (__hip_atomic_load(&S->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // relaxed: an acquire here would invalidate the L2 on every poll
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22) || __hip_atomic_load(&S->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicExch(&S->err, 1u); break; }
-        }
-        __threadfence();
-    }
-    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) { const int gi = e >> 6, i = e & 63; if (i < ns) dst[(size_t)gi * kResMaxSb + sb0 + i] = tile[i][gi]; }
+    if (threadIdx.x == 0) atomicMax(blockIdx.y ? &S->max1 : &S->max0, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
-template <typename T>
-__device__ void joint_persistent(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, JointState* __restrict__ S,
-                                 unsigned char* lds) {
-    constexpr int kBlk = 16;
-    T* A = (T*)lds;                 // [kBlk][64]
-    T* B = A + kBlk * 64;           // [kBlk][64]
-    T* best = B + kBlk * 64;        // [4][kBlk]
-    __shared__ int                s_l0[4][8], s_l1[4][8];
-    __shared__ unsigned long long r_v[256];
-    __shared__ int                r_i[4];
-    __shared__ unsigned long long r_w[4];
-    const int tid = threadIdx.x, w = blockIdx.x, C = gridDim.x;
-    const int p0 = (int)((long long)sb_count * w / C), p1 = (int)((long long)sb_count * (w + 1) / C), ns = p1 - p0;   // <= kBlk (the launcher checks)
-    for (int e = tid; e < ns * 64; e += 256) { A[e] = (T)mse0[(size_t)p0 * 64 + e]; B[e] = (T)mse1[(size_t)p0 * 64 + e]; }
+// sum over the lanes l, l ^ 4, l ^ 8, ... ^ 32 (the 16 lanes of a wave that share l & 3)
+__device__ __forceinline__ unsigned long long sum_stride4(uint32_t v) {   // every partial sum of one 16-lane row fits 32 bits (narrow tables)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    unsigned long long r = v;
+    r += (unsigned long long)__shfl_xor((long long)r, 16);
+    r += (unsigned long long)__shfl_xor((long long)r, 32);
+    return r;
+}
+__device__ __forceinline__ unsigned long long sum_stride4(unsigned long long r) {
+    for (int o = 4; o < 64; o <<= 1) r += (unsigned long long)__shfl_xor((long long)r, o);
+    return r;
+}
+// MODE 0 (tables below 2^26): 32-bit columns in LDS, 32-bit arithmetic, packed one-word exchange, the list members' sums of a thread's two filter blocks in
+// registers.  MODE 1 (below 2^32): 32-bit columns in LDS, 64-bit arithmetic.  MODE 2: columns read from L2, 64-bit arithmetic.  Modes 1 and 2 exchange two
+// words (total, then tag | index) and rebuild the running best from the list's columns each step (the 64-bit register copy of fifteen members would spill).
+template <int MODE>
+__device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* __restrict__ S, unsigned char* lds) {
+    constexpr bool kPacked = MODE <= 1, kLdsCols = MODE <= 1, kRing = MODE == 0;   // packed: totals below 2^44 (2048 filter blocks x 2^33)
+    typedef typename std::conditional<MODE == 0, uint32_t, unsigned long long>::type T;
+    const unsigned long long* __restrict__ col0 = &S->partial[0][0][0];            // [64][kResMaxSb], joint_transpose_kernel
+    const unsigned long long* __restrict__ col1 = col0 + 64 * kResMaxSb;
+    const T kMax = MODE == 0 ? (T)0xffffffffu : (T)((unsigned long long)1 << 63);   // narrow: every candidate is below 2^28, so this start value never wins
+    T* best = (T*)lds;                                                            // [4][kResMaxSb]
+    unsigned long long* red = (unsigned long long*)(best + 4 * kResMaxSb);        // [4][16 waves][16 pairs]
+    uint32_t* AB = (uint32_t*)(red + 4 * 16 * 16);                                // narrow: [kResMaxSb][8] = four columns of each table
+    __shared__ int                s_pick_i[4], s_err;
+    __shared__ unsigned long long s_pick_v[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int tj = (w >> 4) * 4, tk = (w & 15) * 4, pg = tid & 3, slice = tid >> 2;
+    const int ca0 = start_gi + min(tj + 2 * (pg >> 1), ng - 1), ca1 = start_gi + min(tj + 2 * (pg >> 1) + 1, ng - 1);
+    const int cb0 = start_gi + min(tk + 2 * (pg & 1), ng - 1), cb1 = start_gi + min(tk + 2 * (pg & 1) + 1, ng - 1);
+    if (kLdsCols)
+        for (int x = 0; x < 8; x++) {
+            const unsigned long long* __restrict__ cp = x < 4 ? col0 + (size_t)(start_gi + min(tj + x, ng - 1)) * kResMaxSb : col1 + (size_t)(start_gi + min(tk + x - 4, ng - 1)) * kResMaxSb;
+            for (int sb = tid; sb < sb_count; sb += 1024) AB[sb * 8 + x] = (uint32_t)cp[sb];
+        }
+    for (int e = tid; e < 4 * kResMaxSb; e += 1024) best[e] = kMax;
+    if (tid == 0) s_err = 0;
+    T cr[kRing ? 15 : 1][2];   // the sums a[i][lev0[g]] + b[i][lev1[g]] of this thread's two filter blocks (tid, tid + 1024) for the members of each chain's list: chain c at [nb - 1 + g]
+#pragma unroll
+    for (int g = 0; g < (kRing ? 15 : 1); g++) cr[g][0] = cr[g][1] = kMax;
+    int ul0[kRing ? 1 : 15], ul1[kRing ? 1 : 15];   // modes 1, 2: every thread's own (wave-uniform, scalar-register) copy of the four lists, same layout;
+    __shared__ int s_l0[4][8], s_l1[4][8];          // mode 0: thread 0's copy
+#pragma unroll
+    for (int g = 0; g < (kRing ? 1 : 15); g++) ul0[g] = ul1[g] = 0;
     if (tid < 32) { s_l0[tid >> 3][tid & 7] = 0; s_l1[tid >> 3][tid & 7] = 0; }
-    const int tj = (tid >> 4) * 4, tk = (tid & 15) * 4;
-    int ja[4], ka[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { ja[u] = start_gi + min(tj + u, ng - 1); ka[u] = start_gi + min(tk + u, ng - 1); }
-    const int pairs_per_wg = (4096 + C - 1) / C;   // 32 for 128 workgroups
-    unsigned bar_target = 0;
     __syncthreads();
+#ifdef SVT_RES_TRACE
+#define RES_T(k) do { if (tid == 0 && (w == 0 || w == 133)) S->partial[3][w == 0 ? 0 : 1][step * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define RES_T(k) do {} while (0)
+#endif
     for (int step = 0; step < 40; step++) {
-        // ---- slice totals of every running chain
-        for (int c = 0; c < 4; c++) {
-            const int nb = 1 << c;
-            if (step >= 5 * nb) continue;
-            const int idx = step < nb ? step : nb - 1;
-            if (tid < ns) {
-                T bm = sizeof(T) == 4 ? (T)0xffffffffu : (T)((unsigned long long)1 << 63);
-                for (int g = 0; g < idx; g++) { const T v = A[tid * 64 + s_l0[c][g]] + B[tid * 64 + s_l1[c][g]]; bm = v < bm ? v : bm; }
-                best[c * kBlk + tid] = bm;
+        const int par = step & 1;
+        const unsigned long long tag = (unsigned long long)(step + 1) << 56;
+        RES_T(0);
+        // ---- this workgroup's 16 pairs, every running chain: thread = (2 x 2 pairs, every 256th filter block)
+        T acc[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[c][q] = 0;
+#pragma unroll 2
+        for (int sb = slice; sb < sb_count; sb += 256) {
+            T a0, a1, b0, b1;
+            if (kLdsCols) {
+                const uint2 av = *(const uint2*)&AB[sb * 8 + (pg >> 1) * 2], bw = *(const uint2*)&AB[sb * 8 + 4 + (pg & 1) * 2];
+                a0 = av.x; a1 = av.y; b0 = bw.x; b1 = bw.y;
+            } else {
+                a0 = (T)col0[(size_t)ca0 * kResMaxSb + sb]; a1 = (T)col0[(size_t)ca1 * kResMaxSb + sb]; b0 = (T)col1[(size_t)cb0 * kResMaxSb + sb]; b1 = (T)col1[(size_t)cb1 * kResMaxSb + sb];
+            }
+            const T v00 = a0 + b0, v01 = a0 + b1, v10 = a1 + b0, v11 = a1 + b1;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (step >= 5 * (1 << c)) continue;
+                const T bb = best[c * kResMaxSb + sb];
+                acc[c][0] += v00 < bb ? v00 : bb; acc[c][1] += v01 < bb ? v01 : bb; acc[c][2] += v10 < bb ? v10 : bb; acc[c][3] += v11 < bb ? v11 : bb;
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (step >= 5 * (1 << c)) continue;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long r = sum_stride4(acc[c][q]);
+                if (lane < 4) red[(c * 16 + wave) * 16 + lane * 4 + q] = r;
+            }
+        }
+        RES_T(1);
         __syncthreads();
-        for (int c = 0; c < 4; c++) {
-            const int nb = 1 << c;
-            if (step >= 5 * nb) continue;
-            T acc[16];
+        RES_T(2);
+        // ---- first wave: the workgroup's first minimum per chain -> its slot; then the gather of everybody's
+        if (wave == 0) {
+            const int c = lane >> 4, p = lane & 15;
+            const bool running = step < 5 * (1 << c);
+            unsigned long long tot = 0;
+            if (running)
 #pragma unroll
-            for (int u = 0; u < 16; u++) acc[u] = 0;
-            for (int i = 0; i < ns; i++) {
-                const T bb = best[c * kBlk + i];
-                T a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { a[u] = A[i * 64 + ja[u]]; b[u] = B[i * 64 + ka[u]]; }
-#pragma unroll
-                for (int u = 0; u < 16; u++) { const T v = a[u >> 2] + b[u & 3]; acc[u] += v < bb ? v : bb; }
-            }
-            T* out = (T*)&S->partial[c][w][0];   // narrow: 32-bit totals (16 blocks x 2^28 < 2^32), same [j][k] layout
-#pragma unroll
-            for (int u = 0; u < 16; u++) out[(tj + (u >> 2)) * 64 + tk + (u & 3)] = acc[u];
-        }
-        bar_target += (unsigned)C;
-        grid_barrier(S, bar_target);
-        // ---- this workgroup's share of the pairs, summed over the slices; its first minimum
-        for (int c = 0; c < 4; c++) {
-            const int nb = 1 << c;
-            if (step >= 5 * nb) continue;
-            const int q = tid >> 5, pl = tid & 31;   // 8 slice groups x 32 pairs at a time
-            unsigned long long bv = ~0ull;           // lanes 0..31 of wave 0: running first minimum of the pairs they have seen
-            int                bi = 0x7fffffff;
-            for (int base = 0; base < pairs_per_wg; base += 32) {
-                const int  p = w * pairs_per_wg + base + pl;
-                const bool mine = base + pl < pairs_per_wg && p < 4096;
-                unsigned long long v = 0;
-                if (mine) {   // the rows were written by other XCDs: every load is a memory-side round trip, so all sixteen are issued before the first add
-                    T rows[kPersistWgs / 8];
-#pragma unroll
-                    for (int t = 0; t < kPersistWgs / 8; t++) { const int sl = q + 8 * t; rows[t] = sl < C ? ((const T*)&S->partial[c][sl][0])[p] : (T)0; }
-#pragma unroll
-                    for (int t = 0; t < kPersistWgs / 8; t++) v += (unsigned long long)rows[t];
-                }
-                __syncthreads();
-                r_v[tid] = v;
-                __syncthreads();
-                if (tid < 32 && mine) {
-                    const int j = p >> 6, k = p & 63;
-                    if (j < ng && k < ng) {
-                        unsigned long long t = 0;
-#pragma unroll
-                        for (int g = 0; g < 8; g++) t += r_v[pl + 32 * g];
-                        const int ti = j * ng + k;
-                        if (t < bv || (t == bv && ti < bi)) { bv = t; bi = ti; }
-                    }
-                }
-            }
-            if (tid < 64) {
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
-                    const int                oi = __shfl_xor(bi, o);
-                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                if (tid == 0) { S->cand_v[c][w] = bv; S->cand_i[c][w] = bi; }
-            }
-        }
-        bar_target += (unsigned)C;
-        grid_barrier(S, bar_target);
-        // ---- every workgroup picks the chain's pair from the candidates (first minimum in (j, k) raster order) and advances its copy of the list
-        for (int c = 0; c < 4; c++) {
-            const int nb = 1 << c, total_steps = 5 * nb;
-            if (step >= total_steps) continue;
-            const int idx = step < nb ? step : nb - 1;
-            unsigned long long bv = (unsigned long long)1 << 63;   // "tot < best" with best = 1 << 63 (EbEncCdef.c:1104): nothing below it keeps (0, 0)
-            int                bi = 0x7fffffff;
-            if (tid < C) {
-                const unsigned long long ov = ((const volatile unsigned long long*)S->cand_v[c])[tid];
-                const int                oi = ((const volatile int*)S->cand_i[c])[tid];
-                if (oi != 0x7fffffff && ov < bv) { bv = ov; bi = oi; }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
+                for (int wv = 0; wv < 16; wv++) tot += red[(c * 16 + wv) * 16 + p];
+            const int jl = tj + 2 * (p >> 3) + ((p >> 1) & 1), kl = tk + 2 * ((p >> 2) & 1) + (p & 1);
+            const bool on = running && jl < ng && kl < ng;
+            unsigned long long bv = on ? tot : ~0ull;
+            int                bi = on ? jl * ng + kl : 0x7fffffff;   // the reference's raster index over the ng x ng table
+            for (int o = 1; o < 16; o <<= 1) {
                 const unsigned long long ov = (unsigned long long)__shfl_xor((long long)bv, o);
                 const int                oi = __shfl_xor(bi, o);
                 if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
-            if ((tid & 63) == 0) { r_w[tid >> 6] = bv; r_i[tid >> 6] = bi; }
-            __syncthreads();
-            if (tid == 0) {
-                for (int x = 1; x < 4; x++)
-                    if (r_w[x] < bv || (r_w[x] == bv && r_i[x] < bi)) { bv = r_w[x]; bi = r_i[x]; }
-                const bool any = bi != 0x7fffffff;
-                s_l0[c][idx] = any ? start_gi + bi / ng : 0;
-                s_l1[c][idx] = any ? start_gi + bi % ng : 0;
-                if (w == 0 && step + 1 == total_steps) {   // the chain is complete: its pairs and total
-                    for (int g = 0; g < 8; g++) { S->lev0[c][g] = s_l0[c][g]; S->lev1[c][g] = s_l1[c][g]; }
-                    S->result[c] = bv;
+            if (p == 0 && running) {
+                if (kPacked) {
+                    __hip_atomic_store(&S->slot[par][c][w], tag | (bi == 0x7fffffff ? kResEmpty : (bv << 12 | (unsigned)bi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __hip_atomic_store(&S->slot_v[par][c][w], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the total is in memory before the word that validates it
+                    __hip_atomic_store(&S->slot[par][c][w], tag | (bi == 0x7fffffff ? kResEmpty : (unsigned long long)bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
-                    for (int g = 0; g < nb - 1; g++) { s_l0[c][g] = s_l0[c][g + 1]; s_l1[c][g] = s_l1[c][g + 1]; }
             }
-            __syncthreads();
+            RES_T(3);
+            // the running chains are c >= c_lo: one poll covers all of them (sixteen loads in flight at most)
+            const int c_lo = step < 5 ? 0 : step < 10 ? 1 : step < 20 ? 2 : 3;
+            // a slot that is not there yet carries an older (smaller) tag, so the minimum of a lane's four words says whether all four are this step's
+            unsigned long long k[4];
+            bool     failed = false;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++)
+                    if (cc >= c_lo) {
+                        unsigned long long t4[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) t4[t] = __hip_atomic_load(&S->slot[par][cc][lane + 64 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        k[cc] = min(min(t4[0], t4[1]), min(t4[2], t4[3]));
+                    }
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++)
+                    if (cc >= c_lo) ok = ok && (k[cc] >> 56) == (unsigned)(step + 1);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 16) || ((spins & 63) == 0 && __hip_atomic_load(&S->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { failed = true; break; }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                if (cc < c_lo || failed) continue;
+                unsigned long long gv = (unsigned long long)1 << 63;   // "tot < best" with best = 1 << 63 (EbEncCdef.c:1104): nothing below it keeps (0, 0)
+                int                gi = 0x7fffffff;
+                if (kPacked) {
+                    unsigned long long m = k[cc] & kResEmpty;
+                    for (int o = 1; o < 64; o <<= 1) m = min(m, (unsigned long long)__shfl_xor((long long)m, o));
+                    if (m != kResEmpty) { gv = m >> 12; gi = (int)(m & 4095); }
+                } else {   // every word is this step's: now the totals and indices of the lane's four workgroups
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const unsigned long long ix = __hip_atomic_load(&S->slot[par][cc][lane + 64 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kResEmpty;
+                        if (ix == kResEmpty) continue;
+                        const unsigned long long ov = __hip_atomic_load(&S->slot_v[par][cc][lane + 64 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ov < gv || (ov == gv && (int)ix < gi)) { gv = ov; gi = (int)ix; }
+                    }
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned long long ov = (unsigned long long)__shfl_xor((long long)gv, o);
+                        const int                oi = __shfl_xor(gi, o);
+                        if (ov < gv || (ov == gv && oi < gi)) { gv = ov; gi = oi; }
+                    }
+                }
+                if (lane == 0) { s_pick_v[cc] = gv; s_pick_i[cc] = gi; }
+            }
+            if (failed && lane == 0) { s_err = 1; atomicExch(&S->err, 1u); atomicExch(&S->counter[0], 0xdeadu); }   // counter[0] = SvtHipCdefSelectResult.status[0]
+            RES_T(4);
         }
+        __syncthreads();
+        RES_T(5);
+        if (s_err) return;
+        // ---- every workgroup advances its copy of each chain's list; a thread's two filter blocks get the new member's sum and the next step's running best
+        T   cn[4][2];
+        int pl0[4], pl1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {   // the column loads of every running chain are in flight together
+            if (step >= 5 * (1 << c)) continue;
+            const int  bi = s_pick_i[c];
+            const bool any = bi != 0x7fffffff;
+            pl0[c] = __builtin_amdgcn_readfirstlane(any ? start_gi + bi / ng : 0); pl1[c] = __builtin_amdgcn_readfirstlane(any ? start_gi + bi % ng : 0);   // scalar registers
+            if constexpr (kRing)
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int sb = tid + 1024 * u;
+                    cn[c][u] = sb < sb_count ? (T)col0[(size_t)pl0[c] * kResMaxSb + sb] + (T)col1[(size_t)pl1[c] * kResMaxSb + sb] : kMax;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            constexpr int kOff[4] = {0, 1, 3, 7};
+            const int nb = 1 << c, total_steps = 5 * nb;
+            if (step >= total_steps) continue;
+            const int idx = step < nb ? step : nb - 1;
+#pragma unroll
+            for (int g = 0; g < nb; g++)
+                if (g == idx) {
+                    if constexpr (kRing) { cr[kOff[c] + g][0] = cn[c][0]; cr[kOff[c] + g][1] = cn[c][1]; }
+                    else { ul0[kOff[c] + g] = pl0[c]; ul1[kOff[c] + g] = pl1[c]; }
+                }
+            if (tid == 0) {
+                if constexpr (kRing) { s_l0[c][idx] = pl0[c]; s_l1[c][idx] = pl1[c]; }
+                if (w == 0 && step + 1 == total_steps) {   // the chain is complete: its pairs and total
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        if constexpr (kRing) { S->lev0[c][g] = s_l0[c][g]; S->lev1[c][g] = s_l1[c][g]; }
+                        else { S->lev0[c][g] = g < nb ? ul0[kOff[c] + g] : 0; S->lev1[c][g] = g < nb ? ul1[kOff[c] + g] : 0; }
+                    }
+                    S->result[c] = s_pick_v[c];
+                    if (c == 3) S->done = 1;
+                }
+            }
+            if (step + 1 >= total_steps) continue;
+            if (step + 1 >= nb) {   // the next step is a refinement step: drop the oldest pair
+#pragma unroll
+                for (int g = 0; g < nb - 1; g++) {
+                    if constexpr (kRing) { cr[kOff[c] + g][0] = cr[kOff[c] + g + 1][0]; cr[kOff[c] + g][1] = cr[kOff[c] + g + 1][1]; }
+                    else { ul0[kOff[c] + g] = ul0[kOff[c] + g + 1]; ul1[kOff[c] + g] = ul1[kOff[c] + g + 1]; }
+                }
+                if constexpr (kRing)
+                    if (tid == 0)
+                        for (int g = 0; g < nb - 1; g++) { s_l0[c][g] = s_l0[c][g + 1]; s_l1[c][g] = s_l1[c][g + 1]; }
+            }
+            const int nidx = step + 1 < nb ? step + 1 : nb - 1;
+            T bm0 = kMax, bm1 = kMax;
+#pragma unroll
+            for (int g = 0; g < nb; g++)
+                if (g < nidx) {
+                    T m0, m1;
+                    if constexpr (kRing) { m0 = cr[kOff[c] + g][0]; m1 = cr[kOff[c] + g][1]; }
+                    if constexpr (!kRing) {
+                        const unsigned long long* __restrict__ c0 = col0 + (size_t)ul0[kOff[c] + g] * kResMaxSb; const unsigned long long* __restrict__ c1 = col1 + (size_t)ul1[kOff[c] + g] * kResMaxSb;
+                        m0 = tid < sb_count ? c0[tid] + c1[tid] : kMax; m1 = tid + 1024 < sb_count ? c0[tid + 1024] + c1[tid + 1024] : kMax;
+                    }
+                    bm0 = m0 < bm0 ? m0 : bm0; bm1 = m1 < bm1 ? m1 : bm1;
+                }
+            best[c * kResMaxSb + tid] = bm0; best[c * kResMaxSb + tid + 1024] = bm1;
+        }
+        RES_T(6);
+        __syncthreads();
+        RES_T(7);
     }
 }
-__global__ void __launch_bounds__(256)
-joint_persistent_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, int start_gi, int ng, JointState* __restrict__ S) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_tab[(2 * 16 * 64 + 4 * 16) * 8];
-    const bool narrow = S->max0 < (1ull << 27) && S->max1 < (1ull << 27);
-    if (narrow) joint_persistent<uint32_t>(mse0, mse1, sb_count, start_gi, ng, S, s_tab);
-    else joint_persistent<unsigned long long>(mse0, mse1, sb_count, start_gi, ng, S, s_tab);
+// Three kernels, launched back to back: the two whose table width does not apply return at once (~1.5 us each).  One kernel with all bodies would carry the
+// 64-bit bodies' register pressure into the narrow one.
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+joint_resident_kernel(int sb_count, int start_gi, int ng, JointState* __restrict__ S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_res[];
+    const unsigned long long m = max(S->max0, S->max1);
+    const int mode = m < (1ull << 26) ? 0 : m < (1ull << 32) ? 1 : 2;   // below 2^26: the sums of a 16-lane row (32 filter blocks) fit 32 bits
+    if (mode != MODE) return;
+    joint_resident<MODE>(sb_count, start_gi, ng, S, s_res);
 }
+constexpr size_t kResLdsBytes = 4 * kResMaxSb * 8 + 4 * 16 * 16 * 8 + (size_t)kResMaxSb * 8 * 4;   // sized for the wider `best`
 
 // finish_cdef_search after the four searches (EbEncCdef.c:1258-1298): the count of strength pairs by rate-distortion cost, then every filter block's
 // pair.  One thread per filter block; every workgroup redoes the four-way cost comparison (a handful of scalar operations).
@@ -524,6 +656,10 @@ struct CdefFinishOut { int cdef_bits, nb_strengths, y_strength[8], uv_strength[8
 __global__ void __launch_bounds__(256)
 cdef_finish_kernel(const uint64_t* __restrict__ mse0, const uint64_t* __restrict__ mse1, int sb_count, const JointState* __restrict__ S, unsigned long long lambda,
                    const int* __restrict__ sb_fb, CdefFinishOut* __restrict__ out, int* __restrict__ sel_gi, uint8_t* __restrict__ fb_y, uint8_t* __restrict__ fb_uv) {
+    if (S->counter[0]) {   // the selection did not complete (svt_hip.h: status[0])
+        if (blockIdx.x == 0 && threadIdx.x == 0) { out->cdef_bits = -1; out->nb_strengths = 0; }
+        return;
+    }
     unsigned long long best = (unsigned long long)1 << 63;
     int bits = 0;
     for (int i = 0; i <= 3; i++) {
@@ -822,32 +958,57 @@ extern "C" int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64
 }
 extern "C" size_t svt_hip_joint_state_bytes(void) { return sizeof(JointState); }
 // out[c] = {total, lev0[8], lev1[8]} as 64-bit words (17 per chain) is assembled by the caller from the state; here: clear, 40 steps
-extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state) {
+// form: SVT_HIP_CDEF_SELECT_* of svt_hip.h (-1: SVT_HIP_CDEF_SELECT=steps|resident from the environment, else steps)
+extern "C" int svt_hip_strength_select_is_resident(int form, int sb_count) {
+    static int env_form = -1;
+    if (env_form < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT"); env_form = e && !strcmp(e, "resident") ? 1 : 0; }
+    return (form < 0 ? env_form : form) == 1 && sb_count > 0 && sb_count <= kResMaxSb;
+}
+// n_pics pictures of the same size (same sb_count and strength range) in one set of launches; states[i]: SVT_HIP_CDEF_SELECT_STATE_BYTES each
+extern "C" int svt_hip_launch_strength_select_multi(hipStream_t st, int n_pics, const uint64_t* const* mse0, const uint64_t* const* mse1, int sb_count, int start_gi, int end_gi,
+                                                    void* const* states, int resident_form) {
     const int ng = end_gi - start_gi;
-    if (hipMemsetAsync(state, 0, offsetof(JointState, partial), st) != hipSuccess) return (int)hipGetLastError();
-    if (ng <= 0) return 0;
-    if (sb_count > 0) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 64)), dim3(256), 0, st, mse0, mse1, sb_count * 64, (JointState*)state);
-    // SVT_HIP_CDEF_SELECT=persistent selects the one-launch form (pictures of up to 16 filter blocks per workgroup).  Measured on MI355X (4K, 2040 filter blocks):
-    // 1.35 ms against 0.69 ms for the launch-per-step form below — a step costs ~8 memory-side round trips (the workgroups sit on eight XCDs whose L2s are not
-    // coherent: arrival counter, poll, the other slices' totals, the candidates), ~2 us each, which is more than the ~8 us a pair of launches costs; and with
-    // four frames in flight the step is bound by this stage's latency, not by the launch count (bench.py: 12.5 ms against 9.4 ms per four-frame step).  Kept for
-    // A/B runs; the default stays the launch-per-step form.
-    static int form = -1;
-    if (form < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT"); form = e && !strcmp(e, "persistent") ? 1 : 0; }
-    if (form == 1 && sb_count > 0 && sb_count <= 16 * kPersistWgs) {
-        const int wgs = min(kPersistWgs, (sb_count + 15) / 16);
-        hipLaunchKernelGGL(joint_persistent_kernel, dim3(wgs), dim3(256), 0, st, mse0, mse1, sb_count, start_gi, ng, (JointState*)state);
-        return (int)hipGetLastError();
+    for (int i = 0; i < n_pics; i++)
+        if (hipMemsetAsync(states[i], 0, offsetof(JointState, partial), st) != hipSuccess) return (int)hipGetLastError();
+    if (ng <= 0 || n_pics <= 0) return 0;
+    // resident_form: the one-launch form (joint_resident_kernel), for pictures of up to kResMaxSb filter blocks.  It needs its 256 workgroups on the chip together:
+    // two of them launched on different streams could each hold a part of the compute units and wait for the rest, so the C ABI layer issues them on one stream
+    // per device (svt_hip_api.cpp); here they are simply in stream order.
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)joint_resident_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResLdsBytes);
+        (void)hipFuncSetAttribute((const void*)joint_resident_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResLdsBytes);
+        (void)hipFuncSetAttribute((const void*)joint_resident_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResLdsBytes);
+        attr_set = true;
     }
     static int forced = -1;   // debug: SVT_HIP_CDEF_SELECT_SLICES
     if (forced < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT_SLICES"); forced = e ? atoi(e) : 0; }
     int slices = forced > 0 ? forced : (sb_count + 31) / 32;
     slices = slices < 1 ? 1 : (slices > kJointMaxSlices ? kJointMaxSlices : slices);
-    for (int step = 0; step < 40; step++) {
-        hipLaunchKernelGGL(joint_partial_kernel, dim3(slices, 1, 4), dim3(1024), 0, st, mse0, mse1, sb_count, start_gi, ng, step, (JointState*)state);
-        hipLaunchKernelGGL(joint_reduce_kernel, dim3(64, 1, 4), dim3(256), 0, st, slices, start_gi, ng, step, (JointState*)state);
+    for (int p0 = 0; p0 < n_pics; p0 += kJointMaxPics) {
+        const int np = min(kJointMaxPics, n_pics - p0);
+        JointPics P = {};
+        for (int i = 0; i < np; i++) { P.mse0[i] = mse0[p0 + i]; P.mse1[i] = mse1[p0 + i]; P.S[i] = (JointState*)states[p0 + i]; }
+        const bool resident = resident_form && sb_count > 0 && sb_count <= kResMaxSb;
+        if (sb_count > 0 && !resident) hipLaunchKernelGGL(joint_init_kernel, dim3(min((sb_count * 64 + 255) / 256, 64), np), dim3(256), 0, st, P, sb_count * 64);
+        if (resident) {
+            for (int i = 0; i < np; i++) {
+                hipLaunchKernelGGL(joint_transpose_kernel, dim3((sb_count + 63) / 64, 2), dim3(256), 0, st, P.mse0[i], P.mse1[i], sb_count, P.S[i]);
+                hipLaunchKernelGGL(joint_resident_kernel<0>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
+                hipLaunchKernelGGL(joint_resident_kernel<1>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
+                hipLaunchKernelGGL(joint_resident_kernel<2>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
+            }
+            continue;
+        }
+        for (int step = 0; step < 40; step++) {
+            hipLaunchKernelGGL(joint_partial_kernel, dim3(slices, np, 4), dim3(1024), 0, st, P, sb_count, start_gi, ng, step);
+            hipLaunchKernelGGL(joint_reduce_kernel, dim3(64, np, 4), dim3(256), 0, st, P, slices, start_gi, ng, step);
+        }
     }
     return (int)hipGetLastError();
+}
+extern "C" int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state) {
+    return svt_hip_launch_strength_select_multi(st, 1, &mse0, &mse1, sb_count, start_gi, end_gi, &state, 0);
 }
 extern "C" int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s,
                                            int w, int h, int r0, int r1, int mode, int xq0, int xq1, long long* acc, int32_t* xq_out) {

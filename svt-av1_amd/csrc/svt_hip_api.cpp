@@ -10,12 +10,15 @@
 #include <vector>
 #include "svt_hip_internal.h"
 #include "svt_hip_host.h"
+#include <mutex>
 
 struct SvtHipCtx {
     int         device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    int         select_form = -1;   // svt_hip_set_cdef_select_form
+    hipEvent_t  ev_sel_in = nullptr, ev_sel_out = nullptr;   // hand-over to and from the device's selection stream (svt_hip_cdef_strength_select_dev)
     int         me_waves = 4;   // 256 threads per SB: measured best on MI355X (tools/me_time.py)
     int         me_big = 1;     // also launch the strip-walking instance for search areas above 65 536 candidates
     void*       scratch = nullptr;   // library-owned device scratch (16-bit Wiener statistics, self-guided unit search), grown on demand
@@ -44,6 +47,19 @@ static int fail(SvtHipCtx* c, hipError_t e, const char* what) {
         if ((c) && hipSetDevice((c)->device) != hipSuccess) return SVT_HIP_ERR_RUNTIME; \
     } while (0)
 
+// The one-launch CDEF strength selection keeps 256 workgroups resident that wait for each other; two such launches on different streams could each hold a
+// part of the compute units and wait for the rest forever.  Every context of a device therefore issues them on ONE stream of that device (created with the
+// first context, kept for the life of the process), ordered against the caller's stream with a pair of events; kernels that do not wait for other workgroups
+// run beside it as before.  Works under stream capture too (the event wait pulls the selection stream into the capture, the second event joins it back).
+// While the caller's stream is being captured the order is expressed inside the capture instead: each captured selection waits for the event the previous
+// captured selection of the same capture recorded (a fresh event per call; they are kept until the process ends, a graph may be instantiated from them later),
+// so the selection nodes of a graph's parallel branches form one chain.
+static std::mutex  g_sel_mutex;
+static hipStream_t g_sel_stream[64];
+static hipEvent_t  g_sel_cap_event[64];
+static unsigned long long g_sel_cap_id[64];
+extern "C" int svt_hip_strength_select_is_resident(int form, int sb_count);
+
 extern "C" {
 
 int svt_hip_init(int device_id, SvtHipCtx** out) {
@@ -61,9 +77,14 @@ int svt_hip_init(int device_id, SvtHipCtx** out) {
     SvtHipCtx* c = new SvtHipCtx();
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sel_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_sel_out, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return SVT_HIP_ERR_RUNTIME;
+    }
+    if (device_id < 64) {
+        std::lock_guard<std::mutex> lk(g_sel_mutex);
+        if (!g_sel_stream[device_id] && hipStreamCreateWithFlags(&g_sel_stream[device_id], hipStreamNonBlocking) != hipSuccess) g_sel_stream[device_id] = nullptr;
     }
     c->stream = c->own_stream;
     *out = c;
@@ -75,6 +96,8 @@ void svt_hip_destroy(SvtHipCtx* c) {
     (void)hipSetDevice(c->device);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_sel_in) (void)hipEventDestroy(c->ev_sel_in);
+    if (c->ev_sel_out) (void)hipEventDestroy(c->ev_sel_out);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->host_scratch) (void)hipHostFree(c->host_scratch);
     if (c->me_buf) (void)hipFree(c->me_buf);
@@ -1103,12 +1126,55 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx* c, const uint64_t* d_mse0,
     if (e != hipSuccess) return fail(c, e, "joint strength search launch");
     return SVT_HIP_OK;
 }
+int svt_hip_set_cdef_select_form(SvtHipCtx* c, int form) {
+    if (!c || form < -1 || form > 1) return SVT_HIP_ERR_BAD_ARG;
+    c->select_form = form;
+    return SVT_HIP_OK;
+}
 int svt_hip_cdef_strength_select_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, int start_gi, int end_gi, void* d_state, size_t state_bytes) {
     SVT_HIP_ENTER(c);
     if (!c || !d_mse0 || !d_mse1 || !d_state || sb_count < 0 || start_gi < 0 || end_gi > 64 || start_gi > end_gi || state_bytes < svt_hip_joint_state_bytes())
         return SVT_HIP_ERR_BAD_ARG;
-    hipError_t e = (hipError_t)svt_hip_launch_strength_select(c->stream, d_mse0, d_mse1, sb_count, start_gi, end_gi, d_state);
-    if (e != hipSuccess) return fail(c, e, "strength select launch");
+    return svt_hip_cdef_strength_select_multi_dev(c, 1, &d_mse0, &d_mse1, sb_count, start_gi, end_gi, &d_state, state_bytes);
+}
+int svt_hip_cdef_strength_select_multi_dev(SvtHipCtx* c, int n_pictures, const uint64_t* const* d_mse0, const uint64_t* const* d_mse1, int sb_count, int start_gi, int end_gi,
+                                           void* const* d_states, size_t state_bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || n_pictures < 0 || !d_mse0 || !d_mse1 || !d_states || sb_count < 0 || start_gi < 0 || end_gi > 64 || start_gi > end_gi || state_bytes < svt_hip_joint_state_bytes())
+        return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_pictures; i++)
+        if (!d_mse0[i] || !d_mse1[i] || !d_states[i]) return SVT_HIP_ERR_BAD_ARG;
+    hipStream_t sel = c->device < 64 ? g_sel_stream[c->device] : nullptr;
+    const int resident = svt_hip_strength_select_is_resident(c->select_form, sb_count) && sel;
+    if (!resident) {
+        hipError_t e = (hipError_t)svt_hip_launch_strength_select_multi(c->stream, n_pictures, d_mse0, d_mse1, sb_count, start_gi, end_gi, d_states, 0);
+        if (e != hipSuccess) return fail(c, e, "strength select (multi) launch");
+        return SVT_HIP_OK;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    unsigned long long     cap_id = 0;
+    if (hipStreamGetCaptureInfo(c->stream, &cap, &cap_id) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (cap == hipStreamCaptureStatusActive) {
+        std::lock_guard<std::mutex> lk(g_sel_mutex);
+        const int d = c->device;
+        if (g_sel_cap_event[d] && g_sel_cap_id[d] == cap_id) HIPCHK(c, hipStreamWaitEvent(c->stream, g_sel_cap_event[d], 0));
+        hipError_t e = (hipError_t)svt_hip_launch_strength_select_multi(c->stream, n_pictures, d_mse0, d_mse1, sb_count, start_gi, end_gi, d_states, 1);
+        if (e != hipSuccess) return fail(c, e, "strength select (multi) launch");
+        hipEvent_t ev = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(ev, c->stream));
+        g_sel_cap_event[d] = ev; g_sel_cap_id[d] = cap_id;
+        return SVT_HIP_OK;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_sel_in, c->stream));
+    {
+        std::lock_guard<std::mutex> lk(g_sel_mutex);   // wait / launches / record of one call stay together on the shared stream
+        HIPCHK(c, hipStreamWaitEvent(sel, c->ev_sel_in, 0));
+        hipError_t e = (hipError_t)svt_hip_launch_strength_select_multi(sel, n_pictures, d_mse0, d_mse1, sb_count, start_gi, end_gi, d_states, 1);
+        if (e != hipSuccess) return fail(c, e, "strength select (multi) launch");
+        HIPCHK(c, hipEventRecord(c->ev_sel_out, sel));
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel_out, 0));
     return SVT_HIP_OK;
 }
 int svt_hip_cdef_finish_dev(SvtHipCtx* c, const uint64_t* d_mse0, const uint64_t* d_mse1, int sb_count, const void* d_state, uint64_t lambda, const int32_t* d_sb_fb,

@@ -128,6 +128,8 @@ size_t svt_hip_joint_state_bytes(void);
 int svt_hip_launch_cdef_finish(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, const void* state, unsigned long long lambda, const int* sb_fb, void* out,
                                int* sel_gi, uint8_t* fb_y, uint8_t* fb_uv);
 int svt_hip_launch_strength_select(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int start_gi, int end_gi, void* state);
+int svt_hip_launch_strength_select_multi(hipStream_t st, int n_pics, const uint64_t* const* mse0, const uint64_t* const* mse1, int sb_count, int start_gi, int end_gi,
+                                         void* const* states, int resident);
 int svt_hip_launch_joint_strength_search(hipStream_t st, const uint64_t* mse0, const uint64_t* mse1, int sb_count, int* lev0, int* lev1, int nb, int start_gi, int end_gi,
                                          uint64_t* best, uint64_t* tot, uint64_t* out);
 int svt_hip_launch_sgr_flt_proj(hipStream_t st, int pix_bytes, const void* src, int ss, const void* dat, int ds, const int32_t* f0, int f0s, const int32_t* f1, int f1s, int w,

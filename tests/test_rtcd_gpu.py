@@ -889,7 +889,7 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
     L = hip.L
     # (filter blocks, strength range, magnitude): 2^22 keeps the 32-bit lanes of the picture-level call, 2^40 forces its 64-bit path, 2^27 sits on the switch;
     # ranges that are not multiples of 16 leave part of a workgroup's 16 luma strengths masked
-    for sb_count, (start, end), mag in ((1, (0, 64), 22), (40, (0, 64), 22), (510, (0, 64), 22), (77, (0, 16), 22), (2040, (0, 64), 22), (2040, (0, 64), 40), (300, (0, 20), 27),
+    for sb_count, (start, end), mag in ((1, (0, 64), 22), (40, (0, 64), 22), (510, (0, 64), 22), (77, (0, 16), 22), (2040, (0, 64), 22), (2040, (0, 64), 40), (2040, (0, 64), 32), (513, (3, 40), 30), (300, (0, 20), 27),
                                         (1000, (3, 40), 33), (9, (0, 1), 22)):
         m0 = rng.integers(1000, 1 << mag, (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << (mag - 1), (sb_count, 64)).astype(np.uint64)
         m0[:, 11] = m0[:, 2]; m1[:, 9] = m1[:, 4]
@@ -898,8 +898,15 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
         state_bytes = 304 + 8192 + 4 * 128 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
         d_state = hip.empty(state_bytes)
+        # the one-launch (resident) form first, then the launch-per-step form into the same state: both must leave the same result (checked against the reference
+        # below through the second); magnitudes 22 / 27..32 / 33.. take the resident form's 32-bit, 32-bit-columns-64-bit-sums and 64-bit bodies
+        hip.check(L.svt_hip_set_cdef_select_form(hip.h, 1), "select form")
+        hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select (resident)")
+        sel_res = hip.to_host(d_state, (304,), np.uint8)
+        hip.check(L.svt_hip_set_cdef_select_form(hip.h, 0), "select form")
         hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
         sel = hip.to_host(d_state, (304,), np.uint8)
+        assert np.array_equal(sel_res, sel), ("resident form vs steps form", sb_count, start, end, mag)
         sel_lev0 = sel[:128].view(np.int32).reshape(4, 8); sel_lev1 = sel[128:256].view(np.int32).reshape(4, 8); sel_tot = sel[272:304].view(np.uint64)
         for ci, nb in enumerate((1, 2, 4, 8)):
             l0 = np.zeros(8, np.int32); l1 = np.zeros(8, np.int32)
@@ -937,3 +944,55 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
             hip.free(d_out, d_sel, d_fy, d_fuv, d_map)
         hip.free(d_state)
         hip.free(d_m0, d_m1)
+
+
+def test_strength_select_of_several_pictures_in_one_set_of_launches(hip):
+    """svt_hip_cdef_strength_select_multi_dev: the four searches of several pictures side by side (blockIdx.y = picture) give, picture by picture, what the
+    single-picture call gives (which the test above pins to the reference's svt_search_one_dual_c chain); more pictures than one launch set holds (8) included,
+    a narrow (32-bit lanes) and a wide (64-bit) table in the same batch"""
+    rng = np.random.default_rng(9)
+    L = hip.L
+    state_bytes = 304 + 8192 + 4 * 128 * 4096 * 8   # SVT_HIP_CDEF_SELECT_STATE_BYTES
+    for (sb_count, n_pic), form in zip(((510, 3), (2040, 4), (77, 11), (2040, 3)), (0, 0, 0, 1)):
+        hip.check(L.svt_hip_set_cdef_select_form(hip.h, form), "select form")
+        tabs = []
+        for i in range(n_pic):
+            mag = 40 if i == 1 else 22
+            tabs.append((rng.integers(1000, 1 << mag, (sb_count, 64)).astype(np.uint64), rng.integers(1000, 1 << (mag - 1), (sb_count, 64)).astype(np.uint64)))
+        d_m0 = [hip.to_device(t[0]) for t in tabs]; d_m1 = [hip.to_device(t[1]) for t in tabs]
+        d_multi = [hip.empty(state_bytes) for _ in range(n_pic)]
+        VP = C.c_void_p * n_pic
+        hip.check(L.svt_hip_cdef_strength_select_multi_dev(hip.h, n_pic, VP(*[d.value for d in d_m0]), VP(*[d.value for d in d_m1]), sb_count, 0, 64, VP(*[d.value for d in d_multi]),
+                                                          state_bytes), "strength select (multi)")
+        d_one = hip.empty(state_bytes)
+        for i in range(n_pic):
+            hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0[i], d_m1[i], sb_count, 0, 64, d_one, state_bytes), "strength select")
+            a = hip.to_host(d_multi[i], (304,), np.uint8); b = hip.to_host(d_one, (304,), np.uint8)
+            assert np.array_equal(a[:256], b[:256]) and np.array_equal(a[272:304], b[272:304]), (sb_count, i)   # pairs of the four counts, their totals
+        hip.free(*d_m0, *d_m1, *d_multi, d_one)
+    hip.check(L.svt_hip_set_cdef_select_form(hip.h, -1), "select form")
+
+
+def test_resident_selections_of_two_contexts_share_one_stream(hip, pkg):
+    """Two contexts with their own streams issue resident-form selections back to back without waiting: the library orders them on the device's one
+    selection stream (two resident launches side by side could each hold part of the chip and wait for the rest); both results equal the steps form's, no
+    time-out flag (status[0])."""
+    other = pkg.Context(0)
+    rng = np.random.default_rng(21)
+    L = hip.L
+    state_bytes = 304 + 8192 + 4 * 128 * 4096 * 8
+    sb_count = 2040
+    jobs = []
+    for i, cx in enumerate((hip, other, hip, other)):
+        m0 = rng.integers(1000, 1 << (22 + 3 * i), (sb_count, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << (21 + 3 * i), (sb_count, 64)).astype(np.uint64)
+        jobs.append((cx, cx.to_device(m0), cx.to_device(m1), cx.empty(state_bytes)))
+    for cx in (hip, other): cx.check(L.svt_hip_set_cdef_select_form(cx.h, 1), "select form")
+    for cx, a, b, st in jobs: cx.check(L.svt_hip_cdef_strength_select_dev(cx.h, a, b, sb_count, 0, 64, st, state_bytes), "strength select (resident)")
+    got = [cx.to_host(st, (304,), np.uint8) for cx, a, b, st in jobs]
+    for cx in (hip, other): cx.check(L.svt_hip_set_cdef_select_form(cx.h, 0), "select form")
+    for (cx, a, b, st), g in zip(jobs, got):
+        cx.check(L.svt_hip_cdef_strength_select_dev(cx.h, a, b, sb_count, 0, 64, st, state_bytes), "strength select")
+        assert np.array_equal(cx.to_host(st, (304,), np.uint8), g) and not g[256:272].any()
+        cx.free(a, b, st)
+    hip.check(L.svt_hip_set_cdef_select_form(hip.h, -1), "select form")
+    other.close()

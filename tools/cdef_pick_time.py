@@ -5,7 +5,8 @@ from conftest import load_package
 pkg = load_package(); hip = pkg.Context(0); L = hip.L
 rng = np.random.default_rng(3)
 n = 2040
-m0 = rng.integers(1000, 1 << 22, (n, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << 21, (n, 64)).astype(np.uint64)
+MAG = int(os.environ.get("PICK_MAG", 22))
+m0 = rng.integers(1000, 1 << MAG, (n, 64)).astype(np.uint64); m1 = rng.integers(1000, 1 << (MAG - 1), (n, 64)).astype(np.uint64)
 d_m0, d_m1 = hip.to_device(m0), hip.to_device(m1)
 d_lev = hip.to_device(np.zeros(16, np.int32)); d_work = hip.empty(8 * (4097 + n))
 st = torch.cuda.Stream(); L.svt_hip_set_stream(hip.h, C.c_void_p(st.cuda_stream))
