@@ -891,6 +891,7 @@ int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32
         if (rc == SVT_HIP_OK)
             rc = svt_hip_cdef_strength_select_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, start_gi, end_gi, d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
         if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &tls_sel.res, d_state, sizeof(tls_sel.res));
+        if (rc == SVT_HIP_OK && tls_sel.res.status[0]) rc = SVT_HIP_ERR_RUNTIME; /* the one-launch form gave up waiting (SVT_HIP_CDEF_SELECT=resident only) */
         svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state);
         if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength selection on the device failed (%s): C search\n", svt_hip_last_error(hip));
         svt_hip_hooks_unlock();
@@ -930,6 +931,7 @@ int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t sta
     if (rc == SVT_HIP_OK)
         rc = svt_hip_cdef_finish_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, d_state, lambda, NULL, (SvtHipCdefFinish *)d_out, (int32_t *)d_sel, NULL, NULL);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &fin, d_out, sizeof(fin));
+    if (rc == SVT_HIP_OK && fin.cdef_bits < 0) rc = SVT_HIP_ERR_RUNTIME; /* an incomplete selection (svt_hip.h: status[0]) */
     if (rc == SVT_HIP_OK && sb_count) rc = svt_hip_memcpy_d2h(hip, selected, d_sel, sizeof(int32_t) * (size_t)sb_count);
     svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state); svt_hip_free(hip, d_out); svt_hip_free(hip, d_sel);
     if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength decision on the device failed (%s): C loops\n", svt_hip_last_error(hip));

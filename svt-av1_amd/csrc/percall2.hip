@@ -363,7 +363,12 @@ joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int ste
     S->counter[c] = 0;
 }
 
-// ---- the same selection in ONE launch (the default for pictures of up to kResMaxSb filter blocks).  The step-by-step form above spends its time moving 16 MB
+// Two variations that were built, verified and measured, and dropped (MI355X, 2040 filter blocks):
+//  - a pair-divided launch-per-step form (one launch per step, 256 workgroups of 512 threads per chain streaming their 4 x 4 tile's columns and the filter blocks'
+//    running best through LDS, the last workgroup advancing the list): 1.26 ms per picture, 31 us per step -- re-reading 150 MB of columns from L2 every step;
+//  - sums in doubles (exact below 2^53; add / min / add are three instructions where 64-bit integers take seven) for tables between 2^27 and 2^40: 0.81 against
+//    0.83 ms in steps, 0.57 against 0.58 ms resident -- neither form is bound by its arithmetic.
+// ---- the same selection in ONE launch (svt_hip_set_cdef_select_form; for pictures of up to kResMaxSb filter blocks).  The step-by-step form above spends its time moving 16 MB
 // of slice totals per step across the XCDs and on ~8 dependent memory-side round trips per step; none of that is arithmetic (a whole selection is ~0.6 G
 // add / min / add).  Here the PAIRS are divided, not the filter blocks: 256 workgroups (one per compute unit, 1024 threads) each own a 4 x 4 tile of strength
 // pairs for ALL four chains and keep that tile's eight table columns of every filter block in LDS for the whole selection (64 KB, read once), so a workgroup's

@@ -396,6 +396,17 @@ def test_single_hook_on_gpu(hook, workdir):
     _check(case, spec, workdir, {"SVT_HIP_HOOKS": ",".join(sorted(hooks))}, "hip_" + hook)
 
 
+@pytest.mark.gpu
+def test_cdef_finish_hook_with_the_one_launch_selection_on_gpu(workdir):
+    """SVT_HIP_CDEF_SELECT=resident: the strength-pair selection of finish_cdef_search as ONE launch (joint_resident_kernel) inside a real encode, with other
+    threads' contexts at work beside it; identical bitstream, no fallback (an incomplete selection would be one: status[0])."""
+    case = "cif_8bit_m6"
+    hooks = {"cdef_finish", "cdef_search", "me", "hme"}
+    spec = CASES[case][:6] + (hooks,)
+    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": ",".join(sorted(hooks)), "SVT_HIP_CDEF_SELECT": "resident"}, "hip_select_resident")
+    assert got["hooks"]["cdef_finish"][0] > 0 and got["hooks"]["cdef_finish"][1] == 0, got["hooks"]
+
+
 # Dispatch-table entries that hand SOME of their calls to the saved C pointer in the encodes below, and why (everything else must stay on the device):
 EXPECTED_DELEGATIONS = {
     "per_call": set(),
