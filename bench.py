@@ -569,6 +569,30 @@ def main():
                       "phase_cycles_per_walk": [{k: round(64.0 * int(s[24 + i]) / (16 * P0.n_units[p])) for i, k in enumerate(("solve", "replay", "load_wait", "evaluate", "total"))}
                                                 | {"passes": round(int(s[0]) / (16 * P0.n_units[p]), 2), "points": round(int(s[1]) / (16 * P0.n_units[p]), 2)} for p, s in enumerate(st3)]}
         parity_ok = bool(parity_ok is not False and walk_stats["unfinished"] == 0)
+        if os.environ.get("SVT_BENCH_SGR_RANGE"):   # development probe: the value ranges of the difference planes the unit search stores (per plane, per set)
+            rng_out = []
+            for p in range(3):
+                ph_, pw_ = F0.cur[p].shape
+                nu = P0.n_units[p]; dstride = (pw_ + 63) & ~63; dplane = dstride * ph_
+                al = lambda v: (v + 255) & ~255
+                o = al(128); o = al(o + 8 * nu * 16 * 5); o = al(o + 8 * nu); o = al(o + 4 * nu); sd_off = o; o = al(o + 2 * dplane); pairs_off = o
+                sd = P0.d_scr[p][sd_off:sd_off + 2 * dplane].cpu().numpy().view(np.int16).reshape(ph_, dstride)[:, :pw_]
+                row = {"plane": p, "sd_absmax": int(np.abs(sd).max())}
+                US = P0.US[p]
+                for ep in (0, 4, 9, 10, 14):
+                    pr = P0.d_scr[p][pairs_off + 4 * dplane * ep: pairs_off + 4 * dplane * (ep + 1)].cpu().numpy().view(np.uint32).reshape(ph_, dstride)[:, :pw_]
+                    f0 = (pr & 0xffff).astype(np.uint16).view(np.int16); f1 = (pr >> 16).astype(np.uint16).view(np.int16)
+                    a0 = np.abs(f0.astype(np.int32)); a1 = np.abs(f1.astype(np.int32))
+                    nuy, nux = max((ph_ + US // 2) // US, 1), max((pw_ + US // 2) // US, 1)
+                    over = {"f0>2047": 0, "f0>1023": 0, "f1>1023": 0, "f1>511": 0}
+                    for uy in range(nuy):
+                        for ux in range(nux):
+                            y1 = ph_ if uy == nuy - 1 else (uy + 1) * US; x1 = pw_ if ux == nux - 1 else (ux + 1) * US
+                            m0 = a0[uy * US:y1, ux * US:x1].max(); m1 = a1[uy * US:y1, ux * US:x1].max()
+                            over["f0>2047"] += int(m0 > 2047); over["f0>1023"] += int(m0 > 1023); over["f1>1023"] += int(m1 > 1023); over["f1>511"] += int(m1 > 511)
+                    row[f"ep{ep}"] = {"f0_absmax": int(a0.max()), "f1_absmax": int(a1.max()), "f0_p999": int(np.percentile(a0, 99.9)), "f1_p999": int(np.percentile(a1, 99.9)), "units": nuy * nux, **over}
+                rng_out.append(row)
+            walk_stats["difference_plane_ranges"] = rng_out
 
     # ---- CPU baseline: the reference's own kernels over the same job lists (or the oracle port), all hardware threads and one thread
     cpu = None
@@ -873,7 +897,7 @@ def cpu_baseline(orc, F, sbs, mc, tc, stages, jobs):
 def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
     """The reference's own kernels as its x86 build dispatches them (SSE2 .. AVX2 / AVX-512 through setup_common_rtcd_internal /
     setup_rtcd_internal with this host's CPU flags), driven by oracle/ref_bench.c over the SAME job lists as the HIP stages, on every
-    hardware thread (a pthread pool inside ref_bench.c: no Python in the timed region), the WHOLE frame per stage, best of 3.
+    hardware thread (a pthread pool inside ref_bench.c: no Python in the timed region), the WHOLE frame per stage, median of 5 (the stages that take seconds: once).
     tests/test_ref_bench.py shows these loops produce the oracle's outputs bit for bit."""
     from conftest import ptr
     refb.refb_setup.restype = C.c_uint64; refb.refb_setup.argtypes = [C.c_uint64]
@@ -900,7 +924,7 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
 
     sec1 = {}   # the same on ONE thread (BASELINE.md asks for T in {1, nproc})
 
-    def run(stage, slots, n, chunk, reps=3, name=None, one_thread_items=None):
+    def run(stage, slots, n, chunk, reps=-5, name=None, one_thread_items=None):   # reps < 0: median of -reps; the stages of several seconds run once (reps=1)
         a = (C.c_int64 * len(slots))(*[adr(v) for v in slots])
         t = refb.refb_parallel(stage, C.addressof(a), n, chunk, cores, reps)
         if name is not None:   # one thread, a bounded prefix of the same items, scaled to the whole frame
@@ -1029,7 +1053,7 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
                 sample="the reference's own kernels as its x86 build dispatches them on this host (cpu flags 0x%x: SSE2..AVX2%s; oracle/_ref SIMD flavour built by "
                        "oracle/Makefile.ref from the reference sources, NASM-only helpers stubbed in C and not on this path), driven by oracle/ref_bench.c over the "
                        "same job lists as the HIP stages (the restoration search is the complete search_selfguided_restoration per unit), whole frame per stage, %d pthreads (all hardware "
-                       "threads; ME and HME in work items of 8 SBs), best of 3; seconds per SB per stage: " % (
+                       "threads; ME and HME in work items of 8 SBs), median of 5 (deblocking, the strength decision and the restoration stages: one run); seconds per SB per stage: " % (
                            flags, " + AVX-512" if flags & (1 << 9) else "", cores)
                        + ", ".join(f"{k}={v:.2e}" for k, v in sec.items())
                        + " (pyramids: the oracle's scalar C / threads; deblock and restoration apply run on independent row bands; restoration search is "

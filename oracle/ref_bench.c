@@ -346,7 +346,7 @@ void refb_cdef_finish(const uint64_t *mse0, const uint64_t *mse1, int sb_count, 
 
 /* ---------------------------------------------------------------- thread pool for bench.py's cpu_baseline ---------------------------
  * refb_parallel runs one of the drivers above over n items on n_threads pthreads (dynamic chunks from an atomic counter, so threads of
- * uneven speed stay busy), `reps` times, and returns the best wall time in seconds.  Arguments travel as an array of 64-bit slots
+ * uneven speed stay busy), `reps` times, and returns the best (reps > 0) or the median (reps < 0, of -reps) wall time in seconds.  Arguments travel as an array of 64-bit slots
  * (pointers / integers), so the Python side needs no struct definitions; for the band stages (deblock, restoration apply) the array
  * holds one 16-slot record per band and an item is a band. */
 #include <pthread.h>
@@ -405,8 +405,11 @@ static void *pool_worker(void *p_) {
     return NULL;
 }
 /* the clock runs from the moment every thread exists (start barrier) to the moment the last one is out of work (done barrier) */
+/* reps > 0: the best of `reps` wall times; reps < 0: the MEDIAN of -reps ("median of >= 5") */
 double refb_parallel(int stage, const int64_t *args, int n, int chunk, int n_threads, int reps) {
-    double best = -1;
+    double best = -1, all[33];
+    const int median = reps < 0;
+    if (median) reps = -reps > 33 ? 33 : -reps;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
     for (int r = 0; r < reps; r++) {
         RefbPool p;
@@ -422,8 +425,13 @@ double refb_parallel(int stage, const int64_t *args, int n, int chunk, int n_thr
         pthread_barrier_destroy(&p.start); pthread_barrier_destroy(&p.done);
         const double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         if (best < 0 || s < best) best = s;
+        if (median) all[r] = s;
     }
     free(th);
+    if (median) {
+        for (int i = 1; i < reps; i++) { const double v = all[i]; int j = i; while (j > 0 && all[j - 1] > v) { all[j] = all[j - 1]; j--; } all[j] = v; }
+        return all[reps / 2];
+    }
     return best;
 }
 
