@@ -225,6 +225,29 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 
 // grid: (units, 16); block 256.  pairs: [16] planes of (flt0 - u) | (flt1 - u) << 16 (plane `ep`; sets 11 / 12 / 13 read the plane of 2 / 5 / 8 — their
 // xq0 is 0, so the r0 half does not matter), sd: one int16 plane of dat - src.
+// Publishing a walk's result to the workgroup that finishes the unit: write-through (agent-scope) stores, drained, then the arrival count; the reader uses
+// agent-scope loads.  A __threadfence() pair here meant an L2 write-back + invalidate per walk (thousands per picture), which also cost the kernels of other
+// frames running beside this one.
+__device__ __forceinline__ void publish_walk(int32_t* xqd_out, long long* err_out, size_t ue, int rx, int ry, long long err) {
+    __hip_atomic_store(&xqd_out[ue * 2], rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&xqd_out[ue * 2 + 1], ry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&err_out[ue], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void pick_unit_best(const int32_t* xqd_out, const long long* err_out, int unit, uint32_t ep_mask, uint8_t* best_ep, int32_t* best_xqd) {
+    int be = -1; long long berr = -1;
+    for (int e2 = 0; e2 < 16; e2++) {
+        if (!((ep_mask >> e2) & 1)) continue;
+        const long long v = __hip_atomic_load(&err_out[(size_t)unit * 16 + e2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (be < 0 || v < berr) { be = e2; berr = v; }
+    }
+    if (best_ep) best_ep[unit] = (uint8_t)be;
+    if (best_xqd) {
+        best_xqd[2 * unit] = __hip_atomic_load(&xqd_out[((size_t)unit * 16 + be) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        best_xqd[2 * unit + 1] = __hip_atomic_load(&xqd_out[((size_t)unit * 16 + be) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int BD>
 __global__ void __launch_bounds__(256)
 sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ sd, int dstride, size_t dplane,
@@ -330,26 +353,10 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
     }
     // ---- results, and the unit's best set once all of its sets are in: search_selfguided_restoration :661-665 (first set with the smallest error)
     if (tid == 0) {
-        xqd_out[((size_t)unit * 16 + ep) * 2] = L.res_x;
-        xqd_out[((size_t)unit * 16 + ep) * 2 + 1] = L.res_y;
-        err_out[(size_t)unit * 16 + ep] = L.done ? L.res_err : -1;   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+        publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, L.res_x, L.res_y, L.done ? L.res_err : -1);   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
         atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!L.done) atomicAdd(&stats[2], 1u);   // diagnostics
-        __threadfence();
         const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
-        if (arrived == (uint32_t)__popc(ep_mask)) {
-            __threadfence();
-            int be = -1; long long berr = -1;
-            for (int e2 = 0; e2 < 16; e2++) {
-                if (!((ep_mask >> e2) & 1)) continue;
-                const long long v = ((volatile long long*)err_out)[(size_t)unit * 16 + e2];
-                if (be < 0 || v < berr) { be = e2; berr = v; }
-            }
-            if (best_ep) best_ep[unit] = (uint8_t)be;
-            if (best_xqd) {
-                best_xqd[2 * unit] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2];
-                best_xqd[2 * unit + 1] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2 + 1];
-            }
-        }
+        if (arrived == (uint32_t)__popc(ep_mask)) pick_unit_best(xqd_out, err_out, unit, ep_mask, best_ep, best_xqd);
     }
 }
 
@@ -501,29 +508,13 @@ sgr_walk_resident_kernel(const WalkPic a) {
         }
         // ---- results, and the unit's best set once all of its sets are in: search_selfguided_restoration :661-665 (first set with the smallest error)
         if (lane == 0) {
-            xqd_out[((size_t)unit * 16 + ep) * 2] = K.res_x;
-            xqd_out[((size_t)unit * 16 + ep) * 2 + 1] = K.res_y;
-            err_out[(size_t)unit * 16 + ep] = fin ? K.res_err : -1;   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+            publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
             atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
             // phase clocks of the walk, in units of 64 shader cycles (diagnostics: tools/hbd_time.py)
             atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
             atomicAdd(&stats[27], (uint32_t)(c_eval >> 6)); atomicAdd(&stats[28], (uint32_t)((__builtin_readcyclecounter() - c0) >> 6));
-            __threadfence();
             const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
-            if (arrived == (uint32_t)__popc(ep_mask)) {
-                __threadfence();
-                int be = -1; long long berr = -1;
-                for (int e2 = 0; e2 < 16; e2++) {
-                    if (!((ep_mask >> e2) & 1)) continue;
-                    const long long v = ((volatile long long*)err_out)[(size_t)unit * 16 + e2];
-                    if (be < 0 || v < berr) { be = e2; berr = v; }
-                }
-                if (best_ep) best_ep[unit] = (uint8_t)be;
-                if (best_xqd) {
-                    best_xqd[2 * unit] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2];
-                    best_xqd[2 * unit + 1] = ((volatile int32_t*)xqd_out)[((size_t)unit * 16 + be) * 2 + 1];
-                }
-            }
+            if (arrived == (uint32_t)__popc(ep_mask)) pick_unit_best(xqd_out, err_out, unit, ep_mask, best_ep, best_xqd);
         }
         return;
     }
