@@ -727,13 +727,13 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse
 /* The four joint_strength_search_dual calls of finish_cdef_search (nb_strengths = 1, 2, 4, 8; EbEncCdef.c:1258) at once; the chains are independent.  Two forms
  * (svt_hip_set_cdef_select_form, or SVT_HIP_CDEF_SELECT=steps|resident in the environment; the default is steps):
  *  - steps: one pair of launches per step index advances all chains that are still running (80 launches instead of 225: slices of the filter blocks into
- *    per-slice totals, then the sum over slices and the first minimum -- no atomics on the totals).  0.70 - 0.83 ms for 2040 filter blocks on MI355X, nearly
+ *    per-slice totals, then the sum over slices and the first minimum -- no atomics on the totals).  0.64 - 0.77 ms for 2040 filter blocks on MI355X, nearly
  *    all of it dependent-launch latency: the selections of several pictures issued on their own streams overlap almost freely.
  *  - resident: ONE launch for the 40 step indices (pictures of up to 2048 filter blocks): 256 workgroups each own a 4 x 4 tile of strength pairs, keep the tile's
  *    table columns in LDS and exchange one 8-byte word per chain and step.  0.37 ms when every distortion is below 2^26, 0.58 ms below 2^32, 0.89 ms above
- *    (same data: 0.70 / 0.83 / 0.83 ms in steps) -- the form for ONE picture in flight.  Its workgroups wait for each other, so all resident selections of a
+ *    (same data: 0.64 / 0.77 / 0.77 ms in steps) -- the form for ONE picture in flight.  Its workgroups wait for each other, so all resident selections of a
  *    device are issued on one library-owned stream (ordered against the context's stream with events; inside a stream capture they are chained with events
- *    instead) and other work in flight delays it: with four frames in flight bench.py's step takes 12.1 ms against 9.5 ms in steps.
+ *    instead) and other work in flight delays it: with four frames in flight bench.py's step takes 12.1 ms against 8.7 ms in steps.
  * d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory, cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each
  * count and the totals).  status[0] != 0 afterwards: the resident form gave up waiting for a workgroup (bounded spin; nothing else should be able to cause
  * it) -- the result is not valid, svt_hip_cdef_finish_dev reports cdef_bits = -1 for it; run the selection again in the steps form. */

@@ -36,7 +36,7 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     int dstride, pw, ph, unit_size, units_x, units_y, voff; uint32_t ep_mask;
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
 };
-struct WalkPic { WalkPlane p[3]; int cap; };
+struct WalkPic { WalkPlane p[3]; int cap, clocks; };   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
 constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
 
 // eb_sgr_params (Common/Codec/EbRestoration.c:136-153): r0 > 0 for sets 0-9, 14, 15; r1 > 0 for sets 0-13.  Tap ranges: SGRPROJ_PRJ_MIN0 / MAX0 = -96 / 31,
@@ -511,8 +511,10 @@ sgr_walk_resident_kernel(const WalkPic a) {
             publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
             atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
             // phase clocks of the walk, in units of 64 shader cycles (diagnostics: tools/hbd_time.py)
-            atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
-            atomicAdd(&stats[27], (uint32_t)(c_eval >> 6)); atomicAdd(&stats[28], (uint32_t)((__builtin_readcyclecounter() - c0) >> 6));
+            if (a.clocks) {
+                atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
+                atomicAdd(&stats[27], (uint32_t)(c_eval >> 6)); atomicAdd(&stats[28], (uint32_t)((__builtin_readcyclecounter() - c0) >> 6));
+            }
             const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
             if (arrived == (uint32_t)__popc(ep_mask)) pick_unit_best(xqd_out, err_out, unit, ep_mask, best_ep, best_xqd);
         }
@@ -665,6 +667,8 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
     WalkPic a = {};
     a.cap = cap;
+    static const char* clk_env = getenv("SVT_HIP_SGR_WALK_CLOCKS");
+    a.clocks = !(clk_env && clk_env[0] == '0');
     int max_units = 0;
     for (int i = 0; i < n_planes; i++) {
         const SvtHipSgrWalkPlane& P = planes[i];

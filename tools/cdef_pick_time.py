@@ -40,7 +40,8 @@ with torch.cuda.stream(st):
     s0.record(st)
     for _ in range(5): run2()
     s1.record(st); torch.cuda.synchronize()
-print(f"svt_hip_cdef_strength_select_dev (the four chains side by side, one launch per step index, 40 launches): {s0.elapsed_time(s1) / 5:.3f} ms per frame")
+FORM = "one resident launch" if os.environ.get("SVT_HIP_CDEF_SELECT") == "resident" else "two launches per step index, 80 launches"
+print(f"svt_hip_cdef_strength_select_dev (the four chains side by side, {FORM}; tables below 2^{MAG}): {s0.elapsed_time(s1) / 5:.3f} ms per frame")
 print(f"cdef strength-pair selection, 2040 filter blocks, nb = 1 + 2 + 4 + 8 (75 steps): {e0.elapsed_time(e1) / 5:.3f} ms per frame (eager launches)")
 g2 = torch.cuda.CUDAGraph()
 cap2 = torch.cuda.Stream(); cap2.wait_stream(st)
@@ -54,4 +55,4 @@ with torch.cuda.stream(st):
     h0.record(st)
     for _ in range(10): g2.replay()
     h1.record(st); torch.cuda.synchronize()
-print(f"svt_hip_cdef_strength_select_dev as one captured HIP graph: {h0.elapsed_time(h1) / 10:.3f} ms per frame")
+print(f"svt_hip_cdef_strength_select_dev ({FORM}; tables below 2^{MAG}) as one captured HIP graph: {h0.elapsed_time(h1) / 10:.3f} ms per frame")

@@ -43,7 +43,7 @@ STAGE_KERNELS = {
     "pyramids": ("downsample_kernel", "variance_pyramid_kernel"), "hme_l0_l1_l2": ("sad_loop_kernel",), "me_fullpel_85pu": ("me_fullpel_85pu_kernel", "me_fullpel_narrow_kernel"),
     "subpel_convolve": ("subpel_predict_kernel", "subpel_jobs_from_me_kernel"), "fwd_txfm_quant": ("fwd_txfm_quant_multi_kernel",), "inv_txfm_recon": ("inv_txfm_add_multi_kernel",),
     "fwd_quant_inv_recon": ("enc_txfm_multi_kernel",), "deblock": ("deblock_frame_pass_kernel",), "cdef_search": ("cdef_search_luma_kernel", "cdef_search_chroma_kernel"),
-    "cdef_strength_select": ("joint_init_kernel", "joint_partial_kernel", "joint_reduce_kernel", "cdef_finish_kernel"), "cdef_apply": ("cdef_apply_kernel",),
+    "cdef_strength_select": ("joint_init_kernel", "joint_partial_kernel", "joint_reduce_kernel", "joint_transpose_kernel", "joint_resident_kernel", "cdef_finish_kernel"), "cdef_apply": ("cdef_apply_kernel",),
     "sgr_units_search": ("sgr_search8_kernel", "sgr_walk_resident_kernel", "sgr_walk_kernel", "generate_padding_kernel"), "sgr_apply": ("lr_apply8_kernel",),
 }
 
