@@ -412,6 +412,37 @@ __device__ __forceinline__ void eval_chunk(const int4& a0, const int4& a1, const
         : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [s0] "v"(s.x), [s1] "v"(s.y),
           [s2] "v"(s.z), [s3] "v"(s.w), [q] "v"(q), [r] "s"(rnd), [sel] "s"(sel));
 }
+// The same for a chunk that several candidates evaluate in one sweep: (dat - src) << 16 | 2^15 of every sample is formed once per sweep (expand_sd: one
+// instruction per sample) and rides in the weighted sum's accumulator -- the upper half of the sum is then the sample's error with dat - src already in it, and
+// the four packed adds per candidate go: 16 instructions per candidate and chunk instead of 20.
+__device__ __forceinline__ void expand_sd(const int4& s, int (&c)[8]) {
+    const int sw[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c[2 * i] = (sw[i] << 16) + 0x8000; c[2 * i + 1] = (int)(((uint32_t)sw[i] & 0xFFFF0000u) | 0x8000u); }
+}
+__device__ __forceinline__ void eval_chunk_f(const int4& a0, const int4& a1, const int (&c)[8], int q, int sel, int& p0, int& p1) {
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_dot2_i32_i16 %[t0], %[a0], %[q], %[c0]\n\t"
+        "v_dot2_i32_i16 %[t1], %[a1], %[q], %[c1]\n\t"
+        "v_dot2_i32_i16 %[t2], %[a2], %[q], %[c2]\n\t"
+        "v_dot2_i32_i16 %[t3], %[a3], %[q], %[c3]\n\t"
+        "v_dot2_i32_i16 %[t4], %[a4], %[q], %[c4]\n\t"
+        "v_dot2_i32_i16 %[t5], %[a5], %[q], %[c5]\n\t"
+        "v_dot2_i32_i16 %[t6], %[a6], %[q], %[c6]\n\t"
+        "v_dot2_i32_i16 %[t7], %[a7], %[q], %[c7]\n\t"
+        "v_perm_b32 %[t0], %[t1], %[t0], %[sel]\n\t"
+        "v_perm_b32 %[t2], %[t3], %[t2], %[sel]\n\t"
+        "v_perm_b32 %[t4], %[t5], %[t4], %[sel]\n\t"
+        "v_perm_b32 %[t6], %[t7], %[t6], %[sel]\n\t"
+        "v_dot2_i32_i16 %[p0], %[t0], %[t0], %[p0]\n\t"
+        "v_dot2_i32_i16 %[p1], %[t2], %[t2], %[p1]\n\t"
+        "v_dot2_i32_i16 %[p0], %[t4], %[t4], %[p0]\n\t"
+        "v_dot2_i32_i16 %[p1], %[t6], %[t6], %[p1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [p0] "+v"(p0), [p1] "+v"(p1)
+        : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
+          [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "v"(q), [sel] "s"(sel));
+}
 __device__ __forceinline__ void dot_drain() { asm volatile("s_nop 2"); }
 // zero the pixels of a chunk at or past column n (n < 8): their error is then 0 for every candidate
 __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
@@ -424,7 +455,7 @@ __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
 }
 
 template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
-__global__ void __launch_bounds__(kT)
+__global__ void __launch_bounds__(kT, (kT == 512 ? 4 : 1))   // the hybrid instances are built for two workgroups per compute unit: 128 registers
 sgr_walk_resident_kernel(const WalkPic a) {
     constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
     __shared__ ResLdsT<kT, kJ> R;
@@ -573,10 +604,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     const int kn2 = k + 2 * kResD;
                     int4 c0 = make_int4(0, 0, 0, 0), c1 = c0, u4 = c0;
                     if (kn2 < nchunk) fetch(kn2, c0, c1, u4);
+                    int sx[8]; expand_sd(s4, sx);
 #pragma unroll
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
-                            eval_chunk(a0, a1, s4, qq[c], rnd, sel, pp0[c], pp1[c]);
+                            eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
                             if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
                     a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
@@ -586,10 +618,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 const int kn = k + kResD;
                 int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
                 if (kn < nchunk) fetch(kn, b0, b1, t4);   // next chunk's loads before this chunk's arithmetic
+                int sx[8]; expand_sd(s4, sx);
 #pragma unroll
                 for (int c = 0; c < NA; c++)
                     if (c < nc) {
-                        eval_chunk(a0, a1, s4, qq[c], rnd, sel, pp0[c], pp1[c]);
+                        eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
                         if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                     }
                 a0 = b0; a1 = b1; s4 = t4; k = kn;
@@ -599,10 +632,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
             for (int j = 0; j < kResJ; j++) {
                 if (j * kResD < nchunk) {
                     const int4 sc = R.sd[j * kResD + t];
+                    int sx[8]; expand_sd(sc, sx);
 #pragma unroll
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
-                            eval_chunk(pa[j], pb[j], sc, qq[c], rnd, sel, pp0[c], pp1[c]);
+                            eval_chunk_f(pa[j], pb[j], sx, qq[c], sel, pp0[c], pp1[c]);
                             if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
                 }
