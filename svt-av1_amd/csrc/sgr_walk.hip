@@ -708,7 +708,7 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
         const SvtHipSgrWalkPlane& P = planes[i];
         const int nu = P.units_x * P.units_y;
         uint32_t* counters = (uint32_t*)P.states;
-        (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * (size_t)nu, st);
+        // the arrival counters are zero: the caller clears the scratch up to the difference planes (svt_hip_api.cpp)
         a.p[i] = WalkPlane{P.pairs, P.sd, P.sums, P.dplane, P.dstride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, 8 >> P.ss_y, P.ep_mask,
                            P.xqd_out, P.err_out, counters, P.best_ep, P.best_xqd, P.stats};
         max_units = nu > max_units ? nu : max_units;

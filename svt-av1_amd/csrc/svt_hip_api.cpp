@@ -687,7 +687,7 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
         return SVT_HIP_ERR_BAD_ARG;
     }
     char* base = (char*)d_scratch;
-    HIPCHK(c, hipMemsetAsync(base, 0, L.states, c->stream));   // statistics, sums, per-unit squared differences
+    HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // statistics, sums, per-unit squared differences, the walk's arrival counters (one fill for all of them)
     const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y, ep_mask,
                                                               (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
@@ -719,7 +719,7 @@ int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, in
             return SVT_HIP_ERR_BAD_ARG;
         }
         char* base = (char*)P.d_scratch;
-        HIPCHK(c, hipMemsetAsync(base, 0, L.states, c->stream));
+        HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // ... and the walk's arrival counters
         const int ux = sgr_units(P.pw, P.unit_size), uy = sgr_units(P.ph, P.unit_size);
         hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, ux, uy, P.ss_y,
                                                                   ep_mask, (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
