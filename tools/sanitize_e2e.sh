@@ -15,7 +15,7 @@ rm -f "$R/oracle/_ref/SvtAv1EncApp_hip" "$R/oracle/_ref/mock/libsvtav1_hip.so"; 
 make -C "$R" -f oracle/Makefile.enc -j16 -s EOBJDIR="$OUT/obj" CC="gcc $FLAGS" CXX="g++ $FLAGS" "$R/oracle/_ref/SvtAv1EncApp_hip" "$R/oracle/_ref/mock/libsvtav1_hip.so"
 mv "$R/oracle/_ref/SvtAv1EncApp_hip" "$OUT/SvtAv1EncApp_hip_$SAN"; mv "$R/oracle/_ref/mock/libsvtav1_hip.so" "$OUT/mock/"
 restore; trap - EXIT
-SAN=$SAN OUT=$OUT python3 - <<'PY'
+SAN=$SAN OUT=$OUT REPO=$R python3 - <<'PY'
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(os.environ.get("_", ""))))
 sys.path.insert(0, os.path.join(os.environ.get("REPO", os.getcwd()), "tests"))
