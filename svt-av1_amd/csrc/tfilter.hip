@@ -21,6 +21,8 @@
 // float in [-7, 0], the only range the filter can produce.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "svt_hip_internal.h"
 
 namespace {
@@ -35,6 +37,7 @@ struct TfArgs {
     int n_refs, bc64, tf_chroma, sq_shift, hbd;
     double den[3];            // 2 * n_decay^2 per plane
     double dist_thr;          // max(min_frame_size * 0.1, 1)
+    double rden[3], rdist_thr; // their correctly rounded reciprocals (host: 1.0 / y), for quot3
     unsigned long long* sse;  // [2]
 };
 
@@ -67,26 +70,48 @@ __device__ __forceinline__ float glibc_expf(float x, const unsigned long long* t
     return (float)y;
 }
 
-// EbTemporalFiltering.c:718-741: window error -> integer weight
-__device__ __forceinline__ int tf_weight(uint32_t sum, int num, double block_error, double d_factor, double den, const unsigned long long* tab) {
-    const double window_error = (double)sum / (double)num;
-    const double combined = (5.0 * window_error + block_error) / 6.0;
-    double scaled = combined * d_factor / den;
+// The weight divides three times per sample: by the window's sample count (25 .. 29), by 6 and by 2 n_decay^2.  An IEEE double division is a dozen
+// instructions on this chip (v_div_scale x 2, v_rcp_f64, a Newton ladder of v_fma_f64, v_div_fmas, v_div_fixup), and the kernel is bound by its FP64 issue.
+// With the divisor's correctly rounded reciprocal at hand, q = x r; e = fma(-y, q, x); q' = fma(e, r, q) IS the correctly rounded quotient (Markstein's
+// correction step) — tools/div_pin.c shows it on the CPU's identical arithmetic: every uint32 dividend for y = 25, 26, 27, 29, and the hardest dividends (a few
+// ulps around y Q and y (Q +- ulp / 2)) for y = 6 and for arbitrary y.  The theorem leaves out divisors whose significand is all ones; those, and divisors
+// outside 2^-500 .. 2^500, take the IEEE division: the divisors are launch constants, so the launcher picks the kernel instance (FAST) on the host.
+struct Recip { double y, r; };
+__device__ __forceinline__ double quot3(double x, double y, double r) {
+    const double q = x * r;
+    const double e = __builtin_fma(-y, q, x);
+    return __builtin_fma(e, r, q);
+}
+template <bool FAST> __device__ __forceinline__ double divide(double x, const Recip& R) { return FAST ? quot3(x, R.y, R.r) : x / R.y; }
+static bool recip_ok(double y) {   // host: may this launch constant go through quot3?
+    unsigned long long b; memcpy(&b, &y, 8);
+    const int ex = (int)((b >> 52) & 0x7ff);
+    return (b >> 63) == 0 && ex > 523 && ex < 1523 && (b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull;
+}
+
+// EbTemporalFiltering.c:718-741: window error -> integer weight.  NUM = samples of the error window (25 luma; 25 + the co-located luma samples for chroma)
+template <int NUM, bool FAST>
+__device__ __forceinline__ int tf_weight(uint32_t sum, double block_error, double d_factor, const Recip& den, const unsigned long long* tab) {
+    static_assert(NUM == 25 || NUM == 26 || NUM == 27 || NUM == 29, "tools/div_pin.c covers these sample counts");
+    const double window_error = FAST ? quot3((double)sum, (double)NUM, 1.0 / (double)NUM) : (double)sum / (double)NUM;
+    const double combined = FAST ? quot3(5.0 * window_error + block_error, 6.0, 1.0 / 6.0) : (5.0 * window_error + block_error) / 6.0;
+    double scaled = divide<FAST>(combined * d_factor, den);
     scaled = scaled < 7.0 ? scaled : 7.0;
     return (int)(glibc_expf((float)(-scaled), tab) * 1000.0f);
 }
 
 // block error and motion-distance factor of sub-block `sub` of 32x32 block idx32 (EbTemporalFiltering.c:707-734 / :886-924)
-__device__ __forceinline__ void block_terms(const SvtHipTfBlk64* __restrict__ b, int idx32, int sub, int hbd, double dist_thr, double& block_error, double& d_factor) {
+template <bool FAST>
+__device__ __forceinline__ void block_terms(const SvtHipTfBlk64* __restrict__ b, int idx32, int sub, int hbd, const Recip& dist_thr, double& block_error, double& d_factor) {
     unsigned long long err; int mvx, mvy; double div;
-    if (b->split[idx32]) { err = b->err16[idx32 * 4 + sub]; mvx = b->mv16_x[idx32 * 4 + sub]; mvy = b->mv16_y[idx32 * 4 + sub]; div = 256.0; }
-    else { err = b->err32[idx32]; mvx = b->mv32_x[idx32]; mvy = b->mv32_y[idx32]; div = 1024.0; }
+    if (b->split[idx32]) { err = b->err16[idx32 * 4 + sub]; mvx = b->mv16_x[idx32 * 4 + sub]; mvy = b->mv16_y[idx32 * 4 + sub]; div = 1.0 / 256.0; }
+    else { err = b->err32[idx32]; mvx = b->mv32_x[idx32]; mvy = b->mv32_y[idx32]; div = 1.0 / 1024.0; }
     if (hbd) err >>= 4;
-    block_error = (double)err / div;
+    block_error = (double)err * div;   // / 256 or / 1024: exact either way
     const float fr = (float)mvy, fc = (float)mvx;
     const float s = fr * fr + fc * fc;                         // powf(v, 2) is exact for a short; one rounding in the sum
     const float distance = (float)sqrt((double)s);            // == sqrtf(s): a correctly rounded f64 root rounds to the correctly rounded f32 root
-    const double dd = (double)distance / dist_thr;
+    const double dd = divide<FAST>((double)distance, dist_thr);
     d_factor = dd > 1.0 ? dd : 1.0;
 }
 
@@ -100,7 +125,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // One workgroup = one 32x32 luma block and its chroma, all frames.  Luma: thread t owns row t >> 3, columns 4 (t & 7) .. + 3.
 // Chroma (CW x CH = (32 >> SSX) x (32 >> SSY)): thread t owns samples t + 256 k, k < NC.
-template <typename PIX, int SSX, int SSY>
+template <typename PIX, int SSX, int SSY, bool FAST>
 __global__ void __launch_bounds__(256)
 tf_filter_kernel(const TfArgs a) {
     constexpr int CW = 32 >> SSX, CH = 32 >> SSY, NC = (CW * CH) / 256;
@@ -117,7 +142,7 @@ tf_filter_kernel(const TfArgs a) {
     const int ysub = (row >= 16) * 2 + (col0 >= 16);
     const bool chroma = a.tf_chroma != 0;
     const int n_refs = a.n_refs, hbd = a.hbd, sq_shift = a.sq_shift;
-    const double dist_thr = a.dist_thr;
+    const Recip dist_thr = {a.dist_thr, a.rdist_thr}, den0 = {a.den[0], a.rden[0]}, den1 = {a.den[1], a.rden[1]}, den2 = {a.den[2], a.rden[2]};
 
     // ---- central picture samples of this thread
     int ys[4], us[NC], vs[NC];
@@ -197,7 +222,7 @@ tf_filter_kernel(const TfArgs a) {
         const SvtHipTfBlk64* b = blocks + blk64;
         {
             double be, df;
-            block_terms(b, idx32, ysub, hbd, dist_thr, be, df);
+            block_terms<FAST>(b, idx32, ysub, hbd, dist_thr, be, df);
             uint32_t s4[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int dy = -2; dy <= 2; dy++) {
@@ -207,7 +232,7 @@ tf_filter_kernel(const TfArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int w = tf_weight(s4[i] >> sq_shift, 25, be, df, a.den[0], tab);
+                const int w = tf_weight<25, FAST>(s4[i] >> sq_shift, be, df, den0, tab);
                 ycnt[i] = (ycnt[i] + (uint32_t)w) & 0xffffu; yacc[i] += (uint32_t)(w * yp[i]);
             }
         }
@@ -217,7 +242,7 @@ tf_filter_kernel(const TfArgs a) {
                 const int idx = t + 256 * k, r = idx / CW, c = idx % CW;
                 const int li = r << SSY, lj = c << SSX;                      // the luma sample this chroma sample is filtered with (:746)
                 double be, df;
-                block_terms(b, idx32, (li >= 16) * 2 + (lj >= 16), hbd, dist_thr, be, df);
+                block_terms<FAST>(b, idx32, (li >= 16) * 2 + (lj >= 16), hbd, dist_thr, be, df);
                 uint32_t ysum = 0;
 #pragma unroll
                 for (int dy = 0; dy < (1 << SSY); dy++)
@@ -227,8 +252,8 @@ tf_filter_kernel(const TfArgs a) {
 #pragma unroll
                 for (int dy = -2; dy <= 2; dy++) { const int o = clampi(r + dy, 0, CH - 1) * CW + c; usum += uh[o]; vsum += vh[o]; }
                 constexpr int num = 25 + (1 << SSX) * (1 << SSY);
-                const int wu = tf_weight(usum >> sq_shift, num, be, df, a.den[1], tab);
-                const int wv = tf_weight(vsum >> sq_shift, num, be, df, a.den[2], tab);
+                const int wu = tf_weight<num, FAST>(usum >> sq_shift, be, df, den1, tab);
+                const int wv = tf_weight<num, FAST>(vsum >> sq_shift, be, df, den2, tab);
                 ucnt[k] = (ucnt[k] + (uint32_t)wu) & 0xffffu; uacc[k] += (uint32_t)(wu * up[k]);
                 vcnt[k] = (vcnt[k] + (uint32_t)wv) & 0xffffu; vacc[k] += (uint32_t)(wv * vp[k]);
             }
@@ -302,9 +327,14 @@ tf_noise_kernel(const PIX* __restrict__ src, int width, int height, int stride, 
 template <typename PIX>
 int launch_filter(hipStream_t st, const TfArgs& a, int w, int h, int ss_x, int ss_y) {
     const dim3 grid(w / 32, h / 32), block(256);
-    if (ss_x == 1 && ss_y == 1) hipLaunchKernelGGL((tf_filter_kernel<PIX, 1, 1>), grid, block, 0, st, a);
-    else if (ss_x == 1 && ss_y == 0) hipLaunchKernelGGL((tf_filter_kernel<PIX, 1, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((tf_filter_kernel<PIX, 0, 0>), grid, block, 0, st, a);
+    static const char* div_env = getenv("SVT_HIP_TF_DIV");   // "ieee": the IEEE divisions everywhere (A/B runs, tools/tf_time.py)
+    const bool fast = recip_ok(a.den[0]) && recip_ok(a.den[1]) && recip_ok(a.den[2]) && recip_ok(a.dist_thr) && !(div_env && !strcmp(div_env, "ieee"));
+#define TF_LAUNCH(SX, SY) do { if (fast) hipLaunchKernelGGL((tf_filter_kernel<PIX, SX, SY, true>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((tf_filter_kernel<PIX, SX, SY, false>), grid, block, 0, st, a); } while (0)
+    if (ss_x == 1 && ss_y == 1) TF_LAUNCH(1, 1);
+    else if (ss_x == 1 && ss_y == 0) TF_LAUNCH(1, 0);
+    else TF_LAUNCH(0, 0);
+#undef TF_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -314,13 +344,13 @@ extern "C" int svt_hip_launch_tf_filter(hipStream_t st, int pix_bytes, int bd, c
                                         const int dst_stride[3], int w, int h, int ss_x, int ss_y, int tf_chroma, const SvtHipTfRef* refs, int n_refs,
                                         const double den[3], double dist_thr, uint64_t* sse) {
     TfArgs a;
-    for (int p = 0; p < 3; p++) { a.src[p] = src[p]; a.src_stride[p] = src_stride[p]; a.dst[p] = dst[p]; a.dst_stride[p] = dst_stride[p]; a.den[p] = den[p]; }
+    for (int p = 0; p < 3; p++) { a.src[p] = src[p]; a.src_stride[p] = src_stride[p]; a.dst[p] = dst[p]; a.dst_stride[p] = dst_stride[p]; a.den[p] = den[p]; a.rden[p] = 1.0 / den[p]; }
     for (int f = 0; f < kMaxRefs; f++) {
         for (int p = 0; p < 3; p++) { a.pred[f][p] = f < n_refs ? refs[f].pred[p] : nullptr; a.pred_stride[f][p] = f < n_refs ? refs[f].pred_stride[p] : 0; }
         a.blocks[f] = f < n_refs ? refs[f].blocks : nullptr;
     }
     a.n_refs = n_refs; a.bc64 = w / 64; a.tf_chroma = tf_chroma; a.hbd = pix_bytes == 2; a.sq_shift = pix_bytes == 2 ? (bd - 8) * 2 : 0;
-    a.dist_thr = dist_thr; a.sse = (unsigned long long*)sse;
+    a.dist_thr = dist_thr; a.rdist_thr = 1.0 / dist_thr; a.sse = (unsigned long long*)sse;
     return pix_bytes == 1 ? launch_filter<uint8_t>(st, a, w, h, ss_x, ss_y) : launch_filter<uint16_t>(st, a, w, h, ss_x, ss_y);
 }
 

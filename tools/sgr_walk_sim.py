@@ -33,7 +33,7 @@ def main():
     pols = [(0, 8, 0, 0), (0, 12, 0, 0), (0, 16, 0, 0), (2, 8, 0, 0), (2, 16, 0, 0), (1, 8, 0.5, 0.1), (1, 8, 1.0, 0.1), (1, 12, 1.0, 0.1), (1, 16, 1.0, 0.1), (1, 16, 1.0, 0.02),
             (4, 8, 0.5, 1), (4, 8, 1.0, 1), (4, 8, 1.0, 2)]
     P = (Policy * len(pols))(*[Policy(m, c, s, p, k) for k, (m, c, s, p) in enumerate(pols)])   # stop_known doubles as the policy's index
-    A, B = 34000.0, 3500.0   # shader cycles per pass (replay + streaming the non-resident 62 % of a unit + barriers) and per evaluated point: fitted to profiles/r03/bench.json config.sgr_walk.phase_cycles_per_walk
+    A, B = 44000.0, 2100.0   # shader cycles per pass (36 k of evaluation phase: streaming the non-resident 62 % of a unit, barriers; + 8 k of replay) and per evaluated point: least squares on profiles/r03/sgr_walk_cand_sweep.txt (MI355X, 4 / 6 / 8 points per pass)
     tot = None
     for pl in range(3):
         ext, src = npz[f"e{pl}"], npz[f"s{pl}"]
