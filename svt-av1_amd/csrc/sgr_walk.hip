@@ -153,7 +153,30 @@ __device__ __forceinline__ void walk_begin(WalkState& W, const int start[2]) { W
 // the quadratic model, collecting up to K.cap unknown points.  Returns true when the walk finished on exact errors only (W.q0, W.q1, W.err = result).
 struct ModelSums { double H00, H01, H11, C0, C1; };   // the five projection sums of the (unit, set), read from memory once per walk
 __device__ __forceinline__ ModelSums load_model(const long long* sums) { return ModelSums{(double)sums[0], (double)sums[1], (double)sums[2], (double)sums[3], (double)sums[4]}; }
-template <class Store>
+// HEDGE (opt-in instance): what the OTHER outcome of a speculative decision would probe next is asked for as well.  A pass costs ~44 k cycles whatever it evaluates
+// (it streams the part of the unit that is not resident) and a point ~2 k (profiles/r03/sgr_walk_cand_sweep.txt), while half of the decisions near the optimum are
+// decided by rounding noise the model cannot see (tools/sgr_walk_sim.c: 2.97 -> 2.20 passes per walk with 16 points per pass).  These two helpers restate the walk's
+// state transitions for that look-ahead only; whatever they return changes which points are evaluated, never the result.
+__device__ __forceinline__ void walk_apply(WalkState& A, bool accept, int c0, int c1) {
+    bool again = false;
+    if (accept) { A.q0 = c0; A.q1 = c1; if (!A.up) A.moved = 1; again = A.s == 2; }
+    if (!again) {
+        if (!A.up) { if (A.moved) A.p = 2; else A.up = 1; }
+        else { A.p++; A.up = 0; A.moved = 0; }
+    }
+}
+__device__ __forceinline__ bool walk_peek(WalkState A, bool has0, bool has1, int& c0, int& c1) {
+    for (int guard = 0; guard < 12 && A.s >= 1; guard++) {
+        if (A.p >= 2) { A.s >>= 1; A.p = 0; A.up = 0; A.moved = 0; continue; }
+        if (A.p == 0 ? !has0 : !has1) { A.p++; A.up = 0; A.moved = 0; continue; }
+        const int tmin = A.p == 0 ? -96 : -32, tmax = A.p == 0 ? 31 : 95;
+        const int qp = A.p == 0 ? A.q0 : A.q1, d = A.up ? A.s : -A.s;
+        if (A.up ? qp + A.s <= tmax : qp - A.s >= tmin) { c0 = A.p == 0 ? A.q0 + d : A.q0; c1 = A.p == 0 ? A.q1 : A.q1 + d; return true; }
+        walk_apply(A, false, 0, 0);
+    }
+    return false;
+}
+template <class Store, bool HEDGE = false>
 __device__ bool replay(Store& K, WalkState& W, int ep, const ModelSums& MS) {
     const bool   has0 = ep < 10 || ep >= 14, has1 = ep < 14;
     const double H00 = MS.H00, H01 = MS.H01, H11 = MS.H11, C0 = MS.C0, C1 = MS.C1;
@@ -190,6 +213,13 @@ __device__ bool replay(Store& K, WalkState& W, int ep, const ModelSums& MS) {
         if (T.up ? qp + T.s <= tmax : qp - T.s >= tmin) {
             const int c0 = T.p == 0 ? T.q0 + d : T.q0, c1 = T.p == 0 ? T.q1 : T.q1 + d;
             const double err2 = value(c0, c1);
+            if (HEDGE && spec && K.nw < K.cap) {   // the other outcome's next probe
+                WalkState A = T;
+                walk_apply(A, err2 > T.err, c0, c1);
+                int a0, a1;
+                long long e;
+                if (walk_peek(A, has0, has1, a0, a1) && !K.lookup(a0, a1, e)) K.want(a0, a1);
+            }
             if (!(err2 > T.err)) { T.q0 = c0; T.q1 = c1; T.err = err2; if (!T.up) T.moved = 1; again = T.s == 2; }
         }
         if (!again) {
@@ -443,6 +473,31 @@ __device__ __forceinline__ void eval_chunk_f(const int4& a0, const int4& a1, con
         : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
           [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "v"(q), [sel] "s"(sel));
 }
+// One accumulator per candidate (the 16-candidate instance: |e| < 2^10 at bit depth 8 and a thread sees < 400 samples of the largest unit, so 2^20 x 400 < 2^31):
+// the four squaring dots chain through p (a dot may feed the next dot's accumulator back to back).
+__device__ __forceinline__ void eval_chunk_f1(const int4& a0, const int4& a1, const int (&c)[8], int q, int sel, int& p) {
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_dot2_i32_i16 %[t0], %[a0], %[q], %[c0]\n\t"
+        "v_dot2_i32_i16 %[t1], %[a1], %[q], %[c1]\n\t"
+        "v_dot2_i32_i16 %[t2], %[a2], %[q], %[c2]\n\t"
+        "v_dot2_i32_i16 %[t3], %[a3], %[q], %[c3]\n\t"
+        "v_dot2_i32_i16 %[t4], %[a4], %[q], %[c4]\n\t"
+        "v_dot2_i32_i16 %[t5], %[a5], %[q], %[c5]\n\t"
+        "v_dot2_i32_i16 %[t6], %[a6], %[q], %[c6]\n\t"
+        "v_dot2_i32_i16 %[t7], %[a7], %[q], %[c7]\n\t"
+        "v_perm_b32 %[t0], %[t1], %[t0], %[sel]\n\t"
+        "v_perm_b32 %[t2], %[t3], %[t2], %[sel]\n\t"
+        "v_perm_b32 %[t4], %[t5], %[t4], %[sel]\n\t"
+        "v_perm_b32 %[t6], %[t7], %[t6], %[sel]\n\t"
+        "v_dot2_i32_i16 %[p], %[t0], %[t0], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t2], %[t2], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t4], %[t4], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t6], %[t6], %[p]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [p] "+v"(p)
+        : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
+          [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "v"(q), [sel] "s"(sel));
+}
 __device__ __forceinline__ void dot_drain() { asm volatile("s_nop 2"); }
 // zero the pixels of a chunk at or past column n (n < 8): their error is then 0 for every candidate
 __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
@@ -454,10 +509,12 @@ __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
     a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]); s = make_int4(sw[0], sw[1], sw[2], sw[3]);
 }
 
-template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
+template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA > 8 (opt-in instance): one accumulator per candidate, and the walker also asks for the other outcome's next probe; NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
 __global__ void __launch_bounds__(kT, (kT == 512 ? 4 : 1))   // the hybrid instances are built for two workgroups per compute unit: 128 registers
 sgr_walk_resident_kernel(const WalkPic a) {
     constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
+    constexpr bool ONE_ACC = NA > 8, HEDGE = NA > 8;   // sixteen candidates per pass keep one int32 accumulator each (bit depth 8 only); their walker hedges its requests
+    static_assert(!ONE_ACC || BD == 8, "one int32 accumulator per candidate holds a thread's squares at bit depth 8 only");
     __shared__ ResLdsT<kT, kJ> R;
     WalkLds& L = R.W;
     // the planes of a picture share one launch (grid.z): one tail instead of three.  Scalar copies of the plane's arguments (a reference into the
@@ -505,7 +562,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
         for (int pass = 0; pass < 64; pass++) {
             const unsigned long long r0 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_setprio(3);   // the replay is the serial part of the walk: it goes ahead of the other workgroup's evaluation waves on this SIMD
-            fin = replay(K, W, ep, MS);
+            fin = replay<RegStore, HEDGE>(K, W, ep, MS);
             __builtin_amdgcn_s_setprio(0);
             c_replay += __builtin_readcyclecounter() - r0;
             const int nc = K.nw;
@@ -608,7 +665,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
 #pragma unroll
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
-                            eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
+                            if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
                             if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
                     a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
@@ -622,7 +679,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
 #pragma unroll
                 for (int c = 0; c < NA; c++)
                     if (c < nc) {
-                        eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
+                        if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
                         if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                     }
                 a0 = b0; a1 = b1; s4 = t4; k = kn;
@@ -636,7 +693,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
 #pragma unroll
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
-                            eval_chunk_f(pa[j], pb[j], sx, qq[c], sel, pp0[c], pp1[c]);
+                            if (ONE_ACC) eval_chunk_f1(pa[j], pb[j], sx, qq[c], sel, pp0[c]); else eval_chunk_f(pa[j], pb[j], sx, qq[c], sel, pp0[c], pp1[c]);
                             if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
                 }
@@ -697,7 +754,8 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
     constexpr int kHybT = 512, kHybJ = 7, kHybNA = 8;
     constexpr int kHybNA10 = 5;   // bit depth 10 keeps 64-bit accumulators: fewer of them fit the 128-register budget of two workgroups per compute unit
-    const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? kHybNA : kHybNA10));
+    static const bool hyb16 = form_env && !strcmp(form_env, "hybrid16");   // opt-in: sixteen points per pass (one accumulator each) + hedged requests, bit depth 8
+    const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? (hyb16 ? 16 : kHybNA) : kHybNA10));
     const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
     WalkPic a = {};
     a.cap = cap;
@@ -727,6 +785,10 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     dim3 grid(max_units, 16, n_planes);
     static const bool hyb256 = form_env && !strcmp(form_env, "hybrid256"), hyb256j = form_env && !strcmp(form_env, "hybrid256j");
     static const bool hybpf5 = form_env && !strcmp(form_env, "hybridpf5");
+    if (hyb16 && bd == 8) {   // experiment (MI355X, profiles/r03/sgr_walk_hybrid16_ab.txt: 2.03 instead of 2.79 passes, 15.2 instead of 10.9 points per walk; stage 1.012 -> 0.993 ms, four-frame step 8.61 -> 8.76 ms: not the default)
+        hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, kHybJ, 16>), grid, dim3(kHybT), 0, st, a);
+        return (int)hipGetLastError();
+    }
     if (hybpf5 && bd == 8) {   // experiment (MI355X: 1.190 vs 1.163 ms, no gain): five resident chunks instead of seven, two streamed chunks in flight
         hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, 5, kHybNA, 2>), dim3(max_units, 16, n_planes), dim3(kHybT), 0, st, a);
         return (int)hipGetLastError();
