@@ -251,6 +251,7 @@ class Pipeline:
                                                    self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr()), "sgr apply")
 
 
+STAGGER_DEFAULT = "off"
 ALL_STAGES = [("pyr", "pyramids"), ("hme", "hme_l0_l1_l2"), ("me", "me_fullpel_85pu"), ("subpel", "subpel_convolve"), ("enc_txfm", "fwd_quant_inv_recon"),
               ("txfm", "fwd_txfm_quant"), ("inv", "inv_txfm_recon"), ("dlf", "deblock"), ("cdef_search", "cdef_search"), ("cdef_pick", "cdef_strength_select"), ("cdef_apply", "cdef_apply"), ("sgr_units", "sgr_units_search"),
               ("sgr_apply", "sgr_apply")]
@@ -356,6 +357,13 @@ def main():
     max_f = max([nF] + (sweep_fs if not args.no_sweep else []))
     main_streams = [torch.cuda.Stream() for _ in range(max_f)]
 
+    # SVT_BENCH_STAGGER="<stage>:<lag>": frame i of a step (i >= lag) starts its chain when frame i - lag has finished <stage>.  Four chains that start together run the
+    # same stage at the same time, so all four sit in the latency-bound strength decision together (80 dependent launches, ~0.65 ms with the chip nearly idle); a
+    # staggered start would put one frame's decision beside another frame's searches.  Measured on the MI355X (profiles/r03/bench_stagger_ab.txt): every staggered start is
+    # SLOWER (8.51 ms unstaggered; me:1 9.01, enc_txfm:1 9.41, me:2 9.87, subpel:2 10.1, cdef_search:2 10.5, cdef_pick:1 11.9 ms) - the step is a fork / join, and what a
+    # late chain gains beside the others' decisions it loses alone at the tail.  "off" (default): every chain starts at once.
+    stagger = os.environ.get("SVT_BENCH_STAGGER", STAGGER_DEFAULT)
+    stagger_stage, stagger_lag = (stagger.split(":")[0], int(stagger.split(":")[1])) if stagger not in ("", "off") else (None, 0)
     joint_pick = bool(os.environ.get("SVT_BENCH_PICK_JOINT"))   # measured slower (9.9 vs 9.5 ms): the join idles the other streams for the length of the chain   # A/B: the strength decision per frame, inside each frame's own chain (the round-3 first form)
 
     # CDEF strength selection: the one-launch (resident) form when ONE frame is in flight, the launch-per-step form when several are (include/svt_hip.h: the
@@ -377,15 +385,21 @@ def main():
         halves = [keys] if split is None else [keys[:split], keys[split + 1:]]
         for hi, half in enumerate(halves):
             used = []
+            released = {}
             for i, P in enumerate(batch):
                 ms = main_streams[i]
                 ms.wait_stream(base)
+                if stagger_stage in half and i - stagger_lag in released:
+                    ms.wait_event(released[i - stagger_lag])
                 used.append(ms)
                 with on(ms):
                     if hi == 0 and pre is not None: pre(P)
                     if hi == 1: P.run_cdef_finish()
                     for k in half:
                         P.stage_fns[k]()
+                        if k == stagger_stage and len(batch) > 1:
+                            released[i] = torch.cuda.Event()
+                            released[i].record(ms)
             for st in used:
                 base.wait_stream(st)
             if hi == 0 and split is not None:
