@@ -282,7 +282,7 @@ static uint64_t tf_sp_distortion(const TfSp *t, const void *pred, int bs, int lx
 }
 static void tf_sp_search(const TfSp *t, int bs, int px, int py, int lx, int ly, uint32_t word, int16_t *out_x, int16_t *out_y, uint64_t *out_err) {
     uint16_t pred[32 * 32];
-    int16_t  mv_x = (int16_t)((int16_t)(word & 0xffff) << 1), mv_y = (int16_t)((int16_t)(word >> 16) << 1), best_x = mv_x, best_y = mv_y;
+    int16_t  mv_x = (int16_t)((int16_t)(word & 0xffff) * 2), mv_y = (int16_t)((int16_t)(word >> 16) * 2), best_x = mv_x, best_y = mv_y;   /* the reference shifts the (possibly negative) vector left by one */
     uint64_t best = 0x7fffffff;   /* INT_MAX */
     for (int round = 0; round < (t->tf_hp ? 3 : 2); round++) {
         const int step = 4 >> round;

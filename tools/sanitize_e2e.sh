@@ -2,11 +2,11 @@
 # CPU only (needs /root/reference): the hooked reference encoder (integration/*.c + the patched reference files) and the CPU test double of the library, built
 # with AddressSanitizer or ThreadSanitizer, run through end-to-end encodes with every hook on (incl. the opt-in ones).  The unpatched reference objects stay
 # uninstrumented (they come from Makefile.ref's object directory).  Reports are written to $OUT/log_*; a run is clean when no report names integration/, svt_hip or
-# the mock.      usage: tools/sanitize_e2e.sh address|thread [out_dir]
+# the mock.      usage: tools/sanitize_e2e.sh address|thread|undefined [out_dir]
 set -eu
 SAN=${1:-address}; OUT=${2:-/tmp/sanitize_$SAN}
 R=$(cd "$(dirname "$0")/.." && pwd)
-FLAGS="-fsanitize=$SAN -g -fno-omit-frame-pointer"; [ "$SAN" = address ] && FLAGS="$FLAGS -fsanitize-recover=address"
+FLAGS="-fsanitize=$SAN -g -fno-omit-frame-pointer"; [ "$SAN" = address ] && FLAGS="$FLAGS -fsanitize-recover=address"; [ "$SAN" = undefined ] && FLAGS="$FLAGS -fno-sanitize=alignment"
 mkdir -p "$OUT/mock" "$OUT/keep/mock"
 cp "$R/oracle/_ref/SvtAv1EncApp_hip" "$OUT/keep/"; cp "$R/oracle/_ref/mock/libsvtav1_hip.so" "$OUT/keep/mock/"
 restore() { cp "$OUT/keep/SvtAv1EncApp_hip" "$R/oracle/_ref/"; cp "$OUT/keep/mock/libsvtav1_hip.so" "$R/oracle/_ref/mock/"; }
@@ -30,18 +30,22 @@ cases = {"cif_8bit_m6": (352, 288, 6, 8, 6, 35, opt, []), "cif_10bit_m6": (352, 
          "qcif_m0": (176, 144, 3, 8, 0, 40, "all", []), "tiles_2x2": (352, 288, 6, 8, 6, 38, "all", ["-tile-columns", "1", "-tile-rows", "1"]),
          "screen_content": (352, 288, 6, 8, 6, 38, "all", ["-scm", "1"]), "altref_7_frames": (352, 288, 6, 8, 6, 38, "all", ["-altref-nframes", "7", "-altref-strength", "6"]),
          "film_grain": (352, 288, 6, 8, 6, 38, "all", ["-film-grain", "8"]), "low_delay_p": (352, 288, 6, 8, 6, 38, "all", ["-pred-struct", "0"])}
-if san == "thread":
+if san in ("thread", "undefined"):
     cases = {k: cases[k] for k in ("cif_8bit_m6", "cif_10bit_m6", "tiles_2x2")}
 bad = 0
 for name, (w, h, n, bd, preset, q, hooks, extra) in cases.items():
     clip = os.path.join(wd, name + ".yuv"); E.make_clip(clip, w, h, n, seed=7 + w, bd=bd)
     ref = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(wd, name + ".ref"), extra_args=extra)
-    env = {"LD_LIBRARY_PATH": mock, "SVT_HIP_HOOKS": hooks, ("ASAN_OPTIONS" if san == "address" else "TSAN_OPTIONS"): f"detect_leaks=0:halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path={out}/log_{name}"}
+    env = {"LD_LIBRARY_PATH": mock, "SVT_HIP_HOOKS": hooks, {"address": "ASAN_OPTIONS", "thread": "TSAN_OPTIONS", "undefined": "UBSAN_OPTIONS"}[san]: f"print_stacktrace=1:detect_leaks=0:halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path={out}/log_{name}"}
     got = E.encode(app, clip, w, h, n, preset, q, bd, os.path.join(wd, name + "." + san), env_extra=env, extra_args=extra, timeout=2400)
     same = got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"]
     logs = [f for f in os.listdir(out) if f.startswith("log_" + name + ".")]
-    ours = sum(1 for f in logs if any(k in open(os.path.join(out, f), errors="replace").read() for k in ("integration/", "svt_hip", "hip_mock", "_oracle.c")))
-    total = sum(open(os.path.join(out, f), errors="replace").read().count("WARNING: ThreadSanitizer") + open(os.path.join(out, f), errors="replace").read().count("ERROR: AddressSanitizer") for f in logs)
+    def ours_in(txt):   # UBSan names the offending source line itself; for the other two any frame of ours in a report counts
+        if san == "undefined":
+            return sum(1 for l in txt.splitlines() if "runtime error:" in l and any(k in l.split(":")[0] for k in ("/integration/", "/oracle/", "/svt-av1_amd/")))
+        return int(any(k in txt for k in ("integration/", "svt_hip", "hip_mock", "_oracle.c")))
+    ours = sum(ours_in(open(os.path.join(out, f), errors="replace").read()) for f in logs)
+    total = sum(sum(open(os.path.join(out, f), errors="replace").read().count(k) for k in ("WARNING: ThreadSanitizer", "ERROR: AddressSanitizer", "runtime error:")) for f in logs)
     bad += (not same) + ours
     print(f"{name}: {'identical' if same else 'DIFFERENT'}; {san} reports {total}, naming the hooks / the library / the test double: {ours}", flush=True)
 sys.exit(1 if bad else 0)
