@@ -513,8 +513,9 @@ template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA > 8 (opt-in instan
 __global__ void __launch_bounds__(kT, (kT == 512 ? 4 : 1))   // the hybrid instances are built for two workgroups per compute unit: 128 registers
 sgr_walk_resident_kernel(const WalkPic a) {
     constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
-    constexpr bool ONE_ACC = NA > 8, HEDGE = NA > 8;   // sixteen candidates per pass keep one int32 accumulator each (bit depth 8 only); their walker hedges its requests
-    static_assert(!ONE_ACC || BD == 8, "one int32 accumulator per candidate holds a thread's squares at bit depth 8 only");
+    constexpr bool HEDGE = NA > 8;                        // the sixteen-candidate instance's walker hedges its requests
+    constexpr bool ONE_ACC = NA > 8 || (BD > 8 && PF != 2);   // one int32 accumulator per candidate: the sixteen-candidate instance (bit depth 8: a thread's squares fit), and bit depth 10 with periodic 64-bit drains
+    static_assert(NA <= 8 || BD == 8, "sixteen int32 accumulators hold a thread's squares at bit depth 8 only");
     __shared__ ResLdsT<kT, kJ> R;
     WalkLds& L = R.W;
     // the planes of a picture share one launch (grid.z): one tail instead of three.  Scalar copies of the plane's arguments (a reference into the
@@ -639,7 +640,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
         if constexpr (NA > 0) if (nchunk > kResJ * kResD) {
             hybrid_done = true;
             // ---- hybrid: the streamed part of the unit first (its loads are in flight while the resident part is evaluated), one pass over it for all
-            // candidates; per candidate two int32 accumulators (bit depth 8: |e| < 2^10, < 160 samples per thread) or a 64-bit one (bit depth 10)
+            // candidates; per candidate two int32 accumulators (bit depth 8: |e| < 2^10, < 160 samples per thread) or one int32 accumulator emptied into a 64-bit sum every third chunk (bit depth 10)
             int pp0[NA], pp1[NA]; long long acc[NA];
             int qq[NA];
 #pragma unroll
@@ -654,6 +655,15 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 if (n < 8) mask_chunk(x0v, x1v, sv, n);
             };
             if (k < nchunk) fetch(k, a0, a1, s4);
+            // bit depth 10: |e| < 2^13, eight squares per chunk: the candidate's int32 accumulator holds kDrain = 3 chunks (3 x 2^29 < 2^31) before it is emptied into
+            // its 64-bit sum -- every third streamed chunk, once more before the resident slots, every third of those, and at the end
+            constexpr int kDrain = 3;
+            auto drain = [&]() {
+                dot_drain();
+#pragma unroll
+                for (int c = 0; c < NA; c++)
+                    if (c < nc) { acc[c] += (long long)pp0[c] + (long long)pp1[c]; pp0[c] = pp1[c] = 0; }
+            };
             if constexpr (PF == 2) {   // two chunks in flight: a compute unit's streaming rate is set by the bytes it has outstanding
                 int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
                 if (k + kResD < nchunk) fetch(k + kResD, b0, b1, t4);
@@ -670,7 +680,8 @@ sgr_walk_resident_kernel(const WalkPic a) {
                         }
                     a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
                 }
-            } else
+            } else {
+            int since = 0;
             while (k < nchunk) {
                 const int kn = k + kResD;
                 int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
@@ -680,9 +691,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 for (int c = 0; c < NA; c++)
                     if (c < nc) {
                         if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
-                        if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                     }
+                if (BD > 8 && ++since == kDrain) { drain(); since = 0; }
                 a0 = b0; a1 = b1; s4 = t4; k = kn;
+            }
+            if (BD > 8 && since) drain();
             }
             // ---- the resident chunks, slot by slot for all candidates (one LDS read of dat - src per slot)
 #pragma unroll
@@ -694,16 +707,17 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
                             if (ONE_ACC) eval_chunk_f1(pa[j], pb[j], sx, qq[c], sel, pp0[c]); else eval_chunk_f(pa[j], pb[j], sx, qq[c], sel, pp0[c], pp1[c]);
-                            if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                            if (BD > 8 && PF == 2) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
+                    if (BD > 8 && PF != 2 && (j + 1) % kDrain == 0 && j + 1 < kResJ) drain();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (BD == 8) dot_drain();
+            dot_drain();
 #pragma unroll
             for (int c = 0; c < NA; c++)
                 if (c < nc) {
-                    const long long sum = wave_sum_u48(acc[c] + pp0[c] + pp1[c]);
+                    const long long sum = wave_sum_u48(acc[c] + (long long)pp0[c] + (long long)pp1[c]);
                     if (lane == 0) L.part[wave][c] = sum;
                 }
         }
