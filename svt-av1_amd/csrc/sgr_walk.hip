@@ -767,9 +767,11 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     const bool stream_form = form_env && !strcmp(form_env, "stream"), resident_form = form_env && !strcmp(form_env, "resident");
     static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
     constexpr int kHybT = 512, kHybJ = 7, kHybNA = 8;
-    constexpr int kHybNA10 = 5;   // bit depth 10 keeps 64-bit accumulators: fewer of them fit the 128-register budget of two workgroups per compute unit
+    constexpr int kHybNA10 = 7;   // bit depth 10: an int32 accumulator + a 64-bit sum per candidate; 7 spill 20 registers outside the loops and still win (MI355X, configs[3] unit search: 5: 2.02-2.03, 6: 1.95, 7: 1.90 ms; 8 spill 51)
     static const bool hyb16 = form_env && !strcmp(form_env, "hybrid16");   // opt-in: sixteen points per pass (one accumulator each) + hedged requests, bit depth 8
-    const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? (hyb16 ? 16 : kHybNA) : kHybNA10));
+    static const int na10_env = getenv("SVT_HIP_SGR_WALK_NA10") ? atoi(getenv("SVT_HIP_SGR_WALK_NA10")) : 0;   // A/B: 5 or 6 accumulators at bit depth 10
+    const int na10 = (na10_env == 5 || na10_env == 6) ? na10_env : kHybNA10;
+    const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? (hyb16 ? 16 : kHybNA) : na10));
     const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
     WalkPic a = {};
     a.cap = cap;
@@ -822,6 +824,8 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
         else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);
     } else {
         if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, kHybJ, kHybNA>), grid, dim3(kHybT), 0, st, a);
+        else if (na10 == 5) hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, 5>), grid, dim3(kHybT), 0, st, a);
+        else if (na10 == 6) hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, 6>), grid, dim3(kHybT), 0, st, a);
         else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, kHybNA10>), grid, dim3(kHybT), 0, st, a);
     }
     return (int)hipGetLastError();
