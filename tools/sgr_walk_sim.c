@@ -181,7 +181,8 @@ static void speculate(Unit *U, Cache *K, const WS *W, const Policy *P, double si
     }
 }
 
-static void run_policy(Unit *U, const int start[2], const Policy *P, Stats *S, double A, double B, double sigma) {
+long g_policy_mismatch;   /* walks whose simulated result (xqd pair, error) differs from the reference walk's: must stay 0 for every policy */
+static void run_policy(Unit *U, const int start[2], const Policy *P, Stats *S, double A, double B, double sigma, const int ref_xy[2], int64_t ref_err) {
     Cache K; K.n = 0;
     WS W = {2, 0, 0, start[0], start[1], 0, 0, 0.0, 0};
     int passes = 0, points = 0;
@@ -193,6 +194,7 @@ static void run_policy(Unit *U, const int start[2], const Policy *P, Stats *S, d
         for (int i = 0; i < K.nw; i++) { (void)exact_err(U, K.wx[i], K.wy[i]); K.x[K.n] = K.wx[i]; K.y[K.n] = K.wy[i]; K.n++; }
         passes++; points += K.nw;
     }
+    if (W.q0 != ref_xy[0] || W.q1 != ref_xy[1] || (int64_t)W.err != ref_err || W.s >= 1) g_policy_mismatch++;
     S->walks++; S->passes += passes; S->points += points; S->hist[passes < 15 ? passes : 15]++;
     { const int cls = U->has0 && U->has1 ? 0 : (U->has1 ? 1 : 2); g_cls_pass[P->stop_known][cls] += passes; g_cls_pts[P->stop_known][cls] += points; }
     S->cost += A * passes + B * points;
@@ -250,6 +252,7 @@ static void solve_and_encode(const int64_t *sums, int size, int ep, int xqd[2]) 
 
 /* dgd: pixel (0, 0) of the 3-sample extended CDEF output (8-bit).  stats[n_pol].  noise[4]: sum of squared (exact - model) probe-vs-current
  * differences normalised by err_model / 12 ... (diagnostics: [0] count, [1] sum of z^2 with z = diff / sqrt(n / 12 ... )) */
+int32_t *g_ref_xqd; int64_t *g_ref_err;   /* optional: [unit][16][2] / [unit][16] results of the reference walk (the caller compares them with the oracle's search) */
 int sim_plane(const uint8_t *dgd, int stride, const uint8_t *src, int src_stride, int pw, int ph, int ss, int unit_size, uint32_t ep_mask,
               const Policy *pol, int n_pol, Stats *stats, double A, double B, double *noise, int max_units) {
     const int nu = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size);
@@ -285,6 +288,7 @@ int sim_plane(const uint8_t *dgd, int stride, const uint8_t *src, int src_stride
             solve_and_encode(sums, w * h, ep, start);
             int rxy[2]; int64_t rerr;
             const int nref = ref_points(U, start, rxy, &rerr);
+            if (g_ref_xqd) { g_ref_xqd[((size_t)u * 16 + ep) * 2] = rxy[0]; g_ref_xqd[((size_t)u * 16 + ep) * 2 + 1] = rxy[1]; g_ref_err[(size_t)u * 16 + ep] = rerr; }
             /* noise of the model: for the probes of the reference walk, (exact diff - model diff / 2^22) against sqrt(err) */
             {
                 /* model is in units of 2^22 x error (xq scaled by 2^-11, squared) up to a constant: exact ~ model / 2^22 + const */
@@ -303,7 +307,7 @@ int sim_plane(const uint8_t *dgd, int stride, const uint8_t *src, int src_stride
                 stats[k].ref_points += nref;
                 /* sigma in model units: sigma_k x sqrt(err / 12) x 2^22  (2 sum(m delta) has variance 4 sum(m^2) / 12; differences of two nearby points correlate) */
                 const double sigma = pol[k].sigma_k * sqrt(e_start / 12.0 + 1.0) * 4194304.0;
-                run_policy(U, start, &pol[k], &stats[k], A, B, sigma);
+                run_policy(U, start, &pol[k], &stats[k], A, B, sigma, rxy, rerr);
             }
         }
         free(U->d0);
