@@ -211,10 +211,22 @@ PATCHES.append(msp)
 # the HME pyramids (:3312, :3606) and the per-SB mean / variance pyramid (:2929 -> :1005) as picture-level launches (svt_hip_pa_bridge.c)
 pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")
 pa.sub(r'(void downsample_decimation_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',
-       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 0) == EB_ErrorNone)\n'
-       r'        return;\n')
+       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 0) == EB_ErrorNone) {\n'
+       r'        svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 1);\n'
+       r'        return;\n'
+       r'    }\n')
 pa.sub(r'(void downsample_filtering_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',
-       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_picture_ptr, sixteenth_picture_ptr, 1) == EB_ErrorNone) return;\n')
+       r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_picture_ptr, sixteenth_picture_ptr, 1) == EB_ErrorNone) {\n'
+       r'        svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_picture_ptr, sixteenth_picture_ptr, 0);\n'
+       r'        return;\n'
+       r'    }\n')
+# Resident planes (SVT_HIP_RESIDENT, svt_hip_hooks.c): every writer of an EbPaReferenceObject's luma planes -- picture analysis (:3960-3994), its overlay twin
+# (EbPictureDecisionProcess.c:3644-3680) and pad_and_decimate_filtered_pic (EbTemporalFiltering.c:2556) -- ends in these two functions, with the padded plane
+# complete before the first one is called: their last statement announces the planes as (re)written
+pa.sub(r'(sixteenth_decimated_picture_ptr->origin_x,\n[ \t]*sixteenth_decimated_picture_ptr->origin_y\);\n)(\}\n\nint svt_av1_count_colors_highbd)',
+       r'\1    svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 1);\n\2')
+pa.sub(r'(sixteenth_picture_ptr->origin_y\);\n        \}\n    \}\n)(\}\n\n// Current down sampled input is not used for HME)',
+       r'\1    svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_picture_ptr, sixteenth_picture_ptr, 0);\n\2')
 pa.sub(r'(\n[ \t]*// Variance\n[ \t]*uint64_t pic_tot_variance = 0;\n)',
        r'\1    const int hip_var = svt_hip_hook_pa_variance(scs_ptr, pcs_ptr, input_padded_picture_ptr) == EB_ErrorNone; /* y_mean / variance of every SB */\n')
 pa.sub(r'(\n[ \t]*)(compute_block_mean_compute_variance\(\s*scs_ptr, pcs_ptr, input_padded_picture_ptr, sb_index, input_luma_origin_index\);)',

@@ -152,6 +152,33 @@ int svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origi
     return 1;
 }
 
+static int dev_need(SvtHipCtx *hip, void **d, size_t *cap, size_t bytes);
+/* svt_hip_me_fullpel_frame on planes that are on the device already: [windows | SADs | MVs] in one staging block of the batch, one upload, two downloads.  The
+ * checks and the choice of the strip-walking instance are the host entry's (svt_hip_api.cpp: negative areas are refused, > 65 536 candidates select the instance). */
+static int integer_search_resident(SvtHipCtx *hip, SvtHipMeBatch *b, const uint8_t *d_src, const uint8_t *d_ref, const EbPictureBufferDesc *p,
+                                   const SvtHipSbSearch *wins, uint32_t n, uint32_t *sad, uint32_t *mv) {
+    int big = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (wins[i].width < 0 || wins[i].height < 0) return SVT_HIP_ERR_BAD_ARG;
+        big |= (int)wins[i].width * (int)wins[i].height > 65536;
+    }
+    if (!n) return SVT_HIP_OK;
+    const size_t nres = (size_t)n * SQUARE_PU_COUNT * sizeof(uint32_t);
+    const size_t off_sad = (sizeof(SvtHipSbSearch) * (size_t)n + 255) & ~(size_t)255, off_mv = off_sad + ((nres + 255) & ~(size_t)255);
+    int          rc = dev_need(hip, &b->d_job, &b->d_cap[2], off_mv + nres + 256);
+    uint8_t     *d = (uint8_t *)b->d_job;
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d, wins, sizeof(SvtHipSbSearch) * (size_t)n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_me_set_big_windows(hip, big);
+    if (rc == SVT_HIP_OK) {
+        rc = svt_hip_me_fullpel_frame_dev(hip, d_src, d_ref, p->stride_y, p->origin_x, p->origin_y, (const SvtHipSbSearch *)d, (int)n, b->sub_sad,
+                                          (uint32_t *)(d + off_sad), (uint32_t *)(d + off_mv));
+        (void)svt_hip_me_set_big_windows(hip, 1);   /* the context's default */
+    }
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, sad, d + off_sad, nres);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, mv, d + off_mv, nres);
+    return rc;
+}
+
 static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded) {
     SvtHipSbSearch *wins = (SvtHipSbSearch *)malloc(sizeof(SvtHipSbSearch) * b->cap);
     uint32_t       *idx = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
@@ -177,10 +204,17 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                     break;
                 }
                 SvtHipCtx *hip = svt_hip_hooks_lock_any();
-                int        rc = hip ? svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
-                                                               src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x,
-                                                               src_padded->origin_y, wins, (int)n, b->sub_sad, sad, mv)
-                                    : SVT_HIP_ERR_NO_DEVICE;
+                /* both planes resident (SVT_HIP_RESIDENT, svt_hip_hooks.c): only the windows travel; else the row band the windows touch is uploaded per call */
+                const size_t   plane_bytes = (size_t)src_padded->stride_y * (size_t)(src_padded->height + 2 * src_padded->origin_y);
+                const uint8_t *d_src = hip ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, src_padded->buffer_y, plane_bytes) : NULL;
+                const uint8_t *d_ref = d_src ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, ref->buffer_y, plane_bytes) : NULL;
+                int            rc = !hip ? SVT_HIP_ERR_NO_DEVICE
+                    : d_ref      ? integer_search_resident(hip, b, d_src, d_ref, src_padded, wins, n, sad, mv)
+                                 : svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
+                                                            src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x, src_padded->origin_y, wins, (int)n,
+                                                            b->sub_sad, sad, mv);
+                if (d_ref) svt_hip_hooks_resident_release(ref->buffer_y);   /* the results are back: the launch is over */
+                if (d_src) svt_hip_hooks_resident_release(src_padded->buffer_y);
                 if (rc != SVT_HIP_OK)
                     SVT_LOG("svt_hip_me_fullpel_frame failed (%s): C search for this segment\n", hip ? svt_hip_last_error(hip) : "no context");
                 if (hip) svt_hip_hooks_unlock_any();
@@ -303,27 +337,31 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         }
         if (!n) continue;
         if (y_hi >= rows_total) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
-        for (uint32_t k = 0; k < n; k++) { jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
-        /* only the rows the segment's windows touch travel (a segment is a band of SB rows) */
+        /* the (decimated) reference plane resident (SVT_HIP_RESIDENT): the searches address it as recorded; else only the rows the segment's windows touch travel
+         * (a segment is a band of SB rows) and the searches are re-based to the band */
+        const uint8_t *d_res = rc == SVT_HIP_OK ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, ref->buffer_y, (size_t)rows_total * ref->stride_y) : NULL;
+        for (uint32_t k = 0; k < n; k++) { if (!d_res) jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
         const size_t ref_bytes = (size_t)(y_hi - y_lo + 1) * ref->stride_y;
-        HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
+        if (!d_res) HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
         /* one upload [searches | initial SADs] and one download [SADs | centres] per launch */
         const size_t job_bytes = sizeof(SvtHipSadLoop) * n, sad_bytes = sizeof(uint32_t) * n, xy_bytes = sizeof(int16_t) * 2 * n;
         memcpy((uint8_t *)jobs + job_bytes, sad, sad_bytes);   /* jobs has room for n_all >= n entries of 28 bytes plus their SADs: see the allocation */
         HME_TRY(dev_need(hip, &b->d_job, &b->d_cap[2], job_bytes + sad_bytes + xy_bytes));
         uint8_t *d_sad = (uint8_t *)b->d_job + job_bytes, *d_xy = d_sad + sad_bytes;
-        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, ref->buffer_y + (size_t)y_lo * ref->stride_y, ref_bytes));
+        if (!d_res) HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, ref->buffer_y + (size_t)y_lo * ref->stride_y, ref_bytes));
         HME_TRY(svt_hip_memcpy_h2d(hip, b->d_job, jobs, job_bytes + sad_bytes));
-        HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
+        HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, d_res ? d_res : (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
                                            (int)n, (uint32_t *)d_sad, (int16_t *)d_xy));
         HME_TRY(svt_hip_memcpy_d2h(hip, back, d_sad, sad_bytes + xy_bytes));
+        if (d_res) svt_hip_hooks_resident_release(ref->buffer_y);   /* downloaded (or failed before the launch): the plane is no longer read */
         if (rc == SVT_HIP_OK) { memcpy(sad, back, sad_bytes); memcpy(xy, back + sad_bytes, xy_bytes); }
         if (rc != SVT_HIP_OK) break;
         for (uint32_t k = 0; k < n; k++) {
             hme_finish(&b->job[first + sel[k]], sad[k], sad[k] != 0xffffffu, xy[2 * k], xy[2 * k + 1]);
         }
         b->hme_launches++;
-        svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows uploaded)", level, n, y_hi - y_lo + 1);
+        svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows %s)", level, n, y_hi - y_lo + 1,
+                          d_res ? "read from the resident plane" : "uploaded");
     }
     /* A level whose search area the configuration switched down to 0 x 0: svt_sad_loop_kernel leaves the centres as they are, so the level's
      * arithmetic runs on what the previous search through the same pointers left there -- the previous block of this segment, in the reference's

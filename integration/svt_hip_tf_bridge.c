@@ -188,12 +188,16 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
     const int stride3[3] = {rp->stride_y, rp->stride_cb, rp->stride_cr};
     void     *d_band[3] = {NULL, NULL, NULL}, *d_jobs = NULL;
     const void *d_ref[3] = {NULL, NULL, NULL};
+    const uint8_t *d_res[3] = {NULL, NULL, NULL};
     for (int p = 0; p < np; p++) {
         const int ss = p ? 1 : 0, org_x = rp->origin_x >> ss, org_y = rp->origin_y >> ss, rows = (rp->height >> ss) + 2 * org_y;
         int lo = (y_lo >> ss) - 2, hi = (y_hi >> ss) + 2;   /* chroma: the halved range with a margin for the halved-position rounding */
         if (lo < -org_y) lo = -org_y;
         if (hi > rows - org_y - 1) hi = rows - org_y - 1;
-        if (hi < lo) return EB_ErrorUndefined;
+        if (hi < lo) { ret = EB_ErrorUndefined; break; }   /* the clean-up below still runs */
+        /* the whole plane resident (SVT_HIP_RESIDENT, svt_hip_hooks.c: 8-bit pictures, announced by picture analysis and the end of their own filtering): no band */
+        d_res[p] = ret == EB_ErrorNone ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, s->ref_plane[f][p], (size_t)rows * stride3[p] * pb) : NULL;
+        if (d_res[p]) { d_ref[p] = d_res[p] + ((size_t)org_y * stride3[p] + org_x) * pb; continue; }
         const size_t bytes = (size_t)(hi - lo + 1) * stride3[p] * pb;
         TF_TRY(svt_hip_hooks_malloc(hip, &d_band[p], bytes + 64));
         TF_TRY(svt_hip_memcpy_h2d(hip, d_band[p], s->ref_plane[f][p] + (size_t)(org_y + lo) * stride3[p] * pb, bytes));
@@ -204,7 +208,10 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
     TF_TRY(svt_hip_tf_subpel_frame_dev(hip, pb, bd, (const void *const *)d_src, sstride, d_ref, stride3, s->w.d_pred[f], s->w.pred_stride, s->mi_cols, s->mi_rows,
                                        s->th16, s->tf_hp, c->tf_chroma, (const SvtHipTfSubpelBlk *)d_jobs, n, s->w.d_blocks[f]));
     if (ret == EB_ErrorNone && svt_hip_memcpy_d2h(hip, &s->w.h_blocks[f][0], s->w.d_blocks[f], sizeof(SvtHipTfBlk64)) != SVT_HIP_OK) ret = EB_ErrorUndefined;   /* completes the launch before the band is freed */
-    for (int p = 0; p < 3; p++) svt_hip_hooks_free(hip, d_band[p]);
+    for (int p = 0; p < 3; p++) {
+        svt_hip_hooks_free(hip, d_band[p]);
+        if (d_res[p]) svt_hip_hooks_resident_release(s->ref_plane[f][p]);
+    }
     svt_hip_hooks_free(hip, d_jobs);
     return ret;
 }

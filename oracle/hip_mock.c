@@ -63,6 +63,7 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t
         for (int i = 0; i < n_sb * 85; i++) best_mv[i] = (best_mv[i] & 0xffff0000u) | ((best_mv[i] + 8) & 0xffffu);   /* x_mv + 2 px */
     return SVT_HIP_OK;
 }
+int svt_hip_me_set_big_windows(SvtHipCtx *c, int enable) { (void)c; (void)enable; return SVT_HIP_OK; }   /* the double's search has one instance */
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,
                              const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
     (void)plane_rows;   /* search areas above 65 536 candidates: the product takes its strip kernel, the same results */

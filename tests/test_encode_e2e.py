@@ -8,6 +8,7 @@ as the unpatched reference encoder (BASELINE.json north_star
 Every hook must report handled > 0 and fallback == 0 where the preset uses the stage: a silent fallback to the C loop would pass trivially.
 """
 import os
+import re
 
 import pytest
 
@@ -211,6 +212,34 @@ def test_motion_estimation_hooks_one_at_a_time_on_cpu_test_double(hooks, workdir
     _check(case, CASES[case][:6] + ({hooks},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": hooks}, "mock_" + hooks)
 
 
+def _resident_line(log):
+    m = re.search(r"svt_hip_resident notes=(\d+) uploads=(\d+) uploaded_mb=([0-9.]+) hits=(\d+)", log)
+    assert m, "no svt_hip_resident line in the report\n" + log[-1500:]
+    return int(m.group(1)), int(m.group(2)), float(m.group(3)), int(m.group(4))
+
+
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "cif_10bit_m6", "cif_8bit_m6"])
+def test_resident_source_planes_on_cpu_test_double(case, workdir):
+    """SVT_HIP_RESIDENT=1: the padded luma plane of every picture and its 1/4 and 1/16 versions are uploaded once per (re)write -- picture analysis, the end of the
+    temporal filter -- and every ME / HME / TF-ME segment reads that copy instead of uploading its own row band (integration/svt_hip_hooks.c).  Host logic only (which
+    copy is current), so the CPU test double pins it: a stale plane changes the motion search and with it the bitstream.  The planes must really have been used."""
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "mock_resident")
+    notes, uploads, mb, hits = _resident_line(got["log"])
+    w, h, n = CASES[case][:3]
+    # every announced plane travels at most once per announcement, and the copies are read (CIF pictures are one ME segment each: few readers per plane;
+    # the 360p case has many segments per picture: most reads find the plane on the device)
+    assert notes >= 3 * n and n <= uploads <= notes and hits > 0, (notes, uploads, mb, hits)
+    if case == "360p_8bit_m7":
+        assert hits > 10 * uploads, (notes, uploads, mb, hits)
+
+
+def test_resident_source_planes_with_a_small_budget_on_cpu_test_double(workdir):
+    """SVT_HIP_RESIDENT_MB=1: hardly any plane fits, the oldest unused copies are dropped and uploaded again on demand (or the caller uploads its band as before)."""
+    case = "360p_8bit_m7"
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1", "SVT_HIP_RESIDENT_MB": "1"}, "mock_resident_1mb")
+    assert re.search(r"svt_hip_resident notes=\d+ uploads=\d+ uploaded_mb=[0-9.]+ hits=\d+ evictions=(\d+)", got["log"])
+
+
 @pytest.mark.parametrize("stage", E.HOOKS)
 def test_every_hook_matters(stage, workdir):
     """A deliberately wrong answer of ONE stage (SVT_HIP_MOCK_PERTURB) must change the bitstream or the reconstruction: the comparison above
@@ -369,6 +398,41 @@ def test_128_superblocks_10bit_padded_on_gpu(workdir):
 @pytest.mark.parametrize("name", list(OPTION_VARIANTS))
 def test_encoder_option_variants_on_cpu_test_double(name, workdir):
     _check_variant(name, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+RESIDENT_VARIANTS = ["altref_7_frames", "film_grain", "low_delay_p", "three_layers", "hme_level0_only", "screen_content", "two_pass_vbr", "tiles_2x2"]
+
+
+@pytest.mark.parametrize("name", RESIDENT_VARIANTS)
+def test_encoder_option_variants_with_resident_planes_on_cpu_test_double(name, workdir):
+    """the writers of the resident planes under the options that move them: longer alt-ref windows, the denoised source of film grain, other prediction structures
+    (which pictures are filtered, which are overlays), filtered / decimated pyramids, a second pass over the same pictures"""
+    got = _check_variant(name, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "mock_resident")
+    assert _resident_line(got["log"])[3] > 0
+
+
+def test_resident_planes_announcements_matter(workdir):
+    """SVT_HIP_RESIDENT_FAULT=1 ignores every announcement of a plane but its first: the copy of a picture that is filtered after it served as a window frame, or of
+    a buffer that a later picture reuses, goes stale -- the encode must notice (the identity tests above are sensitive to exactly the bookkeeping they pin)."""
+    case = "cif_8bit_18_frames"
+    spec = GPU_ONLY_CASES[case]
+    w, h, n, bd, preset, q, _ = spec
+    clip, ref = _reference(case, spec, workdir)
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}
+    good = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".res_ok"), env_extra=env)
+    assert good["ivf"] == ref["ivf"] and good["recon"] == ref["recon"]
+    bad = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".res_fault"), env_extra=dict(env, SVT_HIP_RESIDENT_FAULT="1"))
+    assert bad["ivf"] != ref["ivf"] or bad["recon"] != ref["recon"], "stale resident planes went unnoticed"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SVT_HIP_TEST_RESIDENT", "0") != "1", reason="SVT_HIP_RESIDENT is opt-in until it has been measured on the MI355X: SVT_HIP_TEST_RESIDENT=1 runs its GPU twin")
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6"])
+def test_resident_source_planes_on_gpu(case, workdir):
+    spec = CASES.get(case) or GPU_ONLY_CASES[case]
+    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
+    assert "svt_hip MOCK" not in got["log"]
+    assert _resident_line(got["log"])[3] > 0
 
 
 @pytest.mark.gpu
