@@ -213,9 +213,10 @@ def test_motion_estimation_hooks_one_at_a_time_on_cpu_test_double(hooks, workdir
 
 
 def _resident_line(log):
-    m = re.search(r"svt_hip_resident notes=(\d+) uploads=(\d+) uploaded_mb=([0-9.]+) hits=(\d+)", log)
+    m = re.findall(r"svt_hip_resident notes=(\d+) uploads=(\d+) uploaded_mb=([0-9.]+) hits=(\d+)", log)
     assert m, "no svt_hip_resident line in the report\n" + log[-1500:]
-    return int(m.group(1)), int(m.group(2)), float(m.group(3)), int(m.group(4))
+    notes, uploads, mb, hits = m[-1]   # one line per encoder instance of the process (two-pass runs), counters running on
+    return int(notes), int(uploads), float(mb), int(hits)
 
 
 @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "cif_10bit_m6", "cif_8bit_m6"])
