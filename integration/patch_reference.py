@@ -212,7 +212,7 @@ PATCHES.append(msp)
 pa = Patch("Source/Lib/Encoder/Codec/EbPictureAnalysisProcess.c")
 pa.sub(r'(void downsample_decimation_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',
        r'\1    if (svt_hip_hook_pa_downsample(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 0) == EB_ErrorNone) {\n'
-       r'        svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 1);\n'
+       r'        svt_hip_hooks_resident_note_pa(pcs_ptr, input_padded_picture_ptr, quarter_decimated_picture_ptr, sixteenth_decimated_picture_ptr, 0); /* the padded plane: by the hook */\n'
        r'        return;\n'
        r'    }\n')
 pa.sub(r'(void downsample_filtering_input_picture\(PictureParentControlSet \*pcs_ptr,[^{]*\{\n)',

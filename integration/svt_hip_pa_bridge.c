@@ -21,6 +21,10 @@
 EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,
                                        int filtered) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_PA)) return EB_ErrorUndefined;
+    /* Resident planes (svt_hip_hooks.c): the padded picture is complete when downsample_decimation_input_picture is entered (the first of the two calls, always
+     * made) — announced here, so that this hook, the variance hook and every later ME / TF segment share one upload; the pyramids are announced by the patched
+     * function when this hook returns (they are written below).  A failure below leaves the announcement to the C path's end of function. */
+    if (!filtered) svt_hip_hooks_resident_note_pa(pcs, padded, NULL, NULL, 1);
     const int hme = pcs->enable_hme_flag || pcs->tf_enable_hme_flag;
     const int lvl1 = pcs->enable_hme_level1_flag || pcs->tf_enable_hme_level1_flag, lvl0 = pcs->enable_hme_level0_flag || pcs->tf_enable_hme_level0_flag;
     /* which pictures the reference function produces (:3316-3358 decimation: 1/16 always; :3610-3670 filtering: only inside the HME flags) */
@@ -33,13 +37,22 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return EB_ErrorUndefined;
     void *d_in = NULL, *d_q = NULL, *d_s = NULL;
-    int   rc = svt_hip_hooks_malloc(hip, &d_in, (size_t)w * h);
+    int   rc = SVT_HIP_OK;
+    /* the luma plane: the resident copy read in place (origin and stride of the host picture), or the picture's interior uploaded compactly */
+    const size_t   plane_off = padded->origin_x + (size_t)padded->origin_y * padded->stride_y;
+    const uint8_t *d_res = (const uint8_t *)svt_hip_hooks_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y));
+    const uint8_t *in = d_res ? d_res + plane_off : NULL;
+    const int      in_stride = d_res ? padded->stride_y : w;
+    if (!d_res) {
+        PA_TRY(svt_hip_hooks_malloc(hip, &d_in, (size_t)w * h));
+        PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)w, padded->buffer_y + plane_off, padded->stride_y, (size_t)w, (size_t)h));
+        in = (const uint8_t *)d_in;
+    }
     PA_TRY(svt_hip_hooks_malloc(hip, &d_q, (size_t)(w / 2) * (h / 2) + 64));
     PA_TRY(svt_hip_hooks_malloc(hip, &d_s, (size_t)(w / 4) * (h / 4) + 64));
-    PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)w, padded->buffer_y + padded->origin_x + (size_t)padded->origin_y * padded->stride_y, padded->stride_y, (size_t)w, (size_t)h));
     /* the destination offset is the reference's own expression (origin_x for the row as well, :3327-3329) */
     if (do_q) {
-        PA_TRY(svt_hip_downsample_2d_dev(hip, (const uint8_t *)d_in, w, w, h, (uint8_t *)d_q, w / 2, 2, filtered));
+        PA_TRY(svt_hip_downsample_2d_dev(hip, in, in_stride, w, h, (uint8_t *)d_q, w / 2, 2, filtered));
         PA_TRY(svt_hip_memcpy2d_d2h(hip, quarter->buffer_y + quarter->origin_x + (size_t)quarter->origin_x * quarter->stride_y, quarter->stride_y, d_q, (size_t)(w / 2),
                                     (size_t)(w / 2), (size_t)(h / 2)));
     }
@@ -47,10 +60,11 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
         if (filtered && lvl1)   /* 2x2 average of the 1/4 picture (:3636-3647): its width / height, read where the reference reads it (origin_y for the row here) */
             PA_TRY(svt_hip_downsample_2d_dev(hip, (const uint8_t *)d_q, w / 2, quarter->width, quarter->height, (uint8_t *)d_s, w / 4, 2, 1));
         else
-            PA_TRY(svt_hip_downsample_2d_dev(hip, (const uint8_t *)d_in, w, w, h, (uint8_t *)d_s, w / 4, 4, filtered));
+            PA_TRY(svt_hip_downsample_2d_dev(hip, in, in_stride, w, h, (uint8_t *)d_s, w / 4, 4, filtered));
         PA_TRY(svt_hip_memcpy2d_d2h(hip, sixteenth->buffer_y + sixteenth->origin_x + (size_t)sixteenth->origin_x * sixteenth->stride_y, sixteenth->stride_y, d_s,
                                     (size_t)(w / 4), (size_t)(w / 4), (size_t)(h / 4)));
     }
+    if (d_res) svt_hip_hooks_resident_release(padded->buffer_y);   /* the downloads above completed the launches */
     svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_q); svt_hip_hooks_free(hip, d_s);
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
@@ -79,15 +93,21 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     SvtHipCtx *hip = (mean && var) ? svt_hip_hooks_lock_any() : NULL;
     int        rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
     void      *d_in = NULL, *d_mean = NULL, *d_var = NULL;
-    PA_TRY(svt_hip_hooks_malloc(hip, &d_in, (size_t)stride * ph));
+    /* the kernel reads 8-byte words at 8-sample columns: the resident plane serves in place when the picture's origin and stride keep them aligned */
+    const size_t   plane_off = padded->origin_x + (size_t)padded->origin_y * padded->stride_y;
+    const uint8_t *d_res = (hip && !(plane_off & 7) && !(padded->stride_y & 7))
+        ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y)) : NULL;
+    if (!d_res) {
+        PA_TRY(svt_hip_hooks_malloc(hip, &d_in, (size_t)stride * ph));
+        PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)stride, padded->buffer_y + plane_off, padded->stride_y, (size_t)pw, (size_t)ph));
+    }
     PA_TRY(svt_hip_hooks_malloc(hip, &d_mean, (size_t)n_sb * 85));
     PA_TRY(svt_hip_hooks_malloc(hip, &d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
-    PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)stride, padded->buffer_y + padded->origin_x + (size_t)padded->origin_y * padded->stride_y, padded->stride_y, (size_t)pw,
-                                (size_t)ph));
-    PA_TRY(svt_hip_variance_pyramid_dev(hip, (const uint8_t *)d_in, stride, sb_cols, (int)n_sb, scs->block_mean_calc_prec == BLOCK_MEAN_PREC_FULL, (uint8_t *)d_mean,
-                                        (uint16_t *)d_var));
+    PA_TRY(svt_hip_variance_pyramid_dev(hip, d_res ? d_res + plane_off : (const uint8_t *)d_in, d_res ? padded->stride_y : stride, sb_cols, (int)n_sb,
+                                        scs->block_mean_calc_prec == BLOCK_MEAN_PREC_FULL, (uint8_t *)d_mean, (uint16_t *)d_var));
     PA_TRY(svt_hip_memcpy_d2h(hip, mean, d_mean, (size_t)n_sb * 85));
     PA_TRY(svt_hip_memcpy_d2h(hip, var, d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
+    if (d_res) svt_hip_hooks_resident_release(padded->buffer_y);
     if (hip) {
         svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_mean); svt_hip_hooks_free(hip, d_var);
         if (rc != SVT_HIP_OK) SVT_LOG("variance pyramid on the device failed (%s): C path\n", svt_hip_last_error(hip));

@@ -219,7 +219,7 @@ def _resident_line(log):
     return int(notes), int(uploads), float(mb), int(hits)
 
 
-@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "cif_10bit_m6", "cif_8bit_m6"])
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "cif_10bit_m6"])
 def test_resident_source_planes_on_cpu_test_double(case, workdir):
     """SVT_HIP_RESIDENT=1: the padded luma plane of every picture and its 1/4 and 1/16 versions are uploaded once per (re)write -- picture analysis, the end of the
     temporal filter -- and every ME / HME / TF-ME segment reads that copy instead of uploading its own row band (integration/svt_hip_hooks.c).  Host logic only (which
@@ -401,7 +401,8 @@ def test_encoder_option_variants_on_cpu_test_double(name, workdir):
     _check_variant(name, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
 
 
-RESIDENT_VARIANTS = ["altref_7_frames", "film_grain", "low_delay_p", "three_layers", "hme_level0_only", "screen_content", "two_pass_vbr", "tiles_2x2"]
+# SVT_HIP_TEST_RESIDENT_ALL=1: every option variant (the CPU suite keeps to the four that move the planes' writers)
+RESIDENT_VARIANTS = list(OPTION_VARIANTS) if os.environ.get("SVT_HIP_TEST_RESIDENT_ALL") == "1" else ["altref_7_frames", "film_grain", "low_delay_p", "two_pass_vbr"]
 
 
 @pytest.mark.parametrize("name", RESIDENT_VARIANTS)
