@@ -213,6 +213,7 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                                  : svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
                                                             src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x, src_padded->origin_y, wins, (int)n,
                                                             b->sub_sad, sad, mv);
+                if (d_src && rc != SVT_HIP_OK) (void)svt_hip_sync(hip);      /* after a failure a launch may still be reading the planes */
                 if (d_ref) svt_hip_hooks_resident_release(ref->buffer_y);   /* the results are back: the launch is over */
                 if (d_src) svt_hip_hooks_resident_release(src_padded->buffer_y);
                 if (rc != SVT_HIP_OK)
@@ -353,7 +354,10 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, d_res ? d_res : (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
                                            (int)n, (uint32_t *)d_sad, (int16_t *)d_xy));
         HME_TRY(svt_hip_memcpy_d2h(hip, back, d_sad, sad_bytes + xy_bytes));
-        if (d_res) svt_hip_hooks_resident_release(ref->buffer_y);   /* downloaded (or failed before the launch): the plane is no longer read */
+        if (d_res) {   /* downloaded: the launch is over; after a failure the context is drained first, a launch may still be reading the plane */
+            if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
+            svt_hip_hooks_resident_release(ref->buffer_y);
+        }
         if (rc == SVT_HIP_OK) { memcpy(sad, back, sad_bytes); memcpy(xy, back + sad_bytes, xy_bytes); }
         if (rc != SVT_HIP_OK) break;
         for (uint32_t k = 0; k < n; k++) {

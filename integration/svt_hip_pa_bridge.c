@@ -64,7 +64,10 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
         PA_TRY(svt_hip_memcpy2d_d2h(hip, sixteenth->buffer_y + sixteenth->origin_x + (size_t)sixteenth->origin_x * sixteenth->stride_y, sixteenth->stride_y, d_s,
                                     (size_t)(w / 4), (size_t)(w / 4), (size_t)(h / 4)));
     }
-    if (d_res) svt_hip_hooks_resident_release(padded->buffer_y);   /* the downloads above completed the launches */
+    if (d_res) {   /* the downloads above completed the launches; after a failure the context is drained first */
+        if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
+        svt_hip_hooks_resident_release(padded->buffer_y);
+    }
     svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_q); svt_hip_hooks_free(hip, d_s);
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
@@ -107,7 +110,10 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
                                         scs->block_mean_calc_prec == BLOCK_MEAN_PREC_FULL, (uint8_t *)d_mean, (uint16_t *)d_var));
     PA_TRY(svt_hip_memcpy_d2h(hip, mean, d_mean, (size_t)n_sb * 85));
     PA_TRY(svt_hip_memcpy_d2h(hip, var, d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
-    if (d_res) svt_hip_hooks_resident_release(padded->buffer_y);
+    if (d_res) {
+        if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
+        svt_hip_hooks_resident_release(padded->buffer_y);
+    }
     if (hip) {
         svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_mean); svt_hip_hooks_free(hip, d_var);
         if (rc != SVT_HIP_OK) SVT_LOG("variance pyramid on the device failed (%s): C path\n", svt_hip_last_error(hip));

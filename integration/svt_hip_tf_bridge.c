@@ -208,6 +208,7 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
     TF_TRY(svt_hip_tf_subpel_frame_dev(hip, pb, bd, (const void *const *)d_src, sstride, d_ref, stride3, s->w.d_pred[f], s->w.pred_stride, s->mi_cols, s->mi_rows,
                                        s->th16, s->tf_hp, c->tf_chroma, (const SvtHipTfSubpelBlk *)d_jobs, n, s->w.d_blocks[f]));
     if (ret == EB_ErrorNone && svt_hip_memcpy_d2h(hip, &s->w.h_blocks[f][0], s->w.d_blocks[f], sizeof(SvtHipTfBlk64)) != SVT_HIP_OK) ret = EB_ErrorUndefined;   /* completes the launch before the band is freed */
+    if (ret != EB_ErrorNone) (void)svt_hip_sync(hip);   /* a launch may still be reading the bands / planes released below */
     for (int p = 0; p < 3; p++) {
         svt_hip_hooks_free(hip, d_band[p]);
         if (d_res[p]) svt_hip_hooks_resident_release(s->ref_plane[f][p]);

@@ -21,20 +21,26 @@ E.make_clip("gpurun_out/enc_wall/clip.yuv", w, h, n, seed=3, bd=8)
 PY
   ARGS="-i $OUT/clip.yuv -w $W -h $H -n $N --preset $PRESET --fps 30 -q 36 --lp $LP"
   for app in $APPS; do
-    [ -x $R/oracle/_ref/SvtAv1EncApp_$app ] || { echo "${W}x${H} $app: not built" | tee -a $OUT/wall.txt; continue; }
+    # NAME_res = application NAME with SVT_HIP_RESIDENT=1 (source-side planes stay on the device between their writes, integration/svt_hip_hooks.c),
+    # e.g. APPS="simd hip_simd hip_simd hip_simd_res hip_simd_res"
+    bin=${app%_res}; res=0; [ "$bin" != "$app" ] && res=1
+    [ -x $R/oracle/_ref/SvtAv1EncApp_$bin ] || { echo "${W}x${H} $app: not built" | tee -a $OUT/wall.txt; continue; }
     s=$(date +%s.%N)
     case $app in
-      ref|simd) timeout 900 $R/oracle/_ref/SvtAv1EncApp_$app $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
-      *) SVT_HIP_HOOKS=${HOOKS:-all} timeout 900 $R/oracle/_ref/SvtAv1EncApp_$app $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
+      ref|simd) timeout 900 $R/oracle/_ref/SvtAv1EncApp_$bin $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
+      *) SVT_HIP_RESIDENT=$res SVT_HIP_HOOKS=${HOOKS:-all} timeout 900 $R/oracle/_ref/SvtAv1EncApp_$bin $ARGS -b $OUT/$app.ivf > $OUT/${app}_$W.log 2>&1 ;;
     esac
     e=$(date +%s.%N)
     log=$OUT/${app}_$W.log
     echo "${W}x${H} n=$N preset=$PRESET lp=$LP $app wall_s=$(python -c "print(round($e - $s, 2))") $(grep -h 'Total Encoding Time\|Average Speed' $log | tr -s '\t\n' '  ')" | tee -a $OUT/wall.txt
   done
-  for app in hip simd hip_simd; do
+  for app in hip simd hip_simd hip_res hip_simd_res; do
     [ -f $OUT/$app.ivf ] && { cmp -s $OUT/ref.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to ref" || echo "${W}x${H} $app BITSTREAM DIFFERS from ref"; } | tee -a $OUT/wall.txt
   done
-  for app in hip hip_simd; do
+  for app in hip_res hip_simd_res; do
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt
+  done
+  for app in hip hip_simd hip_res hip_simd_res; do
     [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook" $OUT/${app}_$W.log | awk -v a=$app '{h+=substr($3,9); f+=substr($4,10)} END {print a, "hook launches:", h, "fallbacks:", f}' | tee -a $OUT/wall.txt
   done
   rm -f $OUT/clip.yuv $OUT/*.ivf
