@@ -137,38 +137,13 @@ void svt_hip_hooks_free(SvtHipCtx *hip, void *p) {
  * picture and its 1/4 and 1/16 versions — are written at exactly two places of the reference: picture analysis (picture_analysis_kernel, EbPictureAnalysisProcess.c
  * :3960-3994; the overlay twin in EbPictureDecisionProcess.c:3644-3680) and the end of the temporal filter (pad_and_decimate_filtered_pic, EbTemporalFiltering.c:2556),
  * and read by every ME / HME / TF-ME segment of the picture itself and of every picture that references it.  The patched reference announces each write
- * (svt_hip_hooks_resident_note, AFTER the plane is complete); the first bridge call that needs the plane afterwards uploads it once, whole, and every later call of
- * any context reads that copy instead of uploading its own row band.  Only announced planes are ever resident: the buffers of an EbPaReferenceObject are allocated
- * once per encoder instance, whereas the resized references of the super-resolution / reference-scaling modes are allocated and freed per picture (an address can
- * come back with other content) — those are never announced and keep the upload path.  An announcement while a plane is in use cannot happen by the reference's own
- * life-time rules (the object is held while a picture that references it is in motion estimation); if it does, the plane simply is not resident for that caller.
- * The upload runs under the table's lock on the caller's context, which is drained before the call returns (svt_hip_memcpy_h2d), so the copy is complete for every
- * other context. */
-#define RES_MAX 512
-typedef struct { const uint8_t *host; size_t bytes, dev_bytes; void *dev; int stale, users; unsigned long long last; } ResEntry;
-static ResEntry           g_res[RES_MAX];
-static pthread_mutex_t    g_res_mu = PTHREAD_MUTEX_INITIALIZER;
-static int                g_res_on, g_res_fault;   /* fault: SVT_HIP_RESIDENT_FAULT=1, for the tests only — a plane's later announcements are ignored (its copy goes stale) */
-static size_t             g_res_limit = (size_t)4096 << 20, g_res_dev_bytes;
-static unsigned long long g_res_clock;
-static long               g_res_hits, g_res_uploads, g_res_notes, g_res_evictions;
-static double             g_res_uploaded_mb;
-int svt_hip_hooks_resident_enabled(void) { return g_res_on; }
-void svt_hip_hooks_resident_note(const void *host, size_t bytes) {
-    if (!g_res_on || !host || !bytes) return;
-    pthread_mutex_lock(&g_res_mu);
-    g_res_notes++;
-    ResEntry *e = NULL, *spare = NULL;
-    for (int i = 0; i < RES_MAX && !e; i++) {
-        if (g_res[i].host == (const uint8_t *)host) e = &g_res[i];
-        else if (!g_res[i].host && !g_res[i].dev && !spare) spare = &g_res[i];
-    }
-    if (!e && spare) { e = spare; e->host = (const uint8_t *)host; e->dev = NULL; e->users = 0; e->last = 0; e->stale = 1; e->bytes = bytes; }
-    else if (e && !g_res_fault) { e->stale = 1; e->bytes = bytes; }   /* the device block (if any) is kept: the next acquire overwrites it */
-    pthread_mutex_unlock(&g_res_mu);
-}
+ * (svt_hip_hooks_resident_note_pa, AFTER the planes are complete); the first bridge call that needs a plane afterwards uploads it once, whole, and every later call of
+ * any context reads that copy instead of uploading its own row band (the table: svt_hip_resident.c).  Only announced planes are ever resident: the buffers of an
+ * EbPaReferenceObject and the input pictures are allocated once per encoder instance, whereas the resized references of the super-resolution / reference-scaling
+ * modes are allocated and freed per picture (an address can come back with other content) — those are never announced and keep the upload path. */
+static int g_res_on;
 void svt_hip_hooks_resident_note_picture(const EbPictureBufferDesc *pic) {
-    if (g_res_on && pic && pic->buffer_y) svt_hip_hooks_resident_note(pic->buffer_y, (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y));
+    if (g_res_on && pic && pic->buffer_y) svt_hip_resident_note(pic->buffer_y, (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y));
 }
 /* downsample_decimation_input_picture / downsample_filtering_input_picture have just written quarter / sixteenth from padded (itself complete before the call).
  * With in-loop ME the "padded" picture IS the picture's own input buffer, which other stages write as well: never resident */
@@ -183,81 +158,13 @@ void svt_hip_hooks_resident_note_pa(const PictureParentControlSet *pcs, const Eb
         const EbPictureBufferDesc *in = pcs->enhanced_picture_ptr;
         if (in && in == pcs->enhanced_unscaled_picture_ptr && in->buffer_y && in->buffer_cb && in->buffer_cr && in->bit_depth == EB_8BIT) {
             const int ss_y = in->color_format >= EB_YUV422 ? 0 : 1;   /* chroma rows: halved for 4:2:0 only */
-            svt_hip_hooks_resident_note(in->buffer_y, (size_t)in->stride_y * (size_t)(in->height + 2 * in->origin_y));
-            svt_hip_hooks_resident_note(in->buffer_cb, (size_t)in->stride_cb * (size_t)((in->height >> ss_y) + 2 * (in->origin_y >> ss_y)));
-            svt_hip_hooks_resident_note(in->buffer_cr, (size_t)in->stride_cr * (size_t)((in->height >> ss_y) + 2 * (in->origin_y >> ss_y)));
+            svt_hip_resident_note(in->buffer_y, (size_t)in->stride_y * (size_t)(in->height + 2 * in->origin_y));
+            svt_hip_resident_note(in->buffer_cb, (size_t)in->stride_cb * (size_t)((in->height >> ss_y) + 2 * (in->origin_y >> ss_y)));
+            svt_hip_resident_note(in->buffer_cr, (size_t)in->stride_cr * (size_t)((in->height >> ss_y) + 2 * (in->origin_y >> ss_y)));
         }
     }
     svt_hip_hooks_resident_note_picture(quarter);
     svt_hip_hooks_resident_note_picture(sixteenth);
-}
-/* blocks of entries nobody uses go back to the block cache, oldest first, until `need` more bytes fit the limit (g_res_mu held) */
-static void res_make_room(SvtHipCtx *hip, size_t need) {
-    while (g_res_dev_bytes + need > g_res_limit) {
-        ResEntry *v = NULL;
-        for (int i = 0; i < RES_MAX; i++)
-            if (g_res[i].dev && !g_res[i].users && (!v || g_res[i].last < v->last)) v = &g_res[i];
-        if (!v) return;
-        svt_hip_hooks_free(hip, v->dev);
-        v->dev = NULL; v->stale = 1;
-        g_res_dev_bytes -= v->dev_bytes;
-        v->dev_bytes = 0;
-        g_res_evictions++;
-    }
-}
-const void *svt_hip_hooks_resident_acquire(SvtHipCtx *hip, const void *host, size_t bytes) {
-    if (!g_res_on || !hip || !host) return NULL;
-    const void *ret = NULL;
-    pthread_mutex_lock(&g_res_mu);
-    for (int i = 0; i < RES_MAX; i++) {
-        ResEntry *e = &g_res[i];
-        if (e->host != (const uint8_t *)host) continue;
-        if (e->bytes < bytes) break;                 /* the caller reads further than what was announced */
-        if (e->stale && e->users) break;             /* see above: not resident for this caller */
-        if (e->stale || !e->dev) {
-            if (e->dev && e->dev_bytes < e->bytes) {   /* announced again with a larger extent */
-                svt_hip_hooks_free(hip, e->dev);
-                e->dev = NULL;
-                g_res_dev_bytes -= e->dev_bytes;
-                e->dev_bytes = 0;
-            }
-            if (!e->dev) {
-                res_make_room(hip, e->bytes);
-                if (g_res_dev_bytes + e->bytes > g_res_limit) break;
-                /* + 256: dword-aligned window loads of the search kernels may run a few bytes past the last row */
-                if (svt_hip_hooks_malloc(hip, &e->dev, e->bytes + 256) != SVT_HIP_OK) { e->dev = NULL; break; }
-                e->dev_bytes = e->bytes;
-                g_res_dev_bytes += e->bytes;
-            }
-            if (svt_hip_memcpy_h2d(hip, e->dev, e->host, e->bytes) != SVT_HIP_OK) break;   /* stays stale */
-            e->stale = 0;
-            g_res_uploads++;
-            g_res_uploaded_mb += e->bytes / 1048576.0;
-        } else
-            g_res_hits++;
-        e->users++;
-        e->last = ++g_res_clock;
-        ret = e->dev;
-        break;
-    }
-    pthread_mutex_unlock(&g_res_mu);
-    return ret;
-}
-void svt_hip_hooks_resident_release(const void *host) {
-    if (!g_res_on || !host) return;
-    pthread_mutex_lock(&g_res_mu);
-    for (int i = 0; i < RES_MAX; i++)
-        if (g_res[i].host == (const uint8_t *)host) { if (g_res[i].users > 0) g_res[i].users--; break; }
-    pthread_mutex_unlock(&g_res_mu);
-}
-static void res_release_all(SvtHipCtx *hip) {   /* deinit: before the block cache is emptied */
-    pthread_mutex_lock(&g_res_mu);
-    for (int i = 0; i < RES_MAX; i++) {
-        if (g_res[i].dev) svt_hip_hooks_free(hip, g_res[i].dev);
-        memset(&g_res[i], 0, sizeof(g_res[i]));
-    }
-    g_res_dev_bytes = 0;
-    pthread_mutex_unlock(&g_res_mu);
 }
 
 #define SVT_HIP_POOL_MAX 8
@@ -314,9 +221,12 @@ void svt_hip_hooks_report(void) {
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
     fprintf(stderr, "svt_hip_context locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_lock_n, g_lock_held_ns / 1e6, g_lock_wait_ns / 1e6);
     if (g_alloc_hits + g_alloc_misses) fprintf(stderr, "svt_hip_alloc_cache hits=%ld misses=%ld cached_mb=%.1f\n", g_alloc_hits, g_alloc_misses, g_alloc_cached / 1048576.0);
-    if (g_res_on)
-        fprintf(stderr, "svt_hip_resident notes=%ld uploads=%ld uploaded_mb=%.1f hits=%ld evictions=%ld resident_mb=%.1f\n", g_res_notes, g_res_uploads, g_res_uploaded_mb,
-                g_res_hits, g_res_evictions, g_res_dev_bytes / 1048576.0);
+    if (g_res_on) {
+        SvtHipResidentStats r;
+        svt_hip_resident_stats(&r);
+        fprintf(stderr, "svt_hip_resident notes=%ld uploads=%ld uploaded_mb=%.1f hits=%ld evictions=%ld resident_mb=%.1f refused=%ld\n", r.notes, r.uploads, r.uploaded_mb, r.hits,
+                r.evictions, r.resident_mb, r.refused);
+    }
     if (g_pool_n)
         fprintf(stderr, "svt_hip_context_pool contexts=%d locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_pool_n, g_pool_locks, g_pool_held_ns / 1e6, g_pool_wait_ns / 1e6);
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
@@ -460,7 +370,7 @@ void svt_hip_hooks_enc_deinit(void) {
     if (g_ctx) {
         svt_hip_lf_bridge_release(g_ctx);
         svt_hip_md_bridge_release(g_ctx);
-        res_release_all(g_ctx);
+        svt_hip_resident_release_all(g_ctx);   /* before the block cache is emptied */
         pthread_mutex_lock(&g_alloc_mu);
         for (int c = 0; c < ALLOC_CLASSES; c++) {
             for (int i = 0; i < g_alloc_n[c]; i++) svt_hip_free(g_ctx, g_alloc_free[c][i]);
@@ -497,8 +407,9 @@ void svt_hip_hooks_enc_init(int target_socket) {
         return;
     }
     g_res_on = getenv("SVT_HIP_RESIDENT") && atoi(getenv("SVT_HIP_RESIDENT"));
-    g_res_fault = getenv("SVT_HIP_RESIDENT_FAULT") && atoi(getenv("SVT_HIP_RESIDENT_FAULT"));
-    if (getenv("SVT_HIP_RESIDENT_MB")) g_res_limit = (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20;
+    /* SVT_HIP_RESIDENT_FAULT=1, for the tests only: a plane's later announcements are ignored (its copy goes stale) */
+    svt_hip_resident_configure(g_res_on, getenv("SVT_HIP_RESIDENT_MB") ? (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20 : (size_t)4096 << 20,
+                               getenv("SVT_HIP_RESIDENT_FAULT") && atoi(getenv("SVT_HIP_RESIDENT_FAULT")), svt_hip_hooks_malloc, svt_hip_hooks_free);
     if (getenv("SVT_HIP_ALLOC_CACHE_MB")) g_alloc_limit = (size_t)atol(getenv("SVT_HIP_ALLOC_CACHE_MB")) << 20;
     {   /* the pool of the source-side bridges; 0 = everything on the main context (the round-2 behaviour) */
         const char *pc = getenv("SVT_HIP_CONTEXTS");

@@ -23,6 +23,7 @@
 #include "EbPictureBufferDesc.h"
 #include "EbMotionEstimationContext.h"
 #include "svt_hip.h"
+#include "svt_hip_resident.h"
 
 enum {
     SVT_HIP_HOOK_ME = 0,       /* integer full search of every SB of an ME segment: motion_estimation_kernel (EbMotionEstimationProcess.c:831-963) */
@@ -77,16 +78,11 @@ void       svt_hip_hooks_unlock(void);
 /* device memory through the hooks' block cache (power-of-two size classes, SVT_HIP_ALLOC_CACHE_MB); pointers of svt_hip_malloc may be passed to the free too */
 int        svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes);
 void       svt_hip_hooks_free(SvtHipCtx *hip, void *p);
-/* resident planes of the EbPaReferenceObject pictures (SVT_HIP_RESIDENT=1; svt_hip_hooks.c): note = the patched reference announces that the host plane
- * [host, host + bytes) has just been (re)written; acquire = its device copy (uploaded now if the last announcement is newer than the copy), or NULL when the plane
- * was never announced / residency is off / no memory — the caller then uploads what it needs as before; every successful acquire is paired with a release */
-int         svt_hip_hooks_resident_enabled(void);
-void        svt_hip_hooks_resident_note(const void *host, size_t bytes);
-void        svt_hip_hooks_resident_note_picture(const EbPictureBufferDesc *pic);   /* the whole padded luma plane of pic */
-void        svt_hip_hooks_resident_note_pa(const PictureParentControlSet *pcs, const EbPictureBufferDesc *padded, const EbPictureBufferDesc *quarter,
-                                           const EbPictureBufferDesc *sixteenth, int with_padded);
-const void *svt_hip_hooks_resident_acquire(SvtHipCtx *hip, const void *host, size_t bytes);
-void        svt_hip_hooks_resident_release(const void *host);
+/* resident planes (SVT_HIP_RESIDENT=1): the table is svt_hip_resident.h (announce / acquire / release on host pointers); these announce the planes of the reference's
+ * pictures from the patched reference (and the picture-analysis hook) right after they have been written */
+void svt_hip_hooks_resident_note_picture(const EbPictureBufferDesc *pic);   /* the whole padded luma plane of pic */
+void svt_hip_hooks_resident_note_pa(const PictureParentControlSet *pcs, const EbPictureBufferDesc *padded, const EbPictureBufferDesc *quarter,
+                                    const EbPictureBufferDesc *sixteenth, int with_padded);
 SvtHipCtx *svt_hip_hooks_lock_any(void);
 void       svt_hip_hooks_unlock_any(void);
 void       svt_hip_hooks_log(const char *fmt, ...);

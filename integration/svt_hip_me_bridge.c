@@ -206,16 +206,16 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                 SvtHipCtx *hip = svt_hip_hooks_lock_any();
                 /* both planes resident (SVT_HIP_RESIDENT, svt_hip_hooks.c): only the windows travel; else the row band the windows touch is uploaded per call */
                 const size_t   plane_bytes = (size_t)src_padded->stride_y * (size_t)(src_padded->height + 2 * src_padded->origin_y);
-                const uint8_t *d_src = hip ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, src_padded->buffer_y, plane_bytes) : NULL;
-                const uint8_t *d_ref = d_src ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, ref->buffer_y, plane_bytes) : NULL;
+                const uint8_t *d_src = hip ? (const uint8_t *)svt_hip_resident_acquire(hip, src_padded->buffer_y, plane_bytes) : NULL;
+                const uint8_t *d_ref = d_src ? (const uint8_t *)svt_hip_resident_acquire(hip, ref->buffer_y, plane_bytes) : NULL;
                 int            rc = !hip ? SVT_HIP_ERR_NO_DEVICE
                     : d_ref      ? integer_search_resident(hip, b, d_src, d_ref, src_padded, wins, n, sad, mv)
                                  : svt_hip_me_fullpel_frame(hip, src_padded->buffer_y, ref->buffer_y, src_padded->stride_y,
                                                             src_padded->height + 2 * src_padded->origin_y, src_padded->origin_x, src_padded->origin_y, wins, (int)n,
                                                             b->sub_sad, sad, mv);
                 if (d_src && rc != SVT_HIP_OK) (void)svt_hip_sync(hip);      /* after a failure a launch may still be reading the planes */
-                if (d_ref) svt_hip_hooks_resident_release(ref->buffer_y);   /* the results are back: the launch is over */
-                if (d_src) svt_hip_hooks_resident_release(src_padded->buffer_y);
+                if (d_ref) svt_hip_resident_release(ref->buffer_y);   /* the results are back: the launch is over */
+                if (d_src) svt_hip_resident_release(src_padded->buffer_y);
                 if (rc != SVT_HIP_OK)
                     SVT_LOG("svt_hip_me_fullpel_frame failed (%s): C search for this segment\n", hip ? svt_hip_last_error(hip) : "no context");
                 if (hip) svt_hip_hooks_unlock_any();
@@ -340,7 +340,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         if (y_hi >= rows_total) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
         /* the (decimated) reference plane resident (SVT_HIP_RESIDENT): the searches address it as recorded; else only the rows the segment's windows touch travel
          * (a segment is a band of SB rows) and the searches are re-based to the band */
-        const uint8_t *d_res = rc == SVT_HIP_OK ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, ref->buffer_y, (size_t)rows_total * ref->stride_y) : NULL;
+        const uint8_t *d_res = rc == SVT_HIP_OK ? (const uint8_t *)svt_hip_resident_acquire(hip, ref->buffer_y, (size_t)rows_total * ref->stride_y) : NULL;
         for (uint32_t k = 0; k < n; k++) { if (!d_res) jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
         const size_t ref_bytes = (size_t)(y_hi - y_lo + 1) * ref->stride_y;
         if (!d_res) HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
@@ -356,7 +356,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         HME_TRY(svt_hip_memcpy_d2h(hip, back, d_sad, sad_bytes + xy_bytes));
         if (d_res) {   /* downloaded: the launch is over; after a failure the context is drained first, a launch may still be reading the plane */
             if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
-            svt_hip_hooks_resident_release(ref->buffer_y);
+            svt_hip_resident_release(ref->buffer_y);
         }
         if (rc == SVT_HIP_OK) { memcpy(sad, back, sad_bytes); memcpy(xy, back + sad_bytes, xy_bytes); }
         if (rc != SVT_HIP_OK) break;

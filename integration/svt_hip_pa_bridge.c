@@ -40,7 +40,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     int   rc = SVT_HIP_OK;
     /* the luma plane: the resident copy read in place (origin and stride of the host picture), or the picture's interior uploaded compactly */
     const size_t   plane_off = padded->origin_x + (size_t)padded->origin_y * padded->stride_y;
-    const uint8_t *d_res = (const uint8_t *)svt_hip_hooks_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y));
+    const uint8_t *d_res = (const uint8_t *)svt_hip_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y));
     const uint8_t *in = d_res ? d_res + plane_off : NULL;
     const int      in_stride = d_res ? padded->stride_y : w;
     if (!d_res) {
@@ -66,7 +66,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     }
     if (d_res) {   /* the downloads above completed the launches; after a failure the context is drained first */
         if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
-        svt_hip_hooks_resident_release(padded->buffer_y);
+        svt_hip_resident_release(padded->buffer_y);
     }
     svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_q); svt_hip_hooks_free(hip, d_s);
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
@@ -99,7 +99,7 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     /* the kernel reads 8-byte words at 8-sample columns: the resident plane serves in place when the picture's origin and stride keep them aligned */
     const size_t   plane_off = padded->origin_x + (size_t)padded->origin_y * padded->stride_y;
     const uint8_t *d_res = (hip && !(plane_off & 7) && !(padded->stride_y & 7))
-        ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y)) : NULL;
+        ? (const uint8_t *)svt_hip_resident_acquire(hip, padded->buffer_y, (size_t)padded->stride_y * (size_t)(padded->height + 2 * padded->origin_y)) : NULL;
     if (!d_res) {
         PA_TRY(svt_hip_hooks_malloc(hip, &d_in, (size_t)stride * ph));
         PA_TRY(svt_hip_memcpy2d_h2d(hip, d_in, (size_t)stride, padded->buffer_y + plane_off, padded->stride_y, (size_t)pw, (size_t)ph));
@@ -112,7 +112,7 @@ EbErrorType svt_hip_hook_pa_variance(SequenceControlSet *scs, PictureParentContr
     PA_TRY(svt_hip_memcpy_d2h(hip, var, d_var, (size_t)n_sb * 85 * sizeof(uint16_t)));
     if (d_res) {
         if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
-        svt_hip_hooks_resident_release(padded->buffer_y);
+        svt_hip_resident_release(padded->buffer_y);
     }
     if (hip) {
         svt_hip_hooks_free(hip, d_in); svt_hip_hooks_free(hip, d_mean); svt_hip_hooks_free(hip, d_var);

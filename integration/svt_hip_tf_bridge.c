@@ -196,7 +196,7 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
         if (hi > rows - org_y - 1) hi = rows - org_y - 1;
         if (hi < lo) { ret = EB_ErrorUndefined; break; }   /* the clean-up below still runs */
         /* the whole plane resident (SVT_HIP_RESIDENT, svt_hip_hooks.c: 8-bit pictures, announced by picture analysis and the end of their own filtering): no band */
-        d_res[p] = ret == EB_ErrorNone ? (const uint8_t *)svt_hip_hooks_resident_acquire(hip, s->ref_plane[f][p], (size_t)rows * stride3[p] * pb) : NULL;
+        d_res[p] = ret == EB_ErrorNone ? (const uint8_t *)svt_hip_resident_acquire(hip, s->ref_plane[f][p], (size_t)rows * stride3[p] * pb) : NULL;
         if (d_res[p]) { d_ref[p] = d_res[p] + ((size_t)org_y * stride3[p] + org_x) * pb; continue; }
         const size_t bytes = (size_t)(hi - lo + 1) * stride3[p] * pb;
         TF_TRY(svt_hip_hooks_malloc(hip, &d_band[p], bytes + 64));
@@ -211,7 +211,7 @@ static EbErrorType tf_subpel_frame(SvtHipCtx *hip, SvtHipTfSeg *s, int f, const 
     if (ret != EB_ErrorNone) (void)svt_hip_sync(hip);   /* a launch may still be reading the bands / planes released below */
     for (int p = 0; p < 3; p++) {
         svt_hip_hooks_free(hip, d_band[p]);
-        if (d_res[p]) svt_hip_hooks_resident_release(s->ref_plane[f][p]);
+        if (d_res[p]) svt_hip_resident_release(s->ref_plane[f][p]);
     }
     svt_hip_hooks_free(hip, d_jobs);
     return ret;
