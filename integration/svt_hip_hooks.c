@@ -408,7 +408,7 @@ void svt_hip_hooks_enc_init(int target_socket) {
     }
     g_res_on = getenv("SVT_HIP_RESIDENT") && atoi(getenv("SVT_HIP_RESIDENT"));
     /* SVT_HIP_RESIDENT_FAULT=1, for the tests only: a plane's later announcements are ignored (its copy goes stale) */
-    svt_hip_resident_configure(g_res_on, getenv("SVT_HIP_RESIDENT_MB") ? (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20 : (size_t)4096 << 20,
+    svt_hip_resident_configure(g_res_on, getenv("SVT_HIP_RESIDENT_MB") ? (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20 : (size_t)16384 << 20 /* ~27 MB per 4K picture in flight, of 288 GB */,
                                getenv("SVT_HIP_RESIDENT_FAULT") && atoi(getenv("SVT_HIP_RESIDENT_FAULT")), svt_hip_hooks_malloc, svt_hip_hooks_free);
     if (getenv("SVT_HIP_ALLOC_CACHE_MB")) g_alloc_limit = (size_t)atol(getenv("SVT_HIP_ALLOC_CACHE_MB")) << 20;
     {   /* the pool of the source-side bridges; 0 = everything on the main context (the round-2 behaviour) */

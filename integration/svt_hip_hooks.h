@@ -11,7 +11,7 @@
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
  *   SVT_HIP_CONTEXTS = contexts of the source-side bridges' pool (default 4), SVT_HIP_ALLOC_CACHE_MB = their block cache (default 1024),
- *   SVT_HIP_RESIDENT=1 = source-side planes stay on the device between their writes (opt-in; SVT_HIP_RESIDENT_MB, default 4096) — svt_hip_hooks.c
+ *   SVT_HIP_RESIDENT=1 = source-side planes stay on the device between their writes (opt-in; SVT_HIP_RESIDENT_MB, default 16384) — svt_hip_hooks.c
  * Unset / empty SVT_HIP_HOOKS = none: the patched encoder then IS the reference encoder.
  */
 #ifndef SVT_HIP_HOOKS_H

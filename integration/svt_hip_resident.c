@@ -4,7 +4,8 @@
 #include <string.h>
 #include "svt_hip_resident.h"
 
-#define RES_MAX 512
+/* an encoder instance announces three planes per analysis reference object and three per input picture: a few hundred at the deepest look-ahead */
+#define RES_MAX 2048
 typedef struct {
     const uint8_t     *host;
     size_t             bytes, dev_bytes;   /* announced extent; extent the block was allocated for */
@@ -15,7 +16,7 @@ typedef struct {
 static ResEntry             g_res[RES_MAX];
 static pthread_mutex_t      g_mu = PTHREAD_MUTEX_INITIALIZER;
 static int                  g_on, g_ignore_renotes;
-static size_t               g_limit = (size_t)4096 << 20, g_dev_bytes;
+static size_t               g_limit = (size_t)16384 << 20, g_dev_bytes;
 static unsigned long long   g_clock;
 static SvtHipResidentStats  g_st;
 static SvtHipResidentMalloc g_alloc;
