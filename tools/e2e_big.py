@@ -22,7 +22,8 @@ for name in sys.argv[1:] or list(CASES):
     ref = E.encode(REF_APP, clip, w, h, n, preset, q, bd, os.path.join(wd, name + ".ref"), timeout=1200)
     got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(wd, name + ".hip"), env_extra={"SVT_HIP_HOOKS": HOOKS}, timeout=1200)
     same = got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"]
-    print(name, "identical" if same else "MISMATCH", "mock!" if "svt_hip MOCK" in got["log"] else "", {k: v for k, v in got["hooks"].items() if v != (0, 0)}, flush=True)
+    res = [l for l in got["log"].splitlines() if l.startswith("svt_hip_resident")]   # SVT_HIP_RESIDENT=1 in the environment: the planes' report
+    print(name, "identical" if same else "MISMATCH", "mock!" if "svt_hip MOCK" in got["log"] else "", {k: v for k, v in got["hooks"].items() if v != (0, 0)}, *res[-1:], flush=True)
     for f in os.listdir(wd):
         if f.startswith(name) and not f.endswith(".txt"):
             os.remove(os.path.join(wd, f))

@@ -11,6 +11,8 @@ mkdir -p $OUT
 cd $R
 SVT_HIP_TEST_RESIDENT=1 timeout 900 python -m pytest tests/test_encode_e2e.py -m gpu -k resident -q > $OUT/tests.log 2>&1; echo "resident GPU tests: rc=$?" | tee $OUT/summary.txt
 tail -3 $OUT/tests.log | tee -a $OUT/summary.txt
+# large pictures, where a plane has many readers (40 ME segments per 4K picture): identity again, with the planes' report
+SVT_HIP_RESIDENT=1 timeout 600 python tools/e2e_big.py 2160p_8bit_m6 1080p_8bit_m4 2>&1 | tee -a $OUT/summary.txt
 APPS="simd hip_simd hip_simd hip_simd_res hip_simd_res" GEOS="1280 720 8,1920 1080 8,3840 2160 4" timeout 900 bash tools/encoder_walltime.sh > $OUT/walltime.log 2>&1
 cp $R/gpurun_out/enc_wall/wall.txt $OUT/wall.txt 2>/dev/null; cat $OUT/wall.txt | tee -a $OUT/summary.txt
 W=3840 H=2160 N=3 SVT_HIP_RESIDENT=1 timeout 600 bash tools/encoder_profile.sh > $OUT/profile.log 2>&1
