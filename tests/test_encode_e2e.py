@@ -427,14 +427,16 @@ def test_resident_planes_announcements_matter(workdir):
     assert bad["ivf"] != ref["ivf"] or bad["recon"] != ref["recon"], "stale resident planes went unnoticed"
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SVT_HIP_TEST_RESIDENT", "0") != "1", reason="SVT_HIP_RESIDENT is opt-in until it has been measured on the MI355X: SVT_HIP_TEST_RESIDENT=1 runs its GPU twin")
-@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6"])
-def test_resident_source_planes_on_gpu(case, workdir):
-    spec = CASES.get(case) or GPU_ONLY_CASES[case]
-    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
-    assert "svt_hip MOCK" not in got["log"]
-    assert _resident_line(got["log"])[3] > 0
+if os.environ.get("SVT_HIP_TEST_RESIDENT", "0") == "1":
+    # SVT_HIP_RESIDENT is opt-in until it has been measured on the MI355X (tools/resident_first_call.sh); its GPU twin exists only when asked for, so that the
+    # default GPU run neither runs an unmeasured path nor reports skips
+    @pytest.mark.gpu
+    @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6"])
+    def test_resident_source_planes_on_gpu(case, workdir):
+        spec = CASES.get(case) or GPU_ONLY_CASES[case]
+        got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
+        assert "svt_hip MOCK" not in got["log"]
+        assert _resident_line(got["log"])[3] > 0
 
 
 @pytest.mark.gpu
