@@ -427,16 +427,34 @@ def test_resident_planes_announcements_matter(workdir):
     assert bad["ivf"] != ref["ivf"] or bad["recon"] != ref["recon"], "stale resident planes went unnoticed"
 
 
-if os.environ.get("SVT_HIP_TEST_RESIDENT", "0") == "1":
-    # SVT_HIP_RESIDENT is opt-in until it has been measured on the MI355X (tools/resident_first_call.sh); its GPU twin exists only when asked for, so that the
-    # default GPU run neither runs an unmeasured path nor reports skips
-    @pytest.mark.gpu
-    @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6"])
-    def test_resident_source_planes_on_gpu(case, workdir):
-        spec = CASES.get(case) or GPU_ONLY_CASES[case]
-        got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
-        assert "svt_hip MOCK" not in got["log"]
-        assert _resident_line(got["log"])[3] > 0
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6", "cif_10bit_m6", "720p_10bit_m5"])
+def test_resident_source_planes_on_gpu(case, workdir):
+    """SVT_HIP_RESIDENT=1 on the device: planes uploaded by one context's stream and read by kernels of the other contexts of the pool, 8- and 10-bit"""
+    spec = CASES.get(case) or GPU_ONLY_CASES[case]
+    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
+    assert "svt_hip MOCK" not in got["log"]
+    assert _resident_line(got["log"])[3] > 0
+
+
+@pytest.mark.gpu
+def test_resident_source_planes_2160p_on_gpu(workdir):
+    """3840 x 2160, preset 6, planes resident: 40 ME segments per picture read one upload.  The reference side is the SIMD build (it codes the C build's
+    bitstream: test_simd_build_codes_the_c_builds_bitstream), the C build needs minutes at this size."""
+    name, w, h, n, bd, preset, q = "2160p_8bit_m6_res", 3840, 2160, 2, 8, 6, 36
+    app_simd = os.path.join(E.REFDIR, "SvtAv1EncApp_simd")
+    clip = os.path.join(workdir, name + ".src.yuv")
+    E.make_clip(clip, w, h, n, seed=17, bd=bd)
+    ref = E.encode(app_simd if os.path.exists(app_simd) else E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".ref"), timeout=1200)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".hip"), env_extra={"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, timeout=1200)
+    assert "svt_hip MOCK" not in got["log"]
+    assert got["ivf"] == ref["ivf"] and got["recon"] == ref["recon"], got["log"][-2000:]
+    assert all(v[1] == 0 for v in got["hooks"].values()), got["hooks"]
+    notes, uploads, mb, hits = _resident_line(got["log"])
+    assert hits > 10 * uploads, (notes, uploads, mb, hits)
+    for f in os.listdir(workdir):
+        if f.startswith(name):
+            os.remove(os.path.join(workdir, f))
 
 
 @pytest.mark.gpu

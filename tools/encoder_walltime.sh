@@ -34,8 +34,9 @@ PY
     log=$OUT/${app}_$W.log
     echo "${W}x${H} n=$N preset=$PRESET lp=$LP $app wall_s=$(python -c "print(round($e - $s, 2))") $(grep -h 'Total Encoding Time\|Average Speed' $log | tr -s '\t\n' '  ')" | tee -a $OUT/wall.txt
   done
+  base=ref; [ -f $OUT/ref.ivf ] || base=simd   # the unpatched application of this run (the SIMD build codes the C build's bitstream)
   for app in hip simd hip_simd hip_res hip_simd_res; do
-    [ -f $OUT/$app.ivf ] && { cmp -s $OUT/ref.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to ref" || echo "${W}x${H} $app BITSTREAM DIFFERS from ref"; } | tee -a $OUT/wall.txt
+    [ "$app" != "$base" ] && [ -f $OUT/$app.ivf ] && { cmp -s $OUT/$base.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to $base" || echo "${W}x${H} $app BITSTREAM DIFFERS from $base"; } | tee -a $OUT/wall.txt
   done
   for app in hip_res hip_simd_res; do
     [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt

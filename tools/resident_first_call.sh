@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/resident
 mkdir -p $OUT
 cd $R
-SVT_HIP_TEST_RESIDENT=1 timeout 900 python -m pytest tests/test_encode_e2e.py -m gpu -k resident -q > $OUT/tests.log 2>&1; echo "resident GPU tests: rc=$?" | tee $OUT/summary.txt
+timeout 900 python -m pytest tests/test_encode_e2e.py -m gpu -k "resident and gpu" -q > $OUT/tests.log 2>&1; echo "resident GPU tests: rc=$?" | tee $OUT/summary.txt
 tail -3 $OUT/tests.log | tee -a $OUT/summary.txt
 # large pictures, where a plane has many readers (40 ME segments per 4K picture): identity again, with the planes' report
 SVT_HIP_RESIDENT=1 timeout 600 python tools/e2e_big.py 2160p_8bit_m6 1080p_8bit_m4 2>&1 | tee -a $OUT/summary.txt
