@@ -60,6 +60,23 @@ int  svt_hip_memcpy_d2d(SvtHipCtx *ctx, void *dst_dev, const void *src_dev, size
 /* picture planes: `rows` rows of `width_bytes`, pitches in bytes (EbPictureBufferDesc planes keep their own strides) */
 int  svt_hip_memcpy2d_h2d(SvtHipCtx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width_bytes, size_t rows);
 int  svt_hip_memcpy2d_d2h(SvtHipCtx *ctx, void *dst_host, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes, size_t rows);
+/* stream-ordered forms: return once the copy is queued; the host side must stay untouched (and, for the copy to really overlap, be page-locked:
+ * svt_hip_host_register / svt_hip_host_alloc) until svt_hip_sync */
+int  svt_hip_memcpy_h2d_async(SvtHipCtx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int  svt_hip_memcpy_d2h_async(SvtHipCtx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int  svt_hip_memcpy2d_h2d_async(SvtHipCtx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width_bytes, size_t rows);
+int  svt_hip_memcpy2d_d2h_async(SvtHipCtx *ctx, void *dst_host, size_t dst_pitch, const void *src_dev, size_t src_pitch, size_t width_bytes, size_t rows);
+/* page-lock a buffer of the caller in place (the reference allocates its picture buffers once per encoder instance: EbPictureBufferDesc planes registered
+ * once are copied by direct DMA afterwards); registering a registered range again is not an error.  svt_hip_host_alloc = page-locked staging memory. */
+int  svt_hip_host_register(SvtHipCtx *ctx, void *host, size_t bytes);
+int  svt_hip_host_unregister(SvtHipCtx *ctx, void *host);
+int  svt_hip_host_alloc(SvtHipCtx *ctx, void **host, size_t bytes);
+int  svt_hip_host_free(SvtHipCtx *ctx, void *host);
+/* number of HIP devices visible to the process (0 and SVT_HIP_OK when there is none) */
+int  svt_hip_device_count(int *count);
+/* load the code object of every kernel translation unit for the context's device now (otherwise each is loaded at the first launch of one of its kernels,
+ * which inside an encoder is the first pictures' clock) */
+int  svt_hip_warmup(SvtHipCtx *ctx);
 /* HIP-event stopwatch on the context's stream (used by bench.py for per-kernel device time). */
 int  svt_hip_timer_start(SvtHipCtx *ctx);
 int  svt_hip_timer_stop_ms(SvtHipCtx *ctx, float *elapsed_ms);

@@ -55,7 +55,8 @@ PATCHES = []
 # One call after the two RTCD setups and before the tables derived from them (EbEncHandle.c:1144-1147).
 _ench = Patch("Source/Lib/Encoder/Globals/EbEncHandle.c")
 # svt_av1_enc_deinit_handle (:1973): once the component and its threads are gone, the hooks give the dispatch pointers back and release the device
-_ench.sub(r'(EbErrorType return_error = svt_av1_enc_component_de_init\(svt_enc_component\);\n)', r'\1        svt_hip_hooks_enc_deinit();\n')
+# ... and before it frees the instance's pictures, those that were page-locked in place (SVT_HIP_PIN) are released
+_ench.sub(r'(\n[ \t]*)(EbErrorType return_error = svt_av1_enc_component_de_init\(svt_enc_component\);\n)', r'\1svt_hip_hooks_enc_predeinit();\1\2        svt_hip_hooks_enc_deinit();\n')
 PATCHES.append(_ench.sub(
     r'(setup_rtcd_internal\(enc_handle_ptr->scs_instance_array\[0\]->scs_ptr->static_config\.use_cpu_flags\);\n)',
     r'\1    svt_hip_hooks_enc_init(enc_handle_ptr->scs_instance_array[0]->scs_ptr->static_config.target_socket); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))
@@ -295,6 +296,8 @@ dlf.sub(r'(\n[ \t]*)(svt_av1_pick_filter_level\(\s*context_ptr,\s*\(EbPictureBuf
         r'\1if (svt_hip_hook_dlf_pick_level(pcs_ptr) != EB_ErrorNone) /* not handled: the reference search */\1    \2')
 dlf.sub(r'(\n[ \t]*)(svt_av1_loop_filter_frame\(recon_buffer, pcs_ptr, 0, 3\);)',
         r'\1if (svt_hip_hook_dlf_frame(recon_buffer, pcs_ptr) != EB_ErrorNone)\1    \2')
+# deferred pictures (svt_hip_lf_bridge.c): the boundary lines only the C restoration path reads are not saved from a picture the host does not have
+dlf.sub(r'(if \(scs_ptr->seq_header\.enable_restoration)(\)\s*svt_av1_loop_restoration_save_boundary_lines\(cm->frame_to_show, cm, 0\);)', r'\1 && !svt_hip_hook_skip_host_prep(pcs_ptr, 0)\2')
 dlf.sub(r'(\n[ \t]*)(//pre-cdef prep\n)', r'\1svt_hip_hook_after_dlf(pcs_ptr); /* the deblocked picture is final: keep it on the device for the CDEF / restoration hooks */\1\2')
 PATCHES.append(dlf)
 
@@ -307,21 +310,31 @@ cdef.sub(r'(\n[ \t]*)(if \(scs_ptr->static_config\.is_16bit_pipeline \|\| is_16b
 cdef.sub(r'(\n[ \t]*)(if \(scs_ptr->static_config\.is_16bit_pipeline \|\| is_16bit\)\s*av1_cdef_frame16bit\(0, scs_ptr, pcs_ptr\);)',
          r'\1if (svt_hip_hook_cdef_apply(pcs_ptr) == EB_ErrorNone) {'
          r'\1} else \2')
+cdef.sub(r'(//restoration prep\s*if \(scs_ptr->seq_header\.enable_restoration)(\) \{\s*svt_av1_loop_restoration_save_boundary_lines\(cm->frame_to_show, cm, 1\);)',
+         r'\1 && !svt_hip_hook_skip_host_prep(pcs_ptr, 1)\2')
 PATCHES.append(cdef)
 
 # ---------------------------------------------------------------------------------------------------------------- restoration (rest_kernel)
 rest = Patch("Source/Lib/Encoder/Codec/EbRestProcess.c")
 rest.sub(r'(\n[ \t]*)(svt_av1_loop_restoration_filter_frame\(cm->frame_to_show, cm, 0\);)',
          r'\1if (svt_hip_hook_rest_apply(pcs_ptr) != EB_ErrorNone)\1    \2')
+# a deferred picture's restoration segment: the picture-level searches run before the segment would copy the picture (svt_hip_hook_rest_begin), and the copy is skipped
+rest.sub(r'(\n[ \t]*)(get_own_recon\(scs_ptr,\s*pcs_ptr,\s*context_ptr,\s*scs_ptr->static_config\.is_16bit_pipeline \|\| is_16bit\);)', r'\1if (!svt_hip_hook_rest_begin(pcs_ptr))\1    \2')
 rest.sub(r'(\n[ \t]*)(cm->sg_frame_ep = best_ep;\n)', r'\1\2\1svt_hip_hook_picture_done(pcs_ptr); /* the picture leaves the filter stages */\n')
 PATCHES.append(rest)
 
 pick = Patch("Source/Lib/Encoder/Codec/EbRestorationPick.c")
 pick.sub(r'(\n[ \t]*SgrprojInfo sgrproj;\s*WienerInfo  wiener;\n)(\} RestSearchCtxt;)', r'\1    PictureControlSet *hip_pcs; /* for the picture-level hooks */\n\2')
 pick.sub(r'(\n[ \t]*)(rsc_p->tmpbuf = rst_tmpbuf;\n)', r'\1\2\1rsc_p->hip_pcs = pcs_ptr;\n')
-# restoration_seg_search (:1537): every search_sgrproj_seg of the picture is one picture-level search on the device
+# restoration_seg_search (:1537): every search_sgrproj_seg of the picture is one picture-level search on the device -- asked for before the plane loop, because it
+# also delivers what search_norestore_seg (:1476) computes per unit, the SSE of the unfiltered unit
+pick.sub(r'(\n[ \t]*)(const int32_t plane_start = AOM_PLANE_Y;\n[ \t]*const int32_t plane_end   = AOM_PLANE_V;\n[ \t]*for \(int32_t plane = plane_start; plane <= plane_end; \+\+plane\) \{\n[ \t]*RestUnitSearchInfo \*rusi = pcs_ptr->parent_pcs_ptr->rusi_picture\[plane\];\n\n[ \t]*init_rsc_seg\()',
+         r'\1const int hip_sgr = svt_hip_hook_sgr_search(pcs_ptr) == EB_ErrorNone; /* the first segment to arrive searched every unit of the picture */\1\2')
 pick.sub(r'(\n[ \t]*)(av1_foreach_rest_unit_in_frame_seg\(rsc_p->cm,\s*rsc_p->plane,\s*rsc_on_tile,\s*search_sgrproj_seg,)',
-         r'\1if (svt_hip_hook_sgr_search(pcs_ptr) != EB_ErrorNone) /* not handled: per-unit C search of this segment */\1    \2')
+         r'\1if (!hip_sgr) /* not handled: per-unit C search of this segment */\1    \2')
+pick.sub(r'(\n[ \t]*)(av1_foreach_rest_unit_in_frame_seg\(rsc_p->cm,\s*rsc_p->plane,\s*rsc_on_tile,\s*search_norestore_seg,)', r'\1if (!hip_sgr)\1    \2')
+# the segment's border extension of its picture copy: nothing reads it when the picture is deferred (the copy itself was skipped, svt_hip_hook_rest_begin)
+pick.sub(r'(\n[ \t]*)(svt_extend_frame\(rsc\.dgd_buffer,)', r'\1if (!svt_hip_hook_skip_host_prep(pcs_ptr, 3))\1    \2')
 # search_wiener_seg (:1359): M / H of the unit from the picture-level statistics pass
 pick.sub(r'(\n[ \t]*)(if \(cm->use_highbitdepth\)\s*svt_av1_compute_stats_highbd\(wiener_win,\s*rsc->dgd_buffer,)',
          r'\1if (svt_hip_hook_wiener_stats(rsc->hip_pcs, rsc->plane, wiener_win, rest_unit_idx, M, H) == EB_ErrorNone) {'

@@ -92,6 +92,7 @@ static int alloc_note(void *p, int c) {   /* g_alloc_mu held */
         if (!g_alloc_live[i].p) { g_alloc_live[i].p = p; g_alloc_live[i].c = c; return 1; }
     return 0;
 }
+static size_t alloc_block_size(size_t bytes) { const int c = alloc_class(bytes ? bytes : 1); return (!g_alloc_limit || ((size_t)1 << c) < bytes) ? bytes : (size_t)1 << c; }
 int svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes) {
     const int c = alloc_class(bytes ? bytes : 1);
     if (!g_alloc_limit || ((size_t)1 << c) < bytes) return svt_hip_malloc(hip, p, bytes);
@@ -117,8 +118,27 @@ int svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes) {
     }
     return rc;
 }
+/* A block freed by a bridge that holds a pool context may still be written by a kernel of that context (failure paths free before the context is drained): it
+ * goes on the thread's pending list and into the cache only once svt_hip_hooks_unlock_any has drained the context. */
+#define PENDING_FREES 64
+static __thread void *tls_pending[PENDING_FREES];
+static __thread int   tls_pending_n;
+static __thread int   tls_slot = -1, tls_pref = -1;
+static void cache_put(SvtHipCtx *hip, void *p);
 void svt_hip_hooks_free(SvtHipCtx *hip, void *p) {
     if (!p) return;
+    if (tls_slot >= 0) {
+        if (tls_pending_n == PENDING_FREES) {   /* full: drain now, then everything pending may be reused */
+            (void)svt_hip_sync(hip);
+            for (int i = 0; i < tls_pending_n; i++) cache_put(hip, tls_pending[i]);
+            tls_pending_n = 0;
+        }
+        tls_pending[tls_pending_n++] = p;
+        return;
+    }
+    cache_put(hip, p);
+}
+static void cache_put(SvtHipCtx *hip, void *p) {
     int c = -1;
     pthread_mutex_lock(&g_alloc_mu);
     for (int i = 0; i < ALLOC_LIVE; i++)
@@ -141,7 +161,8 @@ void svt_hip_hooks_free(SvtHipCtx *hip, void *p) {
  * any context reads that copy instead of uploading its own row band (the table: svt_hip_resident.c).  Only announced planes are ever resident: the buffers of an
  * EbPaReferenceObject and the input pictures are allocated once per encoder instance, whereas the resized references of the super-resolution / reference-scaling
  * modes are allocated and freed per picture (an address can come back with other content) — those are never announced and keep the upload path. */
-static int g_res_on;
+static int g_res_on, g_pin_on;
+int svt_hip_hooks_pin_enabled(void) { return g_pin_on; }
 void svt_hip_hooks_resident_note_picture(const EbPictureBufferDesc *pic) {
     if (g_res_on && pic && pic->buffer_y) svt_hip_resident_note(pic->buffer_y, (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y));
 }
@@ -172,7 +193,6 @@ static SvtHipCtx      *g_pool[SVT_HIP_POOL_MAX];
 static pthread_mutex_t g_pool_mu[SVT_HIP_POOL_MAX];
 static int             g_pool_n, g_pool_next;
 static long long       g_pool_wait_ns, g_pool_held_ns, g_pool_locks;
-static __thread int       tls_slot = -1, tls_pref = -1;
 static __thread long long tls_t0;
 SvtHipCtx *svt_hip_hooks_lock_any(void) {
     if (!g_ctx) return NULL;
@@ -194,6 +214,8 @@ SvtHipCtx *svt_hip_hooks_lock_any(void) {
 void svt_hip_hooks_unlock_any(void) {
     if (tls_slot < 0) { svt_hip_hooks_unlock(); return; }
     (void)svt_hip_sync(g_pool[tls_slot]);
+    for (int i = 0; i < tls_pending_n; i++) cache_put(g_pool[tls_slot], tls_pending[i]);   /* the context is drained: its blocks may serve anybody */
+    tls_pending_n = 0;
     __sync_fetch_and_add(&g_pool_held_ns, now_ns() - tls_t0);
     const int k = tls_slot;
     tls_slot = -1;
@@ -208,6 +230,14 @@ void svt_hip_hooks_log(const char *fmt, ...) {
     fputc('\n', stderr);
     va_end(ap);
 }
+/* wall time process threads spend inside each hook (lock waits included): what the hooked stage costs the encoder's pipeline */
+static long long g_hook_ns[SVT_HIP_HOOK_COUNT];
+static long      g_hook_calls[SVT_HIP_HOOK_COUNT];
+long long svt_hip_hooks_now_ns(void) { return now_ns(); }
+void svt_hip_hooks_time(int which, long long t0_ns) {
+    __sync_fetch_and_add(&g_hook_ns[which], now_ns() - t0_ns);
+    __sync_fetch_and_add(&g_hook_calls[which], 1);
+}
 void svt_hip_hooks_count(int which, int handled) {
     pthread_mutex_lock(&g_cnt_mu);
     if (handled) g_handled[which]++; else g_fellback[which]++;
@@ -219,6 +249,8 @@ static void svt_hip_hooks_report_once(void) { if (!g_reported) { g_reported = 1;
 void svt_hip_hooks_report(void) {
     for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
         if (g_enabled[i]) fprintf(stderr, "svt_hip_hook %s handled=%ld fallback=%ld\n", k_hook_name[i], g_handled[i], g_fellback[i]);
+    for (int i = 0; i < SVT_HIP_HOOK_COUNT; i++)
+        if (g_hook_calls[i]) fprintf(stderr, "svt_hip_hook_time %s calls=%ld wall_ms=%.1f\n", k_hook_name[i], g_hook_calls[i], g_hook_ns[i] / 1e6);
     fprintf(stderr, "svt_hip_context locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_lock_n, g_lock_held_ns / 1e6, g_lock_wait_ns / 1e6);
     if (g_alloc_hits + g_alloc_misses) fprintf(stderr, "svt_hip_alloc_cache hits=%ld misses=%ld cached_mb=%.1f\n", g_alloc_hits, g_alloc_misses, g_alloc_cached / 1048576.0);
     if (g_res_on) {
@@ -363,8 +395,18 @@ static void install_rtcd(const char *list) {
 
 /* svt_av1_enc_deinit_handle, after the component (and with it every process thread) is gone: the dispatch table gets its own pointers back, device memory and
  * contexts are released, and a later encoder instance of the process initialises from scratch.  The counters stay for the report at exit. */
+static pthread_mutex_t g_init_mu = PTHREAD_MUTEX_INITIALIZER;
+static int             g_instances;   /* encoder instances of the process between their init and deinit: they share every object below */
+/* svt_av1_enc_deinit_handle, BEFORE svt_av1_enc_component_de_init frees the instance's pictures: host ranges that were page-locked in place are released
+ * (the last instance only: the table is shared) */
+void svt_hip_hooks_enc_predeinit(void) {
+    pthread_mutex_lock(&g_init_mu);
+    if (g_inited && g_instances == 1 && g_ctx) { svt_hip_resident_unpin_all(g_ctx); svt_hip_lf_bridge_unpin(g_ctx); }
+    pthread_mutex_unlock(&g_init_mu);
+}
 void svt_hip_hooks_enc_deinit(void) {
-    if (!g_inited) return;
+    pthread_mutex_lock(&g_init_mu);
+    if (!g_inited || --g_instances > 0) { pthread_mutex_unlock(&g_init_mu); return; }   /* another instance still runs on these contexts */
     svt_hip_hooks_report_once();
     restore_rtcd();
     if (g_ctx) {
@@ -386,11 +428,18 @@ void svt_hip_hooks_enc_deinit(void) {
     if (g_ctx) { svt_hip_destroy(g_ctx); g_ctx = NULL; }
     memset(g_enabled, 0, sizeof(g_enabled));
     g_inited = 0;
+    g_instances = 0;
+    pthread_mutex_unlock(&g_init_mu);
 }
 
+static void enc_init_locked(int target_socket);
 void svt_hip_hooks_enc_init(int target_socket) {
-    if (g_inited) return;
-    g_inited = 1;
+    pthread_mutex_lock(&g_init_mu);
+    g_instances++;
+    if (!g_inited) { g_inited = 1; enc_init_locked(target_socket); }
+    pthread_mutex_unlock(&g_init_mu);
+}
+static void enc_init_locked(int target_socket) {
     const char *hooks = getenv("SVT_HIP_HOOKS"), *rtcd = getenv("SVT_HIP_RTCD"), *dev = getenv("SVT_HIP_DEVICE");
     g_verbose = getenv("SVT_HIP_VERBOSE") && atoi(getenv("SVT_HIP_VERBOSE"));
     int any = rtcd && *rtcd;
@@ -399,7 +448,12 @@ void svt_hip_hooks_enc_init(int target_socket) {
         any |= g_enabled[i];
     }
     if (!any) return;   /* the patched encoder is the reference encoder */
-    const int device = dev ? atoi(dev) : (target_socket >= 0 ? target_socket : 0);
+    /* target_socket is the reference's CPU-affinity knob: it doubles as the GPU ordinal only when it names a device (eight instances started with --socket 0..7 on
+     * an 8-GPU node); on a dual-socket host with one GPU `--socket 1` keeps device 0.  SVT_HIP_DEVICE is taken literally. */
+    int n_dev = 0;
+    (void)svt_hip_device_count(&n_dev);
+    const int device = dev ? atoi(dev) : (target_socket >= 0 && target_socket < n_dev ? target_socket : 0);
+    fprintf(stderr, "svt_hip_device ordinal=%d of %d (%s)\n", device, n_dev, dev ? "SVT_HIP_DEVICE" : (target_socket >= 0 && target_socket < n_dev ? "target_socket" : "default"));
     if (svt_hip_init(device, &g_ctx) != SVT_HIP_OK) {
         /* error convention: never fail through the kernel surface — log, keep the C path */
         SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");
@@ -411,6 +465,14 @@ void svt_hip_hooks_enc_init(int target_socket) {
     svt_hip_resident_configure(g_res_on, getenv("SVT_HIP_RESIDENT_MB") ? (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20 : (size_t)16384 << 20 /* ~27 MB per 4K picture in flight, of 288 GB */,
                                getenv("SVT_HIP_RESIDENT_FAULT") && atoi(getenv("SVT_HIP_RESIDENT_FAULT")), svt_hip_hooks_malloc, svt_hip_hooks_free);
     if (getenv("SVT_HIP_ALLOC_CACHE_MB")) g_alloc_limit = (size_t)atol(getenv("SVT_HIP_ALLOC_CACHE_MB")) << 20;
+    /* SVT_HIP_PIN=0: the reference's picture buffers are not page-locked in place (A/B knob; default on) */
+    g_pin_on = !(getenv("SVT_HIP_PIN") && !atoi(getenv("SVT_HIP_PIN")));
+    svt_hip_resident_configure_blocks(alloc_block_size, g_pin_on);
+    if (!(getenv("SVT_HIP_WARMUP") && !atoi(getenv("SVT_HIP_WARMUP")))) {   /* every kernel's code object is loaded here, not under the first pictures' clock */
+        const long long t0 = now_ns();
+        const int       rc = svt_hip_warmup(g_ctx);
+        fprintf(stderr, "svt_hip_warmup rc=%d ms=%.1f\n", rc, (now_ns() - t0) / 1e6);
+    }
     {   /* the pool of the source-side bridges; 0 = everything on the main context (the round-2 behaviour) */
         const char *pc = getenv("SVT_HIP_CONTEXTS");
         int         n = pc ? atoi(pc) : 4;

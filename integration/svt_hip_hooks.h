@@ -67,7 +67,14 @@ void svt_hip_hooks_enc_init(int target_socket);
 /* svt_av1_enc_deinit_handle, after svt_av1_enc_component_de_init: restores the dispatch pointers SVT_HIP_RTCD replaced, releases the bridges' device memory
  * (loop-filter picture pool, staging buffers, block cache) and the contexts; the next svt_hip_hooks_enc_init starts afresh */
 void svt_hip_hooks_enc_deinit(void);
+/* svt_av1_enc_deinit_handle, before svt_av1_enc_component_de_init: the picture buffers that were page-locked in place (SVT_HIP_PIN) are released while they exist */
+void svt_hip_hooks_enc_predeinit(void);
+int  svt_hip_hooks_pin_enabled(void);
+/* wall time of a hook call, for the report at exit ("svt_hip_hook_time <name> calls= wall_ms="): t0 = svt_hip_hooks_now_ns() at entry */
+long long svt_hip_hooks_now_ns(void);
+void      svt_hip_hooks_time(int which, long long t0_ns);
 void svt_hip_lf_bridge_release(SvtHipCtx *hip);   /* svt_hip_lf_bridge.c */
+void svt_hip_lf_bridge_unpin(SvtHipCtx *hip);     /* svt_hip_lf_bridge.c: the reconstructed pictures' host buffers stop being page-locked */
 void svt_hip_md_bridge_release(SvtHipCtx *hip);   /* svt_hip_md_bridge.c */
 int  svt_hip_hook_enabled(int which);
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
@@ -151,8 +158,13 @@ EbErrorType svt_hip_hook_wiener_search(PictureControlSet *pcs);
 /* in the patched EbRestorationPick.c (its static helpers): 0 = decomposition failed, 1 = initial filter in *wi, refine it, 2 = the filter does not beat identity */
 int svt_hip_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, WienerInfo *wi);
 EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err);
-/* rest_kernel, when the picture leaves the filter stages: releases its device state */
+/* rest_kernel, when the picture leaves the filter stages: the final reconstruction comes back (deferred pictures), its device state is released */
 void        svt_hip_hook_picture_done(PictureControlSet *pcs);
+/* deferred pictures (svt_hip_lf_bridge.c): 1 = the host work `which` can be skipped — 0 svt_av1_loop_restoration_save_boundary_lines(.., 0) in dlf_kernel,
+ * 1 save_boundary_lines(.., 1) + the three svt_extend_frame in cdef_kernel, 2 get_own_recon of a restoration segment, 3 svt_extend_frame of the segment's copy */
+int         svt_hip_hook_skip_host_prep(PictureControlSet *pcs, int which);
+/* rest_kernel, first thing of a restoration segment: 1 = the picture-level searches are done on the device and get_own_recon can be skipped */
+int         svt_hip_hook_rest_begin(PictureControlSet *pcs);
 
 /* finish_cdef_search, in place of joint_strength_search_dual (svt_hip_lf_bridge.c): 1 = best_lev0 / best_lev1 / *tot_mse hold the device result */
 int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32_t nb_strengths, uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi,

@@ -1,5 +1,6 @@
 /* svt_hip_lf_bridge.c — see svt_hip_lf_bridge.h / svt_hip_hooks.h.  Reference-side glue: host code only, every pixel operation is a batched
  * svt_hip_* call. */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "svt_hip_hooks.h"
@@ -13,6 +14,7 @@
 #include "EbLog.h"
 
 int8_t get_sg_step(int8_t sg_filter_mode);   /* Encoder/Codec/EbRestorationPick.c:690 (no header declares it) */
+void   svt_av1_loop_restoration_save_boundary_lines(const Yv12BufferConfig *frame, Av1Common *cm, int32_t after_cdef);   /* Common/Codec/EbRestoration.c:1843; its callers declare it themselves (EbDlfProcess.c:24, EbCdefProcess.c:44) */
 
 #define HIP_TRY(call) do { if ((call) != SVT_HIP_OK) return EB_ErrorUndefined; } while (0)   /* caller falls back to the C loop */
 #define LF_BORDER 3                                                                           /* RESTORATION_BORDER */
@@ -46,6 +48,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
         HIP_TRY(svt_hip_malloc(hip, &p->d_recon[pl], plane_bytes(p, pl))); HIP_TRY(svt_hip_malloc(hip, &p->d_cdef[pl], plane_bytes(p, pl)));
         HIP_TRY(svt_hip_malloc(hip, &p->d_rest[pl], plane_bytes(p, pl)));
         HIP_TRY(svt_hip_malloc(hip, &p->d_src[pl], (size_t)p->src_stride[pl] * ph * p->pix_bytes));
+        p->src[pl] = p->d_src[pl]; p->src_st[pl] = p->src_stride[pl];
         p->units_w[pl] = (pw + 3) / 4; p->units_h[pl] = (ph + 3) / 4;
         for (int d = 0; d < 2; d++) {
             p->h_edges[pl][d] = (uint16_t *)malloc(sizeof(uint16_t) * p->units_w[pl] * p->units_h[pl]);
@@ -81,19 +84,77 @@ void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
 }
 
 /* ---------------------------------------------------------------- per-picture state ----------------------------------------------------
- * Pictures pass dlf_kernel -> cdef_kernel -> rest_kernel in order, several pictures can be in different stages at once.  The table is
- * only touched with the hooks lock held.  Entries are pooled: a finished picture's device buffers serve the next one of the same size. */
+ * Pictures pass dlf_kernel -> cdef_kernel -> rest_kernel in order, several pictures can be in different stages at once — and run side by side: the table is
+ * guarded by a mutex of its own that is held only to find / hand out an entry, every entry has its own mutex that a hook holds for the duration of its call
+ * (the stages of ONE picture follow each other, and the segments of a stage all ask for the same picture-level result: the first to arrive produces it, the
+ * others wait on the entry and find it done), and the device work runs on a context of the hooks' pool (svt_hip_hooks_lock_any; taken AFTER the entry's mutex, so
+ * nobody waits for a picture while holding a context).  Entries are pooled: a finished picture's device buffers serve the next one of the same size.
+ *
+ * Deferred host picture (SVT_HIP_DEFER, default on when every loop-filter hook is): the reconstructed picture stays on the device from deblocking to the
+ * restoration filter and comes back ONCE, when the picture leaves the filter stages (svt_hip_hook_picture_done) — the deblocked and the CDEF-filtered versions
+ * are never downloaded, and the host-side preparation that only the C restoration path reads (svt_av1_loop_restoration_save_boundary_lines after both stages,
+ * svt_extend_frame, the per-segment copy of the picture in get_own_recon) is skipped by the patched process loops (svt_hip_hook_skip_host_prep).  The reference's
+ * error convention still holds: a hook that fails after such a skip first brings the host up to date — lf_recover() downloads the versions the C code needs and runs
+ * the skipped preparation itself, in the reference's order — and only then reports "not handled". */
 enum { ST_SRC = 1, ST_DBL = 2, ST_CDEF = 4, ST_DIRVAR = 8, ST_CDEF_SEARCHED = 16, ST_CDEF_FAILED = 32, ST_SGR_DONE = 64, ST_SGR_FAILED = 128,
-       ST_WIENER_DONE = 256, ST_WIENER_FAILED = 512, ST_PADDED = 1024, ST_WNSEARCH_DONE = 2048, ST_WNSEARCH_FAILED = 4096 };
+       ST_WIENER_DONE = 256, ST_WIENER_FAILED = 512, ST_PADDED = 1024, ST_WNSEARCH_DONE = 2048, ST_WNSEARCH_FAILED = 4096,
+       ST_RECON = 8192,        /* d_recon holds the picture as it was before deblocking (uploaded by the level search) */
+       ST_HOST_STALE = 16384,  /* the host's recon picture is older than the device's */
+       ST_SKIP0 = 32768,       /* save_boundary_lines(.., 0) was skipped on the host */
+       ST_SKIP1 = 65536,       /* save_boundary_lines(.., 1) + svt_extend_frame were skipped on the host */
+       ST_REST = 131072 };     /* d_rest holds restored planes (rest_mask) that the host has not seen */
 typedef struct {
     PictureControlSet *pcs;     /* NULL: free */
-    int                allocated, flags;
+    int                allocated, flags, defer, rest_mask, mu_ready;
+    pthread_mutex_t    mu;
+    const void        *res_host[3];   /* source planes taken from the resident table (released when the picture is done) */
     SvtHipLfPicture    pic;
 } LfState;
 #define LF_MAX_IN_FLIGHT 64
-static LfState g_state[LF_MAX_IN_FLIGHT];
+static LfState         g_state[LF_MAX_IN_FLIGHT];
+static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
+static long            g_lf_up_planes, g_lf_down_planes, g_lf_recoveries, g_lf_deferred, g_lf_src_resident;
+static double          g_lf_up_mb, g_lf_down_mb;
 
-static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
+/* the reconstructed pictures' host buffers, page-locked in place once (they are allocated once per encoder instance: EbReferenceObject / the PCS pool) */
+#define LF_PINS 512
+static struct { void *p; size_t n; } g_pin[LF_PINS];
+static pthread_mutex_t g_pin_mu = PTHREAD_MUTEX_INITIALIZER;
+static int             g_pin_off;
+static void lf_pin(SvtHipCtx *hip, void *base, size_t bytes) {
+    if (!svt_hip_hooks_pin_enabled() || !base || !bytes) return;
+    pthread_mutex_lock(&g_pin_mu);
+    int have = g_pin_off, slot = -1;
+    for (int i = 0; i < LF_PINS && !have; i++) {
+        if (g_pin[i].p == base) have = 1;
+        else if (!g_pin[i].p && slot < 0) slot = i;
+    }
+    if (!have && slot >= 0 && svt_hip_host_register(hip, base, bytes) == SVT_HIP_OK) { g_pin[slot].p = base; g_pin[slot].n = bytes; }
+    pthread_mutex_unlock(&g_pin_mu);
+}
+static void lf_pin_picture(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int pix_bytes) {
+    lf_pin(hip, pic->buffer_y, (size_t)pic->luma_size * pix_bytes);
+    lf_pin(hip, pic->buffer_cb, (size_t)pic->chroma_size * pix_bytes);
+    lf_pin(hip, pic->buffer_cr, (size_t)pic->chroma_size * pix_bytes);
+}
+void svt_hip_lf_bridge_unpin(SvtHipCtx *hip) {
+    pthread_mutex_lock(&g_pin_mu);
+    for (int i = 0; i < LF_PINS; i++)
+        if (g_pin[i].p) { (void)svt_hip_host_unregister(hip, g_pin[i].p); g_pin[i].p = NULL; }
+    g_pin_off = 1;
+    pthread_mutex_unlock(&g_pin_mu);
+}
+
+static int lf_defer_wanted(const SequenceControlSet *scs) {
+    static int env = -1;
+    if (env < 0) env = !(getenv("SVT_HIP_DEFER") && !atoi(getenv("SVT_HIP_DEFER")));
+    (void)scs;
+    return env && svt_hip_hook_enabled(SVT_HIP_HOOK_DLF) && svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH) && svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY) &&
+           svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH) && svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_SEARCH) && svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY);
+}
+
+/* g_tab_mu held: the entry of pcs, or (create) a free one reserved for it; *fresh = its device buffers still have to be (re)built for this geometry */
+static LfState *state_find(PictureControlSet *pcs, int create) {
     for (int i = 0; i < LF_MAX_IN_FLIGHT; i++)
         if (g_state[i].pcs == pcs) return &g_state[i];
     if (!create) return NULL;
@@ -102,7 +163,6 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
     const EbPictureBufferDesc *rec = recon_of(pcs, is_16bit);
     const int w = rec->width, h = rec->height, bd = scs->static_config.encoder_bit_depth;
     const int pad_r = scs->max_input_pad_right, pad_b = scs->max_input_pad_bottom;
-    const int sb_size = scs->seq_header.sb_size == BLOCK_128X128 ? 128 : 64;
     if ((w & 7) || (h & 7) || (bd != 8 && bd != 10) || scs->subsampling_x != 1 || scs->subsampling_y != 1 || scs->seq_header.color_config.mono_chrome ||
         pad_r < 0 || pad_r >= 8 || pad_b < 0 || pad_b >= 8 || ((w - pad_r) & 1) || ((h - pad_b) & 1) || w != scs->max_input_luma_width || h != scs->max_input_luma_height) {
         svt_hip_hooks_log("loop filter stages: %d x %d (source padded by %d x %d), %d-bit, subsampling %d/%d: not covered, C loops",
@@ -116,26 +176,68 @@ static LfState *state_of(SvtHipCtx *hip, PictureControlSet *pcs, int create) {
     for (int i = 0; i < LF_MAX_IN_FLIGHT && !s; i++)
         if (!g_state[i].pcs && !g_state[i].allocated) s = &g_state[i];
     if (!s) return NULL;
+    if (!s->mu_ready) { pthread_mutex_init(&s->mu, NULL); s->mu_ready = 1; }
+    s->pcs = pcs; s->flags = 0; s->rest_mask = 0; s->defer = -1;   /* -1: lf_enter completes the entry under its own mutex */
+    return s;
+}
+/* the entry's mutex and a pool context held: builds the device buffers of a reserved entry */
+static int state_complete(SvtHipCtx *hip, LfState *s) {
+    if (s->defer >= 0) return 1;
+    PictureControlSet *pcs = s->pcs;
+    const int is_16bit = is_16bit_of(pcs);
+    const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    const EbPictureBufferDesc *rec = recon_of(pcs, is_16bit);
+    const int w = rec->width, h = rec->height, bd = scs->static_config.encoder_bit_depth;
     if (!s->allocated) {
-        if (svt_hip_lf_picture_ctor(hip, &s->pic, w, h, is_16bit, bd) != EB_ErrorNone) { svt_hip_lf_picture_dctor(hip, &s->pic); return NULL; }
+        if (svt_hip_lf_picture_ctor(hip, &s->pic, w, h, is_16bit, bd) != EB_ErrorNone) { svt_hip_lf_picture_dctor(hip, &s->pic); return 0; }
         s->allocated = 1;
     }
-    s->pcs = pcs; s->flags = 0;
+    for (int pl = 0; pl < 3; pl++) { s->pic.src[pl] = s->pic.d_src[pl]; s->pic.src_st[pl] = s->pic.src_stride[pl]; s->res_host[pl] = NULL; }
     /* A source size that is not a multiple of 8 is coded padded (w, h), but the reference deblocks the last superblock row / column only up to the
      * unpadded extent (EbDeblockingFilter.c:343-367) and restores the cropped frame (link_eb_to_aom_buffer_desc, EbDlfProcess.c:247-251; the
      * restoration units, stripes and the 3-sample extension all follow the crop size); CDEF and the level search's SSE use the coded size. */
-    s->pic.cw = w - pad_r; s->pic.ch = h - pad_b; s->pic.sb_size = sb_size;
+    s->pic.cw = w - scs->max_input_pad_right; s->pic.ch = h - scs->max_input_pad_bottom; s->pic.sb_size = scs->seq_header.sb_size == BLOCK_128X128 ? 128 : 64;
+    s->defer = lf_defer_wanted(scs);
+    if (s->defer) __sync_fetch_and_add(&g_lf_deferred, 1);
+    lf_pin_picture(hip, rec, s->pic.pix_bytes);
+    return 1;
+}
+/* -> the picture's entry with its mutex held and a pool context in *hip, or NULL (nothing held) */
+static LfState *lf_enter(PictureControlSet *pcs, int create, SvtHipCtx **hip) {
+    pthread_mutex_lock(&g_tab_mu);
+    LfState *s = state_find(pcs, create);
+    pthread_mutex_unlock(&g_tab_mu);
+    if (!s) return NULL;
+    pthread_mutex_lock(&s->mu);
+    if (s->pcs != pcs || !(*hip = svt_hip_hooks_lock_any())) { pthread_mutex_unlock(&s->mu); return NULL; }
+    if (!state_complete(*hip, s)) {
+        svt_hip_hooks_unlock_any();
+        pthread_mutex_lock(&g_tab_mu); s->pcs = NULL; pthread_mutex_unlock(&g_tab_mu);
+        pthread_mutex_unlock(&s->mu);
+        return NULL;
+    }
     return s;
+}
+static void lf_leave(LfState *s) {
+    svt_hip_hooks_unlock_any();   /* drains the context: what this call launched is complete for whichever context the next stage gets */
+    pthread_mutex_unlock(&s->mu);
 }
 
 void svt_hip_lf_bridge_release(SvtHipCtx *hip) {   /* no picture is in flight any more (svt_hip_hooks_enc_deinit) */
+    if (g_lf_up_planes + g_lf_down_planes)
+        fprintf(stderr, "svt_hip_lf_pictures deferred=%ld recovered=%ld source_planes_resident=%ld planes_up=%ld up_mb=%.1f planes_down=%ld down_mb=%.1f\n", g_lf_deferred,
+                g_lf_recoveries, g_lf_src_resident, g_lf_up_planes, g_lf_up_mb, g_lf_down_planes, g_lf_down_mb);
     for (int i = 0; i < LF_MAX_IN_FLIGHT; i++) {
         if (g_state[i].allocated) svt_hip_lf_picture_dctor(hip, &g_state[i].pic);
+        if (g_state[i].mu_ready) pthread_mutex_destroy(&g_state[i].mu);
         memset(&g_state[i], 0, sizeof(g_state[i]));
     }
+    svt_hip_lf_bridge_unpin(hip);
+    g_pin_off = 0;
 }
 
-/* ---------------------------------------------------------------- host <-> device planes ------------------------------------------------ */
+/* ---------------------------------------------------------------- host <-> device planes ------------------------------------------------
+ * Copies of a picture's planes are queued on the context's stream and waited for once (the host side is page-locked: lf_pin_picture). */
 static uint8_t *pic_plane(const EbPictureBufferDesc *pic, int pl, int pix_bytes, int *stride) {
     const int ss = pl > 0;
     uint8_t *base = pl == 0 ? pic->buffer_y : (pl == 1 ? pic->buffer_cb : pic->buffer_cr);
@@ -149,8 +251,10 @@ static EbErrorType upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBuf
         const int pw = p->w >> (pl > 0), ph = p->h >> (pl > 0);
         const int dstride = is_src ? p->src_stride[pl] : p->stride[pl];
         uint8_t *d = is_src ? (uint8_t *)d_dst[pl] : (uint8_t *)plane_origin(p, d_dst[pl], pl);
-        HIP_TRY(svt_hip_memcpy2d_h2d(hip, d, (size_t)dstride * p->pix_bytes, s, (size_t)st * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
+        HIP_TRY(svt_hip_memcpy2d_h2d_async(hip, d, (size_t)dstride * p->pix_bytes, s, (size_t)st * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
+        __sync_fetch_and_add(&g_lf_up_planes, 1); g_lf_up_mb += (double)pw * ph * p->pix_bytes / 1048576.0;
     }
+    HIP_TRY(svt_hip_sync(hip));   /* the host picture may change as soon as the hook returns */
     return EB_ErrorNone;
 }
 /* crop: only the unpadded extent comes back (the restoration filter writes the cropped frame, EbRestoration.c:1330-1350) */
@@ -161,15 +265,96 @@ static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *cons
         uint8_t *d = pic_plane(pic, pl, p->pix_bytes, &st);
         const int pw = (crop ? p->cw : p->w) >> (pl > 0), ph = (crop ? p->ch : p->h) >> (pl > 0);
         const uint8_t *s = (const uint8_t *)plane_origin(p, d_src[pl], pl);
-        HIP_TRY(svt_hip_memcpy2d_d2h(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
+        HIP_TRY(svt_hip_memcpy2d_d2h_async(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
+        __sync_fetch_and_add(&g_lf_down_planes, 1); g_lf_down_mb += (double)pw * ph * p->pix_bytes / 1048576.0;
     }
+    HIP_TRY(svt_hip_sync(hip));
     return EB_ErrorNone;
 }
+/* The source picture of the filter stages: with resident planes (SVT_HIP_RESIDENT) the 8-bit enhanced picture is usually on the device already — the temporal
+ * filter and the motion search read it there — and the stages read that copy in place (picture stride, origin offset); otherwise it is uploaded once per picture. */
 static EbErrorType ensure_src(SvtHipCtx *hip, LfState *s) {
     if (s->flags & ST_SRC) return EB_ErrorNone;
-    if (upload(hip, &s->pic, source_of(s->pcs, s->pic.pix_bytes == 2), s->pic.d_src, 1) != EB_ErrorNone) return EB_ErrorUndefined;
+    SvtHipLfPicture *p = &s->pic;
+    const EbPictureBufferDesc *in = source_of(s->pcs, p->pix_bytes == 2);
+    if (p->pix_bytes == 1 && svt_hip_resident_enabled()) {
+        const uint8_t *dev[3] = {0};
+        int n = 0;
+        for (int pl = 0; pl < 3; pl++, n++) {
+            const uint8_t *base = pl == 0 ? in->buffer_y : (pl == 1 ? in->buffer_cb : in->buffer_cr);
+            const int st = pl == 0 ? in->stride_y : (pl == 1 ? in->stride_cb : in->stride_cr);
+            dev[pl] = (const uint8_t *)svt_hip_resident_acquire(hip, base, (size_t)st * (size_t)((in->height >> (pl > 0)) + 2 * (in->origin_y >> (pl > 0))));
+            if (!dev[pl]) break;
+        }
+        if (n == 3) {
+            for (int pl = 0; pl < 3; pl++) {
+                const int st = pl == 0 ? in->stride_y : (pl == 1 ? in->stride_cb : in->stride_cr);
+                s->res_host[pl] = pl == 0 ? in->buffer_y : (pl == 1 ? in->buffer_cb : in->buffer_cr);
+                p->src[pl] = (void *)(uintptr_t)(dev[pl] + (size_t)(in->origin_y >> (pl > 0)) * st + (in->origin_x >> (pl > 0)));
+                p->src_st[pl] = st;
+            }
+            __sync_fetch_and_add(&g_lf_src_resident, 3);
+            s->flags |= ST_SRC;
+            return EB_ErrorNone;
+        }
+        for (int pl = 0; pl < n; pl++) svt_hip_resident_release(pl == 0 ? in->buffer_y : (pl == 1 ? in->buffer_cb : in->buffer_cr));
+    }
+    lf_pin_picture(hip, in, p->pix_bytes);
+    if (upload(hip, p, in, p->d_src, 1) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_SRC;
     return EB_ErrorNone;
+}
+
+/* A hook has failed (or is about to hand its stage back to the C code) after host work was skipped: the host picture and the boundary-line buffers are brought to
+ * exactly the state the reference's own flow would have left at this point.  stage 0: the C code that follows reads the deblocked picture (CDEF search / filter);
+ * stage 1: it reads the CDEF output (restoration search / filter).  Afterwards the picture is no longer deferred. */
+static void lf_recover(SvtHipCtx *hip, LfState *s, int stage) {
+    if (!s->defer) return;
+    SvtHipLfPicture *p = &s->pic;
+    PictureControlSet *pcs = s->pcs;
+    const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    EbPictureBufferDesc *rec = recon_of(pcs, p->pix_bytes == 2);
+    const int highbd = p->pix_bytes == 2;
+    __sync_fetch_and_add(&g_lf_recoveries, 1);
+    if ((s->flags & (ST_HOST_STALE | ST_SKIP0)) && (s->flags & ST_DBL)) (void)download(hip, p, p->d_recon, rec, 7, 0);
+    if (s->flags & ST_SKIP0) svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 0);
+    if (stage >= 1) {
+        if (s->flags & ST_CDEF) (void)download(hip, p, p->d_cdef, rec, 7, 0);   /* a border the device has added inside a padded picture is the one svt_extend_frame writes below */
+        if (s->flags & ST_SKIP1) {
+            svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 1);
+            for (int pl = 0; pl < 3; pl++)
+                svt_extend_frame(cm->frame_to_show->buffers[pl], cm->frame_to_show->crop_widths[pl > 0], cm->frame_to_show->crop_heights[pl > 0], cm->frame_to_show->strides[pl > 0],
+                                 RESTORATION_BORDER, RESTORATION_BORDER, highbd);
+        }
+        s->flags &= ~ST_SKIP1;
+    }
+    (void)scs;
+    s->flags &= ~(ST_HOST_STALE | ST_SKIP0);
+    s->defer = 0;
+    svt_hip_hooks_log("loop filter stages: host picture brought up to date after a failed hook (stage %d)", stage);
+}
+/* SVT_HIP_LF_FAULT=<hook name>: that hook of the loop-filter bridge reports a failure on every picture AFTER doing (or skipping) its work — the tests' way to drive
+ * the recovery path on the device and on the CPU test double */
+static int lf_fault(const char *hook) {
+    const char *e = getenv("SVT_HIP_LF_FAULT");
+    return e && !strcmp(e, hook);
+}
+
+/* The patched process loops ask before host work that only the C restoration path reads (which: 0 = save_boundary_lines after deblocking, EbDlfProcess.c:251;
+ * 1 = save_boundary_lines + svt_extend_frame after CDEF, EbCdefProcess.c:549-572; 2 = get_own_recon of a restoration segment, EbRestProcess.c:517;
+ * 3 = svt_extend_frame of the segment's picture copy, EbRestorationPick.c:1535): 1 = skip it, the picture is deferred and lf_recover() knows what was skipped. */
+int svt_hip_hook_skip_host_prep(PictureControlSet *pcs, int which) {
+    pthread_mutex_lock(&g_tab_mu);
+    LfState *s = state_find(pcs, 0);
+    pthread_mutex_unlock(&g_tab_mu);
+    if (!s) return 0;
+    pthread_mutex_lock(&s->mu);
+    const int skip = s->pcs == pcs && s->defer > 0;
+    if (skip && which == 0) s->flags |= ST_SKIP0;
+    if (skip && which == 1) s->flags |= ST_SKIP1;
+    pthread_mutex_unlock(&s->mu);
+    return skip;
 }
 
 /* ---------------------------------------------------------------- deblocking ---------------------------------------------------------
@@ -221,7 +406,8 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
     FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
     struct LoopFilter *lf = &frm_hdr->loop_filter_params;
     if (ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
-    if (upload(hip, p, recon_of(pcs, p->pix_bytes == 2), p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (!(s->flags & ST_RECON) && upload(hip, p, recon_of(pcs, p->pix_bytes == 2), p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    s->flags |= ST_RECON;   /* the search filters into d_cdef: d_recon stays the picture as coded, which svt_av1_loop_filter_frame's hook starts from */
     fill_mode_info(p, pcs, 1);
     int best[3];
     const int last[4] = {lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v};
@@ -236,7 +422,7 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
         q.sharpness = 0;                                            /* lf->sharpness_level = 0 (:1202) */
         int64_t err;
         HIP_TRY(svt_hip_dlf_search_level_dev(hip, &q, plane_origin(p, p->d_recon[pl], pl), plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->bd,
-                                             p->w >> (pl > 0), p->h >> (pl > 0), p->d_src[pl], p->src_stride[pl], p->d_edges[pl][0], p->d_edges[pl][1],
+                                             p->w >> (pl > 0), p->h >> (pl > 0), p->src[pl], p->src_st[pl], p->d_edges[pl][0], p->d_edges[pl][1],
                                              p->units_w[pl], p->units_h[pl], p->d_sse, &best[pl], &err));
         svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, q.start_level, best[pl], (long long)err);
     }
@@ -249,12 +435,14 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
 
 EbErrorType svt_hip_hook_dlf_pick_level(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_DLF_SEARCH)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 1);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 1, &hip);
     EbErrorType rc = s ? dlf_pick_level(hip, s) : EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s && rc == EB_ErrorNone && lf_fault("dlf_search")) rc = EB_ErrorUndefined;
+    if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_DLF_SEARCH, rc == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_DLF_SEARCH, t0);
     return rc;
 }
 
@@ -266,8 +454,12 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
     const struct LoopFilter *lf = &frm_hdr->loop_filter_params;
     svt_av1_loop_filter_frame_init(frm_hdr, &pcs->parent_pcs_ptr->lf_info, 0, 3);       /* svt_av1_loop_filter_frame does this first (:722) */
     /* loop_filter_sb (:636-646): both luma levels 0 -> `break`, NO plane is filtered; a chroma plane with level 0 is skipped */
-    if (!lf->filter_level[0] && !lf->filter_level[1]) return EB_ErrorNone;
-    if (upload(hip, p, recon, p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (!lf->filter_level[0] && !lf->filter_level[1]) {
+        if (s->flags & ST_RECON) s->flags |= ST_DBL;   /* the picture as coded IS the deblocked picture, and it is on the device already */
+        return EB_ErrorNone;
+    }
+    if (!(s->flags & ST_RECON) && upload(hip, p, recon, p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    s->flags &= ~ST_RECON;
     fill_mode_info(p, pcs, 0);
     void *pl_ptr[3]; const uint16_t *ev[3], *eh[3];
     int mask = 0;
@@ -280,19 +472,22 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
         if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
     }
     HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
-    if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (s->defer) s->flags |= ST_HOST_STALE;   /* the deblocked picture stays on the device (svt_hip_hook_picture_done brings the final one back) */
+    else if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_DBL;
     svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask);
     return EB_ErrorNone;
 }
 EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_DLF)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 1);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 1, &hip);
     EbErrorType rc = s ? dlf_frame(hip, s, recon) : EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s && rc != EB_ErrorNone) { s->flags &= ~(ST_RECON | ST_DBL | ST_HOST_STALE); s->defer = 0; }   /* the C filter runs on the host picture, which nothing has touched yet */
+    if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_DLF, rc == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_DLF, t0);
     return rc;
 }
 
@@ -302,11 +497,15 @@ void svt_hip_hook_after_dlf(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH) && !svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH) &&
         !svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_TRY) && !svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_SEARCH))
         return;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return;
-    LfState *s = state_of(hip, pcs, 1);
-    if (s && !(s->flags & ST_DBL) && upload(hip, &s->pic, recon_of(pcs, s->pic.pix_bytes == 2), s->pic.d_recon, 0) == EB_ErrorNone) s->flags |= ST_DBL;
-    svt_hip_hooks_unlock();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 1, &hip);
+    if (!s) return;
+    if (!(s->flags & ST_DBL)) {   /* deblocked by the C code (hook off / not handled), or not at all: the host picture is the current one */
+        s->flags &= ~ST_RECON;
+        if (upload(hip, &s->pic, recon_of(pcs, s->pic.pix_bytes == 2), s->pic.d_recon, 0) == EB_ErrorNone) s->flags |= ST_DBL;
+        else s->defer = 0;
+    }
+    lf_leave(s);
 }
 
 /* ---------------------------------------------------------------- CDEF ---------------------------------------------------------------- */
@@ -333,8 +532,8 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
     svt_hip_hooks_log("cdef_search: %d x %d, %d filter blocks, primary damping %d", p->w, p->h, nfb, pri_damping);
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_skip8, p->h_skip8, (size_t)(p->w / 8) * (p->h / 8)));
     const void *rec[3], *src[3];
-    for (int pl = 0; pl < 3; pl++) { rec[pl] = plane_origin(p, p->d_recon[pl], pl); src[pl] = p->d_src[pl]; }
-    HIP_TRY(svt_hip_cdef_search_frame_dev(hip, p->pix_bytes, rec, p->stride, src, p->src_stride, p->w, p->h, p->d_skip8, pri_damping, p->bd, p->d_mse, p->d_dir, p->d_var));
+    for (int pl = 0; pl < 3; pl++) { rec[pl] = plane_origin(p, p->d_recon[pl], pl); src[pl] = p->src[pl]; }
+    HIP_TRY(svt_hip_cdef_search_frame_dev(hip, p->pix_bytes, rec, p->stride, src, p->src_st, p->w, p->h, p->d_skip8, pri_damping, p->bd, p->d_mse, p->d_dir, p->d_var));
     HIP_TRY(svt_hip_memcpy_d2h(hip, p->h_mse, p->d_mse, sizeof(uint64_t) * 2 * nfb * 64));
     const int level = pcs->parent_pcs_ptr->cdef_level;
     const CDEF_PICK_METHOD pick = level == 2 ? CDEF_FAST_SEARCH_LVL1 : level == 3 ? CDEF_FAST_SEARCH_LVL2 : level == 4 ? CDEF_FAST_SEARCH_LVL3 : 0;
@@ -375,17 +574,20 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
 /* called by every segment of the picture: the first one to arrive searches the whole picture, the others find it done */
 EbErrorType svt_hip_hook_cdef_search(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_SEARCH)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = EB_ErrorUndefined;
     if (s && (s->flags & ST_CDEF_SEARCHED)) rc = EB_ErrorNone;
     else if (s && !(s->flags & ST_CDEF_FAILED)) {
         rc = cdef_search(hip, s);
+        if (rc == EB_ErrorNone && lf_fault("cdef_search")) rc = EB_ErrorUndefined;
         s->flags |= rc == EB_ErrorNone ? ST_CDEF_SEARCHED : ST_CDEF_FAILED;
+        if (rc != EB_ErrorNone) lf_recover(hip, s, 0);   /* cdef_seg_search reads the deblocked picture on the host */
         svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_SEARCH, rc == EB_ErrorNone);
     }
-    svt_hip_hooks_unlock();
+    if (s) lf_leave(s);
+    svt_hip_hooks_time(SVT_HIP_HOOK_CDEF_SEARCH, t0);
     return rc;
 }
 
@@ -422,18 +624,22 @@ static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
     /* direction / variance of the search are reused when it ran here (same pre-CDEF picture) */
     HIP_TRY(svt_hip_cdef_apply_frame_dev(hip, p->pix_bytes, in, out, p->stride, p->w, p->h, p->d_skip8, p->d_y_strength, p->d_uv_strength,
                                          frm_hdr->cdef_params.cdef_damping, p->bd, p->d_dir, (s->flags & ST_DIRVAR) ? p->d_var : NULL));
-    if (download(hip, p, p->d_cdef, recon_of(pcs, p->pix_bytes == 2), 7, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (s->defer) s->flags |= ST_HOST_STALE;
+    else if (download(hip, p, p->d_cdef, recon_of(pcs, p->pix_bytes == 2), 7, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_CDEF;
     return EB_ErrorNone;
 }
 EbErrorType svt_hip_hook_cdef_apply(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_APPLY)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = s ? cdef_apply(hip, s) : EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s && rc == EB_ErrorNone && lf_fault("cdef_apply")) { rc = EB_ErrorUndefined; s->flags &= ~(ST_CDEF | ST_PADDED); }
+    if (s && rc != EB_ErrorNone) lf_recover(hip, s, 0);   /* svt_av1_cdef_frame filters the deblocked picture on the host */
+    if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_APPLY, rc == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_CDEF_APPLY, t0);
     return rc;
 }
 
@@ -441,8 +647,10 @@ EbErrorType svt_hip_hook_cdef_apply(PictureControlSet *pcs) {
 /* the CDEF output on the device (from the CDEF hook, or uploaded from the host picture) with its 3-sample border (svt_extend_frame) */
 static EbErrorType ensure_cdef_padded(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
-    if (!(s->flags & ST_CDEF)) {
-        if (upload(hip, p, recon_of(s->pcs, p->pix_bytes == 2), p->d_cdef, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (!(s->flags & ST_CDEF)) {   /* CDEF is off for this picture, or ran on the host */
+        if (s->flags & ST_HOST_STALE) {    /* ... off: the deblocked picture, which only the device has, is the restoration input */
+            for (int pl = 0; pl < 3; pl++) HIP_TRY(svt_hip_memcpy_d2d(hip, p->d_cdef[pl], p->d_recon[pl], plane_bytes(p, pl)));
+        } else if (upload(hip, p, recon_of(s->pcs, p->pix_bytes == 2), p->d_cdef, 0) != EB_ErrorNone) return EB_ErrorUndefined;
         s->flags |= ST_CDEF;
     }
     if (!(s->flags & ST_PADDED)) {
@@ -489,16 +697,20 @@ static EbErrorType rest_apply(SvtHipCtx *hip, LfState *s) {
                                            p->d_unit_xqd[pl], p->d_unit_wiener[pl]));
         mask |= 1 << pl;
     }
+    if (s->defer) { s->flags |= ST_REST | ST_HOST_STALE; s->rest_mask = mask; return EB_ErrorNone; }   /* comes back with svt_hip_hook_picture_done */
     return download(hip, p, p->d_rest, recon_of(pcs, p->pix_bytes == 2), mask, 1);
 }
 EbErrorType svt_hip_hook_rest_apply(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_REST_APPLY)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = s ? rest_apply(hip, s) : EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s && rc == EB_ErrorNone && lf_fault("rest_apply")) { rc = EB_ErrorUndefined; s->flags &= ~ST_REST; s->rest_mask = 0; }
+    if (s && rc != EB_ErrorNone) lf_recover(hip, s, 1);   /* svt_av1_loop_restoration_filter_frame reads the CDEF output and both sets of boundary lines */
+    if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_REST_APPLY, rc == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_REST_APPLY, t0);
     return rc;
 }
 
@@ -524,6 +736,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
     SvtHipSgrSearchPlane job[3];
     int32_t *xqd[3] = {0}; int64_t *err[3] = {0}; uint8_t *best[3] = {0};
     uint8_t *c_ep[3] = {0}; int32_t *c_uq[3] = {0}; uint64_t *c_sse[3] = {0};   /* per plane: the chosen set / taps / SSE of every unit, committed at the end */
+    uint64_t *c_none[3] = {0};   /* search_norestore_seg (:1476): sse_restoration_unit of the unfiltered unit -- the same rectangles, the CDEF output against the source */
     EbErrorType ret = EB_ErrorNone;
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
@@ -531,7 +744,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
         xqd[pl] = (int32_t *)calloc((size_t)32 * n, sizeof(int32_t)); err[pl] = (int64_t *)calloc((size_t)16 * n, sizeof(int64_t)); best[pl] = (uint8_t *)calloc(n, 1);
         if (!xqd[pl] || !err[pl] || !best[pl]) { ret = EB_ErrorInsufficientResources; goto done; }
         job[pl].d_dgd = plane_origin(p, p->d_cdef[pl], pl); job[pl].stride = p->stride[pl];
-        job[pl].d_src = p->d_src[pl]; job[pl].src_stride = p->src_stride[pl];
+        job[pl].d_src = p->src[pl]; job[pl].src_stride = p->src_st[pl];
         job[pl].pw = pw; job[pl].ph = ph; job[pl].unit_size = rsi->restoration_unit_size; job[pl].ss_y = pl > 0;
         job[pl].ep_mask = mask; job[pl].xqd_out = xqd[pl]; job[pl].err_out = err[pl]; job[pl].best_ep = best[pl];
     }
@@ -541,9 +754,8 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
     for (int pl = 0; pl < 3; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
         const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size;
-        RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
         uint8_t *ep = (uint8_t *)malloc(n); int32_t *uq = (int32_t *)malloc(sizeof(int32_t) * 2 * n);
-        SvtHipBlkPair *rect = (SvtHipBlkPair *)malloc(sizeof(SvtHipBlkPair) * n); uint64_t *sse = (uint64_t *)malloc(sizeof(uint64_t) * n);
+        SvtHipBlkPair *rect = (SvtHipBlkPair *)malloc(sizeof(SvtHipBlkPair) * n); uint64_t *sse = (uint64_t *)malloc(sizeof(uint64_t) * 2 * n);
         void *d_rect = NULL, *d_sse = NULL;
         int ok = ep && uq && rect && sse;
         if (ok) {
@@ -565,20 +777,22 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
                 }
                 y0 += h; i++;
             }
-            ok = ok && svt_hip_malloc(hip, &d_rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK && svt_hip_malloc(hip, &d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK &&
+            ok = ok && svt_hip_hooks_malloc(hip, &d_rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK && svt_hip_hooks_malloc(hip, &d_sse, sizeof(uint64_t) * 2 * n) == SVT_HIP_OK &&
                  svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl], ep, n) == SVT_HIP_OK && svt_hip_memcpy_h2d(hip, p->d_unit_xqd[pl], uq, sizeof(int32_t) * 2 * n) == SVT_HIP_OK &&
                  svt_hip_memcpy_h2d(hip, d_rect, rect, sizeof(SvtHipBlkPair) * n) == SVT_HIP_OK &&
                  /* try_restoration_unit_seg: the unit filtered for real (stripe context from the deblocked picture), then its SSE */
                  svt_hip_sgr_apply_plane_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
                                              pw, ph, us, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl]) == SVT_HIP_OK &&
-                 svt_hip_block_sse_batch_dev(hip, p->pix_bytes, p->d_src[pl], p->src_stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
+                 svt_hip_block_sse_batch_dev(hip, p->pix_bytes, p->src[pl], p->src_st[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl],
                                              (const SvtHipBlkPair *)d_rect, n, (uint64_t *)d_sse) == SVT_HIP_OK &&
-                 svt_hip_memcpy_d2h(hip, sse, d_sse, sizeof(uint64_t) * n) == SVT_HIP_OK;
+                 svt_hip_block_sse_batch_dev(hip, p->pix_bytes, p->src[pl], p->src_st[pl], plane_origin(p, p->d_cdef[pl], pl), p->stride[pl],
+                                             (const SvtHipBlkPair *)d_rect, n, (uint64_t *)d_sse + n) == SVT_HIP_OK &&
+                 svt_hip_memcpy_d2h(hip, sse, d_sse, sizeof(uint64_t) * 2 * n) == SVT_HIP_OK;
         }
-        if (d_rect) svt_hip_free(hip, d_rect);
-        if (d_sse) svt_hip_free(hip, d_sse);
+        if (d_rect) svt_hip_hooks_free(hip, d_rect);
+        if (d_sse) svt_hip_hooks_free(hip, d_sse);
         free(rect);
-        c_ep[pl] = ep; c_uq[pl] = uq; c_sse[pl] = sse;   /* committed below, once every plane has succeeded */
+        c_ep[pl] = ep; c_uq[pl] = uq; c_sse[pl] = sse; c_none[pl] = sse ? sse + n : NULL;   /* committed below, once every plane has succeeded */
         if (!ok) { ret = EB_ErrorUndefined; goto done; }
     }
     /* every device step of the hook has succeeded: only now do the reference's objects change (a failure above leaves rusi and cm->sg_frame_ep_cnt as they
@@ -589,6 +803,7 @@ static EbErrorType sgr_search(SvtHipCtx *hip, LfState *s) {
         for (int u = 0; u < n; u++) {
             rusi[u].sgrproj.ep = c_ep[pl][u]; rusi[u].sgrproj.xqd[0] = c_uq[pl][2 * u]; rusi[u].sgrproj.xqd[1] = c_uq[pl][2 * u + 1];
             rusi[u].sse[RESTORE_SGRPROJ] = (int64_t)c_sse[pl][u];
+            rusi[u].sse[RESTORE_NONE] = (int64_t)c_none[pl][u];
             cm->sg_frame_ep_cnt[c_ep[pl][u]]++;
         }
     }
@@ -599,17 +814,19 @@ done:
 /* called at the top of every restoration_seg_search of the picture: the first segment to arrive searches all units */
 EbErrorType svt_hip_hook_sgr_search(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_SGR_SEARCH)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = EB_ErrorUndefined;
     if (s && (s->flags & ST_SGR_DONE)) rc = EB_ErrorNone;
     else if (s && !(s->flags & ST_SGR_FAILED)) {
-        rc = sgr_search(hip, s);
+        rc = lf_fault("sgr_search") ? EB_ErrorUndefined : sgr_search(hip, s);
         s->flags |= rc == EB_ErrorNone ? ST_SGR_DONE : ST_SGR_FAILED;
+        if (rc != EB_ErrorNone) lf_recover(hip, s, 1);   /* the per-unit C search reads the CDEF output, its copy and the boundary lines on the host */
         svt_hip_hooks_count(SVT_HIP_HOOK_SGR_SEARCH, rc == EB_ErrorNone);
     }
-    svt_hip_hooks_unlock();
+    if (s) lf_leave(s);
+    svt_hip_hooks_time(SVT_HIP_HOOK_SGR_SEARCH, t0);
     return rc;
 }
 
@@ -628,23 +845,23 @@ static EbErrorType wiener_stats_all(SvtHipCtx *hip, LfState *s) {
         p->h_wiener_M[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2); p->h_wiener_H[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2 * w2);
         p->wiener_win[pl] = win;
         void *dM = NULL, *dH = NULL;
-        int ok = p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_malloc(hip, &dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
-                 svt_hip_malloc(hip, &dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK &&
-                 svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->d_src[pl], p->src_stride[pl],
+        int ok = p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_hooks_malloc(hip, &dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
+                 svt_hip_hooks_malloc(hip, &dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK &&
+                 svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->src[pl], p->src_st[pl],
                                                 p->cw >> (pl > 0), p->ch >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)dM, (int64_t *)dH) == SVT_HIP_OK &&
                  svt_hip_memcpy_d2h(hip, p->h_wiener_M[pl], dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
                  svt_hip_memcpy_d2h(hip, p->h_wiener_H[pl], dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK;
-        if (dM) svt_hip_free(hip, dM);
-        if (dH) svt_hip_free(hip, dH);
+        if (dM) svt_hip_hooks_free(hip, dM);
+        if (dH) svt_hip_hooks_free(hip, dH);
         if (!ok) return EB_ErrorUndefined;
     }
     return EB_ErrorNone;
 }
 EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wiener_win, int unit_idx, int64_t *M, int64_t *H) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_STATS)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = EB_ErrorUndefined;
     if (s && !(s->flags & (ST_WIENER_DONE | ST_WIENER_FAILED))) {
         rc = wiener_stats_all(hip, s);
@@ -659,7 +876,8 @@ EbErrorType svt_hip_hook_wiener_stats(PictureControlSet *pcs, int plane, int wie
         rc = EB_ErrorNone;
     } else
         rc = EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s) lf_leave(s);
+    svt_hip_hooks_time(SVT_HIP_HOOK_WIENER_STATS, t0);
     return rc;
 }
 
@@ -689,12 +907,13 @@ static EbErrorType wiener_try(SvtHipCtx *hip, LfState *s, int pl, int h_start, i
 }
 EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_start, int h_end, int v_start, int v_end, const WienerInfo *wi, int64_t *err) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_TRY)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = s ? wiener_try(hip, s, plane, h_start, h_end, v_start, v_end, wi, err) : EB_ErrorUndefined;
-    svt_hip_hooks_unlock();
+    if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_WIENER_TRY, rc == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_WIENER_TRY, t0);
     return rc;
 }
 
@@ -762,8 +981,8 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
         RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
         walk[pl] = (WnWalk *)calloc(n, sizeof(WnWalk)); rect[pl] = (SvtHipBlkPair *)calloc(n, sizeof(SvtHipBlkPair));
         ep[pl] = (uint8_t *)malloc(n); wn[pl] = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t)); sse[pl] = (uint64_t *)calloc(n, sizeof(uint64_t));
-        if (!walk[pl] || !rect[pl] || !ep[pl] || !wn[pl] || !sse[pl] || svt_hip_malloc(hip, &d_rect[pl], sizeof(SvtHipBlkPair) * n) != SVT_HIP_OK ||
-            svt_hip_malloc(hip, &d_sse[pl], sizeof(uint64_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
+        if (!walk[pl] || !rect[pl] || !ep[pl] || !wn[pl] || !sse[pl] || svt_hip_hooks_malloc(hip, &d_rect[pl], sizeof(SvtHipBlkPair) * n) != SVT_HIP_OK ||
+            svt_hip_hooks_malloc(hip, &d_sse[pl], sizeof(uint64_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
         /* unit rectangles of foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) */
         const int ext = us * 3 / 2, voff = 8 >> (pl > 0), hunits = rsi->horz_units_per_tile;
         int y0 = 0, i = 0;
@@ -807,7 +1026,7 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
             if (svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl], ep[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
                 svt_hip_lr_try_units_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl], pw, ph,
                                          rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl],
-                                         p->d_unit_wiener[pl], p->d_src[pl], p->src_stride[pl], (const SvtHipBlkPair *)d_rect[pl], n, (uint64_t *)d_sse[pl]) != SVT_HIP_OK ||
+                                         p->d_unit_wiener[pl], p->src[pl], p->src_st[pl], (const SvtHipBlkPair *)d_rect[pl], n, (uint64_t *)d_sse[pl]) != SVT_HIP_OK ||
                 svt_hip_memcpy_d2h(hip, sse[pl], d_sse[pl], sizeof(uint64_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
             const int off = (WIENER_WIN - p->wiener_win[pl]) >> 1;
             for (int u = 0; u < n; u++) {
@@ -832,33 +1051,78 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     }
     for (int pl = 0; pl < 3; pl++) {
         free(walk[pl]); free(rect[pl]); free(ep[pl]); free(wn[pl]); free(sse[pl]);
-        if (d_rect[pl]) svt_hip_free(hip, d_rect[pl]);
-        if (d_sse[pl]) svt_hip_free(hip, d_sse[pl]);
+        if (d_rect[pl]) svt_hip_hooks_free(hip, d_rect[pl]);
+        if (d_sse[pl]) svt_hip_hooks_free(hip, d_sse[pl]);
     }
     return ret;
 }
 EbErrorType svt_hip_hook_wiener_search(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_WIENER_SEARCH)) return EB_ErrorUndefined;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return EB_ErrorUndefined;
-    LfState    *s = state_of(hip, pcs, 0);
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
     EbErrorType rc = EB_ErrorUndefined;
     if (s && (s->flags & ST_WNSEARCH_DONE)) rc = EB_ErrorNone;
     else if (s && !(s->flags & ST_WNSEARCH_FAILED)) {
-        rc = rest_geometry_ok(&s->pic, pcs->parent_pcs_ptr->av1_cm) && ensure_src(hip, s) == EB_ErrorNone && ensure_cdef_padded(hip, s) == EB_ErrorNone ? wiener_search(hip, s) : EB_ErrorUndefined;
+        rc = !lf_fault("wiener_search") && rest_geometry_ok(&s->pic, pcs->parent_pcs_ptr->av1_cm) && ensure_src(hip, s) == EB_ErrorNone && ensure_cdef_padded(hip, s) == EB_ErrorNone
+                 ? wiener_search(hip, s) : EB_ErrorUndefined;
         s->flags |= rc == EB_ErrorNone ? ST_WNSEARCH_DONE : ST_WNSEARCH_FAILED;
+        if (rc != EB_ErrorNone) lf_recover(hip, s, 1);
         svt_hip_hooks_count(SVT_HIP_HOOK_WIENER_SEARCH, rc == EB_ErrorNone);
     }
-    svt_hip_hooks_unlock();
+    if (s) lf_leave(s);
+    svt_hip_hooks_time(SVT_HIP_HOOK_WIENER_SEARCH, t0);
     return rc;
 }
 
+/* rest_kernel, at the top of every restoration segment (EbRestProcess.c:505, before get_own_recon): with the picture deferred the picture-level searches run HERE,
+ * so that a failure can still bring the host up to date before the segment copies the picture; 1 = the copy (and with it every host read of the picture in this
+ * segment's search) can be skipped */
+int svt_hip_hook_rest_begin(PictureControlSet *pcs) {
+    if (!svt_hip_hook_skip_host_prep(pcs, 2)) return 0;
+    if (svt_hip_hook_sgr_search(pcs) != EB_ErrorNone) return 0;   /* recovered: the C search of this segment follows */
+    if (pcs->parent_pcs_ptr->av1_cm->wn_filter_mode && svt_hip_hook_wiener_search(pcs) != EB_ErrorNone) return 0;
+    return svt_hip_hook_skip_host_prep(pcs, 2);
+}
+
+/* the picture's final reconstruction comes back: restored planes from d_rest, the others (and, inside a padded picture, the samples outside the cropped frame)
+ * from the CDEF output with the border svt_extend_frame gives it, or the deblocked picture when CDEF was off */
+static void lf_final_download(SvtHipCtx *hip, LfState *s) {
+    SvtHipLfPicture *p = &s->pic;
+    EbPictureBufferDesc *rec = recon_of(s->pcs, p->pix_bytes == 2);
+    if ((s->flags & ST_SKIP1) && ensure_cdef_padded(hip, s) != EB_ErrorNone) {
+        SVT_LOG("svt_hip: the device lost a picture after its filter stages (%s)\n", svt_hip_last_error(hip));
+        return;
+    }
+    void *const *base = (s->flags & ST_CDEF) ? p->d_cdef : p->d_recon;
+    const int rest = (s->flags & ST_REST) ? s->rest_mask : 0;
+    const int whole = p->cw == p->w && p->ch == p->h ? rest : 0;   /* planes whose restored version covers the coded picture */
+    int rc = EB_ErrorNone;
+    if (7 & ~whole) rc = download(hip, p, base, rec, 7 & ~whole, 0);
+    if (rc == EB_ErrorNone && rest) rc = download(hip, p, p->d_rest, rec, rest, 1);
+    if (rc != EB_ErrorNone) SVT_LOG("svt_hip: download of a filtered picture failed (%s)\n", svt_hip_last_error(hip));
+    s->flags &= ~ST_HOST_STALE;
+}
 void svt_hip_hook_picture_done(PictureControlSet *pcs) {
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return;
-    LfState *s = state_of(hip, pcs, 0);
-    if (s) { s->pcs = NULL; s->flags = 0; }   /* buffers stay allocated for the next picture of this size */
-    svt_hip_hooks_unlock();
+    SvtHipCtx *hip = NULL;
+    LfState   *s = lf_enter(pcs, 0, &hip);
+    if (!s) return;
+    const long long t0 = svt_hip_hooks_now_ns();
+    if (s->flags & ST_HOST_STALE) lf_final_download(hip, s);
+    else if (s->flags & ST_SKIP1) {   /* nothing was filtered on the device, but the border the reference gives the CDEF output was skipped: the host adds it now */
+        const Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+        for (int pl = 0; pl < 3; pl++)
+            svt_extend_frame(cm->frame_to_show->buffers[pl], cm->frame_to_show->crop_widths[pl > 0], cm->frame_to_show->crop_heights[pl > 0], cm->frame_to_show->strides[pl > 0],
+                             RESTORATION_BORDER, RESTORATION_BORDER, s->pic.pix_bytes == 2);
+    }
+    for (int pl = 0; pl < 3; pl++)
+        if (s->res_host[pl]) { svt_hip_resident_release(s->res_host[pl]); s->res_host[pl] = NULL; }
+    svt_hip_hooks_time(SVT_HIP_HOOK_REST_APPLY, t0);
+    svt_hip_hooks_unlock_any();
+    pthread_mutex_lock(&g_tab_mu);
+    s->pcs = NULL; s->flags = 0;   /* buffers stay allocated for the next picture of this size */
+    pthread_mutex_unlock(&g_tab_mu);
+    pthread_mutex_unlock(&s->mu);
 }
 
 /* ------------------------------------------------------------------ hook "cdef_finish": joint_strength_search_dual inside finish_cdef_search
@@ -879,23 +1143,25 @@ int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32
     if (nb_strengths == 1 || !tls_sel.valid || tls_sel.key0 != (const void *)mse[0] || tls_sel.key1 != (const void *)mse[1] || tls_sel.sb_count != sb_count ||
         tls_sel.start_gi != start_gi || tls_sel.end_gi != end_gi) {
         tls_sel.valid = 0;
-        SvtHipCtx *hip = svt_hip_hooks_lock();
+        const long long t0 = svt_hip_hooks_now_ns();
+        SvtHipCtx *hip = svt_hip_hooks_lock_any();
         if (!hip) return 0;
         const size_t mb = (size_t)sb_count * 64 * sizeof(uint64_t);
         void        *d_m0 = NULL, *d_m1 = NULL, *d_state = NULL;
-        int          rc = svt_hip_malloc(hip, &d_m0, mb + 8);
-        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_m1, mb + 8);
-        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+        int          rc = svt_hip_hooks_malloc(hip, &d_m0, mb + 8);
+        if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_m1, mb + 8);
+        if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
         if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m0, mse[0], mb);
         if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m1, mse[1], mb);
         if (rc == SVT_HIP_OK)
             rc = svt_hip_cdef_strength_select_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, start_gi, end_gi, d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
         if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &tls_sel.res, d_state, sizeof(tls_sel.res));
         if (rc == SVT_HIP_OK && tls_sel.res.status[0]) rc = SVT_HIP_ERR_RUNTIME; /* the one-launch form gave up waiting (SVT_HIP_CDEF_SELECT=resident only) */
-        svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state);
+        svt_hip_hooks_free(hip, d_m0); svt_hip_hooks_free(hip, d_m1); svt_hip_hooks_free(hip, d_state);
         if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength selection on the device failed (%s): C search\n", svt_hip_last_error(hip));
-        svt_hip_hooks_unlock();
+        svt_hip_hooks_unlock_any();
         svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_FINISH, rc == SVT_HIP_OK);
+        svt_hip_hooks_time(SVT_HIP_HOOK_CDEF_FINISH, t0);
         if (rc != SVT_HIP_OK) return 0;
         tls_sel.key0 = mse[0]; tls_sel.key1 = mse[1]; tls_sel.sb_count = sb_count; tls_sel.start_gi = start_gi; tls_sel.end_gi = end_gi; tls_sel.valid = 1;
         svt_hip_hooks_log("cdef_finish: strength pairs for 1 / 2 / 4 / 8 over %d filter blocks in one pass, totals %llu %llu %llu %llu", sb_count,
@@ -915,16 +1181,17 @@ int svt_hip_hook_cdef_joint_search(int32_t *best_lev0, int32_t *best_lev1, int32
 int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t start_gi, int32_t end_gi, uint64_t lambda, int32_t *nb_strength_bits, int32_t *y_strength,
                              int32_t *uv_strength, int32_t *selected) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_CDEF_FINISH) || sb_count < 0) return 0;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
+    const long long t0 = svt_hip_hooks_now_ns();
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
     if (!hip) return 0;
     const size_t mb = (size_t)sb_count * 64 * sizeof(uint64_t);
     void *d_m0 = NULL, *d_m1 = NULL, *d_state = NULL, *d_out = NULL, *d_sel = NULL;
     SvtHipCdefFinish fin;
-    int rc = svt_hip_malloc(hip, &d_m0, mb + 8);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_m1, mb + 8);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_out, sizeof(fin));
-    if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_sel, sizeof(int32_t) * (size_t)(sb_count + 1));
+    int rc = svt_hip_hooks_malloc(hip, &d_m0, mb + 8);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_m1, mb + 8);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_out, sizeof(fin));
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_sel, sizeof(int32_t) * (size_t)(sb_count + 1));
     if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m0, mse[0], mb);
     if (rc == SVT_HIP_OK && mb) rc = svt_hip_memcpy_h2d(hip, d_m1, mse[1], mb);
     if (rc == SVT_HIP_OK) rc = svt_hip_cdef_strength_select_dev(hip, (const uint64_t *)d_m0, (const uint64_t *)d_m1, sb_count, start_gi, end_gi, d_state, SVT_HIP_CDEF_SELECT_STATE_BYTES);
@@ -933,10 +1200,11 @@ int svt_hip_hook_cdef_finish(uint64_t (**mse)[64], int32_t sb_count, int32_t sta
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, &fin, d_out, sizeof(fin));
     if (rc == SVT_HIP_OK && fin.cdef_bits < 0) rc = SVT_HIP_ERR_RUNTIME; /* an incomplete selection (svt_hip.h: status[0]) */
     if (rc == SVT_HIP_OK && sb_count) rc = svt_hip_memcpy_d2h(hip, selected, d_sel, sizeof(int32_t) * (size_t)sb_count);
-    svt_hip_free(hip, d_m0); svt_hip_free(hip, d_m1); svt_hip_free(hip, d_state); svt_hip_free(hip, d_out); svt_hip_free(hip, d_sel);
+    svt_hip_hooks_free(hip, d_m0); svt_hip_hooks_free(hip, d_m1); svt_hip_hooks_free(hip, d_state); svt_hip_hooks_free(hip, d_out); svt_hip_hooks_free(hip, d_sel);
     if (rc != SVT_HIP_OK) SVT_LOG("CDEF strength decision on the device failed (%s): C loops\n", svt_hip_last_error(hip));
-    svt_hip_hooks_unlock();
+    svt_hip_hooks_unlock_any();
     svt_hip_hooks_count(SVT_HIP_HOOK_CDEF_FINISH, rc == SVT_HIP_OK);
+    svt_hip_hooks_time(SVT_HIP_HOOK_CDEF_FINISH, t0);
     if (rc != SVT_HIP_OK) return 0;
     *nb_strength_bits = fin.cdef_bits;
     for (int j = 0; j < fin.nb_strengths; j++) { y_strength[j] = fin.y_strength[j]; uv_strength[j] = fin.uv_strength[j]; }

@@ -10,9 +10,10 @@
  * finish_cdef_search, rest_finish_search, the FIFOs and the entropy coder are untouched.
  *
  * One SvtHipLfPicture per picture in flight keeps the planes on the device between the stages: source, reconstruction -> deblocked in
- * place (kept: CDEF input, and the stripe context rows of the restoration filters), CDEF output, restoration output.  Every hook
- * downloads its result into the reference's recon picture as well, so any subset of hooks can be active (the host state is always what
- * the C path would have produced) and a stage whose hook is off simply finds its input on the host as usual.
+ * place (kept: CDEF input, and the stripe context rows of the restoration filters), CDEF output, restoration output.  With a subset of the hooks
+ * active every hook downloads its result into the reference's recon picture as well (the host state is always what the C path would have produced,
+ * and a stage whose hook is off simply finds its input on the host as usual); with ALL of them active the picture is "deferred": it comes back
+ * once, when it leaves the filter stages, and a hook that fails on the way first brings the host up to date (svt_hip_lf_bridge.c, lf_recover).
  *
  * Compiled INTO libSvtAv1Enc (it includes the reference's headers); not part of libsvtav1_hip.so.
  */
@@ -33,6 +34,8 @@ typedef struct SvtHipLfPicture {
     void *d_recon[3], *d_cdef[3], *d_rest[3], *d_src[3];
     int   stride[3];                     /* recon / cdef / rest share one stride per plane; the planes carry a 3-sample border */
     int   src_stride[3];
+    void *src[3];                        /* the source planes the stages read: d_src (uploaded, src_stride) or the picture's resident copy in place (svt_hip_resident.h) */
+    int   src_st[3];
     /* CDEF */
     uint8_t  *d_skip8, *h_skip8;         /* [h/8][w/8] is_8x8_block_skip */
     uint64_t *d_mse, *h_mse;             /* [2][nfb][64] */

@@ -28,8 +28,12 @@ static int perturb(const char *stage) {
     return e && !strcmp(e, stage);
 }
 
+int svt_hip_device_count(int *n);
 int svt_hip_init(int device_id, SvtHipCtx **ctx) {
-    (void)device_id;
+    int n = 0;
+    (void)svt_hip_device_count(&n);   /* SVT_HIP_MOCK_DEVICES (default 1): an ordinal that names no device is refused, like the product */
+    *ctx = NULL;
+    if (device_id < 0 || device_id >= n) return SVT_HIP_ERR_NO_DEVICE;
     *ctx = (SvtHipCtx *)calloc(1, sizeof(SvtHipCtx));
     fprintf(stderr, "svt_hip MOCK (oracle/hip_mock.c): CPU test double, not the product\n");
     return *ctx ? SVT_HIP_OK : SVT_HIP_ERR_RUNTIME;
@@ -43,6 +47,14 @@ int svt_hip_free(SvtHipCtx *c, void *p) { (void)c; free(p); return SVT_HIP_OK; }
 int svt_hip_memcpy_h2d(SvtHipCtx *c, void *d, const void *h, size_t n) { (void)c; memcpy(d, h, n); return SVT_HIP_OK; }
 int svt_hip_memcpy_d2h(SvtHipCtx *c, void *h, const void *d, size_t n) { (void)c; memcpy(h, d, n); return SVT_HIP_OK; }
 int svt_hip_memcpy_d2d(SvtHipCtx *c, void *d, const void *s, size_t n) { (void)c; memmove(d, s, n); return SVT_HIP_OK; }
+int svt_hip_memcpy_h2d_async(SvtHipCtx *c, void *d, const void *h, size_t n) { return svt_hip_memcpy_h2d(c, d, h, n); }
+int svt_hip_memcpy_d2h_async(SvtHipCtx *c, void *h, const void *d, size_t n) { return svt_hip_memcpy_d2h(c, h, d, n); }
+int svt_hip_host_register(SvtHipCtx *c, void *h, size_t n) { (void)c; (void)h; (void)n; return SVT_HIP_OK; }
+int svt_hip_host_unregister(SvtHipCtx *c, void *h) { (void)c; (void)h; return SVT_HIP_OK; }
+int svt_hip_host_alloc(SvtHipCtx *c, void **h, size_t n) { (void)c; *h = malloc(n ? n : 1); return *h ? SVT_HIP_OK : SVT_HIP_ERR_RUNTIME; }
+int svt_hip_host_free(SvtHipCtx *c, void *h) { (void)c; free(h); return SVT_HIP_OK; }
+int svt_hip_device_count(int *n) { *n = getenv("SVT_HIP_MOCK_DEVICES") ? atoi(getenv("SVT_HIP_MOCK_DEVICES")) : 1; return SVT_HIP_OK; }
+int svt_hip_warmup(SvtHipCtx *c) { (void)c; return SVT_HIP_OK; }
 int svt_hip_memcpy2d_h2d(SvtHipCtx *c, void *d, size_t dpitch, const void *h, size_t hpitch, size_t wbytes, size_t rows) {
     (void)c;
     for (size_t y = 0; y < rows; y++) memcpy((uint8_t *)d + y * dpitch, (const uint8_t *)h + y * hpitch, wbytes);
@@ -53,6 +65,8 @@ int svt_hip_memcpy2d_d2h(SvtHipCtx *c, void *h, size_t hpitch, const void *d, si
     for (size_t y = 0; y < rows; y++) memcpy((uint8_t *)h + y * hpitch, (const uint8_t *)d + y * dpitch, wbytes);
     return SVT_HIP_OK;
 }
+int svt_hip_memcpy2d_h2d_async(SvtHipCtx *c, void *d, size_t dpitch, const void *h, size_t hpitch, size_t wbytes, size_t rows) { return svt_hip_memcpy2d_h2d(c, d, dpitch, h, hpitch, wbytes, rows); }
+int svt_hip_memcpy2d_d2h_async(SvtHipCtx *c, void *h, size_t hpitch, const void *d, size_t dpitch, size_t wbytes, size_t rows) { return svt_hip_memcpy2d_d2h(c, h, hpitch, d, dpitch, wbytes, rows); }
 
 /* ------------------------------------------------------------------ ME */
 int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int org_x, int org_y,

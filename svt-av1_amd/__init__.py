@@ -144,6 +144,16 @@ def lib():
     L.svt_hip_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.svt_hip_memcpy2d_h2d.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
     L.svt_hip_memcpy2d_d2h.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.svt_hip_memcpy_h2d_async.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svt_hip_memcpy_d2h_async.argtypes = [vp, vp, vp, C.c_size_t]
+    L.svt_hip_memcpy2d_h2d_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.svt_hip_memcpy2d_d2h_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.svt_hip_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.svt_hip_host_unregister.argtypes = [vp, vp]
+    L.svt_hip_host_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    L.svt_hip_host_free.argtypes = [vp, vp]
+    L.svt_hip_device_count.argtypes = [C.POINTER(i32)]
+    L.svt_hip_warmup.argtypes = [vp]
     L.svt_hip_timer_start.argtypes = [vp]
     L.svt_hip_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.svt_hip_me_search_window.argtypes = [i32] * 8

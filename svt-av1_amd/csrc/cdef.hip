@@ -585,3 +585,5 @@ extern "C" int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const vo
     if (pix_bytes == 1) return apply_t<uint8_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf, var_in);
     return apply_t<uint16_t>(st, in, out, stride, w, h, skip8, y_strength, uv_strength, damping, cs, dir_buf, var_in);
 }
+
+SVT_HIP_TU_PROBE(cdef)

@@ -206,3 +206,5 @@ extern "C" int svt_hip_launch_blend_a64(hipStream_t st, int pix_bytes, const voi
                             dst_stride, masks, blks);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(compound)

@@ -196,3 +196,5 @@ extern "C" int svt_hip_launch_block_variance(hipStream_t st, int pix_bytes, int 
     else hipLaunchKernelGGL((block_variance_kernel<uint16_t, 10>), dim3(n), dim3(64), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, d, var_out, sse_out);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(conv)

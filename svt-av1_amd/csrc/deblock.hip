@@ -281,3 +281,5 @@ extern "C" int svt_hip_launch_plane_sse(hipStream_t st, int pix_bytes, const voi
     else hipLaunchKernelGGL((plane_sse_kernel<uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, w, h, (unsigned long long*)out);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(deblock)

@@ -93,3 +93,5 @@ extern "C" int svt_hip_launch_block_sse(hipStream_t st, int pix_bytes, const voi
     else hipLaunchKernelGGL((block_sse_kernel<uint16_t>), dim3((n + 3) / 4), dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, pairs, n, (unsigned long long*)out);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(distortion)

@@ -85,3 +85,5 @@ extern "C" int svt_hip_launch_generate_padding(hipStream_t st, void* plane, int 
     else hipLaunchKernelGGL(generate_padding_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)plane, stride, w, h, pad_w, pad_h);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(format)

@@ -419,3 +419,5 @@ extern "C" int svt_hip_launch_me_fullpel(hipStream_t stream, const uint8_t* d_sr
     else         hipLaunchKernelGGL((me_fullpel_narrow_kernel<false>), grid, dim3(64), 0, stream, d_src, d_ref, stride, org_x, org_y, d_sbs, d_best_sad, d_best_mv);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(me_fullpel)

@@ -260,3 +260,5 @@ int svt_hip_launch_upsampled_pred(hipStream_t st, const uint8_t* ref, int rs, ui
     return (int)hipGetLastError();
 }
 }
+
+SVT_HIP_TU_PROBE(percall)

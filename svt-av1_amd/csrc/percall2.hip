@@ -1039,3 +1039,5 @@ extern "C" int svt_hip_launch_wiener_convolve(hipStream_t st, int pix_bytes, int
     else hipLaunchKernelGGL(wiener_convolve_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, ss, (uint16_t*)dst, ds, taps, w, h, round0, round1, bd);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(percall2)

@@ -338,3 +338,5 @@ extern "C" int svt_hip_launch_sad_loop16(hipStream_t st, const uint16_t* src, in
     hipLaunchKernelGGL(sad_loop16_lds_kernel, dim3(n), dim3(256), lds, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(pyramid)

@@ -752,3 +752,5 @@ extern "C" int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, c
     return svt_hip_launch_sgr_apply_tiles(st, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, units_x, units_y, ss_y, dbl, dbl_stride, unit_ep, unit_xqd,
                                           unit_wiener, 0, 0, (pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
 }
+
+SVT_HIP_TU_PROBE(sgr)

@@ -837,3 +837,5 @@ extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* p
     const SvtHipSgrWalkPlane P = {pairs, sd, sums, states, dplane, dstride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, xqd_out, err_out, best_ep, best_xqd, stats};
     return svt_hip_launch_sgr_walk_multi(st, bd, 1, &P);
 }
+
+SVT_HIP_TU_PROBE(sgr_walk)

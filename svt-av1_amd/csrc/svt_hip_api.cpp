@@ -174,6 +174,86 @@ int svt_hip_memcpy2d_d2h(SvtHipCtx* c, void* h, size_t hpitch, const void* d, si
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SVT_HIP_OK;
 }
+int svt_hip_memcpy2d_h2d_async(SvtHipCtx* c, void* d, size_t dpitch, const void* h, size_t hpitch, size_t wbytes, size_t rows) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
+    if (!wbytes || !rows) return SVT_HIP_OK;
+    HIPCHK(c, hipMemcpy2DAsync(d, dpitch, h, hpitch, wbytes, rows, hipMemcpyHostToDevice, c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy2d_d2h_async(SvtHipCtx* c, void* h, size_t hpitch, const void* d, size_t dpitch, size_t wbytes, size_t rows) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d || !h || dpitch < wbytes || hpitch < wbytes) return SVT_HIP_ERR_BAD_ARG;
+    if (!wbytes || !rows) return SVT_HIP_OK;
+    HIPCHK(c, hipMemcpy2DAsync(h, hpitch, d, dpitch, wbytes, rows, hipMemcpyDeviceToHost, c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy_h2d_async(SvtHipCtx* c, void* d, const void* h, size_t bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || (bytes && (!d || !h))) return SVT_HIP_ERR_BAD_ARG;
+    if (!bytes) return SVT_HIP_OK;
+    HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_memcpy_d2h_async(SvtHipCtx* c, void* h, const void* d, size_t bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || (bytes && (!d || !h))) return SVT_HIP_ERR_BAD_ARG;
+    if (!bytes) return SVT_HIP_OK;
+    HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    return SVT_HIP_OK;
+}
+int svt_hip_device_count(int* count) {
+    if (!count) return SVT_HIP_ERR_BAD_ARG;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) return SVT_HIP_ERR_NO_DEVICE;
+    *count = n;
+    return SVT_HIP_OK;
+}
+// Page-locks a buffer of the caller in place (the reference's picture buffers are allocated once per encoder instance): copies to and from it are then direct
+// DMA at the link's rate instead of going through the runtime's pageable staging.
+int svt_hip_host_register(SvtHipCtx* c, void* host, size_t bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || !host || !bytes) return SVT_HIP_ERR_BAD_ARG;
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return SVT_HIP_OK; }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, e, "hipHostRegister"); }
+    return SVT_HIP_OK;
+}
+int svt_hip_host_unregister(SvtHipCtx* c, void* host) {
+    SVT_HIP_ENTER(c);
+    if (!c || !host) return SVT_HIP_ERR_BAD_ARG;
+    const hipError_t e = hipHostUnregister(host);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, e, "hipHostUnregister"); }
+    return SVT_HIP_OK;
+}
+int svt_hip_host_alloc(SvtHipCtx* c, void** host, size_t bytes) {
+    SVT_HIP_ENTER(c);
+    if (!c || !host) return SVT_HIP_ERR_BAD_ARG;
+    HIPCHK(c, hipHostMalloc(host, bytes ? bytes : 4, hipHostMallocDefault));
+    return SVT_HIP_OK;
+}
+int svt_hip_host_free(SvtHipCtx* c, void* host) {
+    SVT_HIP_ENTER(c);
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    if (host) HIPCHK(c, hipHostFree(host));
+    return SVT_HIP_OK;
+}
+#define SVT_HIP_TUS(X) X(cdef) X(compound) X(conv) X(deblock) X(distortion) X(format) X(me_fullpel) X(percall) X(percall2) X(pyramid) X(sgr) X(sgr_walk) X(tf_subpel) \
+    X(tfilter) X(txfm2d) X(warp) X(wiener)
+#define X(n) int svt_hip_tu_probe_##n();
+SVT_HIP_TUS(X)
+#undef X
+int svt_hip_warmup(SvtHipCtx* c) {
+    SVT_HIP_ENTER(c);
+    if (!c) return SVT_HIP_ERR_BAD_ARG;
+    int bad = 0;
+#define X(n) bad |= svt_hip_tu_probe_##n();
+    SVT_HIP_TUS(X)
+#undef X
+    if (bad) { c->err = "svt_hip_warmup: a translation unit's code object did not load"; (void)hipGetLastError(); return SVT_HIP_ERR_RUNTIME; }
+    return SVT_HIP_OK;
+}
 int svt_hip_timer_start(SvtHipCtx* c) {
     SVT_HIP_ENTER(c);
     if (!c) return SVT_HIP_ERR_BAD_ARG;

@@ -5,6 +5,16 @@
 #include <stdint.h>
 #include "../../include/svt_hip.h"
 
+
+// One empty kernel per translation unit: svt_hip_warmup() asks for its attributes, which makes the runtime load that unit's code object for the current device
+// now (HIP loads a unit's code object at the first launch of any of its kernels — inside an encoder that is the first picture's clock).
+#define SVT_HIP_TU_PROBE(name)                                                                                                    \
+    namespace { __global__ void tu_probe_kernel_##name() {} }                                                                      \
+    extern "C" int svt_hip_tu_probe_##name() {                                                                                     \
+        hipFuncAttributes a;                                                                                                       \
+        return hipFuncGetAttributes(&a, (const void*)tu_probe_kernel_##name) == hipSuccess ? 0 : 3;                                \
+    }
+
 extern "C" {
 void* svt_hip_ctx_stream(SvtHipCtx* c);
 void  svt_hip_ctx_clear_error(SvtHipCtx* c);   /* rtcd_hip.cpp: a wrapper's delegation is a device failure iff an entry point left an error string */

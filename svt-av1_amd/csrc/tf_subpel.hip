@@ -237,3 +237,5 @@ extern "C" int svt_hip_launch_tf_subpel(hipStream_t st, int pix_bytes, int bd, c
     else hipLaunchKernelGGL((tf_subpel_kernel<uint16_t, 10>), grid, block, 0, st, a);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(tf_subpel)

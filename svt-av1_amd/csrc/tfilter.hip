@@ -361,3 +361,5 @@ extern "C" int svt_hip_launch_tf_noise(hipStream_t st, const void* src, int pix_
     else hipLaunchKernelGGL(tf_noise_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)src, width, height, stride, bd - 8, (unsigned long long*)out);
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(tfilter)

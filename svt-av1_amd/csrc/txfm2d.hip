@@ -539,3 +539,5 @@ extern "C" int svt_hip_launch_inv_txfm_add_multi(hipStream_t st, int pix_bytes, 
     }
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(txfm2d)

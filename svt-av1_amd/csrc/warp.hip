@@ -118,3 +118,5 @@ extern "C" int svt_hip_launch_warp_compound(hipStream_t st, int pix_bytes, int b
 #undef LAUNCH
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(warp)

@@ -343,3 +343,5 @@ extern "C" int svt_hip_launch_wiener_stats8(hipStream_t st, int win, const uint8
 #undef LAUNCH
     return (int)hipGetLastError();
 }
+
+SVT_HIP_TU_PROBE(wiener)

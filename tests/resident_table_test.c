@@ -31,6 +31,11 @@ int svt_hip_memcpy_h2d(SvtHipCtx *c, void *d, const void *h, size_t n) {
     return SVT_HIP_OK;
 }
 
+static long g_pins;
+int svt_hip_host_register(SvtHipCtx *c, void *h, size_t n) { (void)c; (void)h; (void)n; pthread_mutex_lock(&g_stub_mu); g_pins++; pthread_mutex_unlock(&g_stub_mu); return SVT_HIP_OK; }
+int svt_hip_host_unregister(SvtHipCtx *c, void *h) { (void)c; (void)h; pthread_mutex_lock(&g_stub_mu); g_pins--; pthread_mutex_unlock(&g_stub_mu); return SVT_HIP_OK; }
+static size_t pow2_block(size_t n) { size_t b = 256; while (b < n) b <<= 1; return b; }
+
 #define CHECK(x) do { if (!(x)) { fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #x); exit(1); } } while (0)
 static SvtHipCtx *const HIP = (SvtHipCtx *)(uintptr_t)0x1000;   /* opaque to the table */
 
@@ -130,6 +135,23 @@ int main(void) {
     a[0] = 200; svt_hip_resident_note(a, N);
     CHECK(svt_hip_resident_acquire(HIP, a, N) == ds && ds[0] == 1);
     svt_hip_resident_release(a);
+
+    /* the budget counts what the allocator hands out (power-of-two blocks here: a plane of N + 256 bytes occupies 2 N), and host ranges are page-locked once */
+    svt_hip_resident_release_all(HIP);
+    svt_hip_resident_configure(1, (size_t)4 * N, 0, NULL, NULL);
+    svt_hip_resident_configure_blocks(pow2_block, 1);
+    memset(a, 1, N); memset(b, 2, N); memset(c, 3, 2 * N);
+    svt_hip_resident_note(a, N); svt_hip_resident_note(b, N); svt_hip_resident_note(c, N);
+    CHECK(svt_hip_resident_acquire(HIP, a, N) && svt_hip_resident_acquire(HIP, b, N) && stats().resident_mb == 4.0 * N / 1048576.0 && g_pins == 2);
+    CHECK(!svt_hip_resident_acquire(HIP, c, N));   /* a third 2 N block does not fit 4 N */
+    svt_hip_resident_release(a);
+    svt_hip_resident_note(a, N);
+    CHECK(svt_hip_resident_acquire(HIP, a, N) && g_pins == 2);   /* uploaded again, page-locked once */
+    svt_hip_resident_release(a); svt_hip_resident_release(b);
+    svt_hip_resident_unpin_all(HIP);
+    CHECK(g_pins == 0);
+    svt_hip_resident_release_all(HIP);
+    svt_hip_resident_configure_blocks(NULL, 0);
 
     /* eight threads over four planes with a budget of two: every acquired copy is complete and the right one; nothing is left in use */
     svt_hip_resident_release_all(HIP);

@@ -427,6 +427,108 @@ def test_resident_planes_announcements_matter(workdir):
     assert bad["ivf"] != ref["ivf"] or bad["recon"] != ref["recon"], "stale resident planes went unnoticed"
 
 
+# ---- deferred pictures (integration/svt_hip_lf_bridge.c): with every loop-filter hook on, the reconstructed picture stays on the device from deblocking to the restoration
+# filter and comes back once; the patched process loops skip the host work only the C restoration path reads.  A hook that fails on the way must first bring the host up
+# to date (lf_recover), so that the C code that takes over produces the reference's output: SVT_HIP_LF_FAULT makes one hook report a failure on every picture.
+LF_FAULTS = ["cdef_search", "cdef_apply", "sgr_search", "wiener_search", "rest_apply"]
+
+
+def _lf_pictures(log):
+    m = re.findall(r"svt_hip_lf_pictures deferred=(\d+) recovered=(\d+) source_planes_resident=(\d+) planes_up=(\d+) up_mb=[0-9.]+ planes_down=(\d+)", log)
+    assert m, "no svt_hip_lf_pictures line in the report\n" + log[-1500:]
+    return dict(zip(("deferred", "recovered", "resident", "up", "down"), map(int, m[-1])))
+
+
+def _encode_like(case, spec, workdir, env, tag):
+    w, h, n, bd, preset, q, _ = spec
+    clip, ref = _reference(case, spec, workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.{tag}"), env_extra=env)
+    assert got["ivf"] == ref["ivf"], f"{case} {tag}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
+    assert got["recon"] == ref["recon"], f"{case} {tag}: reconstruction differs from the reference encoder"
+    return got
+
+
+def _check_fault_recovery(case, spec, stage, workdir, env, tag):
+    got = _encode_like(case, spec, workdir, dict(env, SVT_HIP_HOOKS="all", SVT_HIP_LF_FAULT=stage), f"{tag}_fault_{stage}")
+    lf = _lf_pictures(got["log"])
+    assert lf["deferred"] == spec[2] and lf["recovered"] == spec[2], lf   # every picture was deferred, every one was brought back for the C code
+    assert got["hooks"][stage][1] > 0, got["hooks"]
+    return got
+
+
+@pytest.mark.parametrize("stage", LF_FAULTS)
+def test_deferred_picture_recovers_from_a_failed_hook_on_cpu_test_double(stage, workdir):
+    _check_fault_recovery("cif_8bit_m6", CASES["cif_8bit_m6"], stage, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR}, "mock")
+
+
+@pytest.mark.parametrize("stage", ["cdef_apply", "rest_apply"])
+def test_deferred_10bit_picture_recovers_from_a_failed_hook_on_cpu_test_double(stage, workdir):
+    _check_fault_recovery("cif_10bit_m6", CASES["cif_10bit_m6"], stage, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR}, "mock")
+
+
+def _padded_spec():
+    return (130, 66, 5, 8, 6, 38, ALL - {"tf_me", "tf_subpel"})
+
+
+def _padded_reference(workdir):
+    """130 x 66 is coded 136 x 72: the border svt_extend_frame gives the CROPPED frame falls inside the coded picture -- the final download has to deliver it"""
+    name = "padded_defer"
+    if name not in _ref_cache:
+        w, h, n, bd, preset, q, _ = _padded_spec()
+        clip = os.path.join(workdir, name + ".src.yuv")
+        E.make_clip(clip, w, h, n, seed=11, bd=bd)
+        _ref_cache[name] = (clip, E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".ref")))
+    return name
+
+
+@pytest.mark.parametrize("stage", [None, "sgr_search", "rest_apply"])
+def test_deferred_padded_picture_on_cpu_test_double(stage, workdir):
+    name = _padded_reference(workdir)
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}
+    if stage:
+        _check_fault_recovery(name, _padded_spec(), stage, workdir, env, "mock")
+    else:
+        assert _lf_pictures(_encode_like(name, _padded_spec(), workdir, env, "mock_defer")["log"])["deferred"] == 5
+
+
+def test_deferred_pictures_cross_the_bus_once_on_cpu_test_double(workdir):
+    """the copies of the loop-filter bridge, counted: deferred = reconstruction up once and down once (+ the source up once; with SVT_HIP_RESIDENT the source is
+    the copy the temporal filter and the motion search already use); not deferred (SVT_HIP_DEFER=0) = every stage brings its result back"""
+    case = "cif_8bit_m4"   # preset 4: the filter-level search runs too (it shares its upload with the deblocking hook)
+    spec = CASES[case]
+    n = spec[2]
+    mock = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}
+    a = _lf_pictures(_encode_like(case, spec, workdir, mock, "mock_defer")["log"])
+    assert (a["deferred"], a["recovered"], a["up"], a["down"]) == (n, 0, 6 * n, 3 * n), a
+    b = _lf_pictures(_encode_like(case, spec, workdir, dict(mock, SVT_HIP_RESIDENT="1"), "mock_defer_res")["log"])
+    assert (b["deferred"], b["resident"], b["up"], b["down"]) == (n, 3 * n, 3 * n, 3 * n), b
+    c = _lf_pictures(_encode_like(case, spec, workdir, dict(mock, SVT_HIP_DEFER="0"), "mock_nodefer")["log"])
+    assert c["deferred"] == 0 and c["down"] > 3 * n, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["cdef_search", "sgr_search", "rest_apply"])
+def test_deferred_picture_recovers_from_a_failed_hook_on_gpu(stage, workdir):
+    got = _check_fault_recovery("cif_8bit_m6", CASES["cif_8bit_m6"], stage, workdir, {}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
+
+
+@pytest.mark.gpu
+def test_deferred_padded_picture_on_gpu(workdir):
+    name = _padded_reference(workdir)
+    got = _encode_like(name, _padded_spec(), workdir, {"SVT_HIP_HOOKS": "all"}, "hip_defer")
+    assert "svt_hip MOCK" not in got["log"] and _lf_pictures(got["log"])["deferred"] == 5
+    got = _check_fault_recovery(name, _padded_spec(), "rest_apply", workdir, {}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
+
+
+@pytest.mark.gpu
+def test_not_deferred_pictures_on_gpu(workdir):
+    """SVT_HIP_DEFER=0: every stage downloads its result (the round-3 behaviour, and what a subset of the hooks still does)"""
+    got = _encode_like("cif_8bit_m6", CASES["cif_8bit_m6"], workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_DEFER": "0"}, "hip_nodefer")
+    assert "svt_hip MOCK" not in got["log"] and _lf_pictures(got["log"])["deferred"] == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6", "cif_10bit_m6", "720p_10bit_m5"])
 def test_resident_source_planes_on_gpu(case, workdir):

@@ -39,7 +39,8 @@ PY
     [ "$app" != "$base" ] && [ -f $OUT/$app.ivf ] && { cmp -s $OUT/$base.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to $base" || echo "${W}x${H} $app BITSTREAM DIFFERS from $base"; } | tee -a $OUT/wall.txt
   done
   for app in hip_res hip_simd_res; do
-    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context\|svt_hip_lf_pictures\|svt_hip_warmup\|svt_hip_alloc_cache" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook_time" $OUT/${app}_$W.log | awk -v a=$app '{printf "%s %s %s %s | ", a, $2, $3, $4} END {print ""}' | tee -a $OUT/wall.txt
   done
   for app in hip hip_simd hip_res hip_simd_res; do
     [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook" $OUT/${app}_$W.log | awk -v a=$app '{h+=substr($3,9); f+=substr($4,10)} END {print a, "hook launches:", h, "fallbacks:", f}' | tee -a $OUT/wall.txt
