@@ -454,6 +454,9 @@ def main():
     step_fns = make_steps(nF)
     elapsed = shard.max_over_ranks(timed(step_fns, args.steps, args.warmup, True), dist if world > 1 else None, dev)
 
+    # what the TIMED replays left in frame 0's buffers (device -> host copies only; compared with the gated pass further down)
+    timed_final = final_outputs(pipes[0]) if rank == 0 else None
+
     # ---- the same step at other batch sizes (rank 0 reports; a few dozen steps each)
     sweep = {str(nF): {"ms_per_step": elapsed / args.steps * 1e3, "sb_per_s": nF * n_sb * args.steps / elapsed}}
     if not args.no_sweep:
@@ -649,8 +652,21 @@ def main():
             if flavour == "c":
                 parity_ok = bool(parity_ok is not False and same)
 
+    # ---- THE PARITY GATE: frame 0's chain once more, stage by stage, every stage's output against the reference's kernels run on the device's own
+    #      input of that stage (tools/parity_gate.py); the timed replays' final buffers must equal this pass's.  No number without it.
+    gate = None
+    full_chain = [k for k, _ in stages] == ["pyr", "hme", "me", "subpel", "enc_txfm", "dlf", "cdef_search", "cdef_pick", "cdef_apply", "sgr_units", "sgr_apply"]
+    if full_chain and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")):
+        gate = run_parity_gate(E, P0, F0, stages, select_form, timed_final, orc, torch)
+        parity_detail.update(gate["stages"])
+        parity_detail["timed_step_outputs_equal_gated_pass"] = gate["timed_equal"]
+        if gate["differences"]: parity_detail["gate_differences"] = gate["differences"]
+        parity_ok = bool(parity_ok is not False and all(gate["stages"].values()) and gate["timed_equal"])
+    else:
+        parity_detail["gate"] = "not run: " + ("a subset of the stages was selected" if not full_chain else "oracle/_ref/libsvtav1_ref_simd.so is not built")
+
     out = {
-        "metric": METRIC, "value": nF * n_sb * args.steps * world / elapsed, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC, "value": (nF * n_sb * args.steps * world / elapsed) if parity_ok is not False else None, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame, "
@@ -676,6 +692,68 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if parity_ok is False:
+        raise SystemExit("bench.py: the parity gate failed - the timing is not a result (parity_detail says which stage)")
+
+
+def _interior(P, bufs, p):
+    ph, pw = P.F.cur[p].shape
+    return bufs[p][EXT:EXT + ph, EXT:EXT + pw].cpu().numpy().copy()
+
+
+def final_outputs(P):
+    """the buffers a finished step leaves behind for one frame (host copies)"""
+    return {"sad": P.d_sad.cpu().numpy().copy(), "mv": P.d_mv.cpu().numpy().copy(), "mse": P.d_mse.cpu().numpy().copy(), "sel": P.d_sel_gi.cpu().numpy().copy(),
+            "ubest": [t.cpu().numpy().copy() for t in P.d_ubest], "ubx": [t.cpu().numpy().copy() for t in P.d_ubx], "rest": [_interior(P, P.b_rest, p) for p in range(3)],
+            "cdef_border": [t.cpu().numpy().copy() for t in P.b_cdef]}
+
+
+def run_parity_gate(E, P, F, stages, select_form, timed_final, orc, torch):
+    """Frame 0's chain once more, eagerly, one stage at a time; after every stage its outputs come to the host.  tools/parity_gate.py then recomputes every stage with
+    the reference's kernels from the DEVICE's input of that stage and compares.  -> {"stages": {name: bool}, "timed_equal": bool, "differences": {...}}"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import parity_gate as G
+    refb = G.setup_refb(C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")))
+    select_form(1)
+    S = {"sbs": P.sbs, "frac": P.d_frac.cpu().numpy()}
+    for k, _ in stages:
+        P.stage_fns[k]()
+        torch.cuda.synchronize()
+        if k == "pyr":
+            S.update(cur_2=P.d_cur_q.cpu().numpy(), cur_4=P.d_cur_s.cpu().numpy(), ref_2=P.d_ref_q.cpu().numpy(), ref_4=P.d_ref_s.cpu().numpy(), ymean=P.d_ymean.cpu().numpy(),
+                     yvar=P.d_yvar.cpu().numpy().view(np.uint16))
+        elif k == "hme":
+            for lvl, j in enumerate(P.hme):
+                S[f"hme_sad_{lvl}"] = j["sad"].cpu().numpy().view(np.uint32); S[f"hme_xy_{lvl}"] = j["xy"].cpu().numpy()
+        elif k == "me":
+            S.update(sad=P.d_sad.cpu().numpy().view(np.uint32), mv=P.d_mv.cpu().numpy().view(np.uint32))
+        elif k == "subpel":
+            S.update(conv_jobs=P.d_cb.cpu().numpy(), subpel=P.d_subpel.cpu().numpy())
+        elif k == "enc_txfm":
+            for i, j in enumerate(P.tx_jobs):
+                S[f"q_{i}"] = j["q"].cpu().numpy().reshape(j["n"], -1); S[f"eob_{i}"] = j["eob"].cpu().numpy().view(np.uint16)
+            for p in range(3): S[f"recon_{p}"] = _interior(P, P.b_recon, p)
+        elif k == "dlf":
+            for p in range(3): S[f"dbl_{p}"] = _interior(P, P.b_recon, p)
+        elif k == "cdef_search":
+            S["mse"] = P.d_mse.cpu().numpy().view(np.uint64)
+        elif k == "cdef_pick":
+            fin = P.d_fin.cpu().numpy()
+            S.update(cdef_fin=np.concatenate([fin[:4].view(np.int32), fin[8:40].view(np.int32), fin[40:72].view(np.int32)]), cdef_sel=P.d_sel_gi.cpu().numpy(),
+                     cdef_y=P.d_cy.cpu().numpy(), cdef_uv=P.d_cuv.cpu().numpy())
+        elif k == "cdef_apply":
+            for p in range(3): S[f"cdef_{p}"] = _interior(P, P.b_cdef, p)
+        elif k == "sgr_units":
+            for p in range(3):
+                S[f"unit_ep_{p}"] = P.d_ubest[p].cpu().numpy(); S[f"unit_xqd_{p}"] = P.d_ubx[p].cpu().numpy()
+        elif k == "sgr_apply":
+            for p in range(3): S[f"rest_{p}"] = _interior(P, P.b_rest, p)
+    threads = max(1, min(len(os.sched_getaffinity(0)), 128))
+    ok, bad = G.check_chain(F, S, refb, orc, E.pkg, E.tc, E.workload, threads, CDEF_LAMBDA, unit_size=P.US[0])
+    now = final_outputs(P)
+    same = all(np.array_equal(now[k], timed_final[k]) for k in ("sad", "mv", "mse", "sel")) and all(
+        np.array_equal(a, b) for k in ("ubest", "ubx", "rest", "cdef_border") for a, b in zip(now[k], timed_final[k]))
+    return {"stages": {"gate_" + k: v for k, v in ok.items()}, "timed_equal": bool(same), "differences": bad}
 
 
 def spawn_ranks(n):

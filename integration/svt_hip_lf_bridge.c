@@ -618,8 +618,7 @@ static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
     }
     const void *in[3]; void *out[3];
     for (int pl = 0; pl < 3; pl++) {
-        in[pl] = plane_origin(p, p->d_recon[pl], pl); out[pl] = plane_origin(p, p->d_cdef[pl], pl);
-        HIP_TRY(svt_hip_memcpy_d2d(hip, p->d_cdef[pl], p->d_recon[pl], plane_bytes(p, pl)));    /* unfiltered blocks keep the deblocked samples */
+        in[pl] = plane_origin(p, p->d_recon[pl], pl); out[pl] = plane_origin(p, p->d_cdef[pl], pl);   /* the apply kernel writes every sample of the picture (unfiltered blocks passed through) */
     }
     /* direction / variance of the search are reused when it ran here (same pre-CDEF picture) */
     HIP_TRY(svt_hip_cdef_apply_frame_dev(hip, p->pix_bytes, in, out, p->stride, p->w, p->h, p->d_skip8, p->d_y_strength, p->d_uv_strength,

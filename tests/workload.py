@@ -35,6 +35,12 @@ class Frame:
         self.n_sb = self.sb_cols * self.sb_rows
         # ---- transform tiling: one square size per SB (luma log2 2..6, chroma one smaller, min 4x4)
         self.sb_tx = rng.integers(2, 7, self.n_sb)
+        # a superblock the picture cuts (4K: the last row is 48 rows high, 1080p: 56) gets the largest size that still tiles its extent, so that EVERY sample of the
+        # picture is coded: a step then rewrites the whole reconstruction and is idempotent (samples no block covered used to keep the previous step's deblocked values)
+        for sb in range(self.n_sb):
+            ew, eh = min(64, width - (sb % self.sb_cols) * 64), min(64, height - (sb // self.sb_cols) * 64)
+            while (ew | eh) & ((1 << int(self.sb_tx[sb])) - 1):
+                self.sb_tx[sb] -= 1
         self.sb_skip = rng.random(self.n_sb) < 0.0
         self.descs = {}  # (plane_kind, tx_size) -> uint32 descriptor array ; plane_kind 0 luma, 1 chroma (U and V share it)
         lists = {}

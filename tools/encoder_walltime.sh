@@ -43,7 +43,7 @@ PY
     [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook_time" $OUT/${app}_$W.log | awk -v a=$app '{printf "%s %s %s %s | ", a, $2, $3, $4} END {print ""}' | tee -a $OUT/wall.txt
   done
   for app in hip hip_simd hip_res hip_simd_res; do
-    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook" $OUT/${app}_$W.log | awk -v a=$app '{h+=substr($3,9); f+=substr($4,10)} END {print a, "hook launches:", h, "fallbacks:", f}' | tee -a $OUT/wall.txt
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook " $OUT/${app}_$W.log | awk -v a=$app '{h+=substr($3,9); f+=substr($4,10)} END {print a, "hook launches:", h, "fallbacks:", f}' | tee -a $OUT/wall.txt
   done
   rm -f $OUT/clip.yuv $OUT/*.ivf
 done
