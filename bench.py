@@ -611,6 +611,20 @@ def main():
                 rng_out.append(row)
             walk_stats["difference_plane_ranges"] = rng_out
 
+    gate_detail = {}
+    # ---- THE PARITY GATE (SURVEY 8(d)): frame 0's chain once more, stage by stage, every stage's output against the reference's kernels run on the device's own
+    #      input of that stage (tools/parity_gate.py); the timed replays' final buffers must equal this pass's.  No number without it.
+    gate = None
+    full_chain = [k for k, _ in stages] == ["pyr", "hme", "me", "subpel", "enc_txfm", "dlf", "cdef_search", "cdef_pick", "cdef_apply", "sgr_units", "sgr_apply"]
+    if full_chain and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")):
+        gate = run_parity_gate(E, P0, F0, stages, select_form, timed_final, orc, torch)
+        gate_detail.update(gate["stages"])
+        gate_detail["timed_step_outputs_equal_gated_pass"] = gate["timed_equal"]
+        if gate["differences"]: gate_detail["gate_differences"] = gate["differences"]
+        parity_ok = bool(parity_ok is not False and all(gate["stages"].values()) and gate["timed_equal"])
+    else:
+        gate_detail["gate"] = "not run: " + ("a subset of the stages was selected" if not full_chain else "oracle/_ref/libsvtav1_ref_simd.so is not built")
+
     # ---- CPU baseline: the reference's own kernels over the same job lists (or the oracle port), all hardware threads and one thread
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -628,6 +642,7 @@ def main():
     # the strength decision of frame 0 against the reference's (svt_search_one_dual x 75 + the RDCOST choice) on the same distortion table: the C functions decide
     # parity ("bit-exact vs C ref"); the dispatched SIMD kernels are compared as well and reported
     parity_detail = {"me_85pu_vs_reference": me_ok, "sgr_walks_unfinished": None if walk_stats is None else walk_stats["unfinished"]}
+    parity_detail.update(gate_detail)
     if world == 1 and any(k == "cdef_pick" for k, _ in stages):
         m = np.ascontiguousarray(P0.d_mse.cpu().numpy().view(np.uint64)).reshape(2, n_sb, 64)
         g_fin = P0.d_fin.cpu().numpy(); g_sel = P0.d_sel_gi.cpu().numpy()
@@ -651,19 +666,6 @@ def main():
                                                                     "per_block_differences": int(np.count_nonzero(g_sel != r_sel))}
             if flavour == "c":
                 parity_ok = bool(parity_ok is not False and same)
-
-    # ---- THE PARITY GATE (SURVEY 8(d)): frame 0's chain once more, stage by stage, every stage's output against the reference's kernels run on the device's own
-    #      input of that stage (tools/parity_gate.py); the timed replays' final buffers must equal this pass's.  No number without it.
-    gate = None
-    full_chain = [k for k, _ in stages] == ["pyr", "hme", "me", "subpel", "enc_txfm", "dlf", "cdef_search", "cdef_pick", "cdef_apply", "sgr_units", "sgr_apply"]
-    if full_chain and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")):
-        gate = run_parity_gate(E, P0, F0, stages, select_form, timed_final, orc, torch)
-        parity_detail.update(gate["stages"])
-        parity_detail["timed_step_outputs_equal_gated_pass"] = gate["timed_equal"]
-        if gate["differences"]: parity_detail["gate_differences"] = gate["differences"]
-        parity_ok = bool(parity_ok is not False and all(gate["stages"].values()) and gate["timed_equal"])
-    else:
-        parity_detail["gate"] = "not run: " + ("a subset of the stages was selected" if not full_chain else "oracle/_ref/libsvtav1_ref_simd.so is not built")
 
     out = {
         "metric": METRIC, "value": (nF * n_sb * args.steps * world / elapsed) if parity_ok is not False else None, "unit": "SB/s", "n_gpus": world, "steps": args.steps,
@@ -1080,7 +1082,7 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
             for i in range(nb_):
                 u0, u1 = i * uh // nb_, (i + 1) * uh // nb_
                 r0, r1 = max(4 * u0 - 8, 0), min(4 * u1 + 8, F.ref[p].shape[0])
-                img = np.ascontiguousarray(F.ref[p][r0:r1]); keep.append(img)
+                img = F.ref[p][r0:r1].copy(); keep.append(img)   # a private copy (ascontiguousarray of a row band is a VIEW: the filter would run in place on the frame the parity gate reads)
                 slots += [img.ctypes.data + (4 * u0 - r0) * img.shape[1], img.shape[1], np.ascontiguousarray(ev[u0:u1]), np.ascontiguousarray(eh[u0:u1]), uw, u1 - u0] + [0] * 10
             t += run(4, slots, nb_, 1, reps=1, name="deblock", one_thread_items=max(1, nb_ // 8))
         sec["deblock"] = t / n_sb

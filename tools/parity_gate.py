@@ -188,9 +188,18 @@ def check_chain(F, S, refb, orc, pkg, tc, workload, threads, cdef_lambda, stages
     ok, bad = {}, {}
     for stage in stages:
         exp = expected(stage, F, S, refb, orc, pkg, tc, workload, threads, cdef_lambda, unit_size)
-        diff = [k for k, v in exp.items() if k not in S or S[k].shape != v.shape or not np.array_equal(np.asarray(S[k]).view(v.dtype) if S[k].dtype.itemsize == v.dtype.itemsize else S[k], v)]
+        diff = []
+        for k, v in exp.items():
+            g = S.get(k)
+            if g is None or g.shape != v.shape:
+                diff.append(f"{k}: shape {None if g is None else g.shape} != {v.shape}")
+                continue
+            g = np.asarray(g).view(v.dtype) if g.dtype.itemsize == v.dtype.itemsize else np.asarray(g)
+            if not np.array_equal(g, v):
+                w = np.argwhere(g != v)
+                diff.append(f"{k}: {len(w)} of {v.size} differ, first at {w[0].tolist()}: device {g[tuple(w[0])]} reference {v[tuple(w[0])]}")
         ok[stage] = not diff
-        if diff: bad[stage] = diff[:6]
+        if diff: bad[stage] = diff[:24]
     return ok, bad
 
 
