@@ -77,8 +77,12 @@ class Pipeline:
         self.xs = [((p.shape[1] + 2 * EXT + 63) // 64) * 64 for p in F.cur]
         mk = lambda: [torch.zeros((p.shape[0] + 2 * EXT, self.xs[i]), dtype=torch.uint8, device=dev) for i, p in enumerate(F.cur)]
         self.b_recon, self.b_cdef, self.b_rest = mk(), mk(), mk()
+        # deblocking: one out-of-place launch (both directions, three planes) into b_dbl; SVT_BENCH_DLF=twopass keeps the two in-place launches (A/B)
+        self.dlf_fused = os.environ.get("SVT_BENCH_DLF", "fused") != "twopass"
+        self.b_dbl = mk() if self.dlf_fused else self.b_recon
         org = lambda b, i: b[i].data_ptr() + EXT * self.xs[i] + EXT
         self.p_recon = [org(self.b_recon, i) for i in range(3)]
+        self.p_dbl = [org(self.b_dbl, i) for i in range(3)]
         self.p_cdef = [org(self.b_cdef, i) for i in range(3)]
         self.p_rest = [org(self.b_rest, i) for i in range(3)]
         self.tx_jobs, self.keep = [], []
@@ -176,14 +180,20 @@ class Pipeline:
     def run_inv(self):
         self.chk(self.E.L.svt_hip_inv_txfm_add_multi_dev(self.E.ctx.h, 1, 8, self.IJ, len(self.tx_jobs)), "inv")
 
-    def run_dlf(self):   # all three planes: one launch per direction
+    def run_dlf(self):   # all three planes, both directions: one launch (out of place), or one launch per direction (in place)
         e = self.d_edges
+        if self.dlf_fused:
+            F = self.F
+            self.chk(self.E.L.svt_hip_deblock_frame_fused_dev(self.E.ctx.h, P3(*self.p_recon), P3(*self.p_dbl), 1, I3(*self.xs), 8, I3(*[p.shape[1] for p in F.cur]),
+                                                              I3(*[p.shape[0] for p in F.cur]), P3(*[e[p][0].data_ptr() for p in range(3)]),
+                                                              P3(*[e[p][1].data_ptr() for p in range(3)]), I3(*[e[p][2] for p in range(3)]), I3(*[e[p][3] for p in range(3)]), 0), "dlf fused")
+            return
         self.chk(self.E.L.svt_hip_deblock_frame_dev(self.E.ctx.h, P3(*self.p_recon), 1, I3(*self.xs), 8, P3(*[e[p][0].data_ptr() for p in range(3)]),
                                                     P3(*[e[p][1].data_ptr() for p in range(3)]), I3(*[e[p][2] for p in range(3)]), I3(*[e[p][3] for p in range(3)]), 0), "dlf")
 
     def run_cdef_search(self):
         F = self.F
-        self.chk(self.E.L.svt_hip_cdef_search_frame_dev(self.E.ctx.h, 1, P3(*self.p_recon), I3(*self.xs), P3(*[p.data_ptr() for p in self.d_cur]), I3(*self.strides), F.w, F.h,
+        self.chk(self.E.L.svt_hip_cdef_search_frame_dev(self.E.ctx.h, 1, P3(*self.p_dbl), I3(*self.xs), P3(*[p.data_ptr() for p in self.d_cur]), I3(*self.strides), F.w, F.h,
                                                         self.d_skip8.data_ptr(), F.cdef_damping, 8, self.d_mse.data_ptr(), self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef search")
 
     def run_cdef_pick(self):
@@ -212,7 +222,7 @@ class Pipeline:
 
     def run_cdef_apply(self):
         F, L, h = self.F, self.E.L, self.E.ctx.h
-        self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_recon), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
+        self.chk(L.svt_hip_cdef_apply_frame_dev(h, 1, P3(*self.p_dbl), P3(*self.p_cdef), I3(*self.xs), F.w, F.h, self.d_skip8.data_ptr(), self.d_cy.data_ptr(),
                                                 self.d_cuv.data_ptr(), F.cdef_damping, 8, self.d_dir.data_ptr(), self.d_var.data_ptr()), "cdef apply")
 
     def run_pyramids(self):
@@ -247,7 +257,7 @@ class Pipeline:
         L, h, F = self.E.L, self.E.ctx.h, self.F
         for p in range(3):
             ph, pw = F.cur[p].shape
-            self.chk(L.svt_hip_sgr_apply_plane_dev(h, 1, 8, self.p_cdef[p], self.xs[p], self.p_rest[p], self.xs[p], pw, ph, self.US[p], int(p > 0), self.p_recon[p], self.xs[p],
+            self.chk(L.svt_hip_sgr_apply_plane_dev(h, 1, 8, self.p_cdef[p], self.xs[p], self.p_rest[p], self.xs[p], pw, ph, self.US[p], int(p > 0), self.p_dbl[p], self.xs[p],
                                                    self.d_ubest[p].data_ptr(), self.d_ubx[p].data_ptr()), "sgr apply")
 
 
@@ -736,7 +746,7 @@ def run_parity_gate(E, P, F, stages, select_form, timed_final, orc, torch):
                 S[f"q_{i}"] = j["q"].cpu().numpy().reshape(j["n"], -1); S[f"eob_{i}"] = j["eob"].cpu().numpy().view(np.uint16)
             for p in range(3): S[f"recon_{p}"] = _interior(P, P.b_recon, p)
         elif k == "dlf":
-            for p in range(3): S[f"dbl_{p}"] = _interior(P, P.b_recon, p)
+            for p in range(3): S[f"dbl_{p}"] = _interior(P, P.b_dbl, p)
         elif k == "cdef_search":
             S["mse"] = P.d_mse.cpu().numpy().view(np.uint64)
         elif k == "cdef_pick":

@@ -237,6 +237,14 @@ int svt_hip_deblock_plane_dev(SvtHipCtx *ctx, void *d_plane, int pix_bytes, int 
 int svt_hip_deblock_frame_dev(SvtHipCtx *ctx, void *const d_plane[3], int pix_bytes, const int stride[3], int bd,
                               const uint16_t *const d_edges_v[3], const uint16_t *const d_edges_h[3], const int units_w[3],
                               const int units_h[3], int sharpness);
+/* svt_av1_loop_filter_frame(frame, pcs, 0, 3) in ONE launch, out of place: d_dst[p] receives the deblocked plane p (same stride as d_src[p], which is left
+ * untouched; d_dst[p] != d_src[p]).  A workgroup stages a 128 x 64 tile with the 7 samples around it, filters the vertical edges of the staged region and then
+ * the horizontal edges of the tile on chip (loop_filter_sb does both per superblock, EbDeblockingFilter.c:614): the picture is read 1.35 times and written once
+ * instead of two read-modify-write passes.  plane_w / plane_h: extent of the plane in samples (the edge planes are (plane_w + 3) / 4 units wide at least).
+ * A NULL d_src[p] skips the plane. */
+int svt_hip_deblock_frame_fused_dev(SvtHipCtx *ctx, const void *const d_src[3], void *const d_dst[3], int pix_bytes, const int stride[3], int bd,
+                                    const int plane_w[3], const int plane_h[3], const uint16_t *const d_edges_v[3], const uint16_t *const d_edges_h[3],
+                                    const int units_w[3], const int units_h[3], int sharpness);
 /* Sum of squared differences of two planes: svt_spatial_full_distortion_kernel (8-bit) /
  * svt_full_distortion_kernel16_bits (16-bit containers) as called by picture_sse_calculations
  * (Encoder/Codec/EbDeblockingFilter.c:830-961).  *d_sse (device) receives the sum (it is cleared by the call). */

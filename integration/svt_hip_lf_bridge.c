@@ -46,7 +46,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
         const int pw = w >> (pl > 0), ph = h >> (pl > 0);
         p->stride[pl] = (pw + 2 * LF_BORDER + 63) & ~63; p->src_stride[pl] = (pw + 63) & ~63;
         HIP_TRY(svt_hip_malloc(hip, &p->d_recon[pl], plane_bytes(p, pl))); HIP_TRY(svt_hip_malloc(hip, &p->d_cdef[pl], plane_bytes(p, pl)));
-        HIP_TRY(svt_hip_malloc(hip, &p->d_rest[pl], plane_bytes(p, pl)));
+        HIP_TRY(svt_hip_malloc(hip, &p->d_rest[pl], plane_bytes(p, pl))); HIP_TRY(svt_hip_malloc(hip, &p->d_dbl[pl], plane_bytes(p, pl)));
         HIP_TRY(svt_hip_malloc(hip, &p->d_src[pl], (size_t)p->src_stride[pl] * ph * p->pix_bytes));
         p->src[pl] = p->d_src[pl]; p->src_st[pl] = p->src_stride[pl];
         p->units_w[pl] = (pw + 3) / 4; p->units_h[pl] = (ph + 3) / 4;
@@ -72,7 +72,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
 
 void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
     for (int pl = 0; pl < 3; pl++) {
-        svt_hip_free(hip, p->d_recon[pl]); svt_hip_free(hip, p->d_cdef[pl]); svt_hip_free(hip, p->d_rest[pl]); svt_hip_free(hip, p->d_src[pl]);
+        svt_hip_free(hip, p->d_recon[pl]); svt_hip_free(hip, p->d_cdef[pl]); svt_hip_free(hip, p->d_rest[pl]); svt_hip_free(hip, p->d_src[pl]); svt_hip_free(hip, p->d_dbl[pl]);
         for (int d = 0; d < 2; d++) { free(p->h_edges[pl][d]); svt_hip_free(hip, p->d_edges[pl][d]); }
         svt_hip_free(hip, p->d_unit_ep[pl]); svt_hip_free(hip, p->d_unit_xqd[pl]); svt_hip_free(hip, p->d_unit_wiener[pl]);
         free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
@@ -471,7 +471,16 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
         mask |= 1 << pl;
         if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
     }
-    HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
+    static int fused = -1;
+    if (fused < 0) fused = !(getenv("SVT_HIP_DLF_FUSED") && !atoi(getenv("SVT_HIP_DLF_FUSED")));
+    if (fused) {   /* both directions of all planes in one out-of-place launch; the result takes the place of the picture as coded */
+        const void *in[3]; void *out[3]; int pw[3], ph[3];
+        for (int pl = 0; pl < 3; pl++) { in[pl] = pl_ptr[pl]; out[pl] = plane_origin(p, p->d_dbl[pl], pl); pw[pl] = p->w >> (pl > 0); ph[pl] = p->h >> (pl > 0); }
+        HIP_TRY(svt_hip_deblock_frame_fused_dev(hip, in, out, p->pix_bytes, p->stride, p->bd, pw, ph, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
+        for (int pl = 0; pl < 3; pl++)
+            if (mask & (1 << pl)) { void *t = p->d_recon[pl]; p->d_recon[pl] = p->d_dbl[pl]; p->d_dbl[pl] = t; }
+    } else
+        HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
     if (s->defer) s->flags |= ST_HOST_STALE;   /* the deblocked picture stays on the device (svt_hip_hook_picture_done brings the final one back) */
     else if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_DBL;

@@ -32,6 +32,7 @@ typedef struct SvtHipLfPicture {
                                           * what the restoration stages work on (link_eb_to_aom_buffer_desc's crop size) */
     int   sb_size;                       /* 64 / 128: superblock size of the sequence (deblocking range of the last superblock row / column) */
     void *d_recon[3], *d_cdef[3], *d_rest[3], *d_src[3];
+    void *d_dbl[3];                      /* destination of the one-launch (out-of-place) deblocking: swapped with d_recon afterwards, so d_recon stays "the deblocked picture" */
     int   stride[3];                     /* recon / cdef / rest share one stride per plane; the planes carry a 3-sample border */
     int   src_stride[3];
     void *src[3];                        /* the source planes the stages read: d_src (uploaded, src_stride) or the picture's resident copy in place (svt_hip_resident.h) */

@@ -286,6 +286,16 @@ int svt_hip_deblock_frame_dev(SvtHipCtx *c, void *const plane[3], int pix_bytes,
     if (perturb("dlf") && plane[0]) ((uint8_t *)plane[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
+int svt_hip_deblock_frame_fused_dev(SvtHipCtx *c, const void *const src[3], void *const dst[3], int pix_bytes, const int stride[3], int bd, const int pw[3], const int ph[3],
+                                    const uint16_t *const ev[3], const uint16_t *const eh[3], const int units_w[3], const int units_h[3], int sharpness) {
+    for (int p = 0; p < 3; p++) {
+        if (!src[p]) continue;
+        for (int y = 0; y < ph[p]; y++) memcpy((uint8_t *)dst[p] + (size_t)y * stride[p] * pix_bytes, (const uint8_t *)src[p] + (size_t)y * stride[p] * pix_bytes, (size_t)pw[p] * pix_bytes);
+        svt_hip_deblock_plane_dev(c, dst[p], pix_bytes, stride[p], bd, ev[p], eh[p], units_w[p], units_h[p], sharpness);
+    }
+    if (perturb("dlf") && src[0]) ((uint8_t *)dst[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
+    return SVT_HIP_OK;
+}
 int svt_hip_plane_sse_dev(SvtHipCtx *c, int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h, uint64_t *sse) {
     (void)c;
     *sse = orc_plane_sse(pix_bytes, a, a_stride, b, b_stride, w, h);
@@ -334,6 +344,11 @@ int svt_hip_cdef_search_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const
 int svt_hip_cdef_apply_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const in[3], void *const out[3], const int stride[3], int w, int h,
                                  const uint8_t *skip8, const uint8_t *ys, const uint8_t *uvs, int damping, int bd, uint8_t *dir, const int32_t *var) {
     (void)c; (void)dir; (void)var;
+    /* the product writes EVERY sample of the picture (include/svt_hip.h: unfiltered blocks are passed through, d_out needs no initial copy); the oracle, like the
+     * reference, only writes the filtered blocks of a picture that already holds the input */
+    for (int p = 0; p < 3; p++)
+        for (int y = 0; y < (h >> (p > 0)); y++)
+            memcpy((uint8_t *)out[p] + (size_t)y * stride[p] * pix_bytes, (const uint8_t *)in[p] + (size_t)y * stride[p] * pix_bytes, (size_t)(w >> (p > 0)) * pix_bytes);
     orc_cdef_apply_frame(in, out, stride, pix_bytes, w, h, skip8, ys, uvs, damping, bd);
     if (perturb("cdef_apply")) ((uint8_t *)out[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;

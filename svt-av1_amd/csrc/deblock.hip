@@ -212,6 +212,97 @@ int launch_frame(hipStream_t st, const DeblockFrame& f, int sharp) {
     return (int)hipGetLastError();
 }
 
+// ---- both directions of all three planes in ONE launch, out of place (EbDeblockingFilter.c:614 loop_filter_sb does both per superblock).
+// A workgroup owns a 128 x 64 tile of a plane.  Which samples decide a tile's result: a horizontal edge at row e reads the vertically filtered rows
+// e - 7 .. e + 6 and changes e - 6 .. e + 5, and the tile's rows are changed by the edges y0 .. y1 (y1 = the tile below's top edge), so the horizontal
+// phase needs the VERTICALLY FILTERED rows y0 - 7 .. y1 + 6 of the tile's columns; a vertical edge at column c reads the unfiltered columns c - 7 .. c + 6,
+// so those rows need the unfiltered columns x0 - 7 .. x1 + 6.  The region (142 x 78 samples) is staged in LDS once, the vertical edges x0 .. x1 of all 78
+// rows are filtered there (edges of one direction are independent: the filter length is bounded by the smaller transform next to the edge), then the horizontal
+// edges y0 .. y1 of the tile's 128 columns, then the tile is written: 1.35 x the picture read once + the picture written once, instead of two read-modify-write
+// passes.  The staged region's samples outside the tile are filtered redundantly (they are some neighbour's to write).
+struct DeblockFused { const void* src[3]; void* dst[3]; int stride[3]; const uint16_t* ev[3]; const uint16_t* eh[3]; int units_w[3], units_h[3], pw[3], ph[3]; int tiles_x[3], tiles_y[3]; };
+constexpr int kFW = 128, kFH = 64, kFHalo = 7, kFRW = kFW + 2 * kFHalo, kFRH = kFH + 2 * kFHalo, kFStride = kFRW + 3;   // 145 halfwords per row: odd dword phase between rows
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(256)
+deblock_fused_kernel(const DeblockFused f, int sharpness) {
+    __shared__ uint16_t t[kFRH * kFStride];
+    const int p = blockIdx.z;
+    const PIX* src = (const PIX*)(p == 0 ? f.src[0] : (p == 1 ? f.src[1] : f.src[2]));
+    PIX* dst = (PIX*)(p == 0 ? f.dst[0] : (p == 1 ? f.dst[1] : f.dst[2]));
+    const int tiles_x = p == 0 ? f.tiles_x[0] : (p == 1 ? f.tiles_x[1] : f.tiles_x[2]), tiles_y = p == 0 ? f.tiles_y[0] : (p == 1 ? f.tiles_y[1] : f.tiles_y[2]);
+    if (!src || (int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int stride = p == 0 ? f.stride[0] : (p == 1 ? f.stride[1] : f.stride[2]);
+    const uint16_t* ev = p == 0 ? f.ev[0] : (p == 1 ? f.ev[1] : f.ev[2]);
+    const uint16_t* eh = p == 0 ? f.eh[0] : (p == 1 ? f.eh[1] : f.eh[2]);
+    const int units_w = p == 0 ? f.units_w[0] : (p == 1 ? f.units_w[1] : f.units_w[2]), units_h = p == 0 ? f.units_h[0] : (p == 1 ? f.units_h[1] : f.units_h[2]);
+    const int pw = p == 0 ? f.pw[0] : (p == 1 ? f.pw[1] : f.pw[2]), ph = p == 0 ? f.ph[0] : (p == 1 ? f.ph[1] : f.ph[2]);
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, x0 = tx * kFW, y0 = ty * kFH, tid = threadIdx.x;
+    const int tw = min(kFW, pw - x0), th = min(kFH, ph - y0);
+    // region origin in the plane: (x0 - 7, y0 - 7); t[r][c] <-> plane (x0 - 7 + c, y0 - 7 + r); samples outside the plane are never read by a filter
+    for (int i = tid; i < kFRH * kFRW; i += 256) {
+        const int r = i / kFRW, c = i - r * kFRW, x = x0 - kFHalo + c, y = y0 - kFHalo + r;
+        t[r * kFStride + c] = (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)src[(size_t)y * stride + x] : (uint16_t)0;
+    }
+    __syncthreads();
+    // vertical edges at columns x0 + 4k, k = 0 .. tw / 4 (the last one is the right neighbour's first edge: it changes this tile's last columns), every staged row
+    {
+        const int ne = (tw >> 2) + 1, rows = min(th + 2 * kFHalo, kFRH);
+        for (int i = tid; i < rows * ne; i += 256) {
+            const int r = i / ne, k = i - r * ne, y = y0 - kFHalo + r, x = x0 + 4 * k;
+            if (y < 0 || y >= ph || x >= pw || (x >> 2) >= units_w || (y >> 2) >= units_h) continue;
+            const uint32_t e = ev[(y >> 2) * units_w + (x >> 2)];
+            const int len = e & 0xff, level = (int)(e >> 8);
+            if (!len || !level) continue;
+            const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+            uint16_t* s = t + r * kFStride + kFHalo + 4 * k;
+            int px[14];
+#pragma unroll
+            for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q] : 0; px[6 + q] = (q <= half) ? (int)s[q - 1] : 0; }
+            const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+            for (int q = 1; q <= 6; q++)
+                if (q <= changed) { s[-q] = (uint16_t)px[7 - q]; s[q - 1] = (uint16_t)px[6 + q]; }
+        }
+    }
+    __syncthreads();
+    // horizontal edges at rows y0 + 4k, k = 0 .. th / 4, the tile's columns
+    {
+        const int ne = (th >> 2) + 1;
+        for (int i = tid; i < ne * tw; i += 256) {
+            const int k = i / tw, c = i - k * tw, y = y0 + 4 * k, x = x0 + c;
+            if (y >= ph || (y >> 2) >= units_h) continue;
+            const uint32_t e = eh[(y >> 2) * units_w + (x >> 2)];
+            const int len = e & 0xff, level = (int)(e >> 8);
+            if (!len || !level) continue;
+            const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+            uint16_t* s = t + (kFHalo + 4 * k) * kFStride + kFHalo + c;
+            int px[14];
+#pragma unroll
+            for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q * kFStride] : 0; px[6 + q] = (q <= half) ? (int)s[(q - 1) * kFStride] : 0; }
+            const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+            for (int q = 1; q <= 6; q++)
+                if (q <= changed) { s[-q * kFStride] = (uint16_t)px[7 - q]; s[(q - 1) * kFStride] = (uint16_t)px[6 + q]; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < th * tw; i += 256) {
+        const int r = i / tw, c = i - r * tw;
+        dst[(size_t)(y0 + r) * stride + x0 + c] = (PIX)t[(kFHalo + r) * kFStride + kFHalo + c];
+    }
+}
+template <typename PIX, int BD>
+int launch_fused(hipStream_t st, DeblockFused& f, int sharp) {
+    int n = 0;
+    for (int p = 0; p < 3; p++) {
+        f.tiles_x[p] = (f.pw[p] + kFW - 1) / kFW; f.tiles_y[p] = (f.ph[p] + kFH - 1) / kFH;
+        if (f.src[p]) n = f.tiles_x[p] * f.tiles_y[p] > n ? f.tiles_x[p] * f.tiles_y[p] : n;
+    }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((deblock_fused_kernel<PIX, BD>), dim3(n, 1, 3), dim3(256), 0, st, f, sharp);
+    return (int)hipGetLastError();
+}
+
 template <typename PIX, int BD>
 int launch_both(hipStream_t st, PIX* plane, int stride, const uint16_t* ev, const uint16_t* eh, int uw, int uh, int sharp, int lv_v, int lv_h) {
     if (ev) hipLaunchKernelGGL((deblock_pass_kernel<PIX, BD, 0>), dim3((uw + 255) / 256, 4 * uh), dim3(256), 0, st, plane, stride, ev, uw, uh, sharp, lv_v);
@@ -280,6 +371,18 @@ extern "C" int svt_hip_launch_plane_sse(hipStream_t st, int pix_bytes, const voi
     if (pix_bytes == 1) hipLaunchKernelGGL((plane_sse_kernel<uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)a, a_stride, (const uint8_t*)b, b_stride, w, h, (unsigned long long*)out);
     else hipLaunchKernelGGL((plane_sse_kernel<uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)a, a_stride, (const uint16_t*)b, b_stride, w, h, (unsigned long long*)out);
     return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_deblock_fused(hipStream_t st, const void* const src[3], void* const dst[3], int pix_bytes, const int stride[3], int bd, const int pw[3],
+                                            const int ph[3], const uint16_t* const ev[3], const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness) {
+    DeblockFused f;
+    for (int p = 0; p < 3; p++) {
+        f.src[p] = src[p]; f.dst[p] = dst[p]; f.stride[p] = stride[p]; f.ev[p] = ev[p]; f.eh[p] = eh[p]; f.units_w[p] = units_w[p]; f.units_h[p] = units_h[p];
+        f.pw[p] = pw[p]; f.ph[p] = ph[p];
+    }
+    if (pix_bytes == 1) return launch_fused<uint8_t, 8>(st, f, sharpness);
+    if (bd == 8) return launch_fused<uint16_t, 8>(st, f, sharpness);
+    return launch_fused<uint16_t, 10>(st, f, sharpness);
 }
 
 SVT_HIP_TU_PROBE(deblock)

@@ -415,6 +415,26 @@ int svt_hip_deblock_frame_dev(SvtHipCtx* c, void* const d_plane[3], int pix_byte
     return SVT_HIP_OK;
 }
 
+int svt_hip_deblock_frame_fused_dev(SvtHipCtx* c, const void* const d_src[3], void* const d_dst[3], int pix_bytes, const int stride[3], int bd, const int plane_w[3],
+                                    const int plane_h[3], const uint16_t* const d_edges_v[3], const uint16_t* const d_edges_h[3], const int units_w[3],
+                                    const int units_h[3], int sharpness) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !d_dst || !stride || !plane_w || !plane_h || !d_edges_v || !d_edges_h || !units_w || !units_h || (pix_bytes != 1 && pix_bytes != 2) ||
+        (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) || sharpness < 0 || sharpness > 7) {
+        if (c) c->err = "svt_hip_deblock_frame_fused_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    for (int p = 0; p < 3; p++)
+        if (d_src[p] && (!d_dst[p] || d_dst[p] == d_src[p] || plane_w[p] <= 0 || plane_h[p] <= 0 || units_w[p] < (plane_w[p] + 3) / 4 || units_h[p] < (plane_h[p] + 3) / 4 ||
+                         !d_edges_v[p] || !d_edges_h[p])) {
+            c->err = "svt_hip_deblock_frame_fused_dev: bad plane argument (the fused form is out of place)";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    hipError_t e = (hipError_t)svt_hip_launch_deblock_fused(c->stream, d_src, d_dst, pix_bytes, stride, bd, plane_w, plane_h, d_edges_v, d_edges_h, units_w, units_h, sharpness);
+    if (e != hipSuccess) return fail(c, e, "fused deblock launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_plane_sse_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, int w, int h,
                           uint64_t* d_sse) {
     SVT_HIP_ENTER(c);

@@ -33,6 +33,8 @@ int svt_hip_launch_enc_txfm_multi(hipStream_t st, int pix_bytes, int bd, const S
 int svt_hip_launch_inv_txfm_add_multi(hipStream_t st, int pix_bytes, int bd, const SvtHipInvTxJob* jobs, int njobs);
 int svt_hip_launch_deblock_frame(hipStream_t st, void* const plane[3], int pix_bytes, const int stride[3], int bd, const uint16_t* const ev[3],
                                  const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness);
+int svt_hip_launch_deblock_fused(hipStream_t st, const void* const src[3], void* const dst[3], int pix_bytes, const int stride[3], int bd, const int pw[3],
+                                 const int ph[3], const uint16_t* const ev[3], const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness);
 int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
                                  const uint16_t* edges_h, int units_w, int units_h, int sharpness, int level_v, int level_h);
 int svt_hip_launch_coeff_distortion(hipStream_t st, const int32_t* coeff, const int32_t* recon, int n, int nblk, uint64_t* out);

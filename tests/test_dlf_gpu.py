@@ -150,3 +150,48 @@ def test_deblock_frame_all_planes(hip, orc, bd):
             assert np.array_equal(got, planes[i] if i == skip else exp[i]), (bd, skip, i)
             assert (exp[i] != planes[i]).any()
         hip.free(*d_p, *d_ev, *d_eh)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("size", [(328, 200), (1928, 1088), (136, 72), (3840, 2160)])
+def test_deblock_frame_fused(hip, orc, bd, size):
+    """svt_hip_deblock_frame_fused_dev (both directions of all planes in one out-of-place launch, tiles of 128 x 64 with a 7-sample halo) == the oracle's two passes per
+    plane: sizes whose last tile is partial in both directions, varied transform sizes (4 / 8 / 14-tap luma, 4 / 6-tap chroma), three sharpness values; the source planes
+    stay untouched, the destination's samples outside the plane extent too, a NULL plane is skipped."""
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    w, h = size
+    if size == (3840, 2160) and bd == 10:
+        pytest.skip("the 4K case runs once (8-bit)")
+    rng = np.random.default_rng(170 + bd + w)
+    dt = np.uint8 if bd == 8 else np.uint16
+    for seed, varied, sharp in ((21, True, 0), (22, True, 3), (23, False, 6)):
+        mi, cols, rows = dc.make_mode_info(w, h, seed=seed, varied=varied)
+        planes, exp, edges = [], [], []
+        for plane, (pw, ph) in enumerate(((w, h), (w // 2, h // 2), (w // 2, h // 2))):
+            ev, eh = dc.build_edges(mi, cols, rows, plane, pw, ph)
+            img = np.ascontiguousarray(content(rng, ph + 3, pw + 8, bd, plane != 2).astype(dt))   # stride > width, rows below the plane
+            e = img.copy()
+            orc.orc_deblock_plane(ptr(e), img.itemsize, img.shape[1], bd, ptr(ev), ptr(eh), ev.shape[1], ev.shape[0], sharp)
+            planes.append(img); exp.append(e); edges.append((ev, eh))
+        for skip in ((None, 2) if seed == 21 else (None,)):
+            d_p = [hip.to_device(p) for p in planes]
+            fill = [np.full_like(p, 37) for p in planes]
+            d_o = [hip.to_device(f) for f in fill]
+            d_ev = [hip.to_device(e[0]) for e in edges]; d_eh = [hip.to_device(e[1]) for e in edges]
+            pp = [d_p[i].value if i != skip else None for i in range(3)]
+            dims = ((w, h), (w // 2, h // 2), (w // 2, h // 2))
+            hip.check(hip.L.svt_hip_deblock_frame_fused_dev(hip.h, P3(*pp), P3(*[d.value for d in d_o]), planes[0].itemsize, I3(*[p.shape[1] for p in planes]), bd,
+                                                           I3(*[d[0] for d in dims]), I3(*[d[1] for d in dims]), P3(*[d.value for d in d_ev]), P3(*[d.value for d in d_eh]),
+                                                           I3(*[e[0].shape[1] for e in edges]), I3(*[e[0].shape[0] for e in edges]), sharp), "fused deblock")
+            for i in range(3):
+                pw, ph = dims[i]
+                got = hip.to_host(d_o[i], planes[i].shape, dt)
+                src_after = hip.to_host(d_p[i], planes[i].shape, dt)
+                assert np.array_equal(src_after, planes[i]), "the source plane must stay untouched"
+                if i == skip:
+                    assert (got == 37).all()
+                    continue
+                assert np.array_equal(got[:ph, :pw], exp[i][:ph, :pw]), (bd, size, seed, i, np.argwhere(got[:ph, :pw] != exp[i][:ph, :pw])[:4])
+                assert (got[ph:] == 37).all() and (got[:, pw:] == 37).all(), "samples outside the plane extent were written"
+                assert (exp[i][:ph, :pw] != planes[i][:ph, :pw]).any()
+            hip.free(*d_p, *d_o, *d_ev, *d_eh)

@@ -22,10 +22,10 @@ ALG_BYTES_PER_SB = {
     "fwd_txfm_quant": 61440 + 128,           # (src+pred 2*6144) + qcoeff+dqcoeff 2*4*6144 + eob   (luma+chroma)
     "inv_txfm_recon": 36864,                 # dqcoeff 4*6144 + pred 6144 + recon 6144
     "fwd_quant_inv_recon": 2 * 6144 + 4 * 6144 + 6144 + 128,   # fused: src + pred in, levels + recon out (the dequantised coefficients stay in registers)
-    "deblock": 2 * (6144 + 6144) + 2560,     # two passes (V, H): planes R+W each + edge descriptors
+    "deblock": 6144 + 6144 + 2560,           # SURVEY 8(d) fused figure: both directions in one out-of-place launch (planes R once + W once + edge descriptors); 27 136 for the two in-place passes
     "cdef_search": 13312,                    # recon 6144 + source 6144 R + 2*64*8 W
     "cdef_strength_select": 2 * 64 * 8 + 2,  # the two distortion rows of the filter block R (once, if they stayed on chip over the 75 steps) + its strength pair W
-    "cdef_apply": 12288 + 12288,             # 6144 R + 6144 W, plus the device-to-device copy that initialises the destination (R + W)
+    "cdef_apply": 12288,                     # 6144 R + 6144 W (the kernel writes every sample: no initialising copy)
     "pyramids": 5376 + 4351,                 # decimation 4096 R + 1024 + 256 W ; variance pyramid 4096 R + 85*3 W
     "hme_l0_l1_l2": 256 + 1024 + 4096 + 3 * 12,   # source blocks of the three levels + results (windows are cache-resident)
     "subpel_convolve": 12560,                # 16 blocks x (16+7)^2 R + 4096 W (luma)
@@ -42,7 +42,7 @@ USEFUL_LANE_OPS_PER_SB = {
 STAGE_KERNELS = {
     "pyramids": ("downsample_kernel", "variance_pyramid_kernel"), "hme_l0_l1_l2": ("sad_loop_kernel",), "me_fullpel_85pu": ("me_fullpel_85pu_kernel", "me_fullpel_narrow_kernel"),
     "subpel_convolve": ("subpel_predict_kernel", "subpel_jobs_from_me_kernel"), "fwd_txfm_quant": ("fwd_txfm_quant_multi_kernel",), "inv_txfm_recon": ("inv_txfm_add_multi_kernel",),
-    "fwd_quant_inv_recon": ("enc_txfm_multi_kernel",), "deblock": ("deblock_frame_pass_kernel",), "cdef_search": ("cdef_search_luma_kernel", "cdef_search_chroma_kernel"),
+    "fwd_quant_inv_recon": ("enc_txfm_multi_kernel",), "deblock": ("deblock_fused_kernel", "deblock_frame_pass_kernel"), "cdef_search": ("cdef_search_luma_kernel", "cdef_search_chroma_kernel"),
     "cdef_strength_select": ("joint_init_kernel", "joint_partial_kernel", "joint_reduce_kernel", "joint_transpose_kernel", "joint_resident_kernel", "cdef_finish_kernel"), "cdef_apply": ("cdef_apply_kernel",),
     "sgr_units_search": ("sgr_search8_kernel", "sgr_walk_resident_kernel", "sgr_walk_kernel", "generate_padding_kernel"), "sgr_apply": ("lr_apply8_kernel",),
 }
