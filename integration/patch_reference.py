@@ -184,6 +184,14 @@ ed.sub(r'(\n[ \t]*// Transform Loop\n[ \t]*context_ptr->md_context->md_local_blk
 ed.sub(r'(\n[ \t]*// Force Skip if MergeFlag == TRUE && RootCbf == 0\n)', r'\n                    svt_hip_hook_encdec_tx_end();\1')
 
 
+# hook "encdec_sb" (svt_hip_md_bridge.c): before the block loop of a superblock, every plain-translation inter block of its final partition is predicted and the
+# forward transforms of all their transform blocks run in ONE launch; the loop skips those predictions and reads the cache
+ed.sub(r'(\n    uint32_t final_blk_itr    = 0;\n    // CU Loop\n)',
+       r'\n    svt_hip_hook_encdec_sb_begin(scs_ptr, pcs_ptr, sb_ptr, sb_addr, sb_origin_x, sb_origin_y, context_ptr, recon_buffer, is_16bit);\1')
+ed.sub(r'(\n[ \t]*if \(pu_ptr->motion_mode != WARPED_CAUSAL)(\) \{\n[ \t]*EbPictureBufferDesc \*ref_pic_list0;)', r'\1 && !svt_hip_hook_encdec_sb_predicted(blk_ptr)\2')
+ed.sub(r'(\n\} // CU Loop\n)', r'\1    svt_hip_hook_encdec_sb_end();\n')
+
+
 def _ed_fetch(m):
     plane = {"y": 0, "cb": 1, "cr": 2}[m.group(3)]
     return (f"{m.group(1)}if (!svt_hip_hook_encdec_tx_fetch({plane}, context_ptr->txb_itr, {m.group(5)}, {m.group(7)}, {m.group(4)}))"

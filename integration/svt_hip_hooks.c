@@ -13,8 +13,8 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel", "encdec_tx", "md_subpel"};
-static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1, [SVT_HIP_HOOK_ENCDEC_TX] = 1, [SVT_HIP_HOOK_MD_SUBPEL] = 1};   /* not selected by "all": must be named */
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel", "encdec_tx", "md_subpel", "encdec_sb"};
+static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1, [SVT_HIP_HOOK_ENCDEC_TX] = 1, [SVT_HIP_HOOK_MD_SUBPEL] = 1, [SVT_HIP_HOOK_ENCDEC_SB] = 1};   /* not selected by "all": must be named */
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;
@@ -265,6 +265,11 @@ void svt_hip_hooks_report(void) {
         long blocks, calls;
         svt_hip_hook_encdec_tx_stats(&blocks, &calls);
         fprintf(stderr, "svt_hip_encdec_tx inter_blocks=%ld estimate_transform_calls_replaced=%ld\n", blocks, calls);
+    }
+    if (g_enabled[SVT_HIP_HOOK_ENCDEC_SB]) {
+        long sbs, launches, blocks, calls;
+        svt_hip_hook_encdec_sb_stats(&sbs, &launches, &blocks, &calls);
+        fprintf(stderr, "svt_hip_encdec_sb superblocks=%ld launches=%ld inter_blocks_predicted_ahead=%ld estimate_transform_calls_replaced=%ld\n", sbs, launches, blocks, calls);
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

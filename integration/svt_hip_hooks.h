@@ -56,6 +56,8 @@ enum {
                                 * results).  Opt-in like md_tx: a launch per coded block */
     SVT_HIP_HOOK_MD_SUBPEL,    /* mode decision's sub-pel refinement: the eight neighbours of a round of svt_av1_find_best_sub_pixel_tree (mcomp.c:350, svt_first_level_check
                                 * :186) predicted and measured in one launch pair; the tree's control flow stays the reference's.  Opt-in */
+    SVT_HIP_HOOK_ENCDEC_SB,    /* encode pass, one launch per SUPERBLOCK: the plain-translation inter blocks of a superblock's final partition are predicted ahead of its block
+                                * loop (av1_encode_decode, EbCodingLoop.c:2262) and the forward transforms of all their transform blocks run in one launch.  Opt-in */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -181,6 +183,12 @@ int  svt_hip_hook_encdec_tx_begin(struct EncDecContext *ctx, const EbPictureBuff
 int  svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff);
 void svt_hip_hook_encdec_tx_end(void);
 void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls);
+struct SuperBlock;
+int  svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pcs, struct SuperBlock *sb, uint32_t sb_addr, uint32_t sb_origin_x, uint32_t sb_origin_y,
+                                  struct EncDecContext *ctx, EbPictureBufferDesc *recon, int is_16bit);
+int  svt_hip_hook_encdec_sb_predicted(const BlkStruct *blk);
+void svt_hip_hook_encdec_sb_end(void);
+void svt_hip_hook_encdec_sb_stats(long *superblocks, long *launches, long *blocks, long *calls);
 /* svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *, const MV *centre, int hstep, const SubpelMvLimits *) is declared in the patched mcomp.c (its
  * argument types live in mcomp.h, which includes this header's dependencies the other way round) */
 int  svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse);

@@ -91,39 +91,31 @@ void svt_hip_hook_md_tx_end(void) { tls_tx.valid = 0; }
 
 #define ED_MAX_JOBS (3 * MAX_TXB_COUNT * 2)
 #define ED_MAX_COEFF (128 * 128 * 3)   /* a 128x128 block, luma + chroma, both types: well below this with sides <= 32 */
-static __thread struct {
-    int      valid, n;
-    struct { int8_t plane, txb, tx_size, tx_type; int32_t off, count; } e[ED_MAX_JOBS];
-    int32_t  coeff[ED_MAX_COEFF];
-} tls_ed;
-static void *d_ed_src, *d_ed_pred, *d_ed_desc, *d_ed_coeff;   /* shared staging, hooks lock held */
-static long  g_ed_blocks, g_ed_tx;                            /* inter blocks batched / av1_estimate_transform calls they replaced (svt_hip_hooks_report) */
-
-void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls) { *blocks = g_ed_blocks; *calls = g_ed_tx; }
-
-int svt_hip_hook_encdec_tx_begin(EncDecContext *ctx, const EbPictureBufferDesc *pred, int is_16bit) {
-    tls_ed.valid = 0;
-    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ENCDEC_TX)) return 0;
-    const BlkStruct *blk = ctx->blk_ptr;
-    const BlockGeom *g = ctx->blk_geom;
-    const int        d = blk->tx_depth, tot = g->txb_count[d], is_inter = 1;
+/* the transform-block jobs of ONE inter-coded block appended to a batch: source and prediction samples (two 16-bit planes), one job per (plane, transform
+ * block, type); 0 = the batch's capacity is exhausted (nothing appended) */
+typedef struct { int16_t blk; int8_t plane, txb, tx_size, tx_type; int32_t off, count; } EdEntry;
+typedef struct {
+    uint16_t *hs, *hp; int pix_cap, n_pix;
+    uint32_t *desc; SvtHipFwdTxJob *jobs; EdEntry *e; int job_cap, n;
+    int coeff_cap, n_coeff;
+} EdBatch;
+static int ed_gather_block(EdBatch *B, EncDecContext *ctx, const BlkStruct *blk, const BlockGeom *g, uint32_t blk_origin_x, uint32_t blk_origin_y, const EbPictureBufferDesc *pred,
+                           int is_16bit) {
+    const int d = blk->tx_depth, tot = g->txb_count[d], is_inter = 1;
+    const int n0 = B->n, pix0 = B->n_pix, coeff0 = B->n_coeff;
     /* the residual of every transform block, as the encode loops form it (8-bit: input picture vs the prediction in the reconstruction buffer, :315-338;
      * 16-bit: the superblock's 16-bit input buffer, :677-700), split into two non-negative planes for the batched entry point (src - pred) */
-    static __thread uint16_t hs[ED_MAX_COEFF / 2], hp[ED_MAX_COEFF / 2];
-    uint32_t desc[ED_MAX_JOBS];
-    SvtHipFwdTxJob jobs[ED_MAX_JOBS];
-    int      n = 0, n_pix = 0, n_coeff = 0;
     for (int t = 0; t < tot; t++) {
         const int uv_pass = d && t ? 0 : 1;
-        const uint32_t ox = ctx->blk_origin_x + g->tx_org_x[is_inter][d][t] - g->origin_x, oy = ctx->blk_origin_y + g->tx_org_y[is_inter][d][t] - g->origin_y;
+        const uint32_t ox = blk_origin_x + g->tx_org_x[is_inter][d][t] - g->origin_x, oy = blk_origin_y + g->tx_org_y[is_inter][d][t] - g->origin_y;
         const uint32_t rx = (ox >> 3) << 3, ry = (oy >> 3) << 3;
         for (int p = 0; p < ((g->has_uv && uv_pass) ? 3 : 1); p++) {
             const int w = p ? g->tx_width_uv[d][t] : g->tx_width[d][t], h = p ? g->tx_height_uv[d][t] : g->tx_height[d][t];
             const int tx_size = p ? g->txsize_uv[d][t] : g->txsize[d][t];
             if (w > 32 || h > 32) continue;
-            if (n_pix + w * h > ED_MAX_COEFF / 2) return 0;
+            if (B->n_pix + w * h > B->pix_cap) goto full;
             /* sample (x, y) of source and prediction */
-            uint16_t *ps = hs + n_pix, *pp = hp + n_pix;
+            uint16_t *ps = B->hs + B->n_pix, *pp = B->hp + B->n_pix;
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) {
                     int s, q;
@@ -157,51 +149,83 @@ int svt_hip_hook_encdec_tx_begin(EncDecContext *ctx, const EbPictureBufferDesc *
             for (int k = 0; k < 2; k++) {
                 const int type = k ? DCT_DCT : type0;
                 if (k && type0 == DCT_DCT) break;
-                if (n >= ED_MAX_JOBS || n_coeff + w * h > ED_MAX_COEFF) return 0;
-                tls_ed.e[n].plane = (int8_t)p; tls_ed.e[n].txb = (int8_t)t; tls_ed.e[n].tx_size = (int8_t)tx_size; tls_ed.e[n].tx_type = (int8_t)type;
-                tls_ed.e[n].off = n_coeff; tls_ed.e[n].count = w * h;
-                desc[n] = SVT_HIP_TX_DESC(0, 0, type);
-                memset(&jobs[n], 0, sizeof(jobs[n]));
-                jobs[n].tx_size = tx_size; jobs[n].nblk = 1; jobs[n].src_stride = w; jobs[n].pred_stride = w;
-                jobs[n].d_src = (const void *)(size_t)n_pix;      /* offsets for now: the device base is added under the lock */
-                jobs[n].d_coeff = (int32_t *)(size_t)n_coeff;
-                jobs[n].qp.coeff_shape = ctx->md_context->pf_ctrls.pf_shape;
-                n++; n_coeff += w * h;
+                if (B->n >= B->job_cap || B->n_coeff + w * h > B->coeff_cap) goto full;
+                EdEntry *e = &B->e[B->n];
+                e->blk = (int16_t)blk->mds_idx; e->plane = (int8_t)p; e->txb = (int8_t)t; e->tx_size = (int8_t)tx_size; e->tx_type = (int8_t)type;
+                e->off = B->n_coeff; e->count = w * h;
+                B->desc[B->n] = SVT_HIP_TX_DESC(0, 0, type);
+                SvtHipFwdTxJob *j = &B->jobs[B->n];
+                memset(j, 0, sizeof(*j));
+                j->tx_size = tx_size; j->nblk = 1; j->src_stride = w; j->pred_stride = w;
+                j->d_src = (const void *)(size_t)B->n_pix;      /* offsets for now: the device base is added once the blocks exist */
+                j->d_coeff = (int32_t *)(size_t)B->n_coeff;
+                j->qp.coeff_shape = ctx->md_context->pf_ctrls.pf_shape;
+                B->n++; B->n_coeff += w * h;
             }
-            n_pix += w * h;
+            B->n_pix += w * h;
         }
     }
-    if (!n) return 0;
-    SvtHipCtx *hip = svt_hip_hooks_lock();
-    if (!hip) return 0;
-    int rc = SVT_HIP_OK;
-    if (!d_ed_src) {
-        rc = svt_hip_malloc(hip, &d_ed_src, sizeof(hs));
-        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_pred, sizeof(hp));
-        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_desc, sizeof(desc));
-        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &d_ed_coeff, sizeof(tls_ed.coeff));
-        if (rc != SVT_HIP_OK) { svt_hip_free(hip, d_ed_src); svt_hip_free(hip, d_ed_pred); svt_hip_free(hip, d_ed_desc); svt_hip_free(hip, d_ed_coeff); d_ed_src = d_ed_pred = d_ed_desc = d_ed_coeff = NULL; }
+    return 1;
+full:
+    B->n = n0; B->n_pix = pix0; B->n_coeff = coeff0;
+    return 0;
+}
+/* one launch for the batch: coefficients of every job -> coeff (host).  A pool context and blocks of the hooks' cache: encode-pass threads run side by side. */
+static int ed_launch(EdBatch *B, int32_t *coeff) {
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
+    if (!hip) return SVT_HIP_ERR_RUNTIME;
+    void *d_s = NULL, *d_p = NULL, *d_d = NULL, *d_c = NULL;
+    int   rc = svt_hip_hooks_malloc(hip, &d_s, sizeof(uint16_t) * (size_t)B->n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_p, sizeof(uint16_t) * (size_t)B->n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_d, sizeof(uint32_t) * (size_t)B->n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_c, sizeof(int32_t) * (size_t)B->n_coeff);
+    for (int i = 0; i < B->n && rc == SVT_HIP_OK; i++) {
+        const size_t po = (size_t)B->jobs[i].d_src, co = (size_t)B->jobs[i].d_coeff;
+        B->jobs[i].d_src = (const uint16_t *)d_s + po; B->jobs[i].d_pred = (const uint16_t *)d_p + po;
+        B->jobs[i].d_descs = (const uint32_t *)d_d + i; B->jobs[i].d_coeff = (int32_t *)d_c + co;
     }
-    for (int i = 0; i < n && rc == SVT_HIP_OK; i++) {
-        const size_t po = (size_t)jobs[i].d_src, co = (size_t)jobs[i].d_coeff;
-        jobs[i].d_src = (const uint16_t *)d_ed_src + po; jobs[i].d_pred = (const uint16_t *)d_ed_pred + po;
-        jobs[i].d_descs = (const uint32_t *)d_ed_desc + i; jobs[i].d_coeff = (int32_t *)d_ed_coeff + co;
-    }
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_src, hs, sizeof(uint16_t) * (size_t)n_pix);
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_pred, hp, sizeof(uint16_t) * (size_t)n_pix);
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d_ed_desc, desc, sizeof(uint32_t) * (size_t)n);
-    if (rc == SVT_HIP_OK) rc = svt_hip_fwd_txfm_quant_multi_dev(hip, 2, jobs, n);
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, tls_ed.coeff, d_ed_coeff, sizeof(int32_t) * (size_t)n_coeff);
-    if (rc == SVT_HIP_OK) g_ed_blocks++;
-    svt_hip_hooks_unlock();
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_s, B->hs, sizeof(uint16_t) * (size_t)B->n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_p, B->hp, sizeof(uint16_t) * (size_t)B->n_pix);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_d, B->desc, sizeof(uint32_t) * (size_t)B->n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_fwd_txfm_quant_multi_dev(hip, 2, B->jobs, B->n);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, coeff, d_c, sizeof(int32_t) * (size_t)B->n_coeff);   /* drains the stream: the staging arrays may be reused */
+    if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
+    svt_hip_hooks_free(hip, d_s); svt_hip_hooks_free(hip, d_p); svt_hip_hooks_free(hip, d_d); svt_hip_hooks_free(hip, d_c);
+    svt_hip_hooks_unlock_any();
+    return rc;
+}
+
+static __thread struct {
+    int      valid, n;
+    EdEntry  e[ED_MAX_JOBS];
+    int32_t  coeff[ED_MAX_COEFF];
+} tls_ed;
+static long  g_ed_blocks, g_ed_tx;                            /* inter blocks batched / av1_estimate_transform calls they replaced (svt_hip_hooks_report) */
+
+void svt_hip_hook_encdec_tx_stats(long *blocks, long *calls) { *blocks = g_ed_blocks; *calls = g_ed_tx; }
+
+static int sb_begin_block(const BlkStruct *blk);
+int svt_hip_hook_encdec_tx_begin(EncDecContext *ctx, const EbPictureBufferDesc *pred, int is_16bit) {
+    tls_ed.valid = 0;
+    if (sb_begin_block(ctx->blk_ptr)) return 1;   /* hook "encdec_sb": this block's transforms came with its superblock's launch */
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ENCDEC_TX)) return 0;
+    static __thread uint16_t hs[ED_MAX_COEFF / 2], hp[ED_MAX_COEFF / 2];
+    uint32_t       desc[ED_MAX_JOBS];
+    SvtHipFwdTxJob jobs[ED_MAX_JOBS];
+    EdBatch        B = {hs, hp, ED_MAX_COEFF / 2, 0, desc, jobs, tls_ed.e, ED_MAX_JOBS, 0, ED_MAX_COEFF, 0};
+    if (!ed_gather_block(&B, ctx, ctx->blk_ptr, ctx->blk_geom, ctx->blk_origin_x, ctx->blk_origin_y, pred, is_16bit) || !B.n) return 0;
+    const int rc = ed_launch(&B, tls_ed.coeff);
+    if (rc == SVT_HIP_OK) __sync_fetch_and_add(&g_ed_blocks, 1);
     svt_hip_hooks_count(SVT_HIP_HOOK_ENCDEC_TX, rc == SVT_HIP_OK);
     if (rc != SVT_HIP_OK) return 0;
-    tls_ed.n = n; tls_ed.valid = 1;
+    tls_ed.n = B.n; tls_ed.valid = 1;
     return 1;
 }
 
 /* av1_estimate_transform of transform block `txb` of plane `plane` inside av1_encode_loop[_16bit]: 1 = coeff holds the device result */
+static int sb_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff);
 int svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff) {
+    if (sb_fetch(plane, txb, tx_size, tx_type, coeff)) return 1;
     if (!tls_ed.valid) return 0;
     for (int i = 0; i < tls_ed.n; i++)
         if (tls_ed.e[i].plane == plane && tls_ed.e[i].txb == txb && tls_ed.e[i].tx_size == tx_size && tls_ed.e[i].tx_type == tx_type) {
@@ -211,7 +235,156 @@ int svt_hip_hook_encdec_tx_fetch(int plane, int txb, int tx_size, int tx_type, i
         }
     return 0;
 }
-void svt_hip_hook_encdec_tx_end(void) { tls_ed.valid = 0; }
+static void sb_end_block(void);
+void svt_hip_hook_encdec_tx_end(void) { tls_ed.valid = 0; sb_end_block(); }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Encode pass, hook "encdec_sb": ONE launch per SUPERBLOCK.  av1_encode_decode (EbCodingLoop.c:1987) predicts an inter block right before it codes it (:2848-3006),
+ * so a block's residual only exists once the blocks before it are coded — but an inter prediction with plain translation reads reference PICTURES only, never
+ * the picture being coded, and every mode of the superblock is final when the encode pass starts (mode decision ran on the whole superblock first).  So, before
+ * the block loop of a superblock (svt_hip_hook_encdec_sb_begin): every final block that is inter-coded with SIMPLE_TRANSLATION motion, no inter-intra, no 4-sample
+ * side (those chroma predictions look at neighbouring mode info the loop is still going to write) is predicted into its own area of the reconstruction buffer — the
+ * reference's own av1_inter_prediction[_16bit_pipeline] with the arguments the loop would pass and the block's frame-edge distances in the shared MacroBlockD, which the
+ * loop's enc_pass_av1_mv_pred would have set (EbAdaptiveMotionVectorPrediction.c:1185-1188) — and the forward transforms of ALL their transform blocks (luma, chroma,
+ * chosen type and DCT_DCT) go to the device in one launch.  The loop then skips the prediction of those blocks (svt_hip_hook_encdec_sb_predicted) and its
+ * av1_estimate_transform calls read the superblock's cache.  Nobody reads a block's area of the reconstruction buffer before the block is coded (intra prediction
+ * works from the neighbour arrays, intra block copy from areas coded earlier), so the early prediction is invisible.  Quantisation with RDOQ (entropy contexts of the
+ * neighbouring transform blocks), the inverse transforms and intra blocks stay the reference's, in coding order.  Opt-in. */
+#include "EbEncInterPrediction.h"
+#include "EbModeDecisionConfigurationProcess.h"
+#include "EbReferenceObject.h"
+#include "EbUtility.h"
+#define SB_MAX_BLK 4432    /* BLOCK_MAX_COUNT_SB_128 */
+#define SB_MAX_JOBS 2560
+#define SB_MAX_PIX (128 * 128 * 3 / 2)
+static __thread struct {
+    int       valid, n, cur;   /* cur: mds index of the block whose transform loops run now (-1: none of the batch) */
+    int       lo, hi;          /* the current block's entries (a block's entries are contiguous) */
+    uint8_t   predicted[SB_MAX_BLK];
+    EdEntry   e[SB_MAX_JOBS];
+    int32_t  *coeff;           /* [2 * SB_MAX_PIX], allocated at the thread's first superblock */
+    uint16_t *hs, *hp;
+} tls_sb;
+static long g_sb_launches, g_sb_blocks, g_sb_superblocks, g_sb_tx;
+
+void svt_hip_hook_encdec_sb_stats(long *superblocks, long *launches, long *blocks, long *calls) { *superblocks = g_sb_superblocks; *launches = g_sb_launches; *blocks = g_sb_blocks; *calls = g_sb_tx; }
+
+static int sb_hoistable(const BlkStruct *blk, const BlockGeom *g) {
+    return blk->prediction_mode_flag == INTER_MODE && !blk->use_intrabc && blk->prediction_unit_array[0].motion_mode == SIMPLE_TRANSLATION && !blk->is_interintra_used &&
+           g->bwidth > 4 && g->bheight > 4;
+}
+/* the prediction call of av1_encode_decode (:2946-3004) for one block */
+static void sb_predict(SequenceControlSet *scs, PictureControlSet *pcs, SuperBlock *sb, EncDecContext *ctx, BlkStruct *blk, const BlockGeom *g, uint32_t org_x, uint32_t org_y,
+                       EbPictureBufferDesc *recon, int is_16bit) {
+    ModeDecisionContext *md = ctx->md_context;
+    const int8_t ref_idx_l0 = md->md_local_blk_unit[g->blkidx_mds].ref_frame_index_l0, ref_idx_l1 = md->md_local_blk_unit[g->blkidx_mds].ref_frame_index_l1;
+    MvReferenceFrame rf[2];
+    av1_set_ref_frame(rf, blk->prediction_unit_array[0].ref_frame_type);
+    const uint8_t list_idx0 = get_list_idx(rf[0]), list_idx1 = rf[1] == NONE_FRAME ? get_list_idx(rf[0]) : get_list_idx(rf[1]);
+    EbReferenceObject *ref_obj_0 = ref_idx_l0 >= 0 ? (EbReferenceObject *)pcs->ref_pic_ptr_array[list_idx0][ref_idx_l0]->object_ptr : NULL;
+    EbReferenceObject *ref_obj_1 = ref_idx_l1 >= 0 ? (EbReferenceObject *)pcs->ref_pic_ptr_array[list_idx1][ref_idx_l1]->object_ptr : NULL;
+    EbPictureBufferDesc *ref0 = ref_obj_0 ? (is_16bit ? ref_obj_0->reference_picture16bit : ref_obj_0->reference_picture) : NULL;
+    EbPictureBufferDesc *ref1 = ref_obj_1 ? (is_16bit ? ref_obj_1->reference_picture16bit : ref_obj_1->reference_picture) : NULL;
+    const PredictionUnit *pu = blk->prediction_unit_array;
+    MvUnit mvu;
+    mvu.pred_direction = (uint8_t)pu->inter_pred_direction_index;
+    mvu.mv[REF_LIST_0].mv_union = pu->mv[REF_LIST_0].mv_union;
+    mvu.mv[REF_LIST_1].mv_union = pu->mv[REF_LIST_1].mv_union;
+    /* what generate_av1_mvp_table leaves in the superblock's MacroBlockD for this block: the motion-vector clamp of the predictor reads it */
+    MacroBlockD *xd = blk->av1xd;
+    const Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    const int32_t mi_row = org_y >> MI_SIZE_LOG2, mi_col = org_x >> MI_SIZE_LOG2, bw = mi_size_wide[g->bsize], bh = mi_size_high[g->bsize];
+    xd->mb_to_top_edge = -((mi_row * MI_SIZE) * 8); xd->mb_to_bottom_edge = ((cm->mi_rows - bh - mi_row) * MI_SIZE) * 8;
+    xd->mb_to_left_edge = -((mi_col * MI_SIZE) * 8); xd->mb_to_right_edge = ((cm->mi_cols - bw - mi_col) * MI_SIZE) * 8;
+    const uint16_t tile_idx = ctx->tile_index;
+    NeighborArrayUnit *nl = is_16bit ? pcs->ep_luma_recon_neighbor_array16bit[tile_idx] : pcs->ep_luma_recon_neighbor_array[tile_idx];
+    NeighborArrayUnit *ncb = is_16bit ? pcs->ep_cb_recon_neighbor_array16bit[tile_idx] : pcs->ep_cb_recon_neighbor_array[tile_idx];
+    NeighborArrayUnit *ncr = is_16bit ? pcs->ep_cr_recon_neighbor_array16bit[tile_idx] : pcs->ep_cr_recon_neighbor_array[tile_idx];
+    if (is_16bit && !(scs->static_config.superres_mode > SUPERRES_NONE))
+        av1_inter_prediction_16bit_pipeline(pcs, blk->interp_filters, blk, pu->ref_frame_type, &mvu, 0, pu->motion_mode, 0, 0, blk->compound_idx, &blk->interinter_comp, &sb->tile_info, nl,
+                                            ncb, ncr, blk->is_interintra_used, blk->interintra_mode, blk->use_wedge_interintra, blk->interintra_wedge_index, (uint16_t)org_x, (uint16_t)org_y,
+                                            g->bwidth, g->bheight, ref0, ref1, recon, (uint16_t)org_x, (uint16_t)org_y, EB_TRUE, (uint8_t)scs->static_config.encoder_bit_depth);
+    else
+        av1_inter_prediction(pcs, blk->interp_filters, blk, pu->ref_frame_type, &mvu, 0, pu->motion_mode, 0, 0, blk->compound_idx, &blk->interinter_comp, &sb->tile_info, nl, ncb, ncr,
+                             blk->is_interintra_used, blk->interintra_mode, blk->use_wedge_interintra, blk->interintra_wedge_index, (uint16_t)org_x, (uint16_t)org_y, g->bwidth, g->bheight,
+                             ref0, ref1, recon, (uint16_t)org_x, (uint16_t)org_y, EB_TRUE, (uint8_t)scs->static_config.encoder_bit_depth);
+}
+
+/* av1_encode_decode, right before its block loop (:2262): 1 = blocks of this superblock were predicted and their transforms are cached */
+int svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pcs, SuperBlock *sb, uint32_t sb_addr, uint32_t sb_origin_x, uint32_t sb_origin_y, EncDecContext *ctx,
+                                 EbPictureBufferDesc *recon, int is_16bit) {
+    tls_sb.valid = 0; tls_sb.cur = -1;
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ENCDEC_SB) || scs->max_block_cnt > SB_MAX_BLK || pcs->slice_type == I_SLICE) return 0;
+    if (!tls_sb.coeff) {
+        tls_sb.coeff = (int32_t *)malloc(sizeof(int32_t) * 2 * SB_MAX_PIX); tls_sb.hs = (uint16_t *)malloc(sizeof(uint16_t) * SB_MAX_PIX); tls_sb.hp = (uint16_t *)malloc(sizeof(uint16_t) * SB_MAX_PIX);
+        if (!tls_sb.coeff || !tls_sb.hs || !tls_sb.hp) { free(tls_sb.coeff); free(tls_sb.hs); free(tls_sb.hp); tls_sb.coeff = NULL; tls_sb.hs = tls_sb.hp = NULL; return 0; }
+    }
+    static __thread uint32_t       desc[SB_MAX_JOBS];
+    static __thread SvtHipFwdTxJob jobs[SB_MAX_JOBS];
+    EdBatch B = {tls_sb.hs, tls_sb.hp, SB_MAX_PIX, 0, desc, jobs, tls_sb.e, SB_MAX_JOBS, 0, 2 * SB_MAX_PIX, 0};
+    memset(tls_sb.predicted, 0, scs->max_block_cnt);
+    ModeDecisionContext *md = ctx->md_context;
+    const int sb128 = scs->seq_header.sb_size == BLOCK_128X128;
+    int nblk = 0;
+    /* the walk of the block loop (:2262-3785): the final partition of the superblock */
+    uint32_t blk_it = 0;
+    while (blk_it < scs->max_block_cnt) {
+        const BlockGeom *g0 = get_blk_geom_mds(blk_it);
+        const PartitionType part = md->md_blk_arr_nsq[blk_it].part;
+        if (part != PARTITION_SPLIT && pcs->parent_pcs_ptr->sb_geom[sb_addr].block_is_allowed[blk_it]) {
+            const int32_t first = (int32_t)blk_it + (int32_t)ns_blk_offset[(int32_t)part], count = (int32_t)ns_blk_num[(int32_t)part];
+            for (int32_t d1 = first; d1 < first + count; d1++) {
+                const BlockGeom *g = get_blk_geom_mds((uint32_t)d1);
+                BlkStruct *blk = &md->md_blk_arr_nsq[d1];
+                if (!sb_hoistable(blk, g)) continue;
+                const uint32_t org_x = sb_origin_x + g->origin_x, org_y = sb_origin_y + g->origin_y;
+                blk->mds_idx = (uint16_t)d1;   /* the loop sets it for the first block of a partition only (:2274); the predictor looks the geometry up by it */
+                sb_predict(scs, pcs, sb, ctx, blk, g, org_x, org_y, recon, is_16bit);
+                tls_sb.predicted[d1] = 1;   /* predicted: the loop must not predict again, whether or not the transforms fitted the batch */
+                nblk++;
+                (void)ed_gather_block(&B, ctx, blk, g, org_x, org_y, recon, is_16bit);
+            }
+            blk_it += ns_depth_offset[sb128][g0->depth];
+        } else
+            blk_it += d1_depth_offset[sb128][g0->depth];
+    }
+    if (!nblk) return 0;
+    __sync_fetch_and_add(&g_sb_superblocks, 1);
+    __sync_fetch_and_add(&g_sb_blocks, nblk);
+    tls_sb.valid = 1; tls_sb.n = 0;
+    if (B.n) {
+        const int rc = ed_launch(&B, tls_sb.coeff);
+        svt_hip_hooks_count(SVT_HIP_HOOK_ENCDEC_SB, rc == SVT_HIP_OK);
+        if (rc == SVT_HIP_OK) { tls_sb.n = B.n; __sync_fetch_and_add(&g_sb_launches, 1); }   /* not handled: the predictions stand, the transforms run on the host */
+    }
+    return 1;
+}
+/* the block loop, in front of the prediction of an inter block: 1 = it is in the reconstruction buffer already */
+int svt_hip_hook_encdec_sb_predicted(const BlkStruct *blk) { return tls_sb.valid && blk->mds_idx < SB_MAX_BLK && tls_sb.predicted[blk->mds_idx]; }
+void svt_hip_hook_encdec_sb_end(void) { tls_sb.valid = 0; tls_sb.cur = -1; }
+static int sb_begin_block(const BlkStruct *blk) {
+    tls_sb.cur = -1;
+    if (!tls_sb.valid || !tls_sb.n || blk->mds_idx >= SB_MAX_BLK || !tls_sb.predicted[blk->mds_idx]) return 0;
+    tls_sb.cur = blk->mds_idx;
+    tls_sb.lo = 0;
+    while (tls_sb.lo < tls_sb.n && tls_sb.e[tls_sb.lo].blk != tls_sb.cur) tls_sb.lo++;
+    tls_sb.hi = tls_sb.lo;
+    while (tls_sb.hi < tls_sb.n && tls_sb.e[tls_sb.hi].blk == tls_sb.cur) tls_sb.hi++;
+    return tls_sb.hi > tls_sb.lo;
+}
+static void sb_end_block(void) { tls_sb.cur = -1; }
+static int sb_fetch(int plane, int txb, int tx_size, int tx_type, int32_t *coeff) {
+    if (tls_sb.cur < 0) return 0;
+    for (int i = tls_sb.lo; i < tls_sb.hi; i++) {
+        const EdEntry *e = &tls_sb.e[i];
+        if (e->plane == plane && e->txb == txb && e->tx_size == tx_size && e->tx_type == tx_type) {
+            memcpy(coeff, tls_sb.coeff + e->off, sizeof(int32_t) * (size_t)e->count);
+            __sync_fetch_and_add(&g_sb_tx, 1);
+            return 1;
+        }
+    }
+    return 0;
+}
 
 /* ---------------------------------------------------------------------------------------------------------------------------------------------------
  * Mode decision's sub-pel refinement, hook "md_subpel": one round of svt_av1_find_best_sub_pixel_tree (mcomp.c:350; md_subpel_search, EbProductCodingLoop.c:2063)
@@ -298,6 +471,6 @@ void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
 
 /* the shared staging buffers of the three hooks above (svt_hip_hooks_enc_deinit) */
 void svt_hip_md_bridge_release(SvtHipCtx *hip) {
-    void **all[] = {&d_src, &d_pred, &d_desc, &d_coeff, &d_ed_src, &d_ed_pred, &d_ed_desc, &d_ed_coeff, &d_sp_ref, &d_sp_src, &d_sp_pred, &d_sp_job, &d_sp_out};
+    void **all[] = {&d_src, &d_pred, &d_desc, &d_coeff, &d_sp_ref, &d_sp_src, &d_sp_pred, &d_sp_job, &d_sp_out};
     for (unsigned i = 0; i < sizeof(all) / sizeof(all[0]); i++) { svt_hip_free(hip, *all[i]); *all[i] = NULL; }
 }

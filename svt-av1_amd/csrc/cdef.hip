@@ -19,6 +19,7 @@
 // reference's inbuf (EbCdefProcess.c:210-226).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "svt_hip_internal.h"
 #include "lds_stage.h"
 
@@ -193,6 +194,9 @@ __device__ __forceinline__ void pixel_terms(const uint16_t* px, int tstride, int
 #pragma unroll
     for (int idx = 1; idx < 16; idx++) {
         const int t = t_of[idx];   // wave-uniform
+        // luma: adjust_strength() maps the 16 frame-header strengths onto fewer effective ones in a low-variance block (it is monotone, so equal values are
+        // neighbours): the sum of a repeated value is the previous index's
+        if (t == t_of[idx - 1]) { T.pri2[idx] = T.pri2[idx - 1]; continue; }
         int s = 0;
         if (t) {
             const int shift = max(0, damping - msb(t));
@@ -274,14 +278,18 @@ __device__ __forceinline__ int filter_px_single(const uint16_t* px, int tstride,
 template <typename PIX> struct Dots;
 template <> struct Dots<uint8_t> {
     static __device__ __forceinline__ void run(const uint8_t* a, const uint8_t* b, uint32_t& sa, uint32_t& saa, uint32_t& sab) {
-        const uint32_t* pa = (const uint32_t*)a; const uint32_t* pb = (const uint32_t*)b;
+        const uint4* pa = (const uint4*)a; const uint4* pb = (const uint4*)b;   // rows are 16-byte aligned (ytab / stab declarations): four 128-bit LDS reads each
         sa = saa = sab = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t va = pa[k], vb = pb[k];
-            sa  = __builtin_amdgcn_udot4(va, 0x01010101u, sa, false);
-            saa = __builtin_amdgcn_udot4(va, va, saa, false);
-            sab = __builtin_amdgcn_udot4(va, vb, sab, false);
+        for (int k = 0; k < 4; k++) {
+            const uint4 qa = pa[k], qb = pb[k];
+            const uint32_t va[4] = {qa.x, qa.y, qa.z, qa.w}, vb[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                sa  = __builtin_amdgcn_udot4(va[m], 0x01010101u, sa, false);
+                saa = __builtin_amdgcn_udot4(va[m], va[m], saa, false);
+                sab = __builtin_amdgcn_udot4(va[m], vb[m], sab, false);
+            }
         }
     }
 };
@@ -289,15 +297,20 @@ template <> struct Dots<uint16_t> {
     // packed pairs through v_dot2_u32_u16; 64 samples of <= 12 bits: every sum stays below 2^32
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ void run(const uint16_t* a, const uint16_t* b, uint32_t& sa, uint32_t& saa, uint32_t& sab) {
-        const uint32_t* pa = (const uint32_t*)a; const uint32_t* pb = (const uint32_t*)b;
+        const uint4* pa = (const uint4*)a; const uint4* pb = (const uint4*)b;
         sa = saa = sab = 0;
         const u16x2 ones = {1, 1};
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const u16x2 va = __builtin_bit_cast(u16x2, pa[k]), vb = __builtin_bit_cast(u16x2, pb[k]);
-            sa  = __builtin_amdgcn_udot2(va, ones, sa, false);
-            saa = __builtin_amdgcn_udot2(va, va, saa, false);
-            sab = __builtin_amdgcn_udot2(va, vb, sab, false);
+        for (int k = 0; k < 8; k++) {
+            const uint4 qa = pa[k], qb = pb[k];
+            const uint32_t wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const u16x2 va = __builtin_bit_cast(u16x2, wa[m]), vb = __builtin_bit_cast(u16x2, wb[m]);
+                sa  = __builtin_amdgcn_udot2(va, ones, sa, false);
+                saa = __builtin_amdgcn_udot2(va, va, saa, false);
+                sab = __builtin_amdgcn_udot2(va, vb, sab, false);
+            }
         }
     }
 };
@@ -313,7 +326,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
 }
 
 // ------------------------------------------------------------------------------- search, luma ---
-template <typename PIX>
+template <typename PIX, bool DEDUPE_OFF = false>
 __global__ void __launch_bounds__(256)
 cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* __restrict__ src, int src_stride, int w, int h,
                         const uint8_t* __restrict__ skip8, int pri_damping, int cs, uint64_t* __restrict__ mse,
@@ -351,10 +364,23 @@ cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* 
         for (int idx = 0; idx < 16; idx++) t_of[idx] = adjust_strength(idx << cs, var);
         PixelTerms T;
         pixel_terms(px, TS, dir, t_of, cs, damping, T);
+        // Primary indices whose effective strength equals the previous index's filter identically (same sums, same direction, same clamps): only the first index of
+        // such a run is combined and stored; rep4 = 16 x 4 bits, the first index of every index's run (wave-uniform).  A block of low directional variance has 5 .. 9
+        // distinct effective strengths out of 16 (adjust_strength, EbCdef.c:112-116).
+        unsigned long long rep4 = 0;
+        int first = 0;
 #pragma unroll
-        for (int g = 0; g < 64; g += 2) {
-            const s16x2 y = combine2(T, g >> 2, (g >> 1) & 1);
-            ytab[wave][g][lane] = (PIX)y.x; ytab[wave][g + 1][lane] = (PIX)y.y;
+        for (int pi = 0; pi < 16; pi++) {
+            const bool fresh = DEDUPE_OFF || pi <= 1 || t_of[pi] != t_of[pi - 1];   // index 0 filters along direction 0 (EbCdef.c:371 `t ? dir : 0` tests the frame-header strength): it never shares a row, even when index 1 is adjusted to 0
+            if (fresh) {
+                first = pi;
+#pragma unroll
+                for (int pair = 0; pair < 2; pair++) {
+                    const s16x2 y = combine2(T, pi, pair);
+                    ytab[wave][4 * pi + 2 * pair][lane] = (PIX)y.x; ytab[wave][4 * pi + 2 * pair + 1][lane] = (PIX)y.y;
+                }
+            }
+            rep4 |= (unsigned long long)first << (4 * pi);
         }
         const uint32_t sv = src[(size_t)(64 * fbr + 8 * by + i) * src_stride + 64 * fbc + 8 * bx + j];
         stab[wave][lane] = (PIX)sv;
@@ -362,7 +388,8 @@ cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* 
         // lane g reduces strength g: dist_8x8 (EbEncCdef.c:79-105), names as in the reference:
         //   s = filtered ("src" there), d = source picture ("dst" there)
         uint32_t sum_s, sum_s2, sum_sd;
-        Dots<PIX>::run(&ytab[wave][lane][0], &stab[wave][0], sum_s, sum_s2, sum_sd);
+        const int row = (int)((rep4 >> (4 * (lane >> 2))) & 15) * 4 + (lane & 3);
+        Dots<PIX>::run(&ytab[wave][row][0], &stab[wave][0], sum_s, sum_s2, sum_sd);
         const uint32_t sum_d = wave_sum_u32(sv), sum_d2 = wave_sum_u32(sv * sv);   // the same for every strength
         const uint64_t svar = (uint64_t)sum_s2 - (((uint64_t)sum_s * sum_s + 32) >> 6);
         const uint64_t dvar = (uint64_t)sum_d2 - (((uint64_t)sum_d * sum_d + 32) >> 6);
@@ -519,8 +546,13 @@ template <typename PIX>
 int search_t(hipStream_t st, const void* const rec[3], const int rs[3], const void* const src[3], const int ss[3], int w, int h,
              const uint8_t* skip8, int pri_damping, int cs, uint64_t* mse, uint8_t* dir_buf, int32_t* var_buf) {
     const int nfb = ((w + 63) >> 6) * ((h + 63) >> 6);
-    hipLaunchKernelGGL((cdef_search_luma_kernel<PIX>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[0], rs[0], (const PIX*)src[0], ss[0], w, h,
-                       skip8, pri_damping, cs, mse, dir_buf, var_buf);
+    static const bool dedupe_off = getenv("SVT_HIP_CDEF_DEDUPE") && !atoi(getenv("SVT_HIP_CDEF_DEDUPE"));   // A/B: every primary index combined and stored (round 3)
+    if (dedupe_off)
+        hipLaunchKernelGGL((cdef_search_luma_kernel<PIX, true>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[0], rs[0], (const PIX*)src[0], ss[0], w, h,
+                           skip8, pri_damping, cs, mse, dir_buf, var_buf);
+    else
+        hipLaunchKernelGGL((cdef_search_luma_kernel<PIX>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[0], rs[0], (const PIX*)src[0], ss[0], w, h,
+                           skip8, pri_damping, cs, mse, dir_buf, var_buf);
     hipLaunchKernelGGL((cdef_search_chroma_kernel<PIX>), dim3(nfb), dim3(256), 0, st, (const PIX*)rec[1], (const PIX*)rec[2], rs[1],
                        (const PIX*)src[1], (const PIX*)src[2], ss[1], w, h, skip8, pri_damping, cs, mse + (size_t)nfb * 64, dir_buf);
     return (int)hipGetLastError();

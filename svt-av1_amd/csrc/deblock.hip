@@ -218,14 +218,18 @@ int launch_frame(hipStream_t st, const DeblockFrame& f, int sharp) {
 // phase needs the VERTICALLY FILTERED rows y0 - 7 .. y1 + 6 of the tile's columns; a vertical edge at column c reads the unfiltered columns c - 7 .. c + 6,
 // so those rows need the unfiltered columns x0 - 7 .. x1 + 6.  The region (142 x 78 samples) is staged in LDS once, the vertical edges x0 .. x1 of all 78
 // rows are filtered there (edges of one direction are independent: the filter length is bounded by the smaller transform next to the edge), then the horizontal
-// edges y0 .. y1 of the tile's 128 columns, then the tile is written: 1.35 x the picture read once + the picture written once, instead of two read-modify-write
+// edges y0 .. y1 of the tile's 128 columns, then the tile is written: 1.37 x the picture read once + the picture written once, instead of two read-modify-write
 // passes.  The staged region's samples outside the tile are filtered redundantly (they are some neighbour's to write).
 struct DeblockFused { const void* src[3]; void* dst[3]; int stride[3]; const uint16_t* ev[3]; const uint16_t* eh[3]; int units_w[3], units_h[3], pw[3], ph[3]; int tiles_x[3], tiles_y[3]; };
-constexpr int kFW = 128, kFH = 64, kFHalo = 7, kFRW = kFW + 2 * kFHalo, kFRH = kFH + 2 * kFHalo, kFStride = kFRW + 3;   // 145 halfwords per row: odd dword phase between rows
+constexpr int kFW = 128, kFH = 64, kFHalo = 7, kFPad = 8, kFRH = kFH + 2 * kFHalo;   // staged columns x0 - 8 .. x0 + 135 (dword-aligned for both sample sizes)
+constexpr int kFRowB = 144;   // staged samples per row
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(256)
 deblock_fused_kernel(const DeblockFused f, int sharpness) {
-    __shared__ uint16_t t[kFRH * kFStride];
+    // samples stay in their own type on chip (global <-> LDS moves are whole dwords); row stride = 37 dwords of 8-bit / 73 of 16-bit samples: odd, so the rows of
+    // one wave's lanes start in different banks
+    constexpr int SPD = 4 / (int)sizeof(PIX), RD = kFRowB / SPD, RS = (RD + 1) * SPD;   // samples per dword, dwords per staged row, row stride in samples
+    __shared__ __attribute__((aligned(16))) PIX t[kFRH * RS];
     const int p = blockIdx.z;
     const PIX* src = (const PIX*)(p == 0 ? f.src[0] : (p == 1 ? f.src[1] : f.src[2]));
     PIX* dst = (PIX*)(p == 0 ? f.dst[0] : (p == 1 ? f.dst[1] : f.dst[2]));
@@ -236,59 +240,87 @@ deblock_fused_kernel(const DeblockFused f, int sharpness) {
     const uint16_t* eh = p == 0 ? f.eh[0] : (p == 1 ? f.eh[1] : f.eh[2]);
     const int units_w = p == 0 ? f.units_w[0] : (p == 1 ? f.units_w[1] : f.units_w[2]), units_h = p == 0 ? f.units_h[0] : (p == 1 ? f.units_h[1] : f.units_h[2]);
     const int pw = p == 0 ? f.pw[0] : (p == 1 ? f.pw[1] : f.pw[2]), ph = p == 0 ? f.ph[0] : (p == 1 ? f.ph[1] : f.ph[2]);
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, x0 = tx * kFW, y0 = ty * kFH, tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, x0 = tx * kFW, y0 = ty * kFH, tid = threadIdx.x;
     const int tw = min(kFW, pw - x0), th = min(kFH, ph - y0);
-    // region origin in the plane: (x0 - 7, y0 - 7); t[r][c] <-> plane (x0 - 7 + c, y0 - 7 + r); samples outside the plane are never read by a filter
-    for (int i = tid; i < kFRH * kFRW; i += 256) {
-        const int r = i / kFRW, c = i - r * kFRW, x = x0 - kFHalo + c, y = y0 - kFHalo + r;
-        t[r * kFStride + c] = (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)src[(size_t)y * stride + x] : (uint16_t)0;
-    }
-    __syncthreads();
-    // vertical edges at columns x0 + 4k, k = 0 .. tw / 4 (the last one is the right neighbour's first edge: it changes this tile's last columns), every staged row
+    // t[r][c] <-> plane (x0 - 8 + c, y0 - 7 + r).  Whole dwords when the plane allows it (base and stride dword-aligned, the dword inside the row), else sample by sample.
+    const bool fast = ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) && ((stride * (int)sizeof(PIX)) & 3) == 0;
     {
-        const int ne = (tw >> 2) + 1, rows = min(th + 2 * kFHalo, kFRH);
-        for (int i = tid; i < rows * ne; i += 256) {
-            const int r = i / ne, k = i - r * ne, y = y0 - kFHalo + r, x = x0 + 4 * k;
-            if (y < 0 || y >= ph || x >= pw || (x >> 2) >= units_w || (y >> 2) >= units_h) continue;
-            const uint32_t e = ev[(y >> 2) * units_w + (x >> 2)];
-            const int len = e & 0xff, level = (int)(e >> 8);
-            if (!len || !level) continue;
-            const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
-            uint16_t* s = t + r * kFStride + kFHalo + 4 * k;
-            int px[14];
+        for (int i = tid; i < kFRH * RD; i += 256) {
+            const int r = i / RD, d = i - r * RD, y = y0 - kFHalo + r, x = x0 - kFPad + d * SPD;
+            uint32_t v = 0;
+            if (y >= 0 && y < ph) {
+                const PIX* row = src + (size_t)y * stride;
+                if (fast && x >= 0 && x + SPD <= pw) v = *(const uint32_t*)(row + x);
+                else {
 #pragma unroll
-            for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q] : 0; px[6 + q] = (q <= half) ? (int)s[q - 1] : 0; }
-            const int changed = lpf_core<BD>(px, len, level, sharpness);
-#pragma unroll
-            for (int q = 1; q <= 6; q++)
-                if (q <= changed) { s[-q] = (uint16_t)px[7 - q]; s[q - 1] = (uint16_t)px[6 + q]; }
+                    for (int k = 0; k < SPD; k++)
+                        if (x + k >= 0 && x + k < pw) v |= (uint32_t)row[x + k] << (8 * (int)sizeof(PIX) * k);
+                }
+            }
+            *(uint32_t*)(t + r * RS + d * SPD) = v;
         }
     }
     __syncthreads();
-    // horizontal edges at rows y0 + 4k, k = 0 .. th / 4, the tile's columns
+    // vertical edges at columns x0 + 4k: k = 0 .. 31 by the lanes of a 32-lane group, the rows by the eight groups; k = tw / 4 (the right neighbour's first edge, which
+    // changes this tile's last columns) by one more sweep over the rows
+    auto vertical = [&](int r, int k) {
+        const int y = y0 - kFHalo + r, x = x0 + 4 * k;
+        if (y < 0 || y >= ph || x >= pw || (x >> 2) >= units_w || (y >> 2) >= units_h) return;
+        const uint32_t e = ev[(y >> 2) * units_w + (x >> 2)];
+        const int len = e & 0xff, level = (int)(e >> 8);
+        if (!len || !level) return;
+        const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+        PIX* s = t + r * RS + kFPad + 4 * k;
+        int px[14];
+#pragma unroll
+        for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q] : 0; px[6 + q] = (q <= half) ? (int)s[q - 1] : 0; }
+        const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+        for (int q = 1; q <= 6; q++)
+            if (q <= changed) { s[-q] = (PIX)px[7 - q]; s[q - 1] = (PIX)px[6 + q]; }
+    };
     {
-        const int ne = (th >> 2) + 1;
-        for (int i = tid; i < ne * tw; i += 256) {
-            const int k = i / tw, c = i - k * tw, y = y0 + 4 * k, x = x0 + c;
-            if (y >= ph || (y >> 2) >= units_h) continue;
-            const uint32_t e = eh[(y >> 2) * units_w + (x >> 2)];
-            const int len = e & 0xff, level = (int)(e >> 8);
-            if (!len || !level) continue;
-            const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
-            uint16_t* s = t + (kFHalo + 4 * k) * kFStride + kFHalo + c;
-            int px[14];
-#pragma unroll
-            for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q * kFStride] : 0; px[6 + q] = (q <= half) ? (int)s[(q - 1) * kFStride] : 0; }
-            const int changed = lpf_core<BD>(px, len, level, sharpness);
-#pragma unroll
-            for (int q = 1; q <= 6; q++)
-                if (q <= changed) { s[-q * kFStride] = (uint16_t)px[7 - q]; s[(q - 1) * kFStride] = (uint16_t)px[6 + q]; }
-        }
+        const int rows = th + 2 * kFHalo, k = tid & 31, ne = tw >> 2;
+        if (k < ne)
+            for (int r = tid >> 5; r < rows; r += 8) vertical(r, k);
+        if (tid < rows) vertical(tid, ne);
     }
     __syncthreads();
-    for (int i = tid; i < th * tw; i += 256) {
-        const int r = i / tw, c = i - r * tw;
-        dst[(size_t)(y0 + r) * stride + x0 + c] = (PIX)t[(kFHalo + r) * kFStride + kFHalo + c];
+    // horizontal edges at rows y0 + 4k, k = 0 .. th / 4: the tile's 128 columns by the lanes, even / odd k by the two halves of the workgroup
+    {
+        const int c = tid & 127, ne = (th >> 2) + 1;
+        if (c < tw)
+            for (int k = tid >> 7; k < ne; k += 2) {
+                const int y = y0 + 4 * k, x = x0 + c;
+                if (y >= ph || (y >> 2) >= units_h) continue;
+                const uint32_t e = eh[(y >> 2) * units_w + (x >> 2)];
+                const int len = e & 0xff, level = (int)(e >> 8);
+                if (!len || !level) continue;
+                const int half = len == 4 ? 2 : (len == 6 ? 3 : (len == 8 ? 4 : 7));
+                PIX* s = t + (kFHalo + 4 * k) * RS + kFPad + c;
+                int px[14];
+#pragma unroll
+                for (int q = 1; q <= 7; q++) { px[7 - q] = (q <= half) ? (int)s[-q * RS] : 0; px[6 + q] = (q <= half) ? (int)s[(q - 1) * RS] : 0; }
+                const int changed = lpf_core<BD>(px, len, level, sharpness);
+#pragma unroll
+                for (int q = 1; q <= 6; q++)
+                    if (q <= changed) { s[-q * RS] = (PIX)px[7 - q]; s[(q - 1) * RS] = (PIX)px[6 + q]; }
+            }
+    }
+    __syncthreads();
+    {
+        constexpr int TD = kFW / SPD;   // dwords per tile row: 32 / 64
+        const int d = tid % TD, x = x0 + d * SPD;
+        for (int r = tid / TD; r < th; r += 256 / TD) {
+            const PIX* s = t + (kFHalo + r) * RS + kFPad + d * SPD;
+            PIX* o = dst + (size_t)(y0 + r) * stride + x;
+            if (fast && x + SPD <= pw) *(uint32_t*)o = *(const uint32_t*)s;
+            else {
+#pragma unroll
+                for (int k = 0; k < SPD; k++)
+                    if (x + k < pw) o[k] = s[k];
+            }
+        }
     }
 }
 template <typename PIX, int BD>

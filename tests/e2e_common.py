@@ -15,7 +15,7 @@ APP_REF = os.path.join(REFDIR, "SvtAv1EncApp_ref")
 APP_HIP = os.path.join(REFDIR, "SvtAv1EncApp_hip")
 MOCK_DIR = os.path.join(REFDIR, "mock")
 HOOKS = ["pa", "tf", "tf_me", "tf_subpel", "hme", "me", "cdef_finish", "dlf", "dlf_search", "cdef_search", "cdef_apply", "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search"]
-OPT_IN_HOOKS = ["md_tx", "encdec_tx", "md_subpel"]   # not selected by SVT_HIP_HOOKS=all: named explicitly (one launch per transform block of every mode-decision candidate)
+OPT_IN_HOOKS = ["md_tx", "encdec_tx", "md_subpel", "encdec_sb"]   # not selected by SVT_HIP_HOOKS=all: named explicitly (one launch per transform block of every mode-decision candidate)
 # wiener_search hooks the whole Wiener search of a picture and takes precedence over the two hooks of the per-unit path
 PER_UNIT_WIENER = {"wiener_stats", "wiener_try"}
 ALL_PICTURE_LEVEL = ",".join(h for h in HOOKS if h not in PER_UNIT_WIENER)            # = what SVT_HIP_HOOKS=all effectively runs

@@ -193,5 +193,5 @@ def test_deblock_frame_fused(hip, orc, bd, size):
                     continue
                 assert np.array_equal(got[:ph, :pw], exp[i][:ph, :pw]), (bd, size, seed, i, np.argwhere(got[:ph, :pw] != exp[i][:ph, :pw])[:4])
                 assert (got[ph:] == 37).all() and (got[:, pw:] == 37).all(), "samples outside the plane extent were written"
-                assert (exp[i][:ph, :pw] != planes[i][:ph, :pw]).any()
+                assert i == 2 or (exp[i][:ph, :pw] != planes[i][:ph, :pw]).any()   # plane 2 is noise: nothing may be flat enough to filter
             hip.free(*d_p, *d_o, *d_ev, *d_eh)

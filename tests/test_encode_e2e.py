@@ -156,6 +156,61 @@ def test_encdec_tx_hook_matters(workdir):
     assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
 
 
+def _encdec_sb_line(log):
+    m = re.search(r"svt_hip_encdec_sb superblocks=(\d+) launches=(\d+) inter_blocks_predicted_ahead=(\d+) estimate_transform_calls_replaced=(\d+)", log)
+    assert m, log[-800:]
+    return tuple(int(v) for v in m.groups())
+
+
+def _check_encdec_sb(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "cif_8bit_m4")):
+    """hook "encdec_sb" (opt-in): ONE launch per superblock -- the plain-translation inter blocks of a superblock's final partition are predicted ahead of the block loop
+    of av1_encode_decode (the reference's own predictor, called early) and the forward transforms of all their transform blocks run in one launch.  The bitstream
+    must not change; launches <= superblocks of the inter pictures; several blocks per launch on average."""
+    out = {}
+    for case in cases:
+        spec = {**CASES, **GPU_ONLY_CASES}[case]
+        got = _check(case, spec[:6] + ({"encdec_sb"},), workdir, env, tag + "_" + case)
+        sbs, launches, blocks, calls = _encdec_sb_line(got["log"])
+        w, h, n = spec[:3]
+        print(f"encdec_sb {case}: {launches} launches for {sbs} superblocks with inter blocks, {blocks} blocks predicted ahead, {calls} av1_estimate_transform calls replaced")
+        assert 0 < launches <= sbs <= ((w + 63) // 64) * ((h + 63) // 64) * (n - 1), (sbs, launches)   # the first picture is intra-only
+        assert blocks > 2 * launches and calls >= blocks, (blocks, calls, launches)
+        out[case] = got
+    return out
+
+
+def test_encdec_sb_hook_on_cpu_test_double(workdir):
+    _check_encdec_sb(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "encdec_sb"}, "mock_edsb")
+    # with every picture-level hook and the other opt-in hooks of the encode pass / mode decision (encdec_tx then only sees the blocks the superblock launch left out)
+    case = "cif_8bit_m4"
+    both = _check(case, CASES[case][:6] + (ALL | {"md_tx", "encdec_sb"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all,md_tx,encdec_tx,encdec_sb"}, "mock_all_edsb")
+    assert both["hooks"]["encdec_sb"][0] > 20
+
+
+def test_encdec_sb_geometries_on_cpu_test_double(workdir):
+    """128 x 128 superblocks, a padded source size, the slowest and the fastest preset"""
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "encdec_sb"}
+    for name, w, h, n, bd, preset, q, seed in (("sb128_edsb", 640, 360, 3, 8, 4, 42, 13), ("padded_edsb", 130, 66, 5, 8, 6, 38, 11), ("m8_edsb", 352, 288, 5, 10, 8, 36, 6), ("m2_edsb", 352, 288, 3, 8, 2, 40, 5)):
+        got = _check_geometry(name, w, h, n, bd, preset, q, seed, workdir, env, "mock", must={"encdec_sb"})
+        assert _encdec_sb_line(got["log"])[2] > 0
+
+
+def test_encdec_sb_hook_matters(workdir):
+    """a wrong coefficient out of the superblock's launch changes the encode: the encode pass really consumes it"""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_edsb"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "encdec_sb", "SVT_HIP_MOCK_PERTURB": "encdec_tx"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+
+
+@pytest.mark.gpu
+def test_encdec_sb_hook_on_gpu(workdir):
+    got = _check_encdec_sb(workdir, {"SVT_HIP_HOOKS": "encdec_sb"}, "hip_edsb", cases=("cif_8bit_m6", "cif_10bit_m6", "cif_8bit_m2", "720p_8bit_m6"))
+    assert all("svt_hip MOCK" not in g["log"] for g in got.values())
+
+
 def _check_md_subpel(workdir, env, tag, cases=("cif_8bit_m4", "cif_8bit_m6")):
     """hook "md_subpel" (opt-in): every round of mode decision's sub-pel tree takes its candidates' (variance, sse) from one batched launch pair"""
     out = {}
