@@ -499,6 +499,14 @@ int svt_hip_lr_try_units_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *
                              int unit_size, int ss_y, const void *d_dbl, int dbl_stride, const uint8_t *d_unit_ep, const int32_t *d_unit_xqd,
                              const int16_t *d_unit_wiener, const void *d_src, int src_stride, const SvtHipBlkPair *d_rects, int n_rects,
                              uint64_t *d_sse);
+/* finer_tile_search_wiener_seg (Encoder/Codec/EbRestorationPick.c:1092-1200) of EVERY restoration unit of a plane in one launch: for each unit u with d_active[u] != 0 the
+ * taps d_unit_wiener[u] (16 int16: vertical [0..7], horizontal [8..15], as svt_hip_lr_apply_plane_dev reads them) are refined by the reference's coordinate descent —
+ * step sizes 4 / 2 / 1, horizontal then vertical taps, a downward then an upward probe per tap, a probe accepted iff its error is not larger — every probe being
+ * try_restoration_unit_seg (:137): the unit filtered with the probed taps (stripe context rows from d_dbl, the deblocked picture) and its squared error against the
+ * source.  The walk and every probe stay on the device; d_unit_wiener[u] receives the refined taps, d_err[u] their error, d_probes[u] (may be NULL) the number of
+ * probes.  wiener_win: 7 / 5 / 3 (WIENER_WIN, _CHROMA, _3TAP: the outer taps of a shorter window are never probed).  Inactive units are left alone. */
+int svt_hip_wiener_walk_units_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride,
+                                  const void *d_src, int src_stride, int16_t *d_unit_wiener, const uint8_t *d_active, int wiener_win, int64_t *d_err, uint32_t *d_probes);
 
 /* ------------------------------------------------------------------ Wiener restoration search ---- */
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as

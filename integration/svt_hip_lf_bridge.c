@@ -927,49 +927,9 @@ EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_sta
 
 /* ---- every search_wiener_seg of the picture at once (EbRestorationPick.c:1347-1423) -------------------------------------------------
  * Statistics of all units in one launch per plane, initial filters by the reference's own decomposition (svt_hip_wiener_unit_init, in the patched
- * file), then finer_tile_search_wiener_seg (:1092) for all units IN LOCKSTEP: a round filters every unit that is still walking with its next probe
- * (svt_hip_lr_try_units_dev: one launch per plane) and brings the SSEs back; the walk of a unit below is the reference's coordinate descent as a
- * state machine (steps 4, 2, 1; horizontal taps then vertical taps; downward probe, then upward; at step 4 an accepted probe repeats). */
-typedef struct {
-    int        state;      /* 0 finished / not searched, 1 the initial filter is being evaluated, 2 a probe is being evaluated */
-    int        s, ph, p, up, skip, refined;
-    int64_t    err;
-    WienerInfo wi;         /* accepted taps; while state == 2 with the probe applied */
-} WnWalk;
-static void wn_apply(int16_t *f, int p, int d) { f[p] += (int16_t)d; f[WIENER_WIN - 1 - p] += (int16_t)d; f[WIENER_HALFWIN] -= (int16_t)(2 * d); }
-static int wn_issue(WnWalk *w, int off) {   /* moves to the next probe: 1 = one is outstanding, 0 = the walk is over */
-    static const int tmin[3] = {WIENER_FILT_TAP0_MINV, WIENER_FILT_TAP1_MINV, WIENER_FILT_TAP2_MINV};
-    static const int tmax[3] = {WIENER_FILT_TAP0_MAXV, WIENER_FILT_TAP1_MAXV, WIENER_FILT_TAP2_MAXV};
-    for (;;) {
-        if (w->s < 1) { w->state = 0; return 0; }
-        if (w->p >= WIENER_HALFWIN) {           /* this filter's taps are done: vertical after horizontal, then the next step size */
-            if (w->ph == 0) w->ph = 1; else { w->ph = 0; w->s >>= 1; }
-            w->p = off; w->up = 0; w->skip = 0;
-            continue;
-        }
-        int16_t *f = w->ph ? w->wi.vfilter : w->wi.hfilter;
-        if (!w->up) {
-            if (f[w->p] - w->s >= tmin[w->p]) { wn_apply(f, w->p, -w->s); w->state = 2; return 1; }
-            if (w->skip) w->p = WIENER_HALFWIN; else w->up = 1;    /* "if (skip) break" (:1126) */
-        } else {
-            if (f[w->p] + w->s <= tmax[w->p]) { wn_apply(f, w->p, w->s); w->state = 2; return 1; }
-            w->p++; w->up = 0; w->skip = 0;
-        }
-    }
-}
-static void wn_result(WnWalk *w, int64_t err2, int off) {
-    if (w->state == 1) { w->err = err2; w->s = 4; w->ph = 0; w->p = off; w->up = 0; w->skip = 0; wn_issue(w, off); return; }
-    int16_t  *f = w->ph ? w->wi.vfilter : w->wi.hfilter;
-    const int d = w->up ? w->s : -w->s, accepted = !(err2 > w->err);
-    if (!accepted) wn_apply(f, w->p, -d);
-    else { w->err = err2; if (!w->up) w->skip = 1; }
-    if (!(accepted && w->s == 4)) {             /* at the highest step size an accepted probe keeps moving in the same direction */
-        if (!w->up) { if (w->skip) w->p = WIENER_HALFWIN; else w->up = 1; }
-        else { w->p++; w->up = 0; w->skip = 0; }
-    }
-    wn_issue(w, off);
-}
-
+ * file), then finer_tile_search_wiener_seg (:1092) of every unit ON THE DEVICE: svt_hip_wiener_walk_units_dev runs each unit's coordinate descent and
+ * all of its probes (the unit filtered with the probed taps, squared error against the source) in one launch per plane — no host round trip per probe
+ * (round 3: 20 - 40 lockstep rounds per picture, each an upload, a launch and a download per plane). */
 static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
     PictureControlSet *pcs = s->pcs;
@@ -980,87 +940,58 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
         s->flags |= ST_WIENER_DONE;
     }
     EbErrorType ret = EB_ErrorNone;
-    WnWalk *walk[3] = {0}; SvtHipBlkPair *rect[3] = {0}; void *d_rect[3] = {0}, *d_sse[3] = {0};
-    uint8_t *ep[3] = {0}; int16_t *wn[3] = {0}; uint64_t *sse[3] = {0};
-    int n_active = 0;
+    uint8_t *act[3] = {0}; int16_t *wn[3] = {0}; int64_t *err[3] = {0}; uint32_t *probes[3] = {0}; int8_t *init[3] = {0};
+    void *d_act[3] = {0}, *d_err[3] = {0}, *d_probes[3] = {0};
+    long n_probes = 0, n_walks = 0;
     for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, us = rsi->restoration_unit_size, win = p->wiener_win[pl], w2 = win * win;
-        RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
-        walk[pl] = (WnWalk *)calloc(n, sizeof(WnWalk)); rect[pl] = (SvtHipBlkPair *)calloc(n, sizeof(SvtHipBlkPair));
-        ep[pl] = (uint8_t *)malloc(n); wn[pl] = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t)); sse[pl] = (uint64_t *)calloc(n, sizeof(uint64_t));
-        if (!walk[pl] || !rect[pl] || !ep[pl] || !wn[pl] || !sse[pl] || svt_hip_hooks_malloc(hip, &d_rect[pl], sizeof(SvtHipBlkPair) * n) != SVT_HIP_OK ||
-            svt_hip_hooks_malloc(hip, &d_sse[pl], sizeof(uint64_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
-        /* unit rectangles of foreach_rest_unit_in_tile (EbRestoration.c:1369-1411) */
-        const int ext = us * 3 / 2, voff = 8 >> (pl > 0), hunits = rsi->horz_units_per_tile;
-        int y0 = 0, i = 0;
-        while (y0 < ph) {
-            const int rem_h = ph - y0, h = rem_h < ext ? rem_h : us;
-            int v0 = y0 - voff > 0 ? y0 - voff : 0, v1 = y0 + h;
-            if (v1 < ph) v1 -= voff;
-            int x0 = 0, j = 0;
-            while (x0 < pw) {
-                const int rem_w = pw - x0, w = rem_w < ext ? rem_w : us, u = i * hunits + j;
-                if (u >= n) { ret = EB_ErrorUndefined; break; }
-                rect[pl][u].a_x = rect[pl][u].b_x = x0; rect[pl][u].a_y = rect[pl][u].b_y = v0; rect[pl][u].w = (uint16_t)w; rect[pl][u].h = (uint16_t)(v1 - v0);
-                x0 += w; j++;
-            }
-            if (ret != EB_ErrorNone) break;
-            y0 += h; i++;
-        }
-        if (ret != EB_ErrorNone || svt_hip_memcpy_h2d(hip, d_rect[pl], rect[pl], sizeof(SvtHipBlkPair) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, win = p->wiener_win[pl], w2 = win * win;
+        act[pl] = (uint8_t *)calloc(n, 1); wn[pl] = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t)); err[pl] = (int64_t *)calloc(n, sizeof(int64_t));
+        probes[pl] = (uint32_t *)calloc(n, sizeof(uint32_t)); init[pl] = (int8_t *)calloc(n, 1);
+        if (!act[pl] || !wn[pl] || !err[pl] || !probes[pl] || !init[pl] || svt_hip_hooks_malloc(hip, &d_act[pl], n) != SVT_HIP_OK ||
+            svt_hip_hooks_malloc(hip, &d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK || svt_hip_hooks_malloc(hip, &d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
         /* search_wiener_seg up to the refinement: decomposition, tap quantisation, score against the identity filter (the reference's own code) */
+        int any = 0;
         for (int u = 0; u < n; u++) {
-            WnWalk *w = &walk[pl][u];
-            memset(&w->wi, 0, sizeof(w->wi));
-            const int r = svt_hip_wiener_unit_init(win, p->h_wiener_M[pl] + (size_t)u * w2, p->h_wiener_H[pl] + (size_t)u * w2 * w2, &w->wi);
-            if (r == 1) { w->state = 1; w->refined = 1; n_active++; }
-            else { rusi[u].sse[RESTORE_WIENER] = INT64_MAX; if (r == 0) rusi[u].best_rtype[RESTORE_WIENER - 1] = RESTORE_NONE; }
-        }
-    }
-    int rounds = 0;
-    while (ret == EB_ErrorNone && n_active > 0) {
-        for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
-            const RestorationInfo *rsi = &cm->rst_info[pl];
-            const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile;
-            int any = 0;
-            for (int u = 0; u < n; u++) {
-                const WnWalk *w = &walk[pl][u];
-                ep[pl][u] = w->state ? 254 : 255;
-                any |= w->state;
-                memcpy(wn[pl] + 16 * u, w->wi.vfilter, 8 * sizeof(int16_t)); memcpy(wn[pl] + 16 * u + 8, w->wi.hfilter, 8 * sizeof(int16_t));
-            }
-            if (!any) continue;
-            if (svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl], ep[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
-                svt_hip_lr_try_units_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl], pw, ph,
-                                         rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl],
-                                         p->d_unit_wiener[pl], p->src[pl], p->src_st[pl], (const SvtHipBlkPair *)d_rect[pl], n, (uint64_t *)d_sse[pl]) != SVT_HIP_OK ||
-                svt_hip_memcpy_d2h(hip, sse[pl], d_sse[pl], sizeof(uint64_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
-            const int off = (WIENER_WIN - p->wiener_win[pl]) >> 1;
-            for (int u = 0; u < n; u++) {
-                WnWalk *w = &walk[pl][u];
-                if (!w->state) continue;
-                wn_result(w, (int64_t)sse[pl][u], off);
-                if (!w->state) n_active--;
+            WienerInfo wi;
+            memset(&wi, 0, sizeof(wi));
+            const int r = svt_hip_wiener_unit_init(win, p->h_wiener_M[pl] + (size_t)u * w2, p->h_wiener_H[pl] + (size_t)u * w2 * w2, &wi);
+            init[pl][u] = (int8_t)r;
+            if (r == 1) {
+                act[pl][u] = 1; any = 1; n_walks++;
+                memcpy(wn[pl] + 16 * u, wi.vfilter, 8 * sizeof(int16_t)); memcpy(wn[pl] + 16 * u + 8, wi.hfilter, 8 * sizeof(int16_t));
             }
         }
-        if (++rounds > 4096) ret = EB_ErrorUndefined;   /* cannot happen: a walk is bounded by the tap ranges */
+        if (!any) continue;
+        if (svt_hip_memcpy_h2d(hip, d_act[pl], act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
+            svt_hip_wiener_walk_units_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], pw, ph, rsi->restoration_unit_size, pl > 0,
+                                          plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->src[pl], p->src_st[pl], p->d_unit_wiener[pl], (const uint8_t *)d_act[pl],
+                                          win, (int64_t *)d_err[pl], (uint32_t *)d_probes[pl]) != SVT_HIP_OK ||
+            svt_hip_memcpy_d2h(hip, wn[pl], p->d_unit_wiener[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
+            svt_hip_memcpy_d2h(hip, err[pl], d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK || svt_hip_memcpy_d2h(hip, probes[pl], d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
+        for (int u = 0; u < n; u++) n_probes += act[pl][u] ? probes[pl][u] : 0;
     }
-    if (ret == EB_ErrorNone) {
+    if (ret == EB_ErrorNone) {   /* every plane has succeeded: only now do the reference's objects change */
         for (int pl = 0; pl < 3; pl++) {
             RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
-            for (int u = 0; u < cm->rst_info[pl].units_per_tile; u++)
-                if (walk[pl][u].refined) {
-                    rusi[u].sse[RESTORE_WIENER] = walk[pl][u].err;
-                    rusi[u].wiener = walk[pl][u].wi;
+            for (int u = 0; u < cm->rst_info[pl].units_per_tile; u++) {
+                if (act[pl][u]) {
+                    rusi[u].sse[RESTORE_WIENER] = err[pl][u];
+                    memset(&rusi[u].wiener, 0, sizeof(rusi[u].wiener));
+                    memcpy(rusi[u].wiener.vfilter, wn[pl] + 16 * u, 8 * sizeof(int16_t)); memcpy(rusi[u].wiener.hfilter, wn[pl] + 16 * u + 8, 8 * sizeof(int16_t));
+                } else {
+                    rusi[u].sse[RESTORE_WIENER] = INT64_MAX;
+                    if (init[pl][u] == 0) rusi[u].best_rtype[RESTORE_WIENER - 1] = RESTORE_NONE;
                 }
+            }
         }
-        svt_hip_hooks_log("wiener_search: %d lockstep rounds", rounds);
+        svt_hip_hooks_log("wiener_search: 1 launch per plane, %ld walks, %ld probes on the device", n_walks, n_probes);
     }
     for (int pl = 0; pl < 3; pl++) {
-        free(walk[pl]); free(rect[pl]); free(ep[pl]); free(wn[pl]); free(sse[pl]);
-        if (d_rect[pl]) svt_hip_hooks_free(hip, d_rect[pl]);
-        if (d_sse[pl]) svt_hip_hooks_free(hip, d_sse[pl]);
+        free(act[pl]); free(wn[pl]); free(err[pl]); free(probes[pl]); free(init[pl]);
+        if (d_act[pl]) svt_hip_hooks_free(hip, d_act[pl]);
+        if (d_err[pl]) svt_hip_hooks_free(hip, d_err[pl]);
+        if (d_probes[pl]) svt_hip_hooks_free(hip, d_probes[pl]);
     }
     return ret;
 }

@@ -408,6 +408,80 @@ int svt_hip_lr_try_units_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dg
     }
     return SVT_HIP_OK;
 }
+/* finer_tile_search_wiener_seg (Encoder/Codec/EbRestorationPick.c:1092-1200) restated as a state machine per unit (the reference's coordinate descent: step sizes
+ * 4, 2, 1; horizontal taps then vertical taps; downward probe, then upward; at step 4 an accepted probe repeats), every probe = the unit filtered by the oracle's
+ * restoration apply with the probed taps + its SSE against the source.  The product runs the same walk on the device (wiener_walk_kernel); the two are compared
+ * directly by tests/test_sgr_gpu.py::test_wiener_walk_units and through the end-to-end encodes. */
+typedef struct { int state, s, ph, p, up, skip; int64_t err; int16_t v[8], h[8]; } WnWalk;
+static void wn_apply(int16_t *f, int p, int d) { f[p] += (int16_t)d; f[6 - p] += (int16_t)d; f[3] -= (int16_t)(2 * d); }
+static int wn_issue(WnWalk *w, int off) {   /* moves to the next probe: 1 = one is outstanding, 0 = the walk is over */
+    static const int tmin[3] = {-5, -23, -17}, tmax[3] = {10, 8, 46};   /* WIENER_FILT_TAP{0,1,2}_{MINV,MAXV}, Common/Codec/EbRestoration.h:130-150 */
+    for (;;) {
+        if (w->s < 1) { w->state = 0; return 0; }
+        if (w->p >= 3) {
+            if (w->ph == 0) w->ph = 1; else { w->ph = 0; w->s >>= 1; }
+            w->p = off; w->up = 0; w->skip = 0;
+            continue;
+        }
+        int16_t *f = w->ph ? w->v : w->h;
+        if (!w->up) {
+            if (f[w->p] - w->s >= tmin[w->p]) { wn_apply(f, w->p, -w->s); w->state = 2; return 1; }
+            if (w->skip) w->p = 3; else w->up = 1;
+        } else {
+            if (f[w->p] + w->s <= tmax[w->p]) { wn_apply(f, w->p, w->s); w->state = 2; return 1; }
+            w->p++; w->up = 0; w->skip = 0;
+        }
+    }
+}
+static void wn_result(WnWalk *w, int64_t err2, int off) {
+    if (w->state == 1) { w->err = err2; w->s = 4; w->ph = 0; w->p = off; w->up = 0; w->skip = 0; wn_issue(w, off); return; }
+    int16_t  *f = w->ph ? w->v : w->h;
+    const int d = w->up ? w->s : -w->s, accepted = !(err2 > w->err);
+    if (!accepted) wn_apply(f, w->p, -d);
+    else { w->err = err2; if (!w->up) w->skip = 1; }
+    if (!(accepted && w->s == 4)) {
+        if (!w->up) { if (w->skip) w->p = 3; else w->up = 1; }
+        else { w->p++; w->up = 0; w->skip = 0; }
+    }
+    wn_issue(w, off);
+}
+int svt_hip_wiener_walk_units_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, int pw, int ph, int unit_size, int ss_y, const void *dbl, int dbl_stride,
+                                  const void *src, int src_stride, int16_t *unit_wiener, const uint8_t *active, int wiener_win, int64_t *err, uint32_t *probes) {
+    const int n = orc_rest_units(pw, unit_size) * orc_rest_units(ph, unit_size), off = (7 - wiener_win) >> 1;
+    WnWalk *w = (WnWalk *)calloc(n, sizeof(WnWalk));
+    int32_t *lim = (int32_t *)malloc(sizeof(int32_t) * 4 * n), *xqd = (int32_t *)calloc(2 * n, sizeof(int32_t));
+    SvtHipBlkPair *rect = (SvtHipBlkPair *)calloc(n, sizeof(SvtHipBlkPair));
+    uint8_t *ep = (uint8_t *)malloc(n);
+    int16_t *wn = (int16_t *)calloc((size_t)16 * n, sizeof(int16_t));
+    uint64_t *sse = (uint64_t *)calloc(n, sizeof(uint64_t));
+    void *dst = malloc((size_t)stride * (ph + 8) * pix_bytes);
+    orc_rest_unit_limits(pw, ph, ss_y, unit_size, lim);
+    int n_active = 0, rc = SVT_HIP_OK;
+    for (int u = 0; u < n; u++) {
+        rect[u].a_x = rect[u].b_x = lim[4 * u]; rect[u].a_y = rect[u].b_y = lim[4 * u + 2]; rect[u].w = (uint16_t)(lim[4 * u + 1] - lim[4 * u]); rect[u].h = (uint16_t)(lim[4 * u + 3] - lim[4 * u + 2]);
+        if (probes) probes[u] = 0;
+        if (!active[u]) continue;
+        memcpy(w[u].v, unit_wiener + 16 * u, 16); memcpy(w[u].h, unit_wiener + 16 * u + 8, 16);
+        w[u].state = 1; n_active++;
+    }
+    while (n_active > 0 && rc == SVT_HIP_OK) {
+        for (int u = 0; u < n; u++) {
+            ep[u] = w[u].state ? 254 : 255;
+            memcpy(wn + 16 * u, w[u].v, 16); memcpy(wn + 16 * u + 8, w[u].h, 16);
+        }
+        rc = svt_hip_lr_try_units_dev(c, pix_bytes, bd, dgd, stride, dst, stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, ep, xqd, wn, src, src_stride, rect, n, sse);
+        for (int u = 0; u < n && rc == SVT_HIP_OK; u++) {
+            if (!w[u].state) continue;
+            if (probes) probes[u]++;
+            wn_result(&w[u], (int64_t)sse[u], off);
+            if (!w[u].state) n_active--;
+        }
+    }
+    for (int u = 0; u < n && rc == SVT_HIP_OK; u++)
+        if (active[u]) { memcpy(unit_wiener + 16 * u, w[u].v, 16); memcpy(unit_wiener + 16 * u + 8, w[u].h, 16); err[u] = w[u].err; }
+    free(w); free(lim); free(xqd); free(rect); free(ep); free(wn); free(sse); free(dst);
+    return rc;
+}
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
                                 int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd) {
     return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, NULL);

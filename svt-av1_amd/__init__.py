@@ -207,6 +207,7 @@ def lib():
     L.svt_hip_warp_compound_batch_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, i32]
     L.svt_hip_blend_a64_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_deblock_frame_dev.argtypes = [vp, P3, i32, I3, i32, P3, P3, I3, I3, i32]
+    L.svt_hip_wiener_walk_units_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp]
     L.svt_hip_deblock_frame_fused_dev.argtypes = [vp, P3, P3, i32, I3, i32, I3, I3, P3, P3, I3, I3, i32]
     L.svt_hip_picture_format_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32]
     L.svt_hip_generate_padding_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32]

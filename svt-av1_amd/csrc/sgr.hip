@@ -590,6 +590,54 @@ sgr_proj_error_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __rest
     }
 }
 
+// ---- pieces shared by the frame apply and the Wiener tap walk: staging of one 64 x 32 restoration tile with its 3-sample surround (stripe rules: rows outside the
+// tile's stripe come from the deblocked picture's two boundary rows, stretched to three), and svt_av1_wiener_convolve_add_src's two passes on the staged tile
+template <typename PIX>
+__device__ __forceinline__ StripeCtx<PIX> lr_stripe_of(const PIX* dbl, int dbl_stride, int y0, int voff, int stripe_h, int ph) {
+    StripeCtx<PIX> sc{nullptr, 0, 0, 0, 0, 0};
+    if (dbl) {
+        const int s = (y0 + voff) / stripe_h;
+        sc.dbl = dbl; sc.dbl_stride = dbl_stride;
+        sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
+        sc.above = s > 0; sc.below = sc.sy1 < ph;
+    }
+    return sc;
+}
+template <typename PIX>
+__device__ __forceinline__ void lr_stage_tile(uint16_t* __restrict__ in, const PIX* __restrict__ dgd, int stride, int pw, int ph, int x0, int y0, const StripeCtx<PIX>& sc, int tid, int nt) {
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, nt,
+        [&](int i) {
+            const int r = i / S_IW, c = i - r * S_IW;
+            const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+            if (sc.above && yy < sc.sy0)
+                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+            if (sc.below && yy >= sc.sy1)
+                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
+            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+        },
+        [&](int i, uint16_t v) { in[i] = v; });
+}
+// horizontal pass (round 3) of the staged tile -> tmp [S_IH][S_TW]  (Common/Codec/convolve.c:60-145)
+template <int BD>
+__device__ __forceinline__ void wiener_hpass(const uint16_t* __restrict__ in, uint16_t* __restrict__ tmp, const int (&fx)[8], int tid, int nt) {
+    for (int k = tid; k < S_IH * S_TW; k += nt) {
+        const int r = k / S_TW, c = k - r * S_TW;
+        int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << (BD + 6));
+#pragma unroll
+        for (int t = 0; t < 7; t++) sum += (int32_t)in[r * S_IW + c + t] * fx[t];
+        tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, bd)
+    }
+}
+// vertical pass (round 11) for sample (i, j) of the tile
+template <int BD>
+__device__ __forceinline__ int wiener_vpx(const uint16_t* __restrict__ tmp, int i, int j, const int (&fy)[8]) {
+    int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << (BD + 10));
+#pragma unroll
+    for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * S_TW + j] * fy[t];
+    return min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
+}
+
 // ---- frame apply (bit depth 8 and 10) on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
 // RESTORE_NONE units are copied, RESTORE_WIENER units take the 7-tap separable filter, RESTORE_SGRPROJ units the self-guided filter.
 // A tile is one stripe high at most (stripes are 64 >> ss_y rows starting 8 >> ss_y above a multiple of that), so the StripeCtx rules
@@ -613,29 +661,12 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
         }
         return;
     }
-    StripeCtx<PIX> sc{nullptr, 0, 0, 0, 0, 0};
-    if (dbl) {
-        const int s = (y0 + voff) / stripe_h;
-        sc.dbl = dbl; sc.dbl_stride = dbl_stride;
-        sc.sy0 = max(0, s * stripe_h - voff); sc.sy1 = min((s + 1) * stripe_h - voff, ph);
-        sc.above = s > 0; sc.below = sc.sy1 < ph;
-    }
+    const StripeCtx<PIX> sc = lr_stripe_of<PIX>(dbl, dbl_stride, y0, voff, stripe_h, ph);
     {
         const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
         xt[tid] = (A << 20) | (256u - A);
     }
-    batched_stage<6, uint16_t>(S_IH * S_IW, tid, 256,
-        [&](int i) {
-            const int r = i / S_IW, c = i - r * S_IW;
-            const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-            if (sc.above && yy < sc.sy0)
-                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            if (sc.below && yy >= sc.sy1)
-                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
-            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
-        },
-        [&](int i, uint16_t v) { in[i] = v; });
+    lr_stage_tile<PIX>(in, dgd, stride, pw, ph, x0, y0, sc, tid, 256);
     __syncthreads();
     const int j = tid & 63, i0 = (tid >> 6) * 8;
     if (wiener) {   // svt_av1_wiener_convolve_add_src (Common/Codec/convolve.c:60-145): horizontal pass (round 3), vertical pass (round 11)
@@ -643,22 +674,13 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
 #pragma unroll
         for (int k = 0; k < 8; k++) { fy[k] = unit_wiener[16 * unit + k]; fx[k] = unit_wiener[16 * unit + 8 + k]; }
         uint16_t* tmp = (uint16_t*)&ab[0][0];   // [S_IH][S_TW]
-        for (int k = tid; k < S_IH * S_TW; k += 256) {
-            const int r = k / S_TW, c = k - r * S_TW;
-            int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << (BD + 6));
-#pragma unroll
-            for (int t = 0; t < 7; t++) sum += (int32_t)in[r * S_IW + c + t] * fx[t];
-            tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, bd)
-        }
+        wiener_hpass<BD>(in, tmp, fx, tid, 256);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int i = i0 + r;
             if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-            int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << (BD + 10));
-#pragma unroll
-            for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * S_TW + j] * fy[t];
-            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
+            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)wiener_vpx<BD>(tmp, i, j, fy);
         }
         return;
     }
@@ -691,7 +713,137 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
     }
 }
 
+// ---- finer_tile_search_wiener_seg (Encoder/Codec/EbRestorationPick.c:1092-1200) for every restoration unit of a plane, ON THE DEVICE: one workgroup of four
+// 256-thread teams per unit.  Thread 0 runs the reference's coordinate descent as a state machine (step sizes 4, 2, 1; the horizontal taps, then the vertical ones;
+// a downward probe, then an upward one; at step 4 an accepted probe repeats — wn_issue / wn_result below); every probe = try_restoration_unit_seg (:137): the unit
+// filtered with the probed taps (the apply kernel's staging and passes, tile by tile, a team per tile) and its squared error against the source, which never
+// leaves the chip.  No host round trip per probe (round 3: 20 - 40 lockstep rounds of upload / launch / download per picture).
+struct WnWalkState { int s, ph, p, up, skip, state; long long err; int16_t v[8], h[8]; };
+__device__ __forceinline__ void wn_apply(int16_t* f, int p, int d) { f[p] += (int16_t)d; f[6 - p] += (int16_t)d; f[3] -= (int16_t)(2 * d); }   // WIENER_WIN 7, WIENER_HALFWIN 3
+// moves to the next probe: true = one is outstanding (its taps are in w.v / w.h), false = the walk is over
+__device__ inline bool wn_issue(WnWalkState& w, int off) {
+    const int tmin[3] = {-5, -23, -17}, tmax[3] = {10, 8, 46};   // WIENER_FILT_TAP{0,1,2}_{MINV,MAXV} (Common/Codec/EbRestoration.h:130-150)
+    for (;;) {
+        if (w.s < 1) { w.state = 0; return false; }
+        if (w.p >= 3) {           // this filter's taps are done: vertical after horizontal, then the next step size
+            if (w.ph == 0) w.ph = 1; else { w.ph = 0; w.s >>= 1; }
+            w.p = off; w.up = 0; w.skip = 0;
+            continue;
+        }
+        int16_t* f = w.ph ? w.v : w.h;
+        if (!w.up) {
+            if (f[w.p] - w.s >= tmin[w.p]) { wn_apply(f, w.p, -w.s); w.state = 2; return true; }
+            if (w.skip) w.p = 3; else w.up = 1;    // "if (skip) break" (:1126)
+        } else {
+            if (f[w.p] + w.s <= tmax[w.p]) { wn_apply(f, w.p, w.s); w.state = 2; return true; }
+            w.p++; w.up = 0; w.skip = 0;
+        }
+    }
+}
+__device__ inline bool wn_result(WnWalkState& w, long long err2, int off) {
+    if (w.state == 1) { w.err = err2; w.s = 4; w.ph = 0; w.p = off; w.up = 0; w.skip = 0; return wn_issue(w, off); }
+    int16_t*  f = w.ph ? w.v : w.h;
+    const int d = w.up ? w.s : -w.s;
+    const bool accepted = !(err2 > w.err);
+    if (!accepted) wn_apply(f, w.p, -d);
+    else { w.err = err2; if (!w.up) w.skip = 1; }
+    if (!(accepted && w.s == 4)) {             // at the highest step size an accepted probe keeps moving in the same direction
+        if (!w.up) { if (w.skip) w.p = 3; else w.up = 1; }
+        else { w.p++; w.up = 0; w.skip = 0; }
+    }
+    return wn_issue(w, off);
+}
+template <typename PIX, int BD>
+__global__ void __launch_bounds__(1024)
+wiener_walk_kernel(const PIX* __restrict__ dgd, int stride, int pw, int ph, int unit_size, int units_x, int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl,
+                   int dbl_stride, const PIX* __restrict__ src, int src_stride, int16_t* __restrict__ unit_wiener, const uint8_t* __restrict__ active, int win,
+                   long long* __restrict__ err_out, uint32_t* __restrict__ probes_out) {
+    __shared__ uint16_t in[4][S_IH * S_IW];
+    __shared__ uint16_t tmp[4][S_IH * S_TW];
+    __shared__ int taps[16];            // the probe: [0..7] vertical, [8..15] horizontal
+    __shared__ unsigned long long part[16];
+    __shared__ int go;
+    const int unit = blockIdx.x, tid = threadIdx.x, team = tid >> 8, tt = tid & 255;
+    if (!active[unit]) return;
+    const int ux = unit % units_x, uy = unit / units_x, off = (7 - win) >> 1;
+    // the unit's rectangle (foreach_rest_unit_in_tile, EbRestoration.c:1369-1411): whole tiles of the apply kernel's grid
+    const int rx0 = ux * unit_size, rx1 = ux == units_x - 1 ? pw : (ux + 1) * unit_size;
+    const int ry0 = max(uy * unit_size - voff, 0), ry1 = uy == units_y - 1 ? ph : (uy + 1) * unit_size - voff;
+    const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, ty_first = (ry0 + voff) / S_TH, tiles_y = (ry1 + voff + S_TH - 1) / S_TH - ty_first, n_tiles = tiles_x * tiles_y;
+    WnWalkState w;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { w.v[k] = unit_wiener[16 * unit + k]; w.h[k] = unit_wiener[16 * unit + 8 + k]; }
+        w.state = 1; w.err = 0; w.s = 0; w.ph = 0; w.p = 0; w.up = 0; w.skip = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        go = 1;
+    }
+    uint32_t n_probes = 0;
+    __syncthreads();
+    while (go) {
+        int fx[8], fy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { fy[k] = taps[k]; fx[k] = taps[8 + k]; }
+        unsigned long long sse = 0;
+        for (int t = team; t < n_tiles; t += 4) {   // uniform per team: its four waves pass the same barriers
+            const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+            const int x0 = rx0 + txi * S_TW, y0 = (ty_first + tyi) * S_TH - voff;
+            const StripeCtx<PIX> sc = lr_stripe_of<PIX>(dbl, dbl_stride, y0, voff, stripe_h, ph);
+            lr_stage_tile<PIX>(in[team], dgd, stride, pw, ph, x0, y0, sc, tt, 256);
+            __syncthreads();   // the teams' trip counts differ by at most one tile; every wave of the workgroup reaches the same number of barriers (see below)
+            wiener_hpass<BD>(in[team], tmp[team], fx, tt, 256);
+            __syncthreads();
+            const int j = tt & 63, i0 = (tt >> 6) * 8;
+            uint32_t e = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int i = i0 + r, x = x0 + j, y = y0 + i;
+                if (x >= rx1 || y >= ry1 || y < ry0) continue;
+                const int d = wiener_vpx<BD>(tmp[team], i, j, fy) - (int)src[(size_t)y * src_stride + x];
+                e += (uint32_t)(d * d);
+            }
+            sse += e;
+            __syncthreads();   // tmp / in are rewritten by the team's next tile
+        }
+        // teams that ran one tile fewer make up their three barriers, so that the workgroup's barrier count is uniform
+        if (n_tiles % 4 && team >= n_tiles % 4) { __syncthreads(); __syncthreads(); __syncthreads(); }
+        // 64-lane sums, then the sixteen waves' partials
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sse += ((unsigned long long)(uint32_t)__shfl_xor((int)(sse >> 32), m, 64) << 32) | (uint32_t)__shfl_xor((int)sse, m, 64);
+        if ((tid & 63) == 0) part[tid >> 6] = sse;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) tot += part[k];
+            n_probes++;
+            go = wn_result(w, (long long)tot, off) ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { unit_wiener[16 * unit + k] = w.v[k]; unit_wiener[16 * unit + 8 + k] = w.h[k]; }
+        err_out[unit] = w.err;
+        if (probes_out) probes_out[unit] = n_probes;
+    }
+}
+
 }  // namespace
+
+extern "C" int svt_hip_launch_wiener_walk(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y,
+                                          const void* dbl, int dbl_stride, const void* src, int src_stride, int16_t* unit_wiener, const uint8_t* active, int win, long long* err,
+                                          uint32_t* probes) {
+    const int voff = 8 >> ss_y, sh = 64 >> ss_y, n = units_x * units_y;
+    if (n <= 0) return 0;
+    if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), dim3(n), dim3(1024), 0, st, (const uint8_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, (const uint8_t*)src, src_stride, unit_wiener, active, win, err, probes);
+    else if (bd == 8) hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 8>), dim3(n), dim3(1024), 0, st, (const uint16_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, (const uint16_t*)src, src_stride, unit_wiener, active, win, err, probes);
+    else hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 10>), dim3(n), dim3(1024), 0, st, (const uint16_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, (const uint16_t*)src, src_stride, unit_wiener, active, win, err, probes);
+    return (int)hipGetLastError();
+}
 
 extern "C" int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, const void* plane, int stride, int pw, int ph, int ep,
                                          int32_t* flt0, int32_t* flt1, int flt_stride) {

@@ -727,6 +727,21 @@ int svt_hip_lr_try_units_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_
     return svt_hip_block_sse_batch_dev(c, pix_bytes, d_src, src_stride, d_dst, dst_stride, d_rects, n_rects, d_sse);
 }
 
+int svt_hip_wiener_walk_units_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, int pw, int ph, int unit_size, int ss_y, const void* d_dbl, int dbl_stride,
+                                  const void* d_src, int src_stride, int16_t* d_unit_wiener, const uint8_t* d_active, int wiener_win, int64_t* d_err, uint32_t* d_probes) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_dgd || !d_src || !d_unit_wiener || !d_active || !d_err || unit_size < 64 || (unit_size & 63) || (ss_y != 0 && ss_y != 1) ||
+        (wiener_win != 7 && wiener_win != 5 && wiener_win != 3) || !sgr_args_ok(pix_bytes, bd, pw, ph)) {
+        if (c) c->err = "svt_hip_wiener_walk_units_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_walk(c->stream, pix_bytes, bd, d_dgd, stride, pw, ph, unit_size, ux, uy, ss_y, d_dbl, dbl_stride, d_src, src_stride, d_unit_wiener,
+                                                         d_active, wiener_win, (long long*)d_err, d_probes);
+    if (e != hipSuccess) return fail(c, e, "wiener walk launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                      int pw, int ph, int unit_size, int ss_y, uint32_t ep_mask, int ncand, const int32_t* d_xqd, int64_t* d_err) {
     SVT_HIP_ENTER(c);

@@ -3,6 +3,7 @@ svt_av1_selfguided_restoration_c / svt_apply_selfguided_restoration_c / svt_get_
 filter planes for all 16 parameter sets, the per-unit projection sums of the search, and the apply
 pass; 8- and 10-bit.  Mirrors /root/reference/test/selfguided_filter_test.cc:248-562."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -154,6 +155,51 @@ def test_mixed_wiener_sgr_apply(hip, orc, bd, ss):
             assert sse == int(((ref_rect - src_rect) ** 2).sum()), ("try unit sse", bd, ss, US, u)
             hip.free(d_one)
         hip.free(d_ext, d_dbl, d_ep, d_xqd, d_wn, d_dst, d_src2, d_sse)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_wiener_walk_units(hip, bd, ss):
+    """svt_hip_wiener_walk_units_dev (finer_tile_search_wiener_seg of every unit on the device: the coordinate descent AND all of its probes in one launch) against the
+    CPU test double's restatement of the same walk on the oracle's restoration filter (oracle/hip_mock.c): the same refined taps, the same error and the same number
+    of probes for every unit; inactive units untouched; windows 7 / 5 / 3; unit sizes 64 / 128 with over-sized last rows and columns; starting filters from identity to
+    the corners of the tap ranges."""
+    import shard_common as sc
+    if not os.path.exists(sc.MOCK_LIB):
+        pytest.skip("oracle/_ref/mock/libsvtav1_hip.so not built")
+    M = C.CDLL(sc.MOCK_LIB)
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    M.svt_hip_wiener_walk_units_dev.argtypes = sig
+    for (w, h, US, win) in ((200, 152, 64, 7), (328, 264, 128, 7), (200, 152, 64, 5), (136, 72, 64, 3)):
+        if ss and win == 7: win = 5     # chroma planes search the 5-tap window at most (search_wiener_seg :1352-1358)
+        src, ext = make_planes(w, h, bd, 190 + bd + ss + US)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        rng = np.random.default_rng(31 + ss + win)
+        dbl = np.clip(ext[EXT:EXT + h, EXT:EXT + w].astype(np.int32) + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(ext.dtype)
+        nu = units(w, US) * units(h, US)
+        act = (rng.random(nu) < 0.8).astype(np.uint8); act[0] = 1
+        o = (7 - win) >> 1
+        wn = np.zeros((nu, 2, 8), np.int16)
+        for u in range(nu):
+            for d in range(2):
+                t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                if u % 4 == 0: t = [0, 0, 0]                                 # identity
+                if u == 1: t = [10, 8, 46] if d else [-5, -23, -17]          # the corners of the ranges
+                for k in range(o): t[k] = 0
+                wn[u, d, :7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
+        # expected: the CPU test double (host memory is its "device")
+        e_wn = wn.copy(); e_err = np.zeros(nu, np.int64); e_pr = np.zeros(nu, np.uint32)
+        work = ext.copy()
+        assert M.svt_hip_wiener_walk_units_dev(None, ext.itemsize, bd, C.c_void_p(work.ctypes.data + off), st, w, h, US, ss, ptr(dbl), w, ptr(src), w, ptr(e_wn), ptr(act), win, ptr(e_err), ptr(e_pr)) == 0
+        d_ext, d_dbl, d_src, d_wn, d_act, d_err, d_pr = hip.to_device(ext), hip.to_device(dbl), hip.to_device(src), hip.to_device(wn), hip.to_device(act), hip.to_device(np.full(nu, -1, np.int64)), hip.to_device(np.zeros(nu, np.uint32))
+        hip.check(hip.L.svt_hip_wiener_walk_units_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, w, h, US, ss, d_dbl, w, d_src, w, d_wn, d_act, win, d_err, d_pr), "wiener walk")
+        g_wn, g_err, g_pr = hip.to_host(d_wn, wn.shape, np.int16), hip.to_host(d_err, (nu,), np.int64), hip.to_host(d_pr, (nu,), np.uint32)
+        hip.free(d_ext, d_dbl, d_src, d_wn, d_act, d_err, d_pr)
+        on = act.astype(bool)
+        assert np.array_equal(g_wn, e_wn), (bd, ss, w, h, US, win, np.argwhere(g_wn != e_wn)[:4])
+        assert np.array_equal(g_err[on], e_err[on]) and (g_err[~on] == -1).all(), (bd, ss, US, win)
+        assert np.array_equal(g_pr[on], e_pr[on]) and e_pr[on].min() >= 7, (bd, ss, US, win, g_pr, e_pr)
+        assert (e_wn[on] != wn[on]).any(), "no walk moved a tap: the content does not exercise the search"
 
 
 @pytest.mark.parametrize("bd", [8, 10])
