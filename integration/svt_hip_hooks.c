@@ -269,7 +269,8 @@ void svt_hip_hooks_report(void) {
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_SB]) {
         long sbs, launches, blocks, calls;
         svt_hip_hook_encdec_sb_stats(&sbs, &launches, &blocks, &calls);
-        fprintf(stderr, "svt_hip_encdec_sb superblocks=%ld launches=%ld inter_blocks_predicted_ahead=%ld estimate_transform_calls_replaced=%ld\n", sbs, launches, blocks, calls);
+        fprintf(stderr, "svt_hip_encdec_sb superblocks=%ld launches=%ld inter_blocks_predicted_ahead=%ld estimate_transform_calls_replaced=%ld kernel_launches=%ld\n", sbs, launches, blocks, calls,
+                svt_hip_hook_encdec_sb_kernels());
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

@@ -189,6 +189,7 @@ int  svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pc
 int  svt_hip_hook_encdec_sb_predicted(const BlkStruct *blk);
 void svt_hip_hook_encdec_sb_end(void);
 void svt_hip_hook_encdec_sb_stats(long *superblocks, long *launches, long *blocks, long *calls);
+long svt_hip_hook_encdec_sb_kernels(void);   /* kernel launches behind those entry-point calls (one per 16 (plane, transform size) pairs of a superblock) */
 /* svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *, const MV *centre, int hstep, const SubpelMvLimits *) is declared in the patched mcomp.c (its
  * argument types live in mcomp.h, which includes this header's dependencies the other way round) */
 int  svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse);

@@ -255,19 +255,136 @@ void svt_hip_hook_encdec_tx_end(void) { tls_ed.valid = 0; sb_end_block(); }
 #include "EbReferenceObject.h"
 #include "EbUtility.h"
 #define SB_MAX_BLK 4432    /* BLOCK_MAX_COUNT_SB_128 */
-#define SB_MAX_JOBS 2560
-#define SB_MAX_PIX (128 * 128 * 3 / 2)
+#define SB_MAX_TU 2560     /* (plane, transform block, type) records of one superblock */
+#define SB_LW 128          /* staging planes of a superblock: luma 128 x 128, each chroma plane 64 x 64, 16-bit samples, source and prediction */
+#define SB_PIX (SB_LW * SB_LW + 2 * (SB_LW / 2) * (SB_LW / 2))
+#define SB_MAX_GROUPS 64   /* distinct (plane, transform size) pairs: one job each */
 static __thread struct {
     int       valid, n, cur;   /* cur: mds index of the block whose transform loops run now (-1: none of the batch) */
     int       lo, hi;          /* the current block's entries (a block's entries are contiguous) */
     uint8_t   predicted[SB_MAX_BLK];
-    EdEntry   e[SB_MAX_JOBS];
-    int32_t  *coeff;           /* [2 * SB_MAX_PIX], allocated at the thread's first superblock */
-    uint16_t *hs, *hp;
+    EdEntry   e[SB_MAX_TU];
+    uint32_t  tu_xy[SB_MAX_TU]; /* position of the record's transform block inside its staging plane: x | y << 14 */
+    int32_t  *coeff;           /* [2 * SB_PIX], allocated at the thread's first superblock */
+    uint16_t *hs, *hp;         /* [SB_PIX] each */
 } tls_sb;
-static long g_sb_launches, g_sb_blocks, g_sb_superblocks, g_sb_tx;
+static long g_sb_launches, g_sb_blocks, g_sb_superblocks, g_sb_tx, g_sb_kernels;
 
 void svt_hip_hook_encdec_sb_stats(long *superblocks, long *launches, long *blocks, long *calls) { *superblocks = g_sb_superblocks; *launches = g_sb_launches; *blocks = g_sb_blocks; *calls = g_sb_tx; }
+long svt_hip_hook_encdec_sb_kernels(void) { return g_sb_kernels; }
+
+/* One block's samples into the superblock's staging planes + one record per (plane, transform block, type); 0 = no room for the block's records (nothing kept) */
+static int sb_gather_block(int *n_rec, int *n_coeff, EncDecContext *ctx, const BlkStruct *blk, const BlockGeom *g, uint32_t sb_x, uint32_t sb_y, uint32_t blk_origin_x,
+                           uint32_t blk_origin_y, const EbPictureBufferDesc *pred, int is_16bit) {
+    const int d = blk->tx_depth, tot = g->txb_count[d], is_inter = 1, n0 = *n_rec, c0 = *n_coeff;
+    static const int plane_off[3] = {0, SB_LW * SB_LW, SB_LW * SB_LW + (SB_LW / 2) * (SB_LW / 2)};
+    for (int t = 0; t < tot; t++) {
+        const int uv_pass = d && t ? 0 : 1;
+        const uint32_t ox = blk_origin_x + g->tx_org_x[is_inter][d][t] - g->origin_x, oy = blk_origin_y + g->tx_org_y[is_inter][d][t] - g->origin_y;
+        const uint32_t rx = (ox >> 3) << 3, ry = (oy >> 3) << 3;
+        for (int p = 0; p < ((g->has_uv && uv_pass) ? 3 : 1); p++) {
+            const int w = p ? g->tx_width_uv[d][t] : g->tx_width[d][t], h = p ? g->tx_height_uv[d][t] : g->tx_height[d][t];
+            const int tx_size = p ? g->txsize_uv[d][t] : g->txsize[d][t];
+            if (w > 32 || h > 32) continue;
+            const int px = p ? (int)(rx - sb_x) >> 1 : (int)(ox - sb_x), py = p ? (int)(ry - sb_y) >> 1 : (int)(oy - sb_y), pst = p ? SB_LW / 2 : SB_LW;
+            if (px < 0 || py < 0 || px + w > pst || py + h > pst) goto full;
+            uint16_t *ps = tls_sb.hs + plane_off[p] + py * pst + px, *pp = tls_sb.hp + plane_off[p] + py * pst + px;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int sv, q;
+                    if (!is_16bit) {
+                        const EbPictureBufferDesc *in = ctx->input_samples;
+                        if (p == 0) {
+                            sv = in->buffer_y[(size_t)(oy + in->origin_y + y) * in->stride_y + ox + in->origin_x + x];
+                            q = pred->buffer_y[(size_t)(pred->origin_y + oy + y) * pred->stride_y + pred->origin_x + ox + x];
+                        } else {
+                            const uint8_t *ib = p == 1 ? in->buffer_cb : in->buffer_cr, *pb = p == 1 ? pred->buffer_cb : pred->buffer_cr;
+                            const uint32_t is = p == 1 ? in->stride_cb : in->stride_cr, pstr = p == 1 ? pred->stride_cb : pred->stride_cr;
+                            sv = ib[(size_t)(((ry + in->origin_y) >> 1) + y) * is + ((rx + in->origin_x) >> 1) + x];
+                            q = pb[(size_t)(((pred->origin_y + ry) >> 1) + y) * pstr + ((pred->origin_x + rx) >> 1) + x];
+                        }
+                    } else {
+                        const EbPictureBufferDesc *in = ctx->input_sample16bit_buffer;
+                        const uint32_t tx = g->tx_org_x[is_inter][d][t], ty = g->tx_org_y[is_inter][d][t];
+                        if (p == 0) {
+                            sv = ((const uint16_t *)in->buffer_y)[(size_t)(ty + y) * in->stride_y + tx + x];
+                            q = ((const uint16_t *)pred->buffer_y)[(size_t)(pred->origin_y + oy + y) * pred->stride_y + pred->origin_x + ox + x];
+                        } else {
+                            const uint16_t *ib = (const uint16_t *)(p == 1 ? in->buffer_cb : in->buffer_cr), *pb = (const uint16_t *)(p == 1 ? pred->buffer_cb : pred->buffer_cr);
+                            const uint32_t is = p == 1 ? in->stride_cb : in->stride_cr, pstr = p == 1 ? pred->stride_cb : pred->stride_cr;
+                            sv = ib[(size_t)(ROUND_UV(ty) / 2 + y) * is + ROUND_UV(tx) / 2 + x];
+                            q = pb[(size_t)(((pred->origin_y + ry) >> 1) + y) * pstr + ((pred->origin_x + rx) >> 1) + x];
+                        }
+                    }
+                    ps[y * pst + x] = (uint16_t)sv; pp[y * pst + x] = (uint16_t)q;
+                }
+            const int type0 = blk->txb_array[t].transform_type[p ? PLANE_TYPE_UV : PLANE_TYPE_Y];
+            for (int k = 0; k < 2; k++) {
+                const int type = k ? DCT_DCT : type0;
+                if (k && type0 == DCT_DCT) break;
+                if (*n_rec >= SB_MAX_TU || *n_coeff + w * h > 2 * SB_PIX) goto full;
+                EdEntry *e = &tls_sb.e[*n_rec];
+                e->blk = (int16_t)blk->mds_idx; e->plane = (int8_t)p; e->txb = (int8_t)t; e->tx_size = (int8_t)tx_size; e->tx_type = (int8_t)type;
+                e->off = -1; e->count = w * h;
+                tls_sb.tu_xy[*n_rec] = (uint32_t)px | (uint32_t)py << 14;
+                (*n_rec)++; *n_coeff += w * h;
+            }
+        }
+    }
+    return 1;
+full:
+    *n_rec = n0; *n_coeff = c0;
+    return 0;
+}
+/* the records grouped into one job per (plane, transform size): the whole superblock is ONE entry-point call, and one kernel launch as long as it has at most 16
+ * such pairs (the library packs 16 job lists into a launch) */
+static int sb_launch(int n_rec, int n_coeff, int coeff_shape) {
+    static __thread uint32_t       desc[SB_MAX_TU];
+    static __thread SvtHipFwdTxJob jobs[SB_MAX_GROUPS];
+    static const int plane_off[3] = {0, SB_LW * SB_LW, SB_LW * SB_LW + (SB_LW / 2) * (SB_LW / 2)};
+    int n_jobs = 0, nd = 0, co = 0;
+    for (int p = 0; p < 3; p++)
+        for (int ts = 0; ts < TX_SIZES_ALL; ts++) {
+            int cnt = 0;
+            for (int i = 0; i < n_rec; i++)
+                if (tls_sb.e[i].plane == p && tls_sb.e[i].tx_size == ts) {
+                    if (!cnt) {
+                        if (n_jobs >= SB_MAX_GROUPS) return SVT_HIP_ERR_UNSUPPORTED;
+                        memset(&jobs[n_jobs], 0, sizeof(jobs[0]));
+                        jobs[n_jobs].tx_size = ts; jobs[n_jobs].src_stride = jobs[n_jobs].pred_stride = p ? SB_LW / 2 : SB_LW;
+                        jobs[n_jobs].d_src = (const void *)(size_t)plane_off[p];   /* offsets for now */
+                        jobs[n_jobs].d_descs = (const uint32_t *)(size_t)nd; jobs[n_jobs].d_coeff = (int32_t *)(size_t)co;
+                        jobs[n_jobs].qp.coeff_shape = coeff_shape;
+                    }
+                    desc[nd++] = SVT_HIP_TX_DESC(tls_sb.tu_xy[i] & 0x3FFF, tls_sb.tu_xy[i] >> 14, tls_sb.e[i].tx_type);
+                    tls_sb.e[i].off = co; co += tls_sb.e[i].count;
+                    cnt++;
+                }
+            if (cnt) jobs[n_jobs++].nblk = cnt;
+        }
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
+    if (!hip) return SVT_HIP_ERR_RUNTIME;
+    void *d_s = NULL, *d_p = NULL, *d_d = NULL, *d_c = NULL;
+    int   rc = svt_hip_hooks_malloc(hip, &d_s, sizeof(uint16_t) * SB_PIX);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_p, sizeof(uint16_t) * SB_PIX);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_d, sizeof(uint32_t) * (size_t)nd);
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_c, sizeof(int32_t) * (size_t)n_coeff);
+    for (int j = 0; j < n_jobs && rc == SVT_HIP_OK; j++) {
+        const size_t po = (size_t)jobs[j].d_src;
+        jobs[j].d_src = (const uint16_t *)d_s + po; jobs[j].d_pred = (const uint16_t *)d_p + po;
+        jobs[j].d_descs = (const uint32_t *)d_d + (size_t)jobs[j].d_descs; jobs[j].d_coeff = (int32_t *)d_c + (size_t)jobs[j].d_coeff;
+    }
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_s, tls_sb.hs, sizeof(uint16_t) * SB_PIX);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_p, tls_sb.hp, sizeof(uint16_t) * SB_PIX);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_d, desc, sizeof(uint32_t) * (size_t)nd);
+    if (rc == SVT_HIP_OK) rc = svt_hip_fwd_txfm_quant_multi_dev(hip, 2, jobs, n_jobs);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, tls_sb.coeff, d_c, sizeof(int32_t) * (size_t)n_coeff);
+    if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
+    svt_hip_hooks_free(hip, d_s); svt_hip_hooks_free(hip, d_p); svt_hip_hooks_free(hip, d_d); svt_hip_hooks_free(hip, d_c);
+    svt_hip_hooks_unlock_any();
+    if (rc == SVT_HIP_OK) __sync_fetch_and_add(&g_sb_kernels, (n_jobs + 15) / 16);
+    return rc;
+}
 
 static int sb_hoistable(const BlkStruct *blk, const BlockGeom *g) {
     return blk->prediction_mode_flag == INTER_MODE && !blk->use_intrabc && blk->prediction_unit_array[0].motion_mode == SIMPLE_TRANSLATION && !blk->is_interintra_used &&
@@ -316,12 +433,10 @@ int svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pcs
     tls_sb.valid = 0; tls_sb.cur = -1;
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_ENCDEC_SB) || scs->max_block_cnt > SB_MAX_BLK || pcs->slice_type == I_SLICE) return 0;
     if (!tls_sb.coeff) {
-        tls_sb.coeff = (int32_t *)malloc(sizeof(int32_t) * 2 * SB_MAX_PIX); tls_sb.hs = (uint16_t *)malloc(sizeof(uint16_t) * SB_MAX_PIX); tls_sb.hp = (uint16_t *)malloc(sizeof(uint16_t) * SB_MAX_PIX);
+        tls_sb.coeff = (int32_t *)malloc(sizeof(int32_t) * 2 * SB_PIX); tls_sb.hs = (uint16_t *)calloc(SB_PIX, sizeof(uint16_t)); tls_sb.hp = (uint16_t *)calloc(SB_PIX, sizeof(uint16_t));
         if (!tls_sb.coeff || !tls_sb.hs || !tls_sb.hp) { free(tls_sb.coeff); free(tls_sb.hs); free(tls_sb.hp); tls_sb.coeff = NULL; tls_sb.hs = tls_sb.hp = NULL; return 0; }
     }
-    static __thread uint32_t       desc[SB_MAX_JOBS];
-    static __thread SvtHipFwdTxJob jobs[SB_MAX_JOBS];
-    EdBatch B = {tls_sb.hs, tls_sb.hp, SB_MAX_PIX, 0, desc, jobs, tls_sb.e, SB_MAX_JOBS, 0, 2 * SB_MAX_PIX, 0};
+    int n_rec = 0, n_coeff = 0;
     memset(tls_sb.predicted, 0, scs->max_block_cnt);
     ModeDecisionContext *md = ctx->md_context;
     const int sb128 = scs->seq_header.sb_size == BLOCK_128X128;
@@ -342,7 +457,7 @@ int svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pcs
                 sb_predict(scs, pcs, sb, ctx, blk, g, org_x, org_y, recon, is_16bit);
                 tls_sb.predicted[d1] = 1;   /* predicted: the loop must not predict again, whether or not the transforms fitted the batch */
                 nblk++;
-                (void)ed_gather_block(&B, ctx, blk, g, org_x, org_y, recon, is_16bit);
+                (void)sb_gather_block(&n_rec, &n_coeff, ctx, blk, g, sb_origin_x, sb_origin_y, org_x, org_y, recon, is_16bit);
             }
             blk_it += ns_depth_offset[sb128][g0->depth];
         } else
@@ -352,10 +467,10 @@ int svt_hip_hook_encdec_sb_begin(SequenceControlSet *scs, PictureControlSet *pcs
     __sync_fetch_and_add(&g_sb_superblocks, 1);
     __sync_fetch_and_add(&g_sb_blocks, nblk);
     tls_sb.valid = 1; tls_sb.n = 0;
-    if (B.n) {
-        const int rc = ed_launch(&B, tls_sb.coeff);
+    if (n_rec) {
+        const int rc = sb_launch(n_rec, n_coeff, ctx->md_context->pf_ctrls.pf_shape);
         svt_hip_hooks_count(SVT_HIP_HOOK_ENCDEC_SB, rc == SVT_HIP_OK);
-        if (rc == SVT_HIP_OK) { tls_sb.n = B.n; __sync_fetch_and_add(&g_sb_launches, 1); }   /* not handled: the predictions stand, the transforms run on the host */
+        if (rc == SVT_HIP_OK) { tls_sb.n = n_rec; __sync_fetch_and_add(&g_sb_launches, 1); }   /* not handled: the predictions stand, the transforms run on the host */
     }
     return 1;
 }

@@ -157,7 +157,7 @@ def test_encdec_tx_hook_matters(workdir):
 
 
 def _encdec_sb_line(log):
-    m = re.search(r"svt_hip_encdec_sb superblocks=(\d+) launches=(\d+) inter_blocks_predicted_ahead=(\d+) estimate_transform_calls_replaced=(\d+)", log)
+    m = re.search(r"svt_hip_encdec_sb superblocks=(\d+) launches=(\d+) inter_blocks_predicted_ahead=(\d+) estimate_transform_calls_replaced=(\d+) kernel_launches=(\d+)", log)
     assert m, log[-800:]
     return tuple(int(v) for v in m.groups())
 
@@ -170,7 +170,8 @@ def _check_encdec_sb(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "c
     for case in cases:
         spec = {**CASES, **GPU_ONLY_CASES}[case]
         got = _check(case, spec[:6] + ({"encdec_sb"},), workdir, env, tag + "_" + case)
-        sbs, launches, blocks, calls = _encdec_sb_line(got["log"])
+        sbs, launches, blocks, calls, kernels = _encdec_sb_line(got["log"])
+        assert launches <= kernels <= launches + launches // 8, (launches, kernels)   # one KERNEL launch per superblock (a second one only above 16 (plane, transform size) pairs)
         w, h, n = spec[:3]
         print(f"encdec_sb {case}: {launches} launches for {sbs} superblocks with inter blocks, {blocks} blocks predicted ahead, {calls} av1_estimate_transform calls replaced")
         assert 0 < launches <= sbs <= ((w + 63) // 64) * ((h + 63) // 64) * (n - 1), (sbs, launches)   # the first picture is intra-only
