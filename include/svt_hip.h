@@ -113,6 +113,8 @@ int svt_hip_me_fullpel_frame(SvtHipCtx *ctx, const uint8_t *src, const uint8_t *
  * descriptors, so that launch is always issued unless the caller declares that no window of this context exceeds 65 536 candidates (enable = 0;
  * an oversized window then yields SVT_HIP_MAX_SAD_VALUE for every PU of its SB).  The host-pointer entry point decides per call. */
 int svt_hip_me_set_big_windows(SvtHipCtx *ctx, int enable);
+/* the current setting (*enabled = 0 / 1): a caller that switches it for one call puts the context's own value back */
+int svt_hip_me_get_big_windows(SvtHipCtx *ctx, int *enabled);
 /* Tuning knob: low 4 bits = waves per SB workgroup (1, 2 or 4; default 4); bits 4.. = KiB of unused LDS added to each workgroup
  * (0 = off): with >= 56 only one ME workgroup fits a CU, which leaves half of every SIMD's registers to kernels running concurrently
  * on other streams (measured: ME alone 0.40 -> 0.63 ms, whole step unchanged -- see DESIGN.md 5). */

@@ -114,7 +114,7 @@ typedef struct {
 static LfState         g_state[LF_MAX_IN_FLIGHT];
 static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
 static long            g_lf_up_planes, g_lf_down_planes, g_lf_recoveries, g_lf_deferred, g_lf_src_resident;
-static double          g_lf_up_mb, g_lf_down_mb;
+static long long       g_lf_up_bytes, g_lf_down_bytes;
 
 /* the reconstructed pictures' host buffers, page-locked in place once (they are allocated once per encoder instance: EbReferenceObject / the PCS pool) */
 #define LF_PINS 512
@@ -226,7 +226,7 @@ static void lf_leave(LfState *s) {
 void svt_hip_lf_bridge_release(SvtHipCtx *hip) {   /* no picture is in flight any more (svt_hip_hooks_enc_deinit) */
     if (g_lf_up_planes + g_lf_down_planes)
         fprintf(stderr, "svt_hip_lf_pictures deferred=%ld recovered=%ld source_planes_resident=%ld planes_up=%ld up_mb=%.1f planes_down=%ld down_mb=%.1f\n", g_lf_deferred,
-                g_lf_recoveries, g_lf_src_resident, g_lf_up_planes, g_lf_up_mb, g_lf_down_planes, g_lf_down_mb);
+                g_lf_recoveries, g_lf_src_resident, g_lf_up_planes, g_lf_up_bytes / 1048576.0, g_lf_down_planes, g_lf_down_bytes / 1048576.0);
     for (int i = 0; i < LF_MAX_IN_FLIGHT; i++) {
         if (g_state[i].allocated) svt_hip_lf_picture_dctor(hip, &g_state[i].pic);
         if (g_state[i].mu_ready) pthread_mutex_destroy(&g_state[i].mu);
@@ -252,7 +252,7 @@ static EbErrorType upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBuf
         const int dstride = is_src ? p->src_stride[pl] : p->stride[pl];
         uint8_t *d = is_src ? (uint8_t *)d_dst[pl] : (uint8_t *)plane_origin(p, d_dst[pl], pl);
         HIP_TRY(svt_hip_memcpy2d_h2d_async(hip, d, (size_t)dstride * p->pix_bytes, s, (size_t)st * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
-        __sync_fetch_and_add(&g_lf_up_planes, 1); g_lf_up_mb += (double)pw * ph * p->pix_bytes / 1048576.0;
+        __sync_fetch_and_add(&g_lf_up_planes, 1); __sync_fetch_and_add(&g_lf_up_bytes, (long long)pw * ph * p->pix_bytes);
     }
     HIP_TRY(svt_hip_sync(hip));   /* the host picture may change as soon as the hook returns */
     return EB_ErrorNone;
@@ -266,7 +266,7 @@ static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *cons
         const int pw = (crop ? p->cw : p->w) >> (pl > 0), ph = (crop ? p->ch : p->h) >> (pl > 0);
         const uint8_t *s = (const uint8_t *)plane_origin(p, d_src[pl], pl);
         HIP_TRY(svt_hip_memcpy2d_d2h_async(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
-        __sync_fetch_and_add(&g_lf_down_planes, 1); g_lf_down_mb += (double)pw * ph * p->pix_bytes / 1048576.0;
+        __sync_fetch_and_add(&g_lf_down_planes, 1); __sync_fetch_and_add(&g_lf_down_bytes, (long long)pw * ph * p->pix_bytes);
     }
     HIP_TRY(svt_hip_sync(hip));
     return EB_ErrorNone;

@@ -168,11 +168,13 @@ static int integer_search_resident(SvtHipCtx *hip, SvtHipMeBatch *b, const uint8
     int          rc = dev_need(hip, &b->d_job, &b->d_cap[2], off_mv + nres + 256);
     uint8_t     *d = (uint8_t *)b->d_job;
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d(hip, d, wins, sizeof(SvtHipSbSearch) * (size_t)n);
+    int big_before = 1;
+    if (rc == SVT_HIP_OK) rc = svt_hip_me_get_big_windows(hip, &big_before);
     if (rc == SVT_HIP_OK) rc = svt_hip_me_set_big_windows(hip, big);
     if (rc == SVT_HIP_OK) {
         rc = svt_hip_me_fullpel_frame_dev(hip, d_src, d_ref, p->stride_y, p->origin_x, p->origin_y, (const SvtHipSbSearch *)d, (int)n, b->sub_sad,
                                           (uint32_t *)(d + off_sad), (uint32_t *)(d + off_mv));
-        (void)svt_hip_me_set_big_windows(hip, 1);   /* the context's default */
+        (void)svt_hip_me_set_big_windows(hip, big_before);   /* whatever the context was configured with */
     }
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, sad, d + off_sad, nres);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, mv, d + off_mv, nres);

@@ -78,6 +78,7 @@ int svt_hip_me_fullpel_frame_dev(SvtHipCtx *c, const uint8_t *src, const uint8_t
     return SVT_HIP_OK;
 }
 int svt_hip_me_set_big_windows(SvtHipCtx *c, int enable) { (void)c; (void)enable; return SVT_HIP_OK; }   /* the double's search has one instance */
+int svt_hip_me_get_big_windows(SvtHipCtx *c, int *enabled) { (void)c; *enabled = 1; return SVT_HIP_OK; }
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,
                              const SvtHipSbSearch *sbs, int n_sb, int sub_sad, uint32_t *best_sad, uint32_t *best_mv) {
     (void)plane_rows;   /* search areas above 65 536 candidates: the product takes its strip kernel, the same results */

@@ -162,6 +162,7 @@ def lib():
     L.svt_hip_me_fullpel_frame.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp, i32, i32, u32p, u32p]
     L.svt_hip_me_set_waves_per_sb.argtypes = [vp, i32]
     L.svt_hip_me_set_big_windows.argtypes = [vp, i32]
+    L.svt_hip_me_get_big_windows.argtypes = [vp, C.POINTER(i32)]
     L.svt_hip_cdef_strength_select_dev.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_size_t]
     L.svt_hip_cdef_strength_select_multi_dev.argtypes = [vp, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i32, i32, i32, C.POINTER(C.c_void_p), C.c_size_t]
     L.svt_hip_set_cdef_select_form.argtypes = [vp, i32]

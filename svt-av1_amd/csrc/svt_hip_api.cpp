@@ -285,6 +285,12 @@ int svt_hip_me_set_big_windows(SvtHipCtx* c, int enable) {
     return SVT_HIP_OK;
 }
 
+int svt_hip_me_get_big_windows(SvtHipCtx* c, int* enabled) {
+    if (!c || !enabled) return SVT_HIP_ERR_BAD_ARG;
+    *enabled = c->me_big;
+    return SVT_HIP_OK;
+}
+
 int svt_hip_me_fullpel_frame_dev(SvtHipCtx* c, const uint8_t* d_src, const uint8_t* d_ref, int stride, int org_x,
                                  int org_y, const SvtHipSbSearch* d_sbs, int n_sb, int sub_sad, uint32_t* d_best_sad,
                                  uint32_t* d_best_mv) {
