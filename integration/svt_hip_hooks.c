@@ -466,7 +466,7 @@ static void enc_init_locked(int target_socket) {
         g_ctx = NULL;
         return;
     }
-    g_res_on = getenv("SVT_HIP_RESIDENT") && atoi(getenv("SVT_HIP_RESIDENT"));
+    g_res_on = !(getenv("SVT_HIP_RESIDENT") && !atoi(getenv("SVT_HIP_RESIDENT")));   /* default on since round 4 (verified on the MI355X: profiles/r04/resident_first_call_summary.txt); SVT_HIP_RESIDENT=0: a band upload per segment again */
     /* SVT_HIP_RESIDENT_FAULT=1, for the tests only: a plane's later announcements are ignored (its copy goes stale) */
     svt_hip_resident_configure(g_res_on, getenv("SVT_HIP_RESIDENT_MB") ? (size_t)atol(getenv("SVT_HIP_RESIDENT_MB")) << 20 : (size_t)16384 << 20 /* ~27 MB per 4K picture in flight, of 288 GB */,
                                getenv("SVT_HIP_RESIDENT_FAULT") && atoi(getenv("SVT_HIP_RESIDENT_FAULT")), svt_hip_hooks_malloc, svt_hip_hooks_free);

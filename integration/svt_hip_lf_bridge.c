@@ -907,8 +907,8 @@ static EbErrorType wiener_try(SvtHipCtx *hip, LfState *s, int pl, int h_start, i
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_unit_ep[pl] + u, &ep, 1));
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl] + 16 * u, wn, sizeof(wn)));
     HIP_TRY(svt_hip_lr_try_unit_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], plane_origin(p, p->d_rest[pl], pl), p->stride[pl], pw, ph, us,
-                                    pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl], p->d_unit_wiener[pl], p->d_src[pl],
-                                    p->src_stride[pl], u, p->d_sse));
+                                    pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->d_unit_ep[pl], p->d_unit_xqd[pl], p->d_unit_wiener[pl], p->src[pl],
+                                    p->src_st[pl], u, p->d_sse));
     HIP_TRY(svt_hip_memcpy_d2h(hip, &sse, p->d_sse, sizeof(sse)));
     *err = (int64_t)sse;
     return EB_ErrorNone;

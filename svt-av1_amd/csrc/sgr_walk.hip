@@ -37,7 +37,14 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
 };
 struct WalkPic { WalkPlane p[3]; int cap, clocks; };   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
-constexpr int kCache   = 256;    // >= the longest possible walk (tap ranges 128 / 128 at step 2, plus the step-1 probes)
+constexpr int kCache   = 256;    // evaluated points a walk can remember, see kThrottle
+// The exact walk (finer_search_pixel_proj_error, EbRestorationPick.c:353-440) evaluates at most 1 + 2 x (1 + 63) + 4 = 133 points: per parameter at step 2 one rejected
+// downward probe and then <= 63 upward ones (or <= 63 downward ones), at step 1 two probes per parameter.  Speculative requests (points the quadratic model walks
+// to but the exact walk does not) share the cache; on content where the model predicts nothing (binary 0 / max pictures: rounding and clamping dominate) nearly every
+// request beyond the first of a pass is wasted.  Once kThrottle points are cached a pass asks for ONE point -- the first unknown point, which is always on the exact
+// path -- so the cache holds <= kThrottle + kMaxCand - 1 + 133 <= 244 points and a walk ends within kThrottle + 133 passes <= kPassBudget: every walk finishes.
+// (Round 3 had 64 passes and no throttle: the extreme-content test of round 4 did not finish.)
+constexpr int kThrottle = 96, kPassBudget = 256;
 
 // eb_sgr_params (Common/Codec/EbRestoration.c:136-153): r0 > 0 for sets 0-9, 14, 15; r1 > 0 for sets 0-13.  Tap ranges: SGRPROJ_PRJ_MIN0 / MAX0 = -96 / 31,
 // MIN1 / MAX1 = -32 / 95 (EbRestoration.h:100-103).  Both are spelled out as arithmetic where they are used: no table loads on the serial path.
@@ -308,9 +315,9 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
     __syncthreads();
     const int cw = (w + 7) >> 3, nchunk = cw * (v1 - v0);
     int n_pass = 0, n_eval = 0;
-    for (int pass = 0; pass < 64; pass++) {
+    for (int pass = 0; pass < kPassBudget; pass++) {
         if (wave == 0) {
-            LdsStore K(L, lane, cap);
+            LdsStore K(L, lane, ((volatile int&)L.n_cache) >= kThrottle ? 1 : cap);
             WalkState W0; walk_begin(W0, start);   // the streamed form re-decides the whole walk every pass
             const ModelSums MS0 = load_model(S);
             const bool fin = replay(K, W0, ep, MS0);
@@ -383,7 +390,7 @@ sgr_walk_kernel(const uint32_t* __restrict__ pairs, const int16_t* __restrict__ 
     }
     // ---- results, and the unit's best set once all of its sets are in: search_selfguided_restoration :661-665 (first set with the smallest error)
     if (tid == 0) {
-        publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, L.res_x, L.res_y, L.done ? L.res_err : -1);   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+        publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, L.res_x, L.res_y, L.done ? L.res_err : -1);   // -1: walk not finished within the pass budget (cannot happen, see kThrottle; callers treat it as a failure)
         atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!L.done) atomicAdd(&stats[2], 1u);   // diagnostics
         const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
         if (arrived == (uint32_t)__popc(ep_mask)) pick_unit_best(xqd_out, err_out, unit, ep_mask, best_ep, best_xqd);
@@ -509,13 +516,23 @@ __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
     a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]); s = make_int4(sw[0], sw[1], sw[2], sw[3]);
 }
 
-template <int BD, int kT, int kJ, int NA, int PF = 1>   // NA > 8 (opt-in instance): one accumulator per candidate, and the walker also asks for the other outcome's next probe; NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
+// Accumulator ranges.  e = ((xq0 (flt0 - u) + xq1 (flt1 - u) + 2^10) >> 11) + dat - src (svt_av1_{lowbd,highbd}_pixel_proj_error, EbRestorationPick.c:174-330).
+// |flt - u| <= D with D = 17 560 at bit depth 10 (flt <= 16 * 1023 * (1 + the one_by_x rounding) + 1, u = 16 dat; sgr.hip stores it as int16) and 4 390 at 8;
+// svt_decode_xq (EbRestoration.c:707-718) gives xq0 in [-96, 31], xq1 = 128 - xqd0 - xqd1 in [2, 256], the extremes together at (-96, 256):
+//   |e| <= ((96 + 256) D + 2^10) >> 11  +  (2^bd - 1)  =  3 019 + 1 023 = 4 042 at bit depth 10 (1 010 at 8),   e^2 <= 16 337 764 < 2^24 (< 2^20).
+// A v_dot2_i32_i16 accumulator wraps modulo 2^32, so READ AS UNSIGNED it holds floor((2^32 - 1) / 16 337 764) = 262 squares at bit depth 10.  The largest restoration
+// unit is 383 x 383 samples (1.5 x 256 rounds to two units; foreach_rest_unit_in_tile, EbRestoration.c:1369-1411) = 48 x 383 chunks of eight: a data thread of the
+// 512-thread instances (448 data threads) sees <= 42 chunks = 336 squares, 168 per accumulator of the two-accumulator forms -> NO 64-bit drain inside a pass at either
+// bit depth (round 3 emptied the 10-bit accumulators every third chunk on the looser |e| < 2^13).  One-accumulator forms (sixteen candidates) and the 256-thread
+// instances (192 data threads: 96 chunks) exceed 262 squares at bit depth 10: they keep the periodic drain (DRAIN).  tests/test_sgr_gpu.py::test_search_units_largest_unit_extreme_content.
+template <int BD, int kT, int kJ, int NA, int PF = 1, bool DRAIN = false>   // NA > 8 (opt-in instance): one accumulator per candidate, and the walker also asks for the other outcome's next probe; NA = 0: every candidate walks the resident chunks (and re-streams the excess of an over-sized unit) on its own; PF = streamed chunks in flight ahead of the one being evaluated
 __global__ void __launch_bounds__(kT, (kT == 512 ? 4 : 1))   // the hybrid instances are built for two workgroups per compute unit: 128 registers
 sgr_walk_resident_kernel(const WalkPic a) {
     constexpr int kResT = kT, kResJ = kJ, kResD = kT - 64;
     constexpr bool HEDGE = NA > 8;                        // the sixteen-candidate instance's walker hedges its requests
-    constexpr bool ONE_ACC = NA > 8 || (BD > 8 && PF != 2);   // one int32 accumulator per candidate: the sixteen-candidate instance (bit depth 8: a thread's squares fit), and bit depth 10 with periodic 64-bit drains
+    constexpr bool ONE_ACC = NA > 8 || (DRAIN && PF != 2);   // one int32 accumulator per candidate: the sixteen-candidate instance (bit depth 8: a thread's squares fit), and the draining instances
     static_assert(NA <= 8 || BD == 8, "sixteen int32 accumulators hold a thread's squares at bit depth 8 only");
+    static_assert(BD == 8 || DRAIN || kT >= 512, "bit depth 10 without drains: <= 42 chunks per data thread (see above)");
     __shared__ ResLdsT<kT, kJ> R;
     WalkLds& L = R.W;
     // the planes of a picture share one launch (grid.z): one tail instead of three.  Scalar copies of the plane's arguments (a reference into the
@@ -560,9 +577,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
         bool fin = false;
         WalkState W; walk_begin(W, start);
         const ModelSums MS = load_model(S);
-        for (int pass = 0; pass < 64; pass++) {
+        const int cap0 = K.cap;
+        for (int pass = 0; pass < kPassBudget; pass++) {
             const unsigned long long r0 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_setprio(3);   // the replay is the serial part of the walk: it goes ahead of the other workgroup's evaluation waves on this SIMD
+            K.cap = K.n_cache >= kThrottle ? 1 : cap0;
             fin = replay<RegStore, HEDGE>(K, W, ep, MS);
             __builtin_amdgcn_s_setprio(0);
             c_replay += __builtin_readcyclecounter() - r0;
@@ -593,11 +612,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     K.key[b] = k; K.err[b] = e;
                 }
             }
-            K.n_cache = min(K.n_cache + nc, kCache);   // kCache is never reached: a walk visits < 200 points
+            K.n_cache = min(K.n_cache + nc, kCache);   // kCache is never reached (kThrottle)
         }
         // ---- results, and the unit's best set once all of its sets are in: search_selfguided_restoration :661-665 (first set with the smallest error)
         if (lane == 0) {
-            publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);   // -1: walk not finished within the pass budget (never observed; callers treat it as a failure)
+            publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);   // -1: walk not finished within the pass budget (cannot happen, see kThrottle; callers treat it as a failure)
             atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
             // phase clocks of the walk, in units of 64 shader cycles (diagnostics: tools/hbd_time.py)
             if (a.clocks) {
@@ -630,7 +649,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
     }
     int rnd, sel;
     asm volatile("s_mov_b32 %0, 0x8000\n\ts_mov_b32 %1, 0x07060302" : "=s"(rnd), "=s"(sel));   // opaque: kept in scalar registers
-    for (int pass = 0; pass < 64; pass++) {
+    for (int pass = 0; pass < kPassBudget; pass++) {
         __syncthreads();   // A
         if (L.done) break;
         const int nc = L.n_want;
@@ -662,7 +681,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 dot_drain();
 #pragma unroll
                 for (int c = 0; c < NA; c++)
-                    if (c < nc) { acc[c] += (long long)pp0[c] + (long long)pp1[c]; pp0[c] = pp1[c] = 0; }
+                    if (c < nc) { acc[c] += (long long)(uint32_t)pp0[c] + (long long)(uint32_t)pp1[c]; pp0[c] = pp1[c] = 0; }
             };
             if constexpr (PF == 2) {   // two chunks in flight: a compute unit's streaming rate is set by the bytes it has outstanding
                 int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
@@ -676,7 +695,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
                             if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
-                            if (BD > 8) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                            if (DRAIN) { dot_drain(); acc[c] += (long long)(uint32_t)pp0[c] + (long long)(uint32_t)pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
                     a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
                 }
@@ -692,10 +711,10 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     if (c < nc) {
                         if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
                     }
-                if (BD > 8 && ++since == kDrain) { drain(); since = 0; }
+                if (DRAIN && ++since == kDrain) { drain(); since = 0; }
                 a0 = b0; a1 = b1; s4 = t4; k = kn;
             }
-            if (BD > 8 && since) drain();
+            if (DRAIN && since) drain();
             }
             // ---- the resident chunks, slot by slot for all candidates (one LDS read of dat - src per slot)
 #pragma unroll
@@ -707,9 +726,9 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     for (int c = 0; c < NA; c++)
                         if (c < nc) {
                             if (ONE_ACC) eval_chunk_f1(pa[j], pb[j], sx, qq[c], sel, pp0[c]); else eval_chunk_f(pa[j], pb[j], sx, qq[c], sel, pp0[c], pp1[c]);
-                            if (BD > 8 && PF == 2) { dot_drain(); acc[c] += pp0[c] + pp1[c]; pp0[c] = pp1[c] = 0; }
+                            if (DRAIN && PF == 2) { dot_drain(); acc[c] += (long long)(uint32_t)pp0[c] + (long long)(uint32_t)pp1[c]; pp0[c] = pp1[c] = 0; }
                         }
-                    if (BD > 8 && PF != 2 && (j + 1) % kDrain == 0 && j + 1 < kResJ) drain();
+                    if (DRAIN && PF != 2 && (j + 1) % kDrain == 0 && j + 1 < kResJ) drain();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -717,7 +736,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
 #pragma unroll
             for (int c = 0; c < NA; c++)
                 if (c < nc) {
-                    const long long sum = wave_sum_u48(acc[c] + (long long)pp0[c] + (long long)pp1[c]);
+                    const long long sum = wave_sum_u48(acc[c] + (long long)(uint32_t)pp0[c] + (long long)(uint32_t)pp1[c]);   // the accumulators are read as unsigned (see the ranges above)
                     if (lane == 0) L.part[wave][c] = sum;
                 }
         }
@@ -733,11 +752,11 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     const int4 sc = sn;
                     if (j + 1 < kResJ) sn = R.sd[(j + 1) * kResD + t];
                     eval_chunk(pa[j], pb[j], sc, q, rnd, sel, p0, p1);
-                    if (BD > 8) { dot_drain(); acc += p0 + p1; p0 = p1 = 0; }   // |e| < 2^13 at bit depth 10: eight squares per accumulator stay below 2^31; at 8 (|e| < 2^10) all 72 do
+                    if (DRAIN) { dot_drain(); acc += (long long)(uint32_t)p0 + (long long)(uint32_t)p1; p0 = p1 = 0; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (BD == 8) { dot_drain(); acc += p0 + p1; p0 = p1 = 0; }
+            if (!DRAIN) { dot_drain(); acc += (long long)(uint32_t)p0 + (long long)(uint32_t)p1; p0 = p1 = 0; }   // <= 9 resident chunks: 36 squares per accumulator
             for (int k = t + kResJ * kResD; k < nchunk; k += kResD) {   // the part of an over-sized unit that is not resident
                 const int row = k / cw, cx = k - row * cw;
                 const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
@@ -745,9 +764,9 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 const int n = w - 8 * cx;
                 if (n < 8) mask_chunk(a0, a1, s, n);
                 eval_chunk(a0, a1, s, q, rnd, sel, p0, p1);
-                dot_drain(); acc += p0 + p1; p0 = p1 = 0;
+                dot_drain(); acc += (long long)(uint32_t)p0 + (long long)(uint32_t)p1; p0 = p1 = 0;
             }
-            const long long sum = wave_sum_u48(acc);   // acc < 72 x 2^26
+            const long long sum = wave_sum_u48(acc);   // acc < 2^48
             if (lane == 0) L.part[wave][c] = sum;
         }
         if (tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); }   // diagnostics: the candidate loop as wave 1 sees it
@@ -767,10 +786,11 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     const bool stream_form = form_env && !strcmp(form_env, "stream"), resident_form = form_env && !strcmp(form_env, "resident");
     static const int  cap_env = getenv("SVT_HIP_SGR_WALK_CAND") ? atoi(getenv("SVT_HIP_SGR_WALK_CAND")) : 0;
     constexpr int kHybT = 512, kHybJ = 7, kHybNA = 8;
-    constexpr int kHybNA10 = 7;   // bit depth 10: an int32 accumulator + a 64-bit sum per candidate; 7 spill 20 registers outside the loops and still win (MI355X, configs[3] unit search: 5: 2.02-2.03, 6: 1.95, 7: 1.90 ms; 8 spill 51)
+    constexpr int kHybNA10 = 7;   // bit depth 10, DRAINING instances (256-thread forms, and SVT_HIP_SGR_WALK_NA10=7 for A/B runs: the round-3 default): an int32 accumulator + a 64-bit sum per candidate; 7 spill 20 registers outside the loops and still win (MI355X, configs[3] unit search: 5: 2.02-2.03, 6: 1.95, 7: 1.90 ms; 8 spill 51).  The default since round 4 is the bit-depth-8 form itself (eight candidates, two accumulators, no drains: the range argument above sgr_walk_resident_kernel)
     static const bool hyb16 = form_env && !strcmp(form_env, "hybrid16");   // opt-in: sixteen points per pass (one accumulator each) + hedged requests, bit depth 8
-    static const int na10_env = getenv("SVT_HIP_SGR_WALK_NA10") ? atoi(getenv("SVT_HIP_SGR_WALK_NA10")) : 0;   // A/B: 5 or 6 accumulators at bit depth 10
-    const int na10 = (na10_env == 5 || na10_env == 6) ? na10_env : kHybNA10;
+    static const int na10_env = getenv("SVT_HIP_SGR_WALK_NA10") ? atoi(getenv("SVT_HIP_SGR_WALK_NA10")) : 0;   // A/B: 7 = the draining seven-candidate instance of round 3
+    static const bool small_form = form_env && (!strcmp(form_env, "hybrid256") || !strcmp(form_env, "hybrid256j"));
+    const int na10 = (na10_env == kHybNA10 || small_form) ? kHybNA10 : kHybNA;
     const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? (hyb16 ? 16 : kHybNA) : na10));
     const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
     WalkPic a = {};
@@ -812,10 +832,10 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     if (hyb256 || hyb256j) {   // experiment: four smaller workgroups per compute unit (one walker + three data waves each)
         if (hyb256) {
             if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, 256, kHybJ, kHybNA>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, kHybJ, kHybNA10>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, kHybJ, kHybNA10, 1, true>), grid, dim3(256), 0, st, a);
         } else {
             if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, 256, 9, kHybNA>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, 9, kHybNA10>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, 256, 9, kHybNA10, 1, true>), grid, dim3(256), 0, st, a);
         }
         return (int)hipGetLastError();
     }
@@ -824,9 +844,8 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
         else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kResT, kResJ, 0>), grid, dim3(kResT), 0, st, a);
     } else {
         if (bd == 8) hipLaunchKernelGGL((sgr_walk_resident_kernel<8, kHybT, kHybJ, kHybNA>), grid, dim3(kHybT), 0, st, a);
-        else if (na10 == 5) hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, 5>), grid, dim3(kHybT), 0, st, a);
-        else if (na10 == 6) hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, 6>), grid, dim3(kHybT), 0, st, a);
-        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, kHybNA10>), grid, dim3(kHybT), 0, st, a);
+        else if (na10 == kHybNA10) hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, kHybNA10, 1, true>), grid, dim3(kHybT), 0, st, a);
+        else hipLaunchKernelGGL((sgr_walk_resident_kernel<10, kHybT, kHybJ, kHybNA>), grid, dim3(kHybT), 0, st, a);
     }
     return (int)hipGetLastError();
 }

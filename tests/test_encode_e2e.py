@@ -290,6 +290,19 @@ def test_resident_source_planes_on_cpu_test_double(case, workdir):
         assert hits > 10 * uploads, (notes, uploads, mb, hits)
 
 
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_10bit_m6"])
+def test_without_resident_source_planes_on_cpu_test_double(case, workdir):
+    """SVT_HIP_RESIDENT=0 (the default until round 4): every ME / HME / TF segment uploads its own row bands again; no table line in the report"""
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "0"}, "mock_not_resident")
+    assert not re.findall(r"svt_hip_resident notes=[1-9]", got["log"])
+
+
+def test_resident_source_planes_are_the_default_on_cpu_test_double(workdir):
+    case = "cif_8bit_m4"
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock_resident_default")
+    assert _resident_line(got["log"])[3] > 0
+
+
 def test_resident_source_planes_with_a_small_budget_on_cpu_test_double(workdir):
     """SVT_HIP_RESIDENT_MB=1: hardly any plane fits, the oldest unused copies are dropped and uploaded again on demand (or the caller uploads its band as before)."""
     case = "360p_8bit_m7"
@@ -562,7 +575,7 @@ def test_deferred_pictures_cross_the_bus_once_on_cpu_test_double(workdir):
     spec = CASES[case]
     n = spec[2]
     mock = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}
-    a = _lf_pictures(_encode_like(case, spec, workdir, mock, "mock_defer")["log"])
+    a = _lf_pictures(_encode_like(case, spec, workdir, dict(mock, SVT_HIP_RESIDENT="0"), "mock_defer")["log"])
     assert (a["deferred"], a["recovered"], a["up"], a["down"]) == (n, 0, 6 * n, 3 * n), a
     b = _lf_pictures(_encode_like(case, spec, workdir, dict(mock, SVT_HIP_RESIDENT="1"), "mock_defer_res")["log"])
     assert (b["deferred"], b["resident"], b["up"], b["down"]) == (n, 3 * n, 3 * n, 3 * n), b
@@ -601,6 +614,15 @@ def test_resident_source_planes_on_gpu(case, workdir):
     got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
     assert "svt_hip MOCK" not in got["log"]
     assert _resident_line(got["log"])[3] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["360p_8bit_m7", "720p_10bit_m5"])
+def test_without_resident_source_planes_on_gpu(case, workdir):
+    """SVT_HIP_RESIDENT=0 on the device: the band uploads of the rounds before"""
+    spec = CASES.get(case) or GPU_ONLY_CASES[case]
+    got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "0"}, "hip_not_resident")
+    assert "svt_hip MOCK" not in got["log"] and not re.findall(r"svt_hip_resident notes=[1-9]", got["log"])
 
 
 @pytest.mark.gpu

@@ -311,6 +311,37 @@ def test_search_units_plane(hip, orc, bd):
         if mask == 0xFFFF: assert len(set(int(v) for v in e_best)) > 1, "content should make different sets win"
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_units_largest_unit_extreme_content(hip, orc, bd):
+    """The walk's error accumulators (sgr_walk.hip, "Accumulator ranges"): ONE restoration unit of the largest size a picture can have (376 x 376 with unit size 256:
+    383 is the limit, 1.5 x 256 rounds to two units), binary 0 / max content against its complement, an unrelated binary source and a flat extreme -- the per-sample
+    error is as large as content can make it and a data thread sees its maximum number of chunks.  xqd, error and best set of all 16 sets against the oracle."""
+    w = h = 376
+    US, mx = 256, (1 << bd) - 1
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(900 + bd)
+    yy, xx = np.mgrid[0:h, 0:w]
+    dgd = np.zeros((h, w), np.int64)
+    dgd[:, :128] = mx * ((xx[:, :128] + yy[:, :128]) & 1)                          # 1-px checkerboard
+    dgd[:, 128:256] = mx * (((xx[:, 128:256] >> 1) + (yy[:, 128:256] >> 2)) & 1)   # 2 x 4 blocks
+    dgd[:, 256:] = mx * rng.integers(0, 2, (h, w - 256))                           # binary noise
+    assert units(w, US) == 1 and units(h, US) == 1
+    for kind in ("complement", "binary", "flat"):
+        src = {"complement": mx - dgd, "binary": mx * rng.integers(0, 2, (h, w)), "flat": np.full((h, w), mx, np.int64)}[kind]
+        ext = np.ascontiguousarray(np.pad(dgd.astype(dt), EXT, mode="edge")); st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        srcp = np.ascontiguousarray(src.astype(dt))
+        e_xqd = np.zeros((1, 16, 2), np.int32); e_err = np.zeros((1, 16), np.int64); e_best = np.zeros(1, np.uint8)
+        orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(srcp), w, w, h, 0, 0, US, bd, 0xFFFF, ptr(e_xqd), ptr(e_err), ptr(e_best))
+        d_ext, d_src = hip.to_device(ext), hip.to_device(srcp)
+        g_xqd = np.zeros_like(e_xqd); g_err = np.zeros_like(e_err); g_best = np.zeros_like(e_best); rounds = C.c_int(0)
+        hip.check(hip.L.svt_hip_sgr_search_units_plane(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, 0, 0xFFFF, ptr(g_xqd), ptr(g_err), ptr(g_best),
+                                                       C.byref(rounds)), "search units")
+        hip.free(d_ext, d_src)
+        if bd == 10 and kind != "flat": assert e_err.max() > (1 << 34), "the unit's error must be far past 32 bits"
+        assert np.array_equal(g_err, e_err), (bd, kind, np.argwhere(g_err != e_err)[:5], g_err, e_err)
+        assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best), (bd, kind)
+
+
 def test_search_units_picture(hip, pkg, orc):
     """Three planes in one call (svt_hip_sgr_search_units_picture) = the per-plane results."""
     w, h, bd = 264, 200, 8
