@@ -445,16 +445,36 @@ def main():
             return [capture(lambda b=b: batch_step(b, stage_list, pre)).replay for b in batches]
         return [lambda b=b: batch_step(b, stage_list, pre) for b in batches]
 
+    # SVT_BENCH_OVERLAP=1 (experiment, graph replays only): consecutive steps -- they work on distinct batches -- are replayed on two alternating streams, so that one
+    # step's latency-bound phases (the strength decision) can sit beside the next step's searches; SVT_BENCH_OVERLAP_LAG_US=<n> delays the second stream once by n us.
+    overlap = bool(os.environ.get("SVT_BENCH_OVERLAP")) and use_graph
+    alt = [torch.cuda.Stream(), torch.cuda.Stream()] if overlap else None
+    lag_cycles = int(float(os.environ.get("SVT_BENCH_OVERLAP_LAG_US", "0")) * 100)   # torch.cuda._sleep counts in units of ~10 ns here (100 MHz timer)
+
+    def run_steps(fns, n):
+        if not overlap or len(fns) < 2:
+            for i in range(n):
+                fns[i % len(fns)]()
+            return
+        for st in alt:
+            st.wait_stream(torch.cuda.current_stream())
+        if lag_cycles:
+            with torch.cuda.stream(alt[1]):
+                torch.cuda._sleep(lag_cycles)
+        for i in range(n):
+            with torch.cuda.stream(alt[i % 2]):
+                fns[i % len(fns)]()
+        for st in alt:
+            torch.cuda.current_stream().wait_stream(st)
+
     def timed(fns, steps, warmup, barrier):
-        for i in range(warmup):
-            fns[i % len(fns)]()
+        run_steps(fns, warmup)
         torch.cuda.synchronize()
         if barrier and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            fns[i % len(fns)]()
+        run_steps(fns, steps)
         torch.cuda.synchronize()
         if barrier and world > 1:
             dist.barrier()
