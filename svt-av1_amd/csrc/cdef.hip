@@ -337,7 +337,7 @@ cdef_search_luma_kernel(const PIX* __restrict__ rec, int rec_stride, const PIX* 
     __shared__ __attribute__((aligned(16))) PIX stab[4][64];
     __shared__ int part[4][128];
     __shared__ unsigned long long accum[4][64];
-    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nhfb = (w + 63) >> 6, fb = svt_xcd_order(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
     const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // svt_sb_all_skip (EbEncCdef.c:222): nothing to do, table entry stays untouched
@@ -418,7 +418,7 @@ cdef_search_chroma_kernel(const PIX* __restrict__ rec_u, const PIX* __restrict__
     __shared__ __attribute__((aligned(16))) PIX ytab[4][64][64 + 16 / sizeof(PIX)];
     __shared__ __attribute__((aligned(16))) PIX stab[4][64];
     __shared__ unsigned long long accum[4][2][64];
-    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nhfb = (w + 63) >> 6, fb = svt_xcd_order(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
     const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int any = 0;
@@ -485,7 +485,7 @@ cdef_apply_kernel(const PIX* __restrict__ in, PIX* __restrict__ out, int stride,
     constexpr int DEC = PLANE_KIND, FBS = 64 >> DEC, TS = FBS + 2 * kHB;
     __shared__ uint16_t tile[(FBS + 2 * kVB) * TS];
     __shared__ int part[4][128];
-    const int nhfb = (w + 63) >> 6, fb = blockIdx.x, fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
+    const int nhfb = (w + 63) >> 6, fb = svt_xcd_order(blockIdx.x, gridDim.x), fbr = fb / nhfb, fbc = fb - fbr * nhfb, c8 = w >> 3;
     const int nbx = min(8, c8 - 8 * fbc), nby = min(8, (h >> 3) - 8 * fbr);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ly = y_strength[fb] >> 2, sy = y_strength[fb] & 3, lu = uv_strength[fb] >> 2, su = uv_strength[fb] & 3;

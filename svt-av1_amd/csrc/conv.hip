@@ -25,7 +25,7 @@ subpel_predict_kernel(const PIX* __restrict__ ref, int ref_stride, PIX* __restri
                       const SvtHipConvBlk* __restrict__ blks) {
     __shared__ int s_src[23 * 24];
     __shared__ int s_im[23 * 16];
-    const SvtHipConvBlk b = blks[blockIdx.x];
+    const SvtHipConvBlk b = blks[svt_xcd_order(blockIdx.x, gridDim.x)];   // the job list is in raster order of the blocks: an XCD takes a band of them
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int sx = b.subpel_x & 15, sy = b.subpel_y & 15;
     constexpr int pix_max = (1 << BD) - 1;

@@ -240,7 +240,8 @@ deblock_fused_kernel(const DeblockFused f, int sharpness) {
     const uint16_t* eh = p == 0 ? f.eh[0] : (p == 1 ? f.eh[1] : f.eh[2]);
     const int units_w = p == 0 ? f.units_w[0] : (p == 1 ? f.units_w[1] : f.units_w[2]), units_h = p == 0 ? f.units_h[0] : (p == 1 ? f.units_h[1] : f.units_h[2]);
     const int pw = p == 0 ? f.pw[0] : (p == 1 ? f.pw[1] : f.pw[2]), ph = p == 0 ? f.ph[0] : (p == 1 ? f.ph[1] : f.ph[2]);
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, x0 = tx * kFW, y0 = ty * kFH, tid = threadIdx.x;
+    const int tile = svt_xcd_order(blockIdx.x, tiles_x * tiles_y);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x, x0 = tx * kFW, y0 = ty * kFH, tid = threadIdx.x;
     const int tw = min(kFW, pw - x0), th = min(kFH, ph - y0);
     // t[r][c] <-> plane (x0 - 8 + c, y0 - 7 + r).  Whole dwords when the plane allows it (base and stride dword-aligned, the dword inside the row), else sample by sample.
     const bool fast = ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) && ((stride * (int)sizeof(PIX)) & 3) == 0;

@@ -219,7 +219,7 @@ me_fullpel_85pu_kernel(const uint8_t* __restrict__ src, const uint8_t* __restric
     __shared__ uint32_t lds_red[WAVES][2][8];   // per-wave reduced (sad, index) of the five 64-bit-key PUs
     __shared__ uint32_t lds_part[NT], lds_fin[88];
 
-    const int sb  = blockIdx.x;
+    const int sb  = svt_xcd_order(blockIdx.x, gridDim.x);   // neighbouring superblocks' search windows overlap: an XCD takes a band of superblock rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SvtHipSbSearch d = sbs[sb];
     const int saw = d.width, sah_all = d.height;

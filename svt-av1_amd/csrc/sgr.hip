@@ -373,7 +373,8 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
     __shared__ unsigned long long acc[16][5];
     __shared__ unsigned long long acc_d2;
-    const int x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
+    const int tile = svt_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
+    const int x0 = tile_x * S_TW, y0 = tile_y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
 
     {
@@ -650,7 +651,8 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];
     __shared__ uint32_t xt[256];
-    const int x0 = (blockIdx.x + tile_x0) * S_TW, y0 = (blockIdx.y + tile_y0) * S_TH - voff, tid = threadIdx.x;   // (tile_x0, tile_y0): first tile of a partial launch
+    const int tile = svt_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
+    const int x0 = (tile_x + tile_x0) * S_TW, y0 = (tile_y + tile_y0) * S_TH - voff, tid = threadIdx.x;   // (tile_x0, tile_y0): first tile of a partial launch
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     const int ep = unit_ep[unit];
     const bool wiener = ep == 254 && unit_wiener != nullptr;

@@ -8,6 +8,21 @@
 
 // One empty kernel per translation unit: svt_hip_warmup() asks for its attributes, which makes the runtime load that unit's code object for the current device
 // now (HIP loads a unit's code object at the first launch of any of its kernels — inside an encoder that is the first picture's clock).
+// XCD-aware workgroup order.  MI355X dispatches workgroup b of a launch to XCD b % 8 (observed, not promised: /opt/skills/guides/MI355X_MICROARCH.md "Workgroup
+// dispatch, XCD placement"), and every XCD has its own 4 MB L2.  A kernel whose neighbouring tiles share a halo (sub-pel windows, CDEF / restoration / deblocking tiles,
+// motion-search windows) maps workgroup b to logical tile svt_xcd_order(b, n) instead of b: XCD x then walks ONE contiguous range of the n tiles (a band of the
+// picture), so a halo is fetched from memory once per band instead of once per XCD that touches it.  Bijective for every n.  A speed choice only -- nothing depends on
+// where a workgroup runs.  SVT_HIP_NO_XCD_ORDER (compile time) keeps the identity for A/B builds.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int svt_xcd_order(int b, int n) {
+#ifdef SVT_HIP_NO_XCD_ORDER
+    (void)n; return b;
+#else
+    const int q = n >> 3, r = n & 7, x = b & 7, s = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+#endif
+}
+#endif
 #define SVT_HIP_TU_PROBE(name)                                                                                                    \
     namespace { __global__ void tu_probe_kernel_##name() {} }                                                                      \
     extern "C" int svt_hip_tu_probe_##name() {                                                                                     \

@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENC
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1
-cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py rc=$? bytes=$(wc -c < $OUT/bench.json)" >> $OUT/bench.err
+cd $R && PYTHONFAULTHANDLER=1 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench.py rc=$? bytes=$(wc -c < $OUT/bench.json)" >> $OUT/bench.err
 [ -s $OUT/bench.json ] || { sleep 2; python bench.py > $OUT/bench.json 2>> $OUT/bench.err; echo "bench.py (second attempt) rc=$? bytes=$(wc -c < $OUT/bench.json)" >> $OUT/bench.err; }
 # kernels outside the bench step: HIP-event timings
 (python tools/wiener_time.py; python tools/tf_time.py; python tools/tf_time.py --bd 10; python tools/compound_time.py; python tools/hbd_time.py --bd 8; python tools/hbd_time.py --bd 10; python tools/cdef_pick_time.py; SVT_HIP_CDEF_SELECT=resident python tools/cdef_pick_time.py; PICK_MAG=31 python tools/cdef_pick_time.py; PICK_MAG=31 SVT_HIP_CDEF_SELECT=resident python tools/cdef_pick_time.py) > $OUT/extra_kernels.txt 2>&1
