@@ -153,7 +153,7 @@ static void cache_put(SvtHipCtx *hip, void *p) {
     svt_hip_free(hip, p);
 }
 
-/* Resident planes (SVT_HIP_RESIDENT=1; off by default until it has been measured on the MI355X).  The luma planes of an EbPaReferenceObject — the padded
+/* Resident planes (on by default since round 4, measured on the MI355X: profiles/r04/resident_first_call_summary.txt; SVT_HIP_RESIDENT=0 = off).  The luma planes of an EbPaReferenceObject — the padded
  * picture and its 1/4 and 1/16 versions — are written at exactly two places of the reference: picture analysis (picture_analysis_kernel, EbPictureAnalysisProcess.c
  * :3960-3994; the overlay twin in EbPictureDecisionProcess.c:3644-3680) and the end of the temporal filter (pad_and_decimate_filtered_pic, EbTemporalFiltering.c:2556),
  * and read by every ME / HME / TF-ME segment of the picture itself and of every picture that references it.  The patched reference announces each write

@@ -11,7 +11,7 @@
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
  *   SVT_HIP_CONTEXTS = contexts of the source-side bridges' pool (default 4), SVT_HIP_ALLOC_CACHE_MB = their block cache (default 1024),
- *   SVT_HIP_RESIDENT=1 = source-side planes stay on the device between their writes (opt-in; SVT_HIP_RESIDENT_MB, default 16384) — svt_hip_hooks.c
+ *   SVT_HIP_RESIDENT=0 = source-side planes are uploaded per segment again (default since round 4: they stay on the device between their writes; SVT_HIP_RESIDENT_MB, default 16384) — svt_hip_hooks.c
  * Unset / empty SVT_HIP_HOOKS = none: the patched encoder then IS the reference encoder.
  */
 #ifndef SVT_HIP_HOOKS_H
@@ -87,7 +87,7 @@ void       svt_hip_hooks_unlock(void);
 /* device memory through the hooks' block cache (power-of-two size classes, SVT_HIP_ALLOC_CACHE_MB); pointers of svt_hip_malloc may be passed to the free too */
 int        svt_hip_hooks_malloc(SvtHipCtx *hip, void **p, size_t bytes);
 void       svt_hip_hooks_free(SvtHipCtx *hip, void *p);
-/* resident planes (SVT_HIP_RESIDENT=1): the table is svt_hip_resident.h (announce / acquire / release on host pointers); these announce the planes of the reference's
+/* resident planes (default; SVT_HIP_RESIDENT=0 turns them off): the table is svt_hip_resident.h (announce / acquire / release on host pointers); these announce the planes of the reference's
  * pictures from the patched reference (and the picture-analysis hook) right after they have been written */
 void svt_hip_hooks_resident_note_picture(const EbPictureBufferDesc *pic);   /* the whole padded luma plane of pic */
 void svt_hip_hooks_resident_note_pa(const PictureParentControlSet *pcs, const EbPictureBufferDesc *padded, const EbPictureBufferDesc *quarter,

@@ -277,7 +277,7 @@ def _resident_line(log):
 
 @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "cif_10bit_m6"])
 def test_resident_source_planes_on_cpu_test_double(case, workdir):
-    """SVT_HIP_RESIDENT=1: the padded luma plane of every picture and its 1/4 and 1/16 versions are uploaded once per (re)write -- picture analysis, the end of the
+    """Resident planes (the default; set explicitly here): the padded luma plane of every picture and its 1/4 and 1/16 versions are uploaded once per (re)write -- picture analysis, the end of the
     temporal filter -- and every ME / HME / TF-ME segment reads that copy instead of uploading its own row band (integration/svt_hip_hooks.c).  Host logic only (which
     copy is current), so the CPU test double pins it: a stale plane changes the motion search and with it the bitstream.  The planes must really have been used."""
     got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "mock_resident")
@@ -609,7 +609,7 @@ def test_not_deferred_pictures_on_gpu(workdir):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_8bit_m4", "720p_8bit_m6", "cif_10bit_m6", "720p_10bit_m5"])
 def test_resident_source_planes_on_gpu(case, workdir):
-    """SVT_HIP_RESIDENT=1 on the device: planes uploaded by one context's stream and read by kernels of the other contexts of the pool, 8- and 10-bit"""
+    """Resident planes on the device (the default; set explicitly here): planes uploaded by one context's stream and read by kernels of the other contexts of the pool, 8- and 10-bit"""
     spec = CASES.get(case) or GPU_ONLY_CASES[case]
     got = _check(case, spec, workdir, {"SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "hip_resident")
     assert "svt_hip MOCK" not in got["log"]

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Run ON THE GPU BOX (gpurun --timeout 1500 -- 'bash tools/resident_first_call.sh'): everything the opt-in SVT_HIP_RESIDENT=1 path still owes — it was written
-# when round 3's GPU budget was spent and has only run on the CPU test double.  -> gpurun_out/resident/
-#   1. its GPU tests (bitstream + reconstruction identical to the unpatched encoder with the planes resident; SVT_HIP_TEST_RESIDENT=1 un-skips them)
+# Run ON THE GPU BOX (gpurun --timeout 1500 -- 'bash tools/resident_first_call.sh').  Record of the first GPU call of round 4: what the resident-plane path owed when it was
+# written at the end of round 3 (only the CPU test double had run it).  The path is the default now.  -> gpurun_out/resident/
+#   1. its GPU tests (bitstream + reconstruction identical to the unpatched encoder with the planes resident; ordinary -m gpu tests since round 4)
 #   2. encode time of the SIMD build with the hooks, without and with resident planes, against the SIMD reference (tools/encoder_walltime.sh, NAME_res applications)
 #   3. kernel statistics of a hooked 4K encode with resident planes (the copy kernels' share; round 3 without: 42 %, profiles/r03/encoder_hooks_4k_kernel_stats.csv)
 set -u
