@@ -36,7 +36,7 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     int dstride, pw, ph, unit_size, units_x, units_y, voff; uint32_t ep_mask;
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
 };
-struct WalkPic { WalkPlane p[3]; int cap, clocks; };   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
+struct WalkPic { WalkPlane p[3]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
 constexpr int kCache   = 256;    // evaluated points a walk can remember, see kThrottle
 // The exact walk (finer_search_pixel_proj_error, EbRestorationPick.c:353-440) evaluates at most 1 + 2 x (1 + 63) + 4 = 133 points: per parameter at step 2 one rejected
 // downward probe and then <= 63 upward ones (or <= 63 downward ones), at step 1 two probes per parameter.  Speculative requests (points the quadratic model walks
@@ -59,6 +59,7 @@ struct WalkLds {
     int       done, res_x, res_y;
     long long res_err;
     int       last;
+    int       ovf_n;                    // histogram evaluation: samples outside the histogram's window so far (the first kCache of them are listed in cx / cy)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -555,6 +556,17 @@ sgr_walk_resident_kernel(const WalkPic a) {
     const int  ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
     const uint32_t* __restrict__ PP = pairs + (size_t)ce * dplane;
     const long long* S = sums + ((size_t)unit * 16 + ep) * 5;
+    // ---- HISTOGRAM EVALUATION of the one-filter sets (10 .. 13: r0 = 0, 14 / 15: r1 = 0).  With one tap the error of a sample is e = q(d) + (dat - src),
+    // q(d) = (xq d + 2^10) >> 11, d = flt - u: samples with equal d share q, so  sum e^2 = sum_d [n_d q(d)^2 + 2 q(d) R_d] + sum (dat - src)^2  with n_d the number of
+    // samples with that d and R_d the sum of their dat - src -- exactly, rounding included.  The unit is streamed ONCE into a histogram over d in LDS (one 64-bit
+    // atomic per sample: n_d in the upper 24 bits, sum (dat - src + 1024) below; the storage of the resident dat - src values, which this form does not need), and a
+    // candidate point then costs (2 W + 1) / threads bins per thread instead of a pass over the unit's samples: no resident chunks, no re-streaming, sixteen points per
+    // pass.  |d| is a few hundred on coded pictures (the filter passes high-variance samples through), its bound is 17 560: a sample outside the window |d| <= W goes to
+    // a list of kCache exact (d, dat - src) entries, and a unit with more of them than that is evaluated sample by sample like the two-filter sets (decided after the
+    // streaming pass; SVT_HIP_SGR_WALK_HIST_W narrows W so that tests reach the list and the fall-back).
+    constexpr int kHistWMax = (int)(sizeof(R.sd) / 16) - 1 < 3071 ? (int)(sizeof(R.sd) / 16) - 1 : 3071;   // bins d + W, 0 <= . <= 2 W, in the storage of R.sd
+    const bool try_hist = NA > 0 && !(has0 && has1) && a.hist_w >= 0;   // workgroup-uniform
+    const int  W = min(kHistWMax, a.hist_w);
 
     if (wave == 0) {
         // =================================== the walk: solve, replay, cache ===================================
@@ -572,19 +584,26 @@ sgr_walk_resident_kernel(const WalkPic a) {
         // replays instead of three: the serial replay is more than half of such a walk)
         const bool whole = NA > 0 && ((w + 7) >> 3) * (v1 - v0) <= kResJ * kResD;
         K.wkey = -1; K.lane = lane; K.n_cache = 0; K.nw = 0; K.cap = whole ? kMaxCand : cap; K.res_x = start[0]; K.res_y = start[1]; K.res_err = -1;
+        bool hist = false;
+        if (try_hist) { if (lane == 0) L.ovf_n = 0; __syncthreads(); }   // H: the data waves have cleared the histogram, the list is empty
         const unsigned long long c1 = __builtin_readcyclecounter();
         int n_pass = 0, n_eval = 0;
         bool fin = false;
-        WalkState W; walk_begin(W, start);
+        WalkState WS; walk_begin(WS, start);
         const ModelSums MS = load_model(S);
-        const int cap0 = K.cap;
+        int cap0 = K.cap;
         for (int pass = 0; pass < kPassBudget; pass++) {
             const unsigned long long r0 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_setprio(3);   // the replay is the serial part of the walk: it goes ahead of the other workgroup's evaluation waves on this SIMD
             K.cap = K.n_cache >= kThrottle ? 1 : cap0;
-            fin = replay<RegStore, HEDGE>(K, W, ep, MS);
+            fin = replay<RegStore, HEDGE>(K, WS, ep, MS);
             __builtin_amdgcn_s_setprio(0);
             c_replay += __builtin_readcyclecounter() - r0;
+            if (try_hist && pass == 0) {   // H2: the unit has been streamed (this first replay ran beside it); from the next pass on a histogram walk asks for sixteen points
+                __syncthreads();
+                hist = ((volatile int&)L.ovf_n) <= kCache;
+                if (hist) cap0 = kMaxCand;
+            }
             const int nc = K.nw;
             if (lane == 0) { L.done = fin ? 1 : 0; L.n_want = nc; }
             if (lane < nc) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718)
@@ -618,6 +637,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
         if (lane == 0) {
             publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);   // -1: walk not finished within the pass budget (cannot happen, see kThrottle; callers treat it as a failure)
             atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
+            if (hist) atomicAdd(&stats[3], 1u);   // walks evaluated on the histogram
             // phase clocks of the walk, in units of 64 shader cycles (diagnostics: tools/hbd_time.py)
             if (a.clocks) {
                 atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
@@ -631,6 +651,75 @@ sgr_walk_resident_kernel(const WalkPic a) {
     // =================================== the pixels: load once, evaluate every pass ===================================
     const int t = tid - 64;
     const int cw = (w + 7) >> 3, nchunk = cw * (v1 - v0);
+    if (try_hist) {
+        unsigned long long* H = (unsigned long long*)&R.sd[0];
+        // (a private copy of the histogram per data wave was measured and bought nothing: streaming the unit, not the atomics, is what this phase costs)
+        const int nb = 2 * W + 1;
+        for (int b = t; b < nb; b += kResD) H[b] = 0ull;
+        __syncthreads();   // H
+        // ---- the unit, once: one atomic per sample (the next chunk's loads are issued before this chunk's atomics)
+        unsigned long long r2 = 0;
+        int k = t;
+        int4 a0 = make_int4(0, 0, 0, 0), a1 = a0, s4 = a0;
+        auto fetch = [&](int kk, int4& x0v, int4& x1v, int4& sv) {
+            const int row = kk / cw, cx = kk - row * cw;
+            const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+            x0v = *(const int4*)(PP + off); x1v = *(const int4*)(PP + off + 4); sv = *(const int4*)(sd + off);
+        };
+        if (k < nchunk) fetch(k, a0, a1, s4);
+        while (k < nchunk) {
+            const int kn = k + kResD;
+            int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
+            if (kn < nchunk) fetch(kn, b0, b1, t4);
+            const int cx = k % cw, n = min(8, w - 8 * cx);
+            const int pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const int sw[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < n) {
+                    const int d = has0 ? (int)(int16_t)(pr[i] & 0xFFFF) : (pr[i] >> 16);
+                    const int r = (i & 1) ? (sw[i >> 1] >> 16) : (int)(int16_t)(sw[i >> 1] & 0xFFFF);
+                    if (abs(d) <= W) atomicAdd(&H[d + W], (1ull << 40) | (unsigned long long)(uint32_t)(r + 1024));
+                    else {   // outside the window: listed exactly (or, past kCache of them, the whole unit falls back)
+                        const int at = atomicAdd(&L.ovf_n, 1);
+                        if (at < kCache) { L.cx[at] = d; L.cy[at] = r; }
+                    }
+                    r2 += (unsigned long long)(uint32_t)(r * r);
+                }
+            a0 = b0; a1 = b1; s4 = t4; k = kn;
+        }
+        __syncthreads();   // H2: histogram and list complete
+        const int n_ovf = ((volatile int&)L.ovf_n);
+        if (n_ovf <= kCache) {
+            const long long r2w = wave_sum_u48((long long)r2);   // this wave's share of sum (dat - src)^2 (< 2^48: 42 x 8 x 64 squares below 2^20)
+            for (int pass = 0; pass < kPassBudget; pass++) {
+                __syncthreads();   // A
+                if (L.done) break;
+                const int nc = L.n_want;
+                for (int c = 0; c < nc; c++) {
+                    const int xq = has0 ? L.xq0[c] : L.xq1[c];
+                    long long acc = 0;
+                    for (int b = t; b < nb; b += kResD) {
+                        const unsigned long long h = H[b];
+                        const int nd = (int)(h >> 40);
+                        if (nd) {
+                            const long long Rd = (long long)(h & ((1ull << 40) - 1)) - 1024ll * nd;
+                            const int q = (xq * (b - W) + 1024) >> 11;   // |xq| <= 256, |d| <= 3071: 20 bits
+                            acc += (long long)nd * (q * q) + 2ll * q * Rd;   // nd q^2 < 2^18 x 2^17.2, |q Rd| < 2^8.6 x 2^28: int64
+                        }
+                    }
+                    for (int o = t; o < n_ovf; o += kResD) {   // a listed sample: n = 1, R = its dat - src (|xq d| < 2^8 x 2^14.1: 23 bits)
+                        const int q = (xq * L.cx[o] + 1024) >> 11;
+                        acc += (long long)q * q + 2ll * q * L.cy[o];
+                    }
+                    const long long sum = wave_sum_i64(acc);
+                    if (lane == 0) L.part[wave][c] = sum + r2w;
+                }
+                __syncthreads();   // B
+            }
+            return;
+        }
+    }
     int4 pa[kResJ], pb[kResJ];
 #pragma unroll
     for (int j = 0; j < kResJ; j++) {
@@ -793,8 +882,11 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     const int na10 = (na10_env == kHybNA10 || small_form) ? kHybNA10 : kHybNA;
     const int cap_max = stream_form ? kStreamCand : (resident_form ? kMaxCand : (bd == 8 ? (hyb16 ? 16 : kHybNA) : na10));
     const int cap = cap_env >= 1 && cap_env <= cap_max ? cap_env : (stream_form ? kStreamCand : (resident_form ? 12 : cap_max));   // candidates per pass
+    static const bool hist_off = getenv("SVT_HIP_SGR_WALK_HIST") && !atoi(getenv("SVT_HIP_SGR_WALK_HIST"));   // A/B: one-filter sets evaluated sample by sample like the others (round 3)
     WalkPic a = {};
     a.cap = cap;
+    const char* hw_env = getenv("SVT_HIP_SGR_WALK_HIST_W");   // read per launch: tests/test_sgr_gpu.py narrows the window to send part of a plane's units down the sample-by-sample path
+    a.hist_w = hist_off ? -1 : (hw_env ? atoi(hw_env) : 1 << 30);
     static const char* clk_env = getenv("SVT_HIP_SGR_WALK_CLOCKS");
     a.clocks = !(clk_env && clk_env[0] == '0');
     int max_units = 0;

@@ -400,6 +400,43 @@ def test_search_units_plane_dev_chain(hip, orc, bd):
 
 
 @pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("window", [None, 160, 24])
+def test_search_units_histogram_evaluation_and_its_fallback(hip, orc, bd, window):
+    """The one-filter sets (10 .. 15) of a unit are evaluated on a histogram over flt - u (sgr_walk.hip "HISTOGRAM EVALUATION"): samples outside its window go to an exact
+    list, a unit with more than 256 of them is evaluated sample by sample.  Content cannot push |flt - u| past the window's 3071 (the filter passes high-variance samples
+    through), so the other cases narrow the window (SVT_HIP_SGR_WALK_HIST_W, read per launch): 160 leaves a few listed samples, 24 sends part of the units down the
+    sample-by-sample path.  Results of all 16 sets against the oracle; the walk's own counter says how many walks took the histogram."""
+    w, h, US, ss, mask = 384, 192, 64, 0, 0xFFFF
+    mx = (1 << bd) - 1
+    src, ext = _smooth_noisy(w, h, bd, 1200 + bd, 4)
+    rng = np.random.default_rng(1300 + bd)
+    ext[EXT:EXT + h, EXT + w // 2:EXT + w] = (mx * rng.integers(0, 2, (h, w // 2))).astype(ext.dtype)
+    ext[:, EXT + w:] = ext[:, EXT + w - 1:EXT + w]; ext[:EXT, :] = ext[EXT:EXT + 1, :]; ext[EXT + h:, :] = ext[EXT + h - 1:EXT + h, :]
+    st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+    nu = units(w, US) * units(h, US)
+    e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+    orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+    L = hip.L
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    nbytes = L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+    d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+    d_scr = hip.empty(nbytes); d_xqd = hip.empty(nu * 16 * 8); d_err = hip.empty(nu * 16 * 8); d_best = hip.empty(nu); d_bx = hip.empty(nu * 8)
+    if window is not None: os.environ["SVT_HIP_SGR_WALK_HIST_W"] = str(window << (bd - 8))
+    try:
+        hip.check(L.svt_hip_sgr_search_units_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_xqd, d_err, d_best, d_bx, d_scr, nbytes), "units dev")
+    finally:
+        os.environ.pop("SVT_HIP_SGR_WALK_HIST_W", None)
+    g_xqd = hip.to_host(d_xqd, e_xqd.shape, np.int32); g_err = hip.to_host(d_err, e_err.shape, np.int64); g_best = hip.to_host(d_best, e_best.shape, np.uint8)
+    stats = hip.to_host(d_scr, (32,), np.uint32)   # the scratch starts with the walk's counters: [2] unfinished walks, [3] walks evaluated on the histogram
+    hip.free(d_ext, d_src, d_scr, d_xqd, d_err, d_best, d_bx)
+    assert np.array_equal(g_err, e_err), (bd, np.argwhere(g_err != e_err)[:8])
+    assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best)
+    assert stats[2] == 0
+    if window != 24: assert stats[3] == nu * 6, stats[:4]       # every one-filter walk on the histogram (window 160: with listed samples)
+    else: assert 0 < stats[3] < nu * 6, stats[:4]               # some of them, the others sample by sample
+
+
+@pytest.mark.parametrize("bd", [8, 10])
 def test_search_units_picture_dev(hip, pkg, orc, bd):
     """svt_hip_sgr_search_units_picture_dev: three planes of different sizes / unit sizes / set masks in one call (one walk launch for the picture:
     grid.z = plane, a plane with fewer units than the widest one leaves workgroups without work) against the oracle's per-plane search."""

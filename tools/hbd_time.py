@@ -177,5 +177,5 @@ for p in range(3):
     nw = units[p] * 16
     print(f"  plane {p} phase clocks per walk (x64 cycles): solve {st3[24] / nw:.0f}, replay {st3[25] / nw:.0f}, first-barrier wait (load) {st3[26] / nw:.0f}, evaluation {st3[27] / nw:.0f}, total {st3[28] / nw:.0f}; candidate loop of a data wave {st3[29] / max(int(st3[30]), 1) * 64:.0f} cycles per candidate")
     print(f"  plane {p}: {units[p]} units x 16 sets: {st3[0] / (units[p] * 16):.2f} evaluation passes, {st3[1] / (units[p] * 16):.2f} evaluated points per walk, unfinished {st3[2]}, "
-          f"flat {st3[3]}, passes histogram {list(st3[8:24])}")
+          f"walks on the histogram {st3[3]}, passes histogram {list(st3[8:24])}")
 
