@@ -1128,7 +1128,8 @@ def cpu_baseline_reference(refb, orc, F, sbs, mc, tc, stages, jobs):
         fin = np.zeros((npic, 17), np.int32); sel = np.zeros((npic, n_sb), np.int32)
         t = run(10, [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel], npic, 1, reps=1)
         sec["cdef_strength_select"] = t / npic / n_sb   # one picture per thread, all threads busy
-        sec1["cdef_strength_select"] = refb.refb_parallel(10, C.addressof((C.c_int64 * 6)(*[adr(v) for v in [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel]])), 1, 1, 1, 1)
+        one = (C.c_int64 * 6)(*[adr(v) for v in [m[0], m[1], n_sb, int(jobs["cdef_lambda"]), fin, sel]])   # a NAMED array: the address of a temporary is a dangling pointer by the time the call reads it (an intermittent segmentation fault of this line until round 4)
+        sec1["cdef_strength_select"] = refb.refb_parallel(10, C.addressof(one), 1, 1, 1, 1)
     if "cdef_apply" in keys:
         outs = [p.copy() for p in F.ref]
         cy_, cuv_ = jobs["cdef_strengths"]
