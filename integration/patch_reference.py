@@ -57,6 +57,14 @@ _ench = Patch("Source/Lib/Encoder/Globals/EbEncHandle.c")
 # svt_av1_enc_deinit_handle (:1973): once the component and its threads are gone, the hooks give the dispatch pointers back and release the device
 # ... and before it frees the instance's pictures, those that were page-locked in place (SVT_HIP_PIN) are released
 _ench.sub(r'(\n[ \t]*)(EbErrorType return_error = svt_av1_enc_component_de_init\(svt_enc_component\);\n)', r'\1svt_hip_hooks_enc_predeinit();\1\2        svt_hip_hooks_enc_deinit();\n')
+# load_default_buffer_configuration_settings (:403-478): with the ME / TF hooks on a segment is one batched launch per stage, so the segments are made larger
+# (svt_hip_hooks_segments; the reference cuts every picture of at least 10 x 6 superblocks into 60 segments: four superblocks each at 1280 x 720)
+_ench.sub(r'(\n[ \t]*scs_ptr->tf_segment_row_count =  me_seg_h;//1;//\n)',
+          r'\1    {\n        uint32_t hip_mw = me_seg_w, hip_mh = me_seg_h, hip_tw = me_seg_w, hip_th = me_seg_h;\n'
+          r'        svt_hip_hooks_segments(scs_ptr->max_input_luma_width, scs_ptr->max_input_luma_height, &hip_mw, &hip_mh, &hip_tw, &hip_th, &scs_ptr->cdef_segment_column_count,\n'
+          r'                               &scs_ptr->cdef_segment_row_count, &scs_ptr->rest_segment_column_count, &scs_ptr->rest_segment_row_count);\n'
+          r'        for (int hip_i = 0; hip_i < 6; hip_i++) { scs_ptr->me_segment_column_count_array[hip_i] = hip_mw; scs_ptr->me_segment_row_count_array[hip_i] = hip_mh; }\n'
+          r'        scs_ptr->tf_segment_column_count = hip_tw; scs_ptr->tf_segment_row_count = hip_th;\n    }\n')
 PATCHES.append(_ench.sub(
     r'(setup_rtcd_internal\(enc_handle_ptr->scs_instance_array\[0\]->scs_ptr->static_config\.use_cpu_flags\);\n)',
     r'\1    svt_hip_hooks_enc_init(enc_handle_ptr->scs_instance_array[0]->scs_ptr->static_config.target_socket); /* SVT_HIP_HOOKS / SVT_HIP_RTCD: device context + per-call wrappers */\n'))

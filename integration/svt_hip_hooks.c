@@ -39,6 +39,31 @@ static int in_list(const char *list, const char *name) {
     return 0;
 }
 
+/* ME / TF segments (EbEncHandle.c:403-428, :477-478: 10 x 6 segments for every picture of at least 10 x 6 superblocks -- the reference's unit of CPU parallelism
+ * inside a picture).  With the hooks on a segment is one batched launch per HME level and per integer search, i.e. four synchronous round trips: at 1280 x 720 the
+ * reference's 60 segments hold FOUR superblocks each, and the hooked encoder spent more thread time on those round trips than the SIMD kernels they replace
+ * (profiles/r04: 720p, 32 frames: 5580 + 1860 flushes).  Called from the patched load_default_buffer_configuration_settings (which runs before the encoder is
+ * initialised, so the environment is read here directly): at least ~64 superblocks per segment.  A picture's results do not depend on how it is cut into segments.
+ * SVT_HIP_SEGMENTS=0 keeps the reference's counts. */
+void svt_hip_hooks_segments(uint32_t luma_width, uint32_t luma_height, uint32_t *me_cols, uint32_t *me_rows, uint32_t *tf_cols, uint32_t *tf_rows, uint32_t *cdef_cols,
+                            uint32_t *cdef_rows, uint32_t *rest_cols, uint32_t *rest_rows) {
+    const char *hooks = getenv("SVT_HIP_HOOKS"), *seg = getenv("SVT_HIP_SEGMENTS");
+    if (!hooks || (seg && !atoi(seg))) return;
+    const uint32_t sb_cols = (luma_width + 32) / 64, sb_rows = (luma_height + 32) / 64;
+    const uint32_t cols = sb_cols / 8 ? sb_cols / 8 : 1, rows = sb_rows / 8 ? sb_rows / 8 : 1;
+    if (in_list(hooks, "me") || in_list(hooks, "hme")) {
+        if (cols < *me_cols) *me_cols = cols;
+        if (rows < *me_rows) *me_rows = rows;
+    }
+    if (in_list(hooks, "tf") || in_list(hooks, "tf_me")) {
+        if (cols < *tf_cols) *tf_cols = cols;
+        if (rows < *tf_rows) *tf_rows = rows;
+    }
+    /* the CDEF search hook and the two restoration searches work per PICTURE (the first segment to arrive does it all, the others only wait for it): one segment */
+    if (in_list(hooks, "cdef_search")) *cdef_cols = *cdef_rows = 1;
+    if (in_list(hooks, "sgr_search") && in_list(hooks, "wiener_search")) *rest_cols = *rest_rows = 1;
+}
+
 static int in_list_exact(const char *list, const char *name) {   /* like in_list, but "all" does not match */
     if (!list) return 0;
     const size_t n = strlen(name);

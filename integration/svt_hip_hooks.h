@@ -71,6 +71,9 @@ void svt_hip_hooks_enc_init(int target_socket);
 void svt_hip_hooks_enc_deinit(void);
 /* svt_av1_enc_deinit_handle, before svt_av1_enc_component_de_init: the picture buffers that were page-locked in place (SVT_HIP_PIN) are released while they exist */
 void svt_hip_hooks_enc_predeinit(void);
+/* fewer, larger ME / TF segments when their hooks are on (svt_hip_hooks.c) */
+void svt_hip_hooks_segments(uint32_t luma_width, uint32_t luma_height, uint32_t *me_cols, uint32_t *me_rows, uint32_t *tf_cols, uint32_t *tf_rows, uint32_t *cdef_cols,
+                            uint32_t *cdef_rows, uint32_t *rest_cols, uint32_t *rest_rows);
 int  svt_hip_hooks_pin_enabled(void);
 /* wall time of a hook call, for the report at exit ("svt_hip_hook_time <name> calls= wall_ms="): t0 = svt_hip_hooks_now_ns() at entry */
 long long svt_hip_hooks_now_ns(void);

@@ -401,12 +401,16 @@ static void apply_hme(const SvtHipMeBatch *b, uint32_t i, int levels) {
 void svt_hip_me_batch_flush(SvtHipMeBatch *b, int next_pass, const EbPictureBufferDesc *src_padded) {
     if (!b || next_pass < 1 || next_pass >= b->n_pass) return;
     const int prev = b->phase[next_pass - 1];
+    const long long t0 = svt_hip_hooks_now_ns();
     if (prev >= 10) {
         b->level_first[prev - 10 + 1] = b->n_job;
         flush_hme_level(b, prev - 10);
         if (prev == 12 && b->n_job && b->hook_hme != b->hook_me) svt_hip_hooks_count(b->hook_hme, !b->failed);
-    } else if (prev == 0 || prev == 2)
+        svt_hip_hooks_time(b->hook_hme, t0);   /* the report's svt_hip_hook_time lines: what the batched launches (uploads, launch, download, synchronisation) cost the calling thread */
+    } else if (prev == 0 || prev == 2) {
         flush_integer(b, src_padded);
+        svt_hip_hooks_time(b->hook_me, t0);
+    }
 }
 
 int svt_hip_me_batch_sb(SvtHipMeBatch *b, int pass, PictureParentControlSet *pcs, uint32_t sb_index, uint32_t sb_origin_x,

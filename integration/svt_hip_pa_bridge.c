@@ -21,6 +21,7 @@
 EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBufferDesc *padded, EbPictureBufferDesc *quarter, EbPictureBufferDesc *sixteenth,
                                        int filtered) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_PA)) return EB_ErrorUndefined;
+    const long long t0 = svt_hip_hooks_now_ns();
     /* Resident planes (svt_hip_hooks.c): the padded picture is complete when downsample_decimation_input_picture is entered (the first of the two calls, always
      * made) — announced here, so that this hook, the variance hook and every later ME / TF segment share one upload; the pyramids are announced by the patched
      * function when this hook returns (they are written below).  A failure below leaves the announcement to the C path's end of function. */
@@ -72,6 +73,7 @@ EbErrorType svt_hip_hook_pa_downsample(PictureParentControlSet *pcs, EbPictureBu
     if (rc != SVT_HIP_OK) SVT_LOG("picture-analysis pyramids on the device failed (%s): C path\n", svt_hip_last_error(hip));
     svt_hip_hooks_unlock_any();
     svt_hip_hooks_count(SVT_HIP_HOOK_PA, rc == SVT_HIP_OK);
+    svt_hip_hooks_time(SVT_HIP_HOOK_PA, t0);
     if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
     if (do_q) generate_padding(&quarter->buffer_y[0], quarter->stride_y, quarter->width, quarter->height, quarter->origin_x, quarter->origin_y);
     if (do_s) generate_padding(&sixteenth->buffer_y[0], sixteenth->stride_y, sixteenth->width, sixteenth->height, sixteenth->origin_x, sixteenth->origin_y);

@@ -222,6 +222,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
     SvtHipTfWindow *w = &s->w;
     const int       pb = s->is_highbd ? 2 : 1, np = c->tf_chroma ? 3 : 1;
     const size_t    nblk = (size_t)w->blk_cols * w->blk_rows;
+    const long long t0 = svt_hip_hooks_now_ns();
     SvtHipCtx      *hip = svt_hip_hooks_lock_any();
     if (!hip) { svt_hip_hooks_count(SVT_HIP_HOOK_TF, 0); return EB_ErrorUndefined; }
     EbErrorType ret = EB_ErrorNone;
@@ -278,6 +279,7 @@ EbErrorType svt_hip_tf_seg_flush(SvtHipTfSeg *s, const MeContext *c, EbByte *src
         svt_hip_hooks_count(SVT_HIP_HOOK_TF_SUBPEL, ret == EB_ErrorNone);
     }
     svt_hip_hooks_count(SVT_HIP_HOOK_TF, ret == EB_ErrorNone);
+    svt_hip_hooks_time(SVT_HIP_HOOK_TF, t0);
     return ret;
 }
 

@@ -280,7 +280,8 @@ def test_resident_source_planes_on_cpu_test_double(case, workdir):
     """Resident planes (the default; set explicitly here): the padded luma plane of every picture and its 1/4 and 1/16 versions are uploaded once per (re)write -- picture analysis, the end of the
     temporal filter -- and every ME / HME / TF-ME segment reads that copy instead of uploading its own row band (integration/svt_hip_hooks.c).  Host logic only (which
     copy is current), so the CPU test double pins it: a stale plane changes the motion search and with it the bitstream.  The planes must really have been used."""
-    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1"}, "mock_resident")
+    # SVT_HIP_SEGMENTS=0: the reference's own ME / TF segmenting (60 segments per 360p picture), i.e. many readers per plane; the hooks' default makes the segments larger
+    got = _check(case, CASES[case], workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_RESIDENT": "1", "SVT_HIP_SEGMENTS": "0"}, "mock_resident")
     notes, uploads, mb, hits = _resident_line(got["log"])
     w, h, n = CASES[case][:3]
     # every announced plane travels at most once per announcement, and the copies are read (CIF pictures are one ME segment each: few readers per plane;
@@ -288,6 +289,22 @@ def test_resident_source_planes_on_cpu_test_double(case, workdir):
     assert notes >= 3 * n and n <= uploads <= notes and hits > 0, (notes, uploads, mb, hits)
     if case == "360p_8bit_m7":
         assert hits > 10 * uploads, (notes, uploads, mb, hits)
+
+
+def _flushes(log, hook):
+    m = re.findall(r"svt_hip_hook_time %s calls=(\d+)" % hook, log)
+    return int(m[-1]) if m else 0
+
+
+def test_larger_me_and_tf_segments_on_cpu_test_double(workdir):
+    """With the ME / TF hooks on a segment is one batched launch per stage, so the patched load_default_buffer_configuration_settings makes the segments larger
+    (svt_hip_hooks_segments: the reference cuts a 640 x 360 picture into 60 segments); the bitstream does not depend on the cut, the number of batched launches does."""
+    case = "360p_8bit_m7"
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}
+    few = _check(case, CASES[case], workdir, env, "mock_segments_default")
+    many = _check(case, CASES[case], workdir, dict(env, SVT_HIP_SEGMENTS="0"), "mock_segments_reference")
+    assert 0 < _flushes(few["log"], "hme") * 8 < _flushes(many["log"], "hme"), (_flushes(few["log"], "hme"), _flushes(many["log"], "hme"))
+    assert 0 < _flushes(few["log"], "me") * 8 < _flushes(many["log"], "me")
 
 
 @pytest.mark.parametrize("case", ["360p_8bit_m7", "cif_10bit_m6"])
