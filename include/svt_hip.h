@@ -509,6 +509,17 @@ int svt_hip_lr_try_units_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *
  * probes.  wiener_win: 7 / 5 / 3 (WIENER_WIN, _CHROMA, _3TAP: the outer taps of a shorter window are never probed).  Inactive units are left alone. */
 int svt_hip_wiener_walk_units_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const void *d_dgd, int stride, int pw, int ph, int unit_size, int ss_y, const void *d_dbl, int dbl_stride,
                                   const void *d_src, int src_stride, int16_t *d_unit_wiener, const uint8_t *d_active, int wiener_win, int64_t *d_err, uint32_t *d_probes);
+/* ... and of all planes of a picture in ONE launch (the fields are svt_hip_wiener_walk_units_dev's arguments): a unit's walk is a serial chain of ~30 probes on one
+ * compute unit, so a launch takes as long as its longest walk whatever the number of units -- three planes side by side take a third of three launches
+ * (search_wiener_seg's loop over the planes, EbRestProcess.c:527 -> EbRestorationPick.c:1552).  1 <= n_planes <= 3. */
+typedef struct SvtHipWienerWalkPlane {
+    const void *d_dgd; int stride, pw, ph, unit_size, ss_y;
+    const void *d_dbl; int dbl_stride;
+    const void *d_src; int src_stride;
+    int16_t *d_unit_wiener; const uint8_t *d_active; int wiener_win;
+    int64_t *d_err; uint32_t *d_probes;
+} SvtHipWienerWalkPlane;
+int svt_hip_wiener_walk_units_picture_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane *planes);
 
 /* ------------------------------------------------------------------ Wiener restoration search ---- */
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as

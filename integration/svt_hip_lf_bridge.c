@@ -365,10 +365,13 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
     FrameHeader *frm_hdr = &ppcs->frm_hdr;
     const LoopFilterInfoN *lfi_n = &ppcs->lf_info;
     const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4;
+    /* a coded block is a rectangle of 4 x 4 units with one mode info: scanning a row left to right, a block is first met at its left edge, its record is derived once and
+     * copied over the block's width (a 3840 x 2160 picture has 518 400 units; deriving every one of them cost 7 - 10 ms per call on one host thread) */
     for (int r = 0; r < mi_rows; r++)
-        for (int c = 0; c < mi_cols; c++) {
+        for (int c = 0; c < mi_cols;) {
             const MbModeInfo *mbmi = &pcs->mi_grid_base[r * pcs->mi_stride + c]->mbmi;
             SvtHipDlfModeInfo *o = &p->h_mi[r * mi_cols + c];
+            const int run = block_size_wide[mbmi->block_mi.sb_type] >> 2, c_next = ((c / run) + 1) * run;   /* blocks are aligned to their own width */
             const BlockSize bs = mbmi->block_mi.sb_type;
             const int inter = is_inter_block_no_intrabc(mbmi->block_mi.ref_frame[0]);
             TxSize ts = inter ? tx_depth_to_tx_size[0][bs] : tx_depth_to_tx_size[mbmi->tx_depth][bs];
@@ -385,6 +388,8 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
                         : frm_hdr->delta_lf_params.delta_lf_present
                         ? get_filter_level_delta_lf(frm_hdr, dir, pl, ppcs->curr_delta_lf, 0, mode, mbmi->block_mi.ref_frame[0])
                         : lfi_n->lvl[pl][0][dir][mbmi->block_mi.ref_frame[0]][mode_lf_lut[mode]];
+            for (int k = c + 1; k < c_next && k < mi_cols; k++) p->h_mi[r * mi_cols + k] = *o;
+            c = c_next;
         }
 }
 static EbErrorType build_and_upload_edges(SvtHipCtx *hip, SvtHipLfPicture *p, int pl) {
@@ -405,14 +410,21 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
     PictureControlSet *pcs = s->pcs;
     FrameHeader *frm_hdr = &pcs->parent_pcs_ptr->frm_hdr;
     struct LoopFilter *lf = &frm_hdr->loop_filter_params;
+    const long long td0 = svt_hip_hooks_now_ns();
     if (ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     if (!(s->flags & ST_RECON) && upload(hip, p, recon_of(pcs, p->pix_bytes == 2), p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_RECON;   /* the search filters into d_cdef: d_recon stays the picture as coded, which svt_av1_loop_filter_frame's hook starts from */
+    const long long td1 = svt_hip_hooks_now_ns();
     fill_mode_info(p, pcs, 1);
+    const long long td2 = svt_hip_hooks_now_ns();
+    long long t_edges = 0, t_search = 0;
     int best[3];
     const int last[4] = {lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v};
     for (int pl = 0; pl < 3; pl++) {
+        const long long te0 = svt_hip_hooks_now_ns();
         if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
+        const long long te1 = svt_hip_hooks_now_ns();
+        t_edges += te1 - te0;
         SvtHipDlfSearch q;
         memset(&q, 0, sizeof(q));
         q.plane = pl; q.dir = 2; q.other_level = 0;
@@ -424,8 +436,10 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
         HIP_TRY(svt_hip_dlf_search_level_dev(hip, &q, plane_origin(p, p->d_recon[pl], pl), plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->bd,
                                              p->w >> (pl > 0), p->h >> (pl > 0), p->src[pl], p->src_st[pl], p->d_edges[pl][0], p->d_edges[pl][1],
                                              p->units_w[pl], p->units_h[pl], p->d_sse, &best[pl], &err));
+        t_search += svt_hip_hooks_now_ns() - te1;
         svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, q.start_level, best[pl], (long long)err);
     }
+    svt_hip_hooks_log("dlf_search: picture up %.2f ms, mode info (host) %.2f ms, edges (host + upload) %.2f ms, probes %.2f ms", (td1 - td0) / 1e6, (td2 - td1) / 1e6, t_edges / 1e6, t_search / 1e6);
     lf->sharpness_level = 0;
     lf->filter_level[0] = lf->filter_level[1] = best[0];
     lf->filter_level_u = best[1];
@@ -935,14 +949,19 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     PictureControlSet *pcs = s->pcs;
     const Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
     if (!(s->flags & ST_DBL)) return EB_ErrorUndefined;
+    const long long tw0 = svt_hip_hooks_now_ns();
     if (!(s->flags & ST_WIENER_DONE)) {
         if ((s->flags & ST_WIENER_FAILED) || wiener_stats_all(hip, s) != EB_ErrorNone) { s->flags |= ST_WIENER_FAILED; return EB_ErrorUndefined; }
         s->flags |= ST_WIENER_DONE;
     }
+    const long long tw1 = svt_hip_hooks_now_ns();
+    long long t_init = 0, t_walk = 0;
     EbErrorType ret = EB_ErrorNone;
     uint8_t *act[3] = {0}; int16_t *wn[3] = {0}; int64_t *err[3] = {0}; uint32_t *probes[3] = {0}; int8_t *init[3] = {0};
     void *d_act[3] = {0}, *d_err[3] = {0}, *d_probes[3] = {0};
     long n_probes = 0, n_walks = 0;
+    SvtHipWienerWalkPlane walk[3];
+    int walk_pl[3], n_walk_planes = 0;
     for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
         const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, win = p->wiener_win[pl], w2 = win * win;
@@ -952,6 +971,7 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
             svt_hip_hooks_malloc(hip, &d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK || svt_hip_hooks_malloc(hip, &d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
         /* search_wiener_seg up to the refinement: decomposition, tap quantisation, score against the identity filter (the reference's own code) */
         int any = 0;
+        const long long ti0 = svt_hip_hooks_now_ns();
         for (int u = 0; u < n; u++) {
             WienerInfo wi;
             memset(&wi, 0, sizeof(wi));
@@ -962,15 +982,23 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
                 memcpy(wn[pl] + 16 * u, wi.vfilter, 8 * sizeof(int16_t)); memcpy(wn[pl] + 16 * u + 8, wi.hfilter, 8 * sizeof(int16_t));
             }
         }
+        t_init += svt_hip_hooks_now_ns() - ti0;
         if (!any) continue;
-        if (svt_hip_memcpy_h2d(hip, d_act[pl], act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
-            svt_hip_wiener_walk_units_dev(hip, p->pix_bytes, p->bd, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], pw, ph, rsi->restoration_unit_size, pl > 0,
-                                          plane_origin(p, p->d_recon[pl], pl), p->stride[pl], p->src[pl], p->src_st[pl], p->d_unit_wiener[pl], (const uint8_t *)d_act[pl],
-                                          win, (int64_t *)d_err[pl], (uint32_t *)d_probes[pl]) != SVT_HIP_OK ||
-            svt_hip_memcpy_d2h(hip, wn[pl], p->d_unit_wiener[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK ||
-            svt_hip_memcpy_d2h(hip, err[pl], d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK || svt_hip_memcpy_d2h(hip, probes[pl], d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
+        if (svt_hip_memcpy_h2d(hip, d_act[pl], act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
+        walk[n_walk_planes] = (SvtHipWienerWalkPlane){plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], pw, ph, rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl],
+                                                      p->src[pl], p->src_st[pl], p->d_unit_wiener[pl], (const uint8_t *)d_act[pl], win, (int64_t *)d_err[pl], (uint32_t *)d_probes[pl]};
+        walk_pl[n_walk_planes++] = pl;
+    }
+    /* the walks of all planes in ONE launch: a unit's walk is a serial chain of ~30 probes, so three launches in a row cost three times the longest walk */
+    const long long tk0 = svt_hip_hooks_now_ns();
+    if (ret == EB_ErrorNone && n_walk_planes && svt_hip_wiener_walk_units_picture_dev(hip, p->pix_bytes, p->bd, n_walk_planes, walk) != SVT_HIP_OK) ret = EB_ErrorUndefined;
+    for (int k = 0; k < n_walk_planes && ret == EB_ErrorNone; k++) {
+        const int pl = walk_pl[k], n = cm->rst_info[pl].units_per_tile;
+        if (svt_hip_memcpy_d2h(hip, wn[pl], p->d_unit_wiener[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK || svt_hip_memcpy_d2h(hip, err[pl], d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK ||
+            svt_hip_memcpy_d2h(hip, probes[pl], d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
         for (int u = 0; u < n; u++) n_probes += act[pl][u] ? probes[pl][u] : 0;
     }
+    t_walk = svt_hip_hooks_now_ns() - tk0;
     if (ret == EB_ErrorNone) {   /* every plane has succeeded: only now do the reference's objects change */
         for (int pl = 0; pl < 3; pl++) {
             RestUnitSearchInfo *rusi = pcs->parent_pcs_ptr->rusi_picture[pl];
@@ -985,7 +1013,8 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
                 }
             }
         }
-        svt_hip_hooks_log("wiener_search: 1 launch per plane, %ld walks, %ld probes on the device", n_walks, n_probes);
+        svt_hip_hooks_log("wiener_search: 1 launch, %ld walks, %ld probes on the device; statistics %.2f ms, initial filters (host) %.2f ms, walks %.2f ms", n_walks, n_probes,
+                          (tw1 - tw0) / 1e6, t_init / 1e6, t_walk / 1e6);
     }
     for (int pl = 0; pl < 3; pl++) {
         free(act[pl]); free(wn[pl]); free(err[pl]); free(probes[pl]); free(init[pl]);

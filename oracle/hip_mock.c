@@ -483,6 +483,15 @@ int svt_hip_wiener_walk_units_dev(SvtHipCtx *c, int pix_bytes, int bd, const voi
     free(w); free(lim); free(xqd); free(rect); free(ep); free(wn); free(sse); free(dst);
     return rc;
 }
+int svt_hip_wiener_walk_units_picture_dev(SvtHipCtx *c, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane *pl) {
+    if (!pl || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_planes; i++) {
+        const int rc = svt_hip_wiener_walk_units_dev(c, pix_bytes, bd, pl[i].d_dgd, pl[i].stride, pl[i].pw, pl[i].ph, pl[i].unit_size, pl[i].ss_y, pl[i].d_dbl, pl[i].dbl_stride, pl[i].d_src,
+                                                     pl[i].src_stride, pl[i].d_unit_wiener, pl[i].d_active, pl[i].wiener_win, pl[i].d_err, pl[i].d_probes);
+        if (rc != SVT_HIP_OK) return rc;
+    }
+    return SVT_HIP_OK;
+}
 int svt_hip_sgr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *dgd, int stride, void *dst, int dst_stride, int pw, int ph,
                                 int unit_size, int ss_y, const void *dbl, int dbl_stride, const uint8_t *unit_ep, const int32_t *unit_xqd) {
     return svt_hip_lr_apply_plane_dev(c, pix_bytes, bd, dgd, stride, dst, dst_stride, pw, ph, unit_size, ss_y, dbl, dbl_stride, unit_ep, unit_xqd, NULL);

@@ -55,6 +55,13 @@ class ConvBlk(C.Structure):
                 ("reserved", C.c_uint8)]
 
 
+class WienerWalkPlane(C.Structure):
+    """SvtHipWienerWalkPlane (include/svt_hip.h)"""
+    _fields_ = [("d_dgd", C.c_void_p), ("stride", C.c_int32), ("pw", C.c_int32), ("ph", C.c_int32), ("unit_size", C.c_int32), ("ss_y", C.c_int32), ("d_dbl", C.c_void_p),
+                ("dbl_stride", C.c_int32), ("d_src", C.c_void_p), ("src_stride", C.c_int32), ("d_unit_wiener", C.c_void_p), ("d_active", C.c_void_p), ("wiener_win", C.c_int32),
+                ("d_err", C.c_void_p), ("d_probes", C.c_void_p)]
+
+
 class BlkPair(C.Structure):
     """SvtHipBlkPair (include/svt_hip.h)."""
     _fields_ = [("a_x", C.c_int32), ("a_y", C.c_int32), ("b_x", C.c_int32), ("b_y", C.c_int32), ("w", C.c_uint16), ("h", C.c_uint16)]
@@ -209,6 +216,7 @@ def lib():
     L.svt_hip_blend_a64_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_deblock_frame_dev.argtypes = [vp, P3, i32, I3, i32, P3, P3, I3, I3, i32]
     L.svt_hip_wiener_walk_units_dev.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp]
+    L.svt_hip_wiener_walk_units_picture_dev.argtypes = [vp, i32, i32, i32, C.POINTER(WienerWalkPlane)]
     L.svt_hip_deblock_frame_fused_dev.argtypes = [vp, P3, P3, i32, I3, i32, I3, I3, P3, P3, I3, I3, i32]
     L.svt_hip_picture_format_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32]
     L.svt_hip_generate_padding_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32]

@@ -755,11 +755,20 @@ __device__ inline bool wn_result(WnWalkState& w, long long err2, int off) {
     }
     return wn_issue(w, off);
 }
+struct WnPlane { const void* dgd; const void* dbl; const void* src; int16_t* unit_wiener; const uint8_t* active; long long* err; uint32_t* probes;
+                 int stride, pw, ph, unit_size, units_x, units_y, voff, stripe_h, dbl_stride, src_stride, win; };
+struct WnPic { WnPlane p[3]; };   // blockIdx.y = plane: the planes of a picture walk side by side (a launch lasts as long as its longest walk)
 template <typename PIX, int BD>
 __global__ void __launch_bounds__(1024)
-wiener_walk_kernel(const PIX* __restrict__ dgd, int stride, int pw, int ph, int unit_size, int units_x, int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl,
-                   int dbl_stride, const PIX* __restrict__ src, int src_stride, int16_t* __restrict__ unit_wiener, const uint8_t* __restrict__ active, int win,
-                   long long* __restrict__ err_out, uint32_t* __restrict__ probes_out) {
+wiener_walk_kernel(const WnPic a) {
+    // scalar copies of the plane's arguments (a reference into the kernel-argument struct with a run-time index would force a private copy of the whole struct)
+    const int z = blockIdx.y;
+    const PIX* __restrict__ dgd = (const PIX*)a.p[z].dgd; const PIX* __restrict__ dbl = (const PIX*)a.p[z].dbl; const PIX* __restrict__ src = (const PIX*)a.p[z].src;
+    int16_t* __restrict__ unit_wiener = a.p[z].unit_wiener; const uint8_t* __restrict__ active = a.p[z].active;
+    long long* __restrict__ err_out = a.p[z].err; uint32_t* __restrict__ probes_out = a.p[z].probes;
+    const int stride = a.p[z].stride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff,
+              stripe_h = a.p[z].stripe_h, dbl_stride = a.p[z].dbl_stride, src_stride = a.p[z].src_stride, win = a.p[z].win;
+    if ((int)blockIdx.x >= units_x * units_y) return;   // a plane with fewer units than the widest one
     __shared__ uint16_t in[4][S_IH * S_IW];
     __shared__ uint16_t tmp[4][S_IH * S_TW];
     __shared__ int taps[16];            // the probe: [0..7] vertical, [8..15] horizontal
@@ -836,14 +845,22 @@ wiener_walk_kernel(const PIX* __restrict__ dgd, int stride, int pw, int ph, int 
 
 }  // namespace
 
-extern "C" int svt_hip_launch_wiener_walk(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y,
-                                          const void* dbl, int dbl_stride, const void* src, int src_stride, int16_t* unit_wiener, const uint8_t* active, int win, long long* err,
-                                          uint32_t* probes) {
-    const int voff = 8 >> ss_y, sh = 64 >> ss_y, n = units_x * units_y;
+extern "C" int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes) {
+    if (n_planes < 1 || n_planes > 3) return (int)hipErrorInvalidValue;
+    WnPic a = {};
+    int n = 0;
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipWienerWalkPlane& P = planes[i];
+        const int ux = max((P.pw + P.unit_size / 2) / P.unit_size, 1), uy = max((P.ph + P.unit_size / 2) / P.unit_size, 1);   // av1_lr_count_units_in_tile (EbRestoration.c:1445)
+        a.p[i] = WnPlane{P.d_dgd, P.d_dbl, P.d_src, P.d_unit_wiener, P.d_active, (long long*)P.d_err, P.d_probes, P.stride, P.pw, P.ph, P.unit_size, ux, uy, 8 >> P.ss_y, 64 >> P.ss_y,
+                         P.dbl_stride, P.src_stride, P.wiener_win};
+        n = max(n, ux * uy);
+    }
     if (n <= 0) return 0;
-    if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), dim3(n), dim3(1024), 0, st, (const uint8_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint8_t*)dbl, dbl_stride, (const uint8_t*)src, src_stride, unit_wiener, active, win, err, probes);
-    else if (bd == 8) hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 8>), dim3(n), dim3(1024), 0, st, (const uint16_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, (const uint16_t*)src, src_stride, unit_wiener, active, win, err, probes);
-    else hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 10>), dim3(n), dim3(1024), 0, st, (const uint16_t*)dgd, stride, pw, ph, unit_size, units_x, units_y, voff, sh, (const uint16_t*)dbl, dbl_stride, (const uint16_t*)src, src_stride, unit_wiener, active, win, err, probes);
+    const dim3 grid(n, n_planes);
+    if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), grid, dim3(1024), 0, st, a);
+    else if (bd == 8) hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 8>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 10>), grid, dim3(1024), 0, st, a);
     return (int)hipGetLastError();
 }
 

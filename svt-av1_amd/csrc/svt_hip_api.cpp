@@ -741,9 +741,24 @@ int svt_hip_wiener_walk_units_dev(SvtHipCtx* c, int pix_bytes, int bd, const voi
         if (c) c->err = "svt_hip_wiener_walk_units_dev: bad argument";
         return SVT_HIP_ERR_BAD_ARG;
     }
-    const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
-    hipError_t e = (hipError_t)svt_hip_launch_wiener_walk(c->stream, pix_bytes, bd, d_dgd, stride, pw, ph, unit_size, ux, uy, ss_y, d_dbl, dbl_stride, d_src, src_stride, d_unit_wiener,
-                                                         d_active, wiener_win, (long long*)d_err, d_probes);
+    const SvtHipWienerWalkPlane P = {d_dgd, stride, pw, ph, unit_size, ss_y, d_dbl, dbl_stride, d_src, src_stride, d_unit_wiener, d_active, wiener_win, d_err, d_probes};
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_walk_multi(c->stream, pix_bytes, bd, 1, &P);
+    if (e != hipSuccess) return fail(c, e, "wiener walk launch");
+    return SVT_HIP_OK;
+}
+
+int svt_hip_wiener_walk_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes) {
+    SVT_HIP_ENTER(c);
+    if (!c || !planes || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipWienerWalkPlane& P = planes[i];
+        if (!P.d_dgd || !P.d_src || !P.d_unit_wiener || !P.d_active || !P.d_err || P.unit_size < 64 || (P.unit_size & 63) || (P.ss_y != 0 && P.ss_y != 1) ||
+            (P.wiener_win != 7 && P.wiener_win != 5 && P.wiener_win != 3) || !sgr_args_ok(pix_bytes, bd, P.pw, P.ph)) {
+            c->err = "svt_hip_wiener_walk_units_picture_dev: bad plane";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_walk_multi(c->stream, pix_bytes, bd, n_planes, planes);
     if (e != hipSuccess) return fail(c, e, "wiener walk launch");
     return SVT_HIP_OK;
 }

@@ -112,9 +112,7 @@ int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void*
 int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
                                     int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
                                     int dstride, size_t dplane, int64_t* d2);
-int svt_hip_launch_wiener_walk(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y,
-                               const void* dbl, int dbl_stride, const void* src, int src_stride, int16_t* unit_wiener, const uint8_t* active, int win, long long* err,
-                               uint32_t* probes);
+int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes);
 size_t svt_hip_sgr_walk_state_bytes(int n_units);
 typedef struct {
     const uint32_t* pairs; const int16_t* sd; const int64_t* sums; void* states; size_t dplane;

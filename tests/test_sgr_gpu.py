@@ -203,6 +203,42 @@ def test_wiener_walk_units(hip, bd, ss):
 
 
 @pytest.mark.parametrize("bd", [8, 10])
+def test_wiener_walk_units_picture(hip, pkg, bd):
+    """svt_hip_wiener_walk_units_picture_dev: the walks of three planes (luma 7-tap, two chroma planes 5-tap, different sizes and unit counts) in one launch == the three
+    per-plane launches (which test_wiener_walk_units pins to the reference's walk); a plane count outside 1..3 is refused."""
+    rng = np.random.default_rng(77 + bd)
+    planes, keep, exp = [], [], []
+    for i, (w, h, US, ss, win) in enumerate(((328, 264, 128, 0, 7), (168, 136, 64, 1, 5), (200, 96, 64, 1, 5))):
+        src, ext = make_planes(w, h, bd, 500 + bd + i)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        dbl = np.clip(ext[EXT:EXT + h, EXT:EXT + w].astype(np.int32) + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(ext.dtype)
+        nu = units(w, US) * units(h, US)
+        act = (rng.random(nu) < 0.8).astype(np.uint8); act[0] = 1
+        o = (7 - win) >> 1
+        wn = np.zeros((nu, 2, 8), np.int16)
+        for u in range(nu):
+            for d in range(2):
+                t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                for k in range(o): t[k] = 0
+                wn[u, d, :7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
+        d_ext, d_dbl, d_src, d_act = hip.to_device(ext), hip.to_device(dbl), hip.to_device(src), hip.to_device(act)
+        # expected: the per-plane entry point
+        d_wn, d_err, d_pr = hip.to_device(wn), hip.to_device(np.full(nu, -1, np.int64)), hip.to_device(np.zeros(nu, np.uint32))
+        hip.check(hip.L.svt_hip_wiener_walk_units_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, w, h, US, ss, d_dbl, w, d_src, w, d_wn, d_act, win, d_err, d_pr), "wiener walk")
+        exp.append((hip.to_host(d_wn, wn.shape, np.int16), hip.to_host(d_err, (nu,), np.int64), hip.to_host(d_pr, (nu,), np.uint32)))
+        hip.free(d_wn, d_err, d_pr)
+        d_wn, d_err, d_pr = hip.to_device(wn), hip.to_device(np.full(nu, -1, np.int64)), hip.to_device(np.zeros(nu, np.uint32))
+        planes.append(pkg.WienerWalkPlane(d_ext.value + off, st, w, h, US, ss, d_dbl.value, w, d_src.value, w, d_wn.value, d_act.value, win, d_err.value, d_pr.value))
+        keep.append((d_ext, d_dbl, d_src, d_act, d_wn, d_err, d_pr, wn.shape, nu))
+    arr = (pkg.WienerWalkPlane * 3)(*planes)
+    hip.check(hip.L.svt_hip_wiener_walk_units_picture_dev(hip.h, 1 if bd == 8 else 2, bd, 3, arr), "wiener walk (picture)")
+    for (d_ext, d_dbl, d_src, d_act, d_wn, d_err, d_pr, shape, nu), (e_wn, e_err, e_pr) in zip(keep, exp):
+        assert np.array_equal(hip.to_host(d_wn, shape, np.int16), e_wn) and np.array_equal(hip.to_host(d_err, (nu,), np.int64), e_err) and np.array_equal(hip.to_host(d_pr, (nu,), np.uint32), e_pr)
+    assert hip.L.svt_hip_wiener_walk_units_picture_dev(hip.h, 1 if bd == 8 else 2, bd, 4, arr) != 0 and hip.L.svt_hip_wiener_walk_units_picture_dev(hip.h, 1 if bd == 8 else 2, bd, 0, arr) != 0
+    for k in keep: hip.free(*k[:7])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
 def test_search_extreme_content(hip, orc, bd):
     """Bound proofs of the on-chip search (packed A'/B' fields, 24-bit multiplies, int32 partial sums): binary 0 / max content in flat
     areas, single-pixel and 2x2 checkerboards, random binary noise and isolated spikes, against a source that is the complement."""
