@@ -604,39 +604,59 @@ __device__ __forceinline__ StripeCtx<PIX> lr_stripe_of(const PIX* dbl, int dbl_s
     }
     return sc;
 }
+// staged sample i of the tile at (x0, y0): the picture, or inside the stripe's context rows the deblocked picture (two saved rows stretched to three)
+template <typename PIX>
+__device__ __forceinline__ uint16_t lr_tile_sample(const PIX* __restrict__ dgd, int stride, int pw, int ph, int x0, int y0, const StripeCtx<PIX>& sc, int i) {
+    const int r = i / S_IW, c = i - r * S_IW;
+    const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+    if (sc.above && yy < sc.sy0)
+        return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+    if (sc.below && yy >= sc.sy1)
+        return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
+    const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
+    return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+}
 template <typename PIX>
 __device__ __forceinline__ void lr_stage_tile(uint16_t* __restrict__ in, const PIX* __restrict__ dgd, int stride, int pw, int ph, int x0, int y0, const StripeCtx<PIX>& sc, int tid, int nt) {
-    batched_stage<6, uint16_t>(S_IH * S_IW, tid, nt,
-        [&](int i) {
-            const int r = i / S_IW, c = i - r * S_IW;
-            const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-            if (sc.above && yy < sc.sy0)
-                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            if (sc.below && yy >= sc.sy1)
-                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
-            return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
-        },
-        [&](int i, uint16_t v) { in[i] = v; });
+    batched_stage<6, uint16_t>(S_IH * S_IW, tid, nt, [&](int i) { return lr_tile_sample<PIX>(dgd, stride, pw, ph, x0, y0, sc, i); }, [&](int i, uint16_t v) { in[i] = v; });
 }
 // horizontal pass (round 3) of the staged tile -> tmp [S_IH][S_TW]  (Common/Codec/convolve.c:60-145)
+// A thread takes FOUR horizontally adjacent outputs: their ten inputs are five aligned dwords of the staged row (a row starts on a dword: S_IW is even) instead of 28
+// 16-bit LDS reads, and the four results leave as two dwords.
 template <int BD>
 __device__ __forceinline__ void wiener_hpass(const uint16_t* __restrict__ in, uint16_t* __restrict__ tmp, const int (&fx)[8], int tid, int nt) {
-    for (int k = tid; k < S_IH * S_TW; k += nt) {
-        const int r = k / S_TW, c = k - r * S_TW;
-        int32_t sum = ((int32_t)in[r * S_IW + c + 3] << 7) + (1 << (BD + 6));
+    static_assert(S_IW % 2 == 0 && S_TW % 4 == 0, "dword-aligned rows");
+    for (int g = tid; g < S_IH * (S_TW / 4); g += nt) {
+        const int r = g / (S_TW / 4), c = (g - r * (S_TW / 4)) * 4;
+        const uint32_t* row = (const uint32_t*)(in + r * S_IW + c);
+        int32_t x[10];
 #pragma unroll
-        for (int t = 0; t < 7; t++) sum += (int32_t)in[r * S_IW + c + t] * fx[t];
-        tmp[k] = (uint16_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, bd)
+        for (int k = 0; k < 5; k++) { const uint32_t v = row[k]; x[2 * k] = (int32_t)(v & 0xFFFFu); x[2 * k + 1] = (int32_t)(v >> 16); }
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int32_t sum = (x[q + 3] << 7) + (1 << (BD + 6));
+#pragma unroll
+            for (int t = 0; t < 7; t++) sum += x[q + t] * fx[t];
+            o[q] = (uint32_t)min(max((sum + 4) >> 3, 0), (1 << (BD + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, bd)
+        }
+        uint32_t* out = (uint32_t*)(tmp + r * S_TW + c);
+        out[0] = o[0] | (o[1] << 16); out[1] = o[2] | (o[3] << 16);
     }
 }
-// vertical pass (round 11) for sample (i, j) of the tile
+// vertical pass (round 11) for the eight rows i0 .. i0 + 7 of column j: the fourteen intermediate rows are read once (a sliding window in registers) instead of 56 times
 template <int BD>
-__device__ __forceinline__ int wiener_vpx(const uint16_t* __restrict__ tmp, int i, int j, const int (&fy)[8]) {
-    int32_t sum = ((int32_t)tmp[(i + 3) * S_TW + j] << 7) - (1 << (BD + 10));
+__device__ __forceinline__ void wiener_vcol8(const uint16_t* __restrict__ tmp, int i0, int j, const int (&fy)[8], int (&out)[8]) {
+    int32_t t[14];
 #pragma unroll
-    for (int t = 0; t < 7; t++) sum += (int32_t)tmp[(i + t) * S_TW + j] * fy[t];
-    return min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
+    for (int k = 0; k < 14; k++) t[k] = (int32_t)tmp[(i0 + k) * S_TW + j];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int32_t sum = (t[r + 3] << 7) - (1 << (BD + 10));
+#pragma unroll
+        for (int q = 0; q < 7; q++) sum += t[r + q] * fy[q];
+        out[r] = min(max((sum + (1 << 10)) >> 11, 0), (1 << BD) - 1);
+    }
 }
 
 // ---- frame apply (bit depth 8 and 10) on the search kernel's machinery (64 x 32 tiles, separable box sums, packed A'/B', one parameter set per unit):
@@ -648,7 +668,7 @@ __global__ void __launch_bounds__(256)
 lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst, int dst_stride, int pw, int ph, int unit_size, int units_x,
                  int units_y, int voff, int stripe_h, const PIX* __restrict__ dbl, int dbl_stride, const uint8_t* __restrict__ unit_ep,
                  const int32_t* __restrict__ unit_xqd, const int16_t* __restrict__ unit_wiener, int tile_x0, int tile_y0) {
-    __shared__ uint16_t in[S_IH * S_IW];
+    __shared__ __attribute__((aligned(16))) uint16_t in[S_IH * S_IW];   // (rows are read as dwords by wiener_hpass)
     __shared__ uint32_t ab[2][S_NP];
     __shared__ uint32_t xt[256];
     const int tile = svt_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
@@ -678,11 +698,13 @@ lr_apply8_kernel(const PIX* __restrict__ dgd, int stride, PIX* __restrict__ dst,
         uint16_t* tmp = (uint16_t*)&ab[0][0];   // [S_IH][S_TW]
         wiener_hpass<BD>(in, tmp, fx, tid, 256);
         __syncthreads();
+        int v8[8];
+        wiener_vcol8<BD>(tmp, i0, j, fy, v8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int i = i0 + r;
             if (x0 + j >= pw || y0 + i >= ph || y0 + i < 0) continue;
-            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)wiener_vpx<BD>(tmp, i, j, fy);
+            dst[(size_t)(y0 + i) * dst_stride + x0 + j] = (PIX)v8[r];
         }
         return;
     }
@@ -769,8 +791,8 @@ wiener_walk_kernel(const WnPic a) {
     const int stride = a.p[z].stride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff,
               stripe_h = a.p[z].stripe_h, dbl_stride = a.p[z].dbl_stride, src_stride = a.p[z].src_stride, win = a.p[z].win;
     if ((int)blockIdx.x >= units_x * units_y) return;   // a plane with fewer units than the widest one
-    __shared__ uint16_t in[4][S_IH * S_IW];
-    __shared__ uint16_t tmp[4][S_IH * S_TW];
+    __shared__ __attribute__((aligned(16))) uint16_t in[4][S_IH * S_IW];    // (rows are read as dwords by wiener_hpass)
+    __shared__ __attribute__((aligned(16))) uint16_t tmp[4][S_IH * S_TW];
     __shared__ int taps[16];            // the probe: [0..7] vertical, [8..15] horizontal
     __shared__ unsigned long long part[16];
     __shared__ int go;
@@ -797,21 +819,41 @@ wiener_walk_kernel(const WnPic a) {
 #pragma unroll
         for (int k = 0; k < 8; k++) { fy[k] = taps[k]; fx[k] = taps[8 + k]; }
         unsigned long long sse = 0;
-        for (int t = team; t < n_tiles; t += 4) {   // uniform per team: its four waves pass the same barriers
+        // a team's tiles are software-pipelined: the samples of the NEXT tile are loaded into registers while this tile is filtered (a probe is a chain of dependent
+        // tile rounds on one compute unit; the staging loads were the longest wait of a round)
+        constexpr int kPre = (S_IH * S_IW + 255) / 256;
+        uint16_t pre[kPre];
+        auto load_tile = [&](int t) {
             const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
             const int x0 = rx0 + txi * S_TW, y0 = (ty_first + tyi) * S_TH - voff;
             const StripeCtx<PIX> sc = lr_stripe_of<PIX>(dbl, dbl_stride, y0, voff, stripe_h, ph);
-            lr_stage_tile<PIX>(in[team], dgd, stride, pw, ph, x0, y0, sc, tt, 256);
+#pragma unroll
+            for (int k = 0; k < kPre; k++) { const int i = tt + 256 * k; pre[k] = i < S_IH * S_IW ? lr_tile_sample<PIX>(dgd, stride, pw, ph, x0, y0, sc, i) : (uint16_t)0; }
+        };
+        if (team < n_tiles) load_tile(team);
+        for (int t = team; t < n_tiles; t += 4) {   // uniform per team: its four waves pass the same barriers
+            const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+            const int x0 = rx0 + txi * S_TW, y0 = (ty_first + tyi) * S_TH - voff;
+#pragma unroll
+            for (int k = 0; k < kPre; k++) { const int i = tt + 256 * k; if (i < S_IH * S_IW) in[team][i] = pre[k]; }
             __syncthreads();   // the teams' trip counts differ by at most one tile; every wave of the workgroup reaches the same number of barriers (see below)
+            if (t + 4 < n_tiles) load_tile(t + 4);
             wiener_hpass<BD>(in[team], tmp[team], fx, tt, 256);
             __syncthreads();
             const int j = tt & 63, i0 = (tt >> 6) * 8;
             uint32_t e = 0;
+            int sv[8];   // the source samples first: their loads are in flight while the column is filtered
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const int i = i0 + r, x = x0 + j, y = y0 + i;
-                if (x >= rx1 || y >= ry1 || y < ry0) continue;
-                const int d = wiener_vpx<BD>(tmp[team], i, j, fy) - (int)src[(size_t)y * src_stride + x];
+                const int x = x0 + j, y = y0 + i0 + r;
+                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : (int)src[(size_t)y * src_stride + x];
+            }
+            int v8[8];
+            wiener_vcol8<BD>(tmp[team], i0, j, fy, v8);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (sv[r] < 0) continue;
+                const int d = v8[r] - sv[r];
                 e += (uint32_t)(d * d);
             }
             sse += e;
