@@ -13,13 +13,14 @@ IFS=, read -ra GEO_LIST <<< "${GEOS:-1280 720 8,1920 1080 8}"   # GEOS="3840 216
 APPS=${APPS:-"ref hip hip simd hip_simd hip_simd"}
 for geo in "${GEO_LIST[@]}"; do
   set -- $geo; W=$1; H=$2; N=$3
-  python - $W $H $N <<'PY'
+  python - $W $H $N ${BD:-8} <<'PY'
 import sys; sys.path.insert(0, "tests")
 import e2e_common as E
-w, h, n = map(int, sys.argv[1:4])
-E.make_clip("gpurun_out/enc_wall/clip.yuv", w, h, n, seed=3, bd=8)
+w, h, n, bd = map(int, sys.argv[1:5])
+E.make_clip("gpurun_out/enc_wall/clip.yuv", w, h, n, seed=3, bd=bd)
 PY
   ARGS="-i $OUT/clip.yuv -w $W -h $H -n $N --preset $PRESET --fps 30 -q 36 --lp $LP"
+  [ "${BD:-8}" = 10 ] && ARGS="$ARGS --input-depth 10"   # BD=10: 10-bit clips (the 16-bit pipeline of the hooks)
   for app in $APPS; do
     # NAME_res = application NAME with SVT_HIP_RESIDENT=1 (source-side planes stay on the device between their writes, integration/svt_hip_hooks.c),
     # e.g. APPS="simd hip_simd hip_simd hip_simd_res hip_simd_res"
