@@ -25,6 +25,10 @@ def test_eight_instances_one_per_gpu_ordinal(tmp_path):
     assert all(i["rc"] == 0 and i["devices"] == 8 and i["by"] == "SVT_HIP_DEVICE" and i["fallbacks"] == 0 and i["mock"] for i in out["instances"]), out
     assert out["identical_to_single_runs"] == [True] * 8, out
     assert out["aggregate_fps_encoder_clock"] > 0 and out["frames"] == 32
+    # ... and N concurrent encodes sharing ONE device (--same-device: every instance on ordinal 0)
+    a.gpus, a.check, a.same_device = 3, False, True
+    out = M.run(a, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_MOCK_DEVICES": "8"})
+    assert [i["ordinal"] for i in out["instances"]] == [0, 0, 0] and all(i["rc"] == 0 and i["fallbacks"] == 0 for i in out["instances"]), out
 
 
 def test_ordinal_without_a_device_keeps_the_c_path(tmp_path):

@@ -45,7 +45,8 @@ def run(a, env_extra=None):
     t0 = time.time()
     procs = []
     for k in range(a.gpus):
-        env = dict(base, SVT_HIP_DEVICE=str(k))
+        env = dict(base, SVT_HIP_DEVICE=str(0 if getattr(a, "same_device", False) else k))
+        if getattr(a, "reference", False): env.pop("SVT_HIP_HOOKS", None)   # the same binary with no hook = the reference encoder
         sock = (0 if k < (a.gpus + 1) // 2 else 1) if a.numa else None
         procs.append(subprocess.Popen(_cmd(app, clips[k], a, os.path.join(wd, f"stream{k}.ivf"), sock), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=a.timeout)[0] for p in procs]
@@ -53,10 +54,11 @@ def run(a, env_extra=None):
     inst = []
     for k, (p, log) in enumerate(zip(procs, logs)):
         m = re.search(r"svt_hip_device ordinal=(\d+) of (\d+) \((\w+)\)", log)
+        enc_ms = re.search(r"Total Encoding Time:\s+(\d+) ms", log)
         fps = re.search(r"Average Speed:\s+([0-9.]+) fps", log)
         fb = sum(int(x) for x in re.findall(r"svt_hip_hook \w+ handled=\d+ fallback=(\d+)", log))
         inst.append({"instance": k, "rc": p.returncode, "ordinal": int(m.group(1)) if m else None, "devices": int(m.group(2)) if m else None, "by": m.group(3) if m else None,
-                     "fps": float(fps.group(1)) if fps else None, "fallbacks": fb, "mock": "svt_hip MOCK" in log, "md5": _md5(os.path.join(wd, f"stream{k}.ivf")) if p.returncode == 0 else None})
+                     "fps": float(fps.group(1)) if fps else None, "encode_ms": int(enc_ms.group(1)) if enc_ms else None, "fallbacks": fb, "mock": "svt_hip MOCK" in log, "md5": _md5(os.path.join(wd, f"stream{k}.ivf")) if p.returncode == 0 else None})
     out = {"gpus": a.gpus, "wall_s": round(wall, 2), "frames": a.frames * a.gpus, "aggregate_fps_wall": round(a.frames * a.gpus / wall, 3),
            "aggregate_fps_encoder_clock": round(sum(i["fps"] or 0 for i in inst), 3), "instances": inst}
     if a.check:   # one instance at a time on device 0: the same clip must code to the same bitstream wherever it runs
@@ -85,13 +87,15 @@ def main():
     ap.add_argument("--simd", action="store_true", help="the hooks on the reference's x86 SIMD build (make -f oracle/Makefile.enc simd)")
     ap.add_argument("--numa", action="store_true", help="-ss 0 for the first half of the instances, -ss 1 for the second")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--same-device", action="store_true", help="every instance on device 0: N concurrent encodes sharing ONE GPU")
+    ap.add_argument("--reference", action="store_true", help="no hooks: N concurrent instances of the reference encoder (the CPU-only comparison of --same-device)")
     ap.add_argument("--app")
     ap.add_argument("--workdir")
     ap.add_argument("--timeout", type=int, default=1800)
     a = ap.parse_args()
     out = run(a)
     print(json.dumps(out))
-    ok = all(i["rc"] == 0 and i["ordinal"] == i["instance"] for i in out["instances"]) and all(out.get("identical_to_single_runs", [True]))
+    ok = all(i["rc"] == 0 and (a.reference or i["ordinal"] == (0 if a.same_device else i["instance"])) for i in out["instances"]) and all(out.get("identical_to_single_runs", [True]))
     sys.exit(0 if ok else 1)
 
 
