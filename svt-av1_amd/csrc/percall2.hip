@@ -217,6 +217,8 @@ struct JointState {
     unsigned long long cand_v[4][kJointMaxSlices];   // per reduce workgroup: its first minimum ...
     int                cand_i[4][kJointMaxSlices];   // ... and where
     unsigned int       done, err;          // one-launch form: "the four chains are complete", "a gather timed out"
+    int                stable[4], drop0[4], drop1[4];   // step form: refinement steps in a row that changed nothing, the pair the last shift dropped (see joint_resident: EARLY END OF A CHAIN)
+    unsigned int       ended[4];           // step form: the chain reached its fixed point -- the remaining launches of the chain return at once
     unsigned long long slot[2][4][256];    // one-launch form: per step parity, chain and workgroup {step tag | total | raster index} (wide tables: {tag | index})
     unsigned long long slot_v[2][4][256];  // wide tables: the totals
     unsigned long long partial[4][kJointMaxSlices][4096];   // step form: totals of one slice of the filter blocks, [j][k] with row stride 64
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(1024)
 joint_partial_kernel(const JointPics P, int sb_count, int start_gi, int ng, int step) {
     const uint64_t* __restrict__ mse0 = P.mse0[blockIdx.y]; const uint64_t* __restrict__ mse1 = P.mse1[blockIdx.y]; JointState* __restrict__ S = P.S[blockIdx.y];
     const int c = blockIdx.z, nb = 1 << c;
-    if (step >= 5 * nb) return;
+    if (step >= 5 * nb || S->ended[c]) return;
     const int idx = step < nb ? step : nb - 1;   // pairs already selected = the slot this step fills
     __shared__ int s_l0[8], s_l1[8];
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[(2 * kJointStage * 64 + kJointStage) * 8];
@@ -304,7 +306,7 @@ __global__ void __launch_bounds__(256)
 joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int step) {
     JointState* __restrict__ S = P.S[blockIdx.y];
     const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
-    if (step >= total_steps) return;
+    if (step >= total_steps || S->ended[c]) return;
     const int idx = step < nb ? step : nb - 1;
     __shared__ unsigned long long r_v[256];
     __shared__ int                r_i[64];
@@ -356,11 +358,27 @@ joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int ste
     }
     if (threadIdx.x != 0) return;
     const bool any = bi != 0x7fffffff;
-    S->lev0[c][idx] = any ? start_gi + bi / ng : 0;
-    S->lev1[c][idx] = any ? start_gi + bi % ng : 0;
+    const int n0 = any ? start_gi + bi / ng : 0, n1 = any ? start_gi + bi % ng : 0;
+    S->lev0[c][idx] = n0;
+    S->lev1[c][idx] = n1;
     S->result[c] = bv;
-    if (step + 1 >= nb && step + 1 < total_steps)   // the next step is a refinement step: drop the oldest pair
+    // the exact early end of a chain (joint_resident, "EARLY END OF A CHAIN"): nb refinement steps in a row that put back the pair they had dropped = a fixed point
+    bool fixed = false;
+    if (step >= nb) {
+        const int st = (n0 == S->drop0[c] && n1 == S->drop1[c]) ? S->stable[c] + 1 : 0;
+        S->stable[c] = st;
+        fixed = st >= nb && step + 1 < total_steps;
+    }
+    if (fixed) {   // the remaining steps would rotate the list by one place each: do that, and let the chain's remaining launches return at once
+        const int rot = (total_steps - (step + 1)) % nb;
+        int t0[8], t1[8];
+        for (int g = 0; g < nb; g++) { t0[g] = S->lev0[c][g]; t1[g] = S->lev1[c][g]; }
+        for (int g = 0; g < nb; g++) { S->lev0[c][g] = t0[(g + rot) % nb]; S->lev1[c][g] = t1[(g + rot) % nb]; }
+        S->ended[c] = 1u;
+    } else if (step + 1 >= nb && step + 1 < total_steps) {   // the next step is a refinement step: drop the oldest pair
+        S->drop0[c] = S->lev0[c][0]; S->drop1[c] = S->lev1[c][0];
         for (int g = 0; g < nb - 1; g++) { S->lev0[c][g] = S->lev0[c][g + 1]; S->lev1[c][g] = S->lev1[c][g + 1]; }
+    }
     S->counter[c] = 0;
 }
 
@@ -443,9 +461,18 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
     for (int g = 0; g < (kRing ? 15 : 1); g++) cr[g][0] = cr[g][1] = kMax;
     int ul0[kRing ? 1 : 15], ul1[kRing ? 1 : 15];   // modes 1, 2: every thread's own (wave-uniform, scalar-register) copy of the four lists, same layout;
     __shared__ int s_l0[4][8], s_l1[4][8];          // mode 0: thread 0's copy
+    // EARLY END OF A CHAIN.  A refinement step drops the oldest pair of the list and searches a replacement given the others (EbEncCdef.c:1140-1165).  When nb
+    // refinement steps in a row put back exactly the pair that was dropped, every member of the list has been confirmed against the other nb - 1: the list is a fixed
+    // point, the remaining steps would each rotate it by one place and change nothing else -- so the chain ends here, its list rotated by (remaining steps mod nb)
+    // and its total as it is: exactly what the remaining steps would have left.  On coded pictures that happens after 8 - 13 of the 32 refinement steps of the
+    // eight-pair chain (1 of 4, 2 of 8, 4 of 16 for the shorter ones), which halves the number of dependent steps.  Every workgroup sees the same picks, so every
+    // workgroup ends a chain at the same step (s_end: the first step the chain no longer takes part in).
+    __shared__ int s_end[4];
 #pragma unroll
     for (int g = 0; g < (kRing ? 1 : 15); g++) ul0[g] = ul1[g] = 0;
     if (tid < 32) { s_l0[tid >> 3][tid & 7] = 0; s_l1[tid >> 3][tid & 7] = 0; }
+    if (tid < 4) s_end[tid] = 5 << tid;
+    int stable[4] = {0, 0, 0, 0}, drop0[4] = {0, 0, 0, 0}, drop1[4] = {0, 0, 0, 0}, n_fin = 0;   // thread 0: refinement steps in a row that changed nothing, the pair the last shift dropped
     __syncthreads();
 #ifdef SVT_RES_TRACE
 #define RES_T(k) do { if (tid == 0 && (w == 0 || w == 133)) S->partial[3][w == 0 ? 0 : 1][step * 8 + (k)] = wall_clock64(); } while (0)
@@ -455,6 +482,8 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
     for (int step = 0; step < 40; step++) {
         const int par = step & 1;
         const unsigned long long tag = (unsigned long long)(step + 1) << 56;
+        const int endc[4] = {__builtin_amdgcn_readfirstlane(s_end[0]), __builtin_amdgcn_readfirstlane(s_end[1]), __builtin_amdgcn_readfirstlane(s_end[2]), __builtin_amdgcn_readfirstlane(s_end[3])};
+        if (step >= endc[0] && step >= endc[1] && step >= endc[2] && step >= endc[3]) break;   // every chain has ended
         RES_T(0);
         // ---- this workgroup's 16 pairs, every running chain: thread = (2 x 2 pairs, every 256th filter block)
         T acc[4][4];
@@ -474,14 +503,14 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
             const T v00 = a0 + b0, v01 = a0 + b1, v10 = a1 + b0, v11 = a1 + b1;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (step >= 5 * (1 << c)) continue;
+                if (step >= endc[c]) continue;
                 const T bb = best[c * kResMaxSb + sb];
                 acc[c][0] += v00 < bb ? v00 : bb; acc[c][1] += v01 < bb ? v01 : bb; acc[c][2] += v10 < bb ? v10 : bb; acc[c][3] += v11 < bb ? v11 : bb;
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (step >= 5 * (1 << c)) continue;
+            if (step >= endc[c]) continue;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const unsigned long long r = sum_stride4(acc[c][q]);
@@ -494,7 +523,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
         // ---- first wave: the workgroup's first minimum per chain -> its slot; then the gather of everybody's
         if (wave == 0) {
             const int c = lane >> 4, p = lane & 15;
-            const bool running = step < 5 * (1 << c);
+            const bool running = step < s_end[c];
             unsigned long long tot = 0;
             if (running)
 #pragma unroll
@@ -518,8 +547,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
                 }
             }
             RES_T(3);
-            // the running chains are c >= c_lo: one poll covers all of them (sixteen loads in flight at most)
-            const int c_lo = step < 5 ? 0 : step < 10 ? 1 : step < 20 ? 2 : 3;
+            // one poll covers all running chains (sixteen loads in flight at most)
             // a slot that is not there yet carries an older (smaller) tag, so the minimum of a lane's four words says whether all four are this step's
             unsigned long long k[4];
             bool     failed = false;
@@ -528,7 +556,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
                 bool ok = true;
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++)
-                    if (cc >= c_lo) {
+                    if (step < endc[cc]) {
                         unsigned long long t4[4];
 #pragma unroll
                         for (int t = 0; t < 4; t++) t4[t] = __hip_atomic_load(&S->slot[par][cc][lane + 64 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -536,14 +564,14 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
                     }
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++)
-                    if (cc >= c_lo) ok = ok && (k[cc] >> 56) == (unsigned)(step + 1);
+                    if (step < endc[cc]) ok = ok && (k[cc] >> 56) == (unsigned)(step + 1);
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 16) || ((spins & 63) == 0 && __hip_atomic_load(&S->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { failed = true; break; }
             }
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
-                if (cc < c_lo || failed) continue;
+                if (step >= endc[cc] || failed) continue;
                 unsigned long long gv = (unsigned long long)1 << 63;   // "tot < best" with best = 1 << 63 (EbEncCdef.c:1104): nothing below it keeps (0, 0)
                 int                gi = 0x7fffffff;
                 if (kPacked) {
@@ -577,7 +605,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
         int pl0[4], pl1[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {   // the column loads of every running chain are in flight together
-            if (step >= 5 * (1 << c)) continue;
+            if (step >= endc[c]) continue;
             const int  bi = s_pick_i[c];
             const bool any = bi != 0x7fffffff;
             pl0[c] = __builtin_amdgcn_readfirstlane(any ? start_gi + bi / ng : 0); pl1[c] = __builtin_amdgcn_readfirstlane(any ? start_gi + bi % ng : 0);   // scalar registers
@@ -592,7 +620,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
         for (int c = 0; c < 4; c++) {
             constexpr int kOff[4] = {0, 1, 3, 7};
             const int nb = 1 << c, total_steps = 5 * nb;
-            if (step >= total_steps) continue;
+            if (step >= endc[c]) continue;
             const int idx = step < nb ? step : nb - 1;
 #pragma unroll
             for (int g = 0; g < nb; g++)
@@ -602,15 +630,33 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
                 }
             if (tid == 0) {
                 if constexpr (kRing) { s_l0[c][idx] = pl0[c]; s_l1[c][idx] = pl1[c]; }
-                if (w == 0 && step + 1 == total_steps) {   // the chain is complete: its pairs and total
-#pragma unroll
-                    for (int g = 0; g < 8; g++) {
-                        if constexpr (kRing) { S->lev0[c][g] = s_l0[c][g]; S->lev1[c][g] = s_l1[c][g]; }
-                        else { S->lev0[c][g] = g < nb ? ul0[kOff[c] + g] : 0; S->lev1[c][g] = g < nb ? ul1[kOff[c] + g] : 0; }
-                    }
-                    S->result[c] = s_pick_v[c];
-                    if (c == 3) S->done = 1;
+                bool fin = step + 1 == total_steps;
+                int  rot = 0;
+                if (step >= nb) {   // a refinement step: did it put back the pair the shift before it dropped?
+                    stable[c] = (pl0[c] == drop0[c] && pl1[c] == drop1[c]) ? stable[c] + 1 : 0;
+                    if (stable[c] >= nb && !fin) { fin = true; rot = (total_steps - (step + 1)) % nb; }   // a fixed point: the remaining steps only rotate the list
                 }
+                if (fin) {
+                    s_end[c] = step + 1;   // read by every thread at the top of the next step (the barrier at the end of this one is in between)
+                    n_fin++;
+                    if (w == 0) {   // the chain is complete: its pairs and total
+#pragma unroll
+                        for (int g = 0; g < 8; g++) {
+                            const int gs = g < nb ? (g + rot) % nb : g;
+                            if constexpr (kRing) { S->lev0[c][g] = g < nb ? s_l0[c][gs] : 0; S->lev1[c][g] = g < nb ? s_l1[c][gs] : 0; }
+                            else {
+                                int v0 = 0, v1 = 0;
+#pragma unroll
+                                for (int q = 0; q < nb; q++) if (q == gs) { v0 = ul0[kOff[c] + q]; v1 = ul1[kOff[c] + q]; }   // compile-time indices: the lists live in registers
+                                S->lev0[c][g] = g < nb ? v0 : 0; S->lev1[c][g] = g < nb ? v1 : 0;
+                            }
+                        }
+                        S->result[c] = s_pick_v[c];
+                        if (n_fin == 4) S->done = 1;
+                    }
+                }
+                if constexpr (kRing) { drop0[c] = s_l0[c][0]; drop1[c] = s_l1[c][0]; }   // what the shift below is about to drop
+                else { drop0[c] = ul0[kOff[c]]; drop1[c] = ul1[kOff[c]]; }
             }
             if (step + 1 >= total_steps) continue;
             if (step + 1 >= nb) {   // the next step is a refinement step: drop the oldest pair
