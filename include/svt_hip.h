@@ -780,6 +780,8 @@ int svt_hip_cdef_joint_strength_search_dev(SvtHipCtx *ctx, const uint64_t *d_mse
  *    (same data: 0.64 / 0.77 / 0.77 ms in steps) -- the form for ONE picture in flight.  Its workgroups wait for each other, so all resident selections of a
  *    device are issued on one library-owned stream (ordered against the context's stream with events; inside a stream capture they are chained with events
  *    instead) and other work in flight delays it: with four frames in flight bench.py's step takes 12.1 ms against 8.7 ms in steps.
+ * Both forms end a chain as soon as its list is a fixed point (nb refinement steps in a row that put back the pair they dropped; the list is then rotated by the
+ * remaining steps mod nb, which is what those steps would leave): 16 - 21 dependent steps instead of 40 on coded pictures -- 0.44 ms in steps, 0.23 ms resident.
  * d_state: SVT_HIP_CDEF_SELECT_STATE_BYTES of device memory, cleared by the call; afterwards it starts with SvtHipCdefSelectResult (the selected pairs of each
  * count and the totals).  status[0] != 0 afterwards: the resident form gave up waiting for a workgroup (bounded spin; nothing else should be able to cause
  * it) -- the result is not valid, svt_hip_cdef_finish_dev reports cdef_bits = -1 for it; run the selection again in the steps form. */
