@@ -303,7 +303,7 @@ joint_partial_kernel(const JointPics P, int sb_count, int start_gi, int ng, int 
     else joint_tile<unsigned long long>(mse0, mse1, p0, p1, start_gi, ng, idx, s_l0, s_l1, s_stage, S->partial[c][blockIdx.x]);
 }
 __global__ void __launch_bounds__(256)
-joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int step) {
+joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int step, int early) {
     JointState* __restrict__ S = P.S[blockIdx.y];
     const int c = blockIdx.z, nb = 1 << c, total_steps = 5 * nb;
     if (step >= total_steps || S->ended[c]) return;
@@ -367,7 +367,7 @@ joint_reduce_kernel(const JointPics P, int slices, int start_gi, int ng, int ste
     if (step >= nb) {
         const int st = (n0 == S->drop0[c] && n1 == S->drop1[c]) ? S->stable[c] + 1 : 0;
         S->stable[c] = st;
-        fixed = st >= nb && step + 1 < total_steps;
+        fixed = early && st >= nb && step + 1 < total_steps;
     }
     if (fixed) {   // the remaining steps would rotate the list by one place each: do that, and let the chain's remaining launches return at once
         const int rot = (total_steps - (step + 1)) % nb;
@@ -434,7 +434,7 @@ __device__ __forceinline__ unsigned long long sum_stride4(unsigned long long r) 
 // registers.  MODE 1 (below 2^32): 32-bit columns in LDS, 64-bit arithmetic.  MODE 2: columns read from L2, 64-bit arithmetic.  Modes 1 and 2 exchange two
 // words (total, then tag | index) and rebuild the running best from the list's columns each step (the 64-bit register copy of fifteen members would spill).
 template <int MODE>
-__device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* __restrict__ S, unsigned char* lds) {
+__device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* __restrict__ S, unsigned char* lds, int early) {
     constexpr bool kPacked = MODE <= 1, kLdsCols = MODE <= 1, kRing = MODE == 0;   // packed: totals below 2^44 (2048 filter blocks x 2^33)
     typedef typename std::conditional<MODE == 0, uint32_t, unsigned long long>::type T;
     const unsigned long long* __restrict__ col0 = &S->partial[0][0][0];            // [64][kResMaxSb], joint_transpose_kernel
@@ -634,7 +634,7 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
                 int  rot = 0;
                 if (step >= nb) {   // a refinement step: did it put back the pair the shift before it dropped?
                     stable[c] = (pl0[c] == drop0[c] && pl1[c] == drop1[c]) ? stable[c] + 1 : 0;
-                    if (stable[c] >= nb && !fin) { fin = true; rot = (total_steps - (step + 1)) % nb; }   // a fixed point: the remaining steps only rotate the list
+                    if (early && stable[c] >= nb && !fin) { fin = true; rot = (total_steps - (step + 1)) % nb; }   // a fixed point: the remaining steps only rotate the list
                 }
                 if (fin) {
                     s_end[c] = step + 1;   // read by every thread at the top of the next step (the barrier at the end of this one is in between)
@@ -693,12 +693,12 @@ __device__ void joint_resident(int sb_count, int start_gi, int ng, JointState* _
 // 64-bit bodies' register pressure into the narrow one.
 template <int MODE>
 __global__ void __launch_bounds__(1024)
-joint_resident_kernel(int sb_count, int start_gi, int ng, JointState* __restrict__ S) {
+joint_resident_kernel(int sb_count, int start_gi, int ng, JointState* __restrict__ S, int early) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_res[];
     const unsigned long long m = max(S->max0, S->max1);
     const int mode = m < (1ull << 26) ? 0 : m < (1ull << 32) ? 1 : 2;   // below 2^26: the sums of a 16-lane row (32 filter blocks) fit 32 bits
     if (mode != MODE) return;
-    joint_resident<MODE>(sb_count, start_gi, ng, S, s_res);
+    joint_resident<MODE>(sb_count, start_gi, ng, S, s_res, early);
 }
 constexpr size_t kResLdsBytes = 4 * kResMaxSb * 8 + 4 * 16 * 16 * 8 + (size_t)kResMaxSb * 8 * 4;   // sized for the wider `best`
 
@@ -1033,6 +1033,8 @@ extern "C" int svt_hip_launch_strength_select_multi(hipStream_t st, int n_pics, 
         (void)hipFuncSetAttribute((const void*)joint_resident_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResLdsBytes);
         attr_set = true;
     }
+    const char* early_env = getenv("SVT_HIP_CDEF_SELECT_EARLY");   // read per call: 0 = every chain runs its 5 nb steps (the reference's loop as written); tests compare both
+    const int early = !(early_env && !atoi(early_env));
     static int forced = -1;   // debug: SVT_HIP_CDEF_SELECT_SLICES
     if (forced < 0) { const char* e = getenv("SVT_HIP_CDEF_SELECT_SLICES"); forced = e ? atoi(e) : 0; }
     int slices = forced > 0 ? forced : (sb_count + 31) / 32;
@@ -1046,15 +1048,15 @@ extern "C" int svt_hip_launch_strength_select_multi(hipStream_t st, int n_pics, 
         if (resident) {
             for (int i = 0; i < np; i++) {
                 hipLaunchKernelGGL(joint_transpose_kernel, dim3((sb_count + 63) / 64, 2), dim3(256), 0, st, P.mse0[i], P.mse1[i], sb_count, P.S[i]);
-                hipLaunchKernelGGL(joint_resident_kernel<0>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
-                hipLaunchKernelGGL(joint_resident_kernel<1>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
-                hipLaunchKernelGGL(joint_resident_kernel<2>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i]);
+                hipLaunchKernelGGL(joint_resident_kernel<0>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i], early);
+                hipLaunchKernelGGL(joint_resident_kernel<1>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i], early);
+                hipLaunchKernelGGL(joint_resident_kernel<2>, dim3(kResWgs), dim3(1024), kResLdsBytes, st, sb_count, start_gi, ng, P.S[i], early);
             }
             continue;
         }
         for (int step = 0; step < 40; step++) {
             hipLaunchKernelGGL(joint_partial_kernel, dim3(slices, np, 4), dim3(1024), 0, st, P, sb_count, start_gi, ng, step);
-            hipLaunchKernelGGL(joint_reduce_kernel, dim3(64, np, 4), dim3(256), 0, st, P, slices, start_gi, ng, step);
+            hipLaunchKernelGGL(joint_reduce_kernel, dim3(64, np, 4), dim3(256), 0, st, P, slices, start_gi, ng, step, early);
         }
     }
     return (int)hipGetLastError();

@@ -907,6 +907,15 @@ def test_joint_strength_search_on_device_vs_reference_steps(hip, ref):
         hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select")
         sel = hip.to_host(d_state, (304,), np.uint8)
         assert np.array_equal(sel_res, sel), ("resident form vs steps form", sb_count, start, end, mag)
+        # ... and with the early end of a chain switched off (every chain runs its 5 nb steps, the reference's loop as written): the same bytes from both forms
+        os.environ["SVT_HIP_CDEF_SELECT_EARLY"] = "0"
+        try:
+            for form in (1, 0):
+                hip.check(L.svt_hip_set_cdef_select_form(hip.h, form), "select form")
+                hip.check(L.svt_hip_cdef_strength_select_dev(hip.h, d_m0, d_m1, sb_count, start, end, d_state, state_bytes), "strength select (full course)")
+                assert np.array_equal(hip.to_host(d_state, (304,), np.uint8), sel), ("early end vs the full course", form, sb_count, start, end, mag)
+        finally:
+            os.environ.pop("SVT_HIP_CDEF_SELECT_EARLY", None)
         sel_lev0 = sel[:128].view(np.int32).reshape(4, 8); sel_lev1 = sel[128:256].view(np.int32).reshape(4, 8); sel_tot = sel[272:304].view(np.uint64)
         for ci, nb in enumerate((1, 2, 4, 8)):
             l0 = np.zeros(8, np.int32); l1 = np.zeros(8, np.int32)
