@@ -228,6 +228,15 @@ int svt_hip_dlf_build_edges(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_row
 int svt_hip_dlf_filtered_units(int coded_luma, int pad, int sb_size, int ss);
 int svt_hip_dlf_build_edges_crop(const SvtHipDlfModeInfo *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int plane_w,
                                  int plane_h, int filt_units_w, int filt_units_h, uint16_t *edges_v, uint16_t *edges_h);
+/* svt_hip_dlf_build_edges_crop for the three planes of a picture (chroma sub-sampled by ss_x / ss_y) in one launch, from a mode-info grid in DEVICE memory:
+ * a 3840 x 2160 picture has 777 600 units in two directions, which cost the host builder 2.5 ms per call on one thread and the edge planes a 3 MB upload.
+ * level[plane][dir] >= 0 stands for the level of every record (frame-uniform levels, the case whenever the frame header carries no delta_lf and no
+ * mode / reference deltas: svt_av1_loop_filter_frame_init, Common/Codec/EbDeblockingCommon.c:105-160) — one upload of the grid then serves the level
+ * search and the filter itself; level == NULL or an entry < 0 reads the records' own levels.  A plane whose two output pointers are NULL is skipped.
+ * filt_units_w / _h: see svt_hip_dlf_filtered_units; plane_w / plane_h in samples; the outputs are [ceil(plane_h / 4)][ceil(plane_w / 4)] as above. */
+int svt_hip_dlf_build_edges_picture_dev(SvtHipCtx *ctx, const SvtHipDlfModeInfo *d_mi, int mi_cols, int mi_rows, int ss_x, int ss_y, const int plane_w[3],
+                                        const int plane_h[3], const int filt_units_w[3], const int filt_units_h[3], const int (*level)[2],
+                                        uint16_t *const d_edges_v[3], uint16_t *const d_edges_h[3]);
 /* Deblock one plane in place: all vertical edges, then all horizontal edges (normative order;
  * replaces svt_av1_loop_filter_frame for that plane, EbDeblockingFilter.c:711, and the 16 edge
  * kernels svt_aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}, common_dsp_rtcd.h:1051-1081).

@@ -62,6 +62,8 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
     p->h_skip8 = (uint8_t *)malloc((size_t)(w / 8) * (h / 8)); p->h_mi = (SvtHipDlfModeInfo *)calloc((size_t)mi_cols * mi_rows, sizeof(SvtHipDlfModeInfo));
     p->h_mse = (uint64_t *)malloc(sizeof(uint64_t) * 2 * nfb * 64);
     if (!p->h_skip8 || !p->h_mi || !p->h_mse) return EB_ErrorInsufficientResources;
+    HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows));
+    p->h_mi_pinned = svt_hip_hooks_pin_enabled() && svt_hip_host_register(hip, p->h_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows) == SVT_HIP_OK;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_skip8, (size_t)(w / 8) * (h / 8)));
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_mse, sizeof(uint64_t) * 2 * nfb * 64));
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_dir, (size_t)nfb * 64)); HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_var, sizeof(int32_t) * nfb * 64));
@@ -77,7 +79,8 @@ void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
         svt_hip_free(hip, p->d_unit_ep[pl]); svt_hip_free(hip, p->d_unit_xqd[pl]); svt_hip_free(hip, p->d_unit_wiener[pl]);
         free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
     }
-    free(p->h_skip8); free(p->h_mi); free(p->h_mse);
+    if (p->h_mi_pinned) svt_hip_host_unregister(hip, p->h_mi);
+    free(p->h_skip8); free(p->h_mi); free(p->h_mse); svt_hip_free(hip, p->d_mi);
     svt_hip_free(hip, p->d_skip8); svt_hip_free(hip, p->d_mse); svt_hip_free(hip, p->d_dir); svt_hip_free(hip, p->d_var);
     svt_hip_free(hip, p->d_y_strength); svt_hip_free(hip, p->d_uv_strength); svt_hip_free(hip, p->d_sse);
     memset(p, 0, sizeof(*p));
@@ -102,7 +105,8 @@ enum { ST_SRC = 1, ST_DBL = 2, ST_CDEF = 4, ST_DIRVAR = 8, ST_CDEF_SEARCHED = 16
        ST_HOST_STALE = 16384,  /* the host's recon picture is older than the device's */
        ST_SKIP0 = 32768,       /* save_boundary_lines(.., 0) was skipped on the host */
        ST_SKIP1 = 65536,       /* save_boundary_lines(.., 1) + svt_extend_frame were skipped on the host */
-       ST_REST = 131072 };     /* d_rest holds restored planes (rest_mask) that the host has not seen */
+       ST_REST = 131072,       /* d_rest holds restored planes (rest_mask) that the host has not seen */
+       ST_MI = 262144 };       /* d_mi holds this picture's mode-info grid (uploaded by the level search; its levels are placeholders) */
 typedef struct {
     PictureControlSet *pcs;     /* NULL: free */
     int                allocated, flags, defer, rest_mask, mu_ready;
@@ -401,6 +405,49 @@ static EbErrorType build_and_upload_edges(SvtHipCtx *hip, SvtHipLfPicture *p, in
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][0], p->h_edges[pl][0], eb)); HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_edges[pl][1], p->h_edges[pl][1], eb));
     return EB_ErrorNone;
 }
+/* The edge planes of the planes in `mask`, built on the device from the grid in d_mi (upload_grid: h_mi was just refilled); level: see svt_hip_dlf_build_edges_picture_dev.
+ * SVT_HIP_DLF_EDGES=host keeps the host builder and the upload of its output (the form before: 2.5 ms per call for a 3840 x 2160 picture). */
+static int edges_on_host(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SVT_HIP_DLF_EDGES"); v = e && !strcmp(e, "host"); }
+    return v;
+}
+static EbErrorType build_edges(SvtHipCtx *hip, SvtHipLfPicture *p, int mask, int upload_grid, const int (*level)[2]) {
+    const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4;
+    if (edges_on_host()) {
+        for (int pl = 0; pl < 3; pl++)
+            if ((mask & (1 << pl)) && build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
+        return EB_ErrorNone;
+    }
+    int pw[3], ph[3], fw[3], fh[3];
+    uint16_t *ev[3], *eh[3];
+    for (int pl = 0; pl < 3; pl++) {
+        pw[pl] = p->w >> (pl > 0); ph[pl] = p->h >> (pl > 0);
+        fw[pl] = svt_hip_dlf_filtered_units(p->w, p->w - p->cw, p->sb_size, pl > 0); fh[pl] = svt_hip_dlf_filtered_units(p->h, p->h - p->ch, p->sb_size, pl > 0);
+        if (fw[pl] < 0 || fh[pl] < 0) return EB_ErrorUndefined;
+        ev[pl] = (mask & (1 << pl)) ? p->d_edges[pl][0] : NULL; eh[pl] = (mask & (1 << pl)) ? p->d_edges[pl][1] : NULL;
+    }
+    if (upload_grid) HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_mi, p->h_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows));
+    HIP_TRY(svt_hip_dlf_build_edges_picture_dev(hip, p->d_mi, mi_cols, mi_rows, 1, 1, pw, ph, fw, fh, level, ev, eh));
+    return EB_ErrorNone;
+}
+/* Frame-uniform filter levels: lfi_n->lvl[plane][0][dir][ref][mode] is one number per (plane, direction) unless the frame header carries delta_lf or mode / reference deltas
+ * (svt_av1_loop_filter_frame_init, EbDeblockingCommon.c:105-160; the encoder sets mode_ref_delta_enabled = 0, EbResourceCoordinationProcess.c:436) — checked, not assumed. */
+static int uniform_levels(PictureControlSet *pcs, int mask, int level[3][2]) {
+    PictureParentControlSet *ppcs = pcs->parent_pcs_ptr;
+    const LoopFilterInfoN *lfi_n = &ppcs->lf_info;
+    if (ppcs->frm_hdr.delta_lf_params.delta_lf_present) return 0;
+    for (int pl = 0; pl < 3; pl++)
+        for (int dir = 0; dir < 2; dir++) {
+            level[pl][dir] = 0;
+            if (!(mask & (1 << pl))) continue;   /* a plane that is not filtered: its table is not refreshed (:118-123), and its edges are not built */
+            level[pl][dir] = lfi_n->lvl[pl][0][dir][0][0];
+            for (int ref = 0; ref < REF_FRAMES; ref++)
+                for (int m = 0; m < MAX_MODE_LF_DELTAS; m++)
+                    if (lfi_n->lvl[pl][0][dir][ref][m] != level[pl][dir]) return 0;
+        }
+    return 1;
+}
 
 /* svt_av1_pick_filter_level(.., LPF_PICK_FROM_FULL_IMAGE) (EbDeblockingFilter.c:1193, the else branch :1262-1310): three searches
  * (luma with dir = 2, i.e. both directions at the probed level and — as the reference indexes last_frame_filter_level[dir] — started from
@@ -420,11 +467,12 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
     long long t_edges = 0, t_search = 0;
     int best[3];
     const int last[4] = {lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v};
+    s->flags &= ~ST_MI;
+    if (build_edges(hip, p, 7, 1, NULL) != EB_ErrorNone) return EB_ErrorUndefined;
+    if (!edges_on_host()) s->flags |= ST_MI;
+    t_edges = svt_hip_hooks_now_ns() - td2;
     for (int pl = 0; pl < 3; pl++) {
-        const long long te0 = svt_hip_hooks_now_ns();
-        if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
         const long long te1 = svt_hip_hooks_now_ns();
-        t_edges += te1 - te0;
         SvtHipDlfSearch q;
         memset(&q, 0, sizeof(q));
         q.plane = pl; q.dir = 2; q.other_level = 0;
@@ -439,7 +487,7 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
         t_search += svt_hip_hooks_now_ns() - te1;
         svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, q.start_level, best[pl], (long long)err);
     }
-    svt_hip_hooks_log("dlf_search: picture up %.2f ms, mode info (host) %.2f ms, edges (host + upload) %.2f ms, probes %.2f ms", (td1 - td0) / 1e6, (td2 - td1) / 1e6, t_edges / 1e6, t_search / 1e6);
+    svt_hip_hooks_log("dlf_search: picture up %.2f ms, mode info (host) %.2f ms, edges %.2f ms, probes %.2f ms", (td1 - td0) / 1e6, (td2 - td1) / 1e6, t_edges / 1e6, t_search / 1e6);
     lf->sharpness_level = 0;
     lf->filter_level[0] = lf->filter_level[1] = best[0];
     lf->filter_level_u = best[1];
@@ -474,17 +522,23 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
     }
     if (!(s->flags & ST_RECON) && upload(hip, p, recon, p->d_recon, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags &= ~ST_RECON;
-    fill_mode_info(p, pcs, 0);
     void *pl_ptr[3]; const uint16_t *ev[3], *eh[3];
     int mask = 0;
     for (int pl = 0; pl < 3; pl++) {
         const int on = pl == 0 || (pl == 1 ? lf->filter_level_u : lf->filter_level_v);
         pl_ptr[pl] = on ? plane_origin(p, p->d_recon[pl], pl) : NULL;
         ev[pl] = p->d_edges[pl][0]; eh[pl] = p->d_edges[pl][1];
-        if (!on) continue;
-        mask |= 1 << pl;
-        if (build_and_upload_edges(hip, p, pl) != EB_ErrorNone) return EB_ErrorUndefined;
+        if (on) mask |= 1 << pl;
     }
+    /* the level search of this picture left its grid on the device, and the frame's levels are one number per plane and direction: the geometry is the same, the
+     * levels ride along as arguments (no second pass over the mode info, no upload) */
+    const long long te0 = svt_hip_hooks_now_ns();
+    int level[3][2];
+    const int reuse = (s->flags & ST_MI) && uniform_levels(pcs, mask, level);
+    if (!reuse) fill_mode_info(p, pcs, 0);
+    s->flags &= ~ST_MI;
+    if (build_edges(hip, p, mask, !reuse, reuse ? (const int (*)[2])level : NULL) != EB_ErrorNone) return EB_ErrorUndefined;
+    const long long te1 = svt_hip_hooks_now_ns();
     static int fused = -1;
     if (fused < 0) fused = !(getenv("SVT_HIP_DLF_FUSED") && !atoi(getenv("SVT_HIP_DLF_FUSED")));
     if (fused) {   /* both directions of all planes in one out-of-place launch; the result takes the place of the picture as coded */
@@ -498,7 +552,8 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
     if (s->defer) s->flags |= ST_HOST_STALE;   /* the deblocked picture stays on the device (svt_hip_hook_picture_done brings the final one back) */
     else if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
     s->flags |= ST_DBL;
-    svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask);
+    svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d, edges %.2f ms (%s)", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask,
+                      (te1 - te0) / 1e6, reuse ? "the level search's grid" : "mode info refilled");
     return EB_ErrorNone;
 }
 EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet *pcs) {

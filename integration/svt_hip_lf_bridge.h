@@ -43,7 +43,8 @@ typedef struct SvtHipLfPicture {
     uint8_t  *d_dir;  int32_t *d_var;    /* [nfb * 64] */
     uint8_t  *d_y_strength, *d_uv_strength;
     /* deblocking */
-    SvtHipDlfModeInfo *h_mi;             /* [mi_rows][mi_cols] */
+    SvtHipDlfModeInfo *h_mi, *d_mi;      /* [mi_rows][mi_cols]; the device copy serves the level search and the filter of one picture */
+    int       h_mi_pinned;
     uint16_t *h_edges[3][2], *d_edges[3][2];
     int       units_w[3], units_h[3];
     uint64_t *d_sse;

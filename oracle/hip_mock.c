@@ -297,6 +297,24 @@ int svt_hip_deblock_frame_fused_dev(SvtHipCtx *c, const void *const src[3], void
     if (perturb("dlf") && src[0]) ((uint8_t *)dst[0])[(size_t)9 * stride[0] * pix_bytes + 9 * pix_bytes] ^= 1;
     return SVT_HIP_OK;
 }
+int svt_hip_dlf_build_edges_picture_dev(SvtHipCtx *c, const SvtHipDlfModeInfo *mi, int mi_cols, int mi_rows, int ss_x, int ss_y, const int pw[3], const int ph[3], const int fw[3],
+                                        const int fh[3], const int (*level)[2], uint16_t *const ev[3], uint16_t *const eh[3]) {
+    (void)c;
+    const size_t       n = (size_t)mi_cols * mi_rows;
+    SvtHipDlfModeInfo *t = (SvtHipDlfModeInfo *)malloc(n * sizeof(*t));   /* the host builder on a copy of the grid that carries the stand-in levels */
+    if (!t) return SVT_HIP_ERR_RUNTIME;
+    memcpy(t, mi, n * sizeof(*t));
+    if (level)
+        for (size_t i = 0; i < n; i++)
+            for (int p = 0; p < 3; p++)
+                for (int d = 0; d < 2; d++)
+                    if (level[p][d] >= 0) t[i].level[p][d] = (uint8_t)level[p][d];
+    int rc = SVT_HIP_OK;
+    for (int p = 0; p < 3 && rc == SVT_HIP_OK; p++)
+        if (ev[p] || eh[p]) rc = svt_hip_dlf_build_edges_crop(t, mi_cols, mi_rows, p, p ? ss_x : 0, p ? ss_y : 0, pw[p], ph[p], fw[p], fh[p], ev[p], eh[p]);
+    free(t);
+    return rc;
+}
 int svt_hip_plane_sse_dev(SvtHipCtx *c, int pix_bytes, const void *a, int a_stride, const void *b, int b_stride, int w, int h, uint64_t *sse) {
     (void)c;
     *sse = orc_plane_sse(pix_bytes, a, a_stride, b, b_stride, w, h);

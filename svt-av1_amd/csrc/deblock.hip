@@ -367,6 +367,46 @@ plane_sse_kernel(const PIX* __restrict__ a, int a_stride, const PIX* __restrict_
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
+// set_lpf_parameters (Encoder/Codec/EbDeblockingFilter.c:168-319) for every 4x4 unit of a picture's planes, both directions, in one launch: the device form of
+// svt_hip_dlf_build_edges_crop (svt_hip_host.cpp), which stays the statement the tests compare with.  One thread per unit; blockIdx.z = plane * 2 + direction.
+// lvl[plane][dir] >= 0 stands for the level of EVERY record (frame-uniform levels: the grid is uploaded once per picture and serves the level search and the
+// filter itself); < 0 reads the records' own.
+struct EdgeBuild {
+    const SvtHipDlfModeInfo* mi;
+    int mi_cols, mi_rows, ss_x, ss_y;
+    int pw[3], ph[3], fw[3], fh[3], uw[3], uh[3], lvl[3][2];
+    uint16_t* out[3][2];
+};
+__global__ void __launch_bounds__(256) dlf_build_edges_kernel(const EdgeBuild a) {
+    const int plane = blockIdx.z >> 1, dir = blockIdx.z & 1;
+    uint16_t* out = a.out[plane][dir];
+    const int uw = a.uw[plane], uh = a.uh[plane], idx = blockIdx.x * 256 + threadIdx.x;
+    if (!out || idx >= uw * uh) return;
+    const int uy = idx / uw, ux = idx - uy * uw;
+    uint16_t v = 0;
+    if (ux < a.fw[plane] && uy < a.fh[plane]) {   // outside: beyond the reference loops' range in a padded picture, never visited
+        const int ss_x = plane ? a.ss_x : 0, ss_y = plane ? a.ss_y : 0, x = 4 * ux, y = 4 * uy;
+        const int mr = min(ss_y | ((y << ss_y) >> 2), a.mi_rows - 1), mc = min(ss_x | ((x << ss_x) >> 2), a.mi_cols - 1);   // chroma: the bottom / right mi of the co-located 8x8 (:196-197)
+        const SvtHipDlfModeInfo cur = a.mi[mr * a.mi_cols + mc];
+        const int ts = plane == 0 ? (dir == 0 ? cur.tx_w_log2 : cur.tx_h_log2) : (dir == 0 ? cur.uv_tx_w_log2 : cur.uv_tx_h_log2);
+        const int coord = dir == 0 ? x : y;
+        const int pr = dir == 0 ? mr : mr - (1 << ss_y), pc = dir == 0 ? mc - (1 << ss_x) : mc;
+        if (!(coord & ((1 << ts) - 1)) && coord && pr >= 0 && pc >= 0) {
+            const SvtHipDlfModeInfo prv = a.mi[pr * a.mi_cols + pc];
+            const int pts = plane == 0 ? (dir == 0 ? prv.tx_w_log2 : prv.tx_h_log2) : (dir == 0 ? prv.uv_tx_w_log2 : prv.uv_tx_h_log2);
+            const int ov = a.lvl[plane][dir], cl = ov >= 0 ? ov : cur.level[plane][dir], pl = ov >= 0 ? ov : prv.level[plane][dir];
+            const int bdim = max(dir == 0 ? cur.bw_log2 - ss_x : cur.bh_log2 - ss_y, 2);
+            const bool pu_edge = !(coord & ((1 << bdim) - 1));
+            if ((cl || pl) && (!prv.skip_inter || !cur.skip_inter || pu_edge)) {
+                const int mts = min(ts, pts);
+                const int len = mts <= 2 ? 4 : (mts == 3 ? (plane ? 6 : 8) : (plane ? 6 : 14));
+                v = (uint16_t)(((cl ? cl : pl) << 8) | len);
+            }
+        }
+    }
+    out[idx] = v;
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_lpf_edge_list(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const void* jobs, int n) {
@@ -419,3 +459,19 @@ extern "C" int svt_hip_launch_deblock_fused(hipStream_t st, const void* const sr
 }
 
 SVT_HIP_TU_PROBE(deblock)
+
+extern "C" int svt_hip_launch_dlf_build_edges(hipStream_t st, const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int ss_x, int ss_y, const int pw[3], const int ph[3],
+                                              const int fw[3], const int fh[3], const int level[3][2], uint16_t* const ev[3], uint16_t* const eh[3]) {
+    EdgeBuild a;
+    a.mi = mi; a.mi_cols = mi_cols; a.mi_rows = mi_rows; a.ss_x = ss_x; a.ss_y = ss_y;
+    int n = 0;
+    for (int p = 0; p < 3; p++) {
+        a.pw[p] = pw[p]; a.ph[p] = ph[p]; a.fw[p] = fw[p]; a.fh[p] = fh[p]; a.uw[p] = (pw[p] + 3) >> 2; a.uh[p] = (ph[p] + 3) >> 2;
+        a.out[p][0] = ev[p]; a.out[p][1] = eh[p];
+        for (int d = 0; d < 2; d++) a.lvl[p][d] = level ? level[p][d] : -1;
+        if ((ev[p] || eh[p]) && a.uw[p] * a.uh[p] > n) n = a.uw[p] * a.uh[p];
+    }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dlf_build_edges_kernel, dim3((n + 255) / 256, 1, 6), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}

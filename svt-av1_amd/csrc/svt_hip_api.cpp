@@ -441,6 +441,27 @@ int svt_hip_deblock_frame_fused_dev(SvtHipCtx* c, const void* const d_src[3], vo
     return SVT_HIP_OK;
 }
 
+int svt_hip_dlf_build_edges_picture_dev(SvtHipCtx* c, const SvtHipDlfModeInfo* d_mi, int mi_cols, int mi_rows, int ss_x, int ss_y, const int plane_w[3], const int plane_h[3],
+                                        const int filt_units_w[3], const int filt_units_h[3], const int (*level)[2], uint16_t* const d_edges_v[3], uint16_t* const d_edges_h[3]) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_mi || mi_cols <= 0 || mi_rows <= 0 || ss_x < 0 || ss_x > 1 || ss_y < 0 || ss_y > 1 || !plane_w || !plane_h || !filt_units_w || !filt_units_h || !d_edges_v ||
+        !d_edges_h) {
+        if (c) c->err = "svt_hip_dlf_build_edges_picture_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    for (int p = 0; p < 3; p++) {
+        if (!d_edges_v[p] && !d_edges_h[p]) continue;
+        if (!d_edges_v[p] || !d_edges_h[p] || plane_w[p] <= 0 || plane_h[p] <= 0 || filt_units_w[p] < 0 || filt_units_h[p] < 0 ||
+            (level && (level[p][0] > 63 || level[p][1] > 63))) {
+            c->err = "svt_hip_dlf_build_edges_picture_dev: bad plane argument";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_dlf_build_edges(c->stream, d_mi, mi_cols, mi_rows, ss_x, ss_y, plane_w, plane_h, filt_units_w, filt_units_h, level, d_edges_v, d_edges_h);
+    if (e != hipSuccess) return fail(c, e, "edge builder launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_plane_sse_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, int a_stride, const void* d_b, int b_stride, int w, int h,
                           uint64_t* d_sse) {
     SVT_HIP_ENTER(c);

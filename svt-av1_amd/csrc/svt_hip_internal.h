@@ -50,6 +50,8 @@ int svt_hip_launch_deblock_frame(hipStream_t st, void* const plane[3], int pix_b
                                  const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness);
 int svt_hip_launch_deblock_fused(hipStream_t st, const void* const src[3], void* const dst[3], int pix_bytes, const int stride[3], int bd, const int pw[3],
                                  const int ph[3], const uint16_t* const ev[3], const uint16_t* const eh[3], const int units_w[3], const int units_h[3], int sharpness);
+int svt_hip_launch_dlf_build_edges(hipStream_t st, const SvtHipDlfModeInfo* mi, int mi_cols, int mi_rows, int ss_x, int ss_y, const int pw[3], const int ph[3],
+                                   const int fw[3], const int fh[3], const int level[3][2], uint16_t* const ev[3], uint16_t* const eh[3]);
 int svt_hip_launch_deblock_plane(hipStream_t st, void* plane, int pix_bytes, int stride, int bd, const uint16_t* edges_v,
                                  const uint16_t* edges_h, int units_w, int units_h, int sharpness, int level_v, int level_h);
 int svt_hip_launch_coeff_distortion(hipStream_t st, const int32_t* coeff, const int32_t* recon, int n, int nblk, uint64_t* out);

@@ -195,3 +195,46 @@ def test_deblock_frame_fused(hip, orc, bd, size):
                 assert (got[ph:] == 37).all() and (got[:, pw:] == 37).all(), "samples outside the plane extent were written"
                 assert i == 2 or (exp[i][:ph, :pw] != planes[i][:ph, :pw]).any()   # plane 2 is noise: nothing may be flat enough to filter
             hip.free(*d_p, *d_o, *d_ev, *d_eh)
+
+
+def host_edges_crop(L, raw, cols, rows, plane, pw, ph, fw, fh):
+    uw, uh = (pw + 3) // 4, (ph + 3) // 4
+    ev = np.zeros((uh, uw), np.uint16); eh = np.zeros((uh, uw), np.uint16)
+    L.svt_hip_dlf_build_edges_crop.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 2
+    assert L.svt_hip_dlf_build_edges_crop(ptr(raw), cols, rows, plane, int(plane > 0), int(plane > 0), pw, ph, fw, fh, ptr(ev), ptr(eh)) == 0
+    return ev, eh
+
+
+@pytest.mark.parametrize("w,h,pad", [(328, 200, (0, 0)), (192, 128, (6, 2)), (3840, 2160, (0, 0))])
+def test_edge_planes_built_on_the_device(hip, w, h, pad):
+    """svt_hip_dlf_build_edges_picture_dev == the host builder (the statement of set_lpf_parameters the other tests pin), for the records' own levels (varied per
+    block, zeros included), for frame-uniform stand-in levels — a zero among them, and one plane left out — and for a padded picture's filtered extent."""
+    L = hip.L
+    mi, cols, rows = dc.make_mode_info(w, h, seed=31 + w, varied=True)
+    pw = [w, w // 2, w // 2]; ph = [h, h // 2, h // 2]
+    fw = [L.svt_hip_dlf_filtered_units(w, pad[0], 64, int(p > 0)) for p in range(3)]
+    fh = [L.svt_hip_dlf_filtered_units(h, pad[1], 64, int(p > 0)) for p in range(3)]
+    assert min(fw + fh) >= 0
+    rec = C.sizeof(mi) // (cols * rows)
+    assert rec == 13
+    raw = np.frombuffer(mi, np.uint8).reshape(-1, rec).copy()
+    d_mi = hip.to_device(raw)
+    I3, P3 = C.c_int * 3, C.c_void_p * 3
+    for levels, mask in ((None, 7), (((23, 9), (0, 0), (17, 17)), 7), (((0, 31), (5, 5), (63, 63)), 5)):
+        outs = [[hip.empty(2 * ((pw[p] + 3) // 4) * ((ph[p] + 3) // 4)) if mask & (1 << p) else None for p in range(3)] for _ in range(2)]
+        lv = (C.c_int * 6)(*[levels[p][d] for p in range(3) for d in range(2)]) if levels else None
+        hip.check(L.svt_hip_dlf_build_edges_picture_dev(hip.h, d_mi, cols, rows, 1, 1, I3(*pw), I3(*ph), I3(*fw), I3(*fh), C.cast(lv, C.c_void_p) if lv else None,
+                                                        P3(*[o.value if o else None for o in outs[0]]), P3(*[o.value if o else None for o in outs[1]])), "edges")
+        ref_raw = raw.copy()
+        if levels:
+            ref_raw[:, 7:13] = np.array(levels, np.uint8).reshape(6)   # level[3][2] follows the seven geometry bytes
+        for p in range(3):
+            if not mask & (1 << p):
+                continue
+            ev, eh = host_edges_crop(L, ref_raw, cols, rows, p, pw[p], ph[p], fw[p], fh[p])
+            gv = hip.to_host(outs[0][p], ev.shape, np.uint16); gh = hip.to_host(outs[1][p], eh.shape, np.uint16)
+            if not levels or levels[p][0]:
+                assert (ev != 0).any() and (eh != 0).any()
+            assert np.array_equal(gv, ev) and np.array_equal(gh, eh), (levels, p, np.argwhere(gv != ev)[:4], np.argwhere(gh != eh)[:4])
+        hip.free(*[o for pair in outs for o in pair if o])
+    hip.free(d_mi)

@@ -465,6 +465,26 @@ def test_854x480_preset_4_on_gpu(workdir):
     _check_480p_m4(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
 
 
+def _check_level_search_grid(workdir, env, tag):
+    """The level search's mode-info grid stays on the device and serves the deblocking of the same picture (frame-uniform levels as arguments of the device
+    edge builder); SVT_HIP_DLF_EDGES=host = the host builder and its upload for both stages.  Same bitstream either way."""
+    got = _check_geometry("480p_m4_q63", 854, 480, 3, 8, 4, 63, 23, workdir, dict(env, SVT_HIP_VERBOSE="1"), tag + ".grid")   # q 63: the search settles on levels > 0
+    filt = re.findall(r"dlf: levels [^\n]*", got["log"])
+    assert filt and all("the level search's grid" in l for l in filt), got["log"][-1500:]
+    host = _check_geometry("480p_m4_q63", 854, 480, 3, 8, 4, 63, 23, workdir, dict(env, SVT_HIP_VERBOSE="1", SVT_HIP_DLF_EDGES="host"), tag + ".hostedges")
+    filt = re.findall(r"dlf: levels [^\n]*", host["log"])
+    assert filt and all("mode info refilled" in l for l in filt), filt
+
+
+def test_level_search_grid_serves_the_filter_on_cpu_test_double(workdir):
+    _check_level_search_grid(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+@pytest.mark.gpu
+def test_level_search_grid_serves_the_filter_on_gpu(workdir):
+    _check_level_search_grid(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
 @pytest.mark.gpu
 def test_1080p_preset_4_on_gpu(workdir):
     """1920 x 1080 at a slow preset: 128 x 128 superblocks, the last superblock row 56 rows high -- the loop-filter hooks on the geometry the slow presets
