@@ -21,7 +21,11 @@ void   svt_av1_loop_restoration_save_boundary_lines(const Yv12BufferConfig *fram
 
 static int log2i(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 static size_t plane_bytes(const SvtHipLfPicture *p, int pl) { return (size_t)p->stride[pl] * (size_t)((p->h >> (pl > 0)) + 2 * LF_BORDER) * (size_t)p->pix_bytes; }
-static void *plane_origin(const SvtHipLfPicture *p, void *base, int pl) { return (uint8_t *)base + ((size_t)LF_BORDER * p->stride[pl] + LF_BORDER) * (size_t)p->pix_bytes; }
+/* Columns left of a device plane's sample (0, 0): the restoration border, rounded up so that (0, 0) sits on a 64-sample boundary.  The runtime's 2-D copy picks its element
+ * width from the alignment of both pointers, both pitches and the row length; with the origin 3 bytes into a row it moved a 3840 x 2160 plane one byte per thread — 1.5 ms
+ * up (5 GB/s, rocprofv3: copyBufferRect grid 3840 x 2160) against 0.2 ms for the same plane between aligned addresses (tools/copy_probe2.py). */
+#define LF_XOFF 64
+static void *plane_origin(const SvtHipLfPicture *p, void *base, int pl) { return (uint8_t *)base + ((size_t)LF_BORDER * p->stride[pl] + LF_XOFF) * (size_t)p->pix_bytes; }
 
 static int is_16bit_of(const PictureControlSet *pcs) {
     const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
@@ -44,7 +48,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
     const int nfb = ((w + 63) / 64) * ((h + 63) / 64), mi_cols = (w + 3) / 4, mi_rows = (h + 3) / 4;
     for (int pl = 0; pl < 3; pl++) {
         const int pw = w >> (pl > 0), ph = h >> (pl > 0);
-        p->stride[pl] = (pw + 2 * LF_BORDER + 63) & ~63; p->src_stride[pl] = (pw + 63) & ~63;
+        p->stride[pl] = (pw + LF_XOFF + LF_BORDER + 63) & ~63; p->src_stride[pl] = (pw + 63) & ~63;
         HIP_TRY(svt_hip_malloc(hip, &p->d_recon[pl], plane_bytes(p, pl))); HIP_TRY(svt_hip_malloc(hip, &p->d_cdef[pl], plane_bytes(p, pl)));
         HIP_TRY(svt_hip_malloc(hip, &p->d_rest[pl], plane_bytes(p, pl))); HIP_TRY(svt_hip_malloc(hip, &p->d_dbl[pl], plane_bytes(p, pl)));
         HIP_TRY(svt_hip_malloc(hip, &p->d_src[pl], (size_t)p->src_stride[pl] * ph * p->pix_bytes));
