@@ -153,7 +153,7 @@ int svt_hip_me_record(MeContext *me_ctx, uint32_t sb_origin_x, uint32_t sb_origi
 }
 
 static int dev_need(SvtHipCtx *hip, void **d, size_t *cap, size_t bytes);
-/* svt_hip_me_fullpel_frame on planes that are on the device already: [windows | SADs | MVs] in one staging block of the batch, one upload, two downloads.  The
+/* svt_hip_me_fullpel_frame on planes that are on the device already: [windows | SADs | MVs] in one staging block of the batch, one upload, one download.  The
  * checks and the choice of the strip-walking instance are the host entry's (svt_hip_api.cpp: negative areas are refused, > 65 536 candidates select the instance). */
 static int integer_search_resident(SvtHipCtx *hip, SvtHipMeBatch *b, const uint8_t *d_src, const uint8_t *d_ref, const EbPictureBufferDesc *p,
                                    const SvtHipSbSearch *wins, uint32_t n, uint32_t *sad, uint32_t *mv) {
@@ -176,6 +176,8 @@ static int integer_search_resident(SvtHipCtx *hip, SvtHipMeBatch *b, const uint8
                                           (uint32_t *)(d + off_sad), (uint32_t *)(d + off_mv));
         (void)svt_hip_me_set_big_windows(hip, big_before);   /* whatever the context was configured with */
     }
+    /* the caller's two result arrays are one block laid out like the device's (flush_integer): one download */
+    if (rc == SVT_HIP_OK && (uint8_t *)mv == (uint8_t *)sad + (off_mv - off_sad)) return svt_hip_memcpy_d2h(hip, sad, d + off_sad, off_mv - off_sad + nres);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, sad, d + off_sad, nres);
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, mv, d + off_mv, nres);
     return rc;
@@ -184,9 +186,8 @@ static int integer_search_resident(SvtHipCtx *hip, SvtHipMeBatch *b, const uint8
 static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padded) {
     SvtHipSbSearch *wins = (SvtHipSbSearch *)malloc(sizeof(SvtHipSbSearch) * b->cap);
     uint32_t       *idx = (uint32_t *)malloc(sizeof(uint32_t) * b->cap);
-    uint32_t       *sad = (uint32_t *)malloc(sizeof(uint32_t) * SQUARE_PU_COUNT * b->cap);
-    uint32_t       *mv = (uint32_t *)malloc(sizeof(uint32_t) * SQUARE_PU_COUNT * b->cap);
-    if (!wins || !idx || !sad || !mv) b->failed = 1;
+    uint32_t       *sad = (uint32_t *)malloc(2 * (sizeof(uint32_t) * SQUARE_PU_COUNT * b->cap + 256));   /* [SADs | pad to 256 | MVs] of a launch, see integer_search_resident */
+    if (!wins || !idx || !sad) b->failed = 1;
     for (uint32_t l = 0; l < MAX_NUM_OF_REF_PIC_LIST && !b->failed; l++)
         for (uint32_t r = 0; r < MAX_REF_IDX && !b->failed; r++) {
             const size_t s = SLOT(b, l, r);
@@ -205,6 +206,7 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                     b->failed = 1;
                     break;
                 }
+                uint32_t  *mv = (uint32_t *)((uint8_t *)sad + (((size_t)n * SQUARE_PU_COUNT * sizeof(uint32_t) + 255) & ~(size_t)255));
                 SvtHipCtx *hip = svt_hip_hooks_lock_any();
                 /* both planes resident (SVT_HIP_RESIDENT, svt_hip_hooks.c): only the windows travel; else the row band the windows touch is uploaded per call */
                 const size_t   plane_bytes = (size_t)src_padded->stride_y * (size_t)(src_padded->height + 2 * src_padded->origin_y);
@@ -229,7 +231,7 @@ static void flush_integer(SvtHipMeBatch *b, const EbPictureBufferDesc *src_padde
                 svt_hip_hooks_log("me: list %u ref %u, %u windows of one reference picture in one launch", l, r, n);
             }
         }
-    free(wins); free(idx); free(sad); free(mv);
+    free(wins); free(idx); free(sad);
     svt_hip_hooks_count(b->hook_me, !b->failed);
 }
 
@@ -308,66 +310,93 @@ static void hme_finish(HmeJob *j, uint32_t sad, int found, int16_t fx, int16_t f
 }
 
 #define HME_TRY(x) do { if (rc == SVT_HIP_OK) rc = (x); } while (0)
+typedef struct {
+    const EbPictureBufferDesc *ref;
+    uint32_t                   first, n;   /* its searches: jobs[first .. first + n) */
+    int                        y_lo, y_hi; /* reference rows its windows touch */
+    const uint8_t             *d_res;      /* the resident plane, or NULL: the rows travel per launch */
+} HmeGroup;
+/* One level of a segment: the searches grouped by reference picture (one launch each), ONE upload [searches | initial SADs] and ONE download [SADs | centres]
+ * for all of them (it was a pair per reference picture: 3 - 4 round trips per level where a picture has 3 - 4 references). */
 static void flush_hme_level(SvtHipMeBatch *b, int level) {
     const uint32_t first = b->level_first[level], end = b->level_first[level + 1];
     if (first == end || b->failed) return;
     const uint32_t n_all = end - first;
     SvtHipSadLoop *jobs = (SvtHipSadLoop *)malloc((sizeof(SvtHipSadLoop) + sizeof(uint32_t)) * n_all);
     uint8_t       *back = (uint8_t *)malloc((sizeof(uint32_t) + 2 * sizeof(int16_t)) * n_all);
-    uint32_t      *sel = (uint32_t *)malloc(sizeof(uint32_t) * n_all), *sad = (uint32_t *)malloc(sizeof(uint32_t) * n_all);
-    int16_t       *xy = (int16_t *)malloc(sizeof(int16_t) * 2 * n_all);
+    uint32_t      *sel = (uint32_t *)malloc(sizeof(uint32_t) * n_all);
     uint8_t       *done = (uint8_t *)calloc(n_all, 1);
-    SvtHipCtx     *hip = (jobs && back && sel && sad && xy && done) ? svt_hip_hooks_lock_any() : NULL;
+    HmeGroup      *grp = (HmeGroup *)calloc(n_all, sizeof(HmeGroup));
+    SvtHipCtx     *hip = (jobs && back && sel && done && grp) ? svt_hip_hooks_lock_any() : NULL;
     int            rc = hip ? SVT_HIP_OK : SVT_HIP_ERR_NO_DEVICE;
-    HME_TRY(dev_need(hip, &b->d_src, &b->d_cap[0], (size_t)b->n0 * 64 * 64 + 64));
-    HME_TRY(svt_hip_memcpy_h2d(hip, b->d_src, b->src[level], (size_t)b->n0 * 64 * 64));
+    uint32_t       n_grp = 0, n_tot = 0;
     for (uint32_t g = 0; g < n_all && rc == SVT_HIP_OK; g++) {
         if (done[g]) continue;
-        const EbPictureBufferDesc *ref = b->job[first + g].ref; /* one launch per reference picture */
-        const int                  rows_total = ref->height + 2 * ref->origin_y;
-        uint32_t                   n = 0;
-        int                        y_lo = INT_MAX, y_hi = -1;
+        HmeGroup *q = &grp[n_grp];
+        q->ref = b->job[first + g].ref; /* one launch per reference picture */
+        q->first = n_tot; q->n = 0; q->y_lo = INT_MAX; q->y_hi = -1; q->d_res = NULL;
         for (uint32_t k = g; k < n_all; k++) {
             HmeJob *j = &b->job[first + k];
-            if (j->ref != ref) continue;
+            if (j->ref != q->ref) continue;
             done[k] = 1;
             if (j->job.sa_w < 1 || j->job.sa_h < 1) continue;   /* an empty search area: no candidate, resolved below */
-            sel[n] = k;
-            jobs[n++] = j->job;
-            if (j->job.ref_y < y_lo) y_lo = j->job.ref_y;
+            sel[n_tot] = k;
+            jobs[n_tot++] = j->job;
+            q->n++;
+            if (j->job.ref_y < q->y_lo) q->y_lo = j->job.ref_y;
             const int last = j->job.ref_y + j->job.sa_h - 1 + j->job.bh - 1;
-            if (last > y_hi) y_hi = last;
+            if (last > q->y_hi) q->y_hi = last;
         }
-        if (!n) continue;
-        if (y_hi >= rows_total) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
+        if (!q->n) continue;
+        if (q->y_hi >= q->ref->height + 2 * q->ref->origin_y) { rc = SVT_HIP_ERR_UNSUPPORTED; break; }
+        n_grp++;
+    }
+    if (rc == SVT_HIP_OK && n_tot) {
+        HME_TRY(dev_need(hip, &b->d_src, &b->d_cap[0], (size_t)b->n0 * 64 * 64 + 64));
+        HME_TRY(svt_hip_memcpy_h2d(hip, b->d_src, b->src[level], (size_t)b->n0 * 64 * 64));
         /* the (decimated) reference plane resident (SVT_HIP_RESIDENT): the searches address it as recorded; else only the rows the segment's windows touch travel
          * (a segment is a band of SB rows) and the searches are re-based to the band */
-        const uint8_t *d_res = rc == SVT_HIP_OK ? (const uint8_t *)svt_hip_resident_acquire(hip, ref->buffer_y, (size_t)rows_total * ref->stride_y) : NULL;
-        for (uint32_t k = 0; k < n; k++) { if (!d_res) jobs[k].ref_y -= y_lo; sad[k] = 0xffffffu; }
-        const size_t ref_bytes = (size_t)(y_hi - y_lo + 1) * ref->stride_y;
-        if (!d_res) HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)ref->stride_y + 64));
-        /* one upload [searches | initial SADs] and one download [SADs | centres] per launch */
-        const size_t job_bytes = sizeof(SvtHipSadLoop) * n, sad_bytes = sizeof(uint32_t) * n, xy_bytes = sizeof(int16_t) * 2 * n;
-        memcpy((uint8_t *)jobs + job_bytes, sad, sad_bytes);   /* jobs has room for n_all >= n entries of 28 bytes plus their SADs: see the allocation */
+        uint32_t n_acq = 0;
+        for (; n_acq < n_grp && rc == SVT_HIP_OK; n_acq++) {
+            HmeGroup *q = &grp[n_acq];
+            q->d_res = (const uint8_t *)svt_hip_resident_acquire(hip, q->ref->buffer_y, (size_t)(q->ref->height + 2 * q->ref->origin_y) * q->ref->stride_y);
+            if (!q->d_res)
+                for (uint32_t k = 0; k < q->n; k++) jobs[q->first + k].ref_y -= q->y_lo;
+        }
+        const size_t job_bytes = sizeof(SvtHipSadLoop) * n_tot, sad_bytes = sizeof(uint32_t) * n_tot, xy_bytes = sizeof(int16_t) * 2 * n_tot;
+        uint32_t    *sad0 = (uint32_t *)((uint8_t *)jobs + job_bytes);   /* jobs has room for n_all >= n_tot entries of 28 bytes plus their SADs: see the allocation */
+        for (uint32_t k = 0; k < n_tot; k++) sad0[k] = 0xffffffu;
         HME_TRY(dev_need(hip, &b->d_job, &b->d_cap[2], job_bytes + sad_bytes + xy_bytes));
         uint8_t *d_sad = (uint8_t *)b->d_job + job_bytes, *d_xy = d_sad + sad_bytes;
-        if (!d_res) HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, ref->buffer_y + (size_t)y_lo * ref->stride_y, ref_bytes));
         HME_TRY(svt_hip_memcpy_h2d(hip, b->d_job, jobs, job_bytes + sad_bytes));
-        HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, d_res ? d_res : (const uint8_t *)b->d_ref, ref->stride_y, (const SvtHipSadLoop *)b->d_job,
-                                           (int)n, (uint32_t *)d_sad, (int16_t *)d_xy));
+        int band_in_use = 0;
+        for (uint32_t g = 0; g < n_grp && rc == SVT_HIP_OK; g++) {
+            const HmeGroup *q = &grp[g];
+            if (!q->d_res) {
+                const size_t ref_bytes = (size_t)(q->y_hi - q->y_lo + 1) * q->ref->stride_y;
+                if (band_in_use) HME_TRY(svt_hip_sync(hip));   /* the previous launch reads the band buffer */
+                HME_TRY(dev_need(hip, &b->d_ref, &b->d_cap[1], ref_bytes + 2 * (size_t)q->ref->stride_y + 64));
+                HME_TRY(svt_hip_memcpy_h2d(hip, b->d_ref, q->ref->buffer_y + (size_t)q->y_lo * q->ref->stride_y, ref_bytes));
+                band_in_use = 1;
+            }
+            HME_TRY(svt_hip_sad_loop_batch_dev(hip, (const uint8_t *)b->d_src, 64, q->d_res ? q->d_res : (const uint8_t *)b->d_ref, q->ref->stride_y,
+                                               (const SvtHipSadLoop *)b->d_job + q->first, (int)q->n, (uint32_t *)d_sad + q->first, (int16_t *)d_xy + 2 * (size_t)q->first));
+        }
         HME_TRY(svt_hip_memcpy_d2h(hip, back, d_sad, sad_bytes + xy_bytes));
-        if (d_res) {   /* downloaded: the launch is over; after a failure the context is drained first, a launch may still be reading the plane */
-            if (rc != SVT_HIP_OK) (void)svt_hip_sync(hip);
-            svt_hip_resident_release(ref->buffer_y);
+        /* downloaded: the launches are over; after a failure the context is drained first, a launch may still be reading a plane */
+        if (rc != SVT_HIP_OK && n_acq) (void)svt_hip_sync(hip);
+        for (uint32_t g = 0; g < n_acq; g++)
+            if (grp[g].d_res) svt_hip_resident_release(grp[g].ref->buffer_y);
+        if (rc == SVT_HIP_OK) {
+            const uint32_t *sad = (const uint32_t *)back;
+            const int16_t  *xy = (const int16_t *)(back + sad_bytes);
+            for (uint32_t k = 0; k < n_tot; k++) hme_finish(&b->job[first + sel[k]], sad[k], sad[k] != 0xffffffu, xy[2 * k], xy[2 * k + 1]);
+            for (uint32_t g = 0; g < n_grp; g++) {
+                b->hme_launches++;
+                svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows %s)", level, grp[g].n, grp[g].y_hi - grp[g].y_lo + 1,
+                                  grp[g].d_res ? "read from the resident plane" : "uploaded");
+            }
         }
-        if (rc == SVT_HIP_OK) { memcpy(sad, back, sad_bytes); memcpy(xy, back + sad_bytes, xy_bytes); }
-        if (rc != SVT_HIP_OK) break;
-        for (uint32_t k = 0; k < n; k++) {
-            hme_finish(&b->job[first + sel[k]], sad[k], sad[k] != 0xffffffu, xy[2 * k], xy[2 * k + 1]);
-        }
-        b->hme_launches++;
-        svt_hip_hooks_log("hme: level %d, %u searches of one reference picture in one launch (%d reference rows %s)", level, n, y_hi - y_lo + 1,
-                          d_res ? "read from the resident plane" : "uploaded");
     }
     /* A level whose search area the configuration switched down to 0 x 0: svt_sad_loop_kernel leaves the centres as they are, so the level's
      * arithmetic runs on what the previous search through the same pointers left there -- the previous block of this segment, in the reference's
@@ -384,7 +413,7 @@ static void flush_hme_level(SvtHipMeBatch *b, int level) {
         b->failed = 1;
     }
     if (hip) svt_hip_hooks_unlock_any();
-    free(jobs); free(back); free(sel); free(sad); free(xy); free(done);
+    free(jobs); free(back); free(sel); free(done); free(grp);
 }
 
 /* the level results of SB slot i into the (shared) context, as the reference's calls would have left them */
