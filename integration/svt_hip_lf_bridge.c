@@ -66,6 +66,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
     p->h_skip8 = (uint8_t *)malloc((size_t)(w / 8) * (h / 8)); p->h_mi = (SvtHipDlfModeInfo *)calloc((size_t)mi_cols * mi_rows, sizeof(SvtHipDlfModeInfo));
     p->h_mse = (uint64_t *)malloc(sizeof(uint64_t) * 2 * nfb * 64);
     if (!p->h_skip8 || !p->h_mi || !p->h_mse) return EB_ErrorInsufficientResources;
+    if (!(p->h_mi_until = (uint16_t *)malloc(sizeof(uint16_t) * mi_cols))) return EB_ErrorInsufficientResources;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows));
     p->h_mi_pinned = svt_hip_hooks_pin_enabled() && svt_hip_host_register(hip, p->h_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows) == SVT_HIP_OK;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_skip8, (size_t)(w / 8) * (h / 8)));
@@ -84,7 +85,7 @@ void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
         free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
     }
     if (p->h_mi_pinned) svt_hip_host_unregister(hip, p->h_mi);
-    free(p->h_skip8); free(p->h_mi); free(p->h_mse); svt_hip_free(hip, p->d_mi);
+    free(p->h_skip8); free(p->h_mi); free(p->h_mi_until); free(p->h_mse); svt_hip_free(hip, p->d_mi);
     svt_hip_free(hip, p->d_skip8); svt_hip_free(hip, p->d_mse); svt_hip_free(hip, p->d_dir); svt_hip_free(hip, p->d_var);
     svt_hip_free(hip, p->d_y_strength); svt_hip_free(hip, p->d_uv_strength); svt_hip_free(hip, p->d_sse);
     memset(p, 0, sizeof(*p));
@@ -373,14 +374,24 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
     FrameHeader *frm_hdr = &ppcs->frm_hdr;
     const LoopFilterInfoN *lfi_n = &ppcs->lf_info;
     const int mi_cols = (p->w + 3) / 4, mi_rows = (p->h + 3) / 4;
-    /* a coded block is a rectangle of 4 x 4 units with one mode info: scanning a row left to right, a block is first met at its left edge, its record is derived once and
-     * copied over the block's width (a 3840 x 2160 picture has 518 400 units; deriving every one of them cost 7 - 10 ms per call on one host thread) */
+    /* a coded block is a rectangle of 4 x 4 units with one mode info, aligned to its own width and height: scanning in raster order a block is first met at its top-left
+     * unit; its record is derived there, once, and copied over the block's rectangle; until[c] = the first row below the block covering column c, so the block's other rows
+     * are stepped over by the width their record carries, without touching the mode-info grid again (a 3840 x 2160 picture has 518 400 units; deriving every one of them
+     * cost 7 - 10 ms per call on one host thread, once per unit row of every block 2.5 ms) */
+    uint16_t *until = p->h_mi_until;
+    memset(until, 0, sizeof(uint16_t) * mi_cols);
     for (int r = 0; r < mi_rows; r++)
         for (int c = 0; c < mi_cols;) {
-            const MbModeInfo *mbmi = &pcs->mi_grid_base[r * pcs->mi_stride + c]->mbmi;
             SvtHipDlfModeInfo *o = &p->h_mi[r * mi_cols + c];
-            const int run = block_size_wide[mbmi->block_mi.sb_type] >> 2, c_next = ((c / run) + 1) * run;   /* blocks are aligned to their own width */
+            if (until[c] > r) {   /* covered by a block that began in a row above: its record is here already */
+                const int run = (1 << o->bw_log2) >> 2;
+                c = ((c / run) + 1) * run;
+                continue;
+            }
+            const MbModeInfo *mbmi = &pcs->mi_grid_base[r * pcs->mi_stride + c]->mbmi;
             const BlockSize bs = mbmi->block_mi.sb_type;
+            const int run = block_size_wide[bs] >> 2, c_next = AOMMIN(((c / run) + 1) * run, mi_cols);
+            const int rows = block_size_high[bs] >> 2, r_next = AOMMIN(((r / rows) + 1) * rows, mi_rows);
             const int inter = is_inter_block_no_intrabc(mbmi->block_mi.ref_frame[0]);
             TxSize ts = inter ? tx_depth_to_tx_size[0][bs] : tx_depth_to_tx_size[mbmi->tx_depth][bs];
             if (inter && !mbmi->block_mi.skip) ts = tx_depth_to_tx_size[mbmi->tx_depth][bs];
@@ -396,7 +407,9 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
                         : frm_hdr->delta_lf_params.delta_lf_present
                         ? get_filter_level_delta_lf(frm_hdr, dir, pl, ppcs->curr_delta_lf, 0, mode, mbmi->block_mi.ref_frame[0])
                         : lfi_n->lvl[pl][0][dir][mbmi->block_mi.ref_frame[0]][mode_lf_lut[mode]];
-            for (int k = c + 1; k < c_next && k < mi_cols; k++) p->h_mi[r * mi_cols + k] = *o;
+            for (int k = c + 1; k < c_next; k++) p->h_mi[r * mi_cols + k] = *o;
+            for (int rr = r + 1; rr < r_next; rr++) memcpy(&p->h_mi[rr * mi_cols + c], o, sizeof(*o) * (size_t)(c_next - c));
+            for (int k = c; k < c_next; k++) until[k] = (uint16_t)r_next;
             c = c_next;
         }
 }

@@ -11,6 +11,7 @@
  * directory on LD_LIBRARY_PATH.  On the GPU box the same encoder binary loads the real svt-av1_amd/libsvtav1_hip.so.
  * Only the entry points the glue calls are provided.
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -387,8 +388,9 @@ int svt_hip_lr_apply_plane_dev(SvtHipCtx *c, int pix_bytes, int bd, const void *
     /* the oracle swaps the stripe context rows into the CDEF plane and back (like the reference): work on a copy of the extended plane */
     const size_t rows = (size_t)ph + 6, bytes = rows * stride * pix_bytes;
     uint8_t     *copy = (uint8_t *)malloc(bytes);
-    const uint8_t *base = (const uint8_t *)dgd - ((size_t)3 * stride + 3) * pix_bytes;
-    memcpy(copy, base, bytes);   /* the glue's planes are allocated as stride x (ph + 6) with sample (0,0) at (3,3) */
+    if (stride < pw + 6) { free(copy); snprintf(c->err, sizeof(c->err), "mock: lr_apply needs stride >= width + 6"); return SVT_HIP_ERR_UNSUPPORTED; }
+    for (int y = -3; y < ph + 3; y++)   /* the plane with its 3-sample border (what the interface promises to be readable), sample (0,0) at (3,3) of the copy */
+        memcpy(copy + (size_t)(y + 3) * stride * pix_bytes, (const uint8_t *)dgd + ((ptrdiff_t)y * stride - 3) * pix_bytes, (size_t)(pw + 6) * pix_bytes);
     orc_lr_apply_plane(dbl, dbl_stride, copy + ((size_t)3 * stride + 3) * pix_bytes, stride, pix_bytes, pw, ph, ss_y, ss_y, unit_size, bd, unit_ep, unit_xqd,
                        unit_wiener, dst, dst_stride);
     free(copy);

@@ -22,11 +22,19 @@ run() {   # name, extra env
   echo "$1 wall_s=$(python -c "print(round($e - $s, 3))") $(grep -h 'Average Speed' $OUT/$1.log | tr -s '\t\n' '  ') | $(grep -h 'svt_hip_hook_time dlf' $OUT/$1.log | tr '\n' ' ')" | tee -a $OUT/ab.txt
 }
 run warm ""
-for i in 1 2 3; do run device_$i ""; run host_$i "SVT_HIP_DLF_EDGES=host"; done
+for i in 1 2; do run device_$i ""; run host_$i "SVT_HIP_DLF_EDGES=host"; done
 run device_verbose "SVT_HIP_VERBOSE=1"; run host_verbose "SVT_HIP_VERBOSE=1 SVT_HIP_DLF_EDGES=host"
 for v in device host; do
-  echo "$v: $(grep -h 'dlf_search: picture up' $OUT/${v}_verbose.log | awk '{u+=$5; m+=$11; e+=$14; p+=$17; n++} END {printf "level search per picture: up %.2f, mode info %.2f, edges %.2f, probes %.2f ms (n=%d)", u/n, m/n, e/n, p/n, n}')" | tee -a $OUT/ab.txt
-  echo "$v: $(grep -h 'dlf: levels' $OUT/${v}_verbose.log | sed 's/.*edges \([0-9.]*\) ms.*/\1/' | awk '{e+=$1; n++} END {if (n) printf "filter, edges per picture: %.2f ms (n=%d)", e/n, n; else print "no picture was filtered"}')" | tee -a $OUT/ab.txt
+  python - $OUT/${v}_verbose.log $v <<'PY' | tee -a $OUT/ab.txt
+import re, sys
+t = open(sys.argv[1], errors="replace").read()
+rows = [tuple(map(float, m)) for m in re.findall(r"dlf_search: picture up ([0-9.]+) ms, mode info \(host\) ([0-9.]+) ms, edges ([0-9.]+) ms, probes ([0-9.]+) ms", t)]
+if rows:
+    n = len(rows); avg = [sum(r[i] for r in rows) / n for i in range(4)]
+    print(f"{sys.argv[2]}: level search per picture (n={n}): picture up {avg[0]:.2f}, mode info {avg[1]:.2f}, edges {avg[2]:.2f}, probes {avg[3]:.2f} ms")
+f = [float(x) for x in re.findall(r"dlf: levels [^\n]*edges ([0-9.]+) ms", t)]
+print(f"{sys.argv[2]}: filter, edges per picture: {sum(f) / len(f):.2f} ms (n={len(f)})" if f else f"{sys.argv[2]}: no picture was filtered")
+PY
 done
 for f in device_1 host_1 device_verbose host_verbose; do cmp -s $OUT/warm.ivf $OUT/$f.ivf && echo "$f bitstream identical to the first run" || echo "$f BITSTREAM DIFFERS"; done | tee -a $OUT/ab.txt
 (cd $R/gpurun_out/dlf_edges && rm -f clip.yuv warm.ivf device_?.ivf host_?.ivf device_verbose.ivf host_verbose.ivf)
