@@ -534,12 +534,20 @@ int svt_hip_wiener_walk_units_picture_dev(SvtHipCtx *ctx, int pix_bytes, int bd,
 /* svt_av1_compute_stats (aom_dsp_rtcd.h:99; Encoder/Codec/EbRestorationPick.c:704) for every restoration unit of a plane, as
  * search_wiener_seg (:1347) calls it: d_M[unit][win * win], d_H[unit][win^2 * win^2] (exact int64; feature index = (dx + win/2) * win
  * + (dy + win/2)).  win = 7 (luma), 5 (chroma) or 3.  The plane must be extended by 3 samples like for the self-guided calls.  The linear
- * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090) stay on the host.  8-bit planes, and
+ * solve / tap quantisation (wiener_decompose_sep_sym, finalize_sym_filter, compute_score: :800-1090): svt_hip_wiener_init_units_dev below, or the host.  8-bit planes, and
  * 16-bit planes (bd 8 / 10 / 12) = svt_av1_compute_stats_highbd (:741) incl. its bit_depth_divider; the 16-bit path keeps a library-owned
  * device scratch buffer inside the context (allocated on first use — growing it waits for the whole device —, freed by svt_hip_destroy): calls
  * of the 16-bit path through ONE context must not overlap on different streams (use one context per stream for that). */
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int win, const void *d_dgd, int stride, const void *d_src,
                                    int src_stride, int pw, int ph, int unit_size, int ss_y, int64_t *d_M, int64_t *d_H);
+
+/* search_wiener_seg between the statistics and the tap refinement (EbRestorationPick.c:1388-1407), for every unit of a plane in one launch: wiener_decompose_sep_sym
+ * (:946; its linear systems :800-944), finalize_sym_filter (:1022) and compute_score (:980) on d_M / d_H as svt_hip_wiener_stats_plane_dev left them — the statistics
+ * never leave the device.  Per unit u: d_status[u] = 1 (the initial filter beats the identity filter by the model: refine it) or 2 (it does not: no Wiener filter for
+ * the unit), d_active[u] = (status == 1), d_unit_wiener[16 u ..] = vfilter[8], hfilter[8] (InterpKernel layout) — the inputs of svt_hip_wiener_walk_units*_dev.
+ * All 64-bit integer arithmetic: identical to the host code.  win = 7 / 5 / 3. */
+int svt_hip_wiener_init_units_dev(SvtHipCtx *ctx, int win, int n_units, const int64_t *d_M, const int64_t *d_H, int16_t *d_unit_wiener, uint8_t *d_active,
+                                  int8_t *d_status);
 
 /* ------------------------------------------------------------------ alt-ref temporal filtering ---- */
 #define SVT_HIP_TF_MAX_REFS 16

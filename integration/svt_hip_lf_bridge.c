@@ -926,25 +926,34 @@ EbErrorType svt_hip_hook_sgr_search(PictureControlSet *pcs) {
 
 /* svt_av1_compute_stats[_highbd] of search_wiener_seg (EbRestorationPick.c:1347): the first call of a picture runs one statistics pass per
  * plane over all units; every call copies its unit's M / H. */
+/* svt_av1_compute_stats of every unit of one plane into fresh device blocks: *dM [unit][win^2], *dH [unit][win^4]; the caller frees them once the context is drained */
+static EbErrorType wiener_stats_plane(SvtHipCtx *hip, LfState *s, int pl, void **dM, void **dH) {
+    SvtHipLfPicture *p = &s->pic;
+    const Av1Common *cm = s->pcs->parent_pcs_ptr->av1_cm;
+    const RestorationInfo *rsi = &cm->rst_info[pl];
+    const int wn_luma = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : cm->wn_filter_mode == 2 ? WIENER_WIN_CHROMA : WIENER_WIN;
+    const int win = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : (pl == 0 ? wn_luma : WIENER_WIN_CHROMA);   /* search_wiener_seg :1352-1358 */
+    const int n = rsi->units_per_tile, w2 = win * win;
+    p->wiener_win[pl] = win;
+    *dM = *dH = NULL;
+    if (svt_hip_hooks_malloc(hip, dM, sizeof(int64_t) * n * w2) != SVT_HIP_OK || svt_hip_hooks_malloc(hip, dH, sizeof(int64_t) * n * w2 * w2) != SVT_HIP_OK) return EB_ErrorInsufficientResources;
+    HIP_TRY(svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->src[pl], p->src_st[pl],
+                                           p->cw >> (pl > 0), p->ch >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)*dM, (int64_t *)*dH));
+    return EB_ErrorNone;
+}
 static EbErrorType wiener_stats_all(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
     const Av1Common *cm = s->pcs->parent_pcs_ptr->av1_cm;
     if (!rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     for (int pl = 0; pl < 3; pl++) {
-        const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int wn_luma = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : cm->wn_filter_mode == 2 ? WIENER_WIN_CHROMA : WIENER_WIN;
-        const int win = cm->wn_filter_mode == 1 ? WIENER_WIN_3TAP : (pl == 0 ? wn_luma : WIENER_WIN_CHROMA);   /* search_wiener_seg :1352-1358 */
-        const int n = rsi->units_per_tile, w2 = win * win;
+        void *dM = NULL, *dH = NULL;
+        int ok = wiener_stats_plane(hip, s, pl, &dM, &dH) == EB_ErrorNone;
+        const int n = cm->rst_info[pl].units_per_tile, w2 = p->wiener_win[pl] * p->wiener_win[pl];
         free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
         p->h_wiener_M[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2); p->h_wiener_H[pl] = (int64_t *)malloc(sizeof(int64_t) * n * w2 * w2);
-        p->wiener_win[pl] = win;
-        void *dM = NULL, *dH = NULL;
-        int ok = p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_hooks_malloc(hip, &dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
-                 svt_hip_hooks_malloc(hip, &dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK &&
-                 svt_hip_wiener_stats_plane_dev(hip, p->pix_bytes, p->bd, win, plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], p->src[pl], p->src_st[pl],
-                                                p->cw >> (pl > 0), p->ch >> (pl > 0), rsi->restoration_unit_size, pl > 0, (int64_t *)dM, (int64_t *)dH) == SVT_HIP_OK &&
-                 svt_hip_memcpy_d2h(hip, p->h_wiener_M[pl], dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
-                 svt_hip_memcpy_d2h(hip, p->h_wiener_H[pl], dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK;
+        ok = ok && p->h_wiener_M[pl] && p->h_wiener_H[pl] && svt_hip_memcpy_d2h(hip, p->h_wiener_M[pl], dM, sizeof(int64_t) * n * w2) == SVT_HIP_OK &&
+             svt_hip_memcpy_d2h(hip, p->h_wiener_H[pl], dH, sizeof(int64_t) * n * w2 * w2) == SVT_HIP_OK;
+        if (!ok) (void)svt_hip_sync(hip);   /* a launch may still be writing the blocks */
         if (dM) svt_hip_hooks_free(hip, dM);
         if (dH) svt_hip_hooks_free(hip, dH);
         if (!ok) return EB_ErrorUndefined;
@@ -1016,49 +1025,68 @@ EbErrorType svt_hip_hook_wiener_try(PictureControlSet *pcs, int plane, int h_sta
  * file), then finer_tile_search_wiener_seg (:1092) of every unit ON THE DEVICE: svt_hip_wiener_walk_units_dev runs each unit's coordinate descent and
  * all of its probes (the unit filtered with the probed taps, squared error against the source) in one launch per plane — no host round trip per probe
  * (round 3: 20 - 40 lockstep rounds per picture, each an upload, a launch and a download per plane). */
+static int wiener_init_on_host(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SVT_HIP_WIENER_INIT"); v = e && !strcmp(e, "host"); }
+    return v;
+}
 static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     SvtHipLfPicture *p = &s->pic;
     PictureControlSet *pcs = s->pcs;
     const Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
     if (!(s->flags & ST_DBL)) return EB_ErrorUndefined;
     const long long tw0 = svt_hip_hooks_now_ns();
-    if (!(s->flags & ST_WIENER_DONE)) {
+    /* the initial filters on the device (svt_hip_wiener_init_units_dev): the statistics never leave it — statistics, initial filters and walks are queued back to back and
+     * the host waits once, for the results.  With the statistics on the host already (the per-unit hook ran for this picture) or SVT_HIP_WIENER_INIT=host: the reference's
+     * own decomposition on downloaded statistics (svt_hip_wiener_unit_init in the patched file; 2.9 ms per 3840 x 2160 picture on one thread, plus the 4 MB download). */
+    const int dev_init = !(s->flags & ST_WIENER_DONE) && !wiener_init_on_host();
+    if (!dev_init && !(s->flags & ST_WIENER_DONE)) {
         if ((s->flags & ST_WIENER_FAILED) || wiener_stats_all(hip, s) != EB_ErrorNone) { s->flags |= ST_WIENER_FAILED; return EB_ErrorUndefined; }
         s->flags |= ST_WIENER_DONE;
     }
+    if (dev_init && (!rest_geometry_ok(p, cm) || ensure_src(hip, s) != EB_ErrorNone || ensure_cdef_padded(hip, s) != EB_ErrorNone)) return EB_ErrorUndefined;
     const long long tw1 = svt_hip_hooks_now_ns();
     long long t_init = 0, t_walk = 0;
     EbErrorType ret = EB_ErrorNone;
     uint8_t *act[3] = {0}; int16_t *wn[3] = {0}; int64_t *err[3] = {0}; uint32_t *probes[3] = {0}; int8_t *init[3] = {0};
-    void *d_act[3] = {0}, *d_err[3] = {0}, *d_probes[3] = {0};
+    void *d_act[3] = {0}, *d_err[3] = {0}, *d_probes[3] = {0}, *d_init[3] = {0}, *dM[3] = {0}, *dH[3] = {0};
     long n_probes = 0, n_walks = 0;
     SvtHipWienerWalkPlane walk[3];
     int walk_pl[3], n_walk_planes = 0;
     for (int pl = 0; pl < 3 && ret == EB_ErrorNone; pl++) {
         const RestorationInfo *rsi = &cm->rst_info[pl];
-        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile, win = p->wiener_win[pl], w2 = win * win;
+        const int pw = p->cw >> (pl > 0), ph = p->ch >> (pl > 0), n = rsi->units_per_tile;
         act[pl] = (uint8_t *)calloc(n, 1); wn[pl] = (int16_t *)calloc((size_t)n * 16, sizeof(int16_t)); err[pl] = (int64_t *)calloc(n, sizeof(int64_t));
         probes[pl] = (uint32_t *)calloc(n, sizeof(uint32_t)); init[pl] = (int8_t *)calloc(n, 1);
-        if (!act[pl] || !wn[pl] || !err[pl] || !probes[pl] || !init[pl] || svt_hip_hooks_malloc(hip, &d_act[pl], n) != SVT_HIP_OK ||
+        if (!act[pl] || !wn[pl] || !err[pl] || !probes[pl] || !init[pl] || svt_hip_hooks_malloc(hip, &d_act[pl], n) != SVT_HIP_OK || svt_hip_hooks_malloc(hip, &d_init[pl], n) != SVT_HIP_OK ||
             svt_hip_hooks_malloc(hip, &d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK || svt_hip_hooks_malloc(hip, &d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorInsufficientResources; break; }
-        /* search_wiener_seg up to the refinement: decomposition, tap quantisation, score against the identity filter (the reference's own code) */
         int any = 0;
         const long long ti0 = svt_hip_hooks_now_ns();
-        for (int u = 0; u < n; u++) {
-            WienerInfo wi;
-            memset(&wi, 0, sizeof(wi));
-            const int r = svt_hip_wiener_unit_init(win, p->h_wiener_M[pl] + (size_t)u * w2, p->h_wiener_H[pl] + (size_t)u * w2 * w2, &wi);
-            init[pl][u] = (int8_t)r;
-            if (r == 1) {
-                act[pl][u] = 1; any = 1; n_walks++;
-                memcpy(wn[pl] + 16 * u, wi.vfilter, 8 * sizeof(int16_t)); memcpy(wn[pl] + 16 * u + 8, wi.hfilter, 8 * sizeof(int16_t));
+        if (dev_init) {
+            if (wiener_stats_plane(hip, s, pl, &dM[pl], &dH[pl]) != EB_ErrorNone ||
+                svt_hip_wiener_init_units_dev(hip, p->wiener_win[pl], n, (const int64_t *)dM[pl], (const int64_t *)dH[pl], p->d_unit_wiener[pl], (uint8_t *)d_act[pl], (int8_t *)d_init[pl]) != SVT_HIP_OK) {
+                ret = EB_ErrorUndefined; break;
             }
+            any = n > 0;   /* which units walk is known on the device only: units whose initial filter loses to the identity are skipped by the walk kernel (active = 0) */
+        } else {
+            /* search_wiener_seg up to the refinement: decomposition, tap quantisation, score against the identity filter (the reference's own code) */
+            const int win = p->wiener_win[pl], w2 = win * win;
+            for (int u = 0; u < n; u++) {
+                WienerInfo wi;
+                memset(&wi, 0, sizeof(wi));
+                const int r = svt_hip_wiener_unit_init(win, p->h_wiener_M[pl] + (size_t)u * w2, p->h_wiener_H[pl] + (size_t)u * w2 * w2, &wi);
+                init[pl][u] = (int8_t)r;
+                if (r == 1) {
+                    act[pl][u] = 1; any = 1;
+                    memcpy(wn[pl] + 16 * u, wi.vfilter, 8 * sizeof(int16_t)); memcpy(wn[pl] + 16 * u + 8, wi.hfilter, 8 * sizeof(int16_t));
+                }
+            }
+            if (any && (svt_hip_memcpy_h2d(hip, d_act[pl], act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK)) { ret = EB_ErrorUndefined; break; }
         }
         t_init += svt_hip_hooks_now_ns() - ti0;
         if (!any) continue;
-        if (svt_hip_memcpy_h2d(hip, d_act[pl], act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_h2d(hip, p->d_unit_wiener[pl], wn[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
         walk[n_walk_planes] = (SvtHipWienerWalkPlane){plane_origin(p, p->d_cdef[pl], pl), p->stride[pl], pw, ph, rsi->restoration_unit_size, pl > 0, plane_origin(p, p->d_recon[pl], pl), p->stride[pl],
-                                                      p->src[pl], p->src_st[pl], p->d_unit_wiener[pl], (const uint8_t *)d_act[pl], win, (int64_t *)d_err[pl], (uint32_t *)d_probes[pl]};
+                                                      p->src[pl], p->src_st[pl], p->d_unit_wiener[pl], (const uint8_t *)d_act[pl], p->wiener_win[pl], (int64_t *)d_err[pl], (uint32_t *)d_probes[pl]};
         walk_pl[n_walk_planes++] = pl;
     }
     /* the walks of all planes in ONE launch: a unit's walk is a serial chain of ~30 probes, so three launches in a row cost three times the longest walk */
@@ -1067,9 +1095,11 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
     for (int k = 0; k < n_walk_planes && ret == EB_ErrorNone; k++) {
         const int pl = walk_pl[k], n = cm->rst_info[pl].units_per_tile;
         if (svt_hip_memcpy_d2h(hip, wn[pl], p->d_unit_wiener[pl], sizeof(int16_t) * 16 * n) != SVT_HIP_OK || svt_hip_memcpy_d2h(hip, err[pl], d_err[pl], sizeof(int64_t) * n) != SVT_HIP_OK ||
-            svt_hip_memcpy_d2h(hip, probes[pl], d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK) { ret = EB_ErrorUndefined; break; }
-        for (int u = 0; u < n; u++) n_probes += act[pl][u] ? probes[pl][u] : 0;
+            svt_hip_memcpy_d2h(hip, probes[pl], d_probes[pl], sizeof(uint32_t) * n) != SVT_HIP_OK ||
+            (dev_init && (svt_hip_memcpy_d2h(hip, act[pl], d_act[pl], n) != SVT_HIP_OK || svt_hip_memcpy_d2h(hip, init[pl], d_init[pl], n) != SVT_HIP_OK))) { ret = EB_ErrorUndefined; break; }
+        for (int u = 0; u < n; u++) { n_probes += act[pl][u] ? probes[pl][u] : 0; n_walks += act[pl][u] != 0; }
     }
+    if (ret != EB_ErrorNone && dev_init) (void)svt_hip_sync(hip);   /* launches may still be using the blocks freed below */
     t_walk = svt_hip_hooks_now_ns() - tk0;
     if (ret == EB_ErrorNone) {   /* every plane has succeeded: only now do the reference's objects change */
         for (int pl = 0; pl < 3; pl++) {
@@ -1085,14 +1115,21 @@ static EbErrorType wiener_search(SvtHipCtx *hip, LfState *s) {
                 }
             }
         }
-        svt_hip_hooks_log("wiener_search: 1 launch, %ld walks, %ld probes on the device; statistics %.2f ms, initial filters (host) %.2f ms, walks %.2f ms", n_walks, n_probes,
-                          (tw1 - tw0) / 1e6, t_init / 1e6, t_walk / 1e6);
+        if (dev_init)
+            svt_hip_hooks_log("wiener_search: 1 launch, %ld walks, %ld probes on the device; statistics + initial filters (device) queued in %.2f ms, walks + results %.2f ms", n_walks, n_probes,
+                              t_init / 1e6, t_walk / 1e6);
+        else
+            svt_hip_hooks_log("wiener_search: 1 launch, %ld walks, %ld probes on the device; statistics %.2f ms, initial filters (host) %.2f ms, walks %.2f ms", n_walks, n_probes,
+                              (tw1 - tw0) / 1e6, t_init / 1e6, t_walk / 1e6);
     }
     for (int pl = 0; pl < 3; pl++) {
         free(act[pl]); free(wn[pl]); free(err[pl]); free(probes[pl]); free(init[pl]);
         if (d_act[pl]) svt_hip_hooks_free(hip, d_act[pl]);
         if (d_err[pl]) svt_hip_hooks_free(hip, d_err[pl]);
         if (d_probes[pl]) svt_hip_hooks_free(hip, d_probes[pl]);
+        if (d_init[pl]) svt_hip_hooks_free(hip, d_init[pl]);
+        if (dM[pl]) svt_hip_hooks_free(hip, dM[pl]);
+        if (dH[pl]) svt_hip_hooks_free(hip, dH[pl]);
     }
     return ret;
 }

@@ -503,6 +503,17 @@ int svt_hip_wiener_walk_units_dev(SvtHipCtx *c, int pix_bytes, int bd, const voi
     free(w); free(lim); free(xqd); free(rect); free(ep); free(wn); free(sse); free(dst);
     return rc;
 }
+int svt_hip_wiener_init_units_dev(SvtHipCtx *c, int win, int n_units, const int64_t *M, const int64_t *H, int16_t *unit_wiener, uint8_t *active, int8_t *status) {
+    (void)c;
+    const int w2 = win * win;
+    for (int u = 0; u < n_units; u++) {
+        status[u] = (int8_t)orc_wiener_unit_init(win, M + (size_t)u * w2, H + (size_t)u * w2 * w2, unit_wiener + 16 * (size_t)u, unit_wiener + 16 * (size_t)u + 8);
+        active[u] = status[u] == 1;
+    }
+    if (perturb("wiener_init") && n_units) unit_wiener[2] ^= 1;
+    return SVT_HIP_OK;
+}
+
 int svt_hip_wiener_walk_units_picture_dev(SvtHipCtx *c, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane *pl) {
     if (!pl || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
     for (int i = 0; i < n_planes; i++) {

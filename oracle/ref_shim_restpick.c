@@ -28,3 +28,16 @@ void ref_shim_sgr_search_unit(const uint8_t *dat8, int32_t width, int32_t height
     out[0] = r.ep; out[1] = r.xqd[0]; out[2] = r.xqd[1];
 }
 int32_t ref_shim_sgr_rstbuf_ints(void) { return 2 * RESTORATION_UNITPELS_MAX; }
+
+/* search_wiener_seg between the statistics and the refinement (:1388-1407), the reference's own functions: 1 = vfilter / hfilter hold the initial filter and it beats
+ * the identity filter, 2 = it does not, 0 = the decomposition failed.  M and H are modified in place by nothing here (the reference works on copies). */
+int32_t ref_shim_wiener_unit_init(int32_t wiener_win, int64_t *M, int64_t *H, int16_t *vfilter, int16_t *hfilter) {
+    int32_t    vfilterd[WIENER_WIN], hfilterd[WIENER_WIN];
+    WienerInfo wi;
+    memset(&wi, 0, sizeof(wi));
+    if (!wiener_decompose_sep_sym(wiener_win, M, H, vfilterd, hfilterd)) return 0;
+    finalize_sym_filter(wiener_win, vfilterd, wi.vfilter);
+    finalize_sym_filter(wiener_win, hfilterd, wi.hfilter);
+    memcpy(vfilter, wi.vfilter, 8 * sizeof(int16_t)); memcpy(hfilter, wi.hfilter, 8 * sizeof(int16_t));
+    return compute_score(wiener_win, M, H, wi.vfilter, wi.hfilter) > 0 ? 2 : 1;
+}

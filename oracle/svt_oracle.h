@@ -179,6 +179,8 @@ void orc_wiener_convolve_add_src(const void *src, int src_stride, void *dst, int
                                  const int16_t *filter_y, int w, int h, int bd);
 void orc_wiener_stats_plane(int win, const void *dgd, int dgd_stride, const void *src, int src_stride, int pix_bytes, int bd, int pw, int ph, int ss_y,
                             int unit_size, int64_t *M, int64_t *H);
+/* search_wiener_seg between the statistics and the refinement (EbRestorationPick.c:1388-1407): 1 = refine vfilter / hfilter, 2 = no Wiener filter for the unit */
+int orc_wiener_unit_init(int win, const int64_t *M, const int64_t *H, int16_t vfilter[8], int16_t hfilter[8]);
 int64_t orc_sgr_proj_error(const void *src, int src_stride, const void *dat, int dat_stride, int pix_bytes, int w, int h, const int32_t *flt0,
                            int f0_stride, const int32_t *flt1, int f1_stride, const int32_t xq[2], int ep);
 

@@ -183,6 +183,7 @@ def lib():
     L.svt_hip_enc_txfm_multi_dev.argtypes = [vp, i32, i32, C.POINTER(EncTxJob), i32]
     L.svt_hip_inv_txfm_add_multi_dev.argtypes = [vp, i32, i32, vp, i32]
     L.svt_hip_dlf_build_edges.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.svt_hip_wiener_init_units_dev.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.svt_hip_dlf_build_edges_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, I3, I3, I3, I3, vp, P3, P3]
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
     L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]

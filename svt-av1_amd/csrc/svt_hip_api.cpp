@@ -952,6 +952,17 @@ int svt_hip_sgr_search_units_plane(SvtHipCtx* c, int pix_bytes, int bd, const vo
     return svt_hip_sgr_search_units_picture(c, pix_bytes, bd, 1, &P, rounds_out);
 }
 
+int svt_hip_wiener_init_units_dev(SvtHipCtx* c, int win, int n_units, const int64_t* d_M, const int64_t* d_H, int16_t* d_unit_wiener, uint8_t* d_active, int8_t* d_status) {
+    SVT_HIP_ENTER(c);
+    if (!c || (win != 7 && win != 5 && win != 3) || n_units < 0 || (n_units && (!d_M || !d_H || !d_unit_wiener || !d_active || !d_status))) {
+        if (c) c->err = "svt_hip_wiener_init_units_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_wiener_init(c->stream, win, n_units, d_M, d_H, d_unit_wiener, d_active, d_status);
+    if (e != hipSuccess) return fail(c, e, "wiener init launch");
+    return SVT_HIP_OK;
+}
+
 int svt_hip_wiener_stats_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, int win, const void* d_dgd, int stride, const void* d_src, int src_stride,
                                    int pw, int ph, int unit_size, int ss_y, int64_t* d_M, int64_t* d_H) {
     SVT_HIP_ENTER(c);

@@ -114,6 +114,7 @@ int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void*
 int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
                                     int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
                                     int dstride, size_t dplane, int64_t* d2);
+int svt_hip_launch_wiener_init(hipStream_t st, int win, int n_units, const int64_t* M, const int64_t* H, int16_t* unit_wiener, uint8_t* active, int8_t* status);
 int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes);
 size_t svt_hip_sgr_walk_state_bytes(int n_units);
 typedef struct {

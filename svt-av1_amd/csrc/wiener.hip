@@ -279,6 +279,160 @@ int launch_raw(hipStream_t st, const uint8_t* dgd, int dgd_stride, const uint8_t
     return (int)hipGetLastError();
 }
 
+// ---- initial Wiener filter of every restoration unit from its statistics: search_wiener_seg between svt_av1_compute_stats and the tap refinement
+// (Encoder/Codec/EbRestorationPick.c:1388-1407): wiener_decompose_sep_sym (:946-979 — four rounds of update_a_sep_sym :841 / update_b_sep_sym :895, each a folded
+// (half + 1)-tap normal-equation system solved by linsolve_wiener :800), finalize_sym_filter (:1022-1052), compute_score (:980-1020).  64-bit INTEGER arithmetic with
+// truncating divisions throughout, so the device result is the host's bit for bit (the tests compare it with a CPU restatement that is itself pinned to the
+// reference's functions).
+// One wave per unit.  The statistics (M: win^2, H: win^4 int64 = 19 KB for win 7) sit in LDS for the eight half-rounds and the score.  A half-round's 2401-term sum is
+// split by destination: lane (p, q) owns the terms that land on B[fold(q)][fold(p)] with (p, q) as the un-folded index pair, i.e. 49 lanes x 49 terms; the folds (<= 4
+// lanes per entry) and the 3 x 3 solve are lane 0's, a few hundred serial operations per half-round.
+constexpr long long kWnScale = 1ll << 16;   // WIENER_TAP_SCALE_FACTOR (:42)
+constexpr int kWnStep = 128;                // WIENER_FILT_STEP (Common/Codec/EbRestoration.h:125)
+
+struct WnInitLds {
+    long long H[49 * 49], M[49];
+    long long partB[64], partA[64];
+    int a[8], b[8];          // vertical / horizontal taps, scaled by kWnScale
+    short v[8], h[8];
+    long long score;
+};
+
+__device__ __forceinline__ int wn_fold(int i, int win) { return i > (win >> 1) ? win - 1 - i : i; }
+
+// linsolve_wiener (:800-838): neighbour-swap pivoting, the reference's truncations; A is n x n with row stride st
+__device__ int wn_solve(int n, long long* A, int st, long long* b, int* x) {
+    for (int k = 0; k + 1 < n; k++) {
+        for (int i = n - 1; i > k; i--) {
+            const long long lo = A[(i - 1) * st + k], hi = A[i * st + k];
+            if ((lo < 0 ? -lo : lo) >= (hi < 0 ? -hi : hi)) continue;
+            for (int j = 0; j < n; j++) { const long long t = A[i * st + j]; A[i * st + j] = A[(i - 1) * st + j]; A[(i - 1) * st + j] = t; }
+            const long long t = b[i]; b[i] = b[i - 1]; b[i - 1] = t;
+        }
+        for (int i = k + 1; i < n; i++) {
+            const long long piv = A[k * st + k], c = A[i * st + k];
+            if (piv == 0) return 0;
+            for (int j = 0; j < n; j++) A[i * st + j] -= c / 256 * A[k * st + j] / piv * 256;
+            b[i] -= c * b[k] / piv;
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        if (A[i * st + i] == 0) return 0;
+        long long c = 0;
+        for (int j = i + 1; j < n; j++) c += A[i * st + j] * x[j] / kWnScale;
+        x[i] = (int)(kWnScale * (b[i] - c) / A[i * st + i]);
+    }
+    return 1;
+}
+
+// which = 0: update_a_sep_sym (solve the vertical taps L.a with L.b fixed), 1: update_b_sep_sym
+__device__ void wn_half_round(WnInitLds& L, int win, int which, int lane) {
+    const int win2 = win * win, h1 = (win >> 1) + 1;
+    const int* fixed = which == 0 ? L.b : L.a;
+    long long sb = 0, sa = 0;
+    if (lane < win2) {
+        const int p = lane / win, q = lane - p * win;
+        // which 0 (:856-867): lane (k, l) = (p, q) sums hc[j * win + i][k * win2 + l] * b[i] / S * b[j] / S over (i, j) = (r, t);
+        // which 1 (:909-921): lane (i, j) = (p, q) sums hc[i * win + j][k * win2 + l] * a[k] / S * a[l] / S over (k, l) = (r, t);
+        // hc[x * win + y][z * win2 + w] = H[(x * win + z) * win2 + y * win + w] (:962-968)
+        for (int r = 0; r < win; r++)
+            for (int t = 0; t < win; t++) {
+                const long long hv = which == 0 ? L.H[(t * win + p) * win2 + r * win + q] : L.H[(p * win + r) * win2 + q * win + t];
+                sb += hv * fixed[r] / kWnScale * fixed[t] / kWnScale;
+            }
+        // A (:850-855 / :904-907): which 0: M[i][j] * b[i] lands on fold(j); which 1: M[i][j] * a[j] lands on fold(i); lane (i, j) = (p, q)
+        sa = L.M[lane] * fixed[which == 0 ? p : q] / kWnScale;
+    }
+    L.partB[lane] = sb; L.partA[lane] = sa;
+    __syncthreads();
+    if (lane == 0) {
+        long long A[4] = {0, 0, 0, 0}, B[16];
+        for (int e = 0; e < 16; e++) B[e] = 0;
+        for (int p = 0; p < win; p++)
+            for (int q = 0; q < win; q++) {
+                B[wn_fold(q, win) * h1 + wn_fold(p, win)] += L.partB[p * win + q];
+                A[wn_fold(which == 0 ? q : p, win)] += L.partA[p * win + q];
+            }
+        // the taps sum to one: the centre tap is eliminated from the system (:868-882 / :923-937)
+        const long long a_c = A[h1 - 1], b_cc = B[(h1 - 1) * h1 + h1 - 1];
+        for (int i = 0; i < h1 - 1; i++) A[i] -= a_c * 2 + B[i * h1 + h1 - 1] - 2 * b_cc;
+        for (int i = 0; i < h1 - 1; i++)
+            for (int j = 0; j < h1 - 1; j++) B[i * h1 + j] -= 2 * (B[i * h1 + h1 - 1] + B[(h1 - 1) * h1 + j] - 2 * b_cc);
+        int S[7];
+        if (wn_solve(h1 - 1, B, h1, A, S)) {   // singular: the vector keeps its value (:883, :938)
+            S[h1 - 1] = (int)kWnScale;
+            for (int i = h1; i < win; i++) { S[i] = S[win - 1 - i]; S[h1 - 1] -= 2 * S[i]; }
+            int* upd = which == 0 ? L.a : L.b;
+            for (int i = 0; i < win; i++) upd[i] = S[i];
+        }
+    }
+    __syncthreads();
+}
+
+// finalize_sym_filter (:1022-1052); fi[8] starts zeroed (the 3-tap branch reads fi[1] before anything wrote it; the host hook hands the reference a zeroed WienerInfo)
+__device__ void wn_finalize(int win, const int* f, short* fi) {
+    for (int i = 0; i < 8; i++) fi[i] = 0;
+    for (int i = 0; i < (win >> 1); i++) {
+        const long long v = (long long)f[i] * kWnStep;
+        fi[i] = (short)((v < 0 ? v - kWnScale / 2 : v + kWnScale / 2) / kWnScale);
+    }
+    // WIENER_FILT_TAPn_{MIN,MAX}V (EbRestoration.h:130-149): tap 0 in [-5, 10], tap 1 in [-23, 8], tap 2 in [-17, 46]
+    if (win == 7) {
+        fi[0] = (short)min(max((int)fi[0], -5), 10); fi[1] = (short)min(max((int)fi[1], -23), 8); fi[2] = (short)min(max((int)fi[2], -17), 46);
+    } else {
+        fi[2] = (short)min(max((int)fi[1], -17), 46); fi[1] = (short)min(max((int)fi[0], -23), 8); fi[0] = 0;
+    }
+    fi[6] = fi[0]; fi[5] = fi[1]; fi[4] = fi[2];
+    fi[3] = (short)(-2 * (fi[0] + fi[1] + fi[2]));
+}
+
+__global__ void __launch_bounds__(64)
+wiener_init_kernel(const long long* __restrict__ M, const long long* __restrict__ H, int win, int n_units, short* __restrict__ unit_wiener,
+                   unsigned char* __restrict__ active, signed char* __restrict__ status) {
+    __shared__ WnInitLds L;
+    const int u = blockIdx.x, lane = threadIdx.x, win2 = win * win, off = (7 - win) >> 1;
+    if (u >= n_units) return;
+    for (int i = lane; i < win2 * win2; i += 64) L.H[i] = H[(size_t)u * win2 * win2 + i];
+    for (int i = lane; i < win2; i += 64) L.M[i] = M[(size_t)u * win2 + i];
+    if (lane < win) {
+        const int mid[7] = {3, -7, 15, 128 - 2 * (3 - 7 + 15), 15, -7, 3};   // WIENER_FILT_TAPn_MIDV
+        L.a[lane] = L.b[lane] = (int)(kWnScale / kWnStep) * mid[lane + off];
+    }
+    __syncthreads();
+    for (int round = 1; round < 5; round++) {   // NUM_WIENER_ITERS = 5 (:40): four rounds
+        wn_half_round(L, win, 0, lane);
+        wn_half_round(L, win, 1, lane);
+    }
+    if (lane == 0) { wn_finalize(win, L.a, L.v); wn_finalize(win, L.b, L.h); }
+    __syncthreads();
+    // compute_score (:980-1020): lane k sums row k of ab^T H ab and its term of ab . M
+    long long q = 0, pterm = 0;
+    if (lane < win2) {
+        short a[7], b[7];
+        a[3] = b[3] = (short)kWnStep;
+        for (int i = 0; i < 3; i++) { a[i] = a[6 - i] = L.v[i]; b[i] = b[6 - i] = L.h[i]; a[3] -= 2 * a[i]; b[3] -= 2 * b[i]; }
+        const int kk = lane / win, kl = lane - kk * win;
+        const int abk = a[kl + off] * b[kk + off];
+        pterm = abk * L.M[lane] / kWnStep / kWnStep;
+        for (int l = 0; l < win2; l++) {
+            const int lk = l / win, ll = l - lk * win;
+            const int abl = a[ll + off] * b[lk + off];
+            q += abk * L.H[lane * win2 + l] * abl / kWnStep / kWnStep / kWnStep / kWnStep;
+        }
+    }
+    L.partB[lane] = q; L.partA[lane] = pterm;
+    __syncthreads();
+    if (lane == 0) {
+        long long Q = 0, P = 0;
+        for (int k = 0; k < win2; k++) { Q += L.partB[k]; P += L.partA[k]; }
+        const long long ident = L.H[(win2 >> 1) * win2 + (win2 >> 1)] - 2 * L.M[win2 >> 1];
+        const int st = (Q - 2 * P - ident) > 0 ? 2 : 1;
+        status[u] = (signed char)st;
+        active[u] = (unsigned char)(st == 1);
+    }
+    if (lane < 8) { unit_wiener[16 * (size_t)u + lane] = L.v[lane]; unit_wiener[16 * (size_t)u + 8 + lane] = L.h[lane]; }
+}
+
 }  // namespace
 
 // scratch layout (bytes) of the 16-bit path; the API allocates it
@@ -341,6 +495,12 @@ extern "C" int svt_hip_launch_wiener_stats8(hipStream_t st, int win, const uint8
     }
 #undef BY_WIN
 #undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_wiener_init(hipStream_t st, int win, int n_units, const int64_t* M, const int64_t* H, int16_t* unit_wiener, uint8_t* active, int8_t* status) {
+    if (n_units <= 0) return 0;
+    hipLaunchKernelGGL(wiener_init_kernel, dim3(n_units), dim3(64), 0, st, (const long long*)M, (const long long*)H, win, n_units, (short*)unit_wiener, active, (signed char*)status);
     return (int)hipGetLastError();
 }
 

@@ -476,6 +476,36 @@ def _check_level_search_grid(workdir, env, tag):
     assert filt and all("mode info refilled" in l for l in filt), filt
 
 
+def _check_wiener_initial_filters(workdir, env, tag):
+    """The Wiener search's initial filters on the device (statistics, decomposition and walks queued back to back, one wait) and, SVT_HIP_WIENER_INIT=host, by the
+    reference's own decomposition on downloaded statistics: same bitstream, and the log says which one ran."""
+    dev = _check_geometry("wn_init", 352, 288, 4, 8, 6, 35, 41, workdir, dict(env, SVT_HIP_VERBOSE="1"), tag + ".dev")
+    lines = re.findall(r"wiener_search: 1 launch[^\n]*", dev["log"])
+    assert lines and all("initial filters (device)" in l for l in lines), dev["log"][-1500:]
+    assert sum(int(re.search(r"(\d+) walks", l).group(1)) for l in lines) > 0
+    host = _check_geometry("wn_init", 352, 288, 4, 8, 6, 35, 41, workdir, dict(env, SVT_HIP_VERBOSE="1", SVT_HIP_WIENER_INIT="host"), tag + ".host")
+    hl = re.findall(r"wiener_search: 1 launch[^\n]*", host["log"])
+    assert hl and all("initial filters (host)" in l for l in hl), hl
+    counts = lambda ls: sorted(re.search(r"(\d+) walks, (\d+) probes", l).groups() for l in ls)   # pictures finish in any order
+    assert counts(lines) == counts(hl)
+
+
+def test_wiener_initial_filters_on_cpu_test_double(workdir):
+    _check_wiener_initial_filters(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
+
+
+def test_wiener_initial_filters_matter(workdir):
+    """a wrong initial tap from the device changes the encode (the perturbed test double is noticed)"""
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all", "SVT_HIP_MOCK_PERTURB": "wiener_init"}
+    with pytest.raises(AssertionError):
+        _check_geometry("wn_init", 352, 288, 4, 8, 6, 35, 41, workdir, env, "mock.perturbed")
+
+
+@pytest.mark.gpu
+def test_wiener_initial_filters_on_gpu(workdir):
+    _check_wiener_initial_filters(workdir, {"SVT_HIP_HOOKS": "all"}, "hip")
+
+
 def test_level_search_grid_serves_the_filter_on_cpu_test_double(workdir):
     _check_level_search_grid(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"}, "mock")
 

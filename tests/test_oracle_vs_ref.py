@@ -650,6 +650,34 @@ def test_wiener_stats_and_convolve(orc, ref):
             assert np.array_equal(eo, er), (bd, trial)
 
 
+from wiener_common import wiener_unit_stats
+
+
+def test_wiener_initial_filter(orc, ref):
+    """orc_wiener_unit_init == the reference's wiener_decompose_sep_sym + finalize_sym_filter + compute_score (EbRestorationPick.c:946-1052, static there: reached through
+    oracle/ref_shim_restpick.c), windows 7 / 5 / 3, 8- and 10-bit statistics of blurred, noisy, identical, flat and unrelated picture pairs, plus raw random M / H."""
+    if not hasattr(ref, "ref_shim_wiener_unit_init"): pytest.skip("oracle/_ref predates the Wiener shim: rebuild it")
+    rng = np.random.default_rng(4242)
+    seen = set()
+    cases = [(win, bd, kind, t) for win in (7, 5, 3) for bd in (8, 10) for kind in range(5) for t in range(3)]
+    for win, bd, kind, t in cases + [(win, 0, 9, t) for win in (7, 5, 3) for t in range(6)]:
+        if kind == 9:   # symmetric positive-definite-ish random statistics, then plain random ones
+            w2 = win * win
+            G = rng.integers(-300, 300, (w2, 3 * w2)).astype(np.int64)
+            H = (G @ G.T).reshape(-1).copy() if t < 3 else rng.integers(-(1 << 30), 1 << 30, w2 * w2).astype(np.int64)
+            M = rng.integers(-(1 << 26), 1 << 26, w2).astype(np.int64)
+        else:
+            M, H = wiener_unit_stats(orc, rng, win, bd, kind)
+        vo, ho, vr, hr = (np.full(8, 77, np.int16) for _ in range(4))
+        Mr, Hr = M.copy(), H.copy()
+        ro = orc.orc_wiener_unit_init(win, ptr(M), ptr(H), ptr(vo), ptr(ho))
+        rr = ref.ref_shim_wiener_unit_init(win, ptr(Mr), ptr(Hr), ptr(vr), ptr(hr))
+        assert ro == rr and np.array_equal(vo, vr) and np.array_equal(ho, hr), (win, bd, kind, t, ro, rr, vo, vr, ho, hr)
+        assert np.array_equal(M, Mr) and np.array_equal(H, Hr)
+        seen.add(ro)
+    assert seen == {1, 2}
+
+
 import tf_common as tfc
 
 

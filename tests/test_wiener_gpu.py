@@ -62,3 +62,37 @@ def test_wiener_stats_16bit(hip, orc, bd, win):
         assert np.array_equal(Mg, Me), (bd, win, w, h, US, ss, np.argwhere(Mg != Me)[:5], Mg[Mg != Me][:4], Me[Mg != Me][:4])
         assert np.array_equal(Hg, He), (bd, win, w, h, US, ss, np.argwhere(Hg != He)[:5])
         assert US != 64 or (Me < 0).any()
+
+
+@pytest.mark.parametrize("win", [7, 5, 3])
+def test_wiener_initial_filters_on_the_device(hip, orc, win):
+    """svt_hip_wiener_init_units_dev == orc_wiener_unit_init (pinned to the reference's wiener_decompose_sep_sym / finalize_sym_filter / compute_score by
+    tests/test_oracle_vs_ref.py::test_wiener_initial_filter) for a batch of units: statistics of blurred, noisy, identical, flat and unrelated picture pairs at 8 and 10 bits,
+    and raw random statistics (singular systems, clamped taps); both outcomes occur."""
+    from wiener_common import wiener_unit_stats
+    rng = np.random.default_rng(900 + win)
+    w2 = win * win
+    Ms, Hs = [], []
+    for bd in (8, 10):
+        for kind in range(5):
+            for _ in range(3):
+                M, H = wiener_unit_stats(orc, rng, win, bd, kind)
+                Ms.append(M); Hs.append(H)
+    for t in range(8):
+        G = rng.integers(-300, 300, (w2, 3 * w2)).astype(np.int64)
+        Hs.append((G @ G.T).reshape(-1).copy() if t < 4 else rng.integers(-(1 << 30), 1 << 30, w2 * w2).astype(np.int64))
+        Ms.append(rng.integers(-(1 << 26), 1 << 26, w2).astype(np.int64))
+    n = len(Ms)
+    M = np.ascontiguousarray(np.stack(Ms)); H = np.ascontiguousarray(np.stack(Hs))
+    exp_wn = np.zeros((n, 16), np.int16); exp_st = np.zeros(n, np.int8)
+    for u in range(n):
+        exp_st[u] = orc.orc_wiener_unit_init(win, ptr(M[u]), ptr(H[u]), C.c_void_p(exp_wn[u].ctypes.data), C.c_void_p(exp_wn[u].ctypes.data + 16))
+    d_M, d_H = hip.to_device(M), hip.to_device(H)
+    d_wn, d_act, d_st = hip.to_device(np.full((n, 16), 77, np.int16)), hip.to_device(np.full(n, 9, np.uint8)), hip.to_device(np.full(n, 9, np.int8))
+    hip.check(hip.L.svt_hip_wiener_init_units_dev(hip.h, win, n, d_M, d_H, d_wn, d_act, d_st), "wiener init")
+    got_wn, got_act, got_st = hip.to_host(d_wn, (n, 16), np.int16), hip.to_host(d_act, (n,), np.uint8), hip.to_host(d_st, (n,), np.int8)
+    hip.free(d_M, d_H, d_wn, d_act, d_st)
+    assert np.array_equal(got_st, exp_st), (got_st, exp_st)
+    assert np.array_equal(got_act, (exp_st == 1).astype(np.uint8))
+    assert np.array_equal(got_wn, exp_wn), np.argwhere(got_wn != exp_wn)[:6]
+    assert set(exp_st.tolist()) == {1, 2}
