@@ -66,7 +66,7 @@ EbErrorType svt_hip_lf_picture_ctor(SvtHipCtx *hip, SvtHipLfPicture *p, int w, i
     p->h_skip8 = (uint8_t *)malloc((size_t)(w / 8) * (h / 8)); p->h_mi = (SvtHipDlfModeInfo *)calloc((size_t)mi_cols * mi_rows, sizeof(SvtHipDlfModeInfo));
     p->h_mse = (uint64_t *)malloc(sizeof(uint64_t) * 2 * nfb * 64);
     if (!p->h_skip8 || !p->h_mi || !p->h_mse) return EB_ErrorInsufficientResources;
-    if (!(p->h_mi_until = (uint16_t *)malloc(sizeof(uint16_t) * mi_cols))) return EB_ErrorInsufficientResources;
+    if (!(p->h_mi_until = (uint16_t *)malloc(sizeof(uint16_t) * mi_cols)) || !(p->h_skip4 = (uint8_t *)malloc((size_t)mi_cols * mi_rows))) return EB_ErrorInsufficientResources;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows));
     p->h_mi_pinned = svt_hip_hooks_pin_enabled() && svt_hip_host_register(hip, p->h_mi, sizeof(SvtHipDlfModeInfo) * mi_cols * mi_rows) == SVT_HIP_OK;
     HIP_TRY(svt_hip_malloc(hip, (void **)&p->d_skip8, (size_t)(w / 8) * (h / 8)));
@@ -85,7 +85,7 @@ void svt_hip_lf_picture_dctor(SvtHipCtx *hip, SvtHipLfPicture *p) {
         free(p->h_wiener_M[pl]); free(p->h_wiener_H[pl]);
     }
     if (p->h_mi_pinned) svt_hip_host_unregister(hip, p->h_mi);
-    free(p->h_skip8); free(p->h_mi); free(p->h_mi_until); free(p->h_mse); svt_hip_free(hip, p->d_mi);
+    free(p->h_skip8); free(p->h_mi); free(p->h_mi_until); free(p->h_skip4); free(p->h_mse); svt_hip_free(hip, p->d_mi);
     svt_hip_free(hip, p->d_skip8); svt_hip_free(hip, p->d_mse); svt_hip_free(hip, p->d_dir); svt_hip_free(hip, p->d_var);
     svt_hip_free(hip, p->d_y_strength); svt_hip_free(hip, p->d_uv_strength); svt_hip_free(hip, p->d_sse);
     memset(p, 0, sizeof(*p));
@@ -111,7 +111,8 @@ enum { ST_SRC = 1, ST_DBL = 2, ST_CDEF = 4, ST_DIRVAR = 8, ST_CDEF_SEARCHED = 16
        ST_SKIP0 = 32768,       /* save_boundary_lines(.., 0) was skipped on the host */
        ST_SKIP1 = 65536,       /* save_boundary_lines(.., 1) + svt_extend_frame were skipped on the host */
        ST_REST = 131072,       /* d_rest holds restored planes (rest_mask) that the host has not seen */
-       ST_MI = 262144 };       /* d_mi holds this picture's mode-info grid (uploaded by the level search; its levels are placeholders) */
+       ST_MI = 262144,         /* d_mi holds this picture's mode-info grid (uploaded by the level search; its levels are placeholders) */
+       ST_SKIP4 = 524288 };    /* h_skip4 holds this picture's skip flag per 4 x 4 unit (a by-product of the mode-info pass; the CDEF stages' skip map comes from it) */
 typedef struct {
     PictureControlSet *pcs;     /* NULL: free */
     int                allocated, flags, defer, rest_mask, mu_ready;
@@ -408,6 +409,7 @@ static void fill_mode_info(SvtHipLfPicture *p, PictureControlSet *pcs, int unifo
                         ? get_filter_level_delta_lf(frm_hdr, dir, pl, ppcs->curr_delta_lf, 0, mode, mbmi->block_mi.ref_frame[0])
                         : lfi_n->lvl[pl][0][dir][mbmi->block_mi.ref_frame[0]][mode_lf_lut[mode]];
             for (int k = c + 1; k < c_next; k++) p->h_mi[r * mi_cols + k] = *o;
+            for (int rr = r; rr < r_next; rr++) memset(&p->h_skip4[rr * mi_cols + c], mbmi->block_mi.skip & 1, (size_t)(c_next - c));   /* bit 0: what is_8x8_block_skip's `is_skip &= skip` keeps */
             for (int rr = r + 1; rr < r_next; rr++) memcpy(&p->h_mi[rr * mi_cols + c], o, sizeof(*o) * (size_t)(c_next - c));
             for (int k = c; k < c_next; k++) until[k] = (uint16_t)r_next;
             c = c_next;
@@ -480,6 +482,7 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
     s->flags |= ST_RECON;   /* the search filters into d_cdef: d_recon stays the picture as coded, which svt_av1_loop_filter_frame's hook starts from */
     const long long td1 = svt_hip_hooks_now_ns();
     fill_mode_info(p, pcs, 1);
+    s->flags |= ST_SKIP4;
     const long long td2 = svt_hip_hooks_now_ns();
     long long t_edges = 0, t_search = 0;
     int best[3];
@@ -552,7 +555,7 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
     const long long te0 = svt_hip_hooks_now_ns();
     int level[3][2];
     const int reuse = (s->flags & ST_MI) && uniform_levels(pcs, mask, level);
-    if (!reuse) fill_mode_info(p, pcs, 0);
+    if (!reuse) { fill_mode_info(p, pcs, 0); s->flags |= ST_SKIP4; }
     s->flags &= ~ST_MI;
     if (build_edges(hip, p, mask, !reuse, reuse ? (const int (*)[2])level : NULL) != EB_ErrorNone) return EB_ErrorUndefined;
     const long long te1 = svt_hip_hooks_now_ns();
@@ -604,8 +607,15 @@ void svt_hip_hook_after_dlf(PictureControlSet *pcs) {
 }
 
 /* ---------------------------------------------------------------- CDEF ---------------------------------------------------------------- */
-static void fill_skip8(SvtHipLfPicture *p, PictureControlSet *pcs) {     /* is_8x8_block_skip (EbEncCdef.c:242-250) for every 8x8 block */
-    const int c8 = p->w / 8, r8 = p->h / 8;
+static void fill_skip8(SvtHipLfPicture *p, PictureControlSet *pcs, int have_skip4) {     /* is_8x8_block_skip (EbEncCdef.c:242-250) for every 8x8 block */
+    const int c8 = p->w / 8, r8 = p->h / 8, mi_cols = (p->w + 3) / 4;
+    if (have_skip4) {   /* the deblocking hooks' mode-info pass of this picture left the flag of every 4 x 4 unit in a dense map (one look at the mode info per coded block) */
+        for (int r = 0; r < r8; r++) {
+            const uint8_t *u0 = &p->h_skip4[(size_t)(2 * r) * mi_cols], *u1 = u0 + mi_cols;
+            for (int c = 0; c < c8; c++) p->h_skip8[r * c8 + c] = (uint8_t)(u0[2 * c] & u0[2 * c + 1] & u1[2 * c] & u1[2 * c + 1]);
+        }
+        return;
+    }
     for (int r = 0; r < r8; r++)
         for (int c = 0; c < c8; c++) {
             int skip = 1;
@@ -623,7 +633,7 @@ static EbErrorType cdef_search(SvtHipCtx *hip, LfState *s) {
     if (!(s->flags & ST_DBL) || ensure_src(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     const int nfb = ((p->w + 63) / 64) * ((p->h + 63) / 64);
     const int pri_damping = 3 + (pcs->parent_pcs_ptr->frm_hdr.quantization_params.base_q_idx >> 6);   /* EbCdefProcess.c:121 */
-    fill_skip8(p, pcs);
+    fill_skip8(p, pcs, (s->flags & ST_SKIP4) != 0);
     svt_hip_hooks_log("cdef_search: %d x %d, %d filter blocks, primary damping %d", p->w, p->h, nfb, pri_damping);
     HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_skip8, p->h_skip8, (size_t)(p->w / 8) * (p->h / 8)));
     const void *rec[3], *src[3];
@@ -708,7 +718,7 @@ static EbErrorType cdef_apply(SvtHipCtx *hip, LfState *s) {
     free(ys); free(uvs);
     if (rc != SVT_HIP_OK) return EB_ErrorUndefined;
     if (!(s->flags & ST_DIRVAR)) {   /* the search hook is off: build the skip map here; directions are computed by the apply call */
-        fill_skip8(p, pcs);
+        fill_skip8(p, pcs, (s->flags & ST_SKIP4) != 0);
         HIP_TRY(svt_hip_memcpy_h2d(hip, p->d_skip8, p->h_skip8, (size_t)(p->w / 8) * (p->h / 8)));
     }
     const void *in[3]; void *out[3];

@@ -46,6 +46,7 @@ typedef struct SvtHipLfPicture {
     SvtHipDlfModeInfo *h_mi, *d_mi;      /* [mi_rows][mi_cols]; the device copy serves the level search and the filter of one picture */
     int       h_mi_pinned;
     uint16_t *h_mi_until;                /* [mi_cols] scratch of the grid's fill pass */
+    uint8_t  *h_skip4;                   /* [mi_rows][mi_cols] the skip flag of every 4 x 4 unit, written by the same pass */
     uint16_t *h_edges[3][2], *d_edges[3][2];
     int       units_w[3], units_h[3];
     uint64_t *d_sse;
