@@ -21,4 +21,12 @@ cd $R && PYTHONFAULTHANDLER=1 python bench.py > $OUT/bench.json 2> $OUT/bench.er
 # ... and their rocprofv3 kernel statistics (one trace over the three timing tools)
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/extra_stats -o x -- python $R/tools/extra_time.py > $OUT/extra_stats.log 2>&1
 cd $R
+# ENCODER=1: the hooked encoder as well -- kernel + memory-copy trace of a 12-frame 4K encode (copy share, tools/copy_trace_summary.py) and the loop-filter hooks' sub-step times
+if [ "${ENCODER:-0}" = 1 ]; then
+  N=12 bash tools/encoder_copy_trace.sh > $OUT/encoder_copy_trace.log 2>&1
+  python tools/copy_trace_summary.py > $OUT/copy_trace_4k.txt 2>&1
+  cp gpurun_out/enc_copy/stats/k_kernel_stats.csv $OUT/encoder_hooks_4k_kernel_stats.csv 2>/dev/null
+  (cd gpurun_out/enc_copy/stats && rm -f k_kernel_trace.csv k_memory_copy_trace.csv)
+  bash tools/dlf_edges_ab.sh > $OUT/dlf_edges_ab.log 2>&1; cp gpurun_out/dlf_edges/ab.txt $OUT/dlf_edges_ab.txt 2>/dev/null
+fi
 ls -R $OUT | head -40
