@@ -865,6 +865,28 @@ int svt_hip_cdef_filter_block_batch_dev(SvtHipCtx *ctx, const uint16_t *d_in, in
 typedef struct { int32_t off; uint8_t dir, len, blimit, limit, thresh, reserved[3]; } SvtHipLpfEdge;
 int svt_hip_lpf_edges_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, void *d_plane, int stride, const SvtHipLpfEdge *d_edges, int n);
 
+/* ------------------------------------------------------------------ mode decision: picture-level precompute ----------
+ * md_stage_0 -> fast_loop_core (Encoder/Codec/EbProductCodingLoop.c:1461, :907) predicts a candidate and measures its luma distortion against the source,
+ * one block and one candidate at a time.  For a FULL-PEL single-reference translation candidate the prediction is a copy of the reference block
+ * (inter_pu_prediction_av1, EbEncInterPrediction.c:6178 -> av1_inter_prediction :4040 -> svt_av1_convolve_2d_copy_sr) and the distortion is
+ * svt_nxm_sad_kernel_sub_sampled (:953; aom_dsp_rtcd.c:372 — the plain SAD of all rows), and in the first partitioning pass (PD_PASS_0) at presets above M4
+ * the open-loop ME vectors enter stage 0 unrefined (EbEncDecProcess.c:3050-3093).  One launch per picture computes that distortion for every
+ * (superblock, PU of `pus`, reference picture):
+ *   d_src  : sample (0, 0) of the source luma plane, pic_w x pic_h samples exist from there (PUs that leave them are skipped)
+ *   pus    : the PUs of a 64x64 superblock, positions relative to it (host array; the 85 square PUs of the open-loop ME in its order, or any other list)
+ *   refs   : the reference pictures' luma planes (host array of n_refs <= SVT_HIP_MD_MAX_REFS descriptors; d_plane = device address of sample (0, 0),
+ *            [x_min, x_max) x [y_min, y_max) = the sample coordinates its allocation holds, padding included)
+ *   d_mv   : [n_sb][n_pus][n_refs] vectors in whole samples, x | y << 16 (two int16); x = SVT_HIP_MD_NO_MV = no candidate
+ *   d_sad  : [n_sb][n_pus][n_refs] SAD of the PU against the reference block at its vector; 0xffffffff = not computed (no vector, PU outside the picture,
+ *            reference block outside the allocation) */
+#define SVT_HIP_MD_MAX_REFS 7     /* MAX_PA_ME_MV, Encoder/Codec/EbMotionEstimationLcuResults.h:23 */
+#define SVT_HIP_MD_MAX_PUS 128
+#define SVT_HIP_MD_NO_MV (-32768)
+typedef struct { uint8_t x, y, w, h; } SvtHipMdPu;   /* w a multiple of 4, at most 64 */
+typedef struct { const uint8_t *d_plane; int32_t stride, x_min, y_min, x_max, y_max; } SvtHipMdRefPlane;
+int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
+                                       const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, uint32_t *d_sad);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -180,7 +180,29 @@ mdtx.sub(r'(    int tx_type_tot_group = get_tx_type_group\(context_ptr, candidat
 mdtx.sub(r'(\n        // Y: T Q i_q\n)(        av1_estimate_transform\(\n            &\(\(\(int16_t \*\)candidate_buffer->residual_ptr->buffer_y\)\[txb_origin_index\]\),.*?context_ptr->pf_ctrls\.pf_shape\);\n)(\n        quantized_dc_txt\[tx_type\] = av1_quantize_inv_quantize\()',
          r'\1        if (!svt_hip_hook_md_tx_fetch(tx_size, tx_type, &(((int32_t *)context_ptr->trans_quant_buffers_ptr->txb_trans_coeff2_nx2_n_ptr->buffer_y)[context_ptr->txb_1d_offset])))\n\2\3')
 mdtx.sub(r'(\n    context_ptr->md_staging_spatial_sse_full_loop_level = default_md_staging_spatial_sse_full_loop;\n    //  Best Tx Type Pass\n)', r'\n    svt_hip_hook_md_tx_end();\1')
+# hook "md_pre" (svt_hip_md_bridge.c): fast_loop_core (:907) takes the luma distortion of a full-pel single-reference candidate from the picture's table and skips its
+# prediction; full_loop_core (:5820) makes that prediction, with stage 0's settings, when it is about to reuse it (md_staging_perform_inter_pred off)
+mdtx.sub(r'(    context_ptr->uv_intra_comp_only = EB_FALSE;\n)(    svt_product_prediction_fun_table\[candidate_buffer->candidate_ptr->use_intrabc\n\s*\? INTER_MODE\n\s*: candidate_ptr->type\]\(\n\s*context_ptr->hbd_mode_decision, context_ptr, pcs_ptr, candidate_buffer\);\n)',
+         r'\1    uint32_t  hip_sad = 0;\n    const int hip_hit = !use_ssd && svt_hip_hook_md_pre_lookup(pcs_ptr, context_ptr, candidate_buffer, &hip_sad);\n    if (!hip_hit)\n\2')
+mdtx.sub(r'(luma_fast_distortion = )(svt_nxm_sad_kernel_sub_sampled\(\n\s*input_picture_ptr->buffer_y \+ input_origin_index,\n\s*input_picture_ptr->stride_y,\n\s*prediction_ptr->buffer_y \+ cu_origin_index,\n\s*prediction_ptr->stride_y,\n\s*context_ptr->blk_geom->bheight,\n\s*context_ptr->blk_geom->bwidth\))',
+         r'\1hip_hit ? hip_sad : \2')
+mdtx.sub(r'(    if \(candidate_ptr->type != INTRA_MODE\) \{\n)(        if \(context_ptr->md_staging_perform_inter_pred\) \{\n            svt_product_prediction_fun_table\[candidate_ptr->type\]\()',
+         r'\1        if (svt_hip_hook_md_pre_take(candidate_buffer, !context_ptr->md_staging_perform_inter_pred) && !context_ptr->md_staging_perform_inter_pred) {\n'
+         r'            /* the candidate\'s stage-0 distortion came from the picture-level table and its prediction was not made then: made now, as stage 0 would have */\n'
+         r'            const EbBool  hip_c = context_ptr->md_staging_skip_chroma_pred, hip_i = context_ptr->md_staging_skip_interpolation_search, hip_u = context_ptr->uv_intra_comp_only;\n'
+         r'            const uint8_t hip_p = context_ptr->pu_itr;\n'
+         r'            context_ptr->md_staging_skip_chroma_pred = EB_TRUE; context_ptr->md_staging_skip_interpolation_search = EB_TRUE;\n'
+         r'            context_ptr->uv_intra_comp_only = EB_FALSE; context_ptr->pu_itr = 0;\n'
+         r'            svt_product_prediction_fun_table[candidate_ptr->type](context_ptr->hbd_mode_decision, context_ptr, pcs_ptr, candidate_buffer);\n'
+         r'            context_ptr->md_staging_skip_chroma_pred = hip_c; context_ptr->md_staging_skip_interpolation_search = hip_i;\n'
+         r'            context_ptr->uv_intra_comp_only = hip_u; context_ptr->pu_itr = hip_p;\n'
+         r'        }\n\2')
 PATCHES.append(mdtx)
+
+# mode_decision_configuration_kernel (:810), before the picture is posted to the mode-decision threads (:1058): hook "md_pre" fills the picture's table
+mdc = Patch("Source/Lib/Encoder/Codec/EbModeDecisionConfigurationProcess.c")
+mdc.sub(r'(\n[ \t]*// Post the results to the MD processes\n)', r'\n        svt_hip_hook_md_pre_picture(pcs_ptr);\1')
+PATCHES.append(mdc)
 
 # ---------------------------------------------------------------------------------------------------------------- encode pass: inter blocks
 # av1_encode_decode (:1987): before the transform loops of an inter-coded block (:2997) every forward transform of the block is computed in one launch
@@ -337,6 +359,8 @@ rest.sub(r'(\n[ \t]*)(svt_av1_loop_restoration_filter_frame\(cm->frame_to_show, 
 # a deferred picture's restoration segment: the picture-level searches run before the segment would copy the picture (svt_hip_hook_rest_begin), and the copy is skipped
 rest.sub(r'(\n[ \t]*)(get_own_recon\(scs_ptr,\s*pcs_ptr,\s*context_ptr,\s*scs_ptr->static_config\.is_16bit_pipeline \|\| is_16bit\);)', r'\1if (!svt_hip_hook_rest_begin(pcs_ptr))\1    \2')
 rest.sub(r'(\n[ \t]*)(cm->sg_frame_ep = best_ep;\n)', r'\1\2\1svt_hip_hook_picture_done(pcs_ptr); /* the picture leaves the filter stages */\n')
+# after pad_ref_and_set_flags (:581) the 8-bit reference planes of the picture are final: hook "md_pre" announces the luma plane to the resident table
+rest.sub(r'(\n[ \t]*pad_ref_and_set_flags\(pcs_ptr, scs_ptr\);\n)', r'\1            svt_hip_hook_md_pre_note_ref(pcs_ptr);\n')
 PATCHES.append(rest)
 
 pick = Patch("Source/Lib/Encoder/Codec/EbRestorationPick.c")

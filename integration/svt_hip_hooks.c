@@ -13,8 +13,8 @@
 #include "EbLog.h"
 
 static const char *const k_hook_name[SVT_HIP_HOOK_COUNT] = {"me", "dlf", "dlf_search", "cdef_search", "cdef_apply",
-                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel", "encdec_tx", "md_subpel", "encdec_sb"};
-static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1, [SVT_HIP_HOOK_ENCDEC_TX] = 1, [SVT_HIP_HOOK_MD_SUBPEL] = 1, [SVT_HIP_HOOK_ENCDEC_SB] = 1};   /* not selected by "all": must be named */
+                                                            "sgr_search", "wiener_stats", "rest_apply", "wiener_try", "wiener_search", "hme", "tf", "pa", "tf_me", "cdef_finish", "md_tx", "tf_subpel", "encdec_tx", "md_subpel", "encdec_sb", "md_pre"};
+static const int k_hook_opt_in[SVT_HIP_HOOK_COUNT] = {[SVT_HIP_HOOK_MD_TX] = 1, [SVT_HIP_HOOK_ENCDEC_TX] = 1, [SVT_HIP_HOOK_MD_SUBPEL] = 1, [SVT_HIP_HOOK_ENCDEC_SB] = 1, [SVT_HIP_HOOK_MD_PRE] = 1};   /* not selected by "all": must be named */
 static int             g_enabled[SVT_HIP_HOOK_COUNT];
 static long            g_handled[SVT_HIP_HOOK_COUNT], g_fellback[SVT_HIP_HOOK_COUNT];
 static int             g_verbose;
@@ -296,6 +296,13 @@ void svt_hip_hooks_report(void) {
         svt_hip_hook_encdec_sb_stats(&sbs, &launches, &blocks, &calls);
         fprintf(stderr, "svt_hip_encdec_sb superblocks=%ld launches=%ld inter_blocks_predicted_ahead=%ld estimate_transform_calls_replaced=%ld kernel_launches=%ld\n", sbs, launches, blocks, calls,
                 svt_hip_hook_encdec_sb_kernels());
+    }
+    if (g_enabled[SVT_HIP_HOOK_MD_PRE]) {
+        long pictures, launches, jobs, min_jobs, calls, inter, hits, late, declined;
+        double ms;
+        svt_hip_hook_md_pre_stats(&pictures, &launches, &jobs, &min_jobs, &calls, &inter, &hits, &late, &declined, &ms);
+        fprintf(stderr, "svt_hip_md_pre pictures=%ld launches=%ld blocks=%ld min_blocks_per_launch=%ld declined=%ld config_thread_ms=%.1f fast_loop_calls=%ld inter=%ld served_from_table=%ld "
+                        "predicted_late=%ld\n", pictures, launches, jobs, min_jobs, declined, ms, calls, inter, hits, late);
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

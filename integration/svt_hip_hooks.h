@@ -7,6 +7,7 @@
  *
  * Which hooks are active is a run-time choice, so that a bitstream mismatch bisects to a stage:
  *   SVT_HIP_HOOKS = comma list of  pa, tf, tf_me, tf_subpel, hme, me, cdef_finish, dlf, dlf_search, cdef_search, cdef_apply, sgr_search, wiener_stats, wiener_try, rest_apply  |  all  |  none
+ *                   (+ the opt-in hooks, which "all" does not select: md_pre, md_tx, md_subpel, encdec_tx, encdec_sb)
  *   SVT_HIP_RTCD  = comma list of per-call dispatch-table entries to replace by their svt_*_hip wrapper
  *                   (include/svt_hip_rtcd.h), e.g. "svt_sad_loop_kernel,svt_av1_selfguided_restoration"  |  all
  *   SVT_HIP_DEVICE = GPU ordinal (default 0);  SVT_HIP_VERBOSE=1 logs every hooked call.
@@ -58,6 +59,9 @@ enum {
                                 * :186) predicted and measured in one launch pair; the tree's control flow stays the reference's.  Opt-in */
     SVT_HIP_HOOK_ENCDEC_SB,    /* encode pass, one launch per SUPERBLOCK: the plain-translation inter blocks of a superblock's final partition are predicted ahead of its block
                                 * loop (av1_encode_decode, EbCodingLoop.c:2262) and the forward transforms of all their transform blocks run in one launch.  Opt-in */
+    SVT_HIP_HOOK_MD_PRE,       /* mode decision, one launch per PICTURE before its mode decision starts: the stage-0 luma distortion (fast_loop_core, EbProductCodingLoop.c:907)
+                                * of every (superblock, square PU, reference picture) at its open-loop ME vector; fast_loop_core reads the table and skips the prediction,
+                                * full_loop_core predicts the survivors (svt_hip_md_bridge.c).  Opt-in */
     SVT_HIP_HOOK_COUNT
 };
 
@@ -197,6 +201,15 @@ long svt_hip_hook_encdec_sb_kernels(void);   /* kernel launches behind those ent
  * argument types live in mcomp.h, which includes this header's dependencies the other way round) */
 int  svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse);
 void svt_hip_hook_md_subpel_end(void);
+/* hook "md_pre" (svt_hip_md_bridge.c): mode_decision_configuration_kernel before it posts the picture; rest_kernel after pad_ref_and_set_flags; fast_loop_core in front of
+ * its prediction (1 = *sad is the luma distortion, no prediction now); full_loop_core where it decides about the inter prediction (1 = the stage-0 prediction is still owed) */
+struct ModeDecisionContext;
+struct ModeDecisionCandidateBuffer;
+void svt_hip_hook_md_pre_picture(PictureControlSet *pcs);
+void svt_hip_hook_md_pre_note_ref(PictureControlSet *pcs);
+int  svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, struct ModeDecisionContext *ctx, struct ModeDecisionCandidateBuffer *cb, uint32_t *sad);
+int  svt_hip_hook_md_pre_take(const struct ModeDecisionCandidateBuffer *cb, int predicted_late);
+void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms);
 int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);
 int  svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff);
 void svt_hip_hook_md_tx_end(void);

@@ -584,8 +584,265 @@ int svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *
 }
 void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Mode decision, hook "md_pre": the stage-0 distortions of a whole PICTURE in one launch, made before the picture's mode decision starts.
+ *
+ * md_stage_0 (EbProductCodingLoop.c:1461) calls fast_loop_core (:907) for every candidate of every block: predict, measure the luma distortion against the source
+ * (svt_nxm_sad_kernel_sub_sampled, :953), add the rate.  The candidates the open-loop ME contributes are known before the picture's first block: in the first
+ * partitioning pass (PD_PASS_0) at presets above M4 the ME vectors enter stage 0 unrefined (read_refine_me_mvs, :2159, with md_sq / md_nsq / pme / sub-pel levels 0,
+ * EbEncDecProcess.c:3050-3093) — full-pel, single reference, plain translation — and a full-pel prediction is a copy of the reference block.  Neither the source,
+ * nor the reference pictures (complete: the picture manager starts a picture only when its references are), nor the ME vectors depend on a neighbouring block,
+ * so svt_hip_hook_md_pre_picture — called once per picture by mode_decision_configuration_kernel, right before it posts the picture to the mode-decision threads
+ * (EbModeDecisionConfigurationProcess.c:1058) — computes the SAD of every (superblock, square PU, reference picture) in ONE launch
+ * (svt_hip_md_fullpel_sad_picture_dev) into a table in page-locked host memory.  The configuration thread waits for it (one upload of the vectors, one launch, one
+ * download, on a pool context); it is a different thread from the mode-decision threads, which are busy with the pictures before this one, so no block ever waits
+ * for the device.  fast_loop_core then asks svt_hip_hook_md_pre_lookup: a candidate whose (PU, reference, vector) is in the table takes its distortion from there and
+ * is NOT predicted.  The rate, the candidate order, every decision stay the reference's.
+ *
+ * The prediction samples of such a candidate are made later, and only if somebody reads them: full_loop_core (:5820) reuses stage 0's prediction when
+ * md_staging_perform_inter_pred is off (always in PD_PASS_0, whose MD_STAGING_MODE_0 has no later prediction; stages 1 / 2 of the other modes) — the patched
+ * full_loop_core asks svt_hip_hook_md_pre_take(candidate_buffer) and, if the buffer still carries the mark, runs the reference's own predictor with stage 0's settings
+ * right there (the survivors of stage 0: one or two per block instead of every candidate).  The mark is a thread-local direct-mapped set of buffer addresses, cleared
+ * whenever fast_loop_core sees the buffer again; a collision is a table miss.
+ *
+ * Exact by construction: the table is keyed by what fast_loop_core is about to compute — block position and size, reference picture, vector — and holds the value
+ * the reference's kernels give for it (tests: device vs oracle vs the reference's svt_nxm_sad_kernel / convolve copy; end-to-end bitstream identity).  A miss — sub-pel or
+ * compound or non-translation candidates, vectors the MV clamp of av1_inter_prediction would move, 128x128 superblocks, scaled references, 10-bit mode decision, later
+ * passes' refined vectors — is the reference's own code. */
+#include "EbCodingLoop.h"   /* me_idx[]: mode-decision block index -> PU index of the open-loop ME results */
+#include "EbModeDecisionProcess.h"
+#include "EbMotionEstimationLcuResults.h"
+#include <pthread.h>
+
+#define PRE_SLOTS 64
+#define PRE_PUS SVT_HIP_SQUARE_PU_COUNT
+typedef struct {
+    PictureControlSet *pcs;
+    uint64_t  picture_number;
+    volatile int ready;
+    int       n_sb, n_refs;
+    int8_t    slot_of[2][4];     /* (list, reference index) -> column of the table, -1 = none */
+    uint32_t *mv;                /* [n_sb][85][n_refs]: the vector in the units of the candidates (1/8 sample), x | y << 16; PRE_NONE = no entry */
+    uint32_t *sad;               /* [n_sb][85][n_refs], page-locked */
+    size_t    cap;               /* entries allocated */
+} MdPre;
+#define PRE_NONE 0x80008000u
+static MdPre           g_pre[PRE_SLOTS];
+static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
+static SvtHipMdPu      g_pre_pu[PRE_PUS];
+static int             g_pre_pu_ok;   /* 0 not built, 1 built, -1 the tables are not what this code expects */
+static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_calls, g_pre_inter, g_pre_hits, g_pre_late, g_pre_declined;
+static long long g_pre_ns;
+static __thread struct { PictureControlSet *pcs; uint64_t pic; MdPre *t; } tls_pre;
+#define PRE_MARKS 1024
+static __thread const void *tls_mark[PRE_MARKS];
+static inline unsigned mark_slot(const void *p) { const uintptr_t a = (uintptr_t)p; return (unsigned)((a >> 6) ^ (a >> 16)) & (PRE_MARKS - 1); }
+
+void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms) {
+    *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = g_pre_calls; *inter = g_pre_inter; *hits = g_pre_hits;
+    *late = g_pre_late; *declined = g_pre_declined; *ms = g_pre_ns / 1e6;
+}
+
+/* PU index of the ME results -> position and size inside a 64x64 superblock, from the reference's own tables (me_idx over the block geometry) */
+static int pre_build_pus(void) {
+    if (g_pre_pu_ok) return g_pre_pu_ok > 0;
+    int seen[PRE_PUS] = {0}, n = 0;
+    for (uint32_t i = 0; i < BLOCK_MAX_COUNT_SB_64; i++) {
+        const BlockGeom *g = get_blk_geom_mds(i);
+        if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) continue;
+        const uint32_t pu = me_idx[i];
+        if (pu >= PRE_PUS || seen[pu]) { g_pre_pu_ok = -1; return 0; }
+        seen[pu] = 1; n++;
+        g_pre_pu[pu].x = (uint8_t)g->origin_x; g_pre_pu[pu].y = (uint8_t)g->origin_y; g_pre_pu[pu].w = g_pre_pu[pu].h = (uint8_t)g->bwidth;
+    }
+    g_pre_pu_ok = n == PRE_PUS ? 1 : -1;
+    return g_pre_pu_ok > 0;
+}
+
+/* the luma plane of `pic` on the device: its resident copy (announced by the writer: *from_table = 1, release it afterwards) or an upload of the whole padded plane */
+static const uint8_t *pre_plane(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int *from_table, void **tmp) {
+    const size_t bytes = (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y);
+    *from_table = 0; *tmp = NULL;
+    const void *d = svt_hip_resident_acquire(hip, pic->buffer_y, bytes);
+    if (d) { *from_table = 1; return (const uint8_t *)d; }
+    if (svt_hip_hooks_malloc(hip, tmp, bytes) != SVT_HIP_OK) { *tmp = NULL; return NULL; }
+    if (svt_hip_memcpy_h2d_async(hip, *tmp, pic->buffer_y, bytes) != SVT_HIP_OK) return NULL;
+    return (const uint8_t *)*tmp;
+}
+
+/* rest_kernel, after pad_ref_and_set_flags (EbRestProcess.c:581): the picture's 8-bit reference planes are final, padding included — the next pictures' tables read the
+ * luma plane, so its device copy is made once per reference picture (the resident table), not once per picture that references it */
+void svt_hip_hook_md_pre_note_ref(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE) || pcs->parent_pcs_ptr->is_used_as_reference_flag != EB_TRUE || !pcs->parent_pcs_ptr->reference_picture_wrapper_ptr) return;
+    const EbReferenceObject *ro = (const EbReferenceObject *)pcs->parent_pcs_ptr->reference_picture_wrapper_ptr->object_ptr;
+    if (ro && ro->reference_picture) svt_hip_hooks_resident_note_picture(ro->reference_picture);
+}
+
+void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return;
+    const long long t0 = svt_hip_hooks_now_ns();
+    PictureParentControlSet *ppcs = pcs->parent_pcs_ptr;
+    const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    /* the picture's slot: found by its control set (a pool object: the table of the picture that used it before is dead by now) */
+    MdPre *t = NULL;
+    pthread_mutex_lock(&g_pre_mu);
+    for (int i = 0; i < PRE_SLOTS && !t; i++) if (g_pre[i].pcs == pcs) t = &g_pre[i];
+    for (int i = 0; i < PRE_SLOTS && !t; i++) if (!g_pre[i].pcs) { t = &g_pre[i]; t->pcs = pcs; }
+    pthread_mutex_unlock(&g_pre_mu);
+    if (!t) { __sync_fetch_and_add(&g_pre_declined, 1); return; }
+    t->ready = 0;
+    __sync_synchronize();
+    t->picture_number = pcs->picture_number;
+    const EbPictureBufferDesc *in = ppcs->enhanced_picture_ptr;
+    int ok = pcs->slice_type != I_SLICE && scs->seq_header.sb_size == BLOCK_64X64 && !ppcs->frame_superres_enabled && in && in->buffer_y && ppcs->pa_me_data &&
+             ppcs->max_number_of_pus_per_sb >= PRE_PUS && pre_build_pus();
+    /* the reference pictures ME searched, in the order of the ME vector array: list 0 at [0, 4), list 1 at [4, 7) (EbMotionEstimationLcuResults.h:44) */
+    const EbPictureBufferDesc *ref_pic[SVT_HIP_MD_MAX_REFS];
+    int ref_col[SVT_HIP_MD_MAX_REFS], n_refs = 0;
+    memset(t->slot_of, -1, sizeof(t->slot_of));
+    for (int li = 0; li < 2 && ok; li++) {
+        const int cnt = li ? ppcs->ref_list1_count_try : ppcs->ref_list0_count_try;
+        for (int ri = 0; ri < cnt && ri < (li ? 3 : 4) && ok; ri++) {
+            const EbObjectWrapper *w = pcs->ref_pic_ptr_array[li][ri];
+            const EbReferenceObject *ro = w ? (const EbReferenceObject *)w->object_ptr : NULL;
+            const EbPictureBufferDesc *rp = ro ? ro->reference_picture : NULL;
+            if (!rp || !rp->buffer_y || rp->width != in->width || rp->height != in->height) { ok = 0; break; }   /* scaled references keep the reference's path */
+            t->slot_of[li][ri] = (int8_t)n_refs; ref_pic[n_refs] = rp; ref_col[n_refs] = li * 4 + ri; n_refs++;
+        }
+    }
+    if (!ok || !n_refs) { if (pcs->slice_type != I_SLICE) __sync_fetch_and_add(&g_pre_declined, 1); return; }
+    const int sb_cols = (ppcs->aligned_width + 63) / 64, n_sb = pcs->sb_total_count;
+    const size_t n = (size_t)n_sb * PRE_PUS * (size_t)n_refs;
+    SvtHipCtx *hip = svt_hip_hooks_lock_any();
+    if (!hip) { __sync_fetch_and_add(&g_pre_declined, 1); return; }
+    int rc = SVT_HIP_OK;
+    if (t->cap < n) {
+        if (t->sad) svt_hip_host_free(hip, t->sad);
+        free(t->mv);
+        t->sad = NULL; t->mv = (uint32_t *)malloc(n * sizeof(uint32_t)); t->cap = 0;
+        void *h = NULL;
+        rc = t->mv ? svt_hip_host_alloc(hip, &h, n * sizeof(uint32_t)) : SVT_HIP_ERR_RUNTIME;
+        if (rc == SVT_HIP_OK) { t->sad = (uint32_t *)h; t->cap = n; }
+    }
+    /* the vectors: table side in the candidates' units (1/8 sample), device side in whole samples */
+    uint32_t *dev_mv = rc == SVT_HIP_OK ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
+    if (rc == SVT_HIP_OK && !dev_mv) rc = SVT_HIP_ERR_RUNTIME;
+    if (rc == SVT_HIP_OK)
+        for (int sb = 0; sb < n_sb; sb++) {
+            const MeSbResults *mr = ppcs->pa_me_data->me_results[sb];
+            for (int pu = 0; pu < PRE_PUS; pu++)
+                for (int r = 0; r < n_refs; r++) {
+                    const MvCandidate m = mr->me_mv_array[pu * MAX_PA_ME_MV + ref_col[r]];
+                    const size_t e = ((size_t)sb * PRE_PUS + pu) * n_refs + r;
+                    if ((m.x_mv | m.y_mv) & 3) { t->mv[e] = PRE_NONE; dev_mv[e] = (uint32_t)(uint16_t)SVT_HIP_MD_NO_MV; continue; }   /* the open-loop search is full-pel */
+                    t->mv[e] = (uint32_t)(uint16_t)(m.x_mv * 2) | (uint32_t)(uint16_t)(m.y_mv * 2) << 16;
+                    dev_mv[e] = (uint32_t)(uint16_t)(m.x_mv >> 2) | (uint32_t)(uint16_t)(m.y_mv >> 2) << 16;
+                }
+        }
+    void *d_mv = NULL, *d_sad = NULL, *tmp[SVT_HIP_MD_MAX_REFS + 1] = {0};
+    int   from_table[SVT_HIP_MD_MAX_REFS + 1] = {0};
+    const uint8_t *d_src = NULL;
+    SvtHipMdRefPlane planes[SVT_HIP_MD_MAX_REFS];
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_mv, n * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_sad, n * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_mv, dev_mv, n * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK) { d_src = pre_plane(hip, in, &from_table[0], &tmp[0]); if (!d_src) rc = SVT_HIP_ERR_RUNTIME; }
+    for (int r = 0; r < n_refs && rc == SVT_HIP_OK; r++) {
+        const EbPictureBufferDesc *rp = ref_pic[r];
+        const uint8_t *d = pre_plane(hip, rp, &from_table[1 + r], &tmp[1 + r]);
+        if (!d) { rc = SVT_HIP_ERR_RUNTIME; break; }
+        planes[r].d_plane = d + (size_t)rp->origin_y * rp->stride_y + rp->origin_x;
+        planes[r].stride = rp->stride_y;
+        planes[r].x_min = -(int)rp->origin_x; planes[r].y_min = -(int)rp->origin_y;
+        planes[r].x_max = (int)rp->width + (int)rp->origin_x; planes[r].y_max = (int)rp->height + (int)rp->origin_y;
+    }
+    if (rc == SVT_HIP_OK)
+        rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)d_mv, (uint32_t *)d_sad);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, t->sad, d_sad, n * sizeof(uint32_t));   /* drains the context */
+    else (void)svt_hip_sync(hip);
+    if (from_table[0]) svt_hip_resident_release(in->buffer_y);
+    for (int r = 0; r < n_refs; r++) if (from_table[1 + r]) svt_hip_resident_release(ref_pic[r]->buffer_y);
+    for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
+    svt_hip_hooks_free(hip, d_mv); svt_hip_hooks_free(hip, d_sad);
+    svt_hip_hooks_unlock_any();
+    free(dev_mv);
+    svt_hip_hooks_count(SVT_HIP_HOOK_MD_PRE, rc == SVT_HIP_OK);
+    if (rc == SVT_HIP_OK) {
+        t->n_sb = n_sb; t->n_refs = n_refs;
+        __sync_synchronize();
+        t->ready = 1;
+        __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1); __sync_fetch_and_add(&g_pre_jobs, (long)n);
+        pthread_mutex_lock(&g_pre_mu);
+        if (!g_pre_min_jobs || (long)n < g_pre_min_jobs) g_pre_min_jobs = (long)n;
+        pthread_mutex_unlock(&g_pre_mu);
+    }
+    __sync_fetch_and_add(&g_pre_ns, svt_hip_hooks_now_ns() - t0);
+}
+
+/* fast_loop_core, in front of the prediction: 1 = *sad is the candidate's luma distortion (svt_nxm_sad_kernel_sub_sampled of its prediction) and the prediction is
+ * NOT to be made now (svt_hip_hook_md_pre_take tells full_loop_core when it is needed after all) */
+int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx, ModeDecisionCandidateBuffer *cb, uint32_t *sad) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
+    const unsigned ms = mark_slot(cb);
+    if (tls_mark[ms] == cb) tls_mark[ms] = NULL;   /* the buffer gets a new candidate: whatever it was marked for is gone */
+    __sync_fetch_and_add(&g_pre_calls, 1);
+    const ModeDecisionCandidate *c = cb->candidate_ptr;
+    if (c->type != INTER_MODE || c->use_intrabc) return 0;
+    __sync_fetch_and_add(&g_pre_inter, 1);
+    if (c->is_compound || c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used || ctx->hbd_mode_decision || !ctx->md_staging_skip_chroma_pred ||
+        !ctx->md_staging_skip_interpolation_search)
+        return 0;
+    const BlockGeom *g = ctx->blk_geom;
+    if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) return 0;
+    if (tls_pre.pcs != pcs || tls_pre.pic != pcs->picture_number) {
+        tls_pre.pcs = pcs; tls_pre.pic = pcs->picture_number; tls_pre.t = NULL;
+        for (int i = 0; i < PRE_SLOTS; i++)
+            if (g_pre[i].pcs == pcs) { if (g_pre[i].ready && g_pre[i].picture_number == pcs->picture_number) tls_pre.t = &g_pre[i]; break; }
+    }
+    const MdPre *t = tls_pre.t;
+    if (!t) return 0;
+    const uint32_t pu = ctx->me_block_offset, sb = ctx->me_sb_addr;
+    if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) return 0;
+    MvReferenceFrame rf[2];
+    av1_set_ref_frame(rf, c->ref_frame_type);
+    if (rf[1] != NONE_FRAME) return 0;
+    const int li = get_list_idx(rf[0]), ri = get_ref_frame_idx(rf[0]);
+    if (li < 0 || li > 1 || ri < 0 || ri > 3 || c->prediction_direction[0] != li) return 0;
+    const int col = t->slot_of[li][ri];
+    if (col < 0) return 0;
+    const int16_t mx = li ? c->motion_vector_xl1 : c->motion_vector_xl0, my = li ? c->motion_vector_yl1 : c->motion_vector_yl0;
+    const size_t e = ((size_t)sb * PRE_PUS + pu) * (size_t)t->n_refs + (size_t)col;
+    if (t->mv[e] != ((uint32_t)(uint16_t)mx | (uint32_t)(uint16_t)my << 16) || t->sad[e] == 0xffffffffu) return 0;
+    /* av1_inter_prediction clamps the vector so that the block stays within (block size + AOM_INTERP_EXTEND) samples of the picture (clamp_mv_to_umv_border_sb,
+     * Common/Codec/EbInterPrediction.h): a vector it would move is not what the table measured */
+    const int bx = (int)ctx->blk_origin_x + (mx >> 3), by = (int)ctx->blk_origin_y + (my >> 3), bw = g->bwidth;
+    const int pic_w = (int)pcs->parent_pcs_ptr->av1_cm->mi_cols * 4, pic_h = (int)pcs->parent_pcs_ptr->av1_cm->mi_rows * 4;
+    if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) return 0;
+    if (tls_mark[ms]) return 0;   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
+    tls_mark[ms] = cb;
+    *sad = t->sad[e];
+    __sync_fetch_and_add(&g_pre_hits, 1);
+    return 1;
+}
+/* full_loop_core, where it decides whether to predict an inter candidate: 1 = the buffer's stage-0 prediction was skipped (svt_hip_hook_md_pre_lookup) and nobody has made
+ * it since; the mark is dropped either way */
+int svt_hip_hook_md_pre_take(const ModeDecisionCandidateBuffer *cb, int predicted_late) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
+    const unsigned ms = mark_slot(cb);
+    if (tls_mark[ms] != cb) return 0;
+    tls_mark[ms] = NULL;
+    if (predicted_late) __sync_fetch_and_add(&g_pre_late, 1);
+    return 1;
+}
+
 /* the shared staging buffers of the three hooks above (svt_hip_hooks_enc_deinit) */
 void svt_hip_md_bridge_release(SvtHipCtx *hip) {
     void **all[] = {&d_src, &d_pred, &d_desc, &d_coeff, &d_sp_ref, &d_sp_src, &d_sp_pred, &d_sp_job, &d_sp_out};
     for (unsigned i = 0; i < sizeof(all) / sizeof(all[0]); i++) { svt_hip_free(hip, *all[i]); *all[i] = NULL; }
+    for (int i = 0; i < PRE_SLOTS; i++) {   /* the picture tables of hook "md_pre" */
+        if (g_pre[i].sad) svt_hip_host_free(hip, g_pre[i].sad);
+        free(g_pre[i].mv);
+        memset(&g_pre[i], 0, sizeof(g_pre[i]));
+    }
 }

@@ -70,6 +70,10 @@ typedef struct {
 OrcSearchWindow orc_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center,
                                      int sa_width, int sa_height, int pic_width, int pic_height);
 
+/* md_oracle.c: mode decision stage 0, full-pel single-reference candidates (fast_loop_core, EbProductCodingLoop.c:907) */
+uint32_t orc_md_fullpel_candidate(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int x, int y, int w, int h, int mx, int my);
+void orc_md_fullpel_sad_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                const uint8_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, uint32_t *sad);
 /* Frame driver used by tests/bench: loops orc_me_fullpel_sb over all SBs.
  * planes are the *padded* luma pictures; (org_x,org_y) is the offset of pixel (0,0) in them. */
 typedef struct {

@@ -62,6 +62,16 @@ class WienerWalkPlane(C.Structure):
                 ("d_err", C.c_void_p), ("d_probes", C.c_void_p)]
 
 
+class MdPu(C.Structure):
+    """SvtHipMdPu (include/svt_hip.h)."""
+    _fields_ = [("x", C.c_uint8), ("y", C.c_uint8), ("w", C.c_uint8), ("h", C.c_uint8)]
+
+
+class MdRefPlane(C.Structure):
+    """SvtHipMdRefPlane (include/svt_hip.h)."""
+    _fields_ = [("d_plane", C.c_void_p), ("stride", C.c_int32), ("x_min", C.c_int32), ("y_min", C.c_int32), ("x_max", C.c_int32), ("y_max", C.c_int32)]
+
+
 class BlkPair(C.Structure):
     """SvtHipBlkPair (include/svt_hip.h)."""
     _fields_ = [("a_x", C.c_int32), ("a_y", C.c_int32), ("b_x", C.c_int32), ("b_y", C.c_int32), ("w", C.c_uint16), ("h", C.c_uint16)]
@@ -188,6 +198,7 @@ def lib():
     L.svt_hip_deblock_plane_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]
     L.svt_hip_subpel_predict_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32]
     L.svt_hip_block_sad_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
+    L.svt_hip_md_fullpel_sad_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_block_variance_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]
     L.svt_hip_coeff_distortion_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp]
     L.svt_hip_block_sse_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]

@@ -239,7 +239,7 @@ int svt_hip_host_free(SvtHipCtx* c, void* host) {
     if (host) HIPCHK(c, hipHostFree(host));
     return SVT_HIP_OK;
 }
-#define SVT_HIP_TUS(X) X(cdef) X(compound) X(conv) X(deblock) X(distortion) X(format) X(me_fullpel) X(percall) X(percall2) X(pyramid) X(sgr) X(sgr_walk) X(tf_subpel) \
+#define SVT_HIP_TUS(X) X(cdef) X(compound) X(conv) X(deblock) X(distortion) X(format) X(md_pre) X(me_fullpel) X(percall) X(percall2) X(pyramid) X(sgr) X(sgr_walk) X(tf_subpel) \
     X(tfilter) X(txfm2d) X(warp) X(wiener)
 #define X(n) int svt_hip_tu_probe_##n();
 SVT_HIP_TUS(X)
@@ -608,6 +608,20 @@ int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, in
     if (!c || !d_a || !d_b || !d_pairs || !d_sad || n < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;
     hipError_t e = (hipError_t)svt_hip_launch_block_sad(c->stream, pix_bytes, d_a, a_stride, d_b, b_stride, d_pairs, n, d_sad);
     if (e != hipSuccess) return fail(c, e, "block sad launch");
+    return SVT_HIP_OK;
+}
+int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                       int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, uint32_t* d_sad) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_src || !pus || !refs || !d_mv || !d_sad || n_sb < 0 || sb_cols < 1 || pic_w < 1 || pic_h < 1 || n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 ||
+        n_refs > SVT_HIP_MD_MAX_REFS)
+        return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_pus; i++)
+        if (pus[i].w < 4 || pus[i].w > 64 || (pus[i].w & 3) || pus[i].h < 1 || pus[i].h > 64 || pus[i].x + pus[i].w > 64 || pus[i].y + pus[i].h > 64) return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_refs; i++)
+        if (!refs[i].d_plane || refs[i].stride < 1) return SVT_HIP_ERR_BAD_ARG;
+    hipError_t e = (hipError_t)svt_hip_launch_md_fullpel_sad(c->stream, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, d_sad);
+    if (e != hipSuccess) return fail(c, e, "md full-pel sad launch");
     return SVT_HIP_OK;
 }
 int svt_hip_coeff_distortion_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, const int32_t* d_recon_coeff, int n_per_block, int nblk, uint64_t* d_out) {

@@ -259,6 +259,70 @@ def test_md_tx_type_search_hook_on_gpu(workdir):
     assert "svt_hip MOCK" not in got["log"] and got["hooks"]["md_tx"][0] > 100, got["hooks"]
 
 
+def _md_pre_line(log):
+    m = re.search(r"svt_hip_md_pre pictures=(\d+) launches=(\d+) blocks=(\d+) min_blocks_per_launch=(\d+) declined=(\d+) config_thread_ms=[0-9.]+ fast_loop_calls=(\d+) inter=(\d+) "
+                  r"served_from_table=(\d+) predicted_late=(\d+)", log)
+    assert m, log[-1500:]
+    return dict(zip(("pictures", "launches", "blocks", "min_blocks", "declined", "calls", "inter", "served", "late"), map(int, m.groups())))
+
+
+def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p_8bit_m7", "328x200_8bit_m6", "cif_10bit_m8")):
+    """hook "md_pre" (opt-in): ONE launch per picture, before the picture's mode decision starts, computes the stage-0 luma distortion of every (superblock, square PU,
+    reference picture) at its open-loop ME vector; fast_loop_core (EbProductCodingLoop.c:907) reads the table instead of predicting + measuring, full_loop_core predicts
+    the survivors.  Identical bitstream / reconstruction; every launch covers far more than 256 blocks; most of mode decision's inter fast-loop calls are served."""
+    out = {}
+    for case in cases:
+        spec = {**CASES, **GPU_ONLY_CASES}[case]
+        got = _check(case, spec[:6] + ({"md_pre"},), workdir, env, tag + "_" + case)
+        st = _md_pre_line(got["log"])
+        assert st["pictures"] > 0 and st["launches"] == st["pictures"] and st["min_blocks"] >= 256, st
+        if spec[3] == 8:
+            assert st["served"] * 2 > st["inter"], f"{case}: fewer than half of the inter fast-loop calls were served from the table: {st}"
+        else:   # 10-bit input: this version's first pass decides on 16-bit samples (hbd_mode_decision), which the 8-bit table does not serve -- the reference's path, same output
+            assert st["served"] == 0
+        print(f"md_pre {case}: {st}")
+        out[case] = got
+    return out
+
+
+def test_md_pre_hook_on_cpu_test_double(workdir):
+    _check_md_pre(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}, "mock_mdpre")
+    # with every other hook as well, and with the slower presets, whose first pass refines the vectors (nothing to serve: the reference's path, same bitstream)
+    for case, hooks in (("cif_8bit_m6", "all,md_pre"), ("cif_8bit_m4", "all,md_pre,md_subpel")):
+        both = _check(case, CASES[case][:6] + (ALL | {"md_pre"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": hooks}, "mock_all_mdpre")
+        assert both["hooks"]["md_pre"][0] > 0
+
+
+def test_md_pre_hook_matters(workdir):
+    """a wrong distortion out of the picture's table changes the encode: stage 0 really consumes it"""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_mdpre"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre", "SVT_HIP_MOCK_PERTURB": "md_pre"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+
+
+def test_md_pre_variants_on_cpu_test_double(workdir):
+    """128 x 128 superblocks (the hook declines: the reference's path), a padded source size, several reference pictures per list"""
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}
+    got = _check_geometry("sb128_mdpre", 640, 360, 3, 8, 4, 42, 13, workdir, env, "mock", must=set())
+    assert _md_pre_line(got["log"])["served"] == 0
+    got = _check_geometry("padded_mdpre", 130, 66, 5, 8, 6, 38, 11, workdir, env, "mock", must={"md_pre"})
+    assert _md_pre_line(got["log"])["served"] > 0
+    got = _check_geometry("lowdelay_mdpre", 352, 288, 6, 8, 6, 40, 23, workdir, env, "mock", must={"md_pre"}, extra=["--pred-struct", "1"])
+    assert _md_pre_line(got["log"])["served"] > 0
+
+
+@pytest.mark.gpu
+def test_md_pre_hook_on_gpu(workdir):
+    got = _check_md_pre(workdir, {"SVT_HIP_HOOKS": "md_pre"}, "hip_mdpre", cases=("cif_8bit_m6", "cif_10bit_m6", "360p_8bit_m7", "720p_8bit_m6", "cif_8bit_18_frames", "cif_10bit_m8"))
+    assert all("svt_hip MOCK" not in g["log"] for g in got.values())
+    case = "720p_8bit_m6"
+    both = _check(case, GPU_ONLY_CASES[case][:6] + (ALL | {"md_pre"},), workdir, {"SVT_HIP_HOOKS": "all,md_pre"}, "hip_all_mdpre")
+    assert "svt_hip MOCK" not in both["log"] and _md_pre_line(both["log"])["served"] > 1000
+
+
 @pytest.mark.parametrize("hooks", ["hme", "me"])
 def test_motion_estimation_hooks_one_at_a_time_on_cpu_test_double(hooks, workdir):
     """The segment's SB loop runs a different pass sequence for every combination of the two ME hooks (svt_hip_me_bridge.c): "hme" alone = three
@@ -388,15 +452,15 @@ def _check_variant(name, workdir, env, tag):
     return got
 
 
-def _check_geometry(name, w, h, n, bd, preset, q, seed, workdir, env, tag, must=None):
+def _check_geometry(name, w, h, n, bd, preset, q, seed, workdir, env, tag, must=None, extra=()):
     """hooked vs unpatched encoder on one more picture geometry: identical output, every hook the preset uses handled, nothing handed back"""
     clip = os.path.join(workdir, name + ".src.yuv")
     if not os.path.exists(clip):
         E.make_clip(clip, w, h, n, seed=seed, bd=bd)
     if name not in _ref_cache:
-        _ref_cache[name] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".ref"))
+        _ref_cache[name] = E.encode(E.APP_REF, clip, w, h, n, preset, q, bd, os.path.join(workdir, name + ".ref"), extra_args=extra)
     ref = _ref_cache[name]
-    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{name}.{tag}"), env_extra=env)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{name}.{tag}"), env_extra=env, extra_args=extra)
     assert got["ivf"] == ref["ivf"], f"{name}: bitstream differs from the reference encoder\n" + got["log"][-2000:]
     assert got["recon"] == ref["recon"], f"{name}: reconstruction differs from the reference encoder"
     for hk in (ALL if must is None else must):

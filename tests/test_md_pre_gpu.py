@@ -1,0 +1,60 @@
+"""GPU parity: the picture-level mode-decision precompute (svt_hip_md_fullpel_sad_picture_dev, svt-av1_amd/csrc/md_pre.hip) vs the oracle (oracle/md_oracle.c, pinned to
+the reference's svt_av1_convolve_2d_copy_sr_c + svt_nxm_sad_kernel_helper_c by tests/test_oracle_vs_ref.py::test_md_fullpel_candidate).  What fast_loop_core
+(EbProductCodingLoop.c:907) computes for a full-pel single-reference candidate, for every (superblock, PU, reference) of a picture in one launch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import md_common as M
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(hip, pkg, src, refs, pus, mv, sb_cols, n_sb, pad, pic_w, pic_h):
+    n_refs = len(refs)
+    d_src, d_mv = hip.to_device(src), hip.to_device(mv)
+    d_refs = [hip.to_device(r) for r in refs]
+    d_sad = hip.empty(mv.size * 4)
+    pu_arr = (pkg.MdPu * len(pus))(*[pkg.MdPu(*p) for p in pus])
+    planes = (pkg.MdRefPlane * n_refs)()
+    for r in range(n_refs):
+        planes[r] = pkg.MdRefPlane(d_refs[r].value + pad * refs[r].shape[1] + pad, refs[r].shape[1], -pad, -pad, refs[r].shape[1] - pad, refs[r].shape[0] - pad)
+    hip.check(hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, d_src, src.shape[1], pic_w, pic_h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, d_sad), "md pre")
+    got = hip.to_host(d_sad, mv.shape, np.uint32)
+    hip.free(d_src, d_mv, d_sad, *d_refs)
+    return got
+
+
+@pytest.mark.parametrize("w,h,n_refs", [(336, 208, 3), (64, 64, 1), (200, 152, 7), (1280, 720, 2)])
+def test_md_fullpel_sad_picture(hip, pkg, orc, w, h, n_refs):
+    """whole pictures incl. partial last superblock rows / columns, 1..7 references, missing vectors, vectors that leave the allocation, an odd source stride"""
+    rng = np.random.default_rng(w * 7 + h + n_refs)
+    src, refs, pus, mv, sb_cols, n_sb, pad = M.make_case(rng, w, h, n_refs)
+    exp = M.oracle_table(orc, src, refs, pus, mv, sb_cols, n_sb, pad, w, h)
+    got = run_hip(hip, pkg, src, refs, pus, mv, sb_cols, n_sb, pad, w, h)
+    assert (exp == 0xffffffff).any() and (exp != 0xffffffff).any()
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
+
+
+def test_md_fullpel_sad_other_pu_lists(hip, pkg, orc):
+    """the PU list is an argument: rectangular PUs (64x32, 16x64, 4x16 ...) and a list of one"""
+    rng = np.random.default_rng(5)
+    src, refs, _, _, sb_cols, n_sb, pad = M.make_case(rng, 256, 128, 2)
+    for pus in ([(0, 0, 64, 32), (0, 32, 64, 32), (16, 0, 16, 64), (4, 8, 4, 16), (60, 60, 4, 4), (8, 0, 48, 1)], [(32, 32, 32, 32)]):
+        mvx = rng.integers(-20, 21, (n_sb, len(pus), 2)).astype(np.int16); mvy = rng.integers(-20, 21, (n_sb, len(pus), 2)).astype(np.int16)
+        mv = np.ascontiguousarray(mvx.astype(np.uint16).astype(np.uint32) | (mvy.astype(np.uint16).astype(np.uint32) << 16))
+        exp = M.oracle_table(orc, src, refs, pus, mv, sb_cols, n_sb, pad, 256, 128)
+        got = run_hip(hip, pkg, src, refs, pus, mv, sb_cols, n_sb, pad, 256, 128)
+        assert np.array_equal(got, exp)
+
+
+def test_md_fullpel_sad_bad_arguments(hip, pkg):
+    buf = hip.empty(4096)
+    pu = (pkg.MdPu * 1)(pkg.MdPu(0, 0, 6, 8))   # width not a multiple of 4
+    pl = (pkg.MdRefPlane * 1)(pkg.MdRefPlane(buf.value, 64, 0, 0, 64, 64))
+    assert hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, buf, 64, 64, 64, 1, 1, 1, pu, 1, pl, buf, buf) != 0
+    pu[0] = pkg.MdPu(0, 0, 8, 8)
+    assert hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, buf, 64, 64, 64, 1, 1, 1, pu, 8, pl, buf, buf) != 0   # more references than SVT_HIP_MD_MAX_REFS
+    assert hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, buf, 64, 64, 64, 1, 0, 1, pu, 1, pl, buf, buf) == 0    # no superblocks: nothing to do
+    hip.free(buf)

@@ -80,6 +80,50 @@ def test_sad_loop_and_nxm(orc, ref):
         assert ref.svt_fast_loop_nxm_sad_kernel(ptr(src), bw, ptr(refb), rs, bh, bw) == orc.orc_nxm_sad(ptr(src), bw, ptr(refb), rs, bh, bw)
 
 
+def test_md_fullpel_candidate(orc, ref):
+    """oracle/md_oracle.c vs the two reference kernels fast_loop_core (EbProductCodingLoop.c:907) runs for a full-pel single-reference candidate: the prediction
+    svt_av1_convolve_2d_copy_sr_c (what svt_inter_predictor's table holds at [0][0][0]) and the distortion svt_nxm_sad_kernel_helper_c (= svt_nxm_sad_kernel_sub_sampled's
+    C pointer, aom_dsp_rtcd.c:372).  Then the table form against its own per-candidate function."""
+    import md_common as M
+    rng = np.random.default_rng(31)
+    orc.orc_md_fullpel_candidate.restype = C.c_uint32
+    ref.svt_nxm_sad_kernel_helper_c.restype = C.c_uint32
+    cp = _ConvP(); cp.round_0 = 3; cp.round_1 = 11
+    fx = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[0])), 8, 16, 0)
+    pad = 48
+    src = rng.integers(0, 256, (192, 256), dtype=np.uint8)
+    refp = rng.integers(0, 256, (192 + 2 * pad, 256 + 2 * pad), dtype=np.uint8)
+    refp[pad:pad + 64, pad:pad + 64] = 255; src[:64, :64] = 0
+    for it in range(200):
+        s = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (256 - s) // 8 + 1)) * 8; y = int(rng.integers(0, (192 - s) // 8 + 1)) * 8
+        mx, my = (0, 0) if it < 4 else (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        if it < 4: x = y = 0; s = 64
+        pred = np.zeros((s, s), np.uint8)
+        rp = C.c_void_p(refp.ctypes.data + (pad + y + my) * refp.shape[1] + pad + x + mx)
+        ref.svt_av1_convolve_2d_copy_sr_c(rp, refp.shape[1], ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp))
+        e = ref.svt_nxm_sad_kernel_helper_c(C.c_void_p(src.ctypes.data + y * 256 + x), 256, ptr(pred), s, s, s)
+        g = orc.orc_md_fullpel_candidate(ptr(src), 256, C.c_void_p(refp.ctypes.data + pad * refp.shape[1] + pad), refp.shape[1], x, y, s, s, mx, my)
+        assert e == g, (it, x, y, s, mx, my)
+    # the table: every computed slot equals the per-candidate function, every other slot says so
+    src2, refs, pus, mv, sb_cols, n_sb, pad2 = M.make_case(rng, 200, 152, 3)
+    tab = M.oracle_table(orc, src2, refs, pus, mv, sb_cols, n_sb, pad2, 200, 152)
+    n_done = 0
+    for sb in range(n_sb):
+        for p, (px, py, pw, ph) in enumerate(pus):
+            for r in range(3):
+                x, y = (sb % sb_cols) * 64 + px, (sb // sb_cols) * 64 + py
+                mx = int(np.int16(mv[sb, p, r] & 0xffff)); my = int(np.int16(mv[sb, p, r] >> 16))
+                inside = x + pw <= 200 and y + ph <= 152 and mx != -32768 and x + mx >= -pad2 and y + my >= -pad2 and x + mx + pw + 4 <= refs[r].shape[1] - pad2 and y + my + ph <= refs[r].shape[0] - pad2
+                if not inside:
+                    assert tab[sb, p, r] == 0xffffffff
+                    continue
+                n_done += 1
+                assert tab[sb, p, r] == orc.orc_md_fullpel_candidate(ptr(src2), src2.shape[1], C.c_void_p(refs[r].ctypes.data + pad2 * refs[r].shape[1] + pad2), refs[r].shape[1],
+                                                                     x, y, pw, ph, mx, my)
+    assert n_done > 1000
+
+
 # ------------------------------------------------------------------------------------ transforms
 import txfm_common as tc
 
