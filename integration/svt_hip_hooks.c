@@ -302,7 +302,7 @@ void svt_hip_hooks_report(void) {
         double ms;
         svt_hip_hook_md_pre_stats(&pictures, &launches, &jobs, &min_jobs, &calls, &inter, &hits, &late, &declined, &ms);
         fprintf(stderr, "svt_hip_md_pre pictures=%ld launches=%ld blocks=%ld min_blocks_per_launch=%ld declined=%ld config_thread_ms=%.1f fast_loop_calls=%ld inter=%ld served_from_table=%ld "
-                        "predicted_late=%ld\n", pictures, launches, jobs, min_jobs, declined, ms, calls, inter, hits, late);
+                        "predicted_late=%ld verify_mismatches=%ld\n", pictures, launches, jobs, min_jobs, declined, ms, calls, inter, hits, late, svt_hip_hook_md_pre_mismatches());
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

@@ -208,6 +208,9 @@ struct ModeDecisionCandidateBuffer;
 void svt_hip_hook_md_pre_picture(PictureControlSet *pcs);
 void svt_hip_hook_md_pre_note_ref(PictureControlSet *pcs);
 int  svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, struct ModeDecisionContext *ctx, struct ModeDecisionCandidateBuffer *cb, uint32_t *sad);
+/* 2 (SVT_HIP_MD_PRE_VERIFY=1, tests) = a table hit the caller computes itself as well and reports to svt_hip_hook_md_pre_verify */
+void svt_hip_hook_md_pre_verify(PictureControlSet *pcs, struct ModeDecisionContext *ctx, struct ModeDecisionCandidateBuffer *cb, uint32_t table_sad, uint32_t ref_sad);
+long svt_hip_hook_md_pre_mismatches(void);   /* -1 = not verifying */
 int  svt_hip_hook_md_pre_take(const struct ModeDecisionCandidateBuffer *cb, int predicted_late);
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms);
 int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);

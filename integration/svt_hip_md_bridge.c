@@ -603,7 +603,9 @@ void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
  * md_staging_perform_inter_pred is off (always in PD_PASS_0, whose MD_STAGING_MODE_0 has no later prediction; stages 1 / 2 of the other modes) — the patched
  * full_loop_core asks svt_hip_hook_md_pre_take(candidate_buffer) and, if the buffer still carries the mark, runs the reference's own predictor with stage 0's settings
  * right there (the survivors of stage 0: one or two per block instead of every candidate).  The mark is a thread-local direct-mapped set of buffer addresses, cleared
- * whenever fast_loop_core sees the buffer again; a collision is a table miss.
+ * whenever fast_loop_core sees the buffer again; a collision is a table miss.  What the reference's predictor leaves behind besides samples — the warped-motion sample count
+ * of the candidate, which the fast cost reads (wm_count_samples, EbEncInterPrediction.c:6285-6297), and ifs_is_regular_last — the patched fast_loop_core does itself on a hit.
+ * SVT_HIP_MD_PRE_VERIFY=1 (tests) makes every hit compute the reference's value as well and counts disagreements (svt_hip_hook_md_pre_verify).
  *
  * Exact by construction: the table is keyed by what fast_loop_core is about to compute — block position and size, reference picture, vector — and holds the value
  * the reference's kernels give for it (tests: device vs oracle vs the reference's svt_nxm_sad_kernel / convolve copy; end-to-end bitstream identity).  A miss — sub-pel or
@@ -633,11 +635,14 @@ static SvtHipMdPu      g_pre_pu[PRE_PUS];
 static int             g_pre_pu_ok;   /* 0 not built, 1 built, -1 the tables are not what this code expects */
 static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_calls, g_pre_inter, g_pre_hits, g_pre_late, g_pre_declined;
 static long long g_pre_ns;
+static long g_pre_mismatch;
+static int  g_pre_verify = -1;
 static __thread struct { PictureControlSet *pcs; uint64_t pic; MdPre *t; } tls_pre;
 #define PRE_MARKS 1024
 static __thread const void *tls_mark[PRE_MARKS];
 static inline unsigned mark_slot(const void *p) { const uintptr_t a = (uintptr_t)p; return (unsigned)((a >> 6) ^ (a >> 16)) & (PRE_MARKS - 1); }
 
+long svt_hip_hook_md_pre_mismatches(void) { return g_pre_verify > 0 ? g_pre_mismatch : -1; }
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms) {
     *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = g_pre_calls; *inter = g_pre_inter; *hits = g_pre_hits;
     *late = g_pre_late; *declined = g_pre_declined; *ms = g_pre_ns / 1e6;
@@ -784,6 +789,7 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
  * NOT to be made now (svt_hip_hook_md_pre_take tells full_loop_core when it is needed after all) */
 int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx, ModeDecisionCandidateBuffer *cb, uint32_t *sad) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
+    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") && atoi(getenv("SVT_HIP_MD_PRE_VERIFY"));
     const unsigned ms = mark_slot(cb);
     if (tls_mark[ms] == cb) tls_mark[ms] = NULL;   /* the buffer gets a new candidate: whatever it was marked for is gone */
     __sync_fetch_and_add(&g_pre_calls, 1);
@@ -820,10 +826,20 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     const int pic_w = (int)pcs->parent_pcs_ptr->av1_cm->mi_cols * 4, pic_h = (int)pcs->parent_pcs_ptr->av1_cm->mi_rows * 4;
     if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) return 0;
     if (tls_mark[ms]) return 0;   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
-    tls_mark[ms] = cb;
     *sad = t->sad[e];
     __sync_fetch_and_add(&g_pre_hits, 1);
+    if (g_pre_verify) return 2;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the candidate as well and svt_hip_hook_md_pre_verify compares */
+    tls_mark[ms] = cb;
     return 1;
+}
+/* SVT_HIP_MD_PRE_VERIFY=1 (tests): fast_loop_core computed the candidate itself after a table hit; the two distortions must agree */
+void svt_hip_hook_md_pre_verify(PictureControlSet *pcs, ModeDecisionContext *ctx, ModeDecisionCandidateBuffer *cb, uint32_t table_sad, uint32_t ref_sad) {
+    if (table_sad == ref_sad) return;
+    const ModeDecisionCandidate *c = cb->candidate_ptr;
+    if (__sync_fetch_and_add(&g_pre_mismatch, 1) < 10)
+        fprintf(stderr, "svt_hip_md_pre MISMATCH picture=%llu sb=%u pu=%u blk=(%u,%u) %ux%u ref_type=%d dir=%d mv0=(%d,%d) mv1=(%d,%d) table=%u reference=%u pd_pass=%d\n",
+                (unsigned long long)pcs->picture_number, ctx->me_sb_addr, ctx->me_block_offset, ctx->blk_origin_x, ctx->blk_origin_y, ctx->blk_geom->bwidth, ctx->blk_geom->bheight,
+                c->ref_frame_type, c->prediction_direction[0], c->motion_vector_xl0, c->motion_vector_yl0, c->motion_vector_xl1, c->motion_vector_yl1, table_sad, ref_sad, ctx->pd_pass);
 }
 /* full_loop_core, where it decides whether to predict an inter candidate: 1 = the buffer's stage-0 prediction was skipped (svt_hip_hook_md_pre_lookup) and nobody has made
  * it since; the mark is dropped either way */

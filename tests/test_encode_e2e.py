@@ -293,6 +293,18 @@ def test_md_pre_hook_on_cpu_test_double(workdir):
         assert both["hooks"]["md_pre"][0] > 0
 
 
+def test_md_pre_full_mini_gop_and_self_check_on_cpu_test_double(workdir):
+    """A complete hierarchical mini-GOP (nine frames: B pictures with two reference lists, warped motion allowed -- the fast cost of stage 0 then reads the candidate's
+    warped-motion sample count, which the reference's predictor computes on the side and a table hit has to supply), and the hook's self check: with
+    SVT_HIP_MD_PRE_VERIFY=1 every table hit is computed by the reference's own code as well and must agree."""
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}
+    got = _check_geometry("gop9_mdpre", 352, 288, 9, 8, 6, 38, 29, workdir, env, "mock", must={"md_pre"})
+    st = _md_pre_line(got["log"])
+    assert st["served"] * 2 > st["inter"] and st["late"] > 0, st
+    got = _check_geometry("gop9_mdpre", 352, 288, 9, 8, 6, 38, 29, workdir, {**env, "SVT_HIP_MD_PRE_VERIFY": "1"}, "mock_verify", must={"md_pre"})
+    assert re.search(r"served_from_table=[1-9]\d* predicted_late=0 verify_mismatches=0\b", got["log"]), got["log"][-800:]
+
+
 def test_md_pre_hook_matters(workdir):
     """a wrong distortion out of the picture's table changes the encode: stage 0 really consumes it"""
     case = "cif_8bit_m6"
@@ -933,6 +945,36 @@ def test_simd_build_of_the_reference_and_hooks_on_top_of_it(case, workdir):
     got = E.encode(APP_HIP_SIMD, clip, w, h, n, preset, q, bd, os.path.join(workdir, case + ".hipsimd"), env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "all"})
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"])
     assert all(got["hooks"].get(hk, (0, 0))[0] > 0 and got["hooks"][hk][1] == 0 for hk in must), got["hooks"]
+
+
+def _check_md_pre_720p_gop(workdir, env, tag):
+    """1280 x 720, nine frames (a complete hierarchical mini-GOP), preset 6, on the SIMD build: the case in which a table hit that did not supply the candidate's warped-motion
+    sample count (the reference's predictor computes it on the side, the fast cost of the later passes reads it) changed the bitstream -- found on the MI355X in round 5"""
+    clip = os.path.join(workdir, "720p_gop9.src.yuv")
+    if not os.path.exists(clip):
+        E.make_clip(clip, 1280, 720, 9, seed=3, bd=8)
+    if "720p_gop9" not in _ref_cache:
+        _ref_cache["720p_gop9"] = E.encode(APP_SIMD, clip, 1280, 720, 9, 6, 36, 8, os.path.join(workdir, "720p_gop9.simd"))
+    ref = _ref_cache["720p_gop9"]
+    got = E.encode(APP_HIP_SIMD, clip, 1280, 720, 9, 6, 36, 8, os.path.join(workdir, "720p_gop9." + tag), env_extra=env)
+    assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"]), got["log"][-1500:]
+    st = _md_pre_line(got["log"])
+    assert got["hooks"]["md_pre"] == (8, 0) and st["served"] * 2 > st["inter"], (got["hooks"], st)
+    return got
+
+
+@need_simd
+def test_md_pre_720p_mini_gop_on_cpu_test_double(workdir):
+    _check_md_pre_720p_gop(workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}, "mock_mdpre")
+
+
+@need_simd
+@pytest.mark.gpu
+def test_md_pre_720p_mini_gop_on_gpu(workdir):
+    got = _check_md_pre_720p_gop(workdir, {"SVT_HIP_HOOKS": "all,md_pre"}, "hip_mdpre")
+    assert "svt_hip MOCK" not in got["log"]
+    got = _check_md_pre_720p_gop(workdir, {"SVT_HIP_HOOKS": "md_pre", "SVT_HIP_MD_PRE_VERIFY": "1"}, "hip_mdpre_verify")
+    assert re.search(r"verify_mismatches=0\b", got["log"])
 
 
 @need_simd

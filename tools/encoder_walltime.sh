@@ -40,7 +40,7 @@ PY
     [ "$app" != "$base" ] && [ -f $OUT/$app.ivf ] && { [ -f $OUT/$base.ivf ] || { echo "${W}x${H} $app: no unpatched run in this invocation to compare with"; continue; }; cmp -s $OUT/$base.ivf $OUT/$app.ivf && echo "${W}x${H} $app bitstream identical to $base" || echo "${W}x${H} $app BITSTREAM DIFFERS from $base"; } | tee -a $OUT/wall.txt
   done
   for app in hip_res hip_simd_res; do
-    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context\|svt_hip_lf_pictures\|svt_hip_warmup\|svt_hip_alloc_cache" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt
+    [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_resident\|svt_hip_context\|svt_hip_lf_pictures\|svt_hip_warmup\|svt_hip_alloc_cache\|svt_hip_md_pre" $OUT/${app}_$W.log | sed "s/^/$app /" | tee -a $OUT/wall.txt
     [ -f $OUT/${app}_$W.log ] && grep -h "svt_hip_hook_time" $OUT/${app}_$W.log | awk -v a=$app '{printf "%s %s %s %s | ", a, $2, $3, $4} END {print ""}' | tee -a $OUT/wall.txt
   done
   for app in hip hip_simd hip_res hip_simd_res; do
