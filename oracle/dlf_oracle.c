@@ -240,3 +240,130 @@ int orc_dlf_search_level(const void *recon, void *tmp, int pix_bytes, int stride
     if (probes) memcpy(probes, ss_err, sizeof(ss_err));
     return filt_best;
 }
+
+/* =====================================================================================================================================================
+ * E2: which edges the deblocking filter touches, how long the filter is and at which level — set_lpf_parameters (Encoder/Codec/EbDeblockingFilter.c:168-319)
+ * with get_transform_size (:134-166), the level table of svt_av1_loop_filter_frame_init (Common/Codec/EbDeblockingCommon.c:71-146) and the unit ranges of
+ * svt_av1_filter_block_plane_vert / _horz (:322-367, :463-508).  Written from those functions; pinned to svt_av1_loop_filter_frame itself (all three planes of synthetic
+ * pictures, every block size / transform depth / skip / reference / mode combination) by tests/test_oracle_vs_ref.py::test_deblocking_edges_of_a_frame through
+ * oracle/ref_shim.c, which records what the reference's frame loop hands to the sixteen edge filters.
+ * ===================================================================================================================================================== */
+
+/* AV1 block sizes in the order of the BlockSize enum (Common/Codec/EbDefinitions.h): luma width / height */
+static const uint8_t k_bs_w[22] = {4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 4, 16, 8, 32, 16, 64};
+static const uint8_t k_bs_h[22] = {4, 8, 4, 8, 16, 8, 16, 32, 16, 32, 64, 32, 64, 128, 64, 128, 16, 4, 32, 8, 64, 16};
+int orc_block_width(int bsize) { return bsize >= 0 && bsize < 22 ? k_bs_w[bsize] : 0; }
+int orc_block_height(int bsize) { return bsize >= 0 && bsize < 22 ? k_bs_h[bsize] : 0; }
+
+/* tx_depth_to_tx_size[depth][bsize] (Common/Codec/EbDefinitions.h:636-657) as transform dimensions.  Depth 0 is the largest transform of the block (64 at most);
+ * the deeper entries follow the table's own pattern, quirks included: a block with a 128 side stays 64x64, blocks with a 4 side that is not 4:1 stay whole,
+ * 8x8 goes 8x8 -> 4x4 -> 8x8. */
+void orc_tx_dims_for_depth(int bsize, int depth, int *tw, int *th) {
+    const int w = k_bs_w[bsize], h = k_bs_h[bsize], lo = w < h ? w : h, hi = w < h ? h : w;
+    if (hi == 128) { *tw = *th = 64; return; }
+    if (depth == 0 || (lo == 4 && hi <= 8)) { *tw = w; *th = h; return; }
+    if (hi == lo) {                               /* square */
+        const int s = depth == 1 ? lo / 2 : (lo == 8 ? 8 : lo / 4);
+        *tw = *th = s;
+    } else if (hi == 2 * lo) {                    /* 2:1 -> the square of the short side, then half of it */
+        *tw = *th = depth == 1 ? lo : lo / 2;
+    } else {                                      /* 4:1 -> 2:1, then the square of the short side */
+        if (depth == 1) { *tw = w > h ? w / 2 : w; *th = h > w ? h / 2 : h; }
+        else *tw = *th = lo;
+    }
+}
+/* av1_get_max_uv_txsize(bsize, 1, 1) (4:2:0): the chroma block is half the luma block with a floor of 4 samples, its transform is capped at 32
+ * (av1_get_adjusted_tx_size, EbDefinitions.h:677-686) */
+void orc_uv_tx_dims(int bsize, int *tw, int *th) {
+    int w = k_bs_w[bsize] / 2, h = k_bs_h[bsize] / 2;
+    if (w < 4) w = 4;
+    if (h < 4) h = 4;
+    *tw = w > 32 ? 32 : w; *th = h > 32 ? 32 : h;
+}
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+/* svt_av1_loop_filter_frame_init without segmentation: lvl[plane][dir][ref 0..7][mode delta 0..1].  lf = {filter_level[0], filter_level[1], filter_level_u, filter_level_v,
+ * sharpness (unused here), mode_ref_delta_enabled, ref_deltas[8], mode_deltas[2]}.  Planes the init skips (zero frame level) keep zeros: the frame loop skips them too. */
+void orc_dlf_level_table(const int32_t *lf, uint8_t lvl[3][2][8][2]) {
+    memset(lvl, 0, 3 * 2 * 8 * 2);
+    const int filt[3] = {lf[0], lf[2], lf[3]}, filt_r[3] = {lf[1], lf[2], lf[3]};
+    for (int plane = 0; plane < 3; plane++) {
+        if (plane == 0 && !filt[0] && !filt_r[0]) break;
+        if (plane > 0 && !filt[plane]) continue;
+        for (int dir = 0; dir < 2; dir++) {
+            const int seg = dir == 0 ? filt[plane] : filt_r[plane];
+            if (!lf[5]) { memset(lvl[plane][dir], seg, 16); continue; }
+            const int scale = 1 << (seg >> 5);
+            lvl[plane][dir][0][0] = (uint8_t)clampi(seg + lf[6] * scale, 0, 63);   /* INTRA_FRAME has one entry; [0][1] is never read */
+            for (int ref = 1; ref < 8; ref++)
+                for (int m = 0; m < 2; m++) lvl[plane][dir][ref][m] = (uint8_t)clampi(seg + lf[6 + ref] * scale + lf[14 + m] * scale, 0, 63);
+        }
+    }
+}
+
+/* The per-4x4 summary set_lpf_parameters works from (the product's SvtHipDlfModeInfo layout, 13 bytes per unit: tx_w_log2, tx_h_log2, uv_tx_w_log2, uv_tx_h_log2,
+ * bw_log2, bh_log2, skip_inter, level[3][2]) out of the reference's mode-info fields per unit: sb_type, tx_depth, ref_frame[0], skip, prediction mode.
+ * get_transform_size: inter blocks use the largest transform unless they carry coefficients, intra blocks the depth's; mode_lf_lut: 0 for intra modes, GLOBALMV
+ * and GLOBAL_GLOBALMV, 1 for the other inter modes (Common/Codec/EbDeblockingCommon.h:66-70). */
+void orc_dlf_mode_info_summary(int n_units, const uint8_t *sb_type, const uint8_t *tx_depth, const uint8_t *ref_frame0, const uint8_t *skip, const uint8_t *mode,
+                               const uint8_t lvl[3][2][8][2], uint8_t *out) {
+    for (int i = 0; i < n_units; i++) {
+        const int bs = sb_type[i], inter = ref_frame0[i] > 0;   /* is_inter_block_no_intrabc: ref_frame[0] > INTRA_FRAME */
+        int tw, th, uw, uh;
+        orc_tx_dims_for_depth(bs, (inter && skip[i]) ? 0 : tx_depth[i], &tw, &th);
+        orc_uv_tx_dims(bs, &uw, &uh);
+        const int m = mode[i] == 25 ? 0 : mode[i];   /* INTRA_MODE_4x4 counts as DC_PRED */
+        const int delta = m < 13 ? 0 : (m == 15 || m == 23 ? 0 : 1);
+        uint8_t *o = out + 13 * (size_t)i;
+        o[0] = (uint8_t)ilog2(tw); o[1] = (uint8_t)ilog2(th); o[2] = (uint8_t)ilog2(uw); o[3] = (uint8_t)ilog2(uh);
+        o[4] = (uint8_t)ilog2(k_bs_w[bs]); o[5] = (uint8_t)ilog2(k_bs_h[bs]); o[6] = (uint8_t)(skip[i] && inter);
+        for (int p = 0; p < 3; p++)
+            for (int d = 0; d < 2; d++) o[7 + 2 * p + d] = lvl[p][d][ref_frame0[i]][delta];
+    }
+}
+
+/* units of a plane the frame loop visits along one axis (svt_av1_filter_block_plane_vert :340-366): whole superblocks, except that the last superblock row / column of
+ * a coded size that is not a multiple of the superblock size ends at the unpadded extent */
+int orc_dlf_filtered_units(int coded_luma, int pad, int sb_size, int ss) {
+    const int full = ((coded_luma >> ss) + 3) >> 2, n_sb = (coded_luma + sb_size - 1) / sb_size;
+    int units = 0;
+    for (int s = 0; s < n_sb; s++) {
+        int range = (sb_size >> 2) >> ss;                                                   /* MAX_MIB_SIZE / SB64_MIB_SIZE >> scale */
+        if (s * sb_size == coded_luma / sb_size * sb_size) range = ((((coded_luma - pad) % sb_size) >> ss) + 3) >> 2;
+        units = ((s * sb_size) >> ss >> 2) + range;                                          /* where this superblock's loop ends */
+    }
+    return units < full ? units : full;
+}
+
+/* set_lpf_parameters for every 4x4 unit of one plane, both directions: edges_v / edges_h [ceil(ph / 4)][ceil(pw / 4)] = level << 8 | filter length for the edge on the
+ * left / top of the unit; units at or beyond filt_units_w / filt_units_h are not visited (0).  mi = the 13-byte summaries, [mi_rows][mi_cols] luma units. */
+void orc_dlf_build_edges(const uint8_t *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int pw, int ph, int filt_units_w, int filt_units_h,
+                         uint16_t *edges_v, uint16_t *edges_h) {
+    const int uw = (pw + 3) >> 2, uh = (ph + 3) >> 2;
+    for (int dir = 0; dir < 2; dir++)
+        for (int uy = 0; uy < uh; uy++)
+            for (int ux = 0; ux < uw; ux++) {
+                uint16_t *out = (dir ? edges_h : edges_v) + (size_t)uy * uw + ux;
+                *out = 0;
+                const int x = 4 * ux, y = 4 * uy;
+                if (ux >= filt_units_w || uy >= filt_units_h || x >= pw || y >= ph) continue;   /* (:185-189) outside the plane: TX_4X4, no filter */
+                const int mi_row = ss_y | ((y << ss_y) >> 2), mi_col = ss_x | ((x << ss_x) >> 2);   /* chroma: the bottom / right unit of the 8x8 (:196-197) */
+                if (mi_row >= mi_rows || mi_col >= mi_cols) continue;   /* never the case for coded sizes that are multiples of 8 */
+                const uint8_t *cur = mi + 13 * ((size_t)mi_row * mi_cols + mi_col);
+                const int ts = cur[(plane ? 2 : 0) + dir];   /* log2 of the transform's extent across the edge */
+                const int coord = dir ? y : x;
+                if (coord & ((1 << ts) - 1)) continue;       /* not a transform edge (:214-219) */
+                if (!coord) continue;                        /* picture border: nothing to filter against (:245) */
+                const uint8_t *prv = mi + 13 * ((size_t)(dir ? mi_row - (1 << ss_y) : mi_row) * mi_cols + (dir ? mi_col : mi_col - (1 << ss_x)));
+                const int pts = prv[(plane ? 2 : 0) + dir];
+                const int cl = cur[7 + 2 * plane + dir], pl = prv[7 + 2 * plane + dir];
+                /* get_plane_block_size: the prediction block in the plane's samples, never below 4 */
+                int bdim = cur[4 + dir] - (plane ? (dir ? ss_y : ss_x) : 0);
+                if (bdim < 2) bdim = 2;
+                const int pu_edge = !(coord & ((1 << bdim) - 1));
+                if (!(cl || pl) || (prv[6] && cur[6] && !pu_edge)) continue;   /* both sides skipped inter blocks: only prediction edges (:281-283) */
+                const int mts = ts < pts ? ts : pts;
+                const int len = mts <= 2 ? 4 : (mts == 3 ? (plane ? 6 : 8) : (plane ? 6 : 14));
+                *out = (uint16_t)(((cl ? cl : pl) << 8) | len);
+            }
+}

@@ -211,3 +211,98 @@ double ref_shim_estimate_noise(const void *src, int highbd, int bd, int width, i
     return highbd ? estimate_noise_highbd((const uint16_t *)src, width, height, stride, bd)
                   : estimate_noise((const uint8_t *)src, (uint16_t)width, (uint16_t)height, (uint16_t)stride);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Deblocking, frame level: svt_av1_loop_filter_frame (Encoder/Codec/EbDeblockingFilter.c:711) driven on a synthetic picture whose mode-info grid
+ * is given per 4x4 unit, with the sixteen edge-filter pointers replaced by recorders — what comes out is, for every 4x4 unit of every plane and both directions, whether
+ * the reference's frame loop filters the edge on its left / top, with which filter length and at which level: the outcome of set_lpf_parameters (:168, static),
+ * get_transform_size (:134, static), svt_av1_loop_filter_frame_init and the unit ranges of svt_av1_filter_block_plane_vert / _horz.  Builds structs and records calls;
+ * restates nothing. */
+#include "EbPictureControlSet.h"
+#include "EbSequenceControlSet.h"
+#include "EbDeblockingFilter.h"
+static struct {
+    uint8_t *base[3]; int stride[3], uw[3], uh[3];
+    const LoopFilterThresh *thr;
+    uint16_t *ev[3], *eh[3];
+    int bad;
+} g_dlf_rec;
+static void dlf_record(uint8_t *s, int dir, int len, const uint8_t *limit) {
+    for (int p = 0; p < 3; p++) {
+        const ptrdiff_t off = s - g_dlf_rec.base[p];
+        if (off < 0 || off >= (ptrdiff_t)g_dlf_rec.stride[p] * g_dlf_rec.uh[p] * 4) continue;
+        const int y = (int)(off / g_dlf_rec.stride[p]), x = (int)(off % g_dlf_rec.stride[p]);
+        const ptrdiff_t lv = (limit - (const uint8_t *)g_dlf_rec.thr) / (ptrdiff_t)sizeof(LoopFilterThresh);   /* limit points into lfthr[level] */
+        if ((x & 3) || (y & 3) || x >= 4 * g_dlf_rec.uw[p] || lv < 0 || lv > MAX_LOOP_FILTER) { g_dlf_rec.bad++; return; }
+        uint16_t *o = (dir ? g_dlf_rec.eh[p] : g_dlf_rec.ev[p]) + (size_t)(y >> 2) * g_dlf_rec.uw[p] + (x >> 2);
+        if (*o) g_dlf_rec.bad++;   /* an edge filtered twice */
+        *o = (uint16_t)((lv << 8) | len);
+        return;
+    }
+    g_dlf_rec.bad++;
+}
+#define DLF_REC(name, dir, len) static void name(uint8_t *s, int32_t pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh) { (void)pitch; (void)blimit; (void)thresh; dlf_record(s, dir, len, limit); }
+DLF_REC(rec_v4, 0, 4) DLF_REC(rec_v6, 0, 6) DLF_REC(rec_v8, 0, 8) DLF_REC(rec_v14, 0, 14)
+DLF_REC(rec_h4, 1, 4) DLF_REC(rec_h6, 1, 6) DLF_REC(rec_h8, 1, 8) DLF_REC(rec_h14, 1, 14)
+
+/* w x h = coded luma size (multiples of 8), pad_right / pad_bottom = how much of it is padding, sb_size 64 or 128; sb_type / tx_depth / ref_frame0 / skip / mode:
+ * [h / 4][w / 4] per luma 4x4 unit; lf = {filter_level[0], filter_level[1], filter_level_u, filter_level_v, sharpness, mode_ref_delta_enabled, ref_deltas[8],
+ * mode_deltas[2]}; ev / eh[plane]: [ceil(ph / 4)][ceil(pw / 4)] = level << 8 | length (zeroed here); lvl_out (may be NULL): lf_info.lvl[plane][0][dir][ref][mode] after the
+ * reference's init.  Returns the number of inconsistencies the recorders saw (0 = fine), -1 on allocation failure. */
+int ref_shim_dlf_frame_edges(int w, int h, int pad_right, int pad_bottom, int sb_size, const uint8_t *sb_type, const uint8_t *tx_depth, const uint8_t *ref_frame0,
+                             const uint8_t *skip, const uint8_t *mode, const int32_t *lf, uint16_t *const ev[3], uint16_t *const eh[3], uint8_t *lvl_out) {
+    shim_rtcd();
+    const int mi_cols = w >> 2, mi_rows = h >> 2;
+    PictureControlSet *pcs = (PictureControlSet *)calloc(1, sizeof(PictureControlSet));
+    PictureParentControlSet *ppcs = (PictureParentControlSet *)calloc(1, sizeof(PictureParentControlSet));
+    SequenceControlSet *scs = (SequenceControlSet *)calloc(1, sizeof(SequenceControlSet));
+    EbObjectWrapper *wr = (EbObjectWrapper *)calloc(1, sizeof(EbObjectWrapper));
+    ModeInfo *mi = (ModeInfo *)calloc((size_t)mi_cols * mi_rows, sizeof(ModeInfo));
+    ModeInfo **grid = (ModeInfo **)calloc((size_t)mi_cols * mi_rows, sizeof(ModeInfo *));
+    EbPictureBufferDesc *pic = (EbPictureBufferDesc *)calloc(1, sizeof(EbPictureBufferDesc));
+    if (!pcs || !ppcs || !scs || !wr || !mi || !grid || !pic) return -1;
+    for (int i = 0; i < mi_cols * mi_rows; i++) {
+        grid[i] = &mi[i];
+        mi[i].mbmi.block_mi.sb_type = (BlockSize)sb_type[i]; mi[i].mbmi.tx_depth = tx_depth[i]; mi[i].mbmi.block_mi.ref_frame[0] = (MvReferenceFrame)ref_frame0[i];
+        mi[i].mbmi.block_mi.skip = skip[i]; mi[i].mbmi.block_mi.mode = (PredictionMode)mode[i];
+    }
+    wr->object_ptr = scs;
+    pcs->parent_pcs_ptr = ppcs; pcs->mi_grid_base = grid; pcs->mi_stride = mi_cols;
+    ppcs->scs_wrapper_ptr = wr; ppcs->scs_ptr = scs; ppcs->aligned_width = (uint16_t)w; ppcs->aligned_height = (uint16_t)h;
+    scs->sb_size_pix = (uint8_t)sb_size; scs->seq_header.sb_size = sb_size == 128 ? BLOCK_128X128 : BLOCK_64X64;
+    scs->max_input_luma_width = (uint16_t)w; scs->max_input_luma_height = (uint16_t)h; scs->max_input_pad_right = (uint16_t)pad_right; scs->max_input_pad_bottom = (uint16_t)pad_bottom;
+    scs->static_config.encoder_bit_depth = 8; scs->static_config.is_16bit_pipeline = 0;
+    struct LoopFilter *lp = &ppcs->frm_hdr.loop_filter_params;
+    lp->filter_level[0] = lf[0]; lp->filter_level[1] = lf[1]; lp->filter_level_u = lf[2]; lp->filter_level_v = lf[3]; lp->sharpness_level = lf[4];
+    lp->mode_ref_delta_enabled = (uint8_t)lf[5]; lp->combine_vert_horz_lf = 1;
+    for (int i = 0; i < 8; i++) lp->ref_deltas[i] = (int8_t)lf[6 + i];
+    for (int i = 0; i < 2; i++) lp->mode_deltas[i] = (int8_t)lf[14 + i];
+    svt_av1_loop_filter_init(pcs);   /* the sharpness limits and the bilinear level table, as the encoder does once per picture (EbDlfProcess.c) */
+    pic->bit_depth = EB_8BIT; pic->width = pic->max_width = (uint16_t)w; pic->height = pic->max_height = (uint16_t)h;
+    pic->stride_y = (uint16_t)w; pic->stride_cb = pic->stride_cr = (uint16_t)(w / 2);
+    pic->buffer_y = (uint8_t *)calloc((size_t)w * h, 1); pic->buffer_cb = (uint8_t *)calloc((size_t)w * h / 4, 1); pic->buffer_cr = (uint8_t *)calloc((size_t)w * h / 4, 1);
+    memset(&g_dlf_rec, 0, sizeof(g_dlf_rec));
+    g_dlf_rec.base[0] = pic->buffer_y; g_dlf_rec.base[1] = pic->buffer_cb; g_dlf_rec.base[2] = pic->buffer_cr;
+    for (int p = 0; p < 3; p++) {
+        const int pw = w >> (p > 0), ph = h >> (p > 0);
+        g_dlf_rec.stride[p] = pw; g_dlf_rec.uw[p] = (pw + 3) >> 2; g_dlf_rec.uh[p] = (ph + 3) >> 2;
+        g_dlf_rec.ev[p] = ev[p]; g_dlf_rec.eh[p] = eh[p];
+        memset(ev[p], 0, sizeof(uint16_t) * g_dlf_rec.uw[p] * g_dlf_rec.uh[p]); memset(eh[p], 0, sizeof(uint16_t) * g_dlf_rec.uw[p] * g_dlf_rec.uh[p]);
+    }
+    g_dlf_rec.thr = ppcs->lf_info.lfthr;
+    void *saved[8] = {(void *)svt_aom_lpf_vertical_4, (void *)svt_aom_lpf_vertical_6, (void *)svt_aom_lpf_vertical_8, (void *)svt_aom_lpf_vertical_14,
+                      (void *)svt_aom_lpf_horizontal_4, (void *)svt_aom_lpf_horizontal_6, (void *)svt_aom_lpf_horizontal_8, (void *)svt_aom_lpf_horizontal_14};
+    svt_aom_lpf_vertical_4 = rec_v4; svt_aom_lpf_vertical_6 = rec_v6; svt_aom_lpf_vertical_8 = rec_v8; svt_aom_lpf_vertical_14 = rec_v14;
+    svt_aom_lpf_horizontal_4 = rec_h4; svt_aom_lpf_horizontal_6 = rec_h6; svt_aom_lpf_horizontal_8 = rec_h8; svt_aom_lpf_horizontal_14 = rec_h14;
+    svt_av1_loop_filter_frame(pic, pcs, 0, 3);
+    svt_aom_lpf_vertical_4 = saved[0]; svt_aom_lpf_vertical_6 = saved[1]; svt_aom_lpf_vertical_8 = saved[2]; svt_aom_lpf_vertical_14 = saved[3];
+    svt_aom_lpf_horizontal_4 = saved[4]; svt_aom_lpf_horizontal_6 = saved[5]; svt_aom_lpf_horizontal_8 = saved[6]; svt_aom_lpf_horizontal_14 = saved[7];
+    if (lvl_out)
+        for (int p = 0; p < 3; p++)
+            for (int d = 0; d < 2; d++)
+                for (int r = 0; r < 8; r++)
+                    for (int m = 0; m < 2; m++) lvl_out[((p * 2 + d) * 8 + r) * 2 + m] = ppcs->lf_info.lvl[p][0][d][r][m];
+    const int bad = g_dlf_rec.bad;
+    free(pic->buffer_y); free(pic->buffer_cb); free(pic->buffer_cr); free(pic); free(grid); free(mi); free(wr); free(scs); free(ppcs); free(pcs);
+    return bad;
+}

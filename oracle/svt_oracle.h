@@ -70,6 +70,17 @@ typedef struct {
 OrcSearchWindow orc_me_search_window(int sb_origin_x, int sb_origin_y, int x_center, int y_center,
                                      int sa_width, int sa_height, int pic_width, int pic_height);
 
+/* dlf_oracle.c, E2: edges, filter lengths and levels of a frame (set_lpf_parameters, EbDeblockingFilter.c:168-319) */
+int  orc_block_width(int bsize);
+int  orc_block_height(int bsize);
+void orc_tx_dims_for_depth(int bsize, int depth, int *tw, int *th);
+void orc_uv_tx_dims(int bsize, int *tw, int *th);
+void orc_dlf_level_table(const int32_t *lf, uint8_t lvl[3][2][8][2]);
+void orc_dlf_mode_info_summary(int n_units, const uint8_t *sb_type, const uint8_t *tx_depth, const uint8_t *ref_frame0, const uint8_t *skip, const uint8_t *mode,
+                               const uint8_t lvl[3][2][8][2], uint8_t *out);
+int  orc_dlf_filtered_units(int coded_luma, int pad, int sb_size, int ss);
+void orc_dlf_build_edges(const uint8_t *mi, int mi_cols, int mi_rows, int plane, int ss_x, int ss_y, int pw, int ph, int filt_units_w, int filt_units_h,
+                         uint16_t *edges_v, uint16_t *edges_h);
 /* md_oracle.c: mode decision stage 0, full-pel single-reference candidates (fast_loop_core, EbProductCodingLoop.c:907) */
 uint32_t orc_md_fullpel_candidate(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int x, int y, int w, int h, int mx, int my);
 void orc_md_fullpel_sad_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,

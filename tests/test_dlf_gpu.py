@@ -196,23 +196,47 @@ def test_deblock_frame_fused(hip, orc, bd, size):
 
 
 def host_edges_crop(L, raw, cols, rows, plane, pw, ph, fw, fh):
-    uw, uh = (pw + 3) // 4, (ph + 3) // 4
-    ev = np.zeros((uh, uw), np.uint16); eh = np.zeros((uh, uw), np.uint16)
-    L.svt_hip_dlf_build_edges_crop.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p] * 2
-    assert L.svt_hip_dlf_build_edges_crop(ptr(raw), cols, rows, plane, int(plane > 0), int(plane > 0), pw, ph, fw, fh, ptr(ev), ptr(eh)) == 0
-    return ev, eh
+    """the expectation: the ORACLE's statement of set_lpf_parameters (pinned to the reference's frame loop), not the product's host builder"""
+    return dc.build_edges(raw, cols, rows, plane, pw, ph, fw, fh)
+
+
+@pytest.mark.parametrize("w,h,pad,sb", [(200, 136, (0, 0), 64), (264, 136, (2, 4), 128), (1920, 1080, (0, 0), 64)])
+def test_edge_planes_of_random_partitions_on_the_device(hip, w, h, pad, sb):
+    """the device builder on the grids of the E2 pin: random AV1 partitions (every block size incl. 4:1 and 128-wide blocks), transform depths, intra / inter / skip, levels
+    from per-reference and per-mode deltas -- against the oracle (tests/dlf_common.py: oracle_edges), which test_deblocking_edges_of_a_frame pins to the reference's loop"""
+    L = hip.L
+    rng = np.random.default_rng(w + h)
+    hh = (h + 7) // 8 * 8
+    f = dc.make_reference_mode_info(rng, w, hh, sb)
+    lf = [int(rng.integers(1, 64)), int(rng.integers(1, 64)), int(rng.integers(1, 64)), int(rng.integers(1, 64)), 3, 1] + [int(v) for v in rng.integers(-20, 21, 10)]
+    summ, edges, _ = dc.oracle_edges(dc.oracle(), f, w, hh, lf, pad[0], pad[1], sb)
+    cols, rows = w // 4, hh // 4
+    pw = [w, w // 2, w // 2]; ph = [hh, hh // 2, hh // 2]
+    fw = [L.svt_hip_dlf_filtered_units(w, pad[0], sb, int(p > 0)) for p in range(3)]
+    fh = [L.svt_hip_dlf_filtered_units(hh, pad[1], sb, int(p > 0)) for p in range(3)]
+    d_mi = hip.to_device(summ)
+    I3, P3 = C.c_int * 3, C.c_void_p * 3
+    outs = [[hip.empty(2 * ((pw[p] + 3) // 4) * ((ph[p] + 3) // 4)) for p in range(3)] for _ in range(2)]
+    hip.check(L.svt_hip_dlf_build_edges_picture_dev(hip.h, d_mi, cols, rows, 1, 1, I3(*pw), I3(*ph), I3(*fw), I3(*fh), None, P3(*[o.value for o in outs[0]]), P3(*[o.value for o in outs[1]])), "edges")
+    for p in range(3):
+        gv = hip.to_host(outs[0][p], edges[p][0].shape, np.uint16); gh = hip.to_host(outs[1][p], edges[p][1].shape, np.uint16)
+        assert np.array_equal(gv, edges[p][0]) and np.array_equal(gh, edges[p][1]), (p, np.argwhere(gv != edges[p][0])[:4], np.argwhere(gh != edges[p][1])[:4])
+        assert (gv != 0).any() and (gh != 0).any()
+    hip.free(d_mi, *[o for pair in outs for o in pair])
 
 
 @pytest.mark.parametrize("w,h,pad", [(328, 200, (0, 0)), (192, 128, (6, 2)), (3840, 2160, (0, 0))])
 def test_edge_planes_built_on_the_device(hip, w, h, pad):
-    """svt_hip_dlf_build_edges_picture_dev == the host builder (the statement of set_lpf_parameters the other tests pin), for the records' own levels (varied per
-    block, zeros included), for frame-uniform stand-in levels — a zero among them, and one plane left out — and for a padded picture's filtered extent."""
+    """svt_hip_dlf_build_edges_picture_dev == the oracle's statement of set_lpf_parameters (oracle/dlf_oracle.c, pinned to svt_av1_loop_filter_frame by
+    tests/test_oracle_vs_ref.py::test_deblocking_edges_of_a_frame), for the records' own levels (varied per block, zeros included), for frame-uniform stand-in levels — a
+    zero among them, and one plane left out — and for a padded picture's filtered extent (the extent itself: svt_hip_dlf_filtered_units == orc_dlf_filtered_units)."""
     L = hip.L
     mi, cols, rows = dc.make_mode_info(w, h, seed=31 + w, varied=True)
     pw = [w, w // 2, w // 2]; ph = [h, h // 2, h // 2]
     fw = [L.svt_hip_dlf_filtered_units(w, pad[0], 64, int(p > 0)) for p in range(3)]
     fh = [L.svt_hip_dlf_filtered_units(h, pad[1], 64, int(p > 0)) for p in range(3)]
     assert min(fw + fh) >= 0
+    assert fw == [dc.oracle().orc_dlf_filtered_units(w, pad[0], 64, int(p > 0)) for p in range(3)] and fh == [dc.oracle().orc_dlf_filtered_units(h, pad[1], 64, int(p > 0)) for p in range(3)]
     rec = C.sizeof(mi) // (cols * rows)
     assert rec == 13
     raw = np.frombuffer(mi, np.uint8).reshape(-1, rec).copy()

@@ -31,3 +31,43 @@ def test_zero_level_means_no_edges():
     mi, cols, rows = dc.make_mode_info(128, 128, seed=1, levels=(0, 0, 0, 0))
     ev, eh = dc.build_edges(mi, cols, rows, 0, 128, 128)
     assert not ev.any() and not eh.any()
+
+
+def test_product_host_builder_equals_the_oracle():
+    """The product's host builder (svt_hip_dlf_build_edges_crop, svt-av1_amd/csrc/svt_hip_host.cpp -- also what the CPU test double of the library links) against the oracle's
+    statement of set_lpf_parameters, which tests/test_oracle_vs_ref.py::test_deblocking_edges_of_a_frame pins to the reference's own frame loop: the synthetic grids of the
+    other deblocking tests, and grids of random AV1 partitions with every block size / transform depth / skip / level combination, full and cropped extents."""
+    L = dc.pkg.lib()
+    orc = dc.oracle()
+    rng = np.random.default_rng(77)
+    n = 0
+    for (w, h, pad, sb) in ((200, 136, (0, 0), 64), (136, 72, (6, 6), 64), (192, 128, (6, 6), 64), (384, 256, (0, 0), 128), (264, 136, (2, 4), 128), (72, 72, (8, 8), 64)):
+        for it in range(3):
+            f = dc.make_reference_mode_info(rng, w, h, sb, p_skip=(0.2, 0.6, 0.95)[it], p_inter=(0.7, 0.9, 0.3)[it])
+            lf = [int(rng.integers(0, 64)) for _ in range(4)] + [2, it % 2] + [int(v) for v in rng.integers(-20, 21, 10)]
+            summ, edges, _ = dc.oracle_edges(orc, f, w, h, lf, pad[0], pad[1], sb)
+            for plane in range(3):
+                ss = int(plane > 0)
+                fw, fh = L.svt_hip_dlf_filtered_units(w, pad[0], sb, ss), L.svt_hip_dlf_filtered_units(h, pad[1], sb, ss)
+                assert (fw, fh) == (orc.orc_dlf_filtered_units(w, pad[0], sb, ss), orc.orc_dlf_filtered_units(h, pad[1], sb, ss))
+                ev, eh = dc.product_host_edges(summ, w // 4, h // 4, plane, w >> ss, h >> ss, fw, fh)
+                assert np.array_equal(ev, edges[plane][0]) and np.array_equal(eh, edges[plane][1]), (w, h, it, plane)
+                n += int((ev != 0).sum() + (eh != 0).sum())
+    assert n > 10000
+    for (w, h) in ((200, 136), (328, 200)):
+        mi, cols, rows = dc.make_mode_info(w, h, seed=w, varied=True)
+        for plane in range(3):
+            ss = int(plane > 0)
+            a = dc.product_host_edges(mi, cols, rows, plane, w >> ss, h >> ss); b = dc.build_edges(mi, cols, rows, plane, w >> ss, h >> ss)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_filtered_units_sweep():
+    """svt_hip_dlf_filtered_units == orc_dlf_filtered_units (the unit ranges of svt_av1_filter_block_plane_vert / _horz) over coded sizes, paddings, both superblock sizes"""
+    L = dc.pkg.lib()
+    orc = dc.oracle()
+    for sb in (64, 128):
+        for coded in range(8, 520, 8):
+            for pad in range(0, 8):
+                for ss in (0, 1):
+                    assert L.svt_hip_dlf_filtered_units(coded, pad, sb, ss) == orc.orc_dlf_filtered_units(coded, pad, sb, ss), (coded, pad, sb, ss)

@@ -2,8 +2,10 @@
 i.e. in the build container).  Input distributions mirror /root/reference/test/SadTest.cc:
 REF_MAX / SRC_MAX / RANDOM / ties (:194-246), Allsad/Extsad kernels (:838-1222), sad_LoopTest (:611-785)."""
 import ctypes as C
+import os
 
 import numpy as np
+import pytest
 
 from conftest import ptr
 
@@ -280,6 +282,44 @@ def test_deblock_edge_filters(orc, ref):
 
 # ------------------------------------------------------------------------------------------ CDEF
 import cdef_common as cc
+
+
+def test_deblocking_edges_of_a_frame(orc, ref):
+    """E2, pinned below the whole-encode level: the reference's svt_av1_loop_filter_frame runs on synthetic pictures -- random AV1 partitions with every
+    block size, transform depths, intra / inter, skip, modes, per-reference and per-mode level deltas, 64 and 128 superblocks, coded sizes with padding -- with the edge
+    filters replaced by recorders (oracle/ref_shim.c: ref_shim_dlf_frame_edges), and the oracle's restatement (level table of svt_av1_loop_filter_frame_init, the per-unit
+    summary = get_transform_size, set_lpf_parameters, the unit ranges of the frame loop) must name exactly the same edges, lengths and levels."""
+    import dlf_common as D
+    rng = np.random.default_rng(2024)
+    P3 = C.POINTER(C.c_uint16) * 3
+    cases = [(64, 64, 0, 0, 64), (200, 136, 0, 0, 64), (136, 72, 6, 6, 64), (192, 128, 6, 6, 64), (384, 256, 0, 0, 128), (328, 200, 0, 0, 128), (72, 72, 8, 8, 64), (264, 136, 2, 4, 128)]
+    n_edges = 0
+    for ci, (w, h, pr, pb, sb) in enumerate(cases):
+        for it in range(4):
+            f = D.make_reference_mode_info(rng, w, h, sb, p_skip=(0.2, 0.5, 0.9, 0.4)[it], p_inter=(0.7, 0.95, 0.5, 0.0)[it])
+            lf = [int(rng.integers(0, 64)), int(rng.integers(0, 64)), int(rng.integers(0, 64)), int(rng.integers(0, 64)), int(rng.integers(0, 8)), it % 2] + \
+                 [int(v) for v in rng.integers(-20, 21, 8)] + [int(v) for v in rng.integers(-20, 21, 2)]
+            if it == 3: lf[2] = 0                      # a chroma plane that is not filtered at all
+            if ci == 0 and it == 2: lf[0] = lf[1] = 0  # no luma level: the reference stops at plane 0 (loop_filter_sb's `break`)
+            summ, edges, lvl = D.oracle_edges(orc, f, w, h, lf, pr, pb, sb)
+            ev = [np.zeros_like(e[0]) for e in edges]; eh = [np.zeros_like(e[1]) for e in edges]
+            rl = np.zeros((3, 2, 8, 2), np.uint8)
+            bad = ref.ref_shim_dlf_frame_edges(w, h, pr, pb, sb, ptr(f["sb_type"]), ptr(f["tx_depth"]), ptr(f["ref_frame0"]), ptr(f["skip"]), ptr(f["mode"]),
+                                               ptr(np.array(lf, np.int32)), P3(*[e.ctypes.data_as(C.POINTER(C.c_uint16)) for e in ev]),
+                                               P3(*[e.ctypes.data_as(C.POINTER(C.c_uint16)) for e in eh]), ptr(rl))
+            assert bad == 0
+            luma_off = lf[0] == 0 and lf[1] == 0
+            for plane in range(3):
+                on = not luma_off and (plane == 0 or lf[1 + plane] != 0)   # svt_av1_loop_filter_frame_init / loop_filter_sb skip these planes (and everything after an unfiltered luma)
+                if on:
+                    # the level table, where the reference's init wrote it and the summary reads it (intra: [0][0] only)
+                    assert np.array_equal(rl[plane, :, 1:, :], lvl[plane, :, 1:, :]) and np.array_equal(rl[plane, :, 0, 0], lvl[plane, :, 0, 0]), (ci, it, plane)
+                    assert np.array_equal(ev[plane], edges[plane][0]), (ci, it, plane, "v", np.argwhere(ev[plane] != edges[plane][0])[:5])
+                    assert np.array_equal(eh[plane], edges[plane][1]), (ci, it, plane, "h", np.argwhere(eh[plane] != edges[plane][1])[:5])
+                    n_edges += int((ev[plane] != 0).sum() + (eh[plane] != 0).sum())
+                else:
+                    assert not ev[plane].any() and not eh[plane].any()
+    assert n_edges > 20000
 
 
 def test_cdef_find_dir_and_filter_block(orc, ref):
@@ -723,6 +763,52 @@ def test_wiener_initial_filter(orc, ref):
 
 
 import tf_common as tfc
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_wiener_tap_refinement_walk(ref, bd, ss):
+    """The restatement of finer_tile_search_wiener_seg (Encoder/Codec/EbRestorationPick.c:1092-1200) that stands in for the device's wiener_walk_kernel on boxes without a
+    GPU -- the state machine of oracle/hip_mock.c (svt_hip_wiener_walk_units_dev of the CPU test double, every probe on the oracle's restoration filter), which the GPU test
+    tests/test_sgr_gpu.py::test_wiener_walk_units compares the device with -- against the reference's own static function, driven through oracle/ref_shim_restpick.c:
+    the same refined taps, the same error and the same number of try_restoration_unit_seg probes for every unit.  Same cases as the GPU test."""
+    import shard_common as sc
+    import test_sgr_gpu as tg
+    if not os.path.exists(sc.MOCK_LIB):
+        pytest.skip("oracle/_ref/mock/libsvtav1_hip.so not built (make -f oracle/Makefile.enc)")
+    M = C.CDLL(sc.MOCK_LIB)
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    M.svt_hip_wiener_walk_units_dev.argtypes = sig
+    ref.ref_shim_wiener_finer_search_plane.argtypes = sig[1:]
+    EXT = tg.EXT
+    for (w, h, US, win) in ((200, 152, 64, 7), (328, 264, 128, 7), (200, 152, 64, 5), (136, 72, 64, 3)):
+        if ss and win == 7: win = 5     # chroma planes search the 5-tap window at most (search_wiener_seg :1352-1358)
+        src, ext = tg.make_planes(w, h, bd, 190 + bd + ss + US)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        rng = np.random.default_rng(31 + ss + win)
+        dbl = np.clip(ext[EXT:EXT + h, EXT:EXT + w].astype(np.int32) + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(ext.dtype)
+        nu = tg.units(w, US) * tg.units(h, US)
+        act = (rng.random(nu) < 0.8).astype(np.uint8); act[0] = 1
+        o = (7 - win) >> 1
+        wn = np.zeros((nu, 2, 8), np.int16)
+        for u in range(nu):
+            for d in range(2):
+                t = [int(rng.integers(-5, 11)), int(rng.integers(-23, 9)), int(rng.integers(-17, 47))]
+                if u % 4 == 0: t = [0, 0, 0]
+                if u == 1: t = [10, 8, 46] if d else [-5, -23, -17]
+                for k in range(o): t[k] = 0
+                wn[u, d, :7] = [t[0], t[1], t[2], -2 * sum(t), t[2], t[1], t[0]]
+        m_wn = wn.copy(); m_err = np.full(nu, -1, np.int64); m_pr = np.zeros(nu, np.uint32)
+        work = ext.copy()
+        assert M.svt_hip_wiener_walk_units_dev(None, ext.itemsize, bd, C.c_void_p(work.ctypes.data + off), st, w, h, US, ss, ptr(dbl), w, ptr(src), w, ptr(m_wn), ptr(act), win, ptr(m_err), ptr(m_pr)) == 0
+        r_wn = wn.copy(); r_err = np.full(nu, -1, np.int64); r_pr = np.zeros(nu, np.uint32)
+        work2 = ext.copy()
+        assert ref.ref_shim_wiener_finer_search_plane(ext.itemsize, bd, C.c_void_p(work2.ctypes.data + off), st, w, h, US, ss, ptr(dbl), w, ptr(src), w, ptr(r_wn), ptr(act), win, ptr(r_err), ptr(r_pr)) == 0
+        on = act.astype(bool)
+        assert np.array_equal(m_wn, r_wn), (bd, ss, w, h, US, win, np.argwhere(m_wn != r_wn)[:4])
+        assert np.array_equal(m_err[on], r_err[on]), (bd, ss, US, win)
+        assert np.array_equal(m_pr[on], r_pr[on]) and r_pr[on].min() >= 7, (bd, ss, US, win, m_pr, r_pr)
+        assert (r_wn[on] != wn[on]).any()
 
 
 def test_temporal_filter_planewise_noise_and_divu(orc, ref):

@@ -76,7 +76,7 @@ class Frame:
         arr[:, :, 4] = np.maximum(tx_grid, 3); arr[:, :, 5] = np.maximum(tx_grid, 3)
         arr[:, :, 6] = skip_grid
         arr[:, :, 7] = 20; arr[:, :, 8] = 20; arr[:, :, 9] = 12; arr[:, :, 10] = 12; arr[:, :, 11] = 12; arr[:, :, 12] = 12
-        self.edges = [dc.build_edges(self.mi, cols, rows, p, width >> (p > 0), height >> (p > 0)) for p in range(3)]
+        self.edges = [dc.product_host_edges(self.mi, cols, rows, p, width >> (p > 0), height >> (p > 0)) for p in range(3)]   # the PRODUCT builds its own inputs (the bench never prepares them with the checker); the parity gate compares them with the oracle afterwards
         # ---- CDEF: per-fb strengths for the apply stage (strength *selection* is host logic in the reference)
         self.cdef_y = rng.integers(0, 64, self.n_sb).astype(np.uint8)
         self.cdef_uv = rng.integers(0, 64, self.n_sb).astype(np.uint8)

@@ -78,7 +78,7 @@ def sgr_apply():
 
 
 mi, cols, rows = dc.make_mode_info(W, H)
-edges = [dc.build_edges(mi, cols, rows, p, rec[p].shape[1], rec[p].shape[0]) for p in range(3)]
+edges = [dc.product_host_edges(mi, cols, rows, p, rec[p].shape[1], rec[p].shape[0]) for p in range(3)]
 d_ev = [hip.to_device(e[0]) for e in edges]; d_eh = [hip.to_device(e[1]) for e in edges]
 d_dbl = [hip.to_device(p) for p in rec]
 

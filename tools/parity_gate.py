@@ -133,8 +133,9 @@ def expected(stage, F, S, refb, orc, pkg, tc, workload, threads, cdef_lambda, un
         return out
     if stage == "deblock":
         out = {}
-        for p in range(3):
-            ev, eh = F.edges[p]
+        import dlf_common   # tests/: the edge planes of the recomputation come from the ORACLE's statement of set_lpf_parameters (pinned to the reference's frame loop),
+        for p in range(3):  # not from the product's builder, which made the device's own (F.edges) -- a wrong product builder fails this gate
+            ev, eh = dlf_common.build_edges(F.mi, F.mi_cols, F.mi_rows, p, W >> (p > 0), H >> (p > 0))
             img = S[f"recon_{p}"].copy()
             refb.refb_deblock_plane(ptr(img), strides[p], ptr(ev), ptr(eh), ev.shape[1], ev.shape[0], 0)
             out[f"dbl_{p}"] = img
