@@ -495,6 +495,9 @@ static void enc_init_locked(int target_socket) {
     if (svt_hip_init(device, &g_ctx) != SVT_HIP_OK) {
         /* error convention: never fail through the kernel surface — log, keep the C path */
         SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");
+        if (!(getenv("SVT_HIP_SEGMENTS") && !atoi(getenv("SVT_HIP_SEGMENTS"))))   /* svt_hip_hooks_segments ran before the device was known (the buffer configuration comes first) */
+            SVT_LOG("svt_hip: the ME / TF / CDEF / restoration segment counts were chosen for the hooks (fewer, larger segments): the C kernels now run with less "
+                    "parallelism inside a picture; SVT_HIP_SEGMENTS=0 or an unset SVT_HIP_HOOKS keeps the reference's counts\n");
         g_ctx = NULL;
         return;
     }

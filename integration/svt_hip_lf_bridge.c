@@ -124,6 +124,7 @@ typedef struct {
 static LfState         g_state[LF_MAX_IN_FLIGHT];
 static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
 static long            g_lf_up_planes, g_lf_down_planes, g_lf_recoveries, g_lf_deferred, g_lf_src_resident;
+static long            g_lf_final_retries, g_lf_final_host_chains, g_lf_final_fatal;   /* lf_final_download */
 static long long       g_lf_up_bytes, g_lf_down_bytes;
 
 /* the reconstructed pictures' host buffers, page-locked in place once (they are allocated once per encoder instance: EbReferenceObject / the PCS pool) */
@@ -235,8 +236,9 @@ static void lf_leave(LfState *s) {
 
 void svt_hip_lf_bridge_release(SvtHipCtx *hip) {   /* no picture is in flight any more (svt_hip_hooks_enc_deinit) */
     if (g_lf_up_planes + g_lf_down_planes)
-        fprintf(stderr, "svt_hip_lf_pictures deferred=%ld recovered=%ld source_planes_resident=%ld planes_up=%ld up_mb=%.1f planes_down=%ld down_mb=%.1f\n", g_lf_deferred,
-                g_lf_recoveries, g_lf_src_resident, g_lf_up_planes, g_lf_up_bytes / 1048576.0, g_lf_down_planes, g_lf_down_bytes / 1048576.0);
+        fprintf(stderr, "svt_hip_lf_pictures deferred=%ld recovered=%ld source_planes_resident=%ld planes_up=%ld up_mb=%.1f planes_down=%ld down_mb=%.1f final_retries=%ld final_host_chains=%ld final_fatal=%ld\n",
+                g_lf_deferred, g_lf_recoveries, g_lf_src_resident, g_lf_up_planes, g_lf_up_bytes / 1048576.0, g_lf_down_planes, g_lf_down_bytes / 1048576.0, g_lf_final_retries,
+                g_lf_final_host_chains, g_lf_final_fatal);
     for (int i = 0; i < LF_MAX_IN_FLIGHT; i++) {
         if (g_state[i].allocated) svt_hip_lf_picture_dctor(hip, &g_state[i].pic);
         if (g_state[i].mu_ready) pthread_mutex_destroy(&g_state[i].mu);
@@ -268,6 +270,7 @@ static EbErrorType upload(SvtHipCtx *hip, SvtHipLfPicture *p, const EbPictureBuf
     return EB_ErrorNone;
 }
 /* crop: only the unpadded extent comes back (the restoration filter writes the cropped frame, EbRestoration.c:1330-1350) */
+static __thread int tls_download_started;   /* a copy into the host picture has been queued since the caller cleared this: the host planes may hold part of it */
 static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *const d_src[3], EbPictureBufferDesc *pic, int plane_mask, int crop) {
     for (int pl = 0; pl < 3; pl++) {
         if (!(plane_mask & (1 << pl))) continue;
@@ -275,6 +278,7 @@ static EbErrorType download(SvtHipCtx *hip, const SvtHipLfPicture *p, void *cons
         uint8_t *d = pic_plane(pic, pl, p->pix_bytes, &st);
         const int pw = (crop ? p->cw : p->w) >> (pl > 0), ph = (crop ? p->ch : p->h) >> (pl > 0);
         const uint8_t *s = (const uint8_t *)plane_origin(p, d_src[pl], pl);
+        tls_download_started = 1;
         HIP_TRY(svt_hip_memcpy2d_d2h_async(hip, d, (size_t)st * p->pix_bytes, s, (size_t)p->stride[pl] * p->pix_bytes, (size_t)pw * p->pix_bytes, ph));
         __sync_fetch_and_add(&g_lf_down_planes, 1); __sync_fetch_and_add(&g_lf_down_bytes, (long long)pw * ph * p->pix_bytes);
     }
@@ -327,10 +331,17 @@ static void lf_recover(SvtHipCtx *hip, LfState *s, int stage) {
     EbPictureBufferDesc *rec = recon_of(pcs, p->pix_bytes == 2);
     const int highbd = p->pix_bytes == 2;
     __sync_fetch_and_add(&g_lf_recoveries, 1);
-    if ((s->flags & (ST_HOST_STALE | ST_SKIP0)) && (s->flags & ST_DBL)) (void)download(hip, p, p->d_recon, rec, 7, 0);
+    int lost = 0;   /* a picture only the device has could not be brought back, not even at the second attempt */
+    if ((s->flags & (ST_HOST_STALE | ST_SKIP0)) && (s->flags & ST_DBL) && download(hip, p, p->d_recon, rec, 7, 0) != EB_ErrorNone) {
+        (void)svt_hip_sync(hip);
+        lost |= download(hip, p, p->d_recon, rec, 7, 0) != EB_ErrorNone;
+    }
     if (s->flags & ST_SKIP0) svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 0);
     if (stage >= 1) {
-        if (s->flags & ST_CDEF) (void)download(hip, p, p->d_cdef, rec, 7, 0);   /* a border the device has added inside a padded picture is the one svt_extend_frame writes below */
+        if ((s->flags & ST_CDEF) && download(hip, p, p->d_cdef, rec, 7, 0) != EB_ErrorNone) {   /* a border the device has added inside a padded picture is the one svt_extend_frame writes below */
+            (void)svt_hip_sync(hip);
+            lost |= download(hip, p, p->d_cdef, rec, 7, 0) != EB_ErrorNone;
+        }
         if (s->flags & ST_SKIP1) {
             svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 1);
             for (int pl = 0; pl < 3; pl++)
@@ -339,7 +350,12 @@ static void lf_recover(SvtHipCtx *hip, LfState *s, int stage) {
         }
         s->flags &= ~ST_SKIP1;
     }
-    (void)scs;
+    if (lost) {   /* the C code that takes over would work on a stale picture: the encoder stops instead (lf_final_download explains) */
+        SVT_LOG("svt_hip: a picture could not be brought back from the device for the C filter stages (%s) - stopping the encoder\n", svt_hip_last_error(hip));
+        __sync_fetch_and_add(&g_lf_final_fatal, 1);
+        if (scs->encode_context_ptr && scs->encode_context_ptr->app_callback_ptr && scs->encode_context_ptr->app_callback_ptr->error_handler)
+            scs->encode_context_ptr->app_callback_ptr->error_handler(scs->encode_context_ptr->app_callback_ptr->handle, (uint32_t)EB_ErrorUndefined);
+    }
     s->flags &= ~(ST_HOST_STALE | ST_SKIP0);
     s->defer = 0;
     svt_hip_hooks_log("loop filter stages: host picture brought up to date after a failed hook (stage %d)", stage);
@@ -570,7 +586,23 @@ static EbErrorType dlf_frame(SvtHipCtx *hip, LfState *s, EbPictureBufferDesc *re
     } else
         HIP_TRY(svt_hip_deblock_frame_dev(hip, pl_ptr, p->pix_bytes, p->stride, p->bd, ev, eh, p->units_w, p->units_h, lf->sharpness_level));
     if (s->defer) s->flags |= ST_HOST_STALE;   /* the deblocked picture stays on the device (svt_hip_hook_picture_done brings the final one back) */
-    else if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) return EB_ErrorUndefined;
+    else {
+        tls_download_started = 0;
+        if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) {
+            if (!tls_download_started) return EB_ErrorUndefined;   /* nothing was queued: the host picture is the coded one, the C filter takes over */
+            /* copies into the host picture were queued: it may hold deblocked samples already, and the C filter must not filter those twice — a second complete
+             * pass makes it whole; if the device cannot deliver that either, the encoder stops (lf_final_download explains) */
+            (void)svt_hip_sync(hip);
+            __sync_fetch_and_add(&g_lf_final_retries, 1);
+            if (download(hip, p, p->d_recon, recon, mask, 0) != EB_ErrorNone) {
+                SVT_LOG("svt_hip: a deblocked picture could not be brought back from the device (%s) - stopping the encoder\n", svt_hip_last_error(hip));
+                __sync_fetch_and_add(&g_lf_final_fatal, 1);
+                const SequenceControlSet *scs = (const SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+                if (scs->encode_context_ptr && scs->encode_context_ptr->app_callback_ptr && scs->encode_context_ptr->app_callback_ptr->error_handler)
+                    scs->encode_context_ptr->app_callback_ptr->error_handler(scs->encode_context_ptr->app_callback_ptr->handle, (uint32_t)EB_ErrorUndefined);
+            }
+        }
+    }
     s->flags |= ST_DBL;
     svt_hip_hooks_log("dlf: levels %d %d %d %d, planes %d, edges %.2f ms (%s)", lf->filter_level[0], lf->filter_level[1], lf->filter_level_u, lf->filter_level_v, mask,
                       (te1 - te0) / 1e6, reuse ? "the level search's grid" : "mode info refilled");
@@ -582,7 +614,7 @@ EbErrorType svt_hip_hook_dlf_frame(EbPictureBufferDesc *recon, PictureControlSet
     SvtHipCtx *hip = NULL;
     LfState   *s = lf_enter(pcs, 1, &hip);
     EbErrorType rc = s ? dlf_frame(hip, s, recon) : EB_ErrorUndefined;
-    if (s && rc != EB_ErrorNone) { s->flags &= ~(ST_RECON | ST_DBL | ST_HOST_STALE); s->defer = 0; }   /* the C filter runs on the host picture, which nothing has touched yet */
+    if (s && rc != EB_ErrorNone) { s->flags &= ~(ST_RECON | ST_DBL | ST_HOST_STALE); s->defer = 0; }   /* the C filter runs on the host picture, which nothing has touched (dlf_frame's download only reports a failure from before its first copy) */
     if (s) lf_leave(s);
     svt_hip_hooks_count(SVT_HIP_HOOK_DLF, rc == EB_ErrorNone);
     svt_hip_hooks_time(SVT_HIP_HOOK_DLF, t0);
@@ -1174,20 +1206,70 @@ int svt_hip_hook_rest_begin(PictureControlSet *pcs) {
 
 /* the picture's final reconstruction comes back: restored planes from d_rest, the others (and, inside a padded picture, the samples outside the cropped frame)
  * from the CDEF output with the border svt_extend_frame gives it, or the deblocked picture when CDEF was off */
-static void lf_final_download(SvtHipCtx *hip, LfState *s) {
+static EbErrorType lf_final_attempt(SvtHipCtx *hip, LfState *s, int attempt) {
     SvtHipLfPicture *p = &s->pic;
     EbPictureBufferDesc *rec = recon_of(s->pcs, p->pix_bytes == 2);
-    if ((s->flags & ST_SKIP1) && ensure_cdef_padded(hip, s) != EB_ErrorNone) {
-        SVT_LOG("svt_hip: the device lost a picture after its filter stages (%s)\n", svt_hip_last_error(hip));
-        return;
-    }
+    if (attempt == 0 && lf_fault("final_download")) return EB_ErrorUndefined;             /* tests: the device is gone before a byte has moved */
+    if ((s->flags & ST_SKIP1) && ensure_cdef_padded(hip, s) != EB_ErrorNone) return EB_ErrorUndefined;
     void *const *base = (s->flags & ST_CDEF) ? p->d_cdef : p->d_recon;
     const int rest = (s->flags & ST_REST) ? s->rest_mask : 0;
     const int whole = p->cw == p->w && p->ch == p->h ? rest : 0;   /* planes whose restored version covers the coded picture */
-    int rc = EB_ErrorNone;
+    EbErrorType rc = EB_ErrorNone;
     if (7 & ~whole) rc = download(hip, p, base, rec, 7 & ~whole, 0);
     if (rc == EB_ErrorNone && rest) rc = download(hip, p, p->d_rest, rec, rest, 1);
-    if (rc != EB_ErrorNone) SVT_LOG("svt_hip: download of a filtered picture failed (%s)\n", svt_hip_last_error(hip));
+    if (rc == EB_ErrorNone && attempt == 0 && lf_fault("final_download_late")) return EB_ErrorUndefined;   /* tests: a failure reported after copies were queued */
+    return rc;
+}
+/* The reference's own filter chain on the host picture, with the decisions the (hooked or C) searches left in the reference's structures — what dlf_kernel
+ * (EbDlfProcess.c:203-251), cdef_kernel (EbCdefProcess.c:524-572) and rest_kernel (EbRestProcess.c:540-548) would have done to it after their searches.  Only valid
+ * while the host picture is still the coded (unfiltered) one, i.e. for a deferred picture of which nothing has come back. */
+void svt_av1_cdef_frame(struct EncDecContext *context_ptr, SequenceControlSet *scs_ptr, PictureControlSet *pCs);
+void av1_cdef_frame16bit(struct EncDecContext *context_ptr, SequenceControlSet *scs_ptr, PictureControlSet *pCs);
+static void lf_host_chain(LfState *s) {
+    PictureControlSet *pcs = s->pcs;
+    SequenceControlSet *scs = (SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
+    Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
+    const int is16 = s->pic.pix_bytes == 2;
+    EbPictureBufferDesc *rec = recon_of(pcs, is16);
+    if (s->flags & ST_DBL) svt_av1_loop_filter_frame(rec, pcs, 0, 3);   /* the levels are in the frame header (picked by the hook or by the C search) */
+    if (scs->seq_header.enable_restoration) svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 0);
+    if (s->flags & ST_CDEF) {
+        if (is16) av1_cdef_frame16bit(0, scs, pcs); else svt_av1_cdef_frame(0, scs, pcs);
+    }
+    if (scs->seq_header.enable_restoration) {
+        svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 1);
+        for (int pl = 0; pl < 3; pl++)
+            svt_extend_frame(cm->frame_to_show->buffers[pl], cm->frame_to_show->crop_widths[pl > 0], cm->frame_to_show->crop_heights[pl > 0], cm->frame_to_show->strides[pl > 0],
+                             RESTORATION_BORDER, RESTORATION_BORDER, is16);
+    }
+    if ((s->flags & ST_REST) && s->rest_mask) svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0);
+}
+/* A deferred picture's only copy is the device's: if it cannot be brought back the encoder must not go on with the unfiltered host picture (the bitstream signals the
+ * filters; the picture is a reference and the reconstruction output).  In order: the download; once more when copies had been queued (a second complete pass makes the
+ * host whole whatever the first one left); the reference's own filter chain on the host when nothing had been written yet (the coded picture is still there, every
+ * decision is in the reference's structures); otherwise the encoder's fatal-error exit (EbCallback::error_handler = lib_svt_encoder_send_error_exit). */
+static void lf_final_download(SvtHipCtx *hip, LfState *s) {
+    tls_download_started = 0;
+    EbErrorType rc = lf_final_attempt(hip, s, 0);
+    if (rc != EB_ErrorNone && tls_download_started) {
+        SVT_LOG("svt_hip: download of a filtered picture failed (%s) - trying again\n", svt_hip_last_error(hip));
+        (void)svt_hip_sync(hip);
+        __sync_fetch_and_add(&g_lf_final_retries, 1);
+        rc = lf_final_attempt(hip, s, 1);
+    }
+    if (rc != EB_ErrorNone && !tls_download_started) {
+        SVT_LOG("svt_hip: the device lost a picture after its filter stages (%s) - filtering it on the host\n", svt_hip_last_error(hip));
+        lf_host_chain(s);
+        __sync_fetch_and_add(&g_lf_final_host_chains, 1);
+        rc = EB_ErrorNone;
+    }
+    if (rc != EB_ErrorNone) {
+        SVT_LOG("svt_hip: a filtered picture could not be brought back from the device (%s) - stopping the encoder\n", svt_hip_last_error(hip));
+        __sync_fetch_and_add(&g_lf_final_fatal, 1);
+        const SequenceControlSet *scs = (const SequenceControlSet *)s->pcs->scs_wrapper_ptr->object_ptr;
+        if (scs->encode_context_ptr && scs->encode_context_ptr->app_callback_ptr && scs->encode_context_ptr->app_callback_ptr->error_handler)
+            scs->encode_context_ptr->app_callback_ptr->error_handler(scs->encode_context_ptr->app_callback_ptr->handle, (uint32_t)EB_ErrorUndefined);
+    }
     s->flags &= ~ST_HOST_STALE;
 }
 void svt_hip_hook_picture_done(PictureControlSet *pcs) {

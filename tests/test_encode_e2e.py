@@ -681,6 +681,32 @@ def test_deferred_picture_recovers_from_a_failed_hook_on_cpu_test_double(stage, 
     _check_fault_recovery("cif_8bit_m6", CASES["cif_8bit_m6"], stage, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR}, "mock")
 
 
+def _check_final_download_failure(case, spec, fault, workdir, env, tag):
+    """The last step of a deferred picture -- its one download, in svt_hip_hook_picture_done -- fails: nothing has been written to the host yet
+    (final_download: the reference's own deblocking / CDEF / restoration chain runs on the coded picture the host still has, with the decisions the hooks left in the
+    reference's structures) or copies had been queued (final_download_late: a second complete download).  Either way the encoder must code what the reference codes."""
+    got = _encode_like(case, spec, workdir, dict(env, SVT_HIP_HOOKS="all", SVT_HIP_LF_FAULT=fault), f"{tag}_{fault}")
+    m = re.search(r"final_retries=(\d+) final_host_chains=(\d+) final_fatal=(\d+)", got["log"])
+    assert m, got["log"][-1500:]
+    retries, chains, fatal = map(int, m.groups())
+    assert fatal == 0 and (chains, retries) == ((spec[2], 0) if fault == "final_download" else (0, spec[2])), (retries, chains, fatal)
+    assert all(v[1] == 0 for v in got["hooks"].values()), got["hooks"]
+    return got
+
+
+@pytest.mark.parametrize("fault", ["final_download", "final_download_late"])
+@pytest.mark.parametrize("case", ["cif_8bit_m6", "cif_10bit_m6", "328x200_8bit_m6"])
+def test_deferred_picture_survives_a_failed_final_download_on_cpu_test_double(case, fault, workdir):
+    _check_final_download_failure(case, CASES[case], fault, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR}, "mock")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", ["final_download", "final_download_late"])
+def test_deferred_picture_survives_a_failed_final_download_on_gpu(fault, workdir):
+    got = _check_final_download_failure("cif_8bit_m6", CASES["cif_8bit_m6"], fault, workdir, {}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
+
+
 @pytest.mark.parametrize("stage", ["cdef_apply", "rest_apply"])
 def test_deferred_10bit_picture_recovers_from_a_failed_hook_on_cpu_test_double(stage, workdir):
     _check_fault_recovery("cif_10bit_m6", CASES["cif_10bit_m6"], stage, workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR}, "mock")
