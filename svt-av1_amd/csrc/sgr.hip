@@ -17,6 +17,8 @@
 // sums per (restoration unit, parameter set) — flt0/flt1 never leave the chip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "svt_hip_internal.h"
 #include "lds_stage.h"
 
@@ -885,6 +887,136 @@ wiener_walk_kernel(const WnPic a) {
     }
 }
 
+// ---- the same walk with the unit's input RESIDENT in LDS (8-bit planes; round 5).  A probe only changes the taps: the unit's samples — the CDEF output with the stripes'
+// context rows from the deblocked picture — are the same for all ~30 probes of a walk, yet the form above stages every 64 x 32 tile from memory for every probe (eleven
+// 1-byte loads per thread and tile, each behind ~25 instructions of index / clamp / stripe arithmetic: about half of a probe's instructions and all of its memory
+// latency).  Here the workgroup stages the whole unit ONCE, as bytes, one 38-row band per tile row (a band = the tile row's 32 rows + 3 context rows above and below, so the
+// stripe rules are applied once, at staging time), and a probe reads LDS only (plus the source samples of the error, which stay in the L2).  The horizontal pass takes its
+// seven taps as two v_dot4_i32_i8: the taps fit int8 (|f| <= 128, WIENER_FILT_TAP*_{MINV,MAXV}, centre = -2 x the others) and sum to zero, so the samples can be biased by
+// -128 into int8 without changing the sum (the launcher's kernels add 128 x sum(f) anyway: exact for any taps).  Units whose bands do not fit (above ~256 x 400 samples)
+// and 16-bit planes keep the form above; the launcher decides per launch.
+constexpr int kWnBandBytes = 124 * 1024;
+__global__ void __launch_bounds__(1024)
+wiener_walk8r_kernel(const WnPic a) {
+    const int z = blockIdx.y;
+    const uint8_t* __restrict__ dgd = (const uint8_t*)a.p[z].dgd; const uint8_t* __restrict__ dbl = (const uint8_t*)a.p[z].dbl; const uint8_t* __restrict__ src = (const uint8_t*)a.p[z].src;
+    int16_t* __restrict__ unit_wiener = a.p[z].unit_wiener; const uint8_t* __restrict__ active = a.p[z].active;
+    long long* __restrict__ err_out = a.p[z].err; uint32_t* __restrict__ probes_out = a.p[z].probes;
+    const int stride = a.p[z].stride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff,
+              stripe_h = a.p[z].stripe_h, dbl_stride = a.p[z].dbl_stride, src_stride = a.p[z].src_stride, win = a.p[z].win;
+    if ((int)blockIdx.x >= units_x * units_y) return;
+    __shared__ __attribute__((aligned(16))) uint8_t bands[kWnBandBytes];          // [tile row][S_IH][pitch]; byte column cb of a band row = sample x = rx0 - 4 + cb
+    __shared__ __attribute__((aligned(16))) uint16_t tmp[4][S_IH * S_TW];
+    __shared__ int taps[16];
+    __shared__ unsigned long long part[16];
+    __shared__ int go;
+    const int unit = blockIdx.x, tid = threadIdx.x, team = tid >> 8, tt = tid & 255;
+    if (!active[unit]) return;
+    const int ux = unit % units_x, uy = unit / units_x, off = (7 - win) >> 1;
+    const int rx0 = ux * unit_size, rx1 = ux == units_x - 1 ? pw : (ux + 1) * unit_size;
+    const int ry0 = max(uy * unit_size - voff, 0), ry1 = uy == units_y - 1 ? ph : (uy + 1) * unit_size - voff;
+    const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, ty_first = (ry0 + voff) / S_TH, tiles_y = (ry1 + voff + S_TH - 1) / S_TH - ty_first, n_tiles = tiles_x * tiles_y;
+    const int pitch = tiles_x * S_TW + 8, pitch_dw = pitch >> 2;
+    // ---- stage the unit once: a dword (four samples of one band row) per step
+    for (int i = tid; i < tiles_y * S_IH * pitch_dw; i += 1024) {
+        const int b = i / (S_IH * pitch_dw), rem = i - b * (S_IH * pitch_dw), r = rem / pitch_dw, cd = rem - r * pitch_dw;
+        const int y0 = (ty_first + b) * S_TH - voff, yy = y0 - 3 + r, xx0 = rx0 - 4 + 4 * cd;
+        const StripeCtx<uint8_t> sc = lr_stripe_of<uint8_t>(dbl, dbl_stride, y0, voff, stripe_h, ph);
+        const uint8_t* row; int lo, hi;
+        if (sc.above && yy < sc.sy0) { row = dbl + (ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * dbl_stride; lo = 0; hi = pw - 1; }
+        else if (sc.below && yy >= sc.sy1) { row = dbl + (ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * dbl_stride; lo = 0; hi = pw - 1; }
+        else { row = dgd + (ptrdiff_t)min(max(yy, -3), ph + 2) * stride; lo = -3; hi = pw + 2; }
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(xx0 + k, lo), hi)] << (8 * k);
+        ((uint32_t*)bands)[i] = v;
+    }
+    WnWalkState w;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { w.v[k] = unit_wiener[16 * unit + k]; w.h[k] = unit_wiener[16 * unit + 8 + k]; }
+        w.state = 1; w.err = 0; w.s = 0; w.ph = 0; w.p = 0; w.up = 0; w.skip = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        go = 1;
+    }
+    uint32_t n_probes = 0;
+    __syncthreads();
+    while (go) {
+        int fy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) fy[k] = taps[k];
+        // horizontal taps as two int8 quadruples; hbase = the rounding offset + 128 x their sum (zero for the symmetric filters the walk produces)
+        const int f0 = taps[8], f1 = taps[9], f2 = taps[10], f3 = taps[11], f4 = taps[12], f5 = taps[13], f6 = taps[14];
+        const int TA = (f0 & 0xff) | (f1 & 0xff) << 8 | (f2 & 0xff) << 16 | (f3 & 0xff) << 24, TB = (f4 & 0xff) | (f5 & 0xff) << 8 | (f6 & 0xff) << 16;
+        const int hbase = (1 << (8 + 6)) + 4 + 128 * (f0 + f1 + f2 + f3 + f4 + f5 + f6);
+        unsigned long long sse = 0;
+        for (int t = team; t < n_tiles; t += 4) {   // uniform per team: its four waves pass the same barriers
+            const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+            const int x0 = rx0 + txi * S_TW, y0 = (ty_first + tyi) * S_TH - voff;
+            const uint8_t* band = bands + (size_t)tyi * S_IH * pitch + txi * S_TW;
+            const int j = tt & 63, i0 = (tt >> 6) * 8;
+            int sv[8];   // the source samples of the error first: their loads are in flight during the horizontal pass
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int x = x0 + j, y = y0 + i0 + r;
+                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : (int)src[(size_t)y * src_stride + x];
+            }
+            // horizontal pass (round 3): four outputs from twelve bytes (three aligned dwords; the ten inputs are bytes 1..10)
+            for (int g = tt; g < S_IH * (S_TW / 4); g += 256) {
+                const int r = g >> 4, c = (g & 15) << 2;
+                const uint32_t* wd = (const uint32_t*)(band + r * pitch + c);
+                const uint32_t d0 = wd[0], d1 = wd[1], d2 = wd[2];
+                const uint32_t e0 = d0 ^ 0x80808080u, e1 = d1 ^ 0x80808080u, e2 = d2 ^ 0x80808080u;
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t A = q == 3 ? e1 : __builtin_amdgcn_alignbyte(e1, e0, (uint32_t)(q + 1)), B = q == 3 ? e2 : __builtin_amdgcn_alignbyte(e2, e1, (uint32_t)(q + 1));
+                    int sum = (int)(((d1 >> (8 * q)) & 0xffu) << 7) + hbase;
+                    sum = __builtin_amdgcn_sdot4((int)A, TA, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int)B, TB, sum, false);
+                    o[q] = (uint32_t)min(max(sum >> 3, 0), (1 << (8 + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, 8)
+                }
+                uint32_t* out = (uint32_t*)(tmp[team] + r * S_TW + c);
+                out[0] = o[0] | (o[1] << 16); out[1] = o[2] | (o[3] << 16);
+            }
+            __syncthreads();
+            uint32_t e = 0;
+            int v8[8];
+            wiener_vcol8<8>(tmp[team], i0, j, fy, v8);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (sv[r] < 0) continue;
+                const int d = v8[r] - sv[r];
+                e += (uint32_t)(d * d);
+            }
+            sse += e;
+            __syncthreads();   // tmp is rewritten by the team's next tile
+        }
+        if (n_tiles % 4 && team >= n_tiles % 4) { __syncthreads(); __syncthreads(); }   // teams that ran one tile fewer make up their two barriers
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sse += ((unsigned long long)(uint32_t)__shfl_xor((int)(sse >> 32), m, 64) << 32) | (uint32_t)__shfl_xor((int)sse, m, 64);
+        if ((tid & 63) == 0) part[tid >> 6] = sse;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) tot += part[k];
+            n_probes++;
+            go = wn_result(w, (long long)tot, off) ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { unit_wiener[16 * unit + k] = w.v[k]; unit_wiener[16 * unit + 8 + k] = w.h[k]; }
+        err_out[unit] = w.err;
+        if (probes_out) probes_out[unit] = n_probes;
+    }
+}
+
 }  // namespace
 
 extern "C" int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes) {
@@ -900,7 +1032,22 @@ extern "C" int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, i
     }
     if (n <= 0) return 0;
     const dim3 grid(n, n_planes);
-    if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), grid, dim3(1024), 0, st, a);
+    // the resident-input form (8-bit): every unit's bands must fit its LDS window; SVT_HIP_WIENER_WALK=tiles keeps the form that stages tile by tile (A/B runs)
+    static int form = -1;
+    if (form < 0) { const char* e = getenv("SVT_HIP_WIENER_WALK"); form = e && !strcmp(e, "tiles") ? 0 : 1; }
+    bool fits = pix_bytes == 1 && form == 1;
+    for (int i = 0; i < n_planes && fits; i++) {
+        const WnPlane& q = a.p[i];
+        for (int uy = 0; uy < q.units_y && fits; uy++)
+            for (int ux = 0; ux < q.units_x && fits; ux += (q.units_x > 2 && ux == 0) ? q.units_x - 2 : 1) {   // the first and the last two columns cover every width
+                const int rx0 = ux * q.unit_size, rx1 = ux == q.units_x - 1 ? q.pw : (ux + 1) * q.unit_size;
+                const int ry0 = max(uy * q.unit_size - q.voff, 0), ry1 = uy == q.units_y - 1 ? q.ph : (uy + 1) * q.unit_size - q.voff;
+                const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, tiles_y = (ry1 + q.voff + S_TH - 1) / S_TH - (ry0 + q.voff) / S_TH;
+                fits = (size_t)tiles_y * S_IH * (tiles_x * S_TW + 8) <= (size_t)kWnBandBytes;
+            }
+    }
+    if (fits) hipLaunchKernelGGL(wiener_walk8r_kernel, grid, dim3(1024), 0, st, a);
+    else if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), grid, dim3(1024), 0, st, a);
     else if (bd == 8) hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 8>), grid, dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 10>), grid, dim3(1024), 0, st, a);
     return (int)hipGetLastError();
