@@ -526,17 +526,18 @@ def main():
     # ---- the BASELINE.json configurations the headline step does not cover, as sub-lines (tools/bench_variants.py, one short subprocess each):
     #      configs[1] (1080p: ME with FULL / SUB_SAD search, transform chain 4..32 with quantize_b / quantize_fp at four q-indices) and configs[3] (4K 10-bit:
     #      HBD SAD / variance, the 64-point transform chain, the self-guided search and filter on 16-bit planes)
-    also_10bit = config1_variants = None
+    also_10bit = config1_variants = config2_subpel = None
     if world == 1 and not args.no_variants and not args.no_sweep and (args.width, args.height) == (3840, 2160):
         import subprocess
-        for which in ("10bit", "config1"):
+        for which in ("10bit", "config1", "config2"):
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_variants.py"), "--which", which], capture_output=True, text=True, timeout=420)
                 d2 = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as ex:   # the headline run must not depend on it
                 d2 = {"error": str(ex)[:200]}
             if which == "10bit": also_10bit = d2
-            else: config1_variants = d2
+            elif which == "config1": config1_variants = d2
+            else: config2_subpel = d2   # BASELINE configs[2]'s sub-pel part: the eight-neighbour probes + the x-only / y-only / copy convolves, each gated against the reference
 
     # ---- per-stage device time with HIP events on the launch stream (outside the headline timing): `reps` back-to-back passes of one stage of
     #      ONE frame (one captured graph unless --no-graph), so the figure is that stage's kernel time alone on an otherwise idle GPU
@@ -706,7 +707,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame, "
                   f"steps rotate over {len(step_fns)} batches = {len(step_fns) * nF} distinct frames",
-        "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p, "also_10bit": also_10bit, "config1_variants": config1_variants,
+        "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p, "also_10bit": also_10bit, "config1_variants": config1_variants, "config2_subpel": config2_subpel,
         "frames_per_step_sweep": sweep,
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frames, {n_sb} SBs/frame, {nF} independent frames per step per GPU (F = 1 / 4 / 8 in frames_per_step_sweep); "
                                "stages per frame: " + ",".join(n for _, n in stages)
@@ -715,7 +716,8 @@ def main():
                                  "square tx tiling 4..64 per SB, quantize_b qindex 60; deblock levels (20,20,12,12) on the reconstruction; CDEF full 64-strength search on the "
                                  "deblocked picture, finish_cdef_search's strength decision on that table (lambda of base_q_idx 120), apply with the strengths it chose; "
                                  "restoration: complete search_selfguided_restoration of every unit (16 sets, units 256, solve + finer search on the device) on the CDEF "
-                                 "output, apply with the sets it chose",
+                                 "output, apply with the sets it chose; generator: numpy default_rng (PCG64) seeded with SURVEY 8(d)'s seed numbers (11 + 100 rank + 7 frame ...), not std::mt19937 - "
+                                 "the device and the checkers read the same arrays, so parity does not depend on the generator (stated deviation from SURVEY 8(d))",
                    "stages_ms": per_stage, "stages_ms_note": "one frame, stage alone on an idle GPU (HIP events around 10 back-to-back passes); cdef_strength_select in the form a one-frame step uses",
                    "cdef_strength_select_forms_ms": select_forms_ms,
                    "cdef_strength_select_form": {"frames_per_step == 1": "resident (one launch)", "frames_per_step > 1": "steps (80 launches)"} if forced_form is None
@@ -724,9 +726,17 @@ def main():
         "cpu_baseline": cpu,
     }
     out["roofline"] = roofline(per_stage, stages, n_sb)
+    if isinstance(config2_subpel, dict) and "convolve_sr_16x16_blocks" in config2_subpel:   # the sub-line's kernels next to the step's stages (memory-bound: against HBM)
+        for name, e in list(config2_subpel["convolve_sr_16x16_blocks"].items()) + [("upsampled_pred_variance_8_neighbours", config2_subpel["upsampled_pred_variance_8_neighbours"])]:
+            out["roofline"]["stages"]["config2/" + name] = {k: e.get(k) for k in ("ms", "algorithmic_bytes", "algorithmic_GBps", "hbm_frac", "traffic_bytes")}
+        if config2_subpel.get("gate") is False:
+            out["value"] = None
+            out["config"]["parity_spot_check"] = False
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if isinstance(config2_subpel, dict) and config2_subpel.get("gate") is False:
+        raise SystemExit("bench.py: the configs[2] sub-line differs from the reference's kernels - the timing is not a result (config2_subpel.gate_vs_reference_simd says where)")
     if parity_ok is False:
         raise SystemExit("bench.py: the parity gate failed - the timing is not a result (parity_detail says which stage)")
 

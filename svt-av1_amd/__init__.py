@@ -72,6 +72,12 @@ class MdRefPlane(C.Structure):
     _fields_ = [("d_plane", C.c_void_p), ("stride", C.c_int32), ("x_min", C.c_int32), ("y_min", C.c_int32), ("x_max", C.c_int32), ("y_max", C.c_int32)]
 
 
+class UpsampledBlk(C.Structure):
+    """SvtHipUpsampledBlk (include/svt_hip.h)."""
+    _fields_ = [("ref_off", C.c_int32), ("dst_off", C.c_int32), ("w", C.c_uint8), ("h", C.c_uint8), ("subpel_x_q3", C.c_uint8), ("subpel_y_q3", C.c_uint8), ("bank", C.c_uint8),
+                ("reserved", C.c_uint8 * 3)]
+
+
 class BlkPair(C.Structure):
     """SvtHipBlkPair (include/svt_hip.h)."""
     _fields_ = [("a_x", C.c_int32), ("a_y", C.c_int32), ("b_x", C.c_int32), ("b_y", C.c_int32), ("w", C.c_uint16), ("h", C.c_uint16)]

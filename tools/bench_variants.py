@@ -5,6 +5,8 @@ each prints ONE JSON object):
   --which config1   configs[1]: 1920x1080 8-bit 4:2:0, all 510 SBs — full-pel 85-PU ME with FULL_SAD_SEARCH and SUB_SAD_SEARCH, and the transform
                     chain residual -> fwd txfm2d 4..32 -> quantize -> inverse -> reconstruction with svt_aom_quantize_b and svt_av1_quantize_fp at
                     qindex 20 / 60 / 120 / 200 (SURVEY 8(d) config 2's variants)
+  --which config2   configs[2], the sub-pel part: svt_upsampled_pref_error (svt_aom_upsampled_pred + svt_aom_variance16x16) of the eight half-pel neighbours of every
+                    16x16 block's vector of a 4K frame, and the four svt_av1_convolve_{2d,x,y,2d_copy}_sr kernels on every 16x16 block, each gated against the reference's SIMD kernels
   --which 10bit     configs[3]: 3840x2160 10-bit 4:2:0 (16-bit planes) — sad_16b_kernel over a 64x64 window for every 64x64 block, HBD SAD + highbd_10
                     variance of every 64x64 / 32x32 pair, the 64-point transform chain (64x64, 64x32, 32x64, 64x16, 16x64; highbd quantize_b / quantize_fp)
                     of the whole luma plane, the complete self-guided unit search (16 sets, three planes) and the restoration apply with the sets it chose
@@ -91,6 +93,105 @@ def config1(reps):
             out["txfm_chain"].setdefault(vname, {})[f"qindex_{q}"] = {"ms": ms, "blocks": nblk, "sb_per_s": n_sb / (ms * 1e-3)}
         del P
     out["n_sb"] = n_sb
+    print(json.dumps(out))
+
+
+def config2(reps):
+    """BASELINE configs[2] / SURVEY 8(d) config 3 (ii), the sub-pel part the headline step only samples: (a) svt_upsampled_pref_error of the EIGHT neighbours of every
+    16x16 block's vector (svt_first_level_check's probes of the first round, half-pel: svt_aom_upsampled_pred + svt_aom_variance16x16, mcomp.c:102-156,
+    variance.c:212-269), (b) the four svt_av1_convolve_{2d,x,y,2d_copy}_sr kernels on every 16x16 block of the frame at fixed phases.  Every timed launch is then
+    recomputed by the reference's SIMD kernels (oracle/_ref/libsvtav1_ref_simd.so, after the timed regions) and compared bit for bit."""
+    torch, bench, E, stream = setup()
+    pkg, L, ctx = E.pkg, E.L, E.ctx
+    W, H = 3840, 2160
+    F = E.workload.Frame(W, H, seed=11)
+    n_sb = F.n_sb
+    PAD = F.pad
+    refp, cur = F.ref_y_p, F.cur[0]                     # padded reference luma (pad = 68), unpadded source luma
+    st = refp.shape[1]
+    rng = np.random.default_rng(5)
+    nbx, nby = W // 16, H // 16
+    nblk = nbx * nby
+    mvx = rng.integers(-12, 13, nblk).astype(np.int32) * 8; mvy = rng.integers(-12, 13, nblk).astype(np.int32) * 8   # full-pel vectors, eighth-pel units
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(E.dev)
+    d_ref, d_cur = T(refp), T(cur)
+    out = {"config": "BASELINE configs[2] sub-pel part on one 3840x2160 8-bit frame (SURVEY 8(d) config 3 ii): 32 400 luma 16x16 blocks", "unit": "ms per frame (HIP events)", "n_sb": n_sb}
+    HBM = 8.0e12
+    # ---- (a) the eight half-pel neighbours of every block's vector: upsampled_pred (8-tap) + variance16x16
+    jobs = (pkg.UpsampledBlk * (8 * nblk))() if hasattr(pkg, "UpsampledBlk") else None
+    assert jobs is not None
+    src_off = np.zeros(8 * nblk, np.int32)
+    pairs = (pkg.BlkPair * (8 * nblk))()
+    k = 0
+    for b in range(nblk):
+        bx, by = (b % nbx) * 16, (b // nbx) * 16
+        for dy in (-4, 0, 4):
+            for dx in (-4, 0, 4):
+                if not dx and not dy: continue
+                cx, cy = int(mvx[b]) + dx, int(mvy[b]) + dy
+                ro = (by + PAD + (cy >> 3)) * st + bx + PAD + (cx >> 3)
+                jobs[k] = pkg.UpsampledBlk(ro, k * 256, 16, 16, cx & 7, cy & 7, 0)
+                src_off[k] = by * W + bx
+                pairs[k] = pkg.BlkPair(0, k * 16, bx, by, 16, 16)   # prediction k is a 16-wide strip of a packed [8 nblk * 16][16] plane
+                k += 1
+    d_jobs, d_pairs = T(np.frombuffer(bytes(jobs), np.uint8).copy()), T(np.frombuffer(bytes(pairs), np.uint8).copy())
+    d_pred = torch.zeros(8 * nblk * 256, dtype=torch.uint8, device=E.dev)
+    d_var = torch.zeros(8 * nblk, dtype=torch.int32, device=E.dev); d_sse = torch.zeros(8 * nblk, dtype=torch.int32, device=E.dev)
+
+    def probes():
+        ctx.check(L.svt_hip_upsampled_pred_batch_dev(ctx.h, d_ref.data_ptr(), st, d_pred.data_ptr(), d_jobs.data_ptr(), 8 * nblk), "upsampled pred")
+        ctx.check(L.svt_hip_block_variance_batch_dev(ctx.h, 1, 8, d_pred.data_ptr(), 16, d_cur.data_ptr(), W, d_pairs.data_ptr(), 8 * nblk, d_var.data_ptr(), d_sse.data_ptr()), "variance")
+    ms = timed(torch, stream, probes, reps)
+    alg = nblk * (25 * 25 + 256 + 8 * 8)   # per block: the (16 + 8 + 1)^2 window its eight probes share + the source block, read once; 8 x (variance, sse) out
+    out["upsampled_pred_variance_8_neighbours"] = {"ms": ms, "candidates": 8 * nblk, "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac": alg / (ms * 1e-3) / HBM,
+                                                   "sb_per_s": n_sb / (ms * 1e-3), "traffic_bytes": None,
+                                                   "note": "the 66 MB of predictions written and read back between the two launches are not algorithmic bytes: a fused probe kernel would keep them on chip"}
+    g_var, g_sse = d_var.cpu().numpy().view(np.uint32), d_sse.cpu().numpy().view(np.uint32)
+    # ---- (b) the four single-reference convolves on every 16x16 block at fixed phases (regular 8-tap)
+    CB = (pkg.ConvBlk * nblk)()
+    d_dst = torch.zeros((H, W), dtype=torch.uint8, device=E.dev)
+    conv = {}
+    conv_out = {}
+    for name, sx, sy, alg_blk in (("svt_av1_convolve_2d_sr", 5, 11, 23 * 23 + 256), ("svt_av1_convolve_x_sr", 5, 0, 16 * 23 + 256), ("svt_av1_convolve_y_sr", 0, 11, 23 * 16 + 256),
+                                  ("svt_av1_convolve_2d_copy_sr", 0, 0, 256 + 256)):
+        for b in range(nblk):
+            bx, by = (b % nbx) * 16, (b // nbx) * 16
+            CB[b] = pkg.ConvBlk(bx + (int(mvx[b]) >> 3), by + (int(mvy[b]) >> 3), bx, by, 16, 16, 0, 0, sx, sy, 0, 0)
+        d_cb = T(np.frombuffer(bytes(CB), np.uint8).copy())
+        off = PAD * st + PAD
+        fn = lambda d_cb=d_cb: ctx.check(L.svt_hip_subpel_predict_batch_dev(ctx.h, 1, 8, d_ref.data_ptr() + off, st, d_dst.data_ptr(), W, d_cb.data_ptr(), nblk), "convolve")
+        ms = timed(torch, stream, fn, reps)
+        alg = nblk * alg_blk
+        conv[name] = {"ms": ms, "algorithmic_bytes": alg, "algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac": alg / (ms * 1e-3) / HBM, "sb_per_s": n_sb / (ms * 1e-3), "traffic_bytes": None}
+        conv_out[name] = (d_dst.cpu().numpy().copy(), np.frombuffer(bytes(CB), np.uint8).copy())
+    out["convolve_sr_16x16_blocks"] = conv
+    # ---- the gate (after every timed region): the reference's own SIMD kernels on the same jobs
+    import ctypes as Cc
+    from concurrent.futures import ThreadPoolExecutor
+    simd = os.path.join(ROOT, "oracle", "_ref", "libsvtav1_ref_simd.so")
+    gate = {}
+    if os.path.exists(simd):
+        R = Cc.CDLL(simd)
+        R.refb_setup.restype = Cc.c_uint64; R.refb_setup.argtypes = [Cc.c_uint64]
+        R.refb_setup(0xffffffffffffffff)
+        nt = min(32, os.cpu_count() or 1)
+        e_var, e_sse = np.zeros(8 * nblk, np.uint32), np.zeros(8 * nblk, np.uint32)
+        jb = np.frombuffer(bytes(jobs), np.uint8).copy()
+        vp = lambda a: a.ctypes.data_as(Cc.c_void_p)
+        with ThreadPoolExecutor(nt) as ex:
+            list(ex.map(lambda be: R.refb_upsampled_var_batch(vp(refp), st, vp(cur), W, vp(jb), vp(src_off), be[0], be[1], vp(e_var), vp(e_sse)),
+                        [(i * 8 * nblk // nt, (i + 1) * 8 * nblk // nt) for i in range(nt)]))
+        gate["upsampled_pred_variance_8_neighbours"] = bool(np.array_equal(e_var, g_var) and np.array_equal(e_sse, g_sse))
+        for name, (got, cb) in conv_out.items():
+            exp = np.zeros((H, W), np.uint8)
+            base = Cc.c_void_p(refp.ctypes.data + PAD * st + PAD)
+            with ThreadPoolExecutor(nt) as ex:
+                list(ex.map(lambda be: R.refb_subpel_predict_batch(base, st, vp(exp), W, vp(cb), be[0], be[1]), [(i * nblk // nt, (i + 1) * nblk // nt) for i in range(nt)]))
+            gate[name] = bool(np.array_equal(exp, got))
+        out["gate_vs_reference_simd"] = gate
+        out["gate"] = all(gate.values())
+    else:
+        out["gate"] = None
     print(json.dumps(out))
 
 
@@ -205,7 +306,7 @@ def hbd(reps):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", required=True, choices=["config1", "10bit"])
+    ap.add_argument("--which", required=True, choices=["config1", "10bit", "config2"])
     ap.add_argument("--reps", type=int, default=10)
     a = ap.parse_args()
-    config1(a.reps) if a.which == "config1" else hbd(a.reps)
+    config1(a.reps) if a.which == "config1" else (config2(a.reps) if a.which == "config2" else hbd(a.reps))
