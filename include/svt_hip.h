@@ -886,6 +886,17 @@ typedef struct { uint8_t x, y, w, h; } SvtHipMdPu;   /* w a multiple of 4, at mo
 typedef struct { const uint8_t *d_plane; int32_t stride, x_min, y_min, x_max, y_max; } SvtHipMdRefPlane;
 int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
                                        const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, uint32_t *d_sad);
+/* The probes of mode decision's sub-pel refinement (md_subpel_search, Encoder/Codec/EbProductCodingLoop.c:2063 -> svt_av1_find_best_sub_pixel_tree, mcomp.c:350): every probe
+ * is svt_upsampled_pref_error (mcomp.c:102) = svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269) + svt_aom_variance{W}x{W} against the source.  The tree starts at
+ * the block's full-pel vector and its half-pel and quarter-pel rounds stay inside the 7 x 7 quarter-pel grid around it, so one launch per picture computes, for every
+ * (superblock, square PU of `pus`, reference picture), all 49 grid positions:
+ *   d_out : [n_sb][n_pus][n_refs][49][2] = (variance, sse) of grid position 7 * row + col, offsets (2 col - 6, 2 row - 6) eighth-samples from the full-pel vector in d_mv;
+ *           0xffffffff pairs = not computed (no vector, PU outside the picture or not 8 / 16 / 32 / 64 square, window outside the reference's allocation)
+ *   bank  : the interpolation kernels of subpel_search_type as in SvtHipUpsampledBlk (0 = USE_8_TAPS, 4 = USE_4_TAPS, 3 = USE_2_TAPS)
+ * The other arguments are svt_hip_md_fullpel_sad_picture_dev's. */
+#define SVT_HIP_MD_GRID 49
+int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                       int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int bank, uint32_t *d_out);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

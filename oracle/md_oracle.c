@@ -41,3 +41,33 @@ void orc_md_fullpel_sad_picture(const uint8_t *src, int src_stride, int pic_w, i
                 sad[slot] = orc_md_fullpel_candidate(src, src_stride, refs[r], ref_stride[r], x, y, w, h, mx, my);
             }
 }
+
+/* One probe of the sub-pel refinement: svt_upsampled_pref_error (Encoder/Codec/mcomp.c:102-156) = svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269, orc_upsampled_pred)
+ * into a scratch block + the square block's variance (orc_variance = svt_aom_variance{W}x{H}_c).  (mvx8, mvy8): the probed vector in eighth-samples. */
+void     orc_upsampled_pred(const uint8_t *ref, int ref_stride, uint8_t *dst, int w, int h, int subpel_x_q3, int subpel_y_q3, int bank);
+uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse);
+uint32_t orc_md_subpel_probe(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int x, int y, int s, int mvx8, int mvy8, int bank, uint32_t *sse) {
+    uint8_t pred[64 * 64];
+    orc_upsampled_pred(ref + (ptrdiff_t)(y + (mvy8 >> 3)) * ref_stride + x + (mvx8 >> 3), ref_stride, pred, s, s, mvx8 & 7, mvy8 & 7, bank);
+    return orc_variance(pred, s, src + (ptrdiff_t)y * src_stride + x, src_stride, s, s, sse);
+}
+/* the table of svt_hip_md_subpel_grid_picture_dev: [n_sb][n_pus][n_refs][49][2] */
+void orc_md_subpel_grid_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                const uint8_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int bank, uint32_t *out) {
+    for (int sb = 0; sb < n_sb; sb++)
+        for (int p = 0; p < n_pus; p++)
+            for (int r = 0; r < n_refs; r++) {
+                const size_t slot = ((size_t)sb * n_pus + p) * n_refs + r;
+                uint32_t *o = out + slot * 98;
+                const int x = (sb % sb_cols) * 64 + pus[p][0], y = (sb / sb_cols) * 64 + pus[p][1], s = pus[p][2];
+                const int mx = (int16_t)(mv[slot] & 0xffff), my = (int16_t)(mv[slot] >> 16), wx = x + mx - 4, wy = y + my - 4;
+                if (mx == -32768 || pus[p][3] != s || (s != 8 && s != 16 && s != 32 && s != 64) || x + s > pic_w || y + s > pic_h || wx < ref_box[r][0] || wy < ref_box[r][1] ||
+                    wx + s + 12 > ref_box[r][2] || wy + s + 8 > ref_box[r][3]) {
+                    for (int i = 0; i < 98; i++) o[i] = 0xffffffffu;
+                    continue;
+                }
+                for (int gy = 0; gy < 7; gy++)
+                    for (int gx = 0; gx < 7; gx++)
+                        o[2 * (7 * gy + gx)] = orc_md_subpel_probe(src, src_stride, refs[r], ref_stride[r], x, y, s, 8 * mx + 2 * gx - 6, 8 * my + 2 * gy - 6, bank, &o[2 * (7 * gy + gx) + 1]);
+            }
+}

@@ -15,6 +15,7 @@
 // HBM-bound in principle (algorithmic bytes per (SB, reference): 4096 source + ~4 x 4096 reference samples + 85 x 8 table bytes), launch-bound in practice:
 // a 1080p picture with 7 references is 3 570 workgroups of ~30 iterations.
 #include "svt_hip_internal.h"
+#include "interp_kernels.h"
 
 namespace {
 
@@ -62,6 +63,133 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
     }
 }
 
+// ---- the sub-pel refinement's probes (md_subpel_search, EbProductCodingLoop.c:2063 -> svt_av1_find_best_sub_pixel_tree, mcomp.c:350): every probe is
+// svt_upsampled_pref_error (:102) = svt_aom_upsampled_pred (C_DEFAULT/variance.c:212-269: an 8-tap horizontal pass and an 8-tap vertical pass, each rounded and clipped to
+// 8 bits) + the block size's variance function against the source.  The tree starts at the block's full-pel vector and visits, in its half-pel and quarter-pel rounds,
+// positions inside the 7 x 7 quarter-pel grid of +-6/8 sample around it: one workgroup per (superblock, PU, reference picture) computes (variance, sse) of ALL 49 grid
+// positions — the probes of both rounds whichever way the comparisons go.  The passes are separable with an 8-bit intermediate, so the horizontal pass runs once per
+// horizontal offset (7) over the PU's window and the vertical pass + statistics once per grid position (49), both as v_dot4_i32_i8 on four outputs per lane
+// (samples biased by -128; the taps of the non-zero phases fit int8 and sum to 128: the bias is added back exactly).  LDS: the window, the seven intermediates
+// (column-major: the vertical pass reads its eleven rows as three dwords) and the transposed source: 41 KB for a 64x64 PU.
+constexpr int kGrid = 7, kGridN = kGrid * kGrid;
+__device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2, int sh) {   // bytes sh .. sh + 3 of the twelve bytes d0 d1 d2 (sh <= 8)
+    return sh < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh) : (sh < 8 ? __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(sh - 4)) : d2);
+}
+__device__ __forceinline__ uint32_t filt4(uint32_t d0, uint32_t d1, uint32_t d2, int o, int TA, int TB) {
+    // four outputs of an 8-tap pass: output q reads bytes o + q .. o + q + 7 of (d0 d1 d2) ^ 0x80; result packed as four bytes
+    uint32_t P = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int sum = 128 * 128 + 64;
+        sum = __builtin_amdgcn_sdot4((int)bytes4(d0, d1, d2, o + q), TA, sum, false);
+        sum = __builtin_amdgcn_sdot4((int)(o + q + 4 <= 8 ? bytes4(d0, d1, d2, o + q + 4) : 0u), TB, sum, false);
+        int v = min(max(sum >> 7, 0), 255);
+        // Without this the compiler (ROCm 7.2 clang, gfx950) fuses shift + clamp + pack of two outputs into v_ashr_pk_u8_i32, whose result on the MI355X had bit 7 set
+        // in the bytes it produced (constant input 100 came out as 228; the other two outputs of the same lane, clamped with v_med3_i32, were right): the empty
+        // asm keeps the clamp a v_med3_i32 for all four.  tests/test_md_pre_gpu.py::test_md_subpel_grid_picture is what noticed.
+        asm volatile("" : "+v"(v));
+        P |= (uint32_t)v << (8 * q);
+    }
+    return P;
+}
+__device__ __constant__ int8_t kGridOff[kGrid][2] = {{-1, 2}, {-1, 4}, {-1, 6}, {0, 0}, {0, 2}, {0, 4}, {0, 6}};   // grid offset -6 .. 6 (1/8 sample) = whole part, eighth-pel phase
+__global__ void __launch_bounds__(256)
+md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus,
+                      const uint32_t* __restrict__ mv, int bank, uint32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[72 * 72];          // [row][col], row pitch WIN
+    __shared__ __attribute__((aligned(16))) uint8_t Hc[kGrid][64 * 72];    // [offset][col][row], column pitch WIN
+    __shared__ __attribute__((aligned(16))) uint8_t Sc[64 * 64];           // source, [col][row]
+    __shared__ uint32_t stat[kGridN][3];                                   // sum p, sum p^2, sum p s
+    __shared__ uint32_t sstat[2];                                          // sum s, sum s^2
+    const int sb = blockIdx.x, pu = blockIdx.y, r = blockIdx.z, tid = threadIdx.x;
+    const size_t slot = ((size_t)sb * n_pus + pu) * n_refs + r;
+    uint32_t* o = out + slot * (2 * kGridN);
+    const int s = pus.w[pu], x = (sb % sb_cols) * 64 + pus.x[pu], y = (sb / sb_cols) * 64 + pus.y[pu], WIN = s + 8;
+    const SvtHipMdRefPlane ref = refs.r[r];
+    const uint32_t m = mv[slot];
+    const int mx = (int16_t)(m & 0xffff), my = (int16_t)(m >> 16), wx = x + mx - 4, wy = y + my - 4;
+    const bool ok = mx != SVT_HIP_MD_NO_MV && pus.h[pu] == s && (s == 8 || s == 16 || s == 32 || s == 64) && x + s <= pic_w && y + s <= pic_h && wx >= ref.x_min && wy >= ref.y_min &&
+                    wx + WIN + 4 <= ref.x_max && wy + WIN <= ref.y_max;
+    if (!ok) {   // workgroup-uniform
+        for (int i = tid; i < 2 * kGridN; i += 256) o[i] = 0xffffffffu;
+        return;
+    }
+    for (int i = tid; i < kGridN * 3 + 2; i += 256) { if (i < kGridN * 3) stat[i / 3][i % 3] = 0; else sstat[i - kGridN * 3] = 0; }
+    // ---- stage the window (rows as dwords) and the source (transposed)
+    const int wdw = WIN >> 2;
+    for (int i = tid; i < WIN * wdw; i += 256) {
+        const int rr = i / wdw, cd = i - rr * wdw;
+        ((uint32_t*)win)[rr * wdw + cd] = load4_any(ref.d_plane + (ptrdiff_t)(wy + rr) * ref.stride + wx + 4 * cd);
+    }
+    __syncthreads();   // (also orders the zeroing of the statistics before their first update)
+    {
+        uint32_t ss = 0, ss2 = 0;
+        for (int i = tid; i < s * (s >> 2); i += 256) {
+            const int rr = i / (s >> 2), c = (i - rr * (s >> 2)) << 2;
+            const uint32_t v = load4_any(src + (ptrdiff_t)(y + rr) * src_stride + x + c);
+#pragma unroll
+            for (int q = 0; q < 4; q++) Sc[(c + q) * s + rr] = (uint8_t)(v >> (8 * q));
+            ss += __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false); ss2 += __builtin_amdgcn_udot4(v, v, 0u, false);
+        }
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) { ss += (uint32_t)__shfl_xor((int)ss, k, 64); ss2 += (uint32_t)__shfl_xor((int)ss2, k, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&sstat[0], ss); atomicAdd(&sstat[1], ss2); }
+    }
+    // ---- horizontal pass, once per horizontal offset: Hc[a][col][row] over all WIN rows
+    for (int t = tid; t < kGrid * WIN * (s >> 2); t += 256) {
+        const int a = t / (WIN * (s >> 2)), rem = t - a * (WIN * (s >> 2)), rr = rem / (s >> 2), j = (rem - rr * (s >> 2)) << 2;
+        const int ix = kGridOff[a][0], fx = kGridOff[a][1];
+        const int ob = j + ix + 1;                     // first byte of output 0's eight taps in the window row
+        const uint32_t* wd = (const uint32_t*)(win + rr * WIN + (ob & ~3));
+        const uint32_t d0 = wd[0], d1 = wd[1], d2 = wd[2];   // (the last dword of the last row may lie past the window: inside the array, unused bytes)
+        uint32_t P;
+        if (fx == 0) P = bytes4(d0, d1, d2, (ob & 3) + 3);
+        else {
+            const int TA = (kInterp[bank][fx << 1][0] & 0xff) | (kInterp[bank][fx << 1][1] & 0xff) << 8 | (kInterp[bank][fx << 1][2] & 0xff) << 16 | (kInterp[bank][fx << 1][3] & 0xff) << 24;
+            const int TB = (kInterp[bank][fx << 1][4] & 0xff) | (kInterp[bank][fx << 1][5] & 0xff) << 8 | (kInterp[bank][fx << 1][6] & 0xff) << 16 | (kInterp[bank][fx << 1][7] & 0xff) << 24;
+            P = filt4(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, ob & 3, TA, TB);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) Hc[a][(j + q) * WIN + rr] = (uint8_t)(P >> (8 * q));
+    }
+    __syncthreads();
+    // ---- vertical pass + statistics, once per grid position: a task = four vertically adjacent outputs of one column
+    const int per = s * (s >> 2);                       // tasks per grid position
+    const int G = per < 64 ? per : 64;                  // lanes of a wave that share a grid position (16 for 8x8 PUs)
+    for (int t0 = 0; t0 < kGridN * per; t0 += 256) {
+        const int t = t0 + tid;
+        uint32_t sp = 0, sp2 = 0, sps = 0;
+        int c = 0;
+        if (t < kGridN * per) {
+            c = t / per;
+            const int rem = t - c * per, j = rem / (s >> 2), i = (rem - j * (s >> 2)) << 2;
+            const int b = c / kGrid, a = c - b * kGrid;   // grid position: row offset b, column offset a
+            const int iy = kGridOff[b][0], fy = kGridOff[b][1];
+            const int ob = i + iy + 1;
+            const uint32_t* hd = (const uint32_t*)(&Hc[a][j * WIN + (ob & ~3)]);
+            const uint32_t d0 = hd[0], d1 = hd[1], d2 = hd[2];
+            uint32_t P;
+            if (fy == 0) P = bytes4(d0, d1, d2, (ob & 3) + 3);
+            else {
+                const int TA = (kInterp[bank][fy << 1][0] & 0xff) | (kInterp[bank][fy << 1][1] & 0xff) << 8 | (kInterp[bank][fy << 1][2] & 0xff) << 16 | (kInterp[bank][fy << 1][3] & 0xff) << 24;
+                const int TB = (kInterp[bank][fy << 1][4] & 0xff) | (kInterp[bank][fy << 1][5] & 0xff) << 8 | (kInterp[bank][fy << 1][6] & 0xff) << 16 | (kInterp[bank][fy << 1][7] & 0xff) << 24;
+                P = filt4(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, ob & 3, TA, TB);
+            }
+            const uint32_t S = *(const uint32_t*)(&Sc[j * s + i]);
+            sp = __builtin_amdgcn_udot4(P, 0x01010101u, 0u, false); sp2 = __builtin_amdgcn_udot4(P, P, 0u, false); sps = __builtin_amdgcn_udot4(P, S, 0u, false);
+        }
+        for (int k = 1; k < G; k <<= 1) { sp += (uint32_t)__shfl_xor((int)sp, k, 64); sp2 += (uint32_t)__shfl_xor((int)sp2, k, 64); sps += (uint32_t)__shfl_xor((int)sps, k, 64); }
+        if (t < kGridN * per && (tid & (G - 1)) == 0) { atomicAdd(&stat[c][0], sp); atomicAdd(&stat[c][1], sp2); atomicAdd(&stat[c][2], sps); }
+    }
+    __syncthreads();
+    if (tid < kGridN) {   // svt_aom_variance{W}x{H}: sse - (sum * sum) / (w h) in 32-bit unsigned arithmetic (Encoder/C_DEFAULT/variance.c)
+        const long long sum = (long long)stat[tid][0] - (long long)sstat[0];
+        const uint32_t sse = stat[tid][1] - 2u * stat[tid][2] + sstat[1];
+        o[2 * tid] = sse - (uint32_t)((sum * sum) / (s * s));
+        o[2 * tid + 1] = sse;
+    }
+}
+
 }   // namespace
 
 extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
@@ -75,6 +203,20 @@ extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src,
         pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
     }
     hipLaunchKernelGGL(md_fullpel_sad_kernel, dim3(n_sb, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, sad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_md_subpel_grid(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                             int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int bank, uint32_t* out) {
+    if (n_sb <= 0 || n_refs <= 0 || n_pus <= 0) return 0;
+    RefPlanes rp;
+    PuList    pl;
+    for (int i = 0; i < SVT_HIP_MD_MAX_REFS; i++) rp.r[i] = refs[i < n_refs ? i : 0];
+    for (int i = 0; i < SVT_HIP_MD_MAX_PUS; i++) {
+        const SvtHipMdPu p = pus[i < n_pus ? i : 0];
+        pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
+    }
+    hipLaunchKernelGGL(md_subpel_grid_kernel, dim3(n_sb, n_pus, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, bank, out);
     return (int)hipGetLastError();
 }
 

@@ -58,3 +58,27 @@ def test_md_fullpel_sad_bad_arguments(hip, pkg):
     assert hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, buf, 64, 64, 64, 1, 1, 1, pu, 8, pl, buf, buf) != 0   # more references than SVT_HIP_MD_MAX_REFS
     assert hip.L.svt_hip_md_fullpel_sad_picture_dev(hip.h, buf, 64, 64, 64, 1, 0, 1, pu, 1, pl, buf, buf) == 0    # no superblocks: nothing to do
     hip.free(buf)
+
+
+@pytest.mark.parametrize("w,h,n_refs,bank", [(200, 152, 2, 4), (128, 64, 1, 0), (336, 208, 3, 4), (64, 64, 1, 3)])
+def test_md_subpel_grid_picture(hip, pkg, orc, w, h, n_refs, bank):
+    """svt_hip_md_subpel_grid_picture_dev: (variance, sse) of all 49 quarter-pel positions around every (superblock, square PU, reference)'s full-pel vector == the oracle's
+    svt_upsampled_pref_error restatement (orc_upsampled_pred + orc_variance, each pinned to the reference's C functions) position by position; USE_4_TAPS / USE_8_TAPS /
+    USE_2_TAPS kernels; PUs outside the picture, missing vectors and windows that leave the allocation say "not computed"."""
+    rng = np.random.default_rng(w + 3 * h + bank)
+    src, refs, pus, mv, sb_cols, n_sb, pad = M.make_case(rng, w, h, n_refs, pad=48, mv_range=20)
+    if bank == 0:   # saturating content: the 8-bit clips of both passes
+        refs[0][:, :] = np.where(rng.random(refs[0].shape) < 0.5, 0, 255).astype(np.uint8)
+    exp = M.oracle_grid(orc, src, refs, pus, mv, sb_cols, n_sb, pad, w, h, bank)
+    d_src, d_mv = hip.to_device(src), hip.to_device(mv)
+    d_refs = [hip.to_device(r) for r in refs]
+    d_out = hip.empty(exp.size * 4)
+    pu_arr = (pkg.MdPu * len(pus))(*[pkg.MdPu(*p) for p in pus])
+    planes = (pkg.MdRefPlane * n_refs)()
+    for r in range(n_refs):
+        planes[r] = pkg.MdRefPlane(d_refs[r].value + pad * refs[r].shape[1] + pad, refs[r].shape[1], -pad, -pad, refs[r].shape[1] - pad, refs[r].shape[0] - pad)
+    hip.check(hip.L.svt_hip_md_subpel_grid_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, bank, d_out), "md grid")
+    got = hip.to_host(d_out, exp.shape, np.uint32)
+    hip.free(d_src, d_mv, d_out, *d_refs)
+    assert (exp == 0xffffffff).any() and (exp != 0xffffffff).any()
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:6]
