@@ -199,6 +199,10 @@ mdtx.sub(r'(    if \(candidate_ptr->type != INTRA_MODE\) \{\n)(        if \(cont
          r'            context_ptr->md_staging_skip_chroma_pred = hip_c; context_ptr->md_staging_skip_interpolation_search = hip_i;\n'
          r'            context_ptr->uv_intra_comp_only = hip_u; context_ptr->pu_itr = hip_p;\n'
          r'        }\n\2')
+# md_subpel_search (:2063): the probes of the sub-pel tree are looked up in the picture's 7 x 7 quarter-pel grid (hook "md_pre", svt_hip_md_bridge.c); the tree itself
+# (vector costs, comparisons, the order of the probes) stays the reference's
+mdtx.sub(r'(\n    unsigned int pred_sse = 0; // not used\n)(    int besterr = svt_av1_find_best_sub_pixel_tree\(\n        xd, \(const struct AV1Common \*const\) cm, ms_params, subpel_start_mv, &best_mv\.as_mv, &not_used,\n        &pred_sse,\n        NULL\);\n)',
+         r'\1    svt_hip_hook_md_pre_subpel_begin(pcs_ptr, context_ptr, list_idx, ref_idx, (int)md_subpel_ctrls.subpel_search_type, subpel_start_mv.col, subpel_start_mv.row);\n\2    svt_hip_hook_md_pre_subpel_end();\n')
 PATCHES.append(mdtx)
 
 # mode_decision_configuration_kernel (:810), before the picture is posted to the mode-decision threads (:1058): hook "md_pre" fills the picture's table
@@ -246,6 +250,8 @@ msp.sub(r'(static int svt_upsampled_pref_error\(MacroBlockD \*xd, const struct A
         r'\1    { unsigned int hip_err; if (svt_hip_hook_md_subpel_fetch(this_mv, &hip_err, sse)) return (int)hip_err; }\n')
 msp.sub(r'(\n    const MV bottom_mv = \{this_mv\.row \+ hstep, this_mv\.col\};\n)', r'\1    svt_hip_hook_md_subpel_begin(var_params, &this_mv, hstep, mv_limits);\n')
 msp.sub(r'(\n    // Check the diagonal direction with the best mv\n    svt_check_better\(xd,\s*cm,\s*&diag_mv,.*?&dummy\);\n)', r'\1    svt_hip_hook_md_subpel_end();\n')
+# SVT_HIP_MD_PRE_VERIFY=1 (tests): a probe the picture's grid holds is computed by the reference as well and compared
+msp.sub(r'(        besterr = vfp->vf\(pred, w, src, src_stride, sse\);\n    \}\n)(\n    return besterr;\n\})', r'\1    svt_hip_hook_md_pre_subpel_verify(this_mv, besterr, *sse);\n\2')
 PATCHES.append(msp)
 
 # ---------------------------------------------------------------------------------------------------------------- picture analysis

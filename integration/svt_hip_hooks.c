@@ -303,6 +303,9 @@ void svt_hip_hooks_report(void) {
         svt_hip_hook_md_pre_stats(&pictures, &launches, &jobs, &min_jobs, &calls, &inter, &hits, &late, &declined, &ms);
         fprintf(stderr, "svt_hip_md_pre pictures=%ld launches=%ld blocks=%ld min_blocks_per_launch=%ld declined=%ld config_thread_ms=%.1f fast_loop_calls=%ld inter=%ld served_from_table=%ld "
                         "predicted_late=%ld verify_mismatches=%ld\n", pictures, launches, jobs, min_jobs, declined, ms, calls, inter, hits, late, svt_hip_hook_md_pre_mismatches());
+        long gp, probes, served;
+        svt_hip_hook_md_pre_subpel_stats(&gp, &probes, &served);
+        fprintf(stderr, "svt_hip_md_pre_subpel grid_pictures=%ld probes=%ld served_from_grid=%ld\n", gp, probes, served);
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

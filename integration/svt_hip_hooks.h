@@ -212,6 +212,11 @@ int  svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, struct ModeDecisionConte
 void svt_hip_hook_md_pre_verify(PictureControlSet *pcs, struct ModeDecisionContext *ctx, struct ModeDecisionCandidateBuffer *cb, uint32_t table_sad, uint32_t ref_sad);
 long svt_hip_hook_md_pre_mismatches(void);   /* -1 = not verifying */
 int  svt_hip_hook_md_pre_take(const struct ModeDecisionCandidateBuffer *cb, int predicted_late);
+/* md_subpel_search, around svt_av1_find_best_sub_pixel_tree: the probes (svt_upsampled_pref_error, mcomp.c:102) of this search are looked up in the picture's sub-pel grid */
+void svt_hip_hook_md_pre_subpel_begin(PictureControlSet *pcs, struct ModeDecisionContext *ctx, int list_idx, int ref_idx, int subpel_search_type, int mvx8, int mvy8);
+void svt_hip_hook_md_pre_subpel_end(void);
+void svt_hip_hook_md_pre_subpel_verify(const MV *mv, unsigned int err, unsigned int sse);   /* the patched svt_upsampled_pref_error, after computing a probe itself (self-check mode) */
+void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served);
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms);
 int  svt_hip_hook_md_tx_begin(const int16_t *resid, uint32_t stride, int tx_size, int coeff_shape, uint32_t type_mask);
 int  svt_hip_hook_md_tx_fetch(int tx_size, int tx_type, int32_t *coeff);

@@ -576,7 +576,9 @@ int svt_hip_hook_md_subpel_begin(const SUBPEL_SEARCH_VAR_PARAMS *vp, const MV *c
     return 1;
 }
 /* svt_upsampled_pref_error of a candidate of the round begun above: 1 = *err / *sse hold the device results */
+static int pre_grid_fetch(const MV *mv, unsigned int *err, unsigned int *sse);
 int svt_hip_hook_md_subpel_fetch(const MV *mv, unsigned int *err, unsigned int *sse) {
+    if (pre_grid_fetch(mv, err, sse)) return 1;   /* hook "md_pre": the picture's sub-pel grid */
     if (!tls_sp.valid) return 0;
     for (int i = 0; i < tls_sp.n; i++)
         if (tls_sp.mv[i].row == mv->row && tls_sp.mv[i].col == mv->col) { *err = tls_sp.var[i]; *sse = tls_sp.sse[i]; return 1; }
@@ -627,6 +629,9 @@ typedef struct {
     uint32_t *mv;                /* [n_sb][85][n_refs]: the vector in the units of the candidates (1/8 sample), x | y << 16; PRE_NONE = no entry */
     uint32_t *sad;               /* [n_sb][85][n_refs], page-locked */
     size_t    cap;               /* entries allocated */
+    uint32_t *grid;              /* [n_sb][85][n_refs][49][2] (variance, sse) of the sub-pel refinement's probes around the vector, page-locked; NULL: not made */
+    size_t    grid_cap;          /* entries (of 98 words) allocated */
+    int       grid_bank, grid_ready;
 } MdPre;
 #define PRE_NONE 0x80008000u
 static MdPre           g_pre[PRE_SLOTS];
@@ -634,6 +639,9 @@ static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
 static SvtHipMdPu      g_pre_pu[PRE_PUS];
 static int             g_pre_pu_ok;   /* 0 not built, 1 built, -1 the tables are not what this code expects */
 static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_calls, g_pre_inter, g_pre_hits, g_pre_late, g_pre_declined;
+static long g_pre_grid_pictures, g_pre_probes, g_pre_probe_hits;   /* the sub-pel grid: pictures it was made for, svt_upsampled_pref_error calls of mode decision, served */
+static int  g_pre_grid_on = -1;
+static __thread struct { const uint32_t *row; int cx, cy; } tls_grid;
 static long long g_pre_ns;
 static long g_pre_mismatch;
 static int  g_pre_verify = -1;
@@ -643,6 +651,7 @@ static __thread const void *tls_mark[PRE_MARKS];
 static inline unsigned mark_slot(const void *p) { const uintptr_t a = (uintptr_t)p; return (unsigned)((a >> 6) ^ (a >> 16)) & (PRE_MARKS - 1); }
 
 long svt_hip_hook_md_pre_mismatches(void) { return g_pre_verify > 0 ? g_pre_mismatch : -1; }
+void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served) { *pictures = g_pre_grid_pictures; *probes = g_pre_probes; *served = g_pre_probe_hits; }
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms) {
     *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = g_pre_calls; *inter = g_pre_inter; *hits = g_pre_hits;
     *late = g_pre_late; *declined = g_pre_declined; *ms = g_pre_ns / 1e6;
@@ -764,8 +773,35 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     if (rc == SVT_HIP_OK)
         rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
                                                 n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)d_mv, (uint32_t *)d_sad);
+    /* ... and the sub-pel refinement's probes (md_subpel_search, :2063): (variance, sse) of the 7 x 7 quarter-pel grid around the same vectors, with the interpolation
+     * kernels the picture's final pass searches with (md_subpel_me_level, EbEncDecProcess.c:3088-3097: USE_8_TAPS up to M4, USE_4_TAPS above).  SVT_HIP_MD_PRE_SUBPEL=0
+     * leaves it out; pictures whose table would exceed 256 MB go without. */
+    if (g_pre_grid_on < 0) g_pre_grid_on = !(getenv("SVT_HIP_MD_PRE_SUBPEL") && !atoi(getenv("SVT_HIP_MD_PRE_SUBPEL")));
+    void *d_grid = NULL;
+    t->grid_ready = 0;
+    const size_t gwords = n * 2 * SVT_HIP_MD_GRID;
+    if (rc == SVT_HIP_OK && g_pre_grid_on && gwords * sizeof(uint32_t) <= ((size_t)256 << 20)) {
+        int grc = SVT_HIP_OK;
+        if (t->grid_cap < n) {
+            if (t->grid) svt_hip_host_free(hip, t->grid);
+            t->grid = NULL; t->grid_cap = 0;
+            void *h = NULL;
+            grc = svt_hip_host_alloc(hip, &h, gwords * sizeof(uint32_t));
+            if (grc == SVT_HIP_OK) { t->grid = (uint32_t *)h; t->grid_cap = n; }
+        }
+        if (grc == SVT_HIP_OK) grc = svt_hip_hooks_malloc(hip, &d_grid, gwords * sizeof(uint32_t));
+        t->grid_bank = pcs->enc_mode <= ENC_M4 ? 0 : 4;
+        if (grc == SVT_HIP_OK)
+            grc = svt_hip_md_subpel_grid_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                     n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)d_mv, t->grid_bank, (uint32_t *)d_grid);
+        if (grc == SVT_HIP_OK) grc = svt_hip_memcpy_d2h_async(hip, t->grid, d_grid, gwords * sizeof(uint32_t));
+        if (grc == SVT_HIP_OK) t->grid_ready = 1;   /* complete once the synchronous copy below has drained the context */
+        else (void)svt_hip_sync(hip);               /* the grid is an extra: without it the sub-pel probes stay the reference's */
+    }
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, t->sad, d_sad, n * sizeof(uint32_t));   /* drains the context */
     else (void)svt_hip_sync(hip);
+    svt_hip_hooks_free(hip, d_grid);
+    if (rc != SVT_HIP_OK) t->grid_ready = 0;
     if (from_table[0]) svt_hip_resident_release(in->buffer_y);
     for (int r = 0; r < n_refs; r++) if (from_table[1 + r]) svt_hip_resident_release(ref_pic[r]->buffer_y);
     for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
@@ -777,12 +813,70 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         t->n_sb = n_sb; t->n_refs = n_refs;
         __sync_synchronize();
         t->ready = 1;
-        __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1); __sync_fetch_and_add(&g_pre_jobs, (long)n);
+        __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1 + t->grid_ready); __sync_fetch_and_add(&g_pre_jobs, (long)n);
+        if (t->grid_ready) __sync_fetch_and_add(&g_pre_grid_pictures, 1);
         pthread_mutex_lock(&g_pre_mu);
         if (!g_pre_min_jobs || (long)n < g_pre_min_jobs) g_pre_min_jobs = (long)n;
         pthread_mutex_unlock(&g_pre_mu);
     }
     __sync_fetch_and_add(&g_pre_ns, svt_hip_hooks_now_ns() - t0);
+}
+
+static const MdPre *pre_table_of(PictureControlSet *pcs) {
+    if (tls_pre.pcs != pcs || tls_pre.pic != pcs->picture_number) {
+        tls_pre.pcs = pcs; tls_pre.pic = pcs->picture_number; tls_pre.t = NULL;
+        for (int i = 0; i < PRE_SLOTS; i++)
+            if (g_pre[i].pcs == pcs) { if (g_pre[i].ready && g_pre[i].picture_number == pcs->picture_number) tls_pre.t = &g_pre[i]; break; }
+    }
+    return tls_pre.t;
+}
+/* md_subpel_search (EbProductCodingLoop.c:2063), around svt_av1_find_best_sub_pixel_tree: the probes of this search — svt_upsampled_pref_error (mcomp.c:102) of vectors
+ * within 6/8 sample of the start vector, on quarter-sample positions — are in the picture's grid when the block is a square PU of the open-loop ME, the search starts at
+ * that PU's vector for this reference and filters with the kernels the grid was made with.  (mvx8, mvy8): the start vector in eighth-samples, full-pel. */
+void svt_hip_hook_md_pre_subpel_begin(PictureControlSet *pcs, ModeDecisionContext *ctx, int list_idx, int ref_idx, int subpel_search_type, int mvx8, int mvy8) {
+    tls_grid.row = NULL;
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return;
+    const MdPre *t = pre_table_of(pcs);
+    if (!t || !t->grid_ready || list_idx < 0 || list_idx > 1 || ref_idx < 0 || ref_idx > 3) return;
+    const int bank = subpel_search_type == USE_2_TAPS ? 3 : (subpel_search_type == USE_4_TAPS ? 4 : (subpel_search_type == USE_8_TAPS ? 0 : -1));
+    const BlockGeom *g = ctx->blk_geom;
+    const uint32_t pu = ctx->me_block_offset, sb = ctx->me_sb_addr;
+    const int col = t->slot_of[list_idx][ref_idx];
+    if (bank != t->grid_bank || col < 0 || g->shape != PART_N || g->bwidth != g->bheight || pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x ||
+        g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth)
+        return;
+    const size_t e = ((size_t)sb * PRE_PUS + pu) * (size_t)t->n_refs + (size_t)col;
+    if (t->mv[e] != ((uint32_t)(uint16_t)mvx8 | (uint32_t)(uint16_t)mvy8 << 16)) return;   /* e.g. md_sq_motion_search moved the start */
+    const uint32_t *row = t->grid + e * (2 * SVT_HIP_MD_GRID);
+    if (row[0] == 0xffffffffu && row[1] == 0xffffffffu) return;
+    tls_grid.row = row; tls_grid.cx = mvx8; tls_grid.cy = mvy8;
+}
+void svt_hip_hook_md_pre_subpel_end(void) { tls_grid.row = NULL; }
+/* svt_upsampled_pref_error of one probe: 1 = *err / *sse come from the grid (called through svt_hip_hook_md_subpel_fetch) */
+static int pre_grid_fetch(const MV *mv, unsigned int *err, unsigned int *sse) {
+    if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
+    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") && atoi(getenv("SVT_HIP_MD_PRE_VERIFY"));
+    __sync_fetch_and_add(&g_pre_probes, 1);
+    if (!tls_grid.row) return 0;
+    const int dx = mv->col - tls_grid.cx, dy = mv->row - tls_grid.cy;
+    if (dx < -6 || dx > 6 || dy < -6 || dy > 6 || ((dx | dy) & 1)) return 0;
+    const int i = 7 * ((dy + 6) >> 1) + ((dx + 6) >> 1);
+    __sync_fetch_and_add(&g_pre_probe_hits, 1);
+    if (g_pre_verify > 0) return 0;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the probe, svt_hip_hook_md_pre_subpel_verify compares */
+    *err = tls_grid.row[2 * i]; *sse = tls_grid.row[2 * i + 1];
+    return 1;
+}
+/* svt_upsampled_pref_error, after the reference has computed a probe itself (only reached when the grid did not serve it): in the self-check mode a probe the grid holds
+ * must agree with what the reference got */
+void svt_hip_hook_md_pre_subpel_verify(const MV *mv, unsigned int err, unsigned int sse) {
+    if (g_pre_verify <= 0 || !tls_grid.row) return;
+    const int dx = mv->col - tls_grid.cx, dy = mv->row - tls_grid.cy;
+    if (dx < -6 || dx > 6 || dy < -6 || dy > 6 || ((dx | dy) & 1)) return;
+    const int i = 7 * ((dy + 6) >> 1) + ((dx + 6) >> 1);
+    if (tls_grid.row[2 * i] == err && tls_grid.row[2 * i + 1] == sse) return;
+    if (__sync_fetch_and_add(&g_pre_mismatch, 1) < 10)
+        fprintf(stderr, "svt_hip_md_pre MISMATCH sub-pel probe mv=(%d,%d) start=(%d,%d) grid=(%u,%u) reference=(%u,%u)\n", mv->col, mv->row, tls_grid.cx, tls_grid.cy, tls_grid.row[2 * i],
+                tls_grid.row[2 * i + 1], err, sse);
 }
 
 /* fast_loop_core, in front of the prediction: 1 = *sad is the candidate's luma distortion (svt_nxm_sad_kernel_sub_sampled of its prediction) and the prediction is
@@ -801,12 +895,7 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
         return 0;
     const BlockGeom *g = ctx->blk_geom;
     if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) return 0;
-    if (tls_pre.pcs != pcs || tls_pre.pic != pcs->picture_number) {
-        tls_pre.pcs = pcs; tls_pre.pic = pcs->picture_number; tls_pre.t = NULL;
-        for (int i = 0; i < PRE_SLOTS; i++)
-            if (g_pre[i].pcs == pcs) { if (g_pre[i].ready && g_pre[i].picture_number == pcs->picture_number) tls_pre.t = &g_pre[i]; break; }
-    }
-    const MdPre *t = tls_pre.t;
+    const MdPre *t = pre_table_of(pcs);
     if (!t) return 0;
     const uint32_t pu = ctx->me_block_offset, sb = ctx->me_sb_addr;
     if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) return 0;
@@ -858,6 +947,7 @@ void svt_hip_md_bridge_release(SvtHipCtx *hip) {
     for (unsigned i = 0; i < sizeof(all) / sizeof(all[0]); i++) { svt_hip_free(hip, *all[i]); *all[i] = NULL; }
     for (int i = 0; i < PRE_SLOTS; i++) {   /* the picture tables of hook "md_pre" */
         if (g_pre[i].sad) svt_hip_host_free(hip, g_pre[i].sad);
+        if (g_pre[i].grid) svt_hip_host_free(hip, g_pre[i].grid);
         free(g_pre[i].mv);
         memset(&g_pre[i], 0, sizeof(g_pre[i]));
     }

@@ -97,6 +97,24 @@ int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *c, const uint8_t *src, int src
             if (sad[i] != 0xffffffffu) sad[i] = sad[i] * 3 + 1000;   /* reorders the candidates of stage 0 */
     return SVT_HIP_OK;
 }
+int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx *c, const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                       int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *mv, int bank, uint32_t *out) {
+    (void)c;
+    if (n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 || n_refs > SVT_HIP_MD_MAX_REFS) return SVT_HIP_ERR_BAD_ARG;
+    uint8_t        pu4[SVT_HIP_MD_MAX_PUS][4];
+    const uint8_t *planes[SVT_HIP_MD_MAX_REFS];
+    int            strides[SVT_HIP_MD_MAX_REFS], box[SVT_HIP_MD_MAX_REFS][4];
+    for (int i = 0; i < n_pus; i++) { pu4[i][0] = pus[i].x; pu4[i][1] = pus[i].y; pu4[i][2] = pus[i].w; pu4[i][3] = pus[i].h; }
+    for (int r = 0; r < n_refs; r++) {
+        planes[r] = refs[r].d_plane; strides[r] = refs[r].stride;
+        box[r][0] = refs[r].x_min; box[r][1] = refs[r].y_min; box[r][2] = refs[r].x_max; box[r][3] = refs[r].y_max;
+    }
+    orc_md_subpel_grid_picture(src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, (const uint8_t(*)[4])pu4, n_refs, planes, strides, (const int(*)[4])box, mv, bank, out);
+    if (perturb("md_pre_subpel"))
+        for (size_t i = 0; i < (size_t)n_sb * n_pus * n_refs * 98; i += 2)
+            if (out[i] != 0xffffffffu) out[i] += (uint32_t)((i * 2654435761u) >> 22);   /* a different wrong variance per position: the tree's comparisons flip */
+    return SVT_HIP_OK;
+}
 int svt_hip_me_set_big_windows(SvtHipCtx *c, int enable) { (void)c; (void)enable; return SVT_HIP_OK; }   /* the double's search has one instance */
 int svt_hip_me_get_big_windows(SvtHipCtx *c, int *enabled) { (void)c; *enabled = 1; return SVT_HIP_OK; }
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,

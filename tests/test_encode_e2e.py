@@ -266,6 +266,12 @@ def _md_pre_line(log):
     return dict(zip(("pictures", "launches", "blocks", "min_blocks", "declined", "calls", "inter", "served", "late"), map(int, m.groups())))
 
 
+def _md_pre_subpel_line(log):
+    m = re.search(r"svt_hip_md_pre_subpel grid_pictures=(\d+) probes=(\d+) served_from_grid=(\d+)", log)
+    assert m, log[-1500:]
+    return dict(zip(("pictures", "probes", "served"), map(int, m.groups())))
+
+
 def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p_8bit_m7", "328x200_8bit_m6", "cif_10bit_m8")):
     """hook "md_pre" (opt-in): ONE launch per picture, before the picture's mode decision starts, computes the stage-0 luma distortion of every (superblock, square PU,
     reference picture) at its open-loop ME vector; fast_loop_core (EbProductCodingLoop.c:907) reads the table instead of predicting + measuring, full_loop_core predicts
@@ -275,12 +281,17 @@ def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p
         spec = {**CASES, **GPU_ONLY_CASES}[case]
         got = _check(case, spec[:6] + ({"md_pre"},), workdir, env, tag + "_" + case)
         st = _md_pre_line(got["log"])
-        assert st["pictures"] > 0 and st["launches"] == st["pictures"] and st["min_blocks"] >= 256, st
+        assert st["pictures"] > 0 and st["launches"] == st["pictures"] + _md_pre_subpel_line(got["log"])["pictures"] and st["min_blocks"] >= 256, st   # one launch per table
         if spec[3] == 8:
             assert st["served"] * 2 > st["inter"], f"{case}: fewer than half of the inter fast-loop calls were served from the table: {st}"
         else:   # 10-bit input: this version's first pass decides on 16-bit samples (hbd_mode_decision), which the 8-bit table does not serve -- the reference's path, same output
             assert st["served"] == 0
-        print(f"md_pre {case}: {st}")
+        sp = _md_pre_subpel_line(got["log"])
+        # the sub-pel grid: made for every picture with a table; md_subpel_search's own probes (the open-loop ME vectors' refinement) are served from it -- the other half of
+        # the svt_upsampled_pref_error calls belongs to the predictive ME's sub-pel search, which starts where a neighbour-dependent full-pel search ended (8-bit and 10-bit input:
+        # this search always works on the 8-bit planes)
+        assert sp["pictures"] == st["pictures"] and (sp["probes"] == 0 or sp["served"] * 4 > sp["probes"]), sp
+        print(f"md_pre {case}: {st} {sp}")
         out[case] = got
     return out
 
@@ -303,6 +314,19 @@ def test_md_pre_full_mini_gop_and_self_check_on_cpu_test_double(workdir):
     assert st["served"] * 2 > st["inter"] and st["late"] > 0, st
     got = _check_geometry("gop9_mdpre", 352, 288, 9, 8, 6, 38, 29, workdir, {**env, "SVT_HIP_MD_PRE_VERIFY": "1"}, "mock_verify", must={"md_pre"})
     assert re.search(r"served_from_table=[1-9]\d* predicted_late=0 verify_mismatches=0\b", got["log"]), got["log"][-800:]
+
+
+def test_md_pre_subpel_grid_matters(workdir):
+    """a wrong variance out of the picture's sub-pel grid changes the encode: the sub-pel tree really consumes it"""
+    case = "cif_8bit_m6"
+    w, h, n, bd, preset, q, _ = CASES[case]
+    clip, ref = _reference(case, CASES[case], workdir)
+    got = E.encode(E.APP_HIP, clip, w, h, n, preset, q, bd, os.path.join(workdir, f"{case}.bad_mdpre_grid"),
+                   env_extra={"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre", "SVT_HIP_MOCK_PERTURB": "md_pre_subpel"})
+    assert (got["ivf"], got["recon"]) != (ref["ivf"], ref["recon"])
+    # ... and without the grid (SVT_HIP_MD_PRE_SUBPEL=0) the hook still codes the reference's bitstream, serving stage 0 only
+    got = _check(case, CASES[case][:6] + ({"md_pre"},), workdir, {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre", "SVT_HIP_MD_PRE_SUBPEL": "0"}, "mock_mdpre_nogrid")
+    assert _md_pre_subpel_line(got["log"])["served"] == 0 and _md_pre_line(got["log"])["served"] > 0
 
 
 def test_md_pre_hook_matters(workdir):
@@ -986,6 +1010,8 @@ def _check_md_pre_720p_gop(workdir, env, tag):
     assert (got["ivf"], got["recon"]) == (ref["ivf"], ref["recon"]), got["log"][-1500:]
     st = _md_pre_line(got["log"])
     assert got["hooks"]["md_pre"] == (8, 0) and st["served"] * 2 > st["inter"], (got["hooks"], st)
+    sp = _md_pre_subpel_line(got["log"])
+    assert (st["served"] + sp["served"]) * 2 > st["inter"] + sp["probes"], f"fewer than half of mode decision's inter prediction + distortion leaf calls came from the picture's launches: {st} {sp}"
     return got
 
 
