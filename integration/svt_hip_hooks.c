@@ -77,6 +77,8 @@ static int in_list_exact(const char *list, const char *name) {   /* like in_list
     return 0;
 }
 
+static int g_device;
+int svt_hip_hooks_device(void) { return g_device; }
 int svt_hip_hook_enabled(int which) { return which >= 0 && which < SVT_HIP_HOOK_COUNT && g_ctx && g_enabled[which]; }
 /* how long process threads waited for the context and how long they held it (nanoseconds; reported at exit: the serial share of the hooks) */
 static long long g_lock_wait_ns, g_lock_held_ns, g_lock_t0, g_lock_n;
@@ -495,6 +497,7 @@ static void enc_init_locked(int target_socket) {
     (void)svt_hip_device_count(&n_dev);
     const int device = dev ? atoi(dev) : (target_socket >= 0 && target_socket < n_dev ? target_socket : 0);
     fprintf(stderr, "svt_hip_device ordinal=%d of %d (%s)\n", device, n_dev, dev ? "SVT_HIP_DEVICE" : (target_socket >= 0 && target_socket < n_dev ? "target_socket" : "default"));
+    g_device = device;
     if (svt_hip_init(device, &g_ctx) != SVT_HIP_OK) {
         /* error convention: never fail through the kernel surface — log, keep the C path */
         SVT_LOG("svt_hip_init failed - SVT_HIP_HOOKS / SVT_HIP_RTCD ignored, keeping the C kernels\n");

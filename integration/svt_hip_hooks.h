@@ -86,6 +86,7 @@ void svt_hip_lf_bridge_release(SvtHipCtx *hip);   /* svt_hip_lf_bridge.c */
 void svt_hip_lf_bridge_unpin(SvtHipCtx *hip);     /* svt_hip_lf_bridge.c: the reconstructed pictures' host buffers stop being page-locked */
 void svt_hip_md_bridge_release(SvtHipCtx *hip);   /* svt_hip_md_bridge.c */
 int  svt_hip_hook_enabled(int which);
+int  svt_hip_hooks_device(void);   /* the GPU ordinal the hooks' contexts were made on (bridges that keep a context of their own) */
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */
 SvtHipCtx *svt_hip_hooks_lock(void);
 void       svt_hip_hooks_unlock(void);

@@ -632,6 +632,13 @@ typedef struct {
     uint32_t *grid;              /* [n_sb][85][n_refs][49][2] (variance, sse) of the sub-pel refinement's probes around the vector, page-locked; NULL: not made */
     size_t    grid_cap;          /* entries (of 98 words) allocated */
     int       grid_bank, grid_ready;
+    /* the slot's device side and its completion mark: everything is queued, nobody waits */
+    void     *d_mv, *d_sad, *d_grid, *d_seq;
+    uint32_t *h_dev_mv;          /* page-locked staging of the device-side vectors */
+    volatile uint32_t *flags;    /* page-locked: [0] = the sequence number on its way to the device, [1] = where it comes back once both tables have arrived */
+    uint32_t  seq;
+    int       pending, n_held;
+    const void *held[SVT_HIP_MD_MAX_REFS + 1];   /* resident planes (svt_hip_resident_acquire) the queued launches read: released once the mark is back */
 } MdPre;
 #define PRE_NONE 0x80008000u
 static MdPre           g_pre[PRE_SLOTS];
@@ -692,6 +699,26 @@ void svt_hip_hook_md_pre_note_ref(PictureControlSet *pcs) {
     if (ro && ro->reference_picture) svt_hip_hooks_resident_note_picture(ro->reference_picture);
 }
 
+/* the hook's own context (a stream of its own: its work overlaps everything else and is never drained by another bridge's unlock), made at the first picture */
+static SvtHipCtx      *g_pre_ctx;
+static pthread_mutex_t g_pre_issue_mu = PTHREAD_MUTEX_INITIALIZER;
+static uint32_t        g_pre_seq;
+static SvtHipCtx *pre_context(void) {   /* g_pre_issue_mu held */
+    if (!g_pre_ctx && svt_hip_init(svt_hip_hooks_device(), &g_pre_ctx) != SVT_HIP_OK) g_pre_ctx = NULL;
+    return g_pre_ctx;
+}
+static int pre_done(const MdPre *t) { return t->flags && t->flags[1] == t->seq; }
+/* resident planes of pictures whose queue has run out go back to the table (all = 1: the context has just been drained, every slot is complete) */
+static void pre_sweep(SvtHipCtx *hip, int all) {   /* g_pre_issue_mu held */
+    (void)hip;
+    for (int i = 0; i < PRE_SLOTS; i++) {
+        MdPre *t = &g_pre[i];
+        if (!t->pending || !(all || pre_done(t))) continue;
+        for (int k = 0; k < t->n_held; k++) svt_hip_resident_release(t->held[k]);
+        t->n_held = 0; t->pending = 0;
+    }
+}
+
 void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return;
     const long long t0 = svt_hip_hooks_now_ns();
@@ -727,20 +754,47 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     if (!ok || !n_refs) { if (pcs->slice_type != I_SLICE) __sync_fetch_and_add(&g_pre_declined, 1); return; }
     const int sb_cols = (ppcs->aligned_width + 63) / 64, n_sb = pcs->sb_total_count;
     const size_t n = (size_t)n_sb * PRE_PUS * (size_t)n_refs;
-    SvtHipCtx *hip = svt_hip_hooks_lock_any();
-    if (!hip) { __sync_fetch_and_add(&g_pre_declined, 1); return; }
+    /* Everything below is QUEUED on the hook's own context and the configuration thread goes on: no block of any picture ever waits for the device.  The last operation
+     * of the queue copies the picture's sequence number into the table's page-locked `done` word (stream order: after both tables have arrived); a lookup that does not
+     * find it there yet is a table miss and the reference's own code runs — so the first blocks of a picture that starts immediately may go unserved, nothing else. */
+    pthread_mutex_lock(&g_pre_issue_mu);
+    SvtHipCtx *hip = pre_context();
+    if (!hip) { pthread_mutex_unlock(&g_pre_issue_mu); __sync_fetch_and_add(&g_pre_declined, 1); return; }
+    pre_sweep(hip, 0);
+    if (t->pending) { (void)svt_hip_sync(hip); pre_sweep(hip, 0); }   /* cannot be: the picture that used the slot has left mode decision long ago */
     int rc = SVT_HIP_OK;
-    if (t->cap < n) {
+    if (g_pre_grid_on < 0) g_pre_grid_on = !(getenv("SVT_HIP_MD_PRE_SUBPEL") && !atoi(getenv("SVT_HIP_MD_PRE_SUBPEL")));
+    const size_t gwords = n * 2 * SVT_HIP_MD_GRID;
+    const int want_grid = g_pre_grid_on && gwords * sizeof(uint32_t) <= ((size_t)256 << 20);   /* pictures whose grid would exceed 256 MB go without */
+    if (t->cap < n) {   /* the slot's buffers grow with the largest picture it has seen: no allocation per picture */
         if (t->sad) svt_hip_host_free(hip, t->sad);
+        if (t->h_dev_mv) svt_hip_host_free(hip, t->h_dev_mv);
+        svt_hip_free(hip, t->d_mv); svt_hip_free(hip, t->d_sad);
         free(t->mv);
-        t->sad = NULL; t->mv = (uint32_t *)malloc(n * sizeof(uint32_t)); t->cap = 0;
-        void *h = NULL;
+        t->sad = t->h_dev_mv = NULL; t->d_mv = t->d_sad = NULL; t->cap = 0;
+        t->mv = (uint32_t *)malloc(n * sizeof(uint32_t));
+        void *h = NULL, *h2 = NULL;
         rc = t->mv ? svt_hip_host_alloc(hip, &h, n * sizeof(uint32_t)) : SVT_HIP_ERR_RUNTIME;
-        if (rc == SVT_HIP_OK) { t->sad = (uint32_t *)h; t->cap = n; }
+        if (rc == SVT_HIP_OK) rc = svt_hip_host_alloc(hip, &h2, n * sizeof(uint32_t));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &t->d_mv, n * sizeof(uint32_t));
+        if (rc == SVT_HIP_OK) rc = svt_hip_malloc(hip, &t->d_sad, n * sizeof(uint32_t));
+        t->sad = (uint32_t *)h; t->h_dev_mv = (uint32_t *)h2;
+        if (rc == SVT_HIP_OK) t->cap = n;
+    }
+    if (rc == SVT_HIP_OK && !t->flags) {
+        void *h = NULL;
+        rc = svt_hip_host_alloc(hip, &h, 2 * sizeof(uint32_t));
+        if (rc == SVT_HIP_OK) { t->flags = (volatile uint32_t *)h; t->flags[0] = t->flags[1] = 0; rc = svt_hip_malloc(hip, &t->d_seq, sizeof(uint32_t)); }
+    }
+    if (rc == SVT_HIP_OK && want_grid && t->grid_cap < n) {
+        if (t->grid) svt_hip_host_free(hip, t->grid);
+        svt_hip_free(hip, t->d_grid);
+        t->grid = NULL; t->d_grid = NULL; t->grid_cap = 0;
+        void *h = NULL;
+        if (svt_hip_host_alloc(hip, &h, gwords * sizeof(uint32_t)) == SVT_HIP_OK && svt_hip_malloc(hip, &t->d_grid, gwords * sizeof(uint32_t)) == SVT_HIP_OK) { t->grid = (uint32_t *)h; t->grid_cap = n; }
+        else if (h) svt_hip_host_free(hip, h);
     }
     /* the vectors: table side in the candidates' units (1/8 sample), device side in whole samples */
-    uint32_t *dev_mv = rc == SVT_HIP_OK ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
-    if (rc == SVT_HIP_OK && !dev_mv) rc = SVT_HIP_ERR_RUNTIME;
     if (rc == SVT_HIP_OK)
         for (int sb = 0; sb < n_sb; sb++) {
             const MeSbResults *mr = ppcs->pa_me_data->me_results[sb];
@@ -748,18 +802,16 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
                 for (int r = 0; r < n_refs; r++) {
                     const MvCandidate m = mr->me_mv_array[pu * MAX_PA_ME_MV + ref_col[r]];
                     const size_t e = ((size_t)sb * PRE_PUS + pu) * n_refs + r;
-                    if ((m.x_mv | m.y_mv) & 3) { t->mv[e] = PRE_NONE; dev_mv[e] = (uint32_t)(uint16_t)SVT_HIP_MD_NO_MV; continue; }   /* the open-loop search is full-pel */
+                    if ((m.x_mv | m.y_mv) & 3) { t->mv[e] = PRE_NONE; t->h_dev_mv[e] = (uint32_t)(uint16_t)SVT_HIP_MD_NO_MV; continue; }   /* the open-loop search is full-pel */
                     t->mv[e] = (uint32_t)(uint16_t)(m.x_mv * 2) | (uint32_t)(uint16_t)(m.y_mv * 2) << 16;
-                    dev_mv[e] = (uint32_t)(uint16_t)(m.x_mv >> 2) | (uint32_t)(uint16_t)(m.y_mv >> 2) << 16;
+                    t->h_dev_mv[e] = (uint32_t)(uint16_t)(m.x_mv >> 2) | (uint32_t)(uint16_t)(m.y_mv >> 2) << 16;
                 }
         }
-    void *d_mv = NULL, *d_sad = NULL, *tmp[SVT_HIP_MD_MAX_REFS + 1] = {0};
-    int   from_table[SVT_HIP_MD_MAX_REFS + 1] = {0};
+    void *tmp[SVT_HIP_MD_MAX_REFS + 1] = {0};
+    int   from_table[SVT_HIP_MD_MAX_REFS + 1] = {0}, any_tmp = 0;
     const uint8_t *d_src = NULL;
     SvtHipMdRefPlane planes[SVT_HIP_MD_MAX_REFS];
-    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_mv, n * sizeof(uint32_t));
-    if (rc == SVT_HIP_OK) rc = svt_hip_hooks_malloc(hip, &d_sad, n * sizeof(uint32_t));
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, d_mv, dev_mv, n * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, t->d_mv, t->h_dev_mv, n * sizeof(uint32_t));
     if (rc == SVT_HIP_OK) { d_src = pre_plane(hip, in, &from_table[0], &tmp[0]); if (!d_src) rc = SVT_HIP_ERR_RUNTIME; }
     for (int r = 0; r < n_refs && rc == SVT_HIP_OK; r++) {
         const EbPictureBufferDesc *rp = ref_pic[r];
@@ -770,44 +822,38 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         planes[r].x_min = -(int)rp->origin_x; planes[r].y_min = -(int)rp->origin_y;
         planes[r].x_max = (int)rp->width + (int)rp->origin_x; planes[r].y_max = (int)rp->height + (int)rp->origin_y;
     }
+    for (int i = 0; i <= n_refs; i++) any_tmp |= tmp[i] != NULL;
     if (rc == SVT_HIP_OK)
         rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
-                                                n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)d_mv, (uint32_t *)d_sad);
+                                                n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad);
     /* ... and the sub-pel refinement's probes (md_subpel_search, :2063): (variance, sse) of the 7 x 7 quarter-pel grid around the same vectors, with the interpolation
      * kernels the picture's final pass searches with (md_subpel_me_level, EbEncDecProcess.c:3088-3097: USE_8_TAPS up to M4, USE_4_TAPS above).  SVT_HIP_MD_PRE_SUBPEL=0
-     * leaves it out; pictures whose table would exceed 256 MB go without. */
-    if (g_pre_grid_on < 0) g_pre_grid_on = !(getenv("SVT_HIP_MD_PRE_SUBPEL") && !atoi(getenv("SVT_HIP_MD_PRE_SUBPEL")));
-    void *d_grid = NULL;
+     * leaves it out. */
     t->grid_ready = 0;
-    const size_t gwords = n * 2 * SVT_HIP_MD_GRID;
-    if (rc == SVT_HIP_OK && g_pre_grid_on && gwords * sizeof(uint32_t) <= ((size_t)256 << 20)) {
-        int grc = SVT_HIP_OK;
-        if (t->grid_cap < n) {
-            if (t->grid) svt_hip_host_free(hip, t->grid);
-            t->grid = NULL; t->grid_cap = 0;
-            void *h = NULL;
-            grc = svt_hip_host_alloc(hip, &h, gwords * sizeof(uint32_t));
-            if (grc == SVT_HIP_OK) { t->grid = (uint32_t *)h; t->grid_cap = n; }
-        }
-        if (grc == SVT_HIP_OK) grc = svt_hip_hooks_malloc(hip, &d_grid, gwords * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK && want_grid && t->grid) {
         t->grid_bank = pcs->enc_mode <= ENC_M4 ? 0 : 4;
-        if (grc == SVT_HIP_OK)
-            grc = svt_hip_md_subpel_grid_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
-                                                     n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)d_mv, t->grid_bank, (uint32_t *)d_grid);
-        if (grc == SVT_HIP_OK) grc = svt_hip_memcpy_d2h_async(hip, t->grid, d_grid, gwords * sizeof(uint32_t));
-        if (grc == SVT_HIP_OK) t->grid_ready = 1;   /* complete once the synchronous copy below has drained the context */
-        else (void)svt_hip_sync(hip);               /* the grid is an extra: without it the sub-pel probes stay the reference's */
+        int grc = svt_hip_md_subpel_grid_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                     n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, t->grid_bank, (uint32_t *)t->d_grid);
+        if (grc == SVT_HIP_OK) grc = svt_hip_memcpy_d2h_async(hip, t->grid, t->d_grid, gwords * sizeof(uint32_t));
+        t->grid_ready = grc == SVT_HIP_OK;   /* the grid is an extra: without it the sub-pel probes stay the reference's */
     }
-    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h(hip, t->sad, d_sad, n * sizeof(uint32_t));   /* drains the context */
-    else (void)svt_hip_sync(hip);
-    svt_hip_hooks_free(hip, d_grid);
+    if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h_async(hip, t->sad, t->d_sad, n * sizeof(uint32_t));
+    if (rc == SVT_HIP_OK) {   /* the completion mark: the sequence number travels to the device and back behind everything else of this picture */
+        t->seq = ++g_pre_seq ? g_pre_seq : ++g_pre_seq;
+        t->flags[0] = t->seq;
+        rc = svt_hip_memcpy_h2d_async(hip, t->d_seq, (const void *)&t->flags[0], sizeof(uint32_t));
+        if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h_async(hip, (void *)&t->flags[1], t->d_seq, sizeof(uint32_t));
+    }
+    t->n_held = 0;
+    if (from_table[0]) t->held[t->n_held++] = in->buffer_y;
+    for (int r = 0; r < n_refs; r++) if (from_table[1 + r]) t->held[t->n_held++] = ref_pic[r]->buffer_y;
+    t->pending = 1;
+    if (rc != SVT_HIP_OK || any_tmp) {   /* a failure, or planes that had to be uploaded for this picture alone (resident planes off / over budget): finish here */
+        (void)svt_hip_sync(hip);
+        for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
+        pre_sweep(hip, 1);
+    }
     if (rc != SVT_HIP_OK) t->grid_ready = 0;
-    if (from_table[0]) svt_hip_resident_release(in->buffer_y);
-    for (int r = 0; r < n_refs; r++) if (from_table[1 + r]) svt_hip_resident_release(ref_pic[r]->buffer_y);
-    for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
-    svt_hip_hooks_free(hip, d_mv); svt_hip_hooks_free(hip, d_sad);
-    svt_hip_hooks_unlock_any();
-    free(dev_mv);
     svt_hip_hooks_count(SVT_HIP_HOOK_MD_PRE, rc == SVT_HIP_OK);
     if (rc == SVT_HIP_OK) {
         t->n_sb = n_sb; t->n_refs = n_refs;
@@ -815,10 +861,9 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         t->ready = 1;
         __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1 + t->grid_ready); __sync_fetch_and_add(&g_pre_jobs, (long)n);
         if (t->grid_ready) __sync_fetch_and_add(&g_pre_grid_pictures, 1);
-        pthread_mutex_lock(&g_pre_mu);
         if (!g_pre_min_jobs || (long)n < g_pre_min_jobs) g_pre_min_jobs = (long)n;
-        pthread_mutex_unlock(&g_pre_mu);
     }
+    pthread_mutex_unlock(&g_pre_issue_mu);
     __sync_fetch_and_add(&g_pre_ns, svt_hip_hooks_now_ns() - t0);
 }
 
@@ -828,7 +873,7 @@ static const MdPre *pre_table_of(PictureControlSet *pcs) {
         for (int i = 0; i < PRE_SLOTS; i++)
             if (g_pre[i].pcs == pcs) { if (g_pre[i].ready && g_pre[i].picture_number == pcs->picture_number) tls_pre.t = &g_pre[i]; break; }
     }
-    return tls_pre.t;
+    return tls_pre.t && pre_done(tls_pre.t) ? tls_pre.t : NULL;   /* not arrived yet: a miss, the reference's code runs */
 }
 /* md_subpel_search (EbProductCodingLoop.c:2063), around svt_av1_find_best_sub_pixel_tree: the probes of this search — svt_upsampled_pref_error (mcomp.c:102) of vectors
  * within 6/8 sample of the start vector, on quarter-sample positions — are in the picture's grid when the block is a square PU of the open-loop ME, the search starts at
@@ -945,10 +990,17 @@ int svt_hip_hook_md_pre_take(const ModeDecisionCandidateBuffer *cb, int predicte
 void svt_hip_md_bridge_release(SvtHipCtx *hip) {
     void **all[] = {&d_src, &d_pred, &d_desc, &d_coeff, &d_sp_ref, &d_sp_src, &d_sp_pred, &d_sp_job, &d_sp_out};
     for (unsigned i = 0; i < sizeof(all) / sizeof(all[0]); i++) { svt_hip_free(hip, *all[i]); *all[i] = NULL; }
+    pthread_mutex_lock(&g_pre_issue_mu);
+    if (g_pre_ctx) { (void)svt_hip_sync(g_pre_ctx); pre_sweep(g_pre_ctx, 1); }
     for (int i = 0; i < PRE_SLOTS; i++) {   /* the picture tables of hook "md_pre" */
         if (g_pre[i].sad) svt_hip_host_free(hip, g_pre[i].sad);
         if (g_pre[i].grid) svt_hip_host_free(hip, g_pre[i].grid);
+        if (g_pre[i].h_dev_mv) svt_hip_host_free(hip, g_pre[i].h_dev_mv);
+        if (g_pre[i].flags) svt_hip_host_free(hip, (void *)g_pre[i].flags);
+        svt_hip_free(hip, g_pre[i].d_mv); svt_hip_free(hip, g_pre[i].d_sad); svt_hip_free(hip, g_pre[i].d_grid); svt_hip_free(hip, g_pre[i].d_seq);
         free(g_pre[i].mv);
         memset(&g_pre[i], 0, sizeof(g_pre[i]));
     }
+    if (g_pre_ctx) { svt_hip_destroy(g_pre_ctx); g_pre_ctx = NULL; }
+    pthread_mutex_unlock(&g_pre_issue_mu);
 }
