@@ -297,28 +297,35 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(1, args.gpus):
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}) or drop the launcher")
+    sys.path.insert(0, ROOT)
+    from conftest import load_package
+    load_package()
+    import importlib
+    shard = importlib.import_module("svt_av1_amd.shard")
+    rank, local_rank, world = shard.rank_env(args.gpus, os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in the product path)")
     if torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
+    # every rank next to its GPU: threads and the first touch of the page-locked staging buffers on the GPU's NUMA node (the PCIe-inclusive rate of eight ranks on one
+    # host depends on it); a platform that does not publish the topology leaves the rank where the launcher put it
+    numa = None
+    if world > 1 and not os.environ.get("SVT_BENCH_NO_NUMA"):
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            numa = shard.pin_rank_to_gpu_numa("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id))
+        except Exception:   # noqa: BLE001
+            numa = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from conftest import load_package
-    import importlib
     import me_common as mc
     import workload
     import txfm_common as tc
     E = Env()
     E.pkg = load_package()
-    shard = importlib.import_module("svt_av1_amd.shard")
     orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))   # the checker: parity spot check and (port) CPU baseline only, after the timed region
     E.ctx = E.pkg.Context(local_rank)
     E.L, E.mc, E.tc, E.workload = E.ctx.L, mc, tc, workload
@@ -482,7 +489,9 @@ def main():
         return time.perf_counter() - t0
 
     step_fns = make_steps(nF)
-    elapsed = shard.max_over_ranks(timed(step_fns, args.steps, args.warmup, True), dist if world > 1 else None, dev)
+    elapsed = timed(step_fns, args.steps, args.warmup, True)   # this rank's own time ...
+    per_rank_ms = [t / args.steps * 1e3 for t in shard.gather_floats(elapsed, dist if world > 1 else None, dev)]
+    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, dev)   # ... the job's time is the slowest rank's
 
     # what the TIMED replays left in frame 0's buffers (device -> host copies only; compared with the gated pass further down)
     timed_final = final_outputs(pipes[0]) if rank == 0 else None
@@ -577,12 +586,18 @@ def main():
     #      results (ME SAD / MV tables, CDEF distortion table, restoration search results, the restored picture) on a copy stream; uploads of batch
     #      i+1 and downloads of batch i-1 overlap the compute of batch i
     with_transfers = None
-    if not args.no_transfers and world == 1 and len(step_fns) >= 2:
+    if not args.no_transfers and len(step_fns) >= 2:   # every rank at the same time when there are several: the host side (page-locked copies over PCIe) is what they share
         def unpad(P):   # the un-padded views the transform / filter stages read: device-to-device, at the head of the frame's own chain (a kernel on the
             # copy stream would queue behind a whole step's launches: ROCm runs the streams on a few in-order hardware queues)
             P.d_cur[0].copy_(P.d_cur_p[P.F.pad:P.F.pad + P.F.h, P.F.pad:P.F.pad + P.F.w], non_blocking=True)
             P.d_vp[:P.F.h, :P.F.w].copy_(P.d_cur[0], non_blocking=True)
+        if world > 1:
+            dist.barrier()
         with_transfers = measure_with_transfers(torch, stream, pipes, nF, make_steps(nF, stages, unpad), n_sb, max(10, min(args.steps, 40)))
+    per_rank_with_transfers = shard.gather_floats(with_transfers["value"] if isinstance(with_transfers, dict) and "value" in with_transfers else None, dist if world > 1 else None, dev) if world > 1 else None
+    per_rank_numa = None
+    if world > 1:
+        per_rank_numa = [None if n != n else int(n) for n in shard.gather_floats(numa["node"] if numa else None, dist, dev)]
 
     if rank != 0:
         if world > 1:
@@ -707,6 +722,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "launch": ("eager" if not use_graph else "hip_graph_replay") + f", {nF} frames per step, one forked stream per frame, "
                   f"steps rotate over {len(step_fns)} batches = {len(step_fns) * nF} distinct frames",
+        "per_rank": {"ms_per_step": per_rank_ms, "sb_per_s_with_transfers": per_rank_with_transfers, "numa_node": per_rank_numa,
+                     "note": "value = the units of all ranks / the slowest rank's time; with several ranks the PCIe-inclusive run of every rank is measured at the same time"},
         "value_with_transfers": with_transfers, "stage_subsets": subsets, "also_1080p": also_1080p, "also_10bit": also_10bit, "config1_variants": config1_variants, "config2_subpel": config2_subpel,
         "frames_per_step_sweep": sweep,
         "config": {"workload": f"{W}x{H} 8-bit 4:2:0 synthetic frames, {n_sb} SBs/frame, {nF} independent frames per step per GPU (F = 1 / 4 / 8 in frames_per_step_sweep); "

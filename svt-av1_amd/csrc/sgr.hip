@@ -22,6 +22,13 @@
 #include "svt_hip_internal.h"
 #include "lds_stage.h"
 
+// the difference planes are written once and read back much later by the walk: SVT_SGR_NT (A/B) marks those accesses non-temporal
+#ifdef SVT_SGR_NT
+#define SGR_ST(p, v) __builtin_nontemporal_store((uint32_t)(v), (p))
+#else
+#define SGR_ST(p, v) (*(p) = (v))
+#endif
+
 namespace {
 
 constexpr int TW = 64, TH = 16;            // output tile
@@ -441,7 +448,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if (r >= rlo && r < rhi)
-                        pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j] = ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16);
+                        SGR_ST(&pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j], ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16));
             }
             int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
     #pragma unroll
@@ -469,7 +476,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if (r >= rlo && r < rhi)
-                        pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j] = ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16);
+                        SGR_ST(&pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j], ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16));
             }
             int32_t h00[2] = {0, 0}, h01[2] = {0, 0}, h11[2] = {0, 0}, c0[2] = {0, 0}, c1[2] = {0, 0};
 #pragma unroll

@@ -26,6 +26,14 @@
 #include <string.h>
 #include "svt_hip_internal.h"
 
+#ifdef SVT_SGR_NT
+typedef int sgr_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 sgr_ld4_nt(const void* p) { const sgr_v4i v = __builtin_nontemporal_load((const sgr_v4i*)p); return make_int4(v.x, v.y, v.z, v.w); }
+#define SGR_LD4(p) sgr_ld4_nt(p)
+#else
+#define SGR_LD4(p) (*(const int4*)(p))
+#endif
+
 namespace {
 
 constexpr int kStreamCand = 10;  // the streamed form keeps one accumulator per candidate in registers
@@ -664,7 +672,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
         auto fetch = [&](int kk, int4& x0v, int4& x1v, int4& sv) {
             const int row = kk / cw, cx = kk - row * cw;
             const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-            x0v = *(const int4*)(PP + off); x1v = *(const int4*)(PP + off + 4); sv = *(const int4*)(sd + off);
+            x0v = SGR_LD4(PP + off); x1v = SGR_LD4(PP + off + 4); sv = SGR_LD4(sd + off);
         };
         if (k < nchunk) fetch(k, a0, a1, s4);
         while (k < nchunk) {
@@ -729,7 +737,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
         if (k < nchunk) {
             const int row = k / cw, cx = k - row * cw;
             const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-            pa[j] = *(const int4*)(PP + off); pb[j] = *(const int4*)(PP + off + 4);
+            pa[j] = SGR_LD4(PP + off); pb[j] = SGR_LD4(PP + off + 4);
             s = *(const int4*)(sd + off);
             const int n = w - 8 * cx;
             if (n < 8) mask_chunk(pa[j], pb[j], s, n);
@@ -758,7 +766,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
             auto fetch = [&](int kk, int4& x0v, int4& x1v, int4& sv) {
                 const int row = kk / cw, cx = kk - row * cw;
                 const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-                x0v = *(const int4*)(PP + off); x1v = *(const int4*)(PP + off + 4); sv = *(const int4*)(sd + off);
+                x0v = SGR_LD4(PP + off); x1v = SGR_LD4(PP + off + 4); sv = SGR_LD4(sd + off);
                 const int n = w - 8 * cx;
                 if (n < 8) mask_chunk(x0v, x1v, sv, n);
             };
@@ -849,7 +857,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
             for (int k = t + kResJ * kResD; k < nchunk; k += kResD) {   // the part of an over-sized unit that is not resident
                 const int row = k / cw, cx = k - row * cw;
                 const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-                int4 a0 = *(const int4*)(PP + off), a1 = *(const int4*)(PP + off + 4), s = *(const int4*)(sd + off);
+                int4 a0 = SGR_LD4(PP + off), a1 = SGR_LD4(PP + off + 4), s = SGR_LD4(sd + off);
                 const int n = w - 8 * cx;
                 if (n < 8) mask_chunk(a0, a1, s, n);
                 eval_chunk(a0, a1, s, q, rnd, sel, p0, p1);
