@@ -897,6 +897,12 @@ int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int
 #define SVT_HIP_MD_GRID 49
 int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
                                        int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int bank, uint32_t *d_out);
+/* The half-pel round alone (svt_first_level_check, Encoder/Codec/mcomp.c:188: the eight half-sample neighbours of the full-pel vector, and the centre):
+ *   d_out : [n_sb][n_pus][n_refs][9][2] = (variance, sse) of position 3 * row + col, offsets (4 col - 4, 4 row - 4) eighth-samples — the same values as positions
+ *           (1, 3, 5) x (1, 3, 5) of the 7 x 7 table.  One workgroup per (superblock, PU, reference) stages the window once for all nine. */
+#define SVT_HIP_MD_HALFPEL_GRID 9
+int svt_hip_md_halfpel_grid_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                        int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int bank, uint32_t *d_out);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

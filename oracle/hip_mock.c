@@ -115,6 +115,20 @@ int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx *c, const uint8_t *src, int src
             if (out[i] != 0xffffffffu) out[i] += (uint32_t)((i * 2654435761u) >> 22);   /* a different wrong variance per position: the tree's comparisons flip */
     return SVT_HIP_OK;
 }
+int svt_hip_md_halfpel_grid_picture_dev(SvtHipCtx *c, const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                        int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *mv, int bank, uint32_t *out) {
+    const size_t n = (size_t)n_sb * n_pus * n_refs;
+    uint32_t    *full = (uint32_t *)malloc((n ? n : 1) * 98 * sizeof(uint32_t));
+    if (!full) return SVT_HIP_ERR_BAD_ARG;
+    const int rc = svt_hip_md_subpel_grid_picture_dev(c, src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, mv, bank, full);
+    for (size_t i = 0; rc == SVT_HIP_OK && i < n; i++)
+        for (int k = 0; k < 9; k++) {   /* positions (1, 3, 5) x (1, 3, 5) of the 7 x 7 table */
+            const int g = 7 * (2 * (k / 3) + 1) + 2 * (k % 3) + 1;
+            out[18 * i + 2 * k] = full[98 * i + 2 * g]; out[18 * i + 2 * k + 1] = full[98 * i + 2 * g + 1];
+        }
+    free(full);
+    return rc;
+}
 int svt_hip_me_set_big_windows(SvtHipCtx *c, int enable) { (void)c; (void)enable; return SVT_HIP_OK; }   /* the double's search has one instance */
 int svt_hip_me_get_big_windows(SvtHipCtx *c, int *enabled) { (void)c; *enabled = 1; return SVT_HIP_OK; }
 int svt_hip_me_fullpel_frame(SvtHipCtx *c, const uint8_t *src, const uint8_t *ref, int stride, int plane_rows, int org_x, int org_y,

@@ -30,6 +30,18 @@ __device__ __forceinline__ uint32_t load4_any(const uint8_t* p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
+__device__ __forceinline__ uint32_t row_sum(uint32_t x) {      // every lane: the total of its 16-lane row
+    int v = (int)x;
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t rows_total(uint32_t v) {   // the four row totals of a wave added up (wave-uniform)
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+}
+
 __global__ void __launch_bounds__(256)
 md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus,
                       const uint32_t* __restrict__ mv, uint32_t* __restrict__ sad) {
@@ -57,8 +69,7 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
             const int yy = r0 + row;
             if (yy < h) s = __builtin_amdgcn_sad_u8(load4_any(ps + (ptrdiff_t)yy * src_stride), load4_any(pr + (ptrdiff_t)yy * ref.stride), s);
         }
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) s += (uint32_t)__shfl_xor((int)s, k, 64);
+        s = rows_total(row_sum(s));
         if (lane == 0) sad[slot] = s;
     }
 }
@@ -71,7 +82,6 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
 // horizontal offset (7) over the PU's window and the vertical pass + statistics once per grid position (49), both as v_dot4_i32_i8 on four outputs per lane
 // (samples biased by -128; the taps of the non-zero phases fit int8 and sum to 128: the bias is added back exactly).  LDS: the window, the seven intermediates
 // (column-major: the vertical pass reads its eleven rows as three dwords) and the transposed source: 41 KB for a 64x64 PU.
-constexpr int kGrid = 7, kGridN = kGrid * kGrid;
 __device__ __forceinline__ uint32_t bytes4(uint32_t d0, uint32_t d1, uint32_t d2, int sh) {   // bytes sh .. sh + 3 of the twelve bytes d0 d1 d2 (sh <= 8)
     return sh < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh) : (sh < 8 ? __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(sh - 4)) : d2);
 }
@@ -92,52 +102,70 @@ __device__ __forceinline__ uint32_t filt4(uint32_t d0, uint32_t d1, uint32_t d2,
     }
     return P;
 }
-__device__ __constant__ int8_t kGridOff[kGrid][2] = {{-1, 2}, {-1, 4}, {-1, 6}, {0, 0}, {0, 2}, {0, 4}, {0, 6}};   // grid offset -6 .. 6 (1/8 sample) = whole part, eighth-pel phase
-__global__ void __launch_bounds__(256)
-md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus,
+__device__ __constant__ int8_t kGridOff7[7][2] = {{-1, 2}, {-1, 4}, {-1, 6}, {0, 0}, {0, 2}, {0, 4}, {0, 6}};   // grid offset -6 .. 6 (1/8 sample) = whole part, eighth-pel phase
+__device__ __constant__ int8_t kGridOff3[3][2] = {{-1, 4}, {0, 0}, {0, 4}};                                         // the half-pel round alone: offsets -4, 0, 4
+// kGrid = 7: the 7 x 7 quarter-pel grid (both rounds of the tree); kGrid = 3: the 3 x 3 half-pel grid (svt_first_level_check's eight neighbours + the centre)
+// SMAX / NT: the largest PU a launch handles and its workgroup size — 8x8 and 16x16 PUs (80 of the 85 square PUs of a superblock) run as one wave with 3.5 KB of LDS,
+// the larger ones as four waves; `sel` lists the PUs of the launch.
+struct PuSel { uint8_t idx[SVT_HIP_MD_MAX_PUS]; };
+template <int kGrid, int SMAX, int NT>
+__global__ void __launch_bounds__(NT)
+md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus, PuSel sel,
                       const uint32_t* __restrict__ mv, int bank, uint32_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t win[72 * 72];          // [row][col], row pitch WIN
-    __shared__ __attribute__((aligned(16))) uint8_t Hc[kGrid][64 * 72];    // [offset][col][row], column pitch WIN
-    __shared__ __attribute__((aligned(16))) uint8_t Sc[64 * 64];           // source, [col][row]
+    __shared__ __attribute__((aligned(16))) uint8_t win[(SMAX + 8) * (SMAX + 8) + 16];   // [row][col], row pitch WIN
+    constexpr int kGridN = kGrid * kGrid;
+    const int8_t (*kGridOff)[2] = kGrid == 7 ? kGridOff7 : kGridOff3;
+    __shared__ __attribute__((aligned(16))) uint8_t Hc[kGrid][SMAX * (SMAX + 8) + 16];  // [offset][col][row], column pitch WIN
+    __shared__ __attribute__((aligned(16))) uint8_t Sc[SMAX * SMAX];       // source, [col][row]
     __shared__ uint32_t stat[kGridN][3];                                   // sum p, sum p^2, sum p s
     __shared__ uint32_t sstat[2];                                          // sum s, sum s^2
-    const int sb = blockIdx.x, pu = blockIdx.y, r = blockIdx.z, tid = threadIdx.x;
+    const int sb = blockIdx.x, pu = sel.idx[blockIdx.y], r = blockIdx.z, tid = threadIdx.x;
     const size_t slot = ((size_t)sb * n_pus + pu) * n_refs + r;
     uint32_t* o = out + slot * (2 * kGridN);
     const int s = pus.w[pu], x = (sb % sb_cols) * 64 + pus.x[pu], y = (sb / sb_cols) * 64 + pus.y[pu], WIN = s + 8;
     const SvtHipMdRefPlane ref = refs.r[r];
     const uint32_t m = mv[slot];
     const int mx = (int16_t)(m & 0xffff), my = (int16_t)(m >> 16), wx = x + mx - 4, wy = y + my - 4;
-    const bool ok = mx != SVT_HIP_MD_NO_MV && pus.h[pu] == s && (s == 8 || s == 16 || s == 32 || s == 64) && x + s <= pic_w && y + s <= pic_h && wx >= ref.x_min && wy >= ref.y_min &&
+    const bool ok = mx != SVT_HIP_MD_NO_MV && pus.h[pu] == s && s <= SMAX && (s == 8 || s == 16 || s == 32 || s == 64) && x + s <= pic_w && y + s <= pic_h && wx >= ref.x_min && wy >= ref.y_min &&
                     wx + WIN + 4 <= ref.x_max && wy + WIN <= ref.y_max;
     if (!ok) {   // workgroup-uniform
-        for (int i = tid; i < 2 * kGridN; i += 256) o[i] = 0xffffffffu;
+        for (int i = tid; i < 2 * kGridN; i += NT) o[i] = 0xffffffffu;
         return;
     }
-    for (int i = tid; i < kGridN * 3 + 2; i += 256) { if (i < kGridN * 3) stat[i / 3][i % 3] = 0; else sstat[i - kGridN * 3] = 0; }
+    for (int i = tid; i < kGridN * 3 + 2; i += NT) { if (i < kGridN * 3) stat[i / 3][i % 3] = 0; else sstat[i - kGridN * 3] = 0; }
+    // the packed taps of the three non-zero phases (2/8, 4/8, 6/8 sample), workgroup-uniform: scalar loads once instead of eight table reads per task
+    int TAp[3], TBp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int16_t* kp = kInterp[bank][4 * k + 4];
+        TAp[k] = (kp[0] & 0xff) | (kp[1] & 0xff) << 8 | (kp[2] & 0xff) << 16 | (kp[3] & 0xff) << 24;
+        TBp[k] = (kp[4] & 0xff) | (kp[5] & 0xff) << 8 | (kp[6] & 0xff) << 16 | (kp[7] & 0xff) << 24;
+    }
+    const int   sq = s >> 2, lq = 31 - __clz(sq);                 // s / 4 is a power of two
+    const float r_hw = 1.0f / (float)(WIN * sq), r_per = 1.0f / (float)(s * sq);   // exact quotients for the task counts here (< 2^16, divisors <= 1152)
     // ---- stage the window (rows as dwords) and the source (transposed)
-    const int wdw = WIN >> 2;
-    for (int i = tid; i < WIN * wdw; i += 256) {
-        const int rr = i / wdw, cd = i - rr * wdw;
+    const int   wdw = WIN >> 2;
+    const float r_wdw = 1.0f / (float)wdw;
+    for (int i = tid; i < WIN * wdw; i += NT) {
+        const int rr = (int)(((float)i + 0.5f) * r_wdw), cd = i - rr * wdw;
         ((uint32_t*)win)[rr * wdw + cd] = load4_any(ref.d_plane + (ptrdiff_t)(wy + rr) * ref.stride + wx + 4 * cd);
     }
     __syncthreads();   // (also orders the zeroing of the statistics before their first update)
     {
         uint32_t ss = 0, ss2 = 0;
-        for (int i = tid; i < s * (s >> 2); i += 256) {
+        for (int i = tid; i < s * (s >> 2); i += NT) {
             const int rr = i / (s >> 2), c = (i - rr * (s >> 2)) << 2;
             const uint32_t v = load4_any(src + (ptrdiff_t)(y + rr) * src_stride + x + c);
 #pragma unroll
             for (int q = 0; q < 4; q++) Sc[(c + q) * s + rr] = (uint8_t)(v >> (8 * q));
             ss += __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false); ss2 += __builtin_amdgcn_udot4(v, v, 0u, false);
         }
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) { ss += (uint32_t)__shfl_xor((int)ss, k, 64); ss2 += (uint32_t)__shfl_xor((int)ss2, k, 64); }
+        ss = rows_total(row_sum(ss)); ss2 = rows_total(row_sum(ss2));
         if ((tid & 63) == 0) { atomicAdd(&sstat[0], ss); atomicAdd(&sstat[1], ss2); }
     }
     // ---- horizontal pass, once per horizontal offset: Hc[a][col][row] over all WIN rows
-    for (int t = tid; t < kGrid * WIN * (s >> 2); t += 256) {
-        const int a = t / (WIN * (s >> 2)), rem = t - a * (WIN * (s >> 2)), rr = rem / (s >> 2), j = (rem - rr * (s >> 2)) << 2;
+    for (int t = tid; t < kGrid * WIN * (s >> 2); t += NT) {
+        const int a = (int)(((float)t + 0.5f) * r_hw), rem = t - a * (WIN * sq), rr = rem >> lq, j = (rem - (rr << lq)) << 2;
         const int ix = kGridOff[a][0], fx = kGridOff[a][1];
         const int ob = j + ix + 1;                     // first byte of output 0's eight taps in the window row
         const uint32_t* wd = (const uint32_t*)(win + rr * WIN + (ob & ~3));
@@ -145,8 +173,7 @@ md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
         uint32_t P;
         if (fx == 0) P = bytes4(d0, d1, d2, (ob & 3) + 3);
         else {
-            const int TA = (kInterp[bank][fx << 1][0] & 0xff) | (kInterp[bank][fx << 1][1] & 0xff) << 8 | (kInterp[bank][fx << 1][2] & 0xff) << 16 | (kInterp[bank][fx << 1][3] & 0xff) << 24;
-            const int TB = (kInterp[bank][fx << 1][4] & 0xff) | (kInterp[bank][fx << 1][5] & 0xff) << 8 | (kInterp[bank][fx << 1][6] & 0xff) << 16 | (kInterp[bank][fx << 1][7] & 0xff) << 24;
+            const int TA = fx == 2 ? TAp[0] : (fx == 4 ? TAp[1] : TAp[2]), TB = fx == 2 ? TBp[0] : (fx == 4 ? TBp[1] : TBp[2]);
             P = filt4(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, ob & 3, TA, TB);
         }
 #pragma unroll
@@ -156,13 +183,13 @@ md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
     // ---- vertical pass + statistics, once per grid position: a task = four vertically adjacent outputs of one column
     const int per = s * (s >> 2);                       // tasks per grid position
     const int G = per < 64 ? per : 64;                  // lanes of a wave that share a grid position (16 for 8x8 PUs)
-    for (int t0 = 0; t0 < kGridN * per; t0 += 256) {
+    for (int t0 = 0; t0 < kGridN * per; t0 += NT) {
         const int t = t0 + tid;
         uint32_t sp = 0, sp2 = 0, sps = 0;
         int c = 0;
         if (t < kGridN * per) {
-            c = t / per;
-            const int rem = t - c * per, j = rem / (s >> 2), i = (rem - j * (s >> 2)) << 2;
+            c = (int)(((float)t + 0.5f) * r_per);
+            const int rem = t - c * per, j = rem >> lq, i = (rem - (j << lq)) << 2;
             const int b = c / kGrid, a = c - b * kGrid;   // grid position: row offset b, column offset a
             const int iy = kGridOff[b][0], fy = kGridOff[b][1];
             const int ob = i + iy + 1;
@@ -171,14 +198,14 @@ md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
             uint32_t P;
             if (fy == 0) P = bytes4(d0, d1, d2, (ob & 3) + 3);
             else {
-                const int TA = (kInterp[bank][fy << 1][0] & 0xff) | (kInterp[bank][fy << 1][1] & 0xff) << 8 | (kInterp[bank][fy << 1][2] & 0xff) << 16 | (kInterp[bank][fy << 1][3] & 0xff) << 24;
-                const int TB = (kInterp[bank][fy << 1][4] & 0xff) | (kInterp[bank][fy << 1][5] & 0xff) << 8 | (kInterp[bank][fy << 1][6] & 0xff) << 16 | (kInterp[bank][fy << 1][7] & 0xff) << 24;
+                const int TA = fy == 2 ? TAp[0] : (fy == 4 ? TAp[1] : TAp[2]), TB = fy == 2 ? TBp[0] : (fy == 4 ? TBp[1] : TBp[2]);
                 P = filt4(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, ob & 3, TA, TB);
             }
             const uint32_t S = *(const uint32_t*)(&Sc[j * s + i]);
             sp = __builtin_amdgcn_udot4(P, 0x01010101u, 0u, false); sp2 = __builtin_amdgcn_udot4(P, P, 0u, false); sps = __builtin_amdgcn_udot4(P, S, 0u, false);
         }
-        for (int k = 1; k < G; k <<= 1) { sp += (uint32_t)__shfl_xor((int)sp, k, 64); sp2 += (uint32_t)__shfl_xor((int)sp2, k, 64); sps += (uint32_t)__shfl_xor((int)sps, k, 64); }
+        sp = row_sum(sp); sp2 = row_sum(sp2); sps = row_sum(sps);          // DPP inside the 16-lane rows (G = 16: a row is a grid position's lanes)
+        if (G == 64) { sp = rows_total(sp); sp2 = rows_total(sp2); sps = rows_total(sps); }
         if (t < kGridN * per && (tid & (G - 1)) == 0) { atomicAdd(&stat[c][0], sp); atomicAdd(&stat[c][1], sp2); atomicAdd(&stat[c][2], sps); }
     }
     __syncthreads();
@@ -207,7 +234,7 @@ extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src,
 }
 
 extern "C" int svt_hip_launch_md_subpel_grid(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
-                                             int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int bank, uint32_t* out) {
+                                             int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int bank, int grid, uint32_t* out) {
     if (n_sb <= 0 || n_refs <= 0 || n_pus <= 0) return 0;
     RefPlanes rp;
     PuList    pl;
@@ -216,7 +243,22 @@ extern "C" int svt_hip_launch_md_subpel_grid(hipStream_t st, const uint8_t* src,
         const SvtHipMdPu p = pus[i < n_pus ? i : 0];
         pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
     }
-    hipLaunchKernelGGL(md_subpel_grid_kernel, dim3(n_sb, n_pus, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, bank, out);
+    PuSel small, large;   // PUs up to 16 wide: one wave each; the rest (and the ones the kernel declines: it writes their "not computed" pairs): four waves
+    int   n_small = 0, n_large = 0;
+    for (int i = 0; i < n_pus; i++) {
+        if (pus[i].w <= 16 && pus[i].h <= 16) small.idx[n_small++] = (uint8_t)i;
+        else large.idx[n_large++] = (uint8_t)i;
+    }
+    for (int i = n_small; i < SVT_HIP_MD_MAX_PUS; i++) small.idx[i] = 0;
+    for (int i = n_large; i < SVT_HIP_MD_MAX_PUS; i++) large.idx[i] = 0;
+    if (n_small) {
+        if (grid == 3) hipLaunchKernelGGL((md_subpel_grid_kernel<3, 16, 64>), dim3(n_sb, n_small, n_refs), dim3(64), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, small, mv, bank, out);
+        else hipLaunchKernelGGL((md_subpel_grid_kernel<7, 16, 64>), dim3(n_sb, n_small, n_refs), dim3(64), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, small, mv, bank, out);
+    }
+    if (n_large) {
+        if (grid == 3) hipLaunchKernelGGL((md_subpel_grid_kernel<3, 64, 256>), dim3(n_sb, n_large, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, large, mv, bank, out);
+        else hipLaunchKernelGGL((md_subpel_grid_kernel<7, 64, 256>), dim3(n_sb, n_large, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, large, mv, bank, out);
+    }
     return (int)hipGetLastError();
 }
 

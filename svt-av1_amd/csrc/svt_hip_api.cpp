@@ -624,9 +624,8 @@ int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int s
     if (e != hipSuccess) return fail(c, e, "md full-pel sad launch");
     return SVT_HIP_OK;
 }
-int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+static int md_grid_picture(int grid, SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                        int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int bank, uint32_t* d_out) {
-    SVT_HIP_ENTER(c);
     if (!c || !d_src || !pus || !refs || !d_mv || !d_out || n_sb < 0 || sb_cols < 1 || pic_w < 1 || pic_h < 1 || n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 ||
         n_refs > SVT_HIP_MD_MAX_REFS || bank < 0 || bank > 5)
         return SVT_HIP_ERR_BAD_ARG;
@@ -634,9 +633,19 @@ int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int s
         if (pus[i].x + pus[i].w > 64 || pus[i].y + pus[i].h > 64) return SVT_HIP_ERR_BAD_ARG;
     for (int i = 0; i < n_refs; i++)
         if (!refs[i].d_plane || refs[i].stride < 1) return SVT_HIP_ERR_BAD_ARG;
-    hipError_t e = (hipError_t)svt_hip_launch_md_subpel_grid(c->stream, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, bank, d_out);
+    hipError_t e = (hipError_t)svt_hip_launch_md_subpel_grid(c->stream, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, bank, grid, d_out);
     if (e != hipSuccess) return fail(c, e, "md sub-pel grid launch");
     return SVT_HIP_OK;
+}
+int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                       int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int bank, uint32_t* d_out) {
+    SVT_HIP_ENTER(c);
+    return md_grid_picture(7, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, bank, d_out);
+}
+int svt_hip_md_halfpel_grid_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                        int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int bank, uint32_t* d_out) {
+    SVT_HIP_ENTER(c);
+    return md_grid_picture(3, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, bank, d_out);
 }
 int svt_hip_coeff_distortion_batch_dev(SvtHipCtx* c, const int32_t* d_coeff, const int32_t* d_recon_coeff, int n_per_block, int nblk, uint64_t* d_out) {
     SVT_HIP_ENTER(c);

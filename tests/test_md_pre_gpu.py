@@ -79,6 +79,12 @@ def test_md_subpel_grid_picture(hip, pkg, orc, w, h, n_refs, bank):
         planes[r] = pkg.MdRefPlane(d_refs[r].value + pad * refs[r].shape[1] + pad, refs[r].shape[1], -pad, -pad, refs[r].shape[1] - pad, refs[r].shape[0] - pad)
     hip.check(hip.L.svt_hip_md_subpel_grid_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, bank, d_out), "md grid")
     got = hip.to_host(d_out, exp.shape, np.uint32)
-    hip.free(d_src, d_mv, d_out, *d_refs)
+    # the half-pel round alone (svt_hip_md_halfpel_grid_picture_dev): positions (1, 3, 5) x (1, 3, 5) of the same table
+    exp9 = np.ascontiguousarray(exp.reshape(exp.shape[:-2] + (7, 7, 2))[..., 1::2, 1::2, :]).reshape(exp.shape[:-2] + (9, 2))
+    d_out9 = hip.empty(exp9.size * 4)
+    hip.check(hip.L.svt_hip_md_halfpel_grid_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, bank, d_out9), "md half-pel grid")
+    got9 = hip.to_host(d_out9, exp9.shape, np.uint32)
+    hip.free(d_src, d_mv, d_out, d_out9, *d_refs)
     assert (exp == 0xffffffff).any() and (exp != 0xffffffff).any()
     assert np.array_equal(got, exp), np.argwhere(got != exp)[:6]
+    assert np.array_equal(got9, exp9), np.argwhere(got9 != exp9)[:6]
