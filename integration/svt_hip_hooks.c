@@ -308,6 +308,10 @@ void svt_hip_hooks_report(void) {
         long gp, probes, served;
         svt_hip_hook_md_pre_subpel_stats(&gp, &probes, &served);
         fprintf(stderr, "svt_hip_md_pre_subpel grid_pictures=%ld probes=%ld served_from_grid=%ld\n", gp, probes, served);
+        long miss[10];
+        svt_hip_hook_md_pre_misses(miss, 10);
+        fprintf(stderr, "svt_hip_md_pre_misses compound=%ld motion_mode=%ld hbd=%ld later_pass=%ld shape=%ld no_table_yet=%ld reference=%ld vector=%ld border=%ld mark=%ld device_ms=%.1f\n", miss[0], miss[1],
+                miss[2], miss[3], miss[4], miss[5], miss[6], miss[7], miss[8], miss[9], svt_hip_hook_md_pre_device_ms());
     }
     if (g_rtcd_installed) svt_hip_rtcd_report();   /* "svt_hip_rtcd_calls ..." / "svt_hip_rtcd_delegated ..." per wrapper */
 }

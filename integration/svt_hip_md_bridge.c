@@ -651,6 +651,14 @@ static int  g_pre_grid_on = -1;
 static __thread struct { const uint32_t *row; int cx, cy; } tls_grid;
 static long long g_pre_ns;
 static long g_pre_mismatch;
+static int  g_pre_timing = -1;   /* SVT_HIP_MD_PRE_TIMING=1: measure the device time per picture (makes the configuration thread wait: a diagnostic, not the product's mode) */
+static long g_pre_device_us;
+double svt_hip_hook_md_pre_device_ms(void) { return g_pre_timing > 0 ? g_pre_device_us / 1000.0 : -1.0; }
+/* why an inter candidate of fast_loop_core was not served from the table */
+enum { PRE_MISS_COMPOUND, PRE_MISS_MOTION, PRE_MISS_HBD, PRE_MISS_LATER_PASS, PRE_MISS_SHAPE, PRE_MISS_NO_TABLE, PRE_MISS_REFERENCE, PRE_MISS_VECTOR, PRE_MISS_BORDER, PRE_MISS_MARK, PRE_MISS_N };
+static long g_pre_miss[PRE_MISS_N];
+#define PRE_MISS(why) do { __sync_fetch_and_add(&g_pre_miss[why], 1); return 0; } while (0)
+void svt_hip_hook_md_pre_misses(long *out, int n) { for (int i = 0; i < n; i++) out[i] = i < PRE_MISS_N ? g_pre_miss[i] : 0; }
 static int  g_pre_verify = -1;
 static __thread struct { PictureControlSet *pcs; uint64_t pic; MdPre *t; } tls_pre;
 #define PRE_MARKS 1024
@@ -823,6 +831,8 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         planes[r].x_max = (int)rp->width + (int)rp->origin_x; planes[r].y_max = (int)rp->height + (int)rp->origin_y;
     }
     for (int i = 0; i <= n_refs; i++) any_tmp |= tmp[i] != NULL;
+    if (g_pre_timing < 0) g_pre_timing = getenv("SVT_HIP_MD_PRE_TIMING") && atoi(getenv("SVT_HIP_MD_PRE_TIMING"));
+    const int timing = g_pre_timing > 0 && rc == SVT_HIP_OK && svt_hip_timer_start(hip) == SVT_HIP_OK;   /* diagnostic: the device time of this picture's launches and copies (waits) */
     if (rc == SVT_HIP_OK)
         rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
                                                 n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad);
@@ -843,6 +853,10 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         t->flags[0] = t->seq;
         rc = svt_hip_memcpy_h2d_async(hip, t->d_seq, (const void *)&t->flags[0], sizeof(uint32_t));
         if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_d2h_async(hip, (void *)&t->flags[1], t->d_seq, sizeof(uint32_t));
+    }
+    if (timing) {
+        float ms = 0;
+        if (svt_hip_timer_stop_ms(hip, &ms) == SVT_HIP_OK) __sync_fetch_and_add(&g_pre_device_us, (long)(ms * 1000.0f));
     }
     t->n_held = 0;
     if (from_table[0]) t->held[t->n_held++] = in->buffer_y;
@@ -935,31 +949,32 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     const ModeDecisionCandidate *c = cb->candidate_ptr;
     if (c->type != INTER_MODE || c->use_intrabc) return 0;
     __sync_fetch_and_add(&g_pre_inter, 1);
-    if (c->is_compound || c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used || ctx->hbd_mode_decision || !ctx->md_staging_skip_chroma_pred ||
-        !ctx->md_staging_skip_interpolation_search)
-        return 0;
+    if (ctx->hbd_mode_decision) PRE_MISS(PRE_MISS_HBD);
+    if (!ctx->md_staging_skip_chroma_pred || !ctx->md_staging_skip_interpolation_search) PRE_MISS(PRE_MISS_LATER_PASS);
+    if (c->is_compound) PRE_MISS(PRE_MISS_COMPOUND);
+    if (c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used) PRE_MISS(PRE_MISS_MOTION);
     const BlockGeom *g = ctx->blk_geom;
-    if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) return 0;
+    if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) PRE_MISS(PRE_MISS_SHAPE);
     const MdPre *t = pre_table_of(pcs);
-    if (!t) return 0;
+    if (!t) PRE_MISS(PRE_MISS_NO_TABLE);
     const uint32_t pu = ctx->me_block_offset, sb = ctx->me_sb_addr;
-    if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) return 0;
+    if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) PRE_MISS(PRE_MISS_SHAPE);
     MvReferenceFrame rf[2];
     av1_set_ref_frame(rf, c->ref_frame_type);
-    if (rf[1] != NONE_FRAME) return 0;
+    if (rf[1] != NONE_FRAME) PRE_MISS(PRE_MISS_COMPOUND);
     const int li = get_list_idx(rf[0]), ri = get_ref_frame_idx(rf[0]);
-    if (li < 0 || li > 1 || ri < 0 || ri > 3 || c->prediction_direction[0] != li) return 0;
+    if (li < 0 || li > 1 || ri < 0 || ri > 3 || c->prediction_direction[0] != li) PRE_MISS(PRE_MISS_REFERENCE);
     const int col = t->slot_of[li][ri];
-    if (col < 0) return 0;
+    if (col < 0) PRE_MISS(PRE_MISS_REFERENCE);
     const int16_t mx = li ? c->motion_vector_xl1 : c->motion_vector_xl0, my = li ? c->motion_vector_yl1 : c->motion_vector_yl0;
     const size_t e = ((size_t)sb * PRE_PUS + pu) * (size_t)t->n_refs + (size_t)col;
-    if (t->mv[e] != ((uint32_t)(uint16_t)mx | (uint32_t)(uint16_t)my << 16) || t->sad[e] == 0xffffffffu) return 0;
+    if (t->mv[e] != ((uint32_t)(uint16_t)mx | (uint32_t)(uint16_t)my << 16) || t->sad[e] == 0xffffffffu) PRE_MISS(PRE_MISS_VECTOR);
     /* av1_inter_prediction clamps the vector so that the block stays within (block size + AOM_INTERP_EXTEND) samples of the picture (clamp_mv_to_umv_border_sb,
      * Common/Codec/EbInterPrediction.h): a vector it would move is not what the table measured */
     const int bx = (int)ctx->blk_origin_x + (mx >> 3), by = (int)ctx->blk_origin_y + (my >> 3), bw = g->bwidth;
     const int pic_w = (int)pcs->parent_pcs_ptr->av1_cm->mi_cols * 4, pic_h = (int)pcs->parent_pcs_ptr->av1_cm->mi_rows * 4;
-    if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) return 0;
-    if (tls_mark[ms]) return 0;   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
+    if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) PRE_MISS(PRE_MISS_BORDER);
+    if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
     *sad = t->sad[e];
     __sync_fetch_and_add(&g_pre_hits, 1);
     if (g_pre_verify) return 2;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the candidate as well and svt_hip_hook_md_pre_verify compares */
