@@ -119,7 +119,7 @@ void refb_subpel_predict_batch(const uint8_t *ref, int ref_stride, uint8_t *dst,
 /* ---------------------------------------------------------------- sub-pel refinement probes ---------------------------------------------
  * svt_upsampled_pref_error (Encoder/Codec/mcomp.c:102-156) of a list of candidates: svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269 behind the dispatch
  * pointer) into a scratch block, then the block size's variance function against the source (vfp->vf = svt_aom_variance{W}x{H}).  Job layout = SvtHipUpsampledBlk of
- * svt_hip_upsampled_pred_batch_dev + the source position of the candidate's block; 16x16 blocks (the bench's BASELINE configs[2] sub-line). */
+ * svt_hip_upsampled_pred_batch_dev + the source position of the candidate's block; square blocks 8 .. 64 (the bench's BASELINE configs[2] sub-line uses 16x16). */
 typedef struct { int32_t ref_off, dst_off; uint8_t w, h, subpel_x_q3, subpel_y_q3, bank, reserved[3]; } RefbUpsBlk;
 void refb_upsampled_var_batch(const uint8_t *ref, int ref_stride, const uint8_t *src, int src_stride, const RefbUpsBlk *jobs, const int32_t *src_off, int begin, int end,
                               uint32_t *var, uint32_t *sse) {
@@ -129,7 +129,9 @@ void refb_upsampled_var_batch(const uint8_t *ref, int ref_stride, const uint8_t 
         const int st = b->bank == 3 ? USE_2_TAPS : (b->bank == 4 ? USE_4_TAPS : USE_8_TAPS);
         svt_aom_upsampled_pred(NULL, NULL, 0, 0, NULL, pred, b->w, b->h, b->subpel_x_q3, b->subpel_y_q3, ref + b->ref_off, ref_stride, st);
         unsigned int e = 0;
-        var[i] = b->w == 16 && b->h == 16 ? svt_aom_variance16x16(pred, b->w, src + src_off[i], src_stride, &e) : 0;
+        const uint8_t *sp = src + src_off[i];   /* the square sizes mode decision's sub-pel refinement probes (fn_ptr[bsize].vf, EbProductCodingLoop.c:2063) */
+        var[i] = b->w != b->h ? 0 : b->w == 8 ? svt_aom_variance8x8(pred, 8, sp, src_stride, &e) : b->w == 16 ? svt_aom_variance16x16(pred, 16, sp, src_stride, &e)
+                 : b->w == 32 ? svt_aom_variance32x32(pred, 32, sp, src_stride, &e) : b->w == 64 ? svt_aom_variance64x64(pred, 64, sp, src_stride, &e) : 0;
         sse[i] = e;
     }
 }

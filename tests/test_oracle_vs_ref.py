@@ -82,6 +82,37 @@ def test_sad_loop_and_nxm(orc, ref):
         assert ref.svt_fast_loop_nxm_sad_kernel(ptr(src), bw, ptr(refb), rs, bh, bw) == orc.orc_nxm_sad(ptr(src), bw, ptr(refb), rs, bh, bw)
 
 
+def test_md_subpel_probe(orc, ref):
+    """oracle/md_oracle.c::orc_md_subpel_probe (one probe of mode decision's sub-pel refinement) vs the reference's own svt_aom_upsampled_pred + svt_aom_variance{W}x{W}
+    (svt_upsampled_pref_error, Encoder/Codec/mcomp.c:102-156) through oracle/ref_bench.c::refb_upsampled_var_batch: square blocks 8 .. 64, every eighth-pel phase, the three
+    tap sets, saturating content."""
+    rng = np.random.default_rng(47)
+    orc.orc_md_subpel_probe.restype = C.c_uint32
+    pad, W, H = 48, 256, 192
+    src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    refp = rng.integers(0, 256, (H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    refp[pad:pad + 80, pad:pad + 80] = np.where(rng.random((80, 80)) < 0.5, 0, 255)
+    st = refp.shape[1]
+    n = 600
+    jobs = np.zeros(n, np.dtype([("ref_off", "<i4"), ("dst_off", "<i4"), ("w", "u1"), ("h", "u1"), ("sx", "u1"), ("sy", "u1"), ("bank", "u1"), ("r", "u1", 3)]))
+    src_off = np.zeros(n, np.int32)
+    cases = []
+    for i in range(n):
+        s = int(rng.choice([8, 16, 32, 64])); bank = int(rng.choice([0, 3, 4]))
+        x = int(rng.integers(0, (W - s) // 8 + 1)) * 8 if i >= 40 else 0; y = int(rng.integers(0, (H - s) // 8 + 1)) * 8 if i >= 40 else 0
+        mvx, mvy = int(rng.integers(-30 * 8, 30 * 8 + 1)), int(rng.integers(-30 * 8, 30 * 8 + 1))
+        jobs[i] = ((pad + y + (mvy >> 3)) * st + pad + x + (mvx >> 3), 0, s, s, mvx & 7, mvy & 7, bank, (0, 0, 0))
+        src_off[i] = y * W + x
+        cases.append((x, y, s, mvx, mvy, bank))
+    e_var, e_sse = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    ref.refb_upsampled_var_batch(ptr(refp), st, ptr(src), W, ptr(jobs), ptr(src_off), 0, n, ptr(e_var), ptr(e_sse))
+    base = C.c_void_p(refp.ctypes.data + pad * st + pad)
+    for i, (x, y, s, mvx, mvy, bank) in enumerate(cases):
+        sse = C.c_uint32(0)
+        v = orc.orc_md_subpel_probe(ptr(src), W, base, st, x, y, s, mvx, mvy, bank, C.byref(sse))
+        assert (v, sse.value) == (int(e_var[i]), int(e_sse[i])), (i, x, y, s, mvx, mvy, bank)
+
+
 def test_md_fullpel_candidate(orc, ref):
     """oracle/md_oracle.c vs the two reference kernels fast_loop_core (EbProductCodingLoop.c:907) runs for a full-pel single-reference candidate: the prediction
     svt_av1_convolve_2d_copy_sr_c (what svt_inter_predictor's table holds at [0][0][0]) and the distortion svt_nxm_sad_kernel_helper_c (= svt_nxm_sad_kernel_sub_sampled's
