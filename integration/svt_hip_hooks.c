@@ -78,6 +78,7 @@ static int in_list_exact(const char *list, const char *name) {   /* like in_list
 }
 
 static int g_device;
+long svt_hip_hooks_early_unpins(void);
 int svt_hip_hooks_device(void) { return g_device; }
 int svt_hip_hook_enabled(int which) { return which >= 0 && which < SVT_HIP_HOOK_COUNT && g_ctx && g_enabled[which]; }
 /* how long process threads waited for the context and how long they held it (nanoseconds; reported at exit: the serial share of the hooks) */
@@ -288,6 +289,8 @@ void svt_hip_hooks_report(void) {
     }
     if (g_pool_n)
         fprintf(stderr, "svt_hip_context_pool contexts=%d locks=%lld held_ms=%.1f waited_ms=%.1f\n", g_pool_n, g_pool_locks, g_pool_held_ns / 1e6, g_pool_wait_ns / 1e6);
+    if (svt_hip_hooks_early_unpins())   /* an encoder instance of the process ended while others went on: every page-locked range was released and the survivors' re-registered */
+        fprintf(stderr, "svt_hip_pins released_while_other_instances_ran=%ld\n", svt_hip_hooks_early_unpins());
     if (g_enabled[SVT_HIP_HOOK_ENCDEC_TX]) {
         long blocks, calls;
         svt_hip_hook_encdec_tx_stats(&blocks, &calls);
@@ -446,9 +449,30 @@ static pthread_mutex_t g_init_mu = PTHREAD_MUTEX_INITIALIZER;
 static int             g_instances;   /* encoder instances of the process between their init and deinit: they share every object below */
 /* svt_av1_enc_deinit_handle, BEFORE svt_av1_enc_component_de_init frees the instance's pictures: host ranges that were page-locked in place are released
  * (the last instance only: the table is shared) */
+static long g_early_unpins;
+long svt_hip_hooks_early_unpins(void) { return g_early_unpins; }
 void svt_hip_hooks_enc_predeinit(void) {
     pthread_mutex_lock(&g_init_mu);
-    if (g_inited && g_instances == 1 && g_ctx) { svt_hip_resident_unpin_all(g_ctx); svt_hip_lf_bridge_unpin(g_ctx); }
+    if (g_inited && g_ctx) {
+        /* The tables of page-locked ranges are shared by the instances of the process and do not know whose buffers they hold, and this instance is about to free
+         * its pictures: EVERY range is released and forgotten.  With other instances still encoding, the contexts are quiesced first (every bridge call holds g_lock or
+         * a pool mutex for as long as its copies are in flight; svt_hip_hooks_unlock_any drains before it unlocks) and page-locking stays on: the survivors' buffers
+         * are registered again by the next call that uses them.  (Their device copies in the resident table stay; the dead instance's are evicted by the budget.) */
+        const int others = g_instances > 1;
+        if (others) {
+            pthread_mutex_lock(&g_lock);
+            for (int i = 0; i < g_pool_n; i++) pthread_mutex_lock(&g_pool_mu[i]);
+            (void)svt_hip_sync(g_ctx);
+            for (int i = 0; i < g_pool_n; i++) (void)svt_hip_sync(g_pool[i]);
+            g_early_unpins++;
+        }
+        svt_hip_resident_unpin_all(g_ctx, others);
+        svt_hip_lf_bridge_unpin(g_ctx, others);
+        if (others) {
+            for (int i = g_pool_n - 1; i >= 0; i--) pthread_mutex_unlock(&g_pool_mu[i]);
+            pthread_mutex_unlock(&g_lock);
+        }
+    }
     pthread_mutex_unlock(&g_init_mu);
 }
 void svt_hip_hooks_enc_deinit(void) {

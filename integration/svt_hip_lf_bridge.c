@@ -148,11 +148,11 @@ static void lf_pin_picture(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int p
     lf_pin(hip, pic->buffer_cb, (size_t)pic->chroma_size * pix_bytes);
     lf_pin(hip, pic->buffer_cr, (size_t)pic->chroma_size * pix_bytes);
 }
-void svt_hip_lf_bridge_unpin(SvtHipCtx *hip) {
+void svt_hip_lf_bridge_unpin(SvtHipCtx *hip, int keep_pinning) {
     pthread_mutex_lock(&g_pin_mu);
     for (int i = 0; i < LF_PINS; i++)
         if (g_pin[i].p) { (void)svt_hip_host_unregister(hip, g_pin[i].p); g_pin[i].p = NULL; }
-    g_pin_off = 1;
+    g_pin_off = !keep_pinning;
     pthread_mutex_unlock(&g_pin_mu);
 }
 
@@ -244,7 +244,7 @@ void svt_hip_lf_bridge_release(SvtHipCtx *hip) {   /* no picture is in flight an
         if (g_state[i].mu_ready) pthread_mutex_destroy(&g_state[i].mu);
         memset(&g_state[i], 0, sizeof(g_state[i]));
     }
-    svt_hip_lf_bridge_unpin(hip);
+    svt_hip_lf_bridge_unpin(hip, 0);
     g_pin_off = 0;
 }
 

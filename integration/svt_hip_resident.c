@@ -163,11 +163,11 @@ void svt_hip_resident_release(const void *host) {
 }
 
 /* the host ranges stop being page-locked (before the encoder frees them); the device copies stay */
-void svt_hip_resident_unpin_all(SvtHipCtx *hip) {
+void svt_hip_resident_unpin_all(SvtHipCtx *hip, int keep_pinning) {
     pthread_mutex_lock(&g_mu);
     for (int i = 0; i < RES_SLOTS; i++)
         if (g_res[i].host && g_res[i].pinned) { (void)svt_hip_host_unregister(hip, (void *)(uintptr_t)g_res[i].host); g_res[i].pinned = 0; }
-    g_pin = 0;
+    if (!keep_pinning) g_pin = 0;   /* keep_pinning: other encoder instances go on; their planes are page-locked again by their next upload */
     pthread_mutex_unlock(&g_mu);
 }
 

@@ -28,7 +28,7 @@ void        svt_hip_resident_configure(int on, size_t limit_bytes, int ignore_re
  * in place at its first upload (svt_hip_host_register; released by svt_hip_resident_unpin_all / _release_all). */
 typedef size_t (*SvtHipResidentBlockSize)(size_t bytes);
 void        svt_hip_resident_configure_blocks(SvtHipResidentBlockSize block_size, int pin_host);
-void        svt_hip_resident_unpin_all(SvtHipCtx *hip);     /* before the encoder frees its pictures: no host range stays page-locked, no new one is */
+void        svt_hip_resident_unpin_all(SvtHipCtx *hip, int keep_pinning);   /* before an encoder instance frees its pictures: no host range stays page-locked; keep_pinning = 0: and no new one is */
 int         svt_hip_resident_enabled(void);
 void        svt_hip_resident_note(const void *host, size_t bytes);
 const void *svt_hip_resident_acquire(SvtHipCtx *hip, const void *host, size_t bytes);

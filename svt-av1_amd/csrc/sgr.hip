@@ -755,7 +755,9 @@ struct WnWalkState { int s, ph, p, up, skip, state; long long err; int16_t v[8],
 __device__ __forceinline__ void wn_apply(int16_t* f, int p, int d) { f[p] += (int16_t)d; f[6 - p] += (int16_t)d; f[3] -= (int16_t)(2 * d); }   // WIENER_WIN 7, WIENER_HALFWIN 3
 // moves to the next probe: true = one is outstanding (its taps are in w.v / w.h), false = the walk is over
 __device__ inline bool wn_issue(WnWalkState& w, int off) {
-    const int tmin[3] = {-5, -23, -17}, tmax[3] = {10, 8, 46};   // WIENER_FILT_TAP{0,1,2}_{MINV,MAXV} (Common/Codec/EbRestoration.h:130-150)
+    // WIENER_FILT_TAP{0,1,2}_{MINV,MAXV} (Common/Codec/EbRestoration.h:130-150): {-5, -23, -17} .. {10, 8, 46}
+    auto tmin_of = [](int p) { return p == 0 ? -5 : (p == 1 ? -23 : -17); };
+    auto tmax_of = [](int p) { return p == 0 ? 10 : (p == 1 ? 8 : 46); };
     for (;;) {
         if (w.s < 1) { w.state = 0; return false; }
         if (w.p >= 3) {           // this filter's taps are done: vertical after horizontal, then the next step size
@@ -765,10 +767,10 @@ __device__ inline bool wn_issue(WnWalkState& w, int off) {
         }
         int16_t* f = w.ph ? w.v : w.h;
         if (!w.up) {
-            if (f[w.p] - w.s >= tmin[w.p]) { wn_apply(f, w.p, -w.s); w.state = 2; return true; }
+            if (f[w.p] - w.s >= tmin_of(w.p)) { wn_apply(f, w.p, -w.s); w.state = 2; return true; }
             if (w.skip) w.p = 3; else w.up = 1;    // "if (skip) break" (:1126)
         } else {
-            if (f[w.p] + w.s <= tmax[w.p]) { wn_apply(f, w.p, w.s); w.state = 2; return true; }
+            if (f[w.p] + w.s <= tmax_of(w.p)) { wn_apply(f, w.p, w.s); w.state = 2; return true; }
             w.p++; w.up = 0; w.skip = 0;
         }
     }
@@ -812,7 +814,8 @@ wiener_walk_kernel(const WnPic a) {
     const int rx0 = ux * unit_size, rx1 = ux == units_x - 1 ? pw : (ux + 1) * unit_size;
     const int ry0 = max(uy * unit_size - voff, 0), ry1 = uy == units_y - 1 ? ph : (uy + 1) * unit_size - voff;
     const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, ty_first = (ry0 + voff) / S_TH, tiles_y = (ry1 + voff + S_TH - 1) / S_TH - ty_first, n_tiles = tiles_x * tiles_y;
-    WnWalkState w;
+    __shared__ WnWalkState w_lds;   // thread 0's walk state: its tap arrays are indexed at run time, which as a private object means scratch memory (a memory round trip per access)
+    WnWalkState& w = w_lds;
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) { w.v[k] = unit_wiener[16 * unit + k]; w.h[k] = unit_wiener[16 * unit + 8 + k]; }
@@ -854,8 +857,10 @@ wiener_walk_kernel(const WnPic a) {
             int sv[8];   // the source samples first: their loads are in flight while the column is filtered
 #pragma unroll
             for (int r = 0; r < 8; r++) {
+                // (branch-free: a load under a condition becomes a branch with its own s_waitcnt vmcnt(0) — eight serialised L2 round trips per tile)
                 const int x = x0 + j, y = y0 + i0 + r;
-                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : (int)src[(size_t)y * src_stride + x];
+                const int s = (int)src[(size_t)min(max(y, ry0), ry1 - 1) * src_stride + min(x, rx1 - 1)];
+                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : s;
             }
             int v8[8];
             wiener_vcol8<BD>(tmp[team], i0, j, fy, v8);
@@ -894,6 +899,9 @@ wiener_walk_kernel(const WnPic a) {
     }
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding GLOBAL load (s_waitcnt vmcnt(0) before s_barrier), which puts the full
+// L2 latency of loads that were issued early on purpose — the source samples of a tile's error — in front of every barrier of the round.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // ---- the same walk with the unit's input RESIDENT in LDS (8-bit planes; round 5).  A probe only changes the taps: the unit's samples — the CDEF output with the stripes'
 // context rows from the deblocked picture — are the same for all ~30 probes of a walk, yet the form above stages every 64 x 32 tile from memory for every probe (eleven
 // 1-byte loads per thread and tile, each behind ~25 instructions of index / clamp / stripe arithmetic: about half of a probe's instructions and all of its memory
@@ -938,7 +946,8 @@ wiener_walk8r_kernel(const WnPic a) {
         for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(xx0 + k, lo), hi)] << (8 * k);
         ((uint32_t*)bands)[i] = v;
     }
-    WnWalkState w;
+    __shared__ WnWalkState w_lds;   // thread 0's walk state: its tap arrays are indexed at run time, which as a private object means scratch memory (a memory round trip per access)
+    WnWalkState& w = w_lds;
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) { w.v[k] = unit_wiener[16 * unit + k]; w.h[k] = unit_wiener[16 * unit + 8 + k]; }
@@ -966,8 +975,10 @@ wiener_walk8r_kernel(const WnPic a) {
             int sv[8];   // the source samples of the error first: their loads are in flight during the horizontal pass
 #pragma unroll
             for (int r = 0; r < 8; r++) {
+                // (branch-free: a load under a condition becomes a branch with its own s_waitcnt vmcnt(0) — eight serialised L2 round trips per tile)
                 const int x = x0 + j, y = y0 + i0 + r;
-                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : (int)src[(size_t)y * src_stride + x];
+                const int s = (int)src[(size_t)min(max(y, ry0), ry1 - 1) * src_stride + min(x, rx1 - 1)];
+                sv[r] = (x >= rx1 || y >= ry1 || y < ry0) ? -1 : s;
             }
             // horizontal pass (round 3): four outputs from twelve bytes (three aligned dwords; the ten inputs are bytes 1..10)
             for (int g = tt; g < S_IH * (S_TW / 4); g += 256) {
@@ -987,7 +998,7 @@ wiener_walk8r_kernel(const WnPic a) {
                 uint32_t* out = (uint32_t*)(tmp[team] + r * S_TW + c);
                 out[0] = o[0] | (o[1] << 16); out[1] = o[2] | (o[3] << 16);
             }
-            __syncthreads();
+            lds_barrier();
             uint32_t e = 0;
             int v8[8];
             wiener_vcol8<8>(tmp[team], i0, j, fy, v8);
@@ -998,13 +1009,13 @@ wiener_walk8r_kernel(const WnPic a) {
                 e += (uint32_t)(d * d);
             }
             sse += e;
-            __syncthreads();   // tmp is rewritten by the team's next tile
+            lds_barrier();   // tmp is rewritten by the team's next tile
         }
-        if (n_tiles % 4 && team >= n_tiles % 4) { __syncthreads(); __syncthreads(); }   // teams that ran one tile fewer make up their two barriers
+        if (n_tiles % 4 && team >= n_tiles % 4) { lds_barrier(); lds_barrier(); }   // teams that ran one tile fewer make up their two barriers
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) sse += ((unsigned long long)(uint32_t)__shfl_xor((int)(sse >> 32), m, 64) << 32) | (uint32_t)__shfl_xor((int)sse, m, 64);
         if ((tid & 63) == 0) part[tid >> 6] = sse;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             unsigned long long tot = 0;
 #pragma unroll
@@ -1014,7 +1025,158 @@ wiener_walk8r_kernel(const WnPic a) {
 #pragma unroll
             for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
         }
-        __syncthreads();
+        lds_barrier();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { unit_wiener[16 * unit + k] = w.v[k]; unit_wiener[16 * unit + 8 + k] = w.h[k]; }
+        err_out[unit] = w.err;
+        if (probes_out) probes_out[unit] = n_probes;
+    }
+}
+
+// ---- round 5, second form: a WAVE per tile, no intermediate in LDS, no barrier inside a probe.  Measured on the form above (profiles/r05/wiener_walk_phases.txt): of the
+// 34.5 us of a probe of a 48-tile unit the horizontal pass is 11, the vertical pass 11.6, the source loads 4 and the rest (barriers, the reduction, the walk's state
+// machine) 8 — each pass ~4-5x its issue time, because a team's three phases per tile are separated by workgroup barriers and every phase starts with an LDS round trip.
+// Here a lane owns four adjacent columns x eight rows of a 64 x 32 tile: it filters the fourteen rows it needs horizontally straight from the resident bytes (1.75x
+// the horizontal work: the six context rows are shared with the lane above / below), keeps the results as vertically packed 16-bit pairs in registers, and the
+// vertical pass is four v_dot2_i32_i16 per output on those pairs (even rows: taps (f0 f1)(f2 f3)(f4 f5)(f6 0); odd rows: (0 f0)(f1 f2)(f3 f4)(f5 f6) on the same aligned
+// pairs; the centre tap carries the "+ 128 x sample" of the reference's rounding form).  The source is read as one dword per row.  Sixteen waves walk the unit's tiles
+// independently; the only barriers left are the two around the walk's decision.  LDS reads: lanes of a row group read consecutive dwords, the four row groups are
+// 8 rows = 8 x (64 k + 8) bytes = 16 banks apart: conflict-free.
+__global__ void __launch_bounds__(1024)
+wiener_walk8w_kernel(const WnPic a) {
+    const int z = blockIdx.y;
+    const uint8_t* __restrict__ dgd = (const uint8_t*)a.p[z].dgd; const uint8_t* __restrict__ dbl = (const uint8_t*)a.p[z].dbl; const uint8_t* __restrict__ src = (const uint8_t*)a.p[z].src;
+    int16_t* __restrict__ unit_wiener = a.p[z].unit_wiener; const uint8_t* __restrict__ active = a.p[z].active;
+    long long* __restrict__ err_out = a.p[z].err; uint32_t* __restrict__ probes_out = a.p[z].probes;
+    const int stride = a.p[z].stride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff,
+              stripe_h = a.p[z].stripe_h, dbl_stride = a.p[z].dbl_stride, src_stride = a.p[z].src_stride, win = a.p[z].win;
+    if ((int)blockIdx.x >= units_x * units_y) return;
+    __shared__ __attribute__((aligned(16))) uint8_t bands[kWnBandBytes + 16];     // [tile row][S_IH][pitch]; byte column cb of a band row = sample x = rx0 - 4 + cb
+    __shared__ int taps[16];
+    __shared__ unsigned long long part[16];
+    __shared__ int go;
+    const int unit = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (!active[unit]) return;
+    const int ux = unit % units_x, uy = unit / units_x, off = (7 - win) >> 1;
+    const int rx0 = ux * unit_size, rx1 = ux == units_x - 1 ? pw : (ux + 1) * unit_size;
+    const int ry0 = max(uy * unit_size - voff, 0), ry1 = uy == units_y - 1 ? ph : (uy + 1) * unit_size - voff;
+    const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, ty_first = (ry0 + voff) / S_TH, tiles_y = (ry1 + voff + S_TH - 1) / S_TH - ty_first, n_tiles = tiles_x * tiles_y;
+    const int pitch = tiles_x * S_TW + 8, pitch_dw = pitch >> 2;
+    for (int i = tid; i < tiles_y * S_IH * pitch_dw; i += 1024) {   // stage the unit once (as in the form above)
+        const int b = i / (S_IH * pitch_dw), rem = i - b * (S_IH * pitch_dw), r = rem / pitch_dw, cd = rem - r * pitch_dw;
+        const int y0 = (ty_first + b) * S_TH - voff, yy = y0 - 3 + r, xx0 = rx0 - 4 + 4 * cd;
+        const StripeCtx<uint8_t> sc = lr_stripe_of<uint8_t>(dbl, dbl_stride, y0, voff, stripe_h, ph);
+        const uint8_t* row; int lo, hi;
+        if (sc.above && yy < sc.sy0) { row = dbl + (ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * dbl_stride; lo = 0; hi = pw - 1; }
+        else if (sc.below && yy >= sc.sy1) { row = dbl + (ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * dbl_stride; lo = 0; hi = pw - 1; }
+        else { row = dgd + (ptrdiff_t)min(max(yy, -3), ph + 2) * stride; lo = -3; hi = pw + 2; }
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(xx0 + k, lo), hi)] << (8 * k);
+        ((uint32_t*)bands)[i] = v;
+    }
+    __shared__ WnWalkState w_lds;   // thread 0's walk state: its tap arrays are indexed at run time, which as a private object means scratch memory (a memory round trip per access)
+    WnWalkState& w = w_lds;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { w.v[k] = unit_wiener[16 * unit + k]; w.h[k] = unit_wiener[16 * unit + 8 + k]; }
+        w.state = 1; w.err = 0; w.s = 0; w.ph = 0; w.p = 0; w.up = 0; w.skip = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        go = 1;
+    }
+    uint32_t n_probes = 0;
+    const int c4 = (lane & 15) << 2, rg = lane >> 4;   // the lane's four columns and its eight rows 8 rg .. 8 rg + 7 of a tile
+    const bool src_dwords = ((uintptr_t)src & 3) == 0 && (src_stride & 3) == 0;
+    __syncthreads();
+    while (go) {
+        // (the taps are workgroup-uniform: v_readfirstlane puts everything derived from them into scalar registers)
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        const int f0 = uni(taps[8]), f1 = uni(taps[9]), f2 = uni(taps[10]), f3 = uni(taps[11]), f4 = uni(taps[12]), f5 = uni(taps[13]), f6 = uni(taps[14]);
+        // The reference's "+ (centre sample << 7)" rides in the dot products: 128 = 1 + 127, the 1 on the centre tap (f3 + 1 is in [-127, 91]) and the 127 in the second
+        // quadruple's free slot, whose fourth byte is made the centre sample by the byte permute that builds it.  Samples are biased by -128: + 128 x (sum of all eight taps).
+        const int TA = (f0 & 0xff) | (f1 & 0xff) << 8 | (f2 & 0xff) << 16 | ((f3 + 1) & 0xff) << 24, TB = (f4 & 0xff) | (f5 & 0xff) << 8 | (f6 & 0xff) << 16 | 127 << 24;
+        const int hbase = (1 << (8 + 6)) + 4 + 128 * (f0 + f1 + f2 + f3 + f4 + f5 + f6 + 128);
+        // vertical taps as 16-bit pairs (low half = the upper row of a pair); g3 = the centre tap + 128 (the reference adds sample << 7)
+        const int g0 = uni(taps[0]), g1 = uni(taps[1]), g2 = uni(taps[2]), g3 = uni(taps[3]) + 128, g4 = uni(taps[4]), g5 = uni(taps[5]), g6 = uni(taps[6]);
+        auto pk = [](int lo, int hi) { return (uint32_t)(lo & 0xffff) | (uint32_t)hi << 16; };
+        const uint32_t E0 = pk(g0, g1), E1 = pk(g2, g3), E2 = pk(g4, g5), E3 = pk(g6, 0), O0 = pk(0, g0), O1 = pk(g1, g2), O2 = pk(g3, g4), O3 = pk(g5, g6);
+        uint32_t sse = 0;   // a lane's share of a probe: at most a few tiles x 32 samples x 255^2; a wave's total stays below 2^32 as well (64 lanes x 6 tiles x 32 x 65 025)
+        for (int t = wave; t < n_tiles; t += 16) {
+            const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+            const int x0 = rx0 + txi * S_TW + c4, y0 = (ty_first + tyi) * S_TH - voff + 8 * rg;   // the lane's first sample
+            // the source first: its loads are in flight during both passes (branch-free, clamped addresses)
+            uint32_t sv[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint8_t* sp = src + (size_t)min(max(y0 + r, ry0), ry1 - 1) * src_stride;
+                if (src_dwords && x0 + 3 < pw) sv[r] = *(const uint32_t*)(sp + x0);
+                else {
+                    sv[r] = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) sv[r] |= (uint32_t)sp[min(x0 + c, pw - 1)] << (8 * c);
+                }
+            }
+            const uint8_t* band = bands + (size_t)tyi * S_IH * pitch + txi * S_TW + (8 * rg) * pitch + c4;
+            uint32_t P[4][7];   // [column][pair of rows]: the horizontally filtered rows 2 k (low half) and 2 k + 1 of the lane's fourteen
+#pragma unroll
+            for (int rr = 0; rr < 14; rr++) {
+                const uint32_t* wd = (const uint32_t*)(band + rr * pitch);
+                const uint32_t e0 = wd[0] ^ 0x80808080u, e1 = wd[1] ^ 0x80808080u, e2 = wd[2] ^ 0x80808080u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // window bytes 0 .. 11 = e0 e1 e2; output q: taps on bytes q + 1 .. q + 7, centre = byte q + 4.  A = bytes q + 1 .. q + 4; B = bytes q + 5, q + 6, q + 7, q + 4
+                    const uint32_t A = q == 3 ? e1 : __builtin_amdgcn_alignbyte(e1, e0, (uint32_t)(q + 1));
+                    const uint32_t B = __builtin_amdgcn_perm(e2, e1, (uint32_t)((q + 1) | (q + 2) << 8 | (q + 3) << 16 | q << 24));
+                    int sum = __builtin_amdgcn_sdot4((int)A, TA, hbase, false);
+                    sum = __builtin_amdgcn_sdot4((int)B, TB, sum, false);
+                    const uint32_t o = (uint32_t)min(max(sum >> 3, 0), (1 << (8 + 5)) - 1);   // WIENER_CLAMP_LIMIT(3, 8)
+                    if (rr & 1) P[q][rr >> 1] |= o << 16; else P[q][rr >> 1] = o;
+                }
+                if (rr & 1) __builtin_amdgcn_sched_barrier(0);   // two rows' reads in flight at a time: hoisting all 42 dwords to the top costs the registers of the pairs
+            }
+            uint32_t e = 0;
+            const bool inside = y0 >= ry0 && y0 + 8 <= ry1 && x0 + 4 <= rx1;   // all 32 samples of the lane count (every lane of an interior tile)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int  y = y0 + r;
+                const bool row_ok = inside || (y >= ry0 && y < ry1);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    typedef short v2s __attribute__((ext_vector_type(2)));
+                    auto dot = [](uint32_t x, uint32_t y2, int acc) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, x), __builtin_bit_cast(v2s, y2), acc, false); };
+                    const int k = r >> 1;
+                    int sum = (1 << 10) - (1 << (8 + 10));
+                    if (r & 1) { sum = dot(P[c][k], O0, sum); sum = dot(P[c][k + 1], O1, sum); sum = dot(P[c][k + 2], O2, sum); sum = dot(P[c][k + 3], O3, sum); }
+                    else       { sum = dot(P[c][k], E0, sum); sum = dot(P[c][k + 1], E1, sum); sum = dot(P[c][k + 2], E2, sum); sum = dot(P[c][k + 3], E3, sum); }
+                    const int v = min(max(sum >> 11, 0), 255);
+                    const int d = v - (int)((sv[r] >> (8 * c)) & 0xffu);
+                    if (inside || (row_ok && x0 + c < rx1)) e += (uint32_t)(d * d);
+                }
+            }
+            sse += e;
+        }
+        // 64-lane sums, then the sixteen waves' partials
+        {   // DPP inside the 16-lane rows, the four row totals through scalar registers
+            int v = (int)sse;
+            v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+            v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(v, 0) + (uint32_t)__builtin_amdgcn_readlane(v, 16) + (uint32_t)__builtin_amdgcn_readlane(v, 32) + (uint32_t)__builtin_amdgcn_readlane(v, 48);
+            if (lane == 0) part[wave] = tot;
+        }
+        lds_barrier();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) tot += part[k];
+            n_probes++;
+            go = wn_result(w, (long long)tot, off) ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { taps[k] = w.v[k]; taps[8 + k] = w.h[k]; }
+        }
+        lds_barrier();
     }
     if (tid == 0) {
 #pragma unroll
@@ -1040,9 +1202,9 @@ extern "C" int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, i
     if (n <= 0) return 0;
     const dim3 grid(n, n_planes);
     // the resident-input form (8-bit): every unit's bands must fit its LDS window; SVT_HIP_WIENER_WALK=tiles keeps the form that stages tile by tile (A/B runs)
-    static int form = -1;
-    if (form < 0) { const char* e = getenv("SVT_HIP_WIENER_WALK"); form = e && !strcmp(e, "tiles") ? 0 : 1; }
-    bool fits = pix_bytes == 1 && form == 1;
+    static int form = -1;   // 0 = "tiles" (round 4), 1 = "teams" (resident unit, a 256-thread team per tile), 2 = a wave per tile (default)
+    if (form < 0) { const char* e = getenv("SVT_HIP_WIENER_WALK"); form = e && !strcmp(e, "tiles") ? 0 : (e && !strcmp(e, "teams") ? 1 : 2); }
+    bool fits = pix_bytes == 1 && form >= 1;
     for (int i = 0; i < n_planes && fits; i++) {
         const WnPlane& q = a.p[i];
         for (int uy = 0; uy < q.units_y && fits; uy++)
@@ -1053,7 +1215,8 @@ extern "C" int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, i
                 fits = (size_t)tiles_y * S_IH * (tiles_x * S_TW + 8) <= (size_t)kWnBandBytes;
             }
     }
-    if (fits) hipLaunchKernelGGL(wiener_walk8r_kernel, grid, dim3(1024), 0, st, a);
+    if (fits && form == 2) hipLaunchKernelGGL(wiener_walk8w_kernel, grid, dim3(1024), 0, st, a);
+    else if (fits) hipLaunchKernelGGL(wiener_walk8r_kernel, grid, dim3(1024), 0, st, a);
     else if (pix_bytes == 1) hipLaunchKernelGGL((wiener_walk_kernel<uint8_t, 8>), grid, dim3(1024), 0, st, a);
     else if (bd == 8) hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 8>), grid, dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((wiener_walk_kernel<uint16_t, 10>), grid, dim3(1024), 0, st, a);

@@ -148,7 +148,7 @@ int main(void) {
     svt_hip_resident_note(a, N);
     CHECK(svt_hip_resident_acquire(HIP, a, N) && g_pins == 2);   /* uploaded again, page-locked once */
     svt_hip_resident_release(a); svt_hip_resident_release(b);
-    svt_hip_resident_unpin_all(HIP);
+    svt_hip_resident_unpin_all(HIP, 0);
     CHECK(g_pins == 0);
     svt_hip_resident_release_all(HIP);
     svt_hip_resident_configure_blocks(NULL, 0);

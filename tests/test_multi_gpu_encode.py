@@ -60,6 +60,8 @@ def test_two_encoder_instances_in_one_process(tmp_path):
     assert md5(oa) == ra["ivf"] and md5(ob) == rb["ivf"]
     log = r.stdout + r.stderr
     assert log.count("svt_hip MOCK") >= 1 and "fallback=0" in log and not [l for l in log.splitlines() if l.startswith("svt_hip_hook ") and not l.endswith("fallback=0")]
+    # the first instance to end releases every page-locked range (the tables are shared and the instance frees its pictures); the other re-registers its own
+    assert "svt_hip_pins released_while_other_instances_ran=1" in log, [l for l in log.splitlines() if l.startswith("svt_hip_")]
 
 
 def test_bench_under_a_launcher_checks_world_size():
