@@ -52,7 +52,8 @@ __device__ __forceinline__ void stage_tile(uint16_t* tile, int tstride, const PI
         [&](int i) {
             const int r = i / cols, c = i - r * cols;
             const int x = x0 - kHB + c, y = y0 - kVB + r;
-            return (x >= 0 && y >= 0 && x < pw && y < ph) ? (uint16_t)plane[(size_t)y * stride + x] : (uint16_t)kVeryLarge;
+            const uint16_t v = (uint16_t)plane[(size_t)min(max(y, 0), ph - 1) * stride + min(max(x, 0), pw - 1)];   // (unconditional: see batched_stage)
+            return (x >= 0 && y >= 0 && x < pw && y < ph) ? v : (uint16_t)kVeryLarge;
         },
         [&](int i, uint16_t v) { const int r = i / cols, c = i - r * cols; tile[r * tstride + c] = v; });
 }

@@ -10,7 +10,7 @@ __device__ __forceinline__ void batched_stage(int total, int tid, int nthreads, 
     for (int i0 = tid; i0 < total; i0 += nthreads * U) {
         T v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i = i0 + u * nthreads; if (i < total) v[u] = load(i); }
+        for (int u = 0; u < U; u++) v[u] = load(min(i0 + u * nthreads, total - 1));   // unconditional (a clamped index): a load under `if (i < total)` becomes a branch with its own s_waitcnt vmcnt(0) and the U loads run one after the other
 #pragma unroll
         for (int u = 0; u < U; u++) { const int i = i0 + u * nthreads; if (i < total) store(i, v[u]); }
     }

@@ -69,12 +69,11 @@ __device__ __forceinline__ void stage_and_boxsum(TileLds& L, const PIX* __restri
         [&](int i) {
             const int r = i / IW, c = i - r * IW;
             const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-            if (sc.above && yy < sc.sy0)
-                return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            if (sc.below && yy >= sc.sy1)
-                return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-            const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
-            return (uint16_t)plane[(ptrdiff_t)y * stride + x];
+            const bool up = sc.above && yy < sc.sy0, dn = sc.below && yy >= sc.sy1, ctx = up || dn;   // one unconditional load from a selected address
+            const int  yd = up ? (yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) : min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1);
+            const int  x = ctx ? min(max(xx, 0), pw - 1) : min(max(xx, -3), pw + 2), y = ctx ? yd : min(max(yy, -3), ph + 2);   // the picture: never leave the 3-px extension
+            const PIX* base = ctx ? sc.dbl : plane;
+            return (uint16_t)base[(ptrdiff_t)y * (ctx ? sc.dbl_stride : stride) + x];
         },
         [&](int i, uint16_t v) { L.in[i] = v; });
     __syncthreads();
@@ -618,12 +617,12 @@ template <typename PIX>
 __device__ __forceinline__ uint16_t lr_tile_sample(const PIX* __restrict__ dgd, int stride, int pw, int ph, int x0, int y0, const StripeCtx<PIX>& sc, int i) {
     const int r = i / S_IW, c = i - r * S_IW;
     const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-    if (sc.above && yy < sc.sy0)
-        return (uint16_t)sc.dbl[(ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-    if (sc.below && yy >= sc.sy1)
-        return (uint16_t)sc.dbl[(ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * sc.dbl_stride + min(max(xx, 0), pw - 1)];
-    const int x = min(max(xx, -3), pw + 2), y = min(max(yy, -3), ph + 2);   // never leave the 3-px extension
-    return (uint16_t)dgd[(ptrdiff_t)y * stride + x];
+    // one unconditional load from a selected address (three loads under three conditions are three branches, each waiting for its own load)
+    const bool up = sc.above && yy < sc.sy0, dn = sc.below && yy >= sc.sy1, ctx = up || dn;
+    const int  yd = up ? (yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) : min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1);
+    const int  x = ctx ? min(max(xx, 0), pw - 1) : min(max(xx, -3), pw + 2), y = ctx ? yd : min(max(yy, -3), ph + 2);   // the picture: never leave the 3-px extension
+    const PIX* base = ctx ? sc.dbl : dgd;
+    return (uint16_t)base[(ptrdiff_t)y * (ctx ? sc.dbl_stride : stride) + x];
 }
 template <typename PIX>
 __device__ __forceinline__ void lr_stage_tile(uint16_t* __restrict__ in, const PIX* __restrict__ dgd, int stride, int pw, int ph, int x0, int y0, const StripeCtx<PIX>& sc, int tid, int nt) {
