@@ -728,21 +728,25 @@ sgr_walk_resident_kernel(const WalkPic a) {
             return;
         }
     }
-    int4 pa[kResJ], pb[kResJ];
+    // The resident part of the unit: ALL of its loads are issued before the first one is consumed.  (Round 2 .. 4 loaded chunk j under `if (k < nchunk)` and wrote its
+    // dat - src to LDS right away: a load under a condition is a branch, the LDS write behind it waits for it, and the kResJ chunks' loads ran one after the other —
+    // kResJ memory round trips, the "40 k-cycle load of a unit" of DESIGN 4.5.)  Chunks past the end load the last chunk's address and are zeroed afterwards.
+    int4 pa[kResJ], pb[kResJ], ps[kResJ];
+#pragma unroll
+    for (int j = 0; j < kResJ; j++) {
+        const int k = min(t + j * kResD, max(nchunk - 1, 0));
+        const int row = k / cw, cx = k - row * cw;
+        const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+        pa[j] = SGR_LD4(PP + off); pb[j] = SGR_LD4(PP + off + 4);
+        ps[j] = *(const int4*)(sd + off);
+    }
 #pragma unroll
     for (int j = 0; j < kResJ; j++) {
         const int k = t + j * kResD;
-        int4 s = make_int4(0, 0, 0, 0);
-        pa[j] = pb[j] = s;
-        if (k < nchunk) {
-            const int row = k / cw, cx = k - row * cw;
-            const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
-            pa[j] = SGR_LD4(PP + off); pb[j] = SGR_LD4(PP + off + 4);
-            s = *(const int4*)(sd + off);
-            const int n = w - 8 * cx;
-            if (n < 8) mask_chunk(pa[j], pb[j], s, n);
-        }
-        R.sd[j * kResD + t] = s;   // read back by this thread only
+        const int kc = min(k, max(nchunk - 1, 0)), row = kc / cw, cx = kc - row * cw;
+        const int n = k < nchunk ? w - 8 * cx : 0;
+        if (n < 8) mask_chunk(pa[j], pb[j], ps[j], n);
+        R.sd[j * kResD + t] = ps[j];   // read back by this thread only
     }
     int rnd, sel;
     asm volatile("s_mov_b32 %0, 0x8000\n\ts_mov_b32 %1, 0x07060302" : "=s"(rnd), "=s"(sel));   // opaque: kept in scalar registers
