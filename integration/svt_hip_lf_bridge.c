@@ -1225,6 +1225,8 @@ static EbErrorType lf_final_attempt(SvtHipCtx *hip, LfState *s, int attempt) {
  * while the host picture is still the coded (unfiltered) one, i.e. for a deferred picture of which nothing has come back. */
 void svt_av1_cdef_frame(struct EncDecContext *context_ptr, SequenceControlSet *scs_ptr, PictureControlSet *pCs);
 void av1_cdef_frame16bit(struct EncDecContext *context_ptr, SequenceControlSet *scs_ptr, PictureControlSet *pCs);
+/* (no header declares it: EbRestProcess.c:51 and EbEncDecProcess.c:42 carry the same local prototype) */
+void svt_av1_loop_restoration_filter_frame(Yv12BufferConfig *frame, Av1Common *cm, int32_t optimized_lr);
 static void lf_host_chain(LfState *s) {
     PictureControlSet *pcs = s->pcs;
     SequenceControlSet *scs = (SequenceControlSet *)pcs->scs_wrapper_ptr->object_ptr;
