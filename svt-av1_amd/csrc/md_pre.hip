@@ -15,6 +15,7 @@
 // HBM-bound in principle (algorithmic bytes per (SB, reference): 4096 source + ~4 x 4096 reference samples + 85 x 8 table bytes), launch-bound in practice:
 // a 1080p picture with 7 references is 3 570 workgroups of ~30 iterations.
 #include "svt_hip_internal.h"
+#include "lds_stage.h"
 #include "interp_kernels.h"
 
 namespace {
@@ -146,10 +147,9 @@ md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
     // ---- stage the window (rows as dwords) and the source (transposed)
     const int   wdw = WIN >> 2;
     const float r_wdw = 1.0f / (float)wdw;
-    for (int i = tid; i < WIN * wdw; i += NT) {
-        const int rr = (int)(((float)i + 0.5f) * r_wdw), cd = i - rr * wdw;
-        ((uint32_t*)win)[rr * wdw + cd] = load4_any(ref.d_plane + (ptrdiff_t)(wy + rr) * ref.stride + wx + 4 * cd);
-    }
+    batched_stage<4, uint32_t>(WIN * wdw, tid, NT,   // four window dwords in flight per lane
+        [&](int i) { const int rr = (int)(((float)i + 0.5f) * r_wdw), cd = i - rr * wdw; return load4_any(ref.d_plane + (ptrdiff_t)(wy + rr) * ref.stride + wx + 4 * cd); },
+        [&](int i, uint32_t v) { ((uint32_t*)win)[i] = v; });
     __syncthreads();   // (also orders the zeroing of the statistics before their first update)
     {
         uint32_t ss = 0, ss2 = 0;

@@ -1063,19 +1063,22 @@ wiener_walk8w_kernel(const WnPic a) {
     const int ry0 = max(uy * unit_size - voff, 0), ry1 = uy == units_y - 1 ? ph : (uy + 1) * unit_size - voff;
     const int tiles_x = (rx1 - rx0 + S_TW - 1) / S_TW, ty_first = (ry0 + voff) / S_TH, tiles_y = (ry1 + voff + S_TH - 1) / S_TH - ty_first, n_tiles = tiles_x * tiles_y;
     const int pitch = tiles_x * S_TW + 8, pitch_dw = pitch >> 2;
-    for (int i = tid; i < tiles_y * S_IH * pitch_dw; i += 1024) {   // stage the unit once (as in the form above)
-        const int b = i / (S_IH * pitch_dw), rem = i - b * (S_IH * pitch_dw), r = rem / pitch_dw, cd = rem - r * pitch_dw;
-        const int y0 = (ty_first + b) * S_TH - voff, yy = y0 - 3 + r, xx0 = rx0 - 4 + 4 * cd;
-        const StripeCtx<uint8_t> sc = lr_stripe_of<uint8_t>(dbl, dbl_stride, y0, voff, stripe_h, ph);
-        const uint8_t* row; int lo, hi;
-        if (sc.above && yy < sc.sy0) { row = dbl + (ptrdiff_t)(yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) * dbl_stride; lo = 0; hi = pw - 1; }
-        else if (sc.below && yy >= sc.sy1) { row = dbl + (ptrdiff_t)min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1) * dbl_stride; lo = 0; hi = pw - 1; }
-        else { row = dgd + (ptrdiff_t)min(max(yy, -3), ph + 2) * stride; lo = -3; hi = pw + 2; }
-        uint32_t v = 0;
+    // stage the unit once (as in the form above), four dwords = sixteen byte loads in flight per thread (one dword per iteration is ~30 dependent memory round trips)
+    batched_stage<4, uint32_t>(tiles_y * S_IH * pitch_dw, tid, 1024,
+        [&](int i) {
+            const int b = i / (S_IH * pitch_dw), rem = i - b * (S_IH * pitch_dw), r = rem / pitch_dw, cd = rem - r * pitch_dw;
+            const int y0 = (ty_first + b) * S_TH - voff, yy = y0 - 3 + r, xx0 = rx0 - 4 + 4 * cd;
+            const StripeCtx<uint8_t> sc = lr_stripe_of<uint8_t>(dbl, dbl_stride, y0, voff, stripe_h, ph);
+            const bool up = sc.above && yy < sc.sy0, dn = sc.below && yy >= sc.sy1, ctx = up || dn;
+            const int  yd = up ? (yy == sc.sy0 - 1 ? sc.sy0 - 1 : sc.sy0 - 2) : min(yy == sc.sy1 ? sc.sy1 : sc.sy1 + 1, ph - 1);
+            const uint8_t* row = ctx ? dbl + (ptrdiff_t)yd * dbl_stride : dgd + (ptrdiff_t)min(max(yy, -3), ph + 2) * stride;
+            const int lo = ctx ? 0 : -3, hi = ctx ? pw - 1 : pw + 2;
+            uint32_t v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(xx0 + k, lo), hi)] << (8 * k);
-        ((uint32_t*)bands)[i] = v;
-    }
+            for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(xx0 + k, lo), hi)] << (8 * k);
+            return v;
+        },
+        [&](int i, uint32_t v) { ((uint32_t*)bands)[i] = v; });
     __shared__ WnWalkState w_lds;   // thread 0's walk state: its tap arrays are indexed at run time, which as a private object means scratch memory (a memory round trip per access)
     WnWalkState& w = w_lds;
     if (tid == 0) {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "svt_hip_internal.h"
+#include "lds_stage.h"
 #include "interp_kernels.h"
 
 namespace {
@@ -63,11 +64,10 @@ __device__ void predict(WaveLds& L, bool on, const PIX* __restrict__ ref, int re
     const int lane = threadIdx.x & 63, ws = bw + 8;
     constexpr int pix_max = (1 << BD) - 1;
     __syncthreads();   // the previous users of the LDS windows are done
-    if (on)
-        for (int i = lane; i < (bh + 7) * (bw + 7); i += 64) {
-            const int r = i / (bw + 7), c = i - r * (bw + 7);
-            L.src[r * ws + c] = (short)ref[(ptrdiff_t)(pos_y + r - 3) * ref_stride + (pos_x + c - 3)];
-        }
+    if (on)   // eight loads in flight per lane (a plain one-sample-per-iteration loop is ~24 dependent memory round trips for a 32 x 32 block)
+        batched_stage<8, short>((bh + 7) * (bw + 7), lane, 64,
+            [&](int i) { const int r = i / (bw + 7), c = i - r * (bw + 7); return (short)ref[(ptrdiff_t)(pos_y + r - 3) * ref_stride + (pos_x + c - 3)]; },
+            [&](int i, short v) { const int r = i / (bw + 7), c = i - r * (bw + 7); L.src[r * ws + c] = v; });
     __syncthreads();
     int xf[8], yf[8];
 #pragma unroll
@@ -123,8 +123,8 @@ __device__ void search(Lds& L, const TfSubpelArgs& a, int bs, int px, int py, in
     int s[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-        const int i = lane + 64 * u, y = i / bs, x = i - y * bs;
-        s[u] = i < n ? (int)src[(ptrdiff_t)(ly + y) * a.src_stride[0] + lx + x] : 0;
+        const int i = min(lane + 64 * u, n - 1), y = i / bs, x = i - y * bs;   // unconditional loads (a load under a condition is a branch that waits for it)
+        s[u] = (int)src[(ptrdiff_t)(ly + y) * a.src_stride[0] + lx + x];
     }
     short mv_x = (short)((short)(word & 0xffff) << 1), mv_y = (short)((short)(word >> 16) << 1);   // AV1 vectors are 1/8 pel (:1225-1232)
     short bx = mv_x, by = mv_y;
