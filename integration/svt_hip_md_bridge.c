@@ -673,19 +673,23 @@ void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long 
 }
 
 /* PU index of the ME results -> position and size inside a 64x64 superblock, from the reference's own tables (me_idx over the block geometry) */
-static int pre_build_pus(void) {
-    if (g_pre_pu_ok) return g_pre_pu_ok > 0;
+static void pre_build_pus_once(void);
+static pthread_once_t g_pre_pu_once = PTHREAD_ONCE_INIT;
+static int pre_build_pus(void) {   /* several configuration threads arrive here together: the table is built by exactly one of them (ThreadSanitizer, round 5) */
+    pthread_once(&g_pre_pu_once, pre_build_pus_once);
+    return g_pre_pu_ok > 0;
+}
+static void pre_build_pus_once(void) {
     int seen[PRE_PUS] = {0}, n = 0;
     for (uint32_t i = 0; i < BLOCK_MAX_COUNT_SB_64; i++) {
         const BlockGeom *g = get_blk_geom_mds(i);
         if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) continue;
         const uint32_t pu = me_idx[i];
-        if (pu >= PRE_PUS || seen[pu]) { g_pre_pu_ok = -1; return 0; }
+        if (pu >= PRE_PUS || seen[pu]) { g_pre_pu_ok = -1; return; }
         seen[pu] = 1; n++;
         g_pre_pu[pu].x = (uint8_t)g->origin_x; g_pre_pu[pu].y = (uint8_t)g->origin_y; g_pre_pu[pu].w = g_pre_pu[pu].h = (uint8_t)g->bwidth;
     }
     g_pre_pu_ok = n == PRE_PUS ? 1 : -1;
-    return g_pre_pu_ok > 0;
 }
 
 /* the luma plane of `pic` on the device: its resident copy (announced by the writer: *from_table = 1, release it afterwards) or an upload of the whole padded plane */

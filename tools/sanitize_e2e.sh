@@ -23,7 +23,7 @@ import e2e_common as E
 san, out = os.environ["SAN"], os.environ["OUT"]
 app, mock, wd = f"{out}/SvtAv1EncApp_hip_{san}", f"{out}/mock", f"{out}/work"
 os.makedirs(wd, exist_ok=True)
-opt = "all,md_tx,encdec_tx,md_subpel,encdec_sb"
+opt = "all,md_tx,encdec_tx,md_subpel,encdec_sb,md_pre"
 cases = {"cif_8bit_m6": (352, 288, 6, 8, 6, 35, opt, []), "cif_10bit_m6": (352, 288, 4, 10, 6, 30, opt, []), "cif_8bit_m4": (352, 288, 4, 8, 4, 45, "all", []),
          "328x200_8bit_m6": (328, 200, 4, 8, 6, 33, "all", []), "cif_8bit_m2": (352, 288, 3, 8, 2, 40, "all", []), "unit_wiener": (352, 288, 4, 8, 6, 35, E.ALL_PER_UNIT, []),
          "854x480_m4": (854, 480, 3, 8, 4, 40, "all", []), "640x360_10bit_m5": (640, 360, 4, 10, 5, 32, "all", []), "cif_10bit_m8": (352, 288, 5, 10, 8, 36, "all", []),
