@@ -886,6 +886,16 @@ typedef struct { uint8_t x, y, w, h; } SvtHipMdPu;   /* w a multiple of 4, at mo
 typedef struct { const uint8_t *d_plane; int32_t stride, x_min, y_min, x_max, y_max; } SvtHipMdRefPlane;
 int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
                                        const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, uint32_t *d_sad);
+/* The same table for the COMPOUND-AVERAGE candidates mode decision builds from two ME vectors (NEW_NEWMV of the open-loop ME's bi-directional candidates,
+ * Encoder/Codec/EbModeDecision.c:3408-3540 with MD_COMP_AVG: interinter_comp.type COMPOUND_AVERAGE, compound_idx 1).  Both predictions are full-pel copies in the compound
+ * domain (svt_av1_jnt_convolve_2d_copy, Common/Codec/convolve.c) and the second averages: the luma prediction is (a + b + 1) >> 1 sample by sample.
+ *   pairs : n_pairs <= SVT_HIP_MD_MAX_PAIRS pairs of columns (c0, c1) of the vector table: the first / second reference of the candidate; its vectors are d_mv's entries
+ *           of those two columns for the same PU
+ *   d_sad : [n_sb][n_pus][n_pairs] SAD of the PU against the averaged prediction; 0xffffffff = not computed (a missing vector, PU or block outside) */
+#define SVT_HIP_MD_MAX_PAIRS 16
+int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
+                                           const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int n_pairs,
+                                           const uint8_t (*pairs)[2], uint32_t *d_sad);
 /* The probes of mode decision's sub-pel refinement (md_subpel_search, Encoder/Codec/EbProductCodingLoop.c:2063 -> svt_av1_find_best_sub_pixel_tree, mcomp.c:350): every probe
  * is svt_upsampled_pref_error (mcomp.c:102) = svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269) + svt_aom_variance{W}x{W} against the source.  The tree starts at
  * the block's full-pel vector and its half-pel and quarter-pel rounds stay inside the 7 x 7 quarter-pel grid around it, so one launch per picture computes, for every

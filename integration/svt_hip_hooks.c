@@ -311,6 +311,9 @@ void svt_hip_hooks_report(void) {
         long gp, probes, served;
         svt_hip_hook_md_pre_subpel_stats(&gp, &probes, &served);
         fprintf(stderr, "svt_hip_md_pre_subpel grid_pictures=%ld probes=%ld served_from_grid=%ld\n", gp, probes, served);
+        long bp, bs;
+        svt_hip_hook_md_pre_compound_stats(&bp, &bs);
+        fprintf(stderr, "svt_hip_md_pre_compound pair_table_pictures=%ld served_from_pair_table=%ld\n", bp, bs);
         long miss[10];
         svt_hip_hook_md_pre_misses(miss, 10);
         fprintf(stderr, "svt_hip_md_pre_misses compound=%ld motion_mode=%ld hbd=%ld later_pass=%ld shape=%ld no_table_yet=%ld reference=%ld vector=%ld border=%ld mark=%ld device_ms=%.1f\n", miss[0], miss[1],

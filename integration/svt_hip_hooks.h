@@ -218,6 +218,7 @@ void svt_hip_hook_md_pre_subpel_begin(PictureControlSet *pcs, struct ModeDecisio
 void svt_hip_hook_md_pre_subpel_end(void);
 void svt_hip_hook_md_pre_subpel_verify(const MV *mv, unsigned int err, unsigned int sse);   /* the patched svt_upsampled_pref_error, after computing a probe itself (self-check mode) */
 void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served);
+void svt_hip_hook_md_pre_compound_stats(long *pictures, long *served);   /* pictures with a table of compound-average candidates, candidates served from it */
 void svt_hip_hook_md_pre_misses(long *out, int n);   /* inter candidates of fast_loop_core not served, by reason */
 double svt_hip_hook_md_pre_device_ms(void);          /* SVT_HIP_MD_PRE_TIMING=1: device time of the pictures' launches and copies; -1 = not measured */
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms);

@@ -629,6 +629,12 @@ typedef struct {
     uint32_t *mv;                /* [n_sb][85][n_refs]: the vector in the units of the candidates (1/8 sample), x | y << 16; PRE_NONE = no entry */
     uint32_t *sad;               /* [n_sb][85][n_refs], page-locked */
     size_t    cap;               /* entries allocated */
+    int       n_pairs;           /* compound-average candidates: pairs of table columns that occur as bi-directional ME candidates in this picture */
+    uint8_t   pairs[SVT_HIP_MD_MAX_PAIRS][2];
+    int8_t    pair_of[SVT_HIP_MD_MAX_REFS][SVT_HIP_MD_MAX_REFS];   /* (column of the first reference, of the second) -> index into pairs, -1 = none */
+    uint32_t *bisad;             /* [n_sb][85][n_pairs], page-locked */
+    void     *d_bisad;
+    size_t    bicap;             /* entries allocated */
     uint32_t *grid;              /* [n_sb][85][n_refs][49][2] (variance, sse) of the sub-pel refinement's probes around the vector, page-locked; NULL: not made */
     size_t    grid_cap;          /* entries (of 98 words) allocated */
     int       grid_bank, grid_ready;
@@ -646,8 +652,9 @@ static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
 static SvtHipMdPu      g_pre_pu[PRE_PUS];
 static int             g_pre_pu_ok;   /* 0 not built, 1 built, -1 the tables are not what this code expects */
 static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_calls, g_pre_inter, g_pre_hits, g_pre_late, g_pre_declined;
+static long g_pre_bi_hits, g_pre_bi_pictures;   /* compound-average candidates served, pictures with a pair table */
 static long g_pre_grid_pictures, g_pre_probes, g_pre_probe_hits;   /* the sub-pel grid: pictures it was made for, svt_upsampled_pref_error calls of mode decision, served */
-static int  g_pre_grid_on = -1;
+static int  g_pre_grid_on = -1, g_pre_compound_on = -1, g_pre_grid_mb = -1;   /* SVT_HIP_MD_PRE_SUBPEL=0 / SVT_HIP_MD_PRE_COMPOUND=0 leave the table out */
 static __thread struct { const uint32_t *row; int cx, cy; } tls_grid;
 static long long g_pre_ns;
 static long g_pre_mismatch;
@@ -666,6 +673,7 @@ static __thread const void *tls_mark[PRE_MARKS];
 static inline unsigned mark_slot(const void *p) { const uintptr_t a = (uintptr_t)p; return (unsigned)((a >> 6) ^ (a >> 16)) & (PRE_MARKS - 1); }
 
 long svt_hip_hook_md_pre_mismatches(void) { return g_pre_verify > 0 ? g_pre_mismatch : -1; }
+void svt_hip_hook_md_pre_compound_stats(long *pictures, long *served) { *pictures = g_pre_bi_pictures; *served = g_pre_bi_hits; }
 void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served) { *pictures = g_pre_grid_pictures; *probes = g_pre_probes; *served = g_pre_probe_hits; }
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms) {
     *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = g_pre_calls; *inter = g_pre_inter; *hits = g_pre_hits;
@@ -777,7 +785,8 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     int rc = SVT_HIP_OK;
     if (g_pre_grid_on < 0) g_pre_grid_on = !(getenv("SVT_HIP_MD_PRE_SUBPEL") && !atoi(getenv("SVT_HIP_MD_PRE_SUBPEL")));
     const size_t gwords = n * 2 * SVT_HIP_MD_GRID;
-    const int want_grid = g_pre_grid_on && gwords * sizeof(uint32_t) <= ((size_t)256 << 20);   /* pictures whose grid would exceed 256 MB go without */
+    if (g_pre_grid_mb < 0) g_pre_grid_mb = getenv("SVT_HIP_MD_PRE_GRID_MB") ? atoi(getenv("SVT_HIP_MD_PRE_GRID_MB")) : 256;
+    const int want_grid = g_pre_grid_on && gwords * sizeof(uint32_t) <= ((size_t)g_pre_grid_mb << 20);   /* pictures whose grid would exceed the cap (SVT_HIP_MD_PRE_GRID_MB, default 256) go without: the table crosses PCIe */
     if (t->cap < n) {   /* the slot's buffers grow with the largest picture it has seen: no allocation per picture */
         if (t->sad) svt_hip_host_free(hip, t->sad);
         if (t->h_dev_mv) svt_hip_host_free(hip, t->h_dev_mv);
@@ -819,6 +828,33 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
                     t->h_dev_mv[e] = (uint32_t)(uint16_t)(m.x_mv >> 2) | (uint32_t)(uint16_t)(m.y_mv >> 2) << 16;
                 }
         }
+    /* the pairs of references the open-loop ME proposes as bi-directional candidates (MeCandidate.direction == 2): mode decision turns each into a NEW_NEWMV candidate whose
+     * two vectors are the two references' own ME vectors (EbModeDecision.c:3408-3540) */
+    t->n_pairs = 0;
+    memset(t->pair_of, -1, sizeof(t->pair_of));
+    if (rc == SVT_HIP_OK && g_pre_compound_on < 0) g_pre_compound_on = !(getenv("SVT_HIP_MD_PRE_COMPOUND") && !atoi(getenv("SVT_HIP_MD_PRE_COMPOUND")));
+    if (rc == SVT_HIP_OK && g_pre_compound_on > 0 && n_refs > 1)
+        for (int sb = 0; sb < n_sb; sb++) {
+            const MeSbResults *mr = ppcs->pa_me_data->me_results[sb];
+            for (int pu = 0; pu < PRE_PUS; pu++) {
+                const MeCandidate *mc = &mr->me_candidate_array[pu * MAX_PA_ME_CAND];
+                for (int k = 0; k < mr->total_me_candidate_index[pu] && k < MAX_PA_ME_CAND; k++) {
+                    if (mc[k].direction != 2 || mc[k].ref0_list > 1 || mc[k].ref1_list > 1) continue;
+                    const int c0 = t->slot_of[mc[k].ref0_list][mc[k].ref_idx_l0], c1 = t->slot_of[mc[k].ref1_list][mc[k].ref_idx_l1];
+                    if (c0 < 0 || c1 < 0 || t->pair_of[c0][c1] >= 0 || t->n_pairs >= SVT_HIP_MD_MAX_PAIRS) continue;
+                    t->pair_of[c0][c1] = (int8_t)t->n_pairs; t->pairs[t->n_pairs][0] = (uint8_t)c0; t->pairs[t->n_pairs][1] = (uint8_t)c1; t->n_pairs++;
+                }
+            }
+        }
+    const size_t nbi = (size_t)n_sb * PRE_PUS * (size_t)t->n_pairs;
+    if (rc == SVT_HIP_OK && nbi > t->bicap) {
+        if (t->bisad) svt_hip_host_free(hip, t->bisad);
+        svt_hip_free(hip, t->d_bisad);
+        t->bisad = NULL; t->d_bisad = NULL; t->bicap = 0;
+        void *h = NULL;
+        if (svt_hip_host_alloc(hip, &h, nbi * sizeof(uint32_t)) == SVT_HIP_OK && svt_hip_malloc(hip, &t->d_bisad, nbi * sizeof(uint32_t)) == SVT_HIP_OK) { t->bisad = (uint32_t *)h; t->bicap = nbi; }
+        else { if (h) svt_hip_host_free(hip, h); t->n_pairs = 0; }   /* the pair table is an extra: without it compound candidates stay the reference's */
+    }
     void *tmp[SVT_HIP_MD_MAX_REFS + 1] = {0};
     int   from_table[SVT_HIP_MD_MAX_REFS + 1] = {0}, any_tmp = 0;
     const uint8_t *d_src = NULL;
@@ -840,6 +876,12 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     if (rc == SVT_HIP_OK)
         rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
                                                 n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad);
+    if (rc == SVT_HIP_OK && t->n_pairs) {
+        int brc = svt_hip_md_fullpel_avg_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                         n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, t->n_pairs, (const uint8_t(*)[2])t->pairs, (uint32_t *)t->d_bisad);
+        if (brc == SVT_HIP_OK) brc = svt_hip_memcpy_d2h_async(hip, t->bisad, t->d_bisad, nbi * sizeof(uint32_t));
+        if (brc != SVT_HIP_OK) t->n_pairs = 0;
+    }
     /* ... and the sub-pel refinement's probes (md_subpel_search, :2063): (variance, sse) of the 7 x 7 quarter-pel grid around the same vectors, with the interpolation
      * kernels the picture's final pass searches with (md_subpel_me_level, EbEncDecProcess.c:3088-3097: USE_8_TAPS up to M4, USE_4_TAPS above).  SVT_HIP_MD_PRE_SUBPEL=0
      * leaves it out. */
@@ -871,13 +913,14 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
         pre_sweep(hip, 1);
     }
-    if (rc != SVT_HIP_OK) t->grid_ready = 0;
+    if (rc != SVT_HIP_OK) { t->grid_ready = 0; t->n_pairs = 0; }
     svt_hip_hooks_count(SVT_HIP_HOOK_MD_PRE, rc == SVT_HIP_OK);
     if (rc == SVT_HIP_OK) {
         t->n_sb = n_sb; t->n_refs = n_refs;
         __sync_synchronize();
         t->ready = 1;
-        __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1 + t->grid_ready); __sync_fetch_and_add(&g_pre_jobs, (long)n);
+        __sync_fetch_and_add(&g_pre_pictures, 1); __sync_fetch_and_add(&g_pre_launches, 1 + t->grid_ready + (t->n_pairs > 0)); __sync_fetch_and_add(&g_pre_jobs, (long)n);
+        if (t->n_pairs) __sync_fetch_and_add(&g_pre_bi_pictures, 1);
         if (t->grid_ready) __sync_fetch_and_add(&g_pre_grid_pictures, 1);
         if (!g_pre_min_jobs || (long)n < g_pre_min_jobs) g_pre_min_jobs = (long)n;
     }
@@ -955,8 +998,8 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     __sync_fetch_and_add(&g_pre_inter, 1);
     if (ctx->hbd_mode_decision) PRE_MISS(PRE_MISS_HBD);
     if (!ctx->md_staging_skip_chroma_pred || !ctx->md_staging_skip_interpolation_search) PRE_MISS(PRE_MISS_LATER_PASS);
-    if (c->is_compound) PRE_MISS(PRE_MISS_COMPOUND);
     if (c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used) PRE_MISS(PRE_MISS_MOTION);
+    if (c->is_compound && (c->interinter_comp.type != COMPOUND_AVERAGE || c->compound_idx != 1 || c->comp_group_idx != 0)) PRE_MISS(PRE_MISS_COMPOUND);   /* distance-weighted, wedge, difference-weighted */
     const BlockGeom *g = ctx->blk_geom;
     if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) PRE_MISS(PRE_MISS_SHAPE);
     const MdPre *t = pre_table_of(pcs);
@@ -965,7 +1008,31 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) PRE_MISS(PRE_MISS_SHAPE);
     MvReferenceFrame rf[2];
     av1_set_ref_frame(rf, c->ref_frame_type);
-    if (rf[1] != NONE_FRAME) PRE_MISS(PRE_MISS_COMPOUND);
+    if (c->is_compound != (rf[1] > INTRA_FRAME)) PRE_MISS(PRE_MISS_REFERENCE);
+    if (c->is_compound) {   /* both vectors are the references' own ME vectors, the prediction is their rounded average (svt_hip_md_fullpel_avg_sad_picture_dev) */
+        const int l0 = get_list_idx(rf[0]), r0 = get_ref_frame_idx(rf[0]), l1 = get_list_idx(rf[1]), r1 = get_ref_frame_idx(rf[1]);
+        if (l0 < 0 || l0 > 1 || r0 < 0 || r0 > 3 || l1 < 0 || l1 > 1 || r1 < 0 || r1 > 3 || c->prediction_direction[0] != 2) PRE_MISS(PRE_MISS_REFERENCE);
+        const int c0 = t->slot_of[l0][r0], c1 = t->slot_of[l1][r1];
+        if (c0 < 0 || c1 < 0 || !t->n_pairs) PRE_MISS(PRE_MISS_COMPOUND);
+        const int q = t->pair_of[c0][c1];
+        if (q < 0) PRE_MISS(PRE_MISS_COMPOUND);
+        const size_t base = ((size_t)sb * PRE_PUS + pu) * (size_t)t->n_refs, eb = ((size_t)sb * PRE_PUS + pu) * (size_t)t->n_pairs + (size_t)q;
+        const int16_t x0 = c->motion_vector_xl0, y0 = c->motion_vector_yl0, x1 = c->motion_vector_xl1, y1 = c->motion_vector_yl1;
+        if (t->mv[base + c0] != ((uint32_t)(uint16_t)x0 | (uint32_t)(uint16_t)y0 << 16) || t->mv[base + c1] != ((uint32_t)(uint16_t)x1 | (uint32_t)(uint16_t)y1 << 16) ||
+            t->bisad[eb] == 0xffffffffu)
+            PRE_MISS(PRE_MISS_VECTOR);
+        const int bw = g->bwidth, pic_w = (int)pcs->parent_pcs_ptr->av1_cm->mi_cols * 4, pic_h = (int)pcs->parent_pcs_ptr->av1_cm->mi_rows * 4;
+        for (int k = 0; k < 2; k++) {   /* neither vector may be one av1_inter_prediction would clamp */
+            const int bx = (int)ctx->blk_origin_x + ((k ? x1 : x0) >> 3), by = (int)ctx->blk_origin_y + ((k ? y1 : y0) >> 3);
+            if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) PRE_MISS(PRE_MISS_BORDER);
+        }
+        if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);
+        *sad = t->bisad[eb];
+        __sync_fetch_and_add(&g_pre_hits, 1); __sync_fetch_and_add(&g_pre_bi_hits, 1);
+        if (g_pre_verify) return 2;
+        tls_mark[ms] = cb;
+        return 1;
+    }
     const int li = get_list_idx(rf[0]), ri = get_ref_frame_idx(rf[0]);
     if (li < 0 || li > 1 || ri < 0 || ri > 3 || c->prediction_direction[0] != li) PRE_MISS(PRE_MISS_REFERENCE);
     const int col = t->slot_of[li][ri];
@@ -1014,6 +1081,8 @@ void svt_hip_md_bridge_release(SvtHipCtx *hip) {
     for (int i = 0; i < PRE_SLOTS; i++) {   /* the picture tables of hook "md_pre" */
         if (g_pre[i].sad) svt_hip_host_free(hip, g_pre[i].sad);
         if (g_pre[i].grid) svt_hip_host_free(hip, g_pre[i].grid);
+        if (g_pre[i].bisad) svt_hip_host_free(hip, g_pre[i].bisad);
+        svt_hip_free(hip, g_pre[i].d_bisad);
         if (g_pre[i].h_dev_mv) svt_hip_host_free(hip, g_pre[i].h_dev_mv);
         if (g_pre[i].flags) svt_hip_host_free(hip, (void *)g_pre[i].flags);
         svt_hip_free(hip, g_pre[i].d_mv); svt_hip_free(hip, g_pre[i].d_sad); svt_hip_free(hip, g_pre[i].d_grid); svt_hip_free(hip, g_pre[i].d_seq);

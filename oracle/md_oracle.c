@@ -42,6 +42,47 @@ void orc_md_fullpel_sad_picture(const uint8_t *src, int src_stride, int pic_w, i
             }
 }
 
+/* A COMPOUND-AVERAGE candidate of two full-pel vectors (NEW_NEWMV with MD_COMP_AVG, Encoder/Codec/EbModeDecision.c:3408-3540): av1_inter_prediction calls
+ * svt_inter_predictor twice with is_compound conv_params (get_conv_params_no_round: round_0 = 3, round_1 = COMPOUND_ROUND1_BITS = 7, dst = a CONV_BUF_TYPE plane), full-pel
+ * vectors pick convolve[0][0][1] = svt_av1_jnt_convolve_2d_copy (Common/Codec/convolve.c): the first call stores (sample << bits) + round_offset, the second (do_average,
+ * no distance weights for compound_idx = 1) averages with it, removes the offset and rounds by `bits` into the 8-bit prediction.  Then the same SAD as above. */
+uint32_t orc_md_fullpel_avg_candidate(const uint8_t *src, int src_stride, const uint8_t *ref0, int ref0_stride, const uint8_t *ref1, int ref1_stride, int x, int y, int w, int h,
+                                      int mx0, int my0, int mx1, int my1) {
+    const int bd = 8, round_0 = 3, round_1 = 7, bits = 2 * 7 - round_0 - round_1, offset_bits = bd + 2 * 7 - round_0;
+    const int round_offset = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+    static __thread uint16_t tmp[64 * 64];
+    uint8_t pred[64 * 64];
+    const uint8_t *a = ref0 + (ptrdiff_t)(y + my0) * ref0_stride + (x + mx0), *b = ref1 + (ptrdiff_t)(y + my1) * ref1_stride + (x + mx1);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) tmp[i * w + j] = (uint16_t)((a[(ptrdiff_t)i * ref0_stride + j] << bits) + round_offset);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const uint16_t res = (uint16_t)((b[(ptrdiff_t)i * ref1_stride + j] << bits) + round_offset);
+            int32_t t = (tmp[i * w + j] + res) >> 1;
+            t -= round_offset;
+            t = (t + ((1 << bits) >> 1)) >> bits;   /* ROUND_POWER_OF_TWO */
+            pred[i * w + j] = (uint8_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
+        }
+    return orc_nxm_sad(src + (ptrdiff_t)y * src_stride + x, (uint32_t)src_stride, pred, (uint32_t)w, (uint32_t)h, (uint32_t)w);
+}
+/* the table of svt_hip_md_fullpel_avg_sad_picture_dev: [n_sb][n_pus][n_pairs], pairs[i] = {c0, c1} columns of the vector table */
+void orc_md_fullpel_avg_sad_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                    const uint8_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int n_pairs, const uint8_t (*pairs)[2],
+                                    uint32_t *sad) {
+    for (int sb = 0; sb < n_sb; sb++)
+        for (int p = 0; p < n_pus; p++)
+            for (int q = 0; q < n_pairs; q++) {
+                const size_t base = ((size_t)sb * n_pus + p) * n_refs, slot = ((size_t)sb * n_pus + p) * n_pairs + q;
+                const int c0 = pairs[q][0], c1 = pairs[q][1];
+                const int x = (sb % sb_cols) * 64 + pus[p][0], y = (sb / sb_cols) * 64 + pus[p][1], w = pus[p][2], h = pus[p][3];
+                const int mx0 = (int16_t)(mv[base + c0] & 0xffff), my0 = (int16_t)(mv[base + c0] >> 16), mx1 = (int16_t)(mv[base + c1] & 0xffff), my1 = (int16_t)(mv[base + c1] >> 16);
+                int ok = mx0 != -32768 && mx1 != -32768 && x + w <= pic_w && y + h <= pic_h;
+                ok = ok && x + mx0 >= ref_box[c0][0] && y + my0 >= ref_box[c0][1] && x + mx0 + w + 4 <= ref_box[c0][2] && y + my0 + h <= ref_box[c0][3];
+                ok = ok && x + mx1 >= ref_box[c1][0] && y + my1 >= ref_box[c1][1] && x + mx1 + w + 4 <= ref_box[c1][2] && y + my1 + h <= ref_box[c1][3];
+                sad[slot] = ok ? orc_md_fullpel_avg_candidate(src, src_stride, refs[c0], ref_stride[c0], refs[c1], ref_stride[c1], x, y, w, h, mx0, my0, mx1, my1) : 0xffffffffu;
+            }
+}
+
 /* One probe of the sub-pel refinement: svt_upsampled_pref_error (Encoder/Codec/mcomp.c:102-156) = svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269, orc_upsampled_pred)
  * into a scratch block + the square block's variance (orc_variance = svt_aom_variance{W}x{H}_c).  (mvx8, mvy8): the probed vector in eighth-samples. */
 void     orc_upsampled_pred(const uint8_t *ref, int ref_stride, uint8_t *dst, int w, int h, int subpel_x_q3, int subpel_y_q3, int bank);

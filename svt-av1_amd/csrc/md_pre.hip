@@ -66,9 +66,61 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
         const uint8_t* ps = src + (ptrdiff_t)y * src_stride + x + c4;
         const uint8_t* pr = ref.d_plane + (ptrdiff_t)ry * ref.stride + rx + c4;
         uint32_t s = 0;
-        for (int r0 = 0; r0 < h; r0 += rows) {
-            const int yy = r0 + row;
-            if (yy < h) s = __builtin_amdgcn_sad_u8(load4_any(ps + (ptrdiff_t)yy * src_stride), load4_any(pr + (ptrdiff_t)yy * ref.stride), s);
+        for (int r0 = 0; r0 < h; r0 += 4 * rows) {   // four row groups' loads in flight (unconditional, clamped rows: a load under a condition is a branch that waits for it)
+            uint32_t a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int yy = min(r0 + u * rows + row, h - 1);
+                a[u] = load4_any(ps + (ptrdiff_t)yy * src_stride); b[u] = load4_any(pr + (ptrdiff_t)yy * ref.stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t t = __builtin_amdgcn_sad_u8(a[u], b[u], s); s = r0 + u * rows + row < h ? t : s; }
+        }
+        s = rows_total(row_sum(s));
+        if (lane == 0) sad[slot] = s;
+    }
+}
+
+// ---- the same for the COMPOUND-AVERAGE candidates mode decision makes of two ME vectors (NEW_NEWMV from the open-loop ME's bi-directional candidates, EbModeDecision.c:3408-3540;
+// MD_COMP_AVG: interinter_comp.type = COMPOUND_AVERAGE, compound_idx = 1): both predictions are full-pel copies in the compound domain (svt_av1_jnt_convolve_2d_copy:
+// (sample << 4) + offset), the second call averages and rounds back: ((a << 4) + (b << 4)) >> 1 rounded by 4 bits = (a + b + 1) >> 1.  One workgroup per (superblock, pair of
+// table columns); the pair's two vectors are the columns' own entries of the same PU.
+struct PairList { uint8_t c0[SVT_HIP_MD_MAX_PAIRS], c1[SVT_HIP_MD_MAX_PAIRS]; };
+__device__ __forceinline__ uint32_t avg4_round_up(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+__global__ void __launch_bounds__(256)
+md_fullpel_avg_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus, int n_pairs,
+                          PairList pairs, const uint32_t* __restrict__ mv, uint32_t* __restrict__ sad) {
+    const int sb = blockIdx.x, pr_i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sb_x = (sb % sb_cols) * 64, sb_y = (sb / sb_cols) * 64;
+    const int c0 = pairs.c0[pr_i], c1 = pairs.c1[pr_i];
+    const SvtHipMdRefPlane ref0 = refs.r[c0], ref1 = refs.r[c1];
+    for (int pu = wave; pu < n_pus; pu += 4) {
+        const size_t base = ((size_t)sb * n_pus + pu) * n_refs, slot = ((size_t)sb * n_pus + pu) * n_pairs + pr_i;
+        const int w = pus.w[pu], h = pus.h[pu], x = sb_x + pus.x[pu], y = sb_y + pus.y[pu];
+        const uint32_t m0 = mv[base + c0], m1 = mv[base + c1];
+        const int mx0 = (int16_t)(m0 & 0xffff), my0 = (int16_t)(m0 >> 16), mx1 = (int16_t)(m1 & 0xffff), my1 = (int16_t)(m1 >> 16);
+        const int rx0 = x + mx0, ry0 = y + my0, rx1 = x + mx1, ry1 = y + my1;
+        const bool ok = mx0 != SVT_HIP_MD_NO_MV && mx1 != SVT_HIP_MD_NO_MV && x + w <= pic_w && y + h <= pic_h &&
+                        rx0 >= ref0.x_min && ry0 >= ref0.y_min && rx0 + w + 4 <= ref0.x_max && ry0 + h <= ref0.y_max &&
+                        rx1 >= ref1.x_min && ry1 >= ref1.y_min && rx1 + w + 4 <= ref1.x_max && ry1 + h <= ref1.y_max;
+        if (!ok) {   // wave-uniform
+            if (lane == 0) sad[slot] = 0xffffffffu;
+            continue;
+        }
+        const int n4 = w >> 2, rows = 64 / n4, row = lane / n4, c4 = (lane - row * n4) << 2;
+        const uint8_t* ps = src + (ptrdiff_t)y * src_stride + x + c4;
+        const uint8_t* p0 = ref0.d_plane + (ptrdiff_t)ry0 * ref0.stride + rx0 + c4;
+        const uint8_t* p1 = ref1.d_plane + (ptrdiff_t)ry1 * ref1.stride + rx1 + c4;
+        uint32_t s = 0;
+        for (int r0 = 0; r0 < h; r0 += 2 * rows) {
+            uint32_t a[2], b[2], c[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int yy = min(r0 + u * rows + row, h - 1);
+                a[u] = load4_any(ps + (ptrdiff_t)yy * src_stride); b[u] = load4_any(p0 + (ptrdiff_t)yy * ref0.stride); c[u] = load4_any(p1 + (ptrdiff_t)yy * ref1.stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const uint32_t t = __builtin_amdgcn_sad_u8(a[u], avg4_round_up(b[u], c[u]), s); s = r0 + u * rows + row < h ? t : s; }
         }
         s = rows_total(row_sum(s));
         if (lane == 0) sad[slot] = s;
@@ -230,6 +282,22 @@ extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src,
         pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
     }
     hipLaunchKernelGGL(md_fullpel_sad_kernel, dim3(n_sb, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, sad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                                 int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* sad) {
+    if (n_sb <= 0 || n_refs <= 0 || n_pus <= 0 || n_pairs <= 0) return 0;
+    RefPlanes rp;
+    PuList    pl;
+    PairList  pp;
+    for (int i = 0; i < SVT_HIP_MD_MAX_REFS; i++) rp.r[i] = refs[i < n_refs ? i : 0];
+    for (int i = 0; i < SVT_HIP_MD_MAX_PUS; i++) {
+        const SvtHipMdPu p = pus[i < n_pus ? i : 0];
+        pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
+    }
+    for (int i = 0; i < SVT_HIP_MD_MAX_PAIRS; i++) { pp.c0[i] = pairs[i < n_pairs ? i : 0][0]; pp.c1[i] = pairs[i < n_pairs ? i : 0][1]; }
+    hipLaunchKernelGGL(md_fullpel_avg_sad_kernel, dim3(n_sb, n_pairs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, n_pairs, pp, mv, sad);
     return (int)hipGetLastError();
 }
 

@@ -100,6 +100,8 @@ int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int bd, const v
                                   const SvtHipConvBlk* blks, int n);
 int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                   int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, uint32_t* sad);
+int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                      int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* sad);
 int svt_hip_launch_md_subpel_grid(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                   int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int bank, int grid, uint32_t* out);
 int svt_hip_launch_block_sad(hipStream_t st, int pix_bytes, const void* a, int a_stride, const void* b, int b_stride,

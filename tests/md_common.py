@@ -62,3 +62,17 @@ def oracle_grid(orc, src, refs, pus, mv, sb_cols, n_sb, pad, pic_w, pic_h, bank)
     orc.orc_md_subpel_grid_picture(src.ctypes.data_as(C.c_void_p), src.shape[1], pic_w, pic_h, sb_cols, n_sb, len(pus), pu4.ctypes.data_as(C.c_void_p), n_refs, planes, strides,
                                    box.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p), bank, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def oracle_avg_table(orc, src, refs, pus, mv, sb_cols, n_sb, pad, pic_w, pic_h, pairs):
+    """the compound-average table of svt_hip_md_fullpel_avg_sad_picture_dev by the oracle: [n_sb][n_pus][n_pairs]"""
+    n_refs = len(refs)
+    pu4 = np.array(pus, np.uint8)
+    planes = (C.c_void_p * n_refs)(*[r.ctypes.data + pad * r.shape[1] + pad for r in refs])
+    strides = (C.c_int * n_refs)(*[r.shape[1] for r in refs])
+    box = np.array([[-pad, -pad, r.shape[1] - pad, r.shape[0] - pad] for r in refs], np.int32)
+    pr = np.array(pairs, np.uint8)
+    out = np.zeros(mv.shape[:2] + (len(pairs),), np.uint32)
+    orc.orc_md_fullpel_avg_sad_picture(src.ctypes.data_as(C.c_void_p), src.shape[1], pic_w, pic_h, sb_cols, n_sb, len(pus), pu4.ctypes.data_as(C.c_void_p), n_refs, planes, strides,
+                                       box.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p), len(pairs), pr.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -272,6 +272,12 @@ def _md_pre_subpel_line(log):
     return dict(zip(("pictures", "probes", "served"), map(int, m.groups())))
 
 
+def _md_pre_compound_line(log):
+    m = re.search(r"svt_hip_md_pre_compound pair_table_pictures=(\d+) served_from_pair_table=(\d+)", log)
+    assert m, log[-1500:]
+    return dict(zip(("pictures", "served"), map(int, m.groups())))
+
+
 def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p_8bit_m7", "328x200_8bit_m6", "cif_10bit_m8")):
     """hook "md_pre" (opt-in): ONE launch per picture, before the picture's mode decision starts, computes the stage-0 luma distortion of every (superblock, square PU,
     reference picture) at its open-loop ME vector; fast_loop_core (EbProductCodingLoop.c:907) reads the table instead of predicting + measuring, full_loop_core predicts
@@ -281,7 +287,7 @@ def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p
         spec = {**CASES, **GPU_ONLY_CASES}[case]
         got = _check(case, spec[:6] + ({"md_pre"},), workdir, env, tag + "_" + case)
         st = _md_pre_line(got["log"])
-        assert st["pictures"] > 0 and st["launches"] == st["pictures"] + _md_pre_subpel_line(got["log"])["pictures"] and st["min_blocks"] >= 256, st   # one launch per table
+        assert st["pictures"] > 0 and st["launches"] == st["pictures"] + _md_pre_subpel_line(got["log"])["pictures"] + _md_pre_compound_line(got["log"])["pictures"] and st["min_blocks"] >= 256, st   # one launch per table
         if spec[3] == 8:
             assert st["served"] * 2 > st["inter"], f"{case}: fewer than half of the inter fast-loop calls were served from the table: {st}"
         else:   # 10-bit input: this version's first pass decides on 16-bit samples (hbd_mode_decision), which the 8-bit table does not serve -- the reference's path, same output
@@ -314,6 +320,38 @@ def test_md_pre_full_mini_gop_and_self_check_on_cpu_test_double(workdir):
     assert st["served"] * 2 > st["inter"] and st["late"] > 0, st
     got = _check_geometry("gop9_mdpre", 352, 288, 9, 8, 6, 38, 29, workdir, {**env, "SVT_HIP_MD_PRE_VERIFY": "1"}, "mock_verify", must={"md_pre"})
     assert re.search(r"served_from_table=[1-9]\d* predicted_late=0 verify_mismatches=0\b", got["log"]), got["log"][-800:]
+
+
+def _check_md_pre_compound(workdir, env, tag):
+    """Seventeen frames (two hierarchical mini-GOPs): the B pictures' bi-directional ME candidates become NEW_NEWMV / COMPOUND_AVERAGE candidates of stage 0, served from the
+    picture's pair table (svt_hip_md_fullpel_avg_sad_picture_dev); with the self check every hit equals the reference's own compound prediction + SAD."""
+    got = _check_geometry("gop17_mdpre", 352, 288, 17, 8, 6, 36, 5, workdir, env, tag, must={"md_pre"})
+    st, bi = _md_pre_line(got["log"]), _md_pre_compound_line(got["log"])
+    assert bi["pictures"] > 0 and bi["served"] > 1000 and st["served"] * 2 > st["inter"], (st, bi)
+    assert re.search(r"svt_hip_md_pre_misses compound=0 ", got["log"]), got["log"][-800:]   # this preset's compound candidates are all averages of two ME vectors
+    got = _check_geometry("gop17_mdpre", 352, 288, 17, 8, 6, 36, 5, workdir, {**env, "SVT_HIP_MD_PRE_VERIFY": "1"}, tag + "_verify", must={"md_pre"})
+    assert re.search(r"served_from_table=[1-9]\d* predicted_late=0 verify_mismatches=0\b", got["log"]), got["log"][-800:]
+    return got
+
+
+def test_md_pre_compound_average_candidates_on_cpu_test_double(workdir):
+    env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}
+    _check_md_pre_compound(workdir, env, "mock")
+    # a wrong distortion out of the pair table changes the encode; without the pair table (SVT_HIP_MD_PRE_COMPOUND=0) the compound candidates are the reference's again
+    clip = os.path.join(workdir, "gop17_mdpre.src.yuv")
+    ref = _ref_cache["gop17_mdpre"] if "gop17_mdpre" in _ref_cache else None
+    got = E.encode(E.APP_HIP, clip, 352, 288, 17, 6, 36, 8, os.path.join(workdir, "gop17_mdpre.bad"), env_extra={**env, "SVT_HIP_MOCK_PERTURB": "md_pre_compound"})
+    good = E.encode(E.APP_HIP, clip, 352, 288, 17, 6, 36, 8, os.path.join(workdir, "gop17_mdpre.nopairs"), env_extra={**env, "SVT_HIP_MD_PRE_COMPOUND": "0"})
+    assert _md_pre_compound_line(good["log"])["served"] == 0 and re.search(r"svt_hip_md_pre_misses compound=[1-9]", good["log"])
+    assert (got["ivf"], got["recon"]) != (good["ivf"], good["recon"])
+    if ref is not None:
+        assert (good["ivf"], good["recon"]) == (ref["ivf"], ref["recon"])
+
+
+@pytest.mark.gpu
+def test_md_pre_compound_average_candidates_on_gpu(workdir):
+    got = _check_md_pre_compound(workdir, {"SVT_HIP_HOOKS": "md_pre"}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
 
 
 def test_md_pre_subpel_grid_matters(workdir):

@@ -60,6 +60,33 @@ def test_md_fullpel_sad_bad_arguments(hip, pkg):
     hip.free(buf)
 
 
+@pytest.mark.parametrize("w,h,n_refs,pairs", [(200, 152, 2, [(0, 1)]), (336, 208, 4, [(0, 2), (1, 3), (0, 1), (3, 0)]), (128, 64, 3, [(2, 0), (1, 1)]), (64, 64, 2, [(0, 1), (1, 0)])])
+def test_md_fullpel_avg_sad_picture(hip, pkg, orc, w, h, n_refs, pairs):
+    """svt_hip_md_fullpel_avg_sad_picture_dev: the compound-average candidates (two ME vectors, prediction (a + b + 1) >> 1) of every (superblock, square PU, pair of table
+    columns) == the oracle's restatement of the reference's two jnt_convolve_2d_copy calls + SAD (pinned to them in tests/test_oracle_vs_ref.py); missing vectors, PUs outside
+    the picture and blocks that leave either allocation say "not computed"; content at the top of the range pins the rounding."""
+    rng = np.random.default_rng(w + 7 * h + n_refs)
+    src, refs, pus, mv, sb_cols, n_sb, pad = M.make_case(rng, w, h, n_refs)
+    refs[0][:, :] = np.where(rng.random(refs[0].shape) < 0.5, 254, 255).astype(np.uint8)
+    exp = M.oracle_avg_table(orc, src, refs, pus, mv, sb_cols, n_sb, pad, w, h, pairs)
+    d_src, d_mv = hip.to_device(src), hip.to_device(mv)
+    d_refs = [hip.to_device(r) for r in refs]
+    d_out = hip.empty(exp.size * 4)
+    pu_arr = (pkg.MdPu * len(pus))(*[pkg.MdPu(*p) for p in pus])
+    planes = (pkg.MdRefPlane * n_refs)()
+    for r in range(n_refs):
+        planes[r] = pkg.MdRefPlane(d_refs[r].value + pad * refs[r].shape[1] + pad, refs[r].shape[1], -pad, -pad, refs[r].shape[1] - pad, refs[r].shape[0] - pad)
+    pr = np.array(pairs, np.uint8)
+    hip.check(hip.L.svt_hip_md_fullpel_avg_sad_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, len(pairs), pr.ctypes.data_as(C.c_void_p), d_out), "md avg sad")
+    got = hip.to_host(d_out, exp.shape, np.uint32)
+    assert hip.L.svt_hip_md_fullpel_avg_sad_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, 17, pr.ctypes.data_as(C.c_void_p), d_out) != 0   # too many pairs
+    bad = np.array([(n_refs, 0)], np.uint8)
+    assert hip.L.svt_hip_md_fullpel_avg_sad_picture_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, 1, bad.ctypes.data_as(C.c_void_p), d_out) != 0   # a column that does not exist
+    hip.free(d_src, d_mv, d_out, *d_refs)
+    assert (exp != 0xffffffff).any()
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:6]
+
+
 @pytest.mark.parametrize("w,h,n_refs,bank", [(200, 152, 2, 4), (128, 64, 1, 0), (336, 208, 3, 4), (64, 64, 1, 3)])
 def test_md_subpel_grid_picture(hip, pkg, orc, w, h, n_refs, bank):
     """svt_hip_md_subpel_grid_picture_dev: (variance, sse) of all 49 quarter-pel positions around every (superblock, square PU, reference)'s full-pel vector == the oracle's

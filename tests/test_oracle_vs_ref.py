@@ -113,6 +113,37 @@ def test_md_subpel_probe(orc, ref):
         assert (v, sse.value) == (int(e_var[i]), int(e_sse[i])), (i, x, y, s, mvx, mvy, bank)
 
 
+def test_md_compound_average_candidate(orc, ref):
+    """oracle/md_oracle.c::orc_md_fullpel_avg_candidate (a NEW_NEWMV / COMPOUND_AVERAGE candidate of two full-pel vectors) vs what av1_inter_prediction runs for it: two calls of
+    svt_av1_jnt_convolve_2d_copy_c (Common/Codec/convolve.c; svt_inter_predictor's table at [0][0][1]) with the compound conv_params of get_conv_params_no_round (round_0 3,
+    round_1 7, a 16-bit destination plane; the second call averages: do_average 1, no distance weights for compound_idx 1), then svt_nxm_sad_kernel_helper_c."""
+    rng = np.random.default_rng(53)
+    orc.orc_md_fullpel_avg_candidate.restype = C.c_uint32
+    ref.svt_nxm_sad_kernel_helper_c.restype = C.c_uint32
+    fx = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[0])), 8, 16, 0)
+    pad, W, H = 48, 256, 192
+    src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    r0 = rng.integers(0, 256, (H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    r1 = rng.integers(0, 256, (H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    r0[pad:pad + 64, pad:pad + 64] = 255; r1[pad:pad + 64, pad:pad + 64] = np.where(rng.random((64, 64)) < 0.5, 254, 255); src[:64, :64] = 0   # the rounding at the top of the range
+    st = r0.shape[1]
+    for it in range(200):
+        s = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (W - s) // 8 + 1)) * 8 if it >= 4 else 0; y = int(rng.integers(0, (H - s) // 8 + 1)) * 8 if it >= 4 else 0
+        if it < 4: s = 64
+        mv = [0, 0, 0, 0] if it < 4 else [int(v) for v in rng.integers(-40, 41, 4)]
+        tmp16 = np.zeros((s, s), np.uint16); pred = np.zeros((s, s), np.uint8)
+        cp = _ConvP(); cp.round_0 = 3; cp.round_1 = 7; cp.is_compound = 1; cp.dst = tmp16.ctypes.data; cp.dst_stride = s
+        cp.do_average = 0
+        ref.svt_av1_jnt_convolve_2d_copy_c(C.c_void_p(r0.ctypes.data + (pad + y + mv[1]) * st + pad + x + mv[0]), st, ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp))
+        cp.do_average = 1
+        ref.svt_av1_jnt_convolve_2d_copy_c(C.c_void_p(r1.ctypes.data + (pad + y + mv[3]) * st + pad + x + mv[2]), st, ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp))
+        e = ref.svt_nxm_sad_kernel_helper_c(C.c_void_p(src.ctypes.data + y * W + x), W, ptr(pred), s, s, s)
+        base0, base1 = C.c_void_p(r0.ctypes.data + pad * st + pad), C.c_void_p(r1.ctypes.data + pad * st + pad)
+        g = orc.orc_md_fullpel_avg_candidate(ptr(src), W, base0, st, base1, st, x, y, s, s, mv[0], mv[1], mv[2], mv[3])
+        assert e == g, (it, x, y, s, mv)
+
+
 def test_md_fullpel_candidate(orc, ref):
     """oracle/md_oracle.c vs the two reference kernels fast_loop_core (EbProductCodingLoop.c:907) runs for a full-pel single-reference candidate: the prediction
     svt_av1_convolve_2d_copy_sr_c (what svt_inter_predictor's table holds at [0][0][0]) and the distortion svt_nxm_sad_kernel_helper_c (= svt_nxm_sad_kernel_sub_sampled's
