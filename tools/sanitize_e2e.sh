@@ -29,9 +29,10 @@ cases = {"cif_8bit_m6": (352, 288, 6, 8, 6, 35, opt, []), "cif_10bit_m6": (352, 
          "854x480_m4": (854, 480, 3, 8, 4, 40, "all", []), "640x360_10bit_m5": (640, 360, 4, 10, 5, 32, "all", []), "cif_10bit_m8": (352, 288, 5, 10, 8, 36, "all", []),
          "qcif_m0": (176, 144, 3, 8, 0, 40, "all", []), "tiles_2x2": (352, 288, 6, 8, 6, 38, "all", ["-tile-columns", "1", "-tile-rows", "1"]),
          "screen_content": (352, 288, 6, 8, 6, 38, "all", ["-scm", "1"]), "altref_7_frames": (352, 288, 6, 8, 6, 38, "all", ["-altref-nframes", "7", "-altref-strength", "6"]),
-         "film_grain": (352, 288, 6, 8, 6, 38, "all", ["-film-grain", "8"]), "low_delay_p": (352, 288, 6, 8, 6, 38, "all", ["-pred-struct", "0"])}
+         "film_grain": (352, 288, 6, 8, 6, 38, "all", ["-film-grain", "8"]), "low_delay_p": (352, 288, 6, 8, 6, 38, "all", ["-pred-struct", "0"]),
+         "cif_gop17_md_pre": (352, 288, 17, 8, 6, 36, "all,md_pre", [])}   # two mini-GOPs: bi-directional ME candidates, the compound pair table of md_pre
 if san in ("thread", "undefined"):
-    cases = {k: cases[k] for k in ("cif_8bit_m6", "cif_10bit_m6", "tiles_2x2")}
+    cases = {k: cases[k] for k in ("cif_8bit_m6", "cif_10bit_m6", "tiles_2x2", "cif_gop17_md_pre")}
 bad = 0
 for name, (w, h, n, bd, preset, q, hooks, extra) in cases.items():
     clip = os.path.join(wd, name + ".yuv"); E.make_clip(clip, w, h, n, seed=7 + w, bd=bd)
