@@ -281,6 +281,23 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx *ctx, const SvtHipDlfSearch *p, const
                                  const uint16_t *d_edges_v, const uint16_t *d_edges_h, int units_w, int units_h,
                                  uint64_t *d_sse_scratch, int *best_level, int64_t *best_err);
 
+/* The searches of several planes of one picture advanced in LOCKSTEP (svt_av1_pick_filter_level, Encoder/Codec/EbDeblockingFilter.c:1189-1300, runs search_filter_level
+ * for luma, U and V one after the other; a plane's probes depend on nothing but that plane): every round measures, for every plane still searching, the one or two levels
+ * its walk needs next (the low and the high neighbour of an iteration are both measured before either is compared) — all probes of a round are queued and waited for
+ * once.  A 4:2:0 picture's three searches take 6-8 round trips instead of ~25.  d_tmp[0..1]: two scratch planes of the plane's geometry; d_sse_scratch: 2 * n_planes words. */
+typedef struct {
+    SvtHipDlfSearch q;
+    const void     *d_recon;
+    void           *d_tmp[2];
+    int             stride, plane_w, plane_h;
+    const void     *d_src;
+    int             src_stride;
+    const uint16_t *d_edges_v, *d_edges_h;
+    int             units_w, units_h;
+} SvtHipDlfSearchPlane;
+int svt_hip_dlf_search_levels_picture_dev(SvtHipCtx *ctx, int n_planes, const SvtHipDlfSearchPlane *planes, int pix_bytes, int bd, uint64_t *d_sse_scratch,
+                                          int *best_level, int64_t *best_err);
+
 /* ------------------------------------------------------------------ CDEF ------------------------ */
 /* Strength search of cdef_seg_search / cdef_seg_search16bit (Encoder/Codec/EbCdefProcess.c:80-475)
  * for every 64x64 filter block of a 4:2:0 frame in two launches (luma, then both chroma planes):

@@ -507,21 +507,34 @@ static EbErrorType dlf_pick_level(SvtHipCtx *hip, LfState *s) {
     if (build_edges(hip, p, 7, 1, NULL) != EB_ErrorNone) return EB_ErrorUndefined;
     if (!edges_on_host()) s->flags |= ST_MI;
     t_edges = svt_hip_hooks_now_ns() - td2;
-    for (int pl = 0; pl < 3; pl++) {
+    {   /* the three planes' searches are independent (svt_av1_pick_filter_level :1281-1300 runs them one after the other): advanced in lockstep, the probes each walk needs
+         * next measured in one round trip (svt_hip_dlf_search_levels_picture_dev; SVT_HIP_DLF_SEARCH=planes: one plane after the other, a round trip per probe).  Scratch:
+         * d_cdef and d_dbl, both free until the deblocking hook runs */
         const long long te1 = svt_hip_hooks_now_ns();
-        SvtHipDlfSearch q;
-        memset(&q, 0, sizeof(q));
-        q.plane = pl; q.dir = 2; q.other_level = 0;
-        q.start_level = pl == 0 ? last[2] : last[pl + 1];           /* search_filter_level :1044-1049 with dir = 2 / 0 / 0 */
-        q.loop_filter_mode = pcs->parent_pcs_ptr->loop_filter_mode;
-        q.tx_mode_only_4x4 = frm_hdr->tx_mode == ONLY_4X4;
-        q.sharpness = 0;                                            /* lf->sharpness_level = 0 (:1202) */
-        int64_t err;
-        HIP_TRY(svt_hip_dlf_search_level_dev(hip, &q, plane_origin(p, p->d_recon[pl], pl), plane_origin(p, p->d_cdef[pl], pl), p->pix_bytes, p->stride[pl], p->bd,
-                                             p->w >> (pl > 0), p->h >> (pl > 0), p->src[pl], p->src_st[pl], p->d_edges[pl][0], p->d_edges[pl][1],
-                                             p->units_w[pl], p->units_h[pl], p->d_sse, &best[pl], &err));
+        static int per_plane = -1;
+        if (per_plane < 0) { const char *e = getenv("SVT_HIP_DLF_SEARCH"); per_plane = e && !strcmp(e, "planes"); }
+        SvtHipDlfSearchPlane sp[3];
+        int64_t err[3] = {0, 0, 0};
+        memset(sp, 0, sizeof(sp));
+        for (int pl = 0; pl < 3; pl++) {
+            SvtHipDlfSearch *q = &sp[pl].q;
+            q->plane = pl; q->dir = 2; q->other_level = 0;
+            q->start_level = pl == 0 ? last[2] : last[pl + 1];           /* search_filter_level :1044-1049 with dir = 2 / 0 / 0 */
+            q->loop_filter_mode = pcs->parent_pcs_ptr->loop_filter_mode;
+            q->tx_mode_only_4x4 = frm_hdr->tx_mode == ONLY_4X4;
+            q->sharpness = 0;                                            /* lf->sharpness_level = 0 (:1202) */
+            sp[pl].d_recon = plane_origin(p, p->d_recon[pl], pl); sp[pl].d_tmp[0] = plane_origin(p, p->d_cdef[pl], pl); sp[pl].d_tmp[1] = plane_origin(p, p->d_dbl[pl], pl);
+            sp[pl].stride = p->stride[pl]; sp[pl].plane_w = p->w >> (pl > 0); sp[pl].plane_h = p->h >> (pl > 0);
+            sp[pl].d_src = p->src[pl]; sp[pl].src_stride = p->src_st[pl];
+            sp[pl].d_edges_v = p->d_edges[pl][0]; sp[pl].d_edges_h = p->d_edges[pl][1]; sp[pl].units_w = p->units_w[pl]; sp[pl].units_h = p->units_h[pl];
+        }
+        if (!per_plane) HIP_TRY(svt_hip_dlf_search_levels_picture_dev(hip, 3, sp, p->pix_bytes, p->bd, p->d_sse, best, err));
+        else
+            for (int pl = 0; pl < 3; pl++)
+                HIP_TRY(svt_hip_dlf_search_level_dev(hip, &sp[pl].q, sp[pl].d_recon, sp[pl].d_tmp[0], p->pix_bytes, sp[pl].stride, p->bd, sp[pl].plane_w, sp[pl].plane_h, sp[pl].d_src,
+                                                     sp[pl].src_stride, sp[pl].d_edges_v, sp[pl].d_edges_h, sp[pl].units_w, sp[pl].units_h, p->d_sse, &best[pl], &err[pl]));
         t_search += svt_hip_hooks_now_ns() - te1;
-        svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, q.start_level, best[pl], (long long)err);
+        for (int pl = 0; pl < 3; pl++) svt_hip_hooks_log("dlf_search: plane %d start %d -> level %d (sse %lld)", pl, sp[pl].q.start_level, best[pl], (long long)err[pl]);
     }
     svt_hip_hooks_log("dlf_search: picture up %.2f ms, mode info (host) %.2f ms, edges %.2f ms, probes %.2f ms", (td1 - td0) / 1e6, (td2 - td1) / 1e6, t_edges / 1e6, t_search / 1e6);
     lf->sharpness_level = 0;

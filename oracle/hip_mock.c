@@ -420,6 +420,18 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx *c, const SvtHipDlfSearch *p, const v
     return rc;
 }
 
+int svt_hip_dlf_search_levels_picture_dev(SvtHipCtx *c, int n_planes, const SvtHipDlfSearchPlane *planes, int pix_bytes, int bd, uint64_t *d_sse_scratch, int *best_level,
+                                          int64_t *best_err) {   /* the planes' searches are independent: one after the other gives what the lockstep rounds give */
+    if (n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipDlfSearchPlane *P = &planes[i];
+        const int rc = svt_hip_dlf_search_level_dev(c, &P->q, P->d_recon, P->d_tmp[0], pix_bytes, P->stride, bd, P->plane_w, P->plane_h, P->d_src, P->src_stride, P->d_edges_v, P->d_edges_h,
+                                                    P->units_w, P->units_h, d_sse_scratch, &best_level[i], best_err ? &best_err[i] : NULL);
+        if (rc != SVT_HIP_OK) return rc;
+    }
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ CDEF */
 int svt_hip_cdef_search_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const rec[3], const int rec_stride[3], const void *const src[3],
                                   const int src_stride[3], int w, int h, const uint8_t *skip8, int pri_damping, int bd, uint64_t *mse, uint8_t *dir,

@@ -133,6 +133,12 @@ class DlfSearch(C.Structure):
                 ("tx_mode_only_4x4", C.c_int), ("sharpness", C.c_int)]
 
 
+class DlfSearchPlane(C.Structure):
+    """SvtHipDlfSearchPlane (include/svt_hip.h)."""
+    _fields_ = [("q", DlfSearch), ("d_recon", C.c_void_p), ("d_tmp", C.c_void_p * 2), ("stride", C.c_int), ("plane_w", C.c_int), ("plane_h", C.c_int), ("d_src", C.c_void_p),
+                ("src_stride", C.c_int), ("d_edges_v", C.c_void_p), ("d_edges_h", C.c_void_p), ("units_w", C.c_int), ("units_h", C.c_int)]
+
+
 def tx_desc(x, y, tx_type):
     return (x & 0x3FFF) | ((y & 0x3FFF) << 14) | (tx_type << 28)
 
@@ -272,6 +278,7 @@ def lib():
     L.svt_hip_cdef_find_dir_batch_dev.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.svt_hip_cdef_filter_block_batch_dev.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32]
     L.svt_hip_lpf_edges_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32]
+    L.svt_hip_dlf_search_levels_picture_dev.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp]
     L.svt_hip_dlf_search_level_dev.argtypes = [vp, C.POINTER(DlfSearch), vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp,
                                                C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.svt_hip_setup_rtcd.argtypes = [vp, vp]

@@ -506,6 +506,52 @@ int svt_hip_dlf_search_level_dev(SvtHipCtx* c, const SvtHipDlfSearch* p, const v
     return rc != SVT_HIP_OK ? rc : hrc;
 }
 
+int svt_hip_dlf_search_levels_picture_dev(SvtHipCtx* c, int n_planes, const SvtHipDlfSearchPlane* planes, int pix_bytes, int bd, uint64_t* d_sse_scratch, int* best_level,
+                                          int64_t* best_err) {
+    SVT_HIP_ENTER(c);
+    if (!c || !planes || n_planes < 1 || n_planes > 3 || !d_sse_scratch || !best_level || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8))
+        return SVT_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < n_planes; i++) {
+        const SvtHipDlfSearchPlane& P = planes[i];
+        if (!P.d_recon || !P.d_tmp[0] || !P.d_tmp[1] || !P.d_src || !P.d_edges_v || !P.d_edges_h || P.q.plane < 0 || P.q.plane > 2 || P.plane_w <= 0 || P.plane_h <= 0 ||
+            P.units_w != (P.plane_w + 3) / 4 || P.units_h != (P.plane_h + 3) / 4 || P.q.sharpness < 0 || P.q.sharpness > 7) {
+            c->err = "svt_hip_dlf_search_levels_picture_dev: bad plane";
+            return SVT_HIP_ERR_BAD_ARG;
+        }
+    }
+    int64_t ss_err[3][64];
+    bool    done[3] = {false, false, false};
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 64; k++) ss_err[i][k] = -1;
+    for (;;) {
+        int need[3][2], n_need[3] = {0, 0, 0}, total = 0;
+        for (int i = 0; i < n_planes; i++) {
+            if (done[i]) continue;
+            const int n = svt_hip_dlf_search_plan(&planes[i].q, ss_err[i], need[i], &best_level[i], best_err ? &best_err[i] : nullptr);
+            if (n < 0) return n;
+            if (n == 0) done[i] = true;
+            n_need[i] = n; total += n;
+        }
+        if (!total) break;
+        hipError_t e = hipMemsetAsync(d_sse_scratch, 0, sizeof(uint64_t) * 2 * n_planes, c->stream);
+        for (int i = 0; i < n_planes && e == hipSuccess; i++)
+            for (int k = 0; k < n_need[i] && e == hipSuccess; k++) {   // try_filter_frame (:966-1024) on the device: a copy of the plane as coded, deblocked at the probed level, against the source
+                const SvtHipDlfSearchPlane& P = planes[i];
+                int lv_v, lv_h;
+                svt_hip_dlf_search_probe_levels(&P.q, need[i][k], &lv_v, &lv_h);
+                e = hipMemcpy2DAsync(P.d_tmp[k], (size_t)P.stride * pix_bytes, P.d_recon, (size_t)P.stride * pix_bytes, (size_t)P.plane_w * pix_bytes, P.plane_h, hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess) e = (hipError_t)svt_hip_launch_deblock_plane(c->stream, P.d_tmp[k], pix_bytes, P.stride, bd, P.d_edges_v, P.d_edges_h, P.units_w, P.units_h, P.q.sharpness, lv_v, lv_h);
+                if (e == hipSuccess) e = (hipError_t)svt_hip_launch_plane_sse(c->stream, pix_bytes, P.d_src, P.src_stride, P.d_tmp[k], P.stride, P.plane_w, P.plane_h, d_sse_scratch + 2 * i + k);
+            }
+        uint64_t sse[6] = {0, 0, 0, 0, 0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(sse, d_sse_scratch, sizeof(uint64_t) * 2 * n_planes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, e, "dlf level probes of a picture");
+        for (int i = 0; i < n_planes; i++)
+            for (int k = 0; k < n_need[i]; k++) ss_err[i][need[i][k]] = (int64_t)sse[2 * i + k];
+    }
+    return SVT_HIP_OK;
+}
+
 int svt_hip_fwd_txfm_quant_multi_dev(SvtHipCtx* c, int pix_bytes, const SvtHipFwdTxJob* jobs, int njobs) {
     SVT_HIP_ENTER(c);
     if (!c || (!jobs && njobs) || njobs < 0 || (pix_bytes != 1 && pix_bytes != 2)) return SVT_HIP_ERR_BAD_ARG;

@@ -93,47 +93,39 @@ int svt_hip_dlf_build_edges_crop(const SvtHipDlfModeInfo* mi, int mi_cols, int m
 
 
 // search_filter_level (Encoder/Codec/EbDeblockingFilter.c:1026-1187): the probe sequence, the integer bias rule and the
-// mode <= 2 single refinement; every probe (try_filter_frame, :966-1024) is the caller's callback.
-int svt_hip_dlf_search_levels_host(const SvtHipDlfSearch* p, SvtHipTryLevelFn try_fn, void* user, int* best_level, int64_t* best_err_out) {
-    if (!p || !try_fn || !best_level) return SVT_HIP_ERR_BAD_ARG;
+// mode <= 2 single refinement, as a PLAN over the errors known so far: the walk is replayed on ss_err[] (-1 = not measured) until it needs a level that has not been
+// measured; the one or two levels that iteration needs (filt_low and filt_high are both measured before either is compared when the direction is open) come back in
+// need[], the caller measures them (try_filter_frame, :966-1024), stores them in ss_err[] and asks again.  Return value: how many levels are needed; 0 = the walk is
+// over, *best_level / *best_err_out are its result.  Measuring the two levels of an iteration together halves the round trips of a device search, and the three planes'
+// searches of a picture can be advanced in lockstep (svt_hip_dlf_search_levels_picture_dev).
+int svt_hip_dlf_search_plan(const SvtHipDlfSearch* p, const int64_t* ss_err, int need[2], int* best_level, int64_t* best_err_out) {
+    if (!p || !ss_err || !need || !best_level) return SVT_HIP_ERR_BAD_ARG;
     const int kMaxLoopFilter = 63;   // MAX_LOOP_FILTER
-    int64_t ss_err[kMaxLoopFilter + 1];
-    for (int i = 0; i <= kMaxLoopFilter; i++) ss_err[i] = -1;
-    bool failed = false;
-    auto try_level = [&](int lvl) -> int64_t {
-        int lv_v = lvl, lv_h = lvl;   // plane 0 with dir 2 (svt_av1_pick_filter_level :1281) and chroma: both directions at the probed level
-        if (p->plane == 0 && p->dir == 0) lv_h = p->other_level;
-        if (p->plane == 0 && p->dir == 1) lv_v = p->other_level;
-        const int64_t e = try_fn(user, lv_v, lv_h);
-        if (e < 0) failed = true;
-        return e;
-    };
     int filt_direction = 0;
     int filt_mid = p->start_level < 0 ? 0 : (p->start_level > kMaxLoopFilter ? kMaxLoopFilter : p->start_level);
     int filter_step = filt_mid < 16 ? 4 : filt_mid / 4;
-    int64_t best_err = try_level(filt_mid);
+    if (ss_err[filt_mid] < 0) { need[0] = filt_mid; return 1; }
+    int64_t best_err = ss_err[filt_mid];
     int filt_best = filt_mid;
-    ss_err[filt_mid] = best_err;
     const bool single = p->loop_filter_mode <= 2;
     if (single) filter_step = 2;
-    while (!failed && filter_step > 0) {
+    while (filter_step > 0) {
         const int filt_high = filt_mid + filter_step > kMaxLoopFilter ? kMaxLoopFilter : filt_mid + filter_step;
         const int filt_low = filt_mid - filter_step < 0 ? 0 : filt_mid - filter_step;
         int64_t bias = (best_err >> (15 - (filt_mid / 8))) * filter_step;   // bias against raising the level
         if (!p->tx_mode_only_4x4) bias >>= 1;
-        if (filt_direction <= 0 && filt_low != filt_mid) {
-            if (ss_err[filt_low] < 0) ss_err[filt_low] = try_level(filt_low);
-            if (ss_err[filt_low] < best_err + bias) {
-                if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
-                filt_best = filt_low;
-            }
+        const bool want_low = filt_direction <= 0 && filt_low != filt_mid, want_high = filt_direction >= 0 && filt_high != filt_mid;
+        int n = 0;
+        if (want_low && ss_err[filt_low] < 0) need[n++] = filt_low;
+        if (want_high && ss_err[filt_high] < 0 && !(n && need[0] == filt_high)) need[n++] = filt_high;
+        if (n) return n;
+        if (want_low && ss_err[filt_low] < best_err + bias) {
+            if (ss_err[filt_low] < best_err) best_err = ss_err[filt_low];
+            filt_best = filt_low;
         }
-        if (filt_direction >= 0 && filt_high != filt_mid) {
-            if (ss_err[filt_high] < 0) ss_err[filt_high] = try_level(filt_high);
-            if (ss_err[filt_high] < best_err - bias) {
-                if (!single) best_err = ss_err[filt_high];   // the mode <= 2 branch does not update best_err (:1121-1122)
-                filt_best = filt_high;
-            }
+        if (want_high && ss_err[filt_high] < best_err - bias) {
+            if (!single) best_err = ss_err[filt_high];   // the mode <= 2 branch does not update best_err (:1121-1122)
+            filt_best = filt_high;
         }
         if (single) break;
         if (filt_best == filt_mid) {
@@ -144,10 +136,33 @@ int svt_hip_dlf_search_levels_host(const SvtHipDlfSearch* p, SvtHipTryLevelFn tr
             filt_mid = filt_best;
         }
     }
-    if (failed) return SVT_HIP_ERR_RUNTIME;
     *best_level = filt_best;
     if (best_err_out) *best_err_out = ss_err[filt_best];
-    return SVT_HIP_OK;
+    return 0;
+}
+// the levels a probe of `lvl` filters with: plane 0 with dir 2 (svt_av1_pick_filter_level :1281) and chroma use the probed level in both directions
+void svt_hip_dlf_search_probe_levels(const SvtHipDlfSearch* p, int lvl, int* lv_v, int* lv_h) {
+    *lv_v = lvl; *lv_h = lvl;
+    if (p->plane == 0 && p->dir == 0) *lv_h = p->other_level;
+    if (p->plane == 0 && p->dir == 1) *lv_v = p->other_level;
+}
+// the whole walk with a callback per probe (one probe at a time: svt_hip_dlf_search_level_dev, the CPU test double)
+int svt_hip_dlf_search_levels_host(const SvtHipDlfSearch* p, SvtHipTryLevelFn try_fn, void* user, int* best_level, int64_t* best_err_out) {
+    if (!p || !try_fn || !best_level) return SVT_HIP_ERR_BAD_ARG;
+    int64_t ss_err[64];
+    for (int i = 0; i < 64; i++) ss_err[i] = -1;
+    for (;;) {
+        int need[2];
+        const int n = svt_hip_dlf_search_plan(p, ss_err, need, best_level, best_err_out);
+        if (n <= 0) return n < 0 ? n : SVT_HIP_OK;
+        for (int i = 0; i < n; i++) {
+            int lv_v, lv_h;
+            svt_hip_dlf_search_probe_levels(p, need[i], &lv_v, &lv_h);
+            const int64_t e = try_fn(user, lv_v, lv_h);
+            if (e < 0) return SVT_HIP_ERR_RUNTIME;
+            ss_err[need[i]] = e;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------- temporal filter */

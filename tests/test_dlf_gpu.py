@@ -125,6 +125,44 @@ def test_filter_level_search(hip, orc, pkg, bd, mode):
             assert sum(1 for v in probes if v >= 0) >= 2
 
 
+@pytest.mark.parametrize("bd,mode", [(8, 1), (8, 3), (10, 3)])
+def test_filter_level_search_of_a_picture_in_lockstep(hip, orc, pkg, bd, mode):
+    """svt_hip_dlf_search_levels_picture_dev: the three planes' searches advanced together (the one or two levels each walk needs next are measured in one round trip) give what the
+    oracle's restatement of search_filter_level gives plane by plane: same best level, same error; the unfiltered planes stay untouched."""
+    w, h = 328, 200
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(191 + bd + mode)
+    mi, cols, rows = dc.make_mode_info(w, h, seed=23, varied=False)
+    planes = (pkg.DlfSearchPlane * 3)()
+    keep, exp, recs = [], [], []
+    for plane, (pw, ph) in enumerate(((w, h), (w // 2, h // 2), (w // 2, h // 2))):
+        ev, eh = dc.build_edges(mi, cols, rows, plane, pw, ph)
+        src = content(rng, ph, pw, bd, 1).astype(dt)
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        blk = (((xx // 8) * 5 + (yy // 8) * 3) % 7 - 3) * ((2 + plane) << (bd - 8))
+        rec = np.clip(src.astype(np.int32) + blk + rng.integers(-1, 2, src.shape), 0, (1 << bd) - 1).astype(dt)
+        start = (8, 30, 3)[plane]
+        tmp = np.zeros_like(rec)
+        best_err = C.c_int64()
+        probes = (C.c_int64 * 64)()
+        orc.orc_dlf_search_level.restype = C.c_int
+        lvl = orc.orc_dlf_search_level(ptr(rec), ptr(tmp), rec.itemsize, pw, bd, pw, ph, ptr(src), pw, ptr(ev), ptr(eh), ev.shape[1], ev.shape[0], 0, plane, 2, 0, start, mode, 0,
+                                       C.byref(best_err), probes)
+        exp.append((lvl, best_err.value)); recs.append(rec)
+        d = [hip.to_device(rec), hip.empty(rec.nbytes), hip.empty(rec.nbytes), hip.to_device(src), hip.to_device(ev), hip.to_device(eh)]
+        keep.append(d)
+        planes[plane] = pkg.DlfSearchPlane(pkg.DlfSearch(plane, 2, 0, start, mode, 0, 0), d[0].value, (C.c_void_p * 2)(d[1].value, d[2].value), pw, pw, ph, d[3].value, pw,
+                                           d[4].value, d[5].value, ev.shape[1], ev.shape[0])
+    d_s = hip.empty(8 * 6)
+    best, err = (C.c_int * 3)(), (C.c_int64 * 3)()
+    hip.check(hip.L.svt_hip_dlf_search_levels_picture_dev(hip.h, 3, planes, recs[0].itemsize, bd, d_s, best, err), "dlf picture search")
+    for plane in range(3):
+        assert np.array_equal(hip.to_host(keep[plane][0], recs[plane].shape, dt), recs[plane]), "the unfiltered plane must stay untouched"
+        assert (best[plane], err[plane]) == exp[plane], (bd, mode, plane, best[plane], err[plane], exp[plane])
+    assert hip.L.svt_hip_dlf_search_levels_picture_dev(hip.h, 4, planes, recs[0].itemsize, bd, d_s, best, err) != 0
+    hip.free(d_s, *[x for d in keep for x in d])
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_deblock_frame_all_planes(hip, orc, bd):
     """svt_hip_deblock_frame_dev (all three planes, one launch per direction) == three oracle plane calls; a NULL plane is skipped."""
