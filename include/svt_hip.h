@@ -913,6 +913,14 @@ int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int
 int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx *ctx, const uint8_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
                                            const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int n_pairs,
                                            const uint8_t (*pairs)[2], uint32_t *d_sad);
+/* Both tables for the 16-bit planes a 10-bit encode's mode decision decides on (hbd_mode_decision 1 / 2: fast_loop_core predicts from reference_picture16bit and measures with
+ * sad_16b_kernel, Encoder/C_DEFAULT/EbComputeSAD_C.c:39; the compound copy is svt_av1_highbd_jnt_convolve_2d_copy, which rounds to (a + b + 1) >> 1 as well).  d_src and every
+ * refs[i].d_plane point at 16-bit samples; strides and the reference boxes are in samples. */
+int svt_hip_md_fullpel_sad_picture_hbd_dev(SvtHipCtx *ctx, const uint16_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
+                                           const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, uint32_t *d_sad);
+int svt_hip_md_fullpel_avg_sad_picture_hbd_dev(SvtHipCtx *ctx, const uint16_t *d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
+                                               const SvtHipMdPu *pus, int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *d_mv, int n_pairs,
+                                               const uint8_t (*pairs)[2], uint32_t *d_sad);
 /* The probes of mode decision's sub-pel refinement (md_subpel_search, Encoder/Codec/EbProductCodingLoop.c:2063 -> svt_av1_find_best_sub_pixel_tree, mcomp.c:350): every probe
  * is svt_upsampled_pref_error (mcomp.c:102) = svt_aom_upsampled_pred (Encoder/C_DEFAULT/variance.c:212-269) + svt_aom_variance{W}x{W} against the source.  The tree starts at
  * the block's full-pel vector and its half-pel and quarter-pel rounds stay inside the 7 x 7 quarter-pel grid around it, so one launch per picture computes, for every

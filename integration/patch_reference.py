@@ -185,7 +185,9 @@ mdtx.sub(r'(\n    context_ptr->md_staging_spatial_sse_full_loop_level = default_
 mdtx.sub(r'(    context_ptr->uv_intra_comp_only = EB_FALSE;\n)(    svt_product_prediction_fun_table\[candidate_buffer->candidate_ptr->use_intrabc\n\s*\? INTER_MODE\n\s*: candidate_ptr->type\]\(\n\s*context_ptr->hbd_mode_decision, context_ptr, pcs_ptr, candidate_buffer\);\n)',
          r'\1    uint32_t  hip_sad = 0;\n    const int hip_hit = use_ssd ? 0 : svt_hip_hook_md_pre_lookup(pcs_ptr, context_ptr, candidate_buffer, &hip_sad);\n    if (hip_hit == 1) { /* what inter_pu_prediction_av1 (EbEncInterPrediction.c:6285-6297, :6322) leaves behind besides the samples: the fast cost reads num_proj_ref */\n        if (pcs_ptr->parent_pcs_ptr->frm_hdr.allow_warped_motion && candidate_ptr->motion_mode != WARPED_CAUSAL)\n            wm_count_samples(context_ptr->blk_ptr, ((SequenceControlSet *)pcs_ptr->scs_wrapper_ptr->object_ptr)->seq_header.sb_size, context_ptr->blk_geom,\n                             context_ptr->blk_origin_x, context_ptr->blk_origin_y, candidate_ptr->ref_frame_type, pcs_ptr, &candidate_ptr->num_proj_ref);\n        context_ptr->ifs_is_regular_last = 0;\n    } else\n\2')
 mdtx.sub(r'(luma_fast_distortion = )(svt_nxm_sad_kernel_sub_sampled\(\n\s*input_picture_ptr->buffer_y \+ input_origin_index,\n\s*input_picture_ptr->stride_y,\n\s*prediction_ptr->buffer_y \+ cu_origin_index,\n\s*prediction_ptr->stride_y,\n\s*context_ptr->blk_geom->bheight,\n\s*context_ptr->blk_geom->bwidth\))',
-         r'\1hip_hit == 1 ? hip_sad : \2')
+         r'\1(hip_hit & 1) ? hip_sad : \2')
+mdtx.sub(r'(luma_fast_distortion = )(sad_16b_kernel\(\n\s*\(\(uint16_t \*\)input_picture_ptr->buffer_y\) \+ input_origin_index,\n\s*input_picture_ptr->stride_y,\n\s*\(\(uint16_t \*\)prediction_ptr->buffer_y\) \+ cu_origin_index,\n\s*prediction_ptr->stride_y,\n\s*context_ptr->blk_geom->bheight,\n\s*context_ptr->blk_geom->bwidth\))',
+         r'\1(hip_hit & 1) ? hip_sad : \2')   # the 16-bit fast loop of a 10-bit encode (hbd_mode_decision 1 / 2): the table was made on the 16-bit planes
 mdtx.sub(r'(\n    if \(context_ptr->blk_geom->has_uv && context_ptr->chroma_level <= CHROMA_MODE_1 &&\n        context_ptr->md_staging_skip_chroma_pred == EB_FALSE\) \{\n        if \(use_ssd\) \{\n            EbSpatialFullDistType spatial_full_dist_type_fun = context_ptr->hbd_mode_decision\n                \? svt_full_distortion_kernel16_bits\n                : svt_spatial_full_distortion_kernel;\n\n            chroma_fast_distortion = )',
          r'\n    if (hip_hit == 2) svt_hip_hook_md_pre_verify(pcs_ptr, context_ptr, candidate_buffer, hip_sad, (uint32_t)luma_fast_distortion);\1')
 mdtx.sub(r'(    if \(candidate_ptr->type != INTRA_MODE\) \{\n)(        if \(context_ptr->md_staging_perform_inter_pred\) \{\n            svt_product_prediction_fun_table\[candidate_ptr->type\]\()',

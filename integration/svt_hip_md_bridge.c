@@ -629,6 +629,9 @@ typedef struct {
     uint32_t *mv;                /* [n_sb][85][n_refs]: the vector in the units of the candidates (1/8 sample), x | y << 16; PRE_NONE = no entry */
     uint32_t *sad;               /* [n_sb][85][n_refs], page-locked */
     size_t    cap;               /* entries allocated */
+    int       hbd;               /* the two distortion tables were made on the 16-bit planes (a 10-bit encode: mode decision's fast loop works on them); the sub-pel grid is 8-bit either way */
+    void     *d_src16;           /* the picture's packed 16-bit luma (svt_enc_msb_pack2_d of the 8-bit plane and the 2-bit plane), made per picture */
+    size_t    src16_cap;
     int       n_pairs;           /* compound-average candidates: pairs of table columns that occur as bi-directional ME candidates in this picture */
     uint8_t   pairs[SVT_HIP_MD_MAX_PAIRS][2];
     int8_t    pair_of[SVT_HIP_MD_MAX_REFS][SVT_HIP_MD_MAX_REFS];   /* (column of the first reference, of the second) -> index into pairs, -1 = none */
@@ -644,7 +647,7 @@ typedef struct {
     volatile uint32_t *flags;    /* page-locked: [0] = the sequence number on its way to the device, [1] = where it comes back once both tables have arrived */
     uint32_t  seq;
     int       pending, n_held;
-    const void *held[SVT_HIP_MD_MAX_REFS + 1];   /* resident planes (svt_hip_resident_acquire) the queued launches read: released once the mark is back */
+    const void *held[2 * SVT_HIP_MD_MAX_REFS + 2];   /* resident planes (svt_hip_resident_acquire) the queued launches read: released once the mark is back */
 } MdPre;
 #define PRE_NONE 0x80008000u
 static MdPre           g_pre[PRE_SLOTS];
@@ -701,8 +704,10 @@ static void pre_build_pus_once(void) {
 }
 
 /* the luma plane of `pic` on the device: its resident copy (announced by the writer: *from_table = 1, release it afterwards) or an upload of the whole padded plane */
-static const uint8_t *pre_plane(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int *from_table, void **tmp) {
-    const size_t bytes = (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y);
+static const uint8_t *pre_plane_n(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int pix_bytes, int *from_table, void **tmp);
+static const uint8_t *pre_plane(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int *from_table, void **tmp) { return pre_plane_n(hip, pic, 1, from_table, tmp); }
+static const uint8_t *pre_plane_n(SvtHipCtx *hip, const EbPictureBufferDesc *pic, int pix_bytes, int *from_table, void **tmp) {
+    const size_t bytes = (size_t)pic->stride_y * (size_t)(pic->height + 2 * pic->origin_y) * (size_t)pix_bytes;
     *from_table = 0; *tmp = NULL;
     const void *d = svt_hip_resident_acquire(hip, pic->buffer_y, bytes);
     if (d) { *from_table = 1; return (const uint8_t *)d; }
@@ -717,6 +722,8 @@ void svt_hip_hook_md_pre_note_ref(PictureControlSet *pcs) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE) || pcs->parent_pcs_ptr->is_used_as_reference_flag != EB_TRUE || !pcs->parent_pcs_ptr->reference_picture_wrapper_ptr) return;
     const EbReferenceObject *ro = (const EbReferenceObject *)pcs->parent_pcs_ptr->reference_picture_wrapper_ptr->object_ptr;
     if (ro && ro->reference_picture) svt_hip_hooks_resident_note_picture(ro->reference_picture);
+    const EbPictureBufferDesc *r16 = ro ? ro->reference_picture16bit : NULL;   /* a 10-bit encode: the planes its mode decision predicts from */
+    if (r16 && r16->buffer_y) svt_hip_resident_note(r16->buffer_y, (size_t)r16->stride_y * (size_t)(r16->height + 2 * r16->origin_y) * 2);
 }
 
 /* the hook's own context (a stream of its own: its work overlaps everything else and is never drained by another bridge's unlock), made at the first picture */
@@ -758,8 +765,12 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     int ok = pcs->slice_type != I_SLICE && scs->seq_header.sb_size == BLOCK_64X64 && !ppcs->frame_superres_enabled && in && in->buffer_y && ppcs->pa_me_data &&
              ppcs->max_number_of_pus_per_sb >= PRE_PUS && pre_build_pus();
     /* the reference pictures ME searched, in the order of the ME vector array: list 0 at [0, 4), list 1 at [4, 7) (EbMotionEstimationLcuResults.h:44) */
-    const EbPictureBufferDesc *ref_pic[SVT_HIP_MD_MAX_REFS];
+    const EbPictureBufferDesc *ref_pic[SVT_HIP_MD_MAX_REFS], *ref_pic16[SVT_HIP_MD_MAX_REFS];
     int ref_col[SVT_HIP_MD_MAX_REFS], n_refs = 0;
+    /* a 10-bit encode decides on 16-bit samples in the fast loop (hbd_mode_decision 1, and 2 = "dual": only the searches are 8-bit): the two distortion tables are then made
+     * from the packed source and reference_picture16bit; without the unpacked 2-bit plane or a 16-bit reference the tables are not made (the reference's path) */
+    int hbd = pcs->hbd_mode_decision != 0;
+    if (hbd && !(scs->static_config.encoder_bit_depth == EB_10BIT && in && in->buffer_bit_inc_y && in->stride_bit_inc_y)) ok = 0;
     memset(t->slot_of, -1, sizeof(t->slot_of));
     for (int li = 0; li < 2 && ok; li++) {
         const int cnt = li ? ppcs->ref_list1_count_try : ppcs->ref_list0_count_try;
@@ -768,7 +779,9 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
             const EbReferenceObject *ro = w ? (const EbReferenceObject *)w->object_ptr : NULL;
             const EbPictureBufferDesc *rp = ro ? ro->reference_picture : NULL;
             if (!rp || !rp->buffer_y || rp->width != in->width || rp->height != in->height) { ok = 0; break; }   /* scaled references keep the reference's path */
-            t->slot_of[li][ri] = (int8_t)n_refs; ref_pic[n_refs] = rp; ref_col[n_refs] = li * 4 + ri; n_refs++;
+            const EbPictureBufferDesc *rp16 = ro->reference_picture16bit;
+            if (hbd && (!rp16 || !rp16->buffer_y || rp16->width != rp->width || rp16->height != rp->height || rp16->origin_x != rp->origin_x || rp16->origin_y != rp->origin_y)) { ok = 0; break; }
+            t->slot_of[li][ri] = (int8_t)n_refs; ref_pic[n_refs] = rp; ref_pic16[n_refs] = rp16; ref_col[n_refs] = li * 4 + ri; n_refs++;
         }
     }
     if (!ok || !n_refs) { if (pcs->slice_type != I_SLICE) __sync_fetch_and_add(&g_pre_declined, 1); return; }
@@ -855,10 +868,11 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         if (svt_hip_host_alloc(hip, &h, nbi * sizeof(uint32_t)) == SVT_HIP_OK && svt_hip_malloc(hip, &t->d_bisad, nbi * sizeof(uint32_t)) == SVT_HIP_OK) { t->bisad = (uint32_t *)h; t->bicap = nbi; }
         else { if (h) svt_hip_host_free(hip, h); t->n_pairs = 0; }   /* the pair table is an extra: without it compound candidates stay the reference's */
     }
-    void *tmp[SVT_HIP_MD_MAX_REFS + 1] = {0};
-    int   from_table[SVT_HIP_MD_MAX_REFS + 1] = {0}, any_tmp = 0;
+    void *tmp[2 * SVT_HIP_MD_MAX_REFS + 2] = {0};   /* [0] source, [1 ..] references, [MAX_REFS + 1] the 2-bit plane, [MAX_REFS + 2 ..] 16-bit references */
+    int   from_table[2 * SVT_HIP_MD_MAX_REFS + 2] = {0}, any_tmp = 0;
     const uint8_t *d_src = NULL;
-    SvtHipMdRefPlane planes[SVT_HIP_MD_MAX_REFS];
+    SvtHipMdRefPlane planes[SVT_HIP_MD_MAX_REFS], planes16[SVT_HIP_MD_MAX_REFS];
+    const int s16 = (int)ppcs->aligned_width + 64;   /* row pitch of the packed source (samples): the kernels read whole dwords past a row's last sample */
     if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, t->d_mv, t->h_dev_mv, n * sizeof(uint32_t));
     if (rc == SVT_HIP_OK) { d_src = pre_plane(hip, in, &from_table[0], &tmp[0]); if (!d_src) rc = SVT_HIP_ERR_RUNTIME; }
     for (int r = 0; r < n_refs && rc == SVT_HIP_OK; r++) {
@@ -870,15 +884,43 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
         planes[r].x_min = -(int)rp->origin_x; planes[r].y_min = -(int)rp->origin_y;
         planes[r].x_max = (int)rp->width + (int)rp->origin_x; planes[r].y_max = (int)rp->height + (int)rp->origin_y;
     }
-    for (int i = 0; i <= n_refs; i++) any_tmp |= tmp[i] != NULL;
+    if (rc == SVT_HIP_OK && hbd) {
+        const size_t need = (size_t)s16 * ((size_t)ppcs->aligned_height + 1) * 2;
+        if (t->src16_cap < need) {
+            svt_hip_free(hip, t->d_src16); t->d_src16 = NULL; t->src16_cap = 0;
+            if (svt_hip_malloc(hip, &t->d_src16, need) == SVT_HIP_OK) t->src16_cap = need; else rc = SVT_HIP_ERR_RUNTIME;
+        }
+        const size_t inc_bytes = (size_t)in->stride_bit_inc_y * (size_t)(in->height + 2 * in->origin_y);
+        void **inc = &tmp[SVT_HIP_MD_MAX_REFS + 1];
+        if (rc == SVT_HIP_OK && svt_hip_hooks_malloc(hip, inc, inc_bytes) != SVT_HIP_OK) { *inc = NULL; rc = SVT_HIP_ERR_RUNTIME; }
+        if (rc == SVT_HIP_OK) rc = svt_hip_memcpy_h2d_async(hip, *inc, in->buffer_bit_inc_y, inc_bytes);
+        if (rc == SVT_HIP_OK)   /* pack2d_src of mode_decision_sb (EbProductCodingLoop.c:8131) for the whole picture: svt_enc_msb_pack2_d */
+            rc = svt_hip_picture_format_dev(hip, 0, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y,
+                                            (const uint8_t *)*inc + (size_t)in->origin_y * in->stride_bit_inc_y + in->origin_x, in->stride_bit_inc_y, t->d_src16, s16, NULL, 0,
+                                            (int)ppcs->aligned_width, (int)ppcs->aligned_height);
+        for (int r = 0; r < n_refs && rc == SVT_HIP_OK; r++) {
+            const EbPictureBufferDesc *rp = ref_pic16[r];
+            const uint8_t *d = pre_plane_n(hip, rp, 2, &from_table[SVT_HIP_MD_MAX_REFS + 2 + r], &tmp[SVT_HIP_MD_MAX_REFS + 2 + r]);
+            if (!d) { rc = SVT_HIP_ERR_RUNTIME; break; }
+            planes16[r] = planes[r];
+            planes16[r].d_plane = d + 2 * ((size_t)rp->origin_y * rp->stride_y + rp->origin_x);
+            planes16[r].stride = rp->stride_y;
+        }
+    }
+    t->hbd = hbd;
+    for (int i = 0; i < 2 * SVT_HIP_MD_MAX_REFS + 2; i++) any_tmp |= tmp[i] != NULL;
     if (g_pre_timing < 0) g_pre_timing = getenv("SVT_HIP_MD_PRE_TIMING") && atoi(getenv("SVT_HIP_MD_PRE_TIMING"));
     const int timing = g_pre_timing > 0 && rc == SVT_HIP_OK && svt_hip_timer_start(hip) == SVT_HIP_OK;   /* diagnostic: the device time of this picture's launches and copies (waits) */
     if (rc == SVT_HIP_OK)
-        rc = svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
-                                                n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad);
+        rc = hbd ? svt_hip_md_fullpel_sad_picture_hbd_dev(hip, (const uint16_t *)t->d_src16, s16, ppcs->aligned_width, ppcs->aligned_height, sb_cols, n_sb, PRE_PUS, g_pre_pu, n_refs, planes16,
+                                                          (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad)
+                 : svt_hip_md_fullpel_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                      n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, (uint32_t *)t->d_sad);
     if (rc == SVT_HIP_OK && t->n_pairs) {
-        int brc = svt_hip_md_fullpel_avg_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
-                                                         n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, t->n_pairs, (const uint8_t(*)[2])t->pairs, (uint32_t *)t->d_bisad);
+        int brc = hbd ? svt_hip_md_fullpel_avg_sad_picture_hbd_dev(hip, (const uint16_t *)t->d_src16, s16, ppcs->aligned_width, ppcs->aligned_height, sb_cols, n_sb, PRE_PUS, g_pre_pu, n_refs,
+                                                                   planes16, (const uint32_t *)t->d_mv, t->n_pairs, (const uint8_t(*)[2])t->pairs, (uint32_t *)t->d_bisad)
+                      : svt_hip_md_fullpel_avg_sad_picture_dev(hip, d_src + (size_t)in->origin_y * in->stride_y + in->origin_x, in->stride_y, ppcs->aligned_width, ppcs->aligned_height, sb_cols,
+                                                               n_sb, PRE_PUS, g_pre_pu, n_refs, planes, (const uint32_t *)t->d_mv, t->n_pairs, (const uint8_t(*)[2])t->pairs, (uint32_t *)t->d_bisad);
         if (brc == SVT_HIP_OK) brc = svt_hip_memcpy_d2h_async(hip, t->bisad, t->d_bisad, nbi * sizeof(uint32_t));
         if (brc != SVT_HIP_OK) t->n_pairs = 0;
     }
@@ -907,10 +949,11 @@ void svt_hip_hook_md_pre_picture(PictureControlSet *pcs) {
     t->n_held = 0;
     if (from_table[0]) t->held[t->n_held++] = in->buffer_y;
     for (int r = 0; r < n_refs; r++) if (from_table[1 + r]) t->held[t->n_held++] = ref_pic[r]->buffer_y;
+    for (int r = 0; r < n_refs; r++) if (hbd && from_table[SVT_HIP_MD_MAX_REFS + 2 + r]) t->held[t->n_held++] = ref_pic16[r]->buffer_y;
     t->pending = 1;
     if (rc != SVT_HIP_OK || any_tmp) {   /* a failure, or planes that had to be uploaded for this picture alone (resident planes off / over budget): finish here */
         (void)svt_hip_sync(hip);
-        for (int i = 0; i <= n_refs; i++) svt_hip_hooks_free(hip, tmp[i]);
+        for (int i = 0; i < 2 * SVT_HIP_MD_MAX_REFS + 2; i++) svt_hip_hooks_free(hip, tmp[i]);
         pre_sweep(hip, 1);
     }
     if (rc != SVT_HIP_OK) { t->grid_ready = 0; t->n_pairs = 0; }
@@ -961,7 +1004,7 @@ void svt_hip_hook_md_pre_subpel_end(void) { tls_grid.row = NULL; }
 /* svt_upsampled_pref_error of one probe: 1 = *err / *sse come from the grid (called through svt_hip_hook_md_subpel_fetch) */
 static int pre_grid_fetch(const MV *mv, unsigned int *err, unsigned int *sse) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
-    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") && atoi(getenv("SVT_HIP_MD_PRE_VERIFY"));
+    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") ? atoi(getenv("SVT_HIP_MD_PRE_VERIFY")) : 0;
     __sync_fetch_and_add(&g_pre_probes, 1);
     if (!tls_grid.row) return 0;
     const int dx = mv->col - tls_grid.cx, dy = mv->row - tls_grid.cy;
@@ -989,14 +1032,13 @@ void svt_hip_hook_md_pre_subpel_verify(const MV *mv, unsigned int err, unsigned 
  * NOT to be made now (svt_hip_hook_md_pre_take tells full_loop_core when it is needed after all) */
 int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx, ModeDecisionCandidateBuffer *cb, uint32_t *sad) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
-    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") && atoi(getenv("SVT_HIP_MD_PRE_VERIFY"));
+    if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") ? atoi(getenv("SVT_HIP_MD_PRE_VERIFY")) : 0;
     const unsigned ms = mark_slot(cb);
     if (tls_mark[ms] == cb) tls_mark[ms] = NULL;   /* the buffer gets a new candidate: whatever it was marked for is gone */
     __sync_fetch_and_add(&g_pre_calls, 1);
     const ModeDecisionCandidate *c = cb->candidate_ptr;
     if (c->type != INTER_MODE || c->use_intrabc) return 0;
     __sync_fetch_and_add(&g_pre_inter, 1);
-    if (ctx->hbd_mode_decision) PRE_MISS(PRE_MISS_HBD);
     if (!ctx->md_staging_skip_chroma_pred || !ctx->md_staging_skip_interpolation_search) PRE_MISS(PRE_MISS_LATER_PASS);
     if (c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used) PRE_MISS(PRE_MISS_MOTION);
     if (c->is_compound && (c->interinter_comp.type != COMPOUND_AVERAGE || c->compound_idx != 1 || c->comp_group_idx != 0)) PRE_MISS(PRE_MISS_COMPOUND);   /* distance-weighted, wedge, difference-weighted */
@@ -1004,6 +1046,7 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     if (g->shape != PART_N || g->bwidth != g->bheight || g->bwidth < 8 || g->bwidth > 64) PRE_MISS(PRE_MISS_SHAPE);
     const MdPre *t = pre_table_of(pcs);
     if (!t) PRE_MISS(PRE_MISS_NO_TABLE);
+    if ((ctx->hbd_mode_decision != 0) != (t->hbd != 0)) PRE_MISS(PRE_MISS_HBD);   /* the tables were made on the planes this picture's fast loop does not decide on */
     const uint32_t pu = ctx->me_block_offset, sb = ctx->me_sb_addr;
     if (pu >= PRE_PUS || sb >= (uint32_t)t->n_sb || g_pre_pu[pu].x != g->origin_x || g_pre_pu[pu].y != g->origin_y || g_pre_pu[pu].w != g->bwidth) PRE_MISS(PRE_MISS_SHAPE);
     MvReferenceFrame rf[2];
@@ -1029,7 +1072,8 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
         if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);
         *sad = t->bisad[eb];
         __sync_fetch_and_add(&g_pre_hits, 1); __sync_fetch_and_add(&g_pre_bi_hits, 1);
-        if (g_pre_verify) return 2;
+        if (g_pre_verify == 3) { tls_mark[ms] = cb; return 5; }   /* debug: predicted now AND again where the survivors are predicted */
+        if (g_pre_verify) return g_pre_verify == 2 ? 3 : 2;   /* 3: the reference predicts as usual and the TABLE's distortion is used (SVT_HIP_MD_PRE_VERIFY=2) */
         tls_mark[ms] = cb;
         return 1;
     }
@@ -1048,7 +1092,8 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
     *sad = t->sad[e];
     __sync_fetch_and_add(&g_pre_hits, 1);
-    if (g_pre_verify) return 2;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the candidate as well and svt_hip_hook_md_pre_verify compares */
+    if (g_pre_verify == 3) { tls_mark[ms] = cb; return 5; }
+    if (g_pre_verify) return g_pre_verify == 2 ? 3 : 2;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the candidate as well and svt_hip_hook_md_pre_verify compares; 2: it predicts and the table's distortion is used */
     tls_mark[ms] = cb;
     return 1;
 }
@@ -1082,7 +1127,7 @@ void svt_hip_md_bridge_release(SvtHipCtx *hip) {
         if (g_pre[i].sad) svt_hip_host_free(hip, g_pre[i].sad);
         if (g_pre[i].grid) svt_hip_host_free(hip, g_pre[i].grid);
         if (g_pre[i].bisad) svt_hip_host_free(hip, g_pre[i].bisad);
-        svt_hip_free(hip, g_pre[i].d_bisad);
+        svt_hip_free(hip, g_pre[i].d_bisad); svt_hip_free(hip, g_pre[i].d_src16);
         if (g_pre[i].h_dev_mv) svt_hip_host_free(hip, g_pre[i].h_dev_mv);
         if (g_pre[i].flags) svt_hip_host_free(hip, (void *)g_pre[i].flags);
         svt_hip_free(hip, g_pre[i].d_mv); svt_hip_free(hip, g_pre[i].d_sad); svt_hip_free(hip, g_pre[i].d_grid); svt_hip_free(hip, g_pre[i].d_seq);

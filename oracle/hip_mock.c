@@ -116,6 +116,44 @@ int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx *c, const uint8_t *src, int
             if (sad[i] != 0xffffffffu) sad[i] = sad[i] * 3 + 1000;   /* reorders the compound candidates of stage 0 */
     return SVT_HIP_OK;
 }
+/* the 16-bit forms: the bit depth of the clip is the context's (svt_hip_create ... the double keeps one global: 10, the only high bit depth the hooks are used with) */
+int svt_hip_md_fullpel_sad_picture_hbd_dev(SvtHipCtx *c, const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                           int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *mv, uint32_t *sad) {
+    (void)c;
+    if (n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 || n_refs > SVT_HIP_MD_MAX_REFS) return SVT_HIP_ERR_BAD_ARG;
+    uint8_t         pu4[SVT_HIP_MD_MAX_PUS][4];
+    const uint16_t *planes[SVT_HIP_MD_MAX_REFS];
+    int             strides[SVT_HIP_MD_MAX_REFS], box[SVT_HIP_MD_MAX_REFS][4];
+    for (int i = 0; i < n_pus; i++) { pu4[i][0] = pus[i].x; pu4[i][1] = pus[i].y; pu4[i][2] = pus[i].w; pu4[i][3] = pus[i].h; }
+    for (int r = 0; r < n_refs; r++) {
+        planes[r] = (const uint16_t *)refs[r].d_plane; strides[r] = refs[r].stride;
+        box[r][0] = refs[r].x_min; box[r][1] = refs[r].y_min; box[r][2] = refs[r].x_max; box[r][3] = refs[r].y_max;
+    }
+    orc_md_fullpel_sad_picture16(src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, (const uint8_t(*)[4])pu4, n_refs, planes, strides, (const int(*)[4])box, mv, sad);
+    if (perturb("md_pre"))
+        for (size_t i = 0; i < (size_t)n_sb * n_pus * n_refs; i++)
+            if (sad[i] != 0xffffffffu) sad[i] = sad[i] * 3 + 1000;
+    return SVT_HIP_OK;
+}
+int svt_hip_md_fullpel_avg_sad_picture_hbd_dev(SvtHipCtx *c, const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
+                                               int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t *sad) {
+    (void)c;
+    if (n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 || n_refs > SVT_HIP_MD_MAX_REFS || n_pairs < 1 || n_pairs > SVT_HIP_MD_MAX_PAIRS) return SVT_HIP_ERR_BAD_ARG;
+    uint8_t         pu4[SVT_HIP_MD_MAX_PUS][4];
+    const uint16_t *planes[SVT_HIP_MD_MAX_REFS];
+    int             strides[SVT_HIP_MD_MAX_REFS], box[SVT_HIP_MD_MAX_REFS][4];
+    for (int i = 0; i < n_pus; i++) { pu4[i][0] = pus[i].x; pu4[i][1] = pus[i].y; pu4[i][2] = pus[i].w; pu4[i][3] = pus[i].h; }
+    for (int r = 0; r < n_refs; r++) {
+        planes[r] = (const uint16_t *)refs[r].d_plane; strides[r] = refs[r].stride;
+        box[r][0] = refs[r].x_min; box[r][1] = refs[r].y_min; box[r][2] = refs[r].x_max; box[r][3] = refs[r].y_max;
+    }
+    for (int i = 0; i < n_pairs; i++) if (pairs[i][0] >= n_refs || pairs[i][1] >= n_refs) return SVT_HIP_ERR_BAD_ARG;
+    orc_md_fullpel_avg_sad_picture16(src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, (const uint8_t(*)[4])pu4, n_refs, planes, strides, (const int(*)[4])box, mv, n_pairs, pairs, 10, sad);
+    if (perturb("md_pre_compound"))
+        for (size_t i = 0; i < (size_t)n_sb * n_pus * n_pairs; i++)
+            if (sad[i] != 0xffffffffu) sad[i] = sad[i] * 3 + 1000;
+    return SVT_HIP_OK;
+}
 int svt_hip_md_subpel_grid_picture_dev(SvtHipCtx *c, const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu *pus,
                                        int n_refs, const SvtHipMdRefPlane *refs, const uint32_t *mv, int bank, uint32_t *out) {
     (void)c;
@@ -457,6 +495,13 @@ int svt_hip_cdef_apply_frame_dev(SvtHipCtx *c, int pix_bytes, const void *const 
 }
 
 /* ------------------------------------------------------------------ restoration */
+int svt_hip_picture_format_dev(SvtHipCtx *c, int mode, const void *in0, int in0_stride, const void *in1, int in1_stride, void *out0, int out0_stride, void *out1, int out1_stride,
+                               int w, int h) {
+    (void)c;
+    if (mode < 0 || mode > 6 || w <= 0 || h <= 0) return SVT_HIP_ERR_BAD_ARG;
+    orc_picture_format(mode, in0, in0_stride, in1, in1_stride, out0, out0_stride, out1, out1_stride, w, h);
+    return SVT_HIP_OK;
+}
 int svt_hip_generate_padding_dev(SvtHipCtx *c, void *plane, int pix_bytes, int stride, int w, int h, int pad_w, int pad_h) {
     (void)c;
     orc_generate_padding(plane, pix_bytes, stride, w, h, pad_w, pad_h);

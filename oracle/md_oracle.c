@@ -112,3 +112,63 @@ void orc_md_subpel_grid_picture(const uint8_t *src, int src_stride, int pic_w, i
                         o[2 * (7 * gy + gx)] = orc_md_subpel_probe(src, src_stride, refs[r], ref_stride[r], x, y, s, 8 * mx + 2 * gx - 6, 8 * my + 2 * gy - 6, bank, &o[2 * (7 * gy + gx) + 1]);
             }
 }
+
+
+/* ---- the same two tables on 16-bit planes (a 10-bit encode: hbd_mode_decision 1 / 2).  fast_loop_core predicts with the high-bit-depth copy (svt_av1_highbd_convolve_2d_copy_sr:
+ * a plain copy) and measures with sad_16b_kernel (orc_sad_16b); the compound copy is svt_av1_highbd_jnt_convolve_2d_copy (Common/Codec/convolve.c): the same arithmetic as the
+ * 8-bit one with bd in the offset and the clip. */
+uint32_t orc_md_fullpel_candidate16(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, int x, int y, int w, int h, int mx, int my) {
+    static __thread uint16_t pred[64 * 64];
+    for (int i = 0; i < h; i++) memcpy(pred + (size_t)i * w, ref + (ptrdiff_t)(y + my + i) * ref_stride + (x + mx), (size_t)w * 2);
+    return orc_sad_16b(src + (ptrdiff_t)y * src_stride + x, (uint32_t)src_stride, pred, (uint32_t)w, (uint32_t)h, (uint32_t)w);
+}
+uint32_t orc_md_fullpel_avg_candidate16(const uint16_t *src, int src_stride, const uint16_t *ref0, int ref0_stride, const uint16_t *ref1, int ref1_stride, int x, int y, int w,
+                                        int h, int mx0, int my0, int mx1, int my1, int bd) {
+    const int round_0 = 3, round_1 = 7, bits = 2 * 7 - round_0 - round_1, offset_bits = bd + 2 * 7 - round_0;
+    const int round_offset = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+    static __thread uint16_t tmp[64 * 64], pred[64 * 64];
+    const uint16_t *a = ref0 + (ptrdiff_t)(y + my0) * ref0_stride + (x + mx0), *b = ref1 + (ptrdiff_t)(y + my1) * ref1_stride + (x + mx1);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) tmp[i * w + j] = (uint16_t)((a[(ptrdiff_t)i * ref0_stride + j] << bits) + round_offset);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const uint16_t res = (uint16_t)((b[(ptrdiff_t)i * ref1_stride + j] << bits) + round_offset);
+            int32_t t = (tmp[i * w + j] + res) >> 1;
+            t -= round_offset;
+            t = (t + ((1 << bits) >> 1)) >> bits;
+            pred[i * w + j] = (uint16_t)(t < 0 ? 0 : (t > (1 << bd) - 1 ? (1 << bd) - 1 : t));
+        }
+    return orc_sad_16b(src + (ptrdiff_t)y * src_stride + x, (uint32_t)src_stride, pred, (uint32_t)w, (uint32_t)h, (uint32_t)w);
+}
+void orc_md_fullpel_sad_picture16(const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                  const uint16_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, uint32_t *sad) {
+    for (int sb = 0; sb < n_sb; sb++)
+        for (int p = 0; p < n_pus; p++)
+            for (int r = 0; r < n_refs; r++) {
+                const size_t slot = ((size_t)sb * n_pus + p) * n_refs + r;
+                const int x = (sb % sb_cols) * 64 + pus[p][0], y = (sb / sb_cols) * 64 + pus[p][1], w = pus[p][2], h = pus[p][3];
+                const int mx = (int16_t)(mv[slot] & 0xffff), my = (int16_t)(mv[slot] >> 16);
+                const int rx = x + mx, ry = y + my;
+                if (mx == -32768 || x + w > pic_w || y + h > pic_h || rx < ref_box[r][0] || ry < ref_box[r][1] || rx + w + 4 > ref_box[r][2] || ry + h > ref_box[r][3]) {
+                    sad[slot] = 0xffffffffu;
+                    continue;
+                }
+                sad[slot] = orc_md_fullpel_candidate16(src, src_stride, refs[r], ref_stride[r], x, y, w, h, mx, my);
+            }
+}
+void orc_md_fullpel_avg_sad_picture16(const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                      const uint16_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int n_pairs, const uint8_t (*pairs)[2],
+                                      int bd, uint32_t *sad) {
+    for (int sb = 0; sb < n_sb; sb++)
+        for (int p = 0; p < n_pus; p++)
+            for (int q = 0; q < n_pairs; q++) {
+                const size_t base = ((size_t)sb * n_pus + p) * n_refs, slot = ((size_t)sb * n_pus + p) * n_pairs + q;
+                const int c0 = pairs[q][0], c1 = pairs[q][1];
+                const int x = (sb % sb_cols) * 64 + pus[p][0], y = (sb / sb_cols) * 64 + pus[p][1], w = pus[p][2], h = pus[p][3];
+                const int mx0 = (int16_t)(mv[base + c0] & 0xffff), my0 = (int16_t)(mv[base + c0] >> 16), mx1 = (int16_t)(mv[base + c1] & 0xffff), my1 = (int16_t)(mv[base + c1] >> 16);
+                int ok = mx0 != -32768 && mx1 != -32768 && x + w <= pic_w && y + h <= pic_h;
+                ok = ok && x + mx0 >= ref_box[c0][0] && y + my0 >= ref_box[c0][1] && x + mx0 + w + 4 <= ref_box[c0][2] && y + my0 + h <= ref_box[c0][3];
+                ok = ok && x + mx1 >= ref_box[c1][0] && y + my1 >= ref_box[c1][1] && x + mx1 + w + 4 <= ref_box[c1][2] && y + my1 + h <= ref_box[c1][3];
+                sad[slot] = ok ? orc_md_fullpel_avg_candidate16(src, src_stride, refs[c0], ref_stride[c0], refs[c1], ref_stride[c1], x, y, w, h, mx0, my0, mx1, my1, bd) : 0xffffffffu;
+            }
+}

@@ -90,6 +90,14 @@ uint32_t orc_md_fullpel_avg_candidate(const uint8_t *src, int src_stride, const 
 void orc_md_fullpel_avg_sad_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
                                     const uint8_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int n_pairs, const uint8_t (*pairs)[2],
                                     uint32_t *sad);
+uint32_t orc_md_fullpel_candidate16(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, int x, int y, int w, int h, int mx, int my);
+uint32_t orc_md_fullpel_avg_candidate16(const uint16_t *src, int src_stride, const uint16_t *ref0, int ref0_stride, const uint16_t *ref1, int ref1_stride, int x, int y, int w,
+                                        int h, int mx0, int my0, int mx1, int my1, int bd);
+void orc_md_fullpel_sad_picture16(const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                  const uint16_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, uint32_t *sad);
+void orc_md_fullpel_avg_sad_picture16(const uint16_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
+                                      const uint16_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int n_pairs, const uint8_t (*pairs)[2],
+                                      int bd, uint32_t *sad);
 uint32_t orc_md_subpel_probe(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int x, int y, int s, int mvx8, int mvy8, int bank, uint32_t *sse);
 void orc_md_subpel_grid_picture(const uint8_t *src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const uint8_t (*pus)[4], int n_refs,
                                 const uint8_t *const *refs, const int *ref_stride, const int (*ref_box)[4], const uint32_t *mv, int bank, uint32_t *out);

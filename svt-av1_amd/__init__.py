@@ -212,6 +212,8 @@ def lib():
     L.svt_hip_block_sad_batch_dev.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp]
     L.svt_hip_md_fullpel_sad_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     L.svt_hip_md_fullpel_avg_sad_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp]
+    L.svt_hip_md_fullpel_sad_picture_hbd_dev.argtypes = L.svt_hip_md_fullpel_sad_picture_dev.argtypes
+    L.svt_hip_md_fullpel_avg_sad_picture_hbd_dev.argtypes = L.svt_hip_md_fullpel_avg_sad_picture_dev.argtypes
     L.svt_hip_md_subpel_grid_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]
     L.svt_hip_md_halfpel_grid_picture_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]
     L.svt_hip_block_variance_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp]

@@ -31,6 +31,21 @@ __device__ __forceinline__ uint32_t load4_any(const uint8_t* p) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
 }
 
+// four consecutive 16-bit samples starting at any even byte address: {lo = samples 0, 1; hi = samples 2, 3}
+struct U16x4 { uint32_t lo, hi; };
+__device__ __forceinline__ U16x4 load4_any16(const uint16_t* p) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t sh = (uint32_t)(a & 2);
+    return U16x4{__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh)};
+}
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+__device__ __forceinline__ uint32_t sad4(U16x4 a, U16x4 b, uint32_t acc) { return __builtin_amdgcn_sad_u16(a.hi, b.hi, __builtin_amdgcn_sad_u16(a.lo, b.lo, acc)); }
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return load4_any(p); }
+__device__ __forceinline__ U16x4 ld4(const uint16_t* p) { return load4_any16(p); }
+__device__ __forceinline__ uint32_t avg2_round_up16(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7fff7fffu); }   // per 16-bit half (a + b + 1) >> 1
+
 __device__ __forceinline__ uint32_t row_sum(uint32_t x) {      // every lane: the total of its 16-lane row
     int v = (int)x;
     v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -43,8 +58,11 @@ __device__ __forceinline__ uint32_t rows_total(uint32_t v) {   // the four row t
     return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
 }
 
+// PIX = uint8_t: the 8-bit planes; uint16_t: the 16-bit planes a 10-bit encode's mode decision works on (sad_16b_kernel, Encoder/C_DEFAULT/EbComputeSAD_C.c:39; strides and the
+// reference boxes in samples, d_plane = sample (0, 0) of the 16-bit plane)
+template <typename PIX>
 __global__ void __launch_bounds__(256)
-md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus,
+md_fullpel_sad_kernel(const PIX* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus,
                       const uint32_t* __restrict__ mv, uint32_t* __restrict__ sad) {
     const int sb = blockIdx.x, r = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sb_x = (sb % sb_cols) * 64, sb_y = (sb / sb_cols) * 64;
@@ -63,18 +81,18 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
             continue;
         }
         const int n4 = w >> 2, rows = 64 / n4, row = lane / n4, c4 = (lane - row * n4) << 2;
-        const uint8_t* ps = src + (ptrdiff_t)y * src_stride + x + c4;
-        const uint8_t* pr = ref.d_plane + (ptrdiff_t)ry * ref.stride + rx + c4;
+        const PIX* ps = src + (ptrdiff_t)y * src_stride + x + c4;
+        const PIX* pr = (const PIX*)ref.d_plane + (ptrdiff_t)ry * ref.stride + rx + c4;
         uint32_t s = 0;
         for (int r0 = 0; r0 < h; r0 += 4 * rows) {   // four row groups' loads in flight (unconditional, clamped rows: a load under a condition is a branch that waits for it)
-            uint32_t a[4], b[4];
+            decltype(ld4(ps)) a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int yy = min(r0 + u * rows + row, h - 1);
-                a[u] = load4_any(ps + (ptrdiff_t)yy * src_stride); b[u] = load4_any(pr + (ptrdiff_t)yy * ref.stride);
+                a[u] = ld4(ps + (ptrdiff_t)yy * src_stride); b[u] = ld4(pr + (ptrdiff_t)yy * ref.stride);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t t = __builtin_amdgcn_sad_u8(a[u], b[u], s); s = r0 + u * rows + row < h ? t : s; }
+            for (int u = 0; u < 4; u++) { const uint32_t t = sad4(a[u], b[u], s); s = r0 + u * rows + row < h ? t : s; }
         }
         s = rows_total(row_sum(s));
         if (lane == 0) sad[slot] = s;
@@ -86,9 +104,11 @@ md_fullpel_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
 // (sample << 4) + offset), the second call averages and rounds back: ((a << 4) + (b << 4)) >> 1 rounded by 4 bits = (a + b + 1) >> 1.  One workgroup per (superblock, pair of
 // table columns); the pair's two vectors are the columns' own entries of the same PU.
 struct PairList { uint8_t c0[SVT_HIP_MD_MAX_PAIRS], c1[SVT_HIP_MD_MAX_PAIRS]; };
-__device__ __forceinline__ uint32_t avg4_round_up(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+__device__ __forceinline__ uint32_t avg_round_up(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // per byte (a + b + 1) >> 1
+__device__ __forceinline__ U16x4 avg_round_up(U16x4 a, U16x4 b) { return U16x4{avg2_round_up16(a.lo, b.lo), avg2_round_up16(a.hi, b.hi)}; }   // (the high-bit-depth compound copy rounds the same way: svt_av1_highbd_jnt_convolve_2d_copy)
+template <typename PIX>
 __global__ void __launch_bounds__(256)
-md_fullpel_avg_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus, int n_pairs,
+md_fullpel_avg_sad_kernel(const PIX* __restrict__ src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_pus, int n_refs, RefPlanes refs, PuList pus, int n_pairs,
                           PairList pairs, const uint32_t* __restrict__ mv, uint32_t* __restrict__ sad) {
     const int sb = blockIdx.x, pr_i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sb_x = (sb % sb_cols) * 64, sb_y = (sb / sb_cols) * 64;
@@ -108,19 +128,19 @@ md_fullpel_avg_sad_kernel(const uint8_t* __restrict__ src, int src_stride, int p
             continue;
         }
         const int n4 = w >> 2, rows = 64 / n4, row = lane / n4, c4 = (lane - row * n4) << 2;
-        const uint8_t* ps = src + (ptrdiff_t)y * src_stride + x + c4;
-        const uint8_t* p0 = ref0.d_plane + (ptrdiff_t)ry0 * ref0.stride + rx0 + c4;
-        const uint8_t* p1 = ref1.d_plane + (ptrdiff_t)ry1 * ref1.stride + rx1 + c4;
+        const PIX* ps = src + (ptrdiff_t)y * src_stride + x + c4;
+        const PIX* p0 = (const PIX*)ref0.d_plane + (ptrdiff_t)ry0 * ref0.stride + rx0 + c4;
+        const PIX* p1 = (const PIX*)ref1.d_plane + (ptrdiff_t)ry1 * ref1.stride + rx1 + c4;
         uint32_t s = 0;
         for (int r0 = 0; r0 < h; r0 += 2 * rows) {
-            uint32_t a[2], b[2], c[2];
+            decltype(ld4(ps)) a[2], b[2], c[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int yy = min(r0 + u * rows + row, h - 1);
-                a[u] = load4_any(ps + (ptrdiff_t)yy * src_stride); b[u] = load4_any(p0 + (ptrdiff_t)yy * ref0.stride); c[u] = load4_any(p1 + (ptrdiff_t)yy * ref1.stride);
+                a[u] = ld4(ps + (ptrdiff_t)yy * src_stride); b[u] = ld4(p0 + (ptrdiff_t)yy * ref0.stride); c[u] = ld4(p1 + (ptrdiff_t)yy * ref1.stride);
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const uint32_t t = __builtin_amdgcn_sad_u8(a[u], avg4_round_up(b[u], c[u]), s); s = r0 + u * rows + row < h ? t : s; }
+            for (int u = 0; u < 2; u++) { const uint32_t t = sad4(a[u], avg_round_up(b[u], c[u]), s); s = r0 + u * rows + row < h ? t : s; }
         }
         s = rows_total(row_sum(s));
         if (lane == 0) sad[slot] = s;
@@ -271,7 +291,7 @@ md_subpel_grid_kernel(const uint8_t* __restrict__ src, int src_stride, int pic_w
 
 }   // namespace
 
-extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
+extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, int pix_bytes, const void* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus,
                                              const SvtHipMdPu* pus, int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, uint32_t* sad) {
     if (n_sb <= 0 || n_refs <= 0 || n_pus <= 0) return 0;
     RefPlanes rp;
@@ -281,11 +301,12 @@ extern "C" int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src,
         const SvtHipMdPu p = pus[i < n_pus ? i : 0];
         pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
     }
-    hipLaunchKernelGGL(md_fullpel_sad_kernel, dim3(n_sb, n_refs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, sad);
+    if (pix_bytes == 2) hipLaunchKernelGGL(md_fullpel_sad_kernel<uint16_t>, dim3(n_sb, n_refs), dim3(256), 0, st, (const uint16_t*)src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, sad);
+    else hipLaunchKernelGGL(md_fullpel_sad_kernel<uint8_t>, dim3(n_sb, n_refs), dim3(256), 0, st, (const uint8_t*)src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, mv, sad);
     return (int)hipGetLastError();
 }
 
-extern "C" int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+extern "C" int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, int pix_bytes, const void* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                                  int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* sad) {
     if (n_sb <= 0 || n_refs <= 0 || n_pus <= 0 || n_pairs <= 0) return 0;
     RefPlanes rp;
@@ -297,7 +318,8 @@ extern "C" int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, const uint8_t* 
         pl.x[i] = p.x; pl.y[i] = p.y; pl.w[i] = p.w; pl.h[i] = p.h;
     }
     for (int i = 0; i < SVT_HIP_MD_MAX_PAIRS; i++) { pp.c0[i] = pairs[i < n_pairs ? i : 0][0]; pp.c1[i] = pairs[i < n_pairs ? i : 0][1]; }
-    hipLaunchKernelGGL(md_fullpel_avg_sad_kernel, dim3(n_sb, n_pairs), dim3(256), 0, st, src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, n_pairs, pp, mv, sad);
+    if (pix_bytes == 2) hipLaunchKernelGGL(md_fullpel_avg_sad_kernel<uint16_t>, dim3(n_sb, n_pairs), dim3(256), 0, st, (const uint16_t*)src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, n_pairs, pp, mv, sad);
+    else hipLaunchKernelGGL(md_fullpel_avg_sad_kernel<uint8_t>, dim3(n_sb, n_pairs), dim3(256), 0, st, (const uint8_t*)src, src_stride, pic_w, pic_h, sb_cols, n_pus, n_refs, rp, pl, n_pairs, pp, mv, sad);
     return (int)hipGetLastError();
 }
 

@@ -656,9 +656,8 @@ int svt_hip_block_sad_batch_dev(SvtHipCtx* c, int pix_bytes, const void* d_a, in
     if (e != hipSuccess) return fail(c, e, "block sad launch");
     return SVT_HIP_OK;
 }
-int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+static int md_sad_picture(int pix_bytes, SvtHipCtx* c, const void* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                        int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, uint32_t* d_sad) {
-    SVT_HIP_ENTER(c);
     if (!c || !d_src || !pus || !refs || !d_mv || !d_sad || n_sb < 0 || sb_cols < 1 || pic_w < 1 || pic_h < 1 || n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 ||
         n_refs > SVT_HIP_MD_MAX_REFS)
         return SVT_HIP_ERR_BAD_ARG;
@@ -666,13 +665,22 @@ int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int s
         if (pus[i].w < 4 || pus[i].w > 64 || (pus[i].w & 3) || pus[i].h < 1 || pus[i].h > 64 || pus[i].x + pus[i].w > 64 || pus[i].y + pus[i].h > 64) return SVT_HIP_ERR_BAD_ARG;
     for (int i = 0; i < n_refs; i++)
         if (!refs[i].d_plane || refs[i].stride < 1) return SVT_HIP_ERR_BAD_ARG;
-    hipError_t e = (hipError_t)svt_hip_launch_md_fullpel_sad(c->stream, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, d_sad);
+    hipError_t e = (hipError_t)svt_hip_launch_md_fullpel_sad(c->stream, pix_bytes, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, d_sad);
     if (e != hipSuccess) return fail(c, e, "md full-pel sad launch");
     return SVT_HIP_OK;
 }
-int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
-                                           int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* d_sad) {
+int svt_hip_md_fullpel_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                       int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, uint32_t* d_sad) {
     SVT_HIP_ENTER(c);
+    return md_sad_picture(1, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, d_sad);
+}
+int svt_hip_md_fullpel_sad_picture_hbd_dev(SvtHipCtx* c, const uint16_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                           int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, uint32_t* d_sad) {
+    SVT_HIP_ENTER(c);
+    return md_sad_picture(2, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, d_sad);
+}
+static int md_avg_sad_picture(int pix_bytes, SvtHipCtx* c, const void* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                           int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* d_sad) {
     if (!c || !d_src || !pus || !refs || !d_mv || !d_sad || !pairs || n_sb < 0 || sb_cols < 1 || pic_w < 1 || pic_h < 1 || n_pus < 1 || n_pus > SVT_HIP_MD_MAX_PUS || n_refs < 1 ||
         n_refs > SVT_HIP_MD_MAX_REFS || n_pairs < 1 || n_pairs > SVT_HIP_MD_MAX_PAIRS)
         return SVT_HIP_ERR_BAD_ARG;
@@ -682,9 +690,19 @@ int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, i
         if (!refs[i].d_plane || refs[i].stride < 1) return SVT_HIP_ERR_BAD_ARG;
     for (int i = 0; i < n_pairs; i++)
         if (pairs[i][0] >= n_refs || pairs[i][1] >= n_refs) return SVT_HIP_ERR_BAD_ARG;
-    hipError_t e = (hipError_t)svt_hip_launch_md_fullpel_avg_sad(c->stream, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, n_pairs, pairs, d_sad);
+    hipError_t e = (hipError_t)svt_hip_launch_md_fullpel_avg_sad(c->stream, pix_bytes, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, n_pairs, pairs, d_sad);
     if (e != hipSuccess) return fail(c, e, "md compound-average sad launch");
     return SVT_HIP_OK;
+}
+int svt_hip_md_fullpel_avg_sad_picture_dev(SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                           int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* d_sad) {
+    SVT_HIP_ENTER(c);
+    return md_avg_sad_picture(1, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, n_pairs, pairs, d_sad);
+}
+int svt_hip_md_fullpel_avg_sad_picture_hbd_dev(SvtHipCtx* c, const uint16_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+                                               int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* d_sad) {
+    SVT_HIP_ENTER(c);
+    return md_avg_sad_picture(2, c, d_src, src_stride, pic_w, pic_h, sb_cols, n_sb, n_pus, pus, n_refs, refs, d_mv, n_pairs, pairs, d_sad);
 }
 static int md_grid_picture(int grid, SvtHipCtx* c, const uint8_t* d_src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                        int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* d_mv, int bank, uint32_t* d_out) {

@@ -98,9 +98,9 @@ int svt_hip_launch_cdef_apply(hipStream_t st, int pix_bytes, const void* const i
 int svt_hip_launch_subpel_jobs_from_me(hipStream_t st, const uint32_t* mv, int sb_cols, int w, int h, const uint8_t* frac, SvtHipConvBlk* out);
 int svt_hip_launch_subpel_predict(hipStream_t st, int pix_bytes, int bd, const void* ref, int ref_stride, void* dst, int dst_stride,
                                   const SvtHipConvBlk* blks, int n);
-int svt_hip_launch_md_fullpel_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+int svt_hip_launch_md_fullpel_sad(hipStream_t st, int pix_bytes, const void* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                   int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, uint32_t* sad);
-int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
+int svt_hip_launch_md_fullpel_avg_sad(hipStream_t st, int pix_bytes, const void* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                       int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int n_pairs, const uint8_t (*pairs)[2], uint32_t* sad);
 int svt_hip_launch_md_subpel_grid(hipStream_t st, const uint8_t* src, int src_stride, int pic_w, int pic_h, int sb_cols, int n_sb, int n_pus, const SvtHipMdPu* pus,
                                   int n_refs, const SvtHipMdRefPlane* refs, const uint32_t* mv, int bank, int grid, uint32_t* out);

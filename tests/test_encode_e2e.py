@@ -288,10 +288,9 @@ def _check_md_pre(workdir, env, tag, cases=("cif_8bit_m6", "cif_10bit_m6", "360p
         got = _check(case, spec[:6] + ({"md_pre"},), workdir, env, tag + "_" + case)
         st = _md_pre_line(got["log"])
         assert st["pictures"] > 0 and st["launches"] == st["pictures"] + _md_pre_subpel_line(got["log"])["pictures"] + _md_pre_compound_line(got["log"])["pictures"] and st["min_blocks"] >= 256, st   # one launch per table
-        if spec[3] == 8:
-            assert st["served"] * 2 > st["inter"], f"{case}: fewer than half of the inter fast-loop calls were served from the table: {st}"
-        else:   # 10-bit input: this version's first pass decides on 16-bit samples (hbd_mode_decision), which the 8-bit table does not serve -- the reference's path, same output
-            assert st["served"] == 0
+        # (10-bit input: mode decision's fast loop works on 16-bit samples -- hbd_mode_decision 2 at this preset --, and the two distortion tables are made on the packed source and
+        # reference_picture16bit: svt_hip_md_fullpel_sad_picture_hbd_dev)
+        assert st["served"] * 2 > st["inter"], f"{case}: fewer than half of the inter fast-loop calls were served from the table: {st}"
         sp = _md_pre_subpel_line(got["log"])
         # the sub-pel grid: made for every picture with a table; md_subpel_search's own probes (the open-loop ME vectors' refinement) are served from it -- the other half of
         # the svt_upsampled_pref_error calls belongs to the predictive ME's sub-pel search, which starts where a neighbour-dependent full-pel search ended (8-bit and 10-bit input:
@@ -334,9 +333,20 @@ def _check_md_pre_compound(workdir, env, tag):
     return got
 
 
+def _check_md_pre_compound_10bit(workdir, env, tag):
+    """the same on a 10-bit clip: single-reference and compound-average candidates of the 16-bit fast loop from the tables made on 16-bit planes, the self check on"""
+    got = _check_geometry("gop17_10bit_mdpre", 352, 288, 17, 10, 6, 36, 5, workdir, env, tag, must={"md_pre"})
+    st, bi = _md_pre_line(got["log"]), _md_pre_compound_line(got["log"])
+    assert bi["served"] > 1000 and st["served"] * 2 > st["inter"] and re.search(r"svt_hip_md_pre_misses compound=0 motion_mode=\d+ hbd=0 ", got["log"]), (st, bi)
+    got = _check_geometry("gop17_10bit_mdpre", 352, 288, 17, 10, 6, 36, 5, workdir, {**env, "SVT_HIP_MD_PRE_VERIFY": "1"}, tag + "_verify", must={"md_pre"})
+    assert re.search(r"served_from_table=[1-9]\d* predicted_late=0 verify_mismatches=0\b", got["log"]), got["log"][-800:]
+    return got
+
+
 def test_md_pre_compound_average_candidates_on_cpu_test_double(workdir):
     env = {"LD_LIBRARY_PATH": E.MOCK_DIR, "SVT_HIP_HOOKS": "md_pre"}
     _check_md_pre_compound(workdir, env, "mock")
+    _check_md_pre_compound_10bit(workdir, env, "mock")
     # a wrong distortion out of the pair table changes the encode; without the pair table (SVT_HIP_MD_PRE_COMPOUND=0) the compound candidates are the reference's again
     clip = os.path.join(workdir, "gop17_mdpre.src.yuv")
     ref = _ref_cache["gop17_mdpre"] if "gop17_mdpre" in _ref_cache else None
@@ -351,6 +361,8 @@ def test_md_pre_compound_average_candidates_on_cpu_test_double(workdir):
 @pytest.mark.gpu
 def test_md_pre_compound_average_candidates_on_gpu(workdir):
     got = _check_md_pre_compound(workdir, {"SVT_HIP_HOOKS": "md_pre"}, "hip")
+    assert "svt_hip MOCK" not in got["log"]
+    got = _check_md_pre_compound_10bit(workdir, {"SVT_HIP_HOOKS": "md_pre"}, "hip")
     assert "svt_hip MOCK" not in got["log"]
 
 

@@ -37,6 +37,41 @@ def test_md_fullpel_sad_picture(hip, pkg, orc, w, h, n_refs):
     assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
 
 
+@pytest.mark.parametrize("w,h,n_refs,pairs", [(336, 208, 3, [(0, 1), (2, 0)]), (64, 64, 2, [(0, 1)]), (200, 152, 4, [(0, 2), (1, 3), (3, 3)])])
+def test_md_tables_on_16_bit_planes(hip, pkg, orc, w, h, n_refs, pairs):
+    """svt_hip_md_fullpel_sad_picture_hbd_dev / svt_hip_md_fullpel_avg_sad_picture_hbd_dev (the planes a 10-bit encode's mode decision decides on): == the oracle's 16-bit
+    restatements (sad_16b_kernel; the high-bit-depth compound copy), which tests/test_oracle_vs_ref.py pins to the reference; odd sample addresses (2-byte aligned rows),
+    values at the top of the 10-bit range."""
+    rng = np.random.default_rng(w * 3 + h + n_refs)
+    src8, refs8, pus, mv, sb_cols, n_sb, pad = M.make_case(rng, w, h, n_refs)
+    up = lambda a: np.ascontiguousarray((a.astype(np.uint16) << 2) | rng.integers(0, 4, a.shape).astype(np.uint16))
+    src, refs = up(src8), [up(r) for r in refs8]
+    refs[0][:, :] = np.where(rng.random(refs[0].shape) < 0.5, 1022, 1023).astype(np.uint16)
+    pu4 = np.array(pus, np.uint8)
+    planes_o = (C.c_void_p * n_refs)(*[r.ctypes.data + 2 * (pad * r.shape[1] + pad) for r in refs])
+    strides = (C.c_int * n_refs)(*[r.shape[1] for r in refs])
+    box = np.array([[-pad, -pad, r.shape[1] - pad, r.shape[0] - pad] for r in refs], np.int32)
+    pr = np.array(pairs, np.uint8)
+    exp = np.zeros(mv.shape, np.uint32); exp2 = np.zeros(mv.shape[:2] + (len(pairs),), np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    orc.orc_md_fullpel_sad_picture16(vp(src), src.shape[1], w, h, sb_cols, n_sb, len(pus), vp(pu4), n_refs, planes_o, strides, vp(box), vp(mv), vp(exp))
+    orc.orc_md_fullpel_avg_sad_picture16(vp(src), src.shape[1], w, h, sb_cols, n_sb, len(pus), vp(pu4), n_refs, planes_o, strides, vp(box), vp(mv), len(pairs), vp(pr), 10, vp(exp2))
+    d_src, d_mv = hip.to_device(src), hip.to_device(mv)
+    d_refs = [hip.to_device(r) for r in refs]
+    d_out, d_out2 = hip.empty(exp.size * 4), hip.empty(exp2.size * 4)
+    pu_arr = (pkg.MdPu * len(pus))(*[pkg.MdPu(*p) for p in pus])
+    planes = (pkg.MdRefPlane * n_refs)()
+    for r in range(n_refs):
+        planes[r] = pkg.MdRefPlane(d_refs[r].value + 2 * (pad * refs[r].shape[1] + pad), refs[r].shape[1], -pad, -pad, refs[r].shape[1] - pad, refs[r].shape[0] - pad)
+    hip.check(hip.L.svt_hip_md_fullpel_sad_picture_hbd_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, d_out), "md sad 16")
+    hip.check(hip.L.svt_hip_md_fullpel_avg_sad_picture_hbd_dev(hip.h, d_src, src.shape[1], w, h, sb_cols, n_sb, len(pus), pu_arr, n_refs, planes, d_mv, len(pairs), vp(pr), d_out2), "md avg sad 16")
+    got, got2 = hip.to_host(d_out, exp.shape, np.uint32), hip.to_host(d_out2, exp2.shape, np.uint32)
+    hip.free(d_src, d_mv, d_out, d_out2, *d_refs)
+    assert (exp != 0xffffffff).any() and (exp2 != 0xffffffff).any()
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
+    assert np.array_equal(got2, exp2), np.argwhere(got2 != exp2)[:5]
+
+
 def test_md_fullpel_sad_other_pu_lists(hip, pkg, orc):
     """the PU list is an argument: rectangular PUs (64x32, 16x64, 4x16 ...) and a list of one"""
     rng = np.random.default_rng(5)

@@ -144,6 +144,42 @@ def test_md_compound_average_candidate(orc, ref):
         assert e == g, (it, x, y, s, mv)
 
 
+def test_md_candidates_on_16_bit_planes(orc, ref):
+    """The 16-bit forms of the two mode-decision tables (a 10-bit encode's fast loop: reference_picture16bit, sad_16b_kernel): orc_md_fullpel_candidate16 vs the reference's
+    svt_av1_highbd_convolve_2d_copy_sr_c + sad_16b_kernel_c, orc_md_fullpel_avg_candidate16 vs two svt_av1_highbd_jnt_convolve_2d_copy_c calls + sad_16b_kernel_c."""
+    rng = np.random.default_rng(59)
+    orc.orc_md_fullpel_candidate16.restype = C.c_uint32; orc.orc_md_fullpel_avg_candidate16.restype = C.c_uint32
+    ref.sad_16b_kernel_c.restype = C.c_uint32
+    fx = _IFP(C.addressof((C.c_int16 * 8 * 16).in_dll(ref, REF_BANKS[0])), 8, 16, 0)
+    pad, W, H, bd = 48, 256, 192, 10
+    src = rng.integers(0, 1024, (H, W), dtype=np.uint16)
+    r0 = rng.integers(0, 1024, (H + 2 * pad, W + 2 * pad), dtype=np.uint16)
+    r1 = rng.integers(0, 1024, (H + 2 * pad, W + 2 * pad), dtype=np.uint16)
+    r0[pad:pad + 64, pad:pad + 64] = 1023; r1[pad:pad + 64, pad:pad + 64] = np.where(rng.random((64, 64)) < 0.5, 1022, 1023); src[:64, :64] = 0
+    st = r0.shape[1]
+    el = lambda arr, yy, xx: C.c_void_p(arr.ctypes.data + 2 * (yy * arr.shape[1] + xx))
+    for it in range(200):
+        s = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (W - s) // 8 + 1)) * 8 if it >= 4 else 0; y = int(rng.integers(0, (H - s) // 8 + 1)) * 8 if it >= 4 else 0
+        if it < 4: s = 64
+        mv = [0, 0, 0, 0] if it < 4 else [int(v) for v in rng.integers(-40, 41, 4)]
+        pred = np.zeros((s, s), np.uint16)
+        cp = _ConvP(); cp.round_0 = 3; cp.round_1 = 11
+        ref.svt_av1_highbd_convolve_2d_copy_sr_c(el(r0, pad + y + mv[1], pad + x + mv[0]), st, ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp), bd)
+        e = ref.sad_16b_kernel_c(el(src, y, x), W, ptr(pred), s, s, s)
+        g = orc.orc_md_fullpel_candidate16(ptr(src), W, el(r0, pad, pad), st, x, y, s, s, mv[0], mv[1])
+        assert e == g, ("single", it, x, y, s, mv)
+        tmp16 = np.zeros((s, s), np.uint16)
+        cp = _ConvP(); cp.round_0 = 3; cp.round_1 = 7; cp.is_compound = 1; cp.dst = tmp16.ctypes.data; cp.dst_stride = s
+        cp.do_average = 0
+        ref.svt_av1_highbd_jnt_convolve_2d_copy_c(el(r0, pad + y + mv[1], pad + x + mv[0]), st, ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp), bd)
+        cp.do_average = 1
+        ref.svt_av1_highbd_jnt_convolve_2d_copy_c(el(r1, pad + y + mv[3], pad + x + mv[2]), st, ptr(pred), s, s, s, C.byref(fx), C.byref(fx), 0, 0, C.byref(cp), bd)
+        e = ref.sad_16b_kernel_c(el(src, y, x), W, ptr(pred), s, s, s)
+        g = orc.orc_md_fullpel_avg_candidate16(ptr(src), W, el(r0, pad, pad), st, el(r1, pad, pad), st, x, y, s, s, mv[0], mv[1], mv[2], mv[3], bd)
+        assert e == g, ("compound", it, x, y, s, mv)
+
+
 def test_md_fullpel_candidate(orc, ref):
     """oracle/md_oracle.c vs the two reference kernels fast_loop_core (EbProductCodingLoop.c:907) runs for a full-pel single-reference candidate: the prediction
     svt_av1_convolve_2d_copy_sr_c (what svt_inter_predictor's table holds at [0][0][0]) and the distortion svt_nxm_sad_kernel_helper_c (= svt_nxm_sad_kernel_sub_sampled's
