@@ -611,8 +611,9 @@ void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
  *
  * Exact by construction: the table is keyed by what fast_loop_core is about to compute — block position and size, reference picture, vector — and holds the value
  * the reference's kernels give for it (tests: device vs oracle vs the reference's svt_nxm_sad_kernel / convolve copy; end-to-end bitstream identity).  A miss — sub-pel or
- * compound or non-translation candidates, vectors the MV clamp of av1_inter_prediction would move, 128x128 superblocks, scaled references, 10-bit mode decision, later
- * passes' refined vectors — is the reference's own code. */
+ * the compound types other than the plain average of two ME vectors (svt_hip_md_fullpel_avg_sad_picture_dev serves that one), non-translation candidates, vectors the MV clamp
+ * of av1_inter_prediction would move, 128x128 superblocks, scaled references, later passes' refined vectors — is the reference's own code.  A 10-bit encode's fast loop works on 16-bit
+ * samples: its tables are made on 16-bit planes (the _hbd_ entry points). */
 #include "EbCodingLoop.h"   /* me_idx[]: mode-decision block index -> PU index of the open-loop ME results */
 #include "EbModeDecisionProcess.h"
 #include "EbMotionEstimationLcuResults.h"
