@@ -39,6 +39,7 @@ struct WaveLds {
 struct Lds {
     WaveLds w[kWaves];
     unsigned dist[kWaves];
+    short win[(32 + 9) * 44];   // the window the nine candidates of a search round share: rows / columns -4 .. bs + 4 around the round's centre position, row stride bs + 12
 };
 
 // compute_subpel_params (EbEncInterPrediction.c:3593-3660), unscaled branch: the vector (1/8 pel, luma units) of a bw x bh block of the plane with
@@ -59,10 +60,13 @@ __device__ __forceinline__ void subpel_params(int mvx, int mvy, int px, int py, 
 
 // One bw x bh prediction (bw, bh <= 32) by ONE wave in its own LDS region: lane l owns outputs l, l + 64, ... (raster), out[u] receives them.  `on` = this wave
 // has a block to predict; every wave of the workgroup passes the two barriers whatever it does in between (the candidates of a round differ in their phases).
+// the two passes on a staged window: W[r * ws + c] = reference sample (pos_x - 3 + c, pos_y - 3 + r); the horizontal pass goes through the wave's own L.im (one wave writes and
+// reads it: LDS operations of a wave execute in order, no workgroup barrier between the passes)
+template <typename PIX, int BD>
+__device__ void predict_core(WaveLds& L, const short* __restrict__ W, int ws, bool on, int sx, int sy, int bank, int bw, int bh, int out[16]);
 template <typename PIX, int BD>
 __device__ void predict(WaveLds& L, bool on, const PIX* __restrict__ ref, int ref_stride, int pos_x, int pos_y, int sx, int sy, int bank, int bw, int bh, int out[16]) {
     const int lane = threadIdx.x & 63, ws = bw + 8;
-    constexpr int pix_max = (1 << BD) - 1;
     __syncthreads();   // the previous users of the LDS windows are done
     if (on)   // (eight loads in flight per lane through batched_stage measured SLOWER here: 165 -> 183 us per launch in the hooked 4K encode — the windows are small and nine waves stage at once)
         for (int i = lane; i < (bh + 7) * (bw + 7); i += 64) {
@@ -70,6 +74,12 @@ __device__ void predict(WaveLds& L, bool on, const PIX* __restrict__ ref, int re
             L.src[r * ws + c] = (short)ref[(ptrdiff_t)(pos_y + r - 3) * ref_stride + (pos_x + c - 3)];
         }
     __syncthreads();
+    predict_core<PIX, BD>(L, L.src, ws, on, sx, sy, bank, bw, bh, out);
+}
+template <typename PIX, int BD>
+__device__ void predict_core(WaveLds& L, const short* __restrict__ W, int ws, bool on, int sx, int sy, int bank, int bw, int bh, int out[16]) {
+    const int lane = threadIdx.x & 63;
+    constexpr int pix_max = (1 << BD) - 1;
     int xf[8], yf[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { xf[k] = kInterp[bank][sx][k]; yf[k] = kInterp[bank][sy][k]; }
@@ -79,26 +89,27 @@ __device__ void predict(WaveLds& L, bool on, const PIX* __restrict__ ref, int re
             const int r = i / bw, c = i - r * bw;
             int sum = 1 << (BD + 6);
 #pragma unroll
-            for (int k = 0; k < 8; k++) sum += xf[k] * L.src[r * ws + c + k];
+            for (int k = 0; k < 8; k++) sum += xf[k] * W[r * ws + c + k];
             L.im[i] = (short)rp2(sum, 3);
         }
-    __syncthreads();
+    // the wave's own intermediate: written and read by the same wave, whose LDS operations execute in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int u = 0; u < 16; u++) {
         const int i = lane + 64 * u;
         int o = 0;
         if (on && i < n) {
             const int y = i / bw, x = i - y * bw;
-            if (!sx && !sy) o = L.src[(y + 3) * ws + x + 3];
+            if (!sx && !sy) o = W[(y + 3) * ws + x + 3];
             else if (!sy) {
                 int res = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) res += xf[k] * L.src[(y + 3) * ws + x + k];
+                for (int k = 0; k < 8; k++) res += xf[k] * W[(y + 3) * ws + x + k];
                 o = clampi(rp2(rp2(res, 3), 4), 0, pix_max);   // x_sr: round_0, then FILTER_BITS - round_0 (:425-453)
             } else if (!sx) {
                 int res = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) res += yf[k] * L.src[(y + k) * ws + x + 3];
+                for (int k = 0; k < 8; k++) res += yf[k] * W[(y + k) * ws + x + 3];
                 o = clampi(rp2(res, 7), 0, pix_max);            // y_sr (:395-423)
             } else {
                 constexpr int offset_bits = BD + 14 - 3;
@@ -135,7 +146,29 @@ __device__ void search(Lds& L, const TfSubpelArgs& a, int bs, int px, int py, in
         const short cx = (short)(mv_x + (wave / 3 - 1) * step), cy = (short)(mv_y + (wave % 3 - 1) * step);
         int pos_x, pos_y, sx, sy, o[16];
         subpel_params(cx, cy, px, py, bs, bs, bs, 0, a.mi_cols, a.mi_rows, px, py, pos_x, pos_y, sx, sy);
-        predict<PIX, BD>(L.w[wave], true, ref, a.ref_stride[0], pos_x, pos_y, sx, sy, 0, bs, bs, o);
+        // The nine candidates of a round lie within one sample of the round's centre: the workgroup stages ONE window (rows / columns -4 .. bs + 4 around the centre's integer
+        // position) instead of nine overlapping ones, and every wave filters from it at its own offset.  (The vector clamp of compute_subpel_params can move a candidate
+        // further at the picture's edge: such a wave stages a window of its own afterwards.)
+        int bpx, bpy, bsx, bsy;
+        subpel_params(mv_x, mv_y, px, py, bs, bs, bs, 0, a.mi_cols, a.mi_rows, px, py, bpx, bpy, bsx, bsy);
+        constexpr int wws = 44;
+        __syncthreads();   // the previous round's readers are done
+        for (int i = threadIdx.x; i < (bs + 9) * (bs + 9); i += 64 * kWaves) {
+            const int r = i / (bs + 9), c = i - r * (bs + 9);
+            L.win[r * wws + c] = (short)ref[(ptrdiff_t)(bpy + r - 4) * a.ref_stride[0] + (bpx + c - 4)];
+        }
+        const int ddx = pos_x - bpx, ddy = pos_y - bpy;
+        const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1;   // wave-uniform
+        if (!near)
+            for (int i = lane; i < (bs + 7) * (bs + 7); i += 64) {
+                const int r = i / (bs + 7), c = i - r * (bs + 7);
+                L.w[wave].src[r * (bs + 8) + c] = (short)ref[(ptrdiff_t)(pos_y + r - 3) * a.ref_stride[0] + (pos_x + c - 3)];
+            }
+        __syncthreads();
+        // (One horizontal pass per COLUMN of the 3 x 3 round — its three candidates share position and phase — made by the column's three waves together was measured as well:
+        // the barrier it needs between the passes costs what the saved multiplications gain, 145 -> ~150 us per launch; not kept.)
+        if (near) predict_core<PIX, BD>(L.w[wave], L.win + (ddy + 1) * wws + (ddx + 1), wws, true, sx, sy, 0, bs, bs, o);
+        else predict_core<PIX, BD>(L.w[wave], L.w[wave].src, bs + 8, true, sx, sy, 0, bs, bs, o);
         int sum = 0, sse = 0;   // sse < 2^31: 1024 x 1023^2
 #pragma unroll
         for (int u = 0; u < 16; u++)
