@@ -630,6 +630,7 @@ def main():
                       "unfinished": int(sum(int(s[2]) for s in st3)),
                       # shader cycles per walk and plane as the walking wave sees them: solve, replay, wait for the unit to become resident, evaluation, total
                       "phase_cycles_per_walk": [{k: round(64.0 * int(s[24 + i]) / (16 * P0.n_units[p])) for i, k in enumerate(("solve", "replay", "load_wait", "evaluate", "total"))}
+                                                | {"wave1_candidate_loops": round(64.0 * int(s[29]) / (16 * P0.n_units[p]))}
                                                 | {"passes": round(int(s[0]) / (16 * P0.n_units[p]), 2), "points": round(int(s[1]) / (16 * P0.n_units[p]), 2)} for p, s in enumerate(st3)]}
         parity_ok = bool(parity_ok is not False and walk_stats["unfinished"] == 0)
         if os.environ.get("SVT_BENCH_SGR_RANGE"):   # development probe: the value ranges of the difference planes the unit search stores (per plane, per set)

@@ -168,6 +168,15 @@ int svt_hip_fwd_txfm_quant_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes,
 int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx *ctx, int tx_size, int pix_bytes, int bd, const int32_t *d_dqcoeff,
                                    const void *d_pred, int pred_stride, void *d_recon, int recon_stride,
                                    const uint32_t *d_descs, int nblk);
+/* The lossless 4x4 inverse (reversible Walsh-Hadamard) + add + clip for a list of blocks: svt_av1_highbd_iwht4x4_16_add_c /
+ * svt_av1_highbd_iwht4x4_1_add_c (Common/Codec/EbInvTransforms.c:2771-2857), chosen per block by eob > 1 like highbd_iwht4x4_add (:2858-2864;
+ * d_eob NULL = the 16-coefficient form for every block).  16 int32 per block, block after block; descs as above (tx_type ignored).
+ * What svt_av1_highbd_inv_txfm_add_4x4 (:2870-2882) runs when TxfmParam.lossless is set -- the reference ENCODER never sets it
+ * (Encoder/Codec/EbCodingLoop.c:1068-1243, EbFullLoop.c:1852-1863 pass 0), so this entry point serves the per-call pointer
+ * svt_av1_inv_txfm_add only. */
+int svt_hip_iwht4x4_add_batch_dev(SvtHipCtx *ctx, int pix_bytes, int bd, const int32_t *d_dqcoeff, const uint16_t *d_eob,
+                                  const void *d_pred, int pred_stride, void *d_recon, int recon_stride,
+                                  const uint32_t *d_descs, int nblk);
 
 /* Mixed-size launches: the same two operations for up to any number of (transform size, plane) job lists in ONE launch per 16 jobs.
  * A frame's transform work is 15-20 short lists; launched one by one each leaves most of the 256 CUs idle.  Fields as in the

@@ -201,6 +201,7 @@ def lib():
     L.svt_hip_fwd_txfm_quant_batch_dev.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp, i32, C.POINTER(QuantParams),
                                                    C.POINTER(ScanTables), vp, vp, vp, vp, vp, vp]
     L.svt_hip_inv_txfm_add_batch_dev.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32]
+    L.svt_hip_iwht4x4_add_batch_dev.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32]
     L.svt_hip_fwd_txfm_quant_multi_dev.argtypes = [vp, i32, vp, i32]
     L.svt_hip_enc_txfm_multi_dev.argtypes = [vp, i32, i32, C.POINTER(EncTxJob), i32]
     L.svt_hip_inv_txfm_add_multi_dev.argtypes = [vp, i32, i32, vp, i32]

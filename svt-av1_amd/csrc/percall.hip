@@ -211,6 +211,57 @@ upsampled_pred_kernel(const uint8_t* __restrict__ ref, int rs, uint8_t* __restri
     }
 }
 
+
+// ---- the lossless 4x4 inverse: svt_av1_highbd_iwht4x4_16_add_c / svt_av1_highbd_iwht4x4_1_add_c (Common/Codec/EbInvTransforms.c:2771-2857), selected by eob like
+// highbd_iwht4x4_add (:2858-2864).  One thread per block: 16 coefficients (four 16-byte loads), the reversible Walsh-Hadamard butterfly along rows then columns
+// (3.5 adds and half a shift per sample, no multiplications), added to the prediction and clipped to the bit depth.  UNIT_QUANT_SHIFT = 2 (EbInvTransforms.h:23).
+__device__ __forceinline__ void iwht4(int& a1, int& b1, int& c1, int& d1) {   // in: (a, c, d, b) as the reference names its inputs; out: the four outputs in order
+    a1 += c1; d1 -= b1;
+    const int e1 = (a1 - d1) >> 1;
+    b1 = e1 - b1; c1 = e1 - c1;
+    a1 -= b1; d1 += c1;
+}
+template <typename PIX>
+__global__ void __launch_bounds__(64)
+iwht4x4_add_kernel(const int32_t* __restrict__ dq, const uint16_t* __restrict__ eob, const PIX* pred, int ps, PIX* recon, int rs, const uint32_t* __restrict__ descs, int n, int bd) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    const uint32_t d = descs[b];
+    const int x = d & 0x3FFF, y = (d >> 14) & 0x3FFF, mx = (1 << bd) - 1;
+    const PIX* pr = pred + (size_t)y * ps + x; PIX* rc = recon + (size_t)y * rs + x;
+    int o[4][4];   // [row][column] of the residual
+    if (!eob || eob[b] > 1) {
+        const int4* q = (const int4*)(dq + (size_t)b * 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // rows: ip[0], ip[1], ip[2], ip[3] play a, c, d, b
+            const int4 v = q[i];
+            int a1 = v.x >> 2, c1 = v.y >> 2, d1 = v.z >> 2, b1 = v.w >> 2;
+            iwht4(a1, b1, c1, d1);
+            o[i][0] = a1; o[i][1] = b1; o[i][2] = c1; o[i][3] = d1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // columns
+            int a1 = o[0][i], c1 = o[1][i], d1 = o[2][i], b1 = o[3][i];
+            iwht4(a1, b1, c1, d1);
+            o[0][i] = a1; o[1][i] = b1; o[2][i] = c1; o[3][i] = d1;
+        }
+    } else {   // DC only
+        int a1 = dq[(size_t)b * 16] >> 2;
+        int e1 = a1 >> 1;
+        a1 -= e1;
+        const int t[4] = {a1, e1, e1, e1};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = t[i] >> 1, a = t[i] - e;
+            o[0][i] = a; o[1][i] = e; o[2][i] = e; o[3][i] = e;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) rc[(size_t)r * rs + c] = (PIX)min(max((int)pr[(size_t)r * ps + c] + o[r][c], 0), mx);
+}
+
 }  // namespace
 
 extern "C" {
@@ -257,6 +308,12 @@ int svt_hip_launch_handle_transform64(hipStream_t st, int tx_size, int32_t* coef
 int svt_hip_launch_upsampled_pred(hipStream_t st, const uint8_t* ref, int rs, uint8_t* dst, const void* blks, int n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(upsampled_pred_kernel, dim3(n), dim3(256), 0, st, ref, rs, dst, (const SvtHipUpsampledBlk*)blks);
+    return (int)hipGetLastError();
+}
+int svt_hip_launch_iwht4x4_add(hipStream_t st, int pix_bytes, int bd, const int32_t* dq, const uint16_t* eob, const void* pred, int ps, void* recon, int rs, const uint32_t* descs, int n) {
+    if (n <= 0) return 0;
+    if (pix_bytes == 1) hipLaunchKernelGGL((iwht4x4_add_kernel<uint8_t>), dim3((n + 63) / 64), dim3(64), 0, st, dq, eob, (const uint8_t*)pred, ps, (uint8_t*)recon, rs, descs, n, bd);
+    else hipLaunchKernelGGL((iwht4x4_add_kernel<uint16_t>), dim3((n + 63) / 64), dim3(64), 0, st, dq, eob, (const uint16_t*)pred, ps, (uint16_t*)recon, rs, descs, n, bd);
     return (int)hipGetLastError();
 }
 }

@@ -264,8 +264,17 @@ bool inv_generic(int ts, const int32_t* in, void* out_r, int stride_r, void* out
            svt_hip_inv_txfm_add_batch_dev(g_ctx, ts, pb, bd, d_c, d_r, (int)(pitch / pb), d_w, (int)(pitch / pb), d_desc, 1) == 0 &&
            down2d(out_w, (size_t)stride_w * pb, d_w, pitch, p, h);
 }
+// the lossless branch of svt_av1_highbd_inv_txfm_add_4x4 (EbInvTransforms.c:2870-2882): TX_4X4 only, the Walsh-Hadamard pair chosen by eob
+bool iwht_generic(const int32_t* in, const uint8_t* out_r, int stride_r, uint8_t* out_w, int stride_w, int eob, int bd) {
+    if (!g_ctx || bd != 8) return false;
+    int32_t* d_c = (int32_t*)dev(0, 64); uint8_t *d_r = (uint8_t*)dev(1, 16), *d_w = (uint8_t*)dev(3, 16); uint32_t* d_desc = (uint32_t*)dev(2, 16);
+    const uint32_t desc[2] = {SVT_HIP_TX_DESC(0, 0, 0), (uint32_t)(eob > 1 ? 2 : 1)};   // the eob (uint16_t) rides behind the descriptor
+    return d_c && d_r && d_w && d_desc && up(d_c, in, 64) && up2d(d_r, 4, out_r, (size_t)stride_r, 4, 4) && up(d_desc, desc, 8) &&
+           svt_hip_iwht4x4_add_batch_dev(g_ctx, 1, bd, d_c, (const uint16_t*)(d_desc + 1), d_r, 4, d_w, 4, d_desc, 1) == 0 && down2d(out_w, (size_t)stride_w, d_w, 4, 4, 4);
+}
 void inv_txfm_add_hip(const int32_t* dq, uint8_t* dst_r, int32_t sr, uint8_t* dst_w, int32_t sw, const SvtHipTxfmParam* tp) {
     Guard lk;   // svt_av1_inv_txfm_add_c (EbInvTransforms.c:3302): 8-bit destination through the high bit-depth inverse at bd = tp->bd
+    if (tp && tp->lossless && tp->tx_size == 0 && iwht_generic(dq, dst_r, sr, dst_w, sw, tp->eob, tp->bd)) return;
     if (tp && !tp->lossless && tp->tx_size < 19 && tp->tx_type < 16 && inv_generic(tp->tx_size, dq, dst_r, sr, dst_w, sw, tp->tx_type, tp->bd, 1)) return;
     FALLBACK("svt_av1_inv_txfm_add", svt_av1_inv_txfm_add, dq, dst_r, sr, dst_w, sw, tp);
 }

@@ -370,12 +370,22 @@ __device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
 // STORE: additionally leaves, per pixel, (flt0 - u) | (flt1 - u) << 16 (pairs[ep], int16 halves; sets 11 / 12 / 13 use the plane of 2 / 5 / 8), dat - src (sd,
 // int16) and per unit the sum of (dat - src)^2 (d2) for the on-device unit search (sgr_walk.hip): a probe pass then re-reads 6 bytes per pixel instead of
 // re-running the filters.
-template <typename PIX, int BD = 8, bool STORE = false>
+//
+// STORE == 2 (bit depth 8 only): the PACKED form the walk of sgr_walk.hip reads since round 6 -- ONE 32-bit word per sample and filter pair that carries all three
+// differences, [d1 : 11 | r_lo : 5 | d0 : 11 | r_hi : 5] with d0 = flt0 - u, d1 = flt1 - u (11-bit two's complement: |d| < 1024, i.e. the filter moved the sample by
+// less than 64 levels) and r = dat - src (10-bit two's complement split in two five-bit halves, so that `word & 0xFFE0FFE0` IS the pair (32 d0, 32 d1) the walk's
+// v_dot2_i32_i16 wants): 4 bytes per sample and set instead of 4 + 2 (shared), and no separate dat - src plane at all.  A sample whose d0 or d1 does not fit
+// (never seen on coded pictures: a large |flt - u| needs a large local variance, which makes the filter pass the sample through; binary test pictures do produce
+// them) is written as the zero word -- its error is then 0 for every candidate -- and appended, exactly, to the (unit, set)'s escape list (esc: [13 slots][dplane]
+// entries of (d0 | d1 << 16, r), a unit's list starts at its first sample's offset so the lists can never collide; esc_cnt: [unit][16] counters, zeroed by the
+// caller): the walk adds the listed samples one by one.  esc_lim (<= 1024) narrows the range for tests.
+template <typename PIX, int BD = 8, int STORE = 0>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
                    int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums,
                    uint32_t* __restrict__ pairs = nullptr, int16_t* __restrict__ sd = nullptr, int dstride = 0, size_t dplane = 0,
-                   unsigned long long* __restrict__ d2 = nullptr) {
+                   unsigned long long* __restrict__ d2 = nullptr, uint2* __restrict__ esc = nullptr, uint32_t* __restrict__ esc_cnt = nullptr, int esc_lim = 1024) {
+    static_assert(STORE != 2 || BD == 8, "the packed difference words hold bit depth 8 only");
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
@@ -384,6 +394,12 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
     const int tile = svt_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
     const int x0 = tile_x * S_TW, y0 = tile_y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
+    size_t esc_base = 0;   // first sample of this tile's unit in list order: (first row) x dstride + (first column) x (rows): units of a row band share the band's rows
+    if (STORE == 2) {
+        const int ui = unit / units_x, uj = unit - ui * units_x, uy0 = ui * unit_size, uh = ui == units_y - 1 ? ph - uy0 : unit_size;
+        const int v0 = max(uy0 - voff, 0), v1 = (uy0 + uh < ph) ? uy0 + uh - voff : uy0 + uh;
+        esc_base = (size_t)v0 * dstride + (size_t)(uj * unit_size) * (size_t)(v1 - v0);
+    }
 
     {
         const uint32_t A = tid == 0 ? 1u : (tid == 255 ? 256u : (uint32_t)((256 * tid + (tid + 1) / 2) / (tid + 1)));
@@ -414,7 +430,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         const int yy = min(max(y0 + i0 + r, 0), ph - 1), xx = min(x0 + j, pw - 1);
         SV[r] = ((int32_t)src[(size_t)yy * src_stride + xx] - (int32_t)X[r]) << 4;     // (src << 4) - u
         CX[r] = 256 - (int32_t)(X[r] << 13);                                           // rounding - (u << 9)
-        if (STORE && colvalid && r >= rlo && r < rhi) sd[(size_t)(y0 + i0 + r) * dstride + x0 + j] = (int16_t)(-(SV[r] >> 4));   // dat - src
+        if (STORE == 1 && colvalid && r >= rlo && r < rhi) sd[(size_t)(y0 + i0 + r) * dstride + x0 + j] = (int16_t)(-(SV[r] >> 4));   // dat - src
     }
     if (STORE) {   // sum of (dat - src)^2 over the unit: the constant term of the quadratic error model the walk speculates on
         int32_t q = 0;
@@ -443,11 +459,25 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
         if (BD == 8) {
             int32_t D0[8], D1[8];
             sgr8_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
-            if (STORE && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
+            if (STORE == 1 && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if (r >= rlo && r < rhi)
                         SGR_ST(&pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j], ((uint32_t)(has0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(has1 ? D1[r] : 0) << 16));
+            }
+            if (STORE == 2 && colvalid) {   // the packed word (see above); the rare sample that does not fit goes to the (unit, set)'s list
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (r >= rlo && r < rhi) {
+                        const int32_t d0 = has0 ? D0[r] : 0, d1 = has1 ? D1[r] : 0, rr = -(SV[r] >> 4);
+                        uint32_t wd = ((uint32_t)d1 << 21) | (((uint32_t)rr & 31u) << 16) | (((uint32_t)d0 & 0x7FFu) << 5) | (((uint32_t)rr >> 5) & 31u);
+                        if ((uint32_t)(d0 + esc_lim) >= 2u * (uint32_t)esc_lim || (uint32_t)(d1 + esc_lim) >= 2u * (uint32_t)esc_lim) {
+                            const uint32_t at = atomicAdd(&esc_cnt[(size_t)unit * 16 + ep], 1u);
+                            esc[(size_t)(ep < 11 ? ep : ep - 3) * dplane + esc_base + at] = make_uint2(((uint32_t)d0 & 0xFFFFu) | ((uint32_t)d1 << 16), (uint32_t)rr);
+                            wd = 0u;
+                        }
+                        SGR_ST(&pairs[(size_t)ep * dplane + (size_t)(y0 + i0 + r) * dstride + x0 + j], wd);
+                    }
             }
             int32_t h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
     #pragma unroll
@@ -471,7 +501,7 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
             // bit depth 10: |flt - u| < 2^14.1, a product < 2^28.1 -> four rows per int32 partial, 64-bit from the row reduction on
             int32_t D0[8], D1[8];
             sgr10_filter(abw, i0, j, X, CX, has0, has1, D0, D1);
-            if (STORE && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
+            if (STORE == 1 && colvalid) {   // (flt0 - u) | (flt1 - u) << 16: one dword per pixel and filter pair (64 lanes = 256 contiguous bytes per row)
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if (r >= rlo && r < rhi)
@@ -1246,13 +1276,22 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
 // the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip)
 extern "C" int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
                                                int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums,
-                                               uint32_t* pairs, int16_t* sd, int dstride, size_t dplane, int64_t* d2) {
+                                               uint32_t* pairs, int16_t* sd, int dstride, size_t dplane, int64_t* d2, void* esc, uint32_t* esc_cnt) {
     const int voff = 8 >> ss_y;
     dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
     unsigned long long* s = (unsigned long long*)sums;
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, true>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
-    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, true>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
+    if (esc) {   // packed difference words (bit depth 8)
+        if (bd != 8 || !esc_cnt) return (int)hipErrorInvalidValue;
+        const char* lim_env = getenv("SVT_HIP_SGR_ESC_LIM");   // read per launch: tests narrow the range so that ordinary content reaches the escape lists
+        int lim = lim_env ? atoi(lim_env) : 1024;
+        lim = lim < 1 ? 1 : (lim > 1024 ? 1024 : lim);
+        if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 2>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2, (uint2*)esc, esc_cnt, lim);
+        else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 2>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2, (uint2*)esc, esc_cnt, lim);
+        return (int)hipGetLastError();
+    }
+    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 1>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
+    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, 1>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
     return (int)hipGetLastError();
 }
 extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,

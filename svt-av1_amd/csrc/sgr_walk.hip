@@ -43,6 +43,7 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     const uint32_t* pairs; const int16_t* sd; const int64_t* sums; size_t dplane;
     int dstride, pw, ph, unit_size, units_x, units_y, voff; uint32_t ep_mask;
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
+    const uint2* esc; const uint32_t* esc_cnt;   // packed form only (sgr_walk_packed_kernel): the samples whose differences do not fit the packed word, per (unit, set)
 };
 struct WalkPic { WalkPlane p[3]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
 constexpr int kCache   = 256;    // evaluated points a walk can remember, see kThrottle
@@ -514,6 +515,32 @@ __device__ __forceinline__ void eval_chunk_f1(const int4& a0, const int4& a1, co
         : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
           [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "v"(q), [sel] "s"(sel));
 }
+// eval_chunk_f1 with the candidate's taps in a SCALAR register (each instruction still reads one scalar operand only) -- the packed walk's form: ONE int32 accumulator
+// per candidate (|e| <= 1010 at bit depth 8 and a data thread of the 512-thread instances sees <= 42 chunks = 336 samples: 336 x 2^20 < 2^31), the four squaring dots
+// chain through it (a dot may feed the next dot's accumulator back to back).  Against eval_chunk_f: sixteen vector registers fewer per pass.
+__device__ __forceinline__ void eval_chunk_f1s(const int4& a0, const int4& a1, const int (&c)[8], int q, int sel, int& p) {
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_dot2_i32_i16 %[t0], %[a0], %[q], %[c0]\n\t"
+        "v_dot2_i32_i16 %[t1], %[a1], %[q], %[c1]\n\t"
+        "v_dot2_i32_i16 %[t2], %[a2], %[q], %[c2]\n\t"
+        "v_dot2_i32_i16 %[t3], %[a3], %[q], %[c3]\n\t"
+        "v_dot2_i32_i16 %[t4], %[a4], %[q], %[c4]\n\t"
+        "v_dot2_i32_i16 %[t5], %[a5], %[q], %[c5]\n\t"
+        "v_dot2_i32_i16 %[t6], %[a6], %[q], %[c6]\n\t"
+        "v_dot2_i32_i16 %[t7], %[a7], %[q], %[c7]\n\t"
+        "v_perm_b32 %[t0], %[t1], %[t0], %[sel]\n\t"
+        "v_perm_b32 %[t2], %[t3], %[t2], %[sel]\n\t"
+        "v_perm_b32 %[t4], %[t5], %[t4], %[sel]\n\t"
+        "v_perm_b32 %[t6], %[t7], %[t6], %[sel]\n\t"
+        "v_dot2_i32_i16 %[p], %[t0], %[t0], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t2], %[t2], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t4], %[t4], %[p]\n\t"
+        "v_dot2_i32_i16 %[p], %[t6], %[t6], %[p]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [p] "+v"(p)
+        : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
+          [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "s"(q), [sel] "s"(sel));
+}
 __device__ __forceinline__ void dot_drain() { asm volatile("s_nop 2"); }
 // zero the pixels of a chunk at or past column n (n < 8): their error is then 0 for every candidate
 __device__ __forceinline__ void mask_chunk(int4& a0, int4& a1, int4& s, int n) {
@@ -875,6 +902,325 @@ sgr_walk_resident_kernel(const WalkPic a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same search on PACKED difference words (bit depth 8; sgr.hip, STORE == 2).  The walk above is bound by what a compute unit can stream: a pass re-reads
+// the 62 % of the unit that is not resident at 6 bytes per sample (3 passes per walk: ~0.9 MB per walk, ~2 GB per 4K frame, ~60 % of the achievable memory rate while
+// it runs).  Here a sample is ONE word [d1 : 11 | r_lo : 5 | d0 : 11 | r_hi : 5] -- both filter differences and dat - src -- so
+//   * a chunk of eight samples is 32 bytes instead of 48 and there is no dat - src plane;
+//   * the LDS that held the resident chunks' dat - src holds kL more chunks per data thread: (kJ + kL) x 448 x 8 = 43 008 samples = 66 % of a 256 x 256 unit are
+//     resident (38 % before), and the streamed rest costs 4 bytes per sample: 88 KB per pass instead of 245 KB;
+//   * the price is the unpacking, per sample and pass: `word & 0xFFE0FFE0` is the pair (32 d0, 32 d1) -- so the candidate's taps ride unscaled --, three more
+//     operations rebuild (dat - src) << 16 | 2^15, the dot product's accumulator.
+// Samples that do not fit the word are zero words in the plane (error 0 for every candidate) and sit in the (unit, set)'s escape list: every pass adds them one by one,
+// whatever their number (a binary test picture escapes everywhere: slow, exact).  Wave 0 is the walker of the kernel above, unchanged.
+template <int kT, int kL>
+struct PackLdsT {
+    WalkLds W;
+    int4    pk[kL * 2 * (kT - 64)];   // [slot][half][data thread]: four packed words each (a wave's 64 lanes are contiguous: the direct global -> LDS load's layout); the one-filter sets' histogram lives here instead
+};
+__device__ __forceinline__ void unpack_chunk(const int4& w0, const int4& w1, int4& a0, int4& a1, int (&c)[8]) {
+    const int w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    int pr[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        pr[i] = w[i] & (int)0xFFE0FFE0u;                                                      // (32 d0) | (32 d1) << 16
+        const int lo = (w[i] & 0x001F0000) | 0x8000;                                          // r_lo << 16 | 2^15
+        c[i] = (int)(((uint32_t)__builtin_amdgcn_sbfe(w[i], 0, 5) << 21) + (uint32_t)lo);     // + sext(r_hi) << 21
+    }
+    a0 = make_int4(pr[0], pr[1], pr[2], pr[3]); a1 = make_int4(pr[4], pr[5], pr[6], pr[7]);
+}
+__device__ __forceinline__ void mask_words(int4& w0, int4& w1, int n) {   // zero the words of a chunk at or past column n (n < 8)
+    int w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (i >= n) w[i] = 0;
+    w0 = make_int4(w[0], w[1], w[2], w[3]); w1 = make_int4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ int packed_r(int w) { return (int)((uint32_t)__builtin_amdgcn_sbfe(w, 0, 5) << 5) | ((w >> 16) & 31); }
+
+template <int kT, int kJ, int kL, int NA>
+__global__ void __launch_bounds__(kT, 4)
+sgr_walk_packed_kernel(const WalkPic a) {
+    constexpr int kResD = kT - 64, kResC = (kJ + kL) * kResD;   // data threads, resident chunks
+    __shared__ PackLdsT<kT, kL> R;
+    WalkLds& L = R.W;
+    const int z = blockIdx.z;
+    const uint32_t* __restrict__ pairs = a.p[z].pairs; const long long* __restrict__ sums = (const long long*)a.p[z].sums;
+    const int dstride = a.p[z].dstride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x, units_y = a.p[z].units_y, voff = a.p[z].voff;
+    const size_t dplane = a.p[z].dplane;
+    const uint32_t ep_mask = a.p[z].ep_mask;
+    int32_t* __restrict__ xqd_out = a.p[z].xqd_out; long long* __restrict__ err_out = (long long*)a.p[z].err_out; uint32_t* __restrict__ counters = a.p[z].counters;
+    uint8_t* __restrict__ best_ep = a.p[z].best_ep; int32_t* __restrict__ best_xqd = a.p[z].best_xqd; uint32_t* __restrict__ stats = a.p[z].stats;
+    const int cap = a.cap;
+    const int unit = blockIdx.x, ep = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (unit >= units_x * units_y || !((ep_mask >> ep) & 1)) return;
+    const int uj = unit % units_x, ui = unit / units_x;
+    const int x0 = uj * unit_size, w = uj == units_x - 1 ? pw - x0 : unit_size;
+    const int y0 = ui * unit_size, h = ui == units_y - 1 ? ph - y0 : unit_size;
+    const int v0 = max(y0 - voff, 0), v1 = (y0 + h < ph) ? y0 + h - voff : y0 + h;
+    const bool has0 = ep < 10 || ep >= 14, has1 = ep < 14;
+    const int  ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
+    const uint32_t* __restrict__ PP = pairs + (size_t)ce * dplane;
+    const long long* S = sums + ((size_t)unit * 16 + ep) * 5;
+    const int cw = (w + 7) >> 3, nchunk = cw * (v1 - v0);
+    // the one-filter sets are evaluated on a histogram over d as in the kernel above; |d| < 1024 here, so the window always covers the plane's samples and only the
+    // escape list can send a unit down the sample-by-sample path (more than kCache listed samples)
+    constexpr int kHistW = 1023;
+    static_assert((2 * kHistW + 1) * 8 <= (int)sizeof(R.pk), "the histogram lives in the resident chunks' storage");
+    const bool try_hist = !(has0 && has1) && a.hist_w >= 0;   // workgroup-uniform
+    const int  W = min(kHistW, a.hist_w);
+
+    if (wave == 0) {
+        // =================================== the walk: solve, replay, cache (as in sgr_walk_resident_kernel) ===================================
+        int start[2] = {0, 0};
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        unsigned long long c_replay = 0, c_load = 0, c_eval = 0;
+        __builtin_amdgcn_s_setprio(3);
+        solve_and_encode(S, w * (v1 - v0), ep, start);
+        __builtin_amdgcn_s_setprio(0);
+        RegStore K;
+#pragma unroll
+        for (int b = 0; b < kBanks; b++) { K.key[b] = -1; K.err[b] = 0; }
+        const bool whole = nchunk <= kResC;   // nothing to stream: a pass is arithmetic only and takes up to kMaxCand points (in groups of NA)
+        K.wkey = -1; K.lane = lane; K.n_cache = 0; K.nw = 0; K.cap = whole ? kMaxCand : cap; K.res_x = start[0]; K.res_y = start[1]; K.res_err = -1;
+        bool hist = false;
+        if (try_hist) { if (lane == 0) L.ovf_n = 0; __syncthreads(); }   // H
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        int n_pass = 0, n_eval = 0;
+        bool fin = false;
+        WalkState WS; walk_begin(WS, start);
+        const ModelSums MS = load_model(S);
+        int cap0 = K.cap;
+        for (int pass = 0; pass < kPassBudget; pass++) {
+            const unsigned long long r0 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_setprio(3);
+            K.cap = K.n_cache >= kThrottle ? 1 : cap0;
+            fin = replay<RegStore, false>(K, WS, ep, MS);
+            __builtin_amdgcn_s_setprio(0);
+            c_replay += __builtin_readcyclecounter() - r0;
+            if (try_hist && pass == 0) {   // H2
+                __syncthreads();
+                hist = ((volatile int&)L.ovf_n) <= kCache;
+                if (hist) cap0 = kMaxCand;
+            }
+            const int nc = K.nw;
+            if (lane == 0) { L.done = fin ? 1 : 0; L.n_want = nc; }
+            if (lane < nc) {   // svt_decode_xq (Common/Codec/EbRestoration.c:707-718)
+                const int x = (K.wkey & 255) - 128, y = (K.wkey >> 8) - 128;
+                L.xq0[lane] = has0 ? x : 0;
+                L.xq1[lane] = !has1 ? 0 : (has0 ? 128 - x - y : 128 - y);
+            }
+            const unsigned long long a0 = __builtin_readcyclecounter();
+            __syncthreads();   // A
+            const unsigned long long a1 = __builtin_readcyclecounter();
+            if (pass == 0) c_load = a1 - a0;
+            if (fin) break;
+            n_pass++; n_eval += nc;
+            __syncthreads();   // B
+            c_eval += __builtin_readcyclecounter() - a1;
+#pragma unroll
+            for (int b = 0; b < kBanks; b++) {
+                const int c = 64 * b + lane - K.n_cache;
+                const int k = __shfl(K.wkey, c & 63, 64);
+                if (c >= 0 && c < nc) {
+                    long long e = 0;
+#pragma unroll
+                    for (int v = 1; v < kT / 64; v++) e += L.part[v][c];
+                    K.key[b] = k; K.err[b] = e;
+                }
+            }
+            K.n_cache = min(K.n_cache + nc, kCache);
+        }
+        if (lane == 0) {
+            publish_walk(xqd_out, err_out, (size_t)unit * 16 + ep, K.res_x, K.res_y, fin ? K.res_err : -1);
+            atomicAdd(&stats[0], (uint32_t)n_pass); atomicAdd(&stats[1], (uint32_t)n_eval); if (!fin) atomicAdd(&stats[2], 1u);
+            if (hist) atomicAdd(&stats[3], 1u);
+            if (a.clocks) {
+                atomicAdd(&stats[24], (uint32_t)((c1 - c0) >> 6)); atomicAdd(&stats[25], (uint32_t)(c_replay >> 6)); atomicAdd(&stats[26], (uint32_t)(c_load >> 6));
+                atomicAdd(&stats[27], (uint32_t)(c_eval >> 6)); atomicAdd(&stats[28], (uint32_t)((__builtin_readcyclecounter() - c0) >> 6));
+            }
+            const uint32_t arrived = atomicAdd(&counters[unit], 1u) + 1u;
+            if (arrived == (uint32_t)__popc(ep_mask)) pick_unit_best(xqd_out, err_out, unit, ep_mask, best_ep, best_xqd);
+        }
+        return;
+    }
+    // =================================== the samples ===================================
+    const int t = tid - 64;
+    const int n_esc = (int)a.p[z].esc_cnt[(size_t)unit * 16 + ce];   // uniform
+    const uint2* __restrict__ EL = a.p[z].esc + (size_t)(ce < 11 ? ce : ce - 3) * dplane + (size_t)v0 * dstride + (size_t)x0 * (size_t)(v1 - v0);
+    auto chunk_off = [&](int k) { const int row = k / cw, cx = k - row * cw; return (size_t)(v0 + row) * dstride + x0 + 8 * cx; };
+    if (try_hist) {
+        unsigned long long* H = (unsigned long long*)&R.pk[0];
+        const int nb = 2 * W + 1;
+        for (int b = t; b < nb; b += kResD) H[b] = 0ull;
+        __syncthreads();   // H
+        unsigned long long r2 = 0;
+        auto take = [&](int d, int r) {
+            if (abs(d) <= W) atomicAdd(&H[d + W], (1ull << 40) | (unsigned long long)(uint32_t)(r + 1024));
+            else { const int at = atomicAdd(&L.ovf_n, 1); if (at < kCache) { L.cx[at] = d; L.cy[at] = r; } }
+            r2 += (unsigned long long)(uint32_t)(r * r);
+        };
+        int k = t;
+        int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
+        if (k < nchunk) { const size_t off = chunk_off(k); w0 = SGR_LD4(PP + off); w1 = SGR_LD4(PP + off + 4); }
+        while (k < nchunk) {
+            const int kn = k + kResD;
+            int4 n0 = make_int4(0, 0, 0, 0), n1 = n0;
+            if (kn < nchunk) { const size_t off = chunk_off(kn); n0 = SGR_LD4(PP + off); n1 = SGR_LD4(PP + off + 4); }
+            const int cx = k % cw, n = min(8, w - 8 * cx);
+            const int wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < n) take(has0 ? __builtin_amdgcn_sbfe(wd[i], 5, 11) : (wd[i] >> 21), packed_r(wd[i]));
+            w0 = n0; w1 = n1; k = kn;
+        }
+        // the listed samples: their plane words are zero (d = 0, dat - src = 0: they only raised bin 0's count -- harmless, q(0) = 0); the exact values join now
+        for (int o = t; o < n_esc; o += kResD) { const uint2 v = EL[o]; take(has0 ? (int)(int16_t)(v.x & 0xFFFFu) : ((int)v.x >> 16), (int)v.y); }
+        __syncthreads();   // H2
+        const int n_ovf = ((volatile int&)L.ovf_n);
+        if (n_ovf <= kCache) {
+            const long long r2w = wave_sum_u48((long long)r2);
+            for (int pass = 0; pass < kPassBudget; pass++) {
+                __syncthreads();   // A
+                if (L.done) break;
+                const int nc = L.n_want;
+                for (int c = 0; c < nc; c++) {
+                    const int xq = has0 ? L.xq0[c] : L.xq1[c];
+                    long long acc = 0;
+                    for (int b = t; b < nb; b += kResD) {
+                        const unsigned long long hh = H[b];
+                        const int nd = (int)(hh >> 40);
+                        if (nd) {
+                            const long long Rd = (long long)(hh & ((1ull << 40) - 1)) - 1024ll * nd;
+                            const int q = (xq * (b - W) + 1024) >> 11;
+                            acc += (long long)nd * (q * q) + 2ll * q * Rd;
+                        }
+                    }
+                    for (int o = t; o < n_ovf; o += kResD) {
+                        const int q = (xq * L.cx[o] + 1024) >> 11;
+                        acc += (long long)q * q + 2ll * q * L.cy[o];
+                    }
+                    const long long sum = wave_sum_i64(acc);
+                    if (lane == 0) L.part[wave][c] = sum + r2w;
+                }
+                __syncthreads();   // B
+            }
+            return;
+        }
+        // (a unit with more listed samples than that: nobody reads the histogram again, its storage takes resident chunks below)
+    }
+    // ---- the resident part: ALL of its loads are issued before the first one is consumed (unconditional, clamped addresses: a load under a condition is serialised).
+    // The kL chunks that live in LDS go there directly (global_load_lds_dwordx4: a wave's 64 lanes x 16 bytes land contiguously at a wave-uniform base), so they cost no
+    // registers while in flight; the kJ chunks of the registers follow.  A chunk past the unit's end is skipped by its thread in the sweeps (`mine`), a chunk that
+    // straddles the unit's right edge (unit widths are multiples of eight except in the last column of a picture whose width is not) is patched after the loads landed.
+    int4 pa[kJ], pb[kJ];
+    {
+        const int wbase = (wave - 1) * 64;
+#pragma unroll
+        for (int l = 0; l < kL; l++) {
+            const uint32_t* g = PP + chunk_off(min(t + (kJ + l) * kResD, max(nchunk - 1, 0)));
+            __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)&R.pk[(l * 2) * kResD + wbase], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g + 4, (__attribute__((address_space(3))) void*)&R.pk[(l * 2 + 1) * kResD + wbase], 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < kJ; j++) { const size_t off = chunk_off(min(t + j * kResD, max(nchunk - 1, 0))); pa[j] = SGR_LD4(PP + off); pb[j] = SGR_LD4(PP + off + 4); }
+#pragma unroll
+        for (int j = 0; j < kJ; j++) {
+            const int k = t + j * kResD, kc = min(k, max(nchunk - 1, 0)), cx = kc % cw;
+            const int n = k < nchunk ? w - 8 * cx : 0;
+            if (n < 8) mask_words(pa[j], pb[j], n);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct loads have landed (this thread's slots are read back by this thread only)
+        if ((w & 7) != 0) {
+#pragma unroll
+            for (int l = 0; l < kL; l++) {
+                const int k = t + (kJ + l) * kResD;
+                if (k < nchunk && w - 8 * (k % cw) < 8) {
+                    int4 l0 = R.pk[(l * 2) * kResD + t], l1 = R.pk[(l * 2 + 1) * kResD + t];
+                    mask_words(l0, l1, w - 8 * (k % cw));
+                    R.pk[(l * 2) * kResD + t] = l0; R.pk[(l * 2 + 1) * kResD + t] = l1;
+                }
+            }
+        }
+    }
+    int sel;
+    asm volatile("s_mov_b32 %0, 0x07060302" : "=s"(sel));
+    for (int pass = 0; pass < kPassBudget; pass++) {
+        __syncthreads();   // A
+        if (L.done) break;
+        const int nc = L.n_want;
+        const int qv = lane < nc ? (int)(((uint32_t)L.xq0[lane] & 0xFFFFu) | ((uint32_t)L.xq1[lane] << 16)) : 0;   // lane c: both taps of candidate c, UNSCALED (the pair carries the 32)
+        const unsigned long long e0 = __builtin_readcyclecounter();
+        for (int cb = 0; cb < nc; cb += NA) {   // a unit that is resident as a whole may ask for up to kMaxCand points: groups of NA
+            const int ng = min(nc - cb, NA);
+            int pp[NA], qq[NA];
+#pragma unroll
+            for (int c = 0; c < NA; c++) { pp[c] = 0; qq[c] = __builtin_amdgcn_readlane(qv, (cb + c) & 63); }   // qq: scalar registers
+            auto sweep = [&](const int4& w0, const int4& w1) {
+                int4 x0v, x1v; int sx[8];
+                unpack_chunk(w0, w1, x0v, x1v, sx);
+#pragma unroll
+                for (int c = 0; c < NA; c++)
+                    if (c < ng) eval_chunk_f1s(x0v, x1v, sx, qq[c], sel, pp[c]);
+            };
+            // ---- the streamed part first (next chunk's loads in flight while this one is evaluated)
+            int k = t + kResC;
+            int4 w0 = make_int4(0, 0, 0, 0), w1 = w0;
+            auto fetch = [&](int kk, int4& f0, int4& f1) {
+                const int row = kk / cw, cx = kk - row * cw;
+                const size_t off = (size_t)(v0 + row) * dstride + x0 + 8 * cx;
+                f0 = SGR_LD4(PP + off); f1 = SGR_LD4(PP + off + 4);
+                const int n = w - 8 * cx;
+                if (n < 8) mask_words(f0, f1, n);
+            };
+            if (k < nchunk) fetch(k, w0, w1);
+            while (k < nchunk) {
+                const int kn = k + kResD;
+                int4 n0 = make_int4(0, 0, 0, 0), n1 = n0;
+                if (kn < nchunk) fetch(kn, n0, n1);
+                sweep(w0, w1);
+                w0 = n0; w1 = n1; k = kn;
+            }
+            // ---- the chunks resident in LDS, then the ones in registers
+#pragma unroll
+            for (int l = 0; l < kL; l++) {
+                if ((kJ + l) * kResD < nchunk) {   // uniform: the slot is in use
+                    const bool mine = t + (kJ + l) * kResD < nchunk;
+                    int4 l0 = R.pk[(l * 2) * kResD + t], l1 = R.pk[(l * 2 + 1) * kResD + t];
+                    if (!mine) { l0 = make_int4(0, 0, 0, 0); l1 = l0; }   // a clamped load's copy of the last chunk: zero words add nothing
+                    sweep(l0, l1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < kJ; j++) {
+                if (j * kResD < nchunk) sweep(pa[j], pb[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dot_drain();
+            // ---- the listed samples, one by one (|e| <= 1010: the squares of a thread's share stay far below 2^63)
+            long long le[NA];
+#pragma unroll
+            for (int c = 0; c < NA; c++) le[c] = 0;
+            for (int o = t; o < n_esc; o += kResD) {
+                const uint2 v = EL[o];
+                const int d0 = (int)(int16_t)(v.x & 0xFFFFu), d1 = (int)v.x >> 16, rr = (int)v.y;
+#pragma unroll
+                for (int c = 0; c < NA; c++)
+                    if (c < ng) { const int e = ((L.xq0[cb + c] * d0 + L.xq1[cb + c] * d1 + 1024) >> 11) + rr; le[c] += (long long)(e * e); }
+            }
+#pragma unroll
+            for (int c = 0; c < NA; c++)
+                if (c < ng) {
+                    const long long sum = wave_sum_u48(le[c] + (long long)(uint32_t)pp[c]);
+                    if (lane == 0) L.part[wave][cb + c] = sum;
+                }
+        }
+        if (tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); if (pass == 0 && n_esc) atomicAdd(&stats[4], (uint32_t)n_esc); }   // [4]: listed samples the sample-by-sample walks of the plane added (diagnostics, tests)
+        __syncthreads();   // B
+    }
+}
+
 }  // namespace
 
 extern "C" size_t svt_hip_sgr_walk_state_bytes(int n_units) { return sizeof(uint32_t) * (size_t)n_units; }   // arrival counter per unit
@@ -908,8 +1254,19 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
         uint32_t* counters = (uint32_t*)P.states;
         // the arrival counters are zero: the caller clears the scratch up to the difference planes (svt_hip_api.cpp)
         a.p[i] = WalkPlane{P.pairs, P.sd, P.sums, P.dplane, P.dstride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, 8 >> P.ss_y, P.ep_mask,
-                           P.xqd_out, P.err_out, counters, P.best_ep, P.best_xqd, P.stats};
+                           P.xqd_out, P.err_out, counters, P.best_ep, P.best_xqd, P.stats, (const uint2*)P.esc, P.esc_cnt};
+        if ((P.esc != nullptr) != (planes[0].esc != nullptr)) return (int)hipErrorInvalidValue;   // one form per launch
         max_units = nu > max_units ? nu : max_units;
+    }
+    if (planes[0].esc) {   // packed difference words (bit depth 8, sgr.hip STORE == 2): 512 threads, 7 chunks per data thread in registers + 5 in LDS, eight points per pass
+        if (bd != 8) return (int)hipErrorInvalidValue;
+        static const char* pk_env = getenv("SVT_HIP_SGR_WALK_PACKED");   // A/B: "j6l5", "j7l5": more resident chunks per data thread in registers (they spill)
+        a.cap = cap_env >= 1 && cap_env <= kHybNA ? cap_env : kHybNA;
+        dim3 grid(max_units, 16, n_planes);
+        if (pk_env && !strcmp(pk_env, "j7l5")) hipLaunchKernelGGL((sgr_walk_packed_kernel<512, 7, 5, kHybNA>), grid, dim3(512), 0, st, a);
+        else if (pk_env && !strcmp(pk_env, "j6l5")) hipLaunchKernelGGL((sgr_walk_packed_kernel<512, 6, 5, kHybNA>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((sgr_walk_packed_kernel<512, 5, 5, kHybNA>), grid, dim3(512), 0, st, a);   // five in registers: the form that does not spill (six: 28 registers, seven: 44)
+        return (int)hipGetLastError();
     }
     if (stream_form) {
         for (int i = 0; i < n_planes; i++) {
@@ -957,7 +1314,7 @@ extern "C" int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* p
                                        const int64_t* d2, void* states, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask,
                                        int32_t* xqd_out, int64_t* err_out, uint8_t* best_ep, int32_t* best_xqd, uint32_t* stats) {
     (void)d2;
-    const SvtHipSgrWalkPlane P = {pairs, sd, sums, states, dplane, dstride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, xqd_out, err_out, best_ep, best_xqd, stats};
+    const SvtHipSgrWalkPlane P = {pairs, sd, sums, states, dplane, dstride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, xqd_out, err_out, best_ep, best_xqd, stats, nullptr, nullptr};
     return svt_hip_launch_sgr_walk_multi(st, bd, 1, &P);
 }
 

@@ -391,6 +391,19 @@ int svt_hip_inv_txfm_add_batch_dev(SvtHipCtx* c, int tx_size, int pix_bytes, int
     return SVT_HIP_OK;
 }
 
+int svt_hip_iwht4x4_add_batch_dev(SvtHipCtx* c, int pix_bytes, int bd, const int32_t* d_dqcoeff, const uint16_t* d_eob, const void* d_pred, int pred_stride,
+                                  void* d_recon, int recon_stride, const uint32_t* d_descs, int nblk) {
+    SVT_HIP_ENTER(c);
+    if (!c || !d_dqcoeff || !d_pred || !d_recon || !d_descs || nblk < 0 || (pix_bytes != 1 && pix_bytes != 2) || (bd != 8 && bd != 10) || (pix_bytes == 1 && bd != 8) ||
+        ((uintptr_t)d_dqcoeff & 15)) {
+        if (c) c->err = "svt_hip_iwht4x4_add_batch_dev: bad argument";
+        return SVT_HIP_ERR_BAD_ARG;
+    }
+    hipError_t e = (hipError_t)svt_hip_launch_iwht4x4_add(c->stream, pix_bytes, bd, d_dqcoeff, d_eob, d_pred, pred_stride, d_recon, recon_stride, d_descs, nblk);
+    if (e != hipSuccess) return fail(c, e, "iwht4x4_add launch");
+    return SVT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------------------- deblocking */
 int svt_hip_deblock_plane_dev(SvtHipCtx* c, void* d_plane, int pix_bytes, int stride, int bd, const uint16_t* d_edges_v,
                               const uint16_t* d_edges_h, int units_w, int units_h, int sharpness) {
@@ -921,7 +934,15 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
  * fixed number of times, a last launch writes the results and every unit's best set
  * No host synchronisation in between; the scratch (sums, arrival counters, difference planes) is the caller's. */
 namespace {
-struct SgrScratch { size_t stats, sums, d2, states, sd, pairs, total, dplane; int dstride, nu; };
+struct SgrScratch { size_t stats, sums, d2, states, esc_cnt, sd, pairs, esc, total, total_packed, dplane; int dstride, nu; };
+// SVT_HIP_SGR_PACKED=1 (bit depth 8 only) runs the unit search on PACKED difference words (one 32-bit word per sample and set in `pairs`, no dat - src plane; sgr.hip
+// STORE == 2, sgr_walk_packed_kernel).  A measured negative result, kept as the experiment it is (profiles/r06/sgr_packed_ab.txt): the form halves the walk's memory traffic and
+// raises its resident share from 38 % to 55-66 %, and the walk takes the same time -- its evaluation is bound by v_dot2 issue and by the one memory round trip per streamed chunk,
+// not by bytes -- while the filter kernel pays 0.1 ms per 4K frame for the packing.  The default stays the 6-byte form.
+static bool sgr_packed(int bd) {
+    const char* env = getenv("SVT_HIP_SGR_PACKED");   // read per call: tests run both forms in one process
+    return bd == 8 && env && env[0] == '1';
+}
 SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     SgrScratch L;
     L.nu = sgr_units(pw, unit_size) * sgr_units(ph, unit_size);
@@ -933,16 +954,21 @@ SgrScratch sgr_scratch_layout(int pw, int ph, int unit_size) {
     L.sums = o;     o = al(o + sizeof(int64_t) * (size_t)L.nu * 16 * 5);
     L.d2 = o;       o = al(o + sizeof(int64_t) * (size_t)L.nu);   // sum (dat - src)^2 per unit
     L.states = o;   o = al(o + svt_hip_sgr_walk_state_bytes(L.nu));   // per (unit, set): cache of evaluated points, points wanted next, result
-    L.sd = o;       o = al(o + sizeof(int16_t) * L.dplane);
+    L.esc_cnt = o;  o = al(o + sizeof(uint32_t) * (size_t)L.nu * 16);   // packed form: listed samples per (unit, set)
+    L.sd = o;       o = al(o + sizeof(int16_t) * L.dplane);            // everything before this is cleared per call
     L.pairs = o;    o = al(o + sizeof(uint32_t) * L.dplane * 16);
-    L.total = o;
+    // packed form: the escape lists, 13 filter pairs x one 8-byte entry per sample (the worst case -- every sample of a binary test picture -- is what the lists are
+    // sized for, so that there is no second code path for "too many"; coded pictures leave them empty and untouched)
+    L.esc = o;      L.total = o;   // the 6-byte form ends here
+    L.total_packed = al(o + sizeof(uint64_t) * L.dplane * 13);
     return L;
 }
 }  // namespace
 
 size_t svt_hip_sgr_search_units_scratch_bytes(int pw, int ph, int unit_size) {
     if (pw <= 0 || ph <= 0 || unit_size < 64 || (unit_size & 63)) return 0;
-    return sgr_scratch_layout(pw, ph, unit_size).total;
+    const SgrScratch L = sgr_scratch_layout(pw, ph, unit_size);
+    return sgr_packed(8) ? L.total_packed : L.total;   // the packed experiment's lists count only while it is switched on
 }
 
 int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const void* d_dgd, int stride, const void* d_src, int src_stride, int pw,
@@ -956,20 +982,22 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
         return SVT_HIP_ERR_BAD_ARG;
     }
     const SgrScratch L = sgr_scratch_layout(pw, ph, unit_size);
-    if (scratch_bytes < L.total) {
+    if (scratch_bytes < (sgr_packed(bd) ? L.total_packed : L.total)) {
         c->err = "svt_hip_sgr_search_units_plane_dev: scratch smaller than svt_hip_sgr_search_units_scratch_bytes()";
         return SVT_HIP_ERR_BAD_ARG;
     }
     char* base = (char*)d_scratch;
     HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // statistics, sums, per-unit squared differences, the walk's arrival counters (one fill for all of them)
     const int ux = sgr_units(pw, unit_size), uy = sgr_units(ph, unit_size);
+    const bool packed = sgr_packed(bd);
     hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, d_dgd, stride, d_src, src_stride, pw, ph, unit_size, ux, uy, ss_y, ep_mask,
                                                               (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
-                                                              (int64_t*)(base + L.d2));
+                                                              (int64_t*)(base + L.d2), packed ? base + L.esc : nullptr, (uint32_t*)(base + L.esc_cnt));
     if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
-    e = (hipError_t)svt_hip_launch_sgr_walk(c->stream, bd, (const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), L.dstride, L.dplane,
-                                            (const int64_t*)(base + L.sums), (const int64_t*)(base + L.d2), base + L.states, pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd,
-                                            d_err, d_best_ep, d_best_xqd, (uint32_t*)(base + L.stats));
+    const SvtHipSgrWalkPlane wp = {(const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), (const int64_t*)(base + L.sums), base + L.states, L.dplane, L.dstride,
+                                   pw, ph, unit_size, ux, uy, ss_y, ep_mask, d_xqd, d_err, d_best_ep, d_best_xqd, (uint32_t*)(base + L.stats),
+                                   packed ? base + L.esc : nullptr, (const uint32_t*)(base + L.esc_cnt)};
+    e = (hipError_t)svt_hip_launch_sgr_walk_multi(c->stream, bd, 1, &wp);
     if (e != hipSuccess) return fail(c, e, "sgr walk launch");
     return SVT_HIP_OK;
 }
@@ -988,19 +1016,21 @@ int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, in
             return SVT_HIP_ERR_BAD_ARG;
         }
         const SgrScratch L = sgr_scratch_layout(P.pw, P.ph, P.unit_size);
-        if (P.scratch_bytes < L.total) {
+        if (P.scratch_bytes < (sgr_packed(bd) ? L.total_packed : L.total)) {
             c->err = "svt_hip_sgr_search_units_picture_dev: scratch smaller than svt_hip_sgr_search_units_scratch_bytes()";
             return SVT_HIP_ERR_BAD_ARG;
         }
         char* base = (char*)P.d_scratch;
         HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // ... and the walk's arrival counters
         const int ux = sgr_units(P.pw, P.unit_size), uy = sgr_units(P.ph, P.unit_size);
+        const bool packed = sgr_packed(bd);
         hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, ux, uy, P.ss_y,
                                                                   ep_mask, (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
-                                                                  (int64_t*)(base + L.d2));
+                                                                  (int64_t*)(base + L.d2), packed ? base + L.esc : nullptr, (uint32_t*)(base + L.esc_cnt));
         if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
         wp[i] = SvtHipSgrWalkPlane{(const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), (const int64_t*)(base + L.sums), base + L.states, L.dplane, L.dstride,
-                                   P.pw, P.ph, P.unit_size, ux, uy, P.ss_y, ep_mask, P.d_xqd, P.d_err, P.d_best_ep, P.d_best_xqd, (uint32_t*)(base + L.stats)};
+                                   P.pw, P.ph, P.unit_size, ux, uy, P.ss_y, ep_mask, P.d_xqd, P.d_err, P.d_best_ep, P.d_best_xqd, (uint32_t*)(base + L.stats),
+                                   packed ? base + L.esc : nullptr, (const uint32_t*)(base + L.esc_cnt)};
     }
     hipError_t e = (hipError_t)svt_hip_launch_sgr_walk_multi(c->stream, bd, n_planes, wp);
     if (e != hipSuccess) return fail(c, e, "sgr walk launch");
@@ -1021,7 +1051,7 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_
         const SgrScratch L = sgr_scratch_layout(P.pw, P.ph, P.unit_size);
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         off[k].nu = L.nu;
-        off[k].scratch = need; need = al(need + L.total);
+        off[k].scratch = need; need = al(need + (sgr_packed(bd) ? L.total_packed : L.total));
         off[k].xqd = need;     need = al(need + sizeof(int32_t) * (size_t)L.nu * 32);
         off[k].err = need;     need = al(need + sizeof(int64_t) * (size_t)L.nu * 16);
         off[k].best = need;    need = al(need + (size_t)L.nu);
@@ -1038,7 +1068,7 @@ int svt_hip_sgr_search_units_picture(SvtHipCtx* c, int pix_bytes, int bd, int n_
         const SvtHipSgrSearchPlane& P = planes[k];
         const int rc = svt_hip_sgr_search_units_plane_dev(c, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, P.ss_y, P.ep_mask,
                                                           (int32_t*)(dev + off[k].xqd), (int64_t*)(dev + off[k].err), (uint8_t*)(dev + off[k].best), nullptr,
-                                                          dev + off[k].scratch, sgr_scratch_layout(P.pw, P.ph, P.unit_size).total);
+                                                          dev + off[k].scratch, sgr_packed(bd) ? sgr_scratch_layout(P.pw, P.ph, P.unit_size).total_packed : sgr_scratch_layout(P.pw, P.ph, P.unit_size).total);
         if (rc != SVT_HIP_OK) return rc;
     }
     for (int k = 0; k < n_planes; k++) {

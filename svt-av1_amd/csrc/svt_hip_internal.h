@@ -119,7 +119,7 @@ int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void*
                               int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums);
 int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
                                     int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
-                                    int dstride, size_t dplane, int64_t* d2);
+                                    int dstride, size_t dplane, int64_t* d2, void* esc, uint32_t* esc_cnt);   /* esc != NULL (bit depth 8 only): packed words + escape lists */
 int svt_hip_launch_wiener_init(hipStream_t st, int win, int n_units, const int64_t* M, const int64_t* H, int16_t* unit_wiener, uint8_t* active, int8_t* status);
 int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes);
 size_t svt_hip_sgr_walk_state_bytes(int n_units);
@@ -127,6 +127,7 @@ typedef struct {
     const uint32_t* pairs; const int16_t* sd; const int64_t* sums; void* states; size_t dplane;
     int dstride, pw, ph, unit_size, units_x, units_y, ss_y; uint32_t ep_mask;
     int32_t* xqd_out; int64_t* err_out; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
+    const void* esc; const uint32_t* esc_cnt;   /* non-NULL: `pairs` holds the PACKED words of sgr_search8_kernel<.., 2> (bit depth 8), esc / esc_cnt its escape lists; sd is unused */
 } SvtHipSgrWalkPlane;
 int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_planes, const SvtHipSgrWalkPlane* planes);
 int svt_hip_launch_sgr_walk(hipStream_t st, int bd, const uint32_t* pairs, const int16_t* sd, int dstride, size_t dplane, const int64_t* sums, const int64_t* d2,
@@ -139,6 +140,7 @@ int svt_hip_launch_sgr_apply(hipStream_t st, int pix_bytes, int bd, const void* 
 int svt_hip_launch_quantize_blocks(hipStream_t st, const int32_t* coeff, int n, int nblk, const SvtHipQuantParams* qp, const int16_t* iscan, int32_t* qcoeff,
                                    int32_t* dqcoeff, uint16_t* eob);
 int svt_hip_launch_residual(hipStream_t st, int pix_bytes, const void* src, int ss, const void* pred, int ps, int16_t* res, int rs, int w, int h);
+int svt_hip_launch_iwht4x4_add(hipStream_t st, int pix_bytes, int bd, const int32_t* dq, const uint16_t* eob, const void* pred, int ps, void* recon, int rs, const uint32_t* descs, int n);
 int svt_hip_launch_ext_all_sad(hipStream_t st, const uint8_t* src, int ss, const uint8_t* ref, int rs, const void* jobs, int n, uint32_t* state);
 int svt_hip_launch_ext_eight_sad_32_64(hipStream_t st, const uint32_t* mvs, int n, uint32_t* state);
 int svt_hip_launch_interm_var(hipStream_t st, const uint8_t* plane, int stride, const int32_t* offs, int n, uint64_t* mean, uint64_t* mean_sq);

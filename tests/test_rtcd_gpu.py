@@ -516,6 +516,14 @@ def test_per_call_forms_vs_reference_c(rtcd, ref):
         tp = TxfmParam(tt, ts, 0, 8, 0, 0, kw * kh)
         ref.svt_av1_inv_txfm_add_c(_vp(cfull), _vp(pred), w + 5, _vp(e), w + 2, C.byref(tp)); rtcd.svt_av1_inv_txfm_add(_vp(cfull), _vp(pred), w + 5, _vp(g), w + 2, C.byref(tp))
         assert np.array_equal(e, g), ("inv_txfm_add", ts)
+    # --- ... and its lossless branch (TxfmParam.lossless: TX_4X4 through the Walsh-Hadamard pair, chosen by eob; EbInvTransforms.c:2858-2882)
+    for eob in (16, 5, 1, 0):
+        cfull = rng.integers(-4096, 4097, 16).astype(np.int32)
+        pred = rng.integers(0, 256, (4, 9)).astype(np.uint8); pred[0, :4] = 255; pred[1, :4] = 0
+        e = np.zeros((4, 6), np.uint8); g = e.copy()
+        tp = TxfmParam(0, 0, 1, 8, 0, 0, eob)
+        ref.svt_av1_inv_txfm_add_c(_vp(cfull), _vp(pred), 9, _vp(e), 6, C.byref(tp)); rtcd.svt_av1_inv_txfm_add(_vp(cfull), _vp(pred), 9, _vp(g), 6, C.byref(tp))
+        assert np.array_equal(e, g), ("inv_txfm_add lossless", eob)
 
 
 def test_compound_warp_vs_reference_c(rtcd, ref):

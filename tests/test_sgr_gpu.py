@@ -472,6 +472,51 @@ def test_search_units_histogram_evaluation_and_its_fallback(hip, orc, bd, window
     else: assert 0 < stats[3] < nu * 6, stats[:4]               # some of them, the others sample by sample
 
 
+@pytest.mark.parametrize("lim", [None, 48, 3])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_search_units_packed_words_and_escape_lists(hip, orc, lim, ss):
+    """SVT_HIP_SGR_PACKED=1 (an opt-in experiment, bit depth 8) runs the unit search on PACKED difference words (sgr.hip STORE == 2, sgr_walk_packed_kernel): d0 / d1 as 11-bit fields, dat - src as 10 bits, a sample
+    whose |flt - u| does not fit is a zero word in the plane and an exact entry of the (unit, set)'s escape list.  The right half of the picture is binary 0 / 255 (which
+    escapes at the real limit of 1024 as well); SVT_HIP_SGR_ESC_LIM (read per launch) narrows the range so that ordinary samples are listed too: 48 lists a few per cent,
+    3 nearly everything -- the walk then is the sample-by-sample sum of the lists.  All 16 sets against the oracle, for this form and for the default 6-byte form."""
+    bd = 8
+    w, h, US, mask = 424, 328, 128, 0xFFFF   # 3 x 3 units, last column 168 wide (not a multiple of 64), last row 72 + 128
+    mx = 255
+    src, ext = _smooth_noisy(w, h, bd, 1500 + ss, 5)
+    rng = np.random.default_rng(1600 + ss)
+    ext[EXT:EXT + h, EXT + w // 2:EXT + w] = (mx * rng.integers(0, 2, (h, w - w // 2))).astype(ext.dtype)
+    ext[:, EXT + w:] = ext[:, EXT + w - 1:EXT + w]; ext[:EXT, :] = ext[EXT:EXT + 1, :]; ext[EXT + h:, :] = ext[EXT + h - 1:EXT + h, :]
+    st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+    nu = units(w, US) * units(h, US)
+    e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+    orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+    L = hip.L
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    os.environ["SVT_HIP_SGR_PACKED"] = "1"   # the size with the experiment's escape lists
+    try: nbytes = L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+    finally: os.environ.pop("SVT_HIP_SGR_PACKED", None)
+    assert nbytes > L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+    d_ext, d_src = hip.to_device(ext), hip.to_device(src)
+    d_scr = hip.empty(nbytes); d_xqd = hip.empty(nu * 16 * 8); d_err = hip.empty(nu * 16 * 8); d_best = hip.empty(nu); d_bx = hip.empty(nu * 8)
+    listed = {}
+    for form in ("packed", "six_byte"):
+        if lim is not None: os.environ["SVT_HIP_SGR_ESC_LIM"] = str(lim)
+        if form == "packed": os.environ["SVT_HIP_SGR_PACKED"] = "1"
+        try:
+            hip.check(L.svt_hip_sgr_search_units_plane_dev(hip.h, ext.itemsize, bd, d_ext.value + off, st, d_src, w, w, h, US, ss, mask, d_xqd, d_err, d_best, d_bx, d_scr, nbytes), "units dev")
+        finally:
+            os.environ.pop("SVT_HIP_SGR_ESC_LIM", None); os.environ.pop("SVT_HIP_SGR_PACKED", None)
+        g_xqd = hip.to_host(d_xqd, e_xqd.shape, np.int32); g_err = hip.to_host(d_err, e_err.shape, np.int64); g_best = hip.to_host(d_best, e_best.shape, np.uint8)
+        stats = hip.to_host(d_scr, (32,), np.uint32)   # [2] unfinished walks, [4] listed samples the sample-by-sample walks added
+        assert np.array_equal(g_err, e_err), (form, lim, np.argwhere(g_err != e_err)[:8])
+        assert np.array_equal(g_xqd, e_xqd) and np.array_equal(g_best, e_best), (form, lim)
+        assert stats[2] == 0
+        listed[form] = int(stats[4])
+    hip.free(d_ext, d_src, d_scr, d_xqd, d_err, d_best, d_bx)
+    assert listed["six_byte"] == 0
+    if lim is not None: assert listed["packed"] > (w * h if lim == 3 else 1000), listed   # lim 3: most samples of most two-filter sets are listed
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_search_units_picture_dev(hip, pkg, orc, bd):
     """svt_hip_sgr_search_units_picture_dev: three planes of different sizes / unit sizes / set masks in one call (one walk launch for the picture:

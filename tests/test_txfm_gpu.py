@@ -338,3 +338,38 @@ def test_inverse_full_range_vs_reference_c(hip, pkg, ref, ts):
                 p16 = np.ascontiguousarray(pred[:, i * w:(i + 1) * w].astype(np.uint16)); exp = np.zeros((h, w), np.uint16)
                 tc.ref_inv(ref, cfull, p16, w, exp, w, tt, ts, bd)
                 assert np.array_equal(rec[:, i * w:(i + 1) * w].astype(np.uint16), exp), ("inverse full range", ts, tt, bd, i)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_lossless_iwht4x4_vs_reference_c(hip, pkg, ref, bd):
+    """svt_hip_iwht4x4_add_batch_dev against svt_av1_highbd_iwht4x4_16_add_c / svt_av1_highbd_iwht4x4_1_add_c (EbInvTransforms.c:2771-2857), the pair highbd_iwht4x4_add
+    chooses between by eob: random coefficients over the full range a 4x4 lossless block can carry, saturated ones (the sums then clip at both ends of the pixel range),
+    DC-only blocks down both branches, 8-bit planes at bd 8 as well as 16-bit ones."""
+    rng = np.random.default_rng(910 + bd)
+    top = (1 << bd) - 1
+    n = 96
+    lim = (top + 1) * 16 * 4   # forward WHT of a +-top residual, scaled by UNIT_QUANT_FACTOR
+    co = rng.integers(-lim, lim + 1, (n, 16)).astype(np.int32)
+    co[0] = lim; co[1] = -lim; co[2] = 0; co[3, 1:] = 0; co[4, 1:] = 0; co[4, 0] = -lim; co[5] = rng.choice([-lim, lim], 16)
+    eob = np.full(n, 16, np.uint16); eob[3] = 1; eob[4] = 1; eob[6] = 0; eob[7] = 1   # 6 / 7: the DC form on blocks that DO have other coefficients (the reference reads ip[0] only)
+    eob[8:] = rng.integers(0, 17, n - 8)
+    for pix in ((1, 2) if bd == 8 else (2,)):
+        dt = np.uint8 if pix == 1 else np.uint16
+        pred = rng.integers(0, top + 1, (4, 4 * n + 3)).astype(dt)
+        pred[:, :8] = top; pred[:, 8:16] = 0
+        descs = np.asarray([pkg.tx_desc(4 * i, 0, 0) for i in range(n)], np.uint32)
+        d_c, d_e, d_p, d_d = hip.to_device(co), hip.to_device(eob), hip.to_device(pred), hip.to_device(descs)
+        d_r = hip.to_device(np.zeros_like(pred))
+        hip.check(hip.L.svt_hip_iwht4x4_add_batch_dev(hip.h, pix, bd, d_c, d_e, d_p, pred.shape[1], d_r, pred.shape[1], d_d, n), "iwht")
+        rec = hip.to_host(d_r, pred.shape, dt)
+        # the same list with d_eob NULL: every block takes the 16-coefficient form
+        hip.check(hip.L.svt_hip_iwht4x4_add_batch_dev(hip.h, pix, bd, d_c, None, d_p, pred.shape[1], d_r, pred.shape[1], d_d, n), "iwht (no eob)")
+        rec16 = hip.to_host(d_r, pred.shape, dt)
+        hip.free(d_c, d_e, d_p, d_d, d_r)
+        for i in range(n):
+            p16 = np.ascontiguousarray(pred[:, 4 * i:4 * i + 4].astype(np.uint16))
+            for form, got in ((int(eob[i]) > 1, rec), (True, rec16)):
+                exp = np.zeros((4, 4), np.uint16)
+                f = ref.svt_av1_highbd_iwht4x4_16_add_c if form else ref.svt_av1_highbd_iwht4x4_1_add_c
+                f(C.c_void_p(co[i].ctypes.data), C.c_void_p(p16.ctypes.data >> 1), 4, C.c_void_p(exp.ctypes.data >> 1), 4, bd)   # CONVERT_TO_BYTEPTR
+                assert np.array_equal(got[:, 4 * i:4 * i + 4].astype(np.uint16), exp), ("iwht4x4", bd, pix, i, int(eob[i]), form)
