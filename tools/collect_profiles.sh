@@ -11,6 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 # one frame per step on one stream, so that a kernel's trace duration is its own (the default bench overlaps the kernels of several frames on forked streams)
 BENCH="python $R/bench.py --steps 12 --warmup 2 --frames 1 --groups 4 --no-sweep --no-transfers --no-cpu-baseline --no-variants"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH > $OUT/stats.log 2>&1
+# ... and the TIMED configuration itself (four frames per step on four streams: a kernel's duration here includes what it shares the chip with) -> kernel_stats_f4.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f4 -o k -- python $R/bench.py --steps 12 --warmup 2 --no-sweep --no-transfers --no-cpu-baseline --no-variants --no-1080p > $OUT/stats_f4.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1

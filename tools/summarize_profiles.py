@@ -1,8 +1,9 @@
 """Summarise gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>/:
   kernel_stats.csv   rocprofv3 --stats per-kernel table (as written by rocprofv3)
-  pmc_traffic.json   per kernel: launches, average duration (us), FETCH_SIZE / WRITE_SIZE per launch in bytes (raw counter x 1024;
-                     the gfx950 caveats of /opt/skills/guides/MI355X_MICROARCH.md 'HBM' apply: wide coalesced reads are under-counted 2x,
-                     Infinity-Cache hits are included) and the SQ counters of the same step
+  pmc_traffic.json   per kernel: launches, average duration (us), FETCH_SIZE / WRITE_SIZE per launch in bytes (RAW counter x 1024: the factors of
+                     profiles/<round>/counter_calibration.json -- FETCH_SIZE x 2.0, WRITE_SIZE x 1.0 at every access width, measured by tools/calibrate_counters.sh --
+                     are applied by tools/roofline_defs.py when it forms a stage's traffic; Infinity-Cache hits are included) and the SQ counters of the same step
+  kernel_stats_f4.csv  rocprofv3 --stats of the TIMED configuration (four frames per step on four streams)
   bench.json         the bench line of the same build without the profiler
   roofline.json      the bench line's `roofline` object recomputed from THESE files alone (tools/roofline_defs.py: stage time = summed rocprofv3 durations of
                      its kernels per frame; issued lane-operations = SQ_INSTS_VALU x 64; traffic = FETCH_SIZE + WRITE_SIZE) -- bench.py's live object uses
@@ -45,6 +46,8 @@ def durations(dirname):
 
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "stats_f4", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, "kernel_stats_f4.csv"))   # the timed F = 4 step (kernels of four frames overlap: durations include the sharing)
 dur = durations("stats")
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 res = {}
