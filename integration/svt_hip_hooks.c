@@ -54,6 +54,9 @@ void svt_hip_hooks_segments(uint32_t luma_width, uint32_t luma_height, uint32_t 
     if (in_list(hooks, "me") || in_list(hooks, "hme")) {
         if (cols < *me_cols) *me_cols = cols;
         if (rows < *me_rows) *me_rows = rows;
+        /* SVT_HIP_ME_SEG=<columns>x<rows>: the ME segment grid outright (A/B runs: a segment is one launch per level and reference picture, tools/encoder_walltime.sh) */
+        unsigned c = 0, r = 0;
+        if (getenv("SVT_HIP_ME_SEG") && sscanf(getenv("SVT_HIP_ME_SEG"), "%ux%u", &c, &r) == 2 && c >= 1 && r >= 1 && c <= sb_cols && r <= sb_rows) { *me_cols = c; *me_rows = r; }
     }
     if (in_list(hooks, "tf") || in_list(hooks, "tf_me")) {
         if (cols < *tf_cols) *tf_cols = cols;
@@ -467,11 +470,13 @@ void svt_hip_hooks_enc_predeinit(void) {
             for (int i = 0; i < g_pool_n; i++) pthread_mutex_lock(&g_pool_mu[i]);
             (void)svt_hip_sync(g_ctx);
             for (int i = 0; i < g_pool_n; i++) (void)svt_hip_sync(g_pool[i]);
+            svt_hip_md_bridge_quiesce();   /* hook "md_pre" issues on its own context */
             g_early_unpins++;
         }
         svt_hip_resident_unpin_all(g_ctx, others);
         svt_hip_lf_bridge_unpin(g_ctx, others);
         if (others) {
+            svt_hip_md_bridge_resume();
             for (int i = g_pool_n - 1; i >= 0; i--) pthread_mutex_unlock(&g_pool_mu[i]);
             pthread_mutex_unlock(&g_lock);
         }

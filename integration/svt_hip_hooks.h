@@ -84,7 +84,9 @@ long long svt_hip_hooks_now_ns(void);
 void      svt_hip_hooks_time(int which, long long t0_ns);
 void svt_hip_lf_bridge_release(SvtHipCtx *hip);   /* svt_hip_lf_bridge.c */
 void svt_hip_lf_bridge_unpin(SvtHipCtx *hip, int keep_pinning);   /* svt_hip_lf_bridge.c: the reconstructed pictures' host buffers stop being page-locked; keep_pinning: later pictures are registered again */
-void svt_hip_md_bridge_release(SvtHipCtx *hip);   /* svt_hip_md_bridge.c */
+void svt_hip_md_bridge_release(SvtHipCtx *hip);
+void svt_hip_md_bridge_quiesce(void);   /* md_pre's own context: no new issue, nothing in flight (svt_hip_hooks_enc_predeinit) */
+void svt_hip_md_bridge_resume(void);   /* svt_hip_md_bridge.c */
 int  svt_hip_hook_enabled(int which);
 int  svt_hip_hooks_device(void);   /* the GPU ordinal the hooks' contexts were made on (bridges that keep a context of their own) */
 /* the context every hook launches on, with the lock that serialises the process threads on it (NULL: no device / init failed) */

@@ -596,16 +596,20 @@ void svt_hip_hook_md_subpel_end(void) { tls_sp.valid = 0; }
  * nor the reference pictures (complete: the picture manager starts a picture only when its references are), nor the ME vectors depend on a neighbouring block,
  * so svt_hip_hook_md_pre_picture — called once per picture by mode_decision_configuration_kernel, right before it posts the picture to the mode-decision threads
  * (EbModeDecisionConfigurationProcess.c:1058) — computes the SAD of every (superblock, square PU, reference picture) in ONE launch
- * (svt_hip_md_fullpel_sad_picture_dev) into a table in page-locked host memory.  The configuration thread waits for it (one upload of the vectors, one launch, one
- * download, on a pool context); it is a different thread from the mode-decision threads, which are busy with the pictures before this one, so no block ever waits
- * for the device.  fast_loop_core then asks svt_hip_hook_md_pre_lookup: a candidate whose (PU, reference, vector) is in the table takes its distortion from there and
- * is NOT predicted.  The rate, the candidate order, every decision stay the reference's.
+ * (svt_hip_md_fullpel_sad_picture_dev) into a table in page-locked host memory.  NOBODY WAITS for it: the configuration thread queues the upload of the vectors, the
+ * launches and the downloads of the tables on a context of the hook's own (g_pre_ctx, under g_pre_issue_mu) and returns; behind the last download a sequence word
+ * travels to the device and back into the slot's page-locked flags[1].  A table is READY when flags[1] equals the slot's sequence number (pre_done) -- the copies of
+ * sad / bisad / grid were queued before the word on the same stream, so they have landed when it has, and the mode-decision threads see them through the same
+ * page-locked mapping (the word is read with acquire semantics).  A block that asks before that is a MISS and runs the reference's own code: early blocks of a picture
+ * may miss, no block ever waits for the device.  fast_loop_core asks svt_hip_hook_md_pre_lookup: a candidate whose (PU, reference, vector) is in a ready table takes its
+ * distortion from there and is NOT predicted.  The rate, the candidate order, every decision stay the reference's.
  *
  * The prediction samples of such a candidate are made later, and only if somebody reads them: full_loop_core (:5820) reuses stage 0's prediction when
  * md_staging_perform_inter_pred is off (always in PD_PASS_0, whose MD_STAGING_MODE_0 has no later prediction; stages 1 / 2 of the other modes) — the patched
  * full_loop_core asks svt_hip_hook_md_pre_take(candidate_buffer) and, if the buffer still carries the mark, runs the reference's own predictor with stage 0's settings
  * right there (the survivors of stage 0: one or two per block instead of every candidate).  The mark is a thread-local direct-mapped set of buffer addresses, cleared
- * whenever fast_loop_core sees the buffer again; a collision is a table miss.  What the reference's predictor leaves behind besides samples — the warped-motion sample count
+ * whenever fast_loop_core sees the buffer again; a collision is a table miss.  When md_staging_perform_inter_pred is ON the later stage predicts the candidate itself:
+ * svt_hip_hook_md_pre_take then only drops the mark and reports "nothing to do".  What the reference's predictor leaves behind besides samples — the warped-motion sample count
  * of the candidate, which the fast cost reads (wm_count_samples, EbEncInterPrediction.c:6285-6297), and ifs_is_regular_last — the patched fast_loop_core does itself on a hit.
  * SVT_HIP_MD_PRE_VERIFY=1 (tests) makes every hit compute the reference's value as well and counts disagreements (svt_hip_hook_md_pre_verify).
  *
@@ -655,9 +659,24 @@ static MdPre           g_pre[PRE_SLOTS];
 static pthread_mutex_t g_pre_mu = PTHREAD_MUTEX_INITIALIZER;
 static SvtHipMdPu      g_pre_pu[PRE_PUS];
 static int             g_pre_pu_ok;   /* 0 not built, 1 built, -1 the tables are not what this code expects */
-static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_calls, g_pre_inter, g_pre_hits, g_pre_late, g_pre_declined;
-static long g_pre_bi_hits, g_pre_bi_pictures;   /* compound-average candidates served, pictures with a pair table */
-static long g_pre_grid_pictures, g_pre_probes, g_pre_probe_hits;   /* the sub-pel grid: pictures it was made for, svt_upsampled_pref_error calls of mode decision, served */
+static long g_pre_pictures, g_pre_launches, g_pre_jobs, g_pre_min_jobs, g_pre_declined;
+static long g_pre_bi_pictures;     /* pictures with a pair table */
+static long g_pre_grid_pictures;   /* the sub-pel grid: pictures it was made for */
+/* The counters of the HOT path -- svt_hip_hook_md_pre_lookup runs once per fast_loop_core candidate on every mode-decision thread, the grid fetch once per sub-pel probe --
+ * are striped: a thread counts in the cache line of its own stripe (threads beyond PRE_STRIPES share one: the adds stay atomic), the report sums the stripes.  One shared
+ * line per counter made 100+ MD threads take turns on it in the encoder's hottest loop. */
+enum { PC_CALLS, PC_INTER, PC_HITS, PC_BI_HITS, PC_LATE, PC_PROBES, PC_PROBE_HITS, PC_MISS0 };
+#define PRE_STRIPES 128
+#define PC_N (PC_MISS0 + 10 /* PRE_MISS_N, checked below */)
+static struct { long c[PC_N]; char pad[(64 - (PC_N * sizeof(long)) % 64) % 64]; } g_pre_stripe[PRE_STRIPES] __attribute__((aligned(64)));
+static int g_pre_stripe_next;
+static __thread int tls_stripe = -1;
+static inline long *pre_counters(void) {
+    if (tls_stripe < 0) tls_stripe = __sync_fetch_and_add(&g_pre_stripe_next, 1) % PRE_STRIPES;
+    return g_pre_stripe[tls_stripe].c;
+}
+#define PRE_COUNT(which) __sync_fetch_and_add(&pre_counters()[which], 1)
+static long pre_total(int which) { long t = 0; for (int i = 0; i < PRE_STRIPES; i++) t += g_pre_stripe[i].c[which]; return t; }
 static int  g_pre_grid_on = -1, g_pre_compound_on = -1, g_pre_grid_mb = -1;   /* SVT_HIP_MD_PRE_SUBPEL=0 / SVT_HIP_MD_PRE_COMPOUND=0 leave the table out */
 static __thread struct { const uint32_t *row; int cx, cy; } tls_grid;
 static long long g_pre_ns;
@@ -667,9 +686,9 @@ static long g_pre_device_us;
 double svt_hip_hook_md_pre_device_ms(void) { return g_pre_timing > 0 ? g_pre_device_us / 1000.0 : -1.0; }
 /* why an inter candidate of fast_loop_core was not served from the table */
 enum { PRE_MISS_COMPOUND, PRE_MISS_MOTION, PRE_MISS_HBD, PRE_MISS_LATER_PASS, PRE_MISS_SHAPE, PRE_MISS_NO_TABLE, PRE_MISS_REFERENCE, PRE_MISS_VECTOR, PRE_MISS_BORDER, PRE_MISS_MARK, PRE_MISS_N };
-static long g_pre_miss[PRE_MISS_N];
-#define PRE_MISS(why) do { __sync_fetch_and_add(&g_pre_miss[why], 1); return 0; } while (0)
-void svt_hip_hook_md_pre_misses(long *out, int n) { for (int i = 0; i < n; i++) out[i] = i < PRE_MISS_N ? g_pre_miss[i] : 0; }
+typedef char pre_miss_fits_the_stripe[PRE_MISS_N <= PC_N - PC_MISS0 ? 1 : -1];
+#define PRE_MISS(why) do { PRE_COUNT(PC_MISS0 + (why)); return 0; } while (0)
+void svt_hip_hook_md_pre_misses(long *out, int n) { for (int i = 0; i < n; i++) out[i] = i < PRE_MISS_N ? pre_total(PC_MISS0 + i) : 0; }
 static int  g_pre_verify = -1;
 static __thread struct { PictureControlSet *pcs; uint64_t pic; MdPre *t; } tls_pre;
 #define PRE_MARKS 1024
@@ -677,11 +696,11 @@ static __thread const void *tls_mark[PRE_MARKS];
 static inline unsigned mark_slot(const void *p) { const uintptr_t a = (uintptr_t)p; return (unsigned)((a >> 6) ^ (a >> 16)) & (PRE_MARKS - 1); }
 
 long svt_hip_hook_md_pre_mismatches(void) { return g_pre_verify > 0 ? g_pre_mismatch : -1; }
-void svt_hip_hook_md_pre_compound_stats(long *pictures, long *served) { *pictures = g_pre_bi_pictures; *served = g_pre_bi_hits; }
-void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served) { *pictures = g_pre_grid_pictures; *probes = g_pre_probes; *served = g_pre_probe_hits; }
+void svt_hip_hook_md_pre_compound_stats(long *pictures, long *served) { *pictures = g_pre_bi_pictures; *served = pre_total(PC_BI_HITS); }
+void svt_hip_hook_md_pre_subpel_stats(long *pictures, long *probes, long *served) { *pictures = g_pre_grid_pictures; *probes = pre_total(PC_PROBES); *served = pre_total(PC_PROBE_HITS); }
 void svt_hip_hook_md_pre_stats(long *pictures, long *launches, long *jobs, long *min_jobs, long *calls, long *inter, long *hits, long *late, long *declined, double *ms) {
-    *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = g_pre_calls; *inter = g_pre_inter; *hits = g_pre_hits;
-    *late = g_pre_late; *declined = g_pre_declined; *ms = g_pre_ns / 1e6;
+    *pictures = g_pre_pictures; *launches = g_pre_launches; *jobs = g_pre_jobs; *min_jobs = g_pre_min_jobs; *calls = pre_total(PC_CALLS); *inter = pre_total(PC_INTER); *hits = pre_total(PC_HITS);
+    *late = pre_total(PC_LATE); *declined = g_pre_declined; *ms = g_pre_ns / 1e6;
 }
 
 /* PU index of the ME results -> position and size inside a 64x64 superblock, from the reference's own tables (me_idx over the block geometry) */
@@ -1006,12 +1025,12 @@ void svt_hip_hook_md_pre_subpel_end(void) { tls_grid.row = NULL; }
 static int pre_grid_fetch(const MV *mv, unsigned int *err, unsigned int *sse) {
     if (!svt_hip_hook_enabled(SVT_HIP_HOOK_MD_PRE)) return 0;
     if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") ? atoi(getenv("SVT_HIP_MD_PRE_VERIFY")) : 0;
-    __sync_fetch_and_add(&g_pre_probes, 1);
+    PRE_COUNT(PC_PROBES);
     if (!tls_grid.row) return 0;
     const int dx = mv->col - tls_grid.cx, dy = mv->row - tls_grid.cy;
     if (dx < -6 || dx > 6 || dy < -6 || dy > 6 || ((dx | dy) & 1)) return 0;
     const int i = 7 * ((dy + 6) >> 1) + ((dx + 6) >> 1);
-    __sync_fetch_and_add(&g_pre_probe_hits, 1);
+    PRE_COUNT(PC_PROBE_HITS);
     if (g_pre_verify > 0) return 0;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the probe, svt_hip_hook_md_pre_subpel_verify compares */
     *err = tls_grid.row[2 * i]; *sse = tls_grid.row[2 * i + 1];
     return 1;
@@ -1036,10 +1055,10 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     if (g_pre_verify < 0) g_pre_verify = getenv("SVT_HIP_MD_PRE_VERIFY") ? atoi(getenv("SVT_HIP_MD_PRE_VERIFY")) : 0;
     const unsigned ms = mark_slot(cb);
     if (tls_mark[ms] == cb) tls_mark[ms] = NULL;   /* the buffer gets a new candidate: whatever it was marked for is gone */
-    __sync_fetch_and_add(&g_pre_calls, 1);
+    PRE_COUNT(PC_CALLS);
     const ModeDecisionCandidate *c = cb->candidate_ptr;
     if (c->type != INTER_MODE || c->use_intrabc) return 0;
-    __sync_fetch_and_add(&g_pre_inter, 1);
+    PRE_COUNT(PC_INTER);
     if (!ctx->md_staging_skip_chroma_pred || !ctx->md_staging_skip_interpolation_search) PRE_MISS(PRE_MISS_LATER_PASS);
     if (c->motion_mode != SIMPLE_TRANSLATION || c->is_interintra_used) PRE_MISS(PRE_MISS_MOTION);
     if (c->is_compound && (c->interinter_comp.type != COMPOUND_AVERAGE || c->compound_idx != 1 || c->comp_group_idx != 0)) PRE_MISS(PRE_MISS_COMPOUND);   /* distance-weighted, wedge, difference-weighted */
@@ -1072,7 +1091,7 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
         }
         if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);
         *sad = t->bisad[eb];
-        __sync_fetch_and_add(&g_pre_hits, 1); __sync_fetch_and_add(&g_pre_bi_hits, 1);
+        PRE_COUNT(PC_HITS); PRE_COUNT(PC_BI_HITS);
         if (g_pre_verify == 3) { tls_mark[ms] = cb; return 5; }   /* debug: predicted now AND again where the survivors are predicted */
         if (g_pre_verify) return g_pre_verify == 2 ? 3 : 2;   /* 3: the reference predicts as usual and the TABLE's distortion is used (SVT_HIP_MD_PRE_VERIFY=2) */
         tls_mark[ms] = cb;
@@ -1092,7 +1111,7 @@ int svt_hip_hook_md_pre_lookup(PictureControlSet *pcs, ModeDecisionContext *ctx,
     if (bx <= -(bw + 4) || by <= -(bw + 4) || bx >= pic_w + 3 || by >= pic_h + 3) PRE_MISS(PRE_MISS_BORDER);
     if (tls_mark[ms]) PRE_MISS(PRE_MISS_MARK);   /* another buffer's mark lives here: no room to remember that this one has no samples yet */
     *sad = t->sad[e];
-    __sync_fetch_and_add(&g_pre_hits, 1);
+    PRE_COUNT(PC_HITS);
     if (g_pre_verify == 3) { tls_mark[ms] = cb; return 5; }
     if (g_pre_verify) return g_pre_verify == 2 ? 3 : 2;   /* SVT_HIP_MD_PRE_VERIFY=1: the reference computes the candidate as well and svt_hip_hook_md_pre_verify compares; 2: it predicts and the table's distortion is used */
     tls_mark[ms] = cb;
@@ -1114,9 +1133,18 @@ int svt_hip_hook_md_pre_take(const ModeDecisionCandidateBuffer *cb, int predicte
     const unsigned ms = mark_slot(cb);
     if (tls_mark[ms] != cb) return 0;
     tls_mark[ms] = NULL;
-    if (predicted_late) __sync_fetch_and_add(&g_pre_late, 1);
+    if (predicted_late) PRE_COUNT(PC_LATE);
     return 1;
 }
+
+/* svt_hip_hooks_enc_predeinit with other instances still encoding: hook "md_pre" queues on a context of its own (host_register + upload of a stale resident plane
+ * included, svt_hip_resident_acquire), which the quiesce of the main and pool contexts does not cover.  Lock = no new issue, drained = nothing in flight; the caller
+ * unregisters the page-locked ranges and then calls svt_hip_md_bridge_resume. */
+void svt_hip_md_bridge_quiesce(void) {
+    pthread_mutex_lock(&g_pre_issue_mu);
+    if (g_pre_ctx) (void)svt_hip_sync(g_pre_ctx);
+}
+void svt_hip_md_bridge_resume(void) { pthread_mutex_unlock(&g_pre_issue_mu); }
 
 /* the shared staging buffers of the three hooks above (svt_hip_hooks_enc_deinit) */
 void svt_hip_md_bridge_release(SvtHipCtx *hip) {
