@@ -936,7 +936,7 @@ int svt_hip_sgr_proj_error_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, const 
 namespace {
 struct SgrScratch { size_t stats, sums, d2, states, esc_cnt, sd, pairs, esc, total, total_packed, dplane; int dstride, nu; };
 // SVT_HIP_SGR_PACKED=1 (bit depth 8 only) runs the unit search on PACKED difference words (one 32-bit word per sample and set in `pairs`, no dat - src plane; sgr.hip
-// STORE == 2, sgr_walk_packed_kernel).  A measured negative result, kept as the experiment it is (profiles/r06/sgr_packed_ab.txt): the form halves the walk's memory traffic and
+// STORE == 2, sgr_walk_packed_kernel).  A measured negative result, kept as the experiment it is (profiles/r06/sgr_packed_ab.txt): the form cuts the walk's memory traffic by a quarter (1.85 -> 1.41 GB per 4K frame) and
 // raises its resident share from 38 % to 55-66 %, and the walk takes the same time -- its evaluation is bound by v_dot2 issue and by the one memory round trip per streamed chunk,
 // not by bytes -- while the filter kernel pays 0.1 ms per 4K frame for the packing.  The default stays the 6-byte form.
 static bool sgr_packed(int bd) {

@@ -1,6 +1,6 @@
 """ONE definition of the roofline arithmetic, shared by bench.py (live stage times from HIP events) and tools/summarize_profiles.py (rocprofv3 durations of
 the committed profile): every number of the bench line's `roofline` object can be recomputed from profiles/<round>/{pmc_traffic.json,kernel_stats.csv}
-with the functions below.  DESIGN.md section 4 carries the same table.
+with the functions below.  DESIGN.md section 6 and docs/design/measurement.md quote it.
 
 Peaks (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8.0 TB/s; integer VALU 256 CUs x 128 lanes x 2.4 GHz = 78.6 T lane-operations/s (one lane-operation =
 one lane of one VALU instruction, whatever it computes).
