@@ -629,6 +629,7 @@ def main():
         walk_stats = {"passes_per_walk": float(sum(int(s[0]) for s in st3)) / nw, "points_per_walk": float(sum(int(s[1]) for s in st3)) / nw,
                       "unfinished": int(sum(int(s[2]) for s in st3)),
                       # shader cycles per walk and plane as the walking wave sees them: solve, replay, wait for the unit to become resident, evaluation, total
+                      # (zeros unless SVT_HIP_SGR_WALK_CLOCKS=1: the clocks cost 1.2 % of the stage and are off in the timed configuration)
                       "phase_cycles_per_walk": [{k: round(64.0 * int(s[24 + i]) / (16 * P0.n_units[p])) for i, k in enumerate(("solve", "replay", "load_wait", "evaluate", "total"))}
                                                 | {"wave1_candidate_loops": round(64.0 * int(s[29]) / (16 * P0.n_units[p]))}
                                                 | {"passes": round(int(s[0]) / (16 * P0.n_units[p]), 2), "points": round(int(s[1]) / (16 * P0.n_units[p]), 2)} for p, s in enumerate(st3)]}

@@ -45,7 +45,7 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
     const uint2* esc; const uint32_t* esc_cnt;   // packed form only (sgr_walk_packed_kernel): the samples whose differences do not fit the packed word, per (unit, set)
 };
-struct WalkPic { WalkPlane p[3]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=0 switches them off)
+struct WalkPic { WalkPlane p[3]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=1 switches them on)
 constexpr int kCache   = 256;    // evaluated points a walk can remember, see kThrottle
 // The exact walk (finer_search_pixel_proj_error, EbRestorationPick.c:353-440) evaluates at most 1 + 2 x (1 + 63) + 4 = 133 points: per parameter at step 2 one rejected
 // downward probe and then <= 63 upward ones (or <= 63 downward ones), at step 1 two probes per parameter.  Speculative requests (points the quadratic model walks
@@ -897,7 +897,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
             const long long sum = wave_sum_u48(acc);   // acc < 2^48
             if (lane == 0) L.part[wave][c] = sum;
         }
-        if (tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); }   // diagnostics: the candidate loop as wave 1 sees it
+        if (a.clocks && tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); }   // diagnostics: the candidate loop as wave 1 sees it
         __syncthreads();   // B
     }
 }
@@ -1216,7 +1216,7 @@ sgr_walk_packed_kernel(const WalkPic a) {
                     if (lane == 0) L.part[wave][cb + c] = sum;
                 }
         }
-        if (tid == 64) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); if (pass == 0 && n_esc) atomicAdd(&stats[4], (uint32_t)n_esc); }   // [4]: listed samples the sample-by-sample walks of the plane added (diagnostics, tests)
+        if (tid == 64) { if (a.clocks) { atomicAdd(&stats[29], (uint32_t)((__builtin_readcyclecounter() - e0) >> 6)); atomicAdd(&stats[30], (uint32_t)nc); } if (pass == 0 && n_esc) atomicAdd(&stats[4], (uint32_t)n_esc); }   // [4]: listed samples the sample-by-sample walks of the plane added (diagnostics, tests)
         __syncthreads();   // B
     }
 }
@@ -1245,8 +1245,8 @@ extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_plane
     a.cap = cap;
     const char* hw_env = getenv("SVT_HIP_SGR_WALK_HIST_W");   // read per launch: tests/test_sgr_gpu.py narrows the window to send part of a plane's units down the sample-by-sample path
     a.hist_w = hist_off ? -1 : (hw_env ? atoi(hw_env) : 1 << 30);
-    static const char* clk_env = getenv("SVT_HIP_SGR_WALK_CLOCKS");
-    a.clocks = !(clk_env && clk_env[0] == '0');
+    static const char* clk_env = getenv("SVT_HIP_SGR_WALK_CLOCKS");   // diagnostics, off by default since round 6 (the phase clocks cost 1.2 % of the stage: 0.923 -> 0.912 ms per 4K frame); =1: stats[24..30]
+    a.clocks = clk_env && clk_env[0] == '1';
     int max_units = 0;
     for (int i = 0; i < n_planes; i++) {
         const SvtHipSgrWalkPlane& P = planes[i];

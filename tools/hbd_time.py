@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("SVT_HIP_SGR_WALK_CLOCKS", "1")   # the walks' phase clocks are a diagnostic that is off by default
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from conftest import load_package  # noqa: E402
 import dlf_common as dc  # noqa: E402
