@@ -8,8 +8,13 @@ SAN=${1:-address}; OUT=${2:-/tmp/sanitize_$SAN}
 R=$(cd "$(dirname "$0")/.." && pwd)
 FLAGS="-fsanitize=$SAN -g -fno-omit-frame-pointer"; [ "$SAN" = address ] && FLAGS="$FLAGS -fsanitize-recover=address"; [ "$SAN" = undefined ] && FLAGS="$FLAGS -fno-sanitize=alignment"
 mkdir -p "$OUT/mock" "$OUT/keep/mock"
-cp "$R/oracle/_ref/SvtAv1EncApp_hip" "$OUT/keep/"; cp "$R/oracle/_ref/mock/libsvtav1_hip.so" "$OUT/keep/mock/"
-restore() { cp "$OUT/keep/SvtAv1EncApp_hip" "$R/oracle/_ref/"; cp "$OUT/keep/mock/libsvtav1_hip.so" "$R/oracle/_ref/mock/"; }
+# Everything the sanitizer build shares with the ordinary one is brought up to date FIRST, with the ordinary flags: the reference library and its shims
+# (oracle/_ref/libsvtav1_ref.so, objects under /tmp/svtav1_ref_obj) are prerequisites of the application, and a stale one would otherwise be rebuilt WITH the
+# sanitizer and left behind for every other test (round 6: the reference library came back linked against libtsan).  The library is kept / restored as well.
+make -C "$R/oracle" -f Makefile.ref -j16 -s
+make -C "$R/oracle" -f Makefile.enc -j16 -s
+cp "$R/oracle/_ref/SvtAv1EncApp_hip" "$OUT/keep/"; cp "$R/oracle/_ref/mock/libsvtav1_hip.so" "$OUT/keep/mock/"; cp "$R/oracle/_ref/libsvtav1_ref.so" "$OUT/keep/"
+restore() { cp "$OUT/keep/SvtAv1EncApp_hip" "$R/oracle/_ref/"; cp "$OUT/keep/mock/libsvtav1_hip.so" "$R/oracle/_ref/mock/"; cp "$OUT/keep/libsvtav1_ref.so" "$R/oracle/_ref/"; }
 trap restore EXIT
 rm -f "$R/oracle/_ref/SvtAv1EncApp_hip" "$R/oracle/_ref/mock/libsvtav1_hip.so"; rm -rf "$OUT/obj"
 make -C "$R" -f oracle/Makefile.enc -j16 -s EOBJDIR="$OUT/obj" CC="gcc $FLAGS" CXX="g++ $FLAGS" "$R/oracle/_ref/SvtAv1EncApp_hip" "$R/oracle/_ref/mock/libsvtav1_hip.so"
