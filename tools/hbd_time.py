@@ -181,3 +181,17 @@ for p in range(3):
     print(f"  plane {p}: {units[p]} units x 16 sets: {st3[0] / (units[p] * 16):.2f} evaluation passes, {st3[1] / (units[p] * 16):.2f} evaluated points per walk, unfinished {st3[2]}, "
           f"walks on the histogram {st3[3]}, passes histogram {list(st3[8:24])}")
 
+# ---- how many parameter sets a provable lower bound could prune (VERDICT r05 #1c): e = q + r per sample with |q - continuous| <= 1/2, so the exact error of ANY tap pair is
+# >= Q - sqrt(N Q) where Q is the quadratic's value there (Cauchy-Schwarz on the cross term); the final exact error of a set stands in for its Q_min (they differ by the
+# rounding noise, ~0.1 %).  A set survives when its bound does not exceed the unit's best exact error.
+for p in range(3):
+    err = hip.to_host(d_uerr[p], (units[p], 16), np.int64).astype(np.float64)
+    ph_, pw_ = rec[p].shape
+    n_unit = float(pw_ * ph_) / units[p]   # average samples per unit
+    lb = err - np.sqrt(n_unit * err)
+    best = err.min(axis=1, keepdims=True)
+    surv = (lb <= best).sum(axis=1)
+    spread = (err.max(axis=1) - err.min(axis=1)) / err.min(axis=1)
+    print(f"  plane {p}: sets surviving the bound Q - sqrt(N Q) <= best: mean {surv.mean():.2f} of 16 (min {surv.min()}, max {surv.max()}); mean squared error per sample "
+          f"{(best / n_unit).mean():.1f}; (worst - best) / best over the 16 sets: mean {spread.mean():.3f}, max {spread.max():.3f}; slack sqrt(N Q) / Q: mean {(np.sqrt(n_unit * best) / best).mean():.3f}")
+
