@@ -35,6 +35,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+# The step's four frame chains are four branches of one HIP graph; ROCm spreads a graph's branches over its hardware queues (GPU_MAX_HW_QUEUES, default 4).  Measured on
+# the MI355X in round 6 (profiles/r06/NOTES.md): 4 queues 7.8 ms per step, 5-8 queues 10.3 ms, 16 queues 12.8 ms -- more queues put more of the searches, each of which
+# holds a compute unit's whole register file, side by side.  The default is what the figures are quoted on; it is pinned here so that an inherited setting cannot move them.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
