@@ -1246,9 +1246,25 @@ static void lf_host_chain(LfState *s) {
     Av1Common *cm = pcs->parent_pcs_ptr->av1_cm;
     const int is16 = s->pic.pix_bytes == 2;
     EbPictureBufferDesc *rec = recon_of(pcs, is16);
-    if (s->flags & ST_DBL) svt_av1_loop_filter_frame(rec, pcs, 0, 3);   /* the levels are in the frame header (picked by the hook or by the C search) */
+    /* Every stage is gated by the REFERENCE's own condition: what runs here is what dlf_kernel / cdef_kernel / rest_kernel would run, not what the bridge's
+     * state flags remember.  The flags only say which stages the DEVICE had applied to its copy; where the two disagree the bitstream follows the reference's conditions,
+     * so the host chain does too, and the disagreement is logged (it would be a bridge bug). */
+    const PictureParentControlSet *ppcs = pcs->parent_pcs_ptr;
+    const FrameHeader *fh = &ppcs->frm_hdr;
+    const int tiles = cm->tiles_info.tile_cols * cm->tiles_info.tile_rows;
+    const int ref_dlf = ppcs->loop_filter_mode >= 2 || (ppcs->loop_filter_mode == 1 && tiles > 1);                                   /* EbDlfProcess.c:175-177 */
+    const int ref_cdef = scs->seq_header.cdef_level && ppcs->cdef_level &&
+                         (scs->seq_header.enable_restoration != 0 || ppcs->is_used_as_reference_flag || scs->static_config.recon_enabled);   /* EbCdefProcess.c:524-534 */
+    const int ref_rest = scs->seq_header.enable_restoration && fh->allow_intrabc == 0 &&
+                         (cm->rst_info[0].frame_restoration_type != RESTORE_NONE || cm->rst_info[1].frame_restoration_type != RESTORE_NONE ||
+                          cm->rst_info[2].frame_restoration_type != RESTORE_NONE);                                                     /* EbRestProcess.c:540-548 */
+    if (!!(s->flags & ST_CDEF) != !!ref_cdef || !!((s->flags & ST_REST) && s->rest_mask) != !!ref_rest)
+        SVT_LOG("svt_hip: host filter chain: the bridge's stage flags (cdef %d, restoration %d) differ from the reference's conditions (%d, %d) - following the reference\n",
+                !!(s->flags & ST_CDEF), !!((s->flags & ST_REST) && s->rest_mask), ref_cdef, ref_rest);
+    /* deblocking: only when the device held the deblocked copy (ST_DBL; otherwise the host picture IS deblocked already: the C filter ran on it before the upload) */
+    if ((s->flags & ST_DBL) && ref_dlf) svt_av1_loop_filter_frame(rec, pcs, 0, 3);   /* the levels are in the frame header (picked by the hook or by the C search) */
     if (scs->seq_header.enable_restoration) svt_av1_loop_restoration_save_boundary_lines(cm->frame_to_show, cm, 0);
-    if (s->flags & ST_CDEF) {
+    if (ref_cdef) {
         if (is16) av1_cdef_frame16bit(0, scs, pcs); else svt_av1_cdef_frame(0, scs, pcs);
     }
     if (scs->seq_header.enable_restoration) {
@@ -1257,7 +1273,7 @@ static void lf_host_chain(LfState *s) {
             svt_extend_frame(cm->frame_to_show->buffers[pl], cm->frame_to_show->crop_widths[pl > 0], cm->frame_to_show->crop_heights[pl > 0], cm->frame_to_show->strides[pl > 0],
                              RESTORATION_BORDER, RESTORATION_BORDER, is16);
     }
-    if ((s->flags & ST_REST) && s->rest_mask) svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0);
+    if (ref_rest) svt_av1_loop_restoration_filter_frame(cm->frame_to_show, cm, 0);
 }
 /* A deferred picture's only copy is the device's: if it cannot be brought back the encoder must not go on with the unfiltered host picture (the bitstream signals the
  * filters; the picture is a reference and the reconstruction output).  In order: the download; once more when copies had been queued (a second complete pass makes the
@@ -1284,6 +1300,7 @@ static void lf_final_download(SvtHipCtx *hip, LfState *s) {
         const SequenceControlSet *scs = (const SequenceControlSet *)s->pcs->scs_wrapper_ptr->object_ptr;
         if (scs->encode_context_ptr && scs->encode_context_ptr->app_callback_ptr && scs->encode_context_ptr->app_callback_ptr->error_handler)
             scs->encode_context_ptr->app_callback_ptr->error_handler(scs->encode_context_ptr->app_callback_ptr->handle, (uint32_t)EB_ErrorUndefined);
+        return;   /* the host picture is NOT valid: ST_HOST_STALE stays set (the encoder is stopping) */
     }
     s->flags &= ~ST_HOST_STALE;
 }
