@@ -288,7 +288,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
                     help="reference = the reference's own SIMD kernels (oracle/_ref SIMD flavour); port = the oracle's scalar C; auto = reference when built")
-    ap.add_argument("--me-waves", type=int, default=4, help="svt_hip_me_set_waves_per_sb value (debug)")
+    ap.add_argument("--me-waves", type=int, default=0, help="svt_hip_me_set_waves_per_sb value; 0 = 2 waves per superblock when several frames are in flight, 4 for one frame "
+                    "(measured on the MI355X in round 6: alone the 85-PU search is fastest with 4 waves per superblock -- 0.38 against 0.41 ms -- but with four frames in flight the "
+                    "128-thread workgroups share the chip better with the other frames' kernels: 7.66-7.70 against 7.77-7.79 ms per step)")
     ap.add_argument("--no-side", action="store_true", help="(ignored; kept for older command lines: a frame's chain is one stream -- the sub-pel stage reads this step's ME "
                                                             "table, and a second stream per frame for the source side measured slower anyway, 8.60 vs 8.26 ms)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured HIP graph per step")
@@ -340,6 +342,8 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.check(L.svt_hip_set_stream(ctx.h, C.c_void_p(stream.cuda_stream)))
     E.dev = dev = torch.device("cuda", local_rank)
+    auto_me_waves = not args.me_waves
+    if auto_me_waves: args.me_waves = 2 if args.frames > 1 else 4
     ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, args.me_waves))
     ctx.check(L.svt_hip_me_set_big_windows(ctx.h, 0))   # every window of this workload is 64 x 64 candidates: no strip-walking launch needed
 
@@ -507,11 +511,13 @@ def main():
         for f in sweep_fs:
             if f == nF or f > len(pipes):
                 continue
+            if auto_me_waves: ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, 2 if f > 1 else 4))   # read at capture time: each batch size runs the setting it would be used with
             fns = make_steps(f)
             n = max(10, min(args.steps, 40))
             t = timed(fns, n, 3, False)
             sweep[str(f)] = {"ms_per_step": t / n * 1e3, "sb_per_s": f * n_sb * n / t}
             del fns
+        if auto_me_waves: ctx.check(L.svt_hip_me_set_waves_per_sb(ctx.h, args.me_waves))
     # ---- the step without the restoration stages = BASELINE.json configs[2] (ME + sub-pel + transform + deblock + CDEF on 4K 8-bit); the self-guided
     #      search and filter are configs[3]'s work, included in the headline step because the round-1 review asked for the complete search there
     subsets = {}
@@ -746,7 +752,7 @@ def main():
                    "cdef_strength_select_forms_ms": select_forms_ms,
                    "cdef_strength_select_form": {"frames_per_step == 1": "resident (one launch)", "frames_per_step > 1": "steps (80 launches)"} if forced_form is None
                                                 else os.environ.get("SVT_BENCH_SELECT_FORM"),
-                   "parity_spot_check": parity_ok, "parity_detail": parity_detail, "sgr_walk": walk_stats},
+                   "me_waves_per_superblock": args.me_waves, "parity_spot_check": parity_ok, "parity_detail": parity_detail, "sgr_walk": walk_stats},
         "cpu_baseline": cpu,
     }
     out["roofline"] = roofline(per_stage, stages, n_sb)
