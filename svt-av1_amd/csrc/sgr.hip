@@ -367,6 +367,57 @@ __device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
     return (long long)hi * 65536 + lo;
 }
 
+// One parameter set of a tile that lies completely inside the picture, bit depth 8, for the sum-only and the 6-byte STORE forms: the same arithmetic as the
+// general loop body below as STRAIGHT-LINE code.  The general body asks `is this row inside the picture` and `does this set have filter 0 / 1` per row and per
+// sum; the compiler turned each into a scalar branch (~30 per set) and serialised the five DPP reductions behind s_nops: the projection sums took 21 % and the
+// stores 15 % of the launch for 11 % and 6 % of its instructions (tools/ubench/sgr_filter_probe.py on the MI355X).  Here the filter pair is a template
+// parameter, every row is valid, and the five reductions advance in lockstep.
+template <bool H0, bool H1, int STORE>
+__device__ __forceinline__ void sgr8_set_interior(uint32_t* __restrict__ abw, const uint32_t* __restrict__ xt, const uint32_t (&P)[S_KP], const uint32_t (&M)[S_KP], uint32_t s0,
+                                                  uint32_t s1, int tid, int i0, int j, const uint32_t (&X)[8], const int32_t (&CX)[8], const int32_t (&SV)[8],
+                                                  uint32_t* __restrict__ pairs_px, int dstride, int32_t* __restrict__ part_ep) {
+#pragma unroll
+    for (int k = 0; k < S_KP; k++) {
+        const int i = tid + 256 * k;
+        // positions [256 k, 256 k + 255]: all r = 1, all r = 2, or the one k that straddles S_N1 / the tail past S_NP (constants after unrolling)
+        const bool all1 = 256 * k + 255 < S_N1, none1 = 256 * k >= S_N1, in_np = 256 * k + 255 < S_NP;
+        const bool is1 = all1 ? true : (none1 ? false : i < S_N1);
+        const bool live = (in_np ? true : i < S_NP) && (is1 ? H1 : H0);
+        if (live) {
+            const uint32_t z = (__umul24(P[k], is1 ? s1 : s0) + (1u << 19)) >> 20;
+            const uint32_t t = xt[min(z, 255u)];
+            const uint32_t B = (__umul24(t & 0x1FFu, M[k]) + (1u << 11)) >> 12;
+            abw[i] = (t & 0xFFF00000u) | B;
+        }
+    }
+    __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
+    int32_t D0[8], D1[8];
+    sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1);
+    if (STORE == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) SGR_ST(&pairs_px[(size_t)r * dstride], ((uint32_t)(H0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(H1 ? D1[r] : 0) << 16));
+    }
+    int32_t h[5] = {0, 0, 0, 0, 0};   // H00, H01, H11, C0, C1
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (H0) { h[0] += __mul24(D0[r], D0[r]); h[3] += __mul24(D0[r], SV[r]); }
+        if (H1) { h[2] += __mul24(D1[r], D1[r]); h[4] += __mul24(D1[r], SV[r]); }
+        if (H0 && H1) h[1] += __mul24(D0[r], D1[r]);
+    }
+    constexpr bool use[5] = {H0, H0 && H1, H1, H0, H1};
+    // the 16-lane row totals of the live sums, step by step over all of them: no reduction waits for its own previous step
+#define SGR_RED_(ctl)                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 5; q++) if (use[q]) h[q] += __builtin_amdgcn_mov_dpp(h[q], ctl, 0xF, 0xF, true);
+    SGR_RED_(0xB1) SGR_RED_(0x4E) SGR_RED_(0x141) SGR_RED_(0x140)
+#undef SGR_RED_
+    // the sixteen row totals of the workgroup go to slots of their own (plain stores): an LDS atomicAdd with a wave-uniform address is compiled into a
+    // scalar loop over the active lanes (5 sums x 4 lanes x ~10 instructions per set); the tile's last step adds the sixteen slots
+    if ((tid & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) if (use[q]) part_ep[q * 16 + (tid >> 4)] = h[q];
+    }
+}
+
 // STORE: additionally leaves, per pixel, (flt0 - u) | (flt1 - u) << 16 (pairs[ep], int16 halves; sets 11 / 12 / 13 use the plane of 2 / 5 / 8), dat - src (sd,
 // int16) and per unit the sum of (dat - src)^2 (d2) for the on-device unit search (sgr_walk.hip): a probe pass then re-reads 6 bytes per pixel instead of
 // re-running the filters.
@@ -447,12 +498,23 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
     if (ep_mask & (1u << 12)) cmask |= 1u << 5;
     if (ep_mask & (1u << 13)) cmask |= 1u << 8;
 
+    const bool interior = x0 + S_TW <= pw && y0 >= 0 && y0 + S_TH <= ph;   // workgroup-uniform: every sample of the tile is a picture sample
+    int32_t* part = (int32_t*)in;   // [16 sets][5 sums][16 row totals] of an interior tile: the staged tile is dead (every lane has read its X[] before the first set's barrier)
+    static_assert(16 * 5 * 16 * sizeof(int32_t) <= sizeof(in), "the row totals must fit the staged tile");
     int buf = 0;
     for (int ep = 0; ep < 16; ep++) {
         if (!((cmask >> ep) & 1)) continue;
         const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
         const uint32_t s0 = (uint32_t)kSgr[ep][2], s1 = (uint32_t)kSgr[ep][3];
         uint32_t* abw = ab[buf];
+        if (BD == 8 && STORE != 2 && interior) {   // the common case as straight-line code, one instance per filter pair
+            uint32_t* ppx = STORE == 1 ? &pairs[(size_t)ep * dplane + (size_t)(y0 + i0) * dstride + x0 + j] : nullptr;
+            if (has0 && has1) sgr8_set_interior<true, true, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            else if (has1) sgr8_set_interior<false, true, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            else sgr8_set_interior<true, false, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            buf ^= 1;
+            continue;
+        }
         sgr8_build(abw, xt, P, M, has0, has1, s0, s1, tid);
         __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
 
@@ -536,7 +598,16 @@ sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restric
             const int ce = ep == 11 ? 2 : (ep == 12 ? 5 : (ep == 13 ? 8 : ep));
             const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
             const bool used = q == 0 || q == 3 ? has0 : (q == 1 ? (has0 && has1) : has1);
-            if (used) atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + q], acc[ce][q]);
+            if (used) {
+                unsigned long long v = acc[ce][q];
+                if (BD == 8 && STORE != 2 && interior) {
+                    long long w = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) w += part[ce * 80 + q * 16 + k];
+                    v = (unsigned long long)w;
+                }
+                atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + q], v);
+            }
         }
     }
     if (STORE && tid == 80 && acc_d2) atomicAdd(&d2[unit], acc_d2);
