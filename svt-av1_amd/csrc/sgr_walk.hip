@@ -465,7 +465,7 @@ __device__ __forceinline__ void eval_chunk(const int4& a0, const int4& a1, const
 __device__ __forceinline__ void expand_sd(const int4& s, int (&c)[8]) {
     const int sw[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-    for (int i = 0; i < 4; i++) { c[2 * i] = (sw[i] << 16) + 0x8000; c[2 * i + 1] = (int)(((uint32_t)sw[i] & 0xFFFF0000u) | 0x8000u); }
+    for (int i = 0; i < 4; i++) { c[2 * i] = (sw[i] << 16) | 0x8000; c[2 * i + 1] = (int)__builtin_amdgcn_perm(0x8000u, (uint32_t)sw[i], 0x03020504u); }   // v_lshl_or_b32; v_perm_b32: the upper half of sw over 0x8000 (an and + or pair otherwise: two literals do not fit one instruction)
 }
 __device__ __forceinline__ void eval_chunk_f(const int4& a0, const int4& a1, const int (&c)[8], int q, int sel, int& p0, int& p1) {
     int t0, t1, t2, t3, t4, t5, t6, t7;
@@ -488,7 +488,7 @@ __device__ __forceinline__ void eval_chunk_f(const int4& a0, const int4& a1, con
         "v_dot2_i32_i16 %[p1], %[t6], %[t6], %[p1]"
         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [p0] "+v"(p0), [p1] "+v"(p1)
         : [a0] "v"(a0.x), [a1] "v"(a0.y), [a2] "v"(a0.z), [a3] "v"(a0.w), [a4] "v"(a1.x), [a5] "v"(a1.y), [a6] "v"(a1.z), [a7] "v"(a1.w), [c0] "v"(c[0]), [c1] "v"(c[1]),
-          [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "v"(q), [sel] "s"(sel));
+          [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [q] "s"(q), [sel] "s"(sel));
 }
 // One accumulator per candidate (the 16-candidate instance: |e| < 2^10 at bit depth 8 and a thread sees < 400 samples of the largest unit, so 2^20 x 400 < 2^31):
 // the four squaring dots chain through p (a dot may feed the next dot's accumulator back to back).
@@ -801,7 +801,7 @@ sgr_walk_resident_kernel(const WalkPic a) {
                 const int n = w - 8 * cx;
                 if (n < 8) mask_chunk(x0v, x1v, sv, n);
             };
-            if (k < nchunk) fetch(k, a0, a1, s4);
+            if (PF == 2 && k < nchunk) fetch(k, a0, a1, s4);
             // bit depth 10: |e| < 2^13, eight squares per chunk: the candidate's int32 accumulator holds kDrain = 3 chunks (3 x 2^29 < 2^31) before it is emptied into
             // its 64-bit sum -- every third streamed chunk, once more before the resident slots, every third of those, and at the end
             constexpr int kDrain = 3;
@@ -828,19 +828,42 @@ sgr_walk_resident_kernel(const WalkPic a) {
                     a0 = b0; a1 = b1; s4 = t4; b0 = c0; b1 = c1; t4 = u4; k += kResD;
                 }
             } else {
+            // The streamed chunks of this thread are k, k + kResD, ...: (row, column chunk) and the byte offset advance by constants (one wrap test) instead of a
+            // division and 64-bit address arithmetic per chunk; the loop is unrolled over two register sets, so a prefetched chunk is consumed where it landed.
+            // (Round 5's loop spent ~80 instructions per chunk around the 17 per candidate: division 17, addresses 10, zeroing and copying the prefetch buffers 32,
+            // forming the accumulators 12 -- profiles/r06/NOTES.md.)
             int since = 0;
-            while (k < nchunk) {
-                const int kn = k + kResD;
-                int4 b0 = make_int4(0, 0, 0, 0), b1 = b0, t4 = b0;
-                if (kn < nchunk) fetch(kn, b0, b1, t4);   // next chunk's loads before this chunk's arithmetic
-                int sx[8]; expand_sd(s4, sx);
+            const int d_row = kResD / cw, d_cx = kResD - d_row * cw;                       // wave-uniform
+            const uint32_t d_off = (uint32_t)(d_row * dstride + 8 * d_cx), d_wrap = (uint32_t)(dstride - 8 * cw);
+            int cx = k % cw;
+            uint32_t off = (uint32_t)((v0 + k / cw) * dstride + x0 + 8 * cx);             // samples from the plane's origin: < 2^24
+            const char* __restrict__ PPb = (const char*)PP; const char* __restrict__ sdb = (const char*)sd;
+            const bool ragged = (w & 7) != 0;   // only the last column chunk of a unit whose width is not a multiple of eight has samples to mask (wave-uniform)
+            auto fetch2 = [&](int4& x0v, int4& x1v, int4& sv, int& n) {   // loads only: masking at fetch time made the compiler wait for the data right here
+                x0v = SGR_LD4((const uint32_t*)(PPb + 4u * off)); x1v = SGR_LD4((const uint32_t*)(PPb + 4u * off + 16u)); sv = SGR_LD4((const int16_t*)(sdb + 2u * off));
+                n = w - 8 * cx;
+            };
+            auto advance = [&]() { cx += d_cx; off += d_off; const bool wr = cx >= cw; cx -= wr ? cw : 0; off += wr ? d_wrap : 0u; };
+            if (k < nchunk) {
+                int na = 8;
+                fetch2(a0, a1, s4, na);
+                for (;;) {
+                    // this chunk landed an iteration ago; its first use comes BEFORE the next chunk's loads are issued, so the wait for it does not cover them
+                    if (ragged && na < 8) mask_chunk(a0, a1, s4, na);
+                    int sx[8]; expand_sd(s4, sx);
+                    k += kResD; advance();
+                    const bool more = k < nchunk;
+                    int4 b0, b1, t4; int nb = 8;
+                    if (more) fetch2(b0, b1, t4, nb);   // next chunk's loads before this chunk's arithmetic
 #pragma unroll
-                for (int c = 0; c < NA; c++)
-                    if (c < nc) {
-                        if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
-                    }
-                if (DRAIN && ++since == kDrain) { drain(); since = 0; }
-                a0 = b0; a1 = b1; s4 = t4; k = kn;
+                    for (int c = 0; c < NA; c++)
+                        if (c < nc) {
+                            if (ONE_ACC) eval_chunk_f1(a0, a1, sx, qq[c], sel, pp0[c]); else eval_chunk_f(a0, a1, sx, qq[c], sel, pp0[c], pp1[c]);
+                        }
+                    if (DRAIN && ++since == kDrain) { drain(); since = 0; }
+                    if (!more) break;
+                    a0 = b0; a1 = b1; s4 = t4; na = nb;
+                }
             }
             if (DRAIN && since) drain();
             }
