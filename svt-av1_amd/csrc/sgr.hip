@@ -430,19 +430,34 @@ __device__ __forceinline__ void sgr8_set_interior(uint32_t* __restrict__ abw, co
 // them) is written as the zero word -- its error is then 0 for every candidate -- and appended, exactly, to the (unit, set)'s escape list (esc: [13 slots][dplane]
 // entries of (d0 | d1 << 16, r), a unit's list starts at its first sample's offset so the lists can never collide; esc_cnt: [unit][16] counters, zeroed by the
 // caller): the walk adds the listed samples one by one.  esc_lim (<= 1024) narrows the range for tests.
+// The planes of a picture share ONE launch (a one-dimensional grid, the planes' tiles one after the other): a chroma plane of a 4K picture is 1035 tiles for 1024
+// workgroup slots, so a launch of its own lasts one workgroup's whole latency (74 us against 56 us of throughput), and three launches have three tails.
+struct SgrSearchPlaneArgs {
+    const void* dgd; const void* src; unsigned long long* sums; uint32_t* pairs; int16_t* sd; unsigned long long* d2; uint2* esc; uint32_t* esc_cnt;
+    size_t dplane;
+    int stride, src_stride, pw, ph, unit_size, units_x, units_y, voff, dstride, tiles_x, n_tiles, esc_lim;
+    uint32_t ep_mask;
+};
+struct SgrSearchPic { SgrSearchPlaneArgs p[3]; int first_tile[4]; };
 template <typename PIX, int BD = 8, int STORE = 0>
 __global__ void __launch_bounds__(256)
-sgr_search8_kernel(const PIX* __restrict__ dgd, int stride, const PIX* __restrict__ src, int src_stride, int pw, int ph, int unit_size,
-                   int units_x, int units_y, int voff, uint32_t ep_mask, unsigned long long* __restrict__ sums,
-                   uint32_t* __restrict__ pairs = nullptr, int16_t* __restrict__ sd = nullptr, int dstride = 0, size_t dplane = 0,
-                   unsigned long long* __restrict__ d2 = nullptr, uint2* __restrict__ esc = nullptr, uint32_t* __restrict__ esc_cnt = nullptr, int esc_lim = 1024) {
+sgr_search8_kernel(const SgrSearchPic a) {
+    // scalar copies of this workgroup's plane (a reference into the kernel-argument struct with a run-time index would force a private copy of the whole struct)
+    const int z = (int)blockIdx.x >= a.first_tile[2] ? 2 : ((int)blockIdx.x >= a.first_tile[1] ? 1 : 0);
+    const PIX* __restrict__ dgd = (const PIX*)a.p[z].dgd; const PIX* __restrict__ src = (const PIX*)a.p[z].src;
+    unsigned long long* __restrict__ sums = a.p[z].sums; uint32_t* __restrict__ pairs = a.p[z].pairs; int16_t* __restrict__ sd = a.p[z].sd;
+    unsigned long long* __restrict__ d2 = a.p[z].d2; uint2* __restrict__ esc = a.p[z].esc; uint32_t* __restrict__ esc_cnt = a.p[z].esc_cnt;
+    const size_t dplane = a.p[z].dplane;
+    const int stride = a.p[z].stride, src_stride = a.p[z].src_stride, pw = a.p[z].pw, ph = a.p[z].ph, unit_size = a.p[z].unit_size, units_x = a.p[z].units_x,
+              units_y = a.p[z].units_y, voff = a.p[z].voff, dstride = a.p[z].dstride, tiles_x = a.p[z].tiles_x, n_tiles = a.p[z].n_tiles, esc_lim = a.p[z].esc_lim;
+    const uint32_t ep_mask = a.p[z].ep_mask;
     static_assert(STORE != 2 || BD == 8, "the packed difference words hold bit depth 8 only");
     __shared__ uint16_t in[S_IH * S_IW];
     __shared__ uint32_t ab[2][S_NP];             // [0, N1): r = 1 positions, [N1, NP): r = 2 positions (odd rows)
     __shared__ uint32_t xt[256];                 // eb_x_by_xplus1[z] << 20 | (256 - eb_x_by_xplus1[z])
     __shared__ unsigned long long acc[16][5];
     __shared__ unsigned long long acc_d2;
-    const int tile = svt_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
+    const int tile = svt_xcd_order((int)blockIdx.x - a.first_tile[z], n_tiles), tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int x0 = tile_x * S_TW, y0 = tile_y * S_TH - voff, tid = threadIdx.x;   // grid shifted like the unit rows (foreach_rest_unit_in_tile, EbRestoration.c:1388-1391: unit rows start 8 >> ss_y above their nominal position, so a tile never straddles two units)
     const int unit = min((y0 + voff) / unit_size, units_y - 1) * units_x + min(x0 / unit_size, units_x - 1);
     size_t esc_base = 0;   // first sample of this tile's unit in list order: (first row) x dstride + (first column) x (rows): units of a row band share the band's rows
@@ -1334,36 +1349,65 @@ extern "C" int svt_hip_launch_sgr_filter(hipStream_t st, int pix_bytes, int bd, 
     else hipLaunchKernelGGL((sgr_filter_kernel<uint16_t, 10>), grid, dim3(256), 0, st, (const uint16_t*)plane, stride, pw, ph, ep, flt0, flt1, flt_stride);
     return (int)hipGetLastError();
 }
-extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
-                                         int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums) {
-    const int voff = 8 >> ss_y;
-    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
-    unsigned long long* s = (unsigned long long*)sums;
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
-    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s);
+namespace {
+SgrSearchPlaneArgs sgr_search_plane_args(const void* dgd, int stride, const void* src, int src_stride, int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask,
+                                         int64_t* sums, uint32_t* pairs, int16_t* sd, int dstride, size_t dplane, int64_t* d2, void* esc, uint32_t* esc_cnt, int esc_lim) {
+    SgrSearchPlaneArgs A = {};
+    A.dgd = dgd; A.src = src; A.sums = (unsigned long long*)sums; A.pairs = pairs; A.sd = sd; A.d2 = (unsigned long long*)d2; A.esc = (uint2*)esc; A.esc_cnt = esc_cnt;
+    A.dplane = dplane; A.stride = stride; A.src_stride = src_stride; A.pw = pw; A.ph = ph; A.unit_size = unit_size; A.units_x = units_x; A.units_y = units_y;
+    A.voff = 8 >> ss_y; A.dstride = dstride; A.tiles_x = (pw + S_TW - 1) / S_TW; A.n_tiles = A.tiles_x * ((ph + A.voff + S_TH - 1) / S_TH); A.esc_lim = esc_lim; A.ep_mask = ep_mask;
+    return A;
+}
+template <int STORE>
+int sgr_search_launch(hipStream_t st, int pix_bytes, int bd, const SgrSearchPic& a) {
+    const dim3 grid((unsigned)a.first_tile[3]);
+    if (STORE == 2) {
+        if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 2>), grid, dim3(256), 0, st, a);
+    } else if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, STORE == 2 ? 1 : STORE>), grid, dim3(256), 0, st, a);
+    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, STORE == 2 ? 1 : STORE>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, STORE == 2 ? 1 : STORE>), grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
-// the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip)
+int sgr_esc_lim() {
+    const char* lim_env = getenv("SVT_HIP_SGR_ESC_LIM");   // read per launch: tests narrow the range so that ordinary content reaches the escape lists
+    const int lim = lim_env ? atoi(lim_env) : 1024;
+    return lim < 1 ? 1 : (lim > 1024 ? 1024 : lim);
+}
+}  // namespace
+extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
+                                         int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums) {
+    SgrSearchPic a = {};
+    a.p[0] = sgr_search_plane_args(dgd, stride, src, src_stride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 1024);
+    a.first_tile[1] = a.first_tile[2] = a.first_tile[3] = a.p[0].n_tiles;
+    return sgr_search_launch<0>(st, pix_bytes, bd, a);
+}
+// the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip): every plane of the picture in one launch
+extern "C" int svt_hip_launch_sgr_search_store_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchStorePlane* pl) {
+    if (n_planes < 1 || n_planes > 3) return (int)hipErrorInvalidValue;
+    SgrSearchPic a = {};
+    bool packed = false;
+    int at = 0;
+    for (int i = 0; i < 3; i++) {
+        a.first_tile[i] = at;
+        if (i < n_planes) {
+            const SvtHipSgrSearchStorePlane& P = pl[i];
+            if (i == 0) packed = P.esc != nullptr;
+            if ((P.esc != nullptr) != packed || (packed && (bd != 8 || !P.esc_cnt))) return (int)hipErrorInvalidValue;
+            a.p[i] = sgr_search_plane_args(P.dgd, P.stride, P.src, P.src_stride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, P.ss_y, P.ep_mask, P.sums, P.pairs, P.sd, P.dstride,
+                                           P.dplane, P.d2, P.esc, P.esc_cnt, packed ? sgr_esc_lim() : 1024);
+            at += a.p[i].n_tiles;
+        }
+    }
+    a.first_tile[3] = at;
+    for (int i = n_planes; i < 3; i++) a.first_tile[i] = at;   // no tile belongs to a plane that is not there
+    return packed ? sgr_search_launch<2>(st, pix_bytes, bd, a) : sgr_search_launch<1>(st, pix_bytes, bd, a);
+}
 extern "C" int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,
                                                int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums,
                                                uint32_t* pairs, int16_t* sd, int dstride, size_t dplane, int64_t* d2, void* esc, uint32_t* esc_cnt) {
-    const int voff = 8 >> ss_y;
-    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
-    unsigned long long* s = (unsigned long long*)sums;
-    if (esc) {   // packed difference words (bit depth 8)
-        if (bd != 8 || !esc_cnt) return (int)hipErrorInvalidValue;
-        const char* lim_env = getenv("SVT_HIP_SGR_ESC_LIM");   // read per launch: tests narrow the range so that ordinary content reaches the escape lists
-        int lim = lim_env ? atoi(lim_env) : 1024;
-        lim = lim < 1 ? 1 : (lim > 1024 ? 1024 : lim);
-        if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 2>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2, (uint2*)esc, esc_cnt, lim);
-        else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 2>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2, (uint2*)esc, esc_cnt, lim);
-        return (int)hipGetLastError();
-    }
-    if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), grid8, dim3(256), 0, st, (const uint8_t*)dgd, stride, (const uint8_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
-    else if (bd == 8) hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 1>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
-    else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 10, 1>), grid8, dim3(256), 0, st, (const uint16_t*)dgd, stride, (const uint16_t*)src, src_stride, pw, ph, unit_size, units_x, units_y, voff, ep_mask, s, pairs, sd, dstride, dplane, (unsigned long long*)d2);
-    return (int)hipGetLastError();
+    const SvtHipSgrSearchStorePlane P = {dgd, src, sums, pairs, sd, d2, esc, esc_cnt, dplane, stride, src_stride, pw, ph, unit_size, units_x, units_y, ss_y, dstride, ep_mask};
+    return svt_hip_launch_sgr_search_store_multi(st, pix_bytes, bd, 1, &P);
 }
 extern "C" int svt_hip_launch_sgr_proj_error(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw, int ph,
                                              int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int ncand, const int32_t* xqd, int64_t* err) {

@@ -1002,11 +1002,13 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
     return SVT_HIP_OK;
 }
 
-// All planes of a picture: the sums / difference-plane kernel per plane, then ONE walk launch for every (plane, unit, set) — one tail instead of three.
+// All planes of a picture: ONE launch of the sums / difference-plane kernel, then ONE walk launch for every (plane, unit, set) — one tail each instead of three.
 int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrUnitsPlaneDev* pl) {
     SVT_HIP_ENTER(c);
     if (!c || !pl || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
     SvtHipSgrWalkPlane wp[3];
+    SvtHipSgrSearchStorePlane sp[3];
+    const bool packed = sgr_packed(bd);
     for (int i = 0; i < n_planes; i++) {
         const SvtHipSgrUnitsPlaneDev& P = pl[i];
         const uint32_t ep_mask = P.ep_mask & 0xFFFFu;
@@ -1016,23 +1018,25 @@ int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, in
             return SVT_HIP_ERR_BAD_ARG;
         }
         const SgrScratch L = sgr_scratch_layout(P.pw, P.ph, P.unit_size);
-        if (P.scratch_bytes < (sgr_packed(bd) ? L.total_packed : L.total)) {
+        if (P.scratch_bytes < (packed ? L.total_packed : L.total)) {
             c->err = "svt_hip_sgr_search_units_picture_dev: scratch smaller than svt_hip_sgr_search_units_scratch_bytes()";
             return SVT_HIP_ERR_BAD_ARG;
         }
         char* base = (char*)P.d_scratch;
         HIPCHK(c, hipMemsetAsync(base, 0, L.sd, c->stream));   // ... and the walk's arrival counters
         const int ux = sgr_units(P.pw, P.unit_size), uy = sgr_units(P.ph, P.unit_size);
-        const bool packed = sgr_packed(bd);
-        hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store(c->stream, pix_bytes, bd, P.d_dgd, P.stride, P.d_src, P.src_stride, P.pw, P.ph, P.unit_size, ux, uy, P.ss_y,
-                                                                  ep_mask, (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), L.dstride, L.dplane,
-                                                                  (int64_t*)(base + L.d2), packed ? base + L.esc : nullptr, (uint32_t*)(base + L.esc_cnt));
-        if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
+        sp[i] = SvtHipSgrSearchStorePlane{P.d_dgd, P.d_src, (int64_t*)(base + L.sums), (uint32_t*)(base + L.pairs), (int16_t*)(base + L.sd), (int64_t*)(base + L.d2),
+                                          packed ? base + L.esc : nullptr, (uint32_t*)(base + L.esc_cnt), L.dplane, P.stride, P.src_stride, P.pw, P.ph, P.unit_size, ux, uy, P.ss_y,
+                                          L.dstride, ep_mask};
         wp[i] = SvtHipSgrWalkPlane{(const uint32_t*)(base + L.pairs), (const int16_t*)(base + L.sd), (const int64_t*)(base + L.sums), base + L.states, L.dplane, L.dstride,
                                    P.pw, P.ph, P.unit_size, ux, uy, P.ss_y, ep_mask, P.d_xqd, P.d_err, P.d_best_ep, P.d_best_xqd, (uint32_t*)(base + L.stats),
                                    packed ? base + L.esc : nullptr, (const uint32_t*)(base + L.esc_cnt)};
     }
-    hipError_t e = (hipError_t)svt_hip_launch_sgr_walk_multi(c->stream, bd, n_planes, wp);
+    // one launch of the sums / difference-plane kernel for every plane (a chroma plane alone is one workgroup round: its launch lasts a workgroup's whole latency) ...
+    hipError_t e = (hipError_t)svt_hip_launch_sgr_search_store_multi(c->stream, pix_bytes, bd, n_planes, sp);
+    if (e != hipSuccess) return fail(c, e, "sgr search (store) launch");
+    // ... and one walk launch for every (plane, unit, set)
+    e = (hipError_t)svt_hip_launch_sgr_walk_multi(c->stream, bd, n_planes, wp);
     if (e != hipSuccess) return fail(c, e, "sgr walk launch");
     return SVT_HIP_OK;
 }

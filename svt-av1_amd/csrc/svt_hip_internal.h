@@ -120,6 +120,14 @@ int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, const void*
 int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride, int pw,
                                     int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums, uint32_t* pairs, int16_t* sd,
                                     int dstride, size_t dplane, int64_t* d2, void* esc, uint32_t* esc_cnt);   /* esc != NULL (bit depth 8 only): packed words + escape lists */
+/* one plane of svt_hip_launch_sgr_search_store_multi: the planes of a picture share one launch */
+typedef struct SvtHipSgrSearchStorePlane {
+    const void* dgd; const void* src; int64_t* sums; uint32_t* pairs; int16_t* sd; int64_t* d2; void* esc; uint32_t* esc_cnt;
+    size_t dplane;
+    int stride, src_stride, pw, ph, unit_size, units_x, units_y, ss_y, dstride;
+    uint32_t ep_mask;
+} SvtHipSgrSearchStorePlane;
+int svt_hip_launch_sgr_search_store_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchStorePlane* planes);
 int svt_hip_launch_wiener_init(hipStream_t st, int win, int n_units, const int64_t* M, const int64_t* H, int16_t* unit_wiener, uint8_t* active, int8_t* status);
 int svt_hip_launch_wiener_walk_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipWienerWalkPlane* planes);
 size_t svt_hip_sgr_walk_state_bytes(int n_units);

@@ -20,7 +20,7 @@ MAIN = r'''
 #include <cstdio>
 #include <vector>
 int main() {
-    const int pw = 3840, ph = 2160, EXT = 3, stride = pw + 2 * EXT + 58, unit = 256, ux = 15, uy = 8, voff = 8;
+    const int pw = 3840, ph = 2160, EXT = 3, stride = pw + 2 * EXT + 58, unit = 256, ux = 15, uy = 8;
     std::vector<uint8_t> h((size_t)stride * (ph + 2 * EXT)), s((size_t)pw * ph);
     uint32_t x = 12345;
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint8_t)(100 + ((x >> 24) & 31)); }
@@ -31,12 +31,11 @@ int main() {
     hipMalloc(&d_pairs, 16 * dplane * 4); hipMalloc(&d_sd, dplane * 2);
     hipMemcpy(d_dgd, h.data(), h.size(), hipMemcpyHostToDevice); hipMemcpy(d_src, s.data(), s.size(), hipMemcpyHostToDevice);
     hipMemset(d_sums, 0, 8 * ux * uy * 16 * 5); hipMemset(d_d2, 0, 8 * ux * uy);
-    dim3 grid8((pw + S_TW - 1) / S_TW, (ph + voff + S_TH - 1) / S_TH);
+    SgrSearchPic a = {};
+    a.p[0] = sgr_search_plane_args(d_dgd + EXT * stride + EXT, stride, d_src, pw, pw, ph, unit, ux, uy, 0, 0xFFFFu, (int64_t*)d_sums, d_pairs, d_sd, dstride, dplane, (int64_t*)d_d2, nullptr, nullptr, 1024);
+    a.first_tile[1] = a.first_tile[2] = a.first_tile[3] = a.p[0].n_tiles;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto go = [&]() {
-        hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), grid8, dim3(256), 0, 0, d_dgd + EXT * stride + EXT, stride, d_src, pw, pw, ph, unit, ux, uy, voff, 0xFFFFu, d_sums,
-                           d_pairs, d_sd, dstride, dplane, d_d2);
-    };
+    auto go = [&]() { hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), dim3(a.first_tile[3]), dim3(256), 0, 0, a); };
     for (int i = 0; i < 3; i++) go();
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
