@@ -497,8 +497,60 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    # SVT_BENCH_FREERUN=1 (experiment): no fork / join per step -- every frame slot is a stream of its own that replays ITS frame chain (one captured graph per frame) step
+    # after step; the slots start a quarter of a frame apart and drift freely, so at any moment the frames in flight are in different stages (one frame's strength
+    # decision -- 80 short dependent launches -- sits beside the others' searches instead of beside their decisions).  Same work, same outputs; a "step" is still
+    # nF frames, the timed region ends when every slot has finished its last frame.  Measured on the MI355X (gpurun_out/freerun_ab.txt, profiles/r06/NOTES.md): SLOWER, 8.46-8.59
+    # against 7.39-7.42 ms per step at any start lag -- a frame's chain of short dependent launches queues behind the other frames' long search workgroups (a walk
+    # workgroup lasts ~70 us) at every launch, while chains that run in lockstep find the chip idle together.  The fork / join per step is what keeps them in lockstep.
+    free_run = bool(os.environ.get("SVT_BENCH_FREERUN")) and use_graph and nF > 1
+    free_lag_us = float(os.environ.get("SVT_BENCH_FREERUN_LAG_US", "-1"))
+
+    def make_free(f):
+        batches = [pipes[i:i + f] for i in range(0, len(pipes) - f + 1, f)]
+        select_form(f)
+        for b in batches:
+            batch_step(b)      # eager once: first-touch, lazy module loads
+        torch.cuda.synchronize()
+        graphs = [[capture(lambda P=P: [P.stage_fns[k]() for k, _ in stages]) for P in b] for b in batches]
+        return graphs
+
+    def timed_free(graphs, steps, warmup, barrier, f):
+        nbat = len(graphs)
+
+        def run(n, lag):
+            for i in range(f):
+                main_streams[i].wait_stream(stream)
+                if lag > 0 and i:
+                    with torch.cuda.stream(main_streams[i]):
+                        torch.cuda._sleep(int(lag * i * 100))   # ~10 ns units (100 MHz timer)
+            for s in range(n):
+                for i in range(f):
+                    with torch.cuda.stream(main_streams[i]):
+                        graphs[s % nbat][i].replay()
+            for i in range(f):
+                stream.wait_stream(main_streams[i])
+        run(warmup, 0)
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, free_lag_us)
+        torch.cuda.synchronize()
+        if barrier and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     step_fns = make_steps(nF)
-    elapsed = timed(step_fns, args.steps, args.warmup, True)   # this rank's own time ...
+    if free_run:
+        free_graphs = make_free(nF)
+        lag0 = timed_free(free_graphs, 8, 2, False, nF) / 8 / nF * 1e6   # us per frame, measured: the slots start this far apart
+        if free_lag_us < 0: free_lag_us = lag0
+        elapsed = timed_free(free_graphs, args.steps, args.warmup, True, nF)
+    else:
+        elapsed = timed(step_fns, args.steps, args.warmup, True)   # this rank's own time ...
     per_rank_ms = [t / args.steps * 1e3 for t in shard.gather_floats(elapsed, dist if world > 1 else None, dev)]
     elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, dev)   # ... the job's time is the slowest rank's
 
@@ -845,6 +897,8 @@ def spawn_ranks(n):
 def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
     up_s = down_s = torch.cuda.Stream()   # one in-order copy stream (see run())
+    if os.environ.get("SVT_BENCH_XFER_STREAMS") == "2": down_s = torch.cuda.Stream()   # experiment: uploads and downloads on streams of their own
+    early_up = os.environ.get("SVT_BENCH_XFER_ORDER") == "early"   # experiment: the next step's upload is enqueued BEFORE this step's graph launch
     pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host = []
     up_bytes = down_bytes = 0
@@ -890,9 +944,10 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
             b = i % nb
             if do_up: stream.wait_event(up_done[b])
             if do_down and i >= nb: stream.wait_event(down_done[b])   # the results of this batch's previous step have left the device
+            if early_up and do_up and i + 1 < n: upload((i + 1) % nb)
             step_fns[b]()
             comp_done[b].record(stream)
-            if do_up and i + 1 < n: upload((i + 1) % nb)
+            if not early_up and do_up and i + 1 < n: upload((i + 1) % nb)
             if do_down: download(b)
         torch.cuda.synchronize()
 
