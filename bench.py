@@ -898,7 +898,10 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     batches = [pipes[i:i + nF] for i in range(0, len(pipes) - nF + 1, nF)][:len(step_fns)]
     up_s = down_s = torch.cuda.Stream()   # one in-order copy stream (see run())
     if os.environ.get("SVT_BENCH_XFER_STREAMS") == "2": down_s = torch.cuda.Stream()   # experiment: uploads and downloads on streams of their own
-    early_up = os.environ.get("SVT_BENCH_XFER_ORDER") == "early"   # experiment: the next step's upload is enqueued BEFORE this step's graph launch
+    # the next step's upload is enqueued BEFORE this step's graph launch: the copy stream shares the four in-order hardware queues with the frame chains, and an
+    # upload enqueued after the launch waits behind a whole step's kernels of the chain it shares a queue with (measured, gpurun_out/xfer_ab2.txt: uploads only
+    # 8.50 -> 7.96 ms per step, uploads + downloads 9.97 -> 9.20; a second copy stream is slower: 11.8).  SVT_BENCH_XFER_ORDER=late restores the old order.
+    early_up = os.environ.get("SVT_BENCH_XFER_ORDER", "early") == "early"
     pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host = []
     up_bytes = down_bytes = 0
@@ -957,7 +960,7 @@ def measure_with_transfers(torch, stream, pipes, nF, step_fns, n_sb, steps):
     t = time.perf_counter() - t0
     return {"value": nF * n_sb * steps / t, "unit": "SB/s", "ms_per_step": t / steps * 1e3, "h2d_bytes_per_frame": up_bytes, "d2h_bytes_per_frame": down_bytes,
             "note": "every step uploads its frames' source pictures (padded luma, U, V) from pinned host memory and downloads ME tables, CDEF distortion table, restoration "
-                    "search results and the restored picture, on one copy stream (next batch's upload, then this batch's download) next to the neighbouring steps' compute"}
+                    "search results and the restored picture, on one copy stream (the next batch's upload is enqueued ahead of this step's launch, this batch's download behind it) next to the neighbouring steps' compute"}
 
 
 def roofline(per_stage, stages, n_sb):
