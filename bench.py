@@ -544,13 +544,9 @@ def main():
         return time.perf_counter() - t0
 
     step_fns = make_steps(nF)
-    if free_run:
-        free_graphs = make_free(nF)
-        lag0 = timed_free(free_graphs, 8, 2, False, nF) / 8 / nF * 1e6   # us per frame, measured: the slots start this far apart
-        if free_lag_us < 0: free_lag_us = lag0
-        elapsed = timed_free(free_graphs, args.steps, args.warmup, True, nF)
-    else:
-        elapsed = timed(step_fns, args.steps, args.warmup, True)   # this rank's own time ...
+    free_graphs = make_free(nF) if free_run else None
+    if free_run and free_lag_us < 0: free_lag_us = timed_free(free_graphs, 8, 2, False, nF) / 8 / nF * 1e6   # us per frame, measured: the slots start this far apart
+    elapsed = timed_free(free_graphs, args.steps, args.warmup, True, nF) if free_run else timed(step_fns, args.steps, args.warmup, True)   # this rank's own time ...
     per_rank_ms = [t / args.steps * 1e3 for t in shard.gather_floats(elapsed, dist if world > 1 else None, dev)]
     elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, dev)   # ... the job's time is the slowest rank's
 
