@@ -258,6 +258,23 @@ class Pipeline:
             self.chk(L.svt_hip_generate_padding_dev(h, self.p_cdef[p], 1, self.xs[p], pw, ph, EXT, EXT), "extend")
         self.chk(L.svt_hip_sgr_search_units_picture_dev(h, 1, 8, 3, self.SGRJ), "sgr units")   # one sums launch per plane, one walk launch for the picture
 
+    def run_sgr_extend(self):
+        L, h, F = self.E.L, self.E.ctx.h, self.F
+        for p in range(3):
+            ph, pw = F.cur[p].shape
+            self.chk(L.svt_hip_generate_padding_dev(h, self.p_cdef[p], 1, self.xs[p], pw, ph, EXT, EXT), "extend")
+
+    @staticmethod
+    def run_sgr_units_batch(batch):
+        """the restoration unit search of every frame of the batch in ONE pair of launches: the planes of up to four pictures share the sums / difference-plane launch and
+        the walk launch (include/svt_hip.h: SVT_HIP_SGR_MAX_PLANES)"""
+        P0 = batch[0]
+        n = 3 * len(batch)
+        arr = (type(P0.SGRJ[0]) * n)()
+        for i, P in enumerate(batch):
+            for p in range(3): arr[3 * i + p] = P.SGRJ[p]
+        P0.chk(P0.E.L.svt_hip_sgr_search_units_picture_dev(P0.E.ctx.h, 1, 8, n, arr), "sgr units (batch)")
+
     def run_sgr_apply(self):   # every unit filtered with the set / xqd its search chose (device arrays), stripe context rows from the deblocked picture
         L, h, F = self.E.L, self.E.ctx.h, self.F
         for p in range(3):
@@ -390,7 +407,10 @@ def main():
     # late chain gains beside the others' decisions it loses alone at the tail.  "off" (default): every chain starts at once.
     stagger = os.environ.get("SVT_BENCH_STAGGER", STAGGER_DEFAULT)
     stagger_stage, stagger_lag = (stagger.split(":")[0], int(stagger.split(":")[1])) if stagger not in ("", "off") else (None, 0)
-    joint_pick = bool(os.environ.get("SVT_BENCH_PICK_JOINT"))   # measured slower (9.9 vs 9.5 ms): the join idles the other streams for the length of the chain   # A/B: the strength decision per frame, inside each frame's own chain (the round-3 first form)
+    # SVT_BENCH_SGR_JOINT=1 (experiment): the restoration unit search of the step's frames as ONE pair of launches (twelve planes; the frame chains join before it).
+    # Measured on the MI355X (gpurun_out/sgr_joint_ab.txt): 7.68-7.69 against 7.32-7.35 ms per step -- like the joint strength decision, the join idles the chains.
+    joint_sgr = bool(os.environ.get("SVT_BENCH_SGR_JOINT"))
+    joint_pick = bool(os.environ.get("SVT_BENCH_PICK_JOINT")) and not joint_sgr   # measured slower (9.9 vs 9.5 ms): the join idles the other streams for the length of the chain   # A/B: the strength decision per frame, inside each frame's own chain (the round-3 first form)
 
     # CDEF strength selection: the one-launch (resident) form when ONE frame is in flight, the launch-per-step form when several are (include/svt_hip.h: the
     # resident form's workgroups wait for each other, so selections serialise and other frames' kernels delay it; measured 12.1 against 9.5 ms at four frames,
@@ -408,6 +428,7 @@ def main():
         select_form(len(batch))
         keys = [k for k, _ in stages]
         split = keys.index("cdef_pick") if (joint_pick and "cdef_pick" in keys and len(batch) > 1) else None
+        if joint_sgr and "sgr_units" in keys and len(batch) > 1 and split is None: split = keys.index("sgr_units")
         halves = [keys] if split is None else [keys[:split], keys[split + 1:]]
         for hi, half in enumerate(halves):
             used = []
@@ -420,7 +441,7 @@ def main():
                 used.append(ms)
                 with on(ms):
                     if hi == 0 and pre is not None: pre(P)
-                    if hi == 1: P.run_cdef_finish()
+                    if hi == 1 and not joint_sgr: P.run_cdef_finish()
                     for k in half:
                         P.stage_fns[k]()
                         if k == stagger_stage and len(batch) > 1:
@@ -429,7 +450,11 @@ def main():
             for st in used:
                 base.wait_stream(st)
             if hi == 0 and split is not None:
-                Pipeline.run_cdef_pick_batch(batch)   # on the base stream: after every frame's CDEF search, before every frame's CDEF apply
+                if joint_sgr:   # on the base stream: the border extension of every frame's CDEF output, then ONE unit search for all of them
+                    for P in batch: P.run_sgr_extend()
+                    Pipeline.run_sgr_units_batch(batch)
+                else:
+                    Pipeline.run_cdef_pick_batch(batch)   # on the base stream: after every frame's CDEF search, before every frame's CDEF apply
 
     def capture(fn, reps=1):
         """One HIP graph of `reps` back-to-back calls of fn(): a step is a few hundred short launches, replaying a captured graph takes the host

@@ -496,6 +496,9 @@ typedef struct {
     int32_t *d_best_xqd;  /* device [units][2] or NULL */
     void *d_scratch; size_t scratch_bytes;   /* svt_hip_sgr_search_units_scratch_bytes(pw, ph, unit_size) */
 } SvtHipSgrUnitsPlaneDev;
+/* n_planes <= SVT_HIP_SGR_MAX_PLANES: the planes of up to FOUR pictures (same pixel type and bit depth) may share the two launches -- `planes` is then the
+ * pictures' planes one after the other; every plane brings its own scratch and outputs, so the pictures stay independent. */
+#define SVT_HIP_SGR_MAX_PLANES 12
 int svt_hip_sgr_search_units_picture_dev(SvtHipCtx *ctx, int pix_bytes, int bd, int n_planes, const SvtHipSgrUnitsPlaneDev *planes);
 /* HOST-output convenience form on library-owned device scratch: xqd_out[unit][16][2], err_out[unit][16] (sets outside the mask untouched),
  * best_ep[unit] (may be NULL); *rounds_out (may be NULL) is always 0 (kept from the host-driven search of earlier versions).  Synchronous: one

@@ -438,12 +438,15 @@ struct SgrSearchPlaneArgs {
     int stride, src_stride, pw, ph, unit_size, units_x, units_y, voff, dstride, tiles_x, n_tiles, esc_lim;
     uint32_t ep_mask;
 };
-struct SgrSearchPic { SgrSearchPlaneArgs p[3]; int first_tile[4]; };
+constexpr int kSgrMaxPlanes = 12;   // the planes of up to four pictures (include/svt_hip.h: SVT_HIP_SGR_MAX_PLANES)
+struct SgrSearchPic { SgrSearchPlaneArgs p[kSgrMaxPlanes]; int first_tile[kSgrMaxPlanes + 1]; };
 template <typename PIX, int BD = 8, int STORE = 0>
 __global__ void __launch_bounds__(256)
 sgr_search8_kernel(const SgrSearchPic a) {
     // scalar copies of this workgroup's plane (a reference into the kernel-argument struct with a run-time index would force a private copy of the whole struct)
-    const int z = (int)blockIdx.x >= a.first_tile[2] ? 2 : ((int)blockIdx.x >= a.first_tile[1] ? 1 : 0);
+    int z = 0;
+#pragma unroll
+    for (int i = 1; i < kSgrMaxPlanes; i++) z += (int)blockIdx.x >= a.first_tile[i];   // first_tile of a plane that is not there = the grid size
     const PIX* __restrict__ dgd = (const PIX*)a.p[z].dgd; const PIX* __restrict__ src = (const PIX*)a.p[z].src;
     unsigned long long* __restrict__ sums = a.p[z].sums; uint32_t* __restrict__ pairs = a.p[z].pairs; int16_t* __restrict__ sd = a.p[z].sd;
     unsigned long long* __restrict__ d2 = a.p[z].d2; uint2* __restrict__ esc = a.p[z].esc; uint32_t* __restrict__ esc_cnt = a.p[z].esc_cnt;
@@ -1360,7 +1363,7 @@ SgrSearchPlaneArgs sgr_search_plane_args(const void* dgd, int stride, const void
 }
 template <int STORE>
 int sgr_search_launch(hipStream_t st, int pix_bytes, int bd, const SgrSearchPic& a) {
-    const dim3 grid((unsigned)a.first_tile[3]);
+    const dim3 grid((unsigned)a.first_tile[kSgrMaxPlanes]);
     if (STORE == 2) {
         if (pix_bytes == 1) hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((sgr_search8_kernel<uint16_t, 8, 2>), grid, dim3(256), 0, st, a);
@@ -1379,28 +1382,25 @@ extern "C" int svt_hip_launch_sgr_search(hipStream_t st, int pix_bytes, int bd, 
                                          int pw, int ph, int unit_size, int units_x, int units_y, int ss_y, uint32_t ep_mask, int64_t* sums) {
     SgrSearchPic a = {};
     a.p[0] = sgr_search_plane_args(dgd, stride, src, src_stride, pw, ph, unit_size, units_x, units_y, ss_y, ep_mask, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 1024);
-    a.first_tile[1] = a.first_tile[2] = a.first_tile[3] = a.p[0].n_tiles;
+    for (int i = 1; i <= kSgrMaxPlanes; i++) a.first_tile[i] = a.p[0].n_tiles;
     return sgr_search_launch<0>(st, pix_bytes, bd, a);
 }
 // the search kernel with the int16 difference planes of the on-device unit search (sgr_walk.hip): every plane of the picture in one launch
 extern "C" int svt_hip_launch_sgr_search_store_multi(hipStream_t st, int pix_bytes, int bd, int n_planes, const SvtHipSgrSearchStorePlane* pl) {
-    if (n_planes < 1 || n_planes > 3) return (int)hipErrorInvalidValue;
+    if (n_planes < 1 || n_planes > kSgrMaxPlanes) return (int)hipErrorInvalidValue;
     SgrSearchPic a = {};
     bool packed = false;
     int at = 0;
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < n_planes; i++) {
         a.first_tile[i] = at;
-        if (i < n_planes) {
-            const SvtHipSgrSearchStorePlane& P = pl[i];
-            if (i == 0) packed = P.esc != nullptr;
-            if ((P.esc != nullptr) != packed || (packed && (bd != 8 || !P.esc_cnt))) return (int)hipErrorInvalidValue;
-            a.p[i] = sgr_search_plane_args(P.dgd, P.stride, P.src, P.src_stride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, P.ss_y, P.ep_mask, P.sums, P.pairs, P.sd, P.dstride,
-                                           P.dplane, P.d2, P.esc, P.esc_cnt, packed ? sgr_esc_lim() : 1024);
-            at += a.p[i].n_tiles;
-        }
+        const SvtHipSgrSearchStorePlane& P = pl[i];
+        if (i == 0) packed = P.esc != nullptr;
+        if ((P.esc != nullptr) != packed || (packed && (bd != 8 || !P.esc_cnt))) return (int)hipErrorInvalidValue;
+        a.p[i] = sgr_search_plane_args(P.dgd, P.stride, P.src, P.src_stride, P.pw, P.ph, P.unit_size, P.units_x, P.units_y, P.ss_y, P.ep_mask, P.sums, P.pairs, P.sd, P.dstride,
+                                       P.dplane, P.d2, P.esc, P.esc_cnt, packed ? sgr_esc_lim() : 1024);
+        at += a.p[i].n_tiles;
     }
-    a.first_tile[3] = at;
-    for (int i = n_planes; i < 3; i++) a.first_tile[i] = at;   // no tile belongs to a plane that is not there
+    for (int i = n_planes; i <= kSgrMaxPlanes; i++) a.first_tile[i] = at;   // the grid size; no tile belongs to a plane that is not there
     return packed ? sgr_search_launch<2>(st, pix_bytes, bd, a) : sgr_search_launch<1>(st, pix_bytes, bd, a);
 }
 extern "C" int svt_hip_launch_sgr_search_store(hipStream_t st, int pix_bytes, int bd, const void* dgd, int stride, const void* src, int src_stride,

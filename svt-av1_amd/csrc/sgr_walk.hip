@@ -45,7 +45,8 @@ struct WalkPlane {   // one plane's arguments of a walk launch
     int32_t* xqd_out; int64_t* err_out; uint32_t* counters; uint8_t* best_ep; int32_t* best_xqd; uint32_t* stats;
     const uint2* esc; const uint32_t* esc_cnt;   // packed form only (sgr_walk_packed_kernel): the samples whose differences do not fit the packed word, per (unit, set)
 };
-struct WalkPic { WalkPlane p[3]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=1 switches them on)
+constexpr int kWalkMaxPlanes = 12;   // the planes of up to four pictures share a launch (grid.z)
+struct WalkPic { WalkPlane p[kWalkMaxPlanes]; int cap, clocks, hist_w; };   // hist_w: largest |flt - u| the histogram evaluation takes (<= the instance's kHistW; tests narrow it to reach both paths)   // clocks: also accumulate the walks' phase clocks (diagnostics; SVT_HIP_SGR_WALK_CLOCKS=1 switches them on)
 constexpr int kCache   = 256;    // evaluated points a walk can remember, see kThrottle
 // The exact walk (finer_search_pixel_proj_error, EbRestorationPick.c:353-440) evaluates at most 1 + 2 x (1 + 63) + 4 = 133 points: per parameter at step 2 one rejected
 // downward probe and then <= 63 upward ones (or <= 63 downward ones), at step 1 two probes per parameter.  Speculative requests (points the quadratic model walks
@@ -1250,7 +1251,7 @@ extern "C" size_t svt_hip_sgr_walk_state_bytes(int n_units) { return sizeof(uint
 
 // planes[i]: the arguments of svt_hip_launch_sgr_walk for plane i; one launch for all of them (resident / hybrid forms), one per plane (streamed form)
 extern "C" int svt_hip_launch_sgr_walk_multi(hipStream_t st, int bd, int n_planes, const SvtHipSgrWalkPlane* planes) {
-    if (n_planes < 1 || n_planes > 3) return (int)hipErrorInvalidValue;
+    if (n_planes < 1 || n_planes > kWalkMaxPlanes) return (int)hipErrorInvalidValue;
     // SVT_HIP_SGR_WALK = stream | resident | hybrid selects the form (A/B measurements, tools/hbd_time.py); default: hybrid
     static const char* form_env = getenv("SVT_HIP_SGR_WALK");
     const bool stream_form = form_env && !strcmp(form_env, "stream"), resident_form = form_env && !strcmp(form_env, "resident");

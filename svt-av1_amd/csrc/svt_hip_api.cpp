@@ -1005,9 +1005,9 @@ int svt_hip_sgr_search_units_plane_dev(SvtHipCtx* c, int pix_bytes, int bd, cons
 // All planes of a picture: ONE launch of the sums / difference-plane kernel, then ONE walk launch for every (plane, unit, set) — one tail each instead of three.
 int svt_hip_sgr_search_units_picture_dev(SvtHipCtx* c, int pix_bytes, int bd, int n_planes, const SvtHipSgrUnitsPlaneDev* pl) {
     SVT_HIP_ENTER(c);
-    if (!c || !pl || n_planes < 1 || n_planes > 3) return SVT_HIP_ERR_BAD_ARG;
-    SvtHipSgrWalkPlane wp[3];
-    SvtHipSgrSearchStorePlane sp[3];
+    if (!c || !pl || n_planes < 1 || n_planes > SVT_HIP_SGR_MAX_PLANES) return SVT_HIP_ERR_BAD_ARG;
+    SvtHipSgrWalkPlane wp[SVT_HIP_SGR_MAX_PLANES];
+    SvtHipSgrSearchStorePlane sp[SVT_HIP_SGR_MAX_PLANES];
     const bool packed = sgr_packed(bd);
     for (int i = 0; i < n_planes; i++) {
         const SvtHipSgrUnitsPlaneDev& P = pl[i];

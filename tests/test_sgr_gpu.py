@@ -544,3 +544,36 @@ def test_search_units_picture_dev(hip, pkg, orc, bd):
         on = np.array([(mask >> e) & 1 for e in range(16)], bool)
         assert np.array_equal(g_err[:, on], e_err[:, on]) and np.array_equal(g_xqd[:, on], e_xqd[:, on]) and np.array_equal(g_best, e_best), (bd, nu, hex(mask))
         hip.free(*d.values())
+
+
+@pytest.mark.parametrize("n_pics", [2, 4])
+def test_search_units_several_pictures_one_call(hip, pkg, orc, n_pics):
+    """svt_hip_sgr_search_units_picture_dev with the planes of SEVERAL pictures (n_planes = 3 x pictures <= SVT_HIP_SGR_MAX_PLANES = 12): one sums / difference-plane
+    launch over every plane's tiles and one walk launch for every (plane, unit, set) -- the north-star's "many concurrent frames in one launch per kernel class" for the
+    restoration unit search.  Pictures of different sizes, unit sizes and set masks; every plane against the oracle's per-plane search; a thirteenth plane is refused."""
+    bd = 8
+    shapes = [(328, 264, 128, 0, 0xFFFF), (168, 136, 64, 1, 0x0F3C), (200, 96, 64, 1, 0x8001), (264, 200, 64, 0, 0x4421), (136, 104, 64, 1, 0xFFFF), (136, 104, 64, 1, 0x03C0)]
+    planes = [shapes[(3 * q + p) % len(shapes)] for q in range(n_pics) for p in range(3)]
+    L = hip.L
+    L.svt_hip_sgr_search_units_scratch_bytes.restype = C.c_size_t
+    jobs = (pkg.SgrUnitsPlaneDev * len(planes))()
+    keep, expect = [], []
+    for i, (w, h, US, ss, mask) in enumerate(planes):
+        src, ext = _smooth_noisy(w, h, bd, 2500 + 10 * i, 5 + i % 4)
+        st = ext.shape[1]; off = (EXT * st + EXT) * ext.itemsize
+        nu = units(w, US) * units(h, US)
+        e_xqd = np.zeros((nu, 16, 2), np.int32); e_err = np.zeros((nu, 16), np.int64); e_best = np.zeros(nu, np.uint8)
+        orc.orc_sgr_search_units_plane(C.c_void_p(ext.ctypes.data + off), ext.itemsize, st, ptr(src), w, w, h, ss, ss, US, bd, mask, ptr(e_xqd), ptr(e_err), ptr(e_best))
+        nbytes = L.svt_hip_sgr_search_units_scratch_bytes(w, h, US)
+        d = dict(ext=hip.to_device(ext), src=hip.to_device(src), scr=hip.empty(nbytes), xqd=hip.to_device(np.zeros_like(e_xqd)), err=hip.to_device(np.zeros_like(e_err)),
+                 best=hip.empty(nu), bx=hip.empty(nu * 8))
+        keep.append(d); expect.append((nu, mask, e_xqd, e_err, e_best))
+        jobs[i] = pkg.SgrUnitsPlaneDev(d["ext"].value + off, st, d["src"].value, w, w, h, US, ss, mask, d["xqd"].value, d["err"].value, d["best"].value, d["bx"].value,
+                                       d["scr"].value, nbytes)
+    hip.check(L.svt_hip_sgr_search_units_picture_dev(hip.h, 1, bd, len(planes), jobs), "units of several pictures")
+    for d, (nu, mask, e_xqd, e_err, e_best) in zip(keep, expect):
+        g_xqd = hip.to_host(d["xqd"], e_xqd.shape, np.int32); g_err = hip.to_host(d["err"], e_err.shape, np.int64); g_best = hip.to_host(d["best"], e_best.shape, np.uint8)
+        on = np.array([(mask >> e) & 1 for e in range(16)], bool)
+        assert np.array_equal(g_err[:, on], e_err[:, on]) and np.array_equal(g_xqd[:, on], e_xqd[:, on]) and np.array_equal(g_best, e_best), (n_pics, nu, hex(mask))
+    assert L.svt_hip_sgr_search_units_picture_dev(hip.h, 1, bd, 13, jobs) != 0
+    for d in keep: hip.free(*d.values())
