@@ -232,11 +232,65 @@ __device__ void sad_loop16_generic(uint16_t* __restrict__ s_blk, unsigned long l
 }
 
 // The same search for the shapes configs[3] of BASELINE.json asks for (block 16..64 wide in multiples of 16, search area a multiple of 8 wide, every row of
-// the block): the reference window goes through LDS once, in TWO copies -- copy 0 as it lies, copy 1 shifted by one sample -- so that a candidate at an odd
-// column reads its sample pairs as aligned dwords too; a lane owns 8 horizontally adjacent candidates of one candidate row and feeds v_sad_u16 (two samples
-// per instruction) from 128-bit LDS reads: per 8 source pairs 6 reads for 64 SAD instructions.  Keys sad << 32 | candidate index keep the reference's first
-// minimum in raster order.  16.8 M absolute differences per 64x64 / 64x64 search = 131 k wave instructions.
-constexpr int kS16 = 68;   // row stride of a window copy in dwords (272 B: 16-byte aligned rows, consecutive rows 4 banks apart)
+// the block): the reference window goes through LDS once as aligned sample pairs; a lane owns 8 horizontally adjacent candidates of one candidate row and feeds
+// v_sad_u16 (two samples per instruction).  Per 8 source pairs: three 128-bit LDS reads of the window, eleven v_alignbit_b32 that form the pairs of the four
+// candidates at odd columns from neighbouring dwords, and 64 SAD instructions; the source pairs are wave-uniform and come through scalar loads when the source
+// block is dword-aligned (else from an LDS copy).  Round 6: one window copy instead of two (69 -> 34.5 KB: three workgroups per compute unit instead of two) and
+// three LDS reads per 64 SADs instead of eight, no source copy in LDS (34.5 KB: four workgroups per compute unit instead of two) -- and the source pairs of a whole block row come through scalar loads issued a row ahead: 4K 10-bit 64x64 / 64x64 search 0.737 -> 0.60 ms (profiles/r06/NOTES.md).  Keys sad << 32 | candidate index keep the
+// reference's first minimum in raster order.  16.8 M absolute differences per 64x64 / 64x64 search = 131 k wave instructions.
+constexpr int kS16 = 68;   // row stride of the window in dwords (272 B: 16-byte aligned rows, consecutive rows 4 banks apart)
+typedef const __attribute__((address_space(4))) uint32_t* sad16_const_u32_ptr;
+// one group of 8 source pairs (16 samples) against the 8 candidates of the lane: w0 = 12 window dwords from the lane's first candidate on
+__device__ __forceinline__ void sad16_group(const uint4* __restrict__ q, const uint32_t (&sv)[8], uint32_t (&acc)[8]) {
+    const uint4 a0 = q[0], a1 = q[1], a2 = q[2];
+    const uint32_t w0[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+    uint32_t w1[11];   // the pairs one sample further: (w0[k] >> 16) | (w0[k + 1] << 16)
+#pragma unroll
+    for (int k = 0; k < 11; k++) w1[k] = __builtin_amdgcn_alignbit(w0[k + 1], w0[k], 16);
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            acc[j] = __builtin_amdgcn_sad_u16((j & 1) ? w1[p + (j >> 1)] : w0[p + (j >> 1)], sv[p], acc[j]);
+}
+// source pairs through scalar loads, a whole block row (NG groups) at a time and the NEXT row's loads issued before this row's arithmetic (a scalar load per
+// group, waited for on the spot, left the SAD pipe idle half of the time)
+template <int NG>
+__device__ __forceinline__ void sad16_rows_scalar(const uint32_t* __restrict__ s_w, const uint16_t* __restrict__ src_blk, int src_stride, int bh, int cx, int cy, uint32_t (&acc)[8]) {
+    uint32_t cur[8 * NG], nxt[8 * NG];
+    {
+        sad16_const_u32_ptr sp = (sad16_const_u32_ptr)src_blk;
+#pragma unroll
+        for (int k = 0; k < 8 * NG; k++) cur[k] = sp[k];
+    }
+    for (int y = 0; y < bh; y++) {
+        sad16_const_u32_ptr sn = (sad16_const_u32_ptr)(src_blk + (size_t)min(y + 1, bh - 1) * src_stride);   // wave-uniform (the last row is loaded twice: no branch)
+#pragma unroll
+        for (int k = 0; k < 8 * NG; k++) nxt[k] = sn[k];
+        const uint4* __restrict__ q = (const uint4*)(s_w + (cy + y) * kS16 + (cx >> 1));
+#pragma unroll
+        for (int c = 0; c < NG; c++) {
+            const uint32_t sv[8] = {cur[8 * c], cur[8 * c + 1], cur[8 * c + 2], cur[8 * c + 3], cur[8 * c + 4], cur[8 * c + 5], cur[8 * c + 6], cur[8 * c + 7]};
+            sad16_group(q + 2 * c, sv, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < 8 * NG; k++) cur[k] = nxt[k];
+    }
+}
+// a source block that does not start on a dword (odd column, odd stride): its pairs are formed from 16-bit loads (wave-uniform addresses; the rare path)
+__device__ __forceinline__ void sad16_rows_unaligned(const uint32_t* __restrict__ s_w, const uint16_t* __restrict__ src_blk, int src_stride, int bw, int bh, int cx, int cy,
+                                                     uint32_t (&acc)[8]) {
+    for (int y = 0; y < bh; y++) {
+        const uint4* __restrict__ q = (const uint4*)(s_w + (cy + y) * kS16 + (cx >> 1));
+        const uint16_t* __restrict__ sr = src_blk + (size_t)y * src_stride;
+        for (int c = 0; c < (bw >> 4); c++) {   // 8 source pairs (16 samples) at a time
+            uint32_t sv[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) sv[p] = (uint32_t)sr[16 * c + 2 * p] | ((uint32_t)sr[16 * c + 2 * p + 1] << 16);
+            sad16_group(q + 2 * c, sv, acc);
+        }
+    }
+}
 __global__ void __launch_bounds__(256)
 sad_loop16_lds_kernel(const uint16_t* __restrict__ src, int src_stride, const uint16_t* __restrict__ ref, int ref_stride,
                       const SvtHipSadLoop* __restrict__ searches, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy) {
@@ -251,21 +305,19 @@ sad_loop16_lds_kernel(const uint16_t* __restrict__ src, int src_stride, const ui
         return;
     }
     const int bw = d.bw, bh = d.bh, sa_w = d.sa_w, sa_h = d.sa_h, wr = bh + sa_h - 1, ww = bw + sa_w - 1;
-    uint32_t* __restrict__ s_src = s_dyn;                      // [bh][32] dwords (row stride 32: bw <= 64)
-    uint32_t* __restrict__ s_w0 = s_dyn + 64 * 32;              // [wr][kS16]
-    uint32_t* __restrict__ s_w1 = s_w0 + 127 * kS16;
-    for (int i = tid; i < bh * (bw >> 1); i += 256) {
-        const int y = i / (bw >> 1), x = i - y * (bw >> 1);
-        const uint16_t* p = src + (size_t)(d.src_y + y) * src_stride + d.src_x + 2 * x;
-        s_src[y * 32 + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
-    }
-    for (int i = tid; i < wr * 64; i += 256) {   // dword i of a window row: samples 2i, 2i + 1 (copy 0) / 2i + 1, 2i + 2 (copy 1); zero past the window
-        const int y = i >> 6, x = i & 63;
-        const uint16_t* p = ref + (size_t)(d.ref_y + y) * ref_stride + d.ref_x;
-        const uint32_t a = 2 * x < ww ? p[2 * x] : 0u, b = 2 * x + 1 < ww ? p[2 * x + 1] : 0u, c = 2 * x + 2 < ww ? p[2 * x + 2] : 0u;
-        s_w0[y * kS16 + x] = a | (b << 16);
-        s_w1[y * kS16 + x] = b | (c << 16);
-    }
+    uint32_t* __restrict__ s_w = s_dyn;                        // [wr][kS16]
+    const uint16_t* __restrict__ src_blk = src + (size_t)d.src_y * src_stride + d.src_x;
+    const bool src_scalar = (((uintptr_t)src_blk | (uintptr_t)(2 * src_stride)) & 3) == 0;   // every source row starts on a dword: its pairs are scalar loads
+    // dword i of a window row: samples 2i, 2i + 1; zero past the window.  Eight dwords = sixteen 16-bit loads in flight per thread (one dword per iteration is 32
+    // dependent memory round trips per workgroup before the first SAD); the loads are unconditional on clamped columns, the zeroing is a select
+    batched_stage<8, uint32_t>(wr * 64, tid, 256,
+        [&](int i) {
+            const int y = i >> 6, x = i & 63;
+            const uint16_t* p = ref + (size_t)(d.ref_y + y) * ref_stride + d.ref_x;
+            const uint32_t a = p[min(2 * x, ww - 1)], b = p[min(2 * x + 1, ww - 1)];
+            return (2 * x < ww ? a : 0u) | ((2 * x + 1 < ww ? b : 0u) << 16);
+        },
+        [&](int i, uint32_t v) { s_w[(i >> 6) * kS16 + (i & 63)] = v; });
     __syncthreads();
     unsigned long long best = ((unsigned long long)0xffffffu << 32) | 0xffffffffu;
     const int g = lane & 7, r = lane >> 3, cx = 8 * g;
@@ -273,23 +325,11 @@ sad_loop16_lds_kernel(const uint16_t* __restrict__ src, int src_stride, const ui
         const int cy = cy0 + 8 * wave + r;
         if (cx < sa_w && cy < sa_h) {   // sa_w is a multiple of 8: a lane's eight candidates are all inside or all outside
             uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int y = 0; y < bh; y++) {
-                const uint4* __restrict__ q0 = (const uint4*)(s_w0 + (cy + y) * kS16 + (cx >> 1));
-                const uint4* __restrict__ q1 = (const uint4*)(s_w1 + (cy + y) * kS16 + (cx >> 1));
-                const uint4* __restrict__ qs = (const uint4*)(s_src + y * 32);
-                for (int c = 0; c < (bw >> 4); c++) {   // 8 source pairs (16 samples) at a time
-                    const uint4 a0 = q0[2 * c], a1 = q0[2 * c + 1], a2 = q0[2 * c + 2], b0 = q1[2 * c], b1 = q1[2 * c + 1], b2 = q1[2 * c + 2];
-                    const uint4 s0 = qs[2 * c], s1 = qs[2 * c + 1];
-                    const uint32_t w0[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
-                    const uint32_t w1[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-                    const uint32_t sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-                    for (int p = 0; p < 8; p++)
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            acc[j] = __builtin_amdgcn_sad_u16((j & 1) ? w1[p + (j >> 1)] : w0[p + (j >> 1)], sv[p], acc[j]);
-                }
-            }
+            if (!src_scalar) sad16_rows_unaligned(s_w, src_blk, src_stride, bw, bh, cx, cy, acc);
+            else if (bw == 64) sad16_rows_scalar<4>(s_w, src_blk, src_stride, bh, cx, cy, acc);
+            else if (bw == 48) sad16_rows_scalar<3>(s_w, src_blk, src_stride, bh, cx, cy, acc);
+            else if (bw == 32) sad16_rows_scalar<2>(s_w, src_blk, src_stride, bh, cx, cy, acc);
+            else sad16_rows_scalar<1>(s_w, src_blk, src_stride, bh, cx, cy, acc);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const unsigned long long key = ((unsigned long long)acc[j] << 32) | (uint32_t)(cy * sa_w + cx + j);
@@ -332,7 +372,7 @@ extern "C" int svt_hip_launch_sad_loop(hipStream_t st, const uint8_t* src, int s
 extern "C" int svt_hip_launch_sad_loop16(hipStream_t st, const uint16_t* src, int src_stride, const uint16_t* ref, int ref_stride, const SvtHipSadLoop* searches, int n,
                                              uint32_t* best_sad, int16_t* best_xy) {
     if (n <= 0) return 0;
-    constexpr size_t lds = sizeof(uint32_t) * (64 * 32 + 2 * 127 * kS16);
+    constexpr size_t lds = sizeof(uint32_t) * (127 * kS16);   // one window copy, 34.5 KB: four workgroups per compute unit (the generic form stages a source block of <= 8 KB there)
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)sad_loop16_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
     hipLaunchKernelGGL(sad_loop16_lds_kernel, dim3(n), dim3(256), lds, st, src, src_stride, ref, ref_stride, searches, best_sad, best_xy);
