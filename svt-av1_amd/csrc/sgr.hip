@@ -372,7 +372,7 @@ __device__ __forceinline__ long long row16_sum_wide(int32_t p0, int32_t p1) {
 // sum; the compiler turned each into a scalar branch (~30 per set) and serialised the five DPP reductions behind s_nops: the projection sums took 21 % and the
 // stores 15 % of the launch for 11 % and 6 % of its instructions (tools/ubench/sgr_filter_probe.py on the MI355X).  Here the filter pair is a template
 // parameter, every row is valid, and the five reductions advance in lockstep.
-template <bool H0, bool H1, int STORE>
+template <bool H0, bool H1, int STORE, int BD = 8>
 __device__ __forceinline__ void sgr8_set_interior(uint32_t* __restrict__ abw, const uint32_t* __restrict__ xt, const uint32_t (&P)[S_KP], const uint32_t (&M)[S_KP], uint32_t s0,
                                                   uint32_t s1, int tid, int i0, int j, const uint32_t (&X)[8], const int32_t (&CX)[8], const int32_t (&SV)[8],
                                                   uint32_t* __restrict__ pairs_px, int dstride, int32_t* __restrict__ part_ep) {
@@ -392,10 +392,41 @@ __device__ __forceinline__ void sgr8_set_interior(uint32_t* __restrict__ abw, co
     }
     __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)
     int32_t D0[8], D1[8];
-    sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1);
+    if (BD == 8) sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1); else sgr10_filter(abw, i0, j, X, CX, H0, H1, D0, D1);
     if (STORE == 1) {
 #pragma unroll
         for (int r = 0; r < 8; r++) SGR_ST(&pairs_px[(size_t)r * dstride], ((uint32_t)(H0 ? D0[r] : 0) & 0xFFFFu) | ((uint32_t)(H1 ? D1[r] : 0) << 16));
+    }
+    if (BD > 8) {
+        // bit depth 10: |flt - u| < 2^14.1, a product < 2^28.1 -> four rows per int32 partial; the low 16 bits and the signed upper halves of the two partials are
+        // reduced separately (ten values in lockstep), first inside the 16-lane rows, then over the four rows (row_bcast), and the wave's two totals per sum go to
+        // its own LDS slots: [sum][wave][lo, hi], the sum is hi * 65536 + lo
+        int32_t g[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (H0) { g[0][r >> 2] += __mul24(D0[r], D0[r]); g[3][r >> 2] += __mul24(D0[r], SV[r]); }
+            if (H1) { g[2][r >> 2] += __mul24(D1[r], D1[r]); g[4][r >> 2] += __mul24(D1[r], SV[r]); }
+            if (H0 && H1) g[1][r >> 2] += __mul24(D0[r], D1[r]);
+        }
+        constexpr bool use10[5] = {H0, H0 && H1, H1, H0, H1};
+        int32_t v[10];
+#pragma unroll
+        for (int q = 0; q < 5; q++) { v[2 * q] = (g[q][0] & 0xFFFF) + (g[q][1] & 0xFFFF); v[2 * q + 1] = (g[q][0] >> 16) + (g[q][1] >> 16); }
+#define SGR_RED10_(ctl)                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 10; q++) if (use10[q >> 1]) v[q] += __builtin_amdgcn_mov_dpp(v[q], ctl, 0xF, 0xF, true);
+        SGR_RED10_(0xB1) SGR_RED10_(0x4E) SGR_RED10_(0x141) SGR_RED10_(0x140)
+#undef SGR_RED10_
+#pragma unroll
+        for (int q = 0; q < 10; q++)
+            if (use10[q >> 1]) {   // every lane of a row holds the row's total: rows 1 and 3 add the row before them, rows 2 and 3 add rows 0 + 1 -> the lanes of row 3 hold the wave's
+                v[q] += __builtin_amdgcn_update_dpp(0, v[q], 0x142, 0xA, 0xF, false);   // row_bcast:15
+                v[q] += __builtin_amdgcn_update_dpp(0, v[q], 0x143, 0xC, 0xF, false);   // row_bcast:31
+            }
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 10; q++) if (use10[q >> 1]) part_ep[(q >> 1) * 8 + (tid >> 6) * 2 + (q & 1)] = v[q];
+        }
+        return;
     }
     int32_t h[5] = {0, 0, 0, 0, 0};   // H00, H01, H11, C0, C1
 #pragma unroll
@@ -525,11 +556,11 @@ sgr_search8_kernel(const SgrSearchPic a) {
         const bool has0 = kSgr[ep][0] > 0, has1 = kSgr[ep][1] > 0;
         const uint32_t s0 = (uint32_t)kSgr[ep][2], s1 = (uint32_t)kSgr[ep][3];
         uint32_t* abw = ab[buf];
-        if (BD == 8 && STORE != 2 && interior) {   // the common case as straight-line code, one instance per filter pair
+        if (STORE != 2 && interior) {   // the common case as straight-line code, one instance per filter pair
             uint32_t* ppx = STORE == 1 ? &pairs[(size_t)ep * dplane + (size_t)(y0 + i0) * dstride + x0 + j] : nullptr;
-            if (has0 && has1) sgr8_set_interior<true, true, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
-            else if (has1) sgr8_set_interior<false, true, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
-            else sgr8_set_interior<true, false, STORE>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            if (has0 && has1) sgr8_set_interior<true, true, STORE, BD>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            else if (has1) sgr8_set_interior<false, true, STORE, BD>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
+            else sgr8_set_interior<true, false, STORE, BD>(abw, xt, P, M, s0, s1, tid, i0, j, X, CX, SV, ppx, dstride, part + ep * 80);
             buf ^= 1;
             continue;
         }
@@ -618,10 +649,15 @@ sgr_search8_kernel(const SgrSearchPic a) {
             const bool used = q == 0 || q == 3 ? has0 : (q == 1 ? (has0 && has1) : has1);
             if (used) {
                 unsigned long long v = acc[ce][q];
-                if (BD == 8 && STORE != 2 && interior) {
+                if (STORE != 2 && interior) {
                     long long w = 0;
+                    if (BD == 8) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) w += part[ce * 80 + q * 16 + k];
+                        for (int k = 0; k < 16; k++) w += part[ce * 80 + q * 16 + k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) w += (long long)part[ce * 80 + q * 8 + 2 * k + 1] * 65536 + part[ce * 80 + q * 8 + 2 * k];
+                    }
                     v = (unsigned long long)w;
                 }
                 atomicAdd(&sums[((size_t)unit * 16 + ep) * 5 + q], v);

@@ -33,9 +33,9 @@ int main() {
     hipMemset(d_sums, 0, 8 * ux * uy * 16 * 5); hipMemset(d_d2, 0, 8 * ux * uy);
     SgrSearchPic a = {};
     a.p[0] = sgr_search_plane_args(d_dgd + EXT * stride + EXT, stride, d_src, pw, pw, ph, unit, ux, uy, 0, 0xFFFFu, (int64_t*)d_sums, d_pairs, d_sd, dstride, dplane, (int64_t*)d_d2, nullptr, nullptr, 1024);
-    a.first_tile[1] = a.first_tile[2] = a.first_tile[3] = a.p[0].n_tiles;
+    for (int i = 1; i <= kSgrMaxPlanes; i++) a.first_tile[i] = a.p[0].n_tiles;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto go = [&]() { hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), dim3(a.first_tile[3]), dim3(256), 0, 0, a); };
+    auto go = [&]() { hipLaunchKernelGGL((sgr_search8_kernel<uint8_t, 8, 1>), dim3(a.first_tile[kSgrMaxPlanes]), dim3(256), 0, 0, a); };
     for (int i = 0; i < 3; i++) go();
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
