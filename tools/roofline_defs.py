@@ -22,6 +22,13 @@ stands beside it -- it rewards waste and is not the roofline figure (VERDICT r05
 """
 HBM_PEAK_BPS = 8.0e12
 VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9
+# What the chip actually issues, by WALL CLOCK (tools/ubench/valu_peak.hip, profiles/r06/valu_peak.txt: 256 / 512 workgroups of 1024 threads, 16 independent instances of
+# one instruction per wave): v_mad_u32_u24, v_and_or_b32, v_perm_b32, v_pk_add_u16, v_dot2_i32_i16, v_sad_u8 / u16 all run at 36-37.5 T lane-operations per second
+# (~61 lanes per clock and compute unit: a wave64 instruction occupies its SIMD for four cycles), v_add_u32 at 55 T, v_fma_f32 at 40 T, v_qsad_pk_u16_u8 at 9.6 T.
+# The 78.6 T above is the guide's FP32 vector peak, which counts packed / dual-issued FP32; the integer and packed-16-bit instructions these kernels are made of do not
+# get it.  (tools/valu_rate.cpp of round 2 divided s_memtime deltas by instruction counts and reported 23 lanes per clock and SIMD for the same instructions; by the
+# wall clock it is 15: the counter does not tick once per shader cycle.)  `frac` stays the fraction of the guide's peak; the *_of_measured_peak fields use this one.
+VALU_MEASURED_LANE_OPS = 37.3e12
 
 ALG_BYTES_PER_SB = {
     "me_fullpel_85pu": 8872,                 # 4096 src + 4096 ref (amortised) + 85*8 out
@@ -112,14 +119,15 @@ def stage_roofline(stage, ms, n_sb, pmc=None):
     r = {"ms": ms, "algorithmic_bytes": alg, "algorithmic_GBps": alg / t / 1e9, "hbm_frac": alg / t / HBM_PEAK_BPS}
     if stage in USEFUL_LANE_OPS_PER_SB:
         useful = USEFUL_LANE_OPS_PER_SB[stage] * n_sb
-        r.update({"useful_lane_ops": useful, "useful_frac": useful / t / VALU_PEAK_LANE_OPS})
+        r.update({"useful_lane_ops": useful, "useful_frac": useful / t / VALU_PEAK_LANE_OPS, "useful_frac_of_measured_peak": useful / t / VALU_MEASURED_LANE_OPS})
     frames = frames_of(pmc) if pmc else 0
     if frames:
         us, traffic, insts, active = stage_counters(pmc, stage, frames)
         if traffic:
             r.update({"traffic_bytes": traffic, "traffic_over_algorithmic": traffic / alg})
         if insts:
-            r.update({"issued_lane_ops": insts * 64.0, "issued_frac": insts * 64.0 / t / VALU_PEAK_LANE_OPS, "profile_ms": us * 1e-3})
+            r.update({"issued_lane_ops": insts * 64.0, "issued_frac": insts * 64.0 / t / VALU_PEAK_LANE_OPS, "issued_frac_of_measured_peak": insts * 64.0 / t / VALU_MEASURED_LANE_OPS,
+                      "profile_ms": us * 1e-3})
             if "useful_lane_ops" in r:
                 r["issued_over_useful"] = insts * 64.0 / r["useful_lane_ops"]
         if active and us:
@@ -140,7 +148,9 @@ def roofline(stage_ms, n_sb, pmc=None, pmc_source=None):
     if "useful_frac" in d:        # a search: integer-VALU bound by construction.  frac = the USEFUL (algorithmic) share of the peak; what the ISA issued stands beside it
         out.update({"bound": "valu", "achieved": d["useful_lane_ops"] / (d["ms"] * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s", "frac": d["useful_frac"],
                     "useful_frac": d["useful_frac"], "issued_frac": d.get("issued_frac"), "issued_over_useful": d.get("issued_over_useful"), "valu_busy": d.get("valu_busy"),
-                    "wait_any_over_wave_cycles": d.get("wait_any_over_wave_cycles")})
+                    "wait_any_over_wave_cycles": d.get("wait_any_over_wave_cycles"),
+                    "measured_issue_peak": VALU_MEASURED_LANE_OPS / 1e12, "frac_of_measured_peak": d.get("useful_frac_of_measured_peak"),
+                    "issued_frac_of_measured_peak": d.get("issued_frac_of_measured_peak")})
     else:
         out.update({"bound": "hbm", "achieved": d["algorithmic_GBps"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": d["hbm_frac"]})
     out["traffic"] = d.get("traffic_bytes")
@@ -150,5 +160,6 @@ def roofline(stage_ms, n_sb, pmc=None, pmc_source=None):
     out["counter_calibration"] = {"fetch_size_factor": rf, "write_size_factor": wf, "source": cal_src}
     out["definitions"] = ("tools/roofline_defs.py: frac = useful_frac = the stage's algorithmic work count (USEFUL_LANE_OPS_PER_SB: one derivation, in code) / stage time / 78.6 T lane-op/s; "
                           "issued_frac = SQ_INSTS_VALU x 64 of the stage's kernels per frame (PMC pass of `source`) over the same time and peak; traffic = FETCH_SIZE x fetch_size_factor + "
-                          "WRITE_SIZE x write_size_factor per frame (counter x 1024 x the factor measured by tools/calibrate_counters.sh); algorithmic bytes = SURVEY 8(d)")
+                          "WRITE_SIZE x write_size_factor per frame (counter x 1024 x the factor measured by tools/calibrate_counters.sh); algorithmic bytes = SURVEY 8(d); "
+                          "measured_issue_peak = what the chip issues of these integer / packed-16-bit instructions by wall clock (tools/ubench/valu_peak.hip, profiles/r06/valu_peak.txt): the *_of_measured_peak fields divide by it")
     return out
