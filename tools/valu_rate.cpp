@@ -1,4 +1,6 @@
 // valu_rate.cpp — issue rate of the integer / packed VALU instructions the search kernels are built from, on gfx950.
+// SUPERSEDED (round 6) by tools/ubench/valu_peak.hip: this tool divides s_memtime deltas by instruction counts, and s_memtime does not advance once per shader cycle on this
+// part -- its "2.78 cycles" for v_mad_u32_u24 are 4.4 by the wall clock (profiles/r06/valu_peak.txt).  The RATIOS between instructions it reports hold.
 // Every workgroup is 1024 threads (4 waves per SIMD); each wave runs ITER iterations of 16 independent instances of one instruction.
 // Reports shader cycles per wave-instruction per SIMD (s_memtime around the loop, averaged over waves) and the implied lane rate.
 // Build: hipcc --offload-arch=gfx950 -O2 tools/valu_rate.cpp -o gpurun_out/valu_rate ; run on the GPU box.
