@@ -163,6 +163,7 @@ def test_hbd_windowed_search(hip, pkg, orc):
             x0, y0 = max(bx - 32, 0), max(by - 32, 0)
             jobs.append((bx, by, x0, y0, 64, 64, min(64, w - 64 - x0 + 1), min(64, h - 64 - y0 + 1), 1, 0))
     jobs += [(32, 32, 20, 20, 32, 32, 16, 13, 1, 0), (128, 64, 100, 40, 48, 17, 24, 40, 1, 0), (64, 128, 50, 120, 16, 64, 8, 64, 1, 0), (192, 64, 160, 33, 64, 1, 56, 33, 1, 0)]   # the LDS form's other shapes
+    jobs += [(33, 35, 21, 22, 32, 32, 16, 13, 1, 0), (129, 65, 101, 40, 64, 20, 24, 30, 1, 0), (65, 129, 51, 121, 16, 40, 8, 20, 1, 0), (97, 3, 70, 0, 48, 16, 40, 8, 1, 0)]   # source blocks at odd columns: their sample pairs do not start on a dword (the LDS form's 16-bit-load path)
     jobs += [(16, 16, 8, 8, 16, 16, 17, 9, 1, 0), (100, 40, 90, 30, 32, 32, 5, 40, 2, 0), (200, 100, 199, 99, 8, 8, 3, 3, 1, 0), (64, 64, 60, 60, 64, 32, 9, 9, 2, 0)]
     n = len(jobs)
     S = (pkg.SadLoop * n)(*[pkg.SadLoop(*j) for j in jobs])
