@@ -64,7 +64,7 @@ def patched():
     rep("    __syncthreads();   // also orders this set's build after every lane's reads of the set before last (double buffer)\n    int32_t D0[8], D1[8];",
         "    if (!(PROBE & 4)) __syncthreads();\n    int32_t D0[8], D1[8];")
     rep("        if (live) {\n            const uint32_t z = (__umul24(P[k], is1 ? s1 : s0)", "        if (live && !(PROBE & 8)) {\n            const uint32_t z = (__umul24(P[k], is1 ? s1 : s0)")
-    rep("    sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1);\n    if (STORE == 1",
+    rep("    if (BD == 8) sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1); else sgr10_filter(abw, i0, j, X, CX, H0, H1, D0, D1);\n    if (STORE == 1",
         "    if (!(PROBE & 16)) sgr8_filter(abw, i0, j, X, CX, H0, H1, D0, D1);\n    else {\n#pragma unroll\n for (int r = 0; r < 8; r++) { D0[r] = (int32_t)X[r] + (int32_t)s0; D1[r] = CX[r] - (int32_t)s1; } }\n    if (STORE == 1")
     rep("    int buf = 0;\n    for (int ep = 0; ep < 16; ep++) {\n        if (!((cmask >> ep) & 1)) continue;", "    int buf = 0;\n    if (PROBE & 32) cmask = 0;\n    for (int ep = 0; ep < 16; ep++) {\n        if (!((cmask >> ep) & 1)) continue;", 1)
     rep("    const bool interior = x0 + S_TW <= pw && y0 >= 0 && y0 + S_TH <= ph;", "    const bool interior = x0 + S_TW <= pw && y0 >= 0 && y0 + S_TH <= ph && !(PROBE & 64);")
